@@ -1,0 +1,52 @@
+"""ctypes loader for oracle/_build/liboracle.so (C part of the CPU oracle).
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, "csrc", f) for f in ("nmr_raster.c", "sdf.c")]
+    stale = (not os.path.exists(_SO)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s))
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-s"] + (["-B"] if force else []), check=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+        fp = ctypes.POINTER(ctypes.c_float)
+        ip = ctypes.POINTER(ctypes.c_int32)
+        ci, cf = ctypes.c_int, ctypes.c_float
+        _lib.orc_nmr_face_index_map.argtypes = [fp, ci, ci, ci, cf, cf, ip, fp]
+        _lib.orc_nmr_face_index_map.restype = None
+        _lib.orc_nmr_grad_faces_alpha.argtypes = [fp, ip, fp, ci, ci, ci, cf, fp]
+        _lib.orc_nmr_grad_faces_alpha.restype = None
+        _lib.orc_sdf_grid.argtypes = [ip, fp, ci, ci, ci, ci, ci, fp]
+        _lib.orc_sdf_grid.restype = None
+        _lib.orc_point_triangle_distance.argtypes = [fp, fp, fp, fp]
+        _lib.orc_point_triangle_distance.restype = cf
+    return _lib
+
+
+def fptr(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def iptr(a):
+    assert a.dtype == np.int32 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))

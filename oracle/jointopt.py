@@ -1,0 +1,85 @@
+"""CPU restatement of the reference's optimisation loop.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.
+Follows reference homan/jointopt.py:22-201 minus visualisation / video export
+(:159-177,193-200): per-frame dict concatenation (:55-91), HOMan construction with the
+integer int_scale_init=1 (:92-124), optional state_dict resume (:126-127), three Adam
+groups selected by parameter-name substring with lr, 10*lr, 10*lr (:128-151), and the
+step: zero_grad, forward, loss_k * lw[k.replace('loss','lw')], per-key .item() logging,
+sum, backward, step (:178-192).
+"""
+from collections import defaultdict
+
+import torch
+
+from . import yana
+from .model import OracleHOMan
+
+
+def collate_inputs(person_parameters, object_parameters, objvertices, objfaces):
+    """reference homan/jointopt.py:52-91."""
+    cat = torch.cat
+    pp, op = person_parameters, object_parameters
+    return dict(
+        hand_sides=pp[0]["hand_side"],
+        translations_object=cat([o["translations"] for o in op]),
+        rotations_object=cat([o["rotations"] for o in op]),
+        verts_object_og=yana.tensorify(objvertices),
+        faces_object=yana.tensorify(objfaces),
+        target_masks_object=cat([o["target_masks"] for o in op]),
+        target_masks_hand=cat([p["target_masks"] for p in pp]),
+        verts_hand_og=cat([p["verts"] for p in pp]),
+        ref_verts2d_hand=cat([p["verts2d"] for p in pp]),
+        mano_trans=cat([p["mano_trans"] for p in pp]),
+        mano_rot=cat([p["mano_rot"] for p in pp]),
+        mano_pca_pose=cat([p["mano_pca_pose"] for p in pp]),
+        mano_betas=cat([p["mano_betas"] for p in pp]),
+        translations_hand=cat([p["translations"] for p in pp]),
+        rotations_hand=cat([p["rotations"] for p in pp]),
+        faces_hand=pp[0]["faces"],
+        masks_object=cat([o["full_mask"].unsqueeze(0) for o in op]),
+        masks_hand=cat([p["masks"] for p in pp]),
+        cams_hand=cat([p["cams"] for p in pp]),
+        camintr_rois_object=cat([o["K_roi"][:, 0] for o in op]),
+        camintr_rois_hand=cat([p["K_roi"] for p in pp]),
+    )
+
+
+def make_optimizer(model, lr):
+    """reference homan/jointopt.py:128-151."""
+    rigid = [v for k, v in model.named_parameters() if "mano" not in k and "rotation" not in k]
+    rotation = [v for k, v in model.named_parameters() if ("rotation" in k) and ("mano" not in k)]
+    return torch.optim.Adam([{"params": rigid, "lr": lr},
+                             {"params": [model.mano_pca_pose, model.mano_betas], "lr": lr * 10},
+                             {"params": rotation, "lr": lr * 10}])
+
+
+def optimize_hand_object(person_parameters, object_parameters, class_name="default", objvertices=None,
+                         objfaces=None, loss_weights=None, num_iterations=400, lr=1e-2, camintr=None,
+                         hand_proj_mode="persp", optimize_mano=False, optimize_mano_beta=True,
+                         optimize_object_scale=False, state_dict=None, image_size=640, mano_model=None,
+                         rend_size=256, log=True):
+    kw = collate_inputs(person_parameters, object_parameters, objvertices, objfaces)
+    model = OracleHOMan(camintr=camintr, class_name=class_name, int_scale_init=1,
+                        hand_proj_mode=hand_proj_mode, optimize_mano=optimize_mano,
+                        optimize_mano_beta=optimize_mano_beta, optimize_object_scale=optimize_object_scale,
+                        image_size=image_size, mano_model=mano_model, rend_size=rend_size, **kw)
+    if state_dict is not None:
+        model.load_state_dict(state_dict, strict=False)
+    optimizer = make_optimizer(model, lr)
+    loss_evolution = defaultdict(list)
+    for _ in range(num_iterations):
+        optimizer.zero_grad()
+        loss_dict, metric_dict = model(loss_weights=loss_weights)
+        weighted = {k: loss_dict[k] * loss_weights[k.replace("loss", "lw")] for k in loss_dict}
+        if log:
+            for k, val in loss_dict.items():
+                loss_evolution[k].append(val.item())
+            for k, val in metric_dict.items():
+                loss_evolution[k].append(val)
+        loss = sum(weighted.values())
+        if log:
+            loss_evolution["loss"].append(loss.item())
+        loss.backward()
+        optimizer.step()
+    return model, dict(loss_evolution), {}

@@ -1,0 +1,360 @@
+"""CPU restatement (pure torch fp32 + the C leaves) of the reference's model/loss composition.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.  Every function cites the
+reference file:line it follows.  PINNED: tests/test_oracle_golden.py checks this
+module against vectors produced by the reference's own ``homan.homan.HOMan`` /
+``homan.jointopt.optimize_hand_object`` imported over the same leaves
+(tools/refharness/gen_goldens.py -> tests/golden/*.npz).
+"""
+import itertools
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import lbs as o_lbs
+from . import nmr as o_nmr
+from . import sdfgrid as o_sdf
+from . import yana as o_yana
+
+REND_SIZE = 256              # reference homan/constants.py:32
+INTERACTION_Z_THRESH = 3     # reference homan/losses.py:90
+INTERACTION_BBOX_EXPANSION = 0.2   # reference homan/losses.py:95
+
+
+# ----------------------------------------------------------------------------- geometry
+def rot6d_to_matrix(rot_6d):
+    """reference homan/utils/geometry.py:9-27 (cross taken along dim=-1; the reference's
+    dim-less torch.cross differs only when the flattened batch is exactly 3)."""
+    rot_6d = rot_6d.view(-1, 3, 2)
+    a1, a2 = rot_6d[:, :, 0], rot_6d[:, :, 1]
+    b1 = F.normalize(a1)
+    b2 = F.normalize(a2 - torch.einsum("bi,bi->b", b1, a2).unsqueeze(-1) * b1)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-1)
+
+
+def matrix_to_rot6d(rotmat):
+    """reference homan/utils/geometry.py:30-40."""
+    return rotmat.view(-1, 3, 3)[:, :, :2]
+
+
+def transform_persp(meshes, translations, rotations, intrinsic_scales):
+    """reference homan/utils/camera.py:108-139: (s*v) @ R + t and its mesh-detached twin."""
+    scaled = intrinsic_scales.view(-1, 1, 1) * meshes
+    return (torch.matmul(scaled, rotations) + translations,
+            torch.matmul(scaled.detach().clone(), rotations) + translations)
+
+
+def compute_dist_z(verts1, verts2):
+    """reference homan/utils/geometry.py:69-86."""
+    a, b = verts1[:, 2].min(), verts1[:, 2].max()
+    c, d = verts2[:, 2].min(), verts2[:, 2].max()
+    if d >= a and b >= c:
+        return 0.0
+    return torch.min(torch.abs(c - b), torch.abs(a - d))
+
+
+def compute_iou(bbox1, bbox2):
+    """reference homan/utils/bbox.py:111-135 (tensor branch)."""
+    a1 = (bbox1[2] - bbox1[0]) * (bbox1[3] - bbox1[1])
+    a2 = (bbox2[2] - bbox2[0]) * (bbox2[3] - bbox2[1])
+    lt = torch.max(bbox1[:2], bbox2[:2])
+    rb = torch.min(bbox1[2:], bbox2[2:])
+    wh = torch.clamp_min(rb - lt, 0)
+    inter = wh[0] * wh[1]
+    return inter / (a1 + a2 - inter)
+
+
+# ----------------------------------------------------------------------------- 3-D losses
+def compute_smooth_loss(verts_hand, verts_obj):
+    """reference homan/lossutils.py:18-36."""
+    hand_nb = verts_hand.shape[0] // verts_obj.shape[0]
+    hands = torch.cat([verts_hand[i::hand_nb] for i in range(hand_nb)], 1)
+    return {"loss_smooth_obj": ((verts_obj[1:] - verts_obj[:-1]) ** 2).mean(),
+            "loss_smooth_hand": ((hands[1:] - hands[:-1]) ** 2).mean()}
+
+
+def compute_pca_loss(pca):
+    """reference homan/lossutils.py:39-40."""
+    return {"loss_pca": (pca ** 2).mean()}
+
+
+def compute_intrinsic_scale_prior(scales, mean):
+    """reference homan/lossutils.py:107-109."""
+    return torch.sum((scales - mean) ** 2) / scales.shape[0]
+
+
+def sdf_scene_loss(faces_list, vertices, grid_size=32, scale_factor=0.2, sdf=None):
+    """reference homan/interactions/scenesdf.py:77-148 (SDFSceneLoss.forward)."""
+    sdf = o_sdf.SDF(clamp_outside=True) if sdf is None else sdf
+    vertices = [v.float() for v in vertices]
+    n_obj = len(vertices)
+    with torch.no_grad():   # scenesdf.py:37 get_bounding_boxes is no_grad
+        boxes = torch.stack([torch.stack([v.min(1)[0], v.max(1)[0]], 1) for v in vertices], 1)  # (B,n,2,3)
+    centers = boxes.mean(dim=2).unsqueeze(2).permute(1, 0, 2, 3)                      # (n,B,1,3)
+    scales = ((boxes[:, :, 1] - boxes[:, :, 0]) * ((1 + scale_factor) * 0.5)).max(dim=-1)[0].permute(1, 0)
+    phis = []
+    for k in range(n_obj):
+        with torch.no_grad():
+            local = (vertices[k] - centers[k]) / scales[k].view(-1, 1, 1)
+            assert local.min() >= -1 and local.max() <= 1
+            phis.append(sdf(faces_list[k].int(), local.contiguous()).clamp(0))
+    loss = torch.tensor(0.0)
+    dist_values = {}
+    for k, l in itertools.permutations(range(n_obj), 2):
+        local = (vertices[l] - centers[k]) / scales[k].view(-1, 1, 1)
+        d = F.grid_sample(phis[k].float().unsqueeze(1), local.view(local.shape[0], local.shape[1], 1, 1, 3),
+                          align_corners=False)
+        dist_values[(k, l)] = d[:, 0, :, 0, 0] * scales[k].unsqueeze(1)
+        loss = loss + d.sum()
+    return loss, {"sdfs": phis, "dist_values": dist_values}
+
+
+def compute_collision_loss(verts_hand, verts_object, faces_object, closed_hand_faces):
+    """reference homan/lossutils.py:43-64 (sdf branch, one hand)."""
+    loss, _ = sdf_scene_loss([closed_hand_faces, faces_object[0]], [verts_hand, verts_object])
+    return {"loss_collision": loss.mean()}
+
+
+def masked_mean_loss(dists, mask):
+    """reference homan/interactions/contactloss.py:50-57."""
+    mask = mask.float()
+    n = mask.sum()
+    return (mask * dists).sum() / n if n > 0 else torch.Tensor([0])
+
+
+def compute_contact_loss(verts_hand, verts_object, faces_object, closed_hand_faces,
+                         contact_thresh=0.010, collision_thresh=0.020):
+    """reference homan/lossutils.py:112-130 -> interactions/contactloss.py:149-309
+    (contact_mode = collision_mode = 'dist_tanh', contact_target='all', zones='all')."""
+    dists = o_yana.batch_pairwise_dist(verts_hand, verts_object)
+    mins21, idx21 = torch.min(dists, 2)
+    _, meta = sdf_scene_loss([closed_hand_faces, faces_object[0]], [verts_hand, verts_object])
+    exterior = meta["dist_values"][(1, 0)] < 0          # contactloss.py:173 (always False after the clamp)
+    penetr_mask = ~exterior
+    close = torch.gather(verts_object, 1, idx21[:, :, None].expand(-1, -1, 3))   # contactloss.py:11-19
+    anchor = torch.norm(close - verts_hand, 2, 2)
+    contact_vals = contact_thresh * torch.tanh(anchor / contact_thresh)
+    collision_vals = collision_thresh * torch.tanh(anchor / collision_thresh)
+    missed_mask = torch.ones_like(mins21).bool() & exterior
+    missed = masked_mean_loss(contact_vals, missed_mask)
+    penetr = masked_mean_loss(collision_vals, penetr_mask)
+    return {"loss_contact": missed + penetr}
+
+
+# ----------------------------------------------------------------------------- image losses
+def project_bbox(vertices, K, bbox_expansion):
+    """reference homan/losses.py:20-49 (R = I, t = 0, zero distortion, orig_size=1)."""
+    world = vertices * torch.tensor([[[1.0, -1.0, 1.0]]])
+    proj = o_nmr.projection(world, K, torch.eye(3)[None], torch.zeros(1, 3), torch.zeros(1, 5), 1)[:, :, :2]
+    box = torch.cat([proj.min(1)[0], proj.max(1)[0]], 1)
+    if bbox_expansion:
+        center = (box[:, :2] + box[:, 2:]) / 2
+        extent = (box[:, 2:] - box[:, :2]) / 2 * (1 + bbox_expansion)
+        box = torch.cat([center - extent, center + extent], 1)
+    return box
+
+
+class OracleLosses:
+    """reference homan/losses.py:52-242."""
+
+    def __init__(self, camintr, ref_mask_object, keep_mask_object, ref_verts2d_hand, camintr_rois_object,
+                 hand_nb, inter_type, rend_size):
+        self.camintr = camintr.clone()
+        self.ref_mask_object, self.keep_mask_object = ref_mask_object, keep_mask_object
+        self.ref_verts2d_hand = ref_verts2d_hand
+        self.camintr_rois_object = camintr_rois_object
+        self.hand_nb, self.inter_type = hand_nb, inter_type
+        self.renderer = o_nmr.Renderer(image_size=rend_size, K=self.camintr, R=torch.eye(3)[None],
+                                       t=torch.zeros(1, 3), orig_size=1)
+
+    def compute_verts2d_loss_hand(self, verts, image_size):
+        """losses.py:141-164."""
+        camintr = self.camintr.unsqueeze(1).repeat(1, self.hand_nb, 1, 1).view(-1, 3, 3)
+        proj = o_yana.batch_proj2d(verts, camintr)
+        tar = self.ref_verts2d_hand / image_size
+        loss = ((proj - tar) ** 2).sum(-1).mean()
+        dist = (proj * image_size - self.ref_verts2d_hand).norm(2, -1).mean()
+        return {"loss_v2d_hand": loss}, {"v2d_hand": dist.item()}
+
+    def compute_sil_loss_object(self, verts, faces):
+        """losses.py:183-197."""
+        rend = self.renderer(verts, faces, K=self.camintr_rois_object, mode="silhouettes")
+        image = self.keep_mask_object * rend
+        l_m = torch.sum((image - self.ref_mask_object) ** 2) / self.keep_mask_object.sum()
+        loss = torch.Tensor([0.0]) + l_m
+        ious = o_yana.batch_mask_iou(image, self.ref_mask_object)
+        return {"loss_sil_obj": loss / len(verts)}, {"iou_object": ious.mean().item()}
+
+    def assign_interaction_pairs(self, verts_hand, verts_object):
+        """losses.py:98-139."""
+        with torch.no_grad():
+            bo = project_bbox(verts_object, self.camintr, INTERACTION_BBOX_EXPANSION)
+            bh = project_bbox(verts_hand, self.camintr, INTERACTION_BBOX_EXPANSION)
+            out = []
+            for b in range(len(bo)):
+                iou = compute_iou(bo[b], bh[b])
+                z = compute_dist_z(verts_object[b], verts_hand[b])
+                out.append(1 if (iou > 0) and (z < INTERACTION_Z_THRESH) else 0)
+            return out
+
+    def compute_interaction_loss(self, verts_hand_b, verts_object_b):
+        """losses.py:199-242 (returns the un-normalised sum, :233-239)."""
+        loss = torch.Tensor([0.0])
+        min_dists = []
+        for p in range(verts_hand_b.shape[1]):
+            for o in range(verts_object_b.shape[1]):
+                inter = self.assign_interaction_pairs(verts_hand_b[:, p], verts_object_b[:, o])
+                for b, flag in enumerate(inter):
+                    if flag:
+                        v_p, v_o = verts_hand_b[b, p], verts_object_b[b, o]
+                        if self.inter_type == "centroid":
+                            err = F.mse_loss(v_p.mean(0), v_o.mean(0))
+                        else:
+                            err = o_yana.batch_pairwise_dist(v_p[None], v_o[None]).min()
+                        loss = loss + err
+                with torch.no_grad():
+                    md = torch.sqrt(o_yana.batch_pairwise_dist(verts_hand_b[:, p], verts_object_b[:, o])
+                                    ).min(1)[0].min(1)[0]
+                min_dists.append(md)
+        min_dists = torch.stack(min_dists).min(0)[0]
+        return {"loss_inter": loss}, {"handobj_maxdist": torch.max(min_dists).item()}
+
+
+# ----------------------------------------------------------------------------- model
+class OracleHOMan(nn.Module):
+    """reference homan/homan.py:26-237 (ctor), :298-307, :341-382, :421-508; one right hand."""
+
+    def __init__(self, translations_object, rotations_object, verts_object_og, faces_object,
+                 translations_hand, rotations_hand, verts_hand_og, ref_verts2d_hand, hand_sides,
+                 mano_trans, mano_rot, mano_betas, mano_pca_pose, faces_hand, masks_object, masks_hand,
+                 camintr_rois_object, camintr_rois_hand, target_masks_object, target_masks_hand,
+                 class_name="default", cams_hand=None, int_scale_init=1, camintr=None,
+                 optimize_object_scale=False, optimize_ortho_cam=True, hand_proj_mode="persp",
+                 optimize_mano=True, optimize_mano_beta=True, inter_type="centroid", image_size=640,
+                 mano_model=None, rend_size=REND_SIZE):
+        super().__init__()
+        assert hand_proj_mode == "persp"
+        self.translations_object = nn.Parameter(translations_object.detach().clone())
+        rot_o = rotations_object.detach().clone()
+        self.rotations_object = nn.Parameter(
+            (matrix_to_rot6d(rot_o) if rot_o.shape[-1] == 3 else rot_o).detach().clone())
+        self.register_buffer("verts_object_og", verts_object_og)
+        self.translations_hand = nn.Parameter(translations_hand.detach().clone())
+        rot_h = rotations_hand.detach().clone()
+        self.rotations_hand = nn.Parameter((matrix_to_rot6d(rot_h) if rot_h.shape[-1] == 3 else rot_h).clone())
+        if optimize_ortho_cam:
+            self.cams_hand = nn.Parameter(cams_hand)
+        else:
+            self.register_buffer("cams_hand", cams_hand)
+        self.hand_sides, self.hand_nb = hand_sides, len(hand_sides)
+        self.optimize_mano = optimize_mano
+        if optimize_mano:
+            self.mano_pca_pose = nn.Parameter(mano_pca_pose)
+            self.mano_rot = nn.Parameter(mano_rot)
+            self.mano_trans = nn.Parameter(mano_trans)
+        else:
+            self.register_buffer("mano_pca_pose", mano_pca_pose)
+            self.register_buffer("mano_rot", mano_rot)
+        if optimize_mano_beta:
+            self.mano_betas = nn.Parameter(torch.zeros_like(mano_betas))
+            self.register_buffer("int_scales_hand", torch.ones(1) * int_scale_init)
+        else:
+            self.register_buffer("mano_betas", torch.zeros_like(mano_betas))
+            self.int_scales_hand = nn.Parameter(int_scale_init * torch.ones(1))
+        self.register_buffer("verts_hand_og", verts_hand_og)
+        self.register_buffer("ref_verts2d_hand", ref_verts2d_hand)
+        self.optimize_object_scale = optimize_object_scale
+        if optimize_object_scale:
+            self.int_scales_object = nn.Parameter(int_scale_init * torch.ones(1))
+        else:
+            self.register_buffer("int_scales_object", int_scale_init * torch.ones(1))
+        self.register_buffer("int_scale_object_mean", torch.ones(1))
+        self.register_buffer("int_scale_hand_mean", torch.ones(1))
+        self.register_buffer("ref_mask_object", (target_masks_object > 0).float())
+        self.register_buffer("keep_mask_object", (target_masks_object >= 0).float())
+        self.register_buffer("ref_mask_hand", (target_masks_hand > 0).float())
+        self.register_buffer("keep_mask_hand", (target_masks_hand >= 0).float())
+        self.register_buffer("camintr_rois_object", camintr_rois_object)
+        self.register_buffer("camintr_rois_hand", camintr_rois_hand)
+        self.register_buffer("faces_object", faces_object)
+        self.register_buffer("faces_hand", faces_hand)
+        camintr = o_yana.tensorify(camintr).float()
+        if camintr.dim() == 2:
+            camintr = camintr.unsqueeze(0)
+        self.register_buffer("camintr", camintr)
+        self.image_size = image_size
+        self.mano_np = mano_model
+        self.layer_flat = o_lbs.ManoLayer(mano_model, num_pca_comps=16, flat_hand_mean=True)
+        self.hand_components = torch.as_tensor(mano_model["hand_components"][:16])
+        self.hand_mean = torch.as_tensor(mano_model["hand_mean"])
+        self.closed_faces = torch.as_tensor(mano_model["closed_faces"].astype(np.int64))
+        self.losses = OracleLosses(self.camintr, self.ref_mask_object, self.keep_mask_object,
+                                   self.ref_verts2d_hand, self.camintr_rois_object, self.hand_nb,
+                                   inter_type, rend_size)
+
+    def get_verts_object(self):
+        """homan.py:298-307."""
+        return transform_persp(self.verts_object_og, self.translations_object,
+                               rot6d_to_matrix(self.rotations_object), self.int_scales_object.abs())
+
+    def mano_forward(self, pca, rot, betas):
+        """homan/manomodel.py:84-151 (right hand, flat_hand_mean=False -> + hand_mean)."""
+        hand_pose = torch.einsum("bi,bij->bj", pca[:, :16],
+                                 self.hand_components.unsqueeze(0).repeat(pca.shape[0], 1, 1))
+        hand_pose = hand_pose + self.hand_mean.unsqueeze(0).repeat(len(hand_pose), 1)
+        return self.layer_flat(betas=betas, global_orient=rot, hand_pose=hand_pose,
+                               transl=rot.new_zeros(rot.shape[0], 3))[0]
+
+    def get_verts_hand(self, detach_scale=False):
+        """homan.py:341-382 (persp)."""
+        if self.optimize_mano:
+            verts = self.mano_forward(self.mano_pca_pose, self.mano_rot, self.mano_betas)
+            verts_og = verts + self.mano_trans.unsqueeze(1)
+        else:
+            verts_og = self.verts_hand_og
+        scale = self.int_scales_hand.detach() if detach_scale else self.int_scales_hand
+        return transform_persp(verts_og, self.translations_hand, rot6d_to_matrix(self.rotations_hand), scale)
+
+    def forward(self, loss_weights=None):
+        """homan.py:421-508."""
+        lw = loss_weights
+        loss_dict, metric_dict = {}, {}
+        verts_object, _ = self.get_verts_object()
+        verts_hand, verts_hand_det = self.get_verts_hand()
+        verts_hand_det_scale, _ = self.get_verts_hand(detach_scale=True)
+        if lw is None or lw["lw_pca"] > 0:
+            loss_dict.update(compute_pca_loss(self.mano_pca_pose))
+        if lw is None or lw["lw_smooth_hand"] > 0 or lw["lw_smooth_obj"] > 0:
+            loss_dict.update(compute_smooth_loss(verts_hand, verts_object))
+        if lw is None or lw["lw_collision"] > 0:
+            loss_dict.update(compute_collision_loss(verts_hand_det_scale, verts_object.detach(),
+                                                    self.faces_object, self.closed_faces))
+        if lw is None or lw["lw_contact"] > 0:
+            loss_dict.update(compute_contact_loss(verts_hand_det_scale, verts_object, self.faces_object,
+                                                  self.closed_faces))
+        if lw is None or lw["lw_v2d_hand"] > 0:
+            l, m = self.losses.compute_verts2d_loss_hand(verts_hand, self.image_size)
+            loss_dict.update(l)
+            metric_dict.update(m)
+        if lw is None or lw["lw_sil_obj"] > 0:
+            l, m = self.losses.compute_sil_loss_object(verts_object, self.faces_object)
+            loss_dict.update(l)
+            metric_dict.update(m)
+        if lw is None or lw["lw_inter"] > 0:
+            vo = verts_object.unsqueeze(1) if self.optimize_object_scale else verts_object.unsqueeze(1).detach()
+            l, m = self.losses.compute_interaction_loss(verts_hand_det.view(-1, self.hand_nb, 778, 3), vo)
+            loss_dict.update(l)
+            metric_dict.update(m)
+        if lw is None or lw["lw_scale_obj"] > 0:
+            loss_dict["loss_scale_obj"] = compute_intrinsic_scale_prior(self.int_scales_object,
+                                                                        self.int_scale_object_mean)
+        if lw is None or lw["lw_scale_hand"] > 0:
+            loss_dict["loss_scale_hand"] = compute_intrinsic_scale_prior(self.int_scales_hand,
+                                                                         self.int_scale_hand_mean)
+        if lw is not None and lw["lw_depth"] > 0:
+            # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() with no arguments
+            raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments")
+        return loss_dict, metric_dict

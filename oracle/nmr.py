@@ -1,0 +1,150 @@
+"""CPU restatement of the `neural_renderer` surface the reference touches.
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.  PARITY UNPINNED (third-party
+package hassony2/multiperson `neural_renderer` @ HEAD, not in /root/reference).
+
+Reference call sites restated here:
+  nr.projection(vertices, K=, R=, t=, dist_coeffs=, orig_size=)   homan/losses.py:34-41
+  nr.renderer.Renderer(image_size=, K=, R=, t=, orig_size=)       homan/losses.py:73-77, homan/homan.py:168-172
+  renderer(verts, faces, K=, mode="silhouettes") -> (B,S,S)       homan/losses.py:187
+  renderer.render(verts, faces, textures[, K=]) -> (rgb, depth, alpha)   homan/homan.py:391,406,535
+Published algorithm: Kato et al., "Neural 3D Mesh Renderer", CVPR 2018
+(projection with OpenCV-style distortion, fill_back face doubling, hard
+z-buffer rasteriser at 2x supersampling, vertical flip, 2x2 average pool,
+edge-sweep pseudo-gradient).  The rasteriser core is oracle/csrc/nmr_raster.c.
+"""
+import numpy as np
+import torch
+
+from . import clib
+
+DEFAULT_NEAR = 0.1
+DEFAULT_FAR = 100.0
+DEFAULT_EPS = 1e-3
+
+
+def projection(vertices, K, R, t, dist_coeffs, orig_size, eps=1e-9):
+    """[X,Y,Z] -> [u,v,z]: u,v in [-1,1] (v up), z = camera depth."""
+    vertices = torch.matmul(vertices, R.transpose(2, 1)) + t
+    x, y, z = vertices[:, :, 0], vertices[:, :, 1], vertices[:, :, 2]
+    x_ = x / (z + eps)
+    y_ = y / (z + eps)
+    k1 = dist_coeffs[:, None, 0]
+    k2 = dist_coeffs[:, None, 1]
+    p1 = dist_coeffs[:, None, 2]
+    p2 = dist_coeffs[:, None, 3]
+    k3 = dist_coeffs[:, None, 4]
+    r2 = x_ ** 2 + y_ ** 2          # r**2 without the sqrt (avoids 0/0 in autograd at the axis)
+    radial = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
+    x__ = x_ * radial + 2 * p1 * x_ * y_ + p2 * (r2 + 2 * x_ ** 2)
+    y__ = y_ * radial + p1 * (r2 + 2 * y_ ** 2) + 2 * p2 * x_ * y_
+    vertices = torch.stack([x__, y__, torch.ones_like(z)], dim=-1)
+    vertices = torch.matmul(vertices, K.transpose(1, 2))
+    u, v = vertices[:, :, 0], vertices[:, :, 1]
+    v = orig_size - v
+    u = 2 * (u - orig_size / 2.0) / orig_size
+    v = 2 * (v - orig_size / 2.0) / orig_size
+    return torch.stack([u, v, z], dim=-1)
+
+
+def vertices_to_faces(vertices, faces):
+    """(B,V,3),(B,F,3) int -> (B,F,3,3)."""
+    bs, nv = vertices.shape[:2]
+    faces = faces.long() + (torch.arange(bs, device=vertices.device) * nv)[:, None, None]
+    return vertices.reshape(bs * nv, 3)[faces]
+
+
+class _RasterizeAlphaDepth(torch.autograd.Function):
+    """Hard rasterisation of NDC faces -> (alpha, depth) on an `is` grid (no flip, no pool)."""
+
+    @staticmethod
+    def forward(ctx, faces, image_size, near, far, eps):
+        f = np.ascontiguousarray(faces.detach().cpu().numpy(), dtype=np.float32)
+        B, NF = f.shape[:2]
+        idx = np.empty((B, image_size, image_size), np.int32)
+        dep = np.empty((B, image_size, image_size), np.float32)
+        clib.lib().orc_nmr_face_index_map(clib.fptr(f), B, NF, image_size, near, far,
+                                          clib.iptr(idx), clib.fptr(dep))
+        ctx.meta = (B, NF, image_size, eps)
+        ctx.f = f
+        ctx.idx = idx
+        alpha = torch.from_numpy((idx >= 0).astype(np.float32))
+        ctx.mark_non_differentiable
+        return alpha, torch.from_numpy(dep), torch.from_numpy(idx)
+
+    @staticmethod
+    def backward(ctx, grad_alpha, grad_depth, _gi):
+        B, NF, image_size, eps = ctx.meta
+        ga = np.ascontiguousarray(grad_alpha.detach().cpu().numpy(), dtype=np.float32)
+        gf = np.zeros((B, NF, 9), np.float32)
+        clib.lib().orc_nmr_grad_faces_alpha(clib.fptr(ctx.f), clib.iptr(ctx.idx), clib.fptr(ga),
+                                            B, NF, image_size, eps, clib.fptr(gf))
+        # depth gets no pseudo-gradient on the silhouette path (alpha only)
+        return torch.from_numpy(gf).view(B, NF, 3, 3), None, None, None, None
+
+
+def rasterize_alpha_depth(faces, image_size, anti_aliasing=True, near=DEFAULT_NEAR,
+                          far=DEFAULT_FAR, eps=DEFAULT_EPS):
+    """(B,NF,3,3) NDC faces -> alpha, depth (B,S,S): 2x SSAA, vertical flip, 2x2 avg-pool."""
+    s = image_size * 2 if anti_aliasing else image_size
+    alpha, depth, idx = _RasterizeAlphaDepth.apply(faces, s, near, far, eps)
+    alpha = alpha.flip(1)
+    depth = depth.flip(1)
+    if anti_aliasing:
+        alpha = torch.nn.functional.avg_pool2d(alpha[:, None], kernel_size=(2, 2))[:, 0]
+        depth = torch.nn.functional.avg_pool2d(depth[:, None], kernel_size=(2, 2))[:, 0]
+    return alpha, depth, idx
+
+
+class Renderer:
+    """Subset of nr.renderer.Renderer used by the reference (camera_mode='projection')."""
+
+    def __init__(self, image_size=256, anti_aliasing=True, fill_back=True, K=None, R=None, t=None,
+                 dist_coeffs=None, orig_size=1024, near=DEFAULT_NEAR, far=DEFAULT_FAR, **_unused):
+        self.image_size = image_size
+        self.anti_aliasing = anti_aliasing
+        self.fill_back = fill_back
+        self.K, self.R, self.t = K, R, t
+        if dist_coeffs is None:
+            dist_coeffs = torch.zeros(1, 5)
+        self.dist_coeffs = dist_coeffs
+        self.orig_size = orig_size
+        self.near, self.far = near, far
+        self.rasterizer_eps = DEFAULT_EPS
+        # lighting/background attributes the reference assigns (homan/homan.py:173-176)
+        self.light_direction = [0, 1, 0]
+        self.light_intensity_direction = 0.5
+        self.light_intensity_ambient = 0.5
+        self.background_color = [0, 0, 0]
+
+    def _ndc_faces(self, vertices, faces, K, R, t, dist_coeffs, orig_size):
+        if self.fill_back:
+            faces = torch.cat((faces, faces[:, :, [2, 1, 0]]), dim=1)
+        K = self.K if K is None else K
+        R = self.R if R is None else R
+        t = self.t if t is None else t
+        dist_coeffs = self.dist_coeffs if dist_coeffs is None else dist_coeffs
+        orig_size = self.orig_size if orig_size is None else orig_size
+        v = projection(vertices, K, R, t, dist_coeffs, orig_size)
+        return vertices_to_faces(v, faces)
+
+    def render_silhouettes(self, vertices, faces, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        f = self._ndc_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        alpha, _, _ = rasterize_alpha_depth(f, self.image_size, self.anti_aliasing, self.near, self.far,
+                                            self.rasterizer_eps)
+        return alpha
+
+    def render(self, vertices, faces, textures=None, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        f = self._ndc_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        alpha, depth, _ = rasterize_alpha_depth(f, self.image_size, self.anti_aliasing, self.near, self.far,
+                                                self.rasterizer_eps)
+        rgb = alpha[:, None].repeat(1, 3, 1, 1)  # untextured: the hot path never reads rgb
+        return rgb, depth, alpha
+
+    def __call__(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None,
+                 dist_coeffs=None, orig_size=None):
+        if mode == "silhouettes":
+            return self.render_silhouettes(vertices, faces, K, R, t, dist_coeffs, orig_size)
+        if mode is None:
+            return self.render(vertices, faces, textures, K, R, t, dist_coeffs, orig_size)
+        raise ValueError(f"mode {mode} not supported by the oracle renderer")
