@@ -1,0 +1,80 @@
+// hm_common.h -- shared device/host helpers for the homan_amd HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define HM_OK 0
+#define HM_ERR_BAD_ARG (-1)
+#define HM_ERR_LAUNCH (-2)
+#define HM_ERR_UNSUPPORTED (-3)
+
+#define HM_WAVE 64
+
+#define HM_CHECK_ARG(cond) \
+    do {                   \
+        if (!(cond)) return HM_ERR_BAD_ARG; \
+    } while (0)
+
+static inline int hm_launch_status()
+{
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? HM_OK : HM_ERR_LAUNCH;
+}
+
+static inline int hm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- wave-level reductions (64 lanes, deterministic butterfly order) ----
+__device__ __forceinline__ float hm_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float hm_wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float hm_wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in every thread.
+// `red` must hold >= 16 floats of LDS.  Deterministic: fixed tree.
+__device__ __forceinline__ float hm_block_sum(float v, float* red)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = hm_wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nw; ++i) t += red[i];
+    return t;
+}
+__device__ __forceinline__ float hm_block_min(float v, float* red)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = hm_wave_min(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fminf(t, red[i]);
+    return t;
+}
+__device__ __forceinline__ float hm_block_max(float v, float* red)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    v = hm_wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = red[0];
+    for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
+    return t;
+}

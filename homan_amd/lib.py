@@ -1,0 +1,66 @@
+"""ctypes binding of the C ABI in include/homan_amd.h (libhoman_amd.so).
+
+The product path has no CPU fallback: if the HIP library is missing or a call fails, this
+module raises.  Device pointers come from torch tensors (plumbing only: memory + streams).
+"""
+import ctypes
+import os
+
+import torch
+
+from . import build as _build
+
+_LIB = None
+_VP, _I, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes)
+_SIGNATURES = {
+    "hm_sil_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
+    "hm_sil_fwd": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_sil_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_sil_read_idx_map": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
+    "hm_sil_read_faces9": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
+}
+
+
+class HomanAmdError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libhoman_amd.so (after torch, so the HIP runtime already in the process is reused)."""
+    global _LIB
+    if _LIB is None:
+        path = _build.LIB_PATH
+        if not os.path.exists(path):
+            raise HomanAmdError(
+                f"{path} not found: build it with `python -m homan_amd.build` (hipcc, gfx950). "
+                "homan_amd has no CPU fallback.")
+        _LIB = ctypes.CDLL(path)
+        for name, (res, args) in _SIGNATURES.items():
+            try:
+                fn = getattr(_LIB, name)
+            except AttributeError as exc:
+                raise HomanAmdError(f"{path} does not export {name}; rebuild it") from exc
+            fn.restype, fn.argtypes = res, args
+    return _LIB
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "homan_amd ops need contiguous device tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HomanAmdError(f"{what} failed with code {rc}")
