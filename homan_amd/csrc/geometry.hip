@@ -1,0 +1,204 @@
+// geometry.hip -- batched 6-D rotation -> matrix and rigid vertex transform, forward + backward.
+//
+// Replaces reference homan/utils/geometry.py:9-27 (rot6d_to_matrix; cross product taken per row, see
+// DESIGN.md for the reference's dim-less torch.cross quirk at batch==3) and
+// homan/utils/camera.py:108-139 (compute_transformation_persp: (s*v) @ R + t and its mesh-detached twin)
+// as used by homan/homan.py:298-307 (object) and :341-382 (hand).
+#include "hm_common.h"
+
+__device__ __forceinline__ void rot6d_to_mat(const float* r6 /*3x2 row-major*/, float* R /*3x3 row-major*/)
+{
+    const float a1[3] = {r6[0], r6[2], r6[4]}, a2[3] = {r6[1], r6[3], r6[5]};
+    const float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
+    const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    const float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    const float nu = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-12f);
+    const float b2[3] = {u[0] / nu, u[1] / nu, u[2] / nu};
+    const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { R[3 * i] = b1[i]; R[3 * i + 1] = b2[i]; R[3 * i + 2] = b3[i]; }
+}
+
+// dL/dR (3x3 row-major) -> dL/drot6d (3x2 row-major)
+__device__ __forceinline__ void rot6d_backward(const float* r6, const float* dR, float* dr6)
+{
+    const float a1[3] = {r6[0], r6[2], r6[4]}, a2[3] = {r6[1], r6[3], r6[5]};
+    const float n1r = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+    const float n1 = fmaxf(n1r, 1e-12f);
+    const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    const float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    const float nur = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const float nu = fmaxf(nur, 1e-12f);
+    const float b2[3] = {u[0] / nu, u[1] / nu, u[2] / nu};
+    float db1[3] = {dR[0], dR[3], dR[6]}, db2[3] = {dR[1], dR[4], dR[7]};
+    const float db3[3] = {dR[2], dR[5], dR[8]};
+    // b3 = b1 x b2
+    db1[0] += b2[1] * db3[2] - b2[2] * db3[1];
+    db1[1] += b2[2] * db3[0] - b2[0] * db3[2];
+    db1[2] += b2[0] * db3[1] - b2[1] * db3[0];
+    db2[0] += db3[1] * b1[2] - db3[2] * b1[1];
+    db2[1] += db3[2] * b1[0] - db3[0] * b1[2];
+    db2[2] += db3[0] * b1[1] - db3[1] * b1[0];
+    // b2 = u / max(|u|, eps)
+    float du[3];
+    if (nur > 1e-12f) {
+        const float s = b2[0] * db2[0] + b2[1] * db2[1] + b2[2] * db2[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) du[i] = (db2[i] - b2[i] * s) / nu;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) du[i] = db2[i] / nu;
+    }
+    // u = a2 - (b1.a2) b1
+    float da2[3] = {du[0], du[1], du[2]};
+    const float dd = -(du[0] * b1[0] + du[1] * b1[1] + du[2] * b1[2]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { db1[i] += -d * du[i] + dd * a2[i]; da2[i] += dd * b1[i]; }
+    float da1[3];
+    if (n1r > 1e-12f) {
+        const float s = b1[0] * db1[0] + b1[1] * db1[1] + b1[2] * db1[2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) da1[i] = (db1[i] - b1[i] * s) / n1;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) da1[i] = db1[i] / n1;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { dr6[2 * i] = da1[i]; dr6[2 * i + 1] = da2[i]; }
+}
+
+// verts[n,v,:] = (s * mesh[n,v,:]) @ R[n] + t[n]      grid (chunks, N)
+__global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
+                                                   const float* __restrict__ trans, const float* __restrict__ scale,
+                                                   int abs_scale, int N, int V, float* __restrict__ rotmat,
+                                                   float* __restrict__ verts)
+{
+    __shared__ float R[9];
+    const int n = blockIdx.y;
+    if (threadIdx.x == 0) {
+        float r[9];
+        rot6d_to_mat(rot6d + n * 6, r);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = r[k];
+        if (blockIdx.x == 0 && rotmat)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) rotmat[n * 9 + k] = r[k];
+    }
+    __syncthreads();
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= V) return;
+    float s = scale[0];
+    if (abs_scale) s = fabsf(s);
+    const float* m = mesh + ((long)n * V + v) * 3;
+    const float x = s * m[0], y = s * m[1], z = s * m[2];
+    float* o = verts + ((long)n * V + v) * 3;
+    const float* t = trans + n * 3;
+    o[0] = x * R[0] + y * R[3] + z * R[6] + t[0];
+    o[1] = x * R[1] + y * R[4] + z * R[7] + t[1];
+    o[2] = x * R[2] + y * R[5] + z * R[8] + t[2];
+}
+
+// backward: g_full reaches mesh, scale, R, t ; g_rigid (mesh-detached twin) reaches R, t only.  grid (N)
+__global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
+                                                   const float* __restrict__ scale, int abs_scale,
+                                                   const float* __restrict__ g_full, const float* __restrict__ g_rigid,
+                                                   int N, int V, float* __restrict__ g_mesh,
+                                                   float* __restrict__ g_rot6d, float* __restrict__ g_trans,
+                                                   float* __restrict__ g_scale_part)
+{
+    __shared__ float R[9];
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float r[9];
+        rot6d_to_mat(rot6d + n * 6, r);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = r[k];
+    }
+    __syncthreads();
+    const float sraw = scale[0];
+    const float s = abs_scale ? fabsf(sraw) : sraw;
+    float acc[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) acc[k] = 0.f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        const long o = ((long)n * V + v) * 3;
+        const float m[3] = {mesh[o], mesh[o + 1], mesh[o + 2]};
+        float gf[3] = {0.f, 0.f, 0.f}, gt[3];
+        if (g_full) { gf[0] = g_full[o]; gf[1] = g_full[o + 1]; gf[2] = g_full[o + 2]; }
+        gt[0] = gf[0]; gt[1] = gf[1]; gt[2] = gf[2];
+        if (g_rigid) { gt[0] += g_rigid[o]; gt[1] += g_rigid[o + 1]; gt[2] += g_rigid[o + 2]; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[3 * i + j] += (s * m[i]) * gt[j];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[9 + j] += gt[j];
+        // d(s*m)_i = sum_j R[i][j] gf_j
+        const float dm[3] = {R[0] * gf[0] + R[1] * gf[1] + R[2] * gf[2], R[3] * gf[0] + R[4] * gf[1] + R[5] * gf[2],
+                             R[6] * gf[0] + R[7] * gf[1] + R[8] * gf[2]};
+        acc[12] += m[0] * dm[0] + m[1] * dm[1] + m[2] * dm[2];
+        if (g_mesh) { g_mesh[o] = s * dm[0]; g_mesh[o + 1] = s * dm[1]; g_mesh[o + 2] = s * dm[2]; }
+    }
+    float tot[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) tot[k] = hm_block_sum(acc[k], red);
+    if (threadIdx.x == 0) {
+        float dr6[6];
+        rot6d_backward(rot6d + n * 6, tot, dr6);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g_rot6d[n * 6 + k] = dr6[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g_trans[n * 3 + k] = tot[9 + k];
+        if (g_scale_part) g_scale_part[n] = (abs_scale && sraw < 0.f) ? -tot[12] : tot[12];
+    }
+}
+
+// out[i] = s[0] * in[i]   (backward of "loss = f(x)" ops whose unit gradient was produced in the forward)
+__global__ void k_scale_by(const float* __restrict__ in, const float* __restrict__ s, long n, float* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = s[0] * in[i];
+}
+// out[i] = s0[0]*a[i] + s1[0]*b[i]
+__global__ void k_scale2_by(const float* __restrict__ a, const float* __restrict__ s0, const float* __restrict__ b,
+                            const float* __restrict__ s1, long n, float* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = s0[0] * a[i] + s1[0] * b[i];
+}
+
+extern "C" {
+int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, const float* scale, int abs_scale, int N,
+                 int V, float* rotmat, float* verts, hipStream_t stream)
+{
+    HM_CHECK_ARG(mesh && rot6d && trans && scale && verts && N > 0 && V > 0);
+    hipLaunchKernelGGL(k_rigid_fwd, dim3(hm_cdiv(V, 256), N), dim3(256), 0, stream, mesh, rot6d, trans, scale,
+                       abs_scale, N, V, rotmat, verts);
+    return hm_launch_status();
+}
+int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* g_full,
+                 const float* g_rigid, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans,
+                 float* g_scale_part, hipStream_t stream)
+{
+    HM_CHECK_ARG(mesh && rot6d && scale && g_rot6d && g_trans && N > 0 && V > 0);
+    hipLaunchKernelGGL(k_rigid_bwd, dim3(N), dim3(256), 0, stream, mesh, rot6d, scale, abs_scale, g_full, g_rigid, N,
+                       V, g_mesh, g_rot6d, g_trans, g_scale_part);
+    return hm_launch_status();
+}
+int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream)
+{
+    HM_CHECK_ARG(in && s && out && n > 0);
+    hipLaunchKernelGGL(k_scale_by, dim3(hm_cdiv(n, 256)), dim3(256), 0, stream, in, s, n, out);
+    return hm_launch_status();
+}
+int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s1, long n, float* out,
+                 hipStream_t stream)
+{
+    HM_CHECK_ARG(a && b && s0 && s1 && out && n > 0);
+    hipLaunchKernelGGL(k_scale2_by, dim3(hm_cdiv(n, 256)), dim3(256), 0, stream, a, s0, b, s1, n, out);
+    return hm_launch_status();
+}
+}  // extern "C"

@@ -78,3 +78,31 @@ __device__ __forceinline__ float hm_block_max(float v, float* red)
     for (int i = 1; i < nw; ++i) t = fmaxf(t, red[i]);
     return t;
 }
+
+// ---- single-launch grid reduction ("last block finishes") -----------------------------------------
+// Every block stores its partial record, then takes a ticket; the block that draws the last ticket
+// re-reads all records in index order (deterministic) and finishes.  Cross-workgroup visibility follows
+// the CDNA4 rule: producer agent-scope release before the ticket, consumer agent-scope acquire after it
+// (per-XCD L2s / per-CU L1s are not coherent otherwise).  `counter` must be zero on entry; the last
+// block resets it, so one zero-initialised word serves every launch on the stream.
+// Usage:   if (hm_last_block(counter, nblocks, &s_flag)) { ...read partials, write result... }
+// Call with all threads of the block, after the block's partial record was written by thread 0.
+__device__ __forceinline__ bool hm_last_block(unsigned int* counter, unsigned int nblocks, int* s_flag)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int ticket = atomicAdd(counter, 1u);
+        const int last = (ticket == nblocks - 1u);
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            atomicExch(counter, 0u);
+        }
+        *s_flag = last;
+    }
+    __syncthreads();
+    const bool last = *s_flag != 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    return last;
+}

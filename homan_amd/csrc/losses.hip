@@ -1,0 +1,258 @@
+// losses.hip -- the small per-vertex / per-frame losses of the reference, forward value + unit gradient
+// in one launch each (the backward is then a scalar scaling).
+//
+//   hm_v2d_fwd        reference homan/losses.py:141-164  (2-D reprojection of hand vertices + px metric)
+//   hm_smooth_fwd     reference homan/lossutils.py:18-36 (temporal smoothness, hand or object)
+//   hm_priors_fwd     reference homan/lossutils.py:39-40 (PCA prior) and :107-109 (intrinsic scale priors)
+//   hm_inter_fwd/bwd  reference homan/losses.py:20-49,98-139,199-242 + utils/bbox.py:111-135 +
+//                     utils/geometry.py:69-86 (coarse interaction: bbox-IoU / z gating, centroid MSE, summed)
+#include "hm_common.h"
+
+#define RED_THREADS 256
+
+// ------------------------------------------------------------------ v2d
+// grid (nblk). partial records: 2 floats per block.
+__global__ __launch_bounds__(RED_THREADS) void k_v2d(const float* __restrict__ verts, const float* __restrict__ camintr,
+                                                      int hand_nb, const float* __restrict__ ref2d, float image_size,
+                                                      int N, int V, float* __restrict__ unit_grad,
+                                                      float* __restrict__ partials, unsigned int* counter,
+                                                      float* __restrict__ out)
+{
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    const long total = (long)N * V;
+    const float inv_cnt = 1.0f / (float)total;
+    float lsum = 0.f, msum = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / V);
+        const float* k = camintr + (n / hand_nb) * 9;
+        const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+        const float hx = k[0] * x + k[1] * y + k[2] * z;
+        const float hy = k[3] * x + k[4] * y + k[5] * z;
+        const float hz = k[6] * x + k[7] * y + k[8] * z;
+        const float px = hx / hz, py = hy / hz;
+        const float rx = ref2d[2 * i], ry = ref2d[2 * i + 1];
+        const float dx = px - rx / image_size, dy = py - ry / image_size;
+        lsum += dx * dx + dy * dy;
+        const float mx = px * image_size - rx, my = py * image_size - ry;
+        msum += sqrtf(mx * mx + my * my);
+        // d loss / d (px,py) = 2 d / count
+        const float gpx = 2.0f * dx * inv_cnt, gpy = 2.0f * dy * inv_cnt;
+        const float ghx = gpx / hz, ghy = gpy / hz, ghz = -(gpx * hx + gpy * hy) / (hz * hz);
+        unit_grad[3 * i] = k[0] * ghx + k[3] * ghy + k[6] * ghz;
+        unit_grad[3 * i + 1] = k[1] * ghx + k[4] * ghy + k[7] * ghz;
+        unit_grad[3 * i + 2] = k[2] * ghx + k[5] * ghy + k[8] * ghz;
+    }
+    lsum = hm_block_sum(lsum, red);
+    msum = hm_block_sum(msum, red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = lsum; partials[2 * blockIdx.x + 1] = msum; }
+    if (hm_last_block(counter, gridDim.x, &s_flag) && threadIdx.x == 0) {
+        float a = 0.f, b = 0.f;
+        for (unsigned i = 0; i < gridDim.x; ++i) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+        out[0] = a * inv_cnt;
+        out[1] = b * inv_cnt;
+    }
+}
+
+// ------------------------------------------------------------------ temporal smoothness
+// verts (N,V,3), frames interleaved by `hand_nb` (pairs n, n+hand_nb).  loss = mean over pairs of diff^2.
+__global__ __launch_bounds__(RED_THREADS) void k_smooth(const float* __restrict__ verts, int N, int V, int hand_nb,
+                                                         float* __restrict__ unit_grad, float* __restrict__ partials,
+                                                         unsigned int* counter, float* __restrict__ out)
+{
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    const long row = (long)V * 3, total = (long)N * row;
+    const long cnt = (long)(N - hand_nb) * row;
+    const float inv_cnt = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    const long step = (long)hand_nb * row;
+    float lsum = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / row);
+        const float v = verts[i];
+        float g = 0.f;
+        if (n + hand_nb < N) {
+            const float d = verts[i + step] - v;
+            lsum += d * d;
+            g -= d;
+        }
+        if (n - hand_nb >= 0) g += v - verts[i - step];
+        unit_grad[i] = 2.0f * g * inv_cnt;
+    }
+    lsum = hm_block_sum(lsum, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = lsum;
+    if (hm_last_block(counter, gridDim.x, &s_flag) && threadIdx.x == 0) {
+        float a = 0.f;
+        for (unsigned i = 0; i < gridDim.x; ++i) a += partials[i];
+        out[0] = a * inv_cnt;
+    }
+}
+
+// ------------------------------------------------------------------ PCA prior + intrinsic scale priors (one block)
+// out[0] = mean(pca^2), out[1] = sum((s_obj - m_obj)^2)/1, out[2] = same for the hand scale.
+__global__ __launch_bounds__(RED_THREADS) void k_priors(const float* __restrict__ pca, long npca,
+                                                         const float* __restrict__ s_obj, const float* __restrict__ m_obj,
+                                                         const float* __restrict__ s_hand, const float* __restrict__ m_hand,
+                                                         float* __restrict__ g_pca, float* __restrict__ g_sobj,
+                                                         float* __restrict__ g_shand, float* __restrict__ out)
+{
+    __shared__ float red[16];
+    float a = 0.f;
+    const float inv = 1.0f / (float)npca;
+    for (long i = threadIdx.x; i < npca; i += blockDim.x) {
+        const float p = pca[i];
+        a += p * p;
+        g_pca[i] = 2.0f * p * inv;
+    }
+    a = hm_block_sum(a, red);
+    if (threadIdx.x == 0) {
+        out[0] = a * inv;
+        const float d0 = s_obj[0] - m_obj[0], d1 = s_hand[0] - m_hand[0];
+        out[1] = d0 * d0;
+        out[2] = d1 * d1;
+        g_sobj[0] = 2.0f * d0;
+        g_shand[0] = 2.0f * d1;
+    }
+}
+
+// ------------------------------------------------------------------ coarse interaction loss
+// grid (B).  Per frame: expanded 2-D boxes of the projected meshes (y negated, nr.projection with the
+// normalised camera, orig_size 1), IoU>0 and z-gap<thresh gate, MSE of the two centroids.
+// frame record (8 floats): flag, mse, gvec[3] (= flag*2*(ch-co)/3), pad.
+__global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__ vh, const float* __restrict__ vo,
+                                                        const float* __restrict__ camintr, int B, int Vh, int Vo,
+                                                        float expansion, float zthresh, float* __restrict__ frame_rec,
+                                                        unsigned int* counter, float* __restrict__ out)
+{
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    const int b = blockIdx.x;
+    const float* k = camintr + b * 9;
+    float box[2][4], zr[2][2], cen[2][3];
+    for (int which = 0; which < 2; ++which) {
+        const float* v = which == 0 ? vo + (long)b * Vo * 3 : vh + (long)b * Vh * 3;
+        const int V = which == 0 ? Vo : Vh;
+        float umin = 3.4e38f, umax = -3.4e38f, vmin = 3.4e38f, vmax = -3.4e38f, zmin = 3.4e38f, zmax = -3.4e38f;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int i = threadIdx.x; i < V; i += blockDim.x) {
+            const float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
+            const float zz = z + 1e-9f;
+            const float xn = x / zz, yn = (y * -1.0f) / zz;
+            float u = xn * k[0] + yn * k[1];
+            u = u + k[2];
+            float w = xn * k[3] + yn * k[4];
+            w = w + k[5];
+            w = 1.0f - w;
+            u = 2.0f * (u - 0.5f);
+            w = 2.0f * (w - 0.5f);
+            umin = fminf(umin, u); umax = fmaxf(umax, u);
+            vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+            zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+            sx += x; sy += y; sz += z;
+        }
+        umin = hm_block_min(umin, red); umax = hm_block_max(umax, red);
+        vmin = hm_block_min(vmin, red); vmax = hm_block_max(vmax, red);
+        zmin = hm_block_min(zmin, red); zmax = hm_block_max(zmax, red);
+        sx = hm_block_sum(sx, red); sy = hm_block_sum(sy, red); sz = hm_block_sum(sz, red);
+        const float cx = (umin + umax) / 2.0f, cy = (vmin + vmax) / 2.0f;
+        const float ex = (umax - umin) / 2.0f * (1.0f + expansion), ey = (vmax - vmin) / 2.0f * (1.0f + expansion);
+        box[which][0] = cx - ex; box[which][1] = cy - ey; box[which][2] = cx + ex; box[which][3] = cy + ey;
+        zr[which][0] = zmin; zr[which][1] = zmax;
+        cen[which][0] = sx / (float)V; cen[which][1] = sy / (float)V; cen[which][2] = sz / (float)V;
+    }
+    if (threadIdx.x == 0) {
+        // compute_iou(box_obj, box_hand)
+        const float a1 = (box[0][2] - box[0][0]) * (box[0][3] - box[0][1]);
+        const float a2 = (box[1][2] - box[1][0]) * (box[1][3] - box[1][1]);
+        const float w = fmaxf(fminf(box[0][2], box[1][2]) - fmaxf(box[0][0], box[1][0]), 0.f);
+        const float h = fmaxf(fminf(box[0][3], box[1][3]) - fmaxf(box[0][1], box[1][1]), 0.f);
+        const float inter = w * h;
+        const float iou = inter / (a1 + a2 - inter);
+        // compute_dist_z(verts_object, verts_hand)
+        const float a = zr[0][0], bb = zr[0][1], c = zr[1][0], d = zr[1][1];
+        const float zd = (d >= a && bb >= c) ? 0.f : fminf(fabsf(c - bb), fabsf(a - d));
+        const float flag = ((iou > 0.f) && (zd < zthresh)) ? 1.f : 0.f;
+        const float dx = cen[1][0] - cen[0][0], dy = cen[1][1] - cen[0][1], dz = cen[1][2] - cen[0][2];
+        const float mse = (dx * dx + dy * dy + dz * dz) / 3.0f;
+        float* r = frame_rec + b * 8;
+        r[0] = flag; r[1] = mse;
+        r[2] = flag * 2.0f * dx / 3.0f; r[3] = flag * 2.0f * dy / 3.0f; r[4] = flag * 2.0f * dz / 3.0f;
+    }
+    if (hm_last_block(counter, gridDim.x, &s_flag) && threadIdx.x == 0) {
+        float l = 0.f;
+        for (int i = 0; i < B; ++i)
+            if (frame_rec[i * 8] != 0.f) l += frame_rec[i * 8 + 1];
+        out[0] = l;
+    }
+}
+
+// d loss_inter / d verts: hand gets +gvec/Vh, object gets -gvec/Vo (either output may be NULL)
+__global__ void k_inter_bwd(const float* __restrict__ frame_rec, const float* __restrict__ upstream, int B, int Vh,
+                            int Vo, float* __restrict__ g_hand, float* __restrict__ g_obj)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nh = (long)B * Vh * 3, no = (long)B * Vo * 3;
+    const float up = upstream[0];
+    if (g_hand && i < nh) {
+        const int b = (int)(i / ((long)Vh * 3)), c = (int)(i % 3);
+        g_hand[i] = up * frame_rec[b * 8 + 2 + c] / (float)Vh;
+    }
+    if (g_obj && i < no) {
+        const int b = (int)(i / ((long)Vo * 3)), c = (int)(i % 3);
+        g_obj[i] = -up * frame_rec[b * 8 + 2 + c] / (float)Vo;
+    }
+}
+
+extern "C" {
+#define HM_RED_MAX_BLOCKS 256
+// workspace for the reductions: 512 floats of partials + 1 counter word at float offset 512
+// (the whole buffer must be zero-initialised once; the counter resets itself)
+size_t hm_reduce_workspace_bytes(void) { return (512 + 64) * sizeof(float); }
+
+static inline unsigned int* ws_counter(void* ws) { return (unsigned int*)((float*)ws + 512); }
+
+int hm_v2d_fwd(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size, int N,
+               int V, float* unit_grad, float* out2, void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && camintr && ref2d && unit_grad && out2 && workspace && N > 0 && V > 0 && hand_nb > 0);
+    const int nblk = min(HM_RED_MAX_BLOCKS, hm_cdiv((long)N * V, RED_THREADS));
+    hipLaunchKernelGGL(k_v2d, dim3(nblk), dim3(RED_THREADS), 0, stream, verts, camintr, hand_nb, ref2d, image_size, N,
+                       V, unit_grad, (float*)workspace, ws_counter(workspace), out2);
+    return hm_launch_status();
+}
+int hm_smooth_fwd(const float* verts, int N, int V, int hand_nb, float* unit_grad, float* out1, void* workspace,
+                  hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && unit_grad && out1 && workspace && N > 0 && V > 0 && hand_nb > 0);
+    const int nblk = min(HM_RED_MAX_BLOCKS, hm_cdiv((long)N * V * 3, RED_THREADS * 4));
+    hipLaunchKernelGGL(k_smooth, dim3(nblk), dim3(RED_THREADS), 0, stream, verts, N, V, hand_nb, unit_grad,
+                       (float*)workspace, ws_counter(workspace), out1);
+    return hm_launch_status();
+}
+int hm_priors_fwd(const float* pca, long npca, const float* s_obj, const float* m_obj, const float* s_hand,
+                  const float* m_hand, float* g_pca, float* g_sobj, float* g_shand, float* out3, hipStream_t stream)
+{
+    HM_CHECK_ARG(pca && s_obj && m_obj && s_hand && m_hand && g_pca && g_sobj && g_shand && out3 && npca > 0);
+    hipLaunchKernelGGL(k_priors, dim3(1), dim3(RED_THREADS), 0, stream, pca, npca, s_obj, m_obj, s_hand, m_hand, g_pca,
+                       g_sobj, g_shand, out3);
+    return hm_launch_status();
+}
+// frame_rec: (B,8) floats kept for the backward.
+int hm_inter_fwd(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
+                 float expansion, float zthresh, float* frame_rec, float* out1, void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts_hand && verts_obj && camintr && frame_rec && out1 && workspace && B > 0 && Vh > 0 && Vo > 0);
+    hipLaunchKernelGGL(k_inter, dim3(B), dim3(RED_THREADS), 0, stream, verts_hand, verts_obj, camintr, B, Vh, Vo,
+                       expansion, zthresh, frame_rec, ws_counter(workspace), out1);
+    return hm_launch_status();
+}
+int hm_inter_bwd(const float* frame_rec, const float* upstream, int B, int Vh, int Vo, float* g_hand, float* g_obj,
+                 hipStream_t stream)
+{
+    HM_CHECK_ARG(frame_rec && upstream && B > 0 && (g_hand || g_obj));
+    const long n = (long)B * (Vh > Vo ? Vh : Vo) * 3;
+    hipLaunchKernelGGL(k_inter_bwd, dim3(hm_cdiv(n, 256)), dim3(256), 0, stream, frame_rec, upstream, B, Vh, Vo, g_hand,
+                       g_obj);
+    return hm_launch_status();
+}
+}  // extern "C"

@@ -1,0 +1,386 @@
+// mano.hip -- fused MANO linear-blend-skinning forward + backward for CDNA4.
+//
+// Replaces, on the reference's hot path, ManoModel.forward_pca (reference homan/manomodel.py:84-151:
+// hand_pose = pca[:, :16] @ components + hand_mean; layer(betas, global_orient, hand_pose, transl=0))
+// and the third-party `mano` layer it calls (smplx-style LBS: shape blend shapes, joint regression,
+// Rodrigues with angle=|r+1e-8|, pose blend shapes on (R[1:]-I), kinematic chain, skinning), plus the
+// "+ mano_trans" of homan/homan.py:356.  ~40 tiny torch kernels per call become one launch forward and two
+// launches backward.
+//
+// Layout: M (145 x 2334) = [posedirs (135 rows) ; shapedirs^T (10 rows)], row-major in vertex-coordinate
+// index 3v+c, so a wave reading one row for 64 consecutive vertices is coalesced; the joint regressor is
+// folded on the host into J_template (16x3) + J_shapedirs (16x3x10).
+#include "hm_common.h"
+
+#define MANO_V 778
+#define MANO_J 16
+#define MANO_NF 145   // 135 pose-blend features + 10 betas
+#define MANO_CHUNK 256
+#define MANO_NCHUNK 4  // ceil(778/256)
+#define MANO_PART 340  // per-(frame,chunk) partials: 192 dA + 145 dfeat + 3 dtrans
+
+struct ManoModelDev {
+    const float* v_template;   // (778,3)
+    const float* M;            // (145, 2334)
+    const float* J_template;   // (16,3)
+    const float* J_shapedirs;  // (16,3,10)
+    const float* weights;      // (778,16)
+    const float* comps;        // (16,45)
+    const float* hand_mean;    // (45)
+    const int* parents;        // (16)
+};
+
+__device__ __forceinline__ void rodrigues(const float* r, float* R)
+{
+    const float e0 = r[0] + 1e-8f, e1 = r[1] + 1e-8f, e2 = r[2] + 1e-8f;
+    const float a = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+    const float nx = r[0] / a, ny = r[1] / a, nz = r[2] / a;
+    const float s = sinf(a), c1 = 1.0f - cosf(a);
+    // K = [[0,-nz,ny],[nz,0,-nx],[-ny,nx,0]] ; R = I + s K + (1-c) K K
+    const float K[9] = {0.f, -nz, ny, nz, 0.f, -nx, -ny, nx, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float kk = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+            R[3 * i + j] = (i == j ? 1.0f : 0.0f) + s * K[3 * i + j] + c1 * kk;
+        }
+}
+
+// dL/dR -> dL/dr
+__device__ __forceinline__ void rodrigues_backward(const float* r, const float* dR, float* dr)
+{
+    const float e[3] = {r[0] + 1e-8f, r[1] + 1e-8f, r[2] + 1e-8f};
+    const float a = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    const float n[3] = {r[0] / a, r[1] / a, r[2] / a};
+    const float s = sinf(a), c = cosf(a), c1 = 1.0f - c;
+    const float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
+    float KK[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) KK[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    float dRK = 0.f, dRKK = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { dRK += dR[k] * K[k]; dRKK += dR[k] * KK[k]; }
+    float da = c * dRK + s * dRKK;
+    // dK = s dR + (1-c) (dR K^T + K^T dR)
+    float dK[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float t1 = dR[3 * i] * K[3 * j] + dR[3 * i + 1] * K[3 * j + 1] + dR[3 * i + 2] * K[3 * j + 2];   // dR K^T
+            float t2 = K[i] * dR[j] + K[3 + i] * dR[3 + j] + K[6 + i] * dR[6 + j];                            // K^T dR
+            dK[3 * i + j] = s * dR[3 * i + j] + c1 * (t1 + t2);
+        }
+    const float dn[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+    // n = r / a
+    da += -(dn[0] * r[0] + dn[1] * r[1] + dn[2] * r[2]) / (a * a);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) dr[i] = dn[i] / a + da * e[i] / a;
+}
+
+struct ManoShared {
+    float pose[48];
+    float Rl[MANO_J][9];     // local rotations
+    float J[MANO_J][3];      // rest joints
+    float Rw[MANO_J][9];     // world rotations
+    float tw[MANO_J][3];     // world translations (= posed joints)
+    float A[MANO_J][12];     // skinning transforms [R | t] with the rest pose removed
+    float feat[MANO_NF];     // pose feature (135) + betas (10)
+};
+
+// pose / Rodrigues / joints / chain, shared by forward and both backward kernels.  Needs >= 64 threads.
+__device__ __forceinline__ void mano_prepare(const ManoModelDev& m, const float* pca, int pca_stride, const float* rot,
+                                             const float* betas, int b, ManoShared& sh)
+{
+    const int t = threadIdx.x;
+    if (t < 48) {
+        float v;
+        if (t < 3) v = rot[b * 3 + t];
+        else {
+            const int k = t - 3;
+            v = 0.f;
+            for (int i = 0; i < 16; ++i) v += pca[(long)b * pca_stride + i] * m.comps[i * 45 + k];
+            v += m.hand_mean[k];
+        }
+        sh.pose[t] = v;
+    }
+    if (t < 10) sh.feat[135 + t] = betas[b * 10 + t];
+    __syncthreads();
+    if (t < MANO_J) {
+        float R[9];
+        rodrigues(&sh.pose[3 * t], R);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sh.Rl[t][k] = R[k];
+        if (t >= 1)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) sh.feat[9 * (t - 1) + k] = R[k] - ((k % 4 == 0) ? 1.0f : 0.0f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = m.J_template[t * 3 + c];
+            for (int l = 0; l < 10; ++l) v += betas[b * 10 + l] * m.J_shapedirs[(t * 3 + c) * 10 + l];
+            sh.J[t][c] = v;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (int j = 0; j < MANO_J; ++j) {
+            const int p = m.parents[j];
+            if (p < 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) sh.Rw[j][k] = sh.Rl[j][k];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) sh.tw[j][c] = sh.J[j][c];
+            } else {
+                float rel[3] = {sh.J[j][0] - sh.J[p][0], sh.J[j][1] - sh.J[p][1], sh.J[j][2] - sh.J[p][2]};
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        sh.Rw[j][3 * i + k] = sh.Rw[p][3 * i] * sh.Rl[j][k] + sh.Rw[p][3 * i + 1] * sh.Rl[j][3 + k] +
+                                              sh.Rw[p][3 * i + 2] * sh.Rl[j][6 + k];
+                    sh.tw[j][i] = sh.Rw[p][3 * i] * rel[0] + sh.Rw[p][3 * i + 1] * rel[1] + sh.Rw[p][3 * i + 2] * rel[2] +
+                                  sh.tw[p][i];
+                }
+            }
+        }
+        for (int j = 0; j < MANO_J; ++j)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                sh.A[j][4 * i] = sh.Rw[j][3 * i];
+                sh.A[j][4 * i + 1] = sh.Rw[j][3 * i + 1];
+                sh.A[j][4 * i + 2] = sh.Rw[j][3 * i + 2];
+                sh.A[j][4 * i + 3] = sh.tw[j][i] - (sh.Rw[j][3 * i] * sh.J[j][0] + sh.Rw[j][3 * i + 1] * sh.J[j][1] +
+                                                    sh.Rw[j][3 * i + 2] * sh.J[j][2]);
+            }
+    }
+    __syncthreads();
+}
+
+// posed vertex (before skinning) and its blended skinning transform
+__device__ __forceinline__ void mano_vertex(const ManoModelDev& m, const ManoShared& sh, int v, float* vp, float* T)
+{
+#pragma unroll
+    for (int c = 0; c < 3; ++c) vp[c] = m.v_template[3 * v + c];
+    for (int k = 0; k < MANO_NF; ++k) {
+        const float f = sh.feat[k];
+        const float* row = m.M + (long)k * (3 * MANO_V) + 3 * v;
+        vp[0] += f * row[0];
+        vp[1] += f * row[1];
+        vp[2] += f * row[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = 0.f;
+    for (int j = 0; j < MANO_J; ++j) {
+        const float w = m.weights[v * MANO_J + j];
+        if (w != 0.f)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) T[k] += w * sh.A[j][k];
+    }
+}
+
+// grid (4, B).  verts (B,778,3) = LBS + trans ; joints (B,16,3) optional (posed joints + trans)
+__global__ __launch_bounds__(MANO_CHUNK) void k_mano_fwd(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
+                                                          const float* __restrict__ rot, const float* __restrict__ betas,
+                                                          const float* __restrict__ trans, int B,
+                                                          float* __restrict__ verts, float* __restrict__ joints)
+{
+    __shared__ ManoShared sh;
+    const int b = blockIdx.y;
+    mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
+    const float tr[3] = {trans ? trans[b * 3] : 0.f, trans ? trans[b * 3 + 1] : 0.f, trans ? trans[b * 3 + 2] : 0.f};
+    if (joints && blockIdx.x == 0 && threadIdx.x < MANO_J * 3)
+        joints[b * MANO_J * 3 + threadIdx.x] = sh.tw[threadIdx.x / 3][threadIdx.x % 3] + tr[threadIdx.x % 3];
+    const int v = blockIdx.x * MANO_CHUNK + threadIdx.x;
+    if (v >= MANO_V) return;
+    float vp[3], T[12];
+    mano_vertex(m, sh, v, vp, T);
+    float* o = verts + ((long)b * MANO_V + v) * 3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = T[4 * i] * vp[0] + T[4 * i + 1] * vp[1] + T[4 * i + 2] * vp[2] + T[4 * i + 3] + tr[i];
+}
+
+// backward pass 1: grid (4, B) -> partials (B, 4, 340)
+__global__ __launch_bounds__(MANO_CHUNK) void k_mano_bwd1(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
+                                                           const float* __restrict__ rot, const float* __restrict__ betas,
+                                                           const float* __restrict__ gout, int B,
+                                                           float* __restrict__ partials)
+{
+    __shared__ ManoShared sh;
+    __shared__ float s_g[MANO_CHUNK][3];
+    __shared__ float s_vp[MANO_CHUNK][3];
+    __shared__ float s_dvp[MANO_CHUNK * 3];
+    __shared__ float s_w[MANO_CHUNK][MANO_J + 1];
+    __shared__ float red[16];
+    const int b = blockIdx.y, t = threadIdx.x;
+    mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
+    const int v0 = blockIdx.x * MANO_CHUNK;
+    const int v = v0 + t;
+    const int nv = min(MANO_CHUNK, MANO_V - v0);
+    float g[3] = {0.f, 0.f, 0.f};
+    if (v < MANO_V) {
+        float vp[3], T[12];
+        mano_vertex(m, sh, v, vp, T);
+        const float* gp = gout + ((long)b * MANO_V + v) * 3;
+        g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s_g[t][c] = g[c];
+            s_vp[t][c] = vp[c];
+            s_dvp[3 * t + c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
+        }
+        for (int j = 0; j < MANO_J; ++j) s_w[t][j] = m.weights[v * MANO_J + j];
+    }
+    float* out = partials + ((long)b * MANO_NCHUNK + blockIdx.x) * MANO_PART;
+    const float tg0 = hm_block_sum(g[0], red), tg1 = hm_block_sum(g[1], red), tg2 = hm_block_sum(g[2], red);
+    if (t == 0) { out[337] = tg0; out[338] = tg1; out[339] = tg2; }
+    __syncthreads();
+    // dA[j][r][c] = sum_v W[v][j] g[v][r] [vp;1][c]
+    if (t < 192) {
+        const int j = t / 12, r = (t % 12) / 4, c = t % 4;
+        float acc = 0.f;
+        for (int i = 0; i < nv; ++i) acc += s_w[i][j] * s_g[i][r] * (c < 3 ? s_vp[i][c] : 1.0f);
+        out[t] = acc;
+    }
+    // dfeat[k] = sum_{v,c} M[k][3v+c] dvp[v][c]   (one wave per row, coalesced)
+    const int wv = t >> 6, lane = t & 63;
+    for (int k = wv; k < MANO_NF; k += MANO_CHUNK / 64) {
+        const float* row = m.M + (long)k * (3 * MANO_V) + 3 * v0;
+        float acc = 0.f;
+        for (int e = lane; e < 3 * nv; e += 64) acc += row[e] * s_dvp[e];
+        acc = hm_wave_sum(acc);
+        if (lane == 0) out[192 + k] = acc;
+    }
+}
+
+// backward pass 2: grid (B), 64 threads: reduce chunk partials, chain / Rodrigues / PCA backward
+__global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
+                                                   const float* __restrict__ rot, const float* __restrict__ betas,
+                                                   const float* __restrict__ partials, int B, int pca_dim,
+                                                   float* __restrict__ g_pca, float* __restrict__ g_rot,
+                                                   float* __restrict__ g_betas, float* __restrict__ g_trans)
+{
+    __shared__ ManoShared sh;
+    __shared__ float tot[MANO_PART];
+    __shared__ float dRw[MANO_J][9], dtw[MANO_J][3], dJ[MANO_J][3], dRl[MANO_J][9], dpose[48];
+    const int b = blockIdx.x, t = threadIdx.x;
+    mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
+    for (int k = t; k < MANO_PART; k += 64) {
+        float a = 0.f;
+        for (int c = 0; c < MANO_NCHUNK; ++c) a += partials[((long)b * MANO_NCHUNK + c) * MANO_PART + k];
+        tot[k] = a;
+    }
+    __syncthreads();
+    if (t < MANO_J) {
+        const int j = t;
+        const float* dA = &tot[j * 12];
+        // A = [Rw | tw - Rw J]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dRw[j][3 * i + k] = dA[4 * i + k] - dA[4 * i + 3] * sh.J[j][k];
+            dtw[j][i] = dA[4 * i + 3];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            dJ[j][k] = -(sh.Rw[j][k] * dA[3] + sh.Rw[j][3 + k] * dA[7] + sh.Rw[j][6 + k] * dA[11]);
+    }
+    __syncthreads();
+    if (t == 0) {
+        for (int j = MANO_J - 1; j >= 0; --j) {
+            const int p = m.parents[j];
+            if (p < 0) {
+#pragma unroll
+                for (int k = 0; k < 9; ++k) dRl[j][k] = dRw[j][k];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) dJ[j][c] += dtw[j][c];
+                continue;
+            }
+            const float rel[3] = {sh.J[j][0] - sh.J[p][0], sh.J[j][1] - sh.J[p][1], sh.J[j][2] - sh.J[p][2]};
+            // tw_j = Rw_p rel + tw_p
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) dRw[p][3 * i + k] += dtw[j][i] * rel[k];
+                dtw[p][i] += dtw[j][i];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d = sh.Rw[p][k] * dtw[j][0] + sh.Rw[p][3 + k] * dtw[j][1] + sh.Rw[p][6 + k] * dtw[j][2];
+                dJ[j][k] += d;
+                dJ[p][k] -= d;
+            }
+            // Rw_j = Rw_p Rl_j
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    dRw[p][3 * i + k] += dRw[j][3 * i] * sh.Rl[j][3 * k] + dRw[j][3 * i + 1] * sh.Rl[j][3 * k + 1] +
+                                         dRw[j][3 * i + 2] * sh.Rl[j][3 * k + 2];
+                    dRl[j][3 * i + k] = sh.Rw[p][i] * dRw[j][k] + sh.Rw[p][3 + i] * dRw[j][3 + k] +
+                                        sh.Rw[p][6 + i] * dRw[j][6 + k];
+                }
+        }
+    }
+    __syncthreads();
+    if (t < MANO_J) {
+        float dR[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dR[k] = dRl[t][k] + (t >= 1 ? tot[192 + 9 * (t - 1) + k] : 0.f);
+        float dr[3];
+        rodrigues_backward(&sh.pose[3 * t], dR, dr);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dpose[3 * t + c] = dr[c];
+    }
+    __syncthreads();
+    if (t < 3) {
+        g_rot[b * 3 + t] = dpose[t];
+        g_trans[b * 3 + t] = tot[337 + t];
+    }
+    if (t < pca_dim || t < 16) {
+        for (int i = t; i < pca_dim; i += 64) {
+            float a = 0.f;
+            if (i < 16)
+                for (int k = 0; k < 45; ++k) a += m.comps[i * 45 + k] * dpose[3 + k];
+            g_pca[(long)b * pca_dim + i] = a;
+        }
+    }
+    if (t < 10) {
+        float a = tot[192 + 135 + t];
+        for (int j = 0; j < MANO_J; ++j)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a += m.J_shapedirs[(j * 3 + c) * 10 + t] * dJ[j][c];
+        g_betas[b * 10 + t] = a;
+    }
+}
+
+extern "C" {
+// model: 8 device pointers in the order of ManoModelDev.
+int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
+                const float* trans, int B, float* verts, float* joints, hipStream_t stream)
+{
+    HM_CHECK_ARG(model && pca && rot && betas && verts && B > 0 && pca_dim >= 16);
+    ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
+                      (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
+    hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCHUNK, B), dim3(MANO_CHUNK), 0, stream, m, pca, pca_dim, rot, betas, trans,
+                       B, verts, joints);
+    return hm_launch_status();
+}
+size_t hm_mano_workspace_bytes(int B) { return (size_t)B * MANO_NCHUNK * MANO_PART * sizeof(float); }
+int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
+                const float* g_verts, float* g_pca, float* g_rot, float* g_betas, float* g_trans, void* workspace,
+                hipStream_t stream)
+{
+    HM_CHECK_ARG(model && pca && rot && betas && g_verts && g_pca && g_rot && g_betas && g_trans && workspace);
+    HM_CHECK_ARG(B > 0 && pca_dim >= 16);
+    ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
+                      (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
+    hipLaunchKernelGGL(k_mano_bwd1, dim3(MANO_NCHUNK, B), dim3(MANO_CHUNK), 0, stream, m, pca, pca_dim, rot, betas,
+                       g_verts, B, (float*)workspace);
+    hipLaunchKernelGGL(k_mano_bwd2, dim3(B), dim3(64), 0, stream, m, pca, pca_dim, rot, betas, (const float*)workspace,
+                       B, pca_dim, g_pca, g_rot, g_betas, g_trans);
+    return hm_launch_status();
+}
+}  // extern "C"

@@ -1,0 +1,344 @@
+// sdf.hip -- SDF-based interpenetration loss (voxel inside/outside + point-triangle distance + trilinear sampling).
+//
+// Replaces reference homan/lossutils.py:43-64 -> homan/interactions/scenesdf.py:77-148 (SDFSceneLoss.forward) and the
+// third-party CUDA package `sdf` it calls (scenesdf.py:119), for the scene [closed MANO hand, object]:
+//   per object k and frame: AABB -> centre, scale = max_axis(extent) * 0.6 ; phi_k = clamp(SDF(mesh_k), 0) on a 32^3
+//   grid of the normalised box ; for both ordered pairs (k,l): d = grid_sample(phi_k, (verts_l - c_k)/s_k) (trilinear,
+//   zeros padding, align_corners=False) ; loss = sum of every sample (normalised units).  Gradients reach the sampled
+//   vertices only (boxes and phi are built under no_grad in the reference).
+//
+// Exact restructuring (same numbers, far less work than the reference's 4.5e9 voxel-triangle tests / iteration):
+//   * phi is clamped at 0, so only INSIDE voxels carry a value: the sign pass (ray-crossing parity along +x, one
+//     thread per (y,z) row, triangles staged through LDS) produces a 32-bit inside mask per row;
+//   * distances are evaluated lazily, only for inside voxels that a sample point actually touches: the 8 trilinear
+//     corners of each sample are checked against the mask and each needed voxel is evaluated by a full wavefront
+//     (64 lanes stride the triangle list, shuffle-min).
+// Conventions identical to oracle/csrc/sdf.c (voxel centres -1+(i+0.5)*2/N, phi[z][y][x], half-open orientation rule).
+#include "hm_common.h"
+
+#define SDF_N 32
+#define SDF_THREADS 256
+
+__device__ __forceinline__ float dot3(const float* a, const float* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+
+__device__ __forceinline__ float seg_dist(const float* x0, const float* x1, const float* x2)
+{
+    const float dx[3] = {x2[0] - x1[0], x2[1] - x1[1], x2[2] - x1[2]};
+    const float m2 = dot3(dx, dx);
+    const float e[3] = {x2[0] - x0[0], x2[1] - x0[1], x2[2] - x0[2]};
+    float s12 = (m2 > 0.0f) ? dot3(e, dx) / m2 : 0.0f;
+    if (s12 < 0.0f) s12 = 0.0f; else if (s12 > 1.0f) s12 = 1.0f;
+    const float t = 1.0f - s12;
+    const float c[3] = {s12 * x1[0] + t * x2[0], s12 * x1[1] + t * x2[1], s12 * x1[2] + t * x2[2]};
+    const float d[3] = {x0[0] - c[0], x0[1] - c[1], x0[2] - c[2]};
+    return sqrtf(dot3(d, d));
+}
+
+__device__ __forceinline__ float point_triangle_distance(const float* x0, const float* x1, const float* x2, const float* x3)
+{
+    const float x13[3] = {x1[0] - x3[0], x1[1] - x3[1], x1[2] - x3[2]};
+    const float x23[3] = {x2[0] - x3[0], x2[1] - x3[1], x2[2] - x3[2]};
+    const float x03[3] = {x0[0] - x3[0], x0[1] - x3[1], x0[2] - x3[2]};
+    const float m13 = dot3(x13, x13), m23 = dot3(x23, x23), d = dot3(x13, x23);
+    const float invdet = 1.0f / fmaxf(m13 * m23 - d * d, 1e-30f);
+    const float a = dot3(x13, x03), b = dot3(x23, x03);
+    const float w23 = invdet * (m23 * a - d * b);
+    const float w31 = invdet * (m13 * b - d * a);
+    const float w12 = 1.0f - w23 - w31;
+    if (w23 >= 0.0f && w31 >= 0.0f && w12 >= 0.0f) {
+        const float c[3] = {w23 * x1[0] + w31 * x2[0] + w12 * x3[0], w23 * x1[1] + w31 * x2[1] + w12 * x3[1],
+                            w23 * x1[2] + w31 * x2[2] + w12 * x3[2]};
+        const float e[3] = {x0[0] - c[0], x0[1] - c[1], x0[2] - c[2]};
+        return sqrtf(dot3(e, e));
+    }
+    if (w23 > 0.0f) return fminf(seg_dist(x0, x1, x2), seg_dist(x0, x1, x3));
+    if (w31 > 0.0f) return fminf(seg_dist(x0, x1, x2), seg_dist(x0, x2, x3));
+    return fminf(seg_dist(x0, x1, x3), seg_dist(x0, x2, x3));
+}
+
+__device__ __forceinline__ int orient2(float x1, float y1, float x2, float y2, float* tsa)
+{
+    *tsa = y1 * x2 - x1 * y2;
+    if (*tsa > 0.0f) return 1;
+    if (*tsa < 0.0f) return -1;
+    if (y2 > y1) return 1;
+    if (y2 < y1) return -1;
+    if (x1 > x2) return 1;
+    if (x1 < x2) return -1;
+    return 0;
+}
+
+__device__ __forceinline__ bool ray_x_crosses(float cy, float cz, const float* v1, const float* v2, const float* v3,
+                                              float* xhit)
+{
+    const float y1 = v1[1] - cy, z1 = v1[2] - cz, y2 = v2[1] - cy, z2 = v2[2] - cz, y3 = v3[1] - cy, z3 = v3[2] - cz;
+    float a, b, g;
+    const int sa = orient2(y2, z2, y3, z3, &a);
+    if (sa == 0) return false;
+    const int sb = orient2(y3, z3, y1, z1, &b);
+    if (sb != sa) return false;
+    const int sc = orient2(y1, z1, y2, z2, &g);
+    if (sc != sa) return false;
+    const float sum = a + b + g;
+    if (sum == 0.0f) return false;
+    const float fa = a / sum, fb = b / sum, fc = g / sum;
+    *xhit = fa * v1[0] + fb * v2[0] + fc * v3[0];
+    return true;
+}
+
+__device__ __forceinline__ float voxel_centre(int i) { return -1.0f + ((float)i + 0.5f) * (2.0f / (float)SDF_N); }
+
+// ------------------------------------------------------------------ boxes + normalised vertices.  grid (B, 2)
+// object 0 = hand, object 1 = rigid object.  boxes (2,B,4) = centre xyz, scale.  vnorm_k (B,V_k,3).
+__global__ __launch_bounds__(SDF_THREADS) void k_sdf_boxes(const float* __restrict__ v0, int V0, const float* __restrict__ v1,
+                                                            int V1, int B, float scale_factor, float* __restrict__ boxes,
+                                                            float* __restrict__ vn0, float* __restrict__ vn1)
+{
+    __shared__ float red[16];
+    const int b = blockIdx.x, k = blockIdx.y;
+    const int V = k == 0 ? V0 : V1;
+    const float* v = (k == 0 ? v0 : v1) + (long)b * V * 3;
+    float* vn = (k == 0 ? vn0 : vn1) + (long)b * V * 3;
+    float mn[3] = {3.4e38f, 3.4e38f, 3.4e38f}, mx[3] = {-3.4e38f, -3.4e38f, -3.4e38f};
+    for (int i = threadIdx.x; i < V; i += blockDim.x)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { const float x = v[3 * i + c]; mn[c] = fminf(mn[c], x); mx[c] = fmaxf(mx[c], x); }
+    float ctr[3], sc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float lo = hm_block_min(mn[c], red), hi = hm_block_max(mx[c], red);
+        ctr[c] = (lo + hi) / 2.0f;
+        sc = fmaxf(sc, (hi - lo) * ((1.0f + scale_factor) * 0.5f));
+    }
+    if (threadIdx.x == 0) {
+        float* o = boxes + ((long)k * B + b) * 4;
+        o[0] = ctr[0]; o[1] = ctr[1]; o[2] = ctr[2]; o[3] = sc;
+    }
+    for (int i = threadIdx.x; i < V; i += blockDim.x)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vn[3 * i + c] = (v[3 * i + c] - ctr[c]) / sc;
+}
+
+// ------------------------------------------------------------------ sign pass.  grid (N*N/256, B, 2)
+// one thread per (z,y) row; triangles staged through LDS; inside mask bit i <-> voxel x index i.
+__global__ __launch_bounds__(SDF_THREADS) void k_sdf_parity(const float* __restrict__ vn0, const int* __restrict__ f0, int V0,
+                                                             int F0, const float* __restrict__ vn1,
+                                                             const int* __restrict__ f1, int V1, int F1, int B,
+                                                             unsigned int* __restrict__ masks)
+{
+    __shared__ float tri[SDF_THREADS * 9];
+    const int b = blockIdx.y, k = blockIdx.z;
+    const int V = k == 0 ? V0 : V1, F = k == 0 ? F0 : F1;
+    const float* vn = (k == 0 ? vn0 : vn1) + (long)b * V * 3;
+    const int* fc = k == 0 ? f0 : f1;
+    const int row = blockIdx.x * SDF_THREADS + threadIdx.x;       // row = z * N + y
+    const int kz = row / SDF_N, jy = row % SDF_N;
+    const float cy = voxel_centre(jy), cz = voxel_centre(kz);
+    unsigned int mask = 0;
+    for (int base = 0; base < F; base += SDF_THREADS) {
+        const int n = min(SDF_THREADS, F - base);
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+            const int* t = fc + 3 * (base + threadIdx.x);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float* p = vn + 3 * t[q];
+                tri[threadIdx.x * 9 + 3 * q] = p[0];
+                tri[threadIdx.x * 9 + 3 * q + 1] = p[1];
+                tri[threadIdx.x * 9 + 3 * q + 2] = p[2];
+            }
+        }
+        __syncthreads();
+        for (int e = 0; e < n; ++e) {
+            const float* t = tri + 9 * e;
+            // cheap reject on the (y,z) box of the triangle (exact: a crossing needs the point inside the projection)
+            const float ylo = fminf(t[1], fminf(t[4], t[7])), yhi = fmaxf(t[1], fmaxf(t[4], t[7]));
+            const float zlo = fminf(t[2], fminf(t[5], t[8])), zhi = fmaxf(t[2], fmaxf(t[5], t[8]));
+            if (cy < ylo || cy > yhi || cz < zlo || cz > zhi) continue;
+            float xh;
+            if (!ray_x_crosses(cy, cz, t, t + 3, t + 6, &xh)) continue;
+            // m = number of voxel centres with xh > centre (centres increase with i)
+            int m = (int)floorf((xh + 1.0f) * (0.5f * (float)SDF_N) + 0.5f);
+            m = max(0, min(SDF_N, m));
+            while (m > 0 && !(xh > voxel_centre(m - 1))) --m;
+            while (m < SDF_N && xh > voxel_centre(m)) ++m;
+            mask ^= (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
+        }
+    }
+    masks[((long)k * B + b) * (SDF_N * SDF_N) + row] = mask;
+}
+
+// ------------------------------------------------------------------ lazy distance + trilinear sampling
+// grid (chunks, B, 2 pairs).  pair 0: phi of object 0 (hand) sampled at vertices of object 1; pair 1: the reverse.
+// unit gradient (d sum / d world vertex) goes to gsample_l ; per-sample values to dist (optional).
+__global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(
+    const float* __restrict__ v0, const float* __restrict__ vn0, const int* __restrict__ f0, int V0, int F0,
+    const float* __restrict__ v1, const float* __restrict__ vn1, const int* __restrict__ f1, int V1, int F1, int B,
+    const float* __restrict__ boxes, const unsigned int* __restrict__ masks, float* __restrict__ g0,
+    float* __restrict__ g1, float* __restrict__ partials, unsigned int* counter, float* __restrict__ out)
+{
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    const int b = blockIdx.y, pair = blockIdx.z;
+    const int k = pair == 0 ? 0 : 1;                  // SDF owner
+    const int Vl = pair == 0 ? V1 : V0;               // sampled vertex set
+    const float* vl = (pair == 0 ? v1 : v0) + (long)b * Vl * 3;
+    float* gl = (pair == 0 ? g1 : g0) + (long)b * Vl * 3;
+    const int Vk = k == 0 ? V0 : V1, Fk = k == 0 ? F0 : F1;
+    const float* vnk = (k == 0 ? vn0 : vn1) + (long)b * Vk * 3;
+    const int* fk = k == 0 ? f0 : f1;
+    const float* bx = boxes + ((long)k * B + b) * 4;
+    const unsigned int* mk = masks + ((long)k * B + b) * (SDF_N * SDF_N);
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * SDF_THREADS + threadIdx.x;
+    const bool live = i < Vl;
+
+    float ix = 0.f, iy = 0.f, iz = 0.f;
+    int x0 = 0, y0 = 0, z0 = 0;
+    unsigned need = 0;
+    if (live) {
+        const float lx = (vl[3 * i] - bx[0]) / bx[3], ly = (vl[3 * i + 1] - bx[1]) / bx[3], lz = (vl[3 * i + 2] - bx[2]) / bx[3];
+        ix = ((lx + 1.0f) * (float)SDF_N - 1.0f) / 2.0f;
+        iy = ((ly + 1.0f) * (float)SDF_N - 1.0f) / 2.0f;
+        iz = ((lz + 1.0f) * (float)SDF_N - 1.0f) / 2.0f;
+        // keep the integer conversion in range for far-away points (they touch no voxel anyway)
+        const float fx = floorf(fminf(fmaxf(ix, -4.0f), (float)SDF_N + 4.0f));
+        const float fy = floorf(fminf(fmaxf(iy, -4.0f), (float)SDF_N + 4.0f));
+        const float fz = floorf(fminf(fmaxf(iz, -4.0f), (float)SDF_N + 4.0f));
+        x0 = (int)fx; y0 = (int)fy; z0 = (int)fz;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int xx = x0 + (c & 1), yy = y0 + ((c >> 1) & 1), zz = z0 + (c >> 2);
+            if (xx >= 0 && xx < SDF_N && yy >= 0 && yy < SDF_N && zz >= 0 && zz < SDF_N)
+                if ((mk[zz * SDF_N + yy] >> xx) & 1u) need |= 1u << c;
+        }
+    }
+    float phi[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        phi[c] = 0.f;
+        unsigned long long bal = __ballot((need >> c) & 1u);
+        while (bal) {
+            const int t = __ffsll((long long)bal) - 1;
+            bal &= bal - 1;
+            const int xx = __shfl(x0, t, 64) + (c & 1), yy = __shfl(y0, t, 64) + ((c >> 1) & 1), zz = __shfl(z0, t, 64) + (c >> 2);
+            const float ctr[3] = {voxel_centre(xx), voxel_centre(yy), voxel_centre(zz)};
+            float dmin = 1e30f;
+            for (int f = lane; f < Fk; f += 64) {
+                const int* tr = fk + 3 * f;
+                const float d = point_triangle_distance(ctr, vnk + 3 * tr[0], vnk + 3 * tr[1], vnk + 3 * tr[2]);
+                dmin = fminf(dmin, d);
+            }
+            dmin = hm_wave_min(dmin);
+            if (lane == t) phi[c] = dmin;
+        }
+    }
+    float val = 0.f;
+    if (live) {
+        const float x1 = (float)x0 + 1.0f, y1 = (float)y0 + 1.0f, z1 = (float)z0 + 1.0f;
+        const float wx[2] = {x1 - ix, ix - (float)x0}, wy[2] = {y1 - iy, iy - (float)y0}, wz[2] = {z1 - iz, iz - (float)z0};
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+            const float p = phi[c];       // 0 for out-of-bounds / outside corners
+            val += p * wx[dx] * wy[dy] * wz[dz];
+            gx += (dx ? p : -p) * wy[dy] * wz[dz];
+            gy += (dy ? p : -p) * wx[dx] * wz[dz];
+            gz += (dz ? p : -p) * wx[dx] * wy[dy];
+        }
+        const float s = (0.5f * (float)SDF_N) / bx[3];      // d(ix)/d(local) * d(local)/d(world)
+        gl[3 * i] = gx * s; gl[3 * i + 1] = gy * s; gl[3 * i + 2] = gz * s;
+    }
+    val = hm_block_sum(val, red);
+    const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+    if (threadIdx.x == 0) partials[bid] = val;
+    if (hm_last_block(counter, nblk, &s_flag) && threadIdx.x == 0) {
+        float t = 0.f;
+        for (unsigned q = 0; q < nblk; ++q) t += partials[q];
+        out[0] = t;
+    }
+}
+
+// full grid (debug / API completeness: what `SDF()(faces, verts)` returns after the reference's clamp).  grid (N*N*N/256, B)
+__global__ __launch_bounds__(SDF_THREADS) void k_sdf_grid(const float* __restrict__ vn, const int* __restrict__ fc, int V, int F,
+                                                           int B, const unsigned int* __restrict__ masks,
+                                                           float* __restrict__ phi)
+{
+    const int b = blockIdx.y;
+    const int vox = blockIdx.x * SDF_THREADS + threadIdx.x;
+    const int ix = vox % SDF_N, row = vox / SDF_N;
+    const float* v = vn + (long)b * V * 3;
+    float outv = 0.f;
+    if ((masks[(long)b * (SDF_N * SDF_N) + row] >> ix) & 1u) {
+        const float ctr[3] = {voxel_centre(ix), voxel_centre(row % SDF_N), voxel_centre(row / SDF_N)};
+        float dmin = 1e30f;
+        for (int f = 0; f < F; ++f) {
+            const int* tr = fc + 3 * f;
+            dmin = fminf(dmin, point_triangle_distance(ctr, v + 3 * tr[0], v + 3 * tr[1], v + 3 * tr[2]));
+        }
+        outv = dmin;
+    }
+    phi[(long)b * (SDF_N * SDF_N * SDF_N) + vox] = outv;
+}
+
+extern "C" {
+static inline size_t al256s(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t hm_collision_workspace_bytes(int B, int V0, int V1)
+{
+    size_t n = 0;
+    n += al256s((size_t)2 * B * 4 * 4);                      // boxes
+    n += al256s((size_t)B * V0 * 3 * 4);                     // vnorm0
+    n += al256s((size_t)B * V1 * 3 * 4);                     // vnorm1
+    n += al256s((size_t)2 * B * SDF_N * SDF_N * 4);          // masks
+    n += al256s((size_t)2 * B * (hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS)) * 4 + 256);  // partials
+    n += 256;                                                // counter (zero-initialised by the caller once)
+    return n;
+}
+
+struct CollWs { float* boxes; float* vn0; float* vn1; unsigned int* masks; float* partials; unsigned int* counter; };
+static CollWs coll_carve(void* ws, int B, int V0, int V1)
+{
+    char* p = (char*)ws;
+    CollWs w;
+    w.boxes = (float*)p; p += al256s((size_t)2 * B * 4 * 4);
+    w.vn0 = (float*)p; p += al256s((size_t)B * V0 * 3 * 4);
+    w.vn1 = (float*)p; p += al256s((size_t)B * V1 * 3 * 4);
+    w.masks = (unsigned int*)p; p += al256s((size_t)2 * B * SDF_N * SDF_N * 4);
+    w.partials = (float*)p; p += al256s((size_t)2 * B * (hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS)) * 4 + 256);
+    w.counter = (unsigned int*)p;
+    return w;
+}
+
+// Scene of two meshes: 0 = hand (closed faces), 1 = object.  out1[0] = sum of all SDF samples (both ordered pairs);
+// g0 / g1 = d out / d verts0 / d verts1 (unit gradients, (B,V,3)).
+int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, const float* verts1, const int* faces1,
+                     int V1, int F1, int B, float scale_factor, float* g0, float* g1, float* out1, void* workspace,
+                     hipStream_t stream)
+{
+    HM_CHECK_ARG(verts0 && faces0 && verts1 && faces1 && g0 && g1 && out1 && workspace);
+    HM_CHECK_ARG(B > 0 && V0 > 0 && V1 > 0 && F0 > 0 && F1 > 0);
+    CollWs w = coll_carve(workspace, B, V0, V1);
+    hipLaunchKernelGGL(k_sdf_boxes, dim3(B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, scale_factor,
+                       w.boxes, w.vn0, w.vn1);
+    hipLaunchKernelGGL(k_sdf_parity, dim3(SDF_N * SDF_N / SDF_THREADS, B, 2), dim3(SDF_THREADS), 0, stream, w.vn0, faces0,
+                       V0, F0, w.vn1, faces1, V1, F1, B, w.masks);
+    const int chunks = hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS);
+    hipLaunchKernelGGL(k_sdf_sample, dim3(chunks, B, 2), dim3(SDF_THREADS), 0, stream, verts0, w.vn0, faces0, V0, F0,
+                       verts1, w.vn1, faces1, V1, F1, B, w.boxes, w.masks, g0, g1, w.partials, w.counter, out1);
+    return hm_launch_status();
+}
+
+// clamp(SDF, 0) of object `which` (0/1) on the full 32^3 grid, from the workspace of the last hm_collision_fwd.
+int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int V0, int V1, float* phi, void* workspace,
+                           hipStream_t stream)
+{
+    HM_CHECK_ARG(faces && phi && workspace && (which == 0 || which == 1));
+    CollWs w = coll_carve(workspace, B, V0, V1);
+    hipLaunchKernelGGL(k_sdf_grid, dim3(SDF_N * SDF_N * SDF_N / SDF_THREADS, B), dim3(SDF_THREADS), 0, stream,
+                       which == 0 ? w.vn0 : w.vn1, faces, V, F, B, w.masks + (size_t)which * B * SDF_N * SDF_N, phi);
+    return hm_launch_status();
+}
+}  // extern "C"

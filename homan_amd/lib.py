@@ -11,7 +11,7 @@ import torch
 from . import build as _build
 
 _LIB = None
-_VP, _I, _F, _SZ = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+_VP, _I, _F, _SZ, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_long
 
 # name -> (restype, argtypes)
 _SIGNATURES = {
@@ -20,6 +20,24 @@ _SIGNATURES = {
     "hm_sil_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_sil_read_idx_map": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_faces9": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
+    "hm_rigid_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "hm_rigid_bwd": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "hm_scale_by": (_I, [_VP, _VP, _L, _VP, _VP]),
+    "hm_scale2_by": (_I, [_VP, _VP, _VP, _VP, _L, _VP, _VP]),
+    "hm_mano_fwd": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
+    "hm_mano_workspace_bytes": (_SZ, [_I]),
+    "hm_mano_bwd": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_reduce_workspace_bytes": (_SZ, []),
+    "hm_v2d_fwd": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _VP]),
+    "hm_smooth_fwd": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "hm_priors_fwd": (_I, [_VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_inter_fwd": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _VP]),
+    "hm_inter_bwd": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
+    "hm_nn_fwd": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "hm_contact_fwd": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _VP]),
+    "hm_collision_workspace_bytes": (_SZ, [_I, _I, _I]),
+    "hm_collision_fwd": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _VP]),
+    "hm_collision_read_grid": (_I, [_VP, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
 }
 
 

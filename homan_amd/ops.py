@@ -122,3 +122,331 @@ def silhouette_loss(verts, K, keep, ref, keep_sum, sctx, orig_size=1.0):
 
 def silhouette_render(verts, K, sctx, orig_size=1.0):
     return _SilhouetteRender.apply(verts, K, sctx, orig_size)
+
+
+# =============================================================================== shared small state
+class ReduceWorkspace:
+    """Zero-initialised scratch for the single-launch grid reductions (partials + self-resetting ticket)."""
+
+    def __init__(self, device):
+        self.buf = torch.zeros(_lib.lib().hm_reduce_workspace_bytes(), dtype=torch.uint8, device=device)
+
+
+def _scale_by(unit, g):
+    """g (scalar tensor) * unit, in a HIP kernel."""
+    out = torch.empty_like(unit)
+    g = _f32(g).reshape(1)
+    _lib.check(_lib.lib().hm_scale_by(_lib.ptr(unit), _lib.ptr(g), unit.numel(), _lib.ptr(out), _lib.stream()),
+               "hm_scale_by")
+    return out
+
+
+# =============================================================================== rigid transform
+class _RigidTransform(torch.autograd.Function):
+    """reference homan/utils/geometry.py:9-27 + homan/utils/camera.py:108-139:
+    verts = (s * mesh) @ rot6d_to_matrix(rot6d) + t, and the mesh-detached twin (same values; its gradient
+    reaches rotation and translation only)."""
+
+    @staticmethod
+    def forward(ctx, mesh, rot6d, trans, scale, abs_scale):
+        mesh, rot6d, trans, scale = _f32(mesh), _f32(rot6d), _f32(trans), _f32(scale)
+        N, V = mesh.shape[0], mesh.shape[1]
+        verts = torch.empty_like(mesh)
+        _lib.check(_lib.lib().hm_rigid_fwd(_lib.ptr(mesh), _lib.ptr(rot6d), _lib.ptr(trans), _lib.ptr(scale),
+                                           int(abs_scale), N, V, None, _lib.ptr(verts), _lib.stream()), "hm_rigid_fwd")
+        ctx.save_for_backward(mesh, rot6d, scale)
+        ctx.abs_scale = int(abs_scale)
+        ctx.trans_shape = trans.shape
+        return verts, verts.clone()
+
+    @staticmethod
+    def backward(ctx, g_full, g_det):
+        mesh, rot6d, scale = ctx.saved_tensors
+        N, V = mesh.shape[0], mesh.shape[1]
+        need_mesh, need_scale = ctx.needs_input_grad[0], ctx.needs_input_grad[3]
+        g_full = None if g_full is None else _f32(g_full)
+        g_det = None if g_det is None else _f32(g_det)
+        g_mesh = torch.empty_like(mesh) if need_mesh else None
+        g_rot = torch.empty_like(rot6d)
+        g_trans = torch.empty(N, 3, device=mesh.device)
+        g_sp = torch.empty(N, device=mesh.device) if need_scale else None
+        _lib.check(_lib.lib().hm_rigid_bwd(_lib.ptr(mesh), _lib.ptr(rot6d), _lib.ptr(scale), ctx.abs_scale,
+                                           _lib.ptr(g_full), _lib.ptr(g_det), N, V, _lib.ptr(g_mesh), _lib.ptr(g_rot),
+                                           _lib.ptr(g_trans), _lib.ptr(g_sp), _lib.stream()), "hm_rigid_bwd")
+        g_scale = g_sp.sum().reshape(scale.shape) if need_scale else None
+        return g_mesh, g_rot, g_trans.view(ctx.trans_shape), g_scale, None
+
+
+def rigid_transform(mesh, rot6d, trans, scale, abs_scale=False):
+    return _RigidTransform.apply(mesh, rot6d, trans, scale, abs_scale)
+
+
+# =============================================================================== MANO
+class ManoContext:
+    """Device copy of the MANO model in the kernel layout (see csrc/mano.hip) + backward workspace."""
+
+    def __init__(self, model_np, device, num_pca_comps=16, flat_hand_mean=False):
+        import ctypes
+        assert num_pca_comps == 16, "the reference builds ManoModel(pca_comps=16) (homan/homan.py:70)"
+        vt = np.asarray(model_np["v_template"], np.float32)
+        assert vt.shape == (778, 3)
+        sd = np.asarray(model_np["shapedirs"], np.float32)              # (778,3,10)
+        pd = np.asarray(model_np["posedirs"], np.float32)               # (135, 2334)
+        M = np.concatenate([pd, sd.reshape(778 * 3, 10).T], 0)          # (145, 2334)
+        jr = np.asarray(model_np["J_regressor"], np.float32)            # (16,778)
+        J_t = jr @ vt                                                   # (16,3)
+        J_s = np.einsum("jv,vcl->jcl", jr, sd)                          # (16,3,10)
+        hm = np.asarray(model_np["hand_mean"], np.float32)
+        hand_mean = np.zeros_like(hm) if flat_hand_mean else hm
+        host = [vt, M, J_t.astype(np.float32), J_s.astype(np.float32),
+                np.asarray(model_np["lbs_weights"], np.float32),
+                np.asarray(model_np["hand_components"][:16], np.float32), hand_mean]
+        self.tensors = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in host]
+        self.tensors.append(torch.from_numpy(np.asarray(model_np["parents"], np.int32)).to(device))
+        self.ptrs = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in self.tensors])
+        self.device = device
+        self._ws = {}
+
+    def workspace(self, B):
+        if B not in self._ws:
+            self._ws[B] = torch.empty(_lib.lib().hm_mano_workspace_bytes(B), dtype=torch.uint8, device=self.device)
+        return self._ws[B]
+
+
+class _ManoLBS(torch.autograd.Function):
+    """reference homan/manomodel.py:84-151 (forward_pca, right hand) + the `mano` layer + homan/homan.py:356 (+mano_trans)."""
+
+    @staticmethod
+    def forward(ctx, pca, rot, betas, trans, mctx):
+        pca, rot, betas = _f32(pca), _f32(rot), _f32(betas)
+        trans = None if trans is None else _f32(trans)
+        B, P = pca.shape
+        verts = torch.empty(B, 778, 3, device=pca.device)
+        _lib.check(_lib.lib().hm_mano_fwd(mctx.ptrs, _lib.ptr(pca), P, _lib.ptr(rot), _lib.ptr(betas), _lib.ptr(trans), B,
+                                          _lib.ptr(verts), None, _lib.stream()), "hm_mano_fwd")
+        ctx.save_for_backward(pca, rot, betas)
+        ctx.mctx, ctx.has_trans = mctx, trans is not None
+        return verts
+
+    @staticmethod
+    def backward(ctx, g_verts):
+        pca, rot, betas = ctx.saved_tensors
+        B, P = pca.shape
+        g_verts = _f32(g_verts)
+        g_pca, g_rot, g_betas = torch.empty_like(pca), torch.empty_like(rot), torch.empty_like(betas)
+        g_trans = torch.empty(B, 3, device=pca.device)
+        _lib.check(_lib.lib().hm_mano_bwd(ctx.mctx.ptrs, _lib.ptr(pca), P, _lib.ptr(rot), _lib.ptr(betas), B,
+                                          _lib.ptr(g_verts), _lib.ptr(g_pca), _lib.ptr(g_rot), _lib.ptr(g_betas),
+                                          _lib.ptr(g_trans), _lib.ptr(ctx.mctx.workspace(B)), _lib.stream()),
+                   "hm_mano_bwd")
+        return g_pca, g_rot, g_betas, (g_trans if ctx.has_trans else None), None
+
+
+def mano_lbs(pca, rot, betas, trans, mctx):
+    return _ManoLBS.apply(pca, rot, betas, trans, mctx)
+
+
+def mano_joints(pca, rot, betas, trans, mctx):
+    """Posed joints (B,16,3), no gradient (reference homan/homan.py:309-339 is off the optimisation path)."""
+    pca, rot, betas = _f32(pca.detach()), _f32(rot.detach()), _f32(betas.detach())
+    B, P = pca.shape
+    verts = torch.empty(B, 778, 3, device=pca.device)
+    joints = torch.empty(B, 16, 3, device=pca.device)
+    tr = None if trans is None else _f32(trans.detach())
+    _lib.check(_lib.lib().hm_mano_fwd(mctx.ptrs, _lib.ptr(pca), P, _lib.ptr(rot), _lib.ptr(betas), _lib.ptr(tr), B,
+                                      _lib.ptr(verts), _lib.ptr(joints), _lib.stream()), "hm_mano_fwd")
+    return verts, joints
+
+
+# =============================================================================== vertex losses
+class _V2dLoss(torch.autograd.Function):
+    """reference homan/losses.py:141-164."""
+
+    @staticmethod
+    def forward(ctx, verts, camintr, ref2d, image_size, hand_nb, rws):
+        verts = _f32(verts)
+        N, V = verts.shape[:2]
+        unit = torch.empty_like(verts)
+        out = torch.empty(2, device=verts.device)
+        _lib.check(_lib.lib().hm_v2d_fwd(_lib.ptr(verts), _lib.ptr(camintr), int(hand_nb), _lib.ptr(ref2d),
+                                         float(image_size), N, V, _lib.ptr(unit), _lib.ptr(out), _lib.ptr(rws.buf),
+                                         _lib.stream()), "hm_v2d_fwd")
+        ctx.save_for_backward(unit)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_metric):
+        (unit,) = ctx.saved_tensors
+        return _scale_by(unit, g_loss), None, None, None, None, None
+
+
+def v2d_loss(verts, camintr, ref2d, image_size, hand_nb, rws):
+    return _V2dLoss.apply(verts, camintr, ref2d, image_size, hand_nb, rws)
+
+
+class _SmoothLoss(torch.autograd.Function):
+    """reference homan/lossutils.py:18-36 (one term: hand or object)."""
+
+    @staticmethod
+    def forward(ctx, verts, hand_nb, rws):
+        verts = _f32(verts)
+        N, V = verts.shape[:2]
+        unit = torch.empty_like(verts)
+        out = torch.empty(1, device=verts.device)
+        _lib.check(_lib.lib().hm_smooth_fwd(_lib.ptr(verts), N, V, int(hand_nb), _lib.ptr(unit), _lib.ptr(out),
+                                            _lib.ptr(rws.buf), _lib.stream()), "hm_smooth_fwd")
+        ctx.save_for_backward(unit)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (unit,) = ctx.saved_tensors
+        return _scale_by(unit, g), None, None
+
+
+def smooth_loss(verts, hand_nb, rws):
+    return _SmoothLoss.apply(verts, hand_nb, rws)
+
+
+class _Priors(torch.autograd.Function):
+    """reference homan/lossutils.py:39-40 (mean(pca^2)) and :107-109 (scale priors)."""
+
+    @staticmethod
+    def forward(ctx, pca, s_obj, m_obj, s_hand, m_hand):
+        pca, s_obj, s_hand = _f32(pca), _f32(s_obj), _f32(s_hand)
+        g_pca = torch.empty_like(pca)
+        g_so, g_sh = torch.empty_like(s_obj), torch.empty_like(s_hand)
+        out = torch.empty(3, device=pca.device)
+        _lib.check(_lib.lib().hm_priors_fwd(_lib.ptr(pca), pca.numel(), _lib.ptr(s_obj), _lib.ptr(m_obj),
+                                            _lib.ptr(s_hand), _lib.ptr(m_hand), _lib.ptr(g_pca), _lib.ptr(g_so),
+                                            _lib.ptr(g_sh), _lib.ptr(out), _lib.stream()), "hm_priors_fwd")
+        ctx.save_for_backward(g_pca, g_so, g_sh)
+        return out[0], out[1], out[2]
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        g_pca, g_so, g_sh = ctx.saved_tensors
+        return (_scale_by(g_pca, g0) if ctx.needs_input_grad[0] else None,
+                _scale_by(g_so, g1) if ctx.needs_input_grad[1] else None, None,
+                _scale_by(g_sh, g2) if ctx.needs_input_grad[3] else None, None)
+
+
+def priors(pca, s_obj, m_obj, s_hand, m_hand):
+    return _Priors.apply(pca, s_obj, m_obj, s_hand, m_hand)
+
+
+class _InterLoss(torch.autograd.Function):
+    """reference homan/losses.py:199-242 ('centroid'), gating :98-139; returns the un-normalised sum, shape (1,)."""
+
+    @staticmethod
+    def forward(ctx, vh, vo, camintr, expansion, zthresh, rws):
+        vh, vo = _f32(vh), _f32(vo)
+        B, Vh, Vo = vo.shape[0], vh.shape[1], vo.shape[1]
+        assert vh.shape[0] == B, "one hand per frame"
+        rec = torch.empty(B, 8, device=vh.device)
+        out = torch.empty(1, device=vh.device)
+        _lib.check(_lib.lib().hm_inter_fwd(_lib.ptr(vh), _lib.ptr(vo), _lib.ptr(camintr), B, Vh, Vo, float(expansion),
+                                           float(zthresh), _lib.ptr(rec), _lib.ptr(out), _lib.ptr(rws.buf),
+                                           _lib.stream()), "hm_inter_fwd")
+        ctx.save_for_backward(rec)
+        ctx.dims = (B, Vh, Vo)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (rec,) = ctx.saved_tensors
+        B, Vh, Vo = ctx.dims
+        g = _f32(g).reshape(1)
+        gh = torch.empty(B, Vh, 3, device=rec.device) if ctx.needs_input_grad[0] else None
+        go = torch.empty(B, Vo, 3, device=rec.device) if ctx.needs_input_grad[1] else None
+        if gh is not None or go is not None:
+            _lib.check(_lib.lib().hm_inter_bwd(_lib.ptr(rec), _lib.ptr(g), B, Vh, Vo, _lib.ptr(gh), _lib.ptr(go),
+                                               _lib.stream()), "hm_inter_bwd")
+        return gh, go, None, None, None, None
+
+
+def inter_loss(vh, vo, camintr, rws, expansion=0.2, zthresh=3.0):
+    return _InterLoss.apply(vh, vo, camintr, expansion, zthresh, rws)
+
+
+def nearest_vertices(vh, vo, rws):
+    """hand -> object nearest vertex (no grad): idx (B,Vh) int32, squared distance, and the metric
+    max_b min_{i,j} |h_i - o_j| of reference homan/losses.py:225-241."""
+    vh, vo = _f32(vh.detach()), _f32(vo.detach())
+    B, Vh, Vo = vo.shape[0], vh.shape[1], vo.shape[1]
+    idx = torch.empty(B, Vh, dtype=torch.int32, device=vh.device)
+    d2 = torch.empty(B, Vh, device=vh.device)
+    metric = torch.empty(1, device=vh.device)
+    _lib.check(_lib.lib().hm_nn_fwd(_lib.ptr(vh), _lib.ptr(vo), B, Vh, Vo, _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(metric),
+                                    _lib.ptr(rws.buf), _lib.stream()), "hm_nn_fwd")
+    return idx, d2, metric
+
+
+class _ContactLoss(torch.autograd.Function):
+    """reference homan/lossutils.py:112-130 -> interactions/contactloss.py:149-309 as executed (appendix B.1)."""
+
+    @staticmethod
+    def forward(ctx, vh, vo, nn_idx, thresh, rws):
+        vh, vo = _f32(vh), _f32(vo)
+        B, Vh, Vo = vo.shape[0], vh.shape[1], vo.shape[1]
+        gh, go = torch.empty_like(vh), torch.empty_like(vo)
+        out = torch.empty(1, device=vh.device)
+        _lib.check(_lib.lib().hm_contact_fwd(_lib.ptr(vh), _lib.ptr(vo), _lib.ptr(nn_idx), B, Vh, Vo, float(thresh),
+                                             _lib.ptr(gh), _lib.ptr(go), _lib.ptr(out), _lib.ptr(rws.buf),
+                                             _lib.stream()), "hm_contact_fwd")
+        ctx.save_for_backward(gh, go)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gh, go = ctx.saved_tensors
+        return (_scale_by(gh, g) if ctx.needs_input_grad[0] else None,
+                _scale_by(go, g) if ctx.needs_input_grad[1] else None, None, None, None)
+
+
+def contact_loss(vh, vo, nn_idx, rws, thresh=0.020):
+    return _ContactLoss.apply(vh, vo, nn_idx, thresh, rws)
+
+
+class CollisionContext:
+    def __init__(self, faces_hand_closed, faces_obj, B, Vh, Vo, device):
+        self.f0 = torch.as_tensor(np.asarray(faces_hand_closed), dtype=torch.int32).to(device).contiguous()
+        self.f1 = faces_obj.to(device=device, dtype=torch.int32).contiguous()
+        self.B, self.V0, self.V1 = B, Vh, Vo
+        self.ws = torch.zeros(_lib.lib().hm_collision_workspace_bytes(B, Vh, Vo), dtype=torch.uint8, device=device)
+
+    def grid(self, which):
+        """clamp(SDF,0) (B,32,32,32) of mesh `which` from the last forward (debug / API completeness)."""
+        f = self.f0 if which == 0 else self.f1
+        V = self.V0 if which == 0 else self.V1
+        phi = torch.empty(self.B, 32, 32, 32, device=self.ws.device)
+        _lib.check(_lib.lib().hm_collision_read_grid(_lib.ptr(f), V, f.shape[0], self.B, which, self.V0, self.V1,
+                                                     _lib.ptr(phi), _lib.ptr(self.ws), _lib.stream()),
+                   "hm_collision_read_grid")
+        return phi
+
+
+class _CollisionLoss(torch.autograd.Function):
+    """reference homan/lossutils.py:43-64 (sdf branch) -> interactions/scenesdf.py:77-148."""
+
+    @staticmethod
+    def forward(ctx, vh, vo, cctx, scale_factor):
+        vh, vo = _f32(vh), _f32(vo)
+        g0, g1 = torch.empty_like(vh), torch.empty_like(vo)
+        out = torch.empty(1, device=vh.device)
+        _lib.check(_lib.lib().hm_collision_fwd(_lib.ptr(vh), _lib.ptr(cctx.f0), cctx.V0, cctx.f0.shape[0], _lib.ptr(vo),
+                                               _lib.ptr(cctx.f1), cctx.V1, cctx.f1.shape[0], cctx.B, float(scale_factor),
+                                               _lib.ptr(g0), _lib.ptr(g1), _lib.ptr(out), _lib.ptr(cctx.ws),
+                                               _lib.stream()), "hm_collision_fwd")
+        ctx.save_for_backward(g0, g1)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        g0, g1 = ctx.saved_tensors
+        return (_scale_by(g0, g) if ctx.needs_input_grad[0] else None,
+                _scale_by(g1, g) if ctx.needs_input_grad[1] else None, None, None)
+
+
+def collision_loss(vh, vo, cctx, scale_factor=0.2):
+    return _CollisionLoss.apply(vh, vo, cctx, scale_factor)

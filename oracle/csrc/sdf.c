@@ -124,6 +124,10 @@ void orc_sdf_grid(const int32_t *faces, const float *verts, int B, int V, int F,
                 const float *v2 = vb + 3 * faces[3 * f + 1];
                 const float *v3 = vb + 3 * faces[3 * f + 2];
                 float c[3] = {0.0f, cy, cz}, xh;
+                /* a crossing needs the centre inside the (y,z) projection, hence inside its box */
+                if (cy < fminf(v1[1], fminf(v2[1], v3[1])) || cy > fmaxf(v1[1], fmaxf(v2[1], v3[1])) ||
+                    cz < fminf(v1[2], fminf(v2[2], v3[2])) || cz > fmaxf(v1[2], fmaxf(v2[2], v3[2])))
+                    continue;
                 if (!orc_ray_x_crosses(c, v1, v2, v3, &xh)) continue;
                 for (int i = 0; i < N; ++i) {
                     float cx = -1.0f + ((float)i + 0.5f) * h;

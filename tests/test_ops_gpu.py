@@ -1,0 +1,200 @@
+"""Each HIP leaf op vs the CPU oracle (values and gradients).  GPU box."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _close(got, ref, rtol=1e-4, atol_frac=1e-5, msg=""):
+    got, ref = got.detach().cpu().double(), ref.detach().cpu().double()
+    scale = max(ref.abs().max().item(), 1e-30)
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale + atol_frac * scale, f"{msg}: err {err:.3e} scale {scale:.3e}"
+
+
+def _hand_obj(B=4, seed=0):
+    from homan_amd import synth
+    from homan_amd.mano_assets import synthetic_mano
+    g = torch.Generator().manual_seed(seed)
+    m = synthetic_mano(0)
+    vh = torch.from_numpy(m["v_template"])[None].repeat(B, 1, 1) + torch.randn(B, 1, 3, generator=g) * 0.01
+    vh = vh + torch.tensor([0.0, 0.0, 0.55])
+    ov, of = synth.bottle_mesh()
+    vo = torch.from_numpy(ov)[None].repeat(B, 1, 1) + torch.tensor([0.02, 0.0, 0.56]) + torch.randn(B, 1, 3, generator=g) * 0.01
+    return m, vh, vo, torch.from_numpy(of)
+
+
+def test_rigid_transform_and_grads():
+    from homan_amd import ops
+    from oracle import model as om
+    g = torch.Generator().manual_seed(0)
+    N, V = 5, 300
+    mesh = torch.randn(N, V, 3, generator=g) * 0.1
+    rot6d = torch.randn(N, 3, 2, generator=g)
+    trans = torch.randn(N, 1, 3, generator=g)
+    scale = torch.tensor([-1.3])
+    w1, w2 = torch.randn(N, V, 3, generator=g), torch.randn(N, V, 3, generator=g)
+    ins_o = [t.clone().requires_grad_(True) for t in (mesh, rot6d, trans, scale)]
+    v, vd = om.transform_persp(ins_o[0], ins_o[2], om.rot6d_to_matrix(ins_o[1]), ins_o[3].abs())
+    ((v * w1).sum() + (vd * w2).sum()).backward()
+    ins_h = [t.clone().to(DEV).requires_grad_(True) for t in (mesh, rot6d, trans, scale)]
+    vh, vdh = ops.rigid_transform(ins_h[0], ins_h[1], ins_h[2], ins_h[3], abs_scale=True)
+    ((vh * w1.to(DEV)).sum() + (vdh * w2.to(DEV)).sum()).backward()
+    _close(vh, v, msg="verts")
+    _close(vdh, vd, msg="verts_det")
+    for a, b, n in zip(ins_h, ins_o, ("mesh", "rot6d", "trans", "scale")):
+        _close(a.grad, b.grad, rtol=2e-4, msg="grad " + n)
+
+
+def test_mano_lbs_and_grads(mano_model):
+    from homan_amd import ops
+    from oracle import lbs
+    g = torch.Generator().manual_seed(1)
+    B = 6
+    pca = torch.randn(B, 45, generator=g) * 0.4
+    rot = torch.randn(B, 3, generator=g) * 0.5
+    rot[0] = 0.0          # exercises the |r + 1e-8| branch at zero rotation
+    betas = torch.randn(B, 10, generator=g) * 0.5
+    trans = torch.randn(B, 3, generator=g) * 0.05
+    w = torch.randn(B, 778, 3, generator=g)
+    layer = lbs.ManoLayer(mano_model, num_pca_comps=16, flat_hand_mean=True)
+    ins_o = [t.clone().requires_grad_(True) for t in (pca, rot, betas, trans)]
+    hp = ins_o[0][:, :16] @ torch.as_tensor(mano_model["hand_components"][:16]) + torch.as_tensor(mano_model["hand_mean"])
+    vo = layer(betas=ins_o[2], global_orient=ins_o[1], hand_pose=hp, transl=torch.zeros(B, 3))[0] + ins_o[3][:, None]
+    (vo * w).sum().backward()
+    mctx = ops.ManoContext(mano_model, DEV)
+    ins_h = [t.clone().to(DEV).requires_grad_(True) for t in (pca, rot, betas, trans)]
+    vh = ops.mano_lbs(ins_h[0], ins_h[1], ins_h[2], ins_h[3], mctx)
+    (vh * w.to(DEV)).sum().backward()
+    assert (vh.cpu() - vo).abs().max() < 2e-6
+    for a, b, n in zip(ins_h, ins_o, ("pca", "rot", "betas", "trans")):
+        _close(a.grad, b.grad, rtol=3e-4, atol_frac=1e-4, msg="grad " + n)
+    _, joints = ops.mano_joints(ins_h[0], ins_h[1], ins_h[2], ins_h[3], mctx)
+    jo = layer(betas=betas, global_orient=rot, hand_pose=hp.detach(), transl=torch.zeros(B, 3))[1] + trans[:, None]
+    assert (joints.cpu() - jo).abs().max() < 2e-6
+
+
+def test_v2d_smooth_priors():
+    from homan_amd import ops
+    from oracle import model as om
+    g = torch.Generator().manual_seed(2)
+    B, V = 5, 778
+    verts = torch.randn(B, V, 3, generator=g) * 0.05 + torch.tensor([0.0, 0.0, 0.6])
+    camintr = torch.tensor([[1.37, 0, 0.5], [0, 1.37, 0.5], [0, 0, 1.0]]).repeat(B, 1, 1)
+    ref2d = torch.rand(B, V, 2, generator=g) * 256
+    rws = ops.ReduceWorkspace(DEV)
+    losses = om.OracleLosses(camintr, None, None, ref2d, None, 1, "centroid", 32)
+    vo = verts.clone().requires_grad_(True)
+    lo, mo = losses.compute_verts2d_loss_hand(vo, 256)
+    (lo["loss_v2d_hand"] * 7).backward()
+    vh = verts.clone().to(DEV).requires_grad_(True)
+    lh, mh = ops.v2d_loss(vh, camintr.to(DEV), ref2d.to(DEV), 256, 1, rws)
+    (lh * 7).backward()
+    _close(lh, lo["loss_v2d_hand"], msg="v2d loss")
+    np.testing.assert_allclose(mh.item(), mo["v2d_hand"], rtol=1e-5)
+    _close(vh.grad, vo.grad, msg="v2d grad")
+    # smooth
+    vob = torch.randn(B, 1500, 3, generator=g)
+    a, b = verts.clone().requires_grad_(True), vob.clone().requires_grad_(True)
+    sm = om.compute_smooth_loss(a, b)
+    (sm["loss_smooth_hand"] * 3 + sm["loss_smooth_obj"] * 5).backward()
+    ah, bh = verts.clone().to(DEV).requires_grad_(True), vob.clone().to(DEV).requires_grad_(True)
+    sh, so = ops.smooth_loss(ah, 1, rws), ops.smooth_loss(bh, 1, rws)
+    (sh * 3 + so * 5).backward()
+    _close(sh, sm["loss_smooth_hand"], msg="smooth hand")
+    _close(so, sm["loss_smooth_obj"], msg="smooth obj")
+    _close(ah.grad, a.grad, msg="smooth hand grad")
+    _close(bh.grad, b.grad, msg="smooth obj grad")
+    # priors
+    pca = torch.randn(B, 45, generator=g)
+    s_o, s_h = torch.tensor([1.2]), torch.tensor([0.9])
+    po, so_, sh_ = pca.clone().requires_grad_(True), s_o.clone().requires_grad_(True), s_h.clone().requires_grad_(True)
+    ref = om.compute_pca_loss(po)["loss_pca"] * 2 + om.compute_intrinsic_scale_prior(so_, torch.ones(1)) * 3 + \
+        om.compute_intrinsic_scale_prior(sh_, torch.ones(1)) * 4
+    ref.backward()
+    ph, soh, shh = [t.clone().to(DEV).requires_grad_(True) for t in (pca, s_o, s_h)]
+    one = torch.ones(1, device=DEV)
+    l0, l1, l2 = ops.priors(ph, soh, one, shh, one)
+    (l0 * 2 + l1 * 3 + l2 * 4).backward()
+    _close(l0 * 2 + l1 * 3 + l2 * 4, ref, msg="priors")
+    _close(ph.grad, po.grad, msg="pca grad")
+    _close(soh.grad, so_.grad, msg="sobj grad")
+    _close(shh.grad, sh_.grad, msg="shand grad")
+
+
+def test_inter_and_contact(mano_model):
+    from homan_amd import ops
+    from oracle import model as om
+    m, vh, vo, of = _hand_obj(B=5)
+    B = 5
+    camintr = torch.tensor([[1.37, 0, 0.5], [0, 1.37, 0.5], [0, 0, 1.0]]).repeat(B, 1, 1)
+    vh[4] += torch.tensor([0.0, 0.0, 5.0])       # frame 4: z gap > 3 -> not interacting
+    vh[3] += torch.tensor([2.0, 0.0, 0.0])       # frame 3: boxes do not overlap
+    rws = ops.ReduceWorkspace(DEV)
+    losses = om.OracleLosses(camintr, None, None, None, None, 1, "centroid", 32)
+    a, b = vh.clone().requires_grad_(True), vo.clone().requires_grad_(True)
+    lo, mo = losses.compute_interaction_loss(a.view(-1, 1, 778, 3), b.unsqueeze(1))
+    (lo["loss_inter"] * 2).sum().backward()
+    ah, bh = vh.clone().to(DEV).requires_grad_(True), vo.clone().to(DEV).requires_grad_(True)
+    lh = ops.inter_loss(ah, bh, camintr.to(DEV), rws)
+    (lh * 2).sum().backward()
+    assert lh.shape == (1,)
+    _close(lh, lo["loss_inter"], msg="inter")
+    _close(ah.grad, a.grad, msg="inter grad hand")
+    _close(bh.grad, b.grad, msg="inter grad obj")
+    idx, d2, metric = ops.nearest_vertices(ah, bh, rws)
+    np.testing.assert_allclose(metric.item(), mo["handobj_maxdist"], rtol=1e-4)
+    # contact
+    a, b = vh.clone().requires_grad_(True), vo.clone().requires_grad_(True)
+    closed = torch.as_tensor(m["closed_faces"].astype(np.int64))
+    co = om.compute_contact_loss(a, b, of[None].repeat(B, 1, 1), closed)["loss_contact"]
+    (co * 3).sum().backward()
+    ah.grad = None
+    bh.grad = None
+    # nearest-neighbour search: exact (the reference's |x|^2+|y|^2-2xy algebra loses ~1e-7 absolute on d^2 and may
+    # pick another vertex among near-ties), so check it against a float64 brute force ...
+    d_exact = ((vh.double()[:, :, None] - vo.double()[:, None]) ** 2).sum(-1)
+    best = d_exact.min(2)
+    picked = torch.gather(d_exact, 2, idx.cpu().long()[..., None])[..., 0]
+    assert ((picked - best.values) <= 1e-6 * best.values + 1e-12).all()
+    # ... and the loss + gradients with the oracle's own neighbour choice
+    from oracle import yana
+    idx_o = yana.batch_pairwise_dist(vh, vo).min(2)[1]
+    agree = (idx_o == idx.cpu().long()).float().mean().item()
+    assert agree > 0.97, agree
+    ch_own = ops.contact_loss(ah.detach(), bh.detach(), idx, rws)
+    _close(ch_own, co, rtol=2e-4, msg="contact (own neighbours)")
+    ch = ops.contact_loss(ah, bh, idx_o.int().to(DEV), rws)
+    (ch * 3).sum().backward()
+    assert ch.shape == (1,)
+    _close(ch, co, msg="contact")
+    _close(ah.grad, a.grad, rtol=1e-3, atol_frac=1e-3, msg="contact grad hand")
+    _close(bh.grad, b.grad, rtol=1e-3, atol_frac=1e-3, msg="contact grad obj")
+
+
+def test_collision_vs_oracle(mano_model):
+    from homan_amd import ops
+    from oracle import model as om
+    m, vh, vo, of = _hand_obj(B=3, seed=4)
+    B = 3
+    # push the hand into the object so that vertices of each mesh lie inside the other
+    vh = vh + torch.tensor([0.03, 0.0, 0.0])
+    closed = torch.as_tensor(m["closed_faces"].astype(np.int64))
+    a, b = vh.clone().requires_grad_(True), vo.clone().requires_grad_(True)
+    lo, meta = om.sdf_scene_loss([closed, of], [a, b])
+    assert lo.item() > 0
+    (lo * 2).backward()
+    cctx = ops.CollisionContext(m["closed_faces"], of, B, 778, vo.shape[1], DEV)
+    ah, bh = vh.clone().to(DEV).requires_grad_(True), vo.clone().to(DEV).requires_grad_(True)
+    lh = ops.collision_loss(ah, bh, cctx)
+    (lh * 2).backward()
+    for which in (0, 1):
+        ref = meta["sdfs"][which]
+        got = cctx.grid(which).cpu()
+        assert ((got > 0) == (ref > 0)).all(), f"inside masks differ for mesh {which}"
+        _close(got, ref, rtol=1e-5, msg=f"phi {which}")
+    _close(lh, lo, rtol=1e-4, msg="collision loss")
+    _close(ah.grad, a.grad, rtol=1e-3, atol_frac=1e-3, msg="collision grad hand")
+    _close(bh.grad, b.grad, rtol=1e-3, atol_frac=1e-3, msg="collision grad obj")
