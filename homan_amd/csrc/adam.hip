@@ -1,0 +1,73 @@
+// adam.hip -- fused multi-tensor Adam step and sync-free scalar logging for the optimisation loop.
+//
+// Counterpart of the `torch.optim.Adam([...3 groups...])` step at reference homan/jointopt.py:138-151,192, restating
+// torch's single-tensor Adam arithmetic (the implementation the reference's CPU path runs) in fp32:
+//   m = m + (1-b1) (g - m);  v = v*b2 + (1-b2) g g;  step_size = lr / (1 - b1^t);
+//   denom = sqrt(v) / sqrt(1 - b2^t) + eps;  p = p + (-step_size * m) / denom
+// with the bias corrections evaluated in double like the Python scalars they are in torch.  One launch updates every
+// parameter tensor (pointer table in device memory), zeroes the gradients for the next iteration, and the step
+// counter lives on the device so the whole iteration can sit in a hipGraph.
+#include "hm_common.h"
+
+struct AdamSlot {
+    float* p; float* g; float* m; float* v;
+    long n;
+    float lr;
+    int pad;
+};
+
+// grid (blocks_per_tensor, n_tensors)
+__global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots, const int* __restrict__ step, float beta1,
+                                               float beta2, float eps, int zero_grad)
+{
+    const AdamSlot s = slots[blockIdx.y];
+    const double t = (double)(step[0] + 1);
+    const double bc1 = 1.0 - pow((double)beta1, t);
+    const double bc2 = 1.0 - pow((double)beta2, t);
+    const float neg_step = (float)(-((double)s.lr / bc1));
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < s.n; i += (long)gridDim.x * blockDim.x) {
+        const float g = s.g[i];
+        float m = s.m[i], v = s.v[i];
+        m = m + w1 * (g - m);
+        v = v * beta2;
+        v = v + (w2 * g) * g;
+        const float denom = sqrtf(v) / bc2_sqrt + eps;
+        s.p[i] = s.p[i] + (neg_step * m) / denom;
+        s.m[i] = m;
+        s.v[i] = v;
+        if (zero_grad) s.g[i] = 0.f;
+    }
+}
+
+__global__ void k_incr(int* step) { step[0] += 1; }
+
+// log[step*n + i] = src[i] for i < n ; step read from the device counter (sync-free loss_evolution)
+__global__ void k_log(const float* __restrict__ src, int n, const int* __restrict__ step, int max_steps,
+                      float* __restrict__ log)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int t = step[0];
+    if (i < n && t < max_steps) log[(long)t * n + i] = src[i];
+}
+
+extern "C" {
+size_t hm_adam_slot_bytes(void) { return sizeof(AdamSlot); }
+
+int hm_adam_step(const void* slots, int n_tensors, int* step, float beta1, float beta2, float eps, int zero_grad,
+                 int blocks_per_tensor, hipStream_t stream)
+{
+    HM_CHECK_ARG(slots && step && n_tensors > 0 && blocks_per_tensor > 0);
+    hipLaunchKernelGGL(k_adam, dim3(blocks_per_tensor, n_tensors), dim3(256), 0, stream, (const AdamSlot*)slots, step,
+                       beta1, beta2, eps, zero_grad);
+    hipLaunchKernelGGL(k_incr, dim3(1), dim3(1), 0, stream, step);
+    return hm_launch_status();
+}
+int hm_log_scalars(const float* src, int n, const int* step, int max_steps, float* log, hipStream_t stream)
+{
+    HM_CHECK_ARG(src && step && log && n > 0);
+    hipLaunchKernelGGL(k_log, dim3(hm_cdiv(n, 64)), dim3(64), 0, stream, src, n, step, max_steps, log);
+    return hm_launch_status();
+}
+}  // extern "C"

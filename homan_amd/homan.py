@@ -1,0 +1,229 @@
+"""HOMan -- the hand-object model of the reference (reference homan/homan.py:26-508), MI355X-native.
+
+Same constructor keywords, same Parameter / buffer names (so `named_parameters()` filtering by "mano" /
+"rotation" in reference homan/jointopt.py:128-151 and `load_state_dict(strict=False)` of a reference
+`joint_fit.pt` behave identically), same `forward(loss_weights) -> (loss_dict, metric_dict)`,
+`get_verts_object()` and `get_verts_hand(detach_scale=False)`.  All arithmetic runs in the hand-written HIP kernels
+of libhoman_amd.so through `homan_amd.ops`; there is no CPU path.
+
+Not mirrored (visualisation, off the optimisation path): render / render_gt / render_with_gt / save_obj,
+assign_human_masks, textures_* buffers.
+"""
+import torch
+from torch import nn
+
+from . import constants, lossutils, ops
+from .losses import Losses
+from .manomodel import ManoModel
+
+
+def matrix_to_rot6d(rotmat):
+    """reference homan/utils/geometry.py:30-40."""
+    return rotmat.view(-1, 3, 3)[:, :, :2]
+
+
+class HOMan(nn.Module):
+    def __init__(self, translations_object, rotations_object, verts_object_og, faces_object, translations_hand,
+                 rotations_hand, verts_hand_og, ref_verts2d_hand, hand_sides, mano_trans, mano_rot, mano_betas,
+                 mano_pca_pose, faces_hand, masks_object, masks_hand, camintr_rois_object, camintr_rois_hand,
+                 target_masks_object, target_masks_hand, class_name, cams_hand=None, int_scale_init=1.0, camintr=None,
+                 optimize_object_scale=False, optimize_ortho_cam=True, hand_proj_mode="persp", optimize_mano=True,
+                 optimize_mano_beta=True, inter_type="centroid", image_size=640,
+                 # homan_amd extensions (keyword-only use)
+                 mano_model=None, mano_root="extra_data/mano", rend_size=constants.REND_SIZE, sync_metrics=True):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise RuntimeError("homan_amd.HOMan needs an MI355X (ROCm) device; there is no CPU path")
+        dev = torch.device("cuda")
+        f32 = lambda t: t.detach().clone().float()
+
+        self.translations_object = nn.Parameter(f32(translations_object), requires_grad=True)
+        self.hand_proj_mode = hand_proj_mode
+        rotations_object = f32(rotations_object)
+        rot6d_o = matrix_to_rot6d(rotations_object) if rotations_object.shape[-1] == 3 else rotations_object
+        self.rotations_object = nn.Parameter(rot6d_o.detach().clone().contiguous(), requires_grad=True)
+        self.register_buffer("verts_object_og", f32(verts_object_og))
+
+        self.translations_hand = nn.Parameter(f32(translations_hand), requires_grad=True)
+        rotations_hand = f32(rotations_hand)
+        if rotations_hand.shape[-1] == 3:
+            rotations_hand = matrix_to_rot6d(rotations_hand)
+        self.rotations_hand = nn.Parameter(rotations_hand.detach().clone().contiguous(), requires_grad=True)
+        if cams_hand is None:
+            cams_hand = torch.zeros(translations_hand.shape[0], 3)
+        if optimize_ortho_cam:
+            self.cams_hand = nn.Parameter(f32(cams_hand), requires_grad=True)
+        else:
+            self.register_buffer("cams_hand", f32(cams_hand))
+        self.hand_sides = hand_sides
+        self.hand_nb = len(hand_sides)
+        if any(side != "right" for side in hand_sides):
+            raise ValueError(f"hand_sides {hand_sides}: homan_amd builds right hands only")
+        if self.hand_nb != 1:
+            raise NotImplementedError("one hand per frame (every BASELINE configuration); got %d" % self.hand_nb)
+
+        self.optimize_mano = optimize_mano
+        if optimize_mano:
+            self.mano_pca_pose = nn.Parameter(f32(mano_pca_pose), requires_grad=True)
+            self.mano_rot = nn.Parameter(f32(mano_rot), requires_grad=True)
+            self.mano_trans = nn.Parameter(f32(mano_trans), requires_grad=True)
+        else:   # reference homan.py:104-106: no mano_trans at all in this mode
+            self.register_buffer("mano_pca_pose", f32(mano_pca_pose))
+            self.register_buffer("mano_rot", f32(mano_rot))
+        if optimize_mano_beta:
+            self.mano_betas = nn.Parameter(torch.zeros_like(f32(mano_betas)), requires_grad=True)
+            self.register_buffer("int_scales_hand", torch.ones(1).float() * int_scale_init)
+        else:
+            self.register_buffer("mano_betas", torch.zeros_like(f32(mano_betas)))
+            self.int_scales_hand = nn.Parameter(int_scale_init * torch.ones(1).float(), requires_grad=True)
+        self.register_buffer("verts_hand_og", f32(verts_hand_og))
+        self.register_buffer("ref_verts2d_hand", f32(ref_verts2d_hand))
+
+        init_scales = int_scale_init * torch.ones(1).float()
+        # reference homan.py:122: torch.Tensor(int_scale_init) -- raises for a float argument (callers pass int 1)
+        torch.Tensor(int_scale_init)
+        self.optimize_object_scale = optimize_object_scale
+        if optimize_object_scale:
+            self.int_scales_object = nn.Parameter(init_scales, requires_grad=True)
+        else:
+            self.register_buffer("int_scales_object", init_scales)
+        self.register_buffer("int_scale_object_mean", torch.ones(1).float())
+        self.register_buffer("int_scale_hand_mean", torch.ones(1).float())
+        self.register_buffer("ref_mask_object", (target_masks_object > 0).float())
+        self.register_buffer("keep_mask_object", (target_masks_object >= 0).float())
+        self.register_buffer("ref_mask_hand", (target_masks_hand > 0).float())
+        self.register_buffer("keep_mask_hand", (target_masks_hand >= 0).float())
+        self.register_buffer("camintr_rois_object", f32(camintr_rois_object))
+        self.register_buffer("camintr_rois_hand", f32(camintr_rois_hand))
+        self.register_buffer("faces_object", faces_object.detach().clone())
+        self.register_buffer("faces_hand", faces_hand.detach().clone())
+        if camintr is None:
+            camintr = torch.tensor([[[1, 0, 0.5], [0, 1, 0.5], [0, 0, 1]]], dtype=torch.float32)
+        else:
+            camintr = torch.as_tensor(camintr).float()
+            if camintr.dim() == 2:
+                camintr = camintr.unsqueeze(0)
+        batch = translations_object.shape[0]
+        if camintr.shape[0] == 1 and batch > 1:
+            camintr = camintr.repeat(batch, 1, 1)
+        self.register_buffer("camintr", camintr.contiguous())
+        self.image_size = image_size
+        if masks_hand is not None:
+            self.register_buffer("masks_human", masks_hand.detach().clone())
+        if masks_object.dim() == 2:
+            masks_object = masks_object.unsqueeze(0)
+        self.register_buffer("masks_object", masks_object.detach().clone())
+        self.cuda()
+
+        # leaves: MANO layer (kept out of saved checkpoints by its "mano_model" prefix, fit_vid_dataset.py:366-371)
+        self.mano_model = ManoModel(mano_root, pca_comps=16, mano_model=mano_model, device=dev)
+        self.sync_metrics = sync_metrics
+        self.reduce_ws = ops.ReduceWorkspace(dev)
+        num_verts_object = self.verts_object_og.shape[1]
+        self.losses = Losses(renderer=None, ref_mask_object=self.ref_mask_object,
+                             keep_mask_object=self.keep_mask_object, ref_mask_hand=self.ref_mask_hand,
+                             ref_verts2d_hand=self.ref_verts2d_hand, keep_mask_hand=self.keep_mask_hand,
+                             camintr_rois_object=self.camintr_rois_object, camintr_rois_hand=self.camintr_rois_hand,
+                             camintr=self.camintr, class_name=class_name, hand_nb=self.hand_nb, inter_type=inter_type,
+                             faces_object=self.faces_object, num_verts_object=num_verts_object, rend_size=rend_size,
+                             reduce_ws=self.reduce_ws, sync_metrics=sync_metrics)
+        self.collision_ctx = ops.CollisionContext(self.mano_model.closed_faces, self.faces_object[0], batch * self.hand_nb,
+                                                  778, num_verts_object, dev)
+        self._mano_cache = None
+        with torch.no_grad():
+            self.verts_hand_init = self.get_verts_hand()[0].detach().clone()
+            self.verts_object_init = self.get_verts_object()[0].detach().clone()
+
+    # ------------------------------------------------------------------ vertices
+    def get_verts_object(self):
+        """reference homan.py:298-307."""
+        return ops.rigid_transform(self.verts_object_og, self.rotations_object, self.translations_object,
+                                   self.int_scales_object, abs_scale=True)
+
+    def _mano_verts(self):
+        if self._mano_cache is not None:
+            return self._mano_cache
+        res = self.mano_model.forward_pca(self.mano_pca_pose, rot=self.mano_rot, betas=self.mano_betas, side="right",
+                                          trans=self.mano_trans)
+        return res["verts"]
+
+    def get_verts_hand(self, detach_scale=False):
+        """reference homan.py:341-382 (persp)."""
+        verts_hand_og = self._mano_verts() if self.optimize_mano else self.verts_hand_og
+        scale = self.int_scales_hand.detach() if detach_scale else self.int_scales_hand
+        if self.hand_proj_mode == "persp":
+            return ops.rigid_transform(verts_hand_og, self.rotations_hand, self.translations_hand, scale,
+                                       abs_scale=False)
+        if self.hand_proj_mode == "ortho":
+            raise NotImplementedError("hand_proj_mode='ortho' (non-default --hand_proj_mode) is not built")
+        raise ValueError(f"Expected hand_proj_mode {self.hand_proj_mode} to be in [ortho|persp]")
+
+    def get_joints_hand(self):
+        """reference homan.py:309-339 (21 joints incl. finger tips, camera space); no gradient."""
+        with torch.no_grad():
+            joints = self.mano_model.joints(self.mano_pca_pose, self.mano_rot, self.mano_betas)
+            verts = self._mano_verts() - self.mano_trans.unsqueeze(1)
+            tips = verts[:, [745, 317, 444, 556, 673]]
+            full = torch.cat([joints, tips], 1)[:, [0, 13, 14, 15, 16, 1, 2, 3, 17, 4, 5, 6, 18, 10, 11, 12, 19, 7, 8,
+                                                    9, 20]]
+            full = full + self.mano_trans.unsqueeze(1)
+            return ops.rigid_transform(full.contiguous(), self.rotations_hand, self.translations_hand,
+                                       self.int_scales_hand, abs_scale=False)
+
+    # ------------------------------------------------------------------ losses
+    def forward(self, loss_weights=None):
+        """reference homan.py:421-508: a loss whose weight is zero is not computed."""
+        lw = loss_weights
+        on = lambda key: lw is None or lw[key] > 0
+        loss_dict, metric_dict = {}, {}
+        if self.optimize_mano:      # MANO is evaluated once and shared by the reference's two get_verts_hand calls
+            self._mano_cache = None
+            self._mano_cache = self._mano_verts()
+        try:
+            verts_object, _ = self.get_verts_object()
+            verts_hand, verts_hand_det = self.get_verts_hand()
+            if self.int_scales_hand.requires_grad:
+                verts_hand_det_scale, _ = self.get_verts_hand(detach_scale=True)
+            else:       # the scale is a buffer: detaching it changes nothing
+                verts_hand_det_scale = verts_hand
+        finally:
+            self._mano_cache = None
+        want_pca, want_so, want_sh = on("lw_pca"), on("lw_scale_obj"), on("lw_scale_hand")
+        if want_pca or want_so or want_sh:
+            l_pca, l_so, l_sh = ops.priors(self.mano_pca_pose, self.int_scales_object, self.int_scale_object_mean,
+                                           self.int_scales_hand, self.int_scale_hand_mean)
+            if want_pca:
+                loss_dict["loss_pca"] = l_pca
+        if lw is None or lw["lw_smooth_hand"] > 0 or lw["lw_smooth_obj"] > 0:
+            loss_dict.update(lossutils.compute_smooth_loss(verts_hand, verts_object, self.reduce_ws))
+        if on("lw_collision"):
+            loss_dict.update(lossutils.compute_collision_loss(verts_hand_det_scale, verts_object.detach(),
+                                                              self.collision_ctx))
+        nn_cache = None
+        if on("lw_contact"):
+            l_contact, nn_cache = lossutils.compute_contact_loss(verts_hand_det_scale, verts_object, self.reduce_ws)
+            loss_dict.update(l_contact)
+        if on("lw_v2d_hand"):
+            l, m = self.losses.compute_verts2d_loss_hand(verts_hand, image_size=self.image_size,
+                                                         min_hand_size=70 if self.optimize_object_scale else 1000)
+            loss_dict.update(l)
+            metric_dict.update(m)
+        if on("lw_sil_obj"):
+            l, m = self.losses.compute_sil_loss_object(verts_object, self.faces_object)
+            loss_dict.update(l)
+            metric_dict.update(m)
+        if on("lw_inter"):
+            inter_obj = verts_object.unsqueeze(1) if self.optimize_object_scale else verts_object.unsqueeze(1).detach()
+            l, m = self.losses.compute_interaction_loss(verts_hand_det.view(-1, self.hand_nb, 778, 3), inter_obj,
+                                                        nn=nn_cache)
+            loss_dict.update(l)
+            metric_dict.update(m)
+        if want_so:
+            loss_dict["loss_scale_obj"] = l_so
+        if want_sh:
+            loss_dict["loss_scale_hand"] = l_sh
+        if lw is None or lw["lw_depth"] > 0:
+            # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() without its arguments
+            raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
+                            "'masks', 'silhouettes', and 'depths'")
+        return loss_dict, metric_dict

@@ -1,0 +1,55 @@
+"""Image-space losses with the reference's `Losses` surface (reference homan/losses.py:52-242), on HIP kernels."""
+import torch
+
+from . import constants, ops
+
+
+class Losses:
+    def __init__(self, renderer, ref_mask_object, ref_verts2d_hand, keep_mask_object, ref_mask_hand, keep_mask_hand,
+                 camintr_rois_object, camintr_rois_hand, camintr, class_name, inter_type="min", hand_nb=1,
+                 faces_object=None, num_verts_object=None, rend_size=constants.REND_SIZE, reduce_ws=None,
+                 sync_metrics=True):
+        if inter_type != "centroid":
+            raise NotImplementedError("only inter_type='centroid' (the reference default, homan/homan.py:58)")
+        self.inter_type = inter_type
+        self.ref_mask_object, self.keep_mask_object = ref_mask_object, keep_mask_object
+        self.ref_mask_hand, self.keep_mask_hand = ref_mask_hand, keep_mask_hand
+        self.ref_verts2d_hand = ref_verts2d_hand
+        self.camintr_rois_object, self.camintr_rois_hand = camintr_rois_object, camintr_rois_hand
+        self.camintr = camintr.clone()
+        self.thresh = constants.INTERACTION_Z_THRESH
+        self.expansion = constants.INTERACTION_BBOX_EXPANSION
+        self.class_name, self.hand_nb = class_name, hand_nb
+        self.interaction_map = constants.INTERACTION_MAPPING[class_name]
+        self.rws = reduce_ws
+        self.sync_metrics = sync_metrics
+        dev = ref_mask_object.device
+        B = ref_mask_object.shape[0]
+        self.sil_ctx = ops.SilhouetteContext(faces_object, num_verts_object, B, rend_size, dev)
+        self.keep_sum = keep_mask_object.sum().reshape(1)
+        self.last_silhouettes = None
+
+    def _metric(self, t):
+        return t.item() if self.sync_metrics else t.detach()
+
+    def compute_verts2d_loss_hand(self, verts, image_size=640, min_hand_size=70):
+        """reference losses.py:141-164 (the min_hand_size branch is computed and discarded there: no effect)."""
+        loss, dist = ops.v2d_loss(verts, self.camintr, self.ref_verts2d_hand, image_size, self.hand_nb, self.rws)
+        return {"loss_v2d_hand": loss}, {"v2d_hand": self._metric(dist)}
+
+    def compute_sil_loss_object(self, verts, faces=None):
+        """reference losses.py:183-197."""
+        loss, iou, sil = ops.silhouette_loss(verts, self.camintr_rois_object, self.keep_mask_object,
+                                             self.ref_mask_object, self.keep_sum, self.sil_ctx)
+        self.last_silhouettes = sil
+        return {"loss_sil_obj": loss}, {"iou_object": self._metric(iou)}
+
+    def compute_interaction_loss(self, verts_hand_b, verts_object_b, nn=None):
+        """reference losses.py:199-242: verts_hand_b (B, 1, 778, 3), verts_object_b (B, 1, V, 3)."""
+        if verts_hand_b.shape[1] != 1 or verts_object_b.shape[1] != 1:
+            raise NotImplementedError("one hand and one object per frame")
+        vh, vo = verts_hand_b[:, 0], verts_object_b[:, 0]
+        loss = ops.inter_loss(vh, vo, self.camintr, self.rws, self.expansion, self.thresh)
+        if nn is None:
+            nn = ops.nearest_vertices(vh, vo, self.rws)
+        return {"loss_inter": loss}, {"handobj_maxdist": self._metric(nn[2][0])}
