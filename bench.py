@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""bench.py -- optimisation iterations / second of the HOMan joint-optimisation hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): one clip per GPU, 30 frames, 256x256 silhouette raster, MANO hand + ~3000-face
+bottle, full step-1 loss set, Adam step included.  A "step" = one optimisation iteration (forward + backward +
+Adam + loss logging) of one clip, replayed from a hipGraph.  N GPUs = N independent clips (weak scaling, no
+data-path collective).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic HBM bytes per optimisation iteration per clip, SURVEY.md 8(d) (B=30, S=256, F=3000, V=1502)
+def algorithmic_bytes(B, S, F, V, step2=False):
+    c_mano = 778 * 3 * 146 * 4 + 2 * 778 * 16 * 4
+    obj_transform = 4 * B * V * 12
+    mano = 2 * c_mano + 2 * B * 778 * 12
+    raster = B * (5 * F * 36 + 2 * (2 * S) ** 2 * 4 + 7 * S * S * 4) + B * V * 12
+    v2d = 2 * B * 778 * 20 + B * 778 * 12
+    smooth = 2 * B * (V + 778) * 12
+    inter = B * (V + 778) * 12
+    adam = 28 * 79 * B
+    total = obj_transform + mano + raster + v2d + smooth + inter + adam
+    if step2:
+        total += 2 * B * 32 ** 3 * 4 + B * (778 + V) * 12 + (1552 + F) * 12
+        total += 2 * (8 * (778 + V) * 4 * B + B * (778 + V) * 12) + B * 778 * 12
+        total += 3 * B * (778 + V) * 12 + 2 * B * 778 * 4
+    return dict(total=total, raster=raster)
+
+
+def raster_fwd_bytes(B, S, F):
+    """Algorithmic traffic of ONE launch of the dominant kernel (k_raster_fwd): packed (B,F,3,3) face buffer read +
+    8-byte screen boxes read + (2S)^2 int32 index map write + pooled silhouette write + keep/ref read + dimg write
+    + alpha bit-plane write."""
+    return B * (F * 36 + F * 8 + (2 * S) ** 2 * 4 + 4 * S * S * 4 + (2 * S) * (2 * S) // 8)
+
+
+def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256):
+    """Reference CPU path = oracle (CPU restatement) loop on this host, bounded sample."""
+    import torch
+    from oracle.jointopt import collate_inputs, make_optimizer
+    from oracle.model import OracleHOMan
+    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    torch.set_num_threads(threads)
+    kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                        clip["objvertices"], clip["objfaces"])
+    model = OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                        image_size=image_size, mano_model=mano, rend_size=rend_size, **kw)
+    opt = make_optimizer(model, 1e-2)
+
+    def step():
+        opt.zero_grad()
+        ld, md = model(loss_weights=lw)
+        tot = sum(ld[k] * lw[k.replace("loss", "lw")] for k in ld)
+        _ = [v.item() for v in ld.values()]
+        tot.backward()
+        opt.step()
+
+    step()                      # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        step()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 50:
+            break
+    return dict(value=n / el, unit="it/s", cores=threads, kind="port",
+                sample=f"{n} iterations of the same cfg2 clip ({el:.1f} s) after 1 warm-up, oracle loop with per-step .item() logging")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=30)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--step2", action="store_true", help="cfg3: add lw_collision / lw_contact")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
+    import torch
+    import torch.distributed as dist
+    from homan_amd import synth
+    from homan_amd.jointopt import GraphStepper, build_model
+    from homan_amd.mano_assets import synthetic_mano
+
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    mano = synthetic_mano(0)
+    sil_fn, hand_fn = synth.hip_clip_fns(mano)
+    clip = synth.make_clip(seed=rank, frames=args.frames, rend_size=args.size, image_size=args.size, obj="bottle",
+                           silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS if args.step2 else synth.STEP1_LOSS_WEIGHTS)
+    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                        objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                        optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
+                        sync_metrics=False)
+    total_steps = args.warmup + args.steps
+    stepper = GraphStepper(model, lw, 1e-2, total_steps)
+    stepper.run(args.warmup)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    stepper.run(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+
+    evo = stepper.loss_evolution(total_steps)
+    B, S = args.frames, args.size
+    F, V = clip["objfaces"].shape[1], clip["objvertices"].shape[1]
+
+    # --- roofline of the dominant kernel (k_raster_fwd), timed live with HIP events on the launch stream
+    roof = None
+    if rank == 0:
+        from homan_amd import lib as hlib
+        sctx = model.losses.sil_ctx
+        verts = model.get_verts_object()[0].detach().contiguous()
+        K = model.camintr_rois_object
+        pooled = torch.empty(B, S, S, device="cuda")
+        out2 = torch.empty(2, device="cuda")
+        reps = 50
+        ms = torch.zeros(1)
+        rc = hlib.lib().hm_bench_raster_fwd(hlib.ptr(verts), hlib.ptr(sctx.faces), hlib.ptr(K), B, V, F, S,
+                                            hlib.ptr(model.keep_mask_object), hlib.ptr(model.ref_mask_object),
+                                            hlib.ptr(model.losses.keep_sum), hlib.ptr(pooled), hlib.ptr(out2),
+                                            hlib.ptr(sctx.region_order), hlib.ptr(sctx.workspace), reps, ms.data_ptr(), hlib.stream())
+        hlib.check(rc, "hm_bench_raster_fwd")
+        avg_s = ms.item() * 1e-3
+        ach = raster_fwd_bytes(B, S, F) / avg_s / 1e9
+        roof = dict(bound="hbm", kernel="k_raster_fwd", achieved=ach, peak=8000.0, unit="GB/s", frac=ach / 8000.0,
+                    traffic=None, avg_launch_us=avg_s * 1e6,
+                    whole_iteration=dict(algorithmic_bytes=algorithmic_bytes(B, S, F, V, args.step2)["total"],
+                                         achieved_GBps=algorithmic_bytes(B, S, F, V, args.step2)["total"] *
+                                         (args.steps / elapsed) / 1e9))
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(clip, lw, mano, args.cpu_budget, rend_size=S, image_size=S)
+
+    if rank == 0:
+        value = world * args.steps / elapsed
+        line = {
+            "metric": "optimisation iters/sec (30-frame 256^2 clip)", "value": value, "unit": "it/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("cfg3" if args.step2 else "cfg2") +
+                       f": 1 clip/GPU x {B} frames {S}x{S}, synthetic MANO hand + lathe bottle ({F} faces, {V} verts), "
+                       + ("step-2" if args.step2 else "step-1") + " loss set, Adam step + loss logging in the timed region",
+                       "frames": B, "rend_size": S, "faces": int(F), "clips_per_gpu": 1,
+                       "loop": "hipGraph replay of forward+backward+Adam", "parallelism": f"{world} independent clips"},
+            "final_loss": evo["loss"][-1], "first_loss": evo["loss"][0],
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,10 +97,12 @@ __global__ void k_setup_faces(const float* __restrict__ ndc, const int* __restri
     const float ymin = fminf(py[0], fminf(py[1], py[2])), ymax = fmaxf(py[0], fmaxf(py[1], py[2]));
     FaceBox bx;
     if (!(xmax >= -2.0f && ymax >= -2.0f && xmin <= is + 1.0f && ymin <= is + 1.0f)) mask = 0;  // off-screen / NaN
-    int x0 = max(0, (int)floorf(fmaxf(xmin, -2.0f)) - 1);
-    int x1 = min(is - 1, (int)ceilf(fminf(xmax, is + 1.0f)) + 1);
-    int y0 = max(0, (int)floorf(fmaxf(ymin, -2.0f)) - 1);
-    int y1 = min(is - 1, (int)ceilf(fminf(ymax, is + 1.0f)) + 1);
+    // sample p (integer pixel coordinate) can be covered only if min <= p <= max; 0.01 px of slack dwarfs the
+    // rounding of the edge functions, so the box is conservative yet tight
+    int x0 = max(0, (int)ceilf(fmaxf(xmin, -2.0f) - 0.01f));
+    int x1 = min(is - 1, (int)floorf(fminf(xmax, is + 1.0f) + 0.01f));
+    int y0 = max(0, (int)ceilf(fmaxf(ymin, -2.0f) - 0.01f));
+    int y1 = min(is - 1, (int)floorf(fminf(ymax, is + 1.0f) + 0.01f));
     if (x1 < x0 || y1 < y0) mask = 0;
     if (mask == 0) { x0 = y0 = 1; x1 = y1 = 0; }
     bx.x0m = (unsigned short)(x0 | (mask << 14));
@@ -110,13 +112,26 @@ __global__ void k_setup_faces(const float* __restrict__ ndc, const int* __restri
     boxes[i] = bx;
 }
 
-// stage `n` (<=64) queued faces through LDS (one lane per face: vertex data in winding order + barycentric
-// inverse) and let every lane test its four samples against them.
-__device__ __forceinline__ void raster_batch(float* st, const int* q, int n, int b, int F, int is,
+// Rasterise `n` (<=64) queued faces into the wave's tile.  One lane per face builds the face record in registers
+// (vertices in winding order, reciprocal vertex depths, barycentric inverse) and applies a conservative "triangle
+// misses this tile" reject; the surviving records are then broadcast one at a time with v_readlane, i.e. they live
+// in SGPRs while all 64 lanes test their four samples -- no LDS round trip in the inner loop.
+// tile_* = NDC coordinates of the extreme sample centres of the wave's tile.
+__device__ __forceinline__ float rlane(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__device__ __forceinline__ void raster_batch(const int* q, int n, int b, int F, int is,
                                              const float* __restrict__ faces9, const float (&xp)[2],
                                              const float (&yp)[2], const float (&xf)[2], const float (&yf)[2],
-                                             float (&zmin)[4], int (&imin)[4], float znear, float zfar, int lane)
+                                             float (&zmin)[4], int (&imin)[4], float znear, float zfar, int lane,
+                                             float tile_x0, float tile_x1, float tile_y0, float tile_y1)
 {
+    float rec[18];
+    int rfn = -1;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) rec[k] = 0.f;
     if (lane < n) {
         const int e = q[lane];
         const int fi = e & 0x3fffffff, var = e >> 30;
@@ -138,68 +153,119 @@ __device__ __forceinline__ void raster_batch(float* st, const int* q, int n, int
             p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
         const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
                           p[1][0] * (p[2][1] - p[0][1]);
-        float* d = st + lane * STAGE_DW;
+        // conservative reject: some edge has all four tile corners outside by more than the rounding noise of the
+        // edge function (the function is affine, so its extremes over the tile sit at the corners)
+        bool miss = (den == 0.0f);
 #pragma unroll
-        for (int k = 0; k < 9; ++k) d[k] = f[k];
+        for (int k = 0; k < 3; ++k) {
+            const int k1 = (k + 1) % 3;
+            const float ax = f[3 * k], ay = f[3 * k + 1], ex = f[3 * k1] - ax, ey = f[3 * k1 + 1] - ay;
+            bool all_out = true;
+            float mag = 0.f;
+            float lhs[4], rhs[4];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) d[9 + k] = inv[k] / den;
-        reinterpret_cast<int*>(d)[18] = (den == 0.0f) ? -1 : (fi + var * F);
+            for (int cnr = 0; cnr < 4; ++cnr) {
+                const float X = (cnr & 1) ? tile_x1 : tile_x0, Y = (cnr & 2) ? tile_y1 : tile_y0;
+                lhs[cnr] = (Y - ay) * ex;
+                rhs[cnr] = (X - ax) * ey;
+                mag = fmaxf(mag, fabsf(lhs[cnr]) + fabsf(rhs[cnr]));
+            }
+#pragma unroll
+            for (int cnr = 0; cnr < 4; ++cnr) all_out = all_out && (lhs[cnr] < rhs[cnr] - 1e-5f * mag);
+            miss = miss || all_out;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rec[k] = f[k];
+        rec[2] = 1.0f / f[2]; rec[5] = 1.0f / f[5]; rec[8] = 1.0f / f[8];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) rec[9 + k] = inv[k] / den;
+        rfn = miss ? -1 : (fi + var * F);
     }
-    wave_sync();
-    for (int e = 0; e < n; ++e) {
-        const float* d = st + e * STAGE_DW;
-        const int fn = reinterpret_cast<const int*>(d)[18];
-        if (fn < 0) continue;
-        const float f0 = d[0], f1 = d[1], f2 = d[2], f3 = d[3], f4 = d[4], f5 = d[5], f6 = d[6], f7 = d[7],
-                    f8 = d[8];
+    unsigned long long valid = __ballot(rfn >= 0);
+    while (valid) {
+        const int e = __ffsll((long long)valid) - 1;
+        valid &= valid - 1;
+        const int fn = __builtin_amdgcn_readlane(rfn, e);
+        const float f0 = rlane(rec[0], e), f1 = rlane(rec[1], e), f3 = rlane(rec[3], e), f4 = rlane(rec[4], e),
+                    f6 = rlane(rec[6], e), f7 = rlane(rec[7], e);
         const float e0x = f3 - f0, e0y = f4 - f1, e1x = f6 - f3, e1y = f7 - f4, e2x = f0 - f6, e2y = f1 - f7;
+        bool in[4];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
+            const float X = xp[s & 1], Y = yp[s >> 1];
+            in[s] = !(((Y - f1) * e0x < (X - f0) * e0y) || ((Y - f4) * e1x < (X - f3) * e1y) ||
+                      ((Y - f7) * e2x < (X - f6) * e2y));
+        }
+        if (!__any(in[0] || in[1] || in[2] || in[3])) continue;
+        const float rz0 = rlane(rec[2], e), rz1 = rlane(rec[5], e), rz2 = rlane(rec[8], e);
+        // the interpolated depth is a weighted harmonic mean of the vertex depths, hence >= the nearest vertex depth;
+        // 1e-5 relative slack covers its rounding.  Samples already owned by something nearer cannot change.
+        const float znear_face = (1.0f / fmaxf(rz0, fmaxf(rz1, rz2))) * (1.0f - 1e-5f);
+        bool live[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) live[s] = in[s] && !(znear_face > zmin[s]);
+        if (!__any(live[0] || live[1] || live[2] || live[3])) continue;
+        float iv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) iv[k] = rlane(rec[9 + k], e);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (!__any(live[s])) continue;
             const int dy = s >> 1, dx = s & 1;
-            const float X = xp[dx], Y = yp[dy];
-            if (((Y - f1) * e0x < (X - f0) * e0y) || ((Y - f4) * e1x < (X - f3) * e1y) ||
-                ((Y - f7) * e2x < (X - f6) * e2y))
-                continue;
             float wgt[3], ws = 0.0f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                float t = d[9 + 3 * k] * xf[dx];
-                t = t + d[9 + 3 * k + 1] * yf[dy];
-                t = t + d[9 + 3 * k + 2];
+                float t = iv[3 * k] * xf[dx];
+                t = t + iv[3 * k + 1] * yf[dy];
+                t = t + iv[3 * k + 2];
                 t = fminf(fmaxf(t, 0.0f), 1.0f);
                 wgt[k] = t;
                 ws += t;
             }
-            float sum = (wgt[0] / ws) / f2;
-            sum = sum + (wgt[1] / ws) / f5;
-            sum = sum + (wgt[2] / ws) / f8;
-            const float zp = 1.0f / sum;
-            if (!(zp > znear && zp < zfar)) continue;
-            if (zp < zmin[s] || (zp == zmin[s] && fn < imin[s])) { zmin[s] = zp; imin[s] = fn; }
+            float sum = wgt[0] * rz0;
+            sum = sum + wgt[1] * rz1;
+            sum = sum + wgt[2] * rz2;
+            const float zp = ws / sum;
+            const bool hit = in[s] && (zp > znear && zp < zfar) && (zp < zmin[s] || (zp == zmin[s] && fn < imin[s]));
+            if (hit) { zmin[s] = zp; imin[s] = fn; }
         }
     }
-    wave_sync();
 }
 
 // ---------------------------------------------------------------- forward raster
-// one wave per 8x8 output tile.  Outputs: idx_map (B,is,is) int32; alpha16 (B,is,is/16) u16 bit-plane;
-// pooled (B,S,S); optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4).
+// Workgroup = 4 wavefronts = a 2x2 block of 8x8-pixel tiles (a 32x32-sample region); one wave per tile.
+// Binning is two-level and on the fly: the workgroup scans the 8-byte screen boxes of the frame (coalesced,
+// 4 independent loads per thread in flight) and keeps the faces overlapping its region in an LDS candidate list;
+// each wave then filters the candidates against its own tile with ballot compaction.
+// Outputs: idx_map (B,is,is) int32; alpha16 (B,is,is/16) u16 bit-plane; pooled (B,S,S);
+// optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4).
+#define CAND_CAP 1024
+#ifndef HM_RASTER_DBG
+#define HM_RASTER_DBG 0
+#endif
 __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
-    float* __restrict__ partials)
+    float* __restrict__ partials, const short* __restrict__ region_order)
 {
-    __shared__ float stage[RASTER_WAVES][64 * STAGE_DW];
     __shared__ int queue[RASTER_WAVES][192];
+    __shared__ uint2 cand_box[CAND_CAP];
+    __shared__ int cand_id[CAND_CAP];
+    __shared__ int cand_n;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int is = 2 * S, tiles_x = S / HM_TILE, ntiles = tiles_x * tiles_x;
-    const int tile = blockIdx.x * RASTER_WAVES + w;
-    const int b = blockIdx.y;
-    if (tile >= ntiles) return;             // whole wave exits together
-    const int ty = tile / tiles_x, tx = tile % tiles_x;
-    float* st = stage[w];
+    const int is = 2 * S, tiles_x = S / HM_TILE, ntiles = tiles_x * tiles_x, regions_x = tiles_x / 2;
+    // dispatch order: frame fastest, regions from the centre of the ROI outwards (the ROI is cut around the object,
+    // so the expensive regions start first and the cheap border regions fill the tail of the launch)
+    const int region = region_order ? (int)region_order[blockIdx.y] : (int)blockIdx.y;
+    const int rx = region % regions_x, ry = region / regions_x;
+    const int tx = 2 * rx + (w & 1), ty = 2 * ry + (w >> 1);
+    const int tile = ty * tiles_x + tx;
+    const int b = blockIdx.x;
     int* q = queue[w];
+#if HM_RASTER_DBG == 3
+    const unsigned long long t_start = wall_clock64();
+#endif
 
     // this lane's output pixel and its 2x2 samples (flip: output row r <-> sample rows is-1-2r-dy)
     const int r = ty * HM_TILE + (lane >> 3), c = tx * HM_TILE + (lane & 7);
@@ -215,49 +281,90 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     float zmin[4] = {zfar, zfar, zfar, zfar};
     int imin[4] = {-1, -1, -1, -1};
 
-    // tile sample box
+    // sample boxes of this wave's tile and of the workgroup's region
     const int tx0 = tx * HM_STILE, tx1 = tx0 + HM_STILE - 1;
     const int ty1 = is - 1 - ty * HM_STILE, ty0 = ty1 - (HM_STILE - 1);
+    const int gx0 = rx * 2 * HM_STILE, gx1 = gx0 + 2 * HM_STILE - 1;
+    const int gy1 = is - 1 - ry * 2 * HM_STILE, gy0 = gy1 - (2 * HM_STILE - 1);
+    const float tcx0 = (float)(2 * tx0 + 1 - is) / (float)is, tcx1 = (float)(2 * tx1 + 1 - is) / (float)is;
+    const float tcy0 = (float)(2 * ty0 + 1 - is) / (float)is, tcy1 = (float)(2 * ty1 + 1 - is) / (float)is;
 
     int qn = 0;
     const uint2* bx = reinterpret_cast<const uint2*>(boxes) + (long)b * F;
-    for (int base = 0; base < F; base += 64) {
-        // coalesced scan of 64 screen boxes, ballot-compact the overlapping ones into the LDS queue
-        const int fi = base + lane;
-        unsigned mask = 0;
-        if (fi < F) {
-            const uint2 v = bx[fi];
-            const int x0 = v.x & 0x3fff, y0 = (int)(v.x >> 16), x1 = (int)(v.y & 0xffff), y1 = (int)(v.y >> 16);
-            mask = (v.x >> 14) & 3u;
-            if (x1 < tx0 || x0 > tx1 || y1 < ty0 || y0 > ty1) mask = 0;
+#if HM_RASTER_DBG == 2
+    for (int cbase = 0; cbase < 0; cbase += CAND_CAP) {
+#else
+    for (int cbase = 0; cbase < F; cbase += CAND_CAP) {
+#endif
+        if (threadIdx.x == 0) cand_n = 0;
+        __syncthreads();
+        uint2 v[CAND_CAP / 256];
+#pragma unroll
+        for (int k = 0; k < CAND_CAP / 256; ++k) {
+            const int fi = cbase + k * 256 + threadIdx.x;
+            v[k] = (fi < F) ? bx[fi] : make_uint2(0u, 0u);
         }
 #pragma unroll
-        for (int var = 0; var < 2; ++var) {
-            const bool hit = (mask >> var) & 1u;
+        for (int k = 0; k < CAND_CAP / 256; ++k) {
+            const int fi = cbase + k * 256 + threadIdx.x;
+            const int x0 = v[k].x & 0x3fff, y0 = (int)(v[k].x >> 16), x1 = (int)(v[k].y & 0xffff), y1 = (int)(v[k].y >> 16);
+            const bool hit = ((v[k].x >> 14) & 3u) && !(x1 < gx0 || x0 > gx1 || y1 < gy0 || y0 > gy1);
             const unsigned long long bal = __ballot(hit);
-            if (hit) q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = fi | (var << 30);
-            qn += __popcll(bal);
+            int basep = 0;
+            if (lane == 0 && bal) basep = atomicAdd(&cand_n, __popcll(bal));
+            basep = __shfl(basep, 0, 64);
+            if (hit) {
+                const int pos = basep + __popcll(bal & ((1ull << lane) - 1ull));
+                cand_box[pos] = v[k];
+                cand_id[pos] = fi;
+            }
         }
-        wave_sync();
-        while (qn >= 64) {
-            raster_batch(st, q, 64, b, F, is, faces9, xp, yp, xf, yf, zmin, imin, znear, zfar, lane);
-            const int rem = qn - 64;
-            int moved = 0;
-            if (lane < rem) moved = q[64 + lane];
+        __syncthreads();
+        const int n = cand_n;
+        for (int e0 = 0; e0 < n; e0 += 64) {
+            const int e = e0 + lane;
+            unsigned mask = 0;
+            int fi = 0;
+            if (e < n) {
+                const uint2 u = cand_box[e];
+                fi = cand_id[e];
+                const int x0 = u.x & 0x3fff, y0 = (int)(u.x >> 16), x1 = (int)(u.y & 0xffff), y1 = (int)(u.y >> 16);
+                mask = (u.x >> 14) & 3u;
+                if (x1 < tx0 || x0 > tx1 || y1 < ty0 || y0 > ty1) mask = 0;
+            }
+#pragma unroll
+            for (int var = 0; var < 2; ++var) {
+                const bool hit = (mask >> var) & 1u;
+                const unsigned long long bal = __ballot(hit);
+                if (hit) q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = fi | (var << 30);
+                qn += __popcll(bal);
+            }
             wave_sync();
-            if (lane < rem) q[lane] = moved;
-            wave_sync();
-            qn = rem;
+            while (qn >= 64) {
+#if HM_RASTER_DBG != 1
+                raster_batch(q, 64, b, F, is, faces9, xp, yp, xf, yf, zmin, imin, znear, zfar, lane, tcx0, tcx1, tcy0, tcy1);
+#endif
+                const int rem = qn - 64;
+                int moved = 0;
+                if (lane < rem) moved = q[64 + lane];
+                wave_sync();
+                if (lane < rem) q[lane] = moved;
+                wave_sync();
+                qn = rem;
+            }
         }
+        __syncthreads();
     }
-    if (qn > 0) raster_batch(st, q, qn, b, F, is, faces9, xp, yp, xf, yf, zmin, imin, znear, zfar, lane);
+#if HM_RASTER_DBG != 1
+    if (qn > 0) raster_batch(q, qn, b, F, is, faces9, xp, yp, xf, yf, zmin, imin, znear, zfar, lane, tcx0, tcx1, tcy0, tcy1);
+#endif
 
     // ---- outputs
     int* im = idx_map + (long)b * is * is;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-        int2 v = make_int2(imin[2 * dy], imin[2 * dy + 1]);
-        *reinterpret_cast<int2*>(im + (long)(yi0 - dy) * is + xi0) = v;
+        int2 v2 = make_int2(imin[2 * dy], imin[2 * dy + 1]);
+        *reinterpret_cast<int2*>(im + (long)(yi0 - dy) * is + xi0) = v2;
     }
     // alpha bit-plane: 16 sample rows x 16 bits for this tile
     unsigned long long bal[4];
@@ -288,31 +395,35 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         if (lane == 0) {
             float* o = partials + ((long)b * ntiles + tile) * 4;
             o[0] = sq; o[1] = inter; o[2] = uni; o[3] = 0.f;
+#if HM_RASTER_DBG == 3
+            o[3] = (float)(wall_clock64() - t_start);
+            o[2] = (float)(t_start & 0xffffffull);
+#endif
         }
     }
 }
 
+// grid (B): per-frame sums of the tile partials, then the last block finishes:
 // loss = (sum_sq / keep_sum) / B ; iou = mean_b inter_b / (union_b + eps).   out[0]=loss, out[1]=iou
-__global__ void k_sil_reduce(const float* __restrict__ partials, int B, int ntiles, const float* __restrict__ keep_sum,
-                             float* __restrict__ out)
+__global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ partials, int B, int ntiles,
+                                                     const float* __restrict__ keep_sum, float* __restrict__ frame_rec,
+                                                     unsigned int* counter, float* __restrict__ out)
 {
     __shared__ float red[16];
-    __shared__ float acc[2];
-    if (threadIdx.x == 0) { acc[0] = 0.f; acc[1] = 0.f; }
-    float total_sq = 0.f, iou_sum = 0.f;
-    for (int b = 0; b < B; ++b) {
-        float sq = 0.f, in = 0.f, un = 0.f;
-        for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
-            const float* p = partials + ((long)b * ntiles + t) * 4;
-            sq += p[0]; in += p[1]; un += p[2];
-        }
-        sq = hm_block_sum(sq, red);
-        in = hm_block_sum(in, red);
-        un = hm_block_sum(un, red);
-        total_sq += sq;
-        iou_sum += in / (un + 1e-6f);
+    __shared__ int s_flag;
+    const int b = blockIdx.x;
+    float sq = 0.f, in = 0.f, un = 0.f;
+    for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+        const float4 p = *reinterpret_cast<const float4*>(partials + ((long)b * ntiles + t) * 4);
+        sq += p.x; in += p.y; un += p.z;
     }
-    if (threadIdx.x == 0) {
+    sq = hm_block_sum(sq, red);
+    in = hm_block_sum(in, red);
+    un = hm_block_sum(un, red);
+    if (threadIdx.x == 0) { frame_rec[4 * b] = sq; frame_rec[4 * b + 1] = in / (un + 1e-6f); }
+    if (hm_last_block(counter, gridDim.x, &s_flag) && threadIdx.x == 0) {
+        float total_sq = 0.f, iou_sum = 0.f;
+        for (int i = 0; i < B; ++i) { total_sq += frame_rec[4 * i]; iou_sum += frame_rec[4 * i + 1]; }
         out[0] = (total_sq / keep_sum[0]) / (float)B;
         out[1] = iou_sum / (float)B;
     }
@@ -382,11 +493,19 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
 }
 
 // ---------------------------------------------------------------- backward, pass 2: edge sweeps
-// one thread per (b, face, edge, axis); loops the winding variants present.  parts (B,F,2,3,2,2).
+// One wavefront per (frame, face); lanes take the (edge, axis, d0) work items of the face (all six edge/axis
+// combinations packed back to back), so the per-item dependent loads of a whole face are in flight together;
+// per-combination sums come from masked wave reductions.  parts (B,F,2 windings,3 edges,2 axes,2 end points).
 __device__ __forceinline__ float sample_grad(const float* __restrict__ gimg, int S, int is, int xi, int yi)
 {
     return 0.25f * gimg[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
 }
+
+struct SweepCombo {           // wave-uniform description of one (edge, axis) line family
+    float p[3][2];            // p[n][0] sweep coordinate, p[n][1] the other one
+    float slope, num;
+    int dir, d0_from, count;
+};
 
 __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ faces9, const FaceBox* __restrict__ boxes,
                                                    const int* __restrict__ idx_map, const float* __restrict__ gimg,
@@ -394,118 +513,162 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
                                                    const unsigned short* __restrict__ colneg, int B, int F, int S,
                                                    float eps, float* __restrict__ parts)
 {
-    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long)B * F * 6) return;
-    const int axis = (int)(t % 2), e = (int)((t / 2) % 3);
-    const long bf = t / 6;
+    const int lane = threadIdx.x & 63;
+    const long bf = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (bf >= (long)B * F) return;
     const int b = (int)(bf / F), fi = (int)(bf % F);
     const int is = 2 * S;
     const unsigned mask = (reinterpret_cast<const uint2*>(boxes)[bf].x >> 14) & 3u;
     const float* src = faces9 + bf * 9;
     const int* idx = idx_map + (long)b * is * is;
     const float* gi = gimg + (long)b * S * S;
-    // mask words of the sweep lines: axis 0 sweeps along y at fixed x (column masks), axis 1 along x (row masks)
-    const unsigned long long* negw =
-        reinterpret_cast<const unsigned long long*>((axis == 0 ? colneg : rowneg) + (long)b * is * (is / 16));
-    const int wpl = is / 64;     // 64-bit words per line
+    const int wpl = is / 64;     // 64-bit mask words per line
+    float px[3], py[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { px[k] = topix(src[3 * k], is); py[k] = topix(src[3 * k + 1], is); }
+
     for (int var = 0; var < 2; ++var) {
-        float acc0 = 0.0f, acc1 = 0.0f;
-        float* out = parts + (((bf * 2 + var) * 3 + e) * 2 + axis) * 2;
-        if (!((mask >> var) & 1u)) { out[0] = 0.f; out[1] = 0.f; continue; }
+        float* out = parts + (bf * 2 + var) * 12;
+        if (!((mask >> var) & 1u)) {
+            if (lane < 12) out[lane] = 0.f;
+            continue;
+        }
         const int fn = fi + var * F;
-        // oriented vertex k -> source vertex
-        int pi[3];
+        SweepCombo cb[6];
+        int off[7];
+        off[0] = 0;
 #pragma unroll
-        for (int n = 0; n < 3; ++n) { const int k = (e + n) % 3; pi[n] = var ? 2 - k : k; }
-        float p[3][2];
+        for (int e = 0; e < 3; ++e)
 #pragma unroll
-        for (int n = 0; n < 3; ++n) {
-            const float px = topix(src[3 * pi[n]], is), py = topix(src[3 * pi[n] + 1], is);
-            p[n][0] = axis ? py : px;
-            p[n][1] = axis ? px : py;
-        }
-        if (p[0][0] == p[1][0]) { out[0] = 0.f; out[1] = 0.f; continue; }
-        int dir;
-        if (axis == 0) dir = (p[0][0] < p[1][0]) ? -1 : 1;
-        else dir = (p[0][0] < p[1][0]) ? 1 : -1;
-        const int d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.0f);
-        const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)is - 1.0f);
-        const float slope = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]);
-        const float num = p[1][0] - p[0][0];
-        for (int d0 = d0_from; d0 <= d0_to; ++d0) {
-            const float d1_cross = slope * ((float)d0 - p[0][0]) + p[0][1];
-            if (!(d1_cross > -8.0f && d1_cross < (float)is + 8.0f)) continue;
-            const int d1_in = (dir > 0) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
-            const int d1_out = d1_in + dir;
-            if (d1_in < 0 || is <= d1_in) continue;
-            if (d1_out < 0 || is <= d1_out) continue;
-            // pixel (d0,d1) -> (xi,yi): axis 0: xi=d0, yi=d1 ; axis 1: yi=d0, xi=d1
-            const int idx_in = axis ? idx[(long)d0 * is + d1_in] : idx[(long)d1_in * is + d0];
-            const int idx_out = axis ? idx[(long)d0 * is + d1_out] : idx[(long)d1_out * is + d0];
-            const bool use0 = p[1][0] != (float)d0, use1 = p[0][0] != (float)d0;
-            const float c0 = use0 ? num / (p[1][0] - (float)d0) : 0.f;
-            const float c1 = use1 ? num / ((float)d0 - p[0][0]) : 0.f;
-            // ---- outward sweep over samples with alpha==0 and g<0 (mask bits), ascending d1
-            if (idx_in == fn) {
-                const int lim = (dir > 0) ? is - 1 : 0;
-                const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
-                const unsigned long long* line = negw + (long)d0 * wpl;
-                for (int wd = from >> 6; wd <= (to >> 6); ++wd) {
-                    unsigned long long bits = line[wd];
-                    const int lo = wd << 6;
-                    if (from > lo) bits &= ~0ull << (from - lo);
-                    if (to < lo + 63) bits &= ~0ull >> (lo + 63 - to);
-                    while (bits) {
-                        const int d1 = lo + __ffsll((long long)bits) - 1;
-                        bits &= bits - 1;
-                        const float g = axis ? sample_grad(gi, S, is, d1, d0) : sample_grad(gi, S, is, d0, d1);
-                        const float diff = (0.0f - 1.0f) * g;      // (alpha_p - alpha_in) * g, alpha_p=0, alpha_in=1
-                        if (!(diff > 0.0f)) continue;
-                        if (use0) {
-                            float dist = c0 * ((float)d1 - d1_cross) * 2.0f / (float)is;
-                            dist = (0.0f < dist) ? dist + eps : dist - eps;
-                            acc0 -= diff / dist;
+            for (int axis = 0; axis < 2; ++axis) {
+                SweepCombo& c = cb[e * 2 + axis];
+#pragma unroll
+                for (int n = 0; n < 3; ++n) {
+                    const int k = (e + n) % 3, sv = var ? 2 - k : k;
+                    c.p[n][0] = axis ? py[sv] : px[sv];
+                    c.p[n][1] = axis ? px[sv] : py[sv];
+                }
+                int cnt = 0;
+                c.d0_from = 0; c.dir = 0; c.slope = 0.f; c.num = 0.f;
+                if (c.p[0][0] != c.p[1][0]) {
+                    if (axis == 0) c.dir = (c.p[0][0] < c.p[1][0]) ? -1 : 1;
+                    else c.dir = (c.p[0][0] < c.p[1][0]) ? 1 : -1;
+                    c.d0_from = (int)fmaxf(ceilf(fminf(c.p[0][0], c.p[1][0])), 0.0f);
+                    const int d0_to = (int)fminf(fmaxf(c.p[0][0], c.p[1][0]), (float)is - 1.0f);
+                    cnt = max(0, d0_to - c.d0_from + 1);
+                    c.slope = (c.p[1][1] - c.p[0][1]) / (c.p[1][0] - c.p[0][0]);
+                    c.num = c.p[1][0] - c.p[0][0];
+                }
+                c.count = cnt;
+                off[e * 2 + axis + 1] = off[e * 2 + axis] + cnt;
+            }
+        const int total = off[6];
+        float tot[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) tot[k] = 0.f;
+        for (int base = 0; base < total; base += 64) {
+            const int item = base + lane;
+            float acc0 = 0.0f, acc1 = 0.0f;
+            int ci = -1;
+            if (item < total) {
+                ci = 0;
+#pragma unroll
+                for (int k = 1; k < 6; ++k) ci += (item >= off[k]) ? 1 : 0;
+                // select the combo (register array -> explicit selects)
+                SweepCombo c = cb[0];
+#pragma unroll
+                for (int k = 1; k < 6; ++k) if (ci == k) c = cb[k];
+                const int axis = ci & 1;
+                int start = 0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) if (ci == k) start = off[k];
+                const int d0r = c.d0_from + (item - start);
+                const unsigned long long* negw = reinterpret_cast<const unsigned long long*>(
+                    (axis == 0 ? colneg : rowneg) + (long)b * is * (is / 16));
+                const float d1_cross = c.slope * ((float)d0r - c.p[0][0]) + c.p[0][1];
+                if (d1_cross > -8.0f && d1_cross < (float)is + 8.0f) {
+                    const int d1_in = (c.dir > 0) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+                    const int d1_out = d1_in + c.dir;
+                    if (!(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out)) {
+                        const int idx_in = axis ? idx[(long)d0r * is + d1_in] : idx[(long)d1_in * is + d0r];
+                        const int idx_out = axis ? idx[(long)d0r * is + d1_out] : idx[(long)d1_out * is + d0r];
+                        const bool use0 = c.p[1][0] != (float)d0r, use1 = c.p[0][0] != (float)d0r;
+                        const float c0 = use0 ? c.num / (c.p[1][0] - (float)d0r) : 0.f;
+                        const float c1 = use1 ? c.num / ((float)d0r - c.p[0][0]) : 0.f;
+                        // ---- outward sweep over samples with alpha==0 and g<0 (mask bits), ascending d1
+                        if (idx_in == fn) {
+                            const int lim = (c.dir > 0) ? is - 1 : 0;
+                            const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
+                            const unsigned long long* line = negw + (long)d0r * wpl;
+                            for (int wd = from >> 6; wd <= (to >> 6); ++wd) {
+                                unsigned long long bits = line[wd];
+                                const int lo = wd << 6;
+                                if (from > lo) bits &= ~0ull << (from - lo);
+                                if (to < lo + 63) bits &= ~0ull >> (lo + 63 - to);
+                                while (bits) {
+                                    const int d1 = lo + __ffsll((long long)bits) - 1;
+                                    bits &= bits - 1;
+                                    const float g = axis ? sample_grad(gi, S, is, d1, d0r) : sample_grad(gi, S, is, d0r, d1);
+                                    const float diff = (0.0f - 1.0f) * g;
+                                    if (!(diff > 0.0f)) continue;
+                                    if (use0) {
+                                        float dist = c0 * ((float)d1 - d1_cross) * 2.0f / (float)is;
+                                        dist = (0.0f < dist) ? dist + eps : dist - eps;
+                                        acc0 -= diff / dist;
+                                    }
+                                    if (use1) {
+                                        float dist = c1 * ((float)d1 - d1_cross) * 2.0f / (float)is;
+                                        dist = (0.0f < dist) ? dist + eps : dist - eps;
+                                        acc1 -= diff / dist;
+                                    }
+                                }
+                            }
                         }
-                        if (use1) {
-                            float dist = c1 * ((float)d1 - d1_cross) * 2.0f / (float)is;
-                            dist = (0.0f < dist) ? dist + eps : dist - eps;
-                            acc1 -= diff / dist;
+                        // ---- inward sweep over samples owned by this face, only if the outside sample is empty
+                        if (idx_out < 0) {
+                            float c2;
+                            if (((float)d0r - c.p[0][0]) * ((float)d0r - c.p[2][0]) < 0.0f)
+                                c2 = (c.p[2][1] - c.p[0][1]) / (c.p[2][0] - c.p[0][0]) * ((float)d0r - c.p[0][0]) + c.p[0][1];
+                            else
+                                c2 = (c.p[1][1] - c.p[2][1]) / (c.p[1][0] - c.p[2][0]) * ((float)d0r - c.p[2][0]) + c.p[2][1];
+                            if (c2 == c2) {
+                                c2 = fminf(fmaxf(c2, -4.0f), (float)is + 4.0f);
+                                const int lim = (c.dir > 0) ? (int)ceilf(c2) : (int)floorf(c2);
+                                const int from = max(min(d1_in, lim), 0), to = min(max(d1_in, lim), is - 1);
+                                for (int d1 = from; d1 <= to; ++d1) {
+                                    const int id = axis ? idx[(long)d0r * is + d1] : idx[(long)d1 * is + d0r];
+                                    if (id != fn) continue;
+                                    const float g = axis ? sample_grad(gi, S, is, d1, d0r) : sample_grad(gi, S, is, d0r, d1);
+                                    const float diff = (1.0f - 0.0f) * g;
+                                    if (!(diff > 0.0f)) continue;
+                                    if (use0) {
+                                        float dist = c0 * ((float)d1 - d1_cross) * 2.0f / (float)is;
+                                        dist = (0.0f < dist) ? dist + eps : dist - eps;
+                                        acc0 -= diff / dist;
+                                    }
+                                    if (use1) {
+                                        float dist = c1 * ((float)d1 - d1_cross) * 2.0f / (float)is;
+                                        dist = (0.0f < dist) ? dist + eps : dist - eps;
+                                        acc1 -= diff / dist;
+                                    }
+                                }
+                            }
                         }
                     }
                 }
             }
-            // ---- inward sweep over samples owned by this face, only if the outside sample is empty
-            if (idx_out < 0) {
-                float c2;
-                if (((float)d0 - p[0][0]) * ((float)d0 - p[2][0]) < 0.0f)
-                    c2 = (p[2][1] - p[0][1]) / (p[2][0] - p[0][0]) * ((float)d0 - p[0][0]) + p[0][1];
-                else
-                    c2 = (p[1][1] - p[2][1]) / (p[1][0] - p[2][0]) * ((float)d0 - p[2][0]) + p[2][1];
-                if (!(c2 == c2)) continue;
-                c2 = fminf(fmaxf(c2, -4.0f), (float)is + 4.0f);
-                const int lim = (dir > 0) ? (int)ceilf(c2) : (int)floorf(c2);
-                const int from = max(min(d1_in, lim), 0), to = min(max(d1_in, lim), is - 1);
-                for (int d1 = from; d1 <= to; ++d1) {
-                    const int id = axis ? idx[(long)d0 * is + d1] : idx[(long)d1 * is + d0];
-                    if (id != fn) continue;
-                    const float g = axis ? sample_grad(gi, S, is, d1, d0) : sample_grad(gi, S, is, d0, d1);
-                    const float diff = (1.0f - 0.0f) * g;
-                    if (!(diff > 0.0f)) continue;
-                    if (use0) {
-                        float dist = c0 * ((float)d1 - d1_cross) * 2.0f / (float)is;
-                        dist = (0.0f < dist) ? dist + eps : dist - eps;
-                        acc0 -= diff / dist;
-                    }
-                    if (use1) {
-                        float dist = c1 * ((float)d1 - d1_cross) * 2.0f / (float)is;
-                        dist = (0.0f < dist) ? dist + eps : dist - eps;
-                        acc1 -= diff / dist;
-                    }
-                }
+            // masked wave reductions: combination k collects the lanes whose item belongs to it
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (off[k + 1] <= base || off[k] >= base + 64) continue;     // uniform
+                tot[2 * k] += hm_wave_sum(ci == k ? acc0 : 0.f);
+                tot[2 * k + 1] += hm_wave_sum(ci == k ? acc1 : 0.f);
             }
         }
-        out[0] = acc0;
-        out[1] = acc1;
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) out[k] = tot[k];
+        }
     }
 }
 
@@ -554,7 +717,8 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
 {
     const size_t is = 2 * (size_t)S;
-    size_t n = 0;
+    size_t n = 256;                             // counter word (zero-initialised by the caller once)
+    n += al256((size_t)B * 16);                 // per-frame reduction records
     n += al256((size_t)B * V * 3 * 4);          // ndc
     n += al256((size_t)B * F * 9 * 4);          // faces9
     n += al256((size_t)B * F * 8);              // boxes
@@ -570,6 +734,7 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
 }
 
 struct SilWs {
+    unsigned int* counter; float* frame_rec;
     float* ndc; float* faces9; FaceBox* boxes; int* idx_map; unsigned short* alpha16; float* dimg;
     float* partials; float* gimg; unsigned short* rowneg; unsigned short* colneg; float* parts;
 };
@@ -578,6 +743,8 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     const size_t is = 2 * (size_t)S;
     char* p = (char*)ws;
     SilWs w;
+    w.counter = (unsigned int*)p; p += 256;
+    w.frame_rec = (float*)p; p += al256((size_t)B * 16);
     w.ndc = (float*)p; p += al256((size_t)B * V * 3 * 4);
     w.faces9 = (float*)p; p += al256((size_t)B * F * 9 * 4);
     w.boxes = (FaceBox*)p; p += al256((size_t)B * F * 8);
@@ -596,7 +763,8 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 //   keep/ref/keep_sum/loss_out may be NULL (render only).  loss_out[0]=loss_sil, loss_out[1]=mean IoU.
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
-               const float* keep_sum, float* pooled, float* loss_out, void* workspace, hipStream_t stream)
+               const float* keep_sum, float* pooled, float* loss_out, const short* region_order, void* workspace,
+               hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && pooled && workspace);
     HM_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0);
@@ -608,11 +776,12 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv((long)B * F, 256)), dim3(256), 0, stream, w.ndc, faces,
                        faces_bstride, B, V, F, is, w.faces9, w.boxes);
     const bool fused = keep && ref && keep_sum && loss_out;
-    hipLaunchKernelGGL(k_raster_fwd, dim3(hm_cdiv(ntiles, RASTER_WAVES), B), dim3(64 * RASTER_WAVES), 0, stream,
+    hipLaunchKernelGGL(k_raster_fwd, dim3(B, ntiles / RASTER_WAVES), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                       fused ? w.partials : (float*)nullptr);
+                       fused ? w.partials : (float*)nullptr, region_order);
     if (fused)
-        hipLaunchKernelGGL(k_sil_reduce, dim3(1), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, loss_out);
+        hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
+                           w.counter, loss_out);
     return hm_launch_status();
 }
 
@@ -631,11 +800,53 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
     hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                        mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                        w.rowneg, w.colneg);
-    hipLaunchKernelGGL(k_bwd_sweep, dim3(hm_cdiv((long)B * F * 6, 256)), dim3(256), 0, stream, w.faces9, w.boxes,
+    hipLaunchKernelGGL(k_bwd_sweep, dim3(hm_cdiv((long)B * F * 64, 256)), dim3(256), 0, stream, w.faces9, w.boxes,
                        w.idx_map, w.gimg, w.rowneg, w.colneg, B, F, S, eps, w.parts);
     hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                        adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
     return hm_launch_status();
+}
+
+// Measurement hook for bench.py: runs the setup once, then `reps` launches of k_raster_fwd alone between two
+// HIP events recorded on `stream`, and stores the average launch duration in *avg_ms (host pointer).  Synchronises.
+int hm_bench_raster_fwd(const float* verts, const int* faces, const float* K, int B, int V, int F, int S,
+                        const float* keep, const float* ref, const float* keep_sum, float* pooled, float* loss_out,
+                        const short* region_order, void* workspace, int reps, float* avg_ms, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && faces && K && keep && ref && keep_sum && pooled && loss_out && workspace && reps > 0 && avg_ms);
+    int rc = hm_sil_fwd(verts, faces, 0, K, B, V, F, S, 1.0f, 0.1f, 100.0f, keep, ref, keep_sum, pooled, loss_out,
+                        region_order, workspace, stream);
+    if (rc != HM_OK) return rc;
+    SilWs w = carve(workspace, B, V, F, S);
+    const int ntiles = (S / 8) * (S / 8);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return HM_ERR_LAUNCH;
+    hipEventRecord(e0, stream);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(k_raster_fwd, dim3(B, ntiles / RASTER_WAVES), dim3(64 * RASTER_WAVES), 0, stream,
+                           w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
+                           w.partials, region_order);
+    hipEventRecord(e1, stream);
+    hipEventSynchronize(e1);
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    *avg_ms = ms / (float)reps;
+    return hm_launch_status();
+}
+
+int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream)
+{
+    SilWs w = carve((void*)workspace, B, V, F, S);
+    return hipMemcpyAsync(out, w.partials, (size_t)B * (S / 8) * (S / 8) * 16, hipMemcpyDeviceToDevice, stream) == hipSuccess
+               ? HM_OK : HM_ERR_LAUNCH;
+}
+int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks)
+{
+    hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(raster_fwd_blocks, k_raster_fwd, 64 * RASTER_WAVES, 0);
+    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(sweep_blocks, k_bwd_sweep, 256, 0);
+    return (e1 == hipSuccess && e2 == hipSuccess) ? HM_OK : HM_ERR_LAUNCH;
 }
 
 // debug / test access to forward intermediates held in the workspace

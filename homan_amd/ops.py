@@ -40,8 +40,13 @@ class SilhouetteContext:
         self.faces = faces[0].to(device=device, dtype=torch.int32).contiguous()
         off, items = build_adjacency(f0, num_verts)
         self.adj_off, self.adj_items = off.to(device), items.to(device)
+        # 32x32-sample regions ordered from the ROI centre outwards (dispatch order of the forward raster)
+        n = size // 16
+        ry, rx = np.divmod(np.arange(n * n), n)
+        ring = np.maximum(np.abs(2 * rx + 1 - n), np.abs(2 * ry + 1 - n))
+        self.region_order = torch.from_numpy(np.argsort(ring, kind="stable").astype(np.int16)).to(device)
         nbytes = _lib.lib().hm_sil_workspace_bytes(self.B, self.V, self.F, self.S)
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # holds a self-resetting ticket
 
     def idx_map(self):
         out = torch.empty(self.B, 2 * self.S, 2 * self.S, dtype=torch.int32, device=self.workspace.device)
@@ -67,7 +72,8 @@ class _SilhouetteLoss(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, _lib.ptr(keep), _lib.ptr(ref), _lib.ptr(keep_sum),
-            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
+            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.region_order), _lib.ptr(sctx.workspace), _lib.stream()),
+            "hm_sil_fwd")
         ctx.save_for_backward(verts, K, keep_sum)
         ctx.sctx, ctx.orig_size = sctx, orig_size
         ctx.mark_non_differentiable(pooled)
@@ -96,7 +102,7 @@ class _SilhouetteRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
+            _lib.ptr(sctx.region_order), _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
         return pooled

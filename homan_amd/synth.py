@@ -244,3 +244,21 @@ STEP1_LOSS_WEIGHTS = dict(lw_smooth_obj=2000.0, lw_smooth_hand=2000.0, lw_v2d_ha
                           lw_collision=0.0, lw_scale_obj=0.001, lw_scale_hand=0.001)
 STEP2_LOSS_WEIGHTS = dict(STEP1_LOSS_WEIGHTS, lw_collision=0.001, lw_contact=1.0)
 CFG1_LOSS_WEIGHTS = dict({k: 0.0 for k in STEP1_LOSS_WEIGHTS}, lw_sil_obj=1.0, lw_v2d_hand=50.0)
+
+
+def hip_clip_fns(mano_model=None, device="cuda"):
+    """(silhouette_fn, hand_verts_fn) for make_clip backed by the HIP product kernels."""
+    from . import ops
+    mano_model = synthetic_mano(0) if mano_model is None else mano_model
+    mctx = ops.ManoContext(mano_model, device, flat_hand_mean=False)
+
+    def hand_fn(pca, rot, betas):
+        with torch.no_grad():
+            return ops.mano_lbs(pca.to(device), rot.to(device), betas.to(device), None, mctx).cpu()
+
+    def sil_fn(verts, faces, K, size):
+        with torch.no_grad():
+            sctx = ops.SilhouetteContext(faces.to(device), verts.shape[1], verts.shape[0], size, device)
+            return ops.silhouette_render(verts.to(device), K.to(device), sctx).cpu()
+
+    return sil_fn, hand_fn

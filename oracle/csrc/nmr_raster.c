@@ -23,8 +23,11 @@
  *     which is pixel coordinate p = 0.5*(x*is + is - 1) == xi.
  *   - back-facing iff (y2-y0)*(x1-x0) < (y1-y0)*(x2-x0)  (skipped).
  *   - inside iff none of the three edge functions is strictly negative.
- *   - barycentrics from the 3x3 inverse in pixel coordinates, clamped to
- *     [0,1] and renormalised; 1/z interpolated; hit iff near < z < far.
+ *   - barycentrics w_k from the 3x3 inverse in pixel coordinates, clamped to
+ *     [0,1]; perspective-correct depth z = (sum_k w_k) / (sum_k w_k * (1/z_k)),
+ *     i.e. 1/z = sum_k (w_k / sum w) / z_k of the published algorithm with the
+ *     renormalisation folded into one division per sample (reciprocal vertex
+ *     depths 1/z_k are formed once per face); hit iff near < z < far.
  *   - z-buffer: strictly smaller z wins; ties keep the LOWEST face index
  *     (the sequential per-pixel loop order of the upstream kernel).
  *   - zero-area faces (barycentric denominator == 0) are skipped
@@ -85,6 +88,7 @@ void orc_nmr_face_index_map(const float *faces, int B, int NF, int is,
                         p[1][0] * (p[2][1] - p[0][1]);
             if (den == 0.0f) continue;
             for (int k = 0; k < 9; ++k) inv[k] /= den;
+            const float rz0 = 1.0f / f[2], rz1 = 1.0f / f[5], rz2 = 1.0f / f[8];
             float xmin = fminf(p[0][0], fminf(p[1][0], p[2][0]));
             float xmax = fmaxf(p[0][0], fmaxf(p[1][0], p[2][0]));
             float ymin = fminf(p[0][1], fminf(p[1][1], p[2][1]));
@@ -112,11 +116,10 @@ void orc_nmr_face_index_map(const float *faces, int B, int NF, int is,
                         w[k] = t;
                         ws += t;
                     }
-                    for (int k = 0; k < 3; ++k) w[k] /= ws;
-                    float s = w[0] / f[2];
-                    s = s + w[1] / f[5];
-                    s = s + w[2] / f[8];
-                    const float zp = 1.0f / s;
+                    float s = w[0] * rz0;
+                    s = s + w[1] * rz1;
+                    s = s + w[2] * rz2;
+                    const float zp = ws / s;
                     if (!(zp > near && zp < far)) continue;
                     const long pix = (long)yi * is + xi;
                     if (zp < dep[pix]) { dep[pix] = zp; idx[pix] = fn; }
