@@ -11,43 +11,64 @@
 
 #define NN_THREADS 256
 
-// grid (ceil(Vh/256), B)
+// grid (ceil(Vh/64), B).  Workgroup = 64 hand vertices x 4 wavefronts; each wave scans one quarter of every
+// 1024-vertex object tile staged in LDS (all lanes of a wave read the same object vertex: LDS broadcast), then the
+// four partial minima are merged lexicographically on (distance, index) so ties keep the lowest index.
+#define NN_HV 64
+#define NN_TILE 1024
 __global__ __launch_bounds__(NN_THREADS) void k_nn(const float* __restrict__ vh, const float* __restrict__ vo, int B,
                                                     int Vh, int Vo, int* __restrict__ nn_idx, float* __restrict__ nn_d2,
                                                     float* __restrict__ blockmin, unsigned int* counter,
                                                     float* __restrict__ metric_out)
 {
-    __shared__ float tile[NN_THREADS * 3];
+    __shared__ float tile[NN_TILE * 3];
+    __shared__ float s_d[4][NN_HV];
+    __shared__ int s_i[4][NN_HV];
     __shared__ float red[16];
     __shared__ int s_flag;
-    const int b = blockIdx.y, i = blockIdx.x * NN_THREADS + threadIdx.x;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int i = blockIdx.x * NN_HV + lane;
     float hx = 0.f, hy = 0.f, hz = 0.f;
     if (i < Vh) { const float* p = vh + ((long)b * Vh + i) * 3; hx = p[0]; hy = p[1]; hz = p[2]; }
     float best = 3.4e38f;
     int besti = 0;
-    for (int j0 = 0; j0 < Vo; j0 += NN_THREADS) {
-        const int n = min(NN_THREADS, Vo - j0);
+    for (int j0 = 0; j0 < Vo; j0 += NN_TILE) {
+        const int n = min(NN_TILE, Vo - j0);
         __syncthreads();
         for (int e = threadIdx.x; e < 3 * n; e += NN_THREADS) tile[e] = vo[((long)b * Vo + j0) * 3 + e];
         __syncthreads();
-        for (int j = 0; j < n; ++j) {
+        const int lo = q * (NN_TILE / 4), hi = min(lo + NN_TILE / 4, n);
+        for (int j = lo; j < hi; ++j) {
             const float dx = tile[3 * j] - hx, dy = tile[3 * j + 1] - hy, dz = tile[3 * j + 2] - hz;
             const float d = dx * dx + dy * dy + dz * dz;
             if (d < best) { best = d; besti = j0 + j; }
         }
     }
-    if (i < Vh) { nn_idx[(long)b * Vh + i] = besti; nn_d2[(long)b * Vh + i] = best; }
-    const float bm = hm_block_min(i < Vh ? best : 3.4e38f, red);
+    s_d[q][lane] = best;
+    s_i[q][lane] = besti;
+    __syncthreads();
+    float bm = 3.4e38f;
+    if (q == 0) {
+#pragma unroll
+        for (int k = 1; k < 4; ++k) {
+            const float d = s_d[k][lane];
+            const int id = s_i[k][lane];
+            if (d < best || (d == best && id < besti)) { best = d; besti = id; }
+        }
+        if (i < Vh) { nn_idx[(long)b * Vh + i] = besti; nn_d2[(long)b * Vh + i] = best; bm = best; }
+    }
+    bm = hm_block_min(bm, red);
     const unsigned nblk = gridDim.x * gridDim.y;
     if (threadIdx.x == 0) blockmin[b * gridDim.x + blockIdx.x] = bm;
-    if (hm_last_block(counter, nblk, &s_flag) && threadIdx.x == 0) {
+    if (hm_last_block(counter, nblk, &s_flag)) {
         float mx = -3.4e38f;
-        for (int bb = 0; bb < B; ++bb) {
+        for (int bb = threadIdx.x; bb < B; bb += blockDim.x) {
             float m = 3.4e38f;
             for (unsigned c = 0; c < gridDim.x; ++c) m = fminf(m, blockmin[bb * gridDim.x + c]);
             mx = fmaxf(mx, sqrtf(m));
         }
-        metric_out[0] = mx;
+        mx = hm_block_max(mx, red);
+        if (threadIdx.x == 0) metric_out[0] = mx;
     }
 }
 
@@ -92,10 +113,9 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact(const float* __restrict_
     }
     lsum = hm_block_sum(lsum, red);
     if (threadIdx.x == 0) partials[b] = lsum;
-    if (hm_last_block(counter, gridDim.x, &s_flag) && threadIdx.x == 0) {
-        float t = 0.f;
-        for (int i = 0; i < B; ++i) t += partials[i];
-        out[0] = t * inv_cnt;
+    if (hm_last_block(counter, gridDim.x, &s_flag)) {
+        const float t = hm_last_block_sum(partials, B, 1, red);
+        if (threadIdx.x == 0) out[0] = t * inv_cnt;
     }
 }
 
@@ -106,7 +126,7 @@ int hm_nn_fwd(const float* verts_hand, const float* verts_obj, int B, int Vh, in
               float* metric_out, void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(verts_hand && verts_obj && nn_idx && nn_d2 && metric_out && workspace && B > 0 && Vh > 0 && Vo > 0);
-    const int nchunk = hm_cdiv(Vh, NN_THREADS);
+    const int nchunk = hm_cdiv(Vh, NN_HV);
     if ((long)B * nchunk > 512) return HM_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(k_nn, dim3(nchunk, B), dim3(NN_THREADS), 0, stream, verts_hand, verts_obj, B, Vh, Vo, nn_idx,
                        nn_d2, (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out);

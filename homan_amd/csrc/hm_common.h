@@ -23,24 +23,45 @@ static inline int hm_launch_status()
 
 static inline int hm_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// ---- wave-level reductions (64 lanes, deterministic butterfly order) ----
+// ---- wave-level reductions (64 lanes) on DPP: no LDS crossbar round trips (a __shfl_xor butterfly is six dependent
+// ds_bpermute, ~100 cycles each; the DPP forms below are plain VALU moves).  Fixed, deterministic combination order:
+// quad swap, pair swap, row_shr:4, row_shr:8 (row total in lanes 12-15 of every 16-lane row), row_bcast:15 into rows
+// 1 and 3, row_bcast:31 into rows 2 and 3; lane 63 then holds the wave total, which readlane broadcasts.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float hm_dpp(float old, float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v),
+                                                                CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float hm_wave_sum(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += hm_dpp<0xb1, 0xf>(0.f, v);      // quad_perm [1,0,3,2]
+    v += hm_dpp<0x4e, 0xf>(0.f, v);      // quad_perm [2,3,0,1]
+    v += hm_dpp<0x114, 0xf>(0.f, v);     // row_shr:4
+    v += hm_dpp<0x118, 0xf>(0.f, v);     // row_shr:8
+    v += hm_dpp<0x142, 0xa>(0.f, v);     // row_bcast:15 -> rows 1,3
+    v += hm_dpp<0x143, 0xc>(0.f, v);     // row_bcast:31 -> rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float hm_wave_min(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fminf(v, hm_dpp<0xb1, 0xf>(v, v));
+    v = fminf(v, hm_dpp<0x4e, 0xf>(v, v));
+    v = fminf(v, hm_dpp<0x114, 0xf>(v, v));
+    v = fminf(v, hm_dpp<0x118, 0xf>(v, v));
+    v = fminf(v, hm_dpp<0x142, 0xa>(v, v));
+    v = fminf(v, hm_dpp<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float hm_wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, hm_dpp<0xb1, 0xf>(v, v));
+    v = fmaxf(v, hm_dpp<0x4e, 0xf>(v, v));
+    v = fmaxf(v, hm_dpp<0x114, 0xf>(v, v));
+    v = fmaxf(v, hm_dpp<0x118, 0xf>(v, v));
+    v = fmaxf(v, hm_dpp<0x142, 0xa>(v, v));
+    v = fmaxf(v, hm_dpp<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // block-wide sum for blockDim.x <= 1024 (multiple of 64); result valid in every thread.
@@ -105,4 +126,13 @@ __device__ __forceinline__ bool hm_last_block(unsigned int* counter, unsigned in
     const bool last = *s_flag != 0;
     if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     return last;
+}
+
+
+// deterministic parallel sum of `n` partial values with stride `stride` (all threads of the LAST block call it)
+__device__ __forceinline__ float hm_last_block_sum(const float* partials, int n, int stride, float* red)
+{
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a += partials[(long)i * stride];
+    return hm_block_sum(a, red);
 }

@@ -46,11 +46,10 @@ __global__ __launch_bounds__(RED_THREADS) void k_v2d(const float* __restrict__ v
     lsum = hm_block_sum(lsum, red);
     msum = hm_block_sum(msum, red);
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = lsum; partials[2 * blockIdx.x + 1] = msum; }
-    if (hm_last_block(counter, gridDim.x, &s_flag) && threadIdx.x == 0) {
-        float a = 0.f, b = 0.f;
-        for (unsigned i = 0; i < gridDim.x; ++i) { a += partials[2 * i]; b += partials[2 * i + 1]; }
-        out[0] = a * inv_cnt;
-        out[1] = b * inv_cnt;
+    if (hm_last_block(counter, gridDim.x, &s_flag)) {
+        const float a = hm_last_block_sum(partials, gridDim.x, 2, red);
+        const float b = hm_last_block_sum(partials + 1, gridDim.x, 2, red);
+        if (threadIdx.x == 0) { out[0] = a * inv_cnt; out[1] = b * inv_cnt; }
     }
 }
 
@@ -81,10 +80,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_smooth(const float* __restrict_
     }
     lsum = hm_block_sum(lsum, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = lsum;
-    if (hm_last_block(counter, gridDim.x, &s_flag) && threadIdx.x == 0) {
-        float a = 0.f;
-        for (unsigned i = 0; i < gridDim.x; ++i) a += partials[i];
-        out[0] = a * inv_cnt;
+    if (hm_last_block(counter, gridDim.x, &s_flag)) {
+        const float a = hm_last_block_sum(partials, gridDim.x, 1, red);
+        if (threadIdx.x == 0) out[0] = a * inv_cnt;
     }
 }
 
@@ -178,11 +176,12 @@ __global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__
         r[0] = flag; r[1] = mse;
         r[2] = flag * 2.0f * dx / 3.0f; r[3] = flag * 2.0f * dy / 3.0f; r[4] = flag * 2.0f * dz / 3.0f;
     }
-    if (hm_last_block(counter, gridDim.x, &s_flag) && threadIdx.x == 0) {
+    if (hm_last_block(counter, gridDim.x, &s_flag)) {
         float l = 0.f;
-        for (int i = 0; i < B; ++i)
+        for (int i = threadIdx.x; i < B; i += blockDim.x)
             if (frame_rec[i * 8] != 0.f) l += frame_rec[i * 8 + 1];
-        out[0] = l;
+        l = hm_block_sum(l, red);
+        if (threadIdx.x == 0) out[0] = l;
     }
 }
 

@@ -73,7 +73,7 @@ __global__ void k_project(const float* __restrict__ verts, const float* __restri
 // gathers the packed (B,F,3,3) face buffer and the 8-byte screen boxes.
 __global__ void k_setup_faces(const float* __restrict__ ndc, const int* __restrict__ faces, int faces_bstride,
                               int B, int V, int F, int is, float* __restrict__ faces9,
-                              FaceBox* __restrict__ boxes)
+                              FaceBox* __restrict__ boxes, unsigned char* __restrict__ owned)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * F) return;
@@ -89,6 +89,8 @@ __global__ void k_setup_faces(const float* __restrict__ ndc, const int* __restri
     for (int k = 0; k < 3; ++k) { r[3 * k] = f[3 * (2 - k)]; r[3 * k + 1] = f[3 * (2 - k) + 1]; r[3 * k + 2] = f[3 * (2 - k) + 2]; }
 #pragma unroll
     for (int k = 0; k < 9; ++k) faces9[i * 9 + k] = f[k];
+    owned[(long)b * 2 * F + fi] = 0;          // "owns at least one sample" flags, set by the forward raster
+    owned[(long)b * 2 * F + F + fi] = 0;
     unsigned mask = (backside(f) ? 0u : 1u) | (backside(r) ? 0u : 2u);
     float px[3], py[3];
 #pragma unroll
@@ -243,11 +245,14 @@ __device__ __forceinline__ void raster_batch(const int* q, int n, int b, int F, 
 #ifndef HM_RASTER_DBG
 #define HM_RASTER_DBG 0
 #endif
+#ifndef HM_SWEEP_DBG
+#define HM_SWEEP_DBG 0
+#endif
 __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
-    float* __restrict__ partials, const short* __restrict__ region_order)
+    float* __restrict__ partials, const short* __restrict__ region_order, unsigned char* __restrict__ owned)
 {
     __shared__ int queue[RASTER_WAVES][192];
     __shared__ uint2 cand_box[CAND_CAP];
@@ -366,6 +371,10 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         int2 v2 = make_int2(imin[2 * dy], imin[2 * dy + 1]);
         *reinterpret_cast<int2*>(im + (long)(yi0 - dy) * is + xi0) = v2;
     }
+    // faces that own a sample (benign same-value races; consecutive duplicates within a lane are skipped)
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        if (imin[s] >= 0 && (s == 0 || imin[s] != imin[s - 1])) owned[(long)b * 2 * F + imin[s]] = 1;
     // alpha bit-plane: 16 sample rows x 16 bits for this tile
     unsigned long long bal[4];
 #pragma unroll
@@ -421,18 +430,22 @@ __global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ pa
     in = hm_block_sum(in, red);
     un = hm_block_sum(un, red);
     if (threadIdx.x == 0) { frame_rec[4 * b] = sq; frame_rec[4 * b + 1] = in / (un + 1e-6f); }
-    if (hm_last_block(counter, gridDim.x, &s_flag) && threadIdx.x == 0) {
-        float total_sq = 0.f, iou_sum = 0.f;
-        for (int i = 0; i < B; ++i) { total_sq += frame_rec[4 * i]; iou_sum += frame_rec[4 * i + 1]; }
-        out[0] = (total_sq / keep_sum[0]) / (float)B;
-        out[1] = iou_sum / (float)B;
+    if (hm_last_block(counter, gridDim.x, &s_flag)) {
+        const float total_sq = hm_last_block_sum(frame_rec, B, 4, red);
+        const float iou_sum = hm_last_block_sum(frame_rec + 1, B, 4, red);
+        if (threadIdx.x == 0) {
+            out[0] = (total_sq / keep_sum[0]) / (float)B;
+            out[1] = iou_sum / (float)B;
+        }
     }
 }
 
 // ---------------------------------------------------------------- backward, pass 1: masks + sample-gradient image
 // g(b,r,c) = dL/dpooled.  mode 0: gin is that image.  mode 1: gin is dimg (keep*(keep*pool-ref)) and
 // g = upstream[0] * 2 * dimg / keep_sum / B (the fused masked-MSE of losses.py:188-194).
-// Emits gimg (B,S,S) and row/column bit masks of samples with alpha==0 and g<0 ("wants to be filled").
+// Emits gimg (B,S,S) and row/column bit masks, two planes each: plane 0 = samples with alpha==0 and g<0 ("wants to be
+// filled", walked by the outward sweeps), plane 1 = samples with alpha==1 and g>0 ("wants to be emptied", the only
+// samples the inward sweeps can collect from).
 __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin, int mode,
                                                    const float* __restrict__ upstream,
                                                    const float* __restrict__ keep_sum, int B, int S,
@@ -454,19 +467,26 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
         g = s * g / keep_sum[0] / (float)B;
     }
     gimg[po] = g;
-    const bool neg = g < 0.0f;
+    const bool neg = g < 0.0f, pos = g > 0.0f;
     // alpha bits of this lane's 4 samples
     const int yi0 = is - 1 - 2 * r;
+    const long plane = (long)B * is * (is / 16);
+    unsigned aw2[2];
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) aw2[dy] = alpha16[((long)b * is + (yi0 - dy)) * (is / 16) + tx];
+#pragma unroll 1
+    for (int pl = 0; pl < 2; ++pl) {
     unsigned long long bal[4];
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-        const unsigned aw = alpha16[((long)b * is + (yi0 - dy)) * (is / 16) + tx];
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) {
-            const bool empty = !((aw >> (2 * cc + dx)) & 1u);
-            bal[2 * dy + dx] = __ballot(empty && neg);
+            const bool filled = (aw2[dy] >> (2 * cc + dx)) & 1u;
+            bal[2 * dy + dx] = __ballot(pl == 0 ? (!filled && neg) : (filled && pos));
         }
     }
+    unsigned short* rowm = rowneg + pl * plane;
+    unsigned short* colm = colneg + pl * plane;
     if (lane < 16) {            // row words: sample row (rr,dy), bits along x
         const int rr2 = lane >> 1, dy = lane & 1;
         const unsigned a = (unsigned)(bal[2 * dy] >> (8 * rr2)) & 0xffu;
@@ -475,7 +495,7 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
 #pragma unroll
         for (int k = 0; k < 8; ++k) word |= (((a >> k) & 1u) << (2 * k)) | (((o >> k) & 1u) << (2 * k + 1));
         const int yi = is - 1 - 2 * (ty * HM_TILE + rr2) - dy;
-        rowneg[((long)b * is + yi) * (is / 16) + tx] = (unsigned short)word;
+        rowm[((long)b * is + yi) * (is / 16) + tx] = (unsigned short)word;
     } else if (lane < 32) {     // column words: sample column (cc,dx), bits along y (bit = yi - ybase)
         const int l = lane - 16, cc2 = l >> 1, dx = l & 1;
         unsigned word = 0;
@@ -488,14 +508,20 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
             }
         const int xi = 2 * (tx * HM_TILE + cc2) + dx;
         const int ygrp = (is / 16) - 1 - ty;       // 16-sample group along y holding this tile
-        colneg[((long)b * is + xi) * (is / 16) + ygrp] = (unsigned short)word;
+        colm[((long)b * is + xi) * (is / 16) + ygrp] = (unsigned short)word;
     }
+    }   // planes
 }
 
 // ---------------------------------------------------------------- backward, pass 2: edge sweeps
-// One wavefront per (frame, face); lanes take the (edge, axis, d0) work items of the face (all six edge/axis
-// combinations packed back to back), so the per-item dependent loads of a whole face are in flight together;
-// per-combination sums come from masked wave reductions.  parts (B,F,2 windings,3 edges,2 axes,2 end points).
+// Persistent wavefronts, one face at a time; lanes take the (edge, axis, d0) work items of the face (all six
+// edge/axis combinations packed back to back) so the dependent loads of a whole face are in flight together.
+// Both sweeps of an item walk 1-bit/sample planes: the outward sweep the "empty and g<0" plane from the edge to the
+// image border, the inward sweep the "covered and g>0" plane across the triangle.  Lines that run along the
+// silhouette band can hold hundreds of set bits: an item with more than SWEEP_LIGHT bits is handed to the whole
+// wave (64 lanes stride its range, shuffle-reduce), which bounds the serial chain a single lane can own.
+// parts (B,F,2 windings,3 edges,2 axes,2 end points).
+#define SWEEP_LIGHT 12
 __device__ __forceinline__ float sample_grad(const float* __restrict__ gimg, int S, int is, int xi, int yi)
 {
     return 0.25f * gimg[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
@@ -507,169 +533,303 @@ struct SweepCombo {           // wave-uniform description of one (edge, axis) li
     int dir, d0_from, count;
 };
 
+// contribution of sample d1 (pseudo-distance of the crossing to the two end points of the edge)
+__device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, float c0, float c1, bool use0, bool use1,
+                                           float eps, float two_over_is, bool pow2, int is, float& acc0, float& acc1)
+{
+    if (!(diff > 0.0f)) return;
+    const float t = (float)d1 - d1_cross;
+    if (use0) {
+        float dist = c0 * t * 2.0f;
+        dist = pow2 ? dist * two_over_is : dist / (float)is;      // exact either way when is is a power of two
+        dist = (0.0f < dist) ? dist + eps : dist - eps;
+        acc0 -= diff * __builtin_amdgcn_rcpf(dist);       // 1-ulp reciprocal: the pseudo-gradient is compared at 1e-3
+    }
+    if (use1) {
+        float dist = c1 * t * 2.0f;
+        dist = pow2 ? dist * two_over_is : dist / (float)is;
+        dist = (0.0f < dist) ? dist + eps : dist - eps;
+        acc1 -= diff * __builtin_amdgcn_rcpf(dist);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ faces9, const FaceBox* __restrict__ boxes,
                                                    const int* __restrict__ idx_map, const float* __restrict__ gimg,
                                                    const unsigned short* __restrict__ rowneg,
                                                    const unsigned short* __restrict__ colneg, int B, int F, int S,
-                                                   float eps, float* __restrict__ parts)
+                                                   float eps, float* __restrict__ parts, float* __restrict__ dbg,
+                                                   const unsigned char* __restrict__ owned)
 {
-    const int lane = threadIdx.x & 63;
-    const long bf = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    if (bf >= (long)B * F) return;
-    const int b = (int)(bf / F), fi = (int)(bf % F);
+    __shared__ float s_cb[4][6][12];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int is = 2 * S;
-    const unsigned mask = (reinterpret_cast<const uint2*>(boxes)[bf].x >> 14) & 3u;
-    const float* src = faces9 + bf * 9;
-    const int* idx = idx_map + (long)b * is * is;
-    const float* gi = gimg + (long)b * S * S;
-    const int wpl = is / 64;     // 64-bit mask words per line
-    float px[3], py[3];
+    const bool pow2 = (is & (is - 1)) == 0;
+    const float inv_is = 1.0f / (float)is;      // exact for powers of two
+    const int wpl = is / 64;                    // 64-bit mask words per line
+    const long plane_words = (long)B * is * wpl;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long bf = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+         bf < (long)B * F; bf += nwaves) {
+        const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
+        int dbg_items = 0, dbg_bits = 0, dbg_heavy = 0;
+        const int b = (int)(bf / F), fi = (int)(bf % F);
+        const unsigned mask = (reinterpret_cast<const uint2*>(boxes)[bf].x >> 14) & 3u;
+        const float* src = faces9 + bf * 9;
+        const int* idx = idx_map + (long)b * is * is;
+        const float* gi = gimg + (long)b * S * S;
+        const unsigned long long* colw = reinterpret_cast<const unsigned long long*>(colneg) + (long)b * is * wpl;
+        const unsigned long long* roww = reinterpret_cast<const unsigned long long*>(rowneg) + (long)b * is * wpl;
+        float px[3], py[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { px[k] = topix(src[3 * k], is); py[k] = topix(src[3 * k + 1], is); }
+        for (int k = 0; k < 3; ++k) { px[k] = topix(src[3 * k], is); py[k] = topix(src[3 * k + 1], is); }
 
-    for (int var = 0; var < 2; ++var) {
-        float* out = parts + (bf * 2 + var) * 12;
-        if (!((mask >> var) & 1u)) {
-            if (lane < 12) out[lane] = 0.f;
-            continue;
-        }
-        const int fn = fi + var * F;
-        SweepCombo cb[6];
-        int off[7];
-        off[0] = 0;
-#pragma unroll
-        for (int e = 0; e < 3; ++e)
-#pragma unroll
-            for (int axis = 0; axis < 2; ++axis) {
-                SweepCombo& c = cb[e * 2 + axis];
+        for (int var = 0; var < 2; ++var) {
+            float* out = parts + (bf * 2 + var) * 12;
+            const int fn = fi + var * F;
+            // a face that owns no sample has no in-pixel of its own and nothing to sweep inwards over: zero gradient
+            if (!((mask >> var) & 1u) || !owned[(long)b * 2 * F + fn]) {
+                if (lane < 12) out[lane] = 0.f;
+                continue;
+            }
+            // lanes 0..5 build the six (edge, axis) line families of this winding into LDS (they are wave-uniform
+            // data; keeping them out of VGPRs is what lets 8 waves per SIMD hide the memory latency of the sweeps)
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 6) {
+                const int e = lane >> 1, axis = lane & 1;
+                float* c = s_cb[wv][lane];
+                float p[3][2];
 #pragma unroll
                 for (int n = 0; n < 3; ++n) {
                     const int k = (e + n) % 3, sv = var ? 2 - k : k;
-                    c.p[n][0] = axis ? py[sv] : px[sv];
-                    c.p[n][1] = axis ? px[sv] : py[sv];
+                    float xs = px[0], ys = py[0];
+                    if (sv == 1) { xs = px[1]; ys = py[1]; }
+                    if (sv == 2) { xs = px[2]; ys = py[2]; }
+                    p[n][0] = axis ? ys : xs;
+                    p[n][1] = axis ? xs : ys;
                 }
-                int cnt = 0;
-                c.d0_from = 0; c.dir = 0; c.slope = 0.f; c.num = 0.f;
-                if (c.p[0][0] != c.p[1][0]) {
-                    if (axis == 0) c.dir = (c.p[0][0] < c.p[1][0]) ? -1 : 1;
-                    else c.dir = (c.p[0][0] < c.p[1][0]) ? 1 : -1;
-                    c.d0_from = (int)fmaxf(ceilf(fminf(c.p[0][0], c.p[1][0])), 0.0f);
-                    const int d0_to = (int)fminf(fmaxf(c.p[0][0], c.p[1][0]), (float)is - 1.0f);
-                    cnt = max(0, d0_to - c.d0_from + 1);
-                    c.slope = (c.p[1][1] - c.p[0][1]) / (c.p[1][0] - c.p[0][0]);
-                    c.num = c.p[1][0] - c.p[0][0];
+                int cnt = 0, d0_from = 0, dir = 0;
+                float slope = 0.f, num = 0.f;
+                if (p[0][0] != p[1][0]) {
+                    if (axis == 0) dir = (p[0][0] < p[1][0]) ? -1 : 1;
+                    else dir = (p[0][0] < p[1][0]) ? 1 : -1;
+                    d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.0f);
+                    const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)is - 1.0f);
+                    cnt = max(0, d0_to - d0_from + 1);
+                    slope = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]);
+                    num = p[1][0] - p[0][0];
                 }
-                c.count = cnt;
-                off[e * 2 + axis + 1] = off[e * 2 + axis] + cnt;
+                c[0] = p[0][0]; c[1] = p[0][1]; c[2] = p[1][0]; c[3] = p[1][1]; c[4] = p[2][0]; c[5] = p[2][1];
+                c[6] = slope; c[7] = num;
+                reinterpret_cast<int*>(c)[8] = dir;
+                reinterpret_cast<int*>(c)[9] = d0_from;
+                reinterpret_cast<int*>(c)[10] = cnt;
             }
-        const int total = off[6];
-        float tot[12];
+            wave_sync();
+            int off[7];
+            off[0] = 0;
 #pragma unroll
-        for (int k = 0; k < 12; ++k) tot[k] = 0.f;
-        for (int base = 0; base < total; base += 64) {
-            const int item = base + lane;
-            float acc0 = 0.0f, acc1 = 0.0f;
-            int ci = -1;
-            if (item < total) {
-                ci = 0;
+            for (int k = 0; k < 6; ++k) off[k + 1] = off[k] + reinterpret_cast<const int*>(s_cb[wv][k])[10];
+            const int total = off[6];
+            dbg_items += total;
+            float tot[12];
 #pragma unroll
-                for (int k = 1; k < 6; ++k) ci += (item >= off[k]) ? 1 : 0;
-                // select the combo (register array -> explicit selects)
-                SweepCombo c = cb[0];
+            for (int k = 0; k < 12; ++k) tot[k] = 0.f;
+#pragma unroll 1
+            for (int base = 0; base < total; base += 64) {
+                const int item = base + lane;
+                float acc0 = 0.0f, acc1 = 0.0f;
+                int ci = -1;
+                // ---- per-lane item setup
+                int axis = 0, d0r = 0;
+                float d1_cross = 0.f, c0 = 0.f, c1 = 0.f;
+                bool use0 = false, use1 = false;
+                bool act[2] = {false, false};          // [0] outward, [1] inward
+                int rfrom[2] = {0, 0}, rto[2] = {-1, -1};
+                if (item < total) {
+                    ci = 0;
+                    int start = 0;
 #pragma unroll
-                for (int k = 1; k < 6; ++k) if (ci == k) c = cb[k];
-                const int axis = ci & 1;
-                int start = 0;
-#pragma unroll
-                for (int k = 0; k < 6; ++k) if (ci == k) start = off[k];
-                const int d0r = c.d0_from + (item - start);
-                const unsigned long long* negw = reinterpret_cast<const unsigned long long*>(
-                    (axis == 0 ? colneg : rowneg) + (long)b * is * (is / 16));
-                const float d1_cross = c.slope * ((float)d0r - c.p[0][0]) + c.p[0][1];
-                if (d1_cross > -8.0f && d1_cross < (float)is + 8.0f) {
-                    const int d1_in = (c.dir > 0) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
-                    const int d1_out = d1_in + c.dir;
-                    if (!(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out)) {
-                        const int idx_in = axis ? idx[(long)d0r * is + d1_in] : idx[(long)d1_in * is + d0r];
-                        const int idx_out = axis ? idx[(long)d0r * is + d1_out] : idx[(long)d1_out * is + d0r];
-                        const bool use0 = c.p[1][0] != (float)d0r, use1 = c.p[0][0] != (float)d0r;
-                        const float c0 = use0 ? c.num / (c.p[1][0] - (float)d0r) : 0.f;
-                        const float c1 = use1 ? c.num / ((float)d0r - c.p[0][0]) : 0.f;
-                        // ---- outward sweep over samples with alpha==0 and g<0 (mask bits), ascending d1
-                        if (idx_in == fn) {
-                            const int lim = (c.dir > 0) ? is - 1 : 0;
-                            const int from = max(min(d1_out, lim), 0), to = min(max(d1_out, lim), is - 1);
-                            const unsigned long long* line = negw + (long)d0r * wpl;
-                            for (int wd = from >> 6; wd <= (to >> 6); ++wd) {
-                                unsigned long long bits = line[wd];
-                                const int lo = wd << 6;
-                                if (from > lo) bits &= ~0ull << (from - lo);
-                                if (to < lo + 63) bits &= ~0ull >> (lo + 63 - to);
-                                while (bits) {
-                                    const int d1 = lo + __ffsll((long long)bits) - 1;
-                                    bits &= bits - 1;
-                                    const float g = axis ? sample_grad(gi, S, is, d1, d0r) : sample_grad(gi, S, is, d0r, d1);
-                                    const float diff = (0.0f - 1.0f) * g;
-                                    if (!(diff > 0.0f)) continue;
-                                    if (use0) {
-                                        float dist = c0 * ((float)d1 - d1_cross) * 2.0f / (float)is;
-                                        dist = (0.0f < dist) ? dist + eps : dist - eps;
-                                        acc0 -= diff / dist;
-                                    }
-                                    if (use1) {
-                                        float dist = c1 * ((float)d1 - d1_cross) * 2.0f / (float)is;
-                                        dist = (0.0f < dist) ? dist + eps : dist - eps;
-                                        acc1 -= diff / dist;
-                                    }
-                                }
+                    for (int k = 1; k < 6; ++k) if (item >= off[k]) { ci = k; start = off[k]; }
+                    const float* c = s_cb[wv][ci];
+                    const float p00 = c[0], p01 = c[1], p10 = c[2], p11 = c[3], p20 = c[4], p21 = c[5];
+                    const float slope = c[6], num = c[7];
+                    const int dir = reinterpret_cast<const int*>(c)[8], d0_from = reinterpret_cast<const int*>(c)[9];
+                    axis = ci & 1;
+                    d0r = d0_from + (item - start);
+                    d1_cross = slope * ((float)d0r - p00) + p01;
+                    if (d1_cross > -8.0f && d1_cross < (float)is + 8.0f) {
+                        const int d1_in = (dir > 0) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
+                        const int d1_out = d1_in + dir;
+                        if (!(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out)) {
+                            const int idx_in = axis ? idx[(long)d0r * is + d1_in] : idx[(long)d1_in * is + d0r];
+                            const int idx_out = axis ? idx[(long)d0r * is + d1_out] : idx[(long)d1_out * is + d0r];
+                            use0 = p10 != (float)d0r;
+                            use1 = p00 != (float)d0r;
+                            c0 = use0 ? num / (p10 - (float)d0r) : 0.f;
+                            c1 = use1 ? num / ((float)d0r - p00) : 0.f;
+                            if (idx_in == fn) {             // outward: from the sample just outside the edge to the border
+                                const int lim = (dir > 0) ? is - 1 : 0;
+                                rfrom[0] = max(min(d1_out, lim), 0);
+                                rto[0] = min(max(d1_out, lim), is - 1);
+                                act[0] = true;
                             }
-                        }
-                        // ---- inward sweep over samples owned by this face, only if the outside sample is empty
-                        if (idx_out < 0) {
-                            float c2;
-                            if (((float)d0r - c.p[0][0]) * ((float)d0r - c.p[2][0]) < 0.0f)
-                                c2 = (c.p[2][1] - c.p[0][1]) / (c.p[2][0] - c.p[0][0]) * ((float)d0r - c.p[0][0]) + c.p[0][1];
-                            else
-                                c2 = (c.p[1][1] - c.p[2][1]) / (c.p[1][0] - c.p[2][0]) * ((float)d0r - c.p[2][0]) + c.p[2][1];
-                            if (c2 == c2) {
-                                c2 = fminf(fmaxf(c2, -4.0f), (float)is + 4.0f);
-                                const int lim = (c.dir > 0) ? (int)ceilf(c2) : (int)floorf(c2);
-                                const int from = max(min(d1_in, lim), 0), to = min(max(d1_in, lim), is - 1);
-                                for (int d1 = from; d1 <= to; ++d1) {
-                                    const int id = axis ? idx[(long)d0r * is + d1] : idx[(long)d1 * is + d0r];
-                                    if (id != fn) continue;
-                                    const float g = axis ? sample_grad(gi, S, is, d1, d0r) : sample_grad(gi, S, is, d0r, d1);
-                                    const float diff = (1.0f - 0.0f) * g;
-                                    if (!(diff > 0.0f)) continue;
-                                    if (use0) {
-                                        float dist = c0 * ((float)d1 - d1_cross) * 2.0f / (float)is;
-                                        dist = (0.0f < dist) ? dist + eps : dist - eps;
-                                        acc0 -= diff / dist;
-                                    }
-                                    if (use1) {
-                                        float dist = c1 * ((float)d1 - d1_cross) * 2.0f / (float)is;
-                                        dist = (0.0f < dist) ? dist + eps : dist - eps;
-                                        acc1 -= diff / dist;
-                                    }
+                            if (idx_out < 0) {              // inward: across the triangle, only if the outside sample is empty
+                                float c2;
+                                if (((float)d0r - p00) * ((float)d0r - p20) < 0.0f)
+                                    c2 = (p21 - p01) / (p20 - p00) * ((float)d0r - p00) + p01;
+                                else
+                                    c2 = (p11 - p21) / (p10 - p20) * ((float)d0r - p20) + p21;
+                                if (c2 == c2) {
+                                    c2 = fminf(fmaxf(c2, -4.0f), (float)is + 4.0f);
+                                    const int lim = (dir > 0) ? (int)ceilf(c2) : (int)floorf(c2);
+                                    rfrom[1] = max(min(d1_in, lim), 0);
+                                    rto[1] = min(max(d1_in, lim), is - 1);
+                                    act[1] = true;
                                 }
                             }
                         }
                     }
                 }
-            }
-            // masked wave reductions: combination k collects the lanes whose item belongs to it
+                const unsigned long long* line0 = (axis == 0 ? colw : roww) + (long)d0r * wpl;
+                // ---- the two sweeps
+#pragma unroll 1
+                for (int ph = 0; ph < 2; ++ph) {
+                    const int from = rfrom[ph], to = rto[ph];
+                    const bool on = act[ph] && from <= to;
+                    // the whole line of the plane in registers (is <= 512: 8 words = four independent 16-byte loads),
+                    // clipped to [from, to]
+                    unsigned long long wd[8];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                if (off[k + 1] <= base || off[k] >= base + 64) continue;     // uniform
-                tot[2 * k] += hm_wave_sum(ci == k ? acc0 : 0.f);
-                tot[2 * k + 1] += hm_wave_sum(ci == k ? acc1 : 0.f);
-            }
-        }
-        if (lane == 0) {
+                    for (int k = 0; k < 8; ++k) wd[k] = 0ull;
+                    if (on) {
+                        const unsigned long long* line = line0 + ph * plane_words;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) out[k] = tot[k];
-        }
+                        for (int k = 0; k < 8; ++k)
+                            if (k < wpl) wd[k] = line[k];
+                    }
+                    int nb = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int lo = k << 6;
+                        unsigned long long bits = wd[k];
+                        if (!on || to < lo || from > lo + 63) bits = 0ull;
+                        else {
+                            if (from > lo) bits &= ~0ull << (from - lo);
+                            if (to < lo + 63) bits &= ~0ull >> (lo + 63 - to);
+                        }
+                        wd[k] = bits;
+                        nb += __popcll(bits);
+                    }
+                    // Dense lines either go to the whole wave one at a time (cost ~ #dense lanes) or every lane walks its
+                    // own bits (cost ~ longest line); pick the cheaper of the two for this pass (wave-uniform).
+                    const int maxnb = (int)hm_wave_max((float)nb);
+                    const int ndense = __popcll(__ballot(nb > SWEEP_LIGHT));
+                    const bool coop = ndense * 16 < maxnb;
+                    const bool heavy = coop && nb > SWEEP_LIGHT;
+                    if (dbg) { dbg_bits += nb; dbg_heavy += heavy ? 1 : 0; }
+                    if (nb > 0 && !heavy && HM_SWEEP_DBG != 5) {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            unsigned long long bits = wd[k];
+#pragma unroll 1
+                            while (bits) {
+                                // up to four set bits per round: their gradient (and owner) loads are in flight together
+                                int d1s[4];
+                                float gs[4];
+                                bool oks[4];
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    oks[u] = bits != 0ull;
+                                    d1s[u] = oks[u] ? (k << 6) + __ffsll((long long)bits) - 1 : (k << 6);
+                                    bits &= bits - 1;
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u) {
+                                    const int xi = axis ? d1s[u] : d0r, yi = axis ? d0r : d1s[u];
+                                    gs[u] = oks[u] ? sample_grad(gi, S, is, xi, yi) : 0.f;
+                                    if (ph == 1 && oks[u]) oks[u] = idx[(long)yi * is + xi] == fn;
+                                }
+#pragma unroll
+                                for (int u = 0; u < 4; ++u)
+                                    if (oks[u]) sweep_term(ph == 0 ? -gs[u] : gs[u], d1s[u], d1_cross, c0, c1, use0, use1, eps, inv_is, pow2, is, acc0, acc1);
+                            }
+                        }
+                    }
+                    // ---- dense lines: the whole wave works on one lane's range at a time (line words broadcast
+                    //      from the owner's registers; every lane takes positions lane, lane+64, ...)
+                    unsigned long long hv = (HM_SWEEP_DBG == 4) ? 0ull : __ballot(heavy);
+                    // software-pipelined over the heavy lanes: the gradient (and owner) loads of the next line are in
+                    // flight while the current one is reduced
+                    float gk[8], gn[8];
+                    unsigned okc = 0, okn = 0;
+                    int hc = -1, hn = -1;
+#define HM_HEAVY_FETCH(H, G, OK)                                                                                   \
+    {                                                                                                              \
+        const int haxis_ = __builtin_amdgcn_readlane(axis, H), hd0_ = __builtin_amdgcn_readlane(d0r, H);           \
+        OK = 0;                                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                            \
+            const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(wd[k] & 0xffffffffull), H);            \
+            const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(wd[k] >> 32), H);                      \
+            const unsigned long long w_ = ((unsigned long long)hi32 << 32) | lo32;                                 \
+            bool ok_ = (w_ >> lane) & 1ull;                                                                        \
+            const int d1_ = (k << 6) + lane;                                                                       \
+            const int xi_ = haxis_ ? d1_ : hd0_, yi_ = haxis_ ? hd0_ : d1_;                                        \
+            G[k] = ok_ ? sample_grad(gi, S, is, xi_, yi_) : 0.f;                                                   \
+            if (ph == 1 && ok_) ok_ = idx[(long)yi_ * is + xi_] == fn;                                             \
+            OK |= (ok_ ? 1u : 0u) << k;                                                                            \
+        }                                                                                                          \
     }
+                    if (hv) {
+                        hn = __ffsll((long long)hv) - 1;
+                        hv &= hv - 1;
+                        HM_HEAVY_FETCH(hn, gn, okn)
+                    }
+#pragma unroll 1
+                    while (hn >= 0) {
+                        hc = hn;
+                        okc = okn;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) gk[k] = gn[k];
+                        hn = -1;
+                        if (hv) {
+                            hn = __ffsll((long long)hv) - 1;
+                            hv &= hv - 1;
+                            HM_HEAVY_FETCH(hn, gn, okn)
+                        }
+                        const float hcross = rlane(d1_cross, hc), hc0 = rlane(c0, hc), hc1 = rlane(c1, hc);
+                        const bool hu0 = __builtin_amdgcn_readlane((int)use0, hc), hu1 = __builtin_amdgcn_readlane((int)use1, hc);
+                        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if ((okc >> k) & 1u) sweep_term(ph == 0 ? -gk[k] : gk[k], (k << 6) + lane, hcross, hc0, hc1, hu0, hu1, eps, inv_is, pow2, is, a0, a1);
+                        a0 = hm_wave_sum(a0);
+                        a1 = hm_wave_sum(a1);
+                        if (lane == hc) { acc0 += a0; acc1 += a1; }
+                    }
+#undef HM_HEAVY_FETCH
+                }
+                // masked wave reductions: combination k collects the lanes whose item belongs to it
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    if (off[k + 1] <= base || off[k] >= base + 64) continue;     // uniform
+                    tot[2 * k] += hm_wave_sum(ci == k ? acc0 : 0.f);
+                    tot[2 * k + 1] += hm_wave_sum(ci == k ? acc1 : 0.f);
+                }
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) out[k] = tot[k];
+            }
+        }
+        if (dbg) {
+            const float tb = hm_wave_sum((float)dbg_bits), th = hm_wave_sum((float)dbg_heavy);
+            if (lane == 0) {
+                dbg[3 * bf] = tb;
+                dbg[3 * bf + 1] = (float)(wall_clock64() - t_start);
+                dbg[3 * bf + 2] = th;
+            }
+        }
+    }   // face loop
 }
 
 // ---------------------------------------------------------------- backward, pass 3: vertex gather + projection backward
@@ -709,7 +869,10 @@ __global__ void k_bwd_gather(const float* __restrict__ parts, const int* __restr
 }
 
 // ================================================================ C ABI
+static float* g_sweep_dbg = nullptr;   // optional per-wave timing buffer (tools only)
 extern "C" {
+void hm_debug_set_sweep_buffer(float* p) { g_sweep_dbg = p; }
+
 
 // workspace layout helper (bytes), all chunks 256-byte aligned
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -727,9 +890,10 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
     n += al256((size_t)B * S * S * 4);          // dimg
     n += al256((size_t)B * (S / 8) * (S / 8) * 16); // partials
     n += al256((size_t)B * S * S * 4);          // gimg
-    n += al256((size_t)B * is * (is / 16) * 2); // rowneg
-    n += al256((size_t)B * is * (is / 16) * 2); // colneg
+    n += al256((size_t)B * is * (is / 16) * 4); // row masks, 2 planes
+    n += al256((size_t)B * is * (is / 16) * 4); // column masks, 2 planes
     n += al256((size_t)B * F * 24 * 4);         // parts
+    n += al256((size_t)B * F * 2);              // owned
     return n;
 }
 
@@ -737,6 +901,7 @@ struct SilWs {
     unsigned int* counter; float* frame_rec;
     float* ndc; float* faces9; FaceBox* boxes; int* idx_map; unsigned short* alpha16; float* dimg;
     float* partials; float* gimg; unsigned short* rowneg; unsigned short* colneg; float* parts;
+    unsigned char* owned;
 };
 static SilWs carve(void* ws, int B, int V, int F, int S)
 {
@@ -753,9 +918,10 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.dimg = (float*)p; p += al256((size_t)B * S * S * 4);
     w.partials = (float*)p; p += al256((size_t)B * (S / 8) * (S / 8) * 16);
     w.gimg = (float*)p; p += al256((size_t)B * S * S * 4);
-    w.rowneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 2);
-    w.colneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 2);
-    w.parts = (float*)p;
+    w.rowneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4);
+    w.colneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4);
+    w.parts = (float*)p; p += al256((size_t)B * F * 24 * 4);
+    w.owned = (unsigned char*)p;
     return w;
 }
 
@@ -774,11 +940,11 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     const int is = 2 * S, ntiles = (S / 8) * (S / 8);
     hipLaunchKernelGGL(k_project, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, verts, K, B, V, orig_size, w.ndc);
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv((long)B * F, 256)), dim3(256), 0, stream, w.ndc, faces,
-                       faces_bstride, B, V, F, is, w.faces9, w.boxes);
+                       faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned);
     const bool fused = keep && ref && keep_sum && loss_out;
     hipLaunchKernelGGL(k_raster_fwd, dim3(B, ntiles / RASTER_WAVES), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                       fused ? w.partials : (float*)nullptr, region_order);
+                       fused ? w.partials : (float*)nullptr, region_order, w.owned);
     if (fused)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            w.counter, loss_out);
@@ -794,14 +960,14 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
 {
     HM_CHECK_ARG(verts && K && adj_off && adj_items && grad_verts && workspace);
     HM_CHECK_ARG(mode == 0 ? grad_pooled != nullptr : (upstream && keep_sum));
-    if (S % 32 != 0) return HM_ERR_UNSUPPORTED;
+    if (S % 32 != 0 || S > 256) return HM_ERR_UNSUPPORTED;     // sweep keeps a whole mask line (<= 512 bits) in registers
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
     hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                        mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                        w.rowneg, w.colneg);
-    hipLaunchKernelGGL(k_bwd_sweep, dim3(hm_cdiv((long)B * F * 64, 256)), dim3(256), 0, stream, w.faces9, w.boxes,
-                       w.idx_map, w.gimg, w.rowneg, w.colneg, B, F, S, eps, w.parts);
+    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), 2048)), dim3(256), 0, stream, w.faces9, w.boxes,
+                       w.idx_map, w.gimg, w.rowneg, w.colneg, B, F, S, eps, w.parts, g_sweep_dbg, w.owned);
     hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                        adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
     return hm_launch_status();
@@ -825,7 +991,7 @@ int hm_bench_raster_fwd(const float* verts, const int* faces, const float* K, in
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL(k_raster_fwd, dim3(B, ntiles / RASTER_WAVES), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                           w.partials, region_order);
+                           w.partials, region_order, w.owned);
     hipEventRecord(e1, stream);
     hipEventSynchronize(e1);
     float ms = 0.f;

@@ -254,10 +254,9 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(
     const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
     if (threadIdx.x == 0) partials[bid] = val;
-    if (hm_last_block(counter, nblk, &s_flag) && threadIdx.x == 0) {
-        float t = 0.f;
-        for (unsigned q = 0; q < nblk; ++q) t += partials[q];
-        out[0] = t;
+    if (hm_last_block(counter, nblk, &s_flag)) {
+        const float t = hm_last_block_sum(partials, (int)nblk, 1, red);
+        if (threadIdx.x == 0) out[0] = t;
     }
 }
 
