@@ -1,0 +1,157 @@
+/*
+ * homan_amd.h -- C ABI of libhoman_amd.so: the MI355X-native leaves of HOMan's joint-optimisation hot path.
+ *
+ * The reference (hassony2/homan) is pure Python; the native code on its hot path lives in third-party CUDA /
+ * PyTorch extensions (`neural_renderer`, `sdf`, `mano`) bound through pybind torch extensions.  This header is the
+ * drop-in boundary for that native layer: plain C, device pointers + sizes, no torch types.  Each entry point names
+ * the reference call site (file:line under /root/reference) whose arithmetic it carries.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP, gfx950) unless stated otherwise; tensors are dense, row-major, fp32 /
+ *     int32; the caller owns every buffer (outputs and workspaces), the library allocates nothing;
+ *   - all work is enqueued on `stream` and is asynchronous w.r.t. the host (capturable in a hipGraph), except
+ *     hm_bench_raster_fwd and the hm_debug_* helpers;
+ *   - return value: HM_OK (0) or a negative error code; nothing throws across the ABI;
+ *   - re-entrant per (workspace, stream): no global state besides the optional debug hook;
+ *   - workspaces that hold a reduction ticket (hm_reduce_workspace_bytes, hm_sil_workspace_bytes,
+ *     hm_collision_workspace_bytes) must be zero-filled ONCE before first use; the ticket resets itself.
+ *
+ * `hipStream_t` is declared as an opaque pointer so that the header is usable from plain C hosts (ctypes, cgo...).
+ */
+#ifndef HOMAN_AMD_H
+#define HOMAN_AMD_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef HIP_INCLUDE_HIP_HIP_RUNTIME_API_H
+typedef struct ihipStream_t* hipStream_t;
+#endif
+
+#define HM_OK 0
+#define HM_ERR_BAD_ARG (-1)
+#define HM_ERR_LAUNCH (-2)
+#define HM_ERR_UNSUPPORTED (-3)
+
+/* ------------------------------------------------------------------ rigid transforms
+ * reference homan/utils/geometry.py:9-27 (rot6d_to_matrix) + homan/utils/camera.py:108-139
+ * (compute_transformation_persp), called from homan/homan.py:298-307 (object) and :341-382 (hand).
+ *   verts[n,v,:] = (s * mesh[n,v,:]) @ R(rot6d[n]) + trans[n]      s = |scale[0]| if abs_scale else scale[0]
+ * mesh (N,V,3), rot6d (N,3,2), trans (N,3), scale (1), rotmat (N,3,3) optional output, verts (N,V,3). */
+int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, const float* scale, int abs_scale, int N,
+                 int V, float* rotmat, float* verts, hipStream_t stream);
+/* g_full: d/dverts reaching mesh, scale, R, t; g_rigid: d/d(mesh-detached twin) reaching R, t only (either may be
+ * NULL).  Outputs: g_mesh (N,V,3) optional, g_rot6d (N,3,2), g_trans (N,3), g_scale_part (N) optional (sum = d/dscale). */
+int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* g_full,
+                 const float* g_rigid, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans,
+                 float* g_scale_part, hipStream_t stream);
+/* out = s[0] * in ;  out = s0[0]*a + s1[0]*b   (backward of the losses whose unit gradient is produced forward) */
+int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream);
+int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s1, long n, float* out,
+                 hipStream_t stream);
+
+/* ------------------------------------------------------------------ MANO linear blend skinning
+ * reference homan/manomodel.py:84-151 (ManoModel.forward_pca, right hand) + the `mano` layer it calls
+ * (manomodel.py:119-123) + "+ mano_trans" of homan/homan.py:356.
+ * model: host array of 8 device pointers {v_template (778,3), M (145,2334) = [posedirs ; shapedirs^T],
+ *   J_template (16,3), J_shapedirs (16,3,10), lbs_weights (778,16), pca components (16,45), hand_mean (45),
+ *   parents (16) int32}.   pca (B,pca_dim>=16; the first 16 columns drive the mesh), rot (B,3), betas (B,10),
+ *   trans (B,3) or NULL.  verts (B,778,3); joints (B,16,3) optional. */
+int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
+                const float* trans, int B, float* verts, float* joints, hipStream_t stream);
+size_t hm_mano_workspace_bytes(int B);
+int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
+                const float* g_verts, float* g_pca, float* g_rot, float* g_betas, float* g_trans, void* workspace,
+                hipStream_t stream);
+
+/* ------------------------------------------------------------------ silhouette rasteriser + fused masked-MSE / IoU
+ * reference homan/losses.py:183-197 (compute_sil_loss_object) and the `neural_renderer` call inside it
+ * (losses.py:187; renderer built at losses.py:73-77): projection with the ROI intrinsics K (orig_size), fill_back,
+ * hard z-buffer raster at 2S x 2S samples, vertical flip, 2x2 average pool, NMR edge-sweep pseudo-gradient.
+ *   verts (B,V,3) camera space; faces (F,3) int32 shared by all frames (faces_bstride = 0) or (B,F,3) (= 3F);
+ *   K (B,3,3); pooled (B,S,S) silhouettes out.
+ *   Fused loss (all four non-NULL): keep/ref (B,S,S), keep_sum (1) = sum(keep);
+ *     loss_out[0] = sum((keep*sil - ref)^2) / keep_sum / B ; loss_out[1] = mean_b IoU_b   (losses.py:188-196).
+ *   region_order: (S/16)^2 int16 permutation of the 32x32-sample regions giving the dispatch order, or NULL.
+ *   S must be a multiple of 32, S <= 256 for the backward. */
+size_t hm_sil_workspace_bytes(int B, int V, int F, int S);
+int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
+               float orig_size, float znear, float zfar, const float* keep, const float* ref,
+               const float* keep_sum, float* pooled, float* loss_out, const short* region_order, void* workspace,
+               hipStream_t stream);
+/* mode 1: upstream (1) = dL/d loss_out[0]; mode 0: grad_pooled (B,S,S) = dL/d pooled.  adj_off (V+1), adj_items (3F):
+ * CSR vertex -> (face*3 + corner).  grad_verts (B,V,3) overwritten; grad_ndc (B,V,3) optional (d/d projected u,v). */
+int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
+               const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
+               const int* adj_items, float* grad_verts, float* grad_ndc, void* workspace, hipStream_t stream);
+/* forward intermediates kept in the workspace (tests): face-index map (B,2S,2S) int32, packed NDC faces (B,F,9) */
+int hm_sil_read_idx_map(const void* workspace, int B, int V, int F, int S, int* out, hipStream_t stream);
+int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
+
+/* ------------------------------------------------------------------ small losses (value + unit gradient in one launch)
+ * workspace for all of them: hm_reduce_workspace_bytes(), zero-filled once. */
+size_t hm_reduce_workspace_bytes(void);
+/* reference homan/losses.py:141-164: out2[0] = mean sum_xy (proj - ref/image_size)^2, out2[1] = mean px distance */
+int hm_v2d_fwd(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size, int N,
+               int V, float* unit_grad, float* out2, void* workspace, hipStream_t stream);
+/* reference homan/lossutils.py:18-36: temporal smoothness of verts (N,V,3), frames interleaved by hand_nb */
+int hm_smooth_fwd(const float* verts, int N, int V, int hand_nb, float* unit_grad, float* out1, void* workspace,
+                  hipStream_t stream);
+/* reference homan/lossutils.py:39-40 and :107-109: out3 = {mean(pca^2), (s_obj-m_obj)^2, (s_hand-m_hand)^2} */
+int hm_priors_fwd(const float* pca, long npca, const float* s_obj, const float* m_obj, const float* s_hand,
+                  const float* m_hand, float* g_pca, float* g_sobj, float* g_shand, float* out3, hipStream_t stream);
+/* reference homan/losses.py:199-242 ('centroid') with the gating of :98-139 (project_bbox :20-49, compute_iou
+ * utils/bbox.py:111-135, compute_dist_z utils/geometry.py:69-86).  out1 = un-normalised sum; frame_rec (B,8). */
+int hm_inter_fwd(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
+                 float expansion, float zthresh, float* frame_rec, float* out1, void* workspace, hipStream_t stream);
+int hm_inter_bwd(const float* frame_rec, const float* upstream, int B, int Vh, int Vo, float* g_hand, float* g_obj,
+                 hipStream_t stream);
+
+/* ------------------------------------------------------------------ contact (Chamfer direction hand -> object)
+ * reference homan/interactions/contactloss.py:60-79,162-163 (pairwise distances, arg-min over the object) and the
+ * metric of homan/losses.py:225-241: metric_out[0] = max_b sqrt(min_ij |h_i - o_j|^2). */
+int hm_nn_fwd(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
+              float* metric_out, void* workspace, hipStream_t stream);
+/* reference homan/lossutils.py:112-130 -> contactloss.py:149-309 as executed: out1 = mean thresh*tanh(|nn-h|/thresh) */
+int hm_contact_fwd(const float* verts_hand, const float* verts_obj, const int* nn_idx, int B, int Vh, int Vo,
+                   float thresh, float* g_hand, float* g_obj, float* out1, void* workspace, hipStream_t stream);
+
+/* ------------------------------------------------------------------ SDF interpenetration
+ * reference homan/lossutils.py:43-64 -> homan/interactions/scenesdf.py:77-148 and the `sdf` package (scenesdf.py:119).
+ * Scene = {0: hand (closed faces), 1: object}.  out1[0] = sum of grid_sample(clamp(SDF_k,0), verts_l) over both
+ * ordered pairs and all frames; g0 / g1 = d out / d verts0 / d verts1. */
+size_t hm_collision_workspace_bytes(int B, int V0, int V1);
+int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, const float* verts1, const int* faces1,
+                     int V1, int F1, int B, float scale_factor, float* g0, float* g1, float* out1, void* workspace,
+                     hipStream_t stream);
+/* clamp(SDF,0) on the full 32^3 grid of mesh `which`, from the workspace of the last hm_collision_fwd */
+int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int V0, int V1, float* phi,
+                           void* workspace, hipStream_t stream);
+
+/* ------------------------------------------------------------------ optimiser step + logging
+ * reference homan/jointopt.py:138-151,192 (torch.optim.Adam, three groups) and :184-189 (loss_evolution).
+ * slots: n_tensors records {float* p, g, m, v; long n; float lr; int pad} (hm_adam_slot_bytes() each);
+ * step: device int32 counter (incremented); zero_grad != 0 clears g after the update. */
+size_t hm_adam_slot_bytes(void);
+int hm_adam_step(const void* slots, int n_tensors, int* step, float beta1, float beta2, float eps, int zero_grad,
+                 int blocks_per_tensor, hipStream_t stream);
+/* log[step[0]*n + i] = src[i] */
+int hm_log_scalars(const float* src, int n, const int* step, int max_steps, float* log, hipStream_t stream);
+
+/* ------------------------------------------------------------------ measurement / debug hooks (synchronous)
+ * hm_bench_raster_fwd: runs the forward set-up once, then `reps` launches of the raster kernel between two HIP
+ * events on `stream`; *avg_ms (HOST pointer) receives the average launch duration in milliseconds. */
+int hm_bench_raster_fwd(const float* verts, const int* faces, const float* K, int B, int V, int F, int S,
+                        const float* keep, const float* ref, const float* keep_sum, float* pooled, float* loss_out,
+                        const short* region_order, void* workspace, int reps, float* avg_ms, hipStream_t stream);
+int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks);
+int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
+void hm_debug_set_sweep_buffer(float* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOMAN_AMD_H */
