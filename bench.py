@@ -82,6 +82,8 @@ def main():
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--step2", action="store_true", help="cfg3: add lw_collision / lw_contact")
+    ap.add_argument("--loop", choices=["fused", "graph"], default="fused",
+                    help="fused: fixed C-ABI launch sequence (no autograd tape); graph: HOMan.forward + autograd")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -93,7 +95,7 @@ def main():
     import torch
     import torch.distributed as dist
     from homan_amd import synth
-    from homan_amd.jointopt import GraphStepper, build_model
+    from homan_amd.jointopt import FusedStepper, GraphStepper, build_model
     from homan_amd.mano_assets import synthetic_mano
 
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
@@ -112,7 +114,7 @@ def main():
                         optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
                         sync_metrics=False)
     total_steps = args.warmup + args.steps
-    stepper = GraphStepper(model, lw, 1e-2, total_steps)
+    stepper = (GraphStepper if args.loop == "graph" else FusedStepper)(model, lw, 1e-2, total_steps)
     stepper.run(args.warmup)
 
     def barrier():
@@ -173,7 +175,7 @@ def main():
                        f": 1 clip/GPU x {B} frames {S}x{S}, synthetic MANO hand + lathe bottle ({F} faces, {V} verts), "
                        + ("step-2" if args.step2 else "step-1") + " loss set, Adam step + loss logging in the timed region",
                        "frames": B, "rend_size": S, "faces": int(F), "clips_per_gpu": 1,
-                       "loop": "hipGraph replay of forward+backward+Adam", "parallelism": f"{world} independent clips"},
+                       "loop": ("fused C-ABI launch sequence" if args.loop == "fused" else "HOMan.forward + autograd") + ", forward+backward+Adam+logging replayed from a hipGraph", "parallelism": f"{world} independent clips"},
             "final_loss": evo["loss"][-1], "first_loss": evo["loss"][0],
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -170,7 +170,45 @@ __global__ void k_scale2_by(const float* __restrict__ a, const float* __restrict
     if (i < n) out[i] = s0[0] * a[i] + s1[0] * b[i];
 }
 
+// out[i] = w0*a0[i] + w1*a1[i] + w2*a2[i] + w3*a3[i]   (NULL terms are skipped; weights are host constants)
+__global__ void k_lincomb4(const float* __restrict__ a0, float w0, const float* __restrict__ a1, float w1,
+                           const float* __restrict__ a2, float w2, const float* __restrict__ a3, float w3, long n,
+                           float* __restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    if (a0) v += w0 * a0[i];
+    if (a1) v += w1 * a1[i];
+    if (a2) v += w2 * a2[i];
+    if (a3) v += w3 * a3[i];
+    out[i] = v;
+}
+// out[0] = w0 * sum(parts[0..n)) + w1 * extra[0]      (scale gradients: per-frame partials + prior term)
+__global__ void k_sum_small(const float* __restrict__ parts, int n, float w0, const float* __restrict__ extra, float w1,
+                            float* __restrict__ out)
+{
+    __shared__ float red[16];
+    float a = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a += parts[i];
+    a = hm_block_sum(a, red);
+    if (threadIdx.x == 0) out[0] = w0 * a + (extra ? w1 * extra[0] : 0.f);
+}
+
 extern "C" {
+int hm_lincomb4(const float* a0, float w0, const float* a1, float w1, const float* a2, float w2, const float* a3,
+                float w3, long n, float* out, hipStream_t stream)
+{
+    HM_CHECK_ARG(out && n > 0);
+    hipLaunchKernelGGL(k_lincomb4, dim3(hm_cdiv(n, 256)), dim3(256), 0, stream, a0, w0, a1, w1, a2, w2, a3, w3, n, out);
+    return hm_launch_status();
+}
+int hm_sum_small(const float* parts, int n, float w0, const float* extra, float w1, float* out, hipStream_t stream)
+{
+    HM_CHECK_ARG(parts && out && n > 0);
+    hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, stream, parts, n, w0, extra, w1, out);
+    return hm_launch_status();
+}
 int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, const float* scale, int abs_scale, int N,
                  int V, float* rotmat, float* verts, hipStream_t stream)
 {

@@ -6,6 +6,8 @@ Visualisation / video export (reference :159-177,193-200) is not part of the hot
 Two execution modes:
   mode="eager"  the reference's loop verbatim: torch.optim.Adam over the three name-selected groups, per-key
                 `.item()` logging every step (host-synchronous, like the reference).
+  mode="fused"  the iteration as a fixed sequence of C-ABI kernel launches without the autograd tape (FusedStepper),
+                captured in a hipGraph: ~27 launches instead of ~90.  The benchmark path.
   mode="graph"  the same iteration (zero-grad, forward, weighting, backward, Adam with the same arithmetic, logging)
                 captured once into a hipGraph and replayed; losses / metrics are written to a device log by a kernel
                 and read back once at the end (no host sync inside the loop).
@@ -91,12 +93,12 @@ class HmAdam:
         self.grads = [p.grad for p, _ in self.items]       # keep the static buffers alive
         self.blocks = max(1, min(8, (max(p.numel() for p, _ in self.items) + 255) // 256))
 
-    def step(self):
+    def step(self, zero_grad=True):
         for (p, _), g in zip(self.items, self.grads):
             assert p.grad is g, "gradient buffers must stay static (do not call zero_grad(set_to_none=True))"
         _lib.check(_lib.lib().hm_adam_step(_lib.ptr(self.slots), len(self.items), _lib.ptr(self.step_t),
-                                           self.betas[0], self.betas[1], self.eps, 1, self.blocks, _lib.stream()),
-                   "hm_adam_step")
+                                           self.betas[0], self.betas[1], self.eps, int(zero_grad), self.blocks,
+                                           _lib.stream()), "hm_adam_step")
 
 
 class _DeviceLog:
@@ -184,6 +186,202 @@ class GraphStepper:
         return {k: host[:, i].astype(np.float64).tolist() for i, k in enumerate(self.log.keys)}
 
 
+class FusedStepper:
+    """The whole optimisation iteration as a fixed sequence of C-ABI kernel launches (no autograd tape, no torch
+    arithmetic kernels), captured in a hipGraph:
+
+        forward   rigid(obj) . mano . rigid(hand) . priors . smooth x2 . [collision] . [nn] . [contact] . v2d .
+                  silhouettes(project, setup, raster, reduce) . inter . log(total + loss_evolution row)
+        backward  sil(masks, sweeps, gather) . inter . weighted sums of the per-loss vertex gradients .
+                  rigid_bwd(obj) . rigid_bwd(hand) . mano_bwd . prior terms . Adam
+
+    Same kernels, same detach structure and same weighting as HOMan.forward + autograd (reference homan/homan.py:421-508,
+    jointopt.py:178-192); tests/test_model_gpu.py checks the two paths produce the same gradients.  Supports the
+    configurations of BASELINE.json (one right hand, optimize_mano=True, optimize_mano_beta=True, persp); anything
+    else should use mode="graph"."""
+
+    SLOTS = ["loss_pca", "loss_scale_obj", "loss_scale_hand", "loss_smooth_obj", "loss_smooth_hand", "loss_collision",
+             "loss_contact", "loss_v2d_hand", "v2d_hand", "loss_sil_obj", "iou_object", "loss_inter",
+             "handobj_maxdist"]
+
+    def __init__(self, model, loss_weights, lr, max_steps, capture=True):
+        from . import constants, ops
+        m = self.model = model
+        if not (m.optimize_mano and not m.int_scales_hand.requires_grad and m.hand_proj_mode == "persp"):
+            raise NotImplementedError("FusedStepper covers optimize_mano=True, optimize_mano_beta=True, persp")
+        lw = self.lw = {k: float(v) for k, v in loss_weights.items()}
+        if lw.get("lw_depth", 0) > 0:
+            raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
+                            "'masks', 'silhouettes', and 'depths'")
+        self.L, self.c, self.ops = _lib.lib(), constants, ops
+        dev = m.translations_object.device
+        B, Vo, Vh = m.verts_object_og.shape[0], m.verts_object_og.shape[1], 778
+        self.B, self.Vo, self.Vh, self.P = B, Vo, Vh, m.mano_pca_pose.shape[1]
+        f = lambda *shape: torch.zeros(*shape, device=dev)
+        self.vo, self.vm, self.vh = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
+        self.vals = f(len(self.SLOTS) + 1)
+        on = lambda k: lw.get(k, 0.0) > 0
+        self.on = dict(pca=on("lw_pca"), so=on("lw_scale_obj"), sh=on("lw_scale_hand"),
+                       smooth=on("lw_smooth_hand") or on("lw_smooth_obj"), col=on("lw_collision"),
+                       con=on("lw_contact"), v2d=on("lw_v2d_hand"), sil=on("lw_sil_obj"), inter=on("lw_inter"))
+        w = {"loss_pca": lw["lw_pca"] if self.on["pca"] else 0, "loss_scale_obj": lw["lw_scale_obj"] if self.on["so"] else 0,
+             "loss_scale_hand": lw["lw_scale_hand"] if self.on["sh"] else 0,
+             "loss_smooth_obj": lw["lw_smooth_obj"] if self.on["smooth"] else 0,
+             "loss_smooth_hand": lw["lw_smooth_hand"] if self.on["smooth"] else 0,
+             "loss_collision": lw["lw_collision"] if self.on["col"] else 0,
+             "loss_contact": lw["lw_contact"] if self.on["con"] else 0,
+             "loss_v2d_hand": lw["lw_v2d_hand"] if self.on["v2d"] else 0,
+             "loss_sil_obj": lw["lw_sil_obj"] if self.on["sil"] else 0,
+             "loss_inter": lw["lw_inter"] if self.on["inter"] else 0}
+        self.w = w
+        self.weights = torch.tensor([w.get(k, 0.0) for k in self.SLOTS], device=dev)
+        self.keys = [k for k in self.SLOTS if self._reported(k)]
+        # unit gradients / scratch
+        self.U_pca, self.U_so, self.U_sh = f(B, self.P), f(1), f(1)
+        self.U_smo, self.U_smh, self.U_v2d = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
+        self.U_colh, self.U_colo, self.U_conh, self.U_cono = f(B, Vh, 3), f(B, Vo, 3), f(B, Vh, 3), f(B, Vo, 3)
+        self.G_sil, self.G_int_h, self.G_int_o = f(B, Vo, 3), f(B, Vh, 3), f(B, Vo, 3)
+        self.G_o, self.G_h, self.G_mesh = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
+        self.g_pca_mano, self.g_so_part = f(B, self.P), f(B)
+        self.rec = f(B, 8)
+        self.nn_idx = torch.zeros(B, Vh, dtype=torch.int32, device=dev)
+        self.nn_d2 = f(B, Vh)
+        self.pooled = f(B, m.losses.sil_ctx.S, m.losses.sil_ctx.S)
+        self.up_sil, self.up_inter = torch.tensor([w["loss_sil_obj"]], device=dev), torch.tensor([w["loss_inter"]], device=dev)
+        # static gradient buffers for exactly the parameters that receive gradients in this configuration
+        for p in m.parameters():
+            p.grad = None
+        gp = [m.translations_object, m.rotations_object, m.translations_hand, m.rotations_hand, m.mano_pca_pose,
+              m.mano_rot, m.mano_trans, m.mano_betas]
+        if m.optimize_object_scale:
+            gp.append(m.int_scales_object)
+        for p in gp:
+            p.grad = torch.zeros_like(p)
+        self.opt = HmAdam(parameter_groups(m, lr))
+        self.log_buf = torch.zeros(max_steps, len(self.SLOTS) + 1, device=dev)
+        self.max_steps = max_steps
+        self.mctx = m.mano_model.ctx_mean
+        self.graph = None
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.forward_backward()              # warm-up, no optimiser step
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if capture:
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.forward_backward(log=True)
+                self.opt.step(zero_grad=False)
+
+    def _reported(self, k):
+        o = self.on
+        return {"loss_pca": o["pca"], "loss_scale_obj": o["so"], "loss_scale_hand": o["sh"], "loss_smooth_obj": o["smooth"],
+                "loss_smooth_hand": o["smooth"], "loss_collision": o["col"], "loss_contact": o["con"],
+                "loss_v2d_hand": o["v2d"], "v2d_hand": o["v2d"], "loss_sil_obj": o["sil"], "iou_object": o["sil"],
+                "loss_inter": o["inter"], "handobj_maxdist": o["inter"]}[k]
+
+    def _slot(self, name):
+        i = self.SLOTS.index(name)
+        return self.vals.data_ptr() + 4 * i
+
+    def forward_backward(self, log=False):
+        m, L, P, st, ck = self.model, self.L, _lib.ptr, _lib.stream(), _lib.check
+        B, Vo, Vh, c, on, w = self.B, self.Vo, self.Vh, self.c, self.on, self.w
+        rws = P(m.reduce_ws.buf)
+        sctx, cctx = m.losses.sil_ctx, m.collision_ctx
+        pca, rot, betas, mtr = m.mano_pca_pose, m.mano_rot, m.mano_betas, m.mano_trans
+        # ---------------- forward
+        ck(L.hm_rigid_fwd(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object), P(m.int_scales_object),
+                          1, B, Vo, None, P(self.vo), st), "rigid_fwd(obj)")
+        ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None, st), "mano_fwd")
+        ck(L.hm_rigid_fwd(P(self.vm), P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), 0, B, Vh, None,
+                          P(self.vh), st), "rigid_fwd(hand)")
+        if on["pca"] or on["so"] or on["sh"]:
+            ck(L.hm_priors_fwd(P(pca), pca.numel(), P(m.int_scales_object), P(m.int_scale_object_mean),
+                               P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh),
+                               self._slot("loss_pca"), st), "priors")
+        if on["smooth"]:
+            ck(L.hm_smooth_fwd(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws, st), "smooth(obj)")
+            ck(L.hm_smooth_fwd(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws, st), "smooth(hand)")
+        if on["col"]:
+            ck(L.hm_collision_fwd(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
+                                  cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
+                                  self._slot("loss_collision"), P(cctx.ws), st), "collision")
+        if on["con"] or on["inter"]:
+            ck(L.hm_nn_fwd(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx), P(self.nn_d2),
+                           self._slot("handobj_maxdist"), rws, st), "nn")
+        if on["con"]:
+            ck(L.hm_contact_fwd(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH, P(self.U_conh),
+                                P(self.U_cono), self._slot("loss_contact"), rws, st), "contact")
+        if on["v2d"]:
+            ck(L.hm_v2d_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
+                            P(self.U_v2d), self._slot("loss_v2d_hand"), rws, st), "v2d")
+        if on["sil"]:
+            ck(L.hm_sil_fwd(P(self.vo), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
+                            self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
+                            P(m.losses.keep_sum), P(self.pooled), self._slot("loss_sil_obj"), P(sctx.region_order),
+                            P(sctx.workspace), st), "sil_fwd")
+        if on["inter"]:
+            ck(L.hm_inter_fwd(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
+                              float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws, st), "inter")
+        if log:
+            ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
+                              P(self.log_buf), st), "log")
+        # ---------------- backward
+        if on["sil"]:
+            ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS, 1,
+                            P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
+                            P(self.G_sil), None, P(sctx.workspace), st), "sil_bwd")
+        if on["inter"]:
+            ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, P(self.G_int_h),
+                              P(self.G_int_o) if m.optimize_object_scale else None, st), "inter_bwd")
+        # object: smooth + contact + silhouette (+ interaction when the scale is optimised, homan.py:484-487)
+        ck(L.hm_lincomb4(P(self.U_smo) if on["smooth"] else None, w["loss_smooth_obj"],
+                         P(self.U_cono) if on["con"] else None, w["loss_contact"],
+                         P(self.G_sil) if on["sil"] else None, 1.0,
+                         P(self.G_int_o) if (on["inter"] and m.optimize_object_scale) else None, 1.0,
+                         B * Vo * 3, P(self.G_o), st), "lincomb(obj)")
+        # hand (full path: MANO + rigid): smooth + v2d + collision + contact ; interaction reaches the rigid pose only
+        ck(L.hm_lincomb4(P(self.U_smh) if on["smooth"] else None, w["loss_smooth_hand"],
+                         P(self.U_v2d) if on["v2d"] else None, w["loss_v2d_hand"],
+                         P(self.U_colh) if on["col"] else None, w["loss_collision"],
+                         P(self.U_conh) if on["con"] else None, w["loss_contact"],
+                         B * Vh * 3, P(self.G_h), st), "lincomb(hand)")
+        sc_obj = m.optimize_object_scale
+        ck(L.hm_rigid_bwd(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, P(self.G_o), None, B,
+                          Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
+                          P(self.g_so_part) if sc_obj else None, st), "rigid_bwd(obj)")
+        ck(L.hm_rigid_bwd(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, P(self.G_h),
+                          P(self.G_int_h) if on["inter"] else None, B, Vh, P(self.G_mesh), P(m.rotations_hand.grad),
+                          P(m.translations_hand.grad), None, st), "rigid_bwd(hand)")
+        ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
+                         P(self.g_pca_mano) if on["pca"] else P(pca.grad), P(rot.grad), P(betas.grad), P(mtr.grad),
+                         P(self.mctx.workspace(B)), st), "mano_bwd")
+        if on["pca"]:
+            ck(L.hm_lincomb4(P(self.g_pca_mano), 1.0, P(self.U_pca), w["loss_pca"], None, 0.0, None, 0.0, pca.numel(),
+                             P(pca.grad), st), "lincomb(pca)")
+        if sc_obj:
+            ck(L.hm_sum_small(P(self.g_so_part), B, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
+                              P(m.int_scales_object.grad), st), "scale grad")
+
+    def run(self, steps):
+        if self.graph is not None:
+            for _ in range(steps):
+                self.graph.replay()
+        else:
+            for _ in range(steps):
+                self.forward_backward(log=True)
+                self.opt.step(zero_grad=False)
+
+    def loss_evolution(self, steps):
+        torch.cuda.synchronize()
+        host = self.log_buf[:steps].cpu().numpy()
+        out = {k: host[:, self.SLOTS.index(k)].astype(np.float64).tolist() for k in self.keys}
+        out["loss"] = host[:, len(self.SLOTS)].astype(np.float64).tolist()
+        return out
+
+
 def optimize_hand_object(person_parameters, object_parameters, class_name="default", objvertices=None, objfaces=None,
                          loss_weights=None, num_iterations=400, lr=1e-2, images=None, viz_step=10, viz_folder="tmp",
                          camintr=None, hand_proj_mode="persp", optimize_mano=False, optimize_mano_beta=True,
@@ -193,12 +391,13 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
     model = build_model(person_parameters, object_parameters, class_name, objvertices, objfaces, camintr,
                         hand_proj_mode, optimize_mano, optimize_mano_beta, optimize_object_scale, state_dict,
                         image_size, mano_model, rend_size, sync_metrics=(mode == "eager"))
-    if mode == "graph":
-        stepper = GraphStepper(model, loss_weights, lr, num_iterations)
+    if mode in ("graph", "fused"):
+        cls = GraphStepper if mode == "graph" else FusedStepper
+        stepper = cls(model, loss_weights, lr, num_iterations)
         stepper.run(num_iterations)
         return model, stepper.loss_evolution(num_iterations), OrderedDict()
     if mode != "eager":
-        raise ValueError(f"mode {mode} not in [eager|graph]")
+        raise ValueError(f"mode {mode} not in [eager|graph|fused]")
     optimizer = torch.optim.Adam(parameter_groups(model, lr))
     loss_evolution = defaultdict(list)
     for _ in range(num_iterations):

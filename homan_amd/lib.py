@@ -28,6 +28,9 @@ _SIGNATURES = {
     "hm_rigid_bwd": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_scale_by": (_I, [_VP, _VP, _L, _VP, _VP]),
     "hm_scale2_by": (_I, [_VP, _VP, _VP, _VP, _L, _VP, _VP]),
+    "hm_lincomb4": (_I, [_VP, _F, _VP, _F, _VP, _F, _VP, _F, _L, _VP, _VP]),
+    "hm_sum_small": (_I, [_VP, _I, _F, _VP, _F, _VP, _VP]),
+    "hm_log_total": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP]),
     "hm_mano_fwd": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "hm_mano_workspace_bytes": (_SZ, [_I]),
     "hm_mano_bwd": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

@@ -52,6 +52,12 @@ int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int 
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream);
 int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s1, long n, float* out,
                  hipStream_t stream);
+/* out = w0*a0 + w1*a1 + w2*a2 + w3*a3 (NULL terms skipped): the weighted sum of per-loss vertex gradients, i.e. the
+ * `loss = sum_k lw_k * loss_k` weighting of reference homan/jointopt.py:180-188 applied to gradients. */
+int hm_lincomb4(const float* a0, float w0, const float* a1, float w1, const float* a2, float w2, const float* a3,
+                float w3, long n, float* out, hipStream_t stream);
+/* out[0] = w0 * sum(parts[0..n)) + w1 * extra[0]  (extra may be NULL) */
+int hm_sum_small(const float* parts, int n, float w0, const float* extra, float w1, float* out, hipStream_t stream);
 
 /* ------------------------------------------------------------------ MANO linear blend skinning
  * reference homan/manomodel.py:84-151 (ManoModel.forward_pca, right hand) + the `mano` layer it calls
@@ -138,6 +144,9 @@ int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int
 size_t hm_adam_slot_bytes(void);
 int hm_adam_step(const void* slots, int n_tensors, int* step, float beta1, float beta2, float eps, int zero_grad,
                  int blocks_per_tensor, hipStream_t stream);
+/* vals[n] = sum_i weights[i]*vals[i] (the weighted total of jointopt.py:180-188), then log row step[0] = vals[0..n] */
+int hm_log_total(float* vals, const float* weights, int n, const int* step, int max_steps, float* log,
+                 hipStream_t stream);
 /* log[step[0]*n + i] = src[i] */
 int hm_log_scalars(const float* src, int n, const int* step, int max_steps, float* log, hipStream_t stream);
 

@@ -107,3 +107,51 @@ def test_hip_vs_oracle_cfg_sized_clip(mano_model):
     dv = (hm.get_verts_hand()[0].detach().cpu() - om.get_verts_hand()[0].detach()).abs().max().item()
     do = (hm.get_verts_object()[0].detach().cpu() - om.get_verts_object()[0].detach()).abs().max().item()
     assert dv < 1e-6 and do < 1e-6, (dv, do)     # metres
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_fused_step_equals_autograd_path(name, mano_model):
+    """FusedStepper (no autograd tape) vs HOMan.forward + autograd: same losses, same parameter gradients."""
+    from homan_amd.jointopt import FusedStepper
+    rec, model, weights, meta = _build_hip(name, mano_model, sync=False)
+    if not meta["optimize_mano"]:
+        with pytest.raises(NotImplementedError):
+            FusedStepper(model, weights, meta["lr"], 4, capture=False)
+        return
+    loss_dict, metric_dict = model(loss_weights=weights)
+    total = sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict)
+    total.sum().backward()
+    ref_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    ref_losses = {k: float(v.detach().reshape(-1)[0]) for k, v in loss_dict.items()}
+    ref_losses.update({k: float(v) for k, v in metric_dict.items()})
+    ref_losses["loss"] = float(total.detach().reshape(-1)[0])
+    st = FusedStepper(model, weights, meta["lr"], 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    evo = {k: st.log_buf[0, st.SLOTS.index(k)].item() for k in st.keys}
+    evo["loss"] = st.log_buf[0, len(st.SLOTS)].item()
+    assert sorted(evo) == sorted(ref_losses)
+    for k, v in ref_losses.items():
+        np.testing.assert_allclose(evo[k], v, rtol=2e-6, atol=1e-9, err_msg=k)
+    for k, p in model.named_parameters():
+        if k in ref_grads:
+            scale = max(ref_grads[k].abs().max().item(), 1e-20)
+            err = ((p.grad - ref_grads[k]).abs().max() / scale).item()
+            assert err < 2e-5, (k, err)
+        else:
+            assert p.grad is None or k in ("cams_hand",), k
+
+
+def test_fused_trajectory_matches_reference_loop(mano_model):
+    from homan_amd.jointopt import FusedStepper
+    rec, model, weights, meta = _build_hip("ref_step2_cube_b4_s64", mano_model, sync=False)
+    st = FusedStepper(model, weights, meta["lr"], 6)
+    st.run(6)
+    evo = st.loss_evolution(6)
+    ref = rec["evo_loss"][:6]
+    np.testing.assert_allclose(evo["loss"][0], ref[0], rtol=1e-4)
+    np.testing.assert_allclose(evo["loss"][:3], ref[:3], rtol=5e-3)
+    np.testing.assert_allclose(evo["loss"], ref, rtol=0.1)
+    for k in ("loss_sil_obj", "loss_contact", "loss_collision", "iou_object"):
+        np.testing.assert_allclose(evo[k][0], rec["evo_" + k][0], rtol=2e-4, atol=1e-9, err_msg=k)
+    np.testing.assert_array_equal(model.mano_rot.detach().cpu().numpy(), rec["in_mano_rot"])
