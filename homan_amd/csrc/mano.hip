@@ -18,6 +18,7 @@
 #define MANO_CHUNK 256
 #define MANO_NCHUNK 4  // ceil(778/256)
 #define MANO_PART 340  // per-(frame,chunk) partials: 192 dA + 145 dfeat + 3 dtrans
+#define MANO_NCH64 13  // ceil(778/64) vertex chunks of 64
 
 struct ManoModelDev {
     const float* v_template;   // (778,3)
@@ -125,16 +126,27 @@ __device__ __forceinline__ void mano_prepare(const ManoModelDev& m, const float*
         }
     }
     __syncthreads();
-    if (t == 0) {
-        for (int j = 0; j < MANO_J; ++j) {
-            const int p = m.parents[j];
+    // kinematic chain, level by level (joint t waits until its parent's level is done; MANO depth is 3)
+    int depth = 0, par = -1, maxd = 0;
+    if (t < MANO_J) {
+        par = m.parents[t];
+        for (int q = par; q >= 0; q = m.parents[q]) ++depth;
+    }
+    for (int j = 0; j < MANO_J; ++j) {     // depth of the tree, computed identically by every thread
+        int d = 0;
+        for (int q = m.parents[j]; q >= 0; q = m.parents[q]) ++d;
+        maxd = max(maxd, d);
+    }
+    for (int level = 0; level < MANO_J; ++level) {
+        if (t < MANO_J && depth == level) {
+            const int j = t, p = par;
             if (p < 0) {
 #pragma unroll
                 for (int k = 0; k < 9; ++k) sh.Rw[j][k] = sh.Rl[j][k];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) sh.tw[j][c] = sh.J[j][c];
             } else {
-                float rel[3] = {sh.J[j][0] - sh.J[p][0], sh.J[j][1] - sh.J[p][1], sh.J[j][2] - sh.J[p][2]};
+                const float rel[3] = {sh.J[j][0] - sh.J[p][0], sh.J[j][1] - sh.J[p][1], sh.J[j][2] - sh.J[p][2]};
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -146,94 +158,130 @@ __device__ __forceinline__ void mano_prepare(const ManoModelDev& m, const float*
                 }
             }
         }
-        for (int j = 0; j < MANO_J; ++j)
+        __syncthreads();
+        if (level >= maxd) break;          // block-uniform
+    }
+    if (t < MANO_J) {
+        const int j = t;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                sh.A[j][4 * i] = sh.Rw[j][3 * i];
-                sh.A[j][4 * i + 1] = sh.Rw[j][3 * i + 1];
-                sh.A[j][4 * i + 2] = sh.Rw[j][3 * i + 2];
-                sh.A[j][4 * i + 3] = sh.tw[j][i] - (sh.Rw[j][3 * i] * sh.J[j][0] + sh.Rw[j][3 * i + 1] * sh.J[j][1] +
-                                                    sh.Rw[j][3 * i + 2] * sh.J[j][2]);
-            }
+        for (int i = 0; i < 3; ++i) {
+            sh.A[j][4 * i] = sh.Rw[j][3 * i];
+            sh.A[j][4 * i + 1] = sh.Rw[j][3 * i + 1];
+            sh.A[j][4 * i + 2] = sh.Rw[j][3 * i + 2];
+            sh.A[j][4 * i + 3] = sh.tw[j][i] - (sh.Rw[j][3 * i] * sh.J[j][0] + sh.Rw[j][3 * i + 1] * sh.J[j][1] +
+                                                sh.Rw[j][3 * i + 2] * sh.J[j][2]);
+        }
     }
     __syncthreads();
 }
 
-// posed vertex (before skinning) and its blended skinning transform
-__device__ __forceinline__ void mano_vertex(const ManoModelDev& m, const ManoShared& sh, int v, float* vp, float* T)
+// ---- vertex stage.  Workgroup = 64 vertices x 4 wavefronts: wave w accumulates rows [w*37, w*37+37) of the blend
+// matrix for the 64 vertices (three coalesced 4-byte loads per row, rows independent -> loads pipeline), the four
+// partial sums meet in LDS.
+#define MANO_VCH 64
+#define MANO_ROWS_PER_WAVE 37
+__device__ __forceinline__ void mano_posed_chunk(const ManoModelDev& m, const ManoShared& sh, int v0, float (*s_part)[MANO_VCH][3],
+                                                 float (*s_vp)[3])
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int v = min(v0 + lane, MANO_V - 1);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const int k0 = wv * MANO_ROWS_PER_WAVE, k1 = min(MANO_NF, k0 + MANO_ROWS_PER_WAVE);
+    const float* base = m.M + 3 * v;
+#pragma unroll 4
+    for (int k = k0; k < k1; ++k) {
+        const float f = sh.feat[k];
+        const float* row = base + (long)k * (3 * MANO_V);
+        a0 += f * row[0];
+        a1 += f * row[1];
+        a2 += f * row[2];
+    }
+    s_part[wv][lane][0] = a0; s_part[wv][lane][1] = a1; s_part[wv][lane][2] = a2;
+    __syncthreads();
+    if (wv == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            s_vp[lane][c] = m.v_template[3 * v + c] + ((s_part[0][lane][c] + s_part[1][lane][c]) + (s_part[2][lane][c] + s_part[3][lane][c]));
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void mano_skin_transform(const ManoModelDev& m, const ManoShared& sh, int v, float* T)
 {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) vp[c] = m.v_template[3 * v + c];
-    for (int k = 0; k < MANO_NF; ++k) {
-        const float f = sh.feat[k];
-        const float* row = m.M + (long)k * (3 * MANO_V) + 3 * v;
-        vp[0] += f * row[0];
-        vp[1] += f * row[1];
-        vp[2] += f * row[2];
-    }
-#pragma unroll
     for (int k = 0; k < 12; ++k) T[k] = 0.f;
-    for (int j = 0; j < MANO_J; ++j) {
-        const float w = m.weights[v * MANO_J + j];
-        if (w != 0.f)
+    const float4* wrow = reinterpret_cast<const float4*>(m.weights + v * MANO_J);
 #pragma unroll
-            for (int k = 0; k < 12; ++k) T[k] += w * sh.A[j][k];
+    for (int q = 0; q < 4; ++q) {
+        const float4 w4 = wrow[q];
+        const float ws[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = 4 * q + u;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) T[k] += ws[u] * sh.A[j][k];
+        }
     }
 }
 
-// grid (4, B).  verts (B,778,3) = LBS + trans ; joints (B,16,3) optional (posed joints + trans)
-__global__ __launch_bounds__(MANO_CHUNK) void k_mano_fwd(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
-                                                          const float* __restrict__ rot, const float* __restrict__ betas,
-                                                          const float* __restrict__ trans, int B,
-                                                          float* __restrict__ verts, float* __restrict__ joints)
+// grid (13, B).  verts (B,778,3) = LBS + trans ; joints (B,16,3) optional (posed joints + trans)
+__global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
+                                                   const float* __restrict__ rot, const float* __restrict__ betas,
+                                                   const float* __restrict__ trans, int B, float* __restrict__ verts,
+                                                   float* __restrict__ joints)
 {
     __shared__ ManoShared sh;
+    __shared__ float s_part[4][MANO_VCH][3];
+    __shared__ float s_vp[MANO_VCH][3];
     const int b = blockIdx.y;
     mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
     const float tr[3] = {trans ? trans[b * 3] : 0.f, trans ? trans[b * 3 + 1] : 0.f, trans ? trans[b * 3 + 2] : 0.f};
     if (joints && blockIdx.x == 0 && threadIdx.x < MANO_J * 3)
         joints[b * MANO_J * 3 + threadIdx.x] = sh.tw[threadIdx.x / 3][threadIdx.x % 3] + tr[threadIdx.x % 3];
-    const int v = blockIdx.x * MANO_CHUNK + threadIdx.x;
-    if (v >= MANO_V) return;
-    float vp[3], T[12];
-    mano_vertex(m, sh, v, vp, T);
+    const int v0 = blockIdx.x * MANO_VCH;
+    mano_posed_chunk(m, sh, v0, s_part, s_vp);
+    const int v = v0 + threadIdx.x;
+    if (threadIdx.x >= MANO_VCH || v >= MANO_V) return;
+    float T[12];
+    mano_skin_transform(m, sh, v, T);
+    const float* vp = s_vp[threadIdx.x];
     float* o = verts + ((long)b * MANO_V + v) * 3;
 #pragma unroll
     for (int i = 0; i < 3; ++i) o[i] = T[4 * i] * vp[0] + T[4 * i + 1] * vp[1] + T[4 * i + 2] * vp[2] + T[4 * i + 3] + tr[i];
 }
 
-// backward pass 1: grid (4, B) -> partials (B, 4, 340)
-__global__ __launch_bounds__(MANO_CHUNK) void k_mano_bwd1(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
-                                                           const float* __restrict__ rot, const float* __restrict__ betas,
-                                                           const float* __restrict__ gout, int B,
-                                                           float* __restrict__ partials)
+// backward pass 1: grid (13, B) -> partials (B, 13, 340)
+__global__ __launch_bounds__(256) void k_mano_bwd1(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
+                                                    const float* __restrict__ rot, const float* __restrict__ betas,
+                                                    const float* __restrict__ gout, int B, float* __restrict__ partials)
 {
     __shared__ ManoShared sh;
-    __shared__ float s_g[MANO_CHUNK][3];
-    __shared__ float s_vp[MANO_CHUNK][3];
-    __shared__ float s_dvp[MANO_CHUNK * 3];
-    __shared__ float s_w[MANO_CHUNK][MANO_J + 1];
+    __shared__ float s_part[4][MANO_VCH][3];
+    __shared__ float s_vp[MANO_VCH][3];
+    __shared__ float s_g[MANO_VCH][3];
+    __shared__ float s_dvp[MANO_VCH * 3];
+    __shared__ float s_w[MANO_VCH][MANO_J + 1];
     __shared__ float red[16];
     const int b = blockIdx.y, t = threadIdx.x;
     mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
-    const int v0 = blockIdx.x * MANO_CHUNK;
-    const int v = v0 + t;
-    const int nv = min(MANO_CHUNK, MANO_V - v0);
+    const int v0 = blockIdx.x * MANO_VCH;
+    const int nv = min(MANO_VCH, MANO_V - v0);
+    mano_posed_chunk(m, sh, v0, s_part, s_vp);
     float g[3] = {0.f, 0.f, 0.f};
-    if (v < MANO_V) {
-        float vp[3], T[12];
-        mano_vertex(m, sh, v, vp, T);
+    if (t < nv) {
+        const int v = v0 + t;
+        float T[12];
+        mano_skin_transform(m, sh, v, T);
         const float* gp = gout + ((long)b * MANO_V + v) * 3;
         g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             s_g[t][c] = g[c];
-            s_vp[t][c] = vp[c];
             s_dvp[3 * t + c] = T[c] * g[0] + T[4 + c] * g[1] + T[8 + c] * g[2];
         }
         for (int j = 0; j < MANO_J; ++j) s_w[t][j] = m.weights[v * MANO_J + j];
     }
-    float* out = partials + ((long)b * MANO_NCHUNK + blockIdx.x) * MANO_PART;
+    float* out = partials + ((long)b * gridDim.x + blockIdx.x) * MANO_PART;
     const float tg0 = hm_block_sum(g[0], red), tg1 = hm_block_sum(g[1], red), tg2 = hm_block_sum(g[2], red);
     if (t == 0) { out[337] = tg0; out[338] = tg1; out[339] = tg2; }
     __syncthreads();
@@ -244,33 +292,52 @@ __global__ __launch_bounds__(MANO_CHUNK) void k_mano_bwd1(ManoModelDev m, const 
         for (int i = 0; i < nv; ++i) acc += s_w[i][j] * s_g[i][r] * (c < 3 ? s_vp[i][c] : 1.0f);
         out[t] = acc;
     }
-    // dfeat[k] = sum_{v,c} M[k][3v+c] dvp[v][c]   (one wave per row, coalesced)
+    // dfeat[k] = sum_{v,c} M[k][3v+c] dvp[v][c]   (one wave per row, 3 coalesced loads, rows independent)
     const int wv = t >> 6, lane = t & 63;
-    for (int k = wv; k < MANO_NF; k += MANO_CHUNK / 64) {
+    const int ne = 3 * nv;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (lane < ne) d0 = s_dvp[lane];
+    if (lane + 64 < ne) d1 = s_dvp[lane + 64];
+    if (lane + 128 < ne) d2 = s_dvp[lane + 128];
+#pragma unroll 4
+    for (int k = wv; k < MANO_NF; k += 4) {
         const float* row = m.M + (long)k * (3 * MANO_V) + 3 * v0;
         float acc = 0.f;
-        for (int e = lane; e < 3 * nv; e += 64) acc += row[e] * s_dvp[e];
+        if (lane < ne) acc += row[lane] * d0;
+        if (lane + 64 < ne) acc += row[lane + 64] * d1;
+        if (lane + 128 < ne) acc += row[lane + 128] * d2;
         acc = hm_wave_sum(acc);
         if (lane == 0) out[192 + k] = acc;
     }
 }
 
-// backward pass 2: grid (B), 64 threads: reduce chunk partials, chain / Rodrigues / PCA backward
+// backward pass 2: grid (B), 64 threads: reduce chunk partials, chain / Rodrigues / PCA backward (level-parallel)
 __global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
                                                    const float* __restrict__ rot, const float* __restrict__ betas,
-                                                   const float* __restrict__ partials, int B, int pca_dim,
+                                                   const float* __restrict__ partials, int nchunk, int B, int pca_dim,
                                                    float* __restrict__ g_pca, float* __restrict__ g_rot,
                                                    float* __restrict__ g_betas, float* __restrict__ g_trans)
 {
     __shared__ ManoShared sh;
     __shared__ float tot[MANO_PART];
     __shared__ float dRw[MANO_J][9], dtw[MANO_J][3], dJ[MANO_J][3], dRl[MANO_J][9], dpose[48];
+    __shared__ float cR[MANO_J][9], ct[MANO_J][3], cJ[MANO_J][3];     // child -> parent contributions
     const int b = blockIdx.x, t = threadIdx.x;
     mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
     for (int k = t; k < MANO_PART; k += 64) {
         float a = 0.f;
-        for (int c = 0; c < MANO_NCHUNK; ++c) a += partials[((long)b * MANO_NCHUNK + c) * MANO_PART + k];
+        for (int c = 0; c < nchunk; ++c) a += partials[((long)b * nchunk + c) * MANO_PART + k];
         tot[k] = a;
+    }
+    int depth = 0, par = -1, maxd = 0;
+    if (t < MANO_J) {
+        par = m.parents[t];
+        for (int q = par; q >= 0; q = m.parents[q]) ++depth;
+    }
+    for (int j = 0; j < MANO_J; ++j) {
+        int d = 0;
+        for (int q = m.parents[j]; q >= 0; q = m.parents[q]) ++d;
+        maxd = max(maxd, d);
     }
     __syncthreads();
     if (t < MANO_J) {
@@ -288,41 +355,48 @@ __global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* _
             dJ[j][k] = -(sh.Rw[j][k] * dA[3] + sh.Rw[j][3 + k] * dA[7] + sh.Rw[j][6 + k] * dA[11]);
     }
     __syncthreads();
-    if (t == 0) {
-        for (int j = MANO_J - 1; j >= 0; --j) {
-            const int p = m.parents[j];
-            if (p < 0) {
-#pragma unroll
-                for (int k = 0; k < 9; ++k) dRl[j][k] = dRw[j][k];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) dJ[j][c] += dtw[j][c];
-                continue;
-            }
+    // leaves first: joints of one level push their contribution to per-child slots, then every parent collects
+    for (int level = maxd; level >= 1; --level) {
+        if (t < MANO_J && depth == level) {
+            const int j = t, p = par;
             const float rel[3] = {sh.J[j][0] - sh.J[p][0], sh.J[j][1] - sh.J[p][1], sh.J[j][2] - sh.J[p][2]};
-            // tw_j = Rw_p rel + tw_p
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dRw[p][3 * i + k] += dtw[j][i] * rel[k];
-                dtw[p][i] += dtw[j][i];
+                for (int k = 0; k < 3; ++k)       // tw_j = Rw_p rel + tw_p ; Rw_j = Rw_p Rl_j
+                    cR[j][3 * i + k] = dtw[j][i] * rel[k] + dRw[j][3 * i] * sh.Rl[j][3 * k] +
+                                       dRw[j][3 * i + 1] * sh.Rl[j][3 * k + 1] + dRw[j][3 * i + 2] * sh.Rl[j][3 * k + 2];
+                ct[j][i] = dtw[j][i];
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const float d = sh.Rw[p][k] * dtw[j][0] + sh.Rw[p][3 + k] * dtw[j][1] + sh.Rw[p][6 + k] * dtw[j][2];
                 dJ[j][k] += d;
-                dJ[p][k] -= d;
+                cJ[j][k] = -d;
             }
-            // Rw_j = Rw_p Rl_j
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    dRw[p][3 * i + k] += dRw[j][3 * i] * sh.Rl[j][3 * k] + dRw[j][3 * i + 1] * sh.Rl[j][3 * k + 1] +
-                                         dRw[j][3 * i + 2] * sh.Rl[j][3 * k + 2];
-                    dRl[j][3 * i + k] = sh.Rw[p][i] * dRw[j][k] + sh.Rw[p][3 + i] * dRw[j][3 + k] +
-                                        sh.Rw[p][6 + i] * dRw[j][6 + k];
+                for (int k = 0; k < 3; ++k)
+                    dRl[j][3 * i + k] = sh.Rw[p][i] * dRw[j][k] + sh.Rw[p][3 + i] * dRw[j][3 + k] + sh.Rw[p][6 + i] * dRw[j][6 + k];
+        }
+        __syncthreads();
+        if (t < MANO_J && depth == level - 1) {
+            for (int j = 0; j < MANO_J; ++j)
+                if (m.parents[j] == t) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) dRw[t][k] += cR[j][k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { dtw[t][k] += ct[j][k]; dJ[t][k] += cJ[j][k]; }
                 }
         }
+        __syncthreads();
+    }
+    if (t < MANO_J && par < 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dRl[t][k] = dRw[t][k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) dJ[t][c] += dtw[t][c];
     }
     __syncthreads();
     if (t < MANO_J) {
@@ -339,13 +413,11 @@ __global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* _
         g_rot[b * 3 + t] = dpose[t];
         g_trans[b * 3 + t] = tot[337 + t];
     }
-    if (t < pca_dim || t < 16) {
-        for (int i = t; i < pca_dim; i += 64) {
-            float a = 0.f;
-            if (i < 16)
-                for (int k = 0; k < 45; ++k) a += m.comps[i * 45 + k] * dpose[3 + k];
-            g_pca[(long)b * pca_dim + i] = a;
-        }
+    for (int i = t; i < pca_dim; i += 64) {
+        float a = 0.f;
+        if (i < 16)
+            for (int k = 0; k < 45; ++k) a += m.comps[i * 45 + k] * dpose[3 + k];
+        g_pca[(long)b * pca_dim + i] = a;
     }
     if (t < 10) {
         float a = tot[192 + 135 + t];
@@ -364,11 +436,11 @@ int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const f
     HM_CHECK_ARG(model && pca && rot && betas && verts && B > 0 && pca_dim >= 16);
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
-    hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCHUNK, B), dim3(MANO_CHUNK), 0, stream, m, pca, pca_dim, rot, betas, trans,
-                       B, verts, joints);
+    hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, trans, B, verts,
+                       joints);
     return hm_launch_status();
 }
-size_t hm_mano_workspace_bytes(int B) { return (size_t)B * MANO_NCHUNK * MANO_PART * sizeof(float); }
+size_t hm_mano_workspace_bytes(int B) { return (size_t)B * MANO_NCH64 * MANO_PART * sizeof(float); }
 int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
                 const float* g_verts, float* g_pca, float* g_rot, float* g_betas, float* g_trans, void* workspace,
                 hipStream_t stream)
@@ -377,10 +449,10 @@ int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const f
     HM_CHECK_ARG(B > 0 && pca_dim >= 16);
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
-    hipLaunchKernelGGL(k_mano_bwd1, dim3(MANO_NCHUNK, B), dim3(MANO_CHUNK), 0, stream, m, pca, pca_dim, rot, betas,
-                       g_verts, B, (float*)workspace);
+    hipLaunchKernelGGL(k_mano_bwd1, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, g_verts, B,
+                       (float*)workspace);
     hipLaunchKernelGGL(k_mano_bwd2, dim3(B), dim3(64), 0, stream, m, pca, pca_dim, rot, betas, (const float*)workspace,
-                       B, pca_dim, g_pca, g_rot, g_betas, g_trans);
+                       MANO_NCH64, B, pca_dim, g_pca, g_rot, g_betas, g_trans);
     return hm_launch_status();
 }
 }  // extern "C"
