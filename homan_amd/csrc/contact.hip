@@ -72,51 +72,65 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn(const float* __restrict__ vh,
     }
 }
 
-// grid (B).  loss = mean_{b,i} thresh * tanh(a / thresh) ; unit gradients for both vertex sets.
+// grid (1 + ceil(Vo/256), B).  Block x == 0 of a frame: hand side (value, d/d hand vertex, per-frame partial sum,
+// last-block finish).  Blocks x >= 1: 256 object vertices each; every thread scans the frame's nearest-neighbour list
+// (LDS, broadcast reads) and accumulates, in hand-vertex order, the pulls of the hand vertices that picked it --
+// a deterministic scatter without atomics.   loss = mean_{b,i} thresh * tanh(a / thresh).
+__device__ __forceinline__ float contact_pull(const float* h, const float* o, float thresh, float inv_cnt, float* pull,
+                                              float* value)
+{
+    const float dx = o[0] - h[0], dy = o[1] - h[1], dz = o[2] - h[2];
+    const float a = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float th = tanhf(a / thresh);
+    const float k = (a > 0.f) ? (1.0f - th * th) / a * inv_cnt : 0.f;     // d val / d a  / a
+    pull[0] = k * dx; pull[1] = k * dy; pull[2] = k * dz;                  // d/d o ; d/d h is the negative
+    if (value) *value = thresh * th;
+    return k;
+}
+
 __global__ __launch_bounds__(NN_THREADS) void k_contact(const float* __restrict__ vh, const float* __restrict__ vo,
                                                          const int* __restrict__ nn_idx, int B, int Vh, int Vo,
                                                          float thresh, float* __restrict__ g_hand,
                                                          float* __restrict__ g_obj, float* __restrict__ partials,
                                                          unsigned int* counter, float* __restrict__ out)
 {
-    extern __shared__ float dyn[];          // Vh * 4 floats: idx (as int) + pull vector
-    int* s_idx = reinterpret_cast<int*>(dyn);
-    float* s_pull = dyn + Vh;
+    extern __shared__ int s_idx[];          // Vh ints (object blocks only)
     __shared__ float red[16];
     __shared__ int s_flag;
-    const int b = blockIdx.x;
+    const int b = blockIdx.y;
     const float inv_cnt = 1.0f / (float)((long)B * Vh);
-    float lsum = 0.f;
-    for (int i = threadIdx.x; i < Vh; i += NN_THREADS) {
-        const int j = nn_idx[(long)b * Vh + i];
-        const float* h = vh + ((long)b * Vh + i) * 3;
-        const float* o = vo + ((long)b * Vo + j) * 3;
-        const float dx = o[0] - h[0], dy = o[1] - h[1], dz = o[2] - h[2];
-        const float a = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float th = tanhf(a / thresh);
-        lsum += thresh * th;
-        const float k = (a > 0.f) ? (1.0f - th * th) / a * inv_cnt : 0.f;   // d val / d a  / a
-        // d a / d o = diff / a ; d a / d h = -diff / a
-        s_idx[i] = j;
-        s_pull[3 * i] = k * dx; s_pull[3 * i + 1] = k * dy; s_pull[3 * i + 2] = k * dz;
-        float* gh = g_hand + ((long)b * Vh + i) * 3;
-        gh[0] = -k * dx; gh[1] = -k * dy; gh[2] = -k * dz;
+    if (blockIdx.x == 0) {
+        float lsum = 0.f;
+        for (int i = threadIdx.x; i < Vh; i += NN_THREADS) {
+            const int j = nn_idx[(long)b * Vh + i];
+            float pull[3], val;
+            contact_pull(vh + ((long)b * Vh + i) * 3, vo + ((long)b * Vo + j) * 3, thresh, inv_cnt, pull, &val);
+            lsum += val;
+            float* gh = g_hand + ((long)b * Vh + i) * 3;
+            gh[0] = -pull[0]; gh[1] = -pull[1]; gh[2] = -pull[2];
+        }
+        lsum = hm_block_sum(lsum, red);
+        if (threadIdx.x == 0) partials[b] = lsum;
+        if (hm_last_block(counter, gridDim.y, &s_flag)) {
+            const float t = hm_last_block_sum(partials, B, 1, red);
+            if (threadIdx.x == 0) out[0] = t * inv_cnt;
+        }
+        return;
     }
+    for (int i = threadIdx.x; i < Vh; i += NN_THREADS) s_idx[i] = nn_idx[(long)b * Vh + i];
     __syncthreads();
-    // deterministic scatter: every object vertex gathers the hand vertices that picked it, in index order
-    for (int j = threadIdx.x; j < Vo; j += NN_THREADS) {
-        float gx = 0.f, gy = 0.f, gz = 0.f;
-        for (int i = 0; i < Vh; ++i)
-            if (s_idx[i] == j) { gx += s_pull[3 * i]; gy += s_pull[3 * i + 1]; gz += s_pull[3 * i + 2]; }
-        float* go = g_obj + ((long)b * Vo + j) * 3;
-        go[0] = gx; go[1] = gy; go[2] = gz;
-    }
-    lsum = hm_block_sum(lsum, red);
-    if (threadIdx.x == 0) partials[b] = lsum;
-    if (hm_last_block(counter, gridDim.x, &s_flag)) {
-        const float t = hm_last_block_sum(partials, B, 1, red);
-        if (threadIdx.x == 0) out[0] = t * inv_cnt;
-    }
+    const int j = (blockIdx.x - 1) * NN_THREADS + threadIdx.x;
+    if (j >= Vo) return;
+    const float* o = vo + ((long)b * Vo + j) * 3;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int i = 0; i < Vh; ++i)
+        if (s_idx[i] == j) {
+            float pull[3];
+            contact_pull(vh + ((long)b * Vh + i) * 3, o, thresh, inv_cnt, pull, nullptr);
+            gx += pull[0]; gy += pull[1]; gz += pull[2];
+        }
+    float* go = g_obj + ((long)b * Vo + j) * 3;
+    go[0] = gx; go[1] = gy; go[2] = gz;
 }
 
 extern "C" {
@@ -137,7 +151,7 @@ int hm_contact_fwd(const float* verts_hand, const float* verts_obj, const int* n
 {
     HM_CHECK_ARG(verts_hand && verts_obj && nn_idx && g_hand && g_obj && out1 && workspace);
     HM_CHECK_ARG(B > 0 && B <= 512 && Vh > 0 && Vo > 0 && (size_t)Vh * 16 <= 60000);
-    hipLaunchKernelGGL(k_contact, dim3(B), dim3(NN_THREADS), (size_t)Vh * 4 * sizeof(float), stream, verts_hand, verts_obj,
+    hipLaunchKernelGGL(k_contact, dim3(1 + hm_cdiv(Vo, NN_THREADS), B), dim3(NN_THREADS), (size_t)Vh * sizeof(int), stream, verts_hand, verts_obj,
                        nn_idx, B, Vh, Vo, thresh, g_hand, g_obj, (float*)workspace,
                        (unsigned int*)((float*)workspace + 512), out1);
     return hm_launch_status();

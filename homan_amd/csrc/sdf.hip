@@ -92,7 +92,8 @@ __device__ __forceinline__ float voxel_centre(int i) { return -1.0f + ((float)i 
 // object 0 = hand, object 1 = rigid object.  boxes (2,B,4) = centre xyz, scale.  vnorm_k (B,V_k,3).
 __global__ __launch_bounds__(SDF_THREADS) void k_sdf_boxes(const float* __restrict__ v0, int V0, const float* __restrict__ v1,
                                                             int V1, int B, float scale_factor, float* __restrict__ boxes,
-                                                            float* __restrict__ vn0, float* __restrict__ vn1)
+                                                            float* __restrict__ vn0, float* __restrict__ vn1,
+                                                            unsigned int* __restrict__ masks)
 {
     __shared__ float red[16];
     const int b = blockIdx.x, k = blockIdx.y;
@@ -117,55 +118,71 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_boxes(const float* __restri
     for (int i = threadIdx.x; i < V; i += blockDim.x)
 #pragma unroll
         for (int c = 0; c < 3; ++c) vn[3 * i + c] = (v[3 * i + c] - ctr[c]) / sc;
+    unsigned int* mk = masks + ((long)k * B + b) * (SDF_N * SDF_N);      // XOR-accumulated by the sign pass
+    for (int i = threadIdx.x; i < SDF_N * SDF_N; i += blockDim.x) mk[i] = 0u;
 }
 
-// ------------------------------------------------------------------ sign pass.  grid (N*N/256, B, 2)
-// one thread per (z,y) row; triangles staged through LDS; inside mask bit i <-> voxel x index i.
+// ------------------------------------------------------------------ sign pass.  grid (N*N/256, B, chunks0+chunks1)
+// one thread per (z,y) row, one workgroup per (row block, frame, chunk of 256 triangles of one mesh).  The chunk's
+// triangles that can cross the block's z-slab are compacted into LDS; every thread toggles, per crossing, the bits of
+// the voxels in front of the hit, and the chunks are combined with atomicXor (order-independent, hence deterministic).
+// masks must be zero on entry (cleared by k_sdf_boxes).  inside mask bit i <-> voxel x index i.
 __global__ __launch_bounds__(SDF_THREADS) void k_sdf_parity(const float* __restrict__ vn0, const int* __restrict__ f0, int V0,
                                                              int F0, const float* __restrict__ vn1,
                                                              const int* __restrict__ f1, int V1, int F1, int B,
-                                                             unsigned int* __restrict__ masks)
+                                                             int chunks0, unsigned int* __restrict__ masks)
 {
     __shared__ float tri[SDF_THREADS * 9];
-    const int b = blockIdx.y, k = blockIdx.z;
+    __shared__ int s_n;
+    const int b = blockIdx.y;
+    const int k = (int)blockIdx.z < chunks0 ? 0 : 1;
+    const int chunk = k == 0 ? blockIdx.z : blockIdx.z - chunks0;
     const int V = k == 0 ? V0 : V1, F = k == 0 ? F0 : F1;
     const float* vn = (k == 0 ? vn0 : vn1) + (long)b * V * 3;
     const int* fc = k == 0 ? f0 : f1;
     const int row = blockIdx.x * SDF_THREADS + threadIdx.x;       // row = z * N + y
     const int kz = row / SDF_N, jy = row % SDF_N;
     const float cy = voxel_centre(jy), cz = voxel_centre(kz);
-    unsigned int mask = 0;
-    for (int base = 0; base < F; base += SDF_THREADS) {
-        const int n = min(SDF_THREADS, F - base);
-        __syncthreads();
-        if ((int)threadIdx.x < n) {
-            const int* t = fc + 3 * (base + threadIdx.x);
+    // z-slab of this row block (rows are z-major: 256 rows = 8 consecutive z)
+    const float zlo_blk = voxel_centre((blockIdx.x * SDF_THREADS) / SDF_N);
+    const float zhi_blk = voxel_centre((blockIdx.x * SDF_THREADS + SDF_THREADS - 1) / SDF_N);
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int fi = chunk * SDF_THREADS + threadIdx.x;
+    if (fi < F) {
+        const int* t = fc + 3 * fi;
+        float p[9];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const float* p = vn + 3 * t[q];
-                tri[threadIdx.x * 9 + 3 * q] = p[0];
-                tri[threadIdx.x * 9 + 3 * q + 1] = p[1];
-                tri[threadIdx.x * 9 + 3 * q + 2] = p[2];
-            }
+        for (int q = 0; q < 3; ++q) {
+            const float* src = vn + 3 * t[q];
+            p[3 * q] = src[0]; p[3 * q + 1] = src[1]; p[3 * q + 2] = src[2];
         }
-        __syncthreads();
-        for (int e = 0; e < n; ++e) {
-            const float* t = tri + 9 * e;
-            // cheap reject on the (y,z) box of the triangle (exact: a crossing needs the point inside the projection)
-            const float ylo = fminf(t[1], fminf(t[4], t[7])), yhi = fmaxf(t[1], fmaxf(t[4], t[7]));
-            const float zlo = fminf(t[2], fminf(t[5], t[8])), zhi = fmaxf(t[2], fmaxf(t[5], t[8]));
-            if (cy < ylo || cy > yhi || cz < zlo || cz > zhi) continue;
-            float xh;
-            if (!ray_x_crosses(cy, cz, t, t + 3, t + 6, &xh)) continue;
-            // m = number of voxel centres with xh > centre (centres increase with i)
-            int m = (int)floorf((xh + 1.0f) * (0.5f * (float)SDF_N) + 0.5f);
-            m = max(0, min(SDF_N, m));
-            while (m > 0 && !(xh > voxel_centre(m - 1))) --m;
-            while (m < SDF_N && xh > voxel_centre(m)) ++m;
-            mask ^= (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
+        const float zlo = fminf(p[2], fminf(p[5], p[8])), zhi = fmaxf(p[2], fmaxf(p[5], p[8]));
+        if (!(zhi < zlo_blk || zlo > zhi_blk)) {
+            const int pos = atomicAdd(&s_n, 1);           // LDS order is irrelevant: XOR is commutative
+#pragma unroll
+            for (int q = 0; q < 9; ++q) tri[pos * 9 + q] = p[q];
         }
     }
-    masks[((long)k * B + b) * (SDF_N * SDF_N) + row] = mask;
+    __syncthreads();
+    const int n = s_n;
+    unsigned int mask = 0;
+    for (int e = 0; e < n; ++e) {
+        const float* t = tri + 9 * e;
+        // cheap reject on the (y,z) box of the triangle (exact: a crossing needs the point inside the projection)
+        const float ylo = fminf(t[1], fminf(t[4], t[7])), yhi = fmaxf(t[1], fmaxf(t[4], t[7]));
+        const float zlo = fminf(t[2], fminf(t[5], t[8])), zhi = fmaxf(t[2], fmaxf(t[5], t[8]));
+        if (cy < ylo || cy > yhi || cz < zlo || cz > zhi) continue;
+        float xh;
+        if (!ray_x_crosses(cy, cz, t, t + 3, t + 6, &xh)) continue;
+        // m = number of voxel centres with xh > centre (centres increase with i)
+        int m = (int)floorf((xh + 1.0f) * (0.5f * (float)SDF_N) + 0.5f);
+        m = max(0, min(SDF_N, m));
+        while (m > 0 && !(xh > voxel_centre(m - 1))) --m;
+        while (m < SDF_N && xh > voxel_centre(m)) ++m;
+        mask ^= (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
+    }
+    if (mask) atomicXor(&masks[((long)k * B + b) * (SDF_N * SDF_N) + row], mask);
 }
 
 // ------------------------------------------------------------------ lazy distance + trilinear sampling
@@ -226,8 +243,18 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(
             float dmin = 1e30f;
             for (int f = lane; f < Fk; f += 64) {
                 const int* tr = fk + 3 * f;
-                const float d = point_triangle_distance(ctr, vnk + 3 * tr[0], vnk + 3 * tr[1], vnk + 3 * tr[2]);
-                dmin = fminf(dmin, d);
+                const float *q1 = vnk + 3 * tr[0], *q2 = vnk + 3 * tr[1], *q3 = vnk + 3 * tr[2];
+                // distance to the triangle's bounding box bounds the distance to the triangle from below; a triangle
+                // that cannot beat this lane's current minimum is skipped (the minimum itself is unchanged)
+                float lb2 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float lo = fminf(q1[c], fminf(q2[c], q3[c])), hi = fmaxf(q1[c], fmaxf(q2[c], q3[c]));
+                    const float dd = fmaxf(fmaxf(lo - ctr[c], ctr[c] - hi), 0.f);
+                    lb2 += dd * dd;
+                }
+                if (lb2 * 0.9999f > dmin * dmin) continue;
+                dmin = fminf(dmin, point_triangle_distance(ctr, q1, q2, q3));
             }
             dmin = hm_wave_min(dmin);
             if (lane == t) phi[c] = dmin;
@@ -321,9 +348,10 @@ int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, con
     HM_CHECK_ARG(B > 0 && V0 > 0 && V1 > 0 && F0 > 0 && F1 > 0);
     CollWs w = coll_carve(workspace, B, V0, V1);
     hipLaunchKernelGGL(k_sdf_boxes, dim3(B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, scale_factor,
-                       w.boxes, w.vn0, w.vn1);
-    hipLaunchKernelGGL(k_sdf_parity, dim3(SDF_N * SDF_N / SDF_THREADS, B, 2), dim3(SDF_THREADS), 0, stream, w.vn0, faces0,
-                       V0, F0, w.vn1, faces1, V1, F1, B, w.masks);
+                       w.boxes, w.vn0, w.vn1, w.masks);
+    const int chunks0 = hm_cdiv(F0, SDF_THREADS), chunks1 = hm_cdiv(F1, SDF_THREADS);
+    hipLaunchKernelGGL(k_sdf_parity, dim3(SDF_N * SDF_N / SDF_THREADS, B, chunks0 + chunks1), dim3(SDF_THREADS), 0, stream,
+                       w.vn0, faces0, V0, F0, w.vn1, faces1, V1, F1, B, chunks0, w.masks);
     const int chunks = hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS);
     hipLaunchKernelGGL(k_sdf_sample, dim3(chunks, B, 2), dim3(SDF_THREADS), 0, stream, verts0, w.vn0, faces0, V0, F0,
                        verts1, w.vn1, faces1, V1, F1, B, w.boxes, w.masks, g0, g1, w.partials, w.counter, out1);
