@@ -11,17 +11,20 @@
 
 #define NN_THREADS 256
 
-// grid (ceil(Vh/64), B).  Workgroup = 64 hand vertices x 4 wavefronts; each wave scans one quarter of every
-// 1024-vertex object tile staged in LDS (all lanes of a wave read the same object vertex: LDS broadcast), then the
-// four partial minima are merged lexicographically on (distance, index) so ties keep the lowest index.
+// grid (ceil(Vh/64), B).  Workgroup = 64 hand vertices x 4 wavefronts; wave q scans the object vertices
+// [q*64 + 256*m, +64): lane l loads object vertex l of the group (coalesced), the group is then broadcast vertex by
+// vertex with v_readlane (scalar operands, no LDS round trip in the inner loop).  The four partial minima are merged
+// lexicographically on (distance, index) so ties keep the lowest index.
 #define NN_HV 64
-#define NN_TILE 1024
+__device__ __forceinline__ float rl_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __global__ __launch_bounds__(NN_THREADS) void k_nn(const float* __restrict__ vh, const float* __restrict__ vo, int B,
                                                     int Vh, int Vo, int* __restrict__ nn_idx, float* __restrict__ nn_d2,
                                                     float* __restrict__ blockmin, unsigned int* counter,
                                                     float* __restrict__ metric_out)
 {
-    __shared__ float tile[NN_TILE * 3];
     __shared__ float s_d[4][NN_HV];
     __shared__ int s_i[4][NN_HV];
     __shared__ float red[16];
@@ -32,16 +35,15 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn(const float* __restrict__ vh,
     if (i < Vh) { const float* p = vh + ((long)b * Vh + i) * 3; hx = p[0]; hy = p[1]; hz = p[2]; }
     float best = 3.4e38f;
     int besti = 0;
-    for (int j0 = 0; j0 < Vo; j0 += NN_TILE) {
-        const int n = min(NN_TILE, Vo - j0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < 3 * n; e += NN_THREADS) tile[e] = vo[((long)b * Vo + j0) * 3 + e];
-        __syncthreads();
-        const int lo = q * (NN_TILE / 4), hi = min(lo + NN_TILE / 4, n);
-        for (int j = lo; j < hi; ++j) {
-            const float dx = tile[3 * j] - hx, dy = tile[3 * j + 1] - hy, dz = tile[3 * j + 2] - hz;
+    for (int j0 = q * 64; j0 < Vo; j0 += 256) {
+        const int n = min(64, Vo - j0);
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (lane < n) { const float* p = vo + ((long)b * Vo + j0 + lane) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
+#pragma unroll 4
+        for (int k = 0; k < n; ++k) {
+            const float dx = rl_f(ox, k) - hx, dy = rl_f(oy, k) - hy, dz = rl_f(oz, k) - hz;
             const float d = dx * dx + dy * dy + dz * dz;
-            if (d < best) { best = d; besti = j0 + j; }
+            if (d < best) { best = d; besti = j0 + k; }
         }
     }
     s_d[q][lane] = best;
@@ -72,65 +74,64 @@ __global__ __launch_bounds__(NN_THREADS) void k_nn(const float* __restrict__ vh,
     }
 }
 
-// grid (1 + ceil(Vo/256), B).  Block x == 0 of a frame: hand side (value, d/d hand vertex, per-frame partial sum,
-// last-block finish).  Blocks x >= 1: 256 object vertices each; every thread scans the frame's nearest-neighbour list
-// (LDS, broadcast reads) and accumulates, in hand-vertex order, the pulls of the hand vertices that picked it --
-// a deterministic scatter without atomics.   loss = mean_{b,i} thresh * tanh(a / thresh).
-__device__ __forceinline__ float contact_pull(const float* h, const float* o, float thresh, float inv_cnt, float* pull,
-                                              float* value)
+// Contact loss, hand side.  grid (B): value, d/d hand vertex (= minus the pull on the matched object vertex),
+// per-frame partial sums, last-block finish.   loss = mean_{b,i} thresh * tanh(a / thresh).
+__global__ __launch_bounds__(NN_THREADS) void k_contact_hand(const float* __restrict__ vh, const float* __restrict__ vo,
+                                                              const int* __restrict__ nn_idx, int B, int Vh, int Vo,
+                                                              float thresh, float* __restrict__ g_hand,
+                                                              float* __restrict__ partials, unsigned int* counter,
+                                                              float* __restrict__ out)
 {
-    const float dx = o[0] - h[0], dy = o[1] - h[1], dz = o[2] - h[2];
-    const float a = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float th = tanhf(a / thresh);
-    const float k = (a > 0.f) ? (1.0f - th * th) / a * inv_cnt : 0.f;     // d val / d a  / a
-    pull[0] = k * dx; pull[1] = k * dy; pull[2] = k * dz;                  // d/d o ; d/d h is the negative
-    if (value) *value = thresh * th;
-    return k;
-}
-
-__global__ __launch_bounds__(NN_THREADS) void k_contact(const float* __restrict__ vh, const float* __restrict__ vo,
-                                                         const int* __restrict__ nn_idx, int B, int Vh, int Vo,
-                                                         float thresh, float* __restrict__ g_hand,
-                                                         float* __restrict__ g_obj, float* __restrict__ partials,
-                                                         unsigned int* counter, float* __restrict__ out)
-{
-    extern __shared__ int s_idx[];          // Vh ints (object blocks only)
     __shared__ float red[16];
     __shared__ int s_flag;
-    const int b = blockIdx.y;
+    const int b = blockIdx.x;
     const float inv_cnt = 1.0f / (float)((long)B * Vh);
-    if (blockIdx.x == 0) {
-        float lsum = 0.f;
-        for (int i = threadIdx.x; i < Vh; i += NN_THREADS) {
-            const int j = nn_idx[(long)b * Vh + i];
-            float pull[3], val;
-            contact_pull(vh + ((long)b * Vh + i) * 3, vo + ((long)b * Vo + j) * 3, thresh, inv_cnt, pull, &val);
-            lsum += val;
-            float* gh = g_hand + ((long)b * Vh + i) * 3;
-            gh[0] = -pull[0]; gh[1] = -pull[1]; gh[2] = -pull[2];
-        }
-        lsum = hm_block_sum(lsum, red);
-        if (threadIdx.x == 0) partials[b] = lsum;
-        if (hm_last_block(counter, gridDim.y, &s_flag)) {
-            const float t = hm_last_block_sum(partials, B, 1, red);
-            if (threadIdx.x == 0) out[0] = t * inv_cnt;
-        }
-        return;
+    float lsum = 0.f;
+    for (int i = threadIdx.x; i < Vh; i += NN_THREADS) {
+        const int j = nn_idx[(long)b * Vh + i];
+        const float* h = vh + ((long)b * Vh + i) * 3;
+        const float* o = vo + ((long)b * Vo + j) * 3;
+        const float dx = o[0] - h[0], dy = o[1] - h[1], dz = o[2] - h[2];
+        const float a = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float th = tanhf(a / thresh);
+        lsum += thresh * th;
+        const float k = (a > 0.f) ? (1.0f - th * th) / a * inv_cnt : 0.f;     // d val / d a  / a
+        float* gh = g_hand + ((long)b * Vh + i) * 3;                          // d a / d h = -diff / a
+        gh[0] = -k * dx; gh[1] = -k * dy; gh[2] = -k * dz;
     }
-    for (int i = threadIdx.x; i < Vh; i += NN_THREADS) s_idx[i] = nn_idx[(long)b * Vh + i];
-    __syncthreads();
-    const int j = (blockIdx.x - 1) * NN_THREADS + threadIdx.x;
-    if (j >= Vo) return;
-    const float* o = vo + ((long)b * Vo + j) * 3;
+    lsum = hm_block_sum(lsum, red);
+    if (threadIdx.x == 0) partials[b] = lsum;
+    if (hm_last_block(counter, gridDim.x, &s_flag)) {
+        const float t = hm_last_block_sum(partials, B, 1, red);
+        if (threadIdx.x == 0) out[0] = t * inv_cnt;
+    }
+}
+
+// Contact loss, object side.  grid (ceil(Vo/256), B): the gradient of an object vertex is minus the sum of the
+// gradients of the hand vertices that picked it.  Every wave scans the frame's nearest-neighbour list 64 entries at
+// a time (lane l holds entry c*64+l, broadcast with v_readlane) and accumulates matches in hand-vertex order: a
+// deterministic scatter without atomics.
+__global__ __launch_bounds__(NN_THREADS) void k_contact_obj(const int* __restrict__ nn_idx, const float* __restrict__ g_hand,
+                                                             int B, int Vh, int Vo, float* __restrict__ g_obj)
+{
+    const int b = blockIdx.y, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * NN_THREADS + threadIdx.x;
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int i = 0; i < Vh; ++i)
-        if (s_idx[i] == j) {
-            float pull[3];
-            contact_pull(vh + ((long)b * Vh + i) * 3, o, thresh, inv_cnt, pull, nullptr);
-            gx += pull[0]; gy += pull[1]; gz += pull[2];
+    for (int c0 = 0; c0 < Vh; c0 += 64) {
+        const int mine = (c0 + lane < Vh) ? nn_idx[(long)b * Vh + c0 + lane] : -1;
+        const int n = min(64, Vh - c0);
+        for (int k = 0; k < n; ++k) {
+            const int id = __builtin_amdgcn_readlane(mine, k);
+            if (id == j) {
+                const float* gh = g_hand + ((long)b * Vh + c0 + k) * 3;
+                gx -= gh[0]; gy -= gh[1]; gz -= gh[2];
+            }
         }
-    float* go = g_obj + ((long)b * Vo + j) * 3;
-    go[0] = gx; go[1] = gy; go[2] = gz;
+    }
+    if (j < Vo) {
+        float* go = g_obj + ((long)b * Vo + j) * 3;
+        go[0] = gx; go[1] = gy; go[2] = gz;
+    }
 }
 
 extern "C" {
@@ -150,10 +151,11 @@ int hm_contact_fwd(const float* verts_hand, const float* verts_obj, const int* n
                    float thresh, float* g_hand, float* g_obj, float* out1, void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(verts_hand && verts_obj && nn_idx && g_hand && g_obj && out1 && workspace);
-    HM_CHECK_ARG(B > 0 && B <= 512 && Vh > 0 && Vo > 0 && (size_t)Vh * 16 <= 60000);
-    hipLaunchKernelGGL(k_contact, dim3(1 + hm_cdiv(Vo, NN_THREADS), B), dim3(NN_THREADS), (size_t)Vh * sizeof(int), stream, verts_hand, verts_obj,
-                       nn_idx, B, Vh, Vo, thresh, g_hand, g_obj, (float*)workspace,
-                       (unsigned int*)((float*)workspace + 512), out1);
+    HM_CHECK_ARG(B > 0 && B <= 512 && Vh > 0 && Vo > 0);
+    hipLaunchKernelGGL(k_contact_hand, dim3(B), dim3(NN_THREADS), 0, stream, verts_hand, verts_obj, nn_idx, B, Vh, Vo,
+                       thresh, g_hand, (float*)workspace, (unsigned int*)((float*)workspace + 512), out1);
+    hipLaunchKernelGGL(k_contact_obj, dim3(hm_cdiv(Vo, NN_THREADS), B), dim3(NN_THREADS), 0, stream, nn_idx, g_hand, B, Vh,
+                       Vo, g_obj);
     return hm_launch_status();
 }
 }  // extern "C"

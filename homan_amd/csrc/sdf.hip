@@ -93,7 +93,7 @@ __device__ __forceinline__ float voxel_centre(int i) { return -1.0f + ((float)i 
 __global__ __launch_bounds__(SDF_THREADS) void k_sdf_boxes(const float* __restrict__ v0, int V0, const float* __restrict__ v1,
                                                             int V1, int B, float scale_factor, float* __restrict__ boxes,
                                                             float* __restrict__ vn0, float* __restrict__ vn1,
-                                                            unsigned int* __restrict__ masks)
+                                                            unsigned int* __restrict__ masks, float* __restrict__ phi_cache)
 {
     __shared__ float red[16];
     const int b = blockIdx.x, k = blockIdx.y;
@@ -120,6 +120,8 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_boxes(const float* __restri
         for (int c = 0; c < 3; ++c) vn[3 * i + c] = (v[3 * i + c] - ctr[c]) / sc;
     unsigned int* mk = masks + ((long)k * B + b) * (SDF_N * SDF_N);      // XOR-accumulated by the sign pass
     for (int i = threadIdx.x; i < SDF_N * SDF_N; i += blockDim.x) mk[i] = 0u;
+    float4* pc = reinterpret_cast<float4*>(phi_cache + ((long)k * B + b) * (SDF_N * SDF_N * SDF_N));
+    for (int i = threadIdx.x; i < SDF_N * SDF_N * SDF_N / 4; i += blockDim.x) pc[i] = make_float4(-1.f, -1.f, -1.f, -1.f);
 }
 
 // ------------------------------------------------------------------ sign pass.  grid (N*N/256, B, chunks0+chunks1)
@@ -192,7 +194,8 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(
     const float* __restrict__ v0, const float* __restrict__ vn0, const int* __restrict__ f0, int V0, int F0,
     const float* __restrict__ v1, const float* __restrict__ vn1, const int* __restrict__ f1, int V1, int F1, int B,
     const float* __restrict__ boxes, const unsigned int* __restrict__ masks, float* __restrict__ g0,
-    float* __restrict__ g1, float* __restrict__ partials, unsigned int* counter, float* __restrict__ out)
+    float* __restrict__ g1, float* __restrict__ partials, unsigned int* counter, float* __restrict__ out,
+    float* __restrict__ phi_cache)
 {
     __shared__ float red[16];
     __shared__ int s_flag;
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(
     const int* fk = k == 0 ? f0 : f1;
     const float* bx = boxes + ((long)k * B + b) * 4;
     const unsigned int* mk = masks + ((long)k * B + b) * (SDF_N * SDF_N);
+    float* phik = phi_cache + ((long)k * B + b) * (SDF_N * SDF_N * SDF_N);
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * SDF_THREADS + threadIdx.x;
     const bool live = i < Vl;
@@ -240,23 +244,35 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(
             bal &= bal - 1;
             const int xx = __shfl(x0, t, 64) + (c & 1), yy = __shfl(y0, t, 64) + ((c >> 1) & 1), zz = __shfl(z0, t, 64) + (c >> 2);
             const float ctr[3] = {voxel_centre(xx), voxel_centre(yy), voxel_centre(zz)};
-            float dmin = 1e30f;
-            for (int f = lane; f < Fk; f += 64) {
-                const int* tr = fk + 3 * f;
-                const float *q1 = vnk + 3 * tr[0], *q2 = vnk + 3 * tr[1], *q3 = vnk + 3 * tr[2];
-                // distance to the triangle's bounding box bounds the distance to the triangle from below; a triangle
-                // that cannot beat this lane's current minimum is skipped (the minimum itself is unchanged)
-                float lb2 = 0.f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float lo = fminf(q1[c], fminf(q2[c], q3[c])), hi = fmaxf(q1[c], fmaxf(q2[c], q3[c]));
-                    const float dd = fmaxf(fmaxf(lo - ctr[c], ctr[c] - hi), 0.f);
-                    lb2 += dd * dd;
+            const long cache_at = (long)(zz * SDF_N + yy) * SDF_N + xx;
+            float dmin = phik[cache_at];            // per-iteration cache of already evaluated voxels (-1 = not yet)
+            if (dmin < 0.f) {
+                // seed: the distance to the nearest mesh vertex bounds the distance to the surface from above
+                dmin = 1e30f;
+                for (int v = lane; v < Vk; v += 64) {
+                    const float dx = vnk[3 * v] - ctr[0], dy = vnk[3 * v + 1] - ctr[1], dz = vnk[3 * v + 2] - ctr[2];
+                    dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
                 }
-                if (lb2 * 0.9999f > dmin * dmin) continue;
-                dmin = fminf(dmin, point_triangle_distance(ctr, q1, q2, q3));
+                dmin = sqrtf(hm_wave_min(dmin)) * 1.0001f;
+                int it = 0;
+                for (int f = lane; f < Fk; f += 64, ++it) {
+                    const int* tr = fk + 3 * f;
+                    const float *q1 = vnk + 3 * tr[0], *q2 = vnk + 3 * tr[1], *q3 = vnk + 3 * tr[2];
+                    // distance to the triangle's bounding box bounds the distance to the triangle from below; a
+                    // triangle that cannot beat the current minimum is skipped (the minimum itself is unchanged)
+                    float lb2 = 0.f;
+#pragma unroll
+                    for (int cc = 0; cc < 3; ++cc) {
+                        const float lo = fminf(q1[cc], fminf(q2[cc], q3[cc])), hi = fmaxf(q1[cc], fmaxf(q2[cc], q3[cc]));
+                        const float dd = fmaxf(fmaxf(lo - ctr[cc], ctr[cc] - hi), 0.f);
+                        lb2 += dd * dd;
+                    }
+                    if (lb2 * 0.9999f <= dmin * dmin) dmin = fminf(dmin, point_triangle_distance(ctr, q1, q2, q3));
+                    if ((it & 7) == 7) dmin = hm_wave_min(dmin);     // share the bound across the lanes
+                }
+                dmin = hm_wave_min(dmin);
+                if (lane == 0) phik[cache_at] = dmin;
             }
-            dmin = hm_wave_min(dmin);
             if (lane == t) phi[c] = dmin;
         }
     }
@@ -321,10 +337,11 @@ size_t hm_collision_workspace_bytes(int B, int V0, int V1)
     n += al256s((size_t)2 * B * SDF_N * SDF_N * 4);          // masks
     n += al256s((size_t)2 * B * (hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS)) * 4 + 256);  // partials
     n += 256;                                                // counter (zero-initialised by the caller once)
+    n += al256s((size_t)2 * B * SDF_N * SDF_N * SDF_N * 4);  // per-iteration cache of evaluated voxel distances
     return n;
 }
 
-struct CollWs { float* boxes; float* vn0; float* vn1; unsigned int* masks; float* partials; unsigned int* counter; };
+struct CollWs { float* boxes; float* vn0; float* vn1; unsigned int* masks; float* partials; unsigned int* counter; float* phi_cache; };
 static CollWs coll_carve(void* ws, int B, int V0, int V1)
 {
     char* p = (char*)ws;
@@ -334,7 +351,8 @@ static CollWs coll_carve(void* ws, int B, int V0, int V1)
     w.vn1 = (float*)p; p += al256s((size_t)B * V1 * 3 * 4);
     w.masks = (unsigned int*)p; p += al256s((size_t)2 * B * SDF_N * SDF_N * 4);
     w.partials = (float*)p; p += al256s((size_t)2 * B * (hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS)) * 4 + 256);
-    w.counter = (unsigned int*)p;
+    w.counter = (unsigned int*)p; p += 256;
+    w.phi_cache = (float*)p;
     return w;
 }
 
@@ -348,13 +366,13 @@ int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, con
     HM_CHECK_ARG(B > 0 && V0 > 0 && V1 > 0 && F0 > 0 && F1 > 0);
     CollWs w = coll_carve(workspace, B, V0, V1);
     hipLaunchKernelGGL(k_sdf_boxes, dim3(B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, scale_factor,
-                       w.boxes, w.vn0, w.vn1, w.masks);
+                       w.boxes, w.vn0, w.vn1, w.masks, w.phi_cache);
     const int chunks0 = hm_cdiv(F0, SDF_THREADS), chunks1 = hm_cdiv(F1, SDF_THREADS);
     hipLaunchKernelGGL(k_sdf_parity, dim3(SDF_N * SDF_N / SDF_THREADS, B, chunks0 + chunks1), dim3(SDF_THREADS), 0, stream,
                        w.vn0, faces0, V0, F0, w.vn1, faces1, V1, F1, B, chunks0, w.masks);
     const int chunks = hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS);
     hipLaunchKernelGGL(k_sdf_sample, dim3(chunks, B, 2), dim3(SDF_THREADS), 0, stream, verts0, w.vn0, faces0, V0, F0,
-                       verts1, w.vn1, faces1, V1, F1, B, w.boxes, w.masks, g0, g1, w.partials, w.counter, out1);
+                       verts1, w.vn1, faces1, V1, F1, B, w.boxes, w.masks, g0, g1, w.partials, w.counter, out1, w.phi_cache);
     return hm_launch_status();
 }
 
