@@ -973,32 +973,48 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
     return hm_launch_status();
 }
 
-// Measurement hook for bench.py: runs the setup once, then `reps` launches of k_raster_fwd alone between two
-// HIP events recorded on `stream`, and stores the average launch duration in *avg_ms (host pointer).  Synchronises.
-int hm_bench_raster_fwd(const float* verts, const int* faces, const float* K, int B, int V, int F, int S,
-                        const float* keep, const float* ref, const float* keep_sum, float* pooled, float* loss_out,
-                        const short* region_order, void* workspace, int reps, float* avg_ms, hipStream_t stream)
+// Measurement hook for bench.py: runs one full forward + backward (fused-loss mode, upstream = 1) to populate the
+// workspace, then `reps` launches of k_raster_fwd alone and `reps` launches of k_bwd_sweep alone, each bracketed by two
+// HIP events recorded on `stream`; avg_ms[0] / avg_ms[1] (HOST pointer) receive the average launch durations in
+// milliseconds.  Synchronises.
+int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, int B, int V, int F, int S,
+                         const float* keep, const float* ref, const float* keep_sum, float* pooled, float* loss_out,
+                         const short* region_order, const int* adj_off, const int* adj_items, const float* upstream,
+                         float* grad_verts, void* workspace, int reps, float* avg_ms, hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && keep && ref && keep_sum && pooled && loss_out && workspace && reps > 0 && avg_ms);
+    HM_CHECK_ARG(adj_off && adj_items && upstream && grad_verts);
     int rc = hm_sil_fwd(verts, faces, 0, K, B, V, F, S, 1.0f, 0.1f, 100.0f, keep, ref, keep_sum, pooled, loss_out,
                         region_order, workspace, stream);
+    if (rc != HM_OK) return rc;
+    rc = hm_sil_bwd(verts, K, B, V, F, S, 1.0f, 1e-3f, 1, upstream, nullptr, keep_sum, adj_off, adj_items, grad_verts,
+                    nullptr, workspace, stream);
     if (rc != HM_OK) return rc;
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return HM_ERR_LAUNCH;
-    hipEventRecord(e0, stream);
+    float ms = 0.f;
+    (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL(k_raster_fwd, dim3(B, ntiles / RASTER_WAVES), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                            w.partials, region_order, w.owned);
-    hipEventRecord(e1, stream);
-    hipEventSynchronize(e1);
-    float ms = 0.f;
-    hipEventElapsedTime(&ms, e0, e1);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    *avg_ms = ms / (float)reps;
+    (void)hipEventRecord(e1, stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    avg_ms[0] = ms / (float)reps;
+    (void)hipEventRecord(e0, stream);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), 2048)), dim3(256), 0, stream, w.faces9,
+                           w.boxes, w.idx_map, w.gimg, w.rowneg, w.colneg, B, F, S, 1e-3f, w.parts, (float*)nullptr,
+                           w.owned);
+    (void)hipEventRecord(e1, stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    avg_ms[1] = ms / (float)reps;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return hm_launch_status();
 }
 

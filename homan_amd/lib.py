@@ -18,7 +18,8 @@ _SIGNATURES = {
     "hm_sil_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "hm_sil_fwd": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_sil_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "hm_bench_raster_fwd": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP]),
+    "hm_bench_sil_kernels": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I,
+                                  _VP, _VP]),
     "hm_debug_occupancy": (_I, [_VP, _VP]),
     "hm_debug_read_partials": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_debug_set_sweep_buffer": (None, [_VP]),

@@ -151,11 +151,13 @@ int hm_log_total(float* vals, const float* weights, int n, const int* step, int 
 int hm_log_scalars(const float* src, int n, const int* step, int max_steps, float* log, hipStream_t stream);
 
 /* ------------------------------------------------------------------ measurement / debug hooks (synchronous)
- * hm_bench_raster_fwd: runs the forward set-up once, then `reps` launches of the raster kernel between two HIP
- * events on `stream`; *avg_ms (HOST pointer) receives the average launch duration in milliseconds. */
-int hm_bench_raster_fwd(const float* verts, const int* faces, const float* K, int B, int V, int F, int S,
-                        const float* keep, const float* ref, const float* keep_sum, float* pooled, float* loss_out,
-                        const short* region_order, void* workspace, int reps, float* avg_ms, hipStream_t stream);
+ * hm_bench_sil_kernels: one full silhouette forward + backward to populate the workspace, then `reps` launches of the
+ * raster kernel and `reps` launches of the edge-sweep kernel, each bracketed by two HIP events on `stream`;
+ * avg_ms[0..1] (HOST pointer) receive the average launch durations in milliseconds. */
+int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, int B, int V, int F, int S,
+                         const float* keep, const float* ref, const float* keep_sum, float* pooled, float* loss_out,
+                         const short* region_order, const int* adj_off, const int* adj_items, const float* upstream,
+                         float* grad_verts, void* workspace, int reps, float* avg_ms, hipStream_t stream);
 int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks);
 int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
 void hm_debug_set_sweep_buffer(float* p);
