@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--step2", action="store_true", help="cfg3: add lw_collision / lw_contact")
     ap.add_argument("--loop", choices=["fused", "graph"], default="fused",
                     help="fused: fixed C-ABI launch sequence (no autograd tape); graph: HOMan.forward + autograd")
+    ap.add_argument("--multi-clip", type=int, default=8,
+                    help="rank 0, N=1 only: after the headline run, also time this many clips optimised concurrently "
+                         "on one GPU (one hipGraph + stream per clip; BASELINE cfg4 has 8 clips per GPU); 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -104,10 +107,16 @@ def main():
     from homan_amd.mano_assets import synthetic_mano
 
     assert torch.cuda.is_available(), "bench.py measures the HIP path; no GPU visible"
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    torch.cuda.set_device(local_rank % ndev)
+    backend = os.environ.get("HOMAN_BENCH_BACKEND", "nccl")     # "gloo" only to exercise the N>1 path on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            assert world <= ndev, f"{world} ranks but {ndev} GPUs visible"
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     mano = synthetic_mano(0)
     sil_fn, hand_fn = synth.hip_clip_fns(mano)
@@ -134,7 +143,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
 
@@ -180,6 +189,37 @@ def main():
                     whole_iteration=dict(algorithmic_bytes=tot, achieved_GBps=tot * (args.steps / elapsed) / 1e9,
                                          frac=tot * (args.steps / elapsed) / 8.0e12))
 
+    multi = None
+    if rank == 0 and world == 1 and args.multi_clip > 1:
+        C, msteps = args.multi_clip, min(args.steps, 200)
+        steppers, streams = [stepper], [torch.cuda.Stream()]
+        for i in range(1, C):
+            ci = synth.make_clip(seed=1000 + i, frames=args.frames, rend_size=args.size, image_size=args.size,
+                                 obj="bottle", silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+            mi = build_model(copy.deepcopy(ci["person_parameters"]), copy.deepcopy(ci["object_parameters"]),
+                             objvertices=ci["objvertices"], objfaces=ci["objfaces"], camintr=ci["camintr"],
+                             optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
+                             sync_metrics=False)
+            steppers.append(FusedStepper(mi, lw, 1e-2, msteps + 10))
+            streams.append(torch.cuda.Stream())
+        steppers[0] = FusedStepper(model, lw, 1e-2, msteps + 10)       # fresh log buffer for clip 0
+
+        def round_robin(n):
+            for _ in range(n):
+                for st, sm in zip(steppers, streams):
+                    with torch.cuda.stream(sm):
+                        st.graph.replay()
+        torch.cuda.synchronize()
+        round_robin(10)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        round_robin(msteps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        multi = dict(clips=C, steps_per_clip=msteps, value=C * msteps / el, unit="it/s (sum over clips)",
+                     ms_per_round=1e3 * el / msteps,
+                     note="independent clips, one captured hipGraph per clip replayed round-robin on its own HIP stream")
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(clip, lw, mano, args.cpu_budget, rend_size=S, image_size=S)
@@ -196,7 +236,7 @@ def main():
                        "frames": B, "rend_size": S, "faces": int(F), "clips_per_gpu": 1,
                        "loop": ("fused C-ABI launch sequence" if args.loop == "fused" else "HOMan.forward + autograd") + ", forward+backward+Adam+logging replayed from a hipGraph", "parallelism": f"{world} independent clips"},
             "final_loss": evo["loss"][-1], "first_loss": evo["loss"][0],
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "multi_clip": multi,
         }
         print(json.dumps(line))
     if world > 1:
