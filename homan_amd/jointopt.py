@@ -262,6 +262,9 @@ class FusedStepper:
         self.max_steps = max_steps
         self.mctx = m.mano_model.ctx_mean
         self.graph = None
+        self.side = torch.cuda.Stream()
+        self.ev_vo, self.ev_pair = torch.cuda.Event(), torch.cuda.Event()
+        self.reduce_ws_b = ops.ReduceWorkspace(dev)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -286,84 +289,101 @@ class FusedStepper:
         return self.vals.data_ptr() + 4 * i
 
     def forward_backward(self, log=False):
-        m, L, P, st, ck = self.model, self.L, _lib.ptr, _lib.stream(), _lib.check
+        """Two concurrent branches (fork/join on HIP streams, captured as parallel branches of the hipGraph):
+        A (calling stream): object transform, silhouettes forward/backward, object gradients;
+        B (side stream):    MANO, hand transform, priors, 2-D / smoothness / collision / contact / interaction losses,
+                            hand gradients, MANO backward.
+        B waits for the object vertices before the pair-wise losses, A waits for B's object-side gradient terms, both
+        join before the log row and the Adam step."""
+        m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
         B, Vo, Vh, c, on, w = self.B, self.Vo, self.Vh, self.c, self.on, self.w
-        rws = P(m.reduce_ws.buf)
+        main = torch.cuda.current_stream()
+        side = self.side
+        sa, sb = main.cuda_stream, side.cuda_stream
+        rws_a, rws_b = P(m.reduce_ws.buf), P(self.reduce_ws_b.buf)
         sctx, cctx = m.losses.sil_ctx, m.collision_ctx
         pca, rot, betas, mtr = m.mano_pca_pose, m.mano_rot, m.mano_betas, m.mano_trans
-        # ---------------- forward
+        side.wait_stream(main)
+        # ---------------- A: object forward
         ck(L.hm_rigid_fwd(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object), P(m.int_scales_object),
-                          1, B, Vo, None, P(self.vo), st), "rigid_fwd(obj)")
-        ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None, st), "mano_fwd")
-        ck(L.hm_rigid_fwd(P(self.vm), P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), 0, B, Vh, None,
-                          P(self.vh), st), "rigid_fwd(hand)")
-        if on["pca"] or on["so"] or on["sh"]:
-            ck(L.hm_priors_fwd(P(pca), pca.numel(), P(m.int_scales_object), P(m.int_scale_object_mean),
-                               P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh),
-                               self._slot("loss_pca"), st), "priors")
+                          1, B, Vo, None, P(self.vo), sa), "rigid_fwd(obj)")
+        self.ev_vo.record(main)
         if on["smooth"]:
-            ck(L.hm_smooth_fwd(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws, st), "smooth(obj)")
-            ck(L.hm_smooth_fwd(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws, st), "smooth(hand)")
-        if on["col"]:
-            ck(L.hm_collision_fwd(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
-                                  cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
-                                  self._slot("loss_collision"), P(cctx.ws), st), "collision")
-        if on["con"] or on["inter"]:
-            ck(L.hm_nn_fwd(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx), P(self.nn_d2),
-                           self._slot("handobj_maxdist"), rws, st), "nn")
-        if on["con"]:
-            ck(L.hm_contact_fwd(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH, P(self.U_conh),
-                                P(self.U_cono), self._slot("loss_contact"), rws, st), "contact")
-        if on["v2d"]:
-            ck(L.hm_v2d_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
-                            P(self.U_v2d), self._slot("loss_v2d_hand"), rws, st), "v2d")
+            ck(L.hm_smooth_fwd(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_a, sa), "smooth(obj)")
         if on["sil"]:
             ck(L.hm_sil_fwd(P(self.vo), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
                             self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
                             P(m.losses.keep_sum), P(self.pooled), self._slot("loss_sil_obj"), P(sctx.region_order),
-                            P(sctx.workspace), st), "sil_fwd")
-        if on["inter"]:
-            ck(L.hm_inter_fwd(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
-                              float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws, st), "inter")
-        if log:
-            ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
-                              P(self.log_buf), st), "log")
-        # ---------------- backward
-        if on["sil"]:
+                            P(sctx.workspace), sa), "sil_fwd")
             ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS, 1,
                             P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
-                            P(self.G_sil), None, P(sctx.workspace), st), "sil_bwd")
-        if on["inter"]:
-            ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, P(self.G_int_h),
-                              P(self.G_int_o) if m.optimize_object_scale else None, st), "inter_bwd")
-        # object: smooth + contact + silhouette (+ interaction when the scale is optimised, homan.py:484-487)
+                            P(self.G_sil), None, P(sctx.workspace), sa), "sil_bwd")
+        # ---------------- B: hand forward, pair-wise losses, hand backward
+        with torch.cuda.stream(side):
+            ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None, sb), "mano_fwd")
+            ck(L.hm_rigid_fwd(P(self.vm), P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), 0, B, Vh,
+                              None, P(self.vh), sb), "rigid_fwd(hand)")
+            if on["pca"] or on["so"] or on["sh"]:
+                ck(L.hm_priors_fwd(P(pca), pca.numel(), P(m.int_scales_object), P(m.int_scale_object_mean),
+                                   P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
+                                   P(self.U_sh), self._slot("loss_pca"), sb), "priors")
+            if on["smooth"]:
+                ck(L.hm_smooth_fwd(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws_b, sb),
+                   "smooth(hand)")
+            if on["v2d"]:
+                ck(L.hm_v2d_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
+                                P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, sb), "v2d")
+            side.wait_event(self.ev_vo)
+            if on["col"]:
+                ck(L.hm_collision_fwd(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
+                                      cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
+                                      self._slot("loss_collision"), P(cctx.ws), sb), "collision")
+            if on["con"] or on["inter"]:
+                ck(L.hm_nn_fwd(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx), P(self.nn_d2),
+                               self._slot("handobj_maxdist"), rws_b, sb), "nn")
+            if on["con"]:
+                ck(L.hm_contact_fwd(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
+                                    P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws_b, sb), "contact")
+            if on["inter"]:
+                ck(L.hm_inter_fwd(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
+                                  float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws_b, sb),
+                   "inter")
+                ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, P(self.G_int_h),
+                                  P(self.G_int_o) if m.optimize_object_scale else None, sb), "inter_bwd")
+            self.ev_pair.record(side)        # object-side terms of the pair-wise losses are ready
+            # hand (full path: MANO + rigid): smooth + v2d + collision + contact; interaction reaches the rigid pose only
+            ck(L.hm_lincomb4(P(self.U_smh) if on["smooth"] else None, w["loss_smooth_hand"],
+                             P(self.U_v2d) if on["v2d"] else None, w["loss_v2d_hand"],
+                             P(self.U_colh) if on["col"] else None, w["loss_collision"],
+                             P(self.U_conh) if on["con"] else None, w["loss_contact"],
+                             B * Vh * 3, P(self.G_h), sb), "lincomb(hand)")
+            ck(L.hm_rigid_bwd(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, P(self.G_h),
+                              P(self.G_int_h) if on["inter"] else None, B, Vh, P(self.G_mesh),
+                              P(m.rotations_hand.grad), P(m.translations_hand.grad), None, sb), "rigid_bwd(hand)")
+            ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
+                             P(self.g_pca_mano) if on["pca"] else P(pca.grad), P(rot.grad), P(betas.grad), P(mtr.grad),
+                             P(self.mctx.workspace(B)), sb), "mano_bwd")
+            if on["pca"]:
+                ck(L.hm_lincomb4(P(self.g_pca_mano), 1.0, P(self.U_pca), w["loss_pca"], None, 0.0, None, 0.0,
+                                 pca.numel(), P(pca.grad), sb), "lincomb(pca)")
+        # ---------------- A: object backward (smooth + contact + silhouette [+ interaction when the scale is optimised])
+        main.wait_event(self.ev_pair)
         ck(L.hm_lincomb4(P(self.U_smo) if on["smooth"] else None, w["loss_smooth_obj"],
                          P(self.U_cono) if on["con"] else None, w["loss_contact"],
                          P(self.G_sil) if on["sil"] else None, 1.0,
                          P(self.G_int_o) if (on["inter"] and m.optimize_object_scale) else None, 1.0,
-                         B * Vo * 3, P(self.G_o), st), "lincomb(obj)")
-        # hand (full path: MANO + rigid): smooth + v2d + collision + contact ; interaction reaches the rigid pose only
-        ck(L.hm_lincomb4(P(self.U_smh) if on["smooth"] else None, w["loss_smooth_hand"],
-                         P(self.U_v2d) if on["v2d"] else None, w["loss_v2d_hand"],
-                         P(self.U_colh) if on["col"] else None, w["loss_collision"],
-                         P(self.U_conh) if on["con"] else None, w["loss_contact"],
-                         B * Vh * 3, P(self.G_h), st), "lincomb(hand)")
+                         B * Vo * 3, P(self.G_o), sa), "lincomb(obj)")
         sc_obj = m.optimize_object_scale
         ck(L.hm_rigid_bwd(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, P(self.G_o), None, B,
                           Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
-                          P(self.g_so_part) if sc_obj else None, st), "rigid_bwd(obj)")
-        ck(L.hm_rigid_bwd(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, P(self.G_h),
-                          P(self.G_int_h) if on["inter"] else None, B, Vh, P(self.G_mesh), P(m.rotations_hand.grad),
-                          P(m.translations_hand.grad), None, st), "rigid_bwd(hand)")
-        ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
-                         P(self.g_pca_mano) if on["pca"] else P(pca.grad), P(rot.grad), P(betas.grad), P(mtr.grad),
-                         P(self.mctx.workspace(B)), st), "mano_bwd")
-        if on["pca"]:
-            ck(L.hm_lincomb4(P(self.g_pca_mano), 1.0, P(self.U_pca), w["loss_pca"], None, 0.0, None, 0.0, pca.numel(),
-                             P(pca.grad), st), "lincomb(pca)")
+                          P(self.g_so_part) if sc_obj else None, sa), "rigid_bwd(obj)")
+        main.wait_stream(side)               # join
         if sc_obj:
             ck(L.hm_sum_small(P(self.g_so_part), B, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
-                              P(m.int_scales_object.grad), st), "scale grad")
+                              P(m.int_scales_object.grad), sa), "scale grad")
+        if log:
+            ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
+                              P(self.log_buf), sa), "log")
 
     def run(self, steps):
         if self.graph is not None:
