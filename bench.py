@@ -167,8 +167,8 @@ def main():
         rc = hlib.lib().hm_bench_sil_kernels(
             hlib.ptr(verts), hlib.ptr(sctx.faces), hlib.ptr(model.camintr_rois_object), B, V, F, S,
             hlib.ptr(model.keep_mask_object), hlib.ptr(model.ref_mask_object), hlib.ptr(model.losses.keep_sum),
-            hlib.ptr(pooled), hlib.ptr(out2), hlib.ptr(sctx.region_order), hlib.ptr(sctx.adj_off),
-            hlib.ptr(sctx.adj_items), hlib.ptr(one), hlib.ptr(gv), hlib.ptr(sctx.workspace), reps, ms.data_ptr(),
+            hlib.ptr(pooled), hlib.ptr(out2), hlib.ptr(sctx.work_order), hlib.ptr(sctx.adj_off),
+            hlib.ptr(sctx.adj_items), hlib.ptr(sctx.face_order), hlib.ptr(one), hlib.ptr(gv), hlib.ptr(sctx.workspace), reps, ms.data_ptr(),
             hlib.stream())
         hlib.check(rc, "hm_bench_sil_kernels")
         kb = kernel_bytes(B, S, F)

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
-    float* __restrict__ partials, const short* __restrict__ region_order, unsigned char* __restrict__ owned)
+    float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned)
 {
     __shared__ int queue[RASTER_WAVES][192];
     __shared__ uint2 cand_box[CAND_CAP];
@@ -260,13 +260,15 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     __shared__ int cand_n;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int is = 2 * S, tiles_x = S / HM_TILE, ntiles = tiles_x * tiles_x, regions_x = tiles_x / 2;
-    // dispatch order: frame fastest, regions from the centre of the ROI outwards (the ROI is cut around the object,
-    // so the expensive regions start first and the cheap border regions fill the tail of the launch)
-    const int region = region_order ? (int)region_order[blockIdx.y] : (int)blockIdx.y;
+    // dispatch order = work_order[block] = (frame << 16 | region): expensive (frame, region) pairs first so that the
+    // cheap ones fill the tail of the launch (default: centre of the ROI outwards; calibrated: by candidate count)
+    const int regions = regions_x * regions_x;
+    const int wo = work_order ? work_order[blockIdx.x] : (int)(((blockIdx.x % B) << 16) | (blockIdx.x / B));
+    const int region = wo & 0xffff, b = wo >> 16;
+    (void)regions;
     const int rx = region % regions_x, ry = region / regions_x;
     const int tx = 2 * rx + (w & 1), ty = 2 * ry + (w >> 1);
     const int tile = ty * tiles_x + tx;
-    const int b = blockIdx.x;
     int* q = queue[w];
 #if HM_RASTER_DBG == 3
     const unsigned long long t_start = wall_clock64();
@@ -558,7 +560,8 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
                                                    const unsigned short* __restrict__ rowneg,
                                                    const unsigned short* __restrict__ colneg, int B, int F, int S,
                                                    float eps, float* __restrict__ parts, float* __restrict__ dbg,
-                                                   const unsigned char* __restrict__ owned)
+                                                   const unsigned char* __restrict__ owned,
+                                                   const int* __restrict__ face_order)
 {
     __shared__ float s_cb[4][6][12];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -568,8 +571,10 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
     const int wpl = is / 64;                    // 64-bit mask words per line
     const long plane_words = (long)B * is * wpl;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    for (long bf = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-         bf < (long)B * F; bf += nwaves) {
+    for (long slot = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+         slot < (long)B * F; slot += nwaves) {
+        // faces are visited in `face_order` (expensive faces first, dealt round-robin to the persistent waves)
+        const long bf = face_order ? (long)face_order[slot] : slot;
         const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
         int dbg_items = 0, dbg_bits = 0, dbg_heavy = 0;
         const int b = (int)(bf / F), fi = (int)(bf % F);
@@ -929,7 +934,7 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 //   keep/ref/keep_sum/loss_out may be NULL (render only).  loss_out[0]=loss_sil, loss_out[1]=mean IoU.
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
-               const float* keep_sum, float* pooled, float* loss_out, const short* region_order, void* workspace,
+               const float* keep_sum, float* pooled, float* loss_out, const int* work_order, void* workspace,
                hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && pooled && workspace);
@@ -942,9 +947,9 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv((long)B * F, 256)), dim3(256), 0, stream, w.ndc, faces,
                        faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned);
     const bool fused = keep && ref && keep_sum && loss_out;
-    hipLaunchKernelGGL(k_raster_fwd, dim3(B, ntiles / RASTER_WAVES), dim3(64 * RASTER_WAVES), 0, stream,
+    hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                       fused ? w.partials : (float*)nullptr, region_order, w.owned);
+                       fused ? w.partials : (float*)nullptr, work_order, w.owned);
     if (fused)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            w.counter, loss_out);
@@ -956,7 +961,8 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
 // adjacency (CSR over V) describes the shared face topology.  grad_verts (B,V,3) is overwritten.
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
-               const int* adj_items, float* grad_verts, float* grad_ndc, void* workspace, hipStream_t stream)
+               const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
+               hipStream_t stream)
 {
     HM_CHECK_ARG(verts && K && adj_off && adj_items && grad_verts && workspace);
     HM_CHECK_ARG(mode == 0 ? grad_pooled != nullptr : (upstream && keep_sum));
@@ -967,7 +973,7 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
                        mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                        w.rowneg, w.colneg);
     hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), 2048)), dim3(256), 0, stream, w.faces9, w.boxes,
-                       w.idx_map, w.gimg, w.rowneg, w.colneg, B, F, S, eps, w.parts, g_sweep_dbg, w.owned);
+                       w.idx_map, w.gimg, w.rowneg, w.colneg, B, F, S, eps, w.parts, g_sweep_dbg, w.owned, face_order);
     hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                        adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
     return hm_launch_status();
@@ -979,16 +985,17 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
 // milliseconds.  Synchronises.
 int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, int B, int V, int F, int S,
                          const float* keep, const float* ref, const float* keep_sum, float* pooled, float* loss_out,
-                         const short* region_order, const int* adj_off, const int* adj_items, const float* upstream,
-                         float* grad_verts, void* workspace, int reps, float* avg_ms, hipStream_t stream)
+                         const int* work_order, const int* adj_off, const int* adj_items, const int* face_order,
+                         const float* upstream, float* grad_verts, void* workspace, int reps, float* avg_ms,
+                         hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && keep && ref && keep_sum && pooled && loss_out && workspace && reps > 0 && avg_ms);
     HM_CHECK_ARG(adj_off && adj_items && upstream && grad_verts);
     int rc = hm_sil_fwd(verts, faces, 0, K, B, V, F, S, 1.0f, 0.1f, 100.0f, keep, ref, keep_sum, pooled, loss_out,
-                        region_order, workspace, stream);
+                        work_order, workspace, stream);
     if (rc != HM_OK) return rc;
-    rc = hm_sil_bwd(verts, K, B, V, F, S, 1.0f, 1e-3f, 1, upstream, nullptr, keep_sum, adj_off, adj_items, grad_verts,
-                    nullptr, workspace, stream);
+    rc = hm_sil_bwd(verts, K, B, V, F, S, 1.0f, 1e-3f, 1, upstream, nullptr, keep_sum, adj_off, adj_items, face_order,
+                    grad_verts, nullptr, workspace, stream);
     if (rc != HM_OK) return rc;
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
@@ -997,9 +1004,9 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     float ms = 0.f;
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(k_raster_fwd, dim3(B, ntiles / RASTER_WAVES), dim3(64 * RASTER_WAVES), 0, stream,
+        hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                           w.partials, region_order, w.owned);
+                           w.partials, work_order, w.owned);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -1008,7 +1015,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), 2048)), dim3(256), 0, stream, w.faces9,
                            w.boxes, w.idx_map, w.gimg, w.rowneg, w.colneg, B, F, S, 1e-3f, w.parts, (float*)nullptr,
-                           w.owned);
+                           w.owned, face_order);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -1037,6 +1044,12 @@ int hm_sil_read_idx_map(const void* workspace, int B, int V, int F, int S, int* 
     SilWs w = carve((void*)workspace, B, V, F, S);
     return hipMemcpyAsync(out, w.idx_map, (size_t)B * 4 * S * S * 4, hipMemcpyDeviceToDevice, stream) == hipSuccess
                ? HM_OK : HM_ERR_LAUNCH;
+}
+int hm_sil_read_boxes(const void* workspace, int B, int V, int F, int S, void* out, hipStream_t stream)
+{
+    SilWs w = carve((void*)workspace, B, V, F, S);
+    return hipMemcpyAsync(out, w.boxes, (size_t)B * F * 8, hipMemcpyDeviceToDevice, stream) == hipSuccess ? HM_OK
+                                                                                                         : HM_ERR_LAUNCH;
 }
 int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream)
 {

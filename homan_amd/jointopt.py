@@ -271,6 +271,8 @@ class FusedStepper:
             self.forward_backward()              # warm-up, no optimiser step
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        if self.on["sil"]:
+            m.losses.sil_ctx.calibrate()         # cost-sorted launch orders from the current state (scheduling only)
         if capture:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
@@ -313,11 +315,11 @@ class FusedStepper:
         if on["sil"]:
             ck(L.hm_sil_fwd(P(self.vo), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
                             self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
-                            P(m.losses.keep_sum), P(self.pooled), self._slot("loss_sil_obj"), P(sctx.region_order),
+                            P(m.losses.keep_sum), P(self.pooled), self._slot("loss_sil_obj"), P(sctx.work_order),
                             P(sctx.workspace), sa), "sil_fwd")
             ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS, 1,
                             P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
-                            P(self.G_sil), None, P(sctx.workspace), sa), "sil_bwd")
+                            P(sctx.face_order), P(self.G_sil), None, P(sctx.workspace), sa), "sil_bwd")
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
             ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None, sb), "mano_fwd")

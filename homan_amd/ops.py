@@ -40,13 +40,47 @@ class SilhouetteContext:
         self.faces = faces[0].to(device=device, dtype=torch.int32).contiguous()
         off, items = build_adjacency(f0, num_verts)
         self.adj_off, self.adj_items = off.to(device), items.to(device)
-        # 32x32-sample regions ordered from the ROI centre outwards (dispatch order of the forward raster)
+        # dispatch order of the forward raster's (frame, 32x32-sample region) workgroups: default = regions from the
+        # ROI centre outwards, frame fastest; `calibrate()` replaces it by a cost-sorted order
         n = size // 16
         ry, rx = np.divmod(np.arange(n * n), n)
         ring = np.maximum(np.abs(2 * rx + 1 - n), np.abs(2 * ry + 1 - n))
-        self.region_order = torch.from_numpy(np.argsort(ring, kind="stable").astype(np.int16)).to(device)
+        regions = np.argsort(ring, kind="stable").astype(np.int64)
+        wo = (np.arange(batch, dtype=np.int64)[None, :] << 16) | regions[:, None]
+        self.work_order = torch.from_numpy(wo.reshape(-1).astype(np.int32)).to(device)
+        self.face_order = None
         nbytes = _lib.lib().hm_sil_workspace_bytes(self.B, self.V, self.F, self.S)
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # holds a self-resetting ticket
+
+    def calibrate(self):
+        """Cost-sorted launch orders from the screen boxes of the last forward (poses move little during an
+        optimisation, so the statistics of the current state predict the cost of the next iterations):
+        forward raster workgroups by descending candidate count.
+        Pure scheduling: results do not depend on the order."""
+        raw = torch.empty(self.B * self.F * 8, dtype=torch.uint8, device=self.workspace.device)
+        _lib.check(_lib.lib().hm_sil_read_boxes(_lib.ptr(self.workspace), self.B, self.V, self.F, self.S, _lib.ptr(raw),
+                                                _lib.stream()), "hm_sil_read_boxes")
+        bx = raw.cpu().numpy().view(np.uint16).reshape(self.B, self.F, 4).astype(np.int64)
+        valid = (bx[..., 0] >> 14) != 0
+        x0, y0, x1, y1 = bx[..., 0] & 0x3fff, bx[..., 1], bx[..., 2], bx[..., 3]
+        n, is_ = self.S // 16, 2 * self.S
+        # region index of a sample: columns x // 32 ; rows are flipped (tile row 0 holds the largest yi)
+        rx0, rx1 = x0 // 32, x1 // 32
+        ry0, ry1 = (is_ - 1 - y1) // 32, (is_ - 1 - y0) // 32
+        cnt = np.zeros((self.B, n + 1, n + 1), np.int64)
+        bi = np.broadcast_to(np.arange(self.B)[:, None], x0.shape)[valid]
+        a0, a1, c0, c1 = ry0[valid], ry1[valid] + 1, rx0[valid], rx1[valid] + 1
+        np.add.at(cnt, (bi, a0, c0), 1)
+        np.add.at(cnt, (bi, a1, c1), 1)
+        np.add.at(cnt, (bi, a0, c1), -1)
+        np.add.at(cnt, (bi, a1, c0), -1)
+        cnt = cnt.cumsum(1).cumsum(2)[:, :n, :n].reshape(self.B, n * n)
+        order = np.argsort(-cnt.reshape(-1), kind="stable")
+        b_idx, region = np.divmod(order, n * n)
+        self.work_order = torch.from_numpy(((b_idx << 16) | region).astype(np.int32)).to(self.workspace.device)
+        # (the edge sweeps keep the natural face order: sorting faces by box perimeter was measured slower -- it scatters
+        #  neighbouring faces, and with them the cache lines of the index map and the mask planes they share)
+        self.face_order = None
 
     def idx_map(self):
         out = torch.empty(self.B, 2 * self.S, 2 * self.S, dtype=torch.int32, device=self.workspace.device)
@@ -72,7 +106,7 @@ class _SilhouetteLoss(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, _lib.ptr(keep), _lib.ptr(ref), _lib.ptr(keep_sum),
-            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.region_order), _lib.ptr(sctx.workspace), _lib.stream()),
+            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.work_order), _lib.ptr(sctx.workspace), _lib.stream()),
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K, keep_sum)
         ctx.sctx, ctx.orig_size = sctx, orig_size
@@ -88,7 +122,7 @@ class _SilhouetteLoss(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_bwd(
             _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), NMR_EPS, 1,
             _lib.ptr(g_loss), None, _lib.ptr(keep_sum), _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
-            _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
+            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None, None, None, None
 
 
@@ -102,7 +136,7 @@ class _SilhouetteRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.region_order), _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
+            _lib.ptr(sctx.work_order), _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
         return pooled
@@ -116,7 +150,7 @@ class _SilhouetteRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_bwd(
             _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), NMR_EPS, 0,
             None, _lib.ptr(g_img), None, _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
-            _lib.ptr(grad_verts), _lib.ptr(sctx.grad_ndc) if getattr(sctx, "grad_ndc", None) is not None else None,
+            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), _lib.ptr(sctx.grad_ndc) if getattr(sctx, "grad_ndc", None) is not None else None,
             _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None
 

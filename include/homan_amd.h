@@ -81,21 +81,26 @@ int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const f
  *   K (B,3,3); pooled (B,S,S) silhouettes out.
  *   Fused loss (all four non-NULL): keep/ref (B,S,S), keep_sum (1) = sum(keep);
  *     loss_out[0] = sum((keep*sil - ref)^2) / keep_sum / B ; loss_out[1] = mean_b IoU_b   (losses.py:188-196).
- *   region_order: (S/16)^2 int16 permutation of the 32x32-sample regions giving the dispatch order, or NULL.
+ *   work_order: B*(S/16)^2 int32 entries (frame << 16 | region) = dispatch order of the (frame, 32x32-sample region)
+ *     workgroups (a permutation; expensive ones first), or NULL for frame-major order.
  *   S must be a multiple of 32, S <= 256 for the backward. */
 size_t hm_sil_workspace_bytes(int B, int V, int F, int S);
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
-               const float* keep_sum, float* pooled, float* loss_out, const short* region_order, void* workspace,
+               const float* keep_sum, float* pooled, float* loss_out, const int* work_order, void* workspace,
                hipStream_t stream);
 /* mode 1: upstream (1) = dL/d loss_out[0]; mode 0: grad_pooled (B,S,S) = dL/d pooled.  adj_off (V+1), adj_items (3F):
- * CSR vertex -> (face*3 + corner).  grad_verts (B,V,3) overwritten; grad_ndc (B,V,3) optional (d/d projected u,v). */
+ * CSR vertex -> (face*3 + corner).  face_order: B*F int32 permutation of frame*F+face (visiting order of the edge
+ * sweeps, expensive faces first) or NULL.  grad_verts (B,V,3) overwritten; grad_ndc (B,V,3) optional. */
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
-               const int* adj_items, float* grad_verts, float* grad_ndc, void* workspace, hipStream_t stream);
+               const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
+               hipStream_t stream);
 /* forward intermediates kept in the workspace (tests): face-index map (B,2S,2S) int32, packed NDC faces (B,F,9) */
 int hm_sil_read_idx_map(const void* workspace, int B, int V, int F, int S, int* out, hipStream_t stream);
 int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
+/* per-face screen boxes (B,F) x 8 bytes {x0|winding<<14, y0, x1, y1} u16 */
+int hm_sil_read_boxes(const void* workspace, int B, int V, int F, int S, void* out, hipStream_t stream);
 
 /* ------------------------------------------------------------------ small losses (value + unit gradient in one launch)
  * workspace for all of them: hm_reduce_workspace_bytes(), zero-filled once. */
@@ -156,8 +161,9 @@ int hm_log_scalars(const float* src, int n, const int* step, int max_steps, floa
  * avg_ms[0..1] (HOST pointer) receive the average launch durations in milliseconds. */
 int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, int B, int V, int F, int S,
                          const float* keep, const float* ref, const float* keep_sum, float* pooled, float* loss_out,
-                         const short* region_order, const int* adj_off, const int* adj_items, const float* upstream,
-                         float* grad_verts, void* workspace, int reps, float* avg_ms, hipStream_t stream);
+                         const int* work_order, const int* adj_off, const int* adj_items, const int* face_order,
+                         const float* upstream, float* grad_verts, void* workspace, int reps, float* avg_ms,
+                         hipStream_t stream);
 int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks);
 int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
 void hm_debug_set_sweep_buffer(float* p);
