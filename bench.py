@@ -79,6 +79,54 @@ def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256):
                 sample=f"{n} iterations of the same cfg2 clip ({el:.1f} s) after 1 warm-up, oracle loop with per-step .item() logging")
 
 
+def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
+    """cfg5: every rank optimises its clip with step-2 losses; the object scale is one scalar shared by all clips:
+    per step one all-reduce (sum) of its gradient, identical Adam update everywhere."""
+    import torch
+    import torch.distributed as dist
+    from homan_amd import dist as hdist
+    from homan_amd import synth
+    from homan_amd.jointopt import build_model, parameter_groups
+    clip = synth.make_clip(seed=rank, frames=args.frames, rend_size=args.size, image_size=args.size, obj="bottle",
+                           silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                        objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                        optimize_mano=True, optimize_object_scale=True, image_size=args.size, mano_model=mano,
+                        rend_size=args.size, sync_metrics=False)
+    opt = torch.optim.Adam(parameter_groups(model, 1e-2))
+    hdist.optimize_clips_shared_scale([model], [opt], lw, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    hist = hdist.optimize_clips_shared_scale([model], [opt], lw, args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = hdist.max_over_ranks(time.perf_counter() - t0, device="cuda" if backend == "nccl" else "cpu")
+    scale = model.int_scales_object.detach().cpu().reshape(-1)
+    if world > 1:
+        gathered = [torch.zeros_like(scale) for _ in range(world)]
+        dist.all_gather(gathered, scale if backend != "nccl" else scale.cuda())
+        same = all(torch.equal(g.cpu(), gathered[0].cpu()) for g in gathered)
+    else:
+        same = True
+    if rank == 0:
+        print(json.dumps({
+            "metric": "optimisation iters/sec (30-frame 256^2 clip)", "value": world * args.steps / elapsed,
+            "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg5: 1 clip/GPU x {args.frames} frames {args.size}x{args.size}, step-2 losses, "
+                                   "shared object scale (one 4-byte all-reduce per step), eager autograd loop",
+                       "parallelism": f"{world} clips, shared scalar"},
+            "shared_scale_final": float(scale[0]), "replicas_identical": bool(same),
+            "first_loss": hist[0][0], "final_loss": hist[-1][0]}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,6 +140,9 @@ def main():
     ap.add_argument("--multi-clip", type=int, default=8,
                     help="rank 0, N=1 only: after the headline run, also time this many clips optimised concurrently "
                          "on one GPU (one hipGraph + stream per clip; BASELINE cfg4 has 8 clips per GPU); 0 = skip")
+    ap.add_argument("--shared-scale", action="store_true",
+                    help="BASELINE cfg5: step-2 losses with ONE object scale shared by all clips of all ranks (one "
+                         "4-byte all-reduce per step, homan_amd.dist); eager autograd loop, reported under 'cfg5'")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -120,6 +171,8 @@ def main():
 
     mano = synthetic_mano(0)
     sil_fn, hand_fn = synth.hip_clip_fns(mano)
+    if args.shared_scale:
+        return bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn)
     clip = synth.make_clip(seed=rank, frames=args.frames, rend_size=args.size, image_size=args.size, obj="bottle",
                            silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
     lw = dict(synth.STEP2_LOSS_WEIGHTS if args.step2 else synth.STEP1_LOSS_WEIGHTS)
