@@ -242,12 +242,6 @@ __device__ __forceinline__ void raster_batch(const int* q, int n, int b, int F, 
 // Outputs: idx_map (B,is,is) int32; alpha16 (B,is,is/16) u16 bit-plane; pooled (B,S,S);
 // optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4).
 #define CAND_CAP 1024
-#ifndef HM_RASTER_DBG
-#define HM_RASTER_DBG 0
-#endif
-#ifndef HM_SWEEP_DBG
-#define HM_SWEEP_DBG 0
-#endif
 __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
@@ -270,9 +264,6 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const int tx = 2 * rx + (w & 1), ty = 2 * ry + (w >> 1);
     const int tile = ty * tiles_x + tx;
     int* q = queue[w];
-#if HM_RASTER_DBG == 3
-    const unsigned long long t_start = wall_clock64();
-#endif
 
     // this lane's output pixel and its 2x2 samples (flip: output row r <-> sample rows is-1-2r-dy)
     const int r = ty * HM_TILE + (lane >> 3), c = tx * HM_TILE + (lane & 7);
@@ -298,11 +289,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
 
     int qn = 0;
     const uint2* bx = reinterpret_cast<const uint2*>(boxes) + (long)b * F;
-#if HM_RASTER_DBG == 2
-    for (int cbase = 0; cbase < 0; cbase += CAND_CAP) {
-#else
     for (int cbase = 0; cbase < F; cbase += CAND_CAP) {
-#endif
         if (threadIdx.x == 0) cand_n = 0;
         __syncthreads();
         uint2 v[CAND_CAP / 256];
@@ -348,9 +335,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
             }
             wave_sync();
             while (qn >= 64) {
-#if HM_RASTER_DBG != 1
                 raster_batch(q, 64, b, F, is, faces9, xp, yp, xf, yf, zmin, imin, znear, zfar, lane, tcx0, tcx1, tcy0, tcy1);
-#endif
                 const int rem = qn - 64;
                 int moved = 0;
                 if (lane < rem) moved = q[64 + lane];
@@ -362,9 +347,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         }
         __syncthreads();
     }
-#if HM_RASTER_DBG != 1
     if (qn > 0) raster_batch(q, qn, b, F, is, faces9, xp, yp, xf, yf, zmin, imin, znear, zfar, lane, tcx0, tcx1, tcy0, tcy1);
-#endif
 
     // ---- outputs
     int* im = idx_map + (long)b * is * is;
@@ -406,10 +389,6 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         if (lane == 0) {
             float* o = partials + ((long)b * ntiles + tile) * 4;
             o[0] = sq; o[1] = inter; o[2] = uni; o[3] = 0.f;
-#if HM_RASTER_DBG == 3
-            o[3] = (float)(wall_clock64() - t_start);
-            o[2] = (float)(t_start & 0xffffffull);
-#endif
         }
     }
 }
@@ -732,37 +711,58 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
                     const bool coop = ndense * 16 < maxnb;
                     const bool heavy = coop && nb > SWEEP_LIGHT;
                     if (dbg) { dbg_bits += nb; dbg_heavy += heavy ? 1 : 0; }
-                    if (nb > 0 && !heavy && HM_SWEEP_DBG != 5) {
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            unsigned long long bits = wd[k];
+                    if (nb > 0 && !heavy) {
+                        // lane-serial walk, four set bits per round, software-pipelined: the gradient (and owner) loads
+                        // of round r+1 are issued before the arithmetic of round r
+                        int kw = 0;
+                        unsigned long long bits = wd[0];
+                        int left = nb;
+                        int d1n[4];
+                        float gn4[4];
+                        int idn[4];
+                        unsigned okn4 = 0;
+#define HM_LIGHT_FETCH()                                                                                          \
+    {                                                                                                             \
+        okn4 = 0;                                                                                                 \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                           \
+            while (left > 0 && bits == 0ull) {                                                                    \
+                ++kw;                                                                                             \
+                bits = kw == 1 ? wd[1] : kw == 2 ? wd[2] : kw == 3 ? wd[3] : kw == 4 ? wd[4] : kw == 5 ? wd[5]    \
+                                                                       : kw == 6 ? wd[6] : wd[7];                 \
+            }                                                                                                     \
+            const bool has = left > 0;                                                                            \
+            d1n[u] = has ? (kw << 6) + __ffsll((long long)bits) - 1 : 0;                                          \
+            if (has) { bits &= bits - 1; --left; okn4 |= 1u << u; }                                               \
+        }                                                                                                         \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                           \
+            const int xi = axis ? d1n[u] : d0r, yi = axis ? d0r : d1n[u];                                         \
+            const bool has = (okn4 >> u) & 1u;                                                                    \
+            gn4[u] = has ? sample_grad(gi, S, is, xi, yi) : 0.f;                                                  \
+            idn[u] = (ph == 1 && has) ? idx[(long)yi * is + xi] : fn;                                             \
+        }                                                                                                         \
+    }
+                        HM_LIGHT_FETCH()
 #pragma unroll 1
-                            while (bits) {
-                                // up to four set bits per round: their gradient (and owner) loads are in flight together
-                                int d1s[4];
-                                float gs[4];
-                                bool oks[4];
+                        while (okn4) {
+                            int d1c[4];
+                            float gc[4];
+                            unsigned okc4 = 0;
 #pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    oks[u] = bits != 0ull;
-                                    d1s[u] = oks[u] ? (k << 6) + __ffsll((long long)bits) - 1 : (k << 6);
-                                    bits &= bits - 1;
-                                }
-#pragma unroll
-                                for (int u = 0; u < 4; ++u) {
-                                    const int xi = axis ? d1s[u] : d0r, yi = axis ? d0r : d1s[u];
-                                    gs[u] = oks[u] ? sample_grad(gi, S, is, xi, yi) : 0.f;
-                                    if (ph == 1 && oks[u]) oks[u] = idx[(long)yi * is + xi] == fn;
-                                }
-#pragma unroll
-                                for (int u = 0; u < 4; ++u)
-                                    if (oks[u]) sweep_term(ph == 0 ? -gs[u] : gs[u], d1s[u], d1_cross, c0, c1, use0, use1, eps, inv_is, pow2, is, acc0, acc1);
+                            for (int u = 0; u < 4; ++u) {
+                                d1c[u] = d1n[u];
+                                gc[u] = gn4[u];
+                                if (((okn4 >> u) & 1u) && idn[u] == fn) okc4 |= 1u << u;
                             }
+                            HM_LIGHT_FETCH()
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if ((okc4 >> u) & 1u) sweep_term(ph == 0 ? -gc[u] : gc[u], d1c[u], d1_cross, c0, c1, use0, use1, eps, inv_is, pow2, is, acc0, acc1);
                         }
+#undef HM_LIGHT_FETCH
                     }
                     // ---- dense lines: the whole wave works on one lane's range at a time (line words broadcast
                     //      from the owner's registers; every lane takes positions lane, lane+64, ...)
-                    unsigned long long hv = (HM_SWEEP_DBG == 4) ? 0ull : __ballot(heavy);
+                    unsigned long long hv = __ballot(heavy);
                     // software-pipelined over the heavy lanes: the gradient (and owner) loads of the next line are in
                     // flight while the current one is reduced
                     float gk[8], gn[8];
