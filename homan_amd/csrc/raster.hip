@@ -246,7 +246,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
-    float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned)
+    float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned,
+    float* __restrict__ pooled_depth)
 {
     __shared__ int queue[RASTER_WAVES][192];
     __shared__ uint2 cand_box[CAND_CAP];
@@ -378,6 +379,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float pool = 0.25f * (float)cnt;
     const long po = ((long)b * S + r) * S + c;
     pooled[po] = pool;
+    // depth image of nr.Renderer.render (homan.py:391,406): z-buffer (far where empty), flipped, 2x2 average pooled
+    if (pooled_depth) pooled_depth[po] = (((zmin[0] + zmin[1]) + zmin[2]) + zmin[3]) / 4.0f;
     if (partials) {
         const float kp = keep[po], rf = ref[po];
         const float image = kp * pool;
@@ -873,6 +876,194 @@ __global__ void k_bwd_gather(const float* __restrict__ parts, const int* __restr
     grad_verts[3 * i + 2] = -(dxn * x + dyn * y) / (zz * zz);
 }
 
+// ---------------------------------------------------------------- depth-image backward (NMR backward_depth_map)
+// d pooled_depth / d face vertices, analytic: per covered sample of a face, with zp its depth and w_k its (clamped,
+// renormalised) barycentrics,  dz_k += g w_k zp^2 / z_k^2  and  d(x,y)_k += -g w_k zp^2 tmp[l] is/2  with
+// tmp[l] = -sum_m inv[m][l] / z_m.  Both factor through A_k = sum_samples g zp^2 w_k, so a wave per (frame, face)
+// strides the face's sample box, tests ownership in the index map, and reduces three numbers per winding.
+// gf9 (B,F,2,9): gradient w.r.t. the NDC vertices in WINDING order.
+__global__ __launch_bounds__(256) void k_depth_bwd_faces(const float* __restrict__ faces9, const FaceBox* __restrict__ boxes,
+                                                         const int* __restrict__ idx_map, const float* __restrict__ gpd,
+                                                         const unsigned char* __restrict__ owned, int B, int F, int S,
+                                                         float* __restrict__ gf9)
+{
+    const int lane = threadIdx.x & 63;
+    const int is = 2 * S;
+    const long bf = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (bf >= (long)B * F) return;
+    const int b = (int)(bf / F), fi = (int)(bf % F);
+    const uint2 bx = reinterpret_cast<const uint2*>(boxes)[bf];
+    const unsigned mask = (bx.x >> 14) & 3u;
+    const int x0 = bx.x & 0x3fff, y0 = (int)(bx.x >> 16), x1 = (int)(bx.y & 0xffff), y1 = (int)(bx.y >> 16);
+    const float* src = faces9 + bf * 9;
+    const int* idx = idx_map + (long)b * is * is;
+    const float* g = gpd + (long)b * S * S;
+    for (int var = 0; var < 2; ++var) {
+        float* out = gf9 + (bf * 2 + var) * 9;
+        const int fn = fi + var * F;
+        if (!((mask >> var) & 1u) || !owned[(long)b * 2 * F + fn]) {
+            if (lane < 9) out[lane] = 0.f;
+            continue;
+        }
+        float f[9];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int sv = var ? 2 - k : k;
+            f[3 * k] = src[3 * sv]; f[3 * k + 1] = src[3 * sv + 1]; f[3 * k + 2] = src[3 * sv + 2];
+        }
+        float p[3][2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { p[k][0] = topix(f[3 * k], is); p[k][1] = topix(f[3 * k + 1], is); }
+        float inv[9] = {
+            p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+            p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+            p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+        const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]);
+#pragma unroll
+        for (int k = 0; k < 9; ++k) inv[k] = inv[k] / den;
+        const float rz0 = 1.0f / f[2], rz1 = 1.0f / f[5], rz2 = 1.0f / f[8];
+        const int bw = x1 - x0 + 1, n = bw * (y1 - y0 + 1);
+        float A0 = 0.f, A1 = 0.f, A2 = 0.f;
+        for (int e = lane; e < n; e += 64) {
+            const int xi = x0 + e % bw, yi = y0 + e / bw;
+            if (idx[(long)yi * is + xi] != fn) continue;
+            float wgt[3], ws = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float t = inv[3 * k] * (float)xi;
+                t = t + inv[3 * k + 1] * (float)yi;
+                t = t + inv[3 * k + 2];
+                t = fminf(fmaxf(t, 0.0f), 1.0f);
+                wgt[k] = t;
+                ws += t;
+            }
+            float sum = wgt[0] * rz0;
+            sum = sum + wgt[1] * rz1;
+            sum = sum + wgt[2] * rz2;
+            const float zp = ws / sum;
+            const float a = 0.25f * g[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)] * zp * zp;
+            A0 += a * (wgt[0] / ws); A1 += a * (wgt[1] / ws); A2 += a * (wgt[2] / ws);
+        }
+        A0 = hm_wave_sum(A0); A1 = hm_wave_sum(A1); A2 = hm_wave_sum(A2);
+        if (lane == 0) {
+            const float tmp0 = -(inv[0] * rz0 + inv[3] * rz1 + inv[6] * rz2);
+            const float tmp1 = -(inv[1] * rz0 + inv[4] * rz1 + inv[7] * rz2);
+            const float A[3] = {A0, A1, A2}, rz[3] = {rz0, rz1, rz2};
+            const float half_is = 0.5f * (float)is;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                out[3 * k] = -A[k] * tmp0 * half_is;
+                out[3 * k + 1] = -A[k] * tmp1 * half_is;
+                out[3 * k + 2] = A[k] * rz[k] * rz[k];
+            }
+        }
+    }
+}
+
+// vertex gather of gf9 (winding order -> mesh corners) + projection backward (z passes straight through)
+__global__ void k_depth_bwd_gather(const float* __restrict__ gf9, const int* __restrict__ adj_off,
+                                   const int* __restrict__ adj_items, const float* __restrict__ verts,
+                                   const float* __restrict__ K, int B, int V, int F, float orig_size,
+                                   float* __restrict__ grad_verts)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)B * V) return;
+    const int b = (int)(i / V), v = (int)(i % V);
+    float gu = 0.f, gv = 0.f, gz = 0.f;
+    for (int a = adj_off[v]; a < adj_off[v + 1]; ++a) {
+        const int item = adj_items[a], fi = item / 3, k = item % 3;
+        const float* pf = gf9 + ((long)b * F + fi) * 18;
+        gu += pf[3 * k] + pf[9 + 3 * (2 - k)];
+        gv += pf[3 * k + 1] + pf[9 + 3 * (2 - k) + 1];
+        gz += pf[3 * k + 2] + pf[9 + 3 * (2 - k) + 2];
+    }
+    const float* k = K + b * 9;
+    const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+    const float zz = z + 1e-9f;
+    const float du0 = gu * (2.0f / orig_size), dv0 = -gv * (2.0f / orig_size);
+    const float dxn = k[0] * du0 + k[3] * dv0;
+    const float dyn = k[1] * du0 + k[4] * dv0;
+    grad_verts[3 * i] = dxn / zz;
+    grad_verts[3 * i + 1] = dyn / zz;
+    grad_verts[3 * i + 2] = -(dxn * x + dyn * y) / (zz * zz) + gz;
+}
+
+// ---------------------------------------------------------------- ordinal depth loss (PHOSA), two layers
+// reference homan/lossutils.py:133-169 as the method intends (the reference code itself cannot run: see DESIGN.md).
+// layers 0 = object, 1 = hand; d*/a* = pooled depth / alpha renders (B,S,S); m* = instance masks (B,S,S) uint8.
+// rec (5 floats): num_pairs, msum01, S01, msum10, S10.
+__global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__ d0, const float* __restrict__ d1,
+                                                        const float* __restrict__ a0, const float* __restrict__ a1,
+                                                        const unsigned char* __restrict__ m0,
+                                                        const unsigned char* __restrict__ m1, int B, int S,
+                                                        float* __restrict__ frame_part, unsigned int* counter,
+                                                        float* __restrict__ rec, float* __restrict__ out)
+{
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    const int b = blockIdx.x;
+    const long base = (long)b * S * S;
+    float c00 = 0.f, c11 = 0.f, c01 = 0.f, ms01 = 0.f, s01 = 0.f, ms10 = 0.f, s10 = 0.f;
+    for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+        const bool s0 = a0[base + i] == 1.0f, s1 = a1[base + i] == 1.0f;
+        c00 += s0 ? 1.f : 0.f; c11 += s1 ? 1.f : 0.f;
+        if (s0 && s1) {
+            c01 += 1.f;
+            const float z0 = d0[base + i], z1 = d1[base + i];
+            const bool g0 = m0[base + i] != 0, g1 = m1[base + i] != 0;
+            if (g0 && !g1 && z1 < z0) { ms01 += 1.f; s01 += logf(1.0f + expf(fminf(fmaxf(z0 - z1, 0.f), 2.f))); }
+            if (g1 && !g0 && z0 < z1) { ms10 += 1.f; s10 += logf(1.0f + expf(fminf(fmaxf(z1 - z0, 0.f), 2.f))); }
+        }
+    }
+    float v[7] = {c00, c11, c01, ms01, s01, ms10, s10};
+#pragma unroll
+    for (int k = 0; k < 7; ++k) v[k] = hm_block_sum(v[k], red);
+    if (threadIdx.x == 0) {
+        float* o = frame_part + b * 8;
+        o[0] = (v[0] > 0.f ? 1.f : 0.f) + (v[1] > 0.f ? 1.f : 0.f) + 2.f * (v[2] > 0.f ? 1.f : 0.f);   // pairs of this frame
+        o[1] = v[3]; o[2] = v[4]; o[3] = v[5]; o[4] = v[6];
+    }
+    if (hm_last_block(counter, gridDim.x, &s_flag)) {
+        float t[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) t[k] = hm_last_block_sum(frame_part + k, B, 8, red);
+        if (threadIdx.x == 0) {
+            float loss = 0.f;
+            if (t[1] > 0.f) loss += t[2] / t[1];
+            if (t[3] > 0.f) loss += t[4] / t[3];
+            out[0] = loss / t[0];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) rec[k] = t[k];
+        }
+    }
+}
+
+__global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* __restrict__ d1,
+                                    const float* __restrict__ a0, const float* __restrict__ a1,
+                                    const unsigned char* __restrict__ m0, const unsigned char* __restrict__ m1, long n,
+                                    const float* __restrict__ rec, const float* __restrict__ upstream,
+                                    float* __restrict__ g0, float* __restrict__ g1)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r0 = 0.f, r1 = 0.f;
+    if (a0[i] == 1.0f && a1[i] == 1.0f) {
+        const float z0 = d0[i], z1 = d1[i];
+        const bool b0 = m0[i] != 0, b1 = m1[i] != 0;
+        const float up = upstream[0] / rec[0];
+        if (b0 && !b1 && z1 < z0 && rec[1] > 0.f) {
+            const float x = z0 - z1;
+            if (x > 0.f && x < 2.f) { const float sg = 1.0f / (1.0f + expf(-x)); r0 += up * sg / rec[1]; r1 -= up * sg / rec[1]; }
+        }
+        if (b1 && !b0 && z0 < z1 && rec[3] > 0.f) {
+            const float x = z1 - z0;
+            if (x > 0.f && x < 2.f) { const float sg = 1.0f / (1.0f + expf(-x)); r1 += up * sg / rec[3]; r0 -= up * sg / rec[3]; }
+        }
+    }
+    g0[i] = r0;
+    g1[i] = r1;
+}
+
 // ================================================================ C ABI
 static float* g_sweep_dbg = nullptr;   // optional per-wave timing buffer (tools only)
 extern "C" {
@@ -934,12 +1125,12 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 //   keep/ref/keep_sum/loss_out may be NULL (render only).  loss_out[0]=loss_sil, loss_out[1]=mean IoU.
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
-               const float* keep_sum, float* pooled, float* loss_out, const int* work_order, void* workspace,
-               hipStream_t stream)
+               const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+               void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && pooled && workspace);
     HM_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0);
-    if (S % 32 != 0 || 2 * S > 8192 || 2L * F >= (1L << 30)) return HM_ERR_UNSUPPORTED;
+    if (S % 16 != 0 || 2 * S > 8192 || 2L * F >= (1L << 30) || B >= 32768) return HM_ERR_UNSUPPORTED;
     HM_CHECK_ARG(faces_bstride == 0 || faces_bstride == 3 * F);
     SilWs w = carve(workspace, B, V, F, S);
     const int is = 2 * S, ntiles = (S / 8) * (S / 8);
@@ -949,7 +1140,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     const bool fused = keep && ref && keep_sum && loss_out;
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                       fused ? w.partials : (float*)nullptr, work_order, w.owned);
+                       fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth);
     if (fused)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            w.counter, loss_out);
@@ -979,6 +1170,44 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
     return hm_launch_status();
 }
 
+// Backward of the depth image of the last hm_sil_fwd (called with pooled_depth): grad_pooled_depth (B,S,S) ->
+// grad_verts (B,V,3).  Uses faces9 / boxes / idx_map / owned of the workspace; gf9 scratch lives in `parts`.
+int hm_depth_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size,
+                 const float* grad_pooled_depth, const int* adj_off, const int* adj_items, float* grad_verts,
+                 void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && K && grad_pooled_depth && adj_off && adj_items && grad_verts && workspace);
+    if (S % 16 != 0) return HM_ERR_UNSUPPORTED;
+    SilWs w = carve(workspace, B, V, F, S);
+    hipLaunchKernelGGL(k_depth_bwd_faces, dim3(hm_cdiv((long)B * F * 64, 256)), dim3(256), 0, stream, w.faces9, w.boxes,
+                       w.idx_map, grad_pooled_depth, w.owned, B, F, S, w.parts);
+    hipLaunchKernelGGL(k_depth_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
+                       adj_items, verts, K, B, V, F, orig_size, grad_verts);
+    return hm_launch_status();
+}
+
+// Ordinal depth loss between the object (layer 0) and the hand (layer 1).  workspace: hm_reduce_workspace_bytes()
+// zero-filled once + B*8 floats of frame partials appended by the caller (frame_part).  rec (5) is kept for the backward.
+int hm_ordinal_depth_fwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
+                         const unsigned char* m1, int B, int S, float* frame_part, float* rec, float* out1,
+                         void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(d0 && d1 && a0 && a1 && m0 && m1 && frame_part && rec && out1 && workspace && B > 0 && S > 0);
+    hipLaunchKernelGGL(k_ordinal_depth, dim3(B), dim3(256), 0, stream, d0, d1, a0, a1, m0, m1, B, S, frame_part,
+                       (unsigned int*)((float*)workspace + 512), rec, out1);
+    return hm_launch_status();
+}
+int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
+                         const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
+                         float* g1, hipStream_t stream)
+{
+    HM_CHECK_ARG(d0 && d1 && a0 && a1 && m0 && m1 && rec && upstream && g0 && g1);
+    const long n = (long)B * S * S;
+    hipLaunchKernelGGL(k_ordinal_depth_bwd, dim3(hm_cdiv(n, 256)), dim3(256), 0, stream, d0, d1, a0, a1, m0, m1, n, rec,
+                       upstream, g0, g1);
+    return hm_launch_status();
+}
+
 // Measurement hook for bench.py: runs one full forward + backward (fused-loss mode, upstream = 1) to populate the
 // workspace, then `reps` launches of k_raster_fwd alone and `reps` launches of k_bwd_sweep alone, each bracketed by two
 // HIP events recorded on `stream`; avg_ms[0] / avg_ms[1] (HOST pointer) receive the average launch durations in
@@ -992,7 +1221,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     HM_CHECK_ARG(verts && faces && K && keep && ref && keep_sum && pooled && loss_out && workspace && reps > 0 && avg_ms);
     HM_CHECK_ARG(adj_off && adj_items && upstream && grad_verts);
     int rc = hm_sil_fwd(verts, faces, 0, K, B, V, F, S, 1.0f, 0.1f, 100.0f, keep, ref, keep_sum, pooled, loss_out,
-                        work_order, workspace, stream);
+                        work_order, nullptr, workspace, stream);
     if (rc != HM_OK) return rc;
     rc = hm_sil_bwd(verts, K, B, V, F, S, 1.0f, 1e-3f, 1, upstream, nullptr, keep_sum, adj_off, adj_items, face_order,
                     grad_verts, nullptr, workspace, stream);
@@ -1006,7 +1235,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                           w.partials, work_order, w.owned);
+                           w.partials, work_order, w.owned, (float*)nullptr);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);

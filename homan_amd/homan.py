@@ -30,7 +30,8 @@ class HOMan(nn.Module):
                  optimize_object_scale=False, optimize_ortho_cam=True, hand_proj_mode="persp", optimize_mano=True,
                  optimize_mano_beta=True, inter_type="centroid", image_size=640,
                  # homan_amd extensions (keyword-only use)
-                 mano_model=None, mano_root="extra_data/mano", rend_size=constants.REND_SIZE, sync_metrics=True):
+                 mano_model=None, mano_root="extra_data/mano", rend_size=constants.REND_SIZE, sync_metrics=True,
+                 ordinal_depth=False):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError("homan_amd.HOMan needs an MI355X (ROCm) device; there is no CPU path")
@@ -130,6 +131,10 @@ class HOMan(nn.Module):
         self.collision_ctx = ops.CollisionContext(self.mano_model.closed_faces, self.faces_object[0], batch * self.hand_nb,
                                                   778, num_verts_object, dev)
         self._mano_cache = None
+        # ordinal depth term: the reference's own call site cannot run (see forward()); `ordinal_depth=True` opts into the
+        # loss the method describes (homan.py:384-419 + lossutils.py:133-169) instead of reproducing that TypeError
+        self.ordinal_depth = bool(ordinal_depth)
+        self._depth_state = None
         with torch.no_grad():
             self.verts_hand_init = self.get_verts_hand()[0].detach().clone()
             self.verts_object_init = self.get_verts_object()[0].detach().clone()
@@ -171,6 +176,30 @@ class HOMan(nn.Module):
                                        self.int_scales_hand, abs_scale=False)
 
     # ------------------------------------------------------------------ losses
+    def compute_ordinal_depth_loss(self, verts_object=None, verts_hand=None):
+        """reference homan/homan.py:384-419: render object and hand depth at the full-image intrinsics, compare their
+        ordering with the instance masks (lossutils.py:133-169).  One hand (hand_nb == 1)."""
+        if verts_object is None:
+            verts_object, _ = self.get_verts_object()
+        if verts_hand is None:
+            verts_hand, _ = self.get_verts_hand()
+        if self._depth_state is None:
+            size = int(self.image_size)
+            masks_o, masks_h = self.masks_object, self.masks_human
+            if tuple(masks_o.shape[1:]) != (size, size) or tuple(masks_h.shape[1:]) != (size, size) or size % 16:
+                raise NotImplementedError("ordinal depth: instance masks must be (B, image_size, image_size) with "
+                                          f"image_size % 16 == 0, got {tuple(masks_o.shape)} / image_size {size}")
+            batch = verts_object.shape[0]
+            dev = verts_object.device
+            ctx_o = ops.SilhouetteContext(self.faces_object, verts_object.shape[1], batch, size, dev)
+            ctx_h = ops.SilhouetteContext(self.faces_hand[:1].expand(batch, -1, -1), 778, batch, size, dev)
+            self._depth_state = (ctx_o, ctx_h, (masks_o != 0).to(torch.uint8).contiguous(),
+                                 (masks_h != 0).to(torch.uint8).contiguous())
+        ctx_o, ctx_h, m_o, m_h = self._depth_state
+        sil_o, dep_o = ops.depth_render(verts_object, self.camintr, ctx_o, 1.0)
+        sil_h, dep_h = ops.depth_render(verts_hand, self.camintr, ctx_h, 1.0)
+        return {"loss_depth": ops.ordinal_depth_loss(dep_o, dep_h, sil_o, sil_h, m_o, m_h, self.reduce_ws)}
+
     def forward(self, loss_weights=None):
         """reference homan.py:421-508: a loss whose weight is zero is not computed."""
         lw = loss_weights
@@ -222,7 +251,9 @@ class HOMan(nn.Module):
             loss_dict["loss_scale_obj"] = l_so
         if want_sh:
             loss_dict["loss_scale_hand"] = l_sh
-        if lw is None or lw["lw_depth"] > 0:
+        if (lw is None or lw["lw_depth"] > 0) and self.ordinal_depth:
+            loss_dict.update(self.compute_ordinal_depth_loss(verts_object, verts_hand))
+        elif lw is None or lw["lw_depth"] > 0:
             # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() without its arguments
             raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
                             "'masks', 'silhouettes', and 'depths'")

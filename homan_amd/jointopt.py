@@ -124,12 +124,12 @@ def _weighted_total(loss_dict, loss_weights):
 def build_model(person_parameters, object_parameters, class_name="default", objvertices=None, objfaces=None,
                 camintr=None, hand_proj_mode="persp", optimize_mano=False, optimize_mano_beta=True,
                 optimize_object_scale=False, state_dict=None, image_size=640, mano_model=None, rend_size=256,
-                sync_metrics=True):
+                sync_metrics=True, ordinal_depth=False):
     kw = collate_inputs(person_parameters, object_parameters, objvertices, objfaces)
     model = HOMan(camintr=camintr, class_name=class_name, int_scale_init=1, hand_proj_mode=hand_proj_mode,
                   optimize_mano=optimize_mano, optimize_mano_beta=optimize_mano_beta,
                   optimize_object_scale=optimize_object_scale, image_size=image_size, mano_model=mano_model,
-                  rend_size=rend_size, sync_metrics=sync_metrics, **kw)
+                  rend_size=rend_size, sync_metrics=sync_metrics, ordinal_depth=ordinal_depth, **kw)
     if state_dict is not None:
         model.load_state_dict(state_dict, strict=False)
     return model
@@ -211,6 +211,8 @@ class FusedStepper:
             raise NotImplementedError("FusedStepper covers optimize_mano=True, optimize_mano_beta=True, persp")
         lw = self.lw = {k: float(v) for k, v in loss_weights.items()}
         if lw.get("lw_depth", 0) > 0:
+            if getattr(m, "ordinal_depth", False):
+                raise NotImplementedError("the fused loop does not cover lw_depth > 0: use mode='graph' or 'eager'")
             raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
                             "'masks', 'silhouettes', and 'depths'")
         self.L, self.c, self.ops = _lib.lib(), constants, ops
@@ -316,7 +318,7 @@ class FusedStepper:
             ck(L.hm_sil_fwd(P(self.vo), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
                             self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
                             P(m.losses.keep_sum), P(self.pooled), self._slot("loss_sil_obj"), P(sctx.work_order),
-                            P(sctx.workspace), sa), "sil_fwd")
+                            None, P(sctx.workspace), sa), "sil_fwd")
             ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS, 1,
                             P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
                             P(sctx.face_order), P(self.G_sil), None, P(sctx.workspace), sa), "sil_bwd")
@@ -409,10 +411,10 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
                          camintr=None, hand_proj_mode="persp", optimize_mano=False, optimize_mano_beta=True,
                          optimize_object_scale=False, state_dict=None, fps=24, viz_len=7, image_size=640,
                          # homan_amd extensions
-                         mode="eager", mano_model=None, rend_size=256):
+                         mode="eager", mano_model=None, rend_size=256, ordinal_depth=False):
     model = build_model(person_parameters, object_parameters, class_name, objvertices, objfaces, camintr,
                         hand_proj_mode, optimize_mano, optimize_mano_beta, optimize_object_scale, state_dict,
-                        image_size, mano_model, rend_size, sync_metrics=(mode == "eager"))
+                        image_size, mano_model, rend_size, sync_metrics=(mode == "eager"), ordinal_depth=ordinal_depth)
     if mode in ("graph", "fused"):
         cls = GraphStepper if mode == "graph" else FusedStepper
         stepper = cls(model, loss_weights, lr, num_iterations)

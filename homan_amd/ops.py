@@ -106,7 +106,7 @@ class _SilhouetteLoss(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, _lib.ptr(keep), _lib.ptr(ref), _lib.ptr(keep_sum),
-            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.work_order), _lib.ptr(sctx.workspace), _lib.stream()),
+            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.work_order), None, _lib.ptr(sctx.workspace), _lib.stream()),
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K, keep_sum)
         ctx.sctx, ctx.orig_size = sctx, orig_size
@@ -136,7 +136,7 @@ class _SilhouetteRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.work_order), _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
+            _lib.ptr(sctx.work_order), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
         return pooled
@@ -162,6 +162,76 @@ def silhouette_loss(verts, K, keep, ref, keep_sum, sctx, orig_size=1.0):
 
 def silhouette_render(verts, K, sctx, orig_size=1.0):
     return _SilhouetteRender.apply(verts, K, sctx, orig_size)
+
+
+class _DepthRender(torch.autograd.Function):
+    """reference homan/homan.py:391,406: `_, depths, sils = renderer.render(verts, faces, textures, K=)`.
+    -> (silhouettes (B,S,S), depths (B,S,S)); only the depth image is differentiable here (the ordinal depth loss uses
+    the silhouettes as a mask only: lossutils.py:146-149 compares them with ==)."""
+
+    @staticmethod
+    def forward(ctx, verts, K, sctx, orig_size):
+        verts, K = _f32(verts), _f32(K)
+        pooled = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
+        depth = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
+        _lib.check(_lib.lib().hm_sil_fwd(
+            _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
+            float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
+            _lib.ptr(sctx.work_order), _lib.ptr(depth), _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
+        ctx.save_for_backward(verts, K)
+        ctx.sctx, ctx.orig_size = sctx, orig_size
+        ctx.mark_non_differentiable(pooled)
+        return pooled, depth
+
+    @staticmethod
+    def backward(ctx, _g_sil, g_depth):
+        verts, K = ctx.saved_tensors
+        sctx = ctx.sctx
+        grad_verts = torch.empty_like(verts)
+        _lib.check(_lib.lib().hm_depth_bwd(
+            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), _lib.ptr(_f32(g_depth)),
+            _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items), _lib.ptr(grad_verts), _lib.ptr(sctx.workspace),
+            _lib.stream()), "hm_depth_bwd")
+        return grad_verts, None, None, None
+
+
+def depth_render(verts, K, sctx, orig_size):
+    """-> (silhouettes, depths), both (B,S,S).  One SilhouetteContext per rendered mesh (the backward reads the
+    forward's index map from its workspace)."""
+    return _DepthRender.apply(verts, K, sctx, orig_size)
+
+
+class _OrdinalDepthLoss(torch.autograd.Function):
+    """reference homan/lossutils.py:133-169 for the two layers (object, hand) of homan/homan.py:384-419."""
+
+    @staticmethod
+    def forward(ctx, d0, d1, a0, a1, m0, m1, rws):
+        d0, d1, a0, a1 = _f32(d0), _f32(d1), _f32(a0), _f32(a1)
+        B, S = d0.shape[0], d0.shape[1]
+        assert d0.shape == d1.shape == a0.shape == a1.shape == m0.shape == m1.shape == (B, S, S)
+        assert m0.dtype == torch.uint8 and m1.dtype == torch.uint8 and m0.is_contiguous() and m1.is_contiguous()
+        part = torch.empty(B * 8, device=d0.device)
+        rec = torch.empty(5, device=d0.device)
+        out = torch.empty(1, device=d0.device)
+        _lib.check(_lib.lib().hm_ordinal_depth_fwd(
+            _lib.ptr(d0), _lib.ptr(d1), _lib.ptr(a0), _lib.ptr(a1), _lib.ptr(m0), _lib.ptr(m1), B, S, _lib.ptr(part),
+            _lib.ptr(rec), _lib.ptr(out), _lib.ptr(rws.buf), _lib.stream()), "hm_ordinal_depth_fwd")
+        ctx.save_for_backward(d0, d1, a0, a1, m0, m1, rec)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d0, d1, a0, a1, m0, m1, rec = ctx.saved_tensors
+        g0, g1 = torch.empty_like(d0), torch.empty_like(d1)
+        _lib.check(_lib.lib().hm_ordinal_depth_bwd(
+            _lib.ptr(d0), _lib.ptr(d1), _lib.ptr(a0), _lib.ptr(a1), _lib.ptr(m0), _lib.ptr(m1), d0.shape[0], d0.shape[1],
+            _lib.ptr(rec), _lib.ptr(_f32(g).reshape(1)), _lib.ptr(g0), _lib.ptr(g1), _lib.stream()), "hm_ordinal_depth_bwd")
+        return g0, g1, None, None, None, None, None
+
+
+def ordinal_depth_loss(d_obj, d_hand, sil_obj, sil_hand, mask_obj, mask_hand, rws):
+    """0-d loss.  mask_*: (B,S,S) uint8 instance masks."""
+    return _OrdinalDepthLoss.apply(d_obj, d_hand, sil_obj, sil_hand, mask_obj, mask_hand, rws)
 
 
 # =============================================================================== shared small state

@@ -190,6 +190,14 @@ def make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", si
     tm_h = (sil_h > 0.5).float()
     tm_h[(sil_o_in_h > 0.5) & (sil_h <= 0.5)] = -1.0
 
+    # full-image instance masks (PointRend-like modal masks; only the ordinal depth term reads them): the hand sits
+    # in front of the object in this scene, so it owns the overlap
+    if image_size % 16 == 0:
+        full_h = silhouette_fn(verts_hand_gt, hf_t, camintr_nc, image_size).detach().cpu() > 0.5
+        full_o = (silhouette_fn(verts_obj_gt, of_t, camintr_nc, image_size).detach().cpu() > 0.5) & ~full_h
+    else:
+        full_h = full_o = torch.zeros(B, image_size, image_size, dtype=torch.bool)
+
     verts2d = p2d_h + torch.randn(p2d_h.shape, generator=torch_gen)
 
     # perturbed initial state
@@ -217,7 +225,7 @@ def make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", si
             mano_betas=torch.zeros(1, 10),
             mano_pca_pose=torch.zeros(1, pca_dim),
             target_masks=tm_h[b:b + 1].clone(),                     # (1,S,S)
-            masks=torch.zeros(1, image_size, image_size),
+            masks=full_h[b:b + 1].float(),                          # (1,H,W) instance mask
             verts=verts_hand_init[b:b + 1].clone(),                 # (1,778,3)
             verts2d=verts2d[b:b + 1].clone(),                       # (1,778,2) px
             K_roi=K_roi_h[b:b + 1].clone(),                         # (1,3,3)
@@ -228,7 +236,7 @@ def make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", si
             rotations=R_o_init[b:b + 1].clone(),                    # (1,3,3)
             target_masks=tm_o[b:b + 1].clone(),                     # (1,S,S)
             K_roi=K_roi_o[b:b + 1, None].clone(),                   # (1,1,3,3)
-            full_mask=torch.zeros(image_size, image_size),
+            full_mask=full_o[b].float(),                            # (H,W) instance mask
         ))
     gt = dict(verts_object=verts_obj_gt, verts_hand=verts_hand_gt, pca=torch.from_numpy(pca_gt),
               rotations_object=R_o_t, translations_object=t_o_t, rotations_hand=R_h_t,

@@ -83,12 +83,14 @@ int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const f
  *     loss_out[0] = sum((keep*sil - ref)^2) / keep_sum / B ; loss_out[1] = mean_b IoU_b   (losses.py:188-196).
  *   work_order: B*(S/16)^2 int32 entries (frame << 16 | region) = dispatch order of the (frame, 32x32-sample region)
  *     workgroups (a permutation; expensive ones first), or NULL for frame-major order.
- *   S must be a multiple of 32, S <= 256 for the backward. */
+ *   pooled_depth (B,S,S) optional: the depth image nr.Renderer.render returns beside the silhouette (reference
+ *     homan/homan.py:391,406): z-buffer (zfar where empty), flipped, 2x2 average pooled.
+ *   S must be a multiple of 16 (32 and <= 256 for the silhouette backward). */
 size_t hm_sil_workspace_bytes(int B, int V, int F, int S);
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
-               const float* keep_sum, float* pooled, float* loss_out, const int* work_order, void* workspace,
-               hipStream_t stream);
+               const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+               void* workspace, hipStream_t stream);
 /* mode 1: upstream (1) = dL/d loss_out[0]; mode 0: grad_pooled (B,S,S) = dL/d pooled.  adj_off (V+1), adj_items (3F):
  * CSR vertex -> (face*3 + corner).  face_order: B*F int32 permutation of frame*F+face (visiting order of the edge
  * sweeps, expensive faces first) or NULL.  grad_verts (B,V,3) overwritten; grad_ndc (B,V,3) optional. */
@@ -96,6 +98,22 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
                const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
                hipStream_t stream);
+/* Backward of the depth image (neural_renderer backward_depth_map, reached from reference homan/homan.py:391,406):
+ * grad_pooled_depth (B,S,S) -> grad_verts (B,V,3), for the frame state the last hm_sil_fwd left in `workspace`. */
+int hm_depth_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size,
+                 const float* grad_pooled_depth, const int* adj_off, const int* adj_items, float* grad_verts,
+                 void* workspace, hipStream_t stream);
+/* Ordinal depth loss between two rendered layers (0 = object, 1 = hand): reference homan/homan.py:384-419 +
+ * homan/lossutils.py:133-169 (as the method intends; the reference call site raises before reaching it, DESIGN.md).
+ * d*/a*: depth / silhouette renders (B,S,S) f32; m*: instance masks (B,S,S) u8.  frame_part: B*8 floats scratch;
+ * rec: 5 floats {num_pairs, n01, sum01, n10, sum10} kept for the backward; out1[0] = loss.
+ * workspace: the reduce workspace (see the small losses below), zero-filled once. */
+int hm_ordinal_depth_fwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
+                         const unsigned char* m1, int B, int S, float* frame_part, float* rec, float* out1,
+                         void* workspace, hipStream_t stream);
+int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
+                         const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
+                         float* g1, hipStream_t stream);
 /* forward intermediates kept in the workspace (tests): face-index map (B,2S,2S) int32, packed NDC faces (B,F,9) */
 int hm_sil_read_idx_map(const void* workspace, int B, int V, int F, int S, int* out, hipStream_t stream);
 int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);

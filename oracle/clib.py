@@ -35,6 +35,8 @@ def lib():
         _lib.orc_nmr_face_index_map.restype = None
         _lib.orc_nmr_grad_faces_alpha.argtypes = [fp, ip, fp, ci, ci, ci, cf, fp]
         _lib.orc_nmr_grad_faces_alpha.restype = None
+        _lib.orc_nmr_grad_faces_depth.argtypes = [fp, ip, fp, ci, ci, ci, fp]
+        _lib.orc_nmr_grad_faces_depth.restype = None
         _lib.orc_sdf_grid.argtypes = [ip, fp, ci, ci, ci, ci, ci, fp]
         _lib.orc_sdf_grid.restype = None
         _lib.orc_point_triangle_distance.argtypes = [fp, fp, fp, fp]

@@ -242,3 +242,67 @@ void orc_nmr_grad_faces_alpha(const float *faces, const int32_t *idx_map,
         for (int k = 0; k < 9; ++k) out[k] = g[k];
     }
 }
+
+/*
+ * Backward of the depth map w.r.t. the NDC face vertices (the NMR rasteriser's
+ * backward_depth_map kernel, reached from reference homan/homan.py:391,406 when
+ * the depth image carries a gradient).  Per covered sample: with zp its depth
+ * and w_k its clamped, renormalised barycentrics,
+ *     d z_k      +=  g * w_k * zp^2 / z_k^2
+ *     d (x,y)_k  += -g * w_k * zp^2 * tmp[l] * is / 2,  tmp[l] = -sum_m inv[m][l] / z_m.
+ * grad_depth is dL/d depth_map on the same `is` grid; grad_faces (B,NF,9) is
+ * ACCUMULATED into (so it can follow orc_nmr_grad_faces_alpha).
+ */
+void orc_nmr_grad_faces_depth(const float *faces, const int32_t *idx_map,
+                              const float *grad_depth, int B, int NF, int is,
+                              float *grad_faces)
+{
+    const long npix = (long)is * is;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int b = 0; b < B; ++b) {
+        for (int yi = 0; yi < is; ++yi)
+            for (int xi = 0; xi < is; ++xi) {
+                const long pix = b * npix + (long)yi * is + xi;
+                const int fn = idx_map[pix];
+                if (fn < 0) continue;
+                const float g = grad_depth[pix];
+                if (g == 0.0f) continue;
+                const float *f = faces + ((long)b * NF + fn) * 9;
+                float *gf = grad_faces + ((long)b * NF + fn) * 9;
+                float p[3][2];
+                for (int k = 0; k < 3; ++k)
+                    for (int d = 0; d < 2; ++d) p[k][d] = orc_topix(f[3 * k + d], is);
+                float inv[9] = {
+                    p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                    p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                    p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+                const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
+                                  p[1][0] * (p[2][1] - p[0][1]);
+                for (int k = 0; k < 9; ++k) inv[k] /= den;
+                float w[3], ws = 0.0f;
+                for (int k = 0; k < 3; ++k) {
+                    float t = inv[3 * k + 0] * (float)xi;
+                    t = t + inv[3 * k + 1] * (float)yi;
+                    t = t + inv[3 * k + 2];
+                    t = fminf(fmaxf(t, 0.0f), 1.0f);
+                    w[k] = t;
+                    ws += t;
+                }
+                float s = w[0] / f[2];
+                s = s + w[1] / f[5];
+                s = s + w[2] / f[8];
+                const float zp = ws / s;
+                const float zp2 = zp * zp;
+                float tmp[2] = {0.0f, 0.0f};
+                for (int l = 0; l < 2; ++l)
+                    for (int m = 0; m < 3; ++m) tmp[l] += -inv[3 * m + l] / f[3 * m + 2];
+                for (int k = 0; k < 3; ++k) {
+                    const float wk = w[k] / ws;
+                    const float zk = f[3 * k + 2];
+                    gf[3 * k + 2] += g * wk * zp2 / (zk * zk);
+                    for (int l = 0; l < 2; ++l)
+                        gf[3 * k + l] += -g * tmp[l] * wk * zp2 * (float)is / 2.0f;
+                }
+            }
+    }
+}

@@ -58,12 +58,13 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
                          objfaces=None, loss_weights=None, num_iterations=400, lr=1e-2, camintr=None,
                          hand_proj_mode="persp", optimize_mano=False, optimize_mano_beta=True,
                          optimize_object_scale=False, state_dict=None, image_size=640, mano_model=None,
-                         rend_size=256, log=True):
+                         rend_size=256, log=True, ordinal_depth=False):
     kw = collate_inputs(person_parameters, object_parameters, objvertices, objfaces)
     model = OracleHOMan(camintr=camintr, class_name=class_name, int_scale_init=1,
                         hand_proj_mode=hand_proj_mode, optimize_mano=optimize_mano,
                         optimize_mano_beta=optimize_mano_beta, optimize_object_scale=optimize_object_scale,
-                        image_size=image_size, mano_model=mano_model, rend_size=rend_size, **kw)
+                        image_size=image_size, mano_model=mano_model, rend_size=rend_size,
+                        ordinal_depth=ordinal_depth, **kw)
     if state_dict is not None:
         model.load_state_dict(state_dict, strict=False)
     optimizer = make_optimizer(model, lr)

@@ -125,6 +125,31 @@ def masked_mean_loss(dists, mask):
     return (mask * dists).sum() / n if n > 0 else torch.Tensor([0])
 
 
+def compute_ordinal_depth_loss(masks, silhouettes, depths):
+    """lossutils.py:133-169.  masks (B,n,H,W) bool; silhouettes / depths: n x (B,S,S)."""
+    loss = torch.zeros(())
+    num_pairs = 0
+    height, width = masks.shape[2], masks.shape[3]
+    silhouettes = [s[:, :height, :width] for s in silhouettes]
+    depths = [d[:, :height, :width] for d in depths]
+    for i in range(len(silhouettes)):
+        for j in range(len(silhouettes)):
+            has_pred = silhouettes[i] & silhouettes[j]
+            pairs = (has_pred.sum([1, 2]) > 0).sum().item()
+            if pairs == 0:
+                continue
+            num_pairs += pairs
+            front_i_gt = masks[:, i] & (~masks[:, j])
+            front_j_pred = depths[j] < depths[i]
+            mask = front_i_gt & front_j_pred & has_pred
+            if mask.sum() == 0:
+                continue
+            dists = torch.clamp(depths[i] - depths[j], min=0.0, max=2.0)
+            loss = loss + torch.sum(torch.log(1 + torch.exp(dists))[mask]) / mask.sum()
+    loss = loss / num_pairs
+    return {"loss_depth": loss}
+
+
 def compute_contact_loss(verts_hand, verts_object, faces_object, closed_hand_faces,
                          contact_thresh=0.010, collision_thresh=0.020):
     """reference homan/lossutils.py:112-130 -> interactions/contactloss.py:149-309
@@ -234,9 +259,12 @@ class OracleHOMan(nn.Module):
                  class_name="default", cams_hand=None, int_scale_init=1, camintr=None,
                  optimize_object_scale=False, optimize_ortho_cam=True, hand_proj_mode="persp",
                  optimize_mano=True, optimize_mano_beta=True, inter_type="centroid", image_size=640,
-                 mano_model=None, rend_size=REND_SIZE):
+                 mano_model=None, rend_size=REND_SIZE, ordinal_depth=False):
         super().__init__()
         assert hand_proj_mode == "persp"
+        self.ordinal_depth = bool(ordinal_depth)
+        self.register_buffer("masks_object", (masks_object if masks_object.dim() == 3 else masks_object[None]) != 0)
+        self.register_buffer("masks_human", masks_hand != 0)
         self.translations_object = nn.Parameter(translations_object.detach().clone())
         rot_o = rotations_object.detach().clone()
         self.rotations_object = nn.Parameter(
@@ -294,6 +322,29 @@ class OracleHOMan(nn.Module):
         self.losses = OracleLosses(self.camintr, self.ref_mask_object, self.keep_mask_object,
                                    self.ref_verts2d_hand, self.camintr_rois_object, self.hand_nb,
                                    inter_type, rend_size)
+
+    def compute_ordinal_depth_loss(self):
+        """homan.py:384-419: depth renders of the object and of each hand at the full-image intrinsics
+        (Renderer(image_size, K=camintr, orig_size=1), homan.py:168-172), then lossutils.py:133-169.
+        The reference call site (homan.py:506-507) drops the arguments and the loss accumulator there is built with
+        torch.Tensor(0.0) (lossutils.py:140), so the reference itself never evaluates this: restated as written
+        otherwise, with a zero accumulator and without the debug image dumps (lossutils.py:148-153)."""
+        from . import nmr
+        verts_object, _ = self.get_verts_object()
+        verts_hand, _ = self.get_verts_hand()
+        rend = nmr.Renderer(image_size=self.image_size, K=self.camintr, R=torch.eye(3)[None], t=torch.zeros(1, 3),
+                            orig_size=1)
+        sils, depths = [], []
+        _, d, a = rend.render(verts_object, self.faces_object)
+        sils.append(a == 1)
+        depths.append(d)
+        for h in range(self.hand_nb):
+            hv = verts_hand[h::self.hand_nb]
+            _, d, a = rend.render(hv, self.faces_hand[h][None].repeat(hv.shape[0], 1, 1))
+            sils.append(a == 1)
+            depths.append(d)
+        masks = torch.stack([self.masks_object] + [self.masks_human[h::self.hand_nb] for h in range(self.hand_nb)], 1)
+        return compute_ordinal_depth_loss(masks, sils, depths)
 
     def get_verts_object(self):
         """homan.py:298-307."""
@@ -354,7 +405,9 @@ class OracleHOMan(nn.Module):
         if lw is None or lw["lw_scale_hand"] > 0:
             loss_dict["loss_scale_hand"] = compute_intrinsic_scale_prior(self.int_scales_hand,
                                                                          self.int_scale_hand_mean)
-        if lw is not None and lw["lw_depth"] > 0:
+        if lw is not None and lw["lw_depth"] > 0 and self.ordinal_depth:
+            loss_dict.update(self.compute_ordinal_depth_loss())
+        elif lw is not None and lw["lw_depth"] > 0:
             # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() with no arguments
             raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments")
         return loss_dict, metric_dict

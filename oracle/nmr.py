@@ -69,7 +69,6 @@ class _RasterizeAlphaDepth(torch.autograd.Function):
         ctx.f = f
         ctx.idx = idx
         alpha = torch.from_numpy((idx >= 0).astype(np.float32))
-        ctx.mark_non_differentiable
         return alpha, torch.from_numpy(dep), torch.from_numpy(idx)
 
     @staticmethod
@@ -79,7 +78,10 @@ class _RasterizeAlphaDepth(torch.autograd.Function):
         gf = np.zeros((B, NF, 9), np.float32)
         clib.lib().orc_nmr_grad_faces_alpha(clib.fptr(ctx.f), clib.iptr(ctx.idx), clib.fptr(ga),
                                             B, NF, image_size, eps, clib.fptr(gf))
-        # depth gets no pseudo-gradient on the silhouette path (alpha only)
+        if grad_depth is not None and bool((grad_depth != 0).any()):
+            gd = np.ascontiguousarray(grad_depth.detach().cpu().numpy(), dtype=np.float32)
+            clib.lib().orc_nmr_grad_faces_depth(clib.fptr(ctx.f), clib.iptr(ctx.idx), clib.fptr(gd), B, NF,
+                                                image_size, clib.fptr(gf))
         return torch.from_numpy(gf).view(B, NF, 3, 3), None, None, None, None
 
 

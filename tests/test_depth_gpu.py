@@ -1,0 +1,136 @@
+"""Ordinal-depth row on the GPU: depth image, its backward, the loss and the model term vs the oracle."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _scene(mano_model, frames=4, size=64):
+    from homan_amd import synth
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=11, frames=frames, rend_size=size, image_size=size, obj="cube", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    K = torch.from_numpy(clip["camintr"]).float()
+    return clip, K
+
+
+def _oracle_render(verts, faces, K, size):
+    from oracle import nmr
+    r = nmr.Renderer(image_size=size, K=K, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
+    _, depth, alpha = r.render(verts, faces)
+    return alpha, depth
+
+
+@pytest.mark.parametrize("which", ["object", "hand"])
+def test_depth_image_and_backward_match_oracle(which, mano_model):
+    from homan_amd import ops
+    size = 64
+    clip, K = _scene(mano_model, size=size)
+    if which == "object":
+        verts, faces = clip["gt"]["verts_object"], clip["objfaces"]
+    else:
+        verts = clip["gt"]["verts_hand"]
+        faces = torch.from_numpy(mano_model["faces"].astype(np.int32))[None].repeat(verts.shape[0], 1, 1)
+    B, V = verts.shape[:2]
+    vo = verts.clone().requires_grad_(True)
+    a_o, d_o = _oracle_render(vo, faces, K, size)
+    g = torch.from_numpy(np.random.default_rng(3).normal(size=tuple(d_o.shape)).astype(np.float32))
+    (d_o * g).sum().backward()
+
+    sctx = ops.SilhouetteContext(faces.to(DEV), V, B, size, DEV)
+    vh = verts.clone().to(DEV).requires_grad_(True)
+    a_h, d_h = ops.depth_render(vh, K.to(DEV), sctx, 1.0)
+    np.testing.assert_array_equal(a_h.cpu().numpy(), a_o.detach().numpy())
+    np.testing.assert_array_equal(d_h.detach().cpu().numpy(), d_o.detach().numpy())      # same bits
+    (d_h * g.to(DEV)).sum().backward()
+    want, got = vo.grad.numpy(), vh.grad.cpu().numpy()
+    scale = np.abs(want).max()
+    assert scale > 0
+    np.testing.assert_allclose(got / scale, want / scale, atol=1e-4)
+
+
+def test_ordinal_depth_loss_matches_oracle(mano_model):
+    from homan_amd import ops
+    from oracle import model as o_model
+    size = 64
+    clip, K = _scene(mano_model, size=size)
+    B = clip["gt"]["verts_object"].shape[0]
+    hf = torch.from_numpy(mano_model["faces"].astype(np.int32))[None].repeat(B, 1, 1)
+    a0, d0 = _oracle_render(clip["gt"]["verts_object"], clip["objfaces"], K, size)
+    # push the hand a little towards the object so that the two layers overlap with mixed ordering
+    vh = clip["gt"]["verts_hand"] + torch.tensor([0.05, 0.0, 0.03])
+    a1, d1 = _oracle_render(vh, hf, K, size)
+    m0 = (a0 == 1)
+    m1 = (a1 == 1) & ~m0                                   # annotation: the object owns the overlap
+    m1[0] = (a1[0] == 1)                                   # ... except in frame 0: the hand does
+    m0[0] = (a0[0] == 1) & ~m1[0]
+    d0o, d1o = d0.clone().requires_grad_(True), d1.clone().requires_grad_(True)
+    want = o_model.compute_ordinal_depth_loss(torch.stack([m0, m1], 1), [a0 == 1, a1 == 1], [d0o, d1o])["loss_depth"]
+    assert float(want) > 0
+    want.backward()
+
+    rws = ops.ReduceWorkspace(DEV)
+    d0h, d1h = d0.to(DEV).requires_grad_(True), d1.to(DEV).requires_grad_(True)
+    got = ops.ordinal_depth_loss(d0h, d1h, a0.to(DEV), a1.to(DEV), m0.to(torch.uint8).to(DEV).contiguous(),
+                                 m1.to(torch.uint8).to(DEV).contiguous(), rws)
+    np.testing.assert_allclose(got.item(), want.item(), rtol=1e-5)
+    (got * 1.0).backward()
+    for gh, go in ((d0h.grad, d0o.grad), (d1h.grad, d1o.grad)):
+        np.testing.assert_allclose(gh.cpu().numpy(), go.numpy(), rtol=1e-4, atol=1e-9)
+    # second call through the same workspace (self-resetting ticket)
+    got2 = ops.ordinal_depth_loss(d0h.detach(), d1h.detach(), a0.to(DEV), a1.to(DEV),
+                                  m0.to(torch.uint8).to(DEV).contiguous(), m1.to(torch.uint8).to(DEV).contiguous(), rws)
+    assert got2.item() == got.item()
+
+
+def test_model_ordinal_depth_term_matches_oracle(mano_model):
+    """HOMan(ordinal_depth=True) vs OracleHOMan(ordinal_depth=True): loss_depth and its parameter gradients;
+    without the opt-in both reproduce the reference's TypeError (homan.py:506-507)."""
+    from homan_amd import HOMan, synth
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    size = 64
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=5, frames=4, rend_size=size, image_size=size, obj="cube", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    # instance masks that disagree with the initial geometry: the object is annotated in front everywhere
+    for pp, op in zip(clip["person_parameters"], clip["object_parameters"]):
+        full = ((pp["masks"][0] > 0) | (op["full_mask"] > 0))
+        op["full_mask"] = full.float()
+        pp["masks"] = torch.zeros_like(pp["masks"])
+        pp["translations"] = pp["translations"] + torch.tensor([0.06, 0.0, -0.02])    # hand over the object
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                  image_size=size, mano_model=mano_model, rend_size=size)
+    lw = dict({k: 0.0 for k in synth.STEP1_LOSS_WEIGHTS}, lw_depth=1.0)
+    with pytest.raises(TypeError):
+        HOMan(**copy.deepcopy(kw), **common)(loss_weights=lw)
+    om = OracleHOMan(**copy.deepcopy(kw), ordinal_depth=True, **common)
+    hm = HOMan(**copy.deepcopy(kw), ordinal_depth=True, **common)
+    lo, _ = om(loss_weights=lw)
+    lh, _ = hm(loss_weights=lw)
+    assert sorted(lo) == sorted(lh) == ["loss_depth"]
+    assert float(lo["loss_depth"]) > 0
+    np.testing.assert_allclose(lh["loss_depth"].item(), lo["loss_depth"].item(), rtol=1e-4)
+    lo["loss_depth"].backward()
+    lh["loss_depth"].backward()
+    go = {k: p.grad for k, p in om.named_parameters() if p.grad is not None}
+    gh = {k: p.grad for k, p in hm.named_parameters() if p.grad is not None}
+    assert sorted(go) == sorted(gh) and len(go) > 0
+    for k in go:
+        scale = max(go[k].abs().max().item(), 1e-12)
+        np.testing.assert_allclose(gh[k].cpu().numpy() / scale, go[k].numpy() / scale, atol=1e-3, err_msg=k)
+    # a few optimisation steps on the depth term alone reduce it (graph loop; fresh model: the autograd graph kept
+    # alive above belongs to the default stream and cannot be replayed inside a capture)
+    from homan_amd.jointopt import GraphStepper
+    hm2 = HOMan(**copy.deepcopy(kw), ordinal_depth=True, **common)
+    st = GraphStepper(hm2, lw, 1e-2, 20)
+    st.run(20)
+    evo = st.loss_evolution(20)["loss"]
+    assert evo[-1] < evo[0]
