@@ -216,7 +216,7 @@ def main():
         gv = torch.empty(B, V, 3, device="cuda")
         one = torch.ones(1, device="cuda")
         reps = 50
-        ms = torch.zeros(2)
+        ms = torch.zeros(3)
         rc = hlib.lib().hm_bench_sil_kernels(
             hlib.ptr(verts), hlib.ptr(sctx.faces), hlib.ptr(model.camintr_rois_object), B, V, F, S,
             hlib.ptr(model.keep_mask_object), hlib.ptr(model.ref_mask_object), hlib.ptr(model.losses.keep_sum),

@@ -497,25 +497,11 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
     }   // planes
 }
 
-// ---------------------------------------------------------------- backward, pass 2: edge sweeps
-// Persistent wavefronts, one face at a time; lanes take the (edge, axis, d0) work items of the face (all six
-// edge/axis combinations packed back to back) so the dependent loads of a whole face are in flight together.
-// Both sweeps of an item walk 1-bit/sample planes: the outward sweep the "empty and g<0" plane from the edge to the
-// image border, the inward sweep the "covered and g>0" plane across the triangle.  Lines that run along the
-// silhouette band can hold hundreds of set bits: an item with more than SWEEP_LIGHT bits is handed to the whole
-// wave (64 lanes stride its range, shuffle-reduce), which bounds the serial chain a single lane can own.
-// parts (B,F,2 windings,3 edges,2 axes,2 end points).
-#define SWEEP_LIGHT 12
+// ---------------------------------------------------------------- backward: shared helpers
 __device__ __forceinline__ float sample_grad(const float* __restrict__ gimg, int S, int is, int xi, int yi)
 {
     return 0.25f * gimg[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
 }
-
-struct SweepCombo {           // wave-uniform description of one (edge, axis) line family
-    float p[3][2];            // p[n][0] sweep coordinate, p[n][1] the other one
-    float slope, num;
-    int dir, d0_from, count;
-};
 
 // contribution of sample d1 (pseudo-distance of the crossing to the two end points of the edge)
 __device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, float c0, float c1, bool use0, bool use1,
@@ -537,15 +523,98 @@ __device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, f
     }
 }
 
+// ---------------------------------------------------------------- backward, pass 2a: per-line source lists
+// Each sweep of an (edge, axis, d0) item collects from the set bits of ONE line of a plane, restricted to a range.
+// The lines are shared by all the items that cross them (~140 per line), so they are expanded once: a wave per
+// (plane, axis, frame, line) turns the bit line into a compact, position-sorted array of sources
+// {d1, sample gradient, owner face} plus the cumulative bit count at every 64-bit word.  An item then knows its
+// sources as the contiguous slice [lo, lo+nb) of that array (two popcounts), with no bit walking and no dependent
+// gradient / owner loads.
+struct SweepSrc { int d1; float g; int owner; };
+#define SWEEP_CUMW 16           // cumulative-count slots per line (is <= 1024)
+
+__global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restrict__ rowneg,
+                                                   const unsigned short* __restrict__ colneg,
+                                                   const float* __restrict__ gimg, const int* __restrict__ idx_map,
+                                                   int B, int S, SweepSrc* __restrict__ srcs,
+                                                   unsigned short* __restrict__ cum)
+{
+    const int lane = threadIdx.x & 63;
+    const int is = 2 * S, wpl = is / 64;
+    const long L = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+    if (L >= 4L * B * is) return;
+    // L = ((pl * 2 + axis) * B + b) * is + d0
+    const int d0 = (int)(L % is), b = (int)((L / is) % B), pa = (int)(L / ((long)is * B));
+    const int axis = pa & 1, pl = pa >> 1;
+    const long plane_words = (long)B * is * wpl;
+    const unsigned long long* line = reinterpret_cast<const unsigned long long*>(axis == 0 ? colneg : rowneg) +
+                                     pl * plane_words + ((long)b * is + d0) * wpl;
+    const unsigned long long mine = lane < wpl ? line[lane] : 0ull;
+    // exclusive prefix of the word popcounts (wpl <= 16 words: one 16-lane row scan)
+    int c = __popcll(mine);
+    int incl = c;
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);    // row_shr:1
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);    // row_shr:2
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);    // row_shr:4
+    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);    // row_shr:8
+    const int excl = incl - c;
+    if (lane < SWEEP_CUMW) cum[L * SWEEP_CUMW + lane] = (unsigned short)excl;
+    if (__builtin_amdgcn_readlane(incl, 15) == 0) return;
+    const float* gi = gimg + (long)b * S * S;
+    const int* idx = idx_map + (long)b * is * is;
+    SweepSrc* out = srcs + L * is;
+    for (int k = 0; k < wpl; ++k) {
+        const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffull), k);
+        const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), k);
+        const unsigned long long w = ((unsigned long long)hi32 << 32) | lo32;
+        if (w == 0ull) continue;
+        const int base = __builtin_amdgcn_readlane(excl, k);
+        if ((w >> lane) & 1ull) {
+            const int d1 = (k << 6) + lane;
+            const int xi = axis ? d1 : d0, yi = axis ? d0 : d1;
+            SweepSrc r;
+            r.d1 = d1;
+            r.g = 0.25f * gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
+            r.owner = pl ? idx[(long)yi * is + xi] : -1;
+            out[base + __popcll(w & ((1ull << lane) - 1ull))] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- backward, pass 2b: edge sweeps
+// Persistent wavefronts, one face (winding) at a time; lanes take the (edge, axis, d0) work items of the face, all six
+// edge/axis combinations packed back to back.  An item resolves its two sweeps to slices of per-line source arrays
+// (k_bwd_lines); the (item, source) pairs of the 64 items are then FLATTENED over the wave: pair p of the round goes
+// to lane p % 64, which finds its item by a binary search of the items' exclusive pair counts in LDS.  The number of
+// pairs per item is heavy-tailed (mean 2, lines tangent to the silhouette band hold hundreds): walking them lane-serially
+// left ~97 % of the lanes idle.
+// parts (B,F,2 windings,3 edges,2 axes,2 end points).
+struct SweepItem { float x, c0, c1; int base, meta; };      // meta: combo | use0 << 3 | use1 << 4
+
+__device__ __forceinline__ int hm_wave_scan_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ faces9, const FaceBox* __restrict__ boxes,
-                                                   const int* __restrict__ idx_map, const float* __restrict__ gimg,
+                                                   const int* __restrict__ idx_map,
                                                    const unsigned short* __restrict__ rowneg,
-                                                   const unsigned short* __restrict__ colneg, int B, int F, int S,
-                                                   float eps, float* __restrict__ parts, float* __restrict__ dbg,
+                                                   const unsigned short* __restrict__ colneg,
+                                                   const SweepSrc* __restrict__ srcs,
+                                                   const unsigned short* __restrict__ cum, int B, int F, int S,
+                                                   float eps, float* __restrict__ parts,
                                                    const unsigned char* __restrict__ owned,
                                                    const int* __restrict__ face_order)
 {
     __shared__ float s_cb[4][6][12];
+    __shared__ int s_start[4][64];
+    __shared__ SweepItem s_item[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int is = 2 * S;
     const bool pow2 = (is & (is - 1)) == 0;
@@ -555,17 +624,11 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
     for (long slot = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
          slot < (long)B * F; slot += nwaves) {
-        // faces are visited in `face_order` (expensive faces first, dealt round-robin to the persistent waves)
         const long bf = face_order ? (long)face_order[slot] : slot;
-        const unsigned long long t_start = dbg ? wall_clock64() : 0ull;
-        int dbg_items = 0, dbg_bits = 0, dbg_heavy = 0;
         const int b = (int)(bf / F), fi = (int)(bf % F);
         const unsigned mask = (reinterpret_cast<const uint2*>(boxes)[bf].x >> 14) & 3u;
         const float* src = faces9 + bf * 9;
         const int* idx = idx_map + (long)b * is * is;
-        const float* gi = gimg + (long)b * S * S;
-        const unsigned long long* colw = reinterpret_cast<const unsigned long long*>(colneg) + (long)b * is * wpl;
-        const unsigned long long* roww = reinterpret_cast<const unsigned long long*>(rowneg) + (long)b * is * wpl;
         float px[3], py[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { px[k] = topix(src[3 * k], is); py[k] = topix(src[3 * k + 1], is); }
@@ -578,8 +641,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
                 if (lane < 12) out[lane] = 0.f;
                 continue;
             }
-            // lanes 0..5 build the six (edge, axis) line families of this winding into LDS (they are wave-uniform
-            // data; keeping them out of VGPRs is what lets 8 waves per SIMD hide the memory latency of the sweeps)
+            // lanes 0..5 build the six (edge, axis) line families of this winding into LDS (wave-uniform data)
             __builtin_amdgcn_wave_barrier();
             if (lane < 6) {
                 const int e = lane >> 1, axis = lane & 1;
@@ -617,23 +679,32 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
 #pragma unroll
             for (int k = 0; k < 6; ++k) off[k + 1] = off[k] + reinterpret_cast<const int*>(s_cb[wv][k])[10];
             const int total = off[6];
-            dbg_items += total;
+            // per-lane running sums: pairs reach a lane in ascending item order, so the combination index only grows;
+            // (cur, acc0, acc1) is flushed into tot[] when it changes
             float tot[12];
 #pragma unroll
             for (int k = 0; k < 12; ++k) tot[k] = 0.f;
+            int cur = 0;
+            float acc0 = 0.f, acc1 = 0.f;
+#define HM_SWEEP_FLUSH()                                                                     \
+    {                                                                                        \
+        _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) {                                   \
+            tot[2 * k_] += (cur == k_) ? acc0 : 0.f;                                         \
+            tot[2 * k_ + 1] += (cur == k_) ? acc1 : 0.f;                                     \
+        }                                                                                    \
+        acc0 = 0.f;                                                                          \
+        acc1 = 0.f;                                                                          \
+    }
 #pragma unroll 1
             for (int base = 0; base < total; base += 64) {
                 const int item = base + lane;
-                float acc0 = 0.0f, acc1 = 0.0f;
-                int ci = -1;
                 // ---- per-lane item setup
-                int axis = 0, d0r = 0;
+                int ci = 0, axis = 0, d0r = 0;
                 float d1_cross = 0.f, c0 = 0.f, c1 = 0.f;
                 bool use0 = false, use1 = false;
                 bool act[2] = {false, false};          // [0] outward, [1] inward
                 int rfrom[2] = {0, 0}, rto[2] = {-1, -1};
                 if (item < total) {
-                    ci = 0;
                     int start = 0;
 #pragma unroll
                     for (int k = 1; k < 6; ++k) if (item >= off[k]) { ci = k; start = off[k]; }
@@ -658,7 +729,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
                                 const int lim = (dir > 0) ? is - 1 : 0;
                                 rfrom[0] = max(min(d1_out, lim), 0);
                                 rto[0] = min(max(d1_out, lim), is - 1);
-                                act[0] = true;
+                                act[0] = rfrom[0] <= rto[0];
                             }
                             if (idx_out < 0) {              // inward: across the triangle, only if the outside sample is empty
                                 float c2;
@@ -671,170 +742,68 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
                                     const int lim = (dir > 0) ? (int)ceilf(c2) : (int)floorf(c2);
                                     rfrom[1] = max(min(d1_in, lim), 0);
                                     rto[1] = min(max(d1_in, lim), is - 1);
-                                    act[1] = true;
+                                    act[1] = rfrom[1] <= rto[1];
                                 }
                             }
                         }
                     }
                 }
-                const unsigned long long* line0 = (axis == 0 ? colw : roww) + (long)d0r * wpl;
-                // ---- the two sweeps
+                // ---- slices of the line's source array: [lo, lo + nb) for both sweeps (all loads independent)
+                int lo[2] = {0, 0}, nb[2] = {0, 0};
+                long lid[2];
+#pragma unroll
+                for (int ph = 0; ph < 2; ++ph) {
+                    lid[ph] = ((long)(ph * 2 + axis) * B + b) * is + d0r;
+                    if (act[ph]) {
+                        const int from = rfrom[ph], to = rto[ph];
+                        const unsigned long long* line = reinterpret_cast<const unsigned long long*>(axis == 0 ? colneg : rowneg) +
+                                                         ph * plane_words + ((long)b * is + d0r) * wpl;
+                        const unsigned short* cl = cum + lid[ph] * SWEEP_CUMW;
+                        const unsigned long long wf = line[from >> 6], wt = line[to >> 6];
+                        const int cf = cl[from >> 6], ct = cl[to >> 6];
+                        lo[ph] = cf + __popcll(wf & ((1ull << (from & 63)) - 1ull));
+                        nb[ph] = ct + __popcll(wt & (~0ull >> (63 - (to & 63)))) - lo[ph];
+                    }
+                }
+                // ---- the two sweeps, flattened over the wave
 #pragma unroll 1
                 for (int ph = 0; ph < 2; ++ph) {
-                    const int from = rfrom[ph], to = rto[ph];
-                    const bool on = act[ph] && from <= to;
-                    // the whole line of the plane in registers (is <= 512: 8 words = four independent 16-byte loads),
-                    // clipped to [from, to]
-                    unsigned long long wd[8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) wd[k] = 0ull;
-                    if (on) {
-                        const unsigned long long* line = line0 + ph * plane_words;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if (k < wpl) wd[k] = line[k];
-                    }
-                    int nb = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int lo = k << 6;
-                        unsigned long long bits = wd[k];
-                        if (!on || to < lo || from > lo + 63) bits = 0ull;
-                        else {
-                            if (from > lo) bits &= ~0ull << (from - lo);
-                            if (to < lo + 63) bits &= ~0ull >> (lo + 63 - to);
-                        }
-                        wd[k] = bits;
-                        nb += __popcll(bits);
-                    }
-                    // Dense lines either go to the whole wave one at a time (cost ~ #dense lanes) or every lane walks its
-                    // own bits (cost ~ longest line); pick the cheaper of the two for this pass (wave-uniform).
-                    const int maxnb = (int)hm_wave_max((float)nb);
-                    const int ndense = __popcll(__ballot(nb > SWEEP_LIGHT));
-                    const bool coop = ndense * 16 < maxnb;
-                    const bool heavy = coop && nb > SWEEP_LIGHT;
-                    if (dbg) { dbg_bits += nb; dbg_heavy += heavy ? 1 : 0; }
-                    if (nb > 0 && !heavy) {
-                        // lane-serial walk, four set bits per round, software-pipelined: the gradient (and owner) loads
-                        // of round r+1 are issued before the arithmetic of round r
-                        int kw = 0;
-                        unsigned long long bits = wd[0];
-                        int left = nb;
-                        int d1n[4];
-                        float gn4[4];
-                        int idn[4];
-                        unsigned okn4 = 0;
-#define HM_LIGHT_FETCH()                                                                                          \
-    {                                                                                                             \
-        okn4 = 0;                                                                                                 \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                           \
-            while (left > 0 && bits == 0ull) {                                                                    \
-                ++kw;                                                                                             \
-                bits = kw == 1 ? wd[1] : kw == 2 ? wd[2] : kw == 3 ? wd[3] : kw == 4 ? wd[4] : kw == 5 ? wd[5]    \
-                                                                       : kw == 6 ? wd[6] : wd[7];                 \
-            }                                                                                                     \
-            const bool has = left > 0;                                                                            \
-            d1n[u] = has ? (kw << 6) + __ffsll((long long)bits) - 1 : 0;                                          \
-            if (has) { bits &= bits - 1; --left; okn4 |= 1u << u; }                                               \
-        }                                                                                                         \
-        _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                                           \
-            const int xi = axis ? d1n[u] : d0r, yi = axis ? d0r : d1n[u];                                         \
-            const bool has = (okn4 >> u) & 1u;                                                                    \
-            gn4[u] = has ? sample_grad(gi, S, is, xi, yi) : 0.f;                                                  \
-            idn[u] = (ph == 1 && has) ? idx[(long)yi * is + xi] : fn;                                             \
-        }                                                                                                         \
-    }
-                        HM_LIGHT_FETCH()
+                    const int n = nb[ph];
+                    const int incl = hm_wave_scan_incl(n);
+                    const int npairs = __builtin_amdgcn_readlane(incl, 63);
+                    if (npairs == 0) continue;
+                    __builtin_amdgcn_wave_barrier();
+                    s_start[wv][lane] = incl - n;
+                    SweepItem it;
+                    it.x = d1_cross; it.c0 = c0; it.c1 = c1;
+                    it.base = (int)(lid[ph] * is) + lo[ph];
+                    it.meta = ci | (use0 ? 8 : 0) | (use1 ? 16 : 0);
+                    s_item[wv][lane] = it;
+                    wave_sync();
+                    const int* st = s_start[wv];
 #pragma unroll 1
-                        while (okn4) {
-                            int d1c[4];
-                            float gc[4];
-                            unsigned okc4 = 0;
+                    for (int p = lane; p < npairs; p += 64) {
+                        int i = 0;
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                d1c[u] = d1n[u];
-                                gc[u] = gn4[u];
-                                if (((okn4 >> u) & 1u) && idn[u] == fn) okc4 |= 1u << u;
-                            }
-                            HM_LIGHT_FETCH()
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-                                if ((okc4 >> u) & 1u) sweep_term(ph == 0 ? -gc[u] : gc[u], d1c[u], d1_cross, c0, c1, use0, use1, eps, inv_is, pow2, is, acc0, acc1);
-                        }
-#undef HM_LIGHT_FETCH
+                        for (int stp = 32; stp > 0; stp >>= 1)
+                            if (st[i + stp] <= p) i += stp;
+                        const SweepItem q = s_item[wv][i];
+                        const SweepSrc sc = srcs[(long)q.base + (p - st[i])];
+                        const int qc = q.meta & 7;
+                        if (qc != cur) { HM_SWEEP_FLUSH() cur = qc; }
+                        if (ph == 0 || sc.owner == fn)
+                            sweep_term(ph == 0 ? -sc.g : sc.g, sc.d1, q.x, q.c0, q.c1, (q.meta & 8) != 0, (q.meta & 16) != 0,
+                                       eps, inv_is, pow2, is, acc0, acc1);
                     }
-                    // ---- dense lines: the whole wave works on one lane's range at a time (line words broadcast
-                    //      from the owner's registers; every lane takes positions lane, lane+64, ...)
-                    unsigned long long hv = __ballot(heavy);
-                    // software-pipelined over the heavy lanes: the gradient (and owner) loads of the next line are in
-                    // flight while the current one is reduced
-                    float gk[8], gn[8];
-                    unsigned okc = 0, okn = 0;
-                    int hc = -1, hn = -1;
-#define HM_HEAVY_FETCH(H, G, OK)                                                                                   \
-    {                                                                                                              \
-        const int haxis_ = __builtin_amdgcn_readlane(axis, H), hd0_ = __builtin_amdgcn_readlane(d0r, H);           \
-        OK = 0;                                                                                                    \
-        _Pragma("unroll") for (int k = 0; k < 8; ++k) {                                                            \
-            const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(wd[k] & 0xffffffffull), H);            \
-            const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(wd[k] >> 32), H);                      \
-            const unsigned long long w_ = ((unsigned long long)hi32 << 32) | lo32;                                 \
-            bool ok_ = (w_ >> lane) & 1ull;                                                                        \
-            const int d1_ = (k << 6) + lane;                                                                       \
-            const int xi_ = haxis_ ? d1_ : hd0_, yi_ = haxis_ ? hd0_ : d1_;                                        \
-            G[k] = ok_ ? sample_grad(gi, S, is, xi_, yi_) : 0.f;                                                   \
-            if (ph == 1 && ok_) ok_ = idx[(long)yi_ * is + xi_] == fn;                                             \
-            OK |= (ok_ ? 1u : 0u) << k;                                                                            \
-        }                                                                                                          \
-    }
-                    if (hv) {
-                        hn = __ffsll((long long)hv) - 1;
-                        hv &= hv - 1;
-                        HM_HEAVY_FETCH(hn, gn, okn)
-                    }
-#pragma unroll 1
-                    while (hn >= 0) {
-                        hc = hn;
-                        okc = okn;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) gk[k] = gn[k];
-                        hn = -1;
-                        if (hv) {
-                            hn = __ffsll((long long)hv) - 1;
-                            hv &= hv - 1;
-                            HM_HEAVY_FETCH(hn, gn, okn)
-                        }
-                        const float hcross = rlane(d1_cross, hc), hc0 = rlane(c0, hc), hc1 = rlane(c1, hc);
-                        const bool hu0 = __builtin_amdgcn_readlane((int)use0, hc), hu1 = __builtin_amdgcn_readlane((int)use1, hc);
-                        float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if ((okc >> k) & 1u) sweep_term(ph == 0 ? -gk[k] : gk[k], (k << 6) + lane, hcross, hc0, hc1, hu0, hu1, eps, inv_is, pow2, is, a0, a1);
-                        a0 = hm_wave_sum(a0);
-                        a1 = hm_wave_sum(a1);
-                        if (lane == hc) { acc0 += a0; acc1 += a1; }
-                    }
-#undef HM_HEAVY_FETCH
-                }
-                // masked wave reductions: combination k collects the lanes whose item belongs to it
-#pragma unroll
-                for (int k = 0; k < 6; ++k) {
-                    if (off[k + 1] <= base || off[k] >= base + 64) continue;     // uniform
-                    tot[2 * k] += hm_wave_sum(ci == k ? acc0 : 0.f);
-                    tot[2 * k + 1] += hm_wave_sum(ci == k ? acc1 : 0.f);
                 }
             }
+            HM_SWEEP_FLUSH()
+#undef HM_SWEEP_FLUSH
+#pragma unroll
+            for (int k = 0; k < 12; ++k) tot[k] = hm_wave_sum(tot[k]);
             if (lane == 0) {
 #pragma unroll
                 for (int k = 0; k < 12; ++k) out[k] = tot[k];
-            }
-        }
-        if (dbg) {
-            const float tb = hm_wave_sum((float)dbg_bits), th = hm_wave_sum((float)dbg_heavy);
-            if (lane == 0) {
-                dbg[3 * bf] = tb;
-                dbg[3 * bf + 1] = (float)(wall_clock64() - t_start);
-                dbg[3 * bf + 2] = th;
             }
         }
     }   // face loop
@@ -1065,10 +1034,7 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
 }
 
 // ================================================================ C ABI
-static float* g_sweep_dbg = nullptr;   // optional per-wave timing buffer (tools only)
 extern "C" {
-void hm_debug_set_sweep_buffer(float* p) { g_sweep_dbg = p; }
-
 
 // workspace layout helper (bytes), all chunks 256-byte aligned
 static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -1090,6 +1056,8 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
     n += al256((size_t)B * is * (is / 16) * 4); // column masks, 2 planes
     n += al256((size_t)B * F * 24 * 4);         // parts
     n += al256((size_t)B * F * 2);              // owned
+    n += al256(4 * (size_t)B * is * SWEEP_CUMW * 2);            // per-line cumulative source counts
+    n += al256(4 * (size_t)B * is * is * sizeof(SweepSrc));     // per-line source arrays (2 planes x 2 orientations)
     return n;
 }
 
@@ -1097,7 +1065,7 @@ struct SilWs {
     unsigned int* counter; float* frame_rec;
     float* ndc; float* faces9; FaceBox* boxes; int* idx_map; unsigned short* alpha16; float* dimg;
     float* partials; float* gimg; unsigned short* rowneg; unsigned short* colneg; float* parts;
-    unsigned char* owned;
+    unsigned char* owned; unsigned short* cum; SweepSrc* srcs;
 };
 static SilWs carve(void* ws, int B, int V, int F, int S)
 {
@@ -1117,7 +1085,9 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.rowneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4);
     w.colneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4);
     w.parts = (float*)p; p += al256((size_t)B * F * 24 * 4);
-    w.owned = (unsigned char*)p;
+    w.owned = (unsigned char*)p; p += al256((size_t)B * F * 2);
+    w.cum = (unsigned short*)p; p += al256(4 * (size_t)B * is * SWEEP_CUMW * 2);
+    w.srcs = (SweepSrc*)p;
     return w;
 }
 
@@ -1157,14 +1127,16 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
 {
     HM_CHECK_ARG(verts && K && adj_off && adj_items && grad_verts && workspace);
     HM_CHECK_ARG(mode == 0 ? grad_pooled != nullptr : (upstream && keep_sum));
-    if (S % 32 != 0 || S > 256) return HM_ERR_UNSUPPORTED;     // sweep keeps a whole mask line (<= 512 bits) in registers
+    if (S % 32 != 0 || S > 32 * SWEEP_CUMW) return HM_ERR_UNSUPPORTED;     // 64-sample mask words, <= SWEEP_CUMW per line
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
     hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                        mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                        w.rowneg, w.colneg);
+    hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S * 64, 256)), dim3(256), 0, stream, w.rowneg, w.colneg,
+                       w.gimg, w.idx_map, B, S, w.srcs, w.cum);
     hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), 2048)), dim3(256), 0, stream, w.faces9, w.boxes,
-                       w.idx_map, w.gimg, w.rowneg, w.colneg, B, F, S, eps, w.parts, g_sweep_dbg, w.owned, face_order);
+                       w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, eps, w.parts, w.owned, face_order);
     hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                        adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
     return hm_launch_status();
@@ -1243,12 +1215,20 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), 2048)), dim3(256), 0, stream, w.faces9,
-                           w.boxes, w.idx_map, w.gimg, w.rowneg, w.colneg, B, F, S, 1e-3f, w.parts, (float*)nullptr,
-                           w.owned, face_order);
+                           w.boxes, w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, 1e-3f, w.parts, w.owned,
+                           face_order);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
     avg_ms[1] = ms / (float)reps;
+    (void)hipEventRecord(e0, stream);
+    for (int i = 0; i < reps; ++i)
+        hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S * 64, 256)), dim3(256), 0, stream, w.rowneg, w.colneg,
+                           w.gimg, w.idx_map, B, S, w.srcs, w.cum);
+    (void)hipEventRecord(e1, stream);
+    (void)hipEventSynchronize(e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    avg_ms[2] = ms / (float)reps;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return hm_launch_status();

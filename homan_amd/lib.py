@@ -26,7 +26,6 @@ _SIGNATURES = {
     "hm_sil_read_boxes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_debug_occupancy": (_I, [_VP, _VP]),
     "hm_debug_read_partials": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
-    "hm_debug_set_sweep_buffer": (None, [_VP]),
     "hm_sil_read_idx_map": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_faces9": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_rigid_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),

@@ -175,8 +175,8 @@ int hm_log_scalars(const float* src, int n, const int* step, int max_steps, floa
 
 /* ------------------------------------------------------------------ measurement / debug hooks (synchronous)
  * hm_bench_sil_kernels: one full silhouette forward + backward to populate the workspace, then `reps` launches of the
- * raster kernel and `reps` launches of the edge-sweep kernel, each bracketed by two HIP events on `stream`;
- * avg_ms[0..1] (HOST pointer) receive the average launch durations in milliseconds. */
+ * raster kernel, of the edge-sweep kernel and of the line-source kernel, each series bracketed by two HIP events on
+ * `stream`; avg_ms[0..2] (HOST pointer) receive the average launch durations in milliseconds. */
 int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, int B, int V, int F, int S,
                          const float* keep, const float* ref, const float* keep_sum, float* pooled, float* loss_out,
                          const int* work_order, const int* adj_off, const int* adj_items, const int* face_order,
@@ -184,7 +184,6 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
                          hipStream_t stream);
 int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks);
 int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
-void hm_debug_set_sweep_buffer(float* p);
 
 #ifdef __cplusplus
 }
