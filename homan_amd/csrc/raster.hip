@@ -114,134 +114,39 @@ __global__ void k_setup_faces(const float* __restrict__ ndc, const int* __restri
     boxes[i] = bx;
 }
 
-// Rasterise `n` (<=64) queued faces into the wave's tile.  One lane per face builds the face record in registers
-// (vertices in winding order, reciprocal vertex depths, barycentric inverse) and applies a conservative "triangle
-// misses this tile" reject; the surviving records are then broadcast one at a time with v_readlane, i.e. they live
-// in SGPRs while all 64 lanes test their four samples -- no LDS round trip in the inner loop.
-// tile_* = NDC coordinates of the extreme sample centres of the wave's tile.
+__device__ __forceinline__ int hm_wave_scan_incl(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 __device__ __forceinline__ float rlane(float v, int l)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
-__device__ __forceinline__ void raster_batch(const int* q, int n, int b, int F, int is,
-                                             const float* __restrict__ faces9, const float (&xp)[2],
-                                             const float (&yp)[2], const float (&xf)[2], const float (&yf)[2],
-                                             float (&zmin)[4], int (&imin)[4], float znear, float zfar, int lane,
-                                             float tile_x0, float tile_x1, float tile_y0, float tile_y1)
-{
-    float rec[18];
-    int rfn = -1;
-#pragma unroll
-    for (int k = 0; k < 18; ++k) rec[k] = 0.f;
-    if (lane < n) {
-        const int e = q[lane];
-        const int fi = e & 0x3fffffff, var = e >> 30;
-        const float* src = faces9 + ((long)b * F + fi) * 9;
-        float f[9];
-        if (var == 0) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) f[k] = src[k];
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { f[3 * k] = src[3 * (2 - k)]; f[3 * k + 1] = src[3 * (2 - k) + 1]; f[3 * k + 2] = src[3 * (2 - k) + 2]; }
-        }
-        float p[3][2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { p[k][0] = topix(f[3 * k], is); p[k][1] = topix(f[3 * k + 1], is); }
-        const float inv[9] = {
-            p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
-            p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
-            p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
-        const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
-                          p[1][0] * (p[2][1] - p[0][1]);
-        // conservative reject: some edge has all four tile corners outside by more than the rounding noise of the
-        // edge function (the function is affine, so its extremes over the tile sit at the corners)
-        bool miss = (den == 0.0f);
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int k1 = (k + 1) % 3;
-            const float ax = f[3 * k], ay = f[3 * k + 1], ex = f[3 * k1] - ax, ey = f[3 * k1 + 1] - ay;
-            bool all_out = true;
-            float mag = 0.f;
-            float lhs[4], rhs[4];
-#pragma unroll
-            for (int cnr = 0; cnr < 4; ++cnr) {
-                const float X = (cnr & 1) ? tile_x1 : tile_x0, Y = (cnr & 2) ? tile_y1 : tile_y0;
-                lhs[cnr] = (Y - ay) * ex;
-                rhs[cnr] = (X - ax) * ey;
-                mag = fmaxf(mag, fabsf(lhs[cnr]) + fabsf(rhs[cnr]));
-            }
-#pragma unroll
-            for (int cnr = 0; cnr < 4; ++cnr) all_out = all_out && (lhs[cnr] < rhs[cnr] - 1e-5f * mag);
-            miss = miss || all_out;
-        }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) rec[k] = f[k];
-        rec[2] = 1.0f / f[2]; rec[5] = 1.0f / f[5]; rec[8] = 1.0f / f[8];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) rec[9 + k] = inv[k] / den;
-        rfn = miss ? -1 : (fi + var * F);
-    }
-    unsigned long long valid = __ballot(rfn >= 0);
-    while (valid) {
-        const int e = __ffsll((long long)valid) - 1;
-        valid &= valid - 1;
-        const int fn = __builtin_amdgcn_readlane(rfn, e);
-        const float f0 = rlane(rec[0], e), f1 = rlane(rec[1], e), f3 = rlane(rec[3], e), f4 = rlane(rec[4], e),
-                    f6 = rlane(rec[6], e), f7 = rlane(rec[7], e);
-        const float e0x = f3 - f0, e0y = f4 - f1, e1x = f6 - f3, e1y = f7 - f4, e2x = f0 - f6, e2y = f1 - f7;
-        bool in[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const float X = xp[s & 1], Y = yp[s >> 1];
-            in[s] = !(((Y - f1) * e0x < (X - f0) * e0y) || ((Y - f4) * e1x < (X - f3) * e1y) ||
-                      ((Y - f7) * e2x < (X - f6) * e2y));
-        }
-        if (!__any(in[0] || in[1] || in[2] || in[3])) continue;
-        const float rz0 = rlane(rec[2], e), rz1 = rlane(rec[5], e), rz2 = rlane(rec[8], e);
-        // the interpolated depth is a weighted harmonic mean of the vertex depths, hence >= the nearest vertex depth;
-        // 1e-5 relative slack covers its rounding.  Samples already owned by something nearer cannot change.
-        const float znear_face = (1.0f / fmaxf(rz0, fmaxf(rz1, rz2))) * (1.0f - 1e-5f);
-        bool live[4];
-#pragma unroll
-        for (int s = 0; s < 4; ++s) live[s] = in[s] && !(znear_face > zmin[s]);
-        if (!__any(live[0] || live[1] || live[2] || live[3])) continue;
-        float iv[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) iv[k] = rlane(rec[9 + k], e);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (!__any(live[s])) continue;
-            const int dy = s >> 1, dx = s & 1;
-            float wgt[3], ws = 0.0f;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                float t = iv[3 * k] * xf[dx];
-                t = t + iv[3 * k + 1] * yf[dy];
-                t = t + iv[3 * k + 2];
-                t = fminf(fmaxf(t, 0.0f), 1.0f);
-                wgt[k] = t;
-                ws += t;
-            }
-            float sum = wgt[0] * rz0;
-            sum = sum + wgt[1] * rz1;
-            sum = sum + wgt[2] * rz2;
-            const float zp = ws / sum;
-            const bool hit = in[s] && (zp > znear && zp < zfar) && (zp < zmin[s] || (zp == zmin[s] && fn < imin[s]));
-            if (hit) { zmin[s] = zp; imin[s] = fn; }
-        }
-    }
-}
-
 // ---------------------------------------------------------------- forward raster
-// Workgroup = 4 wavefronts = a 2x2 block of 8x8-pixel tiles (a 32x32-sample region); one wave per tile.
-// Binning is two-level and on the fly: the workgroup scans the 8-byte screen boxes of the frame (coalesced,
-// 4 independent loads per thread in flight) and keeps the faces overlapping its region in an LDS candidate list;
-// each wave then filters the candidates against its own tile with ballot compaction.
+// Workgroup = 4 wavefronts = one 32x32-sample region (a 2x2 block of 8x8-pixel output tiles) of one frame.
+//   1. binning on the fly: the workgroup scans the 8-byte screen boxes of the frame (coalesced) and keeps the
+//      (face, winding) entries overlapping its region in an LDS candidate list;
+//   2. one thread per candidate builds the face record (edge vectors, reciprocal depths, barycentric inverse) in LDS
+//      and counts the 4x4-sample blocks of (face box & region);
+//   3. the (candidate, block) units of the pass are FLATTENED over the 256 threads (unit u -> candidate by a binary
+//      search of the exclusive unit counts): every thread tests the 16 samples of its block against its face and
+//      resolves visibility with ds_min_u64 on an LDS z-buffer keyed (depth bits << 32 | face index) -- the smaller
+//      depth wins and equal depths go to the smaller index, which is the strict-z-test-in-ascending-face-order rule
+//      of the rasteriser.  Faces are ~50 samples large: broadcasting one face to a 256-sample tile (round-1 design)
+//      spent >90 % of the sample tests outside the face's box;
+//   4. epilogue: one wave per 8x8 output tile reads its samples back (lane = output pixel, 2x2 samples).
 // Outputs: idx_map (B,is,is) int32; alpha16 (B,is,is/16) u16 bit-plane; pooled (B,S,S);
-// optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4).
-#define CAND_CAP 1024
+// optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4); optional pooled depth.
+#define CAND_CAP 1024      // faces scanned per binning round (<= 2 entries each)
+#define RB_PASS 256        // candidates per record pass (= threads)
 __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
@@ -249,106 +154,210 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned,
     float* __restrict__ pooled_depth)
 {
-    __shared__ int queue[RASTER_WAVES][192];
-    __shared__ uint2 cand_box[CAND_CAP];
-    __shared__ int cand_id[CAND_CAP];
+    __shared__ unsigned long long zb[32 * 32];
+    __shared__ int cand[2 * CAND_CAP];
+    __shared__ float4 recs[RB_PASS][5];
+    __shared__ int ustart[RB_PASS];
+    __shared__ int wsum[RASTER_WAVES];
     __shared__ int cand_n;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int is = 2 * S, tiles_x = S / HM_TILE, ntiles = tiles_x * tiles_x, regions_x = tiles_x / 2;
     // dispatch order = work_order[block] = (frame << 16 | region): expensive (frame, region) pairs first so that the
     // cheap ones fill the tail of the launch (default: centre of the ROI outwards; calibrated: by candidate count)
-    const int regions = regions_x * regions_x;
     const int wo = work_order ? work_order[blockIdx.x] : (int)(((blockIdx.x % B) << 16) | (blockIdx.x / B));
     const int region = wo & 0xffff, b = wo >> 16;
-    (void)regions;
     const int rx = region % regions_x, ry = region / regions_x;
     const int tx = 2 * rx + (w & 1), ty = 2 * ry + (w >> 1);
     const int tile = ty * tiles_x + tx;
-    int* q = queue[w];
 
-    // this lane's output pixel and its 2x2 samples (flip: output row r <-> sample rows is-1-2r-dy)
-    const int r = ty * HM_TILE + (lane >> 3), c = tx * HM_TILE + (lane & 7);
-    const int xi0 = 2 * c, yi0 = is - 1 - 2 * r;   // sample (dy,dx): yi = yi0 - dy, xi = xi0 + dx
-    float xp[2], yp[2], xf[2], yf[2];
-#pragma unroll
-    for (int d = 0; d < 2; ++d) {
-        xp[d] = (float)(2 * (xi0 + d) + 1 - is) / (float)is;
-        yp[d] = (float)(2 * (yi0 - d) + 1 - is) / (float)is;
-        xf[d] = (float)(xi0 + d);
-        yf[d] = (float)(yi0 - d);
-    }
-    float zmin[4] = {zfar, zfar, zfar, zfar};
-    int imin[4] = {-1, -1, -1, -1};
-
-    // sample boxes of this wave's tile and of the workgroup's region
-    const int tx0 = tx * HM_STILE, tx1 = tx0 + HM_STILE - 1;
-    const int ty1 = is - 1 - ty * HM_STILE, ty0 = ty1 - (HM_STILE - 1);
+    // sample box of the workgroup's region
     const int gx0 = rx * 2 * HM_STILE, gx1 = gx0 + 2 * HM_STILE - 1;
     const int gy1 = is - 1 - ry * 2 * HM_STILE, gy0 = gy1 - (2 * HM_STILE - 1);
-    const float tcx0 = (float)(2 * tx0 + 1 - is) / (float)is, tcx1 = (float)(2 * tx1 + 1 - is) / (float)is;
-    const float tcy0 = (float)(2 * ty0 + 1 - is) / (float)is, tcy1 = (float)(2 * ty1 + 1 - is) / (float)is;
+    const float gcx0 = (float)(2 * gx0 + 1 - is) / (float)is, gcx1 = (float)(2 * gx1 + 1 - is) / (float)is;
+    const float gcy0 = (float)(2 * gy0 + 1 - is) / (float)is, gcy1 = (float)(2 * gy1 + 1 - is) / (float)is;
+    const unsigned long long zb_empty = ((unsigned long long)__float_as_uint(zfar) << 32) | 0xffffffffull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) zb[tid + 256 * k] = zb_empty;
 
-    int qn = 0;
     const uint2* bx = reinterpret_cast<const uint2*>(boxes) + (long)b * F;
     for (int cbase = 0; cbase < F; cbase += CAND_CAP) {
-        if (threadIdx.x == 0) cand_n = 0;
+        if (tid == 0) cand_n = 0;
         __syncthreads();
         uint2 v[CAND_CAP / 256];
 #pragma unroll
         for (int k = 0; k < CAND_CAP / 256; ++k) {
-            const int fi = cbase + k * 256 + threadIdx.x;
+            const int fi = cbase + k * 256 + tid;
             v[k] = (fi < F) ? bx[fi] : make_uint2(0u, 0u);
         }
 #pragma unroll
         for (int k = 0; k < CAND_CAP / 256; ++k) {
-            const int fi = cbase + k * 256 + threadIdx.x;
+            const int fi = cbase + k * 256 + tid;
             const int x0 = v[k].x & 0x3fff, y0 = (int)(v[k].x >> 16), x1 = (int)(v[k].y & 0xffff), y1 = (int)(v[k].y >> 16);
-            const bool hit = ((v[k].x >> 14) & 3u) && !(x1 < gx0 || x0 > gx1 || y1 < gy0 || y0 > gy1);
-            const unsigned long long bal = __ballot(hit);
-            int basep = 0;
-            if (lane == 0 && bal) basep = atomicAdd(&cand_n, __popcll(bal));
-            basep = __shfl(basep, 0, 64);
-            if (hit) {
-                const int pos = basep + __popcll(bal & ((1ull << lane) - 1ull));
-                cand_box[pos] = v[k];
-                cand_id[pos] = fi;
+            const unsigned m = (x1 < gx0 || x0 > gx1 || y1 < gy0 || y0 > gy1) ? 0u : ((v[k].x >> 14) & 3u);
+#pragma unroll
+            for (int var = 0; var < 2; ++var) {
+                const bool hit = (m >> var) & 1u;
+                const unsigned long long bal = __ballot(hit);
+                if (bal == 0ull) continue;
+                int basep = 0;
+                if (lane == 0) basep = atomicAdd(&cand_n, __popcll(bal));
+                basep = __builtin_amdgcn_readfirstlane(basep);
+                if (hit) cand[basep + __popcll(bal & ((1ull << lane) - 1ull))] = fi | (var << 30);
             }
         }
         __syncthreads();
         const int n = cand_n;
-        for (int e0 = 0; e0 < n; e0 += 64) {
-            const int e = e0 + lane;
-            unsigned mask = 0;
-            int fi = 0;
-            if (e < n) {
-                const uint2 u = cand_box[e];
-                fi = cand_id[e];
-                const int x0 = u.x & 0x3fff, y0 = (int)(u.x >> 16), x1 = (int)(u.y & 0xffff), y1 = (int)(u.y >> 16);
-                mask = (u.x >> 14) & 3u;
-                if (x1 < tx0 || x0 > tx1 || y1 < ty0 || y0 > ty1) mask = 0;
-            }
+        for (int e0 = 0; e0 < n; e0 += RB_PASS) {
+            // ---- one thread per candidate: face record + number of 4x4 blocks of (box & region)
+            int units = 0;
+            if (e0 + tid < n) {
+                const int e = cand[e0 + tid];
+                const int fi = e & 0x3fffffff, var = e >> 30;
+                const float* src = faces9 + ((long)b * F + fi) * 9;
+                float f[9];
+                if (var == 0) {
 #pragma unroll
-            for (int var = 0; var < 2; ++var) {
-                const bool hit = (mask >> var) & 1u;
-                const unsigned long long bal = __ballot(hit);
-                if (hit) q[qn + __popcll(bal & ((1ull << lane) - 1ull))] = fi | (var << 30);
-                qn += __popcll(bal);
+                    for (int k = 0; k < 9; ++k) f[k] = src[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { f[3 * k] = src[3 * (2 - k)]; f[3 * k + 1] = src[3 * (2 - k) + 1]; f[3 * k + 2] = src[3 * (2 - k) + 2]; }
+                }
+                float p[3][2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { p[k][0] = topix(f[3 * k], is); p[k][1] = topix(f[3 * k + 1], is); }
+                const float inv[9] = {
+                    p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                    p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                    p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+                const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
+                                  p[1][0] * (p[2][1] - p[0][1]);
+                // conservative reject: some edge has all four region corners outside by more than the rounding noise
+                // of the edge function (the function is affine, so its extremes over the region sit at the corners)
+                bool miss = (den == 0.0f);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int k1 = (k + 1) % 3;
+                    const float ax = f[3 * k], ay = f[3 * k + 1], ex = f[3 * k1] - ax, ey = f[3 * k1 + 1] - ay;
+                    bool all_out = true;
+                    float mag = 0.f;
+                    float lhs[4], rhs[4];
+#pragma unroll
+                    for (int cnr = 0; cnr < 4; ++cnr) {
+                        const float X = (cnr & 1) ? gcx1 : gcx0, Y = (cnr & 2) ? gcy1 : gcy0;
+                        lhs[cnr] = (Y - ay) * ex;
+                        rhs[cnr] = (X - ax) * ey;
+                        mag = fmaxf(mag, fabsf(lhs[cnr]) + fabsf(rhs[cnr]));
+                    }
+#pragma unroll
+                    for (int cnr = 0; cnr < 4; ++cnr) all_out = all_out && (lhs[cnr] < rhs[cnr] - 1e-5f * mag);
+                    miss = miss || all_out;
+                }
+                if (!miss) {
+                    const uint2 u = bx[fi];
+                    const int x0 = u.x & 0x3fff, y0 = (int)(u.x >> 16), x1 = (int)(u.y & 0xffff), y1 = (int)(u.y >> 16);
+                    // region-local 4x4 block range
+                    const int bx0 = (max(x0, gx0) - gx0) >> 2, bx1 = (min(x1, gx1) - gx0) >> 2;
+                    const int by0 = (max(y0, gy0) - gy0) >> 2, by1 = (min(y1, gy1) - gy0) >> 2;
+                    const int nbx = bx1 - bx0 + 1;
+                    units = nbx * (by1 - by0 + 1);
+                    recs[tid][0] = make_float4(f[0], f[1], f[3], f[4]);
+                    recs[tid][1] = make_float4(f[6], f[7], 1.0f / f[2], 1.0f / f[5]);
+                    recs[tid][2] = make_float4(1.0f / f[8], inv[0] / den, inv[1] / den, inv[2] / den);
+                    recs[tid][3] = make_float4(inv[3] / den, inv[4] / den, inv[5] / den, inv[6] / den);
+                    recs[tid][4] = make_float4(inv[7] / den, inv[8] / den, __int_as_float(fi + var * F),
+                                               __int_as_float(bx0 | (by0 << 8) | (nbx << 16)));
+                }
             }
-            wave_sync();
-            while (qn >= 64) {
-                raster_batch(q, 64, b, F, is, faces9, xp, yp, xf, yf, zmin, imin, znear, zfar, lane, tcx0, tcx1, tcy0, tcy1);
-                const int rem = qn - 64;
-                int moved = 0;
-                if (lane < rem) moved = q[64 + lane];
-                wave_sync();
-                if (lane < rem) q[lane] = moved;
-                wave_sync();
-                qn = rem;
+            // ---- exclusive prefix of the unit counts over the workgroup
+            const int incl = hm_wave_scan_incl(units);
+            if (lane == 63) wsum[w] = incl;
+            __syncthreads();
+            int woff = 0, total = 0;
+#pragma unroll
+            for (int k = 0; k < RASTER_WAVES; ++k) {
+                const int t = wsum[k];
+                if (k < w) woff += t;
+                total += t;
             }
+            ustart[tid] = woff + incl - units;
+            __syncthreads();
+            // ---- flattened (candidate, block) units
+            for (int u = tid; u < total; u += 256) {
+                int i = 0;
+#pragma unroll
+                for (int stp = RB_PASS / 2; stp > 0; stp >>= 1)
+                    if (ustart[i + stp] <= u) i += stp;
+                const int k = u - ustart[i];
+                const float4 r0 = recs[i][0], r1 = recs[i][1], r2 = recs[i][2], r3 = recs[i][3], r4 = recs[i][4];
+                const int fn = __float_as_int(r4.z), pk = __float_as_int(r4.w);
+                const int nbx = pk >> 16;
+                const int kby = k / nbx;
+                const int sx0 = 4 * ((pk & 0xff) + (k - kby * nbx)), sy0 = 4 * (((pk >> 8) & 0xff) + kby);
+                const float f0 = r0.x, f1 = r0.y, f3 = r0.z, f4 = r0.w, f6 = r1.x, f7 = r1.y;
+                const float e0x = f3 - f0, e0y = f4 - f1, e1x = f6 - f3, e1y = f7 - f4, e2x = f0 - f6, e2y = f1 - f7;
+                float rowv[4][3], colv[4][3], xfv[4], yfv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int xi = gx0 + sx0 + j, yi = gy0 + sy0 + j;
+                    const float X = (float)(2 * xi + 1 - is) / (float)is, Y = (float)(2 * yi + 1 - is) / (float)is;
+                    xfv[j] = (float)xi;
+                    yfv[j] = (float)yi;
+                    rowv[j][0] = (Y - f1) * e0x; rowv[j][1] = (Y - f4) * e1x; rowv[j][2] = (Y - f7) * e2x;
+                    colv[j][0] = (X - f0) * e0y; colv[j][1] = (X - f3) * e1y; colv[j][2] = (X - f6) * e2y;
+                }
+                unsigned inside = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) {
+                        const bool in = !((rowv[j][0] < colv[c4][0]) || (rowv[j][1] < colv[c4][1]) || (rowv[j][2] < colv[c4][2]));
+                        inside |= (in ? 1u : 0u) << (4 * j + c4);
+                    }
+                if (inside == 0u) continue;
+                const float rz0 = r1.z, rz1 = r1.w, rz2 = r2.x;
+                const float iv[9] = {r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w, r4.x, r4.y};
+                while (inside) {
+                    const int sidx = __ffs((int)inside) - 1;
+                    inside &= inside - 1;
+                    const int j = sidx >> 2, c4 = sidx & 3;
+                    const float xf = c4 == 0 ? xfv[0] : c4 == 1 ? xfv[1] : c4 == 2 ? xfv[2] : xfv[3];
+                    const float yf = j == 0 ? yfv[0] : j == 1 ? yfv[1] : j == 2 ? yfv[2] : yfv[3];
+                    float wgt[3], ws = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        float t = iv[3 * q] * xf;
+                        t = t + iv[3 * q + 1] * yf;
+                        t = t + iv[3 * q + 2];
+                        t = fminf(fmaxf(t, 0.0f), 1.0f);
+                        wgt[q] = t;
+                        ws += t;
+                    }
+                    float sum = wgt[0] * rz0;
+                    sum = sum + wgt[1] * rz1;
+                    sum = sum + wgt[2] * rz2;
+                    const float zp = ws / sum;
+                    if (zp > znear && zp < zfar)
+                        atomicMin(&zb[(sy0 + j) * 32 + sx0 + c4],
+                                  ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)fn);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
-    if (qn > 0) raster_batch(q, qn, b, F, is, faces9, xp, yp, xf, yf, zmin, imin, znear, zfar, lane, tcx0, tcx1, tcy0, tcy1);
+    __syncthreads();
+
+    // ---- epilogue: this lane's output pixel and its 2x2 samples (flip: output row r <-> sample rows is-1-2r-dy)
+    const int r = ty * HM_TILE + (lane >> 3), c = tx * HM_TILE + (lane & 7);
+    const int xi0 = 2 * c, yi0 = is - 1 - 2 * r;   // sample (dy,dx): yi = yi0 - dy, xi = xi0 + dx
+    float zmin[4];
+    int imin[4];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const int dy = s4 >> 1, dx = s4 & 1;
+        const unsigned long long key = zb[(yi0 - dy - gy0) * 32 + (xi0 + dx - gx0)];
+        zmin[s4] = __uint_as_float((unsigned)(key >> 32));
+        imin[s4] = (int)(unsigned)(key & 0xffffffffull);      // 0xffffffff -> -1
+    }
 
     // ---- outputs
     int* im = idx_map + (long)b * is * is;
@@ -591,16 +600,6 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
 // parts (B,F,2 windings,3 edges,2 axes,2 end points).
 struct SweepItem { float x, c0, c1; int base, meta; };      // meta: combo | use0 << 3 | use1 << 4
 
-__device__ __forceinline__ int hm_wave_scan_incl(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1,3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2,3
-    return v;
-}
 
 __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ faces9, const FaceBox* __restrict__ boxes,
                                                    const int* __restrict__ idx_map,
