@@ -147,6 +147,9 @@ __device__ __forceinline__ float rlane(float v, int l)
 // optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4); optional pooled depth.
 #define CAND_CAP 1024      // faces scanned per binning round (<= 2 entries each)
 #define RB_PASS 256        // candidates per record pass (= threads)
+#ifndef HM_PRUNE
+#define HM_PRUNE 1
+#endif
 __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
@@ -315,13 +318,29 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
                     }
                 if (inside == 0u) continue;
                 const float rz0 = r1.z, rz1 = r1.w, rz2 = r2.x;
+#if HM_PRUNE
+                // samples already owned by something nearer than the nearest point of this face cannot change (the
+                // interpolated depth is a weighted harmonic mean of the vertex depths; 1e-5 covers its rounding)
+                {
+                    const unsigned zn = __float_as_uint((1.0f / fmaxf(rz0, fmaxf(rz1, rz2))) * (1.0f - 1e-5f));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (((inside >> (4 * j)) & 0xfu) == 0u) continue;
+                        const uint4 ka = *reinterpret_cast<const uint4*>(&zb[(sy0 + j) * 32 + sx0]);
+                        const uint4 kb = *reinterpret_cast<const uint4*>(&zb[(sy0 + j) * 32 + sx0 + 2]);
+                        unsigned keepm = (zn > ka.y ? 0u : 1u) | (zn > ka.w ? 0u : 2u) | (zn > kb.y ? 0u : 4u) | (zn > kb.w ? 0u : 8u);
+                        inside &= ~(0xfu << (4 * j)) | (keepm << (4 * j));
+                    }
+                    if (inside == 0u) continue;
+                }
+#endif
                 const float iv[9] = {r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w, r4.x, r4.y};
+                const int xb = gx0 + sx0, yb = gy0 + sy0;
                 while (inside) {
                     const int sidx = __ffs((int)inside) - 1;
                     inside &= inside - 1;
                     const int j = sidx >> 2, c4 = sidx & 3;
-                    const float xf = c4 == 0 ? xfv[0] : c4 == 1 ? xfv[1] : c4 == 2 ? xfv[2] : xfv[3];
-                    const float yf = j == 0 ? yfv[0] : j == 1 ? yfv[1] : j == 2 ? yfv[2] : yfv[3];
+                    const float xf = (float)(xb + c4), yf = (float)(yb + j);
                     float wgt[3], ws = 0.0f;
 #pragma unroll
                     for (int q = 0; q < 3; ++q) {
