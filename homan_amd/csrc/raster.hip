@@ -130,6 +130,47 @@ __device__ __forceinline__ float rlane(float v, int l)
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// Sweep bit planes of one 8x8-pixel tile (wave = tile, lane = output pixel (lane>>3, lane&7), bal[2*dy+dx] = ballot of
+// "sample (dy,dx) of my pixel is covered"): plane 0 = samples with alpha==0 and g<0 ("wants to be filled", walked by the
+// outward sweeps), plane 1 = samples with alpha==1 and g>0 ("wants to be emptied", the only samples the inward sweeps
+// can collect from); each plane as row words (bits along x) and column words (bits along y).
+__device__ __forceinline__ unsigned spread8(unsigned x)      // bit k of x -> bit 2k
+{
+    x = (x | (x << 4)) & 0x0f0fu;
+    x = (x | (x << 2)) & 0x3333u;
+    x = (x | (x << 1)) & 0x5555u;
+    return x;
+}
+__device__ __forceinline__ void emit_planes(const unsigned long long (&cov)[4], bool neg, bool pos, int b, int B, int is,
+                                            int tx, int ty, int lane, unsigned short* __restrict__ rowneg,
+                                            unsigned short* __restrict__ colneg)
+{
+    const long plane = (long)B * is * (is / 16);
+    const unsigned long long nb = __ballot(neg), pb = __ballot(pos);
+    // lanes 0..15: row word of sample row (rr2 = l>>1, dy = l&1), plane 0 ; lanes 16..31: same for plane 1 ;
+    // lanes 32..47: column word of sample column (cc2 = l>>1, dx = l&1), plane 0 ; lanes 48..63: plane 1
+    const int l = lane & 15, pl = (lane >> 4) & 1, hi = l >> 1, sub = l & 1;
+    unsigned long long b0, b1;          // the two ballots this lane interleaves
+    if (lane < 32) {                    // (dy = sub): dx = 0 -> even bits, dx = 1 -> odd bits
+        b0 = pl == 0 ? (~cov[2 * sub] & nb) : (cov[2 * sub] & pb);
+        b1 = pl == 0 ? (~cov[2 * sub + 1] & nb) : (cov[2 * sub + 1] & pb);
+        const unsigned a = (unsigned)(b0 >> (8 * hi)) & 0xffu, o = (unsigned)(b1 >> (8 * hi)) & 0xffu;
+        const unsigned word = spread8(a) | (spread8(o) << 1);
+        const int yi = is - 1 - 2 * (ty * HM_TILE + hi) - sub;
+        (rowneg + pl * plane)[((long)b * is + yi) * (is / 16) + tx] = (unsigned short)word;
+    } else {                            // (dx = sub): bit 15 - (2*rr2 + dy) <- sample (rr2, dy) of column cc2 = hi
+        b0 = pl == 0 ? (~cov[sub] & nb) : (cov[sub] & pb);                 // dy = 0
+        b1 = pl == 0 ? (~cov[2 + sub] & nb) : (cov[2 + sub] & pb);         // dy = 1
+        // bits 8*rr2 + cc2 -> one byte with row rr2 at bit 7 - rr2
+        const unsigned c0 = (unsigned)((((b0 >> hi) & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
+        const unsigned c1 = (unsigned)((((b1 >> hi) & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
+        const unsigned word = (spread8(c0) << 1) | spread8(c1);
+        const int xi = 2 * (tx * HM_TILE + hi) + sub;
+        const int ygrp = (is / 16) - 1 - ty;       // 16-sample group along y holding this tile
+        (colneg + pl * plane)[((long)b * is + xi) * (is / 16) + ygrp] = (unsigned short)word;
+    }
+}
+
 // ---------------------------------------------------------------- forward raster
 // Workgroup = 4 wavefronts = one 32x32-sample region (a 2x2 block of 8x8-pixel output tiles) of one frame.
 //   1. binning on the fly: the workgroup scans the 8-byte screen boxes of the frame (coalesced) and keeps the
@@ -155,7 +196,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
     float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned,
-    float* __restrict__ pooled_depth)
+    float* __restrict__ pooled_depth, unsigned short* __restrict__ rowneg, unsigned short* __restrict__ colneg)
 {
     __shared__ unsigned long long zb[32 * 32];
     __shared__ int cand[2 * CAND_CAP];
@@ -397,9 +438,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         const int rr = lane >> 1, dy = lane & 1;       // tile-local output row, sub-row
         const unsigned a = (unsigned)(bal[2 * dy] >> (8 * rr)) & 0xffu;      // dx = 0 -> even bits
         const unsigned o = (unsigned)(bal[2 * dy + 1] >> (8 * rr)) & 0xffu;  // dx = 1 -> odd bits
-        unsigned word = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) word |= (((a >> k) & 1u) << (2 * k)) | (((o >> k) & 1u) << (2 * k + 1));
+        const unsigned word = spread8(a) | (spread8(o) << 1);
         const int yi = is - 1 - 2 * (ty * HM_TILE + rr) - dy;
         alpha16[((long)b * is + yi) * (is / 16) + tx] = (unsigned short)word;
     }
@@ -414,6 +453,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         const float image = kp * pool;
         const float diff = image - rf;
         dimg[po] = kp * diff;
+        // sweep planes of the backward for a positive upstream gradient (sign(g) = sign(dimg)), see k_bwd_masks
+        emit_planes(bal, kp * diff < 0.0f, kp * diff > 0.0f, b, B, is, tx, ty, lane, rowneg, colneg);
         const float sq = hm_wave_sum(diff * diff);
         const float inter = hm_wave_sum(image * rf);
         const float uni = hm_wave_sum(fminf(fmaxf(image + rf, 0.0f), 1.0f));
@@ -465,6 +506,9 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
                                                    float* __restrict__ gimg, unsigned short* __restrict__ rowneg,
                                                    unsigned short* __restrict__ colneg)
 {
+    // fused loss with a positive upstream gradient: the forward raster already emitted these planes (sign(g) = sign(dimg))
+    // and k_bwd_lines derives g from dimg itself
+    if (mode == 1 && upstream[0] > 0.0f) return;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int is = 2 * S, tiles_x = S / HM_TILE, ntiles = tiles_x * tiles_x;
     const int tile = blockIdx.x * 4 + w, b = blockIdx.y;
@@ -479,50 +523,16 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
         g = s * g / keep_sum[0] / (float)B;
     }
     gimg[po] = g;
-    const bool neg = g < 0.0f, pos = g > 0.0f;
     // alpha bits of this lane's 4 samples
     const int yi0 = is - 1 - 2 * r;
-    const long plane = (long)B * is * (is / 16);
-    unsigned aw2[2];
-#pragma unroll
-    for (int dy = 0; dy < 2; ++dy) aw2[dy] = alpha16[((long)b * is + (yi0 - dy)) * (is / 16) + tx];
-#pragma unroll 1
-    for (int pl = 0; pl < 2; ++pl) {
-    unsigned long long bal[4];
+    unsigned long long cov[4];
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
+        const unsigned aw = alpha16[((long)b * is + (yi0 - dy)) * (is / 16) + tx];
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) {
-            const bool filled = (aw2[dy] >> (2 * cc + dx)) & 1u;
-            bal[2 * dy + dx] = __ballot(pl == 0 ? (!filled && neg) : (filled && pos));
-        }
+        for (int dx = 0; dx < 2; ++dx) cov[2 * dy + dx] = __ballot((aw >> (2 * cc + dx)) & 1u);
     }
-    unsigned short* rowm = rowneg + pl * plane;
-    unsigned short* colm = colneg + pl * plane;
-    if (lane < 16) {            // row words: sample row (rr,dy), bits along x
-        const int rr2 = lane >> 1, dy = lane & 1;
-        const unsigned a = (unsigned)(bal[2 * dy] >> (8 * rr2)) & 0xffu;
-        const unsigned o = (unsigned)(bal[2 * dy + 1] >> (8 * rr2)) & 0xffu;
-        unsigned word = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) word |= (((a >> k) & 1u) << (2 * k)) | (((o >> k) & 1u) << (2 * k + 1));
-        const int yi = is - 1 - 2 * (ty * HM_TILE + rr2) - dy;
-        rowm[((long)b * is + yi) * (is / 16) + tx] = (unsigned short)word;
-    } else if (lane < 32) {     // column words: sample column (cc,dx), bits along y (bit = yi - ybase)
-        const int l = lane - 16, cc2 = l >> 1, dx = l & 1;
-        unsigned word = 0;
-#pragma unroll
-        for (int rr2 = 0; rr2 < 8; ++rr2)
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy) {
-                const unsigned bit = (unsigned)(bal[2 * dy + dx] >> (8 * rr2 + cc2)) & 1u;
-                word |= bit << (15 - (2 * rr2 + dy));
-            }
-        const int xi = 2 * (tx * HM_TILE + cc2) + dx;
-        const int ygrp = (is / 16) - 1 - ty;       // 16-sample group along y holding this tile
-        colm[((long)b * is + xi) * (is / 16) + ygrp] = (unsigned short)word;
-    }
-    }   // planes
+    emit_planes(cov, g < 0.0f, g > 0.0f, b, B, is, tx, ty, lane, rowneg, colneg);
 }
 
 // ---------------------------------------------------------------- backward: shared helpers
@@ -563,9 +573,11 @@ struct SweepSrc { int d1; float g; int owner; };
 
 __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restrict__ rowneg,
                                                    const unsigned short* __restrict__ colneg,
-                                                   const float* __restrict__ gimg, const int* __restrict__ idx_map,
-                                                   int B, int S, SweepSrc* __restrict__ srcs,
-                                                   unsigned short* __restrict__ cum)
+                                                   const float* __restrict__ gimg, const float* __restrict__ dimg,
+                                                   int mode, const float* __restrict__ upstream,
+                                                   const float* __restrict__ keep_sum,
+                                                   const int* __restrict__ idx_map, int B, int S,
+                                                   SweepSrc* __restrict__ srcs, unsigned short* __restrict__ cum)
 {
     const int lane = threadIdx.x & 63;
     const int is = 2 * S, wpl = is / 64;
@@ -588,7 +600,10 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     const int excl = incl - c;
     if (lane < SWEEP_CUMW) cum[L * SWEEP_CUMW + lane] = (unsigned short)excl;
     if (__builtin_amdgcn_readlane(incl, 15) == 0) return;
-    const float* gi = gimg + (long)b * S * S;
+    // fused loss, positive upstream: g = upstream * 2 * dimg / keep_sum / B (the arithmetic of k_bwd_masks), no gimg pass
+    const bool from_dimg = mode == 2 || (mode == 1 && upstream[0] > 0.0f);
+    const float* gi = (from_dimg ? dimg : gimg) + (long)b * S * S;
+    const float gs = from_dimg ? upstream[0] * 2.0f : 0.f, ks = from_dimg ? keep_sum[0] : 1.f;
     const int* idx = idx_map + (long)b * is * is;
     SweepSrc* out = srcs + L * is;
     for (int k = 0; k < wpl; ++k) {
@@ -602,7 +617,9 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
             const int xi = axis ? d1 : d0, yi = axis ? d0 : d1;
             SweepSrc r;
             r.d1 = d1;
-            r.g = 0.25f * gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
+            float g = gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
+            if (from_dimg) g = gs * g / ks / (float)B;
+            r.g = 0.25f * g;
             r.owner = pl ? idx[(long)yi * is + xi] : -1;
             out[base + __popcll(w & ((1ull << lane) - 1ull))] = r;
         }
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
 // to lane p % 64, which finds its item by a binary search of the items' exclusive pair counts in LDS.  The number of
 // pairs per item is heavy-tailed (mean 2, lines tangent to the silhouette band hold hundreds): walking them lane-serially
 // left ~97 % of the lanes idle.
-// parts (B,F,2 windings,3 edges,2 axes,2 end points).
+// parts (B,F,3 mesh corners,2): d/d(x, y) of the NDC face vertices.
 struct SweepItem { float x, c0, c1; int base, meta; };      // meta: combo | use0 << 3 | use1 << 4
 
 
@@ -651,14 +668,12 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
 #pragma unroll
         for (int k = 0; k < 3; ++k) { px[k] = topix(src[3 * k], is); py[k] = topix(src[3 * k + 1], is); }
 
+        // gradient of the face's three mesh corners (x, y), both windings folded in
+        float fg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int var = 0; var < 2; ++var) {
-            float* out = parts + (bf * 2 + var) * 12;
             const int fn = fi + var * F;
             // a face that owns no sample has no in-pixel of its own and nothing to sweep inwards over: zero gradient
-            if (!((mask >> var) & 1u) || !owned[(long)b * 2 * F + fn]) {
-                if (lane < 12) out[lane] = 0.f;
-                continue;
-            }
+            if (!((mask >> var) & 1u) || !owned[(long)b * 2 * F + fn]) continue;
             // lanes 0..5 build the six (edge, axis) line families of this winding into LDS (wave-uniform data)
             __builtin_amdgcn_wave_barrier();
             if (lane < 6) {
@@ -819,10 +834,21 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
 #undef HM_SWEEP_FLUSH
 #pragma unroll
             for (int k = 0; k < 12; ++k) tot[k] = hm_wave_sum(tot[k]);
-            if (lane == 0) {
+            // tot[(edge * 2 + axis) * 2 + end point]: winding corner ko is end point 0 of edge ko and end point 1 of
+            // edge ko+2; x collects the axis-1 (row) sweeps, y the axis-0 (column) sweeps
 #pragma unroll
-                for (int k = 0; k < 12; ++k) out[k] = tot[k];
+            for (int ko = 0; ko < 3; ++ko) {
+                const int ep = (ko + 2) % 3;
+                const float gx = tot[(ko * 2 + 1) * 2 + 0] + tot[(ep * 2 + 1) * 2 + 1];
+                const float gy = tot[(ko * 2 + 0) * 2 + 0] + tot[(ep * 2 + 0) * 2 + 1];
+                if (var == 0) { fg[2 * ko] += gx; fg[2 * ko + 1] += gy; }
+                else { fg[2 * (2 - ko)] += gx; fg[2 * (2 - ko) + 1] += gy; }
             }
+        }
+        if (lane == 0) {
+            float* out = parts + bf * 6;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) out[k] = fg[k];
         }
     }   // face loop
 }
@@ -839,17 +865,10 @@ __global__ void k_bwd_gather(const float* __restrict__ parts, const int* __restr
     const int b = (int)(i / V), v = (int)(i % V);
     float gu = 0.f, gv = 0.f;
     for (int a = adj_off[v]; a < adj_off[v + 1]; ++a) {
-        const int item = adj_items[a], fi = item / 3, k = item % 3;
-        const float* pf = parts + ((long)b * F + fi) * 24;
-#pragma unroll
-        for (int var = 0; var < 2; ++var) {
-            const float* pv = pf + var * 12;            // [e][axis][2]
-            const int ko = var ? 2 - k : k;             // oriented corner
-            const int ep = (ko + 2) % 3;                // edge where this corner is the second end point
-            // x gets axis 1, y gets axis 0
-            gu += pv[(ko * 2 + 1) * 2 + 0] + pv[(ep * 2 + 1) * 2 + 1];
-            gv += pv[(ko * 2 + 0) * 2 + 0] + pv[(ep * 2 + 0) * 2 + 1];
-        }
+        const int item = adj_items[a];                  // face * 3 + corner = float2 index into parts
+        const float2 g2 = reinterpret_cast<const float2*>(parts + (long)b * F * 6)[item];
+        gu += g2.x;
+        gv += g2.y;
     }
     if (grad_ndc) { grad_ndc[3 * i] = gu; grad_ndc[3 * i + 1] = gv; grad_ndc[3 * i + 2] = 0.f; }
     const float* k = K + b * 9;
@@ -1128,7 +1147,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     const bool fused = keep && ref && keep_sum && loss_out;
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                       fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth);
+                       fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.rowneg, w.colneg);
     if (fused)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            w.counter, loss_out);
@@ -1136,6 +1155,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
 }
 
 // Backward.  mode 1 (fused loss): upstream = d/d loss_sil (device scalar), uses dimg from the forward.
+//            mode 2: as mode 1, and the caller guarantees upstream[0] > 0 (one launch less).
 //            mode 0 (render):     grad_pooled (B,S,S) = dL/d silhouettes.
 // adjacency (CSR over V) describes the shared face topology.  grad_verts (B,V,3) is overwritten.
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
@@ -1145,14 +1165,16 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
 {
     HM_CHECK_ARG(verts && K && adj_off && adj_items && grad_verts && workspace);
     HM_CHECK_ARG(mode == 0 ? grad_pooled != nullptr : (upstream && keep_sum));
+    HM_CHECK_ARG(mode >= 0 && mode <= 2);
     if (S % 32 != 0 || S > 32 * SWEEP_CUMW) return HM_ERR_UNSUPPORTED;     // 64-sample mask words, <= SWEEP_CUMW per line
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
-    hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
-                       mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
-                       w.rowneg, w.colneg);
+    if (mode != 2)      // mode 2: the caller guarantees upstream > 0, the forward's planes are the backward's
+        hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
+                           mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
+                           w.rowneg, w.colneg);
     hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S * 64, 256)), dim3(256), 0, stream, w.rowneg, w.colneg,
-                       w.gimg, w.idx_map, B, S, w.srcs, w.cum);
+                       w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.cum);
     hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), 2048)), dim3(256), 0, stream, w.faces9, w.boxes,
                        w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, eps, w.parts, w.owned, face_order);
     hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
@@ -1225,7 +1247,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                           w.partials, work_order, w.owned, (float*)nullptr);
+                           w.partials, work_order, w.owned, (float*)nullptr, w.rowneg, w.colneg);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -1242,7 +1264,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S * 64, 256)), dim3(256), 0, stream, w.rowneg, w.colneg,
-                           w.gimg, w.idx_map, B, S, w.srcs, w.cum);
+                           w.gimg, w.dimg, 1, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.cum);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);

@@ -319,7 +319,8 @@ class FusedStepper:
                             self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
                             P(m.losses.keep_sum), P(self.pooled), self._slot("loss_sil_obj"), P(sctx.work_order),
                             None, P(sctx.workspace), sa), "sil_fwd")
-            ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS, 1,
+            ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
+                            2 if self.lw["lw_sil_obj"] > 0 else 1,
                             P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
                             P(sctx.face_order), P(self.G_sil), None, P(sctx.workspace), sa), "sil_bwd")
         # ---------------- B: hand forward, pair-wise losses, hand backward

@@ -91,7 +91,8 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
                void* workspace, hipStream_t stream);
-/* mode 1: upstream (1) = dL/d loss_out[0]; mode 0: grad_pooled (B,S,S) = dL/d pooled.  adj_off (V+1), adj_items (3F):
+/* mode 1: upstream (1) = dL/d loss_out[0]; mode 2: same with upstream[0] > 0 guaranteed by the caller (the forward's
+ * sweep planes are reused, one launch less); mode 0: grad_pooled (B,S,S) = dL/d pooled.  adj_off (V+1), adj_items (3F):
  * CSR vertex -> (face*3 + corner).  face_order: B*F int32 permutation of frame*F+face (visiting order of the edge
  * sweeps, expensive faces first) or NULL.  grad_verts (B,V,3) overwritten; grad_ndc (B,V,3) optional. */
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,

@@ -102,8 +102,11 @@ def test_pseudo_gradient_matches_oracle(S, obj):
     assert torch.isfinite(v.grad).all()
 
 
-def test_fused_loss_matches_oracle_end_to_end():
-    """verts -> loss_sil, IoU and d loss / d verts against the oracle renderer + torch autograd."""
+@pytest.mark.parametrize("weight", [3.0, -0.7])
+def test_fused_loss_matches_oracle_end_to_end(weight):
+    """verts -> loss_sil, IoU and d loss / d verts against the oracle renderer + torch autograd.  The NMR pseudo-gradient
+    is not linear in the upstream gradient (it selects samples by its sign): a negative weight takes the path that
+    rebuilds the sweep planes in the backward instead of reusing the forward's."""
     from homan_amd import ops
     from oracle import nmr, yana
     B, S = 4, 64
@@ -119,14 +122,14 @@ def test_fused_loss_matches_oracle_end_to_end():
     image = keep * rend
     loss_o = (torch.sum((image - ref_mask) ** 2) / keep.sum()) / B
     iou_o = yana.batch_mask_iou(image, ref_mask).mean()
-    (loss_o * 3.0).backward()
+    (loss_o * weight).backward()
 
     dev = torch.device("cuda")
     sctx = ops.SilhouetteContext(faces.to(dev), V, B, S, dev)
     vh = verts.to(dev).requires_grad_(True)
     loss_h, iou_h, img_h = ops.silhouette_loss(vh, K.to(dev), keep.to(dev), ref_mask.to(dev),
                                                keep.sum().reshape(1).to(dev), sctx)
-    (loss_h * 3.0).sum().backward()
+    (loss_h * weight).sum().backward()
     mism = (img_h.cpu() != rend.detach()).float().mean().item()
     assert mism < 1e-4, mism            # projection rounding may flip a sample or two
     np.testing.assert_allclose(loss_h.item(), loss_o.item(), rtol=2e-4)
