@@ -17,11 +17,14 @@ struct AdamSlot {
 };
 
 // grid (blocks_per_tensor, n_tensors)
-__global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots, const int* __restrict__ step, float beta1,
+// step[0] = completed steps, step[1] = ticket word (zero between launches): the workgroup that draws the last ticket
+// bumps the step counter, after every workgroup has read it -- no separate increment launch on the critical path.
+__global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots, int* __restrict__ step, float beta1,
                                                float beta2, float eps, int zero_grad)
 {
     const AdamSlot s = slots[blockIdx.y];
-    const double t = (double)(step[0] + 1);
+    const int step_now = __builtin_nontemporal_load(step);
+    const double t = (double)(step_now + 1);
     const double bc1 = 1.0 - pow((double)beta1, t);
     const double bc2 = 1.0 - pow((double)beta2, t);
     const float neg_step = (float)(-((double)s.lr / bc1));
@@ -39,9 +42,15 @@ __global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots
         s.v[i] = v;
         if (zero_grad) s.g[i] = 0.f;
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned nblk = gridDim.x * gridDim.y;
+        if (atomicAdd(reinterpret_cast<unsigned int*>(step) + 1, 1u) == nblk - 1u) {
+            atomicExch(reinterpret_cast<unsigned int*>(step) + 1, 0u);
+            atomicExch(step, step_now + 1);
+        }
+    }
 }
-
-__global__ void k_incr(int* step) { step[0] += 1; }
 
 // log[step*n + i] = src[i] for i < n ; step read from the device counter (sync-free loss_evolution)
 __global__ void k_log(const float* __restrict__ src, int n, const int* __restrict__ step, int max_steps,
@@ -83,7 +92,6 @@ int hm_adam_step(const void* slots, int n_tensors, int* step, float beta1, float
     HM_CHECK_ARG(slots && step && n_tensors > 0 && blocks_per_tensor > 0);
     hipLaunchKernelGGL(k_adam, dim3(blocks_per_tensor, n_tensors), dim3(256), 0, stream, (const AdamSlot*)slots, step,
                        beta1, beta2, eps, zero_grad);
-    hipLaunchKernelGGL(k_incr, dim3(1), dim3(1), 0, stream, step);
     return hm_launch_status();
 }
 int hm_log_scalars(const float* src, int n, const int* step, int max_steps, float* log, hipStream_t stream)

@@ -11,53 +11,73 @@
 
 #define NN_THREADS 256
 
-// grid (ceil(Vh/64), B).  Workgroup = 64 hand vertices x 4 wavefronts; wave q scans the object vertices
-// [q*64 + 256*m, +64): lane l loads object vertex l of the group (coalesced), the group is then broadcast vertex by
-// vertex with v_readlane (scalar operands, no LDS round trip in the inner loop).  The four partial minima are merged
-// lexicographically on (distance, index) so ties keep the lowest index.
-#define NN_HV 64
+// grid (ceil(Vh/128), B).  Workgroup = 128 hand vertices (two per lane: the pair shares every broadcast and the packed
+// fp32 pipes take both) x NN_WAVES wavefronts; wave q scans an equal contiguous share of the object vertices 64 at a
+// time: lane l loads object vertex l of the group (coalesced), the group is then broadcast vertex by vertex with
+// v_readlane (scalar operands, no LDS round trip in the inner loop).  The partial minima are merged lexicographically
+// on (distance, index) so ties keep the lowest index.
+#define NN_HV 128
+#define NN_WAVES 16
 __device__ __forceinline__ float rl_f(float v, int l)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
-__global__ __launch_bounds__(NN_THREADS) void k_nn(const float* __restrict__ vh, const float* __restrict__ vo, int B,
-                                                    int Vh, int Vo, int* __restrict__ nn_idx, float* __restrict__ nn_d2,
-                                                    float* __restrict__ blockmin, unsigned int* counter,
-                                                    float* __restrict__ metric_out)
+__global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ vh, const float* __restrict__ vo, int B,
+                                                       int Vh, int Vo, int* __restrict__ nn_idx, float* __restrict__ nn_d2,
+                                                       float* __restrict__ blockmin, unsigned int* counter,
+                                                       float* __restrict__ metric_out)
 {
-    __shared__ float s_d[4][NN_HV];
-    __shared__ int s_i[4][NN_HV];
+    __shared__ float s_d[NN_WAVES][NN_HV];
+    __shared__ int s_i[NN_WAVES][NN_HV];
     __shared__ float red[16];
     __shared__ int s_flag;
     const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int i = blockIdx.x * NN_HV + lane;
-    float hx = 0.f, hy = 0.f, hz = 0.f;
-    if (i < Vh) { const float* p = vh + ((long)b * Vh + i) * 3; hx = p[0]; hy = p[1]; hz = p[2]; }
-    float best = 3.4e38f;
-    int besti = 0;
-    for (int j0 = q * 64; j0 < Vo; j0 += 256) {
-        const int n = min(64, Vo - j0);
+    float hx[2], hy[2], hz[2], best[2];
+    int besti[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = blockIdx.x * NN_HV + lane + 64 * u;
+        hx[u] = hy[u] = hz[u] = 0.f;
+        if (i < Vh) { const float* p = vh + ((long)b * Vh + i) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2]; }
+        best[u] = 3.4e38f;
+        besti[u] = 0;
+    }
+    const int share = (Vo + NN_WAVES - 1) / NN_WAVES, jend = min(Vo, (q + 1) * share);
+    for (int j0 = q * share; j0 < jend; j0 += 64) {
+        const int n = min(64, jend - j0);
         float ox = 0.f, oy = 0.f, oz = 0.f;
         if (lane < n) { const float* p = vo + ((long)b * Vo + j0 + lane) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
-#pragma unroll 4
-        for (int k = 0; k < n; ++k) {
-            const float dx = rl_f(ox, k) - hx, dy = rl_f(oy, k) - hy, dz = rl_f(oz, k) - hz;
-            const float d = dx * dx + dy * dy + dz * dz;
-            if (d < best) { best = d; besti = j0 + k; }
-        }
+        int k = 0;
+#define NN_STEP(K)                                                                                   \
+    {                                                                                                \
+        const float sx = rl_f(ox, (K)), sy = rl_f(oy, (K)), sz = rl_f(oz, (K));                      \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
+            const float dx = sx - hx[u], dy = sy - hy[u], dz = sz - hz[u];                           \
+            const float d = dx * dx + dy * dy + dz * dz;                                             \
+            const bool lt = d < best[u];                                                             \
+            best[u] = lt ? d : best[u];                                                              \
+            besti[u] = lt ? j0 + (K) : besti[u];                                                     \
+        }                                                                                            \
     }
-    s_d[q][lane] = best;
-    s_i[q][lane] = besti;
+        for (; k + 4 <= n; k += 4) { NN_STEP(k) NN_STEP(k + 1) NN_STEP(k + 2) NN_STEP(k + 3) }
+        for (; k < n; ++k) NN_STEP(k)
+#undef NN_STEP
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { s_d[q][lane + 64 * u] = best[u]; s_i[q][lane + 64 * u] = besti[u]; }
     __syncthreads();
     float bm = 3.4e38f;
-    if (q == 0) {
+    if (threadIdx.x < NN_HV) {
+        const int t = threadIdx.x, i = blockIdx.x * NN_HV + t;
+        float bd = s_d[0][t];
+        int bi = s_i[0][t];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) {
-            const float d = s_d[k][lane];
-            const int id = s_i[k][lane];
-            if (d < best || (d == best && id < besti)) { best = d; besti = id; }
+        for (int k = 1; k < NN_WAVES; ++k) {
+            const float d = s_d[k][t];
+            const int id = s_i[k][t];
+            if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
         }
-        if (i < Vh) { nn_idx[(long)b * Vh + i] = besti; nn_d2[(long)b * Vh + i] = best; bm = best; }
+        if (i < Vh) { nn_idx[(long)b * Vh + i] = bi; nn_d2[(long)b * Vh + i] = bd; bm = bd; }
     }
     bm = hm_block_min(bm, red);
     const unsigned nblk = gridDim.x * gridDim.y;
@@ -141,9 +161,9 @@ int hm_nn_fwd(const float* verts_hand, const float* verts_obj, int B, int Vh, in
               float* metric_out, void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(verts_hand && verts_obj && nn_idx && nn_d2 && metric_out && workspace && B > 0 && Vh > 0 && Vo > 0);
-    const int nchunk = hm_cdiv(Vh, NN_HV);
+    const int nchunk = hm_cdiv(Vh, NN_HV);   // 128 hand vertices per workgroup
     if ((long)B * nchunk > 512) return HM_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_nn, dim3(nchunk, B), dim3(NN_THREADS), 0, stream, verts_hand, verts_obj, B, Vh, Vo, nn_idx,
+    hipLaunchKernelGGL(k_nn, dim3(nchunk, B), dim3(64 * NN_WAVES), 0, stream, verts_hand, verts_obj, B, Vh, Vo, nn_idx,
                        nn_d2, (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out);
     return hm_launch_status();
 }

@@ -100,11 +100,12 @@ __global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mes
     o[2] = x * R[2] + y * R[5] + z * R[8] + t[2];
 }
 
-// backward: g_full reaches mesh, scale, R, t ; g_rigid (mesh-detached twin) reaches R, t only.  grid (N)
+// backward: g_full (+ g_full_b) reaches mesh, scale, R, t ; g_rigid (mesh-detached twin) reaches R, t only.  grid (N)
 __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
                                                    const float* __restrict__ scale, int abs_scale,
-                                                   const float* __restrict__ g_full, const float* __restrict__ g_rigid,
-                                                   int N, int V, float* __restrict__ g_mesh,
+                                                   const float* __restrict__ g_full, const float* __restrict__ g_full_b,
+                                                   const float* __restrict__ g_rigid, int N, int V,
+                                                   float* __restrict__ g_mesh,
                                                    float* __restrict__ g_rot6d, float* __restrict__ g_trans,
                                                    float* __restrict__ g_scale_part)
 {
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
         const float m[3] = {mesh[o], mesh[o + 1], mesh[o + 2]};
         float gf[3] = {0.f, 0.f, 0.f}, gt[3];
         if (g_full) { gf[0] = g_full[o]; gf[1] = g_full[o + 1]; gf[2] = g_full[o + 2]; }
+        if (g_full_b) { gf[0] += g_full_b[o]; gf[1] += g_full_b[o + 1]; gf[2] += g_full_b[o + 2]; }
         gt[0] = gf[0]; gt[1] = gf[1]; gt[2] = gf[2];
         if (g_rigid) { gt[0] += g_rigid[o]; gt[1] += g_rigid[o + 1]; gt[2] += g_rigid[o + 2]; }
 #pragma unroll
@@ -218,11 +220,11 @@ int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, cons
     return hm_launch_status();
 }
 int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* g_full,
-                 const float* g_rigid, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans,
-                 float* g_scale_part, hipStream_t stream)
+                 const float* g_full_b, const float* g_rigid, int N, int V, float* g_mesh, float* g_rot6d,
+                 float* g_trans, float* g_scale_part, hipStream_t stream)
 {
     HM_CHECK_ARG(mesh && rot6d && scale && g_rot6d && g_trans && N > 0 && V > 0);
-    hipLaunchKernelGGL(k_rigid_bwd, dim3(N), dim3(256), 0, stream, mesh, rot6d, scale, abs_scale, g_full, g_rigid, N,
+    hipLaunchKernelGGL(k_rigid_bwd, dim3(N), dim3(256), 0, stream, mesh, rot6d, scale, abs_scale, g_full, g_full_b, g_rigid, N,
                        V, g_mesh, g_rot6d, g_trans, g_scale_part);
     return hm_launch_status();
 }

@@ -90,6 +90,8 @@ struct ManoShared {
     float tw[MANO_J][3];     // world translations (= posed joints)
     float A[MANO_J][12];     // skinning transforms [R | t] with the rest pose removed
     float feat[MANO_NF];     // pose feature (135) + betas (10)
+    int parents[MANO_J];     // kinematic tree, staged once (chasing it through global memory is a chain of dependent loads)
+    int depth[MANO_J];
 };
 
 // pose / Rodrigues / joints / chain, shared by forward and both backward kernels.  Needs >= 64 threads.
@@ -109,8 +111,12 @@ __device__ __forceinline__ void mano_prepare(const ManoModelDev& m, const float*
         sh.pose[t] = v;
     }
     if (t < 10) sh.feat[135 + t] = betas[b * 10 + t];
+    if (t < MANO_J) sh.parents[t] = m.parents[t];
     __syncthreads();
     if (t < MANO_J) {
+        int d = 0;
+        for (int q = sh.parents[t]; q >= 0; q = sh.parents[q]) ++d;
+        sh.depth[t] = d;
         float R[9];
         rodrigues(&sh.pose[3 * t], R);
 #pragma unroll
@@ -128,15 +134,9 @@ __device__ __forceinline__ void mano_prepare(const ManoModelDev& m, const float*
     __syncthreads();
     // kinematic chain, level by level (joint t waits until its parent's level is done; MANO depth is 3)
     int depth = 0, par = -1, maxd = 0;
-    if (t < MANO_J) {
-        par = m.parents[t];
-        for (int q = par; q >= 0; q = m.parents[q]) ++depth;
-    }
-    for (int j = 0; j < MANO_J; ++j) {     // depth of the tree, computed identically by every thread
-        int d = 0;
-        for (int q = m.parents[j]; q >= 0; q = m.parents[q]) ++d;
-        maxd = max(maxd, d);
-    }
+    if (t < MANO_J) { par = sh.parents[t]; depth = sh.depth[t]; }
+#pragma unroll
+    for (int j = 0; j < MANO_J; ++j) maxd = max(maxd, sh.depth[j]);     // depth of the tree, the same in every thread
     for (int level = 0; level < MANO_J; ++level) {
         if (t < MANO_J && depth == level) {
             const int j = t, p = par;
@@ -330,15 +330,9 @@ __global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* _
         tot[k] = a;
     }
     int depth = 0, par = -1, maxd = 0;
-    if (t < MANO_J) {
-        par = m.parents[t];
-        for (int q = par; q >= 0; q = m.parents[q]) ++depth;
-    }
-    for (int j = 0; j < MANO_J; ++j) {
-        int d = 0;
-        for (int q = m.parents[j]; q >= 0; q = m.parents[q]) ++d;
-        maxd = max(maxd, d);
-    }
+    if (t < MANO_J) { par = sh.parents[t]; depth = sh.depth[t]; }
+#pragma unroll
+    for (int j = 0; j < MANO_J; ++j) maxd = max(maxd, sh.depth[j]);
     __syncthreads();
     if (t < MANO_J) {
         const int j = t;
@@ -383,7 +377,7 @@ __global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* _
         __syncthreads();
         if (t < MANO_J && depth == level - 1) {
             for (int j = 0; j < MANO_J; ++j)
-                if (m.parents[j] == t) {
+                if (sh.parents[j] == t) {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) dRw[t][k] += cR[j][k];
 #pragma unroll

@@ -46,15 +46,11 @@ __device__ __forceinline__ void wave_sync()
 }
 
 // ---------------------------------------------------------------- projection (nr.projection, zero distortion)
-// verts (B,V,3) camera space, K (B,3,3) -> ndc (B,V,3) = (u, v, z), u,v in [-1,1], v up.
-__global__ void k_project(const float* __restrict__ verts, const float* __restrict__ K, int B, int V,
-                          float orig_size, float* __restrict__ ndc)
+// camera-space vertex, K (3,3) -> (u, v, z), u,v in [-1,1], v up.
+__device__ __forceinline__ void project_vertex(const float* __restrict__ p, const float* __restrict__ k, float orig_size,
+                                               float* out)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * V) return;
-    const int b = (int)(i / V);
-    const float* k = K + b * 9;
-    const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+    const float x = p[0], y = p[1], z = p[2];
     const float zz = z + 1e-9f;
     const float xn = x / zz, yn = y / zz;
     float u = xn * k[0] + yn * k[1];
@@ -64,14 +60,14 @@ __global__ void k_project(const float* __restrict__ verts, const float* __restri
     v = orig_size - v;
     u = 2.0f * (u - orig_size / 2.0f) / orig_size;
     v = 2.0f * (v - orig_size / 2.0f) / orig_size;
-    ndc[3 * i] = u;
-    ndc[3 * i + 1] = v;
-    ndc[3 * i + 2] = z;
+    out[0] = u; out[1] = v; out[2] = z;
 }
 
 // ---------------------------------------------------------------- face setup
-// gathers the packed (B,F,3,3) face buffer and the 8-byte screen boxes.
-__global__ void k_setup_faces(const float* __restrict__ ndc, const int* __restrict__ faces, int faces_bstride,
+// projects the three vertices of every face (a vertex is shared by ~6 faces: re-projecting it is cheaper than a
+// separate projection launch on the critical path), packs the (B,F,3,3) NDC face buffer and the 8-byte screen boxes.
+__global__ void k_setup_faces(const float* __restrict__ verts, const float* __restrict__ K, float orig_size,
+                              const int* __restrict__ faces, int faces_bstride,
                               int B, int V, int F, int is, float* __restrict__ faces9,
                               FaceBox* __restrict__ boxes, unsigned char* __restrict__ owned)
 {
@@ -81,10 +77,7 @@ __global__ void k_setup_faces(const float* __restrict__ ndc, const int* __restri
     const int* fc = faces + (long)b * faces_bstride + 3 * fi;
     float f[9], r[9];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float* p = ndc + ((long)b * V + fc[k]) * 3;
-        f[3 * k] = p[0]; f[3 * k + 1] = p[1]; f[3 * k + 2] = p[2];
-    }
+    for (int k = 0; k < 3; ++k) project_vertex(verts + ((long)b * V + fc[k]) * 3, K + b * 9, orig_size, f + 3 * k);
 #pragma unroll
     for (int k = 0; k < 3; ++k) { r[3 * k] = f[3 * (2 - k)]; r[3 * k + 1] = f[3 * (2 - k) + 1]; r[3 * k + 2] = f[3 * (2 - k) + 2]; }
 #pragma unroll
@@ -1071,6 +1064,13 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
 }
 
 // ================================================================ C ABI
+#include <stdlib.h>
+static int sweep_blocks()
+{
+    static int v = 0;
+    if (!v) { const char* e = getenv("HM_SWEEP_BLOCKS"); v = e ? atoi(e) : 2048; }
+    return v;
+}
 extern "C" {
 
 // workspace layout helper (bytes), all chunks 256-byte aligned
@@ -1141,16 +1141,26 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     HM_CHECK_ARG(faces_bstride == 0 || faces_bstride == 3 * F);
     SilWs w = carve(workspace, B, V, F, S);
     const int is = 2 * S, ntiles = (S / 8) * (S / 8);
-    hipLaunchKernelGGL(k_project, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, verts, K, B, V, orig_size, w.ndc);
-    hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv((long)B * F, 256)), dim3(256), 0, stream, w.ndc, faces,
+    hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv((long)B * F, 256)), dim3(256), 0, stream, verts, K, orig_size, faces,
                        faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned);
-    const bool fused = keep && ref && keep_sum && loss_out;
+    const bool fused = keep && ref;
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.rowneg, w.colneg);
-    if (fused)
+    if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            w.counter, loss_out);
+    return hm_launch_status();
+}
+
+// The loss / IoU reduction of a forward that was called with keep/ref but loss_out == NULL: the backward does not
+// depend on it, so a caller with a second stream takes it off the critical path.
+int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(keep_sum && loss_out && workspace && B > 0 && S > 0);
+    SilWs w = carve(workspace, B, V, F, S);
+    hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, (S / 8) * (S / 8), keep_sum,
+                       w.frame_rec, w.counter, loss_out);
     return hm_launch_status();
 }
 
@@ -1175,7 +1185,7 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
                            w.rowneg, w.colneg);
     hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S * 64, 256)), dim3(256), 0, stream, w.rowneg, w.colneg,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.cum);
-    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), 2048)), dim3(256), 0, stream, w.faces9, w.boxes,
+    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), sweep_blocks())), dim3(256), 0, stream, w.faces9, w.boxes,
                        w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, eps, w.parts, w.owned, face_order);
     hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                        adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
@@ -1254,7 +1264,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     avg_ms[0] = ms / (float)reps;
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), 2048)), dim3(256), 0, stream, w.faces9,
+        hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), sweep_blocks())), dim3(256), 0, stream, w.faces9,
                            w.boxes, w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, 1e-3f, w.parts, w.owned,
                            face_order);
     (void)hipEventRecord(e1, stream);

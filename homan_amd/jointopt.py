@@ -82,7 +82,7 @@ class HmAdam:
         assert self.items, "run one backward before building HmAdam (static gradient buffers)"
         dev = self.items[0][0].device
         self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p, _ in self.items]
-        self.step_t = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_t = torch.zeros(2, dtype=torch.int32, device=dev)     # {steps done, ticket word of k_adam}
         slot = np.zeros(len(self.items), dtype=[("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"),
                                                  ("lr", "f4"), ("pad", "i4")])
         assert slot.itemsize == _lib.lib().hm_adam_slot_bytes()
@@ -265,7 +265,7 @@ class FusedStepper:
         self.mctx = m.mano_model.ctx_mean
         self.graph = None
         self.side = torch.cuda.Stream()
-        self.ev_vo, self.ev_pair = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_vo, self.ev_pair, self.ev_sil = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self.reduce_ws_b = ops.ReduceWorkspace(dev)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -308,17 +308,15 @@ class FusedStepper:
         sctx, cctx = m.losses.sil_ctx, m.collision_ctx
         pca, rot, betas, mtr = m.mano_pca_pose, m.mano_rot, m.mano_betas, m.mano_trans
         side.wait_stream(main)
-        # ---------------- A: object forward
+        # ---------------- A: object forward -> silhouettes forward + backward (the critical path: nothing else rides it)
         ck(L.hm_rigid_fwd(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object), P(m.int_scales_object),
                           1, B, Vo, None, P(self.vo), sa), "rigid_fwd(obj)")
         self.ev_vo.record(main)
-        if on["smooth"]:
-            ck(L.hm_smooth_fwd(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_a, sa), "smooth(obj)")
         if on["sil"]:
             ck(L.hm_sil_fwd(P(self.vo), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
                             self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
-                            P(m.losses.keep_sum), P(self.pooled), self._slot("loss_sil_obj"), P(sctx.work_order),
-                            None, P(sctx.workspace), sa), "sil_fwd")
+                            None, P(self.pooled), None, P(sctx.work_order), None, P(sctx.workspace), sa), "sil_fwd")
+            self.ev_sil.record(main)         # the loss / IoU reduction runs on the side stream
             ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
                             2 if self.lw["lw_sil_obj"] > 0 else 1,
                             P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
@@ -339,6 +337,9 @@ class FusedStepper:
                 ck(L.hm_v2d_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
                                 P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, sb), "v2d")
             side.wait_event(self.ev_vo)
+            if on["smooth"]:
+                ck(L.hm_smooth_fwd(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, sb),
+                   "smooth(obj)")
             if on["col"]:
                 ck(L.hm_collision_fwd(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
                                       cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
@@ -355,14 +356,21 @@ class FusedStepper:
                    "inter")
                 ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, P(self.G_int_h),
                                   P(self.G_int_o) if m.optimize_object_scale else None, sb), "inter_bwd")
-            self.ev_pair.record(side)        # object-side terms of the pair-wise losses are ready
+            # object-side terms that do not come from the silhouettes: smooth + contact [+ interaction with a free scale]
+            self.obj_part = on["smooth"] or on["con"] or (on["inter"] and m.optimize_object_scale)
+            if self.obj_part:
+                ck(L.hm_lincomb4(P(self.U_smo) if on["smooth"] else None, w["loss_smooth_obj"],
+                                 P(self.U_cono) if on["con"] else None, w["loss_contact"],
+                                 P(self.G_int_o) if (on["inter"] and m.optimize_object_scale) else None, 1.0,
+                                 None, 0.0, B * Vo * 3, P(self.G_o), sb), "lincomb(obj)")
+            self.ev_pair.record(side)        # ... are ready
             # hand (full path: MANO + rigid): smooth + v2d + collision + contact; interaction reaches the rigid pose only
             ck(L.hm_lincomb4(P(self.U_smh) if on["smooth"] else None, w["loss_smooth_hand"],
                              P(self.U_v2d) if on["v2d"] else None, w["loss_v2d_hand"],
                              P(self.U_colh) if on["col"] else None, w["loss_collision"],
                              P(self.U_conh) if on["con"] else None, w["loss_contact"],
                              B * Vh * 3, P(self.G_h), sb), "lincomb(hand)")
-            ck(L.hm_rigid_bwd(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, P(self.G_h),
+            ck(L.hm_rigid_bwd(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, P(self.G_h), None,
                               P(self.G_int_h) if on["inter"] else None, B, Vh, P(self.G_mesh),
                               P(m.rotations_hand.grad), P(m.translations_hand.grad), None, sb), "rigid_bwd(hand)")
             ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
@@ -371,24 +379,26 @@ class FusedStepper:
             if on["pca"]:
                 ck(L.hm_lincomb4(P(self.g_pca_mano), 1.0, P(self.U_pca), w["loss_pca"], None, 0.0, None, 0.0,
                                  pca.numel(), P(pca.grad), sb), "lincomb(pca)")
-        # ---------------- A: object backward (smooth + contact + silhouette [+ interaction when the scale is optimised])
+        # ---------------- A: object backward (silhouette gradient + the side stream's object-side terms)
         main.wait_event(self.ev_pair)
-        ck(L.hm_lincomb4(P(self.U_smo) if on["smooth"] else None, w["loss_smooth_obj"],
-                         P(self.U_cono) if on["con"] else None, w["loss_contact"],
-                         P(self.G_sil) if on["sil"] else None, 1.0,
-                         P(self.G_int_o) if (on["inter"] and m.optimize_object_scale) else None, 1.0,
-                         B * Vo * 3, P(self.G_o), sa), "lincomb(obj)")
         sc_obj = m.optimize_object_scale
-        ck(L.hm_rigid_bwd(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, P(self.G_o), None, B,
+        ck(L.hm_rigid_bwd(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1,
+                          P(self.G_sil) if on["sil"] else None, P(self.G_o) if self.obj_part else None, None, B,
                           Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
                           P(self.g_so_part) if sc_obj else None, sa), "rigid_bwd(obj)")
+        # ---------------- B (tail): silhouette loss reduction and the log row, off the critical path
+        with torch.cuda.stream(side):
+            if on["sil"]:
+                side.wait_event(self.ev_sil)
+                ck(L.hm_sil_reduce(B, Vo, sctx.F, sctx.S, P(m.losses.keep_sum), self._slot("loss_sil_obj"),
+                                   P(sctx.workspace), sb), "sil_reduce")
+            if log:
+                ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
+                                  P(self.log_buf), sb), "log")
         main.wait_stream(side)               # join
         if sc_obj:
             ck(L.hm_sum_small(P(self.g_so_part), B, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
                               P(m.int_scales_object.grad), sa), "scale grad")
-        if log:
-            ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
-                              P(self.log_buf), sa), "log")
 
     def run(self, steps):
         if self.graph is not None:

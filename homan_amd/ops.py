@@ -281,7 +281,7 @@ class _RigidTransform(torch.autograd.Function):
         g_trans = torch.empty(N, 3, device=mesh.device)
         g_sp = torch.empty(N, device=mesh.device) if need_scale else None
         _lib.check(_lib.lib().hm_rigid_bwd(_lib.ptr(mesh), _lib.ptr(rot6d), _lib.ptr(scale), ctx.abs_scale,
-                                           _lib.ptr(g_full), _lib.ptr(g_det), N, V, _lib.ptr(g_mesh), _lib.ptr(g_rot),
+                                           _lib.ptr(g_full), None, _lib.ptr(g_det), N, V, _lib.ptr(g_mesh), _lib.ptr(g_rot),
                                            _lib.ptr(g_trans), _lib.ptr(g_sp), _lib.stream()), "hm_rigid_bwd")
         g_scale = g_sp.sum().reshape(scale.shape) if need_scale else None
         return g_mesh, g_rot, g_trans.view(ctx.trans_shape), g_scale, None

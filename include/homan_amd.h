@@ -43,11 +43,12 @@ typedef struct ihipStream_t* hipStream_t;
  * mesh (N,V,3), rot6d (N,3,2), trans (N,3), scale (1), rotmat (N,3,3) optional output, verts (N,V,3). */
 int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, const float* scale, int abs_scale, int N,
                  int V, float* rotmat, float* verts, hipStream_t stream);
-/* g_full: d/dverts reaching mesh, scale, R, t; g_rigid: d/d(mesh-detached twin) reaching R, t only (either may be
- * NULL).  Outputs: g_mesh (N,V,3) optional, g_rot6d (N,3,2), g_trans (N,3), g_scale_part (N) optional (sum = d/dscale). */
+/* g_full (+ g_full_b, summed): d/dverts reaching mesh, scale, R, t; g_rigid: d/d(mesh-detached twin) reaching R, t only
+ * (each may be NULL).  Outputs: g_mesh (N,V,3) optional, g_rot6d (N,3,2), g_trans (N,3), g_scale_part (N) optional
+ * (sum = d/dscale). */
 int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* g_full,
-                 const float* g_rigid, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans,
-                 float* g_scale_part, hipStream_t stream);
+                 const float* g_full_b, const float* g_rigid, int N, int V, float* g_mesh, float* g_rot6d,
+                 float* g_trans, float* g_scale_part, hipStream_t stream);
 /* out = s[0] * in ;  out = s0[0]*a + s1[0]*b   (backward of the losses whose unit gradient is produced forward) */
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream);
 int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s1, long n, float* out,
@@ -91,6 +92,8 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
                void* workspace, hipStream_t stream);
+/* deferred loss / IoU reduction of an hm_sil_fwd called with keep/ref but loss_out == NULL (off the critical path) */
+int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, void* workspace, hipStream_t stream);
 /* mode 1: upstream (1) = dL/d loss_out[0]; mode 2: same with upstream[0] > 0 guaranteed by the caller (the forward's
  * sweep planes are reused, one launch less); mode 0: grad_pooled (B,S,S) = dL/d pooled.  adj_off (V+1), adj_items (3F):
  * CSR vertex -> (face*3 + corner).  face_order: B*F int32 permutation of frame*F+face (visiting order of the edge
@@ -164,7 +167,8 @@ int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int
 /* ------------------------------------------------------------------ optimiser step + logging
  * reference homan/jointopt.py:138-151,192 (torch.optim.Adam, three groups) and :184-189 (loss_evolution).
  * slots: n_tensors records {float* p, g, m, v; long n; float lr; int pad} (hm_adam_slot_bytes() each);
- * step: device int32 counter (incremented); zero_grad != 0 clears g after the update. */
+ * step: TWO device int32 words {completed steps (incremented by the launch), ticket word (zero between launches)};
+ * zero_grad != 0 clears g after the update. */
 size_t hm_adam_slot_bytes(void);
 int hm_adam_step(const void* slots, int n_tensors, int* step, float beta1, float beta2, float eps, int zero_grad,
                  int blocks_per_tensor, hipStream_t stream);
