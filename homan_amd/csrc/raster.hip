@@ -66,45 +66,86 @@ __device__ __forceinline__ void project_vertex(const float* __restrict__ p, cons
 // ---------------------------------------------------------------- face setup
 // projects the three vertices of every face (a vertex is shared by ~6 faces: re-projecting it is cheaper than a
 // separate projection launch on the critical path), packs the (B,F,3,3) NDC face buffer and the 8-byte screen boxes.
-__global__ void k_setup_faces(const float* __restrict__ verts, const float* __restrict__ K, float orig_size,
-                              const int* __restrict__ faces, int faces_bstride,
-                              int B, int V, int F, int is, float* __restrict__ faces9,
-                              FaceBox* __restrict__ boxes, unsigned char* __restrict__ owned)
+// It also bins the faces into 128x128-sample super-regions (counts aggregated per workgroup in LDS, one global atomic per
+// (workgroup, bin)): a raster workgroup then scans the faces of its super-region instead of the whole frame.  The order
+// inside a bin is arbitrary; the raster resolves visibility with a min, so its result does not depend on it.
+// grid (ceil(F/256), B).  bin_cnt must be zero on entry (the raster's last workgroup resets it).
+#define SR_SHIFT 7         // log2 of the super-region side in samples
+#define SR_MAX 64          // super-regions per frame (is <= 1024)
+__global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ verts, const float* __restrict__ K,
+                                                     float orig_size, const int* __restrict__ faces, int faces_bstride,
+                                                     int B, int V, int F, int is, float* __restrict__ faces9,
+                                                     FaceBox* __restrict__ boxes, unsigned char* __restrict__ owned,
+                                                     int* __restrict__ bin_cnt, int* __restrict__ bin_list)
 {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)B * F) return;
-    const int b = (int)(i / F), fi = (int)(i % F);
-    const int* fc = faces + (long)b * faces_bstride + 3 * fi;
-    float f[9], r[9];
+    __shared__ int s_cnt[SR_MAX], s_base[SR_MAX];
+    const int b = blockIdx.y, fi = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = fi < F;
+    const int nsx = (is + (1 << SR_SHIFT) - 1) >> SR_SHIFT, nsr = nsx * nsx;
+    if (threadIdx.x < SR_MAX) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned mask = 0;
+    int x0 = 1, y0 = 1, x1 = 0, y1 = 0;
+    if (valid) {
+        const long i = (long)b * F + fi;
+        const int* fc = faces + (long)b * faces_bstride + 3 * fi;
+        float f[9], r[9];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) project_vertex(verts + ((long)b * V + fc[k]) * 3, K + b * 9, orig_size, f + 3 * k);
+        for (int k = 0; k < 3; ++k) project_vertex(verts + ((long)b * V + fc[k]) * 3, K + b * 9, orig_size, f + 3 * k);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { r[3 * k] = f[3 * (2 - k)]; r[3 * k + 1] = f[3 * (2 - k) + 1]; r[3 * k + 2] = f[3 * (2 - k) + 2]; }
+        for (int k = 0; k < 3; ++k) { r[3 * k] = f[3 * (2 - k)]; r[3 * k + 1] = f[3 * (2 - k) + 1]; r[3 * k + 2] = f[3 * (2 - k) + 2]; }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) faces9[i * 9 + k] = f[k];
-    owned[(long)b * 2 * F + fi] = 0;          // "owns at least one sample" flags, set by the forward raster
-    owned[(long)b * 2 * F + F + fi] = 0;
-    unsigned mask = (backside(f) ? 0u : 1u) | (backside(r) ? 0u : 2u);
-    float px[3], py[3];
+        for (int k = 0; k < 9; ++k) faces9[i * 9 + k] = f[k];
+        owned[(long)b * 2 * F + fi] = 0;          // "owns at least one sample" flags, set by the forward raster
+        owned[(long)b * 2 * F + F + fi] = 0;
+        mask = (backside(f) ? 0u : 1u) | (backside(r) ? 0u : 2u);
+        float px[3], py[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { px[k] = topix(f[3 * k], is); py[k] = topix(f[3 * k + 1], is); }
-    const float xmin = fminf(px[0], fminf(px[1], px[2])), xmax = fmaxf(px[0], fmaxf(px[1], px[2]));
-    const float ymin = fminf(py[0], fminf(py[1], py[2])), ymax = fmaxf(py[0], fmaxf(py[1], py[2]));
-    FaceBox bx;
-    if (!(xmax >= -2.0f && ymax >= -2.0f && xmin <= is + 1.0f && ymin <= is + 1.0f)) mask = 0;  // off-screen / NaN
-    // sample p (integer pixel coordinate) can be covered only if min <= p <= max; 0.01 px of slack dwarfs the
-    // rounding of the edge functions, so the box is conservative yet tight
-    int x0 = max(0, (int)ceilf(fmaxf(xmin, -2.0f) - 0.01f));
-    int x1 = min(is - 1, (int)floorf(fminf(xmax, is + 1.0f) + 0.01f));
-    int y0 = max(0, (int)ceilf(fmaxf(ymin, -2.0f) - 0.01f));
-    int y1 = min(is - 1, (int)floorf(fminf(ymax, is + 1.0f) + 0.01f));
-    if (x1 < x0 || y1 < y0) mask = 0;
-    if (mask == 0) { x0 = y0 = 1; x1 = y1 = 0; }
-    bx.x0m = (unsigned short)(x0 | (mask << 14));
-    bx.y0 = (unsigned short)y0;
-    bx.x1 = (unsigned short)x1;
-    bx.y1 = (unsigned short)y1;
-    boxes[i] = bx;
+        for (int k = 0; k < 3; ++k) { px[k] = topix(f[3 * k], is); py[k] = topix(f[3 * k + 1], is); }
+        const float xmin = fminf(px[0], fminf(px[1], px[2])), xmax = fmaxf(px[0], fmaxf(px[1], px[2]));
+        const float ymin = fminf(py[0], fminf(py[1], py[2])), ymax = fmaxf(py[0], fmaxf(py[1], py[2]));
+        if (!(xmax >= -2.0f && ymax >= -2.0f && xmin <= is + 1.0f && ymin <= is + 1.0f)) mask = 0;  // off-screen / NaN
+        // sample p (integer pixel coordinate) can be covered only if min <= p <= max; 0.01 px of slack dwarfs the
+        // rounding of the edge functions, so the box is conservative yet tight
+        x0 = max(0, (int)ceilf(fmaxf(xmin, -2.0f) - 0.01f));
+        x1 = min(is - 1, (int)floorf(fminf(xmax, is + 1.0f) + 0.01f));
+        y0 = max(0, (int)ceilf(fmaxf(ymin, -2.0f) - 0.01f));
+        y1 = min(is - 1, (int)floorf(fminf(ymax, is + 1.0f) + 0.01f));
+        if (x1 < x0 || y1 < y0) mask = 0;
+        if (mask == 0) { x0 = y0 = 1; x1 = y1 = 0; }
+        FaceBox bx;
+        bx.x0m = (unsigned short)(x0 | (mask << 14));
+        bx.y0 = (unsigned short)y0;
+        bx.x1 = (unsigned short)x1;
+        bx.y1 = (unsigned short)y1;
+        boxes[i] = bx;
+    }
+    if (!bin_cnt) return;
+    // local slots in LDS, one global reservation per (workgroup, bin)
+    const int sx0 = x0 >> SR_SHIFT, sx1 = x1 >> SR_SHIFT, sy0 = y0 >> SR_SHIFT, sy1 = y1 >> SR_SHIFT;
+    int local[4];                       // a face larger than 2x2 super-regions reserves its further bins one by one
+    int nloc = 0;
+    if (mask)
+        for (int sy = sy0; sy <= sy1; ++sy)
+            for (int sx = sx0; sx <= sx1; ++sx) {
+                if (nloc < 4) local[nloc] = atomicAdd(&s_cnt[sy * nsx + sx], 1);
+                ++nloc;
+            }
+    __syncthreads();
+    if (threadIdx.x < nsr) {
+        const int c = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = c ? atomicAdd(&bin_cnt[b * nsr + threadIdx.x], c) : 0;
+    }
+    __syncthreads();
+    if (mask) {
+        int q = 0;
+        for (int sy = sy0; sy <= sy1; ++sy)
+            for (int sx = sx0; sx <= sx1; ++sx, ++q) {
+                const int sr = sy * nsx + sx;
+                const int at = q < 4 ? s_base[sr] + local[q] : atomicAdd(&bin_cnt[b * nsr + sr], 1);
+                bin_list[((long)b * nsr + sr) * F + at] = fi;
+            }
+    }
 }
 
 __device__ __forceinline__ int hm_wave_scan_incl(int v)
@@ -189,7 +230,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
     float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned,
-    float* __restrict__ pooled_depth, unsigned short* __restrict__ rowneg, unsigned short* __restrict__ colneg)
+    float* __restrict__ pooled_depth, unsigned short* __restrict__ rowneg, unsigned short* __restrict__ colneg,
+    int* __restrict__ bin_cnt, const int* __restrict__ bin_list, unsigned int* __restrict__ done, int reset_bins)
 {
     __shared__ unsigned long long zb[32 * 32];
     __shared__ int cand[2 * CAND_CAP];
@@ -217,18 +259,26 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     for (int k = 0; k < 4; ++k) zb[tid + 256 * k] = zb_empty;
 
     const uint2* bx = reinterpret_cast<const uint2*>(boxes) + (long)b * F;
-    for (int cbase = 0; cbase < F; cbase += CAND_CAP) {
+    // faces to scan: the bin of this region's 128x128-sample super-region (or the whole frame without bins)
+    const int nsx = (is + (1 << SR_SHIFT) - 1) >> SR_SHIFT;
+    const int sr = (gy0 >> SR_SHIFT) * nsx + (gx0 >> SR_SHIFT);
+    const int nscan = bin_cnt ? bin_cnt[b * nsx * nsx + sr] : F;
+    const int* scan = bin_cnt ? bin_list + ((long)b * nsx * nsx + sr) * F : nullptr;
+    for (int cbase = 0; cbase < nscan; cbase += CAND_CAP) {
         if (tid == 0) cand_n = 0;
         __syncthreads();
         uint2 v[CAND_CAP / 256];
+        int vf[CAND_CAP / 256];
 #pragma unroll
         for (int k = 0; k < CAND_CAP / 256; ++k) {
-            const int fi = cbase + k * 256 + tid;
-            v[k] = (fi < F) ? bx[fi] : make_uint2(0u, 0u);
+            const int e = cbase + k * 256 + tid;
+            vf[k] = e < nscan ? (scan ? scan[e] : e) : -1;
         }
 #pragma unroll
+        for (int k = 0; k < CAND_CAP / 256; ++k) v[k] = vf[k] >= 0 ? bx[vf[k]] : make_uint2(0u, 0u);
+#pragma unroll
         for (int k = 0; k < CAND_CAP / 256; ++k) {
-            const int fi = cbase + k * 256 + tid;
+            const int fi = vf[k];
             const int x0 = v[k].x & 0x3fff, y0 = (int)(v[k].x >> 16), x1 = (int)(v[k].y & 0xffff), y1 = (int)(v[k].y >> 16);
             const unsigned m = (x1 < gx0 || x0 > gx1 || y1 < gy0 || y0 > gy1) ? 0u : ((v[k].x >> 14) & 3u);
 #pragma unroll
@@ -398,6 +448,15 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         }
     }
     __syncthreads();
+    // the last workgroup of the launch empties the bins for the next forward (every workgroup has read its count)
+    // (no fence: the counts are read-only during the launch, and an agent-scope release here would write back the L2
+    //  once per workgroup)
+    if (tid == 0 && bin_cnt && reset_bins) {
+        if (atomicAdd(done, 1u) == gridDim.x - 1u) {
+            for (int i2 = 0; i2 < B * nsx * nsx; ++i2) bin_cnt[i2] = 0;
+            atomicExch(done, 0u);
+        }
+    }
 
     // ---- epilogue: this lane's output pixel and its 2x2 samples (flip: output row r <-> sample rows is-1-2r-dy)
     const int r = ty * HM_TILE + (lane >> 3), c = tx * HM_TILE + (lane & 7);
@@ -1093,6 +1152,8 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
     n += al256((size_t)B * is * (is / 16) * 4); // column masks, 2 planes
     n += al256((size_t)B * F * 24 * 4);         // parts
     n += al256((size_t)B * F * 2);              // owned
+    n += al256((size_t)B * SR_MAX * 4 + 256);                  // super-region bin counters + the raster's ticket word
+    n += al256((size_t)B * SR_MAX * F * 4);                    // super-region face lists (worst case: every face in every bin)
     n += al256(4 * (size_t)B * is * SWEEP_CUMW * 2);            // per-line cumulative source counts
     n += al256(4 * (size_t)B * is * is * sizeof(SweepSrc));     // per-line source arrays (2 planes x 2 orientations)
     return n;
@@ -1102,7 +1163,7 @@ struct SilWs {
     unsigned int* counter; float* frame_rec;
     float* ndc; float* faces9; FaceBox* boxes; int* idx_map; unsigned short* alpha16; float* dimg;
     float* partials; float* gimg; unsigned short* rowneg; unsigned short* colneg; float* parts;
-    unsigned char* owned; unsigned short* cum; SweepSrc* srcs;
+    unsigned char* owned; int* bin_cnt; unsigned int* bin_done; int* bin_list; unsigned short* cum; SweepSrc* srcs;
 };
 static SilWs carve(void* ws, int B, int V, int F, int S)
 {
@@ -1123,6 +1184,8 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.colneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4);
     w.parts = (float*)p; p += al256((size_t)B * F * 24 * 4);
     w.owned = (unsigned char*)p; p += al256((size_t)B * F * 2);
+    w.bin_cnt = (int*)p; w.bin_done = (unsigned int*)(p + (size_t)B * SR_MAX * 4); p += al256((size_t)B * SR_MAX * 4 + 256);
+    w.bin_list = (int*)p; p += al256((size_t)B * SR_MAX * F * 4);
     w.cum = (unsigned short*)p; p += al256(4 * (size_t)B * is * SWEEP_CUMW * 2);
     w.srcs = (SweepSrc*)p;
     return w;
@@ -1141,12 +1204,14 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     HM_CHECK_ARG(faces_bstride == 0 || faces_bstride == 3 * F);
     SilWs w = carve(workspace, B, V, F, S);
     const int is = 2 * S, ntiles = (S / 8) * (S / 8);
-    hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv((long)B * F, 256)), dim3(256), 0, stream, verts, K, orig_size, faces,
-                       faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned);
+    int* bins = is <= (SR_MAX == 64 ? 1024 : 0) ? w.bin_cnt : nullptr;      // <= SR_MAX super-regions per frame
+    hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, orig_size, faces,
+                       faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list);
     const bool fused = keep && ref;
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                       fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.rowneg, w.colneg);
+                       fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.rowneg, w.colneg, bins,
+                       w.bin_list, w.bin_done, 1);
     if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            w.counter, loss_out);
@@ -1253,15 +1318,21 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return HM_ERR_LAUNCH;
     float ms = 0.f;
+    // the forward's last workgroup emptied the super-region bins: fill them again and keep them across the timed launches
+    int* bins = 2 * S <= 1024 ? w.bin_cnt : nullptr;
+    hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, 1.0f, faces, 0, B, V, F,
+                       2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list);
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                           w.partials, work_order, w.owned, (float*)nullptr, w.rowneg, w.colneg);
+                           w.partials, work_order, w.owned, (float*)nullptr, w.rowneg, w.colneg, bins, w.bin_list,
+                           w.bin_done, 0);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
     avg_ms[0] = ms / (float)reps;
+    (void)hipMemsetAsync(w.bin_cnt, 0, (size_t)B * SR_MAX * 4, stream);
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i)
         hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), sweep_blocks())), dim3(256), 0, stream, w.faces9,

@@ -13,6 +13,7 @@ Two execution modes:
                 and read back once at the end (no host sync inside the loop).
 """
 import ctypes
+import os
 from collections import OrderedDict, defaultdict
 
 import numpy as np
@@ -264,7 +265,7 @@ class FusedStepper:
         self.max_steps = max_steps
         self.mctx = m.mano_model.ctx_mean
         self.graph = None
-        self.side = torch.cuda.Stream()
+        self.side = torch.cuda.Stream(priority=int(os.environ.get("HM_SIDE_PRIO", "0")))
         self.ev_vo, self.ev_pair, self.ev_sil = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
         self.reduce_ws_b = ops.ReduceWorkspace(dev)
         side = torch.cuda.Stream()
