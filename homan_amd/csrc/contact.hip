@@ -81,12 +81,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
     }
     bm = hm_block_min(bm, red);
     const unsigned nblk = gridDim.x * gridDim.y;
-    if (threadIdx.x == 0) blockmin[b * gridDim.x + blockIdx.x] = bm;
+    if (threadIdx.x == 0) hm_partial_store(blockmin + b * gridDim.x + blockIdx.x, bm);
     if (hm_last_block(counter, nblk, &s_flag)) {
         float mx = -3.4e38f;
         for (int bb = threadIdx.x; bb < B; bb += blockDim.x) {
             float m = 3.4e38f;
-            for (unsigned c = 0; c < gridDim.x; ++c) m = fminf(m, blockmin[bb * gridDim.x + c]);
+            for (unsigned c = 0; c < gridDim.x; ++c) m = fminf(m, hm_partial_load(blockmin + bb * gridDim.x + c));
             mx = fmaxf(mx, sqrtf(m));
         }
         mx = hm_block_max(mx, red);
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_hand(const float* __rest
         gh[0] = -k * dx; gh[1] = -k * dy; gh[2] = -k * dz;
     }
     lsum = hm_block_sum(lsum, red);
-    if (threadIdx.x == 0) partials[b] = lsum;
+    if (threadIdx.x == 0) hm_partial_store(partials + b, lsum);
     if (hm_last_block(counter, gridDim.x, &s_flag)) {
         const float t = hm_last_block_sum(partials, B, 1, red);
         if (threadIdx.x == 0) out[0] = t * inv_cnt;

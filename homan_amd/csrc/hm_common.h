@@ -102,30 +102,36 @@ __device__ __forceinline__ float hm_block_max(float v, float* red)
 
 // ---- single-launch grid reduction ("last block finishes") -----------------------------------------
 // Every block stores its partial record, then takes a ticket; the block that draws the last ticket
-// re-reads all records in index order (deterministic) and finishes.  Cross-workgroup visibility follows
-// the CDNA4 rule: producer agent-scope release before the ticket, consumer agent-scope acquire after it
-// (per-XCD L2s / per-CU L1s are not coherent otherwise).  `counter` must be zero on entry; the last
-// block resets it, so one zero-initialised word serves every launch on the stream.
+// re-reads all records in index order (deterministic) and finishes.  Cross-workgroup visibility: the per-XCD L2s are
+// not coherent with each other, but an agent-scope RELEASE FENCE is the wrong tool here -- it writes back every dirty
+// line of the L2 (buffer_wbl2), once per workgroup, while the rasteriser next door is filling that L2 with its own
+// output (measured: the small reductions and the rasteriser both ran ~1.7x slower when overlapped).  Instead the
+// records themselves travel at agent scope: hm_partial_store (write-through, sc1) by the producer, s_waitcnt vmcnt(0)
+// before the ticket, hm_partial_load (sc1, never served from a stale L2 line) by the finishing block.  Records MUST be
+// written with hm_partial_store by the thread that calls the ticket (thread 0) and read with hm_partial_load.
+// `counter` must be zero on entry; the last block resets it, so one zero-initialised word serves every launch on the
+// stream.
 // Usage:   if (hm_last_block(counter, nblocks, &s_flag)) { ...read partials, write result... }
-// Call with all threads of the block, after the block's partial record was written by thread 0.
+__device__ __forceinline__ void hm_partial_store(float* p, float v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float hm_partial_load(const float* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ bool hm_last_block(unsigned int* counter, unsigned int nblocks, int* s_flag)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int ticket = atomicAdd(counter, 1u);
         const int last = (ticket == nblocks - 1u);
-        if (last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            atomicExch(counter, 0u);
-        }
+        if (last) atomicExch(counter, 0u);
         *s_flag = last;
     }
     __syncthreads();
-    const bool last = *s_flag != 0;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    return last;
+    return *s_flag != 0;
 }
 
 
@@ -133,6 +139,6 @@ __device__ __forceinline__ bool hm_last_block(unsigned int* counter, unsigned in
 __device__ __forceinline__ float hm_last_block_sum(const float* partials, int n, int stride, float* red)
 {
     float a = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) a += partials[(long)i * stride];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a += hm_partial_load(partials + (long)i * stride);
     return hm_block_sum(a, red);
 }

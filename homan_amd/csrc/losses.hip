@@ -45,7 +45,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_v2d(const float* __restrict__ v
     }
     lsum = hm_block_sum(lsum, red);
     msum = hm_block_sum(msum, red);
-    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = lsum; partials[2 * blockIdx.x + 1] = msum; }
+    if (threadIdx.x == 0) { hm_partial_store(partials + 2 * blockIdx.x, lsum); hm_partial_store(partials + 2 * blockIdx.x + 1, msum); }
     if (hm_last_block(counter, gridDim.x, &s_flag)) {
         const float a = hm_last_block_sum(partials, gridDim.x, 2, red);
         const float b = hm_last_block_sum(partials + 1, gridDim.x, 2, red);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_smooth(const float* __restrict_
         unit_grad[i] = 2.0f * g * inv_cnt;
     }
     lsum = hm_block_sum(lsum, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = lsum;
+    if (threadIdx.x == 0) hm_partial_store(partials + blockIdx.x, lsum);
     if (hm_last_block(counter, gridDim.x, &s_flag)) {
         const float a = hm_last_block_sum(partials, gridDim.x, 1, red);
         if (threadIdx.x == 0) out[0] = a * inv_cnt;
@@ -173,13 +173,13 @@ __global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__
         const float dx = cen[1][0] - cen[0][0], dy = cen[1][1] - cen[0][1], dz = cen[1][2] - cen[0][2];
         const float mse = (dx * dx + dy * dy + dz * dz) / 3.0f;
         float* r = frame_rec + b * 8;
-        r[0] = flag; r[1] = mse;
+        hm_partial_store(r, flag); hm_partial_store(r + 1, mse);
         r[2] = flag * 2.0f * dx / 3.0f; r[3] = flag * 2.0f * dy / 3.0f; r[4] = flag * 2.0f * dz / 3.0f;
     }
     if (hm_last_block(counter, gridDim.x, &s_flag)) {
         float l = 0.f;
         for (int i = threadIdx.x; i < B; i += blockDim.x)
-            if (frame_rec[i * 8] != 0.f) l += frame_rec[i * 8 + 1];
+            if (hm_partial_load(frame_rec + i * 8) != 0.f) l += hm_partial_load(frame_rec + i * 8 + 1);
         l = hm_block_sum(l, red);
         if (threadIdx.x == 0) out[0] = l;
     }

@@ -296,7 +296,7 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(
     val = hm_block_sum(val, red);
     const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
-    if (threadIdx.x == 0) partials[bid] = val;
+    if (threadIdx.x == 0) hm_partial_store(partials + bid, val);
     if (hm_last_block(counter, nblk, &s_flag)) {
         const float t = hm_last_block_sum(partials, (int)nblk, 1, red);
         if (threadIdx.x == 0) out[0] = t;

@@ -323,6 +323,8 @@ class FusedStepper:
                             P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
                             P(sctx.face_order), P(self.G_sil), None, P(sctx.workspace), sa), "sil_bwd")
         # ---------------- B: hand forward, pair-wise losses, hand backward
+        if os.environ.get("HM_SERIAL"):
+            side.wait_stream(main)
         with torch.cuda.stream(side):
             ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None, sb), "mano_fwd")
             ck(L.hm_rigid_fwd(P(self.vm), P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), 0, B, Vh,
