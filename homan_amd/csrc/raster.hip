@@ -1125,19 +1125,9 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
 }
 
 // ================================================================ C ABI
-#include <stdlib.h>
-static int raster_lds_pad()
-{
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("HM_RASTER_LDS_PAD"); v = e ? atoi(e) : 0; }
-    return v;
-}
-static int sweep_blocks()
-{
-    static int v = 0;
-    if (!v) { const char* e = getenv("HM_SWEEP_BLOCKS"); v = e ? atoi(e) : 2048; }
-    return v;
-}
+// persistent sweep waves: 4 per SIMD.  More does not speed the sweep up and starves the concurrent hand-side kernels
+// of wave slots (they run on a second stream of the same hipGraph).
+#define SWEEP_BLOCKS 1024
 extern "C" {
 
 // workspace layout helper (bytes), all chunks 256-byte aligned
@@ -1216,7 +1206,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, orig_size, faces,
                        faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list);
     const bool fused = keep && ref;
-    hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), raster_lds_pad(), stream,
+    hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.rowneg, w.colneg, bins,
                        w.bin_list, w.bin_done, 1);
@@ -1258,7 +1248,7 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
                            w.rowneg, w.colneg);
     hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S * 64, 256)), dim3(256), 0, stream, w.rowneg, w.colneg,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.cum);
-    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), sweep_blocks())), dim3(256), 0, stream, w.faces9, w.boxes,
+    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), SWEEP_BLOCKS)), dim3(256), 0, stream, w.faces9, w.boxes,
                        w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, eps, w.parts, w.owned, face_order);
     hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                        adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
@@ -1330,7 +1320,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     int* bins = 2 * S <= 1024 ? w.bin_cnt : nullptr;
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, 1.0f, faces, 0, B, V, F,
                        2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list);
-    const bool cold = getenv("HM_BENCH_COLD") != nullptr;
+    const bool cold = false;   // true: re-bin before every launch (times setup + raster with the reset tickets)
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i) {
         if (cold) {
@@ -1341,7 +1331,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                            w.partials, work_order, w.owned, (float*)nullptr, w.rowneg, w.colneg, bins, w.bin_list,
-                           w.bin_done, cold && getenv("HM_BENCH_TICKET") ? 1 : 0);
+                           w.bin_done, cold ? 1 : 0);
     }
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
@@ -1350,7 +1340,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     (void)hipMemsetAsync(w.bin_cnt, 0, (size_t)B * SR_MAX * 4, stream);
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), sweep_blocks())), dim3(256), 0, stream, w.faces9,
+        hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), SWEEP_BLOCKS)), dim3(256), 0, stream, w.faces9,
                            w.boxes, w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, 1e-3f, w.parts, w.owned,
                            face_order);
     (void)hipEventRecord(e1, stream);

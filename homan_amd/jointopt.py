@@ -13,7 +13,6 @@ Two execution modes:
                 and read back once at the end (no host sync inside the loop).
 """
 import ctypes
-import os
 from collections import OrderedDict, defaultdict
 
 import numpy as np
@@ -265,8 +264,9 @@ class FusedStepper:
         self.max_steps = max_steps
         self.mctx = m.mano_model.ctx_mean
         self.graph = None
-        self.side = torch.cuda.Stream(priority=int(os.environ.get("HM_SIDE_PRIO", "0")))
-        self.ev_vo, self.ev_pair, self.ev_sil = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        self.side = torch.cuda.Stream()
+        self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd = (torch.cuda.Event() for _ in range(4))
+        self.aux = torch.cuda.Stream()
         self.reduce_ws_b = ops.ReduceWorkspace(dev)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -323,8 +323,6 @@ class FusedStepper:
                             P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
                             P(sctx.face_order), P(self.G_sil), None, P(sctx.workspace), sa), "sil_bwd")
         # ---------------- B: hand forward, pair-wise losses, hand backward
-        if os.environ.get("HM_SERIAL"):
-            side.wait_stream(main)
         with torch.cuda.stream(side):
             ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None, sb), "mano_fwd")
             ck(L.hm_rigid_fwd(P(self.vm), P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), 0, B, Vh,
@@ -359,6 +357,20 @@ class FusedStepper:
                    "inter")
                 ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, P(self.G_int_h),
                                   P(self.G_int_o) if m.optimize_object_scale else None, sb), "inter_bwd")
+            # every forward loss value exists now: the silhouette reduction and the log row run on a third stream, off both
+            # chains.  (Only this: HIP stream capture crashes when two captured streams wait for each other's events in
+            # both directions, and the hipGraph executor maps richer fork patterns onto its hardware queues in orders that
+            # serialise the branches -- both measured.)
+            self.ev_fwd.record(side)
+            with torch.cuda.stream(self.aux):
+                self.aux.wait_event(self.ev_fwd)
+                if on["sil"]:
+                    self.aux.wait_event(self.ev_sil)
+                    ck(L.hm_sil_reduce(B, Vo, sctx.F, sctx.S, P(m.losses.keep_sum), self._slot("loss_sil_obj"),
+                                       P(sctx.workspace), self.aux.cuda_stream), "sil_reduce")
+                if log:
+                    ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
+                                      P(self.log_buf), self.aux.cuda_stream), "log")
             # object-side terms that do not come from the silhouettes: smooth + contact [+ interaction with a free scale]
             self.obj_part = on["smooth"] or on["con"] or (on["inter"] and m.optimize_object_scale)
             if self.obj_part:
@@ -389,16 +401,8 @@ class FusedStepper:
                           P(self.G_sil) if on["sil"] else None, P(self.G_o) if self.obj_part else None, None, B,
                           Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
                           P(self.g_so_part) if sc_obj else None, sa), "rigid_bwd(obj)")
-        # ---------------- B (tail): silhouette loss reduction and the log row, off the critical path
-        with torch.cuda.stream(side):
-            if on["sil"]:
-                side.wait_event(self.ev_sil)
-                ck(L.hm_sil_reduce(B, Vo, sctx.F, sctx.S, P(m.losses.keep_sum), self._slot("loss_sil_obj"),
-                                   P(sctx.workspace), sb), "sil_reduce")
-            if log:
-                ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
-                                  P(self.log_buf), sb), "log")
         main.wait_stream(side)               # join
+        main.wait_stream(self.aux)
         if sc_obj:
             ck(L.hm_sum_small(P(self.g_so_part), B, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
                               P(m.int_scales_object.grad), sa), "scale grad")
