@@ -100,11 +100,15 @@ __global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mes
     o[2] = x * R[2] + y * R[5] + z * R[8] + t[2];
 }
 
-// backward: g_full (+ g_full_b) reaches mesh, scale, R, t ; g_rigid (mesh-detached twin) reaches R, t only.  grid (N)
+// backward.  g_full = sum_k w[k] * terms[k] (up to 4 weighted per-vertex gradients, NULL terms skipped) reaches mesh,
+// scale, R, t ; g_rigid (per-vertex) and g_frame (one vector per frame, the same for every vertex) reach R, t only
+// (gradients w.r.t. the mesh-detached twin of the vertices).  Summing the weighted terms here replaces a separate
+// linear-combination launch on the critical chain.  grid (N)
+struct RigidTerms { const float* p[4]; float w[4]; };
 __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
-                                                   const float* __restrict__ scale, int abs_scale,
-                                                   const float* __restrict__ g_full, const float* __restrict__ g_full_b,
-                                                   const float* __restrict__ g_rigid, int N, int V,
+                                                   const float* __restrict__ scale, int abs_scale, RigidTerms terms,
+                                                   const float* __restrict__ g_rigid, const float* __restrict__ g_frame,
+                                                   int frame_stride, float frame_scale, int N, int V,
                                                    float* __restrict__ g_mesh,
                                                    float* __restrict__ g_rot6d, float* __restrict__ g_trans,
                                                    float* __restrict__ g_scale_part)
@@ -121,6 +125,11 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
     __syncthreads();
     const float sraw = scale[0];
     const float s = abs_scale ? fabsf(sraw) : sraw;
+    float gfr[3] = {0.f, 0.f, 0.f};
+    if (g_frame) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gfr[c] = frame_scale * g_frame[(long)n * frame_stride + c];
+    }
     float acc[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) acc[k] = 0.f;
@@ -128,9 +137,12 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
         const long o = ((long)n * V + v) * 3;
         const float m[3] = {mesh[o], mesh[o + 1], mesh[o + 2]};
         float gf[3] = {0.f, 0.f, 0.f}, gt[3];
-        if (g_full) { gf[0] = g_full[o]; gf[1] = g_full[o + 1]; gf[2] = g_full[o + 2]; }
-        if (g_full_b) { gf[0] += g_full_b[o]; gf[1] += g_full_b[o + 1]; gf[2] += g_full_b[o + 2]; }
-        gt[0] = gf[0]; gt[1] = gf[1]; gt[2] = gf[2];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (terms.p[k]) {
+                gf[0] += terms.w[k] * terms.p[k][o]; gf[1] += terms.w[k] * terms.p[k][o + 1]; gf[2] += terms.w[k] * terms.p[k][o + 2];
+            }
+        gt[0] = gf[0] + gfr[0]; gt[1] = gf[1] + gfr[1]; gt[2] = gf[2] + gfr[2];
         if (g_rigid) { gt[0] += g_rigid[o]; gt[1] += g_rigid[o + 1]; gt[2] += g_rigid[o + 2]; }
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -219,13 +231,18 @@ int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, cons
                        abs_scale, N, V, rotmat, verts);
     return hm_launch_status();
 }
-int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* g_full,
-                 const float* g_full_b, const float* g_rigid, int N, int V, float* g_mesh, float* g_rot6d,
-                 float* g_trans, float* g_scale_part, hipStream_t stream)
+int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
+                 const float* weights, int n_terms, const float* g_rigid, const float* g_frame, int frame_stride,
+                 float frame_scale, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part,
+                 hipStream_t stream)
 {
     HM_CHECK_ARG(mesh && rot6d && scale && g_rot6d && g_trans && N > 0 && V > 0);
-    hipLaunchKernelGGL(k_rigid_bwd, dim3(N), dim3(256), 0, stream, mesh, rot6d, scale, abs_scale, g_full, g_full_b, g_rigid, N,
-                       V, g_mesh, g_rot6d, g_trans, g_scale_part);
+    HM_CHECK_ARG(n_terms >= 0 && n_terms <= 4 && (n_terms == 0 || (g_terms && weights)));
+    HM_CHECK_ARG(!g_frame || frame_stride >= 3);
+    RigidTerms t;
+    for (int k = 0; k < 4; ++k) { t.p[k] = k < n_terms ? g_terms[k] : nullptr; t.w[k] = k < n_terms ? weights[k] : 0.f; }
+    hipLaunchKernelGGL(k_rigid_bwd, dim3(N), dim3(256), 0, stream, mesh, rot6d, scale, abs_scale, t, g_rigid, g_frame,
+                       frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part);
     return hm_launch_status();
 }
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream)

@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256) void k_mano_bwd1(ManoModelDev m, const float* 
 __global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
                                                    const float* __restrict__ rot, const float* __restrict__ betas,
                                                    const float* __restrict__ partials, int nchunk, int B, int pca_dim,
+                                                   const float* __restrict__ g_pca_extra, float w_extra,
                                                    float* __restrict__ g_pca, float* __restrict__ g_rot,
                                                    float* __restrict__ g_betas, float* __restrict__ g_trans)
 {
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* _
         float a = 0.f;
         if (i < 16)
             for (int k = 0; k < 45; ++k) a += m.comps[i * 45 + k] * dpose[3 + k];
+        if (g_pca_extra) a += w_extra * g_pca_extra[(long)b * pca_dim + i];      // e.g. the PCA prior's unit gradient
         g_pca[(long)b * pca_dim + i] = a;
     }
     if (t < 10) {
@@ -436,8 +438,8 @@ int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const f
 }
 size_t hm_mano_workspace_bytes(int B) { return (size_t)B * MANO_NCH64 * MANO_PART * sizeof(float); }
 int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
-                const float* g_verts, float* g_pca, float* g_rot, float* g_betas, float* g_trans, void* workspace,
-                hipStream_t stream)
+                const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
+                float* g_trans, void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(model && pca && rot && betas && g_verts && g_pca && g_rot && g_betas && g_trans && workspace);
     HM_CHECK_ARG(B > 0 && pca_dim >= 16);
@@ -446,7 +448,7 @@ int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const f
     hipLaunchKernelGGL(k_mano_bwd1, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, g_verts, B,
                        (float*)workspace);
     hipLaunchKernelGGL(k_mano_bwd2, dim3(B), dim3(64), 0, stream, m, pca, pca_dim, rot, betas, (const float*)workspace,
-                       MANO_NCH64, B, pca_dim, g_pca, g_rot, g_betas, g_trans);
+                       MANO_NCH64, B, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
     return hm_launch_status();
 }
 }  // extern "C"

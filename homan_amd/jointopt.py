@@ -355,8 +355,8 @@ class FusedStepper:
                 ck(L.hm_inter_fwd(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
                                   float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws_b, sb),
                    "inter")
-                ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, P(self.G_int_h),
-                                  P(self.G_int_o) if m.optimize_object_scale else None, sb), "inter_bwd")
+                if m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
+                    ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb), "inter_bwd")
             # every forward loss value exists now: the silhouette reduction and the log row run on a third stream, off both
             # chains.  (Only this: HIP stream capture crashes when two captured streams wait for each other's events in
             # both directions, and the hipGraph executor maps richer fork patterns onto its hardware queues in orders that
@@ -371,35 +371,30 @@ class FusedStepper:
                 if log:
                     ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
                                       P(self.log_buf), self.aux.cuda_stream), "log")
-            # object-side terms that do not come from the silhouettes: smooth + contact [+ interaction with a free scale]
-            self.obj_part = on["smooth"] or on["con"] or (on["inter"] and m.optimize_object_scale)
-            if self.obj_part:
-                ck(L.hm_lincomb4(P(self.U_smo) if on["smooth"] else None, w["loss_smooth_obj"],
-                                 P(self.U_cono) if on["con"] else None, w["loss_contact"],
-                                 P(self.G_int_o) if (on["inter"] and m.optimize_object_scale) else None, 1.0,
-                                 None, 0.0, B * Vo * 3, P(self.G_o), sb), "lincomb(obj)")
-            self.ev_pair.record(side)        # ... are ready
-            # hand (full path: MANO + rigid): smooth + v2d + collision + contact; interaction reaches the rigid pose only
-            ck(L.hm_lincomb4(P(self.U_smh) if on["smooth"] else None, w["loss_smooth_hand"],
-                             P(self.U_v2d) if on["v2d"] else None, w["loss_v2d_hand"],
-                             P(self.U_colh) if on["col"] else None, w["loss_collision"],
-                             P(self.U_conh) if on["con"] else None, w["loss_contact"],
-                             B * Vh * 3, P(self.G_h), sb), "lincomb(hand)")
-            ck(L.hm_rigid_bwd(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, P(self.G_h), None,
-                              P(self.G_int_h) if on["inter"] else None, B, Vh, P(self.G_mesh),
-                              P(m.rotations_hand.grad), P(m.translations_hand.grad), None, sb), "rigid_bwd(hand)")
+            self.ev_pair.record(side)        # object-side terms of the pair-wise losses are ready
+            # hand (full path: MANO + rigid): smooth + v2d + collision + contact, summed with their weights inside the rigid
+            # backward; the interaction term reaches the rigid pose only, as one vector per frame (rec[:, 2:5] / Vh)
+            tp, tw, tn = _lib.terms([(self.U_smh if on["smooth"] else None, w["loss_smooth_hand"]),
+                                     (self.U_v2d if on["v2d"] else None, w["loss_v2d_hand"]),
+                                     (self.U_colh if on["col"] else None, w["loss_collision"]),
+                                     (self.U_conh if on["con"] else None, w["loss_contact"])])
+            ck(L.hm_rigid_bwd(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, tp, tw, tn, None,
+                              (self.rec.data_ptr() + 8) if on["inter"] else None, 8, w["loss_inter"] / Vh, B, Vh,
+                              P(self.G_mesh), P(m.rotations_hand.grad), P(m.translations_hand.grad), None, sb),
+               "rigid_bwd(hand)")
             ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
-                             P(self.g_pca_mano) if on["pca"] else P(pca.grad), P(rot.grad), P(betas.grad), P(mtr.grad),
-                             P(self.mctx.workspace(B)), sb), "mano_bwd")
-            if on["pca"]:
-                ck(L.hm_lincomb4(P(self.g_pca_mano), 1.0, P(self.U_pca), w["loss_pca"], None, 0.0, None, 0.0,
-                                 pca.numel(), P(pca.grad), sb), "lincomb(pca)")
-        # ---------------- A: object backward (silhouette gradient + the side stream's object-side terms)
+                             P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad), P(betas.grad),
+                             P(mtr.grad), P(self.mctx.workspace(B)), sb), "mano_bwd")
+        # ---------------- A: object backward: silhouette gradient + smooth + contact [+ interaction with a free scale],
+        # summed with their weights inside the rigid backward
         main.wait_event(self.ev_pair)
         sc_obj = m.optimize_object_scale
-        ck(L.hm_rigid_bwd(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1,
-                          P(self.G_sil) if on["sil"] else None, P(self.G_o) if self.obj_part else None, None, B,
-                          Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
+        tp, tw, tn = _lib.terms([(self.G_sil if on["sil"] else None, 1.0),
+                                 (self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),
+                                 (self.U_cono if on["con"] else None, w["loss_contact"]),
+                                 (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0)])
+        ck(L.hm_rigid_bwd(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None, None,
+                          0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
                           P(self.g_so_part) if sc_obj else None, sa), "rigid_bwd(obj)")
         main.wait_stream(side)               # join
         main.wait_stream(self.aux)

@@ -30,7 +30,7 @@ _SIGNATURES = {
     "hm_sil_read_idx_map": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_faces9": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_rigid_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
-    "hm_rigid_bwd": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "hm_rigid_bwd": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_scale_by": (_I, [_VP, _VP, _L, _VP, _VP]),
     "hm_scale2_by": (_I, [_VP, _VP, _VP, _VP, _L, _VP, _VP]),
     "hm_lincomb4": (_I, [_VP, _F, _VP, _F, _VP, _F, _VP, _F, _L, _VP, _VP]),
@@ -38,7 +38,7 @@ _SIGNATURES = {
     "hm_log_total": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP]),
     "hm_mano_fwd": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "hm_mano_workspace_bytes": (_SZ, [_I]),
-    "hm_mano_bwd": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_mano_bwd": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_reduce_workspace_bytes": (_SZ, []),
     "hm_v2d_fwd": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _VP]),
     "hm_smooth_fwd": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
@@ -92,6 +92,16 @@ def ptr(t):
 
 def stream():
     return torch.cuda.current_stream().cuda_stream
+
+
+def terms(pairs):
+    """[(tensor or None, weight), ...] -> (host array of device pointers, host array of floats, n) for the entry points
+    that take a weighted list of per-vertex gradients (read by the library at launch time)."""
+    live = [(t, w) for t, w in pairs if t is not None]
+    n = len(live)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[ptr(t) for t, _ in live])
+    ws = (ctypes.c_float * max(n, 1))(*[float(w) for _, w in live])
+    return ptrs, ws, n
 
 
 def check(rc, what):

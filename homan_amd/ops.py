@@ -280,8 +280,9 @@ class _RigidTransform(torch.autograd.Function):
         g_rot = torch.empty_like(rot6d)
         g_trans = torch.empty(N, 3, device=mesh.device)
         g_sp = torch.empty(N, device=mesh.device) if need_scale else None
-        _lib.check(_lib.lib().hm_rigid_bwd(_lib.ptr(mesh), _lib.ptr(rot6d), _lib.ptr(scale), ctx.abs_scale,
-                                           _lib.ptr(g_full), None, _lib.ptr(g_det), N, V, _lib.ptr(g_mesh), _lib.ptr(g_rot),
+        tp, tw, tn = _lib.terms([(g_full, 1.0)])
+        _lib.check(_lib.lib().hm_rigid_bwd(_lib.ptr(mesh), _lib.ptr(rot6d), _lib.ptr(scale), ctx.abs_scale, tp, tw, tn,
+                                           _lib.ptr(g_det), None, 0, 0.0, N, V, _lib.ptr(g_mesh), _lib.ptr(g_rot),
                                            _lib.ptr(g_trans), _lib.ptr(g_sp), _lib.stream()), "hm_rigid_bwd")
         g_scale = g_sp.sum().reshape(scale.shape) if need_scale else None
         return g_mesh, g_rot, g_trans.view(ctx.trans_shape), g_scale, None
@@ -346,7 +347,7 @@ class _ManoLBS(torch.autograd.Function):
         g_pca, g_rot, g_betas = torch.empty_like(pca), torch.empty_like(rot), torch.empty_like(betas)
         g_trans = torch.empty(B, 3, device=pca.device)
         _lib.check(_lib.lib().hm_mano_bwd(ctx.mctx.ptrs, _lib.ptr(pca), P, _lib.ptr(rot), _lib.ptr(betas), B,
-                                          _lib.ptr(g_verts), _lib.ptr(g_pca), _lib.ptr(g_rot), _lib.ptr(g_betas),
+                                          _lib.ptr(g_verts), None, 0.0, _lib.ptr(g_pca), _lib.ptr(g_rot), _lib.ptr(g_betas),
                                           _lib.ptr(g_trans), _lib.ptr(ctx.mctx.workspace(B)), _lib.stream()),
                    "hm_mano_bwd")
         return g_pca, g_rot, g_betas, (g_trans if ctx.has_trans else None), None

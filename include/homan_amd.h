@@ -43,12 +43,15 @@ typedef struct ihipStream_t* hipStream_t;
  * mesh (N,V,3), rot6d (N,3,2), trans (N,3), scale (1), rotmat (N,3,3) optional output, verts (N,V,3). */
 int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, const float* scale, int abs_scale, int N,
                  int V, float* rotmat, float* verts, hipStream_t stream);
-/* g_full (+ g_full_b, summed): d/dverts reaching mesh, scale, R, t; g_rigid: d/d(mesh-detached twin) reaching R, t only
- * (each may be NULL).  Outputs: g_mesh (N,V,3) optional, g_rot6d (N,3,2), g_trans (N,3), g_scale_part (N) optional
- * (sum = d/dscale). */
-int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* g_full,
-                 const float* g_full_b, const float* g_rigid, int N, int V, float* g_mesh, float* g_rot6d,
-                 float* g_trans, float* g_scale_part, hipStream_t stream);
+/* g_terms / weights: HOST arrays of n_terms (<= 4) device pointers (N,V,3) and factors, read at launch; their weighted sum
+ * is d/dverts reaching mesh, scale, R, t (NULL entries are skipped).  g_rigid (N,V,3) and g_frame (one 3-vector per
+ * frame at g_frame + n*frame_stride, times frame_scale, applied to every vertex) reach R, t only: gradients w.r.t. the
+ * mesh-detached twin of the vertices.  Outputs: g_mesh (N,V,3) optional, g_rot6d (N,3,2), g_trans (N,3), g_scale_part (N)
+ * optional (sum = d/dscale). */
+int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
+                 const float* weights, int n_terms, const float* g_rigid, const float* g_frame, int frame_stride,
+                 float frame_scale, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part,
+                 hipStream_t stream);
 /* out = s[0] * in ;  out = s0[0]*a + s1[0]*b   (backward of the losses whose unit gradient is produced forward) */
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream);
 int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s1, long n, float* out,
@@ -70,9 +73,10 @@ int hm_sum_small(const float* parts, int n, float w0, const float* extra, float 
 int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
                 const float* trans, int B, float* verts, float* joints, hipStream_t stream);
 size_t hm_mano_workspace_bytes(int B);
+/* g_pca_extra (B,pca_dim) optional: g_pca = d/d pca through the mesh + w_extra * g_pca_extra (e.g. the PCA prior) */
 int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
-                const float* g_verts, float* g_pca, float* g_rot, float* g_betas, float* g_trans, void* workspace,
-                hipStream_t stream);
+                const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
+                float* g_trans, void* workspace, hipStream_t stream);
 
 /* ------------------------------------------------------------------ silhouette rasteriser + fused masked-MSE / IoU
  * reference homan/losses.py:183-197 (compute_sil_loss_object) and the `neural_renderer` call inside it
