@@ -142,3 +142,20 @@ __device__ __forceinline__ float hm_last_block_sum(const float* partials, int n,
     for (int i = threadIdx.x; i < n; i += blockDim.x) a += hm_partial_load(partials + (long)i * stride);
     return hm_block_sum(a, red);
 }
+
+// ---- rot6d (3x2 row-major, reference homan/utils/geometry.py:9-27) -> rotation matrix (3x3 row-major)
+__device__ __forceinline__ void rot6d_to_mat(const float* r6 /*3x2 row-major*/, float* R /*3x3 row-major*/)
+{
+    const float a1[3] = {r6[0], r6[2], r6[4]}, a2[3] = {r6[1], r6[3], r6[5]};
+    const float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
+    const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
+    const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
+    const float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
+    const float nu = fmaxf(sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]), 1e-12f);
+    const float b2[3] = {u[0] / nu, u[1] / nu, u[2] / nu};
+    const float b3[3] = {b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { R[3 * i] = b1[i]; R[3 * i + 1] = b2[i]; R[3 * i + 2] = b3[i]; }
+}
+
+

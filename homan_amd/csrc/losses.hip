@@ -113,6 +113,97 @@ __global__ __launch_bounds__(RED_THREADS) void k_priors(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------ hand terms in one launch
+// The 2-D reprojection term, the temporal smoothness term (both over the same hand vertices) and the priors are three
+// small reductions that used to be three launches on the hand-side critical chain; here they share one grid and one
+// "last block finishes" ticket.  Same per-element arithmetic as k_v2d / k_smooth / k_priors; partial records: 3 floats
+// per block (v2d loss, px metric, smoothness).  pca == NULL skips the priors.
+__global__ __launch_bounds__(RED_THREADS) void k_hand_terms(
+    const float* __restrict__ verts, const float* __restrict__ camintr, int hand_nb, const float* __restrict__ ref2d,
+    float image_size, int N, int V, float* __restrict__ unit_v2d, float* __restrict__ out_v2d,
+    float* __restrict__ unit_smooth, float* __restrict__ out_smooth, const float* __restrict__ pca, long npca,
+    const float* __restrict__ s_obj, const float* __restrict__ m_obj, const float* __restrict__ s_hand,
+    const float* __restrict__ m_hand, float* __restrict__ g_pca, float* __restrict__ g_sobj,
+    float* __restrict__ g_shand, float* __restrict__ out_priors, float* __restrict__ partials, unsigned int* counter)
+{
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    // ---- v2d
+    const long total = (long)N * V;
+    const float inv_cnt = 1.0f / (float)total;
+    float lsum = 0.f, msum = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / V);
+        const float* k = camintr + (n / hand_nb) * 9;
+        const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+        const float hx = k[0] * x + k[1] * y + k[2] * z;
+        const float hy = k[3] * x + k[4] * y + k[5] * z;
+        const float hz = k[6] * x + k[7] * y + k[8] * z;
+        const float px = hx / hz, py = hy / hz;
+        const float rx = ref2d[2 * i], ry = ref2d[2 * i + 1];
+        const float dx = px - rx / image_size, dy = py - ry / image_size;
+        lsum += dx * dx + dy * dy;
+        const float mx = px * image_size - rx, my = py * image_size - ry;
+        msum += sqrtf(mx * mx + my * my);
+        const float gpx = 2.0f * dx * inv_cnt, gpy = 2.0f * dy * inv_cnt;
+        const float ghx = gpx / hz, ghy = gpy / hz, ghz = -(gpx * hx + gpy * hy) / (hz * hz);
+        unit_v2d[3 * i] = k[0] * ghx + k[3] * ghy + k[6] * ghz;
+        unit_v2d[3 * i + 1] = k[1] * ghx + k[4] * ghy + k[7] * ghz;
+        unit_v2d[3 * i + 2] = k[2] * ghx + k[5] * ghy + k[8] * ghz;
+    }
+    // ---- temporal smoothness
+    const long row = (long)V * 3, etotal = (long)N * row;
+    const long cnt = (long)(N - hand_nb) * row;
+    const float sinv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    const long step = (long)hand_nb * row;
+    float ssum = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < etotal; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / row);
+        const float v = verts[i];
+        float g = 0.f;
+        if (n + hand_nb < N) {
+            const float d = verts[i + step] - v;
+            ssum += d * d;
+            g -= d;
+        }
+        if (n - hand_nb >= 0) g += v - verts[i - step];
+        unit_smooth[i] = 2.0f * g * sinv;
+    }
+    lsum = hm_block_sum(lsum, red);
+    msum = hm_block_sum(msum, red);
+    ssum = hm_block_sum(ssum, red);
+    // ---- priors (block 0)
+    if (pca && blockIdx.x == 0) {
+        float a = 0.f;
+        const float inv = 1.0f / (float)npca;
+        for (long i = threadIdx.x; i < npca; i += blockDim.x) {
+            const float p = pca[i];
+            a += p * p;
+            g_pca[i] = 2.0f * p * inv;
+        }
+        a = hm_block_sum(a, red);
+        if (threadIdx.x == 0) {
+            out_priors[0] = a * inv;
+            const float d0 = s_obj[0] - m_obj[0], d1 = s_hand[0] - m_hand[0];
+            out_priors[1] = d0 * d0;
+            out_priors[2] = d1 * d1;
+            g_sobj[0] = 2.0f * d0;
+            g_shand[0] = 2.0f * d1;
+        }
+    }
+    if (threadIdx.x == 0) {
+        hm_partial_store(partials + 3 * blockIdx.x, lsum);
+        hm_partial_store(partials + 3 * blockIdx.x + 1, msum);
+        hm_partial_store(partials + 3 * blockIdx.x + 2, ssum);
+    }
+    if (hm_last_block(counter, gridDim.x, &s_flag)) {
+        const float a = hm_last_block_sum(partials, gridDim.x, 3, red);
+        const float b = hm_last_block_sum(partials + 1, gridDim.x, 3, red);
+        const float c = hm_last_block_sum(partials + 2, gridDim.x, 3, red);
+        if (threadIdx.x == 0) { out_v2d[0] = a * inv_cnt; out_v2d[1] = b * inv_cnt; out_smooth[0] = c * sinv; }
+    }
+}
+
 // ------------------------------------------------------------------ coarse interaction loss
 // grid (B).  Per frame: expanded 2-D boxes of the projected meshes (y negated, nr.projection with the
 // normalised camera, orig_size 1), IoU>0 and z-gap<thresh gate, MSE of the two centroids.
@@ -234,6 +325,22 @@ int hm_priors_fwd(const float* pca, long npca, const float* s_obj, const float* 
     HM_CHECK_ARG(pca && s_obj && m_obj && s_hand && m_hand && g_pca && g_sobj && g_shand && out3 && npca > 0);
     hipLaunchKernelGGL(k_priors, dim3(1), dim3(RED_THREADS), 0, stream, pca, npca, s_obj, m_obj, s_hand, m_hand, g_pca,
                        g_sobj, g_shand, out3);
+    return hm_launch_status();
+}
+// v2d + smoothness (+ priors when pca != NULL) of the hand vertices in one launch: same outputs as hm_v2d_fwd,
+// hm_smooth_fwd and hm_priors_fwd called one after the other.
+int hm_hand_terms_fwd(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size, int N,
+                      int V, float* unit_v2d, float* out_v2d2, float* unit_smooth, float* out_smooth1, const float* pca,
+                      long npca, const float* s_obj, const float* m_obj, const float* s_hand, const float* m_hand,
+                      float* g_pca, float* g_sobj, float* g_shand, float* out_priors3, void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && camintr && ref2d && unit_v2d && out_v2d2 && unit_smooth && out_smooth1 && workspace);
+    HM_CHECK_ARG(N > 0 && V > 0 && hand_nb > 0);
+    HM_CHECK_ARG(!pca || (npca > 0 && s_obj && m_obj && s_hand && m_hand && g_pca && g_sobj && g_shand && out_priors3));
+    const int nblk = min(170, hm_cdiv((long)N * V * 3, RED_THREADS * 2));     // 3 partial floats per block, 512 in all
+    hipLaunchKernelGGL(k_hand_terms, dim3(nblk), dim3(RED_THREADS), 0, stream, verts, camintr, hand_nb, ref2d, image_size,
+                       N, V, unit_v2d, out_v2d2, unit_smooth, out_smooth1, pca, npca, s_obj, m_obj, s_hand, m_hand, g_pca,
+                       g_sobj, g_shand, out_priors3, (float*)workspace, ws_counter(workspace));
     return hm_launch_status();
 }
 // frame_rec: (B,8) floats kept for the backward.

@@ -228,12 +228,16 @@ __device__ __forceinline__ void mano_skin_transform(const ManoModelDev& m, const
 __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
                                                    const float* __restrict__ rot, const float* __restrict__ betas,
                                                    const float* __restrict__ trans, int B, float* __restrict__ verts,
-                                                   float* __restrict__ joints)
+                                                   float* __restrict__ joints, const float* __restrict__ rigid_rot6d,
+                                                   const float* __restrict__ rigid_trans,
+                                                   const float* __restrict__ rigid_scale, float* __restrict__ verts_world)
 {
     __shared__ ManoShared sh;
     __shared__ float s_part[4][MANO_VCH][3];
     __shared__ float s_vp[MANO_VCH][3];
+    __shared__ float s_R[9];
     const int b = blockIdx.y;
+    if (verts_world && threadIdx.x == 64) rot6d_to_mat(rigid_rot6d + b * 6, s_R);      // published by mano_prepare's barriers
     mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
     const float tr[3] = {trans ? trans[b * 3] : 0.f, trans ? trans[b * 3 + 1] : 0.f, trans ? trans[b * 3 + 2] : 0.f};
     if (joints && blockIdx.x == 0 && threadIdx.x < MANO_J * 3)
@@ -246,8 +250,18 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
     mano_skin_transform(m, sh, v, T);
     const float* vp = s_vp[threadIdx.x];
     float* o = verts + ((long)b * MANO_V + v) * 3;
+    float p[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) o[i] = T[4 * i] * vp[0] + T[4 * i + 1] * vp[1] + T[4 * i + 2] * vp[2] + T[4 * i + 3] + tr[i];
+    for (int i = 0; i < 3; ++i) { p[i] = T[4 * i] * vp[0] + T[4 * i + 1] * vp[1] + T[4 * i + 2] * vp[2] + T[4 * i + 3] + tr[i]; o[i] = p[i]; }
+    if (verts_world) {       // the rigid hand transform of homan.py:341-382, same arithmetic as k_rigid_fwd (no abs on the scale)
+        const float s = rigid_scale[0];
+        const float x = s * p[0], y = s * p[1], z = s * p[2];
+        const float* t = rigid_trans + b * 3;
+        float* ow = verts_world + ((long)b * MANO_V + v) * 3;
+        ow[0] = x * s_R[0] + y * s_R[3] + z * s_R[6] + t[0];
+        ow[1] = x * s_R[1] + y * s_R[4] + z * s_R[7] + t[1];
+        ow[2] = x * s_R[2] + y * s_R[5] + z * s_R[8] + t[2];
+    }
 }
 
 // backward pass 1: grid (13, B) -> partials (B, 13, 340)
@@ -427,13 +441,15 @@ __global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* _
 extern "C" {
 // model: 8 device pointers in the order of ManoModelDev.
 int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
-                const float* trans, int B, float* verts, float* joints, hipStream_t stream)
+                const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d, const float* rigid_trans,
+                const float* rigid_scale, float* verts_world, hipStream_t stream)
 {
     HM_CHECK_ARG(model && pca && rot && betas && verts && B > 0 && pca_dim >= 16);
+    HM_CHECK_ARG(!verts_world || (rigid_rot6d && rigid_trans && rigid_scale));
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
     hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, trans, B, verts,
-                       joints);
+                       joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world);
     return hm_launch_status();
 }
 size_t hm_mano_workspace_bytes(int B) { return (size_t)B * MANO_NCH64 * MANO_PART * sizeof(float); }

@@ -324,19 +324,28 @@ class FusedStepper:
                             P(sctx.face_order), P(self.G_sil), None, P(sctx.workspace), sa), "sil_bwd")
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
-            ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None, sb), "mano_fwd")
-            ck(L.hm_rigid_fwd(P(self.vm), P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), 0, B, Vh,
-                              None, P(self.vh), sb), "rigid_fwd(hand)")
-            if on["pca"] or on["so"] or on["sh"]:
-                ck(L.hm_priors_fwd(P(pca), pca.numel(), P(m.int_scales_object), P(m.int_scale_object_mean),
-                                   P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
-                                   P(self.U_sh), self._slot("loss_pca"), sb), "priors")
-            if on["smooth"]:
-                ck(L.hm_smooth_fwd(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws_b, sb),
-                   "smooth(hand)")
-            if on["v2d"]:
-                ck(L.hm_v2d_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
-                                P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, sb), "v2d")
+            ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
+                             P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh), sb),
+               "mano_fwd + rigid(hand)")
+            pri = on["pca"] or on["so"] or on["sh"]
+            if on["smooth"] and on["v2d"]:       # the three hand-only reductions in one launch
+                ck(L.hm_hand_terms_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
+                                       P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
+                                       self._slot("loss_smooth_hand"), P(pca) if pri else None, pca.numel(),
+                                       P(m.int_scales_object), P(m.int_scale_object_mean), P(m.int_scales_hand),
+                                       P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh),
+                                       self._slot("loss_pca"), rws_b, sb), "hand terms")
+            else:
+                if pri:
+                    ck(L.hm_priors_fwd(P(pca), pca.numel(), P(m.int_scales_object), P(m.int_scale_object_mean),
+                                       P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
+                                       P(self.U_sh), self._slot("loss_pca"), sb), "priors")
+                if on["smooth"]:
+                    ck(L.hm_smooth_fwd(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws_b, sb),
+                       "smooth(hand)")
+                if on["v2d"]:
+                    ck(L.hm_v2d_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
+                                    P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, sb), "v2d")
             side.wait_event(self.ev_vo)
             if on["smooth"]:
                 ck(L.hm_smooth_fwd(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, sb),

@@ -36,13 +36,14 @@ _SIGNATURES = {
     "hm_lincomb4": (_I, [_VP, _F, _VP, _F, _VP, _F, _VP, _F, _L, _VP, _VP]),
     "hm_sum_small": (_I, [_VP, _I, _F, _VP, _F, _VP, _VP]),
     "hm_log_total": (_I, [_VP, _VP, _I, _VP, _I, _VP, _VP]),
-    "hm_mano_fwd": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
+    "hm_mano_fwd": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_mano_workspace_bytes": (_SZ, [_I]),
     "hm_mano_bwd": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_reduce_workspace_bytes": (_SZ, []),
     "hm_v2d_fwd": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _VP]),
     "hm_smooth_fwd": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "hm_priors_fwd": (_I, [_VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_hand_terms_fwd": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _VP, _VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_inter_fwd": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _VP]),
     "hm_inter_bwd": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "hm_nn_fwd": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),

@@ -334,7 +334,7 @@ class _ManoLBS(torch.autograd.Function):
         B, P = pca.shape
         verts = torch.empty(B, 778, 3, device=pca.device)
         _lib.check(_lib.lib().hm_mano_fwd(mctx.ptrs, _lib.ptr(pca), P, _lib.ptr(rot), _lib.ptr(betas), _lib.ptr(trans), B,
-                                          _lib.ptr(verts), None, _lib.stream()), "hm_mano_fwd")
+                                          _lib.ptr(verts), None, None, None, None, None, _lib.stream()), "hm_mano_fwd")
         ctx.save_for_backward(pca, rot, betas)
         ctx.mctx, ctx.has_trans = mctx, trans is not None
         return verts
@@ -365,7 +365,7 @@ def mano_joints(pca, rot, betas, trans, mctx):
     joints = torch.empty(B, 16, 3, device=pca.device)
     tr = None if trans is None else _f32(trans.detach())
     _lib.check(_lib.lib().hm_mano_fwd(mctx.ptrs, _lib.ptr(pca), P, _lib.ptr(rot), _lib.ptr(betas), _lib.ptr(tr), B,
-                                      _lib.ptr(verts), _lib.ptr(joints), _lib.stream()), "hm_mano_fwd")
+                                      _lib.ptr(verts), _lib.ptr(joints), None, None, None, None, _lib.stream()), "hm_mano_fwd")
     return verts, joints
 
 

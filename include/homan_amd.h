@@ -69,9 +69,12 @@ int hm_sum_small(const float* parts, int n, float w0, const float* extra, float 
  * model: host array of 8 device pointers {v_template (778,3), M (145,2334) = [posedirs ; shapedirs^T],
  *   J_template (16,3), J_shapedirs (16,3,10), lbs_weights (778,16), pca components (16,45), hand_mean (45),
  *   parents (16) int32}.   pca (B,pca_dim>=16; the first 16 columns drive the mesh), rot (B,3), betas (B,10),
- *   trans (B,3) or NULL.  verts (B,778,3); joints (B,16,3) optional. */
+ *   trans (B,3) or NULL.  verts (B,778,3); joints (B,16,3) optional.
+ *   verts_world (B,778,3) optional: the rigid hand transform of hm_rigid_fwd (rigid_rot6d (B,3,2), rigid_trans (B,3),
+ *   rigid_scale (1), no abs) applied in the same launch. */
 int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
-                const float* trans, int B, float* verts, float* joints, hipStream_t stream);
+                const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d, const float* rigid_trans,
+                const float* rigid_scale, float* verts_world, hipStream_t stream);
 size_t hm_mano_workspace_bytes(int B);
 /* g_pca_extra (B,pca_dim) optional: g_pca = d/d pca through the mesh + w_extra * g_pca_extra (e.g. the PCA prior) */
 int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
@@ -140,6 +143,11 @@ int hm_smooth_fwd(const float* verts, int N, int V, int hand_nb, float* unit_gra
 /* reference homan/lossutils.py:39-40 and :107-109: out3 = {mean(pca^2), (s_obj-m_obj)^2, (s_hand-m_hand)^2} */
 int hm_priors_fwd(const float* pca, long npca, const float* s_obj, const float* m_obj, const float* s_hand,
                   const float* m_hand, float* g_pca, float* g_sobj, float* g_shand, float* out3, hipStream_t stream);
+/* hm_v2d_fwd + hm_smooth_fwd (+ hm_priors_fwd when pca != NULL) of the hand vertices in ONE launch (same outputs) */
+int hm_hand_terms_fwd(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size, int N,
+                      int V, float* unit_v2d, float* out_v2d2, float* unit_smooth, float* out_smooth1, const float* pca,
+                      long npca, const float* s_obj, const float* m_obj, const float* s_hand, const float* m_hand,
+                      float* g_pca, float* g_sobj, float* g_shand, float* out_priors3, void* workspace, hipStream_t stream);
 /* reference homan/losses.py:199-242 ('centroid') with the gating of :98-139 (project_bbox :20-49, compute_iou
  * utils/bbox.py:111-135, compute_dist_z utils/geometry.py:69-86).  out1 = un-normalised sum; frame_rec (B,8). */
 int hm_inter_fwd(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
