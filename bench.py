@@ -35,15 +35,19 @@ def algorithmic_bytes(B, S, F, V, step2=False):
 
 
 def kernel_bytes(B, S, F):
-    """Algorithmic HBM traffic of ONE launch of the two heavy kernels (every input read once, every output written
-    once).
-      k_raster_fwd: packed (B,F,3,3) faces + 8-byte boxes read; (2S)^2 int32 index map, pooled silhouettes, dimg,
-                    alpha bit-plane written; keep/ref read.
-      k_bwd_sweep : faces + boxes + owned flags + index map + four 1-bit planes + gradient image read; per-face
-                    partial gradients (24 floats) written."""
-    is2 = (2 * S) ** 2
-    return {"k_raster_fwd": B * (F * 36 + F * 8 + is2 * 4 + 4 * S * S * 4 + is2 // 8),
-            "k_bwd_sweep": B * (F * 36 + F * 8 + 2 * F + is2 * 4 + 4 * is2 // 8 + S * S * 4 + F * 96)}
+    """Algorithmic HBM traffic of ONE launch of the heavy silhouette kernels (every input read once, every output
+    written once).
+      k_raster_fwd: packed (B,F,3,3) faces + 8-byte boxes + super-region bin lists read; (2S)^2 int32 index map, pooled
+                    silhouettes, dimg, alpha bit-plane and the four sweep bit-planes written; keep/ref read.
+      k_bwd_sweep : faces + boxes + owned flags + index map + four 1-bit planes + per-line cumulative counts read;
+                    per-face corner gradients (6 floats) written.  (The per-line source arrays are data dependent,
+                    ~0.3 MB per launch here, and not counted.)
+      k_bwd_lines : four 1-bit planes + dimg read, per-line cumulative counts written (+ the source arrays, as above)."""
+    is_ = 2 * S
+    is2 = is_ ** 2
+    return {"k_raster_fwd": B * (F * (36 + 8 + 5) + is2 * 4 + 4 * S * S * 4 + 5 * is2 // 8),
+            "k_bwd_sweep": B * (F * (36 + 8 + 2) + is2 * 4 + 4 * is2 // 8 + 4 * is_ * 32 + F * 24),
+            "k_bwd_lines": B * (4 * is2 // 8 + S * S * 4 + 4 * is_ * 32)}
 
 
 def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256):
@@ -230,7 +234,7 @@ def main():
         if os.path.exists(tpath):
             traffic = json.load(open(tpath)).get("per_launch_bytes", {})
         per = {}
-        for i, name in enumerate(("k_raster_fwd", "k_bwd_sweep")):
+        for i, name in enumerate(("k_raster_fwd", "k_bwd_sweep", "k_bwd_lines")):
             sec = ms[i].item() * 1e-3
             per[name] = dict(avg_launch_us=sec * 1e6, algorithmic_bytes=kb[name], achieved_GBps=kb[name] / sec / 1e9,
                              traffic_bytes=traffic.get(name))
