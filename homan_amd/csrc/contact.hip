@@ -127,41 +127,31 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_hand(const float* __rest
     }
 }
 
-// Contact loss, object side.  grid (ceil(Vo/256), B): the gradient of an object vertex is minus the sum of the
-// gradients of the hand vertices that picked it.  The workgroup stages the frame's nearest-neighbour list and hand
-// gradients in LDS; every wave then walks the list 64 entries at a time, ballots the entries that point into its own 64
-// object vertices (a handful per wave) and lets the owning lane accumulate them in hand-vertex order: a deterministic
-// scatter without atomics, and without a dependent global load per match.
-#define CONTACT_MAX_VH 1024
+// Contact loss, object side.  grid (B): the gradient of an object vertex is minus the sum of the gradients of the hand
+// vertices that picked it.  The picks are heavily skewed (the whole hand usually lands on a few dozen object vertices),
+// so a gather per object vertex serialises on the popular ones; instead every hand vertex adds into a per-frame LDS
+// accumulator with 64-bit FIXED-POINT atomics (2^-44 units): integer addition is associative, so the result does not
+// depend on the order the atomics land in -- deterministic without a sort.  |g| <= 1/(B*Vh) here, far inside the range.
+#define CONTACT_MAX_VO 4096
+#define CONTACT_FIX 17592186044416.0f          // 2^44
 __global__ __launch_bounds__(NN_THREADS) void k_contact_obj(const int* __restrict__ nn_idx, const float* __restrict__ g_hand,
                                                              int B, int Vh, int Vo, float* __restrict__ g_obj)
 {
-    __shared__ int s_id[CONTACT_MAX_VH];
-    __shared__ float s_g[CONTACT_MAX_VH * 3];
-    const int b = blockIdx.y, lane = threadIdx.x & 63;
-    const int j = blockIdx.x * NN_THREADS + threadIdx.x;
-    const int jbase = j - lane;                       // first object vertex of this wave
-    for (int i = threadIdx.x; i < Vh; i += NN_THREADS) s_id[i] = nn_idx[(long)b * Vh + i];
-    for (int i = threadIdx.x; i < 3 * Vh; i += NN_THREADS) s_g[i] = g_hand[(long)b * Vh * 3 + i];
+    __shared__ unsigned long long acc[CONTACT_MAX_VO * 3];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 3 * Vo; i += NN_THREADS) acc[i] = 0ull;
     __syncthreads();
-    float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int c0 = 0; c0 < Vh; c0 += 64) {
-        const int mine = (c0 + lane < Vh) ? s_id[c0 + lane] : -1;
-        unsigned long long hit = __ballot(mine >= jbase && mine < jbase + 64);
-        while (hit) {
-            const int k = __ffsll((long long)hit) - 1;
-            hit &= hit - 1;
-            const int id = __builtin_amdgcn_readlane(mine, k);
-            if (id == j) {
-                const float* gh = s_g + (c0 + k) * 3;
-                gx -= gh[0]; gy -= gh[1]; gz -= gh[2];
-            }
-        }
+    for (int i = threadIdx.x; i < Vh; i += NN_THREADS) {
+        const int j = nn_idx[(long)b * Vh + i];
+        const float* gh = g_hand + ((long)b * Vh + i) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            atomicAdd(&acc[3 * j + c], (unsigned long long)(long long)__float2ll_rn(gh[c] * CONTACT_FIX));
     }
-    if (j < Vo) {
-        float* go = g_obj + ((long)b * Vo + j) * 3;
-        go[0] = gx; go[1] = gy; go[2] = gz;
-    }
+    __syncthreads();
+    float* go = g_obj + (long)b * Vo * 3;
+    for (int i = threadIdx.x; i < 3 * Vo; i += NN_THREADS)
+        go[i] = -(float)(long long)acc[i] * (1.0f / CONTACT_FIX);
 }
 
 extern "C" {
@@ -182,10 +172,10 @@ int hm_contact_fwd(const float* verts_hand, const float* verts_obj, const int* n
 {
     HM_CHECK_ARG(verts_hand && verts_obj && nn_idx && g_hand && g_obj && out1 && workspace);
     HM_CHECK_ARG(B > 0 && B <= 512 && Vh > 0 && Vo > 0);
-    if (Vh > CONTACT_MAX_VH) return HM_ERR_UNSUPPORTED;     // the hand side is staged in LDS (MANO: 778)
+    if (Vo > CONTACT_MAX_VO) return HM_ERR_UNSUPPORTED;     // per-frame object accumulator in LDS (96 KB at 4096 vertices)
     hipLaunchKernelGGL(k_contact_hand, dim3(B), dim3(NN_THREADS), 0, stream, verts_hand, verts_obj, nn_idx, B, Vh, Vo,
                        thresh, g_hand, (float*)workspace, (unsigned int*)((float*)workspace + 512), out1);
-    hipLaunchKernelGGL(k_contact_obj, dim3(hm_cdiv(Vo, NN_THREADS), B), dim3(NN_THREADS), 0, stream, nn_idx, g_hand, B, Vh,
+    hipLaunchKernelGGL(k_contact_obj, dim3(B), dim3(NN_THREADS), 0, stream, nn_idx, g_hand, B, Vh,
                        Vo, g_obj);
     return hm_launch_status();
 }
