@@ -10,9 +10,11 @@
 // Exact restructuring (same numbers, far less work than the reference's 4.5e9 voxel-triangle tests / iteration):
 //   * phi is clamped at 0, so only INSIDE voxels carry a value: the sign pass (ray-crossing parity along +x, one
 //     thread per (y,z) row, triangles staged through LDS) produces a 32-bit inside mask per row;
-//   * distances are evaluated lazily, only for inside voxels that a sample point actually touches: the 8 trilinear
-//     corners of each sample are checked against the mask and each needed voxel is evaluated by a full wavefront
-//     (64 lanes stride the triangle list, shuffle-min).
+//   * distances are evaluated lazily, only for inside voxels that a sample point actually touches: a first pass marks
+//     the 8 trilinear corners of every sample against the mask and appends each newly needed voxel to a per-grid list,
+//     a second pass gives every listed voxel to a wavefront (64 lanes stride packed triangle records, DPP min), a third
+//     pass samples.  (One fused kernel doing all three per sample serialised hundreds of dependent cache probes per
+//     wave: 127 us; the three passes take ~40.)
 // Conventions identical to oracle/csrc/sdf.c (voxel centres -1+(i+0.5)*2/N, phi[z][y][x], half-open orientation rule).
 #include "hm_common.h"
 
@@ -90,10 +92,12 @@ __device__ __forceinline__ float voxel_centre(int i) { return -1.0f + ((float)i 
 
 // ------------------------------------------------------------------ boxes + normalised vertices.  grid (B, 2)
 // object 0 = hand, object 1 = rigid object.  boxes (2,B,4) = centre xyz, scale.  vnorm_k (B,V_k,3).
+// Also clears the per-grid state of the iteration: inside masks, needed-voxel masks, needed-voxel list length.
 __global__ __launch_bounds__(SDF_THREADS) void k_sdf_boxes(const float* __restrict__ v0, int V0, const float* __restrict__ v1,
                                                             int V1, int B, float scale_factor, float* __restrict__ boxes,
                                                             float* __restrict__ vn0, float* __restrict__ vn1,
-                                                            unsigned int* __restrict__ masks, float* __restrict__ phi_cache)
+                                                            unsigned int* __restrict__ masks, unsigned int* __restrict__ needm,
+                                                            int* __restrict__ need_cnt)
 {
     __shared__ float red[16];
     const int b = blockIdx.x, k = blockIdx.y;
@@ -114,184 +118,223 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_boxes(const float* __restri
     if (threadIdx.x == 0) {
         float* o = boxes + ((long)k * B + b) * 4;
         o[0] = ctr[0]; o[1] = ctr[1]; o[2] = ctr[2]; o[3] = sc;
+        need_cnt[k * B + b] = 0;
     }
     for (int i = threadIdx.x; i < V; i += blockDim.x)
 #pragma unroll
         for (int c = 0; c < 3; ++c) vn[3 * i + c] = (v[3 * i + c] - ctr[c]) / sc;
     unsigned int* mk = masks + ((long)k * B + b) * (SDF_N * SDF_N);      // XOR-accumulated by the sign pass
-    for (int i = threadIdx.x; i < SDF_N * SDF_N; i += blockDim.x) mk[i] = 0u;
-    float4* pc = reinterpret_cast<float4*>(phi_cache + ((long)k * B + b) * (SDF_N * SDF_N * SDF_N));
-    for (int i = threadIdx.x; i < SDF_N * SDF_N * SDF_N / 4; i += blockDim.x) pc[i] = make_float4(-1.f, -1.f, -1.f, -1.f);
+    unsigned int* nd = needm + ((long)k * B + b) * (SDF_N * SDF_N);      // OR-accumulated by the need pass
+    for (int i = threadIdx.x; i < SDF_N * SDF_N; i += blockDim.x) { mk[i] = 0u; nd[i] = 0u; }
 }
 
-// ------------------------------------------------------------------ sign pass.  grid (N*N/256, B, chunks0+chunks1)
-// one thread per (z,y) row, one workgroup per (row block, frame, chunk of 256 triangles of one mesh).  The chunk's
-// triangles that can cross the block's z-slab are compacted into LDS; every thread toggles, per crossing, the bits of
-// the voxels in front of the hit, and the chunks are combined with atomicXor (order-independent, hence deterministic).
-// masks must be zero on entry (cleared by k_sdf_boxes).  inside mask bit i <-> voxel x index i.
-__global__ __launch_bounds__(SDF_THREADS) void k_sdf_parity(const float* __restrict__ vn0, const int* __restrict__ f0, int V0,
-                                                             int F0, const float* __restrict__ vn1,
-                                                             const int* __restrict__ f1, int V1, int F1, int B,
-                                                             int chunks0, unsigned int* __restrict__ masks)
+// ------------------------------------------------------------------ triangle records + sign pass.  grid (ceil(Fmax/256), B, 2)
+// One thread per triangle: packs {v1, v2, v3, box lo, box hi} (16 floats, read back coalesced by the distance pass) and
+// casts the +x rays of the (y,z) voxel rows whose centre lies in the triangle's (y,z) box -- a handful per triangle,
+// where a row-centric pass tested every triangle against every row.  Per crossing the bits of the voxels in front of
+// the hit are toggled with atomicXor (order-independent, hence deterministic).  masks must be zero on entry.
+// inside mask bit i <-> voxel x index i.
+#define SDF_TRI_DW 16
+__global__ __launch_bounds__(SDF_THREADS) void k_sdf_tris(const float* __restrict__ vn0, const int* __restrict__ f0, int V0,
+                                                           int F0, const float* __restrict__ vn1,
+                                                           const int* __restrict__ f1, int V1, int F1, int B,
+                                                           float* __restrict__ tris0, float* __restrict__ tris1,
+                                                           unsigned int* __restrict__ masks)
 {
-    __shared__ float tri[SDF_THREADS * 9];
-    __shared__ int s_n;
-    const int b = blockIdx.y;
-    const int k = (int)blockIdx.z < chunks0 ? 0 : 1;
-    const int chunk = k == 0 ? blockIdx.z : blockIdx.z - chunks0;
+    const int b = blockIdx.y, k = blockIdx.z;
     const int V = k == 0 ? V0 : V1, F = k == 0 ? F0 : F1;
+    const int fi = blockIdx.x * SDF_THREADS + threadIdx.x;
+    if (fi >= F) return;
     const float* vn = (k == 0 ? vn0 : vn1) + (long)b * V * 3;
-    const int* fc = k == 0 ? f0 : f1;
-    const int row = blockIdx.x * SDF_THREADS + threadIdx.x;       // row = z * N + y
-    const int kz = row / SDF_N, jy = row % SDF_N;
-    const float cy = voxel_centre(jy), cz = voxel_centre(kz);
-    // z-slab of this row block (rows are z-major: 256 rows = 8 consecutive z)
-    const float zlo_blk = voxel_centre((blockIdx.x * SDF_THREADS) / SDF_N);
-    const float zhi_blk = voxel_centre((blockIdx.x * SDF_THREADS + SDF_THREADS - 1) / SDF_N);
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const int fi = chunk * SDF_THREADS + threadIdx.x;
-    if (fi < F) {
-        const int* t = fc + 3 * fi;
-        float p[9];
+    const int* t = (k == 0 ? f0 : f1) + 3 * fi;
+    float p[9];
 #pragma unroll
-        for (int q = 0; q < 3; ++q) {
-            const float* src = vn + 3 * t[q];
-            p[3 * q] = src[0]; p[3 * q + 1] = src[1]; p[3 * q + 2] = src[2];
-        }
-        const float zlo = fminf(p[2], fminf(p[5], p[8])), zhi = fmaxf(p[2], fmaxf(p[5], p[8]));
-        if (!(zhi < zlo_blk || zlo > zhi_blk)) {
-            const int pos = atomicAdd(&s_n, 1);           // LDS order is irrelevant: XOR is commutative
+    for (int q = 0; q < 3; ++q) {
+        const float* src = vn + 3 * t[q];
+        p[3 * q] = src[0]; p[3 * q + 1] = src[1]; p[3 * q + 2] = src[2];
+    }
+    float lo[3], hi[3];
 #pragma unroll
-            for (int q = 0; q < 9; ++q) tri[pos * 9 + q] = p[q];
+    for (int c = 0; c < 3; ++c) { lo[c] = fminf(p[c], fminf(p[3 + c], p[6 + c])); hi[c] = fmaxf(p[c], fmaxf(p[3 + c], p[6 + c])); }
+    float4* rec = reinterpret_cast<float4*>((k == 0 ? tris0 : tris1) + ((long)b * F + fi) * SDF_TRI_DW);
+    rec[0] = make_float4(p[0], p[1], p[2], p[3]);
+    rec[1] = make_float4(p[4], p[5], p[6], p[7]);
+    rec[2] = make_float4(p[8], lo[0], lo[1], lo[2]);
+    rec[3] = make_float4(hi[0], hi[1], hi[2], 0.f);
+    // voxel rows whose centre can lie inside the (y,z) box: one index of slack either way, the exact test is below
+    const float h = 0.5f * (float)SDF_N;
+    const int j0 = max(0, (int)floorf((lo[1] + 1.0f) * h - 0.5f) - 1), j1 = min(SDF_N - 1, (int)ceilf((hi[1] + 1.0f) * h - 0.5f) + 1);
+    const int k0 = max(0, (int)floorf((lo[2] + 1.0f) * h - 0.5f) - 1), k1 = min(SDF_N - 1, (int)ceilf((hi[2] + 1.0f) * h - 0.5f) + 1);
+    unsigned int* mk = masks + ((long)k * B + b) * (SDF_N * SDF_N);
+    for (int kz = k0; kz <= k1; ++kz) {
+        const float cz = voxel_centre(kz);
+        if (cz < lo[2] || cz > hi[2]) continue;
+        for (int jy = j0; jy <= j1; ++jy) {
+            const float cy = voxel_centre(jy);
+            // exact reject on the (y,z) box of the triangle (a crossing needs the point inside the projection)
+            if (cy < lo[1] || cy > hi[1]) continue;
+            float xh;
+            if (!ray_x_crosses(cy, cz, p, p + 3, p + 6, &xh)) continue;
+            // m = number of voxel centres with xh > centre (centres increase with i)
+            int m = (int)floorf((xh + 1.0f) * h + 0.5f);
+            m = max(0, min(SDF_N, m));
+            while (m > 0 && !(xh > voxel_centre(m - 1))) --m;
+            while (m < SDF_N && xh > voxel_centre(m)) ++m;
+            const unsigned int bits = (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
+            if (bits) atomicXor(&mk[kz * SDF_N + jy], bits);
         }
     }
-    __syncthreads();
-    const int n = s_n;
-    unsigned int mask = 0;
-    for (int e = 0; e < n; ++e) {
-        const float* t = tri + 9 * e;
-        // cheap reject on the (y,z) box of the triangle (exact: a crossing needs the point inside the projection)
-        const float ylo = fminf(t[1], fminf(t[4], t[7])), yhi = fmaxf(t[1], fmaxf(t[4], t[7]));
-        const float zlo = fminf(t[2], fminf(t[5], t[8])), zhi = fmaxf(t[2], fmaxf(t[5], t[8]));
-        if (cy < ylo || cy > yhi || cz < zlo || cz > zhi) continue;
-        float xh;
-        if (!ray_x_crosses(cy, cz, t, t + 3, t + 6, &xh)) continue;
-        // m = number of voxel centres with xh > centre (centres increase with i)
-        int m = (int)floorf((xh + 1.0f) * (0.5f * (float)SDF_N) + 0.5f);
-        m = max(0, min(SDF_N, m));
-        while (m > 0 && !(xh > voxel_centre(m - 1))) --m;
-        while (m < SDF_N && xh > voxel_centre(m)) ++m;
-        mask ^= (m >= 32) ? 0xffffffffu : ((1u << m) - 1u);
-    }
-    if (mask) atomicXor(&masks[((long)k * B + b) * (SDF_N * SDF_N) + row], mask);
 }
 
-// ------------------------------------------------------------------ lazy distance + trilinear sampling
-// grid (chunks, B, 2 pairs).  pair 0: phi of object 0 (hand) sampled at vertices of object 1; pair 1: the reverse.
-// unit gradient (d sum / d world vertex) goes to gsample_l ; per-sample values to dist (optional).
-__global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(
-    const float* __restrict__ v0, const float* __restrict__ vn0, const int* __restrict__ f0, int V0, int F0,
-    const float* __restrict__ v1, const float* __restrict__ vn1, const int* __restrict__ f1, int V1, int F1, int B,
-    const float* __restrict__ boxes, const unsigned int* __restrict__ masks, float* __restrict__ g0,
-    float* __restrict__ g1, float* __restrict__ partials, unsigned int* counter, float* __restrict__ out,
-    float* __restrict__ phi_cache)
+// ------------------------------------------------------------------ sample geometry shared by the need and sample passes
+// pair 0: phi of object 0 (hand) sampled at vertices of object 1; pair 1: the reverse.
+struct SdfSample { float ix, iy, iz; int x0, y0, z0; unsigned need; };
+__device__ __forceinline__ SdfSample sdf_sample_setup(const float* __restrict__ p, const float* __restrict__ bx,
+                                                      const unsigned int* __restrict__ mk)
+{
+    SdfSample r;
+    const float lx = (p[0] - bx[0]) / bx[3], ly = (p[1] - bx[1]) / bx[3], lz = (p[2] - bx[2]) / bx[3];
+    r.ix = ((lx + 1.0f) * (float)SDF_N - 1.0f) / 2.0f;
+    r.iy = ((ly + 1.0f) * (float)SDF_N - 1.0f) / 2.0f;
+    r.iz = ((lz + 1.0f) * (float)SDF_N - 1.0f) / 2.0f;
+    // keep the integer conversion in range for far-away points (they touch no voxel anyway)
+    r.x0 = (int)floorf(fminf(fmaxf(r.ix, -4.0f), (float)SDF_N + 4.0f));
+    r.y0 = (int)floorf(fminf(fmaxf(r.iy, -4.0f), (float)SDF_N + 4.0f));
+    r.z0 = (int)floorf(fminf(fmaxf(r.iz, -4.0f), (float)SDF_N + 4.0f));
+    r.need = 0;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int xx = r.x0 + (c & 1), yy = r.y0 + ((c >> 1) & 1), zz = r.z0 + (c >> 2);
+        if (xx >= 0 && xx < SDF_N && yy >= 0 && yy < SDF_N && zz >= 0 && zz < SDF_N)
+            if ((mk[zz * SDF_N + yy] >> xx) & 1u) r.need |= 1u << c;
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------ need pass.  grid (chunks, B, 2 pairs)
+// marks the inside voxels touched by a sample; the thread that sets a voxel's bit first appends it to the grid's list.
+__global__ __launch_bounds__(SDF_THREADS) void k_sdf_need(const float* __restrict__ v0, int V0, const float* __restrict__ v1,
+                                                           int V1, int B, const float* __restrict__ boxes,
+                                                           const unsigned int* __restrict__ masks,
+                                                           unsigned int* __restrict__ needm, int* __restrict__ need_cnt,
+                                                           int* __restrict__ need_list)
+{
+    const int b = blockIdx.y, pair = blockIdx.z, k = pair;          // SDF owner k, sampled set 1 - k
+    const int Vl = pair == 0 ? V1 : V0;
+    const int i = blockIdx.x * SDF_THREADS + threadIdx.x;
+    if (i >= Vl) return;
+    const float* vl = (pair == 0 ? v1 : v0) + ((long)b * Vl + i) * 3;
+    const long g = (long)k * B + b;
+    const SdfSample sm = sdf_sample_setup(vl, boxes + g * 4, masks + g * (SDF_N * SDF_N));
+    if (!sm.need) return;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        if (!((sm.need >> c) & 1u)) continue;
+        const int xx = sm.x0 + (c & 1), row = (sm.z0 + (c >> 2)) * SDF_N + sm.y0 + ((c >> 1) & 1);
+        const unsigned bit = 1u << xx;
+        if (!(atomicOr(&needm[g * (SDF_N * SDF_N) + row], bit) & bit))
+            need_list[g * (SDF_N * SDF_N * SDF_N) + atomicAdd(&need_cnt[g], 1)] = row * SDF_N + xx;
+    }
+}
+
+// ------------------------------------------------------------------ distance pass.  grid (SDF_DIST_WGS, B, 2 grids)
+// wave w of grid (k, b) evaluates the listed voxels w, w + nwaves, ...: unsigned distance to the mesh = min over the
+// triangles, seeded by the nearest vertex, triangles pruned by the distance to their bounding box.
+#define SDF_DIST_WGS 16
+__global__ __launch_bounds__(SDF_THREADS) void k_sdf_dist(const float* __restrict__ vn0, int V0, int F0,
+                                                           const float* __restrict__ vn1, int V1, int F1, int B,
+                                                           const float* __restrict__ tris0, const float* __restrict__ tris1,
+                                                           const int* __restrict__ need_cnt, const int* __restrict__ need_list,
+                                                           float* __restrict__ phi)
+{
+    const int b = blockIdx.y, k = blockIdx.z, lane = threadIdx.x & 63;
+    const long g = (long)k * B + b;
+    const int n = need_cnt[g];
+    const int wave = blockIdx.x * (SDF_THREADS / 64) + (threadIdx.x >> 6), nwaves = SDF_DIST_WGS * (SDF_THREADS / 64);
+    if (wave >= n) return;
+    const int Vk = k == 0 ? V0 : V1, Fk = k == 0 ? F0 : F1;
+    const float* vnk = (k == 0 ? vn0 : vn1) + (long)b * Vk * 3;
+    const float4* tk = reinterpret_cast<const float4*>((k == 0 ? tris0 : tris1) + (long)b * Fk * SDF_TRI_DW);
+    for (int e = wave; e < n; e += nwaves) {
+        const int vox = need_list[g * (SDF_N * SDF_N * SDF_N) + e];
+        const float ctr[3] = {voxel_centre(vox % SDF_N), voxel_centre((vox / SDF_N) % SDF_N), voxel_centre(vox / (SDF_N * SDF_N))};
+        // seed: the distance to the nearest mesh vertex bounds the distance to the surface from above
+        float dmin = 1e30f;
+        for (int v = lane; v < Vk; v += 64) {
+            const float dx = vnk[3 * v] - ctr[0], dy = vnk[3 * v + 1] - ctr[1], dz = vnk[3 * v + 2] - ctr[2];
+            dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
+        }
+        dmin = sqrtf(hm_wave_min(dmin)) * 1.0001f;
+        // (wave-uniform trip count: the DPP reductions inside need all 64 lanes -- a lane that has left the loop would
+        //  feed them whatever its registers last held)
+        for (int f0 = 0, it = 0; f0 < Fk; f0 += 64, ++it) {
+            const int f = f0 + lane;
+            if (f < Fk) {
+                const float4 r0 = tk[4 * f], r1 = tk[4 * f + 1], r2 = tk[4 * f + 2], r3 = tk[4 * f + 3];
+                // distance to the triangle's bounding box bounds the distance to the triangle from below; a triangle
+                // that cannot beat the current minimum is skipped (the minimum itself is unchanged)
+                const float lo[3] = {r2.y, r2.z, r2.w}, hi[3] = {r3.x, r3.y, r3.z};
+                float lb2 = 0.f;
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    const float dd = fmaxf(fmaxf(lo[cc] - ctr[cc], ctr[cc] - hi[cc]), 0.f);
+                    lb2 += dd * dd;
+                }
+                if (lb2 * 0.9999f <= dmin * dmin) {
+                    const float q1[3] = {r0.x, r0.y, r0.z}, q2[3] = {r0.w, r1.x, r1.y}, q3[3] = {r1.z, r1.w, r2.x};
+                    dmin = fminf(dmin, point_triangle_distance(ctr, q1, q2, q3));
+                }
+            }
+            if ((it & 7) == 7) dmin = hm_wave_min(dmin);     // share the bound across the lanes
+        }
+        dmin = hm_wave_min(dmin);
+        if (lane == 0) phi[g * (SDF_N * SDF_N * SDF_N) + vox] = dmin;
+    }
+}
+
+// ------------------------------------------------------------------ trilinear sampling.  grid (chunks, B, 2 pairs)
+// unit gradient (d sum / d world vertex) goes to g_l of the sampled set; out[0] = sum of all samples.
+__global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(const float* __restrict__ v0, int V0,
+                                                             const float* __restrict__ v1, int V1, int B,
+                                                             const float* __restrict__ boxes,
+                                                             const unsigned int* __restrict__ masks,
+                                                             const float* __restrict__ phig, float* __restrict__ g0,
+                                                             float* __restrict__ g1, float* __restrict__ partials,
+                                                             unsigned int* counter, float* __restrict__ out)
 {
     __shared__ float red[16];
     __shared__ int s_flag;
-    const int b = blockIdx.y, pair = blockIdx.z;
-    const int k = pair == 0 ? 0 : 1;                  // SDF owner
-    const int Vl = pair == 0 ? V1 : V0;               // sampled vertex set
-    const float* vl = (pair == 0 ? v1 : v0) + (long)b * Vl * 3;
-    float* gl = (pair == 0 ? g1 : g0) + (long)b * Vl * 3;
-    const int Vk = k == 0 ? V0 : V1, Fk = k == 0 ? F0 : F1;
-    const float* vnk = (k == 0 ? vn0 : vn1) + (long)b * Vk * 3;
-    const int* fk = k == 0 ? f0 : f1;
-    const float* bx = boxes + ((long)k * B + b) * 4;
-    const unsigned int* mk = masks + ((long)k * B + b) * (SDF_N * SDF_N);
-    float* phik = phi_cache + ((long)k * B + b) * (SDF_N * SDF_N * SDF_N);
-    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.y, pair = blockIdx.z, k = pair;
+    const int Vl = pair == 0 ? V1 : V0;
     const int i = blockIdx.x * SDF_THREADS + threadIdx.x;
-    const bool live = i < Vl;
-
-    float ix = 0.f, iy = 0.f, iz = 0.f;
-    int x0 = 0, y0 = 0, z0 = 0;
-    unsigned need = 0;
-    if (live) {
-        const float lx = (vl[3 * i] - bx[0]) / bx[3], ly = (vl[3 * i + 1] - bx[1]) / bx[3], lz = (vl[3 * i + 2] - bx[2]) / bx[3];
-        ix = ((lx + 1.0f) * (float)SDF_N - 1.0f) / 2.0f;
-        iy = ((ly + 1.0f) * (float)SDF_N - 1.0f) / 2.0f;
-        iz = ((lz + 1.0f) * (float)SDF_N - 1.0f) / 2.0f;
-        // keep the integer conversion in range for far-away points (they touch no voxel anyway)
-        const float fx = floorf(fminf(fmaxf(ix, -4.0f), (float)SDF_N + 4.0f));
-        const float fy = floorf(fminf(fmaxf(iy, -4.0f), (float)SDF_N + 4.0f));
-        const float fz = floorf(fminf(fmaxf(iz, -4.0f), (float)SDF_N + 4.0f));
-        x0 = (int)fx; y0 = (int)fy; z0 = (int)fz;
+    const long g = (long)k * B + b;
+    float val = 0.f;
+    if (i < Vl) {
+        const float* bx = boxes + g * 4;
+        const SdfSample sm = sdf_sample_setup((pair == 0 ? v1 : v0) + ((long)b * Vl + i) * 3, bx, masks + g * (SDF_N * SDF_N));
+        const float* phik = phig + g * (SDF_N * SDF_N * SDF_N);
+        float phi[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const int xx = x0 + (c & 1), yy = y0 + ((c >> 1) & 1), zz = z0 + (c >> 2);
-            if (xx >= 0 && xx < SDF_N && yy >= 0 && yy < SDF_N && zz >= 0 && zz < SDF_N)
-                if ((mk[zz * SDF_N + yy] >> xx) & 1u) need |= 1u << c;
+            const int xx = sm.x0 + (c & 1), yy = sm.y0 + ((c >> 1) & 1), zz = sm.z0 + (c >> 2);
+            phi[c] = ((sm.need >> c) & 1u) ? phik[(long)(zz * SDF_N + yy) * SDF_N + xx] : 0.f;   // 0: out of bounds / outside
         }
-    }
-    float phi[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        phi[c] = 0.f;
-        unsigned long long bal = __ballot((need >> c) & 1u);
-        while (bal) {
-            const int t = __ffsll((long long)bal) - 1;
-            bal &= bal - 1;
-            const int xx = __shfl(x0, t, 64) + (c & 1), yy = __shfl(y0, t, 64) + ((c >> 1) & 1), zz = __shfl(z0, t, 64) + (c >> 2);
-            const float ctr[3] = {voxel_centre(xx), voxel_centre(yy), voxel_centre(zz)};
-            const long cache_at = (long)(zz * SDF_N + yy) * SDF_N + xx;
-            float dmin = phik[cache_at];            // per-iteration cache of already evaluated voxels (-1 = not yet)
-            if (dmin < 0.f) {
-                // seed: the distance to the nearest mesh vertex bounds the distance to the surface from above
-                dmin = 1e30f;
-                for (int v = lane; v < Vk; v += 64) {
-                    const float dx = vnk[3 * v] - ctr[0], dy = vnk[3 * v + 1] - ctr[1], dz = vnk[3 * v + 2] - ctr[2];
-                    dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
-                }
-                dmin = sqrtf(hm_wave_min(dmin)) * 1.0001f;
-                int it = 0;
-                for (int f = lane; f < Fk; f += 64, ++it) {
-                    const int* tr = fk + 3 * f;
-                    const float *q1 = vnk + 3 * tr[0], *q2 = vnk + 3 * tr[1], *q3 = vnk + 3 * tr[2];
-                    // distance to the triangle's bounding box bounds the distance to the triangle from below; a
-                    // triangle that cannot beat the current minimum is skipped (the minimum itself is unchanged)
-                    float lb2 = 0.f;
-#pragma unroll
-                    for (int cc = 0; cc < 3; ++cc) {
-                        const float lo = fminf(q1[cc], fminf(q2[cc], q3[cc])), hi = fmaxf(q1[cc], fmaxf(q2[cc], q3[cc]));
-                        const float dd = fmaxf(fmaxf(lo - ctr[cc], ctr[cc] - hi), 0.f);
-                        lb2 += dd * dd;
-                    }
-                    if (lb2 * 0.9999f <= dmin * dmin) dmin = fminf(dmin, point_triangle_distance(ctr, q1, q2, q3));
-                    if ((it & 7) == 7) dmin = hm_wave_min(dmin);     // share the bound across the lanes
-                }
-                dmin = hm_wave_min(dmin);
-                if (lane == 0) phik[cache_at] = dmin;
-            }
-            if (lane == t) phi[c] = dmin;
-        }
-    }
-    float val = 0.f;
-    if (live) {
-        const float x1 = (float)x0 + 1.0f, y1 = (float)y0 + 1.0f, z1 = (float)z0 + 1.0f;
-        const float wx[2] = {x1 - ix, ix - (float)x0}, wy[2] = {y1 - iy, iy - (float)y0}, wz[2] = {z1 - iz, iz - (float)z0};
+        const float x1 = (float)sm.x0 + 1.0f, y1 = (float)sm.y0 + 1.0f, z1 = (float)sm.z0 + 1.0f;
+        const float wx[2] = {x1 - sm.ix, sm.ix - (float)sm.x0}, wy[2] = {y1 - sm.iy, sm.iy - (float)sm.y0};
+        const float wz[2] = {z1 - sm.iz, sm.iz - (float)sm.z0};
         float gx = 0.f, gy = 0.f, gz = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
-            const float p = phi[c];       // 0 for out-of-bounds / outside corners
+            const float p = phi[c];
             val += p * wx[dx] * wy[dy] * wz[dz];
             gx += (dx ? p : -p) * wy[dy] * wz[dz];
             gy += (dy ? p : -p) * wx[dx] * wz[dz];
             gz += (dz ? p : -p) * wx[dx] * wy[dy];
         }
         const float s = (0.5f * (float)SDF_N) / bx[3];      // d(ix)/d(local) * d(local)/d(world)
-        gl[3 * i] = gx * s; gl[3 * i + 1] = gy * s; gl[3 * i + 2] = gz * s;
+        float* gl = (pair == 0 ? g1 : g0) + ((long)b * Vl + i) * 3;
+        gl[0] = gx * s; gl[1] = gy * s; gl[2] = gz * s;
     }
     val = hm_block_sum(val, red);
     const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
@@ -328,32 +371,33 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_grid(const float* __restric
 extern "C" {
 static inline size_t al256s(size_t x) { return (x + 255) & ~(size_t)255; }
 
-size_t hm_collision_workspace_bytes(int B, int V0, int V1)
-{
-    size_t n = 0;
-    n += al256s((size_t)2 * B * 4 * 4);                      // boxes
-    n += al256s((size_t)B * V0 * 3 * 4);                     // vnorm0
-    n += al256s((size_t)B * V1 * 3 * 4);                     // vnorm1
-    n += al256s((size_t)2 * B * SDF_N * SDF_N * 4);          // masks
-    n += al256s((size_t)2 * B * (hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS)) * 4 + 256);  // partials
-    n += 256;                                                // counter (zero-initialised by the caller once)
-    n += al256s((size_t)2 * B * SDF_N * SDF_N * SDF_N * 4);  // per-iteration cache of evaluated voxel distances
-    return n;
-}
-
-struct CollWs { float* boxes; float* vn0; float* vn1; unsigned int* masks; float* partials; unsigned int* counter; float* phi_cache; };
-static CollWs coll_carve(void* ws, int B, int V0, int V1)
+struct CollWs {
+    float* boxes; float* vn0; float* vn1; unsigned int* masks; unsigned int* needm; int* need_cnt; int* need_list;
+    float* tris0; float* tris1; float* partials; unsigned int* counter; float* phi;
+};
+static size_t coll_layout(void* ws, int B, int V0, int V1, int F0, int F1, CollWs* w)
 {
     char* p = (char*)ws;
-    CollWs w;
-    w.boxes = (float*)p; p += al256s((size_t)2 * B * 4 * 4);
-    w.vn0 = (float*)p; p += al256s((size_t)B * V0 * 3 * 4);
-    w.vn1 = (float*)p; p += al256s((size_t)B * V1 * 3 * 4);
-    w.masks = (unsigned int*)p; p += al256s((size_t)2 * B * SDF_N * SDF_N * 4);
-    w.partials = (float*)p; p += al256s((size_t)2 * B * (hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS)) * 4 + 256);
-    w.counter = (unsigned int*)p; p += 256;
-    w.phi_cache = (float*)p;
-    return w;
+    const size_t grid = (size_t)SDF_N * SDF_N * SDF_N, rows = (size_t)SDF_N * SDF_N;
+    CollWs t;
+    t.counter = (unsigned int*)p; p += 256;                                         // zero-initialised by the caller once
+    t.boxes = (float*)p; p += al256s((size_t)2 * B * 4 * 4);
+    t.vn0 = (float*)p; p += al256s((size_t)B * V0 * 3 * 4);
+    t.vn1 = (float*)p; p += al256s((size_t)B * V1 * 3 * 4);
+    t.masks = (unsigned int*)p; p += al256s(2 * B * rows * 4);
+    t.needm = (unsigned int*)p; p += al256s(2 * B * rows * 4);
+    t.need_cnt = (int*)p; p += al256s((size_t)2 * B * 4);
+    t.need_list = (int*)p; p += al256s(2 * B * grid * 4);                           // worst case: every voxel needed
+    t.tris0 = (float*)p; p += al256s((size_t)B * F0 * SDF_TRI_DW * 4);
+    t.tris1 = (float*)p; p += al256s((size_t)B * F1 * SDF_TRI_DW * 4);
+    t.partials = (float*)p; p += al256s((size_t)2 * B * (hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS)) * 4 + 256);
+    t.phi = (float*)p; p += al256s(2 * B * grid * 4);                               // distances of the needed voxels
+    if (w) *w = t;
+    return (size_t)(p - (char*)ws);
+}
+size_t hm_collision_workspace_bytes(int B, int V0, int V1, int F0, int F1)
+{
+    return coll_layout(nullptr, B, V0, V1, F0, F1, nullptr);
 }
 
 // Scene of two meshes: 0 = hand (closed faces), 1 = object.  out1[0] = sum of all SDF samples (both ordered pairs);
@@ -364,24 +408,29 @@ int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, con
 {
     HM_CHECK_ARG(verts0 && faces0 && verts1 && faces1 && g0 && g1 && out1 && workspace);
     HM_CHECK_ARG(B > 0 && V0 > 0 && V1 > 0 && F0 > 0 && F1 > 0);
-    CollWs w = coll_carve(workspace, B, V0, V1);
+    CollWs w;
+    coll_layout(workspace, B, V0, V1, F0, F1, &w);
     hipLaunchKernelGGL(k_sdf_boxes, dim3(B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, scale_factor,
-                       w.boxes, w.vn0, w.vn1, w.masks, w.phi_cache);
-    const int chunks0 = hm_cdiv(F0, SDF_THREADS), chunks1 = hm_cdiv(F1, SDF_THREADS);
-    hipLaunchKernelGGL(k_sdf_parity, dim3(SDF_N * SDF_N / SDF_THREADS, B, chunks0 + chunks1), dim3(SDF_THREADS), 0, stream,
-                       w.vn0, faces0, V0, F0, w.vn1, faces1, V1, F1, B, chunks0, w.masks);
+                       w.boxes, w.vn0, w.vn1, w.masks, w.needm, w.need_cnt);
+    hipLaunchKernelGGL(k_sdf_tris, dim3(hm_cdiv(F0 > F1 ? F0 : F1, SDF_THREADS), B, 2), dim3(SDF_THREADS), 0, stream, w.vn0,
+                       faces0, V0, F0, w.vn1, faces1, V1, F1, B, w.tris0, w.tris1, w.masks);
     const int chunks = hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS);
-    hipLaunchKernelGGL(k_sdf_sample, dim3(chunks, B, 2), dim3(SDF_THREADS), 0, stream, verts0, w.vn0, faces0, V0, F0,
-                       verts1, w.vn1, faces1, V1, F1, B, w.boxes, w.masks, g0, g1, w.partials, w.counter, out1, w.phi_cache);
+    hipLaunchKernelGGL(k_sdf_need, dim3(chunks, B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, w.boxes,
+                       w.masks, w.needm, w.need_cnt, w.need_list);
+    hipLaunchKernelGGL(k_sdf_dist, dim3(SDF_DIST_WGS, B, 2), dim3(SDF_THREADS), 0, stream, w.vn0, V0, F0, w.vn1, V1, F1, B,
+                       w.tris0, w.tris1, w.need_cnt, w.need_list, w.phi);
+    hipLaunchKernelGGL(k_sdf_sample, dim3(chunks, B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, w.boxes,
+                       w.masks, w.phi, g0, g1, w.partials, w.counter, out1);
     return hm_launch_status();
 }
 
 // clamp(SDF, 0) of object `which` (0/1) on the full 32^3 grid, from the workspace of the last hm_collision_fwd.
-int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int V0, int V1, float* phi, void* workspace,
-                           hipStream_t stream)
+int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int V0, int V1, int F0, int F1, float* phi,
+                           void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(faces && phi && workspace && (which == 0 || which == 1));
-    CollWs w = coll_carve(workspace, B, V0, V1);
+    CollWs w;
+    coll_layout(workspace, B, V0, V1, F0, F1, &w);
     hipLaunchKernelGGL(k_sdf_grid, dim3(SDF_N * SDF_N * SDF_N / SDF_THREADS, B), dim3(SDF_THREADS), 0, stream,
                        which == 0 ? w.vn0 : w.vn1, faces, V, F, B, w.masks + (size_t)which * B * SDF_N * SDF_N, phi);
     return hm_launch_status();

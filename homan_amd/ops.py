@@ -524,7 +524,8 @@ class CollisionContext:
         self.f0 = torch.as_tensor(np.asarray(faces_hand_closed), dtype=torch.int32).to(device).contiguous()
         self.f1 = faces_obj.to(device=device, dtype=torch.int32).contiguous()
         self.B, self.V0, self.V1 = B, Vh, Vo
-        self.ws = torch.zeros(_lib.lib().hm_collision_workspace_bytes(B, Vh, Vo), dtype=torch.uint8, device=device)
+        self.ws = torch.zeros(_lib.lib().hm_collision_workspace_bytes(B, Vh, Vo, self.f0.shape[0], self.f1.shape[0]),
+                              dtype=torch.uint8, device=device)
 
     def grid(self, which):
         """clamp(SDF,0) (B,32,32,32) of mesh `which` from the last forward (debug / API completeness)."""
@@ -532,7 +533,8 @@ class CollisionContext:
         V = self.V0 if which == 0 else self.V1
         phi = torch.empty(self.B, 32, 32, 32, device=self.ws.device)
         _lib.check(_lib.lib().hm_collision_read_grid(_lib.ptr(f), V, f.shape[0], self.B, which, self.V0, self.V1,
-                                                     _lib.ptr(phi), _lib.ptr(self.ws), _lib.stream()),
+                                                     self.f0.shape[0], self.f1.shape[0], _lib.ptr(phi),
+                                                     _lib.ptr(self.ws), _lib.stream()),
                    "hm_collision_read_grid")
         return phi
 

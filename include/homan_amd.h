@@ -168,12 +168,12 @@ int hm_contact_fwd(const float* verts_hand, const float* verts_obj, const int* n
  * reference homan/lossutils.py:43-64 -> homan/interactions/scenesdf.py:77-148 and the `sdf` package (scenesdf.py:119).
  * Scene = {0: hand (closed faces), 1: object}.  out1[0] = sum of grid_sample(clamp(SDF_k,0), verts_l) over both
  * ordered pairs and all frames; g0 / g1 = d out / d verts0 / d verts1. */
-size_t hm_collision_workspace_bytes(int B, int V0, int V1);
+size_t hm_collision_workspace_bytes(int B, int V0, int V1, int F0, int F1);
 int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, const float* verts1, const int* faces1,
                      int V1, int F1, int B, float scale_factor, float* g0, float* g1, float* out1, void* workspace,
                      hipStream_t stream);
 /* clamp(SDF,0) on the full 32^3 grid of mesh `which`, from the workspace of the last hm_collision_fwd */
-int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int V0, int V1, float* phi,
+int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int V0, int V1, int F0, int F1, float* phi,
                            void* workspace, hipStream_t stream);
 
 /* ------------------------------------------------------------------ optimiser step + logging

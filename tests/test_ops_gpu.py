@@ -174,13 +174,20 @@ def test_inter_and_contact(mano_model):
     _close(bh.grad, b.grad, rtol=1e-3, atol_frac=1e-3, msg="contact grad obj")
 
 
-def test_collision_vs_oracle(mano_model):
-    from homan_amd import ops
+@pytest.mark.parametrize("obj", ["bottle", "cube"])
+def test_collision_vs_oracle(obj, mano_model):
+    """SDF interpenetration loss vs the oracle.  The 500-triangle cube (not a multiple of the 64-lane wavefront) with the
+    hand pushed deep inside is the case that once read a reduction result from lanes that had left the loop."""
+    from homan_amd import ops, synth
     from oracle import model as om
     m, vh, vo, of = _hand_obj(B=3, seed=4)
     B = 3
     # push the hand into the object so that vertices of each mesh lie inside the other
     vh = vh + torch.tensor([0.03, 0.0, 0.0])
+    if obj == "cube":
+        ov, of = synth.box_mesh()
+        of = torch.from_numpy(of)
+        vo = torch.from_numpy(ov)[None].repeat(B, 1, 1) * 1.5 + vh.mean(1, keepdim=True) + torch.tensor([0.01, 0.0, 0.0])
     closed = torch.as_tensor(m["closed_faces"].astype(np.int64))
     a, b = vh.clone().requires_grad_(True), vo.clone().requires_grad_(True)
     lo, meta = om.sdf_scene_loss([closed, of], [a, b])
