@@ -19,6 +19,9 @@
 #define MANO_NCHUNK 4  // ceil(778/256)
 #define MANO_PART 340  // per-(frame,chunk) partials: 192 dA + 145 dfeat + 3 dtrans
 #define MANO_NCH64 13  // ceil(778/64) vertex chunks of 64
+// forward state kept for the backward (per frame): the chain state (struct ManoShared, dword copy) + the posed vertices
+#define MANO_STATE_SH 832
+#define MANO_STATE_DW (MANO_STATE_SH + 3 * MANO_V + 2)
 
 struct ManoModelDev {
     const float* v_template;   // (778,3)
@@ -230,7 +233,8 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
                                                    const float* __restrict__ trans, int B, float* __restrict__ verts,
                                                    float* __restrict__ joints, const float* __restrict__ rigid_rot6d,
                                                    const float* __restrict__ rigid_trans,
-                                                   const float* __restrict__ rigid_scale, float* __restrict__ verts_world)
+                                                   const float* __restrict__ rigid_scale, float* __restrict__ verts_world,
+                                                   float* __restrict__ state)
 {
     __shared__ ManoShared sh;
     __shared__ float s_part[4][MANO_VCH][3];
@@ -244,6 +248,14 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
         joints[b * MANO_J * 3 + threadIdx.x] = sh.tw[threadIdx.x / 3][threadIdx.x % 3] + tr[threadIdx.x % 3];
     const int v0 = blockIdx.x * MANO_VCH;
     mano_posed_chunk(m, sh, v0, s_part, s_vp);
+    if (state) {        // chain state once per frame, posed vertices per chunk: the backward reloads instead of recomputing
+        float* st = state + (long)b * MANO_STATE_DW;
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < (int)(sizeof(ManoShared) / 4); i += blockDim.x)
+                st[i] = reinterpret_cast<const float*>(&sh)[i];
+        const int nv3 = 3 * min(MANO_VCH, MANO_V - v0);
+        if ((int)threadIdx.x < nv3) st[MANO_STATE_SH + 3 * v0 + threadIdx.x] = (&s_vp[0][0])[threadIdx.x];
+    }
     const int v = v0 + threadIdx.x;
     if (threadIdx.x >= MANO_VCH || v >= MANO_V) return;
     float T[12];
@@ -264,10 +276,143 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
     }
 }
 
-// backward pass 1: grid (13, B) -> partials (B, 13, 340)
-__global__ __launch_bounds__(256) void k_mano_bwd1(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
-                                                    const float* __restrict__ rot, const float* __restrict__ betas,
-                                                    const float* __restrict__ gout, int B, float* __restrict__ partials)
+static_assert(sizeof(ManoShared) / 4 <= MANO_STATE_SH, "MANO_STATE_SH too small");
+
+// ---- backward, second half (one workgroup per frame: the one that finishes the frame's last vertex chunk): reduce the
+// chunk partials, chain / Rodrigues / PCA backward (level-parallel).  `sh` holds the frame's chain state already.
+struct ManoBwd2Shared {
+    float tot[MANO_PART];
+    float dRw[MANO_J][9], dtw[MANO_J][3], dJ[MANO_J][3], dRl[MANO_J][9], dpose[48];
+    float cR[MANO_J][9], ct[MANO_J][3], cJ[MANO_J][3];     // child -> parent contributions
+};
+__device__ __forceinline__ void mano_bwd2_body(const ManoModelDev& m, const ManoShared& sh, ManoBwd2Shared& w,
+                                               const float* __restrict__ partials, int nchunk, int b, int pca_dim,
+                                               const float* __restrict__ g_pca_extra, float w_extra,
+                                               float* __restrict__ g_pca, float* __restrict__ g_rot,
+                                               float* __restrict__ g_betas, float* __restrict__ g_trans)
+{
+    const int t = threadIdx.x, nt = blockDim.x;
+    for (int k = t; k < MANO_PART; k += nt) {
+        float v[MANO_NCH64];
+#pragma unroll
+        for (int c = 0; c < MANO_NCH64; ++c)        // all requests first, then the (fixed order) sum
+            v[c] = c < nchunk ? hm_partial_load(partials + ((long)b * nchunk + c) * MANO_PART + k) : 0.f;
+        float a = 0.f;
+#pragma unroll
+        for (int c = 0; c < MANO_NCH64; ++c) a += v[c];
+        w.tot[k] = a;
+    }
+    int depth = 0, par = -1, maxd = 0;
+    if (t < MANO_J) { par = sh.parents[t]; depth = sh.depth[t]; }
+#pragma unroll
+    for (int j = 0; j < MANO_J; ++j) maxd = max(maxd, sh.depth[j]);
+    __syncthreads();
+    if (t < MANO_J) {
+        const int j = t;
+        const float* dA = &w.tot[j * 12];
+        // A = [Rw | tw - Rw J]
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) w.dRw[j][3 * i + k] = dA[4 * i + k] - dA[4 * i + 3] * sh.J[j][k];
+            w.dtw[j][i] = dA[4 * i + 3];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            w.dJ[j][k] = -(sh.Rw[j][k] * dA[3] + sh.Rw[j][3 + k] * dA[7] + sh.Rw[j][6 + k] * dA[11]);
+    }
+    __syncthreads();
+    // leaves first: joints of one level push their contribution to per-child slots, then every parent collects
+    for (int level = maxd; level >= 1; --level) {
+        if (t < MANO_J && depth == level) {
+            const int j = t, p = par;
+            const float rel[3] = {sh.J[j][0] - sh.J[p][0], sh.J[j][1] - sh.J[p][1], sh.J[j][2] - sh.J[p][2]};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)       // tw_j = Rw_p rel + tw_p ; Rw_j = Rw_p Rl_j
+                    w.cR[j][3 * i + k] = w.dtw[j][i] * rel[k] + w.dRw[j][3 * i] * sh.Rl[j][3 * k] +
+                                         w.dRw[j][3 * i + 1] * sh.Rl[j][3 * k + 1] + w.dRw[j][3 * i + 2] * sh.Rl[j][3 * k + 2];
+                w.ct[j][i] = w.dtw[j][i];
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float d = sh.Rw[p][k] * w.dtw[j][0] + sh.Rw[p][3 + k] * w.dtw[j][1] + sh.Rw[p][6 + k] * w.dtw[j][2];
+                w.dJ[j][k] += d;
+                w.cJ[j][k] = -d;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    w.dRl[j][3 * i + k] = sh.Rw[p][i] * w.dRw[j][k] + sh.Rw[p][3 + i] * w.dRw[j][3 + k] + sh.Rw[p][6 + i] * w.dRw[j][6 + k];
+        }
+        __syncthreads();
+        if (t < MANO_J && depth == level - 1) {
+            for (int j = 0; j < MANO_J; ++j)
+                if (sh.parents[j] == t) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) w.dRw[t][k] += w.cR[j][k];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { w.dtw[t][k] += w.ct[j][k]; w.dJ[t][k] += w.cJ[j][k]; }
+                }
+        }
+        __syncthreads();
+    }
+    if (t < MANO_J && par < 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) w.dRl[t][k] = w.dRw[t][k];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w.dJ[t][c] += w.dtw[t][c];
+    }
+    __syncthreads();
+    if (t < MANO_J) {
+        float dR[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dR[k] = w.dRl[t][k] + (t >= 1 ? w.tot[192 + 9 * (t - 1) + k] : 0.f);
+        float dr[3];
+        rodrigues_backward(&sh.pose[3 * t], dR, dr);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) w.dpose[3 * t + c] = dr[c];
+    }
+    __syncthreads();
+    if (t < 3) {
+        g_rot[b * 3 + t] = w.dpose[t];
+        g_trans[b * 3 + t] = w.tot[337 + t];
+    }
+    for (int i = t; i < pca_dim; i += nt) {
+        float a = 0.f;
+        if (i < 16) {
+            float cv[45];
+#pragma unroll
+            for (int k = 0; k < 45; ++k) cv[k] = m.comps[i * 45 + k];            // 45 independent loads in flight
+#pragma unroll
+            for (int k = 0; k < 45; ++k) a += cv[k] * w.dpose[3 + k];
+        }
+        if (g_pca_extra) a += w_extra * g_pca_extra[(long)b * pca_dim + i];      // e.g. the PCA prior's unit gradient
+        g_pca[(long)b * pca_dim + i] = a;
+    }
+    if (t < 10) {
+        float a = w.tot[192 + 135 + t];
+        float jv[MANO_J * 3];
+#pragma unroll
+        for (int q = 0; q < MANO_J * 3; ++q) jv[q] = m.J_shapedirs[q * 10 + t];
+#pragma unroll
+        for (int q = 0; q < MANO_J * 3; ++q) a += jv[q] * w.dJ[q / 3][q % 3];
+        g_betas[b * 10 + t] = a;
+    }
+}
+
+// backward: grid (13, B).  First half per (vertex chunk, frame) -> partials (B, 13, 340); the workgroup that finishes
+// the last chunk of a frame (per-frame ticket) runs the second half for that frame -- one launch, and the chain state is
+// reloaded from the forward (`state`) instead of being recomputed when the caller kept it.
+__global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
+                                                   const float* __restrict__ rot, const float* __restrict__ betas,
+                                                   const float* __restrict__ gout, int B, const float* __restrict__ state,
+                                                   float* __restrict__ partials, unsigned int* __restrict__ frame_cnt,
+                                                   int pca_dim, const float* __restrict__ g_pca_extra, float w_extra,
+                                                   float* __restrict__ g_pca, float* __restrict__ g_rot,
+                                                   float* __restrict__ g_betas, float* __restrict__ g_trans)
 {
     __shared__ ManoShared sh;
     __shared__ float s_part[4][MANO_VCH][3];
@@ -276,11 +421,20 @@ __global__ __launch_bounds__(256) void k_mano_bwd1(ManoModelDev m, const float* 
     __shared__ float s_dvp[MANO_VCH * 3];
     __shared__ float s_w[MANO_VCH][MANO_J + 1];
     __shared__ float red[16];
+    __shared__ ManoBwd2Shared w2;
+    __shared__ int s_flag;
     const int b = blockIdx.y, t = threadIdx.x;
-    mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
     const int v0 = blockIdx.x * MANO_VCH;
     const int nv = min(MANO_VCH, MANO_V - v0);
-    mano_posed_chunk(m, sh, v0, s_part, s_vp);
+    if (state) {
+        const float* st = state + (long)b * MANO_STATE_DW;
+        for (int i = t; i < (int)(sizeof(ManoShared) / 4); i += blockDim.x) reinterpret_cast<float*>(&sh)[i] = st[i];
+        if (t < 3 * nv) (&s_vp[0][0])[t] = st[MANO_STATE_SH + 3 * v0 + t];
+        __syncthreads();
+    } else {
+        mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
+        mano_posed_chunk(m, sh, v0, s_part, s_vp);
+    }
     float g[3] = {0.f, 0.f, 0.f};
     if (t < nv) {
         const int v = v0 + t;
@@ -297,14 +451,14 @@ __global__ __launch_bounds__(256) void k_mano_bwd1(ManoModelDev m, const float* 
     }
     float* out = partials + ((long)b * gridDim.x + blockIdx.x) * MANO_PART;
     const float tg0 = hm_block_sum(g[0], red), tg1 = hm_block_sum(g[1], red), tg2 = hm_block_sum(g[2], red);
-    if (t == 0) { out[337] = tg0; out[338] = tg1; out[339] = tg2; }
+    if (t == 0) { hm_partial_store(out + 337, tg0); hm_partial_store(out + 338, tg1); hm_partial_store(out + 339, tg2); }
     __syncthreads();
     // dA[j][r][c] = sum_v W[v][j] g[v][r] [vp;1][c]
     if (t < 192) {
         const int j = t / 12, r = (t % 12) / 4, c = t % 4;
         float acc = 0.f;
         for (int i = 0; i < nv; ++i) acc += s_w[i][j] * s_g[i][r] * (c < 3 ? s_vp[i][c] : 1.0f);
-        out[t] = acc;
+        hm_partial_store(out + t, acc);
     }
     // dfeat[k] = sum_{v,c} M[k][3v+c] dvp[v][c]   (one wave per row, 3 coalesced loads, rows independent)
     const int wv = t >> 6, lane = t & 63;
@@ -313,158 +467,71 @@ __global__ __launch_bounds__(256) void k_mano_bwd1(ManoModelDev m, const float* 
     if (lane < ne) d0 = s_dvp[lane];
     if (lane + 64 < ne) d1 = s_dvp[lane + 64];
     if (lane + 128 < ne) d2 = s_dvp[lane + 128];
-#pragma unroll 4
-    for (int k = wv; k < MANO_NF; k += 4) {
-        const float* row = m.M + (long)k * (3 * MANO_V) + 3 * v0;
-        float acc = 0.f;
-        if (lane < ne) acc += row[lane] * d0;
-        if (lane + 64 < ne) acc += row[lane + 64] * d1;
-        if (lane + 128 < ne) acc += row[lane + 128] * d2;
+    // all the wave's rows are requested before the first one is reduced: the loop is otherwise one memory latency per
+    // four rows with nothing else in flight (this loop was ~15 of the kernel's 36 us)
+    constexpr int ROWS = (MANO_NF + 3) / 4;
+    float r0[ROWS], r1[ROWS], r2[ROWS];
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        const int k = wv + 4 * q;
+        const float* row = m.M + (long)min(k, MANO_NF - 1) * (3 * MANO_V) + 3 * v0;
+        r0[q] = lane < ne ? row[lane] : 0.f;
+        r1[q] = lane + 64 < ne ? row[lane + 64] : 0.f;
+        r2[q] = lane + 128 < ne ? row[lane + 128] : 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < ROWS; ++q) {
+        const int k = wv + 4 * q;
+        float acc = r0[q] * d0;
+        acc += r1[q] * d1;
+        acc += r2[q] * d2;
         acc = hm_wave_sum(acc);
-        if (lane == 0) out[192 + k] = acc;
+        if (lane == 0 && k < MANO_NF) hm_partial_store(out + 192 + k, acc);
     }
-}
-
-// backward pass 2: grid (B), 64 threads: reduce chunk partials, chain / Rodrigues / PCA backward (level-parallel)
-__global__ __launch_bounds__(64) void k_mano_bwd2(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
-                                                   const float* __restrict__ rot, const float* __restrict__ betas,
-                                                   const float* __restrict__ partials, int nchunk, int B, int pca_dim,
-                                                   const float* __restrict__ g_pca_extra, float w_extra,
-                                                   float* __restrict__ g_pca, float* __restrict__ g_rot,
-                                                   float* __restrict__ g_betas, float* __restrict__ g_trans)
-{
-    __shared__ ManoShared sh;
-    __shared__ float tot[MANO_PART];
-    __shared__ float dRw[MANO_J][9], dtw[MANO_J][3], dJ[MANO_J][3], dRl[MANO_J][9], dpose[48];
-    __shared__ float cR[MANO_J][9], ct[MANO_J][3], cJ[MANO_J][3];     // child -> parent contributions
-    const int b = blockIdx.x, t = threadIdx.x;
-    mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
-    for (int k = t; k < MANO_PART; k += 64) {
-        float a = 0.f;
-        for (int c = 0; c < nchunk; ++c) a += partials[((long)b * nchunk + c) * MANO_PART + k];
-        tot[k] = a;
-    }
-    int depth = 0, par = -1, maxd = 0;
-    if (t < MANO_J) { par = sh.parents[t]; depth = sh.depth[t]; }
-#pragma unroll
-    for (int j = 0; j < MANO_J; ++j) maxd = max(maxd, sh.depth[j]);
+    // per-frame ticket: every thread's record stores must have landed before the workgroup takes it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t < MANO_J) {
-        const int j = t;
-        const float* dA = &tot[j * 12];
-        // A = [Rw | tw - Rw J]
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) dRw[j][3 * i + k] = dA[4 * i + k] - dA[4 * i + 3] * sh.J[j][k];
-            dtw[j][i] = dA[4 * i + 3];
-        }
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            dJ[j][k] = -(sh.Rw[j][k] * dA[3] + sh.Rw[j][3 + k] * dA[7] + sh.Rw[j][6 + k] * dA[11]);
+    if (t == 0) {
+        const unsigned int ticket = atomicAdd(frame_cnt + b, 1u);
+        const int last = ticket == gridDim.x - 1u;
+        if (last) atomicExch(frame_cnt + b, 0u);
+        s_flag = last;
     }
     __syncthreads();
-    // leaves first: joints of one level push their contribution to per-child slots, then every parent collects
-    for (int level = maxd; level >= 1; --level) {
-        if (t < MANO_J && depth == level) {
-            const int j = t, p = par;
-            const float rel[3] = {sh.J[j][0] - sh.J[p][0], sh.J[j][1] - sh.J[p][1], sh.J[j][2] - sh.J[p][2]};
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-#pragma unroll
-                for (int k = 0; k < 3; ++k)       // tw_j = Rw_p rel + tw_p ; Rw_j = Rw_p Rl_j
-                    cR[j][3 * i + k] = dtw[j][i] * rel[k] + dRw[j][3 * i] * sh.Rl[j][3 * k] +
-                                       dRw[j][3 * i + 1] * sh.Rl[j][3 * k + 1] + dRw[j][3 * i + 2] * sh.Rl[j][3 * k + 2];
-                ct[j][i] = dtw[j][i];
-            }
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const float d = sh.Rw[p][k] * dtw[j][0] + sh.Rw[p][3 + k] * dtw[j][1] + sh.Rw[p][6 + k] * dtw[j][2];
-                dJ[j][k] += d;
-                cJ[j][k] = -d;
-            }
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int k = 0; k < 3; ++k)
-                    dRl[j][3 * i + k] = sh.Rw[p][i] * dRw[j][k] + sh.Rw[p][3 + i] * dRw[j][3 + k] + sh.Rw[p][6 + i] * dRw[j][6 + k];
-        }
-        __syncthreads();
-        if (t < MANO_J && depth == level - 1) {
-            for (int j = 0; j < MANO_J; ++j)
-                if (sh.parents[j] == t) {
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) dRw[t][k] += cR[j][k];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { dtw[t][k] += ct[j][k]; dJ[t][k] += cJ[j][k]; }
-                }
-        }
-        __syncthreads();
-    }
-    if (t < MANO_J && par < 0) {
-#pragma unroll
-        for (int k = 0; k < 9; ++k) dRl[t][k] = dRw[t][k];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dJ[t][c] += dtw[t][c];
-    }
-    __syncthreads();
-    if (t < MANO_J) {
-        float dR[9];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) dR[k] = dRl[t][k] + (t >= 1 ? tot[192 + 9 * (t - 1) + k] : 0.f);
-        float dr[3];
-        rodrigues_backward(&sh.pose[3 * t], dR, dr);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) dpose[3 * t + c] = dr[c];
-    }
-    __syncthreads();
-    if (t < 3) {
-        g_rot[b * 3 + t] = dpose[t];
-        g_trans[b * 3 + t] = tot[337 + t];
-    }
-    for (int i = t; i < pca_dim; i += 64) {
-        float a = 0.f;
-        if (i < 16)
-            for (int k = 0; k < 45; ++k) a += m.comps[i * 45 + k] * dpose[3 + k];
-        if (g_pca_extra) a += w_extra * g_pca_extra[(long)b * pca_dim + i];      // e.g. the PCA prior's unit gradient
-        g_pca[(long)b * pca_dim + i] = a;
-    }
-    if (t < 10) {
-        float a = tot[192 + 135 + t];
-        for (int j = 0; j < MANO_J; ++j)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) a += m.J_shapedirs[(j * 3 + c) * 10 + t] * dJ[j][c];
-        g_betas[b * 10 + t] = a;
-    }
+    if (s_flag)
+        mano_bwd2_body(m, sh, w2, partials, gridDim.x, b, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
 }
 
 extern "C" {
 // model: 8 device pointers in the order of ManoModelDev.
 int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
                 const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d, const float* rigid_trans,
-                const float* rigid_scale, float* verts_world, hipStream_t stream)
+                const float* rigid_scale, float* verts_world, float* state, hipStream_t stream)
 {
     HM_CHECK_ARG(model && pca && rot && betas && verts && B > 0 && pca_dim >= 16);
     HM_CHECK_ARG(!verts_world || (rigid_rot6d && rigid_trans && rigid_scale));
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
     hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, trans, B, verts,
-                       joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world);
+                       joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world, state);
     return hm_launch_status();
 }
-size_t hm_mano_workspace_bytes(int B) { return (size_t)B * MANO_NCH64 * MANO_PART * sizeof(float); }
+size_t hm_mano_workspace_bytes(int B) { return 512 + (size_t)B * 4 + (size_t)B * MANO_NCH64 * MANO_PART * sizeof(float); }
+size_t hm_mano_state_bytes(int B) { return (size_t)B * MANO_STATE_DW * sizeof(float); }
+// workspace: hm_mano_workspace_bytes(B), zero-filled once (per-frame tickets reset themselves).  state: the buffer the
+// forward filled (hm_mano_state_bytes(B)) for the SAME parameters, or NULL to recompute the chain.
 int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
                 const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
-                float* g_trans, void* workspace, hipStream_t stream)
+                float* g_trans, const float* state, void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(model && pca && rot && betas && g_verts && g_pca && g_rot && g_betas && g_trans && workspace);
     HM_CHECK_ARG(B > 0 && pca_dim >= 16);
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
-    hipLaunchKernelGGL(k_mano_bwd1, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, g_verts, B,
-                       (float*)workspace);
-    hipLaunchKernelGGL(k_mano_bwd2, dim3(B), dim3(64), 0, stream, m, pca, pca_dim, rot, betas, (const float*)workspace,
-                       MANO_NCH64, B, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
+    unsigned int* cnt = (unsigned int*)workspace;
+    float* partials = (float*)((char*)workspace + 256 + (((size_t)B * 4 + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(k_mano_bwd, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, g_verts, B, state,
+                       partials, cnt, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
     return hm_launch_status();
 }
 }  // extern "C"

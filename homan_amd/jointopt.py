@@ -263,6 +263,7 @@ class FusedStepper:
         self.log_buf = torch.zeros(max_steps, len(self.SLOTS) + 1, device=dev)
         self.max_steps = max_steps
         self.mctx = m.mano_model.ctx_mean
+        self.mano_state = torch.empty(self.L.hm_mano_state_bytes(B), dtype=torch.uint8, device=dev)
         self.graph = None
         self.side = torch.cuda.Stream()
         self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd = (torch.cuda.Event() for _ in range(4))
@@ -325,7 +326,8 @@ class FusedStepper:
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
             ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
-                             P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh), sb),
+                             P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
+                             P(self.mano_state), sb),
                "mano_fwd + rigid(hand)")
             pri = on["pca"] or on["so"] or on["sh"]
             if on["smooth"] and on["v2d"]:       # the three hand-only reductions in one launch
@@ -393,7 +395,7 @@ class FusedStepper:
                "rigid_bwd(hand)")
             ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
                              P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad), P(betas.grad),
-                             P(mtr.grad), P(self.mctx.workspace(B)), sb), "mano_bwd")
+                             P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb), "mano_bwd")
         # ---------------- A: object backward: silhouette gradient + smooth + contact [+ interaction with a free scale],
         # summed with their weights inside the rigid backward
         main.wait_event(self.ev_pair)

@@ -320,7 +320,7 @@ class ManoContext:
 
     def workspace(self, B):
         if B not in self._ws:
-            self._ws[B] = torch.empty(_lib.lib().hm_mano_workspace_bytes(B), dtype=torch.uint8, device=self.device)
+            self._ws[B] = torch.zeros(_lib.lib().hm_mano_workspace_bytes(B), dtype=torch.uint8, device=self.device)
         return self._ws[B]
 
 
@@ -333,23 +333,25 @@ class _ManoLBS(torch.autograd.Function):
         trans = None if trans is None else _f32(trans)
         B, P = pca.shape
         verts = torch.empty(B, 778, 3, device=pca.device)
+        state = torch.empty(_lib.lib().hm_mano_state_bytes(B), dtype=torch.uint8, device=pca.device)
         _lib.check(_lib.lib().hm_mano_fwd(mctx.ptrs, _lib.ptr(pca), P, _lib.ptr(rot), _lib.ptr(betas), _lib.ptr(trans), B,
-                                          _lib.ptr(verts), None, None, None, None, None, _lib.stream()), "hm_mano_fwd")
-        ctx.save_for_backward(pca, rot, betas)
+                                          _lib.ptr(verts), None, None, None, None, None, _lib.ptr(state), _lib.stream()),
+                   "hm_mano_fwd")
+        ctx.save_for_backward(pca, rot, betas, state)
         ctx.mctx, ctx.has_trans = mctx, trans is not None
         return verts
 
     @staticmethod
     def backward(ctx, g_verts):
-        pca, rot, betas = ctx.saved_tensors
+        pca, rot, betas, state = ctx.saved_tensors
         B, P = pca.shape
         g_verts = _f32(g_verts)
         g_pca, g_rot, g_betas = torch.empty_like(pca), torch.empty_like(rot), torch.empty_like(betas)
         g_trans = torch.empty(B, 3, device=pca.device)
         _lib.check(_lib.lib().hm_mano_bwd(ctx.mctx.ptrs, _lib.ptr(pca), P, _lib.ptr(rot), _lib.ptr(betas), B,
                                           _lib.ptr(g_verts), None, 0.0, _lib.ptr(g_pca), _lib.ptr(g_rot), _lib.ptr(g_betas),
-                                          _lib.ptr(g_trans), _lib.ptr(ctx.mctx.workspace(B)), _lib.stream()),
-                   "hm_mano_bwd")
+                                          _lib.ptr(g_trans), _lib.ptr(state), _lib.ptr(ctx.mctx.workspace(B)),
+                                          _lib.stream()), "hm_mano_bwd")
         return g_pca, g_rot, g_betas, (g_trans if ctx.has_trans else None), None
 
 
@@ -365,7 +367,8 @@ def mano_joints(pca, rot, betas, trans, mctx):
     joints = torch.empty(B, 16, 3, device=pca.device)
     tr = None if trans is None else _f32(trans.detach())
     _lib.check(_lib.lib().hm_mano_fwd(mctx.ptrs, _lib.ptr(pca), P, _lib.ptr(rot), _lib.ptr(betas), _lib.ptr(tr), B,
-                                      _lib.ptr(verts), _lib.ptr(joints), None, None, None, None, _lib.stream()), "hm_mano_fwd")
+                                      _lib.ptr(verts), _lib.ptr(joints), None, None, None, None, None, _lib.stream()),
+               "hm_mano_fwd")
     return verts, joints
 
 

@@ -71,15 +71,18 @@ int hm_sum_small(const float* parts, int n, float w0, const float* extra, float 
  *   parents (16) int32}.   pca (B,pca_dim>=16; the first 16 columns drive the mesh), rot (B,3), betas (B,10),
  *   trans (B,3) or NULL.  verts (B,778,3); joints (B,16,3) optional.
  *   verts_world (B,778,3) optional: the rigid hand transform of hm_rigid_fwd (rigid_rot6d (B,3,2), rigid_trans (B,3),
- *   rigid_scale (1), no abs) applied in the same launch. */
+ *   rigid_scale (1), no abs) applied in the same launch.
+ *   state (hm_mano_state_bytes(B)) optional: kinematic-chain state + posed vertices kept for hm_mano_bwd. */
 int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
                 const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d, const float* rigid_trans,
-                const float* rigid_scale, float* verts_world, hipStream_t stream);
-size_t hm_mano_workspace_bytes(int B);
-/* g_pca_extra (B,pca_dim) optional: g_pca = d/d pca through the mesh + w_extra * g_pca_extra (e.g. the PCA prior) */
+                const float* rigid_scale, float* verts_world, float* state, hipStream_t stream);
+size_t hm_mano_workspace_bytes(int B);      /* zero-filled once by the caller (self-resetting per-frame tickets) */
+size_t hm_mano_state_bytes(int B);
+/* g_pca_extra (B,pca_dim) optional: g_pca = d/d pca through the mesh + w_extra * g_pca_extra (e.g. the PCA prior).
+ * state: what hm_mano_fwd stored for the SAME parameters, or NULL (the chain is then recomputed). */
 int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
                 const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
-                float* g_trans, void* workspace, hipStream_t stream);
+                float* g_trans, const float* state, void* workspace, hipStream_t stream);
 
 /* ------------------------------------------------------------------ silhouette rasteriser + fused masked-MSE / IoU
  * reference homan/losses.py:183-197 (compute_sil_loss_object) and the `neural_renderer` call inside it
