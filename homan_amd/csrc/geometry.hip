@@ -91,16 +91,31 @@ __global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mes
 // (gradients w.r.t. the mesh-detached twin of the vertices).  Summing the weighted terms here replaces a separate
 // linear-combination launch on the critical chain.  grid (N)
 struct RigidTerms { const float* p[4]; float w[4]; };
+// Optional fifth term: the silhouette gradient, gathered on the fly from the per-(face, corner) NDC gradients of the edge
+// sweeps (hm_sil_bwd called with grad_verts == NULL) and pushed through the projection backward -- the work of
+// k_bwd_gather, without its launch and without the (B,V,3) round trip on the critical chain.
+struct SilGather {
+    const float* parts;        // (B,F,3,2)
+    const int* adj_off;        // (V+1) CSR over vertices
+    const int* adj_items;      // face * 3 + corner
+    const float* cam_verts;    // (B,V,3) camera-space vertices the silhouettes were rendered from
+    const float* K;            // (B,3,3)
+    float orig_size;
+    int F;
+};
 __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
                                                    const float* __restrict__ scale, int abs_scale, RigidTerms terms,
+                                                   SilGather sil,
                                                    const float* __restrict__ g_rigid, const float* __restrict__ g_frame,
                                                    int frame_stride, float frame_scale, int N, int V,
                                                    float* __restrict__ g_mesh,
                                                    float* __restrict__ g_rot6d, float* __restrict__ g_trans,
-                                                   float* __restrict__ g_scale_part)
+                                                   float* __restrict__ g_scale_part, float* __restrict__ partials,
+                                                   unsigned int* __restrict__ frame_cnt)
 {
     __shared__ float R[9];
     __shared__ float red[16];
+    __shared__ int s_flag;
     const int n = blockIdx.x;
     if (threadIdx.x == 0) {
         float r[9];
@@ -119,7 +134,8 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
     float acc[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) acc[k] = 0.f;
-    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    // grid (N, chunks): this workgroup's 256 vertices; the frame's last workgroup (ticket) finishes the frame
+    for (int v = blockIdx.y * blockDim.x + threadIdx.x; v < V; v += gridDim.y * blockDim.x) {
         const long o = ((long)n * V + v) * 3;
         const float m[3] = {mesh[o], mesh[o + 1], mesh[o + 2]};
         float gf[3] = {0.f, 0.f, 0.f}, gt[3];
@@ -128,6 +144,24 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
             if (terms.p[k]) {
                 gf[0] += terms.w[k] * terms.p[k][o]; gf[1] += terms.w[k] * terms.p[k][o + 1]; gf[2] += terms.w[k] * terms.p[k][o + 2];
             }
+        if (sil.parts) {        // same arithmetic as k_bwd_gather (raster.hip)
+            float gu = 0.f, gv = 0.f;
+            const float2* pf = reinterpret_cast<const float2*>(sil.parts + (long)n * sil.F * 6);
+            for (int a = sil.adj_off[v]; a < sil.adj_off[v + 1]; ++a) {
+                const float2 g2 = pf[sil.adj_items[a]];
+                gu += g2.x;
+                gv += g2.y;
+            }
+            const float* k = sil.K + n * 9;
+            const float x = sil.cam_verts[o], y = sil.cam_verts[o + 1], z = sil.cam_verts[o + 2];
+            const float zz = z + 1e-9f;
+            const float du0 = gu * (2.0f / sil.orig_size), dv0 = -gv * (2.0f / sil.orig_size);
+            const float dxn = k[0] * du0 + k[3] * dv0;
+            const float dyn = k[1] * du0 + k[4] * dv0;
+            gf[0] += dxn / zz;
+            gf[1] += dyn / zz;
+            gf[2] += -(dxn * x + dyn * y) / (zz * zz);
+        }
         gt[0] = gf[0] + gfr[0]; gt[1] = gf[1] + gfr[1]; gt[2] = gf[2] + gfr[2];
         if (g_rigid) { gt[0] += g_rigid[o]; gt[1] += g_rigid[o + 1]; gt[2] += g_rigid[o + 2]; }
 #pragma unroll
@@ -145,6 +179,21 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
     float tot[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) tot[k] = hm_block_sum(acc[k], red);
+    if (gridDim.y > 1) {
+        float* rec = partials + ((long)n * gridDim.y + blockIdx.y) * 16;
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) hm_partial_store(rec + k, tot[k]);
+        }
+        if (!hm_last_block(frame_cnt + n, gridDim.y, &s_flag)) return;
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) tot[k] = 0.f;
+            for (unsigned c = 0; c < gridDim.y; ++c)       // fixed order: deterministic
+#pragma unroll
+                for (int k = 0; k < 13; ++k) tot[k] += hm_partial_load(partials + ((long)n * gridDim.y + c) * 16 + k);
+        }
+    }
     if (threadIdx.x == 0) {
         float dr6[6];
         rot6d_backward(rot6d + n * 6, tot, dr6);
@@ -217,19 +266,48 @@ int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, cons
                        abs_scale, N, V, rotmat, verts);
     return hm_launch_status();
 }
-int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
-                 const float* weights, int n_terms, const float* g_rigid, const float* g_frame, int frame_stride,
-                 float frame_scale, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part,
-                 hipStream_t stream)
+#define RIGID_MAX_CHUNKS 16
+size_t hm_rigid_workspace_bytes(int N) { return (((size_t)N * 4 + 255) & ~(size_t)255) + (size_t)N * RIGID_MAX_CHUNKS * 16 * 4; }
+static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
+                            const float* const* g_terms, const float* weights, int n_terms, SilGather sil,
+                            const float* g_rigid, const float* g_frame, int frame_stride, float frame_scale, int N, int V,
+                            float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part, void* workspace,
+                            hipStream_t stream)
 {
     HM_CHECK_ARG(mesh && rot6d && scale && g_rot6d && g_trans && N > 0 && V > 0);
     HM_CHECK_ARG(n_terms >= 0 && n_terms <= 4 && (n_terms == 0 || (g_terms && weights)));
     HM_CHECK_ARG(!g_frame || frame_stride >= 3);
     RigidTerms t;
     for (int k = 0; k < 4; ++k) { t.p[k] = k < n_terms ? g_terms[k] : nullptr; t.w[k] = k < n_terms ? weights[k] : 0.f; }
-    hipLaunchKernelGGL(k_rigid_bwd, dim3(N), dim3(256), 0, stream, mesh, rot6d, scale, abs_scale, t, g_rigid, g_frame,
-                       frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part);
+    // workspace (hm_rigid_workspace_bytes, zero-filled once): per-frame tickets + chunk partials -> grid (N, chunks);
+    // without it one workgroup per frame does everything
+    const int chunks = workspace ? min(RIGID_MAX_CHUNKS, hm_cdiv(V, 256)) : 1;
+    unsigned int* cnt = (unsigned int*)workspace;
+    float* partials = workspace ? (float*)((char*)workspace + (((size_t)N * 4 + 255) & ~(size_t)255)) : nullptr;
+    hipLaunchKernelGGL(k_rigid_bwd, dim3(N, chunks), dim3(256), 0, stream, mesh, rot6d, scale, abs_scale, t, sil, g_rigid,
+                       g_frame, frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, partials, cnt);
     return hm_launch_status();
+}
+int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
+                 const float* weights, int n_terms, const float* g_rigid, const float* g_frame, int frame_stride,
+                 float frame_scale, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part,
+                 void* workspace, hipStream_t stream)
+{
+    SilGather none = {nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, 0};
+    return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, none, g_rigid, g_frame, frame_stride,
+                            frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, workspace, stream);
+}
+// hm_rigid_bwd with the silhouette gradient as an extra full term taken straight from the sweep output: sil_parts =
+// hm_sil_parts(workspace) of an hm_sil_bwd called with grad_verts == NULL; cam_verts / K / orig_size / F as given to it.
+int hm_rigid_bwd_sil(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
+                     const float* weights, int n_terms, const float* sil_parts, const int* adj_off, const int* adj_items,
+                     const float* cam_verts, const float* K, float orig_size, int F, int N, int V, float* g_rot6d,
+                     float* g_trans, float* g_scale_part, void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(sil_parts && adj_off && adj_items && cam_verts && K && F > 0);
+    SilGather sil = {sil_parts, adj_off, adj_items, cam_verts, K, orig_size, F};
+    return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, sil, nullptr, nullptr, 0, 0.f, N, V,
+                            nullptr, g_rot6d, g_trans, g_scale_part, workspace, stream);
 }
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream)
 {

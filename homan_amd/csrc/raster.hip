@@ -810,8 +810,10 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
                             const int idx_out = axis ? idx[(long)d0r * is + d1_out] : idx[(long)d1_out * is + d0r];
                             use0 = p10 != (float)d0r;
                             use1 = p00 != (float)d0r;
-                            c0 = use0 ? num / (p10 - (float)d0r) : 0.f;
-                            c1 = use1 ? num / ((float)d0r - p00) : 0.f;
+                            // 1-ulp reciprocals: these only scale the pseudo-distances (compared at 1e-3), unlike c2
+                            // below, which picks the integer end of the inward range and stays an IEEE division
+                            c0 = use0 ? num * __builtin_amdgcn_rcpf(p10 - (float)d0r) : 0.f;
+                            c1 = use1 ? num * __builtin_amdgcn_rcpf((float)d0r - p00) : 0.f;
                             if (idx_in == fn) {             // outward: from the sample just outside the edge to the border
                                 const int lim = (dir > 0) ? is - 1 : 0;
                                 rfrom[0] = max(min(d1_out, lim), 0);
@@ -1127,7 +1129,9 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
 // ================================================================ C ABI
 // persistent sweep waves: 4 per SIMD.  More does not speed the sweep up and starves the concurrent hand-side kernels
 // of wave slots (they run on a second stream of the same hipGraph).
+#ifndef SWEEP_BLOCKS
 #define SWEEP_BLOCKS 1024
+#endif
 extern "C" {
 
 // workspace layout helper (bytes), all chunks 256-byte aligned
@@ -1236,7 +1240,7 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
                const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
                hipStream_t stream)
 {
-    HM_CHECK_ARG(verts && K && adj_off && adj_items && grad_verts && workspace);
+    HM_CHECK_ARG(verts && K && adj_off && adj_items && workspace);        // grad_verts == NULL: no vertex gather (see hm_sil_parts)
     HM_CHECK_ARG(mode == 0 ? grad_pooled != nullptr : (upstream && keep_sum));
     HM_CHECK_ARG(mode >= 0 && mode <= 2);
     if (S % 32 != 0 || S > 32 * SWEEP_CUMW) return HM_ERR_UNSUPPORTED;     // 64-sample mask words, <= SWEEP_CUMW per line
@@ -1250,9 +1254,16 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.cum);
     hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), SWEEP_BLOCKS)), dim3(256), 0, stream, w.faces9, w.boxes,
                        w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, eps, w.parts, w.owned, face_order);
-    hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
-                       adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
+    if (grad_verts)
+        hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
+                           adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
     return hm_launch_status();
+}
+
+// (B,F,3,2) d loss / d NDC (x, y) per face corner, as left by the last hm_sil_bwd: input of hm_rigid_bwd_sil.
+const float* hm_sil_parts(const void* workspace, int B, int V, int F, int S)
+{
+    return carve((void*)workspace, B, V, F, S).parts;
 }
 
 // Backward of the depth image of the last hm_sil_fwd (called with pooled_depth): grad_pooled_depth (B,S,S) ->

@@ -263,6 +263,8 @@ class FusedStepper:
         self.log_buf = torch.zeros(max_steps, len(self.SLOTS) + 1, device=dev)
         self.max_steps = max_steps
         self.mctx = m.mano_model.ctx_mean
+        self.rigid_ws_h, self.rigid_ws_o = (torch.zeros(self.L.hm_rigid_workspace_bytes(B), dtype=torch.uint8, device=dev)
+                                            for _ in range(2))
         self.mano_state = torch.empty(self.L.hm_mano_state_bytes(B), dtype=torch.uint8, device=dev)
         self.graph = None
         self.side = torch.cuda.Stream()
@@ -322,7 +324,7 @@ class FusedStepper:
             ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
                             2 if self.lw["lw_sil_obj"] > 0 else 1,
                             P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
-                            P(sctx.face_order), P(self.G_sil), None, P(sctx.workspace), sa), "sil_bwd")
+                            P(sctx.face_order), None, None, P(sctx.workspace), sa), "sil_bwd")    # no vertex gather
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
             ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
@@ -391,8 +393,8 @@ class FusedStepper:
                                      (self.U_conh if on["con"] else None, w["loss_contact"])])
             ck(L.hm_rigid_bwd(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, tp, tw, tn, None,
                               (self.rec.data_ptr() + 8) if on["inter"] else None, 8, w["loss_inter"] / Vh, B, Vh,
-                              P(self.G_mesh), P(m.rotations_hand.grad), P(m.translations_hand.grad), None, sb),
-               "rigid_bwd(hand)")
+                              P(self.G_mesh), P(m.rotations_hand.grad), P(m.translations_hand.grad), None,
+                              P(self.rigid_ws_h), sb), "rigid_bwd(hand)")
             ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
                              P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad), P(betas.grad),
                              P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb), "mano_bwd")
@@ -400,13 +402,20 @@ class FusedStepper:
         # summed with their weights inside the rigid backward
         main.wait_event(self.ev_pair)
         sc_obj = m.optimize_object_scale
-        tp, tw, tn = _lib.terms([(self.G_sil if on["sil"] else None, 1.0),
-                                 (self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),
+        tp, tw, tn = _lib.terms([(self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),
                                  (self.U_cono if on["con"] else None, w["loss_contact"]),
                                  (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0)])
-        ck(L.hm_rigid_bwd(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None, None,
-                          0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
-                          P(self.g_so_part) if sc_obj else None, sa), "rigid_bwd(obj)")
+        if on["sil"]:       # the silhouette term is gathered from the sweeps' per-corner gradients inside this launch
+            ck(L.hm_rigid_bwd_sil(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn,
+                                  L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
+                                  P(sctx.adj_items), P(self.vo), P(m.camintr_rois_object), 1.0, sctx.F, B, Vo,
+                                  P(m.rotations_object.grad), P(m.translations_object.grad),
+                                  P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), sa),
+               "rigid_bwd(obj) + silhouette gather")
+        else:
+            ck(L.hm_rigid_bwd(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
+                              None, 0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
+                              P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), sa), "rigid_bwd(obj)")
         main.wait_stream(side)               # join
         main.wait_stream(self.aux)
         if sc_obj:

@@ -17,6 +17,8 @@ _VP, _I, _F, _SZ, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_s
 _SIGNATURES = {
     "hm_sil_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
     "hm_sil_fwd": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_sil_parts": (_VP, [_VP, _I, _I, _I, _I]),
+    "hm_rigid_bwd_sil": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_sil_reduce": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "hm_depth_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_ordinal_depth_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
@@ -30,7 +32,8 @@ _SIGNATURES = {
     "hm_sil_read_idx_map": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_faces9": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_rigid_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
-    "hm_rigid_bwd": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "hm_rigid_bwd": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_rigid_workspace_bytes": (_SZ, [_I]),
     "hm_scale_by": (_I, [_VP, _VP, _L, _VP, _VP]),
     "hm_scale2_by": (_I, [_VP, _VP, _VP, _VP, _L, _VP, _VP]),
     "hm_lincomb4": (_I, [_VP, _F, _VP, _F, _VP, _F, _VP, _F, _L, _VP, _VP]),

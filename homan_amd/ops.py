@@ -252,6 +252,17 @@ def _scale_by(unit, g):
 
 
 # =============================================================================== rigid transform
+_RIGID_WS = {}
+
+
+def _rigid_workspace(N, device):
+    """Zero-initialised ticket / partials buffer of hm_rigid_bwd, one per (frames, device, stream)."""
+    key = (N, str(device), torch.cuda.current_stream().cuda_stream)
+    if key not in _RIGID_WS:
+        _RIGID_WS[key] = torch.zeros(_lib.lib().hm_rigid_workspace_bytes(N), dtype=torch.uint8, device=device)
+    return _RIGID_WS[key]
+
+
 class _RigidTransform(torch.autograd.Function):
     """reference homan/utils/geometry.py:9-27 + homan/utils/camera.py:108-139:
     verts = (s * mesh) @ rot6d_to_matrix(rot6d) + t, and the mesh-detached twin (same values; its gradient
@@ -283,7 +294,8 @@ class _RigidTransform(torch.autograd.Function):
         tp, tw, tn = _lib.terms([(g_full, 1.0)])
         _lib.check(_lib.lib().hm_rigid_bwd(_lib.ptr(mesh), _lib.ptr(rot6d), _lib.ptr(scale), ctx.abs_scale, tp, tw, tn,
                                            _lib.ptr(g_det), None, 0, 0.0, N, V, _lib.ptr(g_mesh), _lib.ptr(g_rot),
-                                           _lib.ptr(g_trans), _lib.ptr(g_sp), _lib.stream()), "hm_rigid_bwd")
+                                           _lib.ptr(g_trans), _lib.ptr(g_sp), _lib.ptr(_rigid_workspace(N, mesh.device)),
+                                           _lib.stream()), "hm_rigid_bwd")
         g_scale = g_sp.sum().reshape(scale.shape) if need_scale else None
         return g_mesh, g_rot, g_trans.view(ctx.trans_shape), g_scale, None
 

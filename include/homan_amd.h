@@ -51,7 +51,17 @@ int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, cons
 int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
                  const float* weights, int n_terms, const float* g_rigid, const float* g_frame, int frame_stride,
                  float frame_scale, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part,
-                 hipStream_t stream);
+                 void* workspace, hipStream_t stream);
+/* workspace of hm_rigid_bwd / hm_rigid_bwd_sil (zero-filled once; per-frame tickets reset themselves): with it the frame
+ * is split over ceil(V/256) workgroups and the last one finishes; NULL = one workgroup per frame. */
+size_t hm_rigid_workspace_bytes(int N);
+/* hm_rigid_bwd with the silhouette gradient as one more full term, gathered on the fly from the per-(face, corner) NDC
+ * gradients of the edge sweeps (sil_parts = hm_sil_parts(workspace) after an hm_sil_bwd called with grad_verts == NULL;
+ * adj_off / adj_items / cam_verts / K / orig_size / F as given to that call): no gather launch, no (N,V,3) round trip. */
+int hm_rigid_bwd_sil(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
+                     const float* weights, int n_terms, const float* sil_parts, const int* adj_off, const int* adj_items,
+                     const float* cam_verts, const float* K, float orig_size, int F, int N, int V, float* g_rot6d,
+                     float* g_trans, float* g_scale_part, void* workspace, hipStream_t stream);
 /* out = s[0] * in ;  out = s0[0]*a + s1[0]*b   (backward of the losses whose unit gradient is produced forward) */
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream);
 int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s1, long n, float* out,
@@ -107,7 +117,8 @@ int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss
 /* mode 1: upstream (1) = dL/d loss_out[0]; mode 2: same with upstream[0] > 0 guaranteed by the caller (the forward's
  * sweep planes are reused, one launch less); mode 0: grad_pooled (B,S,S) = dL/d pooled.  adj_off (V+1), adj_items (3F):
  * CSR vertex -> (face*3 + corner).  face_order: B*F int32 permutation of frame*F+face (visiting order of the edge
- * sweeps, expensive faces first) or NULL.  grad_verts (B,V,3) overwritten; grad_ndc (B,V,3) optional. */
+ * sweeps, expensive faces first) or NULL.  grad_verts (B,V,3) overwritten, or NULL to skip the vertex gather (the
+ * per-corner gradients stay in the workspace: hm_sil_parts / hm_rigid_bwd_sil); grad_ndc (B,V,3) optional. */
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
@@ -128,6 +139,8 @@ int hm_ordinal_depth_fwd(const float* d0, const float* d1, const float* a0, cons
 int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
                          const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
                          float* g1, hipStream_t stream);
+/* device pointer to the (B,F,3,2) per-(face, corner) NDC gradients left in `workspace` by the last hm_sil_bwd */
+const float* hm_sil_parts(const void* workspace, int B, int V, int F, int S);
 /* forward intermediates kept in the workspace (tests): face-index map (B,2S,2S) int32, packed NDC faces (B,F,9) */
 int hm_sil_read_idx_map(const void* workspace, int B, int V, int F, int S, int* out, hipStream_t stream);
 int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
