@@ -76,9 +76,17 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
                                                      float orig_size, const int* __restrict__ faces, int faces_bstride,
                                                      int B, int V, int F, int is, float* __restrict__ faces9,
                                                      FaceBox* __restrict__ boxes, unsigned char* __restrict__ owned,
-                                                     int* __restrict__ bin_cnt, int* __restrict__ bin_list)
+                                                     int* __restrict__ bin_cnt, int* __restrict__ bin_list,
+                                                     const float* __restrict__ rigid_rot6d,
+                                                     const float* __restrict__ rigid_trans,
+                                                     const float* __restrict__ rigid_scale, int rigid_abs)
 {
     __shared__ int s_cnt[SR_MAX], s_base[SR_MAX];
+    __shared__ float s_R[9];
+    // optional rigid transform of mesh-space `verts` (same arithmetic as hm_rigid_fwd, so the camera-space vertices the
+    // other losses get from that entry point are the very numbers rasterised here): the silhouette chain then does not
+    // wait for a separate transform launch
+    if (rigid_rot6d && threadIdx.x == 0) rot6d_to_mat(rigid_rot6d + blockIdx.y * 6, s_R);
     const int b = blockIdx.y, fi = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = fi < F;
     const int nsx = (is + (1 << SR_SHIFT) - 1) >> SR_SHIFT, nsr = nsx * nsx;
@@ -91,7 +99,20 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
         const int* fc = faces + (long)b * faces_bstride + 3 * fi;
         float f[9], r[9];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) project_vertex(verts + ((long)b * V + fc[k]) * 3, K + b * 9, orig_size, f + 3 * k);
+        for (int k = 0; k < 3; ++k) {
+            const float* mv = verts + ((long)b * V + fc[k]) * 3;
+            float cam[3] = {mv[0], mv[1], mv[2]};
+            if (rigid_rot6d) {
+                float sc = rigid_scale[0];
+                if (rigid_abs) sc = fabsf(sc);
+                const float x = sc * mv[0], y = sc * mv[1], z = sc * mv[2];
+                const float* t = rigid_trans + b * 3;
+                cam[0] = x * s_R[0] + y * s_R[3] + z * s_R[6] + t[0];
+                cam[1] = x * s_R[1] + y * s_R[4] + z * s_R[7] + t[1];
+                cam[2] = x * s_R[2] + y * s_R[5] + z * s_R[8] + t[2];
+            }
+            project_vertex(cam, K + b * 9, orig_size, f + 3 * k);
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) { r[3 * k] = f[3 * (2 - k)]; r[3 * k + 1] = f[3 * (2 - k) + 1]; r[3 * k + 2] = f[3 * (2 - k) + 2]; }
 #pragma unroll
@@ -1198,9 +1219,11 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+               const float* rigid_rot6d, const float* rigid_trans, const float* rigid_scale, int rigid_abs,
                void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && pooled && workspace);
+    HM_CHECK_ARG(!rigid_rot6d || (rigid_trans && rigid_scale));
     HM_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0);
     if (S % 16 != 0 || 2 * S > 8192 || 2L * F >= (1L << 30) || B >= 32768) return HM_ERR_UNSUPPORTED;
     HM_CHECK_ARG(faces_bstride == 0 || faces_bstride == 3 * F);
@@ -1208,7 +1231,8 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     const int is = 2 * S, ntiles = (S / 8) * (S / 8);
     int* bins = is <= (SR_MAX == 64 ? 1024 : 0) ? w.bin_cnt : nullptr;      // <= SR_MAX super-regions per frame
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, orig_size, faces,
-                       faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list);
+                       faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list, rigid_rot6d, rigid_trans,
+                       rigid_scale, rigid_abs);
     const bool fused = keep && ref;
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
@@ -1317,7 +1341,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     HM_CHECK_ARG(verts && faces && K && keep && ref && keep_sum && pooled && loss_out && workspace && reps > 0 && avg_ms);
     HM_CHECK_ARG(adj_off && adj_items && upstream && grad_verts);
     int rc = hm_sil_fwd(verts, faces, 0, K, B, V, F, S, 1.0f, 0.1f, 100.0f, keep, ref, keep_sum, pooled, loss_out,
-                        work_order, nullptr, workspace, stream);
+                        work_order, nullptr, nullptr, nullptr, nullptr, 0, workspace, stream);
     if (rc != HM_OK) return rc;
     rc = hm_sil_bwd(verts, K, B, V, F, S, 1.0f, 1e-3f, 1, upstream, nullptr, keep_sum, adj_off, adj_items, face_order,
                     grad_verts, nullptr, workspace, stream);
@@ -1330,14 +1354,16 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     // the forward's last workgroup emptied the super-region bins: fill them again and keep them across the timed launches
     int* bins = 2 * S <= 1024 ? w.bin_cnt : nullptr;
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, 1.0f, faces, 0, B, V, F,
-                       2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list);
+                       2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, 0);
     const bool cold = false;   // true: re-bin before every launch (times setup + raster with the reset tickets)
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i) {
         if (cold) {
             (void)hipMemsetAsync(w.bin_cnt, 0, (size_t)B * SR_MAX * 4, stream);
             hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, 1.0f, faces, 0, B, V, F,
-                               2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list);
+                               2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list, (const float*)nullptr,
+                               (const float*)nullptr, (const float*)nullptr, 0);
         }
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,

@@ -312,14 +312,13 @@ class FusedStepper:
         sctx, cctx = m.losses.sil_ctx, m.collision_ctx
         pca, rot, betas, mtr = m.mano_pca_pose, m.mano_rot, m.mano_betas, m.mano_trans
         side.wait_stream(main)
-        # ---------------- A: object forward -> silhouettes forward + backward (the critical path: nothing else rides it)
-        ck(L.hm_rigid_fwd(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object), P(m.int_scales_object),
-                          1, B, Vo, None, P(self.vo), sa), "rigid_fwd(obj)")
-        self.ev_vo.record(main)
+        # ---------------- A: silhouettes forward + backward (the critical chain: nothing else rides it; the object's rigid
+        # transform is applied inside the face setup, the other losses get the vertices from the side stream)
         if on["sil"]:
-            ck(L.hm_sil_fwd(P(self.vo), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
+            ck(L.hm_sil_fwd(P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
                             self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
-                            None, P(self.pooled), None, P(sctx.work_order), None, P(sctx.workspace), sa), "sil_fwd")
+                            None, P(self.pooled), None, P(sctx.work_order), None, P(m.rotations_object),
+                            P(m.translations_object), P(m.int_scales_object), 1, P(sctx.workspace), sa), "sil_fwd")
             self.ev_sil.record(main)         # the loss / IoU reduction runs on the side stream
             ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
                             2 if self.lw["lw_sil_obj"] > 0 else 1,
@@ -327,6 +326,8 @@ class FusedStepper:
                             P(sctx.face_order), None, None, P(sctx.workspace), sa), "sil_bwd")    # no vertex gather
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
+            ck(L.hm_rigid_fwd(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
+                              P(m.int_scales_object), 1, B, Vo, None, P(self.vo), sb), "rigid_fwd(obj)")
             ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
                              P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
                              P(self.mano_state), sb),
@@ -350,7 +351,6 @@ class FusedStepper:
                 if on["v2d"]:
                     ck(L.hm_v2d_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
                                     P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, sb), "v2d")
-            side.wait_event(self.ev_vo)
             if on["smooth"]:
                 ck(L.hm_smooth_fwd(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, sb),
                    "smooth(obj)")

@@ -106,11 +106,15 @@ int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const f
  *     workgroups (a permutation; expensive ones first), or NULL for frame-major order.
  *   pooled_depth (B,S,S) optional: the depth image nr.Renderer.render returns beside the silhouette (reference
  *     homan/homan.py:391,406): z-buffer (zfar where empty), flipped, 2x2 average pooled.
- *   S must be a multiple of 16 (32 and <= 256 for the silhouette backward). */
+ *   rigid_rot6d (B,3,2) / rigid_trans (B,3) / rigid_scale (1) / rigid_abs optional: `verts` are then mesh-space and the
+ *     rigid transform of hm_rigid_fwd is applied in the face-setup kernel (same arithmetic), so the silhouette chain does
+ *     not wait for a separate transform launch; hm_sil_bwd still takes the camera-space vertices.
+ *   S must be a multiple of 16 (32 and <= 512 for the silhouette backward). */
 size_t hm_sil_workspace_bytes(int B, int V, int F, int S);
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+               const float* rigid_rot6d, const float* rigid_trans, const float* rigid_scale, int rigid_abs,
                void* workspace, hipStream_t stream);
 /* deferred loss / IoU reduction of an hm_sil_fwd called with keep/ref but loss_out == NULL (off the critical path) */
 int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, void* workspace, hipStream_t stream);
