@@ -646,6 +646,8 @@ __device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, f
 struct SweepSrc { int d1; float g; int owner; };
 #define SWEEP_CUMW 16           // cumulative-count slots per line (is <= 1024)
 
+// 16 lanes per line (one DPP row), 16 lines per workgroup: a wave per line spent its life waiting on three dependent
+// memory round trips with 8 of 64 lanes loading; four lines per wave quarter the number of waves in flight.
 __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restrict__ rowneg,
                                                    const unsigned short* __restrict__ colneg,
                                                    const float* __restrict__ gimg, const float* __restrict__ dimg,
@@ -654,27 +656,33 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    const int* __restrict__ idx_map, int B, int S,
                                                    SweepSrc* __restrict__ srcs, unsigned short* __restrict__ cum)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ unsigned long long s_w[16][SWEEP_CUMW];
+    __shared__ int s_ex[16][SWEEP_CUMW];
+    const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int is = 2 * S, wpl = is / 64;
-    const long L = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    if (L >= 4L * B * is) return;
+    const long L = (long)blockIdx.x * 16 + grp;
+    const bool valid = L < 4L * B * is;
     // L = ((pl * 2 + axis) * B + b) * is + d0
     const int d0 = (int)(L % is), b = (int)((L / is) % B), pa = (int)(L / ((long)is * B));
     const int axis = pa & 1, pl = pa >> 1;
     const long plane_words = (long)B * is * wpl;
-    const unsigned long long* line = reinterpret_cast<const unsigned long long*>(axis == 0 ? colneg : rowneg) +
-                                     pl * plane_words + ((long)b * is + d0) * wpl;
-    const unsigned long long mine = lane < wpl ? line[lane] : 0ull;
+    unsigned long long mine = 0ull;
+    if (valid && l < wpl)
+        mine = (reinterpret_cast<const unsigned long long*>(axis == 0 ? colneg : rowneg) + pl * plane_words +
+                ((long)b * is + d0) * wpl)[l];
     // exclusive prefix of the word popcounts (wpl <= 16 words: one 16-lane row scan)
-    int c = __popcll(mine);
+    const int c = __popcll(mine);
     int incl = c;
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);    // row_shr:1
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);    // row_shr:2
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);    // row_shr:4
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);    // row_shr:8
     const int excl = incl - c;
-    if (lane < SWEEP_CUMW) cum[L * SWEEP_CUMW + lane] = (unsigned short)excl;
-    if (__builtin_amdgcn_readlane(incl, 15) == 0) return;
+    if (valid) cum[L * SWEEP_CUMW + l] = (unsigned short)excl;
+    s_w[grp][l] = mine;
+    s_ex[grp][l] = excl;
+    __syncthreads();
+    if (!valid || s_ex[grp][SWEEP_CUMW - 1] + __popcll(s_w[grp][SWEEP_CUMW - 1]) == 0) return;
     // fused loss, positive upstream: g = upstream * 2 * dimg / keep_sum / B (the arithmetic of k_bwd_masks), no gimg pass
     const bool from_dimg = mode == 2 || (mode == 1 && upstream[0] > 0.0f);
     const float* gi = (from_dimg ? dimg : gimg) + (long)b * S * S;
@@ -682,13 +690,14 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     const int* idx = idx_map + (long)b * is * is;
     SweepSrc* out = srcs + L * is;
     for (int k = 0; k < wpl; ++k) {
-        const unsigned lo32 = (unsigned)__builtin_amdgcn_readlane((int)(mine & 0xffffffffull), k);
-        const unsigned hi32 = (unsigned)__builtin_amdgcn_readlane((int)(mine >> 32), k);
-        const unsigned long long w = ((unsigned long long)hi32 << 32) | lo32;
+        const unsigned long long w = s_w[grp][k];
         if (w == 0ull) continue;
-        const int base = __builtin_amdgcn_readlane(excl, k);
-        if ((w >> lane) & 1ull) {
-            const int d1 = (k << 6) + lane;
+        const int base = s_ex[grp][k];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int pos = 16 * q + l;
+            if (!((w >> pos) & 1ull)) continue;
+            const int d1 = (k << 6) + pos;
             const int xi = axis ? d1 : d0, yi = axis ? d0 : d1;
             SweepSrc r;
             r.d1 = d1;
@@ -696,7 +705,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
             if (from_dimg) g = gs * g / ks / (float)B;
             r.g = 0.25f * g;
             r.owner = pl ? idx[(long)yi * is + xi] : -1;
-            out[base + __popcll(w & ((1ull << lane) - 1ull))] = r;
+            out[base + __popcll(w & ((1ull << pos) - 1ull))] = r;
         }
     }
 }
@@ -1274,7 +1283,7 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
         hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                            mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                            w.rowneg, w.colneg);
-    hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S * 64, 256)), dim3(256), 0, stream, w.rowneg, w.colneg,
+    hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.rowneg, w.colneg,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.cum);
     hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), SWEEP_BLOCKS)), dim3(256), 0, stream, w.faces9, w.boxes,
                        w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, eps, w.parts, w.owned, face_order);
@@ -1386,7 +1395,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     avg_ms[1] = ms / (float)reps;
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S * 64, 256)), dim3(256), 0, stream, w.rowneg, w.colneg,
+        hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.rowneg, w.colneg,
                            w.gimg, w.dimg, 1, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.cum);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
