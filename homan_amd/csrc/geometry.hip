@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
                                                    unsigned int* __restrict__ frame_cnt)
 {
     __shared__ float R[9];
-    __shared__ float red[16];
+    __shared__ float red13[16 * 13];
     __shared__ int s_flag;
     const int n = blockIdx.x;
     if (threadIdx.x == 0) {
@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
     }
     float tot[13];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) tot[k] = hm_block_sum(acc[k], red);
+    for (int k = 0; k < 13; ++k) tot[k] = acc[k];
+    hm_block_sum_n<13>(tot, red13);
     if (gridDim.y > 1) {
         float* rec = partials + ((long)n * gridDim.y + blockIdx.y) * 16;
         if (threadIdx.x == 0) {

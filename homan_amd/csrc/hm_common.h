@@ -77,6 +77,27 @@ __device__ __forceinline__ float hm_block_sum(float v, float* red)
     for (int i = 0; i < nw; ++i) t += red[i];
     return t;
 }
+// N block-wide sums with two barriers in all (hm_block_sum costs two per value).  `red` must hold >= 16 * N floats;
+// results valid in every thread, same fixed combination order as hm_block_sum.
+template <int N>
+__device__ __forceinline__ void hm_block_sum_n(float (&v)[N], float* red)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = hm_wave_sum(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) red[k * 16 + w] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        float t = 0.f;
+        for (int i = 0; i < nw; ++i) t += red[k * 16 + i];
+        v[k] = t;
+    }
+}
 __device__ __forceinline__ float hm_block_min(float v, float* red)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
