@@ -238,8 +238,10 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_need(const float* __restric
 }
 
 // ------------------------------------------------------------------ distance pass.  grid (SDF_DIST_WGS, B, 2 grids)
-// wave w of grid (k, b) evaluates the listed voxels w, w + nwaves, ...: unsigned distance to the mesh = min over the
-// triangles, seeded by the nearest vertex, triangles pruned by the distance to their bounding box.
+// workgroup w of grid (k, b) evaluates the listed voxels w, w + SDF_DIST_WGS, ...: unsigned distance to the mesh = min
+// over the triangles, seeded by the nearest vertex, triangles pruned by the distance to their bounding box.  All 256
+// threads share one voxel: a single wave walking the 3000 packed triangles is ~70 dependent memory round trips (60 us for
+// ONE voxel); spread over the workgroup, with the record loads of two rounds in flight, it is a dozen.
 #define SDF_DIST_WGS 16
 __global__ __launch_bounds__(SDF_THREADS) void k_sdf_dist(const float* __restrict__ vn0, int V0, int F0,
                                                            const float* __restrict__ vn1, int V1, int F1, int B,
@@ -247,48 +249,44 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_dist(const float* __restric
                                                            const int* __restrict__ need_cnt, const int* __restrict__ need_list,
                                                            float* __restrict__ phi)
 {
-    const int b = blockIdx.y, k = blockIdx.z, lane = threadIdx.x & 63;
+    __shared__ float red[16];
+    const int b = blockIdx.y, k = blockIdx.z, t = threadIdx.x;
     const long g = (long)k * B + b;
     const int n = need_cnt[g];
-    const int wave = blockIdx.x * (SDF_THREADS / 64) + (threadIdx.x >> 6), nwaves = SDF_DIST_WGS * (SDF_THREADS / 64);
-    if (wave >= n) return;
+    if ((int)blockIdx.x >= n) return;
     const int Vk = k == 0 ? V0 : V1, Fk = k == 0 ? F0 : F1;
     const float* vnk = (k == 0 ? vn0 : vn1) + (long)b * Vk * 3;
     const float4* tk = reinterpret_cast<const float4*>((k == 0 ? tris0 : tris1) + (long)b * Fk * SDF_TRI_DW);
-    for (int e = wave; e < n; e += nwaves) {
+    for (int e = blockIdx.x; e < n; e += SDF_DIST_WGS) {
         const int vox = need_list[g * (SDF_N * SDF_N * SDF_N) + e];
         const float ctr[3] = {voxel_centre(vox % SDF_N), voxel_centre((vox / SDF_N) % SDF_N), voxel_centre(vox / (SDF_N * SDF_N))};
         // seed: the distance to the nearest mesh vertex bounds the distance to the surface from above
         float dmin = 1e30f;
-        for (int v = lane; v < Vk; v += 64) {
+#pragma unroll 4
+        for (int v = t; v < Vk; v += SDF_THREADS) {
             const float dx = vnk[3 * v] - ctr[0], dy = vnk[3 * v + 1] - ctr[1], dz = vnk[3 * v + 2] - ctr[2];
             dmin = fminf(dmin, dx * dx + dy * dy + dz * dz);
         }
-        dmin = sqrtf(hm_wave_min(dmin)) * 1.0001f;
-        // (wave-uniform trip count: the DPP reductions inside need all 64 lanes -- a lane that has left the loop would
-        //  feed them whatever its registers last held)
-        for (int f0 = 0, it = 0; f0 < Fk; f0 += 64, ++it) {
-            const int f = f0 + lane;
-            if (f < Fk) {
-                const float4 r0 = tk[4 * f], r1 = tk[4 * f + 1], r2 = tk[4 * f + 2], r3 = tk[4 * f + 3];
-                // distance to the triangle's bounding box bounds the distance to the triangle from below; a triangle
-                // that cannot beat the current minimum is skipped (the minimum itself is unchanged)
-                const float lo[3] = {r2.y, r2.z, r2.w}, hi[3] = {r3.x, r3.y, r3.z};
-                float lb2 = 0.f;
+        dmin = sqrtf(hm_block_min(dmin, red)) * 1.0001f;
+#pragma unroll 2
+        for (int f = t; f < Fk; f += SDF_THREADS) {
+            const float4 r0 = tk[4 * f], r1 = tk[4 * f + 1], r2 = tk[4 * f + 2], r3 = tk[4 * f + 3];
+            // distance to the triangle's bounding box bounds the distance to the triangle from below; a triangle that
+            // cannot beat the current minimum is skipped (the minimum itself is unchanged)
+            const float lo[3] = {r2.y, r2.z, r2.w}, hi[3] = {r3.x, r3.y, r3.z};
+            float lb2 = 0.f;
 #pragma unroll
-                for (int cc = 0; cc < 3; ++cc) {
-                    const float dd = fmaxf(fmaxf(lo[cc] - ctr[cc], ctr[cc] - hi[cc]), 0.f);
-                    lb2 += dd * dd;
-                }
-                if (lb2 * 0.9999f <= dmin * dmin) {
-                    const float q1[3] = {r0.x, r0.y, r0.z}, q2[3] = {r0.w, r1.x, r1.y}, q3[3] = {r1.z, r1.w, r2.x};
-                    dmin = fminf(dmin, point_triangle_distance(ctr, q1, q2, q3));
-                }
+            for (int cc = 0; cc < 3; ++cc) {
+                const float dd = fmaxf(fmaxf(lo[cc] - ctr[cc], ctr[cc] - hi[cc]), 0.f);
+                lb2 += dd * dd;
             }
-            if ((it & 7) == 7) dmin = hm_wave_min(dmin);     // share the bound across the lanes
+            if (lb2 * 0.9999f <= dmin * dmin) {
+                const float q1[3] = {r0.x, r0.y, r0.z}, q2[3] = {r0.w, r1.x, r1.y}, q3[3] = {r1.z, r1.w, r2.x};
+                dmin = fminf(dmin, point_triangle_distance(ctr, q1, q2, q3));
+            }
         }
-        dmin = hm_wave_min(dmin);
-        if (lane == 0) phi[g * (SDF_N * SDF_N * SDF_N) + vox] = dmin;
+        dmin = hm_block_min(dmin, red);       // (block-uniform: every thread has left the loops)
+        if (t == 0) phi[g * (SDF_N * SDF_N * SDF_N) + vox] = dmin;
     }
 }
 
