@@ -83,10 +83,15 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
     const unsigned nblk = gridDim.x * gridDim.y;
     if (threadIdx.x == 0) hm_partial_store(blockmin + b * gridDim.x + blockIdx.x, bm);
     if (hm_last_block(counter, nblk, &s_flag)) {
+        // all block minima requested at once (one agent-scope load per thread), then min over a frame's chunks, max over
+        // the frames
+        float* s_bm = &s_d[0][0];
+        for (unsigned i2 = threadIdx.x; i2 < nblk; i2 += blockDim.x) s_bm[i2] = hm_partial_load(blockmin + i2);
+        __syncthreads();
         float mx = -3.4e38f;
         for (int bb = threadIdx.x; bb < B; bb += blockDim.x) {
             float m = 3.4e38f;
-            for (unsigned c = 0; c < gridDim.x; ++c) m = fminf(m, hm_partial_load(blockmin + bb * gridDim.x + c));
+            for (unsigned c = 0; c < gridDim.x; ++c) m = fminf(m, s_bm[bb * gridDim.x + c]);
             mx = fmaxf(mx, sqrtf(m));
         }
         mx = hm_block_max(mx, red);
