@@ -22,6 +22,7 @@ struct AdamSlot {
 __global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots, int* __restrict__ step, float beta1,
                                                float beta2, float eps, int zero_grad)
 {
+    HM_LATENCY_KERNEL();
     const AdamSlot s = slots[blockIdx.y];
     const int step_now = __builtin_nontemporal_load(step);
     const double t = (double)(step_now + 1);
@@ -65,6 +66,7 @@ __global__ void k_log(const float* __restrict__ src, int n, const int* __restric
 __global__ void k_log_total(float* __restrict__ vals, const float* __restrict__ w, int n, const int* __restrict__ step,
                             int max_steps, float* __restrict__ log)
 {
+    HM_LATENCY_KERNEL();
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         float t = 0.f;
         for (int i = 0; i < n; ++i)

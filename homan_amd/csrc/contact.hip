@@ -27,6 +27,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
                                                        float* __restrict__ blockmin, unsigned int* counter,
                                                        float* __restrict__ metric_out)
 {
+    HM_LATENCY_KERNEL();
     __shared__ float s_d[NN_WAVES][NN_HV];
     __shared__ int s_i[NN_WAVES][NN_HV];
     __shared__ float red[16];
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_hand(const float* __rest
                                                               float* __restrict__ partials, unsigned int* counter,
                                                               float* __restrict__ out)
 {
+    HM_LATENCY_KERNEL();
     __shared__ float red[16];
     __shared__ int s_flag;
     const int b = blockIdx.x;
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_hand(const float* __rest
 __global__ __launch_bounds__(NN_THREADS) void k_contact_obj(const int* __restrict__ nn_idx, const float* __restrict__ g_hand,
                                                              int B, int Vh, int Vo, float* __restrict__ g_obj)
 {
+    HM_LATENCY_KERNEL();
     __shared__ unsigned long long acc[CONTACT_MAX_VO * 3];
     const int b = blockIdx.x;
     for (int i = threadIdx.x; i < 3 * Vo; i += NN_THREADS) acc[i] = 0ull;

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
                                                    float* __restrict__ g_scale_part, float* __restrict__ partials,
                                                    unsigned int* __restrict__ frame_cnt)
 {
+    HM_LATENCY_KERNEL();
     __shared__ float R[9];
     __shared__ float red13[16 * 13];
     __shared__ int s_flag;

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__
                                                         float expansion, float zthresh, float* __restrict__ frame_rec,
                                                         unsigned int* counter, float* __restrict__ out)
 {
+    HM_LATENCY_KERNEL();
     __shared__ float red[16];
     __shared__ int s_flag;
     const int b = blockIdx.x;
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__
 __global__ void k_inter_bwd(const float* __restrict__ frame_rec, const float* __restrict__ upstream, int B, int Vh,
                             int Vo, float* __restrict__ g_hand, float* __restrict__ g_obj)
 {
+    HM_LATENCY_KERNEL();
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nh = (long)B * Vh * 3, no = (long)B * Vo * 3;
     const float up = upstream[0];

@@ -546,6 +546,7 @@ __global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ pa
                                                      const float* __restrict__ keep_sum, float* __restrict__ frame_rec,
                                                      unsigned int* counter, float* __restrict__ out)
 {
+    HM_LATENCY_KERNEL();
     __shared__ float red[16];
     __shared__ int s_flag;
     const int b = blockIdx.x;

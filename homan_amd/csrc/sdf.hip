@@ -99,6 +99,7 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_boxes(const float* __restri
                                                             unsigned int* __restrict__ masks, unsigned int* __restrict__ needm,
                                                             int* __restrict__ need_cnt)
 {
+    HM_LATENCY_KERNEL();
     __shared__ float red[16];
     const int b = blockIdx.x, k = blockIdx.y;
     const int V = k == 0 ? V0 : V1;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_tris(const float* __restric
                                                            float* __restrict__ tris0, float* __restrict__ tris1,
                                                            unsigned int* __restrict__ masks)
 {
+    HM_LATENCY_KERNEL();
     const int b = blockIdx.y, k = blockIdx.z;
     const int V = k == 0 ? V0 : V1, F = k == 0 ? F0 : F1;
     const int fi = blockIdx.x * SDF_THREADS + threadIdx.x;
@@ -219,6 +221,7 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_need(const float* __restric
                                                            unsigned int* __restrict__ needm, int* __restrict__ need_cnt,
                                                            int* __restrict__ need_list)
 {
+    HM_LATENCY_KERNEL();
     const int b = blockIdx.y, pair = blockIdx.z, k = pair;          // SDF owner k, sampled set 1 - k
     const int Vl = pair == 0 ? V1 : V0;
     const int i = blockIdx.x * SDF_THREADS + threadIdx.x;
@@ -249,6 +252,7 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_dist(const float* __restric
                                                            const int* __restrict__ need_cnt, const int* __restrict__ need_list,
                                                            float* __restrict__ phi)
 {
+    HM_LATENCY_KERNEL();
     __shared__ float red[16];
     const int b = blockIdx.y, k = blockIdx.z, t = threadIdx.x;
     const long g = (long)k * B + b;
@@ -300,6 +304,7 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(const float* __restr
                                                              float* __restrict__ g1, float* __restrict__ partials,
                                                              unsigned int* counter, float* __restrict__ out)
 {
+    HM_LATENCY_KERNEL();
     __shared__ float red[16];
     __shared__ int s_flag;
     const int b = blockIdx.y, pair = blockIdx.z, k = pair;
