@@ -252,7 +252,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
     float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned,
     float* __restrict__ pooled_depth, unsigned short* __restrict__ rowneg, unsigned short* __restrict__ colneg,
-    int* __restrict__ bin_cnt, const int* __restrict__ bin_list, unsigned int* __restrict__ done, int reset_bins)
+    int* __restrict__ bin_cnt, const int* __restrict__ bin_list, unsigned int* __restrict__ done, int reset_bins,
+    unsigned char* __restrict__ region_state, int persistent)
 {
     __shared__ unsigned long long zb[32 * 32];
     __shared__ int cand[2 * CAND_CAP];
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
 #pragma unroll
     for (int k = 0; k < 4; ++k) zb[tid + 256 * k] = zb_empty;
 
+    int had_any = 0;       // block-uniform: some face overlaps this region
     const uint2* bx = reinterpret_cast<const uint2*>(boxes) + (long)b * F;
     // faces to scan: the bin of this region's 128x128-sample super-region (or the whole frame without bins)
     const int nsx = (is + (1 << SR_SHIFT) - 1) >> SR_SHIFT;
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         }
         __syncthreads();
         const int n = cand_n;
+        had_any |= n;
         for (int e0 = 0; e0 < n; e0 += RB_PASS) {
             // ---- one thread per candidate: face record + number of 4x4 blocks of (box & region)
             int units = 0;
@@ -480,6 +483,14 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
             atomicExch(done + slot, 0u);
         }
     }
+
+    // An empty region whose outputs already hold the empty pattern has nothing to write: ~60 % of the regions of a clip
+    // are background in every iteration, and their epilogues (loads of the loss inputs, ~6 KB of stores) were a quarter
+    // of the kernel.  Only valid when the caller keeps passing the same output / loss-input buffers (`persistent`).
+    unsigned char* rstate = region_state + (long)b * regions_x * regions_x + region;
+    if (persistent && !had_any && *rstate == 1) return;
+    __syncthreads();          // every thread has read the state before thread 0 rewrites it below
+    if (tid == 0) *rstate = (persistent && !had_any) ? 1 : 0;
 
     // ---- epilogue: this lane's output pixel and its 2x2 samples (flip: output row r <-> sample rows is-1-2r-dy)
     const int r = ty * HM_TILE + (lane >> 3), c = tx * HM_TILE + (lane & 7);
@@ -1186,6 +1197,7 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
     n += al256((size_t)B * F * 24 * 4);         // parts
     n += al256((size_t)B * F * 2);              // owned
     n += al256((size_t)B * SR_MAX * 8);                        // super-region bin counters + their ticket words
+    n += al256((size_t)B * (S / 16) * (S / 16));               // per-region "outputs hold the empty pattern" flags
     n += al256((size_t)B * SR_MAX * F * 4);                    // super-region face lists (worst case: every face in every bin)
     n += al256(4 * (size_t)B * is * SWEEP_CUMW * 2);            // per-line cumulative source counts
     n += al256(4 * (size_t)B * is * is * sizeof(SweepSrc));     // per-line source arrays (2 planes x 2 orientations)
@@ -1196,7 +1208,8 @@ struct SilWs {
     unsigned int* counter; float* frame_rec;
     float* ndc; float* faces9; FaceBox* boxes; int* idx_map; unsigned short* alpha16; float* dimg;
     float* partials; float* gimg; unsigned short* rowneg; unsigned short* colneg; float* parts;
-    unsigned char* owned; int* bin_cnt; unsigned int* bin_done; int* bin_list; unsigned short* cum; SweepSrc* srcs;
+    unsigned char* owned; int* bin_cnt; unsigned int* bin_done; unsigned char* region_state; int* bin_list;
+    unsigned short* cum; SweepSrc* srcs;
 };
 static SilWs carve(void* ws, int B, int V, int F, int S)
 {
@@ -1218,6 +1231,7 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.parts = (float*)p; p += al256((size_t)B * F * 24 * 4);
     w.owned = (unsigned char*)p; p += al256((size_t)B * F * 2);
     w.bin_cnt = (int*)p; w.bin_done = (unsigned int*)(p + (size_t)B * SR_MAX * 4); p += al256((size_t)B * SR_MAX * 8);
+    w.region_state = (unsigned char*)p; p += al256((size_t)B * (S / 16) * (S / 16));
     w.bin_list = (int*)p; p += al256((size_t)B * SR_MAX * F * 4);
     w.cum = (unsigned short*)p; p += al256(4 * (size_t)B * is * SWEEP_CUMW * 2);
     w.srcs = (SweepSrc*)p;
@@ -1230,7 +1244,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
                const float* rigid_rot6d, const float* rigid_trans, const float* rigid_scale, int rigid_abs,
-               void* workspace, hipStream_t stream)
+               int persistent_outputs, void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && pooled && workspace);
     HM_CHECK_ARG(!rigid_rot6d || (rigid_trans && rigid_scale));
@@ -1247,7 +1261,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.rowneg, w.colneg, bins,
-                       w.bin_list, w.bin_done, 1);
+                       w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs);
     if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            w.counter, loss_out);
@@ -1351,7 +1365,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     HM_CHECK_ARG(verts && faces && K && keep && ref && keep_sum && pooled && loss_out && workspace && reps > 0 && avg_ms);
     HM_CHECK_ARG(adj_off && adj_items && upstream && grad_verts);
     int rc = hm_sil_fwd(verts, faces, 0, K, B, V, F, S, 1.0f, 0.1f, 100.0f, keep, ref, keep_sum, pooled, loss_out,
-                        work_order, nullptr, nullptr, nullptr, nullptr, 0, workspace, stream);
+                        work_order, nullptr, nullptr, nullptr, nullptr, 0, 0, workspace, stream);
     if (rc != HM_OK) return rc;
     rc = hm_sil_bwd(verts, K, B, V, F, S, 1.0f, 1e-3f, 1, upstream, nullptr, keep_sum, adj_off, adj_items, face_order,
                     grad_verts, nullptr, workspace, stream);
@@ -1378,7 +1392,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                            w.partials, work_order, w.owned, (float*)nullptr, w.rowneg, w.colneg, bins, w.bin_list,
-                           w.bin_done, cold ? 1 : 0);
+                           w.bin_done, cold ? 1 : 0, w.region_state, 0);
     }
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);

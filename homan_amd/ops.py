@@ -106,7 +106,7 @@ class _SilhouetteLoss(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, _lib.ptr(keep), _lib.ptr(ref), _lib.ptr(keep_sum),
-            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.work_order), None, None, None, None, 0,
+            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.work_order), None, None, None, None, 0, 0,
             _lib.ptr(sctx.workspace), _lib.stream()),
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K, keep_sum)
@@ -137,7 +137,7 @@ class _SilhouetteRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.work_order), None, None, None, None, 0, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
+            _lib.ptr(sctx.work_order), None, None, None, None, 0, 0, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
         return pooled
@@ -178,7 +178,7 @@ class _DepthRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.work_order), _lib.ptr(depth), None, None, None, 0, _lib.ptr(sctx.workspace), _lib.stream()),
+            _lib.ptr(sctx.work_order), _lib.ptr(depth), None, None, None, 0, 0, _lib.ptr(sctx.workspace), _lib.stream()),
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size

@@ -109,13 +109,16 @@ int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const f
  *   rigid_rot6d (B,3,2) / rigid_trans (B,3) / rigid_scale (1) / rigid_abs optional: `verts` are then mesh-space and the
  *     rigid transform of hm_rigid_fwd is applied in the face-setup kernel (same arithmetic), so the silhouette chain does
  *     not wait for a separate transform launch; hm_sil_bwd still takes the camera-space vertices.
+ *   persistent_outputs != 0: the caller passes the SAME pooled / pooled_depth / keep / ref buffers as in the previous call on
+ *     this workspace (a fixed optimisation loop); regions that were background then and are background now are not
+ *     rewritten.  0 = every output is written.
  *   S must be a multiple of 16 (32 and <= 512 for the silhouette backward). */
 size_t hm_sil_workspace_bytes(int B, int V, int F, int S);
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
                const float* rigid_rot6d, const float* rigid_trans, const float* rigid_scale, int rigid_abs,
-               void* workspace, hipStream_t stream);
+               int persistent_outputs, void* workspace, hipStream_t stream);
 /* deferred loss / IoU reduction of an hm_sil_fwd called with keep/ref but loss_out == NULL (off the critical path) */
 int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, void* workspace, hipStream_t stream);
 /* mode 1: upstream (1) = dL/d loss_out[0]; mode 2: same with upstream[0] > 0 guaranteed by the caller (the forward's

@@ -137,3 +137,48 @@ def test_fused_loss_matches_oracle_end_to_end(weight):
     scale = vo.grad.abs().max()
     err = ((vh.grad.cpu() - vo.grad) / scale).abs()
     assert err.max() < 2e-2 and err.mean() < 1e-4, (err.max(), err.mean())
+
+
+def test_persistent_outputs_skip_is_invisible():
+    """hm_sil_fwd(persistent_outputs=1) leaves background regions untouched when they were background in the previous
+    call: a sequence in which the object wanders across the raster (regions turn empty, covered and empty again) must give
+    the same silhouettes, loss, index map and fused-loss image as fresh full-write calls."""
+    from homan_amd import lib as hlib
+    from homan_amd import ops
+    dev = torch.device("cuda")
+    B, S = 3, 64
+    verts, faces, K, V = _scene(B=B, S=S, obj="cube", seed=5)
+    K = K.clone()
+    K[:, 0, 0] = K[:, 1, 1] = 1.2                          # small object: most regions are background
+    keep = torch.ones(B, S, S)
+    ref = torch.zeros(B, S, S)
+    ref[:, 20:44, 20:44] = 1.0
+    keep_sum = keep.sum().reshape(1)
+    L, P = hlib.lib(), hlib.ptr
+    F = faces.shape[1]
+
+    def call(sctx, v, pooled, out, persistent):
+        hlib.check(L.hm_sil_fwd(P(v), P(sctx.faces), 0, P(Kd), B, V, F, S, 1.0, 0.1, 100.0, P(keepd), P(refd), P(ksd),
+                                P(pooled), P(out), P(sctx.work_order), None, None, None, None, 0, persistent,
+                                P(sctx.workspace), hlib.stream()), "hm_sil_fwd")
+
+    Kd, keepd, refd, ksd = K.to(dev), keep.to(dev), ref.to(dev), keep_sum.to(dev)
+    sp = ops.SilhouetteContext(faces.to(dev), V, B, S, dev)             # persistent sequence
+    pooled_p, out_p = torch.full((B, S, S), 7.0, device=dev), torch.zeros(2, device=dev)
+    shifts = [(0.0, 0.0), (0.12, 0.0), (0.12, 0.1), (-0.1, 0.1), (0.0, 0.0), (0.0, 0.0), (0.3, 0.3), (0.0, -0.12)]
+    for step, (dx, dy) in enumerate(shifts):
+        v = (verts + torch.tensor([dx, dy, 0.0])).to(dev).contiguous()
+        call(sp, v, pooled_p, out_p, 1)
+        sf = ops.SilhouetteContext(faces.to(dev), V, B, S, dev)         # fresh, full-write reference
+        pooled_f, out_f = torch.empty(B, S, S, device=dev), torch.zeros(2, device=dev)
+        call(sf, v, pooled_f, out_f, 0)
+        assert torch.equal(pooled_p, pooled_f), step
+        assert torch.equal(out_p, out_f), step
+        assert torch.equal(sp.idx_map(), sf.idx_map()), step
+        # the backward consumes dimg and the sweep planes from the workspace: same gradients
+        gp, gf = torch.empty(B, V, 3, device=dev), torch.empty(B, V, 3, device=dev)
+        one = torch.ones(1, device=dev)
+        for sc, g in ((sp, gp), (sf, gf)):
+            hlib.check(L.hm_sil_bwd(P(v), P(Kd), B, V, F, S, 1.0, 1e-3, 1, P(one), None, P(ksd), P(sc.adj_off),
+                                    P(sc.adj_items), None, P(g), None, P(sc.workspace), hlib.stream()), "hm_sil_bwd")
+        assert torch.equal(gp, gf), step
