@@ -1392,7 +1392,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                            w.partials, work_order, w.owned, (float*)nullptr, w.rowneg, w.colneg, bins, w.bin_list,
-                           w.bin_done, cold ? 1 : 0, w.region_state, 0);
+                           w.bin_done, cold ? 1 : 0, w.region_state, 1);      // steady state of a fixed loop: background regions skipped
     }
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
