@@ -196,26 +196,27 @@ __device__ __forceinline__ unsigned spread8(unsigned x)      // bit k of x -> bi
     x = (x | (x << 1)) & 0x5555u;
     return x;
 }
-__device__ __forceinline__ void emit_planes(const unsigned long long (&cov)[4], bool neg, bool pos, int b, int B, int is,
+// nb / pb [2*dy+dx] = ballots of "g < 0" / "g > 0" per sample (all four equal when g lives on the pooled grid).
+__device__ __forceinline__ void emit_planes(const unsigned long long (&cov)[4], const unsigned long long (&nb)[4],
+                                            const unsigned long long (&pb)[4], int b, int B, int is,
                                             int tx, int ty, int lane, unsigned short* __restrict__ rowneg,
                                             unsigned short* __restrict__ colneg)
 {
     const long plane = (long)B * is * (is / 16);
-    const unsigned long long nb = __ballot(neg), pb = __ballot(pos);
     // lanes 0..15: row word of sample row (rr2 = l>>1, dy = l&1), plane 0 ; lanes 16..31: same for plane 1 ;
     // lanes 32..47: column word of sample column (cc2 = l>>1, dx = l&1), plane 0 ; lanes 48..63: plane 1
     const int l = lane & 15, pl = (lane >> 4) & 1, hi = l >> 1, sub = l & 1;
     unsigned long long b0, b1;          // the two ballots this lane interleaves
     if (lane < 32) {                    // (dy = sub): dx = 0 -> even bits, dx = 1 -> odd bits
-        b0 = pl == 0 ? (~cov[2 * sub] & nb) : (cov[2 * sub] & pb);
-        b1 = pl == 0 ? (~cov[2 * sub + 1] & nb) : (cov[2 * sub + 1] & pb);
+        b0 = pl == 0 ? (~cov[2 * sub] & nb[2 * sub]) : (cov[2 * sub] & pb[2 * sub]);
+        b1 = pl == 0 ? (~cov[2 * sub + 1] & nb[2 * sub + 1]) : (cov[2 * sub + 1] & pb[2 * sub + 1]);
         const unsigned a = (unsigned)(b0 >> (8 * hi)) & 0xffu, o = (unsigned)(b1 >> (8 * hi)) & 0xffu;
         const unsigned word = spread8(a) | (spread8(o) << 1);
         const int yi = is - 1 - 2 * (ty * HM_TILE + hi) - sub;
         (rowneg + pl * plane)[((long)b * is + yi) * (is / 16) + tx] = (unsigned short)word;
     } else {                            // (dx = sub): bit 15 - (2*rr2 + dy) <- sample (rr2, dy) of column cc2 = hi
-        b0 = pl == 0 ? (~cov[sub] & nb) : (cov[sub] & pb);                 // dy = 0
-        b1 = pl == 0 ? (~cov[2 + sub] & nb) : (cov[2 + sub] & pb);         // dy = 1
+        b0 = pl == 0 ? (~cov[sub] & nb[sub]) : (cov[sub] & pb[sub]);                         // dy = 0
+        b1 = pl == 0 ? (~cov[2 + sub] & nb[2 + sub]) : (cov[2 + sub] & pb[2 + sub]);         // dy = 1
         // bits 8*rr2 + cc2 -> one byte with row rr2 at bit 7 - rr2
         const unsigned c0 = (unsigned)((((b0 >> hi) & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
         const unsigned c1 = (unsigned)((((b1 >> hi) & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned,
     float* __restrict__ pooled_depth, unsigned short* __restrict__ rowneg, unsigned short* __restrict__ colneg,
     int* __restrict__ bin_cnt, const int* __restrict__ bin_list, unsigned int* __restrict__ done, int reset_bins,
-    unsigned char* __restrict__ region_state, int persistent)
+    unsigned char* __restrict__ region_state, int persistent, float* __restrict__ alpha_full)
 {
     __shared__ unsigned long long zb[32 * 32];
     __shared__ int cand[2 * CAND_CAP];
@@ -532,6 +533,13 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const float pool = 0.25f * (float)cnt;
     const long po = ((long)b * S + r) * S + c;
     pooled[po] = pool;
+    // anti_aliasing=False rendering: the silhouette is the sample grid itself (flipped), no pooling
+    if (alpha_full) {
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+            *reinterpret_cast<float2*>(alpha_full + ((long)b * is + 2 * r + dy) * is + xi0) =
+                make_float2(imin[2 * dy] >= 0 ? 1.f : 0.f, imin[2 * dy + 1] >= 0 ? 1.f : 0.f);
+    }
     // depth image of nr.Renderer.render (homan.py:391,406): z-buffer (far where empty), flipped, 2x2 average pooled
     if (pooled_depth) pooled_depth[po] = (((zmin[0] + zmin[1]) + zmin[2]) + zmin[3]) / 4.0f;
     if (partials) {
@@ -540,7 +548,11 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         const float diff = image - rf;
         dimg[po] = kp * diff;
         // sweep planes of the backward for a positive upstream gradient (sign(g) = sign(dimg)), see k_bwd_masks
-        emit_planes(bal, kp * diff < 0.0f, kp * diff > 0.0f, b, B, is, tx, ty, lane, rowneg, colneg);
+        {
+            const unsigned long long nb1 = __ballot(kp * diff < 0.0f), pb1 = __ballot(kp * diff > 0.0f);
+            const unsigned long long nbv[4] = {nb1, nb1, nb1, nb1}, pbv[4] = {pb1, pb1, pb1, pb1};
+            emit_planes(bal, nbv, pbv, b, B, is, tx, ty, lane, rowneg, colneg);
+        }
         const float sq = hm_wave_sum(diff * diff);
         const float inter = hm_wave_sum(image * rf);
         const float uni = hm_wave_sum(fminf(fmaxf(image + rf, 0.0f), 1.0f));
@@ -604,12 +616,6 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
     const int rr = lane >> 3, cc = lane & 7;
     const int r = ty * HM_TILE + rr, c = tx * HM_TILE + cc;
     const long po = ((long)b * S + r) * S + c;
-    float g = gin[po];
-    if (mode == 1) {
-        float s = upstream[0] * 2.0f;
-        g = s * g / keep_sum[0] / (float)B;
-    }
-    gimg[po] = g;
     // alpha bits of this lane's 4 samples
     const int yi0 = is - 1 - 2 * r;
     unsigned long long cov[4];
@@ -619,7 +625,29 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
 #pragma unroll
         for (int dx = 0; dx < 2; ++dx) cov[2 * dy + dx] = __ballot((aw >> (2 * cc + dx)) & 1u);
     }
-    emit_planes(cov, g < 0.0f, g > 0.0f, b, B, is, tx, ty, lane, rowneg, colneg);
+    unsigned long long nbv[4], pbv[4];
+    if (mode == 3) {
+        // anti_aliasing=False: the image IS the sample grid (vertically flipped); gin / gimg are (B,is,is)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const long at = ((long)b * is + 2 * r + dy) * is + 2 * c;
+            const float2 g2 = *reinterpret_cast<const float2*>(gin + at);
+            *reinterpret_cast<float2*>(gimg + at) = g2;
+            nbv[2 * dy] = __ballot(g2.x < 0.0f); pbv[2 * dy] = __ballot(g2.x > 0.0f);
+            nbv[2 * dy + 1] = __ballot(g2.y < 0.0f); pbv[2 * dy + 1] = __ballot(g2.y > 0.0f);
+        }
+    } else {
+        float g = gin[po];
+        if (mode == 1) {
+            float s = upstream[0] * 2.0f;
+            g = s * g / keep_sum[0] / (float)B;
+        }
+        gimg[po] = g;
+        const unsigned long long nb1 = __ballot(g < 0.0f), pb1 = __ballot(g > 0.0f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { nbv[k] = nb1; pbv[k] = pb1; }
+    }
+    emit_planes(cov, nbv, pbv, b, B, is, tx, ty, lane, rowneg, colneg);
 }
 
 // ---------------------------------------------------------------- backward: shared helpers
@@ -713,9 +741,14 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
             const int xi = axis ? d1 : d0, yi = axis ? d0 : d1;
             SweepSrc r;
             r.d1 = d1;
-            float g = gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
-            if (from_dimg) g = gs * g / ks / (float)B;
-            r.g = 0.25f * g;
+            float g;
+            if (mode == 3) g = gimg[((long)b * is + (is - 1 - yi)) * is + xi];       // per-sample gradient (no anti-aliasing)
+            else {
+                g = gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
+                if (from_dimg) g = gs * g / ks / (float)B;
+                g = 0.25f * g;
+            }
+            r.g = g;
             r.owner = pl ? idx[(long)yi * is + xi] : -1;
             out[base + __popcll(w & ((1ull << pos) - 1ull))] = r;
         }
@@ -1191,7 +1224,7 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
     n += al256((size_t)B * is * (is / 16) * 2); // alpha16
     n += al256((size_t)B * S * S * 4);          // dimg
     n += al256((size_t)B * (S / 8) * (S / 8) * 16); // partials
-    n += al256((size_t)B * S * S * 4);          // gimg
+    n += al256((size_t)B * is * is * 4);        // gimg (pooled grid, or the full sample grid without anti-aliasing)
     n += al256((size_t)B * is * (is / 16) * 4); // row masks, 2 planes
     n += al256((size_t)B * is * (is / 16) * 4); // column masks, 2 planes
     n += al256((size_t)B * F * 24 * 4);         // parts
@@ -1225,7 +1258,7 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.alpha16 = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 2);
     w.dimg = (float*)p; p += al256((size_t)B * S * S * 4);
     w.partials = (float*)p; p += al256((size_t)B * (S / 8) * (S / 8) * 16);
-    w.gimg = (float*)p; p += al256((size_t)B * S * S * 4);
+    w.gimg = (float*)p; p += al256((size_t)B * is * is * 4);
     w.rowneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4);
     w.colneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4);
     w.parts = (float*)p; p += al256((size_t)B * F * 24 * 4);
@@ -1243,7 +1276,7 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
-               const float* rigid_rot6d, const float* rigid_trans, const float* rigid_scale, int rigid_abs,
+               float* alpha_full, const float* rigid_rot6d, const float* rigid_trans, const float* rigid_scale, int rigid_abs,
                int persistent_outputs, void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && pooled && workspace);
@@ -1261,7 +1294,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.rowneg, w.colneg, bins,
-                       w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs);
+                       w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full);
     if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            w.counter, loss_out);
@@ -1282,6 +1315,7 @@ int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss
 // Backward.  mode 1 (fused loss): upstream = d/d loss_sil (device scalar), uses dimg from the forward.
 //            mode 2: as mode 1, and the caller guarantees upstream[0] > 0 (one launch less).
 //            mode 0 (render):     grad_pooled (B,S,S) = dL/d silhouettes.
+//            mode 3 (render without anti-aliasing): grad_pooled is (B,2S,2S) = dL/d alpha_full.
 // adjacency (CSR over V) describes the shared face topology.  grad_verts (B,V,3) is overwritten.
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
@@ -1289,8 +1323,8 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
                hipStream_t stream)
 {
     HM_CHECK_ARG(verts && K && adj_off && adj_items && workspace);        // grad_verts == NULL: no vertex gather (see hm_sil_parts)
-    HM_CHECK_ARG(mode == 0 ? grad_pooled != nullptr : (upstream && keep_sum));
-    HM_CHECK_ARG(mode >= 0 && mode <= 2);
+    HM_CHECK_ARG((mode == 0 || mode == 3) ? grad_pooled != nullptr : (upstream && keep_sum));
+    HM_CHECK_ARG(mode >= 0 && mode <= 3);
     if (S % 32 != 0 || S > 32 * SWEEP_CUMW) return HM_ERR_UNSUPPORTED;     // 64-sample mask words, <= SWEEP_CUMW per line
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
@@ -1365,7 +1399,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     HM_CHECK_ARG(verts && faces && K && keep && ref && keep_sum && pooled && loss_out && workspace && reps > 0 && avg_ms);
     HM_CHECK_ARG(adj_off && adj_items && upstream && grad_verts);
     int rc = hm_sil_fwd(verts, faces, 0, K, B, V, F, S, 1.0f, 0.1f, 100.0f, keep, ref, keep_sum, pooled, loss_out,
-                        work_order, nullptr, nullptr, nullptr, nullptr, 0, 0, workspace, stream);
+                        work_order, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, workspace, stream);
     if (rc != HM_OK) return rc;
     rc = hm_sil_bwd(verts, K, B, V, F, S, 1.0f, 1e-3f, 1, upstream, nullptr, keep_sum, adj_off, adj_items, face_order,
                     grad_verts, nullptr, workspace, stream);
@@ -1392,7 +1426,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                            w.partials, work_order, w.owned, (float*)nullptr, w.rowneg, w.colneg, bins, w.bin_list,
-                           w.bin_done, cold ? 1 : 0, w.region_state, 1);      // steady state of a fixed loop: background regions skipped
+                           w.bin_done, cold ? 1 : 0, w.region_state, 1, (float*)nullptr);      // steady state of a fixed loop: background regions skipped
     }
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);

@@ -317,7 +317,7 @@ class FusedStepper:
         if on["sil"]:
             ck(L.hm_sil_fwd(P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
                             self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
-                            None, P(self.pooled), None, P(sctx.work_order), None, P(m.rotations_object),
+                            None, P(self.pooled), None, P(sctx.work_order), None, None, P(m.rotations_object),
                             P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), sa), "sil_fwd")
             self.ev_sil.record(main)         # the loss / IoU reduction runs on the side stream
             ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,

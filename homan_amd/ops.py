@@ -106,7 +106,7 @@ class _SilhouetteLoss(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, _lib.ptr(keep), _lib.ptr(ref), _lib.ptr(keep_sum),
-            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.work_order), None, None, None, None, 0, 0,
+            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.work_order), None, None, None, None, None, 0, 0,
             _lib.ptr(sctx.workspace), _lib.stream()),
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K, keep_sum)
@@ -137,7 +137,8 @@ class _SilhouetteRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.work_order), None, None, None, None, 0, 0, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_fwd")
+            _lib.ptr(sctx.work_order), None, None, None, None, None, 0, 0, _lib.ptr(sctx.workspace), _lib.stream()),
+            "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
         return pooled
@@ -154,6 +155,44 @@ class _SilhouetteRender(torch.autograd.Function):
             _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), _lib.ptr(sctx.grad_ndc) if getattr(sctx, "grad_ndc", None) is not None else None,
             _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None
+
+
+class _SilhouetteRenderNoAA(torch.autograd.Function):
+    """reference homan/pose_optimization.py:89-96,140-141: nr.Renderer(image_size, anti_aliasing=False)(verts, faces,
+    mode='silhouettes') -> (B,image_size,image_size) hard 0/1 coverage.  `sctx` is built with size = image_size // 2
+    (its sample grid IS the image); the backward is the same edge-sweep pseudo-gradient, fed per sample."""
+
+    @staticmethod
+    def forward(ctx, verts, K, sctx, orig_size):
+        verts, K = _f32(verts), _f32(K)
+        n = 2 * sctx.S
+        pooled = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
+        alpha = torch.empty(sctx.B, n, n, device=verts.device)
+        _lib.check(_lib.lib().hm_sil_fwd(
+            _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
+            float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
+            _lib.ptr(sctx.work_order), None, _lib.ptr(alpha), None, None, None, 0, 0, _lib.ptr(sctx.workspace),
+            _lib.stream()), "hm_sil_fwd")
+        ctx.save_for_backward(verts, K)
+        ctx.sctx, ctx.orig_size = sctx, orig_size
+        return alpha
+
+    @staticmethod
+    def backward(ctx, g_img):
+        verts, K = ctx.saved_tensors
+        sctx = ctx.sctx
+        g_img = _f32(g_img)
+        grad_verts = torch.empty_like(verts)
+        _lib.check(_lib.lib().hm_sil_bwd(
+            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), NMR_EPS, 3,
+            None, _lib.ptr(g_img), None, _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
+            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
+        return grad_verts, None, None, None
+
+
+def silhouette_render_noaa(verts, K, sctx, orig_size=1.0):
+    """Hard silhouettes without anti-aliasing, (B, 2*sctx.S, 2*sctx.S)."""
+    return _SilhouetteRenderNoAA.apply(verts, K, sctx, orig_size)
 
 
 def silhouette_loss(verts, K, keep, ref, keep_sum, sctx, orig_size=1.0):
@@ -178,7 +217,8 @@ class _DepthRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.work_order), _lib.ptr(depth), None, None, None, 0, 0, _lib.ptr(sctx.workspace), _lib.stream()),
+            _lib.ptr(sctx.work_order), _lib.ptr(depth), None, None, None, None, 0, 0, _lib.ptr(sctx.workspace),
+            _lib.stream()),
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size

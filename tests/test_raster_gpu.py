@@ -159,7 +159,7 @@ def test_persistent_outputs_skip_is_invisible():
 
     def call(sctx, v, pooled, out, persistent):
         hlib.check(L.hm_sil_fwd(P(v), P(sctx.faces), 0, P(Kd), B, V, F, S, 1.0, 0.1, 100.0, P(keepd), P(refd), P(ksd),
-                                P(pooled), P(out), P(sctx.work_order), None, None, None, None, 0, persistent,
+                                P(pooled), P(out), P(sctx.work_order), None, None, None, None, None, 0, persistent,
                                 P(sctx.workspace), hlib.stream()), "hm_sil_fwd")
 
     Kd, keepd, refd, ksd = K.to(dev), keep.to(dev), ref.to(dev), keep_sum.to(dev)
@@ -182,3 +182,32 @@ def test_persistent_outputs_skip_is_invisible():
             hlib.check(L.hm_sil_bwd(P(v), P(Kd), B, V, F, S, 1.0, 1e-3, 1, P(one), None, P(ksd), P(sc.adj_off),
                                     P(sc.adj_items), None, P(g), None, P(sc.workspace), hlib.stream()), "hm_sil_bwd")
         assert torch.equal(gp, gf), step
+
+
+@pytest.mark.parametrize("obj", ["cube", "bottle"])
+def test_no_antialiasing_render_and_gradient_match_oracle(obj):
+    """nr.Renderer(anti_aliasing=False) (reference homan/pose_optimization.py:89-96): coverage image bit-exact vs the
+    oracle renderer, pseudo-gradient of a generic image loss within the summation-order tolerance."""
+    from homan_amd import ops
+    from oracle import nmr
+    B, S = 3, 64
+    verts, faces, K, V = _scene(B=B, S=S, obj=obj, seed=9)
+    r = nmr.Renderer(image_size=S, K=K, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1, anti_aliasing=False)
+    vo = verts.clone().requires_grad_(True)
+    img_o = r(vo, faces, mode="silhouettes")
+    assert img_o.shape == (B, S, S)
+    gen = torch.Generator().manual_seed(1)
+    target = (torch.rand(B, S, S, generator=gen) > 0.5).float()
+    w = torch.rand(B, S, S, generator=gen)
+    ((w * (img_o - target) ** 2).sum()).backward()
+
+    dev = torch.device("cuda")
+    sctx = ops.SilhouetteContext(faces.to(dev), V, B, S // 2, dev)
+    vh = verts.to(dev).requires_grad_(True)
+    img_h = ops.silhouette_render_noaa(vh, K.to(dev), sctx)
+    mism = (img_h.detach().cpu() != img_o.detach()).float().mean().item()
+    assert mism < 1e-4, mism            # projection rounding may flip a sample or two
+    ((w.to(dev) * (img_h - target.to(dev)) ** 2).sum()).backward()
+    scale = vo.grad.abs().max()
+    err = ((vh.grad.cpu() - vo.grad) / scale).abs()
+    assert err.max() < 2e-2 and err.mean() < 1e-4, (err.max(), err.mean())
