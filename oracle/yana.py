@@ -42,3 +42,25 @@ def batch_pairwise_dist(x, y, use_cuda=False):
     rx = torch.diagonal(xx, dim1=1, dim2=2).unsqueeze(1).expand_as(zz.transpose(2, 1))
     ry = torch.diagonal(yy, dim1=1, dim2=2).unsqueeze(1).expand_as(zz)
     return rx.transpose(2, 1) + ry - 2 * zz
+
+
+def get_K_crop_resize(K, boxes, crop_resize):
+    """libyana.lib3d.kcrop.get_K_crop_resize as called at reference homan/pose_optimization.py:246-248 and
+    homan/homan.py (ROI intrinsics): intrinsics of the crop `boxes` (xyxy, pixels) resized to `crop_resize`.
+    Third-party (hassony2/libyana @ HEAD, adapted from cosypose), absent from /root/reference: PARITY UNPINNED; restated
+    from the published cosypose routine (pixel-centre convention: a crop of width w keeps its centre at (w-1)/2)."""
+    K = K.float().clone()
+    boxes = boxes.float()
+    crop_resize = torch.as_tensor(crop_resize, dtype=torch.float32)
+    final_w, final_h = crop_resize.max(), crop_resize.min()
+    crop_w, crop_h = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    crop_cj, crop_ci = (boxes[:, 0] + boxes[:, 2]) / 2, (boxes[:, 1] + boxes[:, 3]) / 2
+    cx = K[:, 0, 2] + (crop_w - 1) / 2 - crop_cj
+    cy = K[:, 1, 2] + (crop_h - 1) / 2 - crop_ci
+    scale_x, scale_y = final_w / crop_w, final_h / crop_h
+    new_K = K.clone()
+    new_K[:, 0, 0] = scale_x * K[:, 0, 0]
+    new_K[:, 1, 1] = scale_y * K[:, 1, 1]
+    new_K[:, 0, 2] = (final_w - 1) / 2 + scale_x * (cx - (crop_w - 1) / 2)
+    new_K[:, 1, 2] = (final_h - 1) / 2 + scale_y * (cy - (crop_h - 1) / 2)
+    return new_K

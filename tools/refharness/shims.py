@@ -73,6 +73,7 @@ def install(mano_model=None):
         _module("libyana.distutils", batch_pairwise_dist=o_yana.batch_pairwise_dist)
         _module("libyana.lib3d")
         _module("libyana.lib3d.trans3d")
+        _module("libyana.lib3d.kcrop", get_K_crop_resize=o_yana.get_K_crop_resize)
         _module("libyana.visutils")
         _module("libyana.visutils.imagify")
         _module("libyana.vidutils")
@@ -104,3 +105,19 @@ def set_rend_size(size):
     constant that homan.losses imported (value substitution only)."""
     import homan.losses as ref_losses
     ref_losses.REND_SIZE = size
+
+
+def import_pose_optimization(rend_size=None):
+    """The reference's object-pose initialisation (homan/pose_optimization.py), imported in place over the same leaves."""
+    install()
+    cwd = os.getcwd()
+    os.chdir(REFERENCE_ROOT)
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        import homan.pose_optimization as ref_po
+    finally:
+        os.chdir(cwd)
+        sys.path.remove(REFERENCE_ROOT)
+    if rend_size is not None:
+        ref_po.REND_SIZE = rend_size        # value substitution (homan/constants.py:32 fixes 256)
+    return ref_po
