@@ -131,6 +131,64 @@ def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
         dist.destroy_process_group()
 
 
+def pose_init_bench(args):
+    """Object-pose initialisation (reference homan/pose_optimization.py:219-383): N poses x steps on one mask."""
+    import numpy as np
+    import torch
+    from homan_amd import pose_optimization as po
+    from homan_amd import synth
+    n, size, steps = args.pose_init, args.size, (50 if args.steps == 400 else args.steps)
+    ov, of = synth.bottle_mesh()
+    verts, faces = torch.from_numpy(ov), torch.from_numpy(of).long()
+    K = np.array([[480.0, 0, 175.0], [0, 480.0, 175.0], [0, 0, 1.0]], np.float32)
+    sq = np.array([75.0, 60.0, 200.0, 200.0], np.float32)
+    Rgt = torch.tensor(synth._rot_x(1.3) @ synth._rot_y(0.4), dtype=torch.float32)
+    tgt_pose = (verts @ Rgt + torch.tensor([0.0, -0.02, 0.6]))[None]
+    roi = po.get_K_crop_resize(torch.as_tensor(K)[None], torch.tensor([[sq[0], sq[1], sq[0] + sq[2], sq[1] + sq[2]]]), [size])
+    roi[:, :2] /= size
+    tgt_model = po.PoseOptimizer(ref_image=np.zeros((size, size), np.float32), vertices=verts, faces=faces,
+                                 rotation_init=po.matrix_to_rot6d(torch.eye(3)[None]), translation_init=torch.zeros(1, 1, 3), K=roi)
+    from homan_amd import ops
+    with torch.no_grad():
+        mask = ops.silhouette_render_noaa(tgt_pose.cuda(), tgt_model._K_all, tgt_model._sil_ctx).cpu().numpy()[0]
+    ys, xs = np.nonzero(mask > 0)
+    bbox = np.array([sq[0] + xs.min() * sq[2] / size, sq[1] + ys.min() * sq[2] / size,
+                     (xs.max() - xs.min()) * sq[2] / size, (ys.max() - ys.min()) * sq[2] / size], np.float32)
+    torch.manual_seed(0)
+    rots = po.compute_random_rotations(n)
+    fit = lambda k: po.find_optimal_pose(verts, faces, mask, bbox, sq, (350, 350), K=K, num_iterations=k,
+                                         num_initializations=n, rotations_init=rots, rend_size=size)
+    fit(3)                                         # warm-up (allocations, lazy init)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model = fit(steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    with torch.no_grad():
+        _, iou, _ = model()
+    cpu = None
+    if not args.no_cpu_baseline:
+        from oracle import poseopt
+        torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "1")))
+        nc, kc = min(n, 64), 10
+        poseopt.find_optimal_pose(verts, faces, mask, bbox, sq, (350, 350), K=K, num_iterations=1, num_initializations=nc,
+                                  rotations_init=rots[:nc].cpu(), rend_size=size)
+        t1 = time.perf_counter()
+        poseopt.find_optimal_pose(verts, faces, mask, bbox, sq, (350, 350), K=K, num_iterations=kc, num_initializations=nc,
+                                  rotations_init=rots[:nc].cpu(), rend_size=size)
+        ec = time.perf_counter() - t1
+        cpu = dict(value=nc * kc / ec, unit="pose-steps/s", cores=int(os.environ.get("OMP_NUM_THREADS", "1")), kind="port",
+                   sample=f"{nc} poses x {kc} steps of the same fit ({ec:.1f} s), oracle find_optimal_pose")
+    print(json.dumps({"metric": "object-pose initialisation, pose-steps/sec (N poses x one 256^2 mask)",
+                      "value": n * steps / el, "unit": "pose-steps/s", "n_gpus": 1, "steps": steps, "warmup": 3,
+                      "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": f"SURVEY 8f rank 1: find_optimal_pose, {n} poses, lathe bottle (3000 faces), "
+                                             f"{size}x{size} mask, no anti-aliasing, torch Adam + autograd loop over the "
+                                             "HIP rasteriser", "poses": n, "rend_size": size},
+                      "best_iou": float(iou.max()), "seconds_per_fit": el, "cpu_baseline": cpu}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -147,6 +205,10 @@ def main():
     ap.add_argument("--shared-scale", action="store_true",
                     help="BASELINE cfg5: step-2 losses with ONE object scale shared by all clips of all ranks (one "
                          "4-byte all-reduce per step, homan_amd.dist); eager autograd loop, reported under 'cfg5'")
+    ap.add_argument("--pose-init", type=int, default=0, metavar="N",
+                    help="SURVEY 8f rank 1 instead of the headline: one find_optimal_pose fit = N candidate poses of the "
+                         "bottle against one 256x256 instance mask, --steps Adam steps (reference default 50); prints "
+                         "its own JSON line (pose-steps/sec) with a bounded CPU-oracle baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -155,6 +217,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
+    if args.pose_init:
+        return pose_init_bench(args)
     import torch
     import torch.distributed as dist
     from homan_amd import synth

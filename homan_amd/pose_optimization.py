@@ -162,7 +162,12 @@ class PoseOptimizer(nn.Module):
             inter = (image * self.image_ref).sum((1, 2))
             union = (image + self.image_ref).clamp(0, 1).sum((1, 2))
             iou = inter / (union + 1e-6)            # libyana batch_mask_iou
-        loss_dict["chamfer"] = self.lw_chamfer * torch.sum(self.compute_edges(image) * self.edt_ref_edge, dim=(1, 2))
+        if self.lw_chamfer == 0:
+            # the reference still max-pools 500 images forward and backward for a term it multiplies by zero (a third of
+            # its step); 0 * finite = 0 with a zero gradient, so the value and the gradients are the same without it
+            loss_dict["chamfer"] = torch.zeros_like(loss_dict["mask"])
+        else:
+            loss_dict["chamfer"] = self.lw_chamfer * torch.sum(self.compute_edges(image) * self.edt_ref_edge, dim=(1, 2))
         loss_dict["offscreen"] = 100000 * self.compute_offscreen_loss(verts)
         return loss_dict, iou, image
 
