@@ -172,12 +172,68 @@ class PoseOptimizer(nn.Module):
         return loss_dict, iou, image
 
 
+def _graph_loop(model, lr, num_iterations):
+    """`num_iterations` steps of reference pose_optimization.py:330-357 replayed from one captured hipGraph.  The
+    best-ever bookkeeping keeps the reference's order (the pose is copied AFTER the optimiser step that followed the
+    evaluation, :348-353) and its strict `<`."""
+    params = [model.rotations, model.translations]
+    optimizer = torch.optim.Adam(params, lr=lr, capturable=True)
+    dev = model.rotations.device
+    best_loss = torch.full((), float("inf"), device=dev)
+    best_rot, best_trans = torch.zeros_like(model.rotations[0]), torch.zeros_like(model.translations[0])
+    losses_out = torch.zeros(model.rotations.shape[0], device=dev)
+
+    def step():
+        loss_dict, _iou, _sil = model()
+        losses = sum(loss_dict.values())
+        losses.sum().backward()
+        optimizer.step()
+        with torch.no_grad():
+            lmin, ind = losses.min(0)
+            better = lmin < best_loss
+            best_loss.copy_(torch.where(better, lmin, best_loss))
+            sel = ind.reshape(1)             # device-side gather: indexing with a 0-d tensor would sync on its value
+            best_rot.copy_(torch.where(better, model.rotations.index_select(0, sel)[0], best_rot))
+            best_trans.copy_(torch.where(better, model.translations.index_select(0, sel)[0], best_trans))
+            losses_out.copy_(losses)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        # two un-captured steps: lazy initialisation of the optimiser state and of the allocator pools; they ARE steps
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        done = 0
+        for _ in range(min(2, num_iterations)):
+            for p in params:
+                p.grad.zero_()
+            step()
+            done += 1
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if done < num_iterations:
+        graph = torch.cuda.CUDAGraph()
+        for p in params:
+            p.grad.zero_()
+        with torch.cuda.graph(graph):
+            step()
+            for p in params:
+                p.grad.zero_()
+        for _ in range(num_iterations - done):       # (capturing records the step, it does not run it)
+            graph.replay()
+    torch.cuda.synchronize()
+    return losses_out, best_rot.clone(), best_trans.clone()
+
+
 def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=None, num_iterations=50,
                       num_initializations=2000, lr=1e-2, image=None, debug=False, viz_folder="tmp", viz_step=10,
-                      sort_best=True, rotations_init=None, viz=False, rend_size=constants.REND_SIZE):
+                      sort_best=True, rotations_init=None, viz=False, rend_size=constants.REND_SIZE, mode="eager"):
     """reference homan/pose_optimization.py:219-383 (debug plots not provided: `debug` / `viz` / `image` are accepted
     and ignored).  Returns the PoseOptimizer whose `rotations` / `translations` hold the best-ever pose first, then the
-    poses sorted by final loss."""
+    poses sorted by final loss.
+    mode="eager": the reference loop verbatim (one host sync per step for the best-ever bookkeeping);
+    mode="graph": the same step (forward, backward, Adam, best-ever bookkeeping on the device) captured once in a hipGraph
+    and replayed (measured: no faster than the eager loop here, the step is GPU-bound; kept for host-bound setups)."""
     dev = torch.device("cuda")
     vertices = torch.as_tensor(vertices).float().to(dev)
     faces = torch.as_tensor(faces).to(dev)
@@ -193,19 +249,24 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
     camintr_roi[:, :2] = camintr_roi[:, :2] / rend_size          # crop K to normalised rendering space (:321)
     model = PoseOptimizer(ref_image=mask, vertices=vertices, faces=faces, rotation_init=matrix_to_rot6d(rotations_init),
                           translation_init=translations_init, num_initializations=num_initializations, K=camintr_roi)
-    optimizer = torch.optim.Adam(model.parameters(), lr=lr)
-    best_loss_single, best_rots_single, best_trans_single = np.inf, None, None
-    for _ in range(num_iterations):
-        optimizer.zero_grad()
-        loss_dict, _iou, _sil = model()
-        losses = sum(loss_dict.values())
-        losses.sum().backward()
-        optimizer.step()
-        if losses.min() < best_loss_single:
-            ind = torch.argmin(losses)
-            best_loss_single = losses[ind]
-            best_rots_single = model.rotations[ind].detach().clone()
-            best_trans_single = model.translations[ind].detach().clone()
+    if mode == "graph" and num_iterations > 0:
+        losses, best_rots_single, best_trans_single = _graph_loop(model, lr, num_iterations)
+    elif mode in ("eager", "graph"):
+        optimizer = torch.optim.Adam(model.parameters(), lr=lr)
+        best_loss_single, best_rots_single, best_trans_single = np.inf, None, None
+        for _ in range(num_iterations):
+            optimizer.zero_grad()
+            loss_dict, _iou, _sil = model()
+            losses = sum(loss_dict.values())
+            losses.sum().backward()
+            optimizer.step()
+            if losses.min() < best_loss_single:
+                ind = torch.argmin(losses)
+                best_loss_single = losses[ind]
+                best_rots_single = model.rotations[ind].detach().clone()
+                best_trans_single = model.translations[ind].detach().clone()
+    else:
+        raise ValueError(f"mode {mode} not in [eager|graph]")
     best_rots, best_trans, best_losses = model.rotations, model.translations, losses
     if sort_best:
         inds = torch.argsort(best_losses)
