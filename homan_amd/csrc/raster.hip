@@ -254,7 +254,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned,
     float* __restrict__ pooled_depth, unsigned short* __restrict__ rowneg, unsigned short* __restrict__ colneg,
     int* __restrict__ bin_cnt, const int* __restrict__ bin_list, unsigned int* __restrict__ done, int reset_bins,
-    unsigned char* __restrict__ region_state, int persistent, float* __restrict__ alpha_full)
+    unsigned char* __restrict__ region_state, int persistent, float* __restrict__ alpha_full, int mask_shared,
+    float* __restrict__ dimg_full)
 {
     __shared__ unsigned long long zb[32 * 32];
     __shared__ int cand[2 * CAND_CAP];
@@ -542,8 +543,36 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     }
     // depth image of nr.Renderer.render (homan.py:391,406): z-buffer (far where empty), flipped, 2x2 average pooled
     if (pooled_depth) pooled_depth[po] = (((zmin[0] + zmin[1]) + zmin[2]) + zmin[3]) / 4.0f;
-    if (partials) {
-        const float kp = keep[po], rf = ref[po];
+    if (partials && dimg_full) {
+        // per-SAMPLE masked L2 (rendering without anti-aliasing, reference homan/pose_optimization.py:140-143): keep / ref
+        // are (is,is) images [shared by all frames when mask_shared], dimg_full = keep * (keep * alpha - ref) per sample
+        const float* kb = keep + (mask_shared ? 0 : (long)b * is * is);
+        const float* rb = ref + (mask_shared ? 0 : (long)b * is * is);
+        float sqs = 0.f, ins = 0.f, uns = 0.f;
+        unsigned long long nbv[4], pbv[4];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy) {
+            const long at = (long)(2 * r + dy) * is + xi0;
+            const float2 k2 = *reinterpret_cast<const float2*>(kb + at), r2 = *reinterpret_cast<const float2*>(rb + at);
+            const float i0 = k2.x * (imin[2 * dy] >= 0 ? 1.f : 0.f), i1 = k2.y * (imin[2 * dy + 1] >= 0 ? 1.f : 0.f);
+            const float d0 = i0 - r2.x, d1 = i1 - r2.y;
+            const float g0 = k2.x * d0, g1 = k2.y * d1;
+            *reinterpret_cast<float2*>(dimg_full + (long)b * is * is + at) = make_float2(g0, g1);
+            sqs += d0 * d0 + d1 * d1;
+            ins += i0 * r2.x + i1 * r2.y;
+            uns += fminf(fmaxf(i0 + r2.x, 0.0f), 1.0f) + fminf(fmaxf(i1 + r2.y, 0.0f), 1.0f);
+            nbv[2 * dy] = __ballot(g0 < 0.0f); pbv[2 * dy] = __ballot(g0 > 0.0f);
+            nbv[2 * dy + 1] = __ballot(g1 < 0.0f); pbv[2 * dy + 1] = __ballot(g1 > 0.0f);
+        }
+        emit_planes(bal, nbv, pbv, b, B, is, tx, ty, lane, rowneg, colneg);
+        const float sq = hm_wave_sum(sqs), inter = hm_wave_sum(ins), uni = hm_wave_sum(uns);
+        if (lane == 0) {
+            float* o = partials + ((long)b * ntiles + tile) * 4;
+            o[0] = sq; o[1] = inter; o[2] = uni; o[3] = 0.f;
+        }
+    } else if (partials) {
+        const long pm = mask_shared ? (long)r * S + c : po;
+        const float kp = keep[pm], rf = ref[pm];
         const float image = kp * pool;
         const float diff = image - rf;
         dimg[po] = kp * diff;
@@ -567,7 +596,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
 // loss = (sum_sq / keep_sum) / B ; iou = mean_b inter_b / (union_b + eps).   out[0]=loss, out[1]=iou
 __global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ partials, int B, int ntiles,
                                                      const float* __restrict__ keep_sum, float* __restrict__ frame_rec,
-                                                     unsigned int* counter, float* __restrict__ out)
+                                                     unsigned int* counter, float* __restrict__ out,
+                                                     float* __restrict__ frame_out)
 {
     HM_LATENCY_KERNEL();
     __shared__ float red[16];
@@ -582,6 +612,9 @@ __global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ pa
     in = hm_block_sum(in, red);
     un = hm_block_sum(un, red);
     if (threadIdx.x == 0) { hm_partial_store(frame_rec + 4 * b, sq); hm_partial_store(frame_rec + 4 * b + 1, in / (un + 1e-6f)); }
+    // per-frame values (un-normalised sum of squares, IoU): what a loss that keeps the frames apart needs
+    if (frame_out && threadIdx.x == 0) { frame_out[2 * b] = sq; frame_out[2 * b + 1] = in / (un + 1e-6f); }
+    if (!out) return;
     if (hm_last_block(counter, gridDim.x, &s_flag)) {
         const float total_sq = hm_last_block_sum(frame_rec, B, 4, red);
         const float iou_sum = hm_last_block_sum(frame_rec + 1, B, 4, red);
@@ -724,7 +757,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     __syncthreads();
     if (!valid || s_ex[grp][SWEEP_CUMW - 1] + __popcll(s_w[grp][SWEEP_CUMW - 1]) == 0) return;
     // fused loss, positive upstream: g = upstream * 2 * dimg / keep_sum / B (the arithmetic of k_bwd_masks), no gimg pass
-    const bool from_dimg = mode == 2 || (mode == 1 && upstream[0] > 0.0f);
+    const bool from_dimg = mode == 2 || (mode == 1 && upstream[0] > 0.0f);     // (modes 3 / 4 read gimg per sample below)
     const float* gi = (from_dimg ? dimg : gimg) + (long)b * S * S;
     const float gs = from_dimg ? upstream[0] * 2.0f : 0.f, ks = from_dimg ? keep_sum[0] : 1.f;
     const int* idx = idx_map + (long)b * is * is;
@@ -743,6 +776,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
             r.d1 = d1;
             float g;
             if (mode == 3) g = gimg[((long)b * is + (is - 1 - yi)) * is + xi];       // per-sample gradient (no anti-aliasing)
+            else if (mode == 4) g = upstream[b] * 2.0f * gimg[((long)b * is + (is - 1 - yi)) * is + xi];   // fused per-sample L2
             else {
                 g = gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
                 if (from_dimg) g = gs * g / ks / (float)B;
@@ -1276,8 +1310,8 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
-               float* alpha_full, const float* rigid_rot6d, const float* rigid_trans, const float* rigid_scale, int rigid_abs,
-               int persistent_outputs, void* workspace, hipStream_t stream)
+               float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
+               const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && pooled && workspace);
     HM_CHECK_ARG(!rigid_rot6d || (rigid_trans && rigid_scale));
@@ -1294,21 +1328,24 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.rowneg, w.colneg, bins,
-                       w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full);
+                       w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full, mask_shared,
+                       (fused && alpha_full) ? w.gimg : (float*)nullptr);
     if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
-                           w.counter, loss_out);
+                           w.counter, loss_out, (float*)nullptr);
     return hm_launch_status();
 }
 
 // The loss / IoU reduction of a forward that was called with keep/ref but loss_out == NULL: the backward does not
 // depend on it, so a caller with a second stream takes it off the critical path.
-int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, void* workspace, hipStream_t stream)
+// frame_out (B,2) optional: per-frame {sum of squares (un-normalised), IoU}; loss_out may then be NULL.
+int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, float* frame_out, void* workspace,
+                  hipStream_t stream)
 {
-    HM_CHECK_ARG(keep_sum && loss_out && workspace && B > 0 && S > 0);
+    HM_CHECK_ARG(workspace && B > 0 && S > 0 && (frame_out || loss_out) && (!loss_out || keep_sum));
     SilWs w = carve(workspace, B, V, F, S);
     hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, (S / 8) * (S / 8), keep_sum,
-                       w.frame_rec, w.counter, loss_out);
+                       w.frame_rec, w.counter, loss_out, frame_out);
     return hm_launch_status();
 }
 
@@ -1316,6 +1353,7 @@ int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss
 //            mode 2: as mode 1, and the caller guarantees upstream[0] > 0 (one launch less).
 //            mode 0 (render):     grad_pooled (B,S,S) = dL/d silhouettes.
 //            mode 3 (render without anti-aliasing): grad_pooled is (B,2S,2S) = dL/d alpha_full.
+//            mode 4 (fused per-sample L2 of a forward called with alpha_full + keep/ref): upstream (B) = dL/d frame sums, all > 0.
 // adjacency (CSR over V) describes the shared face topology.  grad_verts (B,V,3) is overwritten.
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
@@ -1323,12 +1361,12 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
                hipStream_t stream)
 {
     HM_CHECK_ARG(verts && K && adj_off && adj_items && workspace);        // grad_verts == NULL: no vertex gather (see hm_sil_parts)
-    HM_CHECK_ARG((mode == 0 || mode == 3) ? grad_pooled != nullptr : (upstream && keep_sum));
-    HM_CHECK_ARG(mode >= 0 && mode <= 3);
+    HM_CHECK_ARG((mode == 0 || mode == 3) ? grad_pooled != nullptr : (mode == 4 ? upstream != nullptr : (upstream && keep_sum)));
+    HM_CHECK_ARG(mode >= 0 && mode <= 4);
     if (S % 32 != 0 || S > 32 * SWEEP_CUMW) return HM_ERR_UNSUPPORTED;     // 64-sample mask words, <= SWEEP_CUMW per line
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
-    if (mode != 2)      // mode 2: the caller guarantees upstream > 0, the forward's planes are the backward's
+    if (mode != 2 && mode != 4)      // modes 2 / 4: the caller guarantees upstream > 0, the forward's planes are the backward's
         hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                            mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                            w.rowneg, w.colneg);
@@ -1399,7 +1437,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     HM_CHECK_ARG(verts && faces && K && keep && ref && keep_sum && pooled && loss_out && workspace && reps > 0 && avg_ms);
     HM_CHECK_ARG(adj_off && adj_items && upstream && grad_verts);
     int rc = hm_sil_fwd(verts, faces, 0, K, B, V, F, S, 1.0f, 0.1f, 100.0f, keep, ref, keep_sum, pooled, loss_out,
-                        work_order, nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0, workspace, stream);
+                        work_order, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, workspace, stream);
     if (rc != HM_OK) return rc;
     rc = hm_sil_bwd(verts, K, B, V, F, S, 1.0f, 1e-3f, 1, upstream, nullptr, keep_sum, adj_off, adj_items, face_order,
                     grad_verts, nullptr, workspace, stream);
@@ -1426,7 +1464,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                            w.partials, work_order, w.owned, (float*)nullptr, w.rowneg, w.colneg, bins, w.bin_list,
-                           w.bin_done, cold ? 1 : 0, w.region_state, 1, (float*)nullptr);      // steady state of a fixed loop: background regions skipped
+                           w.bin_done, cold ? 1 : 0, w.region_state, 1, (float*)nullptr, 0, (float*)nullptr);      // steady state of a fixed loop: background regions skipped
     }
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);

@@ -317,7 +317,7 @@ class FusedStepper:
         if on["sil"]:
             ck(L.hm_sil_fwd(P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
                             self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
-                            None, P(self.pooled), None, P(sctx.work_order), None, None, P(m.rotations_object),
+                            None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
                             P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), sa), "sil_fwd")
             self.ev_sil.record(main)         # the loss / IoU reduction runs on the side stream
             ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
@@ -379,7 +379,7 @@ class FusedStepper:
                 self.aux.wait_event(self.ev_fwd)
                 if on["sil"]:
                     self.aux.wait_event(self.ev_sil)
-                    ck(L.hm_sil_reduce(B, Vo, sctx.F, sctx.S, P(m.losses.keep_sum), self._slot("loss_sil_obj"),
+                    ck(L.hm_sil_reduce(B, Vo, sctx.F, sctx.S, P(m.losses.keep_sum), self._slot("loss_sil_obj"), None,
                                        P(sctx.workspace), self.aux.cuda_stream), "sil_reduce")
                 if log:
                     ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,

@@ -16,11 +16,11 @@ _VP, _I, _F, _SZ, _L = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_s
 # name -> (restype, argtypes)
 _SIGNATURES = {
     "hm_sil_workspace_bytes": (_SZ, [_I, _I, _I, _I]),
-    "hm_sil_fwd": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
-                        _I, _I, _VP, _VP]),
+    "hm_sil_fwd": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP,
+                        _VP, _I, _I, _VP, _VP]),
     "hm_sil_parts": (_VP, [_VP, _I, _I, _I, _I]),
     "hm_rigid_bwd_sil": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
-    "hm_sil_reduce": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP]),
+    "hm_sil_reduce": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_depth_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_ordinal_depth_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_ordinal_depth_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),

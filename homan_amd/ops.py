@@ -106,7 +106,7 @@ class _SilhouetteLoss(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, _lib.ptr(keep), _lib.ptr(ref), _lib.ptr(keep_sum),
-            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.work_order), None, None, None, None, None, 0, 0,
+            _lib.ptr(pooled), _lib.ptr(out), _lib.ptr(sctx.work_order), None, None, 0, None, None, None, 0, 0,
             _lib.ptr(sctx.workspace), _lib.stream()),
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K, keep_sum)
@@ -137,7 +137,7 @@ class _SilhouetteRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.work_order), None, None, None, None, None, 0, 0, _lib.ptr(sctx.workspace), _lib.stream()),
+            _lib.ptr(sctx.work_order), None, None, 0, None, None, None, 0, 0, _lib.ptr(sctx.workspace), _lib.stream()),
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
@@ -171,7 +171,7 @@ class _SilhouetteRenderNoAA(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.work_order), None, _lib.ptr(alpha), None, None, None, 0, 0, _lib.ptr(sctx.workspace),
+            _lib.ptr(sctx.work_order), None, _lib.ptr(alpha), 0, None, None, None, 0, 0, _lib.ptr(sctx.workspace),
             _lib.stream()), "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
@@ -193,6 +193,49 @@ class _SilhouetteRenderNoAA(torch.autograd.Function):
 def silhouette_render_noaa(verts, K, sctx, orig_size=1.0):
     """Hard silhouettes without anti-aliasing, (B, 2*sctx.S, 2*sctx.S)."""
     return _SilhouetteRenderNoAA.apply(verts, K, sctx, orig_size)
+
+
+class _MaskedSilhouetteL2NoAA(torch.autograd.Function):
+    """reference homan/pose_optimization.py:138-143 in one pass: image = keep * Renderer(anti_aliasing=False)(verts) ;
+    loss_b = sum((image_b - ref)^2) ; iou_b.  keep / ref: one (n,n) mask shared by all poses.  The backward reuses the
+    sweep planes the forward emitted, which is valid for POSITIVE upstream gradients only (a sum of per-pose losses)."""
+
+    @staticmethod
+    def forward(ctx, verts, K, keep, ref, sctx, orig_size):
+        verts, K = _f32(verts), _f32(K)
+        n = 2 * sctx.S
+        assert keep.shape == (n, n) and ref.shape == (n, n) and keep.is_contiguous() and ref.is_contiguous()
+        pooled = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
+        alpha = torch.empty(sctx.B, n, n, device=verts.device)
+        frame = torch.empty(sctx.B, 2, device=verts.device)
+        _lib.check(_lib.lib().hm_sil_fwd(
+            _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
+            float(orig_size), NMR_NEAR, NMR_FAR, _lib.ptr(keep), _lib.ptr(ref), None, _lib.ptr(pooled), None,
+            _lib.ptr(sctx.work_order), None, _lib.ptr(alpha), 1, None, None, None, 0, 0, _lib.ptr(sctx.workspace),
+            _lib.stream()), "hm_sil_fwd")
+        _lib.check(_lib.lib().hm_sil_reduce(sctx.B, sctx.V, sctx.F, sctx.S, None, None, _lib.ptr(frame),
+                                            _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_reduce")
+        ctx.save_for_backward(verts, K)
+        ctx.sctx, ctx.orig_size = sctx, orig_size
+        ctx.mark_non_differentiable(alpha)
+        return frame[:, 0], frame[:, 1], alpha
+
+    @staticmethod
+    def backward(ctx, g_loss, _g_iou, _g_alpha):
+        verts, K = ctx.saved_tensors
+        sctx = ctx.sctx
+        g_loss = _f32(g_loss).contiguous()
+        grad_verts = torch.empty_like(verts)
+        _lib.check(_lib.lib().hm_sil_bwd(
+            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), NMR_EPS, 4,
+            _lib.ptr(g_loss), None, None, _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
+            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
+        return grad_verts, None, None, None, None, None
+
+
+def masked_silhouette_l2_noaa(verts, K, keep, ref, sctx, orig_size=1.0):
+    """-> (per-pose sum of squares (B,), per-pose IoU (B,), coverage image (B,n,n) [no gradient])."""
+    return _MaskedSilhouetteL2NoAA.apply(verts, K, keep, ref, sctx, orig_size)
 
 
 def silhouette_loss(verts, K, keep, ref, keep_sum, sctx, orig_size=1.0):
@@ -217,7 +260,7 @@ class _DepthRender(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
             float(orig_size), NMR_NEAR, NMR_FAR, None, None, None, _lib.ptr(pooled), None,
-            _lib.ptr(sctx.work_order), _lib.ptr(depth), None, None, None, None, 0, 0, _lib.ptr(sctx.workspace),
+            _lib.ptr(sctx.work_order), _lib.ptr(depth), None, 0, None, None, None, 0, 0, _lib.ptr(sctx.workspace),
             _lib.stream()),
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K)

@@ -102,24 +102,26 @@ class PoseOptimizer(nn.Module):
         size = int(ref_image.shape[0])
         if size % 32:
             raise NotImplementedError(f"the rasteriser needs image sizes that are multiples of 32, got {size}")
-        vertices, faces = torch.as_tensor(vertices).float(), torch.as_tensor(faces)
+        # (every (N,...) buffer is replicated ON the device: the reference builds the 500-fold copies of the mask on the host
+        #  and uploads ~400 MB per fit, which was two thirds of a whole 50-step fit here)
+        vertices, faces = torch.as_tensor(vertices).float().to(dev), torch.as_tensor(faces).to(dev)
         self.register_buffer("vertices", vertices.repeat(num_initializations, 1, 1))
         self.register_buffer("faces", faces.repeat(num_initializations, 1, 1))
         # Convention for the silhouette-aware loss: -1 = occlusion, 0 = background, 1 = foreground (:66-74)
         ref_image = np.asarray(ref_image)
-        image_ref = torch.from_numpy((ref_image > 0).astype(np.float32))
-        keep_mask = torch.from_numpy((ref_image >= 0).astype(np.float32))
+        image_ref = torch.from_numpy((ref_image > 0).astype(np.float32)).to(dev)
+        keep_mask = torch.from_numpy((ref_image >= 0).astype(np.float32)).to(dev)
         self.register_buffer("image_ref", image_ref.repeat(num_initializations, 1, 1))
         self.register_buffer("keep_mask", keep_mask.repeat(num_initializations, 1, 1))
         self.pool = torch.nn.MaxPool2d(kernel_size=kernel_size, stride=1, padding=(kernel_size // 2))
-        self.rotations = nn.Parameter(torch.as_tensor(rotation_init).clone().float(), requires_grad=True)
-        translation_init = torch.as_tensor(translation_init)
+        self.rotations = nn.Parameter(torch.as_tensor(rotation_init).clone().float().to(dev), requires_grad=True)
+        translation_init = torch.as_tensor(translation_init).to(dev)
         if rotation_init.shape[0] != translation_init.shape[0]:
             translation_init = translation_init.repeat(num_initializations, 1, 1)
         self.translations = nn.Parameter(translation_init.clone().float(), requires_grad=True)
         mask_edge = self.compute_edges(image_ref.unsqueeze(0)).cpu().numpy()
         edt = distance_transform_edt(1 - (mask_edge > 0)) ** (power * 2)
-        self.register_buffer("edt_ref_edge", torch.from_numpy(edt).repeat(num_initializations, 1, 1).float())
+        self.register_buffer("edt_ref_edge", torch.from_numpy(edt).float().to(dev).repeat(num_initializations, 1, 1))
         if K is None:
             K = torch.tensor([[[1, 0, 0.5], [0, 1, 0.5], [0, 0, 1]]], dtype=torch.float32)
         self.register_buffer("K", torch.as_tensor(K).float().reshape(-1, 3, 3)[:1].clone())
@@ -127,6 +129,7 @@ class PoseOptimizer(nn.Module):
         self.to(dev)
         n = self.vertices.shape[0]
         self._one = torch.ones(1, device=dev)
+        self._keep1, self._ref1 = self.keep_mask[0].contiguous(), self.image_ref[0].contiguous()
         self._K_all = self.K.repeat(n, 1, 1).contiguous()
         self._sil_ctx = ops.SilhouetteContext(self.faces, self.vertices.shape[1], n, size // 2, dev)
 
@@ -155,18 +158,24 @@ class PoseOptimizer(nn.Module):
 
     def forward(self):
         verts = self.apply_transformation()
-        image = self.keep_mask * ops.silhouette_render_noaa(verts, self._K_all, self._sil_ctx, 1.0)
         loss_dict = {}
-        loss_dict["mask"] = torch.sum((image - self.image_ref) ** 2, dim=(1, 2))
-        with torch.no_grad():
-            inter = (image * self.image_ref).sum((1, 2))
-            union = (image + self.image_ref).clamp(0, 1).sum((1, 2))
-            iou = inter / (union + 1e-6)            # libyana batch_mask_iou
         if self.lw_chamfer == 0:
+            # render + keep-mask + per-pose L2 + IoU in the rasteriser's epilogue (hm_sil_fwd with a per-sample mask)
+            mask_loss, iou, alpha = ops.masked_silhouette_l2_noaa(verts, self._K_all, self._keep1, self._ref1,
+                                                                  self._sil_ctx, 1.0)
+            loss_dict["mask"] = mask_loss
+            iou = iou.detach()
+            image = self.keep_mask * alpha
             # the reference still max-pools 500 images forward and backward for a term it multiplies by zero (a third of
             # its step); 0 * finite = 0 with a zero gradient, so the value and the gradients are the same without it
-            loss_dict["chamfer"] = torch.zeros_like(loss_dict["mask"])
+            loss_dict["chamfer"] = torch.zeros_like(mask_loss)
         else:
+            image = self.keep_mask * ops.silhouette_render_noaa(verts, self._K_all, self._sil_ctx, 1.0)
+            loss_dict["mask"] = torch.sum((image - self.image_ref) ** 2, dim=(1, 2))
+            with torch.no_grad():
+                inter = (image * self.image_ref).sum((1, 2))
+                union = (image + self.image_ref).clamp(0, 1).sum((1, 2))
+                iou = inter / (union + 1e-6)            # libyana batch_mask_iou
             loss_dict["chamfer"] = self.lw_chamfer * torch.sum(self.compute_edges(image) * self.edt_ref_edge, dim=(1, 2))
         loss_dict["offscreen"] = 100000 * self.compute_offscreen_loss(verts)
         return loss_dict, iou, image

@@ -108,7 +108,10 @@ int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const f
  *     homan/homan.py:391,406): z-buffer (zfar where empty), flipped, 2x2 average pooled.
  *   alpha_full (B,2S,2S) optional: the un-pooled coverage image, vertically flipped like the output = what
  *     nr.Renderer(image_size=2S, anti_aliasing=False) returns (reference homan/pose_optimization.py:89-96); its
- *     backward is hm_sil_bwd mode 3.
+ *     backward is hm_sil_bwd mode 3.  With keep / ref given as well, they are (2S,2S)-resolution images and the fused loss is
+ *     per SAMPLE (reference homan/pose_optimization.py:140-143); per-frame sums come from hm_sil_reduce(frame_out), the
+ *     backward is hm_sil_bwd mode 4.
+ *   mask_shared != 0: keep / ref have no batch dimension (one mask for every frame).
  *   rigid_rot6d (B,3,2) / rigid_trans (B,3) / rigid_scale (1) / rigid_abs optional: `verts` are then mesh-space and the
  *     rigid transform of hm_rigid_fwd is applied in the face-setup kernel (same arithmetic), so the silhouette chain does
  *     not wait for a separate transform launch; hm_sil_bwd still takes the camera-space vertices.
@@ -120,11 +123,13 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S);
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
-               float* alpha_full, const float* rigid_rot6d, const float* rigid_trans, const float* rigid_scale, int rigid_abs,
-               int persistent_outputs, void* workspace, hipStream_t stream);
+               float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
+               const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, hipStream_t stream);
 /* deferred loss / IoU reduction of an hm_sil_fwd called with keep/ref but loss_out == NULL (off the critical path) */
-int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, void* workspace, hipStream_t stream);
+int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, float* frame_out, void* workspace,
+                  hipStream_t stream);       /* frame_out (B,2) optional: per-frame {sum of squares, IoU}; loss_out may be NULL then */
 /* mode 3: grad_pooled is (B,2S,2S) = dL/d alpha_full (rendering without anti-aliasing).
+ * mode 4: fused per-sample L2 without anti-aliasing: upstream (B) = dL/d(per-frame sums of squares), all > 0.
  * mode 1: upstream (1) = dL/d loss_out[0]; mode 2: same with upstream[0] > 0 guaranteed by the caller (the forward's
  * sweep planes are reused, one launch less); mode 0: grad_pooled (B,S,S) = dL/d pooled.  adj_off (V+1), adj_items (3F):
  * CSR vertex -> (face*3 + corner).  face_order: B*F int32 permutation of frame*F+face (visiting order of the edge

@@ -159,7 +159,7 @@ def test_persistent_outputs_skip_is_invisible():
 
     def call(sctx, v, pooled, out, persistent):
         hlib.check(L.hm_sil_fwd(P(v), P(sctx.faces), 0, P(Kd), B, V, F, S, 1.0, 0.1, 100.0, P(keepd), P(refd), P(ksd),
-                                P(pooled), P(out), P(sctx.work_order), None, None, None, None, None, 0, persistent,
+                                P(pooled), P(out), P(sctx.work_order), None, None, 0, None, None, None, 0, persistent,
                                 P(sctx.workspace), hlib.stream()), "hm_sil_fwd")
 
     Kd, keepd, refd, ksd = K.to(dev), keep.to(dev), ref.to(dev), keep_sum.to(dev)
