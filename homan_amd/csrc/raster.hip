@@ -709,6 +709,138 @@ __device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, f
     }
 }
 
+// ---------------------------------------------------------------- backward, pass 2b (edge sweeps): work list
+// The work of the NMR pseudo-gradient is the set of (face winding, edge, axis, d0) ITEMS - one per sample line an edge
+// crosses - and, under every item, the (item, source) PAIRS of its two sweeps.  Both levels are flattened:
+//  * compaction blocks riding at the front of the k_bwd_lines launch turn the faces that own at least one sample into a
+//    table of 64-byte records {pixel-space corners, cumulative item counts of the 12 (winding, edge, axis) families}
+//    laid end to end in one global item space (block scan + one 64-bit atomic per block for the block's base: table
+//    order == item order).  Faces that own nothing get their zero gradient written there and never reach the sweep.
+//  * a UNIT is 64 consecutive items = one wave-iteration of k_bwd_sweep, whichever faces they belong to (typically
+//    1-3; a large face spreads over several units, i.e. over several waves).  `ufirst[u]` names the face holding
+//    item 64u.  Every lane rebuilds its item from its face's record in LDS; nothing is wave-serial.
+//  * an item resolves its two sweeps to slices of per-line source arrays (k_bwd_lines); the pairs of the 64 items are
+//    flattened over the wave: pair p goes to lane p % 64, which finds its item by a binary search of the items'
+//    exclusive pair counts in LDS (pairs per item are heavy-tailed: mean 5, lines tangent to the band hold hundreds).
+//  * a lane keeps running sums while its pairs stay on one (face, corner) target and flushes them into the face's six
+//    LDS accumulators when the target changes.  A face inside one unit is stored directly; a face spread over several
+//    units leaves per-unit partials and the unit that draws the last ticket adds them in unit order (deterministic).
+// parts (B,F,3 mesh corners,2): d/d(x, y) of the NDC face vertices.
+struct SweepFace {            // 64 B: one face of the flattened work list
+    int bf, b, off, flags;    // face slot b*F+fi, frame, first item, bit 0: accumulate with atomics (capacity overflow)
+    float px[3], py[3];       // pixel-space corners (px[0..2], py[0..2] contiguous)
+    unsigned short cum[12];   // inclusive item counts of the families, family = winding*6 + edge*2 + axis
+};
+#define SWEEP_PASS_FACES 16   // faces of a unit staged in LDS at a time (a unit with more takes several passes)
+struct SweepItem { float x, c0, c1; int base0, base1, nb0, fn, meta; };   // meta: face | t0<<4 | t1<<7 | use0<<10 | use1<<11
+struct SweepList {
+    SweepFace* tab; int* offs; unsigned int* ufirst; unsigned int* tickets; float* upart;
+    unsigned long long* cnt; unsigned int* done; unsigned long long* total;
+    int ucap, slot_cap;
+};
+
+// item count of the (edge, axis) line family between end points with sweep-axis coordinates a0, a1
+__device__ __forceinline__ int sweep_family(float a0, float a1, int is, int& d0_from)
+{
+    d0_from = 0;
+    if (!(a0 != a1)) return 0;
+    d0_from = (int)fmaxf(ceilf(fminf(a0, a1)), 0.0f);
+    const int d0_to = (int)fminf(fmaxf(a0, a1), (float)is - 1.0f);
+    return max(0, d0_to - d0_from + 1);
+}
+
+// one block = 256 face slots.  `nblk` = number of compaction blocks of the launch.
+__device__ __forceinline__ void sweep_compact(int blk, int nblk, const float* __restrict__ faces9,
+                                              const FaceBox* __restrict__ boxes, const unsigned char* __restrict__ owned,
+                                              int B, int F, int is, float* __restrict__ parts, const SweepList& sl)
+{
+    __shared__ int s_wsum[4][2];
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const long bf = (long)blk * 256 + tid;
+    const bool valid = bf < (long)B * F;
+    int n = 0;
+    SweepFace rec;
+    if (valid) {
+        const int b = (int)(bf / F), fi = (int)(bf - (long)b * F);
+        const unsigned mask = (reinterpret_cast<const uint2*>(boxes)[bf].x >> 14) & 3u;
+        // a winding that owns no sample has no in-pixel of its own and nothing to sweep inwards over: zero gradient
+        const bool act0 = (mask & 1u) && owned[(long)b * 2 * F + fi];
+        const bool act1 = (mask & 2u) && owned[(long)b * 2 * F + F + fi];
+        if (act0 || act1) {
+            const float* src = faces9 + bf * 9;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { rec.px[k] = topix(src[3 * k], is); rec.py[k] = topix(src[3 * k + 1], is); }
+#pragma unroll
+            for (int var = 0; var < 2; ++var)
+#pragma unroll
+                for (int e = 0; e < 3; ++e)
+#pragma unroll
+                    for (int axis = 0; axis < 2; ++axis) {
+                        const int k0 = e, k1 = (e + 1) % 3;
+                        const int v0 = var ? 2 - k0 : k0, v1 = var ? 2 - k1 : k1;
+                        int from;
+                        const int c = sweep_family(axis ? rec.py[v0] : rec.px[v0], axis ? rec.py[v1] : rec.px[v1], is, from);
+                        if (var ? act1 : act0) n += c;
+                        rec.cum[var * 6 + e * 2 + axis] = (unsigned short)n;
+                    }
+            rec.bf = (int)bf;
+            rec.b = b;
+        }
+    }
+    // block-exclusive scan of (items, faces)
+    const int hasf = n > 0 ? 1 : 0;
+    const int inc_i = hm_wave_scan_incl(n), inc_f = hm_wave_scan_incl(hasf);
+    if (lane == 63) { s_wsum[wv][0] = inc_i; s_wsum[wv][1] = inc_f; }
+    __syncthreads();
+    int pre_i = 0, pre_f = 0, tot_i = 0, tot_f = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < wv) { pre_i += s_wsum[k][0]; pre_f += s_wsum[k][1]; }
+        tot_i += s_wsum[k][0];
+        tot_f += s_wsum[k][1];
+    }
+    // A block's items start on a unit boundary (its total is padded to a multiple of 64): which items share a unit, and
+    // so the order in which every sum below is formed, depends only on the block's own faces - never on the order in
+    // which the blocks drew their bases.  Items in the padding belong to no face.
+    if (tid == 0)
+        s_base = tot_f ? atomicAdd(sl.cnt, ((unsigned long long)tot_f << 32) | (unsigned)((tot_i + 63) & ~63)) : 0ull;
+    __syncthreads();
+    const unsigned long long base = s_base;
+    bool zero = valid && n == 0;
+    if (n > 0) {
+        const int off = (int)(base & 0xffffffffull) + pre_i + inc_i - n;
+        const int idx = (int)(base >> 32) + pre_f + inc_f - 1;
+        const int u_lo = off >> 6, u_hi = (off + n - 1) >> 6;
+        const bool over = u_hi >= sl.ucap || u_hi + idx >= sl.slot_cap;
+        rec.off = off;
+        rec.flags = over ? 1 : 0;
+        zero = over && u_hi > u_lo;          // accumulated with float atomics by its units
+        const uint4* r4 = reinterpret_cast<const uint4*>(&rec);
+        uint4* t4 = reinterpret_cast<uint4*>(sl.tab + idx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t4[k] = r4[k];
+        sl.offs[idx] = off;
+        sl.tickets[idx] = 0u;
+        for (int u = (off + 63) >> 6; (u << 6) < off + n && u < sl.ucap; ++u) sl.ufirst[u] = (unsigned)idx;
+    }
+    if (zero) {
+        float* o = parts + bf * 6;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) o[k] = 0.f;
+    }
+    // the last block publishes the totals and re-arms the counters for the next launch
+    __syncthreads();
+    if (tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int t = atomicAdd(sl.done, 1u);
+        if (t == (unsigned)nblk - 1u) {
+            sl.total[0] = atomicExch(sl.cnt, 0ull);
+            atomicExch(sl.done, 0u);
+        }
+    }
+}
+
 // ---------------------------------------------------------------- backward, pass 2a: per-line source lists
 // Each sweep of an (edge, axis, d0) item collects from the set bits of ONE line of a plane, restricted to a range.
 // The lines are shared by all the items that cross them (~140 per line), so they are expanded once: a wave per
@@ -727,13 +859,22 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    int mode, const float* __restrict__ upstream,
                                                    const float* __restrict__ keep_sum,
                                                    const int* __restrict__ idx_map, int B, int S,
-                                                   SweepSrc* __restrict__ srcs, unsigned short* __restrict__ cum)
+                                                   SweepSrc* __restrict__ srcs, uint4* __restrict__ lrec,
+                                                   int ncomp, const float* __restrict__ faces9,
+                                                   const FaceBox* __restrict__ boxes,
+                                                   const unsigned char* __restrict__ owned, int F,
+                                                   float* __restrict__ parts, SweepList sl)
 {
     __shared__ unsigned long long s_w[16][SWEEP_CUMW];
     __shared__ int s_ex[16][SWEEP_CUMW];
+    // the first `ncomp` workgroups build the work list of the edge sweeps (independent of the lines: one launch for both)
+    if ((int)blockIdx.x < ncomp) {
+        sweep_compact(blockIdx.x, ncomp, faces9, boxes, owned, B, F, 2 * S, parts, sl);
+        return;
+    }
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int is = 2 * S, wpl = is / 64;
-    const long L = (long)blockIdx.x * 16 + grp;
+    const long L = (long)(blockIdx.x - ncomp) * 16 + grp;
     const bool valid = L < 4L * B * is;
     // L = ((pl * 2 + axis) * B + b) * is + d0
     const int d0 = (int)(L % is), b = (int)((L / is) % B), pa = (int)(L / ((long)is * B));
@@ -751,7 +892,9 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);    // row_shr:4
     incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);    // row_shr:8
     const int excl = incl - c;
-    if (valid) cum[L * SWEEP_CUMW + l] = (unsigned short)excl;
+    // line record: {64 mask bits, number of set bits before them} per word, one 16-byte load for a sweep end point and
+    // one cache line per line of up to 512 samples
+    if (valid && l < wpl) lrec[L * wpl + l] = make_uint4((unsigned)mine, (unsigned)(mine >> 32), (unsigned)excl, 0u);
     s_w[grp][l] = mine;
     s_ex[grp][l] = excl;
     __syncthreads();
@@ -789,28 +932,14 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     }
 }
 
-// ---------------------------------------------------------------- backward, pass 2b: edge sweeps
-// Persistent wavefronts, one face (winding) at a time; lanes take the (edge, axis, d0) work items of the face, all six
-// edge/axis combinations packed back to back.  An item resolves its two sweeps to slices of per-line source arrays
-// (k_bwd_lines); the (item, source) pairs of the 64 items are then FLATTENED over the wave: pair p of the round goes
-// to lane p % 64, which finds its item by a binary search of the items' exclusive pair counts in LDS.  The number of
-// pairs per item is heavy-tailed (mean 2, lines tangent to the silhouette band hold hundreds): walking them lane-serially
-// left ~97 % of the lanes idle.
-// parts (B,F,3 mesh corners,2): d/d(x, y) of the NDC face vertices.
-struct SweepItem { float x, c0, c1; int base, meta; };      // meta: combo | use0 << 3 | use1 << 4
-
-
-__global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ faces9, const FaceBox* __restrict__ boxes,
-                                                   const int* __restrict__ idx_map,
-                                                   const unsigned short* __restrict__ rowneg,
-                                                   const unsigned short* __restrict__ colneg,
+// ---------------------------------------------------------------- backward, pass 2b: edge sweeps (see the work list above)
+__global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
                                                    const SweepSrc* __restrict__ srcs,
-                                                   const unsigned short* __restrict__ cum, int B, int F, int S,
-                                                   float eps, float* __restrict__ parts,
-                                                   const unsigned char* __restrict__ owned,
-                                                   const int* __restrict__ face_order)
+                                                   const uint4* __restrict__ lrec, int B, int F, int S,
+                                                   float eps, float* __restrict__ parts)
 {
-    __shared__ float s_cb[4][6][12];
+    __shared__ SweepFace s_face[4][SWEEP_PASS_FACES];
+    __shared__ float s_fg[4][SWEEP_PASS_FACES][6];
     __shared__ int s_start[4][64];
     __shared__ SweepItem s_item[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -818,204 +947,235 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(const float* __restrict__ fac
     const bool pow2 = (is & (is - 1)) == 0;
     const float inv_is = 1.0f / (float)is;      // exact for powers of two
     const int wpl = is / 64;                    // 64-bit mask words per line
-    const long plane_words = (long)B * is * wpl;
-    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-    for (long slot = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-         slot < (long)B * F; slot += nwaves) {
-        const long bf = face_order ? (long)face_order[slot] : slot;
-        const int b = (int)(bf / F), fi = (int)(bf % F);
-        const unsigned mask = (reinterpret_cast<const uint2*>(boxes)[bf].x >> 14) & 3u;
-        const float* src = faces9 + bf * 9;
-        const int* idx = idx_map + (long)b * is * is;
-        float px[3], py[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { px[k] = topix(src[3 * k], is); py[k] = topix(src[3 * k + 1], is); }
-
-        // gradient of the face's three mesh corners (x, y), both windings folded in
-        float fg[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int var = 0; var < 2; ++var) {
-            const int fn = fi + var * F;
-            // a face that owns no sample has no in-pixel of its own and nothing to sweep inwards over: zero gradient
-            if (!((mask >> var) & 1u) || !owned[(long)b * 2 * F + fn]) continue;
-            // lanes 0..5 build the six (edge, axis) line families of this winding into LDS (wave-uniform data)
-            __builtin_amdgcn_wave_barrier();
-            if (lane < 6) {
-                const int e = lane >> 1, axis = lane & 1;
-                float* c = s_cb[wv][lane];
-                float p[3][2];
-#pragma unroll
-                for (int n = 0; n < 3; ++n) {
-                    const int k = (e + n) % 3, sv = var ? 2 - k : k;
-                    float xs = px[0], ys = py[0];
-                    if (sv == 1) { xs = px[1]; ys = py[1]; }
-                    if (sv == 2) { xs = px[2]; ys = py[2]; }
-                    p[n][0] = axis ? ys : xs;
-                    p[n][1] = axis ? xs : ys;
-                }
-                int cnt = 0, d0_from = 0, dir = 0;
-                float slope = 0.f, num = 0.f;
-                if (p[0][0] != p[1][0]) {
-                    if (axis == 0) dir = (p[0][0] < p[1][0]) ? -1 : 1;
-                    else dir = (p[0][0] < p[1][0]) ? 1 : -1;
-                    d0_from = (int)fmaxf(ceilf(fminf(p[0][0], p[1][0])), 0.0f);
-                    const int d0_to = (int)fminf(fmaxf(p[0][0], p[1][0]), (float)is - 1.0f);
-                    cnt = max(0, d0_to - d0_from + 1);
-                    slope = (p[1][1] - p[0][1]) / (p[1][0] - p[0][0]);
-                    num = p[1][0] - p[0][0];
-                }
-                c[0] = p[0][0]; c[1] = p[0][1]; c[2] = p[1][0]; c[3] = p[1][1]; c[4] = p[2][0]; c[5] = p[2][1];
-                c[6] = slope; c[7] = num;
-                reinterpret_cast<int*>(c)[8] = dir;
-                reinterpret_cast<int*>(c)[9] = d0_from;
-                reinterpret_cast<int*>(c)[10] = cnt;
+    const unsigned long long tot = sl.total[0];
+    const int N = (int)(tot & 0xffffffffull), W = (int)(tot >> 32);
+    const int U = (N + 63) >> 6;
+    const int nwaves = (int)(((long)gridDim.x * blockDim.x) >> 6);
+    for (int u = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)); u < U; u += nwaves) {
+        int first;
+        if (u < sl.ucap) first = (int)sl.ufirst[u];
+        else {                                   // beyond the unit table: last face with off <= 64u
+            int lo = 0, hi = W - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (sl.offs[mid] <= (u << 6)) lo = mid; else hi = mid - 1;
             }
+            first = lo;
+        }
+        first = __builtin_amdgcn_readfirstlane(first);
+        const int g = (u << 6) + lane;
+        const int o = first + lane < W ? sl.offs[first + lane] : 0x7fffffff;
+        const int nf = __popcll(__ballot(o < (u << 6) + 64));     // sorted: the faces of this unit are a prefix
+        int e = -1;                                               // my face: last one with off <= g
+        for (int i = 0; i < nf; ++i) e += (__builtin_amdgcn_readlane(o, i) <= g) ? 1 : 0;
+        for (int fb = 0; fb < nf; fb += SWEEP_PASS_FACES) {
+            const int nfp = min(SWEEP_PASS_FACES, nf - fb);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < SWEEP_PASS_FACES / 4; ++k) {
+                const int ent = 4 * k + (lane >> 4);
+                if (ent < nfp)
+                    reinterpret_cast<int*>(&s_face[wv][ent])[lane & 15] =
+                        reinterpret_cast<const int*>(sl.tab + first + fb + ent)[lane & 15];
+            }
+            for (int i = lane; i < SWEEP_PASS_FACES * 6; i += 64) (&s_fg[wv][0][0])[i] = 0.f;
             wave_sync();
-            int off[7];
-            off[0] = 0;
+            const int el = e - fb;
+            bool mine = g < N && el >= 0 && el < nfp;
+            // ---- per-lane item setup (lanes without an item run on harmless in-range addresses and are masked below)
+            const SweepFace& fc = s_face[wv][mine ? el : 0];
+            mine = mine && g - fc.off < (int)fc.cum[11];      // (past the last face of a compaction block: padding)
+            const int j = mine ? g - fc.off : 0;
+            int fam = 0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) off[k + 1] = off[k] + reinterpret_cast<const int*>(s_cb[wv][k])[10];
-            const int total = off[6];
-            // per-lane running sums: pairs reach a lane in ascending item order, so the combination index only grows;
-            // (cur, acc0, acc1) is flushed into tot[] when it changes
-            float tot[12];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) tot[k] = 0.f;
-            int cur = 0;
-            float acc0 = 0.f, acc1 = 0.f;
-#define HM_SWEEP_FLUSH()                                                                     \
-    {                                                                                        \
-        _Pragma("unroll") for (int k_ = 0; k_ < 6; ++k_) {                                   \
-            tot[2 * k_] += (cur == k_) ? acc0 : 0.f;                                         \
-            tot[2 * k_ + 1] += (cur == k_) ? acc1 : 0.f;                                     \
-        }                                                                                    \
-        acc0 = 0.f;                                                                          \
-        acc1 = 0.f;                                                                          \
-    }
-#pragma unroll 1
-            for (int base = 0; base < total; base += 64) {
-                const int item = base + lane;
-                // ---- per-lane item setup
-                int ci = 0, axis = 0, d0r = 0;
-                float d1_cross = 0.f, c0 = 0.f, c1 = 0.f;
-                bool use0 = false, use1 = false;
-                bool act[2] = {false, false};          // [0] outward, [1] inward
-                int rfrom[2] = {0, 0}, rto[2] = {-1, -1};
-                if (item < total) {
-                    int start = 0;
-#pragma unroll
-                    for (int k = 1; k < 6; ++k) if (item >= off[k]) { ci = k; start = off[k]; }
-                    const float* c = s_cb[wv][ci];
-                    const float p00 = c[0], p01 = c[1], p10 = c[2], p11 = c[3], p20 = c[4], p21 = c[5];
-                    const float slope = c[6], num = c[7];
-                    const int dir = reinterpret_cast<const int*>(c)[8], d0_from = reinterpret_cast<const int*>(c)[9];
-                    axis = ci & 1;
-                    d0r = d0_from + (item - start);
-                    d1_cross = slope * ((float)d0r - p00) + p01;
-                    if (d1_cross > -8.0f && d1_cross < (float)is + 8.0f) {
-                        const int d1_in = (dir > 0) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross);
-                        const int d1_out = d1_in + dir;
-                        if (!(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out)) {
-                            const int idx_in = axis ? idx[(long)d0r * is + d1_in] : idx[(long)d1_in * is + d0r];
-                            const int idx_out = axis ? idx[(long)d0r * is + d1_out] : idx[(long)d1_out * is + d0r];
-                            use0 = p10 != (float)d0r;
-                            use1 = p00 != (float)d0r;
-                            // 1-ulp reciprocals: these only scale the pseudo-distances (compared at 1e-3), unlike c2
-                            // below, which picks the integer end of the inward range and stays an IEEE division
-                            c0 = use0 ? num * __builtin_amdgcn_rcpf(p10 - (float)d0r) : 0.f;
-                            c1 = use1 ? num * __builtin_amdgcn_rcpf((float)d0r - p00) : 0.f;
-                            if (idx_in == fn) {             // outward: from the sample just outside the edge to the border
-                                const int lim = (dir > 0) ? is - 1 : 0;
-                                rfrom[0] = max(min(d1_out, lim), 0);
-                                rto[0] = min(max(d1_out, lim), is - 1);
-                                act[0] = rfrom[0] <= rto[0];
-                            }
-                            if (idx_out < 0) {              // inward: across the triangle, only if the outside sample is empty
-                                float c2;
-                                if (((float)d0r - p00) * ((float)d0r - p20) < 0.0f)
-                                    c2 = (p21 - p01) / (p20 - p00) * ((float)d0r - p00) + p01;
-                                else
-                                    c2 = (p11 - p21) / (p10 - p20) * ((float)d0r - p20) + p21;
-                                if (c2 == c2) {
-                                    c2 = fminf(fmaxf(c2, -4.0f), (float)is + 4.0f);
-                                    const int lim = (dir > 0) ? (int)ceilf(c2) : (int)floorf(c2);
-                                    rfrom[1] = max(min(d1_in, lim), 0);
-                                    rto[1] = min(max(d1_in, lim), is - 1);
-                                    act[1] = rfrom[1] <= rto[1];
-                                }
-                            }
-                        }
-                    }
+            for (int stp = 8; stp > 0; stp >>= 1)
+                if ((int)fc.cum[fam + stp - 1] <= j) fam += stp;      // fam + stp - 1 <= 11, and cum[11] > j
+            const int fstart = fam ? (int)fc.cum[fam - 1] : 0;
+            const int var = fam >= 6 ? 1 : 0, ci = fam - 6 * var, edge = ci >> 1, axis = ci & 1;
+            const int b = fc.b, fn = fc.bf - b * F + var * F;
+            int v0 = edge, v1 = edge == 2 ? 0 : edge + 1, v2 = edge == 0 ? 2 : edge - 1;
+            if (var) { v0 = 2 - v0; v1 = 2 - v1; v2 = 2 - v2; }
+            const float* pa = axis ? fc.py : fc.px;      // coordinate along which the lines are counted
+            const float* pb = axis ? fc.px : fc.py;      // coordinate along the line
+            const float p00 = pa[v0], p01 = pb[v0], p10 = pa[v1], p11 = pb[v1], p20 = pa[v2], p21 = pb[v2];
+            int dir;
+            if (axis == 0) dir = (p00 < p10) ? -1 : 1;
+            else dir = (p00 < p10) ? 1 : -1;
+            const int d0_from = (int)fmaxf(ceilf(fminf(p00, p10)), 0.0f);
+            const float num = p10 - p00;
+            const float slope = (p11 - p01) / num;
+            const int d0r = mine ? d0_from + (j - fstart) : 0;
+            const float d1_cross = slope * ((float)d0r - p00) + p01;
+            bool geo = mine && d1_cross > -8.0f && d1_cross < (float)is + 8.0f;
+            const int d1_in = geo ? ((dir > 0) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross)) : 0;
+            const int d1_out = d1_in + dir;
+            geo = geo && !(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out);
+            const int a_in = geo ? d1_in : 0, a_out = geo ? d1_out : 0;
+            const int* idx = idx_map + (long)b * is * is;
+            const int idx_in = axis ? idx[(long)d0r * is + a_in] : idx[(long)a_in * is + d0r];
+            const int idx_out = axis ? idx[(long)d0r * is + a_out] : idx[(long)a_out * is + d0r];
+            const bool use0 = p10 != (float)d0r, use1 = p00 != (float)d0r;
+            // 1-ulp reciprocals: these only scale the pseudo-distances (compared at 1e-3), unlike c2 below, which picks
+            // the integer end of the inward range and stays an IEEE division
+            const float c0 = use0 ? num * __builtin_amdgcn_rcpf(p10 - (float)d0r) : 0.f;
+            const float c1 = use1 ? num * __builtin_amdgcn_rcpf((float)d0r - p00) : 0.f;
+            const bool act0 = geo && idx_in == fn;        // outward: my own sample just inside the edge
+            const bool act1 = geo && idx_out < 0;         // inward: only if the sample just outside is empty
+            // [0] outward, from the sample just outside the edge to the border; [1] inward, across the triangle
+            int rfrom[2], rto[2];
+            {
+                const int lim = (dir > 0) ? is - 1 : 0;
+                rfrom[0] = max(min(a_out, lim), 0);
+                rto[0] = min(max(a_out, lim), is - 1);
+            }
+            rfrom[1] = 0;
+            rto[1] = -1;
+            if (act1) {                                   // (silhouette edges only: a few per cent of the items)
+                float c2;
+                if (((float)d0r - p00) * ((float)d0r - p20) < 0.0f)
+                    c2 = (p21 - p01) / (p20 - p00) * ((float)d0r - p00) + p01;
+                else
+                    c2 = (p11 - p21) / (p10 - p20) * ((float)d0r - p20) + p21;
+                if (c2 == c2) {
+                    c2 = fminf(fmaxf(c2, -4.0f), (float)is + 4.0f);
+                    const int lim = (dir > 0) ? (int)ceilf(c2) : (int)floorf(c2);
+                    rfrom[1] = max(min(a_in, lim), 0);
+                    rto[1] = min(max(a_in, lim), is - 1);
                 }
-                // ---- slices of the line's source array: [lo, lo + nb) for both sweeps (all loads independent)
-                int lo[2] = {0, 0}, nb[2] = {0, 0};
-                long lid[2];
+            }
+            // slices of the lines' source arrays: [lo, lo + nb) for both sweeps; only lanes with a sweep touch memory
+            const bool on[2] = {act0 && rfrom[0] <= rto[0], act1 && rfrom[1] <= rto[1]};
+            int lo[2] = {0, 0}, nbp[2] = {0, 0};
+            long lid[2];
+            uint4 rf[2], rt[2];
 #pragma unroll
-                for (int ph = 0; ph < 2; ++ph) {
-                    lid[ph] = ((long)(ph * 2 + axis) * B + b) * is + d0r;
-                    if (act[ph]) {
-                        const int from = rfrom[ph], to = rto[ph];
-                        const unsigned long long* line = reinterpret_cast<const unsigned long long*>(axis == 0 ? colneg : rowneg) +
-                                                         ph * plane_words + ((long)b * is + d0r) * wpl;
-                        const unsigned short* cl = cum + lid[ph] * SWEEP_CUMW;
-                        const unsigned long long wf = line[from >> 6], wt = line[to >> 6];
-                        const int cf = cl[from >> 6], ct = cl[to >> 6];
-                        lo[ph] = cf + __popcll(wf & ((1ull << (from & 63)) - 1ull));
-                        nb[ph] = ct + __popcll(wt & (~0ull >> (63 - (to & 63)))) - lo[ph];
-                    }
+            for (int ph = 0; ph < 2; ++ph) {
+                lid[ph] = ((long)(ph * 2 + axis) * B + b) * is + d0r;
+                rf[ph] = make_uint4(0u, 0u, 0u, 0u);
+                rt[ph] = rf[ph];
+                if (on[ph]) {
+                    const uint4* lr = lrec + lid[ph] * wpl;
+                    rf[ph] = lr[rfrom[ph] >> 6];
+                    rt[ph] = lr[rto[ph] >> 6];
                 }
-                // ---- the two sweeps, flattened over the wave
+            }
+#pragma unroll
+            for (int ph = 0; ph < 2; ++ph) {
+                const unsigned long long wf = rf[ph].x | ((unsigned long long)rf[ph].y << 32);
+                const unsigned long long wt = rt[ph].x | ((unsigned long long)rt[ph].y << 32);
+                lo[ph] = (int)rf[ph].z + __popcll(wf & ((1ull << (rfrom[ph] & 63)) - 1ull));
+                nbp[ph] = on[ph] ? (int)rt[ph].z + __popcll(wt & (~0ull >> (63 - (rto[ph] & 63)))) - lo[ph] : 0;
+            }
+            const int nb0 = nbp[0], nb1 = nbp[1];
+            // ---- the pairs of the 64 items, flattened over the wave
+            const int n = nb0 + nb1;
+            const int incl = hm_wave_scan_incl(n);
+            const int npairs = __builtin_amdgcn_readlane(incl, 63);
+            if (npairs > 0) {
+                __builtin_amdgcn_wave_barrier();
+                s_start[wv][lane] = incl - n;
+                SweepItem it;
+                it.x = d1_cross; it.c0 = c0; it.c1 = c1;
+                it.base0 = (int)(lid[0] * is) + lo[0];
+                it.base1 = (int)(lid[1] * is) + lo[1];
+                it.nb0 = nb0;
+                it.fn = fn;
+                {
+                    const int m0 = var ? 2 - edge : edge, k1 = edge == 2 ? 0 : edge + 1, m1 = var ? 2 - k1 : k1;
+                    const int comp = axis ? 0 : 1;         // row sweeps move x, column sweeps move y
+                    it.meta = (mine ? el : 0) | ((2 * m0 + comp) << 4) | ((2 * m1 + comp) << 7) | (use0 ? 1 << 10 : 0) |
+                              (use1 ? 1 << 11 : 0);
+                }
+                s_item[wv][lane] = it;
+                wave_sync();
+                const int* st = s_start[wv];
+                int cur = -1;
+                float acc0 = 0.f, acc1 = 0.f;
 #pragma unroll 1
-                for (int ph = 0; ph < 2; ++ph) {
-                    const int n = nb[ph];
-                    const int incl = hm_wave_scan_incl(n);
-                    const int npairs = __builtin_amdgcn_readlane(incl, 63);
-                    if (npairs == 0) continue;
-                    __builtin_amdgcn_wave_barrier();
-                    s_start[wv][lane] = incl - n;
-                    SweepItem it;
-                    it.x = d1_cross; it.c0 = c0; it.c1 = c1;
-                    it.base = (int)(lid[ph] * is) + lo[ph];
-                    it.meta = ci | (use0 ? 8 : 0) | (use1 ? 16 : 0);
-                    s_item[wv][lane] = it;
-                    wave_sync();
-                    const int* st = s_start[wv];
-#pragma unroll 1
-                    for (int p = lane; p < npairs; p += 64) {
+                for (int base = 0; base < npairs; base += 256) {
+                    SweepSrc sc[4];
+                    int qi[4];
+                    bool ph1[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (base + 64 * k >= npairs) break;
+                        const int p = min(base + 64 * k + lane, npairs - 1);
                         int i = 0;
 #pragma unroll
                         for (int stp = 32; stp > 0; stp >>= 1)
                             if (st[i + stp] <= p) i += stp;
-                        const SweepItem q = s_item[wv][i];
-                        const SweepSrc sc = srcs[(long)q.base + (p - st[i])];
-                        const int qc = q.meta & 7;
-                        if (qc != cur) { HM_SWEEP_FLUSH() cur = qc; }
-                        if (ph == 0 || sc.owner == fn)
-                            sweep_term(ph == 0 ? -sc.g : sc.g, sc.d1, q.x, q.c0, q.c1, (q.meta & 8) != 0, (q.meta & 16) != 0,
-                                       eps, inv_is, pow2, is, acc0, acc1);
+                        const int r = p - st[i];
+                        const SweepItem& q = s_item[wv][i];
+                        const int q_nb0 = q.nb0;
+                        ph1[k] = r >= q_nb0;
+                        qi[k] = i;
+                        sc[k] = srcs[ph1[k] ? (long)q.base1 + (r - q_nb0) : (long)q.base0 + r];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (base + 64 * k >= npairs) break;
+                        if (base + 64 * k + lane < npairs) {
+                            const SweepItem& q = s_item[wv][qi[k]];
+                            const int meta = q.meta, key = meta & 0x3ff;
+                            if (key != cur) {
+                                if (cur >= 0) {
+                                    float* f = s_fg[wv][cur & 15];
+                                    atomicAdd(f + ((cur >> 4) & 7), acc0);
+                                    atomicAdd(f + ((cur >> 7) & 7), acc1);
+                                }
+                                cur = key;
+                                acc0 = 0.f;
+                                acc1 = 0.f;
+                            }
+                            if (!ph1[k] || sc[k].owner == q.fn)
+                                sweep_term(ph1[k] ? sc[k].g : -sc[k].g, sc[k].d1, q.x, q.c0, q.c1, (meta & (1 << 10)) != 0,
+                                           (meta & (1 << 11)) != 0, eps, inv_is, pow2, is, acc0, acc1);
+                        }
+                    }
+                }
+                if (cur >= 0) {
+                    float* f = s_fg[wv][cur & 15];
+                    atomicAdd(f + ((cur >> 4) & 7), acc0);
+                    atomicAdd(f + ((cur >> 7) & 7), acc1);
+                }
+            }
+            wave_sync();
+            // ---- results of the faces of this pass
+            if (lane < nfp) {
+                const SweepFace& ff = s_face[wv][lane];
+                const int eg = first + fb + lane;
+                const int off = ff.off, nit = (int)ff.cum[11];
+                const int u_lo = off >> 6, u_hi = (off + nit - 1) >> 6;
+                float v[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v[k] = s_fg[wv][lane][k];
+                float* out = parts + (long)ff.bf * 6;
+                if (u_lo == u_hi) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) out[k] = v[k];
+                } else if (ff.flags & 1) {
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) atomicAdd(out + k, v[k]);
+                } else {
+                    float* mp = sl.upart + ((long)u + eg) * 6;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) hm_partial_store(mp + k, v[k]);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    const unsigned int t = atomicAdd(sl.tickets + eg, 1u);
+                    if (t == (unsigned)(u_hi - u_lo)) {
+                        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        for (int uu = u_lo; uu <= u_hi; ++uu) {
+                            const float* rp = sl.upart + ((long)uu + eg) * 6;
+#pragma unroll
+                            for (int k = 0; k < 6; ++k) s[k] += hm_partial_load(rp + k);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) out[k] = s[k];
                     }
                 }
             }
-            HM_SWEEP_FLUSH()
-#undef HM_SWEEP_FLUSH
-#pragma unroll
-            for (int k = 0; k < 12; ++k) tot[k] = hm_wave_sum(tot[k]);
-            // tot[(edge * 2 + axis) * 2 + end point]: winding corner ko is end point 0 of edge ko and end point 1 of
-            // edge ko+2; x collects the axis-1 (row) sweeps, y the axis-0 (column) sweeps
-#pragma unroll
-            for (int ko = 0; ko < 3; ++ko) {
-                const int ep = (ko + 2) % 3;
-                const float gx = tot[(ko * 2 + 1) * 2 + 0] + tot[(ep * 2 + 1) * 2 + 1];
-                const float gy = tot[(ko * 2 + 0) * 2 + 0] + tot[(ep * 2 + 0) * 2 + 1];
-                if (var == 0) { fg[2 * ko] += gx; fg[2 * ko + 1] += gy; }
-                else { fg[2 * (2 - ko)] += gx; fg[2 * (2 - ko) + 1] += gy; }
-            }
-        }
-        if (lane == 0) {
-            float* out = parts + bf * 6;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) out[k] = fg[k];
-        }
-    }   // face loop
+        }   // face passes
+    }   // units
 }
 
 // ---------------------------------------------------------------- backward, pass 3: vertex gather + projection backward
@@ -1239,8 +1399,13 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
 // persistent sweep waves: 4 per SIMD.  More does not speed the sweep up and starves the concurrent hand-side kernels
 // of wave slots (they run on a second stream of the same hipGraph).
 #ifndef SWEEP_BLOCKS
-#define SWEEP_BLOCKS 1024
+#define SWEEP_BLOCKS 1536
 #endif
+// capacity of the sweep work list: units (64 items) indexed by `ufirst`, and per-unit partial slots of faces spread over
+// several units.  256 items per face on average is ~5x what a mesh filling the image produces; beyond it the sweep stays
+// correct (binary search for a unit's first face, float atomics for the faces past the slot table), only slower.
+static inline size_t sweep_ucap(int B, int F) { return (size_t)B * F * 4 + 1024; }
+static inline size_t sweep_slot_cap(int B, int F) { return sweep_ucap(B, F) + (size_t)B * F; }
 extern "C" {
 
 // workspace layout helper (bytes), all chunks 256-byte aligned
@@ -1266,8 +1431,12 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
     n += al256((size_t)B * SR_MAX * 8);                        // super-region bin counters + their ticket words
     n += al256((size_t)B * (S / 16) * (S / 16));               // per-region "outputs hold the empty pattern" flags
     n += al256((size_t)B * SR_MAX * F * 4);                    // super-region face lists (worst case: every face in every bin)
-    n += al256(4 * (size_t)B * is * SWEEP_CUMW * 2);            // per-line cumulative source counts
+    n += al256(4 * (size_t)B * is * (is / 64) * 16);            // per-line records {mask word, sources before it}
     n += al256(4 * (size_t)B * is * is * sizeof(SweepSrc));     // per-line source arrays (2 planes x 2 orientations)
+    n += al256((size_t)B * F * sizeof(SweepFace));              // sweep work list: face records,
+    n += al256((size_t)B * F * 4) * 2;                          //   their first items, their tickets,
+    n += al256(sweep_ucap(B, F) * 4);                           //   first face of every unit,
+    n += al256(sweep_slot_cap(B, F) * 24);                      //   per-unit partials of faces spread over several units
     return n;
 }
 
@@ -1276,7 +1445,8 @@ struct SilWs {
     float* ndc; float* faces9; FaceBox* boxes; int* idx_map; unsigned short* alpha16; float* dimg;
     float* partials; float* gimg; unsigned short* rowneg; unsigned short* colneg; float* parts;
     unsigned char* owned; int* bin_cnt; unsigned int* bin_done; unsigned char* region_state; int* bin_list;
-    unsigned short* cum; SweepSrc* srcs;
+    uint4* lrec; SweepSrc* srcs;
+    SweepList sweep;
 };
 static SilWs carve(void* ws, int B, int V, int F, int S)
 {
@@ -1300,9 +1470,34 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.bin_cnt = (int*)p; w.bin_done = (unsigned int*)(p + (size_t)B * SR_MAX * 4); p += al256((size_t)B * SR_MAX * 8);
     w.region_state = (unsigned char*)p; p += al256((size_t)B * (S / 16) * (S / 16));
     w.bin_list = (int*)p; p += al256((size_t)B * SR_MAX * F * 4);
-    w.cum = (unsigned short*)p; p += al256(4 * (size_t)B * is * SWEEP_CUMW * 2);
-    w.srcs = (SweepSrc*)p;
+    w.lrec = (uint4*)p; p += al256(4 * (size_t)B * is * (is / 64) * 16);
+    w.srcs = (SweepSrc*)p; p += al256(4 * (size_t)B * is * is * sizeof(SweepSrc));
+    w.sweep.tab = (SweepFace*)p; p += al256((size_t)B * F * sizeof(SweepFace));
+    w.sweep.offs = (int*)p; p += al256((size_t)B * F * 4);
+    w.sweep.tickets = (unsigned int*)p; p += al256((size_t)B * F * 4);
+    w.sweep.ufirst = (unsigned int*)p; p += al256(sweep_ucap(B, F) * 4);
+    w.sweep.upart = (float*)p;
+    w.sweep.cnt = (unsigned long long*)(w.counter + 16);        // zero between launches (re-armed by the last compaction block)
+    w.sweep.done = w.counter + 18;
+    w.sweep.total = (unsigned long long*)(w.counter + 20);
+    w.sweep.ucap = (int)sweep_ucap(B, F);
+    w.sweep.slot_cap = (int)sweep_slot_cap(B, F);
     return w;
+}
+
+// pass 2a (+ the work list of pass 2b in its first workgroups) and pass 2b
+static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const float* upstream, const float* keep_sum,
+                         hipStream_t stream)
+{
+    const int ncomp = hm_cdiv((long)B * F, 256);
+    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.rowneg, w.colneg,
+                       w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, w.faces9, w.boxes,
+                       w.owned, F, w.parts, w.sweep);
+}
+static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F, 2), SWEEP_BLOCKS)), dim3(256), 0, stream, w.sweep,
+                       w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts);
 }
 
 // Forward: silhouettes (B,S,S) of `verts` under per-frame intrinsics K, optional fused masked-MSE/IoU.
@@ -1370,10 +1565,8 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
         hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                            mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                            w.rowneg, w.colneg);
-    hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.rowneg, w.colneg,
-                       w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.cum);
-    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), SWEEP_BLOCKS)), dim3(256), 0, stream, w.faces9, w.boxes,
-                       w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, eps, w.parts, w.owned, face_order);
+    launch_lines(w, B, F, S, mode, upstream, keep_sum, stream);
+    launch_sweep(w, B, F, S, eps, stream);
     if (grad_verts)
         hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                            adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
@@ -1472,18 +1665,13 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     avg_ms[0] = ms / (float)reps;
     (void)hipMemsetAsync(w.bin_cnt, 0, (size_t)B * SR_MAX * 4, stream);
     (void)hipEventRecord(e0, stream);
-    for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F * 64, 256), SWEEP_BLOCKS)), dim3(256), 0, stream, w.faces9,
-                           w.boxes, w.idx_map, w.rowneg, w.colneg, w.srcs, w.cum, B, F, S, 1e-3f, w.parts, w.owned,
-                           face_order);
+    for (int i = 0; i < reps; ++i) launch_sweep(w, B, F, S, 1e-3f, stream);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
     avg_ms[1] = ms / (float)reps;
     (void)hipEventRecord(e0, stream);
-    for (int i = 0; i < reps; ++i)
-        hipLaunchKernelGGL(k_bwd_lines, dim3(hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.rowneg, w.colneg,
-                           w.gimg, w.dimg, 1, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.cum);
+    for (int i = 0; i < reps; ++i) launch_lines(w, B, F, S, 1, upstream, keep_sum, stream);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
