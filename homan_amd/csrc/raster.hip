@@ -723,8 +723,10 @@ __device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, f
 //    flattened over the wave: pair p goes to lane p % 64, which finds its item by a binary search of the items'
 //    exclusive pair counts in LDS (pairs per item are heavy-tailed: mean 5, lines tangent to the band hold hundreds).
 //  * a lane keeps running sums while its pairs stay on one (face, corner) target and flushes them into the face's six
-//    LDS accumulators when the target changes.  A face inside one unit is stored directly; a face spread over several
-//    units leaves per-unit partials and the unit that draws the last ticket adds them in unit order (deterministic).
+//    LDS accumulators when the target changes.  A face inside one unit is stored directly; a face cut by one unit
+//    boundary is added by its two units with hardware float atomics onto a zeroed target (commutative: deterministic);
+//    a face spread over three or more units leaves per-unit partials and the unit that draws the last ticket adds them
+//    in unit order (deterministic).
 // parts (B,F,3 mesh corners,2): d/d(x, y) of the NDC face vertices.
 struct SweepFace {            // 64 B: one face of the flattened work list
     int bf, b, off, flags;    // face slot b*F+fi, frame, first item, bit 0: accumulate with atomics (capacity overflow)
@@ -815,7 +817,7 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, const float* __
         const bool over = u_hi >= sl.ucap || u_hi + idx >= sl.slot_cap;
         rec.off = off;
         rec.flags = over ? 1 : 0;
-        zero = over && u_hi > u_lo;          // accumulated with float atomics by its units
+        zero = u_hi > u_lo && (over || u_hi == u_lo + 1);    // accumulated with float atomics by its units
         const uint4* r4 = reinterpret_cast<const uint4*>(&rec);
         uint4* t4 = reinterpret_cast<uint4*>(sl.tab + idx);
 #pragma unroll
@@ -933,6 +935,12 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
 }
 
 // ---------------------------------------------------------------- backward, pass 2b: edge sweeps (see the work list above)
+#ifdef SWEEP_TIMING
+__device__ unsigned long long g_sweep_t[8];
+#define SWT_MARK(k) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) swt[k] += t_ - swt_last; swt_last = t_; }
+#else
+#define SWT_MARK(k)
+#endif
 __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
                                                    const SweepSrc* __restrict__ srcs,
                                                    const uint4* __restrict__ lrec, int B, int F, int S,
@@ -941,6 +949,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
     __shared__ SweepFace s_face[4][SWEEP_PASS_FACES];
     __shared__ float s_fg[4][SWEEP_PASS_FACES][6];
     __shared__ int s_start[4][64];
+    __shared__ int s_head[4][256];
     __shared__ SweepItem s_item[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int is = 2 * S;
@@ -951,6 +960,9 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
     const int N = (int)(tot & 0xffffffffull), W = (int)(tot >> 32);
     const int U = (N + 63) >> 6;
     const int nwaves = (int)(((long)gridDim.x * blockDim.x) >> 6);
+#ifdef SWEEP_TIMING
+    unsigned long long swt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, swt_last = __builtin_readcyclecounter();
+#endif
     for (int u = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)); u < U; u += nwaves) {
         int first;
         if (u < sl.ucap) first = (int)sl.ufirst[u];
@@ -980,6 +992,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             }
             for (int i = lane; i < SWEEP_PASS_FACES * 6; i += 64) (&s_fg[wv][0][0])[i] = 0.f;
             wave_sync();
+            SWT_MARK(0)
             const int el = e - fb;
             bool mine = g < N && el >= 0 && el < nfp;
             // ---- per-lane item setup (lanes without an item run on harmless in-range addresses and are masked below)
@@ -1020,6 +1033,10 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             const float c0 = use0 ? num * __builtin_amdgcn_rcpf(p10 - (float)d0r) : 0.f;
             const float c1 = use1 ? num * __builtin_amdgcn_rcpf((float)d0r - p00) : 0.f;
             const bool act0 = geo && idx_in == fn;        // outward: my own sample just inside the edge
+#ifdef SWEEP_TIMING
+            if (__ballot(act0) == 0x12345ull) continue;   // (never) keeps the mark below after the owner loads
+#endif
+            SWT_MARK(1)
             const bool act1 = geo && idx_out < 0;         // inward: only if the sample just outside is empty
             // [0] outward, from the sample just outside the edge to the border; [1] inward, across the triangle
             int rfrom[2], rto[2];
@@ -1071,6 +1088,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             const int n = nb0 + nb1;
             const int incl = hm_wave_scan_incl(n);
             const int npairs = __builtin_amdgcn_readlane(incl, 63);
+            SWT_MARK(2)
             if (npairs > 0) {
                 __builtin_amdgcn_wave_barrier();
                 s_start[wv][lane] = incl - n;
@@ -1091,20 +1109,39 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                 const int* st = s_start[wv];
                 int cur = -1;
                 float acc0 = 0.f, acc1 = 0.f;
+                int carry = 0;                 // (item + 1) that owns the pairs running into the current batch
+                // 256 pairs per round, four CONSECUTIVE pairs per lane.  Which item a pair belongs to comes from a
+                // scatter + max-scan instead of a search: every item whose first pair falls into the round drops its
+                // number at that position, and a running maximum carries it over the item's pairs.
 #pragma unroll 1
                 for (int base = 0; base < npairs; base += 256) {
+                    int4* hd = reinterpret_cast<int4*>(s_head[wv]);
+                    hd[lane] = make_int4(0, 0, 0, 0);
+                    wave_sync();
+                    const int ex = incl - n;
+                    if (n > 0 && ex >= base && ex < base + 256) s_head[wv][ex - base] = lane + 1;
+                    wave_sync();
+                    const int4 h = hd[lane];
+                    int m[4];
+                    m[0] = h.x; m[1] = max(m[0], h.y); m[2] = max(m[1], h.z); m[3] = max(m[2], h.w);
+                    int inc = m[3];            // inclusive max-scan over the lanes (item numbers are positive: 0 is neutral)
+                    inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false));    // row_shr:1
+                    inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false));    // row_shr:2
+                    inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false));    // row_shr:4
+                    inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false));    // row_shr:8
+                    inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false));    // row_bcast:15
+                    inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false));    // row_bcast:31
+                    int before = __builtin_amdgcn_update_dpp(0, inc, 0x138, 0xf, 0xf, false);       // wave_shr:1
+                    before = max(before, carry);
+                    carry = max(carry, __builtin_amdgcn_readlane(inc, 63));
                     SweepSrc sc[4];
                     int qi[4];
                     bool ph1[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        if (base + 64 * k >= npairs) break;
-                        const int p = min(base + 64 * k + lane, npairs - 1);
-                        int i = 0;
-#pragma unroll
-                        for (int stp = 32; stp > 0; stp >>= 1)
-                            if (st[i + stp] <= p) i += stp;
-                        const int r = p - st[i];
+                        const int p = min(base + 4 * lane + k, npairs - 1);
+                        const int i = max(max(before, m[k]) - 1, 0);
+                        const int r = max(p - st[i], 0);
                         const SweepItem& q = s_item[wv][i];
                         const int q_nb0 = q.nb0;
                         ph1[k] = r >= q_nb0;
@@ -1113,8 +1150,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        if (base + 64 * k >= npairs) break;
-                        if (base + 64 * k + lane < npairs) {
+                        if (base + 4 * lane + k < npairs) {
                             const SweepItem& q = s_item[wv][qi[k]];
                             const int meta = q.meta, key = meta & 0x3ff;
                             if (key != cur) {
@@ -1140,6 +1176,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                 }
             }
             wave_sync();
+            SWT_MARK(3)
             // ---- results of the faces of this pass
             if (lane < nfp) {
                 const SweepFace& ff = s_face[wv][lane];
@@ -1153,9 +1190,11 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                 if (u_lo == u_hi) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) out[k] = v[k];
-                } else if (ff.flags & 1) {
+                } else if ((ff.flags & 1) || u_hi == u_lo + 1) {
+                    // two units: 0 + a + b in either order is the same float, so two fire-and-forget hardware atomics
+                    // are deterministic and nobody waits (the compaction zeroed the target); (capacity overflow: atomics)
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) atomicAdd(out + k, v[k]);
+                    for (int k = 0; k < 6; ++k) unsafeAtomicAdd(out + k, v[k]);
                 } else {
                     float* mp = sl.upart + ((long)u + eg) * 6;
 #pragma unroll
@@ -1174,8 +1213,15 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                     }
                 }
             }
+            SWT_MARK(4)
         }   // face passes
     }   // units
+#ifdef SWEEP_TIMING
+    if (lane == 0) {
+        swt[5] = 1;
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_sweep_t[k], swt[k]);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- backward, pass 3: vertex gather + projection backward
@@ -1399,7 +1445,7 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
 // persistent sweep waves: 4 per SIMD.  More does not speed the sweep up and starves the concurrent hand-side kernels
 // of wave slots (they run on a second stream of the same hipGraph).
 #ifndef SWEEP_BLOCKS
-#define SWEEP_BLOCKS 1536
+#define SWEEP_BLOCKS 1280
 #endif
 // capacity of the sweep work list: units (64 items) indexed by `ufirst`, and per-unit partial slots of faces spread over
 // several units.  256 items per face on average is ~5x what a mesh filling the image produces; beyond it the sweep stays
@@ -1687,6 +1733,16 @@ int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, fl
     return hipMemcpyAsync(out, w.partials, (size_t)B * (S / 8) * (S / 8) * 16, hipMemcpyDeviceToDevice, stream) == hipSuccess
                ? HM_OK : HM_ERR_LAUNCH;
 }
+#ifdef SWEEP_TIMING
+int hm_debug_sweep_timing(unsigned long long* out)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_t), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_t), z, sizeof(z));
+    return HM_OK;
+}
+#endif
 int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks)
 {
     hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(raster_fwd_blocks, k_raster_fwd, 64 * RASTER_WAVES, 0);
