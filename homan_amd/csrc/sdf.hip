@@ -349,6 +349,37 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(const float* __restr
     }
 }
 
+// per-vertex sampled values in world units (what the reference returns as sdf_meta["dist_values"], scenesdf.py:141-146):
+// dv0 (B,V0) = clamp(SDF of mesh 1, 0) at the vertices of mesh 0, times the box scale of mesh 1; dv1 (B,V1) the reverse.
+// grid (chunks, B, 2 pairs), on the grids / boxes / masks left in the workspace by the last hm_collision_fwd.
+__global__ __launch_bounds__(SDF_THREADS) void k_sdf_values(const float* __restrict__ v0, int V0,
+                                                             const float* __restrict__ v1, int V1, int B,
+                                                             const float* __restrict__ boxes,
+                                                             const unsigned int* __restrict__ masks,
+                                                             const float* __restrict__ phig, float* __restrict__ dv0,
+                                                             float* __restrict__ dv1)
+{
+    const int b = blockIdx.y, pair = blockIdx.z, k = pair;
+    const int Vl = pair == 0 ? V1 : V0;
+    const int i = blockIdx.x * SDF_THREADS + threadIdx.x;
+    if (i >= Vl) return;
+    const long g = (long)k * B + b;
+    const float* bx = boxes + g * 4;
+    const SdfSample sm = sdf_sample_setup((pair == 0 ? v1 : v0) + ((long)b * Vl + i) * 3, bx, masks + g * (SDF_N * SDF_N));
+    const float* phik = phig + g * (SDF_N * SDF_N * SDF_N);
+    const float x1 = (float)sm.x0 + 1.0f, y1 = (float)sm.y0 + 1.0f, z1 = (float)sm.z0 + 1.0f;
+    const float wx[2] = {x1 - sm.ix, sm.ix - (float)sm.x0}, wy[2] = {y1 - sm.iy, sm.iy - (float)sm.y0};
+    const float wz[2] = {z1 - sm.iz, sm.iz - (float)sm.z0};
+    float val = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int xx = sm.x0 + (c & 1), yy = sm.y0 + ((c >> 1) & 1), zz = sm.z0 + (c >> 2);
+        const float p = ((sm.need >> c) & 1u) ? phik[(long)(zz * SDF_N + yy) * SDF_N + xx] : 0.f;
+        val += p * wx[c & 1] * wy[(c >> 1) & 1] * wz[c >> 2];
+    }
+    (pair == 0 ? dv1 : dv0)[(long)b * Vl + i] = val * bx[3];
+}
+
 // full grid (debug / API completeness: what `SDF()(faces, verts)` returns after the reference's clamp).  grid (N*N*N/256, B)
 __global__ __launch_bounds__(SDF_THREADS) void k_sdf_grid(const float* __restrict__ vn, const int* __restrict__ fc, int V, int F,
                                                            int B, const unsigned int* __restrict__ masks,
@@ -424,6 +455,22 @@ int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, con
                        w.tris0, w.tris1, w.need_cnt, w.need_list, w.phi);
     hipLaunchKernelGGL(k_sdf_sample, dim3(chunks, B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, w.boxes,
                        w.masks, w.phi, g0, g1, w.partials, w.counter, out1);
+    return hm_launch_status();
+}
+
+// Penetration depths per vertex (reference homan/interactions/scenesdf.py:141-146 dist_values; consumed by
+// homan/eval/pointmetrics.py:102-124): dv0 (B,V0) = depth of the vertices of mesh 0 inside mesh 1, dv1 (B,V1) the reverse,
+// in world units, from the workspace of the last hm_collision_fwd on the same vertices.  Only voxels that call sampled
+// hold distances, so verts0 / verts1 must be the arrays given to it.
+int hm_collision_dist_values(const float* verts0, int V0, const float* verts1, int V1, int F0, int F1, int B, float* dv0,
+                             float* dv1, void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts0 && verts1 && dv0 && dv1 && workspace && B > 0 && V0 > 0 && V1 > 0);
+    CollWs w;
+    coll_layout(workspace, B, V0, V1, F0, F1, &w);
+    const int chunks = hm_cdiv(V0 > V1 ? V0 : V1, SDF_THREADS);
+    hipLaunchKernelGGL(k_sdf_values, dim3(chunks, B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, w.boxes,
+                       w.masks, w.phi, dv0, dv1);
     return hm_launch_status();
 }
 

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "hm_collision_workspace_bytes": (_SZ, [_I, _I, _I, _I, _I]),
     "hm_collision_fwd": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _VP]),
     "hm_collision_read_grid": (_I, [_VP, _I, _I, _I, _I, _I, _I, _I, _I, _VP, _VP, _VP]),
+    "hm_collision_dist_values": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "hm_adam_slot_bytes": (_SZ, []),
     "hm_adam_step": (_I, [_VP, _I, _VP, _F, _F, _F, _I, _I, _VP]),
     "hm_log_scalars": (_I, [_VP, _I, _VP, _I, _VP, _VP]),

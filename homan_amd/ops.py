@@ -663,3 +663,18 @@ class _CollisionLoss(torch.autograd.Function):
 
 def collision_loss(vh, vo, cctx, scale_factor=0.2):
     return _CollisionLoss.apply(vh, vo, cctx, scale_factor)
+
+
+def collision_dist_values(vh, vo, cctx, scale_factor=0.2):
+    """`sdf_meta["dist_values"]` of reference homan/interactions/scenesdf.py:141-146 for the two-mesh scene
+    [hand, object]: {(1, 0): (B,Vh) depth of the hand vertices inside the object, (0, 1): (B,Vo) the reverse}, world
+    units, no gradient.  Runs the SDF forward on (vh, vo) and samples its grids (csrc/sdf.hip)."""
+    with torch.no_grad():
+        vh, vo = _f32(vh.detach()), _f32(vo.detach())
+        collision_loss(vh, vo, cctx, scale_factor)
+        dv0 = torch.empty(vh.shape[:2], device=vh.device)
+        dv1 = torch.empty(vo.shape[:2], device=vo.device)
+        _lib.check(_lib.lib().hm_collision_dist_values(_lib.ptr(vh), cctx.V0, _lib.ptr(vo), cctx.V1, cctx.f0.shape[0],
+                                                       cctx.f1.shape[0], cctx.B, _lib.ptr(dv0), _lib.ptr(dv1),
+                                                       _lib.ptr(cctx.ws), _lib.stream()), "hm_collision_dist_values")
+    return {(1, 0): dv0, (0, 1): dv1}

@@ -204,6 +204,11 @@ size_t hm_collision_workspace_bytes(int B, int V0, int V1, int F0, int F1);
 int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, const float* verts1, const int* faces1,
                      int V1, int F1, int B, float scale_factor, float* g0, float* g1, float* out1, void* workspace,
                      hipStream_t stream);
+/* per-vertex penetration depths in world units (reference homan/interactions/scenesdf.py:141-146 `dist_values`, read by
+ * homan/eval/pointmetrics.py:102-124): dv0 (B,V0) = clamp(SDF of mesh 1, 0) at the vertices of mesh 0 = dist_values[(1,0)],
+ * dv1 (B,V1) = dist_values[(0,1)]; from the workspace of the last hm_collision_fwd on the same verts0 / verts1. */
+int hm_collision_dist_values(const float* verts0, int V0, const float* verts1, int V1, int F0, int F1, int B, float* dv0,
+                             float* dv1, void* workspace, hipStream_t stream);
 /* clamp(SDF,0) on the full 32^3 grid of mesh `which`, from the workspace of the last hm_collision_fwd */
 int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int V0, int V1, int F0, int F1, float* phi,
                            void* workspace, hipStream_t stream);

@@ -118,6 +118,20 @@ def compute_collision_loss(verts_hand, verts_object, faces_object, closed_hand_f
     return {"loss_collision": loss.mean()}
 
 
+def get_inter_metrics(verts_person, verts_object, faces_person, faces_object):
+    """reference homan/eval/pointmetrics.py:102-124: maximal penetration depth of the hand into the object per scene and
+    the has-contact flag, from the scene SDF's dist_values[(1, 0)]."""
+    hand_nb = verts_person.shape[0] // verts_object.shape[0]
+    if hand_nb == 2:
+        verts_person = verts_person.view(-1, hand_nb, verts_person.shape[1], 3).view(verts_object.shape[0], -1, 3)
+        faces_person = torch.cat([faces_person[0], faces_person[1] + verts_person.shape[1]], 0).unsqueeze(0)
+    elif hand_nb > 3:
+        raise ValueError(f"Invalid hand nb {hand_nb}")
+    _, meta = sdf_scene_loss([faces_person[0], faces_object[0]], [verts_person, verts_object])
+    max_depths = meta["dist_values"][(1, 0)].max(1)[0]
+    return {"pen_depths": max_depths.numpy().tolist(), "has_contact": (max_depths > 0).numpy().tolist()}
+
+
 def masked_mean_loss(dists, mask):
     """reference homan/interactions/contactloss.py:50-57."""
     mask = mask.float()

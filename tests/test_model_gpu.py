@@ -155,3 +155,34 @@ def test_fused_trajectory_matches_reference_loop(mano_model):
     for k in ("loss_sil_obj", "loss_contact", "loss_collision", "iou_object"):
         np.testing.assert_allclose(evo[k][0], rec["evo_" + k][0], rtol=2e-4, atol=1e-9, err_msg=k)
     np.testing.assert_array_equal(model.mano_rot.detach().cpu().numpy(), rec["in_mano_rot"])
+
+
+def test_joint_fit_resume_roundtrip(mano_model, tmp_path):
+    """reference fit_vid_dataset.py:365-372 / :322-338: a fit saved as joint_fit.pt and resumed through
+    `state_dict=` (jointopt.py:126-127, strict=False) continues from the very same parameters."""
+    from homan_amd import checkpoint, synth
+    from homan_amd.jointopt import FusedStepper, build_model
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=11, frames=4, rend_size=64, image_size=64, obj="bottle", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+
+    def make(state_dict=None):
+        return build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                           objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                           optimize_mano=True, image_size=64, mano_model=mano_model, rend_size=64, state_dict=state_dict,
+                           sync_metrics=False)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    model = make()
+    FusedStepper(model, lw, 1e-2, 5).run(5)
+    path = tmp_path / "joint_fit.pt"
+    checkpoint.save_joint_fit(model, path)
+    resumed = make(checkpoint.load_joint_fit(path))
+    fresh = make()
+    with torch.no_grad():
+        assert torch.equal(resumed.get_verts_object()[0], model.get_verts_object()[0])
+        assert torch.equal(resumed.get_verts_hand()[0], model.get_verts_hand()[0])
+        assert not torch.equal(fresh.get_verts_object()[0], model.get_verts_object()[0])
+        la, _ = model(loss_weights=lw)
+        lb, _ = resumed(loss_weights=lw)
+    for k in la:
+        assert torch.equal(la[k], lb[k]), k

@@ -205,3 +205,14 @@ def test_collision_vs_oracle(obj, mano_model):
     _close(lh, lo, rtol=1e-4, msg="collision loss")
     _close(ah.grad, a.grad, rtol=1e-3, atol_frac=1e-3, msg="collision grad hand")
     _close(bh.grad, b.grad, rtol=1e-3, atol_frac=1e-3, msg="collision grad obj")
+    # per-vertex penetration depths (reference scenesdf.py:141-146) and the evaluation metric built on them
+    # (reference eval/pointmetrics.py:102-124)
+    from homan_amd import pointmetrics
+    dv = ops.collision_dist_values(vh.to(DEV), vo.to(DEV), cctx)
+    for key in ((1, 0), (0, 1)):
+        assert meta["dist_values"][key].max() > 0
+        _close(dv[key], meta["dist_values"][key].detach(), rtol=1e-4, atol_frac=1e-5, msg=f"dist_values {key}")
+    want = om.get_inter_metrics(vh, vo, closed[None], of[None])
+    got = pointmetrics.get_inter_metrics(vh.to(DEV), vo.to(DEV), closed[None], of[None].to(DEV))
+    assert got["has_contact"] == want["has_contact"] and all(want["has_contact"])
+    np.testing.assert_allclose(got["pen_depths"], want["pen_depths"], rtol=1e-4)

@@ -78,6 +78,24 @@ def test_state_dict_keys_cover_reference(mano_model):
     assert not missing, missing
 
 
+def test_joint_fit_checkpoint_contract(mano_model, tmp_path):
+    """joint_fit.pt (reference fit_vid_dataset.py:365-372): {"state_dict": ...} on CPU without the MANO layer's buffers,
+    holding every key the reference's own file holds and its consumers read (postprocess.py:16-77), values intact."""
+    from homan_amd import checkpoint
+    rec, model, _, _ = _build(NAMES[0], mano_model)
+    path = tmp_path / "joint_fit.pt"
+    checkpoint.save_joint_fit(model, path)
+    raw = torch.load(path)
+    assert set(raw.keys()) == {"state_dict"} and not any("mano_model" in k for k in raw["state_dict"])
+    viz_only = {"masks_human", "masks_object", "textures_hand", "textures_object"}
+    ref_saved = {k for k in rec["state_dict_keys"].tolist() if "mano_model" not in k}
+    assert not (ref_saved - set(raw["state_dict"]) - viz_only)
+    sd = checkpoint.load_joint_fit(path, device="cpu")
+    for k, v in model.state_dict().items():
+        if "mano_model" not in k:
+            assert torch.equal(sd[k], v.detach().cpu()), k
+
+
 def test_mano_rot_trans_never_stepped(mano_model):
     """Reference quirk (jointopt.py:128-151): mano_rot / mano_trans get grads but sit in no Adam group."""
     rec, _, _, _ = _build("ref_step1_cube_b4_s64", mano_model)
