@@ -1253,6 +1253,49 @@ __global__ void k_bwd_gather(const float* __restrict__ parts, const int* __restr
     grad_verts[3 * i + 2] = -(dxn * x + dyn * y) / (zz * zz);
 }
 
+// ---------------------------------------------------------------- rgb output (nr `render`: lighting + texture_size 1)
+// Flat-shaded colour image of the index map left by the last forward: per output pixel the 2x2 samples read their owner
+// face's single texel times light = ambient + directional * relu(<n, dir>), n = normalize((v0-v1) x (v2-v1), eps 1e-5)
+// of the owner WINDING in camera space (the reversed copy of fill_back flips n); empty samples read the background;
+// vertical flip and 2x2 average as for the other outputs.  grid (S*S/256, B).  rgb (B,3,S,S).
+__global__ __launch_bounds__(256) void k_shade_rgb(const int* __restrict__ idx_map, const float* __restrict__ verts,
+                                                   const int* __restrict__ faces, int faces_bstride,
+                                                   const float* __restrict__ textures, int B, int V, int F, int S,
+                                                   float dx, float dy, float dz, float amb, float dirw, float bg0,
+                                                   float bg1, float bg2, float* __restrict__ rgb)
+{
+    const int b = blockIdx.y, pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= S * S) return;
+    const int r = pix / S, c = pix - r * S, is = 2 * S;
+    const int* idx = idx_map + (long)b * is * is;
+    float acc[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int yi = is - 1 - (2 * r + (q >> 1)), xi = 2 * c + (q & 1);
+        const int fn = idx[(long)yi * is + xi];
+        float col[3] = {bg0, bg1, bg2};
+        if (fn >= 0) {
+            const int f = fn >= F ? fn - F : fn;
+            const int* fc = faces + (long)b * faces_bstride + 3 * f;
+            const float* v0 = verts + ((long)b * V + fc[0]) * 3;
+            const float* v1 = verts + ((long)b * V + fc[1]) * 3;
+            const float* v2 = verts + ((long)b * V + fc[2]) * 3;
+            const float a[3] = {v0[0] - v1[0], v0[1] - v1[1], v0[2] - v1[2]};
+            const float e[3] = {v2[0] - v1[0], v2[1] - v1[1], v2[2] - v1[2]};
+            float n[3] = {a[1] * e[2] - a[2] * e[1], a[2] * e[0] - a[0] * e[2], a[0] * e[1] - a[1] * e[0]};
+            const float len = fmaxf(sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]), 1e-5f);
+            float cs = (n[0] / len) * dx + (n[1] / len) * dy + (n[2] / len) * dz;
+            if (fn >= F) cs = -cs;
+            const float light = amb + dirw * fmaxf(cs, 0.f);
+            const float* t = textures + ((long)b * F + f) * 3;
+            col[0] = t[0] * light; col[1] = t[1] * light; col[2] = t[2] * light;
+        }
+        acc[0] += col[0]; acc[1] += col[1]; acc[2] += col[2];
+    }
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) rgb[(((long)b * 3 + ch) * S + r) * S + c] = 0.25f * acc[ch];
+}
+
 // ---------------------------------------------------------------- depth-image backward (NMR backward_depth_map)
 // d pooled_depth / d face vertices, analytic: per covered sample of a face, with zp its depth and w_k its (clamped,
 // renormalised) barycentrics,  dz_k += g w_k zp^2 / z_k^2  and  d(x,y)_k += -g w_k zp^2 tmp[l] is/2  with
@@ -1623,6 +1666,22 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
 const float* hm_sil_parts(const void* workspace, int B, int V, int F, int S)
 {
     return carve((void*)workspace, B, V, F, S).parts;
+}
+
+// rgb image (B,3,S,S) of the last hm_sil_fwd on this workspace (same verts / faces): per-face colours `textures`
+// (B,F,3) under flat lighting, as nr.renderer.Renderer.render returns it for texture_size 1 (reference
+// homan/homan.py:535-538 with the light of :173-176).  light_dir / background: HOST float[3].
+int hm_shade_rgb(const float* verts, const int* faces, int faces_bstride, const float* textures, int B, int V, int F, int S,
+                 const float* light_dir, float intensity_ambient, float intensity_directional, const float* background,
+                 float* rgb, void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && faces && textures && light_dir && background && rgb && workspace);
+    HM_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0);
+    SilWs w = carve(workspace, B, V, F, S);
+    hipLaunchKernelGGL(k_shade_rgb, dim3(hm_cdiv((long)S * S, 256), B), dim3(256), 0, stream, w.idx_map, verts, faces,
+                       faces_bstride, textures, B, V, F, S, light_dir[0], light_dir[1], light_dir[2], intensity_ambient,
+                       intensity_directional, background[0], background[1], background[2], rgb);
+    return hm_launch_status();
 }
 
 // Backward of the depth image of the last hm_sil_fwd (called with pooled_depth): grad_pooled_depth (B,S,S) ->

@@ -6,15 +6,25 @@ Same constructor keywords, same Parameter / buffer names (so `named_parameters()
 `get_verts_object()` and `get_verts_hand(detach_scale=False)`.  All arithmetic runs in the hand-written HIP kernels
 of libhoman_amd.so through `homan_amd.ops`; there is no CPU path.
 
-Not mirrored (visualisation, off the optimisation path): render / render_gt / render_with_gt / save_obj,
-assign_human_masks, textures_* buffers.
+Visualisation (off the optimisation path, no gradients): `model.renderer` (homan_amd.nmr.Renderer with the reference's
+light, homan.py:168-176), the combined scene topology / colour buffers (:177-219) and render / render_gt /
+render_with_gt / render_limem / save_obj (:510-628) on the same rasteriser.  Not mirrored: assign_human_masks (:239-296,
+never called by the reference).
 """
+import numpy as np
 import torch
 from torch import nn
 
-from . import constants, lossutils, ops
+from . import constants, lossutils, nmr, ops, trans3d
 from .losses import Losses
 from .manomodel import ManoModel
+from .meshutils import get_faces_and_textures
+
+
+def combine_verts(verts_list):
+    """reference homan/utils/geometry.py:43-47."""
+    batch_size = verts_list[0].shape[0]
+    return torch.cat([v.reshape(batch_size, -1, 3) for v in verts_list], 1)
 
 
 def matrix_to_rot6d(rotmat):
@@ -97,6 +107,9 @@ class HOMan(nn.Module):
         self.register_buffer("camintr_rois_object", f32(camintr_rois_object))
         self.register_buffer("camintr_rois_hand", f32(camintr_rois_hand))
         self.register_buffer("faces_object", faces_object.detach().clone())
+        # white per-face textures of the single-mesh depth renders (reference homan.py:145-151; state_dict keys)
+        self.register_buffer("textures_object", torch.ones(faces_object.shape[0], faces_object.shape[1], 1, 1, 1, 3))
+        self.register_buffer("textures_hand", torch.ones(faces_hand.shape[0], faces_hand.shape[1], 1, 1, 1, 3))
         self.register_buffer("faces_hand", faces_hand.detach().clone())
         if camintr is None:
             camintr = torch.tensor([[[1, 0, 0.5], [0, 1, 0.5], [0, 0, 1]]], dtype=torch.float32)
@@ -138,6 +151,105 @@ class HOMan(nn.Module):
         with torch.no_grad():
             self.verts_hand_init = self.get_verts_hand()[0].detach().clone()
             self.verts_object_init = self.get_verts_object()[0].detach().clone()
+        self._setup_visualisation(batch)
+
+    # ------------------------------------------------------------------ visualisation (reference homan.py:168-219, 510-628)
+    def _setup_visualisation(self, batch_size):
+        """Renderer with the reference's light and the combined [object, hand...] scene meshes in prediction colours
+        (gold / grey), ground-truth colours (green / blue) and both (:177-219).  Buffers are plain attributes, as in
+        the reference (they are not part of the state_dict)."""
+        self.renderer = nmr.Renderer(image_size=self.image_size, K=self.camintr.clone(), orig_size=1)
+        self.renderer.light_direction = [1, 0.5, 1]
+        self.renderer.light_intensity_direction = 0.3
+        self.renderer.light_intensity_ambient = 0.5
+        self.renderer.background_color = [1.0, 1.0, 1.0]
+        verts_object, verts_hand = self.verts_object_init, self.verts_hand_init
+        ref_verts_list = [verts_object[:1]] + [verts_hand[i:i + 1] for i in range(self.hand_nb)]
+        ref_faces_list = [self.faces_object[:1]] + [self.faces_hand[i:i + 1] for i in range(self.hand_nb)]
+        pred_colors = ["gold"] + ["grey"] * self.hand_nb
+        gt_colors = ["green"] + ["blue"] * self.hand_nb
+        faces, textures = get_faces_and_textures(ref_verts_list, ref_faces_list, color_names=pred_colors)
+        self.faces = faces.repeat(batch_size, 1, 1)
+        self.textures = textures.repeat(batch_size, 1, 1, 1, 1, 1)
+        faces_gt, textures_gt = get_faces_and_textures(ref_verts_list, ref_faces_list, color_names=gt_colors)
+        self.textures_gt = textures_gt.repeat(batch_size, 1, 1, 1, 1, 1)
+        self.faces_gt = faces_gt.repeat(batch_size, 1, 1)
+        faces_with_gt, textures_with_gt = get_faces_and_textures(ref_verts_list + ref_verts_list,
+                                                                 ref_faces_list + ref_faces_list,
+                                                                 color_names=pred_colors + gt_colors)
+        self.textures_with_gt = textures_with_gt.repeat(batch_size, 1, 1, 1, 1, 1)
+        self.faces_with_gt = faces_with_gt.repeat(batch_size, 1, 1)
+
+    def render_limem(self, renderer, verts, faces, textures, K, max_in_batch=5):
+        """:510-544: render in chunks, -> images (N,S,S,3) float in [0,1] (numpy), masks (N,S,S) bool."""
+        sample_nb = verts.shape[0]
+        assert verts.dim() == 3 and verts.shape[2] == 3
+        assert tuple(faces.shape[::2]) == (sample_nb, 3) and tuple(textures.shape[2:]) == (1, 1, 1, 3)
+        assert tuple(K.shape) == (sample_nb, 3, 3)
+        chunk_nb = (sample_nb + 1) // min(max_in_batch, sample_nb) if max_in_batch is not None else 1
+        all_images, all_masks = [], []
+        for vert, face, tex, camintr in zip(verts.chunk(chunk_nb, 0), faces.chunk(chunk_nb, 0),
+                                            textures.chunk(chunk_nb, 0), K.chunk(chunk_nb, 0)):
+            chunk_images, _, chunk_masks = renderer.render(vertices=vert.contiguous(), faces=face.contiguous(),
+                                                           textures=tex.contiguous(), K=camintr.contiguous())
+            all_images.append(np.clip(chunk_images.cpu().numpy().transpose(0, 2, 3, 1), 0, 1))
+            all_masks.append(chunk_masks.cpu().numpy().astype(bool))
+        return np.concatenate(all_images), np.concatenate(all_masks)
+
+    def _viz_K(self, renderer, n):
+        K = renderer.K
+        return (K.repeat(n, 1, 1) if K.shape[0] == 1 else K)[:n]
+
+    def render(self, renderer, rotate=False, viz_len=10, max_in_batch=None):
+        """:546-562."""
+        with torch.no_grad():
+            verts_object = self.get_verts_object()[0]
+            verts_hands = self.get_verts_hand()[0]
+            verts_hands = [verts_hands[i::self.hand_nb] for i in range(self.hand_nb)]
+            verts_combined = combine_verts([verts_object] + verts_hands)
+            if rotate:
+                verts_combined = trans3d.rot_points(verts_combined)
+            n = min(viz_len, verts_combined.shape[0])
+            return self.render_limem(renderer, verts_combined[:viz_len], self.faces[:viz_len], self.textures[:viz_len],
+                                     K=self._viz_K(renderer, n), max_in_batch=max_in_batch)
+
+    def render_gt(self, renderer, verts_hand_gt=None, verts_object_gt=None, rotate=False, viz_len=10, max_in_batch=None):
+        """:564-581."""
+        with torch.no_grad():
+            verts_combined = combine_verts([verts_object_gt, verts_hand_gt])
+            if rotate:
+                verts_combined = trans3d.rot_points(verts_combined)
+            n = min(viz_len, verts_combined.shape[0])
+            return self.render_limem(renderer, verts_combined[:viz_len], self.faces[:viz_len], self.textures_gt[:viz_len],
+                                     K=self._viz_K(renderer, n), max_in_batch=max_in_batch)
+
+    def render_with_gt(self, renderer, verts_hand_gt=None, verts_object_gt=None, rotate=False, viz_len=10, init=False,
+                       max_in_batch=None):
+        """:583-613."""
+        with torch.no_grad():
+            if init:
+                verts_object_pred, verts_hands = self.verts_object_init, self.verts_hand_init
+            else:
+                verts_object_pred, verts_hands = self.get_verts_object()[0], self.get_verts_hand()[0]
+            verts_hands_pred = [verts_hands[i::self.hand_nb] for i in range(self.hand_nb)]
+            verts_list = [verts_object_pred] + verts_hands_pred + [verts_object_gt] + [v for v in verts_hand_gt]
+            verts_combined = combine_verts(verts_list)
+            if rotate:
+                verts_combined = trans3d.rot_points(verts_combined)
+            n = min(viz_len, verts_combined.shape[0])
+            return self.render_limem(renderer, verts_combined[:viz_len], self.faces_with_gt[:viz_len],
+                                     self.textures_with_gt[:viz_len], K=self._viz_K(renderer, n),
+                                     max_in_batch=max_in_batch)
+
+    def save_obj(self, fname):
+        """:615-628: first scene of the clip as a Wavefront OBJ (combined object + hand mesh)."""
+        with torch.no_grad():
+            verts_combined = combine_verts([self.get_verts_object()[0], self.get_verts_hand()[0]])
+        with open(fname, "w") as fp:
+            for v in verts_combined[0].cpu().numpy():
+                fp.write(f"v {v[0]:f} {v[1]:f} {v[2]:f}\n")
+            for face in self.faces[0].cpu().numpy():
+                fp.write(f"f {face[0] + 1:d} {face[1] + 1:d} {face[2] + 1:d}\n")
 
     # ------------------------------------------------------------------ vertices
     def get_verts_object(self):

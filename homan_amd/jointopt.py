@@ -1,7 +1,8 @@
 """Joint hand-object optimisation loop (reference homan/jointopt.py:22-201), MI355X-native.
 
-`optimize_hand_object` keeps the reference signature and return value `(model, loss_evolution, imgs)`.
-Visualisation / video export (reference :159-177,193-200) is not part of the hot path: `imgs` is empty.
+`optimize_hand_object` keeps the reference signature and return value `(model, loss_evolution, imgs)`.  When the
+input `images` are given, a frontal + top-down frame is rendered every `viz_step` iterations and `imgs` maps the
+step to the saved file (reference :158-176); the video export (libyana np2vid, :193-200) is not built.
 
 Two execution modes:
   mode="eager"  the reference's loop verbatim: torch.optim.Adam over the three name-selected groups, per-key
@@ -439,6 +440,25 @@ class FusedStepper:
         return out
 
 
+def save_front_top(model, images, step, viz_folder, viz_len=7):
+    """reference jointopt.py:159-176: frontal overlays over the top-down renders, frames side by side, halved in size
+    (2x2 mean instead of cv2.resize), saved as <viz_folder>/<step:08d>.jpg.  -> path."""
+    import os
+    from PIL import Image
+    from .visualize import visualize_hand_object
+    with torch.no_grad():
+        frontal, top_down = visualize_hand_object(model, images, dist=1, viz_len=viz_len)
+    os.makedirs(viz_folder, exist_ok=True)
+    frontal = np.concatenate([img for img in frontal], 1)
+    top_down = np.concatenate([img for img in top_down], 1)
+    front_top = np.concatenate([frontal, top_down[:frontal.shape[0], :frontal.shape[1]]], 0)
+    h, w = front_top.shape[0] // 2 * 2, front_top.shape[1] // 2 * 2
+    front_top = front_top[:h, :w].reshape(h // 2, 2, w // 2, 2, 3).astype(np.float32).mean((1, 3)).astype(np.uint8)
+    path = os.path.join(viz_folder, f"{step:08d}.jpg")
+    Image.fromarray(front_top).save(path)
+    return path
+
+
 def optimize_hand_object(person_parameters, object_parameters, class_name="default", objvertices=None, objfaces=None,
                          loss_weights=None, num_iterations=400, lr=1e-2, images=None, viz_step=10, viz_folder="tmp",
                          camintr=None, hand_proj_mode="persp", optimize_mano=False, optimize_mano_beta=True,
@@ -448,16 +468,28 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
     model = build_model(person_parameters, object_parameters, class_name, objvertices, objfaces, camintr,
                         hand_proj_mode, optimize_mano, optimize_mano_beta, optimize_object_scale, state_dict,
                         image_size, mano_model, rend_size, sync_metrics=(mode == "eager"), ordinal_depth=ordinal_depth)
+    # visualisation frames every `viz_step` iterations (reference jointopt.py:158-176), only when the caller hands the
+    # input images over; the videos the reference assembles from them (libyana np2vid, :193-200) are not built
+    imgs = OrderedDict()
+    viz = images is not None and viz_step
     if mode in ("graph", "fused"):
         cls = GraphStepper if mode == "graph" else FusedStepper
         stepper = cls(model, loss_weights, lr, num_iterations)
-        stepper.run(num_iterations)
-        return model, stepper.loss_evolution(num_iterations), OrderedDict()
+        step = 0
+        while step < num_iterations:
+            if viz:
+                imgs[step] = save_front_top(model, images, step, viz_folder, viz_len)
+            chunk = min(viz_step, num_iterations - step) if viz else num_iterations
+            stepper.run(chunk)
+            step += chunk
+        return model, stepper.loss_evolution(num_iterations), imgs
     if mode != "eager":
         raise ValueError(f"mode {mode} not in [eager|graph|fused]")
     optimizer = torch.optim.Adam(parameter_groups(model, lr))
     loss_evolution = defaultdict(list)
-    for _ in range(num_iterations):
+    for step in range(num_iterations):
+        if viz and step % viz_step == 0:
+            imgs[step] = save_front_top(model, images, step, viz_folder, viz_len)
         optimizer.zero_grad()
         loss_dict, metric_dict = model(loss_weights=loss_weights)
         loss_dict_weighted = {k: loss_dict[k] * loss_weights[k.replace("loss", "lw")] for k in loss_dict}
@@ -469,4 +501,4 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
         loss_evolution["loss"].append(loss.item())
         loss.backward()
         optimizer.step()
-    return model, dict(loss_evolution), OrderedDict()
+    return model, dict(loss_evolution), imgs

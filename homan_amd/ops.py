@@ -286,6 +286,27 @@ def depth_render(verts, K, sctx, orig_size):
     return _DepthRender.apply(verts, K, sctx, orig_size)
 
 
+def render_rgbd(verts, K, sctx, textures, light_direction=(0, 1, 0), intensity_ambient=0.5, intensity_directional=0.5,
+                background_color=(0, 0, 0), orig_size=1.0):
+    """`renderer.render(vertices, faces, textures, K=)` -> (rgb (B,3,S,S), depth (B,S,S), alpha (B,S,S)) for the
+    reference's per-face colour textures (B,F,1,1,1,3) (reference homan/homan.py:510-545).  Visualisation only: no
+    gradient.  Rasterises with csrc/raster.hip (hm_sil_fwd) and shades its index map (hm_shade_rgb)."""
+    import ctypes
+    with torch.no_grad():
+        verts, K = _f32(verts.detach()), _f32(K)
+        alpha, depth = _DepthRender.apply(verts, K, sctx, orig_size)
+        tex = _f32(textures.reshape(sctx.B, sctx.F, 3))
+        rgb = torch.empty(sctx.B, 3, sctx.S, sctx.S, device=verts.device)
+        ld = (ctypes.c_float * 3)(*[float(x) for x in light_direction])
+        bg = (ctypes.c_float * 3)(*[float(x) for x in background_color])
+        _lib.check(_lib.lib().hm_shade_rgb(_lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(tex), sctx.B, sctx.V,
+                                           sctx.F, sctx.S, ctypes.cast(ld, ctypes.c_void_p),
+                                           float(intensity_ambient), float(intensity_directional),
+                                           ctypes.cast(bg, ctypes.c_void_p), _lib.ptr(rgb), _lib.ptr(sctx.workspace),
+                                           _lib.stream()), "hm_shade_rgb")
+    return rgb, depth, alpha
+
+
 class _OrdinalDepthLoss(torch.autograd.Function):
     """reference homan/lossutils.py:133-169 for the two layers (object, hand) of homan/homan.py:384-419."""
 

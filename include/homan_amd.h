@@ -155,6 +155,14 @@ int hm_ordinal_depth_fwd(const float* d0, const float* d1, const float* a0, cons
 int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
                          const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
                          float* g1, hipStream_t stream);
+/* rgb output of nr.renderer.Renderer.render for the reference's texture_size-1 per-face colours (reference
+ * homan/homan.py:535-538 render_limem, light set at :173-176, colours from homan/meshutils.py:7-51): (B,3,S,S) image of
+ * the LAST hm_sil_fwd on this workspace (same verts / faces), flat lighting ambient + directional * relu(<n, dir>) on the
+ * camera-space face normals, background where no face covers, vertical flip and 2x2 average as the other outputs.
+ * textures (B,F,3); light_dir, background: HOST float[3]. */
+int hm_shade_rgb(const float* verts, const int* faces, int faces_bstride, const float* textures, int B, int V, int F, int S,
+                 const float* light_dir, float intensity_ambient, float intensity_directional, const float* background,
+                 float* rgb, void* workspace, hipStream_t stream);
 /* device pointer to the (B,F,3,2) per-(face, corner) NDC gradients left in `workspace` by the last hm_sil_bwd */
 const float* hm_sil_parts(const void* workspace, int B, int V, int F, int S);
 /* forward intermediates kept in the workspace (tests): face-index map (B,2S,2S) int32, packed NDC faces (B,F,9) */

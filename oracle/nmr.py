@@ -8,6 +8,7 @@ Reference call sites restated here:
   nr.renderer.Renderer(image_size=, K=, R=, t=, orig_size=)       homan/losses.py:73-77, homan/homan.py:168-172
   renderer(verts, faces, K=, mode="silhouettes") -> (B,S,S)       homan/losses.py:187
   renderer.render(verts, faces, textures[, K=]) -> (rgb, depth, alpha)   homan/homan.py:391,406,535
+  (rgb: flat per-face colours under nr.lighting, ambient + directional; homan/homan.py:173-176 sets the light)
 Published algorithm: Kato et al., "Neural 3D Mesh Renderer", CVPR 2018
 (projection with OpenCV-style distortion, fill_back face doubling, hard
 z-buffer rasteriser at 2x supersampling, vertical flip, 2x2 average pool,
@@ -98,6 +99,44 @@ def rasterize_alpha_depth(faces, image_size, anti_aliasing=True, near=DEFAULT_NE
     return alpha, depth, idx
 
 
+def lighting(faces, textures, intensity_ambient=0.5, intensity_directional=0.5, color_ambient=(1, 1, 1),
+             color_directional=(1, 1, 1), direction=(0, 1, 0)):
+    """nr.lighting (UNVERIFIED recollection of the upstream package): per-face flat shading of the textures.
+    faces (B,NF,3,3) camera-space face vertices, textures (B,NF,t,t,t,3).  light = ambient + directional *
+    relu(<normal, direction>), normal = normalize((v0 - v1) x (v2 - v1), eps 1e-5); `direction` is used as given
+    (not normalised)."""
+    bs, nf = faces.shape[:2]
+    light = torch.zeros(bs, nf, 3, dtype=torch.float32)
+    if intensity_ambient != 0:
+        light = light + intensity_ambient * torch.tensor(color_ambient, dtype=torch.float32)[None, None, :]
+    if intensity_directional != 0:
+        f = faces.reshape(bs * nf, 3, 3)
+        v10 = f[:, 0] - f[:, 1]
+        v12 = f[:, 2] - f[:, 1]
+        normals = torch.nn.functional.normalize(torch.cross(v10, v12, dim=1), eps=1e-5).reshape(bs, nf, 3)
+        d = torch.tensor(direction, dtype=torch.float32)[None, None, :]
+        cos = torch.relu((normals * d).sum(2))
+        light = light + intensity_directional * torch.tensor(color_directional, dtype=torch.float32)[None, None, :] \
+            * cos[:, :, None]
+    return textures * light[:, :, None, None, None, :]
+
+
+def shade_index_map(idx, textures, background_color, anti_aliasing=True):
+    """rgb image of a face index map (B,is,is) (no flip yet) under per-face colours: texture_size 1, so every sample
+    of a face reads the face's single texel; empty samples read the background; then the vertical flip and the 2x2
+    average pool of the other outputs.  -> (B,3,S,S)."""
+    B = idx.shape[0]
+    col = textures.reshape(B, -1, 3)
+    bg = torch.tensor(background_color, dtype=torch.float32)
+    ii = torch.as_tensor(idx).long()
+    rgb = torch.where((ii >= 0)[..., None], torch.gather(col, 1, ii.clamp(min=0).reshape(B, -1, 1).expand(-1, -1, 3))
+                      .reshape(*ii.shape, 3), bg.expand(*ii.shape, 3))
+    rgb = rgb.flip(1).permute(0, 3, 1, 2)
+    if anti_aliasing:
+        rgb = torch.nn.functional.avg_pool2d(rgb, kernel_size=(2, 2))
+    return rgb
+
+
 class Renderer:
     """Subset of nr.renderer.Renderer used by the reference (camera_mode='projection')."""
 
@@ -137,10 +176,20 @@ class Renderer:
         return alpha
 
     def render(self, vertices, faces, textures=None, K=None, R=None, t=None, dist_coeffs=None, orig_size=None):
+        """-> (rgb (B,3,S,S), depth (B,S,S), alpha (B,S,S)).  textures (B,F,1,1,1,3) (the only texture size the
+        reference uses, homan/meshutils.py:7-51); None renders white faces (the hot path never reads rgb).  Order as
+        upstream (UNVERIFIED): fill_back doubles faces and textures, lighting on the camera-space faces, projection,
+        rasterisation."""
         f = self._ndc_faces(vertices, faces, K, R, t, dist_coeffs, orig_size)
-        alpha, depth, _ = rasterize_alpha_depth(f, self.image_size, self.anti_aliasing, self.near, self.far,
-                                                self.rasterizer_eps)
-        rgb = alpha[:, None].repeat(1, 3, 1, 1)  # untextured: the hot path never reads rgb
+        alpha, depth, idx = rasterize_alpha_depth(f, self.image_size, self.anti_aliasing, self.near, self.far,
+                                                  self.rasterizer_eps)
+        if textures is None:
+            textures = torch.ones(faces.shape[0], faces.shape[1], 1, 1, 1, 3)
+        faces_l = torch.cat((faces, faces[:, :, [2, 1, 0]]), dim=1) if self.fill_back else faces
+        tex = torch.cat((textures, textures), dim=1) if self.fill_back else textures
+        tex = lighting(vertices_to_faces(vertices.detach(), faces_l), tex.float(), self.light_intensity_ambient,
+                       self.light_intensity_direction, (1, 1, 1), (1, 1, 1), self.light_direction)
+        rgb = shade_index_map(idx, tex, self.background_color, self.anti_aliasing)
         return rgb, depth, alpha
 
     def __call__(self, vertices, faces, textures=None, mode=None, K=None, R=None, t=None,

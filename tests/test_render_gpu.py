@@ -1,0 +1,123 @@
+"""Visualisation renders: rgb / depth / alpha of `renderer.render` and the model-level
+render / visualize_hand_object surface (reference homan/homan.py:510-613, homan/visualize.py:44-128) against the oracle's
+restatement of the NMR `render` output (lighting + per-face colours; PARITY UNPINNED leaf, see oracle/nmr.py)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _scene(B=3, S=64):
+    from homan_amd import synth
+    ov, of = synth.bottle_mesh()
+    g = torch.Generator().manual_seed(3)
+    verts = torch.from_numpy(ov)[None].repeat(B, 1, 1)
+    ang = torch.rand(B, generator=g) * 1.5
+    R = torch.stack([torch.tensor(synth._rot_x(float(a)) @ synth._rot_y(0.3), dtype=torch.float32) for a in ang])
+    verts = verts @ R + torch.tensor([0.0, 0.0, 0.55]) + torch.randn(B, 1, 3, generator=g) * 0.01
+    faces = torch.from_numpy(of).long()[None].repeat(B, 1, 1)
+    K = torch.tensor([[[1.3, 0, 0.5], [0, 1.3, 0.5], [0, 0, 1]]]).repeat(B, 1, 1)
+    tex = torch.rand(B, faces.shape[1], 1, 1, 1, 3, generator=g)
+    return verts, faces, K, tex
+
+
+def test_render_rgb_depth_alpha_vs_oracle():
+    from homan_amd import nmr as hnmr
+    from oracle import nmr as onmr
+    verts, faces, K, tex = _scene()
+    S = 64
+    ro = onmr.Renderer(image_size=S, K=K, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
+    rh = hnmr.Renderer(image_size=S, K=K.to(DEV), orig_size=1)
+    for r in (ro, rh):      # the light of reference homan/homan.py:173-176
+        r.light_direction = [1, 0.5, 1]
+        r.light_intensity_direction = 0.3
+        r.light_intensity_ambient = 0.5
+        r.background_color = [1.0, 1.0, 1.0]
+    rgb_o, dep_o, al_o = ro.render(verts, faces, tex)
+    rgb_h, dep_h, al_h = rh.render(verts.to(DEV), faces.to(DEV), tex.to(DEV))
+    assert torch.equal(al_h.cpu(), al_o)                                   # coverage is integer work: bit-exact
+    np.testing.assert_allclose(dep_h.cpu().numpy(), dep_o.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(rgb_h.cpu().numpy(), rgb_o.numpy(), rtol=0, atol=2e-6)      # float shading: 2e-6 absolute
+    assert 0.03 < float(al_o.mean()) < 0.9 and float(rgb_o.std()) > 0.05   # a real image, lit and partly background
+    sil = rh(verts.to(DEV), faces.to(DEV), mode="silhouettes")
+    assert torch.equal(sil, al_h)
+    # default light / black background (upstream constructor defaults)
+    ro2 = onmr.Renderer(image_size=S, K=K, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
+    rh2 = hnmr.Renderer(image_size=S, K=K.to(DEV), orig_size=1)
+    np.testing.assert_allclose(rh2.render(verts.to(DEV), faces.to(DEV), tex.to(DEV))[0].cpu().numpy(),
+                               ro2.render(verts, faces, tex)[0].numpy(), rtol=0, atol=2e-6)
+
+
+def test_model_render_and_visualize(mano_model, tmp_path):
+    """model.render / render_gt / render_with_gt / visualize_hand_object: shapes, dtypes and the reference's
+    composition - the combined [object, hand] mesh in gold / grey over a white background equals a direct oracle render
+    of the same combined mesh."""
+    from homan_amd import synth, visualize
+    from homan_amd.jointopt import build_model
+    from homan_amd.meshutils import COLORS
+    from oracle import nmr as onmr
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    S = 64
+    clip = synth.make_clip(seed=5, frames=3, rend_size=S, image_size=S, obj="bottle", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                        objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                        optimize_mano=True, image_size=S, mano_model=mano_model, rend_size=S)
+    B = 3
+    Fo, Fh = model.faces_object.shape[1], model.faces_hand.shape[1]
+    assert tuple(model.faces.shape) == (B, Fo + Fh, 3) and tuple(model.textures.shape) == (B, Fo + Fh, 1, 1, 1, 3)
+    np.testing.assert_allclose(model.textures[0, 0].reshape(3).cpu().numpy(), COLORS["gold"], rtol=1e-6)
+    np.testing.assert_allclose(model.textures[0, -1].reshape(3).cpu().numpy(), COLORS["grey"], rtol=1e-6)
+    imgs, masks = model.render(model.renderer, viz_len=7, max_in_batch=2)
+    assert imgs.shape == (B, S, S, 3) and masks.shape == (B, S, S) and masks.dtype == bool and imgs.dtype == np.float32
+    with torch.no_grad():
+        vo, vh = model.get_verts_object()[0].cpu(), model.get_verts_hand()[0].cpu()
+    comb = torch.cat([vo, vh], 1)
+    ro = onmr.Renderer(image_size=S, K=model.camintr.cpu(), R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
+    ro.light_direction, ro.light_intensity_direction, ro.background_color = [1, 0.5, 1], 0.3, [1.0, 1.0, 1.0]
+    rgb_o, _, al_o = ro.render(comb, model.faces.cpu(), model.textures.cpu())
+    np.testing.assert_array_equal(masks, al_o.numpy().astype(bool))
+    np.testing.assert_allclose(imgs, np.clip(rgb_o.numpy().transpose(0, 2, 3, 1), 0, 1), rtol=0, atol=2e-6)
+    # ground-truth colours and the pred + gt overlay
+    g_imgs, _ = model.render_gt(model.renderer, verts_hand_gt=vh.to(DEV), verts_object_gt=vo.to(DEV), viz_len=2)
+    assert g_imgs.shape == (2, S, S, 3) and not np.allclose(g_imgs, imgs[:2])
+    w_imgs, w_masks = model.render_with_gt(model.renderer, verts_hand_gt=[vh.to(DEV) + 0.02], verts_object_gt=vo.to(DEV) + 0.02,
+                                           viz_len=7, max_in_batch=2)
+    assert w_imgs.shape == (B, S, S, 3) and (w_masks.sum() >= masks.sum())
+    images = (np.random.RandomState(0).rand(B, 48, S, 3) * 255).astype(np.uint8)      # h < w: padded to a square
+    front, top = visualize.visualize_hand_object(model, images, viz_len=7, max_in_batch=2)
+    assert front.shape == (B, 48, S, 3) and front.dtype == np.uint8 and top.shape == (B, S, S, 3) and top.dtype == np.uint8
+    m = masks[0][:48]
+    np.testing.assert_array_equal(front[0][m], (imgs[0][:48][m] * 255).astype(np.uint8))
+    np.testing.assert_array_equal(front[0][~m], images[0][~m])
+    assert not np.array_equal(top, (imgs * 255).astype(np.uint8))       # the rotated view differs from the frontal one
+    model.save_obj(tmp_path / "scene.obj")
+    lines = open(tmp_path / "scene.obj").read().splitlines()
+    assert sum(l.startswith("v ") for l in lines) == comb.shape[1] and sum(l.startswith("f ") for l in lines) == Fo + Fh
+
+
+@pytest.mark.parametrize("mode", ["eager", "fused"])
+def test_optimize_hand_object_saves_frames(mode, mano_model, tmp_path):
+    """reference jointopt.py:158-176: a frame every viz_step iterations when the input images are given."""
+    from homan_amd import synth
+    from homan_amd.jointopt import optimize_hand_object
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    S = 64
+    clip = synth.make_clip(seed=5, frames=3, rend_size=S, image_size=S, obj="bottle", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    images = (np.random.RandomState(0).rand(3, S, S, 3) * 255).astype(np.uint8)
+    model, evo, imgs = optimize_hand_object(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                                            objvertices=clip["objvertices"], objfaces=clip["objfaces"],
+                                            camintr=clip["camintr"], loss_weights=dict(synth.STEP2_LOSS_WEIGHTS),
+                                            num_iterations=5, images=images, viz_step=2, viz_folder=str(tmp_path / mode),
+                                            optimize_mano=True, image_size=S, rend_size=S, mano_model=mano_model, mode=mode)
+    assert list(imgs) == [0, 2, 4] and len(evo["loss"]) == 5
+    from PIL import Image
+    im = np.asarray(Image.open(imgs[4]))
+    assert im.shape == (S, 3 * S // 2, 3)       # (frontal over top-down) x 3 frames, halved
