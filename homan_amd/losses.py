@@ -44,6 +44,22 @@ class Losses:
         self.last_silhouettes = sil
         return {"loss_sil_obj": loss}, {"iou_object": self._metric(iou)}
 
+    def compute_sil_loss_hand(self, verts, faces):
+        """reference losses.py:166-181 - present but disabled upstream (its only call site, homan.py:477-481, is commented
+        out, and the body rebinds `verts` inside its own loop, so it cannot run past the first frame).  Built as written
+        for the intent: each hand rendered in its own ROI camera (`camintr_rois_hand[i]`), masked L2 against its target
+        normalised by ITS keep-mask area (unlike the object term, which divides by the area of the whole clip), averaged
+        over the hands.  verts (N,778,3) camera space, faces (N,Fh,3).  Differentiable (NMR pseudo-gradient)."""
+        if getattr(self, "_sil_ctx_hand", None) is None:
+            if faces.shape[0] != verts.shape[0]:          # (hand_nb,Fh,3): hand i of the clip uses faces[i % hand_nb]
+                faces = faces.repeat(verts.shape[0] // faces.shape[0], 1, 1)
+            self._sil_ctx_hand = ops.SilhouetteContext(faces, verts.shape[1], verts.shape[0], self.ref_mask_hand.shape[-1],
+                                                       verts.device)
+        rend = ops.silhouette_render(verts, self.camintr_rois_hand, self._sil_ctx_hand)
+        image = self.keep_mask_hand * rend
+        per_hand = ((image - self.ref_mask_hand) ** 2).sum(dim=(1, 2)) / self.keep_mask_hand.sum(dim=(1, 2))
+        return {"loss_sil_hand": per_hand.sum().reshape(1) / len(verts)}
+
     def compute_interaction_loss(self, verts_hand_b, verts_object_b, nn=None):
         """reference losses.py:199-242: verts_hand_b (B, 1, 778, 3), verts_object_b (B, 1, V, 3)."""
         if verts_hand_b.shape[1] != 1 or verts_object_b.shape[1] != 1:

@@ -200,8 +200,9 @@ class OracleLosses:
     """reference homan/losses.py:52-242."""
 
     def __init__(self, camintr, ref_mask_object, keep_mask_object, ref_verts2d_hand, camintr_rois_object,
-                 hand_nb, inter_type, rend_size):
+                 hand_nb, inter_type, rend_size, ref_mask_hand=None, keep_mask_hand=None, camintr_rois_hand=None):
         self.camintr = camintr.clone()
+        self.ref_mask_hand, self.keep_mask_hand, self.camintr_rois_hand = ref_mask_hand, keep_mask_hand, camintr_rois_hand
         self.ref_mask_object, self.keep_mask_object = ref_mask_object, keep_mask_object
         self.ref_verts2d_hand = ref_verts2d_hand
         self.camintr_rois_object = camintr_rois_object
@@ -226,6 +227,18 @@ class OracleLosses:
         loss = torch.Tensor([0.0]) + l_m
         ious = o_yana.batch_mask_iou(image, self.ref_mask_object)
         return {"loss_sil_obj": loss / len(verts)}, {"iou_object": ious.mean().item()}
+
+    def compute_sil_loss_hand(self, verts, faces):
+        """losses.py:166-181 (disabled upstream, see homan_amd/losses.py): per-hand ROI render, masked L2 normalised by
+        the hand's own keep area, mean over hands - the loop as evidently intended (`verts[i]`; `faces` holds one topology
+        per hand of a frame, homan.py:152, so hand i of the clip uses faces[i % hand_nb])."""
+        loss = torch.Tensor([0.0])
+        for i in range(len(verts)):
+            rend = self.renderer(verts[i].unsqueeze(0), faces[i % len(faces)].unsqueeze(0), K=self.camintr_rois_hand[i].unsqueeze(0),
+                                 mode="silhouettes")
+            image = self.keep_mask_hand[i] * rend
+            loss = loss + torch.sum((image - self.ref_mask_hand[i]) ** 2) / self.keep_mask_hand[i].sum()
+        return {"loss_sil_hand": loss / len(verts)}
 
     def assign_interaction_pairs(self, verts_hand, verts_object):
         """losses.py:98-139."""
@@ -335,7 +348,8 @@ class OracleHOMan(nn.Module):
         self.closed_faces = torch.as_tensor(mano_model["closed_faces"].astype(np.int64))
         self.losses = OracleLosses(self.camintr, self.ref_mask_object, self.keep_mask_object,
                                    self.ref_verts2d_hand, self.camintr_rois_object, self.hand_nb,
-                                   inter_type, rend_size)
+                                   inter_type, rend_size, self.ref_mask_hand, self.keep_mask_hand,
+                                   self.camintr_rois_hand)
 
     def compute_ordinal_depth_loss(self):
         """homan.py:384-419: depth renders of the object and of each hand at the full-image intrinsics

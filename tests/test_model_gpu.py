@@ -107,6 +107,18 @@ def test_hip_vs_oracle_cfg_sized_clip(mano_model):
     dv = (hm.get_verts_hand()[0].detach().cpu() - om.get_verts_hand()[0].detach()).abs().max().item()
     do = (hm.get_verts_object()[0].detach().cpu() - om.get_verts_object()[0].detach()).abs().max().item()
     assert dv < 1e-6 and do < 1e-6, (dv, do)     # metres
+    # hand silhouette term (reference losses.py:166-181, present but disabled upstream): value + NMR pseudo-gradient
+    vo_h = om.get_verts_hand()[0].detach().requires_grad_(True)
+    lo_h = om.losses.compute_sil_loss_hand(vo_h, om.faces_hand)["loss_sil_hand"]
+    lo_h.sum().backward()
+    vh_h = hm.get_verts_hand()[0].detach().requires_grad_(True)
+    lh_h = hm.losses.compute_sil_loss_hand(vh_h, hm.faces_hand)["loss_sil_hand"]
+    lh_h.sum().backward()
+    assert float(lo_h) > 0
+    np.testing.assert_allclose(lh_h.detach().cpu().numpy(), lo_h.detach().numpy(), rtol=1e-5)
+    scale = vo_h.grad.abs().max().item()
+    assert scale > 0
+    np.testing.assert_allclose(vh_h.grad.cpu().numpy(), vo_h.grad.numpy(), rtol=1e-3, atol=1e-3 * scale)
 
 
 @pytest.mark.parametrize("name", NAMES)
