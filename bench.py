@@ -39,15 +39,17 @@ def kernel_bytes(B, S, F):
     written once).
       k_raster_fwd: packed (B,F,3,3) faces + 8-byte boxes + super-region bin lists read; (2S)^2 int32 index map, pooled
                     silhouettes, dimg, alpha bit-plane and the four sweep bit-planes written; keep/ref read.
-      k_bwd_sweep : faces + boxes + owned flags + index map + four 1-bit planes + per-line cumulative counts read;
-                    per-face corner gradients (6 floats) written.  (The per-line source arrays are data dependent,
-                    ~0.3 MB per launch here, and not counted.)
-      k_bwd_lines : four 1-bit planes + dimg read, per-line cumulative counts written (+ the source arrays, as above)."""
+      k_bwd_lines : four 1-bit planes + dimg read, per-line records {64 mask bits, sources before them} written
+                    (16 B per 64 samples); its work-list blocks read faces + boxes + owned flags (46 B per face).
+                    (The per-line source arrays and the face records of the work list are data dependent - sources
+                    ~0.3 MB, ~45 % of the faces are active - and not counted.)
+      k_bwd_sweep : face records of the work list (64 B + 4 B first item, bound: every face), index map, per-line records
+                    read; per-face corner gradients (6 floats) written.  (Source arrays as above.)"""
     is_ = 2 * S
     is2 = is_ ** 2
     return {"k_raster_fwd": B * (F * (36 + 8 + 5) + is2 * 4 + 4 * S * S * 4 + 5 * is2 // 8),
-            "k_bwd_sweep": B * (F * (36 + 8 + 2) + is2 * 4 + 4 * is2 // 8 + 4 * is_ * 32 + F * 24),
-            "k_bwd_lines": B * (4 * is2 // 8 + S * S * 4 + 4 * is_ * 32)}
+            "k_bwd_sweep": B * (F * (64 + 4) + is2 * 4 + is2 + F * 24),
+            "k_bwd_lines": B * (4 * is2 // 8 + S * S * 4 + is2 + F * (36 + 8 + 2))}
 
 
 def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256):

@@ -1583,10 +1583,22 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, w.faces9, w.boxes,
                        w.owned, F, w.parts, w.sweep);
 }
+static int g_sweep_blocks = SWEEP_BLOCKS;
 static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F, 2), SWEEP_BLOCKS)), dim3(256), 0, stream, w.sweep,
+    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F, 2), g_sweep_blocks)), dim3(256), 0, stream, w.sweep,
                        w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts);
+}
+
+// Scheduling hint, no effect on results: number of persistent workgroups of the edge-sweep kernel (default 1280 = 5 per
+// CU).  The sweeps share the GPU with whatever runs on the caller's other streams; a loop whose other stream is the
+// longer chain (collision + contact terms) finishes sooner with fewer sweep workgroups (768).  Process-wide; read when
+// hm_sil_bwd is called (or captured).  Returns the previous value; blocks <= 0 only queries.
+int hm_tune_sweep_blocks(int blocks)
+{
+    const int prev = g_sweep_blocks;
+    if (blocks > 0) g_sweep_blocks = blocks;
+    return prev;
 }
 
 // Forward: silhouettes (B,S,S) of `verts` under per-frame intrinsics K, optional fused masked-MSE/IoU.

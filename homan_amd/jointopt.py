@@ -281,10 +281,14 @@ class FusedStepper:
         if self.on["sil"]:
             m.losses.sil_ctx.calibrate()         # cost-sorted launch orders from the current state (scheduling only)
         if capture:
+            # scheduling hint baked into the captured launches: with the collision / contact terms the hand-side stream is
+            # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way)
+            prev = _lib.lib().hm_tune_sweep_blocks(768 if (self.on["col"] or self.on["con"]) else 1280)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.forward_backward(log=True)
                 self.opt.step(zero_grad=False)
+            _lib.lib().hm_tune_sweep_blocks(prev)
 
     def _reported(self, k):
         o = self.on

@@ -155,6 +155,10 @@ int hm_ordinal_depth_fwd(const float* d0, const float* d1, const float* a0, cons
 int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
                          const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
                          float* g1, hipStream_t stream);
+/* scheduling hint (no reference counterpart, no effect on results): persistent workgroups of the edge-sweep kernel,
+ * default 1280; 768 suits loops whose other streams carry the longer chain (collision + contact terms).  Process-wide,
+ * read when hm_sil_bwd is called or captured.  Returns the previous value; blocks <= 0 only queries. */
+int hm_tune_sweep_blocks(int blocks);
 /* rgb output of nr.renderer.Renderer.render for the reference's texture_size-1 per-face colours (reference
  * homan/homan.py:535-538 render_limem, light set at :173-176, colours from homan/meshutils.py:7-51): (B,3,S,S) image of
  * the LAST hm_sil_fwd on this workspace (same verts / faces), flat lighting ambient + directional * relu(<n, dir>) on the
