@@ -751,47 +751,60 @@ __device__ __forceinline__ int sweep_family(float a0, float a1, int is, int& d0_
     return max(0, d0_to - d0_from + 1);
 }
 
-// one block = 256 face slots.  `nblk` = number of compaction blocks of the launch.
-__device__ __forceinline__ void sweep_compact(int blk, int nblk, const float* __restrict__ faces9,
+// record of face slot bf (corners, cumulative family counts, ids) -> its item count (0: owns no sample / culled)
+__device__ __forceinline__ int sweep_face_record(long bf, const float* __restrict__ faces9, const FaceBox* __restrict__ boxes,
+                                                 const unsigned char* __restrict__ owned, int F, int is, SweepFace& rec)
+{
+    const int b = (int)(bf / F), fi = (int)(bf - (long)b * F);
+    const unsigned mask = (reinterpret_cast<const uint2*>(boxes)[bf].x >> 14) & 3u;
+    // a winding that owns no sample has no in-pixel of its own and nothing to sweep inwards over: zero gradient
+    const bool act0 = (mask & 1u) && owned[(long)b * 2 * F + fi];
+    const bool act1 = (mask & 2u) && owned[(long)b * 2 * F + F + fi];
+    if (!(act0 || act1)) return 0;
+    const float* src = faces9 + bf * 9;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rec.px[k] = topix(src[3 * k], is); rec.py[k] = topix(src[3 * k + 1], is); }
+    int n = 0;
+#pragma unroll
+    for (int var = 0; var < 2; ++var)
+#pragma unroll
+        for (int e = 0; e < 3; ++e)
+#pragma unroll
+            for (int axis = 0; axis < 2; ++axis) {
+                const int k0 = e, k1 = (e + 1) % 3;
+                const int v0 = var ? 2 - k0 : k0, v1 = var ? 2 - k1 : k1;
+                int from;
+                const int c = sweep_family(axis ? rec.py[v0] : rec.px[v0], axis ? rec.py[v1] : rec.px[v1], is, from);
+                if (var ? act1 : act0) n += c;
+                rec.cum[var * 6 + e * 2 + axis] = (unsigned short)n;
+            }
+    rec.bf = (int)bf;
+    rec.b = b;
+    return n;
+}
+
+// one block = 256 * fpt consecutive face slots, fpt (1..4) per thread in thread-major order: one face per thread keeps
+// the blocks' dependent chain short (a clip: a few hundred blocks), four amortise it and the same-address atomics when
+// there are thousands of blocks (500 candidate poses).  `nblk` = number of compaction blocks of the launch.  Two passes
+// over the block's faces: item counts -> block scan -> one atomic for the block's base -> records (rebuilt rather than
+// kept: the line expansion shares this kernel and its register budget).
+__device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const float* __restrict__ faces9,
                                               const FaceBox* __restrict__ boxes, const unsigned char* __restrict__ owned,
                                               int B, int F, int is, float* __restrict__ parts, const SweepList& sl)
 {
     __shared__ int s_wsum[4][2];
     __shared__ unsigned long long s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long bf = (long)blk * 256 + tid;
-    const bool valid = bf < (long)B * F;
-    int n = 0;
-    SweepFace rec;
-    if (valid) {
-        const int b = (int)(bf / F), fi = (int)(bf - (long)b * F);
-        const unsigned mask = (reinterpret_cast<const uint2*>(boxes)[bf].x >> 14) & 3u;
-        // a winding that owns no sample has no in-pixel of its own and nothing to sweep inwards over: zero gradient
-        const bool act0 = (mask & 1u) && owned[(long)b * 2 * F + fi];
-        const bool act1 = (mask & 2u) && owned[(long)b * 2 * F + F + fi];
-        if (act0 || act1) {
-            const float* src = faces9 + bf * 9;
+    const long bf0 = ((long)blk * 256 + tid) * fpt, nbf = (long)B * F;
+    int nk[4], n = 0, hasf = 0;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { rec.px[k] = topix(src[3 * k], is); rec.py[k] = topix(src[3 * k + 1], is); }
-#pragma unroll
-            for (int var = 0; var < 2; ++var)
-#pragma unroll
-                for (int e = 0; e < 3; ++e)
-#pragma unroll
-                    for (int axis = 0; axis < 2; ++axis) {
-                        const int k0 = e, k1 = (e + 1) % 3;
-                        const int v0 = var ? 2 - k0 : k0, v1 = var ? 2 - k1 : k1;
-                        int from;
-                        const int c = sweep_family(axis ? rec.py[v0] : rec.px[v0], axis ? rec.py[v1] : rec.px[v1], is, from);
-                        if (var ? act1 : act0) n += c;
-                        rec.cum[var * 6 + e * 2 + axis] = (unsigned short)n;
-                    }
-            rec.bf = (int)bf;
-            rec.b = b;
-        }
+    for (int k = 0; k < 4; ++k) {
+        SweepFace rec;
+        nk[k] = (k < fpt && bf0 + k < nbf) ? sweep_face_record(bf0 + k, faces9, boxes, owned, F, is, rec) : 0;
+        n += nk[k];
+        hasf += nk[k] > 0 ? 1 : 0;
     }
     // block-exclusive scan of (items, faces)
-    const int hasf = n > 0 ? 1 : 0;
     const int inc_i = hm_wave_scan_incl(n), inc_f = hm_wave_scan_incl(hasf);
     if (lane == 63) { s_wsum[wv][0] = inc_i; s_wsum[wv][1] = inc_f; }
     __syncthreads();
@@ -809,27 +822,36 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, const float* __
         s_base = tot_f ? atomicAdd(sl.cnt, ((unsigned long long)tot_f << 32) | (unsigned)((tot_i + 63) & ~63)) : 0ull;
     __syncthreads();
     const unsigned long long base = s_base;
-    bool zero = valid && n == 0;
-    if (n > 0) {
-        const int off = (int)(base & 0xffffffffull) + pre_i + inc_i - n;
-        const int idx = (int)(base >> 32) + pre_f + inc_f - 1;
-        const int u_lo = off >> 6, u_hi = (off + n - 1) >> 6;
-        const bool over = u_hi >= sl.ucap || u_hi + idx >= sl.slot_cap;
-        rec.off = off;
-        rec.flags = over ? 1 : 0;
-        zero = u_hi > u_lo && (over || u_hi == u_lo + 1);    // accumulated with float atomics by its units
-        const uint4* r4 = reinterpret_cast<const uint4*>(&rec);
-        uint4* t4 = reinterpret_cast<uint4*>(sl.tab + idx);
+    int off = (int)(base & 0xffffffffull) + pre_i + inc_i - n;
+    int idx = (int)(base >> 32) + pre_f + inc_f - hasf;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t4[k] = r4[k];
-        sl.offs[idx] = off;
-        sl.tickets[idx] = 0u;
-        for (int u = (off + 63) >> 6; (u << 6) < off + n && u < sl.ucap; ++u) sl.ufirst[u] = (unsigned)idx;
-    }
-    if (zero) {
-        float* o = parts + bf * 6;
+    for (int k = 0; k < 4; ++k) {
+        const long bf = bf0 + k;
+        if (k >= fpt || bf >= nbf) break;
+        bool zero = nk[k] == 0;
+        if (nk[k] > 0) {
+            SweepFace rec;
+            const int nn = sweep_face_record(bf, faces9, boxes, owned, F, is, rec);
+            const int u_lo = off >> 6, u_hi = (off + nn - 1) >> 6;
+            const bool over = u_hi >= sl.ucap || u_hi + idx >= sl.slot_cap;
+            rec.off = off;
+            rec.flags = over ? 1 : 0;
+            zero = u_hi > u_lo && (over || u_hi == u_lo + 1);    // accumulated with float atomics by its units
+            const uint4* r4 = reinterpret_cast<const uint4*>(&rec);
+            uint4* t4 = reinterpret_cast<uint4*>(sl.tab + idx);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) o[k] = 0.f;
+            for (int q = 0; q < 4; ++q) t4[q] = r4[q];
+            sl.offs[idx] = off;
+            sl.tickets[idx] = 0u;
+            for (int u = (off + 63) >> 6; (u << 6) < off + nn && u < sl.ucap; ++u) sl.ufirst[u] = (unsigned)idx;
+            off += nn;
+            ++idx;
+        }
+        if (zero) {
+            float* o = parts + bf * 6;
+#pragma unroll
+            for (int q = 0; q < 6; ++q) o[q] = 0.f;
+        }
     }
     // the last block publishes the totals and re-arms the counters for the next launch
     __syncthreads();
@@ -862,7 +884,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    const float* __restrict__ keep_sum,
                                                    const int* __restrict__ idx_map, int B, int S,
                                                    SweepSrc* __restrict__ srcs, uint4* __restrict__ lrec,
-                                                   int ncomp, const float* __restrict__ faces9,
+                                                   int ncomp, int fpt, const float* __restrict__ faces9,
                                                    const FaceBox* __restrict__ boxes,
                                                    const unsigned char* __restrict__ owned, int F,
                                                    float* __restrict__ parts, SweepList sl)
@@ -871,7 +893,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     __shared__ int s_ex[16][SWEEP_CUMW];
     // the first `ncomp` workgroups build the work list of the edge sweeps (independent of the lines: one launch for both)
     if ((int)blockIdx.x < ncomp) {
-        sweep_compact(blockIdx.x, ncomp, faces9, boxes, owned, B, F, 2 * S, parts, sl);
+        sweep_compact(blockIdx.x, ncomp, fpt, faces9, boxes, owned, B, F, 2 * S, parts, sl);
         return;
     }
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -1578,9 +1600,10 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const float* upstream, const float* keep_sum,
                          hipStream_t stream)
 {
-    const int ncomp = hm_cdiv((long)B * F, 256);
+    const int fpt = (long)B * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks (see sweep_compact)
+    const int ncomp = hm_cdiv((long)B * F, 256 * fpt);
     hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.rowneg, w.colneg,
-                       w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, w.faces9, w.boxes,
+                       w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
                        w.owned, F, w.parts, w.sweep);
 }
 static int g_sweep_blocks = SWEEP_BLOCKS;
