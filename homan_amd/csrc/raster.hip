@@ -196,35 +196,74 @@ __device__ __forceinline__ unsigned spread8(unsigned x)      // bit k of x -> bi
     x = (x | (x << 1)) & 0x5555u;
     return x;
 }
-// nb / pb [2*dy+dx] = ballots of "g < 0" / "g > 0" per sample (all four equal when g lives on the pooled grid).
-__device__ __forceinline__ void emit_planes(const unsigned long long (&cov)[4], const unsigned long long (&nb)[4],
-                                            const unsigned long long (&pb)[4], int b, int B, int is,
-                                            int tx, int ty, int lane, unsigned short* __restrict__ rowneg,
-                                            unsigned short* __restrict__ colneg)
+// Layout of the sweep planes: TILE-BLOCKED, (B, T, T, 4, 16) u16 with T = is/16 tiles per side and the four
+// (orientation, plane) combinations of a tile side by side: [row words plane 0 | row words plane 1 | column words plane 0 |
+// column words plane 1], 16 words each = the tile's 128 bytes, written by its wave as ONE full cache line.  (Line-major
+// planes made every 2-byte word of a tile a partial write into a different line, and since neighbouring tiles run on
+// different XCDs their dirty fragments never merged in an L2: 64 partial HBM writes per tile, 140 MB per launch.)
+// A 64-sample word of a line is four tiles' words (hm_plane_word64).
+__device__ __forceinline__ long hm_plane_at(int b, int ty, int tx, int combo, int T)
 {
-    const long plane = (long)B * is * (is / 16);
+    return ((((long)b * T + ty) * T + tx) * 4 + combo) * 16;
+}
+// 64 samples [64k, 64k+64) of line d0 of `axis` (1: sample row yi = d0, bits along x ; 0: sample column xi = d0, bits
+// along the 16-sample groups ygrp of emit_planes), plane pl
+__device__ __forceinline__ unsigned long long hm_plane_word64(const unsigned short* __restrict__ planes, int b, int is,
+                                                              int axis, int pl, int d0, int k)
+{
+    const int T = is / 16;
+    unsigned long long w = 0ull;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        unsigned v;
+        if (axis) {
+            const int t = is - 1 - d0;
+            v = planes[hm_plane_at(b, t >> 4, 4 * k + j, pl, T) + (t & 15)];
+        } else {
+            v = planes[hm_plane_at(b, T - 1 - (4 * k + j), d0 >> 4, 2 + pl, T) + (d0 & 15)];
+        }
+        w |= (unsigned long long)v << (16 * j);
+    }
+    return w;
+}
+// nb / pb [2*dy+dx] = ballots of "g < 0" / "g > 0" per sample (all four equal when g lives on the pooled grid).
+struct Ballots4 { unsigned long long s0, s1, s2, s3; };      // [2*dy+dx]; plain scalars, picked with selects only:
+// a lane-dependent index into an array puts the array in scratch memory (80-112 bytes per thread = 100 MB of HBM writes
+// per launch when this was `cov[2 * sub]`)
+__device__ __forceinline__ void emit_planes(const Ballots4 cov, const Ballots4 nb, const Ballots4 pb, int b, int B, int is,
+                                            int tx, int ty, int lane, unsigned short* __restrict__ planes)
+{
     // lanes 0..15: row word of sample row (rr2 = l>>1, dy = l&1), plane 0 ; lanes 16..31: same for plane 1 ;
     // lanes 32..47: column word of sample column (cc2 = l>>1, dx = l&1), plane 0 ; lanes 48..63: plane 1
     const int l = lane & 15, pl = (lane >> 4) & 1, hi = l >> 1, sub = l & 1;
     unsigned long long b0, b1;          // the two ballots this lane interleaves
-    if (lane < 32) {                    // (dy = sub): dx = 0 -> even bits, dx = 1 -> odd bits
-        b0 = pl == 0 ? (~cov[2 * sub] & nb[2 * sub]) : (cov[2 * sub] & pb[2 * sub]);
-        b1 = pl == 0 ? (~cov[2 * sub + 1] & nb[2 * sub + 1]) : (cov[2 * sub + 1] & pb[2 * sub + 1]);
+    unsigned word;
+    const Ballots4 g = pl == 0 ? nb : pb;
+    if (lane < 32) {                    // (dy = sub): dx = 0 -> even bits, dx = 1 -> odd bits ; sample row
+        const unsigned long long c0 = sub ? cov.s2 : cov.s0, c1 = sub ? cov.s3 : cov.s1;      // yi = is-1-2*(ty*8+hi)-sub,
+        const unsigned long long g0 = sub ? g.s2 : g.s0, g1 = sub ? g.s3 : g.s1;              // i.e. (is-1-yi) & 15 = l
+        b0 = pl == 0 ? (~c0 & g0) : (c0 & g0);
+        b1 = pl == 0 ? (~c1 & g1) : (c1 & g1);
         const unsigned a = (unsigned)(b0 >> (8 * hi)) & 0xffu, o = (unsigned)(b1 >> (8 * hi)) & 0xffu;
-        const unsigned word = spread8(a) | (spread8(o) << 1);
-        const int yi = is - 1 - 2 * (ty * HM_TILE + hi) - sub;
-        (rowneg + pl * plane)[((long)b * is + yi) * (is / 16) + tx] = (unsigned short)word;
+        word = spread8(a) | (spread8(o) << 1);
     } else {                            // (dx = sub): bit 15 - (2*rr2 + dy) <- sample (rr2, dy) of column cc2 = hi
-        b0 = pl == 0 ? (~cov[sub] & nb[sub]) : (cov[sub] & pb[sub]);                         // dy = 0
-        b1 = pl == 0 ? (~cov[2 + sub] & nb[2 + sub]) : (cov[2 + sub] & pb[2 + sub]);         // dy = 1
+        const unsigned long long c0 = sub ? cov.s1 : cov.s0, c1 = sub ? cov.s3 : cov.s2;      // dy = 0 / dy = 1 ; sample column
+        const unsigned long long g0 = sub ? g.s1 : g.s0, g1 = sub ? g.s3 : g.s2;              // xi = 16*tx + l
+        b0 = pl == 0 ? (~c0 & g0) : (c0 & g0);
+        b1 = pl == 0 ? (~c1 & g1) : (c1 & g1);
         // bits 8*rr2 + cc2 -> one byte with row rr2 at bit 7 - rr2
-        const unsigned c0 = (unsigned)((((b0 >> hi) & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
-        const unsigned c1 = (unsigned)((((b1 >> hi) & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
-        const unsigned word = (spread8(c0) << 1) | spread8(c1);
-        const int xi = 2 * (tx * HM_TILE + hi) + sub;
-        const int ygrp = (is / 16) - 1 - ty;       // 16-sample group along y holding this tile
-        (colneg + pl * plane)[((long)b * is + xi) * (is / 16) + ygrp] = (unsigned short)word;
+        const unsigned k0 = (unsigned)((((b0 >> hi) & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
+        const unsigned k1 = (unsigned)((((b1 >> hi) & 0x0101010101010101ull) * 0x8040201008040201ull) >> 56);
+        word = (spread8(k0) << 1) | spread8(k1);    // the word of the 16-sample group ygrp = T-1-ty along y
     }
+    // the 64 words of the tile (lane order = memory order, combo = lane >> 4) leave as eight 16-byte stores: sub-dword
+    // stores reach HBM as one partial write each (measured: 54 B of WRITE_SIZE per 2-byte store)
+    const unsigned p2 = (word & 0xffffu) | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)word, 0x101, 0xf, 0xf, false) << 16);   // row_shl:1
+    const unsigned q2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p2, 0x102, 0xf, 0xf, false);      // row_shl:2 : words 2,3
+    const unsigned r2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p2, 0x104, 0xf, 0xf, false);      // row_shl:4 : words 4,5
+    const unsigned s2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q2, 0x104, 0xf, 0xf, false);      // row_shl:4 : words 6,7
+    if ((lane & 7) == 0)
+        *reinterpret_cast<uint4*>(planes + hm_plane_at(b, ty, tx, 0, is / 16) + lane) = make_uint4(p2, q2, r2, s2);
 }
 
 // ---------------------------------------------------------------- forward raster
@@ -252,7 +291,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
     float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned,
-    float* __restrict__ pooled_depth, unsigned short* __restrict__ rowneg, unsigned short* __restrict__ colneg,
+    float* __restrict__ pooled_depth, unsigned short* __restrict__ planes,
     int* __restrict__ bin_cnt, const int* __restrict__ bin_list, unsigned int* __restrict__ done, int reset_bins,
     unsigned char* __restrict__ region_state, int persistent, float* __restrict__ alpha_full, int mask_shared,
     float* __restrict__ dimg_full)
@@ -514,21 +553,26 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         int2 v2 = make_int2(imin[2 * dy], imin[2 * dy + 1]);
         *reinterpret_cast<int2*>(im + (long)(yi0 - dy) * is + xi0) = v2;
     }
-    // faces that own a sample (benign same-value races; consecutive duplicates within a lane are skipped)
+    // faces that own a sample (benign same-value races).  One-byte stores are partial-line writes that never merge
+    // across the XCDs' L2s, so a sample is flagged only by the first lane of its run: not if the same face owns the
+    // previous sample of this pixel, the same sample of the previous lane (left neighbour) or of the lane eight back
+    // (upper neighbour) -- the lowest lane holding a face always stores.
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        if (imin[s] >= 0 && (s == 0 || imin[s] != imin[s - 1])) owned[(long)b * 2 * F + imin[s]] = 1;
+    for (int s = 0; s < 4; ++s) {
+        const int left = __builtin_amdgcn_update_dpp(-2, imin[s], 0x138, 0xf, 0xf, false);            // wave_shr:1
+        const int up = __builtin_amdgcn_ds_bpermute(((lane - 8) & 63) << 2, imin[s]);
+        if (imin[s] >= 0 && (s == 0 || imin[s] != imin[s - 1]) && imin[s] != left && (lane < 8 || imin[s] != up))
+            owned[(long)b * 2 * F + imin[s]] = 1;
+    }
     // alpha bit-plane: 16 sample rows x 16 bits for this tile
-    unsigned long long bal[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) bal[s] = __ballot(imin[s] >= 0);
+    const Ballots4 bal = {__ballot(imin[0] >= 0), __ballot(imin[1] >= 0), __ballot(imin[2] >= 0), __ballot(imin[3] >= 0)};
     if (lane < 16) {
         const int rr = lane >> 1, dy = lane & 1;       // tile-local output row, sub-row
-        const unsigned a = (unsigned)(bal[2 * dy] >> (8 * rr)) & 0xffu;      // dx = 0 -> even bits
-        const unsigned o = (unsigned)(bal[2 * dy + 1] >> (8 * rr)) & 0xffu;  // dx = 1 -> odd bits
+        const unsigned long long be = dy ? bal.s2 : bal.s0, bo = dy ? bal.s3 : bal.s1;    // (selects: see emit_planes)
+        const unsigned a = (unsigned)(be >> (8 * rr)) & 0xffu;      // dx = 0 -> even bits
+        const unsigned o = (unsigned)(bo >> (8 * rr)) & 0xffu;      // dx = 1 -> odd bits
         const unsigned word = spread8(a) | (spread8(o) << 1);
-        const int yi = is - 1 - 2 * (ty * HM_TILE + rr) - dy;
-        alpha16[((long)b * is + yi) * (is / 16) + tx] = (unsigned short)word;
+        alpha16[(((long)b * (is / 16) + ty) * (is / 16) + tx) * 16 + lane] = (unsigned short)word;    // tile-blocked: 32 B / tile
     }
     const int cnt = (imin[0] >= 0) + (imin[1] >= 0) + (imin[2] >= 0) + (imin[3] >= 0);
     const float pool = 0.25f * (float)cnt;
@@ -549,7 +593,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         const float* kb = keep + (mask_shared ? 0 : (long)b * is * is);
         const float* rb = ref + (mask_shared ? 0 : (long)b * is * is);
         float sqs = 0.f, ins = 0.f, uns = 0.f;
-        unsigned long long nbv[4], pbv[4];
+        unsigned long long nq[4], pq[4];     // constant indices only (unrolled)
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy) {
             const long at = (long)(2 * r + dy) * is + xi0;
@@ -561,10 +605,11 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
             sqs += d0 * d0 + d1 * d1;
             ins += i0 * r2.x + i1 * r2.y;
             uns += fminf(fmaxf(i0 + r2.x, 0.0f), 1.0f) + fminf(fmaxf(i1 + r2.y, 0.0f), 1.0f);
-            nbv[2 * dy] = __ballot(g0 < 0.0f); pbv[2 * dy] = __ballot(g0 > 0.0f);
-            nbv[2 * dy + 1] = __ballot(g1 < 0.0f); pbv[2 * dy + 1] = __ballot(g1 > 0.0f);
+            nq[2 * dy] = __ballot(g0 < 0.0f); pq[2 * dy] = __ballot(g0 > 0.0f);
+            nq[2 * dy + 1] = __ballot(g1 < 0.0f); pq[2 * dy + 1] = __ballot(g1 > 0.0f);
         }
-        emit_planes(bal, nbv, pbv, b, B, is, tx, ty, lane, rowneg, colneg);
+        const Ballots4 nbv = {nq[0], nq[1], nq[2], nq[3]}, pbv = {pq[0], pq[1], pq[2], pq[3]};
+        emit_planes(bal, nbv, pbv, b, B, is, tx, ty, lane, planes);
         const float sq = hm_wave_sum(sqs), inter = hm_wave_sum(ins), uni = hm_wave_sum(uns);
         if (lane == 0) {
             float* o = partials + ((long)b * ntiles + tile) * 4;
@@ -579,8 +624,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         // sweep planes of the backward for a positive upstream gradient (sign(g) = sign(dimg)), see k_bwd_masks
         {
             const unsigned long long nb1 = __ballot(kp * diff < 0.0f), pb1 = __ballot(kp * diff > 0.0f);
-            const unsigned long long nbv[4] = {nb1, nb1, nb1, nb1}, pbv[4] = {pb1, pb1, pb1, pb1};
-            emit_planes(bal, nbv, pbv, b, B, is, tx, ty, lane, rowneg, colneg);
+            const Ballots4 nbv = {nb1, nb1, nb1, nb1}, pbv = {pb1, pb1, pb1, pb1};
+            emit_planes(bal, nbv, pbv, b, B, is, tx, ty, lane, planes);
         }
         const float sq = hm_wave_sum(diff * diff);
         const float inter = hm_wave_sum(image * rf);
@@ -635,8 +680,7 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
                                                    const float* __restrict__ upstream,
                                                    const float* __restrict__ keep_sum, int B, int S,
                                                    const unsigned short* __restrict__ alpha16,
-                                                   float* __restrict__ gimg, unsigned short* __restrict__ rowneg,
-                                                   unsigned short* __restrict__ colneg)
+                                                   float* __restrict__ gimg, unsigned short* __restrict__ planes)
 {
     // fused loss with a positive upstream gradient: the forward raster already emitted these planes (sign(g) = sign(dimg))
     // and k_bwd_lines derives g from dimg itself
@@ -650,15 +694,14 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
     const int r = ty * HM_TILE + rr, c = tx * HM_TILE + cc;
     const long po = ((long)b * S + r) * S + c;
     // alpha bits of this lane's 4 samples
-    const int yi0 = is - 1 - 2 * r;
-    unsigned long long cov[4];
+    unsigned long long cq[4];
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-        const unsigned aw = alpha16[((long)b * is + (yi0 - dy)) * (is / 16) + tx];
+        const unsigned aw = alpha16[(((long)b * (is / 16) + ty) * (is / 16) + tx) * 16 + 2 * rr + dy];
 #pragma unroll
-        for (int dx = 0; dx < 2; ++dx) cov[2 * dy + dx] = __ballot((aw >> (2 * cc + dx)) & 1u);
+        for (int dx = 0; dx < 2; ++dx) cq[2 * dy + dx] = __ballot((aw >> (2 * cc + dx)) & 1u);
     }
-    unsigned long long nbv[4], pbv[4];
+    unsigned long long nq[4], pq[4];
     if (mode == 3) {
         // anti_aliasing=False: the image IS the sample grid (vertically flipped); gin / gimg are (B,is,is)
 #pragma unroll
@@ -666,8 +709,8 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
             const long at = ((long)b * is + 2 * r + dy) * is + 2 * c;
             const float2 g2 = *reinterpret_cast<const float2*>(gin + at);
             *reinterpret_cast<float2*>(gimg + at) = g2;
-            nbv[2 * dy] = __ballot(g2.x < 0.0f); pbv[2 * dy] = __ballot(g2.x > 0.0f);
-            nbv[2 * dy + 1] = __ballot(g2.y < 0.0f); pbv[2 * dy + 1] = __ballot(g2.y > 0.0f);
+            nq[2 * dy] = __ballot(g2.x < 0.0f); pq[2 * dy] = __ballot(g2.x > 0.0f);
+            nq[2 * dy + 1] = __ballot(g2.y < 0.0f); pq[2 * dy + 1] = __ballot(g2.y > 0.0f);
         }
     } else {
         float g = gin[po];
@@ -678,9 +721,10 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
         gimg[po] = g;
         const unsigned long long nb1 = __ballot(g < 0.0f), pb1 = __ballot(g > 0.0f);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { nbv[k] = nb1; pbv[k] = pb1; }
+        for (int k = 0; k < 4; ++k) { nq[k] = nb1; pq[k] = pb1; }
     }
-    emit_planes(cov, nbv, pbv, b, B, is, tx, ty, lane, rowneg, colneg);
+    const Ballots4 cov = {cq[0], cq[1], cq[2], cq[3]}, nbv = {nq[0], nq[1], nq[2], nq[3]}, pbv = {pq[0], pq[1], pq[2], pq[3]};
+    emit_planes(cov, nbv, pbv, b, B, is, tx, ty, lane, planes);
 }
 
 // ---------------------------------------------------------------- backward: shared helpers
@@ -877,8 +921,7 @@ struct SweepSrc { int d1; float g; int owner; };
 
 // 16 lanes per line (one DPP row), 16 lines per workgroup: a wave per line spent its life waiting on three dependent
 // memory round trips with 8 of 64 lanes loading; four lines per wave quarter the number of waves in flight.
-__global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restrict__ rowneg,
-                                                   const unsigned short* __restrict__ colneg,
+__global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restrict__ planes,
                                                    const float* __restrict__ gimg, const float* __restrict__ dimg,
                                                    int mode, const float* __restrict__ upstream,
                                                    const float* __restrict__ keep_sum,
@@ -903,11 +946,8 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     // L = ((pl * 2 + axis) * B + b) * is + d0
     const int d0 = (int)(L % is), b = (int)((L / is) % B), pa = (int)(L / ((long)is * B));
     const int axis = pa & 1, pl = pa >> 1;
-    const long plane_words = (long)B * is * wpl;
     unsigned long long mine = 0ull;
-    if (valid && l < wpl)
-        mine = (reinterpret_cast<const unsigned long long*>(axis == 0 ? colneg : rowneg) + pl * plane_words +
-                ((long)b * is + d0) * wpl)[l];
+    if (valid && l < wpl) mine = hm_plane_word64(planes, b, is, axis, pl, d0, l);
     // exclusive prefix of the word popcounts (wpl <= 16 words: one 16-lane row scan)
     const int c = __popcll(mine);
     int incl = c;
@@ -1554,7 +1594,7 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
 struct SilWs {
     unsigned int* counter; float* frame_rec;
     float* ndc; float* faces9; FaceBox* boxes; int* idx_map; unsigned short* alpha16; float* dimg;
-    float* partials; float* gimg; unsigned short* rowneg; unsigned short* colneg; float* parts;
+    float* partials; float* gimg; unsigned short* planes; float* parts;
     unsigned char* owned; int* bin_cnt; unsigned int* bin_done; unsigned char* region_state; int* bin_list;
     uint4* lrec; SweepSrc* srcs;
     SweepList sweep;
@@ -1574,8 +1614,7 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.dimg = (float*)p; p += al256((size_t)B * S * S * 4);
     w.partials = (float*)p; p += al256((size_t)B * (S / 8) * (S / 8) * 16);
     w.gimg = (float*)p; p += al256((size_t)B * is * is * 4);
-    w.rowneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4);
-    w.colneg = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4);
+    w.planes = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4) * 2;      // (B, T, T, 4, 16) u16
     w.parts = (float*)p; p += al256((size_t)B * F * 24 * 4);
     w.owned = (unsigned char*)p; p += al256((size_t)B * F * 2);
     w.bin_cnt = (int*)p; w.bin_done = (unsigned int*)(p + (size_t)B * SR_MAX * 4); p += al256((size_t)B * SR_MAX * 8);
@@ -1602,7 +1641,7 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
 {
     const int fpt = (long)B * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks (see sweep_compact)
     const int ncomp = hm_cdiv((long)B * F, 256 * fpt);
-    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.rowneg, w.colneg,
+    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
                        w.owned, F, w.parts, w.sweep);
 }
@@ -1646,7 +1685,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     const bool fused = keep && ref;
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                       fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.rowneg, w.colneg, bins,
+                       fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.planes, bins,
                        w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full, mask_shared,
                        (fused && alpha_full) ? w.gimg : (float*)nullptr);
     if (fused && keep_sum && loss_out)
@@ -1688,7 +1727,7 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
     if (mode != 2 && mode != 4)      // modes 2 / 4: the caller guarantees upstream > 0, the forward's planes are the backward's
         hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                            mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
-                           w.rowneg, w.colneg);
+                           w.planes);
     launch_lines(w, B, F, S, mode, upstream, keep_sum, stream);
     launch_sweep(w, B, F, S, eps, stream);
     if (grad_verts)
@@ -1796,7 +1835,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
         }
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
-                           w.partials, work_order, w.owned, (float*)nullptr, w.rowneg, w.colneg, bins, w.bin_list,
+                           w.partials, work_order, w.owned, (float*)nullptr, w.planes, bins, w.bin_list,
                            w.bin_done, cold ? 1 : 0, w.region_state, 1, (float*)nullptr, 0, (float*)nullptr);      // steady state of a fixed loop: background regions skipped
     }
     (void)hipEventRecord(e1, stream);
