@@ -800,14 +800,19 @@ __device__ __forceinline__ int sweep_face_record(long bf, const float* __restric
                                                  const unsigned char* __restrict__ owned, int F, int is, SweepFace& rec)
 {
     const int b = (int)(bf / F), fi = (int)(bf - (long)b * F);
+    // (box, flags and corners are requested together: one round trip for the block, whether or not the face is active)
     const unsigned mask = (reinterpret_cast<const uint2*>(boxes)[bf].x >> 14) & 3u;
-    // a winding that owns no sample has no in-pixel of its own and nothing to sweep inwards over: zero gradient
-    const bool act0 = (mask & 1u) && owned[(long)b * 2 * F + fi];
-    const bool act1 = (mask & 2u) && owned[(long)b * 2 * F + F + fi];
-    if (!(act0 || act1)) return 0;
+    const unsigned char own0 = owned[(long)b * 2 * F + fi], own1 = owned[(long)b * 2 * F + F + fi];
     const float* src = faces9 + bf * 9;
+    float sx[3], sy[3];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { rec.px[k] = topix(src[3 * k], is); rec.py[k] = topix(src[3 * k + 1], is); }
+    for (int k = 0; k < 3; ++k) { sx[k] = src[3 * k]; sy[k] = src[3 * k + 1]; }
+    // a winding that owns no sample has no in-pixel of its own and nothing to sweep inwards over: zero gradient
+    const bool act0 = (mask & 1u) && own0;
+    const bool act1 = (mask & 2u) && own1;
+    if (!(act0 || act1)) return 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rec.px[k] = topix(sx[k], is); rec.py[k] = topix(sy[k], is); }
     int n = 0;
 #pragma unroll
     for (int var = 0; var < 2; ++var)
@@ -897,10 +902,10 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const 
             for (int q = 0; q < 6; ++q) o[q] = 0.f;
         }
     }
-    // the last block publishes the totals and re-arms the counters for the next launch
-    __syncthreads();
+    // the last block publishes the totals and re-arms the counters for the next launch.  (Only the counts travel
+    // through this ticket - thread 0 consumed the return value of its own add above -; the records are read by the next
+    // kernel, so nobody waits for their stores here.)
     if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned int t = atomicAdd(sl.done, 1u);
         if (t == (unsigned)nblk - 1u) {
             sl.total[0] = atomicExch(sl.cnt, 0ull);
@@ -1021,11 +1026,18 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
     const unsigned long long tot = sl.total[0];
     const int N = (int)(tot & 0xffffffffull), W = (int)(tot >> 32);
     const int U = (N + 63) >> 6;
-    const int nwaves = (int)(((long)gridDim.x * blockDim.x) >> 6);
 #ifdef SWEEP_TIMING
     unsigned long long swt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, swt_last = __builtin_readcyclecounter();
 #endif
-    for (int u = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)); u < U; u += nwaves) {
+    // XCD-aware unit assignment: workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2, while the
+    // item list is frame-major.  Each XCD therefore takes one contiguous eighth of the units (~ B/8 whole frames): the
+    // index-map lines, line records and source slices of a frame are then fetched into ONE L2 instead of eight (speed
+    // only: nothing depends on where a workgroup really runs).  gridDim.x is a multiple of 8.
+    const int xcd = blockIdx.x & 7;
+    const int xwaves = (int)(gridDim.x >> 3) * 4;
+    const int u_end = (int)(((long)U * (xcd + 1)) >> 3);
+    for (int u = __builtin_amdgcn_readfirstlane((int)(((long)U * xcd) >> 3) + (int)(blockIdx.x >> 3) * 4 + wv); u < u_end;
+         u += xwaves) {
         int first;
         if (u < sl.ucap) first = (int)sl.ufirst[u];
         else {                                   // beyond the unit table: last face with off <= 64u
@@ -1648,7 +1660,8 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
 static int g_sweep_blocks = SWEEP_BLOCKS;
 static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_bwd_sweep, dim3(min(hm_cdiv((long)B * F, 2), g_sweep_blocks)), dim3(256), 0, stream, w.sweep,
+    const int blocks = max(8, min(hm_cdiv((long)B * F, 2), g_sweep_blocks) & ~7);        // a multiple of 8: see the unit loop
+    hipLaunchKernelGGL(k_bwd_sweep, dim3(blocks), dim3(256), 0, stream, w.sweep,
                        w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts);
 }
 

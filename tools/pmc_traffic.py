@@ -3,31 +3,35 @@
 SEPARATE runs with --kernel-trace only, e.g. over `python tools/bench_raster.py 5 both`.
 Counter unit = KB.  per_launch_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is doubled per
 /opt/skills/guides/MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read); WRITE_SIZE is used as reported.
-Usage: python tools/pmc_traffic.py fetch.db write.db > profiles/rNN_pmc_traffic.json"""
+Usage: python tools/pmc_traffic.py fetch.db write.db [last_n_launches] > profiles/rNN_pmc_traffic.json"""
 import json
 import re
 import sqlite3
 import sys
 
 
-def per_kernel(path, counter):
+def per_kernel(path, counter, last=0):
+    """kernel -> (mean counter value per launch, launches averaged); last > 0: only the last `last` launches of each
+    kernel (the measured loop of tools/bench_raster.py, not the launches that synthesise the clip's target masks)."""
     c = sqlite3.connect(path)
-    rows = c.execute("select name, counter_name, avg(value), count(*) from (select E.name as name, E.counter_name as "
-                     "counter_name, sum(E.counter_value) as value from pmc_events E group by E.dispatch_id, E.counter_name) "
-                     "group by name, counter_name").fetchall()
-    out = {}
-    for name, cn, v, n in rows:
+    rows = c.execute("select E.name, E.counter_name, E.dispatch_id, sum(E.counter_value) from pmc_events E "
+                     "group by E.dispatch_id, E.counter_name order by E.dispatch_id").fetchall()
+    per = {}
+    for name, cn, _, v in rows:
         if cn != counter:
             continue
         m = re.match(r"(?:void )?(\w+)", name)
-        short = m.group(1) if m else name
-        out[short] = (v, n)
+        per.setdefault(m.group(1) if m else name, []).append(v)
+    out = {}
+    for k, vals in per.items():
+        vals = vals[-last:] if last else vals
+        out[k] = (sum(vals) / len(vals), len(vals))
     return out
 
 
-def main(fetch_db, write_db):
-    f = per_kernel(fetch_db, "FETCH_SIZE")
-    w = per_kernel(write_db, "WRITE_SIZE")
+def main(fetch_db, write_db, last=0):
+    f = per_kernel(fetch_db, "FETCH_SIZE", last)
+    w = per_kernel(write_db, "WRITE_SIZE", last)
     detail, per = {}, {}
     for k in sorted(set(f) & set(w)):
         if not k.startswith("k_"):
@@ -40,4 +44,4 @@ def main(fetch_db, write_db):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 0)
