@@ -17,7 +17,9 @@
 // v_readlane (scalar operands, no LDS round trip in the inner loop).  The partial minima are merged lexicographically
 // on (distance, index) so ties keep the lowest index.
 #define NN_HV 128
+#ifndef NN_WAVES      // (8 or 16 waves per 128 hand vertices: measured, no gain in the loop)
 #define NN_WAVES 4
+#endif
 __device__ __forceinline__ float rl_f(float v, int l)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
