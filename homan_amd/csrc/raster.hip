@@ -1567,6 +1567,7 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
 // capacity of the sweep work list: units (64 items) indexed by `ufirst`, and per-unit partial slots of faces spread over
 // several units.  256 items per face on average is ~5x what a mesh filling the image produces; beyond it the sweep stays
 // correct (binary search for a unit's first face, float atomics for the faces past the slot table), only slower.
+static int g_sweep_cap_override = 0;
 static inline size_t sweep_ucap(int B, int F) { return (size_t)B * F * 4 + 1024; }
 static inline size_t sweep_slot_cap(int B, int F) { return sweep_ucap(B, F) + (size_t)B * F; }
 extern "C" {
@@ -1644,6 +1645,10 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.sweep.total = (unsigned long long*)(w.counter + 20);
     w.sweep.ucap = (int)sweep_ucap(B, F);
     w.sweep.slot_cap = (int)sweep_slot_cap(B, F);
+    if (g_sweep_cap_override > 0) {          // test hook (hm_debug_sweep_caps): force the beyond-capacity paths
+        w.sweep.ucap = min(w.sweep.ucap, g_sweep_cap_override);
+        w.sweep.slot_cap = min(w.sweep.slot_cap, g_sweep_cap_override);
+    }
     return w;
 }
 
@@ -1889,6 +1894,14 @@ int hm_debug_sweep_timing(unsigned long long* out)
     return HM_OK;
 }
 #endif
+// test hook: cap > 0 shrinks the unit table and the partial-slot table of the sweep work list to `cap` entries (the
+// workspace keeps its size), so that small inputs exercise the beyond-capacity paths; 0 restores the defaults.
+int hm_debug_sweep_caps(int cap)
+{
+    const int prev = g_sweep_cap_override;
+    g_sweep_cap_override = cap > 0 ? cap : 0;
+    return prev;
+}
 int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks)
 {
     hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(raster_fwd_blocks, k_raster_fwd, 64 * RASTER_WAVES, 0);

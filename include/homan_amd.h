@@ -159,6 +159,10 @@ int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, cons
  * default 1280; 768 suits loops whose other streams carry the longer chain (collision + contact terms).  Process-wide,
  * read when hm_sil_bwd is called or captured.  Returns the previous value; blocks <= 0 only queries. */
 int hm_tune_sweep_blocks(int blocks);
+/* test hook: cap > 0 shrinks the capacity tables of the sweep work list so that small inputs take the beyond-capacity
+ * paths (binary search for a unit's first face, atomically accumulated faces); 0 restores the defaults.  Returns the
+ * previous value. */
+int hm_debug_sweep_caps(int cap);
 /* rgb output of nr.renderer.Renderer.render for the reference's texture_size-1 per-face colours (reference
  * homan/homan.py:535-538 render_limem, light set at :173-176, colours from homan/meshutils.py:7-51): (B,3,S,S) image of
  * the LAST hm_sil_fwd on this workspace (same verts / faces), flat lighting ambient + directional * relu(<n, dir>) on the

@@ -211,3 +211,39 @@ def test_no_antialiasing_render_and_gradient_match_oracle(obj):
     scale = vo.grad.abs().max()
     err = ((vh.grad.cpu() - vo.grad) / scale).abs()
     assert err.max() < 2e-2 and err.mean() < 1e-4, (err.max(), err.mean())
+
+
+@pytest.mark.parametrize("obj", ["bottle", "cube"])
+def test_sweep_scheduling_and_capacity_paths_do_not_change_the_gradient(obj):
+    """The edge sweeps' results must not depend on scheduling: the number of persistent workgroups (hm_tune_sweep_blocks)
+    leaves the gradient bit-identical, and with the capacity tables of the work list shrunk to a handful of entries
+    (hm_debug_sweep_caps: binary search for a unit's first face, faces accumulated with float atomics) it still matches
+    to summation order."""
+    from homan_amd import lib as hlib
+    from homan_amd import ops
+    L = hlib.lib()
+    B, S = 3, 64
+    verts, faces, K, V = _scene(B=B, S=S, obj=obj, seed=2)
+    dev = torch.device("cuda")
+    gimg = torch.randn(B, S, S, generator=torch.Generator().manual_seed(7)).to(dev)
+
+    def grad(blocks=0, cap=0):
+        prev_b, prev_c = L.hm_tune_sweep_blocks(blocks), L.hm_debug_sweep_caps(cap)
+        try:
+            sctx = ops.SilhouetteContext(faces.to(dev), V, B, S, dev)
+            v = verts.to(dev).requires_grad_(True)
+            ops.silhouette_render(v, K.to(dev), sctx).backward(gimg)
+            torch.cuda.synchronize()
+            return v.grad.clone()
+        finally:
+            L.hm_tune_sweep_blocks(prev_b)
+            L.hm_debug_sweep_caps(prev_c)
+
+    ref = grad()
+    assert ref.abs().max() > 0
+    for blocks in (8, 64, 768):
+        assert torch.equal(grad(blocks=blocks), ref), blocks
+    scale = ref.abs().max()
+    for cap in (1, 3, 40):
+        np.testing.assert_allclose((grad(cap=cap) / scale).cpu().numpy(), (ref / scale).cpu().numpy(), atol=2e-6,
+                                   err_msg=f"cap {cap}")
