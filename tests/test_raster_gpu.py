@@ -35,7 +35,7 @@ def _oracle_idx(faces9, S):
     return both, idx
 
 
-@pytest.mark.parametrize("S,obj", [(64, "bottle"), (32, "cube"), (128, "bottle")])
+@pytest.mark.parametrize("S,obj", [(64, "bottle"), (32, "cube"), (128, "bottle"), (512, "cube")])
 def test_face_index_map_bit_exact(S, obj):
     from homan_amd import ops
     verts, faces, K, V = _scene(B=3, S=S, obj=obj)
@@ -67,7 +67,7 @@ def test_projection_matches_oracle():
     np.testing.assert_allclose(f9.numpy(), ref.numpy(), rtol=0, atol=2e-6)
 
 
-@pytest.mark.parametrize("S,obj", [(64, "bottle"), (32, "cube")])
+@pytest.mark.parametrize("S,obj", [(64, "bottle"), (32, "cube"), (256, "bottle"), (512, "cube")])     # 512: the largest size
 def test_pseudo_gradient_matches_oracle(S, obj):
     """Same NDC faces + same upstream image gradient -> same per-vertex NDC gradient (sum order differs)."""
     from homan_amd import ops
