@@ -27,11 +27,11 @@ def _scene(B=3, S=64):
     return verts, faces, K, tex
 
 
-def test_render_rgb_depth_alpha_vs_oracle():
+@pytest.mark.parametrize("S", [64, 640])      # 640: the full-image size of the reference's `model.renderer` (EPIC frames)
+def test_render_rgb_depth_alpha_vs_oracle(S):
     from homan_amd import nmr as hnmr
     from oracle import nmr as onmr
-    verts, faces, K, tex = _scene()
-    S = 64
+    verts, faces, K, tex = _scene(B=3 if S == 64 else 2, S=S)
     ro = onmr.Renderer(image_size=S, K=K, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
     rh = hnmr.Renderer(image_size=S, K=K.to(DEV), orig_size=1)
     for r in (ro, rh):      # the light of reference homan/homan.py:173-176
