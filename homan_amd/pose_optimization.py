@@ -286,3 +286,57 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
     model.rotations = nn.Parameter(best_rots)
     model.translations = nn.Parameter(best_trans)
     return model
+
+
+def rot6d_to_matrix(rot_6d):
+    """reference homan/utils/geometry.py:9-27 (3x2 -> 3x3, Gram-Schmidt, cross product per rotation); plain torch: this is
+    result formatting of a handful of matrices, not path arithmetic (the kernels convert in csrc/hm_common.h)."""
+    rot_6d = rot_6d.view(-1, 3, 2)
+    a1, a2 = rot_6d[:, :, 0], rot_6d[:, :, 1]
+    b1 = torch.nn.functional.normalize(a1)
+    b2 = torch.nn.functional.normalize(a2 - torch.einsum("bi,bi->b", b1, a2).unsqueeze(-1) * b1)
+    b3 = torch.cross(b1, b2, dim=1)
+    return torch.stack((b1, b2, b3), dim=-1)
+
+
+def find_optimal_poses(image_size, faces=None, vertices=None, annotations=None, images=None, Ks=None, num_iterations=50,
+                       num_initializations=2000, viz_path="tmp.png", debug=False, rend_size=constants.REND_SIZE,
+                       mode="eager"):
+    """reference homan/pose_optimization.py:386-488 - the entry point of fit_vid_dataset.py:285-296.  One
+    `find_optimal_pose` fit per frame, every frame started from the previous frame's `num_initializations` rotations
+    (`sort_best=False` keeps the candidates aligned across frames); the motion kept is the candidate with the highest mean
+    IoU over the clip (:468).  annotations[i]: {"target_crop_mask" (S,S) ndarray in {-1,0,1}, "bbox" xywh, "square_bbox"
+    xywh, "full_mask" tensor}.  Returns one dict per frame: rotations (1,3,3), translations (1,1,3), verts_trans (1,V,3),
+    target_masks (1,S,S), K_roi (1,1,3,3), masks, verts (1,V,3), full_mask."""
+    vertices, faces = torch.as_tensor(vertices), torch.as_tensor(faces)
+    assert vertices.dim() == 2 and vertices.shape[1] == 3 and faces.dim() == 2 and faces.shape[1] == 3
+    dev = torch.device("cuda")
+    vertices, faces = vertices.float().to(dev), faces.to(dev)
+    previous_rotations, all_object_parameters, all_losses = None, [], []
+    images = images if images is not None else [None] * len(annotations)
+    for image, annotation, K in zip(images, annotations, Ks):
+        model = find_optimal_pose(vertices=vertices, faces=faces, image=image, mask=annotation["target_crop_mask"],
+                                  bbox=annotation["bbox"], square_bbox=annotation["square_bbox"], image_size=image_size,
+                                  K=K, num_iterations=num_iterations, num_initializations=num_initializations, debug=debug,
+                                  sort_best=False, rotations_init=previous_rotations, rend_size=rend_size, mode=mode)
+        with torch.no_grad():
+            _, iou, _ = model()
+            verts_trans = model.apply_transformation()
+            rotations = rot6d_to_matrix(model.rotations.detach())
+        all_object_parameters.append({
+            "rotations": rotations, "translations": model.translations.detach(),
+            "target_masks": torch.from_numpy(np.asarray(annotation["target_crop_mask"])).to(dev),
+            "K_roi": model.K.detach(), "masks": torch.as_tensor(annotation["full_mask"]).to(dev),
+            "verts": vertices.detach(), "verts_trans": verts_trans.detach()})
+        previous_rotations = rotations
+        all_losses.append(iou.detach())
+    all_losses = torch.stack(all_losses)                          # (frame_nb, num_initializations)
+    best_idx = torch.argsort(all_losses.mean(0))[-1]              # highest mean IoU over the sequence
+    all_final_params = []
+    for obj_params, info in zip(all_object_parameters, annotations):
+        final_params = {key: obj_params[key][best_idx].unsqueeze(0) for key in ("rotations", "translations", "verts_trans")}
+        for key in ("target_masks", "K_roi", "masks", "verts"):
+            final_params[key] = obj_params[key].unsqueeze(0)
+        final_params["full_mask"] = torch.as_tensor(info["full_mask"]).to(dev)
+        all_final_params.append(final_params)
+    return all_final_params

@@ -174,3 +174,37 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
     model.rotations = nn.Parameter(best_rots)
     model.translations = nn.Parameter(best_trans)
     return model
+
+
+def find_optimal_poses(image_size, faces=None, vertices=None, annotations=None, images=None, Ks=None, num_iterations=50,
+                       num_initializations=2000, rend_size=REND_SIZE):
+    """pose_optimization.py:386-488: per-frame fits chained through the previous frame's rotations (sort_best=False), the
+    candidate with the highest mean IoU over the clip kept (:468)."""
+    vertices, faces = torch.as_tensor(vertices).float(), torch.as_tensor(faces)
+    previous_rotations, all_object_parameters, all_losses = None, [], []
+    for annotation, K in zip(annotations, Ks):
+        model = find_optimal_pose(vertices, faces, annotation["target_crop_mask"], annotation["bbox"],
+                                  annotation["square_bbox"], image_size, K=K, num_iterations=num_iterations,
+                                  num_initializations=num_initializations, sort_best=False,
+                                  rotations_init=previous_rotations, rend_size=rend_size)
+        with torch.no_grad():
+            _, iou, _ = model()
+            verts_trans = model.apply_transformation()
+        rotations = rot6d_to_matrix(model.rotations.detach())
+        all_object_parameters.append({
+            "rotations": rotations, "translations": model.translations.detach(),
+            "target_masks": torch.from_numpy(np.asarray(annotation["target_crop_mask"])), "K_roi": model.K.detach(),
+            "masks": torch.as_tensor(annotation["full_mask"]), "verts": vertices.detach(),
+            "verts_trans": verts_trans.detach()})
+        previous_rotations = rotations
+        all_losses.append(iou.detach())
+    all_losses = torch.stack(all_losses)
+    best_idx = torch.argsort(all_losses.mean(0))[-1]
+    out = []
+    for obj_params, info in zip(all_object_parameters, annotations):
+        final_params = {key: obj_params[key][best_idx].unsqueeze(0) for key in ("rotations", "translations", "verts_trans")}
+        for key in ("target_masks", "K_roi", "masks", "verts"):
+            final_params[key] = obj_params[key].unsqueeze(0)
+        final_params["full_mask"] = torch.as_tensor(info["full_mask"])
+        out.append(final_params)
+    return out
