@@ -66,12 +66,15 @@ __device__ __forceinline__ void project_vertex(const float* __restrict__ p, cons
 // ---------------------------------------------------------------- face setup
 // projects the three vertices of every face (a vertex is shared by ~6 faces: re-projecting it is cheaper than a
 // separate projection launch on the critical path), packs the (B,F,3,3) NDC face buffer and the 8-byte screen boxes.
-// It also bins the faces into 128x128-sample super-regions (counts aggregated per workgroup in LDS, one global atomic per
+// It also bins the faces into super-regions of 64x64 or 128x128 samples (hm_sr_shift) (counts aggregated per workgroup in LDS, one global atomic per
 // (workgroup, bin)): a raster workgroup then scans the faces of its super-region instead of the whole frame.  The order
 // inside a bin is arbitrary; the raster resolves visibility with a min, so its result does not depend on it.
 // grid (ceil(F/256), B).  bin_cnt must be zero on entry (the raster's last workgroup resets it).
-#define SR_SHIFT 7         // log2 of the super-region side in samples
 #define SR_MAX 64          // super-regions per frame (is <= 1024)
+// log2 of the super-region side in samples: 64^2 up to 512^2 samples, 128^2 above -> at most 8 x 8 = SR_MAX bins.  A
+// region workgroup scans its whole bin, so a bin holds 4 (is <= 512) or 16 regions' worth of faces: the finer bins cut
+// the scan of the 512^2 rasters by 4 (k_raster_fwd 63.5 -> 60.1 us).
+__host__ __device__ __forceinline__ int hm_sr_shift(int is) { return is <= 512 ? 6 : 7; }
 __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ verts, const float* __restrict__ K,
                                                      float orig_size, const int* __restrict__ faces, int faces_bstride,
                                                      int B, int V, int F, int is, float* __restrict__ faces9,
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
     if (rigid_rot6d && threadIdx.x == 0) rot6d_to_mat(rigid_rot6d + blockIdx.y * 6, s_R);
     const int b = blockIdx.y, fi = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = fi < F;
-    const int nsx = (is + (1 << SR_SHIFT) - 1) >> SR_SHIFT, nsr = nsx * nsx;
+    const int nsx = (is + (1 << hm_sr_shift(is)) - 1) >> hm_sr_shift(is), nsr = nsx * nsx;
     if (threadIdx.x < SR_MAX) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     unsigned mask = 0;
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
     }
     if (!bin_cnt) return;
     // local slots in LDS, one global reservation per (workgroup, bin)
-    const int sx0 = x0 >> SR_SHIFT, sx1 = x1 >> SR_SHIFT, sy0 = y0 >> SR_SHIFT, sy1 = y1 >> SR_SHIFT;
+    const int sx0 = x0 >> hm_sr_shift(is), sx1 = x1 >> hm_sr_shift(is), sy0 = y0 >> hm_sr_shift(is), sy1 = y1 >> hm_sr_shift(is);
     int local[4];                       // a face larger than 2x2 super-regions reserves its further bins one by one
     int nloc = 0;
     if (mask)
@@ -323,9 +326,9 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
 
     int had_any = 0;       // block-uniform: some face overlaps this region
     const uint2* bx = reinterpret_cast<const uint2*>(boxes) + (long)b * F;
-    // faces to scan: the bin of this region's 128x128-sample super-region (or the whole frame without bins)
-    const int nsx = (is + (1 << SR_SHIFT) - 1) >> SR_SHIFT;
-    const int sr = (gy0 >> SR_SHIFT) * nsx + (gx0 >> SR_SHIFT);
+    // faces to scan: the bin of this region's super-region (or the whole frame without bins)
+    const int nsx = (is + (1 << hm_sr_shift(is)) - 1) >> hm_sr_shift(is);
+    const int sr = (gy0 >> hm_sr_shift(is)) * nsx + (gx0 >> hm_sr_shift(is));
     const int nscan = bin_cnt ? bin_cnt[b * nsx * nsx + sr] : F;
     const int* scan = bin_cnt ? bin_list + ((long)b * nsx * nsx + sr) * F : nullptr;
     for (int cbase = 0; cbase < nscan; cbase += CAND_CAP) {
@@ -513,11 +516,11 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         }
     }
     __syncthreads();
-    // the last of the (up to 16) workgroups that read a bin empties it for the next forward.  One ticket word per bin:
+    // the last of the (4 or 16) workgroups that read a bin empties it for the next forward.  One ticket word per bin:
     // returning atomics on a single word from all 7680 workgroups serialise (measured +43 us on the launch).
     if (tid == 0 && bin_cnt && reset_bins) {
-        const int per_side = (1 << SR_SHIFT) / (2 * HM_STILE);
-        const int rw = min(per_side, regions_x - per_side * (gx0 >> SR_SHIFT)), rh = min(per_side, regions_x - per_side * (gy0 >> SR_SHIFT));
+        const int per_side = (1 << hm_sr_shift(is)) / (2 * HM_STILE);
+        const int rw = min(per_side, regions_x - per_side * (gx0 >> hm_sr_shift(is))), rh = min(per_side, regions_x - per_side * (gy0 >> hm_sr_shift(is)));
         const int slot = b * nsx * nsx + sr;
         if (atomicAdd(done + slot, 1u) == (unsigned)(rw * rh) - 1u) {
             bin_cnt[slot] = 0;
