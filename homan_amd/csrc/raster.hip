@@ -1016,11 +1016,16 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                                                    const uint4* __restrict__ lrec, int B, int F, int S,
                                                    float eps, float* __restrict__ parts)
 {
-    __shared__ SweepFace s_face[4][SWEEP_PASS_FACES];
+    // LDS copies are padded to an ODD number of dwords (17 / 9): lanes reading the same field of different faces / items
+    // then fall into different banks (64- and 32-byte strides put every second / fourth element on the same bank, and the
+    // kernel is bound by LDS cycles: SQ_LDS_IDX_ACTIVE ~ 90 % of its duration)
+    struct FaceLds { SweepFace f; int pad; };
+    struct ItemLds { SweepItem it; int pad; };
+    __shared__ FaceLds s_face[4][SWEEP_PASS_FACES];
     __shared__ float s_fg[4][SWEEP_PASS_FACES][6];
     __shared__ int s_start[4][64];
     __shared__ int s_head[4][256];
-    __shared__ SweepItem s_item[4][64];
+    __shared__ ItemLds s_item[4][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int is = 2 * S;
     const bool pow2 = (is & (is - 1)) == 0;
@@ -1064,7 +1069,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             for (int k = 0; k < SWEEP_PASS_FACES / 4; ++k) {
                 const int ent = 4 * k + (lane >> 4);
                 if (ent < nfp)
-                    reinterpret_cast<int*>(&s_face[wv][ent])[lane & 15] =
+                    reinterpret_cast<int*>(&s_face[wv][ent].f)[lane & 15] =
                         reinterpret_cast<const int*>(sl.tab + first + fb + ent)[lane & 15];
             }
             for (int i = lane; i < SWEEP_PASS_FACES * 6; i += 64) (&s_fg[wv][0][0])[i] = 0.f;
@@ -1073,7 +1078,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             const int el = e - fb;
             bool mine = g < N && el >= 0 && el < nfp;
             // ---- per-lane item setup (lanes without an item run on harmless in-range addresses and are masked below)
-            const SweepFace& fc = s_face[wv][mine ? el : 0];
+            const SweepFace& fc = s_face[wv][mine ? el : 0].f;
             mine = mine && g - fc.off < (int)fc.cum[11];      // (past the last face of a compaction block: padding)
             const int j = mine ? g - fc.off : 0;
             int fam = 0;
@@ -1179,9 +1184,9 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                     const int m0 = var ? 2 - edge : edge, k1 = edge == 2 ? 0 : edge + 1, m1 = var ? 2 - k1 : k1;
                     const int comp = axis ? 0 : 1;         // row sweeps move x, column sweeps move y
                     it.meta = (mine ? el : 0) | ((2 * m0 + comp) << 4) | ((2 * m1 + comp) << 7) | (use0 ? 1 << 10 : 0) |
-                              (use1 ? 1 << 11 : 0);
+                              (use1 ? 1 << 11 : 0) | (nb0 << 12);        // nb0 <= 1024 rides in the upper bits
                 }
-                s_item[wv][lane] = it;
+                s_item[wv][lane].it = it;
                 wave_sync();
                 const int* st = s_start[wv];
                 int cur = -1;
@@ -1211,25 +1216,31 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                     int before = __builtin_amdgcn_update_dpp(0, inc, 0x138, 0xf, 0xf, false);       // wave_shr:1
                     before = max(before, carry);
                     carry = max(carry, __builtin_amdgcn_readlane(inc, 63));
+                    // (the LDS pipe is this kernel's busiest unit: a pair reads its item's meta word - with the outward
+                    //  count in its upper bits - and one base for the address, then x, c0, c1; base1 / fn only for the rare
+                    //  inward pairs)
                     SweepSrc sc[4];
-                    int qi[4];
+                    int qi[4], qmeta[4];
                     bool ph1[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const int p = min(base + 4 * lane + k, npairs - 1);
                         const int i = max(max(before, m[k]) - 1, 0);
                         const int r = max(p - st[i], 0);
-                        const SweepItem& q = s_item[wv][i];
-                        const int q_nb0 = q.nb0;
+                        const SweepItem& q = s_item[wv][i].it;
+                        qmeta[k] = q.meta;
+                        const int q_nb0 = qmeta[k] >> 12;
                         ph1[k] = r >= q_nb0;
                         qi[k] = i;
-                        sc[k] = srcs[ph1[k] ? (long)q.base1 + (r - q_nb0) : (long)q.base0 + r];
+                        long at = (long)q.base0 + r;
+                        if (ph1[k]) at = (long)q.base1 + (r - q_nb0);
+                        sc[k] = srcs[at];
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (base + 4 * lane + k < npairs) {
-                            const SweepItem& q = s_item[wv][qi[k]];
-                            const int meta = q.meta, key = meta & 0x3ff;
+                            const SweepItem& q = s_item[wv][qi[k]].it;
+                            const int meta = qmeta[k], key = meta & 0x3ff;
                             if (key != cur) {
                                 if (cur >= 0) {
                                     float* f = s_fg[wv][cur & 15];
@@ -1240,7 +1251,9 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                                 acc0 = 0.f;
                                 acc1 = 0.f;
                             }
-                            if (!ph1[k] || sc[k].owner == q.fn)
+                            bool take = true;
+                            if (ph1[k]) take = sc[k].owner == q.fn;
+                            if (take)
                                 sweep_term(ph1[k] ? sc[k].g : -sc[k].g, sc[k].d1, q.x, q.c0, q.c1, (meta & (1 << 10)) != 0,
                                            (meta & (1 << 11)) != 0, eps, inv_is, pow2, is, acc0, acc1);
                         }
@@ -1256,7 +1269,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             SWT_MARK(3)
             // ---- results of the faces of this pass
             if (lane < nfp) {
-                const SweepFace& ff = s_face[wv][lane];
+                const SweepFace& ff = s_face[wv][lane].f;
                 const int eg = first + fb + lane;
                 const int off = ff.off, nit = (int)ff.cum[11];
                 const int u_lo = off >> 6, u_hi = (off + nit - 1) >> 6;
