@@ -148,10 +148,18 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
         if (sil.parts) {        // same arithmetic as k_bwd_gather (raster.hip)
             float gu = 0.f, gv = 0.f;
             const float2* pf = reinterpret_cast<const float2*>(sil.parts + (long)n * sil.F * 6);
-            for (int a = sil.adj_off[v]; a < sil.adj_off[v + 1]; ++a) {
-                const float2 g2 = pf[sil.adj_items[a]];
-                gu += g2.x;
-                gv += g2.y;
+            // eight adjacent corners at a time: all item loads, then all gradient loads (two dependent round trips per
+            // batch instead of two per corner; the valence of a mesh vertex is ~6)
+            const int a1 = sil.adj_off[v + 1];
+            for (int a = sil.adj_off[v]; a < a1; a += 8) {
+                int item[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) item[k] = a + k < a1 ? sil.adj_items[a + k] : -1;
+                float2 g2[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g2[k] = item[k] >= 0 ? pf[item[k]] : make_float2(0.f, 0.f);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { gu += g2[k].x; gv += g2[k].y; }
             }
             const float* k = sil.K + n * 9;
             const float x = sil.cam_verts[o], y = sil.cam_verts[o + 1], z = sil.cam_verts[o + 2];

@@ -1325,11 +1325,17 @@ __global__ void k_bwd_gather(const float* __restrict__ parts, const int* __restr
     if (i >= (long)B * V) return;
     const int b = (int)(i / V), v = (int)(i % V);
     float gu = 0.f, gv = 0.f;
-    for (int a = adj_off[v]; a < adj_off[v + 1]; ++a) {
-        const int item = adj_items[a];                  // face * 3 + corner = float2 index into parts
-        const float2 g2 = reinterpret_cast<const float2*>(parts + (long)b * F * 6)[item];
-        gu += g2.x;
-        gv += g2.y;
+    const float2* pf = reinterpret_cast<const float2*>(parts + (long)b * F * 6);
+    const int a1 = adj_off[v + 1];
+    for (int a = adj_off[v]; a < a1; a += 8) {          // eight corners at a time: item loads, then gradient loads
+        int item[8];                                    // face * 3 + corner = float2 index into parts
+#pragma unroll
+        for (int k = 0; k < 8; ++k) item[k] = a + k < a1 ? adj_items[a + k] : -1;
+        float2 g2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g2[k] = item[k] >= 0 ? pf[item[k]] : make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { gu += g2[k].x; gv += g2[k].y; }
     }
     if (grad_ndc) { grad_ndc[3 * i] = gu; grad_ndc[3 * i + 1] = gv; grad_ndc[3 * i + 2] = 0.f; }
     const float* k = K + b * 9;
