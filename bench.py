@@ -158,14 +158,22 @@ def pose_init_bench(args):
                      (xs.max() - xs.min()) * sq[2] / size, (ys.max() - ys.min()) * sq[2] / size], np.float32)
     torch.manual_seed(0)
     rots = po.compute_random_rotations(n)
-    fit = lambda k: po.find_optimal_pose(verts, faces, mask, bbox, sq, (350, 350), K=K, num_iterations=k,
-                                         num_initializations=n, rotations_init=rots, rend_size=size)
-    fit(3)                                         # warm-up (allocations, lazy init)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    model = fit(steps)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    fit = lambda k, mode: po.find_optimal_pose(verts, faces, mask, bbox, sq, (350, 350), K=K, num_iterations=k,
+                                               num_initializations=n, rotations_init=rots, rend_size=size, mode=mode)
+    # both loops of find_optimal_pose: "eager" = the reference's loop verbatim (torch Adam, one host sync per step), "graph" =
+    # the same step captured in a hipGraph.  The GPU work is the same; the eager loop also needs a host that keeps up with
+    # ~40 launches per 2 ms step, which not every box does - the faster of the two is reported, both are listed.
+    loops, best = {}, None
+    for mode in ("eager", "graph"):
+        fit(3, mode)                               # warm-up (allocations, lazy init)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fitted = fit(steps, mode)
+        torch.cuda.synchronize()
+        loops[mode] = time.perf_counter() - t0
+        if best is None or loops[mode] < loops[best]:
+            best, model = mode, fitted
+    el = loops[best]
     with torch.no_grad():
         _, iou, _ = model()
     cpu = None
@@ -186,8 +194,9 @@ def pose_init_bench(args):
                       "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f32", "data": "synthetic",
                       "config": {"workload": f"SURVEY 8f rank 1: find_optimal_pose, {n} poses, lathe bottle (3000 faces), "
-                                             f"{size}x{size} mask, no anti-aliasing, torch Adam + autograd loop over the "
-                                             "HIP rasteriser", "poses": n, "rend_size": size},
+                                             f"{size}x{size} mask, no anti-aliasing, torch Adam + autograd over the "
+                                             f"HIP rasteriser, loop = {best}", "poses": n, "rend_size": size,
+                                 "pose_steps_per_s_by_loop": {k: n * steps / v for k, v in loops.items()}},
                       "best_iou": float(iou.max()), "seconds_per_fit": el, "cpu_baseline": cpu}))
 
 
