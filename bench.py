@@ -322,11 +322,13 @@ def main():
                                          frac=tot * (args.steps / elapsed) / 8.0e12))
 
     multi = None
-    if rank == 0 and world == 1 and args.multi_clip > 1:
+    if args.multi_clip > 1 and args.loop == "fused":
+        # BASELINE config 4 in miniature: `multi_clip` independent clips per GPU (one optimiser each), every rank its own
+        # set, no collective; aggregate = all clips of all ranks / the slowest rank's time
         C, msteps = args.multi_clip, min(args.steps, 200)
         steppers, streams = [stepper], [torch.cuda.Stream()]
         for i in range(1, C):
-            ci = synth.make_clip(seed=1000 + i, frames=args.frames, rend_size=args.size, image_size=args.size,
+            ci = synth.make_clip(seed=1000 + 100 * rank + i, frames=args.frames, rend_size=args.size, image_size=args.size,
                                  obj="bottle", silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
             mi = build_model(copy.deepcopy(ci["person_parameters"]), copy.deepcopy(ci["object_parameters"]),
                              objvertices=ci["objvertices"], objfaces=ci["objfaces"], camintr=ci["camintr"],
@@ -344,13 +346,22 @@ def main():
         torch.cuda.synchronize()
         round_robin(10)
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t1 = time.perf_counter()
         round_robin(msteps)
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         el = time.perf_counter() - t1
-        multi = dict(clips=C, steps_per_clip=msteps, value=C * msteps / el, unit="it/s (sum over clips)",
-                     ms_per_round=1e3 * el / msteps,
-                     note="independent clips, one captured hipGraph per clip replayed round-robin on its own HIP stream")
+        if world > 1:
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt.item())
+        multi = dict(clips=world * C, clips_per_gpu=C, steps_per_clip=msteps, value=world * C * msteps / el,
+                     unit="it/s (sum over clips)", ms_per_round=1e3 * el / msteps,
+                     note="independent clips, one captured hipGraph per clip replayed round-robin on its own HIP stream; "
+                          "max over ranks")
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
