@@ -133,3 +133,33 @@ def test_contact_loss_of_coincident_point_sets_is_zero(impl, mano_model):
         assert torch.equal(nn[0].cpu(), torch.arange(778)[None].repeat(2, 1).to(nn[0].dtype))
         loss = ops.contact_loss(pts.to(dev), pts.clone().to(dev), nn[0], rws, 0.02)
     assert abs(float(loss.reshape(-1)[0])) < 1e-9
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_pseudo_gradient_pulls_the_silhouette_towards_the_target(impl):
+    """The NMR backward is a heuristic, but its purpose is checkable: for L = sum (silhouette - target)^2 with the target a
+    copy of the shape shifted by +3 px in x and -2 px in y (image rows grow downwards = camera y grows), gradient descent
+    must move every vertex towards +x and -y, i.e. dL/dx < 0 and dL/dy > 0 at all four corners."""
+    S = 64
+    def quad(x0, y0, x1, y1, z=2.0):
+        return torch.tensor([[[x0, y0, 1.0], [x1, y0, 1.0], [x1, y1, 1.0], [x0, y1, 1.0]]]) * z
+    f = torch.tensor([[[0, 1, 2], [0, 2, 3]]])
+    px = 1.0 / S
+    v = quad(0.3, 0.35, 0.6, 0.7).requires_grad_(True)
+    target = _silhouettes(impl, quad(0.3 + 3 * px, 0.35 - 2 * px, 0.6 + 3 * px, 0.7 - 2 * px), f, S)
+    if impl == "oracle":
+        from oracle import nmr
+        r = nmr.Renderer(image_size=S, K=K_UNIT, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
+        img = r(v, f, mode="silhouettes")
+        ((img - target) ** 2).sum().backward()
+        g = v.grad[0]
+    else:
+        from homan_amd import ops
+        dev = torch.device("cuda")
+        sctx = ops.SilhouetteContext(f.to(dev), 4, 1, S, dev)
+        vd = v.detach().to(dev).requires_grad_(True)
+        img = ops.silhouette_render(vd, K_UNIT.to(dev), sctx)
+        ((img - target.to(dev)) ** 2).sum().backward()
+        g = vd.grad[0].cpu()
+    assert bool((g[:, 0] < 0).all()), g           # move right
+    assert bool((g[:, 1] > 0).all()), g           # move up in the image = smaller camera y
