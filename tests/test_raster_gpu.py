@@ -247,3 +247,29 @@ def test_sweep_scheduling_and_capacity_paths_do_not_change_the_gradient(obj):
     for cap in (1, 3, 40):
         np.testing.assert_allclose((grad(cap=cap) / scale).cpu().numpy(), (ref / scale).cpu().numpy(), atol=2e-6,
                                    err_msg=f"cap {cap}")
+
+
+def test_large_batches_take_the_four_faces_per_thread_work_list():
+    """B * F >= 400k switches the sweep work list to four faces per compaction thread (500 candidate poses in the pose
+    initialisation).  804 frames = 268 copies of three poses: every copy must get the gradient of the 3-frame batch (to
+    summation order - the units are composed differently)."""
+    from homan_amd import ops
+    S = 32
+    verts, faces, K, V = _scene(B=3, S=S, obj="cube", seed=4)
+    assert 804 * faces.shape[1] >= 400000
+    dev = torch.device("cuda")
+    gimg = torch.randn(3, S, S, generator=torch.Generator().manual_seed(9))
+
+    def grad(rep):
+        B = 3 * rep
+        sctx = ops.SilhouetteContext(faces.repeat(rep, 1, 1).to(dev), V, B, S, dev)
+        v = verts.repeat(rep, 1, 1).to(dev).requires_grad_(True)
+        ops.silhouette_render(v, K.repeat(rep, 1, 1).to(dev), sctx).backward(gimg.repeat(rep, 1, 1).to(dev))
+        torch.cuda.synchronize()
+        return v.grad.cpu()
+
+    small, large = grad(1), grad(268)
+    scale = small.abs().max()
+    assert scale > 0
+    np.testing.assert_allclose((large.reshape(268, 3, V, 3) / scale).numpy(),
+                               (small[None].expand(268, -1, -1, -1) / scale).numpy(), atol=2e-6)
