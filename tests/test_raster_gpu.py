@@ -273,3 +273,19 @@ def test_large_batches_take_the_four_faces_per_thread_work_list():
     assert scale > 0
     np.testing.assert_allclose((large.reshape(268, 3, V, 3) / scale).numpy(),
                                (small[None].expand(268, -1, -1, -1) / scale).numpy(), atol=2e-6)
+
+
+def test_nothing_visible_gives_empty_images_and_zero_gradients():
+    """Edge case: the whole mesh off-screen (empty work list, zero units) or behind the near plane."""
+    from homan_amd import ops
+    S = 32
+    verts, faces, K, V = _scene(B=2, S=S, obj="cube", seed=6)
+    dev = torch.device("cuda")
+    for shift in (torch.tensor([5.0, 0.0, 0.0]), torch.tensor([0.0, 0.0, -2.0])):
+        sctx = ops.SilhouetteContext(faces.to(dev), V, 2, S, dev)
+        v = (verts + shift).to(dev).requires_grad_(True)
+        img = ops.silhouette_render(v, K.to(dev), sctx)
+        assert float(img.detach().abs().sum()) == 0.0
+        img.backward(torch.ones_like(img))
+        torch.cuda.synchronize()
+        assert torch.isfinite(v.grad).all() and float(v.grad.abs().sum()) == 0.0
