@@ -62,29 +62,37 @@ __global__ void k_log(const float* __restrict__ src, int n, const int* __restric
     if (i < n && t < max_steps) log[(long)t * n + i] = src[i];
 }
 
-// total = sum_i w[i]*vals[i] (i < n) -> vals[n] ; then log row `step` = vals[0..n] (n+1 floats)
+// per clip c (grid (clips)): total = sum_i w[i]*vals[c][i] (i < n) -> vals[c][n] ; then row (step, c) of the log =
+// vals[c][0..n] (n+1 floats).  vals (clips, n+1), log (max_steps, clips, n+1).
 __global__ void k_log_total(float* __restrict__ vals, const float* __restrict__ w, int n, const int* __restrict__ step,
                             int max_steps, float* __restrict__ log)
 {
     HM_LATENCY_KERNEL();
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (threadIdx.x == 0) {
+        const int c = blockIdx.x, nc = gridDim.x;
+        float* v = vals + (long)c * (n + 1);
         float t = 0.f;
         for (int i = 0; i < n; ++i)
-            if (w[i] != 0.f) t += w[i] * vals[i];
-        vals[n] = t;
+            if (w[i] != 0.f) t += w[i] * v[i];
+        v[n] = t;
         const int s = step[0];
         if (s < max_steps)
-            for (int i = 0; i <= n; ++i) log[(long)s * (n + 1) + i] = vals[i];
+            for (int i = 0; i <= n; ++i) log[((long)s * nc + c) * (n + 1) + i] = v[i];
     }
 }
 
 extern "C" {
+int hm_log_total_clips(float* vals, const float* weights, int n, const int* step, int max_steps, float* log, int nclips,
+                       hipStream_t stream)
+{
+    HM_CHECK_ARG(vals && weights && step && log && n > 0 && nclips > 0);
+    hipLaunchKernelGGL(k_log_total, dim3(nclips), dim3(64), 0, stream, vals, weights, n, step, max_steps, log);
+    return hm_launch_status();
+}
 int hm_log_total(float* vals, const float* weights, int n, const int* step, int max_steps, float* log,
                  hipStream_t stream)
 {
-    HM_CHECK_ARG(vals && weights && step && log && n > 0);
-    hipLaunchKernelGGL(k_log_total, dim3(1), dim3(64), 0, stream, vals, weights, n, step, max_steps, log);
-    return hm_launch_status();
+    return hm_log_total_clips(vals, weights, n, step, max_steps, log, 1, stream);
 }
 size_t hm_adam_slot_bytes(void) { return sizeof(AdamSlot); }
 

@@ -27,7 +27,7 @@ __device__ __forceinline__ float rl_f(float v, int l)
 __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ vh, const float* __restrict__ vo, int B,
                                                        int Vh, int Vo, int* __restrict__ nn_idx, float* __restrict__ nn_d2,
                                                        float* __restrict__ blockmin, unsigned int* counter,
-                                                       float* __restrict__ metric_out)
+                                                       float* __restrict__ metric_out, int clip_len, int out_stride)
 {
     HM_LATENCY_KERNEL();
     __shared__ float s_d[NN_WAVES][NN_HV];
@@ -83,8 +83,12 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
         if (i < Vh) { nn_idx[(long)b * Vh + i] = bi; nn_d2[(long)b * Vh + i] = bd; bm = bd; }
     }
     bm = hm_block_min(bm, red);
-    const unsigned nblk = gridDim.x * gridDim.y;
-    if (threadIdx.x == 0) hm_partial_store(blockmin + b * gridDim.x + blockIdx.x, bm);
+    // per clip (clip_len consecutive frames): its own slice of the reduce workspace, its own ticket, its own metric
+    const int clip = b / clip_len, bl = b - clip * clip_len;
+    blockmin += (long)clip * HM_RED_WS_FLOATS;
+    counter += (long)clip * HM_RED_WS_FLOATS;
+    const unsigned nblk = gridDim.x * clip_len;
+    if (threadIdx.x == 0) hm_partial_store(blockmin + bl * gridDim.x + blockIdx.x, bm);
     if (hm_last_block(counter, nblk, &s_flag)) {
         // all block minima requested at once (one agent-scope load per thread), then min over a frame's chunks, max over
         // the frames
@@ -92,13 +96,13 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
         for (unsigned i2 = threadIdx.x; i2 < nblk; i2 += blockDim.x) s_bm[i2] = hm_partial_load(blockmin + i2);
         __syncthreads();
         float mx = -3.4e38f;
-        for (int bb = threadIdx.x; bb < B; bb += blockDim.x) {
+        for (int bb = threadIdx.x; bb < clip_len; bb += blockDim.x) {
             float m = 3.4e38f;
             for (unsigned c = 0; c < gridDim.x; ++c) m = fminf(m, s_bm[bb * gridDim.x + c]);
             mx = fmaxf(mx, sqrtf(m));
         }
         mx = hm_block_max(mx, red);
-        if (threadIdx.x == 0) metric_out[0] = mx;
+        if (threadIdx.x == 0) metric_out[(long)clip * out_stride] = mx;
     }
 }
 
@@ -108,13 +112,15 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_hand(const float* __rest
                                                               const int* __restrict__ nn_idx, int B, int Vh, int Vo,
                                                               float thresh, float* __restrict__ g_hand,
                                                               float* __restrict__ partials, unsigned int* counter,
-                                                              float* __restrict__ out)
+                                                              float* __restrict__ out, int clip_len, int out_stride)
 {
     HM_LATENCY_KERNEL();
     __shared__ float red[16];
     __shared__ int s_flag;
-    const int b = blockIdx.x;
-    const float inv_cnt = 1.0f / (float)((long)B * Vh);
+    const int b = blockIdx.x, clip = b / clip_len, bl = b - clip * clip_len;
+    partials += (long)clip * HM_RED_WS_FLOATS;
+    counter += (long)clip * HM_RED_WS_FLOATS;
+    const float inv_cnt = 1.0f / (float)((long)clip_len * Vh);        // the mean runs over the clip's frames
     float lsum = 0.f;
     for (int i = threadIdx.x; i < Vh; i += NN_THREADS) {
         const int j = nn_idx[(long)b * Vh + i];
@@ -129,10 +135,10 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_hand(const float* __rest
         gh[0] = -k * dx; gh[1] = -k * dy; gh[2] = -k * dz;
     }
     lsum = hm_block_sum(lsum, red);
-    if (threadIdx.x == 0) hm_partial_store(partials + b, lsum);
-    if (hm_last_block(counter, gridDim.x, &s_flag)) {
-        const float t = hm_last_block_sum(partials, B, 1, red);
-        if (threadIdx.x == 0) out[0] = t * inv_cnt;
+    if (threadIdx.x == 0) hm_partial_store(partials + bl, lsum);
+    if (hm_last_block(counter, clip_len, &s_flag)) {
+        const float t = hm_last_block_sum(partials, clip_len, 1, red);
+        if (threadIdx.x == 0) out[(long)clip * out_stride] = t * inv_cnt;
     }
 }
 
@@ -165,28 +171,44 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_obj(const int* __restric
 }
 
 extern "C" {
-// workspace: reuse hm_reduce_workspace_bytes() layout (partials + counter); needs B <= 512 and
-// B*ceil(Vh/256) <= 512 partial floats.
+// workspace: reuse hm_reduce_workspace_bytes() layout (partials + counter), one slice per clip; needs
+// clip frames * ceil(Vh/128) <= 512 partial floats.
+int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
+                    float* metric_out, void* workspace, int clip_len, int out_stride, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts_hand && verts_obj && nn_idx && nn_d2 && metric_out && workspace && B > 0 && Vh > 0 && Vo > 0);
+    HM_CHECK_ARG(HM_CLIP_LEN_OK(B, clip_len));
+    const int nchunk = hm_cdiv(Vh, NN_HV);   // 128 hand vertices per workgroup
+    const int Bc = clip_len ? clip_len : B;
+    if ((long)Bc * nchunk > 512) return HM_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(k_nn, dim3(nchunk, B), dim3(64 * NN_WAVES), 0, stream, verts_hand, verts_obj, B, Vh, Vo, nn_idx,
+                       nn_d2, (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out, Bc, out_stride);
+    return hm_launch_status();
+}
 int hm_nn_fwd(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
               float* metric_out, void* workspace, hipStream_t stream)
 {
-    HM_CHECK_ARG(verts_hand && verts_obj && nn_idx && nn_d2 && metric_out && workspace && B > 0 && Vh > 0 && Vo > 0);
-    const int nchunk = hm_cdiv(Vh, NN_HV);   // 128 hand vertices per workgroup
-    if ((long)B * nchunk > 512) return HM_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_nn, dim3(nchunk, B), dim3(64 * NN_WAVES), 0, stream, verts_hand, verts_obj, B, Vh, Vo, nn_idx,
-                       nn_d2, (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out);
+    return hm_nn_fwd_clips(verts_hand, verts_obj, B, Vh, Vo, nn_idx, nn_d2, metric_out, workspace, 0, 0, stream);
+}
+int hm_contact_fwd_clips(const float* verts_hand, const float* verts_obj, const int* nn_idx, int B, int Vh, int Vo,
+                         float thresh, float* g_hand, float* g_obj, float* out1, void* workspace, int clip_len,
+                         int out_stride, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts_hand && verts_obj && nn_idx && g_hand && g_obj && out1 && workspace);
+    HM_CHECK_ARG(B > 0 && Vh > 0 && Vo > 0 && HM_CLIP_LEN_OK(B, clip_len));
+    const int Bc = clip_len ? clip_len : B;
+    HM_CHECK_ARG(Bc <= 512);
+    if (Vo > CONTACT_MAX_VO) return HM_ERR_UNSUPPORTED;     // per-frame object accumulator in LDS (96 KB at 4096 vertices)
+    hipLaunchKernelGGL(k_contact_hand, dim3(B), dim3(NN_THREADS), 0, stream, verts_hand, verts_obj, nn_idx, B, Vh, Vo,
+                       thresh, g_hand, (float*)workspace, (unsigned int*)((float*)workspace + 512), out1, Bc, out_stride);
+    hipLaunchKernelGGL(k_contact_obj, dim3(B), dim3(NN_THREADS), 0, stream, nn_idx, g_hand, B, Vh,
+                       Vo, g_obj);
     return hm_launch_status();
 }
 int hm_contact_fwd(const float* verts_hand, const float* verts_obj, const int* nn_idx, int B, int Vh, int Vo,
                    float thresh, float* g_hand, float* g_obj, float* out1, void* workspace, hipStream_t stream)
 {
-    HM_CHECK_ARG(verts_hand && verts_obj && nn_idx && g_hand && g_obj && out1 && workspace);
-    HM_CHECK_ARG(B > 0 && B <= 512 && Vh > 0 && Vo > 0);
-    if (Vo > CONTACT_MAX_VO) return HM_ERR_UNSUPPORTED;     // per-frame object accumulator in LDS (96 KB at 4096 vertices)
-    hipLaunchKernelGGL(k_contact_hand, dim3(B), dim3(NN_THREADS), 0, stream, verts_hand, verts_obj, nn_idx, B, Vh, Vo,
-                       thresh, g_hand, (float*)workspace, (unsigned int*)((float*)workspace + 512), out1);
-    hipLaunchKernelGGL(k_contact_obj, dim3(B), dim3(NN_THREADS), 0, stream, nn_idx, g_hand, B, Vh,
-                       Vo, g_obj);
-    return hm_launch_status();
+    return hm_contact_fwd_clips(verts_hand, verts_obj, nn_idx, B, Vh, Vo, thresh, g_hand, g_obj, out1, workspace, 0, 0,
+                                stream);
 }
 }  // extern "C"

@@ -59,7 +59,7 @@ __device__ __forceinline__ void rot6d_backward(const float* r6, const float* dR,
 __global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
                                                    const float* __restrict__ trans, const float* __restrict__ scale,
                                                    int abs_scale, int N, int V, float* __restrict__ rotmat,
-                                                   float* __restrict__ verts)
+                                                   float* __restrict__ verts, int clip_len)
 {
     __shared__ float R[9];
     const int n = blockIdx.y;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mes
     __syncthreads();
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= V) return;
-    float s = scale[0];
+    float s = scale[n / clip_len];          // one scale per clip (clip = clip_len consecutive frames)
     if (abs_scale) s = fabsf(s);
     const float* m = mesh + ((long)n * V + v) * 3;
     const float x = s * m[0], y = s * m[1], z = s * m[2];
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
                                                    float* __restrict__ g_mesh,
                                                    float* __restrict__ g_rot6d, float* __restrict__ g_trans,
                                                    float* __restrict__ g_scale_part, float* __restrict__ partials,
-                                                   unsigned int* __restrict__ frame_cnt)
+                                                   unsigned int* __restrict__ frame_cnt, int clip_len)
 {
     HM_LATENCY_KERNEL();
     __shared__ float R[9];
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
         for (int k = 0; k < 9; ++k) R[k] = r[k];
     }
     __syncthreads();
-    const float sraw = scale[0];
+    const float sraw = scale[n / clip_len];
     const float s = abs_scale ? fabsf(sraw) : sraw;
     float gfr[3] = {0.f, 0.f, 0.f};
     if (g_frame) {
@@ -243,15 +243,17 @@ __global__ void k_lincomb4(const float* __restrict__ a0, float w0, const float* 
     if (a3) v += w3 * a3[i];
     out[i] = v;
 }
-// out[0] = w0 * sum(parts[0..n)) + w1 * extra[0]      (scale gradients: per-frame partials + prior term)
+// out[c] = w0 * sum(parts[c*n .. c*n+n)) + w1 * extra[c]      (scale gradients: per-frame partials + prior term)
+// grid (clips)
 __global__ void k_sum_small(const float* __restrict__ parts, int n, float w0, const float* __restrict__ extra, float w1,
                             float* __restrict__ out)
 {
     __shared__ float red[16];
+    const int c = blockIdx.x;
     float a = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) a += parts[i];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) a += parts[(long)c * n + i];
     a = hm_block_sum(a, red);
-    if (threadIdx.x == 0) out[0] = w0 * a + (extra ? w1 * extra[0] : 0.f);
+    if (threadIdx.x == 0) out[c] = w0 * a + (extra ? w1 * extra[c] : 0.f);
 }
 
 extern "C" {
@@ -262,19 +264,29 @@ int hm_lincomb4(const float* a0, float w0, const float* a1, float w1, const floa
     hipLaunchKernelGGL(k_lincomb4, dim3(hm_cdiv(n, 256)), dim3(256), 0, stream, a0, w0, a1, w1, a2, w2, a3, w3, n, out);
     return hm_launch_status();
 }
+int hm_sum_small_clips(const float* parts, int n, float w0, const float* extra, float w1, float* out, int nclips,
+                       hipStream_t stream)
+{
+    HM_CHECK_ARG(parts && out && n > 0 && nclips > 0);
+    hipLaunchKernelGGL(k_sum_small, dim3(nclips), dim3(64), 0, stream, parts, n, w0, extra, w1, out);
+    return hm_launch_status();
+}
 int hm_sum_small(const float* parts, int n, float w0, const float* extra, float w1, float* out, hipStream_t stream)
 {
-    HM_CHECK_ARG(parts && out && n > 0);
-    hipLaunchKernelGGL(k_sum_small, dim3(1), dim3(64), 0, stream, parts, n, w0, extra, w1, out);
+    return hm_sum_small_clips(parts, n, w0, extra, w1, out, 1, stream);
+}
+int hm_rigid_fwd_clips(const float* mesh, const float* rot6d, const float* trans, const float* scale, int abs_scale, int N,
+                       int V, float* rotmat, float* verts, int clip_len, hipStream_t stream)
+{
+    HM_CHECK_ARG(mesh && rot6d && trans && scale && verts && N > 0 && V > 0 && HM_CLIP_LEN_OK(N, clip_len));
+    hipLaunchKernelGGL(k_rigid_fwd, dim3(hm_cdiv(V, 256), N), dim3(256), 0, stream, mesh, rot6d, trans, scale,
+                       abs_scale, N, V, rotmat, verts, clip_len ? clip_len : N);
     return hm_launch_status();
 }
 int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, const float* scale, int abs_scale, int N,
                  int V, float* rotmat, float* verts, hipStream_t stream)
 {
-    HM_CHECK_ARG(mesh && rot6d && trans && scale && verts && N > 0 && V > 0);
-    hipLaunchKernelGGL(k_rigid_fwd, dim3(hm_cdiv(V, 256), N), dim3(256), 0, stream, mesh, rot6d, trans, scale,
-                       abs_scale, N, V, rotmat, verts);
-    return hm_launch_status();
+    return hm_rigid_fwd_clips(mesh, rot6d, trans, scale, abs_scale, N, V, rotmat, verts, 0, stream);
 }
 #define RIGID_MAX_CHUNKS 16
 size_t hm_rigid_workspace_bytes(int N) { return (((size_t)N * 4 + 255) & ~(size_t)255) + (size_t)N * RIGID_MAX_CHUNKS * 16 * 4; }
@@ -282,9 +294,9 @@ static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* 
                             const float* const* g_terms, const float* weights, int n_terms, SilGather sil,
                             const float* g_rigid, const float* g_frame, int frame_stride, float frame_scale, int N, int V,
                             float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part, void* workspace,
-                            hipStream_t stream)
+                            int clip_len, hipStream_t stream)
 {
-    HM_CHECK_ARG(mesh && rot6d && scale && g_rot6d && g_trans && N > 0 && V > 0);
+    HM_CHECK_ARG(mesh && rot6d && scale && g_rot6d && g_trans && N > 0 && V > 0 && HM_CLIP_LEN_OK(N, clip_len));
     HM_CHECK_ARG(n_terms >= 0 && n_terms <= 4 && (n_terms == 0 || (g_terms && weights)));
     HM_CHECK_ARG(!g_frame || frame_stride >= 3);
     RigidTerms t;
@@ -295,29 +307,48 @@ static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* 
     unsigned int* cnt = (unsigned int*)workspace;
     float* partials = workspace ? (float*)((char*)workspace + (((size_t)N * 4 + 255) & ~(size_t)255)) : nullptr;
     hipLaunchKernelGGL(k_rigid_bwd, dim3(N, chunks), dim3(256), 0, stream, mesh, rot6d, scale, abs_scale, t, sil, g_rigid,
-                       g_frame, frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, partials, cnt);
+                       g_frame, frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, partials, cnt,
+                       clip_len ? clip_len : N);
     return hm_launch_status();
+}
+int hm_rigid_bwd_clips(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
+                       const float* const* g_terms, const float* weights, int n_terms, const float* g_rigid,
+                       const float* g_frame, int frame_stride, float frame_scale, int N, int V, float* g_mesh,
+                       float* g_rot6d, float* g_trans, float* g_scale_part, void* workspace, int clip_len,
+                       hipStream_t stream)
+{
+    SilGather none = {nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, 0};
+    return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, none, g_rigid, g_frame, frame_stride,
+                            frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, workspace, clip_len, stream);
 }
 int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
                  const float* weights, int n_terms, const float* g_rigid, const float* g_frame, int frame_stride,
                  float frame_scale, int N, int V, float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part,
                  void* workspace, hipStream_t stream)
 {
-    SilGather none = {nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, 0};
-    return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, none, g_rigid, g_frame, frame_stride,
-                            frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, workspace, stream);
+    return hm_rigid_bwd_clips(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, g_rigid, g_frame, frame_stride,
+                              frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, workspace, 0, stream);
 }
 // hm_rigid_bwd with the silhouette gradient as an extra full term taken straight from the sweep output: sil_parts =
 // hm_sil_parts(workspace) of an hm_sil_bwd called with grad_verts == NULL; cam_verts / K / orig_size / F as given to it.
+int hm_rigid_bwd_sil_clips(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
+                           const float* const* g_terms, const float* weights, int n_terms, const float* sil_parts,
+                           const int* adj_off, const int* adj_items, const float* cam_verts, const float* K,
+                           float orig_size, int F, int N, int V, float* g_rot6d, float* g_trans, float* g_scale_part,
+                           void* workspace, int clip_len, hipStream_t stream)
+{
+    HM_CHECK_ARG(sil_parts && adj_off && adj_items && cam_verts && K && F > 0);
+    SilGather sil = {sil_parts, adj_off, adj_items, cam_verts, K, orig_size, F};
+    return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, sil, nullptr, nullptr, 0, 0.f, N, V,
+                            nullptr, g_rot6d, g_trans, g_scale_part, workspace, clip_len, stream);
+}
 int hm_rigid_bwd_sil(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
                      const float* weights, int n_terms, const float* sil_parts, const int* adj_off, const int* adj_items,
                      const float* cam_verts, const float* K, float orig_size, int F, int N, int V, float* g_rot6d,
                      float* g_trans, float* g_scale_part, void* workspace, hipStream_t stream)
 {
-    HM_CHECK_ARG(sil_parts && adj_off && adj_items && cam_verts && K && F > 0);
-    SilGather sil = {sil_parts, adj_off, adj_items, cam_verts, K, orig_size, F};
-    return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, sil, nullptr, nullptr, 0, 0.f, N, V,
-                            nullptr, g_rot6d, g_trans, g_scale_part, workspace, stream);
+    return hm_rigid_bwd_sil_clips(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, sil_parts, adj_off, adj_items,
+                                  cam_verts, K, orig_size, F, N, V, g_rot6d, g_trans, g_scale_part, workspace, 0, stream);
 }
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream)
 {

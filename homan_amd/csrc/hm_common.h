@@ -20,6 +20,16 @@
         if (!(cond)) return HM_ERR_BAD_ARG; \
     } while (0)
 
+// ---- clip batches (the *_clips entry points) --------------------------------------------------------------------
+// Several independent clips of equal length are optimised by ONE launch per kernel: the frame axis of every per-frame
+// tensor is the concatenation of the clips (clip c = frames [c*clip_len, (c+1)*clip_len)), every per-clip scalar
+// (intrinsic scales, normalisers, loss values, reduction tickets / partial records) becomes an array with one entry per
+// clip, and per-clip outputs are written `out_stride` floats apart (row c of the caller's (clips, n) table of values).
+// clip_len == 0 means "the N frames are one clip" (the plain entry points).  Each clip's reductions are formed by its
+// own workgroups in the order a single-clip launch uses, so a batched launch returns bit-identical per-clip results.
+#define HM_CLIP_LEN_OK(N, clip_len) ((clip_len) == 0 || ((clip_len) > 0 && (N) % (clip_len) == 0))
+#define HM_RED_WS_FLOATS 576            // per-clip slice of a reduce workspace: 512 partials + ticket word at 512
+
 static inline int hm_launch_status()
 {
     hipError_t e = hipGetLastError();

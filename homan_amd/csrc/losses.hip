@@ -10,16 +10,27 @@
 
 #define RED_THREADS 256
 
+// ------------------------------------------------------------------ clip batches
+// Every reduction kernel below takes grid (nblk, clips): row blockIdx.y works on clip blockIdx.y - N frames of its own,
+// its own slice of the reduce workspace (HM_RED_WS_FLOATS floats: partial records + ticket), its own output row - exactly
+// as a single-clip launch with grid (nblk) would.  CLIP_ADVANCE moves a per-frame pointer to the clip's first frame.
+#define CLIP_ADVANCE(ptr, per_frame) ptr += (long)blockIdx.y * N * (per_frame)
+#define CLIP_WS(partials, counter) partials += (long)blockIdx.y * HM_RED_WS_FLOATS; counter += (long)blockIdx.y * HM_RED_WS_FLOATS
+
 // ------------------------------------------------------------------ v2d
-// grid (nblk). partial records: 2 floats per block.
+// grid (nblk, clips). partial records: 2 floats per block.
 __global__ __launch_bounds__(RED_THREADS) void k_v2d(const float* __restrict__ verts, const float* __restrict__ camintr,
                                                       int hand_nb, const float* __restrict__ ref2d, float image_size,
                                                       int N, int V, float* __restrict__ unit_grad,
                                                       float* __restrict__ partials, unsigned int* counter,
-                                                      float* __restrict__ out)
+                                                      float* __restrict__ out, int out_stride)
 {
     __shared__ float red[16];
     __shared__ int s_flag;
+    CLIP_ADVANCE(verts, V * 3); CLIP_ADVANCE(ref2d, V * 2); CLIP_ADVANCE(unit_grad, V * 3);
+    camintr += (long)blockIdx.y * (N / hand_nb) * 9;
+    CLIP_WS(partials, counter);
+    out += (long)blockIdx.y * out_stride;
     const long total = (long)N * V;
     const float inv_cnt = 1.0f / (float)total;
     float lsum = 0.f, msum = 0.f;
@@ -57,10 +68,13 @@ __global__ __launch_bounds__(RED_THREADS) void k_v2d(const float* __restrict__ v
 // verts (N,V,3), frames interleaved by `hand_nb` (pairs n, n+hand_nb).  loss = mean over pairs of diff^2.
 __global__ __launch_bounds__(RED_THREADS) void k_smooth(const float* __restrict__ verts, int N, int V, int hand_nb,
                                                          float* __restrict__ unit_grad, float* __restrict__ partials,
-                                                         unsigned int* counter, float* __restrict__ out)
+                                                         unsigned int* counter, float* __restrict__ out, int out_stride)
 {
     __shared__ float red[16];
     __shared__ int s_flag;
+    CLIP_ADVANCE(verts, V * 3); CLIP_ADVANCE(unit_grad, V * 3);
+    CLIP_WS(partials, counter);
+    out += (long)blockIdx.y * out_stride;
     const long row = (long)V * 3, total = (long)N * row;
     const long cnt = (long)(N - hand_nb) * row;
     const float inv_cnt = cnt > 0 ? 1.0f / (float)cnt : 0.f;
@@ -86,15 +100,21 @@ __global__ __launch_bounds__(RED_THREADS) void k_smooth(const float* __restrict_
     }
 }
 
-// ------------------------------------------------------------------ PCA prior + intrinsic scale priors (one block)
-// out[0] = mean(pca^2), out[1] = sum((s_obj - m_obj)^2)/1, out[2] = same for the hand scale.
+// ------------------------------------------------------------------ PCA prior + intrinsic scale priors (one block per clip)
+// out[0] = mean(pca^2), out[1] = sum((s_obj - m_obj)^2)/1, out[2] = same for the hand scale.  grid (1, clips); npca =
+// PCA entries of ONE clip; the scales / means / scale gradients are per-clip arrays.
 __global__ __launch_bounds__(RED_THREADS) void k_priors(const float* __restrict__ pca, long npca,
                                                          const float* __restrict__ s_obj, const float* __restrict__ m_obj,
                                                          const float* __restrict__ s_hand, const float* __restrict__ m_hand,
                                                          float* __restrict__ g_pca, float* __restrict__ g_sobj,
-                                                         float* __restrict__ g_shand, float* __restrict__ out)
+                                                         float* __restrict__ g_shand, float* __restrict__ out,
+                                                         int out_stride)
 {
     __shared__ float red[16];
+    pca += (long)blockIdx.y * npca; g_pca += (long)blockIdx.y * npca;
+    s_obj += blockIdx.y; m_obj += blockIdx.y; s_hand += blockIdx.y; m_hand += blockIdx.y;
+    g_sobj += blockIdx.y; g_shand += blockIdx.y;
+    out += (long)blockIdx.y * out_stride;
     float a = 0.f;
     const float inv = 1.0f / (float)npca;
     for (long i = threadIdx.x; i < npca; i += blockDim.x) {
@@ -124,10 +144,22 @@ __global__ __launch_bounds__(RED_THREADS) void k_hand_terms(
     float* __restrict__ unit_smooth, float* __restrict__ out_smooth, const float* __restrict__ pca, long npca,
     const float* __restrict__ s_obj, const float* __restrict__ m_obj, const float* __restrict__ s_hand,
     const float* __restrict__ m_hand, float* __restrict__ g_pca, float* __restrict__ g_sobj,
-    float* __restrict__ g_shand, float* __restrict__ out_priors, float* __restrict__ partials, unsigned int* counter)
+    float* __restrict__ g_shand, float* __restrict__ out_priors, float* __restrict__ partials, unsigned int* counter,
+    int out_stride)
 {
     __shared__ float red[16];
     __shared__ int s_flag;
+    CLIP_ADVANCE(verts, V * 3); CLIP_ADVANCE(ref2d, V * 2); CLIP_ADVANCE(unit_v2d, V * 3); CLIP_ADVANCE(unit_smooth, V * 3);
+    camintr += (long)blockIdx.y * (N / hand_nb) * 9;
+    CLIP_WS(partials, counter);
+    out_v2d += (long)blockIdx.y * out_stride;
+    out_smooth += (long)blockIdx.y * out_stride;
+    if (pca) {
+        pca += (long)blockIdx.y * npca; g_pca += (long)blockIdx.y * npca;
+        s_obj += blockIdx.y; m_obj += blockIdx.y; s_hand += blockIdx.y; m_hand += blockIdx.y;
+        g_sobj += blockIdx.y; g_shand += blockIdx.y;
+        out_priors += (long)blockIdx.y * out_stride;
+    }
     // ---- v2d
     const long total = (long)N * V;
     const float inv_cnt = 1.0f / (float)total;
@@ -211,12 +243,14 @@ __global__ __launch_bounds__(RED_THREADS) void k_hand_terms(
 __global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__ vh, const float* __restrict__ vo,
                                                         const float* __restrict__ camintr, int B, int Vh, int Vo,
                                                         float expansion, float zthresh, float* __restrict__ frame_rec,
-                                                        unsigned int* counter, float* __restrict__ out)
+                                                        unsigned int* counter, float* __restrict__ out, int clip_len,
+                                                        int out_stride)
 {
     HM_LATENCY_KERNEL();
     __shared__ float red[16];
     __shared__ int s_flag;
-    const int b = blockIdx.x;
+    const int b = blockIdx.x, clip = b / clip_len;
+    counter += (long)clip * HM_RED_WS_FLOATS;
     const float* k = camintr + b * 9;
     float box[2][4], zr[2][2], cen[2][3];
     for (int which = 0; which < 2; ++which) {
@@ -268,12 +302,13 @@ __global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__
         hm_partial_store(r, flag); hm_partial_store(r + 1, mse);
         r[2] = flag * 2.0f * dx / 3.0f; r[3] = flag * 2.0f * dy / 3.0f; r[4] = flag * 2.0f * dz / 3.0f;
     }
-    if (hm_last_block(counter, gridDim.x, &s_flag)) {
+    if (hm_last_block(counter, clip_len, &s_flag)) {       // the clip's last frame sums the clip
+        const float* fr = frame_rec + (long)clip * clip_len * 8;
         float l = 0.f;
-        for (int i = threadIdx.x; i < B; i += blockDim.x)
-            if (hm_partial_load(frame_rec + i * 8) != 0.f) l += hm_partial_load(frame_rec + i * 8 + 1);
+        for (int i = threadIdx.x; i < clip_len; i += blockDim.x)
+            if (hm_partial_load(fr + i * 8) != 0.f) l += hm_partial_load(fr + i * 8 + 1);
         l = hm_block_sum(l, red);
-        if (threadIdx.x == 0) out[0] = l;
+        if (threadIdx.x == 0) out[(long)clip * out_stride] = l;
     }
 }
 
@@ -297,62 +332,107 @@ __global__ void k_inter_bwd(const float* __restrict__ frame_rec, const float* __
 
 extern "C" {
 #define HM_RED_MAX_BLOCKS 256
-// workspace for the reductions: 512 floats of partials + 1 counter word at float offset 512
-// (the whole buffer must be zero-initialised once; the counter resets itself)
-size_t hm_reduce_workspace_bytes(void) { return (512 + 64) * sizeof(float); }
+// workspace for the reductions: 512 floats of partials + 1 counter word at float offset 512 (HM_RED_WS_FLOATS floats in
+// all; the whole buffer must be zero-initialised once; the counter resets itself).  A *_clips call needs one such slice
+// per clip, back to back.
+size_t hm_reduce_workspace_bytes(void) { return HM_RED_WS_FLOATS * sizeof(float); }
 
 static inline unsigned int* ws_counter(void* ws) { return (unsigned int*)((float*)ws + 512); }
+// N frames in clips of clip_len (0: one clip) -> frames per clip, number of clips
+static inline int clip_frames(int N, int clip_len) { return clip_len ? clip_len : N; }
+static inline int clip_count(int N, int clip_len) { return clip_len ? N / clip_len : 1; }
 
+int hm_v2d_fwd_clips(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size, int N,
+                     int V, float* unit_grad, float* out2, void* workspace, int clip_len, int out_stride,
+                     hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && camintr && ref2d && unit_grad && out2 && workspace && N > 0 && V > 0 && hand_nb > 0);
+    HM_CHECK_ARG(HM_CLIP_LEN_OK(N, clip_len));
+    const int Nc = clip_frames(N, clip_len);
+    const int nblk = min(HM_RED_MAX_BLOCKS, hm_cdiv((long)Nc * V, RED_THREADS));
+    hipLaunchKernelGGL(k_v2d, dim3(nblk, clip_count(N, clip_len)), dim3(RED_THREADS), 0, stream, verts, camintr, hand_nb,
+                       ref2d, image_size, Nc, V, unit_grad, (float*)workspace, ws_counter(workspace), out2, out_stride);
+    return hm_launch_status();
+}
 int hm_v2d_fwd(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size, int N,
                int V, float* unit_grad, float* out2, void* workspace, hipStream_t stream)
 {
-    HM_CHECK_ARG(verts && camintr && ref2d && unit_grad && out2 && workspace && N > 0 && V > 0 && hand_nb > 0);
-    const int nblk = min(HM_RED_MAX_BLOCKS, hm_cdiv((long)N * V, RED_THREADS));
-    hipLaunchKernelGGL(k_v2d, dim3(nblk), dim3(RED_THREADS), 0, stream, verts, camintr, hand_nb, ref2d, image_size, N,
-                       V, unit_grad, (float*)workspace, ws_counter(workspace), out2);
+    return hm_v2d_fwd_clips(verts, camintr, hand_nb, ref2d, image_size, N, V, unit_grad, out2, workspace, 0, 0, stream);
+}
+int hm_smooth_fwd_clips(const float* verts, int N, int V, int hand_nb, float* unit_grad, float* out1, void* workspace,
+                        int clip_len, int out_stride, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && unit_grad && out1 && workspace && N > 0 && V > 0 && hand_nb > 0 && HM_CLIP_LEN_OK(N, clip_len));
+    const int Nc = clip_frames(N, clip_len);
+    const int nblk = min(HM_RED_MAX_BLOCKS, hm_cdiv((long)Nc * V * 3, RED_THREADS * 4));
+    hipLaunchKernelGGL(k_smooth, dim3(nblk, clip_count(N, clip_len)), dim3(RED_THREADS), 0, stream, verts, Nc, V, hand_nb,
+                       unit_grad, (float*)workspace, ws_counter(workspace), out1, out_stride);
     return hm_launch_status();
 }
 int hm_smooth_fwd(const float* verts, int N, int V, int hand_nb, float* unit_grad, float* out1, void* workspace,
                   hipStream_t stream)
 {
-    HM_CHECK_ARG(verts && unit_grad && out1 && workspace && N > 0 && V > 0 && hand_nb > 0);
-    const int nblk = min(HM_RED_MAX_BLOCKS, hm_cdiv((long)N * V * 3, RED_THREADS * 4));
-    hipLaunchKernelGGL(k_smooth, dim3(nblk), dim3(RED_THREADS), 0, stream, verts, N, V, hand_nb, unit_grad,
-                       (float*)workspace, ws_counter(workspace), out1);
+    return hm_smooth_fwd_clips(verts, N, V, hand_nb, unit_grad, out1, workspace, 0, 0, stream);
+}
+// npca: PCA entries of ONE clip; the scales, their means and the scale gradients hold one entry per clip.
+int hm_priors_fwd_clips(const float* pca, long npca, const float* s_obj, const float* m_obj, const float* s_hand,
+                        const float* m_hand, float* g_pca, float* g_sobj, float* g_shand, float* out3, int nclips,
+                        int out_stride, hipStream_t stream)
+{
+    HM_CHECK_ARG(pca && s_obj && m_obj && s_hand && m_hand && g_pca && g_sobj && g_shand && out3 && npca > 0 && nclips > 0);
+    hipLaunchKernelGGL(k_priors, dim3(1, nclips), dim3(RED_THREADS), 0, stream, pca, npca, s_obj, m_obj, s_hand, m_hand,
+                       g_pca, g_sobj, g_shand, out3, out_stride);
     return hm_launch_status();
 }
 int hm_priors_fwd(const float* pca, long npca, const float* s_obj, const float* m_obj, const float* s_hand,
                   const float* m_hand, float* g_pca, float* g_sobj, float* g_shand, float* out3, hipStream_t stream)
 {
-    HM_CHECK_ARG(pca && s_obj && m_obj && s_hand && m_hand && g_pca && g_sobj && g_shand && out3 && npca > 0);
-    hipLaunchKernelGGL(k_priors, dim3(1), dim3(RED_THREADS), 0, stream, pca, npca, s_obj, m_obj, s_hand, m_hand, g_pca,
-                       g_sobj, g_shand, out3);
-    return hm_launch_status();
+    return hm_priors_fwd_clips(pca, npca, s_obj, m_obj, s_hand, m_hand, g_pca, g_sobj, g_shand, out3, 1, 0, stream);
 }
 // v2d + smoothness (+ priors when pca != NULL) of the hand vertices in one launch: same outputs as hm_v2d_fwd,
-// hm_smooth_fwd and hm_priors_fwd called one after the other.
+// hm_smooth_fwd and hm_priors_fwd called one after the other.  (npca: PCA entries of ONE clip.)
+int hm_hand_terms_fwd_clips(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size,
+                            int N, int V, float* unit_v2d, float* out_v2d2, float* unit_smooth, float* out_smooth1,
+                            const float* pca, long npca, const float* s_obj, const float* m_obj, const float* s_hand,
+                            const float* m_hand, float* g_pca, float* g_sobj, float* g_shand, float* out_priors3,
+                            void* workspace, int clip_len, int out_stride, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && camintr && ref2d && unit_v2d && out_v2d2 && unit_smooth && out_smooth1 && workspace);
+    HM_CHECK_ARG(N > 0 && V > 0 && hand_nb > 0 && HM_CLIP_LEN_OK(N, clip_len));
+    HM_CHECK_ARG(!pca || (npca > 0 && s_obj && m_obj && s_hand && m_hand && g_pca && g_sobj && g_shand && out_priors3));
+    const int Nc = clip_frames(N, clip_len);
+    const int nblk = min(170, hm_cdiv((long)Nc * V * 3, RED_THREADS * 2));     // 3 partial floats per block, 512 in all
+    hipLaunchKernelGGL(k_hand_terms, dim3(nblk, clip_count(N, clip_len)), dim3(RED_THREADS), 0, stream, verts, camintr,
+                       hand_nb, ref2d, image_size, Nc, V, unit_v2d, out_v2d2, unit_smooth, out_smooth1, pca, npca, s_obj,
+                       m_obj, s_hand, m_hand, g_pca, g_sobj, g_shand, out_priors3, (float*)workspace,
+                       ws_counter(workspace), out_stride);
+    return hm_launch_status();
+}
 int hm_hand_terms_fwd(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size, int N,
                       int V, float* unit_v2d, float* out_v2d2, float* unit_smooth, float* out_smooth1, const float* pca,
                       long npca, const float* s_obj, const float* m_obj, const float* s_hand, const float* m_hand,
                       float* g_pca, float* g_sobj, float* g_shand, float* out_priors3, void* workspace, hipStream_t stream)
 {
-    HM_CHECK_ARG(verts && camintr && ref2d && unit_v2d && out_v2d2 && unit_smooth && out_smooth1 && workspace);
-    HM_CHECK_ARG(N > 0 && V > 0 && hand_nb > 0);
-    HM_CHECK_ARG(!pca || (npca > 0 && s_obj && m_obj && s_hand && m_hand && g_pca && g_sobj && g_shand && out_priors3));
-    const int nblk = min(170, hm_cdiv((long)N * V * 3, RED_THREADS * 2));     // 3 partial floats per block, 512 in all
-    hipLaunchKernelGGL(k_hand_terms, dim3(nblk), dim3(RED_THREADS), 0, stream, verts, camintr, hand_nb, ref2d, image_size,
-                       N, V, unit_v2d, out_v2d2, unit_smooth, out_smooth1, pca, npca, s_obj, m_obj, s_hand, m_hand, g_pca,
-                       g_sobj, g_shand, out_priors3, (float*)workspace, ws_counter(workspace));
-    return hm_launch_status();
+    return hm_hand_terms_fwd_clips(verts, camintr, hand_nb, ref2d, image_size, N, V, unit_v2d, out_v2d2, unit_smooth,
+                                   out_smooth1, pca, npca, s_obj, m_obj, s_hand, m_hand, g_pca, g_sobj, g_shand,
+                                   out_priors3, workspace, 0, 0, stream);
 }
 // frame_rec: (B,8) floats kept for the backward.
+int hm_inter_fwd_clips(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
+                       float expansion, float zthresh, float* frame_rec, float* out1, void* workspace, int clip_len,
+                       int out_stride, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts_hand && verts_obj && camintr && frame_rec && out1 && workspace && B > 0 && Vh > 0 && Vo > 0);
+    HM_CHECK_ARG(HM_CLIP_LEN_OK(B, clip_len));
+    hipLaunchKernelGGL(k_inter, dim3(B), dim3(RED_THREADS), 0, stream, verts_hand, verts_obj, camintr, B, Vh, Vo,
+                       expansion, zthresh, frame_rec, ws_counter(workspace), out1, clip_frames(B, clip_len), out_stride);
+    return hm_launch_status();
+}
 int hm_inter_fwd(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
                  float expansion, float zthresh, float* frame_rec, float* out1, void* workspace, hipStream_t stream)
 {
-    HM_CHECK_ARG(verts_hand && verts_obj && camintr && frame_rec && out1 && workspace && B > 0 && Vh > 0 && Vo > 0);
-    hipLaunchKernelGGL(k_inter, dim3(B), dim3(RED_THREADS), 0, stream, verts_hand, verts_obj, camintr, B, Vh, Vo,
-                       expansion, zthresh, frame_rec, ws_counter(workspace), out1);
-    return hm_launch_status();
+    return hm_inter_fwd_clips(verts_hand, verts_obj, camintr, B, Vh, Vo, expansion, zthresh, frame_rec, out1, workspace,
+                              0, 0, stream);
 }
 int hm_inter_bwd(const float* frame_rec, const float* upstream, int B, int Vh, int Vo, float* g_hand, float* g_obj,
                  hipStream_t stream)

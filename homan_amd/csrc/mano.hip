@@ -234,7 +234,7 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
                                                    float* __restrict__ joints, const float* __restrict__ rigid_rot6d,
                                                    const float* __restrict__ rigid_trans,
                                                    const float* __restrict__ rigid_scale, float* __restrict__ verts_world,
-                                                   float* __restrict__ state)
+                                                   float* __restrict__ state, int clip_len)
 {
     __shared__ ManoShared sh;
     __shared__ float s_part[4][MANO_VCH][3];
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
 #pragma unroll
     for (int i = 0; i < 3; ++i) { p[i] = T[4 * i] * vp[0] + T[4 * i + 1] * vp[1] + T[4 * i + 2] * vp[2] + T[4 * i + 3] + tr[i]; o[i] = p[i]; }
     if (verts_world) {       // the rigid hand transform of homan.py:341-382, same arithmetic as k_rigid_fwd (no abs on the scale)
-        const float s = rigid_scale[0];
+        const float s = rigid_scale[b / clip_len];      // one hand scale per clip
         const float x = s * p[0], y = s * p[1], z = s * p[2];
         const float* t = rigid_trans + b * 3;
         float* ow = verts_world + ((long)b * MANO_V + v) * 3;
@@ -505,17 +505,25 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
 
 extern "C" {
 // model: 8 device pointers in the order of ManoModelDev.
-int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
-                const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d, const float* rigid_trans,
-                const float* rigid_scale, float* verts_world, float* state, hipStream_t stream)
+int hm_mano_fwd_clips(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
+                      const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d,
+                      const float* rigid_trans, const float* rigid_scale, float* verts_world, float* state, int clip_len,
+                      hipStream_t stream)
 {
-    HM_CHECK_ARG(model && pca && rot && betas && verts && B > 0 && pca_dim >= 16);
+    HM_CHECK_ARG(model && pca && rot && betas && verts && B > 0 && pca_dim >= 16 && HM_CLIP_LEN_OK(B, clip_len));
     HM_CHECK_ARG(!verts_world || (rigid_rot6d && rigid_trans && rigid_scale));
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
     hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, trans, B, verts,
-                       joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world, state);
+                       joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world, state, clip_len ? clip_len : B);
     return hm_launch_status();
+}
+int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
+                const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d, const float* rigid_trans,
+                const float* rigid_scale, float* verts_world, float* state, hipStream_t stream)
+{
+    return hm_mano_fwd_clips(model, pca, pca_dim, rot, betas, trans, B, verts, joints, rigid_rot6d, rigid_trans,
+                             rigid_scale, verts_world, state, 0, stream);
 }
 size_t hm_mano_workspace_bytes(int B) { return 512 + (size_t)B * 4 + (size_t)B * MANO_NCH64 * MANO_PART * sizeof(float); }
 size_t hm_mano_state_bytes(int B) { return (size_t)B * MANO_STATE_DW * sizeof(float); }

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
                                                      int* __restrict__ bin_cnt, int* __restrict__ bin_list,
                                                      const float* __restrict__ rigid_rot6d,
                                                      const float* __restrict__ rigid_trans,
-                                                     const float* __restrict__ rigid_scale, int rigid_abs)
+                                                     const float* __restrict__ rigid_scale, int rigid_abs, int clip_len)
 {
     __shared__ int s_cnt[SR_MAX], s_base[SR_MAX];
     __shared__ float s_R[9];
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
             const float* mv = verts + ((long)b * V + fc[k]) * 3;
             float cam[3] = {mv[0], mv[1], mv[2]};
             if (rigid_rot6d) {
-                float sc = rigid_scale[0];
+                float sc = rigid_scale[b / clip_len];      // one object scale per clip
                 if (rigid_abs) sc = fabsf(sc);
                 const float x = sc * mv[0], y = sc * mv[1], z = sc * mv[2];
                 const float* t = rigid_trans + b * 3;
@@ -640,12 +640,13 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     }
 }
 
-// grid (B): per-frame sums of the tile partials, then the last block finishes:
-// loss = (sum_sq / keep_sum) / B ; iou = mean_b inter_b / (union_b + eps).   out[0]=loss, out[1]=iou
+// grid (B): per-frame sums of the tile partials, then the last block of every clip (clip_len consecutive frames) finishes:
+// loss = (sum_sq / keep_sum[clip]) / clip_len ; iou = mean_b inter_b / (union_b + eps) over the clip's frames.
+// out[clip*out_stride + 0]=loss, [+1]=iou.  The clip's ticket word is slot 3 of the frame record of its first frame.
 __global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ partials, int B, int ntiles,
                                                      const float* __restrict__ keep_sum, float* __restrict__ frame_rec,
-                                                     unsigned int* counter, float* __restrict__ out,
-                                                     float* __restrict__ frame_out)
+                                                     float* __restrict__ out, float* __restrict__ frame_out, int clip_len,
+                                                     int out_stride)
 {
     HM_LATENCY_KERNEL();
     __shared__ float red[16];
@@ -663,12 +664,14 @@ __global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ pa
     // per-frame values (un-normalised sum of squares, IoU): what a loss that keeps the frames apart needs
     if (frame_out && threadIdx.x == 0) { frame_out[2 * b] = sq; frame_out[2 * b + 1] = in / (un + 1e-6f); }
     if (!out) return;
-    if (hm_last_block(counter, gridDim.x, &s_flag)) {
-        const float total_sq = hm_last_block_sum(frame_rec, B, 4, red);
-        const float iou_sum = hm_last_block_sum(frame_rec + 1, B, 4, red);
+    const int clip = b / clip_len;
+    float* crec = frame_rec + 4L * clip * clip_len;
+    if (hm_last_block(reinterpret_cast<unsigned int*>(crec + 3), clip_len, &s_flag)) {
+        const float total_sq = hm_last_block_sum(crec, clip_len, 4, red);
+        const float iou_sum = hm_last_block_sum(crec + 1, clip_len, 4, red);
         if (threadIdx.x == 0) {
-            out[0] = (total_sq / keep_sum[0]) / (float)B;
-            out[1] = iou_sum / (float)B;
+            out[(long)clip * out_stride] = (total_sq / keep_sum[clip]) / (float)clip_len;
+            out[(long)clip * out_stride + 1] = iou_sum / (float)clip_len;
         }
     }
 }
@@ -683,7 +686,8 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
                                                    const float* __restrict__ upstream,
                                                    const float* __restrict__ keep_sum, int B, int S,
                                                    const unsigned short* __restrict__ alpha16,
-                                                   float* __restrict__ gimg, unsigned short* __restrict__ planes)
+                                                   float* __restrict__ gimg, unsigned short* __restrict__ planes,
+                                                   int clip_len)
 {
     // fused loss with a positive upstream gradient: the forward raster already emitted these planes (sign(g) = sign(dimg))
     // and k_bwd_lines derives g from dimg itself
@@ -719,7 +723,7 @@ __global__ __launch_bounds__(256) void k_bwd_masks(const float* __restrict__ gin
         float g = gin[po];
         if (mode == 1) {
             float s = upstream[0] * 2.0f;
-            g = s * g / keep_sum[0] / (float)B;
+            g = s * g / keep_sum[b / clip_len] / (float)clip_len;
         }
         gimg[po] = g;
         const unsigned long long nb1 = __ballot(g < 0.0f), pb1 = __ballot(g > 0.0f);
@@ -840,14 +844,20 @@ __device__ __forceinline__ int sweep_face_record(long bf, const float* __restric
 // there are thousands of blocks (500 candidate poses).  `nblk` = number of compaction blocks of the launch.  Two passes
 // over the block's faces: item counts -> block scan -> one atomic for the block's base -> records (rebuilt rather than
 // kept: the line expansion shares this kernel and its register budget).
+// A launch over several clips (clip_len frames each) gives every clip its own run of `nblk / clips` compaction blocks over
+// its own face slots: a block never straddles two clips, so the unit composition of a clip - and with it every summation
+// order of its gradients - is the one of a single-clip launch.
 __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const float* __restrict__ faces9,
                                               const FaceBox* __restrict__ boxes, const unsigned char* __restrict__ owned,
-                                              int B, int F, int is, float* __restrict__ parts, const SweepList& sl)
+                                              int B, int F, int is, float* __restrict__ parts, const SweepList& sl,
+                                              int clip_len)
 {
     __shared__ int s_wsum[4][2];
     __shared__ unsigned long long s_base;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const long bf0 = ((long)blk * 256 + tid) * fpt, nbf = (long)B * F;
+    const int per_clip = nblk / (B / clip_len), clip = blk / per_clip;
+    const long cbase = (long)clip * clip_len * F;
+    const long bf0 = cbase + ((long)(blk - clip * per_clip) * 256 + tid) * fpt, nbf = cbase + (long)clip_len * F;
     int nk[4], n = 0, hasf = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -938,13 +948,13 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    int ncomp, int fpt, const float* __restrict__ faces9,
                                                    const FaceBox* __restrict__ boxes,
                                                    const unsigned char* __restrict__ owned, int F,
-                                                   float* __restrict__ parts, SweepList sl)
+                                                   float* __restrict__ parts, SweepList sl, int clip_len)
 {
     __shared__ unsigned long long s_w[16][SWEEP_CUMW];
     __shared__ int s_ex[16][SWEEP_CUMW];
     // the first `ncomp` workgroups build the work list of the edge sweeps (independent of the lines: one launch for both)
     if ((int)blockIdx.x < ncomp) {
-        sweep_compact(blockIdx.x, ncomp, fpt, faces9, boxes, owned, B, F, 2 * S, parts, sl);
+        sweep_compact(blockIdx.x, ncomp, fpt, faces9, boxes, owned, B, F, 2 * S, parts, sl, clip_len);
         return;
     }
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -974,7 +984,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     // fused loss, positive upstream: g = upstream * 2 * dimg / keep_sum / B (the arithmetic of k_bwd_masks), no gimg pass
     const bool from_dimg = mode == 2 || (mode == 1 && upstream[0] > 0.0f);     // (modes 3 / 4 read gimg per sample below)
     const float* gi = (from_dimg ? dimg : gimg) + (long)b * S * S;
-    const float gs = from_dimg ? upstream[0] * 2.0f : 0.f, ks = from_dimg ? keep_sum[0] : 1.f;
+    const float gs = from_dimg ? upstream[0] * 2.0f : 0.f, ks = from_dimg ? keep_sum[b / clip_len] : 1.f;
     const int* idx = idx_map + (long)b * is * is;
     SweepSrc* out = srcs + L * is;
     for (int k = 0; k < wpl; ++k) {
@@ -994,7 +1004,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
             else if (mode == 4) g = upstream[b] * 2.0f * gimg[((long)b * is + (is - 1 - yi)) * is + xi];   // fused per-sample L2
             else {
                 g = gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
-                if (from_dimg) g = gs * g / ks / (float)B;
+                if (from_dimg) g = gs * g / ks / (float)clip_len;
                 g = 0.25f * g;
             }
             r.g = g;
@@ -1676,13 +1686,15 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 
 // pass 2a (+ the work list of pass 2b in its first workgroups) and pass 2b
 static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const float* upstream, const float* keep_sum,
-                         hipStream_t stream)
+                         int clip_len, hipStream_t stream)
 {
-    const int fpt = (long)B * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks (see sweep_compact)
-    const int ncomp = hm_cdiv((long)B * F, 256 * fpt);
+    // work-list blocks: per clip (see sweep_compact), sized by the clip, so that a clip is cut into the same blocks
+    // whether it is launched alone or in a batch
+    const int fpt = (long)clip_len * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks
+    const int ncomp = (B / clip_len) * hm_cdiv((long)clip_len * F, 256 * fpt);
     hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
-                       w.owned, F, w.parts, w.sweep);
+                       w.owned, F, w.parts, w.sweep, clip_len);
 }
 static int g_sweep_blocks = SWEEP_BLOCKS;
 static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
@@ -1705,13 +1717,17 @@ int hm_tune_sweep_blocks(int blocks)
 
 // Forward: silhouettes (B,S,S) of `verts` under per-frame intrinsics K, optional fused masked-MSE/IoU.
 //   keep/ref/keep_sum/loss_out may be NULL (render only).  loss_out[0]=loss_sil, loss_out[1]=mean IoU.
-int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
-               float orig_size, float znear, float zfar, const float* keep, const float* ref,
-               const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
-               float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
-               const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, hipStream_t stream)
+//   *_clips: the B frames are B / clip_len clips of clip_len frames (0: one clip); keep_sum and rigid_scale hold one
+//   entry per clip, the loss / IoU of clip c go to loss_out[c * out_stride + 0 / 1].
+int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
+                     float orig_size, float znear, float zfar, const float* keep, const float* ref,
+                     const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+                     float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
+                     const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, int clip_len,
+                     int out_stride, hipStream_t stream)
 {
-    HM_CHECK_ARG(verts && faces && K && pooled && workspace);
+    HM_CHECK_ARG(verts && faces && K && pooled && workspace && HM_CLIP_LEN_OK(B, clip_len));
+    if (clip_len == 0) clip_len = B;
     HM_CHECK_ARG(!rigid_rot6d || (rigid_trans && rigid_scale));
     HM_CHECK_ARG(B > 0 && V > 0 && F > 0 && S > 0);
     if (S % 16 != 0 || 2 * S > 8192 || 2L * F >= (1L << 30) || B >= 32768) return HM_ERR_UNSUPPORTED;
@@ -1721,7 +1737,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     int* bins = is <= (SR_MAX == 64 ? 1024 : 0) ? w.bin_cnt : nullptr;      // <= SR_MAX super-regions per frame
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, orig_size, faces,
                        faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list, rigid_rot6d, rigid_trans,
-                       rigid_scale, rigid_abs);
+                       rigid_scale, rigid_abs, clip_len);
     const bool fused = keep && ref;
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
@@ -1730,21 +1746,37 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
                        (fused && alpha_full) ? w.gimg : (float*)nullptr);
     if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
-                           w.counter, loss_out, (float*)nullptr);
+                           loss_out, (float*)nullptr, clip_len, out_stride);
     return hm_launch_status();
+}
+int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
+               float orig_size, float znear, float zfar, const float* keep, const float* ref,
+               const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+               float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
+               const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, hipStream_t stream)
+{
+    return hm_sil_fwd_clips(verts, faces, faces_bstride, K, B, V, F, S, orig_size, znear, zfar, keep, ref, keep_sum, pooled,
+                            loss_out, work_order, pooled_depth, alpha_full, mask_shared, rigid_rot6d, rigid_trans,
+                            rigid_scale, rigid_abs, persistent_outputs, workspace, 0, 0, stream);
 }
 
 // The loss / IoU reduction of a forward that was called with keep/ref but loss_out == NULL: the backward does not
 // depend on it, so a caller with a second stream takes it off the critical path.
 // frame_out (B,2) optional: per-frame {sum of squares (un-normalised), IoU}; loss_out may then be NULL.
+int hm_sil_reduce_clips(int B, int V, int F, int S, const float* keep_sum, float* loss_out, float* frame_out,
+                        void* workspace, int clip_len, int out_stride, hipStream_t stream)
+{
+    HM_CHECK_ARG(workspace && B > 0 && S > 0 && (frame_out || loss_out) && (!loss_out || keep_sum));
+    HM_CHECK_ARG(HM_CLIP_LEN_OK(B, clip_len));
+    SilWs w = carve(workspace, B, V, F, S);
+    hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, (S / 8) * (S / 8), keep_sum,
+                       w.frame_rec, loss_out, frame_out, clip_len ? clip_len : B, out_stride);
+    return hm_launch_status();
+}
 int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, float* frame_out, void* workspace,
                   hipStream_t stream)
 {
-    HM_CHECK_ARG(workspace && B > 0 && S > 0 && (frame_out || loss_out) && (!loss_out || keep_sum));
-    SilWs w = carve(workspace, B, V, F, S);
-    hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, (S / 8) * (S / 8), keep_sum,
-                       w.frame_rec, w.counter, loss_out, frame_out);
-    return hm_launch_status();
+    return hm_sil_reduce_clips(B, V, F, S, keep_sum, loss_out, frame_out, workspace, 0, 0, stream);
 }
 
 // Backward.  mode 1 (fused loss): upstream = d/d loss_sil (device scalar), uses dimg from the forward.
@@ -1753,12 +1785,16 @@ int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss
 //            mode 3 (render without anti-aliasing): grad_pooled is (B,2S,2S) = dL/d alpha_full.
 //            mode 4 (fused per-sample L2 of a forward called with alpha_full + keep/ref): upstream (B) = dL/d frame sums, all > 0.
 // adjacency (CSR over V) describes the shared face topology.  grad_verts (B,V,3) is overwritten.
-int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
-               const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
-               const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-               hipStream_t stream)
+//   *_clips (modes 1 / 2): keep_sum holds one entry per clip of clip_len frames and the 1/B of the loss is 1/clip_len;
+//   `upstream` stays one scalar shared by the clips.
+int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
+                     const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
+                     const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
+                     int clip_len, hipStream_t stream)
 {
     HM_CHECK_ARG(verts && K && adj_off && adj_items && workspace);        // grad_verts == NULL: no vertex gather (see hm_sil_parts)
+    HM_CHECK_ARG(HM_CLIP_LEN_OK(B, clip_len));
+    if (clip_len == 0) clip_len = B;
     HM_CHECK_ARG((mode == 0 || mode == 3) ? grad_pooled != nullptr : (mode == 4 ? upstream != nullptr : (upstream && keep_sum)));
     HM_CHECK_ARG(mode >= 0 && mode <= 4);
     if (S % 32 != 0 || S > 32 * SWEEP_CUMW) return HM_ERR_UNSUPPORTED;     // 64-sample mask words, <= SWEEP_CUMW per line
@@ -1767,13 +1803,21 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
     if (mode != 2 && mode != 4)      // modes 2 / 4: the caller guarantees upstream > 0, the forward's planes are the backward's
         hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                            mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
-                           w.planes);
-    launch_lines(w, B, F, S, mode, upstream, keep_sum, stream);
+                           w.planes, clip_len);
+    launch_lines(w, B, F, S, mode, upstream, keep_sum, clip_len, stream);
     launch_sweep(w, B, F, S, eps, stream);
     if (grad_verts)
         hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                            adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
     return hm_launch_status();
+}
+int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
+               const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
+               const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
+               hipStream_t stream)
+{
+    return hm_sil_bwd_clips(verts, K, B, V, F, S, orig_size, eps, mode, upstream, grad_pooled, keep_sum, adj_off, adj_items,
+                            face_order, grad_verts, grad_ndc, workspace, 0, stream);
 }
 
 // (B,F,3,2) d loss / d NDC (x, y) per face corner, as left by the last hm_sil_bwd: input of hm_rigid_bwd_sil.
@@ -1863,7 +1907,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     int* bins = 2 * S <= 1024 ? w.bin_cnt : nullptr;
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, 1.0f, faces, 0, B, V, F,
                        2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, 0);
+                       (const float*)nullptr, 0, B);
     const bool cold = false;   // true: re-bin before every launch (times setup + raster with the reset tickets)
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i) {
@@ -1871,7 +1915,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
             (void)hipMemsetAsync(w.bin_cnt, 0, (size_t)B * SR_MAX * 4, stream);
             hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, 1.0f, faces, 0, B, V, F,
                                2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list, (const float*)nullptr,
-                               (const float*)nullptr, (const float*)nullptr, 0);
+                               (const float*)nullptr, (const float*)nullptr, 0, B);
         }
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
@@ -1890,7 +1934,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     (void)hipEventElapsedTime(&ms, e0, e1);
     avg_ms[1] = ms / (float)reps;
     (void)hipEventRecord(e0, stream);
-    for (int i = 0; i < reps; ++i) launch_lines(w, B, F, S, 1, upstream, keep_sum, stream);
+    for (int i = 0; i < reps; ++i) launch_lines(w, B, F, S, 1, upstream, keep_sum, B, stream);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);

@@ -302,7 +302,8 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(const float* __restr
                                                              const unsigned int* __restrict__ masks,
                                                              const float* __restrict__ phig, float* __restrict__ g0,
                                                              float* __restrict__ g1, float* __restrict__ partials,
-                                                             unsigned int* counter, float* __restrict__ out)
+                                                             unsigned int* counter, float* __restrict__ out, int clip_len,
+                                                             int out_stride)
 {
     HM_LATENCY_KERNEL();
     __shared__ float red[16];
@@ -340,12 +341,17 @@ __global__ __launch_bounds__(SDF_THREADS) void k_sdf_sample(const float* __restr
         gl[0] = gx * s; gl[1] = gy * s; gl[2] = gz * s;
     }
     val = hm_block_sum(val, red);
-    const unsigned bid = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    const unsigned nblk = gridDim.x * gridDim.y * gridDim.z;
+    // per clip (clip_len consecutive frames): the clip's block records sit together, in the order (pair, frame, chunk)
+    // of a single-clip launch, behind its own ticket
+    const int clip = b / clip_len, bl = b - clip * clip_len;
+    const unsigned nblk = gridDim.x * clip_len * gridDim.z;
+    const unsigned bid = (blockIdx.z * clip_len + bl) * gridDim.x + blockIdx.x;
+    partials += (long)clip * nblk;
+    counter += clip;
     if (threadIdx.x == 0) hm_partial_store(partials + bid, val);
     if (hm_last_block(counter, nblk, &s_flag)) {
         const float t = hm_last_block_sum(partials, (int)nblk, 1, red);
-        if (threadIdx.x == 0) out[0] = t;
+        if (threadIdx.x == 0) out[(long)clip * out_stride] = t;
     }
 }
 
@@ -414,7 +420,7 @@ static size_t coll_layout(void* ws, int B, int V0, int V1, int F0, int F1, CollW
     char* p = (char*)ws;
     const size_t grid = (size_t)SDF_N * SDF_N * SDF_N, rows = (size_t)SDF_N * SDF_N;
     CollWs t;
-    t.counter = (unsigned int*)p; p += 256;                                         // zero-initialised by the caller once
+    t.counter = (unsigned int*)p; p += al256s((size_t)B * 4 + 256);                 // one ticket per clip; zero-initialised by the caller once
     t.boxes = (float*)p; p += al256s((size_t)2 * B * 4 * 4);
     t.vn0 = (float*)p; p += al256s((size_t)B * V0 * 3 * 4);
     t.vn1 = (float*)p; p += al256s((size_t)B * V1 * 3 * 4);
@@ -436,12 +442,12 @@ size_t hm_collision_workspace_bytes(int B, int V0, int V1, int F0, int F1)
 
 // Scene of two meshes: 0 = hand (closed faces), 1 = object.  out1[0] = sum of all SDF samples (both ordered pairs);
 // g0 / g1 = d out / d verts0 / d verts1 (unit gradients, (B,V,3)).
-int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, const float* verts1, const int* faces1,
-                     int V1, int F1, int B, float scale_factor, float* g0, float* g1, float* out1, void* workspace,
-                     hipStream_t stream)
+int hm_collision_fwd_clips(const float* verts0, const int* faces0, int V0, int F0, const float* verts1, const int* faces1,
+                           int V1, int F1, int B, float scale_factor, float* g0, float* g1, float* out1, void* workspace,
+                           int clip_len, int out_stride, hipStream_t stream)
 {
     HM_CHECK_ARG(verts0 && faces0 && verts1 && faces1 && g0 && g1 && out1 && workspace);
-    HM_CHECK_ARG(B > 0 && V0 > 0 && V1 > 0 && F0 > 0 && F1 > 0);
+    HM_CHECK_ARG(B > 0 && V0 > 0 && V1 > 0 && F0 > 0 && F1 > 0 && HM_CLIP_LEN_OK(B, clip_len));
     CollWs w;
     coll_layout(workspace, B, V0, V1, F0, F1, &w);
     hipLaunchKernelGGL(k_sdf_boxes, dim3(B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, scale_factor,
@@ -454,8 +460,15 @@ int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, con
     hipLaunchKernelGGL(k_sdf_dist, dim3(SDF_DIST_WGS, B, 2), dim3(SDF_THREADS), 0, stream, w.vn0, V0, F0, w.vn1, V1, F1, B,
                        w.tris0, w.tris1, w.need_cnt, w.need_list, w.phi);
     hipLaunchKernelGGL(k_sdf_sample, dim3(chunks, B, 2), dim3(SDF_THREADS), 0, stream, verts0, V0, verts1, V1, B, w.boxes,
-                       w.masks, w.phi, g0, g1, w.partials, w.counter, out1);
+                       w.masks, w.phi, g0, g1, w.partials, w.counter, out1, clip_len ? clip_len : B, out_stride);
     return hm_launch_status();
+}
+int hm_collision_fwd(const float* verts0, const int* faces0, int V0, int F0, const float* verts1, const int* faces1,
+                     int V1, int F1, int B, float scale_factor, float* g0, float* g1, float* out1, void* workspace,
+                     hipStream_t stream)
+{
+    return hm_collision_fwd_clips(verts0, faces0, V0, F0, verts1, faces1, V1, F1, B, scale_factor, g0, g1, out1, workspace,
+                                  0, 0, stream);
 }
 
 // Penetration depths per vertex (reference homan/interactions/scenesdf.py:141-146 dist_values; consumed by

@@ -2,68 +2,103 @@
 
 The path shards by CLIP: clips share nothing -- separate HOMan instance, optimiser and targets -- and the
 frames of one clip are coupled by the smoothness loss and the per-clip normalisers, so a clip is never split.
-  * BASELINE cfg4: no data-path collective at all (`shard_clips` + one optimiser per shard).
-  * BASELINE cfg5: ONE shared object-scale scalar across all clips (an extension; the reference's scale is per clip,
-    homan/homan.py:121-130): every step each rank all-reduces (sum) the 4-byte gradient of that scalar, then applies
-    the identical Adam update, so the replicas of the scalar stay bit-identical.  The message is latency-bound
-    (4 bytes); link bandwidth and ring-vs-tree are irrelevant.
-The helpers below are device-agnostic (the CPU/gloo tests drive them with world_size 2).
+  * BASELINE cfg4: no data-path collective at all: `shard_clips` gives every rank a contiguous block of clips, which it
+    optimises as ONE clip batch (`optimize_clip_shard`: one launch per kernel over all its clips, one Adam state per clip).
+  * BASELINE cfg5: ONE object-scale scalar tied across all clips (an extension; the reference's scale is per clip,
+    homan/homan.py:121-130).  The tied loss is the sum of the clips' losses (each with its own scale prior), so the
+    scalar's gradient is the sum of the clips' gradients: every step each rank sums its local clips and all-reduces
+    (sum) that ONE fp32, then every replica takes the identical Adam step and the replicas stay bit-identical.  The
+    message is latency-bound (4 bytes); link bandwidth and ring-vs-tree are irrelevant.
+    Product path: `FusedStepper(models, ..., shared_scale=True)` (all-reduce on the compute stream between the two
+    captured halves of the iteration, no host synchronisation).  `optimize_clips_shared_scale` below is the same
+    semantics as a plain autograd loop, device-agnostic (the CPU/gloo tests drive it with world_size 2 and 3).
 """
 import torch
 import torch.distributed as dist
 
 
 def shard_clips(num_clips, rank, world_size):
-    """Contiguous block of clip indices owned by `rank` (64 clips / 8 GPUs -> 8 each, BASELINE cfg4/5)."""
-    per = (num_clips + world_size - 1) // world_size
-    lo = min(rank * per, num_clips)
-    return list(range(lo, min(lo + per, num_clips)))
+    """Contiguous, balanced block of clip indices owned by `rank`: the first `num_clips % world_size` ranks take one
+    clip more (64 clips / 8 GPUs -> 8 each, BASELINE cfg4/5; 9 clips / 8 ranks -> 2,1,1,...)."""
+    base, extra = divmod(num_clips, world_size)
+    lo = rank * base + min(rank, extra)
+    return list(range(lo, lo + base + (1 if rank < extra else 0)))
+
+
+def _active(group=None):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
 def sync_shared_scalar_grad(grad, group=None):
     """Sum the gradient of a shared scalar over all ranks, in place (one all-reduce of 1 fp32 per step)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _active(group):
         dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
     return grad
 
 
-def broadcast_shared_scalar(param, src=0, group=None):
-    """Make every rank start from rank `src`'s value of the shared scalar."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(param.data, src=src, group=group)
-    return param
+def broadcast_shared_scalar(value, src=0, group=None):
+    """Make every rank start from rank `src`'s value of the shared scalar (`value`: tensor, updated in place)."""
+    if _active(group):
+        dist.broadcast(value, src=src, group=group)
+    return value
 
 
 def max_over_ranks(seconds, device=None, group=None):
     """Timing convention of bench.py: the job takes as long as its slowest rank."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _active(group):
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
 
-def optimize_clips_shared_scale(models, optimizers, loss_weights, num_iterations, scale_name="int_scales_object",
-                                group=None):
-    """Step-2 style loop over this rank's clips with ONE object scale shared by every clip of every rank.
+def optimize_clip_shard(models, loss_weights, num_iterations, lr=1e-2, shared_scale=False, group=None):
+    """This rank's clips (HOMan models of identical shapes) as ONE clip batch on its GPU: every kernel launched once per
+    iteration over all the clips (homan_amd.clipbatch), replayed from a hipGraph.  -> list of loss_evolution dicts, one
+    per clip; the models hold their optimised parameters.  cfg4: shared_scale=False, no collective.  cfg5:
+    shared_scale=True (models built with optimize_object_scale=True)."""
+    from .jointopt import FusedStepper
+    if not models:          # a rank without clips still takes part in the collectives of the others
+        if shared_scale and _active(group):
+            z = torch.zeros(1, device="cuda")
+            broadcast_shared_scalar(z, 0, group)
+            for _ in range(num_iterations):
+                sync_shared_scalar_grad(z.zero_(), group)
+        return []
+    stepper = FusedStepper(list(models), loss_weights, lr, num_iterations, shared_scale=shared_scale, group=group)
+    stepper.run(num_iterations)
+    evo = stepper.loss_evolution(num_iterations)
+    return evo if isinstance(evo, list) else [evo]
 
-    models / optimizers: this rank's per-clip models (built with optimize_object_scale=True) and their Adam
-    optimisers (each owning its model's copy of the scalar).  Per step: forward/backward of every local clip, local
-    sum of d loss / d scale, one all-reduce, the summed gradient is written to every local copy, optimisers step.
-    All copies see the same gradient sequence from the same start value, hence stay identical."""
-    for m in models:
-        broadcast_shared_scalar(getattr(m, scale_name), 0, group)
+
+def optimize_clips_shared_scale(models, optimizers, loss_weights, num_iterations, scale_name="int_scales_object",
+                                group=None, device=None):
+    """Tied-scale loop over this rank's clips as plain autograd (any model with the HOMan surface, CPU or GPU).
+
+    models / optimizers: this rank's per-clip models (built with optimize_object_scale=True) and their Adam optimisers
+    (each owning its model's replica of the scalar); either list may be empty on a rank that owns no clip.  Per step:
+    forward/backward of every local clip, local sum of d loss / d scale (zero on an empty rank), ONE all-reduce, the
+    summed gradient is written to every local replica, optimisers step.  All replicas see the same gradient sequence
+    from the same start value, hence stay identical.  Every rank issues exactly one broadcast and `num_iterations`
+    all-reduces whatever its number of clips."""
+    if device is None:
+        device = getattr(models[0], scale_name).device if models else ("cuda" if dist.is_initialized() and
+                                                                       dist.get_backend(group) == "nccl" else "cpu")
+    start = getattr(models[0], scale_name).detach().clone() if models else torch.zeros(1, device=device)
+    broadcast_shared_scalar(start, 0, group)
+    with torch.no_grad():
+        for m in models:
+            getattr(m, scale_name).copy_(start)
     history = []
     for _ in range(num_iterations):
-        local = None
+        local = torch.zeros(1, device=device)
         totals = []
         for model, opt in zip(models, optimizers):
             opt.zero_grad()
             loss_dict, _ = model(loss_weights=loss_weights)
             total = sum(loss_dict[k] * loss_weights[k.replace("loss", "lw")] for k in loss_dict)
             total.sum().backward()
-            g = getattr(model, scale_name).grad
-            local = g.detach().clone() if local is None else local + g.detach()
+            local = local + getattr(model, scale_name).grad.detach().reshape(1)
             totals.append(float(total.detach().sum()))
         sync_shared_scalar_grad(local, group)
         for model, opt in zip(models, optimizers):

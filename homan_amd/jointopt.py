@@ -92,7 +92,7 @@ class HmAdam:
             slot[i] = (p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, 0)
         self.slots = torch.from_numpy(slot.view(np.uint8).copy()).to(dev)
         self.grads = [p.grad for p, _ in self.items]       # keep the static buffers alive
-        self.blocks = max(1, min(8, (max(p.numel() for p, _ in self.items) + 255) // 256))
+        self.blocks = max(1, min(64, (max(p.numel() for p, _ in self.items) + 255) // 256))
 
     def step(self, zero_grad=True):
         for (p, _), g in zip(self.items, self.grads):
@@ -187,6 +187,29 @@ class GraphStepper:
         return {k: host[:, i].astype(np.float64).tolist() for i, k in enumerate(self.log.keys)}
 
 
+_LOOP_STREAMS = {}
+
+
+def _loop_streams(device):
+    """(capture, side, aux, warm-up) HIP streams of the fused loop, one set per device, pairwise distinct.
+    torch hands streams out of a pool of 32 per device, round-robin: a process that builds many steppers eventually draws
+    a side stream that IS the capture stream, and a capture in which two 'streams' wait on each other both ways crashes
+    the HIP graph runtime at replay.  Steppers replay in stream order anyway, so they share one verified set."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _LOOP_STREAMS:
+        got, seen = [], {torch.cuda.current_stream(key).cuda_stream, torch.cuda.default_stream(key).cuda_stream}
+        for _ in range(256):
+            st = torch.cuda.Stream(device=key)
+            if st.cuda_stream not in seen:
+                seen.add(st.cuda_stream)
+                got.append(st)
+            if len(got) == 4:
+                break
+        assert len(got) == 4, "could not obtain four distinct HIP streams"
+        _LOOP_STREAMS[key] = tuple(got)
+    return _LOOP_STREAMS[key]
+
+
 class FusedStepper:
     """The whole optimisation iteration as a fixed sequence of C-ABI kernel launches (no autograd tape, no torch
     arithmetic kernels), captured in a hipGraph:
@@ -199,15 +222,26 @@ class FusedStepper:
     Same kernels, same detach structure and same weighting as HOMan.forward + autograd (reference homan/homan.py:421-508,
     jointopt.py:178-192); tests/test_model_gpu.py checks the two paths produce the same gradients.  Supports the
     configurations of BASELINE.json (one right hand, optimize_mano=True, optimize_mano_beta=True, persp); anything
-    else should use mode="graph"."""
+    else should use mode="graph".
+
+    `model` is one HOMan, or a list of HOMan of identical shapes = a CLIP BATCH (homan_amd.clipbatch): the C clips are
+    then optimised together, every kernel launched once over the C * B frames through the `*_clips` entry points
+    (per-clip normalisers, sums, scales, Adam state and log rows; BASELINE cfg4).  Per clip the arithmetic - including
+    the order of every floating-point sum - is the single-clip one, so a batched step equals C single steps bit for bit.
+    With `shared_scale` (BASELINE cfg5) the object scale is ONE scalar for all clips of all ranks: each clip keeps a
+    replica, the replicas' gradients are summed over the local clips and all-reduced over `group` once per iteration
+    (one 4-byte RCCL all-reduce on the compute stream between the two captured halves of the iteration), and every
+    replica takes the identical Adam step."""
 
     SLOTS = ["loss_pca", "loss_scale_obj", "loss_scale_hand", "loss_smooth_obj", "loss_smooth_hand", "loss_collision",
              "loss_contact", "loss_v2d_hand", "v2d_hand", "loss_sil_obj", "iou_object", "loss_inter",
              "handobj_maxdist"]
 
-    def __init__(self, model, loss_weights, lr, max_steps, capture=True):
+    def __init__(self, model, loss_weights, lr, max_steps, capture=True, shared_scale=False, group=None):
         from . import constants, ops
-        m = self.model = model
+        from .clipbatch import ClipBatch, ClipReduceWorkspace
+        m = self.model = model if isinstance(model, ClipBatch) else ClipBatch(model if isinstance(model, (list, tuple))
+                                                                             else [model])
         if not (m.optimize_mano and not m.int_scales_hand.requires_grad and m.hand_proj_mode == "persp"):
             raise NotImplementedError("FusedStepper covers optimize_mano=True, optimize_mano_beta=True, persp")
         lw = self.lw = {k: float(v) for k, v in loss_weights.items()}
@@ -216,13 +250,18 @@ class FusedStepper:
                 raise NotImplementedError("the fused loop does not cover lw_depth > 0: use mode='graph' or 'eager'")
             raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
                             "'masks', 'silhouettes', and 'depths'")
+        self.shared_scale, self.group = bool(shared_scale), group
+        if self.shared_scale and not m.optimize_object_scale:
+            raise ValueError("shared_scale needs models built with optimize_object_scale=True")
         self.L, self.c, self.ops = _lib.lib(), constants, ops
         dev = m.translations_object.device
-        B, Vo, Vh = m.verts_object_og.shape[0], m.verts_object_og.shape[1], 778
-        self.B, self.Vo, self.Vh, self.P = B, Vo, Vh, m.mano_pca_pose.shape[1]
+        B, Vo, Vh = m.B, m.verts_object_og.shape[1], 778          # B = frames of the whole batch
+        C, NS = m.C, len(self.SLOTS) + 1
+        self.B, self.C, self.clip_len, self.NS = B, C, m.clip_len, NS
+        self.Vo, self.Vh, self.P = Vo, Vh, m.mano_pca_pose.shape[1]
         f = lambda *shape: torch.zeros(*shape, device=dev)
         self.vo, self.vm, self.vh = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
-        self.vals = f(len(self.SLOTS) + 1)
+        self.vals = f(C, NS)                                      # row c: the loss / metric slots of clip c + its total
         on = lambda k: lw.get(k, 0.0) > 0
         self.on = dict(pca=on("lw_pca"), so=on("lw_scale_obj"), sh=on("lw_scale_hand"),
                        smooth=on("lw_smooth_hand") or on("lw_smooth_obj"), col=on("lw_collision"),
@@ -240,7 +279,7 @@ class FusedStepper:
         self.weights = torch.tensor([w.get(k, 0.0) for k in self.SLOTS], device=dev)
         self.keys = [k for k in self.SLOTS if self._reported(k)]
         # unit gradients / scratch
-        self.U_pca, self.U_so, self.U_sh = f(B, self.P), f(1), f(1)
+        self.U_pca, self.U_so, self.U_sh = f(B, self.P), f(C), f(C)
         self.U_smo, self.U_smh, self.U_v2d = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
         self.U_colh, self.U_colo, self.U_conh, self.U_cono = f(B, Vh, 3), f(B, Vo, 3), f(B, Vh, 3), f(B, Vo, 3)
         self.G_sil, self.G_int_h, self.G_int_o = f(B, Vo, 3), f(B, Vh, 3), f(B, Vo, 3)
@@ -249,7 +288,7 @@ class FusedStepper:
         self.rec = f(B, 8)
         self.nn_idx = torch.zeros(B, Vh, dtype=torch.int32, device=dev)
         self.nn_d2 = f(B, Vh)
-        self.pooled = f(B, m.losses.sil_ctx.S, m.losses.sil_ctx.S)
+        self.pooled = f(B, m.sil_ctx.S, m.sil_ctx.S)
         self.up_sil, self.up_inter = torch.tensor([w["loss_sil_obj"]], device=dev), torch.tensor([w["loss_inter"]], device=dev)
         # static gradient buffers for exactly the parameters that receive gradients in this configuration
         for p in m.parameters():
@@ -261,34 +300,68 @@ class FusedStepper:
         for p in gp:
             p.grad = torch.zeros_like(p)
         self.opt = HmAdam(parameter_groups(m, lr))
-        self.log_buf = torch.zeros(max_steps, len(self.SLOTS) + 1, device=dev)
+        self.log_buf = torch.zeros(max_steps, C, NS, device=dev)
         self.max_steps = max_steps
         self.mctx = m.mano_model.ctx_mean
         self.rigid_ws_h, self.rigid_ws_o = (torch.zeros(self.L.hm_rigid_workspace_bytes(B), dtype=torch.uint8, device=dev)
                                             for _ in range(2))
         self.mano_state = torch.empty(self.L.hm_mano_state_bytes(B), dtype=torch.uint8, device=dev)
-        self.graph = None
-        self.side = torch.cuda.Stream()
+        self.graph = self.graph_b = None
+        self.cap_stream, self.side, self.aux, side = _loop_streams(dev)
         self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd = (torch.cuda.Event() for _ in range(4))
-        self.aux = torch.cuda.Stream()
-        self.reduce_ws_b = ops.ReduceWorkspace(dev)
-        side = torch.cuda.Stream()
+        self.reduce_ws_b = ClipReduceWorkspace(dev, C)
+        if self.shared_scale:
+            self._sync_shared_scale_start()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             self.forward_backward()              # warm-up, no optimiser step
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if self.on["sil"]:
-            m.losses.sil_ctx.calibrate()         # cost-sorted launch orders from the current state (scheduling only)
+            m.sil_ctx.calibrate()                # cost-sorted launch orders from the current state (scheduling only)
         if capture:
             # scheduling hint baked into the captured launches: with the collision / contact terms the hand-side stream is
             # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way)
-            prev = _lib.lib().hm_tune_sweep_blocks(768 if (self.on["col"] or self.on["con"]) else 1280)
+            prev = _lib.lib().hm_tune_sweep_blocks(768 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=self.cap_stream):
                 self.forward_backward(log=True)
-                self.opt.step(zero_grad=False)
+                if not self.shared_scale:
+                    self.opt.step(zero_grad=False)
+            if self.shared_scale:        # the all-reduce of the scale gradient runs between two captured halves
+                self.graph_b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph_b, stream=self.cap_stream):
+                    self._spread_shared_scale_grad()
+                    self.opt.step(zero_grad=False)
             _lib.lib().hm_tune_sweep_blocks(prev)
+
+    # ---- shared object scale (BASELINE cfg5): C local replicas of one scalar, kept identical on every rank
+    def _dist_on(self):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _sync_shared_scale_start(self):
+        import torch.distributed as dist
+        s = self.model.int_scales_object
+        with torch.no_grad():
+            s0 = s.data[:1].clone()              # one element on the wire whatever the number of local clips
+            if self._dist_on():
+                dist.broadcast(s0, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
+                               group=self.group)
+            s.copy_(s0.expand_as(s))
+        self.g_shared = torch.zeros(1, device=s.device)
+
+    def _reduce_shared_scale_grad(self):
+        """One fp32 per step over xGMI: sum over ranks of (sum over local clips of d loss / d scale), on the compute
+        stream, no host synchronisation."""
+        import torch.distributed as dist
+        if self._dist_on():
+            dist.all_reduce(self.g_shared, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _spread_shared_scale_grad(self):
+        # every replica receives the global sum (identical Adam steps keep the replicas bit-identical)
+        g = self.model.int_scales_object.grad
+        g.copy_(self.g_shared.expand_as(g))
 
     def _reported(self, k):
         o = self.on
@@ -298,6 +371,7 @@ class FusedStepper:
                 "loss_inter": o["inter"], "handobj_maxdist": o["inter"]}[k]
 
     def _slot(self, name):
+        """device address of slot `name` of clip 0; clip c is `self.NS` floats further (the kernels' out_stride)"""
         i = self.SLOTS.index(name)
         return self.vals.data_ptr() + 4 * i
 
@@ -307,72 +381,77 @@ class FusedStepper:
         B (side stream):    MANO, hand transform, priors, 2-D / smoothness / collision / contact / interaction losses,
                             hand gradients, MANO backward.
         B waits for the object vertices before the pair-wise losses, A waits for B's object-side gradient terms, both
-        join before the log row and the Adam step."""
+        join before the log row and the Adam step.  Every launch covers all the clips of the batch (clip_len frames
+        each, per-clip scalars NS floats apart in `vals`)."""
         m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
         B, Vo, Vh, c, on, w = self.B, self.Vo, self.Vh, self.c, self.on, self.w
+        CL, NS, C = self.clip_len, self.NS, self.C
         main = torch.cuda.current_stream()
         side = self.side
         sa, sb = main.cuda_stream, side.cuda_stream
         rws_a, rws_b = P(m.reduce_ws.buf), P(self.reduce_ws_b.buf)
-        sctx, cctx = m.losses.sil_ctx, m.collision_ctx
+        sctx, cctx = m.sil_ctx, m.collision_ctx
         pca, rot, betas, mtr = m.mano_pca_pose, m.mano_rot, m.mano_betas, m.mano_trans
+        npca = self.P * CL                       # PCA entries of one clip
         side.wait_stream(main)
         # ---------------- A: silhouettes forward + backward (the critical chain: nothing else rides it; the object's rigid
         # transform is applied inside the face setup, the other losses get the vertices from the side stream)
         if on["sil"]:
-            ck(L.hm_sil_fwd(P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0,
-                            self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
-                            None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
-                            P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), sa), "sil_fwd")
+            ck(L.hm_sil_fwd_clips(P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S,
+                                  1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
+                                  None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
+                                  P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, sa),
+               "sil_fwd")
             self.ev_sil.record(main)         # the loss / IoU reduction runs on the side stream
-            ck(L.hm_sil_bwd(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
-                            2 if self.lw["lw_sil_obj"] > 0 else 1,
-                            P(self.up_sil), None, P(m.losses.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
-                            P(sctx.face_order), None, None, P(sctx.workspace), sa), "sil_bwd")    # no vertex gather
+            ck(L.hm_sil_bwd_clips(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
+                                  2 if self.lw["lw_sil_obj"] > 0 else 1,
+                                  P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
+                                  P(sctx.face_order), None, None, P(sctx.workspace), CL, sa), "sil_bwd")    # no vertex gather
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
-            ck(L.hm_rigid_fwd(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
-                              P(m.int_scales_object), 1, B, Vo, None, P(self.vo), sb), "rigid_fwd(obj)")
-            ck(L.hm_mano_fwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
-                             P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
-                             P(self.mano_state), sb),
+            ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
+                                    P(m.int_scales_object), 1, B, Vo, None, P(self.vo), CL, sb), "rigid_fwd(obj)")
+            ck(L.hm_mano_fwd_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
+                                   P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
+                                   P(self.mano_state), CL, sb),
                "mano_fwd + rigid(hand)")
             pri = on["pca"] or on["so"] or on["sh"]
             if on["smooth"] and on["v2d"]:       # the three hand-only reductions in one launch
-                ck(L.hm_hand_terms_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
-                                       P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
-                                       self._slot("loss_smooth_hand"), P(pca) if pri else None, pca.numel(),
-                                       P(m.int_scales_object), P(m.int_scale_object_mean), P(m.int_scales_hand),
-                                       P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh),
-                                       self._slot("loss_pca"), rws_b, sb), "hand terms")
+                ck(L.hm_hand_terms_fwd_clips(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
+                                             P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
+                                             self._slot("loss_smooth_hand"), P(pca) if pri else None, npca,
+                                             P(m.int_scales_object), P(m.int_scale_object_mean), P(m.int_scales_hand),
+                                             P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh),
+                                             self._slot("loss_pca"), rws_b, CL, NS, sb), "hand terms")
             else:
                 if pri:
-                    ck(L.hm_priors_fwd(P(pca), pca.numel(), P(m.int_scales_object), P(m.int_scale_object_mean),
-                                       P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
-                                       P(self.U_sh), self._slot("loss_pca"), sb), "priors")
+                    ck(L.hm_priors_fwd_clips(P(pca), npca, P(m.int_scales_object), P(m.int_scale_object_mean),
+                                             P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
+                                             P(self.U_sh), self._slot("loss_pca"), C, NS, sb), "priors")
                 if on["smooth"]:
-                    ck(L.hm_smooth_fwd(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws_b, sb),
-                       "smooth(hand)")
+                    ck(L.hm_smooth_fwd_clips(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws_b,
+                                             CL, NS, sb), "smooth(hand)")
                 if on["v2d"]:
-                    ck(L.hm_v2d_fwd(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
-                                    P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, sb), "v2d")
+                    ck(L.hm_v2d_fwd_clips(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
+                                          P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, CL, NS, sb), "v2d")
             if on["smooth"]:
-                ck(L.hm_smooth_fwd(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, sb),
-                   "smooth(obj)")
+                ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
+                                         sb), "smooth(obj)")
             if on["col"]:
-                ck(L.hm_collision_fwd(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
-                                      cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
-                                      self._slot("loss_collision"), P(cctx.ws), sb), "collision")
+                ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
+                                            cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
+                                            self._slot("loss_collision"), P(cctx.ws), CL, NS, sb), "collision")
             if on["con"] or on["inter"]:
-                ck(L.hm_nn_fwd(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx), P(self.nn_d2),
-                               self._slot("handobj_maxdist"), rws_b, sb), "nn")
+                ck(L.hm_nn_fwd_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx), P(self.nn_d2),
+                                     self._slot("handobj_maxdist"), rws_b, CL, NS, sb), "nn")
             if on["con"]:
-                ck(L.hm_contact_fwd(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
-                                    P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws_b, sb), "contact")
+                ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
+                                          P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws_b, CL, NS, sb),
+                   "contact")
             if on["inter"]:
-                ck(L.hm_inter_fwd(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
-                                  float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws_b, sb),
-                   "inter")
+                ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
+                                        float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws_b, CL,
+                                        NS, sb), "inter")
                 if m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
                     ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb), "inter_bwd")
             # every forward loss value exists now: the silhouette reduction and the log row run on a third stream, off both
@@ -384,11 +463,11 @@ class FusedStepper:
                 self.aux.wait_event(self.ev_fwd)
                 if on["sil"]:
                     self.aux.wait_event(self.ev_sil)
-                    ck(L.hm_sil_reduce(B, Vo, sctx.F, sctx.S, P(m.losses.keep_sum), self._slot("loss_sil_obj"), None,
-                                       P(sctx.workspace), self.aux.cuda_stream), "sil_reduce")
+                    ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
+                                             P(sctx.workspace), CL, NS, self.aux.cuda_stream), "sil_reduce")
                 if log:
-                    ck(L.hm_log_total(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
-                                      P(self.log_buf), self.aux.cuda_stream), "log")
+                    ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
+                                            self.max_steps, P(self.log_buf), C, self.aux.cuda_stream), "log")
             self.ev_pair.record(side)        # object-side terms of the pair-wise losses are ready
             # hand (full path: MANO + rigid): smooth + v2d + collision + contact, summed with their weights inside the rigid
             # backward; the interaction term reaches the rigid pose only, as one vector per frame (rec[:, 2:5] / Vh)
@@ -396,10 +475,10 @@ class FusedStepper:
                                      (self.U_v2d if on["v2d"] else None, w["loss_v2d_hand"]),
                                      (self.U_colh if on["col"] else None, w["loss_collision"]),
                                      (self.U_conh if on["con"] else None, w["loss_contact"])])
-            ck(L.hm_rigid_bwd(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, tp, tw, tn, None,
-                              (self.rec.data_ptr() + 8) if on["inter"] else None, 8, w["loss_inter"] / Vh, B, Vh,
-                              P(self.G_mesh), P(m.rotations_hand.grad), P(m.translations_hand.grad), None,
-                              P(self.rigid_ws_h), sb), "rigid_bwd(hand)")
+            ck(L.hm_rigid_bwd_clips(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, tp, tw, tn, None,
+                                    (self.rec.data_ptr() + 8) if on["inter"] else None, 8, w["loss_inter"] / Vh, B, Vh,
+                                    P(self.G_mesh), P(m.rotations_hand.grad), P(m.translations_hand.grad), None,
+                                    P(self.rigid_ws_h), CL, sb), "rigid_bwd(hand)")
             ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
                              P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad), P(betas.grad),
                              P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb), "mano_bwd")
@@ -411,37 +490,57 @@ class FusedStepper:
                                  (self.U_cono if on["con"] else None, w["loss_contact"]),
                                  (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0)])
         if on["sil"]:       # the silhouette term is gathered from the sweeps' per-corner gradients inside this launch
-            ck(L.hm_rigid_bwd_sil(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn,
-                                  L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
-                                  P(sctx.adj_items), P(self.vo), P(m.camintr_rois_object), 1.0, sctx.F, B, Vo,
-                                  P(m.rotations_object.grad), P(m.translations_object.grad),
-                                  P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), sa),
+            ck(L.hm_rigid_bwd_sil_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn,
+                                        L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
+                                        P(sctx.adj_items), P(self.vo), P(m.camintr_rois_object), 1.0, sctx.F, B, Vo,
+                                        P(m.rotations_object.grad), P(m.translations_object.grad),
+                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sa),
                "rigid_bwd(obj) + silhouette gather")
         else:
-            ck(L.hm_rigid_bwd(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
-                              None, 0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
-                              P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), sa), "rigid_bwd(obj)")
+            ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
+                                    None, 0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
+                                    P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sa), "rigid_bwd(obj)")
         main.wait_stream(side)               # join
         main.wait_stream(self.aux)
-        if sc_obj:
-            ck(L.hm_sum_small(P(self.g_so_part), B, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
-                              P(m.int_scales_object.grad), sa), "scale grad")
+        if sc_obj:          # per clip: sum of the frames' d loss / d scale + the scale prior's term
+            ck(L.hm_sum_small_clips(P(self.g_so_part), CL, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
+                                    P(m.int_scales_object.grad), C, sa), "scale grad")
+            if self.shared_scale:
+                # ONE scalar tied across the clips: its gradient is the sum of the replicas' gradients - local clips
+                # here, ranks in _reduce_shared_scale_grad
+                ck(L.hm_sum_small_clips(P(m.int_scales_object.grad), C, 1.0, None, 0.0, P(self.g_shared), 1, sa),
+                   "shared scale grad")
+
+    def _iteration(self):
+        if self.graph is not None:
+            self.graph.replay()
+            if self.shared_scale:
+                self._reduce_shared_scale_grad()
+                self.graph_b.replay()
+        else:
+            self.forward_backward(log=True)
+            if self.shared_scale:
+                self._reduce_shared_scale_grad()
+                self._spread_shared_scale_grad()
+            self.opt.step(zero_grad=False)
 
     def run(self, steps):
-        if self.graph is not None:
-            for _ in range(steps):
-                self.graph.replay()
-        else:
-            for _ in range(steps):
-                self.forward_backward(log=True)
-                self.opt.step(zero_grad=False)
+        for _ in range(steps):
+            self._iteration()
 
-    def loss_evolution(self, steps):
+    def loss_evolution(self, steps, clip=None):
+        """{name: [float] * steps} of one clip (reference jointopt.py:184-189); a batch of several clips returns the list
+        of its clips' dictionaries unless `clip` picks one."""
         torch.cuda.synchronize()
-        host = self.log_buf[:steps].cpu().numpy()
-        out = {k: host[:, self.SLOTS.index(k)].astype(np.float64).tolist() for k in self.keys}
-        out["loss"] = host[:, len(self.SLOTS)].astype(np.float64).tolist()
-        return out
+        host = self.log_buf[:steps].cpu().numpy()           # (steps, C, NS)
+
+        def one(ci):
+            out = {k: host[:, ci, self.SLOTS.index(k)].astype(np.float64).tolist() for k in self.keys}
+            out["loss"] = host[:, ci, len(self.SLOTS)].astype(np.float64).tolist()
+            return out
+        if clip is not None:
+            return one(clip)
+        return one(0) if self.C == 1 else [one(ci) for ci in range(self.C)]
 
 
 def save_front_top(model, images, step, viz_folder, viz_len=7):

@@ -243,6 +243,80 @@ int hm_log_total(float* vals, const float* weights, int n, const int* step, int 
 /* log[step[0]*n + i] = src[i] */
 int hm_log_scalars(const float* src, int n, const int* step, int max_steps, float* log, hipStream_t stream);
 
+/* ------------------------------------------------------------------ clip batches: C clips, ONE launch per kernel
+ * reference: clips are independent optimisations (one HOMan + one Adam per clip, homan/jointopt.py:92-151); the only
+ * sharding hook upstream is the strided sample selection of fit_vid_dataset.py:54-55,190.  Frames of one clip stay
+ * coupled through the smoothness term (homan/lossutils.py:18-36) and the per-clip normalisers (sum(keep) and 1/B of
+ * homan/losses.py:189-194, the means of losses.py:158 / lossutils.py:39-40 / contactloss.py:284-285, the per-clip
+ * sums of losses.py:233-239 and scenesdf.py:147), so a batch concatenates whole clips along the frame axis:
+ *   - N (or B) = clips * clip_len frames, clip c = frames [c*clip_len, (c+1)*clip_len); clip_len == 0: one clip;
+ *   - every per-clip scalar input (scale, s_obj, m_obj, s_hand, m_hand, keep_sum, rigid_scale) is an array with one
+ *     entry per clip; every per-clip scalar output is written at out + c*out_stride (+ the offsets of the plain call);
+ *   - reduce workspaces hold `clips` slices of hm_reduce_workspace_bytes() back to back (zero-filled once);
+ *   - the clips must share V, F, S and the face topology; vertices, masks, cameras are per frame as before.
+ * Each clip's sums are formed by its own workgroups in the order of a single-clip launch: a batched call returns, per
+ * clip, bit-identical results to the plain entry point called on that clip alone (tests/test_clip_batch_gpu.py).
+ * The plain entry points above are these with clip_len = 0, out_stride = 0. */
+int hm_rigid_fwd_clips(const float* mesh, const float* rot6d, const float* trans, const float* scale, int abs_scale, int N,
+                       int V, float* rotmat, float* verts, int clip_len, hipStream_t stream);
+int hm_rigid_bwd_clips(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
+                       const float* const* g_terms, const float* weights, int n_terms, const float* g_rigid,
+                       const float* g_frame, int frame_stride, float frame_scale, int N, int V, float* g_mesh,
+                       float* g_rot6d, float* g_trans, float* g_scale_part, void* workspace, int clip_len,
+                       hipStream_t stream);
+int hm_rigid_bwd_sil_clips(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
+                           const float* const* g_terms, const float* weights, int n_terms, const float* sil_parts,
+                           const int* adj_off, const int* adj_items, const float* cam_verts, const float* K,
+                           float orig_size, int F, int N, int V, float* g_rot6d, float* g_trans, float* g_scale_part,
+                           void* workspace, int clip_len, hipStream_t stream);
+/* out[c] = w0 * sum(parts[c*n .. c*n+n)) + w1 * extra[c] */
+int hm_sum_small_clips(const float* parts, int n, float w0, const float* extra, float w1, float* out, int nclips,
+                       hipStream_t stream);
+int hm_mano_fwd_clips(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
+                      const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d,
+                      const float* rigid_trans, const float* rigid_scale, float* verts_world, float* state, int clip_len,
+                      hipStream_t stream);
+int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
+                     float orig_size, float znear, float zfar, const float* keep, const float* ref,
+                     const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+                     float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
+                     const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, int clip_len,
+                     int out_stride, hipStream_t stream);
+int hm_sil_reduce_clips(int B, int V, int F, int S, const float* keep_sum, float* loss_out, float* frame_out,
+                        void* workspace, int clip_len, int out_stride, hipStream_t stream);
+int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
+                     const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
+                     const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
+                     int clip_len, hipStream_t stream);
+int hm_v2d_fwd_clips(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size, int N,
+                     int V, float* unit_grad, float* out2, void* workspace, int clip_len, int out_stride,
+                     hipStream_t stream);
+int hm_smooth_fwd_clips(const float* verts, int N, int V, int hand_nb, float* unit_grad, float* out1, void* workspace,
+                        int clip_len, int out_stride, hipStream_t stream);
+/* npca = PCA entries of ONE clip (pca holds nclips * npca) */
+int hm_priors_fwd_clips(const float* pca, long npca, const float* s_obj, const float* m_obj, const float* s_hand,
+                        const float* m_hand, float* g_pca, float* g_sobj, float* g_shand, float* out3, int nclips,
+                        int out_stride, hipStream_t stream);
+int hm_hand_terms_fwd_clips(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size,
+                            int N, int V, float* unit_v2d, float* out_v2d2, float* unit_smooth, float* out_smooth1,
+                            const float* pca, long npca, const float* s_obj, const float* m_obj, const float* s_hand,
+                            const float* m_hand, float* g_pca, float* g_sobj, float* g_shand, float* out_priors3,
+                            void* workspace, int clip_len, int out_stride, hipStream_t stream);
+int hm_inter_fwd_clips(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
+                       float expansion, float zthresh, float* frame_rec, float* out1, void* workspace, int clip_len,
+                       int out_stride, hipStream_t stream);
+int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
+                    float* metric_out, void* workspace, int clip_len, int out_stride, hipStream_t stream);
+int hm_contact_fwd_clips(const float* verts_hand, const float* verts_obj, const int* nn_idx, int B, int Vh, int Vo,
+                         float thresh, float* g_hand, float* g_obj, float* out1, void* workspace, int clip_len,
+                         int out_stride, hipStream_t stream);
+int hm_collision_fwd_clips(const float* verts0, const int* faces0, int V0, int F0, const float* verts1, const int* faces1,
+                           int V1, int F1, int B, float scale_factor, float* g0, float* g1, float* out1, void* workspace,
+                           int clip_len, int out_stride, hipStream_t stream);
+/* vals (nclips, n+1), log (max_steps, nclips, n+1): per clip the weighted total, then its row of the log */
+int hm_log_total_clips(float* vals, const float* weights, int n, const int* step, int max_steps, float* log, int nclips,
+                       hipStream_t stream);
+
 /* ------------------------------------------------------------------ measurement / debug hooks (synchronous)
  * hm_bench_sil_kernels: one full silhouette forward + backward to populate the workspace, then `reps` launches of the
  * raster kernel, of the edge-sweep kernel and of the line-source kernel, each series bracketed by two HIP events on

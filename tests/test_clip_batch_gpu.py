@@ -1,0 +1,116 @@
+"""Clip batches (BASELINE cfg4 / cfg5 in miniature): C clips optimised by ONE launch per kernel must equal C
+single-clip optimisations BIT FOR BIT - loss_evolution rows and final parameters - and the shared object scale of
+cfg5 must follow the tied-parameter semantics of homan_amd.dist.  GPU box."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _clips(mano, seeds, frames, size, obj, **kw):
+    from homan_amd import synth
+    from homan_amd.jointopt import build_model
+    sil_fn, hand_fn = synth.hip_clip_fns(mano)
+    models = []
+    for seed in seeds:
+        clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
+                               hand_verts_fn=hand_fn)
+        models.append(build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                                  objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                                  optimize_mano=True, image_size=size, mano_model=mano, rend_size=size,
+                                  sync_metrics=False, **kw))
+    return models
+
+
+PARAMS = ["translations_object", "rotations_object", "translations_hand", "rotations_hand", "mano_pca_pose", "mano_betas",
+          "mano_rot", "mano_trans", "int_scales_object"]
+
+
+def _compare(mano, seeds, frames, size, obj, lw, steps, **kw):
+    from homan_amd.jointopt import FusedStepper
+    singles = _clips(mano, seeds, frames, size, obj, **kw)
+    evo_single = []
+    for m in singles:
+        st = FusedStepper(m, lw, 1e-2, steps)
+        st.run(steps)
+        evo_single.append(st.loss_evolution(steps))
+    batch = _clips(mano, seeds, frames, size, obj, **kw)
+    st = FusedStepper(batch, lw, 1e-2, steps)
+    st.run(steps)
+    evo_batch = st.loss_evolution(steps)
+    assert len(evo_batch) == len(seeds)
+    for c, (es, eb) in enumerate(zip(evo_single, evo_batch)):
+        assert sorted(es) == sorted(eb)
+        for k in es:
+            np.testing.assert_array_equal(np.asarray(eb[k]), np.asarray(es[k]), err_msg=f"clip {c} {k}")
+        assert np.isfinite(es["loss"]).all() and min(es["loss"]) > 0
+    for c, (ms, mb) in enumerate(zip(singles, batch)):
+        for k in PARAMS:
+            a, b = getattr(ms, k).detach(), getattr(mb, k).detach()
+            assert torch.equal(a, b), f"clip {c} {k}: max diff {(a - b).abs().max().item()}"
+        # each model of the batch holds its own result: its own forward sees the optimised parameters
+        assert torch.equal(ms.get_verts_object()[0], mb.get_verts_object()[0])
+
+
+@pytest.mark.parametrize("step2", [False, True])
+def test_batched_step_equals_single_steps_bitwise(mano_model, step2):
+    from homan_amd import synth
+    lw = dict(synth.STEP2_LOSS_WEIGHTS if step2 else synth.STEP1_LOSS_WEIGHTS)
+    _compare(mano_model, [3, 4, 5], 4, 64, "cube", lw, 12)
+
+
+def test_batched_free_object_scale_bitwise(mano_model):
+    from homan_amd import synth
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    lw["lw_scale_obj"] = 10.0
+    _compare(mano_model, [11, 12], 5, 64, "cube", lw, 8, optimize_object_scale=True)
+
+
+def test_cfg1_weights_batched_bitwise(mano_model):
+    """BASELINE cfg1's loss set (silhouette + 2-D keypoints only): the separate v2d / priors launches of the fused loop."""
+    from homan_amd import synth
+    _compare(mano_model, [0, 1], 10, 128, "cube", dict(synth.CFG1_LOSS_WEIGHTS), 6)
+
+
+def test_cfg4_miniature_full_size_clips(mano_model):
+    """two cfg2-sized clips (30 frames, 256^2, 3000-face bottle) in one batch == alone, bit for bit"""
+    from homan_amd import synth
+    _compare(mano_model, [0, 1], 30, 256, "bottle", dict(synth.STEP1_LOSS_WEIGHTS), 5)
+
+
+def test_shared_scale_fused_matches_tied_eager(mano_model):
+    """cfg5 semantics on one rank (process group of size 1, backend nccl = RCCL): the fused loop with `shared_scale`
+    keeps the replicas of the scalar identical and follows the eager tied-parameter loop of homan_amd.dist."""
+    import torch.distributed as dist
+    from homan_amd import dist as hdist
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, parameter_groups
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        lw = dict(synth.STEP2_LOSS_WEIGHTS)
+        lw["lw_scale_obj"] = 10.0
+        steps = 4
+        eager = _clips(mano_model, [21, 22], 4, 64, "cube", optimize_object_scale=True)
+        opts = [torch.optim.Adam(parameter_groups(m, 1e-2)) for m in eager]
+        hist = hdist.optimize_clips_shared_scale(eager, opts, lw, steps)
+        fused = _clips(mano_model, [21, 22], 4, 64, "cube", optimize_object_scale=True)
+        st = FusedStepper(fused, lw, 1e-2, steps, shared_scale=True)
+        st.run(steps)
+        evo = st.loss_evolution(steps)
+        s = st.model.int_scales_object.detach().cpu().numpy()
+        assert s[0] == s[1] and abs(float(s[0]) - 1.0) > 1e-4          # replicas identical, and the scalar moved
+        np.testing.assert_allclose(s[0], eager[0].int_scales_object.detach().cpu().numpy()[0], rtol=2e-4)
+        np.testing.assert_allclose([evo[0]["loss"][0], evo[1]["loss"][0]], hist[0], rtol=2e-4)
+        np.testing.assert_allclose([evo[0]["loss"][1], evo[1]["loss"][1]], hist[1], rtol=5e-3)
+    finally:
+        if created:
+            dist.destroy_process_group()

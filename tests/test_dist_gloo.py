@@ -35,7 +35,7 @@ def _weights():
     return lw
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, num_clips=NUM_CLIPS):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
@@ -43,20 +43,21 @@ def _worker(rank, world, port, out_dir):
     from homan_amd import dist as hdist
     from homan_amd.mano_assets import synthetic_mano
     mano = synthetic_mano(0)
-    mine = hdist.shard_clips(NUM_CLIPS, rank, world)
+    mine = hdist.shard_clips(num_clips, rank, world)
     pairs = [_build(seed, mano) for seed in mine]
     models, opts = [p[0] for p in pairs], [p[1] for p in pairs]
     hist = hdist.optimize_clips_shared_scale(models, opts, _weights(), STEPS)
-    np.save(os.path.join(out_dir, f"scale_{rank}.npy"), models[0].int_scales_object.detach().numpy())
-    np.save(os.path.join(out_dir, f"hist_{rank}.npy"), np.asarray(hist))
+    scales = np.asarray([m.int_scales_object.detach().numpy()[0] for m in models], np.float32)
+    np.save(os.path.join(out_dir, f"scale_{rank}.npy"), scales)
+    np.save(os.path.join(out_dir, f"hist_{rank}.npy"), np.asarray(hist).reshape(STEPS, len(models)))
     dist.destroy_process_group()
 
 
 def test_shared_scale_allreduce_world2(tmp_path):
     port = 29500 + (os.getpid() % 2000)
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
-    s0 = np.load(tmp_path / "scale_0.npy")
-    s1 = np.load(tmp_path / "scale_1.npy")
+    s0 = np.load(tmp_path / "scale_0.npy")[:1]
+    s1 = np.load(tmp_path / "scale_1.npy")[:1]
     np.testing.assert_array_equal(s0, s1)               # replicas of the shared scalar stay bit-identical
     assert abs(float(s0[0]) - 1.0) > 1e-4                # ... and it actually moved
 
@@ -70,3 +71,32 @@ def test_shared_scale_allreduce_world2(tmp_path):
     np.testing.assert_allclose(pairs[0][0].int_scales_object.detach().numpy(), s0, rtol=1e-6)
     h0, h1 = np.load(tmp_path / "hist_0.npy"), np.load(tmp_path / "hist_1.npy")
     np.testing.assert_allclose(np.concatenate([h0, h1], 1), np.asarray(hist), rtol=1e-5)
+
+
+def test_shard_clips_is_balanced_and_complete():
+    sys.path.insert(0, ROOT)
+    from homan_amd import dist as hdist
+    for n, w in ((64, 8), (9, 8), (2, 3), (0, 2), (7, 3)):
+        shards = [hdist.shard_clips(n, r, w) for r in range(w)]
+        assert sum(shards, []) == list(range(n))                        # contiguous blocks, every clip exactly once
+        sizes = [len(s) for s in shards]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    assert [len(hdist.shard_clips(9, r, 8)) for r in range(8)] == [2, 1, 1, 1, 1, 1, 1, 1]
+
+
+def test_shared_scale_uneven_shards_and_empty_rank(tmp_path):
+    """3 ranks, 2 clips -> shards [1, 1, 0]: the rank without a clip issues the same collectives (one broadcast, one
+    all-reduce per step, a zero gradient) and nobody deadlocks; 2 ranks, 3 clips -> shards [2, 1]."""
+    for world, clips in ((3, 2), (2, 3)):
+        out = tmp_path / f"w{world}"
+        out.mkdir()
+        port = 31500 + (os.getpid() % 2000) + world
+        mp.spawn(_worker, args=(world, port, str(out), clips), nprocs=world, join=True)
+        scales = np.concatenate([np.load(out / f"scale_{r}.npy") for r in range(world)])
+        assert scales.size == clips and np.all(scales == scales[0]) and abs(float(scales[0]) - 1.0) > 1e-4
+        from homan_amd import dist as hdist
+        from homan_amd.mano_assets import synthetic_mano
+        mano = synthetic_mano(0)
+        pairs = [_build(seed, mano) for seed in range(clips)]
+        hdist.optimize_clips_shared_scale([p[0] for p in pairs], [p[1] for p in pairs], _weights(), STEPS)
+        np.testing.assert_allclose(pairs[0][0].int_scales_object.detach().numpy()[0], scales[0], rtol=1e-6)

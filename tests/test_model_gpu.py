@@ -140,8 +140,8 @@ def test_fused_step_equals_autograd_path(name, mano_model):
     st = FusedStepper(model, weights, meta["lr"], 4, capture=False)
     st.forward_backward(log=True)
     torch.cuda.synchronize()
-    evo = {k: st.log_buf[0, st.SLOTS.index(k)].item() for k in st.keys}
-    evo["loss"] = st.log_buf[0, len(st.SLOTS)].item()
+    evo = {k: st.log_buf[0, 0, st.SLOTS.index(k)].item() for k in st.keys}      # log rows are (step, clip, slot)
+    evo["loss"] = st.log_buf[0, 0, len(st.SLOTS)].item()
     assert sorted(evo) == sorted(ref_losses)
     for k, v in ref_losses.items():
         np.testing.assert_allclose(evo[k], v, rtol=2e-6, atol=1e-9, err_msg=k)
