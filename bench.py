@@ -4,7 +4,15 @@
 Workload (BASELINE.json configs[1]): one clip per GPU, 30 frames, 256x256 silhouette raster, MANO hand + ~3000-face
 bottle, full step-1 loss set, Adam step included.  A "step" = one optimisation iteration (forward + backward +
 Adam + loss logging) of one clip, replayed from a hipGraph.  N GPUs = N independent clips (weak scaling, no
-data-path collective).  Prints ONE JSON line on rank 0.
+data-path collective).  Prints ONE JSON line on rank 0, which also carries
+  roofline          the dominant kernel timed with HIP events INSIDE the optimisation loop (launch by launch, next to the
+                    other streams' work), algorithmic bytes / that time / 8 TB/s; PMC traffic of the steady-state loop
+                    from profiles/ (tools/pmc_loop.sh) when it was measured on the same shapes;
+  multi_clip        BASELINE cfg4 in miniature: `--multi-clip` clips per GPU as ONE clip batch (one launch per kernel over
+                    all clips), with the whole-iteration roofline fraction of that run;
+  final_loss_parity HIP vs the CPU oracle from identical inputs: cfg2 over the steps the CPU baseline leg runs anyway,
+                    and BASELINE cfg1 (10 frames 128^2, cube, sil + v2d, 100 steps) in full over several seeds;
+  cpu_baseline      the oracle loop timed on this host (bounded sample).
 """
 import argparse
 import copy
@@ -65,15 +73,19 @@ def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256):
                         image_size=image_size, mano_model=mano, rend_size=rend_size, **kw)
     opt = make_optimizer(model, 1e-2)
 
+    evo = []
+
     def step():
         opt.zero_grad()
         ld, md = model(loss_weights=lw)
         tot = sum(ld[k] * lw[k.replace("loss", "lw")] for k in ld)
-        _ = [v.item() for v in ld.values()]
+        row = {k: v.item() for k, v in ld.items()}
+        row["loss"] = tot.item()
+        evo.append(row)
         tot.backward()
         opt.step()
 
-    step()                      # warm-up
+    step()                      # warm-up (and step 0 of the trajectory compared in final_loss_parity)
     n, t0 = 0, time.perf_counter()
     while True:
         step()
@@ -82,55 +94,148 @@ def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256):
         if el > budget_s or n >= 50:
             break
     return dict(value=n / el, unit="it/s", cores=threads, kind="port",
-                sample=f"{n} iterations of the same cfg2 clip ({el:.1f} s) after 1 warm-up, oracle loop with per-step .item() logging")
+                sample=f"{n} iterations of the same cfg2 clip ({el:.1f} s) after 1 warm-up, oracle loop with per-step .item() logging"), evo
+
+
+def trajectory_parity(evo_hip, evo_cpu, tol=1e-4):
+    """HIP vs oracle loss_evolution from identical inputs: per-loss relative difference per step, the first step at which
+    any loss differs by more than `tol` (BASELINE north_star: 1e-4 relative), the differences at the last common step."""
+    n = min(len(evo_cpu), len(evo_hip["loss"]))
+    keys = [k for k in evo_cpu[0] if k in evo_hip]
+    rel = {k: [abs(evo_hip[k][i] - evo_cpu[i][k]) / max(abs(evo_cpu[i][k]), 1e-12) for i in range(n)] for k in keys}
+    worst = [max(rel[k][i] for k in keys) for i in range(n)]
+    first = next((i for i, w in enumerate(worst) if w > tol), None)
+    return dict(steps_compared=n, tol=tol, first_step_over_tol=first, max_rel_diff_step0=worst[0],
+                rel_diff_last_step={k: rel[k][n - 1] for k in keys}, max_rel_diff_per_step=worst)
+
+
+def cfg1_parity(mano, seeds, steps=100, frames=10, size=128):
+    """BASELINE cfg1 (the configuration the reference CPU path is defined on): 1 clip, 10 frames 128x128, MANO right hand
+    + 1 rigid cube, silhouette + 2-D keypoint losses only, 100 Adam steps.  HIP fused loop vs CPU oracle loop from
+    identical inputs, per seed: final weighted loss of both, relative difference, first step over 1e-4, max final-vertex
+    difference (mm); plus the CPU oracle's rate on this configuration."""
+    import numpy as np
+    import torch
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, build_model
+    from oracle.jointopt import optimize_hand_object as oracle_opt
+    sil_fn, hand_fn = synth.hip_clip_fns(mano)
+    lw = dict(synth.CFG1_LOSS_WEIGHTS)
+    rows, cpu_s, gpu_s, control = [], 0.0, 0.0, None
+    for seed in seeds:
+        clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj="cube", silhouette_fn=sil_fn,
+                               hand_verts_fn=hand_fn)
+        common = dict(objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                      optimize_mano=True, image_size=size, mano_model=mano, rend_size=size)
+        model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                            sync_metrics=False, **common)
+        st = FusedStepper(model, lw, 1e-2, steps)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        st.run(steps)
+        torch.cuda.synchronize()
+        gpu_s += time.perf_counter() - tg
+        evo_h = st.loss_evolution(steps)
+        t0 = time.perf_counter()
+        om, evo_c, _ = oracle_opt(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                                  loss_weights=lw, num_iterations=steps, lr=1e-2, **common)
+        cpu_s += time.perf_counter() - t0
+        rel = [abs(a - b) / max(abs(b), 1e-12) for a, b in zip(evo_h["loss"], evo_c["loss"])]
+        with torch.no_grad():
+            dvo = (model.get_verts_object()[0].cpu() - om.get_verts_object()[0]).abs().max().item()
+            dvh = (model.get_verts_hand()[0].cpu() - om.get_verts_hand()[0]).abs().max().item()
+        if control is None:
+            # control experiment: the CPU oracle against ITSELF from inputs that differ by 1e-7 m in one object translation -
+            # how far apart two runs of the same implementation end up says how much of the HIP-vs-CPU distance is the
+            # algorithm's own sensitivity (piecewise-constant silhouette loss, Adam's normalised steps)
+            op2 = copy.deepcopy(clip["object_parameters"])
+            op2[0]["translations"] = op2[0]["translations"] + 1e-7
+            om2, evo_p, _ = oracle_opt(copy.deepcopy(clip["person_parameters"]), op2, loss_weights=lw, num_iterations=steps,
+                                       lr=1e-2, **common)
+            with torch.no_grad():
+                control = dict(seed=seed, perturbation_m=1e-7,
+                               final_vertex_diff_mm=dict(
+                                   object=1e3 * (om2.get_verts_object()[0] - om.get_verts_object()[0]).abs().max().item(),
+                                   hand=1e3 * (om2.get_verts_hand()[0] - om.get_verts_hand()[0]).abs().max().item()),
+                               rel_diff_final_loss=abs(evo_p["loss"][-1] - evo_c["loss"][-1]) / abs(evo_c["loss"][-1]),
+                               first_step_over_tol=next((i for i, (a, b) in enumerate(zip(evo_p["loss"], evo_c["loss"]))
+                                                         if abs(a - b) / max(abs(b), 1e-12) > 1e-4), None))
+        rows.append(dict(seed=seed, first_loss=evo_c["loss"][0], final_loss_hip=evo_h["loss"][-1],
+                         final_loss_cpu=evo_c["loss"][-1], rel_diff_final=rel[-1], rel_diff_step0=rel[0],
+                         first_step_over_tol=next((i for i, r in enumerate(rel) if r > 1e-4), None),
+                         final_vertex_diff_mm=dict(object=1e3 * dvo, hand=1e3 * dvh)))
+    fh, fc = np.array([r["final_loss_hip"] for r in rows]), np.array([r["final_loss_cpu"] for r in rows])
+    return dict(config="cfg1: 1 clip, 10 frames 128x128, cube, lw_sil_obj=1 lw_v2d_hand=50, %d Adam steps" % steps,
+                seeds=rows, final_loss_mean=dict(hip=float(fh.mean()), cpu=float(fc.mean())),
+                final_loss_std=dict(hip=float(fh.std()), cpu=float(fc.std())),
+                max_rel_diff_final=float(max(r["rel_diff_final"] for r in rows)),
+                cpu_vs_cpu_control=control,
+                cpu_its_per_s=len(seeds) * steps / cpu_s, hip_its_per_s=len(seeds) * steps / gpu_s,
+                cores=int(os.environ.get("OMP_NUM_THREADS", "1")))
 
 
 def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
-    """cfg5: every rank optimises its clip with step-2 losses; the object scale is one scalar shared by all clips:
-    per step one all-reduce (sum) of its gradient, identical Adam update everywhere."""
+    """BASELINE cfg5: `--multi-clip` clips per GPU (default 8) with step-2 losses as ONE clip batch per rank, the object
+    scale ONE scalar tied across all clips of all ranks: per step one 4-byte all-reduce (sum) of its gradient on the
+    compute stream between the two captured halves of the iteration, identical Adam update everywhere."""
     import torch
     import torch.distributed as dist
     from homan_amd import dist as hdist
     from homan_amd import synth
-    from homan_amd.jointopt import build_model, parameter_groups
-    clip = synth.make_clip(seed=rank, frames=args.frames, rend_size=args.size, image_size=args.size, obj="bottle",
-                           silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+    from homan_amd.jointopt import FusedStepper, build_model
+    if not dist.is_initialized():          # N=1: a process group of one rank, so that the RCCL call is really issued
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend, rank=0, world_size=1,
+                                **({"device_id": torch.device("cuda", torch.cuda.current_device())} if backend == "nccl" else {}))
+    C = max(1, args.multi_clip)
     lw = dict(synth.STEP2_LOSS_WEIGHTS)
-    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
-                        objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
-                        optimize_mano=True, optimize_object_scale=True, image_size=args.size, mano_model=mano,
-                        rend_size=args.size, sync_metrics=False)
-    opt = torch.optim.Adam(parameter_groups(model, 1e-2))
-    hdist.optimize_clips_shared_scale([model], [opt], lw, args.warmup)
+    models = []
+    for i in range(C):
+        clip = synth.make_clip(seed=100 * rank + i, frames=args.frames, rend_size=args.size, image_size=args.size,
+                               obj="bottle", silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+        models.append(build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                                  objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                                  optimize_mano=True, optimize_object_scale=True, image_size=args.size, mano_model=mano,
+                                  rend_size=args.size, sync_metrics=False))
+    total = args.warmup + args.steps
+    st = FusedStepper(models, lw, 1e-2, total, shared_scale=True)
+    st.run(args.warmup)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    hist = hdist.optimize_clips_shared_scale([model], [opt], lw, args.steps)
+    st.run(args.steps)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    dist.barrier()
+    torch.cuda.synchronize()
     elapsed = hdist.max_over_ranks(time.perf_counter() - t0, device="cuda" if backend == "nccl" else "cpu")
-    scale = model.int_scales_object.detach().cpu().reshape(-1)
-    if world > 1:
-        gathered = [torch.zeros_like(scale) for _ in range(world)]
-        dist.all_gather(gathered, scale if backend != "nccl" else scale.cuda())
-        same = all(torch.equal(g.cpu(), gathered[0].cpu()) for g in gathered)
-    else:
-        same = True
+    evo = st.loss_evolution(total)
+    evo = evo if isinstance(evo, list) else [evo]
+    scale = st.model.int_scales_object.detach().reshape(-1)
+    gathered = [torch.zeros(1, device=scale.device) for _ in range(world)]
+    dist.all_gather(gathered, scale[:1].contiguous())
+    same = bool((scale == scale[0]).all()) and all(torch.equal(g, gathered[0]) for g in gathered)
     if rank == 0:
+        F, V = int(models[0].faces_object.shape[1]), int(models[0].verts_object_og.shape[1])
+        tot = algorithmic_bytes(args.frames, args.size, F, V, True)["total"]
+        value = world * C * args.steps / elapsed
         print(json.dumps({
-            "metric": "optimisation iters/sec (30-frame 256^2 clip)", "value": world * args.steps / elapsed,
+            "metric": "optimisation iters/sec (30-frame 256^2 clip)", "value": value,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg5: 1 clip/GPU x {args.frames} frames {args.size}x{args.size}, step-2 losses, "
-                                   "shared object scale (one 4-byte all-reduce per step), eager autograd loop",
-                       "parallelism": f"{world} clips, shared scalar"},
-            "shared_scale_final": float(scale[0]), "replicas_identical": bool(same),
-            "first_loss": hist[0][0], "final_loss": hist[-1][0]}))
-    if world > 1:
-        dist.destroy_process_group()
+            "config": {"workload": f"cfg5: {C} clips/GPU x {args.frames} frames {args.size}x{args.size} as one clip batch, "
+                                   "step-2 losses, ONE object scale tied across all clips (one 4-byte all-reduce per step, "
+                                   f"backend {backend}), fused launch sequence replayed from two hipGraphs around the collective",
+                       "clips_per_gpu": C, "parallelism": f"{world * C} clips on {world} ranks, shared scalar"},
+            "roofline": dict(bound="hbm", unit="GB/s", peak=8000.0 * world, achieved=tot * value / 1e9,
+                             frac=tot * value / (8.0e12 * world), kernel="whole iteration", traffic=None,
+                             note="SURVEY 8(d) algorithmic bytes per clip-iteration (cfg3 set) x clip-iterations/s"),
+            "cpu_baseline": None,
+            "shared_scale_final": float(scale[0]), "replicas_identical": same,
+            "first_loss": [e["loss"][0] for e in evo], "final_loss": [e["loss"][-1] for e in evo]}))
+    dist.destroy_process_group()
 
 
 def pose_init_bench(args):
@@ -211,11 +316,15 @@ def main():
     ap.add_argument("--loop", choices=["fused", "graph"], default="fused",
                     help="fused: fixed C-ABI launch sequence (no autograd tape); graph: HOMan.forward + autograd")
     ap.add_argument("--multi-clip", type=int, default=8,
-                    help="rank 0, N=1 only: after the headline run, also time this many clips optimised concurrently "
-                         "on one GPU (one hipGraph + stream per clip; BASELINE cfg4 has 8 clips per GPU); 0 = skip")
+                    help="after the headline run, also time this many clips per GPU optimised as ONE clip batch (one launch "
+                         "per kernel over all clips; BASELINE cfg4 has 8 clips per GPU); 0 = skip")
+    ap.add_argument("--parity-seeds", type=int, default=5,
+                    help="final_loss_parity: number of cfg1 clips (10 frames 128^2, 100 steps) run on both the HIP loop and "
+                         "the CPU oracle; 0 = skip")
     ap.add_argument("--shared-scale", action="store_true",
-                    help="BASELINE cfg5: step-2 losses with ONE object scale shared by all clips of all ranks (one "
-                         "4-byte all-reduce per step, homan_amd.dist); eager autograd loop, reported under 'cfg5'")
+                    help="BASELINE cfg5 instead of the headline: --multi-clip clips per GPU as one clip batch, step-2 losses, "
+                         "ONE object scale tied across all clips of all ranks (one 4-byte all-reduce per step inside the "
+                         "fused loop)")
     ap.add_argument("--pose-init", type=int, default=0, metavar="N",
                     help="SURVEY 8f rank 1 instead of the headline: one find_optimal_pose fit = N candidate poses of the "
                          "bottle against one 256x256 instance mask, --steps Adam steps (reference default 50); prints "
@@ -283,89 +392,104 @@ def main():
     B, S = args.frames, args.size
     F, V = clip["objfaces"].shape[1], clip["objvertices"].shape[1]
 
-    # --- roofline of the dominant kernel: the two silhouette kernels are timed live with HIP events on the launch
-    #     stream (after the timed loop, on the final state of the clip); the slower one is reported as dominant
+    # --- roofline of the dominant kernel, measured INSIDE the loop: the same iteration issued launch by launch on the real
+    #     HIP streams (not from the captured graph: ROCm has no timing events inside graphs), with HIP events recorded by the
+    #     library on the launch stream around k_raster_fwd / k_bwd_lines / k_bwd_sweep (hm_debug_sil_timing); the hand-side
+    #     stream overlaps them exactly as in the graph, and the clip is in the steady state the timed region left it in
     roof = None
-    if rank == 0:
+    if rank == 0 and args.loop == "fused":
+        import ctypes
         from homan_amd import lib as hlib
-        sctx = model.losses.sil_ctx
-        verts = model.get_verts_object()[0].detach().contiguous()
-        pooled = torch.empty(B, S, S, device="cuda")
-        out2 = torch.empty(2, device="cuda")
-        gv = torch.empty(B, V, 3, device="cuda")
-        one = torch.ones(1, device="cuda")
-        reps = 50
-        ms = torch.zeros(3)
-        rc = hlib.lib().hm_bench_sil_kernels(
-            hlib.ptr(verts), hlib.ptr(sctx.faces), hlib.ptr(model.camintr_rois_object), B, V, F, S,
-            hlib.ptr(model.keep_mask_object), hlib.ptr(model.ref_mask_object), hlib.ptr(model.losses.keep_sum),
-            hlib.ptr(pooled), hlib.ptr(out2), hlib.ptr(sctx.work_order), hlib.ptr(sctx.adj_off),
-            hlib.ptr(sctx.adj_items), hlib.ptr(sctx.face_order), hlib.ptr(one), hlib.ptr(gv), hlib.ptr(sctx.workspace), reps, ms.data_ptr(),
-            hlib.stream())
-        hlib.check(rc, "hm_bench_sil_kernels")
+        L = hlib.lib()
+        reps = max(10, min(50, args.steps))
+        ms3 = (ctypes.c_float * 3)()
+        acc = [0.0, 0.0, 0.0]
+        hlib.check(L.hm_debug_sil_timing(1), "hm_debug_sil_timing")
+        for _ in range(reps):
+            stepper.forward_backward(log=False)
+            stepper.opt.step(zero_grad=False)
+            hlib.check(L.hm_debug_sil_timing_read(ctypes.cast(ms3, ctypes.c_void_p)), "hm_debug_sil_timing_read")
+            torch.cuda.synchronize()
+            for i in range(3):
+                acc[i] += ms3[i]
+        hlib.check(L.hm_debug_sil_timing(0), "hm_debug_sil_timing")
         kb = kernel_bytes(B, S, F)
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("per_launch_bytes", {})
+        pmc = {}
+        ppath = os.path.join(ROOT, "profiles", "r02_pmc_loop.json")
+        if os.path.exists(ppath):
+            pj = json.load(open(ppath))
+            if pj.get("shape") == dict(frames=B, rend_size=S, faces=int(F), step2=bool(args.step2)):
+                pmc = pj.get("per_launch", {})      # measured on the same shapes, same steady-state loop
         per = {}
-        for i, name in enumerate(("k_raster_fwd", "k_bwd_sweep", "k_bwd_lines")):
-            sec = ms[i].item() * 1e-3
-            per[name] = dict(avg_launch_us=sec * 1e6, algorithmic_bytes=kb[name], achieved_GBps=kb[name] / sec / 1e9,
-                             traffic_bytes=traffic.get(name))
+        for i, name in enumerate(("k_raster_fwd", "k_bwd_lines", "k_bwd_sweep")):
+            sec = acc[i] / reps * 1e-3
+            rec = dict(avg_launch_us=sec * 1e6, algorithmic_bytes=kb[name], achieved_GBps=kb[name] / sec / 1e9)
+            c = pmc.get(name, {})
+            if c:
+                rec["traffic_bytes"] = c.get("traffic_bytes")
+                if c.get("SQ_INSTS_VALU"):
+                    # VALU issue roof: a wave64 VALU instruction occupies its SIMD16 for 4 cycles -> 1024 SIMDs x 2.4 GHz / 4
+                    rec["valu_wave_instr"] = c["SQ_INSTS_VALU"]
+                    rec["valu_frac"] = c["SQ_INSTS_VALU"] / (sec * 1024 * 2.4e9 / 4)
+            per[name] = rec
         dom = max(per, key=lambda k: per[k]["avg_launch_us"])
         tot = algorithmic_bytes(B, S, F, V, args.step2)["total"]
         roof = dict(bound="hbm", kernel=dom, achieved=per[dom]["achieved_GBps"], peak=8000.0, unit="GB/s",
-                    frac=per[dom]["achieved_GBps"] / 8000.0, traffic=per[dom]["traffic_bytes"],
-                    avg_launch_us=per[dom]["avg_launch_us"], kernels=per,
+                    frac=per[dom]["achieved_GBps"] / 8000.0, traffic=per[dom].get("traffic_bytes"),
+                    avg_launch_us=per[dom]["avg_launch_us"], valu_frac=per[dom].get("valu_frac"),
+                    timing=f"HIP events on the launch stream around each kernel, inside {reps} iterations of the loop issued "
+                           "launch by launch after the timed region (same streams, same overlap, steady state)",
+                    traffic_source=("profiles/r02_pmc_loop.json (rocprofv3 --pmc passes over the steady-state loop, "
+                                    "tools/pmc_loop.sh)" if per[dom].get("traffic_bytes") else None),
+                    kernels=per,
                     whole_iteration=dict(algorithmic_bytes=tot, achieved_GBps=tot * (args.steps / elapsed) / 1e9,
                                          frac=tot * (args.steps / elapsed) / 8.0e12))
 
     multi = None
     if args.multi_clip > 1 and args.loop == "fused":
-        # BASELINE config 4 in miniature: `multi_clip` independent clips per GPU (one optimiser each), every rank its own
-        # set, no collective; aggregate = all clips of all ranks / the slowest rank's time
+        # BASELINE config 4 in miniature: `multi_clip` independent clips per GPU as ONE clip batch (homan_amd.clipbatch):
+        # every kernel is launched once per iteration over all the clips (per-clip normalisers, Adam state, log rows), the
+        # whole batched iteration is one hipGraph; every rank its own set, no collective; aggregate = all clips of all
+        # ranks / the slowest rank's time.  Bit-identical to optimising the clips one by one (tests/test_clip_batch_gpu.py).
         C, msteps = args.multi_clip, min(args.steps, 200)
-        steppers, streams = [stepper], [torch.cuda.Stream()]
-        for i in range(1, C):
+        models = []
+        for i in range(C):
             ci = synth.make_clip(seed=1000 + 100 * rank + i, frames=args.frames, rend_size=args.size, image_size=args.size,
                                  obj="bottle", silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
-            mi = build_model(copy.deepcopy(ci["person_parameters"]), copy.deepcopy(ci["object_parameters"]),
-                             objvertices=ci["objvertices"], objfaces=ci["objfaces"], camintr=ci["camintr"],
-                             optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
-                             sync_metrics=False)
-            steppers.append(FusedStepper(mi, lw, 1e-2, msteps + 10))
-            streams.append(torch.cuda.Stream())
-        steppers[0] = FusedStepper(model, lw, 1e-2, msteps + 10)       # fresh log buffer for clip 0
-
-        def round_robin(n):
-            for _ in range(n):
-                for st, sm in zip(steppers, streams):
-                    with torch.cuda.stream(sm):
-                        st.graph.replay()
-        torch.cuda.synchronize()
-        round_robin(10)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+            models.append(build_model(copy.deepcopy(ci["person_parameters"]), copy.deepcopy(ci["object_parameters"]),
+                                      objvertices=ci["objvertices"], objfaces=ci["objfaces"], camintr=ci["camintr"],
+                                      optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
+                                      sync_metrics=False))
+        bst = FusedStepper(models, lw, 1e-2, msteps + 10)
+        bst.run(10)
+        barrier()
         t1 = time.perf_counter()
-        round_robin(msteps)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        bst.run(msteps)
+        barrier()
         el = time.perf_counter() - t1
         if world > 1:
             tt = torch.tensor([el], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
-        multi = dict(clips=world * C, clips_per_gpu=C, steps_per_clip=msteps, value=world * C * msteps / el,
+        mval = world * C * msteps / el
+        mtot = algorithmic_bytes(B, S, F, V, args.step2)["total"]
+        multi = dict(clips=world * C, clips_per_gpu=C, steps_per_clip=msteps, value=mval,
                      unit="it/s (sum over clips)", ms_per_round=1e3 * el / msteps,
-                     note="independent clips, one captured hipGraph per clip replayed round-robin on its own HIP stream; "
+                     vs_single_clip=mval / (world * args.steps / elapsed),
+                     roofline=dict(bound="hbm", unit="GB/s", peak=8000.0 * world,
+                                   achieved=mtot * mval / 1e9, frac=mtot * mval / (8.0e12 * world),
+                                   note="whole iteration: SURVEY 8(d) algorithmic bytes per clip-iteration x clip-iterations/s"),
+                     note="one clip batch per GPU: ONE launch per kernel over all clips, one hipGraph per iteration; "
                           "max over ranks")
+        del bst, models
 
-    cpu = None
+    cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(clip, lw, mano, args.cpu_budget, rend_size=S, image_size=S)
+        cpu, evo_cpu = cpu_baseline(clip, lw, mano, args.cpu_budget, rend_size=S, image_size=S)
+        parity = dict(cfg2_first_steps=trajectory_parity(evo, evo_cpu),
+                      cfg1=cfg1_parity(mano, seeds=list(range(args.parity_seeds))) if args.parity_seeds > 0 else None,
+                      bar="north_star: 1e-4 relative on losses, 1e-3 mm on final vertices; the hard rasteriser makes the "
+                          "loss piecewise constant in the pose, so trajectories separate once a sample flips (DESIGN.md 2)")
 
     if rank == 0:
         value = world * args.steps / elapsed
@@ -379,7 +503,7 @@ def main():
                        "frames": B, "rend_size": S, "faces": int(F), "clips_per_gpu": 1,
                        "loop": ("fused C-ABI launch sequence" if args.loop == "fused" else "HOMan.forward + autograd") + ", forward+backward+Adam+logging replayed from a hipGraph", "parallelism": f"{world} independent clips"},
             "final_loss": evo["loss"][-1], "first_loss": evo["loss"][0],
-            "roofline": roof, "cpu_baseline": cpu, "multi_clip": multi,
+            "roofline": roof, "cpu_baseline": cpu, "multi_clip": multi, "final_loss_parity": parity,
         }
         print(json.dumps(line))
     if world > 1:

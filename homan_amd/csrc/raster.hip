@@ -1600,6 +1600,12 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
 // several units.  256 items per face on average is ~5x what a mesh filling the image produces; beyond it the sweep stays
 // correct (binary search for a unit's first face, float atomics for the faces past the slot table), only slower.
 static int g_sweep_cap_override = 0;
+// measurement hook (hm_debug_sil_timing): HIP events recorded on the launch stream right before / after the three heavy
+// kernels of the silhouette chain, so a caller that drives the optimisation loop launch by launch (not from a captured
+// graph) reads the duration each kernel had INSIDE the loop, next to whatever runs on the other streams
+static hipEvent_t g_tev[6];
+static int g_timing = 0;
+#define HM_TIME_MARK(k, stream) do { if (g_timing) (void)hipEventRecord(g_tev[k], stream); } while (0)
 static inline size_t sweep_ucap(int B, int F) { return (size_t)B * F * 4 + 1024; }
 static inline size_t sweep_slot_cap(int B, int F) { return sweep_ucap(B, F) + (size_t)B * F; }
 extern "C" {
@@ -1739,11 +1745,13 @@ int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, co
                        faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list, rigid_rot6d, rigid_trans,
                        rigid_scale, rigid_abs, clip_len);
     const bool fused = keep && ref;
+    HM_TIME_MARK(0, stream);
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.planes, bins,
                        w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full, mask_shared,
                        (fused && alpha_full) ? w.gimg : (float*)nullptr);
+    HM_TIME_MARK(1, stream);
     if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            loss_out, (float*)nullptr, clip_len, out_stride);
@@ -1804,8 +1812,11 @@ int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, in
         hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                            mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                            w.planes, clip_len);
+    HM_TIME_MARK(2, stream);
     launch_lines(w, B, F, S, mode, upstream, keep_sum, clip_len, stream);
+    HM_TIME_MARK(3, stream);
     launch_sweep(w, B, F, S, eps, stream);
+    HM_TIME_MARK(4, stream);
     if (grad_verts)
         hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                            adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
@@ -1944,6 +1955,30 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     return hm_launch_status();
 }
 
+// enable != 0: from now on hm_sil_fwd / hm_sil_bwd record HIP events around k_raster_fwd, k_bwd_lines and k_bwd_sweep on
+// their launch stream (do not enable while a stream capture is in progress); 0: stop and release the events.
+int hm_debug_sil_timing(int enable)
+{
+    if (enable && !g_timing) {
+        for (int k = 0; k < 5; ++k)
+            if (hipEventCreate(&g_tev[k]) != hipSuccess) return HM_ERR_LAUNCH;
+        g_timing = 1;
+    } else if (!enable && g_timing) {
+        g_timing = 0;
+        for (int k = 0; k < 5; ++k) (void)hipEventDestroy(g_tev[k]);
+    }
+    return HM_OK;
+}
+// durations (ms) of the LAST timed k_raster_fwd, k_bwd_lines, k_bwd_sweep launches -> ms3 (HOST pointer).  Waits for them.
+int hm_debug_sil_timing_read(float* ms3)
+{
+    HM_CHECK_ARG(ms3 && g_timing);
+    if (hipEventSynchronize(g_tev[4]) != hipSuccess) return HM_ERR_LAUNCH;
+    if (hipEventElapsedTime(ms3, g_tev[0], g_tev[1]) != hipSuccess) return HM_ERR_LAUNCH;
+    if (hipEventElapsedTime(ms3 + 1, g_tev[2], g_tev[3]) != hipSuccess) return HM_ERR_LAUNCH;
+    if (hipEventElapsedTime(ms3 + 2, g_tev[3], g_tev[4]) != hipSuccess) return HM_ERR_LAUNCH;
+    return HM_OK;
+}
 int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream)
 {
     SilWs w = carve((void*)workspace, B, V, F, S);

@@ -32,6 +32,8 @@ _SIGNATURES = {
                                   _I, _VP, _VP]),
     "hm_sil_read_boxes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_debug_occupancy": (_I, [_VP, _VP]),
+    "hm_debug_sil_timing": (_I, [_I]),
+    "hm_debug_sil_timing_read": (_I, [_VP]),
     "hm_debug_read_partials": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_idx_map": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_faces9": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),

@@ -326,6 +326,13 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
                          const int* work_order, const int* adj_off, const int* adj_items, const int* face_order,
                          const float* upstream, float* grad_verts, void* workspace, int reps, float* avg_ms,
                          hipStream_t stream);
+/* hm_debug_sil_timing(1): from then on hm_sil_fwd / hm_sil_bwd record HIP events on their launch stream right before and
+ * after k_raster_fwd, k_bwd_lines and k_bwd_sweep, so a caller that issues the optimisation loop launch by launch (not from
+ * a captured graph) measures the duration each kernel has inside the loop, next to the work of the other streams;
+ * hm_debug_sil_timing_read: durations in ms of the last timed launches {raster, lines, sweep} -> HOST float[3] (waits).
+ * Process-wide; hm_debug_sil_timing(0) releases the events. */
+int hm_debug_sil_timing(int enable);
+int hm_debug_sil_timing_read(float* ms3);
 int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks);
 int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
 

@@ -1,0 +1,59 @@
+"""Times the fused loop on a batch of C cfg2/cfg3 clips (one launch per kernel over C*30 frames) -> one JSON line.
+usage: python tools/bench_clips.py [--clips 8] [--steps 200] [--warmup 20] [--step2] [--sweep-blocks N]"""
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--clips", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--frames", type=int, default=30)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--step2", action="store_true")
+    ap.add_argument("--sweep-blocks", type=int, default=0)
+    ap.add_argument("--no-graph", action="store_true", help="issue the iteration launch by launch instead of replaying a hipGraph")
+    args = ap.parse_args()
+    import torch
+    from homan_amd import lib as hlib
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, build_model
+    from homan_amd.mano_assets import synthetic_mano
+    mano = synthetic_mano(0)
+    sil_fn, hand_fn = synth.hip_clip_fns(mano)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS if args.step2 else synth.STEP1_LOSS_WEIGHTS)
+    models = []
+    for i in range(args.clips):
+        c = synth.make_clip(seed=i, frames=args.frames, rend_size=args.size, image_size=args.size, obj="bottle",
+                            silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+        models.append(build_model(copy.deepcopy(c["person_parameters"]), copy.deepcopy(c["object_parameters"]),
+                                  objvertices=c["objvertices"], objfaces=c["objfaces"], camintr=c["camintr"],
+                                  optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
+                                  sync_metrics=False))
+    if args.sweep_blocks:
+        hlib.lib().hm_tune_sweep_blocks(args.sweep_blocks)
+    total = args.warmup + args.steps
+    st = FusedStepper(models if args.clips > 1 else models[0], lw, 1e-2, total, capture=not args.no_graph)
+    st.run(args.warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st.run(args.steps)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    evo = st.loss_evolution(total)
+    evo = evo if isinstance(evo, list) else [evo]
+    print(json.dumps(dict(clips=args.clips, steps=args.steps, step2=args.step2, frames=args.frames, rend_size=args.size,
+                          faces=int(models[0].faces_object.shape[1]), graph=not args.no_graph, ms_per_round=1e3 * el / args.steps,
+                          its_per_s=args.clips * args.steps / el, us_per_clip_iteration=1e6 * el / args.steps / args.clips,
+                          first_loss=[e["loss"][0] for e in evo], final_loss=[e["loss"][-1] for e in evo])))
+
+
+if __name__ == "__main__":
+    main()

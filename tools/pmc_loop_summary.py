@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Summarise the rocprofv3 --pmc passes of tools/pmc_loop.sh into the JSON bench.py reads (profiles/rNN_pmc_loop.json).
+traffic_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch: the counters are in KB, FETCH_SIZE is doubled as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes for gfx950 (it tallies 128-byte requests at 64 B), WRITE_SIZE is used
+as reported (uncalibrated).  SQ_* cycle counters are quad-cycles summed over all waves / SIMDs."""
+import collections
+import glob
+import json
+import os
+import re
+import sqlite3
+import sys
+
+
+def main(out_dir, last):
+    tab = collections.defaultdict(dict)
+    shape = None
+    for log in sorted(glob.glob(os.path.join(out_dir, "run*.log"))):
+        for line in open(log):
+            if line.startswith("{"):
+                j = json.loads(line)
+                shape = dict(frames=j["frames"], rend_size=j["rend_size"], faces=j["faces"], step2=j["step2"])
+                clips = j["clips"]
+    for db in sorted(glob.glob(os.path.join(out_dir, "*.db"))):
+        c = sqlite3.connect(db)
+        rows = c.execute("select E.name, E.counter_name, E.dispatch_id, sum(E.counter_value) from pmc_events E "
+                         "group by E.dispatch_id, E.counter_name order by E.dispatch_id").fetchall()
+        per = collections.defaultdict(list)
+        for name, cn, _, v in rows:
+            m = re.match(r"(?:void )?(\w+)", name)
+            per[(m.group(1) if m else name, cn)].append(v)
+        for (k, cn), vals in per.items():
+            if k.startswith("k_"):
+                vals = vals[-last:]
+                tab[k][cn] = sum(vals) / len(vals)
+                tab[k]["launches_averaged"] = len(vals)
+    for k, t in tab.items():
+        if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
+            t["traffic_bytes"] = int((2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024)
+    keep = ("k_raster_fwd", "k_bwd_lines", "k_bwd_sweep", "k_setup_faces", "k_mano_fwd", "k_mano_bwd", "k_nn", "k_rigid_bwd")
+    print(json.dumps(dict(note=__doc__.strip(), shape=shape, clips=clips,
+                          per_launch={k: tab[k] for k in keep if k in tab}), indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], int(sys.argv[2]))
