@@ -284,12 +284,19 @@ __device__ __forceinline__ void emit_planes(const Ballots4 cov, const Ballots4 n
 //   4. epilogue: one wave per 8x8 output tile reads its samples back (lane = output pixel, 2x2 samples).
 // Outputs: idx_map (B,is,is) int32; alpha16 (B,is,is/16) u16 bit-plane; pooled (B,S,S);
 // optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4); optional pooled depth.
-#define CAND_CAP 1024      // faces scanned per binning round (<= 2 entries each)
-#define RB_PASS 256        // candidates per record pass (= threads)
+#ifndef CAND_CAP
+#define CAND_CAP 512       // faces scanned per binning round (<= 2 entries each)
+#endif
+#ifndef RB_PASS
+#define RB_PASS 128        // candidates per record pass (<= threads; a region sees ~60 candidates, and LDS is occupancy)
+#endif
 #ifndef HM_PRUNE
 #define HM_PRUNE 1
 #endif
-__global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
+#ifndef RASTER_WPE
+#define RASTER_WPE 6       // waves per SIMD the register budget is sized for (LDS: 25 KB per workgroup = 6 per CU)
+#endif
+__global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_eu(RASTER_WPE, 8))) void k_raster_fwd(
     const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
@@ -297,14 +304,17 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     float* __restrict__ pooled_depth, unsigned short* __restrict__ planes,
     int* __restrict__ bin_cnt, const int* __restrict__ bin_list, unsigned int* __restrict__ done, int reset_bins,
     unsigned char* __restrict__ region_state, int persistent, float* __restrict__ alpha_full, int mask_shared,
-    float* __restrict__ dimg_full)
+    float* __restrict__ dimg_full, const unsigned int* __restrict__ hint)
 {
     __shared__ unsigned long long zb[32 * 32];
     __shared__ int cand[2 * CAND_CAP];
     __shared__ float4 recs[RB_PASS][5];
     __shared__ int ustart[RB_PASS];
+    __shared__ unsigned czn[RB_PASS];           // per candidate: bits of the nearest depth it can produce
+    __shared__ unsigned hz[64];                 // per 4x4 block: largest owner depth (bits) of its 16 samples
+    __shared__ unsigned short uq[RASTER_WAVES][128];   // per wave: far-class units that passed the hidden-block test
     __shared__ int wsum[RASTER_WAVES];
-    __shared__ int cand_n;
+    __shared__ int cand_n[2];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
     const int is = 2 * S, tiles_x = S / HM_TILE, ntiles = tiles_x * tiles_x, regions_x = tiles_x / 2;
     // dispatch order = work_order[block] = (frame << 16 | region): expensive (frame, region) pairs first so that the
@@ -320,19 +330,114 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     const int gy1 = is - 1 - ry * 2 * HM_STILE, gy0 = gy1 - (2 * HM_STILE - 1);
     const float gcx0 = (float)(2 * gx0 + 1 - is) / (float)is, gcx1 = (float)(2 * gx1 + 1 - is) / (float)is;
     const float gcy0 = (float)(2 * gy0 + 1 - is) / (float)is, gcy1 = (float)(2 * gy1 + 1 - is) / (float)is;
+    const bool pow2 = (is & (is - 1)) == 0;
+    const float inv_is = 1.0f / (float)is;       // exact for powers of two
     const unsigned long long zb_empty = ((unsigned long long)__float_as_uint(zfar) << 32) | 0xffffffffull;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) zb[tid + 256 * k] = zb_empty;
 
     int had_any = 0;       // block-uniform: some face overlaps this region
     const uint2* bx = reinterpret_cast<const uint2*>(boxes) + (long)b * F;
     // faces to scan: the bin of this region's super-region (or the whole frame without bins)
     const int nsx = (is + (1 << hm_sr_shift(is)) - 1) >> hm_sr_shift(is);
     const int sr = (gy0 >> hm_sr_shift(is)) * nsx + (gx0 >> hm_sr_shift(is));
+    // the two words every workgroup needs first, requested together: the size of its bin and the state of its outputs
+    unsigned char* rstate = region_state + (long)b * regions_x * regions_x + region;
     const int nscan = bin_cnt ? bin_cnt[b * nsx * nsx + sr] : F;
+    const int rstate0 = persistent ? (int)*rstate : 0;
     const int* scan = bin_cnt ? bin_list + ((long)b * nsx * nsx + sr) * F : nullptr;
+    // An empty bin in front of outputs that already hold the empty pattern: nothing to rasterise, nothing to write (~60 %
+    // of the workgroups of a clip, every iteration) - leave before touching LDS.  (The bin ticket still has to be drawn.)
+    const bool idle = nscan == 0 && rstate0 == 1;
+    if (!idle) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) zb[tid + 256 * k] = zb_empty;
+    }
+    // winding class rasterised FIRST (scheduling hint, see hm_sil_hint_near_winding): on a closed mesh one winding class
+    // holds the camera-facing surface and owns every sample, the other is hidden behind it
+    const int near_w = hint ? (int)(hint[0] & 1u) : 0;
+    // ---- one (candidate, 4x4 block) unit: inside tests, hidden-sample pruning, depth + z-buffer min
+    auto unit_body = [&](const int i, const int k) {
+        const float4 r0 = recs[i][0], r1 = recs[i][1], r4 = recs[i][4];
+        const int fn = __float_as_int(r4.z), pk = __float_as_int(r4.w);
+        const int nbx = (pk >> 6) & 15;
+        const int kby = (k * (pk >> 10)) >> 16;          // k / nbx (k < 64, reciprocal packed by the record builder)
+        const int sx0 = 4 * ((pk & 7) + (k - kby * nbx)), sy0 = 4 * (((pk >> 3) & 7) + kby);
+        // edge by edge (row / column terms of one edge live at a time: the register budget is the kernel's occupancy):
+        // sample (j, c4) is inside iff for every edge !(row term < column term)
+        float Xs[4], Ys[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int xi = gx0 + sx0 + j, yi = gy0 + sy0 + j;
+            // sample positions: (2 i + 1 - is) / is ; a power-of-two `is` makes the product with 1/is the same float as
+            // the IEEE quotient (eight 14-instruction divisions per unit otherwise)
+            const float xn = (float)(2 * xi + 1 - is), yn = (float)(2 * yi + 1 - is);
+            Xs[j] = pow2 ? xn * inv_is : xn / (float)is;
+            Ys[j] = pow2 ? yn * inv_is : yn / (float)is;
+        }
+        unsigned inside = 0xffffu;
+        {
+            const float vx[3] = {r0.x, r0.z, r1.x}, vy[3] = {r0.y, r0.w, r1.y};
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const int e1 = e == 2 ? 0 : e + 1;
+                const float ex = vx[e1] - vx[e], ey = vy[e1] - vy[e];
+                float rv[4], cv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { rv[j] = (Ys[j] - vy[e]) * ex; cv[j] = (Xs[j] - vx[e]) * ey; }
+                unsigned m = 0;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) m |= (rv[j] < cv[c4] ? 0u : 1u) << (4 * j + c4);
+                inside &= m;
+            }
+        }
+        if (inside == 0u) return;
+#if HM_PRUNE
+        // samples already owned by something nearer than the nearest point of this face cannot change (the
+        // interpolated depth is a weighted harmonic mean of the vertex depths; 1e-5 covers its rounding)
+        {
+            const unsigned zn = czn[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (((inside >> (4 * j)) & 0xfu) == 0u) continue;
+                const uint4 ka = *reinterpret_cast<const uint4*>(&zb[(sy0 + j) * 32 + sx0]);
+                const uint4 kb = *reinterpret_cast<const uint4*>(&zb[(sy0 + j) * 32 + sx0 + 2]);
+                unsigned keepm = (zn > ka.y ? 0u : 1u) | (zn > ka.w ? 0u : 2u) | (zn > kb.y ? 0u : 4u) | (zn > kb.w ? 0u : 8u);
+                inside &= ~(0xfu << (4 * j)) | (keepm << (4 * j));
+            }
+            if (inside == 0u) return;
+        }
+#endif
+        const float4 r2 = recs[i][2], r3 = recs[i][3];
+        const float rz0 = r1.z, rz1 = r1.w, rz2 = r2.x;
+        const float iv[9] = {r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w, r4.x, r4.y};
+        const int xb = gx0 + sx0, yb = gy0 + sy0;
+        while (inside) {
+            const int sidx = __ffs((int)inside) - 1;
+            inside &= inside - 1;
+            const int j = sidx >> 2, c4 = sidx & 3;
+            const float xf = (float)(xb + c4), yf = (float)(yb + j);
+            float wgt[3], ws = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                float t = iv[3 * q] * xf;
+                t = t + iv[3 * q + 1] * yf;
+                t = t + iv[3 * q + 2];
+                t = fminf(fmaxf(t, 0.0f), 1.0f);
+                wgt[q] = t;
+                ws += t;
+            }
+            float sum = wgt[0] * rz0;
+            sum = sum + wgt[1] * rz1;
+            sum = sum + wgt[2] * rz2;
+            const float zp = ws / sum;
+            if (zp > znear && zp < zfar)
+                atomicMin(&zb[(sy0 + j) * 32 + sx0 + c4],
+                          ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)fn);
+        }
+    };
     for (int cbase = 0; cbase < nscan; cbase += CAND_CAP) {
-        if (tid == 0) cand_n = 0;
+        if (tid == 0) { cand_n[0] = 0; cand_n[1] = 0; }
         __syncthreads();
         uint2 v[CAND_CAP / 256];
         int vf[CAND_CAP / 256];
@@ -353,166 +458,156 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
                 const bool hit = (m >> var) & 1u;
                 const unsigned long long bal = __ballot(hit);
                 if (bal == 0ull) continue;
+                // the near class fills the candidate array from the front, the far class from the back
+                const int cls = var == near_w ? 0 : 1;
                 int basep = 0;
-                if (lane == 0) basep = atomicAdd(&cand_n, __popcll(bal));
+                if (lane == 0) basep = atomicAdd(&cand_n[cls], __popcll(bal));
                 basep = __builtin_amdgcn_readfirstlane(basep);
-                if (hit) cand[basep + __popcll(bal & ((1ull << lane) - 1ull))] = fi | (var << 30);
+                const int at = basep + __popcll(bal & ((1ull << lane) - 1ull));
+                if (hit) cand[cls ? 2 * CAND_CAP - 1 - at : at] = fi | (var << 30);
             }
         }
         __syncthreads();
-        const int n = cand_n;
-        had_any |= n;
-        for (int e0 = 0; e0 < n; e0 += RB_PASS) {
-            // ---- one thread per candidate: face record + number of 4x4 blocks of (box & region)
-            int units = 0;
-            if (e0 + tid < n) {
-                const int e = cand[e0 + tid];
-                const int fi = e & 0x3fffffff, var = e >> 30;
-                const float* src = faces9 + ((long)b * F + fi) * 9;
-                float f[9];
-                if (var == 0) {
+        had_any |= cand_n[0] | cand_n[1];
+        for (int cls = 0; cls < 2; ++cls) {
+            const int n = cand_n[cls];
+            if (cls == 1 && n > 0) {
+                // hidden-block test for the far class: per 4x4 block, the largest owner depth the near class (and earlier
+                // rounds) left in the z-buffer (zfar while any of its samples is empty)
+                if (tid < 64) hz[tid] = 0u;
+                __syncthreads();
+                const int blk = tid >> 2, row = (blk >> 3) * 4 + (tid & 3), col0 = (blk & 7) * 4;
+                const uint4 ka = *reinterpret_cast<const uint4*>(&zb[row * 32 + col0]);
+                const uint4 kb = *reinterpret_cast<const uint4*>(&zb[row * 32 + col0 + 2]);
+                atomicMax(&hz[blk], max(max(ka.y, ka.w), max(kb.y, kb.w)));
+                __syncthreads();
+            }
+            for (int e0 = 0; e0 < n; e0 += RB_PASS) {
+                // ---- one thread per candidate: face record + number of 4x4 blocks of (box & region)
+                int units = 0;
+                if (tid < RB_PASS && e0 + tid < n) {
+                    const int e = cand[cls ? 2 * CAND_CAP - 1 - (e0 + tid) : e0 + tid];
+                    const int fi = e & 0x3fffffff, var = e >> 30;
+                    const float* src = faces9 + ((long)b * F + fi) * 9;
+                    float f[9];
+                    if (var == 0) {
 #pragma unroll
-                    for (int k = 0; k < 9; ++k) f[k] = src[k];
+                        for (int k = 0; k < 9; ++k) f[k] = src[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) { f[3 * k] = src[3 * (2 - k)]; f[3 * k + 1] = src[3 * (2 - k) + 1]; f[3 * k + 2] = src[3 * (2 - k) + 2]; }
+                    }
+                    float p[3][2];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { p[k][0] = topix(f[3 * k], is); p[k][1] = topix(f[3 * k + 1], is); }
+                    const float inv[9] = {
+                        p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                        p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                        p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+                    const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
+                                      p[1][0] * (p[2][1] - p[0][1]);
+                    // conservative reject: some edge has all four region corners outside by more than the rounding noise
+                    // of the edge function (the function is affine, so its extremes over the region sit at the corners)
+                    bool miss = (den == 0.0f);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const int k1 = (k + 1) % 3;
+                        const float ax = f[3 * k], ay = f[3 * k + 1], ex = f[3 * k1] - ax, ey = f[3 * k1 + 1] - ay;
+                        bool all_out = true;
+                        float mag = 0.f;
+                        float lhs[4], rhs[4];
+#pragma unroll
+                        for (int cnr = 0; cnr < 4; ++cnr) {
+                            const float X = (cnr & 1) ? gcx1 : gcx0, Y = (cnr & 2) ? gcy1 : gcy0;
+                            lhs[cnr] = (Y - ay) * ex;
+                            rhs[cnr] = (X - ax) * ey;
+                            mag = fmaxf(mag, fabsf(lhs[cnr]) + fabsf(rhs[cnr]));
+                        }
+#pragma unroll
+                        for (int cnr = 0; cnr < 4; ++cnr) all_out = all_out && (lhs[cnr] < rhs[cnr] - 1e-5f * mag);
+                        miss = miss || all_out;
+                    }
+                    if (!miss) {
+                        const uint2 u = bx[fi];
+                        const int x0 = u.x & 0x3fff, y0 = (int)(u.x >> 16), x1 = (int)(u.y & 0xffff), y1 = (int)(u.y >> 16);
+                        // region-local 4x4 block range
+                        const int bx0 = (max(x0, gx0) - gx0) >> 2, bx1 = (min(x1, gx1) - gx0) >> 2;
+                        const int by0 = (max(y0, gy0) - gy0) >> 2, by1 = (min(y1, gy1) - gy0) >> 2;
+                        const int nbx = bx1 - bx0 + 1;
+                        units = nbx * (by1 - by0 + 1);
+                        const float rz0 = 1.0f / f[2], rz1 = 1.0f / f[5], rz2 = 1.0f / f[8];
+                        recs[tid][0] = make_float4(f[0], f[1], f[3], f[4]);
+                        recs[tid][1] = make_float4(f[6], f[7], rz0, rz1);
+                        recs[tid][2] = make_float4(rz2, inv[0] / den, inv[1] / den, inv[2] / den);
+                        recs[tid][3] = make_float4(inv[3] / den, inv[4] / den, inv[5] / den, inv[6] / den);
+                        recs[tid][4] = make_float4(inv[7] / den, inv[8] / den, __int_as_float(fi + var * F),
+                                                   __int_as_float(bx0 | (by0 << 3) | (nbx << 6) | (((0x10000 + nbx - 1) / nbx) << 10)));
+                        // nearest depth the face can produce (the interpolated depth is a weighted harmonic mean of the
+                        // vertex depths), with 1e-5 of slack for its rounding: the pruning threshold of its units
+                        czn[tid] = __float_as_uint((1.0f / fmaxf(rz0, fmaxf(rz1, rz2))) * (1.0f - 1e-5f));
+                    }
+                }
+                // ---- exclusive prefix of the unit counts over the workgroup
+                const int incl = hm_wave_scan_incl(units);
+                if (lane == 63) wsum[w] = incl;
+                __syncthreads();
+                int woff = 0, total = 0;
+#pragma unroll
+                for (int k = 0; k < RASTER_WAVES; ++k) {
+                    const int t = wsum[k];
+                    if (k < w) woff += t;
+                    total += t;
+                }
+                if (tid < RB_PASS) ustart[tid] = woff + incl - units;
+                __syncthreads();
+                if (cls == 0) {
+                    // ---- near class: flattened (candidate, block) units, one per thread and trip
+                    for (int u = tid; u < total; u += 256) {
+                        int i = 0;
+#pragma unroll
+                        for (int stp = RB_PASS / 2; stp > 0; stp >>= 1)
+                            if (ustart[i + stp] <= u) i += stp;
+                        unit_body(i, u - ustart[i]);
+                    }
                 } else {
+                    // ---- far class: most units sit behind the near surface.  A wave first tests 64 units against the
+                    // hidden-block depths (one LDS word each) and queues the survivors; the unit body runs on full waves
+                    // of survivors only (a divergent early-out would leave the wave paying for its one visible unit)
+                    int qn = 0;
+                    for (int u0 = 64 * w; u0 < total; u0 += 256) {
+                        const int u = u0 + lane;
+                        bool pass = false;
+                        int ent = 0;
+                        if (u < total) {
+                            int i = 0;
 #pragma unroll
-                    for (int k = 0; k < 3; ++k) { f[3 * k] = src[3 * (2 - k)]; f[3 * k + 1] = src[3 * (2 - k) + 1]; f[3 * k + 2] = src[3 * (2 - k) + 2]; }
-                }
-                float p[3][2];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { p[k][0] = topix(f[3 * k], is); p[k][1] = topix(f[3 * k + 1], is); }
-                const float inv[9] = {
-                    p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
-                    p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
-                    p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
-                const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
-                                  p[1][0] * (p[2][1] - p[0][1]);
-                // conservative reject: some edge has all four region corners outside by more than the rounding noise
-                // of the edge function (the function is affine, so its extremes over the region sit at the corners)
-                bool miss = (den == 0.0f);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int k1 = (k + 1) % 3;
-                    const float ax = f[3 * k], ay = f[3 * k + 1], ex = f[3 * k1] - ax, ey = f[3 * k1 + 1] - ay;
-                    bool all_out = true;
-                    float mag = 0.f;
-                    float lhs[4], rhs[4];
-#pragma unroll
-                    for (int cnr = 0; cnr < 4; ++cnr) {
-                        const float X = (cnr & 1) ? gcx1 : gcx0, Y = (cnr & 2) ? gcy1 : gcy0;
-                        lhs[cnr] = (Y - ay) * ex;
-                        rhs[cnr] = (X - ax) * ey;
-                        mag = fmaxf(mag, fabsf(lhs[cnr]) + fabsf(rhs[cnr]));
+                            for (int stp = RB_PASS / 2; stp > 0; stp >>= 1)
+                                if (ustart[i + stp] <= u) i += stp;
+                            const int k = u - ustart[i];
+                            const int pk = __float_as_int(recs[i][4].w);
+                            const int nbx = (pk >> 6) & 15, kby = (k * (pk >> 10)) >> 16;
+                            const int blk = (((pk >> 3) & 7) + kby) * 8 + (pk & 7) + (k - kby * nbx);
+                            pass = !(czn[i] > hz[blk]);
+                            ent = i | (k << 8);
+                        }
+                        const unsigned long long bal = __ballot(pass);
+                        if (pass) uq[w][qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)ent;
+                        qn += __popcll(bal);
+                        wave_sync();
+                        if (qn >= 64) {
+                            qn -= 64;
+                            const int e = uq[w][qn + lane];
+                            wave_sync();
+                            unit_body(e & 0xff, e >> 8);
+                        }
                     }
-#pragma unroll
-                    for (int cnr = 0; cnr < 4; ++cnr) all_out = all_out && (lhs[cnr] < rhs[cnr] - 1e-5f * mag);
-                    miss = miss || all_out;
+                    if (lane < qn) {
+                        const int e = uq[w][lane];
+                        unit_body(e & 0xff, e >> 8);
+                    }
                 }
-                if (!miss) {
-                    const uint2 u = bx[fi];
-                    const int x0 = u.x & 0x3fff, y0 = (int)(u.x >> 16), x1 = (int)(u.y & 0xffff), y1 = (int)(u.y >> 16);
-                    // region-local 4x4 block range
-                    const int bx0 = (max(x0, gx0) - gx0) >> 2, bx1 = (min(x1, gx1) - gx0) >> 2;
-                    const int by0 = (max(y0, gy0) - gy0) >> 2, by1 = (min(y1, gy1) - gy0) >> 2;
-                    const int nbx = bx1 - bx0 + 1;
-                    units = nbx * (by1 - by0 + 1);
-                    recs[tid][0] = make_float4(f[0], f[1], f[3], f[4]);
-                    recs[tid][1] = make_float4(f[6], f[7], 1.0f / f[2], 1.0f / f[5]);
-                    recs[tid][2] = make_float4(1.0f / f[8], inv[0] / den, inv[1] / den, inv[2] / den);
-                    recs[tid][3] = make_float4(inv[3] / den, inv[4] / den, inv[5] / den, inv[6] / den);
-                    recs[tid][4] = make_float4(inv[7] / den, inv[8] / den, __int_as_float(fi + var * F),
-                                               __int_as_float(bx0 | (by0 << 8) | (nbx << 16)));
-                }
+                __syncthreads();
             }
-            // ---- exclusive prefix of the unit counts over the workgroup
-            const int incl = hm_wave_scan_incl(units);
-            if (lane == 63) wsum[w] = incl;
-            __syncthreads();
-            int woff = 0, total = 0;
-#pragma unroll
-            for (int k = 0; k < RASTER_WAVES; ++k) {
-                const int t = wsum[k];
-                if (k < w) woff += t;
-                total += t;
-            }
-            ustart[tid] = woff + incl - units;
-            __syncthreads();
-            // ---- flattened (candidate, block) units
-            for (int u = tid; u < total; u += 256) {
-                int i = 0;
-#pragma unroll
-                for (int stp = RB_PASS / 2; stp > 0; stp >>= 1)
-                    if (ustart[i + stp] <= u) i += stp;
-                const int k = u - ustart[i];
-                const float4 r0 = recs[i][0], r1 = recs[i][1], r2 = recs[i][2], r3 = recs[i][3], r4 = recs[i][4];
-                const int fn = __float_as_int(r4.z), pk = __float_as_int(r4.w);
-                const int nbx = pk >> 16;
-                const int kby = k / nbx;
-                const int sx0 = 4 * ((pk & 0xff) + (k - kby * nbx)), sy0 = 4 * (((pk >> 8) & 0xff) + kby);
-                const float f0 = r0.x, f1 = r0.y, f3 = r0.z, f4 = r0.w, f6 = r1.x, f7 = r1.y;
-                const float e0x = f3 - f0, e0y = f4 - f1, e1x = f6 - f3, e1y = f7 - f4, e2x = f0 - f6, e2y = f1 - f7;
-                float rowv[4][3], colv[4][3], xfv[4], yfv[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int xi = gx0 + sx0 + j, yi = gy0 + sy0 + j;
-                    const float X = (float)(2 * xi + 1 - is) / (float)is, Y = (float)(2 * yi + 1 - is) / (float)is;
-                    xfv[j] = (float)xi;
-                    yfv[j] = (float)yi;
-                    rowv[j][0] = (Y - f1) * e0x; rowv[j][1] = (Y - f4) * e1x; rowv[j][2] = (Y - f7) * e2x;
-                    colv[j][0] = (X - f0) * e0y; colv[j][1] = (X - f3) * e1y; colv[j][2] = (X - f6) * e2y;
-                }
-                unsigned inside = 0;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-                        const bool in = !((rowv[j][0] < colv[c4][0]) || (rowv[j][1] < colv[c4][1]) || (rowv[j][2] < colv[c4][2]));
-                        inside |= (in ? 1u : 0u) << (4 * j + c4);
-                    }
-                if (inside == 0u) continue;
-                const float rz0 = r1.z, rz1 = r1.w, rz2 = r2.x;
-#if HM_PRUNE
-                // samples already owned by something nearer than the nearest point of this face cannot change (the
-                // interpolated depth is a weighted harmonic mean of the vertex depths; 1e-5 covers its rounding)
-                {
-                    const unsigned zn = __float_as_uint((1.0f / fmaxf(rz0, fmaxf(rz1, rz2))) * (1.0f - 1e-5f));
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (((inside >> (4 * j)) & 0xfu) == 0u) continue;
-                        const uint4 ka = *reinterpret_cast<const uint4*>(&zb[(sy0 + j) * 32 + sx0]);
-                        const uint4 kb = *reinterpret_cast<const uint4*>(&zb[(sy0 + j) * 32 + sx0 + 2]);
-                        unsigned keepm = (zn > ka.y ? 0u : 1u) | (zn > ka.w ? 0u : 2u) | (zn > kb.y ? 0u : 4u) | (zn > kb.w ? 0u : 8u);
-                        inside &= ~(0xfu << (4 * j)) | (keepm << (4 * j));
-                    }
-                    if (inside == 0u) continue;
-                }
-#endif
-                const float iv[9] = {r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w, r4.x, r4.y};
-                const int xb = gx0 + sx0, yb = gy0 + sy0;
-                while (inside) {
-                    const int sidx = __ffs((int)inside) - 1;
-                    inside &= inside - 1;
-                    const int j = sidx >> 2, c4 = sidx & 3;
-                    const float xf = (float)(xb + c4), yf = (float)(yb + j);
-                    float wgt[3], ws = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        float t = iv[3 * q] * xf;
-                        t = t + iv[3 * q + 1] * yf;
-                        t = t + iv[3 * q + 2];
-                        t = fminf(fmaxf(t, 0.0f), 1.0f);
-                        wgt[q] = t;
-                        ws += t;
-                    }
-                    float sum = wgt[0] * rz0;
-                    sum = sum + wgt[1] * rz1;
-                    sum = sum + wgt[2] * rz2;
-                    const float zp = ws / sum;
-                    if (zp > znear && zp < zfar)
-                        atomicMin(&zb[(sy0 + j) * 32 + sx0 + c4],
-                                  ((unsigned long long)__float_as_uint(zp) << 32) | (unsigned)fn);
-                }
-            }
-            __syncthreads();
         }
     }
     __syncthreads();
@@ -531,8 +626,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
     // An empty region whose outputs already hold the empty pattern has nothing to write: ~60 % of the regions of a clip
     // are background in every iteration, and their epilogues (loads of the loss inputs, ~6 KB of stores) were a quarter
     // of the kernel.  Only valid when the caller keeps passing the same output / loss-input buffers (`persistent`).
-    unsigned char* rstate = region_state + (long)b * regions_x * regions_x + region;
-    if (persistent && !had_any && *rstate == 1) return;
+    if (persistent && !had_any && rstate0 == 1) return;
     __syncthreads();          // every thread has read the state before thread 0 rewrites it below
     if (tid == 0) *rstate = (persistent && !had_any) ? 1 : 0;
 
@@ -620,7 +714,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) void k_raster_fwd(
         }
     } else if (partials) {
         const long pm = mask_shared ? (long)r * S + c : po;
-        const float kp = keep[pm], rf = ref[pm];
+        const float kp = keep[pm], rf = ref[pm];      // (requesting them at kernel start was measured: no gain, +3 registers)
         const float image = kp * pool;
         const float diff = image - rf;
         dimg[po] = kp * diff;
@@ -1015,6 +1109,9 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
 }
 
 // ---------------------------------------------------------------- backward, pass 2b: edge sweeps (see the work list above)
+#ifdef SWEEP_STATS
+__device__ unsigned long long g_sweep_n[8];      // items, geo, act0, act1, on0, on1, pairs, units
+#endif
 #ifdef SWEEP_TIMING
 __device__ unsigned long long g_sweep_t[8];
 #define SWT_MARK(k) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) swt[k] += t_ - swt_last; swt_last = t_; }
@@ -1176,6 +1273,14 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                 nbp[ph] = on[ph] ? (int)rt[ph].z + __popcll(wt & (~0ull >> (63 - (rto[ph] & 63)))) - lo[ph] : 0;
             }
             const int nb0 = nbp[0], nb1 = nbp[1];
+#ifdef SWEEP_STATS
+            {
+                const unsigned long long c[7] = {__popcll(__ballot(mine)), __popcll(__ballot(geo)), __popcll(__ballot(act0)),
+                                                 __popcll(__ballot(act1)), __popcll(__ballot(nb0 > 0)), __popcll(__ballot(nb1 > 0)),
+                                                 (unsigned long long)hm_wave_scan_incl(nb0 + nb1)};
+                if (lane == 63) { for (int k = 0; k < 7; ++k) atomicAdd(&g_sweep_n[k], c[k]); atomicAdd(&g_sweep_n[7], 1ull); }
+            }
+#endif
             // ---- the pairs of the 64 items, flattened over the wave
             const int n = nb0 + nb1;
             const int incl = hm_wave_scan_incl(n);
@@ -1750,7 +1855,7 @@ int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, co
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.planes, bins,
                        w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full, mask_shared,
-                       (fused && alpha_full) ? w.gimg : (float*)nullptr);
+                       (fused && alpha_full) ? w.gimg : (float*)nullptr, w.counter + 24);
     HM_TIME_MARK(1, stream);
     if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
@@ -1766,6 +1871,16 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
     return hm_sil_fwd_clips(verts, faces, faces_bstride, K, B, V, F, S, orig_size, znear, zfar, keep, ref, keep_sum, pooled,
                             loss_out, work_order, pooled_depth, alpha_full, mask_shared, rigid_rot6d, rigid_trans,
                             rigid_scale, rigid_abs, persistent_outputs, workspace, 0, 0, stream);
+}
+
+// Scheduling hint, no effect on results: which winding class of the mesh (0: faces as stored, 1: reversed copies of
+// fill_back) holds the camera-facing surface.  The forward rasterises that class first and tests the units of the other
+// class against per-block hidden depths before doing any per-sample work: on a closed mesh the far class owns nothing.
+// Stored in the workspace (stream-ordered 4-byte write); the zero-filled default is class 0.
+int hm_sil_hint_near_winding(void* workspace, int winding, hipStream_t stream)
+{
+    HM_CHECK_ARG(workspace && (winding == 0 || winding == 1));
+    return hipMemsetAsync((char*)workspace + 24 * 4, winding, 1, stream) == hipSuccess ? HM_OK : HM_ERR_LAUNCH;
 }
 
 // The loss / IoU reduction of a forward that was called with keep/ref but loss_out == NULL: the backward does not
@@ -1931,7 +2046,8 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                            w.partials, work_order, w.owned, (float*)nullptr, w.planes, bins, w.bin_list,
-                           w.bin_done, cold ? 1 : 0, w.region_state, 1, (float*)nullptr, 0, (float*)nullptr);      // steady state of a fixed loop: background regions skipped
+                           w.bin_done, cold ? 1 : 0, w.region_state, 1, (float*)nullptr, 0, (float*)nullptr,
+                           w.counter + 24);      // steady state of a fixed loop: background regions skipped
     }
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
@@ -1985,6 +2101,16 @@ int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, fl
     return hipMemcpyAsync(out, w.partials, (size_t)B * (S / 8) * (S / 8) * 16, hipMemcpyDeviceToDevice, stream) == hipSuccess
                ? HM_OK : HM_ERR_LAUNCH;
 }
+#ifdef SWEEP_STATS
+int hm_debug_sweep_stats(unsigned long long* out)
+{
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_n), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_n), z, sizeof(z));
+    return HM_OK;
+}
+#endif
 #ifdef SWEEP_TIMING
 int hm_debug_sweep_timing(unsigned long long* out)
 {

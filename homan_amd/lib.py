@@ -19,6 +19,7 @@ _SIGNATURES = {
     "hm_sil_fwd": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP,
                         _VP, _I, _I, _VP, _VP]),
     "hm_sil_parts": (_VP, [_VP, _I, _I, _I, _I]),
+    "hm_sil_hint_near_winding": (_I, [_VP, _I, _VP]),
     "hm_tune_sweep_blocks": (_I, [_I]),
     "hm_debug_sweep_caps": (_I, [_I]),
     "hm_shade_rgb": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _VP, _F, _F, _VP, _VP, _VP, _VP]),
@@ -97,7 +98,7 @@ def lib():
     """Load libhoman_amd.so (after torch, so the HIP runtime already in the process is reused)."""
     global _LIB
     if _LIB is None:
-        path = _build.LIB_PATH
+        path = os.environ.get("HOMAN_AMD_LIB", _build.LIB_PATH)      # (A/B runs of kernel variants: tools/ab_build.sh)
         if not os.path.exists(path):
             raise HomanAmdError(
                 f"{path} not found: build it with `python -m homan_amd.build` (hipcc, gfx950). "

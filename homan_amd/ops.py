@@ -78,6 +78,13 @@ class SilhouetteContext:
         order = np.argsort(-cnt.reshape(-1), kind="stable")
         b_idx, region = np.divmod(order, n * n)
         self.work_order = torch.from_numpy(((b_idx << 16) | region).astype(np.int32)).to(self.workspace.device)
+        # winding class that owns the samples (the camera-facing surface of a closed mesh): rasterised first, the other
+        # class is then rejected block-wise behind it
+        idx = self.idx_map()
+        near = int(((idx >= self.F).sum() > ((idx >= 0) & (idx < self.F)).sum()).item())
+        _lib.check(_lib.lib().hm_sil_hint_near_winding(_lib.ptr(self.workspace), near, _lib.stream()),
+                   "hm_sil_hint_near_winding")
+        self.near_winding = near
         # (the edge sweeps keep the natural face order: sorting faces by box perimeter was measured slower -- it scatters
         #  neighbouring faces, and with them the cache lines of the index map and the mask planes they share)
         self.face_order = None

@@ -125,6 +125,10 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
                const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
                float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
                const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, hipStream_t stream);
+/* scheduling hint (no reference counterpart, no effect on results): winding class (0: faces as stored, 1: the reversed
+ * copies of fill_back) that holds the camera-facing surface of the mesh rendered on this workspace.  hm_sil_fwd rasterises
+ * it first and rejects the units of the other class against per-block hidden depths before any per-sample work. */
+int hm_sil_hint_near_winding(void* workspace, int winding, hipStream_t stream);
 /* deferred loss / IoU reduction of an hm_sil_fwd called with keep/ref but loss_out == NULL (off the critical path) */
 int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss_out, float* frame_out, void* workspace,
                   hipStream_t stream);       /* frame_out (B,2) optional: per-frame {sum of squares, IoU}; loss_out may be NULL then */
