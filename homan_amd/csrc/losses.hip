@@ -252,6 +252,10 @@ __global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__
     const int b = blockIdx.x, clip = b / clip_len;
     counter += (long)clip * HM_RED_WS_FLOATS;
     const float* k = camintr + b * 9;
+    // the 2 x 9 block reductions (six extrema + three sums per mesh) meet in LDS behind ONE barrier: wave results by DPP,
+    // then the per-wave values combined in wave order (the order hm_block_sum uses, so the sums are the same floats)
+    __shared__ float s_red[2][9][RED_THREADS / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float box[2][4], zr[2][2], cen[2][3];
     for (int which = 0; which < 2; ++which) {
         const float* v = which == 0 ? vo + (long)b * Vo * 3 : vh + (long)b * Vh * 3;
@@ -274,15 +278,34 @@ __global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__
             zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
             sx += x; sy += y; sz += z;
         }
-        umin = hm_block_min(umin, red); umax = hm_block_max(umax, red);
-        vmin = hm_block_min(vmin, red); vmax = hm_block_max(vmax, red);
-        zmin = hm_block_min(zmin, red); zmax = hm_block_max(zmax, red);
-        sx = hm_block_sum(sx, red); sy = hm_block_sum(sy, red); sz = hm_block_sum(sz, red);
-        const float cx = (umin + umax) / 2.0f, cy = (vmin + vmax) / 2.0f;
-        const float ex = (umax - umin) / 2.0f * (1.0f + expansion), ey = (vmax - vmin) / 2.0f * (1.0f + expansion);
-        box[which][0] = cx - ex; box[which][1] = cy - ey; box[which][2] = cx + ex; box[which][3] = cy + ey;
-        zr[which][0] = zmin; zr[which][1] = zmax;
-        cen[which][0] = sx / (float)V; cen[which][1] = sy / (float)V; cen[which][2] = sz / (float)V;
+        const float r9[9] = {hm_wave_min(umin), hm_wave_max(umax), hm_wave_min(vmin), hm_wave_max(vmax), hm_wave_min(zmin),
+                             hm_wave_max(zmax), hm_wave_sum(sx), hm_wave_sum(sy), hm_wave_sum(sz)};
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) s_red[which][q][wv] = r9[q];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int which = 0; which < 2; ++which) {
+            const int V = which == 0 ? Vo : Vh;
+            float t[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                float a = q < 6 ? s_red[which][q][0] : 0.f;
+                for (int i = q < 6 ? 1 : 0; i < nw; ++i) {
+                    const float x = s_red[which][q][i];
+                    a = q >= 6 ? a + x : ((q & 1) ? fmaxf(a, x) : fminf(a, x));
+                }
+                t[q] = a;
+            }
+            const float cx = (t[0] + t[1]) / 2.0f, cy = (t[2] + t[3]) / 2.0f;
+            const float ex = (t[1] - t[0]) / 2.0f * (1.0f + expansion), ey = (t[3] - t[2]) / 2.0f * (1.0f + expansion);
+            box[which][0] = cx - ex; box[which][1] = cy - ey; box[which][2] = cx + ex; box[which][3] = cy + ey;
+            zr[which][0] = t[4]; zr[which][1] = t[5];
+            cen[which][0] = t[6] / (float)V; cen[which][1] = t[7] / (float)V; cen[which][2] = t[8] / (float)V;
+        }
     }
     if (threadIdx.x == 0) {
         // compute_iou(box_obj, box_hand)
