@@ -879,6 +879,8 @@ struct SweepFace {            // 64 B: one face of the flattened work list
     unsigned short cum[12];   // inclusive item counts of the families, family = winding*6 + edge*2 + axis
 };
 #define SWEEP_PASS_FACES 16   // faces of a unit staged in LDS at a time (a unit with more takes several passes)
+#define SWEEP_USHIFT 8         // a unit = 256 consecutive items of the global list (see k_bwd_sweep)
+#define SWEEP_UNIT (1 << SWEEP_USHIFT)
 struct SweepItem { float x, c0, c1; int base0, base1, nb0, fn, meta; };   // meta: face | t0<<4 | t1<<7 | use0<<10 | use1<<11
 struct SweepList {
     SweepFace* tab; int* offs; unsigned int* ufirst; unsigned int* tickets; float* upart;
@@ -971,11 +973,11 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const 
         tot_i += s_wsum[k][0];
         tot_f += s_wsum[k][1];
     }
-    // A block's items start on a unit boundary (its total is padded to a multiple of 64): which items share a unit, and
+    // A block's items start on a unit boundary (its total is padded to a multiple of SWEEP_UNIT): which items share a unit, and
     // so the order in which every sum below is formed, depends only on the block's own faces - never on the order in
     // which the blocks drew their bases.  Items in the padding belong to no face.
     if (tid == 0)
-        s_base = tot_f ? atomicAdd(sl.cnt, ((unsigned long long)tot_f << 32) | (unsigned)((tot_i + 63) & ~63)) : 0ull;
+        s_base = tot_f ? atomicAdd(sl.cnt, ((unsigned long long)tot_f << 32) | (unsigned)((tot_i + SWEEP_UNIT - 1) & ~(SWEEP_UNIT - 1))) : 0ull;
     __syncthreads();
     const unsigned long long base = s_base;
     int off = (int)(base & 0xffffffffull) + pre_i + inc_i - n;
@@ -988,7 +990,7 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const 
         if (nk[k] > 0) {
             SweepFace rec;
             const int nn = sweep_face_record(bf, faces9, boxes, owned, F, is, rec);
-            const int u_lo = off >> 6, u_hi = (off + nn - 1) >> 6;
+            const int u_lo = off >> SWEEP_USHIFT, u_hi = (off + nn - 1) >> SWEEP_USHIFT;
             const bool over = u_hi >= sl.ucap || u_hi + idx >= sl.slot_cap;
             rec.off = off;
             rec.flags = over ? 1 : 0;
@@ -999,7 +1001,8 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const 
             for (int q = 0; q < 4; ++q) t4[q] = r4[q];
             sl.offs[idx] = off;
             sl.tickets[idx] = 0u;
-            for (int u = (off + 63) >> 6; (u << 6) < off + nn && u < sl.ucap; ++u) sl.ufirst[u] = (unsigned)idx;
+            for (int u = (off + SWEEP_UNIT - 1) >> SWEEP_USHIFT; (u << SWEEP_USHIFT) < off + nn && u < sl.ucap; ++u)
+                sl.ufirst[u] = (unsigned)idx;
             off += nn;
             ++idx;
         }
@@ -1042,7 +1045,8 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    int ncomp, int fpt, const float* __restrict__ faces9,
                                                    const FaceBox* __restrict__ boxes,
                                                    const unsigned char* __restrict__ owned, int F,
-                                                   float* __restrict__ parts, SweepList sl, int clip_len)
+                                                   float* __restrict__ parts, SweepList sl, int clip_len,
+                                                   unsigned short* __restrict__ lsum)
 {
     __shared__ unsigned long long s_w[16][SWEEP_CUMW];
     __shared__ int s_ex[16][SWEEP_CUMW];
@@ -1071,6 +1075,20 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     // line record: {64 mask bits, number of set bits before them} per word, one 16-byte load for a sweep end point and
     // one cache line per line of up to 512 samples
     if (valid && l < wpl) lrec[L * wpl + l] = make_uint4((unsigned)mine, (unsigned)(mine >> 32), (unsigned)excl, 0u);
+    // line summary for the sweeps' early-out, 8 bytes per (line, plane) at lsum[(((b*2 + axis)*is + d0)*2 + pl)*4 ..]:
+    // {first set position, last set position + 1 (0: empty line), mask of the non-empty 64-sample words}: an item whose sweep
+    // range cannot reach a set bit never looks further
+    {
+        int lo = mine ? 64 * l + __builtin_ctzll(mine) : 0xffff, hi = mine ? 64 * l + 64 - __builtin_clzll(mine) : 0;
+        lo = min(lo, __builtin_amdgcn_update_dpp(0xffff, lo, 0x111, 0xf, 0xf, false)); hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false));
+        lo = min(lo, __builtin_amdgcn_update_dpp(0xffff, lo, 0x112, 0xf, 0xf, false)); hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, false));
+        lo = min(lo, __builtin_amdgcn_update_dpp(0xffff, lo, 0x114, 0xf, 0xf, false)); hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, false));
+        lo = min(lo, __builtin_amdgcn_update_dpp(0xffff, lo, 0x118, 0xf, 0xf, false)); hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, false));
+        const unsigned wm = (unsigned)(__ballot(mine != 0ull) >> (16 * (grp & 3))) & 0xffffu;
+        if (valid && l == 15)       // row_shr scans: lane 15 of the row holds the row's result
+            *reinterpret_cast<uint2*>(lsum + ((((long)b * 2 + axis) * is + d0) * 2 + pl) * 4) =
+                make_uint2((unsigned)lo | ((unsigned)hi << 16), wm);
+    }
     s_w[grp][l] = mine;
     s_ex[grp][l] = excl;
     __syncthreads();
@@ -1112,20 +1130,62 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
 #ifdef SWEEP_STATS
 __device__ unsigned long long g_sweep_n[8];      // items, geo, act0, act1, on0, on1, pairs, units
 #endif
-#ifdef SWEEP_TIMING
-__device__ unsigned long long g_sweep_t[8];
-#define SWT_MARK(k) { const unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) swt[k] += t_ - swt_last; swt_last = t_; }
-#else
-#define SWT_MARK(k)
-#endif
+// geometry of item j of face record fc: which (winding, edge, axis) family, which line d0r, where the edge crosses it
+struct SweepGeo {
+    int var, edge, axis, d0r, dir, a_in, a_out;
+    float p00, p01, p10, p11, p20, p21, num, d1_cross;
+    bool geo;
+};
+__device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, bool mine, int is)
+{
+    SweepGeo q;
+    int fam = 0;
+#pragma unroll
+    for (int stp = 8; stp > 0; stp >>= 1)
+        if ((int)fc.cum[fam + stp - 1] <= j) fam += stp;      // fam + stp - 1 <= 11, and cum[11] > j
+    const int fstart = fam ? (int)fc.cum[fam - 1] : 0;
+    q.var = fam >= 6 ? 1 : 0;
+    const int ci = fam - 6 * q.var;
+    q.edge = ci >> 1;
+    q.axis = ci & 1;
+    int v0 = q.edge, v1 = q.edge == 2 ? 0 : q.edge + 1, v2 = q.edge == 0 ? 2 : q.edge - 1;
+    if (q.var) { v0 = 2 - v0; v1 = 2 - v1; v2 = 2 - v2; }
+    const float* pa = q.axis ? fc.py : fc.px;      // coordinate along which the lines are counted
+    const float* pb = q.axis ? fc.px : fc.py;      // coordinate along the line
+    q.p00 = pa[v0]; q.p01 = pb[v0]; q.p10 = pa[v1]; q.p11 = pb[v1]; q.p20 = pa[v2]; q.p21 = pb[v2];
+    if (q.axis == 0) q.dir = (q.p00 < q.p10) ? -1 : 1;
+    else q.dir = (q.p00 < q.p10) ? 1 : -1;
+    const int d0_from = (int)fmaxf(ceilf(fminf(q.p00, q.p10)), 0.0f);
+    q.num = q.p10 - q.p00;
+    const float slope = (q.p11 - q.p01) / q.num;
+    q.d0r = mine ? d0_from + (j - fstart) : 0;
+    q.d1_cross = slope * ((float)q.d0r - q.p00) + q.p01;
+    bool geo = mine && q.d1_cross > -8.0f && q.d1_cross < (float)is + 8.0f;
+    const int d1_in = geo ? ((q.dir > 0) ? (int)floorf(q.d1_cross) : (int)ceilf(q.d1_cross)) : 0;
+    const int d1_out = d1_in + q.dir;
+    geo = geo && !(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out);
+    q.a_in = geo ? d1_in : 0;
+    q.a_out = geo ? d1_out : 0;
+    q.geo = geo;
+    return q;
+}
+
+// A wave takes UNITS of 256 consecutive items.  Per unit and per pass of <= 16 faces:
+//   stage 1  every item (64 per trip): family + line geometry, then ONE 8-byte load of its line's summary {first / last set
+//            position of both planes} - in the steady state of a fit ~70 % of the items have no source their sweeps could
+//            reach (the bands of disagreement between render and target are thin) and stop here; the others are queued;
+//   stage 2  the queued items, 64 per trip on full waves: owner tests at the edge, line records, the source slices of the
+//            two sweeps, and the (item, source) pairs flattened over the wave as before.
+// Filtering before the expensive half is what the 256-item unit is for: a 64-item unit leaves ~19 survivors, a quarter of a
+// wave, and a divergent early-out saves nothing.  Unit composition depends only on the compaction block the items come from.
 __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
                                                    const SweepSrc* __restrict__ srcs,
                                                    const uint4* __restrict__ lrec, int B, int F, int S,
-                                                   float eps, float* __restrict__ parts)
+                                                   float eps, float* __restrict__ parts,
+                                                   const unsigned short* __restrict__ lsum)
 {
     // LDS copies are padded to an ODD number of dwords (17 / 9): lanes reading the same field of different faces / items
-    // then fall into different banks (64- and 32-byte strides put every second / fourth element on the same bank, and the
-    // kernel is bound by LDS cycles: SQ_LDS_IDX_ACTIVE ~ 90 % of its duration)
+    // then fall into different banks (64- and 32-byte strides put every second / fourth element on the same bank)
     struct FaceLds { SweepFace f; int pad; };
     struct ItemLds { SweepItem it; int pad; };
     __shared__ FaceLds s_face[4][SWEEP_PASS_FACES];
@@ -1133,6 +1193,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
     __shared__ int s_start[4][64];
     __shared__ int s_head[4][256];
     __shared__ ItemLds s_item[4][64];
+    __shared__ unsigned short s_q[4][SWEEP_UNIT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int is = 2 * S;
     const bool pow2 = (is & (is - 1)) == 0;
@@ -1140,10 +1201,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
     const int wpl = is / 64;                    // 64-bit mask words per line
     const unsigned long long tot = sl.total[0];
     const int N = (int)(tot & 0xffffffffull), W = (int)(tot >> 32);
-    const int U = (N + 63) >> 6;
-#ifdef SWEEP_TIMING
-    unsigned long long swt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, swt_last = __builtin_readcyclecounter();
-#endif
+    const int U = (N + SWEEP_UNIT - 1) >> SWEEP_USHIFT;
     // XCD-aware unit assignment: workgroups are dealt to the 8 XCDs round-robin and every XCD has its own L2, while the
     // item list is frame-major.  Each XCD therefore takes one contiguous eighth of the units (~ B/8 whole frames): the
     // index-map lines, line records and source slices of a frame are then fetched into ONE L2 instead of eight (speed
@@ -1153,24 +1211,26 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
     const int u_end = (int)(((long)U * (xcd + 1)) >> 3);
     for (int u = __builtin_amdgcn_readfirstlane((int)(((long)U * xcd) >> 3) + (int)(blockIdx.x >> 3) * 4 + wv); u < u_end;
          u += xwaves) {
+        const int ubeg = u << SWEEP_USHIFT, uend = ubeg + SWEEP_UNIT;
         int first;
         if (u < sl.ucap) first = (int)sl.ufirst[u];
-        else {                                   // beyond the unit table: last face with off <= 64u
+        else {                                   // beyond the unit table: last face with off <= first item of the unit
             int lo = 0, hi = W - 1;
             while (lo < hi) {
                 const int mid = (lo + hi + 1) >> 1;
-                if (sl.offs[mid] <= (u << 6)) lo = mid; else hi = mid - 1;
+                if (sl.offs[mid] <= ubeg) lo = mid; else hi = mid - 1;
             }
             first = lo;
         }
         first = __builtin_amdgcn_readfirstlane(first);
-        const int g = (u << 6) + lane;
-        const int o = first + lane < W ? sl.offs[first + lane] : 0x7fffffff;
-        const int nf = __popcll(__ballot(o < (u << 6) + 64));     // sorted: the faces of this unit are a prefix
-        int e = -1;                                               // my face: last one with off <= g
-        for (int i = 0; i < nf; ++i) e += (__builtin_amdgcn_readlane(o, i) <= g) ? 1 : 0;
-        for (int fb = 0; fb < nf; fb += SWEEP_PASS_FACES) {
-            const int nfp = min(SWEEP_PASS_FACES, nf - fb);
+        for (int fb = 0;; fb += SWEEP_PASS_FACES) {
+            // first items of the pass's faces and of the face behind them (lane 16): sorted, so the faces inside the unit
+            // are a prefix
+            const int o = (lane <= SWEEP_PASS_FACES && first + fb + lane < W) ? sl.offs[first + fb + lane] : 0x7fffffff;
+            const int nfp = __popcll(__ballot(lane < SWEEP_PASS_FACES && o < uend));
+            if (nfp == 0) break;
+            const int it_lo = max(ubeg, __builtin_amdgcn_readlane(o, 0));
+            const int it_hi = min(min(uend, N), __builtin_amdgcn_readlane(o, nfp));     // (lane nfp: next face, or "none")
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < SWEEP_PASS_FACES / 4; ++k) {
@@ -1181,38 +1241,59 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             }
             for (int i = lane; i < SWEEP_PASS_FACES * 6; i += 64) (&s_fg[wv][0][0])[i] = 0.f;
             wave_sync();
-            SWT_MARK(0)
-            const int el = e - fb;
-            bool mine = g < N && el >= 0 && el < nfp;
-            // ---- per-lane item setup (lanes without an item run on harmless in-range addresses and are masked below)
-            const SweepFace& fc = s_face[wv][mine ? el : 0].f;
-            mine = mine && g - fc.off < (int)fc.cum[11];      // (past the last face of a compaction block: padding)
-            const int j = mine ? g - fc.off : 0;
-            int fam = 0;
+            // ---------------- stage 1: which items have a source in reach?  Four trips cover the unit; the summary loads of
+            // all of them are in flight before the first is tested (one dependent round trip per unit, not per trip)
+            int qn = 0;
+            {
+                uint4 sm[4];
+                int s_ain[4], s_aout[4], s_lo[4], s_hi[4], s_ent[4];
+                bool s_geo[4], s_pos[4];
 #pragma unroll
-            for (int stp = 8; stp > 0; stp >>= 1)
-                if ((int)fc.cum[fam + stp - 1] <= j) fam += stp;      // fam + stp - 1 <= 11, and cum[11] > j
-            const int fstart = fam ? (int)fc.cum[fam - 1] : 0;
-            const int var = fam >= 6 ? 1 : 0, ci = fam - 6 * var, edge = ci >> 1, axis = ci & 1;
+                for (int t = 0; t < 4; ++t) {
+                    const int g = it_lo + 64 * t + lane;
+                    int el = -1;                                      // my face: last one of the pass with off <= g
+                    for (int i = 0; i < nfp; ++i) el += (__builtin_amdgcn_readlane(o, i) <= g) ? 1 : 0;
+                    const SweepFace& fc = s_face[wv][max(el, 0)].f;
+                    // (past the last face of a compaction block: padding that belongs to no face)
+                    const bool mine = g < it_hi && el >= 0 && g - fc.off < (int)fc.cum[11];
+                    const SweepGeo q = sweep_item_geo(fc, mine ? g - fc.off : 0, mine, is);
+                    sm[t] = *reinterpret_cast<const uint4*>(lsum + (((long)fc.b * 2 + q.axis) * is + q.d0r) * 8);
+                    s_ain[t] = q.a_in; s_aout[t] = q.a_out; s_geo[t] = q.geo; s_pos[t] = q.dir > 0;
+                    // the inward sweep stays inside the triangle: its extent along the line bounds the range
+                    const float tmin = fminf(q.p01, fminf(q.p11, q.p21)), tmax = fmaxf(q.p01, fmaxf(q.p11, q.p21));
+                    s_lo[t] = q.dir > 0 ? max(0, (int)floorf(fmaxf(tmin, 0.f)) - 1) : q.a_in;
+                    s_hi[t] = q.dir > 0 ? q.a_in : min(is - 1, (int)ceilf(fminf(tmax, (float)is)) + 1);
+                    s_ent[t] = (g - ubeg) | (max(el, 0) << 8);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int min0 = (int)(sm[t].x & 0xffffu), end0 = (int)(sm[t].x >> 16);
+                    const int min1 = (int)(sm[t].z & 0xffffu), end1 = (int)(sm[t].z >> 16);
+                    // outward: plane 0 from the sample just outside the edge to the border (exact)
+                    const bool out_ok = s_pos[t] ? end0 > s_aout[t] : min0 <= s_aout[t];
+                    // inward: plane 1 inside [s_lo, s_hi] (first / last position, then the 64-sample words in between)
+                    const int wlo = s_lo[t] >> 6, whi = s_hi[t] >> 6;
+                    const bool in_ok = s_lo[t] <= s_hi[t] && min1 <= s_hi[t] && end1 > s_lo[t] &&
+                                       ((sm[t].w >> wlo) & ((2u << (whi - wlo)) - 1u)) != 0u;
+                    const bool reach = s_geo[t] && (out_ok || in_ok);
+                    const unsigned long long bal = __ballot(reach);
+                    if (reach) s_q[wv][qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)s_ent[t];
+                    qn += __popcll(bal);
+                }
+            }
+            wave_sync();
+            // ---------------- stage 2: the items that may collect something, 64 per trip
+            for (int s0 = 0; s0 < qn; s0 += 64) {
+            bool mine = s0 + lane < qn;
+            const int ent = mine ? (int)s_q[wv][s0 + lane] : 0;
+            const int g = ubeg + (ent & 0xff), el = ent >> 8;
+            const SweepFace& fc = s_face[wv][el].f;
+            const SweepGeo q = sweep_item_geo(fc, mine ? g - fc.off : 0, mine, is);
+            const int var = q.var, edge = q.edge, axis = q.axis, d0r = q.d0r, dir = q.dir, a_in = q.a_in, a_out = q.a_out;
+            const float p00 = q.p00, p01 = q.p01, p10 = q.p10, p11 = q.p11, p20 = q.p20, p21 = q.p21, num = q.num;
+            const float d1_cross = q.d1_cross;
+            const bool geo = q.geo;
             const int b = fc.b, fn = fc.bf - b * F + var * F;
-            int v0 = edge, v1 = edge == 2 ? 0 : edge + 1, v2 = edge == 0 ? 2 : edge - 1;
-            if (var) { v0 = 2 - v0; v1 = 2 - v1; v2 = 2 - v2; }
-            const float* pa = axis ? fc.py : fc.px;      // coordinate along which the lines are counted
-            const float* pb = axis ? fc.px : fc.py;      // coordinate along the line
-            const float p00 = pa[v0], p01 = pb[v0], p10 = pa[v1], p11 = pb[v1], p20 = pa[v2], p21 = pb[v2];
-            int dir;
-            if (axis == 0) dir = (p00 < p10) ? -1 : 1;
-            else dir = (p00 < p10) ? 1 : -1;
-            const int d0_from = (int)fmaxf(ceilf(fminf(p00, p10)), 0.0f);
-            const float num = p10 - p00;
-            const float slope = (p11 - p01) / num;
-            const int d0r = mine ? d0_from + (j - fstart) : 0;
-            const float d1_cross = slope * ((float)d0r - p00) + p01;
-            bool geo = mine && d1_cross > -8.0f && d1_cross < (float)is + 8.0f;
-            const int d1_in = geo ? ((dir > 0) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross)) : 0;
-            const int d1_out = d1_in + dir;
-            geo = geo && !(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out);
-            const int a_in = geo ? d1_in : 0, a_out = geo ? d1_out : 0;
             const int* idx = idx_map + (long)b * is * is;
             const int idx_in = axis ? idx[(long)d0r * is + a_in] : idx[(long)a_in * is + d0r];
             const int idx_out = axis ? idx[(long)d0r * is + a_out] : idx[(long)a_out * is + d0r];
@@ -1222,10 +1303,6 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             const float c0 = use0 ? num * __builtin_amdgcn_rcpf(p10 - (float)d0r) : 0.f;
             const float c1 = use1 ? num * __builtin_amdgcn_rcpf((float)d0r - p00) : 0.f;
             const bool act0 = geo && idx_in == fn;        // outward: my own sample just inside the edge
-#ifdef SWEEP_TIMING
-            if (__ballot(act0) == 0x12345ull) continue;   // (never) keeps the mark below after the owner loads
-#endif
-            SWT_MARK(1)
             const bool act1 = geo && idx_out < 0;         // inward: only if the sample just outside is empty
             // [0] outward, from the sample just outside the edge to the border; [1] inward, across the triangle
             int rfrom[2], rto[2];
@@ -1237,11 +1314,11 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             rfrom[1] = 0;
             rto[1] = -1;
             if (act1) {                                   // (silhouette edges only: a few per cent of the items)
-                float c2;
-                if (((float)d0r - p00) * ((float)d0r - p20) < 0.0f)
-                    c2 = (p21 - p01) / (p20 - p00) * ((float)d0r - p00) + p01;
-                else
-                    c2 = (p11 - p21) / (p10 - p20) * ((float)d0r - p20) + p21;
+                // crossing of the line with the other edge it meets: one division on selected operands
+                const bool far02 = ((float)d0r - p00) * ((float)d0r - p20) < 0.0f;
+                const float na = far02 ? p21 - p01 : p11 - p21, da = far02 ? p20 - p00 : p10 - p20;
+                const float ba = far02 ? p00 : p20, oa = far02 ? p01 : p21;
+                float c2 = na / da * ((float)d0r - ba) + oa;
                 if (c2 == c2) {
                     c2 = fminf(fmaxf(c2, -4.0f), (float)is + 4.0f);
                     const int lim = (dir > 0) ? (int)ceilf(c2) : (int)floorf(c2);
@@ -1285,7 +1362,6 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             const int n = nb0 + nb1;
             const int incl = hm_wave_scan_incl(n);
             const int npairs = __builtin_amdgcn_readlane(incl, 63);
-            SWT_MARK(2)
             if (npairs > 0) {
                 __builtin_amdgcn_wave_barrier();
                 s_start[wv][lane] = incl - n;
@@ -1298,7 +1374,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                 {
                     const int m0 = var ? 2 - edge : edge, k1 = edge == 2 ? 0 : edge + 1, m1 = var ? 2 - k1 : k1;
                     const int comp = axis ? 0 : 1;         // row sweeps move x, column sweeps move y
-                    it.meta = (mine ? el : 0) | ((2 * m0 + comp) << 4) | ((2 * m1 + comp) << 7) | (use0 ? 1 << 10 : 0) |
+                    it.meta = el | ((2 * m0 + comp) << 4) | ((2 * m1 + comp) << 7) | (use0 ? 1 << 10 : 0) |
                               (use1 ? 1 << 11 : 0) | (nb0 << 12);        // nb0 <= 1024 rides in the upper bits
                 }
                 s_item[wv][lane].it = it;
@@ -1342,19 +1418,19 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                         const int p = min(base + 4 * lane + k, npairs - 1);
                         const int i = max(max(before, m[k]) - 1, 0);
                         const int r = max(p - st[i], 0);
-                        const SweepItem& q = s_item[wv][i].it;
-                        qmeta[k] = q.meta;
+                        const SweepItem& qq = s_item[wv][i].it;
+                        qmeta[k] = qq.meta;
                         const int q_nb0 = qmeta[k] >> 12;
                         ph1[k] = r >= q_nb0;
                         qi[k] = i;
-                        long at = (long)q.base0 + r;
-                        if (ph1[k]) at = (long)q.base1 + (r - q_nb0);
+                        long at = (long)qq.base0 + r;
+                        if (ph1[k]) at = (long)qq.base1 + (r - q_nb0);
                         sc[k] = srcs[at];
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         if (base + 4 * lane + k < npairs) {
-                            const SweepItem& q = s_item[wv][qi[k]].it;
+                            const SweepItem& qq = s_item[wv][qi[k]].it;
                             const int meta = qmeta[k], key = meta & 0x3ff;
                             if (key != cur) {
                                 if (cur >= 0) {
@@ -1367,9 +1443,9 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                                 acc1 = 0.f;
                             }
                             bool take = true;
-                            if (ph1[k]) take = sc[k].owner == q.fn;
+                            if (ph1[k]) take = sc[k].owner == qq.fn;
                             if (take)
-                                sweep_term(ph1[k] ? sc[k].g : -sc[k].g, sc[k].d1, q.x, q.c0, q.c1, (meta & (1 << 10)) != 0,
+                                sweep_term(ph1[k] ? sc[k].g : -sc[k].g, sc[k].d1, qq.x, qq.c0, qq.c1, (meta & (1 << 10)) != 0,
                                            (meta & (1 << 11)) != 0, eps, inv_is, pow2, is, acc0, acc1);
                         }
                     }
@@ -1381,13 +1457,13 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                 }
             }
             wave_sync();
-            SWT_MARK(3)
+            }   // stage-2 trips
             // ---- results of the faces of this pass
             if (lane < nfp) {
                 const SweepFace& ff = s_face[wv][lane].f;
                 const int eg = first + fb + lane;
                 const int off = ff.off, nit = (int)ff.cum[11];
-                const int u_lo = off >> 6, u_hi = (off + nit - 1) >> 6;
+                const int u_lo = off >> SWEEP_USHIFT, u_hi = (off + nit - 1) >> SWEEP_USHIFT;
                 float v[6];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) v[k] = s_fg[wv][lane][k];
@@ -1407,26 +1483,20 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     const unsigned int t = atomicAdd(sl.tickets + eg, 1u);
                     if (t == (unsigned)(u_hi - u_lo)) {
-                        float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        float sacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                         for (int uu = u_lo; uu <= u_hi; ++uu) {
                             const float* rp = sl.upart + ((long)uu + eg) * 6;
 #pragma unroll
-                            for (int k = 0; k < 6; ++k) s[k] += hm_partial_load(rp + k);
+                            for (int k = 0; k < 6; ++k) sacc[k] += hm_partial_load(rp + k);
                         }
 #pragma unroll
-                        for (int k = 0; k < 6; ++k) out[k] = s[k];
+                        for (int k = 0; k < 6; ++k) out[k] = sacc[k];
                     }
                 }
             }
-            SWT_MARK(4)
+            if (nfp < SWEEP_PASS_FACES) break;          // the face behind this pass starts beyond the unit
         }   // face passes
     }   // units
-#ifdef SWEEP_TIMING
-    if (lane == 0) {
-        swt[5] = 1;
-        for (int k = 0; k < 6; ++k) atomicAdd(&g_sweep_t[k], swt[k]);
-    }
-#endif
 }
 
 // ---------------------------------------------------------------- backward, pass 3: vertex gather + projection backward
@@ -1739,6 +1809,7 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
     n += al256((size_t)B * (S / 16) * (S / 16));               // per-region "outputs hold the empty pattern" flags
     n += al256((size_t)B * SR_MAX * F * 4);                    // super-region face lists (worst case: every face in every bin)
     n += al256(4 * (size_t)B * is * (is / 64) * 16);            // per-line records {mask word, sources before it}
+    n += al256((size_t)B * 2 * is * 16);                        // per-line summaries {first, last+1, word mask} x 2 planes
     n += al256(4 * (size_t)B * is * is * sizeof(SweepSrc));     // per-line source arrays (2 planes x 2 orientations)
     n += al256((size_t)B * F * sizeof(SweepFace));              // sweep work list: face records,
     n += al256((size_t)B * F * 4) * 2;                          //   their first items, their tickets,
@@ -1752,7 +1823,7 @@ struct SilWs {
     float* ndc; float* faces9; FaceBox* boxes; int* idx_map; unsigned short* alpha16; float* dimg;
     float* partials; float* gimg; unsigned short* planes; float* parts;
     unsigned char* owned; int* bin_cnt; unsigned int* bin_done; unsigned char* region_state; int* bin_list;
-    uint4* lrec; SweepSrc* srcs;
+    uint4* lrec; SweepSrc* srcs; unsigned short* lsum;
     SweepList sweep;
 };
 static SilWs carve(void* ws, int B, int V, int F, int S)
@@ -1777,6 +1848,7 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.region_state = (unsigned char*)p; p += al256((size_t)B * (S / 16) * (S / 16));
     w.bin_list = (int*)p; p += al256((size_t)B * SR_MAX * F * 4);
     w.lrec = (uint4*)p; p += al256(4 * (size_t)B * is * (is / 64) * 16);
+    w.lsum = (unsigned short*)p; p += al256((size_t)B * 2 * is * 16);
     w.srcs = (SweepSrc*)p; p += al256(4 * (size_t)B * is * is * sizeof(SweepSrc));
     w.sweep.tab = (SweepFace*)p; p += al256((size_t)B * F * sizeof(SweepFace));
     w.sweep.offs = (int*)p; p += al256((size_t)B * F * 4);
@@ -1805,14 +1877,14 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
     const int ncomp = (B / clip_len) * hm_cdiv((long)clip_len * F, 256 * fpt);
     hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
-                       w.owned, F, w.parts, w.sweep, clip_len);
+                       w.owned, F, w.parts, w.sweep, clip_len, w.lsum);
 }
 static int g_sweep_blocks = SWEEP_BLOCKS;
 static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
 {
     const int blocks = max(8, min(hm_cdiv((long)B * F, 2), g_sweep_blocks) & ~7);        // a multiple of 8: see the unit loop
     hipLaunchKernelGGL(k_bwd_sweep, dim3(blocks), dim3(256), 0, stream, w.sweep,
-                       w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts);
+                       w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts, w.lsum);
 }
 
 // Scheduling hint, no effect on results: number of persistent workgroups of the edge-sweep kernel (default 1280 = 5 per
@@ -2108,16 +2180,6 @@ int hm_debug_sweep_stats(unsigned long long* out)
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_n), sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_n), z, sizeof(z));
-    return HM_OK;
-}
-#endif
-#ifdef SWEEP_TIMING
-int hm_debug_sweep_timing(unsigned long long* out)
-{
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_t), sizeof(z));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_t), z, sizeof(z));
     return HM_OK;
 }
 #endif

@@ -188,6 +188,18 @@ class GraphStepper:
         return {k: host[:, i].astype(np.float64).tolist() for i, k in enumerate(self.log.keys)}
 
 
+def _morton_order(verts):
+    """permutation of the (V,3) vertices along a 3-D Morton curve (10 bits per axis): consecutive vertices are neighbours"""
+    v = verts.detach().float().cpu().numpy()
+    lo, hi = v.min(0), v.max(0)
+    q = np.clip(((v - lo) / np.maximum(hi - lo, 1e-12) * 1023.0).astype(np.int64), 0, 1023)
+    code = np.zeros(len(v), np.int64)
+    for bit in range(10):
+        for ax in range(3):
+            code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
+    return torch.from_numpy(np.argsort(code, kind="stable").astype(np.int32))
+
+
 _LOOP_STREAMS = {}
 
 
@@ -292,6 +304,7 @@ class FusedStepper:
         self.rec = f(B, 8)
         self.nn_idx = torch.zeros(B, Vh, dtype=torch.int32, device=dev)
         self.nn_d2 = f(B, Vh)
+        self.obj_order = _morton_order(m.verts_object_og[0]).to(dev)      # spatial sort of the rigid mesh (metric-only search)
         self.pooled = f(B, m.sil_ctx.S, m.sil_ctx.S)
         self.up_sil, self.up_inter = torch.tensor([w["loss_sil_obj"]], device=dev), torch.tensor([w["loss_inter"]], device=dev)
         # static gradient buffers for exactly the parameters that receive gradients in this configuration
@@ -312,7 +325,7 @@ class FusedStepper:
         self.mano_state = torch.empty(self.L.hm_mano_state_bytes(B), dtype=torch.uint8, device=dev)
         self.graph = self.graph_b = None
         self.cap_stream, self.side, self.aux, side = _loop_streams(dev)
-        self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd = (torch.cuda.Event() for _ in range(4))
+        self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd, self.ev_smo = (torch.cuda.Event() for _ in range(5))
         self.reduce_ws_b = ClipReduceWorkspace(dev, C)
         if self.shared_scale:
             self._sync_shared_scale_start()
@@ -398,6 +411,23 @@ class FusedStepper:
         pca, rot, betas, mtr = m.mano_pca_pose, m.mano_rot, m.mano_betas, m.mano_trans
         npca = self.P * CL                       # PCA entries of one clip
         side.wait_stream(main)
+        def aux_block():
+            # the silhouette reduction and the log row run on a third stream, off both chains.  (Only this: HIP stream
+            # capture crashes when two captured streams wait for each other's events in both directions, and the hipGraph
+            # executor maps richer fork patterns onto its hardware queues in orders that serialise the branches -- both
+            # measured.  WHERE this block is issued matters too: issued after the hand-side backward, the executor runs it
+            # behind that chain, +20 us on the iteration.)
+            with torch.cuda.stream(self.aux):
+                self.aux.wait_event(self.ev_fwd)
+                if on["smooth"] and self.smooth_obj_on_main:
+                    self.aux.wait_event(self.ev_smo)         # (that loss value comes from the calling stream here)
+                if on["sil"]:
+                    self.aux.wait_event(self.ev_sil)
+                    ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
+                                             P(sctx.workspace), CL, NS, self.aux.cuda_stream), "sil_reduce")
+                if log:
+                    ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
+                                            self.max_steps, P(self.log_buf), C, self.aux.cuda_stream), "log")
         # ---------------- A: silhouettes forward + backward (the critical chain: nothing else rides it; the object's rigid
         # transform is applied inside the face setup, the other losses get the vertices from the side stream)
         if on["sil"]:
@@ -450,8 +480,10 @@ class FusedStepper:
             if on["con"] or on["inter"]:     # (step-1 sets need it for the logged metric only; moving it to the third
                 # stream was measured: +1 % at one clip, -9 % on an 8-clip batch - the graph executor serialises the fork.
                 # Capturing the hand-side forward kernels BEFORE the silhouette chain: -38 %, same reason.)
-                ck(L.hm_nn_fwd_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx), P(self.nn_d2),
-                                     self._slot("handobj_maxdist"), rws_b, CL, NS, sb), "nn")
+                # (without the contact term only the logged distance is needed: metric-only search)
+                ck(L.hm_nn_fwd_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if on["con"] else None,
+                                     P(self.nn_d2) if on["con"] else None, self._slot("handobj_maxdist"), rws_b, CL, NS,
+                                     P(self.obj_order), sb), "nn")
             if on["con"]:
                 ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
                                           P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws_b, CL, NS, sb),
@@ -462,20 +494,9 @@ class FusedStepper:
                                         NS, sb), "inter")
                 if m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
                     ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb), "inter_bwd")
-            # every forward loss value exists now: the silhouette reduction and the log row run on a third stream, off both
-            # chains.  (Only this: HIP stream capture crashes when two captured streams wait for each other's events in
-            # both directions, and the hipGraph executor maps richer fork patterns onto its hardware queues in orders that
-            # serialise the branches -- both measured.)
-            self.ev_fwd.record(side)
-            with torch.cuda.stream(self.aux):
-                self.aux.wait_event(self.ev_fwd)
-                if on["sil"]:
-                    self.aux.wait_event(self.ev_sil)
-                    ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
-                                             P(sctx.workspace), CL, NS, self.aux.cuda_stream), "sil_reduce")
-                if log:
-                    ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
-                                            self.max_steps, P(self.log_buf), C, self.aux.cuda_stream), "log")
+            self.ev_fwd.record(side)         # every forward loss value of this stream exists now
+            if not self.smooth_obj_on_main:
+                aux_block()
             self.ev_pair.record(side)        # object-side terms of the pair-wise losses are ready
             # hand (full path: MANO + rigid): smooth + v2d + collision + contact, summed with their weights inside the rigid
             # backward; the interaction term reaches the rigid pose only, as one vector per frame (rec[:, 2:5] / Vh)
@@ -498,6 +519,9 @@ class FusedStepper:
             main.wait_event(self.ev_vo)
             ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_a, CL, NS,
                                      sa), "smooth(obj)")
+            self.ev_smo.record(main)
+        if self.smooth_obj_on_main:
+            aux_block()
         main.wait_event(self.ev_pair)
         sc_obj = m.optimize_object_scale
         tp, tw, tn = _lib.terms([(self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),

@@ -608,13 +608,14 @@ def inter_loss(vh, vo, camintr, rws, expansion=0.2, zthresh=3.0):
     return _InterLoss.apply(vh, vo, camintr, expansion, zthresh, rws)
 
 
-def nearest_vertices(vh, vo, rws):
+def nearest_vertices(vh, vo, rws, metric_only=False):
     """hand -> object nearest vertex (no grad): idx (B,Vh) int32, squared distance, and the metric
-    max_b min_{i,j} |h_i - o_j| of reference homan/losses.py:225-241."""
+    max_b min_{i,j} |h_i - o_j| of reference homan/losses.py:225-241.  metric_only: (None, None, metric) - the same exact
+    value from the pruned search."""
     vh, vo = _f32(vh.detach()), _f32(vo.detach())
     B, Vh, Vo = vo.shape[0], vh.shape[1], vo.shape[1]
-    idx = torch.empty(B, Vh, dtype=torch.int32, device=vh.device)
-    d2 = torch.empty(B, Vh, device=vh.device)
+    idx = None if metric_only else torch.empty(B, Vh, dtype=torch.int32, device=vh.device)
+    d2 = None if metric_only else torch.empty(B, Vh, device=vh.device)
     metric = torch.empty(1, device=vh.device)
     _lib.check(_lib.lib().hm_nn_fwd(_lib.ptr(vh), _lib.ptr(vo), B, Vh, Vo, _lib.ptr(idx), _lib.ptr(d2), _lib.ptr(metric),
                                     _lib.ptr(rws.buf), _lib.stream()), "hm_nn_fwd")

@@ -209,7 +209,8 @@ int hm_inter_bwd(const float* frame_rec, const float* upstream, int B, int Vh, i
 
 /* ------------------------------------------------------------------ contact (Chamfer direction hand -> object)
  * reference homan/interactions/contactloss.py:60-79,162-163 (pairwise distances, arg-min over the object) and the
- * metric of homan/losses.py:225-241: metric_out[0] = max_b sqrt(min_ij |h_i - o_j|^2). */
+ * metric of homan/losses.py:225-241: metric_out[0] = max_b sqrt(min_ij |h_i - o_j|^2).  nn_idx = nn_d2 = NULL: metric only
+ * (the same exact value; object-vertex groups that cannot hold the minimum are skipped by a bounding-sphere test). */
 int hm_nn_fwd(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
               float* metric_out, void* workspace, hipStream_t stream);
 /* reference homan/lossutils.py:112-130 -> contactloss.py:149-309 as executed: out1 = mean thresh*tanh(|nn-h|/thresh) */
@@ -309,8 +310,11 @@ int hm_hand_terms_fwd_clips(const float* verts, const float* camintr, int hand_n
 int hm_inter_fwd_clips(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
                        float expansion, float zthresh, float* frame_rec, float* out1, void* workspace, int clip_len,
                        int out_stride, hipStream_t stream);
+/* obj_order (Vo) optional, metric-only calls: a permutation of the object vertices, visited in that order (a spatial sort of
+ * the rigid mesh makes 64 consecutive vertices a compact patch: scheduling only, the result is the exact minimum) */
 int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
-                    float* metric_out, void* workspace, int clip_len, int out_stride, hipStream_t stream);
+                    float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
+                    hipStream_t stream);
 int hm_contact_fwd_clips(const float* verts_hand, const float* verts_obj, const int* nn_idx, int B, int Vh, int Vo,
                          float thresh, float* g_hand, float* g_obj, float* out1, void* workspace, int clip_len,
                          int out_stride, hipStream_t stream);

@@ -146,6 +146,9 @@ def test_inter_and_contact(mano_model):
     _close(bh.grad, b.grad, msg="inter grad obj")
     idx, d2, metric = ops.nearest_vertices(ah, bh, rws)
     np.testing.assert_allclose(metric.item(), mo["handobj_maxdist"], rtol=1e-4)
+    # metric-only search (object-vertex groups pruned by bounding spheres): the very same float
+    assert ops.nearest_vertices(ah, bh, rws, metric_only=True)[2].item() == metric.item()
+    assert float(d2.min(1).values.max().sqrt()) == metric.item()
     # contact
     a, b = vh.clone().requires_grad_(True), vo.clone().requires_grad_(True)
     closed = torch.as_tensor(m["closed_faces"].astype(np.int64))
