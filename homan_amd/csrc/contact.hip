@@ -27,8 +27,7 @@ __device__ __forceinline__ float rl_f(float v, int l)
 __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ vh, const float* __restrict__ vo, int B,
                                                        int Vh, int Vo, int* __restrict__ nn_idx, float* __restrict__ nn_d2,
                                                        float* __restrict__ blockmin, unsigned int* counter,
-                                                       float* __restrict__ metric_out, int clip_len, int out_stride,
-                                                       const int* __restrict__ obj_order)
+                                                       float* __restrict__ metric_out, int clip_len, int out_stride)
 {
     HM_LATENCY_KERNEL();
     __shared__ float s_d[NN_WAVES][NN_HV];
@@ -47,39 +46,10 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
         besti[u] = 0;
     }
     const int share = (Vo + NN_WAVES - 1) / NN_WAVES, jend = min(Vo, (q + 1) * share);
-    // METRIC ONLY (nn_idx == NULL: the step-1 loss sets, where the search feeds nothing but the logged hand-object distance
-    // of reference losses.py:225-241): only the smallest distance of the frame matters, so a group of 64 object vertices is
-    // scanned only if its bounding sphere comes closer to some hand vertex of this wave than the smallest distance found so
-    // far - the closest approach of hand and object is a small neighbourhood, ~85 % of the groups are skipped.  The
-    // result is the exact minimum (the bound carries a 1e-5 margin for its own rounding).
-    const bool metric_only = nn_idx == nullptr;
-    float wave_best = 3.4e38f;         // wave-uniform: min over this wave's hand vertices so far
     for (int j0 = q * share; j0 < jend; j0 += 64) {
         const int n = min(64, jend - j0);
         float ox = 0.f, oy = 0.f, oz = 0.f;
-        if (lane < n) {
-            // (metric only: object vertices visited in a caller-given order - spatially sorted, so that 64 consecutive ones
-            //  are a compact patch with a small bounding sphere)
-            const int jv = (metric_only && obj_order) ? obj_order[j0 + lane] : j0 + lane;
-            const float* p = vo + ((long)b * Vo + jv) * 3;
-            ox = p[0]; oy = p[1]; oz = p[2];
-        }
-        if (metric_only) {
-            const float inv_n = 1.0f / (float)n;
-            const float cx = hm_wave_sum(ox) * inv_n, cy = hm_wave_sum(oy) * inv_n, cz = hm_wave_sum(oz) * inv_n;
-            const float ex = ox - cx, ey = oy - cy, ez = oz - cz;
-            const float rg = sqrtf(hm_wave_max(lane < n ? ex * ex + ey * ey + ez * ez : 0.f));
-            float lb = 3.4e38f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (blockIdx.x * NN_HV + lane + 64 * u < Vh) {
-                    const float dx = cx - hx[u], dy = cy - hy[u], dz = cz - hz[u];
-                    lb = fminf(lb, sqrtf(dx * dx + dy * dy + dz * dz));
-                }
-            }
-            lb = hm_wave_min(lb) - rg;                      // no hand vertex of the wave is closer to the group than this
-            if (lb > 0.f && lb * (1.0f - 1e-5f) > sqrtf(wave_best) * (1.0f + 1e-5f)) continue;
-        }
+        if (lane < n) { const float* p = vo + ((long)b * Vo + j0 + lane) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
         int k = 0;
 #define NN_STEP(K)                                                                                   \
     {                                                                                                \
@@ -95,13 +65,6 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
         for (; k + 4 <= n; k += 4) { NN_STEP(k) NN_STEP(k + 1) NN_STEP(k + 2) NN_STEP(k + 3) }
         for (; k < n; ++k) NN_STEP(k)
 #undef NN_STEP
-        if (metric_only) {
-            float m2 = 3.4e38f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-                if (blockIdx.x * NN_HV + lane + 64 * u < Vh) m2 = fminf(m2, best[u]);
-            wave_best = hm_wave_min(m2);
-        }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) { s_d[q][lane + 64 * u] = best[u]; s_i[q][lane + 64 * u] = besti[u]; }
@@ -117,10 +80,7 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
             const int id = s_i[k][t];
             if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
         }
-        if (i < Vh) {
-            if (nn_idx) { nn_idx[(long)b * Vh + i] = bi; nn_d2[(long)b * Vh + i] = bd; }
-            bm = bd;
-        }
+        if (i < Vh) { nn_idx[(long)b * Vh + i] = bi; nn_d2[(long)b * Vh + i] = bd; bm = bd; }
     }
     bm = hm_block_min(bm, red);
     // per clip (clip_len consecutive frames): its own slice of the reduce workspace, its own ticket, its own metric
@@ -132,6 +92,107 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
     if (hm_last_block(counter, nblk, &s_flag)) {
         // all block minima requested at once (one agent-scope load per thread), then min over a frame's chunks, max over
         // the frames
+        float* s_bm = &s_d[0][0];
+        for (unsigned i2 = threadIdx.x; i2 < nblk; i2 += blockDim.x) s_bm[i2] = hm_partial_load(blockmin + i2);
+        __syncthreads();
+        float mx = -3.4e38f;
+        for (int bb = threadIdx.x; bb < clip_len; bb += blockDim.x) {
+            float m = 3.4e38f;
+            for (unsigned c = 0; c < gridDim.x; ++c) m = fminf(m, s_bm[bb * gridDim.x + c]);
+            mx = fmaxf(mx, sqrtf(m));
+        }
+        mx = hm_block_max(mx, red);
+        if (threadIdx.x == 0) metric_out[(long)clip * out_stride] = mx;
+    }
+}
+
+// METRIC ONLY (the step-1 loss sets, where the search feeds nothing but the logged hand-object distance of reference
+// losses.py:225-241): only the smallest distance of the frame matters.  grid (ceil(Vh/128), B), 4 waves, all holding the
+// same 128 hand vertices (2 per lane).
+//   1. bounding spheres of the groups of 64 object vertices (visited in `obj_order`: a spatial sort of the rigid mesh makes
+//      a group a compact patch), groups dealt to the waves round-robin;
+//   2. per group: the hand vertex nearest to its centre gives an UPPER bound on the frame's minimum (centre distance +
+//      radius: some vertex of the group is at least that close) and a LOWER bound for the group (centre distance - radius);
+//   3. only the groups whose lower bound does not exceed the best upper bound are scanned exactly (same arithmetic as k_nn):
+//      the closest approach of hand and object is a small neighbourhood, typically 2-3 of ~24 groups.
+// The result is the exact minimum (bounds carry a 1e-5 margin for their own rounding); blockmin / ticket / finish as k_nn.
+#define NN_MAX_GROUPS 64
+__global__ __launch_bounds__(64 * NN_WAVES) void k_nn_min(const float* __restrict__ vh, const float* __restrict__ vo, int B,
+                                                           int Vh, int Vo, float* __restrict__ blockmin,
+                                                           unsigned int* counter, float* __restrict__ metric_out,
+                                                           int clip_len, int out_stride, const int* __restrict__ obj_order)
+{
+    HM_LATENCY_KERNEL();
+    __shared__ float s_sph[NN_MAX_GROUPS][4];
+    __shared__ float s_lb[NN_MAX_GROUPS];
+    __shared__ unsigned s_ub;
+    __shared__ int s_list[NN_MAX_GROUPS], s_n;
+    __shared__ float s_d[NN_WAVES][NN_HV];
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int ng = (Vo + 63) >> 6;
+    float hx[2], hy[2], hz[2];
+    bool hv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = blockIdx.x * NN_HV + lane + 64 * u;
+        hv[u] = i < Vh;
+        hx[u] = hy[u] = hz[u] = 0.f;
+        if (hv[u]) { const float* p = vh + ((long)b * Vh + i) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2]; }
+    }
+    if (threadIdx.x == 0) { s_ub = 0x7f7fffffu; s_n = 0; }
+    __syncthreads();
+    // 1 + 2: spheres and bounds of this wave's groups
+    for (int g = q; g < ng; g += NN_WAVES) {
+        const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
+        const float inv_n = 1.0f / (float)n;
+        const float cx = hm_wave_sum(ox) * inv_n, cy = hm_wave_sum(oy) * inv_n, cz = hm_wave_sum(oz) * inv_n;
+        const float ex = ox - cx, ey = oy - cy, ez = oz - cz;
+        const float rg = sqrtf(hm_wave_max(lane < n ? ex * ex + ey * ey + ez * ez : 0.f)) * (1.0f + 1e-5f);
+        float dc = 3.4e38f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (hv[u]) {
+                const float dx = cx - hx[u], dy = cy - hy[u], dz = cz - hz[u];
+                dc = fminf(dc, sqrtf(dx * dx + dy * dy + dz * dz));
+            }
+        dc = hm_wave_min(dc);
+        if (lane == 0) {
+            s_lb[g] = dc * (1.0f - 1e-5f) - rg;
+            atomicMin(&s_ub, __float_as_uint((dc * (1.0f + 1e-5f) + rg)));      // positive floats order like their bits
+        }
+    }
+    __syncthreads();
+    // 3: groups that can hold the minimum
+    if ((int)threadIdx.x < ng && s_lb[threadIdx.x] <= __uint_as_float(s_ub)) s_list[atomicAdd(&s_n, 1)] = threadIdx.x;
+    __syncthreads();
+    const int ns = s_n;
+    float best[2] = {3.4e38f, 3.4e38f};
+    for (int e = q; e < ns; e += NN_WAVES) {
+        const int g = s_list[e];
+        const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
+        for (int k = 0; k < n; ++k) {
+            const float sx = rl_f(ox, k), sy = rl_f(oy, k), sz = rl_f(oz, k);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float dx = sx - hx[u], dy = sy - hy[u], dz = sz - hz[u];
+                best[u] = fminf(best[u], dx * dx + dy * dy + dz * dz);
+            }
+        }
+    }
+    float bm = fminf(hv[0] ? best[0] : 3.4e38f, hv[1] ? best[1] : 3.4e38f);
+    bm = hm_block_min(bm, red);
+    const int clip = b / clip_len, bl = b - clip * clip_len;
+    blockmin += (long)clip * HM_RED_WS_FLOATS;
+    counter += (long)clip * HM_RED_WS_FLOATS;
+    const unsigned nblk = gridDim.x * clip_len;
+    if (threadIdx.x == 0) hm_partial_store(blockmin + bl * gridDim.x + blockIdx.x, bm);
+    if (hm_last_block(counter, nblk, &s_flag)) {
         float* s_bm = &s_d[0][0];
         for (unsigned i2 = threadIdx.x; i2 < nblk; i2 += blockDim.x) s_bm[i2] = hm_partial_load(blockmin + i2);
         __syncthreads();
@@ -223,9 +284,14 @@ int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int 
     const int nchunk = hm_cdiv(Vh, NN_HV);   // 128 hand vertices per workgroup
     const int Bc = clip_len ? clip_len : B;
     if ((long)Bc * nchunk > 512) return HM_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(k_nn, dim3(nchunk, B), dim3(64 * NN_WAVES), 0, stream, verts_hand, verts_obj, B, Vh, Vo, nn_idx,
-                       nn_d2, (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out, Bc, out_stride,
-                       obj_order);
+    if (!nn_idx && Vo <= 64 * NN_MAX_GROUPS)
+        hipLaunchKernelGGL(k_nn_min, dim3(nchunk, B), dim3(64 * NN_WAVES), 0, stream, verts_hand, verts_obj, B, Vh, Vo,
+                           (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out, Bc, out_stride, obj_order);
+    else {
+        if (!nn_idx) return HM_ERR_UNSUPPORTED;     // metric-only search: <= 4096 object vertices
+        hipLaunchKernelGGL(k_nn, dim3(nchunk, B), dim3(64 * NN_WAVES), 0, stream, verts_hand, verts_obj, B, Vh, Vo, nn_idx,
+                           nn_d2, (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out, Bc, out_stride);
+    }
     return hm_launch_status();
 }
 int hm_nn_fwd(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,

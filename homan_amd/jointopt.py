@@ -339,7 +339,8 @@ class FusedStepper:
         if capture:
             # scheduling hint baked into the captured launches: with the collision / contact terms the hand-side stream is
             # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way)
-            prev = _lib.lib().hm_tune_sweep_blocks(768 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
+            sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (768 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
+            prev = _lib.lib().hm_tune_sweep_blocks(sb)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.cap_stream):
                 self.forward_backward(log=True)
