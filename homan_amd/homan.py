@@ -298,9 +298,9 @@ class HOMan(nn.Module):
         if self._depth_state is None:
             size = int(self.image_size)
             masks_o, masks_h = self.masks_object, self.masks_human
-            if tuple(masks_o.shape[1:]) != (size, size) or tuple(masks_h.shape[1:]) != (size, size) or size % 16:
-                raise NotImplementedError("ordinal depth: instance masks must be (B, image_size, image_size) with "
-                                          f"image_size % 16 == 0, got {tuple(masks_o.shape)} / image_size {size}")
+            if tuple(masks_o.shape[1:]) != (size, size) or tuple(masks_h.shape[1:]) != (size, size):
+                raise NotImplementedError("ordinal depth: instance masks must be (B, image_size, image_size), got "
+                                          f"{tuple(masks_o.shape)} / image_size {size}")
             batch = verts_object.shape[0]
             dev = verts_object.device
             ctx_o = ops.SilhouetteContext(self.faces_object, verts_object.shape[1], batch, size, dev)

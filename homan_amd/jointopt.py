@@ -263,6 +263,9 @@ class FusedStepper:
                 raise NotImplementedError("the fused loop does not cover lw_depth > 0: use mode='graph' or 'eager'")
             raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
                             "'masks', 'silhouettes', and 'depths'")
+        if m.sil_ctx.padded:
+            raise NotImplementedError("the fused loop renders the silhouettes at rend_size % 32 == 0 (the reference's "
+                                      "REND_SIZE is 256); other sizes: mode='graph' or 'eager'")
         self.shared_scale, self.group = bool(shared_scale), group
         if self.shared_scale and not m.optimize_object_scale:
             raise ValueError("shared_scale needs models built with optimize_object_scale=True")

@@ -36,6 +36,15 @@ class SilhouetteContext:
         f0 = faces[0].detach().cpu().numpy()
         if batch > 1:
             assert bool((faces == faces[:1]).all()), "per-frame topologies must be identical"
+        # The kernels tile the image in 32x32-pixel blocks (64-sample mask words of the edge sweeps).  Any other image size
+        # (the reference's Core50 setting renders at 350, homan/getdataset.py:35) is rendered on the next multiple of 32
+        # with the first two rows of K scaled by size / padded size: the top-left size x size block of that render shows
+        # exactly the rays of the requested image (same pinhole, coarser normalisation), the rest is cropped away.  Sample
+        # positions then round differently from a native render of that size: coverage agrees up to projection rounding
+        # (tests/test_render_gpu.py), where multiples of 32 are bit-exact against the oracle.
+        self.size = int(size)
+        size = (self.size + 31) // 32 * 32
+        self.padded = size != self.size
         self.B, self.V, self.F, self.S = batch, num_verts, f0.shape[0], size
         self.faces = faces[0].to(device=device, dtype=torch.int32).contiguous()
         off, items = build_adjacency(f0, num_verts)
@@ -51,6 +60,23 @@ class SilhouetteContext:
         self.face_order = None
         nbytes = _lib.lib().hm_sil_workspace_bytes(self.B, self.V, self.F, self.S)
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # holds a self-resetting ticket
+
+    # ---- image sizes that are not a multiple of 32 (see __init__)
+    def K_eff(self, K):
+        if not self.padded:
+            return K
+        K = K.clone()
+        K[:, :2, :] *= self.size / self.S
+        return K.contiguous()
+
+    def crop(self, img):
+        return img[..., :self.size, :self.size].contiguous() if self.padded else img
+
+    def pad(self, img, value=0.0):
+        if not self.padded:
+            return img
+        d = self.S - self.size
+        return torch.nn.functional.pad(img, (0, d, 0, d), value=value).contiguous()
 
     def calibrate(self):
         """Cost-sorted launch orders from the screen boxes of the last forward (poses move little during an
@@ -107,7 +133,8 @@ class _SilhouetteLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, verts, K, keep, ref, keep_sum, sctx, orig_size):
-        verts, K = _f32(verts), _f32(K)
+        verts, K = _f32(verts), sctx.K_eff(_f32(K))
+        keep, ref = sctx.pad(keep), sctx.pad(ref)          # (padding: keep = 0, so it counts for nothing)
         pooled = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
         out = torch.empty(2, device=verts.device)
         _lib.check(_lib.lib().hm_sil_fwd(
@@ -118,6 +145,7 @@ class _SilhouetteLoss(torch.autograd.Function):
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K, keep_sum)
         ctx.sctx, ctx.orig_size = sctx, orig_size
+        pooled = sctx.crop(pooled)
         ctx.mark_non_differentiable(pooled)
         return out[0:1], out[1], pooled
 
@@ -139,7 +167,7 @@ class _SilhouetteRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, verts, K, sctx, orig_size):
-        verts, K = _f32(verts), _f32(K)
+        verts, K = _f32(verts), sctx.K_eff(_f32(K))
         pooled = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
         _lib.check(_lib.lib().hm_sil_fwd(
             _lib.ptr(verts), _lib.ptr(sctx.faces), 0, _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S,
@@ -148,13 +176,13 @@ class _SilhouetteRender(torch.autograd.Function):
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
-        return pooled
+        return sctx.crop(pooled)
 
     @staticmethod
     def backward(ctx, g_img, grad_ndc_out=None):
         verts, K = ctx.saved_tensors
         sctx = ctx.sctx
-        g_img = _f32(g_img)
+        g_img = sctx.pad(_f32(g_img))
         grad_verts = torch.empty_like(verts)
         _lib.check(_lib.lib().hm_sil_bwd(
             _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), NMR_EPS, 0,
@@ -261,7 +289,7 @@ class _DepthRender(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, verts, K, sctx, orig_size):
-        verts, K = _f32(verts), _f32(K)
+        verts, K = _f32(verts), sctx.K_eff(_f32(K))
         pooled = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
         depth = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
         _lib.check(_lib.lib().hm_sil_fwd(
@@ -272,6 +300,7 @@ class _DepthRender(torch.autograd.Function):
             "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
+        pooled, depth = sctx.crop(pooled), sctx.crop(depth)
         ctx.mark_non_differentiable(pooled)
         return pooled, depth
 
@@ -281,7 +310,8 @@ class _DepthRender(torch.autograd.Function):
         sctx = ctx.sctx
         grad_verts = torch.empty_like(verts)
         _lib.check(_lib.lib().hm_depth_bwd(
-            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), _lib.ptr(_f32(g_depth)),
+            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size),
+            _lib.ptr(sctx.pad(_f32(g_depth))),
             _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items), _lib.ptr(grad_verts), _lib.ptr(sctx.workspace),
             _lib.stream()), "hm_depth_bwd")
         return grad_verts, None, None, None
@@ -301,7 +331,7 @@ def render_rgbd(verts, K, sctx, textures, light_direction=(0, 1, 0), intensity_a
     import ctypes
     with torch.no_grad():
         verts, K = _f32(verts.detach()), _f32(K)
-        alpha, depth = _DepthRender.apply(verts, K, sctx, orig_size)
+        alpha, depth = _DepthRender.apply(verts, K, sctx, orig_size)      # (cropped to the requested size)
         tex = _f32(textures.reshape(sctx.B, sctx.F, 3))
         rgb = torch.empty(sctx.B, 3, sctx.S, sctx.S, device=verts.device)
         ld = (ctypes.c_float * 3)(*[float(x) for x in light_direction])
@@ -311,7 +341,7 @@ def render_rgbd(verts, K, sctx, textures, light_direction=(0, 1, 0), intensity_a
                                            float(intensity_ambient), float(intensity_directional),
                                            ctypes.cast(bg, ctypes.c_void_p), _lib.ptr(rgb), _lib.ptr(sctx.workspace),
                                            _lib.stream()), "hm_shade_rgb")
-    return rgb, depth, alpha
+    return sctx.crop(rgb), depth, alpha
 
 
 class _OrdinalDepthLoss(torch.autograd.Function):

@@ -192,11 +192,8 @@ def make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", si
 
     # full-image instance masks (PointRend-like modal masks; only the ordinal depth term reads them): the hand sits
     # in front of the object in this scene, so it owns the overlap
-    if image_size % 16 == 0:
-        full_h = silhouette_fn(verts_hand_gt, hf_t, camintr_nc, image_size).detach().cpu() > 0.5
-        full_o = (silhouette_fn(verts_obj_gt, of_t, camintr_nc, image_size).detach().cpu() > 0.5) & ~full_h
-    else:
-        full_h = full_o = torch.zeros(B, image_size, image_size, dtype=torch.bool)
+    full_h = silhouette_fn(verts_hand_gt, hf_t, camintr_nc, image_size).detach().cpu() > 0.5
+    full_o = (silhouette_fn(verts_obj_gt, of_t, camintr_nc, image_size).detach().cpu() > 0.5) & ~full_h
 
     verts2d = p2d_h + torch.randn(p2d_h.shape, generator=torch_gen)
 

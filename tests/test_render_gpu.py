@@ -121,3 +121,66 @@ def test_optimize_hand_object_saves_frames(mode, mano_model, tmp_path):
     from PIL import Image
     im = np.asarray(Image.open(imgs[4]))
     assert im.shape == (S, 3 * S // 2, 3)       # (frontal over top-down) x 3 frames, halved
+
+
+def test_render_at_350_the_core50_image_size():
+    """reference homan/getdataset.py:35 sets image_size=350 for Core50 and homan/homan.py:168-176 builds the renderer at
+    image_size: not a multiple of 32, rendered on a 352 grid with rescaled intrinsics and cropped (ops.SilhouetteContext).
+    Same rays, different rounding of the sample positions: coverage / depth / colour agree with the oracle's native 350
+    render except on a sliver of boundary samples."""
+    from homan_amd import nmr as hnmr
+    from homan_amd import ops
+    from oracle import nmr as onmr
+    S = 350
+    verts, faces, K, tex = _scene(B=2, S=S)
+    ro = onmr.Renderer(image_size=S, K=K, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
+    rh = hnmr.Renderer(image_size=S, K=K.to(DEV), orig_size=1)
+    rgb_o, dep_o, al_o = ro.render(verts, faces, tex)
+    rgb_h, dep_h, al_h = rh.render(verts.to(DEV), faces.to(DEV), tex.to(DEV))
+    assert tuple(al_h.shape) == (2, S, S) and tuple(rgb_h.shape) == (2, 3, S, S) and tuple(dep_h.shape) == (2, S, S)
+    diff = (al_h.cpu() != al_o)
+    assert float(diff.float().mean()) < 2e-4, float(diff.float().mean())          # boundary samples only
+    assert float((al_h.cpu() - al_o).abs().max()) <= 0.25                          # ... and one sample of four at most
+    same = ~diff
+    np.testing.assert_allclose(dep_h.cpu()[same].numpy(), dep_o[same].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rgb_h.cpu().permute(0, 2, 3, 1)[same].numpy(), rgb_o.permute(0, 2, 3, 1)[same].numpy(), atol=2e-3)
+    assert 0.03 < float(al_o.mean()) < 0.9
+    # the differentiable silhouette at 350: value and NMR pseudo-gradient against the oracle's native 350 render
+    ctx = ops.SilhouetteContext(faces.to(DEV), verts.shape[1], 2, S, DEV)
+    vh = verts.to(DEV).clone().requires_grad_(True)
+    sil_h = ops.silhouette_render(vh, K.to(DEV), ctx)
+    g = torch.Generator().manual_seed(0)
+    w = torch.rand(2, S, S, generator=g) - 0.5
+    (sil_h * w.to(DEV)).sum().backward()
+    vo_ = verts.clone().requires_grad_(True)
+    sil_o = ro(vo_, faces, mode="silhouettes")
+    (sil_o * w).sum().backward()
+    assert tuple(sil_h.shape) == (2, S, S)
+    assert float((sil_h.detach().cpu() != sil_o.detach()).float().mean()) < 2e-4
+    scale = vo_.grad.abs().max().item()
+    assert scale > 0
+    err = (vh.grad.cpu() - vo_.grad).abs().max().item() / scale
+    assert err < 0.05, err      # boundary samples flip between the two grids: a few per cent of the largest entry
+
+
+def test_core50_sized_model_depth_term_and_viz(mano_model):
+    """image_size=350 end to end: HOMan builds, `render` / `visualize_hand_object` work, and the ordinal depth term
+    (reference homan/homan.py:384-419) evaluates and back-propagates at the full-image size."""
+    from homan_amd import synth, visualize
+    from homan_amd.jointopt import build_model
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=2, frames=2, rend_size=64, image_size=350, obj="cube", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                        objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                        optimize_mano=True, image_size=350, mano_model=mano_model, rend_size=64, ordinal_depth=True)
+    imgs, masks = model.render(model.renderer, viz_len=2)
+    assert imgs.shape == (2, 350, 350, 3) and masks.shape == (2, 350, 350) and masks.any()
+    images = (np.random.RandomState(0).rand(2, 350, 350, 3) * 255).astype(np.uint8)
+    front, top = visualize.visualize_hand_object(model, images, viz_len=2)
+    assert front.shape == (2, 350, 350, 3)
+    lw = dict(synth.STEP1_LOSS_WEIGHTS, lw_depth=1.0)
+    loss_dict, _ = model(loss_weights=lw)
+    assert "loss_depth" in loss_dict and torch.isfinite(loss_dict["loss_depth"]).all()
+    sum(loss_dict[k] * lw[k.replace("loss", "lw")] for k in loss_dict).sum().backward()
+    assert torch.isfinite(model.translations_object.grad).all()
