@@ -52,40 +52,33 @@ def get_K_crop_resize(K, boxes, crop_resize):
     return new_K
 
 
+def _centre_and_diagonal(lo, hi):
+    """axis-aligned 2-D boxes given by their corners (n,2) -> centres (n,2), diagonal lengths (n,)"""
+    return (lo + hi) / 2, (hi - lo).norm(dim=-1)
+
+
 def TCO_init_from_boxes_zup_autodepth(boxes_2d, model_points_3d, K):
-    """reference homan/lib3d/optitrans.py:83-127: translation matching the projected box of the points with an xywh box."""
-    model_points_3d = torch.as_tensor(model_points_3d)
-    bsz, device = model_points_3d.shape[0], model_points_3d.device
-    K = torch.as_tensor(K, dtype=torch.float32).to(device)
-    boxes_2d = torch.as_tensor(boxes_2d, dtype=torch.float32).to(device)
-    if boxes_2d.dim() == 1:
-        boxes_2d = boxes_2d.unsqueeze(0)
-    if boxes_2d.shape[0] != bsz:
-        boxes_2d = boxes_2d.repeat(bsz, 1)
-    if K.dim() == 2:
-        K = K.unsqueeze(0)
-    if K.shape[0] != bsz:
-        K = K.repeat(bsz, 1, 1)
-    assert boxes_2d.shape[-1] == 4 and boxes_2d.dim() == 2
-    boxes_2d = torch.stack([boxes_2d[:, 0], boxes_2d[:, 1], boxes_2d[:, 0] + boxes_2d[:, 2],
-                            boxes_2d[:, 1] + boxes_2d[:, 3]], 1)
-    diag_bb = (boxes_2d[:, [2, 3]] - boxes_2d[:, [0, 1]]).norm(2, -1)
-    bb_xy_centers = (boxes_2d[:, [0, 1]] + boxes_2d[:, [2, 3]]) / 2
-    fxfy = K[:, [0, 1], [0, 1]]
-    cxcy = K[:, [0, 1], [2, 2]]
-    z = fxfy.new_ones(bsz, 1)
-    xy_init = ((bb_xy_centers - cxcy) * z) / fxfy
-    trans = torch.cat([xy_init, z], 1)
+    """Translation that makes the projected bounding box of the points match an xywh target box (counterpart of reference
+    homan/lib3d/optitrans.py:83-127, same name so that callers of the reference find it): start on the ray through the
+    box centre at unit depth, then ten fixed-point rounds - rescale the depth by the ratio of the box diagonals, shift
+    x / y by the back-projected offset of the box centres."""
+    pts = torch.as_tensor(model_points_3d).float()
+    n, dev = pts.shape[0], pts.device
+    cam = torch.as_tensor(K, dtype=torch.float32).to(dev).reshape(-1, 3, 3).expand(n, 3, 3)
+    xywh = torch.as_tensor(boxes_2d, dtype=torch.float32).to(dev).reshape(-1, 4).expand(n, 4)
+    target_centre, target_diag = _centre_and_diagonal(xywh[:, :2], xywh[:, :2] + xywh[:, 2:])
+    focal = torch.stack([cam[:, 0, 0], cam[:, 1, 1]], -1)
+    principal = cam[:, :2, 2]
+    depth = torch.ones(n, 1, device=dev)
+    xy = (target_centre - principal) * depth / focal
     for _ in range(10):
-        pts = model_points_3d + trans.unsqueeze(1)
-        hom = K.bmm(pts.transpose(1, 2)).transpose(1, 2)
-        proj_pts = hom[:, :, :2] / hom[:, :, 2:]
-        diag_proj = (proj_pts.min(1)[0] - proj_pts.max(1)[0]).norm(2, -1)
-        proj_xy_centers = (proj_pts.min(1)[0] + proj_pts.max(1)[0]) / 2
-        z = z + z * (diag_proj / diag_bb - 1).unsqueeze(-1)
-        xy_init = xy_init + ((bb_xy_centers - proj_xy_centers) * z) / fxfy
-        trans = torch.cat([xy_init, z], 1)
-    return trans
+        placed = pts + torch.cat([xy, depth], 1)[:, None]
+        hom = placed @ cam.transpose(1, 2)
+        uv = hom[..., :2] / hom[..., 2:]
+        centre, diag = _centre_and_diagonal(uv.amin(1), uv.amax(1))
+        depth = depth * (diag / target_diag)[:, None]           # (= depth + depth * (ratio - 1))
+        xy = xy + (target_centre - centre) * depth / focal
+    return torch.cat([xy, depth], 1)
 
 
 class PoseOptimizer(nn.Module):
@@ -100,34 +93,35 @@ class PoseOptimizer(nn.Module):
             raise RuntimeError("homan_amd.pose_optimization needs an MI355X (ROCm) device; there is no CPU path")
         dev = torch.device("cuda")
         size = int(ref_image.shape[0])
-        if size % 32:
-            raise NotImplementedError(f"the rasteriser needs image sizes that are multiples of 32, got {size}")
-        # (every (N,...) buffer is replicated ON the device: the reference builds the 500-fold copies of the mask on the host
-        #  and uploads ~400 MB per fit, which was two thirds of a whole 50-step fit here)
-        vertices, faces = torch.as_tensor(vertices).float().to(dev), torch.as_tensor(faces).to(dev)
-        self.register_buffer("vertices", vertices.repeat(num_initializations, 1, 1))
-        self.register_buffer("faces", faces.repeat(num_initializations, 1, 1))
-        # Convention for the silhouette-aware loss: -1 = occlusion, 0 = background, 1 = foreground (:66-74)
-        ref_image = np.asarray(ref_image)
-        image_ref = torch.from_numpy((ref_image > 0).astype(np.float32)).to(dev)
-        keep_mask = torch.from_numpy((ref_image >= 0).astype(np.float32)).to(dev)
-        self.register_buffer("image_ref", image_ref.repeat(num_initializations, 1, 1))
-        self.register_buffer("keep_mask", keep_mask.repeat(num_initializations, 1, 1))
+        if size % 64:
+            raise NotImplementedError(f"pose initialisation renders without anti-aliasing on a size/2 tile grid: mask sizes "
+                                      f"must be multiples of 64 (the reference's REND_SIZE is 256), got {size}")
+        # Every per-candidate buffer is ONE device array replicated on the device (the reference builds the 500-fold copies
+        # of the mask on the host and uploads ~400 MB per fit, which was two thirds of a whole 50-step fit here).
+        n = num_initializations
+        tile = lambda t: t.to(dev).repeat(n, *([1] * (t.dim())))          # (…) -> (n, …)
+        self.register_buffer("vertices", tile(torch.as_tensor(vertices).float().reshape(-1, 3)))
+        self.register_buffer("faces", tile(torch.as_tensor(faces).reshape(-1, 3)))
+        # instance mask convention (:66-74): -1 = occluded (not compared), 0 = background, 1 = object
+        mask = torch.as_tensor(np.asarray(ref_image)).float()
+        target, compared = (mask > 0).float(), (mask >= 0).float()
+        self.register_buffer("image_ref", tile(target))
+        self.register_buffer("keep_mask", tile(compared))
         self.pool = torch.nn.MaxPool2d(kernel_size=kernel_size, stride=1, padding=(kernel_size // 2))
-        self.rotations = nn.Parameter(torch.as_tensor(rotation_init).clone().float().to(dev), requires_grad=True)
-        translation_init = torch.as_tensor(translation_init).to(dev)
-        if rotation_init.shape[0] != translation_init.shape[0]:
-            translation_init = translation_init.repeat(num_initializations, 1, 1)
-        self.translations = nn.Parameter(translation_init.clone().float(), requires_grad=True)
-        mask_edge = self.compute_edges(image_ref.unsqueeze(0)).cpu().numpy()
-        edt = distance_transform_edt(1 - (mask_edge > 0)) ** (power * 2)
-        self.register_buffer("edt_ref_edge", torch.from_numpy(edt).float().to(dev).repeat(num_initializations, 1, 1))
+        # candidate poses: 6-D rotations (n,3,2) and translations (n,1,3); a single translation serves every candidate
+        rot0, trans0 = torch.as_tensor(rotation_init).float(), torch.as_tensor(translation_init).float()
+        if trans0.shape[0] != rot0.shape[0]:
+            trans0 = trans0.repeat(n, 1, 1)
+        self.rotations = nn.Parameter(rot0.clone().to(dev), requires_grad=True)
+        self.translations = nn.Parameter(trans0.clone().to(dev), requires_grad=True)
+        # one-way chamfer term: distance transform of the target's edge band, raised to 2 * power (:76-80)
+        band = self.compute_edges(target[None, None].to(dev))[0, 0].cpu().numpy() > 0
+        self.register_buffer("edt_ref_edge", tile(torch.from_numpy(distance_transform_edt(~band) ** (power * 2)).float()))
         if K is None:
             K = torch.tensor([[[1, 0, 0.5], [0, 1, 0.5], [0, 0, 1]]], dtype=torch.float32)
         self.register_buffer("K", torch.as_tensor(K).float().reshape(-1, 3, 3)[:1].clone())
         self.image_size, self.lw_chamfer = size, lw_chamfer
         self.to(dev)
-        n = self.vertices.shape[0]
         self._one = torch.ones(1, device=dev)
         self._keep1, self._ref1 = self.keep_mask[0].contiguous(), self.image_ref[0].contiguous()
         self._K_all = self.K.repeat(n, 1, 1).contiguous()
@@ -144,14 +138,11 @@ class PoseOptimizer(nn.Module):
         k = self.K[0]
         u = k[0, 0] * xn + k[0, 1] * yn + k[0, 2]
         v = 1.0 - (k[1, 0] * xn + k[1, 1] * yn + k[1, 2])
-        coord_xy = torch.stack([2 * (u - 0.5), 2 * (v - 0.5)], -1)
-        coord_z = z.unsqueeze(-1)
-        zeros = torch.zeros_like(coord_z)
-        lower_right = torch.max(coord_xy - 1, zeros).sum(dim=(1, 2))
-        upper_left = torch.max(-1 - coord_xy, zeros).sum(dim=(1, 2))
-        behind = torch.max(-coord_z, zeros).sum(dim=(1, 2))
-        too_far = torch.max(coord_z - NMR_FAR, zeros).sum(dim=(1, 2))
-        return lower_right + upper_left + behind + too_far
+        ndc = torch.stack([2 * (u - 0.5), 2 * (v - 0.5)], -1)            # (n,V,2), on screen iff inside [-1,1]^2
+        relu = torch.nn.functional.relu
+        # hinge on each of the six clipping planes, summed per candidate: right/bottom, left/top, behind the camera, beyond far
+        return (relu(ndc - 1).sum(dim=(1, 2)) + relu(-1 - ndc).sum(dim=(1, 2)) + relu(-z).sum(dim=1) +
+                relu(z - NMR_FAR).sum(dim=1))
 
     def compute_edges(self, silhouette):
         return self.pool(silhouette) - silhouette
