@@ -163,3 +163,57 @@ def test_pseudo_gradient_pulls_the_silhouette_towards_the_target(impl):
         g = vd.grad[0].cpu()
     assert bool((g[:, 0] < 0).all()), g           # move right
     assert bool((g[:, 1] > 0).all()), g           # move up in the image = smaller camera y
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_pseudo_gradient_magnitude_of_a_single_edge(impl):
+    """MAGNITUDE of the NMR pseudo-gradient (Kato et al. 2018, backward of the silhouette) on a case small enough to write
+    down: one triangle whose right edge B-C is vertical at sample position x_e, and an upstream gradient dL/dsilhouette
+    that is -1 on ONE pixel column right of the edge (rows of the middle of the edge), 0 elsewhere.  Only the row sweeps of
+    that edge meet a non-zero gradient: for every sample row d0 crossing the edge, every uncovered sample s right of it with
+    g_s = dL/dpixel / 4 < 0 adds  g_s / (dist + eps)  to an end point e of the edge, dist = (x_s - x_e) * (2 / is) / w_e(d0),
+    w_e = the end point's interpolation weight on that row, eps = 1e-3.  The sum is evaluated here in float64 and pushed
+    through d(NDC x)/d(camera x) = 2 / z."""
+    S, z, eps = 64, 2.0, 1e-3
+    is_ = 2 * S
+    x_e = 0.6 + 0.3 / is_                       # sample position 76.6: the last covered sample of a row is 76
+    A, Bv, C = (0.15, 0.5), (x_e, 0.2), (x_e, 0.8)
+    v = (torch.tensor([[[A[0], A[1], 1.0], [Bv[0], Bv[1], 1.0], [C[0], C[1], 1.0]]]) * z)
+    f = torch.tensor([[[0, 1, 2]]])
+    col, rows = 40, range(24, 40)
+    W = torch.zeros(1, S, S)
+    W[0, rows.start:rows.stop, col] = -1.0
+    if impl == "oracle":
+        from oracle import nmr
+        vv = v.clone().requires_grad_(True)
+        r = nmr.Renderer(image_size=S, K=K_UNIT, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
+        img = r(vv, f, mode="silhouettes")
+        (img * W).sum().backward()
+        g = vv.grad[0].double().numpy()
+    else:
+        from homan_amd import ops
+        dev = torch.device("cuda")
+        sctx = ops.SilhouetteContext(f.to(dev), 3, 1, S, dev)
+        vv = v.to(dev).requires_grad_(True)
+        img = ops.silhouette_render(vv, K_UNIT.to(dev), sctx)
+        (img * W.to(dev)).sum().backward()
+        g = vv.grad[0].double().cpu().numpy()
+        img = img.cpu()
+    assert img[0, 30, 30] == 1 and img[0, 30, col] == 0                     # inside left of the edge, empty at the column
+    px_e = x_e * is_ - 0.5                                                  # sample-space position of the edge
+    py = {1: (1 - Bv[1]) * is_ - 0.5, 2: (1 - C[1]) * is_ - 0.5}            # end points along the sample rows (y is flipped)
+    expected = {}
+    for e, other in ((1, 2), (2, 1)):
+        acc = 0.0
+        for d0 in range(int(np.ceil(min(py.values()))), int(np.floor(max(py.values()))) + 1):
+            row = (is_ - 1 - d0) >> 1
+            if row not in rows:
+                continue
+            w_e = (py[other] - d0) / (py[other] - py[e])
+            for xs in (2 * col, 2 * col + 1):
+                acc += (0.25 * -1.0) / ((xs - px_e) * (2.0 / is_) / w_e + eps)
+        expected[e] = acc * 2.0 / z
+    for e in (1, 2):
+        np.testing.assert_allclose(g[e, 0], expected[e], rtol=2e-4, err_msg=f"vertex {e}")
+        assert expected[e] < 0                                              # gradient descent moves the edge right, into the column
+    assert abs(g[0, 0]) < 1e-7 * abs(expected[1])                           # the apex's edges sweep away from the column

@@ -51,6 +51,29 @@ def test_forward_matches_reference_goldens(name, mano_model):
     assert not (set(rec["state_dict_keys"].tolist()) - sd - viz_only)
 
 
+@pytest.mark.parametrize("name", NAMES)
+def test_pinned_step_matches_reference(name, mano_model):
+    """Per-step pin: the HIP model at the reference loop's parameters after `pin_step` Adam steps vs the reference's own
+    forward / backward there (losses 1e-4 relative = north_star, gradients 2e-3 of the largest entry)."""
+    rec, model, weights, meta = _build_hip(name, mano_model)
+    pinned = {k[4:]: torch.from_numpy(rec[k]).cuda() for k in rec if k.startswith("pin_")}
+    _, unexpected = model.load_state_dict(pinned, strict=False)
+    assert not unexpected
+    loss_dict, metric_dict = model(loss_weights=weights)
+    for k in (k[7:] for k in rec if k.startswith("pinfwd_")):
+        np.testing.assert_allclose(loss_dict[k].detach().cpu().numpy(), rec["pinfwd_" + k], rtol=1e-4, atol=1e-9, err_msg=k)
+    for k in (k[10:] for k in rec if k.startswith("pinmetric_")):
+        np.testing.assert_allclose(metric_dict[k], float(rec["pinmetric_" + k]), rtol=2e-4, err_msg=k)
+    sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict).sum().backward()
+    for k, p in model.named_parameters():
+        ref = rec["pingrad_" + k]
+        if ref.size == 0:
+            assert p.grad is None, k
+            continue
+        scale = max(np.abs(ref).max(), 1e-12)
+        np.testing.assert_allclose(p.grad.cpu().numpy() / scale, ref / scale, atol=2e-3, err_msg=k)
+
+
 @pytest.mark.parametrize("name", ["ref_step1_cube_b4_s64", "ref_step2_cube_b4_s64"])
 def test_short_trajectory_eager_and_graph(name, mano_model):
     """First optimisation steps against the reference loop's loss_evolution, in both loop modes.  The hard

@@ -116,3 +116,52 @@ def test_mano_rot_trans_never_stepped(mano_model):
     np.testing.assert_array_equal(rec["final_mano_rot"], rec["in_mano_rot"])
     np.testing.assert_array_equal(rec["final_mano_trans"], rec["in_mano_trans"])
     assert np.abs(rec["grad_mano_rot"]).max() > 0
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_pinned_step_forward_and_grads(name, mano_model):
+    """Per-step pin: the reference loop's parameters after `pin_step` Adam steps are loaded into the restatement, and ONE
+    forward / backward there must match the reference's own forward / backward at those parameters at single-step
+    tolerance (losses 2e-5, gradients 5e-5 of the largest entry) - no trajectory, hence no chaotic separation to hide in."""
+    rec, model, weights, meta = _build(name, mano_model)
+    assert int(rec["meta_pin_step"]) >= 3
+    pinned = {k[4:]: torch.from_numpy(rec[k]) for k in rec if k.startswith("pin_")}
+    assert any(not np.array_equal(rec["pin_" + k], rec["in_" + k]) for k in ("translations_object", "translations_hand"))
+    missing, unexpected = model.load_state_dict(pinned, strict=False)
+    assert not unexpected
+    loss_dict, metric_dict = model(loss_weights=weights)
+    for k in (k[7:] for k in rec if k.startswith("pinfwd_")):
+        np.testing.assert_allclose(loss_dict[k].detach().numpy(), rec["pinfwd_" + k], rtol=2e-5, atol=1e-9, err_msg=k)
+    for k in (k[10:] for k in rec if k.startswith("pinmetric_")):
+        np.testing.assert_allclose(metric_dict[k], float(rec["pinmetric_" + k]), rtol=2e-5, err_msg=k)
+    sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict).backward()
+    for k, p in model.named_parameters():
+        ref = rec["pingrad_" + k]
+        if ref.size == 0:
+            assert p.grad is None, k
+            continue
+        scale = max(np.abs(ref).max(), 1e-12)
+        np.testing.assert_allclose(p.grad.numpy() / scale, ref / scale, atol=5e-5, err_msg=k)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/homan"),
+                    reason="needs the reference checkout (build container only)")
+def test_committed_golden_regenerates_from_the_reference(tmp_path):
+    """tools/refharness/gen_goldens.py, run now against /root/reference with the current synth generator, reproduces a
+    committed fixture: the goldens are the reference's outputs for today's inputs, not a stale snapshot."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    name = "ref_rigid_cube_b5_s32"
+    env = dict(os.environ, HOMAN_GOLDEN_OUT=str(tmp_path), PYTHONDONTWRITEBYTECODE="1")
+    subprocess.run([sys.executable, os.path.join(root, "tools", "refharness", "gen_goldens.py"), name], check=True, env=env,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
+    new = np.load(tmp_path / (name + ".npz"))
+    old = np.load(os.path.join(util.GOLDEN_DIR, name + ".npz"))
+    assert sorted(new.files) == sorted(old.files)
+    for k in old.files:
+        if k.startswith(("in_", "meta_", "lw_", "state_dict_keys")):
+            np.testing.assert_array_equal(new[k], old[k], err_msg=k)        # inputs: exactly today's generator
+        else:
+            np.testing.assert_allclose(new[k], old[k], rtol=1e-5, atol=1e-7, err_msg=k)      # outputs (thread-count slack)

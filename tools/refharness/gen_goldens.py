@@ -48,7 +48,7 @@ def flat_inputs(clip):
 
 
 def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scale=False,
-             optimize_mano=True, init_steps=0):
+             optimize_mano=True, init_steps=0, pin_step=5):
     shims.set_rend_size(size)
     clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj,
                            silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
@@ -67,7 +67,7 @@ def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scal
     # single forward/backward at the initial state: losses, metrics, grads of every Parameter
     model, _, _ = ref_jointopt.optimize_hand_object(
         copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
-        loss_weights=weights, num_iterations=0 if False else 1, viz_folder=tempfile.mkdtemp(), **common)
+        loss_weights=weights, num_iterations=1, viz_folder=tempfile.mkdtemp(), **common)
     # (the loop above already took one Adam step; rebuild an un-stepped model for the gradient record)
     kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
                         clip["objvertices"], clip["objfaces"])
@@ -98,8 +98,36 @@ def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scal
     for k, v in model.state_dict().items():
         if k in dict(model.named_parameters()) or k.startswith("int_scales"):
             rec["final_" + k] = v.detach().numpy()
-    os.makedirs(OUT, exist_ok=True)
-    np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
+    # per-step pin: the reference loop's parameters after `pin_step` steps, and ONE forward / backward of the
+    # reference model AT those parameters.  A restatement loaded with the same parameters must reproduce these at single-step
+    # tolerance - a semantic error that only shows once the optimiser has moved (Adam state aside) cannot hide behind the
+    # chaotic separation of long trajectories.
+    pin_step = min(pin_step, steps)
+    model_k, _, _ = ref_jointopt.optimize_hand_object(
+        copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+        loss_weights=weights, num_iterations=pin_step, viz_folder=tempfile.mkdtemp(), **common)
+    pinned = {k: v.detach().clone() for k, v in model_k.named_parameters()}
+    at_k = ref_homan.HOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1,
+                           hand_proj_mode="persp", optimize_mano=optimize_mano, optimize_mano_beta=True,
+                           optimize_object_scale=optimize_object_scale, image_size=size,
+                           **collate_inputs(copy.deepcopy(clip["person_parameters"]),
+                                            copy.deepcopy(clip["object_parameters"]), clip["objvertices"],
+                                            clip["objfaces"]))
+    at_k.load_state_dict(pinned, strict=False)
+    ld, md = at_k(loss_weights=weights)
+    sum(ld[k] * weights[k.replace("loss", "lw")] for k in ld).backward()
+    rec["meta_pin_step"] = np.int64(pin_step)
+    for k, v in pinned.items():
+        rec["pin_" + k] = v.numpy()
+    for k, v in ld.items():
+        rec["pinfwd_" + k] = v.detach().numpy()
+    for k, v in md.items():
+        rec["pinmetric_" + k] = np.float64(v)
+    for k, p in at_k.named_parameters():
+        rec["pingrad_" + k] = (p.grad.numpy() if p.grad is not None else np.zeros(0, np.float32))
+    out_dir = os.environ.get("HOMAN_GOLDEN_OUT", OUT)
+    os.makedirs(out_dir, exist_ok=True)
+    np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
     print(name, "loss", evo["loss"][0], "->", evo["loss"][-1])
 
 
