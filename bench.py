@@ -220,7 +220,7 @@ def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
         F, V = int(models[0].faces_object.shape[1]), int(models[0].verts_object_og.shape[1])
         tot = algorithmic_bytes(args.frames, args.size, F, V, True)["total"]
         value = world * C * args.steps / elapsed
-        print(json.dumps({
+        emit({
             "metric": "optimisation iters/sec (30-frame 256^2 clip)", "value": value,
             "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -234,7 +234,7 @@ def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
                              note="SURVEY 8(d) algorithmic bytes per clip-iteration (cfg3 set) x clip-iterations/s"),
             "cpu_baseline": None,
             "shared_scale_final": float(scale[0]), "replicas_identical": same,
-            "first_loss": [e["loss"][0] for e in evo], "final_loss": [e["loss"][-1] for e in evo]}))
+            "first_loss": [e["loss"][0] for e in evo], "final_loss": [e["loss"][-1] for e in evo]})
     dist.destroy_process_group()
 
 
@@ -294,7 +294,7 @@ def pose_init_bench(args):
         ec = time.perf_counter() - t1
         cpu = dict(value=nc * kc / ec, unit="pose-steps/s", cores=int(os.environ.get("OMP_NUM_THREADS", "1")), kind="port",
                    sample=f"{nc} poses x {kc} steps of the same fit ({ec:.1f} s), oracle find_optimal_pose")
-    print(json.dumps({"metric": "object-pose initialisation, pose-steps/sec (N poses x one 256^2 mask)",
+    emit({"metric": "object-pose initialisation, pose-steps/sec (N poses x one 256^2 mask)",
                       "value": n * steps / el, "unit": "pose-steps/s", "n_gpus": 1, "steps": steps, "warmup": 3,
                       "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f32", "data": "synthetic",
@@ -302,10 +302,29 @@ def pose_init_bench(args):
                                              f"{size}x{size} mask, no anti-aliasing, torch Adam + autograd over the "
                                              f"HIP rasteriser, loop = {best}", "poses": n, "rend_size": size,
                                  "pose_steps_per_s_by_loop": {k: n * steps / v for k, v in loops.items()}},
-                      "best_iou": float(iou.max()), "seconds_per_fit": el, "cpu_baseline": cpu}))
+                      "best_iou": float(iou.max()), "seconds_per_fit": el, "cpu_baseline": cpu})
+
+
+_REAL_STDOUT = None
+
+
+def _quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries print there too (RCCL writes its version banner to fd 1 when
+    a process group comes up), so everything but the final line is routed to stderr."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(line) + "\n").encode())
 
 
 def main():
+    _quiet_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
@@ -505,7 +524,7 @@ def main():
             "final_loss": evo["loss"][-1], "first_loss": evo["loss"][0],
             "roofline": roof, "cpu_baseline": cpu, "multi_clip": multi, "final_loss_parity": parity,
         }
-        print(json.dumps(line))
+        emit(line)
     if world > 1:
         dist.destroy_process_group()
 

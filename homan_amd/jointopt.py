@@ -4,7 +4,7 @@
 input `images` are given, a frontal + top-down frame is rendered every `viz_step` iterations and `imgs` maps the
 step to the saved file (reference :158-176); the video export (libyana np2vid, :193-200) is not built.
 
-Two execution modes:
+Execution modes (`mode=`, a homan_amd extension; default "auto" = "fused" when it covers the configuration, else "graph"):
   mode="eager"  the reference's loop verbatim: torch.optim.Adam over the three name-selected groups, per-key
                 `.item()` logging every step (host-synchronous, like the reference).
   mode="fused"  the iteration as a fixed sequence of C-ABI kernel launches without the autograd tape (FusedStepper),
@@ -609,7 +609,14 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
                          camintr=None, hand_proj_mode="persp", optimize_mano=False, optimize_mano_beta=True,
                          optimize_object_scale=False, state_dict=None, fps=24, viz_len=7, image_size=640,
                          # homan_amd extensions
-                         mode="eager", mano_model=None, rend_size=256, ordinal_depth=False):
+                         mode="auto", mano_model=None, rend_size=256, ordinal_depth=False):
+    if mode == "auto":
+        # the fused launch sequence when it covers the configuration (every BASELINE config: the CLI's optimize_mano=1,
+        # optimize_mano_beta, persp, no depth term, silhouettes on a multiple of 32), else the same iteration through
+        # HOMan.forward + autograd in a hipGraph; mode="eager" is the reference's loop verbatim (host sync per logged value)
+        fused_ok = (optimize_mano and optimize_mano_beta and hand_proj_mode == "persp" and rend_size % 32 == 0 and
+                    not (loss_weights or {}).get("lw_depth", 0) > 0)
+        mode = "fused" if fused_ok else "graph"
     model = build_model(person_parameters, object_parameters, class_name, objvertices, objfaces, camintr,
                         hand_proj_mode, optimize_mano, optimize_mano_beta, optimize_object_scale, state_dict,
                         image_size, mano_model, rend_size, sync_metrics=(mode == "eager"), ordinal_depth=ordinal_depth)
@@ -629,7 +636,7 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
             step += chunk
         return model, stepper.loss_evolution(num_iterations), imgs
     if mode != "eager":
-        raise ValueError(f"mode {mode} not in [eager|graph|fused]")
+        raise ValueError(f"mode {mode} not in [auto|eager|graph|fused]")
     optimizer = torch.optim.Adam(parameter_groups(model, lr))
     loss_evolution = defaultdict(list)
     for step in range(num_iterations):

@@ -16,3 +16,4 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
 done
 cd $R
 python tools/pmc_loop_summary.py $O $LAST
+rm -rf $O

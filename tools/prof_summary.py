@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Summarise a rocprofv3 rocpd SQLite database (kernel trace) into the per-kernel table committed under profiles/.
-Usage: python tools/prof_summary.py gpurun_out/prof_x/x_results.db [> profiles/rNN_x.txt]"""
+Usage: python tools/prof_summary.py gpurun_out/prof_x/x_results.db ["profiled command"] [> profiles/rNN_x.txt]"""
 import sqlite3
 import sys
 
 
-def main(path):
+def main(path, cmd=None):
     c = sqlite3.connect(path)
     rows = c.execute(
         "select s.kernel_name, count(*), sum(d.end - d.start), min(d.end-d.start), max(d.end-d.start), "
@@ -16,6 +16,8 @@ def main(path):
     total = sum(r[2] for r in rows)
     span = c.execute("select min(start), max(end) from rocpd_kernel_dispatch").fetchone()
     print(f"# source: {path}")
+    if cmd:
+        print(f"# command: rocprofv3 --kernel-trace --stats -- {cmd}")
     print(f"# kernels: {len(rows)}  dispatches: {sum(r[1] for r in rows)}  sum(kernel time) {total/1e6:.3f} ms  "
           f"trace span {(span[1]-span[0])/1e6:.3f} ms")
     print(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>9s} {'min_us':>8s} {'max_us':>8s} {'%':>6s} "
@@ -27,4 +29,4 @@ def main(path):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1])
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Regenerates the round's evidence under gpurun_out/ on the GPU box (copy what is to be judged into profiles/):
+#   rNN_pmc_loop.json            PMC passes over the steady-state loop (tools/pmc_loop.sh); bench.py reads profiles/rNN_pmc_loop.json
+#   rNN_bench_cfg{2,3,5}.json    bench lines (cfg2 = the driver's default command)
+#   rNN_p_cfg2_headline_*        rocprofv3 --kernel-trace --stats of the headline loop alone: its per-kernel averages are
+#                                the ones bench.py's roofline object must agree with
+#   rNN_p_cfg4_batch8_*          the same for an 8-clip batch
+# usage (GPU box): bash tools/profile_round.sh r02
+R=$(cd "$(dirname "$0")/.." && pwd); N=${1:-r02}; O=$R/gpurun_out; mkdir -p $O
+cd $R
+bash tools/pmc_loop.sh > $O/${N}_pmc_loop.json 2>/dev/null
+cp $O/${N}_pmc_loop.json profiles/${N}_pmc_loop.json
+python bench.py > $O/${N}_bench_cfg2.json 2> $O/${N}_bench_cfg2.err
+python bench.py --step2 --parity-seeds 0 > $O/${N}_bench_cfg3.json 2>/dev/null
+python bench.py --shared-scale --steps 200 > $O/${N}_bench_cfg5_n1.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+HEAD="python bench.py --multi-clip 0 --parity-seeds 0 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats -d $O/ph -o ph -- python $R/bench.py --multi-clip 0 --parity-seeds 0 --no-cpu-baseline > $O/${N}_bench_cfg2_profiled.json 2>/dev/null
+BATCH="python tools/bench_clips.py --clips 8 --steps 100"
+rocprofv3 --kernel-trace --stats -d $O/pb -o pb -- python $R/tools/bench_clips.py --clips 8 --steps 100 > $O/${N}_bench_batch8_profiled.json 2>/dev/null
+cd $R
+python tools/prof_summary.py $O/ph/ph_results.db "$HEAD" > $O/${N}_p_cfg2_headline_kernel_stats.txt
+python tools/prof_timeline.py $O/ph/ph_results.db > $O/${N}_p_cfg2_headline_timeline.txt
+python tools/prof_summary.py $O/pb/pb_results.db "$BATCH" > $O/${N}_p_cfg4_batch8_kernel_stats.txt
+python tools/prof_timeline.py $O/pb/pb_results.db > $O/${N}_p_cfg4_batch8_timeline.txt
+rm -rf $O/ph $O/pb
