@@ -82,7 +82,8 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
                                                      int* __restrict__ bin_cnt, int* __restrict__ bin_list,
                                                      const float* __restrict__ rigid_rot6d,
                                                      const float* __restrict__ rigid_trans,
-                                                     const float* __restrict__ rigid_scale, int rigid_abs, int clip_len)
+                                                     const float* __restrict__ rigid_scale, int rigid_abs, int clip_len,
+                                                     float* __restrict__ cam_out, int nfb)
 {
     __shared__ int s_cnt[SR_MAX], s_base[SR_MAX];
     __shared__ float s_R[9];
@@ -90,6 +91,24 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
     // other losses get from that entry point are the very numbers rasterised here): the silhouette chain then does not
     // wait for a separate transform launch
     if (rigid_rot6d && threadIdx.x == 0) rot6d_to_mat(rigid_rot6d + blockIdx.y * 6, s_R);
+    if ((int)blockIdx.x >= nfb) {
+        // vertex blocks behind the face blocks (cam_out != NULL): the camera-space vertices themselves, for the caller's
+        // other losses - the arithmetic of k_rigid_fwd, so hm_rigid_fwd on the same inputs returns the same floats, and the
+        // caller's second stream no longer opens with a transform launch of its own
+        __syncthreads();
+        const int bb = blockIdx.y, v = ((int)blockIdx.x - nfb) * blockDim.x + threadIdx.x;
+        if (v >= V) return;
+        float sc = rigid_scale[bb / clip_len];
+        if (rigid_abs) sc = fabsf(sc);
+        const float* m = verts + ((long)bb * V + v) * 3;
+        const float x = sc * m[0], y = sc * m[1], z = sc * m[2];
+        const float* t = rigid_trans + bb * 3;
+        float* o = cam_out + ((long)bb * V + v) * 3;
+        o[0] = x * s_R[0] + y * s_R[3] + z * s_R[6] + t[0];
+        o[1] = x * s_R[1] + y * s_R[4] + z * s_R[7] + t[1];
+        o[2] = x * s_R[2] + y * s_R[5] + z * s_R[8] + t[2];
+        return;
+    }
     const int b = blockIdx.y, fi = blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = fi < F;
     const int nsx = (is + (1 << hm_sr_shift(is)) - 1) >> hm_sr_shift(is), nsr = nsx * nsx;
@@ -1907,7 +1926,7 @@ int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, co
                      const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
                      float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
                      const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, int clip_len,
-                     int out_stride, hipStream_t stream)
+                     int out_stride, float* cam_verts_out, hipStream_t stream)
 {
     HM_CHECK_ARG(verts && faces && K && pooled && workspace && HM_CLIP_LEN_OK(B, clip_len));
     if (clip_len == 0) clip_len = B;
@@ -1918,9 +1937,11 @@ int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, co
     SilWs w = carve(workspace, B, V, F, S);
     const int is = 2 * S, ntiles = (S / 8) * (S / 8);
     int* bins = is <= (SR_MAX == 64 ? 1024 : 0) ? w.bin_cnt : nullptr;      // <= SR_MAX super-regions per frame
-    hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, orig_size, faces,
-                       faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list, rigid_rot6d, rigid_trans,
-                       rigid_scale, rigid_abs, clip_len);
+    HM_CHECK_ARG(!cam_verts_out || rigid_rot6d);
+    const int nfb = hm_cdiv(F, 256);
+    hipLaunchKernelGGL(k_setup_faces, dim3(nfb + (cam_verts_out ? hm_cdiv(V, 256) : 0), B), dim3(256), 0, stream, verts, K,
+                       orig_size, faces, faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list,
+                       rigid_rot6d, rigid_trans, rigid_scale, rigid_abs, clip_len, cam_verts_out, nfb);
     const bool fused = keep && ref;
     HM_TIME_MARK(0, stream);
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
@@ -1942,7 +1963,7 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
 {
     return hm_sil_fwd_clips(verts, faces, faces_bstride, K, B, V, F, S, orig_size, znear, zfar, keep, ref, keep_sum, pooled,
                             loss_out, work_order, pooled_depth, alpha_full, mask_shared, rigid_rot6d, rigid_trans,
-                            rigid_scale, rigid_abs, persistent_outputs, workspace, 0, 0, stream);
+                            rigid_scale, rigid_abs, persistent_outputs, workspace, 0, 0, nullptr, stream);
 }
 
 // Scheduling hint, no effect on results: which winding class of the mesh (0: faces as stored, 1: reversed copies of
@@ -2105,7 +2126,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     int* bins = 2 * S <= 1024 ? w.bin_cnt : nullptr;
     hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, 1.0f, faces, 0, B, V, F,
                        2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, 0, B);
+                       (const float*)nullptr, 0, B, (float*)nullptr, hm_cdiv(F, 256));
     const bool cold = false;   // true: re-bin before every launch (times setup + raster with the reset tickets)
     (void)hipEventRecord(e0, stream);
     for (int i = 0; i < reps; ++i) {
@@ -2113,7 +2134,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
             (void)hipMemsetAsync(w.bin_cnt, 0, (size_t)B * SR_MAX * 4, stream);
             hipLaunchKernelGGL(k_setup_faces, dim3(hm_cdiv(F, 256), B), dim3(256), 0, stream, verts, K, 1.0f, faces, 0, B, V, F,
                                2 * S, w.faces9, w.boxes, w.owned, bins, w.bin_list, (const float*)nullptr,
-                               (const float*)nullptr, (const float*)nullptr, 0, B);
+                               (const float*)nullptr, (const float*)nullptr, 0, B, (float*)nullptr, hm_cdiv(F, 256));
         }
         hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,

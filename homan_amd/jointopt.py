@@ -274,6 +274,9 @@ class FusedStepper:
         B, Vo, Vh = m.B, m.verts_object_og.shape[1], 778          # B = frames of the whole batch
         C, NS = m.C, len(self.SLOTS) + 1
         self.B, self.C, self.clip_len, self.NS = B, C, m.clip_len, NS
+        # third stream for the silhouette reduction + log row: it pays on a clip batch (+1.5 %); at one clip the graph executor
+        # spends two cross-queue hops (~10 us each) on it, and two streams are 5-6 % faster (same-box A/B, cfg2 and cfg3)
+        self.use_aux = (os.environ.get("HOMAN_AUX") or ("1" if C > 1 else "0")) != "0"
         self.Vo, self.Vh, self.P = Vo, Vh, m.mano_pca_pose.shape[1]
         f = lambda *shape: torch.zeros(*shape, device=dev)
         self.vo, self.vm, self.vh = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
@@ -415,7 +418,19 @@ class FusedStepper:
         pca, rot, betas, mtr = m.mano_pca_pose, m.mano_rot, m.mano_betas, m.mano_trans
         npca = self.P * CL                       # PCA entries of one clip
         side.wait_stream(main)
+        use_aux = self.use_aux
+
+        def tail_block(stream_obj):
+            if on["sil"]:
+                ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
+                                         P(sctx.workspace), CL, NS, stream_obj.cuda_stream), "sil_reduce")
+            if log:
+                ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
+                                        self.max_steps, P(self.log_buf), C, stream_obj.cuda_stream), "log")
+
         def aux_block():
+            if not use_aux:
+                return
             # the silhouette reduction and the log row run on a third stream, off both chains.  (Only this: HIP stream
             # capture crashes when two captured streams wait for each other's events in both directions, and the hipGraph
             # executor maps richer fork patterns onto its hardware queues in orders that serialise the branches -- both
@@ -438,18 +453,18 @@ class FusedStepper:
             ck(L.hm_sil_fwd_clips(P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S,
                                   1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
                                   None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
-                                  P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, sa),
-               "sil_fwd")
-            self.ev_sil.record(main)         # the loss / IoU reduction runs on the side stream
+                                  P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS,
+                                  P(self.vo), sa), "sil_fwd")      # (also writes the camera-space vertices self.vo)
+            self.ev_sil.record(main)         # loss / IoU reduction on the third stream; self.vo for the side stream
             ck(L.hm_sil_bwd_clips(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
                                   2 if self.lw["lw_sil_obj"] > 0 else 1,
                                   P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
                                   P(sctx.face_order), None, None, P(sctx.workspace), CL, sa), "sil_bwd")    # no vertex gather
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
-            ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
-                                    P(m.int_scales_object), 1, B, Vo, None, P(self.vo), CL, sb), "rigid_fwd(obj)")
-            if on["smooth"] and self.smooth_obj_on_main:
+            if not on["sil"]:    # (with the silhouette term the face setup of hm_sil_fwd has written self.vo already)
+                ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
+                                        P(m.int_scales_object), 1, B, Vo, None, P(self.vo), CL, sb), "rigid_fwd(obj)")
                 self.ev_vo.record(side)
             ck(L.hm_mano_fwd_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
                                    P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
@@ -474,6 +489,8 @@ class FusedStepper:
                 if on["v2d"]:
                     ck(L.hm_v2d_fwd_clips(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
                                           P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, CL, NS, sb), "v2d")
+            if on["sil"]:
+                side.wait_event(self.ev_sil)         # self.vo: camera-space object vertices from the calling stream
             if on["smooth"] and not self.smooth_obj_on_main:
                 ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
                                          sb), "smooth(obj)")
@@ -520,7 +537,8 @@ class FusedStepper:
         if on["smooth"] and self.smooth_obj_on_main:
             # the object's smoothness term only feeds the object's pose gradients: it rides the silhouette chain (behind the
             # sweeps) instead of lengthening the hand-side chain, which is the longer one at one clip
-            main.wait_event(self.ev_vo)
+            if not on["sil"]:
+                main.wait_event(self.ev_vo)
             ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_a, CL, NS,
                                      sa), "smooth(obj)")
             self.ev_smo.record(main)
@@ -542,8 +560,18 @@ class FusedStepper:
             ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
                                     None, 0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
                                     P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sa), "rigid_bwd(obj)")
+        if not use_aux:
+            # two streams only: the silhouette reduction rides the tail of the silhouette chain (the shorter one at one
+            # clip), the log row follows the join
+            if on["sil"]:
+                ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
+                                         P(sctx.workspace), CL, NS, sa), "sil_reduce")
         main.wait_stream(side)               # join
-        main.wait_stream(self.aux)
+        if use_aux:
+            main.wait_stream(self.aux)
+        elif log:
+            ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
+                                    self.max_steps, P(self.log_buf), C, sa), "log")
         if sc_obj:          # per clip: sum of the frames' d loss / d scale + the scale prior's term
             ck(L.hm_sum_small_clips(P(self.g_so_part), CL, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
                                     P(m.int_scales_object.grad), C, sa), "scale grad")

@@ -74,7 +74,7 @@ _SIGNATURES = {
     "hm_sum_small_clips": (_I, [_VP, _I, _F, _VP, _F, _VP, _I, _VP]),
     "hm_mano_fwd_clips": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_sil_fwd_clips": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP,
-                              _VP, _VP, _I, _I, _VP, _I, _I, _VP]),
+                              _VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
     "hm_sil_reduce_clips": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_sil_bwd_clips": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_v2d_fwd_clips": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _I, _I, _VP]),

@@ -286,7 +286,9 @@ int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, co
                      const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
                      float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
                      const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, int clip_len,
-                     int out_stride, hipStream_t stream);
+                     int out_stride, float* cam_verts_out, hipStream_t stream);
+/*   cam_verts_out (B,V,3) optional (with the rigid_* arguments): the camera-space vertices = what hm_rigid_fwd returns for
+ *   the same inputs (same arithmetic, same floats), written by extra workgroups of the face-setup launch. */
 int hm_sil_reduce_clips(int B, int V, int F, int S, const float* keep_sum, float* loss_out, float* frame_out,
                         void* workspace, int clip_len, int out_stride, hipStream_t stream);
 int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
