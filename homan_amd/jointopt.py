@@ -299,7 +299,7 @@ class FusedStepper:
         self.keys = [k for k in self.SLOTS if self._reported(k)]
         # with the collision / contact terms the hand-side stream is by far the longer chain: the object's smoothness term
         # (it only feeds the object's pose gradients) then rides the silhouette chain (measured: cfg3 +5 %, cfg2 -6 %)
-        self.smooth_obj_on_main = self.on["col"] or self.on["con"]
+        self.smooth_obj_on_main = (self.on["col"] or self.on["con"]) and m.C == 1      # (a clip batch: -4 %)
         # unit gradients / scratch
         self.U_pca, self.U_so, self.U_sh = f(B, self.P), f(C), f(C)
         self.U_smo, self.U_smh, self.U_v2d = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
