@@ -344,8 +344,9 @@ class FusedStepper:
             m.sil_ctx.calibrate()                # cost-sorted launch orders from the current state (scheduling only)
         if capture:
             # scheduling hint baked into the captured launches: with the collision / contact terms the hand-side stream is
-            # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way)
-            sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (768 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
+            # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way;
+            # same-box A/B on cfg3: 1280 -> 4030, 768 -> 4130, 512 -> 4194 it/s)
+            sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (512 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
             prev = _lib.lib().hm_tune_sweep_blocks(sb)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.cap_stream):
