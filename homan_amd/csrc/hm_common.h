@@ -13,7 +13,10 @@
 // First statement of the small, latency-bound kernels: raise the wave's issue priority.  They share the SIMDs with the
 // persistent edge-sweep waves (older, and issue-bound), and at equal priority a lone young wave got ~1/5 of the issue
 // slots: the hand-side kernels ran 2-5x longer whenever they overlapped the sweep.
-#define HM_LATENCY_KERNEL() __builtin_amdgcn_s_setprio(3)
+#ifndef HM_PRIO
+#define HM_PRIO 3
+#endif
+#define HM_LATENCY_KERNEL() __builtin_amdgcn_s_setprio(HM_PRIO)
 
 #define HM_CHECK_ARG(cond) \
     do {                   \

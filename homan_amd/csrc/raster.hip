@@ -11,12 +11,17 @@
 //   fill_back (both windings, index f and F+f), vertical flip, 2x2 average pool; backward =
 //   per-(face,edge,axis) line sweeps comparing in/out alpha (Kato et al. 2018).
 //
-// Design (CDNA4): one 64-lane wavefront per 8x8 output tile (= 16x16 samples, 4 samples/lane,
-// z-min in registers, no atomics); faces are binned on the fly by a coalesced scan of the 8-byte
-// per-face screen boxes with ballot compaction into an LDS queue; hit faces are staged through
-// LDS (vertex data + 3x3 barycentric inverse computed once per (tile,face) by one lane) and
-// broadcast-read by all lanes.  The backward line sweeps run on 1-bit/sample masks built by a
-// tile pre-pass, so the "sweep to the image border" of the algorithm touches 8 words, not 512 px.
+// Design (CDNA4), see DESIGN.md section 4 for the measurements behind each choice:
+//   forward   k_setup_faces (thread / face: optional rigid transform, projection, tight sample box, super-region bins; extra
+//             workgroups write the camera-space vertices) -> k_raster_fwd (workgroup = 32x32-sample region: candidates of
+//             its bin split into the camera-facing winding class and the hidden one; (candidate, 4x4 block) units
+//             flattened over the threads; visibility by ds_min_u64 on an LDS z-buffer = the strict z test in ascending face
+//             order, bit-exact; hidden-class units filtered against per-block depths and run on full waves of survivors;
+//             epilogue per 8x8 output tile: index map, pooled silhouette, fused masked-MSE / IoU terms, sweep bit planes);
+//   backward  k_bwd_lines (bit lines -> position-sorted source arrays + per-word records + per-line summaries; its first
+//             workgroups build the flattened work list of the sweeps) -> k_bwd_sweep (persistent waves over 256-item
+//             units: summary filter, then owner tests / slices / (item, source) pairs on full waves) -> per-corner NDC
+//             gradients, gathered per vertex by k_bwd_gather or inside hm_rigid_bwd_sil.
 #include "hm_common.h"
 
 #define HM_TILE 8          // output pixels per tile side

@@ -90,9 +90,9 @@ class HOMan(nn.Module):
         self.register_buffer("verts_hand_og", f32(verts_hand_og))
         self.register_buffer("ref_verts2d_hand", f32(ref_verts2d_hand))
 
-        init_scales = int_scale_init * torch.ones(1).float()
-        # reference homan.py:122: torch.Tensor(int_scale_init) -- raises for a float argument (callers pass int 1)
-        torch.Tensor(int_scale_init)
+        # (reference homan.py:122 wraps the argument in torch.Tensor(...), which raises for its own float default 1.0 -
+        #  callers pass the int 1, jointopt.py:118; any real number is accepted here)
+        init_scales = float(int_scale_init) * torch.ones(1).float()
         self.optimize_object_scale = optimize_object_scale
         if optimize_object_scale:
             self.int_scales_object = nn.Parameter(init_scales, requires_grad=True)
