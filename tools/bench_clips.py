@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--step2", action="store_true")
     ap.add_argument("--sweep-blocks", type=int, default=0)
+    ap.add_argument("--object-scale", action="store_true", help="optimize_object_scale=True (one free scale per clip)")
+    ap.add_argument("--shared-scale", action="store_true", help="ONE scale tied across the clips (BASELINE cfg5)")
     ap.add_argument("--no-graph", action="store_true", help="issue the iteration launch by launch instead of replaying a hipGraph")
     args = ap.parse_args()
     import torch
@@ -36,11 +38,12 @@ def main():
         models.append(build_model(copy.deepcopy(c["person_parameters"]), copy.deepcopy(c["object_parameters"]),
                                   objvertices=c["objvertices"], objfaces=c["objfaces"], camintr=c["camintr"],
                                   optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
-                                  sync_metrics=False))
+                                  sync_metrics=False, optimize_object_scale=args.object_scale or args.shared_scale))
     if args.sweep_blocks:
         hlib.lib().hm_tune_sweep_blocks(args.sweep_blocks)
     total = args.warmup + args.steps
-    st = FusedStepper(models if args.clips > 1 else models[0], lw, 1e-2, total, capture=not args.no_graph)
+    st = FusedStepper(models if args.clips > 1 else models[0], lw, 1e-2, total, capture=not args.no_graph,
+                      shared_scale=args.shared_scale)
     st.run(args.warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
