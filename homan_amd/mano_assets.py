@@ -140,6 +140,39 @@ def synthetic_mano(seed=0):
     return out
 
 
+def mirrored(model):
+    """The other hand of a MANO-shaped model: every geometric quantity reflected in y (the lateral axis of the synthetic
+    hand), face windings reversed so that normals stay outward; pose basis and mean pose kept.  Stands in for
+    MANO_LEFT.pkl next to a synthetic right hand (the real left model is a separate licensed file, read by `get_mano`)."""
+    key = ("mirror", id(model))
+    if key in _CACHE:
+        return _CACHE[key][1]
+    flip = np.array([1.0, -1.0, 1.0], np.float32)
+    out = dict(model)
+    out["v_template"] = (model["v_template"] * flip).astype(np.float32)
+    out["shapedirs"] = (model["shapedirs"] * flip[None, :, None]).astype(np.float32)
+    out["posedirs"] = (model["posedirs"].reshape(NUM_POSE_BASIS, NUM_VERTS, 3) * flip).reshape(NUM_POSE_BASIS, -1).astype(np.float32)
+    out["faces"] = np.ascontiguousarray(model["faces"][:, ::-1])
+    if model.get("closed_faces") is not None:
+        out["closed_faces"] = np.ascontiguousarray(model["closed_faces"][:, ::-1])
+    out["side"] = "left" if model.get("side", "right") == "right" else "right"
+    _CACHE[key] = (model, out)          # (keeps `model` alive: the key is its id)
+    return out
+
+
+def hand_models(mano_model=None, mano_root="extra_data/mano"):
+    """{"right": model, "left": model} from whatever the caller has: a {"right", "left"} dictionary, one (right-hand) model
+    - its mirror image then serves as the left hand -, or nothing (the files under `mano_root`, else synthetic)."""
+    if isinstance(mano_model, dict) and "right" in mano_model and "v_template" not in mano_model:
+        right = mano_model["right"]
+        return {"right": right, "left": mano_model.get("left") or mirrored(right)}
+    if mano_model is not None:
+        return {"right": mano_model, "left": mirrored(mano_model)}
+    right = get_mano(mano_root, "right")
+    left_file = os.path.join(mano_root, "MANO_LEFT.pkl")
+    return {"right": right, "left": get_mano(mano_root, "left") if os.path.exists(left_file) else mirrored(right)}
+
+
 class _Stub:
     """Stand-in for chumpy objects inside the official MANO pickles."""
 

@@ -119,14 +119,17 @@ def _k_roi(K_px, x0, y0, side):
 
 
 def make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", silhouette_fn=None,
-              hand_verts_fn=None, mano=None, pca_dim=45):
+              hand_verts_fn=None, mano=None, pca_dim=45, hands=("right",)):
     """Build one synthetic clip.
 
     silhouette_fn(verts (B,V,3), faces (B,F,3) int32, K (B,3,3), size) -> (B,size,size)
         renderer used for the target masks (HIP product path on the GPU, the
         oracle in CPU tests; both give the same bits).
-    hand_verts_fn(pca (B,P), rot (B,3), betas (B,10)) -> (B,778,3)
+    hand_verts_fn(pca (B,P), rot (B,3), betas (B,10)[, side]) -> (B,778,3)
         MANO forward used for the ground truth (same remark).
+    hands: sides of the hands in the clip, hand 0 first ("right" alone: every BASELINE config; ("right", "left"): the
+        second hand holds the object from the other side; per-frame dicts then carry h entries per field, hands
+        interleaved frame-major after collation like the reference expects, homan/homan.py:62-63).
     Returns dict(person_parameters, object_parameters, objvertices, objfaces,
                  camintr, image_size, gt=...).
     """
@@ -210,23 +213,62 @@ def make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", si
                                     torch.zeros(B, 10)).detach().cpu().float()
     verts_hand_init = torch.matmul(hand_local_init, R_h_init) + t_h_init
 
+    # per-hand tracks: hand 0 above (its random draws are interleaved with the object's: clips with one hand are unchanged),
+    # further hands from generators of their own
+    tracks = [dict(side=hands[0], faces=hand_faces, t_init=t_h_init, R_init=R_h_init, mano_rot=torch.from_numpy(rot_gt),
+                   tm=tm_h, full=full_h, verts_init=verts_hand_init, verts2d=verts2d, K_roi=K_roi_h, verts_gt=verts_hand_gt)]
+    assert hands[0] == "right", "hand 0 is the right hand of the BASELINE clips"
+    for hi, side in enumerate(hands[1:], start=1):
+        from .mano_assets import hand_models
+        rng_h = np.random.default_rng(seed + 7919 * hi)
+        gen_h = torch.Generator().manual_seed(seed + 7919 * hi)
+        sgn = -1.0 if hi % 2 else 1.0                     # the other side of the object
+        t_hh = t_o + np.array([-sgn * (radius + 0.075), 0.0, -0.02 - 0.01 * hi])
+        R_hh = np.stack([_rot_y(sgn * (0.4 + 0.01 * ti)) @ _rot_x(-0.3) for ti in t])
+        pca_h = np.zeros((B, pca_dim), np.float32)
+        pca_h[:, :16] = (rng_h.normal(size=16) * 0.3)[None] + rng_h.normal(size=(B, 16)) * 0.02
+        rot_h = (np.array([0.1, 0.2 * sgn, 0.15]) + rng_h.normal(size=(B, 3)) * 0.01).astype(np.float32)
+        R_hh_t, t_hh_t = torch.from_numpy(R_hh).float(), torch.from_numpy(t_hh).float()[:, None]
+        local_gt = hand_verts_fn(torch.from_numpy(pca_h), torch.from_numpy(rot_h), torch.zeros(B, 10), side).detach().cpu().float()
+        v_gt = torch.matmul(local_gt, R_hh_t) + t_hh_t
+        faces_h = torch.from_numpy(hand_models(mano)[side]["faces"].astype(np.int32))
+        hf_h = faces_h[None].repeat(B, 1, 1)
+        p2d = _proj_px(v_gt, K_px)
+        xh2, yh2, sh2 = _square_roi(p2d, BBOX_EXPANSION_FACTOR)
+        K_roi2 = _k_roi(K_px, xh2, yh2, sh2)
+        sil = silhouette_fn(v_gt, hf_h, K_roi2, rend_size).detach().cpu()
+        sil_o_in = silhouette_fn(verts_obj_gt, of_t, K_roi2, rend_size).detach().cpu()
+        tm = (sil > 0.5).float()
+        tm[(sil_o_in > 0.5) & (sil <= 0.5)] = -1.0
+        tm_o[silhouette_fn(v_gt, hf_h, K_roi_o, rend_size).detach().cpu() > 0.5] = -1.0       # it occludes the object too
+        full = silhouette_fn(v_gt, hf_h, camintr_nc, image_size).detach().cpu() > 0.5
+        full_o = full_o & ~full
+        R_init = R_hh_t.clone()
+        R_init[:, :, :2] += torch.randn(B, 3, 2, generator=gen_h) * 0.05
+        t_init = t_hh_t + torch.randn(B, 1, 3, generator=gen_h) * 0.005
+        local_init = hand_verts_fn(torch.zeros(B, pca_dim), torch.from_numpy(rot_h), torch.zeros(B, 10), side).detach().cpu().float()
+        tracks.append(dict(side=side, faces=faces_h, t_init=t_init, R_init=R_init, mano_rot=torch.from_numpy(rot_h), tm=tm,
+                           full=full, verts_init=torch.matmul(local_init, R_init) + t_init,
+                           verts2d=p2d + torch.randn(p2d.shape, generator=gen_h), K_roi=K_roi2, verts_gt=v_gt))
+
     person_parameters, object_parameters = [], []
     for b in range(B):
+        cat = lambda key: torch.cat([tr[key][b:b + 1] for tr in tracks])           # (h, ...)
         person_parameters.append(dict(
-            translations=t_h_init[b:b + 1].clone(),                 # (1,1,3)
-            rotations=R_h_init[b:b + 1].clone(),                    # (1,3,3)
-            hand_side=["right"],
-            faces=hand_faces[None].clone(),                         # (1,1538,3)
-            mano_trans=torch.from_numpy(mano_trans_gt[b:b + 1]).clone(),
-            mano_rot=torch.from_numpy(rot_gt[b:b + 1]).clone(),
-            mano_betas=torch.zeros(1, 10),
-            mano_pca_pose=torch.zeros(1, pca_dim),
-            target_masks=tm_h[b:b + 1].clone(),                     # (1,S,S)
-            masks=full_h[b:b + 1].float(),                          # (1,H,W) instance mask
-            verts=verts_hand_init[b:b + 1].clone(),                 # (1,778,3)
-            verts2d=verts2d[b:b + 1].clone(),                       # (1,778,2) px
-            K_roi=K_roi_h[b:b + 1].clone(),                         # (1,3,3)
-            cams=torch.tensor([[1.0, 0.0, 0.0]]),
+            translations=cat("t_init").clone(),                     # (h,1,3)
+            rotations=cat("R_init").clone(),                        # (h,3,3)
+            hand_side=[tr["side"] for tr in tracks],
+            faces=torch.stack([tr["faces"] for tr in tracks]).clone(),      # (h,1538,3)
+            mano_trans=torch.zeros(len(tracks), 3),
+            mano_rot=cat("mano_rot").clone(),
+            mano_betas=torch.zeros(len(tracks), 10),
+            mano_pca_pose=torch.zeros(len(tracks), pca_dim),
+            target_masks=cat("tm").clone(),                         # (h,S,S)
+            masks=cat("full").float(),                              # (h,H,W) instance masks
+            verts=cat("verts_init").clone(),                        # (h,778,3)
+            verts2d=cat("verts2d").clone(),                         # (h,778,2) px
+            K_roi=cat("K_roi").clone(),                             # (h,3,3)
+            cams=torch.tensor([[1.0, 0.0, 0.0]]).repeat(len(tracks), 1),
         ))
         object_parameters.append(dict(
             translations=t_o_init[b:b + 1].clone(),                 # (1,1,3)
@@ -254,12 +296,13 @@ CFG1_LOSS_WEIGHTS = dict({k: 0.0 for k in STEP1_LOSS_WEIGHTS}, lw_sil_obj=1.0, l
 def hip_clip_fns(mano_model=None, device="cuda"):
     """(silhouette_fn, hand_verts_fn) for make_clip backed by the HIP product kernels."""
     from . import ops
+    from .manomodel import ManoModel
     mano_model = synthetic_mano(0) if mano_model is None else mano_model
-    mctx = ops.ManoContext(mano_model, device, flat_hand_mean=False)
+    mm = ManoModel(mano_model=mano_model, device=device)
 
-    def hand_fn(pca, rot, betas):
+    def hand_fn(pca, rot, betas, side="right"):
         with torch.no_grad():
-            return ops.mano_lbs(pca.to(device), rot.to(device), betas.to(device), None, mctx).cpu()
+            return mm.forward_pca(pca.to(device), rot=rot.to(device), betas=betas.to(device), side=side)["verts"].cpu()
 
     def sil_fn(verts, faces, K, size):
         with torch.no_grad():

@@ -21,13 +21,14 @@ def load_golden(name):
     weights = {"lw_" + k[3:]: float(v) for k, v in rec.items() if k.startswith("lw_")}
     meta = dict(image_size=int(rec["meta_image_size"]), steps=int(rec["meta_steps"]),
                 optimize_object_scale=bool(rec["meta_optimize_object_scale"]),
-                optimize_mano=bool(rec["meta_optimize_mano"]), lr=float(rec["meta_lr"]))
+                optimize_mano=bool(rec["meta_optimize_mano"]), lr=float(rec["meta_lr"]),
+                hand_sides=[str(x) for x in rec["meta_hand_sides"]] if "meta_hand_sides" in rec else ["right"])
     return rec, inputs, rec["in_camintr"], weights, meta
 
 
 def model_kwargs(inputs, camintr, meta):
     kw = dict(inputs)
-    kw.update(hand_sides=["right"], camintr=camintr, class_name="default", int_scale_init=1,
+    kw.update(hand_sides=list(meta["hand_sides"]), camintr=camintr, class_name="default", int_scale_init=1,
               hand_proj_mode="persp", optimize_mano=meta["optimize_mano"], optimize_mano_beta=True,
               optimize_object_scale=meta["optimize_object_scale"], image_size=meta["image_size"])
     return kw
@@ -35,11 +36,17 @@ def model_kwargs(inputs, camintr, meta):
 
 def oracle_clip_fns(mano_model):
     """(silhouette_fn, hand_verts_fn) backed by the CPU oracle, for homan_amd.synth.make_clip."""
+    from homan_amd.mano_assets import hand_models
     from oracle import lbs, nmr
-    layer = lbs.ManoLayer(mano_model, num_pca_comps=16, flat_hand_mean=False)
+    layers = {side: lbs.ManoLayer(m, num_pca_comps=16, flat_hand_mean=False) for side, m in hand_models(mano_model).items()}
 
-    def hand_fn(pca, rot, betas):
+    def hand_fn(pca, rot, betas, side="right"):
+        layer = layers[side]
         hp = pca[:, :16] @ layer.hand_components
+        if side == "left":          # homan/manomodel.py:131-132, applied before the mean pose is added
+            hp = hp.clone()
+            hp[:, 1::3] *= -1
+            hp[:, 2::3] *= -1
         return layer(betas=betas, global_orient=rot, hand_pose=hp, transl=torch.zeros(len(rot), 3))[0]
 
     def sil_fn(verts, faces, K, size):

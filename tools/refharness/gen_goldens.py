@@ -23,12 +23,17 @@ from homan_amd.mano_assets import synthetic_mano  # noqa: E402
 
 OUT = os.path.join(shims.REPO_ROOT, "tests", "golden")
 MANO = synthetic_mano(0)
-_layer = lbs.ManoLayer(MANO, num_pca_comps=16, flat_hand_mean=False)
+from homan_amd.mano_assets import hand_models  # noqa: E402
+_layers = {side: lbs.ManoLayer(m, num_pca_comps=16, flat_hand_mean=False) for side, m in hand_models(MANO).items()}
 
 
-def hand_fn(pca, rot, betas):
-    hp = pca[:, :16] @ _layer.hand_components
-    return _layer(betas=betas, global_orient=rot, hand_pose=hp, transl=torch.zeros(len(rot), 3))[0]
+def hand_fn(pca, rot, betas, side="right"):
+    hp = pca[:, :16] @ _layers[side].hand_components
+    if side == "left":      # the ground-truth pose only: the reference's own left path runs inside its HOMan below
+        hp = hp.clone()
+        hp[:, 1::3] *= -1
+        hp[:, 2::3] *= -1
+    return _layers[side](betas=betas, global_orient=rot, hand_pose=hp, transl=torch.zeros(len(rot), 3))[0]
 
 
 def sil_fn(verts, faces, K, size):
@@ -48,16 +53,17 @@ def flat_inputs(clip):
 
 
 def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scale=False,
-             optimize_mano=True, init_steps=0, pin_step=5):
+             optimize_mano=True, init_steps=0, pin_step=5, hands=("right",)):
     shims.set_rend_size(size)
     clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj,
-                           silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+                           silhouette_fn=sil_fn, hand_verts_fn=hand_fn, hands=hands)
     rec = flat_inputs(clip)
     rec["meta_image_size"] = np.int64(size)
     rec["meta_steps"] = np.int64(steps)
     rec["meta_optimize_object_scale"] = np.int64(optimize_object_scale)
     rec["meta_optimize_mano"] = np.int64(optimize_mano)
     rec["meta_lr"] = np.float64(1e-2)
+    rec["meta_hand_sides"] = np.array(list(hands))
     for k, v in weights.items():
         rec["lw_" + k[3:]] = np.float64(v)
 
@@ -147,6 +153,12 @@ def main():
              weights=dict(synth.STEP2_LOSS_WEIGHTS), steps=6, optimize_object_scale=True)
     _maybe("ref_rigid_cube_b5_s32", seed=3, frames=5, size=32, obj="cube",
              weights=dict(synth.STEP1_LOSS_WEIGHTS), steps=10, optimize_mano=False)
+    # two hands, right + left (hand_nb = 2): every loss of the refinement step, so that the multi-hand branches of
+    # lossutils.py:51-64,114-131 (collision over three meshes, contact per hand) and the left MANO path are pinned
+    _maybe("ref_step2_twohands_cube_b4_s64", seed=4, frames=4, size=64, obj="cube",
+             weights=dict(synth.STEP2_LOSS_WEIGHTS), steps=8, hands=("right", "left"))
+    _maybe("ref_step1_twohands_cube_b4_s64", seed=5, frames=4, size=64, obj="cube",
+             weights=dict(synth.STEP1_LOSS_WEIGHTS), steps=8, hands=("right", "left"))
 
 
 if __name__ == "__main__":

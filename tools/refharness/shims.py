@@ -56,8 +56,11 @@ def install(mano_model=None):
 
         def mano_load(model_path=None, num_pca_comps=16, use_pca=False, is_right=True, model_type="mano",
                       batch_size=1, flat_hand_mean=True, **_):
-            return o_lbs.ManoLayer(mano_model, num_pca_comps=num_pca_comps, flat_hand_mean=flat_hand_mean,
-                                   use_pca=use_pca)
+            # homan/manomodel.py:19-80 names the side through the file it asks for (is_right is True in every call there)
+            from homan_amd.mano_assets import hand_models
+            side = "left" if model_path is not None and "LEFT" in os.path.basename(model_path) else "right"
+            return o_lbs.ManoLayer(hand_models(mano_model)[side], num_pca_comps=num_pca_comps,
+                                   flat_hand_mean=flat_hand_mean, use_pca=use_pca)
 
         _module("mano.model", load=mano_load)
         _module("libyana")
