@@ -253,6 +253,10 @@ class FusedStepper:
     def __init__(self, model, loss_weights, lr, max_steps, capture=True, shared_scale=False, group=None):
         from . import constants, ops
         from .clipbatch import ClipBatch, ClipReduceWorkspace
+        for one in (model.models if isinstance(model, ClipBatch) else model if isinstance(model, (list, tuple)) else [model]):
+            if list(one.hand_sides) != ["right"]:
+                raise NotImplementedError("the fused loop covers one right hand per frame (every BASELINE configuration); "
+                                          "two hands / a left hand: mode='graph' or 'eager'")
         m = self.model = model if isinstance(model, ClipBatch) else ClipBatch(model if isinstance(model, (list, tuple))
                                                                              else [model])
         if not (m.optimize_mano and not m.int_scales_hand.requires_grad and m.hand_proj_mode == "persp"):
@@ -644,7 +648,8 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
         # optimize_mano_beta, persp, no depth term, silhouettes on a multiple of 32), else the same iteration through
         # HOMan.forward + autograd in a hipGraph; mode="eager" is the reference's loop verbatim (host sync per logged value)
         fused_ok = (optimize_mano and optimize_mano_beta and hand_proj_mode == "persp" and rend_size % 32 == 0 and
-                    not (loss_weights or {}).get("lw_depth", 0) > 0)
+                    not (loss_weights or {}).get("lw_depth", 0) > 0 and
+                    list(person_parameters[0]["hand_side"]) == ["right"])
         mode = "fused" if fused_ok else "graph"
     model = build_model(person_parameters, object_parameters, class_name, objvertices, objfaces, camintr,
                         hand_proj_mode, optimize_mano, optimize_mano_beta, optimize_object_scale, state_dict,

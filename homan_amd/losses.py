@@ -61,11 +61,25 @@ class Losses:
         return {"loss_sil_hand": per_hand.sum().reshape(1) / len(verts)}
 
     def compute_interaction_loss(self, verts_hand_b, verts_object_b, nn=None):
-        """reference losses.py:199-242: verts_hand_b (B, 1, 778, 3), verts_object_b (B, 1, V, 3)."""
-        if verts_hand_b.shape[1] != 1 or verts_object_b.shape[1] != 1:
-            raise NotImplementedError("one hand and one object per frame")
-        vh, vo = verts_hand_b[:, 0], verts_object_b[:, 0]
-        loss = ops.inter_loss(vh, vo, self.camintr, self.rws, self.expansion, self.thresh)
-        if nn is None:
-            nn = ops.nearest_vertices(vh, vo, self.rws)
-        return {"loss_inter": loss}, {"handobj_maxdist": self._metric(nn[2][0])}
+        """reference losses.py:199-242: verts_hand_b (B, hand_nb, 778, 3), verts_object_b (B, 1, V, 3).  The loss adds the
+        terms of the hands (:207-239); the metric is the largest, over the frames, of the distance from the object to the
+        NEAREST hand (:225-241).  `nn`: nearest-vertex search(es) already made by the contact term."""
+        if verts_object_b.shape[1] != 1:
+            raise NotImplementedError("one object per frame")
+        vo = verts_object_b[:, 0]
+        hand_nb = verts_hand_b.shape[1]
+        if hand_nb == 1:
+            vh = verts_hand_b[:, 0]
+            loss = ops.inter_loss(vh, vo, self.camintr, self.rws, self.expansion, self.thresh)
+            if nn is None:
+                nn = ops.nearest_vertices(vh, vo, self.rws)
+            return {"loss_inter": loss}, {"handobj_maxdist": self._metric(nn[2][0])}
+        loss, per_frame = None, []
+        for p in range(hand_nb):
+            vh = verts_hand_b[:, p].contiguous()
+            term = ops.inter_loss(vh, vo, self.camintr, self.rws, self.expansion, self.thresh)
+            loss = term if loss is None else loss + term
+            d2 = (nn[p] if nn is not None else ops.nearest_vertices(vh, vo, self.rws))[1]
+            per_frame.append(d2.min(1)[0])
+        maxdist = torch.stack(per_frame).min(0)[0].max().clamp_min(0).sqrt()
+        return {"loss_inter": loss}, {"handobj_maxdist": self._metric(maxdist)}

@@ -171,10 +171,12 @@ def make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", si
     t_o_t = torch.from_numpy(t_o).float()[:, None]
     t_h_t = torch.from_numpy(t_h).float()[:, None]
     verts_obj_gt = torch.matmul(ov_t, R_o_t) + t_o_t
+    side0 = () if hands[0] == "right" else (hands[0],)          # (renderers written before `side` existed keep working)
     hand_local_gt = hand_verts_fn(torch.from_numpy(pca_gt), torch.from_numpy(rot_gt),
-                                  torch.zeros(B, 10)).detach().cpu().float()
+                                  torch.zeros(B, 10), *side0).detach().cpu().float()
     verts_hand_gt = torch.matmul(hand_local_gt + torch.from_numpy(mano_trans_gt)[:, None], R_h_t) + t_h_t
-    hand_faces = torch.from_numpy(mano["faces"].astype(np.int32))
+    from .mano_assets import hand_models
+    hand_faces = torch.from_numpy(hand_models(mano)[hands[0]]["faces"].astype(np.int32))
     hf_t = hand_faces[None].repeat(B, 1, 1)
 
     # ROIs and targets
@@ -210,16 +212,14 @@ def make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", si
     t_o_init = t_o_t + torch.randn(B, 1, 3, generator=torch_gen) * 0.005
     t_h_init = t_h_t + torch.randn(B, 1, 3, generator=torch_gen) * 0.005
     hand_local_init = hand_verts_fn(torch.zeros(B, pca_dim), torch.from_numpy(rot_gt),
-                                    torch.zeros(B, 10)).detach().cpu().float()
+                                    torch.zeros(B, 10), *side0).detach().cpu().float()
     verts_hand_init = torch.matmul(hand_local_init, R_h_init) + t_h_init
 
     # per-hand tracks: hand 0 above (its random draws are interleaved with the object's: clips with one hand are unchanged),
     # further hands from generators of their own
     tracks = [dict(side=hands[0], faces=hand_faces, t_init=t_h_init, R_init=R_h_init, mano_rot=torch.from_numpy(rot_gt),
                    tm=tm_h, full=full_h, verts_init=verts_hand_init, verts2d=verts2d, K_roi=K_roi_h, verts_gt=verts_hand_gt)]
-    assert hands[0] == "right", "hand 0 is the right hand of the BASELINE clips"
     for hi, side in enumerate(hands[1:], start=1):
-        from .mano_assets import hand_models
         rng_h = np.random.default_rng(seed + 7919 * hi)
         gen_h = torch.Generator().manual_seed(seed + 7919 * hi)
         sgn = -1.0 if hi % 2 else 1.0                     # the other side of the object

@@ -9,6 +9,10 @@ from tests import util
 
 pytestmark = pytest.mark.gpu
 NAMES = util.golden_names()
+# handobj_maxdist: the reference takes its distances from |a|^2 + |b|^2 - 2ab in fp32 (libyana batch_pairwise_dist,
+# losses.py:227): at |a|^2 ~ 0.36 m^2 the rounding of that expansion is eps * 0.72 / (2 d) ~ 4e-6 m at d = 6 mm.  The kernel
+# differences the coordinates first; the reference's own rounding error is the tolerance (absolute, 1e-5 m).
+METRIC_ATOL = {"handobj_maxdist": 1e-5}
 
 
 def _build_hip(name, mano_model, sync=True):
@@ -32,7 +36,7 @@ def test_forward_matches_reference_goldens(name, mano_model):
         assert got.shape == ref.shape, (k, got.shape, ref.shape)
         np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-9, err_msg=k)
     for k in (k[7:] for k in rec if k.startswith("metric_")):
-        np.testing.assert_allclose(metric_dict[k], float(rec["metric_" + k]), rtol=2e-4, err_msg=k)
+        np.testing.assert_allclose(metric_dict[k], float(rec["metric_" + k]), rtol=2e-4, atol=METRIC_ATOL.get(k, 0), err_msg=k)
     total = sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict)
     total.sum().backward()
     for k, p in model.named_parameters():
@@ -63,7 +67,8 @@ def test_pinned_step_matches_reference(name, mano_model):
     for k in (k[7:] for k in rec if k.startswith("pinfwd_")):
         np.testing.assert_allclose(loss_dict[k].detach().cpu().numpy(), rec["pinfwd_" + k], rtol=1e-4, atol=1e-9, err_msg=k)
     for k in (k[10:] for k in rec if k.startswith("pinmetric_")):
-        np.testing.assert_allclose(metric_dict[k], float(rec["pinmetric_" + k]), rtol=2e-4, err_msg=k)
+        np.testing.assert_allclose(metric_dict[k], float(rec["pinmetric_" + k]), rtol=2e-4, atol=METRIC_ATOL.get(k, 0),
+                                   err_msg=k)
     sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict).sum().backward()
     for k, p in model.named_parameters():
         ref = rec["pingrad_" + k]
@@ -74,7 +79,8 @@ def test_pinned_step_matches_reference(name, mano_model):
         np.testing.assert_allclose(p.grad.cpu().numpy() / scale, ref / scale, atol=2e-3, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["ref_step1_cube_b4_s64", "ref_step2_cube_b4_s64"])
+@pytest.mark.parametrize("name", ["ref_step1_cube_b4_s64", "ref_step2_cube_b4_s64", "ref_step2_twohands_cube_b4_s64",
+                                  "ref_step1_lefthand_cube_b4_s64"])
 def test_short_trajectory_eager_and_graph(name, mano_model):
     """First optimisation steps against the reference loop's loss_evolution, in both loop modes.  The hard
     rasteriser makes long trajectories chaotic (a 1e-7 perturbation flips samples), so the comparison is tight on
@@ -103,6 +109,25 @@ def test_short_trajectory_eager_and_graph(name, mano_model):
         np.testing.assert_allclose(evo, ref, rtol=0.1, err_msg=mode)
         sd = model.state_dict()
         np.testing.assert_array_equal(sd["mano_rot"].cpu().numpy(), rec["in_mano_rot"])      # never stepped
+
+
+def test_two_hands_through_optimize_hand_object(mano_model):
+    """hand_nb = 2 (right + left) through the public entry: `mode="auto"` leaves the fused loop (one right hand only) for
+    the graph-captured HOMan.forward iteration and follows the reference loop's loss_evolution of the golden."""
+    from homan_amd import synth
+    from homan_amd.jointopt import optimize_hand_object
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    clip = synth.make_clip(seed=4, frames=4, rend_size=64, image_size=64, obj="cube", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn, hands=("right", "left"))
+    rec, _, _, weights, meta = util.load_golden("ref_step2_twohands_cube_b4_s64")
+    np.testing.assert_allclose(clip["person_parameters"][0]["verts"].numpy(), rec["in_verts_hand_og"][:2], atol=2e-6)
+    model, evo, _ = optimize_hand_object(clip["person_parameters"], clip["object_parameters"], objvertices=clip["objvertices"],
+                                         objfaces=clip["objfaces"], loss_weights=weights, num_iterations=4, lr=meta["lr"],
+                                         camintr=clip["camintr"], optimize_mano=True, image_size=64, mano_model=mano_model,
+                                         rend_size=64)
+    assert model.hand_nb == 2 and model.get_verts_hand()[0].shape == (8, 778, 3)
+    np.testing.assert_allclose(evo["loss"][0], rec["evo_loss"][0], rtol=1e-4)
+    np.testing.assert_allclose(evo["loss"][:3], rec["evo_loss"][:3], rtol=5e-3)
 
 
 def test_hip_vs_oracle_cfg_sized_clip(mano_model):
@@ -149,7 +174,7 @@ def test_fused_step_equals_autograd_path(name, mano_model):
     """FusedStepper (no autograd tape) vs HOMan.forward + autograd: same losses, same parameter gradients."""
     from homan_amd.jointopt import FusedStepper
     rec, model, weights, meta = _build_hip(name, mano_model, sync=False)
-    if not meta["optimize_mano"]:
+    if not meta["optimize_mano"] or meta["hand_sides"] != ["right"]:       # outside the fused loop: it must say so
         with pytest.raises(NotImplementedError):
             FusedStepper(model, weights, meta["lr"], 4, capture=False)
         return

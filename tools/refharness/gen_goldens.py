@@ -157,6 +157,8 @@ def main():
     # lossutils.py:51-64,114-131 (collision over three meshes, contact per hand) and the left MANO path are pinned
     _maybe("ref_step2_twohands_cube_b4_s64", seed=4, frames=4, size=64, obj="cube",
              weights=dict(synth.STEP2_LOSS_WEIGHTS), steps=8, hands=("right", "left"))
+    _maybe("ref_step1_lefthand_cube_b4_s64", seed=6, frames=4, size=64, obj="cube",
+             weights=dict(synth.STEP1_LOSS_WEIGHTS), steps=8, hands=("left",))
     _maybe("ref_step1_twohands_cube_b4_s64", seed=5, frames=4, size=64, obj="cube",
              weights=dict(synth.STEP1_LOSS_WEIGHTS), steps=8, hands=("right", "left"))
 
