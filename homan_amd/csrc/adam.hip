@@ -19,12 +19,39 @@ struct AdamSlot {
 // grid (blocks_per_tensor, n_tensors)
 // step[0] = completed steps, step[1] = ticket word (zero between launches): the workgroup that draws the last ticket
 // bumps the step counter, after every workgroup has read it -- no separate increment launch on the critical path.
-__global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots, int* __restrict__ step, float beta1,
-                                               float beta2, float eps, int zero_grad)
+// Optional log row (vals != NULL): one more grid row (blockIdx.y == n_tensors) writes what k_log_total writes - the weighted
+// total of every clip and row `step` of the log - before it draws its tickets: the step counter moves only after every
+// workgroup has read it, so the row lands in the slot of the step being taken, and the iteration has one launch less.
+__device__ __forceinline__ void log_total_clip(float* __restrict__ vals, const float* __restrict__ w, int n, int s,
+                                               int max_steps, float* __restrict__ log, int c, int nc)
+{
+    float* v = vals + (long)c * (n + 1);
+    float t = 0.f;
+    for (int i = 0; i < n; ++i)
+        if (w[i] != 0.f) t += w[i] * v[i];
+    v[n] = t;
+    if (s < max_steps)
+        for (int i = 0; i <= n; ++i) log[((long)s * nc + c) * (n + 1) + i] = v[i];
+}
+__global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots, int n_tensors, int* __restrict__ step,
+                                               float beta1, float beta2, float eps, int zero_grad, float* __restrict__ vals,
+                                               const float* __restrict__ log_w, int log_n, int max_steps,
+                                               float* __restrict__ log, int nclips)
 {
     HM_LATENCY_KERNEL();
-    const AdamSlot s = slots[blockIdx.y];
     const int step_now = __builtin_nontemporal_load(step);
+    if ((int)blockIdx.y == n_tensors) {
+        if (threadIdx.x == 0) {
+            for (int c = blockIdx.x; c < nclips; c += gridDim.x) log_total_clip(vals, log_w, log_n, step_now, max_steps, log, c, nclips);
+            const unsigned nblk = gridDim.x * gridDim.y;
+            if (atomicAdd(reinterpret_cast<unsigned int*>(step) + 1, 1u) == nblk - 1u) {
+                atomicExch(reinterpret_cast<unsigned int*>(step) + 1, 0u);
+                atomicExch(step, step_now + 1);
+            }
+        }
+        return;
+    }
+    const AdamSlot s = slots[blockIdx.y];
     const double t = (double)(step_now + 1);
     const double bc1 = 1.0 - pow((double)beta1, t);
     const double bc2 = 1.0 - pow((double)beta2, t);
@@ -68,17 +95,7 @@ __global__ void k_log_total(float* __restrict__ vals, const float* __restrict__ 
                             int max_steps, float* __restrict__ log)
 {
     HM_LATENCY_KERNEL();
-    if (threadIdx.x == 0) {
-        const int c = blockIdx.x, nc = gridDim.x;
-        float* v = vals + (long)c * (n + 1);
-        float t = 0.f;
-        for (int i = 0; i < n; ++i)
-            if (w[i] != 0.f) t += w[i] * v[i];
-        v[n] = t;
-        const int s = step[0];
-        if (s < max_steps)
-            for (int i = 0; i <= n; ++i) log[((long)s * nc + c) * (n + 1) + i] = v[i];
-    }
+    if (threadIdx.x == 0) log_total_clip(vals, w, n, step[0], max_steps, log, blockIdx.x, gridDim.x);
 }
 
 extern "C" {
@@ -100,8 +117,20 @@ int hm_adam_step(const void* slots, int n_tensors, int* step, float beta1, float
                  int blocks_per_tensor, hipStream_t stream)
 {
     HM_CHECK_ARG(slots && step && n_tensors > 0 && blocks_per_tensor > 0);
-    hipLaunchKernelGGL(k_adam, dim3(blocks_per_tensor, n_tensors), dim3(256), 0, stream, (const AdamSlot*)slots, step,
-                       beta1, beta2, eps, zero_grad);
+    hipLaunchKernelGGL(k_adam, dim3(blocks_per_tensor, n_tensors), dim3(256), 0, stream, (const AdamSlot*)slots, n_tensors,
+                       step, beta1, beta2, eps, zero_grad, (float*)nullptr, (const float*)nullptr, 0, 0, (float*)nullptr, 0);
+    return hm_launch_status();
+}
+// hm_log_total_clips + hm_adam_step in ONE launch (same values, same log row: the row is written before the step counter
+// moves): the log of the step being taken costs no launch of its own.
+int hm_adam_step_log(const void* slots, int n_tensors, int* step, float beta1, float beta2, float eps, int zero_grad,
+                     int blocks_per_tensor, float* vals, const float* weights, int n, int max_steps, float* log, int nclips,
+                     hipStream_t stream)
+{
+    HM_CHECK_ARG(slots && step && n_tensors > 0 && blocks_per_tensor > 0);
+    HM_CHECK_ARG(vals && weights && log && n > 0 && nclips > 0);
+    hipLaunchKernelGGL(k_adam, dim3(blocks_per_tensor, n_tensors + 1), dim3(256), 0, stream, (const AdamSlot*)slots, n_tensors,
+                       step, beta1, beta2, eps, zero_grad, vals, weights, n, max_steps, log, nclips);
     return hm_launch_status();
 }
 int hm_log_scalars(const float* src, int n, const int* step, int max_steps, float* log, hipStream_t stream)

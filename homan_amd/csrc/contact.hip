@@ -8,6 +8,7 @@
 // (max over frames of the minimum hand-object vertex distance).
 // The (B,778,V_o) distance matrix (140 MB at cfg3) is never materialised: object vertices stream through LDS.
 #include "hm_common.h"
+#include "pair_bodies.h"
 
 #define NN_THREADS 256
 
@@ -16,14 +17,6 @@
 // time: lane l loads object vertex l of the group (coalesced), the group is then broadcast vertex by vertex with
 // v_readlane (scalar operands, no LDS round trip in the inner loop).  The partial minima are merged lexicographically
 // on (distance, index) so ties keep the lowest index.
-#define NN_HV 128
-#ifndef NN_WAVES      // (8 or 16 waves per 128 hand vertices: measured, no gain in the loop)
-#define NN_WAVES 4
-#endif
-__device__ __forceinline__ float rl_f(float v, int l)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-}
 __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ vh, const float* __restrict__ vo, int B,
                                                        int Vh, int Vo, int* __restrict__ nn_idx, float* __restrict__ nn_d2,
                                                        float* __restrict__ blockmin, unsigned int* counter,
@@ -116,95 +109,14 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
 //   3. only the groups whose lower bound does not exceed the best upper bound are scanned exactly (same arithmetic as k_nn):
 //      the closest approach of hand and object is a small neighbourhood, typically 2-3 of ~24 groups.
 // The result is the exact minimum (bounds carry a 1e-5 margin for their own rounding); blockmin / ticket / finish as k_nn.
-#define NN_MAX_GROUPS 64
 __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_min(const float* __restrict__ vh, const float* __restrict__ vo, int B,
                                                            int Vh, int Vo, float* __restrict__ blockmin,
                                                            unsigned int* counter, float* __restrict__ metric_out,
                                                            int clip_len, int out_stride, const int* __restrict__ obj_order)
 {
     HM_LATENCY_KERNEL();
-    __shared__ float s_sph[NN_MAX_GROUPS][4];
-    __shared__ float s_lb[NN_MAX_GROUPS];
-    __shared__ unsigned s_ub;
-    __shared__ int s_list[NN_MAX_GROUPS], s_n;
-    __shared__ float s_d[NN_WAVES][NN_HV];
-    __shared__ float red[16];
-    __shared__ int s_flag;
-    const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int ng = (Vo + 63) >> 6;
-    float hx[2], hy[2], hz[2];
-    bool hv[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = blockIdx.x * NN_HV + lane + 64 * u;
-        hv[u] = i < Vh;
-        hx[u] = hy[u] = hz[u] = 0.f;
-        if (hv[u]) { const float* p = vh + ((long)b * Vh + i) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2]; }
-    }
-    if (threadIdx.x == 0) { s_ub = 0x7f7fffffu; s_n = 0; }
-    __syncthreads();
-    // 1 + 2: spheres and bounds of this wave's groups
-    for (int g = q; g < ng; g += NN_WAVES) {
-        const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
-        float ox = 0.f, oy = 0.f, oz = 0.f;
-        if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
-        const float inv_n = 1.0f / (float)n;
-        const float cx = hm_wave_sum(ox) * inv_n, cy = hm_wave_sum(oy) * inv_n, cz = hm_wave_sum(oz) * inv_n;
-        const float ex = ox - cx, ey = oy - cy, ez = oz - cz;
-        const float rg = sqrtf(hm_wave_max(lane < n ? ex * ex + ey * ey + ez * ez : 0.f)) * (1.0f + 1e-5f);
-        float dc = 3.4e38f;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-            if (hv[u]) {
-                const float dx = cx - hx[u], dy = cy - hy[u], dz = cz - hz[u];
-                dc = fminf(dc, sqrtf(dx * dx + dy * dy + dz * dz));
-            }
-        dc = hm_wave_min(dc);
-        if (lane == 0) {
-            s_lb[g] = dc * (1.0f - 1e-5f) - rg;
-            atomicMin(&s_ub, __float_as_uint((dc * (1.0f + 1e-5f) + rg)));      // positive floats order like their bits
-        }
-    }
-    __syncthreads();
-    // 3: groups that can hold the minimum
-    if ((int)threadIdx.x < ng && s_lb[threadIdx.x] <= __uint_as_float(s_ub)) s_list[atomicAdd(&s_n, 1)] = threadIdx.x;
-    __syncthreads();
-    const int ns = s_n;
-    float best[2] = {3.4e38f, 3.4e38f};
-    for (int e = q; e < ns; e += NN_WAVES) {
-        const int g = s_list[e];
-        const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
-        float ox = 0.f, oy = 0.f, oz = 0.f;
-        if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
-        for (int k = 0; k < n; ++k) {
-            const float sx = rl_f(ox, k), sy = rl_f(oy, k), sz = rl_f(oz, k);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const float dx = sx - hx[u], dy = sy - hy[u], dz = sz - hz[u];
-                best[u] = fminf(best[u], dx * dx + dy * dy + dz * dz);
-            }
-        }
-    }
-    float bm = fminf(hv[0] ? best[0] : 3.4e38f, hv[1] ? best[1] : 3.4e38f);
-    bm = hm_block_min(bm, red);
-    const int clip = b / clip_len, bl = b - clip * clip_len;
-    blockmin += (long)clip * HM_RED_WS_FLOATS;
-    counter += (long)clip * HM_RED_WS_FLOATS;
-    const unsigned nblk = gridDim.x * clip_len;
-    if (threadIdx.x == 0) hm_partial_store(blockmin + bl * gridDim.x + blockIdx.x, bm);
-    if (hm_last_block(counter, nblk, &s_flag)) {
-        float* s_bm = &s_d[0][0];
-        for (unsigned i2 = threadIdx.x; i2 < nblk; i2 += blockDim.x) s_bm[i2] = hm_partial_load(blockmin + i2);
-        __syncthreads();
-        float mx = -3.4e38f;
-        for (int bb = threadIdx.x; bb < clip_len; bb += blockDim.x) {
-            float m = 3.4e38f;
-            for (unsigned c = 0; c < gridDim.x; ++c) m = fminf(m, s_bm[bb * gridDim.x + c]);
-            mx = fmaxf(mx, sqrtf(m));
-        }
-        mx = hm_block_max(mx, red);
-        if (threadIdx.x == 0) metric_out[(long)clip * out_stride] = mx;
-    }
+    nn_min_body(vh, vo, B, Vh, Vo, blockmin, counter, metric_out, clip_len, out_stride, obj_order, blockIdx.x, blockIdx.y,
+                gridDim.x);
 }
 
 // Contact loss, hand side.  grid (B): value, d/d hand vertex (= minus the pull on the matched object vertex),

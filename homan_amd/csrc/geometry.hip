@@ -196,12 +196,23 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
             for (int k = 0; k < 13; ++k) hm_partial_store(rec + k, tot[k]);
         }
         if (!hm_last_block(frame_cnt + n, gridDim.y, &s_flag)) return;
+        // all records in ONE round trip (a thread per value), then the sums in chunk order: deterministic, and the frame's
+        // tail is one memory latency instead of one per chunk (<= 16 chunks x 13 values fit red13)
+#ifdef HM_RIGID_SERIAL_TAIL      // (A/B: the round-1 tail, one dependent round trip per chunk)
+        if (threadIdx.x == 0)
+            for (unsigned c = 0; c < gridDim.y; ++c)
+                for (int k = 0; k < 13; ++k) red13[c * 13 + k] = hm_partial_load(partials + ((long)n * gridDim.y + c) * 16 + k);
+#else
+        if (threadIdx.x < 13 * gridDim.y)
+            red13[threadIdx.x] = hm_partial_load(partials + ((long)n * gridDim.y + threadIdx.x / 13) * 16 + threadIdx.x % 13);
+#endif
+        __syncthreads();
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < 13; ++k) tot[k] = 0.f;
-            for (unsigned c = 0; c < gridDim.y; ++c)       // fixed order: deterministic
+            for (unsigned c = 0; c < gridDim.y; ++c)       // fixed order
 #pragma unroll
-                for (int k = 0; k < 13; ++k) tot[k] += hm_partial_load(partials + ((long)n * gridDim.y + c) * 16 + k);
+                for (int k = 0; k < 13; ++k) tot[k] += red13[c * 13 + k];
         }
     }
     if (threadIdx.x == 0) {

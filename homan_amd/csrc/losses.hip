@@ -7,8 +7,7 @@
 //   hm_inter_fwd/bwd  reference homan/losses.py:20-49,98-139,199-242 + utils/bbox.py:111-135 +
 //                     utils/geometry.py:69-86 (coarse interaction: bbox-IoU / z gating, centroid MSE, summed)
 #include "hm_common.h"
-
-#define RED_THREADS 256
+#include "pair_bodies.h"
 
 // ------------------------------------------------------------------ clip batches
 // Every reduction kernel below takes grid (nblk, clips): row blockIdx.y works on clip blockIdx.y - N frames of its own,
@@ -70,34 +69,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_smooth(const float* __restrict_
                                                          float* __restrict__ unit_grad, float* __restrict__ partials,
                                                          unsigned int* counter, float* __restrict__ out, int out_stride)
 {
-    __shared__ float red[16];
-    __shared__ int s_flag;
-    CLIP_ADVANCE(verts, V * 3); CLIP_ADVANCE(unit_grad, V * 3);
-    CLIP_WS(partials, counter);
-    out += (long)blockIdx.y * out_stride;
-    const long row = (long)V * 3, total = (long)N * row;
-    const long cnt = (long)(N - hand_nb) * row;
-    const float inv_cnt = cnt > 0 ? 1.0f / (float)cnt : 0.f;
-    const long step = (long)hand_nb * row;
-    float lsum = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(i / row);
-        const float v = verts[i];
-        float g = 0.f;
-        if (n + hand_nb < N) {
-            const float d = verts[i + step] - v;
-            lsum += d * d;
-            g -= d;
-        }
-        if (n - hand_nb >= 0) g += v - verts[i - step];
-        unit_grad[i] = 2.0f * g * inv_cnt;
-    }
-    lsum = hm_block_sum(lsum, red);
-    if (threadIdx.x == 0) hm_partial_store(partials + blockIdx.x, lsum);
-    if (hm_last_block(counter, gridDim.x, &s_flag)) {
-        const float a = hm_last_block_sum(partials, gridDim.x, 1, red);
-        if (threadIdx.x == 0) out[0] = a * inv_cnt;
-    }
+    smooth_body(verts, N, V, hand_nb, unit_grad, partials, counter, out, out_stride, blockIdx.x, blockIdx.y, gridDim.x);
 }
 
 // ------------------------------------------------------------------ PCA prior + intrinsic scale priors (one block per clip)
@@ -147,93 +119,9 @@ __global__ __launch_bounds__(RED_THREADS) void k_hand_terms(
     float* __restrict__ g_shand, float* __restrict__ out_priors, float* __restrict__ partials, unsigned int* counter,
     int out_stride)
 {
-    __shared__ float red[16];
-    __shared__ int s_flag;
-    CLIP_ADVANCE(verts, V * 3); CLIP_ADVANCE(ref2d, V * 2); CLIP_ADVANCE(unit_v2d, V * 3); CLIP_ADVANCE(unit_smooth, V * 3);
-    camintr += (long)blockIdx.y * (N / hand_nb) * 9;
-    CLIP_WS(partials, counter);
-    out_v2d += (long)blockIdx.y * out_stride;
-    out_smooth += (long)blockIdx.y * out_stride;
-    if (pca) {
-        pca += (long)blockIdx.y * npca; g_pca += (long)blockIdx.y * npca;
-        s_obj += blockIdx.y; m_obj += blockIdx.y; s_hand += blockIdx.y; m_hand += blockIdx.y;
-        g_sobj += blockIdx.y; g_shand += blockIdx.y;
-        out_priors += (long)blockIdx.y * out_stride;
-    }
-    // ---- v2d
-    const long total = (long)N * V;
-    const float inv_cnt = 1.0f / (float)total;
-    float lsum = 0.f, msum = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(i / V);
-        const float* k = camintr + (n / hand_nb) * 9;
-        const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
-        const float hx = k[0] * x + k[1] * y + k[2] * z;
-        const float hy = k[3] * x + k[4] * y + k[5] * z;
-        const float hz = k[6] * x + k[7] * y + k[8] * z;
-        const float px = hx / hz, py = hy / hz;
-        const float rx = ref2d[2 * i], ry = ref2d[2 * i + 1];
-        const float dx = px - rx / image_size, dy = py - ry / image_size;
-        lsum += dx * dx + dy * dy;
-        const float mx = px * image_size - rx, my = py * image_size - ry;
-        msum += sqrtf(mx * mx + my * my);
-        const float gpx = 2.0f * dx * inv_cnt, gpy = 2.0f * dy * inv_cnt;
-        const float ghx = gpx / hz, ghy = gpy / hz, ghz = -(gpx * hx + gpy * hy) / (hz * hz);
-        unit_v2d[3 * i] = k[0] * ghx + k[3] * ghy + k[6] * ghz;
-        unit_v2d[3 * i + 1] = k[1] * ghx + k[4] * ghy + k[7] * ghz;
-        unit_v2d[3 * i + 2] = k[2] * ghx + k[5] * ghy + k[8] * ghz;
-    }
-    // ---- temporal smoothness
-    const long row = (long)V * 3, etotal = (long)N * row;
-    const long cnt = (long)(N - hand_nb) * row;
-    const float sinv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
-    const long step = (long)hand_nb * row;
-    float ssum = 0.f;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < etotal; i += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(i / row);
-        const float v = verts[i];
-        float g = 0.f;
-        if (n + hand_nb < N) {
-            const float d = verts[i + step] - v;
-            ssum += d * d;
-            g -= d;
-        }
-        if (n - hand_nb >= 0) g += v - verts[i - step];
-        unit_smooth[i] = 2.0f * g * sinv;
-    }
-    lsum = hm_block_sum(lsum, red);
-    msum = hm_block_sum(msum, red);
-    ssum = hm_block_sum(ssum, red);
-    // ---- priors (block 0)
-    if (pca && blockIdx.x == 0) {
-        float a = 0.f;
-        const float inv = 1.0f / (float)npca;
-        for (long i = threadIdx.x; i < npca; i += blockDim.x) {
-            const float p = pca[i];
-            a += p * p;
-            g_pca[i] = 2.0f * p * inv;
-        }
-        a = hm_block_sum(a, red);
-        if (threadIdx.x == 0) {
-            out_priors[0] = a * inv;
-            const float d0 = s_obj[0] - m_obj[0], d1 = s_hand[0] - m_hand[0];
-            out_priors[1] = d0 * d0;
-            out_priors[2] = d1 * d1;
-            g_sobj[0] = 2.0f * d0;
-            g_shand[0] = 2.0f * d1;
-        }
-    }
-    if (threadIdx.x == 0) {
-        hm_partial_store(partials + 3 * blockIdx.x, lsum);
-        hm_partial_store(partials + 3 * blockIdx.x + 1, msum);
-        hm_partial_store(partials + 3 * blockIdx.x + 2, ssum);
-    }
-    if (hm_last_block(counter, gridDim.x, &s_flag)) {
-        const float a = hm_last_block_sum(partials, gridDim.x, 3, red);
-        const float b = hm_last_block_sum(partials + 1, gridDim.x, 3, red);
-        const float c = hm_last_block_sum(partials + 2, gridDim.x, 3, red);
-        if (threadIdx.x == 0) { out_v2d[0] = a * inv_cnt; out_v2d[1] = b * inv_cnt; out_smooth[0] = c * sinv; }
-    }
+    hand_terms_body(verts, camintr, hand_nb, ref2d, image_size, N, V, unit_v2d, out_v2d, unit_smooth, out_smooth, pca, npca, s_obj,
+                    m_obj, s_hand, m_hand, g_pca, g_sobj, g_shand, out_priors, partials, counter, out_stride, blockIdx.x,
+                    blockIdx.y, gridDim.x);
 }
 
 // ------------------------------------------------------------------ coarse interaction loss
@@ -247,92 +135,7 @@ __global__ __launch_bounds__(RED_THREADS) void k_inter(const float* __restrict__
                                                         int out_stride)
 {
     HM_LATENCY_KERNEL();
-    __shared__ float red[16];
-    __shared__ int s_flag;
-    const int b = blockIdx.x, clip = b / clip_len;
-    counter += (long)clip * HM_RED_WS_FLOATS;
-    const float* k = camintr + b * 9;
-    // the 2 x 9 block reductions (six extrema + three sums per mesh) meet in LDS behind ONE barrier: wave results by DPP,
-    // then the per-wave values combined in wave order (the order hm_block_sum uses, so the sums are the same floats)
-    __shared__ float s_red[2][9][RED_THREADS / 64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float box[2][4], zr[2][2], cen[2][3];
-    for (int which = 0; which < 2; ++which) {
-        const float* v = which == 0 ? vo + (long)b * Vo * 3 : vh + (long)b * Vh * 3;
-        const int V = which == 0 ? Vo : Vh;
-        float umin = 3.4e38f, umax = -3.4e38f, vmin = 3.4e38f, vmax = -3.4e38f, zmin = 3.4e38f, zmax = -3.4e38f;
-        float sx = 0.f, sy = 0.f, sz = 0.f;
-        for (int i = threadIdx.x; i < V; i += blockDim.x) {
-            const float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
-            const float zz = z + 1e-9f;
-            const float xn = x / zz, yn = (y * -1.0f) / zz;
-            float u = xn * k[0] + yn * k[1];
-            u = u + k[2];
-            float w = xn * k[3] + yn * k[4];
-            w = w + k[5];
-            w = 1.0f - w;
-            u = 2.0f * (u - 0.5f);
-            w = 2.0f * (w - 0.5f);
-            umin = fminf(umin, u); umax = fmaxf(umax, u);
-            vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
-            zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
-            sx += x; sy += y; sz += z;
-        }
-        const float r9[9] = {hm_wave_min(umin), hm_wave_max(umax), hm_wave_min(vmin), hm_wave_max(vmax), hm_wave_min(zmin),
-                             hm_wave_max(zmax), hm_wave_sum(sx), hm_wave_sum(sy), hm_wave_sum(sz)};
-        if (lane == 0) {
-#pragma unroll
-            for (int q = 0; q < 9; ++q) s_red[which][q][wv] = r9[q];
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int nw = blockDim.x >> 6;
-        for (int which = 0; which < 2; ++which) {
-            const int V = which == 0 ? Vo : Vh;
-            float t[9];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                float a = q < 6 ? s_red[which][q][0] : 0.f;
-                for (int i = q < 6 ? 1 : 0; i < nw; ++i) {
-                    const float x = s_red[which][q][i];
-                    a = q >= 6 ? a + x : ((q & 1) ? fmaxf(a, x) : fminf(a, x));
-                }
-                t[q] = a;
-            }
-            const float cx = (t[0] + t[1]) / 2.0f, cy = (t[2] + t[3]) / 2.0f;
-            const float ex = (t[1] - t[0]) / 2.0f * (1.0f + expansion), ey = (t[3] - t[2]) / 2.0f * (1.0f + expansion);
-            box[which][0] = cx - ex; box[which][1] = cy - ey; box[which][2] = cx + ex; box[which][3] = cy + ey;
-            zr[which][0] = t[4]; zr[which][1] = t[5];
-            cen[which][0] = t[6] / (float)V; cen[which][1] = t[7] / (float)V; cen[which][2] = t[8] / (float)V;
-        }
-    }
-    if (threadIdx.x == 0) {
-        // compute_iou(box_obj, box_hand)
-        const float a1 = (box[0][2] - box[0][0]) * (box[0][3] - box[0][1]);
-        const float a2 = (box[1][2] - box[1][0]) * (box[1][3] - box[1][1]);
-        const float w = fmaxf(fminf(box[0][2], box[1][2]) - fmaxf(box[0][0], box[1][0]), 0.f);
-        const float h = fmaxf(fminf(box[0][3], box[1][3]) - fmaxf(box[0][1], box[1][1]), 0.f);
-        const float inter = w * h;
-        const float iou = inter / (a1 + a2 - inter);
-        // compute_dist_z(verts_object, verts_hand)
-        const float a = zr[0][0], bb = zr[0][1], c = zr[1][0], d = zr[1][1];
-        const float zd = (d >= a && bb >= c) ? 0.f : fminf(fabsf(c - bb), fabsf(a - d));
-        const float flag = ((iou > 0.f) && (zd < zthresh)) ? 1.f : 0.f;
-        const float dx = cen[1][0] - cen[0][0], dy = cen[1][1] - cen[0][1], dz = cen[1][2] - cen[0][2];
-        const float mse = (dx * dx + dy * dy + dz * dz) / 3.0f;
-        float* r = frame_rec + b * 8;
-        hm_partial_store(r, flag); hm_partial_store(r + 1, mse);
-        r[2] = flag * 2.0f * dx / 3.0f; r[3] = flag * 2.0f * dy / 3.0f; r[4] = flag * 2.0f * dz / 3.0f;
-    }
-    if (hm_last_block(counter, clip_len, &s_flag)) {       // the clip's last frame sums the clip
-        const float* fr = frame_rec + (long)clip * clip_len * 8;
-        float l = 0.f;
-        for (int i = threadIdx.x; i < clip_len; i += blockDim.x)
-            if (hm_partial_load(fr + i * 8) != 0.f) l += hm_partial_load(fr + i * 8 + 1);
-        l = hm_block_sum(l, red);
-        if (threadIdx.x == 0) out[(long)clip * out_stride] = l;
-    }
+    inter_body(vh, vo, camintr, B, Vh, Vo, expansion, zthresh, frame_rec, counter, out, clip_len, out_stride, blockIdx.x);
 }
 
 // d loss_inter / d verts: hand gets +gvec/Vh, object gets -gvec/Vo (either output may be NULL)

@@ -1,0 +1,336 @@
+// pair_bodies.h -- bodies of three small reduction kernels as device functions on VIRTUAL block coordinates (bx, by, gdx
+// instead of blockIdx.x / blockIdx.y / gridDim.x), so that each runs either as its own launch (losses.hip: k_smooth, k_inter;
+// contact.hip: k_nn_min) or as a block range of the fused pair-terms launch (pairterms.hip).  256 threads per block in
+// every case; the arithmetic and the summation orders do not depend on which way a body is launched.
+#pragma once
+#include "hm_common.h"
+
+#define RED_THREADS 256
+#define NN_HV 128
+#ifndef NN_WAVES      // (8 or 16 waves per 128 hand vertices: measured, no gain in the loop)
+#define NN_WAVES 4
+#endif
+#define NN_MAX_GROUPS 64
+__device__ __forceinline__ float rl_f(float v, int l)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+// temporal smoothness (reference homan/lossutils.py:18-36): see k_smooth
+__device__ __forceinline__ void smooth_body(const float* __restrict__ verts, int N, int V, int hand_nb,
+                                            float* __restrict__ unit_grad, float* __restrict__ partials,
+                                            unsigned int* counter, float* __restrict__ out, int out_stride, int bx, int by,
+                                            int gdx)
+{
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    verts += (long)by * N * (V * 3); unit_grad += (long)by * N * (V * 3);
+    partials += (long)by * HM_RED_WS_FLOATS; counter += (long)by * HM_RED_WS_FLOATS;
+    out += (long)by * out_stride;
+    const long row = (long)V * 3, total = (long)N * row;
+    const long cnt = (long)(N - hand_nb) * row;
+    const float inv_cnt = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    const long step = (long)hand_nb * row;
+    float lsum = 0.f;
+    for (long i = (long)bx * blockDim.x + threadIdx.x; i < total; i += (long)gdx * blockDim.x) {
+        const int n = (int)(i / row);
+        const float v = verts[i];
+        float g = 0.f;
+        if (n + hand_nb < N) {
+            const float d = verts[i + step] - v;
+            lsum += d * d;
+            g -= d;
+        }
+        if (n - hand_nb >= 0) g += v - verts[i - step];
+        unit_grad[i] = 2.0f * g * inv_cnt;
+    }
+    lsum = hm_block_sum(lsum, red);
+    if (threadIdx.x == 0) hm_partial_store(partials + bx, lsum);
+    if (hm_last_block(counter, gdx, &s_flag)) {
+        const float a = hm_last_block_sum(partials, gdx, 1, red);
+        if (threadIdx.x == 0) out[0] = a * inv_cnt;
+    }
+}
+
+// coarse interaction loss (reference homan/losses.py:199-242): see k_inter
+__device__ __forceinline__ void inter_body(const float* __restrict__ vh, const float* __restrict__ vo,
+                                           const float* __restrict__ camintr, int B, int Vh, int Vo, float expansion,
+                                           float zthresh, float* __restrict__ frame_rec, unsigned int* counter,
+                                           float* __restrict__ out, int clip_len, int out_stride, int bx)
+{
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    const int b = bx, clip = b / clip_len;
+    counter += (long)clip * HM_RED_WS_FLOATS;
+    const float* k = camintr + b * 9;
+    // the 2 x 9 block reductions (six extrema + three sums per mesh) meet in LDS behind ONE barrier: wave results by DPP,
+    // then the per-wave values combined in wave order (the order hm_block_sum uses, so the sums are the same floats)
+    __shared__ float s_red[2][9][RED_THREADS / 64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float box[2][4], zr[2][2], cen[2][3];
+    for (int which = 0; which < 2; ++which) {
+        const float* v = which == 0 ? vo + (long)b * Vo * 3 : vh + (long)b * Vh * 3;
+        const int V = which == 0 ? Vo : Vh;
+        float umin = 3.4e38f, umax = -3.4e38f, vmin = 3.4e38f, vmax = -3.4e38f, zmin = 3.4e38f, zmax = -3.4e38f;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int i = threadIdx.x; i < V; i += blockDim.x) {
+            const float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
+            const float zz = z + 1e-9f;
+            const float xn = x / zz, yn = (y * -1.0f) / zz;
+            float u = xn * k[0] + yn * k[1];
+            u = u + k[2];
+            float w = xn * k[3] + yn * k[4];
+            w = w + k[5];
+            w = 1.0f - w;
+            u = 2.0f * (u - 0.5f);
+            w = 2.0f * (w - 0.5f);
+            umin = fminf(umin, u); umax = fmaxf(umax, u);
+            vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+            zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+            sx += x; sy += y; sz += z;
+        }
+        const float r9[9] = {hm_wave_min(umin), hm_wave_max(umax), hm_wave_min(vmin), hm_wave_max(vmax), hm_wave_min(zmin),
+                             hm_wave_max(zmax), hm_wave_sum(sx), hm_wave_sum(sy), hm_wave_sum(sz)};
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 9; ++q) s_red[which][q][wv] = r9[q];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nw = blockDim.x >> 6;
+        for (int which = 0; which < 2; ++which) {
+            const int V = which == 0 ? Vo : Vh;
+            float t[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                float a = q < 6 ? s_red[which][q][0] : 0.f;
+                for (int i = q < 6 ? 1 : 0; i < nw; ++i) {
+                    const float x = s_red[which][q][i];
+                    a = q >= 6 ? a + x : ((q & 1) ? fmaxf(a, x) : fminf(a, x));
+                }
+                t[q] = a;
+            }
+            const float cx = (t[0] + t[1]) / 2.0f, cy = (t[2] + t[3]) / 2.0f;
+            const float ex = (t[1] - t[0]) / 2.0f * (1.0f + expansion), ey = (t[3] - t[2]) / 2.0f * (1.0f + expansion);
+            box[which][0] = cx - ex; box[which][1] = cy - ey; box[which][2] = cx + ex; box[which][3] = cy + ey;
+            zr[which][0] = t[4]; zr[which][1] = t[5];
+            cen[which][0] = t[6] / (float)V; cen[which][1] = t[7] / (float)V; cen[which][2] = t[8] / (float)V;
+        }
+    }
+    if (threadIdx.x == 0) {
+        // compute_iou(box_obj, box_hand)
+        const float a1 = (box[0][2] - box[0][0]) * (box[0][3] - box[0][1]);
+        const float a2 = (box[1][2] - box[1][0]) * (box[1][3] - box[1][1]);
+        const float w = fmaxf(fminf(box[0][2], box[1][2]) - fmaxf(box[0][0], box[1][0]), 0.f);
+        const float h = fmaxf(fminf(box[0][3], box[1][3]) - fmaxf(box[0][1], box[1][1]), 0.f);
+        const float inter = w * h;
+        const float iou = inter / (a1 + a2 - inter);
+        // compute_dist_z(verts_object, verts_hand)
+        const float a = zr[0][0], bb = zr[0][1], c = zr[1][0], d = zr[1][1];
+        const float zd = (d >= a && bb >= c) ? 0.f : fminf(fabsf(c - bb), fabsf(a - d));
+        const float flag = ((iou > 0.f) && (zd < zthresh)) ? 1.f : 0.f;
+        const float dx = cen[1][0] - cen[0][0], dy = cen[1][1] - cen[0][1], dz = cen[1][2] - cen[0][2];
+        const float mse = (dx * dx + dy * dy + dz * dz) / 3.0f;
+        float* r = frame_rec + b * 8;
+        hm_partial_store(r, flag); hm_partial_store(r + 1, mse);
+        r[2] = flag * 2.0f * dx / 3.0f; r[3] = flag * 2.0f * dy / 3.0f; r[4] = flag * 2.0f * dz / 3.0f;
+    }
+    if (hm_last_block(counter, clip_len, &s_flag)) {       // the clip's last frame sums the clip
+        const float* fr = frame_rec + (long)clip * clip_len * 8;
+        float l = 0.f;
+        for (int i = threadIdx.x; i < clip_len; i += blockDim.x)
+            if (hm_partial_load(fr + i * 8) != 0.f) l += hm_partial_load(fr + i * 8 + 1);
+        l = hm_block_sum(l, red);
+        if (threadIdx.x == 0) out[(long)clip * out_stride] = l;
+    }
+}
+
+// metric-only nearest-vertex search (reference homan/losses.py:225-241): see k_nn_min
+__device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const float* __restrict__ vo, int B, int Vh, int Vo,
+                                            float* __restrict__ blockmin, unsigned int* counter,
+                                            float* __restrict__ metric_out, int clip_len, int out_stride,
+                                            const int* __restrict__ obj_order, int bx, int by, int gdx)
+{
+    __shared__ float s_sph[NN_MAX_GROUPS][4];
+    __shared__ float s_lb[NN_MAX_GROUPS];
+    __shared__ unsigned s_ub;
+    __shared__ int s_list[NN_MAX_GROUPS], s_n;
+    __shared__ float s_d[NN_WAVES][NN_HV];
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    const int b = by, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int ng = (Vo + 63) >> 6;
+    float hx[2], hy[2], hz[2];
+    bool hv[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = bx * NN_HV + lane + 64 * u;
+        hv[u] = i < Vh;
+        hx[u] = hy[u] = hz[u] = 0.f;
+        if (hv[u]) { const float* p = vh + ((long)b * Vh + i) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2]; }
+    }
+    if (threadIdx.x == 0) { s_ub = 0x7f7fffffu; s_n = 0; }
+    __syncthreads();
+    // 1 + 2: spheres and bounds of this wave's groups
+    for (int g = q; g < ng; g += NN_WAVES) {
+        const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
+        const float inv_n = 1.0f / (float)n;
+        const float cx = hm_wave_sum(ox) * inv_n, cy = hm_wave_sum(oy) * inv_n, cz = hm_wave_sum(oz) * inv_n;
+        const float ex = ox - cx, ey = oy - cy, ez = oz - cz;
+        const float rg = sqrtf(hm_wave_max(lane < n ? ex * ex + ey * ey + ez * ez : 0.f)) * (1.0f + 1e-5f);
+        float dc = 3.4e38f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (hv[u]) {
+                const float dx = cx - hx[u], dy = cy - hy[u], dz = cz - hz[u];
+                dc = fminf(dc, sqrtf(dx * dx + dy * dy + dz * dz));
+            }
+        dc = hm_wave_min(dc);
+        if (lane == 0) {
+            s_lb[g] = dc * (1.0f - 1e-5f) - rg;
+            atomicMin(&s_ub, __float_as_uint((dc * (1.0f + 1e-5f) + rg)));      // positive floats order like their bits
+        }
+    }
+    __syncthreads();
+    // 3: groups that can hold the minimum
+    if ((int)threadIdx.x < ng && s_lb[threadIdx.x] <= __uint_as_float(s_ub)) s_list[atomicAdd(&s_n, 1)] = threadIdx.x;
+    __syncthreads();
+    const int ns = s_n;
+    float best[2] = {3.4e38f, 3.4e38f};
+    for (int e = q; e < ns; e += NN_WAVES) {
+        const int g = s_list[e];
+        const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
+        float ox = 0.f, oy = 0.f, oz = 0.f;
+        if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
+        for (int k = 0; k < n; ++k) {
+            const float sx = rl_f(ox, k), sy = rl_f(oy, k), sz = rl_f(oz, k);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const float dx = sx - hx[u], dy = sy - hy[u], dz = sz - hz[u];
+                best[u] = fminf(best[u], dx * dx + dy * dy + dz * dz);
+            }
+        }
+    }
+    float bm = fminf(hv[0] ? best[0] : 3.4e38f, hv[1] ? best[1] : 3.4e38f);
+    bm = hm_block_min(bm, red);
+    const int clip = b / clip_len, bl = b - clip * clip_len;
+    blockmin += (long)clip * HM_RED_WS_FLOATS;
+    counter += (long)clip * HM_RED_WS_FLOATS;
+    const unsigned nblk = gdx * clip_len;
+    if (threadIdx.x == 0) hm_partial_store(blockmin + bl * gdx + bx, bm);
+    if (hm_last_block(counter, nblk, &s_flag)) {
+        float* s_bm = &s_d[0][0];
+        for (unsigned i2 = threadIdx.x; i2 < nblk; i2 += blockDim.x) s_bm[i2] = hm_partial_load(blockmin + i2);
+        __syncthreads();
+        float mx = -3.4e38f;
+        for (int bb = threadIdx.x; bb < clip_len; bb += blockDim.x) {
+            float m = 3.4e38f;
+            for (unsigned c = 0; c < gdx; ++c) m = fminf(m, s_bm[bb * gdx + c]);
+            mx = fmaxf(mx, sqrtf(m));
+        }
+        mx = hm_block_max(mx, red);
+        if (threadIdx.x == 0) metric_out[(long)clip * out_stride] = mx;
+    }
+}
+
+// 2-D reprojection + temporal smoothness of the hand vertices + priors: see k_hand_terms
+__device__ __forceinline__ void hand_terms_body(
+    const float* __restrict__ verts, const float* __restrict__ camintr, int hand_nb, const float* __restrict__ ref2d,
+    float image_size, int N, int V, float* __restrict__ unit_v2d, float* __restrict__ out_v2d,
+    float* __restrict__ unit_smooth, float* __restrict__ out_smooth, const float* __restrict__ pca, long npca,
+    const float* __restrict__ s_obj, const float* __restrict__ m_obj, const float* __restrict__ s_hand,
+    const float* __restrict__ m_hand, float* __restrict__ g_pca, float* __restrict__ g_sobj,
+    float* __restrict__ g_shand, float* __restrict__ out_priors, float* __restrict__ partials, unsigned int* counter,
+    int out_stride, int bx, int by, int gdx)
+{
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    verts += (long)by * N * (V * 3); ref2d += (long)by * N * (V * 2); unit_v2d += (long)by * N * (V * 3); unit_smooth += (long)by * N * (V * 3);
+    camintr += (long)by * (N / hand_nb) * 9;
+    partials += (long)by * HM_RED_WS_FLOATS; counter += (long)by * HM_RED_WS_FLOATS;
+    out_v2d += (long)by * out_stride;
+    out_smooth += (long)by * out_stride;
+    if (pca) {
+        pca += (long)by * npca; g_pca += (long)by * npca;
+        s_obj += by; m_obj += by; s_hand += by; m_hand += by;
+        g_sobj += by; g_shand += by;
+        out_priors += (long)by * out_stride;
+    }
+    // ---- v2d
+    const long total = (long)N * V;
+    const float inv_cnt = 1.0f / (float)total;
+    float lsum = 0.f, msum = 0.f;
+    for (long i = (long)bx * blockDim.x + threadIdx.x; i < total; i += (long)gdx * blockDim.x) {
+        const int n = (int)(i / V);
+        const float* k = camintr + (n / hand_nb) * 9;
+        const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+        const float hx = k[0] * x + k[1] * y + k[2] * z;
+        const float hy = k[3] * x + k[4] * y + k[5] * z;
+        const float hz = k[6] * x + k[7] * y + k[8] * z;
+        const float px = hx / hz, py = hy / hz;
+        const float rx = ref2d[2 * i], ry = ref2d[2 * i + 1];
+        const float dx = px - rx / image_size, dy = py - ry / image_size;
+        lsum += dx * dx + dy * dy;
+        const float mx = px * image_size - rx, my = py * image_size - ry;
+        msum += sqrtf(mx * mx + my * my);
+        const float gpx = 2.0f * dx * inv_cnt, gpy = 2.0f * dy * inv_cnt;
+        const float ghx = gpx / hz, ghy = gpy / hz, ghz = -(gpx * hx + gpy * hy) / (hz * hz);
+        unit_v2d[3 * i] = k[0] * ghx + k[3] * ghy + k[6] * ghz;
+        unit_v2d[3 * i + 1] = k[1] * ghx + k[4] * ghy + k[7] * ghz;
+        unit_v2d[3 * i + 2] = k[2] * ghx + k[5] * ghy + k[8] * ghz;
+    }
+    // ---- temporal smoothness
+    const long row = (long)V * 3, etotal = (long)N * row;
+    const long cnt = (long)(N - hand_nb) * row;
+    const float sinv = cnt > 0 ? 1.0f / (float)cnt : 0.f;
+    const long step = (long)hand_nb * row;
+    float ssum = 0.f;
+    for (long i = (long)bx * blockDim.x + threadIdx.x; i < etotal; i += (long)gdx * blockDim.x) {
+        const int n = (int)(i / row);
+        const float v = verts[i];
+        float g = 0.f;
+        if (n + hand_nb < N) {
+            const float d = verts[i + step] - v;
+            ssum += d * d;
+            g -= d;
+        }
+        if (n - hand_nb >= 0) g += v - verts[i - step];
+        unit_smooth[i] = 2.0f * g * sinv;
+    }
+    lsum = hm_block_sum(lsum, red);
+    msum = hm_block_sum(msum, red);
+    ssum = hm_block_sum(ssum, red);
+    // ---- priors (block 0)
+    if (pca && bx == 0) {
+        float a = 0.f;
+        const float inv = 1.0f / (float)npca;
+        for (long i = threadIdx.x; i < npca; i += blockDim.x) {
+            const float p = pca[i];
+            a += p * p;
+            g_pca[i] = 2.0f * p * inv;
+        }
+        a = hm_block_sum(a, red);
+        if (threadIdx.x == 0) {
+            out_priors[0] = a * inv;
+            const float d0 = s_obj[0] - m_obj[0], d1 = s_hand[0] - m_hand[0];
+            out_priors[1] = d0 * d0;
+            out_priors[2] = d1 * d1;
+            g_sobj[0] = 2.0f * d0;
+            g_shand[0] = 2.0f * d1;
+        }
+    }
+    if (threadIdx.x == 0) {
+        hm_partial_store(partials + 3 * bx, lsum);
+        hm_partial_store(partials + 3 * bx + 1, msum);
+        hm_partial_store(partials + 3 * bx + 2, ssum);
+    }
+    if (hm_last_block(counter, gdx, &s_flag)) {
+        const float a = hm_last_block_sum(partials, gdx, 3, red);
+        const float b = hm_last_block_sum(partials + 1, gdx, 3, red);
+        const float c = hm_last_block_sum(partials + 2, gdx, 3, red);
+        if (threadIdx.x == 0) { out_v2d[0] = a * inv_cnt; out_v2d[1] = b * inv_cnt; out_smooth[0] = c * sinv; }
+    }
+}

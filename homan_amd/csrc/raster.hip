@@ -761,15 +761,13 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
 // grid (B): per-frame sums of the tile partials, then the last block of every clip (clip_len consecutive frames) finishes:
 // loss = (sum_sq / keep_sum[clip]) / clip_len ; iou = mean_b inter_b / (union_b + eps) over the clip's frames.
 // out[clip*out_stride + 0]=loss, [+1]=iou.  The clip's ticket word is slot 3 of the frame record of its first frame.
-__global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ partials, int B, int ntiles,
-                                                     const float* __restrict__ keep_sum, float* __restrict__ frame_rec,
-                                                     float* __restrict__ out, float* __restrict__ frame_out, int clip_len,
-                                                     int out_stride)
+__device__ __forceinline__ void sil_reduce_frame(int b, const float* __restrict__ partials, int ntiles,
+                                                 const float* __restrict__ keep_sum, float* __restrict__ frame_rec,
+                                                 float* __restrict__ out, float* __restrict__ frame_out, int clip_len,
+                                                 int out_stride)
 {
-    HM_LATENCY_KERNEL();
     __shared__ float red[16];
     __shared__ int s_flag;
-    const int b = blockIdx.x;
     float sq = 0.f, in = 0.f, un = 0.f;
     for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
         const float4 p = *reinterpret_cast<const float4*>(partials + ((long)b * ntiles + t) * 4);
@@ -792,6 +790,14 @@ __global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ pa
             out[(long)clip * out_stride + 1] = iou_sum / (float)clip_len;
         }
     }
+}
+__global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ partials, int B, int ntiles,
+                                                     const float* __restrict__ keep_sum, float* __restrict__ frame_rec,
+                                                     float* __restrict__ out, float* __restrict__ frame_out, int clip_len,
+                                                     int out_stride)
+{
+    HM_LATENCY_KERNEL();
+    sil_reduce_frame(blockIdx.x, partials, ntiles, keep_sum, frame_rec, out, frame_out, clip_len, out_stride);
 }
 
 // ---------------------------------------------------------------- backward, pass 1: masks + sample-gradient image
@@ -1070,7 +1076,9 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    const FaceBox* __restrict__ boxes,
                                                    const unsigned char* __restrict__ owned, int F,
                                                    float* __restrict__ parts, SweepList sl, int clip_len,
-                                                   unsigned short* __restrict__ lsum)
+                                                   unsigned short* __restrict__ lsum, int nred,
+                                                   const float* __restrict__ red_partials, float* __restrict__ frame_rec,
+                                                   float* __restrict__ loss_out, int out_stride)
 {
     __shared__ unsigned long long s_w[16][SWEEP_CUMW];
     __shared__ int s_ex[16][SWEEP_CUMW];
@@ -1079,9 +1087,16 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
         sweep_compact(blockIdx.x, ncomp, fpt, faces9, boxes, owned, B, F, 2 * S, parts, sl, clip_len);
         return;
     }
+    // the next `nred` (= B or 0) finish the forward's fused loss: one launch less on the chain of a caller that only needs
+    // the loss value for its log (see hm_sil_bwd_clips)
+    if ((int)blockIdx.x < ncomp + nred) {
+        sil_reduce_frame(blockIdx.x - ncomp, red_partials, (S / 8) * (S / 8), keep_sum, frame_rec, loss_out, nullptr, clip_len,
+                         out_stride);
+        return;
+    }
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int is = 2 * S, wpl = is / 64;
-    const long L = (long)(blockIdx.x - ncomp) * 16 + grp;
+    const long L = (long)(blockIdx.x - ncomp - nred) * 16 + grp;
     const bool valid = L < 4L * B * is;
     // L = ((pl * 2 + axis) * B + b) * is + d0
     const int d0 = (int)(L % is), b = (int)((L / is) % B), pa = (int)(L / ((long)is * B));
@@ -1152,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
 
 // ---------------------------------------------------------------- backward, pass 2b: edge sweeps (see the work list above)
 #ifdef SWEEP_STATS
-__device__ unsigned long long g_sweep_n[8];      // items, geo, act0, act1, on0, on1, pairs, units
+__device__ unsigned long long g_sweep_n[12];     // stage 2: items, geo, act0, act1, on0, on1, pairs, trips; stage 1: items, geo, reach; pair rounds
 #endif
 // geometry of item j of face record fc: which (winding, edge, axis) family, which line d0r, where the edge crosses it
 struct SweepGeo {
@@ -1301,6 +1316,14 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                                        ((sm[t].w >> wlo) & ((2u << (whi - wlo)) - 1u)) != 0u;
                     const bool reach = s_geo[t] && (out_ok || in_ok);
                     const unsigned long long bal = __ballot(reach);
+#ifdef SWEEP_STATS
+                    const unsigned long long gbal = __ballot(s_geo[t]);
+                    if (lane == 0) {
+                        atomicAdd(&g_sweep_n[8], (unsigned long long)max(0, min(64, it_hi - (it_lo + 64 * t))));
+                        atomicAdd(&g_sweep_n[9], (unsigned long long)__popcll(gbal));
+                        atomicAdd(&g_sweep_n[10], (unsigned long long)__popcll(bal));
+                    }
+#endif
                     if (reach) s_q[wv][qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)s_ent[t];
                     qn += __popcll(bal);
                 }
@@ -1412,6 +1435,9 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                 // number at that position, and a running maximum carries it over the item's pairs.
 #pragma unroll 1
                 for (int base = 0; base < npairs; base += 256) {
+#ifdef SWEEP_STATS
+                    if (lane == 0) atomicAdd(&g_sweep_n[11], 1ull);
+#endif
                     int4* hd = reinterpret_cast<int4*>(s_head[wv]);
                     hd[lane] = make_int4(0, 0, 0, 0);
                     wave_sync();
@@ -1893,15 +1919,16 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 
 // pass 2a (+ the work list of pass 2b in its first workgroups) and pass 2b
 static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const float* upstream, const float* keep_sum,
-                         int clip_len, hipStream_t stream)
+                         int clip_len, hipStream_t stream, float* loss_out = nullptr, int out_stride = 0)
 {
+    const int nred = loss_out ? B : 0;
     // work-list blocks: per clip (see sweep_compact), sized by the clip, so that a clip is cut into the same blocks
     // whether it is launched alone or in a batch
     const int fpt = (long)clip_len * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks
     const int ncomp = (B / clip_len) * hm_cdiv((long)clip_len * F, 256 * fpt);
-    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
+    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + nred + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
-                       w.owned, F, w.parts, w.sweep, clip_len, w.lsum);
+                       w.owned, F, w.parts, w.sweep, clip_len, w.lsum, nred, w.partials, w.frame_rec, loss_out, out_stride);
 }
 static int g_sweep_blocks = SWEEP_BLOCKS;
 static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
@@ -1926,13 +1953,17 @@ int hm_tune_sweep_blocks(int blocks)
 //   keep/ref/keep_sum/loss_out may be NULL (render only).  loss_out[0]=loss_sil, loss_out[1]=mean IoU.
 //   *_clips: the B frames are B / clip_len clips of clip_len frames (0: one clip); keep_sum and rigid_scale hold one
 //   entry per clip, the loss / IoU of clip c go to loss_out[c * out_stride + 0 / 1].
-int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
-                     float orig_size, float znear, float zfar, const float* keep, const float* ref,
-                     const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
-                     float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
-                     const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, int clip_len,
-                     int out_stride, float* cam_verts_out, hipStream_t stream)
+//   *_phase_clips: the same forward in two calls for a caller that forks a second stream off the camera-space vertices:
+//   phases = 1 launches the face setup only (cam_verts_out is complete when it ends), 2 the rasteriser (+ reduction) only,
+//   3 both (= hm_sil_fwd_clips); both calls take the same arguments.
+int hm_sil_fwd_phase_clips(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
+                           float orig_size, float znear, float zfar, const float* keep, const float* ref,
+                           const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+                           float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
+                           const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, int clip_len,
+                           int out_stride, float* cam_verts_out, int phases, hipStream_t stream)
 {
+    HM_CHECK_ARG(phases >= 1 && phases <= 3);
     HM_CHECK_ARG(verts && faces && K && pooled && workspace && HM_CLIP_LEN_OK(B, clip_len));
     if (clip_len == 0) clip_len = B;
     HM_CHECK_ARG(!rigid_rot6d || (rigid_trans && rigid_scale));
@@ -1944,9 +1975,11 @@ int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, co
     int* bins = is <= (SR_MAX == 64 ? 1024 : 0) ? w.bin_cnt : nullptr;      // <= SR_MAX super-regions per frame
     HM_CHECK_ARG(!cam_verts_out || rigid_rot6d);
     const int nfb = hm_cdiv(F, 256);
-    hipLaunchKernelGGL(k_setup_faces, dim3(nfb + (cam_verts_out ? hm_cdiv(V, 256) : 0), B), dim3(256), 0, stream, verts, K,
-                       orig_size, faces, faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list,
-                       rigid_rot6d, rigid_trans, rigid_scale, rigid_abs, clip_len, cam_verts_out, nfb);
+    if (phases & 1)
+        hipLaunchKernelGGL(k_setup_faces, dim3(nfb + (cam_verts_out ? hm_cdiv(V, 256) : 0), B), dim3(256), 0, stream, verts, K,
+                           orig_size, faces, faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list,
+                           rigid_rot6d, rigid_trans, rigid_scale, rigid_abs, clip_len, cam_verts_out, nfb);
+    if (!(phases & 2)) return hm_launch_status();
     const bool fused = keep && ref;
     HM_TIME_MARK(0, stream);
     hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
@@ -1959,6 +1992,18 @@ int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, co
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
                            loss_out, (float*)nullptr, clip_len, out_stride);
     return hm_launch_status();
+}
+int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
+                     float orig_size, float znear, float zfar, const float* keep, const float* ref,
+                     const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+                     float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
+                     const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, int clip_len,
+                     int out_stride, float* cam_verts_out, hipStream_t stream)
+{
+    return hm_sil_fwd_phase_clips(verts, faces, faces_bstride, K, B, V, F, S, orig_size, znear, zfar, keep, ref, keep_sum, pooled,
+                                  loss_out, work_order, pooled_depth, alpha_full, mask_shared, rigid_rot6d, rigid_trans,
+                                  rigid_scale, rigid_abs, persistent_outputs, workspace, clip_len, out_stride, cam_verts_out, 3,
+                                  stream);
 }
 int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                float orig_size, float znear, float zfar, const float* keep, const float* ref,
@@ -2007,12 +2052,15 @@ int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss
 //            mode 4 (fused per-sample L2 of a forward called with alpha_full + keep/ref): upstream (B) = dL/d frame sums, all > 0.
 // adjacency (CSR over V) describes the shared face topology.  grad_verts (B,V,3) is overwritten.
 //   *_clips (modes 1 / 2): keep_sum holds one entry per clip of clip_len frames and the 1/B of the loss is 1/clip_len;
-//   `upstream` stays one scalar shared by the clips.
+//   `upstream` stays one scalar shared by the clips.  loss_out (optional, modes 1 / 2): the loss / IoU reduction of a forward
+//   called with keep / ref but loss_out == NULL (what hm_sil_reduce_clips computes, same arithmetic) rides at the front of
+//   the backward's first launch: clip c's values at loss_out[c * out_stride + 0 / 1].
 int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                      const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                      const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-                     int clip_len, hipStream_t stream)
+                     int clip_len, float* loss_out, int out_stride, hipStream_t stream)
 {
+    HM_CHECK_ARG(!loss_out || ((mode == 1 || mode == 2) && keep_sum));
     HM_CHECK_ARG(verts && K && adj_off && adj_items && workspace);        // grad_verts == NULL: no vertex gather (see hm_sil_parts)
     HM_CHECK_ARG(HM_CLIP_LEN_OK(B, clip_len));
     if (clip_len == 0) clip_len = B;
@@ -2026,7 +2074,7 @@ int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, in
                            mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                            w.planes, clip_len);
     HM_TIME_MARK(2, stream);
-    launch_lines(w, B, F, S, mode, upstream, keep_sum, clip_len, stream);
+    launch_lines(w, B, F, S, mode, upstream, keep_sum, clip_len, stream, loss_out, out_stride);
     HM_TIME_MARK(3, stream);
     launch_sweep(w, B, F, S, eps, stream);
     HM_TIME_MARK(4, stream);
@@ -2041,7 +2089,7 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
                hipStream_t stream)
 {
     return hm_sil_bwd_clips(verts, K, B, V, F, S, orig_size, eps, mode, upstream, grad_pooled, keep_sum, adj_off, adj_items,
-                            face_order, grad_verts, grad_ndc, workspace, 0, stream);
+                            face_order, grad_verts, grad_ndc, workspace, 0, nullptr, 0, stream);
 }
 
 // (B,F,3,2) d loss / d NDC (x, y) per face corner, as left by the last hm_sil_bwd: input of hm_rigid_bwd_sil.
@@ -2202,7 +2250,7 @@ int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, fl
 #ifdef SWEEP_STATS
 int hm_debug_sweep_stats(unsigned long long* out)
 {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_n), sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_n), z, sizeof(z));

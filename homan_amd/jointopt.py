@@ -95,9 +95,18 @@ class HmAdam:
         self.grads = [p.grad for p, _ in self.items]       # keep the static buffers alive
         self.blocks = max(1, min(64, (max(p.numel() for p, _ in self.items) + 255) // 256))
 
-    def step(self, zero_grad=True):
+    def step(self, zero_grad=True, log=None):
+        """log = (vals (C, n+1), weights (n), n, max_steps, log_buf, C): the log row of the step being taken is written by the
+        same launch (hm_adam_step_log = hm_log_total_clips + hm_adam_step)."""
         for (p, _), g in zip(self.items, self.grads):
             assert p.grad is g, "gradient buffers must stay static (do not call zero_grad(set_to_none=True))"
+        if log is not None:
+            vals, weights, n, max_steps, log_buf, nclips = log
+            _lib.check(_lib.lib().hm_adam_step_log(_lib.ptr(self.slots), len(self.items), _lib.ptr(self.step_t),
+                                                   self.betas[0], self.betas[1], self.eps, int(zero_grad), self.blocks,
+                                                   _lib.ptr(vals), _lib.ptr(weights), n, max_steps, _lib.ptr(log_buf),
+                                                   nclips, _lib.stream()), "hm_adam_step_log")
+            return
         _lib.check(_lib.lib().hm_adam_step(_lib.ptr(self.slots), len(self.items), _lib.ptr(self.step_t),
                                            self.betas[0], self.betas[1], self.eps, int(zero_grad), self.blocks,
                                            _lib.stream()), "hm_adam_step")
@@ -281,6 +290,12 @@ class FusedStepper:
         # third stream for the silhouette reduction + log row: it pays on a clip batch (+1.5 %); at one clip the graph executor
         # spends two cross-queue hops (~10 us each) on it, and two streams are 5-6 % faster (same-box A/B, cfg2 and cfg3)
         self.use_aux = (os.environ.get("HOMAN_AUX") or ("1" if C > 1 else "0")) != "0"
+        # two streams, no shared scale: the log row of a step is written by the Adam launch itself (one launch less)
+        self.log_in_adam = (not self.use_aux and not self.shared_scale and
+                            os.environ.get("HOMAN_LOG_IN_ADAM", "1") != "0")
+        self.fork_after_setup = os.environ.get("HOMAN_FORK_AFTER_SETUP", "1") != "0"
+        # the silhouette loss / IoU values (log only) come out of the backward's first launch: one launch less on the chain
+        self.sil_reduce_in_bwd = os.environ.get("HOMAN_SIL_REDUCE_IN_BWD", "1") != "0"
         self.Vo, self.Vh, self.P = Vo, Vh, m.mano_pca_pose.shape[1]
         f = lambda *shape: torch.zeros(*shape, device=dev)
         self.vo, self.vm, self.vh = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
@@ -335,8 +350,14 @@ class FusedStepper:
         self.mano_state = torch.empty(self.L.hm_mano_state_bytes(B), dtype=torch.uint8, device=dev)
         self.graph = self.graph_b = None
         self.cap_stream, self.side, self.aux, side = _loop_streams(dev)
-        self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd, self.ev_smo = (torch.cuda.Event() for _ in range(5))
+        self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd, self.ev_smo, self.ev_ras = (torch.cuda.Event() for _ in range(6))
         self.reduce_ws_b = ClipReduceWorkspace(dev, C)
+        # (the terms of the fused pair-terms launch run side by side: a reduce workspace each)
+        self.reduce_ws_c, self.reduce_ws_d, self.reduce_ws_e = (ClipReduceWorkspace(dev, C) for _ in range(3))
+        # (one clip: the hand-side chain is the iteration's critical path, -6 %; a batch hides that chain under the silhouette
+        #  chain and the fused launch only adds contention there, +1.6 %)
+        self.pair_fused = (os.environ.get("HOMAN_PAIR_FUSED") or ("1" if C == 1 else "0")) != "0"
+        self.hand_terms_fused = os.environ.get("HOMAN_HT_FUSED", "1") != "0"
         if self.shared_scale:
             self._sync_shared_scale_start()
         side.wait_stream(torch.cuda.current_stream())
@@ -354,9 +375,9 @@ class FusedStepper:
             prev = _lib.lib().hm_tune_sweep_blocks(sb)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.cap_stream):
-                self.forward_backward(log=True)
+                self.forward_backward(log=not self.log_in_adam)
                 if not self.shared_scale:
-                    self.opt.step(zero_grad=False)
+                    self.opt.step(zero_grad=False, log=self._adam_log())
             if self.shared_scale:        # the all-reduce of the scale gradient runs between two captured halves
                 self.graph_b = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph_b, stream=self.cap_stream):
@@ -426,7 +447,7 @@ class FusedStepper:
         use_aux = self.use_aux
 
         def tail_block(stream_obj):
-            if on["sil"]:
+            if on["sil"] and not self.sil_reduce_in_bwd:
                 ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
                                          P(sctx.workspace), CL, NS, stream_obj.cuda_stream), "sil_reduce")
             if log:
@@ -445,8 +466,8 @@ class FusedStepper:
                 self.aux.wait_event(self.ev_fwd)
                 if on["smooth"] and self.smooth_obj_on_main:
                     self.aux.wait_event(self.ev_smo)         # (that loss value comes from the calling stream here)
-                if on["sil"]:
-                    self.aux.wait_event(self.ev_sil)
+                if on["sil"] and not self.sil_reduce_in_bwd:
+                    self.aux.wait_event(self.ev_ras)
                     ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
                                              P(sctx.workspace), CL, NS, self.aux.cuda_stream), "sil_reduce")
                 if log:
@@ -455,16 +476,29 @@ class FusedStepper:
         # ---------------- A: silhouettes forward + backward (the critical chain: nothing else rides it; the object's rigid
         # transform is applied inside the face setup, the other losses get the vertices from the side stream)
         if on["sil"]:
-            ck(L.hm_sil_fwd_clips(P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S,
-                                  1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
-                                  None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
-                                  P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS,
-                                  P(self.vo), sa), "sil_fwd")      # (also writes the camera-space vertices self.vo)
-            self.ev_sil.record(main)         # loss / IoU reduction on the third stream; self.vo for the side stream
+            fwd_args = (P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S,
+                        1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
+                        None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
+                        P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, P(self.vo))
+            if self.fork_after_setup:
+                # the face setup (which also writes the camera-space vertices self.vo), the fork of the side stream, then the
+                # rasteriser: the pair-wise losses do not wait for the raster and the raster has one successor on its chain
+                ck(L.hm_sil_fwd_phase_clips(*fwd_args, 1, sa), "sil_fwd(setup)")
+                self.ev_sil.record(main)
+                ck(L.hm_sil_fwd_phase_clips(*fwd_args, 2, sa), "sil_fwd(raster)")
+                if use_aux and not self.sil_reduce_in_bwd:
+                    self.ev_ras.record(main)     # the tile partials of the fused loss, for the reduction on the third stream
+            else:
+                ck(L.hm_sil_fwd_clips(*fwd_args, sa), "sil_fwd")      # (also writes the camera-space vertices self.vo)
+                self.ev_sil.record(main)         # self.vo for the side stream
+                if use_aux and not self.sil_reduce_in_bwd:
+                    self.ev_ras.record(main)
             ck(L.hm_sil_bwd_clips(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
                                   2 if self.lw["lw_sil_obj"] > 0 else 1,
                                   P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
-                                  P(sctx.face_order), None, None, P(sctx.workspace), CL, sa), "sil_bwd")    # no vertex gather
+                                  P(sctx.face_order), None, None, P(sctx.workspace), CL,
+                                  self._slot("loss_sil_obj") if self.sil_reduce_in_bwd else None, NS, sa),
+               "sil_bwd")    # no vertex gather; the loss / IoU values come out of its first launch
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
             if not on["sil"]:    # (with the silhouette term the face setup of hm_sil_fwd has written self.vo already)
@@ -476,13 +510,22 @@ class FusedStepper:
                                    P(self.mano_state), CL, sb),
                "mano_fwd + rigid(hand)")
             pri = on["pca"] or on["so"] or on["sh"]
-            if on["smooth"] and on["v2d"]:       # the three hand-only reductions in one launch
-                ck(L.hm_hand_terms_fwd_clips(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
-                                             P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
-                                             self._slot("loss_smooth_hand"), P(pca) if pri else None, npca,
-                                             P(m.int_scales_object), P(m.int_scale_object_mean), P(m.int_scales_hand),
-                                             P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh),
-                                             self._slot("loss_pca"), rws_b, CL, NS, sb), "hand terms")
+            # pair terms that feed nothing to each other go in ONE launch (csrc/pairterms.hip): the interaction term, the
+            # object's smoothness when it rides this stream, the metric-only search (no contact term) and the hand-only
+            # reductions
+            sm_here = on["smooth"] and not self.smooth_obj_on_main
+            fuse = self.pair_fused and on["inter"] and (sm_here or not on["con"]) and Vo <= 4096
+            nn_fused = fuse and not on["con"]
+            ht_fused = fuse and self.hand_terms_fused and on["smooth"] and on["v2d"]
+            ht_args = (P(m.ref_verts2d_hand), float(m.image_size), P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
+                       self._slot("loss_smooth_hand"), P(pca) if pri else None, npca,
+                       P(m.int_scales_object), P(m.int_scale_object_mean), P(m.int_scales_hand),
+                       P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh), self._slot("loss_pca"))
+            if ht_fused:
+                pass
+            elif on["smooth"] and on["v2d"]:       # the three hand-only reductions in one launch
+                ck(L.hm_hand_terms_fwd_clips(P(self.vh), P(m.camintr), 1, ht_args[0], ht_args[1], B, Vh, *ht_args[2:], rws_b, CL,
+                                             NS, sb), "hand terms")
             else:
                 if pri:
                     ck(L.hm_priors_fwd_clips(P(pca), npca, P(m.int_scales_object), P(m.int_scale_object_mean),
@@ -496,14 +539,15 @@ class FusedStepper:
                                           P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, CL, NS, sb), "v2d")
             if on["sil"]:
                 side.wait_event(self.ev_sil)         # self.vo: camera-space object vertices from the calling stream
-            if on["smooth"] and not self.smooth_obj_on_main:
+            if sm_here and not fuse:
                 ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
                                          sb), "smooth(obj)")
             if on["col"]:
                 ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
                                             cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
                                             self._slot("loss_collision"), P(cctx.ws), CL, NS, sb), "collision")
-            if on["con"] or on["inter"]:     # (step-1 sets need it for the logged metric only; moving it to the third
+            if (on["con"] or on["inter"]) and not nn_fused:
+                # (step-1 sets need it for the logged metric only; moving it to the third
                 # stream was measured: +1 % at one clip, -9 % on an 8-clip batch - the graph executor serialises the fork.
                 # Capturing the hand-side forward kernels BEFORE the silhouette chain: -38 %, same reason.)
                 # (without the contact term only the logged distance is needed: metric-only search)
@@ -514,12 +558,22 @@ class FusedStepper:
                 ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
                                           P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws_b, CL, NS, sb),
                    "contact")
-            if on["inter"]:
+            if fuse:
+                ck(L.hm_pair_terms_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo,
+                                             self._slot("handobj_maxdist") if nn_fused else None, P(self.obj_order), rws_b,
+                                             c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(self.rec),
+                                             self._slot("loss_inter"), P(self.reduce_ws_c.buf),
+                                             P(self.U_smo) if sm_here else None,
+                                             self._slot("loss_smooth_obj") if sm_here else None, P(self.reduce_ws_d.buf),
+                                             *(ht_args if ht_fused else (None, 0.0, None, None, None, None, None, 0, None, None,
+                                                                         None, None, None, None, None, None)),
+                                             P(self.reduce_ws_e.buf), CL, NS, sb), "pair terms")
+            elif on["inter"]:
                 ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
                                         float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws_b, CL,
                                         NS, sb), "inter")
-                if m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
-                    ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb), "inter_bwd")
+            if on["inter"] and m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
+                ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb), "inter_bwd")
             self.ev_fwd.record(side)         # every forward loss value of this stream exists now
             if not self.smooth_obj_on_main:
                 aux_block()
@@ -568,7 +622,7 @@ class FusedStepper:
         if not use_aux:
             # two streams only: the silhouette reduction rides the tail of the silhouette chain (the shorter one at one
             # clip), the log row follows the join
-            if on["sil"]:
+            if on["sil"] and not self.sil_reduce_in_bwd:
                 ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
                                          P(sctx.workspace), CL, NS, sa), "sil_reduce")
         main.wait_stream(side)               # join
@@ -586,6 +640,11 @@ class FusedStepper:
                 ck(L.hm_sum_small_clips(P(m.int_scales_object.grad), C, 1.0, None, 0.0, P(self.g_shared), 1, sa),
                    "shared scale grad")
 
+    def _adam_log(self):
+        if not self.log_in_adam:
+            return None
+        return (self.vals, self.weights, len(self.SLOTS), self.max_steps, self.log_buf, self.C)
+
     def _iteration(self):
         if self.graph is not None:
             self.graph.replay()
@@ -593,11 +652,11 @@ class FusedStepper:
                 self._reduce_shared_scale_grad()
                 self.graph_b.replay()
         else:
-            self.forward_backward(log=True)
+            self.forward_backward(log=not self.log_in_adam)
             if self.shared_scale:
                 self._reduce_shared_scale_grad()
                 self._spread_shared_scale_grad()
-            self.opt.step(zero_grad=False)
+            self.opt.step(zero_grad=False, log=self._adam_log())
 
     def run(self, steps):
         for _ in range(steps):

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "hm_collision_dist_values": (_I, [_VP, _I, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP]),
     "hm_adam_slot_bytes": (_SZ, []),
     "hm_adam_step": (_I, [_VP, _I, _VP, _F, _F, _F, _I, _I, _VP]),
+    "hm_adam_step_log": (_I, [_VP, _I, _VP, _F, _F, _F, _I, _I, _VP, _VP, _I, _I, _VP, _I, _VP]),
     "hm_log_scalars": (_I, [_VP, _I, _VP, _I, _VP, _VP]),
     # clip batches (C clips, one launch per kernel): the plain signatures + clip_len [+ out_stride]
     "hm_rigid_fwd_clips": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP]),
@@ -75,13 +76,18 @@ _SIGNATURES = {
     "hm_mano_fwd_clips": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_sil_fwd_clips": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP,
                               _VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
+    "hm_sil_fwd_phase_clips": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP,
+                                    _VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _VP]),
     "hm_sil_reduce_clips": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP]),
-    "hm_sil_bwd_clips": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "hm_sil_bwd_clips": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _VP]),
     "hm_v2d_fwd_clips": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_smooth_fwd_clips": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_priors_fwd_clips": (_I, [_VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_hand_terms_fwd_clips": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _VP, _VP, _L, _VP, _VP, _VP, _VP, _VP, _VP,
                                      _VP, _VP, _VP, _I, _I, _VP]),
+    "hm_pair_terms_fwd_clips": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP,
+                                     _VP, _F, _VP, _VP, _VP, _VP, _VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
+                                     _I, _I, _VP]),
     "hm_inter_fwd_clips": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_nn_fwd_clips": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
     "hm_contact_fwd_clips": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _I, _I, _VP]),

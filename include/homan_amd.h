@@ -242,6 +242,11 @@ int hm_collision_read_grid(const int* faces, int V, int F, int B, int which, int
 size_t hm_adam_slot_bytes(void);
 int hm_adam_step(const void* slots, int n_tensors, int* step, float beta1, float beta2, float eps, int zero_grad,
                  int blocks_per_tensor, hipStream_t stream);
+/* hm_log_total_clips + hm_adam_step in one launch: the log row of the step being taken (weighted totals + every slot of
+ * `vals`) is written by an extra grid row before the device step counter moves. */
+int hm_adam_step_log(const void* slots, int n_tensors, int* step, float beta1, float beta2, float eps, int zero_grad,
+                     int blocks_per_tensor, float* vals, const float* weights, int n, int max_steps, float* log, int nclips,
+                     hipStream_t stream);
 /* vals[n] = sum_i weights[i]*vals[i] (the weighted total of jointopt.py:180-188), then log row step[0] = vals[0..n] */
 int hm_log_total(float* vals, const float* weights, int n, const int* step, int max_steps, float* log,
                  hipStream_t stream);
@@ -289,12 +294,24 @@ int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, co
                      int out_stride, float* cam_verts_out, hipStream_t stream);
 /*   cam_verts_out (B,V,3) optional (with the rigid_* arguments): the camera-space vertices = what hm_rigid_fwd returns for
  *   the same inputs (same arithmetic, same floats), written by extra workgroups of the face-setup launch. */
+/* The same forward in two calls, for a caller that forks a second stream off the camera-space vertices: phases = 1 launches
+ * the face setup only (cam_verts_out is complete when it ends), 2 the rasteriser (+ reduction) only, 3 both; both calls take
+ * the same arguments. */
+int hm_sil_fwd_phase_clips(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
+                           float orig_size, float znear, float zfar, const float* keep, const float* ref,
+                           const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
+                           float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
+                           const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, int clip_len,
+                           int out_stride, float* cam_verts_out, int phases, hipStream_t stream);
 int hm_sil_reduce_clips(int B, int V, int F, int S, const float* keep_sum, float* loss_out, float* frame_out,
                         void* workspace, int clip_len, int out_stride, hipStream_t stream);
 int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                      const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                      const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-                     int clip_len, hipStream_t stream);
+                     int clip_len, float* loss_out, int out_stride, hipStream_t stream);
+/*   loss_out (optional, modes 1 / 2): the loss / IoU reduction of hm_sil_reduce_clips (same arithmetic) done by extra
+ *   workgroups at the front of the backward's first launch, for a forward that was called with loss_out == NULL: the value
+ *   is only logged, so it need not cost a launch on the chain raster -> lines -> sweeps. */
 int hm_v2d_fwd_clips(const float* verts, const float* camintr, int hand_nb, const float* ref2d, float image_size, int N,
                      int V, float* unit_grad, float* out2, void* workspace, int clip_len, int out_stride,
                      hipStream_t stream);
@@ -312,6 +329,23 @@ int hm_hand_terms_fwd_clips(const float* verts, const float* camintr, int hand_n
 int hm_inter_fwd_clips(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
                        float expansion, float zthresh, float* frame_rec, float* out1, void* workspace, int clip_len,
                        int out_stride, hipStream_t stream);
+/* Up to three terms of the frames' (hand, object) vertex pairs in ONE launch (csrc/pairterms.hip); every term is optional
+ * (output pointer NULL) and returns what its own entry point returns on the same inputs:
+ *   metric_out -> hm_nn_fwd_clips with nn_idx = nn_d2 = NULL (<= 4096 object vertices)          reduce workspace ws_nn
+ *   out_inter  -> hm_inter_fwd_clips (frame records `frame_rec`)                                 reduce workspace ws_inter
+ *   out_smooth -> hm_smooth_fwd_clips(verts_obj, ..., hand_nb = 1) (unit gradient `unit_smooth`) reduce workspace ws_smooth
+ *   ht_out_v2d2 -> hm_hand_terms_fwd_clips(verts_hand, camintr, hand_nb = 1, ht_...) (one hand per frame)  workspace ws_hand
+ * The workspaces must be distinct (the terms run side by side).  Replaces, in one go, reference homan/losses.py:199-242
+ * (loss + logged distance) and the object half of homan/lossutils.py:18-36. */
+int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
+                            float* metric_out, const int* obj_order, void* ws_nn, float expansion, float zthresh,
+                            float* frame_rec, float* out_inter, void* ws_inter, float* unit_smooth, float* out_smooth,
+                            void* ws_smooth,
+                            const float* ht_ref2d, float ht_image_size, float* ht_unit_v2d, float* ht_out_v2d2,
+                            float* ht_unit_smooth, float* ht_out_smooth1, const float* ht_pca, long ht_npca,
+                            const float* ht_s_obj, const float* ht_m_obj, const float* ht_s_hand, const float* ht_m_hand,
+                            float* ht_g_pca, float* ht_g_sobj, float* ht_g_shand, float* ht_out_priors3, void* ws_hand,
+                            int clip_len, int out_stride, hipStream_t stream);
 /* obj_order (Vo) optional, metric-only calls: a permutation of the object vertices, visited in that order (a spatial sort of
  * the rigid mesh makes 64 consecutive vertices a compact patch: scheduling only, the result is the exact minimum) */
 int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,

@@ -1,0 +1,47 @@
+"""Work counters of k_bwd_sweep in the steady state of a cfg2 fit (debug build: tools/ab_build.sh stats -DSWEEP_STATS;
+HOMAN_AMD_LIB=scratch/lib_stats.so python tools/sweep_stats.py).  GPU box."""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--warm", type=int, default=100)
+    ap.add_argument("--step2", action="store_true")
+    a = ap.parse_args()
+    from homan_amd import lib as _lib, synth
+    from homan_amd.jointopt import FusedStepper, build_model
+    from homan_amd.mano_assets import synthetic_mano
+    mano = synthetic_mano(0)
+    sil_fn, hand_fn = synth.hip_clip_fns(mano)
+    clip = synth.make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    model = build_model(clip["person_parameters"], clip["object_parameters"], objvertices=clip["objvertices"],
+                        objfaces=clip["objfaces"], camintr=clip["camintr"], optimize_mano=True, image_size=256,
+                        mano_model=mano, rend_size=256, sync_metrics=False)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS if a.step2 else synth.STEP1_LOSS_WEIGHTS)
+    st = FusedStepper(model, lw, 1e-2, a.warm + 8, capture=False)
+    L = _lib.lib()
+    L.hm_debug_sweep_stats.argtypes = [ctypes.c_void_p]
+    out = (ctypes.c_ulonglong * 12)()
+    names = ["s2_items", "s2_geo", "act0", "act1", "on0", "on1", "pairs", "s2_trips", "s1_items", "s1_geo", "s1_reach",
+             "pair_rounds"]
+    marks = (0, 20, a.warm)
+    for step in range(a.warm + 1):
+        if step in marks:
+            L.hm_debug_sweep_stats(out)          # reset
+        st.run(1)
+        if step in marks:
+            L.hm_debug_sweep_stats(out)
+            print(f"step {step}: " + "  ".join(f"{n}={int(v)}" for n, v in zip(names, out)))
+
+
+if __name__ == "__main__":
+    main()
