@@ -17,6 +17,17 @@
 #define HM_PRIO 3
 #endif
 #define HM_LATENCY_KERNEL() __builtin_amdgcn_s_setprio(HM_PRIO)
+// the kernels of the hand-side chain that are long enough to matter to whatever they overlap (MANO backward, pair terms),
+// and the three heavy kernels of the silhouette chain: separately tunable (A/B builds)
+#ifndef HM_HAND_PRIO
+#define HM_HAND_PRIO HM_PRIO
+#endif
+#define HM_HAND_KERNEL() __builtin_amdgcn_s_setprio(HM_HAND_PRIO)
+#ifdef HM_CHAIN_PRIO
+#define HM_CHAIN_KERNEL() __builtin_amdgcn_s_setprio(HM_CHAIN_PRIO)
+#else
+#define HM_CHAIN_KERNEL()
+#endif
 
 #define HM_CHECK_ARG(cond) \
     do {                   \

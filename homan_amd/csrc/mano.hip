@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
                                                    float* __restrict__ g_pca, float* __restrict__ g_rot,
                                                    float* __restrict__ g_betas, float* __restrict__ g_trans)
 {
-    HM_LATENCY_KERNEL();
+    HM_HAND_KERNEL();
     __shared__ ManoShared sh;
     __shared__ float s_part[4][MANO_VCH][3];
     __shared__ float s_vp[MANO_VCH][3];

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_pair_terms(
     int sm_nblk, float* __restrict__ unit_smooth, float* __restrict__ sm_partials, unsigned int* sm_counter,
     float* __restrict__ out_smooth, HandTerms ht, int clips)
 {
-    HM_LATENCY_KERNEL();
+    HM_HAND_KERNEL();
     int i = blockIdx.x;
     const int n_nn = metric_out ? nchunk * B : 0, n_in = out_inter ? B : 0;
     if (i < n_nn) {

@@ -308,6 +308,12 @@ __device__ __forceinline__ void emit_planes(const Ballots4 cov, const Ballots4 n
 //   4. epilogue: one wave per 8x8 output tile reads its samples back (lane = output pixel, 2x2 samples).
 // Outputs: idx_map (B,is,is) int32; alpha16 (B,is,is/16) u16 bit-plane; pooled (B,S,S);
 // optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4); optional pooled depth.
+#ifdef RASTER_PHASES
+__device__ unsigned long long g_raster_ph[12];   // cycles of wave 0: scan, near records, near units, far hz + records, far units, tail; workgroups: active, idle; units near / far
+#define RPH_MARK(k) do { if (tid == 0) { const unsigned long long t_ = clock64(); rph[k] += t_ - rph_t; rph_t = t_; } } while (0)
+#else
+#define RPH_MARK(k)
+#endif
 #ifndef CAND_CAP
 #define CAND_CAP 512       // faces scanned per binning round (<= 2 entries each)
 #endif
@@ -330,6 +336,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     unsigned char* __restrict__ region_state, int persistent, float* __restrict__ alpha_full, int mask_shared,
     float* __restrict__ dimg_full, const unsigned int* __restrict__ hint)
 {
+    HM_CHAIN_KERNEL();
     __shared__ unsigned long long zb[32 * 32];
     __shared__ int cand[2 * CAND_CAP];
     __shared__ float4 recs[RB_PASS][5];
@@ -371,6 +378,10 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     // An empty bin in front of outputs that already hold the empty pattern: nothing to rasterise, nothing to write (~60 %
     // of the workgroups of a clip, every iteration) - leave before touching LDS.  (The bin ticket still has to be drawn.)
     const bool idle = nscan == 0 && rstate0 == 1;
+#ifdef RASTER_PHASES
+    unsigned long long rph[6] = {0, 0, 0, 0, 0, 0}, rph_t = clock64();
+    unsigned long long rph_units[3] = {0, 0, 0};
+#endif
     if (!idle) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) zb[tid + 256 * k] = zb_empty;
@@ -492,6 +503,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
             }
         }
         __syncthreads();
+        RPH_MARK(0);
         had_any |= cand_n[0] | cand_n[1];
         for (int cls = 0; cls < 2; ++cls) {
             const int n = cand_n[cls];
@@ -584,6 +596,10 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
                 }
                 if (tid < RB_PASS) ustart[tid] = woff + incl - units;
                 __syncthreads();
+                RPH_MARK(cls == 0 ? 1 : 3);
+#ifdef RASTER_PHASES
+                rph_units[cls] += total;
+#endif
                 if (cls == 0) {
                     // ---- near class: flattened (candidate, block) units, one per thread and trip
                     for (int u = tid; u < total; u += 256) {
@@ -631,12 +647,14 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
                     }
                 }
                 __syncthreads();
+                RPH_MARK(cls == 0 ? 2 : 4);
             }
         }
     }
     __syncthreads();
     // the last of the (4 or 16) workgroups that read a bin empties it for the next forward.  One ticket word per bin:
-    // returning atomics on a single word from all 7680 workgroups serialise (measured +43 us on the launch).
+    // returning atomics on a single word from all 7680 workgroups serialise (measured +43 us on the launch).  (Drawing the
+    // ticket right after the scan and using the answer at the very end was measured: k_raster_fwd 51.8 -> 55.5 us.)
     if (tid == 0 && bin_cnt && reset_bins) {
         const int per_side = (1 << hm_sr_shift(is)) / (2 * HM_STILE);
         const int rw = min(per_side, regions_x - per_side * (gx0 >> hm_sr_shift(is))), rh = min(per_side, regions_x - per_side * (gy0 >> hm_sr_shift(is)));
@@ -650,7 +668,12 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     // An empty region whose outputs already hold the empty pattern has nothing to write: ~60 % of the regions of a clip
     // are background in every iteration, and their epilogues (loads of the loss inputs, ~6 KB of stores) were a quarter
     // of the kernel.  Only valid when the caller keeps passing the same output / loss-input buffers (`persistent`).
-    if (persistent && !had_any && rstate0 == 1) return;
+    if (persistent && !had_any && rstate0 == 1) {
+#ifdef RASTER_PHASES
+        if (tid == 0) atomicAdd(&g_raster_ph[7], 1ull);
+#endif
+        return;
+    }
     __syncthreads();          // every thread has read the state before thread 0 rewrites it below
     if (tid == 0) *rstate = (persistent && !had_any) ? 1 : 0;
 
@@ -756,6 +779,15 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
             o[0] = sq; o[1] = inter; o[2] = uni; o[3] = 0.f;
         }
     }
+#ifdef RASTER_PHASES
+    RPH_MARK(5);
+    if (tid == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd(&g_raster_ph[k], rph[k]);
+        atomicAdd(&g_raster_ph[6], 1ull);
+        atomicAdd(&g_raster_ph[8], rph_units[0]);
+        atomicAdd(&g_raster_ph[9], rph_units[1]);
+    }
+#endif
 }
 
 // grid (B): per-frame sums of the tile partials, then the last block of every clip (clip_len consecutive frames) finishes:
@@ -1080,6 +1112,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    const float* __restrict__ red_partials, float* __restrict__ frame_rec,
                                                    float* __restrict__ loss_out, int out_stride)
 {
+    HM_CHAIN_KERNEL();
     __shared__ unsigned long long s_w[16][SWEEP_CUMW];
     __shared__ int s_ex[16][SWEEP_CUMW];
     // the first `ncomp` workgroups build the work list of the edge sweeps (independent of the lines: one launch for both)
@@ -1225,6 +1258,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
 {
     // LDS copies are padded to an ODD number of dwords (17 / 9): lanes reading the same field of different faces / items
     // then fall into different banks (64- and 32-byte strides put every second / fourth element on the same bank)
+    HM_CHAIN_KERNEL();
     struct FaceLds { SweepFace f; int pad; };
     struct ItemLds { SweepItem it; int pad; };
     __shared__ FaceLds s_face[4][SWEEP_PASS_FACES];
@@ -2247,6 +2281,16 @@ int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, fl
     return hipMemcpyAsync(out, w.partials, (size_t)B * (S / 8) * (S / 8) * 16, hipMemcpyDeviceToDevice, stream) == hipSuccess
                ? HM_OK : HM_ERR_LAUNCH;
 }
+#ifdef RASTER_PHASES
+int hm_debug_raster_phases(unsigned long long* out)
+{
+    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_raster_ph), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raster_ph), z, sizeof(z));
+    return HM_OK;
+}
+#endif
 #ifdef SWEEP_STATS
 int hm_debug_sweep_stats(unsigned long long* out)
 {

@@ -295,7 +295,8 @@ class FusedStepper:
                             os.environ.get("HOMAN_LOG_IN_ADAM", "1") != "0")
         self.fork_after_setup = os.environ.get("HOMAN_FORK_AFTER_SETUP", "1") != "0"
         # the silhouette loss / IoU values (log only) come out of the backward's first launch: one launch less on the chain
-        self.sil_reduce_in_bwd = os.environ.get("HOMAN_SIL_REDUCE_IN_BWD", "1") != "0"
+        # (two streams only: with the third stream the reduction and the log row stay there, behind the raster's event)
+        self.sil_reduce_in_bwd = not self.use_aux and os.environ.get("HOMAN_SIL_REDUCE_IN_BWD", "1") != "0"
         self.Vo, self.Vh, self.P = Vo, Vh, m.mano_pca_pose.shape[1]
         f = lambda *shape: torch.zeros(*shape, device=dev)
         self.vo, self.vm, self.vh = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)

@@ -1,5 +1,6 @@
-"""Work counters of k_bwd_sweep in the steady state of a cfg2 fit (debug build: tools/ab_build.sh stats -DSWEEP_STATS;
-HOMAN_AMD_LIB=scratch/lib_stats.so python tools/sweep_stats.py).  GPU box."""
+"""Work counters of k_bwd_sweep and phase cycles of k_raster_fwd in the steady state of a cfg2 fit (debug build:
+tools/ab_build.sh stats -DSWEEP_STATS -DRASTER_PHASES; HOMAN_AMD_LIB=scratch/lib_stats.so python tools/sweep_stats.py).
+GPU box."""
 import argparse
 import ctypes
 import os
@@ -30,6 +31,10 @@ def main():
     st = FusedStepper(model, lw, 1e-2, a.warm + 8, capture=False)
     L = _lib.lib()
     L.hm_debug_sweep_stats.argtypes = [ctypes.c_void_p]
+    L.hm_debug_raster_phases.argtypes = [ctypes.c_void_p]
+    rout = (ctypes.c_ulonglong * 12)()
+    rnames = ["scan", "near_rec", "near_units", "far_hz_rec", "far_units", "tail", "wg_active", "wg_idle", "units_near",
+              "units_far", "-", "-"]
     out = (ctypes.c_ulonglong * 12)()
     names = ["s2_items", "s2_geo", "act0", "act1", "on0", "on1", "pairs", "s2_trips", "s1_items", "s1_geo", "s1_reach",
              "pair_rounds"]
@@ -37,10 +42,17 @@ def main():
     for step in range(a.warm + 1):
         if step in marks:
             L.hm_debug_sweep_stats(out)          # reset
+            L.hm_debug_raster_phases(rout)
         st.run(1)
         if step in marks:
             L.hm_debug_sweep_stats(out)
             print(f"step {step}: " + "  ".join(f"{n}={int(v)}" for n, v in zip(names, out)))
+            L.hm_debug_raster_phases(rout)
+            tot = sum(int(rout[k]) for k in range(6))
+            print(f"   raster wave-0 cycles per active workgroup: " + "  ".join(
+                f"{n}={int(v) / max(1, int(rout[6])):.0f}" for n, v in zip(rnames[:6], rout)) +
+                f"  (total {tot / max(1, int(rout[6])):.0f});  active {int(rout[6])} idle {int(rout[7])}  units/wg near "
+                f"{int(rout[8]) / max(1, int(rout[6])):.0f} far {int(rout[9]) / max(1, int(rout[6])):.0f}")
 
 
 if __name__ == "__main__":
