@@ -381,6 +381,10 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
 #ifdef RASTER_PHASES
     unsigned long long rph[6] = {0, 0, 0, 0, 0, 0}, rph_t = clock64();
     unsigned long long rph_units[3] = {0, 0, 0};
+    unsigned rph_pairs = 0;      // per lane: covered samples
+    __shared__ unsigned s_rph_iters;      // wave trips of the covered-sample loop, all waves
+    if (tid == 0) s_rph_iters = 0u;
+    __syncthreads();
 #endif
     if (!idle) {
 #pragma unroll
@@ -441,6 +445,13 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
                 inside &= ~(0xfu << (4 * j)) | (keepm << (4 * j));
             }
             if (inside == 0u) return;
+        }
+#endif
+#ifdef RASTER_PHASES
+        rph_pairs += __popc(inside);
+        {   // trips of the loop below = the fullest of the lanes that got here
+            const unsigned mx = (unsigned)hm_wave_max((float)__popc(inside));
+            if (lane == __ffsll((long long)__ballot(1)) - 1) atomicAdd(&s_rph_iters, mx);
         }
 #endif
         const float4 r2 = recs[i][2], r3 = recs[i][3];
@@ -786,6 +797,12 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
         atomicAdd(&g_raster_ph[6], 1ull);
         atomicAdd(&g_raster_ph[8], rph_units[0]);
         atomicAdd(&g_raster_ph[9], rph_units[1]);
+    }
+    {
+        const unsigned wp = (unsigned)hm_wave_sum((float)rph_pairs);
+        if (lane == 0) atomicAdd(&g_raster_ph[11], (unsigned long long)wp);
+        __syncthreads();
+        if (tid == 0) atomicAdd(&g_raster_ph[10], (unsigned long long)s_rph_iters);
     }
 #endif
 }
@@ -1254,7 +1271,8 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                                                    const SweepSrc* __restrict__ srcs,
                                                    const uint4* __restrict__ lrec, int B, int F, int S,
                                                    float eps, float* __restrict__ parts,
-                                                   const unsigned short* __restrict__ lsum)
+                                                   const unsigned short* __restrict__ lsum,
+                                                   const unsigned short* __restrict__ alpha16)
 {
     // LDS copies are padded to an ODD number of dwords (17 / 9): lanes reading the same field of different faces / items
     // then fall into different banks (64- and 32-byte strides put every second / fourth element on the same bank)
@@ -1319,7 +1337,8 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             int qn = 0;
             {
                 uint4 sm[4];
-                int s_ain[4], s_aout[4], s_lo[4], s_hi[4], s_ent[4];
+                int s_ain[4], s_aout[4], s_lo[4], s_hi[4], s_ent[4], s_own[4], s_fn[4];
+                unsigned short s_aw[4];
                 bool s_geo[4], s_pos[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -1331,6 +1350,17 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                     const bool mine = g < it_hi && el >= 0 && g - fc.off < (int)fc.cum[11];
                     const SweepGeo q = sweep_item_geo(fc, mine ? g - fc.off : 0, mine, is);
                     sm[t] = *reinterpret_cast<const uint4*>(lsum + (((long)fc.b * 2 + q.axis) * is + q.d0r) * 8);
+                    // the two samples at the edge, requested with the summary (one round trip): the owner of the sample just
+                    // inside (the outward sweep runs only from a sample this winding owns) and the alpha word of the sample
+                    // just outside (the inward sweep only from an empty one)
+                    {
+                        const int xi_in = q.axis ? q.a_in : q.d0r, yi_in = q.axis ? q.d0r : q.a_in;
+                        const int xi_out = q.axis ? q.a_out : q.d0r, yo = is - 1 - (q.axis ? q.d0r : q.a_out);
+                        s_own[t] = idx_map[((long)fc.b * is + yi_in) * is + xi_in];
+                        s_aw[t] = alpha16[((((long)fc.b * (is >> 4)) + (yo >> 4)) * (is >> 4) + (xi_out >> 4)) * 16 + (yo & 15)];
+                        s_aw[t] = (unsigned short)((s_aw[t] >> (xi_out & 15)) & 1u);
+                        s_fn[t] = fc.bf - fc.b * F + q.var * F;
+                    }
                     s_ain[t] = q.a_in; s_aout[t] = q.a_out; s_geo[t] = q.geo; s_pos[t] = q.dir > 0;
                     // the inward sweep stays inside the triangle: its extent along the line bounds the range
                     const float tmin = fminf(q.p01, fminf(q.p11, q.p21)), tmax = fmaxf(q.p01, fmaxf(q.p11, q.p21));
@@ -1348,7 +1378,9 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                     const int wlo = s_lo[t] >> 6, whi = s_hi[t] >> 6;
                     const bool in_ok = s_lo[t] <= s_hi[t] && min1 <= s_hi[t] && end1 > s_lo[t] &&
                                        ((sm[t].w >> wlo) & ((2u << (whi - wlo)) - 1u)) != 0u;
-                    const bool reach = s_geo[t] && (out_ok || in_ok);
+                    const bool a0 = s_geo[t] && s_own[t] == s_fn[t] && out_ok;       // exact: the outward sweep has pairs
+                    const bool a1 = s_geo[t] && s_aw[t] == 0 && in_ok;                // (the inward range is refined in stage 2)
+                    const bool reach = a0 || a1;
                     const unsigned long long bal = __ballot(reach);
 #ifdef SWEEP_STATS
                     const unsigned long long gbal = __ballot(s_geo[t]);
@@ -1358,7 +1390,8 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                         atomicAdd(&g_sweep_n[10], (unsigned long long)__popcll(bal));
                     }
 #endif
-                    if (reach) s_q[wv][qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)s_ent[t];
+                    if (reach) s_q[wv][qn + __popcll(bal & ((1ull << lane) - 1ull))] =
+                                   (unsigned short)(s_ent[t] | (a0 ? 1 << 12 : 0) | (a1 ? 1 << 13 : 0));
                     qn += __popcll(bal);
                 }
             }
@@ -1367,7 +1400,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             for (int s0 = 0; s0 < qn; s0 += 64) {
             bool mine = s0 + lane < qn;
             const int ent = mine ? (int)s_q[wv][s0 + lane] : 0;
-            const int g = ubeg + (ent & 0xff), el = ent >> 8;
+            const int g = ubeg + (ent & 0xff), el = (ent >> 8) & 15;
             const SweepFace& fc = s_face[wv][el].f;
             const SweepGeo q = sweep_item_geo(fc, mine ? g - fc.off : 0, mine, is);
             const int var = q.var, edge = q.edge, axis = q.axis, d0r = q.d0r, dir = q.dir, a_in = q.a_in, a_out = q.a_out;
@@ -1375,16 +1408,13 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             const float d1_cross = q.d1_cross;
             const bool geo = q.geo;
             const int b = fc.b, fn = fc.bf - b * F + var * F;
-            const int* idx = idx_map + (long)b * is * is;
-            const int idx_in = axis ? idx[(long)d0r * is + a_in] : idx[(long)a_in * is + d0r];
-            const int idx_out = axis ? idx[(long)d0r * is + a_out] : idx[(long)a_out * is + d0r];
             const bool use0 = p10 != (float)d0r, use1 = p00 != (float)d0r;
             // 1-ulp reciprocals: these only scale the pseudo-distances (compared at 1e-3), unlike c2 below, which picks
             // the integer end of the inward range and stays an IEEE division
             const float c0 = use0 ? num * __builtin_amdgcn_rcpf(p10 - (float)d0r) : 0.f;
             const float c1 = use1 ? num * __builtin_amdgcn_rcpf((float)d0r - p00) : 0.f;
-            const bool act0 = geo && idx_in == fn;        // outward: my own sample just inside the edge
-            const bool act1 = geo && idx_out < 0;         // inward: only if the sample just outside is empty
+            const bool act0 = geo && (ent & (1 << 12));   // outward: my own sample just inside the edge      (stage 1 looked
+            const bool act1 = geo && (ent & (1 << 13));   // inward: only if the sample just outside is empty   both up)
             // [0] outward, from the sample just outside the edge to the border; [1] inward, across the triangle
             int rfrom[2], rto[2];
             {
@@ -1969,7 +1999,7 @@ static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStre
 {
     const int blocks = max(8, min(hm_cdiv((long)B * F, 2), g_sweep_blocks) & ~7);        // a multiple of 8: see the unit loop
     hipLaunchKernelGGL(k_bwd_sweep, dim3(blocks), dim3(256), 0, stream, w.sweep,
-                       w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts, w.lsum);
+                       w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts, w.lsum, w.alpha16);
 }
 
 // Scheduling hint, no effect on results: number of persistent workgroups of the edge-sweep kernel (default 1280 = 5 per

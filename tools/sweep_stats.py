@@ -52,7 +52,8 @@ def main():
             print(f"   raster wave-0 cycles per active workgroup: " + "  ".join(
                 f"{n}={int(v) / max(1, int(rout[6])):.0f}" for n, v in zip(rnames[:6], rout)) +
                 f"  (total {tot / max(1, int(rout[6])):.0f});  active {int(rout[6])} idle {int(rout[7])}  units/wg near "
-                f"{int(rout[8]) / max(1, int(rout[6])):.0f} far {int(rout[9]) / max(1, int(rout[6])):.0f}")
+                f"{int(rout[8]) / max(1, int(rout[6])):.0f} far {int(rout[9]) / max(1, int(rout[6])):.0f}  covered pairs "
+                f"{int(rout[11])}  wave trips of the covered-sample loop {int(rout[10])} (lane fill {int(rout[11]) / max(1, 64 * int(rout[10])):.2f})")
 
 
 if __name__ == "__main__":
