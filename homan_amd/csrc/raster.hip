@@ -2002,6 +2002,18 @@ static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStre
                        w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts, w.lsum, w.alpha16);
 }
 
+// Scheduling hint, no effect on results: bytes of unused dynamic LDS added to every k_raster_fwd launch.  The rasteriser's
+// 24.9 KB of LDS and 80 registers fill a CU with 6 workgroups and leave nothing for the kernels of the caller's other
+// stream (72 registers for the MANO forward: it then waits for the raster's tail); 3 KB of ballast caps the CU at 5
+// workgroups.  Process-wide; read when hm_sil_fwd is called (or captured).  Returns the previous value; < 0 only queries.
+static int g_raster_lds_pad = 0;
+int hm_tune_raster_lds_pad(int bytes)
+{
+    const int prev = g_raster_lds_pad;
+    if (bytes >= 0) g_raster_lds_pad = bytes;
+    return prev;
+}
+
 // Scheduling hint, no effect on results: number of persistent workgroups of the edge-sweep kernel (default 1280 = 5 per
 // CU).  The sweeps share the GPU with whatever runs on the caller's other streams; a loop whose other stream is the
 // longer chain (collision + contact terms) finishes sooner with fewer sweep workgroups (768).  Process-wide; read when
@@ -2046,7 +2058,7 @@ int hm_sil_fwd_phase_clips(const float* verts, const int* faces, int faces_bstri
     if (!(phases & 2)) return hm_launch_status();
     const bool fused = keep && ref;
     HM_TIME_MARK(0, stream);
-    hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), 0, stream,
+    hipLaunchKernelGGL(k_raster_fwd, dim3(B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), g_raster_lds_pad, stream,
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.planes, bins,
                        w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full, mask_shared,

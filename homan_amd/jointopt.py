@@ -374,6 +374,11 @@ class FusedStepper:
             # same-box A/B on cfg3: 1280 -> 4030, 768 -> 4130, 512 -> 4194 it/s)
             sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (512 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
             prev = _lib.lib().hm_tune_sweep_blocks(sb)
+            # same idea for the rasteriser: 8 KB of LDS ballast = 4 workgroups per CU instead of 6 leaves registers for the
+            # hand-side kernels (cfg3 one clip: 4347 -> 4500 it/s; cfg2, where that chain is short: 5820 -> 5500, so not there)
+            pad = os.environ.get("HOMAN_RASTER_PAD")
+            pad = int(pad) if pad is not None else (8192 if (self.on["col"] or self.on["con"]) and C == 1 else 0)
+            prev_pad = _lib.lib().hm_tune_raster_lds_pad(pad)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.cap_stream):
                 self.forward_backward(log=not self.log_in_adam)
@@ -385,6 +390,7 @@ class FusedStepper:
                     self._spread_shared_scale_grad()
                     self.opt.step(zero_grad=False)
             _lib.lib().hm_tune_sweep_blocks(prev)
+            _lib.lib().hm_tune_raster_lds_pad(prev_pad)
 
     # ---- shared object scale (BASELINE cfg5): C local replicas of one scalar, kept identical on every rank
     def _dist_on(self):

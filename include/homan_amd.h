@@ -163,6 +163,10 @@ int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, cons
  * default 1280; 768 suits loops whose other streams carry the longer chain (collision + contact terms).  Process-wide,
  * read when hm_sil_bwd is called or captured.  Returns the previous value; blocks <= 0 only queries. */
 int hm_tune_sweep_blocks(int blocks);
+/* Scheduling hint, no effect on results: bytes of unused dynamic LDS added to every rasteriser launch (3072 caps a CU at 5
+ * rasteriser workgroups instead of 6, which leaves registers / LDS for the kernels of the caller's other stream).  Process-wide,
+ * read when hm_sil_fwd is called (or captured).  Returns the previous value; bytes < 0 only queries. */
+int hm_tune_raster_lds_pad(int bytes);
 /* test hook: cap > 0 shrinks the capacity tables of the sweep work list so that small inputs take the beyond-capacity
  * paths (binary search for a unit's first face, atomically accumulated faces); 0 restores the defaults.  Returns the
  * previous value. */
