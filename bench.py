@@ -411,27 +411,35 @@ def main():
     B, S = args.frames, args.size
     F, V = clip["objfaces"].shape[1], clip["objvertices"].shape[1]
 
-    # --- roofline of the dominant kernel, measured INSIDE the loop: the same iteration issued launch by launch on the real
-    #     HIP streams (not from the captured graph: ROCm has no timing events inside graphs), with HIP events recorded by the
-    #     library on the launch stream around k_raster_fwd / k_bwd_lines / k_bwd_sweep (hm_debug_sil_timing); the hand-side
-    #     stream overlaps them exactly as in the graph, and the clip is in the steady state the timed region left it in
+    # --- roofline of the dominant kernel, measured INSIDE the replayed graph: ROCm allows no timing events in a captured graph,
+    #     so the three heavy kernels stamp the device wall clock themselves (hm_sil_timestamps: every workgroup stores
+    #     s_memrealtime at entry and exit into a slot pair of its own; one scalar load per workgroup when switched off, as in
+    #     the timed region).  `reps` more replays of THE SAME graph, back to back (arming and saving are stream-ordered 48-byte device
+    #     operations, no host synchronisation): same launches, same overlap with the hand-side stream, the steady state the
+    #     timed region left behind.  The rocprofv3 --kernel-trace averages of this
+    #     command (profiles/) are the cross-check.
     roof = None
     if rank == 0 and args.loop == "fused":
         import ctypes
         from homan_amd import lib as hlib
         L = hlib.lib()
         reps = max(10, min(50, args.steps))
-        ms3 = (ctypes.c_float * 3)()
+        us3 = (ctypes.c_float * 3)()
         acc = [0.0, 0.0, 0.0]
-        hlib.check(L.hm_debug_sil_timing(1), "hm_debug_sil_timing")
-        for _ in range(reps):
-            stepper.forward_backward(log=False)
-            stepper.opt.step(zero_grad=False)
-            hlib.check(L.hm_debug_sil_timing_read(ctypes.cast(ms3, ctypes.c_void_p)), "hm_debug_sil_timing_read")
-            torch.cuda.synchronize()
-            for i in range(3):
-                acc[i] += ms3[i]
-        hlib.check(L.hm_debug_sil_timing(0), "hm_debug_sil_timing")
+        sctx = stepper.model.sil_ctx
+        ws, dims = hlib.ptr(sctx.workspace), (sctx.B, sctx.V, sctx.F, sctx.S)
+        saved = torch.zeros(reps, L.hm_sil_timestamps_bytes(*dims) // 8, dtype=torch.int64, device="cuda")
+        for i in range(reps):          # back to back like the timed region: arm (async memsets), replay, save (48-byte device copy)
+            hlib.check(L.hm_sil_timestamps(ws, *dims, 1, hlib.stream()), "hm_sil_timestamps")
+            stepper.run(1)
+            hlib.check(L.hm_sil_timestamps_save(ws, *dims, saved[i].data_ptr(), hlib.stream()), "hm_sil_timestamps_save")
+        hlib.check(L.hm_sil_timestamps(ws, *dims, 0, hlib.stream()), "hm_sil_timestamps")
+        for i in range(reps):
+            hlib.check(L.hm_sil_timestamps_read(None, *dims, saved[i].data_ptr(), ctypes.cast(us3, ctypes.c_void_p), hlib.stream()),
+                       "hm_sil_timestamps_read")
+            for k in range(3):
+                acc[k] += us3[k] * 1e-3           # ms
+        torch.cuda.synchronize()
         kb = kernel_bytes(B, S, F)
         pmc = {}
         ppath = os.path.join(ROOT, "profiles", "r02_pmc_loop.json")
@@ -456,8 +464,8 @@ def main():
         roof = dict(bound="hbm", kernel=dom, achieved=per[dom]["achieved_GBps"], peak=8000.0, unit="GB/s",
                     frac=per[dom]["achieved_GBps"] / 8000.0, traffic=per[dom].get("traffic_bytes"),
                     avg_launch_us=per[dom]["avg_launch_us"], valu_frac=per[dom].get("valu_frac"),
-                    timing=f"HIP events on the launch stream around each kernel, inside {reps} iterations of the loop issued "
-                           "launch by launch after the timed region (same streams, same overlap, steady state)",
+                    timing=f"device wall clock stored by every workgroup at entry and exit (earliest start to latest end) in "
+                           f"{reps} more replays of the timed hipGraph (hm_sil_timestamps); same launches, same overlap",
                     traffic_source=("profiles/r02_pmc_loop.json (rocprofv3 --pmc passes over the steady-state loop, "
                                     "tools/pmc_loop.sh)" if per[dom].get("traffic_bytes") else None),
                     kernels=per,

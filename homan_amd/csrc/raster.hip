@@ -308,6 +308,18 @@ __device__ __forceinline__ void emit_planes(const Ballots4 cov, const Ballots4 n
 //   4. epilogue: one wave per 8x8 output tile reads its samples back (lane = output pixel, 2x2 samples).
 // Outputs: idx_map (B,is,is) int32; alpha16 (B,is,is/16) u16 bit-plane; pooled (B,S,S);
 // optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4); optional pooled depth.
+// In-graph timing (hm_sil_timestamps): byte 1 of workspace word 24 switches it on; then every workgroup of the three heavy
+// kernels (every wave of the persistent sweep kernel) stores the device wall clock (s_memrealtime, constant rate) at its
+// entry and at its exit into a slot pair of its own - plain 8-byte stores, no same-address atomics that would stretch the
+// kernel being measured; the host takes the earliest start and the latest end.  Off: one scalar load per workgroup.
+__device__ __forceinline__ bool hm_ts_enabled(const unsigned int* __restrict__ flag_word)
+{
+    return flag_word && ((flag_word[0] >> 8) & 1u);
+}
+__device__ __forceinline__ void hm_ts_store(unsigned long long* __restrict__ slots, long unit, int which, unsigned long long t)
+{
+    __builtin_nontemporal_store(t, slots + 2 * unit + which);
+}
 #ifdef RASTER_PHASES
 __device__ unsigned long long g_raster_ph[12];   // cycles of wave 0: scan, near records, near units, far hz + records, far units, tail; workgroups: active, idle; units near / far
 #define RPH_MARK(k) do { if (tid == 0) { const unsigned long long t_ = clock64(); rph[k] += t_ - rph_t; rph_t = t_; } } while (0)
@@ -334,9 +346,10 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     float* __restrict__ pooled_depth, unsigned short* __restrict__ planes,
     int* __restrict__ bin_cnt, const int* __restrict__ bin_list, unsigned int* __restrict__ done, int reset_bins,
     unsigned char* __restrict__ region_state, int persistent, float* __restrict__ alpha_full, int mask_shared,
-    float* __restrict__ dimg_full, const unsigned int* __restrict__ hint)
+    float* __restrict__ dimg_full, const unsigned int* __restrict__ hint, unsigned long long* __restrict__ ts_slots)
 {
     HM_CHAIN_KERNEL();
+    const unsigned long long ts_t0 = (unsigned long long)wall_clock64();       // (see hm_ts_enabled)
     __shared__ unsigned long long zb[32 * 32];
     __shared__ int cand[2 * CAND_CAP];
     __shared__ float4 recs[RB_PASS][5];
@@ -378,6 +391,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     // An empty bin in front of outputs that already hold the empty pattern: nothing to rasterise, nothing to write (~60 %
     // of the workgroups of a clip, every iteration) - leave before touching LDS.  (The bin ticket still has to be drawn.)
     const bool idle = nscan == 0 && rstate0 == 1;
+    const bool ts_on = hm_ts_enabled(hint) && tid == 0;
+    if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 0, ts_t0);
 #ifdef RASTER_PHASES
     unsigned long long rph[6] = {0, 0, 0, 0, 0, 0}, rph_t = clock64();
     unsigned long long rph_units[3] = {0, 0, 0};
@@ -790,6 +805,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
             o[0] = sq; o[1] = inter; o[2] = uni; o[3] = 0.f;
         }
     }
+    if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
 #ifdef RASTER_PHASES
     RPH_MARK(5);
     if (tid == 0) {
@@ -1127,14 +1143,20 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    float* __restrict__ parts, SweepList sl, int clip_len,
                                                    unsigned short* __restrict__ lsum, int nred,
                                                    const float* __restrict__ red_partials, float* __restrict__ frame_rec,
-                                                   float* __restrict__ loss_out, int out_stride)
+                                                   float* __restrict__ loss_out, int out_stride,
+                                                   const unsigned int* __restrict__ ts_flag,
+                                                   unsigned long long* __restrict__ ts_slots)
 {
     HM_CHAIN_KERNEL();
+    const unsigned long long ts_t0 = (unsigned long long)wall_clock64();
+    const bool ts_on = hm_ts_enabled(ts_flag) && threadIdx.x == 0;
+    if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 0, ts_t0);
     __shared__ unsigned long long s_w[16][SWEEP_CUMW];
     __shared__ int s_ex[16][SWEEP_CUMW];
     // the first `ncomp` workgroups build the work list of the edge sweeps (independent of the lines: one launch for both)
     if ((int)blockIdx.x < ncomp) {
         sweep_compact(blockIdx.x, ncomp, fpt, faces9, boxes, owned, B, F, 2 * S, parts, sl, clip_len);
+        if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
         return;
     }
     // the next `nred` (= B or 0) finish the forward's fused loss: one launch less on the chain of a caller that only needs
@@ -1142,9 +1164,12 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     if ((int)blockIdx.x < ncomp + nred) {
         sil_reduce_frame(blockIdx.x - ncomp, red_partials, (S / 8) * (S / 8), keep_sum, frame_rec, loss_out, nullptr, clip_len,
                          out_stride);
+        if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
         return;
     }
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    // (the 16 rows of a workgroup leave at different times: each folds its exit into the workgroup's own end slot)
+    const bool ts_row = l == 0 && hm_ts_enabled(ts_flag);
     const int is = 2 * S, wpl = is / 64;
     const long L = (long)(blockIdx.x - ncomp - nred) * 16 + grp;
     const bool valid = L < 4L * B * is;
@@ -1181,7 +1206,10 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     s_w[grp][l] = mine;
     s_ex[grp][l] = excl;
     __syncthreads();
-    if (!valid || s_ex[grp][SWEEP_CUMW - 1] + __popcll(s_w[grp][SWEEP_CUMW - 1]) == 0) return;
+    if (!valid || s_ex[grp][SWEEP_CUMW - 1] + __popcll(s_w[grp][SWEEP_CUMW - 1]) == 0) {
+        if (ts_row) atomicMax(ts_slots + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64());
+        return;
+    }
     // fused loss, positive upstream: g = upstream * 2 * dimg / keep_sum / B (the arithmetic of k_bwd_masks), no gimg pass
     const bool from_dimg = mode == 2 || (mode == 1 && upstream[0] > 0.0f);     // (modes 3 / 4 read gimg per sample below)
     const float* gi = (from_dimg ? dimg : gimg) + (long)b * S * S;
@@ -1213,6 +1241,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
             out[base + __popcll(w & ((1ull << pos) - 1ull))] = r;
         }
     }
+    if (ts_row) atomicMax(ts_slots + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64());
 }
 
 // ---------------------------------------------------------------- backward, pass 2b: edge sweeps (see the work list above)
@@ -1272,11 +1301,16 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                                                    const uint4* __restrict__ lrec, int B, int F, int S,
                                                    float eps, float* __restrict__ parts,
                                                    const unsigned short* __restrict__ lsum,
-                                                   const unsigned short* __restrict__ alpha16)
+                                                   const unsigned short* __restrict__ alpha16,
+                                                   const unsigned int* __restrict__ ts_flag,
+                                                   unsigned long long* __restrict__ ts_slots)
 {
     // LDS copies are padded to an ODD number of dwords (17 / 9): lanes reading the same field of different faces / items
     // then fall into different banks (64- and 32-byte strides put every second / fourth element on the same bank)
     HM_CHAIN_KERNEL();
+    const unsigned long long ts_t0 = (unsigned long long)wall_clock64();
+    const bool ts_on = hm_ts_enabled(ts_flag) && (threadIdx.x & 63) == 0;       // every wave: they walk their units independently
+    if (ts_on) hm_ts_store(ts_slots, (long)blockIdx.x * 4 + (threadIdx.x >> 6), 0, ts_t0);
     struct FaceLds { SweepFace f; int pad; };
     struct ItemLds { SweepItem it; int pad; };
     __shared__ FaceLds s_face[4][SWEEP_PASS_FACES];
@@ -1611,6 +1645,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             if (nfp < SWEEP_PASS_FACES) break;          // the face behind this pass starts beyond the unit
         }   // face passes
     }   // units
+    if (ts_on) hm_ts_store(ts_slots, (long)blockIdx.x * 4 + (threadIdx.x >> 6), 1, (unsigned long long)wall_clock64());
 }
 
 // ---------------------------------------------------------------- backward, pass 3: vertex gather + projection backward
@@ -1895,6 +1930,11 @@ static int g_sweep_cap_override = 0;
 static hipEvent_t g_tev[6];
 static int g_timing = 0;
 #define HM_TIME_MARK(k, stream) do { if (g_timing) (void)hipEventRecord(g_tev[k], stream); } while (0)
+// timestamp slots of hm_sil_timestamps: {start, end} per raster workgroup, per lines workgroup, per sweep wave
+#define TS_SWEEP_WGS 4096
+static inline size_t ts_raster_units(int B, int S) { return (size_t)B * (S / 8) * (S / 8) / RASTER_WAVES; }
+static inline size_t ts_lines_units(int B, int F, int S) { return (size_t)B * F / 256 + 2 * (size_t)B + 64 + (size_t)B * S / 2 + 8; }
+static inline size_t ts_units(int B, int F, int S) { return ts_raster_units(B, S) + ts_lines_units(B, F, S) + 4 * TS_SWEEP_WGS; }
 static inline size_t sweep_ucap(int B, int F) { return (size_t)B * F * 4 + 1024; }
 static inline size_t sweep_slot_cap(int B, int F) { return sweep_ucap(B, F) + (size_t)B * F; }
 extern "C" {
@@ -1929,6 +1969,7 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
     n += al256((size_t)B * F * 4) * 2;                          //   their first items, their tickets,
     n += al256(sweep_ucap(B, F) * 4);                           //   first face of every unit,
     n += al256(sweep_slot_cap(B, F) * 24);                      //   per-unit partials of faces spread over several units
+    n += al256(ts_units(B, F, S) * 16);                          // in-graph timestamps (hm_sil_timestamps)
     return n;
 }
 
@@ -1939,6 +1980,7 @@ struct SilWs {
     unsigned char* owned; int* bin_cnt; unsigned int* bin_done; unsigned char* region_state; int* bin_list;
     uint4* lrec; SweepSrc* srcs; unsigned short* lsum;
     SweepList sweep;
+    unsigned long long* ts;      // {start, end} slots: raster workgroups | lines workgroups | sweep waves
 };
 static SilWs carve(void* ws, int B, int V, int F, int S)
 {
@@ -1968,7 +2010,8 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.sweep.offs = (int*)p; p += al256((size_t)B * F * 4);
     w.sweep.tickets = (unsigned int*)p; p += al256((size_t)B * F * 4);
     w.sweep.ufirst = (unsigned int*)p; p += al256(sweep_ucap(B, F) * 4);
-    w.sweep.upart = (float*)p;
+    w.sweep.upart = (float*)p; p += al256(sweep_slot_cap(B, F) * 24);
+    w.ts = (unsigned long long*)p;
     w.sweep.cnt = (unsigned long long*)(w.counter + 16);        // zero between launches (re-armed by the last compaction block)
     w.sweep.done = w.counter + 18;
     w.sweep.total = (unsigned long long*)(w.counter + 20);
@@ -1992,14 +2035,16 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
     const int ncomp = (B / clip_len) * hm_cdiv((long)clip_len * F, 256 * fpt);
     hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + nred + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
-                       w.owned, F, w.parts, w.sweep, clip_len, w.lsum, nred, w.partials, w.frame_rec, loss_out, out_stride);
+                       w.owned, F, w.parts, w.sweep, clip_len, w.lsum, nred, w.partials, w.frame_rec, loss_out, out_stride,
+                       w.counter + 24, w.ts + 2 * ts_raster_units(B, S));
 }
 static int g_sweep_blocks = SWEEP_BLOCKS;
 static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
 {
-    const int blocks = max(8, min(hm_cdiv((long)B * F, 2), g_sweep_blocks) & ~7);        // a multiple of 8: see the unit loop
+    const int blocks = max(8, min(min(hm_cdiv((long)B * F, 2), g_sweep_blocks), TS_SWEEP_WGS) & ~7);   // a multiple of 8: see the unit loop
     hipLaunchKernelGGL(k_bwd_sweep, dim3(blocks), dim3(256), 0, stream, w.sweep,
-                       w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts, w.lsum, w.alpha16);
+                       w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts, w.lsum, w.alpha16, w.counter + 24,
+                       w.ts + 2 * (ts_raster_units(B, S) + ts_lines_units(B, F, S)));
 }
 
 // Scheduling hint, no effect on results: bytes of unused dynamic LDS added to every k_raster_fwd launch.  The rasteriser's
@@ -2062,7 +2107,7 @@ int hm_sil_fwd_phase_clips(const float* verts, const int* faces, int faces_bstri
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.planes, bins,
                        w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full, mask_shared,
-                       (fused && alpha_full) ? w.gimg : (float*)nullptr, w.counter + 24);
+                       (fused && alpha_full) ? w.gimg : (float*)nullptr, w.counter + 24, w.ts);
     HM_TIME_MARK(1, stream);
     if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
@@ -2269,7 +2314,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                            w.partials, work_order, w.owned, (float*)nullptr, w.planes, bins, w.bin_list,
                            w.bin_done, cold ? 1 : 0, w.region_state, 1, (float*)nullptr, 0, (float*)nullptr,
-                           w.counter + 24);      // steady state of a fixed loop: background regions skipped
+                           w.counter + 24, w.ts);      // steady state of a fixed loop: background regions skipped
     }
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
@@ -2305,6 +2350,57 @@ int hm_debug_sil_timing(int enable)
         g_timing = 0;
         for (int k = 0; k < 5; ++k) (void)hipEventDestroy(g_tev[k]);
     }
+    return HM_OK;
+}
+// In-graph timing of the same three kernels: device wall-clock stamps stored by the workgroups themselves (see
+// hm_ts_enabled above), so the numbers come from launches replayed from a captured hipGraph - where ROCm allows no events.
+//   hm_sil_timestamps(ws, B, V, F, S, 1, stream): switch on and arm (two async memsets, no host synchronisation); call
+//   before every replay;  (..., 0, stream): switch off
+//   hm_sil_timestamps_bytes(B, V, F, S): size of one record of raw stamps
+//   hm_sil_timestamps_save(ws, B, V, F, S, dst, stream): async device copy of the raw stamps to `dst` - a caller that must
+//   not synchronise between replays saves every iteration's record and reads them all at the end
+//   hm_sil_timestamps_read(ws, B, V, F, S, saved, us3, stream): waits for the stream; durations (earliest start to latest
+//   end over the workgroups) of k_raster_fwd, k_bwd_lines, k_bwd_sweep in microseconds -> us3 (HOST), from `saved` (a
+//   hm_sil_timestamps_save record) or, saved == NULL, from the workspace itself (0 for a kernel that did not run)
+size_t hm_sil_timestamps_bytes(int B, int V, int F, int S) { (void)V; return ts_units(B, F, S) * 16; }
+int hm_sil_timestamps(void* workspace, int B, int V, int F, int S, int enable, hipStream_t stream)
+{
+    HM_CHECK_ARG(workspace && B > 0 && F > 0 && S > 0);
+    SilWs w = carve(workspace, B, V, F, S);
+    if (hipMemsetAsync((char*)workspace + 24 * 4 + 1, enable ? 1 : 0, 1, stream) != hipSuccess) return HM_ERR_LAUNCH;
+    if (enable && hipMemsetAsync(w.ts, 0, ts_units(B, F, S) * 16, stream) != hipSuccess) return HM_ERR_LAUNCH;
+    return HM_OK;
+}
+int hm_sil_timestamps_save(const void* workspace, int B, int V, int F, int S, void* dst, hipStream_t stream)
+{
+    HM_CHECK_ARG(workspace && dst);
+    SilWs w = carve((void*)workspace, B, V, F, S);
+    return hipMemcpyAsync(dst, w.ts, ts_units(B, F, S) * 16, hipMemcpyDeviceToDevice, stream) == hipSuccess ? HM_OK : HM_ERR_LAUNCH;
+}
+int hm_sil_timestamps_read(const void* workspace, int B, int V, int F, int S, const void* saved, float* us3, hipStream_t stream)
+{
+    HM_CHECK_ARG((workspace || saved) && us3 && B > 0 && F > 0 && S > 0);
+    const size_t n = ts_units(B, F, S);
+    unsigned long long* t = (unsigned long long*)malloc(n * 16);
+    if (!t) return HM_ERR_LAUNCH;
+    const void* src = saved ? saved : (const void*)carve((void*)workspace, B, V, F, S).ts;
+    if (hipMemcpyAsync(t, src, n * 16, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) {
+        free(t);
+        return HM_ERR_LAUNCH;
+    }
+    int dev = 0, khz = 0;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    const size_t lo[4] = {0, ts_raster_units(B, S), ts_raster_units(B, S) + ts_lines_units(B, F, S), n};
+    for (int k = 0; k < 3; ++k) {
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        for (size_t u = lo[k]; u < lo[k + 1]; ++u) {
+            if (t[2 * u] != 0ull && t[2 * u] < t0) t0 = t[2 * u];
+            if (t[2 * u + 1] > t1) t1 = t[2 * u + 1];
+        }
+        us3[k] = (t0 != ~0ull && t1 > t0) ? (float)((double)(t1 - t0) * 1e3 / (double)khz) : 0.f;
+    }
+    free(t);
     return HM_OK;
 }
 // durations (ms) of the LAST timed k_raster_fwd, k_bwd_lines, k_bwd_sweep launches -> ms3 (HOST pointer).  Waits for them.

@@ -521,7 +521,7 @@ class FusedStepper:
             # object's smoothness when it rides this stream, the metric-only search (no contact term) and the hand-only
             # reductions
             sm_here = on["smooth"] and not self.smooth_obj_on_main
-            fuse = self.pair_fused and on["inter"] and (sm_here or not on["con"]) and Vo <= 4096
+            fuse = self.pair_fused and on["inter"] and Vo <= 4096
             nn_fused = fuse and not on["con"]
             ht_fused = fuse and self.hand_terms_fused and on["smooth"] and on["v2d"]
             ht_args = (P(m.ref_verts2d_hand), float(m.image_size), P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
@@ -549,22 +549,25 @@ class FusedStepper:
             if sm_here and not fuse:
                 ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
                                          sb), "smooth(obj)")
+            def search_and_contact(stream_obj, rws):
+                sx = stream_obj.cuda_stream
+                if (on["con"] or on["inter"]) and not nn_fused:
+                    # (without the contact term only the logged distance is needed: metric-only search)
+                    ck(L.hm_nn_fwd_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if on["con"] else None,
+                                         P(self.nn_d2) if on["con"] else None, self._slot("handobj_maxdist"), rws, CL, NS,
+                                         P(self.obj_order), sx), "nn")
+                if on["con"]:
+                    ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
+                                              P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws, CL, NS, sx),
+                       "contact")
             if on["col"]:
                 ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
                                             cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
                                             self._slot("loss_collision"), P(cctx.ws), CL, NS, sb), "collision")
-            if (on["con"] or on["inter"]) and not nn_fused:
-                # (step-1 sets need it for the logged metric only; moving it to the third
-                # stream was measured: +1 % at one clip, -9 % on an 8-clip batch - the graph executor serialises the fork.
-                # Capturing the hand-side forward kernels BEFORE the silhouette chain: -38 %, same reason.)
-                # (without the contact term only the logged distance is needed: metric-only search)
-                ck(L.hm_nn_fwd_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if on["con"] else None,
-                                     P(self.nn_d2) if on["con"] else None, self._slot("handobj_maxdist"), rws_b, CL, NS,
-                                     P(self.obj_order), sb), "nn")
-            if on["con"]:
-                ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
-                                          P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws_b, CL, NS, sb),
-                   "contact")
+            # (the search on a third stream at one clip / step 1: +1 %; -9 % on an 8-clip batch.  Search + contact as a third
+            #  branch next to the collision term: the HIP graph runtime crashes at replay when two side branches wait for
+            #  each other's events.  Capturing the hand-side forward kernels BEFORE the silhouette chain: -38 %.)
+            search_and_contact(side, rws_b)
             if fuse:
                 ck(L.hm_pair_terms_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo,
                                              self._slot("handobj_maxdist") if nn_fused else None, P(self.obj_order), rws_b,

@@ -35,6 +35,10 @@ _SIGNATURES = {
     "hm_sil_read_boxes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_debug_occupancy": (_I, [_VP, _VP]),
     "hm_debug_sil_timing": (_I, [_I]),
+    "hm_sil_timestamps_bytes": (_SZ, [_I, _I, _I, _I]),
+    "hm_sil_timestamps": (_I, [_VP, _I, _I, _I, _I, _I, _VP]),
+    "hm_sil_timestamps_save": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
+    "hm_sil_timestamps_read": (_I, [_VP, _I, _I, _I, _I, _VP, _VP, _VP]),
     "hm_debug_sil_timing_read": (_I, [_VP]),
     "hm_debug_read_partials": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_idx_map": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),

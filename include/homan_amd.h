@@ -379,6 +379,17 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
  * a captured graph) measures the duration each kernel has inside the loop, next to the work of the other streams;
  * hm_debug_sil_timing_read: durations in ms of the last timed launches {raster, lines, sweep} -> HOST float[3] (waits).
  * Process-wide; hm_debug_sil_timing(0) releases the events. */
+/* In-graph timing of k_raster_fwd / k_bwd_lines / k_bwd_sweep: every workgroup (every wave of the persistent sweep kernel)
+ * stores the device wall clock (s_memrealtime) at entry and exit into a slot pair of its own inside the silhouette workspace
+ * - for launches replayed from a captured hipGraph, where ROCm allows no events.  B, V, F, S as given to
+ * hm_sil_workspace_bytes.  hm_sil_timestamps(..., 1, stream) switches on and arms (async memsets; call before every replay),
+ * (..., 0, stream) switches off; hm_sil_timestamps_save copies the raw stamps (hm_sil_timestamps_bytes) to `dst` on the
+ * device without synchronising; hm_sil_timestamps_read waits for `stream` and returns earliest-start-to-latest-end of the
+ * three kernels in microseconds (HOST float[3]) from `saved` or, saved == NULL, from the workspace. */
+size_t hm_sil_timestamps_bytes(int B, int V, int F, int S);
+int hm_sil_timestamps(void* workspace, int B, int V, int F, int S, int enable, hipStream_t stream);
+int hm_sil_timestamps_save(const void* workspace, int B, int V, int F, int S, void* dst, hipStream_t stream);
+int hm_sil_timestamps_read(const void* workspace, int B, int V, int F, int S, const void* saved, float* us3, hipStream_t stream);
 int hm_debug_sil_timing(int enable);
 int hm_debug_sil_timing_read(float* ms3);
 int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks);

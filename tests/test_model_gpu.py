@@ -246,3 +246,32 @@ def test_joint_fit_resume_roundtrip(mano_model, tmp_path):
         lb, _ = resumed(loss_weights=lw)
     for k in la:
         assert torch.equal(la[k], lb[k]), k
+
+
+def test_in_graph_timestamps_are_invisible_to_the_results(mano_model):
+    """hm_sil_timestamps: the three heavy kernels of the silhouette chain stamp the device wall clock while they are replayed
+    from the captured hipGraph (bench.py's roofline timing).  The durations are positive and sane, and the optimisation - loss
+    rows and parameters - is bit for bit the one of an untimed twin."""
+    import ctypes
+    from homan_amd import lib as hl
+    from homan_amd.jointopt import FusedStepper
+    name, steps = "ref_step2_cube_b4_s64", 4
+    outs = []
+    for timed in (False, True):
+        rec, model, weights, meta = _build_hip(name, mano_model, sync=False)
+        st = FusedStepper(model, weights, meta["lr"], steps)
+        sctx = model.losses.sil_ctx
+        ws, us3, dims = hl.ptr(sctx.workspace), (ctypes.c_float * 3)(), (sctx.B, sctx.V, sctx.F, sctx.S)
+        for _ in range(steps):
+            if timed:
+                hl.check(hl.lib().hm_sil_timestamps(ws, *dims, 1, hl.stream()), "hm_sil_timestamps")
+            st.run(1)
+            if timed:
+                hl.check(hl.lib().hm_sil_timestamps_read(ws, *dims, None, ctypes.cast(us3, ctypes.c_void_p), hl.stream()), "read")
+                assert all(0.5 < us3[i] < 5e3 for i in range(3)), list(us3)
+        outs.append((st.loss_evolution(steps), {k: v.detach().clone() for k, v in model.named_parameters()}))
+    (evo_a, par_a), (evo_b, par_b) = outs
+    for k in evo_a:
+        np.testing.assert_array_equal(np.asarray(evo_a[k]), np.asarray(evo_b[k]), err_msg=k)
+    for k in par_a:
+        assert torch.equal(par_a[k], par_b[k]), k

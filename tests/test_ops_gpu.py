@@ -219,3 +219,89 @@ def test_collision_vs_oracle(obj, mano_model):
     got = pointmetrics.get_inter_metrics(vh.to(DEV), vo.to(DEV), closed[None], of[None].to(DEV))
     assert got["has_contact"] == want["has_contact"] and all(want["has_contact"])
     np.testing.assert_allclose(got["pen_depths"], want["pen_depths"], rtol=1e-4)
+
+
+def test_pair_terms_launch_equals_its_four_entry_points():
+    """hm_pair_terms_fwd_clips (search | interaction | object smoothness | hand terms as block ranges of ONE launch) returns,
+    bit for bit, what hm_nn_fwd_clips / hm_inter_fwd_clips / hm_smooth_fwd_clips / hm_hand_terms_fwd_clips return - two
+    clips of four frames, per-clip outputs `stride` floats apart."""
+    from homan_amd import constants as c
+    from homan_amd import lib as hl
+    from homan_amd.clipbatch import ClipReduceWorkspace
+    L, P = hl.lib(), hl.ptr
+    g = torch.Generator().manual_seed(5)
+    C, CL, Vh, Vo, stride = 2, 4, 778, 1500, 14
+    B = C * CL
+    vh = (torch.randn(B, Vh, 3, generator=g) * 0.04 + torch.tensor([0.02, 0.0, 0.6])).to(DEV)
+    vo = (torch.randn(B, Vo, 3, generator=g) * 0.05 + torch.tensor([0.0, 0.0, 0.62])).to(DEV)
+    camintr = torch.tensor([[1.37, 0, 0.5], [0, 1.37, 0.5], [0, 0, 1.0]]).repeat(B, 1, 1).to(DEV)
+    ref2d = (torch.rand(B, Vh, 2, generator=g) * 256).to(DEV)
+    pca = torch.randn(B, 45, generator=g).to(DEV)
+    s_o, s_h, one = torch.tensor([1.2, 0.8], device=DEV), torch.tensor([1.0, 1.0], device=DEV), torch.ones(C, device=DEV)
+    order = torch.randperm(Vo, generator=g).to(torch.int32).to(DEV)
+    stream = hl.stream()
+
+    def run(fused):
+        z = lambda *s: torch.zeros(*s, device=DEV)
+        vals, rec = z(C, stride), z(B, 8)
+        u_smo, u_v2d, u_smh, u_pca, u_so, u_sh = z(B, Vo, 3), z(B, Vh, 3), z(B, Vh, 3), z(B, 45), z(C), z(C)
+        ws = [ClipReduceWorkspace(DEV, C) for _ in range(4)]
+        slot = lambda i: vals.data_ptr() + 4 * i
+        ht = (P(ref2d), 256.0, P(u_v2d), slot(0), P(u_smh), slot(2), P(pca), CL * 45, P(s_o), P(one), P(s_h), P(one), P(u_pca),
+              P(u_so), P(u_sh), slot(3))
+        if fused:
+            hl.check(L.hm_pair_terms_fwd_clips(P(vh), P(vo), P(camintr), B, Vh, Vo, slot(6), P(order), P(ws[0].buf),
+                                               c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(rec), slot(7),
+                                               P(ws[1].buf), P(u_smo), slot(8), P(ws[2].buf), *ht, P(ws[3].buf), CL, stride,
+                                               stream), "pair terms")
+        else:
+            hl.check(L.hm_nn_fwd_clips(P(vh), P(vo), B, Vh, Vo, None, None, slot(6), P(ws[0].buf), CL, stride, P(order), stream),
+                     "nn")
+            hl.check(L.hm_inter_fwd_clips(P(vh), P(vo), P(camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
+                                          float(c.INTERACTION_Z_THRESH), P(rec), slot(7), P(ws[1].buf), CL, stride, stream), "inter")
+            hl.check(L.hm_smooth_fwd_clips(P(vo), B, Vo, 1, P(u_smo), slot(8), P(ws[2].buf), CL, stride, stream), "smooth")
+            hl.check(L.hm_hand_terms_fwd_clips(P(vh), P(camintr), 1, ht[0], ht[1], B, Vh, *ht[2:], P(ws[3].buf), CL, stride,
+                                               stream), "hand terms")
+        torch.cuda.synchronize()
+        return [t.clone() for t in (vals, rec, u_smo, u_v2d, u_smh, u_pca, u_so, u_sh)]
+
+    a, b = run(True), run(False)
+    assert a[0].abs().sum() > 0 and (a[0][0] != a[0][1]).any()
+    for x, y, name in zip(a, b, ["vals", "rec", "u_smo", "u_v2d", "u_smh", "u_pca", "u_so", "u_sh"]):
+        assert torch.equal(x, y), name
+
+
+def test_adam_step_with_log_row_equals_two_launches():
+    """hm_adam_step_log = hm_log_total_clips + hm_adam_step: same parameters, same moments, same log rows, and the row lands
+    in the slot of the step being taken (the step counter moves after every workgroup has read it)."""
+    from homan_amd.jointopt import HmAdam
+    from homan_amd import lib as hl
+    g = torch.Generator().manual_seed(9)
+    C, n, steps = 3, 13, 5
+    weights = torch.rand(n, generator=g).to(DEV)
+    weights[2] = 0.0
+
+    def run(fused):
+        gg = torch.Generator().manual_seed(11)
+        params = [torch.nn.Parameter(torch.randn(7, 45, generator=gg).to(DEV)), torch.nn.Parameter(torch.randn(3000, generator=gg).to(DEV))]
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        opt = HmAdam([{"params": params[:1], "lr": 1e-2}, {"params": params[1:], "lr": 1e-1}])
+        vals, log = torch.zeros(C, n + 1, device=DEV), torch.zeros(steps, C, n + 1, device=DEV)
+        for t in range(steps):
+            for p in params:
+                p.grad.copy_(torch.randn(p.shape, generator=gg).to(DEV))
+            vals[:, :n] = torch.rand(C, n, generator=gg).to(DEV)
+            if fused:
+                opt.step(zero_grad=False, log=(vals, weights, n, steps, log, C))
+            else:
+                hl.check(hl.lib().hm_log_total_clips(hl.ptr(vals), hl.ptr(weights), n, hl.ptr(opt.step_t), steps, hl.ptr(log),
+                                                     C, hl.stream()), "log")
+                opt.step(zero_grad=False)
+        torch.cuda.synchronize()
+        return [p.detach().clone() for p in params] + [log.clone(), opt.step_t.clone()] + [m for ms in opt.state for m in ms]
+
+    a, b = run(True), run(False)
+    assert int(a[3][0]) == steps and a[2].abs().sum() > 0
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
