@@ -103,7 +103,7 @@ struct SilGather {
     float orig_size;
     int F;
 };
-__global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
+__global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
                                                    const float* __restrict__ scale, int abs_scale, RigidTerms terms,
                                                    SilGather sil,
                                                    const float* __restrict__ g_rigid, const float* __restrict__ g_frame,
@@ -114,17 +114,13 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
                                                    unsigned int* __restrict__ frame_cnt, int clip_len)
 {
     HM_LATENCY_KERNEL();
-    __shared__ float R[9];
     __shared__ float red13[16 * 13];
     __shared__ int s_flag;
     const int n = blockIdx.x;
-    if (threadIdx.x == 0) {
-        float r[9];
-        rot6d_to_mat(rot6d + n * 6, r);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = r[k];
-    }
-    __syncthreads();
+    // (every thread builds the frame's rotation itself from six uniform loads: no LDS hand-over, no barrier in front of the
+    //  vertex loads - this kernel is a chain of dependent round trips on the tail of both streams)
+    float R[9];
+    rot6d_to_mat(rot6d + n * 6, R);
     const float sraw = scale[n / clip_len];
     const float s = abs_scale ? fabsf(sraw) : sraw;
     float gfr[3] = {0.f, 0.f, 0.f};
@@ -135,7 +131,9 @@ __global__ __launch_bounds__(256) void k_rigid_bwd(const float* __restrict__ mes
     float acc[13];
 #pragma unroll
     for (int k = 0; k < 13; ++k) acc[k] = 0.f;
-    // grid (N, chunks): this workgroup's 256 vertices; the frame's last workgroup (ticket) finishes the frame
+    // grid (N, chunks): this workgroup's share of the vertices (up to 1024 threads x 4: ONE workgroup per frame for meshes of
+    // <= 4096 vertices, no chunk records / ticket / second round trip); with several chunks the frame's last workgroup
+    // (ticket) finishes the frame
     for (int v = blockIdx.y * blockDim.x + threadIdx.x; v < V; v += gridDim.y * blockDim.x) {
         const long o = ((long)n * V + v) * 3;
         const float m[3] = {mesh[o], mesh[o + 1], mesh[o + 2]};
@@ -314,10 +312,11 @@ static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* 
     for (int k = 0; k < 4; ++k) { t.p[k] = k < n_terms ? g_terms[k] : nullptr; t.w[k] = k < n_terms ? weights[k] : 0.f; }
     // workspace (hm_rigid_workspace_bytes, zero-filled once): per-frame tickets + chunk partials -> grid (N, chunks);
     // without it one workgroup per frame does everything
-    const int chunks = workspace ? min(RIGID_MAX_CHUNKS, hm_cdiv(V, 256)) : 1;
+    const int threads = V > 512 ? 1024 : 256;
+    const int chunks = workspace ? min(RIGID_MAX_CHUNKS, hm_cdiv(V, 4 * threads)) : 1;
     unsigned int* cnt = (unsigned int*)workspace;
     float* partials = workspace ? (float*)((char*)workspace + (((size_t)N * 4 + 255) & ~(size_t)255)) : nullptr;
-    hipLaunchKernelGGL(k_rigid_bwd, dim3(N, chunks), dim3(256), 0, stream, mesh, rot6d, scale, abs_scale, t, sil, g_rigid,
+    hipLaunchKernelGGL(k_rigid_bwd, dim3(N, chunks), dim3(threads), 0, stream, mesh, rot6d, scale, abs_scale, t, sil, g_rigid,
                        g_frame, frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, partials, cnt,
                        clip_len ? clip_len : N);
     return hm_launch_status();

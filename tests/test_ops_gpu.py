@@ -26,11 +26,12 @@ def _hand_obj(B=4, seed=0):
     return m, vh, vo, torch.from_numpy(of)
 
 
-def test_rigid_transform_and_grads():
+@pytest.mark.parametrize("V", [300, 1502, 9000])     # 256 threads | one 1024-thread workgroup per frame | chunks + ticket
+def test_rigid_transform_and_grads(V):
     from homan_amd import ops
     from oracle import model as om
     g = torch.Generator().manual_seed(0)
-    N, V = 5, 300
+    N = 5
     mesh = torch.randn(N, V, 3, generator=g) * 0.1
     rot6d = torch.randn(N, 3, 2, generator=g)
     trans = torch.randn(N, 1, 3, generator=g)
