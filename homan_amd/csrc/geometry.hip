@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mes
 // scale, R, t ; g_rigid (per-vertex) and g_frame (one vector per frame, the same for every vertex) reach R, t only
 // (gradients w.r.t. the mesh-detached twin of the vertices).  Summing the weighted terms here replaces a separate
 // linear-combination launch on the critical chain.  grid (N)
-struct RigidTerms { const float* p[4]; float w[4]; };
+struct RigidTerms { const float* p[5]; float w[5]; };
 // Optional fifth term: the silhouette gradient, gathered on the fly from the per-(face, corner) NDC gradients of the edge
 // sweeps (hm_sil_bwd called with grad_verts == NULL) and pushed through the projection backward -- the work of
 // k_bwd_gather, without its launch and without the (B,V,3) round trip on the critical chain.
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
         const float m[3] = {mesh[o], mesh[o + 1], mesh[o + 2]};
         float gf[3] = {0.f, 0.f, 0.f}, gt[3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < 5; ++k)
             if (terms.p[k]) {
                 gf[0] += terms.w[k] * terms.p[k][o]; gf[1] += terms.w[k] * terms.p[k][o + 1]; gf[2] += terms.w[k] * terms.p[k][o + 2];
             }
@@ -306,10 +306,10 @@ static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* 
                             int clip_len, hipStream_t stream)
 {
     HM_CHECK_ARG(mesh && rot6d && scale && g_rot6d && g_trans && N > 0 && V > 0 && HM_CLIP_LEN_OK(N, clip_len));
-    HM_CHECK_ARG(n_terms >= 0 && n_terms <= 4 && (n_terms == 0 || (g_terms && weights)));
+    HM_CHECK_ARG(n_terms >= 0 && n_terms <= 5 && (n_terms == 0 || (g_terms && weights)));
     HM_CHECK_ARG(!g_frame || frame_stride >= 3);
     RigidTerms t;
-    for (int k = 0; k < 4; ++k) { t.p[k] = k < n_terms ? g_terms[k] : nullptr; t.w[k] = k < n_terms ? weights[k] : 0.f; }
+    for (int k = 0; k < 5; ++k) { t.p[k] = k < n_terms ? g_terms[k] : nullptr; t.w[k] = k < n_terms ? weights[k] : 0.f; }
     // workspace (hm_rigid_workspace_bytes, zero-filled once): per-frame tickets + chunk partials -> grid (N, chunks);
     // without it one workgroup per frame does everything
     const int threads = V > 512 ? 1024 : 256;

@@ -310,6 +310,22 @@ class HOMan(nn.Module):
                                        self.int_scales_hand, abs_scale=False)
 
     # ------------------------------------------------------------------ losses
+    def depth_contexts(self):
+        """(object raster context, hand raster context, object instance mask u8, hand instance mask u8) of the ordinal depth
+        term, at the full-image size (built once)."""
+        if self._depth_state is None:
+            size = int(self.image_size)
+            masks_o, masks_h = self.masks_object, self.masks_human
+            if tuple(masks_o.shape[1:]) != (size, size) or tuple(masks_h.shape[1:]) != (size, size):
+                raise NotImplementedError("ordinal depth: instance masks must be (B, image_size, image_size), got "
+                                          f"{tuple(masks_o.shape)} / image_size {size}")
+            batch, dev = self.translations_object.shape[0], self.translations_object.device
+            ctx_o = ops.SilhouetteContext(self.faces_object, self.verts_object_og.shape[1], batch, size, dev)
+            ctx_h = ops.SilhouetteContext(self.faces_hand[:1].expand(batch, -1, -1), 778, batch, size, dev)
+            self._depth_state = (ctx_o, ctx_h, (masks_o != 0).to(torch.uint8).contiguous(),
+                                 (masks_h != 0).to(torch.uint8).contiguous())
+        return self._depth_state
+
     def compute_ordinal_depth_loss(self, verts_object=None, verts_hand=None):
         """reference homan/homan.py:384-419: render object and hand depth at the full-image intrinsics, compare their
         ordering with the instance masks (lossutils.py:133-169).  One hand (hand_nb == 1)."""
@@ -319,19 +335,7 @@ class HOMan(nn.Module):
             verts_object, _ = self.get_verts_object()
         if verts_hand is None:
             verts_hand, _ = self.get_verts_hand()
-        if self._depth_state is None:
-            size = int(self.image_size)
-            masks_o, masks_h = self.masks_object, self.masks_human
-            if tuple(masks_o.shape[1:]) != (size, size) or tuple(masks_h.shape[1:]) != (size, size):
-                raise NotImplementedError("ordinal depth: instance masks must be (B, image_size, image_size), got "
-                                          f"{tuple(masks_o.shape)} / image_size {size}")
-            batch = verts_object.shape[0]
-            dev = verts_object.device
-            ctx_o = ops.SilhouetteContext(self.faces_object, verts_object.shape[1], batch, size, dev)
-            ctx_h = ops.SilhouetteContext(self.faces_hand[:1].expand(batch, -1, -1), 778, batch, size, dev)
-            self._depth_state = (ctx_o, ctx_h, (masks_o != 0).to(torch.uint8).contiguous(),
-                                 (masks_h != 0).to(torch.uint8).contiguous())
-        ctx_o, ctx_h, m_o, m_h = self._depth_state
+        ctx_o, ctx_h, m_o, m_h = self.depth_contexts()
         sil_o, dep_o = ops.depth_render(verts_object, self.camintr, ctx_o, 1.0)
         sil_h, dep_h = ops.depth_render(verts_hand, self.camintr, ctx_h, 1.0)
         return {"loss_depth": ops.ordinal_depth_loss(dep_o, dep_h, sil_o, sil_h, m_o, m_h, self.reduce_ws)}

@@ -257,7 +257,7 @@ class FusedStepper:
 
     SLOTS = ["loss_pca", "loss_scale_obj", "loss_scale_hand", "loss_smooth_obj", "loss_smooth_hand", "loss_collision",
              "loss_contact", "loss_v2d_hand", "v2d_hand", "loss_sil_obj", "iou_object", "loss_inter",
-             "handobj_maxdist"]
+             "handobj_maxdist", "loss_depth"]
 
     def __init__(self, model, loss_weights, lr, max_steps, capture=True, shared_scale=False, group=None):
         from . import constants, ops
@@ -272,10 +272,13 @@ class FusedStepper:
             raise NotImplementedError("FusedStepper covers optimize_mano=True, optimize_mano_beta=True, persp")
         lw = self.lw = {k: float(v) for k, v in loss_weights.items()}
         if lw.get("lw_depth", 0) > 0:
-            if getattr(m, "ordinal_depth", False):
-                raise NotImplementedError("the fused loop does not cover lw_depth > 0: use mode='graph' or 'eager'")
-            raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
-                            "'masks', 'silhouettes', and 'depths'")
+            if not getattr(m, "ordinal_depth", False):
+                # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() without its arguments
+                raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
+                                "'masks', 'silhouettes', and 'depths'")
+            if m.C > 1:
+                raise NotImplementedError("the ordinal depth term normalises over one clip: the fused loop covers it for one "
+                                          "clip at a time (a clip batch: mode='graph' per clip)")
         if m.sil_ctx.padded:
             raise NotImplementedError("the fused loop renders the silhouettes at rend_size % 32 == 0 (the reference's "
                                       "REND_SIZE is 256); other sizes: mode='graph' or 'eager'")
@@ -304,7 +307,8 @@ class FusedStepper:
         on = lambda k: lw.get(k, 0.0) > 0
         self.on = dict(pca=on("lw_pca"), so=on("lw_scale_obj"), sh=on("lw_scale_hand"),
                        smooth=on("lw_smooth_hand") or on("lw_smooth_obj"), col=on("lw_collision"),
-                       con=on("lw_contact"), v2d=on("lw_v2d_hand"), sil=on("lw_sil_obj"), inter=on("lw_inter"))
+                       con=on("lw_contact"), v2d=on("lw_v2d_hand"), sil=on("lw_sil_obj"), inter=on("lw_inter"),
+                       depth=on("lw_depth"))
         w = {"loss_pca": lw["lw_pca"] if self.on["pca"] else 0, "loss_scale_obj": lw["lw_scale_obj"] if self.on["so"] else 0,
              "loss_scale_hand": lw["lw_scale_hand"] if self.on["sh"] else 0,
              "loss_smooth_obj": lw["lw_smooth_obj"] if self.on["smooth"] else 0,
@@ -313,7 +317,8 @@ class FusedStepper:
              "loss_contact": lw["lw_contact"] if self.on["con"] else 0,
              "loss_v2d_hand": lw["lw_v2d_hand"] if self.on["v2d"] else 0,
              "loss_sil_obj": lw["lw_sil_obj"] if self.on["sil"] else 0,
-             "loss_inter": lw["lw_inter"] if self.on["inter"] else 0}
+             "loss_inter": lw["lw_inter"] if self.on["inter"] else 0,
+             "loss_depth": lw["lw_depth"] if self.on["depth"] else 0}
         self.w = w
         self.weights = torch.tensor([w.get(k, 0.0) for k in self.SLOTS], device=dev)
         self.keys = [k for k in self.SLOTS if self._reported(k)]
@@ -333,6 +338,19 @@ class FusedStepper:
         self.obj_order = _morton_order(m.verts_object_og[0]).to(dev)      # spatial sort of the rigid mesh (metric-only search)
         self.pooled = f(B, m.sil_ctx.S, m.sil_ctx.S)
         self.up_sil, self.up_inter = torch.tensor([w["loss_sil_obj"]], device=dev), torch.tensor([w["loss_inter"]], device=dev)
+        if self.on["depth"]:
+            # ordinal depth term (reference homan.py:384-419, opt-in): object and hand rendered with depth at the full-image
+            # camera, the pair-wise ordinal loss, and its gradient back through both depth images to the camera-space vertices
+            self.dctx = m.models[0].depth_contexts()
+            ctx_o, ctx_h = self.dctx[0], self.dctx[1]
+            if ctx_o.padded:
+                raise NotImplementedError("the fused loop renders the depth images at image_size % 32 == 0; other sizes: "
+                                          "mode='graph' or 'eager'")
+            Sd = ctx_o.S
+            self.d_sil_o, self.d_dep_o, self.d_sil_h, self.d_dep_h = f(B, Sd, Sd), f(B, Sd, Sd), f(B, Sd, Sd), f(B, Sd, Sd)
+            self.d_go, self.d_gh, self.d_part, self.d_rec = f(B, Sd, Sd), f(B, Sd, Sd), f(B * 8), f(5)
+            self.G_dep_o, self.G_dep_h = f(B, Vo, 3), f(B, Vh, 3)
+            self.up_depth = torch.tensor([w["loss_depth"]], device=dev)
         # static gradient buffers for exactly the parameters that receive gradients in this configuration
         for p in m.parameters():
             p.grad = None
@@ -425,7 +443,7 @@ class FusedStepper:
         return {"loss_pca": o["pca"], "loss_scale_obj": o["so"], "loss_scale_hand": o["sh"], "loss_smooth_obj": o["smooth"],
                 "loss_smooth_hand": o["smooth"], "loss_collision": o["col"], "loss_contact": o["con"],
                 "loss_v2d_hand": o["v2d"], "v2d_hand": o["v2d"], "loss_sil_obj": o["sil"], "iou_object": o["sil"],
-                "loss_inter": o["inter"], "handobj_maxdist": o["inter"]}[k]
+                "loss_inter": o["inter"], "handobj_maxdist": o["inter"], "loss_depth": o["depth"]}[k]
 
     def _slot(self, name):
         """device address of slot `name` of clip 0; clip c is `self.NS` floats further (the kernels' out_stride)"""
@@ -584,6 +602,22 @@ class FusedStepper:
                                         NS, sb), "inter")
             if on["inter"] and m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
                 ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb), "inter_bwd")
+            if on["depth"]:
+                ctx_o, ctx_h, m_o, m_h = self.dctx
+                Sd, K = ctx_o.S, P(m.camintr)
+                for verts, ctx, V_, sil, dep in ((self.vo, ctx_o, Vo, self.d_sil_o, self.d_dep_o),
+                                                 (self.vh, ctx_h, Vh, self.d_sil_h, self.d_dep_h)):
+                    ck(L.hm_sil_fwd(P(verts), P(ctx.faces), 0, K, B, V_, ctx.F, Sd, 1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR,
+                                    None, None, None, P(sil), None, P(ctx.work_order), P(dep), None, 0, None, None, None, 0, 0,
+                                    P(ctx.workspace), sb), "depth render")
+                ck(L.hm_ordinal_depth_fwd(P(self.d_dep_o), P(self.d_dep_h), P(self.d_sil_o), P(self.d_sil_h), P(m_o), P(m_h), B,
+                                          Sd, P(self.d_part), P(self.d_rec), self._slot("loss_depth"), rws_b, sb), "ordinal depth")
+                ck(L.hm_ordinal_depth_bwd(P(self.d_dep_o), P(self.d_dep_h), P(self.d_sil_o), P(self.d_sil_h), P(m_o), P(m_h), B,
+                                          Sd, P(self.d_rec), P(self.up_depth), P(self.d_go), P(self.d_gh), sb), "ordinal depth bwd")
+                for verts, ctx, V_, g, G in ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o),
+                                             (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h)):
+                    ck(L.hm_depth_bwd(P(verts), K, B, V_, ctx.F, Sd, 1.0, P(g), P(ctx.adj_off), P(ctx.adj_items), P(G),
+                                      P(ctx.workspace), sb), "depth bwd")
             self.ev_fwd.record(side)         # every forward loss value of this stream exists now
             if not self.smooth_obj_on_main:
                 aux_block()
@@ -593,7 +627,8 @@ class FusedStepper:
             tp, tw, tn = _lib.terms([(self.U_smh if on["smooth"] else None, w["loss_smooth_hand"]),
                                      (self.U_v2d if on["v2d"] else None, w["loss_v2d_hand"]),
                                      (self.U_colh if on["col"] else None, w["loss_collision"]),
-                                     (self.U_conh if on["con"] else None, w["loss_contact"])])
+                                     (self.U_conh if on["con"] else None, w["loss_contact"]),
+                                     (self.G_dep_h if on["depth"] else None, 1.0)])       # (already times its weight)
             ck(L.hm_rigid_bwd_clips(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, tp, tw, tn, None,
                                     (self.rec.data_ptr() + 8) if on["inter"] else None, 8, w["loss_inter"] / Vh, B, Vh,
                                     P(self.G_mesh), P(m.rotations_hand.grad), P(m.translations_hand.grad), None,
@@ -617,7 +652,8 @@ class FusedStepper:
         sc_obj = m.optimize_object_scale
         tp, tw, tn = _lib.terms([(self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),
                                  (self.U_cono if on["con"] else None, w["loss_contact"]),
-                                 (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0)])
+                                 (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0),
+                                 (self.G_dep_o if on["depth"] else None, 1.0)])
         if on["sil"]:       # the silhouette term is gathered from the sweeps' per-corner gradients inside this launch
             ck(L.hm_rigid_bwd_sil_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn,
                                         L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
@@ -716,9 +752,9 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
         # the fused launch sequence when it covers the configuration (every BASELINE config: the CLI's optimize_mano=1,
         # optimize_mano_beta, persp, no depth term, silhouettes on a multiple of 32), else the same iteration through
         # HOMan.forward + autograd in a hipGraph; mode="eager" is the reference's loop verbatim (host sync per logged value)
+        depth_on = (loss_weights or {}).get("lw_depth", 0) > 0
         fused_ok = (optimize_mano and optimize_mano_beta and hand_proj_mode == "persp" and rend_size % 32 == 0 and
-                    not (loss_weights or {}).get("lw_depth", 0) > 0 and
-                    list(person_parameters[0]["hand_side"]) == ["right"])
+                    (not depth_on or image_size % 32 == 0) and list(person_parameters[0]["hand_side"]) == ["right"])
         mode = "fused" if fused_ok else "graph"
     model = build_model(person_parameters, object_parameters, class_name, objvertices, objfaces, camintr,
                         hand_proj_mode, optimize_mano, optimize_mano_beta, optimize_object_scale, state_dict,

@@ -43,7 +43,7 @@ typedef struct ihipStream_t* hipStream_t;
  * mesh (N,V,3), rot6d (N,3,2), trans (N,3), scale (1), rotmat (N,3,3) optional output, verts (N,V,3). */
 int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, const float* scale, int abs_scale, int N,
                  int V, float* rotmat, float* verts, hipStream_t stream);
-/* g_terms / weights: HOST arrays of n_terms (<= 4) device pointers (N,V,3) and factors, read at launch; their weighted sum
+/* g_terms / weights: HOST arrays of n_terms (<= 5) device pointers (N,V,3) and factors, read at launch; their weighted sum
  * is d/dverts reaching mesh, scale, R, t (NULL entries are skipped).  g_rigid (N,V,3) and g_frame (one 3-vector per
  * frame at g_frame + n*frame_stride, times frame_scale, applied to every vertex) reach R, t only: gradients w.r.t. the
  * mesh-detached twin of the vertices.  Outputs: g_mesh (N,V,3) optional, g_rot6d (N,3,2), g_trans (N,3), g_scale_part (N)

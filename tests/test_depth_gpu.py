@@ -134,3 +134,52 @@ def test_model_ordinal_depth_term_matches_oracle(mano_model):
     st.run(20)
     evo = st.loss_evolution(20)["loss"]
     assert evo[-1] < evo[0]
+
+
+def test_fused_loop_covers_the_ordinal_depth_term(mano_model):
+    """FusedStepper with lw_depth > 0 (opt-in `ordinal_depth=True`): its launch sequence - two depth renders at the image
+    camera, the ordinal loss, its backward through both depth images into the rigid / MANO backward - gives the losses and the
+    parameter gradients of HOMan.forward + autograd, next to the other step-2 terms; without the opt-in it raises the
+    reference's TypeError; a few captured steps reduce the term."""
+    from homan_amd import HOMan, synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle.jointopt import collate_inputs
+    size = 64
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    clip = synth.make_clip(seed=5, frames=4, rend_size=size, image_size=size, obj="cube", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    for pp, op in zip(clip["person_parameters"], clip["object_parameters"]):
+        full = ((pp["masks"][0] > 0) | (op["full_mask"] > 0))
+        op["full_mask"] = full.float()
+        pp["masks"] = torch.zeros_like(pp["masks"])
+        pp["translations"] = pp["translations"] + torch.tensor([0.06, 0.0, -0.02])    # hand over the object
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=size,
+                  mano_model=mano_model, rend_size=size, sync_metrics=False)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS, lw_depth=2.0)
+    with pytest.raises(TypeError):
+        FusedStepper(HOMan(**copy.deepcopy(kw), **common), lw, 1e-2, 2, capture=False)
+    model = HOMan(**copy.deepcopy(kw), ordinal_depth=True, **common)
+    loss_dict, _ = model(loss_weights=lw)
+    assert float(loss_dict["loss_depth"]) > 0
+    total = sum(loss_dict[k] * lw[k.replace("loss", "lw")] for k in loss_dict)
+    total.sum().backward()
+    ref_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    ref_losses = {k: float(v.detach().reshape(-1)[0]) for k, v in loss_dict.items()}
+    st = FusedStepper(model, lw, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    for k, v in ref_losses.items():
+        np.testing.assert_allclose(st.log_buf[0, 0, st.SLOTS.index(k)].item(), v, rtol=2e-6, atol=1e-9, err_msg=k)
+    np.testing.assert_allclose(st.log_buf[0, 0, len(st.SLOTS)].item(), float(total.detach().reshape(-1)[0]), rtol=2e-6)
+    for k, p in model.named_parameters():
+        if k in ref_grads:
+            scale = max(ref_grads[k].abs().max().item(), 1e-20)
+            assert ((p.grad - ref_grads[k]).abs().max() / scale).item() < 2e-5, k
+    # captured loop on the depth term alone: it goes down
+    model2 = HOMan(**copy.deepcopy(kw), ordinal_depth=True, **common)
+    lw_d = dict({k: 0.0 for k in synth.STEP1_LOSS_WEIGHTS}, lw_depth=1.0)
+    st2 = FusedStepper(model2, lw_d, 1e-2, 20)
+    st2.run(20)
+    evo = st2.loss_evolution(20)
+    assert sorted(evo) == ["loss", "loss_depth"] and evo["loss_depth"][-1] < evo["loss_depth"][0]
