@@ -389,8 +389,9 @@ class FusedStepper:
         if capture:
             # scheduling hint baked into the captured launches: with the collision / contact terms the hand-side stream is
             # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way;
-            # same-box A/B on cfg3: 1280 -> 4030, 768 -> 4130, 512 -> 4194 it/s)
-            sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (512 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
+            # same-box A/B on cfg3, round 2 before the launch fusions: 1280 -> 4030, 768 -> 4130, 512 -> 4194 it/s; after them,
+            # with the raster ballast below: 512 -> 4408, 768 -> 4552, 1024 -> 4537, 1280 -> 4512)
+            sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (768 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
             prev = _lib.lib().hm_tune_sweep_blocks(sb)
             # same idea for the rasteriser: 8 KB of LDS ballast = 4 workgroups per CU instead of 6 leaves registers for the
             # hand-side kernels (cfg3 one clip: 4347 -> 4500 it/s; cfg2, where that chain is short: 5820 -> 5500, so not there)
