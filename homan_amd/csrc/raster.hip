@@ -1254,7 +1254,41 @@ struct SweepGeo {
     float p00, p01, p10, p11, p20, p21, num, d1_cross;
     bool geo;
 };
-__device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, bool mine, int is)
+// Per (face of the pass, family) constants, built once per pass by the wave (k_bwd_sweep): the slope of the edge along the
+// line axis (the IEEE division every item of the family used to repeat), the family's first line and the order of its two
+// end points.  {slope bits, d0_from | (p00 < p10) << 16}
+struct SweepLite { int var, axis, d0r, a_in, a_out; bool geo, pos; };
+__device__ __forceinline__ SweepLite sweep_item_lite(const SweepFace& fc, const int2* __restrict__ famtab, int j, bool mine, int is)
+{
+    SweepLite q;
+    int fam = 0;
+#pragma unroll
+    for (int stp = 8; stp > 0; stp >>= 1)
+        if ((int)fc.cum[fam + stp - 1] <= j) fam += stp;
+    const int fstart = fam ? (int)fc.cum[fam - 1] : 0;
+    q.var = fam >= 6 ? 1 : 0;
+    const int ci = fam - 6 * q.var;
+    q.axis = ci & 1;
+    const int edge = ci >> 1, v0 = q.var ? 2 - edge : edge;
+    const float p00 = (q.axis ? fc.py : fc.px)[v0], p01 = (q.axis ? fc.px : fc.py)[v0];
+    const int2 ft = famtab[fam];
+    const float slope = __int_as_float(ft.x);
+    const bool lt = (ft.y >> 16) & 1;
+    const int dir = q.axis == 0 ? (lt ? -1 : 1) : (lt ? 1 : -1);
+    q.d0r = mine ? (ft.y & 0xffff) + (j - fstart) : 0;
+    const float d1_cross = slope * ((float)q.d0r - p00) + p01;
+    bool geo = mine && d1_cross > -8.0f && d1_cross < (float)is + 8.0f;
+    const int d1_in = geo ? ((dir > 0) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross)) : 0;
+    const int d1_out = d1_in + dir;
+    geo = geo && !(d1_in < 0 || is <= d1_in || d1_out < 0 || is <= d1_out);
+    q.a_in = geo ? d1_in : 0;
+    q.a_out = geo ? d1_out : 0;
+    q.geo = geo;
+    q.pos = dir > 0;
+    return q;
+}
+__device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, bool mine, int is,
+                                                   const int2* __restrict__ famtab = nullptr)
 {
     SweepGeo q;
     int fam = 0;
@@ -1275,7 +1309,7 @@ __device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, b
     else q.dir = (q.p00 < q.p10) ? 1 : -1;
     const int d0_from = (int)fmaxf(ceilf(fminf(q.p00, q.p10)), 0.0f);
     q.num = q.p10 - q.p00;
-    const float slope = (q.p11 - q.p01) / q.num;
+    const float slope = famtab ? __int_as_float(famtab[fam].x) : (q.p11 - q.p01) / q.num;     // (the same float either way)
     q.d0r = mine ? d0_from + (j - fstart) : 0;
     q.d1_cross = slope * ((float)q.d0r - q.p00) + q.p01;
     bool geo = mine && q.d1_cross > -8.0f && q.d1_cross < (float)is + 8.0f;
@@ -1296,7 +1330,7 @@ __device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, b
 //            two sweeps, and the (item, source) pairs flattened over the wave as before.
 // Filtering before the expensive half is what the 256-item unit is for: a 64-item unit leaves ~19 survivors, a quarter of a
 // wave, and a divergent early-out saves nothing.  Unit composition depends only on the compaction block the items come from.
-__global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
                                                    const SweepSrc* __restrict__ srcs,
                                                    const uint4* __restrict__ lrec, int B, int F, int S,
                                                    float eps, float* __restrict__ parts,
@@ -1319,6 +1353,8 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
     __shared__ int s_head[4][256];
     __shared__ ItemLds s_item[4][64];
     __shared__ unsigned short s_q[4][SWEEP_UNIT];
+    __shared__ int2 s_fam[4][SWEEP_PASS_FACES][12];      // per (face of the pass, family): see sweep_item_lite
+    __shared__ int s_fb[4][SWEEP_PASS_FACES][2];         // per (face, axis): range of the inward sweeps, lo | hi << 16
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int is = 2 * S;
     const bool pow2 = (is & (is - 1)) == 0;
@@ -1366,14 +1402,41 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
             }
             for (int i = lane; i < SWEEP_PASS_FACES * 6; i += 64) (&s_fg[wv][0][0])[i] = 0.f;
             wave_sync();
+            // family constants of the pass's faces: one division per (face, family) instead of one per item
+            for (int idx = lane; idx < nfp * 12; idx += 64) {
+                const int e = idx / 12, fam = idx - 12 * e;
+                const SweepFace& f = s_face[wv][e].f;
+                const int var = fam >= 6 ? 1 : 0, ci = fam - 6 * var, edge = ci >> 1, axis = ci & 1;
+                int v0 = edge, v1 = edge == 2 ? 0 : edge + 1;
+                if (var) { v0 = 2 - v0; v1 = 2 - v1; }
+                const float* pa = axis ? f.py : f.px;
+                const float* pb = axis ? f.px : f.py;
+                const float p00 = pa[v0], p10 = pa[v1], p01 = pb[v0], p11 = pb[v1];
+                const float slope = (p11 - p01) / (p10 - p00);
+                const int d0_from = (int)fmaxf(ceilf(fminf(p00, p10)), 0.0f);
+                s_fam[wv][e][fam] = make_int2(__float_as_int(slope), (d0_from & 0xffff) | ((p00 < p10) ? 1 << 16 : 0));
+            }
+            if (lane < 2 * nfp) {
+                // the inward sweep stays inside the triangle: its extent along the line bounds the range
+                const int e = lane >> 1, axis = lane & 1;
+                const SweepFace& f = s_face[wv][e].f;
+                const float* pb = axis ? f.px : f.py;
+                const float tmin = fminf(pb[0], fminf(pb[1], pb[2])), tmax = fmaxf(pb[0], fmaxf(pb[1], pb[2]));
+                s_fb[wv][e][axis] = max(0, (int)floorf(fmaxf(tmin, 0.f)) - 1) | (min(is - 1, (int)ceilf(fminf(tmax, (float)is)) + 1) << 16);
+            }
+            wave_sync();
+#if defined(SWEEP_EXP) && SWEEP_EXP == 2          // (timing experiment: metadata loads only; results are wrong)
+            if (eps > 0.f) { if (nfp < SWEEP_PASS_FACES) break; else continue; }
+#endif
             // ---------------- stage 1: which items have a source in reach?  Four trips cover the unit; the summary loads of
             // all of them are in flight before the first is tested (one dependent round trip per unit, not per trip)
             int qn = 0;
             {
                 uint4 sm[4];
-                int s_ain[4], s_aout[4], s_lo[4], s_hi[4], s_ent[4], s_own[4], s_fn[4];
+                // (per trip, packed - the four trips' state lives in registers until their loads have landed:
+                //  s_io = a_in | pos << 12 | geo << 13, s_lohi = lo | hi << 16 of the inward range)
+                int s_io[4], s_lohi[4], s_ent[4], s_own[4], s_fn[4];
                 unsigned short s_aw[4];
-                bool s_geo[4], s_pos[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int g = it_lo + 64 * t + lane;
@@ -1382,7 +1445,7 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                     const SweepFace& fc = s_face[wv][max(el, 0)].f;
                     // (past the last face of a compaction block: padding that belongs to no face)
                     const bool mine = g < it_hi && el >= 0 && g - fc.off < (int)fc.cum[11];
-                    const SweepGeo q = sweep_item_geo(fc, mine ? g - fc.off : 0, mine, is);
+                    const SweepLite q = sweep_item_lite(fc, s_fam[wv][max(el, 0)], mine ? g - fc.off : 0, mine, is);
                     sm[t] = *reinterpret_cast<const uint4*>(lsum + (((long)fc.b * 2 + q.axis) * is + q.d0r) * 8);
                     // the two samples at the edge, requested with the summary (one round trip): the owner of the sample just
                     // inside (the outward sweep runs only from a sample this winding owns) and the alpha word of the sample
@@ -1395,29 +1458,32 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                         s_aw[t] = (unsigned short)((s_aw[t] >> (xi_out & 15)) & 1u);
                         s_fn[t] = fc.bf - fc.b * F + q.var * F;
                     }
-                    s_ain[t] = q.a_in; s_aout[t] = q.a_out; s_geo[t] = q.geo; s_pos[t] = q.dir > 0;
-                    // the inward sweep stays inside the triangle: its extent along the line bounds the range
-                    const float tmin = fminf(q.p01, fminf(q.p11, q.p21)), tmax = fmaxf(q.p01, fmaxf(q.p11, q.p21));
-                    s_lo[t] = q.dir > 0 ? max(0, (int)floorf(fmaxf(tmin, 0.f)) - 1) : q.a_in;
-                    s_hi[t] = q.dir > 0 ? q.a_in : min(is - 1, (int)ceilf(fminf(tmax, (float)is)) + 1);
+                    s_io[t] = q.a_in | (q.pos ? 1 << 12 : 0) | (q.geo ? 1 << 13 : 0);
+                    {
+                        const int fbv = s_fb[wv][max(el, 0)][q.axis];
+                        s_lohi[t] = q.pos ? ((fbv & 0xffff) | (q.a_in << 16)) : (q.a_in | (fbv & 0xffff0000));
+                    }
                     s_ent[t] = (g - ubeg) | (max(el, 0) << 8);
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const int min0 = (int)(sm[t].x & 0xffffu), end0 = (int)(sm[t].x >> 16);
                     const int min1 = (int)(sm[t].z & 0xffffu), end1 = (int)(sm[t].z >> 16);
+                    const bool pos = (s_io[t] >> 12) & 1, geo_t = (s_io[t] >> 13) & 1;
+                    const int a_in_t = s_io[t] & 0xfff, a_out_t = a_in_t + (pos ? 1 : -1);
+                    const int lo_t = s_lohi[t] & 0xffff, hi_t = s_lohi[t] >> 16;
                     // outward: plane 0 from the sample just outside the edge to the border (exact)
-                    const bool out_ok = s_pos[t] ? end0 > s_aout[t] : min0 <= s_aout[t];
-                    // inward: plane 1 inside [s_lo, s_hi] (first / last position, then the 64-sample words in between)
-                    const int wlo = s_lo[t] >> 6, whi = s_hi[t] >> 6;
-                    const bool in_ok = s_lo[t] <= s_hi[t] && min1 <= s_hi[t] && end1 > s_lo[t] &&
+                    const bool out_ok = pos ? end0 > a_out_t : min0 <= a_out_t;
+                    // inward: plane 1 inside [lo, hi] (first / last position, then the 64-sample words in between)
+                    const int wlo = lo_t >> 6, whi = hi_t >> 6;
+                    const bool in_ok = lo_t <= hi_t && min1 <= hi_t && end1 > lo_t &&
                                        ((sm[t].w >> wlo) & ((2u << (whi - wlo)) - 1u)) != 0u;
-                    const bool a0 = s_geo[t] && s_own[t] == s_fn[t] && out_ok;       // exact: the outward sweep has pairs
-                    const bool a1 = s_geo[t] && s_aw[t] == 0 && in_ok;                // (the inward range is refined in stage 2)
+                    const bool a0 = geo_t && s_own[t] == s_fn[t] && out_ok;       // exact: the outward sweep has pairs
+                    const bool a1 = geo_t && s_aw[t] == 0 && in_ok;                // (the inward range is refined in stage 2)
                     const bool reach = a0 || a1;
                     const unsigned long long bal = __ballot(reach);
 #ifdef SWEEP_STATS
-                    const unsigned long long gbal = __ballot(s_geo[t]);
+                    const unsigned long long gbal = __ballot(geo_t);
                     if (lane == 0) {
                         atomicAdd(&g_sweep_n[8], (unsigned long long)max(0, min(64, it_hi - (it_lo + 64 * t))));
                         atomicAdd(&g_sweep_n[9], (unsigned long long)__popcll(gbal));
@@ -1430,13 +1496,16 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                 }
             }
             wave_sync();
+#if defined(SWEEP_EXP) && SWEEP_EXP == 1          // (timing experiment: no stage 2; results are wrong)
+            if (eps > 0.f) qn = 0;
+#endif
             // ---------------- stage 2: the items that may collect something, 64 per trip
             for (int s0 = 0; s0 < qn; s0 += 64) {
             bool mine = s0 + lane < qn;
             const int ent = mine ? (int)s_q[wv][s0 + lane] : 0;
             const int g = ubeg + (ent & 0xff), el = (ent >> 8) & 15;
             const SweepFace& fc = s_face[wv][el].f;
-            const SweepGeo q = sweep_item_geo(fc, mine ? g - fc.off : 0, mine, is);
+            const SweepGeo q = sweep_item_geo(fc, mine ? g - fc.off : 0, mine, is, s_fam[wv][el]);
             const int var = q.var, edge = q.edge, axis = q.axis, d0r = q.d0r, dir = q.dir, a_in = q.a_in, a_out = q.a_out;
             const float p00 = q.p00, p01 = q.p01, p10 = q.p10, p11 = q.p11, p20 = q.p20, p21 = q.p21, num = q.num;
             const float d1_cross = q.d1_cross;
@@ -1533,6 +1602,12 @@ __global__ __launch_bounds__(256) void k_bwd_sweep(SweepList sl, const int* __re
                 // number at that position, and a running maximum carries it over the item's pairs.
 #pragma unroll 1
                 for (int base = 0; base < npairs; base += 256) {
+#if defined(SWEEP_EXP) && SWEEP_EXP == 3          // (timing experiment: at most one pair round per trip; results are wrong)
+                    if (base > 0 && eps > 0.f) break;
+#endif
+#if defined(SWEEP_EXP) && SWEEP_EXP == 4          // (timing experiment: no pair rounds at all; results are wrong)
+                    if (eps > 0.f) break;
+#endif
 #ifdef SWEEP_STATS
                     if (lane == 0) atomicAdd(&g_sweep_n[11], 1ull);
 #endif
