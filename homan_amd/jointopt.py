@@ -266,6 +266,9 @@ class FusedStepper:
             if list(one.hand_sides) != ["right"]:
                 raise NotImplementedError("the fused loop covers one right hand per frame (every BASELINE configuration); "
                                           "two hands / a left hand: mode='graph' or 'eager'")
+            if one.losses.inter_type != "centroid":
+                raise NotImplementedError("the fused loop covers inter_type='centroid' (the reference default); 'min': "
+                                          "mode='graph' or 'eager'")
         m = self.model = model if isinstance(model, ClipBatch) else ClipBatch(model if isinstance(model, (list, tuple))
                                                                              else [model])
         if not (m.optimize_mano and not m.int_scales_hand.requires_grad and m.hand_proj_mode == "persp"):

@@ -9,8 +9,8 @@ class Losses:
                  camintr_rois_object, camintr_rois_hand, camintr, class_name, inter_type="min", hand_nb=1,
                  faces_object=None, num_verts_object=None, rend_size=constants.REND_SIZE, reduce_ws=None,
                  sync_metrics=True):
-        if inter_type != "centroid":
-            raise NotImplementedError("only inter_type='centroid' (the reference default, homan/homan.py:58)")
+        if inter_type not in ("centroid", "min"):
+            raise ValueError(f"inter_type {inter_type} not in [centroid|min]")
         self.inter_type = inter_type
         self.ref_mask_object, self.keep_mask_object = ref_mask_object, keep_mask_object
         self.ref_mask_hand, self.keep_mask_hand = ref_mask_hand, keep_mask_hand
@@ -68,18 +68,30 @@ class Losses:
             raise NotImplementedError("one object per frame")
         vo = verts_object_b[:, 0]
         hand_nb = verts_hand_b.shape[1]
-        if hand_nb == 1:
+        if hand_nb == 1 and self.inter_type == "centroid":
             vh = verts_hand_b[:, 0]
             loss = ops.inter_loss(vh, vo, self.camintr, self.rws, self.expansion, self.thresh)
             if nn is None:
                 nn = ops.nearest_vertices(vh, vo, self.rws)
             return {"loss_inter": loss}, {"handobj_maxdist": self._metric(nn[2][0])}
+        if hand_nb == 1 and nn is not None:
+            nn = [nn]
         loss, per_frame = None, []
         for p in range(hand_nb):
             vh = verts_hand_b[:, p].contiguous()
-            term = ops.inter_loss(vh, vo, self.camintr, self.rws, self.expansion, self.thresh)
+            search = nn[p] if nn is not None else ops.nearest_vertices(vh, vo, self.rws)
+            if self.inter_type == "centroid":
+                term = ops.inter_loss(vh, vo, self.camintr, self.rws, self.expansion, self.thresh)
+            else:
+                # inter_type "min" (:219-221): the smallest squared vertex distance of every interacting frame - the search
+                # names the closest pair, the term itself is formed on the two gathered vertices (differentiable in both)
+                flags = ops.interaction_flags(vh, vo, self.camintr, self.rws, self.expansion, self.thresh)
+                i_star = search[1].argmin(1)
+                j_star = search[0].gather(1, i_star[:, None]).long()[:, 0]
+                rows = torch.arange(vh.shape[0], device=vh.device)
+                diff = vh[rows, i_star] - vo[rows, j_star]
+                term = ((diff * diff).sum(1) * flags.float()).sum().reshape(1)
             loss = term if loss is None else loss + term
-            d2 = (nn[p] if nn is not None else ops.nearest_vertices(vh, vo, self.rws))[1]
-            per_frame.append(d2.min(1)[0])
+            per_frame.append(search[1].min(1)[0])
         maxdist = torch.stack(per_frame).min(0)[0].max().clamp_min(0).sqrt()
         return {"loss_inter": loss}, {"handobj_maxdist": self._metric(maxdist)}

@@ -638,6 +638,20 @@ def inter_loss(vh, vo, camintr, rws, expansion=0.2, zthresh=3.0):
     return _InterLoss.apply(vh, vo, camintr, expansion, zthresh, rws)
 
 
+def interaction_flags(vh, vo, camintr, rws, expansion=0.2, zthresh=3.0):
+    """(B,) bool, no grad: which frames the coarse interaction term applies to (expanded 2-D boxes overlap and the depth ranges
+    are closer than `zthresh`; reference homan/losses.py:98-139), from the frame records of hm_inter_fwd."""
+    with torch.no_grad():
+        vh, vo = _f32(vh.detach()), _f32(vo.detach())
+        B = vo.shape[0]
+        rec = torch.empty(B, 8, device=vh.device)
+        out = torch.empty(1, device=vh.device)
+        _lib.check(_lib.lib().hm_inter_fwd(_lib.ptr(vh), _lib.ptr(vo), _lib.ptr(camintr), B, vh.shape[1], vo.shape[1],
+                                           float(expansion), float(zthresh), _lib.ptr(rec), _lib.ptr(out), _lib.ptr(rws.buf),
+                                           _lib.stream()), "hm_inter_fwd")
+        return rec[:, 0] != 0
+
+
 def nearest_vertices(vh, vo, rws, metric_only=False):
     """hand -> object nearest vertex (no grad): idx (B,Vh) int32, squared distance, and the metric
     max_b min_{i,j} |h_i - o_j| of reference homan/losses.py:225-241.  metric_only: (None, None, metric) - the same exact

@@ -48,6 +48,8 @@ def test_adam_trajectory(name, mano_model):
     """The oracle loop reproduces the reference loop's loss_evolution and final parameters."""
     from oracle.jointopt import make_optimizer
     rec, model, weights, meta = _build(name, mano_model)
+    if not meta["has_trajectory"]:
+        pytest.skip("forward / backward golden only (a model option the reference's loop does not expose)")
     opt = make_optimizer(model, meta["lr"])
     evo = {}
     for _ in range(meta["steps"]):
@@ -124,6 +126,8 @@ def test_pinned_step_forward_and_grads(name, mano_model):
     forward / backward there must match the reference's own forward / backward at those parameters at single-step
     tolerance (losses 2e-5, gradients 5e-5 of the largest entry) - no trajectory, hence no chaotic separation to hide in."""
     rec, model, weights, meta = _build(name, mano_model)
+    if not meta["has_trajectory"]:
+        pytest.skip("forward / backward golden only")
     assert int(rec["meta_pin_step"]) >= 3
     pinned = {k[4:]: torch.from_numpy(rec[k]) for k in rec if k.startswith("pin_")}
     assert any(not np.array_equal(rec["pin_" + k], rec["in_" + k]) for k in ("translations_object", "translations_hand"))

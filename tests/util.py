@@ -22,7 +22,9 @@ def load_golden(name):
     meta = dict(image_size=int(rec["meta_image_size"]), steps=int(rec["meta_steps"]),
                 optimize_object_scale=bool(rec["meta_optimize_object_scale"]),
                 optimize_mano=bool(rec["meta_optimize_mano"]), lr=float(rec["meta_lr"]),
-                hand_sides=[str(x) for x in rec["meta_hand_sides"]] if "meta_hand_sides" in rec else ["right"])
+                hand_sides=[str(x) for x in rec["meta_hand_sides"]] if "meta_hand_sides" in rec else ["right"],
+                inter_type=str(rec["meta_inter_type"]) if "meta_inter_type" in rec else "centroid",
+                has_trajectory="evo_loss" in rec)
     return rec, inputs, rec["in_camintr"], weights, meta
 
 
@@ -30,7 +32,8 @@ def model_kwargs(inputs, camintr, meta):
     kw = dict(inputs)
     kw.update(hand_sides=list(meta["hand_sides"]), camintr=camintr, class_name="default", int_scale_init=1,
               hand_proj_mode="persp", optimize_mano=meta["optimize_mano"], optimize_mano_beta=True,
-              optimize_object_scale=meta["optimize_object_scale"], image_size=meta["image_size"])
+              optimize_object_scale=meta["optimize_object_scale"], image_size=meta["image_size"],
+              inter_type=meta["inter_type"])
     return kw
 
 

@@ -53,7 +53,7 @@ def flat_inputs(clip):
 
 
 def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scale=False,
-             optimize_mano=True, init_steps=0, pin_step=5, hands=("right",)):
+             optimize_mano=True, init_steps=0, pin_step=5, hands=("right",), inter_type="centroid"):
     shims.set_rend_size(size)
     clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj,
                            silhouette_fn=sil_fn, hand_verts_fn=hand_fn, hands=hands)
@@ -64,6 +64,7 @@ def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scal
     rec["meta_optimize_mano"] = np.int64(optimize_mano)
     rec["meta_lr"] = np.float64(1e-2)
     rec["meta_hand_sides"] = np.array(list(hands))
+    rec["meta_inter_type"] = np.array(inter_type)
     for k, v in weights.items():
         rec["lw_" + k[3:]] = np.float64(v)
 
@@ -79,7 +80,7 @@ def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scal
                         clip["objvertices"], clip["objfaces"])
     fresh = ref_homan.HOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1,
                             hand_proj_mode="persp", optimize_mano=optimize_mano, optimize_mano_beta=True,
-                            optimize_object_scale=optimize_object_scale, image_size=size, **kw)
+                            optimize_object_scale=optimize_object_scale, image_size=size, inter_type=inter_type, **kw)
     loss_dict, metric_dict = fresh(loss_weights=weights)
     total = sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict)
     total.backward()
@@ -94,6 +95,14 @@ def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scal
     rec["verts_object"] = vo.detach().numpy()
     rec["verts_hand"] = vh.detach().numpy()
     rec["state_dict_keys"] = np.array(sorted(fresh.state_dict().keys()))
+    if inter_type != "centroid":
+        # the reference's loop (jointopt.optimize_hand_object) builds its HOMan with the default interaction term: a non-default
+        # `inter_type` is pinned by the forward / backward of the model alone
+        out_dir = os.environ.get("HOMAN_GOLDEN_OUT", OUT)
+        os.makedirs(out_dir, exist_ok=True)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
+        print(name, "fwd only, loss_inter", rec["fwd_loss_inter"])
+        return
 
     # trajectory with the reference's own loop
     model, evo, _ = ref_jointopt.optimize_hand_object(
@@ -157,6 +166,9 @@ def main():
     # lossutils.py:51-64,114-131 (collision over three meshes, contact per hand) and the left MANO path are pinned
     _maybe("ref_step2_twohands_cube_b4_s64", seed=4, frames=4, size=64, obj="cube",
              weights=dict(synth.STEP2_LOSS_WEIGHTS), steps=8, hands=("right", "left"))
+    # non-default interaction term of the model (homan/losses.py:219-221): smallest squared vertex distance
+    _maybe("ref_step2_intermin_cube_b4_s64", seed=1, frames=4, size=64, obj="cube",
+             weights=dict(synth.STEP2_LOSS_WEIGHTS), steps=1, inter_type="min")
     _maybe("ref_step1_lefthand_cube_b4_s64", seed=6, frames=4, size=64, obj="cube",
              weights=dict(synth.STEP1_LOSS_WEIGHTS), steps=8, hands=("left",))
     _maybe("ref_step1_twohands_cube_b4_s64", seed=5, frames=4, size=64, obj="cube",
