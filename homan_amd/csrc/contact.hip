@@ -112,11 +112,15 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ 
 __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_min(const float* __restrict__ vh, const float* __restrict__ vo, int B,
                                                            int Vh, int Vo, float* __restrict__ blockmin,
                                                            unsigned int* counter, float* __restrict__ metric_out,
-                                                           int clip_len, int out_stride, const int* __restrict__ obj_order)
+                                                           int clip_len, int out_stride, const int* __restrict__ obj_order,
+                                                           const float* __restrict__ sph_mesh,
+                                                           const float* __restrict__ obj_rot6d,
+                                                           const float* __restrict__ obj_trans,
+                                                           const float* __restrict__ obj_scale)
 {
     HM_LATENCY_KERNEL();
     nn_min_body(vh, vo, B, Vh, Vo, blockmin, counter, metric_out, clip_len, out_stride, obj_order, blockIdx.x, blockIdx.y,
-                gridDim.x);
+                gridDim.x, sph_mesh, obj_rot6d, obj_trans, obj_scale);
 }
 
 // Contact loss, hand side.  grid (B): value, d/d hand vertex (= minus the pull on the matched object vertex),
@@ -186,10 +190,38 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_obj(const int* __restric
 extern "C" {
 // workspace: reuse hm_reduce_workspace_bytes() layout (partials + counter), one slice per clip; needs
 // clip frames * ceil(Vh/128) <= 512 partial floats.
+int hm_nn_fwd_rigid_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
+                          float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
+                          const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
+                          hipStream_t stream);
+// Scheduling hint, no effect on results: bytes of unused dynamic LDS added to the metric-only search launches.  The search is
+// a chain of dependent loads in small workgroups (24 registers, 4.6 KB of LDS): eight of them fit on a CU and then hold ALL
+// its wave slots while they wait - in an 8-clip batch (1680 workgroups) the line expansion of the silhouette chain, which
+// runs next to it, took 250 us instead of 170.  64 KB of ballast = two search workgroups per CU.  Process-wide, read when
+// the search is called (or captured).  Returns the previous value; bytes < 0 only queries.
+static int g_nn_lds_pad = 0;
+int hm_tune_nn_lds_pad(int bytes)
+{
+    const int prev = g_nn_lds_pad;
+    if (bytes >= 0) g_nn_lds_pad = bytes;
+    return prev;
+}
 int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
                     float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
                     hipStream_t stream)
 {
+    return hm_nn_fwd_rigid_clips(verts_hand, verts_obj, B, Vh, Vo, nn_idx, nn_d2, metric_out, workspace, clip_len, out_stride,
+                                 obj_order, nullptr, nullptr, nullptr, nullptr, stream);
+}
+// metric-only calls on a RIGID object: obj_spheres (B, ceil(Vo/64), 4) = centre + radius, in MESH space, of the groups of 64
+// vertices taken in `obj_order`; obj_rot6d (B,3,2) / obj_trans (B,3) / obj_scale (one per clip, used as |s|) = the transform
+// that produced verts_obj (hm_rigid_fwd with abs_scale).  Scheduling data only: the result is the exact minimum.
+int hm_nn_fwd_rigid_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
+                          float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
+                          const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
+                          hipStream_t stream)
+{
+    HM_CHECK_ARG(!obj_spheres || (obj_rot6d && obj_trans && obj_scale));
     // nn_idx == nn_d2 == NULL: metric only (exact, with pruning of the object-vertex groups that cannot hold the minimum)
     HM_CHECK_ARG(verts_hand && verts_obj && metric_out && workspace && B > 0 && Vh > 0 && Vo > 0 && (!nn_idx == !nn_d2));
     HM_CHECK_ARG(HM_CLIP_LEN_OK(B, clip_len));
@@ -197,8 +229,9 @@ int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int 
     const int Bc = clip_len ? clip_len : B;
     if ((long)Bc * nchunk > 512) return HM_ERR_UNSUPPORTED;
     if (!nn_idx && Vo <= 64 * NN_MAX_GROUPS)
-        hipLaunchKernelGGL(k_nn_min, dim3(nchunk, B), dim3(64 * NN_WAVES), 0, stream, verts_hand, verts_obj, B, Vh, Vo,
-                           (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out, Bc, out_stride, obj_order);
+        hipLaunchKernelGGL(k_nn_min, dim3(nchunk, B), dim3(64 * NN_WAVES), g_nn_lds_pad, stream, verts_hand, verts_obj, B, Vh, Vo,
+                           (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out, Bc, out_stride, obj_order,
+                           obj_spheres, obj_rot6d, obj_trans, obj_scale);
     else {
         if (!nn_idx) return HM_ERR_UNSUPPORTED;     // metric-only search: <= 4096 object vertices
         hipLaunchKernelGGL(k_nn, dim3(nchunk, B), dim3(64 * NN_WAVES), 0, stream, verts_hand, verts_obj, B, Vh, Vo, nn_idx,

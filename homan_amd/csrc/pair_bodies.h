@@ -150,7 +150,11 @@ __device__ __forceinline__ void inter_body(const float* __restrict__ vh, const f
 __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const float* __restrict__ vo, int B, int Vh, int Vo,
                                             float* __restrict__ blockmin, unsigned int* counter,
                                             float* __restrict__ metric_out, int clip_len, int out_stride,
-                                            const int* __restrict__ obj_order, int bx, int by, int gdx)
+                                            const int* __restrict__ obj_order, int bx, int by, int gdx,
+                                            const float* __restrict__ sph_mesh = nullptr,
+                                            const float* __restrict__ obj_rot6d = nullptr,
+                                            const float* __restrict__ obj_trans = nullptr,
+                                            const float* __restrict__ obj_scale = nullptr)
 {
     __shared__ float s_sph[NN_MAX_GROUPS][4];
     __shared__ float s_lb[NN_MAX_GROUPS];
@@ -171,16 +175,36 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
         if (hv[u]) { const float* p = vh + ((long)b * Vh + i) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2]; }
     }
     if (threadIdx.x == 0) { s_ub = 0x7f7fffffu; s_n = 0; }
+    if (sph_mesh && (int)threadIdx.x < ng) {
+        // the object is rigid: the bounding spheres of its groups are a table in MESH space (built once by the caller), and a
+        // lane per group carries centre and radius into this frame's camera space - instead of every workgroup loading and
+        // reducing all the groups' vertices again (in an 8-clip batch that was 15 M wave-instructions per launch, next to the
+        // line expansion it shares the GPU with)
+        float R[9];
+        rot6d_to_mat(obj_rot6d + b * 6, R);
+        const float sc = fabsf(obj_scale[b / clip_len]);
+        const float* c = sph_mesh + ((long)b * ng + threadIdx.x) * 4;
+        const float x = sc * c[0], y = sc * c[1], z = sc * c[2];
+        const float* t = obj_trans + b * 3;
+        s_sph[threadIdx.x][0] = x * R[0] + y * R[3] + z * R[6] + t[0];
+        s_sph[threadIdx.x][1] = x * R[1] + y * R[4] + z * R[7] + t[1];
+        s_sph[threadIdx.x][2] = x * R[2] + y * R[5] + z * R[8] + t[2];
+        s_sph[threadIdx.x][3] = sc * c[3] * (1.0f + 1e-4f) + 1e-6f;      // (slack for the rounding of both transforms)
+    }
     __syncthreads();
     // 1 + 2: spheres and bounds of this wave's groups
     for (int g = q; g < ng; g += NN_WAVES) {
-        const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
-        float ox = 0.f, oy = 0.f, oz = 0.f;
-        if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
-        const float inv_n = 1.0f / (float)n;
-        const float cx = hm_wave_sum(ox) * inv_n, cy = hm_wave_sum(oy) * inv_n, cz = hm_wave_sum(oz) * inv_n;
-        const float ex = ox - cx, ey = oy - cy, ez = oz - cz;
-        const float rg = sqrtf(hm_wave_max(lane < n ? ex * ex + ey * ey + ez * ez : 0.f)) * (1.0f + 1e-5f);
+        float cx, cy, cz, rg;
+        if (sph_mesh) { cx = s_sph[g][0]; cy = s_sph[g][1]; cz = s_sph[g][2]; rg = s_sph[g][3]; }
+        else {
+            const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
+            float ox = 0.f, oy = 0.f, oz = 0.f;
+            if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
+            const float inv_n = 1.0f / (float)n;
+            cx = hm_wave_sum(ox) * inv_n; cy = hm_wave_sum(oy) * inv_n; cz = hm_wave_sum(oz) * inv_n;
+            const float ex = ox - cx, ey = oy - cy, ez = oz - cz;
+            rg = sqrtf(hm_wave_max(lane < n ? ex * ex + ey * ey + ez * ez : 0.f)) * (1.0f + 1e-5f);
+        }
         float dc = 3.4e38f;
 #pragma unroll
         for (int u = 0; u < 2; ++u)

@@ -339,6 +339,23 @@ class FusedStepper:
         self.nn_idx = torch.zeros(B, Vh, dtype=torch.int32, device=dev)
         self.nn_d2 = f(B, Vh)
         self.obj_order = _morton_order(m.verts_object_og[0]).to(dev)      # spatial sort of the rigid mesh (metric-only search)
+        # bounding spheres, in MESH space, of the groups of 64 vertices in that order, per frame (a clip's frames share one mesh,
+        # the clips of a batch need not): centre = mean, radius = farthest vertex.  The search carries them into camera space
+        # with the frame's rigid transform instead of reducing the transformed vertices of every group in every workgroup.
+        with torch.no_grad():
+            ng = (Vo + 63) // 64
+            vs = m.verts_object_og.detach()[:, self.obj_order.long()]                       # (B, Vo, 3) in group order
+            pad = ng * 64 - Vo
+            valid = torch.ones(Vo + pad, dtype=torch.bool, device=dev)
+            if pad:
+                vs = torch.cat([vs, vs[:, -1:].expand(-1, pad, -1)], 1)           # (repeats of a real vertex change nothing
+                valid[Vo:] = False                                                #  but the mean: masked out of it below)
+            grp = vs.reshape(B, ng, 64, 3)
+            wgt = valid.reshape(1, ng, 64, 1).float()
+            ctr = (grp * wgt).sum(2) / wgt.sum(2)
+            rad = ((grp - ctr[:, :, None]) ** 2).sum(-1).sqrt().amax(2)
+            self.obj_spheres = torch.cat([ctr, rad[..., None]], -1).contiguous()             # (B, ng, 4)
+        self.nn_spheres = os.environ.get("HOMAN_NN_SPHERES", "1") != "0"
         self.pooled = f(B, m.sil_ctx.S, m.sil_ctx.S)
         self.up_sil, self.up_inter = torch.tensor([w["loss_sil_obj"]], device=dev), torch.tensor([w["loss_inter"]], device=dev)
         if self.on["depth"]:
@@ -401,6 +418,12 @@ class FusedStepper:
             pad = os.environ.get("HOMAN_RASTER_PAD")
             pad = int(pad) if pad is not None else (8192 if (self.on["col"] or self.on["con"]) and C == 1 else 0)
             prev_pad = _lib.lib().hm_tune_raster_lds_pad(pad)
+            # and for the metric-only search of a clip batch: its 1680 small, latency-bound workgroups otherwise take every wave
+            # slot of the CUs next to the line expansion (lines 250 -> 226 us, iteration -4.4 % at 3 search workgroups per CU;
+            # 2 per CU make the search itself the tail)
+            nn_pad = os.environ.get("HOMAN_NN_PAD")
+            nn_pad = int(nn_pad) if nn_pad is not None else (40960 if C > 1 and not self.on["con"] else 0)
+            prev_nn_pad = _lib.lib().hm_tune_nn_lds_pad(nn_pad)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.cap_stream):
                 self.forward_backward(log=not self.log_in_adam)
@@ -413,6 +436,7 @@ class FusedStepper:
                     self.opt.step(zero_grad=False)
             _lib.lib().hm_tune_sweep_blocks(prev)
             _lib.lib().hm_tune_raster_lds_pad(prev_pad)
+            _lib.lib().hm_tune_nn_lds_pad(prev_nn_pad)
 
     # ---- shared object scale (BASELINE cfg5): C local replicas of one scalar, kept identical on every rank
     def _dist_on(self):
@@ -575,9 +599,10 @@ class FusedStepper:
                 sx = stream_obj.cuda_stream
                 if (on["con"] or on["inter"]) and not nn_fused:
                     # (without the contact term only the logged distance is needed: metric-only search)
-                    ck(L.hm_nn_fwd_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if on["con"] else None,
-                                         P(self.nn_d2) if on["con"] else None, self._slot("handobj_maxdist"), rws, CL, NS,
-                                         P(self.obj_order), sx), "nn")
+                    ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if on["con"] else None,
+                                               P(self.nn_d2) if on["con"] else None, self._slot("handobj_maxdist"), rws, CL, NS,
+                                               P(self.obj_order), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
+                                               P(m.translations_object), P(m.int_scales_object), sx), "nn")
                 if on["con"]:
                     ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
                                               P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws, CL, NS, sx),
@@ -599,7 +624,8 @@ class FusedStepper:
                                              self._slot("loss_smooth_obj") if sm_here else None, P(self.reduce_ws_d.buf),
                                              *(ht_args if ht_fused else (None, 0.0, None, None, None, None, None, 0, None, None,
                                                                          None, None, None, None, None, None)),
-                                             P(self.reduce_ws_e.buf), CL, NS, sb), "pair terms")
+                                             P(self.reduce_ws_e.buf), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
+                                             P(m.translations_object), P(m.int_scales_object), CL, NS, sb), "pair terms")
             elif on["inter"]:
                 ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
                                         float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws_b, CL,
@@ -689,6 +715,21 @@ class FusedStepper:
                 # here, ranks in _reduce_shared_scale_grad
                 ck(L.hm_sum_small_clips(P(m.int_scales_object.grad), C, 1.0, None, 0.0, P(self.g_shared), 1, sa),
                    "shared scale grad")
+
+    def sil_chain_only(self):
+        """Measurement helper (tools/bench_sil_kernels.py --chain): just the silhouette chain of an iteration - face setup,
+        raster, lines, sweeps - on the current stream, with nothing on any other stream."""
+        m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
+        sctx, B, Vo, CL, NS = m.sil_ctx, self.B, self.Vo, self.clip_len, self.NS
+        sa = torch.cuda.current_stream().cuda_stream
+        ck(L.hm_sil_fwd_clips(P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S,
+                              1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
+                              None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
+                              P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, P(self.vo),
+                              sa), "sil_fwd")
+        ck(L.hm_sil_bwd_clips(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS, 2,
+                              P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items), P(sctx.face_order),
+                              None, None, P(sctx.workspace), CL, None, NS, sa), "sil_bwd")
 
     def _adam_log(self):
         if not self.log_in_adam:

@@ -22,6 +22,7 @@ _SIGNATURES = {
     "hm_sil_hint_near_winding": (_I, [_VP, _I, _VP]),
     "hm_tune_sweep_blocks": (_I, [_I]),
     "hm_tune_raster_lds_pad": (_I, [_I]),
+    "hm_tune_nn_lds_pad": (_I, [_I]),
     "hm_debug_sweep_caps": (_I, [_I]),
     "hm_shade_rgb": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _VP, _F, _F, _VP, _VP, _VP, _VP]),
     "hm_rigid_bwd_sil": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
@@ -92,9 +93,10 @@ _SIGNATURES = {
                                      _VP, _VP, _VP, _I, _I, _VP]),
     "hm_pair_terms_fwd_clips": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP,
                                      _VP, _F, _VP, _VP, _VP, _VP, _VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
-                                     _I, _I, _VP]),
+                                     _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_inter_fwd_clips": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_nn_fwd_clips": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
+    "hm_nn_fwd_rigid_clips": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_contact_fwd_clips": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_collision_fwd_clips": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_log_total_clips": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _VP]),

@@ -167,6 +167,9 @@ int hm_tune_sweep_blocks(int blocks);
  * rasteriser workgroups instead of 6, which leaves registers / LDS for the kernels of the caller's other stream).  Process-wide,
  * read when hm_sil_fwd is called (or captured).  Returns the previous value; bytes < 0 only queries. */
 int hm_tune_raster_lds_pad(int bytes);
+/* Same for the metric-only nearest-vertex search (small latency-bound workgroups that otherwise take every wave slot of a CU
+ * next to the kernel they overlap): 65536 = two search workgroups per CU. */
+int hm_tune_nn_lds_pad(int bytes);
 /* test hook: cap > 0 shrinks the capacity tables of the sweep work list so that small inputs take the beyond-capacity
  * paths (binary search for a unit's first face, atomically accumulated faces); 0 restores the defaults.  Returns the
  * previous value. */
@@ -349,12 +352,22 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                             float* ht_unit_smooth, float* ht_out_smooth1, const float* ht_pca, long ht_npca,
                             const float* ht_s_obj, const float* ht_m_obj, const float* ht_s_hand, const float* ht_m_hand,
                             float* ht_g_pca, float* ht_g_sobj, float* ht_g_shand, float* ht_out_priors3, void* ws_hand,
+                            const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
                             int clip_len, int out_stride, hipStream_t stream);
 /* obj_order (Vo) optional, metric-only calls: a permutation of the object vertices, visited in that order (a spatial sort of
  * the rigid mesh makes 64 consecutive vertices a compact patch: scheduling only, the result is the exact minimum) */
 int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
                     float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
                     hipStream_t stream);
+/* The metric-only search on a RIGID object: obj_spheres (B, ceil(Vo/64), 4) = centre + radius, in MESH space, of the groups of
+ * 64 vertices taken in `obj_order` (built once by the caller); obj_rot6d (B,3,2) / obj_trans (B,3) / obj_scale (one per clip,
+ * used as |s|) = the transform that produced verts_obj (hm_rigid_fwd with abs_scale).  A lane per group carries its sphere
+ * into camera space instead of every workgroup reducing all the groups' vertices again.  Scheduling data only: the result is
+ * the exact minimum (the spheres only decide which groups are scanned).  All four NULL = hm_nn_fwd_clips. */
+int hm_nn_fwd_rigid_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
+                          float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
+                          const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
+                          hipStream_t stream);
 int hm_contact_fwd_clips(const float* verts_hand, const float* verts_obj, const int* nn_idx, int B, int Vh, int Vo,
                          float thresh, float* g_hand, float* g_obj, float* out1, void* workspace, int clip_len,
                          int out_stride, hipStream_t stream);

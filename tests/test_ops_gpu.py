@@ -253,8 +253,8 @@ def test_pair_terms_launch_equals_its_four_entry_points():
         if fused:
             hl.check(L.hm_pair_terms_fwd_clips(P(vh), P(vo), P(camintr), B, Vh, Vo, slot(6), P(order), P(ws[0].buf),
                                                c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(rec), slot(7),
-                                               P(ws[1].buf), P(u_smo), slot(8), P(ws[2].buf), *ht, P(ws[3].buf), CL, stride,
-                                               stream), "pair terms")
+                                               P(ws[1].buf), P(u_smo), slot(8), P(ws[2].buf), *ht, P(ws[3].buf), None, None, None, None,
+                                               CL, stride, stream), "pair terms")
         else:
             hl.check(L.hm_nn_fwd_clips(P(vh), P(vo), B, Vh, Vo, None, None, slot(6), P(ws[0].buf), CL, stride, P(order), stream),
                      "nn")
@@ -306,3 +306,43 @@ def test_adam_step_with_log_row_equals_two_launches():
     assert int(a[3][0]) == steps and a[2].abs().sum() > 0
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+def test_metric_search_with_rigid_group_spheres_is_exact():
+    """hm_nn_fwd_rigid_clips: bounding spheres of the object's vertex groups carried from MESH space into every frame by the
+    rigid transform only decide which groups are scanned - the metric is the same float as without them, and the true
+    max-over-frames of the min hand-object vertex distance (float64 brute force)."""
+    from homan_amd import lib as hl
+    from homan_amd import ops
+    from homan_amd.clipbatch import ClipReduceWorkspace
+    from homan_amd.jointopt import _morton_order
+    L, P = hl.lib(), hl.ptr
+    g = torch.Generator().manual_seed(3)
+    C, CL, Vh, Vo = 2, 3, 778, 1502
+    B = C * CL
+    mesh = (torch.randn(1, Vo, 3, generator=g) * torch.tensor([0.03, 0.03, 0.08])).repeat(B, 1, 1).to(DEV)
+    rot6d = torch.randn(B, 3, 2, generator=g).to(DEV)
+    trans = (torch.randn(B, 1, 3, generator=g) * 0.02 + torch.tensor([0.0, 0.0, 0.6])).to(DEV)
+    scale = torch.tensor([1.3, -0.8], device=DEV)                      # one per clip, used as |s|
+    vo = torch.cat([ops.rigid_transform(mesh[c * CL:(c + 1) * CL], rot6d[c * CL:(c + 1) * CL], trans[c * CL:(c + 1) * CL],
+                                        scale[c:c + 1], abs_scale=True)[0] for c in range(C)]).contiguous()
+    vh = (torch.randn(B, Vh, 3, generator=g) * 0.04 + torch.tensor([0.09, 0.0, 0.6])).to(DEV)
+    order = _morton_order(mesh[0]).to(DEV)
+    ng = (Vo + 63) // 64
+    vs = mesh[:, order.long()]
+    vs = torch.cat([vs, vs[:, -1:].expand(-1, ng * 64 - Vo, -1)], 1).reshape(B, ng, 64, 3)
+    ctr = torch.stack([vs[:, k, :(64 if k < ng - 1 else Vo - 64 * (ng - 1))].mean(1) for k in range(ng)], 1)
+    rad = ((vs - ctr[:, :, None]) ** 2).sum(-1).sqrt().amax(2)
+    spheres = torch.cat([ctr, rad[..., None]], -1).contiguous()
+    outs = []
+    for sph in (None, spheres):
+        out = torch.zeros(C, 5, device=DEV)
+        ws = ClipReduceWorkspace(DEV, C)
+        hl.check(L.hm_nn_fwd_rigid_clips(P(vh), P(vo), B, Vh, Vo, None, None, P(out), P(ws.buf), CL, 5, P(order),
+                                         P(sph) if sph is not None else None, P(rot6d), P(trans.reshape(B, 3).contiguous()),
+                                         P(scale), hl.stream()), "nn")
+        torch.cuda.synchronize()
+        outs.append(out[:, 0].clone())
+    assert torch.equal(outs[0], outs[1])
+    d = torch.cdist(vh.double(), vo.double()).amin((1, 2)).reshape(C, CL).amax(1)
+    np.testing.assert_allclose(outs[1].cpu().numpy(), d.cpu().numpy(), rtol=1e-5)

@@ -22,6 +22,10 @@ def main():
     ap.add_argument("--object-scale", action="store_true", help="optimize_object_scale=True (one free scale per clip)")
     ap.add_argument("--shared-scale", action="store_true", help="ONE scale tied across the clips (BASELINE cfg5)")
     ap.add_argument("--no-graph", action="store_true", help="issue the iteration launch by launch instead of replaying a hipGraph")
+    ap.add_argument("--cfg1", action="store_true", help="silhouette + 2-D keypoint terms only (no pair-wise losses on the side stream)")
+    ap.add_argument("--lw", action="append", default=[], help="override a loss weight, e.g. --lw lw_inter=0")
+    ap.add_argument("--stamps", type=int, default=0, help="after the timed region: this many more replays with in-kernel "
+                    "timestamps -> durations of raster / lines / sweep inside the graph")
     args = ap.parse_args()
     import torch
     from homan_amd import lib as hlib
@@ -30,7 +34,10 @@ def main():
     from homan_amd.mano_assets import synthetic_mano
     mano = synthetic_mano(0)
     sil_fn, hand_fn = synth.hip_clip_fns(mano)
-    lw = dict(synth.STEP2_LOSS_WEIGHTS if args.step2 else synth.STEP1_LOSS_WEIGHTS)
+    lw = dict(synth.CFG1_LOSS_WEIGHTS if args.cfg1 else synth.STEP2_LOSS_WEIGHTS if args.step2 else synth.STEP1_LOSS_WEIGHTS)
+    for kv in args.lw:
+        k, v = kv.split("=")
+        lw[k] = float(v)
     models = []
     for i in range(args.clips):
         c = synth.make_clip(seed=i, frames=args.frames, rend_size=args.size, image_size=args.size, obj="bottle",
@@ -50,9 +57,27 @@ def main():
     st.run(args.steps)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    stamps = None
+    if args.stamps:
+        import ctypes
+        L = hlib.lib()
+        sctx = st.model.sil_ctx
+        ws, dims = hlib.ptr(sctx.workspace), (sctx.B, sctx.V, sctx.F, sctx.S)
+        us3, acc = (ctypes.c_float * 3)(), [0.0, 0.0, 0.0]
+        saved = torch.zeros(args.stamps, L.hm_sil_timestamps_bytes(*dims) // 8, dtype=torch.int64, device="cuda")
+        for i in range(args.stamps):
+            hlib.check(L.hm_sil_timestamps(ws, *dims, 1, hlib.stream()), "ts")
+            st.run(1)
+            hlib.check(L.hm_sil_timestamps_save(ws, *dims, saved[i].data_ptr(), hlib.stream()), "save")
+        hlib.check(L.hm_sil_timestamps(ws, *dims, 0, hlib.stream()), "ts")
+        for i in range(args.stamps):
+            hlib.check(L.hm_sil_timestamps_read(None, *dims, saved[i].data_ptr(), ctypes.cast(us3, ctypes.c_void_p), hlib.stream()), "read")
+            for k in range(3):
+                acc[k] += us3[k] / args.stamps
+        stamps = dict(raster_us=round(acc[0], 1), lines_us=round(acc[1], 1), sweep_us=round(acc[2], 1))
     evo = st.loss_evolution(total)
     evo = evo if isinstance(evo, list) else [evo]
-    print(json.dumps(dict(clips=args.clips, steps=args.steps, step2=args.step2, frames=args.frames, rend_size=args.size,
+    print(json.dumps(dict(in_graph_us=stamps, clips=args.clips, steps=args.steps, step2=args.step2, frames=args.frames, rend_size=args.size,
                           faces=int(models[0].faces_object.shape[1]), graph=not args.no_graph, ms_per_round=1e3 * el / args.steps,
                           its_per_s=args.clips * args.steps / el, us_per_clip_iteration=1e6 * el / args.steps / args.clips,
                           first_loss=[e["loss"][0] for e in evo], final_loss=[e["loss"][-1] for e in evo])))

@@ -19,6 +19,9 @@ def main():
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--near", type=int, default=-1, help="force the near-winding hint (0/1); -1: as calibrated")
+    ap.add_argument("--chain", action="store_true", help="also time the three kernels inside the setup -> raster -> lines -> "
+                    "sweeps SEQUENCE of an iteration (in-kernel timestamps), with nothing on any other stream: their cost "
+                    "with the data flow of the loop but without its hand-side stream")
     args = ap.parse_args()
     import torch
     from homan_amd import lib as hlib
@@ -54,7 +57,24 @@ def main():
         hlib.ptr(m.ref_mask_object), hlib.ptr(ksum), hlib.ptr(pooled), hlib.ptr(out2), hlib.ptr(sctx.work_order),
         hlib.ptr(sctx.adj_off), hlib.ptr(sctx.adj_items), None, hlib.ptr(one), hlib.ptr(gv), hlib.ptr(sctx.workspace),
         args.reps, ms.data_ptr(), hlib.stream()), "hm_bench_sil_kernels")
-    print(json.dumps(dict(clips=args.clips, frames=B, near_calibrated=getattr(sctx, "near_winding", None), near_forced=args.near, raster_us=1e3 * ms[0].item(), sweep_us=1e3 * ms[1].item(),
+    chain = None
+    if args.chain:
+        import ctypes
+        L = hlib.lib()
+        ws, dims = hlib.ptr(sctx.workspace), (sctx.B, sctx.V, sctx.F, sctx.S)
+        us3, acc = (ctypes.c_float * 3)(), [0.0, 0.0, 0.0]
+        saved = torch.zeros(args.reps, L.hm_sil_timestamps_bytes(*dims) // 8, dtype=torch.int64, device="cuda")
+        for i in range(args.reps):
+            hlib.check(L.hm_sil_timestamps(ws, *dims, 1, hlib.stream()), "ts")
+            st.sil_chain_only()
+            hlib.check(L.hm_sil_timestamps_save(ws, *dims, saved[i].data_ptr(), hlib.stream()), "save")
+        hlib.check(L.hm_sil_timestamps(ws, *dims, 0, hlib.stream()), "ts")
+        for i in range(args.reps):
+            hlib.check(L.hm_sil_timestamps_read(None, *dims, saved[i].data_ptr(), ctypes.cast(us3, ctypes.c_void_p), hlib.stream()), "read")
+            for k in range(3):
+                acc[k] += us3[k] / args.reps
+        chain = dict(raster_us=acc[0], lines_us=acc[1], sweep_us=acc[2])
+    print(json.dumps(dict(chain=chain, clips=args.clips, frames=B, near_calibrated=getattr(sctx, "near_winding", None), near_forced=args.near, raster_us=1e3 * ms[0].item(), sweep_us=1e3 * ms[1].item(),
                           lines_us=1e3 * ms[2].item(), per_clip_us=[1e3 * ms[i].item() / args.clips for i in range(3)])))
 
 
