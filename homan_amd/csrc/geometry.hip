@@ -265,6 +265,7 @@ __global__ void k_sum_small(const float* __restrict__ parts, int n, float w0, co
     if (threadIdx.x == 0) out[c] = w0 * a + (extra ? w1 * extra[c] : 0.f);
 }
 
+int g_hm_lds_pad[HM_PAD_FAMILIES] = {0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" {
 int hm_lincomb4(const float* a0, float w0, const float* a1, float w1, const float* a2, float w2, const float* a3,
                 float w3, long n, float* out, hipStream_t stream)
@@ -297,6 +298,15 @@ int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, cons
 {
     return hm_rigid_fwd_clips(mesh, rot6d, trans, scale, abs_scale, N, V, rotmat, verts, 0, stream);
 }
+// see hm_common.h: family 0 MANO forward, 1 MANO backward, 2 smoothness / interaction / hand-terms launches, 3 the fused
+// pair-terms launch, 4 rigid backward.  Process-wide, read at launch (or capture).  Returns the previous value; bytes < 0 queries.
+int hm_tune_lds_pad(int family, int bytes)
+{
+    if (family < 0 || family >= HM_PAD_FAMILIES) return -1;
+    const int prev = g_hm_lds_pad[family];
+    if (bytes >= 0) g_hm_lds_pad[family] = bytes;
+    return prev;
+}
 #define RIGID_MAX_CHUNKS 16
 size_t hm_rigid_workspace_bytes(int N) { return (((size_t)N * 4 + 255) & ~(size_t)255) + (size_t)N * RIGID_MAX_CHUNKS * 16 * 4; }
 static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
@@ -316,7 +326,7 @@ static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* 
     const int chunks = workspace ? min(RIGID_MAX_CHUNKS, hm_cdiv(V, 4 * threads)) : 1;
     unsigned int* cnt = (unsigned int*)workspace;
     float* partials = workspace ? (float*)((char*)workspace + (((size_t)N * 4 + 255) & ~(size_t)255)) : nullptr;
-    hipLaunchKernelGGL(k_rigid_bwd, dim3(N, chunks), dim3(threads), 0, stream, mesh, rot6d, scale, abs_scale, t, sil, g_rigid,
+    hipLaunchKernelGGL(k_rigid_bwd, dim3(N, chunks), dim3(threads), g_hm_lds_pad[HM_PAD_RIGID_BWD], stream, mesh, rot6d, scale, abs_scale, t, sil, g_rigid,
                        g_frame, frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, partials, cnt,
                        clip_len ? clip_len : N);
     return hm_launch_status();

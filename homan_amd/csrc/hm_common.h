@@ -29,6 +29,12 @@
 #define HM_CHAIN_KERNEL()
 #endif
 
+// LDS ballast per kernel family (hm_tune_lds_pad, geometry.hip): unused dynamic LDS that caps how many workgroups of a small,
+// latency-bound kernel fit on a CU next to the heavy kernel it overlaps (they would otherwise hold every wave slot while
+// they wait on memory).  Scheduling only.
+enum { HM_PAD_MANO_FWD = 0, HM_PAD_MANO_BWD = 1, HM_PAD_SMALL_LOSSES = 2, HM_PAD_PAIR_TERMS = 3, HM_PAD_RIGID_BWD = 4, HM_PAD_FAMILIES = 8 };
+extern int g_hm_lds_pad[HM_PAD_FAMILIES];
+
 #define HM_CHECK_ARG(cond) \
     do {                   \
         if (!(cond)) return HM_ERR_BAD_ARG; \

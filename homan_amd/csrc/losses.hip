@@ -191,7 +191,7 @@ int hm_smooth_fwd_clips(const float* verts, int N, int V, int hand_nb, float* un
     HM_CHECK_ARG(verts && unit_grad && out1 && workspace && N > 0 && V > 0 && hand_nb > 0 && HM_CLIP_LEN_OK(N, clip_len));
     const int Nc = clip_frames(N, clip_len);
     const int nblk = min(HM_RED_MAX_BLOCKS, hm_cdiv((long)Nc * V * 3, RED_THREADS * 4));
-    hipLaunchKernelGGL(k_smooth, dim3(nblk, clip_count(N, clip_len)), dim3(RED_THREADS), 0, stream, verts, Nc, V, hand_nb,
+    hipLaunchKernelGGL(k_smooth, dim3(nblk, clip_count(N, clip_len)), dim3(RED_THREADS), g_hm_lds_pad[HM_PAD_SMALL_LOSSES], stream, verts, Nc, V, hand_nb,
                        unit_grad, (float*)workspace, ws_counter(workspace), out1, out_stride);
     return hm_launch_status();
 }
@@ -228,7 +228,7 @@ int hm_hand_terms_fwd_clips(const float* verts, const float* camintr, int hand_n
     HM_CHECK_ARG(!pca || (npca > 0 && s_obj && m_obj && s_hand && m_hand && g_pca && g_sobj && g_shand && out_priors3));
     const int Nc = clip_frames(N, clip_len);
     const int nblk = min(170, hm_cdiv((long)Nc * V * 3, RED_THREADS * 2));     // 3 partial floats per block, 512 in all
-    hipLaunchKernelGGL(k_hand_terms, dim3(nblk, clip_count(N, clip_len)), dim3(RED_THREADS), 0, stream, verts, camintr,
+    hipLaunchKernelGGL(k_hand_terms, dim3(nblk, clip_count(N, clip_len)), dim3(RED_THREADS), g_hm_lds_pad[HM_PAD_SMALL_LOSSES], stream, verts, camintr,
                        hand_nb, ref2d, image_size, Nc, V, unit_v2d, out_v2d2, unit_smooth, out_smooth1, pca, npca, s_obj,
                        m_obj, s_hand, m_hand, g_pca, g_sobj, g_shand, out_priors3, (float*)workspace,
                        ws_counter(workspace), out_stride);
@@ -250,7 +250,7 @@ int hm_inter_fwd_clips(const float* verts_hand, const float* verts_obj, const fl
 {
     HM_CHECK_ARG(verts_hand && verts_obj && camintr && frame_rec && out1 && workspace && B > 0 && Vh > 0 && Vo > 0);
     HM_CHECK_ARG(HM_CLIP_LEN_OK(B, clip_len));
-    hipLaunchKernelGGL(k_inter, dim3(B), dim3(RED_THREADS), 0, stream, verts_hand, verts_obj, camintr, B, Vh, Vo,
+    hipLaunchKernelGGL(k_inter, dim3(B), dim3(RED_THREADS), g_hm_lds_pad[HM_PAD_SMALL_LOSSES], stream, verts_hand, verts_obj, camintr, B, Vh, Vo,
                        expansion, zthresh, frame_rec, ws_counter(workspace), out1, clip_frames(B, clip_len), out_stride);
     return hm_launch_status();
 }

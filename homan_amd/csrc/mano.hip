@@ -514,7 +514,7 @@ int hm_mano_fwd_clips(const void* const* model, const float* pca, int pca_dim, c
     HM_CHECK_ARG(!verts_world || (rigid_rot6d && rigid_trans && rigid_scale));
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
-    hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, trans, B, verts,
+    hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, B), dim3(256), g_hm_lds_pad[HM_PAD_MANO_FWD], stream, m, pca, pca_dim, rot, betas, trans, B, verts,
                        joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world, state, clip_len ? clip_len : B);
     return hm_launch_status();
 }
@@ -539,7 +539,7 @@ int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const f
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
     unsigned int* cnt = (unsigned int*)workspace;
     float* partials = (float*)((char*)workspace + 256 + (((size_t)B * 4 + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(k_mano_bwd, dim3(MANO_NCH64, B), dim3(256), 0, stream, m, pca, pca_dim, rot, betas, g_verts, B, state,
+    hipLaunchKernelGGL(k_mano_bwd, dim3(MANO_NCH64, B), dim3(256), g_hm_lds_pad[HM_PAD_MANO_BWD], stream, m, pca, pca_dim, rot, betas, g_verts, B, state,
                        partials, cnt, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
     return hm_launch_status();
 }

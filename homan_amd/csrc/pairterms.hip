@@ -92,7 +92,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                     min(170, hm_cdiv((long)Bc * Vh * 3, RED_THREADS * 2))};       // = hm_hand_terms_fwd_clips' grid
     const int blocks = (metric_out ? nchunk * B : 0) + (out_inter ? B : 0) + (ht_out_v2d2 ? ht.nblk * clips : 0) +
                        (out_smooth ? sm_nblk * clips : 0);
-    hipLaunchKernelGGL(k_pair_terms, dim3(blocks), dim3(256), 0, stream, verts_hand, verts_obj, camintr, B, Vh, Vo, Bc,
+    hipLaunchKernelGGL(k_pair_terms, dim3(blocks), dim3(256), g_hm_lds_pad[HM_PAD_PAIR_TERMS], stream, verts_hand, verts_obj, camintr, B, Vh, Vo, Bc,
                        out_stride, nchunk, (float*)ws_nn, ws_nn ? (unsigned int*)((float*)ws_nn + 512) : nullptr, metric_out,
                        obj_order, expansion, zthresh, frame_rec,
                        ws_inter ? (unsigned int*)((float*)ws_inter + 512) : nullptr, out_inter, sm_nblk, unit_smooth,

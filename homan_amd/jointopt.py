@@ -424,6 +424,8 @@ class FusedStepper:
             nn_pad = os.environ.get("HOMAN_NN_PAD")
             nn_pad = int(nn_pad) if nn_pad is not None else (40960 if C > 1 and not self.on["con"] else 0)
             prev_nn_pad = _lib.lib().hm_tune_nn_lds_pad(nn_pad)
+            fam_pads = [int(x) for x in os.environ.get("HOMAN_FAM_PADS", "0,0,0,0,0").split(",")]
+            prev_fam = [_lib.lib().hm_tune_lds_pad(i, v) for i, v in enumerate(fam_pads)]
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.cap_stream):
                 self.forward_backward(log=not self.log_in_adam)
@@ -437,6 +439,8 @@ class FusedStepper:
             _lib.lib().hm_tune_sweep_blocks(prev)
             _lib.lib().hm_tune_raster_lds_pad(prev_pad)
             _lib.lib().hm_tune_nn_lds_pad(prev_nn_pad)
+            for i, v in enumerate(prev_fam):
+                _lib.lib().hm_tune_lds_pad(i, v)
 
     # ---- shared object scale (BASELINE cfg5): C local replicas of one scalar, kept identical on every rank
     def _dist_on(self):

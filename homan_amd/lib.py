@@ -23,6 +23,7 @@ _SIGNATURES = {
     "hm_tune_sweep_blocks": (_I, [_I]),
     "hm_tune_raster_lds_pad": (_I, [_I]),
     "hm_tune_nn_lds_pad": (_I, [_I]),
+    "hm_tune_lds_pad": (_I, [_I, _I]),
     "hm_debug_sweep_caps": (_I, [_I]),
     "hm_shade_rgb": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _VP, _F, _F, _VP, _VP, _VP, _VP]),
     "hm_rigid_bwd_sil": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),

@@ -170,6 +170,10 @@ int hm_tune_raster_lds_pad(int bytes);
 /* Same for the metric-only nearest-vertex search (small latency-bound workgroups that otherwise take every wave slot of a CU
  * next to the kernel they overlap): 65536 = two search workgroups per CU. */
 int hm_tune_nn_lds_pad(int bytes);
+/* The same ballast for the other kernels of the hand side, by family: 0 MANO forward, 1 MANO backward, 2 the smoothness /
+ * interaction / hand-terms launches, 3 the fused pair-terms launch, 4 rigid backward.  Returns the previous value (-1: no such
+ * family); bytes < 0 only queries. */
+int hm_tune_lds_pad(int family, int bytes);
 /* test hook: cap > 0 shrinks the capacity tables of the sweep work list so that small inputs take the beyond-capacity
  * paths (binary search for a unit's first face, atomically accumulated faces); 0 restores the defaults.  Returns the
  * previous value. */
