@@ -933,20 +933,20 @@ __device__ __forceinline__ float sample_grad(const float* __restrict__ gimg, int
 __device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, float c0, float c1, bool use0, bool use1,
                                            float eps, float two_over_is, bool pow2, int is, float& acc0, float& acc1)
 {
-    if (!(diff > 0.0f)) return;
+    // straight-line (selects, no branches): every listed source has diff > 0 and nearly every item uses both end points, so
+    // the conditions are almost always true and a taken branch costs more than the arithmetic it would skip.  A masked term
+    // is an exact +0: acc - 0 == acc.
     const float t = (float)d1 - d1_cross;
-    if (use0) {
-        float dist = c0 * t * 2.0f;
-        dist = pow2 ? dist * two_over_is : dist / (float)is;      // exact either way when is is a power of two
-        dist = (0.0f < dist) ? dist + eps : dist - eps;
-        acc0 -= diff * __builtin_amdgcn_rcpf(dist);       // 1-ulp reciprocal: the pseudo-gradient is compared at 1e-3
-    }
-    if (use1) {
-        float dist = c1 * t * 2.0f;
-        dist = pow2 ? dist * two_over_is : dist / (float)is;
-        dist = (0.0f < dist) ? dist + eps : dist - eps;
-        acc1 -= diff * __builtin_amdgcn_rcpf(dist);
-    }
+    const bool live = diff > 0.0f;
+    float dist0 = c0 * t * 2.0f, dist1 = c1 * t * 2.0f;
+    if (pow2) { dist0 = dist0 * two_over_is; dist1 = dist1 * two_over_is; }       // exact either way when is is a power of two
+    else { dist0 = dist0 / (float)is; dist1 = dist1 / (float)is; }
+    dist0 = (0.0f < dist0) ? dist0 + eps : dist0 - eps;
+    dist1 = (0.0f < dist1) ? dist1 + eps : dist1 - eps;
+    // 1-ulp reciprocal: the pseudo-gradient is compared at 1e-3
+    const float g0 = diff * __builtin_amdgcn_rcpf(dist0), g1 = diff * __builtin_amdgcn_rcpf(dist1);
+    acc0 -= (live && use0) ? g0 : 0.0f;
+    acc1 -= (live && use1) ? g1 : 0.0f;
 }
 
 // ---------------------------------------------------------------- backward, pass 2b (edge sweeps): work list
@@ -1665,11 +1665,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                                 acc0 = 0.f;
                                 acc1 = 0.f;
                             }
-                            bool take = true;
-                            if (ph1[k]) take = sc[k].owner == qq.fn;
-                            if (take)
-                                sweep_term(ph1[k] ? sc[k].g : -sc[k].g, sc[k].d1, qq.x, qq.c0, qq.c1, (meta & (1 << 10)) != 0,
-                                           (meta & (1 << 11)) != 0, eps, inv_is, pow2, is, acc0, acc1);
+                            // (an inward pair counts only if this winding owns the source: masked by a zero `diff`)
+                            const bool take = !ph1[k] || sc[k].owner == qq.fn;
+                            sweep_term(take ? (ph1[k] ? sc[k].g : -sc[k].g) : 0.0f, sc[k].d1, qq.x, qq.c0, qq.c1,
+                                       (meta & (1 << 10)) != 0, (meta & (1 << 11)) != 0, eps, inv_is, pow2, is, acc0, acc1);
                         }
                     }
                 }
