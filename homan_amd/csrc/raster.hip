@@ -1652,9 +1652,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        if (base + 4 * lane + k < npairs) {
+                        {
+                            // (a slot past the last pair repeats the last pair's loads and is masked: same key, zero term)
+                            const bool valid = base + 4 * lane + k < npairs;
                             const SweepItem& qq = s_item[wv][qi[k]].it;
-                            const int meta = qmeta[k], key = meta & 0x3ff;
+                            const int meta = qmeta[k], key = valid ? (meta & 0x3ff) : cur;
                             if (key != cur) {
                                 if (cur >= 0) {
                                     float* f = s_fg[wv][cur & 15];
@@ -1666,7 +1668,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
                                 acc1 = 0.f;
                             }
                             // (an inward pair counts only if this winding owns the source: masked by a zero `diff`)
-                            const bool take = !ph1[k] || sc[k].owner == qq.fn;
+                            const bool take = valid && (!ph1[k] || sc[k].owner == qq.fn);
                             sweep_term(take ? (ph1[k] ? sc[k].g : -sc[k].g) : 0.0f, sc[k].d1, qq.x, qq.c0, qq.c1,
                                        (meta & (1 << 10)) != 0, (meta & (1 << 11)) != 0, eps, inv_is, pow2, is, acc0, acc1);
                         }
