@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerates the round's evidence under gpurun_out/ on the GPU box (copy what is to be judged into profiles/):
 #   rNN_pmc_loop.json            PMC passes over the steady-state loop (tools/pmc_loop.sh); bench.py reads profiles/rNN_pmc_loop.json
-#   rNN_bench_cfg{2,3,5}.json    bench lines (cfg2 = the driver's default command)
+#   rNN_bench_cfg{2,3,5}.json    bench lines (cfg2 = the driver's default command; _driver_flags = --steps 20 --warmup 5)
 #   rNN_p_cfg2_headline_*        rocprofv3 --kernel-trace --stats of the headline loop alone: its per-kernel averages are
 #                                the ones bench.py's roofline object must agree with
 #   rNN_p_cfg4_batch8_*          the same for an 8-clip batch
@@ -11,6 +11,7 @@ cd $R
 bash tools/pmc_loop.sh > $O/${N}_pmc_loop.json 2>/dev/null
 cp $O/${N}_pmc_loop.json profiles/${N}_pmc_loop.json
 python bench.py > $O/${N}_bench_cfg2.json 2> $O/${N}_bench_cfg2.err
+python bench.py --steps 20 --warmup 5 > $O/${N}_bench_cfg2_driver_flags.json 2>/dev/null      # the flags the driver passed in round 1: iterations 5-25 of a fresh fit
 python bench.py --step2 --parity-seeds 0 > $O/${N}_bench_cfg3.json 2>/dev/null
 python bench.py --shared-scale --steps 200 > $O/${N}_bench_cfg5_n1.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
