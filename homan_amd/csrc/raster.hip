@@ -1248,6 +1248,9 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
 #ifdef SWEEP_STATS
 __device__ unsigned long long g_sweep_n[12];     // stage 2: items, geo, act0, act1, on0, on1, pairs, trips; stage 1: items, geo, reach; pair rounds
 #endif
+#ifdef SWEEP_UNIT_PROFILE
+__device__ int g_unit_prof[65536][4];            // per unit: wall-clock ticks, face passes, stage-2 trips | queued items << 8, pair rounds
+#endif
 // geometry of item j of face record fc: which (winding, edge, axis) family, which line d0r, where the edge crosses it
 struct SweepGeo {
     int var, edge, axis, d0r, dir, a_in, a_out;
@@ -1330,7 +1333,10 @@ __device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, b
 //            two sweeps, and the (item, source) pairs flattened over the wave as before.
 // Filtering before the expensive half is what the 256-item unit is for: a 64-item unit leaves ~19 survivors, a quarter of a
 // wave, and a divergent early-out saves nothing.  Unit composition depends only on the compaction block the items come from.
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
+#ifndef SWEEP_WAVES_EU
+#define SWEEP_WAVES_EU 5
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES_EU, 8))) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
                                                    const SweepSrc* __restrict__ srcs,
                                                    const uint4* __restrict__ lrec, int B, int F, int S,
                                                    float eps, float* __restrict__ parts,
@@ -1370,35 +1376,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
     const int xcd = blockIdx.x & 7;
     const int xwaves = (int)(gridDim.x >> 3) * 4;
     const int u_end = (int)(((long)U * (xcd + 1)) >> 3);
+    // (a unit's first face comes from the unit table; the wave requests the NEXT unit's entry together with the current
+    //  unit's records, so only a wave's first unit pays that round trip)
+    int first_ahead = -1;
     for (int u = __builtin_amdgcn_readfirstlane((int)(((long)U * xcd) >> 3) + (int)(blockIdx.x >> 3) * 4 + wv); u < u_end;
          u += xwaves) {
         const int ubeg = u << SWEEP_USHIFT, uend = ubeg + SWEEP_UNIT;
-        int first;
-        if (u < sl.ucap) first = (int)sl.ufirst[u];
-        else {                                   // beyond the unit table: last face with off <= first item of the unit
-            int lo = 0, hi = W - 1;
-            while (lo < hi) {
-                const int mid = (lo + hi + 1) >> 1;
-                if (sl.offs[mid] <= ubeg) lo = mid; else hi = mid - 1;
+#ifdef SWEEP_UNIT_PROFILE
+        const unsigned long long up_t0 = wall_clock64();
+        int up_pass = 0, up_trips = 0, up_q = 0, up_rounds = 0;
+#endif
+        int first = first_ahead;
+        if (first < 0) {
+            if (u < sl.ucap) first = (int)sl.ufirst[u];
+            else {                                   // beyond the unit table: last face with off <= first item of the unit
+                int lo = 0, hi = W - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (sl.offs[mid] <= ubeg) lo = mid; else hi = mid - 1;
+                }
+                first = lo;
             }
-            first = lo;
+            first = __builtin_amdgcn_readfirstlane(first);
         }
-        first = __builtin_amdgcn_readfirstlane(first);
+        const int u_ahead = u + xwaves;
+        int ahead_v = -1;
+        if (u_ahead < u_end && u_ahead < sl.ucap) ahead_v = (int)sl.ufirst[u_ahead];
         for (int fb = 0;; fb += SWEEP_PASS_FACES) {
             // first items of the pass's faces and of the face behind them (lane 16): sorted, so the faces inside the unit
             // are a prefix
+            // (the records of the 16 faces that MAY belong to the pass are requested with their first items, not after them:
+            //  one round trip; the rows of faces beyond the unit are dropped)
             const int o = (lane <= SWEEP_PASS_FACES && first + fb + lane < W) ? sl.offs[first + fb + lane] : 0x7fffffff;
+            int row[SWEEP_PASS_FACES / 4];
+#pragma unroll
+            for (int k = 0; k < SWEEP_PASS_FACES / 4; ++k) {
+                const int fi = first + fb + 4 * k + (lane >> 4);
+                row[k] = fi < W ? reinterpret_cast<const int*>(sl.tab + fi)[lane & 15] : 0;
+            }
+            if (fb == 0) first_ahead = __builtin_amdgcn_readfirstlane(ahead_v);
             const int nfp = __popcll(__ballot(lane < SWEEP_PASS_FACES && o < uend));
             if (nfp == 0) break;
+#ifdef SWEEP_UNIT_PROFILE
+            ++up_pass;
+#endif
             const int it_lo = max(ubeg, __builtin_amdgcn_readlane(o, 0));
             const int it_hi = min(min(uend, N), __builtin_amdgcn_readlane(o, nfp));     // (lane nfp: next face, or "none")
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < SWEEP_PASS_FACES / 4; ++k) {
                 const int ent = 4 * k + (lane >> 4);
-                if (ent < nfp)
-                    reinterpret_cast<int*>(&s_face[wv][ent].f)[lane & 15] =
-                        reinterpret_cast<const int*>(sl.tab + first + fb + ent)[lane & 15];
+                if (ent < nfp) reinterpret_cast<int*>(&s_face[wv][ent].f)[lane & 15] = row[k];
             }
             for (int i = lane; i < SWEEP_PASS_FACES * 6; i += 64) (&s_fg[wv][0][0])[i] = 0.f;
             wave_sync();
@@ -1500,7 +1528,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             if (eps > 0.f) qn = 0;
 #endif
             // ---------------- stage 2: the items that may collect something, 64 per trip
+#ifdef SWEEP_UNIT_PROFILE
+            up_q += qn;
+#endif
             for (int s0 = 0; s0 < qn; s0 += 64) {
+#ifdef SWEEP_UNIT_PROFILE
+            ++up_trips;
+#endif
             bool mine = s0 + lane < qn;
             const int ent = mine ? (int)s_q[wv][s0 + lane] : 0;
             const int g = ubeg + (ent & 0xff), el = (ent >> 8) & 15;
@@ -1611,6 +1645,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
 #ifdef SWEEP_STATS
                     if (lane == 0) atomicAdd(&g_sweep_n[11], 1ull);
 #endif
+#ifdef SWEEP_UNIT_PROFILE
+                    ++up_rounds;
+#endif
                     int4* hd = reinterpret_cast<int4*>(s_head[wv]);
                     hd[lane] = make_int4(0, 0, 0, 0);
                     wave_sync();
@@ -1720,6 +1757,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 8))) voi
             }
             if (nfp < SWEEP_PASS_FACES) break;          // the face behind this pass starts beyond the unit
         }   // face passes
+#ifdef SWEEP_UNIT_PROFILE
+        if (lane == 0 && u < 65536) {
+            g_unit_prof[u][0] = (int)(wall_clock64() - up_t0); g_unit_prof[u][1] = up_pass;
+            g_unit_prof[u][2] = up_trips | (up_q << 8); g_unit_prof[u][3] = up_rounds;
+        }
+#endif
     }   // units
     if (ts_on) hm_ts_store(ts_slots, (long)blockIdx.x * 4 + (threadIdx.x >> 6), 1, (unsigned long long)wall_clock64());
 }
@@ -2502,6 +2545,16 @@ int hm_debug_raster_phases(unsigned long long* out)
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_raster_ph), sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raster_ph), z, sizeof(z));
+    return HM_OK;
+}
+#endif
+#ifdef SWEEP_UNIT_PROFILE
+int hm_debug_unit_profile(int* out)              // 65536 x 4 ints, then cleared
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_unit_prof), sizeof(int) * 65536 * 4);
+    static int z[65536][4];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_unit_prof), z, sizeof(z));
     return HM_OK;
 }
 #endif
