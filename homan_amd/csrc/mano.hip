@@ -97,11 +97,12 @@ struct ManoShared {
     int depth[MANO_J];
 };
 
-// pose / Rodrigues / joints / chain, shared by forward and both backward kernels.  Needs >= 64 threads.
+// pose / Rodrigues / joints / chain, shared by forward and both backward kernels.  `t` = index of the thread among the
+// >= 64 that prepare frame b into `sh` (the barriers are the workgroup's: every wave of a workgroup calls this together,
+// each group of threads with a frame and a state of its own - or all of them with t = threadIdx.x and one frame).
 __device__ __forceinline__ void mano_prepare(const ManoModelDev& m, const float* pca, int pca_stride, const float* rot,
-                                             const float* betas, int b, ManoShared& sh)
+                                             const float* betas, int b, ManoShared& sh, int t)
 {
-    const int t = threadIdx.x;
     if (t < 48) {
         float v;
         if (t < 3) v = rot[b * 3 + t];
@@ -227,7 +228,13 @@ __device__ __forceinline__ void mano_skin_transform(const ManoModelDev& m, const
     }
 }
 
-// grid (13, B).  verts (B,778,3) = LBS + trans ; joints (B,16,3) optional (posed joints + trans)
+// grid (13, ceil(B / 4)).  verts (B,778,3) = LBS + trans ; joints (B,16,3) optional (posed joints + trans).
+// A workgroup = one chunk of 64 vertices for FOUR consecutive frames, wave f owning frame f: the four chains are prepared
+// side by side (one per wave), then every wave streams ITS 37 rows of the blend matrix once and accumulates them for all
+// four frames - the 1.35 MB matrix is read from L2 once per four frames instead of once per frame (a 240-frame batch moved
+// 324 MB through L2 per launch) - and wave f finishes frame f: partial sums, skinning, rigid transform, state for the backward.
+// Per frame the arithmetic is unchanged (same rows per partial, same order), so results do not depend on how frames are grouped.
+#define MANO_FPW 4     // frames per workgroup = waves per workgroup
 __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
                                                    const float* __restrict__ rot, const float* __restrict__ betas,
                                                    const float* __restrict__ trans, int B, float* __restrict__ verts,
@@ -236,31 +243,63 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
                                                    const float* __restrict__ rigid_scale, float* __restrict__ verts_world,
                                                    float* __restrict__ state, int clip_len)
 {
-    __shared__ ManoShared sh;
-    __shared__ float s_part[4][MANO_VCH][3];
-    __shared__ float s_vp[MANO_VCH][3];
-    __shared__ float s_R[9];
-    const int b = blockIdx.y;
-    if (verts_world && threadIdx.x == 64) rot6d_to_mat(rigid_rot6d + b * 6, s_R);      // published by mano_prepare's barriers
-    mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
+    __shared__ ManoShared shs[MANO_FPW];
+    __shared__ float s_part[4][MANO_FPW][MANO_VCH][3];
+    __shared__ float s_vp[MANO_FPW][MANO_VCH][3];
+    __shared__ float s_R[MANO_FPW][9];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b_raw = blockIdx.y * MANO_FPW + wv;
+    const bool live = b_raw < B;                 // (a frame past the end repeats the last one and stores nothing)
+    const int b = min(b_raw, B - 1);
+    ManoShared& sh = shs[wv];
+    if (verts_world && lane == 48) rot6d_to_mat(rigid_rot6d + b * 6, s_R[wv]);      // published by mano_prepare's barriers
+    mano_prepare(m, pca, pca_stride, rot, betas, b, sh, lane);
     const float tr[3] = {trans ? trans[b * 3] : 0.f, trans ? trans[b * 3 + 1] : 0.f, trans ? trans[b * 3 + 2] : 0.f};
-    if (joints && blockIdx.x == 0 && threadIdx.x < MANO_J * 3)
-        joints[b * MANO_J * 3 + threadIdx.x] = sh.tw[threadIdx.x / 3][threadIdx.x % 3] + tr[threadIdx.x % 3];
+    if (joints && live && blockIdx.x == 0 && lane < MANO_J * 3)
+        joints[b * MANO_J * 3 + lane] = sh.tw[lane / 3][lane % 3] + tr[lane % 3];
     const int v0 = blockIdx.x * MANO_VCH;
-    mano_posed_chunk(m, sh, v0, s_part, s_vp);
+    const int v = min(v0 + lane, MANO_V - 1);
+    {
+        float a[MANO_FPW][3];
+#pragma unroll
+        for (int f = 0; f < MANO_FPW; ++f) a[f][0] = a[f][1] = a[f][2] = 0.f;
+        const int k0 = wv * MANO_ROWS_PER_WAVE, k1 = min(MANO_NF, k0 + MANO_ROWS_PER_WAVE);
+        const float* base = m.M + 3 * v;
+#pragma unroll 4
+        for (int k = k0; k < k1; ++k) {
+            const float* row = base + (long)k * (3 * MANO_V);
+            const float r0 = row[0], r1 = row[1], r2 = row[2];
+#pragma unroll
+            for (int f = 0; f < MANO_FPW; ++f) {
+                const float ft = shs[f].feat[k];
+                a[f][0] += ft * r0;
+                a[f][1] += ft * r1;
+                a[f][2] += ft * r2;
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < MANO_FPW; ++f) {
+            s_part[wv][f][lane][0] = a[f][0]; s_part[wv][f][lane][1] = a[f][1]; s_part[wv][f][lane][2] = a[f][2];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        s_vp[wv][lane][c] = m.v_template[3 * v + c] + ((s_part[0][wv][lane][c] + s_part[1][wv][lane][c]) +
+                                                       (s_part[2][wv][lane][c] + s_part[3][wv][lane][c]));
+    __builtin_amdgcn_wave_barrier();
+    if (!live) return;
     if (state) {        // chain state once per frame, posed vertices per chunk: the backward reloads instead of recomputing
         float* st = state + (long)b * MANO_STATE_DW;
         if (blockIdx.x == 0)
-            for (int i = threadIdx.x; i < (int)(sizeof(ManoShared) / 4); i += blockDim.x)
-                st[i] = reinterpret_cast<const float*>(&sh)[i];
+            for (int i = lane; i < (int)(sizeof(ManoShared) / 4); i += 64) st[i] = reinterpret_cast<const float*>(&sh)[i];
         const int nv3 = 3 * min(MANO_VCH, MANO_V - v0);
-        if ((int)threadIdx.x < nv3) st[MANO_STATE_SH + 3 * v0 + threadIdx.x] = (&s_vp[0][0])[threadIdx.x];
+        for (int i = lane; i < nv3; i += 64) st[MANO_STATE_SH + 3 * v0 + i] = (&s_vp[wv][0][0])[i];
     }
-    const int v = v0 + threadIdx.x;
-    if (threadIdx.x >= MANO_VCH || v >= MANO_V) return;
+    if (v0 + lane >= MANO_V) return;
     float T[12];
     mano_skin_transform(m, sh, v, T);
-    const float* vp = s_vp[threadIdx.x];
+    const float* vp = s_vp[wv][lane];
     float* o = verts + ((long)b * MANO_V + v) * 3;
     float p[3];
 #pragma unroll
@@ -269,10 +308,11 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
         const float s = rigid_scale[b / clip_len];      // one hand scale per clip
         const float x = s * p[0], y = s * p[1], z = s * p[2];
         const float* t = rigid_trans + b * 3;
+        const float* R = s_R[wv];
         float* ow = verts_world + ((long)b * MANO_V + v) * 3;
-        ow[0] = x * s_R[0] + y * s_R[3] + z * s_R[6] + t[0];
-        ow[1] = x * s_R[1] + y * s_R[4] + z * s_R[7] + t[1];
-        ow[2] = x * s_R[2] + y * s_R[5] + z * s_R[8] + t[2];
+        ow[0] = x * R[0] + y * R[3] + z * R[6] + t[0];
+        ow[1] = x * R[1] + y * R[4] + z * R[7] + t[1];
+        ow[2] = x * R[2] + y * R[5] + z * R[8] + t[2];
     }
 }
 
@@ -433,7 +473,7 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
         if (t < 3 * nv) (&s_vp[0][0])[t] = st[MANO_STATE_SH + 3 * v0 + t];
         __syncthreads();
     } else {
-        mano_prepare(m, pca, pca_stride, rot, betas, b, sh);
+        mano_prepare(m, pca, pca_stride, rot, betas, b, sh, threadIdx.x);
         mano_posed_chunk(m, sh, v0, s_part, s_vp);
     }
     float g[3] = {0.f, 0.f, 0.f};
@@ -514,7 +554,7 @@ int hm_mano_fwd_clips(const void* const* model, const float* pca, int pca_dim, c
     HM_CHECK_ARG(!verts_world || (rigid_rot6d && rigid_trans && rigid_scale));
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
-    hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, B), dim3(256), g_hm_lds_pad[HM_PAD_MANO_FWD], stream, m, pca, pca_dim, rot, betas, trans, B, verts,
+    hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, (B + MANO_FPW - 1) / MANO_FPW), dim3(256), g_hm_lds_pad[HM_PAD_MANO_FWD], stream, m, pca, pca_dim, rot, betas, trans, B, verts,
                        joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world, state, clip_len ? clip_len : B);
     return hm_launch_status();
 }

@@ -395,6 +395,12 @@ class FusedStepper:
         self.reduce_ws_c, self.reduce_ws_d, self.reduce_ws_e = (ClipReduceWorkspace(dev, C) for _ in range(3))
         # (one clip: the hand-side chain is the iteration's critical path, -6 %; a batch hides that chain under the silhouette
         #  chain and the fused launch only adds contention there, +1.6 %)
+        # a clip batch: the pair-wise terms wait for the END of the rasteriser.  They used to start there anyway, behind a MANO
+        # forward as long as the raster; since that launch reads the blend matrix once per four frames it is over early, and the
+        # search / smoothness / interaction launches next to the raster cost it more (362 -> 433 us) than they gain next to the
+        # line expansion (230 -> 162 us)
+        self.pairs_after_raster = (self.use_aux and not self.sil_reduce_in_bwd and
+                                   (os.environ.get("HOMAN_PAIRS_AFTER_RASTER") or "1") != "0")
         self.pair_fused = (os.environ.get("HOMAN_PAIR_FUSED") or ("1" if C == 1 else "0")) != "0"
         self.hand_terms_fused = os.environ.get("HOMAN_HT_FUSED", "1") != "0"
         if self.shared_scale:
@@ -416,7 +422,7 @@ class FusedStepper:
             # same idea for the rasteriser: 8 KB of LDS ballast = 4 workgroups per CU instead of 6 leaves registers for the
             # hand-side kernels (cfg3 one clip: 4347 -> 4500 it/s; cfg2, where that chain is short: 5820 -> 5500, so not there)
             pad = os.environ.get("HOMAN_RASTER_PAD")
-            pad = int(pad) if pad is not None else (8192 if (self.on["col"] or self.on["con"]) and C == 1 else 0)
+            pad = int(pad) if pad is not None else (4096 if (self.on["col"] or self.on["con"]) and C == 1 else 0)
             prev_pad = _lib.lib().hm_tune_raster_lds_pad(pad)
             # and for the metric-only search of a clip batch: its 1680 small, latency-bound workgroups otherwise take every wave
             # slot of the CUs next to the line expansion (lines 250 -> 226 us, iteration -4.4 % at 3 search workgroups per CU;
@@ -596,6 +602,8 @@ class FusedStepper:
                                           P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, CL, NS, sb), "v2d")
             if on["sil"]:
                 side.wait_event(self.ev_sil)         # self.vo: camera-space object vertices from the calling stream
+                if self.pairs_after_raster:
+                    side.wait_event(self.ev_ras)     # (scheduling only, see __init__)
             if sm_here and not fuse:
                 ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
                                          sb), "smooth(obj)")
