@@ -346,7 +346,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     float* __restrict__ pooled_depth, unsigned short* __restrict__ planes,
     int* __restrict__ bin_cnt, const int* __restrict__ bin_list, unsigned int* __restrict__ done, int reset_bins,
     unsigned char* __restrict__ region_state, int persistent, float* __restrict__ alpha_full, int mask_shared,
-    float* __restrict__ dimg_full, const unsigned int* __restrict__ hint, unsigned long long* __restrict__ ts_slots)
+    float* __restrict__ dimg_full, const unsigned int* __restrict__ hint, unsigned long long* __restrict__ ts_slots,
+    int* __restrict__ wo_dyn, unsigned int* __restrict__ wg_cost)
 {
     HM_CHAIN_KERNEL();
     const unsigned long long ts_t0 = (unsigned long long)wall_clock64();       // (see hm_ts_enabled)
@@ -363,7 +364,14 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     const int is = 2 * S, tiles_x = S / HM_TILE, ntiles = tiles_x * tiles_x, regions_x = tiles_x / 2;
     // dispatch order = work_order[block] = (frame << 16 | region): expensive (frame, region) pairs first so that the
     // cheap ones fill the tail of the launch (default: centre of the ROI outwards; calibrated: by candidate count)
-    const int wo = work_order ? work_order[blockIdx.x] : (int)(((blockIdx.x % B) << 16) | (blockIdx.x / B));
+    // Adaptive order (hm_tune_raster_reorder, wo_dyn != NULL): every workgroup leaves the time it took in wg_cost and the
+    // entry it served in wo_dyn; a workgroup of the backward's first launch sorts the entries by that time, longest first,
+    // for the NEXT forward of this workspace (hint word 2 then says "use wo_dyn").  What is expensive moves during a fit;
+    // an order taken from the poses at its start is stale after a few dozen iterations.
+    const bool dyn = wo_dyn && hint[2] != 0u;
+    const int wo = dyn ? wo_dyn[blockIdx.x]
+                       : work_order ? work_order[blockIdx.x] : (int)(((blockIdx.x % B) << 16) | (blockIdx.x / B));
+    if (wo_dyn && !dyn && threadIdx.x == 0) wo_dyn[blockIdx.x] = wo;
     const int region = wo & 0xffff, b = wo >> 16;
     const int rx = region % regions_x, ry = region / regions_x;
     const int tx = 2 * rx + (w & 1), ty = 2 * ry + (w >> 1);
@@ -698,6 +706,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
 #ifdef RASTER_PHASES
         if (tid == 0) atomicAdd(&g_raster_ph[7], 1ull);
 #endif
+        if (wg_cost && tid == 0) wg_cost[blockIdx.x] = 0u;
         return;
     }
     __syncthreads();          // every thread has read the state before thread 0 rewrites it below
@@ -806,6 +815,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
         }
     }
     if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
+    if (wg_cost && tid == 0) wg_cost[blockIdx.x] = (unsigned)min((unsigned long long)wall_clock64() - ts_t0, 0xfffffffeull) + 1u;
 #ifdef RASTER_PHASES
     RPH_MARK(5);
     if (tid == 0) {
@@ -1129,6 +1139,75 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const 
 struct SweepSrc { int d1; float g; int owner; };
 #define SWEEP_CUMW 16           // cumulative-count slots per line (is <= 1024)
 
+// One workgroup (256 threads): the forward raster's launch order for the next iteration = its entries sorted by the time their
+// workgroups took in this one, longest first (counting sort on 40 ns units, 1024 bins; the order inside a bin is whatever the
+// LDS atomics give: scheduling only, results do not depend on the order).  wo_dyn (n) is rewritten through wo_tmp (n).
+__device__ __forceinline__ void raster_reorder(int* __restrict__ wo_dyn, int* __restrict__ wo_tmp,
+                                               const unsigned int* __restrict__ wg_cost, unsigned int* __restrict__ dyn_flag, int n)
+{
+    __shared__ unsigned s_hist[1024];
+    __shared__ unsigned s_wsum[4];
+    __shared__ unsigned s_zero;          // entries of idle workgroups (time 0: most of a clip's regions are background): they go
+                                         // last in any order, placed by wave ballots - thousands of LDS atomics on ONE bin serialise
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int i = tid; i < 1024; i += 256) s_hist[i] = 0u;
+    if (tid == 0) s_zero = 0u;
+    __syncthreads();
+    // (16 loads in flight per thread and pass: a dependent load per entry would make this workgroup the launch's tail)
+    for (int base = 0; base < n; base += 256 * 16) {
+        unsigned cv[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int i = base + 256 * k + tid; cv[k] = i < n ? wg_cost[i] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (base + 256 * k + tid < n && cv[k] != 0u) atomicAdd(&s_hist[1023 - min(cv[k] >> 2, 1023u)], 1u);
+    }
+    __syncthreads();
+    // exclusive prefix over the bins: four consecutive bins per thread, wave scan, wave totals
+    unsigned c[4], tot = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { c[k] = s_hist[4 * tid + k]; tot += c[k]; }
+    const unsigned incl = (unsigned)hm_wave_scan_incl((int)tot);
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    unsigned base0 = incl - tot;
+    for (int q = 0; q < wv; ++q) base0 += s_wsum[q];
+    const unsigned n_busy = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s_hist[4 * tid + k] = base0; base0 += c[k]; }
+    __syncthreads();
+    for (int base = 0; base < n; base += 256 * 16) {
+        unsigned cv[16];
+        int ev[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int i = base + 256 * k + tid;
+            cv[k] = i < n ? wg_cost[i] : 0u;
+            ev[k] = i < n ? wo_dyn[i] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const bool in = base + 256 * k + tid < n, zero = in && cv[k] == 0u;
+            const unsigned long long zb = __ballot(zero);
+            unsigned zbase = 0u;
+            if (lane == 0 && zb) zbase = atomicAdd(&s_zero, (unsigned)__popcll(zb));
+            zbase = (unsigned)__builtin_amdgcn_readfirstlane((int)zbase);
+            if (zero) wo_tmp[n_busy + zbase + (unsigned)__popcll(zb & ((1ull << lane) - 1ull))] = ev[k];
+            else if (in) wo_tmp[atomicAdd(&s_hist[1023 - min(cv[k] >> 2, 1023u)], 1u)] = ev[k];
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int base = 0; base < n; base += 256 * 16) {
+        int ev[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int i = base + 256 * k + tid; ev[k] = i < n ? __builtin_nontemporal_load(wo_tmp + i) : 0; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int i = base + 256 * k + tid; if (i < n) wo_dyn[i] = ev[k]; }
+    }
+    if (tid == 0) *dyn_flag = 1u;
+}
+
 // 16 lanes per line (one DPP row), 16 lines per workgroup: a wave per line spent its life waiting on three dependent
 // memory round trips with 8 of 64 lanes loading; four lines per wave quarter the number of waves in flight.
 __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restrict__ planes,
@@ -1145,24 +1224,34 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    const float* __restrict__ red_partials, float* __restrict__ frame_rec,
                                                    float* __restrict__ loss_out, int out_stride,
                                                    const unsigned int* __restrict__ ts_flag,
-                                                   unsigned long long* __restrict__ ts_slots)
+                                                   unsigned long long* __restrict__ ts_slots, int nsort,
+                                                   int* __restrict__ wo_dyn, int* __restrict__ wo_tmp,
+                                                   const unsigned int* __restrict__ wg_cost,
+                                                   unsigned int* __restrict__ dyn_flag, int n_wo)
 {
     HM_CHAIN_KERNEL();
     const unsigned long long ts_t0 = (unsigned long long)wall_clock64();
     const bool ts_on = hm_ts_enabled(ts_flag) && threadIdx.x == 0;
     if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 0, ts_t0);
+    // (optional first workgroup: the raster's launch order for the next forward, see raster_reorder)
+    if (nsort && blockIdx.x == 0) {
+        raster_reorder(wo_dyn, wo_tmp, wg_cost, dyn_flag, n_wo);
+        if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
+        return;
+    }
+    const int blk = (int)blockIdx.x - nsort;
     __shared__ unsigned long long s_w[16][SWEEP_CUMW];
     __shared__ int s_ex[16][SWEEP_CUMW];
     // the first `ncomp` workgroups build the work list of the edge sweeps (independent of the lines: one launch for both)
-    if ((int)blockIdx.x < ncomp) {
-        sweep_compact(blockIdx.x, ncomp, fpt, faces9, boxes, owned, B, F, 2 * S, parts, sl, clip_len);
+    if (blk < ncomp) {
+        sweep_compact(blk, ncomp, fpt, faces9, boxes, owned, B, F, 2 * S, parts, sl, clip_len);
         if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
         return;
     }
     // the next `nred` (= B or 0) finish the forward's fused loss: one launch less on the chain of a caller that only needs
     // the loss value for its log (see hm_sil_bwd_clips)
-    if ((int)blockIdx.x < ncomp + nred) {
-        sil_reduce_frame(blockIdx.x - ncomp, red_partials, (S / 8) * (S / 8), keep_sum, frame_rec, loss_out, nullptr, clip_len,
+    if (blk < ncomp + nred) {
+        sil_reduce_frame(blk - ncomp, red_partials, (S / 8) * (S / 8), keep_sum, frame_rec, loss_out, nullptr, clip_len,
                          out_stride);
         if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
         return;
@@ -1171,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     // (the 16 rows of a workgroup leave at different times: each folds its exit into the workgroup's own end slot)
     const bool ts_row = l == 0 && hm_ts_enabled(ts_flag);
     const int is = 2 * S, wpl = is / 64;
-    const long L = (long)(blockIdx.x - ncomp - nred) * 16 + grp;
+    const long L = (long)(blk - ncomp - nred) * 16 + grp;
     const bool valid = L < 4L * B * is;
     // L = ((pl * 2 + axis) * B + b) * is + d0
     const int d0 = (int)(L % is), b = (int)((L / is) % B), pa = (int)(L / ((long)is * B));
@@ -2089,6 +2178,7 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
     n += al256(sweep_ucap(B, F) * 4);                           //   first face of every unit,
     n += al256(sweep_slot_cap(B, F) * 24);                      //   per-unit partials of faces spread over several units
     n += al256(ts_units(B, F, S) * 16);                          // in-graph timestamps (hm_sil_timestamps)
+    n += al256(ts_raster_units(B, S) * 4) * 3;                   // adaptive raster launch order: entries, scratch, times
     return n;
 }
 
@@ -2100,6 +2190,7 @@ struct SilWs {
     uint4* lrec; SweepSrc* srcs; unsigned short* lsum;
     SweepList sweep;
     unsigned long long* ts;      // {start, end} slots: raster workgroups | lines workgroups | sweep waves
+    int* wo_dyn; int* wo_tmp; unsigned int* wg_cost;      // adaptive raster launch order (hm_tune_raster_reorder)
 };
 static SilWs carve(void* ws, int B, int V, int F, int S)
 {
@@ -2130,7 +2221,10 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.sweep.tickets = (unsigned int*)p; p += al256((size_t)B * F * 4);
     w.sweep.ufirst = (unsigned int*)p; p += al256(sweep_ucap(B, F) * 4);
     w.sweep.upart = (float*)p; p += al256(sweep_slot_cap(B, F) * 24);
-    w.ts = (unsigned long long*)p;
+    w.ts = (unsigned long long*)p; p += al256(ts_units(B, F, S) * 16);
+    w.wo_dyn = (int*)p; p += al256(ts_raster_units(B, S) * 4);
+    w.wo_tmp = (int*)p; p += al256(ts_raster_units(B, S) * 4);
+    w.wg_cost = (unsigned int*)p;
     w.sweep.cnt = (unsigned long long*)(w.counter + 16);        // zero between launches (re-armed by the last compaction block)
     w.sweep.done = w.counter + 18;
     w.sweep.total = (unsigned long long*)(w.counter + 20);
@@ -2143,6 +2237,10 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     return w;
 }
 
+// Scheduling hint, no effect on results (hm_tune_raster_reorder): while it is on, the forward launches of hm_sil_fwd record
+// what every raster workgroup cost and the first launch of hm_sil_bwd re-sorts the raster's launch order by it (kept in the
+// workspace; the caller's work_order only seeds it).  Read when the entry points are called (or captured).
+static int g_raster_reorder = 0;
 // pass 2a (+ the work list of pass 2b in its first workgroups) and pass 2b
 static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const float* upstream, const float* keep_sum,
                          int clip_len, hipStream_t stream, float* loss_out = nullptr, int out_stride = 0)
@@ -2152,10 +2250,12 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
     // whether it is launched alone or in a batch
     const int fpt = (long)clip_len * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks
     const int ncomp = (B / clip_len) * hm_cdiv((long)clip_len * F, 256 * fpt);
-    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + nred + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
+    const int nsort = g_raster_reorder ? 1 : 0;      // (see hm_tune_raster_reorder)
+    hipLaunchKernelGGL(k_bwd_lines, dim3(nsort + ncomp + nred + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
                        w.owned, F, w.parts, w.sweep, clip_len, w.lsum, nred, w.partials, w.frame_rec, loss_out, out_stride,
-                       w.counter + 24, w.ts + 2 * ts_raster_units(B, S));
+                       w.counter + 24, w.ts + 2 * ts_raster_units(B, S), nsort, w.wo_dyn, w.wo_tmp, w.wg_cost, w.counter + 26,
+                       (int)ts_raster_units(B, S));
 }
 static int g_sweep_blocks = SWEEP_BLOCKS;
 static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
@@ -2175,6 +2275,14 @@ int hm_tune_raster_lds_pad(int bytes)
 {
     const int prev = g_raster_lds_pad;
     if (bytes >= 0) g_raster_lds_pad = bytes;
+    return prev;
+}
+// Scheduling hint, no effect on results: adaptive launch order of the forward raster (see g_raster_reorder).  enable > 0: on,
+// 0: off, < 0: query.  Returns the previous value.  Process-wide; read when hm_sil_fwd / hm_sil_bwd are called (or captured).
+int hm_tune_raster_reorder(int enable)
+{
+    const int prev = g_raster_reorder;
+    if (enable >= 0) g_raster_reorder = enable ? 1 : 0;
     return prev;
 }
 
@@ -2226,7 +2334,8 @@ int hm_sil_fwd_phase_clips(const float* verts, const int* faces, int faces_bstri
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.planes, bins,
                        w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full, mask_shared,
-                       (fused && alpha_full) ? w.gimg : (float*)nullptr, w.counter + 24, w.ts);
+                       (fused && alpha_full) ? w.gimg : (float*)nullptr, w.counter + 24, w.ts,
+                       g_raster_reorder ? w.wo_dyn : (int*)nullptr, g_raster_reorder ? w.wg_cost : (unsigned int*)nullptr);
     HM_TIME_MARK(1, stream);
     if (fused && keep_sum && loss_out)
         hipLaunchKernelGGL(k_sil_reduce, dim3(B), dim3(256), 0, stream, w.partials, B, ntiles, keep_sum, w.frame_rec,
@@ -2433,7 +2542,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
                            w.faces9, w.boxes, B, F, S, 0.1f, 100.0f, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                            w.partials, work_order, w.owned, (float*)nullptr, w.planes, bins, w.bin_list,
                            w.bin_done, cold ? 1 : 0, w.region_state, 1, (float*)nullptr, 0, (float*)nullptr,
-                           w.counter + 24, w.ts);      // steady state of a fixed loop: background regions skipped
+                           w.counter + 24, w.ts, (int*)nullptr, (unsigned int*)nullptr);      // steady state of a fixed loop: background regions skipped
     }
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);

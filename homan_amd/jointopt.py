@@ -424,6 +424,14 @@ class FusedStepper:
             pad = os.environ.get("HOMAN_RASTER_PAD")
             pad = int(pad) if pad is not None else (4096 if (self.on["col"] or self.on["con"]) and C == 1 else 0)
             prev_pad = _lib.lib().hm_tune_raster_lds_pad(pad)
+            # the raster's launch order follows the measured cost of its workgroups from iteration to iteration
+            # (hm_tune_raster_reorder; same-box A/B: raster 57 -> 45 us inside the graph at one clip, 356 -> 298 us at eight.  The
+            # iteration gains 0.3-1 % where the silhouette chain is the longer one - clip batches, the step-2 loss sets - and 2 %
+            # over iterations 5-25 of a step-1 fit; in the steady state of a one-clip step-1 fit the hand-side stream has
+            # been running in the raster's tail and then lands on the lines and the sweeps: -4 %, so not there)
+            ro = os.environ.get("HOMAN_RASTER_REORDER")
+            ro = int(ro) if ro is not None else int(C > 1 or self.on["col"] or self.on["con"])
+            prev_reorder = _lib.lib().hm_tune_raster_reorder(ro)
             # and for the metric-only search of a clip batch: its 1680 small, latency-bound workgroups otherwise take every wave
             # slot of the CUs next to the line expansion (lines 250 -> 226 us, iteration -4.4 % at 3 search workgroups per CU;
             # 2 per CU make the search itself the tail)
@@ -444,6 +452,7 @@ class FusedStepper:
                     self.opt.step(zero_grad=False)
             _lib.lib().hm_tune_sweep_blocks(prev)
             _lib.lib().hm_tune_raster_lds_pad(prev_pad)
+            _lib.lib().hm_tune_raster_reorder(prev_reorder)
             _lib.lib().hm_tune_nn_lds_pad(prev_nn_pad)
             for i, v in enumerate(prev_fam):
                 _lib.lib().hm_tune_lds_pad(i, v)

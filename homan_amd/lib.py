@@ -22,6 +22,7 @@ _SIGNATURES = {
     "hm_sil_hint_near_winding": (_I, [_VP, _I, _VP]),
     "hm_tune_sweep_blocks": (_I, [_I]),
     "hm_tune_raster_lds_pad": (_I, [_I]),
+    "hm_tune_raster_reorder": (_I, [_I]),
     "hm_tune_nn_lds_pad": (_I, [_I]),
     "hm_tune_lds_pad": (_I, [_I, _I]),
     "hm_debug_sweep_caps": (_I, [_I]),

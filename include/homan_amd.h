@@ -167,6 +167,11 @@ int hm_tune_sweep_blocks(int blocks);
  * rasteriser workgroups instead of 6, which leaves registers / LDS for the kernels of the caller's other stream).  Process-wide,
  * read when hm_sil_fwd is called (or captured).  Returns the previous value; bytes < 0 only queries. */
 int hm_tune_raster_lds_pad(int bytes);
+/* Scheduling hint, no effect on results: adaptive launch order of the rasteriser's workgroups.  While on, the forward launches
+ * record the time every workgroup took and the backward's first launch re-sorts the order, longest first, for the next forward
+ * of the same workspace (the `work_order` argument only seeds it): what is expensive moves during a fit.  enable > 0 / 0 / < 0
+ * (query).  Process-wide, read when hm_sil_fwd / hm_sil_bwd are called (or captured).  Returns the previous value. */
+int hm_tune_raster_reorder(int enable);
 /* Same for the metric-only nearest-vertex search (small latency-bound workgroups that otherwise take every wave slot of a CU
  * next to the kernel they overlap): 65536 = two search workgroups per CU. */
 int hm_tune_nn_lds_pad(int bytes);

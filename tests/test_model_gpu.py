@@ -251,6 +251,29 @@ def test_joint_fit_resume_roundtrip(mano_model, tmp_path):
         assert torch.equal(la[k], lb[k]), k
 
 
+def test_adaptive_raster_order_is_invisible_to_the_results(mano_model, monkeypatch):
+    """hm_tune_raster_reorder: the rasteriser's workgroups record what they cost and the backward's first launch re-sorts the
+    launch order for the next forward (a scheduling hint captured with the iteration).  Ten iterations with the hint forced on
+    and forced off give bit-identical loss rows and parameters: the order kept in the workspace stays a permutation of the
+    (frame, region) entries - a region rendered twice or not at all would show in the moving silhouettes."""
+    from homan_amd import lib as hl
+    from homan_amd.jointopt import FusedStepper
+    name, steps = "ref_step2_cube_b4_s64", 10
+    outs = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("HOMAN_RASTER_REORDER", on)
+        rec, model, weights, meta = _build_hip(name, mano_model, sync=False)
+        st = FusedStepper(model, weights, meta["lr"], steps)
+        assert hl.lib().hm_tune_raster_reorder(-1) == 0          # (the hint is restored after the capture)
+        st.run(steps)
+        outs.append((st.loss_evolution(steps), {k: v.detach().clone() for k, v in model.named_parameters()}))
+    (evo_a, par_a), (evo_b, par_b) = outs
+    for k in evo_a:
+        np.testing.assert_array_equal(np.asarray(evo_a[k]), np.asarray(evo_b[k]), err_msg=k)
+    for k in par_a:
+        assert torch.equal(par_a[k], par_b[k]), k
+
+
 def test_in_graph_timestamps_are_invisible_to_the_results(mano_model):
     """hm_sil_timestamps: the three heavy kernels of the silhouette chain stamp the device wall clock while they are replayed
     from the captured hipGraph (bench.py's roofline timing).  The durations are positive and sane, and the optimisation - loss
