@@ -147,6 +147,12 @@ __device__ __forceinline__ void inter_body(const float* __restrict__ vh, const f
 }
 
 // metric-only nearest-vertex search (reference homan/losses.py:225-241): see k_nn_min
+#ifdef NN_PHASES
+static __device__ unsigned long long g_nn_ph[10];     // wall-clock ticks of thread 0, summed over workgroups: loads+spheres, bounds, list, scan, reduce+ticket, finish; workgroups; survivors
+#define NNP_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_nn_ph[k], t_ - nnp_t); nnp_t = t_; } } while (0)
+#else
+#define NNP_MARK(k)
+#endif
 __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const float* __restrict__ vo, int B, int Vh, int Vo,
                                             float* __restrict__ blockmin, unsigned int* counter,
                                             float* __restrict__ metric_out, int clip_len, int out_stride,
@@ -154,17 +160,22 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
                                             const float* __restrict__ sph_mesh = nullptr,
                                             const float* __restrict__ obj_rot6d = nullptr,
                                             const float* __restrict__ obj_trans = nullptr,
-                                            const float* __restrict__ obj_scale = nullptr)
+                                            const float* __restrict__ obj_scale = nullptr,
+                                            const int* __restrict__ hand_order = nullptr)
 {
     __shared__ float s_sph[NN_MAX_GROUPS][4];
     __shared__ float s_lb[NN_MAX_GROUPS];
     __shared__ unsigned s_ub;
+    __shared__ int s_first[NN_WAVES];
     __shared__ int s_list[NN_MAX_GROUPS], s_n;
     __shared__ float s_d[NN_WAVES][NN_HV];
     __shared__ float red[16];
     __shared__ int s_flag;
     const int b = by, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     const int ng = (Vo + 63) >> 6;
+#ifdef NN_PHASES
+    unsigned long long nnp_t = wall_clock64();
+#endif
     float hx[2], hy[2], hz[2];
     bool hv[2];
 #pragma unroll
@@ -172,9 +183,12 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
         const int i = bx * NN_HV + lane + 64 * u;
         hv[u] = i < Vh;
         hx[u] = hy[u] = hz[u] = 0.f;
-        if (hv[u]) { const float* p = vh + ((long)b * Vh + i) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2]; }
+        // (hand_order: a spatial sort of the hand's vertices - the minimum does not care which vertex sits in which lane, and
+        //  a workgroup whose 128 vertices are one patch of the hand instead of a sample of all of it has few groups in reach)
+        if (hv[u]) { const float* p = vh + ((long)b * Vh + (hand_order ? hand_order[i] : i)) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2]; }
     }
-    if (threadIdx.x == 0) { s_ub = 0x7f7fffffu; s_n = 0; }
+    if (threadIdx.x == 0) { s_ub = 0x7f7fffffu; s_n = 0; }      // (s_ub: smallest exact squared distance of the first scans)
+    if (threadIdx.x < NN_WAVES) s_first[threadIdx.x] = -1;
     if (sph_mesh && (int)threadIdx.x < ng) {
         // the object is rigid: the bounding spheres of its groups are a table in MESH space (built once by the caller), and a
         // lane per group carries centre and radius into this frame's camera space - instead of every workgroup loading and
@@ -192,6 +206,7 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
         s_sph[threadIdx.x][3] = sc * c[3] * (1.0f + 1e-4f) + 1e-6f;      // (slack for the rounding of both transforms)
     }
     __syncthreads();
+    NNP_MARK(0);
     // 1 + 2: spheres and bounds of this wave's groups
     for (int g = q; g < ng; g += NN_WAVES) {
         float cx, cy, cz, rg;
@@ -213,19 +228,27 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
                 dc = fminf(dc, sqrtf(dx * dx + dy * dy + dz * dz));
             }
         dc = hm_wave_min(dc);
-        if (lane == 0) {
-            s_lb[g] = dc * (1.0f - 1e-5f) - rg;
-            atomicMin(&s_ub, __float_as_uint((dc * (1.0f + 1e-5f) + rg)));      // positive floats order like their bits
+        if (lane == 0) s_lb[g] = dc * (1.0f - 1e-5f) - rg;      // no vertex of the group is closer to any of the 128
+    }
+    __syncthreads();
+    NNP_MARK(1);
+    // 3: the NN_WAVES groups with the smallest lower bounds are scanned first, one per wave: the smallest exact distance
+    // found there is a far tighter upper bound than "centre distance + radius" (with a hand that touches the object nearly
+    // every group passed that test: 21.5 of 24 at cfg2) ...
+    int rank = NN_MAX_GROUPS;
+    if ((int)threadIdx.x < ng) {
+        const float mine = s_lb[threadIdx.x];
+        rank = 0;
+        for (int g = 0; g < ng; ++g) {
+            const float o = s_lb[g];
+            rank += (o < mine || (o == mine && g < (int)threadIdx.x)) ? 1 : 0;
         }
     }
     __syncthreads();
-    // 3: groups that can hold the minimum
-    if ((int)threadIdx.x < ng && s_lb[threadIdx.x] <= __uint_as_float(s_ub)) s_list[atomicAdd(&s_n, 1)] = threadIdx.x;
+    if (rank < NN_WAVES) { s_first[rank] = threadIdx.x; s_lb[threadIdx.x] = 3.4e38f; }      // (scanned below: never listed again)
     __syncthreads();
-    const int ns = s_n;
     float best[2] = {3.4e38f, 3.4e38f};
-    for (int e = q; e < ns; e += NN_WAVES) {
-        const int g = s_list[e];
+    auto scan_group = [&](const int g) {
         const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
         float ox = 0.f, oy = 0.f, oz = 0.f;
         if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
@@ -237,15 +260,37 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
                 best[u] = fminf(best[u], dx * dx + dy * dy + dz * dz);
             }
         }
+    };
+    if (s_first[q] >= 0) {
+        scan_group(s_first[q]);
+        const float wm = hm_wave_min(fminf(hv[0] ? best[0] : 3.4e38f, hv[1] ? best[1] : 3.4e38f));
+        if (lane == 0) atomicMin(&s_ub, __float_as_uint(wm));          // squared distance, positive
     }
+    __syncthreads();
+    // ... 4: and only the groups whose lower bound does not exceed it are scanned as well
+    const float ub_exact = sqrtf(__uint_as_float(s_ub)) * (1.0f + 1e-5f) + 1e-7f;
+    if ((int)threadIdx.x < ng && s_lb[threadIdx.x] <= ub_exact) s_list[atomicAdd(&s_n, 1)] = threadIdx.x;
+    __syncthreads();
+    const int ns = s_n;
+    NNP_MARK(2);
+#ifdef NN_PHASES
+    if (threadIdx.x == 0) { atomicAdd(&g_nn_ph[6], 1ull); atomicAdd(&g_nn_ph[7], (unsigned long long)ns); }
+#endif
+    for (int e = q; e < ns; e += NN_WAVES) scan_group(s_list[e]);
     float bm = fminf(hv[0] ? best[0] : 3.4e38f, hv[1] ? best[1] : 3.4e38f);
+#ifdef NN_PHASES
+    __syncthreads();
+    NNP_MARK(3);
+#endif
     bm = hm_block_min(bm, red);
     const int clip = b / clip_len, bl = b - clip * clip_len;
     blockmin += (long)clip * HM_RED_WS_FLOATS;
     counter += (long)clip * HM_RED_WS_FLOATS;
     const unsigned nblk = gdx * clip_len;
     if (threadIdx.x == 0) hm_partial_store(blockmin + bl * gdx + bx, bm);
-    if (hm_last_block(counter, nblk, &s_flag)) {
+    const bool nn_last_blk = hm_last_block(counter, nblk, &s_flag);
+    NNP_MARK(4);
+    if (nn_last_blk) {
         float* s_bm = &s_d[0][0];
         for (unsigned i2 = threadIdx.x; i2 < nblk; i2 += blockDim.x) s_bm[i2] = hm_partial_load(blockmin + i2);
         __syncthreads();

@@ -25,14 +25,15 @@ __global__ __launch_bounds__(256) void k_pair_terms(
     // smoothness of the object vertices (sm_nblk x clips blocks; out_smooth == NULL: none)
     int sm_nblk, float* __restrict__ unit_smooth, float* __restrict__ sm_partials, unsigned int* sm_counter,
     float* __restrict__ out_smooth, HandTerms ht, int clips, const float* __restrict__ sph_mesh,
-    const float* __restrict__ obj_rot6d, const float* __restrict__ obj_trans, const float* __restrict__ obj_scale)
+    const float* __restrict__ obj_rot6d, const float* __restrict__ obj_trans, const float* __restrict__ obj_scale,
+    const int* __restrict__ hand_order)
 {
     HM_HAND_KERNEL();
     int i = blockIdx.x;
     const int n_nn = metric_out ? nchunk * B : 0, n_in = out_inter ? B : 0;
     if (i < n_nn) {
         nn_min_body(vh, vo, B, Vh, Vo, nn_blockmin, nn_counter, metric_out, clip_len, out_stride, obj_order, i % nchunk,
-                    i / nchunk, nchunk, sph_mesh, obj_rot6d, obj_trans, obj_scale);
+                    i / nchunk, nchunk, sph_mesh, obj_rot6d, obj_trans, obj_scale, hand_order);
         return;
     }
     i -= n_nn;
@@ -60,7 +61,7 @@ extern "C" {
 //   out_inter    -> hm_inter_fwd_clips(...)                             frame records `frame_rec`    workspace ws_inter
 //   out_smooth   -> hm_smooth_fwd_clips(verts_obj, ..., hand_nb = 1)    unit gradient `unit_smooth`  workspace ws_smooth
 //   ht_out_v2d2  -> hm_hand_terms_fwd_clips(verts_hand, camintr, hand_nb = 1, ...) (one hand per frame)      workspace ws_hand
-//   obj_spheres / obj_rot6d / obj_trans / obj_scale: optional, see hm_nn_fwd_rigid_clips (scheduling data of the search)
+//   obj_spheres / obj_rot6d / obj_trans / obj_scale / hand_order: optional, see hm_nn_fwd_rigid_clips (scheduling data of the search)
 // The reduce workspaces (hm_reduce_workspace_bytes() per clip each) must be distinct: the terms run concurrently.
 int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, const float* camintr, int B, int Vh, int Vo,
                             float* metric_out, const int* obj_order, void* ws_nn, float expansion, float zthresh,
@@ -71,7 +72,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                             const float* ht_s_obj, const float* ht_m_obj, const float* ht_s_hand, const float* ht_m_hand,
                             float* ht_g_pca, float* ht_g_sobj, float* ht_g_shand, float* ht_out_priors3, void* ws_hand,
                             const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
-                            int clip_len, int out_stride, hipStream_t stream)
+                            const int* hand_order, int clip_len, int out_stride, hipStream_t stream)
 {
     HM_CHECK_ARG(!obj_spheres || (obj_rot6d && obj_trans && obj_scale));
     HM_CHECK_ARG(verts_hand && verts_obj && B > 0 && Vh > 0 && Vo > 0 && HM_CLIP_LEN_OK(B, clip_len));
@@ -97,7 +98,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                        obj_order, expansion, zthresh, frame_rec,
                        ws_inter ? (unsigned int*)((float*)ws_inter + 512) : nullptr, out_inter, sm_nblk, unit_smooth,
                        (float*)ws_smooth, ws_smooth ? (unsigned int*)((float*)ws_smooth + 512) : nullptr, out_smooth, ht, clips,
-                       obj_spheres, obj_rot6d, obj_trans, obj_scale);
+                       obj_spheres, obj_rot6d, obj_trans, obj_scale, hand_order);
     return hm_launch_status();
 }
 }  // extern "C"

@@ -339,6 +339,9 @@ class FusedStepper:
         self.nn_idx = torch.zeros(B, Vh, dtype=torch.int32, device=dev)
         self.nn_d2 = f(B, Vh)
         self.obj_order = _morton_order(m.verts_object_og[0]).to(dev)      # spatial sort of the rigid mesh (metric-only search)
+        # ... and of the hand: its template's vertices in the same kind of order, so that the 128 hand vertices of a search
+        # workgroup are a patch of the hand, not a sample of all of it (articulation moves the patches, it does not mix them)
+        self.hand_order = _morton_order(m.mano_model.ctx_mean.tensors[0]).to(dev)
         # bounding spheres, in MESH space, of the groups of 64 vertices in that order, per frame (a clip's frames share one mesh,
         # the clips of a batch need not): centre = mean, radius = farthest vertex.  The search carries them into camera space
         # with the frame's rigid transform instead of reducing the transformed vertices of every group in every workgroup.
@@ -425,12 +428,11 @@ class FusedStepper:
             pad = int(pad) if pad is not None else (4096 if (self.on["col"] or self.on["con"]) and C == 1 else 0)
             prev_pad = _lib.lib().hm_tune_raster_lds_pad(pad)
             # the raster's launch order follows the measured cost of its workgroups from iteration to iteration
-            # (hm_tune_raster_reorder; same-box A/B: raster 57 -> 45 us inside the graph at one clip, 356 -> 298 us at eight.  The
-            # iteration gains 0.3-1 % where the silhouette chain is the longer one - clip batches, the step-2 loss sets - and 2 %
-            # over iterations 5-25 of a step-1 fit; in the steady state of a one-clip step-1 fit the hand-side stream has
-            # been running in the raster's tail and then lands on the lines and the sweeps: -4 %, so not there)
-            ro = os.environ.get("HOMAN_RASTER_REORDER")
-            ro = int(ro) if ro is not None else int(C > 1 or self.on["col"] or self.on["con"])
+            # (hm_tune_raster_reorder; same-box A/B: raster 57 -> 45 us inside the graph at one clip, 356 -> 298 us at eight; the
+            # iteration: clip batches and the step-2 sets +0.3..1 %, one-clip step-1 fits +4 % in the steady state and over
+            # iterations 5-25 - but only since the metric-only search got shorter: while the hand-side chain was as long as the
+            # silhouette chain it had been running in the raster's tail and a shorter raster pushed it under the sweeps, -4 %)
+            ro = int(os.environ.get("HOMAN_RASTER_REORDER", "1"))
             prev_reorder = _lib.lib().hm_tune_raster_reorder(ro)
             # and for the metric-only search of a clip batch: its 1680 small, latency-bound workgroups otherwise take every wave
             # slot of the CUs next to the line expansion (lines 250 -> 226 us, iteration -4.4 % at 3 search workgroups per CU;
@@ -623,7 +625,7 @@ class FusedStepper:
                     ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if on["con"] else None,
                                                P(self.nn_d2) if on["con"] else None, self._slot("handobj_maxdist"), rws, CL, NS,
                                                P(self.obj_order), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                               P(m.translations_object), P(m.int_scales_object), sx), "nn")
+                                               P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sx), "nn")
                 if on["con"]:
                     ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
                                               P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws, CL, NS, sx),
@@ -646,7 +648,8 @@ class FusedStepper:
                                              *(ht_args if ht_fused else (None, 0.0, None, None, None, None, None, 0, None, None,
                                                                          None, None, None, None, None, None)),
                                              P(self.reduce_ws_e.buf), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                             P(m.translations_object), P(m.int_scales_object), CL, NS, sb), "pair terms")
+                                             P(m.translations_object), P(m.int_scales_object), P(self.hand_order), CL, NS, sb),
+                   "pair terms")
             elif on["inter"]:
                 ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
                                         float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws_b, CL,

@@ -362,6 +362,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                             const float* ht_s_obj, const float* ht_m_obj, const float* ht_s_hand, const float* ht_m_hand,
                             float* ht_g_pca, float* ht_g_sobj, float* ht_g_shand, float* ht_out_priors3, void* ws_hand,
                             const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
+                            const int* hand_order,
                             int clip_len, int out_stride, hipStream_t stream);
 /* obj_order (Vo) optional, metric-only calls: a permutation of the object vertices, visited in that order (a spatial sort of
  * the rigid mesh makes 64 consecutive vertices a compact patch: scheduling only, the result is the exact minimum) */
@@ -376,6 +377,7 @@ int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int 
 int hm_nn_fwd_rigid_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
                           float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
                           const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
+                            const int* hand_order,
                           hipStream_t stream);
 int hm_contact_fwd_clips(const float* verts_hand, const float* verts_obj, const int* nn_idx, int B, int Vh, int Vo,
                          float thresh, float* g_hand, float* g_obj, float* out1, void* workspace, int clip_len,

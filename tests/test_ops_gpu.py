@@ -254,7 +254,7 @@ def test_pair_terms_launch_equals_its_four_entry_points():
             hl.check(L.hm_pair_terms_fwd_clips(P(vh), P(vo), P(camintr), B, Vh, Vo, slot(6), P(order), P(ws[0].buf),
                                                c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(rec), slot(7),
                                                P(ws[1].buf), P(u_smo), slot(8), P(ws[2].buf), *ht, P(ws[3].buf), None, None, None, None,
-                                               CL, stride, stream), "pair terms")
+                                               None, CL, stride, stream), "pair terms")
         else:
             hl.check(L.hm_nn_fwd_clips(P(vh), P(vo), B, Vh, Vo, None, None, slot(6), P(ws[0].buf), CL, stride, P(order), stream),
                      "nn")
@@ -335,14 +335,17 @@ def test_metric_search_with_rigid_group_spheres_is_exact():
     rad = ((vs - ctr[:, :, None]) ** 2).sum(-1).sqrt().amax(2)
     spheres = torch.cat([ctr, rad[..., None]], -1).contiguous()
     outs = []
-    for sph in (None, spheres):
+    # (and with the hand's vertices dealt to the workgroups in another order - a spatial sort in the loop, any permutation here)
+    perm = torch.randperm(Vh, generator=torch.Generator().manual_seed(3)).to(device=DEV, dtype=torch.int32)
+    for sph, ho in ((None, None), (spheres, None), (spheres, perm), (None, perm)):
         out = torch.zeros(C, 5, device=DEV)
         ws = ClipReduceWorkspace(DEV, C)
         hl.check(L.hm_nn_fwd_rigid_clips(P(vh), P(vo), B, Vh, Vo, None, None, P(out), P(ws.buf), CL, 5, P(order),
                                          P(sph) if sph is not None else None, P(rot6d), P(trans.reshape(B, 3).contiguous()),
-                                         P(scale), hl.stream()), "nn")
+                                         P(scale), P(ho) if ho is not None else None, hl.stream()), "nn")
         torch.cuda.synchronize()
         outs.append(out[:, 0].clone())
-    assert torch.equal(outs[0], outs[1])
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o)
     d = torch.cdist(vh.double(), vo.double()).amin((1, 2)).reshape(C, CL).amax(1)
     np.testing.assert_allclose(outs[1].cpu().numpy(), d.cpu().numpy(), rtol=1e-5)
