@@ -247,23 +247,29 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
     __syncthreads();
     if (rank < NN_WAVES) { s_first[rank] = threadIdx.x; s_lb[threadIdx.x] = 3.4e38f; }      // (scanned below: never listed again)
     __syncthreads();
-    float best[2] = {3.4e38f, 3.4e38f};
+    // running minima as the BITS of the squared distances (non-negative floats order like their bits: one integer min per
+    // pair instead of a NaN-quieting float min), four object vertices per trip with the trip count in a scalar: a wave is
+    // alone on its SIMD here, so the four independent chains are what hides the arithmetic latency
+    unsigned bestu[2] = {0x7f7fffffu, 0x7f7fffffu};
     auto scan_group = [&](const int g) {
-        const int j = 64 * g + lane, n = min(64, Vo - 64 * g);
+        const int j = 64 * g + lane, n = __builtin_amdgcn_readfirstlane(min(64, Vo - 64 * g));
         float ox = 0.f, oy = 0.f, oz = 0.f;
         if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
-        for (int k = 0; k < n; ++k) {
+        auto step = [&](const int k) {
             const float sx = rl_f(ox, k), sy = rl_f(oy, k), sz = rl_f(oz, k);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const float dx = sx - hx[u], dy = sy - hy[u], dz = sz - hz[u];
-                best[u] = fminf(best[u], dx * dx + dy * dy + dz * dz);
+                bestu[u] = min(bestu[u], __float_as_uint(dx * dx + dy * dy + dz * dz));
             }
-        }
+        };
+        int k = 0;
+        for (; k + 4 <= n; k += 4) { step(k); step(k + 1); step(k + 2); step(k + 3); }
+        for (; k < n; ++k) step(k);
     };
     if (s_first[q] >= 0) {
         scan_group(s_first[q]);
-        const float wm = hm_wave_min(fminf(hv[0] ? best[0] : 3.4e38f, hv[1] ? best[1] : 3.4e38f));
+        const float wm = hm_wave_min(fminf(hv[0] ? __uint_as_float(bestu[0]) : 3.4e38f, hv[1] ? __uint_as_float(bestu[1]) : 3.4e38f));
         if (lane == 0) atomicMin(&s_ub, __float_as_uint(wm));          // squared distance, positive
     }
     __syncthreads();
@@ -277,7 +283,7 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
     if (threadIdx.x == 0) { atomicAdd(&g_nn_ph[6], 1ull); atomicAdd(&g_nn_ph[7], (unsigned long long)ns); }
 #endif
     for (int e = q; e < ns; e += NN_WAVES) scan_group(s_list[e]);
-    float bm = fminf(hv[0] ? best[0] : 3.4e38f, hv[1] ? best[1] : 3.4e38f);
+    float bm = fminf(hv[0] ? __uint_as_float(bestu[0]) : 3.4e38f, hv[1] ? __uint_as_float(bestu[1]) : 3.4e38f);
 #ifdef NN_PHASES
     __syncthreads();
     NNP_MARK(3);

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     // dispatch order = work_order[block] = (frame << 16 | region): expensive (frame, region) pairs first so that the
     // cheap ones fill the tail of the launch (default: centre of the ROI outwards; calibrated: by candidate count)
     // Adaptive order (hm_tune_raster_reorder, wo_dyn != NULL): every workgroup leaves the time it took in wg_cost and the
-    // entry it served in wo_dyn; a workgroup of the backward's first launch sorts the entries by that time, longest first,
+    // entry it served in wo_dyn; a workgroup of the backward's sweep launch sorts the entries by that time, longest first,
     // for the NEXT forward of this workspace (hint word 2 then says "use wo_dyn").  What is expensive moves during a fit;
     // an order taken from the poses at its start is stale after a few dozen iterations.
     const bool dyn = wo_dyn && hint[2] != 0u;
@@ -1143,9 +1143,9 @@ struct SweepSrc { int d1; float g; int owner; };
 // workgroups took in this one, longest first (counting sort on 40 ns units, 1024 bins; the order inside a bin is whatever the
 // LDS atomics give: scheduling only, results do not depend on the order).  wo_dyn (n) is rewritten through wo_tmp (n).
 __device__ __forceinline__ void raster_reorder(int* __restrict__ wo_dyn, int* __restrict__ wo_tmp,
-                                               const unsigned int* __restrict__ wg_cost, unsigned int* __restrict__ dyn_flag, int n)
+                                               const unsigned int* __restrict__ wg_cost, unsigned int* __restrict__ dyn_flag, int n,
+                                               unsigned* __restrict__ s_hist)       // 1024 words of the caller's LDS
 {
-    __shared__ unsigned s_hist[1024];
     __shared__ unsigned s_wsum[4];
     __shared__ unsigned s_zero;          // entries of idle workgroups (time 0: most of a clip's regions are background): they go
                                          // last in any order, placed by wave ballots - thousands of LDS atomics on ONE bin serialise
@@ -1224,22 +1224,13 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    const float* __restrict__ red_partials, float* __restrict__ frame_rec,
                                                    float* __restrict__ loss_out, int out_stride,
                                                    const unsigned int* __restrict__ ts_flag,
-                                                   unsigned long long* __restrict__ ts_slots, int nsort,
-                                                   int* __restrict__ wo_dyn, int* __restrict__ wo_tmp,
-                                                   const unsigned int* __restrict__ wg_cost,
-                                                   unsigned int* __restrict__ dyn_flag, int n_wo)
+                                                   unsigned long long* __restrict__ ts_slots)
 {
     HM_CHAIN_KERNEL();
     const unsigned long long ts_t0 = (unsigned long long)wall_clock64();
     const bool ts_on = hm_ts_enabled(ts_flag) && threadIdx.x == 0;
     if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 0, ts_t0);
-    // (optional first workgroup: the raster's launch order for the next forward, see raster_reorder)
-    if (nsort && blockIdx.x == 0) {
-        raster_reorder(wo_dyn, wo_tmp, wg_cost, dyn_flag, n_wo);
-        if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
-        return;
-    }
-    const int blk = (int)blockIdx.x - nsort;
+    const int blk = (int)blockIdx.x;
     __shared__ unsigned long long s_w[16][SWEEP_CUMW];
     __shared__ int s_ex[16][SWEEP_CUMW];
     // the first `ncomp` workgroups build the work list of the edge sweeps (independent of the lines: one launch for both)
@@ -1432,7 +1423,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                                                    const unsigned short* __restrict__ lsum,
                                                    const unsigned short* __restrict__ alpha16,
                                                    const unsigned int* __restrict__ ts_flag,
-                                                   unsigned long long* __restrict__ ts_slots)
+                                                   unsigned long long* __restrict__ ts_slots, int nsort,
+                                                   int* __restrict__ wo_dyn, int* __restrict__ wo_tmp,
+                                                   const unsigned int* __restrict__ wg_cost,
+                                                   unsigned int* __restrict__ dyn_flag, int n_wo)
 {
     // LDS copies are padded to an ODD number of dwords (17 / 9): lanes reading the same field of different faces / items
     // then fall into different banks (64- and 32-byte strides put every second / fourth element on the same bank)
@@ -1450,6 +1444,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
     __shared__ unsigned short s_q[4][SWEEP_UNIT];
     __shared__ int2 s_fam[4][SWEEP_PASS_FACES][12];      // per (face of the pass, family): see sweep_item_lite
     __shared__ int s_fb[4][SWEEP_PASS_FACES][2];         // per (face, axis): range of the inward sweeps, lo | hi << 16
+    // (optional workgroup 0: the forward raster's launch order for the next iteration, see raster_reorder - it rides this launch,
+    //  the longest of the backward, so that it is nobody's tail; its histogram lives in s_head)
+    if (nsort && blockIdx.x == 0) {
+        raster_reorder(wo_dyn, wo_tmp, wg_cost, dyn_flag, n_wo, reinterpret_cast<unsigned*>(&s_head[0][0]));
+        if (ts_on) hm_ts_store(ts_slots, (long)blockIdx.x * 4 + (threadIdx.x >> 6), 1, (unsigned long long)wall_clock64());
+        return;
+    }
+    const int wid = (int)blockIdx.x - nsort, nwork = (int)gridDim.x - nsort;      // worker index / count (a multiple of 8)
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int is = 2 * S;
     const bool pow2 = (is & (is - 1)) == 0;
@@ -1462,13 +1464,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
     // item list is frame-major.  Each XCD therefore takes one contiguous eighth of the units (~ B/8 whole frames): the
     // index-map lines, line records and source slices of a frame are then fetched into ONE L2 instead of eight (speed
     // only: nothing depends on where a workgroup really runs).  gridDim.x is a multiple of 8.
-    const int xcd = blockIdx.x & 7;
-    const int xwaves = (int)(gridDim.x >> 3) * 4;
+    const int xcd = wid & 7;
+    const int xwaves = (nwork >> 3) * 4;
     const int u_end = (int)(((long)U * (xcd + 1)) >> 3);
     // (a unit's first face comes from the unit table; the wave requests the NEXT unit's entry together with the current
     //  unit's records, so only a wave's first unit pays that round trip)
     int first_ahead = -1;
-    for (int u = __builtin_amdgcn_readfirstlane((int)(((long)U * xcd) >> 3) + (int)(blockIdx.x >> 3) * 4 + wv); u < u_end;
+    for (int u = __builtin_amdgcn_readfirstlane((int)(((long)U * xcd) >> 3) + (wid >> 3) * 4 + wv); u < u_end;
          u += xwaves) {
         const int ubeg = u << SWEEP_USHIFT, uend = ubeg + SWEEP_UNIT;
 #ifdef SWEEP_UNIT_PROFILE
@@ -2250,20 +2252,20 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
     // whether it is launched alone or in a batch
     const int fpt = (long)clip_len * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks
     const int ncomp = (B / clip_len) * hm_cdiv((long)clip_len * F, 256 * fpt);
-    const int nsort = g_raster_reorder ? 1 : 0;      // (see hm_tune_raster_reorder)
-    hipLaunchKernelGGL(k_bwd_lines, dim3(nsort + ncomp + nred + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
+    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + nred + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
                        w.owned, F, w.parts, w.sweep, clip_len, w.lsum, nred, w.partials, w.frame_rec, loss_out, out_stride,
-                       w.counter + 24, w.ts + 2 * ts_raster_units(B, S), nsort, w.wo_dyn, w.wo_tmp, w.wg_cost, w.counter + 26,
-                       (int)ts_raster_units(B, S));
+                       w.counter + 24, w.ts + 2 * ts_raster_units(B, S));
 }
 static int g_sweep_blocks = SWEEP_BLOCKS;
 static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
 {
-    const int blocks = max(8, min(min(hm_cdiv((long)B * F, 2), g_sweep_blocks), TS_SWEEP_WGS) & ~7);   // a multiple of 8: see the unit loop
-    hipLaunchKernelGGL(k_bwd_sweep, dim3(blocks), dim3(256), 0, stream, w.sweep,
+    const int nsort = g_raster_reorder ? 1 : 0;      // (see hm_tune_raster_reorder: one workgroup more, eight workers less)
+    const int blocks = max(8, (min(min(hm_cdiv((long)B * F, 2), g_sweep_blocks), TS_SWEEP_WGS - 8) & ~7) - 8 * nsort);   // workers: a multiple of 8, see the unit loop
+    hipLaunchKernelGGL(k_bwd_sweep, dim3(nsort + blocks), dim3(256), 0, stream, w.sweep,
                        w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts, w.lsum, w.alpha16, w.counter + 24,
-                       w.ts + 2 * (ts_raster_units(B, S) + ts_lines_units(B, F, S)));
+                       w.ts + 2 * (ts_raster_units(B, S) + ts_lines_units(B, F, S)), nsort, w.wo_dyn, w.wo_tmp, w.wg_cost,
+                       w.counter + 26, (int)ts_raster_units(B, S));
 }
 
 // Scheduling hint, no effect on results: bytes of unused dynamic LDS added to every k_raster_fwd launch.  The rasteriser's
