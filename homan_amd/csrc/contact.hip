@@ -12,91 +12,15 @@
 
 #define NN_THREADS 256
 
-// grid (ceil(Vh/128), B).  Workgroup = 128 hand vertices (two per lane: the pair shares every broadcast and the packed
-// fp32 pipes take both) x NN_WAVES wavefronts; wave q scans an equal contiguous share of the object vertices 64 at a
-// time: lane l loads object vertex l of the group (coalesced), the group is then broadcast vertex by vertex with
-// v_readlane (scalar operands, no LDS round trip in the inner loop).  The partial minima are merged lexicographically
-// on (distance, index) so ties keep the lowest index.
+// grid (ceil(Vh/128), B): nn_full_body (pair_bodies.h) as a launch of its own
 __global__ __launch_bounds__(64 * NN_WAVES) void k_nn(const float* __restrict__ vh, const float* __restrict__ vo, int B,
                                                        int Vh, int Vo, int* __restrict__ nn_idx, float* __restrict__ nn_d2,
                                                        float* __restrict__ blockmin, unsigned int* counter,
                                                        float* __restrict__ metric_out, int clip_len, int out_stride)
 {
     HM_LATENCY_KERNEL();
-    __shared__ float s_d[NN_WAVES][NN_HV];
-    __shared__ int s_i[NN_WAVES][NN_HV];
-    __shared__ float red[16];
-    __shared__ int s_flag;
-    const int b = blockIdx.y, lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    float hx[2], hy[2], hz[2], best[2];
-    int besti[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = blockIdx.x * NN_HV + lane + 64 * u;
-        hx[u] = hy[u] = hz[u] = 0.f;
-        if (i < Vh) { const float* p = vh + ((long)b * Vh + i) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2]; }
-        best[u] = 3.4e38f;
-        besti[u] = 0;
-    }
-    const int share = (Vo + NN_WAVES - 1) / NN_WAVES, jend = min(Vo, (q + 1) * share);
-    for (int j0 = q * share; j0 < jend; j0 += 64) {
-        const int n = min(64, jend - j0);
-        float ox = 0.f, oy = 0.f, oz = 0.f;
-        if (lane < n) { const float* p = vo + ((long)b * Vo + j0 + lane) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
-        int k = 0;
-#define NN_STEP(K)                                                                                   \
-    {                                                                                                \
-        const float sx = rl_f(ox, (K)), sy = rl_f(oy, (K)), sz = rl_f(oz, (K));                      \
-        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                              \
-            const float dx = sx - hx[u], dy = sy - hy[u], dz = sz - hz[u];                           \
-            const float d = dx * dx + dy * dy + dz * dz;                                             \
-            const bool lt = d < best[u];                                                             \
-            best[u] = lt ? d : best[u];                                                              \
-            besti[u] = lt ? j0 + (K) : besti[u];                                                     \
-        }                                                                                            \
-    }
-        for (; k + 4 <= n; k += 4) { NN_STEP(k) NN_STEP(k + 1) NN_STEP(k + 2) NN_STEP(k + 3) }
-        for (; k < n; ++k) NN_STEP(k)
-#undef NN_STEP
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { s_d[q][lane + 64 * u] = best[u]; s_i[q][lane + 64 * u] = besti[u]; }
-    __syncthreads();
-    float bm = 3.4e38f;
-    if (threadIdx.x < NN_HV) {
-        const int t = threadIdx.x, i = blockIdx.x * NN_HV + t;
-        float bd = s_d[0][t];
-        int bi = s_i[0][t];
-#pragma unroll
-        for (int k = 1; k < NN_WAVES; ++k) {
-            const float d = s_d[k][t];
-            const int id = s_i[k][t];
-            if (d < bd || (d == bd && id < bi)) { bd = d; bi = id; }
-        }
-        if (i < Vh) { nn_idx[(long)b * Vh + i] = bi; nn_d2[(long)b * Vh + i] = bd; bm = bd; }
-    }
-    bm = hm_block_min(bm, red);
-    // per clip (clip_len consecutive frames): its own slice of the reduce workspace, its own ticket, its own metric
-    const int clip = b / clip_len, bl = b - clip * clip_len;
-    blockmin += (long)clip * HM_RED_WS_FLOATS;
-    counter += (long)clip * HM_RED_WS_FLOATS;
-    const unsigned nblk = gridDim.x * clip_len;
-    if (threadIdx.x == 0) hm_partial_store(blockmin + bl * gridDim.x + blockIdx.x, bm);
-    if (hm_last_block(counter, nblk, &s_flag)) {
-        // all block minima requested at once (one agent-scope load per thread), then min over a frame's chunks, max over
-        // the frames
-        float* s_bm = &s_d[0][0];
-        for (unsigned i2 = threadIdx.x; i2 < nblk; i2 += blockDim.x) s_bm[i2] = hm_partial_load(blockmin + i2);
-        __syncthreads();
-        float mx = -3.4e38f;
-        for (int bb = threadIdx.x; bb < clip_len; bb += blockDim.x) {
-            float m = 3.4e38f;
-            for (unsigned c = 0; c < gridDim.x; ++c) m = fminf(m, s_bm[bb * gridDim.x + c]);
-            mx = fmaxf(mx, sqrtf(m));
-        }
-        mx = hm_block_max(mx, red);
-        if (threadIdx.x == 0) metric_out[(long)clip * out_stride] = mx;
-    }
+    nn_full_body(vh, vo, B, Vh, Vo, nn_idx, nn_d2, blockmin, counter, metric_out, clip_len, out_stride, blockIdx.x, blockIdx.y,
+                 gridDim.x);
 }
 
 // METRIC ONLY (the step-1 loss sets, where the search feeds nothing but the logged hand-object distance of reference

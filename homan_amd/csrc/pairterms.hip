@@ -26,14 +26,18 @@ __global__ __launch_bounds__(256) void k_pair_terms(
     int sm_nblk, float* __restrict__ unit_smooth, float* __restrict__ sm_partials, unsigned int* sm_counter,
     float* __restrict__ out_smooth, HandTerms ht, int clips, const float* __restrict__ sph_mesh,
     const float* __restrict__ obj_rot6d, const float* __restrict__ obj_trans, const float* __restrict__ obj_scale,
-    const int* __restrict__ hand_order)
+    const int* __restrict__ hand_order, int* __restrict__ nn_idx, float* __restrict__ nn_d2)
 {
     HM_HAND_KERNEL();
     int i = blockIdx.x;
     const int n_nn = metric_out ? nchunk * B : 0, n_in = out_inter ? B : 0;
     if (i < n_nn) {
-        nn_min_body(vh, vo, B, Vh, Vo, nn_blockmin, nn_counter, metric_out, clip_len, out_stride, obj_order, i % nchunk,
-                    i / nchunk, nchunk, sph_mesh, obj_rot6d, obj_trans, obj_scale, hand_order);
+        if (nn_idx)       // the full search (nearest object vertex of every hand vertex, for the contact term) instead
+            nn_full_body(vh, vo, B, Vh, Vo, nn_idx, nn_d2, nn_blockmin, nn_counter, metric_out, clip_len, out_stride, i % nchunk,
+                         i / nchunk, nchunk);
+        else
+            nn_min_body(vh, vo, B, Vh, Vo, nn_blockmin, nn_counter, metric_out, clip_len, out_stride, obj_order, i % nchunk,
+                        i / nchunk, nchunk, sph_mesh, obj_rot6d, obj_trans, obj_scale, hand_order);
         return;
     }
     i -= n_nn;
@@ -58,6 +62,7 @@ extern "C" {
 // One launch for up to three terms of the frames' (hand, object) vertex pairs; every term is optional (its output pointer
 // NULL) and equals its own entry point on the same inputs:
 //   metric_out   -> hm_nn_fwd_clips(..., nn_idx = nn_d2 = NULL, ...)   [<= 4096 object vertices]   workspace ws_nn
+//                   (nn_idx / nn_d2 != NULL: hm_nn_fwd_clips WITH them - the full search the contact term needs)
 //   out_inter    -> hm_inter_fwd_clips(...)                             frame records `frame_rec`    workspace ws_inter
 //   out_smooth   -> hm_smooth_fwd_clips(verts_obj, ..., hand_nb = 1)    unit gradient `unit_smooth`  workspace ws_smooth
 //   ht_out_v2d2  -> hm_hand_terms_fwd_clips(verts_hand, camintr, hand_nb = 1, ...) (one hand per frame)      workspace ws_hand
@@ -72,8 +77,10 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                             const float* ht_s_obj, const float* ht_m_obj, const float* ht_s_hand, const float* ht_m_hand,
                             float* ht_g_pca, float* ht_g_sobj, float* ht_g_shand, float* ht_out_priors3, void* ws_hand,
                             const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
-                            const int* hand_order, int clip_len, int out_stride, hipStream_t stream)
+                            const int* hand_order, int* nn_idx, float* nn_d2, int clip_len, int out_stride,
+                            hipStream_t stream)
 {
+    HM_CHECK_ARG((!nn_idx == !nn_d2) && (!nn_idx || metric_out));
     HM_CHECK_ARG(!obj_spheres || (obj_rot6d && obj_trans && obj_scale));
     HM_CHECK_ARG(verts_hand && verts_obj && B > 0 && Vh > 0 && Vo > 0 && HM_CLIP_LEN_OK(B, clip_len));
     HM_CHECK_ARG(metric_out || out_inter || out_smooth || ht_out_v2d2);
@@ -84,7 +91,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                  (!out_smooth || (ws_smooth && unit_smooth)));
     const int Bc = clip_len ? clip_len : B, clips = B / Bc;
     const int nchunk = hm_cdiv(Vh, NN_HV);
-    if (metric_out && ((long)Bc * nchunk > 512 || Vo > 64 * NN_MAX_GROUPS)) return HM_ERR_UNSUPPORTED;
+    if (metric_out && ((long)Bc * nchunk > 512 || (!nn_idx && Vo > 64 * NN_MAX_GROUPS))) return HM_ERR_UNSUPPORTED;
     if (out_inter && Bc > 512) return HM_ERR_UNSUPPORTED;
     const int sm_nblk = min(256, hm_cdiv((long)Bc * Vo * 3, RED_THREADS * 4));       // = hm_smooth_fwd_clips' grid
     HandTerms ht = {ht_ref2d, ht_image_size, ht_unit_v2d, ht_out_v2d2, ht_unit_smooth, ht_out_smooth1, ht_pca, ht_npca,
@@ -98,7 +105,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                        obj_order, expansion, zthresh, frame_rec,
                        ws_inter ? (unsigned int*)((float*)ws_inter + 512) : nullptr, out_inter, sm_nblk, unit_smooth,
                        (float*)ws_smooth, ws_smooth ? (unsigned int*)((float*)ws_smooth + 512) : nullptr, out_smooth, ht, clips,
-                       obj_spheres, obj_rot6d, obj_trans, obj_scale, hand_order);
+                       obj_spheres, obj_rot6d, obj_trans, obj_scale, hand_order, nn_idx, nn_d2);
     return hm_launch_status();
 }
 }  // extern "C"

@@ -406,6 +406,7 @@ class FusedStepper:
                                    (os.environ.get("HOMAN_PAIRS_AFTER_RASTER") or "1") != "0")
         self.pair_fused = (os.environ.get("HOMAN_PAIR_FUSED") or ("1" if C == 1 else "0")) != "0"
         self.hand_terms_fused = os.environ.get("HOMAN_HT_FUSED", "1") != "0"
+        self.nn_full_fused = os.environ.get("HOMAN_NN_FULL_FUSED", "1") != "0"
         if self.shared_scale:
             self._sync_shared_scale_start()
         side.wait_stream(torch.cuda.current_stream())
@@ -590,6 +591,9 @@ class FusedStepper:
             sm_here = on["smooth"] and not self.smooth_obj_on_main
             fuse = self.pair_fused and on["inter"] and Vo <= 4096
             nn_fused = fuse and not on["con"]
+            # with the contact term the FULL search (nearest object vertex of every hand vertex) is the launch's first block
+            # range instead, and the contact launches follow it: one launch less on the hand-side chain of the step-2 sets
+            nn_full_fused = fuse and on["con"] and self.nn_full_fused
             ht_fused = fuse and self.hand_terms_fused and on["smooth"] and on["v2d"]
             ht_args = (P(m.ref_verts2d_hand), float(m.image_size), P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
                        self._slot("loss_smooth_hand"), P(pca) if pri else None, npca,
@@ -620,7 +624,7 @@ class FusedStepper:
                                          sb), "smooth(obj)")
             def search_and_contact(stream_obj, rws):
                 sx = stream_obj.cuda_stream
-                if (on["con"] or on["inter"]) and not nn_fused:
+                if (on["con"] or on["inter"]) and not nn_fused and not nn_full_fused:
                     # (without the contact term only the logged distance is needed: metric-only search)
                     ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if on["con"] else None,
                                                P(self.nn_d2) if on["con"] else None, self._slot("handobj_maxdist"), rws, CL, NS,
@@ -637,10 +641,12 @@ class FusedStepper:
             # (the search on a third stream at one clip / step 1: +1 %; -9 % on an 8-clip batch.  Search + contact as a third
             #  branch next to the collision term: the HIP graph runtime crashes at replay when two side branches wait for
             #  each other's events.  Capturing the hand-side forward kernels BEFORE the silhouette chain: -38 %.)
-            search_and_contact(side, rws_b)
+            if not nn_full_fused:
+                search_and_contact(side, rws_b)
             if fuse:
                 ck(L.hm_pair_terms_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo,
-                                             self._slot("handobj_maxdist") if nn_fused else None, P(self.obj_order), rws_b,
+                                             self._slot("handobj_maxdist") if (nn_fused or nn_full_fused) else None,
+                                             P(self.obj_order), rws_b,
                                              c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(self.rec),
                                              self._slot("loss_inter"), P(self.reduce_ws_c.buf),
                                              P(self.U_smo) if sm_here else None,
@@ -648,8 +654,12 @@ class FusedStepper:
                                              *(ht_args if ht_fused else (None, 0.0, None, None, None, None, None, 0, None, None,
                                                                          None, None, None, None, None, None)),
                                              P(self.reduce_ws_e.buf), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                             P(m.translations_object), P(m.int_scales_object), P(self.hand_order), CL, NS, sb),
+                                             P(m.translations_object), P(m.int_scales_object), P(self.hand_order),
+                                             P(self.nn_idx) if nn_full_fused else None, P(self.nn_d2) if nn_full_fused else None,
+                                             CL, NS, sb),
                    "pair terms")
+                if nn_full_fused:
+                    search_and_contact(side, rws_b)          # (the contact launches only: the search ran above)
             elif on["inter"]:
                 ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
                                         float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws_b, CL,

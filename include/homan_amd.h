@@ -362,7 +362,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                             const float* ht_s_obj, const float* ht_m_obj, const float* ht_s_hand, const float* ht_m_hand,
                             float* ht_g_pca, float* ht_g_sobj, float* ht_g_shand, float* ht_out_priors3, void* ws_hand,
                             const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
-                            const int* hand_order,
+                            const int* hand_order, int* nn_idx, float* nn_d2,
                             int clip_len, int out_stride, hipStream_t stream);
 /* obj_order (Vo) optional, metric-only calls: a permutation of the object vertices, visited in that order (a spatial sort of
  * the rigid mesh makes 64 consecutive vertices a compact patch: scheduling only, the result is the exact minimum) */

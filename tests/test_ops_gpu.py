@@ -254,7 +254,7 @@ def test_pair_terms_launch_equals_its_four_entry_points():
             hl.check(L.hm_pair_terms_fwd_clips(P(vh), P(vo), P(camintr), B, Vh, Vo, slot(6), P(order), P(ws[0].buf),
                                                c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(rec), slot(7),
                                                P(ws[1].buf), P(u_smo), slot(8), P(ws[2].buf), *ht, P(ws[3].buf), None, None, None, None,
-                                               None, CL, stride, stream), "pair terms")
+                                               None, None, None, CL, stride, stream), "pair terms")
         else:
             hl.check(L.hm_nn_fwd_clips(P(vh), P(vo), B, Vh, Vo, None, None, slot(6), P(ws[0].buf), CL, stride, P(order), stream),
                      "nn")
