@@ -443,6 +443,12 @@ __device__ __forceinline__ void mano_bwd2_body(const ManoModelDev& m, const Mano
     }
 }
 
+#ifdef MANO_PHASES
+static __device__ unsigned long long g_mano_ph[16];
+#define MPH_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_mano_ph[k], t_ - mph_t); mph_t = t_; } } while (0)
+#else
+#define MPH_MARK(k)
+#endif
 // backward: grid (13, B).  First half per (vertex chunk, frame) -> partials (B, 13, 340); the workgroup that finishes
 // the last chunk of a frame (per-frame ticket) runs the second half for that frame -- one launch, and the chain state is
 // reloaded from the forward (`state`) instead of being recomputed when the caller kept it.
@@ -467,6 +473,10 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
     const int b = blockIdx.y, t = threadIdx.x;
     const int v0 = blockIdx.x * MANO_VCH;
     const int nv = min(MANO_VCH, MANO_V - v0);
+#ifdef MANO_PHASES
+    unsigned long long mph_t = wall_clock64();
+    if (t == 0) atomicAdd(&g_mano_ph[15], 1ull);
+#endif
     if (state) {
         const float* st = state + (long)b * MANO_STATE_DW;
         for (int i = t; i < (int)(sizeof(ManoShared) / 4); i += blockDim.x) reinterpret_cast<float*>(&sh)[i] = st[i];
@@ -476,6 +486,7 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
         mano_prepare(m, pca, pca_stride, rot, betas, b, sh, threadIdx.x);
         mano_posed_chunk(m, sh, v0, s_part, s_vp);
     }
+    MPH_MARK(0);
     float g[3] = {0.f, 0.f, 0.f};
     if (t < nv) {
         const int v = v0 + t;
@@ -490,10 +501,12 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
         }
         for (int j = 0; j < MANO_J; ++j) s_w[t][j] = m.weights[v * MANO_J + j];
     }
+    MPH_MARK(1);
     float* out = partials + ((long)b * gridDim.x + blockIdx.x) * MANO_PART;
     const float tg0 = hm_block_sum(g[0], red), tg1 = hm_block_sum(g[1], red), tg2 = hm_block_sum(g[2], red);
     if (t == 0) { hm_partial_store(out + 337, tg0); hm_partial_store(out + 338, tg1); hm_partial_store(out + 339, tg2); }
     __syncthreads();
+    MPH_MARK(2);
     // dA[j][r][c] = sum_v W[v][j] g[v][r] [vp;1][c]
     if (t < 192) {
         const int j = t / 12, r = (t % 12) / 4, c = t % 4;
@@ -501,6 +514,8 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
         for (int i = 0; i < nv; ++i) acc += s_w[i][j] * s_g[i][r] * (c < 3 ? s_vp[i][c] : 1.0f);
         hm_partial_store(out + t, acc);
     }
+    __syncthreads();
+    MPH_MARK(3);
     // dfeat[k] = sum_{v,c} M[k][3v+c] dvp[v][c]   (one wave per row, 3 coalesced loads, rows independent)
     const int wv = t >> 6, lane = t & 63;
     const int ne = 3 * nv;
@@ -532,6 +547,7 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
     // per-frame ticket: every thread's record stores must have landed before the workgroup takes it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    MPH_MARK(4);
     if (t == 0) {
         const unsigned int ticket = atomicAdd(frame_cnt + b, 1u);
         const int last = ticket == gridDim.x - 1u;
@@ -539,8 +555,15 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
         s_flag = last;
     }
     __syncthreads();
-    if (s_flag)
+    MPH_MARK(5);
+    if (s_flag) {
         mano_bwd2_body(m, sh, w2, partials, gridDim.x, b, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
+#ifdef MANO_PHASES
+        __syncthreads();
+        MPH_MARK(6);
+        if (t == 0) atomicAdd(&g_mano_ph[14], 1ull);
+#endif
+    }
 }
 
 extern "C" {
@@ -583,4 +606,14 @@ int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const f
                        partials, cnt, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
     return hm_launch_status();
 }
+#ifdef MANO_PHASES
+int hm_debug_mano_phases(unsigned long long* out)
+{
+    unsigned long long z[16] = {0};
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mano_ph), sizeof(z));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_mano_ph), z, sizeof(z));
+    return HM_OK;
+}
+#endif
 }  // extern "C"
