@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots
                                                float* __restrict__ log, int nclips)
 {
     HM_LATENCY_KERNEL();
+    HM_STAMP_START(0);
     const int step_now = __builtin_nontemporal_load(step);
     if ((int)blockIdx.y == n_tensors) {
         if (threadIdx.x == 0) {
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots
             atomicExch(step, step_now + 1);
         }
     }
+    HM_STAMP_END(0);
 }
 
 // log[step*n + i] = src[i] for i < n ; step read from the device counter (sync-free loss_evolution)
@@ -139,4 +141,14 @@ int hm_log_scalars(const float* src, int n, const int* step, int max_steps, floa
     hipLaunchKernelGGL(k_log, dim3(hm_cdiv(n, 64)), dim3(64), 0, stream, src, n, step, max_steps, log);
     return hm_launch_status();
 }
+#ifdef HM_CHAIN_STAMPS
+int hm_debug_chain_adam(unsigned long long* out, int reset)
+{
+    unsigned long long z[8] = {~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0};
+    (void)hipDeviceSynchronize();
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ts), sizeof(z));
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_ts), z, sizeof(z));
+    return HM_OK;
+}
+#endif
 }  // extern "C"

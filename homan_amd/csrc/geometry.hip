@@ -114,6 +114,7 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
                                                    unsigned int* __restrict__ frame_cnt, int clip_len)
 {
     HM_LATENCY_KERNEL();
+    HM_STAMP_START(sil.parts ? 1 : 0);
     __shared__ float red13[16 * 13];
     __shared__ int s_flag;
     const int n = blockIdx.x;
@@ -222,6 +223,7 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
         for (int k = 0; k < 3; ++k) g_trans[n * 3 + k] = tot[9 + k];
         if (g_scale_part) g_scale_part[n] = (abs_scale && sraw < 0.f) ? -tot[12] : tot[12];
     }
+    HM_STAMP_END(sil.parts ? 1 : 0);
 }
 
 // out[i] = s[0] * in[i]   (backward of "loss = f(x)" ops whose unit gradient was produced in the forward)
@@ -383,4 +385,14 @@ int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s
     hipLaunchKernelGGL(k_scale2_by, dim3(hm_cdiv(n, 256)), dim3(256), 0, stream, a, s0, b, s1, n, out);
     return hm_launch_status();
 }
+#ifdef HM_CHAIN_STAMPS
+int hm_debug_chain_geometry(unsigned long long* out, int reset)
+{
+    unsigned long long z[8] = {~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0};
+    (void)hipDeviceSynchronize();
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ts), sizeof(z));
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_ts), z, sizeof(z));
+    return HM_OK;
+}
+#endif
 }  // extern "C"

@@ -17,6 +17,14 @@
 #define HM_PRIO 3
 #endif
 #define HM_LATENCY_KERNEL() __builtin_amdgcn_s_setprio(HM_PRIO)
+#ifdef HM_CHAIN_STAMPS      // debug build: first-start / last-end wall clock of a few small kernels (one array per translation unit)
+static __device__ unsigned long long g_chain_ts[8];
+#define HM_STAMP_START(k) do { if (threadIdx.x == 0) atomicMin(&g_chain_ts[2 * (k)], (unsigned long long)wall_clock64()); } while (0)
+#define HM_STAMP_END(k) do { if (threadIdx.x == 0) atomicMax(&g_chain_ts[2 * (k) + 1], (unsigned long long)wall_clock64()); } while (0)
+#else
+#define HM_STAMP_START(k)
+#define HM_STAMP_END(k)
+#endif
 // the kernels of the hand-side chain that are long enough to matter to whatever they overlap (MANO backward, pair terms),
 // and the three heavy kernels of the silhouette chain: separately tunable (A/B builds)
 #ifndef HM_HAND_PRIO

@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
                                                      const float* __restrict__ rigid_scale, int rigid_abs, int clip_len,
                                                      float* __restrict__ cam_out, int nfb)
 {
+    HM_STAMP_START(0);
     __shared__ int s_cnt[SR_MAX], s_base[SR_MAX];
     __shared__ float s_R[9];
     // optional rigid transform of mesh-space `verts` (same arithmetic as hm_rigid_fwd, so the camera-space vertices the
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
                 bin_list[((long)b * nsr + sr) * F + at] = fi;
             }
     }
+    HM_STAMP_END(0);
 }
 
 __device__ __forceinline__ int hm_wave_scan_incl(int v)
@@ -2713,4 +2715,14 @@ int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float*
     return hipMemcpyAsync(out, w.faces9, (size_t)B * F * 9 * 4, hipMemcpyDeviceToDevice, stream) == hipSuccess
                ? HM_OK : HM_ERR_LAUNCH;
 }
+#ifdef HM_CHAIN_STAMPS
+int hm_debug_chain_raster(unsigned long long* out, int reset)
+{
+    unsigned long long z[8] = {~0ull, 0, ~0ull, 0, ~0ull, 0, ~0ull, 0};
+    (void)hipDeviceSynchronize();
+    if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_chain_ts), sizeof(z));
+    if (reset) (void)hipMemcpyToSymbol(HIP_SYMBOL(g_chain_ts), z, sizeof(z));
+    return HM_OK;
+}
+#endif
 }  // extern "C"
