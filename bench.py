@@ -174,6 +174,157 @@ def cfg1_parity(mano, seeds, steps=100, frames=10, size=128):
                 cores=int(os.environ.get("OMP_NUM_THREADS", "1")))
 
 
+def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottle", seed=0, lr=1e-2, free_run=True,
+                    clip=None, lw=None, tol=1e-4):
+    """Teacher-forced parity along the HIP trajectory (reference loop: homan/jointopt.py:158-192).
+
+    The fused loop runs `steps` iterations one replay at a time.  BEFORE every step its parameters are loaded into the CPU
+    oracle, which evaluates THAT step there: loss_dict (bar 1e-4 relative), parameter gradients (error / largest entry),
+    camera-space vertices (mm) and the face-index map of the silhouette raster (samples whose owner differs).  Every step is
+    a single-step comparison at identical parameters, so no trajectory can hide in it; the hard rasteriser's chaos only
+    enters through what the comparison measures - a flipped sample.
+    With `free_run` a second oracle optimises from the same start with torch's Adam (the reference loop): the distance of
+    the two FREE trajectories per step (parameters in ulps / absolute, samples that differ, weighted loss) says when they
+    separate and the lock-step numbers of the step before say what differed first."""
+    import numpy as np
+    import torch
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, build_model
+    from oracle import nmr as o_nmr
+    from oracle.jointopt import collate_inputs, make_optimizer
+    from oracle.model import OracleHOMan
+    if clip is None:
+        sil_fn, hand_fn = synth.hip_clip_fns(mano)
+        clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
+                               hand_verts_fn=hand_fn)
+    if lw is None:
+        lw = dict(synth.STEP2_LOSS_WEIGHTS if step2 else synth.STEP1_LOSS_WEIGHTS)
+    common = dict(objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"], optimize_mano=True,
+                  image_size=size, mano_model=mano, rend_size=size)
+    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                        sync_metrics=False, **common)
+    st = FusedStepper(model, lw, lr, steps)
+
+    def oracle_model():
+        kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                            clip["objvertices"], clip["objfaces"])
+        return OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                           image_size=size, mano_model=mano, rend_size=size, **kw)
+
+    def oracle_idx(om):
+        with torch.no_grad():
+            r = om.losses.renderer
+            f = r._ndc_faces(om.get_verts_object()[0], om.faces_object, om.camintr_rois_object, None, None, None, None)
+            return o_nmr._RasterizeAlphaDepth.apply(f, 2 * size, r.near, r.far, r.rasterizer_eps)[2].numpy()
+
+    def fwd_bwd(om):
+        for p in om.parameters():
+            p.grad = None
+        ld, md = om(loss_weights=lw)
+        tot = sum(ld[k] * lw[k.replace("loss", "lw")] for k in ld)
+        tot.sum().backward()
+        row = {k: float(v.detach().reshape(-1)[0]) for k, v in ld.items()}
+        row.update({k: float(v) for k, v in md.items()})
+        row["loss"] = float(tot.detach().reshape(-1)[0])
+        return row
+
+    forced = oracle_model()
+    free = oracle_model() if free_run else None
+    opt = make_optimizer(free, lr) if free_run else None
+    sctx = st.model.sil_ctx
+    rows, free_rows = [], []
+    for i in range(steps):
+        params = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
+        st.run(1)
+        torch.cuda.synchronize()
+        hip = st.loss_evolution(i + 1)
+        hip = {k: v[i] for k, v in hip.items()}
+        grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+        idx_h = sctx.idx_map().cpu().numpy()
+        vo_h, vh_h = st.vo.cpu().numpy(), st.vh.cpu().numpy()
+        forced.load_state_dict(params, strict=False)
+        cpu = fwd_bwd(forced)
+        with torch.no_grad():
+            vo_c, vh_c = forced.get_verts_object()[0].numpy(), forced.get_verts_hand()[0].numpy()
+        rel = {k: abs(hip[k] - cpu[k]) / max(abs(cpu[k]), 1e-12) for k in cpu if k in hip and k.startswith("loss")}
+        # logged metrics (not part of the objective).  handobj_maxdist: the reference forms |a|^2 + |b|^2 - 2ab in fp32
+        # (libyana batch_pairwise_dist, losses.py:227), whose own rounding is ~4e-6 m at a 6 mm gap; the kernel differences
+        # the coordinates first -> compared in metres
+        met = {k: abs(hip[k] - cpu[k]) / max(abs(cpu[k]), 1e-12) for k in cpu if k in hip and not k.startswith("loss")}
+        maxdist_abs = abs(hip["handobj_maxdist"] - cpu["handobj_maxdist"]) if "handobj_maxdist" in cpu and "handobj_maxdist" in hip else 0.0
+        gerr = {}
+        for k, p in forced.named_parameters():
+            if p.grad is None or k not in grads:
+                continue
+            ref = p.grad.numpy()
+            gerr[k] = float(np.abs(grads[k] - ref).max() / max(np.abs(ref).max(), 1e-30))
+        worst_loss = max(rel, key=rel.get)
+        worst_grad = max(gerr, key=gerr.get)
+        col_given = None
+        if "loss_collision" in cpu:
+            # the same oracle term evaluated on the HIP loop's HAND vertices (1 ulp from the oracle's: the MANO sums run in
+            # another order; the object's vertices are bit-equal): what is left of the difference is the SDF kernels'
+            from oracle import model as o_model
+            with torch.no_grad():
+                cg = float(o_model.compute_collision_loss(torch.from_numpy(vh_h), torch.from_numpy(vo_h), forced.faces_object,
+                                                          forced.closed_faces)["loss_collision"])
+            col_given = abs(hip["loss_collision"] - cg) / max(abs(cg), 1e-12)
+        rows.append(dict(step=i, max_rel_loss=rel[worst_loss], worst_loss=worst_loss, worst_loss_value=cpu[worst_loss],
+                         weighted_share=abs(hip[worst_loss] - cpu[worst_loss]) * lw[worst_loss.replace("loss", "lw")] / max(abs(cpu["loss"]), 1e-12)
+                         if worst_loss != "loss" else rel[worst_loss], max_grad_err=gerr[worst_grad],
+                         worst_grad=worst_grad, flipped_samples=int((idx_h != oracle_idx(forced)).sum()),
+                         vert_diff_mm=dict(object=1e3 * float(np.abs(vo_h - vo_c).max()), hand=1e3 * float(np.abs(vh_h - vh_c).max())),
+                         vert_equal=dict(object=bool(np.array_equal(vo_h, vo_c)), hand=bool(np.array_equal(vh_h, vh_c))),
+                         rel_loss=rel, rel_metric=met, handobj_maxdist_abs_m=maxdist_abs,
+                         collision_rel_given_hip_vertices=col_given))
+        if free_run:
+            # the free-running reference loop, one step behind the comparison: its parameters BEFORE its step i against the
+            # HIP loop's parameters before step i
+            fp = {k: p.detach().numpy() for k, p in free.named_parameters()}
+            dist = {k: float(np.abs(fp[k] - params[k].numpy()).max()) for k in fp if k in params}
+            wk = max(dist, key=dist.get)
+            fidx = oracle_idx(free)
+            opt.zero_grad()
+            frow = fwd_bwd(free)
+            opt.step()
+            free_rows.append(dict(step=i, max_param_diff=dist[wk], worst_param=wk,
+                                  samples_differing=int((idx_h != fidx).sum()),
+                                  rel_diff_total=abs(hip["loss"] - frow["loss"]) / max(abs(frow["loss"]), 1e-12),
+                                  rel_diff_worst=max(abs(hip[k] - frow[k]) / max(abs(frow[k]), 1e-12)
+                                                     for k in frow if k in hip and k.startswith("loss"))))
+    out = dict(config=("cfg3" if step2 else "cfg2") + f"-shaped: {frames} frames {size}x{size}, {obj}, "
+               + ("step-2" if step2 else "step-1") + f" loss set, {steps} steps of the fused loop, every step re-evaluated by "
+               "the CPU oracle at the HIP parameters", steps=steps, tol=tol,
+               max_rel_loss=max(r["max_rel_loss"] for r in rows), max_grad_err=max(r["max_grad_err"] for r in rows),
+               flipped_samples=sum(r["flipped_samples"] for r in rows),
+               max_vert_diff_mm=dict(object=max(r["vert_diff_mm"]["object"] for r in rows),
+                                     hand=max(r["vert_diff_mm"]["hand"] for r in rows)),
+               object_vertices_bit_equal=all(r["vert_equal"]["object"] for r in rows),
+               max_rel_metric={k: max(r["rel_metric"].get(k, 0.0) for r in rows) for k in rows[0]["rel_metric"]},
+               max_handobj_maxdist_abs_m=max(r["handobj_maxdist_abs_m"] for r in rows),
+               max_collision_rel_given_hip_vertices=(max(r["collision_rel_given_hip_vertices"] for r in rows)
+                                                     if rows[0]["collision_rel_given_hip_vertices"] is not None else None),
+               first_step_over_tol=next((r["step"] for r in rows if r["max_rel_loss"] > tol), None),
+               worst_loss_per_key={k: max(r["rel_loss"].get(k, 0.0) for r in rows) for k in rows[0]["rel_loss"]},
+               worst_grad_per_step=[(r["worst_grad"], r["max_grad_err"]) for r in rows][:8],
+               per_step=[{k: r[k] for k in ("step", "max_rel_loss", "worst_loss", "worst_loss_value", "weighted_share",
+                                            "max_grad_err", "worst_grad", "flipped_samples")} for r in rows])
+    if free_run:
+        sep = next((r["step"] for r in free_rows if r["rel_diff_worst"] > tol), None)
+        first_flip = next((r["step"] for r in free_rows if r["samples_differing"] > 0), None)
+        out["free_run"] = dict(
+            what="HIP fused loop vs the CPU oracle loop (torch Adam), both free-running from identical inputs",
+            first_step_over_tol=sep, first_step_with_differing_samples=first_flip,
+            max_param_diff_per_step=[r["max_param_diff"] for r in free_rows][:12],
+            samples_differing_per_step=[r["samples_differing"] for r in free_rows][:12],
+            rel_diff_worst_per_step=[r["rel_diff_worst"] for r in free_rows][:12],
+            at_separation=(free_rows[sep] if sep is not None else None),
+            before_separation=(dict(lockstep=rows[sep - 1]["max_grad_err"], worst_grad=rows[sep - 1]["worst_grad"],
+                                    free=free_rows[sep - 1]) if sep else None),
+            final=free_rows[-1])
+    return out
+
+
 def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
     """BASELINE cfg5: `--multi-clip` clips per GPU (default 8) with step-2 losses as ONE clip batch per rank, the object
     scale ONE scalar tied across all clips of all ranks: per step one 4-byte all-reduce (sum) of its gradient on the

@@ -24,15 +24,39 @@ INTERACTION_BBOX_EXPANSION = 0.2   # reference homan/losses.py:95
 
 
 # ----------------------------------------------------------------------------- geometry
+def _dot3(a, b):
+    """(a0*b0 + a1*b1) + a2*b2 with every product and sum a separate IEEE fp32 operation (one torch kernel each: no fused
+    multiply-add, no dependence on the host BLAS or on how a reduction kernel vectorises)."""
+    return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]
+
+
+def _sqrt_exact(x):
+    """correctly rounded fp32 square root: torch.sqrt on contiguous fp32 tensors goes through MKL's vector math, which is
+    NOT correctly rounded (0.65 % of random inputs differ from IEEE by one ulp here, and which ones depends on layout and
+    length); the square root of the double, rounded once to fp32, is."""
+    return torch.sqrt(x.double()).float()
+
+
 def rot6d_to_matrix(rot_6d):
-    """reference homan/utils/geometry.py:9-27 (cross taken along dim=-1; the reference's
-    dim-less torch.cross differs only when the flattened batch is exactly 3)."""
-    rot_6d = rot_6d.view(-1, 3, 2)
-    a1, a2 = rot_6d[:, :, 0], rot_6d[:, :, 1]
-    b1 = F.normalize(a1)
-    b2 = F.normalize(a2 - torch.einsum("bi,bi->b", b1, a2).unsqueeze(-1) * b1)
-    b3 = torch.cross(b1, b2, dim=-1)
-    return torch.stack((b1, b2, b3), dim=-1)
+    """reference homan/utils/geometry.py:9-27 (cross taken along dim=-1; the reference's dim-less torch.cross differs
+    only when the flattened batch is exactly 3).
+
+    Evaluation order written out operation by operation: the reference's F.normalize / einsum / torch.cross round
+    differently from host to host (vectorised reductions, MKL's FMA chains in bmm - measured: the same call gives
+    different last bits for B = 4 and B = 240), and an ulp in R moves vertices across sample centres of the hard
+    rasteriser.  Same mathematics (F.normalize = v / max(|v|, 1e-12)); the HIP kernels follow this order
+    (csrc/hm_common.h rot6d_to_mat), so rotations - and with them vertices and coverage - agree bit for bit."""
+    r = rot_6d.view(-1, 3, 2)
+    a1 = [r[:, i, 0] for i in range(3)]
+    a2 = [r[:, i, 1] for i in range(3)]
+    n1 = _sqrt_exact(_dot3(a1, a1)).clamp_min(1e-12)
+    b1 = [a / n1 for a in a1]
+    d = _dot3(b1, a2)
+    u = [a2[i] - d * b1[i] for i in range(3)]
+    nu = _sqrt_exact(_dot3(u, u)).clamp_min(1e-12)
+    b2 = [x / nu for x in u]
+    b3 = [b1[1] * b2[2] - b1[2] * b2[1], b1[2] * b2[0] - b1[0] * b2[2], b1[0] * b2[1] - b1[1] * b2[0]]
+    return torch.stack((torch.stack(b1, -1), torch.stack(b2, -1), torch.stack(b3, -1)), dim=-1)
 
 
 def matrix_to_rot6d(rotmat):
@@ -40,11 +64,19 @@ def matrix_to_rot6d(rotmat):
     return rotmat.view(-1, 3, 3)[:, :, :2]
 
 
+def _rowvec_times_matrix(v, m):
+    """(N,V,3) @ (N,3,3) as ((x*m0j + y*m1j) + z*m2j), one IEEE operation per product / sum (torch.matmul on the CPU is an
+    MKL FMA chain for V >= 45 and a plain loop below: measured here; see rot6d_to_matrix)."""
+    x, y, z = v[:, :, 0:1], v[:, :, 1:2], v[:, :, 2:3]
+    return (x * m[:, None, 0, :] + y * m[:, None, 1, :]) + z * m[:, None, 2, :]
+
+
 def transform_persp(meshes, translations, rotations, intrinsic_scales):
-    """reference homan/utils/camera.py:108-139: (s*v) @ R + t and its mesh-detached twin."""
+    """reference homan/utils/camera.py:108-139: (s*v) @ R + t and its mesh-detached twin (products written out, see
+    _rowvec_times_matrix)."""
     scaled = intrinsic_scales.view(-1, 1, 1) * meshes
-    return (torch.matmul(scaled, rotations) + translations,
-            torch.matmul(scaled.detach().clone(), rotations) + translations)
+    return (_rowvec_times_matrix(scaled, rotations) + translations,
+            _rowvec_times_matrix(scaled.detach().clone(), rotations) + translations)
 
 
 def compute_dist_z(verts1, verts2):

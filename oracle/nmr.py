@@ -25,9 +25,19 @@ DEFAULT_EPS = 1e-3
 
 
 def projection(vertices, K, R, t, dist_coeffs, orig_size, eps=1e-9):
-    """[X,Y,Z] -> [u,v,z]: u,v in [-1,1] (v up), z = camera depth."""
-    vertices = torch.matmul(vertices, R.transpose(2, 1)) + t
-    x, y, z = vertices[:, :, 0], vertices[:, :, 1], vertices[:, :, 2]
+    """[X,Y,Z] -> [u,v,z]: u,v in [-1,1] (v up), z = camera depth.
+
+    The two 3x3 products are written out as ((a*m0 + b*m1) + c*m2) with one IEEE fp32 operation per product / sum
+    (upstream: torch.matmul = cuBLAS, whose rounding no CPU reproduces; torch's CPU matmul is an FMA chain or a plain loop
+    depending on the size).  A fixed order makes the projected vertices - and the coverage decisions of the hard rasteriser
+    that depend on their last bit - a function of the inputs alone; the HIP kernel (csrc/raster.hip project_vertex) follows
+    the same order, bit for bit."""
+    Rt = R.expand(vertices.shape[0], 3, 3) if R.shape[0] != vertices.shape[0] else R
+    X, Y, Z = vertices[:, :, 0], vertices[:, :, 1], vertices[:, :, 2]
+    tt = t.reshape(-1, 1, 3)
+    x = ((X * Rt[:, None, 0, 0] + Y * Rt[:, None, 0, 1]) + Z * Rt[:, None, 0, 2]) + tt[:, :, 0]
+    y = ((X * Rt[:, None, 1, 0] + Y * Rt[:, None, 1, 1]) + Z * Rt[:, None, 1, 2]) + tt[:, :, 1]
+    z = ((X * Rt[:, None, 2, 0] + Y * Rt[:, None, 2, 1]) + Z * Rt[:, None, 2, 2]) + tt[:, :, 2]
     x_ = x / (z + eps)
     y_ = y / (z + eps)
     k1 = dist_coeffs[:, None, 0]
@@ -39,9 +49,8 @@ def projection(vertices, K, R, t, dist_coeffs, orig_size, eps=1e-9):
     radial = 1 + k1 * r2 + k2 * r2 ** 2 + k3 * r2 ** 3
     x__ = x_ * radial + 2 * p1 * x_ * y_ + p2 * (r2 + 2 * x_ ** 2)
     y__ = y_ * radial + p1 * (r2 + 2 * y_ ** 2) + 2 * p2 * x_ * y_
-    vertices = torch.stack([x__, y__, torch.ones_like(z)], dim=-1)
-    vertices = torch.matmul(vertices, K.transpose(1, 2))
-    u, v = vertices[:, :, 0], vertices[:, :, 1]
+    u = (x__ * K[:, None, 0, 0] + y__ * K[:, None, 0, 1]) + K[:, None, 0, 2]
+    v = (x__ * K[:, None, 1, 0] + y__ * K[:, None, 1, 1]) + K[:, None, 1, 2]
     v = orig_size - v
     u = 2 * (u - orig_size / 2.0) / orig_size
     v = 2 * (v - orig_size / 2.0) / orig_size

@@ -13,6 +13,7 @@ NAMES = util.golden_names()
 # losses.py:227): at |a|^2 ~ 0.36 m^2 the rounding of that expansion is eps * 0.72 / (2 d) ~ 4e-6 m at d = 6 mm.  The kernel
 # differences the coordinates first; the reference's own rounding error is the tolerance (absolute, 1e-5 m).
 METRIC_ATOL = {"handobj_maxdist": 1e-5}
+GRAD_ATOL = 5e-5      # parameter gradients vs the reference goldens, as a fraction of the tensor's largest entry
 
 
 def _build_hip(name, mano_model, sync=True):
@@ -46,9 +47,12 @@ def test_forward_matches_reference_goldens(name, mano_model):
             continue
         scale = max(np.abs(ref).max(), 1e-12)
         got = p.grad.cpu().numpy()
-        # the NMR pseudo-gradient sums ~1e3 terms of mixed sign: compare at 1e-3 of the largest entry
-        np.testing.assert_allclose(got / scale, ref / scale, atol=2e-3, err_msg=k)
-    np.testing.assert_allclose(model.get_verts_object()[0].detach().cpu().numpy(), rec["verts_object"], atol=2e-7)
+        # rotation, rigid transform and projection follow the oracle's operation order (bit-equal vertices and coverage,
+        # tests/test_lockstep_gpu.py), what is left is the summation order of the gradients: 5e-5 of the largest entry
+        np.testing.assert_allclose(got / scale, ref / scale, atol=GRAD_ATOL, err_msg=k)
+    # (the golden's vertices come from the reference's own torch.matmul on the generating host - an MKL FMA chain, 2 ulp
+    #  from the written-out products at ~1 m, see tests/test_oracle_golden.py)
+    np.testing.assert_allclose(model.get_verts_object()[0].detach().cpu().numpy(), rec["verts_object"], atol=3e-7)
     np.testing.assert_allclose(model.get_verts_hand()[0].detach().cpu().numpy(), rec["verts_hand"], atol=2e-6)
     sd = set(model.state_dict().keys())
     viz_only = set()      # every reference key exists, the white depth-render textures included
@@ -58,7 +62,7 @@ def test_forward_matches_reference_goldens(name, mano_model):
 @pytest.mark.parametrize("name", NAMES)
 def test_pinned_step_matches_reference(name, mano_model):
     """Per-step pin: the HIP model at the reference loop's parameters after `pin_step` Adam steps vs the reference's own
-    forward / backward there (losses 1e-4 relative = north_star, gradients 2e-3 of the largest entry)."""
+    forward / backward there (losses 1e-4 relative = north_star, gradients 5e-5 of the largest entry)."""
     rec, model, weights, meta = _build_hip(name, mano_model)
     if not meta["has_trajectory"]:
         pytest.skip("forward / backward golden only")
@@ -78,7 +82,7 @@ def test_pinned_step_matches_reference(name, mano_model):
             assert p.grad is None, k
             continue
         scale = max(np.abs(ref).max(), 1e-12)
-        np.testing.assert_allclose(p.grad.cpu().numpy() / scale, ref / scale, atol=2e-3, err_msg=k)
+        np.testing.assert_allclose(p.grad.cpu().numpy() / scale, ref / scale, atol=GRAD_ATOL, err_msg=k)
 
 
 @pytest.mark.parametrize("name", ["ref_step1_cube_b4_s64", "ref_step2_cube_b4_s64", "ref_step2_twohands_cube_b4_s64",

@@ -43,8 +43,11 @@ def test_rigid_transform_and_grads(V):
     ins_h = [t.clone().to(DEV).requires_grad_(True) for t in (mesh, rot6d, trans, scale)]
     vh, vdh = ops.rigid_transform(ins_h[0], ins_h[1], ins_h[2], ins_h[3], abs_scale=True)
     ((vh * w1.to(DEV)).sum() + (vdh * w2.to(DEV)).sum()).backward()
-    _close(vh, v, msg="verts")
-    _close(vdh, vd, msg="verts_det")
+    # the oracle writes rot6d -> R and (s v) R + t out operation by operation and the kernel follows that order with
+    # -ffp-contract=off: the vertices the rasteriser sees are the oracle's BIT FOR BIT (coverage of the hard rasteriser
+    # depends on their last bit)
+    np.testing.assert_array_equal(vh.detach().cpu().numpy(), v.detach().numpy())
+    np.testing.assert_array_equal(vdh.detach().cpu().numpy(), vd.detach().numpy())
     for a, b, n in zip(ins_h, ins_o, ("mesh", "rot6d", "trans", "scale")):
         _close(a.grad, b.grad, rtol=2e-4, msg="grad " + n)
 

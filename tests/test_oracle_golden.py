@@ -39,8 +39,10 @@ def test_forward_losses_metrics_and_grads(name, mano_model):
             continue
         scale = max(np.abs(ref).max(), 1e-12)
         np.testing.assert_allclose(p.grad.numpy() / scale, ref / scale, atol=5e-5, err_msg=k)
-    np.testing.assert_allclose(model.get_verts_object()[0].detach().numpy(), rec["verts_object"], atol=1e-7)
-    np.testing.assert_allclose(model.get_verts_hand()[0].detach().numpy(), rec["verts_hand"], atol=1e-7)
+    # vertices vs the reference's own torch.matmul on this host: the oracle writes its 3x3 products out operation by operation
+    # (oracle/model.py rot6d_to_matrix), MKL's bmm is an FMA chain: <= 2 ulp at ~1 m = 2.4e-7 m (north_star: 1e-6 m)
+    np.testing.assert_allclose(model.get_verts_object()[0].detach().numpy(), rec["verts_object"], atol=3e-7)
+    np.testing.assert_allclose(model.get_verts_hand()[0].detach().numpy(), rec["verts_hand"], atol=3e-7)
 
 
 @pytest.mark.parametrize("name", NAMES)
