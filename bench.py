@@ -60,8 +60,10 @@ def kernel_bytes(B, S, F):
             "k_bwd_lines": B * (4 * is2 // 8 + S * S * 4 + is2 + F * (36 + 8 + 2))}
 
 
-def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256):
-    """Reference CPU path = oracle (CPU restatement) loop on this host, bounded sample."""
+def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256, ordinal_depth=False):
+    """Reference CPU path = oracle (CPU restatement) loop on this host, bounded sample, in the two modes of SURVEY 8(d):
+    with the per-step `.item()` logging of reference jointopt.py:184-190 (API-faithful; `value`) and without it
+    (`value_logging_off`: the same iterations with no host read-back of the losses)."""
     import torch
     from oracle.jointopt import collate_inputs, make_optimizer
     from oracle.model import OracleHOMan
@@ -70,18 +72,19 @@ def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256):
     kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
                         clip["objvertices"], clip["objfaces"])
     model = OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
-                        image_size=image_size, mano_model=mano, rend_size=rend_size, **kw)
+                        image_size=image_size, mano_model=mano, rend_size=rend_size, ordinal_depth=ordinal_depth, **kw)
     opt = make_optimizer(model, 1e-2)
 
     evo = []
 
-    def step():
+    def step(logging=True):
         opt.zero_grad()
         ld, md = model(loss_weights=lw)
         tot = sum(ld[k] * lw[k.replace("loss", "lw")] for k in ld)
-        row = {k: v.item() for k, v in ld.items()}
-        row["loss"] = tot.item()
-        evo.append(row)
+        if logging:
+            row = {k: v.item() for k, v in ld.items()}
+            row["loss"] = tot.item()
+            evo.append(row)
         tot.backward()
         opt.step()
 
@@ -91,10 +94,18 @@ def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256):
         step()
         n += 1
         el = time.perf_counter() - t0
-        if el > budget_s or n >= 50:
+        if el > 0.7 * budget_s or n >= 50:
             break
-    return dict(value=n / el, unit="it/s", cores=threads, kind="port",
-                sample=f"{n} iterations of the same cfg2 clip ({el:.1f} s) after 1 warm-up, oracle loop with per-step .item() logging"), evo
+    m, t1 = 0, time.perf_counter()
+    while True:
+        step(logging=False)
+        m += 1
+        el2 = time.perf_counter() - t1
+        if el2 > 0.3 * budget_s or m >= 20:
+            break
+    return dict(value=n / el, unit="it/s", cores=threads, kind="port", value_logging_off=m / el2,
+                sample=f"{n} iterations of the same clip ({el:.1f} s) after 1 warm-up, oracle loop with the reference's per-step "
+                       f".item() logging; then {m} more iterations ({el2:.1f} s) with the logging off"), evo
 
 
 def trajectory_parity(evo_hip, evo_cpu, tol=1e-4):
@@ -367,6 +378,29 @@ def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
     gathered = [torch.zeros(1, device=scale.device) for _ in range(world)]
     dist.all_gather(gathered, scale[:1].contiguous())
     same = bool((scale == scale[0]).all()) and all(torch.equal(g, gathered[0]) for g in gathered)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the same tied-scale semantics as a plain autograd loop over the CPU oracle (homan_amd.dist.optimize_clips_shared_scale,
+        # the loop the gloo tests drive), on a bounded sample: two of the clips, a few iterations
+        from oracle.jointopt import collate_inputs, make_optimizer
+        from oracle.model import OracleHOMan
+        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+        torch.set_num_threads(threads)
+        oms = []
+        for i in range(min(C, 2)):
+            clip = synth.make_clip(seed=100 * rank + i, frames=args.frames, rend_size=args.size, image_size=args.size,
+                                   obj="bottle", silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+            kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                                clip["objvertices"], clip["objfaces"])
+            oms.append(OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                                   optimize_object_scale=True, image_size=args.size, mano_model=mano, rend_size=args.size, **kw))
+        opts = [make_optimizer(m, 1e-2) for m in oms]
+        hdist.optimize_clips_shared_scale(oms, opts, lw, 1, device="cpu")          # warm-up
+        tc = time.perf_counter()
+        hdist.optimize_clips_shared_scale(oms, opts, lw, 3, device="cpu")
+        ec = time.perf_counter() - tc
+        cpu = dict(value=len(oms) * 3 / ec, unit="it/s (sum over clips)", cores=threads, kind="port",
+                   sample=f"{len(oms)} of the clips x 3 tied-scale iterations ({ec:.1f} s) after 1 warm-up, oracle autograd loop")
     if rank == 0:
         F, V = int(models[0].faces_object.shape[1]), int(models[0].verts_object_og.shape[1])
         tot = algorithmic_bytes(args.frames, args.size, F, V, True)["total"]
@@ -383,7 +417,7 @@ def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
             "roofline": dict(bound="hbm", unit="GB/s", peak=8000.0 * world, achieved=tot * value / 1e9,
                              frac=tot * value / (8.0e12 * world), kernel="whole iteration", traffic=None,
                              note="SURVEY 8(d) algorithmic bytes per clip-iteration (cfg3 set) x clip-iterations/s"),
-            "cpu_baseline": None,
+            "cpu_baseline": cpu,
             "shared_scale_final": float(scale[0]), "replicas_identical": same,
             "first_loss": [e["loss"][0] for e in evo], "final_loss": [e["loss"][-1] for e in evo]})
     dist.destroy_process_group()
@@ -499,6 +533,17 @@ def main():
                     help="SURVEY 8f rank 1 instead of the headline: one find_optimal_pose fit = N candidate poses of the "
                          "bottle against one 256x256 instance mask, --steps Adam steps (reference default 50); prints "
                          "its own JSON line (pose-steps/sec) with a bounded CPU-oracle baseline")
+    ap.add_argument("--depth", action="store_true",
+                    help="cfg2 as BASELINE.json words it (sil/kp/depth/smooth): the ordinal depth term of reference "
+                         "homan.py:384-419 switched on (lw_depth=1, HOMan(ordinal_depth=True); the reference's own call site "
+                         "raises, see DESIGN.md row a19)")
+    ap.add_argument("--steady", type=int, default=2000,
+                    help="steady_state leg after the headline: the same fit continued to iteration >= 400, then this many "
+                         "timed iterations (BASELINE cfg2 is a 400-step fit; a short --steps/--warmup headline times the first, "
+                         "heavier iterations); 0 = skip")
+    ap.add_argument("--lockstep", type=int, default=24,
+                    help="final_loss_parity.lockstep: this many steps of the fused loop re-evaluated by the CPU oracle at the "
+                         "HIP parameters (teacher-forced), plus the free-running comparison; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -534,12 +579,17 @@ def main():
     clip = synth.make_clip(seed=rank, frames=args.frames, rend_size=args.size, image_size=args.size, obj="bottle",
                            silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
     lw = dict(synth.STEP2_LOSS_WEIGHTS if args.step2 else synth.STEP1_LOSS_WEIGHTS)
+    if args.depth:
+        lw["lw_depth"] = 1.0
     model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
                         objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
                         optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
-                        sync_metrics=False)
-    total_steps = args.warmup + args.steps
-    stepper = (GraphStepper if args.loop == "graph" else FusedStepper)(model, lw, 1e-2, total_steps)
+                        sync_metrics=False, ordinal_depth=args.depth)
+    fused = args.loop == "fused"
+    steady_warm = max(0, 400 - (args.warmup + args.steps)) if args.steady > 0 and fused else 0
+    stamp_reps = max(10, min(50, args.steps))
+    total_steps = args.warmup + args.steps + (2 * stamp_reps + steady_warm + args.steady if fused else 0)
+    stepper = (FusedStepper if fused else GraphStepper)(model, lw, 1e-2, total_steps)
     stepper.run(args.warmup)
 
     def barrier():
@@ -548,17 +598,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    stepper.run(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+    def timed(n):
+        barrier()
+        t0 = time.perf_counter()
+        stepper.run(n)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = t.item()
+        return el
 
-    evo = stepper.loss_evolution(total_steps)
+    elapsed = timed(args.steps)
     B, S = args.frames, args.size
     F, V = clip["objfaces"].shape[1], clip["objvertices"].shape[1]
 
@@ -566,15 +618,12 @@ def main():
     #     so the three heavy kernels stamp the device wall clock themselves (hm_sil_timestamps: every workgroup stores
     #     s_memrealtime at entry and exit into a slot pair of its own; one scalar load per workgroup when switched off, as in
     #     the timed region).  `reps` more replays of THE SAME graph, back to back (arming and saving are stream-ordered 48-byte device
-    #     operations, no host synchronisation): same launches, same overlap with the hand-side stream, the steady state the
-    #     timed region left behind.  The rocprofv3 --kernel-trace averages of this
-    #     command (profiles/) are the cross-check.
-    roof = None
-    if rank == 0 and args.loop == "fused":
+    #     operations, no host synchronisation): same launches, same overlap with the hand-side stream, the state the
+    #     timed region left behind.  The rocprofv3 --kernel-trace averages of this command (profiles/) are the cross-check.
+    def stamp_roofline(its_per_s, reps):
         import ctypes
         from homan_amd import lib as hlib
         L = hlib.lib()
-        reps = max(10, min(50, args.steps))
         us3 = (ctypes.c_float * 3)()
         acc = [0.0, 0.0, 0.0]
         sctx = stepper.model.sil_ctx
@@ -592,12 +641,14 @@ def main():
                 acc[k] += us3[k] * 1e-3           # ms
         torch.cuda.synchronize()
         kb = kernel_bytes(B, S, F)
-        pmc = {}
-        ppath = os.path.join(ROOT, "profiles", "r02_pmc_loop.json")
-        if os.path.exists(ppath):
-            pj = json.load(open(ppath))
-            if pj.get("shape") == dict(frames=B, rend_size=S, faces=int(F), step2=bool(args.step2)):
-                pmc = pj.get("per_launch", {})      # measured on the same shapes, same steady-state loop
+        pmc, psrc = {}, None
+        for cand in ("r03_pmc_loop.json", "r02_pmc_loop.json"):
+            ppath = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(ppath):
+                pj = json.load(open(ppath))
+                if pj.get("shape") == dict(frames=B, rend_size=S, faces=int(F), step2=bool(args.step2)) and not args.depth:
+                    pmc, psrc = pj.get("per_launch", {}), cand      # measured on the same shapes, same steady-state loop
+                    break
         per = {}
         for i, name in enumerate(("k_raster_fwd", "k_bwd_lines", "k_bwd_sweep")):
             sec = acc[i] / reps * 1e-3
@@ -606,22 +657,48 @@ def main():
             if c:
                 rec["traffic_bytes"] = c.get("traffic_bytes")
                 if c.get("SQ_INSTS_VALU"):
-                    # VALU issue roof: a wave64 VALU instruction occupies its SIMD16 for 4 cycles -> 1024 SIMDs x 2.4 GHz / 4
+                    # VALU issue roof.  A wave64 VALU instruction runs on a SIMD16 as four passes of 16 lanes: 4 cycles of the
+                    # SIMD's VALU per instruction, which is what the counters show (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU, in
+                    # quad-cycles per instruction: ~1.0) -> 1024 SIMDs x 2.4 GHz / 4.  The micro-architecture guide's
+                    # "wave scheduling" section quotes 2 cycles (dual-issue / packed rate): `valu_frac_2cyc` is the same
+                    # count against THAT peak, i.e. half of valu_frac.  DESIGN.md section 5 reconciles the two.
                     rec["valu_wave_instr"] = c["SQ_INSTS_VALU"]
                     rec["valu_frac"] = c["SQ_INSTS_VALU"] / (sec * 1024 * 2.4e9 / 4)
+                    rec["valu_frac_2cyc"] = c["SQ_INSTS_VALU"] / (sec * 1024 * 2.4e9 / 2)
+                    if c.get("SQ_ACTIVE_INST_VALU"):
+                        rec["quad_cycles_per_valu_instr"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"]
             per[name] = rec
         dom = max(per, key=lambda k: per[k]["avg_launch_us"])
         tot = algorithmic_bytes(B, S, F, V, args.step2)["total"]
-        roof = dict(bound="hbm", kernel=dom, achieved=per[dom]["achieved_GBps"], peak=8000.0, unit="GB/s",
+        return dict(bound="hbm", kernel=dom, achieved=per[dom]["achieved_GBps"], peak=8000.0, unit="GB/s",
                     frac=per[dom]["achieved_GBps"] / 8000.0, traffic=per[dom].get("traffic_bytes"),
                     avg_launch_us=per[dom]["avg_launch_us"], valu_frac=per[dom].get("valu_frac"),
                     timing=f"device wall clock stored by every workgroup at entry and exit (earliest start to latest end) in "
                            f"{reps} more replays of the timed hipGraph (hm_sil_timestamps); same launches, same overlap",
-                    traffic_source=("profiles/r02_pmc_loop.json (rocprofv3 --pmc passes over the steady-state loop, "
-                                    "tools/pmc_loop.sh)" if per[dom].get("traffic_bytes") else None),
+                    traffic_source=(f"profiles/{psrc} (rocprofv3 --pmc passes over the steady-state loop, tools/pmc_loop.sh)"
+                                    if per[dom].get("traffic_bytes") else None),
                     kernels=per,
-                    whole_iteration=dict(algorithmic_bytes=tot, achieved_GBps=tot * (args.steps / elapsed) / 1e9,
-                                         frac=tot * (args.steps / elapsed) / 8.0e12))
+                    whole_iteration=dict(algorithmic_bytes=tot, achieved_GBps=tot * its_per_s / 1e9,
+                                         frac=tot * its_per_s / 8.0e12))
+
+    roof = steady = None
+    if fused:
+        r = stamp_roofline(args.steps / elapsed, stamp_reps) if rank == 0 else stepper.run(stamp_reps)
+        roof = r if rank == 0 else None
+        if args.steady > 0:
+            # the steady state of the same fit (BASELINE cfg2 is a 400-step fit: iterations 5-25, which short driver flags
+            # time, are its heaviest - the band where render and target disagree is still wide, the sweeps see 5-10 M pairs
+            # instead of 1.4 M): continue to iteration >= 400, then time `--steady` more
+            stepper.run(steady_warm)
+            first = args.warmup + args.steps + stamp_reps + steady_warm
+            el_s = timed(args.steady)
+            sroof = stamp_roofline(args.steady / el_s, stamp_reps) if rank == 0 else stepper.run(stamp_reps)
+            if rank == 0:
+                steady = dict(value=world * args.steady / el_s, unit="it/s", ms_per_step=1e3 * el_s / args.steady,
+                              steps=args.steady, first_timed_iteration=first, seconds=el_s, roofline=sroof,
+                              note="same process, same fit, same hipGraph as the headline; max over ranks")
+
+    evo = stepper.loss_evolution(args.warmup + args.steps)
 
     multi = None
     if args.multi_clip > 1 and args.loop == "fused":
@@ -663,8 +740,10 @@ def main():
 
     cpu = parity = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu, evo_cpu = cpu_baseline(clip, lw, mano, args.cpu_budget, rend_size=S, image_size=S)
+        cpu, evo_cpu = cpu_baseline(clip, lw, mano, args.cpu_budget, rend_size=S, image_size=S, ordinal_depth=args.depth)
         parity = dict(cfg2_first_steps=trajectory_parity(evo, evo_cpu),
+                      lockstep=(lockstep_parity(mano, step2=args.step2, steps=args.lockstep, frames=B, size=S, clip=clip, lw=lw)
+                                if args.lockstep > 0 and not args.depth else None),
                       cfg1=cfg1_parity(mano, seeds=list(range(args.parity_seeds))) if args.parity_seeds > 0 else None,
                       bar="north_star: 1e-4 relative on losses, 1e-3 mm on final vertices; the hard rasteriser makes the "
                           "loss piecewise constant in the pose, so trajectories separate once a sample flips (DESIGN.md 2)")
@@ -677,11 +756,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("cfg3" if args.step2 else "cfg2") +
                        f": 1 clip/GPU x {B} frames {S}x{S}, synthetic MANO hand + lathe bottle ({F} faces, {V} verts), "
-                       + ("step-2" if args.step2 else "step-1") + " loss set, Adam step + loss logging in the timed region",
+                       + ("step-2" if args.step2 else "step-1") + " loss set" + (" + ordinal depth term (lw_depth=1)" if args.depth else "")
+                       + ", Adam step + loss logging in the timed region",
                        "frames": B, "rend_size": S, "faces": int(F), "clips_per_gpu": 1,
                        "loop": ("fused C-ABI launch sequence" if args.loop == "fused" else "HOMan.forward + autograd") + ", forward+backward+Adam+logging replayed from a hipGraph", "parallelism": f"{world} independent clips"},
             "final_loss": evo["loss"][-1], "first_loss": evo["loss"][0],
-            "roofline": roof, "cpu_baseline": cpu, "multi_clip": multi, "final_loss_parity": parity,
+            "roofline": roof, "steady_state": steady, "cpu_baseline": cpu, "multi_clip": multi,
+            "final_loss_parity": parity,
         }
         emit(line)
     if world > 1:

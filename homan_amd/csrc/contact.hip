@@ -89,26 +89,29 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_hand(const float* __rest
 // so a gather per object vertex serialises on the popular ones; instead every hand vertex adds into a per-frame LDS
 // accumulator with 64-bit FIXED-POINT atomics (2^-44 units): integer addition is associative, so the result does not
 // depend on the order the atomics land in -- deterministic without a sort.  |g| <= 1/(B*Vh) here, far inside the range.
-#define CONTACT_MAX_VO 4096
+#define CONTACT_MAX_VO 4096                    // object vertices per workgroup (96 KB of LDS accumulators)
 #define CONTACT_FIX 17592186044416.0f          // 2^44
+// grid (B, ceil(Vo / CONTACT_MAX_VO)): a workgroup owns one range of object vertices and adds the hand vertices that picked
+// a vertex of its range (every workgroup of the frame walks the frame's 778 picks; meshes of up to 4096 vertices are one range)
 __global__ __launch_bounds__(NN_THREADS) void k_contact_obj(const int* __restrict__ nn_idx, const float* __restrict__ g_hand,
                                                              int B, int Vh, int Vo, float* __restrict__ g_obj)
 {
     HM_LATENCY_KERNEL();
     __shared__ unsigned long long acc[CONTACT_MAX_VO * 3];
-    const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < 3 * Vo; i += NN_THREADS) acc[i] = 0ull;
+    const int b = blockIdx.x, lo = blockIdx.y * CONTACT_MAX_VO, n = min(Vo - lo, CONTACT_MAX_VO);
+    for (int i = threadIdx.x; i < 3 * n; i += NN_THREADS) acc[i] = 0ull;
     __syncthreads();
     for (int i = threadIdx.x; i < Vh; i += NN_THREADS) {
-        const int j = nn_idx[(long)b * Vh + i];
+        const int j = nn_idx[(long)b * Vh + i] - lo;
+        if (j < 0 || j >= n) continue;
         const float* gh = g_hand + ((long)b * Vh + i) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c)
             atomicAdd(&acc[3 * j + c], (unsigned long long)(long long)__float2ll_rn(gh[c] * CONTACT_FIX));
     }
     __syncthreads();
-    float* go = g_obj + (long)b * Vo * 3;
-    for (int i = threadIdx.x; i < 3 * Vo; i += NN_THREADS)
+    float* go = g_obj + ((long)b * Vo + lo) * 3;
+    for (int i = threadIdx.x; i < 3 * n; i += NN_THREADS)
         go[i] = -(float)(long long)acc[i] * (1.0f / CONTACT_FIX);
 }
 
@@ -179,10 +182,9 @@ int hm_contact_fwd_clips(const float* verts_hand, const float* verts_obj, const 
     HM_CHECK_ARG(B > 0 && Vh > 0 && Vo > 0 && HM_CLIP_LEN_OK(B, clip_len));
     const int Bc = clip_len ? clip_len : B;
     HM_CHECK_ARG(Bc <= 512);
-    if (Vo > CONTACT_MAX_VO) return HM_ERR_UNSUPPORTED;     // per-frame object accumulator in LDS (96 KB at 4096 vertices)
     hipLaunchKernelGGL(k_contact_hand, dim3(B), dim3(NN_THREADS), 0, stream, verts_hand, verts_obj, nn_idx, B, Vh, Vo,
                        thresh, g_hand, (float*)workspace, (unsigned int*)((float*)workspace + 512), out1, Bc, out_stride);
-    hipLaunchKernelGGL(k_contact_obj, dim3(B), dim3(NN_THREADS), 0, stream, nn_idx, g_hand, B, Vh,
+    hipLaunchKernelGGL(k_contact_obj, dim3(B, hm_cdiv(Vo, CONTACT_MAX_VO)), dim3(NN_THREADS), 0, stream, nn_idx, g_hand, B, Vh,
                        Vo, g_obj);
     return hm_launch_status();
 }

@@ -29,17 +29,33 @@ def _active(group=None):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+def _staged(t, group):
+    """gloo moves host memory: a device tensor goes through a host copy there (the test / debugging backend that lets
+    several ranks share ONE GPU; under nccl = RCCL the collective runs on the device tensor, on the compute stream)"""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def sync_shared_scalar_grad(grad, group=None):
     """Sum the gradient of a shared scalar over all ranks, in place (one all-reduce of 1 fp32 per step)."""
     if _active(group):
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+        if _staged(grad, group):
+            host = grad.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            grad.copy_(host)
+        else:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
     return grad
 
 
 def broadcast_shared_scalar(value, src=0, group=None):
     """Make every rank start from rank `src`'s value of the shared scalar (`value`: tensor, updated in place)."""
     if _active(group):
-        dist.broadcast(value, src=src, group=group)
+        if _staged(value, group):
+            host = value.detach().cpu()
+            dist.broadcast(host, src=src, group=group)
+            value.copy_(host)
+        else:
+            dist.broadcast(value, src=src, group=group)
     return value
 
 
@@ -47,12 +63,17 @@ def max_over_ranks(seconds, device=None, group=None):
     """Timing convention of bench.py: the job takes as long as its slowest rank."""
     if not _active(group):
         return seconds
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64, device="cpu" if dist.get_backend(group) == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
     return float(t.item())
 
 
-def optimize_clip_shard(models, loss_weights, num_iterations, lr=1e-2, shared_scale=False, group=None):
+def group_src(group=None):
+    """global rank of the group's first member: the one source every side of a shared-scalar broadcast must name"""
+    return dist.get_global_rank(group, 0) if group is not None else 0
+
+
+def optimize_clip_shard(models, loss_weights, num_iterations, lr=1e-2, shared_scale=False, group=None, device=None):
     """This rank's clips (HOMan models of identical shapes) as ONE clip batch on its GPU: every kernel launched once per
     iteration over all the clips (homan_amd.clipbatch), replayed from a hipGraph.  -> list of loss_evolution dicts, one
     per clip; the models hold their optimised parameters.  cfg4: shared_scale=False, no collective.  cfg5:
@@ -60,8 +81,10 @@ def optimize_clip_shard(models, loss_weights, num_iterations, lr=1e-2, shared_sc
     from .jointopt import FusedStepper
     if not models:          # a rank without clips still takes part in the collectives of the others
         if shared_scale and _active(group):
-            z = torch.zeros(1, device="cuda")
-            broadcast_shared_scalar(z, 0, group)
+            if device is None:      # where the collectives of this group live: the GPU under RCCL, the host under gloo
+                device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
+            z = torch.zeros(1, device=device)
+            broadcast_shared_scalar(z, group_src(group), group)     # same source as FusedStepper._sync_shared_scale_start
             for _ in range(num_iterations):
                 sync_shared_scalar_grad(z.zero_(), group)
         return []
@@ -85,7 +108,7 @@ def optimize_clips_shared_scale(models, optimizers, loss_weights, num_iterations
         device = getattr(models[0], scale_name).device if models else ("cuda" if dist.is_initialized() and
                                                                        dist.get_backend(group) == "nccl" else "cpu")
     start = getattr(models[0], scale_name).detach().clone() if models else torch.zeros(1, device=device)
-    broadcast_shared_scalar(start, 0, group)
+    broadcast_shared_scalar(start, group_src(group), group)
     with torch.no_grad():
         for m in models:
             getattr(m, scale_name).copy_(start)

@@ -174,22 +174,18 @@ class HOMan(nn.Module):
         self.renderer.light_intensity_direction = 0.3
         self.renderer.light_intensity_ambient = 0.5
         self.renderer.background_color = [1.0, 1.0, 1.0]
-        verts_object, verts_hand = self.verts_object_init, self.verts_hand_init
-        ref_verts_list = [verts_object[:1]] + [verts_hand[i:i + 1] for i in range(self.hand_nb)]
-        ref_faces_list = [self.faces_object[:1]] + [self.faces_hand[i:i + 1] for i in range(self.hand_nb)]
-        pred_colors = ["gold"] + ["grey"] * self.hand_nb
-        gt_colors = ["green"] + ["blue"] * self.hand_nb
-        faces, textures = get_faces_and_textures(ref_verts_list, ref_faces_list, color_names=pred_colors)
-        self.faces = faces.repeat(batch_size, 1, 1)
-        self.textures = textures.repeat(batch_size, 1, 1, 1, 1, 1)
-        faces_gt, textures_gt = get_faces_and_textures(ref_verts_list, ref_faces_list, color_names=gt_colors)
-        self.textures_gt = textures_gt.repeat(batch_size, 1, 1, 1, 1, 1)
-        self.faces_gt = faces_gt.repeat(batch_size, 1, 1)
-        faces_with_gt, textures_with_gt = get_faces_and_textures(ref_verts_list + ref_verts_list,
-                                                                 ref_faces_list + ref_faces_list,
-                                                                 color_names=pred_colors + gt_colors)
-        self.textures_with_gt = textures_with_gt.repeat(batch_size, 1, 1, 1, 1, 1)
-        self.faces_with_gt = faces_with_gt.repeat(batch_size, 1, 1)
+        # one scene = object first, then the hands (first frame's meshes give the per-mesh face counts).  Three colourings
+        # of it, each stored as `faces<suffix>` / `textures<suffix>` replicated over the frames (:177-219): the fit
+        # (gold object, grey hands), the ground truth (green, blue), and both in one scene (fit meshes, then truth meshes).
+        scene = [(self.verts_object_init[:1], self.faces_object[:1])]
+        scene += [(self.verts_hand_init[h:h + 1], self.faces_hand[h:h + 1]) for h in range(self.hand_nb)]
+        fit_palette = ["gold"] + ["grey"] * self.hand_nb
+        truth_palette = ["green"] + ["blue"] * self.hand_nb
+        for suffix, meshes, palette in (("", scene, fit_palette), ("_gt", scene, truth_palette),
+                                        ("_with_gt", scene + scene, fit_palette + truth_palette)):
+            f, tex = get_faces_and_textures([v for v, _ in meshes], [t for _, t in meshes], color_names=palette)
+            setattr(self, "faces" + suffix, f.repeat(batch_size, 1, 1))
+            setattr(self, "textures" + suffix, tex.repeat(batch_size, 1, 1, 1, 1, 1))
 
     def render_limem(self, renderer, verts, faces, textures, K, max_in_batch=5):
         """:510-544: render in chunks, -> images (N,S,S,3) float in [0,1] (numpy), masks (N,S,S) bool."""

@@ -422,43 +422,48 @@ class FusedStepper:
             # same-box A/B on cfg3, round 2 before the launch fusions: 1280 -> 4030, 768 -> 4130, 512 -> 4194 it/s; after them,
             # with the raster ballast below: 512 -> 4408, 768 -> 4552, 1024 -> 4537, 1280 -> 4512)
             sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (768 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
-            prev = _lib.lib().hm_tune_sweep_blocks(sb)
+            pad = os.environ.get("HOMAN_RASTER_PAD")
             # same idea for the rasteriser: 8 KB of LDS ballast = 4 workgroups per CU instead of 6 leaves registers for the
             # hand-side kernels (cfg3 one clip: 4347 -> 4500 it/s; cfg2, where that chain is short: 5820 -> 5500, so not there)
-            pad = os.environ.get("HOMAN_RASTER_PAD")
             pad = int(pad) if pad is not None else (4096 if (self.on["col"] or self.on["con"]) and C == 1 else 0)
-            prev_pad = _lib.lib().hm_tune_raster_lds_pad(pad)
             # the raster's launch order follows the measured cost of its workgroups from iteration to iteration
             # (hm_tune_raster_reorder; same-box A/B: raster 57 -> 45 us inside the graph at one clip, 356 -> 298 us at eight; the
             # iteration: clip batches and the step-2 sets +0.3..1 %, one-clip step-1 fits +4 % in the steady state and over
             # iterations 5-25 - but only since the metric-only search got shorter: while the hand-side chain was as long as the
             # silhouette chain it had been running in the raster's tail and a shorter raster pushed it under the sweeps, -4 %)
             ro = int(os.environ.get("HOMAN_RASTER_REORDER", "1"))
-            prev_reorder = _lib.lib().hm_tune_raster_reorder(ro)
             # and for the metric-only search of a clip batch: its 1680 small, latency-bound workgroups otherwise take every wave
             # slot of the CUs next to the line expansion (lines 250 -> 226 us, iteration -4.4 % at 3 search workgroups per CU;
             # 2 per CU make the search itself the tail)
             nn_pad = os.environ.get("HOMAN_NN_PAD")
             nn_pad = int(nn_pad) if nn_pad is not None else (40960 if C > 1 and not self.on["con"] else 0)
-            prev_nn_pad = _lib.lib().hm_tune_nn_lds_pad(nn_pad)
             fam_pads = [int(x) for x in os.environ.get("HOMAN_FAM_PADS", "0,0,0,0,0").split(",")]
-            prev_fam = [_lib.lib().hm_tune_lds_pad(i, v) for i, v in enumerate(fam_pads)]
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.cap_stream):
-                self.forward_backward(log=not self.log_in_adam)
-                if not self.shared_scale:
-                    self.opt.step(zero_grad=False, log=self._adam_log())
-            if self.shared_scale:        # the all-reduce of the scale gradient runs between two captured halves
-                self.graph_b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph_b, stream=self.cap_stream):
-                    self._spread_shared_scale_grad()
-                    self.opt.step(zero_grad=False)
-            _lib.lib().hm_tune_sweep_blocks(prev)
-            _lib.lib().hm_tune_raster_lds_pad(prev_pad)
-            _lib.lib().hm_tune_raster_reorder(prev_reorder)
-            _lib.lib().hm_tune_nn_lds_pad(prev_nn_pad)
-            for i, v in enumerate(prev_fam):
-                _lib.lib().hm_tune_lds_pad(i, v)
+            # the hints are process-wide values read when a launch is issued (= captured): set, capture, restore - whatever
+            # happens in between (a capture that raises must not leave them changed for the next stepper)
+            tune = _lib.lib()
+            prev = tune.hm_tune_sweep_blocks(sb)
+            prev_pad = tune.hm_tune_raster_lds_pad(pad)
+            prev_reorder = tune.hm_tune_raster_reorder(ro)
+            prev_nn_pad = tune.hm_tune_nn_lds_pad(nn_pad)
+            prev_fam = [tune.hm_tune_lds_pad(i, v) for i, v in enumerate(fam_pads)]
+            try:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self.cap_stream):
+                    self.forward_backward(log=not self.log_in_adam)
+                    if not self.shared_scale:
+                        self.opt.step(zero_grad=False, log=self._adam_log())
+                if self.shared_scale:        # the all-reduce of the scale gradient runs between two captured halves
+                    self.graph_b = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_b, stream=self.cap_stream):
+                        self._spread_shared_scale_grad()
+                        self.opt.step(zero_grad=False)
+            finally:
+                tune.hm_tune_sweep_blocks(prev)
+                tune.hm_tune_raster_lds_pad(prev_pad)
+                tune.hm_tune_raster_reorder(prev_reorder)
+                tune.hm_tune_nn_lds_pad(prev_nn_pad)
+                for i, v in enumerate(prev_fam):
+                    tune.hm_tune_lds_pad(i, v)
 
     # ---- shared object scale (BASELINE cfg5): C local replicas of one scalar, kept identical on every rank
     def _dist_on(self):
@@ -471,17 +476,17 @@ class FusedStepper:
         with torch.no_grad():
             s0 = s.data[:1].clone()              # one element on the wire whatever the number of local clips
             if self._dist_on():
-                dist.broadcast(s0, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0,
-                               group=self.group)
+                from .dist import broadcast_shared_scalar, group_src
+                broadcast_shared_scalar(s0, group_src(self.group), self.group)
             s.copy_(s0.expand_as(s))
         self.g_shared = torch.zeros(1, device=s.device)
 
     def _reduce_shared_scale_grad(self):
         """One fp32 per step over xGMI: sum over ranks of (sum over local clips of d loss / d scale), on the compute
         stream, no host synchronisation."""
-        import torch.distributed as dist
         if self._dist_on():
-            dist.all_reduce(self.g_shared, op=dist.ReduceOp.SUM, group=self.group)
+            from .dist import sync_shared_scalar_grad
+            sync_shared_scalar_grad(self.g_shared, self.group)
 
     def _spread_shared_scale_grad(self):
         # every replica receives the global sum (identical Adam steps keep the replicas bit-identical)
@@ -625,9 +630,11 @@ class FusedStepper:
             def search_and_contact(stream_obj, rws):
                 sx = stream_obj.cuda_stream
                 if (on["con"] or on["inter"]) and not nn_fused and not nn_full_fused:
-                    # (without the contact term only the logged distance is needed: metric-only search)
-                    ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if on["con"] else None,
-                                               P(self.nn_d2) if on["con"] else None, self._slot("handobj_maxdist"), rws, CL, NS,
+                    # (without the contact term only the logged distance is needed: metric-only search - its group table
+                    #  covers 4096 object vertices, larger meshes take the full search for the same number)
+                    full = on["con"] or Vo > 4096
+                    ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if full else None,
+                                               P(self.nn_d2) if full else None, self._slot("handobj_maxdist"), rws, CL, NS,
                                                P(self.obj_order), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
                                                P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sx), "nn")
                 if on["con"]:
@@ -827,14 +834,12 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
                          optimize_object_scale=False, state_dict=None, fps=24, viz_len=7, image_size=640,
                          # homan_amd extensions
                          mode="auto", mano_model=None, rend_size=256, ordinal_depth=False):
-    if mode == "auto":
-        # the fused launch sequence when it covers the configuration (every BASELINE config: the CLI's optimize_mano=1,
-        # optimize_mano_beta, persp, no depth term, silhouettes on a multiple of 32), else the same iteration through
-        # HOMan.forward + autograd in a hipGraph; mode="eager" is the reference's loop verbatim (host sync per logged value)
-        depth_on = (loss_weights or {}).get("lw_depth", 0) > 0
-        fused_ok = (optimize_mano and optimize_mano_beta and hand_proj_mode == "persp" and rend_size % 32 == 0 and
-                    (not depth_on or image_size % 32 == 0) and list(person_parameters[0]["hand_side"]) == ["right"])
-        mode = "fused" if fused_ok else "graph"
+    auto = mode == "auto"
+    if auto:
+        # the fused launch sequence whenever FusedStepper accepts the configuration (every BASELINE config), else the same
+        # iteration through HOMan.forward + autograd in a hipGraph; mode="eager" is the reference's loop verbatim (host sync
+        # per logged value).  FusedStepper's own capability guards decide (below): no second copy of them here.
+        mode = "fused"
     model = build_model(person_parameters, object_parameters, class_name, objvertices, objfaces, camintr,
                         hand_proj_mode, optimize_mano, optimize_mano_beta, optimize_object_scale, state_dict,
                         image_size, mano_model, rend_size, sync_metrics=(mode == "eager"), ordinal_depth=ordinal_depth)
@@ -843,8 +848,15 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
     imgs = OrderedDict()
     viz = images is not None and viz_step
     if mode in ("graph", "fused"):
-        cls = GraphStepper if mode == "graph" else FusedStepper
-        stepper = cls(model, loss_weights, lr, num_iterations)
+        if mode == "fused":
+            try:
+                stepper = FusedStepper(model, loss_weights, lr, num_iterations)
+            except (NotImplementedError, _lib.HomanAmdError):
+                if not auto:
+                    raise
+                mode = "graph"        # a configuration the fused launch sequence does not cover
+        if mode == "graph":
+            stepper = GraphStepper(model, loss_weights, lr, num_iterations)
         step = 0
         while step < num_iterations:
             if viz:

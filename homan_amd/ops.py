@@ -78,6 +78,23 @@ class SilhouetteContext:
         d = self.S - self.size
         return torch.nn.functional.pad(img, (0, d, 0, d), value=value).contiguous()
 
+    def eps(self):
+        """the rasteriser's eps (NDC units, added to every pseudo-distance of the backward) in the units of the grid the
+        kernels render on: a padded render's NDC is the requested image's times size / S, and d loss / d NDC is carried
+        back through that factor, so eps scales with it (otherwise the gradient is off by ~eps / pixel pitch: 1-2 %)"""
+        return NMR_EPS * self.size / self.S if self.padded else NMR_EPS
+
+    def crop_samples(self, img):
+        """(.., 2S, 2S) sample-resolution image -> the (.., 2 size, 2 size) block the caller asked for (no-AA renders)"""
+        n = 2 * self.size
+        return img[..., :n, :n].contiguous() if self.padded else img
+
+    def pad_samples(self, img, value=0.0):
+        if not self.padded:
+            return img
+        d = 2 * (self.S - self.size)
+        return torch.nn.functional.pad(img, (0, d, 0, d), value=value).contiguous()
+
     def calibrate(self):
         """Cost-sorted launch orders from the screen boxes of the last forward (poses move little during an
         optimisation, so the statistics of the current state predict the cost of the next iterations):
@@ -156,7 +173,7 @@ class _SilhouetteLoss(torch.autograd.Function):
         g_loss = _f32(g_loss).reshape(1)
         grad_verts = torch.empty_like(verts)
         _lib.check(_lib.lib().hm_sil_bwd(
-            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), NMR_EPS, 1,
+            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), sctx.eps(), 1,
             _lib.ptr(g_loss), None, _lib.ptr(keep_sum), _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
             _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None, None, None, None
@@ -185,7 +202,7 @@ class _SilhouetteRender(torch.autograd.Function):
         g_img = sctx.pad(_f32(g_img))
         grad_verts = torch.empty_like(verts)
         _lib.check(_lib.lib().hm_sil_bwd(
-            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), NMR_EPS, 0,
+            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), sctx.eps(), 0,
             None, _lib.ptr(g_img), None, _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
             _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), _lib.ptr(sctx.grad_ndc) if getattr(sctx, "grad_ndc", None) is not None else None,
             _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
@@ -199,7 +216,7 @@ class _SilhouetteRenderNoAA(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, verts, K, sctx, orig_size):
-        verts, K = _f32(verts), _f32(K)
+        verts, K = _f32(verts), sctx.K_eff(_f32(K))       # (sizes off the 64-sample grid: padded render, cropped below)
         n = 2 * sctx.S
         pooled = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
         alpha = torch.empty(sctx.B, n, n, device=verts.device)
@@ -210,16 +227,16 @@ class _SilhouetteRenderNoAA(torch.autograd.Function):
             _lib.stream()), "hm_sil_fwd")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
-        return alpha
+        return sctx.crop_samples(alpha)
 
     @staticmethod
     def backward(ctx, g_img):
         verts, K = ctx.saved_tensors
         sctx = ctx.sctx
-        g_img = _f32(g_img)
+        g_img = sctx.pad_samples(_f32(g_img))
         grad_verts = torch.empty_like(verts)
         _lib.check(_lib.lib().hm_sil_bwd(
-            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), NMR_EPS, 3,
+            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), sctx.eps(), 3,
             None, _lib.ptr(g_img), None, _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
             _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None
@@ -237,8 +254,9 @@ class _MaskedSilhouetteL2NoAA(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, verts, K, keep, ref, sctx, orig_size):
-        verts, K = _f32(verts), _f32(K)
+        verts, K = _f32(verts), sctx.K_eff(_f32(K))
         n = 2 * sctx.S
+        keep, ref = sctx.pad_samples(keep), sctx.pad_samples(ref)      # (padding: keep = 0, it counts for nothing)
         assert keep.shape == (n, n) and ref.shape == (n, n) and keep.is_contiguous() and ref.is_contiguous()
         pooled = torch.empty(sctx.B, sctx.S, sctx.S, device=verts.device)
         alpha = torch.empty(sctx.B, n, n, device=verts.device)
@@ -252,6 +270,7 @@ class _MaskedSilhouetteL2NoAA(torch.autograd.Function):
                                             _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_reduce")
         ctx.save_for_backward(verts, K)
         ctx.sctx, ctx.orig_size = sctx, orig_size
+        alpha = sctx.crop_samples(alpha)
         ctx.mark_non_differentiable(alpha)
         return frame[:, 0], frame[:, 1], alpha
 
@@ -262,7 +281,7 @@ class _MaskedSilhouetteL2NoAA(torch.autograd.Function):
         g_loss = _f32(g_loss).contiguous()
         grad_verts = torch.empty_like(verts)
         _lib.check(_lib.lib().hm_sil_bwd(
-            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), NMR_EPS, 4,
+            _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), sctx.eps(), 4,
             _lib.ptr(g_loss), None, None, _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
             _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None, None, None

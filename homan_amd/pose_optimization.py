@@ -93,9 +93,10 @@ class PoseOptimizer(nn.Module):
             raise RuntimeError("homan_amd.pose_optimization needs an MI355X (ROCm) device; there is no CPU path")
         dev = torch.device("cuda")
         size = int(ref_image.shape[0])
-        if size % 64:
-            raise NotImplementedError(f"pose initialisation renders without anti-aliasing on a size/2 tile grid: mask sizes "
-                                      f"must be multiples of 64 (the reference's REND_SIZE is 256), got {size}")
+        if size % 2:
+            raise NotImplementedError(f"pose initialisation renders on a grid of 2x2-sample pixels: even mask sizes only "
+                                      f"(the reference's REND_SIZE is 256), got {size}")
+        # (sizes off the kernels' 64-sample tile grid are rendered on the next one and cropped: ops.SilhouetteContext)
         # Every per-candidate buffer is ONE device array replicated on the device (the reference builds the 500-fold copies
         # of the mask on the host and uploads ~400 MB per fit, which was two thirds of a whole 50-step fit here).
         n = num_initializations
@@ -249,34 +250,47 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
     camintr_roi[:, :2] = camintr_roi[:, :2] / rend_size          # crop K to normalised rendering space (:321)
     model = PoseOptimizer(ref_image=mask, vertices=vertices, faces=faces, rotation_init=matrix_to_rot6d(rotations_init),
                           translation_init=translations_init, num_initializations=num_initializations, K=camintr_roi)
-    if mode == "graph" and num_iterations > 0:
-        losses, best_rots_single, best_trans_single = _graph_loop(model, lr, num_iterations)
-    elif mode in ("eager", "graph"):
-        optimizer = torch.optim.Adam(model.parameters(), lr=lr)
-        best_loss_single, best_rots_single, best_trans_single = np.inf, None, None
-        for _ in range(num_iterations):
-            optimizer.zero_grad()
-            loss_dict, _iou, _sil = model()
-            losses = sum(loss_dict.values())
-            losses.sum().backward()
-            optimizer.step()
-            if losses.min() < best_loss_single:
-                ind = torch.argmin(losses)
-                best_loss_single = losses[ind]
-                best_rots_single = model.rotations[ind].detach().clone()
-                best_trans_single = model.translations[ind].detach().clone()
-    else:
+    if mode not in ("eager", "graph"):
         raise ValueError(f"mode {mode} not in [eager|graph]")
-    best_rots, best_trans, best_losses = model.rotations, model.translations, losses
-    if sort_best:
-        inds = torch.argsort(best_losses)
-        best_trans = best_trans[inds][:num_initializations].detach().clone()
-        best_rots = best_rots[inds][:num_initializations].detach().clone()
-        best_rots = torch.cat((best_rots_single.unsqueeze(0), best_rots[:-1]), 0)
-        best_trans = torch.cat((best_trans_single.unsqueeze(0), best_trans[:-1]), 0)
-    model.rotations = nn.Parameter(best_rots)
-    model.translations = nn.Parameter(best_trans)
+    if mode == "graph" and num_iterations > 0:
+        final_losses, champion_rot, champion_trans = _graph_loop(model, lr, num_iterations)
+    else:
+        final_losses, champion_rot, champion_trans = _host_loop(model, lr, num_iterations)
+    _install_ranked_poses(model, final_losses, champion_rot, champion_trans, sort_best)
     return model
+
+
+def _host_loop(model, lr, num_iterations):
+    """The reference's fit loop (:330-357) with torch Adam, one host round trip per step for the champion test.  The
+    champion is the pose with the smallest loss EVER evaluated (strict `<`), recorded as it stands after the optimiser step
+    that followed that evaluation (:348-353 copy the parameters behind `optimizer.step()`)."""
+    adam = torch.optim.Adam(model.parameters(), lr=lr)
+    champion = dict(loss=float("inf"), rot=None, trans=None)
+    per_pose = None
+    for _ in range(num_iterations):
+        adam.zero_grad()
+        terms, _, _ = model()
+        per_pose = sum(terms.values())
+        per_pose.sum().backward()
+        adam.step()
+        value, where = per_pose.detach().min(0)
+        if float(value) < champion["loss"]:
+            champion = dict(loss=float(value), rot=model.rotations.detach()[where].clone(),
+                            trans=model.translations.detach()[where].clone())
+    return per_pose, champion["rot"], champion["trans"]
+
+
+def _install_ranked_poses(model, final_losses, champion_rot, champion_trans, ranked):
+    """What the caller reads back (:359-381): unranked = the candidates in their original order (`find_optimal_poses`
+    needs them aligned from frame to frame); ranked = the champion in slot 0, then the candidates by ascending final loss
+    with the last one dropped so that the count stays `num_initializations`."""
+    rots, trans = model.rotations.detach(), model.translations.detach()
+    if ranked:
+        order = torch.argsort(final_losses.detach())[:-1]
+        rots = torch.cat([champion_rot[None], rots[order]])
+        trans = torch.cat([champion_trans[None], trans[order]])
+    model.rotations = nn.Parameter(rots.clone())
+    model.translations = nn.Parameter(trans.clone())
 
 
 def rot6d_to_matrix(rot_6d):
@@ -299,35 +313,38 @@ def find_optimal_poses(image_size, faces=None, vertices=None, annotations=None, 
     IoU over the clip (:468).  annotations[i]: {"target_crop_mask" (S,S) ndarray in {-1,0,1}, "bbox" xywh, "square_bbox"
     xywh, "full_mask" tensor}.  Returns one dict per frame: rotations (1,3,3), translations (1,1,3), verts_trans (1,V,3),
     target_masks (1,S,S), K_roi (1,1,3,3), masks, verts (1,V,3), full_mask."""
-    vertices, faces = torch.as_tensor(vertices), torch.as_tensor(faces)
-    assert vertices.dim() == 2 and vertices.shape[1] == 3 and faces.dim() == 2 and faces.shape[1] == 3
+    mesh_v, mesh_f = torch.as_tensor(vertices), torch.as_tensor(faces)
+    if mesh_v.dim() != 2 or mesh_v.shape[1] != 3 or mesh_f.dim() != 2 or mesh_f.shape[1] != 3:
+        raise AssertionError("vertices (V,3) and faces (F,3) of ONE mesh expected")
     dev = torch.device("cuda")
-    vertices, faces = vertices.float().to(dev), faces.to(dev)
-    previous_rotations, all_object_parameters, all_losses = None, [], []
-    images = images if images is not None else [None] * len(annotations)
-    for image, annotation, K in zip(images, annotations, Ks):
-        model = find_optimal_pose(vertices=vertices, faces=faces, image=image, mask=annotation["target_crop_mask"],
-                                  bbox=annotation["bbox"], square_bbox=annotation["square_bbox"], image_size=image_size,
-                                  K=K, num_iterations=num_iterations, num_initializations=num_initializations, debug=debug,
-                                  sort_best=False, rotations_init=previous_rotations, rend_size=rend_size, mode=mode)
+    mesh_v, mesh_f = mesh_v.float().to(dev), mesh_f.to(dev)
+    frames = len(annotations)
+    pictures = list(images) if images is not None else [None] * frames
+    # pass 1: frame by frame, all candidates kept side by side (frame t starts from frame t-1's fitted rotations)
+    cand_rot, cand_trans, cand_verts, cand_iou, roi_K = [], [], [], [], []
+    seed_rotations = None
+    for t in range(frames):
+        ann = annotations[t]
+        fit = find_optimal_pose(vertices=mesh_v, faces=mesh_f, image=pictures[t], mask=ann["target_crop_mask"],
+                                bbox=ann["bbox"], square_bbox=ann["square_bbox"], image_size=image_size, K=Ks[t],
+                                num_iterations=num_iterations, num_initializations=num_initializations, debug=debug,
+                                sort_best=False, rotations_init=seed_rotations, rend_size=rend_size, mode=mode)
         with torch.no_grad():
-            _, iou, _ = model()
-            verts_trans = model.apply_transformation()
-            rotations = rot6d_to_matrix(model.rotations.detach())
-        all_object_parameters.append({
-            "rotations": rotations, "translations": model.translations.detach(),
-            "target_masks": torch.from_numpy(np.asarray(annotation["target_crop_mask"])).to(dev),
-            "K_roi": model.K.detach(), "masks": torch.as_tensor(annotation["full_mask"]).to(dev),
-            "verts": vertices.detach(), "verts_trans": verts_trans.detach()})
-        previous_rotations = rotations
-        all_losses.append(iou.detach())
-    all_losses = torch.stack(all_losses)                          # (frame_nb, num_initializations)
-    best_idx = torch.argsort(all_losses.mean(0))[-1]              # highest mean IoU over the sequence
-    all_final_params = []
-    for obj_params, info in zip(all_object_parameters, annotations):
-        final_params = {key: obj_params[key][best_idx].unsqueeze(0) for key in ("rotations", "translations", "verts_trans")}
-        for key in ("target_masks", "K_roi", "masks", "verts"):
-            final_params[key] = obj_params[key].unsqueeze(0)
-        final_params["full_mask"] = torch.as_tensor(info["full_mask"]).to(dev)
-        all_final_params.append(final_params)
-    return all_final_params
+            cand_iou.append(fit()[1].detach())
+            cand_verts.append(fit.apply_transformation().detach())
+            seed_rotations = rot6d_to_matrix(fit.rotations.detach())
+        cand_rot.append(seed_rotations)
+        cand_trans.append(fit.translations.detach())
+        roi_K.append(fit.K.detach())
+    # pass 2: ONE candidate index for the whole clip - the one whose IoU, averaged over the frames, is highest (:468)
+    # (last entry of the ascending argsort, as the reference takes it: same pick as it on ties, e.g. all-zero IoUs)
+    winner = int(torch.argsort(torch.stack(cand_iou).mean(0))[-1])
+    results = []
+    for t in range(frames):
+        ann = annotations[t]
+        full = torch.as_tensor(ann["full_mask"]).to(dev)
+        results.append({"rotations": cand_rot[t][winner][None], "translations": cand_trans[t][winner][None],
+                        "verts_trans": cand_verts[t][winner][None],
+                        "target_masks": torch.from_numpy(np.asarray(ann["target_crop_mask"])).to(dev)[None],
+                        "K_roi": roi_K[t][None], "masks": full[None], "verts": mesh_v[None], "full_mask": full})
+    return results

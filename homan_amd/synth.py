@@ -138,7 +138,9 @@ def make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", si
     rng = np.random.default_rng(seed)
     torch_gen = torch.Generator().manual_seed(seed)
     B = frames
-    if obj == "cube":
+    if isinstance(obj, (tuple, list)):        # (vertices (V,3), faces (F,3)) of a mesh of the caller's
+        ov, of = np.asarray(obj[0], np.float32), np.asarray(obj[1], np.int32)
+    elif obj == "cube":
         ov, of = box_mesh()
     elif obj == "bottle":
         ov, of = bottle_mesh()

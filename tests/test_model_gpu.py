@@ -209,6 +209,43 @@ def test_fused_step_equals_autograd_path(name, mano_model):
             assert p.grad is None or k in ("cams_hand",), k
 
 
+@pytest.mark.parametrize("weights_name", ["STEP1_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS"])
+def test_fused_loop_on_a_mesh_over_4096_vertices(weights_name, mano_model):
+    """Object meshes beyond the metric-only search's group table (4096 vertices, e.g. un-decimated YCB models): the fused
+    loop takes the full search for the logged distance, the contact scatter walks the object in ranges of 4096 vertices -
+    same losses and gradients as HOMan.forward + autograd, and `mode="auto"` runs it."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, build_model, optimize_hand_object
+    ov, of = synth.bottle_mesh(segments=90, rings=50)
+    assert ov.shape[0] > 4096
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    clip = synth.make_clip(seed=3, frames=4, rend_size=64, image_size=64, obj=(ov, of), silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    weights = dict(getattr(synth, weights_name))
+    common = dict(objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"], optimize_mano=True,
+                  image_size=64, mano_model=mano_model, rend_size=64)
+    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                        sync_metrics=False, **common)
+    loss_dict, metric_dict = model(loss_weights=weights)
+    total = sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict)
+    total.sum().backward()
+    ref_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    ref = {k: float(v.detach().reshape(-1)[0]) for k, v in loss_dict.items()}
+    ref.update({k: float(v) for k, v in metric_dict.items()})
+    st = FusedStepper(model, weights, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    for k, v in ref.items():
+        np.testing.assert_allclose(st.log_buf[0, 0, st.SLOTS.index(k)].item(), v, rtol=2e-6, atol=1e-9, err_msg=k)
+    for k, p in model.named_parameters():
+        if k in ref_grads:
+            scale = max(ref_grads[k].abs().max().item(), 1e-20)
+            assert ((p.grad - ref_grads[k]).abs().max() / scale).item() < 2e-5, k
+    _, evo, _ = optimize_hand_object(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                                     loss_weights=weights, num_iterations=3, **common)
+    assert np.isfinite(evo["loss"]).all() and abs(evo["loss"][0] - float(total.detach().reshape(-1)[0])) < 1e-5 * abs(evo["loss"][0])
+
+
 def test_fused_trajectory_matches_reference_loop(mano_model):
     from homan_amd.jointopt import FusedStepper
     rec, model, weights, meta = _build_hip("ref_step2_cube_b4_s64", mano_model, sync=False)
