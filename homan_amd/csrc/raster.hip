@@ -323,7 +323,7 @@ __device__ __forceinline__ void hm_ts_store(unsigned long long* __restrict__ slo
     __builtin_nontemporal_store(t, slots + 2 * unit + which);
 }
 #ifdef RASTER_PHASES
-__device__ unsigned long long g_raster_ph[12];   // cycles of wave 0: scan, near records, near units, far hz + records, far units, tail; workgroups: active, idle; units near / far
+__device__ unsigned long long g_raster_ph[24];   // cycles of wave 0: scan, near records, near units, far hz + records, far units, tail; workgroups: active, idle; units near / far
 #define RPH_MARK(k) do { if (tid == 0) { const unsigned long long t_ = clock64(); rph[k] += t_ - rph_t; rph_t = t_; } } while (0)
 #else
 #define RPH_MARK(k)
@@ -561,6 +561,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
                     const int e = cand[cls ? 2 * CAND_CAP - 1 - (e0 + tid) : e0 + tid];
                     const int fi = e & 0x3fffffff, var = e >> 30;
                     const float* src = faces9 + ((long)b * F + fi) * 9;
+                    const uint2 u = bx[fi];          // (requested with the vertices: one round trip per record, not two)
                     float f[9];
                     if (var == 0) {
 #pragma unroll
@@ -600,13 +601,20 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
                         miss = miss || all_out;
                     }
                     if (!miss) {
-                        const uint2 u = bx[fi];
                         const int x0 = u.x & 0x3fff, y0 = (int)(u.x >> 16), x1 = (int)(u.y & 0xffff), y1 = (int)(u.y >> 16);
                         // region-local 4x4 block range
                         const int bx0 = (max(x0, gx0) - gx0) >> 2, bx1 = (min(x1, gx1) - gx0) >> 2;
                         const int by0 = (max(y0, gy0) - gy0) >> 2, by1 = (min(y1, gy1) - gy0) >> 2;
                         const int nbx = bx1 - bx0 + 1;
                         units = nbx * (by1 - by0 + 1);
+#ifdef RASTER_PHASES
+                        {   // what the unit count would be with blocks anchored at the corner of (box & region)
+                            const int wx = min(x1, gx1) - max(x0, gx0) + 1, wy = min(y1, gy1) - max(y0, gy0) + 1;
+                            atomicAdd(&g_raster_ph[14 + cls], (unsigned long long)(((wx + 3) >> 2) * ((wy + 3) >> 2)));
+                            atomicAdd(&g_raster_ph[16 + cls], (unsigned long long)(((wx + 7) >> 3) * ((wy + 1) >> 1)));
+                            atomicAdd(&g_raster_ph[18 + cls], (unsigned long long)(wx * wy));
+                        }
+#endif
                         const float rz0 = 1.0f / f[2], rz1 = 1.0f / f[5], rz2 = 1.0f / f[8];
                         recs[tid][0] = make_float4(f[0], f[1], f[3], f[4]);
                         recs[tid][1] = make_float4(f[6], f[7], rz0, rz1);
@@ -632,6 +640,21 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
                 }
                 if (tid < RB_PASS) ustart[tid] = woff + incl - units;
                 __syncthreads();
+#ifdef RASTER_PHASES
+                if (tid < RB_PASS && e0 + tid < n) atomicAdd(&g_raster_ph[12 + cls], 1ull);
+                if (cls == 1 && tid < RB_PASS && e0 + tid < n && units > 0) {
+                    // far candidates with at least one block that is not hidden behind the near class
+                    const int pk = __float_as_int(recs[tid][4].w);
+                    const int nbx = (pk >> 6) & 15;
+                    bool any = false;
+                    for (int k = 0; k < units; ++k) {
+                        const int kby = k / nbx;
+                        const int blk = (((pk >> 3) & 7) + kby) * 8 + (pk & 7) + (k - kby * nbx);
+                        any = any || !(czn[tid] > hz[blk]);
+                    }
+                    if (any) atomicAdd(&g_raster_ph[20], 1ull);
+                }
+#endif
                 RPH_MARK(cls == 0 ? 1 : 3);
 #ifdef RASTER_PHASES
                 rph_units[cls] += total;
@@ -667,6 +690,9 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
                             ent = i | (k << 8);
                         }
                         const unsigned long long bal = __ballot(pass);
+#ifdef RASTER_PHASES
+                        if (lane == 0) atomicAdd(&g_raster_ph[21], (unsigned long long)__popcll(bal));
+#endif
                         if (pass) uq[w][qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)ent;
                         qn += __popcll(bal);
                         wave_sync();
@@ -2654,7 +2680,7 @@ int hm_debug_read_partials(const void* workspace, int B, int V, int F, int S, fl
 #ifdef RASTER_PHASES
 int hm_debug_raster_phases(unsigned long long* out)
 {
-    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[24] = {0};
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_raster_ph), sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raster_ph), z, sizeof(z));

@@ -32,7 +32,7 @@ def main():
     L = _lib.lib()
     L.hm_debug_sweep_stats.argtypes = [ctypes.c_void_p]
     L.hm_debug_raster_phases.argtypes = [ctypes.c_void_p]
-    rout = (ctypes.c_ulonglong * 12)()
+    rout = (ctypes.c_ulonglong * 24)()
     rnames = ["scan", "near_rec", "near_units", "far_hz_rec", "far_units", "tail", "wg_active", "wg_idle", "units_near",
               "units_far", "-", "-"]
     out = (ctypes.c_ulonglong * 12)()
@@ -54,6 +54,10 @@ def main():
                 f"  (total {tot / max(1, int(rout[6])):.0f});  active {int(rout[6])} idle {int(rout[7])}  units/wg near "
                 f"{int(rout[8]) / max(1, int(rout[6])):.0f} far {int(rout[9]) / max(1, int(rout[6])):.0f}  covered pairs "
                 f"{int(rout[11])}  wave trips of the covered-sample loop {int(rout[10])} (lane fill {int(rout[11]) / max(1, 64 * int(rout[10])):.2f})")
+            print(f"   candidates near {int(rout[12])} far {int(rout[13])}; far candidates with a surviving block {int(rout[20])}, far units "
+                  f"surviving the hidden-block test {int(rout[21])} of {int(rout[9])}; units if 4x4 blocks were anchored at the box corner: "
+                  f"near {int(rout[14])} (now {int(rout[8])}) far {int(rout[15])}; as 8x2 blocks: near {int(rout[16])} far {int(rout[17])}; box samples "
+                  f"near {int(rout[18])} far {int(rout[19])}")
 
 
 if __name__ == "__main__":
