@@ -19,7 +19,7 @@ from . import ops
 
 # Parameters / buffers concatenated along the frame axis (leading dimension = frames of the clip)
 _PER_FRAME = ["translations_object", "rotations_object", "translations_hand", "rotations_hand", "cams_hand",
-              "mano_pca_pose", "mano_rot", "mano_trans", "mano_betas", "verts_object_og", "ref_verts2d_hand",
+              "mano_pca_pose", "mano_rot", "mano_trans", "mano_betas", "verts_object_og", "verts_hand_og", "ref_verts2d_hand",
               "ref_mask_object", "keep_mask_object", "camintr_rois_object", "camintr"]
 # (1,) per model -> (C,) per batch
 _PER_CLIP = ["int_scales_object", "int_scales_hand", "int_scale_object_mean", "int_scale_hand_mean"]
@@ -75,7 +75,7 @@ class ClipBatch(nn.Module):
                     for i, p in enumerate(parts):
                         p.data = cat.data[i * n:(i + 1) * n]
             faces = m0.faces_object[:1].expand(self.B, -1, -1)
-            self.sil_ctx = ops.SilhouetteContext(faces, m0.verts_object_og.shape[1], self.B, m0.losses.sil_ctx.S, dev)
+            self.sil_ctx = ops.SilhouetteContext(faces, m0.verts_object_og.shape[1], self.B, m0.losses.sil_ctx.size, dev)
             self.keep_sum = torch.cat([m.losses.keep_sum for m in models]).contiguous()
             self.collision_ctx = ops.CollisionContext(m0.mano_model.closed_faces, m0.faces_object[0], self.B, 778,
                                                       m0.verts_object_og.shape[1], dev)

@@ -263,16 +263,18 @@ class FusedStepper:
         from . import constants, ops
         from .clipbatch import ClipBatch, ClipReduceWorkspace
         for one in (model.models if isinstance(model, ClipBatch) else model if isinstance(model, (list, tuple)) else [model]):
-            if list(one.hand_sides) != ["right"]:
-                raise NotImplementedError("the fused loop covers one right hand per frame (every BASELINE configuration); "
-                                          "two hands / a left hand: mode='graph' or 'eager'")
+            if len(one.hand_sides) != 1:
+                raise NotImplementedError("the fused loop covers one hand per frame, right or left (every BASELINE "
+                                          "configuration); two hands: mode='graph' or 'eager'")
             if one.losses.inter_type != "centroid":
                 raise NotImplementedError("the fused loop covers inter_type='centroid' (the reference default); 'min': "
                                           "mode='graph' or 'eager'")
         m = self.model = model if isinstance(model, ClipBatch) else ClipBatch(model if isinstance(model, (list, tuple))
                                                                              else [model])
-        if not (m.optimize_mano and not m.int_scales_hand.requires_grad and m.hand_proj_mode == "persp"):
-            raise NotImplementedError("FusedStepper covers optimize_mano=True, optimize_mano_beta=True, persp")
+        if len({tuple(one.hand_sides) for one in m.models}) != 1:
+            raise NotImplementedError("the clips of a batch share the hand side (one MANO model per launch)")
+        if m.int_scales_hand.requires_grad or m.hand_proj_mode != "persp":
+            raise NotImplementedError("FusedStepper covers optimize_mano_beta=True (the hand scale a buffer) and persp")
         lw = self.lw = {k: float(v) for k, v in loss_weights.items()}
         if lw.get("lw_depth", 0) > 0:
             if not getattr(m, "ordinal_depth", False):
@@ -282,9 +284,6 @@ class FusedStepper:
             if m.C > 1:
                 raise NotImplementedError("the ordinal depth term normalises over one clip: the fused loop covers it for one "
                                           "clip at a time (a clip batch: mode='graph' per clip)")
-        if m.sil_ctx.padded:
-            raise NotImplementedError("the fused loop renders the silhouettes at rend_size % 32 == 0 (the reference's "
-                                      "REND_SIZE is 256); other sizes: mode='graph' or 'eager'")
         self.shared_scale, self.group = bool(shared_scale), group
         if self.shared_scale and not m.optimize_object_scale:
             raise ValueError("shared_scale needs models built with optimize_object_scale=True")
@@ -341,7 +340,9 @@ class FusedStepper:
         self.obj_order = _morton_order(m.verts_object_og[0]).to(dev)      # spatial sort of the rigid mesh (metric-only search)
         # ... and of the hand: its template's vertices in the same kind of order, so that the 128 hand vertices of a search
         # workgroup are a patch of the hand, not a sample of all of it (articulation moves the patches, it does not mix them)
-        self.hand_order = _morton_order(m.mano_model.ctx_mean.tensors[0]).to(dev)
+        side = m.models[0].hand_sides[0]
+        self.mctx = m.mano_model.ctx_mean if side == "right" else m.mano_model._left_ctx(False)      # (see ManoModel)
+        self.hand_order = _morton_order(self.mctx.tensors[0]).to(dev)
         # bounding spheres, in MESH space, of the groups of 64 vertices in that order, per frame (a clip's frames share one mesh,
         # the clips of a batch need not): centre = mean, radius = farthest vertex.  The search carries them into camera space
         # with the frame's rigid transform instead of reducing the transformed vertices of every group in every workgroup.
@@ -360,6 +361,13 @@ class FusedStepper:
             self.obj_spheres = torch.cat([ctr, rad[..., None]], -1).contiguous()             # (B, ng, 4)
         self.nn_spheres = os.environ.get("HOMAN_NN_SPHERES", "1") != "0"
         self.pooled = f(B, m.sil_ctx.S, m.sil_ctx.S)
+        # silhouettes at a size off the kernels' 32-pixel tile grid (the reference's REND_SIZE is 256): rendered on the next
+        # multiple with the first two rows of K rescaled and the masks padded with keep = 0 (ops.SilhouetteContext); all three
+        # are constants of the fit, built once; eps of the pseudo-gradient in the padded grid's NDC units
+        sx = m.sil_ctx
+        self.sil_K = sx.K_eff(m.camintr_rois_object).contiguous()
+        self.sil_keep, self.sil_ref = sx.pad(m.keep_mask_object), sx.pad(m.ref_mask_object)
+        self.sil_eps = sx.eps()
         self.up_sil, self.up_inter = torch.tensor([w["loss_sil_obj"]], device=dev), torch.tensor([w["loss_inter"]], device=dev)
         if self.on["depth"]:
             # ordinal depth term (reference homan.py:384-419, opt-in): object and hand rendered with depth at the full-image
@@ -377,8 +385,9 @@ class FusedStepper:
         # static gradient buffers for exactly the parameters that receive gradients in this configuration
         for p in m.parameters():
             p.grad = None
-        gp = [m.translations_object, m.rotations_object, m.translations_hand, m.rotations_hand, m.mano_pca_pose,
-              m.mano_rot, m.mano_trans, m.mano_betas]
+        gp = [m.translations_object, m.rotations_object, m.translations_hand, m.rotations_hand]
+        if m.optimize_mano:          # (optimize_mano=False, the reference function's own default: the hand mesh is the
+            gp += [m.mano_pca_pose, m.mano_rot, m.mano_trans, m.mano_betas]      # constant `verts_hand_og`, homan.py:357-358)
         if m.optimize_object_scale:
             gp.append(m.int_scales_object)
         for p in gp:
@@ -386,7 +395,6 @@ class FusedStepper:
         self.opt = HmAdam(parameter_groups(m, lr))
         self.log_buf = torch.zeros(max_steps, C, NS, device=dev)
         self.max_steps = max_steps
-        self.mctx = m.mano_model.ctx_mean
         self.rigid_ws_h, self.rigid_ws_o = (torch.zeros(self.L.hm_rigid_workspace_bytes(B), dtype=torch.uint8, device=dev)
                                             for _ in range(2))
         self.mano_state = torch.empty(self.L.hm_mano_state_bytes(B), dtype=torch.uint8, device=dev)
@@ -521,7 +529,8 @@ class FusedStepper:
         sa, sb = main.cuda_stream, side.cuda_stream
         rws_a, rws_b = P(m.reduce_ws.buf), P(self.reduce_ws_b.buf)
         sctx, cctx = m.sil_ctx, m.collision_ctx
-        pca, rot, betas, mtr = m.mano_pca_pose, m.mano_rot, m.mano_betas, m.mano_trans
+        pca, rot, betas = m.mano_pca_pose, m.mano_rot, m.mano_betas
+        mtr = m.mano_trans if m.optimize_mano else None
         npca = self.P * CL                       # PCA entries of one clip
         side.wait_stream(main)
         use_aux = self.use_aux
@@ -556,8 +565,8 @@ class FusedStepper:
         # ---------------- A: silhouettes forward + backward (the critical chain: nothing else rides it; the object's rigid
         # transform is applied inside the face setup, the other losses get the vertices from the side stream)
         if on["sil"]:
-            fwd_args = (P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S,
-                        1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
+            fwd_args = (P(m.verts_object_og), P(sctx.faces), 0, P(self.sil_K), B, Vo, sctx.F, sctx.S,
+                        1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(self.sil_keep), P(self.sil_ref),
                         None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
                         P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, P(self.vo))
             if self.fork_after_setup:
@@ -573,7 +582,7 @@ class FusedStepper:
                 self.ev_sil.record(main)         # self.vo for the side stream
                 if use_aux and not self.sil_reduce_in_bwd:
                     self.ev_ras.record(main)
-            ck(L.hm_sil_bwd_clips(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS,
+            ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps,
                                   2 if self.lw["lw_sil_obj"] > 0 else 1,
                                   P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
                                   P(sctx.face_order), None, None, P(sctx.workspace), CL,
@@ -585,10 +594,14 @@ class FusedStepper:
                 ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
                                         P(m.int_scales_object), 1, B, Vo, None, P(self.vo), CL, sb), "rigid_fwd(obj)")
                 self.ev_vo.record(side)
-            ck(L.hm_mano_fwd_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
-                                   P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
-                                   P(self.mano_state), CL, sb),
-               "mano_fwd + rigid(hand)")
+            if m.optimize_mano:
+                ck(L.hm_mano_fwd_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
+                                       P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
+                                       P(self.mano_state), CL, sb),
+                   "mano_fwd + rigid(hand)")
+            else:           # the hand mesh is the constant `verts_hand_og` (reference homan.py:357-358): rigid transform only
+                ck(L.hm_rigid_fwd_clips(P(m.verts_hand_og), P(m.rotations_hand), P(m.translations_hand),
+                                        P(m.int_scales_hand), 0, B, Vh, None, P(self.vh), CL, sb), "rigid_fwd(hand)")
             pri = on["pca"] or on["so"] or on["sh"]
             # pair terms that feed nothing to each other go in ONE launch (csrc/pairterms.hip): the interaction term, the
             # object's smoothness when it rides this stream, the metric-only search (no contact term) and the hand-only
@@ -700,13 +713,15 @@ class FusedStepper:
                                      (self.U_colh if on["col"] else None, w["loss_collision"]),
                                      (self.U_conh if on["con"] else None, w["loss_contact"]),
                                      (self.G_dep_h if on["depth"] else None, 1.0)])       # (already times its weight)
-            ck(L.hm_rigid_bwd_clips(P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), 0, tp, tw, tn, None,
+            ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
+                                    P(m.int_scales_hand), 0, tp, tw, tn, None,
                                     (self.rec.data_ptr() + 8) if on["inter"] else None, 8, w["loss_inter"] / Vh, B, Vh,
-                                    P(self.G_mesh), P(m.rotations_hand.grad), P(m.translations_hand.grad), None,
-                                    P(self.rigid_ws_h), CL, sb), "rigid_bwd(hand)")
-            ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
-                             P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad), P(betas.grad),
-                             P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb), "mano_bwd")
+                                    P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
+                                    P(m.translations_hand.grad), None, P(self.rigid_ws_h), CL, sb), "rigid_bwd(hand)")
+            if m.optimize_mano:
+                ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
+                                 P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
+                                 P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb), "mano_bwd")
         # ---------------- A: object backward: silhouette gradient + smooth + contact [+ interaction with a free scale],
         # summed with their weights inside the rigid backward
         if on["smooth"] and self.smooth_obj_on_main:
@@ -728,7 +743,7 @@ class FusedStepper:
         if on["sil"]:       # the silhouette term is gathered from the sweeps' per-corner gradients inside this launch
             ck(L.hm_rigid_bwd_sil_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn,
                                         L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
-                                        P(sctx.adj_items), P(self.vo), P(m.camintr_rois_object), 1.0, sctx.F, B, Vo,
+                                        P(sctx.adj_items), P(self.vo), P(self.sil_K), 1.0, sctx.F, B, Vo,
                                         P(m.rotations_object.grad), P(m.translations_object.grad),
                                         P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sa),
                "rigid_bwd(obj) + silhouette gather")
@@ -763,12 +778,12 @@ class FusedStepper:
         m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
         sctx, B, Vo, CL, NS = m.sil_ctx, self.B, self.Vo, self.clip_len, self.NS
         sa = torch.cuda.current_stream().cuda_stream
-        ck(L.hm_sil_fwd_clips(P(m.verts_object_og), P(sctx.faces), 0, P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S,
-                              1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(m.keep_mask_object), P(m.ref_mask_object),
+        ck(L.hm_sil_fwd_clips(P(m.verts_object_og), P(sctx.faces), 0, P(self.sil_K), B, Vo, sctx.F, sctx.S,
+                              1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(self.sil_keep), P(self.sil_ref),
                               None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
                               P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, P(self.vo),
                               sa), "sil_fwd")
-        ck(L.hm_sil_bwd_clips(P(self.vo), P(m.camintr_rois_object), B, Vo, sctx.F, sctx.S, 1.0, self.ops.NMR_EPS, 2,
+        ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps, 2,
                               P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items), P(sctx.face_order),
                               None, None, P(sctx.workspace), CL, None, NS, sa), "sil_bwd")
 

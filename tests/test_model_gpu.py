@@ -180,8 +180,8 @@ def test_fused_step_equals_autograd_path(name, mano_model):
     """FusedStepper (no autograd tape) vs HOMan.forward + autograd: same losses, same parameter gradients."""
     from homan_amd.jointopt import FusedStepper
     rec, model, weights, meta = _build_hip(name, mano_model, sync=False)
-    if not meta["optimize_mano"] or meta["hand_sides"] != ["right"] or meta["inter_type"] != "centroid":
-        # outside the fused loop: it must say so
+    if len(meta["hand_sides"]) != 1 or meta["inter_type"] != "centroid":
+        # outside the fused loop (two hands; the interaction term's non-default 'min' form): it must say so
         with pytest.raises(NotImplementedError):
             FusedStepper(model, weights, meta["lr"], 4, capture=False)
         return
@@ -207,6 +207,16 @@ def test_fused_step_equals_autograd_path(name, mano_model):
             assert err < 2e-5, (k, err)
         else:
             assert p.grad is None or k in ("cams_hand",), k
+    # ... and a few captured steps follow the autograd loop (left hands and optimize_mano=False included)
+    rec2, fresh, _, _ = _build_hip(name, mano_model, sync=False)
+    from homan_amd.jointopt import GraphStepper
+    gs = GraphStepper(fresh, weights, meta["lr"], 3)
+    gs.run(3)
+    rec3, again, _, _ = _build_hip(name, mano_model, sync=False)
+    fs = FusedStepper(again, weights, meta["lr"], 3)
+    fs.run(3)
+    np.testing.assert_allclose(fs.loss_evolution(3)["loss"][:2], gs.loss_evolution(3)["loss"][:2], rtol=1e-5)
+    np.testing.assert_allclose(fs.loss_evolution(3)["loss"], gs.loss_evolution(3)["loss"], rtol=2e-2)
 
 
 @pytest.mark.parametrize("weights_name", ["STEP1_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS"])
@@ -244,6 +254,51 @@ def test_fused_loop_on_a_mesh_over_4096_vertices(weights_name, mano_model):
     _, evo, _ = optimize_hand_object(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
                                      loss_weights=weights, num_iterations=3, **common)
     assert np.isfinite(evo["loss"]).all() and abs(evo["loss"][0] - float(total.detach().reshape(-1)[0])) < 1e-5 * abs(evo["loss"][0])
+
+
+def test_fused_loop_at_a_render_size_off_the_tile_grid(mano_model):
+    """rend_size % 32 != 0 (the reference's REND_SIZE is 256, but the silhouette size is the caller's): the fused loop renders
+    on the padded grid with rescaled intrinsics, padded masks and eps in the padded grid's units - same losses and gradients
+    as HOMan.forward + autograd, alone and in a clip batch."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, build_model
+    size = 80
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    weights = dict(synth.STEP2_LOSS_WEIGHTS)
+
+    def make(seed):
+        clip = synth.make_clip(seed=seed, frames=4, rend_size=size, image_size=size, obj="cube", silhouette_fn=sil_fn,
+                               hand_verts_fn=hand_fn)
+        return build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                           objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                           optimize_mano=True, image_size=size, mano_model=mano_model, rend_size=size, sync_metrics=False)
+    model = make(2)
+    assert model.losses.sil_ctx.padded
+    loss_dict, metric_dict = model(loss_weights=weights)
+    total = sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict)
+    total.sum().backward()
+    ref_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    ref = {k: float(v.detach().reshape(-1)[0]) for k, v in loss_dict.items()}
+    ref.update({k: float(v) for k, v in metric_dict.items()})
+    st = FusedStepper(model, weights, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    for k, v in ref.items():
+        np.testing.assert_allclose(st.log_buf[0, 0, st.SLOTS.index(k)].item(), v, rtol=2e-6, atol=1e-9, err_msg=k)
+    for k, p in model.named_parameters():
+        if k in ref_grads:
+            scale = max(ref_grads[k].abs().max().item(), 1e-20)
+            assert ((p.grad - ref_grads[k]).abs().max() / scale).item() < 2e-5, k
+    # a batch of two such clips == the clips alone, bit for bit
+    solo = []
+    for seed in (2, 3):
+        one = FusedStepper(make(seed), weights, 1e-2, 4)
+        one.run(4)
+        solo.append(one.loss_evolution(4)["loss"])
+    both = FusedStepper([make(2), make(3)], weights, 1e-2, 4)
+    both.run(4)
+    for e, want in zip(both.loss_evolution(4), solo):
+        np.testing.assert_array_equal(e["loss"], want)
 
 
 def test_fused_trajectory_matches_reference_loop(mano_model):
