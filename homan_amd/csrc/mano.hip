@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
                                                    float* __restrict__ joints, const float* __restrict__ rigid_rot6d,
                                                    const float* __restrict__ rigid_trans,
                                                    const float* __restrict__ rigid_scale, float* __restrict__ verts_world,
-                                                   float* __restrict__ state, int clip_len)
+                                                   float* __restrict__ state, int clip_len, int row0, int row_stride)
 {
     __shared__ ManoShared shs[MANO_FPW];
     __shared__ float s_part[4][MANO_FPW][MANO_VCH][3];
@@ -250,7 +250,10 @@ __global__ __launch_bounds__(256) void k_mano_fwd(ManoModelDev m, const float* _
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int b_raw = blockIdx.y * MANO_FPW + wv;
     const bool live = b_raw < B;                 // (a frame past the end repeats the last one and stores nothing)
-    const int b = min(b_raw, B - 1);
+    // frame of this launch -> row of the caller's arrays: row0 + frame * row_stride (two hands per frame are interleaved
+    // frame-major, reference homan.py:62-63: hand i of every frame = rows i, i + 2, ... through ITS side's model; one hand:
+    // row == frame).  Every per-row array - parameters, vertices, state - is addressed by the row; clip_len counts rows.
+    const int b = (min(b_raw, B - 1)) * row_stride + row0;
     ManoShared& sh = shs[wv];
     if (verts_world && lane == 48) rot6d_to_mat(rigid_rot6d + b * 6, s_R[wv]);      // published by mano_prepare's barriers
     mano_prepare(m, pca, pca_stride, rot, betas, b, sh, lane);
@@ -326,7 +329,7 @@ struct ManoBwd2Shared {
     float cR[MANO_J][9], ct[MANO_J][3], cJ[MANO_J][3];     // child -> parent contributions
 };
 __device__ __forceinline__ void mano_bwd2_body(const ManoModelDev& m, const ManoShared& sh, ManoBwd2Shared& w,
-                                               const float* __restrict__ partials, int nchunk, int b, int pca_dim,
+                                               const float* __restrict__ partials, int nchunk, int lb, int b, int pca_dim,
                                                const float* __restrict__ g_pca_extra, float w_extra,
                                                float* __restrict__ g_pca, float* __restrict__ g_rot,
                                                float* __restrict__ g_betas, float* __restrict__ g_trans)
@@ -336,7 +339,7 @@ __device__ __forceinline__ void mano_bwd2_body(const ManoModelDev& m, const Mano
         float v[MANO_NCH64];
 #pragma unroll
         for (int c = 0; c < MANO_NCH64; ++c)        // all requests first, then the (fixed order) sum
-            v[c] = c < nchunk ? hm_partial_load(partials + ((long)b * nchunk + c) * MANO_PART + k) : 0.f;
+            v[c] = c < nchunk ? hm_partial_load(partials + ((long)lb * nchunk + c) * MANO_PART + k) : 0.f;
         float a = 0.f;
 #pragma unroll
         for (int c = 0; c < MANO_NCH64; ++c) a += v[c];
@@ -458,7 +461,8 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
                                                    float* __restrict__ partials, unsigned int* __restrict__ frame_cnt,
                                                    int pca_dim, const float* __restrict__ g_pca_extra, float w_extra,
                                                    float* __restrict__ g_pca, float* __restrict__ g_rot,
-                                                   float* __restrict__ g_betas, float* __restrict__ g_trans)
+                                                   float* __restrict__ g_betas, float* __restrict__ g_trans, int row0,
+                                                   int row_stride)
 {
     HM_HAND_KERNEL();
     __shared__ ManoShared sh;
@@ -470,7 +474,8 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
     __shared__ float red[16];
     __shared__ ManoBwd2Shared w2;
     __shared__ int s_flag;
-    const int b = blockIdx.y, t = threadIdx.x;
+    // lb: frame of this launch (partials, tickets); b: its row in the caller's arrays (see k_mano_fwd)
+    const int lb = blockIdx.y, b = lb * row_stride + row0, t = threadIdx.x;
     const int v0 = blockIdx.x * MANO_VCH;
     const int nv = min(MANO_VCH, MANO_V - v0);
 #ifdef MANO_PHASES
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
         for (int j = 0; j < MANO_J; ++j) s_w[t][j] = m.weights[v * MANO_J + j];
     }
     MPH_MARK(1);
-    float* out = partials + ((long)b * gridDim.x + blockIdx.x) * MANO_PART;
+    float* out = partials + ((long)lb * gridDim.x + blockIdx.x) * MANO_PART;
     const float tg0 = hm_block_sum(g[0], red), tg1 = hm_block_sum(g[1], red), tg2 = hm_block_sum(g[2], red);
     if (t == 0) { hm_partial_store(out + 337, tg0); hm_partial_store(out + 338, tg1); hm_partial_store(out + 339, tg2); }
     __syncthreads();
@@ -549,15 +554,15 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
     __syncthreads();
     MPH_MARK(4);
     if (t == 0) {
-        const unsigned int ticket = atomicAdd(frame_cnt + b, 1u);
+        const unsigned int ticket = atomicAdd(frame_cnt + lb, 1u);
         const int last = ticket == gridDim.x - 1u;
-        if (last) atomicExch(frame_cnt + b, 0u);
+        if (last) atomicExch(frame_cnt + lb, 0u);
         s_flag = last;
     }
     __syncthreads();
     MPH_MARK(5);
     if (s_flag) {
-        mano_bwd2_body(m, sh, w2, partials, gridDim.x, b, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
+        mano_bwd2_body(m, sh, w2, partials, gridDim.x, lb, b, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
 #ifdef MANO_PHASES
         __syncthreads();
         MPH_MARK(6);
@@ -568,6 +573,24 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
 
 extern "C" {
 // model: 8 device pointers in the order of ManoModelDev.
+// hm_mano_fwd_rows / hm_mano_bwd_rows: frame f of the launch is row row0 + f * row_stride of EVERY per-row array (parameters,
+// gradients, vertices, state; arrays sized for B * row_stride rows) - the strided slice `i::hand_nb` of reference
+// homan.py:343-358 without a copy.  clip_len counts rows.
+int hm_mano_fwd_rows(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
+                     const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d,
+                     const float* rigid_trans, const float* rigid_scale, float* verts_world, float* state, int clip_len,
+                     int row0, int row_stride, hipStream_t stream)
+{
+    HM_CHECK_ARG(model && pca && rot && betas && verts && B > 0 && pca_dim >= 16 && row_stride >= 1 && row0 >= 0 && row0 < row_stride);
+    HM_CHECK_ARG(clip_len >= 0 && (clip_len == 0 || (B * row_stride) % clip_len == 0));
+    HM_CHECK_ARG(!verts_world || (rigid_rot6d && rigid_trans && rigid_scale));
+    ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
+                      (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
+    hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, (B + MANO_FPW - 1) / MANO_FPW), dim3(256), g_hm_lds_pad[HM_PAD_MANO_FWD], stream, m, pca, pca_dim, rot, betas, trans, B, verts,
+                       joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world, state, clip_len ? clip_len : B * row_stride,
+                       row0, row_stride);
+    return hm_launch_status();
+}
 int hm_mano_fwd_clips(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
                       const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d,
                       const float* rigid_trans, const float* rigid_scale, float* verts_world, float* state, int clip_len,
@@ -578,7 +601,7 @@ int hm_mano_fwd_clips(const void* const* model, const float* pca, int pca_dim, c
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
     hipLaunchKernelGGL(k_mano_fwd, dim3(MANO_NCH64, (B + MANO_FPW - 1) / MANO_FPW), dim3(256), g_hm_lds_pad[HM_PAD_MANO_FWD], stream, m, pca, pca_dim, rot, betas, trans, B, verts,
-                       joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world, state, clip_len ? clip_len : B);
+                       joints, rigid_rot6d, rigid_trans, rigid_scale, verts_world, state, clip_len ? clip_len : B, 0, 1);
     return hm_launch_status();
 }
 int hm_mano_fwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
@@ -592,19 +615,26 @@ size_t hm_mano_workspace_bytes(int B) { return 512 + (size_t)B * 4 + (size_t)B *
 size_t hm_mano_state_bytes(int B) { return (size_t)B * MANO_STATE_DW * sizeof(float); }
 // workspace: hm_mano_workspace_bytes(B), zero-filled once (per-frame tickets reset themselves).  state: the buffer the
 // forward filled (hm_mano_state_bytes(B)) for the SAME parameters, or NULL to recompute the chain.
-int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
-                const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
-                float* g_trans, const float* state, void* workspace, hipStream_t stream)
+int hm_mano_bwd_rows(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
+                     const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
+                     float* g_trans, const float* state, void* workspace, int row0, int row_stride, hipStream_t stream)
 {
     HM_CHECK_ARG(model && pca && rot && betas && g_verts && g_pca && g_rot && g_betas && g_trans && workspace);
-    HM_CHECK_ARG(B > 0 && pca_dim >= 16);
+    HM_CHECK_ARG(B > 0 && pca_dim >= 16 && row_stride >= 1 && row0 >= 0 && row0 < row_stride);
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
     unsigned int* cnt = (unsigned int*)workspace;
     float* partials = (float*)((char*)workspace + 256 + (((size_t)B * 4 + 255) & ~(size_t)255));
     hipLaunchKernelGGL(k_mano_bwd, dim3(MANO_NCH64, B), dim3(256), g_hm_lds_pad[HM_PAD_MANO_BWD], stream, m, pca, pca_dim, rot, betas, g_verts, B, state,
-                       partials, cnt, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
+                       partials, cnt, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans, row0, row_stride);
     return hm_launch_status();
+}
+int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
+                const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
+                float* g_trans, const float* state, void* workspace, hipStream_t stream)
+{
+    return hm_mano_bwd_rows(model, pca, pca_dim, rot, betas, B, g_verts, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans,
+                            state, workspace, 0, 1, stream);
 }
 #ifdef MANO_PHASES
 int hm_debug_mano_phases(unsigned long long* out)

@@ -263,9 +263,8 @@ class FusedStepper:
         from . import constants, ops
         from .clipbatch import ClipBatch, ClipReduceWorkspace
         for one in (model.models if isinstance(model, ClipBatch) else model if isinstance(model, (list, tuple)) else [model]):
-            if len(one.hand_sides) != 1:
-                raise NotImplementedError("the fused loop covers one hand per frame, right or left (every BASELINE "
-                                          "configuration); two hands: mode='graph' or 'eager'")
+            if len(one.hand_sides) not in (1, 2):
+                raise NotImplementedError("one or two hands per frame")
             if one.losses.inter_type != "centroid":
                 raise NotImplementedError("the fused loop covers inter_type='centroid' (the reference default); 'min': "
                                           "mode='graph' or 'eager'")
@@ -275,7 +274,13 @@ class FusedStepper:
             raise NotImplementedError("the clips of a batch share the hand side (one MANO model per launch)")
         if m.int_scales_hand.requires_grad or m.hand_proj_mode != "persp":
             raise NotImplementedError("FusedStepper covers optimize_mano_beta=True (the hand scale a buffer) and persp")
+        self.h = h = len(m.models[0].hand_sides)
+        if h > 1 and (m.C > 1 or shared_scale):
+            raise NotImplementedError("two hands per frame: the fused loop takes one clip at a time (a batch of two-hand "
+                                      "clips: one stepper per clip, or mode='graph')")
         lw = self.lw = {k: float(v) for k, v in loss_weights.items()}
+        if lw.get("lw_depth", 0) > 0 and h > 1:
+            raise NotImplementedError("ordinal depth term: one hand per frame")          # (as HOMan.compute_ordinal_depth_loss)
         if lw.get("lw_depth", 0) > 0:
             if not getattr(m, "ordinal_depth", False):
                 # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() without its arguments
@@ -304,7 +309,8 @@ class FusedStepper:
         self.sil_reduce_in_bwd = not self.use_aux and os.environ.get("HOMAN_SIL_REDUCE_IN_BWD", "1") != "0"
         self.Vo, self.Vh, self.P = Vo, Vh, m.mano_pca_pose.shape[1]
         f = lambda *shape: torch.zeros(*shape, device=dev)
-        self.vo, self.vm, self.vh = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
+        N = self.N = B * h                                        # hand rows (hands interleaved frame-major, homan.py:62-63)
+        self.vo, self.vm, self.vh = f(B, Vo, 3), f(N, Vh, 3), f(N, Vh, 3)
         self.vals = f(C, NS)                                      # row c: the loss / metric slots of clip c + its total
         on = lambda k: lw.get(k, 0.0) > 0
         self.on = dict(pca=on("lw_pca"), so=on("lw_scale_obj"), sh=on("lw_scale_hand"),
@@ -328,13 +334,26 @@ class FusedStepper:
         # (it only feeds the object's pose gradients) then rides the silhouette chain (measured: cfg3 +5 %, cfg2 -6 %)
         self.smooth_obj_on_main = (self.on["col"] or self.on["con"]) and m.C == 1      # (a clip batch: -4 %)
         # unit gradients / scratch
-        self.U_pca, self.U_so, self.U_sh = f(B, self.P), f(C), f(C)
-        self.U_smo, self.U_smh, self.U_v2d = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
-        self.U_colh, self.U_colo, self.U_conh, self.U_cono = f(B, Vh, 3), f(B, Vo, 3), f(B, Vh, 3), f(B, Vo, 3)
-        self.G_sil, self.G_int_h, self.G_int_o = f(B, Vo, 3), f(B, Vh, 3), f(B, Vo, 3)
-        self.G_o, self.G_h, self.G_mesh = f(B, Vo, 3), f(B, Vh, 3), f(B, Vh, 3)
-        self.g_pca_mano, self.g_so_part = f(B, self.P), f(B)
-        self.rec = f(B, 8)
+        self.U_pca, self.U_so, self.U_sh = f(N, self.P), f(C), f(C)
+        self.U_smo, self.U_smh, self.U_v2d = f(B, Vo, 3), f(N, Vh, 3), f(N, Vh, 3)
+        self.U_colh, self.U_colo, self.U_conh, self.U_cono = f(N, Vh, 3), f(B, Vo, 3), f(N, Vh, 3), f(B, Vo, 3)
+        self.G_sil, self.G_int_h, self.G_int_o = f(B, Vo, 3), f(N, Vh, 3), f(B, Vo, 3)
+        self.G_o, self.G_h, self.G_mesh = f(B, Vo, 3), f(N, Vh, 3), f(N, Vh, 3)
+        self.g_pca_mano, self.g_so_part = f(N, self.P), f(B)
+        self.rec = f(N, 8)
+        if h > 1:
+            # two hands: the pair-wise terms see one hand at a time as a dense (B,778,3) array (hand i = rows i::h)
+            self.vh_d = [f(B, Vh, 3) for _ in range(h)]
+            self.nn_idx_d = [torch.zeros(B, Vh, dtype=torch.int32, device=dev) for _ in range(h)]
+            self.nn_d2_d = [f(B, Vh) for _ in range(h)]
+            self.U_conh_d, self.U_cono_d = [f(B, Vh, 3) for _ in range(h)], [f(B, Vo, 3) for _ in range(h)]
+            self.U_colh2, self.U_col_d = f(N, Vh, 3), [f(B, Vh, 3) for _ in range(4)]      # (h0|h1), (h0|obj), (h1|obj): hand sides
+            self.U_colo_d = f(B, Vo, 3)
+            self.rec_d, self.G_int_o_d = [f(B, 8) for _ in range(h)], [f(B, Vo, 3) for _ in range(h)]
+            self.tmp_h, self.tmp_col = f(h, 4), f(3)
+            self.rws_h = [ClipReduceWorkspace(dev, 1) for _ in range(h)]
+            self.hand_ctx = [m.mano_model.ctx_mean if sd == "right" else m.mano_model._left_ctx(False)
+                             for sd in m.models[0].hand_sides]
         self.nn_idx = torch.zeros(B, Vh, dtype=torch.int32, device=dev)
         self.nn_d2 = f(B, Vh)
         self.obj_order = _morton_order(m.verts_object_og[0]).to(dev)      # spatial sort of the rigid mesh (metric-only search)
@@ -395,9 +414,9 @@ class FusedStepper:
         self.opt = HmAdam(parameter_groups(m, lr))
         self.log_buf = torch.zeros(max_steps, C, NS, device=dev)
         self.max_steps = max_steps
-        self.rigid_ws_h, self.rigid_ws_o = (torch.zeros(self.L.hm_rigid_workspace_bytes(B), dtype=torch.uint8, device=dev)
-                                            for _ in range(2))
-        self.mano_state = torch.empty(self.L.hm_mano_state_bytes(B), dtype=torch.uint8, device=dev)
+        self.rigid_ws_h, self.rigid_ws_o = (torch.zeros(self.L.hm_rigid_workspace_bytes(n), dtype=torch.uint8, device=dev)
+                                            for n in (N, B))
+        self.mano_state = torch.empty(self.L.hm_mano_state_bytes(N), dtype=torch.uint8, device=dev)
         self.graph = self.graph_b = None
         self.cap_stream, self.side, self.aux, side = _loop_streams(dev)
         self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd, self.ev_smo, self.ev_ras = (torch.cuda.Event() for _ in range(6))
@@ -521,6 +540,8 @@ class FusedStepper:
         B waits for the object vertices before the pair-wise losses, A waits for B's object-side gradient terms, both
         join before the log row and the Adam step.  Every launch covers all the clips of the batch (clip_len frames
         each, per-clip scalars NS floats apart in `vals`)."""
+        if self.h > 1:
+            return self._forward_backward_hands(log)
         m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
         B, Vo, Vh, c, on, w = self.B, self.Vo, self.Vh, self.c, self.on, self.w
         CL, NS, C = self.clip_len, self.NS, self.C
@@ -771,6 +792,161 @@ class FusedStepper:
                 # here, ranks in _reduce_shared_scale_grad
                 ck(L.hm_sum_small_clips(P(m.int_scales_object.grad), C, 1.0, None, 0.0, P(self.g_shared), 1, sa),
                    "shared scale grad")
+
+    def _forward_backward_hands(self, log=False):
+        """The iteration for TWO hands per frame (reference homan.py:341-358, lossutils.py:51-59,116-127, losses.py:207-241),
+        one clip.  Hand rows are interleaved frame-major [h0_t0, h1_t0, h0_t1, ...] like the model's Parameters: the MANO
+        launches walk the strided slice of their hand through its side's model (hm_mano_*_rows), the hand-only terms and the
+        rigid backward run once over all rows (the kernels' hand_nb), and the pair-wise terms see each hand as a dense copy:
+        contact = mean over the hands, interaction = their sum, collision = the three two-mesh scenes (h0|h1), (h0|obj),
+        (h1|obj), logged distance = largest per-frame distance to the NEAREST hand.  Same kernels and values as
+        HOMan.forward + autograd; not tuned like the one-hand sequence (no fused pair-term launch)."""
+        m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
+        B, N, h, Vo, Vh, c, on, w = self.B, self.N, self.h, self.Vo, self.Vh, self.c, self.on, self.w
+        NS = self.NS
+        main, side = torch.cuda.current_stream(), self.side
+        sa, sb = main.cuda_stream, side.cuda_stream
+        rws_a, rws_b = P(m.reduce_ws.buf), P(self.reduce_ws_b.buf)
+        sctx, cctx = m.sil_ctx, m.collision_ctx
+        pca, rot, betas = m.mano_pca_pose, m.mano_rot, m.mano_betas
+        mtr = m.mano_trans if m.optimize_mano else None
+        slot = self._slot
+        side.wait_stream(main)
+        # ---------------- A: silhouettes forward + backward (as in the one-hand sequence)
+        if on["sil"]:
+            fwd_args = (P(m.verts_object_og), P(sctx.faces), 0, P(self.sil_K), B, Vo, sctx.F, sctx.S,
+                        1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(self.sil_keep), P(self.sil_ref),
+                        None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
+                        P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), 0, NS, P(self.vo))
+            ck(L.hm_sil_fwd_phase_clips(*fwd_args, 1, sa), "sil_fwd(setup)")
+            self.ev_sil.record(main)
+            ck(L.hm_sil_fwd_phase_clips(*fwd_args, 2, sa), "sil_fwd(raster)")
+            ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps,
+                                  2 if self.lw["lw_sil_obj"] > 0 else 1, P(self.up_sil), None, P(m.keep_sum),
+                                  P(sctx.adj_off), P(sctx.adj_items), P(sctx.face_order), None, None, P(sctx.workspace), 0,
+                                  slot("loss_sil_obj"), NS, sa), "sil_bwd")
+        # ---------------- B: hands
+        with torch.cuda.stream(side):
+            if not on["sil"]:
+                ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
+                                        P(m.int_scales_object), 1, B, Vo, None, P(self.vo), 0, sb), "rigid_fwd(obj)")
+                self.ev_vo.record(side)
+            if m.optimize_mano:
+                for i, hctx in enumerate(self.hand_ctx):       # hand i = rows i::h through the model of its side
+                    ck(L.hm_mano_fwd_rows(hctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
+                                          P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
+                                          P(self.mano_state), 0, i, h, sb), "mano_fwd + rigid(hand %d)" % i)
+            else:
+                ck(L.hm_rigid_fwd_clips(P(m.verts_hand_og), P(m.rotations_hand), P(m.translations_hand),
+                                        P(m.int_scales_hand), 0, N, Vh, None, P(self.vh), 0, sb), "rigid_fwd(hands)")
+            if on["pca"] or on["so"] or on["sh"]:
+                ck(L.hm_priors_fwd_clips(P(pca), self.P * N, P(m.int_scales_object), P(m.int_scale_object_mean),
+                                         P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
+                                         P(self.U_sh), slot("loss_pca"), 1, NS, sb), "priors")
+            if on["smooth"]:
+                ck(L.hm_smooth_fwd_clips(P(self.vh), N, Vh, h, P(self.U_smh), slot("loss_smooth_hand"), rws_b, 0, NS, sb),
+                   "smooth(hands)")
+            if on["v2d"]:
+                ck(L.hm_v2d_fwd_clips(P(self.vh), P(m.camintr), h, P(m.ref_verts2d_hand), float(m.image_size), N, Vh,
+                                      P(self.U_v2d), slot("loss_v2d_hand"), rws_b, 0, NS, sb), "v2d")
+            if on["sil"]:
+                side.wait_event(self.ev_sil)
+            if on["smooth"]:
+                ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), slot("loss_smooth_obj"), rws_b, 0, NS, sb),
+                   "smooth(obj)")
+            pairwise = on["con"] or on["inter"] or on["col"]
+            if pairwise:
+                for i in range(h):
+                    self.vh_d[i].copy_(self.vh[i::h])
+            tmp = self.tmp_h
+            for i in range(h):
+                rws_i = P(self.rws_h[i].buf)
+                if on["con"] or on["inter"]:
+                    ck(L.hm_nn_fwd(P(self.vh_d[i]), P(self.vo), B, Vh, Vo, P(self.nn_idx_d[i]), P(self.nn_d2_d[i]),
+                                   tmp[i, 2:3].data_ptr(), rws_i, sb), "nn(hand %d)" % i)
+                if on["con"]:
+                    ck(L.hm_contact_fwd(P(self.vh_d[i]), P(self.vo), P(self.nn_idx_d[i]), B, Vh, Vo, c.COLLISION_THRESH,
+                                        P(self.U_conh_d[i]), P(self.U_cono_d[i]), tmp[i, 0:1].data_ptr(), rws_i, sb),
+                       "contact(hand %d)" % i)
+                if on["inter"]:
+                    ck(L.hm_inter_fwd(P(self.vh_d[i]), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
+                                      float(c.INTERACTION_Z_THRESH), P(self.rec_d[i]), tmp[i, 1:2].data_ptr(), rws_i, sb),
+                       "inter(hand %d)" % i)
+                    if m.optimize_object_scale:
+                        ck(L.hm_inter_bwd(P(self.rec_d[i]), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o_d[i]), sb),
+                           "inter_bwd(hand %d)" % i)
+            if on["col"]:
+                # scene [hand 0, hand 1, object] (lossutils.py:53-59): the three two-mesh scenes of HOMan.collision_ctx
+                scenes = ((self.vh_d[0], self.vh_d[1], self.U_col_d[0], self.U_col_d[1]),
+                          (self.vh_d[0], self.vo, self.U_col_d[2], self.U_colo_d),
+                          (self.vh_d[1], self.vo, self.U_col_d[3], self.U_colo_d))
+                for k, (cc, (va, vb, ga, gb)) in enumerate(zip(cctx, scenes)):
+                    ck(L.hm_collision_fwd(P(va), P(cc.f0), cc.V0, cc.f0.shape[0], P(vb), P(cc.f1), cc.V1, cc.f1.shape[0], B,
+                                          c.SDF_SCALE_FACTOR, P(ga), P(gb), self.tmp_col[k:k + 1].data_ptr(), P(cc.ws), sb),
+                       "collision(scene %d)" % k)
+            # ---- the hands' values combined like the reference does, gradients back onto the interleaved rows
+            with torch.cuda.stream(side):
+                v0 = self.vals[0]
+                if on["con"]:
+                    v0[self.SLOTS.index("loss_contact")] = torch.stack([tmp[i, 0] for i in range(h)]).mean()
+                    for i in range(h):
+                        self.U_conh[i::h].copy_(self.U_conh_d[i])
+                if on["inter"]:
+                    v0[self.SLOTS.index("loss_inter")] = tmp[0, 1] + tmp[1, 1]
+                    per_frame = torch.stack([d.min(1)[0] for d in self.nn_d2_d]).min(0)[0]
+                    v0[self.SLOTS.index("handobj_maxdist")] = per_frame.max().clamp_min(0).sqrt()
+                    for i in range(h):
+                        self.rec[i::h].copy_(self.rec_d[i])
+                    if m.optimize_object_scale:
+                        torch.add(self.G_int_o_d[0], self.G_int_o_d[1], out=self.G_int_o)
+                if on["col"]:
+                    v0[self.SLOTS.index("loss_collision")] = (self.tmp_col[0] + self.tmp_col[1]) + self.tmp_col[2]
+                    self.U_colh[0::h].copy_(self.U_col_d[0])      # from the (h0|h1) scene ...
+                    self.U_colh[1::h].copy_(self.U_col_d[1])
+                    self.U_colh2[0::h].copy_(self.U_col_d[2])     # ... and from each hand's scene with the object
+                    self.U_colh2[1::h].copy_(self.U_col_d[3])
+            self.ev_pair.record(side)
+            tp, tw, tn = _lib.terms([(self.U_smh if on["smooth"] else None, w["loss_smooth_hand"]),
+                                     (self.U_v2d if on["v2d"] else None, w["loss_v2d_hand"]),
+                                     (self.U_colh if on["col"] else None, w["loss_collision"]),
+                                     (self.U_colh2 if on["col"] else None, w["loss_collision"]),
+                                     (self.U_conh if on["con"] else None, w["loss_contact"] / h)])
+            ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
+                                    P(m.int_scales_hand), 0, tp, tw, tn, None,
+                                    (self.rec.data_ptr() + 8) if on["inter"] else None, 8, w["loss_inter"] / Vh, N, Vh,
+                                    P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
+                                    P(m.translations_hand.grad), None, P(self.rigid_ws_h), 0, sb), "rigid_bwd(hands)")
+            if m.optimize_mano:
+                for i, hctx in enumerate(self.hand_ctx):
+                    ck(L.hm_mano_bwd_rows(hctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
+                                          P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
+                                          P(betas.grad), P(mtr.grad), P(self.mano_state), P(hctx.workspace(B)), i, h, sb),
+                       "mano_bwd(hand %d)" % i)
+        # ---------------- A: object backward
+        main.wait_event(self.ev_pair)
+        sc_obj = m.optimize_object_scale
+        tp, tw, tn = _lib.terms([(self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),
+                                 (self.U_cono_d[0] if on["con"] else None, w["loss_contact"] / h),
+                                 (self.U_cono_d[1] if on["con"] else None, w["loss_contact"] / h),
+                                 (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0)])
+        if on["sil"]:
+            ck(L.hm_rigid_bwd_sil_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn,
+                                        L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
+                                        P(sctx.adj_items), P(self.vo), P(self.sil_K), 1.0, sctx.F, B, Vo,
+                                        P(m.rotations_object.grad), P(m.translations_object.grad),
+                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), 0, sa),
+               "rigid_bwd(obj) + silhouette gather")
+        else:
+            ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
+                                    None, 0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
+                                    P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), 0, sa), "rigid_bwd(obj)")
+        main.wait_stream(side)
+        if log:
+            ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
+                                    P(self.log_buf), 1, sa), "log")
+        if sc_obj:
+            ck(L.hm_sum_small_clips(P(self.g_so_part), B, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
+                                    P(m.int_scales_object.grad), 1, sa), "scale grad")
 
     def sil_chain_only(self):
         """Measurement helper (tools/bench_sil_kernels.py --chain): just the silhouette chain of an iteration - face setup,

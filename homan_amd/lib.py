@@ -82,6 +82,8 @@ _SIGNATURES = {
                                     _VP, _I, _VP]),
     "hm_sum_small_clips": (_I, [_VP, _I, _F, _VP, _F, _VP, _I, _VP]),
     "hm_mano_fwd_clips": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
+    "hm_mano_fwd_rows": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
+    "hm_mano_bwd_rows": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _F, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_sil_fwd_clips": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP,
                               _VP, _VP, _I, _I, _VP, _I, _I, _VP, _VP]),
     "hm_sil_fwd_phase_clips": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP,

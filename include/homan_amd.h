@@ -302,6 +302,17 @@ int hm_mano_fwd_clips(const void* const* model, const float* pca, int pca_dim, c
                       const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d,
                       const float* rigid_trans, const float* rigid_scale, float* verts_world, float* state, int clip_len,
                       hipStream_t stream);
+/* Two hands per frame arrive interleaved frame-major [h0_t0, h1_t0, h0_t1, ...] and hand i is the strided slice i::hand_nb of
+ * every MANO parameter, through the MANO model of ITS side (reference homan/homan.py:62-63,343-358).  The *_rows entry points
+ * evaluate such a slice in place: frame f of the launch is row row0 + f * row_stride of EVERY per-row array (parameters,
+ * gradients, vertices, state; all sized for B * row_stride rows); clip_len counts rows. */
+int hm_mano_fwd_rows(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas,
+                     const float* trans, int B, float* verts, float* joints, const float* rigid_rot6d,
+                     const float* rigid_trans, const float* rigid_scale, float* verts_world, float* state, int clip_len,
+                     int row0, int row_stride, hipStream_t stream);
+int hm_mano_bwd_rows(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
+                     const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
+                     float* g_trans, const float* state, void* workspace, int row0, int row_stride, hipStream_t stream);
 int hm_sil_fwd_clips(const float* verts, const int* faces, int faces_bstride, const float* K, int B, int V, int F, int S,
                      float orig_size, float znear, float zfar, const float* keep, const float* ref,
                      const float* keep_sum, float* pooled, float* loss_out, const int* work_order, float* pooled_depth,
