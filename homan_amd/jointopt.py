@@ -265,9 +265,6 @@ class FusedStepper:
         for one in (model.models if isinstance(model, ClipBatch) else model if isinstance(model, (list, tuple)) else [model]):
             if len(one.hand_sides) not in (1, 2):
                 raise NotImplementedError("one or two hands per frame")
-            if one.losses.inter_type != "centroid":
-                raise NotImplementedError("the fused loop covers inter_type='centroid' (the reference default); 'min': "
-                                          "mode='graph' or 'eager'")
         m = self.model = model if isinstance(model, ClipBatch) else ClipBatch(model if isinstance(model, (list, tuple))
                                                                              else [model])
         if len({tuple(one.hand_sides) for one in m.models}) != 1:
@@ -275,6 +272,11 @@ class FusedStepper:
         if m.int_scales_hand.requires_grad or m.hand_proj_mode != "persp":
             raise NotImplementedError("FusedStepper covers optimize_mano_beta=True (the hand scale a buffer) and persp")
         self.h = h = len(m.models[0].hand_sides)
+        kinds = {one.losses.inter_type for one in m.models}
+        # inter_type "min" (reference losses.py:219-221, a HOMan option its loop cannot select): one hand, one clip
+        self.inter_min = kinds == {"min"}
+        if len(kinds) != 1 or (self.inter_min and (h > 1 or m.C > 1)):
+            raise NotImplementedError("inter_type='min' in the fused loop: one hand, one clip (else mode='graph' or 'eager')")
         if h > 1 and (m.C > 1 or shared_scale):
             raise NotImplementedError("two hands per frame: the fused loop takes one clip at a time (a batch of two-hand "
                                       "clips: one stepper per clip, or mode='graph')")
@@ -341,6 +343,8 @@ class FusedStepper:
         self.G_o, self.G_h, self.G_mesh = f(B, Vo, 3), f(N, Vh, 3), f(N, Vh, 3)
         self.g_pca_mano, self.g_so_part = f(N, self.P), f(B)
         self.rec = f(N, 8)
+        if self.inter_min:
+            self.G_min_h, self.tmp_inter, self.rows = f(N, Vh, 3), f(2), torch.arange(B, device=dev)
         if h > 1:
             # two hands: the pair-wise terms see one hand at a time as a dense (B,778,3) array (hand i = rows i::h)
             self.vh_d = [f(B, Vh, 3) for _ in range(h)]
@@ -628,7 +632,7 @@ class FusedStepper:
             # object's smoothness when it rides this stream, the metric-only search (no contact term) and the hand-only
             # reductions
             sm_here = on["smooth"] and not self.smooth_obj_on_main
-            fuse = self.pair_fused and on["inter"] and Vo <= 4096
+            fuse = self.pair_fused and on["inter"] and Vo <= 4096 and not self.inter_min
             nn_fused = fuse and not on["con"]
             # with the contact term the FULL search (nearest object vertex of every hand vertex) is the launch's first block
             # range instead, and the contact launches follow it: one launch less on the hand-side chain of the step-2 sets
@@ -666,7 +670,7 @@ class FusedStepper:
                 if (on["con"] or on["inter"]) and not nn_fused and not nn_full_fused:
                     # (without the contact term only the logged distance is needed: metric-only search - its group table
                     #  covers 4096 object vertices, larger meshes take the full search for the same number)
-                    full = on["con"] or Vo > 4096
+                    full = on["con"] or Vo > 4096 or self.inter_min      # ('min' names the closest PAIR: indices needed)
                     ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if full else None,
                                                P(self.nn_d2) if full else None, self._slot("handobj_maxdist"), rws, CL, NS,
                                                P(self.obj_order), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
@@ -703,9 +707,26 @@ class FusedStepper:
                     search_and_contact(side, rws_b)          # (the contact launches only: the search ran above)
             elif on["inter"]:
                 ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
-                                        float(c.INTERACTION_Z_THRESH), P(self.rec), self._slot("loss_inter"), rws_b, CL,
+                                        float(c.INTERACTION_Z_THRESH), P(self.rec),
+                                        P(self.tmp_inter) if self.inter_min else self._slot("loss_inter"), rws_b, CL,
                                         NS, sb), "inter")
-            if on["inter"] and m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
+            if on["inter"] and self.inter_min:
+                # inter_type "min" (losses.py:219-221): on the frames the gate lets through (rec[:, 0], same gate as the
+                # centroid form) the smallest squared vertex distance; the search names the pair, the term and its
+                # gradient live on the two vertices (hand: rigid pose only - the mesh-detached twin; object: only with a free
+                # scale).  A handful of small device ops, same expressions as Losses.compute_interaction_loss.
+                flags = (self.rec[:, 0] != 0).float()
+                i_star = self.nn_d2.argmin(1)
+                j_star = self.nn_idx.gather(1, i_star[:, None]).long()[:, 0]
+                diff = self.vh[self.rows, i_star] - self.vo[self.rows, j_star]
+                self.vals[0, self.SLOTS.index("loss_inter")] = ((diff * diff).sum(1) * flags).sum()
+                pull = (2.0 * w["loss_inter"]) * diff * flags[:, None]
+                self.G_min_h.zero_()
+                self.G_min_h[self.rows, i_star] = pull
+                if m.optimize_object_scale:
+                    self.G_int_o.zero_()
+                    self.G_int_o[self.rows, j_star] = -pull
+            elif on["inter"] and m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
                 ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb), "inter_bwd")
             if on["depth"]:
                 ctx_o, ctx_h, m_o, m_h = self.dctx
@@ -735,8 +756,10 @@ class FusedStepper:
                                      (self.U_conh if on["con"] else None, w["loss_contact"]),
                                      (self.G_dep_h if on["depth"] else None, 1.0)])       # (already times its weight)
             ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
-                                    P(m.int_scales_hand), 0, tp, tw, tn, None,
-                                    (self.rec.data_ptr() + 8) if on["inter"] else None, 8, w["loss_inter"] / Vh, B, Vh,
+                                    P(m.int_scales_hand), 0, tp, tw, tn,
+                                    P(self.G_min_h) if (on["inter"] and self.inter_min) else None,
+                                    (self.rec.data_ptr() + 8) if (on["inter"] and not self.inter_min) else None, 8,
+                                    w["loss_inter"] / Vh, B, Vh,
                                     P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
                                     P(m.translations_hand.grad), None, P(self.rigid_ws_h), CL, sb), "rigid_bwd(hand)")
             if m.optimize_mano:

@@ -180,11 +180,6 @@ def test_fused_step_equals_autograd_path(name, mano_model):
     """FusedStepper (no autograd tape) vs HOMan.forward + autograd: same losses, same parameter gradients."""
     from homan_amd.jointopt import FusedStepper
     rec, model, weights, meta = _build_hip(name, mano_model, sync=False)
-    if meta["inter_type"] != "centroid":
-        # outside the fused loop (the interaction term's non-default 'min' form): it must say so
-        with pytest.raises(NotImplementedError):
-            FusedStepper(model, weights, meta["lr"], 4, capture=False)
-        return
     loss_dict, metric_dict = model(loss_weights=weights)
     total = sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict)
     total.sum().backward()
