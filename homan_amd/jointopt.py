@@ -424,6 +424,10 @@ class FusedStepper:
         self.graph = self.graph_b = None
         self.cap_stream, self.side, self.aux, side = _loop_streams(dev)
         self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd, self.ev_smo, self.ev_ras = (torch.cuda.Event() for _ in range(6))
+        self.ev_hand, self.ev_col = torch.cuda.Event(), torch.cuda.Event()
+        # (option, off: one clip, step-2 sets - the collision chain on the side stream, the rest of the hand side on the third
+        #  stream, see forward_backward; measured +-0.4 % on cfg3: both chains already share a work-bound GPU)
+        self.col_on_aux = (os.environ.get("HOMAN_COL_AUX") or "0") != "0" and C == 1 and self.h == 1
         self.reduce_ws_b = ClipReduceWorkspace(dev, C)
         # (the terms of the fused pair-terms launch run side by side: a reduce workspace each)
         self.reduce_ws_c, self.reduce_ws_d, self.reduce_ws_e = (ClipReduceWorkspace(dev, C) for _ in range(3))
@@ -662,9 +666,25 @@ class FusedStepper:
                 side.wait_event(self.ev_sil)         # self.vo: camera-space object vertices from the calling stream
                 if self.pairs_after_raster:
                     side.wait_event(self.ev_ras)     # (scheduling only, see __init__)
+            # one clip, step-2 sets: the collision term (five SDF launches) and the search / contact / interaction launches
+            # both start from the two vertex buffers and feed nothing to each other.  The collision chain stays on this
+            # stream; everything else of the hand side - and, behind both, the hand's gradient launches - moves to the third
+            # stream, which joins the calling stream (the HIP graph runtime crashes at replay when a forked stream rejoins
+            # the SIDE stream: measured twice; forks that rejoin the origin are fine)
+            split = on["col"] and self.col_on_aux and not use_aux
+            side2, sb2 = (self.aux, self.aux.cuda_stream) if split else (side, sb)
+            if on["col"]:
+                if split:
+                    self.ev_hand.record(side)        # both vertex buffers exist on this stream from here on
+                ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
+                                            cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
+                                            self._slot("loss_collision"), P(cctx.ws), CL, NS, sb), "collision")
+                if split:
+                    self.ev_col.record(side)
+                    side2.wait_event(self.ev_hand)
             if sm_here and not fuse:
                 ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
-                                         sb), "smooth(obj)")
+                                         sb2), "smooth(obj)")
             def search_and_contact(stream_obj, rws):
                 sx = stream_obj.cuda_stream
                 if (on["con"] or on["inter"]) and not nn_fused and not nn_full_fused:
@@ -679,15 +699,11 @@ class FusedStepper:
                     ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
                                               P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws, CL, NS, sx),
                        "contact")
-            if on["col"]:
-                ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
-                                            cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
-                                            self._slot("loss_collision"), P(cctx.ws), CL, NS, sb), "collision")
             # (the search on a third stream at one clip / step 1: +1 %; -9 % on an 8-clip batch.  Search + contact as a third
             #  branch next to the collision term: the HIP graph runtime crashes at replay when two side branches wait for
             #  each other's events.  Capturing the hand-side forward kernels BEFORE the silhouette chain: -38 %.)
             if not nn_full_fused:
-                search_and_contact(side, rws_b)
+                search_and_contact(side2, rws_b)
             if fuse:
                 ck(L.hm_pair_terms_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo,
                                              self._slot("handobj_maxdist") if (nn_fused or nn_full_fused) else None,
@@ -701,33 +717,34 @@ class FusedStepper:
                                              P(self.reduce_ws_e.buf), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
                                              P(m.translations_object), P(m.int_scales_object), P(self.hand_order),
                                              P(self.nn_idx) if nn_full_fused else None, P(self.nn_d2) if nn_full_fused else None,
-                                             CL, NS, sb),
+                                             CL, NS, sb2),
                    "pair terms")
                 if nn_full_fused:
-                    search_and_contact(side, rws_b)          # (the contact launches only: the search ran above)
+                    search_and_contact(side2, rws_b)          # (the contact launches only: the search ran above)
             elif on["inter"]:
                 ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
                                         float(c.INTERACTION_Z_THRESH), P(self.rec),
                                         P(self.tmp_inter) if self.inter_min else self._slot("loss_inter"), rws_b, CL,
-                                        NS, sb), "inter")
+                                        NS, sb2), "inter")
             if on["inter"] and self.inter_min:
-                # inter_type "min" (losses.py:219-221): on the frames the gate lets through (rec[:, 0], same gate as the
-                # centroid form) the smallest squared vertex distance; the search names the pair, the term and its
-                # gradient live on the two vertices (hand: rigid pose only - the mesh-detached twin; object: only with a free
-                # scale).  A handful of small device ops, same expressions as Losses.compute_interaction_loss.
-                flags = (self.rec[:, 0] != 0).float()
-                i_star = self.nn_d2.argmin(1)
-                j_star = self.nn_idx.gather(1, i_star[:, None]).long()[:, 0]
-                diff = self.vh[self.rows, i_star] - self.vo[self.rows, j_star]
-                self.vals[0, self.SLOTS.index("loss_inter")] = ((diff * diff).sum(1) * flags).sum()
-                pull = (2.0 * w["loss_inter"]) * diff * flags[:, None]
-                self.G_min_h.zero_()
-                self.G_min_h[self.rows, i_star] = pull
-                if m.optimize_object_scale:
-                    self.G_int_o.zero_()
-                    self.G_int_o[self.rows, j_star] = -pull
+                with torch.cuda.stream(side2):
+                    # inter_type "min" (losses.py:219-221): on the frames the gate lets through (rec[:, 0], same gate as the
+                    # centroid form) the smallest squared vertex distance; the search names the pair, the term and its
+                    # gradient live on the two vertices (hand: rigid pose only - the mesh-detached twin; object: only with a free
+                    # scale).  A handful of small device ops, same expressions as Losses.compute_interaction_loss.
+                    flags = (self.rec[:, 0] != 0).float()
+                    i_star = self.nn_d2.argmin(1)
+                    j_star = self.nn_idx.gather(1, i_star[:, None]).long()[:, 0]
+                    diff = self.vh[self.rows, i_star] - self.vo[self.rows, j_star]
+                    self.vals[0, self.SLOTS.index("loss_inter")] = ((diff * diff).sum(1) * flags).sum()
+                    pull = (2.0 * w["loss_inter"]) * diff * flags[:, None]
+                    self.G_min_h.zero_()
+                    self.G_min_h[self.rows, i_star] = pull
+                    if m.optimize_object_scale:
+                        self.G_int_o.zero_()
+                        self.G_int_o[self.rows, j_star] = -pull
             elif on["inter"] and m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
-                ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb), "inter_bwd")
+                ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb2), "inter_bwd")
             if on["depth"]:
                 ctx_o, ctx_h, m_o, m_h = self.dctx
                 Sd, K = ctx_o.S, P(m.camintr)
@@ -735,19 +752,21 @@ class FusedStepper:
                                                  (self.vh, ctx_h, Vh, self.d_sil_h, self.d_dep_h)):
                     ck(L.hm_sil_fwd(P(verts), P(ctx.faces), 0, K, B, V_, ctx.F, Sd, 1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR,
                                     None, None, None, P(sil), None, P(ctx.work_order), P(dep), None, 0, None, None, None, 0, 0,
-                                    P(ctx.workspace), sb), "depth render")
+                                    P(ctx.workspace), sb2), "depth render")
                 ck(L.hm_ordinal_depth_fwd(P(self.d_dep_o), P(self.d_dep_h), P(self.d_sil_o), P(self.d_sil_h), P(m_o), P(m_h), B,
-                                          Sd, P(self.d_part), P(self.d_rec), self._slot("loss_depth"), rws_b, sb), "ordinal depth")
+                                          Sd, P(self.d_part), P(self.d_rec), self._slot("loss_depth"), rws_b, sb2), "ordinal depth")
                 ck(L.hm_ordinal_depth_bwd(P(self.d_dep_o), P(self.d_dep_h), P(self.d_sil_o), P(self.d_sil_h), P(m_o), P(m_h), B,
-                                          Sd, P(self.d_rec), P(self.up_depth), P(self.d_go), P(self.d_gh), sb), "ordinal depth bwd")
+                                          Sd, P(self.d_rec), P(self.up_depth), P(self.d_go), P(self.d_gh), sb2), "ordinal depth bwd")
                 for verts, ctx, V_, g, G in ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o),
                                              (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h)):
                     ck(L.hm_depth_bwd(P(verts), K, B, V_, ctx.F, Sd, 1.0, P(g), P(ctx.adj_off), P(ctx.adj_items), P(G),
-                                      P(ctx.workspace), sb), "depth bwd")
-            self.ev_fwd.record(side)         # every forward loss value of this stream exists now
+                                      P(ctx.workspace), sb2), "depth bwd")
+            if split:
+                side2.wait_event(self.ev_col)    # the collision term's hand gradients, from the side stream
+            self.ev_fwd.record(side2)         # every forward loss value of this stream exists now
             if not self.smooth_obj_on_main:
                 aux_block()
-            self.ev_pair.record(side)        # object-side terms of the pair-wise losses are ready
+            self.ev_pair.record(side2)        # object-side terms of the pair-wise losses are ready
             # hand (full path: MANO + rigid): smooth + v2d + collision + contact, summed with their weights inside the rigid
             # backward; the interaction term reaches the rigid pose only, as one vector per frame (rec[:, 2:5] / Vh)
             tp, tw, tn = _lib.terms([(self.U_smh if on["smooth"] else None, w["loss_smooth_hand"]),
@@ -761,11 +780,11 @@ class FusedStepper:
                                     (self.rec.data_ptr() + 8) if (on["inter"] and not self.inter_min) else None, 8,
                                     w["loss_inter"] / Vh, B, Vh,
                                     P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
-                                    P(m.translations_hand.grad), None, P(self.rigid_ws_h), CL, sb), "rigid_bwd(hand)")
+                                    P(m.translations_hand.grad), None, P(self.rigid_ws_h), CL, sb2), "rigid_bwd(hand)")
             if m.optimize_mano:
                 ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
                                  P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
-                                 P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb), "mano_bwd")
+                                 P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb2), "mano_bwd")
         # ---------------- A: object backward: silhouette gradient + smooth + contact [+ interaction with a free scale],
         # summed with their weights inside the rigid backward
         if on["smooth"] and self.smooth_obj_on_main:
@@ -802,7 +821,7 @@ class FusedStepper:
                 ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
                                          P(sctx.workspace), CL, NS, sa), "sil_reduce")
         main.wait_stream(side)               # join
-        if use_aux:
+        if use_aux or (on["col"] and self.col_on_aux):
             main.wait_stream(self.aux)
         elif log:
             ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
