@@ -74,24 +74,17 @@ def group_src(group=None):
 
 
 def optimize_clip_shard(models, loss_weights, num_iterations, lr=1e-2, shared_scale=False, group=None, device=None):
-    """This rank's clips (HOMan models of identical shapes) as ONE clip batch on its GPU: every kernel launched once per
-    iteration over all the clips (homan_amd.clipbatch), replayed from a hipGraph.  -> list of loss_evolution dicts, one
-    per clip; the models hold their optimised parameters.  cfg4: shared_scale=False, no collective.  cfg5:
+    """This rank's clips on its GPU: clips of equal shape as ONE clip batch (every kernel launched once per iteration over all
+    of them, homan_amd.clipbatch), the batches of different shapes - other object meshes, other lengths - one after the other
+    inside every iteration (jointopt.ShardStepper), all replayed from hipGraphs.  -> list of loss_evolution dicts, one per
+    clip, in the order given; the models hold their optimised parameters.  cfg4: shared_scale=False, no collective.  cfg5:
     shared_scale=True (models built with optimize_object_scale=True)."""
-    from .jointopt import FusedStepper
-    if not models:          # a rank without clips still takes part in the collectives of the others
-        if shared_scale and _active(group):
-            if device is None:      # where the collectives of this group live: the GPU under RCCL, the host under gloo
-                device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else "cpu"
-            z = torch.zeros(1, device=device)
-            broadcast_shared_scalar(z, group_src(group), group)     # same source as FusedStepper._sync_shared_scale_start
-            for _ in range(num_iterations):
-                sync_shared_scalar_grad(z.zero_(), group)
-        return []
-    stepper = FusedStepper(list(models), loss_weights, lr, num_iterations, shared_scale=shared_scale, group=group)
+    from .jointopt import ShardStepper
+    # (a rank without clips builds a stepper-less ShardStepper: it issues the one broadcast and the per-step all-reduce of
+    #  a tied scale with a zero gradient, like every other rank)
+    stepper = ShardStepper(list(models), loss_weights, lr, num_iterations, shared_scale=shared_scale, group=group)
     stepper.run(num_iterations)
-    evo = stepper.loss_evolution(num_iterations)
-    return evo if isinstance(evo, list) else [evo]
+    return stepper.loss_evolution(num_iterations)
 
 
 def optimize_clips_shared_scale(models, optimizers, loss_weights, num_iterations, scale_name="int_scales_object",

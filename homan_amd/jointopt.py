@@ -259,7 +259,7 @@ class FusedStepper:
              "loss_contact", "loss_v2d_hand", "v2d_hand", "loss_sil_obj", "iou_object", "loss_inter",
              "handobj_maxdist", "loss_depth"]
 
-    def __init__(self, model, loss_weights, lr, max_steps, capture=True, shared_scale=False, group=None):
+    def __init__(self, model, loss_weights, lr, max_steps, capture=True, shared_scale=False, group=None, collectives=True):
         from . import constants, ops
         from .clipbatch import ClipBatch, ClipReduceWorkspace
         for one in (model.models if isinstance(model, ClipBatch) else model if isinstance(model, (list, tuple)) else [model]):
@@ -292,6 +292,9 @@ class FusedStepper:
                 raise NotImplementedError("the ordinal depth term normalises over one clip: the fused loop covers it for one "
                                           "clip at a time (a clip batch: mode='graph' per clip)")
         self.shared_scale, self.group = bool(shared_scale), group
+        # collectives=False: the caller (ShardStepper: several steppers of one rank) issues the broadcast / all-reduce of the
+        # tied scale itself - every rank must issue the same number of collectives whatever its number of steppers
+        self.collectives = bool(collectives)
         if self.shared_scale and not m.optimize_object_scale:
             raise ValueError("shared_scale needs models built with optimize_object_scale=True")
         self.L, self.c, self.ops = _lib.lib(), constants, ops
@@ -503,7 +506,8 @@ class FusedStepper:
     # ---- shared object scale (BASELINE cfg5): C local replicas of one scalar, kept identical on every rank
     def _dist_on(self):
         import torch.distributed as dist
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return (self.collectives and dist.is_available() and dist.is_initialized() and
+                dist.get_world_size(self.group) > 1)
 
     def _sync_shared_scale_start(self):
         import torch.distributed as dist
@@ -1040,6 +1044,82 @@ class FusedStepper:
         if clip is not None:
             return one(clip)
         return one(0) if self.C == 1 else [one(ci) for ci in range(self.C)]
+
+
+def _shape_signature(model):
+    """what the clips of one clip batch must share (homan_amd.clipbatch): frames, object topology, hands, sizes, options"""
+    faces = model.faces_object[0].detach().cpu().numpy()
+    return (int(model.translations_object.shape[0]), int(model.verts_object_og.shape[1]), faces.shape[0], hash(faces.tobytes()),
+            tuple(model.hand_sides), bool(model.optimize_mano), bool(model.optimize_object_scale), model.hand_proj_mode,
+            int(model.image_size), int(model.losses.sil_ctx.size), int(model.mano_pca_pose.shape[1]),
+            bool(model.int_scales_hand.requires_grad), model.losses.inter_type, bool(getattr(model, "ordinal_depth", False)))
+
+
+class ShardStepper:
+    """A rank's clips of ANY shapes (a real Core50 shard: every clip its own object mesh, reference homan/datasets/
+    core50.py:22-42, and its own length, fit_vid_dataset.py:190): clips that agree in shape are optimised as ONE clip batch
+    (one launch per kernel over all of them, FusedStepper on a list), and the batches of the different shapes follow each
+    other inside every iteration, each replayed from its own hipGraph.  Every clip keeps its own optimiser and ends up with
+    exactly the result of optimising it alone (bit for bit, like the clips of one batch).
+
+    shared_scale (BASELINE cfg5): ONE object scale tied across all clips of all ranks.  The steppers compute their clips'
+    gradient sums, this class adds them, issues the rank's ONE all-reduce per iteration (and its one broadcast at the start)
+    - so ranks with different numbers of shape groups, or with none, stay in step - and hands the global sum back."""
+
+    def __init__(self, models, loss_weights, lr, max_steps, shared_scale=False, group=None, capture=True):
+        from . import dist as hdist
+        self.models, self.shared_scale, self.group, self.hdist = list(models), bool(shared_scale), group, hdist
+        groups = OrderedDict()
+        for i, mdl in enumerate(self.models):
+            groups.setdefault(_shape_signature(mdl), []).append(i)
+        self.index = list(groups.values())                    # per stepper: positions of its clips in `models`
+        self.steppers = [FusedStepper([self.models[i] for i in idxs], loss_weights, lr, max_steps, capture=capture,
+                                      shared_scale=shared_scale, group=group, collectives=False) for idxs in self.index]
+        if self.shared_scale:
+            dev = self.models[0].int_scales_object.device if self.models else None
+            if dev is None:     # a rank without clips: the collectives of the others, on the device of the group's backend
+                import torch.distributed as tdist
+                dev = (torch.device("cuda", torch.cuda.current_device())
+                       if (tdist.is_initialized() and tdist.get_backend(group) == "nccl") else torch.device("cpu"))
+            start = (self.steppers[0].model.int_scales_object.detach()[:1].clone() if self.steppers
+                     else torch.zeros(1, device=dev))
+            hdist.broadcast_shared_scalar(start, hdist.group_src(group), group)
+            with torch.no_grad():
+                for st in self.steppers:
+                    st.model.int_scales_object.copy_(start.expand_as(st.model.int_scales_object))
+            self.total = torch.zeros(1, device=dev)
+
+    def run(self, steps):
+        for _ in range(steps):
+            if not self.shared_scale:
+                for st in self.steppers:
+                    st._iteration()
+                continue
+            self.total.zero_()
+            for st in self.steppers:            # forward + backward of every shape group; st.g_shared = sum over its clips
+                if st.graph is not None:
+                    st.graph.replay()
+                else:
+                    st.forward_backward(log=True)
+                self.total += st.g_shared
+            self.hdist.sync_shared_scalar_grad(self.total, self.group)
+            for st in self.steppers:
+                st.g_shared.copy_(self.total)
+                if st.graph_b is not None:
+                    st.graph_b.replay()
+                else:
+                    st._spread_shared_scale_grad()
+                    st.opt.step(zero_grad=False)
+
+    def loss_evolution(self, steps):
+        """one dictionary per clip, in the order the models were given"""
+        out = [None] * len(self.models)
+        for st, idxs in zip(self.steppers, self.index):
+            evo = st.loss_evolution(steps)
+            evo = evo if isinstance(evo, list) else [evo]
+            for i, e in zip(idxs, evo):
+                out[i] = e
+        return out
 
 
 def save_front_top(model, images, step, viz_folder, viz_len=7):

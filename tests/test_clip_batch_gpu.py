@@ -114,3 +114,59 @@ def test_shared_scale_fused_matches_tied_eager(mano_model):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_heterogeneous_shard_equals_solo_runs_bitwise(mano_model):
+    """A shard as a real dataset hands it over (reference homan/datasets/core50.py:22-42: every clip its own object mesh;
+    fit_vid_dataset.py:190: its own length): cube clips of 8 frames and a bottle clip of 10, in arbitrary order.  ShardStepper
+    batches the clips that agree in shape and runs the batches of different shapes one after the other inside every iteration;
+    every clip ends up with exactly the rows and parameters of optimising it alone."""
+    from homan_amd import dist as hdist
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, ShardStepper
+    lw, steps = dict(synth.STEP2_LOSS_WEIGHTS), 6
+    spec = [(3, 8, "cube"), (4, 10, "bottle"), (5, 8, "cube")]
+    build = lambda: [_clips(mano_model, [seed], frames, 64, obj)[0] for seed, frames, obj in spec]
+    solo, evo_solo = build(), []
+    for m in solo:
+        st = FusedStepper(m, lw, 1e-2, steps)
+        st.run(steps)
+        evo_solo.append(st.loss_evolution(steps))
+    shard = build()
+    sh = ShardStepper(shard, lw, 1e-2, steps)
+    assert sorted(len(i) for i in sh.index) == [1, 2]              # the two cubes share a batch, the bottle has its own
+    sh.run(steps)
+    for c, (es, eb) in enumerate(zip(evo_solo, sh.loss_evolution(steps))):
+        for k in es:
+            np.testing.assert_array_equal(np.asarray(eb[k]), np.asarray(es[k]), err_msg=f"clip {c} {k}")
+    for c, (ms, mb) in enumerate(zip(solo, shard)):
+        for k in PARAMS:
+            assert torch.equal(getattr(ms, k).detach(), getattr(mb, k).detach()), f"clip {c} {k}"
+    # the public entry point (what a rank of bench.py --gpus N / a dataset driver calls) takes the same shard
+    again = build()
+    evo = hdist.optimize_clip_shard(again, lw, steps)
+    for es, eb in zip(evo_solo, evo):
+        np.testing.assert_array_equal(np.asarray(eb["loss"]), np.asarray(es["loss"]))
+
+
+def test_heterogeneous_shard_with_a_tied_scale(mano_model):
+    """cfg5 semantics over clips of different shapes: one scalar for all of them, replicas identical in every shape group,
+    and the same trajectory as the plain autograd tied loop of homan_amd.dist over the same (HIP) models."""
+    from homan_amd import dist as hdist
+    from homan_amd import synth
+    from homan_amd.jointopt import ShardStepper, parameter_groups
+    lw, steps = dict(synth.STEP2_LOSS_WEIGHTS), 4
+    lw["lw_scale_obj"] = 10.0
+    spec = [(3, 8, "cube"), (4, 10, "bottle"), (5, 8, "cube")]
+    build = lambda: [_clips(mano_model, [seed], frames, 64, obj, optimize_object_scale=True)[0] for seed, frames, obj in spec]
+    eager = build()
+    opts = [torch.optim.Adam(parameter_groups(m, 1e-2)) for m in eager]
+    hist = hdist.optimize_clips_shared_scale(eager, opts, lw, steps)
+    shard = build()
+    sh = ShardStepper(shard, lw, 1e-2, steps, shared_scale=True)
+    sh.run(steps)
+    s = np.asarray([float(m.int_scales_object.detach().cpu()[0]) for m in shard], np.float32)
+    assert (s == s[0]).all() and abs(float(s[0]) - 1.0) > 1e-4
+    np.testing.assert_allclose(s[0], float(eager[0].int_scales_object.detach().cpu()[0]), rtol=2e-4)
+    evo = sh.loss_evolution(steps)
+    np.testing.assert_allclose([e["loss"][0] for e in evo], hist[0], rtol=2e-4)
