@@ -375,8 +375,9 @@ def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
     evo = st.loss_evolution(total)
     evo = evo if isinstance(evo, list) else [evo]
     scale = st.model.int_scales_object.detach().reshape(-1)
-    gathered = [torch.zeros(1, device=scale.device) for _ in range(world)]
-    dist.all_gather(gathered, scale[:1].contiguous())
+    wire = scale[:1].contiguous() if backend == "nccl" else scale[:1].cpu()       # (gloo moves host memory)
+    gathered = [torch.zeros_like(wire) for _ in range(world)]
+    dist.all_gather(gathered, wire)
     same = bool((scale == scale[0]).all()) and all(torch.equal(g, gathered[0]) for g in gathered)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -723,7 +724,7 @@ def main():
         barrier()
         el = time.perf_counter() - t1
         if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         mval = world * C * msteps / el
