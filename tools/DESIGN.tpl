@@ -1,0 +1,362 @@
+# DESIGN — homan_amd: HOMan's joint-optimisation hot path on MI355X (gfx950)
+
+Scope is exactly SURVEY.md §8 (the grading contract): rows (a)–(e), then the four "next" rows of §8f, each to the same
+parity bar.  Everything else in the reference (detection, tracking, datasets, mask / hand-pose networks, dataset
+evaluation) stays out of scope.  All `path:line` citations are relative to `/root/reference/`.  This file is the CURRENT
+design and the current numbers; how the kernels got here - every measured step and every reverted experiment - is in
+`EXPERIMENTS.md`.
+
+## 0. §8 rows → where they live
+
+| §8 row | What | Where |
+|---|---|---|
+| (a) a1 loop | `optimize_hand_object`, three Adam groups, weighting, logging | `homan_amd/jointopt.py` (`mode="auto"` (default) = `"fused"` whenever `FusedStepper` accepts the configuration - its own guards decide - else `"graph"`; `"eager"` = reference loop verbatim; `GraphStepper` = the same autograd iteration in a hipGraph; `FusedStepper` = the iteration as a fixed C-ABI launch sequence on two (one clip) or three (clip batch) streams in a hipGraph, the benchmark path - one clip, a BATCH of equal-shaped clips (`homan_amd/clipbatch.py`), or through `ShardStepper` a shard of clips of any shapes), `csrc/adam.hip` |
+| (a) a2,a3,a7,a20 | `HOMan` module: parameter/buffer surface, `get_verts_*`, `forward` | `homan_amd/homan.py` |
+| (a) a4–a6 | rot6d→R, rigid transform (+ mesh-detached twin) | `csrc/geometry.hip` (`hm_rigid_fwd/bwd`) |
+| (a) a8 + N3 | `ManoModel.forward_pca` + MANO LBS | `csrc/mano.hip` (`hm_mano_fwd/bwd`), `homan_amd/manomodel.py`, `mano_assets.py` |
+| (a) a9,a10,a13,a15 | pca / smooth / v2d / scale priors | `csrc/losses.hip` |
+| (a) a11,a12 + N1 | silhouette renderer + masked MSE + IoU | `csrc/raster.hip` (`hm_sil_fwd/bwd`) |
+| (a) a14 | coarse interaction loss + gating + min-distance metric | `csrc/losses.hip` (`hm_inter_*`), `csrc/contact.hip` (`hm_nn_fwd`) |
+| (a) a16,a17 + N2 | SDF collision loss | `csrc/sdf.hip` (`hm_collision_fwd`) |
+| (a) a18 | contact loss (as executed, Appendix B.1) | `csrc/contact.hip` |
+| (a) a19 | ordinal depth | `csrc/raster.hip`: depth image out of `hm_sil_fwd` (`pooled_depth`), `hm_depth_bwd`, `hm_ordinal_depth_fwd/bwd`. The reference call site is broken (`homan.py:506-507` raises `TypeError`, `lossutils.py:140` builds the accumulator with `torch.Tensor(0.0)`): the default still raises that `TypeError`; `HOMan(ordinal_depth=True)` opts into the loss the method describes, in all three loops - eager, graph and the fused launch sequence (`FusedStepper`, `lw_depth > 0`, one clip; any render size since the rasteriser pads to a multiple of 32, the fused depth renders at `image_size % 32 == 0`). **Oracle-pinned only** (no reference output exists to pin against) |
+| (b) boundary | Python surface + C ABI | `homan_amd/{homan,losses,lossutils,manomodel,jointopt}.py`, `include/homan_amd.h`, `INTEGRATION.md` |
+| (c) oracle | CPU restatement + reference-generated goldens | `oracle/`, `tools/refharness/`, `tests/golden/` |
+| (d) measurement | bench, roofline, CPU baseline, rocprof | `bench.py`, `profiles/`, `tools/prof_summary.py` |
+| (e) multi-GPU | clip sharding, clip batches per rank, heterogeneous shards, shared-scale all-reduce inside the fused loop | `homan_amd/dist.py`, `homan_amd/clipbatch.py`, `jointopt.ShardStepper`, `FusedStepper(shared_scale=True)`, `bench.py --gpus N [--shared-scale]`, `tests/test_dist_gloo.py` (CPU, oracle model), `tests/test_dist_gpu.py` (N ranks on one GPU through the fused loop, cfg5 at full size), `tests/test_clip_batch_gpu.py` |
+| (f) rank 1 | object-pose initialisation (`pose_optimization.py:37-160,219-383`, `lib3d/optitrans.py:83-127`) | `homan_amd/pose_optimization.py` (`PoseOptimizer`, `find_optimal_pose`, and the clip-level `find_optimal_poses` of `:386-488` that `fit_vid_dataset.py:285-296` calls) over the same rasteriser run without anti-aliasing (`hm_sil_fwd` `alpha_full` with the masked L2 + IoU fused per sample, `hm_sil_bwd` modes 3 / 4); oracle `oracle/poseopt.py`; golden from the reference's own module (`tools/refharness/gen_goldens_poseinit.py`); `bench.py --pose-init` |
+| (f) rank 2 | hand silhouette term (`losses.py:166-181`) + ordinal depth (`homan.py:384-419`, `lossutils.py:133-169`), both present-but-disabled upstream | `Losses.compute_sil_loss_hand` (per-hand ROI render, own keep-mask normalisation; the reference body cannot run past its first frame, built for the evident intent) ; ordinal depth = row a19.  Oracle-pinned |
+| (f) rank 3 | textured / shaded renders for visualisation (`homan.py:168-219,510-628`, `visualize.py:44-128`, `meshutils.py:7-51`, `jointopt.py:158-176`) | rgb output of the rasteriser (`hm_shade_rgb`: NMR flat lighting on the forward's index map), `homan_amd/nmr.py` (`model.renderer`), `HOMan.render / render_gt / render_with_gt / render_limem / save_obj`, `homan_amd/{meshutils,visualize,trans3d}.py`, frames out of `optimize_hand_object`; oracle `oracle/nmr.py` (`lighting`, `shade_index_map`); `tests/test_render_gpu.py` |
+| (f) rank 4 | checkpoint / evaluation hand-off (`fit_vid_dataset.py:365-372,322-338`, `postprocess.py:16-77`, `eval/pointmetrics.py:102-124`) | `homan_amd/checkpoint.py` (`joint_fit.pt` contract, files interchange with the reference's), `homan_amd/pointmetrics.py::get_inter_metrics` on `hm_collision_fwd` + `hm_collision_dist_values` (per-vertex penetration depths = `sdf_meta["dist_values"]`) |
+
+## 1. The path and its boundary
+
+Hot path = `homan.jointopt.optimize_hand_object` (`homan/jointopt.py:22-201`) → `HOMan.forward`
+(`homan/homan.py:421-508`) → `homan/losses.py`, `homan/lossutils.py`, `homan/interactions/{scenesdf,contactloss}.py`,
+`homan/utils/{geometry,camera,bbox}.py`, `homan/manomodel.py` → third-party leaves `neural_renderer`, `sdf`, `mano`.
+
+Two boundaries are kept:
+
+* **Python (what the reference's callers see).**  `homan_amd.HOMan` has the reference constructor keywords
+  (`homan.py:27-60`), the same Parameter / buffer *names* (so the name-substring Adam grouping of
+  `jointopt.py:128-151` and `load_state_dict(strict=False)` of a `joint_fit.pt` behave identically), the same
+  `forward(loss_weights) -> (loss_dict, metric_dict)` keys / shapes (`()` except `loss_contact, loss_sil_obj, loss_inter`
+  = `(1,)`), `get_verts_object()`, `get_verts_hand(detach_scale=False)`.  `homan_amd.optimize_hand_object` has the
+  reference signature and return triple.  Extensions are keyword-only (`mano_model`, `rend_size`, `mode`).
+* **C ABI (`include/homan_amd.h`, `libhoman_amd.so`).**  Plain pointers + sizes + `hipStream_t`, caller-owned buffers,
+  error codes, no torch types.  The Python layer binds it with `ctypes` (`homan_amd/lib.py`); torch supplies device
+  memory, streams, the autograd tape and `torch.distributed` only.  There is **no CPU fallback**: `lib.lib()` raises if
+  the library is missing, `HOMan.__init__` raises without a GPU, and `homan_amd` never imports `oracle`.  Every entry point
+  of the loop also exists as `hm_*_clips(..., clip_len[, out_stride])` (frame axis = several clips laid end to end, per-clip
+  scalars and outputs as arrays) and the MANO pair as `hm_mano_{fwd,bwd}_rows` (a strided slice of the rows: hand `i` of
+  two interleaved hands through the model of its side, `homan.py:343-358`, without a copy).
+
+**What the default `mode="auto"` runs in the fused launch sequence** (everything a golden exists for): one hand, right or
+left, or two hands per frame (one clip); `optimize_mano` on or off (`jointopt.py:36`: off is the reference function's own
+default); `inter_type` `"centroid"` or `"min"` (one hand, one clip); a free or tied object scale; silhouettes at ANY
+`rend_size` and any image size (sizes off the 32-pixel tile grid render on the next multiple with the first two rows of K
+rescaled, masks padded with keep = 0 and the rasteriser's eps scaled - same rays, cropped outputs; the one difference of a
+padded render: a face that leaves the image through its right / bottom border still lies inside the raster, so its edges
+sweep where a native render of that size culls them); object meshes of any size (the metric-only search covers 4096
+vertices, larger meshes take the full search; the contact scatter walks the object in ranges of 4096).  What falls back to
+the graph loop: `hand_proj_mode="ortho"` (raises, section 7), the depth term in a clip batch, a batch of two-hand clips.
+
+Reference quirks reproduced on purpose (SURVEY Appendix B): `loss_contact ≡ mean 0.02·tanh(d_NN/0.02)`; `loss_inter` is
+the un-normalised sum; `mano_rot`/`mano_trans` get gradients but are in no Adam group; `mano_betas` start at zero;
+`int_scale_init` must be an `int`; `loss_sil_obj` divides by `Σkeep` of the whole clip, then by `B`; `lw_depth>0` raises
+`TypeError`; `optimize_mano=False` has no `mano_trans`.  **Documented divergence:** `rot6d_to_matrix` takes the cross
+product per row; the reference's dim-less `torch.cross` (`utils/geometry.py:26`) silently crosses along the batch axis
+when the flattened batch is exactly 3 (goldens therefore never use 3 frames).
+
+## 2. Oracle and parity status
+
+`oracle/` is test infrastructure (only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` /
+`final_loss_parity` legs import it).
+
+* **Composition layer — PINNED.**  `tools/refharness/` imports the reference's own `homan/{homan,losses,lossutils,
+  jointopt}.py`, `interactions/*`, `utils/*` *in place* (no copy, no bytecode) with `.cuda()` neutralised and the oracle
+  leaves injected as `neural_renderer`, `sdf`, `mano.model`, `libyana.*`; `gen_goldens.py` runs the reference's
+  `HOMan.forward` / `optimize_hand_object` on seeded synthetic clips and writes inputs + `loss_dict`, `metric_dict`, every
+  Parameter gradient, the parameters after 5 reference steps with the reference's forward / backward THERE, 6-20-step
+  `loss_evolution`, final parameters to `tests/golden/*.npz` (8 cases: step-1, step-2, free scale, `optimize_mano=False`,
+  two hands step-1 / step-2, a lone left hand, `inter_type="min"`) + the pose-initialisation golden.
+  `tests/test_oracle_golden.py` pins `oracle/model.py` + `oracle/jointopt.py` to them (losses 2e-5, gradients 5e-5 of max,
+  vertices 3e-7 m, trajectories 5e-4) and re-runs the generator against `/root/reference` to check the committed file.
+* **Leaves — PARITY UNPINNED.**  `neural_renderer`, `sdf` (hassony2/multiperson @ HEAD), `mano` (hassony2/MANO @ HEAD),
+  `libyana` (@ HEAD) are un-vendored, un-pinned, absent from `/root/reference`, and the reference holds no tests or golden
+  vectors for them; `MANO_RIGHT.pkl` is licensed and absent.  `oracle/csrc/nmr_raster.c`, `oracle/csrc/sdf.c`,
+  `oracle/lbs.py`, `oracle/yana.py` restate the *published* algorithms (Kato et al. 2018 NMR; SDFGen-style voxel SDF; smplx
+  LBS) and write down every convention they fix.  The reference build is **unbuildable here** (Python only; its native leaves
+  are CUDA extensions whose sources are not in the tree), so there is no `oracle/_ref`.  `tests/test_known_answers.py`
+  anchors oracle AND kernels to analytic truths any correct implementation satisfies (full-screen quad, half-plane edge in
+  quarter steps, fill_back, cube SDF `h − max|x_i|`, LBS at rest, coincident contact = 0, pseudo-gradient magnitude of a
+  single edge in float64).
+* **Evaluation-order choices of the oracle** (same mathematics; upstream's own rounding - nvcc FMA contraction, cuBLAS - is
+  not reproducible on any CPU): depth `z = Σw / Σ(w_k·(1/z_k))` with one division per sample; and, since round 3, the rotation
+  (`rot6d_to_matrix`), the rigid transform `(s·v)·R + t` and the projection written out OPERATION BY OPERATION with a
+  correctly rounded square root.  Measured reason: `torch.sqrt` on contiguous fp32 goes through MKL's vector math and is not
+  correctly rounded (0.65 % of inputs one ulp off, depending on layout), the CPU `torch.matmul` is an FMA chain for V ≥ 45
+  and a plain loop below, `F.normalize` / `torch.cross` round differently with the batch size - the reference's literal
+  expressions give different last bits on different hosts, and one ulp in R moves a vertex across a sample centre.  The
+  kernels follow the written-out order with `-ffp-contract=off` on both sides.
+
+HIP ↔ oracle parity is exact where the domain is discrete and tolerance-bound where it is fp32 summation order:
+
+| Quantity | Bar | Test |
+|---|---|---|
+| rotation, rigid transform, projected NDC faces | **bit-exact** | `test_ops_gpu.py::test_rigid_transform_and_grads`, `test_raster_gpu.py::test_projection_matches_oracle` |
+| face-index map (B,2S,2S), pooled silhouettes | **bit-exact** (from the PARAMETERS, end to end) | `test_face_index_map_bit_exact`, `tests/test_lockstep_gpu.py` (0 flipped samples along 50 cfg2 / cfg3 steps) |
+| SDF inside/outside masks | **bit-exact** | `test_ops_gpu.py::test_collision_vs_oracle` |
+| every `loss_dict` entry vs reference goldens | **1e-4 relative** (BASELINE north_star) | `test_model_gpu.py::test_forward_matches_reference_goldens`, `test_pinned_step_matches_reference` |
+| parameter gradients vs goldens | **5e-5** of max per tensor (2e-3 before round 3) | same |
+| NMR pseudo-gradient per vertex | 2e-5 of max | `test_pseudo_gradient_matches_oracle` |
+| **every step of a full-size trajectory, teacher-forced** | losses 1e-5 (cfg2) / 1e-4 (cfg3; `loss_collision` 1e-3, see below), gradients 2e-5 / 5e-4 of max, object vertices bit-equal, hand 1e-3 mm | `tests/test_lockstep_gpu.py` |
+| C clips in one launch per kernel vs C solo runs; shape groups of a shard vs solo runs; 2 ranks vs one 2-clip batch | **bit-exact** (rows, final parameters) | `tests/test_clip_batch_gpu.py`, `tests/test_dist_gpu.py` |
+| fused launch sequence vs `HOMan.forward` + autograd | losses 2e-6, gradients 2e-5 of max, every golden incl. two hands / left / `min` / `optimize_mano=False` | `test_fused_step_equals_autograd_path` |
+| pose initialisation vs the reference module's golden | mask loss within the number of samples that differ, gradients 2e-3 of max | `tests/test_poseinit.py` |
+
+**Final-loss / final-vertex parity (the second half of BASELINE's metric) — what is bounded and what cannot be.**
+`bench.lockstep_parity` (`final_loss_parity.lockstep` of the bench line, `tests/test_lockstep_gpu.py`) runs the fused loop at
+cfg2 / cfg3 size and BEFORE every step loads its parameters into the CPU oracle, which evaluates that step there.
+Measured over 30-50 steps (`profiles/r03_lockstep_cfg{2,3}.json`): zero flipped samples, object vertices bit-equal,
+`loss_sil_obj` equal to the last bit, every loss of the step-1 set within 2.4e-7, gradients within 1.9e-6 of their largest
+entry, hand vertices within 6e-5 mm (one ulp: the MANO blend sums run in another order and sin / cos come from another libm).
+The one term above 1e-5 is `loss_collision` (up to 1.8e-4 in one of 30 cfg3 steps): a sum of a few small trilinear SDF
+samples, conditioned at ~1e-4 against the one-ulp difference of the HAND's vertices - evaluated by the oracle ON the HIP
+vertices it agrees to 1.1e-7, and its weighted share of the objective is < 1e-8.
+The FREE trajectories (HIP loop vs oracle loop with torch Adam) from identical inputs: step 0 agrees to 1e-7, the first
+differing samples appear at step 1 (5 of 7.9 M) - after the first optimiser step, never before -, 455 differ at step 2, and
+the 1e-4 band is left at step 10 (cfg2) while the lock-step error of that step is still 8e-7.  So the measured cause of the
+divergence is not a difference in what is computed: gradients that agree to 2e-6 give parameters that differ in the last
+bits after one Adam step, a last-bit difference flips a sample of the hard rasteriser, and Adam - whose step is
+`lr · m̂/√v̂`, i.e. normalised - turns a 1e-3 relative change of a gradient into a 1e-4 rad change of a rotation, which flips
+hundreds.  The control experiment says the same of the reference algorithm itself: the CPU oracle against ITSELF from inputs
+that differ by 1e-7 m ends 14 mm apart in the object (0.0 mm in the hand, driven by the smooth keypoint term) and leaves the
+1e-4 band at step 3 (`final_loss_parity.cfg1.cpu_vs_cpu_control`).  The 1e-4 / 1e-3 mm bar therefore holds per step along
+the whole trajectory (tested), and for the end state of the smooth part of the problem (hand: 1.8e-4 mm after 100 cfg1
+steps); the end state of the object is bounded by what is well defined - the distribution of final losses over seeds, within
+5 % (`tests/test_parity_gpu.py`).
+
+## 3. Data layout in HBM (per clip, B frames, S=256 → 512² samples, F faces, V vertices)
+
+| Buffer | Shape / type | Bytes (cfg2) | Producer → consumer |
+|---|---|---|---|
+| `faces9` (packed face buffer) | (B,F,3,3) f32 NDC | 3.2 MB | `k_setup_faces` → `k_raster_fwd` (record build), sweep work list |
+| `boxes` | (B,F) 4×u16 sample box + 2-bit winding mask | 0.7 MB | `k_setup_faces` → `k_raster_fwd`, sweep work list |
+| `bin_cnt`, `bin_list` | (B,64) i32 ; (B,64,F) i32 — faces per 64² super-region (128² above 512² samples) | ≤ 23 MB (≈ 0.6 MB used) | `k_setup_faces` → `k_raster_fwd` |
+| `idx_map` | (B,512,512) i32, −1 = background | 31.5 MB | `k_raster_fwd` → `k_bwd_lines`, `k_bwd_sweep`, `k_depth_bwd_faces` |
+| `alpha16` | (B,32,32,16) u16, 1 bit / sample, tile-blocked | 1 MB | `k_raster_fwd` → `k_bwd_masks` (generic backward only) |
+| `pooled`, `dimg` (`gimg`: generic backward) | (B,256,256) f32 | 7.9 MB each | raster → reduce / lines |
+| sweep planes | (B,32,32,4,16) u16, **tile-blocked**: the row / column words of both planes of an 8×8-pixel tile side by side = one 128-byte line per tile | 3.9 MB | `k_raster_fwd` epilogue (fused loss) or `k_bwd_masks` → `k_bwd_lines` |
+| `lrec` | (4,B,512) lines × 8 × {64 mask bits, sources before them} (16 B) — one cache line per line | 7.9 MB | `k_bwd_lines` → `k_bwd_sweep` |
+| `lsum` | (B,2 axes,512 lines) × 2 planes × {first set position, last + 1, 16-bit mask of non-empty 64-sample words} (16 B per line) | 0.5 MB | `k_bwd_lines` → `k_bwd_sweep` stage 1 |
+| `srcs` | (4,B,512) lines × ≤512 × {d1, g, owner} | 377 MB reserved, ≈ 0.3 MB touched | `k_bwd_lines` → `k_bwd_sweep` |
+| `owned` | (B,2F) u8 | 0.2 MB | `k_raster_fwd` → work list |
+| sweep work list: `tab`, `offs`, `ufirst` | active faces × 64 B {corners in pixels, cumulative item counts of the 12 (winding, edge, axis) families, first item} ; first face of every 64-item unit | ≤ 5.8 MB + 0.4 MB + 1.4 MB (≈ 45 % of the faces active) | compaction blocks of `k_bwd_lines` → `k_bwd_sweep` |
+| `parts` | (B,F,3,2) f32 corner gradients | 2.2 MB | `k_bwd_sweep` → `k_bwd_gather` / `k_rigid_bwd` |
+| MANO model `M` | (145,2334) f32 = [posedirs; shapedirsᵀ] | 1.35 MB | constant, L2-resident |
+| SDF: `tris` | (B,F_k,16) f32 packed triangle + box | 8.7 MB | `k_sdf_tris` → `k_sdf_dist` |
+| SDF: `masks`, `needm`, `need_list`, `phi` | 32² u32 rows ; ≤ 32³ voxel ids / distances per (mesh, frame) | 0.5 MB + sparse | sign → need → distance → sample |
+
+Everything of one clip stays resident (≈ 0.5 GB reserved, ≈ 80 MB touched per iteration); a 288 GB GPU holds hundreds
+of clips.
+
+**Clip batches (cfg4 / cfg5).**  C clips of equal shape are ONE set of the arrays above with the frame axis C·B long: clip
+c = frames [c·B, (c+1)·B).  Per-frame tensors (poses, vertices, masks, cameras, every workspace array) are simply longer;
+per-clip scalars become (C,) arrays (`int_scales_*`, `Σkeep`, scale-prior unit gradients); the loss / metric slots are a
+(C, 14) table (`out_stride` = 14 floats), the log is (steps, C, 14); reduce workspaces hold C slices of 576 floats
+(partials + ticket) back to back; the sweeps' work list gives every clip its own run of compaction blocks.  `ClipBatch`
+(`homan_amd/clipbatch.py`) builds this from C `HOMan` models and re-points each model's Parameters to views of the batched
+storage, so every model ends up holding its own result.  8 clips of cfg2: ≈ 4 GB reserved.
+
+## 4. Kernels (all hand-written HIP, wave64, no MFMA — there is no dense contraction on this path)
+
+`bound` = which roofline limits the kernel at its design point; bytes are algorithmic HBM bytes per launch for cfg2
+(B=30, S=256, F=3000, V=1502).  One optimisation iteration = 10 launches (cfg2: setup, raster, lines, sweeps, object
+gradients, Adam + log row | MANO forward, pair terms, hand gradients, MANO backward) / 20 (cfg3) on two HIP streams for one
+clip; a clip batch keeps the terms in launches of their own and adds a third stream (15 / 22 launches).  Every kernel takes a batch of clips in ONE launch: per-frame kernels index their per-clip
+scalars by `frame / clip_len`; reduction kernels add a grid row (or ticket) per clip, each clip's sums formed by its own
+workgroups in the order of a single-clip launch - which is why a batched step is bit-identical to C single steps.
+
+| Kernel | Work decomposition | Bound | Alg. bytes / launch |
+|---|---|---|---|
+| `k_setup_faces` | thread / face: optional rigid transform of the mesh-space vertex (the silhouette chain does not wait for `hm_rigid_fwd`), projects its 3 vertices (no separate projection launch), windings, tight sample box; bins the face into 64² super-regions (128² above 512² samples; LDS-aggregated counts, one global atomic per (workgroup, bin)); extra workgroups write the camera-space vertices for the other losses (same arithmetic as `k_rigid_fwd`: the hand-side stream no longer opens with a transform launch) | HBM | B·(V·24 + F·(12+36+8+2+5)) = 6.7 MB |
+| **`k_raster_fwd`** | workgroup = one 32×32-sample region: scans the faces of its super-region; candidates are split by WINDING CLASS - the class that holds the camera-facing surface of the mesh (a scheduling hint set by `calibrate()` from the index map; any value is correct) fills the candidate array from the front, the other from the back; one thread per candidate builds the face record in LDS (+ the nearest depth the face can produce); the (candidate, 4×4-sample block) units are **flattened** over the 256 threads (binary search of the exclusive unit counts); visibility = `ds_min_u64` on an LDS z-buffer keyed (depth bits ≪ 32 \| face) = strict z test in ascending face order, bit-exact.  The near class runs first; then per 4×4 block the largest owner depth is taken (`hz`), and the units of the far class are first tested against it, 64 per wave trip, the survivors queued per wave and the unit body run on FULL waves of survivors (a divergent early-out would leave the wave paying for its one visible unit: on a closed mesh ~85 % of the far units are hidden).  Sample positions of power-of-two grids by one multiplication (eight IEEE divisions per unit before).  Epilogue per 8×8 output tile: index map, pooled silhouette, fused masked-MSE terms, alpha plane and the four sweep bit planes of the backward (one full cache line per tile, ballots picked with selects: no scratch); in a fixed loop (`persistent_outputs`) an empty bin in front of outputs that already hold the empty pattern leaves before touching LDS (60 % of the workgroups).  25 KB of LDS and 80 VGPRs: 6 workgroups per CU (4 before: +20 %) | latency × residency, then VALU (`valu_frac` 0.54) | B·(F·49 + 512²·4 + 4·S²·4 + 5·512²/8) = **72.2 MB** |
+| `k_sil_reduce` | block / frame + last-block finish.  One clip: the same body rides as B extra workgroups at the front of the `k_bwd_lines` launch (`hm_sil_bwd_clips(..., loss_out)`): the value is only logged, so it costs no launch; a clip batch keeps it on the third stream | latency | 0.5 MB |
+| `k_bwd_masks` | generic backward only (arbitrary `dL/dsilhouette`, or a negative loss weight): wave / tile, sweep planes via ballots | HBM | ≈ 21 MB |
+| `k_bwd_lines` | one DPP row (16 lanes) / (plane, orientation, frame, line), 16 lines / workgroup: expands a bit line into a position-sorted array of sources {d1, g, owner} + a 16-byte record per 64-bit word {mask, sources before it} (row scan).  Its first ⌈B·F/256⌉ workgroups build the **work list** of the sweeps instead: faces that own a sample → 64-byte records laid end to end in one global item space (block scan, one 64-bit atomic per block; a block's items start on a 64-item boundary so that the composition of every unit — and with it every summation order — is independent of the order in which blocks draw their bases) | latency | B·(4·512²/8 + S²·4 + 512² + F·46) = 23.8 MB |
+| **`k_bwd_sweep`** | persistent waves; a **unit** = 256 consecutive (face, winding, edge, axis, d0) items of the global list, whichever faces they belong to (a big face spreads over several waves, small faces share one), handled per pass of ≤ 16 faces staged in LDS together with their per-(face, family) constants - edge slope, first line, end-point order: one IEEE division per family instead of one per item, built by the wave right after the staging - and per-(face, axis) inward ranges.  **Stage 1** (every item, 64 per trip, four trips whose loads are all in flight before the first is tested): family by a 4-step search of the cumulative counts, line geometry from the family constants, then three loads requested together: the line's 16-byte summary, the owner of the sample just inside the edge and the alpha word of the sample just outside - the outward sweep needs a sample this winding owns AND a plane-0 source beyond the edge (exact from first / last position), the inward sweep an empty sample outside AND a plane-1 source inside the triangle's extent (positions + word mask); in the steady state of a fit 71 % of the items stop here (1.95 M items → 557 k, of which 555 k do have pairs) and the rest are queued with the two decisions.  **Stage 2** (queued items on full waves): two 16-byte record loads + popcounts give the slices `[lo, lo+nb)` of the line's source array; the (item, source) pairs are **flattened** over the wave, four consecutive pairs per lane, item of a pair by scatter + max-scan; per-lane running sums flushed into the face's six LDS accumulators when the (face, corner) target changes; a face inside one unit is stored, a face cut by one unit boundary is added by two commutative hardware float atomics, a face over ≥ 3 units goes through per-unit partials + ticket (deterministic in all three cases); **XCD-aware**: each XCD (workgroup id mod 8) takes one contiguous eighth of the units, so a frame's index-map lines, line records and source slices are fetched into one L2 instead of eight | VALU issue + dependent-load latency (`valu_frac` 0.48) | B·(F·(68+24) + 512²·4 + 512²) = **47.6 MB** |
+| `k_bwd_gather` | thread / vertex over CSR adjacency: one `float2` per (face, corner) (deterministic, no atomics) + projection backward.  Autograd path only: the fused loop gathers inside `k_rigid_bwd` (`hm_rigid_bwd_sil`) | HBM | B·(F·24·2 + V·24) = 5.4 MB |
+| `k_rigid_fwd/bwd` | forward: thread / vertex; backward: grid (frame, 256-vertex chunk), sums up to four weighted per-vertex gradient terms + a per-frame vector + optionally the silhouette gradient gathered from the sweeps' per-corner output (no gather / linear-combination launches), 13 block sums behind two barriers, per-frame ticket, rot6d backward by the finishing workgroup | latency | ≤ 4·B·V·12 |
+| `k_mano_fwd`, `k_mano_bwd` | forward: (13 vertex chunks × ⌈B/4⌉) blocks, a workgroup = one chunk of 64 vertices for FOUR consecutive frames, wave f owning frame f: four chains prepared side by side, then every wave streams its 37 rows of the blend matrix `M` ONCE and accumulates them for all four frames (the 1.35 MB matrix crosses L2 once per four frames: a 240-frame batch used to pull 324 MB through L2 per launch), wave f finishes frame f (partials, skinning, rigid transform, state); per frame the arithmetic and its order are unchanged, so frame grouping is invisible in the results.  Backward: (13 × B) blocks; kinematic tree staged in LDS, chain level-parallel; `M` rows streamed coalesced with all of a wave's rows requested before the first is reduced; rigid hand transform fused into the forward epilogue; the forward keeps the chain state + posed vertices for the backward; backward = ONE launch: chunk partials, then the frame's last workgroup (per-frame ticket) runs the chain / Rodrigues / PCA backward with the prior folded in | L2 / latency | 2·C_mano + 2·B·778·12 |
+| `k_hand_terms` | 2-D reprojection + temporal smoothness + priors of the hand in one launch, one ticket | latency | ≈ 1.5 MB |
+| **`k_pair_terms`** (`csrc/pairterms.hip`) | one clip: the terms that start from the two vertex buffers and feed nothing to each other as BLOCK RANGES of one grid - [search \| interaction \| hand terms \| object smoothness] - each with its own reduce workspace and ticket; the search is the metric-only one on the step-1 sets and the FULL one (`nn_full_body`, the body of `k_nn`, with the contact launches behind it) when the contact term is on (cfg3: 214 → 202 µs per iteration).  The bodies are shared with the stand-alone kernels (`pair_bodies.h`: device functions on virtual block coordinates), so the floats are the same either way (`test_pair_terms_launch_equals_its_four_entry_points`, and every batched == single test: batches use the stand-alone launches).  Four launches and three graph edges of the hand-side chain become one: 5100 → 5430 it/s | latency | ≈ 2 MB |
+| `k_smooth`, `k_inter`, `k_contact_hand` | grid-stride + "last block finishes" ticket | latency | 10–100 KB |
+| `k_nn` | (contact term on) 128 hand vertices (2 / lane) × 4 waves splitting the object vertices; 64-vertex groups broadcast with `v_readlane` (SGPR operands) | VALU | B·(778+V)·12 |
+| `k_nn_min` | (step-1 sets: the search only feeds the logged hand-object distance) bounding spheres of 64-vertex groups of the Morton-ordered rigid mesh, carried from a mesh-space table into the frame; per group a lower bound for the workgroup's 128 hand vertices (nearest centre distance − radius); the four groups with the smallest bounds are scanned first, one per wave, and their exact minimum is the upper bound - with "centre distance + radius" 21.5 of the 24 groups of the bottle passed when the hand touches it, now 5.6 do; scans run four object vertices per trip on scalar trip counts with the minima kept as integer bits (a wave is alone on its SIMD: the independent chains hide the arithmetic latency); the result is the same float as `k_nn`'s.  42 → 24 µs stand-alone, and this launch range was the longest link of the hand-side chain | latency | B·(778+V)·12 |
+| `k_contact_obj` | block / frame: hand-vertex gradients added into an LDS accumulator with 64-bit **fixed-point** atomics (order-independent ⇒ deterministic without a sort; the picks are skewed onto a few object vertices) | LDS | B·(778·16 + V·12) |
+| `k_sdf_boxes`, `k_sdf_tris`, `k_sdf_need`, `k_sdf_dist`, `k_sdf_sample` | AABB + normalise; thread / triangle: packed record + +x ray parity of the few (y,z) rows under the triangle (`atomicXor` of 32-bit inside masks); thread / sample: marks touched inside voxels, first setter appends to the grid's list; workgroup / listed voxel: nearest-vertex seed + box-pruned scan of the packed triangles (a single wave was ~70 dependent round trips for one voxel); thread / sample: trilinear value + gradient, ticket reduction | latency | ≈ B·(778+V)·36 + 8.7 MB |
+| `k_depth_bwd_faces`, `k_depth_bwd_gather` (a19) | wave / (frame, face): strides the face's sample box, tests ownership in the index map, reduces the three sums `A_k = Σ g·zp²·w_k` the NMR depth backward factors through (DPP); thread / vertex gather + projection backward | HBM (index-map reads) | B·(512²·4·ρ + S²·4 + F·(44+72)) (ρ ≈ box overlap) |
+| `k_ordinal_depth`, `k_ordinal_depth_bwd` (a19) | block / frame partial sums (pairs, mask counts, softplus sums) + last-block finish; element-wise backward | HBM | B·S²·(4·4+2) fwd, + B·S²·8 bwd |
+| `k_adam` | one launch for all tensors (pointer table), bias corrections in double, zeroes grads; the last workgroup (ticket) bumps the device step counter.  One clip: an extra grid row writes the log row of the step being taken (weighted total + every loss / metric slot) before it draws its tickets (`hm_adam_step_log` = `hm_log_total_clips` + `hm_adam_step`, same floats, one launch less on the tail) | latency | 28·79·B |
+
+Whole iteration (SURVEY §8d byte model): 144.1 MB (cfg2), 161.8 MB (cfg3).
+
+CDNA4 specifics used: wave64 ballots for binning / compaction; **flattening of heavy-tailed per-item work over the
+wave or workgroup** (DPP `row_shr` / `row_bcast` inclusive scans, then an LDS binary search or a scatter + DPP max-scan
+to map work back to its owner) in both heavy kernels, at two levels in the sweep (items over the waves of the whole grid,
+pairs over the lanes of a wave) — faces are ~50 samples and sweep items ~5 sources on average but hundreds at the tail,
+lane-serial loops left > 90 % of the lanes idle and a wave per face left the grid waiting for its largest face;
+commutativity instead of ordering (a value cut in two is added with two hardware float atomics onto zero: 0 + a + b is
+the same float in either order); `ds_min_u64` z-buffer in LDS; `v_readlane` → SGPR broadcast; DPP wave reductions (always at wave-uniform points:
+a lane that has left a loop feeds them stale registers); single-launch grid reductions whose partial records travel as
+agent-scope (sc1) stores / loads instead of release / acquire fences (a release fence writes back the whole L2 of the
+XCD — expensive next to a kernel that is filling it); per-bin tickets instead of one ticket word for 7680 workgroups
+(same-address returning atomics serialise: +43 µs measured); order-independent integer / XOR / min atomics wherever a
+scatter would otherwise need a sort to stay deterministic; `s_setprio` on the latency-bound kernels (a lone young wave
+next to four issue-bound persistent sweep waves got ~1/5 of the SIMD's issue slots: the hand-side kernels ran 2–5× longer
+whenever they overlapped the sweep); hipGraph replay of the whole iteration (forward + backward +
+Adam + logging, no host sync) on three captured streams.
+
+Stream structure of the fused loop (`FusedStepper`): A (face setup incl. the object's rigid transform and the camera-space
+vertices → raster → lines [+ loss reduction] → sweeps → object pose gradients incl. the silhouette gather), B (MANO + hand
+transform → pair terms → hand + MANO backward); B forks off A right after the face setup (`hm_sil_fwd_phase_clips`: the
+camera-space vertices are complete there, the raster keeps ONE successor); join → Adam + log row.  A clip batch adds C (the
+silhouette reduction + log rows on a third stream: +1.5 % there, while at one clip two streams are 5-6 % faster - same-box
+A/B).  HIP-runtime and hardware facts that shaped it (all measured):
+* stream capture crashes when two captured side streams wait for each other's events (a third branch for search + contact
+  next to the collision term dies at replay), and torch hands streams out of a pool of 32 - a process that builds many
+  steppers eventually draws a "side" stream that IS its capture stream - so all steppers share one verified set of distinct
+  streams (`_loop_streams`) and parallelism inside a chain comes from multi-term LAUNCHES, not from more streams;
+* consecutive kernels of one queue follow each other without a gap; every cross-queue edge costs 5-10 µs.  At one clip the
+  iteration is two chains of short latency-bound launches of about equal length: shortening one alone changes nothing
+  (loss reduction folded into the lines launch: ±0; fork after the setup: ±0), shortening both does (pair terms −12 µs,
+  log row in Adam −5 µs, then the fork +3 %);
+* what looked like the graph executor "serialising" richer fork patterns is mostly RESOURCE STARVATION: six rasteriser
+  workgroups fill a CU's LDS (149 of 160 KB) and registers (480 of 512 per lane), so a kernel of the other stream that
+  needs 72 registers (MANO forward) is not scheduled until the rasteriser's workgroups drain - whether it runs under the
+  raster or after it depends on which of the two root nodes the command processor happened to start first.  8 KB of LDS
+  ballast on the raster (4 workgroups / CU, `hm_tune_raster_lds_pad`) buys +3.5 % where the hand-side chain is the long
+  one (cfg3, one clip) and costs 5 % where it is not (cfg2) - applied like the sweep's workgroup count, per loss set.
+
+## 5. Measured (MI355X, round 3; evidence under `profiles/r03_*`, regenerated by `tools/profile_round.sh r03`)
+
+`python bench.py` = the driver's command: cfg2, 400 steps after 20 warm-up, then - same process, same fit, same hipGraph -
+a `steady_state` leg (iteration ≥ 400, 2000 timed iterations, 0.33 s) so that ONE line carries both regimes whatever
+`--steps / --warmup` the driver passes.
+
+| Quantity | Value |
+|---|---|
+| cfg2 (1 clip, 30 frames 256², bottle 3000 faces, step-1 losses), headline | **@CFG2@ it/s** (@CFG2MS@ ms / iteration); `steady_state` **@STEADY@ it/s** |
+| the same with the driver's round-1 flags `--steps 20 --warmup 5` (iterations 5-25 of a fresh fit: 5-10 M sweep pairs instead of 1.4 M) | @DRV@ it/s headline, @DRVSTEADY@ it/s in its `steady_state` leg |
+| cfg2 as BASELINE.json words it, with the ordinal depth term (`--depth`) | @DEPTH@ it/s |
+| cfg3 (step-2: + collision + contact) | **@CFG3@ it/s** |
+| cfg4 in miniature: 8 clips per GPU as ONE clip batch (`multi_clip`) | **@MULTI@ it/s** summed = @MULTIX@ × one clip; whole-iteration roofline fraction @MULTIF@ |
+| cfg5 on one rank (8 clips, step-2, one tied scale, RCCL call issued) | @CFG5@ it/s |
+| 2 ranks on ONE GPU through gloo (the driver's `torch.distributed.run` line; weak scaling has nothing to scale on one GPU - this is the N > 1 code path, not a speed-up) | cfg2: @G2@ it/s summed; cfg5 (2 x 4 clips, tied scale): @G5@ it/s, replicas identical |
+| CPU baseline (oracle loop, 64 host threads) | @CPU@ it/s with the reference's per-step `.item()` logging, @CPUOFF@ it/s without → GPU / CPU ≈ @RATIO@ × (target ≥ 50 ×) |
+| whole iteration vs the SURVEY §8d byte model (144.1 MB) | @WHOLE@ of 8 TB/s at one clip |
+
+**Roofline of the heavy kernels, inside the replayed graph** (ROCm allows no timing events inside graphs, so every
+workgroup of the three kernels stores `s_memrealtime` at entry and exit, `hm_sil_timestamps`; `bench.py` replays THE SAME
+graph 50 more times and averages; `rocprofv3 --kernel-trace --stats` of the same command, `profiles/r03_p_cfg2_headline_kernel_stats.txt`,
+agrees to a few per cent, see the note in EXPERIMENTS.md on what the profiler itself moves):
+
+| kernel (cfg2, steady state) | µs / launch | algorithmic MB | GB/s | frac of 8 TB/s | PMC traffic MB | VALU wave-instr | valu_frac (4-cycle / 2-cycle) |
+|---|---|---|---|---|---|---|---|
+| `k_raster_fwd` | @RAS@ | 72.2 | @RASG@ | @RASF@ | @RAST@ | @RASV@ | @RASVF@ |
+| `k_bwd_sweep` (`roofline.kernel`: the longest launch) | @SWP@ | 47.6 | @SWPG@ | @SWPF@ | @SWPT@ | @SWPV@ | @SWPVF@ |
+| `k_bwd_lines` | @LIN@ | 23.8 | @LING@ | @LINF@ | @LINT@ | @LINV@ | @LINVF@ |
+
+`valu_frac` = `SQ_INSTS_VALU` ÷ (launch time × 1024 SIMDs × 2.4 GHz ÷ 4).  The 4: a wave64 VALU instruction runs on a
+SIMD16 as four passes of 16 lanes, and the counters say so - `SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU` = 1.02 quad-cycles
+(= 4.1 cycles) per instruction for all three kernels (`quad_cycles_per_valu_instr` in the bench line).  The micro-architecture
+guide's "wave scheduling" section quotes 2 cycles - the rate of dual-issued / packed fp32, which this integer- and
+compare-heavy code rarely reaches (`v_pk_*` are 3 % of the raster's instructions); the bench line carries the same count
+against that peak as `valu_frac_2cyc` (half the value).  Either way the reading is the same: traffic is AT the byte model
+(the kernels are not HBM-bound), and they issue VALU on one third to two thirds of all SIMD cycles; the rest is dependent
+loads (7-8 global round trips per raster workgroup) and LDS.
+
+**What bounds the iteration** (EXPERIMENTS.md, round 3).  The silhouette chain is serial and it IS the iteration: setup 12 +
+raster 45 + lines 26 + sweeps 46 + object gradients 16 + Adam 4 µs + ≈17 µs of graph edges = 165 µs; the hand side (MANO,
+pair terms, hand gradients) runs under it - removing the MANO backward altogether buys +1.5 %.  The three heavy kernels are
+within 1.5-3 × of the VALU roof on work whose size the algorithm sets (2.07 M covered (face, sample) pairs, 1.95 M sweep
+items of which 29 % have a source in reach, 1.4 M (item, source) pairs), so what is left is instruction count per item;
+this round's two attempts at it for the raster - box-anchored blocks (−11 % units, not worth the rewrite) and far-class
+candidates dropped before their records (80 % fewer records, kernel +5 %: a record pass costs its wave the same whether 6 or
+31 lanes are live) - did not pay, and the verdict's kernel targets (raster ≤ 38, sweep ≤ 38, lines ≤ 18 µs) are NOT met.
+
+## 6. Multi-GPU
+
+The path shards by clip with no data-path collective (cfg4).  One process per GPU; `dist.shard_clips` deals contiguous,
+balanced blocks of clips to the ranks (64 clips / 8 GPUs = 8 each; 9 / 8 = 2,1,1,...), and each rank optimises ITS clips
+through `dist.optimize_clip_shard(models, ...)` → `ShardStepper`: clips that agree in shape (frames, object topology, hands,
+sizes) form ONE clip batch - every kernel launched once per iteration over all of them, one Adam state per clip - and the
+batches of different shapes (a real Core50 shard: every clip its own object mesh, `homan/datasets/core50.py:22-42`, and its
+own length, `fit_vid_dataset.py:190`) follow each other inside every iteration, each replayed from its own hipGraph.  Every
+clip ends up with exactly the result of optimising it alone, bit for bit (`tests/test_clip_batch_gpu.py`).  What is NOT
+built: one launch per kernel over clips of DIFFERENT shapes (per-clip CSR offsets in every `hm_*_clips` kernel).
+
+cfg5 ties ONE object scale across all clips of all ranks (an extension; the reference's scale is per clip,
+`homan/homan.py:121-130`).  The tied loss is the sum of the clips' losses, so the scalar's gradient is the sum of the clips'
+gradients (each with its own scale prior).  Every clip keeps a replica; per step: per-clip gradients, the sum over the rank's
+clips, ONE all-reduce (sum) of 1 fp32 over RCCL/xGMI issued on the compute stream between the two captured halves of the
+iteration (no host synchronisation), the global sum written to every replica, identical Adam steps - replicas stay
+bit-identical.  `ShardStepper` issues exactly one broadcast at the start and one all-reduce per step whatever the rank's
+number of shape groups (also zero: a rank without clips), so uneven shards cannot desynchronise the ranks.  4-byte message ⇒
+latency-bound; link bandwidth and ring-vs-tree are irrelevant.  Where the tied scalar GOES is the objective's doing: in the
+cfg5 bench run it grows 1 → 2.65 over 400 steps - with the object's depth free, scale and depth trade off along a valley of
+the silhouette term, the contact term (mean tanh of the distance from every hand vertex to the NEAREST object vertex) falls
+when the object's surface comes closer to the hand, the prior's weight is 1e-3, and Adam moves a parameter whose gradient
+keeps its sign by ~lr per step; the CPU oracle driven through the same tied loop takes the same path
+(`test_tied_scale_trajectory_matches_the_cpu_oracle_loop`).
+
+**N > 1 on hardware.**  No multi-GPU node is available to this build; the scaling curve is the driver's to measure.  What IS
+exercised on the one GPU: 2 and 3 processes sharing `cuda:0` under `gloo` (device tensors staged through the host there,
+`dist._staged`; under nccl = RCCL the collective runs on the device tensor) run `dist.optimize_clip_shard` - the fused
+launch sequence, two hipGraphs around the collective - on even, uneven ([2,1]) and empty ([1,1,0]) shards: replicas
+bit-identical across ranks, 2 ranks × 1 clip bit-identical to one 2-clip batch, un-tied shards bit-identical to solo runs
+(`tests/test_dist_gpu.py`); cfg5 itself at full size (8 × 30 × 256², step-2, tied scale, one-rank nccl group);
+`bench.py --gpus 2` lines under `profiles/r03_bench_*_gpus2_gloo.json`.
+
+### Two hands, left hands (`hand_nb = 2`, `hand_sides = ["right", "left"]`)
+
+`homan/homan.py:62-63,341-358`: hands arrive interleaved frame-major `[h0_t0, h1_t0, h0_t1, ...]`; hand `i` is the strided
+slice `i::hand_nb` of every MANO parameter, evaluated by the MANO layer of ITS side and re-interleaved.
+* left MANO (`manomodel.py:124-140`): the left model's PCA basis with the y / z components of every joint's axis-angle
+  negated before the mean pose is added - folded into the left `ManoContext`'s basis, so one kernel serves both sides.
+  `MANO_LEFT.pkl` is read when present; next to the synthetic right hand the left model is its mirror image.
+* fused loop: the MANO launches walk their hand's rows in place (`hm_mano_*_rows`), the hand-only terms and the rigid
+  backward run once over all rows (the kernels' `hand_nb`), the pair-wise terms see each hand as a dense copy: contact = mean
+  over the hands (`lossutils.py:116-127`), interaction = their sum, logged distance = largest per-frame distance to the
+  NEAREST hand (`losses.py:207-241`), collision (`lossutils.py:51-59`) = the scene `[hand 0, hand 1, object]` with both hands'
+  closed topology in reversed winding, as three two-mesh launches (every mesh's SDF depends on its own vertices only and the
+  loss is a sum over ordered pairs, `scenesdf.py:131-146`).
+Parity: `tests/golden/ref_step{1,2}_twohands_cube_b4_s64.npz` and `ref_step1_lefthand_cube_b4_s64.npz` come from the
+reference's own `HOMan` / `jointopt` at `hand_nb = 2` and with a lone left hand; oracle, HIP model and fused loop are pinned
+against them like against the single-hand goldens.
+
+## 7. Out of scope (and why)
+
+Evidence extraction (detectron2 / FrankMocap networks), datasets, tracking, dataset-level evaluation (chamfer / ADD-S on
+ground truth, codalab dumps), html / video export: SURVEY §8 marks them out of the hot path and their inputs (weights,
+data) are not available.  `hand_proj_mode="ortho"` (`homan/utils/camera.py:59-105`) converts its weak-perspective camera with
+`libyana.camutils.camconvs.batch_weakcam2persptrans`, a third-party function that is neither in `/root/reference` nor pinned
+anywhere: unbuildable as a parity claim, it raises `NotImplementedError`; `contact_mode≠dist_tanh`: non-default branches of a
+file the reference never reaches.  More than two hands: the reference's own collision term de-interleaves with a stride of 2
+(`lossutils.py:58`).  `assign_human_masks` (`homan.py:239-296`): never called by the reference.
+
+## 8. Known gaps / next (ranked)
+
+1. Kernel targets of the last verdict (raster ≤ 38, sweep ≤ 38, lines ≤ 18 µs in the graph; driver-flag line ≥ 5500,
+   8-clip batch ≥ 9500 it/s) are not met: 45 / 46 / 26 µs, 4 770 and 8 600 it/s.  What the round's counters say is left:
+   the raster spends 7-8 dependent global round trips per workgroup (a 16-byte `{face, box}` bin entry and vertices staged
+   by the scanning thread would remove two of them) and ~2.6 VALU issue slots + a VCC hazard per inside test; the sweep's
+   stage 1 costs ~250 instructions per 64 items, 71 % of which it rejects (a per-(face, family) reject before the items
+   are enumerated would cut that two- to three-fold); the line expansion takes 2.2 × its stand-alone time in an 8-clip batch
+   because latency-bound neighbours hold its wave slots.  All three need restructuring, not tuning.
+2. One launch per kernel over clips of DIFFERENT shapes (today: shape groups of a shard in sequence, section 6).
+3. The ordinal depth term in a clip batch and with two hands; `inter_type="min"` in a batch or with two hands (graph loop).
+4. Bit-equal HAND vertices (the object's are): needs the oracle's LBS written out in the kernel's summation order and a
+   shared sin / cos; it would take `loss_collision`'s per-step error from 1e-4 to 1e-7 like the other terms.
+5. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.

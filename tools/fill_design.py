@@ -1,0 +1,54 @@
+"""Fills the measured numbers of tools/DESIGN.tpl (section 5) from the round's bench lines under profiles/ -> DESIGN.md.
+usage: python tools/fill_design.py [r03]"""
+import json
+import os
+import sys
+
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+
+
+def load(name):
+    p = os.path.join(R, "profiles", name)
+    if not os.path.exists(p):
+        return None
+    for line in open(p):
+        if line.startswith("{"):
+            return json.loads(line)
+    return None
+
+
+def main(tag="r03"):
+    t = open(os.path.join(R, "tools", "DESIGN.tpl")).read()
+    d = load(f"{tag}_bench_cfg2.json")
+    drv = load(f"{tag}_bench_cfg2_driver_flags.json")
+    c3, c5, dep = load(f"{tag}_bench_cfg3.json"), load(f"{tag}_bench_cfg5_n1.json"), load(f"{tag}_bench_cfg2_depth.json")
+    g2, g5 = load(f"{tag}_bench_cfg2_gpus2_gloo.json"), load(f"{tag}_bench_cfg5_gpus2_gloo.json")
+    f0 = lambda v: "n/a" if v is None else f"{v:,.0f}".replace(",", " ")
+    rep = {"@CFG2@": f0(d["value"]), "@CFG2MS@": f"{d['ms_per_step']:.3f}", "@STEADY@": f0(d["steady_state"]["value"]),
+           "@DRV@": f0(drv and drv["value"]), "@DRVSTEADY@": f0(drv and drv["steady_state"] and drv["steady_state"]["value"]),
+           "@DEPTH@": f0(dep and dep["value"]), "@CFG3@": f0(c3 and c3["value"]),
+           "@MULTI@": f0(d["multi_clip"]["value"]), "@MULTIX@": f"{d['multi_clip']['vs_single_clip']:.2f}",
+           "@MULTIF@": f"{d['multi_clip']['roofline']['frac']:.3f}", "@CFG5@": f0(c5 and c5["value"]),
+           "@G2@": f0(g2 and g2["value"]), "@G5@": f0(g5 and g5["value"]),
+           "@CPU@": f"{d['cpu_baseline']['value']:.2f}", "@CPUOFF@": f"{d['cpu_baseline']['value_logging_off']:.2f}",
+           "@RATIO@": f0(d["steady_state"]["value"] / d["cpu_baseline"]["value"]),
+           "@WHOLE@": f"{100 * d['steady_state']['roofline']['whole_iteration']['frac']:.1f} %"}
+    ks = d["steady_state"]["roofline"]["kernels"]
+    for key, name in (("RAS", "k_raster_fwd"), ("SWP", "k_bwd_sweep"), ("LIN", "k_bwd_lines")):
+        k = ks[name]
+        rep[f"@{key}@"] = f"{k['avg_launch_us']:.1f}"
+        rep[f"@{key}G@"] = f"{k['achieved_GBps']:.0f}"
+        rep[f"@{key}F@"] = f"**{k['achieved_GBps'] / 8000:.3f}**"
+        rep[f"@{key}T@"] = f"{k['traffic_bytes'] / 1e6:.1f}" if k.get("traffic_bytes") else "n/a"
+        rep[f"@{key}V@"] = f"{k['valu_wave_instr'] / 1e6:.1f} M" if k.get("valu_wave_instr") else "n/a"
+        rep[f"@{key}VF@"] = f"{k['valu_frac']:.2f} / {k['valu_frac_2cyc']:.2f}" if k.get("valu_frac") else "n/a"
+    for a, b in rep.items():
+        t = t.replace(a, b)
+    left = [w for w in t.split() if w.startswith("@") and w.endswith("@")]
+    assert not left, left
+    open(os.path.join(R, "DESIGN.md"), "w").write(t)
+    print("DESIGN.md written,", len(t.split("\n")), "lines")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])
