@@ -29,6 +29,40 @@
 #define RASTER_WAVES 4     // tiles per workgroup
 #define STAGE_DW 20        // dwords per staged face in LDS (9 verts + 9 inverse + id + pad)
 
+// output stores of the rasteriser's epilogue: -DRASTER_NT_STORES=1 makes them non-temporal (streamed past the L2: an A/B knob
+// for the few microseconds of cache write-back between this launch and the next one of its chain)
+typedef int hm_v2i __attribute__((ext_vector_type(2)));
+typedef unsigned hm_v4u __attribute__((ext_vector_type(4)));
+#ifndef RASTER_NT_STORES
+#define RASTER_NT_STORES 0
+#endif
+__device__ __forceinline__ void hm_out_store(float* p, float v)
+{
+#if RASTER_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+__device__ __forceinline__ void hm_out_store2(int* p, int a, int b)
+{
+#if RASTER_NT_STORES
+    hm_v2i v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<hm_v2i*>(p));
+#else
+    *reinterpret_cast<int2*>(p) = make_int2(a, b);
+#endif
+}
+__device__ __forceinline__ void hm_out_store4(unsigned short* p, unsigned a, unsigned b, unsigned c, unsigned d)
+{
+#if RASTER_NT_STORES
+    hm_v4u v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<hm_v4u*>(p));
+#else
+    *reinterpret_cast<uint4*>(p) = make_uint4(a, b, c, d);
+#endif
+}
+
 struct FaceBox {           // 8 bytes per face: sample-space box + winding mask in x0[15:14]
     unsigned short x0m, y0, x1, y1;
 };
@@ -291,8 +325,7 @@ __device__ __forceinline__ void emit_planes(const Ballots4 cov, const Ballots4 n
     const unsigned q2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p2, 0x102, 0xf, 0xf, false);      // row_shl:2 : words 2,3
     const unsigned r2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)p2, 0x104, 0xf, 0xf, false);      // row_shl:4 : words 4,5
     const unsigned s2 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)q2, 0x104, 0xf, 0xf, false);      // row_shl:4 : words 6,7
-    if ((lane & 7) == 0)
-        *reinterpret_cast<uint4*>(planes + hm_plane_at(b, ty, tx, 0, is / 16) + lane) = make_uint4(p2, q2, r2, s2);
+    if ((lane & 7) == 0) hm_out_store4(planes + hm_plane_at(b, ty, tx, 0, is / 16) + lane, p2, q2, r2, s2);
 }
 
 // ---------------------------------------------------------------- forward raster
@@ -757,8 +790,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     int* im = idx_map + (long)b * is * is;
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
-        int2 v2 = make_int2(imin[2 * dy], imin[2 * dy + 1]);
-        *reinterpret_cast<int2*>(im + (long)(yi0 - dy) * is + xi0) = v2;
+        hm_out_store2(im + (long)(yi0 - dy) * is + xi0, imin[2 * dy], imin[2 * dy + 1]);
     }
     // faces that own a sample (benign same-value races).  One-byte stores are partial-line writes that never merge
     // across the XCDs' L2s, so a sample is flagged only by the first lane of its run: not if the same face owns the
@@ -784,7 +816,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     const int cnt = (imin[0] >= 0) + (imin[1] >= 0) + (imin[2] >= 0) + (imin[3] >= 0);
     const float pool = 0.25f * (float)cnt;
     const long po = ((long)b * S + r) * S + c;
-    pooled[po] = pool;
+    hm_out_store(pooled + po, pool);
     // anti_aliasing=False rendering: the silhouette is the sample grid itself (flipped), no pooling
     if (alpha_full) {
 #pragma unroll
@@ -827,7 +859,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
         const float kp = keep[pm], rf = ref[pm];      // (requesting them at kernel start was measured: no gain, +3 registers)
         const float image = kp * pool;
         const float diff = image - rf;
-        dimg[po] = kp * diff;
+        hm_out_store(dimg + po, kp * diff);
         // sweep planes of the backward for a positive upstream gradient (sign(g) = sign(dimg)), see k_bwd_masks
         {
             const unsigned long long nb1 = __ballot(kp * diff < 0.0f), pb1 = __ballot(kp * diff > 0.0f);
