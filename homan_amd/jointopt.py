@@ -288,9 +288,6 @@ class FusedStepper:
                 # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() without its arguments
                 raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
                                 "'masks', 'silhouettes', and 'depths'")
-            if m.C > 1:
-                raise NotImplementedError("the ordinal depth term normalises over one clip: the fused loop covers it for one "
-                                          "clip at a time (a clip batch: mode='graph' per clip)")
         self.shared_scale, self.group = bool(shared_scale), group
         # collectives=False: the caller (ShardStepper: several steppers of one rank) issues the broadcast / all-reduce of the
         # tied scale itself - every rank must issue the same number of collectives whatever its number of steppers
@@ -398,14 +395,27 @@ class FusedStepper:
         if self.on["depth"]:
             # ordinal depth term (reference homan.py:384-419, opt-in): object and hand rendered with depth at the full-image
             # camera, the pair-wise ordinal loss, and its gradient back through both depth images to the camera-space vertices
-            self.dctx = m.models[0].depth_contexts()
+            if C == 1:
+                self.dctx = m.models[0].depth_contexts()
+            else:
+                # a clip batch: the two depth renders run over all frames at once, the ordinal term (it normalises over ONE
+                # clip: pairs, mask counts) per clip on its slice of the images
+                m0_, size = m.models[0], int(m.image_size)
+                for one in m.models:
+                    if tuple(one.masks_object.shape[1:]) != (size, size) or tuple(one.masks_human.shape[1:]) != (size, size):
+                        raise NotImplementedError("ordinal depth: instance masks must be (B, image_size, image_size)")
+                self.dctx = (ops.SilhouetteContext(m0_.faces_object[:1].expand(B, -1, -1), Vo, B, size, dev),
+                             ops.SilhouetteContext(m0_.faces_hand[:1].expand(B, -1, -1), 778, B, size, dev),
+                             torch.cat([(one.masks_object != 0).to(torch.uint8) for one in m.models]).contiguous(),
+                             torch.cat([(one.masks_human != 0).to(torch.uint8) for one in m.models]).contiguous())
             ctx_o, ctx_h = self.dctx[0], self.dctx[1]
             if ctx_o.padded:
                 raise NotImplementedError("the fused loop renders the depth images at image_size % 32 == 0; other sizes: "
                                           "mode='graph' or 'eager'")
             Sd = ctx_o.S
             self.d_sil_o, self.d_dep_o, self.d_sil_h, self.d_dep_h = f(B, Sd, Sd), f(B, Sd, Sd), f(B, Sd, Sd), f(B, Sd, Sd)
-            self.d_go, self.d_gh, self.d_part, self.d_rec = f(B, Sd, Sd), f(B, Sd, Sd), f(B * 8), f(5)
+            self.d_go, self.d_gh, self.d_part, self.d_rec = f(B, Sd, Sd), f(B, Sd, Sd), f(B * 8), f(C, 8)
+            self.rws_depth = ClipReduceWorkspace(dev, C)
             self.G_dep_o, self.G_dep_h = f(B, Vo, 3), f(B, Vh, 3)
             self.up_depth = torch.tensor([w["loss_depth"]], device=dev)
         # static gradient buffers for exactly the parameters that receive gradients in this configuration
@@ -757,10 +767,16 @@ class FusedStepper:
                     ck(L.hm_sil_fwd(P(verts), P(ctx.faces), 0, K, B, V_, ctx.F, Sd, 1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR,
                                     None, None, None, P(sil), None, P(ctx.work_order), P(dep), None, 0, None, None, None, 0, 0,
                                     P(ctx.workspace), sb2), "depth render")
-                ck(L.hm_ordinal_depth_fwd(P(self.d_dep_o), P(self.d_dep_h), P(self.d_sil_o), P(self.d_sil_h), P(m_o), P(m_h), B,
-                                          Sd, P(self.d_part), P(self.d_rec), self._slot("loss_depth"), rws_b, sb2), "ordinal depth")
-                ck(L.hm_ordinal_depth_bwd(P(self.d_dep_o), P(self.d_dep_h), P(self.d_sil_o), P(self.d_sil_h), P(m_o), P(m_h), B,
-                                          Sd, P(self.d_rec), P(self.up_depth), P(self.d_go), P(self.d_gh), sb2), "ordinal depth bwd")
+                rw_bytes = L.hm_reduce_workspace_bytes()
+                for ci in range(C):           # per clip: the term normalises over the clip's own pairs and mask counts
+                    fr = slice(ci * CL, (ci + 1) * CL)
+                    args = (P(self.d_dep_o[fr]), P(self.d_dep_h[fr]), P(self.d_sil_o[fr]), P(self.d_sil_h[fr]), P(m_o[fr]),
+                            P(m_h[fr]), CL, Sd)
+                    ck(L.hm_ordinal_depth_fwd(*args, P(self.d_part[8 * ci * CL:]), P(self.d_rec[ci]),
+                                              self._slot("loss_depth") + 4 * NS * ci,
+                                              self.rws_depth.buf.data_ptr() + rw_bytes * ci, sb2), "ordinal depth")
+                    ck(L.hm_ordinal_depth_bwd(*args, P(self.d_rec[ci]), P(self.up_depth), P(self.d_go[fr]), P(self.d_gh[fr]),
+                                              sb2), "ordinal depth bwd")
                 for verts, ctx, V_, g, G in ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o),
                                              (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h)):
                     ck(L.hm_depth_bwd(P(verts), K, B, V_, ctx.F, Sd, 1.0, P(g), P(ctx.adj_off), P(ctx.adj_items), P(G),

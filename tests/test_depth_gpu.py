@@ -183,3 +183,40 @@ def test_fused_loop_covers_the_ordinal_depth_term(mano_model):
     st2.run(20)
     evo = st2.loss_evolution(20)
     assert sorted(evo) == ["loss", "loss_depth"] and evo["loss_depth"][-1] < evo["loss_depth"][0]
+
+
+def test_depth_term_in_a_clip_batch_equals_solo_runs_bitwise(mano_model):
+    """The ordinal depth term normalises over ONE clip (pairs, mask counts): in a clip batch the two depth renders run over
+    all frames at once and the term per clip on its slice - rows and parameters bit-identical to optimising the clips alone."""
+    from homan_amd import HOMan, synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle.jointopt import collate_inputs
+    size, steps = 64, 5
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS, lw_depth=2.0)
+
+    def make(seed):
+        clip = synth.make_clip(seed=seed, frames=4, rend_size=size, image_size=size, obj="cube", silhouette_fn=sil_fn,
+                               hand_verts_fn=hand_fn)
+        for pp, op in zip(clip["person_parameters"], clip["object_parameters"]):
+            op["full_mask"] = ((pp["masks"][0] > 0) | (op["full_mask"] > 0)).float()
+            pp["masks"] = torch.zeros_like(pp["masks"])
+            pp["translations"] = pp["translations"] + torch.tensor([0.06, 0.0, -0.02])    # hand over the object
+        kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+        return HOMan(**kw, camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                     image_size=size, mano_model=mano_model, rend_size=size, sync_metrics=False, ordinal_depth=True)
+    solo = []
+    for seed in (5, 6):
+        m = make(seed)
+        st = FusedStepper(m, lw, 1e-2, steps)
+        st.run(steps)
+        solo.append((m, st.loss_evolution(steps)))
+        assert max(solo[-1][1]["loss_depth"]) > 0
+    batch = [make(5), make(6)]
+    sb = FusedStepper(batch, lw, 1e-2, steps)
+    sb.run(steps)
+    for (ms, es), mb, eb in zip(solo, batch, sb.loss_evolution(steps)):
+        for k in es:
+            np.testing.assert_array_equal(np.asarray(eb[k]), np.asarray(es[k]), err_msg=k)
+        for k in ("translations_object", "rotations_object", "translations_hand", "rotations_hand", "mano_pca_pose"):
+            assert torch.equal(getattr(ms, k).detach(), getattr(mb, k).detach()), k

@@ -44,7 +44,8 @@ def main(tag="r03"):
         rep[f"@{key}VF@"] = f"{k['valu_frac']:.2f} / {k['valu_frac_2cyc']:.2f}" if k.get("valu_frac") else "n/a"
     for a, b in rep.items():
         t = t.replace(a, b)
-    left = [w for w in t.split() if w.startswith("@") and w.endswith("@")]
+    import re
+    left = re.findall(r"@[A-Z0-9]+@", t)
     assert not left, left
     open(os.path.join(R, "DESIGN.md"), "w").write(t)
     print("DESIGN.md written,", len(t.split("\n")), "lines")
