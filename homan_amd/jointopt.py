@@ -302,6 +302,9 @@ class FusedStepper:
         # third stream for the silhouette reduction + log row: it pays on a clip batch (+1.5 %); at one clip the graph executor
         # spends two cross-queue hops (~10 us each) on it, and two streams are 5-6 % faster (same-box A/B, cfg2 and cfg3)
         self.use_aux = (os.environ.get("HOMAN_AUX") or ("1" if C > 1 else "0")) != "0"
+        if lw.get("lw_depth", 0) > 0:
+            self.use_aux = False         # (with the depth launches on the side stream the three-stream graph dies at replay in
+                                         #  the HIP runtime, like the other patterns listed at _loop_streams: two streams)
         # two streams, no shared scale: the log row of a step is written by the Adam launch itself (one launch less)
         self.log_in_adam = (not self.use_aux and not self.shared_scale and
                             os.environ.get("HOMAN_LOG_IN_ADAM", "1") != "0")
