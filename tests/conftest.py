@@ -16,3 +16,20 @@ def pytest_configure(config):
 def mano_model():
     from homan_amd.mano_assets import synthetic_mano
     return synthetic_mano(0)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_objects():
+    """hipGraphs, their private memory pools and the steppers' buffers go when the test's objects do: collect them right
+    after every test instead of whenever the cycle collector runs (a process that piles up several dozen captured graphs
+    has crashed inside the HIP runtime at a later replay)."""
+    yield
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    except ImportError:
+        pass

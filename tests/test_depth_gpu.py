@@ -1,5 +1,6 @@
 """Ordinal-depth row on the GPU: depth image, its backward, the loss and the model term vs the oracle."""
 import copy
+import os
 
 import numpy as np
 import pytest
@@ -89,7 +90,18 @@ def test_ordinal_depth_loss_matches_oracle(mano_model):
     assert got2.item() == got.item()
 
 
-def test_model_ordinal_depth_term_matches_oracle(mano_model):
+def _graph_depth_steps(rank, kw, common, lw, out):
+    import sys
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    from homan_amd import HOMan
+    from homan_amd.jointopt import GraphStepper
+    hm2 = HOMan(**copy.deepcopy(kw), ordinal_depth=True, **common)
+    st = GraphStepper(hm2, lw, 1e-2, 20)
+    st.run(20)
+    np.save(out, np.asarray(st.loss_evolution(20)["loss"]))
+
+
+def test_model_ordinal_depth_term_matches_oracle(mano_model, tmp_path):
     """HOMan(ordinal_depth=True) vs OracleHOMan(ordinal_depth=True): loss_depth and its parameter gradients;
     without the opt-in both reproduce the reference's TypeError (homan.py:506-507)."""
     from homan_amd import HOMan, synth
@@ -126,13 +138,14 @@ def test_model_ordinal_depth_term_matches_oracle(mano_model):
     for k in go:
         scale = max(go[k].abs().max().item(), 1e-12)
         np.testing.assert_allclose(gh[k].cpu().numpy() / scale, go[k].numpy() / scale, atol=1e-3, err_msg=k)
-    # a few optimisation steps on the depth term alone reduce it (graph loop; fresh model: the autograd graph kept
-    # alive above belongs to the default stream and cannot be replayed inside a capture)
-    from homan_amd.jointopt import GraphStepper
-    hm2 = HOMan(**copy.deepcopy(kw), ordinal_depth=True, **common)
-    st = GraphStepper(hm2, lw, 1e-2, 20)
-    st.run(20)
-    evo = st.loss_evolution(20)["loss"]
+    # a few optimisation steps on the depth term alone reduce it (graph loop over HOMan.forward + autograd).  In a process of
+    # its own: a captured autograd iteration with the depth renders in it, followed later IN THE SAME PROCESS by a
+    # three-stream clip-batch graph, has crashed inside the HIP graph runtime at that later replay (measured: this test +
+    # test_fused_loop_at_a_render_size_off_the_tile_grid, nothing else needed); neither graph is at fault on its own.
+    import torch.multiprocessing as mp
+    out = tmp_path / "evo.npy"
+    mp.spawn(_graph_depth_steps, args=(kw, common, lw, str(out)), nprocs=1, join=True)
+    evo = np.load(out)
     assert evo[-1] < evo[0]
 
 
