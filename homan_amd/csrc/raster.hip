@@ -2112,6 +2112,15 @@ __global__ void k_depth_bwd_gather(const float* __restrict__ gf9, const int* __r
 // reference homan/lossutils.py:133-169 as the method intends (the reference code itself cannot run: see DESIGN.md).
 // layers 0 = object, 1 = hand; d*/a* = pooled depth / alpha renders (B,S,S); m* = instance masks (B,S,S) uint8.
 // rec (5 floats): num_pairs, msum01, S01, msum10, S10.
+// grid (ORD_CHUNKS, B): a frame's pixels are split over ORD_CHUNKS workgroups (one workgroup per frame walked 256 pixels per
+// thread behind four to six dependent loads each: 95 us for 30 frames of 256^2, the longest launch of the depth term).  The
+// frame record (8 words of frame_part, ZERO on entry, re-zeroed by the finishing workgroup) collects the chunks with 64-bit
+// integer atomics - exact and order-independent, so the result does not depend on which chunk lands first:
+//   words 0-1  pixels of layer 0 | layer 1 << 21 | both << 42   (21 bits each: S <= 1024)
+//   words 2-3  pixels ordered wrongly: (annotated 0 in front) | (annotated 1 in front) << 32
+//   words 4-5 / 6-7  softplus sums of the two kinds, fixed point 2^-32 (a workgroup's own float sum, then integer adds)
+#define ORD_CHUNKS 16
+#define ORD_FIX 4294967296.0       // 2^32
 __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__ d0, const float* __restrict__ d1,
                                                         const float* __restrict__ a0, const float* __restrict__ a1,
                                                         const unsigned char* __restrict__ m0,
@@ -2121,10 +2130,12 @@ __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__
 {
     __shared__ float red[16];
     __shared__ int s_flag;
-    const int b = blockIdx.x;
+    __shared__ float s_t[5];
+    const int b = blockIdx.y;
     const long base = (long)b * S * S;
+    const int per = (S * S + ORD_CHUNKS - 1) / ORD_CHUNKS, i0 = blockIdx.x * per, i1 = min(S * S, i0 + per);
     float c00 = 0.f, c11 = 0.f, c01 = 0.f, ms01 = 0.f, s01 = 0.f, ms10 = 0.f, s10 = 0.f;
-    for (int i = threadIdx.x; i < S * S; i += blockDim.x) {
+    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
         const bool s0 = a0[base + i] == 1.0f, s1 = a1[base + i] == 1.0f;
         c00 += s0 ? 1.f : 0.f; c11 += s1 ? 1.f : 0.f;
         if (s0 && s1) {
@@ -2138,16 +2149,31 @@ __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__
     float v[7] = {c00, c11, c01, ms01, s01, ms10, s10};
 #pragma unroll
     for (int k = 0; k < 7; ++k) v[k] = hm_block_sum(v[k], red);
+    unsigned long long* fr = reinterpret_cast<unsigned long long*>(frame_part) + (long)b * 4;
     if (threadIdx.x == 0) {
-        float* o = frame_part + b * 8;
-        hm_partial_store(o, (v[0] > 0.f ? 1.f : 0.f) + (v[1] > 0.f ? 1.f : 0.f) + 2.f * (v[2] > 0.f ? 1.f : 0.f));   // pairs of this frame
-        hm_partial_store(o + 1, v[3]); hm_partial_store(o + 2, v[4]); hm_partial_store(o + 3, v[5]); hm_partial_store(o + 4, v[6]);
+        atomicAdd(fr, (unsigned long long)v[0] | ((unsigned long long)v[1] << 21) | ((unsigned long long)v[2] << 42));
+        atomicAdd(fr + 1, (unsigned long long)v[3] | ((unsigned long long)v[5] << 32));
+        atomicAdd(fr + 2, (unsigned long long)((double)v[4] * ORD_FIX));
+        atomicAdd(fr + 3, (unsigned long long)((double)v[6] * ORD_FIX));
     }
-    if (hm_last_block(counter, gridDim.x, &s_flag)) {
-        float t[5];
-#pragma unroll
-        for (int k = 0; k < 5; ++k) t[k] = hm_last_block_sum(frame_part + k, B, 8, red);
+    if (hm_last_block(counter, gridDim.x * gridDim.y, &s_flag)) {
+        // the frames in frame order (fixed), one thread: B is a clip's length
         if (threadIdx.x == 0) {
+            float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+            unsigned long long* all = reinterpret_cast<unsigned long long*>(frame_part);
+            for (int f = 0; f < B; ++f) {
+                const unsigned long long w0 = __hip_atomic_load(all + 4L * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w1 = __hip_atomic_load(all + 4L * f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w2 = __hip_atomic_load(all + 4L * f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w3 = __hip_atomic_load(all + 4L * f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const bool h0 = (w0 & 0x1fffffull) != 0ull, h1 = ((w0 >> 21) & 0x1fffffull) != 0ull, h01 = (w0 >> 42) != 0ull;
+                t[0] += (h0 ? 1.f : 0.f) + (h1 ? 1.f : 0.f) + 2.f * (h01 ? 1.f : 0.f);        // pairs of this frame
+                t[1] += (float)(unsigned)(w1 & 0xffffffffull);
+                t[2] += (float)((double)w2 / ORD_FIX);
+                t[3] += (float)(unsigned)(w1 >> 32);
+                t[4] += (float)((double)w3 / ORD_FIX);
+                all[4L * f] = 0ull; all[4L * f + 1] = 0ull; all[4L * f + 2] = 0ull; all[4L * f + 3] = 0ull;     // re-armed
+            }
             float loss = 0.f;
             if (t[1] > 0.f) loss += t[2] / t[1];
             if (t[3] > 0.f) loss += t[4] / t[3];
@@ -2548,7 +2574,8 @@ int hm_ordinal_depth_fwd(const float* d0, const float* d1, const float* a0, cons
                          void* workspace, hipStream_t stream)
 {
     HM_CHECK_ARG(d0 && d1 && a0 && a1 && m0 && m1 && frame_part && rec && out1 && workspace && B > 0 && S > 0);
-    hipLaunchKernelGGL(k_ordinal_depth, dim3(B), dim3(256), 0, stream, d0, d1, a0, a1, m0, m1, B, S, frame_part,
+    HM_CHECK_ARG(S <= 1024 && ((uintptr_t)frame_part & 7) == 0);
+    hipLaunchKernelGGL(k_ordinal_depth, dim3(ORD_CHUNKS, B), dim3(256), 0, stream, d0, d1, a0, a1, m0, m1, B, S, frame_part,
                        (unsigned int*)((float*)workspace + 512), rec, out1);
     return hm_launch_status();
 }

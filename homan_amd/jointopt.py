@@ -440,7 +440,7 @@ class FusedStepper:
         self.graph = self.graph_b = None
         self.cap_stream, self.side, self.aux, side = _loop_streams(dev)
         self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd, self.ev_smo, self.ev_ras = (torch.cuda.Event() for _ in range(6))
-        self.ev_hand, self.ev_col = torch.cuda.Event(), torch.cuda.Event()
+        self.ev_hand, self.ev_col, self.ev_dep, self.ev_dgrad = (torch.cuda.Event() for _ in range(4))
         # (option, off: one clip, step-2 sets - the collision chain on the side stream, the rest of the hand side on the third
         #  stream, see forward_backward; measured +-0.4 % on cfg3: both chains already share a work-bound GPU)
         self.col_on_aux = (os.environ.get("HOMAN_COL_AUX") or "0") != "0" and C == 1 and self.h == 1
@@ -628,6 +628,12 @@ class FusedStepper:
                 self.ev_sil.record(main)         # self.vo for the side stream
                 if use_aux and not self.sil_reduce_in_bwd:
                     self.ev_ras.record(main)
+            if on["depth"]:
+                # the OBJECT's depth render of the ordinal depth term rides this chain, right behind the silhouette raster (its
+                # vertices are the face setup's): the hand's render runs on the side stream meanwhile - two renders after each
+                # other there made the hand side twice as long as this chain
+                self._depth_render(self.vo, self.dctx[0], Vo, self.d_sil_o, self.d_dep_o, sa)
+                self.ev_dep.record(main)
             ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps,
                                   2 if self.lw["lw_sil_obj"] > 0 else 1,
                                   P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
@@ -765,11 +771,11 @@ class FusedStepper:
             if on["depth"]:
                 ctx_o, ctx_h, m_o, m_h = self.dctx
                 Sd, K = ctx_o.S, P(m.camintr)
-                for verts, ctx, V_, sil, dep in ((self.vo, ctx_o, Vo, self.d_sil_o, self.d_dep_o),
-                                                 (self.vh, ctx_h, Vh, self.d_sil_h, self.d_dep_h)):
-                    ck(L.hm_sil_fwd(P(verts), P(ctx.faces), 0, K, B, V_, ctx.F, Sd, 1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR,
-                                    None, None, None, P(sil), None, P(ctx.work_order), P(dep), None, 0, None, None, None, 0, 0,
-                                    P(ctx.workspace), sb2), "depth render")
+                self._depth_render(self.vh, ctx_h, Vh, self.d_sil_h, self.d_dep_h, sb2)
+                if on["sil"]:
+                    side2.wait_event(self.ev_dep)        # the object's depth image, from the calling stream
+                else:
+                    self._depth_render(self.vo, ctx_o, Vo, self.d_sil_o, self.d_dep_o, sb2)
                 rw_bytes = L.hm_reduce_workspace_bytes()
                 for ci in range(C):           # per clip: the term normalises over the clip's own pairs and mask counts
                     fr = slice(ci * CL, (ci + 1) * CL)
@@ -780,8 +786,12 @@ class FusedStepper:
                                               self.rws_depth.buf.data_ptr() + rw_bytes * ci, sb2), "ordinal depth")
                     ck(L.hm_ordinal_depth_bwd(*args, P(self.d_rec[ci]), P(self.up_depth), P(self.d_go[fr]), P(self.d_gh[fr]),
                                               sb2), "ordinal depth bwd")
-                for verts, ctx, V_, g, G in ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o),
-                                             (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h)):
+                # the two depth images' backward passes are independent: the hand's stays here, the object's goes to the
+                # calling stream (idle between its sweeps and the object's gradient launch) when that stream made the render
+                self.ev_dgrad.record(side2)
+                for verts, ctx, V_, g, G in (((self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h),) if on["sil"] else
+                                             ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o),
+                                              (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h))):
                     ck(L.hm_depth_bwd(P(verts), K, B, V_, ctx.F, Sd, 1.0, P(g), P(ctx.adj_off), P(ctx.adj_items), P(G),
                                       P(ctx.workspace), sb2), "depth bwd")
             if split:
@@ -820,6 +830,11 @@ class FusedStepper:
             self.ev_smo.record(main)
         if self.smooth_obj_on_main:
             aux_block()
+        if on["depth"] and on["sil"]:
+            main.wait_event(self.ev_dgrad)       # d loss / d (object's depth image), from the side stream
+            ctx_o = self.dctx[0]
+            ck(L.hm_depth_bwd(P(self.vo), P(m.camintr), B, Vo, ctx_o.F, ctx_o.S, 1.0, P(self.d_go), P(ctx_o.adj_off),
+                              P(ctx_o.adj_items), P(self.G_dep_o), P(ctx_o.workspace), sa), "depth bwd(obj)")
         main.wait_event(self.ev_pair)
         sc_obj = m.optimize_object_scale
         tp, tw, tn = _lib.terms([(self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),
@@ -1027,6 +1042,13 @@ class FusedStepper:
         ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps, 2,
                               P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items), P(sctx.face_order),
                               None, None, P(sctx.workspace), CL, None, NS, sa), "sil_bwd")
+
+    def _depth_render(self, verts, ctx, V_, sil, dep, stream_id):
+        """depth + silhouette images of one mesh at the full-image camera (reference homan.py:391,406), all frames"""
+        m, L, P = self.model, self.L, _lib.ptr
+        _lib.check(L.hm_sil_fwd(P(verts), P(ctx.faces), 0, P(m.camintr), self.B, V_, ctx.F, ctx.S, 1.0, self.ops.NMR_NEAR,
+                                self.ops.NMR_FAR, None, None, None, P(sil), None, P(ctx.work_order), P(dep), None, 0, None, None,
+                                None, 0, 0, P(ctx.workspace), stream_id), "depth render")
 
     def _adam_log(self):
         if not self.log_in_adam:

@@ -372,7 +372,7 @@ class _OrdinalDepthLoss(torch.autograd.Function):
         B, S = d0.shape[0], d0.shape[1]
         assert d0.shape == d1.shape == a0.shape == a1.shape == m0.shape == m1.shape == (B, S, S)
         assert m0.dtype == torch.uint8 and m1.dtype == torch.uint8 and m0.is_contiguous() and m1.is_contiguous()
-        part = torch.empty(B * 8, device=d0.device)
+        part = torch.zeros(B * 8, device=d0.device)          # (per-frame records: zero on entry, see the header)
         rec = torch.empty(5, device=d0.device)
         out = torch.empty(1, device=d0.device)
         _lib.check(_lib.lib().hm_ordinal_depth_fwd(

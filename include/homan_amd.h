@@ -150,7 +150,8 @@ int hm_depth_bwd(const float* verts, const float* K, int B, int V, int F, int S,
                  void* workspace, hipStream_t stream);
 /* Ordinal depth loss between two rendered layers (0 = object, 1 = hand): reference homan/homan.py:384-419 +
  * homan/lossutils.py:133-169 (as the method intends; the reference call site raises before reaching it, DESIGN.md).
- * d*/a*: depth / silhouette renders (B,S,S) f32; m*: instance masks (B,S,S) u8.  frame_part: B*8 floats scratch;
+ * d*/a*: depth / silhouette renders (B,S,S) f32; m*: instance masks (B,S,S) u8.  frame_part: B*8 floats (8-byte aligned),
+ * ZERO-filled once by the caller (per-frame integer records of the chunk workgroups; the call leaves them zero again);
  * rec: 5 floats {num_pairs, n01, sum01, n10, sum10} kept for the backward; out1[0] = loss.
  * workspace: the reduce workspace (see the small losses below), zero-filled once. */
 int hm_ordinal_depth_fwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
