@@ -170,3 +170,27 @@ def test_heterogeneous_shard_with_a_tied_scale(mano_model):
     np.testing.assert_allclose(s[0], float(eager[0].int_scales_object.detach().cpu()[0]), rtol=2e-4)
     evo = sh.loss_evolution(steps)
     np.testing.assert_allclose([e["loss"][0] for e in evo], hist[0], rtol=2e-4)
+
+
+def test_cfg4_full_shard_eight_full_size_clips(mano_model):
+    """BASELINE cfg4 as one rank of it runs: EIGHT clips of 30 frames at 256^2 (bottle, step-1 losses) as one clip batch - one
+    launch per kernel over 240 frames.  Every clip's rows are finite, and clip 5 (any one would do) is bit-identical to the
+    same clip optimised alone."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    lw, steps = dict(synth.STEP1_LOSS_WEIGHTS), 4
+    batch = _clips(mano_model, list(range(8)), 30, 256, "bottle")
+    st = FusedStepper(batch, lw, 1e-2, steps)
+    st.run(steps)
+    evo = st.loss_evolution(steps)
+    assert len(evo) == 8
+    for e in evo:
+        assert all(np.isfinite(v).all() for v in e.values())
+    (alone,) = _clips(mano_model, [5], 30, 256, "bottle")
+    sa = FusedStepper(alone, lw, 1e-2, steps)
+    sa.run(steps)
+    for k, v in sa.loss_evolution(steps).items():
+        np.testing.assert_array_equal(np.asarray(evo[5][k]), np.asarray(v), err_msg=k)
+    for k in PARAMS:
+        if hasattr(alone, k):
+            assert torch.equal(getattr(alone, k).detach(), getattr(batch[5], k).detach()), k
