@@ -2492,10 +2492,13 @@ int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss
 //   `upstream` stays one scalar shared by the clips.  loss_out (optional, modes 1 / 2): the loss / IoU reduction of a forward
 //   called with keep / ref but loss_out == NULL (what hm_sil_reduce_clips computes, same arithmetic) rides at the front of
 //   the backward's first launch: clip c's values at loss_out[c * out_stride + 0 / 1].
-int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
-                     const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
-                     const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-                     int clip_len, float* loss_out, int out_stride, hipStream_t stream)
+// phases: bit 0 = sample-gradient masks (generic modes) + line expansion + work list, bit 1 = edge sweeps + vertex gather: the
+// backward in two calls for a caller that lets other streams wait for the END of the line expansion (the kernel of the chain
+// that suffers most from latency-bound neighbours holding its wave slots); hm_sil_bwd_clips = both
+int hm_sil_bwd_phase_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
+                           const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
+                           const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
+                           int clip_len, float* loss_out, int out_stride, int phases, hipStream_t stream)
 {
     HM_CHECK_ARG(!loss_out || ((mode == 1 || mode == 2) && keep_sum));
     HM_CHECK_ARG(verts && K && adj_off && adj_items && workspace);        // grad_verts == NULL: no vertex gather (see hm_sil_parts)
@@ -2506,19 +2509,29 @@ int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, in
     if (S % 32 != 0 || S > 32 * SWEEP_CUMW) return HM_ERR_UNSUPPORTED;     // 64-sample mask words, <= SWEEP_CUMW per line
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
-    if (mode != 2 && mode != 4)      // modes 2 / 4: the caller guarantees upstream > 0, the forward's planes are the backward's
+    HM_CHECK_ARG(phases >= 1 && phases <= 3);
+    if ((phases & 1) && mode != 2 && mode != 4)      // modes 2 / 4: the caller guarantees upstream > 0, the forward's planes are the backward's
         hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                            mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                            w.planes, clip_len);
     HM_TIME_MARK(2, stream);
-    launch_lines(w, B, F, S, mode, upstream, keep_sum, clip_len, stream, loss_out, out_stride);
+    if (phases & 1) launch_lines(w, B, F, S, mode, upstream, keep_sum, clip_len, stream, loss_out, out_stride);
     HM_TIME_MARK(3, stream);
+    if (!(phases & 2)) return hm_launch_status();
     launch_sweep(w, B, F, S, eps, stream);
     HM_TIME_MARK(4, stream);
     if (grad_verts)
         hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
                            adj_items, verts, K, B, V, F, orig_size, grad_ndc, grad_verts);
     return hm_launch_status();
+}
+int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
+                     const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
+                     const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
+                     int clip_len, float* loss_out, int out_stride, hipStream_t stream)
+{
+    return hm_sil_bwd_phase_clips(verts, K, B, V, F, S, orig_size, eps, mode, upstream, grad_pooled, keep_sum, adj_off, adj_items,
+                                  face_order, grad_verts, grad_ndc, workspace, clip_len, loss_out, out_stride, 3, stream);
 }
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,

@@ -455,6 +455,13 @@ class FusedStepper:
         # line expansion (230 -> 162 us)
         self.pairs_after_raster = (self.use_aux and not self.sil_reduce_in_bwd and
                                    (os.environ.get("HOMAN_PAIRS_AFTER_RASTER") or "1") != "0")
+        # a clip batch: the pair-wise terms of the side stream wait for the END of the line expansion (the backward in two
+        # calls) - that kernel is latency-bound and takes 200 us instead of 150 next to neighbours that hold its wave slots -
+        # and the sweeps run 1024 persistent workgroups instead of 1280 so that the hand's gradient launches find registers
+        # next to them (same-box A/B, 8 clips: step-1 8 650 -> 8 865 it/s, step-2 7 142 -> 7 332; either change alone loses)
+        self.pairs_after_lines = (os.environ.get("HOMAN_PAIRS_AFTER_LINES") or "1") != "0" and C > 1 and self.on["sil"]
+        self.ev_lines = torch.cuda.Event()
+        self.nn_early = (os.environ.get("HOMAN_NN_EARLY") or "0") != "0"
         self.pair_fused = (os.environ.get("HOMAN_PAIR_FUSED") or ("1" if C == 1 else "0")) != "0"
         self.hand_terms_fused = os.environ.get("HOMAN_HT_FUSED", "1") != "0"
         self.nn_full_fused = os.environ.get("HOMAN_NN_FULL_FUSED", "1") != "0"
@@ -472,7 +479,8 @@ class FusedStepper:
             # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way;
             # same-box A/B on cfg3, round 2 before the launch fusions: 1280 -> 4030, 768 -> 4130, 512 -> 4194 it/s; after them,
             # with the raster ballast below: 512 -> 4408, 768 -> 4552, 1024 -> 4537, 1280 -> 4512)
-            sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (768 if (self.on["col"] or self.on["con"]) and C == 1 else 1280)
+            sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (768 if (self.on["col"] or self.on["con"]) and C == 1 else
+                                                                    1024 if self.pairs_after_lines else 1280)
             pad = os.environ.get("HOMAN_RASTER_PAD")
             # same idea for the rasteriser: 8 KB of LDS ballast = 4 workgroups per CU instead of 6 leaves registers for the
             # hand-side kernels (cfg3 one clip: 4347 -> 4500 it/s; cfg2, where that chain is short: 5820 -> 5500, so not there)
@@ -634,12 +642,20 @@ class FusedStepper:
                 # other there made the hand side twice as long as this chain
                 self._depth_render(self.vo, self.dctx[0], Vo, self.d_sil_o, self.d_dep_o, sa)
                 self.ev_dep.record(main)
-            ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps,
-                                  2 if self.lw["lw_sil_obj"] > 0 else 1,
-                                  P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
-                                  P(sctx.face_order), None, None, P(sctx.workspace), CL,
-                                  self._slot("loss_sil_obj") if self.sil_reduce_in_bwd else None, NS, sa),
-               "sil_bwd")    # no vertex gather; the loss / IoU values come out of its first launch
+            bwd_args = (P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps,
+                        2 if self.lw["lw_sil_obj"] > 0 else 1,
+                        P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
+                        P(sctx.face_order), None, None, P(sctx.workspace), CL,
+                        self._slot("loss_sil_obj") if self.sil_reduce_in_bwd else None, NS)
+            # (no vertex gather; the loss / IoU values come out of its first launch)
+            if self.pairs_after_lines:
+                # a clip batch: the line expansion - latency-bound, and the kernel of this chain that suffers most from
+                # neighbours holding its wave slots - runs ALONE; the pair-wise terms of the side stream wait for its end
+                ck(L.hm_sil_bwd_phase_clips(*bwd_args, 1, sa), "sil_bwd(lines)")
+                self.ev_lines.record(main)
+                ck(L.hm_sil_bwd_phase_clips(*bwd_args, 2, sa), "sil_bwd(sweeps)")
+            else:
+                ck(L.hm_sil_bwd_clips(*bwd_args, sa), "sil_bwd")
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
             if not on["sil"]:    # (with the silhouette term the face setup of hm_sil_fwd has written self.vo already)
@@ -685,9 +701,20 @@ class FusedStepper:
                 if on["v2d"]:
                     ck(L.hm_v2d_fwd_clips(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
                                           P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, CL, NS, sb), "v2d")
+            nn_early = False
             if on["sil"]:
                 side.wait_event(self.ev_sil)         # self.vo: camera-space object vertices from the calling stream
-                if self.pairs_after_raster:
+                if self.pairs_after_lines:
+                    # (the metric-only search - it feeds nothing but the logged hand-object distance, and is the longest
+                    #  launch of the hand side in a batch - can run before that wait, next to the rasteriser)
+                    nn_early = self.nn_early and on["inter"] and not on["con"] and Vo <= 4096 and not self.inter_min
+                    if nn_early:
+                        ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, None, None, self._slot("handobj_maxdist"),
+                                                   rws_b, CL, NS, P(self.obj_order),
+                                                   (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
+                                                   P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sb), "nn")
+                    side.wait_event(self.ev_lines)   # (scheduling only, see the silhouette chain above)
+                elif self.pairs_after_raster:
                     side.wait_event(self.ev_ras)     # (scheduling only, see __init__)
             # one clip, step-2 sets: the collision term (five SDF launches) and the search / contact / interaction launches
             # both start from the two vertex buffers and feed nothing to each other.  The collision chain stays on this
@@ -710,7 +737,7 @@ class FusedStepper:
                                          sb2), "smooth(obj)")
             def search_and_contact(stream_obj, rws):
                 sx = stream_obj.cuda_stream
-                if (on["con"] or on["inter"]) and not nn_fused and not nn_full_fused:
+                if (on["con"] or on["inter"]) and not nn_fused and not nn_full_fused and not nn_early:
                     # (without the contact term only the logged distance is needed: metric-only search - its group table
                     #  covers 4096 object vertices, larger meshes take the full search for the same number)
                     full = on["con"] or Vo > 4096 or self.inter_min      # ('min' names the closest PAIR: indices needed)

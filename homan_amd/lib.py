@@ -90,6 +90,8 @@ _SIGNATURES = {
                                     _VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _VP]),
     "hm_sil_reduce_clips": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_sil_bwd_clips": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _VP]),
+    "hm_sil_bwd_phase_clips": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _I,
+                                    _VP]),
     "hm_v2d_fwd_clips": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_smooth_fwd_clips": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_priors_fwd_clips": (_I, [_VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),

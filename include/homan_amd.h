@@ -337,6 +337,12 @@ int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, in
                      const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                      const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
                      int clip_len, float* loss_out, int out_stride, hipStream_t stream);
+/* The same backward in two calls (phases: bit 0 = masks + line expansion + work list, bit 1 = edge sweeps + vertex gather; 3 =
+ * hm_sil_bwd_clips), for a caller whose other streams wait for the END of the line expansion. */
+int hm_sil_bwd_phase_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
+                     const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
+                     const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
+                     int clip_len, float* loss_out, int out_stride, int phases, hipStream_t stream);
 /*   loss_out (optional, modes 1 / 2): the loss / IoU reduction of hm_sil_reduce_clips (same arithmetic) done by extra
  *   workgroups at the front of the backward's first launch, for a forward that was called with loss_out == NULL: the value
  *   is only logged, so it need not cost a launch on the chain raster -> lines -> sweeps. */
