@@ -197,7 +197,7 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | `k_contact_obj` | block / frame: hand-vertex gradients added into an LDS accumulator with 64-bit **fixed-point** atomics (order-independent ⇒ deterministic without a sort; the picks are skewed onto a few object vertices) | LDS | B·(778·16 + V·12) |
 | `k_sdf_boxes`, `k_sdf_tris`, `k_sdf_need`, `k_sdf_dist`, `k_sdf_sample` | AABB + normalise; thread / triangle: packed record + +x ray parity of the few (y,z) rows under the triangle (`atomicXor` of 32-bit inside masks); thread / sample: marks touched inside voxels, first setter appends to the grid's list; workgroup / listed voxel: nearest-vertex seed + box-pruned scan of the packed triangles (a single wave was ~70 dependent round trips for one voxel); thread / sample: trilinear value + gradient, ticket reduction | latency | ≈ B·(778+V)·36 + 8.7 MB |
 | `k_depth_bwd_faces`, `k_depth_bwd_gather` (a19) | wave / (frame, face): strides the face's sample box, tests ownership in the index map, reduces the three sums `A_k = Σ g·zp²·w_k` the NMR depth backward factors through (DPP); thread / vertex gather + projection backward | HBM (index-map reads) | B·(512²·4·ρ + S²·4 + F·(44+72)) (ρ ≈ box overlap) |
-| `k_ordinal_depth`, `k_ordinal_depth_bwd` (a19) | block / frame partial sums (pairs, mask counts, softplus sums) + last-block finish; element-wise backward | HBM | B·S²·(4·4+2) fwd, + B·S²·8 bwd |
+| `k_ordinal_depth`, `k_ordinal_depth_bwd` (a19) | 16 chunk workgroups per frame; a frame's record collects them with 64-bit INTEGER atomics (pixel counts packed, softplus sums in 2⁻³² fixed point: order-independent, so deterministic), last workgroup finishes the clip; element-wise backward.  In the fused loop the object's depth render and depth backward ride the calling stream (behind the silhouette raster / behind the sweeps), the hand's the side stream | HBM | B·S²·(4·4+2) fwd, + B·S²·8 bwd |
 | `k_adam` | one launch for all tensors (pointer table), bias corrections in double, zeroes grads; the last workgroup (ticket) bumps the device step counter.  One clip: an extra grid row writes the log row of the step being taken (weighted total + every loss / metric slot) before it draws its tickets (`hm_adam_step_log` = `hm_log_total_clips` + `hm_adam_step`, same floats, one launch less on the tail) | latency | 28·79·B |
 
 Whole iteration (SURVEY §8d byte model): 144.1 MB (cfg2), 161.8 MB (cfg3).
@@ -220,24 +220,20 @@ Adam + logging, no host sync) on three captured streams.
 
 Stream structure of the fused loop (`FusedStepper`): A (face setup incl. the object's rigid transform and the camera-space
 vertices → raster → lines [+ loss reduction] → sweeps → object pose gradients incl. the silhouette gather), B (MANO + hand
-transform → pair terms → hand + MANO backward); B forks off A right after the face setup (`hm_sil_fwd_phase_clips`: the
-camera-space vertices are complete there, the raster keeps ONE successor); join → Adam + log row.  A clip batch adds C (the
-silhouette reduction + log rows on a third stream: +1.5 % there, while at one clip two streams are 5-6 % faster - same-box
-A/B).  HIP-runtime and hardware facts that shaped it (all measured):
-* stream capture crashes when two captured side streams wait for each other's events (a third branch for search + contact
-  next to the collision term dies at replay), and torch hands streams out of a pool of 32 - a process that builds many
-  steppers eventually draws a "side" stream that IS its capture stream - so all steppers share one verified set of distinct
-  streams (`_loop_streams`) and parallelism inside a chain comes from multi-term LAUNCHES, not from more streams;
+transform → pair terms → hand + MANO backward); B forks off A right after the face setup (`hm_sil_fwd_phase_clips`); join →
+Adam + log row.  A clip batch adds C (silhouette reduction + log rows), lets B's pair-wise terms wait for the END of the line
+expansion (`hm_sil_bwd_phase_clips`: that kernel is latency-bound and takes 200 instead of 150 µs next to neighbours that hold
+its wave slots) and runs 1024 instead of 1280 persistent sweep workgroups so that the hand's gradient launches find registers
+next to them.  HIP-runtime and hardware facts that shaped it (all measured, EXPERIMENTS.md):
+* stream capture crashes at replay when a forked stream rejoins a stream other than the one it forked from (a third branch
+  for search + contact next to the collision term; the collision chain on the third stream joining the side stream), and
+  with the depth term's launches on the side stream a three-stream graph dies too (depth: two streams); torch hands streams
+  out of a pool of 32, so all steppers share one verified set of distinct streams (`_loop_streams`);
 * consecutive kernels of one queue follow each other without a gap; every cross-queue edge costs 5-10 µs.  At one clip the
-  iteration is two chains of short latency-bound launches of about equal length: shortening one alone changes nothing
-  (loss reduction folded into the lines launch: ±0; fork after the setup: ±0), shortening both does (pair terms −12 µs,
-  log row in Adam −5 µs, then the fork +3 %);
-* what looked like the graph executor "serialising" richer fork patterns is mostly RESOURCE STARVATION: six rasteriser
-  workgroups fill a CU's LDS (149 of 160 KB) and registers (480 of 512 per lane), so a kernel of the other stream that
-  needs 72 registers (MANO forward) is not scheduled until the rasteriser's workgroups drain - whether it runs under the
-  raster or after it depends on which of the two root nodes the command processor happened to start first.  8 KB of LDS
-  ballast on the raster (4 workgroups / CU, `hm_tune_raster_lds_pad`) buys +3.5 % where the hand-side chain is the long
-  one (cfg3, one clip) and costs 5 % where it is not (cfg2) - applied like the sweep's workgroup count, per loss set.
+  silhouette chain IS the iteration; the hand side is hidden under it (removing the MANO backward altogether: +1.5 %);
+* kernels that share the GPU stretch each other: six rasteriser workgroups fill a CU's LDS and registers, five sweep waves
+  per SIMD leave 32 registers - whether a hand-side kernel runs under a heavy kernel or after it is a matter of residency,
+  which the LDS ballast knobs (`hm_tune_*`) and the sweep's workgroup count steer per loss set.
 
 ## 5. Measured (MI355X, round 3; evidence under `profiles/r03_*`, regenerated by `tools/profile_round.sh r03`)
 
