@@ -345,7 +345,7 @@ file the reference never reaches.  More than two hands: the reference's own coll
 ## 8. Known gaps / next (ranked)
 
 1. Kernel targets of the last verdict (raster ≤ 38, sweep ≤ 38, lines ≤ 18 µs in the graph; driver-flag line ≥ 5500,
-   8-clip batch ≥ 9500 it/s) are not met: 45 / 46 / 26 µs, 4 770 and 8 600 it/s.  What the round's counters say is left:
+   8-clip batch ≥ 9500 it/s) are not met: 45 / 46 / 26 µs, 4 790 and 8 800 it/s.  What the round's counters say is left:
    the raster spends 7-8 dependent global round trips per workgroup (a 16-byte `{face, box}` bin entry and vertices staged
    by the scanning thread would remove two of them) and ~2.6 VALU issue slots + a VCC hazard per inside test; the sweep's
    stage 1 costs ~250 instructions per 64 items, 71 % of which it rejects (a per-(face, family) reject before the items
