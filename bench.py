@@ -451,11 +451,11 @@ def pose_init_bench(args):
     rots = po.compute_random_rotations(n)
     fit = lambda k, mode: po.find_optimal_pose(verts, faces, mask, bbox, sq, (350, 350), K=K, num_iterations=k,
                                                num_initializations=n, rotations_init=rots, rend_size=size, mode=mode)
-    # both loops of find_optimal_pose: "eager" = the reference's loop verbatim (torch Adam, one host sync per step), "graph" =
-    # the same step captured in a hipGraph.  The GPU work is the same; the eager loop also needs a host that keeps up with
-    # ~40 launches per 2 ms step, which not every box does - the faster of the two is reported, both are listed.
+    # the loops of find_optimal_pose: "eager" = the reference's loop verbatim (torch autograd + Adam, one host sync per step),
+    # "graph" = that step captured in a hipGraph, "fused" (the default of find_optimal_pose) = the step as a fixed C-ABI launch
+    # sequence without the autograd tape, in a hipGraph.  The fastest is reported, all are listed.
     loops, best = {}, None
-    for mode in ("eager", "graph"):
+    for mode in ("eager", "graph", "fused"):
         fit(3, mode)                               # warm-up (allocations, lazy init)
         torch.cuda.synchronize()
         t0 = time.perf_counter()

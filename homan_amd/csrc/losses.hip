@@ -156,7 +156,55 @@ __global__ void k_inter_bwd(const float* __restrict__ frame_rec, const float* __
     }
 }
 
+// ------------------------------------------------------------------ off-screen penalty of the pose initialisation
+// reference homan/pose_optimization.py:112-135: hinge on the six clipping planes of the projected vertices (NDC x, y in
+// [-1,1] under nr.projection(K, R=I, t=0, orig_size=1), 0 < z < far), summed over the vertices of one candidate pose.
+// grid (N): value out[n] = weight * sum, and d out / d vertex (N,V,3) in the same pass (K: ONE 3x3 camera for all poses).
+__global__ __launch_bounds__(256) void k_offscreen(const float* __restrict__ verts, const float* __restrict__ K, int V,
+                                                   float zfar, float weight, float* __restrict__ out,
+                                                   float* __restrict__ grad)
+{
+    __shared__ float red[16];
+    const int n = blockIdx.x;
+    const float k00 = K[0], k01 = K[1], k02 = K[2], k10 = K[3], k11 = K[4], k12 = K[5];
+    float acc = 0.f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        const long o = ((long)n * V + v) * 3;
+        const float x = verts[o], y = verts[o + 1], z = verts[o + 2];
+        const float zz = z + 1e-9f;
+        const float xn = x / zz, yn = y / zz;
+        float u = k00 * xn + k01 * yn;
+        u = u + k02;
+        float w = k10 * xn + k11 * yn;
+        w = 1.0f - (w + k12);
+        const float nu = 2.0f * (u - 0.5f), nv = 2.0f * (w - 0.5f);
+        // relu(ndc - 1) + relu(-1 - ndc) per component, relu(-z), relu(z - far); d relu / dx = [x > 0]
+        float val = fmaxf(nu - 1.0f, 0.f) + fmaxf(nv - 1.0f, 0.f);
+        val += fmaxf(-1.0f - nu, 0.f) + fmaxf(-1.0f - nv, 0.f);
+        val += fmaxf(-z, 0.f);
+        val += fmaxf(z - zfar, 0.f);
+        acc += val;
+        const float gu = (nu - 1.0f > 0.f ? 1.f : 0.f) - (-1.0f - nu > 0.f ? 1.f : 0.f);
+        const float gv = (nv - 1.0f > 0.f ? 1.f : 0.f) - (-1.0f - nv > 0.f ? 1.f : 0.f);
+        const float gz = (z - zfar > 0.f ? 1.f : 0.f) - (-z > 0.f ? 1.f : 0.f);
+        const float du = 2.0f * gu, dw = -2.0f * gv;             // d / d u, d / d (k10 xn + k11 yn + k12)
+        const float dxn = k00 * du + k10 * dw, dyn = k01 * du + k11 * dw;
+        grad[o] = weight * (dxn / zz);
+        grad[o + 1] = weight * (dyn / zz);
+        grad[o + 2] = weight * (gz - (dxn * x + dyn * y) / (zz * zz));
+    }
+    acc = hm_block_sum(acc, red);
+    if (threadIdx.x == 0) out[n] = weight * acc;
+}
+
 extern "C" {
+int hm_offscreen_fwd(const float* verts, const float* K, int N, int V, float zfar, float weight, float* out, float* grad,
+                     hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && K && out && grad && N > 0 && V > 0);
+    hipLaunchKernelGGL(k_offscreen, dim3(N), dim3(256), 0, stream, verts, K, V, zfar, weight, out, grad);
+    return hm_launch_status();
+}
 #define HM_RED_MAX_BLOCKS 256
 // workspace for the reductions: 512 floats of partials + 1 counter word at float offset 512 (HM_RED_WS_FLOATS floats in
 // all; the whole buffer must be zero-initialised once; the counter resets itself).  A *_clips call needs one such slice

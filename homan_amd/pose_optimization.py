@@ -226,15 +226,93 @@ def _graph_loop(model, lr, num_iterations):
     return losses_out, best_rot.clone(), best_trans.clone()
 
 
+def _fused_loop(model, lr, num_iterations):
+    """`num_iterations` steps of reference pose_optimization.py:330-357 as a fixed sequence of C-ABI launches, no autograd
+    tape, replayed from one hipGraph: rigid transform of the n candidates, off-screen penalty (value + vertex gradients in
+    one launch, hm_offscreen_fwd), no-anti-aliasing raster with the masked L2 + IoU fused per sample, edge sweeps, pose
+    gradients with the silhouette gather inside (hm_rigid_bwd_sil), the fused multi-tensor Adam - what the eager loop spends
+    on torch's element-wise kernels (a third of its step) is gone.  The chamfer term is multiplied by its weight 0 at the
+    reference's only call site and is not evaluated (PoseOptimizer.forward does the same).  Best-ever bookkeeping as in
+    `_graph_loop`: the pose is copied AFTER the optimiser step that followed the evaluation (:348-353), strict `<`."""
+    from . import lib as _lib
+    from .jointopt import HmAdam
+    assert model.lw_chamfer == 0, "the fused loop covers the reference's configuration (lw_chamfer = 0)"
+    L, P, ck = _lib.lib(), _lib.ptr, _lib.check
+    sctx, dev = model._sil_ctx, model.rotations.device
+    n, V, F, S = sctx.B, sctx.V, sctx.F, sctx.S
+    f = lambda *shape: torch.zeros(*shape, device=dev)
+    verts, g_off, off = f(n, V, 3), f(n, V, 3), f(n)
+    pooled, alpha, frame = f(n, S, S), f(n, 2 * S, 2 * S), f(n, 2)
+    keep, ref = sctx.pad_samples(model._keep1), sctx.pad_samples(model._ref1)
+    K_all, K_one, eps = sctx.K_eff(model._K_all).contiguous(), model.K[0].contiguous(), sctx.eps()
+    ones = torch.ones(n, device=dev)
+    rws = torch.zeros(L.hm_rigid_workspace_bytes(n), dtype=torch.uint8, device=dev)
+    params = [model.rotations, model.translations]
+    for p in params:
+        p.grad = torch.zeros_like(p)
+    opt = HmAdam([{"params": params, "lr": lr}])
+    tp, tw, tn = _lib.terms([(g_off, 1.0)])
+    best_loss = torch.full((), float("inf"), device=dev)
+    best_rot, best_trans = torch.zeros_like(model.rotations[0]), torch.zeros_like(model.translations[0])
+    losses_out = f(n)
+
+    def step():
+        st = _lib.stream()
+        ck(L.hm_rigid_fwd(P(model.vertices), P(model.rotations), P(model.translations), P(model._one), 0, n, V, None, P(verts),
+                          st), "hm_rigid_fwd")
+        ck(L.hm_offscreen_fwd(P(verts), P(K_one), n, V, NMR_FAR, 100000.0, P(off), P(g_off), st), "hm_offscreen_fwd")
+        ck(L.hm_sil_fwd(P(verts), P(sctx.faces), 0, P(K_all), n, V, F, S, 1.0, ops.NMR_NEAR, ops.NMR_FAR, P(keep), P(ref), None,
+                        P(pooled), None, P(sctx.work_order), None, P(alpha), 1, None, None, None, 0, 0, P(sctx.workspace), st),
+           "hm_sil_fwd")
+        ck(L.hm_sil_reduce(n, V, F, S, None, None, P(frame), P(sctx.workspace), st), "hm_sil_reduce")
+        ck(L.hm_sil_bwd(P(verts), P(K_all), n, V, F, S, 1.0, eps, 4, P(ones), None, None, P(sctx.adj_off), P(sctx.adj_items),
+                        P(sctx.face_order), None, None, P(sctx.workspace), st), "hm_sil_bwd")
+        ck(L.hm_rigid_bwd_sil(P(model.vertices), P(model.rotations), P(model._one), 0, tp, tw, tn,
+                              L.hm_sil_parts(P(sctx.workspace), n, V, F, S), P(sctx.adj_off), P(sctx.adj_items), P(verts),
+                              P(K_all), 1.0, F, n, V, P(model.rotations.grad), P(model.translations.grad), None, P(rws), st),
+           "hm_rigid_bwd_sil")
+        opt.step(zero_grad=False)
+        with torch.no_grad():
+            losses = frame[:, 0] + off           # mask + (chamfer = 0) + offscreen, the order of sum(loss_dict.values())
+            lmin, ind = losses.min(0)
+            better = lmin < best_loss
+            best_loss.copy_(torch.where(better, lmin, best_loss))
+            sel = ind.reshape(1)
+            best_rot.copy_(torch.where(better, model.rotations.index_select(0, sel)[0], best_rot))
+            best_trans.copy_(torch.where(better, model.translations.index_select(0, sel)[0], best_trans))
+            losses_out.copy_(losses)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    done = 0
+    with torch.cuda.stream(side):
+        for _ in range(min(2, num_iterations)):          # un-captured steps (lazy initialisation); they ARE steps
+            step()
+            done += 1
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    if done < num_iterations:
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        for _ in range(num_iterations - done):
+            graph.replay()
+    torch.cuda.synchronize()
+    for p in params:
+        p.grad = None
+    return losses_out, best_rot.clone(), best_trans.clone()
+
+
 def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=None, num_iterations=50,
                       num_initializations=2000, lr=1e-2, image=None, debug=False, viz_folder="tmp", viz_step=10,
-                      sort_best=True, rotations_init=None, viz=False, rend_size=constants.REND_SIZE, mode="eager"):
+                      sort_best=True, rotations_init=None, viz=False, rend_size=constants.REND_SIZE, mode="auto"):
     """reference homan/pose_optimization.py:219-383 (debug plots not provided: `debug` / `viz` / `image` are accepted
     and ignored).  Returns the PoseOptimizer whose `rotations` / `translations` hold the best-ever pose first, then the
     poses sorted by final loss.
-    mode="eager": the reference loop verbatim (one host sync per step for the best-ever bookkeeping);
-    mode="graph": the same step (forward, backward, Adam, best-ever bookkeeping on the device) captured once in a hipGraph
-    and replayed (measured: no faster than the eager loop here, the step is GPU-bound; kept for host-bound setups)."""
+    mode="auto" (default) = "fused": the step as a fixed C-ABI launch sequence without the autograd tape, in a hipGraph
+    (`_fused_loop`);
+    mode="eager": the reference loop verbatim (torch autograd + Adam, one host sync per step for the best-ever bookkeeping);
+    mode="graph": that same autograd step captured once in a hipGraph and replayed."""
     dev = torch.device("cuda")
     vertices = torch.as_tensor(vertices).float().to(dev)
     faces = torch.as_tensor(faces).to(dev)
@@ -250,9 +328,13 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
     camintr_roi[:, :2] = camintr_roi[:, :2] / rend_size          # crop K to normalised rendering space (:321)
     model = PoseOptimizer(ref_image=mask, vertices=vertices, faces=faces, rotation_init=matrix_to_rot6d(rotations_init),
                           translation_init=translations_init, num_initializations=num_initializations, K=camintr_roi)
-    if mode not in ("eager", "graph"):
-        raise ValueError(f"mode {mode} not in [eager|graph]")
-    if mode == "graph" and num_iterations > 0:
+    if mode == "auto":
+        mode = "fused"
+    if mode not in ("eager", "graph", "fused"):
+        raise ValueError(f"mode {mode} not in [auto|fused|eager|graph]")
+    if mode == "fused" and num_iterations > 0:
+        final_losses, champion_rot, champion_trans = _fused_loop(model, lr, num_iterations)
+    elif mode == "graph" and num_iterations > 0:
         final_losses, champion_rot, champion_trans = _graph_loop(model, lr, num_iterations)
     else:
         final_losses, champion_rot, champion_trans = _host_loop(model, lr, num_iterations)
@@ -306,7 +388,7 @@ def rot6d_to_matrix(rot_6d):
 
 def find_optimal_poses(image_size, faces=None, vertices=None, annotations=None, images=None, Ks=None, num_iterations=50,
                        num_initializations=2000, viz_path="tmp.png", debug=False, rend_size=constants.REND_SIZE,
-                       mode="eager"):
+                       mode="auto"):
     """reference homan/pose_optimization.py:386-488 - the entry point of fit_vid_dataset.py:285-296.  One
     `find_optimal_pose` fit per frame, every frame started from the previous frame's `num_initializations` rotations
     (`sort_best=False` keeps the candidates aligned across frames); the motion kept is the candidate with the highest mean

@@ -62,6 +62,11 @@ int hm_rigid_bwd_sil(const float* mesh, const float* rot6d, const float* scale, 
                      const float* weights, int n_terms, const float* sil_parts, const int* adj_off, const int* adj_items,
                      const float* cam_verts, const float* K, float orig_size, int F, int N, int V, float* g_rot6d,
                      float* g_trans, float* g_scale_part, void* workspace, hipStream_t stream);
+/* Off-screen penalty of the object-pose initialisation, reference homan/pose_optimization.py:112-135: hinge on the six
+ * clipping planes of the projected vertices (K: ONE (3,3) camera, normalised, orig_size 1), per candidate pose:
+ * out[n] = weight * sum_v (...), grad (N,V,3) = d out[n] / d verts[n]. */
+int hm_offscreen_fwd(const float* verts, const float* K, int N, int V, float zfar, float weight, float* out, float* grad,
+                     hipStream_t stream);
 /* out = s[0] * in ;  out = s0[0]*a + s1[0]*b   (backward of the losses whose unit gradient is produced forward) */
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream);
 int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s1, long n, float* out,
