@@ -1044,8 +1044,11 @@ struct SweepFace {            // 64 B: one face of the flattened work list
     unsigned short cum[12];   // inclusive item counts of the families, family = winding*6 + edge*2 + axis
 };
 #define SWEEP_PASS_FACES 16   // faces of a unit staged in LDS at a time (a unit with more takes several passes)
+#ifndef SWEEP_USHIFT
 #define SWEEP_USHIFT 8         // a unit = 256 consecutive items of the global list (see k_bwd_sweep)
+#endif
 #define SWEEP_UNIT (1 << SWEEP_USHIFT)
+#define SWEEP_TRIPS (SWEEP_UNIT / 64)      // stage-1 trips of a unit
 struct SweepItem { float x, c0, c1; int base0, base1, nb0, fn, meta; };   // meta: face | t0<<4 | t1<<7 | use0<<10 | use1<<11
 struct SweepList {
     SweepFace* tab; int* offs; unsigned int* ufirst; unsigned int* tickets; float* upart;
@@ -1611,13 +1614,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
             // all of them are in flight before the first is tested (one dependent round trip per unit, not per trip)
             int qn = 0;
             {
-                uint4 sm[4];
+                uint4 sm[SWEEP_TRIPS];
                 // (per trip, packed - the four trips' state lives in registers until their loads have landed:
                 //  s_io = a_in | pos << 12 | geo << 13, s_lohi = lo | hi << 16 of the inward range)
-                int s_io[4], s_lohi[4], s_ent[4], s_own[4], s_fn[4];
-                unsigned short s_aw[4];
+                int s_io[SWEEP_TRIPS], s_lohi[SWEEP_TRIPS], s_ent[SWEEP_TRIPS], s_own[SWEEP_TRIPS], s_fn[SWEEP_TRIPS];
+                unsigned short s_aw[SWEEP_TRIPS];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < SWEEP_TRIPS; ++t) {
                     const int g = it_lo + 64 * t + lane;
                     int el = -1;                                      // my face: last one of the pass with off <= g
                     for (int i = 0; i < nfp; ++i) el += (__builtin_amdgcn_readlane(o, i) <= g) ? 1 : 0;
@@ -1645,7 +1648,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                     s_ent[t] = (g - ubeg) | (max(el, 0) << 8);
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
+                for (int t = 0; t < SWEEP_TRIPS; ++t) {
                     const int min0 = (int)(sm[t].x & 0xffffu), end0 = (int)(sm[t].x >> 16);
                     const int min1 = (int)(sm[t].z & 0xffffu), end1 = (int)(sm[t].z >> 16);
                     const bool pos = (s_io[t] >> 12) & 1, geo_t = (s_io[t] >> 13) & 1;
