@@ -485,8 +485,9 @@ def pose_init_bench(args):
                       "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f32", "data": "synthetic",
                       "config": {"workload": f"SURVEY 8f rank 1: find_optimal_pose, {n} poses, lathe bottle (3000 faces), "
-                                             f"{size}x{size} mask, no anti-aliasing, torch Adam + autograd over the "
-                                             f"HIP rasteriser, loop = {best}", "poses": n, "rend_size": size,
+                                             f"{size}x{size} mask, no anti-aliasing, Adam step in the timed region, "
+                                             f"loop = {best} (eager / graph: torch autograd + Adam over the HIP rasteriser; "
+                                             f"fused: C-ABI launch sequence in a hipGraph)", "poses": n, "rend_size": size,
                                  "pose_steps_per_s_by_loop": {k: n * steps / v for k, v in loops.items()}},
                       "best_iou": float(iou.max()), "seconds_per_fit": el, "cpu_baseline": cpu})
 

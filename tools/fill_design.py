@@ -33,6 +33,12 @@ def main(tag="r03"):
            "@CPU@": f"{d['cpu_baseline']['value']:.2f}", "@CPUOFF@": f"{d['cpu_baseline']['value_logging_off']:.2f}",
            "@RATIO@": f0(d["steady_state"]["value"] / d["cpu_baseline"]["value"]),
            "@WHOLE@": f"{100 * d['steady_state']['roofline']['whole_iteration']['frac']:.1f} %"}
+    po = load(f"{tag}_bench_poseinit.json")
+    loops = (po or {}).get("config", {}).get("pose_steps_per_s_by_loop", {})
+    rep.update({"@POSE@": f0(po and po["value"]), "@POSEMS@": "n/a" if not po else f"{po['ms_per_step']:.2f}",
+                "@POSEFIT@": "n/a" if not po else f"{po['seconds_per_fit']:.3f}",
+                "@POSELOOPS@": ", ".join(f"{k} {f0(v)}" for k, v in loops.items()) or "n/a",
+                "@POSECPU@": f0(po and po["cpu_baseline"]["value"])})
     ks = d["steady_state"]["roofline"]["kernels"]
     for key, name in (("RAS", "k_raster_fwd"), ("SWP", "k_bwd_sweep"), ("LIN", "k_bwd_lines")):
         k = ks[name]

@@ -15,6 +15,7 @@ python bench.py --steps 20 --warmup 5 > $O/${N}_bench_cfg2_driver_flags.json 2>/
 python bench.py --step2 --parity-seeds 0 > $O/${N}_bench_cfg3.json 2>/dev/null
 python bench.py --shared-scale --steps 200 > $O/${N}_bench_cfg5_n1.json 2>/dev/null
 python bench.py --depth --parity-seeds 0 --multi-clip 0 > $O/${N}_bench_cfg2_depth.json 2>/dev/null          # cfg2 as BASELINE.json words it (sil/kp/depth/smooth)
+python bench.py --pose-init 500 > $O/${N}_bench_poseinit.json 2>/dev/null                                     # object-pose initialisation
 # N > 1 ranks on the one GPU of this box (gloo moves the collectives' 4 bytes through the host): the launch line of the driver
 HOMAN_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 \
     bench.py --gpus 2 --steps 200 --warmup 20 --multi-clip 2 --steady 0 > $O/${N}_bench_cfg2_gpus2_gloo.json 2>/dev/null
