@@ -1271,8 +1271,21 @@ __device__ __forceinline__ void raster_reorder(int* __restrict__ wo_dyn, int* __
     if (tid == 0) *dyn_flag = 1u;
 }
 
-// 16 lanes per line (one DPP row), 16 lines per workgroup: a wave per line spent its life waiting on three dependent
-// memory round trips with 8 of 64 lanes loading; four lines per wave quarter the number of waves in flight.
+// 16 lanes per line (one DPP row) and LINES_NL consecutive lines per row, 16 rows per workgroup.  (History: a wave per line spent
+// its life waiting on three dependent memory round trips with 8 of 64 lanes loading; four lines per wave quartered the waves in
+// flight; two lines per ROW halve the workgroups again - 2 300 instead of 4 200 at one clip, about one resident round - and
+// the two lines' mask words arrive in the same 4-byte loads: consecutive lines are neighbouring 16-bit words of the same
+// tiles.  The sources of a 64-sample word are requested together, not one dependent load per set bit.  Four lines per row
+// make the rows with a line tangent to a band the launch's tail: 22 us at two, 32 us at four, 25.5 us at one.)
+#ifndef LINES_NL
+#define LINES_NL 2
+#endif
+// which 16 * LINES_NL lines the i-th of the n line workgroups takes (scheduling only)
+#ifdef LINES_REVERSED
+#define LINES_BLK(i, n) ((n) - 1 - (i))
+#else
+#define LINES_BLK(i, n) (i)
+#endif
 __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restrict__ planes,
                                                    const float* __restrict__ gimg, const float* __restrict__ dimg,
                                                    int mode, const float* __restrict__ upstream,
@@ -1294,8 +1307,8 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     const bool ts_on = hm_ts_enabled(ts_flag) && threadIdx.x == 0;
     if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 0, ts_t0);
     const int blk = (int)blockIdx.x;
-    __shared__ unsigned long long s_w[16][SWEEP_CUMW];
-    __shared__ int s_ex[16][SWEEP_CUMW];
+    __shared__ unsigned long long s_w[16][LINES_NL][SWEEP_CUMW];
+    __shared__ int s_ex[16][LINES_NL][SWEEP_CUMW];
     // the first `ncomp` workgroups build the work list of the edge sweeps (independent of the lines: one launch for both)
     if (blk < ncomp) {
         sweep_compact(blk, ncomp, fpt, faces9, boxes, owned, B, F, 2 * S, parts, sl, clip_len);
@@ -1313,43 +1326,79 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
     // (the 16 rows of a workgroup leave at different times: each folds its exit into the workgroup's own end slot)
     const bool ts_row = l == 0 && hm_ts_enabled(ts_flag);
-    const int is = 2 * S, wpl = is / 64;
-    const long L = (long)(blk - ncomp - nred) * 16 + grp;
-    const bool valid = L < 4L * B * is;
+    const int is = 2 * S, wpl = is / 64, T = is / 16;
+    // first of the row's LINES_NL lines (is is a multiple of 64: a row's lines share plane, orientation and frame)
+    const long L0 = ((long)(LINES_BLK(blk - ncomp - nred, (int)gridDim.x - ncomp - nred)) * 16 + grp) * LINES_NL;
+    const bool valid = L0 < 4L * B * is;
     // L = ((pl * 2 + axis) * B + b) * is + d0
-    const int d0 = (int)(L % is), b = (int)((L / is) % B), pa = (int)(L / ((long)is * B));
+    const int d00 = (int)(L0 % is), b = (int)((L0 / is) % B), pa = (int)(L0 / ((long)is * B));
     const int axis = pa & 1, pl = pa >> 1;
-    unsigned long long mine = 0ull;
-    if (valid && l < wpl) mine = hm_plane_word64(planes, b, is, axis, pl, d0, l);
-    // exclusive prefix of the word popcounts (wpl <= 16 words: one 16-lane row scan)
-    const int c = __popcll(mine);
-    int incl = c;
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);    // row_shr:1
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);    // row_shr:2
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);    // row_shr:4
-    incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);    // row_shr:8
-    const int excl = incl - c;
-    // line record: {64 mask bits, number of set bits before them} per word, one 16-byte load for a sweep end point and
-    // one cache line per line of up to 512 samples
-    if (valid && l < wpl) lrec[L * wpl + l] = make_uint4((unsigned)mine, (unsigned)(mine >> 32), (unsigned)excl, 0u);
-    // line summary for the sweeps' early-out, 8 bytes per (line, plane) at lsum[(((b*2 + axis)*is + d0)*2 + pl)*4 ..]:
-    // {first set position, last set position + 1 (0: empty line), mask of the non-empty 64-sample words}: an item whose sweep
-    // range cannot reach a set bit never looks further
-    {
-        int lo = mine ? 64 * l + __builtin_ctzll(mine) : 0xffff, hi = mine ? 64 * l + 64 - __builtin_clzll(mine) : 0;
+    // 64 samples [64 l, 64 l + 64) of the LINES_NL lines: four tiles' words, and in every tile the lines' words are neighbours
+    // (axis 1: sample row t = is - 1 - d0, so line j is word LINES_NL - 1 - j of the aligned group; axis 0: word j) - see
+    // hm_plane_word64
+    unsigned long long mine[LINES_NL];
+#pragma unroll
+    for (int j = 0; j < LINES_NL; ++j) mine[j] = 0ull;
+    if (valid && l < wpl) {
+        unsigned long long raw[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            long at;
+            if (axis) {
+                const int t = is - 1 - d00 - (LINES_NL - 1);          // lowest sample row of the group
+                at = hm_plane_at(b, t >> 4, 4 * l + jj, pl, T) + (t & 15);
+            } else {
+                at = hm_plane_at(b, T - 1 - (4 * l + jj), d00 >> 4, 2 + pl, T) + (d00 & 15);
+            }
+#if LINES_NL == 4
+            raw[jj] = *reinterpret_cast<const unsigned long long*>(planes + at);
+#elif LINES_NL == 2
+            raw[jj] = *reinterpret_cast<const unsigned int*>(planes + at);
+#else
+            raw[jj] = planes[at];
+#endif
+        }
+#pragma unroll
+        for (int j = 0; j < LINES_NL; ++j) {
+            const int sel = axis ? LINES_NL - 1 - j : j;
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) mine[j] |= ((raw[jj] >> (16 * sel)) & 0xffffull) << (16 * jj);
+        }
+    }
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < LINES_NL; ++j) {
+        const long L = L0 + j;
+        const int d0 = d00 + j;
+        // exclusive prefix of the word popcounts (wpl <= 16 words: one 16-lane row scan)
+        const int c = __popcll(mine[j]);
+        int incl = c;
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);    // row_shr:1
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);    // row_shr:2
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);    // row_shr:4
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);    // row_shr:8
+        const int excl = incl - c;
+        // line record: {64 mask bits, number of set bits before them} per word, one 16-byte load for a sweep end point and
+        // one cache line per line of up to 512 samples
+        if (valid && l < wpl) lrec[L * wpl + l] = make_uint4((unsigned)mine[j], (unsigned)(mine[j] >> 32), (unsigned)excl, 0u);
+        // line summary for the sweeps' early-out, 8 bytes per (line, plane) at lsum[(((b*2 + axis)*is + d0)*2 + pl)*4 ..]:
+        // {first set position, last set position + 1 (0: empty line), mask of the non-empty 64-sample words}: an item whose
+        // sweep range cannot reach a set bit never looks further
+        int lo = mine[j] ? 64 * l + __builtin_ctzll(mine[j]) : 0xffff, hi = mine[j] ? 64 * l + 64 - __builtin_clzll(mine[j]) : 0;
         lo = min(lo, __builtin_amdgcn_update_dpp(0xffff, lo, 0x111, 0xf, 0xf, false)); hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x111, 0xf, 0xf, false));
         lo = min(lo, __builtin_amdgcn_update_dpp(0xffff, lo, 0x112, 0xf, 0xf, false)); hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x112, 0xf, 0xf, false));
         lo = min(lo, __builtin_amdgcn_update_dpp(0xffff, lo, 0x114, 0xf, 0xf, false)); hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x114, 0xf, 0xf, false));
         lo = min(lo, __builtin_amdgcn_update_dpp(0xffff, lo, 0x118, 0xf, 0xf, false)); hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, false));
-        const unsigned wm = (unsigned)(__ballot(mine != 0ull) >> (16 * (grp & 3))) & 0xffffu;
+        const unsigned wm = (unsigned)(__ballot(mine[j] != 0ull) >> (16 * (grp & 3))) & 0xffffu;
         if (valid && l == 15)       // row_shr scans: lane 15 of the row holds the row's result
             *reinterpret_cast<uint2*>(lsum + ((((long)b * 2 + axis) * is + d0) * 2 + pl) * 4) =
                 make_uint2((unsigned)lo | ((unsigned)hi << 16), wm);
+        any = any || wm != 0u;
+        s_w[grp][j][l] = mine[j];
+        s_ex[grp][j][l] = excl;
     }
-    s_w[grp][l] = mine;
-    s_ex[grp][l] = excl;
-    __syncthreads();
-    if (!valid || s_ex[grp][SWEEP_CUMW - 1] + __popcll(s_w[grp][SWEEP_CUMW - 1]) == 0) {
+    wave_sync();          // (a row's words are written and read by lanes of ONE wave)
+    if (!valid || !any) {
         if (ts_row) atomicMax(ts_slots + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64());
         return;
     }
@@ -1357,31 +1406,48 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     const bool from_dimg = mode == 2 || (mode == 1 && upstream[0] > 0.0f);     // (modes 3 / 4 read gimg per sample below)
     const float* gi = (from_dimg ? dimg : gimg) + (long)b * S * S;
     const float gs = from_dimg ? upstream[0] * 2.0f : 0.f, ks = from_dimg ? keep_sum[b / clip_len] : 1.f;
+    const float up4 = mode == 4 ? upstream[b] * 2.0f : 0.f;
     const int* idx = idx_map + (long)b * is * is;
-    SweepSrc* out = srcs + L * is;
-    for (int k = 0; k < wpl; ++k) {
-        const unsigned long long w = s_w[grp][k];
-        if (w == 0ull) continue;
-        const int base = s_ex[grp][k];
+    const float* gfull = gimg + (long)b * is * is;
+#pragma unroll 1
+    for (int j = 0; j < LINES_NL; ++j) {
+        const int d0 = d00 + j;
+        SweepSrc* out = srcs + (L0 + j) * is;
+        for (int k = 0; k < wpl; ++k) {
+            const unsigned long long w = s_w[grp][j][k];
+            if (w == 0ull) continue;
+            const int base = s_ex[grp][j][k];
+            // the (up to four) sources of this lane in the word: all loads first, then the records
+            float gl[4];
+            int ow[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int pos = 16 * q + l;
-            if (!((w >> pos) & 1ull)) continue;
-            const int d1 = (k << 6) + pos;
-            const int xi = axis ? d1 : d0, yi = axis ? d0 : d1;
-            SweepSrc r;
-            r.d1 = d1;
-            float g;
-            if (mode == 3) g = gimg[((long)b * is + (is - 1 - yi)) * is + xi];       // per-sample gradient (no anti-aliasing)
-            else if (mode == 4) g = upstream[b] * 2.0f * gimg[((long)b * is + (is - 1 - yi)) * is + xi];   // fused per-sample L2
-            else {
-                g = gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
-                if (from_dimg) g = gs * g / ks / (float)clip_len;
-                g = 0.25f * g;
+            for (int q = 0; q < 4; ++q) {
+                const int pos = 16 * q + l;
+                gl[q] = 0.f;
+                ow[q] = -1;
+                if (!((w >> pos) & 1ull)) continue;
+                const int d1 = (k << 6) + pos;
+                const int xi = axis ? d1 : d0, yi = axis ? d0 : d1;
+                if (mode == 3 || mode == 4) gl[q] = gfull[(long)(is - 1 - yi) * is + xi];      // per-sample gradient (no anti-aliasing)
+                else gl[q] = gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
+                if (pl) ow[q] = idx[(long)yi * is + xi];
             }
-            r.g = g;
-            r.owner = pl ? idx[(long)yi * is + xi] : -1;
-            out[base + __popcll(w & ((1ull << pos) - 1ull))] = r;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int pos = 16 * q + l;
+                if (!((w >> pos) & 1ull)) continue;
+                SweepSrc r;
+                r.d1 = (k << 6) + pos;
+                float g = gl[q];
+                if (mode == 4) g = up4 * g;                                   // fused per-sample L2
+                else if (mode != 3) {
+                    if (from_dimg) g = gs * g / ks / (float)clip_len;
+                    g = 0.25f * g;
+                }
+                r.g = g;
+                r.owner = ow[q];
+                out[base + __popcll(w & ((1ull << pos) - 1ull))] = r;
+            }
         }
     }
     if (ts_row) atomicMax(ts_slots + 2 * blockIdx.x + 1, (unsigned long long)wall_clock64());
@@ -2341,7 +2407,7 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
     // whether it is launched alone or in a batch
     const int fpt = (long)clip_len * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks
     const int ncomp = (B / clip_len) * hm_cdiv((long)clip_len * F, 256 * fpt);
-    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + nred + hm_cdiv(4L * B * 2 * S, 16)), dim3(256), 0, stream, w.planes,
+    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + nred + hm_cdiv(4L * B * 2 * S, 16 * LINES_NL)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
                        w.owned, F, w.parts, w.sweep, clip_len, w.lsum, nred, w.partials, w.frame_rec, loss_out, out_stride,
                        w.counter + 24, w.ts + 2 * ts_raster_units(B, S));

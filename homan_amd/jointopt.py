@@ -173,7 +173,7 @@ class GraphStepper:
             self.log = _DeviceLog(list(loss_dict) + list(metric_dict) + ["loss"], max_steps, self.opt.step_t)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph = _lib.new_graph()
         with torch.cuda.graph(self.graph):
             loss_dict, metric_dict, total = self._fwd_bwd(record=True)
             self.opt.step()
@@ -506,13 +506,13 @@ class FusedStepper:
             prev_nn_pad = tune.hm_tune_nn_lds_pad(nn_pad)
             prev_fam = [tune.hm_tune_lds_pad(i, v) for i, v in enumerate(fam_pads)]
             try:
-                self.graph = torch.cuda.CUDAGraph()
+                self.graph = _lib.new_graph()
                 with torch.cuda.graph(self.graph, stream=self.cap_stream):
                     self.forward_backward(log=not self.log_in_adam)
                     if not self.shared_scale:
                         self.opt.step(zero_grad=False, log=self._adam_log())
                 if self.shared_scale:        # the all-reduce of the scale gradient runs between two captured halves
-                    self.graph_b = torch.cuda.CUDAGraph()
+                    self.graph_b = _lib.new_graph()
                     with torch.cuda.graph(self.graph_b, stream=self.cap_stream):
                         self._spread_shared_scale_grad()
                         self.opt.step(zero_grad=False)

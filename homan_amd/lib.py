@@ -161,3 +161,18 @@ def terms(pairs):
 def check(rc, what):
     if rc != 0:
         raise HomanAmdError(f"{what} failed with code {rc}")
+
+
+# Graphs kept alive for the life of the process (HOMAN_KEEP_GRAPHS=1, set by tests/conftest.py).  ROCm 7.0's graph executor
+# has crashed in hip::Graph::UpdateStreams at the replay of a NEW graph after several dozen graphs had been created AND
+# destroyed in the process (a test suite; never seen in a fitting process, which builds a handful) - graphs that are never
+# destroyed do not trigger it.  A captured graph here owns no large buffers (the steppers allocate before capture).
+_KEPT_GRAPHS = []
+
+
+def new_graph():
+    import torch
+    g = torch.cuda.CUDAGraph()
+    if os.environ.get("HOMAN_KEEP_GRAPHS", "0") != "0":
+        _KEPT_GRAPHS.append(g)
+    return g

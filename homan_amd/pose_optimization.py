@@ -14,6 +14,7 @@ import torch.nn as nn
 from scipy.ndimage import distance_transform_edt
 
 from . import constants, ops
+from . import lib as _lib
 from .homan import matrix_to_rot6d
 
 NMR_FAR = 100.0
@@ -213,7 +214,7 @@ def _graph_loop(model, lr, num_iterations):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     if done < num_iterations:
-        graph = torch.cuda.CUDAGraph()
+        graph = _lib.new_graph()
         for p in params:
             p.grad.zero_()
         with torch.cuda.graph(graph):
@@ -234,7 +235,6 @@ def _fused_loop(model, lr, num_iterations):
     on torch's element-wise kernels (a third of its step) is gone.  The chamfer term is multiplied by its weight 0 at the
     reference's only call site and is not evaluated (PoseOptimizer.forward does the same).  Best-ever bookkeeping as in
     `_graph_loop`: the pose is copied AFTER the optimiser step that followed the evaluation (:348-353), strict `<`."""
-    from . import lib as _lib
     from .jointopt import HmAdam
     assert model.lw_chamfer == 0, "the fused loop covers the reference's configuration (lw_chamfer = 0)"
     L, P, ck = _lib.lib(), _lib.ptr, _lib.check
@@ -292,7 +292,7 @@ def _fused_loop(model, lr, num_iterations):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     if done < num_iterations:
-        graph = torch.cuda.CUDAGraph()
+        graph = _lib.new_graph()
         with torch.cuda.graph(graph):
             step()
         for _ in range(num_iterations - done):

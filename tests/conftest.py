@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# see homan_amd.lib.new_graph: the suite creates (and would destroy) ~100 hipGraphs in one process
+os.environ.setdefault("HOMAN_KEEP_GRAPHS", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
@@ -25,11 +29,14 @@ def _release_device_objects():
     has crashed inside the HIP runtime at a later replay)."""
     yield
     import gc
-    gc.collect()
     try:
         import torch
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-            torch.cuda.empty_cache()
+        gpu = torch.cuda.is_available()
     except ImportError:
-        pass
+        gpu = False
+    if gpu:
+        torch.cuda.synchronize()         # (nothing of the test is in flight when its graphs are destroyed)
+    gc.collect()
+    if gpu:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
