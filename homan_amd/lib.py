@@ -163,16 +163,16 @@ def check(rc, what):
         raise HomanAmdError(f"{what} failed with code {rc}")
 
 
-# Graphs kept alive for the life of the process (HOMAN_KEEP_GRAPHS=1, set by tests/conftest.py).  ROCm 7.0's graph executor
-# has crashed in hip::Graph::UpdateStreams at the replay of a NEW graph after several dozen graphs had been created AND
-# destroyed in the process (a test suite; never seen in a fitting process, which builds a handful) - graphs that are never
-# destroyed do not trigger it.  A captured graph here owns no large buffers (the steppers allocate before capture).
+# Graphs are kept alive for the life of the process (HOMAN_KEEP_GRAPHS=0 switches that off).  ROCm 7.0's graph executor has
+# crashed in hip::Graph::UpdateStreams at the first replay of a NEW graph after several dozen graphs had been created AND
+# destroyed in the process - a test suite, or a fitting process that walks a dataset clip by clip, one stepper per clip.
+# Graphs that are never destroyed do not trigger it, and a captured graph here owns no large buffer (the steppers allocate
+# before capture): a few kilobytes per fitted clip.
 _KEPT_GRAPHS = []
 
 
 def new_graph():
-    import torch
     g = torch.cuda.CUDAGraph()
-    if os.environ.get("HOMAN_KEEP_GRAPHS", "0") != "0":
+    if os.environ.get("HOMAN_KEEP_GRAPHS", "1") != "0":
         _KEPT_GRAPHS.append(g)
     return g

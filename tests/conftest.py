@@ -8,10 +8,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# see homan_amd.lib.new_graph: the suite creates (and would destroy) ~100 hipGraphs in one process
-os.environ.setdefault("HOMAN_KEEP_GRAPHS", "1")
-
-
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
