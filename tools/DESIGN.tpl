@@ -184,7 +184,7 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | **`k_raster_fwd`** | workgroup = one 32×32-sample region: scans the faces of its super-region; candidates are split by WINDING CLASS - the class that holds the camera-facing surface of the mesh (a scheduling hint set by `calibrate()` from the index map; any value is correct) fills the candidate array from the front, the other from the back; one thread per candidate builds the face record in LDS (+ the nearest depth the face can produce); the (candidate, 4×4-sample block) units are **flattened** over the 256 threads (binary search of the exclusive unit counts); visibility = `ds_min_u64` on an LDS z-buffer keyed (depth bits ≪ 32 \| face) = strict z test in ascending face order, bit-exact.  The near class runs first; then per 4×4 block the largest owner depth is taken (`hz`), and the units of the far class are first tested against it, 64 per wave trip, the survivors queued per wave and the unit body run on FULL waves of survivors (a divergent early-out would leave the wave paying for its one visible unit: on a closed mesh ~85 % of the far units are hidden).  Sample positions of power-of-two grids by one multiplication (eight IEEE divisions per unit before).  Epilogue per 8×8 output tile: index map, pooled silhouette, fused masked-MSE terms, alpha plane and the four sweep bit planes of the backward (one full cache line per tile, ballots picked with selects: no scratch); in a fixed loop (`persistent_outputs`) an empty bin in front of outputs that already hold the empty pattern leaves before touching LDS (60 % of the workgroups).  25 KB of LDS and 80 VGPRs: 6 workgroups per CU (4 before: +20 %) | latency × residency, then VALU (`valu_frac` 0.54) | B·(F·49 + 512²·4 + 4·S²·4 + 5·512²/8) = **72.2 MB** |
 | `k_sil_reduce` | block / frame + last-block finish.  One clip: the same body rides as B extra workgroups at the front of the `k_bwd_lines` launch (`hm_sil_bwd_clips(..., loss_out)`): the value is only logged, so it costs no launch; a clip batch keeps it on the third stream | latency | 0.5 MB |
 | `k_bwd_masks` | generic backward only (arbitrary `dL/dsilhouette`, or a negative loss weight): wave / tile, sweep planes via ballots | HBM | ≈ 21 MB |
-| `k_bwd_lines` | one DPP row (16 lanes) / (plane, orientation, frame, line), 16 lines / workgroup: expands a bit line into a position-sorted array of sources {d1, g, owner} + a 16-byte record per 64-bit word {mask, sources before it} (row scan).  Its first ⌈B·F/256⌉ workgroups build the **work list** of the sweeps instead: faces that own a sample → 64-byte records laid end to end in one global item space (block scan, one 64-bit atomic per block; a block's items start on a 64-item boundary so that the composition of every unit — and with it every summation order — is independent of the order in which blocks draw their bases) | latency | B·(4·512²/8 + S²·4 + 512² + F·46) = 23.8 MB |
+| `k_bwd_lines` | one DPP row (16 lanes) per TWO consecutive lines of a (plane, orientation, frame), 32 lines / workgroup (their mask words arrive in the same 4-byte loads; the launch is about one resident round of workgroups): expands a bit line into a position-sorted array of sources {d1, g, owner} + a 16-byte record per 64-bit word {mask, sources before it} (row scan).  Its first ⌈B·F/256⌉ workgroups build the **work list** of the sweeps instead: faces that own a sample → 64-byte records laid end to end in one global item space (block scan, one 64-bit atomic per block; a block's items start on a 64-item boundary so that the composition of every unit — and with it every summation order — is independent of the order in which blocks draw their bases) | latency | B·(4·512²/8 + S²·4 + 512² + F·46) = 23.8 MB |
 | **`k_bwd_sweep`** | persistent waves; a **unit** = 256 consecutive (face, winding, edge, axis, d0) items of the global list, whichever faces they belong to (a big face spreads over several waves, small faces share one), handled per pass of ≤ 16 faces staged in LDS together with their per-(face, family) constants - edge slope, first line, end-point order: one IEEE division per family instead of one per item, built by the wave right after the staging - and per-(face, axis) inward ranges.  **Stage 1** (every item, 64 per trip, four trips whose loads are all in flight before the first is tested): family by a 4-step search of the cumulative counts, line geometry from the family constants, then three loads requested together: the line's 16-byte summary, the owner of the sample just inside the edge and the alpha word of the sample just outside - the outward sweep needs a sample this winding owns AND a plane-0 source beyond the edge (exact from first / last position), the inward sweep an empty sample outside AND a plane-1 source inside the triangle's extent (positions + word mask); in the steady state of a fit 71 % of the items stop here (1.95 M items → 557 k, of which 555 k do have pairs) and the rest are queued with the two decisions.  **Stage 2** (queued items on full waves): two 16-byte record loads + popcounts give the slices `[lo, lo+nb)` of the line's source array; the (item, source) pairs are **flattened** over the wave, four consecutive pairs per lane, item of a pair by scatter + max-scan; per-lane running sums flushed into the face's six LDS accumulators when the (face, corner) target changes; a face inside one unit is stored, a face cut by one unit boundary is added by two commutative hardware float atomics, a face over ≥ 3 units goes through per-unit partials + ticket (deterministic in all three cases); **XCD-aware**: each XCD (workgroup id mod 8) takes one contiguous eighth of the units, so a frame's index-map lines, line records and source slices are fetched into one L2 instead of eight | VALU issue + dependent-load latency (`valu_frac` 0.48) | B·(F·(68+24) + 512²·4 + 512²) = **47.6 MB** |
 | `k_bwd_gather` | thread / vertex over CSR adjacency: one `float2` per (face, corner) (deterministic, no atomics) + projection backward.  Autograd path only: the fused loop gathers inside `k_rigid_bwd` (`hm_rigid_bwd_sil`) | HBM | B·(F·24·2 + V·24) = 5.4 MB |
 | `k_rigid_fwd/bwd` | forward: thread / vertex; backward: grid (frame, 256-vertex chunk), sums up to four weighted per-vertex gradient terms + a per-frame vector + optionally the silhouette gradient gathered from the sweeps' per-corner output (no gather / linear-combination launches), 13 block sums behind two barriers, per-frame ticket, rot6d backward by the finishing workgroup | latency | ≤ 4·B·V·12 |
@@ -346,7 +346,11 @@ file the reference never reaches.  More than two hands: the reference's own coll
 ## 8. Known gaps / next (ranked)
 
 1. Kernel targets of the last verdict (raster ≤ 38, sweep ≤ 38, lines ≤ 18 µs in the graph; driver-flag line ≥ 5500,
-   8-clip batch ≥ 9500 it/s) are not met: 45 / 46 / 26 µs, 4 790 and 8 800 it/s.  What the round's counters say is left:
+   8-clip batch ≥ 9500 it/s) are not met: 45 / 46 / 22 µs, 4 820 and 8 980 it/s.  The sweep is issue-bound at its 96 registers
+   (2 250 VALU wave-instructions per 256-item unit, ~85 % of the issue slots until its tail; 10 % of the waves run 16 us
+   longer than the other 90 %), so neither more waves, nor pipelined pair rounds, nor other unit sizes helped
+   (EXPERIMENTS.md); the object-gradient + Adam tail of the chain does not get shorter inside the sweep launch either (a
+   cross-queue edge in front of a long node costs the graph executor ~20 us).  What the round's counters say is left:
    the raster spends 7-8 dependent global round trips per workgroup (a 16-byte `{face, box}` bin entry and vertices staged
    by the scanning thread would remove two of them) and ~2.6 VALU issue slots + a VCC hazard per inside test; the sweep's
    stage 1 costs ~250 instructions per 64 items, 71 % of which it rejects (a per-(face, family) reject before the items
