@@ -197,7 +197,62 @@ __global__ __launch_bounds__(256) void k_offscreen(const float* __restrict__ ver
     if (threadIdx.x == 0) out[n] = weight * acc;
 }
 
+// Best-ever bookkeeping of the pose initialisation's loop (reference homan/pose_optimization.py:340-353), one workgroup:
+// losses[i] = sums[i * stride] + extra[i]; (lmin, ind) = first minimum (torch.argmin); if lmin < best_loss[0] (strict; a NaN
+// among the losses makes the minimum NaN, as torch.min does: no update) the pose of candidate `ind` - as it is NOW, i.e. after
+// the optimiser step that followed the evaluation - becomes the best one.
+__global__ __launch_bounds__(256) void k_pose_keep_best(const float* __restrict__ sums, int stride, const float* __restrict__ extra,
+                                                        int n, const float* __restrict__ rot6d, const float* __restrict__ trans,
+                                                        float* __restrict__ best_loss, float* __restrict__ best_rot,
+                                                        float* __restrict__ best_trans, float* __restrict__ losses_out)
+{
+    __shared__ float s_v[4];
+    __shared__ int s_i[4], s_nan[4];
+    float v = INFINITY;
+    int at = 0x7fffffff, bad = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float l = sums[(long)i * stride] + extra[i];
+        losses_out[i] = l;
+        if (l != l) bad = 1;
+        if (l < v) { v = l; at = i; }           // (ascending i per thread: the first minimum of the thread)
+    }
+    // wave minimum with the lowest index among equals, then the four waves
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(v, o);
+        const int oi = __shfl_xor(at, o);
+        bad |= __shfl_xor(bad, o);
+        if (ov < v || (ov == v && oi < at)) { v = ov; at = oi; }
+    }
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_v[w] = v; s_i[w] = at; s_nan[w] = bad; }
+    __syncthreads();
+    if (threadIdx.x < 9) {
+        float bv = s_v[0];
+        int bi = s_i[0], nb = s_nan[0];
+        for (int k = 1; k < 4; ++k) {
+            nb |= s_nan[k];
+            if (s_v[k] < bv || (s_v[k] == bv && s_i[k] < bi)) { bv = s_v[k]; bi = s_i[k]; }
+        }
+        // (lanes 0..8 are one wave: all of them have read best_loss before lane 0 writes it)
+        const bool better = !nb && bi < n && bv < best_loss[0];
+        if (better) {
+            const int e = threadIdx.x;
+            if (e < 6) best_rot[e] = rot6d[(long)bi * 6 + e];
+            else best_trans[e - 6] = trans[(long)bi * 3 + (e - 6)];
+            if (e == 0) best_loss[0] = bv;
+        }
+    }
+}
+
 extern "C" {
+int hm_pose_keep_best(const float* sums, int stride, const float* extra, int n, const float* rot6d, const float* trans,
+                      float* best_loss, float* best_rot6d, float* best_trans, float* losses_out, hipStream_t stream)
+{
+    HM_CHECK_ARG(sums && extra && rot6d && trans && best_loss && best_rot6d && best_trans && losses_out && n > 0 && stride > 0);
+    hipLaunchKernelGGL(k_pose_keep_best, dim3(1), dim3(256), 0, stream, sums, stride, extra, n, rot6d, trans, best_loss,
+                       best_rot6d, best_trans, losses_out);
+    return hm_launch_status();
+}
 int hm_offscreen_fwd(const float* verts, const float* K, int N, int V, float zfar, float weight, float* out, float* grad,
                      hipStream_t stream)
 {

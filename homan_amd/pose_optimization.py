@@ -252,7 +252,7 @@ def _fused_loop(model, lr, num_iterations):
         p.grad = torch.zeros_like(p)
     opt = HmAdam([{"params": params, "lr": lr}])
     tp, tw, tn = _lib.terms([(g_off, 1.0)])
-    best_loss = torch.full((), float("inf"), device=dev)
+    best_loss = torch.full((1,), float("inf"), device=dev)
     best_rot, best_trans = torch.zeros_like(model.rotations[0]), torch.zeros_like(model.translations[0])
     losses_out = f(n)
 
@@ -272,15 +272,9 @@ def _fused_loop(model, lr, num_iterations):
                               P(K_all), 1.0, F, n, V, P(model.rotations.grad), P(model.translations.grad), None, P(rws), st),
            "hm_rigid_bwd_sil")
         opt.step(zero_grad=False)
-        with torch.no_grad():
-            losses = frame[:, 0] + off           # mask + (chamfer = 0) + offscreen, the order of sum(loss_dict.values())
-            lmin, ind = losses.min(0)
-            better = lmin < best_loss
-            best_loss.copy_(torch.where(better, lmin, best_loss))
-            sel = ind.reshape(1)
-            best_rot.copy_(torch.where(better, model.rotations.index_select(0, sel)[0], best_rot))
-            best_trans.copy_(torch.where(better, model.translations.index_select(0, sel)[0], best_trans))
-            losses_out.copy_(losses)
+        # mask + (chamfer = 0) + offscreen, the order of sum(loss_dict.values()); best-ever bookkeeping in the same launch
+        ck(L.hm_pose_keep_best(P(frame), 2, P(off), n, P(model.rotations), P(model.translations), P(best_loss), P(best_rot),
+                               P(best_trans), P(losses_out), st), "hm_pose_keep_best")
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())

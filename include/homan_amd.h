@@ -67,6 +67,11 @@ int hm_rigid_bwd_sil(const float* mesh, const float* rot6d, const float* scale, 
  * out[n] = weight * sum_v (...), grad (N,V,3) = d out[n] / d verts[n]. */
 int hm_offscreen_fwd(const float* verts, const float* K, int N, int V, float zfar, float weight, float* out, float* grad,
                      hipStream_t stream);
+/* Best-ever bookkeeping of the pose initialisation's loop, reference homan/pose_optimization.py:340-353, in one launch:
+ * losses_out[i] = sums[i * stride] + extra[i]; if the first minimum (torch.argmin) is < best_loss[0], candidate ind's CURRENT
+ * rot6d (6) / trans (3) and the minimum are copied to best_rot6d / best_trans / best_loss (one float, start it at +inf). */
+int hm_pose_keep_best(const float* sums, int stride, const float* extra, int n, const float* rot6d, const float* trans,
+                      float* best_loss, float* best_rot6d, float* best_trans, float* losses_out, hipStream_t stream);
 /* out = s[0] * in ;  out = s0[0]*a + s1[0]*b   (backward of the losses whose unit gradient is produced forward) */
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream);
 int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s1, long n, float* out,

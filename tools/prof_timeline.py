@@ -22,8 +22,9 @@ def main(path, marker="k_adam", back=3):
         if short.startswith("_Z"):
             import re
             m = re.match(r"_Z(\d+)", short)
-            n = int(m.group(1))
-            short = short[2 + len(m.group(1)):2 + len(m.group(1)) + n]
+            if m:                                    # (plain names only; templates / namespaces are printed mangled)
+                n = int(m.group(1))
+                short = short[2 + len(m.group(1)):2 + len(m.group(1)) + n]
         print(f"{(st-t0)/1e3:9.1f} {(en-st)/1e3:8.1f} {(en-t0)/1e3:8.1f} {q:3d} {sid:3d}  {short[:60]}")
 
 
