@@ -2199,7 +2199,6 @@ __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__
 {
     __shared__ float red[16];
     __shared__ int s_flag;
-    __shared__ float s_t[5];
     const int b = blockIdx.y;
     const long base = (long)b * S * S;
     const int per = (S * S + ORD_CHUNKS - 1) / ORD_CHUNKS, i0 = blockIdx.x * per, i1 = min(S * S, i0 + per);
