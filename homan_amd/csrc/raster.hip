@@ -999,24 +999,27 @@ __device__ __forceinline__ float sample_grad(const float* __restrict__ gimg, int
     return 0.25f * gimg[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
 }
 
-// contribution of sample d1 (pseudo-distance of the crossing to the two end points of the edge)
-__device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, float c0, float c1, bool use0, bool use1,
-                                           float eps, float two_over_is, bool pow2, int is, float& acc0, float& acc1)
+// contribution of sample d1 (pseudo-distance of the crossing to the two end points of the edge).  k0 / k1: the item's
+// constants c * 2 / is, folded once per item (sweep_item_scale) instead of three multiplications per pair and end point
+__device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, float k0, float k1, bool use0, bool use1,
+                                           float eps, float& acc0, float& acc1)
 {
     // straight-line (selects, no branches): every listed source has diff > 0 and nearly every item uses both end points, so
     // the conditions are almost always true and a taken branch costs more than the arithmetic it would skip.  A masked term
     // is an exact +0: acc - 0 == acc.
     const float t = (float)d1 - d1_cross;
     const bool live = diff > 0.0f;
-    float dist0 = c0 * t * 2.0f, dist1 = c1 * t * 2.0f;
-    if (pow2) { dist0 = dist0 * two_over_is; dist1 = dist1 * two_over_is; }       // exact either way when is is a power of two
-    else { dist0 = dist0 / (float)is; dist1 = dist1 / (float)is; }
-    dist0 = (0.0f < dist0) ? dist0 + eps : dist0 - eps;
-    dist1 = (0.0f < dist1) ? dist1 + eps : dist1 - eps;
+    float dist0 = k0 * t, dist1 = k1 * t;
+    dist0 += (0.0f < dist0) ? eps : -eps;          // (dist == 0 goes to -eps, like the reference's `0 < dist` test)
+    dist1 += (0.0f < dist1) ? eps : -eps;
     // 1-ulp reciprocal: the pseudo-gradient is compared at 1e-3
     const float g0 = diff * __builtin_amdgcn_rcpf(dist0), g1 = diff * __builtin_amdgcn_rcpf(dist1);
     acc0 -= (live && use0) ? g0 : 0.0f;
     acc1 -= (live && use1) ? g1 : 0.0f;
+}
+__device__ __forceinline__ float sweep_item_scale(float c, float two_over_is, bool pow2, int is)
+{
+    return pow2 ? (c * 2.0f) * two_over_is : (c * 2.0f) / (float)is;
 }
 
 // ---------------------------------------------------------------- backward, pass 2b (edge sweeps): work list
@@ -1834,7 +1837,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                 __builtin_amdgcn_wave_barrier();
                 s_start[wv][lane] = incl - n;
                 SweepItem it;
-                it.x = d1_cross; it.c0 = c0; it.c1 = c1;
+                it.x = d1_cross;
+                it.c0 = sweep_item_scale(c0, inv_is, pow2, is);
+                it.c1 = sweep_item_scale(c1, inv_is, pow2, is);
                 it.base0 = (int)(lid[0] * is) + lo[0];
                 it.base1 = (int)(lid[1] * is) + lo[1];
                 it.nb0 = nb0;
@@ -1927,7 +1932,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                             // (an inward pair counts only if this winding owns the source: masked by a zero `diff`)
                             const bool take = valid && (!ph1[k] || sc[k].owner == qq.fn);
                             sweep_term(take ? (ph1[k] ? sc[k].g : -sc[k].g) : 0.0f, sc[k].d1, qq.x, qq.c0, qq.c1,
-                                       (meta & (1 << 10)) != 0, (meta & (1 << 11)) != 0, eps, inv_is, pow2, is, acc0, acc1);
+                                       (meta & (1 << 10)) != 0, (meta & (1 << 11)) != 0, eps, acc0, acc1);
                         }
                     }
                 }
