@@ -115,6 +115,56 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_obj(const int* __restric
         go[i] = -(float)(long long)acc[i] * (1.0f / CONTACT_FIX);
 }
 
+// Both sides in ONE launch for meshes of one range (Vo <= CONTACT_MAX_VO): the hand vertex's gradient goes to memory and,
+// from the register, into the frame's fixed-point accumulators - the same values and the same (order-free) integer sums as
+// the two launches, one launch less on the hand-side chain of the step-2 loss sets.  grid (B)
+__global__ __launch_bounds__(NN_THREADS) void k_contact_both(const float* __restrict__ vh, const float* __restrict__ vo,
+                                                              const int* __restrict__ nn_idx, int B, int Vh, int Vo,
+                                                              float thresh, float* __restrict__ g_hand,
+                                                              float* __restrict__ g_obj, float* __restrict__ partials,
+                                                              unsigned int* counter, float* __restrict__ out, int clip_len,
+                                                              int out_stride)
+{
+    HM_LATENCY_KERNEL();
+    __shared__ unsigned long long acc[CONTACT_MAX_VO * 3];
+    __shared__ float red[16];
+    __shared__ int s_flag;
+    const int b = blockIdx.x, clip = b / clip_len, bl = b - clip * clip_len;
+    partials += (long)clip * HM_RED_WS_FLOATS;
+    counter += (long)clip * HM_RED_WS_FLOATS;
+    const float inv_cnt = 1.0f / (float)((long)clip_len * Vh);        // the mean runs over the clip's frames
+    // (the picks and the hand vertices are requested before the accumulators are cleared)
+    for (int i = threadIdx.x; i < 3 * Vo; i += NN_THREADS) acc[i] = 0ull;
+    __syncthreads();
+    float lsum = 0.f;
+    for (int i = threadIdx.x; i < Vh; i += NN_THREADS) {
+        const int j = nn_idx[(long)b * Vh + i];
+        const float* h = vh + ((long)b * Vh + i) * 3;
+        const float* o = vo + ((long)b * Vo + j) * 3;
+        const float dx = o[0] - h[0], dy = o[1] - h[1], dz = o[2] - h[2];
+        const float a = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float th = tanhf(a / thresh);
+        lsum += thresh * th;
+        const float k = (a > 0.f) ? (1.0f - th * th) / a * inv_cnt : 0.f;     // d val / d a  / a
+        const float g[3] = {-k * dx, -k * dy, -k * dz};                       // d a / d h = -diff / a
+        float* gh = g_hand + ((long)b * Vh + i) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gh[c] = g[c];
+            atomicAdd(&acc[3 * j + c], (unsigned long long)(long long)__float2ll_rn(g[c] * CONTACT_FIX));
+        }
+    }
+    lsum = hm_block_sum(lsum, red);          // (its barriers also order the atomics above before the reads below)
+    float* go = g_obj + (long)b * Vo * 3;
+    for (int i = threadIdx.x; i < 3 * Vo; i += NN_THREADS)
+        go[i] = -(float)(long long)acc[i] * (1.0f / CONTACT_FIX);
+    if (threadIdx.x == 0) hm_partial_store(partials + bl, lsum);
+    if (hm_last_block(counter, clip_len, &s_flag)) {
+        const float t = hm_last_block_sum(partials, clip_len, 1, red);
+        if (threadIdx.x == 0) out[(long)clip * out_stride] = t * inv_cnt;
+    }
+}
+
 extern "C" {
 // workspace: reuse hm_reduce_workspace_bytes() layout (partials + counter), one slice per clip; needs
 // clip frames * ceil(Vh/128) <= 512 partial floats.
@@ -182,6 +232,12 @@ int hm_contact_fwd_clips(const float* verts_hand, const float* verts_obj, const 
     HM_CHECK_ARG(B > 0 && Vh > 0 && Vo > 0 && HM_CLIP_LEN_OK(B, clip_len));
     const int Bc = clip_len ? clip_len : B;
     HM_CHECK_ARG(Bc <= 512);
+    if (Vo <= CONTACT_MAX_VO) {          // one range of object vertices: both sides in one launch
+        hipLaunchKernelGGL(k_contact_both, dim3(B), dim3(NN_THREADS), 0, stream, verts_hand, verts_obj, nn_idx, B, Vh, Vo,
+                           thresh, g_hand, g_obj, (float*)workspace, (unsigned int*)((float*)workspace + 512), out1, Bc,
+                           out_stride);
+        return hm_launch_status();
+    }
     hipLaunchKernelGGL(k_contact_hand, dim3(B), dim3(NN_THREADS), 0, stream, verts_hand, verts_obj, nn_idx, B, Vh, Vo,
                        thresh, g_hand, (float*)workspace, (unsigned int*)((float*)workspace + 512), out1, Bc, out_stride);
     hipLaunchKernelGGL(k_contact_obj, dim3(B, hm_cdiv(Vo, CONTACT_MAX_VO)), dim3(NN_THREADS), 0, stream, nn_idx, g_hand, B, Vh,

@@ -192,6 +192,7 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | `k_hand_terms` | 2-D reprojection + temporal smoothness + priors of the hand in one launch, one ticket | latency | ≈ 1.5 MB |
 | **`k_pair_terms`** (`csrc/pairterms.hip`) | one clip: the terms that start from the two vertex buffers and feed nothing to each other as BLOCK RANGES of one grid - [search \| interaction \| hand terms \| object smoothness] - each with its own reduce workspace and ticket; the search is the metric-only one on the step-1 sets and the FULL one (`nn_full_body`, the body of `k_nn`, with the contact launches behind it) when the contact term is on (cfg3: 214 → 202 µs per iteration).  The bodies are shared with the stand-alone kernels (`pair_bodies.h`: device functions on virtual block coordinates), so the floats are the same either way (`test_pair_terms_launch_equals_its_four_entry_points`, and every batched == single test: batches use the stand-alone launches).  Four launches and three graph edges of the hand-side chain become one: 5100 → 5430 it/s | latency | ≈ 2 MB |
 | `k_smooth`, `k_inter`, `k_contact_hand` | grid-stride + "last block finishes" ticket | latency | 10–100 KB |
+| `k_contact_both` | contact term, both sides in one launch (object meshes of ≤ 4096 vertices; larger: `k_contact_hand` + `k_contact_obj` over ranges of 4096): per frame the hand vertices' gradients go to memory and, from the register, into 64-bit fixed-point LDS accumulators of the object's vertices (order-free integer sums: deterministic) | latency | B·(778·36 + V·12) |
 | `k_nn` | (contact term on) 128 hand vertices (2 / lane) × 4 waves splitting the object vertices; 64-vertex groups broadcast with `v_readlane` (SGPR operands) | VALU | B·(778+V)·12 |
 | `k_nn_min` | (step-1 sets: the search only feeds the logged hand-object distance) bounding spheres of 64-vertex groups of the Morton-ordered rigid mesh, carried from a mesh-space table into the frame; per group a lower bound for the workgroup's 128 hand vertices (nearest centre distance − radius); the four groups with the smallest bounds are scanned first, one per wave, and their exact minimum is the upper bound - with "centre distance + radius" 21.5 of the 24 groups of the bottle passed when the hand touches it, now 5.6 do; scans run four object vertices per trip on scalar trip counts with the minima kept as integer bits (a wave is alone on its SIMD: the independent chains hide the arithmetic latency); the result is the same float as `k_nn`'s.  42 → 24 µs stand-alone, and this launch range was the longest link of the hand-side chain | latency | B·(778+V)·12 |
 | `k_contact_obj` | block / frame: hand-vertex gradients added into an LDS accumulator with 64-bit **fixed-point** atomics (order-independent ⇒ deterministic without a sort; the picks are skewed onto a few object vertices) | LDS | B·(778·16 + V·12) |
