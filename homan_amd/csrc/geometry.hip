@@ -6,55 +6,6 @@
 // as used by homan/homan.py:298-307 (object) and :341-382 (hand).
 #include "hm_common.h"
 
-// dL/dR (3x3 row-major) -> dL/drot6d (3x2 row-major)
-__device__ __forceinline__ void rot6d_backward(const float* r6, const float* dR, float* dr6)
-{
-    const float a1[3] = {r6[0], r6[2], r6[4]}, a2[3] = {r6[1], r6[3], r6[5]};
-    const float n1r = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
-    const float n1 = fmaxf(n1r, 1e-12f);
-    const float b1[3] = {a1[0] / n1, a1[1] / n1, a1[2] / n1};
-    const float d = b1[0] * a2[0] + b1[1] * a2[1] + b1[2] * a2[2];
-    const float u[3] = {a2[0] - d * b1[0], a2[1] - d * b1[1], a2[2] - d * b1[2]};
-    const float nur = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
-    const float nu = fmaxf(nur, 1e-12f);
-    const float b2[3] = {u[0] / nu, u[1] / nu, u[2] / nu};
-    float db1[3] = {dR[0], dR[3], dR[6]}, db2[3] = {dR[1], dR[4], dR[7]};
-    const float db3[3] = {dR[2], dR[5], dR[8]};
-    // b3 = b1 x b2
-    db1[0] += b2[1] * db3[2] - b2[2] * db3[1];
-    db1[1] += b2[2] * db3[0] - b2[0] * db3[2];
-    db1[2] += b2[0] * db3[1] - b2[1] * db3[0];
-    db2[0] += db3[1] * b1[2] - db3[2] * b1[1];
-    db2[1] += db3[2] * b1[0] - db3[0] * b1[2];
-    db2[2] += db3[0] * b1[1] - db3[1] * b1[0];
-    // b2 = u / max(|u|, eps)
-    float du[3];
-    if (nur > 1e-12f) {
-        const float s = b2[0] * db2[0] + b2[1] * db2[1] + b2[2] * db2[2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) du[i] = (db2[i] - b2[i] * s) / nu;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) du[i] = db2[i] / nu;
-    }
-    // u = a2 - (b1.a2) b1
-    float da2[3] = {du[0], du[1], du[2]};
-    const float dd = -(du[0] * b1[0] + du[1] * b1[1] + du[2] * b1[2]);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { db1[i] += -d * du[i] + dd * a2[i]; da2[i] += dd * b1[i]; }
-    float da1[3];
-    if (n1r > 1e-12f) {
-        const float s = b1[0] * db1[0] + b1[1] * db1[1] + b1[2] * db1[2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) da1[i] = (db1[i] - b1[i] * s) / n1;
-    } else {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) da1[i] = db1[i] / n1;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) { dr6[2 * i] = da1[i]; dr6[2 * i + 1] = da2[i]; }
-}
-
 // verts[n,v,:] = (s * mesh[n,v,:]) @ R[n] + t[n]      grid (chunks, N)
 __global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
                                                    const float* __restrict__ trans, const float* __restrict__ scale,
@@ -90,7 +41,6 @@ __global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mes
 // scale, R, t ; g_rigid (per-vertex) and g_frame (one vector per frame, the same for every vertex) reach R, t only
 // (gradients w.r.t. the mesh-detached twin of the vertices).  Summing the weighted terms here replaces a separate
 // linear-combination launch on the critical chain.  grid (N)
-struct RigidTerms { const float* p[5]; float w[5]; };
 // Optional fifth term: the silhouette gradient, gathered on the fly from the per-(face, corner) NDC gradients of the edge
 // sweeps (hm_sil_bwd called with grad_verts == NULL) and pushed through the projection backward -- the work of
 // k_bwd_gather, without its launch and without the (B,V,3) round trip on the critical chain.

@@ -11,13 +11,14 @@
 // index 3v+c, so a wave reading one row for 64 consecutive vertices is coalesced; the joint regressor is
 // folded on the host into J_template (16x3) + J_shapedirs (16x3x10).
 #include "hm_common.h"
+#include <string.h>
 
 #define MANO_V 778
 #define MANO_J 16
 #define MANO_NF 145   // 135 pose-blend features + 10 betas
 #define MANO_CHUNK 256
 #define MANO_NCHUNK 4  // ceil(778/256)
-#define MANO_PART 340  // per-(frame,chunk) partials: 192 dA + 145 dfeat + 3 dtrans
+#define MANO_PART 352  // per-(frame,chunk) partials: 192 dA + 145 dfeat + 3 dtrans + 12 of the fused rigid backward (dR, dt)
 #define MANO_NCH64 13  // ceil(778/64) vertex chunks of 64
 // forward state kept for the backward (per frame): the chain state (struct ManoShared, dword copy) + the posed vertices
 #define MANO_STATE_SH 832
@@ -452,9 +453,26 @@ static __device__ unsigned long long g_mano_ph[16];
 #else
 #define MPH_MARK(k)
 #endif
-// backward: grid (13, B).  First half per (vertex chunk, frame) -> partials (B, 13, 340); the workgroup that finishes
+// Optional (mesh != NULL): the backward of the hand's RIGID transform (k_rigid_bwd, geometry.hip) inside this launch.  The
+// gradient w.r.t. the model-space vertex that `gout` would hold is formed on the fly from the per-vertex terms on the
+// world-space vertex (same expressions as k_rigid_bwd), the chunk's twelve sums of dR / dt ride the chunk record, and the
+// frame's finishing workgroup turns them into d rot6d / d translation: one launch less on the hand-side chain.
+struct ManoRigid {
+    const float* mesh;            // (rows, 778, 3): the forward's model-space vertices
+    const float* rot6d;           // (rows, 3, 2)
+    const float* scale;           // one per clip of clip_len rows
+    int clip_len;
+    RigidTerms terms;             // weighted gradient terms on the world-space vertices (reach mesh, R, t)
+    const float* g_rigid;         // optional per-vertex term that reaches R, t only
+    const float* g_frame;         // optional per-row vector (frame_stride floats apart, times frame_scale) that reaches R, t only
+    int frame_stride;
+    float frame_scale;
+    float* g_rot6d; float* g_trans;
+};
+// backward: grid (13, B).  First half per (vertex chunk, frame) -> partials (B, 13, MANO_PART); the workgroup that finishes
 // the last chunk of a frame (per-frame ticket) runs the second half for that frame -- one launch, and the chain state is
 // reloaded from the forward (`state`) instead of being recomputed when the caller kept it.
+template <bool RIGID>
 __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* __restrict__ pca, int pca_stride,
                                                    const float* __restrict__ rot, const float* __restrict__ betas,
                                                    const float* __restrict__ gout, int B, const float* __restrict__ state,
@@ -462,7 +480,7 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
                                                    int pca_dim, const float* __restrict__ g_pca_extra, float w_extra,
                                                    float* __restrict__ g_pca, float* __restrict__ g_rot,
                                                    float* __restrict__ g_betas, float* __restrict__ g_trans, int row0,
-                                                   int row_stride)
+                                                   int row_stride, ManoRigid mr)
 {
     HM_HAND_KERNEL();
     __shared__ ManoShared sh;
@@ -493,12 +511,45 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
     }
     MPH_MARK(0);
     float g[3] = {0.f, 0.f, 0.f};
+    float racc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) racc[k] = 0.f;
     if (t < nv) {
         const int v = v0 + t;
         float T[12];
         mano_skin_transform(m, sh, v, T);
-        const float* gp = gout + ((long)b * MANO_V + v) * 3;
-        g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+        if (RIGID) {
+            // rigid backward of this vertex (the arithmetic of k_rigid_bwd): gf reaches the mesh, gt = gf + the rigid-only terms
+            const long o = ((long)b * MANO_V + v) * 3;
+            float R[9];
+            rot6d_to_mat(mr.rot6d + (long)b * 6, R);
+            const float s = mr.scale[b / mr.clip_len];
+            const float mv[3] = {mr.mesh[o], mr.mesh[o + 1], mr.mesh[o + 2]};
+            float gf[3] = {0.f, 0.f, 0.f}, gt[3];
+#pragma unroll
+            for (int k = 0; k < 5; ++k)
+                if (mr.terms.p[k]) {
+                    gf[0] += mr.terms.w[k] * mr.terms.p[k][o]; gf[1] += mr.terms.w[k] * mr.terms.p[k][o + 1];
+                    gf[2] += mr.terms.w[k] * mr.terms.p[k][o + 2];
+                }
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                gt[c] = gf[c] + (mr.g_frame ? mr.frame_scale * mr.g_frame[(long)b * mr.frame_stride + c] : 0.f);
+            if (mr.g_rigid) { gt[0] += mr.g_rigid[o]; gt[1] += mr.g_rigid[o + 1]; gt[2] += mr.g_rigid[o + 2]; }
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) racc[3 * i + j] = (s * mv[i]) * gt[j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) racc[9 + j] = gt[j];
+            // d(s*m)_i = sum_j R[i][j] gf_j ; d m = s * that
+            g[0] = s * (R[0] * gf[0] + R[1] * gf[1] + R[2] * gf[2]);
+            g[1] = s * (R[3] * gf[0] + R[4] * gf[1] + R[5] * gf[2]);
+            g[2] = s * (R[6] * gf[0] + R[7] * gf[1] + R[8] * gf[2]);
+        } else {
+            const float* gp = gout + ((long)b * MANO_V + v) * 3;
+            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+        }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             s_g[t][c] = g[c];
@@ -510,6 +561,12 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
     float* out = partials + ((long)lb * gridDim.x + blockIdx.x) * MANO_PART;
     const float tg0 = hm_block_sum(g[0], red), tg1 = hm_block_sum(g[1], red), tg2 = hm_block_sum(g[2], red);
     if (t == 0) { hm_partial_store(out + 337, tg0); hm_partial_store(out + 338, tg1); hm_partial_store(out + 339, tg2); }
+    if (RIGID) {
+        __syncthreads();
+        float* red12 = &s_part[0][0][0];          // (>= 16 * 12 floats; the posed-chunk scratch is free by now)
+        hm_block_sum_n<12>(racc, red12);
+        if (t < 12) hm_partial_store(out + 340 + t, racc[t]);
+    }
     __syncthreads();
     MPH_MARK(2);
     // dA[j][r][c] = sum_v W[v][j] g[v][r] [vp;1][c]
@@ -563,6 +620,17 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
     MPH_MARK(5);
     if (s_flag) {
         mano_bwd2_body(m, sh, w2, partials, gridDim.x, lb, b, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans);
+        if (RIGID) {
+            __syncthreads();
+            if (t == 0) {              // the frame's dR (9) and dt (3), summed over the chunks in chunk order by the body above
+                float dr6[6];
+                rot6d_backward(mr.rot6d + (long)b * 6, &w2.tot[340], dr6);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) mr.g_rot6d[(long)b * 6 + k] = dr6[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) mr.g_trans[(long)b * 3 + k] = w2.tot[349 + k];
+            }
+        }
 #ifdef MANO_PHASES
         __syncthreads();
         MPH_MARK(6);
@@ -615,19 +683,59 @@ size_t hm_mano_workspace_bytes(int B) { return 512 + (size_t)B * 4 + (size_t)B *
 size_t hm_mano_state_bytes(int B) { return (size_t)B * MANO_STATE_DW * sizeof(float); }
 // workspace: hm_mano_workspace_bytes(B), zero-filled once (per-frame tickets reset themselves).  state: the buffer the
 // forward filled (hm_mano_state_bytes(B)) for the SAME parameters, or NULL to recompute the chain.
-int hm_mano_bwd_rows(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
-                     const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
-                     float* g_trans, const float* state, void* workspace, int row0, int row_stride, hipStream_t stream)
+static int mano_bwd_launch(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
+                           const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot,
+                           float* g_betas, float* g_trans, const float* state, void* workspace, int row0, int row_stride,
+                           const ManoRigid& mr, hipStream_t stream)
 {
-    HM_CHECK_ARG(model && pca && rot && betas && g_verts && g_pca && g_rot && g_betas && g_trans && workspace);
+    HM_CHECK_ARG(model && pca && rot && betas && (g_verts || mr.mesh) && g_pca && g_rot && g_betas && g_trans && workspace);
     HM_CHECK_ARG(B > 0 && pca_dim >= 16 && row_stride >= 1 && row0 >= 0 && row0 < row_stride);
     ManoModelDev m = {(const float*)model[0], (const float*)model[1], (const float*)model[2], (const float*)model[3],
                       (const float*)model[4], (const float*)model[5], (const float*)model[6], (const int*)model[7]};
     unsigned int* cnt = (unsigned int*)workspace;
     float* partials = (float*)((char*)workspace + 256 + (((size_t)B * 4 + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(k_mano_bwd, dim3(MANO_NCH64, B), dim3(256), g_hm_lds_pad[HM_PAD_MANO_BWD], stream, m, pca, pca_dim, rot, betas, g_verts, B, state,
-                       partials, cnt, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans, row0, row_stride);
+    if (mr.mesh)
+        hipLaunchKernelGGL(k_mano_bwd<true>, dim3(MANO_NCH64, B), dim3(256), g_hm_lds_pad[HM_PAD_MANO_BWD], stream, m, pca, pca_dim, rot, betas,
+                           g_verts, B, state, partials, cnt, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans, row0,
+                           row_stride, mr);
+    else
+        hipLaunchKernelGGL(k_mano_bwd<false>, dim3(MANO_NCH64, B), dim3(256), g_hm_lds_pad[HM_PAD_MANO_BWD], stream, m, pca, pca_dim, rot, betas,
+                           g_verts, B, state, partials, cnt, pca_dim, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans, row0,
+                           row_stride, mr);
     return hm_launch_status();
+}
+int hm_mano_bwd_rows(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
+                     const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
+                     float* g_trans, const float* state, void* workspace, int row0, int row_stride, hipStream_t stream)
+{
+    ManoRigid none;
+    memset(&none, 0, sizeof(none));
+    return mano_bwd_launch(model, pca, pca_dim, rot, betas, B, g_verts, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans,
+                           state, workspace, row0, row_stride, none, stream);
+}
+// hm_rigid_bwd_clips of the hand (no mesh gradient buffer in between) + hm_mano_bwd in ONE launch: mesh = the forward's
+// model-space vertices (B,778,3), rigid_* = the hand's rigid pose (scale: one per clip of clip_len frames, 0 = one clip),
+// g_terms / weights / g_rigid / g_frame / frame_stride / frame_scale as hm_rigid_bwd_clips, g_rigid_rot6d (B,3,2) and
+// g_rigid_trans (B,3) receive the rigid pose's gradients.  Same expressions as the two launches; the twelve sums of dR / dt
+// are formed per vertex chunk and added in chunk order (last bits differ from hm_rigid_bwd_clips' 1024-thread sum).
+int hm_mano_bwd_rigid_clips(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
+                            const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
+                            float* g_trans, const float* state, void* workspace, const float* mesh, const float* rigid_rot6d,
+                            const float* rigid_scale, const float* const* g_terms, const float* weights, int n_terms,
+                            const float* g_rigid, const float* g_frame, int frame_stride, float frame_scale,
+                            float* g_rigid_rot6d, float* g_rigid_trans, int clip_len, hipStream_t stream)
+{
+    HM_CHECK_ARG(mesh && rigid_rot6d && rigid_scale && g_rigid_rot6d && g_rigid_trans && HM_CLIP_LEN_OK(B, clip_len));
+    HM_CHECK_ARG(n_terms >= 0 && n_terms <= 5 && (n_terms == 0 || (g_terms && weights)));
+    HM_CHECK_ARG(!g_frame || frame_stride >= 3);
+    ManoRigid mr;
+    memset(&mr, 0, sizeof(mr));
+    mr.mesh = mesh; mr.rot6d = rigid_rot6d; mr.scale = rigid_scale; mr.clip_len = clip_len ? clip_len : B;
+    for (int k = 0; k < 5; ++k) { mr.terms.p[k] = k < n_terms ? g_terms[k] : nullptr; mr.terms.w[k] = k < n_terms ? weights[k] : 0.f; }
+    mr.g_rigid = g_rigid; mr.g_frame = g_frame; mr.frame_stride = frame_stride; mr.frame_scale = frame_scale;
+    mr.g_rot6d = g_rigid_rot6d; mr.g_trans = g_rigid_trans;
+    return mano_bwd_launch(model, pca, pca_dim, rot, betas, B, nullptr, g_pca_extra, w_extra, g_pca, g_rot, g_betas, g_trans,
+                           state, workspace, 0, 1, mr, stream);
 }
 int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
                 const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,

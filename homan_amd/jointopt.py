@@ -461,6 +461,11 @@ class FusedStepper:
         # next to them (same-box A/B, 8 clips: step-1 8 650 -> 8 865 it/s, step-2 7 142 -> 7 332; either change alone loses)
         self.pairs_after_lines = (os.environ.get("HOMAN_PAIRS_AFTER_LINES") or "1") != "0" and C > 1 and self.on["sil"]
         self.ev_lines = torch.cuda.Event()
+        # the hand's rigid backward inside the MANO backward's launch (hm_mano_bwd_rigid_clips): one clip, step-2 sets - where
+        # the hand-side chain is the iteration's critical path (cfg3 +2 %); elsewhere that chain is hidden and the larger
+        # launch only gets in the sweeps' way (cfg2 -1.3 %, clip batches -2..3 %)
+        self.mano_bwd_rigid = (os.environ.get("HOMAN_MANO_BWD_RIGID") or
+                               ("1" if C == 1 and (self.on["col"] or self.on["con"]) else "0")) != "0"
         self.nn_early = (os.environ.get("HOMAN_NN_EARLY") or "0") != "0"
         self.pair_fused = (os.environ.get("HOMAN_PAIR_FUSED") or ("1" if C == 1 else "0")) != "0"
         self.hand_terms_fused = os.environ.get("HOMAN_HT_FUSED", "1") != "0"
@@ -834,17 +839,26 @@ class FusedStepper:
                                      (self.U_colh if on["col"] else None, w["loss_collision"]),
                                      (self.U_conh if on["con"] else None, w["loss_contact"]),
                                      (self.G_dep_h if on["depth"] else None, 1.0)])       # (already times its weight)
-            ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
-                                    P(m.int_scales_hand), 0, tp, tw, tn,
-                                    P(self.G_min_h) if (on["inter"] and self.inter_min) else None,
-                                    (self.rec.data_ptr() + 8) if (on["inter"] and not self.inter_min) else None, 8,
-                                    w["loss_inter"] / Vh, B, Vh,
-                                    P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
-                                    P(m.translations_hand.grad), None, P(self.rigid_ws_h), CL, sb2), "rigid_bwd(hand)")
-            if m.optimize_mano:
-                ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
-                                 P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
-                                 P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb2), "mano_bwd")
+            g_rig = P(self.G_min_h) if (on["inter"] and self.inter_min) else None
+            g_frm = (self.rec.data_ptr() + 8) if (on["inter"] and not self.inter_min) else None
+            if m.optimize_mano and self.mano_bwd_rigid:
+                # the hand's rigid backward inside the MANO backward's launch: one launch less on this chain
+                ck(L.hm_mano_bwd_rigid_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B,
+                                             P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
+                                             P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)),
+                                             P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), tp, tw, tn, g_rig, g_frm, 8,
+                                             w["loss_inter"] / Vh, P(m.rotations_hand.grad), P(m.translations_hand.grad), CL,
+                                             sb2), "mano_bwd + rigid_bwd(hand)")
+            else:
+                ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
+                                        P(m.int_scales_hand), 0, tp, tw, tn, g_rig, g_frm, 8, w["loss_inter"] / Vh, B, Vh,
+                                        P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
+                                        P(m.translations_hand.grad), None, P(self.rigid_ws_h), CL, sb2), "rigid_bwd(hand)")
+                if m.optimize_mano:
+                    ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
+                                     P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
+                                     P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb2),
+                       "mano_bwd")
         # ---------------- A: object backward: silhouette gradient + smooth + contact [+ interaction with a free scale],
         # summed with their weights inside the rigid backward
         if on["smooth"] and self.smooth_obj_on_main:

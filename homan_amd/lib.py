@@ -58,6 +58,8 @@ _SIGNATURES = {
     "hm_mano_state_bytes": (_SZ, [_I]),
     "hm_mano_workspace_bytes": (_SZ, [_I]),
     "hm_mano_bwd": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_mano_bwd_rigid_clips": (_I, [_VP, _VP, _I, _VP, _VP, _I, _VP, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I,
+                                     _VP, _VP, _I, _F, _VP, _VP, _I, _VP]),
     "hm_reduce_workspace_bytes": (_SZ, []),
     "hm_v2d_fwd": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _VP]),
     "hm_smooth_fwd": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _VP]),

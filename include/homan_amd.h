@@ -103,6 +103,17 @@ size_t hm_mano_state_bytes(int B);
 int hm_mano_bwd(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
                 const float* g_verts, const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
                 float* g_trans, const float* state, void* workspace, hipStream_t stream);
+/* hm_rigid_bwd_clips of the hand + hm_mano_bwd in ONE launch (no mesh-gradient buffer in between): mesh = the forward's
+ * model-space vertices (B,778,3), rigid_rot6d / rigid_scale = the hand's rigid pose (scale: one per clip of clip_len frames),
+ * g_terms .. frame_scale as hm_rigid_bwd_clips, g_rigid_rot6d (B,3,2) / g_rigid_trans (B,3) receive the rigid pose's gradients.
+ * Replaces the hand branch of loss.backward() through reference homan/homan.py:341-382 (rigid transform) and
+ * homan/manomodel.py:84-151 (LBS).  Same expressions as the two launches; the sums of dR / dt are formed per vertex chunk. */
+int hm_mano_bwd_rigid_clips(const void* const* model, const float* pca, int pca_dim, const float* rot, const float* betas, int B,
+                            const float* g_pca_extra, float w_extra, float* g_pca, float* g_rot, float* g_betas,
+                            float* g_trans, const float* state, void* workspace, const float* mesh, const float* rigid_rot6d,
+                            const float* rigid_scale, const float* const* g_terms, const float* weights, int n_terms,
+                            const float* g_rigid, const float* g_frame, int frame_stride, float frame_scale,
+                            float* g_rigid_rot6d, float* g_rigid_trans, int clip_len, hipStream_t stream);
 
 /* ------------------------------------------------------------------ silhouette rasteriser + fused masked-MSE / IoU
  * reference homan/losses.py:183-197 (compute_sil_loss_object) and the `neural_renderer` call inside it
