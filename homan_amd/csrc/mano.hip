@@ -516,8 +516,6 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
     for (int k = 0; k < 12; ++k) racc[k] = 0.f;
     if (t < nv) {
         const int v = v0 + t;
-        float T[12];
-        mano_skin_transform(m, sh, v, T);
         if (RIGID) {
             // rigid backward of this vertex (the arithmetic of k_rigid_bwd): gf reaches the mesh, gt = gf + the rigid-only terms
             const long o = ((long)b * MANO_V + v) * 3;
@@ -550,6 +548,18 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
             const float* gp = gout + ((long)b * MANO_V + v) * 3;
             g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
         }
+    }
+    float* out = partials + ((long)lb * gridDim.x + blockIdx.x) * MANO_PART;
+    if (RIGID) {
+        float* red12 = &s_part[0][0][0];          // (>= 16 * 12 floats; the posed-chunk scratch is free by now)
+        hm_block_sum_n<12>(racc, red12);
+        if (t < 12) hm_partial_store(out + 340 + t, racc[t]);
+        __syncthreads();
+    }
+    if (t < nv) {
+        const int v = v0 + t;
+        float T[12];
+        mano_skin_transform(m, sh, v, T);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             s_g[t][c] = g[c];
@@ -558,15 +568,8 @@ __global__ __launch_bounds__(256) void k_mano_bwd(ManoModelDev m, const float* _
         for (int j = 0; j < MANO_J; ++j) s_w[t][j] = m.weights[v * MANO_J + j];
     }
     MPH_MARK(1);
-    float* out = partials + ((long)lb * gridDim.x + blockIdx.x) * MANO_PART;
     const float tg0 = hm_block_sum(g[0], red), tg1 = hm_block_sum(g[1], red), tg2 = hm_block_sum(g[2], red);
     if (t == 0) { hm_partial_store(out + 337, tg0); hm_partial_store(out + 338, tg1); hm_partial_store(out + 339, tg2); }
-    if (RIGID) {
-        __syncthreads();
-        float* red12 = &s_part[0][0][0];          // (>= 16 * 12 floats; the posed-chunk scratch is free by now)
-        hm_block_sum_n<12>(racc, red12);
-        if (t < 12) hm_partial_store(out + 340 + t, racc[t]);
-    }
     __syncthreads();
     MPH_MARK(2);
     // dA[j][r][c] = sum_v W[v][j] g[v][r] [vp;1][c]

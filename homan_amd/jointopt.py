@@ -461,11 +461,9 @@ class FusedStepper:
         # next to them (same-box A/B, 8 clips: step-1 8 650 -> 8 865 it/s, step-2 7 142 -> 7 332; either change alone loses)
         self.pairs_after_lines = (os.environ.get("HOMAN_PAIRS_AFTER_LINES") or "1") != "0" and C > 1 and self.on["sil"]
         self.ev_lines = torch.cuda.Event()
-        # the hand's rigid backward inside the MANO backward's launch (hm_mano_bwd_rigid_clips): one clip, step-2 sets - where
-        # the hand-side chain is the iteration's critical path (cfg3 +2 %); elsewhere that chain is hidden and the larger
-        # launch only gets in the sweeps' way (cfg2 -1.3 %, clip batches -2..3 %)
-        self.mano_bwd_rigid = (os.environ.get("HOMAN_MANO_BWD_RIGID") or
-                               ("1" if C == 1 and (self.on["col"] or self.on["con"]) else "0")) != "0"
+        # the hand's rigid backward inside the MANO backward's launch (hm_mano_bwd_rigid_clips): one launch less on the hand-side
+        # chain.  One clip: cfg2 +1.3 %, cfg3 +1.4 %; a clip batch hides that chain under the silhouette chain and loses 1-1.6 %
+        self.mano_bwd_rigid = (os.environ.get("HOMAN_MANO_BWD_RIGID") or ("1" if C == 1 else "0")) != "0"
         self.nn_early = (os.environ.get("HOMAN_NN_EARLY") or "0") != "0"
         self.pair_fused = (os.environ.get("HOMAN_PAIR_FUSED") or ("1" if C == 1 else "0")) != "0"
         self.hand_terms_fused = os.environ.get("HOMAN_HT_FUSED", "1") != "0"

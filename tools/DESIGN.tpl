@@ -188,7 +188,7 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | **`k_bwd_sweep`** | persistent waves; a **unit** = 256 consecutive (face, winding, edge, axis, d0) items of the global list, whichever faces they belong to (a big face spreads over several waves, small faces share one), handled per pass of ≤ 16 faces staged in LDS together with their per-(face, family) constants - edge slope, first line, end-point order: one IEEE division per family instead of one per item, built by the wave right after the staging - and per-(face, axis) inward ranges.  **Stage 1** (every item, 64 per trip, four trips whose loads are all in flight before the first is tested): family by a 4-step search of the cumulative counts, line geometry from the family constants, then three loads requested together: the line's 16-byte summary, the owner of the sample just inside the edge and the alpha word of the sample just outside - the outward sweep needs a sample this winding owns AND a plane-0 source beyond the edge (exact from first / last position), the inward sweep an empty sample outside AND a plane-1 source inside the triangle's extent (positions + word mask); in the steady state of a fit 71 % of the items stop here (1.95 M items → 557 k, of which 555 k do have pairs) and the rest are queued with the two decisions.  **Stage 2** (queued items on full waves): two 16-byte record loads + popcounts give the slices `[lo, lo+nb)` of the line's source array; the (item, source) pairs are **flattened** over the wave, four consecutive pairs per lane, item of a pair by scatter + max-scan; per-lane running sums flushed into the face's six LDS accumulators when the (face, corner) target changes; a face inside one unit is stored, a face cut by one unit boundary is added by two commutative hardware float atomics, a face over ≥ 3 units goes through per-unit partials + ticket (deterministic in all three cases); **XCD-aware**: each XCD (workgroup id mod 8) takes one contiguous eighth of the units, so a frame's index-map lines, line records and source slices are fetched into one L2 instead of eight | VALU issue + dependent-load latency (`valu_frac` 0.48) | B·(F·(68+24) + 512²·4 + 512²) = **47.6 MB** |
 | `k_bwd_gather` | thread / vertex over CSR adjacency: one `float2` per (face, corner) (deterministic, no atomics) + projection backward.  Autograd path only: the fused loop gathers inside `k_rigid_bwd` (`hm_rigid_bwd_sil`) | HBM | B·(F·24·2 + V·24) = 5.4 MB |
 | `k_rigid_fwd/bwd` | forward: thread / vertex; backward: grid (frame, 256-vertex chunk), sums up to four weighted per-vertex gradient terms + a per-frame vector + optionally the silhouette gradient gathered from the sweeps' per-corner output (no gather / linear-combination launches), 13 block sums behind two barriers, per-frame ticket, rot6d backward by the finishing workgroup | latency | ≤ 4·B·V·12 |
-| `k_mano_fwd`, `k_mano_bwd` | forward: (13 vertex chunks × ⌈B/4⌉) blocks, a workgroup = one chunk of 64 vertices for FOUR consecutive frames, wave f owning frame f: four chains prepared side by side, then every wave streams its 37 rows of the blend matrix `M` ONCE and accumulates them for all four frames (the 1.35 MB matrix crosses L2 once per four frames: a 240-frame batch used to pull 324 MB through L2 per launch), wave f finishes frame f (partials, skinning, rigid transform, state); per frame the arithmetic and its order are unchanged, so frame grouping is invisible in the results.  Backward: (13 × B) blocks; kinematic tree staged in LDS, chain level-parallel; `M` rows streamed coalesced with all of a wave's rows requested before the first is reduced; rigid hand transform fused into the forward epilogue; the forward keeps the chain state + posed vertices for the backward; backward = ONE launch: chunk partials, then the frame's last workgroup (per-frame ticket) runs the chain / Rodrigues / PCA backward with the prior folded in; `k_mano_bwd<true>` (`hm_mano_bwd_rigid_clips`, one clip with the step-2 terms) also does the hand's rigid backward - no mesh-gradient buffer, no `k_rigid_bwd` launch for the hand | L2 / latency | 2·C_mano + 2·B·778·12 |
+| `k_mano_fwd`, `k_mano_bwd` | forward: (13 vertex chunks × ⌈B/4⌉) blocks, a workgroup = one chunk of 64 vertices for FOUR consecutive frames, wave f owning frame f: four chains prepared side by side, then every wave streams its 37 rows of the blend matrix `M` ONCE and accumulates them for all four frames (the 1.35 MB matrix crosses L2 once per four frames: a 240-frame batch used to pull 324 MB through L2 per launch), wave f finishes frame f (partials, skinning, rigid transform, state); per frame the arithmetic and its order are unchanged, so frame grouping is invisible in the results.  Backward: (13 × B) blocks; kinematic tree staged in LDS, chain level-parallel; `M` rows streamed coalesced with all of a wave's rows requested before the first is reduced; rigid hand transform fused into the forward epilogue; the forward keeps the chain state + posed vertices for the backward; backward = ONE launch: chunk partials, then the frame's last workgroup (per-frame ticket) runs the chain / Rodrigues / PCA backward with the prior folded in; `k_mano_bwd<true>` (`hm_mano_bwd_rigid_clips`, one clip) also does the hand's rigid backward - no mesh-gradient buffer, no `k_rigid_bwd` launch for the hand | L2 / latency | 2·C_mano + 2·B·778·12 |
 | `k_hand_terms` | 2-D reprojection + temporal smoothness + priors of the hand in one launch, one ticket | latency | ≈ 1.5 MB |
 | **`k_pair_terms`** (`csrc/pairterms.hip`) | one clip: the terms that start from the two vertex buffers and feed nothing to each other as BLOCK RANGES of one grid - [search \| interaction \| hand terms \| object smoothness] - each with its own reduce workspace and ticket; the search is the metric-only one on the step-1 sets and the FULL one (`nn_full_body`, the body of `k_nn`, with the contact launches behind it) when the contact term is on (cfg3: 214 → 202 µs per iteration).  The bodies are shared with the stand-alone kernels (`pair_bodies.h`: device functions on virtual block coordinates), so the floats are the same either way (`test_pair_terms_launch_equals_its_four_entry_points`, and every batched == single test: batches use the stand-alone launches).  Four launches and three graph edges of the hand-side chain become one: 5100 → 5430 it/s | latency | ≈ 2 MB |
 | `k_smooth`, `k_inter`, `k_contact_hand` | grid-stride + "last block finishes" ticket | latency | 10–100 KB |
