@@ -347,7 +347,7 @@ file the reference never reaches.  More than two hands: the reference's own coll
 ## 8. Known gaps / next (ranked)
 
 1. Kernel targets of the last verdict (raster ≤ 38, sweep ≤ 38, lines ≤ 18 µs in the graph; driver-flag line ≥ 5500,
-   8-clip batch ≥ 9500 it/s) are not met: 45 / 45 / 22 µs, 4 900 and 9 050 it/s.  The sweep is issue-bound at its 96 registers
+   8-clip batch ≥ 9500 it/s) are not met: 45 / 45 / 22 µs, 4 860 and 9 020 it/s.  The sweep is issue-bound at its 96 registers
    (2 250 VALU wave-instructions per 256-item unit, ~85 % of the issue slots until its tail; 10 % of the waves run 16 us
    longer than the other 90 %), so neither more waves, nor pipelined pair rounds, nor other unit sizes helped
    (EXPERIMENTS.md); the object-gradient + Adam tail of the chain does not get shorter inside the sweep launch either (a
