@@ -510,6 +510,23 @@ def emit(line):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(line) + "\n").encode())
 
 
+def _launch_ranks(n):
+    """Re-executes this command under torch.distributed.run with n ranks on this node (rendezvous on 127.0.0.1, a free port);
+    rank 0 of the children prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=_REAL_STDOUT if _REAL_STDOUT is not None else None)
+    if r.returncode:
+        raise SystemExit(r.returncode)
+
+
 def main():
     _quiet_stdout()
     ap = argparse.ArgumentParser()
@@ -550,9 +567,17 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
 
+    if args.pose_init:
+        assert args.gpus == 1, "--pose-init is a one-GPU line"
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the line the driver
+        # uses for N > 1) and hand their single JSON line through.  The children see WORLD_SIZE and take the branch below.
+        return _launch_ranks(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, (f"--gpus {args.gpus} but WORLD_SIZE={world}: the rank count comes from the launcher; "
+                                f"a mismatch would report {world} GPU(s) as {args.gpus}")
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
     if args.pose_init:
         return pose_init_bench(args)
@@ -762,6 +787,10 @@ def main():
                        + ", Adam step + loss logging in the timed region",
                        "frames": B, "rend_size": S, "faces": int(F), "clips_per_gpu": 1,
                        "loop": ("fused C-ABI launch sequence" if args.loop == "fused" else "HOMan.forward + autograd") + ", forward+backward+Adam+logging replayed from a hipGraph", "parallelism": f"{world} independent clips"},
+            # BASELINE's second reading of the metric: clips/s (a clip = one 400-step fit) absolute and as the fraction of the
+            # N x 8 TB/s HBM roof the SURVEY 8(d) byte model of those iterations amounts to
+            "clips_per_s": value / 400.0,
+            "clips_per_s_hbm_frac": algorithmic_bytes(B, S, F, V, args.step2)["total"] * value / (8.0e12 * world),
             "final_loss": evo["loss"][-1], "first_loss": evo["loss"][0],
             "roofline": roof, "steady_state": steady, "cpu_baseline": cpu, "multi_clip": multi,
             "final_loss_parity": parity,

@@ -183,3 +183,13 @@ def test_shard_clips():
     assert all(len(s) == 8 for s in shards) and sorted(sum(shards, [])) == list(range(64))
     shards = [shard_clips(10, r, 4) for r in range(4)]
     assert sorted(sum(shards, [])) == list(range(10)) and max(len(s) for s in shards) == 3
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """bench.py --gpus N under a launcher that started another number of ranks must not report N (the flag was
+    parsed and ignored).  Checked before anything touches the GPU."""
+    import subprocess
+    import sys
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

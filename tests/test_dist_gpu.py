@@ -211,3 +211,21 @@ def test_tied_scale_trajectory_matches_the_cpu_oracle_loop(mano_model):
     assert abs(track_o[-1] - 1.0) > 2e-3                                   # it moves ...
     np.testing.assert_allclose(track_h[:3], track_o[:3], atol=2e-5)         # ... identically at first ...
     np.testing.assert_allclose(track_h, track_o, atol=5e-3)                 # ... and the same way afterwards
+
+
+def test_bench_gpus_n_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (torch.distributed.run on 127.0.0.1) and
+    reports n_gpus = 2; gloo because the box has one GPU (both ranks share cuda:0)."""
+    import json
+    import subprocess
+    env = dict(os.environ, HOMAN_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--frames", "4", "--size", "64", "--multi-clip", "0", "--parity-seeds", "0", "--lockstep", "0",
+                        "--steady", "0", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["clips_per_s"] > 0
