@@ -185,6 +185,102 @@ def cfg1_parity(mano, seeds, steps=100, frames=10, size=128):
                 cores=int(os.environ.get("OMP_NUM_THREADS", "1")))
 
 
+def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube", seed=0, lr=1e-2, lw=None, clip=None,
+                    tol=1e-4, stages=True):
+    """BASELINE's end-state bar, free-running: the HIP fused loop and the CPU oracle loop optimise the same clip from identical
+    inputs for `steps` iterations, nobody teacher-forced (reference loop: homan/jointopt.py:158-192).
+
+    The oracle runs its REPRODUCIBLE form (oracle.jointopt.reproducible_step): the object's gradient chain and Adam written
+    out with order-independent sums - same mathematics as autograd + torch.optim.Adam (tests/test_objchain.py), a defined
+    rounding.  The HIP kernels form the same sums (include/homan_amd.h, ORDER-INDEPENDENT SUMS), so on the step-1 loss sets -
+    where the object's chain does not depend on the hand (homan/homan.py:482-490) - `rotations_object` /
+    `translations_object` must be BIT-EQUAL after every step; reported per step, with the first differing step (None = never),
+    the final vertex distances in mm and the relative loss differences (bars: 1e-3 mm, 1e-4)."""
+    import numpy as np
+    import torch
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, build_model
+    from oracle import objchain
+    from oracle.jointopt import collate_inputs, make_optimizer, reproducible_step
+    from oracle.model import OracleHOMan
+    if clip is None:
+        sil_fn, hand_fn = synth.hip_clip_fns(mano)
+        clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
+                               hand_verts_fn=hand_fn)
+    if lw is None:
+        lw = dict(synth.STEP2_LOSS_WEIGHTS if step2 else synth.STEP1_LOSS_WEIGHTS)
+    common = dict(objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"], optimize_mano=True,
+                  image_size=size, mano_model=mano, rend_size=size)
+    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                        sync_metrics=False, **common)
+    st = FusedStepper(model, lw, lr, steps)
+    kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                        clip["objvertices"], clip["objfaces"])
+    om = OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                     image_size=size, mano_model=mano, rend_size=size, **kw)
+    opt = make_optimizer(om, lr, reproducible=True)
+    obj_keys = ("rotations_object", "translations_object")
+    rows, first_obj_diff, stage_report = [], None, None
+    t_cpu = 0.0
+    for i in range(steps):
+        if stages and first_obj_diff is None:
+            before = {k: getattr(om, k).detach().numpy().copy() for k in obj_keys}
+        st.run(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ld, md, tot = reproducible_step(om, lw, opt)
+        t_cpu += time.perf_counter() - t0
+        hip = {k: v[i] for k, v in st.loss_evolution(i + 1).items()}
+        cpu = {k: float(v.detach().reshape(-1)[0]) for k, v in ld.items()}
+        cpu["loss"] = float(tot.detach().reshape(-1)[0])
+        rel = {k: abs(hip[k] - cpu[k]) / max(abs(cpu[k]), 1e-12) for k in cpu if k in hip}
+        hp = {k: p.detach().cpu().numpy() for k, p in model.named_parameters()}
+        cp = {k: p.detach().numpy().copy() for k, p in om.named_parameters()}
+        eq = {k: bool(np.array_equal(hp[k], cp[k].reshape(hp[k].shape))) for k in obj_keys}
+        pdiff = {k: float(np.abs(hp[k] - cp[k].reshape(hp[k].shape)).max()) for k in hp if k in cp}
+        if first_obj_diff is None and not all(eq.values()):
+            first_obj_diff = i
+            if stages:
+                # where along the chain did step i differ?  The oracle's chain re-evaluated at the parameters BEFORE the step
+                # against what the HIP loop left behind (gradients, per-corner sums, vertices, index map)
+                for k in obj_keys:
+                    getattr(om, k).data.copy_(torch.from_numpy(before[k]))
+                g_c, stg = objchain.object_pose_grads(om, lw, return_stages=True)
+                sctx = st.model.sil_ctx
+                parts_h = sctx.parts().cpu().numpy()
+                stage_report = dict(
+                    step=i,
+                    verts_equal=bool(np.array_equal(st.vo.cpu().numpy(), stg["verts"])),
+                    idx_map_differing=int((sctx.idx_map().cpu().numpy() != stg["idx"]).sum()),
+                    parts_equal=bool(np.array_equal(parts_h, stg["parts"])) if "parts" in stg else None,
+                    parts_max_abs_diff=float(np.abs(parts_h - stg["parts"]).max()) if "parts" in stg else None,
+                    parts_differing=int((parts_h != stg["parts"]).sum()) if "parts" in stg else None,
+                    parts_max_abs=float(np.abs(stg["parts"]).max()) if "parts" in stg else None,
+                    grads_equal={k: bool(np.array_equal(getattr(model, k).grad.cpu().numpy().reshape(g_c[k].shape), g_c[k]))
+                                 for k in obj_keys},
+                    grads_max_rel={k: float(np.abs(getattr(model, k).grad.cpu().numpy().reshape(g_c[k].shape) - g_c[k]).max()
+                                            / max(np.abs(g_c[k]).max(), 1e-30)) for k in obj_keys})
+                for k in obj_keys:      # (put the oracle back on its own trajectory)
+                    getattr(om, k).data.copy_(torch.from_numpy(cp[k]))
+        rows.append(dict(step=i, object_bit_equal=all(eq.values()), max_rel_loss=max(rel.values()),
+                         worst_loss=max(rel, key=rel.get), max_param_diff=max(pdiff.values()),
+                         worst_param=max(pdiff, key=pdiff.get)))
+    with torch.no_grad():
+        dvo = 1e3 * (model.get_verts_object()[0].cpu() - om.get_verts_object()[0]).abs().max().item()
+        dvh = 1e3 * (model.get_verts_hand()[0].cpu() - om.get_verts_hand()[0]).abs().max().item()
+    return dict(config=f"{frames} frames {size}x{size}, {obj}, " + ("step-2" if step2 else "step-1 / custom") +
+                f" loss set, {steps} free-running steps: HIP fused loop vs the CPU oracle's reproducible loop",
+                steps=steps, tol=tol, first_step_object_params_differ=first_obj_diff,
+                object_params_bit_equal_all_steps=first_obj_diff is None,
+                first_step_over_tol=next((r["step"] for r in rows if r["max_rel_loss"] > tol), None),
+                max_rel_loss=max(r["max_rel_loss"] for r in rows), worst_loss=max(rows, key=lambda r: r["max_rel_loss"])["worst_loss"],
+                final_rel_loss=rows[-1]["max_rel_loss"], final_vertex_diff_mm=dict(object=dvo, hand=dvh),
+                final_max_param_diff=rows[-1]["max_param_diff"], final_worst_param=rows[-1]["worst_param"],
+                stage_report=stage_report, cpu_its_per_s=steps / max(t_cpu, 1e-9),
+                cores=int(os.environ.get("OMP_NUM_THREADS", "1")),
+                per_step=[{k: r[k] for k in ("step", "object_bit_equal", "max_rel_loss", "max_param_diff")} for r in rows][:: max(1, steps // 25)])
+
+
 def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottle", seed=0, lr=1e-2, free_run=True,
                     clip=None, lw=None, tol=1e-4):
     """Teacher-forced parity along the HIP trajectory (reference loop: homan/jointopt.py:158-192).

@@ -33,6 +33,15 @@ __device__ __forceinline__ void log_total_clip(float* __restrict__ vals, const f
     if (s < max_steps)
         for (int i = 0; i <= n; ++i) log[((long)s * nc + c) * (n + 1) + i] = v[i];
 }
+__device__ __forceinline__ double adam_pow(double b, int t)
+{
+    double r = 1.0;
+    for (; t > 0; t >>= 1) {
+        if (t & 1) r = r * b;
+        b = b * b;
+    }
+    return r;
+}
 __global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots, int n_tensors, int* __restrict__ step,
                                                float beta1, float beta2, float eps, int zero_grad, float* __restrict__ vals,
                                                const float* __restrict__ log_w, int log_n, int max_steps,
@@ -53,9 +62,10 @@ __global__ __launch_bounds__(256) void k_adam(const AdamSlot* __restrict__ slots
         return;
     }
     const AdamSlot s = slots[blockIdx.y];
-    const double t = (double)(step_now + 1);
-    const double bc1 = 1.0 - pow((double)beta1, t);
-    const double bc2 = 1.0 - pow((double)beta2, t);
+    // beta^t by square-and-multiply in double: IEEE products in a fixed order, i.e. a function of (beta, t) alone - the CPU
+    // oracle's Adam (oracle/adam.py) forms the same doubles, where a libm pow() may differ in the last bit from host to host
+    const double bc1 = 1.0 - adam_pow((double)beta1, step_now + 1);
+    const double bc2 = 1.0 - adam_pow((double)beta2, step_now + 1);
     const float neg_step = (float)(-((double)s.lr / bc1));
     const float bc2_sqrt = (float)sqrt(bc2);
     const float w1 = (float)(1.0 - (double)beta1), w2 = (float)(1.0 - (double)beta2);

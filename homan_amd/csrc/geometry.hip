@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_rigid_fwd(const float* __restrict__ mes
 // sweeps (hm_sil_bwd called with grad_verts == NULL) and pushed through the projection backward -- the work of
 // k_bwd_gather, without its launch and without the (B,V,3) round trip on the critical chain.
 struct SilGather {
-    const float* parts;        // (B,F,3,2)
+    const double* parts;       // (B,F,3,2) exact per-corner sums (hm_sil_parts)
     const int* adj_off;        // (V+1) CSR over vertices
     const int* adj_items;      // face * 3 + corner
     const float* cam_verts;    // (B,V,3) camera-space vertices the silhouettes were rendered from
@@ -53,6 +53,10 @@ struct SilGather {
     float orig_size;
     int F;
 };
+// EXACT: the 13 per-frame sums over the vertices are order-independent (every addend rounded to the grid of `magic`, summed in
+// double: hm_quant) - with the exact per-corner sums of the sweeps the object's pose gradients are then a function of the
+// SET of terms, the same floats whatever the launch geometry, and the same as the CPU oracle's (oracle/csrc/objchain.c).
+template <bool EXACT>
 __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ mesh, const float* __restrict__ rot6d,
                                                    const float* __restrict__ scale, int abs_scale, RigidTerms terms,
                                                    SilGather sil,
@@ -61,11 +65,12 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
                                                    float* __restrict__ g_mesh,
                                                    float* __restrict__ g_rot6d, float* __restrict__ g_trans,
                                                    float* __restrict__ g_scale_part, float* __restrict__ partials,
-                                                   unsigned int* __restrict__ frame_cnt, int clip_len)
+                                                   unsigned int* __restrict__ frame_cnt, int clip_len, double magic)
 {
     HM_LATENCY_KERNEL();
     HM_STAMP_START(sil.parts ? 1 : 0);
     __shared__ float red13[16 * 13];
+    __shared__ double red13d[EXACT ? 16 * 13 : 1];
     __shared__ int s_flag;
     const int n = blockIdx.x;
     // (every thread builds the frame's rotation itself from six uniform loads: no LDS hand-over, no barrier in front of the
@@ -80,8 +85,9 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
         for (int c = 0; c < 3; ++c) gfr[c] = frame_scale * g_frame[(long)n * frame_stride + c];
     }
     float acc[13];
+    double accd[13];
 #pragma unroll
-    for (int k = 0; k < 13; ++k) acc[k] = 0.f;
+    for (int k = 0; k < 13; ++k) { acc[k] = 0.f; accd[k] = 0.0; }
     // grid (N, chunks): this workgroup's share of the vertices (up to 1024 threads x 4: ONE workgroup per frame for meshes of
     // <= 4096 vertices, no chunk records / ticket / second round trip); with several chunks the frame's last workgroup
     // (ticket) finishes the frame
@@ -95,8 +101,8 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
                 gf[0] += terms.w[k] * terms.p[k][o]; gf[1] += terms.w[k] * terms.p[k][o + 1]; gf[2] += terms.w[k] * terms.p[k][o + 2];
             }
         if (sil.parts) {        // same arithmetic as k_bwd_gather (raster.hip)
-            float gu = 0.f, gv = 0.f;
-            const float2* pf = reinterpret_cast<const float2*>(sil.parts + (long)n * sil.F * 6);
+            double su = 0.0, sv = 0.0;       // exact: the per-corner sums are multiples of one quantum
+            const double2* pf = reinterpret_cast<const double2*>(sil.parts + (long)n * sil.F * 6);
             // eight adjacent corners at a time: all item loads, then all gradient loads (two dependent round trips per
             // batch instead of two per corner; the valence of a mesh vertex is ~6)
             const int a1 = sil.adj_off[v + 1];
@@ -104,12 +110,13 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
                 int item[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) item[k] = a + k < a1 ? sil.adj_items[a + k] : -1;
-                float2 g2[8];
+                double2 g2[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) g2[k] = item[k] >= 0 ? pf[item[k]] : make_float2(0.f, 0.f);
+                for (int k = 0; k < 8; ++k) g2[k] = item[k] >= 0 ? pf[item[k]] : make_double2(0.0, 0.0);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) { gu += g2[k].x; gv += g2[k].y; }
+                for (int k = 0; k < 8; ++k) { su += g2[k].x; sv += g2[k].y; }
             }
+            const float gu = (float)su, gv = (float)sv;
             const float* k = sil.K + n * 9;
             const float x = sil.cam_verts[o], y = sil.cam_verts[o + 1], z = sil.cam_verts[o + 2];
             const float zz = z + 1e-9f;
@@ -122,24 +129,60 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
         }
         gt[0] = gf[0] + gfr[0]; gt[1] = gf[1] + gfr[1]; gt[2] = gf[2] + gfr[2];
         if (g_rigid) { gt[0] += g_rigid[o]; gt[1] += g_rigid[o + 1]; gt[2] += g_rigid[o + 2]; }
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) acc[3 * i + j] += (s * m[i]) * gt[j];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) acc[9 + j] += gt[j];
         // d(s*m)_i = sum_j R[i][j] gf_j
         const float dm[3] = {R[0] * gf[0] + R[1] * gf[1] + R[2] * gf[2], R[3] * gf[0] + R[4] * gf[1] + R[5] * gf[2],
                              R[6] * gf[0] + R[7] * gf[1] + R[8] * gf[2]};
-        acc[12] += m[0] * dm[0] + m[1] * dm[1] + m[2] * dm[2];
+        if (EXACT) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) accd[3 * i + j] += hm_quant((s * m[i]) * gt[j], magic);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) accd[9 + j] += hm_quant(gt[j], magic);
+            accd[12] += hm_quant(m[0] * dm[0] + m[1] * dm[1] + m[2] * dm[2], magic);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[3 * i + j] += (s * m[i]) * gt[j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[9 + j] += gt[j];
+            acc[12] += m[0] * dm[0] + m[1] * dm[1] + m[2] * dm[2];
+        }
         if (g_mesh) { g_mesh[o] = s * dm[0]; g_mesh[o + 1] = s * dm[1]; g_mesh[o + 2] = s * dm[2]; }
     }
     float tot[13];
+    if (EXACT) {
+        hm_block_sum_n_f64<13>(accd, red13d);
+        if (gridDim.y > 1) {
+            // chunk records of 13 doubles (32 floats apart), agent-scope stores / loads like the float records; the frame's last
+            // workgroup adds them - in any order: the sums are exact
+            double* rec = reinterpret_cast<double*>(partials + ((long)n * gridDim.y + blockIdx.y) * 32);
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < 13; ++k) __hip_atomic_store(rec + k, accd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (!hm_last_block(frame_cnt + n, gridDim.y, &s_flag)) return;
+            if (threadIdx.x < 13 * gridDim.y)
+                red13d[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const double*>(partials + ((long)n * gridDim.y + threadIdx.x / 13) * 32) + threadIdx.x % 13,
+                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (threadIdx.x == 0) {
+#pragma unroll
+                for (int k = 0; k < 13; ++k) accd[k] = 0.0;
+                for (unsigned c = 0; c < gridDim.y; ++c)
+#pragma unroll
+                    for (int k = 0; k < 13; ++k) accd[k] += red13d[c * 13 + k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 13; ++k) tot[k] = (float)accd[k];
+    } else {
 #pragma unroll
     for (int k = 0; k < 13; ++k) tot[k] = acc[k];
     hm_block_sum_n<13>(tot, red13);
     if (gridDim.y > 1) {
-        float* rec = partials + ((long)n * gridDim.y + blockIdx.y) * 16;
+        float* rec = partials + ((long)n * gridDim.y + blockIdx.y) * 32;
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int k = 0; k < 13; ++k) hm_partial_store(rec + k, tot[k]);
@@ -147,14 +190,8 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
         if (!hm_last_block(frame_cnt + n, gridDim.y, &s_flag)) return;
         // all records in ONE round trip (a thread per value), then the sums in chunk order: deterministic, and the frame's
         // tail is one memory latency instead of one per chunk (<= 16 chunks x 13 values fit red13)
-#ifdef HM_RIGID_SERIAL_TAIL      // (A/B: the round-1 tail, one dependent round trip per chunk)
-        if (threadIdx.x == 0)
-            for (unsigned c = 0; c < gridDim.y; ++c)
-                for (int k = 0; k < 13; ++k) red13[c * 13 + k] = hm_partial_load(partials + ((long)n * gridDim.y + c) * 16 + k);
-#else
         if (threadIdx.x < 13 * gridDim.y)
-            red13[threadIdx.x] = hm_partial_load(partials + ((long)n * gridDim.y + threadIdx.x / 13) * 16 + threadIdx.x % 13);
-#endif
+            red13[threadIdx.x] = hm_partial_load(partials + ((long)n * gridDim.y + threadIdx.x / 13) * 32 + threadIdx.x % 13);
         __syncthreads();
         if (threadIdx.x == 0) {
 #pragma unroll
@@ -163,6 +200,7 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
 #pragma unroll
                 for (int k = 0; k < 13; ++k) tot[k] += red13[c * 13 + k];
         }
+    }
     }
     if (threadIdx.x == 0) {
         float dr6[6];
@@ -260,13 +298,14 @@ int hm_tune_lds_pad(int family, int bytes)
     return prev;
 }
 #define RIGID_MAX_CHUNKS 16
-size_t hm_rigid_workspace_bytes(int N) { return (((size_t)N * 4 + 255) & ~(size_t)255) + (size_t)N * RIGID_MAX_CHUNKS * 16 * 4; }
+size_t hm_rigid_workspace_bytes(int N) { return (((size_t)N * 4 + 255) & ~(size_t)255) + (size_t)N * RIGID_MAX_CHUNKS * 32 * 4; }
 static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
                             const float* const* g_terms, const float* weights, int n_terms, SilGather sil,
                             const float* g_rigid, const float* g_frame, int frame_stride, float frame_scale, int N, int V,
                             float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part, void* workspace,
-                            int clip_len, hipStream_t stream)
+                            int clip_len, int exact, int sum_log2q, hipStream_t stream)
 {
+    HM_CHECK_ARG(sum_log2q <= 0 && sum_log2q >= -60);
     HM_CHECK_ARG(mesh && rot6d && scale && g_rot6d && g_trans && N > 0 && V > 0 && HM_CLIP_LEN_OK(N, clip_len));
     HM_CHECK_ARG(n_terms >= 0 && n_terms <= 5 && (n_terms == 0 || (g_terms && weights)));
     HM_CHECK_ARG(!g_frame || frame_stride >= 3);
@@ -278,9 +317,14 @@ static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* 
     const int chunks = workspace ? min(RIGID_MAX_CHUNKS, hm_cdiv(V, 4 * threads)) : 1;
     unsigned int* cnt = (unsigned int*)workspace;
     float* partials = workspace ? (float*)((char*)workspace + (((size_t)N * 4 + 255) & ~(size_t)255)) : nullptr;
-    hipLaunchKernelGGL(k_rigid_bwd, dim3(N, chunks), dim3(threads), g_hm_lds_pad[HM_PAD_RIGID_BWD], stream, mesh, rot6d, scale, abs_scale, t, sil, g_rigid,
-                       g_frame, frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, partials, cnt,
-                       clip_len ? clip_len : N);
+    if (exact)
+        hipLaunchKernelGGL(k_rigid_bwd<true>, dim3(N, chunks), dim3(threads), g_hm_lds_pad[HM_PAD_RIGID_BWD], stream, mesh, rot6d, scale,
+                           abs_scale, t, sil, g_rigid, g_frame, frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans,
+                           g_scale_part, partials, cnt, clip_len ? clip_len : N, hm_sum_magic(sum_log2q));
+    else
+        hipLaunchKernelGGL(k_rigid_bwd<false>, dim3(N, chunks), dim3(threads), g_hm_lds_pad[HM_PAD_RIGID_BWD], stream, mesh, rot6d, scale,
+                           abs_scale, t, sil, g_rigid, g_frame, frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans,
+                           g_scale_part, partials, cnt, clip_len ? clip_len : N, 0.0);
     return hm_launch_status();
 }
 int hm_rigid_bwd_clips(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
@@ -291,7 +335,7 @@ int hm_rigid_bwd_clips(const float* mesh, const float* rot6d, const float* scale
 {
     SilGather none = {nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, 0};
     return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, none, g_rigid, g_frame, frame_stride,
-                            frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, workspace, clip_len, stream);
+                            frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, workspace, clip_len, 0, 0, stream);
 }
 int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
                  const float* weights, int n_terms, const float* g_rigid, const float* g_frame, int frame_stride,
@@ -303,24 +347,26 @@ int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int 
 }
 // hm_rigid_bwd with the silhouette gradient as an extra full term taken straight from the sweep output: sil_parts =
 // hm_sil_parts(workspace) of an hm_sil_bwd called with grad_verts == NULL; cam_verts / K / orig_size / F as given to it.
+// The per-frame sums over the vertices are exact sums on the grid 2^sum_log2q (0: the default, 2^-44) like the per-corner
+// sums they start from: the pose gradients do not depend on the launch geometry.
 int hm_rigid_bwd_sil_clips(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
-                           const float* const* g_terms, const float* weights, int n_terms, const float* sil_parts,
+                           const float* const* g_terms, const float* weights, int n_terms, const double* sil_parts,
                            const int* adj_off, const int* adj_items, const float* cam_verts, const float* K,
                            float orig_size, int F, int N, int V, float* g_rot6d, float* g_trans, float* g_scale_part,
-                           void* workspace, int clip_len, hipStream_t stream)
+                           void* workspace, int clip_len, int sum_log2q, hipStream_t stream)
 {
     HM_CHECK_ARG(sil_parts && adj_off && adj_items && cam_verts && K && F > 0);
     SilGather sil = {sil_parts, adj_off, adj_items, cam_verts, K, orig_size, F};
     return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, sil, nullptr, nullptr, 0, 0.f, N, V,
-                            nullptr, g_rot6d, g_trans, g_scale_part, workspace, clip_len, stream);
+                            nullptr, g_rot6d, g_trans, g_scale_part, workspace, clip_len, 1, sum_log2q, stream);
 }
 int hm_rigid_bwd_sil(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
-                     const float* weights, int n_terms, const float* sil_parts, const int* adj_off, const int* adj_items,
+                     const float* weights, int n_terms, const double* sil_parts, const int* adj_off, const int* adj_items,
                      const float* cam_verts, const float* K, float orig_size, int F, int N, int V, float* g_rot6d,
-                     float* g_trans, float* g_scale_part, void* workspace, hipStream_t stream)
+                     float* g_trans, float* g_scale_part, void* workspace, int sum_log2q, hipStream_t stream)
 {
     return hm_rigid_bwd_sil_clips(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, sil_parts, adj_off, adj_items,
-                                  cam_verts, K, orig_size, F, N, V, g_rot6d, g_trans, g_scale_part, workspace, 0, stream);
+                                  cam_verts, K, orig_size, F, N, V, g_rot6d, g_trans, g_scale_part, workspace, 0, sum_log2q, stream);
 }
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream)
 {

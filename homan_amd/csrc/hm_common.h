@@ -271,5 +271,45 @@ __device__ __forceinline__ void rot6d_backward(const float* r6, const float* dR,
     for (int i = 0; i < 3; ++i) { dr6[2 * i] = da1[i]; dr6[2 * i + 1] = da2[i]; }
 }
 
+// ---- order-independent sums ("exact accumulation").  Every gradient term on the object's chain is rounded to a multiple of
+// the quantum q = 2^log2q (a value of `magic` = 1.5 * 2^(52 + log2q): (x + magic) - magic in double is x rounded to the grid,
+// round-to-nearest-even) and summed in DOUBLE: sums of multiples of q are exact while they stay below 2^53 q, so they do not
+// depend on the order in which lanes, waves, units or workgroups add them - the result is a function of the SET of terms.
+// The CPU oracle (oracle/csrc/objchain.c) forms the same set with the same per-term arithmetic, which makes the pseudo-
+// gradient - and with it the free-running object trajectory of a fit - bit-equal on both sides.  Default grid 2^-44
+// (5.7e-14: below the float ulp of the per-corner sums of a normalised silhouette loss; exact up to |sum| < 512); a
+// caller whose gradients are O(1) and larger (pose initialisation) passes a coarser one.
+#define HM_SUM_LOG2Q_DEFAULT (-44)
+__host__ __device__ __forceinline__ double hm_sum_magic(int log2q)
+{
+    return 6755399441055744.0 /* 1.5 * 2^52 */ * __builtin_ldexp(1.0, log2q ? log2q : HM_SUM_LOG2Q_DEFAULT);
+}
+__device__ __forceinline__ double hm_quant(float x, double magic) { return ((double)x + magic) - magic; }
+
+// block-wide sums of N doubles (blockDim.x <= 1024, multiple of 64); results valid in every thread.  `red` must hold >= 16 * N
+// doubles.  Meant for EXACT sums (multiples of one quantum, see hm_quant): the combination order is then immaterial.
+template <int N>
+__device__ __forceinline__ void hm_block_sum_n_f64(double (&v)[N], double* red)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
+    }
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) red[k * 16 + w] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double t = 0.0;
+        for (int i = 0; i < nw; ++i) t += red[k * 16 + i];
+        v[k] = t;
+    }
+}
+
 // weighted per-vertex gradient terms of a rigid backward (see k_rigid_bwd, geometry.hip): up to five, NULL = skipped
 struct RigidTerms { const float* p[5]; float w[5]; };

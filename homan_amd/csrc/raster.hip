@@ -1000,25 +1000,26 @@ __device__ __forceinline__ float sample_grad(const float* __restrict__ gimg, int
 }
 
 // contribution of sample d1 (pseudo-distance of the crossing to the two end points of the edge).  k0 / k1: the item's
-// constants c * 2 / is, folded once per item (sweep_item_scale) instead of three multiplications per pair and end point
+// constants (c * 2) / is, folded once per item (sweep_item_scale) instead of three operations per pair and end point.
+// IEEE divisions: the term is a defined function of its operands, the same float on the GPU and in the oracle.
 __device__ __forceinline__ void sweep_term(float diff, int d1, float d1_cross, float k0, float k1, bool use0, bool use1,
-                                           float eps, float& acc0, float& acc1)
+                                           float eps, double magic, double& acc0, double& acc1)
 {
     // straight-line (selects, no branches): every listed source has diff > 0 and nearly every item uses both end points, so
     // the conditions are almost always true and a taken branch costs more than the arithmetic it would skip.  A masked term
-    // is an exact +0: acc - 0 == acc.
+    // is an exact 0.
     const float t = (float)d1 - d1_cross;
     const bool live = diff > 0.0f;
     float dist0 = k0 * t, dist1 = k1 * t;
     dist0 += (0.0f < dist0) ? eps : -eps;          // (dist == 0 goes to -eps, like the reference's `0 < dist` test)
     dist1 += (0.0f < dist1) ? eps : -eps;
-    // 1-ulp reciprocal: the pseudo-gradient is compared at 1e-3
-    const float g0 = diff * __builtin_amdgcn_rcpf(dist0), g1 = diff * __builtin_amdgcn_rcpf(dist1);
-    acc0 -= (live && use0) ? g0 : 0.0f;
-    acc1 -= (live && use1) ? g1 : 0.0f;
+    const float g0 = diff / dist0, g1 = diff / dist1;
+    acc0 -= hm_quant((live && use0) ? g0 : 0.0f, magic);
+    acc1 -= hm_quant((live && use1) ? g1 : 0.0f, magic);
 }
 __device__ __forceinline__ float sweep_item_scale(float c, float two_over_is, bool pow2, int is)
 {
+    // (c * 2) / is; for a power of two the product with the exact inverse is the same float
     return pow2 ? (c * 2.0f) * two_over_is : (c * 2.0f) / (float)is;
 }
 
@@ -1116,7 +1117,7 @@ __device__ __forceinline__ int sweep_face_record(long bf, const float* __restric
 // order of its gradients - is the one of a single-clip launch.
 __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const float* __restrict__ faces9,
                                               const FaceBox* __restrict__ boxes, const unsigned char* __restrict__ owned,
-                                              int B, int F, int is, float* __restrict__ parts, const SweepList& sl,
+                                              int B, int F, int is, double* __restrict__ parts, const SweepList& sl,
                                               int clip_len)
 {
     __shared__ int s_wsum[4][2];
@@ -1165,7 +1166,7 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const 
             const bool over = u_hi >= sl.ucap || u_hi + idx >= sl.slot_cap;
             rec.off = off;
             rec.flags = over ? 1 : 0;
-            zero = u_hi > u_lo && (over || u_hi == u_lo + 1);    // accumulated with float atomics by its units
+            zero = u_hi > u_lo;                                  // accumulated with double atomics by its units
             const uint4* r4 = reinterpret_cast<const uint4*>(&rec);
             uint4* t4 = reinterpret_cast<uint4*>(sl.tab + idx);
 #pragma unroll
@@ -1178,9 +1179,9 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const 
             ++idx;
         }
         if (zero) {
-            float* o = parts + bf * 6;
+            double* o = parts + bf * 6;
 #pragma unroll
-            for (int q = 0; q < 6; ++q) o[q] = 0.f;
+            for (int q = 0; q < 6; ++q) o[q] = 0.0;
         }
     }
     // the last block publishes the totals and re-arms the counters for the next launch.  (Only the counts travel
@@ -1298,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                                                    int ncomp, int fpt, const float* __restrict__ faces9,
                                                    const FaceBox* __restrict__ boxes,
                                                    const unsigned char* __restrict__ owned, int F,
-                                                   float* __restrict__ parts, SweepList sl, int clip_len,
+                                                   double* __restrict__ parts, SweepList sl, int clip_len,
                                                    unsigned short* __restrict__ lsum, int nred,
                                                    const float* __restrict__ red_partials, float* __restrict__ frame_rec,
                                                    float* __restrict__ loss_out, int out_stride,
@@ -1551,7 +1552,7 @@ __device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, b
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES_EU, 8))) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
                                                    const SweepSrc* __restrict__ srcs,
                                                    const uint4* __restrict__ lrec, int B, int F, int S,
-                                                   float eps, float* __restrict__ parts,
+                                                   float eps, double magic, double* __restrict__ parts,
                                                    const unsigned short* __restrict__ lsum,
                                                    const unsigned short* __restrict__ alpha16,
                                                    const unsigned int* __restrict__ ts_flag,
@@ -1569,7 +1570,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
     struct FaceLds { SweepFace f; int pad; };
     struct ItemLds { SweepItem it; int pad; };
     __shared__ FaceLds s_face[4][SWEEP_PASS_FACES];
-    __shared__ float s_fg[4][SWEEP_PASS_FACES][6];
+    __shared__ double s_fg[4][SWEEP_PASS_FACES][6];
     __shared__ int s_start[4][64];
     __shared__ int s_head[4][256];
     __shared__ ItemLds s_item[4][64];
@@ -1651,7 +1652,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                 const int ent = 4 * k + (lane >> 4);
                 if (ent < nfp) reinterpret_cast<int*>(&s_face[wv][ent].f)[lane & 15] = row[k];
             }
-            for (int i = lane; i < SWEEP_PASS_FACES * 6; i += 64) (&s_fg[wv][0][0])[i] = 0.f;
+            for (int i = lane; i < SWEEP_PASS_FACES * 6; i += 64) (&s_fg[wv][0][0])[i] = 0.0;
             wave_sync();
             // family constants of the pass's faces: one division per (face, family) instead of one per item
             for (int idx = lane; idx < nfp * 12; idx += 64) {
@@ -1769,10 +1770,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
             const bool geo = q.geo;
             const int b = fc.b, fn = fc.bf - b * F + var * F;
             const bool use0 = p10 != (float)d0r, use1 = p00 != (float)d0r;
-            // 1-ulp reciprocals: these only scale the pseudo-distances (compared at 1e-3), unlike c2 below, which picks
-            // the integer end of the inward range and stays an IEEE division
-            const float c0 = use0 ? num * __builtin_amdgcn_rcpf(p10 - (float)d0r) : 0.f;
-            const float c1 = use1 ? num * __builtin_amdgcn_rcpf((float)d0r - p00) : 0.f;
+            // (IEEE divisions, like c2 below: every operand of a term is a defined function of the face and the line)
+            const float c0 = use0 ? num / (p10 - (float)d0r) : 0.f;
+            const float c1 = use1 ? num / ((float)d0r - p00) : 0.f;
             const bool act0 = geo && (ent & (1 << 12));   // outward: my own sample just inside the edge      (stage 1 looked
             const bool act1 = geo && (ent & (1 << 13));   // inward: only if the sample just outside is empty   both up)
             // [0] outward, from the sample just outside the edge to the border; [1] inward, across the triangle
@@ -1854,7 +1854,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                 wave_sync();
                 const int* st = s_start[wv];
                 int cur = -1;
-                float acc0 = 0.f, acc1 = 0.f;
+                double acc0 = 0.0, acc1 = 0.0;
                 int carry = 0;                 // (item + 1) that owns the pairs running into the current batch
                 // 256 pairs per round, four CONSECUTIVE pairs per lane.  Which item a pair belongs to comes from a
                 // scatter + max-scan instead of a search: every item whose first pair falls into the round drops its
@@ -1921,63 +1921,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                             const int meta = qmeta[k], key = valid ? (meta & 0x3ff) : cur;
                             if (key != cur) {
                                 if (cur >= 0) {
-                                    float* f = s_fg[wv][cur & 15];
-                                    atomicAdd(f + ((cur >> 4) & 7), acc0);
-                                    atomicAdd(f + ((cur >> 7) & 7), acc1);
+                                    double* f = s_fg[wv][cur & 15];
+                                    unsafeAtomicAdd(f + ((cur >> 4) & 7), acc0);
+                                    unsafeAtomicAdd(f + ((cur >> 7) & 7), acc1);
                                 }
                                 cur = key;
-                                acc0 = 0.f;
-                                acc1 = 0.f;
+                                acc0 = 0.0;
+                                acc1 = 0.0;
                             }
                             // (an inward pair counts only if this winding owns the source: masked by a zero `diff`)
                             const bool take = valid && (!ph1[k] || sc[k].owner == qq.fn);
                             sweep_term(take ? (ph1[k] ? sc[k].g : -sc[k].g) : 0.0f, sc[k].d1, qq.x, qq.c0, qq.c1,
-                                       (meta & (1 << 10)) != 0, (meta & (1 << 11)) != 0, eps, acc0, acc1);
+                                       (meta & (1 << 10)) != 0, (meta & (1 << 11)) != 0, eps, magic, acc0, acc1);
                         }
                     }
                 }
                 if (cur >= 0) {
-                    float* f = s_fg[wv][cur & 15];
-                    atomicAdd(f + ((cur >> 4) & 7), acc0);
-                    atomicAdd(f + ((cur >> 7) & 7), acc1);
+                    double* f = s_fg[wv][cur & 15];
+                    unsafeAtomicAdd(f + ((cur >> 4) & 7), acc0);
+                    unsafeAtomicAdd(f + ((cur >> 7) & 7), acc1);
                 }
             }
             wave_sync();
             }   // stage-2 trips
-            // ---- results of the faces of this pass
+            // ---- results of the faces of this pass.  The sums are exact (see hm_quant), so a face cut by unit boundaries is
+            // simply added by its units with hardware double atomics onto the target the compaction zeroed: any order gives
+            // the same value, nobody waits, no partial records, no tickets.
             if (lane < nfp) {
                 const SweepFace& ff = s_face[wv][lane].f;
-                const int eg = first + fb + lane;
                 const int off = ff.off, nit = (int)ff.cum[11];
                 const int u_lo = off >> SWEEP_USHIFT, u_hi = (off + nit - 1) >> SWEEP_USHIFT;
-                float v[6];
+                double v[6];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) v[k] = s_fg[wv][lane][k];
-                float* out = parts + (long)ff.bf * 6;
+                double* out = parts + (long)ff.bf * 6;
                 if (u_lo == u_hi) {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) out[k] = v[k];
-                } else if ((ff.flags & 1) || u_hi == u_lo + 1) {
-                    // two units: 0 + a + b in either order is the same float, so two fire-and-forget hardware atomics
-                    // are deterministic and nobody waits (the compaction zeroed the target); (capacity overflow: atomics)
+                } else {
 #pragma unroll
                     for (int k = 0; k < 6; ++k) unsafeAtomicAdd(out + k, v[k]);
-                } else {
-                    float* mp = sl.upart + ((long)u + eg) * 6;
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) hm_partial_store(mp + k, v[k]);
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    const unsigned int t = atomicAdd(sl.tickets + eg, 1u);
-                    if (t == (unsigned)(u_hi - u_lo)) {
-                        float sacc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                        for (int uu = u_lo; uu <= u_hi; ++uu) {
-                            const float* rp = sl.upart + ((long)uu + eg) * 6;
-#pragma unroll
-                            for (int k = 0; k < 6; ++k) sacc[k] += hm_partial_load(rp + k);
-                        }
-#pragma unroll
-                        for (int k = 0; k < 6; ++k) out[k] = sacc[k];
-                    }
                 }
             }
             if (nfp < SWEEP_PASS_FACES) break;          // the face behind this pass starts beyond the unit
@@ -1994,7 +1977,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
 
 // ---------------------------------------------------------------- backward, pass 3: vertex gather + projection backward
 // adjacency: CSR over vertices, items = face*3 + corner (shared topology) ; grad_verts (B,V,3) overwritten.
-__global__ void k_bwd_gather(const float* __restrict__ parts, const int* __restrict__ adj_off,
+__global__ void k_bwd_gather(const double* __restrict__ parts, const int* __restrict__ adj_off,
                              const int* __restrict__ adj_items, const float* __restrict__ verts,
                              const float* __restrict__ K, int B, int V, int F, float orig_size,
                              float* __restrict__ grad_ndc, float* __restrict__ grad_verts)
@@ -2002,19 +1985,20 @@ __global__ void k_bwd_gather(const float* __restrict__ parts, const int* __restr
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)B * V) return;
     const int b = (int)(i / V), v = (int)(i % V);
-    float gu = 0.f, gv = 0.f;
-    const float2* pf = reinterpret_cast<const float2*>(parts + (long)b * F * 6);
+    double su = 0.0, sv = 0.0;                          // exact: the per-corner sums are multiples of the quantum
+    const double2* pf = reinterpret_cast<const double2*>(parts + (long)b * F * 6);
     const int a1 = adj_off[v + 1];
     for (int a = adj_off[v]; a < a1; a += 8) {          // eight corners at a time: item loads, then gradient loads
-        int item[8];                                    // face * 3 + corner = float2 index into parts
+        int item[8];                                    // face * 3 + corner = double2 index into parts
 #pragma unroll
         for (int k = 0; k < 8; ++k) item[k] = a + k < a1 ? adj_items[a + k] : -1;
-        float2 g2[8];
+        double2 g2[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) g2[k] = item[k] >= 0 ? pf[item[k]] : make_float2(0.f, 0.f);
+        for (int k = 0; k < 8; ++k) g2[k] = item[k] >= 0 ? pf[item[k]] : make_double2(0.0, 0.0);
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { gu += g2[k].x; gv += g2[k].y; }
+        for (int k = 0; k < 8; ++k) { su += g2[k].x; sv += g2[k].y; }
     }
+    const float gu = (float)su, gv = (float)sv;
     if (grad_ndc) { grad_ndc[3 * i] = gu; grad_ndc[3 * i + 1] = gv; grad_ndc[3 * i + 2] = 0.f; }
     const float* k = K + b * 9;
     const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
@@ -2346,7 +2330,7 @@ size_t hm_sil_workspace_bytes(int B, int V, int F, int S)
 struct SilWs {
     unsigned int* counter; float* frame_rec;
     float* ndc; float* faces9; FaceBox* boxes; int* idx_map; unsigned short* alpha16; float* dimg;
-    float* partials; float* gimg; unsigned short* planes; float* parts;
+    float* partials; float* gimg; unsigned short* planes; double* parts;
     unsigned char* owned; int* bin_cnt; unsigned int* bin_done; unsigned char* region_state; int* bin_list;
     uint4* lrec; SweepSrc* srcs; unsigned short* lsum;
     SweepList sweep;
@@ -2369,7 +2353,7 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
     w.partials = (float*)p; p += al256((size_t)B * (S / 8) * (S / 8) * 16);
     w.gimg = (float*)p; p += al256((size_t)B * is * is * 4);
     w.planes = (unsigned short*)p; p += al256((size_t)B * is * (is / 16) * 4) * 2;      // (B, T, T, 4, 16) u16
-    w.parts = (float*)p; p += al256((size_t)B * F * 24 * 4);
+    w.parts = (double*)p; p += al256((size_t)B * F * 24 * 4);      // (6 doubles per face for the sweeps; 9 floats for the depth backward)
     w.owned = (unsigned char*)p; p += al256((size_t)B * F * 2);
     w.bin_cnt = (int*)p; w.bin_done = (unsigned int*)(p + (size_t)B * SR_MAX * 4); p += al256((size_t)B * SR_MAX * 8);
     w.region_state = (unsigned char*)p; p += al256((size_t)B * (S / 16) * (S / 16));
@@ -2417,12 +2401,12 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
                        w.counter + 24, w.ts + 2 * ts_raster_units(B, S));
 }
 static int g_sweep_blocks = SWEEP_BLOCKS;
-static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, hipStream_t stream)
+static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, int sum_log2q, hipStream_t stream)
 {
     const int nsort = g_raster_reorder ? 1 : 0;      // (see hm_tune_raster_reorder: one workgroup more, eight workers less)
     const int blocks = max(8, (min(min(hm_cdiv((long)B * F, 2), g_sweep_blocks), TS_SWEEP_WGS - 8) & ~7) - 8 * nsort);   // workers: a multiple of 8, see the unit loop
     hipLaunchKernelGGL(k_bwd_sweep, dim3(nsort + blocks), dim3(256), 0, stream, w.sweep,
-                       w.idx_map, w.srcs, w.lrec, B, F, S, eps, w.parts, w.lsum, w.alpha16, w.counter + 24,
+                       w.idx_map, w.srcs, w.lrec, B, F, S, eps, hm_sum_magic(sum_log2q), w.parts, w.lsum, w.alpha16, w.counter + 24,
                        w.ts + 2 * (ts_raster_units(B, S) + ts_lines_units(B, F, S)), nsort, w.wo_dyn, w.wo_tmp, w.wg_cost,
                        w.counter + 26, (int)ts_raster_units(B, S));
 }
@@ -2571,9 +2555,10 @@ int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss
 int hm_sil_bwd_phase_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                            const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                            const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-                           int clip_len, float* loss_out, int out_stride, int phases, hipStream_t stream)
+                           int clip_len, float* loss_out, int out_stride, int phases, int sum_log2q, hipStream_t stream)
 {
     HM_CHECK_ARG(!loss_out || ((mode == 1 || mode == 2) && keep_sum));
+    HM_CHECK_ARG(sum_log2q <= 0 && sum_log2q >= -60);
     HM_CHECK_ARG(verts && K && adj_off && adj_items && workspace);        // grad_verts == NULL: no vertex gather (see hm_sil_parts)
     HM_CHECK_ARG(HM_CLIP_LEN_OK(B, clip_len));
     if (clip_len == 0) clip_len = B;
@@ -2591,7 +2576,7 @@ int hm_sil_bwd_phase_clips(const float* verts, const float* K, int B, int V, int
     if (phases & 1) launch_lines(w, B, F, S, mode, upstream, keep_sum, clip_len, stream, loss_out, out_stride);
     HM_TIME_MARK(3, stream);
     if (!(phases & 2)) return hm_launch_status();
-    launch_sweep(w, B, F, S, eps, stream);
+    launch_sweep(w, B, F, S, eps, sum_log2q, stream);
     HM_TIME_MARK(4, stream);
     if (grad_verts)
         hipLaunchKernelGGL(k_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
@@ -2601,22 +2586,23 @@ int hm_sil_bwd_phase_clips(const float* verts, const float* K, int B, int V, int
 int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                      const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                      const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-                     int clip_len, float* loss_out, int out_stride, hipStream_t stream)
+                     int clip_len, float* loss_out, int out_stride, int sum_log2q, hipStream_t stream)
 {
     return hm_sil_bwd_phase_clips(verts, K, B, V, F, S, orig_size, eps, mode, upstream, grad_pooled, keep_sum, adj_off, adj_items,
-                                  face_order, grad_verts, grad_ndc, workspace, clip_len, loss_out, out_stride, 3, stream);
+                                  face_order, grad_verts, grad_ndc, workspace, clip_len, loss_out, out_stride, 3, sum_log2q, stream);
 }
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-               hipStream_t stream)
+               int sum_log2q, hipStream_t stream)
 {
     return hm_sil_bwd_clips(verts, K, B, V, F, S, orig_size, eps, mode, upstream, grad_pooled, keep_sum, adj_off, adj_items,
-                            face_order, grad_verts, grad_ndc, workspace, 0, nullptr, 0, stream);
+                            face_order, grad_verts, grad_ndc, workspace, 0, nullptr, 0, sum_log2q, stream);
 }
 
-// (B,F,3,2) d loss / d NDC (x, y) per face corner, as left by the last hm_sil_bwd: input of hm_rigid_bwd_sil.
-const float* hm_sil_parts(const void* workspace, int B, int V, int F, int S)
+// (B,F,3,2) DOUBLES: d loss / d NDC (x, y) per face corner, as left by the last hm_sil_bwd (exact sums of terms on the
+// grid 2^sum_log2q, see hm_quant): input of hm_rigid_bwd_sil.
+const double* hm_sil_parts(const void* workspace, int B, int V, int F, int S)
 {
     return carve((void*)workspace, B, V, F, S).parts;
 }
@@ -2647,8 +2633,8 @@ int hm_depth_bwd(const float* verts, const float* K, int B, int V, int F, int S,
     if (S % 16 != 0) return HM_ERR_UNSUPPORTED;
     SilWs w = carve(workspace, B, V, F, S);
     hipLaunchKernelGGL(k_depth_bwd_faces, dim3(hm_cdiv((long)B * F * 64, 256)), dim3(256), 0, stream, w.faces9, w.boxes,
-                       w.idx_map, grad_pooled_depth, w.owned, B, F, S, w.parts);
-    hipLaunchKernelGGL(k_depth_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, w.parts, adj_off,
+                       w.idx_map, grad_pooled_depth, w.owned, B, F, S, (float*)w.parts);
+    hipLaunchKernelGGL(k_depth_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, (const float*)w.parts, adj_off,
                        adj_items, verts, K, B, V, F, orig_size, grad_verts);
     return hm_launch_status();
 }
@@ -2692,7 +2678,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
                         work_order, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, workspace, stream);
     if (rc != HM_OK) return rc;
     rc = hm_sil_bwd(verts, K, B, V, F, S, 1.0f, 1e-3f, 1, upstream, nullptr, keep_sum, adj_off, adj_items, face_order,
-                    grad_verts, nullptr, workspace, stream);
+                    grad_verts, nullptr, workspace, 0, stream);
     if (rc != HM_OK) return rc;
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
@@ -2725,7 +2711,7 @@ int hm_bench_sil_kernels(const float* verts, const int* faces, const float* K, i
     avg_ms[0] = ms / (float)reps;
     (void)hipMemsetAsync(w.bin_cnt, 0, (size_t)B * SR_MAX * 4, stream);
     (void)hipEventRecord(e0, stream);
-    for (int i = 0; i < reps; ++i) launch_sweep(w, B, F, S, 1e-3f, stream);
+    for (int i = 0; i < reps; ++i) launch_sweep(w, B, F, S, 1e-3f, 0, stream);
     (void)hipEventRecord(e1, stream);
     (void)hipEventSynchronize(e1);
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -2884,6 +2870,13 @@ int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float*
 {
     SilWs w = carve((void*)workspace, B, V, F, S);
     return hipMemcpyAsync(out, w.faces9, (size_t)B * F * 9 * 4, hipMemcpyDeviceToDevice, stream) == hipSuccess
+               ? HM_OK : HM_ERR_LAUNCH;
+}
+// (B,F,3,2) doubles: the per-(face, corner) sums of the last backward (tests: compared bit for bit with the CPU oracle)
+int hm_sil_read_parts(const void* workspace, int B, int V, int F, int S, double* out, hipStream_t stream)
+{
+    SilWs w = carve((void*)workspace, B, V, F, S);
+    return hipMemcpyAsync(out, w.parts, (size_t)B * F * 6 * 8, hipMemcpyDeviceToDevice, stream) == hipSuccess
                ? HM_OK : HM_ERR_LAUNCH;
 }
 #ifdef HM_CHAIN_STAMPS

@@ -650,15 +650,16 @@ class FusedStepper:
                         P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
                         P(sctx.face_order), None, None, P(sctx.workspace), CL,
                         self._slot("loss_sil_obj") if self.sil_reduce_in_bwd else None, NS)
+            q2 = sctx.sum_log2q          # grid of the order-independent sums (the same for the sweeps and the rigid backward)
             # (no vertex gather; the loss / IoU values come out of its first launch)
             if self.pairs_after_lines:
                 # a clip batch: the line expansion - latency-bound, and the kernel of this chain that suffers most from
                 # neighbours holding its wave slots - runs ALONE; the pair-wise terms of the side stream wait for its end
-                ck(L.hm_sil_bwd_phase_clips(*bwd_args, 1, sa), "sil_bwd(lines)")
+                ck(L.hm_sil_bwd_phase_clips(*bwd_args, 1, q2, sa), "sil_bwd(lines)")
                 self.ev_lines.record(main)
-                ck(L.hm_sil_bwd_phase_clips(*bwd_args, 2, sa), "sil_bwd(sweeps)")
+                ck(L.hm_sil_bwd_phase_clips(*bwd_args, 2, q2, sa), "sil_bwd(sweeps)")
             else:
-                ck(L.hm_sil_bwd_clips(*bwd_args, sa), "sil_bwd")
+                ck(L.hm_sil_bwd_clips(*bwd_args, q2, sa), "sil_bwd")
         # ---------------- B: hand forward, pair-wise losses, hand backward
         with torch.cuda.stream(side):
             if not on["sil"]:    # (with the silhouette term the face setup of hm_sil_fwd has written self.vo already)
@@ -885,7 +886,7 @@ class FusedStepper:
                                         L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
                                         P(sctx.adj_items), P(self.vo), P(self.sil_K), 1.0, sctx.F, B, Vo,
                                         P(m.rotations_object.grad), P(m.translations_object.grad),
-                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sa),
+                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sctx.sum_log2q, sa),
                "rigid_bwd(obj) + silhouette gather")
         else:
             ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
@@ -943,7 +944,7 @@ class FusedStepper:
             ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps,
                                   2 if self.lw["lw_sil_obj"] > 0 else 1, P(self.up_sil), None, P(m.keep_sum),
                                   P(sctx.adj_off), P(sctx.adj_items), P(sctx.face_order), None, None, P(sctx.workspace), 0,
-                                  slot("loss_sil_obj"), NS, sa), "sil_bwd")
+                                  slot("loss_sil_obj"), NS, sctx.sum_log2q, sa), "sil_bwd")
         # ---------------- B: hands
         with torch.cuda.stream(side):
             if not on["sil"]:
@@ -1053,7 +1054,7 @@ class FusedStepper:
                                         L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
                                         P(sctx.adj_items), P(self.vo), P(self.sil_K), 1.0, sctx.F, B, Vo,
                                         P(m.rotations_object.grad), P(m.translations_object.grad),
-                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), 0, sa),
+                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), 0, sctx.sum_log2q, sa),
                "rigid_bwd(obj) + silhouette gather")
         else:
             ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
@@ -1080,7 +1081,7 @@ class FusedStepper:
                               sa), "sil_fwd")
         ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps, 2,
                               P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items), P(sctx.face_order),
-                              None, None, P(sctx.workspace), CL, None, NS, sa), "sil_bwd")
+                              None, None, P(sctx.workspace), CL, None, NS, sctx.sum_log2q, sa), "sil_bwd")
 
     def _depth_render(self, verts, ctx, V_, sil, dep, stream_id):
         """depth + silhouette images of one mesh at the full-image camera (reference homan.py:391,406), all frames"""

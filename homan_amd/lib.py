@@ -27,12 +27,12 @@ _SIGNATURES = {
     "hm_tune_lds_pad": (_I, [_I, _I]),
     "hm_debug_sweep_caps": (_I, [_I]),
     "hm_shade_rgb": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _VP, _F, _F, _VP, _VP, _VP, _VP]),
-    "hm_rigid_bwd_sil": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
+    "hm_rigid_bwd_sil": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_sil_reduce": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_depth_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_ordinal_depth_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_ordinal_depth_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
-    "hm_sil_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_sil_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_bench_sil_kernels": (_I, [_VP, _VP, _VP, _I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
                                   _I, _VP, _VP]),
     "hm_sil_read_boxes": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
@@ -46,6 +46,7 @@ _SIGNATURES = {
     "hm_debug_read_partials": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_idx_map": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_faces9": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
+    "hm_sil_read_parts": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_rigid_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "hm_rigid_bwd": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_rigid_workspace_bytes": (_SZ, [_I]),
@@ -83,7 +84,7 @@ _SIGNATURES = {
     "hm_rigid_fwd_clips": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP]),
     "hm_rigid_bwd_clips": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_rigid_bwd_sil_clips": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP,
-                                    _VP, _I, _VP]),
+                                    _VP, _I, _I, _VP]),
     "hm_sum_small_clips": (_I, [_VP, _I, _F, _VP, _F, _VP, _I, _VP]),
     "hm_mano_fwd_clips": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_mano_fwd_rows": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),
@@ -93,9 +94,9 @@ _SIGNATURES = {
     "hm_sil_fwd_phase_clips": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP,
                                     _VP, _VP, _I, _I, _VP, _I, _I, _VP, _I, _VP]),
     "hm_sil_reduce_clips": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP]),
-    "hm_sil_bwd_clips": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _VP]),
+    "hm_sil_bwd_clips": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _I, _VP]),
     "hm_sil_bwd_phase_clips": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _I,
-                                    _VP]),
+                                    _I, _VP]),
     "hm_v2d_fwd_clips": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_smooth_fwd_clips": (_I, [_VP, _I, _I, _I, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_priors_fwd_clips": (_I, [_VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),

@@ -58,6 +58,10 @@ class SilhouetteContext:
         wo = (np.arange(batch, dtype=np.int64)[None, :] << 16) | regions[:, None]
         self.work_order = torch.from_numpy(wo.reshape(-1).astype(np.int32)).to(device)
         self.face_order = None
+        # grid of the backward's order-independent sums (include/homan_amd.h, "ORDER-INDEPENDENT SUMS"): 0 = the default
+        # 2^-44, right for the normalised silhouette loss of the joint fit; the pose initialisation's unnormalised sums of
+        # squares set a coarser one
+        self.sum_log2q = 0
         nbytes = _lib.lib().hm_sil_workspace_bytes(self.B, self.V, self.F, self.S)
         self.workspace = torch.zeros(nbytes, dtype=torch.uint8, device=device)   # holds a self-resetting ticket
 
@@ -138,6 +142,13 @@ class SilhouetteContext:
                                                   _lib.ptr(out), _lib.stream()), "hm_sil_read_idx_map")
         return out
 
+    def parts(self):
+        """(B,F,3,2) float64: per-(face, corner) NDC gradients of the last backward (exact sums, see include/homan_amd.h)"""
+        out = torch.empty(self.B, self.F, 3, 2, dtype=torch.float64, device=self.workspace.device)
+        _lib.check(_lib.lib().hm_sil_read_parts(_lib.ptr(self.workspace), self.B, self.V, self.F, self.S,
+                                                _lib.ptr(out), _lib.stream()), "hm_sil_read_parts")
+        return out
+
     def faces9(self):
         out = torch.empty(self.B, self.F, 9, device=self.workspace.device)
         _lib.check(_lib.lib().hm_sil_read_faces9(_lib.ptr(self.workspace), self.B, self.V, self.F, self.S,
@@ -175,7 +186,7 @@ class _SilhouetteLoss(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_bwd(
             _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), sctx.eps(), 1,
             _lib.ptr(g_loss), None, _lib.ptr(keep_sum), _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
-            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
+            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), sctx.sum_log2q, _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None, None, None, None
 
 
@@ -205,7 +216,7 @@ class _SilhouetteRender(torch.autograd.Function):
             _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), sctx.eps(), 0,
             None, _lib.ptr(g_img), None, _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
             _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), _lib.ptr(sctx.grad_ndc) if getattr(sctx, "grad_ndc", None) is not None else None,
-            _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
+            _lib.ptr(sctx.workspace), sctx.sum_log2q, _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None
 
 
@@ -238,7 +249,7 @@ class _SilhouetteRenderNoAA(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_bwd(
             _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), sctx.eps(), 3,
             None, _lib.ptr(g_img), None, _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
-            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
+            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), sctx.sum_log2q, _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None
 
 
@@ -283,7 +294,7 @@ class _MaskedSilhouetteL2NoAA(torch.autograd.Function):
         _lib.check(_lib.lib().hm_sil_bwd(
             _lib.ptr(verts), _lib.ptr(K), sctx.B, sctx.V, sctx.F, sctx.S, float(ctx.orig_size), sctx.eps(), 4,
             _lib.ptr(g_loss), None, None, _lib.ptr(sctx.adj_off), _lib.ptr(sctx.adj_items),
-            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), _lib.stream()), "hm_sil_bwd")
+            _lib.ptr(sctx.face_order), _lib.ptr(grad_verts), None, _lib.ptr(sctx.workspace), sctx.sum_log2q, _lib.stream()), "hm_sil_bwd")
         return grad_verts, None, None, None, None, None
 
 

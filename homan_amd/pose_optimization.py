@@ -128,6 +128,10 @@ class PoseOptimizer(nn.Module):
         self._keep1, self._ref1 = self.keep_mask[0].contiguous(), self.image_ref[0].contiguous()
         self._K_all = self.K.repeat(n, 1, 1).contiguous()
         self._sil_ctx = ops.SilhouetteContext(self.faces, self.vertices.shape[1], n, size // 2, dev)
+        # the masked L2 of :138-143 is an unnormalised sum of squares: per-sample gradients are O(1), pseudo-gradient terms up
+        # to 2 / eps, per-frame sums up to ~1e7 - the order-independent sums of the backward run on the grid 2^-24 (exact up to
+        # 5e8, resolution 6e-8) instead of the joint fit's 2^-44
+        self._sil_ctx.sum_log2q = -24
 
     def apply_transformation(self):
         """:98-103: vertices @ rot6d_to_matrix(rotations) + translations (csrc/geometry.hip, unit scale)."""
@@ -266,10 +270,11 @@ def _fused_loop(model, lr, num_iterations):
            "hm_sil_fwd")
         ck(L.hm_sil_reduce(n, V, F, S, None, None, P(frame), P(sctx.workspace), st), "hm_sil_reduce")
         ck(L.hm_sil_bwd(P(verts), P(K_all), n, V, F, S, 1.0, eps, 4, P(ones), None, None, P(sctx.adj_off), P(sctx.adj_items),
-                        P(sctx.face_order), None, None, P(sctx.workspace), st), "hm_sil_bwd")
+                        P(sctx.face_order), None, None, P(sctx.workspace), sctx.sum_log2q, st), "hm_sil_bwd")
         ck(L.hm_rigid_bwd_sil(P(model.vertices), P(model.rotations), P(model._one), 0, tp, tw, tn,
                               L.hm_sil_parts(P(sctx.workspace), n, V, F, S), P(sctx.adj_off), P(sctx.adj_items), P(verts),
-                              P(K_all), 1.0, F, n, V, P(model.rotations.grad), P(model.translations.grad), None, P(rws), st),
+                              P(K_all), 1.0, F, n, V, P(model.rotations.grad), P(model.translations.grad), None, P(rws),
+                              sctx.sum_log2q, st),
            "hm_rigid_bwd_sil")
         opt.step(zero_grad=False)
         # mask + (chamfer = 0) + offscreen, the order of sum(loss_dict.values()); best-ever bookkeeping in the same launch

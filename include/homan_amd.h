@@ -59,9 +59,17 @@ size_t hm_rigid_workspace_bytes(int N);
  * gradients of the edge sweeps (sil_parts = hm_sil_parts(workspace) after an hm_sil_bwd called with grad_verts == NULL;
  * adj_off / adj_items / cam_verts / K / orig_size / F as given to that call): no gather launch, no (N,V,3) round trip. */
 int hm_rigid_bwd_sil(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
-                     const float* weights, int n_terms, const float* sil_parts, const int* adj_off, const int* adj_items,
+                     const float* weights, int n_terms, const double* sil_parts, const int* adj_off, const int* adj_items,
                      const float* cam_verts, const float* K, float orig_size, int F, int N, int V, float* g_rot6d,
-                     float* g_trans, float* g_scale_part, void* workspace, hipStream_t stream);
+                     float* g_trans, float* g_scale_part, void* workspace, int sum_log2q, hipStream_t stream);
+/* ORDER-INDEPENDENT SUMS (sum_log2q).  Every reduction on the object's gradient chain - the per-(face, corner) sums of the
+ * edge sweeps, the vertex gather, the per-frame sums of the rigid backward - rounds its addends to multiples of the quantum
+ * 2^sum_log2q (0 = the default 2^-44; -60 <= sum_log2q <= 0) and adds them in double, which is exact while |sum| < 2^53
+ * quanta: the result is a function of the SET of addends, independent of launch geometry, unit composition and atomics'
+ * arrival order, and the CPU oracle (oracle/csrc/objchain.c) reproduces it bit for bit.  With the per-term arithmetic in
+ * IEEE operations this makes the free-running object trajectory of reference homan/jointopt.py:158-192 bit-equal to the
+ * CPU path's.  Callers whose gradients are O(1) or larger (pose initialisation: unnormalised sums of squares) pass a
+ * coarser grid, e.g. -24; both calls of a backward (hm_sil_bwd*, hm_rigid_bwd_sil*) must be given the same value. */
 /* Off-screen penalty of the object-pose initialisation, reference homan/pose_optimization.py:112-135: hinge on the six
  * clipping planes of the projected vertices (K: ONE (3,3) camera, normalised, orig_size 1), per candidate pose:
  * out[n] = weight * sum_v (...), grad (N,V,3) = d out[n] / d verts[n]. */
@@ -163,7 +171,7 @@ int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss
 int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-               hipStream_t stream);
+               int sum_log2q, hipStream_t stream);
 /* Backward of the depth image (neural_renderer backward_depth_map, reached from reference homan/homan.py:391,406):
  * grad_pooled_depth (B,S,S) -> grad_verts (B,V,3), for the frame state the last hm_sil_fwd left in `workspace`. */
 int hm_depth_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size,
@@ -213,11 +221,14 @@ int hm_debug_sweep_caps(int cap);
 int hm_shade_rgb(const float* verts, const int* faces, int faces_bstride, const float* textures, int B, int V, int F, int S,
                  const float* light_dir, float intensity_ambient, float intensity_directional, const float* background,
                  float* rgb, void* workspace, hipStream_t stream);
-/* device pointer to the (B,F,3,2) per-(face, corner) NDC gradients left in `workspace` by the last hm_sil_bwd */
-const float* hm_sil_parts(const void* workspace, int B, int V, int F, int S);
+/* device pointer to the (B,F,3,2) DOUBLES left in `workspace` by the last hm_sil_bwd: per-(face, corner) NDC gradients as
+ * exact sums on the grid 2^sum_log2q */
+const double* hm_sil_parts(const void* workspace, int B, int V, int F, int S);
 /* forward intermediates kept in the workspace (tests): face-index map (B,2S,2S) int32, packed NDC faces (B,F,9) */
 int hm_sil_read_idx_map(const void* workspace, int B, int V, int F, int S, int* out, hipStream_t stream);
 int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
+/* the (B,F,3,2) doubles of hm_sil_parts copied to a caller's device buffer (tests) */
+int hm_sil_read_parts(const void* workspace, int B, int V, int F, int S, double* out, hipStream_t stream);
 /* per-face screen boxes (B,F) x 8 bytes {x0|winding<<14, y0, x1, y1} u16 */
 int hm_sil_read_boxes(const void* workspace, int B, int V, int F, int S, void* out, hipStream_t stream);
 
@@ -313,10 +324,10 @@ int hm_rigid_bwd_clips(const float* mesh, const float* rot6d, const float* scale
                        float* g_rot6d, float* g_trans, float* g_scale_part, void* workspace, int clip_len,
                        hipStream_t stream);
 int hm_rigid_bwd_sil_clips(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
-                           const float* const* g_terms, const float* weights, int n_terms, const float* sil_parts,
+                           const float* const* g_terms, const float* weights, int n_terms, const double* sil_parts,
                            const int* adj_off, const int* adj_items, const float* cam_verts, const float* K,
                            float orig_size, int F, int N, int V, float* g_rot6d, float* g_trans, float* g_scale_part,
-                           void* workspace, int clip_len, hipStream_t stream);
+                           void* workspace, int clip_len, int sum_log2q, hipStream_t stream);
 /* out[c] = w0 * sum(parts[c*n .. c*n+n)) + w1 * extra[c] */
 int hm_sum_small_clips(const float* parts, int n, float w0, const float* extra, float w1, float* out, int nclips,
                        hipStream_t stream);
@@ -357,13 +368,13 @@ int hm_sil_reduce_clips(int B, int V, int F, int S, const float* keep_sum, float
 int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                      const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                      const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-                     int clip_len, float* loss_out, int out_stride, hipStream_t stream);
+                     int clip_len, float* loss_out, int out_stride, int sum_log2q, hipStream_t stream);
 /* The same backward in two calls (phases: bit 0 = masks + line expansion + work list, bit 1 = edge sweeps + vertex gather; 3 =
  * hm_sil_bwd_clips), for a caller whose other streams wait for the END of the line expansion. */
 int hm_sil_bwd_phase_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,
                      const float* upstream, const float* grad_pooled, const float* keep_sum, const int* adj_off,
                      const int* adj_items, const int* face_order, float* grad_verts, float* grad_ndc, void* workspace,
-                     int clip_len, float* loss_out, int out_stride, int phases, hipStream_t stream);
+                     int clip_len, float* loss_out, int out_stride, int phases, int sum_log2q, hipStream_t stream);
 /*   loss_out (optional, modes 1 / 2): the loss / IoU reduction of hm_sil_reduce_clips (same arithmetic) done by extra
  *   workgroups at the front of the backward's first launch, for a forward that was called with loss_out == NULL: the value
  *   is only logged, so it need not cost a launch on the chain raster -> lines -> sweeps. */

@@ -14,7 +14,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, "csrc", f) for f in ("nmr_raster.c", "sdf.c")]
+    srcs = [os.path.join(_HERE, "csrc", f) for f in ("nmr_raster.c", "sdf.c", "objchain.c")]
     stale = (not os.path.exists(_SO)) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s))
     if force or stale:
@@ -41,12 +41,25 @@ def lib():
         _lib.orc_sdf_grid.restype = None
         _lib.orc_point_triangle_distance.argtypes = [fp, fp, fp, fp]
         _lib.orc_point_triangle_distance.restype = cf
+        dp, vp = ctypes.POINTER(ctypes.c_double), ctypes.c_void_p
+        _lib.orc_nmr_grad_faces_alpha_exact.argtypes = [fp, ip, fp, ci, ci, ci, cf, ci, dp]
+        _lib.orc_nmr_grad_faces_alpha_exact.restype = None
+        _lib.orc_rigid_bwd_sil_exact.argtypes = [fp, fp, cf, ci, vp, fp, ci, dp, ip, ip, fp, fp, cf, ci, ci, ci, ci, fp, fp,
+                                                 fp, fp]
+        _lib.orc_rigid_bwd_sil_exact.restype = None
+        _lib.orc_sum_magic.argtypes = [ci]
+        _lib.orc_sum_magic.restype = ctypes.c_double
     return _lib
 
 
 def fptr(a):
     assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_float))
+
+
+def dptr(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
 
 
 def iptr(a):

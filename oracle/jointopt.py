@@ -16,6 +16,33 @@ from . import yana
 from .model import OracleHOMan
 
 
+def parameter_groups(model, lr):
+    """reference homan/jointopt.py:128-151."""
+    rigid = [v for k, v in model.named_parameters() if "mano" not in k and "rotation" not in k]
+    rotation = [v for k, v in model.named_parameters() if ("rotation" in k) and ("mano" not in k)]
+    return [{"params": rigid, "lr": lr},
+            {"params": [model.mano_pca_pose, model.mano_betas], "lr": lr * 10},
+            {"params": rotation, "lr": lr * 10}]
+
+
+def reproducible_step(model, loss_weights, optimizer, log2q=0):
+    """One iteration of the loop below with the parts fp32 leaves open pinned down (oracle/objchain.py, oracle/adam.py):
+    forward + autograd as always, then the object's pose gradients REPLACED by the written-out chain with order-independent
+    sums (same mathematics, a defined rounding), then the written-out Adam (`optimizer` = oracle.adam.Adam).  The object's
+    trajectory is then a function of the inputs alone - the same for any number of host threads - and bit-equal to the HIP
+    loop's.  -> (loss_dict, metric_dict, total)."""
+    from . import objchain
+    optimizer.zero_grad()
+    loss_dict, metric_dict = model(loss_weights=loss_weights)
+    loss = sum(loss_dict[k] * loss_weights[k.replace("loss", "lw")] for k in loss_dict)
+    loss.backward()
+    grads = objchain.object_pose_grads(model, loss_weights, log2q)
+    model.rotations_object.grad = torch.from_numpy(grads["rotations_object"]).reshape(model.rotations_object.shape)
+    model.translations_object.grad = torch.from_numpy(grads["translations_object"]).reshape(model.translations_object.shape)
+    optimizer.step()
+    return loss_dict, metric_dict, loss
+
+
 def collate_inputs(person_parameters, object_parameters, objvertices, objfaces):
     """reference homan/jointopt.py:52-91."""
     cat = torch.cat
@@ -45,20 +72,19 @@ def collate_inputs(person_parameters, object_parameters, objvertices, objfaces):
     )
 
 
-def make_optimizer(model, lr):
-    """reference homan/jointopt.py:128-151."""
-    rigid = [v for k, v in model.named_parameters() if "mano" not in k and "rotation" not in k]
-    rotation = [v for k, v in model.named_parameters() if ("rotation" in k) and ("mano" not in k)]
-    return torch.optim.Adam([{"params": rigid, "lr": lr},
-                             {"params": [model.mano_pca_pose, model.mano_betas], "lr": lr * 10},
-                             {"params": rotation, "lr": lr * 10}])
+def make_optimizer(model, lr, reproducible=False):
+    """reference homan/jointopt.py:128-151.  reproducible: the written-out Adam of oracle/adam.py (see reproducible_step)."""
+    if reproducible:
+        from .adam import Adam
+        return Adam(parameter_groups(model, lr))
+    return torch.optim.Adam(parameter_groups(model, lr))
 
 
 def optimize_hand_object(person_parameters, object_parameters, class_name="default", objvertices=None,
                          objfaces=None, loss_weights=None, num_iterations=400, lr=1e-2, camintr=None,
                          hand_proj_mode="persp", optimize_mano=False, optimize_mano_beta=True,
                          optimize_object_scale=False, state_dict=None, image_size=640, mano_model=None,
-                         rend_size=256, log=True, ordinal_depth=False):
+                         rend_size=256, log=True, ordinal_depth=False, reproducible=False):
     kw = collate_inputs(person_parameters, object_parameters, objvertices, objfaces)
     model = OracleHOMan(camintr=camintr, class_name=class_name, int_scale_init=1,
                         hand_proj_mode=hand_proj_mode, optimize_mano=optimize_mano,
@@ -67,9 +93,18 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
                         ordinal_depth=ordinal_depth, **kw)
     if state_dict is not None:
         model.load_state_dict(state_dict, strict=False)
-    optimizer = make_optimizer(model, lr)
+    optimizer = make_optimizer(model, lr, reproducible)
     loss_evolution = defaultdict(list)
     for _ in range(num_iterations):
+        if reproducible:        # (same loop; the object's gradient chain and Adam in their written-out forms)
+            loss_dict, metric_dict, loss = reproducible_step(model, loss_weights, optimizer)
+            if log:
+                for k, val in loss_dict.items():
+                    loss_evolution[k].append(val.item())
+                for k, val in metric_dict.items():
+                    loss_evolution[k].append(val)
+                loss_evolution["loss"].append(loss.item())
+            continue
         optimizer.zero_grad()
         loss_dict, metric_dict = model(loss_weights=loss_weights)
         weighted = {k: loss_dict[k] * loss_weights[k.replace("loss", "lw")] for k in loss_dict}

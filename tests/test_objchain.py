@@ -1,0 +1,110 @@
+"""The written-out object chain (oracle/objchain.py, oracle/csrc/objchain.c, oracle/adam.py) against the faithful
+restatement it must agree with - autograd through OracleHOMan.forward (pinned to the reference's goldens by
+tests/test_oracle_golden.py) and torch.optim.Adam - and the property it exists for: its results do not depend on the
+number of host threads.  CPU only."""
+import copy
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def _clip_model(mano_model, seed=0, frames=4, size=64, obj="cube"):
+    from homan_amd import synth
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    return OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                       image_size=size, mano_model=mano_model, rend_size=size, **kw), clip
+
+
+@pytest.mark.parametrize("obj", ["cube", "bottle"])
+def test_written_out_chain_equals_autograd(obj, mano_model):
+    from homan_amd import synth
+    from oracle import objchain
+    model, _ = _clip_model(mano_model, seed=3, obj=obj)
+    lw = dict(synth.STEP1_LOSS_WEIGHTS)
+    loss_dict, _ = model(loss_weights=lw)
+    sum(loss_dict[k] * lw[k.replace("loss", "lw")] for k in loss_dict).backward()
+    got = objchain.object_pose_grads(model, lw)
+    for name in ("rotations_object", "translations_object"):
+        ref = getattr(model, name).grad.numpy()
+        scale = np.abs(ref).max()
+        assert scale > 0
+        np.testing.assert_allclose(got[name].reshape(ref.shape) / scale, ref / scale, atol=2e-5, err_msg=name)
+
+
+def test_exact_pseudo_gradient_equals_the_faithful_loop(mano_model):
+    """per (face, corner): the exact-sum variant against orc_nmr_grad_faces_alpha (the published loop order, fp32 sums)"""
+    from homan_amd import synth
+    from oracle import clib, objchain
+    model, _ = _clip_model(mano_model, seed=5, obj="bottle")
+    lw = dict(synth.STEP1_LOSS_WEIGHTS)
+    _, st = objchain.object_pose_grads(model, lw, return_stages=True)
+    f, idx, ga = st["faces_ndc"], st["idx"], st["grad_alpha"]
+    B, NF = f.shape[:2]
+    gf = np.zeros((B, NF, 9), np.float32)
+    clib.lib().orc_nmr_grad_faces_alpha(clib.fptr(f), clib.iptr(idx), clib.fptr(ga), B, NF, idx.shape[1], 1e-3, clib.fptr(gf))
+    gf = gf.reshape(B, NF, 3, 3)[..., :2]
+    F = NF // 2
+    ref = gf[:, :F] + gf[:, F:, ::-1]                 # corner k of the reversed copy is mesh corner 2 - k
+    scale = np.abs(ref).max()
+    assert scale > 0
+    np.testing.assert_allclose(st["parts"] / scale, ref / scale, atol=2e-6)
+
+
+def test_written_out_adam_equals_torch_adam():
+    from oracle.adam import Adam
+    torch.manual_seed(0)
+    a = [torch.nn.Parameter(torch.randn(7, 3)), torch.nn.Parameter(torch.randn(5))]
+    b = [torch.nn.Parameter(p.detach().clone()) for p in a]
+    ta = torch.optim.Adam([{"params": a[:1], "lr": 1e-2}, {"params": a[1:], "lr": 1e-1}])
+    tb = Adam([{"params": b[:1], "lr": 1e-2}, {"params": b[1:], "lr": 1e-1}])
+    for step in range(25):
+        gs = [torch.randn_like(p) * (10.0 ** (step % 5 - 3)) for p in a]
+        for p, q, g in zip(a, b, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        ta.step()
+        tb.step()
+        for p, q in zip(a, b):
+            np.testing.assert_allclose(q.detach().numpy(), p.detach().numpy(), rtol=2e-6, atol=1e-7)
+
+
+_THREADS_SCRIPT = """
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+torch.set_num_threads(int(sys.argv[1]))
+from homan_amd.mano_assets import synthetic_mano
+from homan_amd import synth
+from tests.test_objchain import _clip_model
+from oracle.jointopt import make_optimizer, reproducible_step
+mano = synthetic_mano(0)
+model, _ = _clip_model(mano, seed=1, frames=4, size=64, obj="cube")
+lw = dict(synth.CFG1_LOSS_WEIGHTS)
+opt = make_optimizer(model, 1e-2, reproducible=True)
+for _ in range(12):
+    reproducible_step(model, lw, opt)
+np.save(sys.argv[2], np.concatenate([model.rotations_object.detach().numpy().ravel(), model.translations_object.detach().numpy().ravel()]))
+"""
+
+
+def test_object_trajectory_does_not_depend_on_the_thread_count(tmp_path):
+    """the oracle's end state was a function of OMP_NUM_THREADS.  With the written-out chain the object's
+    parameters after 12 steps are bit-identical at 1 and 4 threads."""
+    outs = []
+    for nt in (1, 4):
+        out = str(tmp_path / f"p{nt}.npy")
+        env = dict(os.environ, OMP_NUM_THREADS=str(nt), MKL_NUM_THREADS=str(nt))
+        subprocess.run([sys.executable, "-c", _THREADS_SCRIPT.format(root=ROOT), str(nt), out], check=True, env=env, cwd=ROOT)
+        outs.append(np.load(out))
+    assert np.array_equal(outs[0], outs[1])

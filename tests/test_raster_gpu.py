@@ -181,7 +181,7 @@ def test_persistent_outputs_skip_is_invisible():
         one = torch.ones(1, device=dev)
         for sc, g in ((sp, gp), (sf, gf)):
             hlib.check(L.hm_sil_bwd(P(v), P(Kd), B, V, F, S, 1.0, 1e-3, 1, P(one), None, P(ksd), P(sc.adj_off),
-                                    P(sc.adj_items), None, P(g), None, P(sc.workspace), hlib.stream()), "hm_sil_bwd")
+                                    P(sc.adj_items), None, P(g), None, P(sc.workspace), 0, hlib.stream()), "hm_sil_bwd")
         assert torch.equal(gp, gf), step
 
 
