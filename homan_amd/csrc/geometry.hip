@@ -313,8 +313,10 @@ static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* 
     for (int k = 0; k < 5; ++k) { t.p[k] = k < n_terms ? g_terms[k] : nullptr; t.w[k] = k < n_terms ? weights[k] : 0.f; }
     // workspace (hm_rigid_workspace_bytes, zero-filled once): per-frame tickets + chunk partials -> grid (N, chunks);
     // without it one workgroup per frame does everything
-    const int threads = V > 512 ? 1024 : 256;
-    const int chunks = workspace ? min(RIGID_MAX_CHUNKS, hm_cdiv(V, 4 * threads)) : 1;
+    // exact sums: any split of the vertices gives the same result, so the frame goes to ceil(V / 256) small workgroups (one
+    // vertex per thread: one pass through the chain of dependent loads instead of one per vertex of a thread's share)
+    const int threads = exact ? 256 : (V > 512 ? 1024 : 256);
+    const int chunks = workspace ? min(RIGID_MAX_CHUNKS, hm_cdiv(V, exact ? threads : 4 * threads)) : 1;
     unsigned int* cnt = (unsigned int*)workspace;
     float* partials = workspace ? (float*)((char*)workspace + (((size_t)N * 4 + 255) & ~(size_t)255)) : nullptr;
     if (exact)

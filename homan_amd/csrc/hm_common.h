@@ -288,15 +288,30 @@ __device__ __forceinline__ double hm_quant(float x, double magic) { return ((dou
 
 // block-wide sums of N doubles (blockDim.x <= 1024, multiple of 64); results valid in every thread.  `red` must hold >= 16 * N
 // doubles.  Meant for EXACT sums (multiples of one quantum, see hm_quant): the combination order is then immaterial.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double hm_dpp_f64(double v)          // lanes the DPP control leaves unwritten read 0.0
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double hm_wave_sum_f64(double v)       // same DPP tree as hm_wave_sum: plain VALU moves, no LDS
+{
+    v += hm_dpp_f64<0xb1, 0xf>(v);
+    v += hm_dpp_f64<0x4e, 0xf>(v);
+    v += hm_dpp_f64<0x114, 0xf>(v);
+    v += hm_dpp_f64<0x118, 0xf>(v);
+    v += hm_dpp_f64<0x142, 0xa>(v);
+    v += hm_dpp_f64<0x143, 0xc>(v);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
 template <int N>
 __device__ __forceinline__ void hm_block_sum_n_f64(double (&v)[N], double* red)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
 #pragma unroll
-    for (int k = 0; k < N; ++k) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off, 64);
-    }
+    for (int k = 0; k < N; ++k) v[k] = hm_wave_sum_f64(v[k]);
+    if (nw == 1) return;
     __syncthreads();
     if (lane == 0) {
 #pragma unroll

@@ -498,7 +498,10 @@ class FusedStepper:
             # slot of the CUs next to the line expansion (lines 250 -> 226 us, iteration -4.4 % at 3 search workgroups per CU;
             # 2 per CU make the search itself the tail)
             nn_pad = os.environ.get("HOMAN_NN_PAD")
-            nn_pad = int(nn_pad) if nn_pad is not None else (40960 if C > 1 and not self.on["con"] else 0)
+            # (34 KB: with the sweep's 30.5 KB workgroups a CU then holds 4 sweeps + 1 search, 2 + 2 or 1 + 3 - the mixes the
+            #  40 KB ballast gave next to the 28.9 KB workgroups of the float sweeps; at 40 KB the search found room only
+            #  next to THREE sweep workgroups and took 297 instead of 137 us, same-box profile)
+            nn_pad = int(nn_pad) if nn_pad is not None else (34816 if C > 1 and not self.on["con"] else 0)
             fam_pads = [int(x) for x in os.environ.get("HOMAN_FAM_PADS", "0,0,0,0,0").split(",")]
             # the hints are process-wide values read when a launch is issued (= captured): set, capture, restore - whatever
             # happens in between (a capture that raises must not leave them changed for the next stepper)

@@ -33,9 +33,16 @@ def reproducible_step(model, loss_weights, optimizer, log2q=0):
     loop's.  -> (loss_dict, metric_dict, total)."""
     from . import objchain
     optimizer.zero_grad()
-    loss_dict, metric_dict = model(loss_weights=loss_weights)
-    loss = sum(loss_dict[k] * loss_weights[k.replace("loss", "lw")] for k in loss_dict)
-    loss.backward()
+    obj = (model.rotations_object, model.translations_object)
+    for p in obj:               # (their gradients come from the written-out chain below: autograd need not walk the renderer)
+        p.requires_grad_(False)
+    try:
+        loss_dict, metric_dict = model(loss_weights=loss_weights)
+        loss = sum(loss_dict[k] * loss_weights[k.replace("loss", "lw")] for k in loss_dict)
+        loss.backward()
+    finally:
+        for p in obj:
+            p.requires_grad_(True)
     grads = objchain.object_pose_grads(model, loss_weights, log2q)
     model.rotations_object.grad = torch.from_numpy(grads["rotations_object"]).reshape(model.rotations_object.shape)
     model.translations_object.grad = torch.from_numpy(grads["translations_object"]).reshape(model.translations_object.shape)

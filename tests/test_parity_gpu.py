@@ -1,18 +1,18 @@
-"""Final-loss / final-vertex parity after a full optimisation (the second half of BASELINE.json's metric), bounded.
+"""Final-loss / final-vertex parity after a full optimisation: the second half of BASELINE.json's metric, at north_star's
+bars (1e-4 relative on every loss along the way, 1e-3 mm on the final vertices).
 
 BASELINE cfg1 - 1 clip, 10 frames 128x128, cube, silhouette + 2-D keypoint losses, 100 Adam steps, the configuration the
-reference CPU path is defined on - is optimised by the HIP fused loop and by the CPU oracle loop from identical inputs
-(the measurement bench.py reports as `final_loss_parity.cfg1`).
+reference CPU path is defined on - is optimised by the HIP fused loop and by the CPU oracle loop from identical inputs, both
+FREE-running (the measurement bench.py reports as `final_loss_parity.cfg1`; reference loop: homan/jointopt.py:158-192).
 
-What can be bounded and what cannot: the keypoint term is smooth, and the hand it drives ends within 1e-3 mm of the CPU
-path after 100 steps (north_star's vertex bar).  The silhouette term is piecewise constant in the pose (hard rasteriser)
-and Adam normalises step sizes, so the OBJECT's trajectory is chaotic: two runs of the SAME implementation whose inputs
-differ by 1e-7 m end centimetres apart (the control experiment below measures it).  For the object the test therefore
-bounds what is well defined - the first steps, and the final loss value, which both runs reach equally well."""
+Why this can hold although the silhouette term is piecewise constant in the pose (a last-bit difference in a parameter flips
+a sample, Adam's normalised steps amplify it: rounds 1-3 measured centimetres after 100 steps): every reduction on the
+object's gradient chain is an order-independent sum on both sides (include/homan_amd.h "ORDER-INDEPENDENT SUMS",
+oracle/objchain.py) and every per-term operation is IEEE, so the object's parameters are BIT-EQUAL after every step - there
+is nothing to amplify.  The hand is driven by smooth terms and stays within a few ulp."""
 import os
 import sys
 
-import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -23,19 +23,26 @@ def test_cfg1_final_loss_and_vertex_parity(mano_model):
     sys.path.insert(0, ROOT)
     import bench
     out = bench.cfg1_parity(mano_model, seeds=[0, 1, 2], steps=100)
-    ctrl = out["cpu_vs_cpu_control"]
     for row in out["seeds"]:
-        assert row["rel_diff_step0"] < 1e-5, row                          # identical inputs, identical first loss
-        assert row["first_step_over_tol"] is None or row["first_step_over_tol"] >= 3, row
-        assert row["final_vertex_diff_mm"]["hand"] < 1e-3, row            # smooth part of the problem: north_star's bar
-        assert row["rel_diff_final"] < 0.10, row                          # same optimum quality (chaotic path, same basin)
-        assert row["final_loss_hip"] < 0.35 * row["first_loss"] and row["final_loss_cpu"] < 0.35 * row["first_loss"]
-    # the object's final vertices: HIP-vs-CPU distance is of the order the CPU path has against itself under a 1e-7 m
-    # perturbation of one input - i.e. it measures the algorithm's sensitivity, not a discrepancy between implementations
-    worst = max(r["final_vertex_diff_mm"]["object"] for r in out["seeds"])
-    assert ctrl["final_vertex_diff_mm"]["object"] > 1.0, ctrl             # the control itself separates by millimetres+
-    assert worst < 40 * max(ctrl["final_vertex_diff_mm"]["object"], 5.0), (worst, ctrl)
-    assert ctrl["final_vertex_diff_mm"]["hand"] < 1e-3
-    # distributions of the final loss agree
-    m = out["final_loss_mean"]
-    assert abs(m["hip"] - m["cpu"]) < 0.05 * m["cpu"], m
+        assert row["first_step_over_tol"] is None, row                    # every logged loss within 1e-4 at every step
+        assert row["max_rel_diff_any_step"] < 1e-4, row
+        assert row["object_params_bit_equal"], row                        # rotations_object / translations_object, final
+        assert row["final_vertex_diff_mm"]["object"] < 1e-3, row          # north_star's vertex bar (in fact 0.0)
+        assert row["final_vertex_diff_mm"]["hand"] < 1e-3, row
+        assert row["final_loss_hip"] < 0.35 * row["first_loss"], row      # ... of a fit that did converge
+    assert out["all_within_bars"]
+    # the control: the CPU path against ITSELF from inputs that differ by 1e-7 m still separates by millimetres - the
+    # problem is as sensitive as ever, the two implementations simply no longer differ
+    ctrl = out["cpu_vs_cpu_control"]
+    assert ctrl["final_vertex_diff_mm"]["object"] > 1.0, ctrl
+
+
+def test_free_running_object_trajectory_is_bit_equal_step1_set(mano_model):
+    """a cfg2-shaped clip (bottle, full step-1 loss set: silhouette + smoothness reach the object) at reduced size: object pose
+    parameters bit-equal after each of 60 free-running steps, all losses within 1e-4, final vertices within 1e-3 mm"""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = bench.free_run_parity(mano_model, steps=60, frames=8, size=96, obj="bottle")
+    assert out["object_params_bit_equal_all_steps"], out["stage_report"]
+    assert out["first_step_over_tol"] is None, (out["max_rel_loss"], out["worst_loss"])
+    assert out["final_vertex_diff_mm"]["object"] == 0.0 and out["final_vertex_diff_mm"]["hand"] < 1e-3, out["final_vertex_diff_mm"]
