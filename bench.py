@@ -276,6 +276,7 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
     with torch.no_grad():
         dvo = 1e3 * (model.get_verts_object()[0].cpu() - om.get_verts_object()[0]).abs().max().item()
         dvh = 1e3 * (model.get_verts_hand()[0].cpu() - om.get_verts_hand()[0]).abs().max().item()
+    frames, obj = len(clip["object_parameters"]), f"{clip['objfaces'].shape[1]} faces"
     return dict(config=f"{frames} frames {size}x{size}, {obj}, " + ("step-2" if step2 else "step-1 / custom") +
                 f" loss set, {steps} free-running steps: HIP fused loop vs the CPU oracle's reproducible loop",
                 steps=steps, tol=tol, first_step_object_params_differ=first_obj_diff,
@@ -287,6 +288,41 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
                 stage_report=stage_report, cpu_its_per_s=steps / max(t_cpu, 1e-9),
                 cores=int(os.environ.get("OMP_NUM_THREADS", "1")),
                 per_step=[{k: r[k] for k in ("step", "object_bit_equal", "max_rel_loss", "max_param_diff")} for r in rows][:: max(1, steps // 25)])
+
+
+def end_to_end_clips(mano, lw, clips=16, clips_per_batch=8, steps=400, frames=30, size=256, seed0=2000):
+    """BASELINE cfg4's clips/s, END TO END: `clips` cfg2-shaped clips fitted `steps` iterations each through resident steppers
+    (homan_amd.jointopt.ClipFitter, the sample loop of reference fit_vid_dataset.py:190-379), timed from the per-frame input
+    dicts on the host to the results (parameters, vertices, loss_evolution) back on the host - model build, workspace
+    allocation, calibration and graph capture included for the first batch of a shape, input load + replay + read-back for
+    the others.  Generating the synthetic clips (the dataset / detector side) is outside the timed region."""
+    import torch
+    from homan_amd import synth
+    from homan_amd.jointopt import ClipFitter
+    sil_fn, hand_fn = synth.hip_clip_fns(mano)
+    data = [synth.make_clip(seed=seed0 + i, frames=frames, rend_size=size, image_size=size, obj="bottle", silhouette_fn=sil_fn,
+                            hand_verts_fn=hand_fn) for i in range(clips)]
+    fitter = ClipFitter(lw, num_iterations=steps, optimize_mano=True, image_size=size, mano_model=mano, rend_size=size,
+                        clips_per_batch=clips_per_batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = fitter.fit(data)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    t = fitter.timing
+    first = clips_per_batch                       # the clips of the batch that built the stepper
+    reused_clips = clips - first
+    per_reused = (t["load"] + (t["iterations"] + t["read_back"]) * reused_clips / clips) / max(reused_clips, 1)
+    its = t["iterations"] / clips
+    return dict(clips=clips, clips_per_batch=clips_per_batch, steps_per_clip=steps, seconds=el, clips_per_s_end_to_end=clips / el,
+                split_s={k: t[k] for k in ("collate", "build", "load", "iterations", "read_back")},
+                steppers_built=t["built"], batches_reused=t["reused"],
+                repeated_shape=dict(seconds_per_clip=per_reused, clips_per_s=1.0 / per_reused,
+                                    setup_fraction_of_fit=(t["load"] / max(reused_clips, 1)) / its,
+                                    note="a clip of a shape already resident: input load + its share of the replays + read-back"),
+                final_loss_mean=float(sum(r["loss_evolution"]["loss"][-1] for r in res) / clips),
+                what="ClipFitter: one resident stepper (buffers, workspaces, ONE hipGraph) per shape signature; wall clock from "
+                     "the input dicts to the results on the host")
 
 
 def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottle", seed=0, lr=1e-2, free_run=True,
@@ -671,6 +707,9 @@ def main():
                     help="final_loss_parity.free_run: this many FREE-running steps of the headline clip on the HIP loop and on the "
                          "CPU oracle's reproducible loop - object pose parameters bit-equal after every step, losses within 1e-4, "
                          "final vertices within 1e-3 mm (profiles/ holds a 400-step run); 0 = skip")
+    ap.add_argument("--e2e-clips", type=int, default=16,
+                    help="end_to_end: this many clips of the headline shape fitted 400 steps each through resident steppers "
+                         "(ClipFitter), wall clock from the input dicts to the results on the host; 0 = skip")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     args = ap.parse_args()
@@ -887,6 +926,11 @@ def main():
                           "so no sample flips; cfg2_first_steps is the headline run against the cpu_baseline leg's plain oracle "
                           "loop (torch Adam, autograd), which separates once a sample flips")
 
+    e2e = None
+    if rank == 0 and world == 1 and fused and args.e2e_clips > 0 and not args.depth:
+        del stepper
+        e2e = end_to_end_clips(mano, lw, clips=args.e2e_clips, clips_per_batch=max(1, min(args.multi_clip or 1, args.e2e_clips // 2)),
+                               steps=400, frames=B, size=S)
     if rank == 0:
         value = world * args.steps / elapsed
         line = {
@@ -905,7 +949,8 @@ def main():
             "clips_per_s_hbm_frac": algorithmic_bytes(B, S, F, V, args.step2)["total"] * value / (8.0e12 * world),
             "final_loss": evo["loss"][-1], "first_loss": evo["loss"][0],
             "roofline": roof, "steady_state": steady, "cpu_baseline": cpu, "multi_clip": multi,
-            "final_loss_parity": parity,
+            "final_loss_parity": parity, "end_to_end": e2e,
+            "clips_per_s_end_to_end": e2e["clips_per_s_end_to_end"] if e2e else None,
         }
         emit(line)
     if world > 1:

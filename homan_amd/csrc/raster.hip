@@ -2872,6 +2872,15 @@ int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float*
     return hipMemcpyAsync(out, w.faces9, (size_t)B * F * 9 * 4, hipMemcpyDeviceToDevice, stream) == hipSuccess
                ? HM_OK : HM_ERR_LAUNCH;
 }
+// hm_sil_fwd with persistent_outputs skips the epilogue of an empty region whose outputs already hold the empty pattern - which
+// depends on the loss inputs (keep / ref).  A caller that REUSES a workspace and its output buffers for another clip (new
+// masks in the same buffers) calls this once after loading them: every region writes its outputs again on the next forward.
+int hm_sil_invalidate_outputs(void* workspace, int B, int V, int F, int S, hipStream_t stream)
+{
+    HM_CHECK_ARG(workspace && B > 0 && S > 0);
+    SilWs w = carve(workspace, B, V, F, S);
+    return hipMemsetAsync(w.region_state, 0, (size_t)B * (S / 16) * (S / 16), stream) == hipSuccess ? HM_OK : HM_ERR_LAUNCH;
+}
 // (B,F,3,2) doubles: the per-(face, corner) sums of the last backward (tests: compared bit for bit with the CPU oracle)
 int hm_sil_read_parts(const void* workspace, int B, int V, int F, int S, double* out, hipStream_t stream)
 {

@@ -164,6 +164,76 @@ class HOMan(nn.Module):
             self.verts_object_init = self.get_verts_object()[0].detach().clone()
         self._setup_visualisation(batch)
 
+    # ------------------------------------------------------------------ another clip into the same model
+    def load_clip(self, translations_object, rotations_object, verts_object_og, translations_hand, rotations_hand,
+                  verts_hand_og, ref_verts2d_hand, mano_trans, mano_rot, mano_betas, mano_pca_pose, masks_object, masks_hand,
+                  camintr_rois_object, camintr_rois_hand, target_masks_object, target_masks_hand, cams_hand=None,
+                  camintr=None, int_scale_init=1.0, faces_object=None, faces_hand=None, hand_sides=None, **_same):
+        """The data arguments of the constructor (reference homan/homan.py:27-60) for ANOTHER clip of the same shapes, copied
+        IN PLACE into this model's Parameters and buffers: every context, workspace and captured graph built on them stays
+        valid (a resident stepper fits a stream of clips without rebuilding anything, jointopt.ClipFitter).  Same
+        preprocessing as __init__: rotation matrices -> 6-D, betas start at zero (:108), scales at `int_scale_init`,
+        target masks -> ref / keep (:131-134).  Topologies and hand sides are the model's own (checked when given)."""
+        f32 = lambda t: torch.as_tensor(t).detach().float()
+
+        def put(dst, src):
+            src = f32(src)
+            if tuple(src.shape) != tuple(dst.shape):
+                raise ValueError(f"load_clip: shape {tuple(src.shape)} does not fit the model's {tuple(dst.shape)}")
+            dst.data.copy_(src, non_blocking=True)
+
+        def rot6d(r):
+            r = f32(r)
+            return matrix_to_rot6d(r) if r.shape[-1] == 3 else r
+
+        if hand_sides is not None and list(hand_sides) != list(self.hand_sides):
+            raise ValueError("load_clip: other hand sides")
+        if faces_object is not None and not torch.equal(torch.as_tensor(faces_object)[0].cpu(), self.faces_object[0].cpu()):
+            raise ValueError("load_clip: other object topology")
+        with torch.no_grad():
+            put(self.translations_object, translations_object)
+            put(self.rotations_object, rot6d(rotations_object))
+            put(self.verts_object_og, verts_object_og)
+            put(self.translations_hand, translations_hand)
+            put(self.rotations_hand, rot6d(rotations_hand))
+            put(self.cams_hand, cams_hand if cams_hand is not None else torch.zeros_like(self.cams_hand))
+            put(self.mano_pca_pose, mano_pca_pose)
+            put(self.mano_rot, mano_rot)
+            if self.optimize_mano:
+                put(self.mano_trans, mano_trans)
+            self.mano_betas.data.zero_()
+            self.int_scales_hand.data.fill_(float(int_scale_init))
+            self.int_scales_object.data.fill_(float(int_scale_init))
+            put(self.verts_hand_og, verts_hand_og)
+            put(self.ref_verts2d_hand, ref_verts2d_hand)
+            tmo = f32(target_masks_object).to(self.ref_mask_object.device, non_blocking=True)
+            tmh = f32(target_masks_hand).to(self.ref_mask_hand.device, non_blocking=True)
+            put(self.ref_mask_object, tmo > 0)
+            put(self.keep_mask_object, tmo >= 0)
+            put(self.ref_mask_hand, tmh > 0)
+            put(self.keep_mask_hand, tmh >= 0)
+            put(self.camintr_rois_object, camintr_rois_object)
+            put(self.camintr_rois_hand, camintr_rois_hand)
+            if camintr is not None:
+                c = torch.as_tensor(camintr).float()
+                c = c.unsqueeze(0) if c.dim() == 2 else c
+                put(self.camintr, c.expand_as(self.camintr) if c.shape[0] == 1 else c)
+                self.losses.camintr.copy_(self.camintr)
+            if masks_hand is not None and hasattr(self, "masks_human"):
+                self.masks_human.copy_(torch.as_tensor(masks_hand).to(self.masks_human.dtype))
+            mo = torch.as_tensor(masks_object)
+            self.masks_object.copy_((mo.unsqueeze(0) if mo.dim() == 2 else mo).to(self.masks_object.dtype))
+            self.losses.keep_sum.copy_(self.keep_mask_object.sum().reshape(1))
+            self.losses.sil_ctx.invalidate_outputs()
+            self._mano_cache = None
+            if self._depth_state is not None:
+                ctx_o, ctx_h, m_o, m_h = self._depth_state
+                m_o.copy_((self.masks_object != 0).to(torch.uint8))
+                m_h.copy_((self.masks_human != 0).to(torch.uint8))
+            self.verts_hand_init.copy_(self.get_verts_hand()[0].detach())
+            self.verts_object_init.copy_(self.get_verts_object()[0].detach())
+            self._mano_cache = None
+
     # ------------------------------------------------------------------ visualisation (reference homan.py:168-219, 510-628)
     def _setup_visualisation(self, batch_size):
         """Renderer with the reference's light and the combined [object, hand...] scene meshes in prediction colours

@@ -174,7 +174,7 @@ class GraphStepper:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = _lib.new_graph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, pool=_lib.autograd_pool()):
             loss_dict, metric_dict, total = self._fwd_bwd(record=True)
             self.opt.step()
 
@@ -372,19 +372,10 @@ class FusedStepper:
         # bounding spheres, in MESH space, of the groups of 64 vertices in that order, per frame (a clip's frames share one mesh,
         # the clips of a batch need not): centre = mean, radius = farthest vertex.  The search carries them into camera space
         # with the frame's rigid transform instead of reducing the transformed vertices of every group in every workgroup.
+        self.Vo, self.B = Vo, B
         with torch.no_grad():
-            ng = (Vo + 63) // 64
-            vs = m.verts_object_og.detach()[:, self.obj_order.long()]                       # (B, Vo, 3) in group order
-            pad = ng * 64 - Vo
-            valid = torch.ones(Vo + pad, dtype=torch.bool, device=dev)
-            if pad:
-                vs = torch.cat([vs, vs[:, -1:].expand(-1, pad, -1)], 1)           # (repeats of a real vertex change nothing
-                valid[Vo:] = False                                                #  but the mean: masked out of it below)
-            grp = vs.reshape(B, ng, 64, 3)
-            wgt = valid.reshape(1, ng, 64, 1).float()
-            ctr = (grp * wgt).sum(2) / wgt.sum(2)
-            rad = ((grp - ctr[:, :, None]) ** 2).sum(-1).sqrt().amax(2)
-            self.obj_spheres = torch.cat([ctr, rad[..., None]], -1).contiguous()             # (B, ng, 4)
+            # (repeats of a real vertex pad the last group: they change nothing but the mean, and are masked out of it)
+            self.obj_spheres = self._group_spheres()                                         # (B, ng, 4)
         self.nn_spheres = os.environ.get("HOMAN_NN_SPHERES", "1") != "0"
         self.pooled = f(B, m.sil_ctx.S, m.sil_ctx.S)
         # silhouettes at a size off the kernels' 32-pixel tile grid (the reference's REND_SIZE is 256): rendered on the next
@@ -529,6 +520,65 @@ class FusedStepper:
                 tune.hm_tune_nn_lds_pad(prev_nn_pad)
                 for i, v in enumerate(prev_fam):
                     tune.hm_tune_lds_pad(i, v)
+
+    # ---- other clips into the resident stepper
+    def reload(self, clip_inputs):
+        """`clip_inputs`: one dict of HOMan data arguments per clip of the batch (what `collate_inputs` returns, + camintr),
+        clips of exactly the shapes and topology this stepper was built for.  Everything that depends on the clip is copied in
+        place - Parameters, buffers, per-clip normalisers, the search's bounding spheres - and everything that depends on the
+        FIT is reset - Adam moments, step counter, loss slots -; buffers, workspaces, streams and the captured hipGraph are
+        reused as they are.  The next `run(steps)` is the fit of the new clips, bit-identical to the fit a freshly built
+        stepper would make (tests/test_clip_fitter_gpu.py)."""
+        m = self.model
+        if self.on["depth"] and m.C > 1:
+            raise NotImplementedError("reload: the depth term's per-clip instance masks of a clip batch are not resident")
+        if len(clip_inputs) != m.C:
+            raise ValueError(f"reload: {len(clip_inputs)} clips for a stepper of {m.C}")
+        from .clipbatch import _PER_CLIP, _PER_FRAME
+        with torch.no_grad():
+            for c, (one, kw) in enumerate(zip(m.models, clip_inputs)):
+                one.load_clip(**kw)
+                if m.C > 1:     # the batch's own concatenated copies of the BUFFERS (Parameters are views of its storage)
+                    for k in _PER_FRAME + _PER_CLIP:
+                        if hasattr(m, k) and not isinstance(getattr(m, k), torch.nn.Parameter):
+                            m.clip_slice(getattr(m, k), c).copy_(getattr(one, k))
+                    m.keep_sum[c:c + 1].copy_(one.losses.keep_sum)
+            if m.C > 1:
+                m.sil_ctx.invalidate_outputs()
+            sx = m.sil_ctx
+            if sx.padded:       # (unpadded: these ARE the model's tensors)
+                self.sil_K.copy_(sx.K_eff(m.camintr_rois_object))
+                self.sil_keep.copy_(sx.pad(m.keep_mask_object))
+                self.sil_ref.copy_(sx.pad(m.ref_mask_object))
+            self.obj_spheres.copy_(self._group_spheres())
+            if self.on["depth"]:
+                self.dctx = m.models[0].depth_contexts()
+            for st_m, st_v in self.opt.state:
+                st_m.zero_()
+                st_v.zero_()
+            self.opt.step_t.zero_()
+            self.vals.zero_()
+            for p in m.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
+            if self.shared_scale:
+                self._sync_shared_scale_start()
+
+    def _group_spheres(self):
+        """bounding spheres, in MESH space, of the groups of 64 object vertices in `obj_order`, per frame: (B, groups, 4)"""
+        m, Vo, B = self.model, self.Vo, self.B
+        ng = (Vo + 63) // 64
+        vs = m.verts_object_og.detach()[:, self.obj_order.long()]
+        pad = ng * 64 - Vo
+        valid = torch.ones(Vo + pad, dtype=torch.bool, device=vs.device)
+        if pad:
+            vs = torch.cat([vs, vs[:, -1:].expand(-1, pad, -1)], 1)
+            valid[Vo:] = False
+        grp = vs.reshape(B, ng, 64, 3)
+        wgt = valid.reshape(1, ng, 64, 1).float()
+        ctr = (grp * wgt).sum(2) / wgt.sum(2)
+        rad = ((grp - ctr[:, :, None]) ** 2).sum(-1).sqrt().amax(2)
+        return torch.cat([ctr, rad[..., None]], -1).contiguous()
 
     # ---- shared object scale (BASELINE cfg5): C local replicas of one scalar, kept identical on every rank
     def _dist_on(self):
@@ -1206,6 +1256,109 @@ class ShardStepper:
         return out
 
 
+def _input_signature(kw, image_size, rend_size):
+    """what a resident stepper is built for, read off the collated inputs of a clip (cf. _shape_signature of a built model)"""
+    faces = np.ascontiguousarray(torch.as_tensor(kw["faces_object"])[0].cpu().numpy())
+    return (int(kw["translations_object"].shape[0]), int(kw["verts_object_og"].shape[1]), faces.shape[0], hash(faces.tobytes()),
+            tuple(kw["hand_sides"]), int(kw["mano_pca_pose"].shape[1]), tuple(kw["target_masks_object"].shape[1:]),
+            tuple(kw["masks_object"].shape[-2:]), int(image_size), int(rend_size))
+
+
+class ClipFitter:
+    """A stream of clips through RESIDENT steppers: the sample loop of reference fit_vid_dataset.py:190-379 - for every clip
+    `optimize_hand_object(...)`, then `model.state_dict()` / `get_verts_*` read back - without rebuilding anything for a clip
+    whose shapes have been seen before.  Per shape signature (frames, object topology, hands, sizes) ONE set of device buffers,
+    workspaces and ONE captured hipGraph stays resident (`max_resident` signatures, least recently used evicted); a new clip
+    of a known shape is copied into the static buffers (`FusedStepper.reload`), the graph replayed `num_iterations` times,
+    the results copied out.  What a fresh fit spends on building the model, zero-filling ~0.5 GB of workspace, calibrating
+    and capturing (about twice a 400-step fit) is paid once per shape, and the process holds a bounded
+    number of graphs however many clips it walks.  Results are bit-identical to fresh fits (tests/test_clip_fitter_gpu.py).
+
+    `clips_per_batch` > 1: clips of one shape are fitted that many at a time as one clip batch (one launch per kernel over
+    all of them); a last, smaller group of a shape runs through a stepper of its own size.
+    fit(clips) -> one result per clip, in order: {"loss_evolution", "state_dict" (Parameters + the buffers
+    fit_vid_dataset.py:366-379 / postprocess.py:16-77 read, host tensors), "verts_object", "verts_hand"}.
+    `timing` accumulates the seconds spent per stage {collate, build, load, iterations, read_back} and the clip count."""
+
+    READ_BACK = ["translations_object", "rotations_object", "translations_hand", "rotations_hand", "mano_pca_pose", "mano_rot",
+                 "mano_trans", "mano_betas", "int_scales_object", "int_scales_hand", "cams_hand"]
+
+    def __init__(self, loss_weights, num_iterations=400, lr=1e-2, clips_per_batch=1, max_resident=4, class_name="default",
+                 hand_proj_mode="persp", optimize_mano=True, optimize_mano_beta=True, optimize_object_scale=False,
+                 image_size=640, mano_model=None, rend_size=256, ordinal_depth=False):
+        self.lw, self.steps, self.lr = dict(loss_weights), int(num_iterations), float(lr)
+        self.cpb, self.max_resident = max(1, int(clips_per_batch)), max(1, int(max_resident))
+        self.model_kw = dict(class_name=class_name, int_scale_init=1, hand_proj_mode=hand_proj_mode, optimize_mano=optimize_mano,
+                             optimize_mano_beta=optimize_mano_beta, optimize_object_scale=optimize_object_scale,
+                             image_size=image_size, mano_model=mano_model, rend_size=rend_size, sync_metrics=False,
+                             ordinal_depth=ordinal_depth)
+        self.resident = OrderedDict()          # (signature, clips) -> FusedStepper
+        self.timing = dict(collate=0.0, build=0.0, load=0.0, iterations=0.0, read_back=0.0, clips=0, built=0, reused=0)
+
+    def _clock(self):
+        import time
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def _inputs(self, clip):
+        kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+        kw["camintr"] = clip.get("camintr")
+        return kw
+
+    def fit(self, clips):
+        t0 = self._clock()
+        nt = torch.get_num_threads()
+        torch.set_num_threads(1)       # (a few hundred small concatenations: waking a 64-thread pool for each costs 1.5 ms)
+        try:
+            kws = [self._inputs(c) for c in clips]
+        finally:
+            torch.set_num_threads(nt)
+        self.timing["collate"] += self._clock() - t0
+        groups = OrderedDict()
+        for i, kw in enumerate(kws):
+            groups.setdefault(_input_signature(kw, self.model_kw["image_size"], self.model_kw["rend_size"]), []).append(i)
+        results = [None] * len(clips)
+        for sig, idxs in groups.items():
+            for lo in range(0, len(idxs), self.cpb):
+                chunk = idxs[lo:lo + self.cpb]
+                for i, r in zip(chunk, self._fit_group(sig, [kws[i] for i in chunk])):
+                    results[i] = r
+        self.timing["clips"] += len(clips)
+        return results
+
+    def _fit_group(self, sig, kws):
+        key = (sig, len(kws))
+        t0 = self._clock()
+        stepper = self.resident.get(key)
+        if stepper is None:
+            models = [HOMan(**self.model_kw, **kw) for kw in kws]
+            stepper = FusedStepper(models, self.lw, self.lr, self.steps)
+            self.resident[key] = stepper
+            while len(self.resident) > self.max_resident:
+                self.resident.popitem(last=False)         # (its graph stays in lib._KEPT_GRAPHS: a few kilobytes)
+            self.timing["build"] += self._clock() - t0
+            self.timing["built"] += 1
+        else:
+            self.resident.move_to_end(key)
+            stepper.reload(kws)
+            self.timing["load"] += self._clock() - t0
+            self.timing["reused"] += 1
+        t1 = self._clock()
+        stepper.run(self.steps)
+        t2 = self._clock()
+        self.timing["iterations"] += t2 - t1
+        evo = stepper.loss_evolution(self.steps)
+        evo = evo if isinstance(evo, list) else [evo]
+        out = []
+        with torch.no_grad():
+            for one, e in zip(stepper.model.models, evo):
+                sd = {k: getattr(one, k).detach().cpu() for k in self.READ_BACK if hasattr(one, k)}
+                out.append(dict(loss_evolution=e, state_dict=sd, verts_object=one.get_verts_object()[0].detach().cpu(),
+                                verts_hand=one.get_verts_hand()[0].detach().cpu()))
+        self.timing["read_back"] += self._clock() - t2
+        return out
+
+
 def save_front_top(model, images, step, viz_folder, viz_len=7):
     """reference jointopt.py:159-176: frontal overlays over the top-down renders, frames side by side, halved in size
     (2x2 mean instead of cv2.resize), saved as <viz_folder>/<step:08d>.jpg.  -> path."""
@@ -1248,7 +1401,7 @@ def optimize_hand_object(person_parameters, object_parameters, class_name="defau
         if mode == "fused":
             try:
                 stepper = FusedStepper(model, loss_weights, lr, num_iterations)
-            except (NotImplementedError, _lib.HomanAmdError):
+            except NotImplementedError:       # (the capability guards only: a library error is a bug and propagates)
                 if not auto:
                     raise
                 mode = "graph"        # a configuration the fused launch sequence does not cover

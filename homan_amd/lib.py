@@ -47,6 +47,7 @@ _SIGNATURES = {
     "hm_sil_read_idx_map": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_faces9": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
     "hm_sil_read_parts": (_I, [_VP, _I, _I, _I, _I, _VP, _VP]),
+    "hm_sil_invalidate_outputs": (_I, [_VP, _I, _I, _I, _I, _VP]),
     "hm_rigid_fwd": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP]),
     "hm_rigid_bwd": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_rigid_workspace_bytes": (_SZ, [_I]),
@@ -180,3 +181,20 @@ def new_graph():
     if os.environ.get("HOMAN_KEEP_GRAPHS", "1") != "0":
         _KEPT_GRAPHS.append(g)
     return g
+
+
+# ... which holds for the FUSED steppers only.  A graph that captures HOMan.forward + autograd (jointopt.GraphStepper, the
+# eager-style loop of pose_optimization._graph_loop) owns every activation of the iteration in its private memory pool -
+# hundreds of MB per clip / frame - and keeping such graphs alive kept that memory too.  Those captures share ONE pool
+# (`torch.cuda.graph(g, pool=autograd_pool())`): the activations are temporaries, freed by the end of the capture, so the next
+# capture reuses the same blocks - the graphs stay alive (no destroy, no crash), the memory is bounded by the largest
+# iteration plus the few small tensors each capture keeps (tools/soak_dataset.py walks a dataset in graph mode).  Sound
+# because steppers are replayed one at a time and nothing but their kept outputs lives across replays.
+_AUTOGRAD_POOL = None
+
+
+def autograd_pool():
+    global _AUTOGRAD_POOL
+    if _AUTOGRAD_POOL is None:
+        _AUTOGRAD_POOL = torch.cuda.graph_pool_handle()
+    return _AUTOGRAD_POOL

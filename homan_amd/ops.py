@@ -142,6 +142,11 @@ class SilhouetteContext:
                                                   _lib.ptr(out), _lib.stream()), "hm_sil_read_idx_map")
         return out
 
+    def invalidate_outputs(self):
+        """the loss inputs (keep / ref masks) in the caller's buffers changed: see hm_sil_invalidate_outputs"""
+        _lib.check(_lib.lib().hm_sil_invalidate_outputs(_lib.ptr(self.workspace), self.B, self.V, self.F, self.S,
+                                                        _lib.stream()), "hm_sil_invalidate_outputs")
+
     def parts(self):
         """(B,F,3,2) float64: per-(face, corner) NDC gradients of the last backward (exact sums, see include/homan_amd.h)"""
         out = torch.empty(self.B, self.F, 3, 2, dtype=torch.float64, device=self.workspace.device)

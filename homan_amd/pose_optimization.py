@@ -221,7 +221,7 @@ def _graph_loop(model, lr, num_iterations):
         graph = _lib.new_graph()
         for p in params:
             p.grad.zero_()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, pool=_lib.autograd_pool()):
             step()
             for p in params:
                 p.grad.zero_()

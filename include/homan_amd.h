@@ -227,6 +227,10 @@ const double* hm_sil_parts(const void* workspace, int B, int V, int F, int S);
 /* forward intermediates kept in the workspace (tests): face-index map (B,2S,2S) int32, packed NDC faces (B,F,9) */
 int hm_sil_read_idx_map(const void* workspace, int B, int V, int F, int S, int* out, hipStream_t stream);
 int hm_sil_read_faces9(const void* workspace, int B, int V, int F, int S, float* out, hipStream_t stream);
+/* hm_sil_fwd(persistent_outputs = 1) leaves the epilogue of an empty region out when its outputs already hold the empty
+ * pattern, which depends on keep / ref.  After loading ANOTHER clip's masks into the same buffers (a resident stepper fitting
+ * a stream of clips, reference fit_vid_dataset.py:190-379) call this once: the next forward writes every region again. */
+int hm_sil_invalidate_outputs(void* workspace, int B, int V, int F, int S, hipStream_t stream);
 /* the (B,F,3,2) doubles of hm_sil_parts copied to a caller's device buffer (tests) */
 int hm_sil_read_parts(const void* workspace, int B, int V, int F, int S, double* out, hipStream_t stream);
 /* per-face screen boxes (B,F) x 8 bytes {x0|winding<<14, y0, x1, y1} u16 */
