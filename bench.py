@@ -42,7 +42,7 @@ def algorithmic_bytes(B, S, F, V, step2=False):
     return dict(total=total, raster=raster)
 
 
-def kernel_bytes(B, S, F):
+def kernel_bytes(B, S, F, noaa=False):
     """Algorithmic HBM traffic of ONE launch of the heavy silhouette kernels (every input read once, every output
     written once).
       k_raster_fwd: packed (B,F,3,3) faces + 8-byte boxes + super-region bin lists read; (2S)^2 int32 index map, pooled
@@ -52,11 +52,17 @@ def kernel_bytes(B, S, F):
                     (The per-line source arrays and the face records of the work list are data dependent - sources
                     ~0.3 MB, ~45 % of the faces are active - and not counted.)
       k_bwd_sweep : face records of the work list (64 B + 4 B first item, bound: every face), index map, per-line records
-                    read; per-face corner gradients (6 floats) written.  (Source arrays as above.)"""
+                    read; per-face corner gradients (6 doubles: exact sums) written.  (Source arrays as above.)
+    noaa (the pose initialisation: rendering without anti-aliasing): the raster writes the per-sample coverage image and the
+    per-sample loss gradient instead of the pooled ones, the line expansion reads that per-sample gradient."""
     is_ = 2 * S
     is2 = is_ ** 2
+    if noaa:
+        return {"k_raster_fwd": B * (F * (36 + 8 + 5) + is2 * 4 + 2 * is2 * 4 + S * S * 4 + 5 * is2 // 8),
+                "k_bwd_sweep": B * (F * (64 + 4) + is2 * 4 + is2 + F * 48),
+                "k_bwd_lines": B * (4 * is2 // 8 + is2 * 4 + is2 + F * (36 + 8 + 2))}
     return {"k_raster_fwd": B * (F * (36 + 8 + 5) + is2 * 4 + 4 * S * S * 4 + 5 * is2 // 8),
-            "k_bwd_sweep": B * (F * (64 + 4) + is2 * 4 + is2 + F * 24),
+            "k_bwd_sweep": B * (F * (64 + 4) + is2 * 4 + is2 + F * 48),
             "k_bwd_lines": B * (4 * is2 // 8 + S * S * 4 + is2 + F * (36 + 8 + 2))}
 
 
@@ -326,7 +332,7 @@ def end_to_end_clips(mano, lw, clips=16, clips_per_batch=8, steps=400, frames=30
 
 
 def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottle", seed=0, lr=1e-2, free_run=True,
-                    clip=None, lw=None, tol=1e-4):
+                    clip=None, lw=None, tol=1e-4, ordinal_depth=False):
     """Teacher-forced parity along the HIP trajectory (reference loop: homan/jointopt.py:158-192).
 
     The fused loop runs `steps` iterations one replay at a time.  BEFORE every step its parameters are loaded into the CPU
@@ -350,17 +356,30 @@ def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottl
                                hand_verts_fn=hand_fn)
     if lw is None:
         lw = dict(synth.STEP2_LOSS_WEIGHTS if step2 else synth.STEP1_LOSS_WEIGHTS)
+    if ordinal_depth:           # cfg2 as BASELINE.json words it (sil / kp / depth / smooth): reference homan.py:384-419
+        lw = dict(lw, lw_depth=1.0)
     common = dict(objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"], optimize_mano=True,
                   image_size=size, mano_model=mano, rend_size=size)
     model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
-                        sync_metrics=False, **common)
+                        sync_metrics=False, ordinal_depth=ordinal_depth, **common)
     st = FusedStepper(model, lw, lr, steps)
 
     def oracle_model():
         kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
                             clip["objvertices"], clip["objfaces"])
         return OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
-                           image_size=size, mano_model=mano, rend_size=size, **kw)
+                           image_size=size, mano_model=mano, rend_size=size, ordinal_depth=ordinal_depth, **kw)
+
+    def oracle_depth_idx(om):
+        """face-index maps of the two depth renders of the ordinal depth term (object, hand) at the full-image camera"""
+        with torch.no_grad():
+            r = o_nmr.Renderer(image_size=size, K=om.camintr, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
+            out = []
+            for v, fc in ((om.get_verts_object()[0], om.faces_object),
+                          (om.get_verts_hand()[0], om.faces_hand[0][None].repeat(om.camintr.shape[0], 1, 1))):
+                f = r._ndc_faces(v, fc, om.camintr, None, None, None, None)
+                out.append(o_nmr._RasterizeAlphaDepth.apply(f, 2 * size, r.near, r.far, r.rasterizer_eps)[2].numpy())
+            return out
 
     def oracle_idx(om):
         with torch.no_grad():
@@ -392,6 +411,7 @@ def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottl
         hip = {k: v[i] for k, v in hip.items()}
         grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
         idx_h = sctx.idx_map().cpu().numpy()
+        didx_h = [st.dctx[0].idx_map().cpu().numpy(), st.dctx[1].idx_map().cpu().numpy()] if ordinal_depth else None
         vo_h, vh_h = st.vo.cpu().numpy(), st.vh.cpu().numpy()
         forced.load_state_dict(params, strict=False)
         cpu = fwd_bwd(forced)
@@ -427,7 +447,9 @@ def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottl
                          vert_diff_mm=dict(object=1e3 * float(np.abs(vo_h - vo_c).max()), hand=1e3 * float(np.abs(vh_h - vh_c).max())),
                          vert_equal=dict(object=bool(np.array_equal(vo_h, vo_c)), hand=bool(np.array_equal(vh_h, vh_c))),
                          rel_loss=rel, rel_metric=met, handobj_maxdist_abs_m=maxdist_abs,
-                         collision_rel_given_hip_vertices=col_given))
+                         collision_rel_given_hip_vertices=col_given,
+                         flipped_depth_samples=([int((a != b).sum()) for a, b in zip(didx_h, oracle_depth_idx(forced))]
+                                                if ordinal_depth else None)))
         if free_run:
             # the free-running reference loop, one step behind the comparison: its parameters BEFORE its step i against the
             # HIP loop's parameters before step i
@@ -444,10 +466,13 @@ def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottl
                                   rel_diff_worst=max(abs(hip[k] - frow[k]) / max(abs(frow[k]), 1e-12)
                                                      for k in frow if k in hip and k.startswith("loss"))))
     out = dict(config=("cfg3" if step2 else "cfg2") + f"-shaped: {frames} frames {size}x{size}, {obj}, "
-               + ("step-2" if step2 else "step-1") + f" loss set, {steps} steps of the fused loop, every step re-evaluated by "
+               + ("step-2" if step2 else "step-1") + " loss set" + (" + ordinal depth term" if ordinal_depth else "") + f", {steps} steps of the fused loop, every step re-evaluated by "
                "the CPU oracle at the HIP parameters", steps=steps, tol=tol,
                max_rel_loss=max(r["max_rel_loss"] for r in rows), max_grad_err=max(r["max_grad_err"] for r in rows),
                flipped_samples=sum(r["flipped_samples"] for r in rows),
+               # (object: its vertices are bit-equal, so is its depth render; hand: vertices one ulp apart, a sample may flip)
+               flipped_depth_samples=(dict(object=sum(r["flipped_depth_samples"][0] for r in rows),
+                                           hand=sum(r["flipped_depth_samples"][1] for r in rows)) if ordinal_depth else None),
                max_vert_diff_mm=dict(object=max(r["vert_diff_mm"]["object"] for r in rows),
                                      hand=max(r["vert_diff_mm"]["hand"] for r in rows)),
                object_vertices_bit_equal=all(r["vert_equal"]["object"] for r in rows),
@@ -595,7 +620,7 @@ def pose_init_bench(args):
     # "graph" = that step captured in a hipGraph, "fused" (the default of find_optimal_pose) = the step as a fixed C-ABI launch
     # sequence without the autograd tape, in a hipGraph.  The fastest is reported, all are listed.
     loops, best = {}, None
-    for mode in ("eager", "graph", "fused"):
+    for mode in os.environ.get("HOMAN_POSEINIT_LOOPS", "eager,graph,fused").split(","):
         fit(3, mode)                               # warm-up (allocations, lazy init)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -607,6 +632,37 @@ def pose_init_bench(args):
     el = loops[best]
     with torch.no_grad():
         _, iou, _ = model()
+    # roofline of the dominant kernel of the fused step, measured inside its replayed hipGraph (the kernels stamp the device wall
+    # clock, as for the headline): a fit of the same candidates, its last `reps` replays stamped
+    reps = 20
+    trans0 = po.TCO_init_from_boxes_zup_autodepth(bbox, torch.matmul(verts.unsqueeze(0), rots), torch.as_tensor(K)[None]).unsqueeze(1)
+    sm = po.PoseOptimizer(ref_image=mask, vertices=verts, faces=faces, rotation_init=po.matrix_to_rot6d(rots),
+                          translation_init=trans0, num_initializations=n, K=roi)
+    stamps = po._fused_loop(sm, 1e-2, max(steps - reps, 3), stamp_reps=reps)[3]
+    kb = kernel_bytes(n, size // 2, int(faces.shape[0]), noaa=True)
+    pmc = {}
+    ppath = os.path.join(ROOT, "profiles", "r04_pmc_poseinit.json")
+    if os.path.exists(ppath):
+        pj = json.load(open(ppath))
+        if pj.get("shape") == dict(poses=n, size=size, faces=int(faces.shape[0])):
+            pmc = pj.get("per_launch", {})
+    per = {}
+    for name, us in stamps.items():
+        rec = dict(avg_launch_us=us, algorithmic_bytes=kb[name], achieved_GBps=kb[name] / (us * 1e-6) / 1e9)
+        c = pmc.get(name, {})
+        if c.get("traffic_bytes"):
+            rec["traffic_bytes"] = c["traffic_bytes"]
+        if c.get("SQ_INSTS_VALU"):
+            rec["valu_wave_instr"] = c["SQ_INSTS_VALU"]
+            rec["valu_frac"] = c["SQ_INSTS_VALU"] / (us * 1e-6 * 1024 * 2.4e9 / 4)
+        per[name] = rec
+    dom = max(per, key=lambda k: per[k]["avg_launch_us"])
+    roof = dict(bound="hbm", kernel=dom, achieved=per[dom]["achieved_GBps"], peak=8000.0, unit="GB/s",
+                frac=per[dom]["achieved_GBps"] / 8000.0, traffic=per[dom].get("traffic_bytes"),
+                avg_launch_us=per[dom]["avg_launch_us"], kernels=per,
+                timing=f"device wall clock stored by every workgroup at entry and exit in the last {reps} replays of a "
+                       f"{steps}-step fit's hipGraph (hm_sil_timestamps)",
+                traffic_source="profiles/r04_pmc_poseinit.json (rocprofv3 --pmc passes, tools/pmc_poseinit.sh)" if per[dom].get("traffic_bytes") else None)
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import poseopt
@@ -629,7 +685,7 @@ def pose_init_bench(args):
                                              f"loop = {best} (eager / graph: torch autograd + Adam over the HIP rasteriser; "
                                              f"fused: C-ABI launch sequence in a hipGraph)", "poses": n, "rend_size": size,
                                  "pose_steps_per_s_by_loop": {k: n * steps / v for k, v in loops.items()}},
-                      "best_iou": float(iou.max()), "seconds_per_fit": el, "cpu_baseline": cpu})
+                      "best_iou": float(iou.max()), "seconds_per_fit": el, "roofline": roof, "cpu_baseline": cpu})
 
 
 _REAL_STDOUT = None
@@ -916,8 +972,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, evo_cpu = cpu_baseline(clip, lw, mano, args.cpu_budget, rend_size=S, image_size=S, ordinal_depth=args.depth)
         parity = dict(cfg2_first_steps=trajectory_parity(evo, evo_cpu),
-                      lockstep=(lockstep_parity(mano, step2=args.step2, steps=args.lockstep, frames=B, size=S, clip=clip, lw=lw)
-                                if args.lockstep > 0 and not args.depth else None),
+                      lockstep=(lockstep_parity(mano, step2=args.step2, steps=args.lockstep, frames=B, size=S, clip=clip, lw=lw,
+                                                free_run=not args.depth, ordinal_depth=args.depth)
+                                if args.lockstep > 0 else None),
                       cfg1=cfg1_parity(mano, seeds=list(range(args.parity_seeds))) if args.parity_seeds > 0 else None,
                       free_run=(free_run_parity(mano, step2=False, steps=args.freerun, frames=B, size=S, clip=clip, lw=lw)
                                 if args.freerun > 0 and not args.step2 and not args.depth else None),

@@ -231,14 +231,17 @@ def _graph_loop(model, lr, num_iterations):
     return losses_out, best_rot.clone(), best_trans.clone()
 
 
-def _fused_loop(model, lr, num_iterations):
+def _fused_loop(model, lr, num_iterations, stamp_reps=0):
     """`num_iterations` steps of reference pose_optimization.py:330-357 as a fixed sequence of C-ABI launches, no autograd
     tape, replayed from one hipGraph: rigid transform of the n candidates, off-screen penalty (value + vertex gradients in
     one launch, hm_offscreen_fwd), no-anti-aliasing raster with the masked L2 + IoU fused per sample, edge sweeps, pose
     gradients with the silhouette gather inside (hm_rigid_bwd_sil), the fused multi-tensor Adam - what the eager loop spends
     on torch's element-wise kernels (a third of its step) is gone.  The chamfer term is multiplied by its weight 0 at the
     reference's only call site and is not evaluated (PoseOptimizer.forward does the same).  Best-ever bookkeeping as in
-    `_graph_loop`: the pose is copied AFTER the optimiser step that followed the evaluation (:348-353), strict `<`."""
+    `_graph_loop`: the pose is copied AFTER the optimiser step that followed the evaluation (:348-353), strict `<`.
+    stamp_reps > 0 (bench.py): that many MORE replays of the same graph with the heavy silhouette kernels stamping the device
+    wall clock (hm_sil_timestamps); their average durations in microseconds (raster, lines, sweep) are returned as a 4th
+    element."""
     from .jointopt import HmAdam
     assert model.lw_chamfer == 0, "the fused loop covers the reference's configuration (lw_chamfer = 0)"
     L, P, ck = _lib.lib(), _lib.ptr, _lib.check
@@ -297,8 +300,27 @@ def _fused_loop(model, lr, num_iterations):
         for _ in range(num_iterations - done):
             graph.replay()
     torch.cuda.synchronize()
+    stamps = None
+    if stamp_reps > 0 and done < num_iterations:
+        import ctypes
+        ws, dims = P(sctx.workspace), (n, V, F, S)
+        saved = torch.zeros(stamp_reps, L.hm_sil_timestamps_bytes(*dims) // 8, dtype=torch.int64, device=dev)
+        for i in range(stamp_reps):
+            ck(L.hm_sil_timestamps(ws, *dims, 1, _lib.stream()), "hm_sil_timestamps")
+            graph.replay()
+            ck(L.hm_sil_timestamps_save(ws, *dims, saved[i].data_ptr(), _lib.stream()), "hm_sil_timestamps_save")
+        ck(L.hm_sil_timestamps(ws, *dims, 0, _lib.stream()), "hm_sil_timestamps")
+        us3, acc = (ctypes.c_float * 3)(), [0.0, 0.0, 0.0]
+        for i in range(stamp_reps):
+            ck(L.hm_sil_timestamps_read(None, *dims, saved[i].data_ptr(), ctypes.cast(us3, ctypes.c_void_p), _lib.stream()),
+               "hm_sil_timestamps_read")
+            acc = [a + u for a, u in zip(acc, us3)]
+        torch.cuda.synchronize()
+        stamps = dict(zip(("k_raster_fwd", "k_bwd_lines", "k_bwd_sweep"), (a / stamp_reps for a in acc)))
     for p in params:
         p.grad = None
+    if stamp_reps > 0:
+        return losses_out, best_rot.clone(), best_trans.clone(), stamps
     return losses_out, best_rot.clone(), best_trans.clone()
 
 

@@ -14,7 +14,7 @@ import torch.nn as nn
 from scipy.ndimage import distance_transform_edt
 
 from . import nmr, yana
-from .model import matrix_to_rot6d, rot6d_to_matrix
+from .model import _rowvec_times_matrix, matrix_to_rot6d, rot6d_to_matrix
 
 REND_SIZE = 256          # reference homan/constants.py
 
@@ -72,9 +72,13 @@ class PoseOptimizer(nn.Module):
     only leaf: hard silhouettes without anti-aliasing."""
 
     def __init__(self, ref_image, vertices, faces, rotation_init, translation_init, num_initializations=1, kernel_size=7,
-                 K=None, power=0.25, lw_chamfer=0, render_fn=None):
+                 K=None, power=0.25, lw_chamfer=0, render_fn=None, written_out=False):
         assert ref_image.shape[0] == ref_image.shape[1], "Must be square."
         super().__init__()
+        # written_out: the rigid transform as ((x*R0j + y*R1j) + z*R2j) + t, one IEEE operation per product / sum (the order
+        # the HIP kernels follow: coverage then agrees with them bit for bit).  Default: the reference's torch.matmul
+        # (:109), whose rounding depends on the host BLAS - the form the reference-generated golden is compared in.
+        self.written_out = bool(written_out)
         self.register_buffer("vertices", vertices.repeat(num_initializations, 1, 1))
         self.register_buffer("faces", faces.repeat(num_initializations, 1, 1))
         # Convention for the silhouette-aware loss: -1 = occlusion, 0 = background, 1 = foreground (:66-74)
@@ -99,6 +103,8 @@ class PoseOptimizer(nn.Module):
         self.render_fn = render_fn if render_fn is not None else oracle_render
 
     def apply_transformation(self):
+        if self.written_out:
+            return _rowvec_times_matrix(self.vertices, rot6d_to_matrix(self.rotations)) + self.translations
         return torch.matmul(self.vertices, rot6d_to_matrix(self.rotations)) + self.translations
 
     def compute_offscreen_loss(self, verts):

@@ -41,6 +41,23 @@ def test_lockstep_cfg2_full_size(mano_model):
     assert out["worst_loss_per_key"]["loss_sil_obj"] < 1e-6
 
 
+def test_lockstep_cfg2_with_the_depth_term_full_size(mano_model):
+    """cfg2 as BASELINE.json words it - sil / kp / DEPTH / smooth - at 30 frames x 256^2: the ordinal depth term of reference
+    homan.py:384-419 / lossutils.py:133-169 (oracle-pinned: the reference's own call site raises) in the fused loop, every one of
+    24 steps re-evaluated by the CPU oracle at the HIP parameters.  Losses incl. loss_depth within 1e-4, zero flipped samples in
+    the silhouette raster and in the object's depth render (full-image camera); the hand's vertices are one ulp from the
+    oracle's, so its depth render may differ in a sample."""
+    sys.path.insert(0, ROOT)
+    import bench
+    out = bench.lockstep_parity(mano_model, step2=False, steps=24, free_run=False, ordinal_depth=True)
+    assert out["first_step_over_tol"] is None, out["per_step"]
+    assert out["worst_loss_per_key"]["loss_depth"] < 1e-4, out["worst_loss_per_key"]
+    assert out["flipped_samples"] == 0 and out["flipped_depth_samples"]["object"] == 0, (out["flipped_samples"], out["flipped_depth_samples"])
+    assert out["flipped_depth_samples"]["hand"] <= 2, out["flipped_depth_samples"]       # (hand vertices: one ulp from the oracle's)
+    assert out["object_vertices_bit_equal"]
+    assert out["max_grad_err"] < 2e-4, out["worst_grad_per_step"]
+
+
 def test_lockstep_cfg3_full_size(mano_model):
     sys.path.insert(0, ROOT)
     import bench
