@@ -214,6 +214,172 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
     HM_STAMP_END(sil.parts ? 1 : 0);
 }
 
+// The object's rigid backward of the fused loops (exact sums, silhouette gather): one workgroup of up to 1024 threads per
+// (frame, chunk of 1024 * NV vertices), every thread NV vertices whose dependent loads - CSR offsets -> corner items ->
+// per-corner sums - are issued STAGE BY STAGE for all NV at once: the kernel is a chain of round trips on the tail of the
+// iteration, and a loop over a thread's vertices walked that chain once per vertex.  Meshes of <= 1024 * NV vertices (the
+// 1502-vertex bottle at NV = 2) are one workgroup per frame: no chunk records, no ticket, no second round trip.
+// Optional temporal-smoothness term of the SAME vertices (reference homan/lossutils.py:18-36), formed here from the
+// camera-space vertices of the neighbouring frames with the arithmetic of smooth_body (pair_bodies.h): the object's chain then
+// waits for nothing the hand-side stream produces.  It is added FIRST, like the first entry of `terms` used to be.
+struct SmoothIn { const float* verts; float w; };
+template <int NV, int MAXT>
+__global__ __launch_bounds__(MAXT) void k_rigid_bwd_x(const float* __restrict__ mesh, const float* __restrict__ rot6d,
+                                                     const float* __restrict__ scale, int abs_scale, RigidTerms terms,
+                                                     SilGather sil, SmoothIn sm, int N, int V, float* __restrict__ g_rot6d,
+                                                     float* __restrict__ g_trans, float* __restrict__ g_scale_part,
+                                                     float* __restrict__ partials, unsigned int* __restrict__ frame_cnt,
+                                                     int clip_len, double magic)
+{
+    HM_LATENCY_KERNEL();
+    HM_STAMP_START(1);
+    __shared__ double red13d[16 * 13];
+    __shared__ int s_flag;
+    const int n = blockIdx.x;
+    float R[9];
+    rot6d_to_mat(rot6d + n * 6, R);
+    const float sraw = scale[n / clip_len];
+    const float s = abs_scale ? fabsf(sraw) : sraw;
+    const int fl = n % clip_len;                                    // frame inside its clip (smoothness: no term across clips)
+    const long row = (long)V * 3;
+    const long scnt = (long)(clip_len - 1) * row;
+    const float inv_cnt = scnt > 0 ? 1.0f / (float)scnt : 0.f;
+    int vv[NV];
+    bool ok[NV];
+    // ---- stage A: everything addressed by the vertex alone
+    int a0[NV], a1[NV];
+    float m[NV][3], cv[NV][3], tv[NV][5][3], nb[NV][2][3];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        vv[j] = ((int)blockIdx.y * NV + j) * (int)blockDim.x + (int)threadIdx.x;
+        ok[j] = vv[j] < V;
+        const int v = ok[j] ? vv[j] : 0;
+        const long o = ((long)n * V + v) * 3;
+        a0[j] = sil.parts ? sil.adj_off[v] : 0;
+        a1[j] = sil.parts ? sil.adj_off[v + 1] : 0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            m[j][c] = mesh[o + c];
+            cv[j][c] = sil.parts ? sil.cam_verts[o + c] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) tv[j][k][c] = terms.p[k] ? terms.p[k][o + c] : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            nb[j][0][c] = (sm.verts && fl + 1 < clip_len) ? sm.verts[o + row + c] : 0.f;
+            nb[j][1][c] = (sm.verts && fl >= 1) ? sm.verts[o - row + c] : 0.f;
+        }
+    }
+    float sv[NV][3];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) sv[j][c] = sm.verts ? sm.verts[((long)n * V + (ok[j] ? vv[j] : 0)) * 3 + c] : 0.f;
+    // ---- stage B: the first eight corner items of every vertex; stage C: their per-corner sums
+    int item[NV][8];
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) item[j][k] = (ok[j] && a0[j] + k < a1[j]) ? sil.adj_items[a0[j] + k] : -1;
+    double su[NV], sw[NV];
+    {
+        const double2* pf = reinterpret_cast<const double2*>(sil.parts + (long)n * sil.F * 6);
+        double2 g2[NV][8];
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g2[j][k] = item[j][k] >= 0 ? pf[item[j][k]] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            su[j] = 0.0; sw[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { su[j] += g2[j][k].x; sw[j] += g2[j][k].y; }
+            for (int a = a0[j] + 8; ok[j] && a < a1[j]; ++a) {          // (valence > 8: rare)
+                const double2 g = pf[sil.adj_items[a]];
+                su[j] += g.x; sw[j] += g.y;
+            }
+        }
+    }
+    double accd[13];
+#pragma unroll
+    for (int k = 0; k < 13; ++k) accd[k] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        if (!ok[j]) continue;
+        float gf[3] = {0.f, 0.f, 0.f}, gt[3];
+        if (sm.verts) {         // smooth_body: g = -(v[t+1] - v) + (v - v[t-1]); unit = 2 g / count
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float g = 0.f;
+                if (fl + 1 < clip_len) { const float d = nb[j][0][c] - sv[j][c]; g -= d; }
+                if (fl >= 1) g += sv[j][c] - nb[j][1][c];
+                gf[c] += sm.w * (2.0f * g * inv_cnt);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (terms.p[k]) {
+                gf[0] += terms.w[k] * tv[j][k][0]; gf[1] += terms.w[k] * tv[j][k][1]; gf[2] += terms.w[k] * tv[j][k][2];
+            }
+        if (sil.parts) {        // the arithmetic of k_bwd_gather (raster.hip)
+            const float gu = (float)su[j], gv = (float)sw[j];
+            const float* k = sil.K + n * 9;
+            const float x = cv[j][0], y = cv[j][1], z = cv[j][2];
+            const float zz = z + 1e-9f;
+            const float du0 = gu * (2.0f / sil.orig_size), dv0 = -gv * (2.0f / sil.orig_size);
+            const float dxn = k[0] * du0 + k[3] * dv0;
+            const float dyn = k[1] * du0 + k[4] * dv0;
+            gf[0] += dxn / zz;
+            gf[1] += dyn / zz;
+            gf[2] += -(dxn * x + dyn * y) / (zz * zz);
+        }
+        gt[0] = gf[0] + 0.f; gt[1] = gf[1] + 0.f; gt[2] = gf[2] + 0.f;
+        const float dm[3] = {R[0] * gf[0] + R[1] * gf[1] + R[2] * gf[2], R[3] * gf[0] + R[4] * gf[1] + R[5] * gf[2],
+                             R[6] * gf[0] + R[7] * gf[1] + R[8] * gf[2]};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) accd[3 * i + q] += hm_quant((s * m[j][i]) * gt[q], magic);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) accd[9 + q] += hm_quant(gt[q], magic);
+        accd[12] += hm_quant(m[j][0] * dm[0] + m[j][1] * dm[1] + m[j][2] * dm[2], magic);
+    }
+    hm_block_sum_n_f64<13>(accd, red13d);
+    if (gridDim.y > 1) {
+        double* rec = reinterpret_cast<double*>(partials + ((long)n * gridDim.y + blockIdx.y) * 32);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) __hip_atomic_store(rec + k, accd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!hm_last_block(frame_cnt + n, gridDim.y, &s_flag)) return;
+        if (threadIdx.x < 13 * gridDim.y)
+            red13d[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const double*>(partials + ((long)n * gridDim.y + threadIdx.x / 13) * 32) + threadIdx.x % 13,
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < 13; ++k) accd[k] = 0.0;
+            for (unsigned c = 0; c < gridDim.y; ++c)
+#pragma unroll
+                for (int k = 0; k < 13; ++k) accd[k] += red13d[c * 13 + k];
+        }
+    }
+    if (threadIdx.x == 0) {
+        float tot[13], dr6[6];
+#pragma unroll
+        for (int k = 0; k < 13; ++k) tot[k] = (float)accd[k];
+        rot6d_backward(rot6d + n * 6, tot, dr6);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g_rot6d[n * 6 + k] = dr6[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) g_trans[n * 3 + k] = tot[9 + k];
+        if (g_scale_part) g_scale_part[n] = (abs_scale && sraw < 0.f) ? -tot[12] : tot[12];
+    }
+    HM_STAMP_END(1);
+}
+
 // out[i] = s[0] * in[i]   (backward of "loss = f(x)" ops whose unit gradient was produced in the forward)
 __global__ void k_scale_by(const float* __restrict__ in, const float* __restrict__ s, long n, float* __restrict__ out)
 {
@@ -298,12 +464,22 @@ int hm_tune_lds_pad(int family, int bytes)
     return prev;
 }
 #define RIGID_MAX_CHUNKS 16
+// Scheduling hint, no effect on results (the sums are exact): 1 = the object's rigid backward of the fused loops as ceil(V / 256)
+// small workgroups per frame + ticket instead of one large workgroup per frame.  Process-wide, read at launch (or capture).
+// Returns the previous value; < 0 only queries.
+static int g_rigid_chunked = 1;      // (same-box A/B, cfg2: chunked 6295 it/s, one 768-thread workgroup per frame 6110)
+int hm_tune_rigid_chunked(int enable)
+{
+    const int prev = g_rigid_chunked;
+    if (enable >= 0) g_rigid_chunked = enable ? 1 : 0;
+    return prev;
+}
 size_t hm_rigid_workspace_bytes(int N) { return (((size_t)N * 4 + 255) & ~(size_t)255) + (size_t)N * RIGID_MAX_CHUNKS * 32 * 4; }
 static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
                             const float* const* g_terms, const float* weights, int n_terms, SilGather sil,
                             const float* g_rigid, const float* g_frame, int frame_stride, float frame_scale, int N, int V,
                             float* g_mesh, float* g_rot6d, float* g_trans, float* g_scale_part, void* workspace,
-                            int clip_len, int exact, int sum_log2q, hipStream_t stream)
+                            int clip_len, int exact, int sum_log2q, SmoothIn smooth, hipStream_t stream)
 {
     HM_CHECK_ARG(sum_log2q <= 0 && sum_log2q >= -60);
     HM_CHECK_ARG(mesh && rot6d && scale && g_rot6d && g_trans && N > 0 && V > 0 && HM_CLIP_LEN_OK(N, clip_len));
@@ -319,6 +495,23 @@ static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* 
     const int chunks = workspace ? min(RIGID_MAX_CHUNKS, hm_cdiv(V, exact ? threads : 4 * threads)) : 1;
     unsigned int* cnt = (unsigned int*)workspace;
     float* partials = workspace ? (float*)((char*)workspace + (((size_t)N * 4 + 255) & ~(size_t)255)) : nullptr;
+    // one workgroup per frame whenever the mesh fits: <= 1024 vertices one per thread, <= 1536 two per thread on 768 threads (12
+    // waves: 170 registers each, the 64 of the staged double2 loads included - at 1024 threads the 128-register cap spilled)
+    const int nv = (V > 1024 && !g_rigid_chunked) ? 2 : 1;
+    const int thr = g_rigid_chunked ? 256 : (nv == 2 ? 768 : (V > 512 ? 1024 : (V > 256 ? 512 : 256)));
+    if (exact && !g_rigid && !g_frame && !g_mesh && (workspace ? V <= RIGID_MAX_CHUNKS * thr * nv : V <= thr * nv)) {
+        // (the fused loops' object chain: stage-wise loads of NV vertices per thread, see k_rigid_bwd_x)
+        const int ch = hm_cdiv(V, thr * nv);
+        const double magic = hm_sum_magic(sum_log2q);
+        if (nv == 2)
+            hipLaunchKernelGGL((k_rigid_bwd_x<2, 768>), dim3(N, ch), dim3(thr), g_hm_lds_pad[HM_PAD_RIGID_BWD], stream, mesh, rot6d, scale,
+                               abs_scale, t, sil, smooth, N, V, g_rot6d, g_trans, g_scale_part, partials, cnt, clip_len ? clip_len : N, magic);
+        else
+            hipLaunchKernelGGL((k_rigid_bwd_x<1, 1024>), dim3(N, ch), dim3(thr), g_hm_lds_pad[HM_PAD_RIGID_BWD], stream, mesh, rot6d, scale,
+                               abs_scale, t, sil, smooth, N, V, g_rot6d, g_trans, g_scale_part, partials, cnt, clip_len ? clip_len : N, magic);
+        return hm_launch_status();
+    }
+    HM_CHECK_ARG(!smooth.verts);
     if (exact)
         hipLaunchKernelGGL(k_rigid_bwd<true>, dim3(N, chunks), dim3(threads), g_hm_lds_pad[HM_PAD_RIGID_BWD], stream, mesh, rot6d, scale,
                            abs_scale, t, sil, g_rigid, g_frame, frame_stride, frame_scale, N, V, g_mesh, g_rot6d, g_trans,
@@ -337,7 +530,8 @@ int hm_rigid_bwd_clips(const float* mesh, const float* rot6d, const float* scale
 {
     SilGather none = {nullptr, nullptr, nullptr, nullptr, nullptr, 1.0f, 0};
     return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, none, g_rigid, g_frame, frame_stride,
-                            frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, workspace, clip_len, 0, 0, stream);
+                            frame_scale, N, V, g_mesh, g_rot6d, g_trans, g_scale_part, workspace, clip_len, 0, 0,
+                            SmoothIn{nullptr, 0.f}, stream);
 }
 int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
                  const float* weights, int n_terms, const float* g_rigid, const float* g_frame, int frame_stride,
@@ -351,16 +545,21 @@ int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int 
 // hm_sil_parts(workspace) of an hm_sil_bwd called with grad_verts == NULL; cam_verts / K / orig_size / F as given to it.
 // The per-frame sums over the vertices are exact sums on the grid 2^sum_log2q (0: the default, 2^-44) like the per-corner
 // sums they start from: the pose gradients do not depend on the launch geometry.
+// smooth_verts (optional): the camera-space vertices (N,V,3) of the same mesh; the gradient of smooth_weight *
+// mean((v[t+1] - v[t])^2) over every clip's frames (reference homan/lossutils.py:18-36) is formed inside the launch and added
+// BEFORE `g_terms` - the values hm_smooth_fwd_clips' unit gradient times the weight would give as first term.
 int hm_rigid_bwd_sil_clips(const float* mesh, const float* rot6d, const float* scale, int abs_scale,
                            const float* const* g_terms, const float* weights, int n_terms, const double* sil_parts,
                            const int* adj_off, const int* adj_items, const float* cam_verts, const float* K,
                            float orig_size, int F, int N, int V, float* g_rot6d, float* g_trans, float* g_scale_part,
-                           void* workspace, int clip_len, int sum_log2q, hipStream_t stream)
+                           void* workspace, int clip_len, int sum_log2q, const float* smooth_verts, float smooth_weight,
+                           hipStream_t stream)
 {
     HM_CHECK_ARG(sil_parts && adj_off && adj_items && cam_verts && K && F > 0);
     SilGather sil = {sil_parts, adj_off, adj_items, cam_verts, K, orig_size, F};
     return rigid_bwd_launch(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, sil, nullptr, nullptr, 0, 0.f, N, V,
-                            nullptr, g_rot6d, g_trans, g_scale_part, workspace, clip_len, 1, sum_log2q, stream);
+                            nullptr, g_rot6d, g_trans, g_scale_part, workspace, clip_len, 1, sum_log2q,
+                            SmoothIn{smooth_verts, smooth_weight}, stream);
 }
 int hm_rigid_bwd_sil(const float* mesh, const float* rot6d, const float* scale, int abs_scale, const float* const* g_terms,
                      const float* weights, int n_terms, const double* sil_parts, const int* adj_off, const int* adj_items,
@@ -368,7 +567,8 @@ int hm_rigid_bwd_sil(const float* mesh, const float* rot6d, const float* scale, 
                      float* g_trans, float* g_scale_part, void* workspace, int sum_log2q, hipStream_t stream)
 {
     return hm_rigid_bwd_sil_clips(mesh, rot6d, scale, abs_scale, g_terms, weights, n_terms, sil_parts, adj_off, adj_items,
-                                  cam_verts, K, orig_size, F, N, V, g_rot6d, g_trans, g_scale_part, workspace, 0, sum_log2q, stream);
+                                  cam_verts, K, orig_size, F, N, V, g_rot6d, g_trans, g_scale_part, workspace, 0, sum_log2q,
+                                  nullptr, 0.f, stream);
 }
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream)
 {

@@ -1459,7 +1459,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
 
 // ---------------------------------------------------------------- backward, pass 2b: edge sweeps (see the work list above)
 #ifdef SWEEP_STATS
-__device__ unsigned long long g_sweep_n[12];     // stage 2: items, geo, act0, act1, on0, on1, pairs, trips; stage 1: items, geo, reach; pair rounds
+__device__ unsigned long long g_sweep_n[16];     // stage 2: items, geo, act0, act1, on0, on1, pairs, trips; stage 1: items, geo, reach; pair rounds
 #endif
 #ifdef SWEEP_UNIT_PROFILE
 __device__ int g_unit_prof[65536][4];            // per unit: wall-clock ticks, face passes, stage-2 trips | queued items << 8, pair rounds
@@ -1740,6 +1740,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                         atomicAdd(&g_sweep_n[8], (unsigned long long)max(0, min(64, it_hi - (it_lo + 64 * t))));
                         atomicAdd(&g_sweep_n[9], (unsigned long long)__popcll(gbal));
                         atomicAdd(&g_sweep_n[10], (unsigned long long)__popcll(bal));
+                    }
+                    {
+                        const unsigned long long b12 = __ballot(geo_t && s_own[t] == s_fn[t]), b13 = __ballot(a0);
+                        const unsigned long long b14 = __ballot(geo_t && s_aw[t] == 0), b15 = __ballot(a1);
+                        if (lane == 0) {
+                            atomicAdd(&g_sweep_n[12], (unsigned long long)__popcll(b12)); atomicAdd(&g_sweep_n[13], (unsigned long long)__popcll(b13));
+                            atomicAdd(&g_sweep_n[14], (unsigned long long)__popcll(b14)); atomicAdd(&g_sweep_n[15], (unsigned long long)__popcll(b15));
+                        }
                     }
 #endif
                     if (reach) s_q[wv][qn + __popcll(bal & ((1ull << lane) - 1ull))] =
@@ -2831,7 +2839,7 @@ int hm_debug_unit_profile(int* out)              // 65536 x 4 ints, then cleared
 #ifdef SWEEP_STATS
 int hm_debug_sweep_stats(unsigned long long* out)
 {
-    unsigned long long z[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     (void)hipDeviceSynchronize();
     (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_n), sizeof(z));
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_n), z, sizeof(z));

@@ -502,6 +502,7 @@ class FusedStepper:
             prev_reorder = tune.hm_tune_raster_reorder(ro)
             prev_nn_pad = tune.hm_tune_nn_lds_pad(nn_pad)
             prev_fam = [tune.hm_tune_lds_pad(i, v) for i, v in enumerate(fam_pads)]
+            prev_rc = tune.hm_tune_rigid_chunked(int(os.environ.get("HOMAN_RIGID_CHUNKED", "1")))
             try:
                 self.graph = _lib.new_graph()
                 with torch.cuda.graph(self.graph, stream=self.cap_stream):
@@ -520,6 +521,7 @@ class FusedStepper:
                 tune.hm_tune_nn_lds_pad(prev_nn_pad)
                 for i, v in enumerate(prev_fam):
                     tune.hm_tune_lds_pad(i, v)
+                tune.hm_tune_rigid_chunked(prev_rc)
 
     # ---- other clips into the resident stepper
     def reload(self, clip_inputs):
@@ -928,9 +930,15 @@ class FusedStepper:
             ctx_o = self.dctx[0]
             ck(L.hm_depth_bwd(P(self.vo), P(m.camintr), B, Vo, ctx_o.F, ctx_o.S, 1.0, P(self.d_go), P(ctx_o.adj_off),
                               P(ctx_o.adj_items), P(self.G_dep_o), P(ctx_o.workspace), sa), "depth bwd(obj)")
-        main.wait_event(self.ev_pair)
         sc_obj = m.optimize_object_scale
-        tp, tw, tn = _lib.terms([(self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),
+        # the object's smoothness gradient is formed INSIDE the rigid backward from the camera-space vertices the face setup
+        # wrote (same floats as the unit gradient of the smoothness launch times its weight): on the step-1 sets this chain
+        # then needs nothing from the side stream before the join - one cross-queue edge less on the iteration's tail
+        sm_in = on["smooth"] and on["sil"] and os.environ.get("HOMAN_SMOOTH_IN_RIGID", "1") != "0"
+        side_terms = on["con"] or (on["inter"] and sc_obj) or (on["smooth"] and not sm_in) or not on["sil"]
+        if side_terms:
+            main.wait_event(self.ev_pair)
+        tp, tw, tn = _lib.terms([(self.U_smo if (on["smooth"] and not sm_in) else None, w["loss_smooth_obj"]),
                                  (self.U_cono if on["con"] else None, w["loss_contact"]),
                                  (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0),
                                  (self.G_dep_o if on["depth"] else None, 1.0)])
@@ -939,7 +947,8 @@ class FusedStepper:
                                         L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
                                         P(sctx.adj_items), P(self.vo), P(self.sil_K), 1.0, sctx.F, B, Vo,
                                         P(m.rotations_object.grad), P(m.translations_object.grad),
-                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sctx.sum_log2q, sa),
+                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sctx.sum_log2q,
+                                        P(self.vo) if sm_in else None, w["loss_smooth_obj"], sa),
                "rigid_bwd(obj) + silhouette gather")
         else:
             ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
@@ -1107,7 +1116,7 @@ class FusedStepper:
                                         L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
                                         P(sctx.adj_items), P(self.vo), P(self.sil_K), 1.0, sctx.F, B, Vo,
                                         P(m.rotations_object.grad), P(m.translations_object.grad),
-                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), 0, sctx.sum_log2q, sa),
+                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), 0, sctx.sum_log2q, None, 0.0, sa),
                "rigid_bwd(obj) + silhouette gather")
         else:
             ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "hm_tune_raster_reorder": (_I, [_I]),
     "hm_tune_nn_lds_pad": (_I, [_I]),
     "hm_tune_lds_pad": (_I, [_I, _I]),
+    "hm_tune_rigid_chunked": (_I, [_I]),
     "hm_debug_sweep_caps": (_I, [_I]),
     "hm_shade_rgb": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _VP, _F, _F, _VP, _VP, _VP, _VP]),
     "hm_rigid_bwd_sil": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _VP]),
@@ -85,7 +86,7 @@ _SIGNATURES = {
     "hm_rigid_fwd_clips": (_I, [_VP, _VP, _VP, _VP, _I, _I, _I, _VP, _VP, _I, _VP]),
     "hm_rigid_bwd_clips": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _I, _F, _I, _I, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_rigid_bwd_sil_clips": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP,
-                                    _VP, _I, _I, _VP]),
+                                    _VP, _I, _I, _VP, _F, _VP]),
     "hm_sum_small_clips": (_I, [_VP, _I, _F, _VP, _F, _VP, _I, _VP]),
     "hm_mano_fwd_clips": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_mano_fwd_rows": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _I, _VP]),

@@ -55,6 +55,10 @@ int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int 
 /* workspace of hm_rigid_bwd / hm_rigid_bwd_sil (zero-filled once; per-frame tickets reset themselves): with it the frame
  * is split over ceil(V/256) workgroups and the last one finishes; NULL = one workgroup per frame. */
 size_t hm_rigid_workspace_bytes(int N);
+/* Scheduling hint, no effect on results (exact sums): 1 = hm_rigid_bwd_sil* as ceil(V / 256) small workgroups per frame + a
+ * per-frame ticket instead of one large workgroup per frame.  Process-wide, read at launch / capture; returns the previous
+ * value; < 0 only queries. */
+int hm_tune_rigid_chunked(int enable);
 /* hm_rigid_bwd with the silhouette gradient as one more full term, gathered on the fly from the per-(face, corner) NDC
  * gradients of the edge sweeps (sil_parts = hm_sil_parts(workspace) after an hm_sil_bwd called with grad_verts == NULL;
  * adj_off / adj_items / cam_verts / K / orig_size / F as given to that call): no gather launch, no (N,V,3) round trip. */
@@ -331,7 +335,11 @@ int hm_rigid_bwd_sil_clips(const float* mesh, const float* rot6d, const float* s
                            const float* const* g_terms, const float* weights, int n_terms, const double* sil_parts,
                            const int* adj_off, const int* adj_items, const float* cam_verts, const float* K,
                            float orig_size, int F, int N, int V, float* g_rot6d, float* g_trans, float* g_scale_part,
-                           void* workspace, int clip_len, int sum_log2q, hipStream_t stream);
+                           void* workspace, int clip_len, int sum_log2q, const float* smooth_verts, float smooth_weight,
+                           hipStream_t stream);
+/*   smooth_verts (optional): camera-space vertices (N,V,3) of the same mesh; the gradient of smooth_weight * the temporal
+ *   smoothness term of every clip (reference homan/lossutils.py:18-36) is formed inside the launch and added before g_terms -
+ *   the floats hm_smooth_fwd_clips' unit gradient times the weight gives as a first term, without waiting for that launch. */
 /* out[c] = w0 * sum(parts[c*n .. c*n+n)) + w1 * extra[c] */
 int hm_sum_small_clips(const float* parts, int n, float w0, const float* extra, float w1, float* out, int nclips,
                        hipStream_t stream);

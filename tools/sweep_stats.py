@@ -1,5 +1,5 @@
 """Work counters of k_bwd_sweep and phase cycles of k_raster_fwd in the steady state of a cfg2 fit (debug build:
-tools/ab_build.sh stats -DSWEEP_STATS -DRASTER_PHASES; HOMAN_AMD_LIB=scratch/lib_stats.so python tools/sweep_stats.py).
+tools/ab_build.sh stats -DSWEEP_STATS -DRASTER_PHASES; HOMAN_AMD_LIB=variants/lib_stats.so python tools/sweep_stats.py).
 GPU box."""
 import argparse
 import ctypes
@@ -35,9 +35,9 @@ def main():
     rout = (ctypes.c_ulonglong * 24)()
     rnames = ["scan", "near_rec", "near_units", "far_hz_rec", "far_units", "tail", "wg_active", "wg_idle", "units_near",
               "units_far", "-", "-"]
-    out = (ctypes.c_ulonglong * 12)()
+    out = (ctypes.c_ulonglong * 16)()
     names = ["s2_items", "s2_geo", "act0", "act1", "on0", "on1", "pairs", "s2_trips", "s1_items", "s1_geo", "s1_reach",
-             "pair_rounds"]
+             "pair_rounds", "s1_own", "s1_a0", "s1_out_empty", "s1_a1"]
     marks = (0, 20, a.warm)
     for step in range(a.warm + 1):
         if step in marks:
