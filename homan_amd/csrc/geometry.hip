@@ -497,8 +497,10 @@ static int rigid_bwd_launch(const float* mesh, const float* rot6d, const float* 
     float* partials = workspace ? (float*)((char*)workspace + (((size_t)N * 4 + 255) & ~(size_t)255)) : nullptr;
     // one workgroup per frame whenever the mesh fits: <= 1024 vertices one per thread, <= 1536 two per thread on 768 threads (12
     // waves: 170 registers each, the 64 of the staged double2 loads included - at 1024 threads the 128-register cap spilled)
-    const int nv = (V > 1024 && !g_rigid_chunked) ? 2 : 1;
-    const int thr = g_rigid_chunked ? 256 : (nv == 2 ? 768 : (V > 512 ? 1024 : (V > 256 ? 512 : 256)));
+    // (meshes beyond 16 chunks of 256 vertices: 768 threads x 2 vertices per chunk, up to 24 576 vertices)
+    const bool small = g_rigid_chunked && V <= RIGID_MAX_CHUNKS * 256;
+    const int nv = small ? 1 : (V > 1024 ? 2 : 1);
+    const int thr = small ? 256 : (nv == 2 ? 768 : (V > 512 ? 1024 : (V > 256 ? 512 : 256)));
     if (exact && !g_rigid && !g_frame && !g_mesh && (workspace ? V <= RIGID_MAX_CHUNKS * thr * nv : V <= thr * nv)) {
         // (the fused loops' object chain: stage-wise loads of NV vertices per thread, see k_rigid_bwd_x)
         const int ch = hm_cdiv(V, thr * nv);

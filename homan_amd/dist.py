@@ -29,10 +29,20 @@ def _active(group=None):
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+_WARNED_STAGED = False
+
+
 def _staged(t, group):
     """gloo moves host memory: a device tensor goes through a host copy there (the test / debugging backend that lets
     several ranks share ONE GPU; under nccl = RCCL the collective runs on the device tensor, on the compute stream)"""
-    return t.is_cuda and dist.get_backend(group) == "gloo"
+    global _WARNED_STAGED
+    staged = t.is_cuda and dist.get_backend(group) == "gloo"
+    if staged and not _WARNED_STAGED:
+        import warnings
+        warnings.warn("homan_amd.dist: device tensors in a gloo group are staged through the host (one blocking copy each way "
+                      "per collective): fine for tests on one GPU, not a production path - use backend 'nccl' (RCCL)")
+        _WARNED_STAGED = True
+    return staged
 
 
 def sync_shared_scalar_grad(grad, group=None):
@@ -73,7 +83,7 @@ def group_src(group=None):
     return dist.get_global_rank(group, 0) if group is not None else 0
 
 
-def optimize_clip_shard(models, loss_weights, num_iterations, lr=1e-2, shared_scale=False, group=None, device=None):
+def optimize_clip_shard(models, loss_weights, num_iterations, lr=1e-2, shared_scale=False, group=None):
     """This rank's clips on its GPU: clips of equal shape as ONE clip batch (every kernel launched once per iteration over all
     of them, homan_amd.clipbatch), the batches of different shapes - other object meshes, other lengths - one after the other
     inside every iteration (jointopt.ShardStepper), all replayed from hipGraphs.  -> list of loss_evolution dicts, one per

@@ -158,6 +158,11 @@ class HOMan(nn.Module):
         # ordinal depth term: the reference's own call site cannot run (see forward()); `ordinal_depth=True` opts into the
         # loss the method describes (homan.py:384-419 + lossutils.py:133-169) instead of reproducing that TypeError
         self.ordinal_depth = bool(ordinal_depth)
+        if self.ordinal_depth and int(image_size) > 1024:
+            # hm_ordinal_depth_fwd packs a frame's three pixel counts into 21-bit fields of one 64-bit atomic: 1024^2 = 2^20
+            # pixels per frame is its limit (the term is rendered at image_size, reference homan.py:168-172)
+            raise NotImplementedError(f"ordinal depth term: image_size {image_size} > 1024 (rendered at image_size; scale the "
+                                      "instance masks and intrinsics down, or leave ordinal_depth off)")
         self._depth_state = None
         with torch.no_grad():
             self.verts_hand_init = self.get_verts_hand()[0].detach().clone()

@@ -934,7 +934,7 @@ class FusedStepper:
         # the object's smoothness gradient is formed INSIDE the rigid backward from the camera-space vertices the face setup
         # wrote (same floats as the unit gradient of the smoothness launch times its weight): on the step-1 sets this chain
         # then needs nothing from the side stream before the join - one cross-queue edge less on the iteration's tail
-        sm_in = on["smooth"] and on["sil"] and os.environ.get("HOMAN_SMOOTH_IN_RIGID", "1") != "0"
+        sm_in = on["smooth"] and on["sil"] and Vo <= 24576 and os.environ.get("HOMAN_SMOOTH_IN_RIGID", "1") != "0"
         side_terms = on["con"] or (on["inter"] and sc_obj) or (on["smooth"] and not sm_in) or not on["sil"]
         if side_terms:
             main.wait_event(self.ev_pair)

@@ -37,6 +37,14 @@ def _sqrt_exact(x):
     return torch.sqrt(x.double()).float()
 
 
+# REFERENCE_FORM: evaluate the rotation and the rigid transform with the reference's literal expressions (F.normalize /
+# einsum / torch.cross / torch.matmul, whose last bits are the host BLAS's) instead of the written-out operation order below.
+# tests/test_oracle_golden.py switches it on for the comparison with the reference-generated vertices at 1e-7: the untouched,
+# reference-faithful path the golden pins; everything that is compared BIT FOR BIT with the HIP kernels uses the written-out
+# order (the default).
+REFERENCE_FORM = False
+
+
 def rot6d_to_matrix(rot_6d):
     """reference homan/utils/geometry.py:9-27 (cross taken along dim=-1; the reference's dim-less torch.cross differs
     only when the flattened batch is exactly 3).
@@ -46,6 +54,11 @@ def rot6d_to_matrix(rot_6d):
     different last bits for B = 4 and B = 240), and an ulp in R moves vertices across sample centres of the hard
     rasteriser.  Same mathematics (F.normalize = v / max(|v|, 1e-12)); the HIP kernels follow this order
     (csrc/hm_common.h rot6d_to_mat), so rotations - and with them vertices and coverage - agree bit for bit."""
+    if REFERENCE_FORM:
+        r = rot_6d.view(-1, 3, 2)
+        b1 = F.normalize(r[:, :, 0])
+        b2 = F.normalize(r[:, :, 1] - torch.einsum("bi,bi->b", b1, r[:, :, 1]).unsqueeze(-1) * b1)
+        return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-1)
     r = rot_6d.view(-1, 3, 2)
     a1 = [r[:, i, 0] for i in range(3)]
     a2 = [r[:, i, 1] for i in range(3)]
@@ -75,6 +88,8 @@ def transform_persp(meshes, translations, rotations, intrinsic_scales):
     """reference homan/utils/camera.py:108-139: (s*v) @ R + t and its mesh-detached twin (products written out, see
     _rowvec_times_matrix)."""
     scaled = intrinsic_scales.view(-1, 1, 1) * meshes
+    if REFERENCE_FORM:
+        return (torch.matmul(scaled, rotations) + translations, torch.matmul(scaled.detach().clone(), rotations) + translations)
     return (_rowvec_times_matrix(scaled, rotations) + translations,
             _rowvec_times_matrix(scaled.detach().clone(), rotations) + translations)
 

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="issue the iteration launch by launch instead of replaying a hipGraph")
     ap.add_argument("--cfg1", action="store_true", help="silhouette + 2-D keypoint terms only (no pair-wise losses on the side stream)")
     ap.add_argument("--lw", action="append", default=[], help="override a loss weight, e.g. --lw lw_inter=0")
+    ap.add_argument("--groups", type=int, default=1, help="split the clips into this many clip batches, each with its own hipGraph, "
+                    "replayed CONCURRENTLY on streams of their own (kernels of different stages of different groups overlap)")
     ap.add_argument("--stamps", type=int, default=0, help="after the timed region: this many more replays with in-kernel "
                     "timestamps -> durations of raster / lines / sweep inside the graph")
     args = ap.parse_args()
@@ -49,6 +51,35 @@ def main():
     if args.sweep_blocks:
         hlib.lib().hm_tune_sweep_blocks(args.sweep_blocks)
     total = args.warmup + args.steps
+    if args.groups > 1:
+        per = args.clips // args.groups
+        sts = [FusedStepper(models[g * per:(g + 1) * per] if per > 1 else models[g * per], lw, 1e-2, total) for g in range(args.groups)]
+        streams = [torch.cuda.Stream() for _ in sts]
+
+        def run(n):
+            cur = torch.cuda.current_stream()
+            for s_ in streams:
+                s_.wait_stream(cur)
+            for _ in range(n):
+                for st_, s_ in zip(sts, streams):
+                    with torch.cuda.stream(s_):
+                        st_.graph.replay()
+            for s_ in streams:
+                cur.wait_stream(s_)
+        run(args.warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        evo = []
+        for st_ in sts:
+            e = st_.loss_evolution(total)
+            evo += e if isinstance(e, list) else [e]
+        print(json.dumps(dict(clips=args.clips, groups=args.groups, steps=args.steps, step2=args.step2, ms_per_round=1e3 * el / args.steps,
+                              its_per_s=args.clips * args.steps / el, us_per_clip_iteration=1e6 * el / args.steps / args.clips,
+                              first_loss=[e["loss"][0] for e in evo], final_loss=[e["loss"][-1] for e in evo])))
+        return
     st = FusedStepper(models if args.clips > 1 else models[0], lw, 1e-2, total, capture=not args.no_graph,
                       shared_scale=args.shared_scale)
     st.run(args.warmup)
