@@ -574,176 +574,153 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
         __syncthreads();
         RPH_MARK(0);
         had_any |= cand_n[0] | cand_n[1];
-        for (int cls = 0; cls < 2; ++cls) {
-            const int n = cand_n[cls];
-            if (cls == 1 && n > 0) {
+        // Records of BOTH winding classes in one pass: wave 0 builds up to 64 near-class records, wave 1 up to 64 far-class
+        // records at the same time (a region sees ~27 + ~31 candidates) - one round trip to the packed faces and one stretch of
+        // record arithmetic per round instead of one per class (the far class's pass was a quarter of the workgroup's time,
+        // with three waves waiting at its barrier).  Then the near units, the hidden-block depths they leave, the far units.
+        const int n_near = cand_n[0], n_far = cand_n[1];
+        for (int e0 = 0; e0 < n_near || e0 < n_far; e0 += RB_PASS / 2) {
+            // ---- one thread per candidate: face record + number of 4x4 blocks of (box & region)
+            int units = 0;
+            const int cls = tid >> 6, ci = e0 + (tid & 63);
+            if (tid < RB_PASS && ci < (cls ? n_far : n_near)) {
+                const int e = cand[cls ? 2 * CAND_CAP - 1 - ci : ci];
+                const int fi = e & 0x3fffffff, var = e >> 30;
+                const float* src = faces9 + ((long)b * F + fi) * 9;
+                const uint2 u = bx[fi];          // (requested with the vertices: one round trip per record, not two)
+                float f[9];
+                if (var == 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) f[k] = src[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) { f[3 * k] = src[3 * (2 - k)]; f[3 * k + 1] = src[3 * (2 - k) + 1]; f[3 * k + 2] = src[3 * (2 - k) + 2]; }
+                }
+                float p[3][2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { p[k][0] = topix(f[3 * k], is); p[k][1] = topix(f[3 * k + 1], is); }
+                const float inv[9] = {
+                    p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                    p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                    p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+                const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
+                                  p[1][0] * (p[2][1] - p[0][1]);
+                // conservative reject: some edge has all four region corners outside by more than the rounding noise
+                // of the edge function (the function is affine, so its extremes over the region sit at the corners)
+                bool miss = (den == 0.0f);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int k1 = (k + 1) % 3;
+                    const float ax = f[3 * k], ay = f[3 * k + 1], ex = f[3 * k1] - ax, ey = f[3 * k1 + 1] - ay;
+                    bool all_out = true;
+                    float mag = 0.f;
+                    float lhs[4], rhs[4];
+#pragma unroll
+                    for (int cnr = 0; cnr < 4; ++cnr) {
+                        const float X = (cnr & 1) ? gcx1 : gcx0, Y = (cnr & 2) ? gcy1 : gcy0;
+                        lhs[cnr] = (Y - ay) * ex;
+                        rhs[cnr] = (X - ax) * ey;
+                        mag = fmaxf(mag, fabsf(lhs[cnr]) + fabsf(rhs[cnr]));
+                    }
+#pragma unroll
+                    for (int cnr = 0; cnr < 4; ++cnr) all_out = all_out && (lhs[cnr] < rhs[cnr] - 1e-5f * mag);
+                    miss = miss || all_out;
+                }
+                if (!miss) {
+                    const int x0 = u.x & 0x3fff, y0 = (int)(u.x >> 16), x1 = (int)(u.y & 0xffff), y1 = (int)(u.y >> 16);
+                    // region-local 4x4 block range
+                    const int bx0 = (max(x0, gx0) - gx0) >> 2, bx1 = (min(x1, gx1) - gx0) >> 2;
+                    const int by0 = (max(y0, gy0) - gy0) >> 2, by1 = (min(y1, gy1) - gy0) >> 2;
+                    const int nbx = bx1 - bx0 + 1;
+                    units = nbx * (by1 - by0 + 1);
+                    const float rz0 = 1.0f / f[2], rz1 = 1.0f / f[5], rz2 = 1.0f / f[8];
+                    recs[tid][0] = make_float4(f[0], f[1], f[3], f[4]);
+                    recs[tid][1] = make_float4(f[6], f[7], rz0, rz1);
+                    recs[tid][2] = make_float4(rz2, inv[0] / den, inv[1] / den, inv[2] / den);
+                    recs[tid][3] = make_float4(inv[3] / den, inv[4] / den, inv[5] / den, inv[6] / den);
+                    recs[tid][4] = make_float4(inv[7] / den, inv[8] / den, __int_as_float(fi + var * F),
+                                               __int_as_float(bx0 | (by0 << 3) | (nbx << 6) | (((0x10000 + nbx - 1) / nbx) << 10)));
+                    // nearest depth the face can produce (the interpolated depth is a weighted harmonic mean of the
+                    // vertex depths), with 1e-5 of slack for its rounding: the pruning threshold of its units
+                    czn[tid] = __float_as_uint((1.0f / fmaxf(rz0, fmaxf(rz1, rz2))) * (1.0f - 1e-5f));
+                }
+            }
+            // ---- exclusive prefix of the unit counts, per class = per wave (waves 0 / 1; no cross-wave sums)
+            const int incl = hm_wave_scan_incl(units);
+            if (lane == 63 && w < 2) wsum[w] = incl;
+            if (tid < RB_PASS) ustart[tid] = incl - units;
+            __syncthreads();
+            const int total_near = wsum[0], total_far = wsum[1];
+#ifdef RASTER_PHASES
+            if (tid < RB_PASS && ci < (cls ? n_far : n_near)) atomicAdd(&g_raster_ph[12 + cls], 1ull);
+            rph_units[0] += total_near;
+            rph_units[1] += total_far;
+#endif
+            RPH_MARK(1);
+            // ---- near class: flattened (candidate, block) units, one per thread and trip
+            for (int u = tid; u < total_near; u += 256) {
+                int i = 0;
+#pragma unroll
+                for (int stp = RB_PASS / 4; stp > 0; stp >>= 1)
+                    if (ustart[i + stp] <= u) i += stp;             // (i + stp <= 63)
+                unit_body(i, u - ustart[i]);
+            }
+            RPH_MARK(2);
+            if (total_far > 0) {
                 // hidden-block test for the far class: per 4x4 block, the largest owner depth the near class (and earlier
                 // rounds) left in the z-buffer (zfar while any of its samples is empty)
                 if (tid < 64) hz[tid] = 0u;
                 __syncthreads();
-                const int blk = tid >> 2, row = (blk >> 3) * 4 + (tid & 3), col0 = (blk & 7) * 4;
-                const uint4 ka = *reinterpret_cast<const uint4*>(&zb[row * 32 + col0]);
-                const uint4 kb = *reinterpret_cast<const uint4*>(&zb[row * 32 + col0 + 2]);
-                atomicMax(&hz[blk], max(max(ka.y, ka.w), max(kb.y, kb.w)));
-                __syncthreads();
-            }
-            for (int e0 = 0; e0 < n; e0 += RB_PASS) {
-                // ---- one thread per candidate: face record + number of 4x4 blocks of (box & region)
-                int units = 0;
-                if (tid < RB_PASS && e0 + tid < n) {
-                    const int e = cand[cls ? 2 * CAND_CAP - 1 - (e0 + tid) : e0 + tid];
-                    const int fi = e & 0x3fffffff, var = e >> 30;
-                    const float* src = faces9 + ((long)b * F + fi) * 9;
-                    const uint2 u = bx[fi];          // (requested with the vertices: one round trip per record, not two)
-                    float f[9];
-                    if (var == 0) {
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) f[k] = src[k];
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) { f[3 * k] = src[3 * (2 - k)]; f[3 * k + 1] = src[3 * (2 - k) + 1]; f[3 * k + 2] = src[3 * (2 - k) + 2]; }
-                    }
-                    float p[3][2];
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { p[k][0] = topix(f[3 * k], is); p[k][1] = topix(f[3 * k + 1], is); }
-                    const float inv[9] = {
-                        p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
-                        p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
-                        p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
-                    const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) +
-                                      p[1][0] * (p[2][1] - p[0][1]);
-                    // conservative reject: some edge has all four region corners outside by more than the rounding noise
-                    // of the edge function (the function is affine, so its extremes over the region sit at the corners)
-                    bool miss = (den == 0.0f);
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const int k1 = (k + 1) % 3;
-                        const float ax = f[3 * k], ay = f[3 * k + 1], ex = f[3 * k1] - ax, ey = f[3 * k1 + 1] - ay;
-                        bool all_out = true;
-                        float mag = 0.f;
-                        float lhs[4], rhs[4];
-#pragma unroll
-                        for (int cnr = 0; cnr < 4; ++cnr) {
-                            const float X = (cnr & 1) ? gcx1 : gcx0, Y = (cnr & 2) ? gcy1 : gcy0;
-                            lhs[cnr] = (Y - ay) * ex;
-                            rhs[cnr] = (X - ax) * ey;
-                            mag = fmaxf(mag, fabsf(lhs[cnr]) + fabsf(rhs[cnr]));
-                        }
-#pragma unroll
-                        for (int cnr = 0; cnr < 4; ++cnr) all_out = all_out && (lhs[cnr] < rhs[cnr] - 1e-5f * mag);
-                        miss = miss || all_out;
-                    }
-                    if (!miss) {
-                        const int x0 = u.x & 0x3fff, y0 = (int)(u.x >> 16), x1 = (int)(u.y & 0xffff), y1 = (int)(u.y >> 16);
-                        // region-local 4x4 block range
-                        const int bx0 = (max(x0, gx0) - gx0) >> 2, bx1 = (min(x1, gx1) - gx0) >> 2;
-                        const int by0 = (max(y0, gy0) - gy0) >> 2, by1 = (min(y1, gy1) - gy0) >> 2;
-                        const int nbx = bx1 - bx0 + 1;
-                        units = nbx * (by1 - by0 + 1);
-#ifdef RASTER_PHASES
-                        {   // what the unit count would be with blocks anchored at the corner of (box & region)
-                            const int wx = min(x1, gx1) - max(x0, gx0) + 1, wy = min(y1, gy1) - max(y0, gy0) + 1;
-                            atomicAdd(&g_raster_ph[14 + cls], (unsigned long long)(((wx + 3) >> 2) * ((wy + 3) >> 2)));
-                            atomicAdd(&g_raster_ph[16 + cls], (unsigned long long)(((wx + 7) >> 3) * ((wy + 1) >> 1)));
-                            atomicAdd(&g_raster_ph[18 + cls], (unsigned long long)(wx * wy));
-                        }
-#endif
-                        const float rz0 = 1.0f / f[2], rz1 = 1.0f / f[5], rz2 = 1.0f / f[8];
-                        recs[tid][0] = make_float4(f[0], f[1], f[3], f[4]);
-                        recs[tid][1] = make_float4(f[6], f[7], rz0, rz1);
-                        recs[tid][2] = make_float4(rz2, inv[0] / den, inv[1] / den, inv[2] / den);
-                        recs[tid][3] = make_float4(inv[3] / den, inv[4] / den, inv[5] / den, inv[6] / den);
-                        recs[tid][4] = make_float4(inv[7] / den, inv[8] / den, __int_as_float(fi + var * F),
-                                                   __int_as_float(bx0 | (by0 << 3) | (nbx << 6) | (((0x10000 + nbx - 1) / nbx) << 10)));
-                        // nearest depth the face can produce (the interpolated depth is a weighted harmonic mean of the
-                        // vertex depths), with 1e-5 of slack for its rounding: the pruning threshold of its units
-                        czn[tid] = __float_as_uint((1.0f / fmaxf(rz0, fmaxf(rz1, rz2))) * (1.0f - 1e-5f));
-                    }
+                {
+                    const int blk = tid >> 2, row = (blk >> 3) * 4 + (tid & 3), col0 = (blk & 7) * 4;
+                    const uint4 ka = *reinterpret_cast<const uint4*>(&zb[row * 32 + col0]);
+                    const uint4 kb = *reinterpret_cast<const uint4*>(&zb[row * 32 + col0 + 2]);
+                    atomicMax(&hz[blk], max(max(ka.y, ka.w), max(kb.y, kb.w)));
                 }
-                // ---- exclusive prefix of the unit counts over the workgroup
-                const int incl = hm_wave_scan_incl(units);
-                if (lane == 63) wsum[w] = incl;
                 __syncthreads();
-                int woff = 0, total = 0;
-#pragma unroll
-                for (int k = 0; k < RASTER_WAVES; ++k) {
-                    const int t = wsum[k];
-                    if (k < w) woff += t;
-                    total += t;
-                }
-                if (tid < RB_PASS) ustart[tid] = woff + incl - units;
-                __syncthreads();
-#ifdef RASTER_PHASES
-                if (tid < RB_PASS && e0 + tid < n) atomicAdd(&g_raster_ph[12 + cls], 1ull);
-                if (cls == 1 && tid < RB_PASS && e0 + tid < n && units > 0) {
-                    // far candidates with at least one block that is not hidden behind the near class
-                    const int pk = __float_as_int(recs[tid][4].w);
-                    const int nbx = (pk >> 6) & 15;
-                    bool any = false;
-                    for (int k = 0; k < units; ++k) {
-                        const int kby = k / nbx;
-                        const int blk = (((pk >> 3) & 7) + kby) * 8 + (pk & 7) + (k - kby * nbx);
-                        any = any || !(czn[tid] > hz[blk]);
-                    }
-                    if (any) atomicAdd(&g_raster_ph[20], 1ull);
-                }
-#endif
-                RPH_MARK(cls == 0 ? 1 : 3);
-#ifdef RASTER_PHASES
-                rph_units[cls] += total;
-#endif
-                if (cls == 0) {
-                    // ---- near class: flattened (candidate, block) units, one per thread and trip
-                    for (int u = tid; u < total; u += 256) {
+                RPH_MARK(3);
+                // ---- far class: most units sit behind the near surface.  A wave first tests 64 units against the
+                // hidden-block depths (one LDS word each) and queues the survivors; the unit body runs on full waves
+                // of survivors only (a divergent early-out would leave the wave paying for its one visible unit)
+                int qn = 0;
+                for (int u0 = 64 * w; u0 < total_far; u0 += 256) {
+                    const int u = u0 + lane;
+                    bool pass = false;
+                    int ent = 0;
+                    if (u < total_far) {
                         int i = 0;
 #pragma unroll
-                        for (int stp = RB_PASS / 2; stp > 0; stp >>= 1)
-                            if (ustart[i + stp] <= u) i += stp;
-                        unit_body(i, u - ustart[i]);
+                        for (int stp = RB_PASS / 4; stp > 0; stp >>= 1)
+                            if (ustart[RB_PASS / 2 + i + stp] <= u) i += stp;
+                        i += RB_PASS / 2;
+                        const int k = u - ustart[i];
+                        const int pk = __float_as_int(recs[i][4].w);
+                        const int nbx = (pk >> 6) & 15, kby = (k * (pk >> 10)) >> 16;
+                        const int blk = (((pk >> 3) & 7) + kby) * 8 + (pk & 7) + (k - kby * nbx);
+                        pass = !(czn[i] > hz[blk]);
+                        ent = i | (k << 8);
                     }
-                } else {
-                    // ---- far class: most units sit behind the near surface.  A wave first tests 64 units against the
-                    // hidden-block depths (one LDS word each) and queues the survivors; the unit body runs on full waves
-                    // of survivors only (a divergent early-out would leave the wave paying for its one visible unit)
-                    int qn = 0;
-                    for (int u0 = 64 * w; u0 < total; u0 += 256) {
-                        const int u = u0 + lane;
-                        bool pass = false;
-                        int ent = 0;
-                        if (u < total) {
-                            int i = 0;
-#pragma unroll
-                            for (int stp = RB_PASS / 2; stp > 0; stp >>= 1)
-                                if (ustart[i + stp] <= u) i += stp;
-                            const int k = u - ustart[i];
-                            const int pk = __float_as_int(recs[i][4].w);
-                            const int nbx = (pk >> 6) & 15, kby = (k * (pk >> 10)) >> 16;
-                            const int blk = (((pk >> 3) & 7) + kby) * 8 + (pk & 7) + (k - kby * nbx);
-                            pass = !(czn[i] > hz[blk]);
-                            ent = i | (k << 8);
-                        }
-                        const unsigned long long bal = __ballot(pass);
+                    const unsigned long long bal = __ballot(pass);
 #ifdef RASTER_PHASES
-                        if (lane == 0) atomicAdd(&g_raster_ph[21], (unsigned long long)__popcll(bal));
+                    if (lane == 0) atomicAdd(&g_raster_ph[21], (unsigned long long)__popcll(bal));
 #endif
-                        if (pass) uq[w][qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)ent;
-                        qn += __popcll(bal);
+                    if (pass) uq[w][qn + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)ent;
+                    qn += __popcll(bal);
+                    wave_sync();
+                    if (qn >= 64) {
+                        qn -= 64;
+                        const int e = uq[w][qn + lane];
                         wave_sync();
-                        if (qn >= 64) {
-                            qn -= 64;
-                            const int e = uq[w][qn + lane];
-                            wave_sync();
-                            unit_body(e & 0xff, e >> 8);
-                        }
-                    }
-                    if (lane < qn) {
-                        const int e = uq[w][lane];
                         unit_body(e & 0xff, e >> 8);
                     }
                 }
-                __syncthreads();
-                RPH_MARK(cls == 0 ? 2 : 4);
+                if (lane < qn) {
+                    const int e = uq[w][lane];
+                    unit_body(e & 0xff, e >> 8);
+                }
             }
+            __syncthreads();
+            RPH_MARK(4);
         }
     }
     __syncthreads();
