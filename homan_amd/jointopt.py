@@ -1232,13 +1232,54 @@ class ShardStepper:
                     st.model.int_scales_object.copy_(start.expand_as(st.model.int_scales_object))
             self.total = torch.zeros(1, device=dev)
 
+    def _group_streams(self):
+        """one replay stream per shape group: the groups' hipGraphs run CONCURRENTLY.  A one-clip graph is ~90 us of launch
+        and edge latency around ~70 us of kernels, and the kernels of different stages of different groups overlap: eight
+        one-clip groups side by side reach 7 800 it/s against 6 290 one after the other (8 clips of ONE shape as a batch: 8 900)."""
+        if getattr(self, "_streams", None) is None:
+            self._streams = [torch.cuda.Stream() for _ in self.steppers]
+        return self._streams
+
     def run(self, steps):
+        concurrent = (len(self.steppers) > 1 and all(st.graph is not None for st in self.steppers) and
+                      os.environ.get("HOMAN_SHARD_CONCURRENT", "1") != "0")
+        cur = torch.cuda.current_stream()
+        if concurrent and not self.shared_scale:
+            # independent clips, no collective: every group simply replays its `steps` iterations on its own stream
+            streams = self._group_streams()
+            for s in streams:
+                s.wait_stream(cur)
+            for _ in range(steps):
+                for st, s in zip(self.steppers, streams):
+                    with torch.cuda.stream(s):
+                        st.graph.replay()
+            for s in streams:
+                cur.wait_stream(s)
+            return
         for _ in range(steps):
             if not self.shared_scale:
                 for st in self.steppers:
                     st._iteration()
                 continue
             self.total.zero_()
+            if concurrent:      # the two halves of the iteration of every group side by side, the collective in between
+                streams = self._group_streams()
+                for st, s in zip(self.steppers, streams):
+                    s.wait_stream(cur)
+                    with torch.cuda.stream(s):
+                        st.graph.replay()
+                for st, s in zip(self.steppers, streams):
+                    cur.wait_stream(s)
+                    self.total += st.g_shared
+                self.hdist.sync_shared_scalar_grad(self.total, self.group)
+                for st, s in zip(self.steppers, streams):
+                    s.wait_stream(cur)
+                    with torch.cuda.stream(s):
+                        st.g_shared.copy_(self.total)
+                        st.graph_b.replay()
+                for s in streams:
+                    cur.wait_stream(s)
+                continue
             for st in self.steppers:            # forward + backward of every shape group; st.g_shared = sum over its clips
                 if st.graph is not None:
                     st.graph.replay()

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--lw", action="append", default=[], help="override a loss weight, e.g. --lw lw_inter=0")
     ap.add_argument("--groups", type=int, default=1, help="split the clips into this many clip batches, each with its own hipGraph, "
                     "replayed CONCURRENTLY on streams of their own (kernels of different stages of different groups overlap)")
+    ap.add_argument("--mixed", action="store_true", help="a heterogeneous shard through dist.optimize_clip_shard's ShardStepper: the "
+                    "clips alternate between four shapes (bottle 30 x 256^2, cube 30 x 256^2, bottle 20 x 256^2, cube 20 x 256^2)")
     ap.add_argument("--stamps", type=int, default=0, help="after the timed region: this many more replays with in-kernel "
                     "timestamps -> durations of raster / lines / sweep inside the graph")
     args = ap.parse_args()
@@ -42,7 +44,9 @@ def main():
         lw[k] = float(v)
     models = []
     for i in range(args.clips):
-        c = synth.make_clip(seed=i, frames=args.frames, rend_size=args.size, image_size=args.size, obj="bottle",
+        obj, frames = (("bottle", args.frames), ("cube", args.frames), ("bottle", 2 * args.frames // 3),
+                       ("cube", 2 * args.frames // 3))[i % 4] if args.mixed else ("bottle", args.frames)
+        c = synth.make_clip(seed=i, frames=frames, rend_size=args.size, image_size=args.size, obj=obj,
                             silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
         models.append(build_model(copy.deepcopy(c["person_parameters"]), copy.deepcopy(c["object_parameters"]),
                                   objvertices=c["objvertices"], objfaces=c["objfaces"], camintr=c["camintr"],
@@ -51,6 +55,20 @@ def main():
     if args.sweep_blocks:
         hlib.lib().hm_tune_sweep_blocks(args.sweep_blocks)
     total = args.warmup + args.steps
+    if args.mixed:
+        from homan_amd.jointopt import ShardStepper
+        sh = ShardStepper(models, lw, 1e-2, total)
+        sh.run(args.warmup)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sh.run(args.steps)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        evo = sh.loss_evolution(total)
+        print(json.dumps(dict(clips=args.clips, shape_groups=len(sh.steppers), steps=args.steps, ms_per_round=1e3 * el / args.steps,
+                              its_per_s=args.clips * args.steps / el, concurrent=os.environ.get("HOMAN_SHARD_CONCURRENT", "1") != "0",
+                              final_loss=[e["loss"][-1] for e in evo])))
+        return
     if args.groups > 1:
         per = args.clips // args.groups
         sts = [FusedStepper(models[g * per:(g + 1) * per] if per > 1 else models[g * per], lw, 1e-2, total) for g in range(args.groups)]
