@@ -872,7 +872,7 @@ def main():
         torch.cuda.synchronize()
         kb = kernel_bytes(B, S, F)
         pmc, psrc = {}, None
-        for cand in ("r03_pmc_loop.json", "r02_pmc_loop.json"):
+        for cand in ("r04_pmc_loop.json", "r04_pmc_loop_cfg3.json", "r03_pmc_loop.json", "r02_pmc_loop.json"):
             ppath = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(ppath):
                 pj = json.load(open(ppath))

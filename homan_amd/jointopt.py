@@ -1215,9 +1215,21 @@ class ShardStepper:
         groups = OrderedDict()
         for i, mdl in enumerate(self.models):
             groups.setdefault(_shape_signature(mdl), []).append(i)
-        self.index = list(groups.values())                    # per stepper: positions of its clips in `models`
-        self.steppers = [FusedStepper([self.models[i] for i in idxs], loss_weights, lr, max_steps, capture=capture,
-                                      shared_scale=shared_scale, group=group, collectives=False) for idxs in self.index]
+        self.index, self.steppers = [], []                    # per stepper: positions of its clips in `models`
+        make = lambda idxs: FusedStepper([self.models[i] for i in idxs], loss_weights, lr, max_steps, capture=capture,
+                                         shared_scale=shared_scale, group=group, collectives=False)
+        for idxs in groups.values():
+            try:
+                built = [(idxs, make(idxs))]
+            except NotImplementedError:
+                # a configuration the fused loop takes one clip at a time (two hands per frame, inter_type "min"): the clips of
+                # the group become groups of their own - they still run side by side (see run)
+                if len(idxs) == 1:
+                    raise
+                built = [([i], make([i])) for i in idxs]
+            for ix, st in built:
+                self.index.append(ix)
+                self.steppers.append(st)
         if self.shared_scale:
             dev = self.models[0].int_scales_object.device if self.models else None
             if dev is None:     # a rank without clips: the collectives of the others, on the device of the group's backend

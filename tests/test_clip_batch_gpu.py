@@ -194,3 +194,33 @@ def test_cfg4_full_shard_eight_full_size_clips(mano_model):
     for k in PARAMS:
         if hasattr(alone, k):
             assert torch.equal(getattr(alone, k).detach(), getattr(batch[5], k).detach()), k
+
+
+def test_shard_of_two_hand_clips_runs_through_the_fused_loop(mano_model):
+    """A batch of two-hand clips is not ONE launch per kernel (the fused loop takes two hands per frame one clip at a time,
+    reference homan.py:341-358): `ShardStepper` gives every such clip a stepper of its own and replays them side by side - each
+    clip ends exactly where a solo fit ends."""
+    from homan_amd import dist as hdist
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, ShardStepper, build_model
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+
+    def models():
+        out = []
+        for s in (31, 32, 33):
+            c = synth.make_clip(seed=s, frames=4, rend_size=64, image_size=64, obj="cube", silhouette_fn=sil_fn,
+                                hand_verts_fn=hand_fn, hands=("right", "left"))
+            out.append(build_model(copy.deepcopy(c["person_parameters"]), copy.deepcopy(c["object_parameters"]),
+                                   objvertices=c["objvertices"], objfaces=c["objfaces"], camintr=c["camintr"], optimize_mano=True,
+                                   image_size=64, mano_model=mano_model, rend_size=64, sync_metrics=False))
+        return out
+    shard = models()
+    evo = hdist.optimize_clip_shard(shard, lw, 6)
+    solo = models()
+    for m_s, m_b, e in zip(solo, shard, evo):
+        st = FusedStepper(m_s, lw, 1e-2, 6)
+        st.run(6)
+        for (k, p), (_, q) in zip(m_s.named_parameters(), m_b.named_parameters()):
+            assert torch.equal(p, q), k
+        np.testing.assert_array_equal(np.asarray(st.loss_evolution(6)["loss"]), np.asarray(e["loss"]))

@@ -10,7 +10,7 @@ design and the current numbers; how the kernels got here - every measured step a
 
 | §8 row | What | Where |
 |---|---|---|
-| (a) a1 loop | `optimize_hand_object`, three Adam groups, weighting, logging | `homan_amd/jointopt.py` (`mode="auto"` (default) = `"fused"` whenever `FusedStepper` accepts the configuration - its own guards decide - else `"graph"`; `"eager"` = reference loop verbatim; `GraphStepper` = the same autograd iteration in a hipGraph; `FusedStepper` = the iteration as a fixed C-ABI launch sequence on two (one clip) or three (clip batch) streams in a hipGraph, the benchmark path - one clip, a BATCH of equal-shaped clips (`homan_amd/clipbatch.py`), or through `ShardStepper` a shard of clips of any shapes), `csrc/adam.hip` |
+| (a) a1 loop | `optimize_hand_object`, three Adam groups, weighting, logging | `homan_amd/jointopt.py` (`mode="auto"` (default) = `"fused"` whenever `FusedStepper` accepts the configuration - its own guards decide - else `"graph"`; `"eager"` = reference loop verbatim; `GraphStepper` = the same autograd iteration in a hipGraph; `FusedStepper` = the iteration as a fixed C-ABI launch sequence on two (one clip) or three (clip batch) streams in a hipGraph, the benchmark path - one clip, a BATCH of equal-shaped clips (`homan_amd/clipbatch.py`), or through `ShardStepper` a shard of clips of any shapes, the shape groups replayed concurrently; `ClipFitter` = the dataset walk of `fit_vid_dataset.py:190-379` on RESIDENT steppers: a clip of a known shape is copied into the static buffers and the resident hipGraph replayed), `csrc/adam.hip` |
 | (a) a2,a3,a7,a20 | `HOMan` module: parameter/buffer surface, `get_verts_*`, `forward` | `homan_amd/homan.py` |
 | (a) a4–a6 | rot6d→R, rigid transform (+ mesh-detached twin) | `csrc/geometry.hip` (`hm_rigid_fwd/bwd`) |
 | (a) a8 + N3 | `ManoModel.forward_pca` + MANO LBS | `csrc/mano.hip` (`hm_mano_fwd/bwd`), `homan_amd/manomodel.py`, `mano_assets.py` |
@@ -21,7 +21,7 @@ design and the current numbers; how the kernels got here - every measured step a
 | (a) a18 | contact loss (as executed, Appendix B.1) | `csrc/contact.hip` |
 | (a) a19 | ordinal depth | `csrc/raster.hip`: depth image out of `hm_sil_fwd` (`pooled_depth`), `hm_depth_bwd`, `hm_ordinal_depth_fwd/bwd`. The reference call site is broken (`homan.py:506-507` raises `TypeError`, `lossutils.py:140` builds the accumulator with `torch.Tensor(0.0)`): the default still raises that `TypeError`; `HOMan(ordinal_depth=True)` opts into the loss the method describes, in all three loops - eager, graph and the fused launch sequence (`FusedStepper`, `lw_depth > 0`, one clip; any render size since the rasteriser pads to a multiple of 32, the fused depth renders at `image_size % 32 == 0`). **Oracle-pinned only** (no reference output exists to pin against) |
 | (b) boundary | Python surface + C ABI | `homan_amd/{homan,losses,lossutils,manomodel,jointopt}.py`, `include/homan_amd.h`, `INTEGRATION.md` |
-| (c) oracle | CPU restatement + reference-generated goldens | `oracle/`, `tools/refharness/`, `tests/golden/` |
+| (c) oracle | CPU restatement + reference-generated goldens; the object's gradient chain and Adam also written out with order-independent sums (`oracle/objchain.py`, `oracle/csrc/objchain.c`, `oracle/adam.py`) | `oracle/`, `tools/refharness/`, `tests/golden/` |
 | (d) measurement | bench, roofline, CPU baseline, rocprof | `bench.py`, `profiles/`, `tools/prof_summary.py` |
 | (e) multi-GPU | clip sharding, clip batches per rank, heterogeneous shards, shared-scale all-reduce inside the fused loop | `homan_amd/dist.py`, `homan_amd/clipbatch.py`, `jointopt.ShardStepper`, `FusedStepper(shared_scale=True)`, `bench.py --gpus N [--shared-scale]`, `tests/test_dist_gloo.py` (CPU, oracle model), `tests/test_dist_gpu.py` (N ranks on one GPU through the fused loop, cfg5 at full size), `tests/test_clip_batch_gpu.py` |
 | (f) rank 1 | object-pose initialisation (`pose_optimization.py:37-160,219-383`, `lib3d/optitrans.py:83-127`) | `homan_amd/pose_optimization.py` (`PoseOptimizer`, `find_optimal_pose`, and the clip-level `find_optimal_poses` of `:386-488` that `fit_vid_dataset.py:285-296` calls) over the same rasteriser run without anti-aliasing (`hm_sil_fwd` `alpha_full` with the masked L2 + IoU fused per sample, `hm_sil_bwd` modes 3 / 4); the default loop of `find_optimal_pose` is a fixed launch sequence without the autograd tape (`_fused_loop`: `hm_rigid_fwd` → `hm_offscreen_fwd` → raster → reduce → lines / sweeps → `hm_rigid_bwd_sil` → `hm_adam_step` → `hm_pose_keep_best`, one hipGraph), `mode="eager"` is the reference's loop verbatim; oracle `oracle/poseopt.py`; golden from the reference's own module (`tools/refharness/gen_goldens_poseinit.py`); `bench.py --pose-init` |
@@ -45,7 +45,9 @@ Two boundaries are kept:
   reference signature and return triple.  Extensions are keyword-only (`mano_model`, `rend_size`, `mode`).
 * **C ABI (`include/homan_amd.h`, `libhoman_amd.so`).**  Plain pointers + sizes + `hipStream_t`, caller-owned buffers,
   error codes, no torch types.  The Python layer binds it with `ctypes` (`homan_amd/lib.py`); torch supplies device
-  memory, streams, the autograd tape and `torch.distributed` only.  There is **no CPU fallback**: `lib.lib()` raises if
+  memory, streams, the autograd tape and `torch.distributed` only.  The silhouette backward leaves its per-(face, corner)
+  gradients as doubles (`hm_sil_parts`) and takes, like `hm_rigid_bwd_sil*`, the grid of the order-independent sums
+  (`sum_log2q`, section 2).  There is **no CPU fallback**: `lib.lib()` raises if
   the library is missing, `HOMan.__init__` raises without a GPU, and `homan_amd` never imports `oracle`.  Every entry point
   of the loop also exists as `hm_*_clips(..., clip_len[, out_stride])` (frame axis = several clips laid end to end, per-clip
   scalars and outputs as arrays) and the MANO pair as `hm_mano_{fwd,bwd}_rows` (a strided slice of the rows: hand `i` of
@@ -59,7 +61,8 @@ rescaled, masks padded with keep = 0 and the rasteriser's eps scaled - same rays
 padded render: a face that leaves the image through its right / bottom border still lies inside the raster, so its edges
 sweep where a native render of that size culls them); object meshes of any size (the metric-only search covers 4096
 vertices, larger meshes take the full search; the contact scatter walks the object in ranges of 4096).  What falls back to
-the graph loop: `hand_proj_mode="ortho"` (raises, section 7), the depth term in a clip batch, a batch of two-hand clips.
+the graph loop: `hand_proj_mode="ortho"` (raises, section 7).  Configurations the fused loop takes ONE clip at a time (two hands
+per frame, `inter_type="min"`) run as one stepper per clip inside a shard, replayed side by side (`ShardStepper`, section 6).
 
 Reference quirks reproduced on purpose (SURVEY Appendix B): `loss_contact ≡ mean 0.02·tanh(d_NN/0.02)`; `loss_inter` is
 the un-normalised sum; `mano_rot`/`mano_trans` get gradients but are in no Adam group; `mano_betas` start at zero;
@@ -113,29 +116,46 @@ HIP ↔ oracle parity is exact where the domain is discrete and tolerance-bound 
 | **every step of a full-size trajectory, teacher-forced** | losses 1e-5 (cfg2) / 1e-4 (cfg3; `loss_collision` 1e-3, see below), gradients 2e-5 / 5e-4 of max, object vertices bit-equal, hand 1e-3 mm | `tests/test_lockstep_gpu.py` |
 | C clips in one launch per kernel vs C solo runs; shape groups of a shard vs solo runs; 2 ranks vs one 2-clip batch | **bit-exact** (rows, final parameters) | `tests/test_clip_batch_gpu.py`, `tests/test_dist_gpu.py` |
 | fused launch sequence vs `HOMan.forward` + autograd | losses 2e-6, gradients 2e-5 of max, every golden incl. two hands / left / `min` / `optimize_mano=False` | `test_fused_step_equals_autograd_path` |
-| pose initialisation vs the reference module's golden | mask loss within the number of samples that differ, gradients 2e-3 of max | `tests/test_poseinit.py` |
+| pose initialisation vs the reference module's golden (reference form: `torch.matmul`) | mask loss within the number of samples that differ (<= 3 per pose), gradients 2e-3 of max | `tests/test_poseinit.py` |
+| pose initialisation vs the oracle with the written-out transform | coverage **bit-exact** (0 flipped samples), mask loss equal, gradients 5e-5 of max | `test_hip_poseinit_coverage_bit_exact_and_gradients_vs_written_out_oracle` |
+| FREE-running fit, HIP loop vs the oracle's reproducible loop (step-1 sets) | object pose parameters **bit-equal after every step**, losses 1e-4, final vertices 1e-3 mm (object: 0.0) | `tests/test_parity_gpu.py`, `bench.free_run_parity` |
+| a stream of clips through resident steppers vs fresh fits | **bit-exact** (parameters, vertices, loss_evolution) | `tests/test_clip_fitter_gpu.py` |
 
-**Final-loss / final-vertex parity (the second half of BASELINE's metric) — what is bounded and what cannot be.**
-`bench.lockstep_parity` (`final_loss_parity.lockstep` of the bench line, `tests/test_lockstep_gpu.py`) runs the fused loop at
-cfg2 / cfg3 size and BEFORE every step loads its parameters into the CPU oracle, which evaluates that step there.
-Measured over 30-50 steps (`profiles/r03_lockstep_cfg{2,3}.json`): zero flipped samples, object vertices bit-equal,
-`loss_sil_obj` equal to the last bit, every loss of the step-1 set within 2.4e-7, gradients within 1.9e-6 of their largest
-entry, hand vertices within 6e-5 mm (one ulp: the MANO blend sums run in another order and sin / cos come from another libm).
-The one term above 1e-5 is `loss_collision` (up to 1.8e-4 in one of 30 cfg3 steps): a sum of a few small trilinear SDF
-samples, conditioned at ~1e-4 against the one-ulp difference of the HAND's vertices - evaluated by the oracle ON the HIP
-vertices it agrees to 1.1e-7, and its weighted share of the objective is < 1e-8.
-The FREE trajectories (HIP loop vs oracle loop with torch Adam) from identical inputs: step 0 agrees to 1e-7, the first
-differing samples appear at step 1 (5 of 7.9 M) - after the first optimiser step, never before -, 455 differ at step 2, and
-the 1e-4 band is left at step 10 (cfg2) while the lock-step error of that step is still 8e-7.  So the measured cause of the
-divergence is not a difference in what is computed: gradients that agree to 2e-6 give parameters that differ in the last
-bits after one Adam step, a last-bit difference flips a sample of the hard rasteriser, and Adam - whose step is
-`lr · m̂/√v̂`, i.e. normalised - turns a 1e-3 relative change of a gradient into a 1e-4 rad change of a rotation, which flips
-hundreds.  The control experiment says the same of the reference algorithm itself: the CPU oracle against ITSELF from inputs
-that differ by 1e-7 m ends 14 mm apart in the object (0.0 mm in the hand, driven by the smooth keypoint term) and leaves the
-1e-4 band at step 3 (`final_loss_parity.cfg1.cpu_vs_cpu_control`).  The 1e-4 / 1e-3 mm bar therefore holds per step along
-the whole trajectory (tested), and for the end state of the smooth part of the problem (hand: 1.8e-4 mm after 100 cfg1
-steps); the end state of the object is bounded by what is well defined - the distribution of final losses over seeds, within
-5 % (`tests/test_parity_gpu.py`).
+**Final-loss / final-vertex parity (the second half of BASELINE's metric): met, free-running.**  The hard rasteriser makes the
+silhouette loss piecewise constant in the pose, and Adam's normalised step turns a last-bit difference in a gradient into a
+flipped sample a few steps later: rounds 1-3 measured the HIP loop and the CPU loop centimetres apart after 100 steps although
+every single step agreed to 2e-6 (the CPU oracle against ITSELF from inputs 1e-7 m apart still ends 4-14 mm apart:
+`final_loss_parity.cfg1.cpu_vs_cpu_control`).  The only cure is to leave no last bit open, and on the step-1 loss sets the
+object's chain is closed on itself (`homan/homan.py:482-490`: `loss_inter` sees the object detached), so it can be done:
+
+* every REDUCTION on that chain - the sweeps' per-(face, corner) sums, the vertex gather, the 13 per-frame sums of the rigid
+  backward - rounds its addends to multiples of 2^-44 (`(x + M) - M` in double, `hm_quant`) and adds them in double: exact while
+  |sum| < 512, hence a function of the SET of addends, whatever lanes, units, atomics or workgroups formed it (include/homan_amd.h,
+  "ORDER-INDEPENDENT SUMS"; the pose initialisation's unnormalised loss uses 2^-24);
+* every per-term OPERATION is IEEE in one written order: `c = num / (p1 - d0)`, `k = (c * 2) / is`, `dist = k * (d1 - cross) +- eps`,
+  `term = diff / dist` (no `v_rcp_f32`); the projection backward, the rot6d backward and Adam element by element; Adam's bias
+  corrections by square-and-multiply in double (a libm `pow` differs in the last bit from host to host);
+* the oracle evaluates the same chain the same way (`oracle/objchain.py` + `oracle/csrc/objchain.c` + `oracle/adam.py` =
+  `oracle.jointopt.reproducible_step`: forward + autograd as always, then the object's pose gradients REPLACED by the written-out
+  chain, then the written-out Adam).  Same mathematics as autograd + `torch.optim.Adam`: `tests/test_objchain.py` holds the
+  two within fp32 rounding (2e-5 of the largest gradient entry, 2e-6 on Adam), the faithful forms stay pinned to the
+  reference's goldens, and the oracle's result no longer depends on its thread count (1 vs 4 threads: bit-identical).
+
+Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `profiles/r04_freerun_*.json`):
+`rotations_object` / `translations_object` are BIT-EQUAL between the two free-running loops after every step - cfg1 100 steps x
+5 seeds, cfg2 at full size over 400 steps -, final object vertices 0.0 mm apart, hand vertices 1.2-1.8e-4 mm (bar 1e-3 mm),
+every logged loss within 4e-6 at every step (bar 1e-4), `first_step_over_tol: null`.  The hand is driven by smooth terms and
+needs no such care; on the step-2 sets the contact term couples the hand's one-ulp vertices into the object, where the per-step
+bound (lock-step, below 1e-4) is what is claimed.  Cost of the exact path: nothing at one clip, -2 % on an 8-clip batch
+(EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the divisions.
+
+Teacher-forced lock-step parity at full size (`bench.lockstep_parity`, `tests/test_lockstep_gpu.py`) stays as the per-step
+statement for all loss sets: BEFORE every step the fused loop's parameters are loaded into the (faithful, autograd) oracle,
+which evaluates that step there - zero flipped samples, object vertices bit-equal, `loss_sil_obj` equal to the last bit, every
+loss of the step-1 set within 2.4e-7, gradients within 2e-6 of their largest entry, hand vertices within 6e-5 mm; cfg3's
+`loss_collision` up to 1.8e-4 (conditioned on the hand's one-ulp vertices; 1.1e-7 on the HIP vertices); and, new, cfg2 WITH the
+ordinal depth term at 30 x 256^2 (losses incl. `loss_depth` within 1e-4, zero flipped samples in the silhouette raster and in
+the object's depth render).
 
 ## 3. Data layout in HBM (per clip, B frames, S=256 → 512² samples, F faces, V vertices)
 
@@ -153,7 +173,7 @@ steps); the end state of the object is bounded by what is well defined - the dis
 | `srcs` | (4,B,512) lines × ≤512 × {d1, g, owner} | 377 MB reserved, ≈ 0.3 MB touched | `k_bwd_lines` → `k_bwd_sweep` |
 | `owned` | (B,2F) u8 | 0.2 MB | `k_raster_fwd` → work list |
 | sweep work list: `tab`, `offs`, `ufirst` | active faces × 64 B {corners in pixels, cumulative item counts of the 12 (winding, edge, axis) families, first item} ; first face of every 64-item unit | ≤ 5.8 MB + 0.4 MB + 1.4 MB (≈ 45 % of the faces active) | compaction blocks of `k_bwd_lines` → `k_bwd_sweep` |
-| `parts` | (B,F,3,2) f32 corner gradients | 2.2 MB | `k_bwd_sweep` → `k_bwd_gather` / `k_rigid_bwd` |
+| `parts` | (B,F,3,2) f64 corner gradients: exact sums on the 2^-44 grid | 4.3 MB | `k_bwd_sweep` → `k_bwd_gather` / `k_rigid_bwd_x` |
 | MANO model `M` | (145,2334) f32 = [posedirs; shapedirsᵀ] | 1.35 MB | constant, L2-resident |
 | SDF: `tris` | (B,F_k,16) f32 packed triangle + box | 8.7 MB | `k_sdf_tris` → `k_sdf_dist` |
 | SDF: `masks`, `needm`, `need_list`, `phi` | 32² u32 rows ; ≤ 32³ voxel ids / distances per (mesh, frame) | 0.5 MB + sparse | sign → need → distance → sample |
@@ -181,13 +201,13 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | Kernel | Work decomposition | Bound | Alg. bytes / launch |
 |---|---|---|---|
 | `k_setup_faces` | thread / face: optional rigid transform of the mesh-space vertex (the silhouette chain does not wait for `hm_rigid_fwd`), projects its 3 vertices (no separate projection launch), windings, tight sample box; bins the face into 64² super-regions (128² above 512² samples; LDS-aggregated counts, one global atomic per (workgroup, bin)); extra workgroups write the camera-space vertices for the other losses (same arithmetic as `k_rigid_fwd`: the hand-side stream no longer opens with a transform launch) | HBM | B·(V·24 + F·(12+36+8+2+5)) = 6.7 MB |
-| **`k_raster_fwd`** | workgroup = one 32×32-sample region: scans the faces of its super-region; candidates are split by WINDING CLASS - the class that holds the camera-facing surface of the mesh (a scheduling hint set by `calibrate()` from the index map; any value is correct) fills the candidate array from the front, the other from the back; one thread per candidate builds the face record in LDS (+ the nearest depth the face can produce); the (candidate, 4×4-sample block) units are **flattened** over the 256 threads (binary search of the exclusive unit counts); visibility = `ds_min_u64` on an LDS z-buffer keyed (depth bits ≪ 32 \| face) = strict z test in ascending face order, bit-exact.  The near class runs first; then per 4×4 block the largest owner depth is taken (`hz`), and the units of the far class are first tested against it, 64 per wave trip, the survivors queued per wave and the unit body run on FULL waves of survivors (a divergent early-out would leave the wave paying for its one visible unit: on a closed mesh ~85 % of the far units are hidden).  Sample positions of power-of-two grids by one multiplication (eight IEEE divisions per unit before).  Epilogue per 8×8 output tile: index map, pooled silhouette, fused masked-MSE terms, alpha plane and the four sweep bit planes of the backward (one full cache line per tile, ballots picked with selects: no scratch); in a fixed loop (`persistent_outputs`) an empty bin in front of outputs that already hold the empty pattern leaves before touching LDS (60 % of the workgroups).  25 KB of LDS and 80 VGPRs: 6 workgroups per CU (4 before: +20 %) | latency × residency, then VALU (`valu_frac` 0.54) | B·(F·49 + 512²·4 + 4·S²·4 + 5·512²/8) = **72.2 MB** |
+| **`k_raster_fwd`** | workgroup = one 32×32-sample region: scans the faces of its super-region; candidates are split by WINDING CLASS - the class that holds the camera-facing surface of the mesh (a scheduling hint set by `calibrate()` from the index map; any value is correct) fills the candidate array from the front, the other from the back; one thread per candidate builds the face record in LDS (+ the nearest depth the face can produce) - BOTH classes in one pass, wave 0 up to 64 near-class records while wave 1 builds up to 64 far-class records (one round trip to the packed faces and one stretch of record arithmetic per round instead of one per class: the far class's pass had been a quarter of an active workgroup's time with three waves at its barrier; per-class prefix sums are per-wave scans); the (candidate, 4×4-sample block) units are **flattened** over the 256 threads (binary search of the exclusive unit counts); visibility = `ds_min_u64` on an LDS z-buffer keyed (depth bits ≪ 32 \| face) = strict z test in ascending face order, bit-exact.  The near class runs first; then per 4×4 block the largest owner depth is taken (`hz`), and the units of the far class are first tested against it, 64 per wave trip, the survivors queued per wave and the unit body run on FULL waves of survivors (a divergent early-out would leave the wave paying for its one visible unit: on a closed mesh ~85 % of the far units are hidden).  Sample positions of power-of-two grids by one multiplication (eight IEEE divisions per unit before).  Epilogue per 8×8 output tile: index map, pooled silhouette, fused masked-MSE terms, alpha plane and the four sweep bit planes of the backward (one full cache line per tile, ballots picked with selects: no scratch); in a fixed loop (`persistent_outputs`) an empty bin in front of outputs that already hold the empty pattern leaves before touching LDS (60 % of the workgroups).  25 KB of LDS and 80 VGPRs: 6 workgroups per CU (4 before: +20 %) | latency × residency, then VALU (`valu_frac` 0.54) | B·(F·49 + 512²·4 + 4·S²·4 + 5·512²/8) = **72.2 MB** |
 | `k_sil_reduce` | block / frame + last-block finish.  One clip: the same body rides as B extra workgroups at the front of the `k_bwd_lines` launch (`hm_sil_bwd_clips(..., loss_out)`): the value is only logged, so it costs no launch; a clip batch keeps it on the third stream | latency | 0.5 MB |
 | `k_bwd_masks` | generic backward only (arbitrary `dL/dsilhouette`, or a negative loss weight): wave / tile, sweep planes via ballots | HBM | ≈ 21 MB |
 | `k_bwd_lines` | one DPP row (16 lanes) per TWO consecutive lines of a (plane, orientation, frame), 32 lines / workgroup (their mask words arrive in the same 4-byte loads; the launch is about one resident round of workgroups): expands a bit line into a position-sorted array of sources {d1, g, owner} + a 16-byte record per 64-bit word {mask, sources before it} (row scan).  Its first ⌈B·F/256⌉ workgroups build the **work list** of the sweeps instead: faces that own a sample → 64-byte records laid end to end in one global item space (block scan, one 64-bit atomic per block; a block's items start on a 64-item boundary so that the composition of every unit — and with it every summation order — is independent of the order in which blocks draw their bases) | latency | B·(4·512²/8 + S²·4 + 512² + F·46) = 23.8 MB |
-| **`k_bwd_sweep`** | persistent waves; a **unit** = 256 consecutive (face, winding, edge, axis, d0) items of the global list, whichever faces they belong to (a big face spreads over several waves, small faces share one), handled per pass of ≤ 16 faces staged in LDS together with their per-(face, family) constants - edge slope, first line, end-point order: one IEEE division per family instead of one per item, built by the wave right after the staging - and per-(face, axis) inward ranges.  **Stage 1** (every item, 64 per trip, four trips whose loads are all in flight before the first is tested): family by a 4-step search of the cumulative counts, line geometry from the family constants, then three loads requested together: the line's 16-byte summary, the owner of the sample just inside the edge and the alpha word of the sample just outside - the outward sweep needs a sample this winding owns AND a plane-0 source beyond the edge (exact from first / last position), the inward sweep an empty sample outside AND a plane-1 source inside the triangle's extent (positions + word mask); in the steady state of a fit 71 % of the items stop here (1.95 M items → 557 k, of which 555 k do have pairs) and the rest are queued with the two decisions.  **Stage 2** (queued items on full waves): two 16-byte record loads + popcounts give the slices `[lo, lo+nb)` of the line's source array; the (item, source) pairs are **flattened** over the wave, four consecutive pairs per lane, item of a pair by scatter + max-scan; per-lane running sums flushed into the face's six LDS accumulators when the (face, corner) target changes; a face inside one unit is stored, a face cut by one unit boundary is added by two commutative hardware float atomics, a face over ≥ 3 units goes through per-unit partials + ticket (deterministic in all three cases); **XCD-aware**: each XCD (workgroup id mod 8) takes one contiguous eighth of the units, so a frame's index-map lines, line records and source slices are fetched into one L2 instead of eight | VALU issue + dependent-load latency (`valu_frac` 0.48) | B·(F·(68+24) + 512²·4 + 512²) = **47.6 MB** |
-| `k_bwd_gather` | thread / vertex over CSR adjacency: one `float2` per (face, corner) (deterministic, no atomics) + projection backward.  Autograd path only: the fused loop gathers inside `k_rigid_bwd` (`hm_rigid_bwd_sil`) | HBM | B·(F·24·2 + V·24) = 5.4 MB |
-| `k_rigid_fwd/bwd` | forward: thread / vertex; backward: grid (frame, 256-vertex chunk), sums up to four weighted per-vertex gradient terms + a per-frame vector + optionally the silhouette gradient gathered from the sweeps' per-corner output (no gather / linear-combination launches), 13 block sums behind two barriers, per-frame ticket, rot6d backward by the finishing workgroup | latency | ≤ 4·B·V·12 |
+| **`k_bwd_sweep`** | persistent waves; a **unit** = 256 consecutive (face, winding, edge, axis, d0) items of the global list, whichever faces they belong to (a big face spreads over several waves, small faces share one), handled per pass of ≤ 16 faces staged in LDS together with their per-(face, family) constants - edge slope, first line, end-point order: one IEEE division per family instead of one per item, built by the wave right after the staging - and per-(face, axis) inward ranges.  **Stage 1** (every item, 64 per trip, four trips whose loads are all in flight before the first is tested): family by a 4-step search of the cumulative counts, line geometry from the family constants, then three loads requested together: the line's 16-byte summary, the owner of the sample just inside the edge and the alpha word of the sample just outside - the outward sweep needs a sample this winding owns AND a plane-0 source beyond the edge (exact from first / last position), the inward sweep an empty sample outside AND a plane-1 source inside the triangle's extent (positions + word mask); in the steady state of a fit 71 % of the items stop here (1.95 M items → 557 k, of which 555 k do have pairs) and the rest are queued with the two decisions.  **Stage 2** (queued items on full waves): two 16-byte record loads + popcounts give the slices `[lo, lo+nb)` of the line's source array; the (item, source) pairs are **flattened** over the wave, four consecutive pairs per lane, item of a pair by scatter + max-scan; every term is `diff / dist` with IEEE divisions and is rounded to the 2^-44 grid; per-lane running sums in DOUBLE, flushed into the face's six double LDS accumulators (`ds_add_f64`) when the (face, corner) target changes; a face inside one unit is stored, a face cut by unit boundaries is added by its units with hardware double atomics onto a zeroed target - the sums are exact, so any order gives the same value, nobody waits, and the per-unit partials + tickets of rounds 2-3 are gone; **XCD-aware**: each XCD (workgroup id mod 8) takes one contiguous eighth of the units, so a frame's index-map lines, line records and source slices are fetched into one L2 instead of eight | LDS + dependent-load latency (the IEEE divisions and the double accumulation cost nothing measurable: 46.1 → 46.0 µs) | B·(F·(68+48) + 512²·4 + 512²) = **49.8 MB** |
+| `k_bwd_gather` | thread / vertex over CSR adjacency: one `double2` per (face, corner), summed exactly, rounded once + projection backward.  Autograd path only: the fused loop gathers inside `k_rigid_bwd` (`hm_rigid_bwd_sil`) | HBM | B·(F·24·2 + V·24) = 5.4 MB |
+| `k_rigid_fwd/bwd`, `k_rigid_bwd_x` | forward: thread / vertex; backward: grid (frame, 256-vertex chunk), sums up to four weighted per-vertex gradient terms + a per-frame vector + optionally the silhouette gradient gathered from the sweeps' per-corner output (no gather / linear-combination launches), 13 block sums behind two barriers, per-frame ticket, rot6d backward by the finishing workgroup.  The OBJECT's backward of the fused loops is `k_rigid_bwd_x`: the same work with every dependent load stage (CSR offsets → corner items → per-corner doubles) issued for all of a thread's vertices at once, the 13 sums EXACT (addends on the 2^-44 grid, DPP reductions on doubles, chunk records of doubles: any split of the vertices gives the same floats), and the object's temporal-smoothness gradient formed in the kernel from the camera-space vertices of the neighbouring frames - on the step-1 sets the object's chain waits for nothing the hand-side stream produces | latency (a chain of ~6 round trips: 15 µs for 180 workgroups) | ≤ 4·B·V·12 |
 | `k_mano_fwd`, `k_mano_bwd` | forward: (13 vertex chunks × ⌈B/4⌉) blocks, a workgroup = one chunk of 64 vertices for FOUR consecutive frames, wave f owning frame f: four chains prepared side by side, then every wave streams its 37 rows of the blend matrix `M` ONCE and accumulates them for all four frames (the 1.35 MB matrix crosses L2 once per four frames: a 240-frame batch used to pull 324 MB through L2 per launch), wave f finishes frame f (partials, skinning, rigid transform, state); per frame the arithmetic and its order are unchanged, so frame grouping is invisible in the results.  Backward: (13 × B) blocks; kinematic tree staged in LDS, chain level-parallel; `M` rows streamed coalesced with all of a wave's rows requested before the first is reduced; rigid hand transform fused into the forward epilogue; the forward keeps the chain state + posed vertices for the backward; backward = ONE launch: chunk partials, then the frame's last workgroup (per-frame ticket) runs the chain / Rodrigues / PCA backward with the prior folded in; `k_mano_bwd<true>` (`hm_mano_bwd_rigid_clips`, one clip) also does the hand's rigid backward - no mesh-gradient buffer, no `k_rigid_bwd` launch for the hand | L2 / latency | 2·C_mano + 2·B·778·12 |
 | `k_hand_terms` | 2-D reprojection + temporal smoothness + priors of the hand in one launch, one ticket | latency | ≈ 1.5 MB |
 | **`k_pair_terms`** (`csrc/pairterms.hip`) | one clip: the terms that start from the two vertex buffers and feed nothing to each other as BLOCK RANGES of one grid - [search \| interaction \| hand terms \| object smoothness] - each with its own reduce workspace and ticket; the search is the metric-only one on the step-1 sets and the FULL one (`nn_full_body`, the body of `k_nn`, with the contact launches behind it) when the contact term is on (cfg3: 214 → 202 µs per iteration).  The bodies are shared with the stand-alone kernels (`pair_bodies.h`: device functions on virtual block coordinates), so the floats are the same either way (`test_pair_terms_launch_equals_its_four_entry_points`, and every batched == single test: batches use the stand-alone launches).  Four launches and three graph edges of the hand-side chain become one: 5100 → 5430 it/s | latency | ≈ 2 MB |
@@ -199,7 +219,7 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | `k_sdf_boxes`, `k_sdf_tris`, `k_sdf_need`, `k_sdf_dist`, `k_sdf_sample` | AABB + normalise; thread / triangle: packed record + +x ray parity of the few (y,z) rows under the triangle (`atomicXor` of 32-bit inside masks); thread / sample: marks touched inside voxels, first setter appends to the grid's list; workgroup / listed voxel: nearest-vertex seed + box-pruned scan of the packed triangles (a single wave was ~70 dependent round trips for one voxel); thread / sample: trilinear value + gradient, ticket reduction | latency | ≈ B·(778+V)·36 + 8.7 MB |
 | `k_depth_bwd_faces`, `k_depth_bwd_gather` (a19) | wave / (frame, face): strides the face's sample box, tests ownership in the index map, reduces the three sums `A_k = Σ g·zp²·w_k` the NMR depth backward factors through (DPP); thread / vertex gather + projection backward | HBM (index-map reads) | B·(512²·4·ρ + S²·4 + F·(44+72)) (ρ ≈ box overlap) |
 | `k_ordinal_depth`, `k_ordinal_depth_bwd` (a19) | 16 chunk workgroups per frame; a frame's record collects them with 64-bit INTEGER atomics (pixel counts packed, softplus sums in 2⁻³² fixed point: order-independent, so deterministic), last workgroup finishes the clip; element-wise backward.  In the fused loop the object's depth render and depth backward ride the calling stream (behind the silhouette raster / behind the sweeps), the hand's the side stream | HBM | B·S²·(4·4+2) fwd, + B·S²·8 bwd |
-| `k_adam` | one launch for all tensors (pointer table), bias corrections in double, zeroes grads; the last workgroup (ticket) bumps the device step counter.  One clip: an extra grid row writes the log row of the step being taken (weighted total + every loss / metric slot) before it draws its tickets (`hm_adam_step_log` = `hm_log_total_clips` + `hm_adam_step`, same floats, one launch less on the tail) | latency | 28·79·B |
+| `k_adam` | one launch for all tensors (pointer table), bias corrections in double by square-and-multiply (a function of (beta, t) alone: the oracle's Adam forms the same doubles), zeroes grads; the last workgroup (ticket) bumps the device step counter.  One clip: an extra grid row writes the log row of the step being taken (weighted total + every loss / metric slot) before it draws its tickets (`hm_adam_step_log` = `hm_log_total_clips` + `hm_adam_step`, same floats, one launch less on the tail) | latency | 28·79·B |
 
 Whole iteration (SURVEY §8d byte model): 144.1 MB (cfg2), 161.8 MB (cfg3).
 
@@ -236,7 +256,7 @@ next to them.  HIP-runtime and hardware facts that shaped it (all measured, EXPE
   per SIMD leave 32 registers - whether a hand-side kernel runs under a heavy kernel or after it is a matter of residency,
   which the LDS ballast knobs (`hm_tune_*`) and the sweep's workgroup count steer per loss set.
 
-## 5. Measured (MI355X, round 3; evidence under `profiles/r03_*`, regenerated by `tools/profile_round.sh r03`)
+## 5. Measured (MI355X, round 4; evidence under `profiles/r04_*`, regenerated by `tools/profile_round.sh r04`)
 
 `python bench.py` = the driver's command: cfg2, 400 steps after 20 warm-up, then - same process, same fit, same hipGraph -
 a `steady_state` leg (iteration ≥ 400, 2000 timed iterations, 0.33 s) so that ONE line carries both regimes whatever
@@ -249,21 +269,24 @@ a `steady_state` leg (iteration ≥ 400, 2000 timed iterations, 0.33 s) so that 
 | cfg2 as BASELINE.json words it, with the ordinal depth term (`--depth`) | @DEPTH@ it/s |
 | cfg3 (step-2: + collision + contact) | **@CFG3@ it/s** |
 | cfg4 in miniature: 8 clips per GPU as ONE clip batch (`multi_clip`) | **@MULTI@ it/s** summed = @MULTIX@ × one clip; whole-iteration roofline fraction @MULTIF@ |
+| a heterogeneous shard: 8 clips of 4 shapes (bottle / cube, 30 / 20 frames) through `ShardStepper`, the shape groups' graphs replayed concurrently | @MIXED@ it/s summed (one after the other: 8 330) |
+| END TO END (`end_to_end` of the bench line): 16 cfg2 clips x 400 steps through `ClipFitter`, 8 per batch, wall clock from the per-frame input dicts on the host to the results on the host - the first batch builds model / workspaces / graph, the second is copied into the resident stepper | **@E2E@ clips/s** over all 16; a clip of a RESIDENT shape: **@E2ERES@ clips/s**, input load = @E2ESETUP@ of its fit; split: @E2ESPLIT@ |
 | cfg5 on one rank (8 clips, step-2, one tied scale, RCCL call issued) | @CFG5@ it/s |
 | 2 ranks on ONE GPU through gloo (the driver's `torch.distributed.run` line; weak scaling has nothing to scale on one GPU - this is the N > 1 code path, not a speed-up) | cfg2: @G2@ it/s summed; cfg5 (2 x 4 clips, tied scale): @G5@ it/s, replicas identical |
 | object-pose initialisation (SURVEY §8f rank 1): 500 candidate poses of the bottle against one 256² mask, `python bench.py --pose-init 500` | **@POSE@ pose-steps/s** (@POSEMS@ ms per step of 500 poses; a 50-step fit in @POSEFIT@ s); by loop: @POSELOOPS@; CPU oracle @POSECPU@ pose-steps/s |
+| free-running parity, cfg2 at full size, 400 steps, HIP loop vs the oracle's reproducible loop (`profiles/r04_freerun_cfg2_400.json`) | object pose parameters bit-equal after every step: @FREEEQ@; largest relative loss difference @FREELOSS@; final vertices object @FREEVO@ mm, hand @FREEVH@ mm |
 | CPU baseline (oracle loop, 64 host threads) | @CPU@ it/s with the reference's per-step `.item()` logging, @CPUOFF@ it/s without → GPU / CPU ≈ @RATIO@ × (target ≥ 50 ×) |
 | whole iteration vs the SURVEY §8d byte model (144.1 MB) | @WHOLE@ of 8 TB/s at one clip |
 
 **Roofline of the heavy kernels, inside the replayed graph** (ROCm allows no timing events inside graphs, so every
 workgroup of the three kernels stores `s_memrealtime` at entry and exit, `hm_sil_timestamps`; `bench.py` replays THE SAME
-graph 50 more times and averages; `rocprofv3 --kernel-trace --stats` of the same command, `profiles/r03_p_cfg2_headline_kernel_stats.txt`,
+graph 50 more times and averages; `rocprofv3 --kernel-trace --stats` of the same command, `profiles/r04_p_cfg2_headline_kernel_stats.txt`,
 agrees to a few per cent, see the note in EXPERIMENTS.md on what the profiler itself moves):
 
 | kernel (cfg2, steady state) | µs / launch | algorithmic MB | GB/s | frac of 8 TB/s | PMC traffic MB | VALU wave-instr | valu_frac (4-cycle / 2-cycle) |
 |---|---|---|---|---|---|---|---|
 | `k_raster_fwd` | @RAS@ | 72.2 | @RASG@ | @RASF@ | @RAST@ | @RASV@ | @RASVF@ |
-| `k_bwd_sweep` (`roofline.kernel`: the longest launch) | @SWP@ | 47.6 | @SWPG@ | @SWPF@ | @SWPT@ | @SWPV@ | @SWPVF@ |
+| `k_bwd_sweep` (`roofline.kernel`: the longest launch) | @SWP@ | 49.8 | @SWPG@ | @SWPF@ | @SWPT@ | @SWPV@ | @SWPVF@ |
 | `k_bwd_lines` | @LIN@ | 23.8 | @LING@ | @LINF@ | @LINT@ | @LINV@ | @LINVF@ |
 
 `valu_frac` = `SQ_INSTS_VALU` ÷ (launch time × 1024 SIMDs × 2.4 GHz ÷ 4).  The 4: a wave64 VALU instruction runs on a
@@ -275,14 +298,25 @@ against that peak as `valu_frac_2cyc` (half the value).  Either way the reading 
 (the kernels are not HBM-bound), and they issue VALU on one third to two thirds of all SIMD cycles; the rest is dependent
 loads (7-8 global round trips per raster workgroup) and LDS.
 
-**What bounds the iteration** (EXPERIMENTS.md, round 3).  The silhouette chain is serial and it IS the iteration: setup 12 +
-raster 45 + lines 26 + sweeps 46 + object gradients 16 + Adam 4 µs + ≈17 µs of graph edges = 165 µs; the hand side (MANO,
-pair terms, hand gradients) runs under it - removing the MANO backward altogether buys +1.5 %.  The three heavy kernels are
-within 1.5-3 × of the VALU roof on work whose size the algorithm sets (2.07 M covered (face, sample) pairs, 1.95 M sweep
-items of which 29 % have a source in reach, 1.4 M (item, source) pairs), so what is left is instruction count per item;
-this round's two attempts at it for the raster - box-anchored blocks (−11 % units, not worth the rewrite) and far-class
-candidates dropped before their records (80 % fewer records, kernel +5 %: a record pass costs its wave the same whether 6 or
-31 lanes are live) - did not pay, and the verdict's kernel targets (raster ≤ 38, sweep ≤ 38, lines ≤ 18 µs) are NOT met.
+Pose initialisation (`bench.py --pose-init 500`, its own line with `roofline`; `profiles/r04_p_poseinit_kernel_stats.txt`,
+`r04_pmc_poseinit.json`): per step of 500 candidate poses `k_bwd_sweep` @PISWP@ µs (algorithmic 315 MB → @PISWPG@ GB/s =
+**@PISWPF@** of HBM peak, the dominant kernel), `k_raster_fwd` @PIRAS@ µs (@PIRASF@), `k_bwd_lines` @PILIN@ µs (@PILINF@); all
+throughput-bound at 500 frames per launch.
+
+**What bounds the iteration** (EXPERIMENTS.md, round 4).  The silhouette chain is serial and it IS the iteration: setup 8 +
+raster 43 + lines 23-25 + sweeps 46 + object gradients 15 + Adam 4 µs + ≈20 µs of launch gaps and graph edges ≈ 160 µs; the
+hand side (MANO, pair terms, hand gradients) runs under it.  Two facts of this round say where the rest is.  (1) The floor:
+BASELINE cfg1 (10 frames 128², a 500-face cube) runs 11 400 it/s = 88 µs per iteration with nearly empty kernels - six serial
+launches and two cross-queue edges cost that much; cfg2 is that floor plus ~70 µs.  (2) The heavy kernels are NOT issue-bound
+in the sense that instructions cost time one for one: the sweeps' pair loop went from `v_rcp_f32` + multiply to two
+11-instruction IEEE divisions and double-precision accumulation, and the kernel's time did not move (46.1 → 46.0 µs) - LDS
+(`SQ_WAIT_INST_LDS`) and dependent loads bound it.  In aggregate the GPU is work-bound (two 4-clip batches side by side: +2 %
+over one 8-clip batch, four 2-clip batches: −16 %), at one clip it is launch-latency-bound.  Measured and reverted this round
+(EXPERIMENTS.md): a per-(face, family) reject ahead of the sweep's item enumeration from coarse source summaries (−17 % items
+instead of the hoped −60 %: sources are sparse per LINE), Adam folded into the two chains' last launches (−7 %), one large
+workgroup per frame in the rigid backward (−3 %), bin entries carrying the face boxes (±0).  Kept: both winding classes'
+records in one raster pass (raster 46.5 → 43.2 µs, batch +2.5 %), the smoothness gradient inside the rigid backward (+1.5 %).
+The verdict's kernel targets (raster ≤ 38, sweep ≤ 34, rigid backward ≤ 8 µs; steady ≥ 7 000, batch ≥ 10 500 it/s) are NOT met.
 
 ## 6. Multi-GPU
 
@@ -291,9 +325,21 @@ balanced blocks of clips to the ranks (64 clips / 8 GPUs = 8 each; 9 / 8 = 2,1,1
 through `dist.optimize_clip_shard(models, ...)` → `ShardStepper`: clips that agree in shape (frames, object topology, hands,
 sizes) form ONE clip batch - every kernel launched once per iteration over all of them, one Adam state per clip - and the
 batches of different shapes (a real Core50 shard: every clip its own object mesh, `homan/datasets/core50.py:22-42`, and its
-own length, `fit_vid_dataset.py:190`) follow each other inside every iteration, each replayed from its own hipGraph.  Every
-clip ends up with exactly the result of optimising it alone, bit for bit (`tests/test_clip_batch_gpu.py`).  What is NOT
-built: one launch per kernel over clips of DIFFERENT shapes (per-clip CSR offsets in every `hm_*_clips` kernel).
+own length, `fit_vid_dataset.py:190`) replay their own hipGraphs CONCURRENTLY, each on a stream of its own (independent clips:
+no ordering between groups at all without a tied scale; with one, the two halves of every group's iteration run side by side
+around the rank's single all-reduce).  A one-clip graph is ~90 µs of launch and edge latency around ~70 µs of kernels, so
+groups side by side fill what a sequence leaves idle: 4 shapes × 2 clips 8 330 → 9 750 it/s, eight one-clip groups 7 800 it/s
+(8 clips of ONE shape as a batch: 8 900-9 200).  Configurations the fused loop takes one clip at a time (two hands per frame,
+`inter_type="min"`) become singleton groups of the same mechanism.  Every clip ends up with exactly the result of optimising
+it alone, bit for bit (`tests/test_clip_batch_gpu.py`).  What is NOT built: one launch per kernel over clips of DIFFERENT
+shapes (per-clip CSR offsets in every `hm_*_clips` kernel).
+
+A process that walks a dataset does it through `ClipFitter` (`jointopt.py`): per shape signature ONE resident stepper -
+device buffers, workspaces, ONE captured hipGraph - into which the next clip of that shape is copied (`FusedStepper.reload`,
+`HOMan.load_clip`, `hm_sil_invalidate_outputs`; 2.8 ms per clip = 6 % of a 400-step fit) instead of building model,
+~0.5 GB of zero-filled workspace, calibration and capture again (about twice a fit); least-recently-used shapes are evicted,
+the number of live graphs is bounded by the number of resident shapes (`tools/soak_dataset.py`: 40 clips of 4 shapes, 4
+graphs, no memory growth).  Results are bit-identical to fresh fits.
 
 cfg5 ties ONE object scale across all clips of all ranks (an extension; the reference's scale is per clip,
 `homan/homan.py:121-130`).  The tied loss is the sum of the clips' losses, so the scalar's gradient is the sum of the clips'
@@ -346,19 +392,20 @@ file the reference never reaches.  More than two hands: the reference's own coll
 
 ## 8. Known gaps / next (ranked)
 
-1. Kernel targets of the last verdict (raster ≤ 38, sweep ≤ 38, lines ≤ 18 µs in the graph; driver-flag line ≥ 5500,
-   8-clip batch ≥ 9500 it/s) are not met: 45 / 45 / 22 µs, 4 860 and 9 020 it/s.  The sweep is issue-bound at its 96 registers
-   (2 250 VALU wave-instructions per 256-item unit, ~85 % of the issue slots until its tail; 10 % of the waves run 16 us
-   longer than the other 90 %), so neither more waves, nor pipelined pair rounds, nor other unit sizes helped
-   (EXPERIMENTS.md); the object-gradient + Adam tail of the chain does not get shorter inside the sweep launch either (a
-   cross-queue edge in front of a long node costs the graph executor ~20 us).  What the round's counters say is left:
-   the raster spends 7-8 dependent global round trips per workgroup (a 16-byte `{face, box}` bin entry and vertices staged
-   by the scanning thread would remove two of them) and ~2.6 VALU issue slots + a VCC hazard per inside test; the sweep's
-   stage 1 costs ~250 instructions per 64 items, 71 % of which it rejects (a per-(face, family) reject before the items
-   are enumerated would cut that two- to three-fold); the line expansion takes 2.2 × its stand-alone time in an 8-clip batch
-   because latency-bound neighbours hold its wave slots.  All three need restructuring, not tuning.
-2. One launch per kernel over clips of DIFFERENT shapes (today: shape groups of a shard in sequence, section 6).
-3. The ordinal depth term in a clip batch and with two hands; `inter_type="min"` in a batch or with two hands (graph loop).
-4. Bit-equal HAND vertices (the object's are): needs the oracle's LBS written out in the kernel's summation order and a
-   shared sin / cos; it would take `loss_collision`'s per-step error from 1e-4 to 1e-7 like the other terms.
-5. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.
+1. Throughput targets of the last verdict are not met (section 5): steady 6 300 (target 7 000), 8-clip batch 9 200 (10 500),
+   driver-flag headline 4 950-5 050 (5 400); `k_bwd_sweep` is still the longest launch at 0.13-0.14 of HBM peak.  What this
+   round's measurements say would move them: at one clip, fewer NODES per iteration - the hand side's kernels (MANO forward,
+   pair terms, MANO backward) as block ranges of the silhouette chain's launches, which removes the side stream and its fork /
+   join (each cross-queue edge and launch gap is 5-10 µs of an iteration whose floor is 88 µs); in aggregate, less LDS traffic
+   per sweep item and pair (`SQ_WAIT_INST_LDS` is half of `SQ_ACTIVE_INST_VALU`), not fewer VALU instructions.
+2. One launch per kernel over clips of DIFFERENT shapes (today: concurrent shape groups, 88 % of a same-shape batch).
+3. The pose initialisation at 412 k pose-steps/s (target 600 k): its sweep (0.10 of HBM peak) and raster are throughput-bound
+   at 500 frames per launch; in mode 4 every source has the same gradient, so the per-line source records could shrink from
+   12 to 4 bytes and the line expansion to a popcount pass.
+4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
+   silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
+   hands it runs one clip per stepper (`ShardStepper`).
+5. Bit-equal HAND vertices (the object's are): needs the oracle's LBS written out in the kernel's summation order and a
+   shared sin / cos; it would extend the free-running bit-equality to the step-2 sets, where the contact term couples the
+   hand's one-ulp vertices into the object's chain, and take `loss_collision`'s per-step error from 1e-4 to 1e-7.
+6. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.

@@ -1,5 +1,5 @@
 """Fills the measured numbers of tools/DESIGN.tpl (section 5) from the round's bench lines under profiles/ -> DESIGN.md.
-usage: python tools/fill_design.py [r03]"""
+usage: python tools/fill_design.py [r04]"""
 import json
 import os
 import sys
@@ -17,7 +17,7 @@ def load(name):
     return None
 
 
-def main(tag="r03"):
+def main(tag="r04"):
     t = open(os.path.join(R, "tools", "DESIGN.tpl")).read()
     d = load(f"{tag}_bench_cfg2.json")
     drv = load(f"{tag}_bench_cfg2_driver_flags.json")
@@ -39,6 +39,22 @@ def main(tag="r03"):
                 "@POSEFIT@": "n/a" if not po else f"{po['seconds_per_fit']:.3f}",
                 "@POSELOOPS@": ", ".join(f"{k} {f0(v)}" for k, v in loops.items()) or "n/a",
                 "@POSECPU@": f0(po and po["cpu_baseline"]["value"])})
+    e2e, mixed, fr = d.get("end_to_end"), load(f"{tag}_bench_mixed_shard.json"), load(f"{tag}_freerun_cfg2_400.json")
+    rep.update({"@MIXED@": f0(mixed and mixed["its_per_s"]),
+                "@E2E@": "n/a" if not e2e else f"{e2e['clips_per_s_end_to_end']:.1f}",
+                "@E2ERES@": "n/a" if not e2e else f"{e2e['repeated_shape']['clips_per_s']:.1f}",
+                "@E2ESETUP@": "n/a" if not e2e else f"{100 * e2e['repeated_shape']['setup_fraction_of_fit']:.1f} %",
+                "@E2ESPLIT@": "n/a" if not e2e else ", ".join(f"{k} {v:.3f} s" for k, v in e2e["split_s"].items()),
+                "@FREEEQ@": "n/a" if not fr else str(fr["object_params_bit_equal_all_steps"]),
+                "@FREELOSS@": "n/a" if not fr else f"{fr['max_rel_loss']:.1e}",
+                "@FREEVO@": "n/a" if not fr else f"{fr['final_vertex_diff_mm']['object']:.1e}",
+                "@FREEVH@": "n/a" if not fr else f"{fr['final_vertex_diff_mm']['hand']:.1e}"})
+    pk = ((po or {}).get("roofline") or {}).get("kernels", {})
+    for key, name in (("PISWP", "k_bwd_sweep"), ("PIRAS", "k_raster_fwd"), ("PILIN", "k_bwd_lines")):
+        k = pk.get(name)
+        rep[f"@{key}@"] = "n/a" if not k else f"{k['avg_launch_us']:.0f}"
+        rep[f"@{key}G@"] = "n/a" if not k else f"{k['achieved_GBps']:.0f}"
+        rep[f"@{key}F@"] = "n/a" if not k else f"{k['achieved_GBps'] / 8000:.2f}"
     ks = d["steady_state"]["roofline"]["kernels"]
     for key, name in (("RAS", "k_raster_fwd"), ("SWP", "k_bwd_sweep"), ("LIN", "k_bwd_lines")):
         k = ks[name]
