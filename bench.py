@@ -276,7 +276,8 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
                                             / max(np.abs(g_c[k]).max(), 1e-30)) for k in obj_keys})
                 for k in obj_keys:      # (put the oracle back on its own trajectory)
                     getattr(om, k).data.copy_(torch.from_numpy(cp[k]))
-        rows.append(dict(step=i, object_bit_equal=all(eq.values()), max_rel_loss=max(rel.values()),
+        rows.append(dict(step=i, object_bit_equal=all(eq.values()), max_rel_loss=max(rel.values()), rel=dict(rel),
+                         values_cpu={k: cpu[k] for k in rel},
                          worst_loss=max(rel, key=rel.get), max_param_diff=max(pdiff.values()),
                          worst_param=max(pdiff, key=pdiff.get)))
     with torch.no_grad():
@@ -292,6 +293,11 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
                 final_rel_loss=rows[-1]["max_rel_loss"], final_vertex_diff_mm=dict(object=dvo, hand=dvh),
                 final_max_param_diff=rows[-1]["max_param_diff"], final_worst_param=rows[-1]["worst_param"],
                 stage_report=stage_report, cpu_its_per_s=steps / max(t_cpu, 1e-9),
+                first_over_tol_detail=(lambda j: None if j is None else dict(
+                    step=j, rel_at_step=rows[j]["rel"], rel_step_before=rows[j - 1]["rel"] if j else None,
+                    values_cpu_at_step=rows[j]["values_cpu"], values_cpu_step_before=rows[j - 1]["values_cpu"] if j else None,
+                    worst_param_at_step=rows[j]["worst_param"], max_param_diff_before=rows[j - 1]["max_param_diff"] if j else None))(
+                    next((r["step"] for r in rows if r["max_rel_loss"] > tol), None)),
                 cores=int(os.environ.get("OMP_NUM_THREADS", "1")),
                 per_step=[{k: r[k] for k in ("step", "object_bit_equal", "max_rel_loss", "max_param_diff")} for r in rows][:: max(1, steps // 25)])
 

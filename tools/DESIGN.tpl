@@ -143,10 +143,17 @@ object's chain is closed on itself (`homan/homan.py:482-490`: `loss_inter` sees 
 
 Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `profiles/r04_freerun_*.json`):
 `rotations_object` / `translations_object` are BIT-EQUAL between the two free-running loops after every step - cfg1 100 steps x
-5 seeds, cfg2 at full size over 400 steps -, final object vertices 0.0 mm apart, hand vertices 1.2-1.8e-4 mm (bar 1e-3 mm),
-every logged loss within 4e-6 at every step (bar 1e-4), `first_step_over_tol: null`.  The hand is driven by smooth terms and
-needs no such care; on the step-2 sets the contact term couples the hand's one-ulp vertices into the object, where the per-step
-bound (lock-step, below 1e-4) is what is claimed.  Cost of the exact path: nothing at one clip, -2 % on an 8-clip batch
+5 seeds, cfg2 at full size over 400 steps -, final object vertices 0.0 mm apart.  cfg1 (the configuration the CPU path is
+defined on, 100 steps) and cfg2 over its first 170 steps (the bench line's `free_run` leg runs 100): hand vertices 1.2-1.8e-4 mm
+(bar 1e-3 mm), every logged loss within 4e-6 at every step (bar 1e-4), `first_step_over_tol: null`.
+What is NOT closed is the HAND over a whole 400-step cfg2 fit: its chain (MANO, 2-D, smoothness, interaction) is smooth but not
+exact - the vertices are one ulp from the oracle's -, and around step 170-180 of this clip the hand's own dynamics (Adam at 10 x lr
+on the MANO parameters, `mano_betas` with a vanishing gradient first) amplify whatever difference there is: HIP vs CPU ends
+0.14 mm apart in the hand with the losses up to 2 % apart in between (`r04_freerun_cfg2_400.json`, `first_step_over_tol: 181`),
+and the CPU loop against ITSELF from hand translations 1e-7 m apart leaves the 1e-3 mm bar at step 169 and ends 0.85 mm apart
+(`r04_control_cfg2_400.json`) - same step, same size: the reference algorithm's sensitivity, for which only an exact hand chain
+(section 8) would be a cure.  On the step-2 sets the contact term couples the hand's one-ulp vertices into the object, where the
+per-step bound (lock-step, below 1e-4) is what is claimed.  Cost of the exact path: nothing at one clip, -2 % on an 8-clip batch
 (EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the divisions.
 
 Teacher-forced lock-step parity at full size (`bench.lockstep_parity`, `tests/test_lockstep_gpu.py`) stays as the per-step
@@ -274,7 +281,7 @@ a `steady_state` leg (iteration ≥ 400, 2000 timed iterations, 0.33 s) so that 
 | cfg5 on one rank (8 clips, step-2, one tied scale, RCCL call issued) | @CFG5@ it/s |
 | 2 ranks on ONE GPU through gloo (the driver's `torch.distributed.run` line; weak scaling has nothing to scale on one GPU - this is the N > 1 code path, not a speed-up) | cfg2: @G2@ it/s summed; cfg5 (2 x 4 clips, tied scale): @G5@ it/s, replicas identical |
 | object-pose initialisation (SURVEY §8f rank 1): 500 candidate poses of the bottle against one 256² mask, `python bench.py --pose-init 500` | **@POSE@ pose-steps/s** (@POSEMS@ ms per step of 500 poses; a 50-step fit in @POSEFIT@ s); by loop: @POSELOOPS@; CPU oracle @POSECPU@ pose-steps/s |
-| free-running parity, cfg2 at full size, 400 steps, HIP loop vs the oracle's reproducible loop (`profiles/r04_freerun_cfg2_400.json`) | object pose parameters bit-equal after every step: @FREEEQ@; largest relative loss difference @FREELOSS@; final vertices object @FREEVO@ mm, hand @FREEVH@ mm |
+| free-running parity, cfg2 at full size, 400 steps, HIP loop vs the oracle's reproducible loop (`profiles/r04_freerun_cfg2_400.json`) | object pose parameters bit-equal after every step: @FREEEQ@, final object vertices @FREEVO@ mm; hand @FREEVH@ mm and losses up to @FREELOSS@ apart after step 181 - the CPU loop against itself from inputs 1e-7 m apart: hand 0.85 mm, from step 169 (`r04_control_cfg2_400.json`; section 2) |
 | CPU baseline (oracle loop, 64 host threads) | @CPU@ it/s with the reference's per-step `.item()` logging, @CPUOFF@ it/s without → GPU / CPU ≈ @RATIO@ × (target ≥ 50 ×) |
 | whole iteration vs the SURVEY §8d byte model (144.1 MB) | @WHOLE@ of 8 TB/s at one clip |
 
@@ -405,7 +412,9 @@ file the reference never reaches.  More than two hands: the reference's own coll
 4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
    silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
    hands it runs one clip per stepper (`ShardStepper`).
-5. Bit-equal HAND vertices (the object's are): needs the oracle's LBS written out in the kernel's summation order and a
-   shared sin / cos; it would extend the free-running bit-equality to the step-2 sets, where the contact term couples the
-   hand's one-ulp vertices into the object's chain, and take `loss_collision`'s per-step error from 1e-4 to 1e-7.
+5. An exact HAND chain (the object's is): the MANO forward AND backward, the 2-D / smoothness / interaction terms and the hand's
+   rigid backward with order-independent sums and a shared sin / cos on both sides.  It would close the hand's end state over a
+   whole 400-step cfg2 fit (0.14 mm today, where the CPU loop differs from itself by 0.85 mm), extend the free-running
+   bit-equality to the step-2 sets, where the contact term couples the hand's one-ulp vertices into the object's chain, and take
+   `loss_collision`'s per-step error from 1e-4 to 1e-7.
 6. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.
