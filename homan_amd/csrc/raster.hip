@@ -1030,6 +1030,7 @@ struct SweepFace {            // 64 B: one face of the flattened work list
 #endif
 #define SWEEP_UNIT (1 << SWEEP_USHIFT)
 #define SWEEP_TRIPS (SWEEP_UNIT / 64)      // stage-1 trips of a unit
+#define SWEEP_TBATCH (SWEEP_TRIPS < 4 ? SWEEP_TRIPS : 4)      // trips whose loads are in flight together
 struct SweepItem { float x, c0, c1; int base0, base1, nb0, fn, meta; };   // meta: face | t0<<4 | t1<<7 | use0<<10 | use1<<11
 struct SweepList {
     SweepFace* tab; int* offs; unsigned int* ufirst; unsigned int* tickets; float* upart;
@@ -1661,14 +1662,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
             // all of them are in flight before the first is tested (one dependent round trip per unit, not per trip)
             int qn = 0;
             {
-                uint4 sm[SWEEP_TRIPS];
+              for (int tb = 0; tb < SWEEP_TRIPS; tb += SWEEP_TBATCH) {      // (<= 4 trips' loads in flight at a time: registers)
+                uint4 sm[SWEEP_TBATCH];
                 // (per trip, packed - the four trips' state lives in registers until their loads have landed:
                 //  s_io = a_in | pos << 12 | geo << 13, s_lohi = lo | hi << 16 of the inward range)
-                int s_io[SWEEP_TRIPS], s_lohi[SWEEP_TRIPS], s_ent[SWEEP_TRIPS], s_own[SWEEP_TRIPS], s_fn[SWEEP_TRIPS];
-                unsigned short s_aw[SWEEP_TRIPS];
+                int s_io[SWEEP_TBATCH], s_lohi[SWEEP_TBATCH], s_ent[SWEEP_TBATCH], s_own[SWEEP_TBATCH], s_fn[SWEEP_TBATCH];
+                unsigned short s_aw[SWEEP_TBATCH];
 #pragma unroll
-                for (int t = 0; t < SWEEP_TRIPS; ++t) {
-                    const int g = it_lo + 64 * t + lane;
+                for (int t = 0; t < SWEEP_TBATCH; ++t) {
+                    const int g = it_lo + 64 * (tb + t) + lane;
                     int el = -1;                                      // my face: last one of the pass with off <= g
                     for (int i = 0; i < nfp; ++i) el += (__builtin_amdgcn_readlane(o, i) <= g) ? 1 : 0;
                     const SweepFace& fc = s_face[wv][max(el, 0)].f;
@@ -1692,10 +1694,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                         const int fbv = s_fb[wv][max(el, 0)][q.axis];
                         s_lohi[t] = q.pos ? ((fbv & 0xffff) | (q.a_in << 16)) : (q.a_in | (fbv & 0xffff0000));
                     }
-                    s_ent[t] = (g - ubeg) | (max(el, 0) << 8);
+                    s_ent[t] = (g - ubeg) | (max(el, 0) << SWEEP_USHIFT);
                 }
 #pragma unroll
-                for (int t = 0; t < SWEEP_TRIPS; ++t) {
+                for (int t = 0; t < SWEEP_TBATCH; ++t) {
                     const int min0 = (int)(sm[t].x & 0xffffu), end0 = (int)(sm[t].x >> 16);
                     const int min1 = (int)(sm[t].z & 0xffffu), end1 = (int)(sm[t].z >> 16);
                     const bool pos = (s_io[t] >> 12) & 1, geo_t = (s_io[t] >> 13) & 1;
@@ -1714,7 +1716,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
 #ifdef SWEEP_STATS
                     const unsigned long long gbal = __ballot(geo_t);
                     if (lane == 0) {
-                        atomicAdd(&g_sweep_n[8], (unsigned long long)max(0, min(64, it_hi - (it_lo + 64 * t))));
+                        atomicAdd(&g_sweep_n[8], (unsigned long long)max(0, min(64, it_hi - (it_lo + 64 * (tb + t)))));
                         atomicAdd(&g_sweep_n[9], (unsigned long long)__popcll(gbal));
                         atomicAdd(&g_sweep_n[10], (unsigned long long)__popcll(bal));
                     }
@@ -1728,9 +1730,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                     }
 #endif
                     if (reach) s_q[wv][qn + __popcll(bal & ((1ull << lane) - 1ull))] =
-                                   (unsigned short)(s_ent[t] | (a0 ? 1 << 12 : 0) | (a1 ? 1 << 13 : 0));
+                                   (unsigned short)(s_ent[t] | (a0 ? 1 << 14 : 0) | (a1 ? 1 << 15 : 0));
                     qn += __popcll(bal);
                 }
+              }
             }
             wave_sync();
 #if defined(SWEEP_EXP) && SWEEP_EXP == 1          // (timing experiment: no stage 2; results are wrong)
@@ -1746,7 +1749,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
 #endif
             bool mine = s0 + lane < qn;
             const int ent = mine ? (int)s_q[wv][s0 + lane] : 0;
-            const int g = ubeg + (ent & 0xff), el = (ent >> 8) & 15;
+            const int g = ubeg + (ent & (SWEEP_UNIT - 1)), el = (ent >> SWEEP_USHIFT) & 15;
             const SweepFace& fc = s_face[wv][el].f;
             const SweepGeo q = sweep_item_geo(fc, mine ? g - fc.off : 0, mine, is, s_fam[wv][el]);
             const int var = q.var, edge = q.edge, axis = q.axis, d0r = q.d0r, dir = q.dir, a_in = q.a_in, a_out = q.a_out;
@@ -1758,8 +1761,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
             // (IEEE divisions, like c2 below: every operand of a term is a defined function of the face and the line)
             const float c0 = use0 ? num / (p10 - (float)d0r) : 0.f;
             const float c1 = use1 ? num / ((float)d0r - p00) : 0.f;
-            const bool act0 = geo && (ent & (1 << 12));   // outward: my own sample just inside the edge      (stage 1 looked
-            const bool act1 = geo && (ent & (1 << 13));   // inward: only if the sample just outside is empty   both up)
+            const bool act0 = geo && (ent & (1 << 14));   // outward: my own sample just inside the edge      (stage 1 looked
+            const bool act1 = geo && (ent & (1 << 15));   // inward: only if the sample just outside is empty   both up)
             // [0] outward, from the sample just outside the edge to the border; [1] inward, across the triangle
             int rfrom[2], rto[2];
             {
