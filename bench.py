@@ -482,6 +482,7 @@ def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottl
                max_vert_diff_mm=dict(object=max(r["vert_diff_mm"]["object"] for r in rows),
                                      hand=max(r["vert_diff_mm"]["hand"] for r in rows)),
                object_vertices_bit_equal=all(r["vert_equal"]["object"] for r in rows),
+               hand_vertices_bit_equal=all(r["vert_equal"]["hand"] for r in rows),
                max_rel_metric={k: max(r["rel_metric"].get(k, 0.0) for r in rows) for k in rows[0]["rel_metric"]},
                max_handobj_maxdist_abs_m=max(r["handobj_maxdist_abs_m"] for r in rows),
                max_collision_rel_given_hip_vertices=(max(r["collision_rel_given_hip_vertices"] for r in rows)

@@ -207,6 +207,40 @@ __device__ __forceinline__ float hm_last_block_sum(const float* partials, int n,
     return hm_block_sum(a, red);
 }
 
+// ---- sin / cos of an fp32 angle as a DEFINED function: argument reduction by pi/2 and the fdlibm kernel polynomials in
+// double, one IEEE operation at a time, the results rounded to fp32.  libm's / OCML's sinf and cosf agree with it to an ulp, but
+// not with each other in the last bit - and the CPU oracle (oracle/csrc/lbs_exact.c, same operations) has to produce the hand's
+// Rodrigues rotations bit for bit.  |a| up to ~1e5 (two-term Cody-Waite reduction); joint angles are a few radians.
+__host__ __device__ __forceinline__ void hm_sincos(float af, float* sn, float* cs)
+{
+    const double a = (double)af;
+    const double k = __builtin_rint(a * 0.63661977236758138243);                  // 2 / pi
+    double r = a - k * 1.57079632673412561417e+00;                                 // pi/2, upper 33 bits
+    r = r - k * 6.07710050650619224932e-11;                                        // pi/2 - upper part
+    const double z = r * r;
+    // sin(r) on [-pi/4, pi/4]
+    double ps = 1.58969099521155010221e-10;
+    ps = -2.50507602534068634195e-08 + z * ps;
+    ps = 2.75573137070700676789e-06 + z * ps;
+    ps = -1.98412698298579493134e-04 + z * ps;
+    ps = 8.33333333332248946124e-03 + z * ps;
+    ps = -1.66666666666666324348e-01 + z * ps;
+    const double s = r + (r * z) * ps;
+    // cos(r)
+    double pc = -1.13596475577881948265e-11;
+    pc = 2.08757232129817482790e-09 + z * pc;
+    pc = -2.75573143513906633035e-07 + z * pc;
+    pc = 2.48015872894767294178e-05 + z * pc;
+    pc = -1.38888888888741095749e-03 + z * pc;
+    pc = 4.16666666666666019037e-02 + z * pc;
+    const double c = (1.0 - 0.5 * z) + (z * z) * pc;
+    const int q = (int)((long long)k) & 3;
+    const double sv = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    const double cv = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+    *sn = (float)sv;
+    *cs = (float)cv;
+}
+
 // ---- rot6d (3x2 row-major, reference homan/utils/geometry.py:9-27) -> rotation matrix (3x3 row-major)
 __device__ __forceinline__ void rot6d_to_mat(const float* r6 /*3x2 row-major*/, float* R /*3x3 row-major*/)
 {

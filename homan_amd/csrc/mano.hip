@@ -40,7 +40,9 @@ __device__ __forceinline__ void rodrigues(const float* r, float* R)
     const float e0 = r[0] + 1e-8f, e1 = r[1] + 1e-8f, e2 = r[2] + 1e-8f;
     const float a = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
     const float nx = r[0] / a, ny = r[1] / a, nz = r[2] / a;
-    const float s = sinf(a), c1 = 1.0f - cosf(a);
+    float s, cs_;
+    hm_sincos(a, &s, &cs_);          // (a defined function of a: the oracle evaluates the same operations)
+    const float c1 = 1.0f - cs_;
     // K = [[0,-nz,ny],[nz,0,-nx],[-ny,nx,0]] ; R = I + s K + (1-c) K K
     const float K[9] = {0.f, -nz, ny, nz, 0.f, -nx, -ny, nx, 0.f};
 #pragma unroll
@@ -58,7 +60,9 @@ __device__ __forceinline__ void rodrigues_backward(const float* r, const float* 
     const float e[3] = {r[0] + 1e-8f, r[1] + 1e-8f, r[2] + 1e-8f};
     const float a = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
     const float n[3] = {r[0] / a, r[1] / a, r[2] / a};
-    const float s = sinf(a), c = cosf(a), c1 = 1.0f - c;
+    float s, c;
+    hm_sincos(a, &s, &c);
+    const float c1 = 1.0f - c;
     const float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
     float KK[9];
 #pragma unroll

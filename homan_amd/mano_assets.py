@@ -140,6 +140,26 @@ def synthetic_mano(seed=0):
     return out
 
 
+def kernel_layout(model_np, flat_hand_mean=False):
+    """The model arrays in the layout csrc/mano.hip reads (model DATA, shared by the kernels' host side and the CPU oracle's
+    written-out forward): v_template (778,3), M (145,2334) = [posedirs ; shapedirs^T], the joint regressor folded into
+    J_template (16,3) + J_shapedirs (16,3,10) - formed in DOUBLE and rounded once, so that the floats do not depend on the
+    host's BLAS -, lbs weights (778,16), the first 16 PCA components (16,45), the mean pose (45), parents (16) int32."""
+    vt = np.asarray(model_np["v_template"], np.float32)
+    assert vt.shape == (778, 3)
+    sd = np.asarray(model_np["shapedirs"], np.float32)              # (778,3,10)
+    pd = np.asarray(model_np["posedirs"], np.float32)               # (135, 2334)
+    M = np.concatenate([pd, sd.reshape(778 * 3, 10).T], 0)          # (145, 2334)
+    jr = np.asarray(model_np["J_regressor"], np.float64)            # (16,778)
+    J_t = (jr @ vt.astype(np.float64)).astype(np.float32)           # (16,3)
+    J_s = np.einsum("jv,vcl->jcl", jr, sd.astype(np.float64)).astype(np.float32)      # (16,3,10)
+    hm = np.asarray(model_np["hand_mean"], np.float32)
+    hand_mean = np.zeros_like(hm) if flat_hand_mean else hm
+    host = [vt, M, J_t, J_s, np.asarray(model_np["lbs_weights"], np.float32),
+            np.asarray(model_np["hand_components"][:16], np.float32), hand_mean, np.asarray(model_np["parents"], np.int32)]
+    return [np.ascontiguousarray(a) for a in host]
+
+
 def mirrored(model):
     """The other hand of a MANO-shaped model: every geometric quantity reflected in y (the lateral axis of the synthetic
     hand), face windings reversed so that normals stay outward; pose basis and mean pose kept.  Stands in for

@@ -489,21 +489,8 @@ class ManoContext:
     def __init__(self, model_np, device, num_pca_comps=16, flat_hand_mean=False):
         import ctypes
         assert num_pca_comps == 16, "the reference builds ManoModel(pca_comps=16) (homan/homan.py:70)"
-        vt = np.asarray(model_np["v_template"], np.float32)
-        assert vt.shape == (778, 3)
-        sd = np.asarray(model_np["shapedirs"], np.float32)              # (778,3,10)
-        pd = np.asarray(model_np["posedirs"], np.float32)               # (135, 2334)
-        M = np.concatenate([pd, sd.reshape(778 * 3, 10).T], 0)          # (145, 2334)
-        jr = np.asarray(model_np["J_regressor"], np.float32)            # (16,778)
-        J_t = jr @ vt                                                   # (16,3)
-        J_s = np.einsum("jv,vcl->jcl", jr, sd)                          # (16,3,10)
-        hm = np.asarray(model_np["hand_mean"], np.float32)
-        hand_mean = np.zeros_like(hm) if flat_hand_mean else hm
-        host = [vt, M, J_t.astype(np.float32), J_s.astype(np.float32),
-                np.asarray(model_np["lbs_weights"], np.float32),
-                np.asarray(model_np["hand_components"][:16], np.float32), hand_mean]
-        self.tensors = [torch.from_numpy(np.ascontiguousarray(a)).to(device) for a in host]
-        self.tensors.append(torch.from_numpy(np.asarray(model_np["parents"], np.int32)).to(device))
+        from .mano_assets import kernel_layout
+        self.tensors = [torch.from_numpy(a).to(device) for a in kernel_layout(model_np, flat_hand_mean)]
         self.ptrs = (ctypes.c_void_p * 8)(*[t.data_ptr() for t in self.tensors])
         self.device = device
         self._ws = {}

@@ -14,7 +14,7 @@ _lib = None
 
 
 def build(force=False):
-    srcs = [os.path.join(_HERE, "csrc", f) for f in ("nmr_raster.c", "sdf.c", "objchain.c")]
+    srcs = [os.path.join(_HERE, "csrc", f) for f in ("nmr_raster.c", "sdf.c", "objchain.c", "lbs_exact.c")]
     stale = (not os.path.exists(_SO)) or any(
         os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs if os.path.exists(s))
     if force or stale:
@@ -47,6 +47,17 @@ def lib():
         _lib.orc_rigid_bwd_sil_exact.argtypes = [fp, fp, cf, ci, vp, fp, ci, dp, ip, ip, fp, fp, cf, ci, ci, ci, ci, fp, fp,
                                                  fp, fp]
         _lib.orc_rigid_bwd_sil_exact.restype = None
+        _lib.orc_mano_forward.argtypes = [fp, fp, fp, fp, fp, fp, fp, ip, fp, ci, fp, fp, ci, fp]
+        _lib.orc_mano_forward.restype = None
+        _lib.orc_hand_chain.argtypes = [fp, fp, fp, fp, fp, fp, fp, ip, fp, ci, fp, fp, fp, fp, cf, vp, fp, ci, fp, ci, cf, fp, cf, ci,
+                                        fp, fp, fp, fp, fp, fp]
+        _lib.orc_hand_chain.restype = None
+        _lib.orc_v2d_unit_grad.argtypes = [fp, fp, fp, cf, ci, ci, fp]
+        _lib.orc_v2d_unit_grad.restype = None
+        _lib.orc_inter_rec.argtypes = [fp, fp, fp, ci, ci, ci, cf, cf, ci, fp]
+        _lib.orc_inter_rec.restype = None
+        _lib.orc_sincos.argtypes = [cf, fp, fp]
+        _lib.orc_sincos.restype = None
         _lib.orc_sum_magic.argtypes = [ci]
         _lib.orc_sum_magic.restype = ctypes.c_double
     return _lib

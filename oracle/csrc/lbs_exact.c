@@ -1,0 +1,501 @@
+/*
+ * oracle/csrc/lbs_exact.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * The MANO layer's forward (pose from PCA coefficients, Rodrigues, shape / pose blend shapes, joint regression, kinematic
+ * chain, rest-pose removal, linear blend skinning: the published smplx / MANO algorithm that oracle/lbs.py restates with
+ * torch) written out operation by operation in ONE evaluation order, so that the hand's vertices are a defined function of
+ * the parameters - the order csrc/mano.hip uses, hence bit-equal with the HIP kernels.  Same mathematics as oracle/lbs.py
+ * (tests/test_objchain.py: within fp32 rounding of it); what fp32 leaves open is fixed as follows:
+ *   - every sum runs sequentially from 0 in ascending index (PCA 16 terms, shape 10, skinning 16 joints); the 145 blend rows
+ *     as four partial sums of 37 rows, combined as (p0 + p1) + (p2 + p3), then added to the template;
+ *   - the joint regressor is folded into J_template (16,3) + J_shapedirs (16,3,10) (formed in double, rounded once);
+ *   - sin / cos by oc_sincos below (argument reduction + fdlibm kernel polynomials in double, rounded to fp32);
+ *   - 3x3 / 3-vector products left to right, no fused multiply-add (build with -ffp-contract=off).
+ * Reference call sites of the layer: homan/manomodel.py:84-151; homan/homan.py:341-358.
+ */
+#include <math.h>
+#include <stdint.h>
+
+#define NV 778
+#define NJ 16
+#define NF 145
+#define ROWS_PER_PART 37
+
+static void oc_sincos(float af, float *sn, float *cs)
+{
+    const double a = (double)af;
+    const double k = rint(a * 0.63661977236758138243);
+    double r = a - k * 1.57079632673412561417e+00;
+    r = r - k * 6.07710050650619224932e-11;
+    const double z = r * r;
+    double ps = 1.58969099521155010221e-10;
+    ps = -2.50507602534068634195e-08 + z * ps;
+    ps = 2.75573137070700676789e-06 + z * ps;
+    ps = -1.98412698298579493134e-04 + z * ps;
+    ps = 8.33333333332248946124e-03 + z * ps;
+    ps = -1.66666666666666324348e-01 + z * ps;
+    const double s = r + (r * z) * ps;
+    double pc = -1.13596475577881948265e-11;
+    pc = 2.08757232129817482790e-09 + z * pc;
+    pc = -2.75573143513906633035e-07 + z * pc;
+    pc = 2.48015872894767294178e-05 + z * pc;
+    pc = -1.38888888888741095749e-03 + z * pc;
+    pc = 4.16666666666666019037e-02 + z * pc;
+    const double c = (1.0 - 0.5 * z) + (z * z) * pc;
+    const int q = (int)((long long)k) & 3;
+    const double sv = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
+    const double cv = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
+    *sn = (float)sv;
+    *cs = (float)cv;
+}
+void orc_sincos(float a, float *sn, float *cs) { oc_sincos(a, sn, cs); }
+
+static void oc_rodrigues(const float *r, float *R)
+{
+    const float e0 = r[0] + 1e-8f, e1 = r[1] + 1e-8f, e2 = r[2] + 1e-8f;
+    const float a = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+    const float nx = r[0] / a, ny = r[1] / a, nz = r[2] / a;
+    float s, cs_;
+    oc_sincos(a, &s, &cs_);
+    const float c1 = 1.0f - cs_;
+    const float K[9] = {0.f, -nz, ny, nz, 0.f, -nx, -ny, nx, 0.f};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float kk = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+            R[3 * i + j] = (i == j ? 1.0f : 0.0f) + s * K[3 * i + j] + c1 * kk;
+        }
+}
+
+/* chain state of one frame: what csrc/mano.hip keeps in ManoShared */
+typedef struct {
+    float pose[48], Rl[NJ][9], J[NJ][3], Rw[NJ][9], tw[NJ][3], A[NJ][12], feat[NF];
+    int depth[NJ], maxd;
+} OcManoState;
+
+typedef struct {
+    const float *v_template, *M, *J_template, *J_shapedirs, *weights, *comps, *hand_mean;
+    const int32_t *parents;
+} OcManoModel;
+
+static void oc_mano_prepare(const OcManoModel *m, const float *pca, int pca_stride, const float *rot, const float *betas, int b,
+                            OcManoState *st)
+{
+    const int32_t *parents = m->parents;
+    for (int t = 0; t < 48; ++t) {
+        float v;
+        if (t < 3) v = rot[b * 3 + t];
+        else {
+            const int k = t - 3;
+            v = 0.f;
+            for (int i = 0; i < 16; ++i) v += pca[(long)b * pca_stride + i] * m->comps[i * 45 + k];
+            v += m->hand_mean[k];
+        }
+        st->pose[t] = v;
+    }
+    for (int t = 0; t < 10; ++t) st->feat[135 + t] = betas[b * 10 + t];
+    int maxd = 0;
+    for (int t = 0; t < NJ; ++t) {
+        int d = 0;
+        for (int q = parents[t]; q >= 0; q = parents[q]) ++d;
+        st->depth[t] = d;
+        if (d > maxd) maxd = d;
+        float R[9];
+        oc_rodrigues(&st->pose[3 * t], R);
+        for (int k = 0; k < 9; ++k) st->Rl[t][k] = R[k];
+        if (t >= 1)
+            for (int k = 0; k < 9; ++k) st->feat[9 * (t - 1) + k] = R[k] - ((k % 4 == 0) ? 1.0f : 0.0f);
+        for (int c = 0; c < 3; ++c) {
+            float v = m->J_template[t * 3 + c];
+            for (int l = 0; l < 10; ++l) v += betas[b * 10 + l] * m->J_shapedirs[(t * 3 + c) * 10 + l];
+            st->J[t][c] = v;
+        }
+    }
+    st->maxd = maxd;
+    for (int level = 0; level <= maxd; ++level)
+        for (int j = 0; j < NJ; ++j) {
+            if (st->depth[j] != level) continue;
+            const int p = parents[j];
+            if (p < 0) {
+                for (int k = 0; k < 9; ++k) st->Rw[j][k] = st->Rl[j][k];
+                for (int c = 0; c < 3; ++c) st->tw[j][c] = st->J[j][c];
+            } else {
+                const float rel[3] = {st->J[j][0] - st->J[p][0], st->J[j][1] - st->J[p][1], st->J[j][2] - st->J[p][2]};
+                for (int i = 0; i < 3; ++i) {
+                    for (int k = 0; k < 3; ++k)
+                        st->Rw[j][3 * i + k] = st->Rw[p][3 * i] * st->Rl[j][k] + st->Rw[p][3 * i + 1] * st->Rl[j][3 + k] +
+                                               st->Rw[p][3 * i + 2] * st->Rl[j][6 + k];
+                    st->tw[j][i] = st->Rw[p][3 * i] * rel[0] + st->Rw[p][3 * i + 1] * rel[1] + st->Rw[p][3 * i + 2] * rel[2] +
+                                   st->tw[p][i];
+                }
+            }
+        }
+    for (int j = 0; j < NJ; ++j)
+        for (int i = 0; i < 3; ++i) {
+            st->A[j][4 * i] = st->Rw[j][3 * i];
+            st->A[j][4 * i + 1] = st->Rw[j][3 * i + 1];
+            st->A[j][4 * i + 2] = st->Rw[j][3 * i + 2];
+            st->A[j][4 * i + 3] = st->tw[j][i] - (st->Rw[j][3 * i] * st->J[j][0] + st->Rw[j][3 * i + 1] * st->J[j][1] +
+                                                  st->Rw[j][3 * i + 2] * st->J[j][2]);
+        }
+}
+
+/* blended rest-pose vertex v (template + shape / pose blend shapes) */
+static void oc_mano_vp(const OcManoModel *m, const OcManoState *st, int v, float *vp)
+{
+    for (int c = 0; c < 3; ++c) {
+        float part[4];
+        for (int w = 0; w < 4; ++w) {
+            const int k0 = w * ROWS_PER_PART, k1 = (k0 + ROWS_PER_PART < NF) ? k0 + ROWS_PER_PART : NF;
+            float a = 0.f;
+            for (int k = k0; k < k1; ++k) a += st->feat[k] * m->M[(long)k * (3 * NV) + 3 * v + c];
+            part[w] = a;
+        }
+        vp[c] = m->v_template[3 * v + c] + ((part[0] + part[1]) + (part[2] + part[3]));
+    }
+}
+
+static void oc_mano_skin(const OcManoModel *m, const OcManoState *st, int v, float *T)
+{
+    for (int k = 0; k < 12; ++k) T[k] = 0.f;
+    for (int j = 0; j < NJ; ++j)
+        for (int k = 0; k < 12; ++k) T[k] += m->weights[v * NJ + j] * st->A[j][k];
+}
+
+/*
+ * pca (B, pca_stride) [first 16 columns used], rot (B,3), betas (B,10) -> verts (B,778,3) WITHOUT the model-space translation
+ * (the caller adds mano_trans: the kernel's last addition).  Model arrays in the kernel's layout (homan_amd.mano_assets.
+ * kernel_layout): v_template (778,3), M (145,2334) = [posedirs ; shapedirs^T], J_template (16,3), J_shapedirs (16,3,10),
+ * weights (778,16), comps (16,45), hand_mean (45), parents (16).
+ */
+void orc_mano_forward(const float *v_template, const float *M, const float *J_template, const float *J_shapedirs,
+                      const float *weights, const float *comps, const float *hand_mean, const int32_t *parents,
+                      const float *pca, int pca_stride, const float *rot, const float *betas, int B, float *verts)
+{
+    const OcManoModel m = {v_template, M, J_template, J_shapedirs, weights, comps, hand_mean, parents};
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        OcManoState st;
+        oc_mano_prepare(&m, pca, pca_stride, rot, betas, b, &st);
+        for (int v = 0; v < NV; ++v) {
+            float vp[3], T[12];
+            oc_mano_vp(&m, &st, v, vp);
+            oc_mano_skin(&m, &st, v, T);
+            float *o = verts + ((long)b * NV + v) * 3;
+            for (int i = 0; i < 3; ++i) o[i] = T[4 * i] * vp[0] + T[4 * i + 1] * vp[1] + T[4 * i + 2] * vp[2] + T[4 * i + 3];
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * The HAND's gradient chain of one optimisation step, written out in the evaluation order of csrc/mano.hip's backward
+ * (k_mano_bwd<RIGID> + mano_bwd2_body): the same mathematics as autograd through oracle/lbs.py and transform_persp (reference
+ * homan/homan.py:341-382, manomodel.py:84-151), with every reduction in ONE stated order:
+ *   - vertices in 13 chunks of 64; inside a chunk a sum over the vertices is either sequential (the 16 x 12 skinning sums) or the
+ *     six-step pairwise tree of oc_wave_sum (DPP tree of hm_wave_sum: quads, rows of 16, rows 0-1 / 2-3, halves);
+ *   - the chunk results are added sequentially, chunk 0 first;
+ *   - kinematic chain leaves first, a parent collecting its children in ascending joint index.
+ * ---------------------------------------------------------------------------------------------------------------------- */
+void oc_rot6d_to_mat(const float *r6, float *R);                 /* objchain.c */
+void oc_rot6d_backward(const float *r6, const float *dR, float *dr6);
+
+static float oc_wave_sum(const float *a)      /* 64 values -> the value hm_wave_sum leaves in lane 63 */
+{
+    float R[4];
+    for (int r = 0; r < 4; ++r) {
+        float Q[4];
+        for (int q = 0; q < 4; ++q) {
+            const float *x = a + 16 * r + 4 * q;
+            Q[q] = (x[3] + x[2]) + (x[1] + x[0]);
+        }
+        R[r] = (Q[3] + Q[2]) + (Q[1] + Q[0]);
+    }
+    return (R[3] + R[2]) + (R[1] + R[0]);
+}
+/* hm_block_sum over a 256-thread workgroup whose waves 1..3 hold zeros */
+static float oc_block_sum64(const float *a)
+{
+    const float z[64] = {0.f};
+    float t = 0.f;
+    t += oc_wave_sum(a);
+    for (int w = 1; w < 4; ++w) t += oc_wave_sum(z);
+    return t;
+}
+
+static void oc_rodrigues_backward(const float *r, const float *dR, float *dr)
+{
+    const float e[3] = {r[0] + 1e-8f, r[1] + 1e-8f, r[2] + 1e-8f};
+    const float a = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+    const float n[3] = {r[0] / a, r[1] / a, r[2] / a};
+    float s, c;
+    oc_sincos(a, &s, &c);
+    const float c1 = 1.0f - c;
+    const float K[9] = {0.f, -n[2], n[1], n[2], 0.f, -n[0], -n[1], n[0], 0.f};
+    float KK[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) KK[3 * i + j] = K[3 * i] * K[j] + K[3 * i + 1] * K[3 + j] + K[3 * i + 2] * K[6 + j];
+    float dRK = 0.f, dRKK = 0.f;
+    for (int k = 0; k < 9; ++k) { dRK += dR[k] * K[k]; dRKK += dR[k] * KK[k]; }
+    float da = c * dRK + s * dRKK;
+    float dK[9];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float t1 = dR[3 * i] * K[3 * j] + dR[3 * i + 1] * K[3 * j + 1] + dR[3 * i + 2] * K[3 * j + 2];
+            float t2 = K[i] * dR[j] + K[3 + i] * dR[3 + j] + K[6 + i] * dR[6 + j];
+            dK[3 * i + j] = s * dR[3 * i + j] + c1 * (t1 + t2);
+        }
+    const float dn[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+    da += -(dn[0] * r[0] + dn[1] * r[1] + dn[2] * r[2]) / (a * a);
+    for (int i = 0; i < 3; ++i) dr[i] = dn[i] / a + da * e[i] / a;
+}
+
+#define NCH 13
+#define PART 352
+/*
+ * mesh (B,778,3): the forward's model-space vertices (LBS + mano_trans); rot6d (B,6), scale: the hand's rigid pose;
+ * terms[k] (B,778,3) with weights tw[k]: gradient terms on the camera-space vertices (they reach the mesh and the rigid pose);
+ * g_frame (B, frame_stride) or NULL: one vector per frame, times frame_scale, that reaches the rigid pose only;
+ * g_pca_extra (B, pca_stride) or NULL, times w_extra: added to the PCA gradient (the prior's unit gradient).
+ * -> g_pca (B,pca_stride), g_rot (B,3), g_betas (B,10), g_trans (B,3) [MANO], g_rot6d (B,6), g_rtrans (B,3) [rigid]
+ */
+void orc_hand_chain(const float *v_template, const float *M, const float *J_template, const float *J_shapedirs,
+                    const float *weights, const float *comps, const float *hand_mean, const int32_t *parents,
+                    const float *pca, int pca_stride, const float *rot, const float *betas, const float *mesh,
+                    const float *rot6d, float scale, const float *const *terms, const float *tw, int n_terms,
+                    const float *g_frame, int frame_stride, float frame_scale, const float *g_pca_extra, float w_extra, int B,
+                    float *g_pca, float *g_rot, float *g_betas, float *g_trans, float *g_rot6d, float *g_rtrans)
+{
+    const OcManoModel m = {v_template, M, J_template, J_shapedirs, weights, comps, hand_mean, parents};
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        OcManoState st;
+        oc_mano_prepare(&m, pca, pca_stride, rot, betas, b, &st);
+        float R[9];
+        oc_rot6d_to_mat(rot6d + (long)b * 6, R);
+        const float s = scale;
+        static const float zero64[64] = {0.f};
+        float tot[PART];
+        float part[NCH][PART];
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int v0 = ch * 64, nv = (NV - v0 < 64) ? NV - v0 : 64;
+            float racc[12][64], g[3][64], s_g[64][3], s_vp[64][3], s_dvp[192], s_w[64][NJ];
+            for (int k = 0; k < 12; ++k) for (int t = 0; t < 64; ++t) racc[k][t] = 0.f;
+            for (int c = 0; c < 3; ++c) for (int t = 0; t < 64; ++t) g[c][t] = 0.f;
+            for (int t = 0; t < 192; ++t) s_dvp[t] = 0.f;
+            for (int t = 0; t < nv; ++t) {
+                const int v = v0 + t;
+                const long o = ((long)b * NV + v) * 3;
+                const float mv[3] = {mesh[o], mesh[o + 1], mesh[o + 2]};
+                float gf[3] = {0.f, 0.f, 0.f}, gt[3];
+                for (int k = 0; k < n_terms; ++k) {
+                    gf[0] += tw[k] * terms[k][o]; gf[1] += tw[k] * terms[k][o + 1]; gf[2] += tw[k] * terms[k][o + 2];
+                }
+                for (int c = 0; c < 3; ++c)
+                    gt[c] = gf[c] + (g_frame ? frame_scale * g_frame[(long)b * frame_stride + c] : 0.f);
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) racc[3 * i + j][t] = (s * mv[i]) * gt[j];
+                for (int j = 0; j < 3; ++j) racc[9 + j][t] = gt[j];
+                g[0][t] = s * (R[0] * gf[0] + R[1] * gf[1] + R[2] * gf[2]);
+                g[1][t] = s * (R[3] * gf[0] + R[4] * gf[1] + R[5] * gf[2]);
+                g[2][t] = s * (R[6] * gf[0] + R[7] * gf[1] + R[8] * gf[2]);
+                float T[12];
+                oc_mano_skin(&m, &st, v, T);
+                oc_mano_vp(&m, &st, v, s_vp[t]);
+                for (int c = 0; c < 3; ++c) {
+                    s_g[t][c] = g[c][t];
+                    s_dvp[3 * t + c] = T[c] * g[0][t] + T[4 + c] * g[1][t] + T[8 + c] * g[2][t];
+                }
+                for (int j = 0; j < NJ; ++j) s_w[t][j] = weights[v * NJ + j];
+            }
+            float *out = part[ch];
+            for (int k = 0; k < 12; ++k) out[340 + k] = oc_block_sum64(racc[k]);
+            for (int c = 0; c < 3; ++c) out[337 + c] = oc_block_sum64(g[c]);
+            for (int t = 0; t < 192; ++t) {
+                const int j = t / 12, r = (t % 12) / 4, c = t % 4;
+                float acc = 0.f;
+                for (int i = 0; i < nv; ++i) acc += s_w[i][j] * s_g[i][r] * (c < 3 ? s_vp[i][c] : 1.0f);
+                out[t] = acc;
+            }
+            const int ne = 3 * nv;
+            for (int k = 0; k < NF; ++k) {
+                const float *row = M + (long)k * (3 * NV) + 3 * v0;
+                float acc[64];
+                for (int lane = 0; lane < 64; ++lane) {
+                    const float r0 = lane < ne ? row[lane] : 0.f, r1 = lane + 64 < ne ? row[lane + 64] : 0.f;
+                    const float r2 = lane + 128 < ne ? row[lane + 128] : 0.f;
+                    const float d0 = lane < ne ? s_dvp[lane] : 0.f, d1 = lane + 64 < ne ? s_dvp[lane + 64] : 0.f;
+                    const float d2 = lane + 128 < ne ? s_dvp[lane + 128] : 0.f;
+                    float a = r0 * d0;
+                    a += r1 * d1;
+                    a += r2 * d2;
+                    acc[lane] = a;
+                }
+                out[192 + k] = oc_wave_sum(acc);
+            }
+            (void)zero64;
+        }
+        for (int k = 0; k < PART; ++k) {
+            float a = 0.f;
+            for (int c = 0; c < NCH; ++c) a += part[c][k];
+            tot[k] = a;
+        }
+        /* second half: chain / Rodrigues / PCA backward */
+        float dRw[NJ][9], dtw[NJ][3], dJ[NJ][3], dRl[NJ][9], dpose[48], cR[NJ][9], ct[NJ][3], cJ[NJ][3];
+        for (int j = 0; j < NJ; ++j) {
+            const float *dA = &tot[j * 12];
+            for (int i = 0; i < 3; ++i) {
+                for (int k = 0; k < 3; ++k) dRw[j][3 * i + k] = dA[4 * i + k] - dA[4 * i + 3] * st.J[j][k];
+                dtw[j][i] = dA[4 * i + 3];
+            }
+            for (int k = 0; k < 3; ++k)
+                dJ[j][k] = -(st.Rw[j][k] * dA[3] + st.Rw[j][3 + k] * dA[7] + st.Rw[j][6 + k] * dA[11]);
+        }
+        for (int level = st.maxd; level >= 1; --level) {
+            for (int j = 0; j < NJ; ++j) {
+                if (st.depth[j] != level) continue;
+                const int p = parents[j];
+                const float rel[3] = {st.J[j][0] - st.J[p][0], st.J[j][1] - st.J[p][1], st.J[j][2] - st.J[p][2]};
+                for (int i = 0; i < 3; ++i) {
+                    for (int k = 0; k < 3; ++k)
+                        cR[j][3 * i + k] = dtw[j][i] * rel[k] + dRw[j][3 * i] * st.Rl[j][3 * k] +
+                                           dRw[j][3 * i + 1] * st.Rl[j][3 * k + 1] + dRw[j][3 * i + 2] * st.Rl[j][3 * k + 2];
+                    ct[j][i] = dtw[j][i];
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const float d = st.Rw[p][k] * dtw[j][0] + st.Rw[p][3 + k] * dtw[j][1] + st.Rw[p][6 + k] * dtw[j][2];
+                    dJ[j][k] += d;
+                    cJ[j][k] = -d;
+                }
+                for (int i = 0; i < 3; ++i)
+                    for (int k = 0; k < 3; ++k)
+                        dRl[j][3 * i + k] = st.Rw[p][i] * dRw[j][k] + st.Rw[p][3 + i] * dRw[j][3 + k] + st.Rw[p][6 + i] * dRw[j][6 + k];
+            }
+            for (int t = 0; t < NJ; ++t) {
+                if (st.depth[t] != level - 1) continue;
+                for (int j = 0; j < NJ; ++j)
+                    if (parents[j] == t) {
+                        for (int k = 0; k < 9; ++k) dRw[t][k] += cR[j][k];
+                        for (int k = 0; k < 3; ++k) { dtw[t][k] += ct[j][k]; dJ[t][k] += cJ[j][k]; }
+                    }
+            }
+        }
+        for (int t = 0; t < NJ; ++t)
+            if (parents[t] < 0) {
+                for (int k = 0; k < 9; ++k) dRl[t][k] = dRw[t][k];
+                for (int c = 0; c < 3; ++c) dJ[t][c] += dtw[t][c];
+            }
+        for (int t = 0; t < NJ; ++t) {
+            float dR[9], dr[3];
+            for (int k = 0; k < 9; ++k) dR[k] = dRl[t][k] + (t >= 1 ? tot[192 + 9 * (t - 1) + k] : 0.f);
+            oc_rodrigues_backward(&st.pose[3 * t], dR, dr);
+            for (int c = 0; c < 3; ++c) dpose[3 * t + c] = dr[c];
+        }
+        for (int t = 0; t < 3; ++t) {
+            g_rot[b * 3 + t] = dpose[t];
+            g_trans[b * 3 + t] = tot[337 + t];
+        }
+        for (int i = 0; i < pca_stride; ++i) {
+            float a = 0.f;
+            if (i < 16)
+                for (int k = 0; k < 45; ++k) a += comps[i * 45 + k] * dpose[3 + k];
+            if (g_pca_extra) a += w_extra * g_pca_extra[(long)b * pca_stride + i];
+            g_pca[(long)b * pca_stride + i] = a;
+        }
+        for (int t = 0; t < 10; ++t) {
+            float a = tot[192 + 135 + t];
+            for (int q = 0; q < NJ * 3; ++q) a += J_shapedirs[q * 10 + t] * dJ[q / 3][q % 3];
+            g_betas[b * 10 + t] = a;
+        }
+        float dr6[6];
+        oc_rot6d_backward(rot6d + (long)b * 6, &tot[340], dr6);
+        for (int k = 0; k < 6; ++k) g_rot6d[(long)b * 6 + k] = dr6[k];
+        for (int k = 0; k < 3; ++k) g_rtrans[(long)b * 3 + k] = tot[349 + k];
+    }
+}
+
+/* 2-D reprojection term's unit gradient on the camera-space hand vertices (reference homan/losses.py:141-164; csrc/pair_bodies.h
+ * hand_terms_body): element-wise.  verts (N,V,3), K (N,3,3), ref2d (N,V,2) -> unit (N,V,3) */
+void orc_v2d_unit_grad(const float *verts, const float *camintr, const float *ref2d, float image_size, int N, int V, float *unit)
+{
+    const long total = (long)N * V;
+    const float inv_cnt = 1.0f / (float)total;
+    for (long i = 0; i < total; ++i) {
+        const float *k = camintr + (i / V) * 9;
+        const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+        const float hx = k[0] * x + k[1] * y + k[2] * z;
+        const float hy = k[3] * x + k[4] * y + k[5] * z;
+        const float hz = k[6] * x + k[7] * y + k[8] * z;
+        const float px = hx / hz, py = hy / hz;
+        const float rx = ref2d[2 * i], ry = ref2d[2 * i + 1];
+        const float dx = px - rx / image_size, dy = py - ry / image_size;
+        const float gpx = 2.0f * dx * inv_cnt, gpy = 2.0f * dy * inv_cnt;
+        const float ghx = gpx / hz, ghy = gpy / hz, ghz = -(gpx * hx + gpy * hy) / (hz * hz);
+        unit[3 * i] = k[0] * ghx + k[3] * ghy + k[6] * ghz;
+        unit[3 * i + 1] = k[1] * ghx + k[4] * ghy + k[7] * ghz;
+        unit[3 * i + 2] = k[2] * ghx + k[5] * ghy + k[8] * ghz;
+    }
+}
+
+/* Coarse interaction term (reference homan/losses.py:199-242, utils/bbox.py:111-135, utils/geometry.py:69-86; csrc/pair_bodies.h
+ * inter_body): per frame {gate, centroid MSE, gate * 2 (c_hand - c_obj) / 3}.  The centroid sums: `nthreads` strided partial sums
+ * (thread t takes vertices t, t + nthreads, ...), 64 at a time through oc_wave_sum, the wave results added in wave order.
+ * vh (B,Vh,3), vo (B,Vo,3), K (B,3,3) -> rec (B,8) [0]=gate [1]=mse [2..4]=vector */
+void orc_inter_rec(const float *vh, const float *vo, const float *camintr, int B, int Vh, int Vo, float expansion, float zthresh,
+                   int nthreads, float *rec)
+{
+    for (int b = 0; b < B; ++b) {
+        const float *k = camintr + b * 9;
+        float box[2][4], zr[2][2], cen[2][3];
+        for (int which = 0; which < 2; ++which) {
+            const float *v = which == 0 ? vo + (long)b * Vo * 3 : vh + (long)b * Vh * 3;
+            const int V = which == 0 ? Vo : Vh;
+            float umin = 3.4e38f, umax = -3.4e38f, vmin = 3.4e38f, vmax = -3.4e38f, zmin = 3.4e38f, zmax = -3.4e38f;
+            float sx[1024], sy[1024], sz[1024];
+            for (int t = 0; t < nthreads; ++t) {
+                float ax = 0.f, ay = 0.f, az = 0.f;
+                for (int i = t; i < V; i += nthreads) {
+                    const float x = v[3 * i], y = v[3 * i + 1], z = v[3 * i + 2];
+                    const float zz = z + 1e-9f;
+                    const float xn = x / zz, yn = (y * -1.0f) / zz;
+                    float u = xn * k[0] + yn * k[1];
+                    u = u + k[2];
+                    float w = xn * k[3] + yn * k[4];
+                    w = w + k[5];
+                    w = 1.0f - w;
+                    u = 2.0f * (u - 0.5f);
+                    w = 2.0f * (w - 0.5f);
+                    umin = fminf(umin, u); umax = fmaxf(umax, u);
+                    vmin = fminf(vmin, w); vmax = fmaxf(vmax, w);
+                    zmin = fminf(zmin, z); zmax = fmaxf(zmax, z);
+                    ax += x; ay += y; az += z;
+                }
+                sx[t] = ax; sy[t] = ay; sz[t] = az;
+            }
+            float t9[9] = {umin, umax, vmin, vmax, zmin, zmax, 0.f, 0.f, 0.f};
+            for (int w = 0; w < nthreads / 64; ++w) {
+                t9[6] = t9[6] + oc_wave_sum(sx + 64 * w);
+                t9[7] = t9[7] + oc_wave_sum(sy + 64 * w);
+                t9[8] = t9[8] + oc_wave_sum(sz + 64 * w);
+            }
+            const float cx = (t9[0] + t9[1]) / 2.0f, cy = (t9[2] + t9[3]) / 2.0f;
+            const float ex = (t9[1] - t9[0]) / 2.0f * (1.0f + expansion), ey = (t9[3] - t9[2]) / 2.0f * (1.0f + expansion);
+            box[which][0] = cx - ex; box[which][1] = cy - ey; box[which][2] = cx + ex; box[which][3] = cy + ey;
+            zr[which][0] = t9[4]; zr[which][1] = t9[5];
+            cen[which][0] = t9[6] / (float)V; cen[which][1] = t9[7] / (float)V; cen[which][2] = t9[8] / (float)V;
+        }
+        const float a1 = (box[0][2] - box[0][0]) * (box[0][3] - box[0][1]);
+        const float a2 = (box[1][2] - box[1][0]) * (box[1][3] - box[1][1]);
+        const float w = fmaxf(fminf(box[0][2], box[1][2]) - fmaxf(box[0][0], box[1][0]), 0.f);
+        const float h = fmaxf(fminf(box[0][3], box[1][3]) - fmaxf(box[0][1], box[1][1]), 0.f);
+        const float inter = w * h;
+        const float iou = inter / (a1 + a2 - inter);
+        const float a = zr[0][0], bb = zr[0][1], c = zr[1][0], d = zr[1][1];
+        const float zd = (d >= a && bb >= c) ? 0.f : fminf(fabsf(c - bb), fabsf(a - d));
+        const float flag = ((iou > 0.f) && (zd < zthresh)) ? 1.f : 0.f;
+        const float dx = cen[1][0] - cen[0][0], dy = cen[1][1] - cen[0][1], dz = cen[1][2] - cen[0][2];
+        float *r = rec + b * 8;
+        r[0] = flag;
+        r[1] = (dx * dx + dy * dy + dz * dz) / 3.0f;
+        r[2] = flag * 2.0f * dx / 3.0f; r[3] = flag * 2.0f * dy / 3.0f; r[4] = flag * 2.0f * dz / 3.0f;
+        r[5] = r[6] = r[7] = 0.f;
+    }
+}

@@ -167,7 +167,7 @@ void orc_nmr_grad_faces_alpha_exact(const float *faces, const int32_t *idx_map, 
 }
 
 /* rot6d (3x2 row-major) -> R (3x3 row-major), reference homan/utils/geometry.py:9-27, order of oracle/model.py rot6d_to_matrix */
-static void oc_rot6d_to_mat(const float *r6, float *R)
+void oc_rot6d_to_mat(const float *r6, float *R)
 {
     const float a1[3] = {r6[0], r6[2], r6[4]}, a2[3] = {r6[1], r6[3], r6[5]};
     const float n1 = fmaxf(sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]), 1e-12f);
@@ -181,7 +181,7 @@ static void oc_rot6d_to_mat(const float *r6, float *R)
 }
 
 /* dL/dR -> dL/drot6d: the chain rule through the Gram-Schmidt construction above, one fixed order of operations */
-static void oc_rot6d_backward(const float *r6, const float *dR, float *dr6)
+void oc_rot6d_backward(const float *r6, const float *dR, float *dr6)
 {
     const float a1[3] = {r6[0], r6[2], r6[4]}, a2[3] = {r6[1], r6[3], r6[5]};
     const float n1r = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);

@@ -28,9 +28,10 @@ def parameter_groups(model, lr):
 def reproducible_step(model, loss_weights, optimizer, log2q=0):
     """One iteration of the loop below with the parts fp32 leaves open pinned down (oracle/objchain.py, oracle/adam.py):
     forward + autograd as always, then the object's pose gradients REPLACED by the written-out chain with order-independent
-    sums (same mathematics, a defined rounding), then the written-out Adam (`optimizer` = oracle.adam.Adam).  The object's
-    trajectory is then a function of the inputs alone - the same for any number of host threads - and bit-equal to the HIP
-    loop's.  -> (loss_dict, metric_dict, total)."""
+    sums (same mathematics, a defined rounding) and - for the loss sets oracle/handchain.py covers - the hand's by ITS written-out
+    chain, then the written-out Adam (`optimizer` = oracle.adam.Adam).  The trajectory of those parameters is then a function of
+    the inputs alone - the same for any number of host threads - and bit-equal to the HIP loop's.
+    -> (loss_dict, metric_dict, total)."""
     from . import objchain
     optimizer.zero_grad()
     obj = (model.rotations_object, model.translations_object)
@@ -44,8 +45,14 @@ def reproducible_step(model, loss_weights, optimizer, log2q=0):
         for p in obj:
             p.requires_grad_(True)
     grads = objchain.object_pose_grads(model, loss_weights, log2q)
-    model.rotations_object.grad = torch.from_numpy(grads["rotations_object"]).reshape(model.rotations_object.shape)
-    model.translations_object.grad = torch.from_numpy(grads["translations_object"]).reshape(model.translations_object.shape)
+    try:        # the hand's chain in its written-out order too, where it covers the loss set (one hand, step-1 terms)
+        from . import handchain
+        grads.update(handchain.hand_param_grads(model, loss_weights))
+    except NotImplementedError:
+        pass    # (autograd's gradients stay: same mathematics, rounding left to torch)
+    for k, g in grads.items():
+        p = getattr(model, k)
+        p.grad = torch.from_numpy(g).reshape(p.shape)
     optimizer.step()
     return loss_dict, metric_dict, loss
 

@@ -60,6 +60,42 @@ def lbs(betas, full_pose, model):
     return verts, posed_joints
 
 
+class _WrittenOutVerts(torch.autograd.Function):
+    """Hand vertices (model space, before the translation) from (pca, rot, betas) in the written-out evaluation order of
+    oracle/csrc/lbs_exact.c - bit-equal with csrc/mano.hip - with the gradients of the torch restatement above at the same
+    inputs (same mathematics: the two forwards agree within fp32 rounding, tests/test_objchain.py)."""
+
+    @staticmethod
+    def forward(ctx, pca, rot, betas, layout, faithful_fn):
+        import numpy as np
+        from . import clib
+        B = pca.shape[0]
+        p = np.ascontiguousarray(pca.detach().numpy(), np.float32)
+        r = np.ascontiguousarray(rot.detach().numpy(), np.float32)
+        be = np.ascontiguousarray(betas.detach().numpy(), np.float32)
+        out = np.empty((B, 778, 3), np.float32)
+        vt, M, Jt, Js, w, comps, mean, parents = layout
+        clib.lib().orc_mano_forward(clib.fptr(vt), clib.fptr(M), clib.fptr(Jt), clib.fptr(Js), clib.fptr(w), clib.fptr(comps),
+                                    clib.fptr(mean), clib.iptr(parents), clib.fptr(p), p.shape[1], clib.fptr(r), clib.fptr(be),
+                                    B, clib.fptr(out))
+        ctx.save_for_backward(pca, rot, betas)
+        ctx.faithful_fn = faithful_fn
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        pca, rot, betas = ctx.saved_tensors
+        with torch.enable_grad():
+            ins = [t.detach().requires_grad_(True) for t in (pca, rot, betas)]
+            v = ctx.faithful_fn(*ins)
+            grads = torch.autograd.grad(v, ins, g, allow_unused=True)
+        return grads[0], grads[1], grads[2], None, None
+
+
+def written_out_verts(pca, rot, betas, layout, faithful_fn):
+    return _WrittenOutVerts.apply(pca, rot, betas, layout, faithful_fn)
+
+
 class ManoLayer(torch.nn.Module):
     """What `mano.model.load(...)` returns, as far as the reference uses it."""
 

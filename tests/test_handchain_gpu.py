@@ -1,0 +1,78 @@
+"""The hand's gradient chain, HIP fused step vs the CPU oracle's written-out chain (oracle/handchain.py): BIT-EQUAL gradients
+for every hand parameter at identical parameters, stage by stage (unit gradients of the 2-D and smoothness terms, the
+interaction term's per-frame records, then the six parameter gradients), and from there every parameter of a free-running fit.
+Reference: homan/homan.py:341-382, 421-508; homan/manomodel.py:84-151; loop homan/jointopt.py:158-192.  GPU box."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+HAND = ("mano_pca_pose", "mano_rot", "mano_betas", "mano_trans", "rotations_hand", "translations_hand")
+
+
+def _pair(mano_model, seed, frames, size, obj):
+    from homan_amd import HOMan, synth
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=size,
+                  mano_model=mano_model, rend_size=size)
+    return HOMan(**copy.deepcopy(kw), **common), OracleHOMan(**copy.deepcopy(kw), **common)
+
+
+@pytest.mark.parametrize("weights_name,obj", [("STEP1_LOSS_WEIGHTS", "bottle"), ("CFG1_LOSS_WEIGHTS", "cube")])
+def test_hand_gradients_bit_equal(weights_name, obj, mano_model):
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle import handchain
+    hm, om = _pair(mano_model, seed=11, frames=6, size=128, obj=obj)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():        # off the initial pose: non-zero shape / PCA coefficients / model-space translation
+        for name, amp in (("mano_betas", 0.3), ("mano_pca_pose", 0.2), ("mano_trans", 0.01), ("mano_rot", 0.05)):
+            d = amp * torch.randn(getattr(om, name).shape, generator=g)
+            getattr(om, name).add_(d)
+            getattr(hm, name).add_(d.to(getattr(hm, name).device))
+    lw = dict(getattr(synth, weights_name))
+    st = FusedStepper(hm, lw, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    want, stg = handchain.hand_param_grads(om, lw, return_stages=True)
+    assert np.array_equal(st.vh.cpu().numpy(), stg["vh"]) and np.array_equal(st.vm.cpu().numpy(), stg["mesh"])
+    assert np.array_equal(st.vo.cpu().numpy(), stg["vo"])
+    names = [n for n, on in (("U_smh", lw["lw_smooth_hand"] > 0 or lw["lw_smooth_obj"] > 0), ("U_v2d", lw["lw_v2d_hand"] > 0)) if on]
+    for n, (arr, _) in zip(names, stg["terms"]):
+        assert np.array_equal(getattr(st, n).cpu().numpy(), arr), n
+    if stg["rec"] is not None:
+        assert np.array_equal(st.rec.cpu().numpy()[:, [0, 2, 3, 4]], stg["rec"][:, [0, 2, 3, 4]])
+    report = {}
+    for k in HAND:
+        got = getattr(st.model, k).grad.cpu().numpy().reshape(want[k].shape)
+        report[k] = (bool(np.array_equal(got, want[k])), float(np.abs(got - want[k]).max() / max(np.abs(want[k]).max(), 1e-30)))
+    assert all(eq for eq, _ in report.values()), report
+
+
+def test_every_parameter_bit_equal_in_a_free_run(mano_model):
+    """30 free-running steps of the step-1 loss set (reference loop homan/jointopt.py:158-192): HIP fused loop vs the oracle's
+    reproducible loop (written-out object chain, hand chain and Adam) - EVERY parameter bit-equal after every step."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle.jointopt import make_optimizer, reproducible_step
+    hm, om = _pair(mano_model, seed=12, frames=6, size=128, obj="bottle")
+    lw = dict(synth.STEP1_LOSS_WEIGHTS)
+    st = FusedStepper(hm, lw, 1e-2, 30)
+    opt = make_optimizer(om, 1e-2, reproducible=True)
+    for i in range(30):
+        st.run(1)
+        reproducible_step(om, lw, opt)
+        torch.cuda.synchronize()
+        cpu = dict(om.named_parameters())
+        diff = [k for k, p in hm.named_parameters()
+                if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
+        assert not diff, (i, diff)

@@ -132,6 +132,17 @@ def test_two_hands_through_optimize_hand_object(mano_model):
                                          camintr=clip["camintr"], optimize_mano=True, image_size=64, mano_model=mano_model,
                                          rend_size=64)
     assert model.hand_nb == 2 and model.get_verts_hand()[0].shape == (8, 778, 3)
+    # right + left hands through their own side's model: vertices bit-equal with the oracle's written-out layer at the fitted
+    # parameters
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    om = OracleHOMan(**kw, camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=64,
+                     mano_model=mano_model, rend_size=64)
+    with torch.no_grad():
+        for k, p in om.named_parameters():
+            p.copy_(dict(model.named_parameters())[k].detach().cpu())
+    assert torch.equal(model.get_verts_hand()[0].detach().cpu(), om.get_verts_hand()[0].detach())
     np.testing.assert_allclose(evo["loss"][0], rec["evo_loss"][0], rtol=1e-4)
     np.testing.assert_allclose(evo["loss"][:3], rec["evo_loss"][:3], rtol=5e-3)
 
@@ -161,6 +172,9 @@ def test_hip_vs_oracle_cfg_sized_clip(mano_model):
     dv = (hm.get_verts_hand()[0].detach().cpu() - om.get_verts_hand()[0].detach()).abs().max().item()
     do = (hm.get_verts_object()[0].detach().cpu() - om.get_verts_object()[0].detach()).abs().max().item()
     assert dv < 1e-6 and do < 1e-6, (dv, do)     # metres
+    # ... and, since both sides evaluate ONE written-out operation order (oracle/csrc/lbs_exact.c <-> csrc/mano.hip for the MANO
+    # layer, oracle.model.transform_persp <-> the rigid kernels), bit for bit:
+    assert dv == 0.0 and do == 0.0, (dv, do)
     # hand silhouette term (reference losses.py:166-181, present but disabled upstream): value + NMR pseudo-gradient
     vo_h = om.get_verts_hand()[0].detach().requires_grad_(True)
     lo_h = om.losses.compute_sil_loss_hand(vo_h, om.faces_hand)["loss_sil_hand"]

@@ -44,6 +44,64 @@ def test_written_out_chain_equals_autograd(obj, mano_model):
         np.testing.assert_allclose(got[name].reshape(ref.shape) / scale, ref / scale, atol=2e-5, err_msg=name)
 
 
+@pytest.mark.parametrize("weights_name", ["STEP1_LOSS_WEIGHTS", "CFG1_LOSS_WEIGHTS"])
+def test_written_out_hand_chain_equals_autograd(weights_name, mano_model):
+    """oracle/handchain.py (2-D reprojection, smoothness, interaction, PCA prior -> rigid backward -> MANO backward, one stated
+    evaluation order) against autograd through the torch restatement of the same model: every hand parameter's gradient within
+    fp32 rounding of its largest entry."""
+    from homan_amd import synth
+    from oracle import handchain
+    model, _ = _clip_model(mano_model, seed=2, obj="bottle")
+    with torch.no_grad():           # off the initial pose: non-zero shape and PCA coefficients, a model-space translation
+        g = torch.Generator().manual_seed(0)
+        model.mano_betas.add_(0.3 * torch.randn(model.mano_betas.shape, generator=g))
+        model.mano_pca_pose.add_(0.2 * torch.randn(model.mano_pca_pose.shape, generator=g))
+        model.mano_trans.add_(0.01 * torch.randn(model.mano_trans.shape, generator=g))
+    lw = dict(getattr(synth, weights_name))
+    loss_dict, _ = model(loss_weights=lw)
+    sum(loss_dict[k] * lw[k.replace("loss", "lw")] for k in loss_dict).backward()
+    got = handchain.hand_param_grads(model, lw)
+    assert sorted(got) == ["mano_betas", "mano_pca_pose", "mano_rot", "mano_trans", "rotations_hand", "translations_hand"]
+    for name, g in got.items():
+        ref = getattr(model, name).grad.numpy()
+        scale = np.abs(ref).max()
+        assert scale > 0, name
+        np.testing.assert_allclose(g.reshape(ref.shape) / scale, ref / scale, atol=2e-5, err_msg=name)
+    with pytest.raises(NotImplementedError):
+        handchain.hand_param_grads(model, dict(synth.STEP2_LOSS_WEIGHTS))
+
+
+def test_written_out_mano_layer_equals_the_torch_restatement(mano_model):
+    """oracle/csrc/lbs_exact.c (the evaluation order shared with csrc/mano.hip) vs oracle/lbs.py (torch): the same vertices to
+    an ulp, right and left hands; and its sin / cos against libm in double."""
+    from oracle import clib
+    from oracle import model as o_model
+    from homan_amd import synth
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=4, frames=4, rend_size=64, image_size=64, obj="cube", silhouette_fn=sil_fn, hand_verts_fn=hand_fn,
+                           hands=("right", "left"))
+    from oracle.jointopt import collate_inputs
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    model = o_model.OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=64,
+                                mano_model=mano_model, rend_size=64, **kw)
+    with torch.no_grad():
+        model.mano_betas.add_(0.3 * torch.randn(model.mano_betas.shape, generator=torch.Generator().manual_seed(1)))
+        a = model.get_verts_hand()[0].numpy().copy()
+        o_model.REFERENCE_FORM = True
+        try:
+            b = model.get_verts_hand()[0].numpy().copy()
+        finally:
+            o_model.REFERENCE_FORM = False
+    assert np.abs(a - b).max() < 2.5e-7 and np.abs(a - b).max() > 0          # (two evaluation orders of fp32: not the same bits)
+    ang = np.concatenate([np.linspace(-7, 7, 20001), [0.0, 1e-8, 1e3, -1e4]]).astype(np.float32)
+    s, c = np.empty(1, np.float32), np.empty(1, np.float32)
+    err = 0.0
+    for x in ang:
+        clib.lib().orc_sincos(float(x), clib.fptr(s), clib.fptr(c))
+        err = max(err, abs(float(s[0]) - np.sin(np.float64(x))), abs(float(c[0]) - np.cos(np.float64(x))))
+    assert err < 6.1e-8, err             # half an ulp of fp32 at 1
+
+
 def test_exact_pseudo_gradient_equals_the_faithful_loop(mano_model):
     """per (face, corner): the exact-sum variant against orc_nmr_grad_faces_alpha (the published loop order, fp32 sums)"""
     from homan_amd import synth
@@ -83,28 +141,31 @@ def test_written_out_adam_equals_torch_adam():
 _THREADS_SCRIPT = """
 import sys, numpy as np, torch
 sys.path.insert(0, {root!r})
-torch.set_num_threads(int(sys.argv[1]))
 from homan_amd.mano_assets import synthetic_mano
 from homan_amd import synth
 from tests.test_objchain import _clip_model
 from oracle.jointopt import make_optimizer, reproducible_step
 mano = synthetic_mano(0)
+torch.set_num_threads(1)            # (the INPUTS - 2-D targets projected with torch - are made the same way in both runs)
 model, _ = _clip_model(mano, seed=1, frames=4, size=64, obj="cube")
-lw = dict(synth.CFG1_LOSS_WEIGHTS)
+torch.set_num_threads(int(sys.argv[1]))
+lw = dict(getattr(synth, sys.argv[3]))
 opt = make_optimizer(model, 1e-2, reproducible=True)
 for _ in range(12):
     reproducible_step(model, lw, opt)
-np.save(sys.argv[2], np.concatenate([model.rotations_object.detach().numpy().ravel(), model.translations_object.detach().numpy().ravel()]))
+np.save(sys.argv[2], np.concatenate([p.detach().numpy().ravel() for _, p in sorted(model.named_parameters())]))
 """
 
 
-def test_object_trajectory_does_not_depend_on_the_thread_count(tmp_path):
-    """the oracle's end state was a function of OMP_NUM_THREADS.  With the written-out chain the object's
-    parameters after 12 steps are bit-identical at 1 and 4 threads."""
+@pytest.mark.parametrize("weights_name", ["CFG1_LOSS_WEIGHTS", "STEP1_LOSS_WEIGHTS"])
+def test_trajectory_does_not_depend_on_the_thread_count(weights_name, tmp_path):
+    """the oracle's end state was a function of OMP_NUM_THREADS.  With the written-out chains (object: oracle/
+    objchain.py, hand: oracle/handchain.py) EVERY parameter after 12 steps is bit-identical at 1 and 4 threads."""
     outs = []
     for nt in (1, 4):
         out = str(tmp_path / f"p{nt}.npy")
         env = dict(os.environ, OMP_NUM_THREADS=str(nt), MKL_NUM_THREADS=str(nt))
-        subprocess.run([sys.executable, "-c", _THREADS_SCRIPT.format(root=ROOT), str(nt), out], check=True, env=env, cwd=ROOT)
+        subprocess.run([sys.executable, "-c", _THREADS_SCRIPT.format(root=ROOT), str(nt), out, weights_name], check=True, env=env,
+                       cwd=ROOT)
         outs.append(np.load(out))
     assert np.array_equal(outs[0], outs[1])

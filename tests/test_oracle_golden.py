@@ -17,8 +17,18 @@ def _build(name, mano_model):
     return rec, model, weights, meta
 
 
+@pytest.fixture(params=["reference_form", "written_out"])
+def form(request):
+    """Both evaluation orders of the restatement are pinned to the reference's outputs: the reference's literal expressions
+    (oracle.model.REFERENCE_FORM) and the written-out operation order the HIP kernels are compared with bit for bit."""
+    from oracle import model as o_model
+    o_model.REFERENCE_FORM = request.param == "reference_form"
+    yield request.param
+    o_model.REFERENCE_FORM = False
+
+
 @pytest.mark.parametrize("name", NAMES)
-def test_forward_losses_metrics_and_grads(name, mano_model):
+def test_forward_losses_metrics_and_grads(name, mano_model, form):
     rec, model, weights, meta = _build(name, mano_model)
     loss_dict, metric_dict = model(loss_weights=weights)
     fwd_keys = sorted(k[4:] for k in rec if k.startswith("fwd_"))
@@ -27,7 +37,10 @@ def test_forward_losses_metrics_and_grads(name, mano_model):
         ref = rec["fwd_" + k]
         got = loss_dict[k].detach().numpy()
         assert got.shape == ref.shape, k
-        np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-9, err_msg=k)
+        # loss_collision = a handful of trilinear SDF samples at a few vertices just inside the other surface: one ulp of a
+        # hand vertex (the written-out MANO order differs from torch's matmuls there) moves it by up to ~5e-5 of itself
+        rtol = 1e-4 if (k == "loss_collision" and form == "written_out") else 2e-5
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=1e-9, err_msg=k)
     for k in (k[7:] for k in rec if k.startswith("metric_")):
         np.testing.assert_allclose(metric_dict[k], float(rec["metric_" + k]), rtol=2e-5, err_msg=k)
     total = sum(loss_dict[k] * weights[k.replace("loss", "lw")] for k in loss_dict)

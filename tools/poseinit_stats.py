@@ -34,11 +34,20 @@ L.hm_debug_sweep_stats.argtypes = [ctypes.c_void_p]
 out = (ctypes.c_ulonglong * 16)()
 names = ["s2_items", "s2_geo", "act0", "act1", "on0", "on1", "pairs", "s2_trips", "s1_items", "s1_geo", "s1_reach", "pair_rounds",
          "s1_own", "s1_a0", "s1_out_empty", "s1_a1"]
+L.hm_debug_raster_phases.argtypes = [ctypes.c_void_p]
+rout = (ctypes.c_ulonglong * 24)()
+rnames = ["scan", "records", "near_units", "hz", "far_units", "tail"]
 for steps in (3, 10, 25, 50):
     m = po.PoseOptimizer(ref_image=mask, vertices=verts, faces=faces, rotation_init=po.matrix_to_rot6d(rots), translation_init=trans0,
                          num_initializations=n, K=roi)
     po._fused_loop(m, 1e-2, steps - 1)
     L.hm_debug_sweep_stats(out)
+    L.hm_debug_raster_phases(rout)
     po._fused_loop(m, 1e-2, 2)        # (two un-captured steps: counted below)
     L.hm_debug_sweep_stats(out)
+    L.hm_debug_raster_phases(rout)
+    act = max(1, int(rout[6]))
+    print("   raster wave-0 cycles per active workgroup: " + "  ".join(f"{k}={int(v) / act:.0f}" for k, v in zip(rnames, rout)) +
+          f"; active {int(rout[6]) // 2} idle {int(rout[7]) // 2} per launch; candidates near {int(rout[12]) // 2} far {int(rout[13]) // 2}; "
+          f"units near {int(rout[8]) // 2} far {int(rout[9]) // 2}, far surviving {int(rout[21]) // 2}; covered pairs {int(rout[11]) // 2}")
     print(f"around step {steps}: per launch " + "  ".join(f"{k}={int(v) // 2}" for k, v in zip(names, out)))
