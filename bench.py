@@ -159,6 +159,9 @@ def cfg1_parity(mano, seeds, steps=100, frames=10, size=128):
         cpu_s += time.perf_counter() - t0
         obj_equal = all(np.array_equal(getattr(model, k).detach().cpu().numpy().ravel(), getattr(om, k).detach().numpy().ravel())
                         for k in ("rotations_object", "translations_object"))
+        cpu_params = dict(om.named_parameters())
+        all_equal = all(np.array_equal(p.detach().cpu().numpy().ravel(), cpu_params[k].detach().numpy().ravel())
+                        for k, p in model.named_parameters() if k in cpu_params)
         rel = [abs(a - b) / max(abs(b), 1e-12) for a, b in zip(evo_h["loss"], evo_c["loss"])]
         with torch.no_grad():
             dvo = (model.get_verts_object()[0].cpu() - om.get_verts_object()[0]).abs().max().item()
@@ -183,11 +186,12 @@ def cfg1_parity(mano, seeds, steps=100, frames=10, size=128):
                          final_loss_cpu=evo_c["loss"][-1], rel_diff_final=rel[-1], rel_diff_step0=rel[0],
                          first_step_over_tol=next((i for i, r in enumerate(rel) if r > 1e-4), None),
                          max_rel_diff_any_step=max(rel), object_params_bit_equal=bool(obj_equal),
+                         all_params_bit_equal=bool(all_equal),
                          final_vertex_diff_mm=dict(object=1e3 * dvo, hand=1e3 * dvh)))
     fh, fc = np.array([r["final_loss_hip"] for r in rows]), np.array([r["final_loss_cpu"] for r in rows])
     return dict(config="cfg1: 1 clip, 10 frames 128x128, cube, lw_sil_obj=1 lw_v2d_hand=50, %d Adam steps; HIP fused loop vs the "
                        "CPU oracle's reproducible loop (oracle.jointopt.reproducible_step: the reference loop with the object's "
-                       "gradient chain and Adam written out with order-independent sums)" % steps,
+                       "gradient chain - order-independent sums -, the hand's - one stated order - and Adam written out)" % steps,
                 bars=dict(loss_rel=1e-4, vertex_mm=1e-3),
                 all_within_bars=all(r["first_step_over_tol"] is None and r["final_vertex_diff_mm"]["object"] < 1e-3
                                     and r["final_vertex_diff_mm"]["hand"] < 1e-3 for r in rows),
@@ -204,9 +208,9 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
     """BASELINE's end-state bar, free-running: the HIP fused loop and the CPU oracle loop optimise the same clip from identical
     inputs for `steps` iterations, nobody teacher-forced (reference loop: homan/jointopt.py:158-192).
 
-    The oracle runs its REPRODUCIBLE form (oracle.jointopt.reproducible_step): the object's gradient chain and Adam written
-    out with order-independent sums - same mathematics as autograd + torch.optim.Adam (tests/test_objchain.py), a defined
-    rounding.  The HIP kernels form the same sums (include/homan_amd.h, ORDER-INDEPENDENT SUMS), so on the step-1 loss sets -
+    The oracle runs its REPRODUCIBLE form (oracle.jointopt.reproducible_step): the object's gradient chain (order-independent
+    sums), the hand's (one stated order, step-1 loss sets: oracle/handchain.py) and Adam written out - same mathematics as
+    autograd + torch.optim.Adam (tests/test_objchain.py), a defined rounding.  The HIP kernels form the same sums (include/homan_amd.h, ORDER-INDEPENDENT SUMS), so on the step-1 loss sets -
     where the object's chain does not depend on the hand (homan/homan.py:482-490) - `rotations_object` /
     `translations_object` must be BIT-EQUAL after every step; reported per step, with the first differing step (None = never),
     the final vertex distances in mm and the relative loss differences (bars: 1e-3 mm, 1e-4)."""
@@ -234,7 +238,7 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
                      image_size=size, mano_model=mano, rend_size=size, **kw)
     opt = make_optimizer(om, lr, reproducible=True)
     obj_keys = ("rotations_object", "translations_object")
-    rows, first_obj_diff, stage_report = [], None, None
+    rows, first_obj_diff, stage_report, first_any_diff = [], None, None, None
     t_cpu = 0.0
     for i in range(steps):
         if stages and first_obj_diff is None:
@@ -251,6 +255,9 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
         hp = {k: p.detach().cpu().numpy() for k, p in model.named_parameters()}
         cp = {k: p.detach().numpy().copy() for k, p in om.named_parameters()}
         eq = {k: bool(np.array_equal(hp[k], cp[k].reshape(hp[k].shape))) for k in obj_keys}
+        differing = sorted(k for k in hp if k in cp and not np.array_equal(hp[k], cp[k].reshape(hp[k].shape)))
+        if first_any_diff is None and differing:
+            first_any_diff = dict(step=i, parameters=differing)
         pdiff = {k: float(np.abs(hp[k] - cp[k].reshape(hp[k].shape)).max()) for k in hp if k in cp}
         if first_obj_diff is None and not all(eq.values()):
             first_obj_diff = i
@@ -288,6 +295,7 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
                 f" loss set, {steps} free-running steps: HIP fused loop vs the CPU oracle's reproducible loop",
                 steps=steps, tol=tol, first_step_object_params_differ=first_obj_diff,
                 object_params_bit_equal_all_steps=first_obj_diff is None,
+                first_step_any_param_differs=first_any_diff, all_params_bit_equal_all_steps=first_any_diff is None,
                 first_step_over_tol=next((r["step"] for r in rows if r["max_rel_loss"] > tol), None),
                 max_rel_loss=max(r["max_rel_loss"] for r in rows), worst_loss=max(rows, key=lambda r: r["max_rel_loss"])["worst_loss"],
                 final_rel_loss=rows[-1]["max_rel_loss"], final_vertex_diff_mm=dict(object=dvo, hand=dvh),
@@ -626,10 +634,20 @@ def pose_init_bench(args):
     # the loops of find_optimal_pose: "eager" = the reference's loop verbatim (torch autograd + Adam, one host sync per step),
     # "graph" = that step captured in a hipGraph, "fused" (the default of find_optimal_pose) = the step as a fixed C-ABI launch
     # sequence without the autograd tape, in a hipGraph.  The fastest is reported, all are listed.
-    loops, best = {}, None
+    loops, best, cold = {}, None, None
     for mode in os.environ.get("HOMAN_POSEINIT_LOOPS", "eager,graph,fused").split(","):
         fit(3, mode)                               # warm-up (allocations, lazy init)
         torch.cuda.synchronize()
+        if mode == "fused":
+            # the fused loop is run by a RESIDENT fitter (po.PoseFitter, one per mesh / candidate count / mask size - what the
+            # per-frame fits of find_optimal_poses share): the timed fit below reuses the one the warm-up built.  A fit that
+            # builds everything itself (the first frame of a clip) is timed beside it.
+            os.environ["HOMAN_POSE_FITTER"] = "0"
+            t0 = time.perf_counter()
+            fit(steps, mode)
+            torch.cuda.synchronize()
+            cold = time.perf_counter() - t0
+            del os.environ["HOMAN_POSE_FITTER"]
         t0 = time.perf_counter()
         fitted = fit(steps, mode)
         torch.cuda.synchronize()
@@ -690,8 +708,12 @@ def pose_init_bench(args):
                       "config": {"workload": f"SURVEY 8f rank 1: find_optimal_pose, {n} poses, lathe bottle (3000 faces), "
                                              f"{size}x{size} mask, no anti-aliasing, Adam step in the timed region, "
                                              f"loop = {best} (eager / graph: torch autograd + Adam over the HIP rasteriser; "
-                                             f"fused: C-ABI launch sequence in a hipGraph)", "poses": n, "rend_size": size,
-                                 "pose_steps_per_s_by_loop": {k: n * steps / v for k, v in loops.items()}},
+                                             f"fused: C-ABI launch sequence in a hipGraph, run by the resident fitter "
+                                             f"find_optimal_pose keeps per mesh - the state of every fit of a clip but its "
+                                             f"first; `cold_fit` = a fit that builds everything itself)",
+                                 "poses": n, "rend_size": size,
+                                 "pose_steps_per_s_by_loop": {k: n * steps / v for k, v in loops.items()},
+                                 "cold_fit": (dict(seconds_per_fit=cold, pose_steps_per_s=n * steps / cold) if cold else None)},
                       "best_iou": float(iou.max()), "seconds_per_fit": el, "roofline": roof, "cpu_baseline": cpu})
 
 

@@ -87,7 +87,7 @@ class PoseOptimizer(nn.Module):
     penalty over `num_initializations` candidate poses of one mesh against one instance mask)."""
 
     def __init__(self, ref_image, vertices, faces, rotation_init, translation_init, num_initializations=1, kernel_size=7,
-                 K=None, power=0.25, lw_chamfer=0, textures=None):
+                 K=None, power=0.25, lw_chamfer=0, textures=None, _shared=None):
         assert ref_image.shape[0] == ref_image.shape[1], "Must be square."
         super().__init__()
         if not torch.cuda.is_available():
@@ -98,17 +98,23 @@ class PoseOptimizer(nn.Module):
             raise NotImplementedError(f"pose initialisation renders on a grid of 2x2-sample pixels: even mask sizes only "
                                       f"(the reference's REND_SIZE is 256), got {size}")
         # (sizes off the kernels' 64-sample tile grid are rendered on the next one and cropped: ops.SilhouetteContext)
-        # Every per-candidate buffer is ONE device array replicated on the device (the reference builds the 500-fold copies
-        # of the mask on the host and uploads ~400 MB per fit, which was two thirds of a whole 50-step fit here).
-        n = num_initializations
-        tile = lambda t: t.to(dev).repeat(n, *([1] * (t.dim())))          # (…) -> (n, …)
-        self.register_buffer("vertices", tile(torch.as_tensor(vertices).float().reshape(-1, 3)))
-        self.register_buffer("faces", tile(torch.as_tensor(faces).reshape(-1, 3)))
+        # The reference builds n-fold copies of the mask, its keep mask and the edge distance transform on the host and uploads
+        # ~400 MB per fit (two thirds of a whole 50-step fit here).  The kernels read ONE copy of each (`_keep1`, `_ref1`);
+        # `image_ref` / `keep_mask` / `edt_ref_edge` are still there under the reference's names, as broadcast views.
+        n = self._n = num_initializations
+        self._power, self._kernel_size = power, kernel_size
+        # `_shared`: another PoseOptimizer of the same mesh, candidate count and mask size (the resident fitter's): the mesh
+        # copies and the rasteriser's context - which hold nothing of a fit between two calls - are used, not rebuilt
+        if _shared is not None:
+            self.register_buffer("vertices", _shared.vertices, persistent=False)
+            self.register_buffer("faces", _shared.faces, persistent=False)
+        else:
+            tile = lambda t: t.to(dev).repeat(n, *([1] * (t.dim())))          # (…) -> (n, …)
+            self.register_buffer("vertices", tile(torch.as_tensor(vertices).float().reshape(-1, 3)))
+            self.register_buffer("faces", tile(torch.as_tensor(faces).reshape(-1, 3)))
         # instance mask convention (:66-74): -1 = occluded (not compared), 0 = background, 1 = object
-        mask = torch.as_tensor(np.asarray(ref_image)).float()
-        target, compared = (mask > 0).float(), (mask >= 0).float()
-        self.register_buffer("image_ref", tile(target))
-        self.register_buffer("keep_mask", tile(compared))
+        mask = torch.as_tensor(np.asarray(ref_image)).float().to(dev)
+        self._ref1, self._keep1 = (mask > 0).float().contiguous(), (mask >= 0).float().contiguous()
         self.pool = torch.nn.MaxPool2d(kernel_size=kernel_size, stride=1, padding=(kernel_size // 2))
         # candidate poses: 6-D rotations (n,3,2) and translations (n,1,3); a single translation serves every candidate
         rot0, trans0 = torch.as_tensor(rotation_init).float(), torch.as_tensor(translation_init).float()
@@ -116,22 +122,38 @@ class PoseOptimizer(nn.Module):
             trans0 = trans0.repeat(n, 1, 1)
         self.rotations = nn.Parameter(rot0.clone().to(dev), requires_grad=True)
         self.translations = nn.Parameter(trans0.clone().to(dev), requires_grad=True)
-        # one-way chamfer term: distance transform of the target's edge band, raised to 2 * power (:76-80)
-        band = self.compute_edges(target[None, None].to(dev))[0, 0].cpu().numpy() > 0
-        self.register_buffer("edt_ref_edge", tile(torch.from_numpy(distance_transform_edt(~band) ** (power * 2)).float()))
+        self._edt1 = None           # one-way chamfer term's distance transform (:76-80): built when first read (weight 0 upstream)
         if K is None:
             K = torch.tensor([[[1, 0, 0.5], [0, 1, 0.5], [0, 0, 1]]], dtype=torch.float32)
         self.register_buffer("K", torch.as_tensor(K).float().reshape(-1, 3, 3)[:1].clone())
         self.image_size, self.lw_chamfer = size, lw_chamfer
         self.to(dev)
-        self._one = torch.ones(1, device=dev)
-        self._keep1, self._ref1 = self.keep_mask[0].contiguous(), self.image_ref[0].contiguous()
         self._K_all = self.K.repeat(n, 1, 1).contiguous()
-        self._sil_ctx = ops.SilhouetteContext(self.faces, self.vertices.shape[1], n, size // 2, dev)
-        # the masked L2 of :138-143 is an unnormalised sum of squares: per-sample gradients are O(1), pseudo-gradient terms up
-        # to 2 / eps, per-frame sums up to ~1e7 - the order-independent sums of the backward run on the grid 2^-24 (exact up to
-        # 5e8, resolution 6e-8) instead of the joint fit's 2^-44
-        self._sil_ctx.sum_log2q = -24
+        if _shared is not None:
+            self._one, self._sil_ctx = _shared._one, _shared._sil_ctx
+        else:
+            self._one = torch.ones(1, device=dev)
+            self._sil_ctx = ops.SilhouetteContext(self.faces, self.vertices.shape[1], n, size // 2, dev)
+            # the masked L2 of :138-143 is an unnormalised sum of squares: per-sample gradients are O(1), pseudo-gradient terms
+            # up to 2 / eps, per-frame sums up to ~1e7 - the order-independent sums of the backward run on the grid 2^-24 (exact
+            # up to 5e8, resolution 6e-8) instead of the joint fit's 2^-44
+            self._sil_ctx.sum_log2q = -24
+
+    # the reference's per-candidate buffers, as views of the single copies
+    @property
+    def image_ref(self):
+        return self._ref1[None].expand(self._n, -1, -1)
+
+    @property
+    def keep_mask(self):
+        return self._keep1[None].expand(self._n, -1, -1)
+
+    @property
+    def edt_ref_edge(self):
+        if self._edt1 is None:
+            band = self.compute_edges(self._ref1[None, None])[0, 0].cpu().numpy() > 0
+            self._edt1 = torch.from_numpy(distance_transform_edt(~band) ** (self._power * 2)).float().to(self._ref1.device)
+        return self._edt1[None].expand(self._n, -1, -1)
 
     def apply_transformation(self):
         """:98-103: vertices @ rot6d_to_matrix(rotations) + translations (csrc/geometry.hip, unit scale)."""
@@ -231,83 +253,118 @@ def _graph_loop(model, lr, num_iterations):
     return losses_out, best_rot.clone(), best_trans.clone()
 
 
-def _fused_loop(model, lr, num_iterations, stamp_reps=0):
-    """`num_iterations` steps of reference pose_optimization.py:330-357 as a fixed sequence of C-ABI launches, no autograd
-    tape, replayed from one hipGraph: rigid transform of the n candidates, off-screen penalty (value + vertex gradients in
+class _FusedPoseLoop:
+    """The step of reference pose_optimization.py:330-357 as a fixed sequence of C-ABI launches, no autograd tape, captured
+    once in a hipGraph and replayed: rigid transform of the n candidates, off-screen penalty (value + vertex gradients in
     one launch, hm_offscreen_fwd), no-anti-aliasing raster with the masked L2 + IoU fused per sample, edge sweeps, pose
     gradients with the silhouette gather inside (hm_rigid_bwd_sil), the fused multi-tensor Adam - what the eager loop spends
     on torch's element-wise kernels (a third of its step) is gone.  The chamfer term is multiplied by its weight 0 at the
     reference's only call site and is not evaluated (PoseOptimizer.forward does the same).  Best-ever bookkeeping as in
     `_graph_loop`: the pose is copied AFTER the optimiser step that followed the evaluation (:348-353), strict `<`.
-    stamp_reps > 0 (bench.py): that many MORE replays of the same graph with the heavy silhouette kernels stamping the device
-    wall clock (hm_sil_timestamps); their average durations in microseconds (raster, lines, sweep) are returned as a 4th
-    element."""
-    from .jointopt import HmAdam
-    assert model.lw_chamfer == 0, "the fused loop covers the reference's configuration (lw_chamfer = 0)"
-    L, P, ck = _lib.lib(), _lib.ptr, _lib.check
-    sctx, dev = model._sil_ctx, model.rotations.device
-    n, V, F, S = sctx.B, sctx.V, sctx.F, sctx.S
-    f = lambda *shape: torch.zeros(*shape, device=dev)
-    verts, g_off, off = f(n, V, 3), f(n, V, 3), f(n)
-    pooled, alpha, frame = f(n, S, S), f(n, 2 * S, 2 * S), f(n, 2)
-    keep, ref = sctx.pad_samples(model._keep1), sctx.pad_samples(model._ref1)
-    K_all, K_one, eps = sctx.K_eff(model._K_all).contiguous(), model.K[0].contiguous(), sctx.eps()
-    ones = torch.ones(n, device=dev)
-    rws = torch.zeros(L.hm_rigid_workspace_bytes(n), dtype=torch.uint8, device=dev)
-    params = [model.rotations, model.translations]
-    for p in params:
-        p.grad = torch.zeros_like(p)
-    opt = HmAdam([{"params": params, "lr": lr}])
-    tp, tw, tn = _lib.terms([(g_off, 1.0)])
-    best_loss = torch.full((1,), float("inf"), device=dev)
-    best_rot, best_trans = torch.zeros_like(model.rotations[0]), torch.zeros_like(model.translations[0])
-    losses_out = f(n)
 
-    def step():
-        st = _lib.stream()
-        ck(L.hm_rigid_fwd(P(model.vertices), P(model.rotations), P(model.translations), P(model._one), 0, n, V, None, P(verts),
-                          st), "hm_rigid_fwd")
-        ck(L.hm_offscreen_fwd(P(verts), P(K_one), n, V, NMR_FAR, 100000.0, P(off), P(g_off), st), "hm_offscreen_fwd")
-        ck(L.hm_sil_fwd(P(verts), P(sctx.faces), 0, P(K_all), n, V, F, S, 1.0, ops.NMR_NEAR, ops.NMR_FAR, P(keep), P(ref), None,
-                        P(pooled), None, P(sctx.work_order), None, P(alpha), 1, None, None, None, 0, 0, P(sctx.workspace), st),
-           "hm_sil_fwd")
-        ck(L.hm_sil_reduce(n, V, F, S, None, None, P(frame), P(sctx.workspace), st), "hm_sil_reduce")
-        ck(L.hm_sil_bwd(P(verts), P(K_all), n, V, F, S, 1.0, eps, 4, P(ones), None, None, P(sctx.adj_off), P(sctx.adj_items),
-                        P(sctx.face_order), None, None, P(sctx.workspace), sctx.sum_log2q, st), "hm_sil_bwd")
-        ck(L.hm_rigid_bwd_sil(P(model.vertices), P(model.rotations), P(model._one), 0, tp, tw, tn,
-                              L.hm_sil_parts(P(sctx.workspace), n, V, F, S), P(sctx.adj_off), P(sctx.adj_items), P(verts),
-                              P(K_all), 1.0, F, n, V, P(model.rotations.grad), P(model.translations.grad), None, P(rws),
-                              sctx.sum_log2q, st),
-           "hm_rigid_bwd_sil")
-        opt.step(zero_grad=False)
-        # mask + (chamfer = 0) + offscreen, the order of sum(loss_dict.values()); best-ever bookkeeping in the same launch
-        ck(L.hm_pose_keep_best(P(frame), 2, P(off), n, P(model.rotations), P(model.translations), P(best_loss), P(best_rot),
-                               P(best_trans), P(losses_out), st), "hm_pose_keep_best")
+    The loop is BOUND to one PoseOptimizer: the graph reads its `rotations` / `translations` / `_keep1` / `_ref1` / `K` where
+    they lie.  `restart()` makes it the loop of a new fit whose data the caller copied INTO those tensors (PoseFitter)."""
 
-    side = torch.cuda.Stream()
-    side.wait_stream(torch.cuda.current_stream())
-    done = 0
-    with torch.cuda.stream(side):
-        for _ in range(min(2, num_iterations)):          # un-captured steps (lazy initialisation); they ARE steps
-            step()
-            done += 1
-    torch.cuda.current_stream().wait_stream(side)
-    torch.cuda.synchronize()
-    if done < num_iterations:
-        graph = _lib.new_graph()
-        with torch.cuda.graph(graph):
-            step()
+    def __init__(self, model, lr):
+        from .jointopt import HmAdam
+        assert model.lw_chamfer == 0, "the fused loop covers the reference's configuration (lw_chamfer = 0)"
+        self.model, self.lr = model, lr
+        L, P, ck = _lib.lib(), _lib.ptr, _lib.check
+        sctx, dev = model._sil_ctx, model.rotations.device
+        n, V, F, S = sctx.B, sctx.V, sctx.F, sctx.S
+        f = lambda *shape: torch.zeros(*shape, device=dev)
+        verts, g_off, off = f(n, V, 3), f(n, V, 3), f(n)
+        pooled, alpha, frame = f(n, S, S), f(n, 2 * S, 2 * S), f(n, 2)
+        # (views of the model's own tensors when the mask size lies on the kernels' tile grid, copies otherwise: refresh())
+        self.keep, self.ref = sctx.pad_samples(model._keep1).contiguous(), sctx.pad_samples(model._ref1).contiguous()
+        self.K_all, self.K_one, eps = sctx.K_eff(model._K_all).contiguous(), model.K[0].contiguous(), sctx.eps()
+        keep, ref, K_all, K_one = self.keep, self.ref, self.K_all, self.K_one
+        ones = torch.ones(n, device=dev)
+        rws = torch.zeros(L.hm_rigid_workspace_bytes(n), dtype=torch.uint8, device=dev)
+        params = self.params = [model.rotations, model.translations]
+        for p in params:
+            p.grad = torch.zeros_like(p)
+        opt = self.opt = HmAdam([{"params": params, "lr": lr}])
+        tp, tw, tn = _lib.terms([(g_off, 1.0)])
+        self.best_loss = best_loss = torch.full((1,), float("inf"), device=dev)
+        self.best_rot, self.best_trans = torch.zeros_like(model.rotations[0]), torch.zeros_like(model.translations[0])
+        best_rot, best_trans = self.best_rot, self.best_trans
+        self.losses_out = losses_out = f(n)
+        self._keepalive = (verts, g_off, off, pooled, alpha, frame, ones, rws, tp, tw)
+
+        def step():
+            st = _lib.stream()
+            ck(L.hm_rigid_fwd(P(model.vertices), P(model.rotations), P(model.translations), P(model._one), 0, n, V, None, P(verts),
+                              st), "hm_rigid_fwd")
+            ck(L.hm_offscreen_fwd(P(verts), P(K_one), n, V, NMR_FAR, 100000.0, P(off), P(g_off), st), "hm_offscreen_fwd")
+            ck(L.hm_sil_fwd(P(verts), P(sctx.faces), 0, P(K_all), n, V, F, S, 1.0, ops.NMR_NEAR, ops.NMR_FAR, P(keep), P(ref), None,
+                            P(pooled), None, P(sctx.work_order), None, P(alpha), 1, None, None, None, 0, 0, P(sctx.workspace), st),
+               "hm_sil_fwd")
+            ck(L.hm_sil_reduce(n, V, F, S, None, None, P(frame), P(sctx.workspace), st), "hm_sil_reduce")
+            ck(L.hm_sil_bwd(P(verts), P(K_all), n, V, F, S, 1.0, eps, 4, P(ones), None, None, P(sctx.adj_off), P(sctx.adj_items),
+                            P(sctx.face_order), None, None, P(sctx.workspace), sctx.sum_log2q, st), "hm_sil_bwd")
+            ck(L.hm_rigid_bwd_sil(P(model.vertices), P(model.rotations), P(model._one), 0, tp, tw, tn,
+                                  L.hm_sil_parts(P(sctx.workspace), n, V, F, S), P(sctx.adj_off), P(sctx.adj_items), P(verts),
+                                  P(K_all), 1.0, F, n, V, P(model.rotations.grad), P(model.translations.grad), None, P(rws),
+                                  sctx.sum_log2q, st),
+               "hm_rigid_bwd_sil")
+            opt.step(zero_grad=False)
+            # mask + (chamfer = 0) + offscreen, the order of sum(loss_dict.values()); best-ever bookkeeping in the same launch
+            ck(L.hm_pose_keep_best(P(frame), 2, P(off), n, P(model.rotations), P(model.translations), P(best_loss), P(best_rot),
+                                   P(best_trans), P(losses_out), st), "hm_pose_keep_best")
+
+        self._step = step
+        self.graph = None
+
+    def restart(self):
+        """a new fit in the bound model's tensors: derived inputs refreshed, optimiser and best-ever state as new"""
+        m, sctx = self.model, self.model._sil_ctx
+        for dst, src in ((self.keep, sctx.pad_samples(m._keep1)), (self.ref, sctx.pad_samples(m._ref1)),
+                         (self.K_all, sctx.K_eff(m._K_all)), (self.K_one, m.K[0])):
+            if dst.data_ptr() != src.data_ptr():
+                dst.copy_(src)
+        for mm, vv in self.opt.state:
+            mm.zero_()
+            vv.zero_()
+        self.opt.step_t.zero_()
+        for p in self.params:
+            p.grad.zero_()
+        self.best_loss.fill_(float("inf"))
+        sctx.invalidate_outputs()
+
+    def run(self, num_iterations):
+        """`num_iterations` steps.  The first two steps of a loop's life run un-captured (lazy initialisation of the library)
+        - they ARE steps, same launches - then one step is captured and every further step, of this and of later fits, is a
+        replay.  -> (final losses (n,), best-ever rotation, best-ever translation)"""
+        done = 0
+        if self.graph is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(min(2, num_iterations)):
+                    self._step()
+                    done += 1
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            if done < num_iterations:
+                self.graph = _lib.new_graph()
+                with torch.cuda.graph(self.graph):
+                    self._step()
         for _ in range(num_iterations - done):
-            graph.replay()
-    torch.cuda.synchronize()
-    stamps = None
-    if stamp_reps > 0 and done < num_iterations:
+            self.graph.replay()
+        return self.losses_out, self.best_rot.clone(), self.best_trans.clone()
+
+    def stamped_replays(self, stamp_reps):
+        """(bench.py) `stamp_reps` MORE replays with the heavy silhouette kernels stamping the device wall clock
+        (hm_sil_timestamps) -> their average durations in microseconds (raster, lines, sweep)"""
         import ctypes
-        ws, dims = P(sctx.workspace), (n, V, F, S)
-        saved = torch.zeros(stamp_reps, L.hm_sil_timestamps_bytes(*dims) // 8, dtype=torch.int64, device=dev)
+        L, P, ck = _lib.lib(), _lib.ptr, _lib.check
+        sctx = self.model._sil_ctx
+        ws, dims = P(sctx.workspace), (sctx.B, sctx.V, sctx.F, sctx.S)
+        saved = torch.zeros(stamp_reps, L.hm_sil_timestamps_bytes(*dims) // 8, dtype=torch.int64, device=sctx.workspace.device)
         for i in range(stamp_reps):
             ck(L.hm_sil_timestamps(ws, *dims, 1, _lib.stream()), "hm_sil_timestamps")
-            graph.replay()
+            self.graph.replay()
             ck(L.hm_sil_timestamps_save(ws, *dims, saved[i].data_ptr(), _lib.stream()), "hm_sil_timestamps_save")
         ck(L.hm_sil_timestamps(ws, *dims, 0, _lib.stream()), "hm_sil_timestamps")
         us3, acc = (ctypes.c_float * 3)(), [0.0, 0.0, 0.0]
@@ -316,12 +373,78 @@ def _fused_loop(model, lr, num_iterations, stamp_reps=0):
                "hm_sil_timestamps_read")
             acc = [a + u for a, u in zip(acc, us3)]
         torch.cuda.synchronize()
-        stamps = dict(zip(("k_raster_fwd", "k_bwd_lines", "k_bwd_sweep"), (a / stamp_reps for a in acc)))
-    for p in params:
-        p.grad = None
-    if stamp_reps > 0:
-        return losses_out, best_rot.clone(), best_trans.clone(), stamps
-    return losses_out, best_rot.clone(), best_trans.clone()
+        return dict(zip(("k_raster_fwd", "k_bwd_lines", "k_bwd_sweep"), (a / stamp_reps for a in acc)))
+
+    def release(self):
+        for p in self.params:
+            p.grad = None
+
+
+def _fused_loop(model, lr, num_iterations, stamp_reps=0):
+    """One fit of `model` by a fused loop of its own (`_FusedPoseLoop`).  stamp_reps > 0 (bench.py): that many MORE replays of
+    the same graph with the kernels' timestamps on; their average durations are returned as a 4th element."""
+    loop = _FusedPoseLoop(model, lr)
+    out = loop.run(num_iterations)
+    torch.cuda.synchronize()
+    stamps = loop.stamped_replays(stamp_reps) if (stamp_reps > 0 and loop.graph is not None) else None
+    loop.release()
+    return out + (stamps,) if stamp_reps > 0 else out
+
+
+class PoseFitter:
+    """A RESIDENT pose initialiser for one mesh, candidate count and mask size: the mesh copies, the rasteriser's context, the
+    loop's buffers and its captured hipGraph are built once; every further fit copies its mask, intrinsics and starting poses
+    into place and replays.  `find_optimal_pose` keeps one per (mesh, n, size, lr) - the per-frame fits of `find_optimal_poses`
+    (reference homan/pose_optimization.py:386-488: one fit per frame of a clip, same mesh) pay the construction once."""
+
+    def __init__(self, vertices, faces, num_initializations, size, lr):
+        n = num_initializations
+        rot0 = matrix_to_rot6d(torch.eye(3)[None].repeat(n, 1, 1))
+        self.shell = PoseOptimizer(ref_image=np.zeros((size, size), np.float32), vertices=vertices, faces=faces, rotation_init=rot0,
+                                   translation_init=torch.tensor([[[0.0, 0.0, 1.0]]]), num_initializations=n,
+                                   K=torch.tensor([[[1.0, 0, 0.5], [0, 1.0, 0.5], [0, 0, 1]]]))
+        self.loop = _FusedPoseLoop(self.shell, lr)
+        self.n, self.size = n, size
+        self.fits = 0
+
+    def fit(self, mask, rotation_init, translation_init, K, num_iterations):
+        """-> (PoseOptimizer holding the fitted candidates in their original order, final losses, champion rotation, champion
+        translation); the returned module shares this fitter's mesh copies and rasteriser context, nothing of the fit."""
+        sh = self.shell
+        result = PoseOptimizer(ref_image=mask, vertices=None, faces=None, rotation_init=rotation_init,
+                               translation_init=translation_init, num_initializations=self.n, K=K, _shared=sh)
+        with torch.no_grad():
+            sh._keep1.copy_(result._keep1)
+            sh._ref1.copy_(result._ref1)
+            sh.K.copy_(result.K)
+            sh._K_all.copy_(result._K_all)
+            sh.rotations.copy_(result.rotations)
+            sh.translations.copy_(result.translations)
+        self.loop.restart()
+        losses, champ_rot, champ_trans = self.loop.run(num_iterations)
+        with torch.no_grad():
+            result.rotations.copy_(sh.rotations)
+            result.translations.copy_(sh.translations)
+        self.fits += 1
+        return result, losses.clone(), champ_rot, champ_trans
+
+
+_FITTERS = {}
+_FITTERS_MAX = 4        # (each holds the rasteriser's workspace of n candidates: ~1 GB at 500 x 256^2)
+
+
+def _resident_fitter(vertices, faces, n, size, lr):
+    import os
+    if os.environ.get("HOMAN_POSE_FITTER", "1") == "0":
+        return None
+    key = (hash(vertices.detach().cpu().numpy().tobytes()), hash(faces.detach().cpu().numpy().tobytes()), tuple(vertices.shape),
+           tuple(faces.shape), int(n), int(size), float(lr))
+    fitter = _FITTERS.get(key)
+    if fitter is None:
+        while len(_FITTERS) >= _FITTERS_MAX:
+            _FITTERS.pop(next(iter(_FITTERS)))
+        fitter = _FITTERS[key] = PoseFitter(vertices, faces, n, size, lr)
+    return fitter
 
 
 def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=None, num_iterations=50,
@@ -331,7 +454,8 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
     and ignored).  Returns the PoseOptimizer whose `rotations` / `translations` hold the best-ever pose first, then the
     poses sorted by final loss.
     mode="auto" (default) = "fused": the step as a fixed C-ABI launch sequence without the autograd tape, in a hipGraph
-    (`_fused_loop`);
+    (`_FusedPoseLoop`), run by a resident `PoseFitter` kept per (mesh, candidates, mask size, lr) - HOMAN_POSE_FITTER=0
+    builds everything anew per call;
     mode="eager": the reference loop verbatim (torch autograd + Adam, one host sync per step for the best-ever bookkeeping);
     mode="graph": that same autograd step captured once in a hipGraph and replayed."""
     dev = torch.device("cuda")
@@ -347,12 +471,20 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
     translations_init = TCO_init_from_boxes_zup_autodepth(bbox, torch.matmul(vertices.unsqueeze(0), rotations_init),
                                                           Kb).unsqueeze(1)
     camintr_roi[:, :2] = camintr_roi[:, :2] / rend_size          # crop K to normalised rendering space (:321)
-    model = PoseOptimizer(ref_image=mask, vertices=vertices, faces=faces, rotation_init=matrix_to_rot6d(rotations_init),
-                          translation_init=translations_init, num_initializations=num_initializations, K=camintr_roi)
     if mode == "auto":
         mode = "fused"
     if mode not in ("eager", "graph", "fused"):
         raise ValueError(f"mode {mode} not in [auto|fused|eager|graph]")
+    fitter = None
+    if mode == "fused" and num_iterations > 0 and np.asarray(mask).shape[0] % 2 == 0:
+        fitter = _resident_fitter(vertices, faces, num_initializations, int(np.asarray(mask).shape[0]), lr)
+    if fitter is not None:
+        model, final_losses, champion_rot, champion_trans = fitter.fit(mask, matrix_to_rot6d(rotations_init), translations_init,
+                                                                       camintr_roi, num_iterations)
+        _install_ranked_poses(model, final_losses, champion_rot, champion_trans, sort_best)
+        return model
+    model = PoseOptimizer(ref_image=mask, vertices=vertices, faces=faces, rotation_init=matrix_to_rot6d(rotations_init),
+                          translation_init=translations_init, num_initializations=num_initializations, K=camintr_roi)
     if mode == "fused" and num_iterations > 0:
         final_losses, champion_rot, champion_trans = _fused_loop(model, lr, num_iterations)
     elif mode == "graph" and num_iterations > 0:

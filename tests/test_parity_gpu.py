@@ -8,8 +8,9 @@ FREE-running (the measurement bench.py reports as `final_loss_parity.cfg1`; refe
 Why this can hold although the silhouette term is piecewise constant in the pose (a last-bit difference in a parameter flips
 a sample, Adam's normalised steps amplify it: rounds 1-3 measured centimetres after 100 steps): every reduction on the
 object's gradient chain is an order-independent sum on both sides (include/homan_amd.h "ORDER-INDEPENDENT SUMS",
-oracle/objchain.py) and every per-term operation is IEEE, so the object's parameters are BIT-EQUAL after every step - there
-is nothing to amplify.  The hand is driven by smooth terms and stays within a few ulp."""
+oracle/objchain.py), the hand's chain runs in ONE stated evaluation order on both sides (oracle/handchain.py,
+oracle/csrc/lbs_exact.c <-> csrc/mano.hip, csrc/pair_bodies.h) and every per-term operation is IEEE, so EVERY parameter is
+BIT-EQUAL after every step - there is nothing to amplify."""
 import os
 import sys
 
@@ -27,8 +28,9 @@ def test_cfg1_final_loss_and_vertex_parity(mano_model):
         assert row["first_step_over_tol"] is None, row                    # every logged loss within 1e-4 at every step
         assert row["max_rel_diff_any_step"] < 1e-4, row
         assert row["object_params_bit_equal"], row                        # rotations_object / translations_object, final
+        assert row["all_params_bit_equal"], row                           # ... and the hand's six tensors
         assert row["final_vertex_diff_mm"]["object"] < 1e-3, row          # north_star's vertex bar (in fact 0.0)
-        assert row["final_vertex_diff_mm"]["hand"] < 1e-3, row
+        assert row["final_vertex_diff_mm"]["hand"] == 0.0, row            # (the hand's chain is bit-equal too)
         assert row["final_loss_hip"] < 0.35 * row["first_loss"], row      # ... of a fit that did converge
     assert out["all_within_bars"]
     # the control: the CPU path against ITSELF from inputs that differ by 1e-7 m still separates by millimetres - the
@@ -37,12 +39,13 @@ def test_cfg1_final_loss_and_vertex_parity(mano_model):
     assert ctrl["final_vertex_diff_mm"]["object"] > 1.0, ctrl
 
 
-def test_free_running_object_trajectory_is_bit_equal_step1_set(mano_model):
-    """a cfg2-shaped clip (bottle, full step-1 loss set: silhouette + smoothness reach the object) at reduced size: object pose
-    parameters bit-equal after each of 60 free-running steps, all losses within 1e-4, final vertices within 1e-3 mm"""
+def test_free_running_trajectory_is_bit_equal_step1_set(mano_model):
+    """a cfg2-shaped clip (bottle, full step-1 loss set) at reduced size: EVERY parameter - object pose, hand pose, MANO pose /
+    shape / translation - bit-equal after each of 60 free-running steps, all losses within 1e-4, final vertices identical"""
     sys.path.insert(0, ROOT)
     import bench
     out = bench.free_run_parity(mano_model, steps=60, frames=8, size=96, obj="bottle")
     assert out["object_params_bit_equal_all_steps"], out["stage_report"]
     assert out["first_step_over_tol"] is None, (out["max_rel_loss"], out["worst_loss"])
-    assert out["final_vertex_diff_mm"]["object"] == 0.0 and out["final_vertex_diff_mm"]["hand"] < 1e-3, out["final_vertex_diff_mm"]
+    assert out["all_params_bit_equal_all_steps"], out["first_step_any_param_differs"]
+    assert out["final_vertex_diff_mm"]["object"] == 0.0 and out["final_vertex_diff_mm"]["hand"] == 0.0, out["final_vertex_diff_mm"]

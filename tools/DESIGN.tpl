@@ -139,22 +139,29 @@ object's chain is closed on itself (`homan/homan.py:482-490`: `loss_inter` sees 
   `oracle.jointopt.reproducible_step`: forward + autograd as always, then the object's pose gradients REPLACED by the written-out
   chain, then the written-out Adam).  Same mathematics as autograd + `torch.optim.Adam`: `tests/test_objchain.py` holds the
   two within fp32 rounding (2e-5 of the largest gradient entry, 2e-6 on Adam), the faithful forms stay pinned to the
-  reference's goldens, and the oracle's result no longer depends on its thread count (1 vs 4 threads: bit-identical).
+  reference's goldens, and the oracle's result no longer depends on its thread count (1 vs 4 threads: bit-identical);
+* the HAND's chain needs no new sums - `csrc/mano.hip` and `csrc/pair_bodies.h` were deterministic already (fixed vertex chunks,
+  DPP trees, chunk records added in chunk order, no data atomics) - but one DEFINED order on both sides: `hm_sincos` (argument
+  reduction + the fdlibm kernel polynomials in double, rounded to fp32; libm's and OCML's `sinf` differ in the last bit) is shared
+  by the kernels and the oracle, the MANO layer's forward is written out in the kernels' order (`oracle/csrc/lbs_exact.c`:
+  `orc_mano_forward`; joint regressor folded in double, so no host BLAS is involved) and so is the backward of the whole hand
+  side (`orc_hand_chain`: per-vertex terms, the rigid backward's 12 sums, skinning / blend-shape / chain / Rodrigues / PCA
+  backward with the kernels' reduction trees; `orc_v2d_unit_grad`, `orc_inter_rec`; `oracle/handchain.py`).  The torch
+  restatement of the layer (`oracle/lbs.py`, `oracle.model.REFERENCE_FORM`) stays: both forms are pinned to the reference's
+  goldens (`tests/test_oracle_golden.py`, both parametrisations) and to each other within an ulp.
 
-Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `profiles/r04_freerun_*.json`):
-`rotations_object` / `translations_object` are BIT-EQUAL between the two free-running loops after every step - cfg1 100 steps x
-5 seeds, cfg2 at full size over 400 steps -, final object vertices 0.0 mm apart.  cfg1 (the configuration the CPU path is
-defined on, 100 steps) and cfg2 over its first 170 steps (the bench line's `free_run` leg runs 100): hand vertices 1.2-1.8e-4 mm
-(bar 1e-3 mm), every logged loss within 4e-6 at every step (bar 1e-4), `first_step_over_tol: null`.
-What is NOT closed is the HAND over a whole 400-step cfg2 fit: its chain (MANO, 2-D, smoothness, interaction) is smooth but not
-exact - the vertices are one ulp from the oracle's -, and around step 170-180 of this clip the hand's own dynamics (Adam at 10 x lr
-on the MANO parameters, `mano_betas` with a vanishing gradient first) amplify whatever difference there is: HIP vs CPU ends
-0.14 mm apart in the hand with the losses up to 2 % apart in between (`r04_freerun_cfg2_400.json`, `first_step_over_tol: 181`),
-and the CPU loop against ITSELF from hand translations 1e-7 m apart leaves the 1e-3 mm bar at step 169 and ends 0.85 mm apart
-(`r04_control_cfg2_400.json`) - same step, same size: the reference algorithm's sensitivity, for which only an exact hand chain
-(section 8) would be a cure.  On the step-2 sets the contact term couples the hand's one-ulp vertices into the object, where the
-per-step bound (lock-step, below 1e-4) is what is claimed.  Cost of the exact path: nothing at one clip, -2 % on an 8-clip batch
-(EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the divisions.
+Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`,
+`profiles/r04_freerun_*.json`): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
+`translations_hand`, `mano_pca_pose`, `mano_rot`, `mano_betas`, `mano_trans` - is BIT-EQUAL between the two free-running loops
+after every step: cfg1 100 steps x 5 seeds, cfg2 at full size over 400 steps (`all_params_bit_equal_all_steps: true`), final
+vertices 0.0 mm apart for the object AND the hand, every logged loss within 3.4e-7 at every step (bar 1e-4; the logged VALUES are
+parallel float sums and keep their rounding, the trajectory does not see them).  Until the hand's chain was written out (first
+half of this round) the hand separated around step 170-180 of the cfg2 clip - 0.14 mm at step 400 - exactly where the CPU loop
+separates from ITSELF when its hand translations start 1e-7 m apart (`r04_control_cfg2_400.json`: 0.85 mm): Adam at 10 x lr on
+the MANO parameters amplifies any difference, so only a chain without any could close it.  The step-2 sets (contact, collision)
+are not written out: there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
+path: nothing at one clip, -2 % on an 8-clip batch (EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the
+divisions; the hand side's kernels did not change but for the sin / cos.
 
 Teacher-forced lock-step parity at full size (`bench.lockstep_parity`, `tests/test_lockstep_gpu.py`) stays as the per-step
 statement for all loss sets: BEFORE every step the fused loop's parameters are loaded into the (faithful, autograd) oracle,
@@ -281,7 +288,7 @@ a `steady_state` leg (iteration ≥ 400, 2000 timed iterations, 0.33 s) so that 
 | cfg5 on one rank (8 clips, step-2, one tied scale, RCCL call issued) | @CFG5@ it/s |
 | 2 ranks on ONE GPU through gloo (the driver's `torch.distributed.run` line; weak scaling has nothing to scale on one GPU - this is the N > 1 code path, not a speed-up) | cfg2: @G2@ it/s summed; cfg5 (2 x 4 clips, tied scale): @G5@ it/s, replicas identical |
 | object-pose initialisation (SURVEY §8f rank 1): 500 candidate poses of the bottle against one 256² mask, `python bench.py --pose-init 500` | **@POSE@ pose-steps/s** (@POSEMS@ ms per step of 500 poses; a 50-step fit in @POSEFIT@ s); by loop: @POSELOOPS@; CPU oracle @POSECPU@ pose-steps/s |
-| free-running parity, cfg2 at full size, 400 steps, HIP loop vs the oracle's reproducible loop (`profiles/r04_freerun_cfg2_400.json`) | object pose parameters bit-equal after every step: @FREEEQ@, final object vertices @FREEVO@ mm; hand @FREEVH@ mm and losses up to @FREELOSS@ apart after step 181 - the CPU loop against itself from inputs 1e-7 m apart: hand 0.85 mm, from step 169 (`r04_control_cfg2_400.json`; section 2) |
+| free-running parity, cfg2 at full size, 400 steps, HIP loop vs the oracle's reproducible loop (`profiles/r04_freerun_cfg2_400.json`) | every parameter (object pose, hand pose, MANO) bit-equal after every step: @FREEALL@ (object alone: @FREEEQ@), final vertices object @FREEVO@ mm / hand @FREEVH@ mm, largest relative loss difference at any step @FREELOSS@ (section 2; the control `r04_control_cfg2_400.json`: the CPU loop against itself from inputs 1e-7 m apart ends 0.85 mm apart) |
 | CPU baseline (oracle loop, 64 host threads) | @CPU@ it/s with the reference's per-step `.item()` logging, @CPUOFF@ it/s without → GPU / CPU ≈ @RATIO@ × (target ≥ 50 ×) |
 | whole iteration vs the SURVEY §8d byte model (144.1 MB) | @WHOLE@ of 8 TB/s at one clip |
 
@@ -412,9 +419,9 @@ file the reference never reaches.  More than two hands: the reference's own coll
 4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
    silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
    hands it runs one clip per stepper (`ShardStepper`).
-5. An exact HAND chain (the object's is): the MANO forward AND backward, the 2-D / smoothness / interaction terms and the hand's
-   rigid backward with order-independent sums and a shared sin / cos on both sides.  It would close the hand's end state over a
-   whole 400-step cfg2 fit (0.14 mm today, where the CPU loop differs from itself by 0.85 mm), extend the free-running
-   bit-equality to the step-2 sets, where the contact term couples the hand's one-ulp vertices into the object's chain, and take
-   `loss_collision`'s per-step error from 1e-4 to 1e-7.
+5. The step-2 sets written out like the step-1 sets are: the nearest-vertex search, the contact zones and the SDF collision
+   term (grid build + trilinear samples) in one stated order on both sides.  The hand's and the object's vertices are bit-equal
+   already, so this is oracle work (`oracle/handchain.py` raises NotImplementedError for `lw_contact` / `lw_collision` today) plus
+   order-independent sums where those kernels add with atomics; it would extend the free-running bit-equality from cfg1 / cfg2 to
+   cfg3 / cfg5.
 6. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.

@@ -1,2 +1,2 @@
 R=$(pwd); O=$R/gpurun_out
-timeout 1200 python -m pytest tests/test_handchain_gpu.py -q > $O/g32_hand.log 2>&1; tail -40 $O/g32_hand.log
+timeout 2700 python -m pytest tests -m gpu -q > $O/g36_tests.log 2>&1; tail -6 $O/g36_tests.log

@@ -46,6 +46,7 @@ def main(tag="r04"):
                 "@E2ESETUP@": "n/a" if not e2e else f"{100 * e2e['repeated_shape']['setup_fraction_of_fit']:.1f} %",
                 "@E2ESPLIT@": "n/a" if not e2e else ", ".join(f"{k} {v:.3f} s" for k, v in e2e["split_s"].items()),
                 "@FREEEQ@": "n/a" if not fr else str(fr["object_params_bit_equal_all_steps"]),
+                "@FREEALL@": "n/a" if not fr else str(fr.get("all_params_bit_equal_all_steps")),
                 "@FREELOSS@": "n/a" if not fr else f"{fr['max_rel_loss']:.1e}",
                 "@FREEVO@": "n/a" if not fr else f"{fr['final_vertex_diff_mm']['object']:.1e}",
                 "@FREEVH@": "n/a" if not fr else f"{fr['final_vertex_diff_mm']['hand']:.1e}"})
