@@ -70,7 +70,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_hand(const float* __rest
         const float* o = vo + ((long)b * Vo + j) * 3;
         const float dx = o[0] - h[0], dy = o[1] - h[1], dz = o[2] - h[2];
         const float a = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float th = tanhf(a / thresh);
+        const float th = hm_tanh(a / thresh);
         lsum += thresh * th;
         const float k = (a > 0.f) ? (1.0f - th * th) / a * inv_cnt : 0.f;     // d val / d a  / a
         float* gh = g_hand + ((long)b * Vh + i) * 3;                          // d a / d h = -diff / a
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(NN_THREADS) void k_contact_both(const float* __rest
         const float* o = vo + ((long)b * Vo + j) * 3;
         const float dx = o[0] - h[0], dy = o[1] - h[1], dz = o[2] - h[2];
         const float a = sqrtf(dx * dx + dy * dy + dz * dz);
-        const float th = tanhf(a / thresh);
+        const float th = hm_tanh(a / thresh);
         lsum += thresh * th;
         const float k = (a > 0.f) ? (1.0f - th * th) / a * inv_cnt : 0.f;     // d val / d a  / a
         const float g[3] = {-k * dx, -k * dy, -k * dz};                       // d a / d h = -diff / a

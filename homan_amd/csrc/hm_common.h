@@ -241,6 +241,34 @@ __host__ __device__ __forceinline__ void hm_sincos(float af, float* sn, float* c
     *cs = (float)cv;
 }
 
+// ---- tanh of an fp32 argument as a DEFINED function, like hm_sincos: e = exp(-2|x|) by a ln2 reduction and the fdlibm exp
+// kernel in double, tanh = (1 - e) / (1 + e) in double, rounded to fp32 (OCML's and glibc's tanhf differ in the last bit; the
+// oracle's written-out contact term, oracle/csrc/lbs_exact.c oc_tanh, evaluates the same operations).
+__host__ __device__ __forceinline__ float hm_tanh(float xf)
+{
+    const double ax = xf < 0.f ? -(double)xf : (double)xf;
+    if (ax > 20.0) return xf < 0.f ? -1.0f : 1.0f;
+    if (ax < 0.01) {        // (1 - e loses the small argument: odd series, next term 62/2835 x^9)
+        const double q = ax * ax;
+        const double sm = ax * (1.0 + q * (-3.33333333333333314830e-01 + q * (1.33333333333333331483e-01 + q * -5.39682539682539708542e-02)));
+        return (float)(xf < 0.f ? -sm : sm);
+    }
+    const double t = -2.0 * ax;
+    const double k = __builtin_rint(t * 1.44269504088896338700e+00);
+    const double r = (t - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
+    const double z = r * r;
+    double p = 4.13813679705723846039e-08;
+    p = -1.65339022054652515390e-06 + z * p;
+    p = 6.61375632143793436117e-05 + z * p;
+    p = -2.77777777770155933842e-03 + z * p;
+    p = 1.66666666666666019037e-01 + z * p;
+    const double c = r - z * p;
+    const double er = 1.0 - ((r * c) / (c - 2.0) - r);
+    const double e = __builtin_ldexp(er, (int)k);
+    const double th = (1.0 - e) / (1.0 + e);
+    return (float)(xf < 0.f ? -th : th);
+}
+
 // ---- rot6d (3x2 row-major, reference homan/utils/geometry.py:9-27) -> rotation matrix (3x3 row-major)
 __device__ __forceinline__ void rot6d_to_mat(const float* r6 /*3x2 row-major*/, float* R /*3x3 row-major*/)
 {

@@ -56,6 +56,14 @@ def lib():
         _lib.orc_v2d_unit_grad.restype = None
         _lib.orc_inter_rec.argtypes = [fp, fp, fp, ci, ci, ci, cf, cf, ci, fp]
         _lib.orc_inter_rec.restype = None
+        _lib.orc_nn_search.argtypes = [fp, fp, ci, ci, ci, ip]
+        _lib.orc_nn_search.restype = None
+        _lib.orc_contact_grads.argtypes = [fp, fp, ip, ci, ci, ci, cf, ci, fp, fp]
+        _lib.orc_contact_grads.restype = None
+        _lib.orc_sdf_sample_grad.argtypes = [fp, fp, fp, ci, ci, ci, fp]
+        _lib.orc_sdf_sample_grad.restype = None
+        _lib.orc_tanh.argtypes = [cf]
+        _lib.orc_tanh.restype = cf
         _lib.orc_sincos.argtypes = [cf, fp, fp]
         _lib.orc_sincos.restype = None
         _lib.orc_sum_magic.argtypes = [ci]

@@ -15,6 +15,7 @@
  */
 #include <math.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #define NV 778
 #define NJ 16
@@ -497,5 +498,122 @@ void orc_inter_rec(const float *vh, const float *vo, const float *camintr, int B
         r[1] = (dx * dx + dy * dy + dz * dz) / 3.0f;
         r[2] = flag * 2.0f * dx / 3.0f; r[3] = flag * 2.0f * dy / 3.0f; r[4] = flag * 2.0f * dz / 3.0f;
         r[5] = r[6] = r[7] = 0.f;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Step-2 terms (contact, collision) in the kernels' order: csrc/contact.hip, csrc/pair_bodies.h nn_full_body, csrc/sdf.hip.
+ * ---------------------------------------------------------------------------------------------------------------------- */
+static float oc_tanh(float xf)        /* csrc/hm_common.h hm_tanh, same operations */
+{
+    const double ax = xf < 0.f ? -(double)xf : (double)xf;
+    if (ax > 20.0) return xf < 0.f ? -1.0f : 1.0f;
+    if (ax < 0.01) {
+        const double q = ax * ax;
+        const double sm = ax * (1.0 + q * (-3.33333333333333314830e-01 + q * (1.33333333333333331483e-01 + q * -5.39682539682539708542e-02)));
+        return (float)(xf < 0.f ? -sm : sm);
+    }
+    const double t = -2.0 * ax;
+    const double k = rint(t * 1.44269504088896338700e+00);
+    const double r = (t - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
+    const double z = r * r;
+    double p = 4.13813679705723846039e-08;
+    p = -1.65339022054652515390e-06 + z * p;
+    p = 6.61375632143793436117e-05 + z * p;
+    p = -2.77777777770155933842e-03 + z * p;
+    p = 1.66666666666666019037e-01 + z * p;
+    const double c = r - z * p;
+    const double er = 1.0 - ((r * c) / (c - 2.0) - r);
+    const double e = ldexp(er, (int)k);
+    const double th = (1.0 - e) / (1.0 + e);
+    return (float)(xf < 0.f ? -th : th);
+}
+float orc_tanh(float x) { return oc_tanh(x); }
+
+/* nearest object vertex of every hand vertex (reference homan/interactions/contactloss.py:60-79, 162-163): squared distance
+ * (ox-hx)^2 + (oy-hy)^2 + (oz-hz)^2 left to right, ties -> the lowest index.  -> idx (B,Vh) */
+void orc_nn_search(const float *vh, const float *vo, int B, int Vh, int Vo, int32_t *idx)
+{
+#pragma omp parallel for schedule(static)
+    for (long bi = 0; bi < (long)B * Vh; ++bi) {
+        const int b = (int)(bi / Vh);
+        const float *h = vh + bi * 3;
+        float best = 3.4e38f;
+        int besti = 0;
+        for (int j = 0; j < Vo; ++j) {
+            const float *o = vo + ((long)b * Vo + j) * 3;
+            const float dx = o[0] - h[0], dy = o[1] - h[1], dz = o[2] - h[2];
+            const float d = dx * dx + dy * dy + dz * dz;
+            if (d < best) { best = d; besti = j; }
+        }
+        idx[bi] = besti;
+    }
+}
+
+/* contact term as the reference executes it (contactloss.py:228-257 with an empty attraction mask: mean over the clip's
+ * frames and hand vertices of thresh * tanh(|nn - h| / thresh)): unit gradient on the hand vertices, and on the object
+ * vertices minus the sum of the gradients of the hand vertices that picked them - an exact sum in 2^-44 fixed point.
+ * -> g_hand (B,Vh,3), g_obj (B,Vo,3) */
+void orc_contact_grads(const float *vh, const float *vo, const int32_t *idx, int B, int Vh, int Vo, float thresh, int clip_len,
+                       float *g_hand, float *g_obj)
+{
+    const float FIX = 17592186044416.0f;      /* 2^44 */
+    const float inv_cnt = 1.0f / (float)((long)clip_len * Vh);
+    for (int b = 0; b < B; ++b) {
+        long long *acc = (long long *)calloc((size_t)Vo * 3, sizeof(long long));
+        for (int i = 0; i < Vh; ++i) {
+            const int j = idx[(long)b * Vh + i];
+            const float *h = vh + ((long)b * Vh + i) * 3;
+            const float *o = vo + ((long)b * Vo + j) * 3;
+            const float dx = o[0] - h[0], dy = o[1] - h[1], dz = o[2] - h[2];
+            const float a = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float th = oc_tanh(a / thresh);
+            const float k = (a > 0.f) ? (1.0f - th * th) / a * inv_cnt : 0.f;
+            const float g[3] = {-k * dx, -k * dy, -k * dz};
+            for (int c = 0; c < 3; ++c) {
+                g_hand[((long)b * Vh + i) * 3 + c] = g[c];
+                acc[3 * j + c] += llrintf(g[c] * FIX);
+            }
+        }
+        for (int i = 0; i < 3 * Vo; ++i) g_obj[(long)b * Vo * 3 + i] = -(float)acc[i] * (1.0f / FIX);
+        free(acc);
+    }
+}
+
+/* Collision term, one ordered pair (reference homan/interactions/scenesdf.py:124-146): d sum_i trilinear(phi, (p_i - c) / s) /
+ * d p_i for the points p (B,V,3) against the clamped SDF grid phi (B,N,N,N; [z][y][x], zero outside the mesh and out of
+ * bounds) of the mesh whose box is boxes (B,4) = centre xyz, scale.  align_corners = False.  Element-wise; csrc/sdf.hip
+ * k_sdf_sample.  -> g (B,V,3) */
+void orc_sdf_sample_grad(const float *pts, const float *boxes, const float *phig, int B, int V, int N, float *g)
+{
+#pragma omp parallel for schedule(static)
+    for (long bi = 0; bi < (long)B * V; ++bi) {
+        const int b = (int)(bi / V);
+        const float *p = pts + bi * 3, *bx = boxes + b * 4;
+        const float *phik = phig + (long)b * N * N * N;
+        const float lx = (p[0] - bx[0]) / bx[3], ly = (p[1] - bx[1]) / bx[3], lz = (p[2] - bx[2]) / bx[3];
+        const float ix = ((lx + 1.0f) * (float)N - 1.0f) / 2.0f;
+        const float iy = ((ly + 1.0f) * (float)N - 1.0f) / 2.0f;
+        const float iz = ((lz + 1.0f) * (float)N - 1.0f) / 2.0f;
+        const int x0 = (int)floorf(fminf(fmaxf(ix, -4.0f), (float)N + 4.0f));
+        const int y0 = (int)floorf(fminf(fmaxf(iy, -4.0f), (float)N + 4.0f));
+        const int z0 = (int)floorf(fminf(fmaxf(iz, -4.0f), (float)N + 4.0f));
+        float phi[8];
+        for (int c = 0; c < 8; ++c) {
+            const int xx = x0 + (c & 1), yy = y0 + ((c >> 1) & 1), zz = z0 + (c >> 2);
+            phi[c] = (xx >= 0 && xx < N && yy >= 0 && yy < N && zz >= 0 && zz < N) ? phik[((long)zz * N + yy) * N + xx] : 0.f;
+        }
+        const float x1 = (float)x0 + 1.0f, y1 = (float)y0 + 1.0f, z1 = (float)z0 + 1.0f;
+        const float wx[2] = {x1 - ix, ix - (float)x0}, wy[2] = {y1 - iy, iy - (float)y0}, wz[2] = {z1 - iz, iz - (float)z0};
+        float gx = 0.f, gy = 0.f, gz = 0.f;
+        for (int c = 0; c < 8; ++c) {
+            const int dx = c & 1, dy = (c >> 1) & 1, dz = c >> 2;
+            const float q = phi[c];
+            gx += (dx ? q : -q) * wy[dy] * wz[dz];
+            gy += (dy ? q : -q) * wx[dx] * wz[dz];
+            gz += (dz ? q : -q) * wx[dx] * wy[dy];
+        }
+        const float s = (0.5f * (float)N) / bx[3];
+        g[bi * 3] = gx * s; g[bi * 3 + 1] = gy * s; g[bi * 3 + 2] = gz * s;
     }
 }

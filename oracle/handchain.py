@@ -4,7 +4,8 @@ oracle/__init__.py).
 `hand_param_grads(model, loss_weights)` evaluates, for an `oracle.model.OracleHOMan` (one hand, optimize_mano, the hand scale a
 buffer) at its current parameters, the gradients of
     lw_v2d_hand * loss_v2d_hand + lw_smooth_hand * loss_smooth_hand + lw_inter * loss_inter + lw_pca * loss_pca
-- the terms that reach the hand in the step-1 loss sets of reference homan/homan.py:421-508 - with respect to mano_pca_pose,
+    [+ lw_collision * loss_collision + lw_contact * loss_contact]
+- the terms that reach the hand in the step-1 [step-2] loss sets of reference homan/homan.py:421-508 - with respect to mano_pca_pose,
 mano_rot, mano_betas, mano_trans, rotations_hand and translations_hand, as one fixed sequence of IEEE fp32 operations
 (oracle/csrc/lbs_exact.c: orc_hand_chain, orc_v2d_unit_grad, orc_inter_rec).  Same mathematics as autograd through
 `OracleHOMan.forward` (tests/test_objchain.py: equal within fp32 rounding); every reduction runs in a stated order - the one
@@ -16,6 +17,9 @@ Chain (file:line of what each stage restates):
   coarse interaction: gate + centroid difference per frame    homan/losses.py:199-242 (reaches the rigid pose only: the mesh
                                                               is detached there, homan/homan.py:482-490)
   PCA prior                                                   homan/lossutils.py:39-40
+  collision: trilinear samples of the object's clamped SDF     homan/lossutils.py:43-64, interactions/scenesdf.py:77-148
+  contact: nearest object vertex, tanh-saturated distance      homan/lossutils.py:112-130, interactions/contactloss.py:60-79,
+                                                              162-163, 228-257 (also reaches the object: oracle/objchain.py)
   rigid transform backward, rot6d backward                    homan/utils/camera.py:108-139, utils/geometry.py:9-27
   MANO layer backward (skinning, blend shapes, chain,         homan/manomodel.py:84-151 (smplx-style LBS)
   Rodrigues, PCA)
@@ -49,14 +53,69 @@ def inter_records(vh, vo, camintr):
     return rec
 
 
-def hand_param_grads(model, loss_weights, return_stages=False):
+COLLISION_THRESH = 0.020     # reference homan/interactions/contactloss.py compute_contact_loss default (lossutils.py:112-130)
+SDF_SCALE_FACTOR = 0.2       # reference homan/interactions/scenesdf.py:77 SDFSceneLoss.forward(scale_factor=0.2)
+SDF_N = 32
+
+
+def nearest_object_vertex(vh, vo):
+    B, Vh = vh.shape[:2]
+    idx = np.empty((B, Vh), np.int32)
+    clib.lib().orc_nn_search(clib.fptr(vh), clib.fptr(vo), B, Vh, vo.shape[1], clib.iptr(idx))
+    return idx
+
+
+def contact_unit_grads(vh, vo, idx):
+    """-> (d loss_contact / d hand vertices (B,Vh,3), d loss_contact / d object vertices (B,Vo,3))"""
+    B, Vh, Vo = vh.shape[0], vh.shape[1], vo.shape[1]
+    gh, go = np.empty((B, Vh, 3), f32), np.empty((B, Vo, 3), f32)
+    clib.lib().orc_contact_grads(clib.fptr(vh), clib.fptr(vo), clib.iptr(idx), B, Vh, Vo, COLLISION_THRESH, B, clib.fptr(gh),
+                                 clib.fptr(go))
+    return gh, go
+
+
+def scene_box(verts):
+    """(B,V,3) -> (B,4) = centre xyz, scale of the normalised box (scenesdf.py:100-112; csrc/sdf.hip k_sdf_boxes)"""
+    lo, hi = verts.min(1), verts.max(1)
+    ctr = (lo + hi) / f32(2.0)
+    sc = ((hi - lo) * ((f32(1.0) + f32(SDF_SCALE_FACTOR)) * f32(0.5))).max(1)
+    return np.ascontiguousarray(np.concatenate([ctr, sc[:, None]], 1), f32)
+
+
+def collision_unit_grad(points, mesh_verts, mesh_faces):
+    """d loss_collision / d points (B,V,3): `points` sampled in the clamped SDF of the mesh (mesh_verts (B,Vm,3), mesh_faces (F,3));
+    the other ordered pair of the scene reaches the mesh that is detached in the step-2 objective (homan/homan.py:476-480)."""
+    from . import sdfgrid
+    box = scene_box(mesh_verts)
+    local = np.ascontiguousarray((mesh_verts - box[:, None, :3]) / box[:, None, 3:4], f32)
+    phi = sdfgrid.SDF(clamp_outside=True)(torch.as_tensor(mesh_faces).int(), torch.from_numpy(local), SDF_N).numpy()
+    phi = np.ascontiguousarray(np.maximum(phi, f32(0.0)), f32)
+    g = np.empty_like(points)
+    clib.lib().orc_sdf_sample_grad(clib.fptr(points), clib.fptr(box), clib.fptr(phi), points.shape[0], points.shape[1], SDF_N,
+                                   clib.fptr(g))
+    return g, dict(box=box, phi=phi)
+
+
+def pair_terms(model, vh, vo, loss_weights):
+    """The step-2 terms between the two meshes at their current vertices -> dict(col_hand, con_hand, con_obj, nn_idx, ...)"""
+    out = {}
+    if loss_weights.get("lw_collision", 0.0) > 0:
+        out["col_hand"], out["col_stage"] = collision_unit_grad(vh, vo, model.faces_object[0].numpy())
+    if loss_weights.get("lw_contact", 0.0) > 0:
+        out["nn_idx"] = nearest_object_vertex(vh, vo)
+        out["con_hand"], out["con_obj"] = contact_unit_grads(vh, vo, out["nn_idx"])
+    return out
+
+
+def hand_param_grads(model, loss_weights, return_stages=False, pair=None):
     """-> {name: float32 numpy array shaped like the parameter} for the six hand parameters (see the module docstring)."""
     lw = loss_weights
     on = lambda k: lw.get(k, 0.0) > 0
-    if (on("lw_collision") or on("lw_contact") or on("lw_depth") or on("lw_sil_hand") or model.hand_nb != 1 or
-            not model.optimize_mano or not isinstance(model.mano_betas, torch.nn.Parameter) or
-            model.int_scales_hand.requires_grad or model.losses.inter_type != "centroid"):
-        raise NotImplementedError("the written-out hand chain covers the step-1 loss sets of a one-hand clip")
+    if (on("lw_depth") or on("lw_sil_hand") or model.hand_nb != 1 or not model.optimize_mano or
+            not isinstance(model.mano_betas, torch.nn.Parameter) or model.int_scales_hand.requires_grad or
+            model.losses.inter_type != "centroid" or model.optimize_object_scale):
+        raise NotImplementedError("the written-out hand chain covers the step-1 / step-2 loss sets of a one-hand clip with a "
+                                  "fixed object scale")
     side = model.hand_sides[0]
     c = lambda t: np.ascontiguousarray(t.detach().numpy(), f32)
     with torch.no_grad():
@@ -72,6 +131,12 @@ def hand_param_grads(model, loss_weights, return_stages=False):
         terms.append((smooth_unit_grad(vh), lw["lw_smooth_hand"]))
     if on("lw_v2d_hand"):
         terms.append((v2d_unit_grad(vh, K, c(model.ref_verts2d_hand), model.image_size), lw["lw_v2d_hand"]))
+    if on("lw_collision") or on("lw_contact"):
+        pair = pair_terms(model, vh, vo, lw) if pair is None else pair
+        if on("lw_collision"):
+            terms.append((pair["col_hand"], lw["lw_collision"]))
+        if on("lw_contact"):
+            terms.append((pair["con_hand"], lw["lw_contact"]))
     rec = inter_records(vh, vo, K) if on("lw_inter") else None
     pca = c(model.mano_pca_pose)
     P = pca.shape[1]
@@ -96,5 +161,5 @@ def hand_param_grads(model, loss_weights, return_stages=False):
     out["rotations_hand"] = out["rotations_hand"].reshape(B, 3, 2)
     out["translations_hand"] = out["translations_hand"].reshape(B, 1, 3)
     if return_stages:
-        return out, dict(mesh=mesh, vh=vh, vo=vo, terms=terms, rec=rec)
+        return out, dict(mesh=mesh, vh=vh, vo=vo, terms=terms, rec=rec, pair=pair)
     return out

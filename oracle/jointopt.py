@@ -10,6 +10,7 @@ sum, backward, step (:178-192).
 """
 from collections import defaultdict
 
+import numpy as np
 import torch
 
 from . import yana
@@ -44,10 +45,16 @@ def reproducible_step(model, loss_weights, optimizer, log2q=0):
     finally:
         for p in obj:
             p.requires_grad_(True)
-    grads = objchain.object_pose_grads(model, loss_weights, log2q)
-    try:        # the hand's chain in its written-out order too, where it covers the loss set (one hand, step-1 terms)
-        from . import handchain
-        grads.update(handchain.hand_param_grads(model, loss_weights))
+    from . import handchain
+    pair = None
+    if loss_weights.get("lw_contact", 0) > 0 or loss_weights.get("lw_collision", 0) > 0:     # step-2 terms between the meshes
+        with torch.no_grad():
+            vh = np.ascontiguousarray(model.get_verts_hand()[0].numpy(), np.float32)
+            vo = np.ascontiguousarray(model.get_verts_object()[0].numpy(), np.float32)
+        pair = handchain.pair_terms(model, vh, vo, loss_weights)
+    grads = objchain.object_pose_grads(model, loss_weights, log2q, contact_obj=pair.get("con_obj") if pair else None)
+    try:        # the hand's chain in its written-out order too, where it covers the configuration (one hand, fixed scale)
+        grads.update(handchain.hand_param_grads(model, loss_weights, pair=pair))
     except NotImplementedError:
         pass    # (autograd's gradients stay: same mathematics, rounding left to torch)
     for k, g in grads.items():

@@ -90,11 +90,13 @@ def rigid_bwd_sil_exact(mesh, rot6d, scale, abs_scale, terms, parts, adj, cam_ve
     return g_rot, g_tr, g_sc, g_v
 
 
-def object_pose_grads(model, loss_weights, log2q=0, return_stages=False):
-    """-> {"rotations_object": (B,3,2), "translations_object": (B,1,3)} float32 numpy (see the module docstring)."""
+def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact_obj=None):
+    """-> {"rotations_object": (B,3,2), "translations_object": (B,1,3)} float32 numpy (see the module docstring).
+    contact_obj: d loss_contact / d object vertices (B,V,3) of the step-2 sets (oracle/handchain.py pair_terms)."""
     lw = loss_weights
-    if lw.get("lw_contact", 0) > 0 or lw.get("lw_depth", 0) > 0 or model.optimize_object_scale:
-        raise NotImplementedError("the written-out object chain covers the step-1 loss sets (silhouette + smoothness)")
+    if lw.get("lw_depth", 0) > 0 or model.optimize_object_scale or (lw.get("lw_contact", 0) > 0 and contact_obj is None):
+        raise NotImplementedError("the written-out object chain covers silhouette + smoothness (+ the contact term's gradient "
+                                  "on the object's vertices, handed in) at a fixed scale")
     with torch.no_grad():
         verts_t, _ = model.get_verts_object()
         rend = model.losses.renderer
@@ -119,6 +121,8 @@ def object_pose_grads(model, loss_weights, log2q=0, return_stages=False):
     terms = []
     if lw.get("lw_smooth_obj", 0) > 0 or lw.get("lw_smooth_hand", 0) > 0:
         terms.append((smooth_unit_grad(verts), lw["lw_smooth_obj"]))
+    if lw.get("lw_contact", 0) > 0:
+        terms.append((np.ascontiguousarray(contact_obj, f32), lw["lw_contact"]))
     adj = build_adjacency(model.faces_object[0].numpy(), V)
     mesh = np.ascontiguousarray(model.verts_object_og.detach().numpy(), f32)
     rot6d = np.ascontiguousarray(model.rotations_object.detach().numpy().reshape(B, 6), f32)

@@ -27,26 +27,42 @@ def _pair(mano_model, seed, frames, size, obj):
     return HOMan(**copy.deepcopy(kw), **common), OracleHOMan(**copy.deepcopy(kw), **common)
 
 
-@pytest.mark.parametrize("weights_name,obj", [("STEP1_LOSS_WEIGHTS", "bottle"), ("CFG1_LOSS_WEIGHTS", "cube")])
+@pytest.mark.parametrize("weights_name,obj", [("STEP1_LOSS_WEIGHTS", "bottle"), ("CFG1_LOSS_WEIGHTS", "cube"),
+                                              ("STEP2_LOSS_WEIGHTS", "bottle")])
 def test_hand_gradients_bit_equal(weights_name, obj, mano_model):
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
-    from oracle import handchain
+    from oracle import handchain, objchain
     hm, om = _pair(mano_model, seed=11, frames=6, size=128, obj=obj)
     g = torch.Generator().manual_seed(3)
     with torch.no_grad():        # off the initial pose: non-zero shape / PCA coefficients / model-space translation
-        for name, amp in (("mano_betas", 0.3), ("mano_pca_pose", 0.2), ("mano_trans", 0.01), ("mano_rot", 0.05)):
+        moves = [("mano_betas", 0.3), ("mano_pca_pose", 0.2), ("mano_trans", 0.01), ("mano_rot", 0.05)]
+        for name, amp in moves:
             d = amp * torch.randn(getattr(om, name).shape, generator=g)
             getattr(om, name).add_(d)
             getattr(hm, name).add_(d.to(getattr(hm, name).device))
+        if weights_name == "STEP2_LOSS_WEIGHTS":     # the hand pushed INTO the object: the collision term is active
+            d = 0.6 * (om.translations_object - om.translations_hand)
+            om.translations_hand.add_(d)
+            hm.translations_hand.add_(d.to(hm.translations_hand.device))
     lw = dict(getattr(synth, weights_name))
     st = FusedStepper(hm, lw, 1e-2, 4, capture=False)
     st.forward_backward(log=True)
     torch.cuda.synchronize()
     want, stg = handchain.hand_param_grads(om, lw, return_stages=True)
+    if weights_name == "STEP2_LOSS_WEIGHTS":
+        pair = stg["pair"]
+        assert np.array_equal(st.nn_idx.cpu().numpy(), pair["nn_idx"])
+        assert np.array_equal(st.U_conh.cpu().numpy(), pair["con_hand"]) and np.array_equal(st.U_cono.cpu().numpy(), pair["con_obj"])
+        assert np.abs(pair["col_hand"]).max() > 0                      # (the term is live in this scene)
+        assert np.array_equal(st.U_colh.cpu().numpy(), pair["col_hand"])
+        want_o = objchain.object_pose_grads(om, lw, contact_obj=pair["con_obj"])
+        for k, v in want_o.items():
+            assert np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v), k
     assert np.array_equal(st.vh.cpu().numpy(), stg["vh"]) and np.array_equal(st.vm.cpu().numpy(), stg["mesh"])
     assert np.array_equal(st.vo.cpu().numpy(), stg["vo"])
-    names = [n for n, on in (("U_smh", lw["lw_smooth_hand"] > 0 or lw["lw_smooth_obj"] > 0), ("U_v2d", lw["lw_v2d_hand"] > 0)) if on]
+    names = [n for n, on in (("U_smh", lw["lw_smooth_hand"] > 0 or lw["lw_smooth_obj"] > 0), ("U_v2d", lw["lw_v2d_hand"] > 0),
+                             ("U_colh", lw["lw_collision"] > 0), ("U_conh", lw["lw_contact"] > 0)) if on]
     for n, (arr, _) in zip(names, stg["terms"]):
         assert np.array_equal(getattr(st, n).cpu().numpy(), arr), n
     if stg["rec"] is not None:
@@ -58,14 +74,16 @@ def test_hand_gradients_bit_equal(weights_name, obj, mano_model):
     assert all(eq for eq, _ in report.values()), report
 
 
-def test_every_parameter_bit_equal_in_a_free_run(mano_model):
-    """30 free-running steps of the step-1 loss set (reference loop homan/jointopt.py:158-192): HIP fused loop vs the oracle's
-    reproducible loop (written-out object chain, hand chain and Adam) - EVERY parameter bit-equal after every step."""
+@pytest.mark.parametrize("weights_name", ["STEP1_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS"])
+def test_every_parameter_bit_equal_in_a_free_run(weights_name, mano_model):
+    """30 free-running steps of the step-1 / step-2 loss sets (reference loop homan/jointopt.py:158-192): HIP fused loop vs the
+    oracle's reproducible loop (written-out object chain, hand chain, pair terms and Adam) - EVERY parameter bit-equal after
+    every step."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle.jointopt import make_optimizer, reproducible_step
     hm, om = _pair(mano_model, seed=12, frames=6, size=128, obj="bottle")
-    lw = dict(synth.STEP1_LOSS_WEIGHTS)
+    lw = dict(getattr(synth, weights_name))
     st = FusedStepper(hm, lw, 1e-2, 30)
     opt = make_optimizer(om, 1e-2, reproducible=True)
     for i in range(30):

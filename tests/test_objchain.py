@@ -68,7 +68,46 @@ def test_written_out_hand_chain_equals_autograd(weights_name, mano_model):
         assert scale > 0, name
         np.testing.assert_allclose(g.reshape(ref.shape) / scale, ref / scale, atol=2e-5, err_msg=name)
     with pytest.raises(NotImplementedError):
-        handchain.hand_param_grads(model, dict(synth.STEP2_LOSS_WEIGHTS))
+        handchain.hand_param_grads(model, dict(synth.STEP2_LOSS_WEIGHTS, lw_depth=1.0))
+
+
+def test_written_out_step2_terms_equal_autograd(mano_model):
+    """The step-2 terms written out (oracle/handchain.py pair_terms: nearest object vertex, contact, collision samples) against
+    autograd through the faithful restatement, with the hand pushed into the object so that the collision term is live.
+    The written-out search differences the coordinates before squaring (as the kernels do); the reference's |a|^2 + |b|^2 - 2ab
+    (contactloss.py:60-79; its rounding error at |a|^2 ~ 0.36 m^2 is ~4e-8 m^2) names another neighbour for a few hand
+    vertices with two object vertices at almost the same distance: the contact term's own gradient on the object's rotation
+    differs by ~2 % of ITS largest entry there - 1e-4 of the whole gradient.  That is the tolerance below."""
+    from homan_amd import synth
+    from oracle import handchain, objchain
+    from oracle import yana as o_yana
+    model, _ = _clip_model(mano_model, seed=2, obj="bottle")
+    with torch.no_grad():
+        model.translations_hand.add_(torch.tensor([0.03, 0.0, 0.0]))
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    loss_dict, _ = model(loss_weights=lw)
+    assert float(loss_dict["loss_collision"].detach()) > 0
+    sum(loss_dict[k] * lw[k.replace("loss", "lw")] for k in loss_dict).backward()
+    got, stg = handchain.hand_param_grads(model, lw, return_stages=True)
+    got.update(objchain.object_pose_grads(model, lw, contact_obj=stg["pair"]["con_obj"]))
+    for name, g in got.items():
+        ref = getattr(model, name).grad.numpy()
+        scale = np.abs(ref).max()
+        np.testing.assert_allclose(g.reshape(ref.shape) / scale, ref / scale, atol=3e-4 if "object" in name else 5e-5, err_msg=name)
+    # the picks themselves: the same vertex, or one at the same distance to within the expansion's rounding
+    with torch.no_grad():
+        vh, vo = model.get_verts_hand()[0], model.get_verts_object()[0]
+        ref_idx = torch.min(o_yana.batch_pairwise_dist(vh, vo), 2)[1].numpy()
+    idx = stg["pair"]["nn_idx"]
+    other = np.nonzero(idx != ref_idx)
+    assert len(other[0]) < 0.05 * idx.size
+    d2 = lambda ii: ((stg["vh"][other[0], other[1]].astype(np.float64) - stg["vo"][other[0], ii[other]]) ** 2).sum(-1)
+    assert np.all(np.abs(d2(idx) - d2(ref_idx)) < 1e-7) and np.all(d2(idx) <= d2(ref_idx) + 1e-12)       # (squared metres)
+    # tanh as a defined function: within half an ulp of libm's in double
+    from oracle import clib
+    xs = np.concatenate([np.linspace(0, 12, 50001), [1e-9, 25.0]]).astype(np.float32)
+    err = max(abs(float(clib.lib().orc_tanh(float(x))) - np.tanh(np.float64(x))) / max(np.tanh(np.float64(x)), 1e-30) for x in xs[1:])
+    assert err < 6.1e-8, err
 
 
 def test_written_out_mano_layer_equals_the_torch_restatement(mano_model):
@@ -157,7 +196,7 @@ np.save(sys.argv[2], np.concatenate([p.detach().numpy().ravel() for _, p in sort
 """
 
 
-@pytest.mark.parametrize("weights_name", ["CFG1_LOSS_WEIGHTS", "STEP1_LOSS_WEIGHTS"])
+@pytest.mark.parametrize("weights_name", ["CFG1_LOSS_WEIGHTS", "STEP1_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS"])
 def test_trajectory_does_not_depend_on_the_thread_count(weights_name, tmp_path):
     """the oracle's end state was a function of OMP_NUM_THREADS.  With the written-out chains (object: oracle/
     objchain.py, hand: oracle/handchain.py) EVERY parameter after 12 steps is bit-identical at 1 and 4 threads."""

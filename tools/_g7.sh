@@ -1,2 +1,2 @@
 R=$(pwd); O=$R/gpurun_out
-timeout 2700 python -m pytest tests -m gpu -q > $O/g36_tests.log 2>&1; tail -6 $O/g36_tests.log
+timeout 1200 python -m pytest tests/test_handchain_gpu.py -q > $O/g37_hand.log 2>&1; tail -40 $O/g37_hand.log | cut -c1-400
