@@ -790,8 +790,9 @@ def main():
                          "HIP parameters (teacher-forced), plus the free-running comparison; 0 = skip")
     ap.add_argument("--freerun", type=int, default=100,
                     help="final_loss_parity.free_run: this many FREE-running steps of the headline clip on the HIP loop and on the "
-                         "CPU oracle's reproducible loop - object pose parameters bit-equal after every step, losses within 1e-4, "
-                         "final vertices within 1e-3 mm (profiles/ holds a 400-step run); 0 = skip")
+                         "CPU oracle's reproducible loop - every parameter bit-equal after every step, losses within 1e-4, "
+                         "final vertices identical (profiles/ holds 400-step runs of cfg2 and cfg3; with --step2 at most 40 steps, "
+                         "the CPU side runs 0.5 it/s); 0 = skip")
     ap.add_argument("--e2e-clips", type=int, default=16,
                     help="end_to_end: this many clips of the headline shape fitted 400 steps each through resident steppers "
                          "(ClipFitter), wall clock from the input dicts to the results on the host; 0 = skip")
@@ -1005,12 +1006,15 @@ def main():
                                                 free_run=not args.depth, ordinal_depth=args.depth)
                                 if args.lockstep > 0 else None),
                       cfg1=cfg1_parity(mano, seeds=list(range(args.parity_seeds))) if args.parity_seeds > 0 else None,
-                      free_run=(free_run_parity(mano, step2=False, steps=args.freerun, frames=B, size=S, clip=clip, lw=lw)
-                                if args.freerun > 0 and not args.step2 and not args.depth else None),
+                      free_run=(free_run_parity(mano, step2=args.step2, steps=min(args.freerun, 40) if args.step2 else args.freerun,
+                                                frames=B, size=S, clip=clip, lw=lw)
+                                if args.freerun > 0 and not args.depth else None),
                       bar="north_star: 1e-4 relative on losses, 1e-3 mm on final vertices.  cfg1 / free_run compare FREE-running "
-                          "trajectories: the object's gradient chain sums in an order-independent way on both sides (DESIGN.md 2), "
-                          "so no sample flips; cfg2_first_steps is the headline run against the cpu_baseline leg's plain oracle "
-                          "loop (torch Adam, autograd), which separates once a sample flips")
+                          "trajectories: the object's gradient chain sums in an order-independent way and the hand's chain and "
+                          "the step-2 pair terms run in one stated order on both sides (DESIGN.md 2), so EVERY parameter is "
+                          "bit-equal after every step (profiles/r04_freerun_cfg{2,3}_400.json: 400 steps); cfg2_first_steps is "
+                          "the headline run against the cpu_baseline leg's plain oracle loop (torch Adam, autograd), which "
+                          "separates once a sample flips")
 
     e2e = None
     if rank == 0 and world == 1 and fused and args.e2e_clips > 0 and not args.depth:

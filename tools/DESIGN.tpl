@@ -148,18 +148,31 @@ object's chain is closed on itself (`homan/homan.py:482-490`: `loss_inter` sees 
   side (`orc_hand_chain`: per-vertex terms, the rigid backward's 12 sums, skinning / blend-shape / chain / Rodrigues / PCA
   backward with the kernels' reduction trees; `orc_v2d_unit_grad`, `orc_inter_rec`; `oracle/handchain.py`).  The torch
   restatement of the layer (`oracle/lbs.py`, `oracle.model.REFERENCE_FORM`) stays: both forms are pinned to the reference's
-  goldens (`tests/test_oracle_golden.py`, both parametrisations) and to each other within an ulp.
+  goldens (`tests/test_oracle_golden.py`, both parametrisations) and to each other within an ulp;
+* the step-2 PAIR TERMS the same way (`oracle/handchain.py` `pair_terms`, C in `oracle/csrc/lbs_exact.c`): the nearest object
+  vertex of every hand vertex by differenced coordinates, ties to the lowest index (`orc_nn_search` <-> `nn_full_body`); the
+  contact term with a shared `hm_tanh` (ln2 reduction + the fdlibm exp kernel in double; OCML's and glibc's `tanhf` differ in the
+  last bit), element-wise on the hand, on the object the kernels' 2^-44 fixed-point sum of the picks' gradients - an integer sum,
+  exact in any order (`orc_contact_grads` <-> `k_contact_both`); the collision term's gradient as the eight-corner trilinear
+  expression of `k_sdf_sample` on the oracle's own SDF grid (`orc_sdf_sample_grad`; the grids - a min over triangles of one
+  shared point-triangle routine, signs by ray parity - were bit-equal already).  One deviation from the reference's arithmetic
+  is inherited from the kernels and stated: the reference ranks neighbours by `|a|^2 + |b|^2 - 2ab` (contactloss.py:60-79), whose
+  rounding (~4e-8 m^2 at |a|^2 ~ 0.36 m^2) names another neighbour when two object vertices are within that of each other; the
+  faithful form stays in `oracle/model.py`, and `tests/test_objchain.py` bounds the difference (picks at the same distance
+  to 1e-7 m^2, gradients within 3e-4).
 
 Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`,
 `profiles/r04_freerun_*.json`): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
 `translations_hand`, `mano_pca_pose`, `mano_rot`, `mano_betas`, `mano_trans` - is BIT-EQUAL between the two free-running loops
-after every step: cfg1 100 steps x 5 seeds, cfg2 at full size over 400 steps (`all_params_bit_equal_all_steps: true`), final
+after every step: cfg1 100 steps x 5 seeds, cfg2 and cfg3 (step-2: collision + contact) at full size over 400 steps
+(`r04_freerun_cfg2_400.json`, `r04_freerun_cfg3_400.json`: `all_params_bit_equal_all_steps: true`), final
 vertices 0.0 mm apart for the object AND the hand, every logged loss within 3.4e-7 at every step (bar 1e-4; the logged VALUES are
 parallel float sums and keep their rounding, the trajectory does not see them).  Until the hand's chain was written out (first
 half of this round) the hand separated around step 170-180 of the cfg2 clip - 0.14 mm at step 400 - exactly where the CPU loop
 separates from ITSELF when its hand translations start 1e-7 m apart (`r04_control_cfg2_400.json`: 0.85 mm): Adam at 10 x lr on
-the MANO parameters amplifies any difference, so only a chain without any could close it.  The step-2 sets (contact, collision)
-are not written out: there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
+the MANO parameters amplifies any difference, so only a chain without any could close it.  Not written out: the ordinal depth
+term, two hands per frame and a free object scale (`oracle/handchain.py` raises NotImplementedError, the oracle then keeps
+autograd's gradients); there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
 path: nothing at one clip, -2 % on an 8-clip batch (EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the
 divisions; the hand side's kernels did not change but for the sin / cos.
 
@@ -419,9 +432,8 @@ file the reference never reaches.  More than two hands: the reference's own coll
 4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
    silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
    hands it runs one clip per stepper (`ShardStepper`).
-5. The step-2 sets written out like the step-1 sets are: the nearest-vertex search, the contact zones and the SDF collision
-   term (grid build + trilinear samples) in one stated order on both sides.  The hand's and the object's vertices are bit-equal
-   already, so this is oracle work (`oracle/handchain.py` raises NotImplementedError for `lw_contact` / `lw_collision` today) plus
-   order-independent sums where those kernels add with atomics; it would extend the free-running bit-equality from cfg1 / cfg2 to
-   cfg3 / cfg5.
+5. The written-out chains cover one hand, a fixed object scale and the step-1 / step-2 loss sets (cfg1, cfg2, cfg3).  cfg5's
+   free object scale (one more sum per frame in the rigid backward, the prior, the tied gradient), two hands (the second hand's
+   rows through the left model; three SDF scenes) and the ordinal depth term (two more renders and their pair-wise sums) are not:
+   free-running fits of those configurations are compared per step (lock-step) only.
 6. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.
