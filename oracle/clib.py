@@ -62,6 +62,8 @@ def lib():
         _lib.orc_contact_grads.restype = None
         _lib.orc_sdf_sample_grad.argtypes = [fp, fp, fp, ci, ci, ci, fp]
         _lib.orc_sdf_sample_grad.restype = None
+        _lib.orc_block_sum.argtypes = [fp, ci, ci]
+        _lib.orc_block_sum.restype = cf
         _lib.orc_tanh.argtypes = [cf]
         _lib.orc_tanh.restype = cf
         _lib.orc_sincos.argtypes = [cf, fp, fp]

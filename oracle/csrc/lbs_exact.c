@@ -617,3 +617,18 @@ void orc_sdf_sample_grad(const float *pts, const float *boxes, const float *phig
         g[bi * 3] = gx * s; g[bi * 3 + 1] = gy * s; g[bi * 3 + 2] = gz * s;
     }
 }
+
+/* hm_block_sum of n values taken by `nthreads` threads in strides (csrc/hm_common.h): thread t adds parts[t], parts[t + nthreads],
+ * ...; the 64 threads of a wave meet in oc_wave_sum; the wave results are added in wave order. */
+float orc_block_sum(const float *parts, int n, int nthreads)
+{
+    float a[1024];
+    for (int t = 0; t < nthreads; ++t) {
+        float acc = 0.f;
+        for (int i = t; i < n; i += nthreads) acc += parts[i];
+        a[t] = acc;
+    }
+    float tot = 0.f;
+    for (int w = 0; w < nthreads / 64; ++w) tot += oc_wave_sum(a + 64 * w);
+    return tot;
+}

@@ -113,9 +113,8 @@ def hand_param_grads(model, loss_weights, return_stages=False, pair=None):
     on = lambda k: lw.get(k, 0.0) > 0
     if (on("lw_depth") or on("lw_sil_hand") or model.hand_nb != 1 or not model.optimize_mano or
             not isinstance(model.mano_betas, torch.nn.Parameter) or model.int_scales_hand.requires_grad or
-            model.losses.inter_type != "centroid" or model.optimize_object_scale):
-        raise NotImplementedError("the written-out hand chain covers the step-1 / step-2 loss sets of a one-hand clip with a "
-                                  "fixed object scale")
+            model.losses.inter_type != "centroid"):
+        raise NotImplementedError("the written-out hand chain covers the step-1 / step-2 loss sets of a one-hand clip")
     side = model.hand_sides[0]
     c = lambda t: np.ascontiguousarray(t.detach().numpy(), f32)
     with torch.no_grad():

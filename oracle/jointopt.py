@@ -36,6 +36,8 @@ def reproducible_step(model, loss_weights, optimizer, log2q=0):
     from . import objchain
     optimizer.zero_grad()
     obj = (model.rotations_object, model.translations_object)
+    if model.optimize_object_scale:         # (the scale's gradient needs the renderer's backward: autograd walks it then)
+        obj = ()
     for p in obj:               # (their gradients come from the written-out chain below: autograd need not walk the renderer)
         p.requires_grad_(False)
     try:
@@ -52,7 +54,14 @@ def reproducible_step(model, loss_weights, optimizer, log2q=0):
             vh = np.ascontiguousarray(model.get_verts_hand()[0].numpy(), np.float32)
             vo = np.ascontiguousarray(model.get_verts_object()[0].numpy(), np.float32)
         pair = handchain.pair_terms(model, vh, vo, loss_weights)
-    grads = objchain.object_pose_grads(model, loss_weights, log2q, contact_obj=pair.get("con_obj") if pair else None)
+    rec = None
+    if model.optimize_object_scale and loss_weights.get("lw_inter", 0) > 0:     # (the term then reaches the object too)
+        with torch.no_grad():
+            rec = handchain.inter_records(np.ascontiguousarray(model.get_verts_hand()[0].numpy(), np.float32),
+                                          np.ascontiguousarray(model.get_verts_object()[0].numpy(), np.float32),
+                                          np.ascontiguousarray(model.camintr.numpy(), np.float32))
+    grads = objchain.object_pose_grads(model, loss_weights, log2q, contact_obj=pair.get("con_obj") if pair else None,
+                                       inter_rec=rec)
     try:        # the hand's chain in its written-out order too, where it covers the configuration (one hand, fixed scale)
         grads.update(handchain.hand_param_grads(model, loss_weights, pair=pair))
     except NotImplementedError:

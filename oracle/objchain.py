@@ -90,13 +90,17 @@ def rigid_bwd_sil_exact(mesh, rot6d, scale, abs_scale, terms, parts, adj, cam_ve
     return g_rot, g_tr, g_sc, g_v
 
 
-def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact_obj=None):
-    """-> {"rotations_object": (B,3,2), "translations_object": (B,1,3)} float32 numpy (see the module docstring).
-    contact_obj: d loss_contact / d object vertices (B,V,3) of the step-2 sets (oracle/handchain.py pair_terms)."""
+def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact_obj=None, inter_rec=None):
+    """-> {"rotations_object": (B,3,2), "translations_object": (B,1,3)[, "int_scales_object": (1,)]} float32 numpy (see the module
+    docstring).  contact_obj: d loss_contact / d object vertices (B,V,3) of the step-2 sets (oracle/handchain.py pair_terms).
+    With a free object scale (optimize_object_scale; the object is then NOT detached in the interaction term, homan/homan.py:
+    482-490) inter_rec (B,8) are that term's per-frame records (oracle/handchain.py inter_records)."""
     lw = loss_weights
-    if lw.get("lw_depth", 0) > 0 or model.optimize_object_scale or (lw.get("lw_contact", 0) > 0 and contact_obj is None):
-        raise NotImplementedError("the written-out object chain covers silhouette + smoothness (+ the contact term's gradient "
-                                  "on the object's vertices, handed in) at a fixed scale")
+    free_scale = bool(model.optimize_object_scale)
+    if (lw.get("lw_depth", 0) > 0 or (lw.get("lw_contact", 0) > 0 and contact_obj is None) or
+            (free_scale and lw.get("lw_inter", 0) > 0 and inter_rec is None)):
+        raise NotImplementedError("the written-out object chain covers silhouette + smoothness (+ the contact / interaction "
+                                  "terms' gradients on the object's vertices, handed in)")
     with torch.no_grad():
         verts_t, _ = model.get_verts_object()
         rend = model.losses.renderer
@@ -123,13 +127,25 @@ def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact
         terms.append((smooth_unit_grad(verts), lw["lw_smooth_obj"]))
     if lw.get("lw_contact", 0) > 0:
         terms.append((np.ascontiguousarray(contact_obj, f32), lw["lw_contact"]))
+    if free_scale and lw.get("lw_inter", 0) > 0:
+        # d (lw_inter * loss_inter) / d object vertex = -lw_inter * gate * 2 (c_hand - c_obj) / 3 / V, the same for every vertex
+        gi = (f32(0.0) - f32(lw["lw_inter"])) * np.ascontiguousarray(inter_rec[:, 2:5], f32) / f32(V)
+        terms.append((np.ascontiguousarray(np.broadcast_to(gi[:, None, :], (B, V, 3)), f32), 1.0))
     adj = build_adjacency(model.faces_object[0].numpy(), V)
     mesh = np.ascontiguousarray(model.verts_object_og.detach().numpy(), f32)
     rot6d = np.ascontiguousarray(model.rotations_object.detach().numpy().reshape(B, 6), f32)
     K = np.ascontiguousarray(model.camintr_rois_object.numpy(), f32)
-    g_rot, g_tr, _, g_v = rigid_bwd_sil_exact(mesh, rot6d, float(model.int_scales_object.detach()[0]), 1, terms, parts, adj, verts,
-                                              K, 1.0, F, log2q)
+    g_rot, g_tr, g_sc, g_v = rigid_bwd_sil_exact(mesh, rot6d, float(model.int_scales_object.detach()[0]), 1, terms, parts, adj,
+                                                 verts, K, 1.0, F, log2q)
     out = {"rotations_object": g_rot.reshape(B, 3, 2), "translations_object": g_tr.reshape(B, 1, 3)}
+    if free_scale:
+        # the clip's scale gradient: the frames' partial sums (one 64-thread block sum, csrc/geometry.hip k_sum_small) + the prior
+        # of homan/lossutils.py:107-109 (d (s - mean)^2 = 2 (s - mean))
+        g = f32(1.0) * f32(clib.lib().orc_block_sum(clib.fptr(np.ascontiguousarray(g_sc, f32)), B, 64))
+        if lw.get("lw_scale_obj", 0) > 0:
+            d0 = f32(model.int_scales_object.detach().numpy().reshape(-1)[0]) - f32(np.asarray(model.int_scale_object_mean).reshape(-1)[0])
+            g = g + f32(lw["lw_scale_obj"]) * (f32(2.0) * d0)
+        out["int_scales_object"] = np.asarray([g], f32)
     if return_stages:
         stages.update(g_verts=g_v, terms=terms)
         return out, stages

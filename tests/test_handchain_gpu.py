@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 HAND = ("mano_pca_pose", "mano_rot", "mano_betas", "mano_trans", "rotations_hand", "translations_hand")
 
 
-def _pair(mano_model, seed, frames, size, obj):
+def _pair(mano_model, seed, frames, size, obj, **options):
     from homan_amd import HOMan, synth
     from oracle.jointopt import collate_inputs
     from oracle.model import OracleHOMan
@@ -23,7 +23,7 @@ def _pair(mano_model, seed, frames, size, obj):
                            hand_verts_fn=hand_fn)
     kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
     common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=size,
-                  mano_model=mano_model, rend_size=size)
+                  mano_model=mano_model, rend_size=size, **options)
     return HOMan(**copy.deepcopy(kw), **common), OracleHOMan(**copy.deepcopy(kw), **common)
 
 
@@ -94,3 +94,40 @@ def test_every_parameter_bit_equal_in_a_free_run(weights_name, mano_model):
         diff = [k for k, p in hm.named_parameters()
                 if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
         assert not diff, (i, diff)
+
+
+def test_free_object_scale_bit_equal(mano_model):
+    """optimize_object_scale=True (BASELINE cfg5's option, one clip: the scale free): the step-2 set, gradients of all nine
+    parameters - the scale's among them: the frames' exact partial sums, one block sum, the prior - bit-equal at perturbed
+    parameters, then 25 free-running steps bit-equal in every parameter."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle import handchain, objchain
+    from oracle.jointopt import make_optimizer, reproducible_step
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    hm, om = _pair(mano_model, seed=13, frames=6, size=128, obj="bottle", optimize_object_scale=True)
+    with torch.no_grad():
+        d = 0.6 * (om.translations_object - om.translations_hand)
+        for m in (om, hm):
+            m.translations_hand.add_(d.to(m.translations_hand.device))
+            m.int_scales_object.add_(0.07)
+    st = FusedStepper(hm, lw, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    want, stg = handchain.hand_param_grads(om, lw, return_stages=True)
+    want.update(objchain.object_pose_grads(om, lw, contact_obj=stg["pair"]["con_obj"], inter_rec=stg["rec"]))
+    assert "int_scales_object" in want
+    report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
+    assert all(report.values()), report
+    hm, om = _pair(mano_model, seed=14, frames=6, size=128, obj="bottle", optimize_object_scale=True)
+    st = FusedStepper(hm, lw, 1e-2, 25)
+    opt = make_optimizer(om, 1e-2, reproducible=True)
+    for i in range(25):
+        st.run(1)
+        reproducible_step(om, lw, opt)
+        torch.cuda.synchronize()
+        cpu = dict(om.named_parameters())
+        diff = [k for k, p in hm.named_parameters()
+                if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
+        assert not diff, (i, diff)
+    assert abs(float(om.int_scales_object.detach()[0]) - 1.0) > 1e-3          # (the scale did move)

@@ -141,6 +141,34 @@ def test_written_out_mano_layer_equals_the_torch_restatement(mano_model):
     assert err < 6.1e-8, err             # half an ulp of fp32 at 1
 
 
+def test_written_out_chain_with_a_free_object_scale(mano_model):
+    """optimize_object_scale=True: the interaction term reaches the object (homan/homan.py:482-490), the scale gets the frames'
+    partial sums + its prior (homan/lossutils.py:107-109) - all nine parameters against autograd."""
+    from homan_amd import synth
+    from oracle import handchain, objchain
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=2, frames=4, rend_size=64, image_size=64, obj="bottle", silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    model = OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                        optimize_object_scale=True, image_size=64, mano_model=mano_model, rend_size=64, **kw)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    with torch.no_grad():
+        model.translations_hand.add_(torch.tensor([0.03, 0.0, 0.0]))
+        model.int_scales_object.add_(0.05)
+    loss_dict, _ = model(loss_weights=lw)
+    sum(loss_dict[k] * lw[k.replace("loss", "lw")] for k in loss_dict).backward()
+    got, stg = handchain.hand_param_grads(model, lw, return_stages=True)
+    got.update(objchain.object_pose_grads(model, lw, contact_obj=stg["pair"]["con_obj"], inter_rec=stg["rec"]))
+    assert len(got) == 9
+    for name, g in got.items():
+        ref = getattr(model, name).grad.numpy()
+        scale = np.abs(ref).max()
+        np.testing.assert_allclose(g.reshape(ref.shape) / scale, ref / scale, atol=3e-4 if "rotations_object" in name else 5e-5,
+                                   err_msg=name)
+
+
 def test_exact_pseudo_gradient_equals_the_faithful_loop(mano_model):
     """per (face, corner): the exact-sum variant against orc_nmr_grad_faces_alpha (the published loop order, fp32 sums)"""
     from homan_amd import synth
