@@ -269,6 +269,25 @@ __host__ __device__ __forceinline__ float hm_tanh(float xf)
     return (float)(xf < 0.f ? -th : th);
 }
 
+// ---- logistic function 1 / (1 + exp(-x)) of an fp32 argument as a DEFINED function (same exp kernel as hm_tanh), |x| < ~700:
+// the ordinal depth term's gradient (oracle/csrc/lbs_exact.c oc_sigmoid evaluates the same operations).
+__host__ __device__ __forceinline__ float hm_sigmoid(float xf)
+{
+    const double t = -(double)xf;
+    const double k = __builtin_rint(t * 1.44269504088896338700e+00);
+    const double r = (t - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
+    const double z = r * r;
+    double p = 4.13813679705723846039e-08;
+    p = -1.65339022054652515390e-06 + z * p;
+    p = 6.61375632143793436117e-05 + z * p;
+    p = -2.77777777770155933842e-03 + z * p;
+    p = 1.66666666666666019037e-01 + z * p;
+    const double c = r - z * p;
+    const double er = 1.0 - ((r * c) / (c - 2.0) - r);
+    const double e = __builtin_ldexp(er, (int)k);
+    return (float)(1.0 / (1.0 + e));
+}
+
 // ---- rot6d (3x2 row-major, reference homan/utils/geometry.py:9-27) -> rotation matrix (3x3 row-major)
 __device__ __forceinline__ void rot6d_to_mat(const float* r6 /*3x2 row-major*/, float* R /*3x3 row-major*/)
 {

@@ -2244,11 +2244,11 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
         const float up = upstream[0] / rec[0];
         if (b0 && !b1 && z1 < z0 && rec[1] > 0.f) {
             const float x = z0 - z1;
-            if (x > 0.f && x < 2.f) { const float sg = 1.0f / (1.0f + expf(-x)); r0 += up * sg / rec[1]; r1 -= up * sg / rec[1]; }
+            if (x > 0.f && x < 2.f) { const float sg = hm_sigmoid(x); r0 += up * sg / rec[1]; r1 -= up * sg / rec[1]; }
         }
         if (b1 && !b0 && z0 < z1 && rec[3] > 0.f) {
             const float x = z1 - z0;
-            if (x > 0.f && x < 2.f) { const float sg = 1.0f / (1.0f + expf(-x)); r1 += up * sg / rec[3]; r0 -= up * sg / rec[3]; }
+            if (x > 0.f && x < 2.f) { const float sg = hm_sigmoid(x); r1 += up * sg / rec[3]; r0 -= up * sg / rec[3]; }
         }
     }
     g0[i] = r0;

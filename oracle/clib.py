@@ -62,6 +62,15 @@ def lib():
         _lib.orc_contact_grads.restype = None
         _lib.orc_sdf_sample_grad.argtypes = [fp, fp, fp, ci, ci, ci, fp]
         _lib.orc_sdf_sample_grad.restype = None
+        u8p = ctypes.POINTER(ctypes.c_uint8)
+        _lib.orc_ordinal_depth_grad.argtypes = [fp, fp, u8p, u8p, u8p, u8p, ci, ci, cf, fp, fp, fp]
+        _lib.orc_ordinal_depth_grad.restype = None
+        _lib.orc_depth_bwd_faces.argtypes = [fp, ip, fp, ci, ci, ci, fp]
+        _lib.orc_depth_bwd_faces.restype = None
+        _lib.orc_depth_bwd_gather.argtypes = [fp, ip, ip, fp, fp, ci, ci, ci, cf, fp]
+        _lib.orc_depth_bwd_gather.restype = None
+        _lib.orc_sigmoid.argtypes = [cf]
+        _lib.orc_sigmoid.restype = cf
         _lib.orc_block_sum.argtypes = [fp, ci, ci]
         _lib.orc_block_sum.restype = cf
         _lib.orc_tanh.argtypes = [cf]
@@ -81,6 +90,11 @@ def fptr(a):
 def dptr(a):
     assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def u8ptr(a):
+    assert a.dtype == np.uint8 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
 
 
 def iptr(a):

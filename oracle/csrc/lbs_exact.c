@@ -632,3 +632,192 @@ float orc_block_sum(const float *parts, int n, int nthreads)
     for (int w = 0; w < nthreads / 64; ++w) tot += oc_wave_sum(a + 64 * w);
     return tot;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Ordinal depth term (reference homan/homan.py:384-419, lossutils.py:133-169, as the method intends: the reference's own call
+ * site raises) in the kernels' order: csrc/raster.hip k_ordinal_depth_bwd, k_depth_bwd_faces, k_depth_bwd_gather.
+ * ---------------------------------------------------------------------------------------------------------------------- */
+static float oc_sigmoid(float xf)      /* csrc/hm_common.h hm_sigmoid */
+{
+    const double t = -(double)xf;
+    const double k = rint(t * 1.44269504088896338700e+00);
+    const double r = (t - k * 6.93147180369123816490e-01) - k * 1.90821492927058770002e-10;
+    const double z = r * r;
+    double p = 4.13813679705723846039e-08;
+    p = -1.65339022054652515390e-06 + z * p;
+    p = 6.61375632143793436117e-05 + z * p;
+    p = -2.77777777770155933842e-03 + z * p;
+    p = 1.66666666666666019037e-01 + z * p;
+    const double c = r - z * p;
+    const double er = 1.0 - ((r * c) / (c - 2.0) - r);
+    const double e = ldexp(er, (int)k);
+    return (float)(1.0 / (1.0 + e));
+}
+float orc_sigmoid(float x) { return oc_sigmoid(x); }
+
+/* d (upstream * loss_depth) / d the two pooled depth images.  d0 / d1 (B,S,S) pooled depths, a0 / a1 (B,S,S) uint8: pixel fully
+ * covered (pooled alpha == 1), m0 / m1 (B,S,S) uint8 instance masks; layers 0 = object, 1 = hand.  The normalisers are counts
+ * (exact): pairs = sum over frames of [layer 0 present] + [layer 1 present] + 2 [both on some pixel]; n01 / n10 = pixels where
+ * the annotation puts 0 / 1 in front and the render disagrees.  -> g0, g1 (B,S,S) */
+void orc_ordinal_depth_grad(const float *d0, const float *d1, const uint8_t *a0, const uint8_t *a1, const uint8_t *m0,
+                            const uint8_t *m1, int B, int S, float upstream, float *g0, float *g1, float *rec)
+{
+    const long npx = (long)S * S;
+    float t0 = 0.f, t1 = 0.f, t3 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        long c0 = 0, c1 = 0, c01 = 0, n01 = 0, n10 = 0;
+        for (long i = b * npx; i < (b + 1) * npx; ++i) {
+            c0 += a0[i] != 0; c1 += a1[i] != 0;
+            if (a0[i] && a1[i]) {
+                ++c01;
+                if (m0[i] && !m1[i] && d1[i] < d0[i]) ++n01;
+                if (m1[i] && !m0[i] && d0[i] < d1[i]) ++n10;
+            }
+        }
+        t0 += (c0 ? 1.f : 0.f) + (c1 ? 1.f : 0.f) + 2.f * (c01 ? 1.f : 0.f);
+        t1 += (float)(unsigned)n01;
+        t3 += (float)(unsigned)n10;
+    }
+    rec[0] = t0; rec[1] = t1; rec[3] = t3; rec[2] = rec[4] = 0.f;
+    for (long i = 0; i < B * npx; ++i) {
+        float r0 = 0.f, r1 = 0.f;
+        if (a0[i] && a1[i]) {
+            const float z0 = d0[i], z1 = d1[i];
+            const float up = upstream / t0;
+            if (m0[i] && !m1[i] && z1 < z0 && t1 > 0.f) {
+                const float x = z0 - z1;
+                if (x > 0.f && x < 2.f) { const float sg = oc_sigmoid(x); r0 += up * sg / t1; r1 -= up * sg / t1; }
+            }
+            if (m1[i] && !m0[i] && z0 < z1 && t3 > 0.f) {
+                const float x = z1 - z0;
+                if (x > 0.f && x < 2.f) { const float sg = oc_sigmoid(x); r1 += up * sg / t3; r0 -= up * sg / t3; }
+            }
+        }
+        g0[i] = r0; g1[i] = r1;
+    }
+}
+
+static inline float oc_topix2(float v, int is)
+{
+    float a = v * (float)is;
+    a = a + (float)is;
+    a = a - 1.0f;
+    return 0.5f * a;
+}
+static inline int oc_backside2(const float *f) { return (f[7] - f[1]) * (f[3] - f[0]) < (f[4] - f[1]) * (f[6] - f[0]); }
+
+/* Backward of the pooled depth image w.r.t. the NDC face vertices (NMR backward_depth_map), per (frame, face, winding) in the
+ * order of k_depth_bwd_faces: the face's sample box (k_setup_faces: pixel-space extent, 0.01 px of slack, clipped) is walked
+ * row-major by 64 lanes in strides, each lane adding its samples in turn, the lanes meeting in oc_wave_sum.
+ * faces9 (B,F,9): NDC vertices of the mesh faces; idx_map (B,is,is) owner per sample (face, or F + face for the reversed
+ * winding, -1 empty), is = 2 S; gpd (B,S,S): gradient on the pooled depth.  -> gf9 (B,F,2,9) in winding order */
+void orc_depth_bwd_faces(const float *faces9, const int32_t *idx_map, const float *gpd, int B, int F, int S, float *gf9)
+{
+    const int is = 2 * S;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (long bf = 0; bf < (long)B * F; ++bf) {
+        const int b = (int)(bf / F), fi = (int)(bf % F);
+        const float *src = faces9 + bf * 9;
+        const int32_t *idx = idx_map + (long)b * is * is;
+        const float *g = gpd + (long)b * S * S;
+        float rv[9];
+        for (int k = 0; k < 3; ++k) { rv[3 * k] = src[3 * (2 - k)]; rv[3 * k + 1] = src[3 * (2 - k) + 1]; rv[3 * k + 2] = src[3 * (2 - k) + 2]; }
+        unsigned mask = (oc_backside2(src) ? 0u : 1u) | (oc_backside2(rv) ? 0u : 2u);
+        float bpx[3], bpy[3];
+        for (int k = 0; k < 3; ++k) { bpx[k] = oc_topix2(src[3 * k], is); bpy[k] = oc_topix2(src[3 * k + 1], is); }
+        const float xmin = fminf(bpx[0], fminf(bpx[1], bpx[2])), xmax = fmaxf(bpx[0], fmaxf(bpx[1], bpx[2]));
+        const float ymin = fminf(bpy[0], fminf(bpy[1], bpy[2])), ymax = fmaxf(bpy[0], fmaxf(bpy[1], bpy[2]));
+        if (!(xmax >= -2.0f && ymax >= -2.0f && xmin <= is + 1.0f && ymin <= is + 1.0f)) mask = 0;
+        int x0 = (int)ceilf(fmaxf(xmin, -2.0f) - 0.01f), x1 = (int)floorf(fminf(xmax, is + 1.0f) + 0.01f);
+        int y0 = (int)ceilf(fmaxf(ymin, -2.0f) - 0.01f), y1 = (int)floorf(fminf(ymax, is + 1.0f) + 0.01f);
+        if (x0 < 0) x0 = 0;
+        if (y0 < 0) y0 = 0;
+        if (x1 > is - 1) x1 = is - 1;
+        if (y1 > is - 1) y1 = is - 1;
+        if (x1 < x0 || y1 < y0) mask = 0;
+        for (int var = 0; var < 2; ++var) {
+            float *out = gf9 + (bf * 2 + var) * 9;
+            const int fn = fi + var * F;
+            for (int k = 0; k < 9; ++k) out[k] = 0.f;
+            if (!((mask >> var) & 1u)) continue;
+            const int bw = x1 - x0 + 1, n = bw * (y1 - y0 + 1);
+            int owns = 0;
+            for (int e = 0; e < n && !owns; ++e) owns = idx[(long)(y0 + e / bw) * is + x0 + e % bw] == fn;
+            if (!owns) continue;
+            float f[9];
+            for (int k = 0; k < 3; ++k) {
+                const int sv = var ? 2 - k : k;
+                f[3 * k] = src[3 * sv]; f[3 * k + 1] = src[3 * sv + 1]; f[3 * k + 2] = src[3 * sv + 2];
+            }
+            float p[3][2];
+            for (int k = 0; k < 3; ++k) { p[k][0] = oc_topix2(f[3 * k], is); p[k][1] = oc_topix2(f[3 * k + 1], is); }
+            float inv[9] = {
+                p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+            const float den = p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1]) + p[1][0] * (p[2][1] - p[0][1]);
+            for (int k = 0; k < 9; ++k) inv[k] = inv[k] / den;
+            const float rz0 = 1.0f / f[2], rz1 = 1.0f / f[5], rz2 = 1.0f / f[8];
+            float L0[64], L1[64], L2[64];
+            for (int lane = 0; lane < 64; ++lane) {
+                float A0 = 0.f, A1 = 0.f, A2 = 0.f;
+                for (int e = lane; e < n; e += 64) {
+                    const int xi = x0 + e % bw, yi = y0 + e / bw;
+                    if (idx[(long)yi * is + xi] != fn) continue;
+                    float wgt[3], ws = 0.f;
+                    for (int k = 0; k < 3; ++k) {
+                        float t = inv[3 * k] * (float)xi;
+                        t = t + inv[3 * k + 1] * (float)yi;
+                        t = t + inv[3 * k + 2];
+                        t = fminf(fmaxf(t, 0.0f), 1.0f);
+                        wgt[k] = t;
+                        ws += t;
+                    }
+                    float sum = wgt[0] * rz0;
+                    sum = sum + wgt[1] * rz1;
+                    sum = sum + wgt[2] * rz2;
+                    const float zp = ws / sum;
+                    const float a = 0.25f * g[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)] * zp * zp;
+                    A0 += a * (wgt[0] / ws); A1 += a * (wgt[1] / ws); A2 += a * (wgt[2] / ws);
+                }
+                L0[lane] = A0; L1[lane] = A1; L2[lane] = A2;
+            }
+            const float A[3] = {oc_wave_sum(L0), oc_wave_sum(L1), oc_wave_sum(L2)}, rz[3] = {rz0, rz1, rz2};
+            const float tmp0 = -(inv[0] * rz0 + inv[3] * rz1 + inv[6] * rz2);
+            const float tmp1 = -(inv[1] * rz0 + inv[4] * rz1 + inv[7] * rz2);
+            const float half_is = 0.5f * (float)is;
+            for (int k = 0; k < 3; ++k) {
+                out[3 * k] = -A[k] * tmp0 * half_is;
+                out[3 * k + 1] = -A[k] * tmp1 * half_is;
+                out[3 * k + 2] = A[k] * rz[k] * rz[k];
+            }
+        }
+    }
+}
+
+/* vertex gather of gf9 (winding order -> mesh corners, the adjacency lists in ascending (face, corner) order) + backward of
+ * the projection (z passes straight through): k_depth_bwd_gather.  verts (B,V,3) camera space, K (B,3,3) -> grad (B,V,3) */
+void orc_depth_bwd_gather(const float *gf9, const int32_t *adj_off, const int32_t *adj_items, const float *verts, const float *K,
+                          int B, int V, int F, float orig_size, float *grad_verts)
+{
+    for (long i = 0; i < (long)B * V; ++i) {
+        const int b = (int)(i / V), v = (int)(i % V);
+        float gu = 0.f, gv = 0.f, gz = 0.f;
+        for (int a = adj_off[v]; a < adj_off[v + 1]; ++a) {
+            const int item = adj_items[a], fi = item / 3, k = item % 3;
+            const float *pf = gf9 + ((long)b * F + fi) * 18;
+            gu += pf[3 * k] + pf[9 + 3 * (2 - k)];
+            gv += pf[3 * k + 1] + pf[9 + 3 * (2 - k) + 1];
+            gz += pf[3 * k + 2] + pf[9 + 3 * (2 - k) + 2];
+        }
+        const float *k = K + b * 9;
+        const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+        const float zz = z + 1e-9f;
+        const float du0 = gu * (2.0f / orig_size), dv0 = -gv * (2.0f / orig_size);
+        const float dxn = k[0] * du0 + k[3] * dv0;
+        const float dyn = k[1] * du0 + k[4] * dv0;
+        grad_verts[3 * i] = dxn / zz;
+        grad_verts[3 * i + 1] = dyn / zz;
+        grad_verts[3 * i + 2] = -(dxn * x + dyn * y) / (zz * zz) + gz;
+    }
+}

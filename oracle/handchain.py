@@ -107,11 +107,11 @@ def pair_terms(model, vh, vo, loss_weights):
     return out
 
 
-def hand_param_grads(model, loss_weights, return_stages=False, pair=None):
+def hand_param_grads(model, loss_weights, return_stages=False, pair=None, depth_hand=None):
     """-> {name: float32 numpy array shaped like the parameter} for the six hand parameters (see the module docstring)."""
     lw = loss_weights
     on = lambda k: lw.get(k, 0.0) > 0
-    if (on("lw_depth") or on("lw_sil_hand") or model.hand_nb != 1 or not model.optimize_mano or
+    if ((on("lw_depth") and depth_hand is None) or on("lw_sil_hand") or model.hand_nb != 1 or not model.optimize_mano or
             not isinstance(model.mano_betas, torch.nn.Parameter) or model.int_scales_hand.requires_grad or
             model.losses.inter_type != "centroid"):
         raise NotImplementedError("the written-out hand chain covers the step-1 / step-2 loss sets of a one-hand clip")
@@ -136,6 +136,8 @@ def hand_param_grads(model, loss_weights, return_stages=False, pair=None):
             terms.append((pair["col_hand"], lw["lw_collision"]))
         if on("lw_contact"):
             terms.append((pair["con_hand"], lw["lw_contact"]))
+    if on("lw_depth"):          # d (lw_depth * loss_depth) / d hand vertices (oracle/depthchain.py), already times its weight
+        terms.append((np.ascontiguousarray(depth_hand, f32), 1.0))
     rec = inter_records(vh, vo, K) if on("lw_inter") else None
     pca = c(model.mano_pca_pose)
     P = pca.shape[1]

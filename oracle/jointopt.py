@@ -60,10 +60,14 @@ def reproducible_step(model, loss_weights, optimizer, log2q=0):
             rec = handchain.inter_records(np.ascontiguousarray(model.get_verts_hand()[0].numpy(), np.float32),
                                           np.ascontiguousarray(model.get_verts_object()[0].numpy(), np.float32),
                                           np.ascontiguousarray(model.camintr.numpy(), np.float32))
+    dep_o = dep_h = None
+    if loss_weights.get("lw_depth", 0) > 0 and getattr(model, "ordinal_depth", False) and model.hand_nb == 1:
+        from . import depthchain
+        dep_o, dep_h = depthchain.depth_vertex_grads(model, loss_weights["lw_depth"])
     grads = objchain.object_pose_grads(model, loss_weights, log2q, contact_obj=pair.get("con_obj") if pair else None,
-                                       inter_rec=rec)
+                                       inter_rec=rec, depth_obj=dep_o)
     try:        # the hand's chain in its written-out order too, where it covers the configuration (one hand, fixed scale)
-        grads.update(handchain.hand_param_grads(model, loss_weights, pair=pair))
+        grads.update(handchain.hand_param_grads(model, loss_weights, pair=pair, depth_hand=dep_h))
     except NotImplementedError:
         pass    # (autograd's gradients stay: same mathematics, rounding left to torch)
     for k, g in grads.items():

@@ -131,3 +131,58 @@ def test_free_object_scale_bit_equal(mano_model):
                 if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
         assert not diff, (i, diff)
     assert abs(float(om.int_scales_object.detach()[0]) - 1.0) > 1e-3          # (the scale did move)
+
+
+def _depth_pair(mano_model, seed, frames, size):
+    """a clip whose instance masks DISAGREE with the initial geometry (the object annotated in front everywhere, the hand moved
+    over it): the ordinal depth term is live"""
+    from homan_amd import HOMan, synth
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj="bottle", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn)
+    for pp, op in zip(clip["person_parameters"], clip["object_parameters"]):
+        op["full_mask"] = ((pp["masks"][0] > 0) | (op["full_mask"] > 0)).float()
+        pp["masks"] = torch.zeros_like(pp["masks"])
+        pp["translations"] = pp["translations"] + torch.tensor([0.06, 0.0, -0.02])
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=size,
+                  mano_model=mano_model, rend_size=size, ordinal_depth=True)
+    return HOMan(**copy.deepcopy(kw), **common), OracleHOMan(**copy.deepcopy(kw), **common)
+
+
+def test_ordinal_depth_term_bit_equal(mano_model):
+    """cfg2 as BASELINE.json words it (sil / kp / DEPTH / smooth): the depth term's chain - pooled depth images, per-pixel
+    gradient (shared logistic function), depth-map backward per face, vertex gather - stage by stage, all eight parameter
+    gradients, then 25 free-running steps bit-equal in every parameter."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle import depthchain, handchain, objchain
+    from oracle.jointopt import make_optimizer, reproducible_step
+    lw = dict(synth.STEP1_LOSS_WEIGHTS, lw_depth=1.0)
+    hm, om = _depth_pair(mano_model, seed=15, frames=6, size=128)
+    st = FusedStepper(hm, lw, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    dep_o, dep_h, stg = depthchain.depth_vertex_grads(om, lw["lw_depth"], return_stages=True)
+    assert stg["rec"][1] + stg["rec"][3] > 0                                  # (wrongly ordered pixels exist: the term is live)
+    assert np.array_equal(st.d_dep_o.cpu().numpy(), stg["pooled"][0]) and np.array_equal(st.d_dep_h.cpu().numpy(), stg["pooled"][1])
+    assert np.array_equal(st.d_go.cpu().numpy(), stg["g"][0]) and np.array_equal(st.d_gh.cpu().numpy(), stg["g"][1])
+    assert np.abs(dep_o).max() > 0 and np.abs(dep_h).max() > 0
+    assert np.array_equal(st.G_dep_o.cpu().numpy(), dep_o) and np.array_equal(st.G_dep_h.cpu().numpy(), dep_h)
+    want = handchain.hand_param_grads(om, lw, depth_hand=dep_h)
+    want.update(objchain.object_pose_grads(om, lw, depth_obj=dep_o))
+    report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
+    assert all(report.values()), report
+    hm, om = _depth_pair(mano_model, seed=16, frames=6, size=128)
+    st = FusedStepper(hm, lw, 1e-2, 25)
+    opt = make_optimizer(om, 1e-2, reproducible=True)
+    for i in range(25):
+        st.run(1)
+        reproducible_step(om, lw, opt)
+        torch.cuda.synchronize()
+        cpu = dict(om.named_parameters())
+        diff = [k for k, p in hm.named_parameters()
+                if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
+        assert not diff, (i, diff)

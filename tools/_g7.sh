@@ -1,2 +1,2 @@
 R=$(pwd); O=$R/gpurun_out
-timeout 900 python -m pytest tests/test_poseinit.py -q -m gpu -k resident > $O/g41.log 2>&1; tail -30 $O/g41.log | cut -c1-400
+timeout 1200 python -m pytest tests/test_handchain_gpu.py -q -k ordinal_depth > $O/g42.log 2>&1; tail -30 $O/g42.log | cut -c1-600
