@@ -204,7 +204,7 @@ def cfg1_parity(mano, seeds, steps=100, frames=10, size=128):
 
 
 def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube", seed=0, lr=1e-2, lw=None, clip=None,
-                    tol=1e-4, stages=True):
+                    tol=1e-4, stages=True, ordinal_depth=False):
     """BASELINE's end-state bar, free-running: the HIP fused loop and the CPU oracle loop optimise the same clip from identical
     inputs for `steps` iterations, nobody teacher-forced (reference loop: homan/jointopt.py:158-192).
 
@@ -227,15 +227,17 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
                                hand_verts_fn=hand_fn)
     if lw is None:
         lw = dict(synth.STEP2_LOSS_WEIGHTS if step2 else synth.STEP1_LOSS_WEIGHTS)
+    if ordinal_depth:
+        lw = dict(lw, lw_depth=1.0)
     common = dict(objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"], optimize_mano=True,
-                  image_size=size, mano_model=mano, rend_size=size)
+                  image_size=size, mano_model=mano, rend_size=size, ordinal_depth=ordinal_depth)
     model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
                         sync_metrics=False, **common)
     st = FusedStepper(model, lw, lr, steps)
     kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
                         clip["objvertices"], clip["objfaces"])
     om = OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
-                     image_size=size, mano_model=mano, rend_size=size, **kw)
+                     image_size=size, mano_model=mano, rend_size=size, ordinal_depth=ordinal_depth, **kw)
     opt = make_optimizer(om, lr, reproducible=True)
     obj_keys = ("rotations_object", "translations_object")
     rows, first_obj_diff, stage_report, first_any_diff = [], None, None, None
@@ -292,7 +294,7 @@ def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube
         dvh = 1e3 * (model.get_verts_hand()[0].cpu() - om.get_verts_hand()[0]).abs().max().item()
     frames, obj = len(clip["object_parameters"]), f"{clip['objfaces'].shape[1]} faces"
     return dict(config=f"{frames} frames {size}x{size}, {obj}, " + ("step-2" if step2 else "step-1 / custom") +
-                f" loss set, {steps} free-running steps: HIP fused loop vs the CPU oracle's reproducible loop",
+                f" loss set{' + ordinal depth term' if ordinal_depth else ''}, {steps} free-running steps: HIP fused loop vs the CPU oracle's reproducible loop",
                 steps=steps, tol=tol, first_step_object_params_differ=first_obj_diff,
                 object_params_bit_equal_all_steps=first_obj_diff is None,
                 first_step_any_param_differs=first_any_diff, all_params_bit_equal_all_steps=first_any_diff is None,
@@ -1006,9 +1008,10 @@ def main():
                                                 free_run=not args.depth, ordinal_depth=args.depth)
                                 if args.lockstep > 0 else None),
                       cfg1=cfg1_parity(mano, seeds=list(range(args.parity_seeds))) if args.parity_seeds > 0 else None,
-                      free_run=(free_run_parity(mano, step2=args.step2, steps=min(args.freerun, 40) if args.step2 else args.freerun,
-                                                frames=B, size=S, clip=clip, lw=lw)
-                                if args.freerun > 0 and not args.depth else None),
+                      free_run=(free_run_parity(mano, step2=args.step2,
+                                                steps=min(args.freerun, 40) if (args.step2 or args.depth) else args.freerun,
+                                                frames=B, size=S, clip=clip, lw=lw, ordinal_depth=args.depth)
+                                if args.freerun > 0 else None),
                       bar="north_star: 1e-4 relative on losses, 1e-3 mm on final vertices.  cfg1 / free_run compare FREE-running "
                           "trajectories: the object's gradient chain sums in an order-independent way and the hand's chain and "
                           "the step-2 pair terms run in one stated order on both sides (DESIGN.md 2), so EVERY parameter is "

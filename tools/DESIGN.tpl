@@ -159,20 +159,28 @@ object's chain is closed on itself (`homan/homan.py:482-490`: `loss_inter` sees 
   is inherited from the kernels and stated: the reference ranks neighbours by `|a|^2 + |b|^2 - 2ab` (contactloss.py:60-79), whose
   rounding (~4e-8 m^2 at |a|^2 ~ 0.36 m^2) names another neighbour when two object vertices are within that of each other; the
   faithful form stays in `oracle/model.py`, and `tests/test_objchain.py` bounds the difference (picks at the same distance
-  to 1e-7 m^2, gradients within 3e-4).
+  to 1e-7 m^2, gradients within 3e-4);
+* the ORDINAL DEPTH term (`oracle/depthchain.py`): both meshes rendered at the full-image camera by the oracle's rasteriser
+  (owner maps and z-buffers bit-equal with the kernels'), the four samples of a pixel pooled as `((s00 + s01) + s10) + s11`, the
+  per-pixel gradient with counts as normalisers and a shared `hm_sigmoid`, NMR's depth-map backward per (face, winding) with the
+  kernel's walk of the face's sample box (64 lanes in strides, then the wave tree - `orc_depth_bwd_faces`), the vertex gather in
+  adjacency order, the results as one more term of the two rigid / MANO backward passes;
+* a FREE OBJECT SCALE (cfg5's option): the interaction term then reaches the object's vertices, the scale's gradient is the
+  frames' exact partial sums through one block sum plus the prior's term (`oracle/objchain.py`).
 
 Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`,
 `profiles/r04_freerun_*.json`): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
 `translations_hand`, `mano_pca_pose`, `mano_rot`, `mano_betas`, `mano_trans` - is BIT-EQUAL between the two free-running loops
-after every step: cfg1 100 steps x 5 seeds, cfg2 and cfg3 (step-2: collision + contact) at full size over 400 steps
-(`r04_freerun_cfg2_400.json`, `r04_freerun_cfg3_400.json`: `all_params_bit_equal_all_steps: true`), final
+after every step: cfg1 100 steps x 5 seeds; cfg2, cfg2 + ordinal depth term and cfg3 (step-2: collision + contact) at full size
+over 400 steps (`r04_freerun_cfg2_400.json`, `r04_freerun_cfg2_depth_400.json`, `r04_freerun_cfg3_400.json`:
+`all_params_bit_equal_all_steps: true`); the step-2 set with a free object scale over 25 steps (`tests/test_handchain_gpu.py`); final
 vertices 0.0 mm apart for the object AND the hand, every logged loss within 3.4e-7 at every step (bar 1e-4; the logged VALUES are
 parallel float sums and keep their rounding, the trajectory does not see them).  Until the hand's chain was written out (first
 half of this round) the hand separated around step 170-180 of the cfg2 clip - 0.14 mm at step 400 - exactly where the CPU loop
 separates from ITSELF when its hand translations start 1e-7 m apart (`r04_control_cfg2_400.json`: 0.85 mm): Adam at 10 x lr on
-the MANO parameters amplifies any difference, so only a chain without any could close it.  Not written out: the ordinal depth
-term, two hands per frame and a free object scale (`oracle/handchain.py` raises NotImplementedError, the oracle then keeps
-autograd's gradients); there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
+the MANO parameters amplifies any difference, so only a chain without any could close it.  Not written out: two hands per frame,
+`inter_type="min"`, `optimize_mano=False` (`oracle/handchain.py` raises NotImplementedError, the oracle then keeps autograd's
+gradients for the hand); there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
 path: nothing at one clip, -2 % on an 8-clip batch (EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the
 divisions; the hand side's kernels did not change but for the sin / cos.
 
@@ -432,8 +440,8 @@ file the reference never reaches.  More than two hands: the reference's own coll
 4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
    silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
    hands it runs one clip per stepper (`ShardStepper`).
-5. The written-out chains cover one hand, a fixed object scale and the step-1 / step-2 loss sets (cfg1, cfg2, cfg3).  cfg5's
-   free object scale (one more sum per frame in the rigid backward, the prior, the tied gradient), two hands (the second hand's
-   rows through the left model; three SDF scenes) and the ordinal depth term (two more renders and their pair-wise sums) are not:
-   free-running fits of those configurations are compared per step (lock-step) only.
+5. The written-out chains cover one hand with `optimize_mano`, the centroid interaction term, every loss set of BASELINE's
+   configurations (step 1, step 1 + depth, step 2) and a fixed or free object scale.  Two hands (the second hand's rows through
+   the left model, three SDF scenes), `inter_type="min"` and the tied scale ACROSS clips / ranks (a sum over clips in rank order)
+   are compared per step (lock-step) only.
 6. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.

@@ -1,2 +1,2 @@
 R=$(pwd); O=$R/gpurun_out
-timeout 1200 python -m pytest tests/test_handchain_gpu.py -q -k ordinal_depth > $O/g42.log 2>&1; tail -30 $O/g42.log | cut -c1-600
+python tools/chain_parity.py cfg2depth 400 > $O/g43_cfg2depth_400.json 2>$O/g43.err; tail -c 300 $O/g43_cfg2depth_400.json; tail -3 $O/g43.err

@@ -1,5 +1,5 @@
 """GPU box: free-running HIP loop vs the CPU oracle's reproducible loop (bench.free_run_parity), a few configurations.
-usage: python tools/chain_parity.py [cfg1|cfg2small|cfg2|cfg3|cfg2ctrl] [steps]"""
+usage: python tools/chain_parity.py [cfg1|cfg2small|cfg2|cfg2depth|cfg3|cfg2ctrl] [steps]"""
 import json
 import os
 import sys
@@ -46,6 +46,8 @@ elif which == "cfg2ctrl":
     out = dict(what="CPU oracle (reproducible loop) vs itself, cfg2 full size, hand translations perturbed by 1e-7 m", steps=steps,
                final=rows[-1], first_step_hand_over_bar=next((r["step"] for r in rows if r["hand_mm"] > 1e-3), None),
                per_step=rows[:: max(1, steps // 25)])
+elif which == "cfg2depth":
+    out = bench.free_run_parity(mano, steps=steps, frames=30, size=256, obj="bottle", ordinal_depth=True)
 elif which == "cfg3":
     out = bench.free_run_parity(mano, step2=True, steps=steps, frames=30, size=256, obj="bottle")
 elif which == "cfg2small":
