@@ -71,6 +71,8 @@ def lib():
         _lib.orc_depth_bwd_gather.restype = None
         _lib.orc_sigmoid.argtypes = [cf]
         _lib.orc_sigmoid.restype = cf
+        _lib.orc_offscreen.argtypes = [fp, fp, ci, ci, cf, cf, ci, fp, fp]
+        _lib.orc_offscreen.restype = None
         _lib.orc_block_sum.argtypes = [fp, ci, ci]
         _lib.orc_block_sum.restype = cf
         _lib.orc_tanh.argtypes = [cf]

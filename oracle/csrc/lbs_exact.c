@@ -821,3 +821,45 @@ void orc_depth_bwd_gather(const float *gf9, const int32_t *adj_off, const int32_
         grad_verts[3 * i + 2] = -(dxn * x + dyn * y) / (zz * zz) + gz;
     }
 }
+
+/* ------------------------------------------------------------------------------------------------------------------------
+ * Pose initialisation: off-screen penalty (reference homan/pose_optimization.py:112-135) in the order of csrc/losses.hip
+ * k_offscreen - hinges on the six clipping planes per vertex, element-wise gradient; the value of a candidate = weight * the
+ * sum over its vertices taken by `nthreads` threads in strides, waves through oc_wave_sum, wave results in wave order.
+ * verts (n,V,3), K: ONE 3x3 camera -> out (n), grad (n,V,3) */
+void orc_offscreen(const float *verts, const float *K, int n, int V, float zfar, float weight, int nthreads, float *out, float *grad)
+{
+    const float k00 = K[0], k01 = K[1], k02 = K[2], k10 = K[3], k11 = K[4], k12 = K[5];
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < n; ++c) {
+        float acc[1024];
+        for (int t = 0; t < nthreads; ++t) acc[t] = 0.f;
+        for (int v = 0; v < V; ++v) {
+            const long o = ((long)c * V + v) * 3;
+            const float x = verts[o], y = verts[o + 1], z = verts[o + 2];
+            const float zz = z + 1e-9f;
+            const float xn = x / zz, yn = y / zz;
+            float u = k00 * xn + k01 * yn;
+            u = u + k02;
+            float w = k10 * xn + k11 * yn;
+            w = 1.0f - (w + k12);
+            const float nu = 2.0f * (u - 0.5f), nv = 2.0f * (w - 0.5f);
+            float val = fmaxf(nu - 1.0f, 0.f) + fmaxf(nv - 1.0f, 0.f);
+            val += fmaxf(-1.0f - nu, 0.f) + fmaxf(-1.0f - nv, 0.f);
+            val += fmaxf(-z, 0.f);
+            val += fmaxf(z - zfar, 0.f);
+            acc[v % nthreads] += val;          /* thread t = v mod nthreads meets its vertices in ascending order */
+            const float gu = (nu - 1.0f > 0.f ? 1.f : 0.f) - (-1.0f - nu > 0.f ? 1.f : 0.f);
+            const float gv = (nv - 1.0f > 0.f ? 1.f : 0.f) - (-1.0f - nv > 0.f ? 1.f : 0.f);
+            const float gz = (z - zfar > 0.f ? 1.f : 0.f) - (-z > 0.f ? 1.f : 0.f);
+            const float du = 2.0f * gu, dw = -2.0f * gv;
+            const float dxn = k00 * du + k10 * dw, dyn = k01 * du + k11 * dw;
+            grad[o] = weight * (dxn / zz);
+            grad[o + 1] = weight * (dyn / zz);
+            grad[o + 2] = weight * (gz - (dxn * x + dyn * y) / (zz * zz));
+        }
+        float tot = 0.f;
+        for (int w = 0; w < nthreads / 64; ++w) tot += oc_wave_sum(acc + 64 * w);
+        out[c] = weight * tot;
+    }
+}

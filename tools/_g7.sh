@@ -1,2 +1,2 @@
 R=$(pwd); O=$R/gpurun_out
-python tools/chain_parity.py cfg2depth 400 > $O/g43_cfg2depth_400.json 2>$O/g43.err; tail -c 300 $O/g43_cfg2depth_400.json; tail -3 $O/g43.err
+timeout 900 python -m pytest tests/test_poseinit.py -q -m gpu -k "written_out_oracle or resident" > $O/g44.log 2>&1; tail -30 $O/g44.log | cut -c1-500
