@@ -73,6 +73,15 @@ def test_mano_lbs_and_grads(mano_model):
     vh = ops.mano_lbs(ins_h[0], ins_h[1], ins_h[2], ins_h[3], mctx)
     (vh * w.to(DEV)).sum().backward()
     assert (vh.cpu() - vo).abs().max() < 2e-6
+    # against the layer written out in the kernels' evaluation order (oracle/csrc/lbs_exact.c): the same bits
+    from homan_amd.mano_assets import kernel_layout
+    from oracle import clib
+    lay = kernel_layout(mano_model, flat_hand_mean=False)
+    exact = np.empty((B, 778, 3), np.float32)
+    p_, r_, b_ = (np.ascontiguousarray(t.numpy(), np.float32) for t in (pca, rot, betas))
+    clib.lib().orc_mano_forward(*[clib.fptr(a) for a in lay[:7]], clib.iptr(lay[7]), clib.fptr(p_), 45, clib.fptr(r_), clib.fptr(b_),
+                                B, clib.fptr(exact))
+    assert np.array_equal(vh.detach().cpu().numpy(), exact + trans.numpy()[:, None])
     for a, b, n in zip(ins_h, ins_o, ("pca", "rot", "betas", "trans")):
         _close(a.grad, b.grad, rtol=3e-4, atol_frac=1e-4, msg="grad " + n)
     _, joints = ops.mano_joints(ins_h[0], ins_h[1], ins_h[2], ins_h[3], mctx)
@@ -209,6 +218,9 @@ def test_collision_vs_oracle(obj, mano_model):
         got = cctx.grid(which).cpu()
         assert ((got > 0) == (ref > 0)).all(), f"inside masks differ for mesh {which}"
         _close(got, ref, rtol=1e-5, msg=f"phi {which}")
+        # ... bit for bit, in fact: a min over the triangles of ONE point-triangle routine (csrc/sdf.hip <-> oracle/csrc/sdf.c);
+        # the written-out collision term of the free-running parity runs relies on it (oracle/handchain.py)
+        assert torch.equal(got, ref.float().clamp(min=0)), f"phi {which}: {(got - ref).abs().max().item()}"
     _close(lh, lo, rtol=1e-4, msg="collision loss")
     _close(ah.grad, a.grad, rtol=1e-3, atol_frac=1e-3, msg="collision grad hand")
     _close(bh.grad, b.grad, rtol=1e-3, atol_frac=1e-3, msg="collision grad obj")
