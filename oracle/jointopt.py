@@ -26,15 +26,16 @@ def parameter_groups(model, lr):
             {"params": rotation, "lr": lr * 10}]
 
 
-def reproducible_step(model, loss_weights, optimizer, log2q=0):
-    """One iteration of the loop below with the parts fp32 leaves open pinned down (oracle/objchain.py, oracle/adam.py):
+def reproducible_grads(model, loss_weights, log2q=0):
+    """The gradients of one iteration of the loop below with the parts fp32 leaves open pinned down (oracle/objchain.py, oracle/adam.py):
     forward + autograd as always, then the object's pose gradients REPLACED by the written-out chain with order-independent
     sums (same mathematics, a defined rounding) and - for the loss sets oracle/handchain.py covers - the hand's by ITS written-out
-    chain, then the written-out Adam (`optimizer` = oracle.adam.Adam).  The trajectory of those parameters is then a function of
-    the inputs alone - the same for any number of host threads - and bit-equal to the HIP loop's.
+    chain; they are left in the parameters' `.grad`.  With the written-out Adam (`reproducible_step`) the trajectory is then a
+    function of the inputs alone - the same for any number of host threads - and bit-equal to the HIP loop's.
     -> (loss_dict, metric_dict, total)."""
     from . import objchain
-    optimizer.zero_grad()
+    for p in model.parameters():
+        p.grad = None
     obj = (model.rotations_object, model.translations_object)
     if model.optimize_object_scale:         # (the scale's gradient needs the renderer's backward: autograd walks it then)
         obj = ()
@@ -73,8 +74,32 @@ def reproducible_step(model, loss_weights, optimizer, log2q=0):
     for k, g in grads.items():
         p = getattr(model, k)
         p.grad = torch.from_numpy(g).reshape(p.shape)
-    optimizer.step()
     return loss_dict, metric_dict, loss
+
+
+def reproducible_step(model, loss_weights, optimizer, log2q=0):
+    """`reproducible_grads` + the written-out Adam (`optimizer` = oracle.adam.Adam).  -> (loss_dict, metric_dict, total)"""
+    out = reproducible_grads(model, loss_weights, log2q)
+    optimizer.step()
+    return out
+
+
+def reproducible_step_shared_scale(models, optimizers, loss_weights, log2q=0):
+    """One step of BASELINE cfg5's loop on ONE rank: clips with ONE object scale between them (models built with
+    optimize_object_scale=True, their scalars equal on entry; reference homan/jointopt.py:158-192 per clip, the tie as in
+    homan_amd.dist.optimize_clips_shared_scale).  Every clip's gradients by `reproducible_grads`, the clips' d loss / d scale
+    added by one 64-thread block sum (csrc/geometry.hip k_sum_small, as the fused loop adds them), the sum written to every
+    replica, every clip's written-out Adam stepped - the replicas stay identical.  -> [(loss_dict, metric_dict, total)]"""
+    from . import clib
+    outs = [reproducible_grads(m, loss_weights, log2q) for m in models]
+    g = np.ascontiguousarray([float(m.int_scales_object.grad.reshape(-1)[0]) for m in models], np.float32)
+    tied = np.float32(1.0) * np.float32(clib.lib().orc_block_sum(clib.fptr(g), len(models), 64)) + np.float32(0.0)
+    for m, opt in zip(models, optimizers):
+        m.int_scales_object.grad = torch.full_like(m.int_scales_object, float(tied))
+        opt.step()
+    return outs
+
+
 
 
 def collate_inputs(person_parameters, object_parameters, objvertices, objfaces):

@@ -186,3 +186,31 @@ def test_ordinal_depth_term_bit_equal(mano_model):
         diff = [k for k, p in hm.named_parameters()
                 if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
         assert not diff, (i, diff)
+
+
+def test_tied_object_scale_over_three_clips_bit_equal(mano_model):
+    """BASELINE cfg5 on one rank: three clips with ONE object scale between them, step-2 loss set.  The fused loop (one clip batch,
+    shared_scale=True: the clips' scale gradients added by one block sum, the sum spread to every replica) vs the oracle's
+    reproducible tied loop (oracle.jointopt.reproducible_step_shared_scale): every parameter of every clip bit-equal after each
+    of 20 free-running steps, the replicas of the scalar identical throughout."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle.jointopt import make_optimizer, reproducible_step_shared_scale
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    pairs = [_pair(mano_model, seed=s, frames=6, size=128, obj="bottle", optimize_object_scale=True) for s in (21, 22, 23)]
+    hms, oms = [p[0] for p in pairs], [p[1] for p in pairs]
+    st = FusedStepper(hms, lw, 1e-2, 20, shared_scale=True)
+    opts = [make_optimizer(m, 1e-2, reproducible=True) for m in oms]
+    names = [k for k, _ in oms[0].named_parameters()]
+    for i in range(20):
+        st.run(1)
+        reproducible_step_shared_scale(oms, opts, lw)
+        torch.cuda.synchronize()
+        s_h = st.model.int_scales_object.detach().cpu().numpy().reshape(-1)
+        assert np.all(s_h == s_h[0]) and len({float(m.int_scales_object.detach()[0]) for m in oms}) == 1
+        for c, om in enumerate(oms):
+            cpu = dict(om.named_parameters())
+            for k in names:
+                got = st.model.clip_slice(getattr(st.model, k), c).detach().cpu().numpy()
+                assert np.array_equal(got.reshape(-1), cpu[k].detach().numpy().reshape(-1)), (i, c, k)
+    assert abs(float(oms[0].int_scales_object.detach()[0]) - 1.0) > 1e-3

@@ -166,7 +166,9 @@ object's chain is closed on itself (`homan/homan.py:482-490`: `loss_inter` sees 
   kernel's walk of the face's sample box (64 lanes in strides, then the wave tree - `orc_depth_bwd_faces`), the vertex gather in
   adjacency order, the results as one more term of the two rigid / MANO backward passes;
 * a FREE OBJECT SCALE (cfg5's option): the interaction term then reaches the object's vertices, the scale's gradient is the
-  frames' exact partial sums through one block sum plus the prior's term (`oracle/objchain.py`).
+  frames' exact partial sums through one block sum plus the prior's term (`oracle/objchain.py`); tied across the clips of a
+  rank, the clips' gradients meet in one more block sum and every replica takes the sum
+  (`oracle.jointopt.reproducible_step_shared_scale`).
 
 Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`,
 `profiles/r04_freerun_*.json`): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
@@ -441,7 +443,8 @@ file the reference never reaches.  More than two hands: the reference's own coll
    silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
    hands it runs one clip per stepper (`ShardStepper`).
 5. The written-out chains cover one hand with `optimize_mano`, the centroid interaction term, every loss set of BASELINE's
-   configurations (step 1, step 1 + depth, step 2) and a fixed or free object scale.  Two hands (the second hand's rows through
-   the left model, three SDF scenes), `inter_type="min"` and the tied scale ACROSS clips / ranks (a sum over clips in rank order)
-   are compared per step (lock-step) only.
+   configurations (step 1, step 1 + depth, step 2), a fixed or free object scale, and the scale tied across the clips of one
+   rank (cfg5: the clips' gradients through one block sum, `reproducible_step_shared_scale`; three clips bit-equal over 20
+   steps).  Two hands (the second hand's rows through the left model, three SDF scenes) and `inter_type="min"` are compared per
+   step (lock-step) only; across RANKS the tied gradient is one fp32 all-reduce, whose order for more than two ranks is RCCL's.
 6. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.
