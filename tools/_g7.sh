@@ -1,2 +1,2 @@
 R=$(pwd); O=$R/gpurun_out
-timeout 1200 python -m pytest tests/test_handchain_gpu.py -q -k tied_object_scale > $O/g46.log 2>&1; tail -30 $O/g46.log | cut -c1-500
+python tools/poseinit_tune.py > $O/g47_tune.json 2>$O/g47.err; cat $O/g47_tune.json; tail -2 $O/g47.err
