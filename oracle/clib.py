@@ -52,7 +52,11 @@ def lib():
         _lib.orc_hand_chain.argtypes = [fp, fp, fp, fp, fp, fp, fp, ip, fp, ci, fp, fp, fp, fp, cf, vp, fp, ci, fp, ci, cf, fp, cf, ci,
                                         fp, fp, fp, fp, fp, fp]
         _lib.orc_hand_chain.restype = None
-        _lib.orc_v2d_unit_grad.argtypes = [fp, fp, fp, cf, ci, ci, fp]
+        _lib.orc_v2d_unit_grad.argtypes = [fp, fp, fp, cf, ci, ci, ci, fp]
+        _lib.orc_mano_bwd_rows.argtypes = [fp, fp, fp, fp, fp, fp, fp, ip, fp, ci, fp, fp, fp, fp, cf, ci, ci, ci, fp, fp, fp, fp]
+        _lib.orc_mano_bwd_rows.restype = None
+        _lib.orc_rigid_bwd_rows.argtypes = [fp, fp, cf, vp, fp, ci, fp, ci, cf, ci, ci, ci, fp, fp, fp]
+        _lib.orc_rigid_bwd_rows.restype = None
         _lib.orc_v2d_unit_grad.restype = None
         _lib.orc_inter_rec.argtypes = [fp, fp, fp, ci, ci, ci, cf, cf, ci, fp]
         _lib.orc_inter_rec.restype = None

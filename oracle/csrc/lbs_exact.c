@@ -258,20 +258,22 @@ static void oc_rodrigues_backward(const float *r, const float *dR, float *dr)
  * g_pca_extra (B, pca_stride) or NULL, times w_extra: added to the PCA gradient (the prior's unit gradient).
  * -> g_pca (B,pca_stride), g_rot (B,3), g_betas (B,10), g_trans (B,3) [MANO], g_rot6d (B,6), g_rtrans (B,3) [rigid]
  */
-void orc_hand_chain(const float *v_template, const float *M, const float *J_template, const float *J_shapedirs,
+static void oc_hand_chain_rows(const float *v_template, const float *M, const float *J_template, const float *J_shapedirs,
                     const float *weights, const float *comps, const float *hand_mean, const int32_t *parents,
                     const float *pca, int pca_stride, const float *rot, const float *betas, const float *mesh,
                     const float *rot6d, float scale, const float *const *terms, const float *tw, int n_terms,
                     const float *g_frame, int frame_stride, float frame_scale, const float *g_pca_extra, float w_extra, int B,
-                    float *g_pca, float *g_rot, float *g_betas, float *g_trans, float *g_rot6d, float *g_rtrans)
+                    float *g_pca, float *g_rot, float *g_betas, float *g_trans, float *g_rot6d, float *g_rtrans,
+                    const float *gmesh, int row0, int row_stride)
 {
     const OcManoModel m = {v_template, M, J_template, J_shapedirs, weights, comps, hand_mean, parents};
 #pragma omp parallel for schedule(static)
-    for (int b = 0; b < B; ++b) {
+    for (int lb = 0; lb < B; ++lb) {
+        const int b = lb * row_stride + row0;
         OcManoState st;
         oc_mano_prepare(&m, pca, pca_stride, rot, betas, b, &st);
-        float R[9];
-        oc_rot6d_to_mat(rot6d + (long)b * 6, R);
+        float R[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (!gmesh) oc_rot6d_to_mat(rot6d + (long)b * 6, R);
         const float s = scale;
         static const float zero64[64] = {0.f};
         float tot[PART];
@@ -285,6 +287,18 @@ void orc_hand_chain(const float *v_template, const float *M, const float *J_temp
             for (int t = 0; t < nv; ++t) {
                 const int v = v0 + t;
                 const long o = ((long)b * NV + v) * 3;
+                if (gmesh) {        /* the model-space gradient is handed in (csrc/mano.hip k_mano_bwd<false>) */
+                    g[0][t] = gmesh[o]; g[1][t] = gmesh[o + 1]; g[2][t] = gmesh[o + 2];
+                    float T[12];
+                    oc_mano_skin(&m, &st, v, T);
+                    oc_mano_vp(&m, &st, v, s_vp[t]);
+                    for (int c = 0; c < 3; ++c) {
+                        s_g[t][c] = g[c][t];
+                        s_dvp[3 * t + c] = T[c] * g[0][t] + T[4 + c] * g[1][t] + T[8 + c] * g[2][t];
+                    }
+                    for (int j = 0; j < NJ; ++j) s_w[t][j] = weights[v * NJ + j];
+                    continue;
+                }
                 const float mv[3] = {mesh[o], mesh[o + 1], mesh[o + 2]};
                 float gf[3] = {0.f, 0.f, 0.f}, gt[3];
                 for (int k = 0; k < n_terms; ++k) {
@@ -406,21 +420,94 @@ void orc_hand_chain(const float *v_template, const float *M, const float *J_temp
             for (int q = 0; q < NJ * 3; ++q) a += J_shapedirs[q * 10 + t] * dJ[q / 3][q % 3];
             g_betas[b * 10 + t] = a;
         }
-        float dr6[6];
-        oc_rot6d_backward(rot6d + (long)b * 6, &tot[340], dr6);
-        for (int k = 0; k < 6; ++k) g_rot6d[(long)b * 6 + k] = dr6[k];
-        for (int k = 0; k < 3; ++k) g_rtrans[(long)b * 3 + k] = tot[349 + k];
+        if (!gmesh) {
+            float dr6[6];
+            oc_rot6d_backward(rot6d + (long)b * 6, &tot[340], dr6);
+            for (int k = 0; k < 6; ++k) g_rot6d[(long)b * 6 + k] = dr6[k];
+            for (int k = 0; k < 3; ++k) g_rtrans[(long)b * 3 + k] = tot[349 + k];
+        }
+    }
+}
+void orc_hand_chain(const float *v_template, const float *M, const float *J_template, const float *J_shapedirs,
+                    const float *weights, const float *comps, const float *hand_mean, const int32_t *parents,
+                    const float *pca, int pca_stride, const float *rot, const float *betas, const float *mesh,
+                    const float *rot6d, float scale, const float *const *terms, const float *tw, int n_terms,
+                    const float *g_frame, int frame_stride, float frame_scale, const float *g_pca_extra, float w_extra, int B,
+                    float *g_pca, float *g_rot, float *g_betas, float *g_trans, float *g_rot6d, float *g_rtrans)
+{
+    oc_hand_chain_rows(v_template, M, J_template, J_shapedirs, weights, comps, hand_mean, parents, pca, pca_stride, rot, betas, mesh,
+                       rot6d, scale, terms, tw, n_terms, g_frame, frame_stride, frame_scale, g_pca_extra, w_extra, B, g_pca, g_rot,
+                       g_betas, g_trans, g_rot6d, g_rtrans, NULL, 0, 1);
+}
+/* The MANO layer's backward alone for the rows row0, row0 + row_stride, ... (B of them) of arrays holding B * row_stride rows
+ * (two hands per frame are interleaved frame-major, reference homan/homan.py:62-63, each hand through its side's model): the
+ * model-space vertex gradient gmesh (rows,778,3) is handed in (csrc/mano.hip k_mano_bwd<false>, hm_mano_bwd_rows). */
+void orc_mano_bwd_rows(const float *v_template, const float *M, const float *J_template, const float *J_shapedirs,
+                       const float *weights, const float *comps, const float *hand_mean, const int32_t *parents,
+                       const float *pca, int pca_stride, const float *rot, const float *betas, const float *gmesh,
+                       const float *g_pca_extra, float w_extra, int B, int row0, int row_stride, float *g_pca, float *g_rot,
+                       float *g_betas, float *g_trans)
+{
+    oc_hand_chain_rows(v_template, M, J_template, J_shapedirs, weights, comps, hand_mean, parents, pca, pca_stride, rot, betas, NULL,
+                       NULL, 1.0f, NULL, NULL, 0, NULL, 0, 0.f, g_pca_extra, w_extra, B, g_pca, g_rot, g_betas, g_trans, NULL, NULL,
+                       gmesh, row0, row_stride);
+}
+
+/* The hands' rigid backward as a launch of its own (csrc/geometry.hip k_rigid_bwd<false>, one workgroup of `nthreads` threads per
+ * row, V <= nthreads: thread v holds vertex v; 13 block sums - waves through oc_wave_sum, wave results in wave order).
+ * mesh (N,V,3) model-space vertices, rot6d (N,6), one scale; terms / g_frame as in orc_hand_chain.
+ * -> g_mesh (N,V,3), g_rot6d (N,6), g_trans (N,3) */
+void orc_rigid_bwd_rows(const float *mesh, const float *rot6d, float scale, const float *const *terms, const float *tw, int n_terms,
+                        const float *g_frame, int frame_stride, float frame_scale, int N, int V, int nthreads, float *g_mesh,
+                        float *g_rot6d, float *g_trans)
+{
+#pragma omp parallel for schedule(static)
+    for (int n = 0; n < N; ++n) {
+        float R[9];
+        oc_rot6d_to_mat(rot6d + (long)n * 6, R);
+        const float s = scale;
+        float gfr[3] = {0.f, 0.f, 0.f};
+        if (g_frame)
+            for (int c = 0; c < 3; ++c) gfr[c] = frame_scale * g_frame[(long)n * frame_stride + c];
+        float acc[13][1024];
+        for (int k = 0; k < 13; ++k) for (int t = 0; t < nthreads; ++t) acc[k][t] = 0.f;
+        for (int v = 0; v < V; ++v) {
+            const long o = ((long)n * V + v) * 3;
+            const float m[3] = {mesh[o], mesh[o + 1], mesh[o + 2]};
+            float gf[3] = {0.f, 0.f, 0.f}, gt[3];
+            for (int k = 0; k < n_terms; ++k) {
+                gf[0] += tw[k] * terms[k][o]; gf[1] += tw[k] * terms[k][o + 1]; gf[2] += tw[k] * terms[k][o + 2];
+            }
+            gt[0] = gf[0] + gfr[0]; gt[1] = gf[1] + gfr[1]; gt[2] = gf[2] + gfr[2];
+            const float dm[3] = {R[0] * gf[0] + R[1] * gf[1] + R[2] * gf[2], R[3] * gf[0] + R[4] * gf[1] + R[5] * gf[2],
+                                 R[6] * gf[0] + R[7] * gf[1] + R[8] * gf[2]};
+            const int t = v % nthreads;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j) acc[3 * i + j][t] += (s * m[i]) * gt[j];
+            for (int j = 0; j < 3; ++j) acc[9 + j][t] += gt[j];
+            acc[12][t] += m[0] * dm[0] + m[1] * dm[1] + m[2] * dm[2];
+            g_mesh[o] = s * dm[0]; g_mesh[o + 1] = s * dm[1]; g_mesh[o + 2] = s * dm[2];
+        }
+        float tot[13];
+        for (int k = 0; k < 13; ++k) {
+            float a = 0.f;
+            for (int w = 0; w < nthreads / 64; ++w) a += oc_wave_sum(acc[k] + 64 * w);
+            tot[k] = a;
+        }
+        oc_rot6d_backward(rot6d + (long)n * 6, tot, g_rot6d + (long)n * 6);
+        for (int k = 0; k < 3; ++k) g_trans[(long)n * 3 + k] = tot[9 + k];
     }
 }
 
 /* 2-D reprojection term's unit gradient on the camera-space hand vertices (reference homan/losses.py:141-164; csrc/pair_bodies.h
- * hand_terms_body): element-wise.  verts (N,V,3), K (N,3,3), ref2d (N,V,2) -> unit (N,V,3) */
-void orc_v2d_unit_grad(const float *verts, const float *camintr, const float *ref2d, float image_size, int N, int V, float *unit)
+ * hand_terms_body): element-wise.  verts (N,V,3), K (N / hand_nb,3,3), ref2d (N,V,2) -> unit (N,V,3) */
+void orc_v2d_unit_grad(const float *verts, const float *camintr, const float *ref2d, float image_size, int N, int V, int hand_nb,
+                       float *unit)
 {
     const long total = (long)N * V;
     const float inv_cnt = 1.0f / (float)total;
     for (long i = 0; i < total; ++i) {
-        const float *k = camintr + (i / V) * 9;
+        const float *k = camintr + ((i / V) / hand_nb) * 9;      /* rows are interleaved frame-major: one camera per frame */
         const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
         const float hx = k[0] * x + k[1] * y + k[2] * z;
         const float hy = k[3] * x + k[4] * y + k[5] * z;

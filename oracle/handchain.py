@@ -37,11 +37,26 @@ f32 = np.float32
 BLOCK_THREADS = 256          # workgroup size of the interaction term's per-frame reduction (csrc/pair_bodies.h RED_THREADS)
 
 
-def v2d_unit_grad(verts, camintr, ref2d, image_size):
+def v2d_unit_grad(verts, camintr, ref2d, image_size, hand_nb=1):
     N, V = verts.shape[:2]
     out = np.empty((N, V, 3), f32)
-    clib.lib().orc_v2d_unit_grad(clib.fptr(verts), clib.fptr(camintr), clib.fptr(ref2d), float(image_size), N, V, clib.fptr(out))
+    clib.lib().orc_v2d_unit_grad(clib.fptr(verts), clib.fptr(camintr), clib.fptr(ref2d), float(image_size), N, V, hand_nb,
+                                 clib.fptr(out))
     return out
+
+
+def smooth_unit_grad_rows(verts, hand_nb):
+    """temporal smoothness of rows interleaved frame-major (hand i of every frame = rows i, i + hand_nb, ...): the neighbours of
+    a row are hand_nb rows away (csrc/pair_bodies.h smooth_body); hand_nb = 1 is oracle.objchain.smooth_unit_grad"""
+    v = np.ascontiguousarray(verts, f32)
+    N, h = v.shape[0], hand_nb
+    cnt = (N - h) * v.shape[1] * 3
+    inv_cnt = f32(1.0) / f32(cnt) if cnt > 0 else f32(0.0)
+    g = np.zeros_like(v)
+    if N > h:
+        g[:-h] = f32(0.0) - (v[h:] - v[:-h])
+        g[h:] = g[h:] + (v[h:] - v[:-h])
+    return (f32(2.0) * g) * inv_cnt
 
 
 def inter_records(vh, vo, camintr):
@@ -107,10 +122,108 @@ def pair_terms(model, vh, vo, loss_weights):
     return out
 
 
-def hand_param_grads(model, loss_weights, return_stages=False, pair=None, depth_hand=None):
+def two_hand_terms(model, loss_weights):
+    """Two hands per frame (rows interleaved frame-major, right / left through their own models; reference homan/homan.py:62-63,
+    341-358; lossutils.py:53-59, 116-127; losses.py:199-242): everything between the meshes, per hand, in the order of the fused
+    loop's two-hand path.  -> dict(vh, vo, mesh, terms [(array (N,778,3), weight)], rec (N,8), obj_terms [(array (B,Vo,3), weight)])"""
+    lw = loss_weights
+    on = lambda k: lw.get(k, 0.0) > 0
+    h = 2
+    c = lambda t: np.ascontiguousarray(t.detach().numpy(), f32)
+    with torch.no_grad():
+        per_hand = [model.mano_forward(model.mano_pca_pose[i::h], model.mano_rot[i::h], model.mano_betas[i::h], side)
+                    for i, side in enumerate(model.hand_sides)]
+        mesh_t = torch.stack(per_hand).transpose(0, 1).contiguous().view(-1, 778, 3) + model.mano_trans.unsqueeze(1)
+        vh_t, _ = model.get_verts_hand()
+        vo_t, _ = model.get_verts_object()
+    mesh, vh, vo = c(mesh_t), c(vh_t), c(vo_t)
+    N, B, Vo = vh.shape[0], vo.shape[0], vo.shape[1]
+    K = c(model.camintr)
+    hands = [np.ascontiguousarray(vh[i::h]) for i in range(h)]
+    terms, obj_terms = [], []
+    if on("lw_smooth_hand") or on("lw_smooth_obj"):
+        terms.append((smooth_unit_grad_rows(vh, h), lw["lw_smooth_hand"]))
+    if on("lw_v2d_hand"):
+        terms.append((v2d_unit_grad(vh, K, c(model.ref_verts2d_hand), model.image_size, h), lw["lw_v2d_hand"]))
+    stages = {}
+    if on("lw_collision"):
+        rev = np.ascontiguousarray(np.asarray(model.closed_faces)[:, ::-1])          # both hands in reversed winding (:53-59)
+        fo = model.faces_object[0].numpy()
+        d = [collision_unit_grad(hands[0], hands[1], rev)[0], collision_unit_grad(hands[1], hands[0], rev)[0],
+             collision_unit_grad(hands[0], vo, fo)[0], collision_unit_grad(hands[1], vo, fo)[0]]
+        for a, b in ((d[0], d[1]), (d[2], d[3])):          # from the hand-hand scene, then from each hand's scene with the object
+            u = np.empty((N, 778, 3), f32)
+            u[0::h], u[1::h] = a, b
+            terms.append((u, lw["lw_collision"]))
+        stages["col"] = d
+    if on("lw_contact"):
+        u = np.empty((N, 778, 3), f32)
+        stages["nn_idx"], stages["con_obj"] = [], []
+        for i in range(h):
+            idx = nearest_object_vertex(hands[i], vo)
+            gh, go = contact_unit_grads(hands[i], vo, idx)
+            u[i::h] = gh
+            obj_terms.append((go, lw["lw_contact"] / h))
+            stages["nn_idx"].append(idx)
+            stages["con_obj"].append(go)
+        terms.append((u, lw["lw_contact"] / h))
+    rec = None
+    if on("lw_inter"):
+        rec = np.zeros((N, 8), f32)
+        for i in range(h):
+            rec[i::h] = inter_records(hands[i], vo, K)
+        if model.optimize_object_scale:                 # the term reaches the (not detached) object then: sum over the hands
+            gi = [((f32(0.0) - f32(lw["lw_inter"])) * np.ascontiguousarray(rec[i::h, 2:5]) / f32(Vo)) for i in range(h)]
+            g = gi[0] + gi[1]
+            obj_terms.append((np.ascontiguousarray(np.broadcast_to(g[:, None, :], (B, Vo, 3)), f32), 1.0))
+    return dict(vh=vh, vo=vo, mesh=mesh, terms=terms, rec=rec, obj_terms=obj_terms, stages=stages)
+
+
+def _two_hand_param_grads(model, loss_weights, return_stages, two=None):
+    lw = loss_weights
+    on = lambda k: lw.get(k, 0.0) > 0
+    h = 2
+    c = lambda t: np.ascontiguousarray(t.detach().numpy(), f32)
+    two = two_hand_terms(model, lw) if two is None else two
+    N = two["vh"].shape[0]
+    B = N // h
+    pca = c(model.mano_pca_pose)
+    P = pca.shape[1]
+    arrs = [np.ascontiguousarray(t, f32) for t, _ in two["terms"]]
+    ptrs = (ctypes.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+    ws = np.asarray([w for _, w in two["terms"]] or [0.0], f32)
+    g_frame = np.ascontiguousarray(two["rec"][:, 2:5]) if two["rec"] is not None else None
+    g_mesh, g_r6, g_rt = np.empty((N, 778, 3), f32), np.zeros((N, 6), f32), np.zeros((N, 3), f32)
+    # the hands' rigid backward as a launch of its own: one workgroup of 1024 threads per row (csrc/geometry.hip k_rigid_bwd<false>)
+    clib.lib().orc_rigid_bwd_rows(clib.fptr(two["mesh"]), clib.fptr(c(model.rotations_hand).reshape(N, 6)),
+                                  float(model.int_scales_hand.detach()[0]), ptrs, clib.fptr(ws), len(arrs),
+                                  clib.fptr(g_frame) if g_frame is not None else None, 3,
+                                  float(f32(lw["lw_inter"] / 778)) if g_frame is not None else 0.0, N, 778, 1024, clib.fptr(g_mesh),
+                                  clib.fptr(g_r6), clib.fptr(g_rt))
+    g_extra = np.ascontiguousarray((f32(2.0) * pca) * (f32(1.0) / f32(pca.size)), f32) if on("lw_pca") else None
+    out = dict(mano_pca_pose=np.zeros((N, P), f32), mano_rot=np.zeros((N, 3), f32), mano_betas=np.zeros((N, 10), f32),
+               mano_trans=np.zeros((N, 3), f32))
+    rot, betas = c(model.mano_rot), c(model.mano_betas)
+    for i, side in enumerate(model.hand_sides):
+        lay = model.hands[side]["layout"]
+        clib.lib().orc_mano_bwd_rows(*[clib.fptr(a) for a in lay[:7]], clib.iptr(lay[7]), clib.fptr(pca), P, clib.fptr(rot),
+                                     clib.fptr(betas), clib.fptr(g_mesh), clib.fptr(g_extra) if g_extra is not None else None,
+                                     float(lw.get("lw_pca", 0.0)), B, i, h, clib.fptr(out["mano_pca_pose"]),
+                                     clib.fptr(out["mano_rot"]), clib.fptr(out["mano_betas"]), clib.fptr(out["mano_trans"]))
+    out["rotations_hand"], out["translations_hand"] = g_r6.reshape(N, 3, 2), g_rt.reshape(N, 1, 3)
+    if return_stages:
+        return out, dict(two, g_mesh=g_mesh)
+    return out
+
+
+def hand_param_grads(model, loss_weights, return_stages=False, pair=None, depth_hand=None, two=None):
     """-> {name: float32 numpy array shaped like the parameter} for the six hand parameters (see the module docstring)."""
     lw = loss_weights
     on = lambda k: lw.get(k, 0.0) > 0
+    if (model.hand_nb == 2 and not on("lw_depth") and not on("lw_sil_hand") and model.optimize_mano and
+            isinstance(model.mano_betas, torch.nn.Parameter) and not model.int_scales_hand.requires_grad and
+            model.losses.inter_type == "centroid"):
+        return _two_hand_param_grads(model, lw, return_stages, two)
     if ((on("lw_depth") and depth_hand is None) or on("lw_sil_hand") or model.hand_nb != 1 or not model.optimize_mano or
             not isinstance(model.mano_betas, torch.nn.Parameter) or model.int_scales_hand.requires_grad or
             model.losses.inter_type != "centroid"):

@@ -49,6 +49,18 @@ def reproducible_grads(model, loss_weights, log2q=0):
         for p in obj:
             p.requires_grad_(True)
     from . import handchain
+    if model.hand_nb == 2 and not loss_weights.get("lw_depth", 0) > 0:
+        # two hands per frame: the terms between the meshes per hand, then the object's and the hands' chains
+        two = handchain.two_hand_terms(model, loss_weights)
+        grads = objchain.object_pose_grads(model, loss_weights, log2q, obj_terms=two["obj_terms"])
+        try:
+            grads.update(handchain.hand_param_grads(model, loss_weights, two=two))
+        except NotImplementedError:
+            pass
+        for k, g in grads.items():
+            p = getattr(model, k)
+            p.grad = torch.from_numpy(g).reshape(p.shape)
+        return loss_dict, metric_dict, loss
     pair = None
     if loss_weights.get("lw_contact", 0) > 0 or loss_weights.get("lw_collision", 0) > 0:     # step-2 terms between the meshes
         with torch.no_grad():

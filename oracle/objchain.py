@@ -90,15 +90,17 @@ def rigid_bwd_sil_exact(mesh, rot6d, scale, abs_scale, terms, parts, adj, cam_ve
     return g_rot, g_tr, g_sc, g_v
 
 
-def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact_obj=None, inter_rec=None, depth_obj=None):
+def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact_obj=None, inter_rec=None, depth_obj=None,
+                      obj_terms=None):
     """-> {"rotations_object": (B,3,2), "translations_object": (B,1,3)[, "int_scales_object": (1,)]} float32 numpy (see the module
     docstring).  contact_obj: d loss_contact / d object vertices (B,V,3) of the step-2 sets (oracle/handchain.py pair_terms).
     With a free object scale (optimize_object_scale; the object is then NOT detached in the interaction term, homan/homan.py:
     482-490) inter_rec (B,8) are that term's per-frame records (oracle/handchain.py inter_records)."""
     lw = loss_weights
     free_scale = bool(model.optimize_object_scale)
-    if ((lw.get("lw_depth", 0) > 0 and depth_obj is None) or (lw.get("lw_contact", 0) > 0 and contact_obj is None) or
-            (free_scale and lw.get("lw_inter", 0) > 0 and inter_rec is None)):
+    if obj_terms is None and ((lw.get("lw_depth", 0) > 0 and depth_obj is None) or
+                              (lw.get("lw_contact", 0) > 0 and contact_obj is None) or
+                              (free_scale and lw.get("lw_inter", 0) > 0 and inter_rec is None)):
         raise NotImplementedError("the written-out object chain covers silhouette + smoothness (+ the contact / interaction "
                                   "terms' gradients on the object's vertices, handed in)")
     with torch.no_grad():
@@ -125,9 +127,11 @@ def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact
     terms = []
     if lw.get("lw_smooth_obj", 0) > 0 or lw.get("lw_smooth_hand", 0) > 0:
         terms.append((smooth_unit_grad(verts), lw["lw_smooth_obj"]))
-    if lw.get("lw_contact", 0) > 0:
+    if obj_terms is not None:           # (two hands: the pair terms' gradients on the object, ready-made, oracle/handchain.py)
+        terms.extend((np.ascontiguousarray(a, f32), w) for a, w in obj_terms)
+    elif lw.get("lw_contact", 0) > 0:
         terms.append((np.ascontiguousarray(contact_obj, f32), lw["lw_contact"]))
-    if free_scale and lw.get("lw_inter", 0) > 0:
+    if obj_terms is None and free_scale and lw.get("lw_inter", 0) > 0:
         # d (lw_inter * loss_inter) / d object vertex = -lw_inter * gate * 2 (c_hand - c_obj) / 3 / V, the same for every vertex
         gi = (f32(0.0) - f32(lw["lw_inter"])) * np.ascontiguousarray(inter_rec[:, 2:5], f32) / f32(V)
         terms.append((np.ascontiguousarray(np.broadcast_to(gi[:, None, :], (B, V, 3)), f32), 1.0))

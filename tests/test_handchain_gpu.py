@@ -14,13 +14,13 @@ pytestmark = pytest.mark.gpu
 HAND = ("mano_pca_pose", "mano_rot", "mano_betas", "mano_trans", "rotations_hand", "translations_hand")
 
 
-def _pair(mano_model, seed, frames, size, obj, **options):
+def _pair(mano_model, seed, frames, size, obj, hands=("right",), **options):
     from homan_amd import HOMan, synth
     from oracle.jointopt import collate_inputs
     from oracle.model import OracleHOMan
     sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
     clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
-                           hand_verts_fn=hand_fn)
+                           hand_verts_fn=hand_fn, hands=hands)
     kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
     common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=size,
                   mano_model=mano_model, rend_size=size, **options)
@@ -214,3 +214,53 @@ def test_tied_object_scale_over_three_clips_bit_equal(mano_model):
                 got = st.model.clip_slice(getattr(st.model, k), c).detach().cpu().numpy()
                 assert np.array_equal(got.reshape(-1), cpu[k].detach().numpy().reshape(-1)), (i, c, k)
     assert abs(float(oms[0].int_scales_object.detach()[0]) - 1.0) > 1e-3
+
+
+@pytest.mark.parametrize("free_scale", [False, True])
+def test_two_hands_bit_equal(free_scale, mano_model):
+    """Two hands per frame (right + left, rows interleaved frame-major; reference homan/homan.py:62-63, 341-358, lossutils.py:
+    53-59, 116-127), step-2 loss set: the per-hand pair terms (search, contact, interaction records, the three collision scenes),
+    the hands' rigid backward as a launch of its own, the MANO backward per hand through its side's model - every stage, every
+    parameter gradient, then 20 free-running steps bit-equal in every parameter."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle import handchain, objchain
+    from oracle.jointopt import make_optimizer, reproducible_step
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    opts = dict(optimize_object_scale=True) if free_scale else {}
+    hm, om = _pair(mano_model, seed=31, frames=6, size=128, obj="bottle", hands=("right", "left"), **opts)
+    g = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for name, amp in (("mano_betas", 0.3), ("mano_pca_pose", 0.2), ("mano_trans", 0.01), ("mano_rot", 0.05)):
+            d = amp * torch.randn(getattr(om, name).shape, generator=g)
+            getattr(om, name).add_(d)
+            getattr(hm, name).add_(d.to(getattr(hm, name).device))
+        d = 0.5 * (om.translations_object.repeat_interleave(2, 0) - om.translations_hand)     # both hands into the object
+        om.translations_hand.add_(d)
+        hm.translations_hand.add_(d.to(hm.translations_hand.device))
+    st = FusedStepper(hm, lw, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    two = handchain.two_hand_terms(om, lw)
+    assert np.array_equal(st.vh.cpu().numpy(), two["vh"]) and np.array_equal(st.vm.cpu().numpy(), two["mesh"])
+    for n, (arr, _) in zip(("U_smh", "U_v2d", "U_colh", "U_colh2", "U_conh"), two["terms"]):
+        assert np.array_equal(getattr(st, n).cpu().numpy(), arr), n
+    assert np.abs(two["terms"][2][0]).max() > 0 and np.abs(two["terms"][3][0]).max() > 0        # both collision families live
+    assert np.array_equal(st.rec.cpu().numpy()[:, [0, 2, 3, 4]], two["rec"][:, [0, 2, 3, 4]])
+    want, stg = handchain.hand_param_grads(om, lw, return_stages=True, two=two)
+    assert np.array_equal(st.G_mesh.cpu().numpy(), stg["g_mesh"])
+    want.update(objchain.object_pose_grads(om, lw, obj_terms=two["obj_terms"]))
+    assert ("int_scales_object" in want) == free_scale
+    report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
+    assert all(report.values()), report
+    hm, om = _pair(mano_model, seed=32, frames=6, size=128, obj="bottle", hands=("right", "left"), **opts)
+    st = FusedStepper(hm, lw, 1e-2, 20)
+    opt = make_optimizer(om, 1e-2, reproducible=True)
+    for i in range(20):
+        st.run(1)
+        reproducible_step(om, lw, opt)
+        torch.cuda.synchronize()
+        cpu = dict(om.named_parameters())
+        diff = [k for k, p in hm.named_parameters()
+                if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
+        assert not diff, (i, diff)

@@ -16,13 +16,13 @@ from tests import util
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def _clip_model(mano_model, seed=0, frames=4, size=64, obj="cube"):
+def _clip_model(mano_model, seed=0, frames=4, size=64, obj="cube", hands=("right",)):
     from homan_amd import synth
     from oracle.jointopt import collate_inputs
     from oracle.model import OracleHOMan
     sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
     clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
-                           hand_verts_fn=hand_fn)
+                           hand_verts_fn=hand_fn, hands=hands)
     kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
     return OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
                        image_size=size, mano_model=mano_model, rend_size=size, **kw), clip
@@ -169,6 +169,39 @@ def test_written_out_chain_with_a_free_object_scale(mano_model):
                                    err_msg=name)
 
 
+@pytest.mark.parametrize("free_scale", [False, True])
+def test_written_out_chain_with_two_hands(free_scale, mano_model):
+    """hand_nb = 2 (right + left), step-2 set, both hands moved into the object: the written-out chains (oracle/handchain.py
+    two_hand_terms: per-hand search / contact / interaction, three collision scenes; the hands' rigid backward; the MANO
+    backward per hand through its side's model) against autograd through the faithful restatement."""
+    from homan_amd import synth
+    from oracle import handchain, objchain
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=4, frames=4, rend_size=64, image_size=64, obj="cube", silhouette_fn=sil_fn, hand_verts_fn=hand_fn,
+                           hands=("right", "left"))
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    model = OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                        optimize_object_scale=free_scale, image_size=64, mano_model=mano_model, rend_size=64, **kw)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    with torch.no_grad():
+        model.mano_betas.add_(0.2 * torch.randn(model.mano_betas.shape, generator=torch.Generator().manual_seed(0)))
+        model.translations_hand.add_(0.5 * (model.translations_object.repeat_interleave(2, 0) - model.translations_hand))
+    loss_dict, _ = model(loss_weights=lw)
+    assert float(loss_dict["loss_collision"].detach()) > 0
+    sum(loss_dict[k] * lw[k.replace("loss", "lw")] for k in loss_dict).backward()
+    two = handchain.two_hand_terms(model, lw)
+    got = handchain.hand_param_grads(model, lw, two=two)
+    got.update(objchain.object_pose_grads(model, lw, obj_terms=two["obj_terms"]))
+    assert len(got) == (9 if free_scale else 8)
+    for name, g in got.items():
+        ref = getattr(model, name).grad.numpy()
+        scale = np.abs(ref).max()
+        np.testing.assert_allclose(g.reshape(ref.shape) / scale, ref / scale, atol=3e-4 if "rotations_object" in name else 1e-4,
+                                   err_msg=name)
+
+
 def test_exact_pseudo_gradient_equals_the_faithful_loop(mano_model):
     """per (face, corner): the exact-sum variant against orc_nmr_grad_faces_alpha (the published loop order, fp32 sums)"""
     from homan_amd import synth
@@ -214,7 +247,8 @@ from tests.test_objchain import _clip_model
 from oracle.jointopt import make_optimizer, reproducible_step
 mano = synthetic_mano(0)
 torch.set_num_threads(1)            # (the INPUTS - 2-D targets projected with torch - are made the same way in both runs)
-model, _ = _clip_model(mano, seed=1, frames=4, size=64, obj="cube")
+model, _ = _clip_model(mano, seed=1, frames=4, size=64, obj="cube", **(dict(hands=("right", "left")) if sys.argv[3].endswith("+2") else dict()))
+sys.argv[3] = sys.argv[3].replace("+2", "")
 torch.set_num_threads(int(sys.argv[1]))
 lw = dict(getattr(synth, sys.argv[3]))
 opt = make_optimizer(model, 1e-2, reproducible=True)
@@ -224,7 +258,7 @@ np.save(sys.argv[2], np.concatenate([p.detach().numpy().ravel() for _, p in sort
 """
 
 
-@pytest.mark.parametrize("weights_name", ["CFG1_LOSS_WEIGHTS", "STEP1_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS"])
+@pytest.mark.parametrize("weights_name", ["CFG1_LOSS_WEIGHTS", "STEP1_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS+2"])
 def test_trajectory_does_not_depend_on_the_thread_count(weights_name, tmp_path):
     """the oracle's end state was a function of OMP_NUM_THREADS.  With the written-out chains (object: oracle/
     objchain.py, hand: oracle/handchain.py) EVERY parameter after 12 steps is bit-identical at 1 and 4 threads."""
