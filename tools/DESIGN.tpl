@@ -180,9 +180,11 @@ vertices 0.0 mm apart for the object AND the hand, every logged loss within 3.4e
 parallel float sums and keep their rounding, the trajectory does not see them).  Until the hand's chain was written out (first
 half of this round) the hand separated around step 170-180 of the cfg2 clip - 0.14 mm at step 400 - exactly where the CPU loop
 separates from ITSELF when its hand translations start 1e-7 m apart (`r04_control_cfg2_400.json`: 0.85 mm): Adam at 10 x lr on
-the MANO parameters amplifies any difference, so only a chain without any could close it.  Not written out: two hands per frame,
-`inter_type="min"`, `optimize_mano=False` (`oracle/handchain.py` raises NotImplementedError, the oracle then keeps autograd's
-gradients for the hand); there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
+the MANO parameters amplifies any difference, so only a chain without any could close it.  Two hands per frame (right + left,
+rows interleaved, the step-2 set with its three collision scenes, fixed or free scale) are written out as well and bit-equal over
+20 free-running steps (`tests/test_handchain_gpu.py::test_two_hands_bit_equal`).  Not written out: `inter_type="min"`,
+`optimize_mano=False`, the depth term with two hands (`oracle/handchain.py` raises NotImplementedError, the oracle then keeps
+autograd's gradients for the hand); there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
 path: nothing at one clip, -2 % on an 8-clip batch (EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the
 divisions; the hand side's kernels did not change but for the sin / cos.
 
@@ -445,6 +447,8 @@ file the reference never reaches.  More than two hands: the reference's own coll
 5. The written-out chains cover one hand with `optimize_mano`, the centroid interaction term, every loss set of BASELINE's
    configurations (step 1, step 1 + depth, step 2), a fixed or free object scale, and the scale tied across the clips of one
    rank (cfg5: the clips' gradients through one block sum, `reproducible_step_shared_scale`; three clips bit-equal over 20
-   steps).  Two hands (the second hand's rows through the left model, three SDF scenes) and `inter_type="min"` are compared per
-   step (lock-step) only; across RANKS the tied gradient is one fp32 all-reduce, whose order for more than two ranks is RCCL's.
+   steps), and two hands per frame (each hand's rows through its side's model, per-hand pair terms, three SDF scenes, the hands'
+   rigid backward as the launch of its own the two-hand loop uses).  `inter_type="min"`, `optimize_mano=False` and the depth term
+   with two hands are compared per step (lock-step) only; across RANKS the tied gradient is one fp32 all-reduce, whose order for
+   more than two ranks is RCCL's.
 6. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.

@@ -1,2 +1,2 @@
 R=$(pwd); O=$R/gpurun_out
-python tools/poseinit_tune.py > $O/g47_tune.json 2>$O/g47.err; cat $O/g47_tune.json; tail -2 $O/g47.err
+timeout 1500 python -m pytest tests/test_handchain_gpu.py -q -k two_hands > $O/g48.log 2>&1; tail -30 $O/g48.log | cut -c1-700
