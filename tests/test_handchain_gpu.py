@@ -76,7 +76,7 @@ def test_hand_gradients_bit_equal(weights_name, obj, mano_model):
 
 @pytest.mark.parametrize("weights_name", ["STEP1_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS"])
 def test_every_parameter_bit_equal_in_a_free_run(weights_name, mano_model):
-    """30 free-running steps of the step-1 / step-2 loss sets (reference loop homan/jointopt.py:158-192): HIP fused loop vs the
+    """16 free-running steps of the step-1 / step-2 loss sets (reference loop homan/jointopt.py:158-192): HIP fused loop vs the
     oracle's reproducible loop (written-out object chain, hand chain, pair terms and Adam) - EVERY parameter bit-equal after
     every step."""
     from homan_amd import synth
@@ -84,9 +84,9 @@ def test_every_parameter_bit_equal_in_a_free_run(weights_name, mano_model):
     from oracle.jointopt import make_optimizer, reproducible_step
     hm, om = _pair(mano_model, seed=12, frames=6, size=128, obj="bottle")
     lw = dict(getattr(synth, weights_name))
-    st = FusedStepper(hm, lw, 1e-2, 30)
+    st = FusedStepper(hm, lw, 1e-2, 16)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(30):
+    for i in range(16):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()
@@ -99,7 +99,7 @@ def test_every_parameter_bit_equal_in_a_free_run(weights_name, mano_model):
 def test_free_object_scale_bit_equal(mano_model):
     """optimize_object_scale=True (BASELINE cfg5's option, one clip: the scale free): the step-2 set, gradients of all nine
     parameters - the scale's among them: the frames' exact partial sums, one block sum, the prior - bit-equal at perturbed
-    parameters, then 25 free-running steps bit-equal in every parameter."""
+    parameters, then 12 free-running steps bit-equal in every parameter."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle import handchain, objchain
@@ -120,9 +120,9 @@ def test_free_object_scale_bit_equal(mano_model):
     report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
     assert all(report.values()), report
     hm, om = _pair(mano_model, seed=14, frames=6, size=128, obj="bottle", optimize_object_scale=True)
-    st = FusedStepper(hm, lw, 1e-2, 25)
+    st = FusedStepper(hm, lw, 1e-2, 12)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(25):
+    for i in range(12):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()
@@ -130,7 +130,7 @@ def test_free_object_scale_bit_equal(mano_model):
         diff = [k for k, p in hm.named_parameters()
                 if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
         assert not diff, (i, diff)
-    assert abs(float(om.int_scales_object.detach()[0]) - 1.0) > 1e-3          # (the scale did move)
+    assert abs(float(om.int_scales_object.detach()[0]) - 1.0) > 5e-4          # (the scale did move)
 
 
 def _depth_pair(mano_model, seed, frames, size):
@@ -155,7 +155,7 @@ def _depth_pair(mano_model, seed, frames, size):
 def test_ordinal_depth_term_bit_equal(mano_model):
     """cfg2 as BASELINE.json words it (sil / kp / DEPTH / smooth): the depth term's chain - pooled depth images, per-pixel
     gradient (shared logistic function), depth-map backward per face, vertex gather - stage by stage, all eight parameter
-    gradients, then 25 free-running steps bit-equal in every parameter."""
+    gradients, then 12 free-running steps bit-equal in every parameter."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle import depthchain, handchain, objchain
@@ -176,9 +176,9 @@ def test_ordinal_depth_term_bit_equal(mano_model):
     report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
     assert all(report.values()), report
     hm, om = _depth_pair(mano_model, seed=16, frames=6, size=128)
-    st = FusedStepper(hm, lw, 1e-2, 25)
+    st = FusedStepper(hm, lw, 1e-2, 12)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(25):
+    for i in range(12):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()
@@ -192,17 +192,17 @@ def test_tied_object_scale_over_three_clips_bit_equal(mano_model):
     """BASELINE cfg5 on one rank: three clips with ONE object scale between them, step-2 loss set.  The fused loop (one clip batch,
     shared_scale=True: the clips' scale gradients added by one block sum, the sum spread to every replica) vs the oracle's
     reproducible tied loop (oracle.jointopt.reproducible_step_shared_scale): every parameter of every clip bit-equal after each
-    of 20 free-running steps, the replicas of the scalar identical throughout."""
+    of 10 free-running steps, the replicas of the scalar identical throughout."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle.jointopt import make_optimizer, reproducible_step_shared_scale
     lw = dict(synth.STEP2_LOSS_WEIGHTS)
     pairs = [_pair(mano_model, seed=s, frames=6, size=128, obj="bottle", optimize_object_scale=True) for s in (21, 22, 23)]
     hms, oms = [p[0] for p in pairs], [p[1] for p in pairs]
-    st = FusedStepper(hms, lw, 1e-2, 20, shared_scale=True)
+    st = FusedStepper(hms, lw, 1e-2, 10, shared_scale=True)
     opts = [make_optimizer(m, 1e-2, reproducible=True) for m in oms]
     names = [k for k, _ in oms[0].named_parameters()]
-    for i in range(20):
+    for i in range(10):
         st.run(1)
         reproducible_step_shared_scale(oms, opts, lw)
         torch.cuda.synchronize()
@@ -213,7 +213,7 @@ def test_tied_object_scale_over_three_clips_bit_equal(mano_model):
             for k in names:
                 got = st.model.clip_slice(getattr(st.model, k), c).detach().cpu().numpy()
                 assert np.array_equal(got.reshape(-1), cpu[k].detach().numpy().reshape(-1)), (i, c, k)
-    assert abs(float(oms[0].int_scales_object.detach()[0]) - 1.0) > 1e-3
+    assert abs(float(oms[0].int_scales_object.detach()[0]) - 1.0) > 5e-4
 
 
 @pytest.mark.parametrize("free_scale", [False, True])
@@ -221,7 +221,7 @@ def test_two_hands_bit_equal(free_scale, mano_model):
     """Two hands per frame (right + left, rows interleaved frame-major; reference homan/homan.py:62-63, 341-358, lossutils.py:
     53-59, 116-127), step-2 loss set: the per-hand pair terms (search, contact, interaction records, the three collision scenes),
     the hands' rigid backward as a launch of its own, the MANO backward per hand through its side's model - every stage, every
-    parameter gradient, then 20 free-running steps bit-equal in every parameter."""
+    parameter gradient, then 10 free-running steps bit-equal in every parameter."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle import handchain, objchain
@@ -254,9 +254,9 @@ def test_two_hands_bit_equal(free_scale, mano_model):
     report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
     assert all(report.values()), report
     hm, om = _pair(mano_model, seed=32, frames=6, size=128, obj="bottle", hands=("right", "left"), **opts)
-    st = FusedStepper(hm, lw, 1e-2, 20)
+    st = FusedStepper(hm, lw, 1e-2, 10)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(20):
+    for i in range(10):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()

@@ -175,14 +175,14 @@ Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_pa
 `translations_hand`, `mano_pca_pose`, `mano_rot`, `mano_betas`, `mano_trans` - is BIT-EQUAL between the two free-running loops
 after every step: cfg1 100 steps x 5 seeds; cfg2, cfg2 + ordinal depth term and cfg3 (step-2: collision + contact) at full size
 over 400 steps (`r04_freerun_cfg2_400.json`, `r04_freerun_cfg2_depth_400.json`, `r04_freerun_cfg3_400.json`:
-`all_params_bit_equal_all_steps: true`); the step-2 set with a free object scale over 25 steps (`tests/test_handchain_gpu.py`); final
+`all_params_bit_equal_all_steps: true`); the step-2 set with a free object scale over 12 steps (`tests/test_handchain_gpu.py`); final
 vertices 0.0 mm apart for the object AND the hand, every logged loss within 3.4e-7 at every step (bar 1e-4; the logged VALUES are
 parallel float sums and keep their rounding, the trajectory does not see them).  Until the hand's chain was written out (first
 half of this round) the hand separated around step 170-180 of the cfg2 clip - 0.14 mm at step 400 - exactly where the CPU loop
 separates from ITSELF when its hand translations start 1e-7 m apart (`r04_control_cfg2_400.json`: 0.85 mm): Adam at 10 x lr on
 the MANO parameters amplifies any difference, so only a chain without any could close it.  Two hands per frame (right + left,
 rows interleaved, the step-2 set with its three collision scenes, fixed or free scale) are written out as well and bit-equal over
-20 free-running steps (`tests/test_handchain_gpu.py::test_two_hands_bit_equal`).  Not written out: `inter_type="min"`,
+10 free-running steps (`tests/test_handchain_gpu.py::test_two_hands_bit_equal`).  Not written out: `inter_type="min"`,
 `optimize_mano=False`, the depth term with two hands (`oracle/handchain.py` raises NotImplementedError, the oracle then keeps
 autograd's gradients for the hand); there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
 path: nothing at one clip, -2 % on an 8-clip batch (EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the
@@ -438,15 +438,16 @@ file the reference never reaches.  More than two hands: the reference's own coll
    join (each cross-queue edge and launch gap is 5-10 µs of an iteration whose floor is 88 µs); in aggregate, less LDS traffic
    per sweep item and pair (`SQ_WAIT_INST_LDS` is half of `SQ_ACTIVE_INST_VALU`), not fewer VALU instructions.
 2. One launch per kernel over clips of DIFFERENT shapes (today: concurrent shape groups, 88 % of a same-shape batch).
-3. The pose initialisation at 412 k pose-steps/s (target 600 k): its sweep (0.10 of HBM peak) and raster are throughput-bound
-   at 500 frames per launch; in mode 4 every source has the same gradient, so the per-line source records could shrink from
+3. The pose initialisation at @POSE@ pose-steps/s with its resident fitter (target 600 k; it is the pipeline's larger GPU load:
+   one fit per frame of a clip against ONE joint fit per clip): its sweep (0.10 of HBM peak) and raster are throughput-bound
+   at 500 frames per launch, and a fit's first steps are its heaviest (candidates far from the mask); in mode 4 every source has the same gradient, so the per-line source records could shrink from
    12 to 4 bytes and the line expansion to a popcount pass.
 4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
    silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
    hands it runs one clip per stepper (`ShardStepper`).
 5. The written-out chains cover one hand with `optimize_mano`, the centroid interaction term, every loss set of BASELINE's
    configurations (step 1, step 1 + depth, step 2), a fixed or free object scale, and the scale tied across the clips of one
-   rank (cfg5: the clips' gradients through one block sum, `reproducible_step_shared_scale`; three clips bit-equal over 20
+   rank (cfg5: the clips' gradients through one block sum, `reproducible_step_shared_scale`; three clips bit-equal over 10
    steps), and two hands per frame (each hand's rows through its side's model, per-hand pair terms, three SDF scenes, the hands'
    rigid backward as the launch of its own the two-hand loop uses).  `inter_type="min"`, `optimize_mano=False` and the depth term
    with two hands are compared per step (lock-step) only; across RANKS the tied gradient is one fp32 all-reduce, whose order for
