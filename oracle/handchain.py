@@ -224,15 +224,18 @@ def hand_param_grads(model, loss_weights, return_stages=False, pair=None, depth_
             isinstance(model.mano_betas, torch.nn.Parameter) and not model.int_scales_hand.requires_grad and
             model.losses.inter_type == "centroid"):
         return _two_hand_param_grads(model, lw, return_stages, two)
-    if ((on("lw_depth") and depth_hand is None) or on("lw_sil_hand") or model.hand_nb != 1 or not model.optimize_mano or
-            not isinstance(model.mano_betas, torch.nn.Parameter) or model.int_scales_hand.requires_grad or
-            model.losses.inter_type != "centroid"):
+    if ((on("lw_depth") and depth_hand is None) or on("lw_sil_hand") or model.hand_nb != 1 or
+            (model.optimize_mano and not isinstance(model.mano_betas, torch.nn.Parameter)) or
+            model.int_scales_hand.requires_grad or model.losses.inter_type != "centroid"):
         raise NotImplementedError("the written-out hand chain covers the step-1 / step-2 loss sets of a one-hand clip")
     side = model.hand_sides[0]
     c = lambda t: np.ascontiguousarray(t.detach().numpy(), f32)
     with torch.no_grad():
-        lbs_verts = model.mano_forward(model.mano_pca_pose, model.mano_rot, model.mano_betas, side)
-        mesh_t = lbs_verts + model.mano_trans.unsqueeze(1)
+        if model.optimize_mano:
+            lbs_verts = model.mano_forward(model.mano_pca_pose, model.mano_rot, model.mano_betas, side)
+            mesh_t = lbs_verts + model.mano_trans.unsqueeze(1)
+        else:                                   # the hand mesh is an input (homan/homan.py:104-106): only its rigid pose moves
+            mesh_t = model.verts_hand_og
         vh_t, _ = model.get_verts_hand()
         vo_t, _ = model.get_verts_object()
     mesh, vh, vo = c(mesh_t), c(vh_t), c(vo_t)
@@ -252,6 +255,22 @@ def hand_param_grads(model, loss_weights, return_stages=False, pair=None, depth_
     if on("lw_depth"):          # d (lw_depth * loss_depth) / d hand vertices (oracle/depthchain.py), already times its weight
         terms.append((np.ascontiguousarray(depth_hand, f32), 1.0))
     rec = inter_records(vh, vo, K) if on("lw_inter") else None
+    if not model.optimize_mano:
+        # rigid pose only: the launch of its own (csrc/geometry.hip k_rigid_bwd<false>, one 1024-thread workgroup per frame)
+        arrs = [np.ascontiguousarray(t, f32) for t, _ in terms]
+        ptrs = (ctypes.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
+        ws = np.asarray([w for _, w in terms] or [0.0], f32)
+        g_frame = np.ascontiguousarray(rec[:, 2:5]) if rec is not None else None
+        g_mesh, g_r6, g_rt = np.empty((B, 778, 3), f32), np.zeros((B, 6), f32), np.zeros((B, 3), f32)
+        clib.lib().orc_rigid_bwd_rows(clib.fptr(mesh), clib.fptr(c(model.rotations_hand).reshape(B, 6)),
+                                      float(model.int_scales_hand.detach()[0]), ptrs, clib.fptr(ws), len(arrs),
+                                      clib.fptr(g_frame) if g_frame is not None else None, 3,
+                                      float(f32(lw["lw_inter"] / 778)) if g_frame is not None else 0.0, B, 778, 1024,
+                                      clib.fptr(g_mesh), clib.fptr(g_r6), clib.fptr(g_rt))
+        out = dict(rotations_hand=g_r6.reshape(B, 3, 2), translations_hand=g_rt.reshape(B, 1, 3))
+        if return_stages:
+            return out, dict(mesh=mesh, vh=vh, vo=vo, terms=terms, rec=rec, pair=pair)
+        return out
     pca = c(model.mano_pca_pose)
     P = pca.shape[1]
     g_extra = None

@@ -264,3 +264,50 @@ def test_two_hands_bit_equal(free_scale, mano_model):
         diff = [k for k, p in hm.named_parameters()
                 if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
         assert not diff, (i, diff)
+
+
+def test_fixed_hand_mesh_bit_equal(mano_model):
+    """optimize_mano=False (reference homan/homan.py:104-106: the hand mesh is an input, only its rigid pose is optimised),
+    step-2 set: gradients of the four pose tensors, then 12 free-running steps, bit-equal."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle import handchain, objchain
+    from oracle.jointopt import make_optimizer, reproducible_step
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    from homan_amd import HOMan
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+
+    def build(seed):
+        clip = synth.make_clip(seed=seed, frames=6, rend_size=128, image_size=128, obj="bottle", silhouette_fn=sil_fn,
+                               hand_verts_fn=hand_fn)
+        kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+        common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=False, image_size=128,
+                      mano_model=mano_model, rend_size=128)
+        return HOMan(**copy.deepcopy(kw), **common), OracleHOMan(**copy.deepcopy(kw), **common)
+
+    hm, om = build(41)
+    with torch.no_grad():
+        d = 0.6 * (om.translations_object - om.translations_hand)
+        om.translations_hand.add_(d)
+        hm.translations_hand.add_(d.to(hm.translations_hand.device))
+    st = FusedStepper(hm, lw, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    want, stg = handchain.hand_param_grads(om, lw, return_stages=True)
+    assert sorted(want) == ["rotations_hand", "translations_hand"]
+    want.update(objchain.object_pose_grads(om, lw, contact_obj=stg["pair"]["con_obj"]))
+    report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
+    assert all(report.values()), report
+    hm, om = build(42)
+    st = FusedStepper(hm, lw, 1e-2, 12)
+    opt = make_optimizer(om, 1e-2, reproducible=True)
+    for i in range(12):
+        st.run(1)
+        reproducible_step(om, lw, opt)
+        torch.cuda.synchronize()
+        cpu = dict(om.named_parameters())
+        diff = [k for k, p in hm.named_parameters()
+                if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
+        assert not diff, (i, diff)
