@@ -53,14 +53,15 @@ def kernel_bytes(B, S, F, noaa=False):
                     ~0.3 MB, ~45 % of the faces are active - and not counted.)
       k_bwd_sweep : face records of the work list (64 B + 4 B first item, bound: every face), index map, per-line records
                     read; per-face corner gradients (6 doubles: exact sums) written.  (Source arrays as above.)
-    noaa (the pose initialisation: rendering without anti-aliasing): the raster writes the per-sample coverage image and the
-    per-sample loss gradient instead of the pooled ones, the line expansion reads that per-sample gradient."""
+    noaa (the pose initialisation's fused loop: rendering without anti-aliasing, per-sample masked L2 against ONE binary mask,
+    hm_sil_fwd mask_shared = 3 + hm_sil_bwd mode 5): no per-sample image leaves the raster - the index map, the pooled
+    silhouette and the bit-planes are its outputs - and the line expansion reads no gradient (it is -1 / +1 by plane)."""
     is_ = 2 * S
     is2 = is_ ** 2
     if noaa:
-        return {"k_raster_fwd": B * (F * (36 + 8 + 5) + is2 * 4 + 2 * is2 * 4 + S * S * 4 + 5 * is2 // 8),
+        return {"k_raster_fwd": B * (F * (36 + 8 + 5) + is2 * 4 + S * S * 4 + 5 * is2 // 8),
                 "k_bwd_sweep": B * (F * (64 + 4) + is2 * 4 + is2 + F * 48),
-                "k_bwd_lines": B * (4 * is2 // 8 + is2 * 4 + is2 + F * (36 + 8 + 2))}
+                "k_bwd_lines": B * (4 * is2 // 8 + is2 + F * (36 + 8 + 2))}
     return {"k_raster_fwd": B * (F * (36 + 8 + 5) + is2 * 4 + 4 * S * S * 4 + 5 * is2 // 8),
             "k_bwd_sweep": B * (F * (64 + 4) + is2 * 4 + is2 + F * 48),
             "k_bwd_lines": B * (4 * is2 // 8 + S * S * 4 + is2 + F * (36 + 8 + 2))}

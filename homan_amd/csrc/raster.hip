@@ -806,8 +806,9 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     if (partials && dimg_full) {
         // per-SAMPLE masked L2 (rendering without anti-aliasing, reference homan/pose_optimization.py:140-143): keep / ref
         // are (is,is) images [shared by all frames when mask_shared], dimg_full = keep * (keep * alpha - ref) per sample
-        const float* kb = keep + (mask_shared ? 0 : (long)b * is * is);
-        const float* rb = ref + (mask_shared ? 0 : (long)b * is * is);
+        const float* kb = keep + ((mask_shared & 1) ? 0 : (long)b * is * is);
+        const float* rb = ref + ((mask_shared & 1) ? 0 : (long)b * is * is);
+        const bool ps_store = !(mask_shared & 2);          // bit 1: no per-sample outputs (the backward runs in mode 5)
         float sqs = 0.f, ins = 0.f, uns = 0.f;
         unsigned long long nq[4], pq[4];     // constant indices only (unrolled)
 #pragma unroll
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
             const float i0 = k2.x * (imin[2 * dy] >= 0 ? 1.f : 0.f), i1 = k2.y * (imin[2 * dy + 1] >= 0 ? 1.f : 0.f);
             const float d0 = i0 - r2.x, d1 = i1 - r2.y;
             const float g0 = k2.x * d0, g1 = k2.y * d1;
-            *reinterpret_cast<float2*>(dimg_full + (long)b * is * is + at) = make_float2(g0, g1);
+            if (ps_store) *reinterpret_cast<float2*>(dimg_full + (long)b * is * is + at) = make_float2(g0, g1);
             sqs += d0 * d0 + d1 * d1;
             ins += i0 * r2.x + i1 * r2.y;
             uns += fminf(fmaxf(i0 + r2.x, 0.0f), 1.0f) + fminf(fmaxf(i1 + r2.y, 0.0f), 1.0f);
@@ -832,7 +833,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
             o[0] = sq; o[1] = inter; o[2] = uni; o[3] = 0.f;
         }
     } else if (partials) {
-        const long pm = mask_shared ? (long)r * S + c : po;
+        const long pm = (mask_shared & 1) ? (long)r * S + c : po;
         const float kp = keep[pm], rf = ref[pm];      // (requesting them at kernel start was measured: no gain, +3 registers)
         const float image = kp * pool;
         const float diff = image - rf;
@@ -1388,7 +1389,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     const bool from_dimg = mode == 2 || (mode == 1 && upstream[0] > 0.0f);     // (modes 3 / 4 read gimg per sample below)
     const float* gi = (from_dimg ? dimg : gimg) + (long)b * S * S;
     const float gs = from_dimg ? upstream[0] * 2.0f : 0.f, ks = from_dimg ? keep_sum[b / clip_len] : 1.f;
-    const float up4 = mode == 4 ? upstream[b] * 2.0f : 0.f;
+    const float up4 = (mode == 4 || mode == 5) ? upstream[b] * 2.0f : 0.f;
     const int* idx = idx_map + (long)b * is * is;
     const float* gfull = gimg + (long)b * is * is;
 #pragma unroll 1
@@ -1410,7 +1411,9 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                 if (!((w >> pos) & 1ull)) continue;
                 const int d1 = (k << 6) + pos;
                 const int xi = axis ? d1 : d0, yi = axis ? d0 : d1;
-                if (mode == 3 || mode == 4) gl[q] = gfull[(long)(is - 1 - yi) * is + xi];      // per-sample gradient (no anti-aliasing)
+                if (mode == 5) gl[q] = pl ? 1.0f : -1.0f;         // binary masks: keep (keep alpha - ref) is -1 where an uncovered
+                                                                  // sample pulls and +1 where a covered one pushes - no load
+                else if (mode == 3 || mode == 4) gl[q] = gfull[(long)(is - 1 - yi) * is + xi];      // per-sample gradient (no anti-aliasing)
                 else gl[q] = gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
                 if (pl) ow[q] = idx[(long)yi * is + xi];
             }
@@ -1421,7 +1424,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                 SweepSrc r;
                 r.d1 = (k << 6) + pos;
                 float g = gl[q];
-                if (mode == 4) g = up4 * g;                                   // fused per-sample L2
+                if (mode == 4 || mode == 5) g = up4 * g;                      // fused per-sample L2
                 else if (mode != 3) {
                     if (from_dimg) g = gs * g / ks / (float)clip_len;
                     g = 0.25f * g;
@@ -2467,7 +2470,7 @@ int hm_sil_fwd_phase_clips(const float* verts, const int* faces, int faces_bstri
                        w.faces9, w.boxes, B, F, S, znear, zfar, w.idx_map, w.alpha16, pooled, keep, ref, w.dimg,
                        fused ? w.partials : (float*)nullptr, work_order, w.owned, pooled_depth, w.planes, bins,
                        w.bin_list, w.bin_done, 1, w.region_state, persistent_outputs, alpha_full, mask_shared,
-                       (fused && alpha_full) ? w.gimg : (float*)nullptr, w.counter + 24, w.ts,
+                       (fused && (alpha_full || (mask_shared & 2))) ? w.gimg : (float*)nullptr, w.counter + 24, w.ts,
                        g_raster_reorder ? w.wo_dyn : (int*)nullptr, g_raster_reorder ? w.wg_cost : (unsigned int*)nullptr);
     HM_TIME_MARK(1, stream);
     if (fused && keep_sum && loss_out)
@@ -2550,13 +2553,13 @@ int hm_sil_bwd_phase_clips(const float* verts, const float* K, int B, int V, int
     HM_CHECK_ARG(verts && K && adj_off && adj_items && workspace);        // grad_verts == NULL: no vertex gather (see hm_sil_parts)
     HM_CHECK_ARG(HM_CLIP_LEN_OK(B, clip_len));
     if (clip_len == 0) clip_len = B;
-    HM_CHECK_ARG((mode == 0 || mode == 3) ? grad_pooled != nullptr : (mode == 4 ? upstream != nullptr : (upstream && keep_sum)));
-    HM_CHECK_ARG(mode >= 0 && mode <= 4);
+    HM_CHECK_ARG((mode == 0 || mode == 3) ? grad_pooled != nullptr : ((mode == 4 || mode == 5) ? upstream != nullptr : (upstream && keep_sum)));
+    HM_CHECK_ARG(mode >= 0 && mode <= 5);
     if (S % 32 != 0 || S > 32 * SWEEP_CUMW) return HM_ERR_UNSUPPORTED;     // 64-sample mask words, <= SWEEP_CUMW per line
     SilWs w = carve(workspace, B, V, F, S);
     const int ntiles = (S / 8) * (S / 8);
     HM_CHECK_ARG(phases >= 1 && phases <= 3);
-    if ((phases & 1) && mode != 2 && mode != 4)      // modes 2 / 4: the caller guarantees upstream > 0, the forward's planes are the backward's
+    if ((phases & 1) && mode != 2 && mode != 4 && mode != 5)      // modes 2 / 4 / 5: the caller guarantees upstream > 0, the forward's planes are the backward's
         hipLaunchKernelGGL(k_bwd_masks, dim3(hm_cdiv(ntiles, 4), B), dim3(256), 0, stream,
                            mode == 1 ? w.dimg : grad_pooled, mode, upstream, keep_sum, B, S, w.alpha16, w.gimg,
                            w.planes, clip_len);

@@ -274,7 +274,7 @@ class _FusedPoseLoop:
         n, V, F, S = sctx.B, sctx.V, sctx.F, sctx.S
         f = lambda *shape: torch.zeros(*shape, device=dev)
         verts, g_off, off = f(n, V, 3), f(n, V, 3), f(n)
-        pooled, alpha, frame = f(n, S, S), f(n, 2 * S, 2 * S), f(n, 2)
+        pooled, frame = f(n, S, S), f(n, 2)
         # (views of the model's own tensors when the mask size lies on the kernels' tile grid, copies otherwise: refresh())
         self.keep, self.ref = sctx.pad_samples(model._keep1).contiguous(), sctx.pad_samples(model._ref1).contiguous()
         self.K_all, self.K_one, eps = sctx.K_eff(model._K_all).contiguous(), model.K[0].contiguous(), sctx.eps()
@@ -290,18 +290,19 @@ class _FusedPoseLoop:
         self.best_rot, self.best_trans = torch.zeros_like(model.rotations[0]), torch.zeros_like(model.translations[0])
         best_rot, best_trans = self.best_rot, self.best_trans
         self.losses_out = losses_out = f(n)
-        self._keepalive = (verts, g_off, off, pooled, alpha, frame, ones, rws, tp, tw)
+        self._keepalive = (verts, g_off, off, pooled, frame, ones, rws, tp, tw)
 
         def step():
             st = _lib.stream()
             ck(L.hm_rigid_fwd(P(model.vertices), P(model.rotations), P(model.translations), P(model._one), 0, n, V, None, P(verts),
                               st), "hm_rigid_fwd")
             ck(L.hm_offscreen_fwd(P(verts), P(K_one), n, V, NMR_FAR, 100000.0, P(off), P(g_off), st), "hm_offscreen_fwd")
+            # (mask_shared = 1 | 2: one binary mask for every candidate, no per-sample outputs - see include/homan_amd.h)
             ck(L.hm_sil_fwd(P(verts), P(sctx.faces), 0, P(K_all), n, V, F, S, 1.0, ops.NMR_NEAR, ops.NMR_FAR, P(keep), P(ref), None,
-                            P(pooled), None, P(sctx.work_order), None, P(alpha), 1, None, None, None, 0, 0, P(sctx.workspace), st),
+                            P(pooled), None, P(sctx.work_order), None, None, 3, None, None, None, 0, 0, P(sctx.workspace), st),
                "hm_sil_fwd")
             ck(L.hm_sil_reduce(n, V, F, S, None, None, P(frame), P(sctx.workspace), st), "hm_sil_reduce")
-            ck(L.hm_sil_bwd(P(verts), P(K_all), n, V, F, S, 1.0, eps, 4, P(ones), None, None, P(sctx.adj_off), P(sctx.adj_items),
+            ck(L.hm_sil_bwd(P(verts), P(K_all), n, V, F, S, 1.0, eps, 5, P(ones), None, None, P(sctx.adj_off), P(sctx.adj_items),
                             P(sctx.face_order), None, None, P(sctx.workspace), sctx.sum_log2q, st), "hm_sil_bwd")
             ck(L.hm_rigid_bwd_sil(P(model.vertices), P(model.rotations), P(model._one), 0, tp, tw, tn,
                                   L.hm_sil_parts(P(sctx.workspace), n, V, F, S), P(sctx.adj_off), P(sctx.adj_items), P(verts),

@@ -144,7 +144,10 @@ int hm_mano_bwd_rigid_clips(const void* const* model, const float* pca, int pca_
  *     backward is hm_sil_bwd mode 3.  With keep / ref given as well, they are (2S,2S)-resolution images and the fused loss is
  *     per SAMPLE (reference homan/pose_optimization.py:140-143); per-frame sums come from hm_sil_reduce(frame_out), the
  *     backward is hm_sil_bwd mode 4.
- *   mask_shared != 0: keep / ref have no batch dimension (one mask for every frame).
+ *   mask_shared: bit 0 - keep / ref have no batch dimension (one mask for every frame); bit 1 (with (2S,2S) keep / ref) - the
+ *     per-sample loss WITHOUT its per-sample outputs: alpha_full may be NULL, nothing of (B,2S,2S) size is written; the masks
+ *     must be binary (0 / 1) and the backward is hm_sil_bwd mode 5 (the pose initialisation's loop: 500 candidates write
+ *     260 MB less per step).
  *   rigid_rot6d (B,3,2) / rigid_trans (B,3) / rigid_scale (1) / rigid_abs optional: `verts` are then mesh-space and the
  *     rigid transform of hm_rigid_fwd is applied in the face-setup kernel (same arithmetic), so the silhouette chain does
  *     not wait for a separate transform launch; hm_sil_bwd still takes the camera-space vertices.
@@ -167,6 +170,8 @@ int hm_sil_reduce(int B, int V, int F, int S, const float* keep_sum, float* loss
                   hipStream_t stream);       /* frame_out (B,2) optional: per-frame {sum of squares, IoU}; loss_out may be NULL then */
 /* mode 3: grad_pooled is (B,2S,2S) = dL/d alpha_full (rendering without anti-aliasing).
  * mode 4: fused per-sample L2 without anti-aliasing: upstream (B) = dL/d(per-frame sums of squares), all > 0.
+ * mode 5: mode 4 for BINARY keep / ref masks: keep (keep alpha - ref) is -1 at every uncovered sample that pulls and +1 at every
+ *   covered one that pushes, so the line pass reads no per-sample gradient (same results as mode 4 on such masks, bit for bit).
  * mode 1: upstream (1) = dL/d loss_out[0]; mode 2: same with upstream[0] > 0 guaranteed by the caller (the forward's
  * sweep planes are reused, one launch less); mode 0: grad_pooled (B,S,S) = dL/d pooled.  adj_off (V+1), adj_items (3F):
  * CSR vertex -> (face*3 + corner).  face_order: B*F int32 permutation of frame*F+face (visiting order of the edge
