@@ -1,7 +1,14 @@
-R=$(pwd); O=$R/gpurun_out
-timeout 900 python -m pytest tests/test_poseinit.py -q -m gpu > $O/g52.log 2>&1; tail -8 $O/g52.log | cut -c1-300
-HOMAN_POSEINIT_LOOPS=fused python bench.py --pose-init 500 --no-cpu-baseline > $O/g52_bench.json 2>$O/g52b.err; python - <<'PY'
-import json
-d=json.loads(open('gpurun_out/g52_bench.json').read().strip().splitlines()[-1])
-print(d['value'], d['ms_per_step'], d['config']['cold_fit'], {k:(v['avg_launch_us']) for k,v in d['roofline']['kernels'].items()})
-PY
+R=$(pwd); O=$R/gpurun_out; N=r04
+cd $R
+bash tools/pmc_poseinit.sh > $O/${N}_pmc_poseinit.json 2>/dev/null
+cp $O/${N}_pmc_poseinit.json profiles/${N}_pmc_poseinit.json
+python bench.py --pose-init 500 > $O/${N}_bench_poseinit.json 2>/dev/null
+cd /tmp && export TMPDIR=/tmp
+POSE="HOMAN_POSEINIT_LOOPS=fused python bench.py --pose-init 500 --no-cpu-baseline"
+HOMAN_POSEINIT_LOOPS=fused rocprofv3 --kernel-trace --stats -d $O/pp -o pp -- python $R/bench.py --pose-init 500 --no-cpu-baseline > /dev/null 2>&1
+cd $R
+python tools/prof_summary.py $O/pp/pp_results.db "$POSE" > $O/${N}_p_poseinit_kernel_stats.txt
+python tools/prof_timeline.py $O/pp/pp_results.db > $O/${N}_p_poseinit_timeline.txt
+rm -rf $O/pp
+python tools/poseinit_phases.py > $O/${N}_poseinit_phases.json 2>/dev/null
+head -c 700 $O/${N}_bench_poseinit.json; echo; head -12 $O/${N}_p_poseinit_kernel_stats.txt | cut -c1-140
