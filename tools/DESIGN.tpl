@@ -24,7 +24,7 @@ design and the current numbers; how the kernels got here - every measured step a
 | (c) oracle | CPU restatement + reference-generated goldens; the object's gradient chain and Adam also written out with order-independent sums (`oracle/objchain.py`, `oracle/csrc/objchain.c`, `oracle/adam.py`) | `oracle/`, `tools/refharness/`, `tests/golden/` |
 | (d) measurement | bench, roofline, CPU baseline, rocprof | `bench.py`, `profiles/`, `tools/prof_summary.py` |
 | (e) multi-GPU | clip sharding, clip batches per rank, heterogeneous shards, shared-scale all-reduce inside the fused loop | `homan_amd/dist.py`, `homan_amd/clipbatch.py`, `jointopt.ShardStepper`, `FusedStepper(shared_scale=True)`, `bench.py --gpus N [--shared-scale]`, `tests/test_dist_gloo.py` (CPU, oracle model), `tests/test_dist_gpu.py` (N ranks on one GPU through the fused loop, cfg5 at full size), `tests/test_clip_batch_gpu.py` |
-| (f) rank 1 | object-pose initialisation (`pose_optimization.py:37-160,219-383`, `lib3d/optitrans.py:83-127`) | `homan_amd/pose_optimization.py` (`PoseOptimizer`, `find_optimal_pose`, and the clip-level `find_optimal_poses` of `:386-488` that `fit_vid_dataset.py:285-296` calls) over the same rasteriser run without anti-aliasing (`hm_sil_fwd` `alpha_full` with the masked L2 + IoU fused per sample, `hm_sil_bwd` modes 3 / 4); the default loop of `find_optimal_pose` is a fixed launch sequence without the autograd tape (`_fused_loop`: `hm_rigid_fwd` → `hm_offscreen_fwd` → raster → reduce → lines / sweeps → `hm_rigid_bwd_sil` → `hm_adam_step` → `hm_pose_keep_best`, one hipGraph), `mode="eager"` is the reference's loop verbatim; oracle `oracle/poseopt.py`; golden from the reference's own module (`tools/refharness/gen_goldens_poseinit.py`); `bench.py --pose-init` |
+| (f) rank 1 | object-pose initialisation (`pose_optimization.py:37-160,219-383`, `lib3d/optitrans.py:83-127`) | `homan_amd/pose_optimization.py` (`PoseOptimizer`, `find_optimal_pose`, and the clip-level `find_optimal_poses` of `:386-488` that `fit_vid_dataset.py:285-296` calls) over the same rasteriser run without anti-aliasing (`hm_sil_fwd` `alpha_full` with the masked L2 + IoU fused per sample, `hm_sil_bwd` modes 3 / 4 / 5); the default loop of `find_optimal_pose` is a fixed launch sequence without the autograd tape, run by a resident `PoseFitter` (`_FusedPoseLoop`: `hm_rigid_fwd` → `hm_offscreen_fwd` → raster → reduce → lines / sweeps → `hm_rigid_bwd_sil` → `hm_adam_step` → `hm_pose_keep_best`, one hipGraph), `mode="eager"` is the reference's loop verbatim; oracle `oracle/poseopt.py`; golden from the reference's own module (`tools/refharness/gen_goldens_poseinit.py`); `bench.py --pose-init` |
 | (f) rank 2 | hand silhouette term (`losses.py:166-181`) + ordinal depth (`homan.py:384-419`, `lossutils.py:133-169`), both present-but-disabled upstream | `Losses.compute_sil_loss_hand` (per-hand ROI render, own keep-mask normalisation; the reference body cannot run past its first frame, built for the evident intent) ; ordinal depth = row a19.  Oracle-pinned |
 | (f) rank 3 | textured / shaded renders for visualisation (`homan.py:168-219,510-628`, `visualize.py:44-128`, `meshutils.py:7-51`, `jointopt.py:158-176`) | rgb output of the rasteriser (`hm_shade_rgb`: NMR flat lighting on the forward's index map), `homan_amd/nmr.py` (`model.renderer`), `HOMan.render / render_gt / render_with_gt / render_limem / save_obj`, `homan_amd/{meshutils,visualize,trans3d}.py`, frames out of `optimize_hand_object`; oracle `oracle/nmr.py` (`lighting`, `shade_index_map`); `tests/test_render_gpu.py` |
 | (f) rank 4 | checkpoint / evaluation hand-off (`fit_vid_dataset.py:365-372,322-338`, `postprocess.py:16-77`, `eval/pointmetrics.py:102-124`) | `homan_amd/checkpoint.py` (`joint_fit.pt` contract, files interchange with the reference's), `homan_amd/pointmetrics.py::get_inter_metrics` on `hm_collision_fwd` + `hm_collision_dist_values` (per-vertex penetration depths = `sdf_meta["dist_values"]`) |
@@ -440,8 +440,10 @@ file the reference never reaches.  More than two hands: the reference's own coll
 2. One launch per kernel over clips of DIFFERENT shapes (today: concurrent shape groups, 88 % of a same-shape batch).
 3. The pose initialisation at @POSE@ pose-steps/s with its resident fitter (target 600 k; it is the pipeline's larger GPU load:
    one fit per frame of a clip against ONE joint fit per clip): its sweep (0.10 of HBM peak) and raster are throughput-bound
-   at 500 frames per launch, and a fit's first steps are its heaviest (candidates far from the mask); in mode 4 every source has the same gradient, so the per-line source records could shrink from
-   12 to 4 bytes and the line expansion to a popcount pass.
+   at 500 frames per launch, and a fit's first steps are its heaviest (candidates far from the mask); the line expansion no longer gathers a gradient (mode 5: -1 / +1 by plane) but still moves 4.6x its byte model
+   (`r04_pmc_poseinit.json`: 538 MB against 118 MB) - the owner of every covered source is gathered from the index map, along
+   columns for one of the two axes, though only the rare inward pairs of the sweeps ask for it: looked up there instead, the line
+   pass would stream.
 4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
    silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
    hands it runs one clip per stepper (`ShardStepper`).
