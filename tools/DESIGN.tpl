@@ -441,9 +441,8 @@ file the reference never reaches.  More than two hands: the reference's own coll
 3. The pose initialisation at @POSE@ pose-steps/s with its resident fitter (target 600 k; it is the pipeline's larger GPU load:
    one fit per frame of a clip against ONE joint fit per clip): its sweep (0.10 of HBM peak) and raster are throughput-bound
    at 500 frames per launch, and a fit's first steps are its heaviest (candidates far from the mask); the line expansion no longer gathers a gradient (mode 5: -1 / +1 by plane) but still moves 4.6x its byte model
-   (`r04_pmc_poseinit.json`: 538 MB against 118 MB) - the owner of every covered source is gathered from the index map, along
-   columns for one of the two axes, though only the rare inward pairs of the sweeps ask for it: looked up there instead, the line
-   pass would stream.
+   (`r04_pmc_poseinit.json`: 538 MB against 118 MB) - neither the owner gathers nor the size of the source records (both
+   measured, EXPERIMENTS.md): its scattered small record stores per line and plane.
 4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
    silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
    hands it runs one clip per stepper (`ShardStepper`).
