@@ -1,6 +1,5 @@
+# scratch GPU script of the build sessions (gpurun -- 'bash tools/_g7.sh'): the whole GPU suite, the default bench line, smoke
 R=$(pwd); O=$R/gpurun_out
-for m in regions frames frames_centre regions; do
-HOMAN_POSE_ORDER=$m HOMAN_POSEINIT_LOOPS=fused python bench.py --pose-init 500 --no-cpu-baseline 2>/dev/null | python -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$m', round(d['value']), {k:round(v['avg_launch_us']) for k,v in d['roofline']['kernels'].items()})"
-done
+timeout 3000 python -m pytest tests -m gpu -x -q > $O/g60_tests.log 2>&1; tail -4 $O/g60_tests.log
+( time python bench.py > $O/g60_bench_default.json 2>$O/g60_bench.err ) 2>&1 | tail -4
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
