@@ -109,16 +109,18 @@ HIP ↔ oracle parity is exact where the domain is discrete and tolerance-bound 
 |---|---|---|
 | rotation, rigid transform, projected NDC faces | **bit-exact** | `test_ops_gpu.py::test_rigid_transform_and_grads`, `test_raster_gpu.py::test_projection_matches_oracle` |
 | face-index map (B,2S,2S), pooled silhouettes | **bit-exact** (from the PARAMETERS, end to end) | `test_face_index_map_bit_exact`, `tests/test_lockstep_gpu.py` (0 flipped samples along 50 cfg2 / cfg3 steps) |
-| SDF inside/outside masks | **bit-exact** | `test_ops_gpu.py::test_collision_vs_oracle` |
+| SDF inside/outside masks AND distance grids; MANO vertices (right, left, two hands) | **bit-exact** | `test_ops_gpu.py::test_collision_vs_oracle`, `::test_mano_lbs_and_grads`, `test_model_gpu.py` |
 | every `loss_dict` entry vs reference goldens | **1e-4 relative** (BASELINE north_star) | `test_model_gpu.py::test_forward_matches_reference_goldens`, `test_pinned_step_matches_reference` |
 | parameter gradients vs goldens | **5e-5** of max per tensor (2e-3 before round 3) | same |
 | NMR pseudo-gradient per vertex | 2e-5 of max | `test_pseudo_gradient_matches_oracle` |
-| **every step of a full-size trajectory, teacher-forced** | losses 1e-5 (cfg2) / 1e-4 (cfg3; `loss_collision` 1e-3, see below), gradients 2e-5 / 5e-4 of max, object vertices bit-equal, hand 1e-3 mm | `tests/test_lockstep_gpu.py` |
+| **every step of a full-size trajectory, teacher-forced, vs the FAITHFUL (autograd) oracle** | losses 1e-5 (measured 3.3e-7, `loss_collision` 1.4e-7), gradients 2e-5 (cfg2) / 5e-4 (cfg3: the reference's nearest-vertex search in near-ties) of max, object AND hand vertices bit-equal, 0 flipped samples (silhouette and both depth renders) | `tests/test_lockstep_gpu.py` |
 | C clips in one launch per kernel vs C solo runs; shape groups of a shard vs solo runs; 2 ranks vs one 2-clip batch | **bit-exact** (rows, final parameters) | `tests/test_clip_batch_gpu.py`, `tests/test_dist_gpu.py` |
 | fused launch sequence vs `HOMan.forward` + autograd | losses 2e-6, gradients 2e-5 of max, every golden incl. two hands / left / `min` / `optimize_mano=False` | `test_fused_step_equals_autograd_path` |
 | pose initialisation vs the reference module's golden (reference form: `torch.matmul`) | mask loss within the number of samples that differ (<= 3 per pose), gradients 2e-3 of max | `tests/test_poseinit.py` |
-| pose initialisation vs the oracle with the written-out transform | coverage **bit-exact** (0 flipped samples), mask loss equal, gradients 5e-5 of max | `test_hip_poseinit_coverage_bit_exact_and_gradients_vs_written_out_oracle` |
-| FREE-running fit, HIP loop vs the oracle's reproducible loop (step-1 sets) | object pose parameters **bit-equal after every step**, losses 1e-4, final vertices 1e-3 mm (object: 0.0) | `tests/test_parity_gpu.py`, `bench.free_run_parity` |
+| pose initialisation vs the oracle with the written-out transform | coverage **bit-exact** (0 flipped samples), mask loss equal, gradients 5e-5 of max (autograd side) | `test_hip_poseinit_coverage_bit_exact_and_gradients_vs_written_out_oracle` |
+| pose initialisation, a WHOLE free-running fit vs the oracle's written-out loop (`oracle/posechain.py`) | every candidate's rotation / translation, the per-candidate losses, the best-ever pose **bit-equal** | `test_fused_poseinit_fit_bit_equal_with_the_written_out_oracle` |
+| every stage of the gradient chains at identical parameters vs the oracle's WRITTEN-OUT chains (unit gradients, interaction records, nearest-vertex picks, contact / collision / depth gradients, model-space gradient) and all parameter gradients | **bit-equal** | `tests/test_handchain_gpu.py` |
+| FREE-running fit, HIP loop vs the oracle's reproducible loop: cfg1; cfg2; cfg2 + depth; cfg3; free / tied object scale; two hands; `optimize_mano=False` | EVERY parameter **bit-equal after every step** (400 steps at full size for cfg2 / cfg2 + depth / cfg3), losses 1e-4 (measured 3.6e-7), final vertices 0.0 mm | `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`, `bench.free_run_parity`, `profiles/r04_freerun_*.json` |
 | a stream of clips through resident steppers vs fresh fits | **bit-exact** (parameters, vertices, loss_evolution) | `tests/test_clip_fitter_gpu.py` |
 
 **Final-loss / final-vertex parity (the second half of BASELINE's metric): met, free-running.**  The hard rasteriser makes the
