@@ -36,9 +36,9 @@ def reproducible_grads(model, loss_weights, log2q=0):
     from . import objchain
     for p in model.parameters():
         p.grad = None
-    obj = (model.rotations_object, model.translations_object)
-    if model.optimize_object_scale:         # (the scale's gradient needs the renderer's backward: autograd walks it then)
-        obj = ()
+    obj = [model.rotations_object, model.translations_object]
+    if model.optimize_object_scale:
+        obj.append(model.int_scales_object)
     for p in obj:               # (their gradients come from the written-out chain below: autograd need not walk the renderer)
         p.requires_grad_(False)
     try:

@@ -1,5 +1,3 @@
-# scratch GPU script of the build sessions (gpurun -- 'bash tools/_g7.sh'): the whole GPU suite, the default bench line, smoke
+# scratch GPU script of the build sessions (gpurun -- 'bash tools/_g7.sh')
 R=$(pwd); O=$R/gpurun_out
-timeout 3000 python -m pytest tests -m gpu -x -q > $O/g60_tests.log 2>&1; tail -4 $O/g60_tests.log
-( time python bench.py > $O/g60_bench_default.json 2>$O/g60_bench.err ) 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+timeout 1500 python -m pytest tests/test_handchain_gpu.py -q -k "free_object_scale or tied_object_scale or two_hands" > $O/g61.log 2>&1; tail -4 $O/g61.log | cut -c1-300
