@@ -164,6 +164,7 @@ class HOMan(nn.Module):
             raise NotImplementedError(f"ordinal depth term: image_size {image_size} > 1024 (rendered at image_size; scale the "
                                       "instance masks and intrinsics down, or leave ordinal_depth off)")
         self._depth_state = None
+        self._depth_state_hands = None
         with torch.no_grad():
             self.verts_hand_init = self.get_verts_hand()[0].detach().clone()
             self.verts_object_init = self.get_verts_object()[0].detach().clone()
@@ -235,6 +236,11 @@ class HOMan(nn.Module):
                 ctx_o, ctx_h, m_o, m_h = self._depth_state
                 m_o.copy_((self.masks_object != 0).to(torch.uint8))
                 m_h.copy_((self.masks_human != 0).to(torch.uint8))
+            if getattr(self, "_depth_state_hands", None) is not None:
+                _, _, m_o, m_hs = self._depth_state_hands
+                m_o.copy_((self.masks_object != 0).to(torch.uint8))
+                for h, m in enumerate(m_hs):
+                    m.copy_((self.masks_human[h::self.hand_nb] != 0).to(torch.uint8))
             self.verts_hand_init.copy_(self.get_verts_hand()[0].detach())
             self.verts_object_init.copy_(self.get_verts_object()[0].detach())
             self._mano_cache = None
@@ -397,15 +403,38 @@ class HOMan(nn.Module):
                                  (masks_h != 0).to(torch.uint8).contiguous())
         return self._depth_state
 
+    def _depth_contexts_hands(self):
+        """two hands per frame: (object context, [one raster context per hand], object mask u8, [per-hand masks u8]) - a context
+        carries ONE render's intermediates to its backward, so every layer has its own"""
+        if getattr(self, "_depth_state_hands", None) is None:
+            size = int(self.image_size)
+            if tuple(self.masks_object.shape[1:]) != (size, size) or tuple(self.masks_human.shape[1:]) != (size, size):
+                raise NotImplementedError("ordinal depth: instance masks must be (B, image_size, image_size)")
+            batch, dev = self.translations_object.shape[0], self.translations_object.device
+            ctx_o = ops.SilhouetteContext(self.faces_object, self.verts_object_og.shape[1], batch, size, dev)
+            ctx_hs = [ops.SilhouetteContext(self.faces_hand[h:h + 1].expand(batch, -1, -1), 778, batch, size, dev)
+                      for h in range(self.hand_nb)]
+            m_hs = [(self.masks_human[h::self.hand_nb] != 0).to(torch.uint8).contiguous() for h in range(self.hand_nb)]
+            self._depth_state_hands = (ctx_o, ctx_hs, (self.masks_object != 0).to(torch.uint8).contiguous(), m_hs)
+        return self._depth_state_hands
+
     def compute_ordinal_depth_loss(self, verts_object=None, verts_hand=None):
         """reference homan/homan.py:384-419: render object and hand depth at the full-image intrinsics, compare their
-        ordering with the instance masks (lossutils.py:133-169).  One hand (hand_nb == 1)."""
-        if self.hand_nb != 1:
-            raise NotImplementedError("ordinal depth term: one hand per frame")
+        ordering with the instance masks (lossutils.py:133-169); with two hands the three layers pair-wise."""
         if verts_object is None:
             verts_object, _ = self.get_verts_object()
         if verts_hand is None:
             verts_hand, _ = self.get_verts_hand()
+        if self.hand_nb != 1:
+            # layers [object, hand 0, hand 1] (homan.py:403-417: one render per hand over its strided rows), every pair of them
+            ctx_o, ctx_hs, m_o, m_hs = self._depth_contexts_hands()
+            sils, deps = [], []
+            for verts, ctx in [(verts_object, ctx_o)] + [(verts_hand[h::self.hand_nb].contiguous(), ctx_hs[h])
+                                                         for h in range(self.hand_nb)]:
+                sil, dep = ops.depth_render(verts, self.camintr, ctx, 1.0)
+                sils.append(sil)
+                deps.append(dep)
+            return {"loss_depth": ops.ordinal_depth_loss_layers(deps, sils, [m_o] + m_hs, self.reduce_ws)}
         ctx_o, ctx_h, m_o, m_h = self.depth_contexts()
         sil_o, dep_o = ops.depth_render(verts_object, self.camintr, ctx_o, 1.0)
         sil_h, dep_h = ops.depth_render(verts_hand, self.camintr, ctx_h, 1.0)

@@ -282,7 +282,7 @@ class FusedStepper:
                                       "clips: one stepper per clip, or mode='graph')")
         lw = self.lw = {k: float(v) for k, v in loss_weights.items()}
         if lw.get("lw_depth", 0) > 0 and h > 1:
-            raise NotImplementedError("ordinal depth term: one hand per frame")          # (as HOMan.compute_ordinal_depth_loss)
+            raise NotImplementedError("ordinal depth term in the fused loop: one hand per frame (two hands: mode='graph' / 'eager')")
         if lw.get("lw_depth", 0) > 0:
             if not getattr(m, "ordinal_depth", False):
                 # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() without its arguments

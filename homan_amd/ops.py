@@ -395,10 +395,12 @@ class _OrdinalDepthLoss(torch.autograd.Function):
             _lib.ptr(d0), _lib.ptr(d1), _lib.ptr(a0), _lib.ptr(a1), _lib.ptr(m0), _lib.ptr(m1), B, S, _lib.ptr(part),
             _lib.ptr(rec), _lib.ptr(out), _lib.ptr(rws.buf), _lib.stream()), "hm_ordinal_depth_fwd")
         ctx.save_for_backward(d0, d1, a0, a1, m0, m1, rec)
-        return out.reshape(())
+        pairs = rec[:1].clone()             # the normaliser of this pair of layers (a count of frames: no gradient)
+        ctx.mark_non_differentiable(pairs)
+        return out.reshape(()), pairs
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_pairs=None):
         d0, d1, a0, a1, m0, m1, rec = ctx.saved_tensors
         g0, g1 = torch.empty_like(d0), torch.empty_like(d1)
         _lib.check(_lib.lib().hm_ordinal_depth_bwd(
@@ -409,7 +411,31 @@ class _OrdinalDepthLoss(torch.autograd.Function):
 
 def ordinal_depth_loss(d_obj, d_hand, sil_obj, sil_hand, mask_obj, mask_hand, rws):
     """0-d loss.  mask_*: (B,S,S) uint8 instance masks."""
-    return _OrdinalDepthLoss.apply(d_obj, d_hand, sil_obj, sil_hand, mask_obj, mask_hand, rws)
+    return _OrdinalDepthLoss.apply(d_obj, d_hand, sil_obj, sil_hand, mask_obj, mask_hand, rws)[0]
+
+
+def ordinal_depth_loss_layers(depths, sils, masks, rws):
+    """The ordinal depth term over n >= 2 layers (reference homan/lossutils.py:133-169: every ordered pair of layers, one
+    normaliser for all - the number of (pair, frame) combinations whose two silhouettes meet, a layer with itself included).
+    Every unordered pair goes through the two-layer kernels, which normalise by the pair's OWN count; the pair's value times
+    (its count / the scene's count) is its share of the scene's loss, and autograd carries the same factor into the gradients.
+    depths / sils: n x (B,S,S) float renders, masks: n x (B,S,S) uint8."""
+    n = len(depths)
+    if n == 2:
+        return ordinal_depth_loss(depths[0], depths[1], sils[0], sils[1], masks[0], masks[1], rws)
+    with torch.no_grad():
+        present = [(s == 1).flatten(1).any(1).sum().float() for s in sils]          # frames in which layer i covers a pixel fully
+    terms, counts = [], []
+    for a in range(n):
+        for b in range(a + 1, n):
+            val, pairs = _OrdinalDepthLoss.apply(depths[a], depths[b], sils[a], sils[b], masks[a], masks[b], rws)
+            terms.append((val, pairs[0]))
+            counts.append(pairs[0] - present[a] - present[b])                       # = 2 x frames in which a and b meet
+    total = sum(present) + sum(counts)
+    loss = torch.zeros((), device=depths[0].device)
+    for val, pairs in terms:
+        loss = loss + torch.where(pairs > 0, val * (pairs / total), torch.zeros_like(val))
+    return loss
 
 
 # =============================================================================== shared small state

@@ -233,3 +233,52 @@ def test_depth_term_in_a_clip_batch_equals_solo_runs_bitwise(mano_model):
             np.testing.assert_array_equal(np.asarray(eb[k]), np.asarray(es[k]), err_msg=k)
         for k in ("translations_object", "rotations_object", "translations_hand", "rotations_hand", "mano_pca_pose"):
             assert torch.equal(getattr(ms, k).detach(), getattr(mb, k).detach()), k
+
+
+def test_ordinal_depth_term_with_two_hands_matches_oracle(mano_model):
+    """hand_nb = 2: the three layers [object, right hand, left hand] of reference homan.py:384-419 pair-wise (lossutils.py:133-169,
+    one normaliser over every ordered pair incl. a layer with itself).  HOMan(ordinal_depth=True) vs the oracle: value and
+    parameter gradients; a few eager steps of `optimize_hand_object` bring the term down."""
+    from homan_amd import HOMan, synth
+    from homan_amd.jointopt import optimize_hand_object
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    size = 64
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=4, frames=4, rend_size=size, image_size=size, obj="cube", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn, hands=("right", "left"))
+    # annotations that disagree with the geometry: the object in front everywhere, both hands moved over it
+    for pp, op in zip(clip["person_parameters"], clip["object_parameters"]):
+        op["full_mask"] = ((pp["masks"].sum(0) > 0) | (op["full_mask"] > 0)).float()
+        pp["masks"] = torch.zeros_like(pp["masks"])
+        pp["translations"] = pp["translations"] + torch.tensor([[[0.05, 0.0, -0.02]], [[-0.05, 0.0, -0.02]]])[:pp["translations"].shape[0]]
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=size,
+                  mano_model=mano_model, rend_size=size, ordinal_depth=True)
+    lw = dict({k: 0.0 for k in synth.STEP1_LOSS_WEIGHTS}, lw_depth=1.0)
+    om = OracleHOMan(**copy.deepcopy(kw), **common)
+    hm = HOMan(**copy.deepcopy(kw), **common)
+    assert hm.hand_nb == 2
+    lo, _ = om(loss_weights=lw)
+    lh, _ = hm(loss_weights=lw)
+    assert float(lo["loss_depth"]) > 0
+    np.testing.assert_allclose(lh["loss_depth"].item(), lo["loss_depth"].item(), rtol=1e-4)
+    lo["loss_depth"].backward()
+    lh["loss_depth"].backward()
+    go = {k: p.grad for k, p in om.named_parameters() if p.grad is not None}
+    gh = {k: p.grad for k, p in hm.named_parameters() if p.grad is not None}
+    assert sorted(go) == sorted(gh) and len(go) > 0
+    for k in go:
+        scale = max(go[k].abs().max().item(), 1e-12)
+        np.testing.assert_allclose(gh[k].cpu().numpy() / scale, go[k].numpy() / scale, atol=1e-3, err_msg=k)
+    model, evo, _ = optimize_hand_object(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                                         objvertices=clip["objvertices"], objfaces=clip["objfaces"], loss_weights=lw,
+                                         num_iterations=8, lr=1e-2, camintr=clip["camintr"], optimize_mano=True, image_size=size,
+                                         mano_model=mano_model, rend_size=size, ordinal_depth=True, mode="eager")
+    assert evo["loss_depth"][-1] < evo["loss_depth"][0]
+    # (mode="auto" takes the graph loop for this configuration: the fused loop covers the term with one hand per frame.  Not run
+    #  here: a captured autograd iteration with depth renders followed later in the same process by a clip-batch graph has
+    #  crashed the HIP graph runtime, see test_model_ordinal_depth_term_matches_oracle)
+    from homan_amd.jointopt import FusedStepper
+    with pytest.raises(NotImplementedError):
+        FusedStepper(hm, lw, 1e-2, 2)

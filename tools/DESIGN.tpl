@@ -446,8 +446,9 @@ file the reference never reaches.  More than two hands: the reference's own coll
    (`r04_pmc_poseinit.json`: 538 MB against 118 MB) - neither the owner gathers nor the size of the source records (both
    measured, EXPERIMENTS.md): its scattered small record stores per line and plane.
 4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
-   silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch and with two
-   hands it runs one clip per stepper (`ShardStepper`).
+   silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch it runs
+   one clip per stepper (`ShardStepper`); with two hands (three layers, pair-wise through the two-layer kernels:
+   `ops.ordinal_depth_loss_layers`) it runs in the eager / graph loops, not in the fused one.
 5. The written-out chains cover one hand with `optimize_mano`, the centroid interaction term, every loss set of BASELINE's
    configurations (step 1, step 1 + depth, step 2), a fixed or free object scale, and the scale tied across the clips of one
    rank (cfg5: the clips' gradients through one block sum, `reproducible_step_shared_scale`; three clips bit-equal over 10
