@@ -1,3 +1,4 @@
-# scratch GPU script of the build sessions (gpurun -- 'bash tools/_g7.sh')
+# scratch GPU script of the build sessions (gpurun -- 'bash tools/_g7.sh'): the whole GPU suite + smoke
 R=$(pwd); O=$R/gpurun_out
-timeout 1500 python -m pytest tests/test_depth_gpu.py -q > $O/g62.log 2>&1; tail -30 $O/g62.log | cut -c1-400
+timeout 3000 python -m pytest tests -m gpu -x -q > $O/g63_tests.log 2>&1; tail -3 $O/g63_tests.log | cut -c1-200
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
