@@ -60,6 +60,11 @@ def lib():
         _lib.orc_v2d_unit_grad.restype = None
         _lib.orc_inter_rec.argtypes = [fp, fp, fp, ci, ci, ci, cf, cf, ci, fp]
         _lib.orc_inter_rec.restype = None
+        _lib.orc_nn_search_d2.argtypes = [fp, fp, ci, ci, ci, ip, fp]
+        _lib.orc_nn_search_d2.restype = None
+        _lib.orc_hand_chain_rigid.argtypes = [fp, fp, fp, fp, fp, fp, fp, ip, fp, ci, fp, fp, fp, fp, cf, vp, fp, ci, fp, fp, cf, ci,
+                                              fp, fp, fp, fp, fp, fp]
+        _lib.orc_hand_chain_rigid.restype = None
         _lib.orc_nn_search.argtypes = [fp, fp, ci, ci, ci, ip]
         _lib.orc_nn_search.restype = None
         _lib.orc_contact_grads.argtypes = [fp, fp, ip, ci, ci, ci, cf, ci, fp, fp]

@@ -264,7 +264,7 @@ static void oc_hand_chain_rows(const float *v_template, const float *M, const fl
                     const float *rot6d, float scale, const float *const *terms, const float *tw, int n_terms,
                     const float *g_frame, int frame_stride, float frame_scale, const float *g_pca_extra, float w_extra, int B,
                     float *g_pca, float *g_rot, float *g_betas, float *g_trans, float *g_rot6d, float *g_rtrans,
-                    const float *gmesh, int row0, int row_stride)
+                    const float *gmesh, int row0, int row_stride, const float *g_rigid)
 {
     const OcManoModel m = {v_template, M, J_template, J_shapedirs, weights, comps, hand_mean, parents};
 #pragma omp parallel for schedule(static)
@@ -306,6 +306,7 @@ static void oc_hand_chain_rows(const float *v_template, const float *M, const fl
                 }
                 for (int c = 0; c < 3; ++c)
                     gt[c] = gf[c] + (g_frame ? frame_scale * g_frame[(long)b * frame_stride + c] : 0.f);
+                if (g_rigid) { gt[0] += g_rigid[o]; gt[1] += g_rigid[o + 1]; gt[2] += g_rigid[o + 2]; }   /* reaches R, t only */
                 for (int i = 0; i < 3; ++i)
                     for (int j = 0; j < 3; ++j) racc[3 * i + j][t] = (s * mv[i]) * gt[j];
                 for (int j = 0; j < 3; ++j) racc[9 + j][t] = gt[j];
@@ -437,7 +438,20 @@ void orc_hand_chain(const float *v_template, const float *M, const float *J_temp
 {
     oc_hand_chain_rows(v_template, M, J_template, J_shapedirs, weights, comps, hand_mean, parents, pca, pca_stride, rot, betas, mesh,
                        rot6d, scale, terms, tw, n_terms, g_frame, frame_stride, frame_scale, g_pca_extra, w_extra, B, g_pca, g_rot,
-                       g_betas, g_trans, g_rot6d, g_rtrans, NULL, 0, 1);
+                       g_betas, g_trans, g_rot6d, g_rtrans, NULL, 0, 1, NULL);
+}
+/* the same with one more per-vertex term g_rigid (B,778,3) that reaches the rigid pose only (inter_type "min", reference
+ * homan/losses.py:219-221: the closest pair's pull on the mesh-detached hand) */
+void orc_hand_chain_rigid(const float *v_template, const float *M, const float *J_template, const float *J_shapedirs,
+                    const float *weights, const float *comps, const float *hand_mean, const int32_t *parents,
+                    const float *pca, int pca_stride, const float *rot, const float *betas, const float *mesh,
+                    const float *rot6d, float scale, const float *const *terms, const float *tw, int n_terms,
+                    const float *g_rigid, const float *g_pca_extra, float w_extra, int B,
+                    float *g_pca, float *g_rot, float *g_betas, float *g_trans, float *g_rot6d, float *g_rtrans)
+{
+    oc_hand_chain_rows(v_template, M, J_template, J_shapedirs, weights, comps, hand_mean, parents, pca, pca_stride, rot, betas, mesh,
+                       rot6d, scale, terms, tw, n_terms, NULL, 0, 0.f, g_pca_extra, w_extra, B, g_pca, g_rot,
+                       g_betas, g_trans, g_rot6d, g_rtrans, NULL, 0, 1, g_rigid);
 }
 /* The MANO layer's backward alone for the rows row0, row0 + row_stride, ... (B of them) of arrays holding B * row_stride rows
  * (two hands per frame are interleaved frame-major, reference homan/homan.py:62-63, each hand through its side's model): the
@@ -450,7 +464,7 @@ void orc_mano_bwd_rows(const float *v_template, const float *M, const float *J_t
 {
     oc_hand_chain_rows(v_template, M, J_template, J_shapedirs, weights, comps, hand_mean, parents, pca, pca_stride, rot, betas, NULL,
                        NULL, 1.0f, NULL, NULL, 0, NULL, 0, 0.f, g_pca_extra, w_extra, B, g_pca, g_rot, g_betas, g_trans, NULL, NULL,
-                       gmesh, row0, row_stride);
+                       gmesh, row0, row_stride, NULL);
 }
 
 /* The hands' rigid backward as a launch of its own (csrc/geometry.hip k_rigid_bwd<false>, one workgroup of `nthreads` threads per
@@ -619,7 +633,9 @@ float orc_tanh(float x) { return oc_tanh(x); }
 
 /* nearest object vertex of every hand vertex (reference homan/interactions/contactloss.py:60-79, 162-163): squared distance
  * (ox-hx)^2 + (oy-hy)^2 + (oz-hz)^2 left to right, ties -> the lowest index.  -> idx (B,Vh) */
-void orc_nn_search(const float *vh, const float *vo, int B, int Vh, int Vo, int32_t *idx)
+void orc_nn_search_d2(const float *vh, const float *vo, int B, int Vh, int Vo, int32_t *idx, float *d2);
+void orc_nn_search(const float *vh, const float *vo, int B, int Vh, int Vo, int32_t *idx) { orc_nn_search_d2(vh, vo, B, Vh, Vo, idx, NULL); }
+void orc_nn_search_d2(const float *vh, const float *vo, int B, int Vh, int Vo, int32_t *idx, float *d2)
 {
 #pragma omp parallel for schedule(static)
     for (long bi = 0; bi < (long)B * Vh; ++bi) {
@@ -634,6 +650,7 @@ void orc_nn_search(const float *vh, const float *vo, int B, int Vh, int Vo, int3
             if (d < best) { best = d; besti = j; }
         }
         idx[bi] = besti;
+        if (d2) d2[bi] = best;
     }
 }
 

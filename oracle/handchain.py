@@ -111,6 +111,25 @@ def collision_unit_grad(points, mesh_verts, mesh_faces):
     return g, dict(box=box, phi=phi)
 
 
+def min_pair_pull(vh, vo, rec, lw_inter):
+    """inter_type "min": -> (g_rigid (B,Vh,3): lw_inter * d (gate * |h_i* - o_j*|^2) / d h on the one vertex i* per frame, zeros
+    elsewhere; dict(i_star, j_star, pull)).  (i*, j*) = the closest pair: j by the nearest-vertex search of every hand vertex,
+    i = the first hand vertex with the smallest of those squared distances."""
+    B, Vh = vh.shape[:2]
+    idx = np.empty((B, Vh), np.int32)
+    d2 = np.empty((B, Vh), f32)
+    clib.lib().orc_nn_search_d2(clib.fptr(vh), clib.fptr(vo), B, Vh, vo.shape[1], clib.iptr(idx), clib.fptr(d2))
+    rows = np.arange(B)
+    i_star = d2.argmin(1)
+    j_star = idx[rows, i_star]
+    flags = (rec[:, 0] != 0).astype(f32)
+    diff = vh[rows, i_star] - vo[rows, j_star]
+    pull = (f32(2.0 * lw_inter) * diff) * flags[:, None]
+    g = np.zeros((B, Vh, 3), f32)
+    g[rows, i_star] = pull
+    return g, dict(i_star=i_star, j_star=j_star, pull=pull)
+
+
 def pair_terms(model, vh, vo, loss_weights):
     """The step-2 terms between the two meshes at their current vertices -> dict(col_hand, con_hand, con_obj, nn_idx, ...)"""
     out = {}
@@ -224,9 +243,11 @@ def hand_param_grads(model, loss_weights, return_stages=False, pair=None, depth_
             isinstance(model.mano_betas, torch.nn.Parameter) and not model.int_scales_hand.requires_grad and
             model.losses.inter_type == "centroid"):
         return _two_hand_param_grads(model, lw, return_stages, two)
+    inter_min = model.losses.inter_type == "min"
     if ((on("lw_depth") and depth_hand is None) or on("lw_sil_hand") or model.hand_nb != 1 or
             (model.optimize_mano and not isinstance(model.mano_betas, torch.nn.Parameter)) or
-            model.int_scales_hand.requires_grad or model.losses.inter_type != "centroid"):
+            model.int_scales_hand.requires_grad or model.losses.inter_type not in ("centroid", "min") or
+            (inter_min and not model.optimize_mano)):
         raise NotImplementedError("the written-out hand chain covers the step-1 / step-2 loss sets of a one-hand clip")
     side = model.hand_sides[0]
     c = lambda t: np.ascontiguousarray(t.detach().numpy(), f32)
@@ -255,6 +276,12 @@ def hand_param_grads(model, loss_weights, return_stages=False, pair=None, depth_
     if on("lw_depth"):          # d (lw_depth * loss_depth) / d hand vertices (oracle/depthchain.py), already times its weight
         terms.append((np.ascontiguousarray(depth_hand, f32), 1.0))
     rec = inter_records(vh, vo, K) if on("lw_inter") else None
+    g_rigid = None
+    if inter_min and on("lw_inter"):
+        # inter_type "min" (homan/losses.py:219-221): on the frames the gate lets through, the smallest squared distance between a
+        # hand and an object vertex; the pair is named by the search (first minimum), the pull acts on the hand's vertex - rigid
+        # pose only, the mesh is detached there (homan/homan.py:482-490)
+        g_rigid, min_stage = min_pair_pull(vh, vo, rec, lw["lw_inter"])
     if not model.optimize_mano:
         # rigid pose only: the launch of its own (csrc/geometry.hip k_rigid_bwd<false>, one 1024-thread workgroup per frame)
         arrs = [np.ascontiguousarray(t, f32) for t, _ in terms]
@@ -279,10 +306,24 @@ def hand_param_grads(model, loss_weights, return_stages=False, pair=None, depth_
     arrs = [np.ascontiguousarray(t, f32) for t, _ in terms]
     ptrs = (ctypes.c_void_p * max(len(arrs), 1))(*[a.ctypes.data for a in arrs])
     ws = np.asarray([w for _, w in terms] or [0.0], f32)
-    g_frame = np.ascontiguousarray(rec[:, 2:5]) if rec is not None else None
+    g_frame = np.ascontiguousarray(rec[:, 2:5]) if (rec is not None and not inter_min) else None
     out = dict(mano_pca_pose=np.zeros((B, P), f32), mano_rot=np.zeros((B, 3), f32), mano_betas=np.zeros((B, 10), f32),
                mano_trans=np.zeros((B, 3), f32), rotations_hand=np.zeros((B, 6), f32), translations_hand=np.zeros((B, 3), f32))
     lay = model.hands[side]["layout"]
+    if g_rigid is not None:
+        clib.lib().orc_hand_chain_rigid(*[clib.fptr(a) for a in lay[:7]], clib.iptr(lay[7]), clib.fptr(pca), P,
+                                        clib.fptr(c(model.mano_rot)), clib.fptr(c(model.mano_betas)), clib.fptr(mesh),
+                                        clib.fptr(c(model.rotations_hand).reshape(B, 6)), float(model.int_scales_hand.detach()[0]),
+                                        ptrs, clib.fptr(ws), len(arrs), clib.fptr(g_rigid),
+                                        clib.fptr(g_extra) if g_extra is not None else None, float(lw.get("lw_pca", 0.0)), B,
+                                        clib.fptr(out["mano_pca_pose"]), clib.fptr(out["mano_rot"]), clib.fptr(out["mano_betas"]),
+                                        clib.fptr(out["mano_trans"]), clib.fptr(out["rotations_hand"]),
+                                        clib.fptr(out["translations_hand"]))
+        out["rotations_hand"] = out["rotations_hand"].reshape(B, 3, 2)
+        out["translations_hand"] = out["translations_hand"].reshape(B, 1, 3)
+        if return_stages:
+            return out, dict(mesh=mesh, vh=vh, vo=vo, terms=terms, rec=rec, pair=pair, g_rigid=g_rigid, min_pair=min_stage)
+        return out
     clib.lib().orc_hand_chain(*[clib.fptr(a) for a in lay[:7]], clib.iptr(lay[7]), clib.fptr(pca), P, clib.fptr(c(model.mano_rot)),
                               clib.fptr(c(model.mano_betas)), clib.fptr(mesh), clib.fptr(c(model.rotations_hand).reshape(B, 6)),
                               float(model.int_scales_hand.detach()[0]), ptrs, clib.fptr(ws), len(arrs),

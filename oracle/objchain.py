@@ -131,6 +131,8 @@ def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact
         terms.extend((np.ascontiguousarray(a, f32), w) for a, w in obj_terms)
     elif lw.get("lw_contact", 0) > 0:
         terms.append((np.ascontiguousarray(contact_obj, f32), lw["lw_contact"]))
+    if obj_terms is None and free_scale and lw.get("lw_inter", 0) > 0 and model.losses.inter_type != "centroid":
+        raise NotImplementedError("free object scale with inter_type 'min': hand the object's term in through obj_terms")
     if obj_terms is None and free_scale and lw.get("lw_inter", 0) > 0:
         # d (lw_inter * loss_inter) / d object vertex = -lw_inter * gate * 2 (c_hand - c_obj) / 3 / V, the same for every vertex
         gi = (f32(0.0) - f32(lw["lw_inter"])) * np.ascontiguousarray(inter_rec[:, 2:5], f32) / f32(V)

@@ -311,3 +311,34 @@ def test_fixed_hand_mesh_bit_equal(mano_model):
         diff = [k for k, p in hm.named_parameters()
                 if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
         assert not diff, (i, diff)
+
+
+def test_inter_type_min_bit_equal(mano_model):
+    """inter_type="min" (reference homan/losses.py:219-221, a HOMan option its loop cannot select): the closest hand-object vertex
+    pair per gated frame pulls on the hand's rigid pose.  Step-2 set: all gradients, then 12 free-running steps, bit-equal."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle import handchain, objchain
+    from oracle.jointopt import make_optimizer, reproducible_step
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+    hm, om = _pair(mano_model, seed=51, frames=6, size=128, obj="bottle", inter_type="min")
+    st = FusedStepper(hm, lw, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    want, stg = handchain.hand_param_grads(om, lw, return_stages=True)
+    assert np.abs(stg["g_rigid"]).max() > 0                                  # (the gate lets frames through: the term is live)
+    assert np.array_equal(st.G_min_h.cpu().numpy(), stg["g_rigid"])
+    want.update(objchain.object_pose_grads(om, lw, contact_obj=stg["pair"]["con_obj"]))
+    report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
+    assert all(report.values()), report
+    hm, om = _pair(mano_model, seed=52, frames=6, size=128, obj="bottle", inter_type="min")
+    st = FusedStepper(hm, lw, 1e-2, 12)
+    opt = make_optimizer(om, 1e-2, reproducible=True)
+    for i in range(12):
+        st.run(1)
+        reproducible_step(om, lw, opt)
+        torch.cuda.synchronize()
+        cpu = dict(om.named_parameters())
+        diff = [k for k, p in hm.named_parameters()
+                if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
+        assert not diff, (i, diff)

@@ -184,8 +184,9 @@ half of this round) the hand separated around step 170-180 of the cfg2 clip - 0.
 separates from ITSELF when its hand translations start 1e-7 m apart (`r04_control_cfg2_400.json`: 0.85 mm): Adam at 10 x lr on
 the MANO parameters amplifies any difference, so only a chain without any could close it.  Two hands per frame (right + left,
 rows interleaved, the step-2 set with its three collision scenes, fixed or free scale) are written out as well and bit-equal over
-10 free-running steps (`tests/test_handchain_gpu.py::test_two_hands_bit_equal`).  So is `optimize_mano=False` (the hand mesh an input, its rigid
-pose optimised).  Not written out: `inter_type="min"` and the depth term with two hands (`oracle/handchain.py` raises NotImplementedError, the oracle then keeps
+10 free-running steps (`tests/test_handchain_gpu.py::test_two_hands_bit_equal`).  So are `optimize_mano=False` (the hand mesh an input, its rigid
+pose optimised) and `inter_type="min"` (the closest vertex pair's pull on the hand's rigid pose).  Not written out: the depth term
+with two hands and `inter_type="min"` with a free scale (`oracle/handchain.py` raises NotImplementedError, the oracle then keeps
 autograd's gradients for the hand); there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
 path: nothing at one clip, -2 % on an 8-clip batch (EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the
 divisions; the hand side's kernels did not change but for the sin / cos.
@@ -453,7 +454,7 @@ file the reference never reaches.  More than two hands: the reference's own coll
    configurations (step 1, step 1 + depth, step 2), a fixed or free object scale, and the scale tied across the clips of one
    rank (cfg5: the clips' gradients through one block sum, `reproducible_step_shared_scale`; three clips bit-equal over 10
    steps), and two hands per frame (each hand's rows through its side's model, per-hand pair terms, three SDF scenes, the hands'
-   rigid backward as the launch of its own the two-hand loop uses).  `optimize_mano=False` is covered too; `inter_type="min"` and the depth term
-   with two hands are compared per step (lock-step) only; across RANKS the tied gradient is one fp32 all-reduce, whose order for
+   rigid backward as the launch of its own the two-hand loop uses).  `optimize_mano=False` and `inter_type="min"` are covered too; the depth term
+   with two hands is compared with the faithful oracle only (value, gradients); across RANKS the tied gradient is one fp32 all-reduce, whose order for
    more than two ranks is RCCL's.
 6. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.
