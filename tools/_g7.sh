@@ -1,3 +1,3 @@
-# scratch GPU script of the build sessions (gpurun -- 'bash tools/_g7.sh')
+# scratch GPU script of the build sessions (gpurun -- 'bash tools/_g7.sh'): the whole GPU suite with durations
 R=$(pwd); O=$R/gpurun_out
-timeout 1500 python -m pytest tests/test_handchain_gpu.py -q -k inter_type_min > $O/g64.log 2>&1; tail -25 $O/g64.log | cut -c1-500
+timeout 3000 python -m pytest tests -m gpu -x -q --durations=25 > $O/g65_tests.log 2>&1; grep -A30 "slowest" $O/g65_tests.log | cut -c1-150; tail -2 $O/g65_tests.log
