@@ -4,15 +4,17 @@
 Workload (BASELINE.json configs[1]): one clip per GPU, 30 frames, 256x256 silhouette raster, MANO hand + ~3000-face
 bottle, full step-1 loss set, Adam step included.  A "step" = one optimisation iteration (forward + backward +
 Adam + loss logging) of one clip, replayed from a hipGraph.  N GPUs = N independent clips (weak scaling, no
-data-path collective).  Prints ONE JSON line on rank 0, which also carries
-  roofline          the dominant kernel timed with HIP events INSIDE the optimisation loop (launch by launch, next to the
-                    other streams' work), algorithmic bytes / that time / 8 TB/s; PMC traffic of the steady-state loop
-                    from profiles/ (tools/pmc_loop.sh) when it was measured on the same shapes;
-  multi_clip        BASELINE cfg4 in miniature: `--multi-clip` clips per GPU as ONE clip batch (one launch per kernel over
-                    all clips), with the whole-iteration roofline fraction of that run;
-  final_loss_parity HIP vs the CPU oracle from identical inputs: cfg2 over the steps the CPU baseline leg runs anyway,
-                    and BASELINE cfg1 (10 frames 128^2, cube, sil + v2d, 100 steps) in full over several seeds;
-  cpu_baseline      the oracle loop timed on this host (bounded sample).
+data-path collective).  Prints ONE JSON line (<= 2 KB) on rank 0 - the LAST line of
+stdout - with the contract's keys plus
+  roofline          the dominant kernel timed INSIDE the replayed graph (device wall-clock stamps, hm_sil_timestamps), its
+                    algorithmic bytes / that time / 8 TB/s (live); `traffic` / `valu_frac` from the committed PMC passes
+                    under profiles/ (tools/pmc_loop.sh) when they were measured on the same shapes (`traffic_source` says so);
+  cpu_baseline      the oracle loop timed on this host (bounded sample, rank 0 at N = 1 only);
+  steady_state      one number: the same fit past iteration 400;
+  multi_clip        one number: BASELINE cfg4 in miniature, `--multi-clip` clips per GPU as ONE clip batch;
+  ranks / per_rank_its   what the process group reports and every rank's own rate (N > 1).
+Everything else (per-kernel tables, notes, and with `--parity` the HIP-vs-oracle legs of bench_parity.py) goes to
+gpurun_out/bench_detail.json and stderr.  The default run finishes in about a minute.
 """
 import argparse
 import copy
@@ -113,410 +115,6 @@ def cpu_baseline(clip, lw, mano, budget_s=20.0, rend_size=256, image_size=256, o
     return dict(value=n / el, unit="it/s", cores=threads, kind="port", value_logging_off=m / el2,
                 sample=f"{n} iterations of the same clip ({el:.1f} s) after 1 warm-up, oracle loop with the reference's per-step "
                        f".item() logging; then {m} more iterations ({el2:.1f} s) with the logging off"), evo
-
-
-def trajectory_parity(evo_hip, evo_cpu, tol=1e-4):
-    """HIP vs oracle loss_evolution from identical inputs: per-loss relative difference per step, the first step at which
-    any loss differs by more than `tol` (BASELINE north_star: 1e-4 relative), the differences at the last common step."""
-    n = min(len(evo_cpu), len(evo_hip["loss"]))
-    keys = [k for k in evo_cpu[0] if k in evo_hip]
-    rel = {k: [abs(evo_hip[k][i] - evo_cpu[i][k]) / max(abs(evo_cpu[i][k]), 1e-12) for i in range(n)] for k in keys}
-    worst = [max(rel[k][i] for k in keys) for i in range(n)]
-    first = next((i for i, w in enumerate(worst) if w > tol), None)
-    return dict(steps_compared=n, tol=tol, first_step_over_tol=first, max_rel_diff_step0=worst[0],
-                rel_diff_last_step={k: rel[k][n - 1] for k in keys}, max_rel_diff_per_step=worst)
-
-
-def cfg1_parity(mano, seeds, steps=100, frames=10, size=128):
-    """BASELINE cfg1 (the configuration the reference CPU path is defined on): 1 clip, 10 frames 128x128, MANO right hand
-    + 1 rigid cube, silhouette + 2-D keypoint losses only, 100 Adam steps.  HIP fused loop vs CPU oracle loop (its reproducible
-    form, see free_run_parity) from identical inputs, per seed: final weighted loss of both, relative difference, first step over 1e-4, max final-vertex
-    difference (mm); plus the CPU oracle's rate on this configuration."""
-    import numpy as np
-    import torch
-    from homan_amd import synth
-    from homan_amd.jointopt import FusedStepper, build_model
-    from oracle.jointopt import optimize_hand_object as oracle_opt
-    sil_fn, hand_fn = synth.hip_clip_fns(mano)
-    lw = dict(synth.CFG1_LOSS_WEIGHTS)
-    rows, cpu_s, gpu_s, control = [], 0.0, 0.0, None
-    for seed in seeds:
-        clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj="cube", silhouette_fn=sil_fn,
-                               hand_verts_fn=hand_fn)
-        common = dict(objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
-                      optimize_mano=True, image_size=size, mano_model=mano, rend_size=size)
-        model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
-                            sync_metrics=False, **common)
-        st = FusedStepper(model, lw, 1e-2, steps)
-        torch.cuda.synchronize()
-        tg = time.perf_counter()
-        st.run(steps)
-        torch.cuda.synchronize()
-        gpu_s += time.perf_counter() - tg
-        evo_h = st.loss_evolution(steps)
-        t0 = time.perf_counter()
-        om, evo_c, _ = oracle_opt(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
-                                  loss_weights=lw, num_iterations=steps, lr=1e-2, reproducible=True, **common)
-        cpu_s += time.perf_counter() - t0
-        obj_equal = all(np.array_equal(getattr(model, k).detach().cpu().numpy().ravel(), getattr(om, k).detach().numpy().ravel())
-                        for k in ("rotations_object", "translations_object"))
-        cpu_params = dict(om.named_parameters())
-        all_equal = all(np.array_equal(p.detach().cpu().numpy().ravel(), cpu_params[k].detach().numpy().ravel())
-                        for k, p in model.named_parameters() if k in cpu_params)
-        rel = [abs(a - b) / max(abs(b), 1e-12) for a, b in zip(evo_h["loss"], evo_c["loss"])]
-        with torch.no_grad():
-            dvo = (model.get_verts_object()[0].cpu() - om.get_verts_object()[0]).abs().max().item()
-            dvh = (model.get_verts_hand()[0].cpu() - om.get_verts_hand()[0]).abs().max().item()
-        if control is None:
-            # control experiment: the CPU oracle against ITSELF from inputs that differ by 1e-7 m in one object translation -
-            # how far apart two runs of the same implementation end up says how much of the HIP-vs-CPU distance is the
-            # algorithm's own sensitivity (piecewise-constant silhouette loss, Adam's normalised steps)
-            op2 = copy.deepcopy(clip["object_parameters"])
-            op2[0]["translations"] = op2[0]["translations"] + 1e-7
-            om2, evo_p, _ = oracle_opt(copy.deepcopy(clip["person_parameters"]), op2, loss_weights=lw, num_iterations=steps,
-                                       lr=1e-2, reproducible=True, **common)
-            with torch.no_grad():
-                control = dict(seed=seed, perturbation_m=1e-7,
-                               final_vertex_diff_mm=dict(
-                                   object=1e3 * (om2.get_verts_object()[0] - om.get_verts_object()[0]).abs().max().item(),
-                                   hand=1e3 * (om2.get_verts_hand()[0] - om.get_verts_hand()[0]).abs().max().item()),
-                               rel_diff_final_loss=abs(evo_p["loss"][-1] - evo_c["loss"][-1]) / abs(evo_c["loss"][-1]),
-                               first_step_over_tol=next((i for i, (a, b) in enumerate(zip(evo_p["loss"], evo_c["loss"]))
-                                                         if abs(a - b) / max(abs(b), 1e-12) > 1e-4), None))
-        rows.append(dict(seed=seed, first_loss=evo_c["loss"][0], final_loss_hip=evo_h["loss"][-1],
-                         final_loss_cpu=evo_c["loss"][-1], rel_diff_final=rel[-1], rel_diff_step0=rel[0],
-                         first_step_over_tol=next((i for i, r in enumerate(rel) if r > 1e-4), None),
-                         max_rel_diff_any_step=max(rel), object_params_bit_equal=bool(obj_equal),
-                         all_params_bit_equal=bool(all_equal),
-                         final_vertex_diff_mm=dict(object=1e3 * dvo, hand=1e3 * dvh)))
-    fh, fc = np.array([r["final_loss_hip"] for r in rows]), np.array([r["final_loss_cpu"] for r in rows])
-    return dict(config="cfg1: 1 clip, 10 frames 128x128, cube, lw_sil_obj=1 lw_v2d_hand=50, %d Adam steps; HIP fused loop vs the "
-                       "CPU oracle's reproducible loop (oracle.jointopt.reproducible_step: the reference loop with the object's "
-                       "gradient chain - order-independent sums -, the hand's - one stated order - and Adam written out)" % steps,
-                bars=dict(loss_rel=1e-4, vertex_mm=1e-3),
-                all_within_bars=all(r["first_step_over_tol"] is None and r["final_vertex_diff_mm"]["object"] < 1e-3
-                                    and r["final_vertex_diff_mm"]["hand"] < 1e-3 for r in rows),
-                seeds=rows, final_loss_mean=dict(hip=float(fh.mean()), cpu=float(fc.mean())),
-                final_loss_std=dict(hip=float(fh.std()), cpu=float(fc.std())),
-                max_rel_diff_final=float(max(r["rel_diff_final"] for r in rows)),
-                cpu_vs_cpu_control=control,
-                cpu_its_per_s=len(seeds) * steps / cpu_s, hip_its_per_s=len(seeds) * steps / gpu_s,
-                cores=int(os.environ.get("OMP_NUM_THREADS", "1")))
-
-
-def free_run_parity(mano, step2=False, steps=100, frames=10, size=128, obj="cube", seed=0, lr=1e-2, lw=None, clip=None,
-                    tol=1e-4, stages=True, ordinal_depth=False):
-    """BASELINE's end-state bar, free-running: the HIP fused loop and the CPU oracle loop optimise the same clip from identical
-    inputs for `steps` iterations, nobody teacher-forced (reference loop: homan/jointopt.py:158-192).
-
-    The oracle runs its REPRODUCIBLE form (oracle.jointopt.reproducible_step): the object's gradient chain (order-independent
-    sums), the hand's (one stated order, step-1 loss sets: oracle/handchain.py) and Adam written out - same mathematics as
-    autograd + torch.optim.Adam (tests/test_objchain.py), a defined rounding.  The HIP kernels form the same sums (include/homan_amd.h, ORDER-INDEPENDENT SUMS), so on the step-1 loss sets -
-    where the object's chain does not depend on the hand (homan/homan.py:482-490) - `rotations_object` /
-    `translations_object` must be BIT-EQUAL after every step; reported per step, with the first differing step (None = never),
-    the final vertex distances in mm and the relative loss differences (bars: 1e-3 mm, 1e-4)."""
-    import numpy as np
-    import torch
-    from homan_amd import synth
-    from homan_amd.jointopt import FusedStepper, build_model
-    from oracle import objchain
-    from oracle.jointopt import collate_inputs, make_optimizer, reproducible_step
-    from oracle.model import OracleHOMan
-    if clip is None:
-        sil_fn, hand_fn = synth.hip_clip_fns(mano)
-        clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
-                               hand_verts_fn=hand_fn)
-    if lw is None:
-        lw = dict(synth.STEP2_LOSS_WEIGHTS if step2 else synth.STEP1_LOSS_WEIGHTS)
-    if ordinal_depth:
-        lw = dict(lw, lw_depth=1.0)
-    common = dict(objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"], optimize_mano=True,
-                  image_size=size, mano_model=mano, rend_size=size, ordinal_depth=ordinal_depth)
-    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
-                        sync_metrics=False, **common)
-    st = FusedStepper(model, lw, lr, steps)
-    kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
-                        clip["objvertices"], clip["objfaces"])
-    om = OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
-                     image_size=size, mano_model=mano, rend_size=size, ordinal_depth=ordinal_depth, **kw)
-    opt = make_optimizer(om, lr, reproducible=True)
-    obj_keys = ("rotations_object", "translations_object")
-    rows, first_obj_diff, stage_report, first_any_diff = [], None, None, None
-    t_cpu = 0.0
-    for i in range(steps):
-        if stages and first_obj_diff is None:
-            before = {k: getattr(om, k).detach().numpy().copy() for k in obj_keys}
-        st.run(1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ld, md, tot = reproducible_step(om, lw, opt)
-        t_cpu += time.perf_counter() - t0
-        hip = {k: v[i] for k, v in st.loss_evolution(i + 1).items()}
-        cpu = {k: float(v.detach().reshape(-1)[0]) for k, v in ld.items()}
-        cpu["loss"] = float(tot.detach().reshape(-1)[0])
-        rel = {k: abs(hip[k] - cpu[k]) / max(abs(cpu[k]), 1e-12) for k in cpu if k in hip}
-        hp = {k: p.detach().cpu().numpy() for k, p in model.named_parameters()}
-        cp = {k: p.detach().numpy().copy() for k, p in om.named_parameters()}
-        eq = {k: bool(np.array_equal(hp[k], cp[k].reshape(hp[k].shape))) for k in obj_keys}
-        differing = sorted(k for k in hp if k in cp and not np.array_equal(hp[k], cp[k].reshape(hp[k].shape)))
-        if first_any_diff is None and differing:
-            first_any_diff = dict(step=i, parameters=differing)
-        pdiff = {k: float(np.abs(hp[k] - cp[k].reshape(hp[k].shape)).max()) for k in hp if k in cp}
-        if first_obj_diff is None and not all(eq.values()):
-            first_obj_diff = i
-            if stages:
-                # where along the chain did step i differ?  The oracle's chain re-evaluated at the parameters BEFORE the step
-                # against what the HIP loop left behind (gradients, per-corner sums, vertices, index map)
-                for k in obj_keys:
-                    getattr(om, k).data.copy_(torch.from_numpy(before[k]))
-                g_c, stg = objchain.object_pose_grads(om, lw, return_stages=True)
-                sctx = st.model.sil_ctx
-                parts_h = sctx.parts().cpu().numpy()
-                stage_report = dict(
-                    step=i,
-                    verts_equal=bool(np.array_equal(st.vo.cpu().numpy(), stg["verts"])),
-                    idx_map_differing=int((sctx.idx_map().cpu().numpy() != stg["idx"]).sum()),
-                    parts_equal=bool(np.array_equal(parts_h, stg["parts"])) if "parts" in stg else None,
-                    parts_max_abs_diff=float(np.abs(parts_h - stg["parts"]).max()) if "parts" in stg else None,
-                    parts_differing=int((parts_h != stg["parts"]).sum()) if "parts" in stg else None,
-                    parts_max_abs=float(np.abs(stg["parts"]).max()) if "parts" in stg else None,
-                    grads_equal={k: bool(np.array_equal(getattr(model, k).grad.cpu().numpy().reshape(g_c[k].shape), g_c[k]))
-                                 for k in obj_keys},
-                    grads_max_rel={k: float(np.abs(getattr(model, k).grad.cpu().numpy().reshape(g_c[k].shape) - g_c[k]).max()
-                                            / max(np.abs(g_c[k]).max(), 1e-30)) for k in obj_keys})
-                for k in obj_keys:      # (put the oracle back on its own trajectory)
-                    getattr(om, k).data.copy_(torch.from_numpy(cp[k]))
-        rows.append(dict(step=i, object_bit_equal=all(eq.values()), max_rel_loss=max(rel.values()), rel=dict(rel),
-                         values_cpu={k: cpu[k] for k in rel},
-                         worst_loss=max(rel, key=rel.get), max_param_diff=max(pdiff.values()),
-                         worst_param=max(pdiff, key=pdiff.get)))
-    with torch.no_grad():
-        dvo = 1e3 * (model.get_verts_object()[0].cpu() - om.get_verts_object()[0]).abs().max().item()
-        dvh = 1e3 * (model.get_verts_hand()[0].cpu() - om.get_verts_hand()[0]).abs().max().item()
-    frames, obj = len(clip["object_parameters"]), f"{clip['objfaces'].shape[1]} faces"
-    return dict(config=f"{frames} frames {size}x{size}, {obj}, " + ("step-2" if step2 else "step-1 / custom") +
-                f" loss set{' + ordinal depth term' if ordinal_depth else ''}, {steps} free-running steps: HIP fused loop vs the CPU oracle's reproducible loop",
-                steps=steps, tol=tol, first_step_object_params_differ=first_obj_diff,
-                object_params_bit_equal_all_steps=first_obj_diff is None,
-                first_step_any_param_differs=first_any_diff, all_params_bit_equal_all_steps=first_any_diff is None,
-                first_step_over_tol=next((r["step"] for r in rows if r["max_rel_loss"] > tol), None),
-                max_rel_loss=max(r["max_rel_loss"] for r in rows), worst_loss=max(rows, key=lambda r: r["max_rel_loss"])["worst_loss"],
-                final_rel_loss=rows[-1]["max_rel_loss"], final_vertex_diff_mm=dict(object=dvo, hand=dvh),
-                final_max_param_diff=rows[-1]["max_param_diff"], final_worst_param=rows[-1]["worst_param"],
-                stage_report=stage_report, cpu_its_per_s=steps / max(t_cpu, 1e-9),
-                first_over_tol_detail=(lambda j: None if j is None else dict(
-                    step=j, rel_at_step=rows[j]["rel"], rel_step_before=rows[j - 1]["rel"] if j else None,
-                    values_cpu_at_step=rows[j]["values_cpu"], values_cpu_step_before=rows[j - 1]["values_cpu"] if j else None,
-                    worst_param_at_step=rows[j]["worst_param"], max_param_diff_before=rows[j - 1]["max_param_diff"] if j else None))(
-                    next((r["step"] for r in rows if r["max_rel_loss"] > tol), None)),
-                cores=int(os.environ.get("OMP_NUM_THREADS", "1")),
-                per_step=[{k: r[k] for k in ("step", "object_bit_equal", "max_rel_loss", "max_param_diff")} for r in rows][:: max(1, steps // 25)])
-
-
-def end_to_end_clips(mano, lw, clips=16, clips_per_batch=8, steps=400, frames=30, size=256, seed0=2000):
-    """BASELINE cfg4's clips/s, END TO END: `clips` cfg2-shaped clips fitted `steps` iterations each through resident steppers
-    (homan_amd.jointopt.ClipFitter, the sample loop of reference fit_vid_dataset.py:190-379), timed from the per-frame input
-    dicts on the host to the results (parameters, vertices, loss_evolution) back on the host - model build, workspace
-    allocation, calibration and graph capture included for the first batch of a shape, input load + replay + read-back for
-    the others.  Generating the synthetic clips (the dataset / detector side) is outside the timed region."""
-    import torch
-    from homan_amd import synth
-    from homan_amd.jointopt import ClipFitter
-    sil_fn, hand_fn = synth.hip_clip_fns(mano)
-    data = [synth.make_clip(seed=seed0 + i, frames=frames, rend_size=size, image_size=size, obj="bottle", silhouette_fn=sil_fn,
-                            hand_verts_fn=hand_fn) for i in range(clips)]
-    fitter = ClipFitter(lw, num_iterations=steps, optimize_mano=True, image_size=size, mano_model=mano, rend_size=size,
-                        clips_per_batch=clips_per_batch)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    res = fitter.fit(data)
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    t = fitter.timing
-    first = clips_per_batch                       # the clips of the batch that built the stepper
-    reused_clips = clips - first
-    per_reused = (t["load"] + (t["iterations"] + t["read_back"]) * reused_clips / clips) / max(reused_clips, 1)
-    its = t["iterations"] / clips
-    return dict(clips=clips, clips_per_batch=clips_per_batch, steps_per_clip=steps, seconds=el, clips_per_s_end_to_end=clips / el,
-                split_s={k: t[k] for k in ("collate", "build", "load", "iterations", "read_back")},
-                steppers_built=t["built"], batches_reused=t["reused"],
-                repeated_shape=dict(seconds_per_clip=per_reused, clips_per_s=1.0 / per_reused,
-                                    setup_fraction_of_fit=(t["load"] / max(reused_clips, 1)) / its,
-                                    note="a clip of a shape already resident: input load + its share of the replays + read-back"),
-                final_loss_mean=float(sum(r["loss_evolution"]["loss"][-1] for r in res) / clips),
-                what="ClipFitter: one resident stepper (buffers, workspaces, ONE hipGraph) per shape signature; wall clock from "
-                     "the input dicts to the results on the host")
-
-
-def lockstep_parity(mano, step2=False, steps=50, frames=30, size=256, obj="bottle", seed=0, lr=1e-2, free_run=True,
-                    clip=None, lw=None, tol=1e-4, ordinal_depth=False):
-    """Teacher-forced parity along the HIP trajectory (reference loop: homan/jointopt.py:158-192).
-
-    The fused loop runs `steps` iterations one replay at a time.  BEFORE every step its parameters are loaded into the CPU
-    oracle, which evaluates THAT step there: loss_dict (bar 1e-4 relative), parameter gradients (error / largest entry),
-    camera-space vertices (mm) and the face-index map of the silhouette raster (samples whose owner differs).  Every step is
-    a single-step comparison at identical parameters, so no trajectory can hide in it; the hard rasteriser's chaos only
-    enters through what the comparison measures - a flipped sample.
-    With `free_run` a second oracle optimises from the same start with torch's Adam (the reference loop): the distance of
-    the two FREE trajectories per step (parameters in ulps / absolute, samples that differ, weighted loss) says when they
-    separate and the lock-step numbers of the step before say what differed first."""
-    import numpy as np
-    import torch
-    from homan_amd import synth
-    from homan_amd.jointopt import FusedStepper, build_model
-    from oracle import nmr as o_nmr
-    from oracle.jointopt import collate_inputs, make_optimizer
-    from oracle.model import OracleHOMan
-    if clip is None:
-        sil_fn, hand_fn = synth.hip_clip_fns(mano)
-        clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
-                               hand_verts_fn=hand_fn)
-    if lw is None:
-        lw = dict(synth.STEP2_LOSS_WEIGHTS if step2 else synth.STEP1_LOSS_WEIGHTS)
-    if ordinal_depth:           # cfg2 as BASELINE.json words it (sil / kp / depth / smooth): reference homan.py:384-419
-        lw = dict(lw, lw_depth=1.0)
-    common = dict(objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"], optimize_mano=True,
-                  image_size=size, mano_model=mano, rend_size=size)
-    model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
-                        sync_metrics=False, ordinal_depth=ordinal_depth, **common)
-    st = FusedStepper(model, lw, lr, steps)
-
-    def oracle_model():
-        kw = collate_inputs(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
-                            clip["objvertices"], clip["objfaces"])
-        return OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
-                           image_size=size, mano_model=mano, rend_size=size, ordinal_depth=ordinal_depth, **kw)
-
-    def oracle_depth_idx(om):
-        """face-index maps of the two depth renders of the ordinal depth term (object, hand) at the full-image camera"""
-        with torch.no_grad():
-            r = o_nmr.Renderer(image_size=size, K=om.camintr, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
-            out = []
-            for v, fc in ((om.get_verts_object()[0], om.faces_object),
-                          (om.get_verts_hand()[0], om.faces_hand[0][None].repeat(om.camintr.shape[0], 1, 1))):
-                f = r._ndc_faces(v, fc, om.camintr, None, None, None, None)
-                out.append(o_nmr._RasterizeAlphaDepth.apply(f, 2 * size, r.near, r.far, r.rasterizer_eps)[2].numpy())
-            return out
-
-    def oracle_idx(om):
-        with torch.no_grad():
-            r = om.losses.renderer
-            f = r._ndc_faces(om.get_verts_object()[0], om.faces_object, om.camintr_rois_object, None, None, None, None)
-            return o_nmr._RasterizeAlphaDepth.apply(f, 2 * size, r.near, r.far, r.rasterizer_eps)[2].numpy()
-
-    def fwd_bwd(om):
-        for p in om.parameters():
-            p.grad = None
-        ld, md = om(loss_weights=lw)
-        tot = sum(ld[k] * lw[k.replace("loss", "lw")] for k in ld)
-        tot.sum().backward()
-        row = {k: float(v.detach().reshape(-1)[0]) for k, v in ld.items()}
-        row.update({k: float(v) for k, v in md.items()})
-        row["loss"] = float(tot.detach().reshape(-1)[0])
-        return row
-
-    forced = oracle_model()
-    free = oracle_model() if free_run else None
-    opt = make_optimizer(free, lr) if free_run else None
-    sctx = st.model.sil_ctx
-    rows, free_rows = [], []
-    for i in range(steps):
-        params = {k: p.detach().cpu().clone() for k, p in model.named_parameters()}
-        st.run(1)
-        torch.cuda.synchronize()
-        hip = st.loss_evolution(i + 1)
-        hip = {k: v[i] for k, v in hip.items()}
-        grads = {k: p.grad.detach().cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
-        idx_h = sctx.idx_map().cpu().numpy()
-        didx_h = [st.dctx[0].idx_map().cpu().numpy(), st.dctx[1].idx_map().cpu().numpy()] if ordinal_depth else None
-        vo_h, vh_h = st.vo.cpu().numpy(), st.vh.cpu().numpy()
-        forced.load_state_dict(params, strict=False)
-        cpu = fwd_bwd(forced)
-        with torch.no_grad():
-            vo_c, vh_c = forced.get_verts_object()[0].numpy(), forced.get_verts_hand()[0].numpy()
-        rel = {k: abs(hip[k] - cpu[k]) / max(abs(cpu[k]), 1e-12) for k in cpu if k in hip and k.startswith("loss")}
-        # logged metrics (not part of the objective).  handobj_maxdist: the reference forms |a|^2 + |b|^2 - 2ab in fp32
-        # (libyana batch_pairwise_dist, losses.py:227), whose own rounding is ~4e-6 m at a 6 mm gap; the kernel differences
-        # the coordinates first -> compared in metres
-        met = {k: abs(hip[k] - cpu[k]) / max(abs(cpu[k]), 1e-12) for k in cpu if k in hip and not k.startswith("loss")}
-        maxdist_abs = abs(hip["handobj_maxdist"] - cpu["handobj_maxdist"]) if "handobj_maxdist" in cpu and "handobj_maxdist" in hip else 0.0
-        gerr = {}
-        for k, p in forced.named_parameters():
-            if p.grad is None or k not in grads:
-                continue
-            ref = p.grad.numpy()
-            gerr[k] = float(np.abs(grads[k] - ref).max() / max(np.abs(ref).max(), 1e-30))
-        worst_loss = max(rel, key=rel.get)
-        worst_grad = max(gerr, key=gerr.get)
-        col_given = None
-        if "loss_collision" in cpu:
-            # the same oracle term evaluated on the HIP loop's HAND vertices (1 ulp from the oracle's: the MANO sums run in
-            # another order; the object's vertices are bit-equal): what is left of the difference is the SDF kernels'
-            from oracle import model as o_model
-            with torch.no_grad():
-                cg = float(o_model.compute_collision_loss(torch.from_numpy(vh_h), torch.from_numpy(vo_h), forced.faces_object,
-                                                          forced.closed_faces)["loss_collision"])
-            col_given = abs(hip["loss_collision"] - cg) / max(abs(cg), 1e-12)
-        rows.append(dict(step=i, max_rel_loss=rel[worst_loss], worst_loss=worst_loss, worst_loss_value=cpu[worst_loss],
-                         weighted_share=abs(hip[worst_loss] - cpu[worst_loss]) * lw[worst_loss.replace("loss", "lw")] / max(abs(cpu["loss"]), 1e-12)
-                         if worst_loss != "loss" else rel[worst_loss], max_grad_err=gerr[worst_grad],
-                         worst_grad=worst_grad, flipped_samples=int((idx_h != oracle_idx(forced)).sum()),
-                         vert_diff_mm=dict(object=1e3 * float(np.abs(vo_h - vo_c).max()), hand=1e3 * float(np.abs(vh_h - vh_c).max())),
-                         vert_equal=dict(object=bool(np.array_equal(vo_h, vo_c)), hand=bool(np.array_equal(vh_h, vh_c))),
-                         rel_loss=rel, rel_metric=met, handobj_maxdist_abs_m=maxdist_abs,
-                         collision_rel_given_hip_vertices=col_given,
-                         flipped_depth_samples=([int((a != b).sum()) for a, b in zip(didx_h, oracle_depth_idx(forced))]
-                                                if ordinal_depth else None)))
-        if free_run:
-            # the free-running reference loop, one step behind the comparison: its parameters BEFORE its step i against the
-            # HIP loop's parameters before step i
-            fp = {k: p.detach().numpy() for k, p in free.named_parameters()}
-            dist = {k: float(np.abs(fp[k] - params[k].numpy()).max()) for k in fp if k in params}
-            wk = max(dist, key=dist.get)
-            fidx = oracle_idx(free)
-            opt.zero_grad()
-            frow = fwd_bwd(free)
-            opt.step()
-            free_rows.append(dict(step=i, max_param_diff=dist[wk], worst_param=wk,
-                                  samples_differing=int((idx_h != fidx).sum()),
-                                  rel_diff_total=abs(hip["loss"] - frow["loss"]) / max(abs(frow["loss"]), 1e-12),
-                                  rel_diff_worst=max(abs(hip[k] - frow[k]) / max(abs(frow[k]), 1e-12)
-                                                     for k in frow if k in hip and k.startswith("loss"))))
-    out = dict(config=("cfg3" if step2 else "cfg2") + f"-shaped: {frames} frames {size}x{size}, {obj}, "
-               + ("step-2" if step2 else "step-1") + " loss set" + (" + ordinal depth term" if ordinal_depth else "") + f", {steps} steps of the fused loop, every step re-evaluated by "
-               "the CPU oracle at the HIP parameters", steps=steps, tol=tol,
-               max_rel_loss=max(r["max_rel_loss"] for r in rows), max_grad_err=max(r["max_grad_err"] for r in rows),
-               flipped_samples=sum(r["flipped_samples"] for r in rows),
-               # (object: its vertices are bit-equal, so is its depth render; hand: vertices one ulp apart, a sample may flip)
-               flipped_depth_samples=(dict(object=sum(r["flipped_depth_samples"][0] for r in rows),
-                                           hand=sum(r["flipped_depth_samples"][1] for r in rows)) if ordinal_depth else None),
-               max_vert_diff_mm=dict(object=max(r["vert_diff_mm"]["object"] for r in rows),
-                                     hand=max(r["vert_diff_mm"]["hand"] for r in rows)),
-               object_vertices_bit_equal=all(r["vert_equal"]["object"] for r in rows),
-               hand_vertices_bit_equal=all(r["vert_equal"]["hand"] for r in rows),
-               max_rel_metric={k: max(r["rel_metric"].get(k, 0.0) for r in rows) for k in rows[0]["rel_metric"]},
-               max_handobj_maxdist_abs_m=max(r["handobj_maxdist_abs_m"] for r in rows),
-               max_collision_rel_given_hip_vertices=(max(r["collision_rel_given_hip_vertices"] for r in rows)
-                                                     if rows[0]["collision_rel_given_hip_vertices"] is not None else None),
-               first_step_over_tol=next((r["step"] for r in rows if r["max_rel_loss"] > tol), None),
-               worst_loss_per_key={k: max(r["rel_loss"].get(k, 0.0) for r in rows) for k in rows[0]["rel_loss"]},
-               worst_grad_per_step=[(r["worst_grad"], r["max_grad_err"]) for r in rows][:8],
-               per_step=[{k: r[k] for k in ("step", "max_rel_loss", "worst_loss", "worst_loss_value", "weighted_share",
-                                            "max_grad_err", "worst_grad", "flipped_samples")} for r in rows])
-    if free_run:
-        sep = next((r["step"] for r in free_rows if r["rel_diff_worst"] > tol), None)
-        first_flip = next((r["step"] for r in free_rows if r["samples_differing"] > 0), None)
-        out["free_run"] = dict(
-            what="HIP fused loop vs the CPU oracle loop (torch Adam), both free-running from identical inputs",
-            first_step_over_tol=sep, first_step_with_differing_samples=first_flip,
-            max_param_diff_per_step=[r["max_param_diff"] for r in free_rows][:12],
-            samples_differing_per_step=[r["samples_differing"] for r in free_rows][:12],
-            rel_diff_worst_per_step=[r["rel_diff_worst"] for r in free_rows][:12],
-            at_separation=(free_rows[sep] if sep is not None else None),
-            before_separation=(dict(lockstep=rows[sep - 1]["max_grad_err"], worst_grad=rows[sep - 1]["worst_grad"],
-                                    free=free_rows[sep - 1]) if sep else None),
-            final=free_rows[-1])
-    return out
 
 
 def bench_shared_scale(args, rank, world, backend, mano, sil_fn, hand_fn):
@@ -669,8 +267,9 @@ def pose_init_bench(args):
     stamps = po._fused_loop(sm, 1e-2, max(steps - reps, 3), stamp_reps=reps)[3]
     kb = kernel_bytes(n, size // 2, int(faces.shape[0]), noaa=True)
     pmc = {}
-    ppath = os.path.join(ROOT, "profiles", "r04_pmc_poseinit.json")
-    if os.path.exists(ppath):
+    ppath = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_poseinit.json", "r04_pmc_poseinit.json"))
+                  if os.path.exists(p)), None)
+    if ppath:
         pj = json.load(open(ppath))
         if pj.get("shape") == dict(poses=n, size=size, faces=int(faces.shape[0])):
             pmc = pj.get("per_launch", {})
@@ -690,7 +289,7 @@ def pose_init_bench(args):
                 avg_launch_us=per[dom]["avg_launch_us"], kernels=per,
                 timing=f"device wall clock stored by every workgroup at entry and exit in the last {reps} replays of a "
                        f"{steps}-step fit's hipGraph (hm_sil_timestamps)",
-                traffic_source="profiles/r04_pmc_poseinit.json (rocprofv3 --pmc passes, tools/pmc_poseinit.sh)" if per[dom].get("traffic_bytes") else None)
+                traffic_source=f"profiles/{os.path.basename(ppath)} (committed rocprofv3 --pmc passes, tools/pmc_poseinit.sh)" if per[dom].get("traffic_bytes") else None)
     cpu = None
     if not args.no_cpu_baseline:
         from oracle import poseopt
@@ -721,6 +320,7 @@ def pose_init_bench(args):
 
 
 _REAL_STDOUT = None
+MAX_LINE_BYTES = 2048          # the driver parses the LAST stdout line; round 4's 23 KB line did not parse
 
 
 def _quiet_stdout():
@@ -733,9 +333,81 @@ def _quiet_stdout():
         os.dup2(2, 1)
 
 
-def emit(line):
+def _num(x, digits=5):
+    """floats of the line at `digits` significant digits (the full values go to the detail file)"""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    if isinstance(x, dict):
+        return {k: _num(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_num(v, digits) for v in x]
+    return x
+
+
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "valu_frac", "traffic_source")
+CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+
+
+def compact_line(full):
+    """The ONE stdout line (<= MAX_LINE_BYTES): the contract's keys, `roofline` and `cpu_baseline` as flat objects, and at most
+    one-number summaries of the other legs.  `full` is the complete record (per-kernel tables, per-step traces, notes) - it
+    goes to the detail file and stderr.  tests/test_cabi_and_host.py builds a line from canned numbers and checks the bound."""
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    cfg = dict(full.get("config") or {})
+    if len(str(cfg.get("workload", ""))) > 300:
+        cfg["workload"] = str(cfg["workload"])[:297] + "..."
+    line["config"] = {k: v for k, v in cfg.items() if isinstance(v, (int, float, str, bool)) or v is None}
+    r = full.get("roofline")
+    line["roofline"] = None if not r else {k: r.get(k) for k in ROOFLINE_KEYS if k in r}
+    if line["roofline"] and r.get("whole_iteration"):
+        line["roofline"]["whole_iteration_frac"] = r["whole_iteration"].get("frac")
+    c = full.get("cpu_baseline")
+    line["cpu_baseline"] = None if not c else {k: c.get(k) for k in CPU_KEYS if k in c}
+    if line["cpu_baseline"] and len(str(line["cpu_baseline"].get("sample", ""))) > 160:
+        line["cpu_baseline"]["sample"] = str(line["cpu_baseline"]["sample"])[:157] + "..."
+    for k in ("clips_per_s", "clips_per_s_hbm_frac", "first_loss", "final_loss", "ranks", "backend", "per_rank_its",
+              "shared_scale_final", "replicas_identical", "best_iou", "seconds_per_fit", "parity_ok", "parity_vs", "detail"):
+        if full.get(k) is not None:
+            line[k] = full[k]
+    for k in ("steady_state", "multi_clip"):
+        leg = full.get(k)
+        if leg:
+            line[k] = {kk: leg[kk] for kk in ("value", "unit", "ms_per_step", "ms_per_round", "clips_per_gpu", "frac") if kk in leg}
+            if k == "steady_state" and leg.get("roofline"):
+                line[k]["dominant_kernel_us"] = leg["roofline"].get("avg_launch_us")
+                line[k]["frac"] = leg["roofline"].get("frac")
+            if k == "multi_clip" and leg.get("roofline"):
+                line[k]["frac"] = leg["roofline"].get("frac")
+    line = _num(line)
+    s = json.dumps(line)
+    if len(s) > MAX_LINE_BYTES:           # never let an over-long line out again: drop the optional tail, keep the contract
+        for k in ("per_rank_its", "multi_clip", "steady_state", "clips_per_s_hbm_frac", "first_loss", "final_loss"):
+            line.pop(k, None)
+            if len(json.dumps(line)) <= MAX_LINE_BYTES:
+                break
+    return line
+
+
+def emit(full):
+    """Writes the complete record to the detail file (gpurun_out/bench_detail.json unless $HOMAN_BENCH_DETAIL names another
+    path) and to stderr, and the compact line - the LAST line of stdout - to the real stdout."""
+    path = os.environ.get("HOMAN_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        full = dict(full, detail=os.path.relpath(path, ROOT))
+    except OSError as e:                  # a read-only tree must not cost the line
+        sys.stderr.write(f"bench.py: detail file not written ({e})\n")
+    sys.stderr.write("bench detail: " + json.dumps(full) + "\n")
+    sys.stderr.flush()
     sys.stdout.flush()
-    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (json.dumps(line) + "\n").encode())
+    out = json.dumps(compact_line(full))
+    assert len(out) <= MAX_LINE_BYTES and "\n" not in out, len(out)
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (out + "\n").encode())
 
 
 def _launch_ranks(n):
@@ -755,6 +427,14 @@ def _launch_ranks(n):
         raise SystemExit(r.returncode)
 
 
+_T0 = time.perf_counter()
+
+
+def _leg(name):
+    sys.stderr.write(f"[bench {time.perf_counter() - _T0:6.1f} s] {name}\n")
+    sys.stderr.flush()
+
+
 def main():
     _quiet_stdout()
     ap = argparse.ArgumentParser()
@@ -769,9 +449,6 @@ def main():
     ap.add_argument("--multi-clip", type=int, default=8,
                     help="after the headline run, also time this many clips per GPU optimised as ONE clip batch (one launch "
                          "per kernel over all clips; BASELINE cfg4 has 8 clips per GPU); 0 = skip")
-    ap.add_argument("--parity-seeds", type=int, default=5,
-                    help="final_loss_parity: number of cfg1 clips (10 frames 128^2, 100 steps) run on both the HIP loop and "
-                         "the CPU oracle; 0 = skip")
     ap.add_argument("--shared-scale", action="store_true",
                     help="BASELINE cfg5 instead of the headline: --multi-clip clips per GPU as one clip batch, step-2 losses, "
                          "ONE object scale tied across all clips of all ranks (one 4-byte all-reduce per step inside the "
@@ -784,23 +461,22 @@ def main():
                     help="cfg2 as BASELINE.json words it (sil/kp/depth/smooth): the ordinal depth term of reference "
                          "homan.py:384-419 switched on (lw_depth=1, HOMan(ordinal_depth=True); the reference's own call site "
                          "raises, see DESIGN.md row a19)")
-    ap.add_argument("--steady", type=int, default=2000,
+    ap.add_argument("--steady", type=int, default=1000,
                     help="steady_state leg after the headline: the same fit continued to iteration >= 400, then this many "
                          "timed iterations (BASELINE cfg2 is a 400-step fit; a short --steps/--warmup headline times the first, "
                          "heavier iterations); 0 = skip")
-    ap.add_argument("--lockstep", type=int, default=24,
-                    help="final_loss_parity.lockstep: this many steps of the fused loop re-evaluated by the CPU oracle at the "
-                         "HIP parameters (teacher-forced), plus the free-running comparison; 0 = skip")
-    ap.add_argument("--freerun", type=int, default=100,
-                    help="final_loss_parity.free_run: this many FREE-running steps of the headline clip on the HIP loop and on the "
-                         "CPU oracle's reproducible loop - every parameter bit-equal after every step, losses within 1e-4, "
-                         "final vertices identical (profiles/ holds 400-step runs of cfg2 and cfg3; with --step2 at most 40 steps, "
-                         "the CPU side runs 0.5 it/s); 0 = skip")
-    ap.add_argument("--e2e-clips", type=int, default=16,
-                    help="end_to_end: this many clips of the headline shape fitted 400 steps each through resident steppers "
-                         "(ClipFitter), wall clock from the input dicts to the results on the host; 0 = skip")
+    ap.add_argument("--parity", action="store_true",
+                    help="opt-in: the parity and end-to-end legs of bench_parity.py (cfg1 x --parity-seeds, --lockstep teacher-forced "
+                         "steps, --freerun free-running steps, --e2e-clips through ClipFitter).  They are what pytest -m gpu "
+                         "asserts on (tests/test_parity_gpu.py, test_lockstep_gpu.py); their records go to the detail file, "
+                         "the line gets `parity_ok`")
+    ap.add_argument("--parity-seeds", type=int, default=5)
+    ap.add_argument("--lockstep", type=int, default=24)
+    ap.add_argument("--freerun", type=int, default=100)
+    ap.add_argument("--e2e-clips", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-budget", type=float, default=10.0,
+                    help="seconds of CPU work of the cpu_baseline leg (rank 0, N = 1 only)")
     args = ap.parse_args()
 
     if args.pose_init:
@@ -817,6 +493,7 @@ def main():
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
     if args.pose_init:
         return pose_init_bench(args)
+    _leg("import torch")
     import torch
     import torch.distributed as dist
     from homan_amd import synth
@@ -835,6 +512,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    _leg("synthetic clip")
     mano = synthetic_mano(0)
     sil_fn, hand_fn = synth.hip_clip_fns(mano)
     if args.shared_scale:
@@ -844,6 +522,7 @@ def main():
     lw = dict(synth.STEP2_LOSS_WEIGHTS if args.step2 else synth.STEP1_LOSS_WEIGHTS)
     if args.depth:
         lw["lw_depth"] = 1.0
+    _leg("model + stepper (calibration, graph capture)")
     model = build_model(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
                         objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
                         optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
@@ -861,19 +540,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(n):
+    per_rank = []
+
+    def timed(n, keep=None):
         barrier()
         t0 = time.perf_counter()
         stepper.run(n)
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0            # this rank's own time (before it waits for the others)
         barrier()
         el = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([el], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dev = "cuda" if backend == "nccl" else "cpu"
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = t.item()
+            if keep is not None:
+                o = torch.tensor([own], dtype=torch.float64, device=dev)
+                g = [torch.zeros_like(o) for _ in range(world)]
+                dist.all_gather(g, o)
+                keep.extend(n / float(x.item()) for x in g)
+        elif keep is not None:
+            keep.append(n / own)
         return el
 
-    elapsed = timed(args.steps)
+    _leg(f"headline: {args.steps} timed iterations")
+    elapsed = timed(args.steps, per_rank)
     B, S = args.frames, args.size
     F, V = clip["objfaces"].shape[1], clip["objvertices"].shape[1]
 
@@ -905,7 +597,7 @@ def main():
         torch.cuda.synchronize()
         kb = kernel_bytes(B, S, F)
         pmc, psrc = {}, None
-        for cand in ("r04_pmc_loop.json", "r04_pmc_loop_cfg3.json", "r03_pmc_loop.json", "r02_pmc_loop.json"):
+        for cand in PMC_FILES:
             ppath = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(ppath):
                 pj = json.load(open(ppath))
@@ -938,7 +630,8 @@ def main():
                     avg_launch_us=per[dom]["avg_launch_us"], valu_frac=per[dom].get("valu_frac"),
                     timing=f"device wall clock stored by every workgroup at entry and exit (earliest start to latest end) in "
                            f"{reps} more replays of the timed hipGraph (hm_sil_timestamps); same launches, same overlap",
-                    traffic_source=(f"profiles/{psrc} (rocprofv3 --pmc passes over the steady-state loop, tools/pmc_loop.sh)"
+                    # `achieved` / `avg_launch_us` are LIVE (this run); `traffic` / `valu_frac` come from the committed PMC passes
+                    traffic_source=(f"profiles/{psrc} (committed rocprofv3 --pmc passes, not this run)"
                                     if per[dom].get("traffic_bytes") else None),
                     kernels=per,
                     whole_iteration=dict(algorithmic_bytes=tot, achieved_GBps=tot * its_per_s / 1e9,
@@ -946,12 +639,14 @@ def main():
 
     roof = steady = None
     if fused:
+        _leg("roofline stamps")
         r = stamp_roofline(args.steps / elapsed, stamp_reps) if rank == 0 else stepper.run(stamp_reps)
         roof = r if rank == 0 else None
         if args.steady > 0:
             # the steady state of the same fit (BASELINE cfg2 is a 400-step fit: iterations 5-25, which short driver flags
             # time, are its heaviest - the band where render and target disagree is still wide, the sweeps see 5-10 M pairs
             # instead of 1.4 M): continue to iteration >= 400, then time `--steady` more
+            _leg(f"steady state: {args.steady} timed iterations")
             stepper.run(steady_warm)
             first = args.warmup + args.steps + stamp_reps + steady_warm
             el_s = timed(args.steady)
@@ -969,7 +664,8 @@ def main():
         # every kernel is launched once per iteration over all the clips (per-clip normalisers, Adam state, log rows), the
         # whole batched iteration is one hipGraph; every rank its own set, no collective; aggregate = all clips of all
         # ranks / the slowest rank's time.  Bit-identical to optimising the clips one by one (tests/test_clip_batch_gpu.py).
-        C, msteps = args.multi_clip, min(args.steps, 200)
+        _leg(f"multi_clip: {args.multi_clip} clips as one batch")
+        C, msteps = args.multi_clip, min(max(args.steps, 100), 200)
         models = []
         for i in range(C):
             ci = synth.make_clip(seed=1000 + 100 * rank + i, frames=args.frames, rend_size=args.size, image_size=args.size,
@@ -1001,30 +697,42 @@ def main():
                           "max over ranks")
         del bst, models
 
-    cpu = parity = None
+    cpu = parity = e2e = None
+    parity_ok = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        _leg(f"cpu_baseline: oracle loop, {args.cpu_budget:.0f} s budget")
         cpu, evo_cpu = cpu_baseline(clip, lw, mano, args.cpu_budget, rend_size=S, image_size=S, ordinal_depth=args.depth)
-        parity = dict(cfg2_first_steps=trajectory_parity(evo, evo_cpu),
-                      lockstep=(lockstep_parity(mano, step2=args.step2, steps=args.lockstep, frames=B, size=S, clip=clip, lw=lw,
-                                                free_run=not args.depth, ordinal_depth=args.depth)
-                                if args.lockstep > 0 else None),
-                      cfg1=cfg1_parity(mano, seeds=list(range(args.parity_seeds))) if args.parity_seeds > 0 else None,
-                      free_run=(free_run_parity(mano, step2=args.step2,
-                                                steps=min(args.freerun, 40) if (args.step2 or args.depth) else args.freerun,
-                                                frames=B, size=S, clip=clip, lw=lw, ordinal_depth=args.depth)
-                                if args.freerun > 0 else None),
-                      bar="north_star: 1e-4 relative on losses, 1e-3 mm on final vertices.  cfg1 / free_run compare FREE-running "
-                          "trajectories: the object's gradient chain sums in an order-independent way and the hand's chain and "
-                          "the step-2 pair terms run in one stated order on both sides (DESIGN.md 2), so EVERY parameter is "
-                          "bit-equal after every step (profiles/r04_freerun_cfg{2,3}_400.json: 400 steps); cfg2_first_steps is "
-                          "the headline run against the cpu_baseline leg's plain oracle loop (torch Adam, autograd), which "
-                          "separates once a sample flips")
-
-    e2e = None
-    if rank == 0 and world == 1 and fused and args.e2e_clips > 0 and not args.depth:
+        if args.parity:
+            import bench_parity as bp
+            _leg("parity legs (opt-in)")
+            parity = dict(cfg2_first_steps=bp.trajectory_parity(evo, evo_cpu),
+                          lockstep=(bp.lockstep_parity(mano, step2=args.step2, steps=args.lockstep, frames=B, size=S, clip=clip,
+                                                       lw=lw, free_run=not args.depth, ordinal_depth=args.depth)
+                                    if args.lockstep > 0 else None),
+                          cfg1=bp.cfg1_parity(mano, seeds=list(range(args.parity_seeds))) if args.parity_seeds > 0 else None,
+                          free_run=(bp.free_run_parity(mano, step2=args.step2,
+                                                       steps=min(args.freerun, 40) if (args.step2 or args.depth) else args.freerun,
+                                                       frames=B, size=S, clip=clip, lw=lw, ordinal_depth=args.depth)
+                                    if args.freerun > 0 else None),
+                          bar="north_star: 1e-4 relative on losses, 1e-3 mm on final vertices.  cfg1 / free_run compare FREE-running "
+                              "trajectories, HIP fused loop vs the oracle's REPRODUCIBLE (written-out) loop: every parameter "
+                              "bit-equal after every step.  cfg2_first_steps is the headline run against the cpu_baseline leg's "
+                              "FAITHFUL oracle loop (torch Adam, autograd), which separates once a sample flips (DESIGN.md 2)")
+            checks = []
+            if parity["cfg1"]:
+                checks.append(bool(parity["cfg1"]["all_within_bars"]))
+            if parity["free_run"]:
+                fr = parity["free_run"]
+                checks.append(fr["first_step_over_tol"] is None and max(fr["final_vertex_diff_mm"].values()) < 1e-3)
+            if parity["lockstep"]:
+                checks.append(parity["lockstep"]["first_step_over_tol"] is None)
+            parity_ok = all(checks) if checks else None
+    if args.parity and rank == 0 and world == 1 and fused and args.e2e_clips > 0 and not args.depth:
+        import bench_parity as bp
+        _leg("end to end (opt-in)")
         del stepper
-        e2e = end_to_end_clips(mano, lw, clips=args.e2e_clips, clips_per_batch=max(1, min(args.multi_clip or 1, args.e2e_clips // 2)),
-                               steps=400, frames=B, size=S)
+        e2e = bp.end_to_end_clips(mano, lw, clips=args.e2e_clips,
+                                  clips_per_batch=max(1, min(args.multi_clip or 1, args.e2e_clips // 2)), steps=400, frames=B, size=S)
     if rank == 0:
         value = world * args.steps / elapsed
         line = {
@@ -1032,23 +740,32 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("cfg3" if args.step2 else "cfg2") +
-                       f": 1 clip/GPU x {B} frames {S}x{S}, synthetic MANO hand + lathe bottle ({F} faces, {V} verts), "
-                       + ("step-2" if args.step2 else "step-1") + " loss set" + (" + ordinal depth term (lw_depth=1)" if args.depth else "")
-                       + ", Adam step + loss logging in the timed region",
+                       f": 1 clip/GPU x {B} frames {S}x{S}, MANO hand + bottle ({F} faces), "
+                       + ("step-2" if args.step2 else "step-1") + " losses" + (" + ordinal depth" if args.depth else "")
+                       + ", fwd+bwd+Adam+logging per step from a hipGraph",
                        "frames": B, "rend_size": S, "faces": int(F), "clips_per_gpu": 1,
-                       "loop": ("fused C-ABI launch sequence" if args.loop == "fused" else "HOMan.forward + autograd") + ", forward+backward+Adam+logging replayed from a hipGraph", "parallelism": f"{world} independent clips"},
+                       "loop": "fused" if fused else "autograd graph", "parallelism": f"{world} independent clips"},
             # BASELINE's second reading of the metric: clips/s (a clip = one 400-step fit) absolute and as the fraction of the
             # N x 8 TB/s HBM roof the SURVEY 8(d) byte model of those iterations amounts to
             "clips_per_s": value / 400.0,
             "clips_per_s_hbm_frac": algorithmic_bytes(B, S, F, V, args.step2)["total"] * value / (8.0e12 * world),
             "final_loss": evo["loss"][-1], "first_loss": evo["loss"][0],
+            # what the process group itself says (N > 1: RCCL's rank count), and every rank's own rate over the timed region
+            "ranks": dist.get_world_size() if world > 1 else 1, "backend": (dist.get_backend() if world > 1 else None),
+            "per_rank_its": per_rank,
             "roofline": roof, "steady_state": steady, "cpu_baseline": cpu, "multi_clip": multi,
+            "parity_ok": parity_ok,
+            "parity_vs": ("oracle's reproducible (written-out) loop, end state" if parity_ok is not None else None),
             "final_loss_parity": parity, "end_to_end": e2e,
             "clips_per_s_end_to_end": e2e["clips_per_s_end_to_end"] if e2e else None,
         }
+        _leg("done")
         emit(line)
     if world > 1:
         dist.destroy_process_group()
+
+
+PMC_FILES = ("r05_pmc_loop.json", "r05_pmc_loop_cfg3.json", "r04_pmc_loop.json", "r04_pmc_loop_cfg3.json")
 
 
 if __name__ == "__main__":

@@ -193,3 +193,33 @@ def test_bench_refuses_a_rank_count_that_differs_from_gpus():
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], env=env, capture_output=True, text=True)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
+
+
+def test_bench_line_is_compact_and_keeps_the_contract():
+    """The driver parses the LAST stdout line of bench.py; round 4's 23 KB line (per-step parity traces inside) came back as
+    `parsed: null`.  Build the line from a canned full record - the round-4 one, traces and all - and from a synthetic worst
+    case, and hold the bound and the contract's keys."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_cfg2_driver_flags.json")))
+    assert len(json.dumps(full)) > 20000                       # (the record that did not parse)
+    worst = dict(full, per_rank_its=[6249.123456789] * 8, ranks=8, backend="nccl", parity_ok=True,
+                 parity_vs="oracle's reproducible (written-out) loop, end state",
+                 config=dict(full["config"], workload="x" * 5000, nested={"a": [1] * 1000}))
+    for rec in (full, worst):
+        line = bench.compact_line(rec)
+        s = json.dumps(line)
+        assert len(s) <= bench.MAX_LINE_BYTES < 4096, len(s)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in line, k
+        assert isinstance(line["config"]["workload"], str)
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_us"):
+            assert k in line["roofline"], k
+        assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-4
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in line["cpu_baseline"], k
+        assert "final_loss_parity" not in line and "end_to_end" not in line and "kernels" not in line["roofline"]
+        assert json.loads(s) == line

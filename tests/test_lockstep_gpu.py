@@ -37,7 +37,7 @@ def _check(out, loss_bar, grad_bar=2e-5, loose=()):
 
 def test_lockstep_cfg2_full_size(mano_model):
     sys.path.insert(0, ROOT)
-    import bench
+    import bench_parity as bench
     out = bench.lockstep_parity(mano_model, step2=False, steps=50, free_run=False)
     _check(out, 1e-5)
     assert out["worst_loss_per_key"]["loss_sil_obj"] < 1e-6
@@ -49,7 +49,7 @@ def test_lockstep_cfg2_with_the_depth_term_full_size(mano_model):
     24 steps re-evaluated by the CPU oracle at the HIP parameters.  Losses incl. loss_depth within 1e-4, zero flipped samples in
     the silhouette raster and in both depth renders (full-image camera; object and hand vertices are bit-equal)."""
     sys.path.insert(0, ROOT)
-    import bench
+    import bench_parity as bench
     out = bench.lockstep_parity(mano_model, step2=False, steps=24, free_run=False, ordinal_depth=True)
     assert out["first_step_over_tol"] is None, out["per_step"]
     assert out["worst_loss_per_key"]["loss_depth"] < 1e-4, out["worst_loss_per_key"]
@@ -62,7 +62,7 @@ def test_lockstep_cfg2_with_the_depth_term_full_size(mano_model):
 
 def test_lockstep_cfg3_full_size(mano_model):
     sys.path.insert(0, ROOT)
-    import bench
+    import bench_parity as bench
     out = bench.lockstep_parity(mano_model, step2=True, steps=30, free_run=False)      # (the CPU side runs ~0.5 it/s on this set)
     # Losses: every term within 1e-5 of the faithful oracle's (measured 2.4e-7; `loss_collision` - a handful of trilinear SDF
     # samples, conditioned at ~1e-4 per ulp of a hand vertex - came down from 2e-4 to 1.4e-7 when the hand's vertices became
@@ -81,7 +81,7 @@ def test_free_running_divergence_is_chaos_not_semantics(mano_model):
     the 1e-4 band is left the lock-step comparison is still at rounding level - i.e. the separation is the algorithm's
     sensitivity to last-bit parameter differences (Adam normalises the step size), not a difference in what is computed."""
     sys.path.insert(0, ROOT)
-    import bench
+    import bench_parity as bench
     out = bench.lockstep_parity(mano_model, step2=False, steps=14, frames=10, size=128, obj="cube", free_run=True)
     fr = out["free_run"]
     assert fr["samples_differing_per_step"][0] == 0

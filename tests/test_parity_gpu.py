@@ -22,7 +22,7 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 def test_cfg1_final_loss_and_vertex_parity(mano_model):
     sys.path.insert(0, ROOT)
-    import bench
+    import bench_parity as bench
     out = bench.cfg1_parity(mano_model, seeds=[0, 1, 2], steps=100)
     for row in out["seeds"]:
         assert row["first_step_over_tol"] is None, row                    # every logged loss within 1e-4 at every step
@@ -43,7 +43,7 @@ def test_free_running_trajectory_is_bit_equal_step1_set(mano_model):
     """a cfg2-shaped clip (bottle, full step-1 loss set) at reduced size: EVERY parameter - object pose, hand pose, MANO pose /
     shape / translation - bit-equal after each of 60 free-running steps, all losses within 1e-4, final vertices identical"""
     sys.path.insert(0, ROOT)
-    import bench
+    import bench_parity as bench
     out = bench.free_run_parity(mano_model, steps=60, frames=8, size=96, obj="bottle")
     assert out["object_params_bit_equal_all_steps"], out["stage_report"]
     assert out["first_step_over_tol"] is None, (out["max_rel_loss"], out["worst_loss"])

@@ -6,7 +6,7 @@ import sys
 
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
-import bench  # noqa: E402
+import bench_parity as bench  # noqa: E402
 from homan_amd import synth  # noqa: E402
 from homan_amd.mano_assets import synthetic_mano  # noqa: E402
 

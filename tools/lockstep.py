@@ -22,7 +22,7 @@ def main():
     os.environ.setdefault("OMP_NUM_THREADS", str(min(os.cpu_count() or 1, 64)))
     import torch
     torch.set_num_threads(int(os.environ["OMP_NUM_THREADS"]))
-    import bench
+    import bench_parity as bench
     from homan_amd.mano_assets import synthetic_mano
     out = bench.lockstep_parity(synthetic_mano(0), step2=args.step2, steps=args.steps, frames=args.frames, size=args.size,
                                 obj=args.obj, seed=args.seed, free_run=not args.no_free)
