@@ -1151,7 +1151,6 @@ __device__ __forceinline__ void sweep_compact(int blk, int nblk, int fpt, const 
 #pragma unroll
             for (int q = 0; q < 4; ++q) t4[q] = r4[q];
             sl.offs[idx] = off;
-            sl.tickets[idx] = 0u;
             for (int u = (off + SWEEP_UNIT - 1) >> SWEEP_USHIFT; (u << SWEEP_USHIFT) < off + nn && u < sl.ucap; ++u)
                 sl.ufirst[u] = (unsigned)idx;
             off += nn;

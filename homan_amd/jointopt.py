@@ -428,7 +428,8 @@ class FusedStepper:
         self.rigid_ws_h, self.rigid_ws_o = (torch.zeros(self.L.hm_rigid_workspace_bytes(n), dtype=torch.uint8, device=dev)
                                             for n in (N, B))
         self.mano_state = torch.empty(self.L.hm_mano_state_bytes(N), dtype=torch.uint8, device=dev)
-        self.graph = self.graph_b = None
+        self.graph = self.graph_b = self.graph_k = None
+        self.graph_iters = int(os.environ.get("HOMAN_GRAPH_ITERS") or "1")
         self.cap_stream, self.side, self.aux, side = _loop_streams(dev)
         self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd, self.ev_smo, self.ev_ras = (torch.cuda.Event() for _ in range(6))
         self.ev_hand, self.ev_col, self.ev_dep, self.ev_dgrad = (torch.cuda.Event() for _ in range(4))
@@ -514,6 +515,15 @@ class FusedStepper:
                     with torch.cuda.graph(self.graph_b, stream=self.cap_stream):
                         self._spread_shared_scale_grad()
                         self.opt.step(zero_grad=False)
+                elif self.graph_iters > 1:
+                    # K iterations in ONE graph: the boundary between two replays (the executor's own start-up, a few
+                    # microseconds of an iteration that lasts 160) is paid once per K iterations; run() replays this graph
+                    # for every full K and the one-iteration graph for the rest - the same launches either way
+                    self.graph_k = _lib.new_graph()
+                    with torch.cuda.graph(self.graph_k, stream=self.cap_stream):
+                        for _ in range(self.graph_iters):
+                            self.forward_backward(log=not self.log_in_adam)
+                            self.opt.step(zero_grad=False, log=self._adam_log())
             finally:
                 tune.hm_tune_sweep_blocks(prev)
                 tune.hm_tune_raster_lds_pad(prev_pad)
@@ -1171,6 +1181,10 @@ class FusedStepper:
             self.opt.step(zero_grad=False, log=self._adam_log())
 
     def run(self, steps):
+        if self.graph_k is not None:
+            while steps >= self.graph_iters:
+                self.graph_k.replay()
+                steps -= self.graph_iters
         for _ in range(steps):
             self._iteration()
 

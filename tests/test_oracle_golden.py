@@ -99,7 +99,10 @@ def test_adam_trajectory(name, mano_model):
     assert split >= 3, f"trajectories separate at step {split}"
     for k, v in evo.items():
         np.testing.assert_allclose(np.array(v)[:split], rec["evo_" + k][:split], rtol=5e-4, atol=1e-7, err_msg=k)
-        np.testing.assert_allclose(np.array(v)[split:], rec["evo_" + k][split:], rtol=0.35, atol=1e-6, err_msg=k)
+        # (a term that has converged to a few samples' worth of its start - cfg1's silhouette term ends at 2 % of it - moves
+        #  by its own size when one sample flips: the band gets a floor of 5 % of the term's first value)
+        np.testing.assert_allclose(np.array(v)[split:], rec["evo_" + k][split:], rtol=0.35,
+                                   atol=1e-6 + 0.05 * abs(float(rec["evo_" + k][0])), err_msg=k)
     sd = model.state_dict()
     for k in (k[6:] for k in rec if k.startswith("final_")):
         # (after a separation Adam's sign-like steps, lr 0.1 on the rotation group, move the runs apart by ~lr per step)

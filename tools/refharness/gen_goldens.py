@@ -53,7 +53,7 @@ def flat_inputs(clip):
 
 
 def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scale=False,
-             optimize_mano=True, init_steps=0, pin_step=5, hands=("right",), inter_type="centroid"):
+             optimize_mano=True, init_steps=0, pin_step=5, hands=("right",), inter_type="centroid", fwd_only=False):
     shims.set_rend_size(size)
     clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj,
                            silhouette_fn=sil_fn, hand_verts_fn=hand_fn, hands=hands)
@@ -95,9 +95,10 @@ def run_case(name, seed, frames, size, obj, weights, steps, optimize_object_scal
     rec["verts_object"] = vo.detach().numpy()
     rec["verts_hand"] = vh.detach().numpy()
     rec["state_dict_keys"] = np.array(sorted(fresh.state_dict().keys()))
-    if inter_type != "centroid":
+    if inter_type != "centroid" or fwd_only:
         # the reference's loop (jointopt.optimize_hand_object) builds its HOMan with the default interaction term: a non-default
-        # `inter_type` is pinned by the forward / backward of the model alone
+        # `inter_type` is pinned by the forward / backward of the model alone.  `fwd_only`: the BASELINE-sized clips
+        # (30 frames 256^2), where one forward / backward of the reference over the CPU leaves is what a test can afford
         out_dir = os.environ.get("HOMAN_GOLDEN_OUT", OUT)
         os.makedirs(out_dir, exist_ok=True)
         np.savez_compressed(os.path.join(out_dir, name + ".npz"), **rec)
@@ -173,6 +174,15 @@ def main():
              weights=dict(synth.STEP1_LOSS_WEIGHTS), steps=8, hands=("left",))
     _maybe("ref_step1_twohands_cube_b4_s64", seed=5, frames=4, size=64, obj="cube",
              weights=dict(synth.STEP1_LOSS_WEIGHTS), steps=8, hands=("right", "left"))
+    # BASELINE.json's own configurations at FULL size (the oracle <-> reference tie had only been made at 4-5
+    # frames x 32-64^2).  cfg1 = configs[0], the configuration the reference's CPU path is defined on: the whole 100-step
+    # fit of the reference's loop; cfg2 / cfg3 = configs[1] / [2]: one forward / backward of the reference's HOMan
+    _maybe("ref_cfg1_cube_b10_s128", seed=0, frames=10, size=128, obj="cube",
+             weights=dict(synth.CFG1_LOSS_WEIGHTS), steps=100)
+    _maybe("ref_cfg2_bottle_b30_s256", seed=0, frames=30, size=256, obj="bottle",
+             weights=dict(synth.STEP1_LOSS_WEIGHTS), steps=1, fwd_only=True)
+    _maybe("ref_cfg3_bottle_b30_s256", seed=0, frames=30, size=256, obj="bottle",
+             weights=dict(synth.STEP2_LOSS_WEIGHTS), steps=1, fwd_only=True)
 
 
 if __name__ == "__main__":
