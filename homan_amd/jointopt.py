@@ -429,7 +429,9 @@ class FusedStepper:
                                             for n in (N, B))
         self.mano_state = torch.empty(self.L.hm_mano_state_bytes(N), dtype=torch.uint8, device=dev)
         self.graph = self.graph_b = self.graph_k = None
-        self.graph_iters = int(os.environ.get("HOMAN_GRAPH_ITERS") or "1")
+        # iterations per replay of the second graph (run()): one clip, no collective between the halves of an iteration.  The
+        # turnaround between two replays is ~5 us of a 160 us iteration (same-box A/B: +2-3 % at 4, no more at 8 / 16)
+        self.graph_iters = int(os.environ.get("HOMAN_GRAPH_ITERS") or ("4" if C == 1 else "1"))
         self.cap_stream, self.side, self.aux, side = _loop_streams(dev)
         self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd, self.ev_smo, self.ev_ras = (torch.cuda.Event() for _ in range(6))
         self.ev_hand, self.ev_col, self.ev_dep, self.ev_dgrad = (torch.cuda.Event() for _ in range(4))
