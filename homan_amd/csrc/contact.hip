@@ -175,9 +175,9 @@ int hm_nn_fwd_rigid_clips(const float* verts_hand, const float* verts_obj, int B
 // Scheduling hint, no effect on results: bytes of unused dynamic LDS added to the metric-only search launches.  The search is
 // a chain of dependent loads in small workgroups (24 registers, 4.6 KB of LDS): eight of them fit on a CU and then hold ALL
 // its wave slots while they wait - in an 8-clip batch (1680 workgroups) the line expansion of the silhouette chain, which
-// runs next to it, took 250 us instead of 170.  64 KB of ballast = two search workgroups per CU.  Process-wide, read when
+// runs next to it, took 250 us instead of 170.  64 KB of ballast = two search workgroups per CU.  Per calling thread (thread-local), read when
 // the search is called (or captured).  Returns the previous value; bytes < 0 only queries.
-static int g_nn_lds_pad = 0;
+static thread_local int g_nn_lds_pad = 0;
 int hm_tune_nn_lds_pad(int bytes)
 {
     const int prev = g_nn_lds_pad;

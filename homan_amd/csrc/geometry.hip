@@ -421,7 +421,7 @@ __global__ void k_sum_small(const float* __restrict__ parts, int n, float w0, co
     if (threadIdx.x == 0) out[c] = w0 * a + (extra ? w1 * extra[c] : 0.f);
 }
 
-int g_hm_lds_pad[HM_PAD_FAMILIES] = {0, 0, 0, 0, 0, 0, 0, 0};
+thread_local int g_hm_lds_pad[HM_PAD_FAMILIES] = {0, 0, 0, 0, 0, 0, 0, 0};
 extern "C" {
 int hm_lincomb4(const float* a0, float w0, const float* a1, float w1, const float* a2, float w2, const float* a3,
                 float w3, long n, float* out, hipStream_t stream)
@@ -455,7 +455,7 @@ int hm_rigid_fwd(const float* mesh, const float* rot6d, const float* trans, cons
     return hm_rigid_fwd_clips(mesh, rot6d, trans, scale, abs_scale, N, V, rotmat, verts, 0, stream);
 }
 // see hm_common.h: family 0 MANO forward, 1 MANO backward, 2 smoothness / interaction / hand-terms launches, 3 the fused
-// pair-terms launch, 4 rigid backward.  Process-wide, read at launch (or capture).  Returns the previous value; bytes < 0 queries.
+// pair-terms launch, 4 rigid backward.  Per calling thread (thread-local), read at launch (or capture).  Returns the previous value; bytes < 0 queries.
 int hm_tune_lds_pad(int family, int bytes)
 {
     if (family < 0 || family >= HM_PAD_FAMILIES) return -1;
@@ -465,9 +465,9 @@ int hm_tune_lds_pad(int family, int bytes)
 }
 #define RIGID_MAX_CHUNKS 16
 // Scheduling hint, no effect on results (the sums are exact): 1 = the object's rigid backward of the fused loops as ceil(V / 256)
-// small workgroups per frame + ticket instead of one large workgroup per frame.  Process-wide, read at launch (or capture).
+// small workgroups per frame + ticket instead of one large workgroup per frame.  Per calling thread (thread-local), read at launch (or capture).
 // Returns the previous value; < 0 only queries.
-static int g_rigid_chunked = 1;      // (same-box A/B, cfg2: chunked 6295 it/s, one 768-thread workgroup per frame 6110)
+static thread_local int g_rigid_chunked = 1;      // (same-box A/B, cfg2: chunked 6295 it/s, one 768-thread workgroup per frame 6110)
 int hm_tune_rigid_chunked(int enable)
 {
     const int prev = g_rigid_chunked;

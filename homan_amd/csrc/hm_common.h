@@ -41,7 +41,7 @@ static __device__ unsigned long long g_chain_ts[8];
 // latency-bound kernel fit on a CU next to the heavy kernel it overlaps (they would otherwise hold every wave slot while
 // they wait on memory).  Scheduling only.
 enum { HM_PAD_MANO_FWD = 0, HM_PAD_MANO_BWD = 1, HM_PAD_SMALL_LOSSES = 2, HM_PAD_PAIR_TERMS = 3, HM_PAD_RIGID_BWD = 4, HM_PAD_FAMILIES = 8 };
-extern int g_hm_lds_pad[HM_PAD_FAMILIES];
+extern thread_local int g_hm_lds_pad[HM_PAD_FAMILIES];      // (launch hints are per calling thread)
 
 #define HM_CHECK_ARG(cond) \
     do {                   \

@@ -2375,7 +2375,7 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 // Scheduling hint, no effect on results (hm_tune_raster_reorder): while it is on, the forward launches of hm_sil_fwd record
 // what every raster workgroup cost and the first launch of hm_sil_bwd re-sorts the raster's launch order by it (kept in the
 // workspace; the caller's work_order only seeds it).  Read when the entry points are called (or captured).
-static int g_raster_reorder = 0;
+static thread_local int g_raster_reorder = 0;
 // pass 2a (+ the work list of pass 2b in its first workgroups) and pass 2b
 static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const float* upstream, const float* keep_sum,
                          int clip_len, hipStream_t stream, float* loss_out = nullptr, int out_stride = 0)
@@ -2390,7 +2390,7 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
                        w.owned, F, w.parts, w.sweep, clip_len, w.lsum, nred, w.partials, w.frame_rec, loss_out, out_stride,
                        w.counter + 24, w.ts + 2 * ts_raster_units(B, S));
 }
-static int g_sweep_blocks = SWEEP_BLOCKS;
+static thread_local int g_sweep_blocks = SWEEP_BLOCKS;
 static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, int sum_log2q, hipStream_t stream)
 {
     const int nsort = g_raster_reorder ? 1 : 0;      // (see hm_tune_raster_reorder: one workgroup more, eight workers less)
@@ -2404,8 +2404,8 @@ static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, int sum
 // Scheduling hint, no effect on results: bytes of unused dynamic LDS added to every k_raster_fwd launch.  The rasteriser's
 // 24.9 KB of LDS and 80 registers fill a CU with 6 workgroups and leave nothing for the kernels of the caller's other
 // stream (72 registers for the MANO forward: it then waits for the raster's tail); 3 KB of ballast caps the CU at 5
-// workgroups.  Process-wide; read when hm_sil_fwd is called (or captured).  Returns the previous value; < 0 only queries.
-static int g_raster_lds_pad = 0;
+// workgroups.  Per calling thread (thread-local); read when hm_sil_fwd is called (or captured).  Returns the previous value; < 0 only queries.
+static thread_local int g_raster_lds_pad = 0;
 int hm_tune_raster_lds_pad(int bytes)
 {
     const int prev = g_raster_lds_pad;
@@ -2413,7 +2413,7 @@ int hm_tune_raster_lds_pad(int bytes)
     return prev;
 }
 // Scheduling hint, no effect on results: adaptive launch order of the forward raster (see g_raster_reorder).  enable > 0: on,
-// 0: off, < 0: query.  Returns the previous value.  Process-wide; read when hm_sil_fwd / hm_sil_bwd are called (or captured).
+// 0: off, < 0: query.  Returns the previous value.  Per calling thread (thread-local); read when hm_sil_fwd / hm_sil_bwd are called (or captured).
 int hm_tune_raster_reorder(int enable)
 {
     const int prev = g_raster_reorder;
@@ -2423,7 +2423,7 @@ int hm_tune_raster_reorder(int enable)
 
 // Scheduling hint, no effect on results: number of persistent workgroups of the edge-sweep kernel (default 1280 = 5 per
 // CU).  The sweeps share the GPU with whatever runs on the caller's other streams; a loop whose other stream is the
-// longer chain (collision + contact terms) finishes sooner with fewer sweep workgroups (768).  Process-wide; read when
+// longer chain (collision + contact terms) finishes sooner with fewer sweep workgroups (768).  Per calling thread (thread-local); read when
 // hm_sil_bwd is called (or captured).  Returns the previous value; blocks <= 0 only queries.
 int hm_tune_sweep_blocks(int blocks)
 {

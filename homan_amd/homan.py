@@ -220,11 +220,13 @@ class HOMan(nn.Module):
             put(self.keep_mask_hand, tmh >= 0)
             put(self.camintr_rois_object, camintr_rois_object)
             put(self.camintr_rois_hand, camintr_rois_hand)
-            if camintr is not None:
-                c = torch.as_tensor(camintr).float()
-                c = c.unsqueeze(0) if c.dim() == 2 else c
-                put(self.camintr, c.expand_as(self.camintr) if c.shape[0] == 1 else c)
-                self.losses.camintr.copy_(self.camintr)
+            # (no intrinsics = the constructor's default, homan.py:113-116 - NOT the previous clip's: a clip loaded into a
+            #  resident model must fit exactly like a freshly built one)
+            c = (torch.tensor([[[1, 0, 0.5], [0, 1, 0.5], [0, 0, 1]]], dtype=torch.float32) if camintr is None
+                 else torch.as_tensor(camintr).float())
+            c = c.unsqueeze(0) if c.dim() == 2 else c
+            put(self.camintr, c.expand_as(self.camintr) if c.shape[0] == 1 else c)
+            self.losses.camintr.copy_(self.camintr)
             if masks_hand is not None and hasattr(self, "masks_human"):
                 self.masks_human.copy_(torch.as_tensor(masks_hand).to(self.masks_human.dtype))
             mo = torch.as_tensor(masks_object)

@@ -177,6 +177,13 @@ class GraphStepper:
         with torch.cuda.graph(self.graph, pool=_lib.autograd_pool()):
             loss_dict, metric_dict, total = self._fwd_bwd(record=True)
             self.opt.step()
+        # Nothing allocated inside the capture stays referenced: captures share ONE memory pool (lib.autograd_pool), so a
+        # tensor kept from this capture sits in a block an older stepper's replay reuses as a temporary - two live graph-mode
+        # steppers replayed alternately would silently overwrite each other's kept tensors.  What a caller reads
+        # lives outside the pool: Parameters, their .grad buffers and the log (allocated before the capture).
+        del loss_dict, metric_dict, total
+        model.losses.last_silhouettes = None
+        model._mano_cache = None
 
     def _fwd_bwd(self, record=False):
         loss_dict, metric_dict = self.model(loss_weights=self.lw)
@@ -1371,6 +1378,7 @@ class ClipFitter:
                              image_size=image_size, mano_model=mano_model, rend_size=rend_size, sync_metrics=False,
                              ordinal_depth=ordinal_depth)
         self.resident = OrderedDict()          # (signature, clips) -> FusedStepper
+        self._one_by_one = set()          # shape signatures whose clips the fused loop takes one at a time
         self.timing = dict(collate=0.0, build=0.0, load=0.0, iterations=0.0, read_back=0.0, clips=0, built=0, reused=0)
 
     def _clock(self):
@@ -1406,11 +1414,23 @@ class ClipFitter:
 
     def _fit_group(self, sig, kws):
         key = (sig, len(kws))
+        # configurations the fused loop takes one clip at a time (two hands per frame, inter_type="min"; the depth term, whose
+        # per-clip instance masks a resident BATCH cannot reload): clip by clip through (sig, 1) steppers, like ShardStepper's
+        # singleton groups - decided when the shape is first seen, not on its second batch
+        if len(kws) > 1 and (sig in self._one_by_one or self.lw.get("lw_depth", 0) > 0):
+            return [r for kw in kws for r in self._fit_group(sig, [kw])]
         t0 = self._clock()
         stepper = self.resident.get(key)
         if stepper is None:
             models = [HOMan(**self.model_kw, **kw) for kw in kws]
-            stepper = FusedStepper(models, self.lw, self.lr, self.steps)
+            try:
+                stepper = FusedStepper(models, self.lw, self.lr, self.steps)
+            except NotImplementedError:
+                if len(kws) == 1:
+                    raise
+                del models
+                self._one_by_one.add(sig)
+                return [r for kw in kws for r in self._fit_group(sig, [kw])]
             self.resident[key] = stepper
             while len(self.resident) > self.max_resident:
                 self.resident.popitem(last=False)         # (its graph stays in lib._KEPT_GRAPHS: a few kilobytes)

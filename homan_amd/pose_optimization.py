@@ -430,21 +430,50 @@ class PoseFitter:
         return result, losses.clone(), champ_rot, champ_trans
 
 
-_FITTERS = {}
-_FITTERS_MAX = 4        # (each holds the rasteriser's workspace of n candidates: ~1 GB at 500 x 256^2)
+from collections import OrderedDict
+
+_FITTERS = OrderedDict()        # least recently used first
+_DIGESTS = {}                   # (data_ptr, version, shape) of a mesh tensor -> digest of its bytes (one host copy per tensor state)
 
 
-def _resident_fitter(vertices, faces, n, size, lr):
+def _fitters_max():
+    """Resident fitters kept (each holds the rasteriser's workspace of its n candidates: ~1 GB at 500 x 256^2).  Default 2 - the
+    mesh of the clip being initialised and the one before -; HOMAN_POSE_FITTERS_MAX overrides, release_pose_fitters() frees."""
+    import os
+    return max(1, int(os.environ.get("HOMAN_POSE_FITTERS_MAX", "2")))
+
+
+def release_pose_fitters():
+    """Drops every resident PoseFitter (device buffers, workspaces, captured graphs' buffers) - call it between the pose
+    initialisation of a dataset walk and the joint fits when the memory is wanted back.  PoseOptimizers returned by earlier
+    fits stay valid (they hold references to what they share)."""
+    _FITTERS.clear()
+    _DIGESTS.clear()
+
+
+def _digest(t):
+    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.dtype))
+    d = _DIGESTS.get(key)
+    if d is None:
+        if len(_DIGESTS) > 64:
+            _DIGESTS.clear()
+        d = _DIGESTS[key] = hash(t.detach().cpu().numpy().tobytes())
+    return d
+
+
+def _resident_fitter(vertices, faces, n, size, lr, mesh_key=None):
     import os
     if os.environ.get("HOMAN_POSE_FITTER", "1") == "0":
         return None
-    key = (hash(vertices.detach().cpu().numpy().tobytes()), hash(faces.detach().cpu().numpy().tobytes()), tuple(vertices.shape),
-           tuple(faces.shape), int(n), int(size), float(lr))
+    mesh_key = mesh_key or (_digest(vertices), _digest(faces))
+    key = (*mesh_key, tuple(vertices.shape), tuple(faces.shape), int(n), int(size), float(lr))
     fitter = _FITTERS.get(key)
     if fitter is None:
-        while len(_FITTERS) >= _FITTERS_MAX:
-            _FITTERS.pop(next(iter(_FITTERS)))
+        while len(_FITTERS) >= _fitters_max():
+            _FITTERS.popitem(last=False)              # least recently used
         fitter = _FITTERS[key] = PoseFitter(vertices, faces, n, size, lr)
+    else:
+        _FITTERS.move_to_end(key)
     return fitter
 
 
@@ -460,6 +489,7 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
     mode="eager": the reference loop verbatim (torch autograd + Adam, one host sync per step for the best-ever bookkeeping);
     mode="graph": that same autograd step captured once in a hipGraph and replayed."""
     dev = torch.device("cuda")
+    mesh_key = ((_digest(vertices), _digest(faces)) if torch.is_tensor(vertices) and torch.is_tensor(faces) else None)     # (the caller's tensors: digested once per tensor state)
     vertices = torch.as_tensor(vertices).float().to(dev)
     faces = torch.as_tensor(faces).to(dev)
     x, y, b, _ = [float(t) for t in square_bbox]
@@ -478,7 +508,7 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
         raise ValueError(f"mode {mode} not in [auto|fused|eager|graph]")
     fitter = None
     if mode == "fused" and num_iterations > 0 and np.asarray(mask).shape[0] % 2 == 0:
-        fitter = _resident_fitter(vertices, faces, num_initializations, int(np.asarray(mask).shape[0]), lr)
+        fitter = _resident_fitter(vertices, faces, num_initializations, int(np.asarray(mask).shape[0]), lr, mesh_key)
     if fitter is not None:
         model, final_losses, champion_rot, champion_trans = fitter.fit(mask, matrix_to_rot6d(rotations_init), translations_init,
                                                                        camintr_roi, num_iterations)

@@ -12,7 +12,10 @@
  *   - all work is enqueued on `stream` and is asynchronous w.r.t. the host (capturable in a hipGraph), except
  *     hm_bench_raster_fwd and the hm_debug_* helpers;
  *   - return value: HM_OK (0) or a negative error code; nothing throws across the ABI;
- *   - re-entrant per (workspace, stream): no global state besides the optional debug hook;
+ *   - re-entrant per (workspace, stream).  State outside the caller's buffers: the hm_tune_* LAUNCH HINTS (grid sizes / LDS
+ *     ballast of a few kernels: scheduling only, never results), which are PER CALLING THREAD (thread-local) and read when an
+ *     entry point is called or captured - a thread sets them, issues or captures its launches, restores them; threads do not
+ *     see each other's values; and the process-wide hm_debug_* hooks (timing events, capacity overrides: test tools);
  *   - workspaces that hold a reduction ticket (hm_reduce_workspace_bytes, hm_sil_workspace_bytes,
  *     hm_collision_workspace_bytes) must be zero-filled ONCE before first use; the ticket resets itself.
  *
@@ -56,7 +59,7 @@ int hm_rigid_bwd(const float* mesh, const float* rot6d, const float* scale, int 
  * is split over ceil(V/256) workgroups and the last one finishes; NULL = one workgroup per frame. */
 size_t hm_rigid_workspace_bytes(int N);
 /* Scheduling hint, no effect on results (exact sums): 1 = hm_rigid_bwd_sil* as ceil(V / 256) small workgroups per frame + a
- * per-frame ticket instead of one large workgroup per frame.  Process-wide, read at launch / capture; returns the previous
+ * per-frame ticket instead of one large workgroup per frame.  Per calling thread (thread-local), read at launch / capture; returns the previous
  * value; < 0 only queries. */
 int hm_tune_rigid_chunked(int enable);
 /* hm_rigid_bwd with the silhouette gradient as one more full term, gathered on the fly from the per-(face, corner) NDC
@@ -199,17 +202,17 @@ int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, cons
                          const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
                          float* g1, hipStream_t stream);
 /* scheduling hint (no reference counterpart, no effect on results): persistent workgroups of the edge-sweep kernel,
- * default 1280; 768 suits loops whose other streams carry the longer chain (collision + contact terms).  Process-wide,
+ * default 1280; 768 suits loops whose other streams carry the longer chain (collision + contact terms).  Per calling thread (thread-local),
  * read when hm_sil_bwd is called or captured.  Returns the previous value; blocks <= 0 only queries. */
 int hm_tune_sweep_blocks(int blocks);
 /* Scheduling hint, no effect on results: bytes of unused dynamic LDS added to every rasteriser launch (3072 caps a CU at 5
- * rasteriser workgroups instead of 6, which leaves registers / LDS for the kernels of the caller's other stream).  Process-wide,
+ * rasteriser workgroups instead of 6, which leaves registers / LDS for the kernels of the caller's other stream).  Per calling thread (thread-local),
  * read when hm_sil_fwd is called (or captured).  Returns the previous value; bytes < 0 only queries. */
 int hm_tune_raster_lds_pad(int bytes);
 /* Scheduling hint, no effect on results: adaptive launch order of the rasteriser's workgroups.  While on, the forward launches
  * record the time every workgroup took and the backward's first launch re-sorts the order, longest first, for the next forward
  * of the same workspace (the `work_order` argument only seeds it): what is expensive moves during a fit.  enable > 0 / 0 / < 0
- * (query).  Process-wide, read when hm_sil_fwd / hm_sil_bwd are called (or captured).  Returns the previous value. */
+ * (query).  Per calling thread (thread-local), read when hm_sil_fwd / hm_sil_bwd are called (or captured).  Returns the previous value. */
 int hm_tune_raster_reorder(int enable);
 /* Same for the metric-only nearest-vertex search (small latency-bound workgroups that otherwise take every wave slot of a CU
  * next to the kernel they overlap): 65536 = two search workgroups per CU. */

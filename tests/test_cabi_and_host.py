@@ -223,3 +223,33 @@ def test_bench_line_is_compact_and_keeps_the_contract():
             assert k in line["cpu_baseline"], k
         assert "final_loss_parity" not in line and "end_to_end" not in line and "kernels" not in line["roofline"]
         assert json.loads(s) == line
+
+
+def test_launch_hints_are_per_thread_and_profiling_globals_are_not_in_the_release_build():
+    """include/homan_amd.h: the only state outside the caller's buffers are the hm_tune_* launch hints, and those are
+    thread-local - a thread that sets one does not change what another thread's launches read (they were
+    process-wide statics).  And the device-side profiling arrays of the instrumented builds (-DRASTER_PHASES, -DSWEEP_STATS,
+    -DSWEEP_UNIT_PROFILE, -DHM_CHAIN_STAMPS) are not part of the shipped library."""
+    import threading
+    from homan_amd import build, lib
+    L = lib.lib()
+    default = L.hm_tune_sweep_blocks(0)                     # (<= 0: query)
+    seen = {}
+    try:
+        assert L.hm_tune_sweep_blocks(768) == default and L.hm_tune_sweep_blocks(0) == 768
+
+        def other():
+            seen["start"] = L.hm_tune_sweep_blocks(0)       # a fresh thread reads the default, not this thread's 768
+            L.hm_tune_sweep_blocks(512)
+            seen["own"] = L.hm_tune_sweep_blocks(0)
+            seen["pad"] = L.hm_tune_raster_lds_pad(4096)
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert seen == {"start": default, "own": 512, "pad": 0}
+        assert L.hm_tune_sweep_blocks(0) == 768 and L.hm_tune_raster_lds_pad(-1) == 0
+    finally:
+        L.hm_tune_sweep_blocks(default)
+    blob = open(build.LIB_PATH, "rb").read()
+    for name in (b"g_raster_ph", b"g_sweep_n", b"g_unit_prof", b"g_chain_ts"):
+        assert name not in blob, name

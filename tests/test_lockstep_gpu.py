@@ -63,7 +63,7 @@ def test_lockstep_cfg2_with_the_depth_term_full_size(mano_model):
 def test_lockstep_cfg3_full_size(mano_model):
     sys.path.insert(0, ROOT)
     import bench_parity as bench
-    out = bench.lockstep_parity(mano_model, step2=True, steps=30, free_run=False)      # (the CPU side runs ~0.5 it/s on this set)
+    out = bench.lockstep_parity(mano_model, step2=True, steps=50, free_run=False)      # (full length again, ADVICE r4: the faithful-form leg is the independent check; the CPU side runs ~0.5 it/s on this set)
     # Losses: every term within 1e-5 of the faithful oracle's (measured 2.4e-7; `loss_collision` - a handful of trilinear SDF
     # samples, conditioned at ~1e-4 per ulp of a hand vertex - came down from 2e-4 to 1.4e-7 when the hand's vertices became
     # bit-equal).  Gradients: 5e-4 of the largest entry (measured 3.1e-4), all of it the contact term's NEAREST-VERTEX picks:
