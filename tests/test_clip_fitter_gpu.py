@@ -80,3 +80,29 @@ def test_mixed_shapes_batches_and_eviction(mano_model):
     for res, (model, evo) in zip(small.fit(clips[:2]) + small.fit(clips[2:4]), fresh[:4]):
         _same(res, model, evo)
     assert small.timing["built"] == 4 and len(small.resident) == 1
+
+
+def test_clip_without_intrinsics_and_one_at_a_time_configurations(mano_model):
+    """ADVICE r4.  (1) A clip WITHOUT `camintr` behind one with: the resident model takes the constructor's default intrinsics
+    (reference homan.py:113-116), not the previous clip's - bit-identical to a fresh fit.  (2) Configurations the fused loop
+    takes one clip at a time (two hands per frame) with clips_per_batch=2: fitted clip by clip through a resident one-clip
+    stepper instead of raising out of fit(), results those of fresh fits."""
+    from homan_amd import synth
+    from homan_amd.jointopt import ClipFitter
+    lw = dict(synth.STEP1_LOSS_WEIGHTS)
+    a, b = _clip(mano_model, 31), _clip(mano_model, 32)
+    b = dict(b, camintr=None)
+    fitter = ClipFitter(lw, num_iterations=STEPS, optimize_mano=True, image_size=64, mano_model=mano_model, rend_size=64)
+    res = fitter.fit([a, b])
+    assert fitter.timing["built"] == 1 and fitter.timing["reused"] == 1
+    for clip, r in zip((a, b), res):
+        _same(r, *_fresh(mano_model, clip, lw))
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    two = [synth.make_clip(seed=s, frames=4, rend_size=64, image_size=64, obj="cube", silhouette_fn=sil_fn, hand_verts_fn=hand_fn,
+                           hands=("right", "left")) for s in (41, 42, 43)]
+    pair = ClipFitter(lw, num_iterations=STEPS, clips_per_batch=2, optimize_mano=True, image_size=64, mano_model=mano_model,
+                      rend_size=64)
+    out = pair.fit(two)
+    assert len(out) == 3 and pair.timing["built"] == 1 and pair.timing["reused"] == 2
+    for clip, r in zip(two, out):
+        _same(r, *_fresh(mano_model, clip, lw))

@@ -41,12 +41,16 @@ def _models(mano, seeds, frames=4, size=64, obj="cube"):
     return out
 
 
-def _rank_main(rank, world, port, out_dir, num_clips, shared):
+def _rank_main(rank, world, port, out_dir, num_clips, shared, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
-    torch.cuda.set_device(0)                       # every rank on the one GPU
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                          # one GPU per rank, RCCL over xGMI (a multi-GPU node only)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)                   # every rank on the one GPU
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     from homan_amd import dist as hdist
     from homan_amd.mano_assets import synthetic_mano
     mano = synthetic_mano(0)
@@ -63,12 +67,12 @@ def _rank_main(rank, world, port, out_dir, num_clips, shared):
     dist.destroy_process_group()
 
 
-def _spawn(world, clips, shared, tmp_path, tag):
+def _spawn(world, clips, shared, tmp_path, tag, backend="gloo"):
     import torch.multiprocessing as mp
     out = tmp_path / tag
     out.mkdir()
-    port = 23000 + (os.getpid() % 4000) + 7 * world + clips
-    mp.spawn(_rank_main, args=(world, port, str(out), clips, shared), nprocs=world, join=True)
+    port = 23000 + (os.getpid() % 4000) + 7 * world + clips + (500 if backend == "nccl" else 0)
+    mp.spawn(_rank_main, args=(world, port, str(out), clips, shared, backend), nprocs=world, join=True)
     cat = lambda name: np.concatenate([np.load(out / f"{name}_{r}.npy") for r in range(world)])
     return cat("scale"), cat("loss"), cat("rot")
 
@@ -87,6 +91,24 @@ def test_two_ranks_fused_shared_scale_equal_the_one_process_batch(mano_model, tm
     np.testing.assert_array_equal(np.asarray([m.int_scales_object.detach().cpu().numpy()[0] for m in models]), scale)
     np.testing.assert_array_equal(np.asarray([e["loss"] for e in evo]), loss)
     np.testing.assert_array_equal(np.asarray([m.rotations_object.detach().cpu().numpy() for m in models]).reshape(2, -1), rot)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL between ranks); the 1-GPU box runs the gloo twin above")
+def test_two_ranks_on_two_gpus_over_rccl(mano_model, tmp_path):
+    """The same protocol with RCCL carrying the collective between two GPUs (nccl had only ever run one-rank groups
+    here): 2 ranks x 2 clips through optimize_clip_shard(shared_scale=True), one all-reduce of one fp32 per step on the compute
+    stream between the two captured halves.  Replicas bit-identical across the ranks, and the same optimisation as the four
+    clips as ONE 4-clip batch in one process."""
+    from homan_amd.jointopt import FusedStepper
+    scale, loss, rot = _spawn(2, 4, True, tmp_path, "nccl_w2c4", backend="nccl")
+    assert np.all(scale == scale[0]) and abs(float(scale[0]) - 1.0) > 1e-4 and np.isfinite(loss).all()
+    models = _models(mano_model, [40, 41, 42, 43])
+    st = FusedStepper(models, _weights(), 1e-2, STEPS, shared_scale=True)
+    st.run(STEPS)
+    # (the one-process batch sums the four gradients in one block sum, the ranks sum two and two and RCCL adds the halves: the
+    #  tied scalar may differ in its last bit - every step within 1e-6 relative - while each rank's replicas are identical)
+    np.testing.assert_allclose(np.asarray([m.int_scales_object.detach().cpu().numpy()[0] for m in models]), scale, rtol=1e-5)
+    np.testing.assert_allclose(np.asarray([e["loss"] for e in st.loss_evolution(STEPS)]), loss, rtol=1e-4)
 
 
 def test_ranks_without_collective_equal_single_clips(mano_model, tmp_path):
