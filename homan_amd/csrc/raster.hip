@@ -1518,6 +1518,19 @@ __device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, b
     return q;
 }
 
+// Global addresses of the hot loops: with W32 (every array of the workspace below 4 GB, checked by the host) an element address
+// is the array's base - a scalar register pair - plus a 32-bit BYTE offset formed in 32-bit arithmetic, which is the
+// addressing mode of the global loads themselves; with 64-bit element indices a third of stage 1's instructions were the
+// 64-bit multiply-adds, sign extensions and shifts of its three addresses.
+template <bool W32> struct HmOff { typedef long t; };
+template <> struct HmOff<true> { typedef unsigned t; };
+template <bool W32, class T>
+__device__ __forceinline__ const T* hm_at(const T* __restrict__ base, typename HmOff<W32>::t i)
+{
+    if (W32) return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned)(i * (unsigned)sizeof(T)));
+    return base + i;
+}
+
 // A wave takes UNITS of 256 consecutive items.  Per unit and per pass of <= 16 faces:
 //   stage 1  every item (64 per trip): family + line geometry, then ONE 8-byte load of its line's summary {first / last set
 //            position of both planes} - in the steady state of a fit ~70 % of the items have no source their sweeps could
@@ -1529,6 +1542,7 @@ __device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, b
 #ifndef SWEEP_WAVES_EU
 #define SWEEP_WAVES_EU 5
 #endif
+template <bool W32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES_EU, 8))) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
                                                    const SweepSrc* __restrict__ srcs,
                                                    const uint4* __restrict__ lrec, int B, int F, int S,
@@ -1544,6 +1558,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
     // LDS copies are padded to an ODD number of dwords (17 / 9): lanes reading the same field of different faces / items
     // then fall into different banks (64- and 32-byte strides put every second / fourth element on the same bank)
     HM_CHAIN_KERNEL();
+    typedef typename HmOff<W32>::t OFF;
     const unsigned long long ts_t0 = (unsigned long long)wall_clock64();
     const bool ts_on = hm_ts_enabled(ts_flag) && (threadIdx.x & 63) == 0;       // every wave: they walk their units independently
     if (ts_on) hm_ts_store(ts_slots, (long)blockIdx.x * 4 + (threadIdx.x >> 6), 0, ts_t0);
@@ -1679,15 +1694,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                     // (past the last face of a compaction block: padding that belongs to no face)
                     const bool mine = g < it_hi && el >= 0 && g - fc.off < (int)fc.cum[11];
                     const SweepLite q = sweep_item_lite(fc, s_fam[wv][max(el, 0)], mine ? g - fc.off : 0, mine, is);
-                    sm[t] = *reinterpret_cast<const uint4*>(lsum + (((long)fc.b * 2 + q.axis) * is + q.d0r) * 8);
+                    sm[t] = *reinterpret_cast<const uint4*>(hm_at<W32>(lsum, (((OFF)fc.b * 2 + q.axis) * is + q.d0r) * 8));
                     // the two samples at the edge, requested with the summary (one round trip): the owner of the sample just
                     // inside (the outward sweep runs only from a sample this winding owns) and the alpha word of the sample
                     // just outside (the inward sweep only from an empty one)
                     {
                         const int xi_in = q.axis ? q.a_in : q.d0r, yi_in = q.axis ? q.d0r : q.a_in;
                         const int xi_out = q.axis ? q.a_out : q.d0r, yo = is - 1 - (q.axis ? q.d0r : q.a_out);
-                        s_own[t] = idx_map[((long)fc.b * is + yi_in) * is + xi_in];
-                        s_aw[t] = alpha16[((((long)fc.b * (is >> 4)) + (yo >> 4)) * (is >> 4) + (xi_out >> 4)) * 16 + (yo & 15)];
+                        s_own[t] = *hm_at<W32>(idx_map, ((OFF)fc.b * is + yi_in) * is + xi_in);
+                        s_aw[t] = *hm_at<W32>(alpha16, ((((OFF)fc.b * (is >> 4)) + (yo >> 4)) * (is >> 4) + (xi_out >> 4)) * 16 + (yo & 15));
                         s_aw[t] = (unsigned short)((s_aw[t] >> (xi_out & 15)) & 1u);
                         s_fn[t] = fc.bf - fc.b * F + q.var * F;
                     }
@@ -1790,17 +1805,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
             // slices of the lines' source arrays: [lo, lo + nb) for both sweeps; only lanes with a sweep touch memory
             const bool on[2] = {act0 && rfrom[0] <= rto[0], act1 && rfrom[1] <= rto[1]};
             int lo[2] = {0, 0}, nbp[2] = {0, 0};
-            long lid[2];
+            OFF lid[2];
             uint4 rf[2], rt[2];
 #pragma unroll
             for (int ph = 0; ph < 2; ++ph) {
-                lid[ph] = ((long)(ph * 2 + axis) * B + b) * is + d0r;
+                lid[ph] = ((OFF)(ph * 2 + axis) * B + b) * is + d0r;
                 rf[ph] = make_uint4(0u, 0u, 0u, 0u);
                 rt[ph] = rf[ph];
                 if (on[ph]) {
-                    const uint4* lr = lrec + lid[ph] * wpl;
-                    rf[ph] = lr[rfrom[ph] >> 6];
-                    rt[ph] = lr[rto[ph] >> 6];
+                    rf[ph] = *hm_at<W32>(lrec, lid[ph] * wpl + (rfrom[ph] >> 6));
+                    rt[ph] = *hm_at<W32>(lrec, lid[ph] * wpl + (rto[ph] >> 6));
                 }
             }
 #pragma unroll
@@ -1898,9 +1912,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                         const int q_nb0 = qmeta[k] >> 12;
                         ph1[k] = r >= q_nb0;
                         qi[k] = i;
-                        long at = (long)qq.base0 + r;
-                        if (ph1[k]) at = (long)qq.base1 + (r - q_nb0);
-                        sc[k] = srcs[at];
+                        OFF at = (OFF)qq.base0 + r;
+                        if (ph1[k]) at = (OFF)qq.base1 + (r - q_nb0);
+                        sc[k] = *hm_at<W32>(srcs, at);
                     }
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -2395,7 +2409,9 @@ static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, int sum
 {
     const int nsort = g_raster_reorder ? 1 : 0;      // (see hm_tune_raster_reorder: one workgroup more, eight workers less)
     const int blocks = max(8, (min(min(hm_cdiv((long)B * F, 2), g_sweep_blocks), TS_SWEEP_WGS - 8) & ~7) - 8 * nsort);   // workers: a multiple of 8, see the unit loop
-    hipLaunchKernelGGL(k_bwd_sweep, dim3(nsort + blocks), dim3(256), 0, stream, w.sweep,
+    // (32-bit byte offsets while the largest array the sweep indexes - the per-line source arrays - stays below 4 GB)
+    const bool w32 = 4.0 * B * (2.0 * S) * (2.0 * S) * sizeof(SweepSrc) < 4.0e9;
+    hipLaunchKernelGGL(w32 ? k_bwd_sweep<true> : k_bwd_sweep<false>, dim3(nsort + blocks), dim3(256), 0, stream, w.sweep,
                        w.idx_map, w.srcs, w.lrec, B, F, S, eps, hm_sum_magic(sum_log2q), w.parts, w.lsum, w.alpha16, w.counter + 24,
                        w.ts + 2 * (ts_raster_units(B, S) + ts_lines_units(B, F, S)), nsort, w.wo_dyn, w.wo_tmp, w.wg_cost,
                        w.counter + 26, (int)ts_raster_units(B, S));
@@ -2839,7 +2855,7 @@ int hm_debug_sweep_caps(int cap)
 int hm_debug_occupancy(int* raster_fwd_blocks, int* sweep_blocks)
 {
     hipError_t e1 = hipOccupancyMaxActiveBlocksPerMultiprocessor(raster_fwd_blocks, k_raster_fwd, 64 * RASTER_WAVES, 0);
-    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(sweep_blocks, k_bwd_sweep, 256, 0);
+    hipError_t e2 = hipOccupancyMaxActiveBlocksPerMultiprocessor(sweep_blocks, k_bwd_sweep<true>, 256, 0);
     return (e1 == hipSuccess && e2 == hipSuccess) ? HM_OK : HM_ERR_LAUNCH;
 }
 
