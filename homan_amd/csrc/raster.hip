@@ -188,6 +188,11 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
         const float xmin = fminf(px[0], fminf(px[1], px[2])), xmax = fmaxf(px[0], fmaxf(px[1], px[2]));
         const float ymin = fminf(py[0], fminf(py[1], py[2])), ymax = fmaxf(py[0], fmaxf(py[1], py[2]));
         if (!(xmax >= -2.0f && ymax >= -2.0f && xmin <= is + 1.0f && ymin <= is + 1.0f)) mask = 0;  // off-screen / NaN
+        // a vertex projected beyond 1e15 (a camera-space depth within 1e-15 of the image plane), or not finite: the edge
+        // functions of such a face overflow to inf - inf; culled here and in the oracle (oracle/csrc/nmr_raster.c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (!(fabsf(f[3 * k]) <= 1e15f && fabsf(f[3 * k + 1]) <= 1e15f)) mask = 0;
         // sample p (integer pixel coordinate) can be covered only if min <= p <= max; 0.01 px of slack dwarfs the
         // rounding of the edge functions, so the box is conservative yet tight
         x0 = max(0, (int)ceilf(fmaxf(xmin, -2.0f) - 0.01f));
@@ -395,7 +400,10 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     __shared__ unsigned short uq[RASTER_WAVES][128];   // per wave: far-class units that passed the hidden-block test
     __shared__ int wsum[RASTER_WAVES];
     __shared__ int cand_n[2];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, tid = threadIdx.x;
+    // (wave-uniform values the compiler cannot prove uniform - the wave index, the work-order entry - go through
+    //  readfirstlane: everything derived from them (region box, corner coordinates, bin, frame offsets) then lives in scalar
+    //  registers and is computed once per wave by the scalar unit instead of per lane)
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, tid = threadIdx.x;
     const int is = 2 * S, tiles_x = S / HM_TILE, ntiles = tiles_x * tiles_x, regions_x = tiles_x / 2;
     // dispatch order = work_order[block] = (frame << 16 | region): expensive (frame, region) pairs first so that the
     // cheap ones fill the tail of the launch (default: centre of the ROI outwards; calibrated: by candidate count)
@@ -404,8 +412,8 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     // for the NEXT forward of this workspace (hint word 2 then says "use wo_dyn").  What is expensive moves during a fit;
     // an order taken from the poses at its start is stale after a few dozen iterations.
     const bool dyn = wo_dyn && hint[2] != 0u;
-    const int wo = dyn ? wo_dyn[blockIdx.x]
-                       : work_order ? work_order[blockIdx.x] : (int)(((blockIdx.x % B) << 16) | (blockIdx.x / B));
+    const int wo = __builtin_amdgcn_readfirstlane(dyn ? wo_dyn[blockIdx.x]
+                                                     : work_order ? work_order[blockIdx.x] : (int)(((blockIdx.x % B) << 16) | (blockIdx.x / B)));
     if (wo_dyn && !dyn && threadIdx.x == 0) wo_dyn[blockIdx.x] = wo;
     const int region = wo & 0xffff, b = wo >> 16;
     const int rx = region % regions_x, ry = region / regions_x;
@@ -470,7 +478,15 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
             Xs[j] = pow2 ? xn * inv_is : xn / (float)is;
             Ys[j] = pow2 ? yn * inv_is : yn / (float)is;
         }
-        unsigned inside = 0xffffu;
+        // "rv < cv" as the SIGN BIT of rv - cv, shifted into the mask by one v_alignbit: two instructions per (sample, edge)
+        // where the compare needed v_cmp + s_nop + v_cndmask + v_or.  Same decision as the compare for every pair of FINITE
+        // operands once rv cannot be -0 (the one case where the signs lie: (-0) - (+0) = -0, while -0 < +0 is false): rv + 0.0f
+        // turns -0 into +0 and nothing else, four additions per edge.  Distinct floats never difference to zero, equal ones
+        // give +0.  Faces whose products could overflow were culled by the face setup (|NDC| <= 1e15, like the oracle).
+        // The three edges' differences of a sample are OR-ed (the sign bit of the OR is "outside some edge") into sixteen
+        // accumulators, one edge at a time - the empty asm keeps the compiler from holding all 48 differences for one v_or3
+        // per sample, which cost the kernel its register budget (18 spilled values) - then one v_alignbit per sample.
+        unsigned acc[16];
         {
             const float vx[3] = {r0.x, r0.z, r1.x}, vy[3] = {r0.y, r0.w, r1.y};
 #pragma unroll
@@ -479,15 +495,20 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
                 const float ex = vx[e1] - vx[e], ey = vy[e1] - vy[e];
                 float rv[4], cv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { rv[j] = (Ys[j] - vy[e]) * ex; cv[j] = (Xs[j] - vx[e]) * ey; }
-                unsigned m = 0;
+                for (int j = 0; j < 4; ++j) { rv[j] = (Ys[j] - vy[e]) * ex + 0.0f; cv[j] = (Xs[j] - vx[e]) * ey; }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int idx = 0; idx < 16; ++idx) {
+                    const unsigned d = __float_as_uint(rv[idx >> 2] - cv[idx & 3]);
+                    acc[idx] = e ? (acc[idx] | d) : d;
+                }
 #pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) m |= (rv[j] < cv[c4] ? 0u : 1u) << (4 * j + c4);
-                inside &= m;
+                for (int idx = 0; idx < 16; ++idx) asm volatile("" : "+v"(acc[idx]));
             }
         }
+        unsigned outside = 0u;
+#pragma unroll
+        for (int idx = 15; idx >= 0; --idx) outside = __builtin_amdgcn_alignbit(outside, acc[idx], 31);      // sample idx -> bit idx
+        unsigned inside = ~outside & 0xffffu;
         if (inside == 0u) return;
 #if HM_PRUNE
         // samples already owned by something nearer than the nearest point of this face cannot change (the

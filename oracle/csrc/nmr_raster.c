@@ -31,13 +31,23 @@
  *   - z-buffer: strictly smaller z wins; ties keep the LOWEST face index
  *     (the sequential per-pixel loop order of the upstream kernel).
  *   - zero-area faces (barycentric denominator == 0) are skipped
- *     (upstream would propagate inf/nan; documented divergence).
+ *     (upstream would propagate inf/nan; documented divergence); so are faces
+ *     with a vertex projected beyond |1e15| or not finite (same reason).
  *   - edges whose two end points share the sweep coordinate are skipped in the
  *     backward (upstream divides by zero there).
  */
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+
+/* a vertex projected beyond 1e15 (or not finite): the edge functions would overflow to inf - inf; such a face is culled
+ * (the product kernels cull it in their face setup) */
+static inline int orc_insane(const float *f)
+{
+    for (int k = 0; k < 3; ++k)
+        if (!(fabsf(f[3 * k]) <= 1e15f && fabsf(f[3 * k + 1]) <= 1e15f)) return 1;
+    return 0;
+}
 
 static inline int orc_backside(const float *f)
 {
@@ -76,7 +86,7 @@ void orc_nmr_face_index_map(const float *faces, int B, int NF, int is,
         for (long i = 0; i < npix; ++i) { idx[i] = -1; dep[i] = far; }
         for (int fn = 0; fn < NF; ++fn) {
             const float *f = faces + ((long)b * NF + fn) * 9;
-            if (orc_backside(f)) continue;
+            if (orc_backside(f) || orc_insane(f)) continue;
             float p[3][2];
             for (int k = 0; k < 3; ++k)
                 for (int d = 0; d < 2; ++d) p[k][d] = orc_topix(f[3 * k + d], is);
