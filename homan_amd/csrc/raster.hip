@@ -23,6 +23,7 @@
 //             units: summary filter, then owner tests / slices / (item, source) pairs on full waves) -> per-corner NDC
 //             gradients, gathered per vertex by k_bwd_gather or inside hm_rigid_bwd_sil.
 #include "hm_common.h"
+#include <type_traits>
 
 #define HM_TILE 8          // output pixels per tile side
 #define HM_STILE 16        // samples per tile side (2x SSAA)
@@ -1274,6 +1275,20 @@ __device__ __forceinline__ void raster_reorder(int* __restrict__ wo_dyn, int* __
     if (tid == 0) *dyn_flag = 1u;
 }
 
+// Global addresses of the hot loops: with W32 (every array of the workspace below 4 GB, checked by the host) an element address
+// is the array's base - a scalar register pair - plus a 32-bit BYTE offset formed in 32-bit arithmetic, which is the
+// addressing mode of the global loads themselves; with 64-bit element indices a third of stage 1's instructions were the
+// 64-bit multiply-adds, sign extensions and shifts of its three addresses.
+template <bool W32> struct HmOff { typedef long t; };
+template <> struct HmOff<true> { typedef unsigned t; };
+template <bool W32, class T>
+__device__ __forceinline__ T* hm_at(T* __restrict__ base, typename HmOff<W32>::t i)          // (T may be const)
+{
+    typedef typename std::conditional<std::is_const<T>::value, const char, char>::type byte_t;
+    if (W32) return reinterpret_cast<T*>(reinterpret_cast<byte_t*>(base) + (unsigned)(i * (unsigned)sizeof(T)));
+    return base + i;
+}
+
 // 16 lanes per line (one DPP row) and LINES_NL consecutive lines per row, 16 rows per workgroup.  (History: a wave per line spent
 // its life waiting on three dependent memory round trips with 8 of 64 lanes loading; four lines per wave quartered the waves in
 // flight; two lines per ROW halve the workgroups again - 2 300 instead of 4 200 at one clip, about one resident round - and
@@ -1289,6 +1304,7 @@ __device__ __forceinline__ void raster_reorder(int* __restrict__ wo_dyn, int* __
 #else
 #define LINES_BLK(i, n) (i)
 #endif
+template <bool W32>
 __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restrict__ planes,
                                                    const float* __restrict__ gimg, const float* __restrict__ dimg,
                                                    int mode, const float* __restrict__ upstream,
@@ -1326,15 +1342,19 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
         if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
         return;
     }
+    typedef typename HmOff<W32>::t OFF;
     const int l = threadIdx.x & 15, grp = threadIdx.x >> 4;
     // (the 16 rows of a workgroup leave at different times: each folds its exit into the workgroup's own end slot)
     const bool ts_row = l == 0 && hm_ts_enabled(ts_flag);
     const int is = 2 * S, wpl = is / 64, T = is / 16;
-    // first of the row's LINES_NL lines (is is a multiple of 64: a row's lines share plane, orientation and frame)
-    const long L0 = ((long)(LINES_BLK(blk - ncomp - nred, (int)gridDim.x - ncomp - nred)) * 16 + grp) * LINES_NL;
-    const bool valid = L0 < 4L * B * is;
-    // L = ((pl * 2 + axis) * B + b) * is + d0
-    const int d00 = (int)(L0 % is), b = (int)((L0 / is) % B), pa = (int)(L0 / ((long)is * B));
+    // The workgroup's 16 * LINES_NL consecutive lines (is is a multiple of 64 >= 16 * LINES_NL: they share plane, orientation
+    // and frame), decomposed ONCE per workgroup in scalar registers - L = ((pl * 2 + axis) * B + b) * is + d0 - and the row's
+    // first line from there (the 64-bit divisions per lane were a tenth of this kernel's instructions)
+    const unsigned Lw = (unsigned)(LINES_BLK(blk - ncomp - nred, (int)gridDim.x - ncomp - nred)) * (16u * LINES_NL);
+    const bool valid = Lw < 4u * (unsigned)B * (unsigned)is;
+    const unsigned fr = Lw / (unsigned)is;                                  // (plane-orientation, frame) index
+    const int d00 = (int)(Lw - fr * (unsigned)is) + grp * LINES_NL, b = (int)(fr % (unsigned)B), pa = (int)(fr / (unsigned)B);
+    const OFF L0 = (OFF)Lw + (OFF)(grp * LINES_NL);
     const int axis = pa & 1, pl = pa >> 1;
     // 64 samples [64 l, 64 l + 64) of the LINES_NL lines: four tiles' words, and in every tile the lines' words are neighbours
     // (axis 1: sample row t = is - 1 - d0, so line j is word LINES_NL - 1 - j of the aligned group; axis 0: word j) - see
@@ -1346,19 +1366,19 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
         unsigned long long raw[4];
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
-            long at;
+            OFF at;          // hm_plane_at, in the offset type
             if (axis) {
                 const int t = is - 1 - d00 - (LINES_NL - 1);          // lowest sample row of the group
-                at = hm_plane_at(b, t >> 4, 4 * l + jj, pl, T) + (t & 15);
+                at = ((((OFF)b * T + (t >> 4)) * T + (4 * l + jj)) * 4 + pl) * 16 + (t & 15);
             } else {
-                at = hm_plane_at(b, T - 1 - (4 * l + jj), d00 >> 4, 2 + pl, T) + (d00 & 15);
+                at = ((((OFF)b * T + (T - 1 - (4 * l + jj))) * T + (d00 >> 4)) * 4 + (2 + pl)) * 16 + (d00 & 15);
             }
 #if LINES_NL == 4
-            raw[jj] = *reinterpret_cast<const unsigned long long*>(planes + at);
+            raw[jj] = *reinterpret_cast<const unsigned long long*>(hm_at<W32>(planes, at));
 #elif LINES_NL == 2
-            raw[jj] = *reinterpret_cast<const unsigned int*>(planes + at);
+            raw[jj] = *reinterpret_cast<const unsigned int*>(hm_at<W32>(planes, at));
 #else
-            raw[jj] = planes[at];
+            raw[jj] = *hm_at<W32>(planes, at);
 #endif
         }
 #pragma unroll
@@ -1371,7 +1391,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
     bool any = false;
 #pragma unroll
     for (int j = 0; j < LINES_NL; ++j) {
-        const long L = L0 + j;
+        const OFF L = L0 + j;
         const int d0 = d00 + j;
         // exclusive prefix of the word popcounts (wpl <= 16 words: one 16-lane row scan)
         const int c = __popcll(mine[j]);
@@ -1383,7 +1403,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
         const int excl = incl - c;
         // line record: {64 mask bits, number of set bits before them} per word, one 16-byte load for a sweep end point and
         // one cache line per line of up to 512 samples
-        if (valid && l < wpl) lrec[L * wpl + l] = make_uint4((unsigned)mine[j], (unsigned)(mine[j] >> 32), (unsigned)excl, 0u);
+        if (valid && l < wpl) *hm_at<W32>(lrec, L * wpl + l) = make_uint4((unsigned)mine[j], (unsigned)(mine[j] >> 32), (unsigned)excl, 0u);
         // line summary for the sweeps' early-out, 8 bytes per (line, plane) at lsum[(((b*2 + axis)*is + d0)*2 + pl)*4 ..]:
         // {first set position, last set position + 1 (0: empty line), mask of the non-empty 64-sample words}: an item whose
         // sweep range cannot reach a set bit never looks further
@@ -1394,7 +1414,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
         lo = min(lo, __builtin_amdgcn_update_dpp(0xffff, lo, 0x118, 0xf, 0xf, false)); hi = max(hi, __builtin_amdgcn_update_dpp(0, hi, 0x118, 0xf, 0xf, false));
         const unsigned wm = (unsigned)(__ballot(mine[j] != 0ull) >> (16 * (grp & 3))) & 0xffffu;
         if (valid && l == 15)       // row_shr scans: lane 15 of the row holds the row's result
-            *reinterpret_cast<uint2*>(lsum + ((((long)b * 2 + axis) * is + d0) * 2 + pl) * 4) =
+            *reinterpret_cast<uint2*>(hm_at<W32>(lsum, ((((OFF)b * 2 + axis) * is + d0) * 2 + pl) * 4)) =
                 make_uint2((unsigned)lo | ((unsigned)hi << 16), wm);
         any = any || wm != 0u;
         s_w[grp][j][l] = mine[j];
@@ -1415,7 +1435,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
 #pragma unroll 1
     for (int j = 0; j < LINES_NL; ++j) {
         const int d0 = d00 + j;
-        SweepSrc* out = srcs + (L0 + j) * is;
+        const OFF out0 = (L0 + j) * is;          // the line's source array starts at srcs[out0]
         for (int k = 0; k < wpl; ++k) {
             const unsigned long long w = s_w[grp][j][k];
             if (w == 0ull) continue;
@@ -1433,9 +1453,9 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                 const int xi = axis ? d1 : d0, yi = axis ? d0 : d1;
                 if (mode == 5) gl[q] = pl ? 1.0f : -1.0f;         // binary masks: keep (keep alpha - ref) is -1 where an uncovered
                                                                   // sample pulls and +1 where a covered one pushes - no load
-                else if (mode == 3 || mode == 4) gl[q] = gfull[(long)(is - 1 - yi) * is + xi];      // per-sample gradient (no anti-aliasing)
-                else gl[q] = gi[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
-                if (pl) ow[q] = idx[(long)yi * is + xi];
+                else if (mode == 3 || mode == 4) gl[q] = gfull[(is - 1 - yi) * is + xi];      // per-sample gradient (no anti-aliasing); (frame-local: < 2^22)
+                else gl[q] = gi[((is - 1 - yi) >> 1) * S + (xi >> 1)];
+                if (pl) ow[q] = idx[yi * is + xi];
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1451,7 +1471,7 @@ __global__ __launch_bounds__(256) void k_bwd_lines(const unsigned short* __restr
                 }
                 r.g = g;
                 r.owner = ow[q];
-                out[base + __popcll(w & ((1ull << pos) - 1ull))] = r;
+                *hm_at<W32>(srcs, out0 + (OFF)(base + __popcll(w & ((1ull << pos) - 1ull)))) = r;
             }
         }
     }
@@ -1537,19 +1557,6 @@ __device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, b
     q.a_out = geo ? d1_out : 0;
     q.geo = geo;
     return q;
-}
-
-// Global addresses of the hot loops: with W32 (every array of the workspace below 4 GB, checked by the host) an element address
-// is the array's base - a scalar register pair - plus a 32-bit BYTE offset formed in 32-bit arithmetic, which is the
-// addressing mode of the global loads themselves; with 64-bit element indices a third of stage 1's instructions were the
-// 64-bit multiply-adds, sign extensions and shifts of its three addresses.
-template <bool W32> struct HmOff { typedef long t; };
-template <> struct HmOff<true> { typedef unsigned t; };
-template <bool W32, class T>
-__device__ __forceinline__ const T* hm_at(const T* __restrict__ base, typename HmOff<W32>::t i)
-{
-    if (W32) return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (unsigned)(i * (unsigned)sizeof(T)));
-    return base + i;
 }
 
 // A wave takes UNITS of 256 consecutive items.  Per unit and per pass of <= 16 faces:
@@ -2420,7 +2427,8 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
     // whether it is launched alone or in a batch
     const int fpt = (long)clip_len * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks
     const int ncomp = (B / clip_len) * hm_cdiv((long)clip_len * F, 256 * fpt);
-    hipLaunchKernelGGL(k_bwd_lines, dim3(ncomp + nred + hm_cdiv(4L * B * 2 * S, 16 * LINES_NL)), dim3(256), 0, stream, w.planes,
+    const bool w32 = 4.0 * B * (2.0 * S) * (2.0 * S) * sizeof(SweepSrc) < 4.0e9;      // (as in launch_sweep)
+    hipLaunchKernelGGL(w32 ? k_bwd_lines<true> : k_bwd_lines<false>, dim3(ncomp + nred + hm_cdiv(4L * B * 2 * S, 16 * LINES_NL)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
                        w.owned, F, w.parts, w.sweep, clip_len, w.lsum, nred, w.partials, w.frame_rec, loss_out, out_stride,
                        w.counter + 24, w.ts + 2 * ts_raster_units(B, S));
