@@ -47,7 +47,8 @@ def test_reloaded_stepper_equals_fresh_fits(step2, mano_model):
     graphs0 = len(lib._KEPT_GRAPHS)
     results = fitter.fit(clips)
     assert fitter.timing["built"] == 1 and fitter.timing["reused"] == 2
-    assert len(lib._KEPT_GRAPHS) - graphs0 == 1               # one captured graph for the three clips
+    # one resident stepper for the three clips: its one-iteration graph and its K-iterations-per-replay twin, nothing per clip
+    assert len(lib._KEPT_GRAPHS) - graphs0 == 2
     for clip, res in zip(clips, results):
         model, evo = _fresh(mano_model, clip, lw)
         _same(res, model, evo)
