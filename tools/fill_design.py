@@ -1,5 +1,5 @@
 """Fills the measured numbers of tools/DESIGN.tpl (section 5) from the round's bench lines under profiles/ -> DESIGN.md.
-usage: python tools/fill_design.py [r04]"""
+usage: python tools/fill_design.py [r05]"""
 import json
 import os
 import sys
@@ -11,13 +11,18 @@ def load(name):
     p = os.path.join(R, "profiles", name)
     if not os.path.exists(p):
         return None
-    for line in open(p):
+    text = open(p).read()
+    try:                                   # a full record (bench.py's detail file, indented) ...
+        return json.loads(text)
+    except ValueError:
+        pass
+    for line in text.split("\n"):          # ... or a one-line record behind other output
         if line.startswith("{"):
             return json.loads(line)
     return None
 
 
-def main(tag="r04"):
+def main(tag="r05"):
     t = open(os.path.join(R, "tools", "DESIGN.tpl")).read()
     d = load(f"{tag}_bench_cfg2.json")
     drv = load(f"{tag}_bench_cfg2_driver_flags.json")

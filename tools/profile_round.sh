@@ -7,8 +7,8 @@
 #                                 the ones bench.py's roofline object must agree with
 #   rNN_p_cfg4_batch8_*           the same for an 8-clip batch;  rNN_p_poseinit_*  for the pose initialisation's fused loop
 #   rNN_freerun_cfg2_400.json     400 free-running steps, HIP loop vs the oracle's reproducible loop (object parameters bit-equal)
-# usage (GPU box): bash tools/profile_round.sh r04
-R=$(cd "$(dirname "$0")/.." && pwd); N=${1:-r04}; O=$R/gpurun_out; mkdir -p $O
+# usage (GPU box): bash tools/profile_round.sh r05   (~35 min; copy gpurun_out/r05_* into profiles/)
+R=$(cd "$(dirname "$0")/.." && pwd); N=${1:-r05}; O=$R/gpurun_out; mkdir -p $O
 cd $R
 bash tools/pmc_loop.sh > $O/${N}_pmc_loop.json 2>/dev/null
 cp $O/${N}_pmc_loop.json profiles/${N}_pmc_loop.json
@@ -16,20 +16,25 @@ bash tools/pmc_loop.sh --step2 > $O/${N}_pmc_loop_cfg3.json 2>/dev/null
 cp $O/${N}_pmc_loop_cfg3.json profiles/${N}_pmc_loop_cfg3.json
 bash tools/pmc_poseinit.sh > $O/${N}_pmc_poseinit.json 2>/dev/null
 cp $O/${N}_pmc_poseinit.json profiles/${N}_pmc_poseinit.json
-python bench.py > $O/${N}_bench_cfg2.json 2> $O/${N}_bench_cfg2.err
-python bench.py --steps 20 --warmup 5 > $O/${N}_bench_cfg2_driver_flags.json 2>/dev/null      # the flags the driver passed in round 1: iterations 5-25 of a fresh fit
-python bench.py --step2 --parity-seeds 0 --e2e-clips 0 > $O/${N}_bench_cfg3.json 2>/dev/null
-python bench.py --shared-scale --steps 200 > $O/${N}_bench_cfg5_n1.json 2>/dev/null
-python bench.py --depth --parity-seeds 0 --multi-clip 0 --e2e-clips 0 > $O/${N}_bench_cfg2_depth.json 2>/dev/null          # cfg2 as BASELINE.json words it (sil/kp/depth/smooth)
-python bench.py --pose-init 500 > $O/${N}_bench_poseinit.json 2>/dev/null                                     # object-pose initialisation
+# bench lines: the COMPACT line bench.py prints goes to *_line.json, the full record (bench.py's detail file) to *.json
+b() { # name, bench flags...
+  n=$1; shift
+  HOMAN_BENCH_DETAIL=$O/${N}_bench_$n.json python bench.py "$@" > $O/${N}_bench_${n}_line.json 2> $O/${N}_bench_$n.err
+}
+b cfg2_driver_flags --gpus 1 --steps 20 --warmup 5          # the driver's command: iterations 5-25 of a fresh fit
+b cfg2 --parity                                             # the default workload + the opt-in parity / end-to-end legs
+b cfg3 --step2
+b cfg5_n1 --shared-scale --steps 200
+b cfg2_depth --depth --multi-clip 0                         # cfg2 as BASELINE.json words it (sil/kp/depth/smooth)
+b poseinit --pose-init 500                                  # object-pose initialisation
 python tools/chain_parity.py cfg2 400 > $O/${N}_freerun_cfg2_400.json 2>/dev/null
 python tools/bench_clips.py --clips 8 --steps 200 --mixed > $O/${N}_bench_mixed_shard.json 2>/dev/null
 # N > 1 ranks on the one GPU of this box (gloo moves the collectives' 4 bytes through the host): bench.py starts its ranks itself
-HOMAN_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 200 --warmup 20 --multi-clip 2 --steady 0 --e2e-clips 0 > $O/${N}_bench_cfg2_gpus2_gloo.json 2>/dev/null
-HOMAN_BENCH_BACKEND=gloo python bench.py --gpus 2 --shared-scale --multi-clip 4 --steps 100 --warmup 10 > $O/${N}_bench_cfg5_gpus2_gloo.json 2>/dev/null
+HOMAN_BENCH_BACKEND=gloo b cfg2_gpus2_gloo --gpus 2 --steps 200 --warmup 20 --multi-clip 2 --steady 0
+HOMAN_BENCH_BACKEND=gloo b cfg5_gpus2_gloo --gpus 2 --shared-scale --multi-clip 4 --steps 100 --warmup 10
 cd /tmp && export TMPDIR=/tmp
-HEAD="python bench.py --multi-clip 0 --parity-seeds 0 --lockstep 0 --freerun 0 --e2e-clips 0 --no-cpu-baseline"
-rocprofv3 --kernel-trace --stats -d $O/ph -o ph -- python $R/bench.py --multi-clip 0 --parity-seeds 0 --lockstep 0 --freerun 0 --e2e-clips 0 --no-cpu-baseline > $O/${N}_bench_cfg2_profiled.json 2>/dev/null
+HEAD="python bench.py --multi-clip 0 --no-cpu-baseline"
+HOMAN_BENCH_DETAIL=$O/${N}_bench_cfg2_profiled.json rocprofv3 --kernel-trace --stats -d $O/ph -o ph -- python $R/bench.py --multi-clip 0 --no-cpu-baseline > /dev/null 2>&1
 BATCH="python tools/bench_clips.py --clips 8 --steps 100"
 rocprofv3 --kernel-trace --stats -d $O/pb -o pb -- python $R/tools/bench_clips.py --clips 8 --steps 100 > $O/${N}_bench_batch8_profiled.json 2>/dev/null
 POSE="HOMAN_POSEINIT_LOOPS=fused python bench.py --pose-init 500 --no-cpu-baseline"
