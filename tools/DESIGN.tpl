@@ -85,6 +85,21 @@ when the flattened batch is exactly 3 (goldens therefore never use 3 frames).
   two hands step-1 / step-2, a lone left hand, `inter_type="min"`) + the pose-initialisation golden.
   `tests/test_oracle_golden.py` pins `oracle/model.py` + `oracle/jointopt.py` to them (losses 2e-5, gradients 5e-5 of max,
   vertices 3e-7 m, trajectories 5e-4) and re-runs the generator against `/root/reference` to check the committed file.
+  Round 5 added the BASELINE-sized cases: `ref_cfg1_cube_b10_s128` (configs[0], the configuration the reference's CPU path is
+  defined on: forward / backward, the 5-step pin and the reference loop's whole 100-step `loss_evolution`) and
+  `ref_cfg2_bottle_b30_s256` / `ref_cfg3_bottle_b30_s256` (configs[1] / [2]: one forward / backward of the reference's `HOMan`
+  at 30 frames x 256^2).  Oracle (both forms) and HIP model are pinned against them like against the small ones; the fused
+  loop's cfg1 fit follows the reference's `loss_evolution` (`tests/test_model_gpu.py::test_cfg1_full_fit_follows_the_reference_loop`:
+  tight for the 5-6 steps the two runs see the same coverage, then 35 % + 5 % of a term's first value, final total within 10 %;
+  measured: total within 5.6 % at every one of the 100 steps, final 0.00672 vs 0.00656).
+* **What "bit-equal" is measured against.**  Two forms of the oracle exist.  The FAITHFUL form (`oracle.model.REFERENCE_FORM`,
+  autograd + `torch.optim.Adam`: the reference's literal expressions) is what the goldens pin and what the teacher-forced
+  lock-step tests compare with, at tolerances (losses 1e-5, gradients 2e-5 / 5e-4).  The WRITTEN-OUT form (the same
+  mathematics with every reduction and transcendental in one stated order, `oracle/{objchain,handchain,depthchain,posechain}.py`,
+  `oracle/csrc/{objchain,lbs_exact}.c`) was written next to the kernels, and the "bit-equal after every step" statements of
+  this file are HIP against THAT form.  The bridge between the two forms is tolerance-based (`tests/test_objchain.py`: 2e-5 of
+  the largest gradient entry, 2e-6 on Adam; both forms against the goldens).  Independence from the reference therefore rests
+  on the goldens and the faithful-form lock-step legs (50 steps each for cfg2 and cfg3, at full size), not on the bit-equality.
 * **Leaves — PARITY UNPINNED.**  `neural_renderer`, `sdf` (hassony2/multiperson @ HEAD), `mano` (hassony2/MANO @ HEAD),
   `libyana` (@ HEAD) are un-vendored, un-pinned, absent from `/root/reference`, and the reference holds no tests or golden
   vectors for them; `MANO_RIGHT.pkl` is licensed and absent.  `oracle/csrc/nmr_raster.c`, `oracle/csrc/sdf.c`,
@@ -120,7 +135,7 @@ HIP ↔ oracle parity is exact where the domain is discrete and tolerance-bound 
 | pose initialisation vs the oracle with the written-out transform | coverage **bit-exact** (0 flipped samples), mask loss equal, gradients 5e-5 of max (autograd side) | `test_hip_poseinit_coverage_bit_exact_and_gradients_vs_written_out_oracle` |
 | pose initialisation, a WHOLE free-running fit vs the oracle's written-out loop (`oracle/posechain.py`) | every candidate's rotation / translation, the per-candidate losses, the best-ever pose **bit-equal** | `test_fused_poseinit_fit_bit_equal_with_the_written_out_oracle` |
 | every stage of the gradient chains at identical parameters vs the oracle's WRITTEN-OUT chains (unit gradients, interaction records, nearest-vertex picks, contact / collision / depth gradients, model-space gradient) and all parameter gradients | **bit-equal** | `tests/test_handchain_gpu.py` |
-| FREE-running fit, HIP loop vs the oracle's reproducible loop: cfg1; cfg2; cfg2 + depth; cfg3; free / tied object scale; two hands; `optimize_mano=False` | EVERY parameter **bit-equal after every step** (400 steps at full size for cfg2 / cfg2 + depth / cfg3), losses 1e-4 (measured 3.6e-7), final vertices 0.0 mm | `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`, `bench.free_run_parity`, `profiles/r04_freerun_*.json` |
+| FREE-running fit, HIP loop vs the oracle's reproducible loop: cfg1; cfg2; cfg2 + depth; cfg3; free / tied object scale; two hands; `optimize_mano=False` | EVERY parameter **bit-equal after every step** (400 steps at full size for cfg2 / cfg2 + depth / cfg3), losses 1e-4 (measured 3.6e-7), final vertices 0.0 mm | `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`, `bench_parity.free_run_parity`, `profiles/r05_freerun_cfg2_400.json` (this round's kernels), `profiles/r04_freerun_*.json` |
 | a stream of clips through resident steppers vs fresh fits | **bit-exact** (parameters, vertices, loss_evolution) | `tests/test_clip_fitter_gpu.py` |
 
 **Final-loss / final-vertex parity (the second half of BASELINE's metric): met, free-running.**  The hard rasteriser makes the
@@ -173,7 +188,7 @@ object's chain is closed on itself (`homan/homan.py:482-490`: `loss_inter` sees 
   (`oracle.jointopt.reproducible_step_shared_scale`).
 
 Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`,
-`profiles/r04_freerun_*.json`): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
+`profiles/r05_freerun_cfg2_400.json`, `profiles/r04_freerun_*.json`): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
 `translations_hand`, `mano_pca_pose`, `mano_rot`, `mano_betas`, `mano_trans` - is BIT-EQUAL between the two free-running loops
 after every step: cfg1 100 steps x 5 seeds; cfg2, cfg2 + ordinal depth term and cfg3 (step-2: collision + contact) at full size
 over 400 steps (`r04_freerun_cfg2_400.json`, `r04_freerun_cfg2_depth_400.json`, `r04_freerun_cfg3_400.json`:
@@ -243,11 +258,11 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | Kernel | Work decomposition | Bound | Alg. bytes / launch |
 |---|---|---|---|
 | `k_setup_faces` | thread / face: optional rigid transform of the mesh-space vertex (the silhouette chain does not wait for `hm_rigid_fwd`), projects its 3 vertices (no separate projection launch), windings, tight sample box; bins the face into 64² super-regions (128² above 512² samples; LDS-aggregated counts, one global atomic per (workgroup, bin)); extra workgroups write the camera-space vertices for the other losses (same arithmetic as `k_rigid_fwd`: the hand-side stream no longer opens with a transform launch) | HBM | B·(V·24 + F·(12+36+8+2+5)) = 6.7 MB |
-| **`k_raster_fwd`** | workgroup = one 32×32-sample region: scans the faces of its super-region; candidates are split by WINDING CLASS - the class that holds the camera-facing surface of the mesh (a scheduling hint set by `calibrate()` from the index map; any value is correct) fills the candidate array from the front, the other from the back; one thread per candidate builds the face record in LDS (+ the nearest depth the face can produce) - BOTH classes in one pass, wave 0 up to 64 near-class records while wave 1 builds up to 64 far-class records (one round trip to the packed faces and one stretch of record arithmetic per round instead of one per class: the far class's pass had been a quarter of an active workgroup's time with three waves at its barrier; per-class prefix sums are per-wave scans); the (candidate, 4×4-sample block) units are **flattened** over the 256 threads (binary search of the exclusive unit counts); visibility = `ds_min_u64` on an LDS z-buffer keyed (depth bits ≪ 32 \| face) = strict z test in ascending face order, bit-exact.  The near class runs first; then per 4×4 block the largest owner depth is taken (`hz`), and the units of the far class are first tested against it, 64 per wave trip, the survivors queued per wave and the unit body run on FULL waves of survivors (a divergent early-out would leave the wave paying for its one visible unit: on a closed mesh ~85 % of the far units are hidden).  Sample positions of power-of-two grids by one multiplication (eight IEEE divisions per unit before).  Epilogue per 8×8 output tile: index map, pooled silhouette, fused masked-MSE terms, alpha plane and the four sweep bit planes of the backward (one full cache line per tile, ballots picked with selects: no scratch); in a fixed loop (`persistent_outputs`) an empty bin in front of outputs that already hold the empty pattern leaves before touching LDS (60 % of the workgroups).  25 KB of LDS and 80 VGPRs: 6 workgroups per CU (4 before: +20 %) | latency × residency, then VALU (`valu_frac` 0.54) | B·(F·49 + 512²·4 + 4·S²·4 + 5·512²/8) = **72.2 MB** |
+| **`k_raster_fwd`** | workgroup = one 32×32-sample region: scans the faces of its super-region; candidates are split by WINDING CLASS - the class that holds the camera-facing surface of the mesh (a scheduling hint set by `calibrate()` from the index map; any value is correct) fills the candidate array from the front, the other from the back; one thread per candidate builds the face record in LDS (+ the nearest depth the face can produce) - BOTH classes in one pass, wave 0 up to 64 near-class records while wave 1 builds up to 64 far-class records (one round trip to the packed faces and one stretch of record arithmetic per round instead of one per class: the far class's pass had been a quarter of an active workgroup's time with three waves at its barrier; per-class prefix sums are per-wave scans); the (candidate, 4×4-sample block) units are **flattened** over the 256 threads (binary search of the exclusive unit counts); visibility = `ds_min_u64` on an LDS z-buffer keyed (depth bits ≪ 32 \| face) = strict z test in ascending face order, bit-exact.  The near class runs first; then per 4×4 block the largest owner depth is taken (`hz`), and the units of the far class are first tested against it, 64 per wave trip, the survivors queued per wave and the unit body run on FULL waves of survivors (a divergent early-out would leave the wave paying for its one visible unit: on a closed mesh ~85 % of the far units are hidden).  Sample positions of power-of-two grids by one multiplication (eight IEEE divisions per unit before).  Epilogue per 8×8 output tile: index map, pooled silhouette, fused masked-MSE terms, alpha plane and the four sweep bit planes of the backward (one full cache line per tile, ballots picked with selects: no scratch); in a fixed loop (`persistent_outputs`) an empty bin in front of outputs that already hold the empty pattern leaves before touching LDS (60 % of the workgroups).  The inside test of a unit is arithmetic, not compares: `rv < cv` is the SIGN BIT of `rv - cv` (after `rv + 0.0f`, which turns the one case where the sign lies, -0, into +0), the three edges' differences OR-ed into sixteen accumulators and shifted into the mask by one `v_alignbit` per sample - 156 instead of 221 instructions per unit (round 5); faces with a vertex projected beyond 1e15 are culled by the face setup and by the oracle (their edge functions overflow to inf - inf).  Wave-uniform values (work-order entry, wave index and everything derived) go through `readfirstlane` into scalar registers.  25 KB of LDS and 80 VGPRs (no spills): 6 workgroups per CU (7 per CU at 72 registers: measured slower, EXPERIMENTS r5) | latency × residency (5-6 dependent round trips per active workgroup), VALU-bound only when the GPU is full (clip batch, pose initialisation) | B·(F·49 + 512²·4 + 4·S²·4 + 5·512²/8) = **72.2 MB** |
 | `k_sil_reduce` | block / frame + last-block finish.  One clip: the same body rides as B extra workgroups at the front of the `k_bwd_lines` launch (`hm_sil_bwd_clips(..., loss_out)`): the value is only logged, so it costs no launch; a clip batch keeps it on the third stream | latency | 0.5 MB |
 | `k_bwd_masks` | generic backward only (arbitrary `dL/dsilhouette`, or a negative loss weight): wave / tile, sweep planes via ballots | HBM | ≈ 21 MB |
-| `k_bwd_lines` | one DPP row (16 lanes) per TWO consecutive lines of a (plane, orientation, frame), 32 lines / workgroup (their mask words arrive in the same 4-byte loads; the launch is about one resident round of workgroups): expands a bit line into a position-sorted array of sources {d1, g, owner} + a 16-byte record per 64-bit word {mask, sources before it} (row scan).  Its first ⌈B·F/256⌉ workgroups build the **work list** of the sweeps instead: faces that own a sample → 64-byte records laid end to end in one global item space (block scan, one 64-bit atomic per block; a block's items start on a 64-item boundary so that the composition of every unit — and with it every summation order — is independent of the order in which blocks draw their bases) | latency | B·(4·512²/8 + S²·4 + 512² + F·46) = 23.8 MB |
-| **`k_bwd_sweep`** | persistent waves; a **unit** = 256 consecutive (face, winding, edge, axis, d0) items of the global list, whichever faces they belong to (a big face spreads over several waves, small faces share one), handled per pass of ≤ 16 faces staged in LDS together with their per-(face, family) constants - edge slope, first line, end-point order: one IEEE division per family instead of one per item, built by the wave right after the staging - and per-(face, axis) inward ranges.  **Stage 1** (every item, 64 per trip, four trips whose loads are all in flight before the first is tested): family by a 4-step search of the cumulative counts, line geometry from the family constants, then three loads requested together: the line's 16-byte summary, the owner of the sample just inside the edge and the alpha word of the sample just outside - the outward sweep needs a sample this winding owns AND a plane-0 source beyond the edge (exact from first / last position), the inward sweep an empty sample outside AND a plane-1 source inside the triangle's extent (positions + word mask); in the steady state of a fit 71 % of the items stop here (1.95 M items → 557 k, of which 555 k do have pairs) and the rest are queued with the two decisions.  **Stage 2** (queued items on full waves): two 16-byte record loads + popcounts give the slices `[lo, lo+nb)` of the line's source array; the (item, source) pairs are **flattened** over the wave, four consecutive pairs per lane, item of a pair by scatter + max-scan; every term is `diff / dist` with IEEE divisions and is rounded to the 2^-44 grid; per-lane running sums in DOUBLE, flushed into the face's six double LDS accumulators (`ds_add_f64`) when the (face, corner) target changes; a face inside one unit is stored, a face cut by unit boundaries is added by its units with hardware double atomics onto a zeroed target - the sums are exact, so any order gives the same value, nobody waits, and the per-unit partials + tickets of rounds 2-3 are gone; **XCD-aware**: each XCD (workgroup id mod 8) takes one contiguous eighth of the units, so a frame's index-map lines, line records and source slices are fetched into one L2 instead of eight | LDS + dependent-load latency (the IEEE divisions and the double accumulation cost nothing measurable: 46.1 → 46.0 µs) | B·(F·(68+48) + 512²·4 + 512²) = **49.8 MB** |
+| `k_bwd_lines` | one DPP row (16 lanes) per TWO consecutive lines of a (plane, orientation, frame), 32 lines / workgroup (their mask words arrive in the same 4-byte loads; the launch is about one resident round of workgroups): expands a bit line into a position-sorted array of sources {d1, g, owner} + a 16-byte record per 64-bit word {mask, sources before it} (row scan).  Its first ⌈B·F/256⌉ workgroups build the **work list** of the sweeps instead: faces that own a sample → 64-byte records laid end to end in one global item space (block scan, one 64-bit atomic per block; a block's items start on a 64-item boundary so that the composition of every unit — and with it every summation order — is independent of the order in which blocks draw their bases).  Round 5: the 32 lines of a workgroup share plane, orientation and frame - decomposed once per workgroup in scalar registers (two 64-bit divisions per lane before) - and every address is a scalar base + 32-bit byte offset (`hm_at<W32>`) | latency | B·(4·512²/8 + S²·4 + 512² + F·46 [reads] + 4·512·8·16 + 2·512·16 + F·56 [line records, summaries, work list]) = 37.2 MB (+ 12 B per source and orientation, data dependent) |
+| **`k_bwd_sweep`** | persistent waves; a **unit** = 256 consecutive (face, winding, edge, axis, d0) items of the global list, whichever faces they belong to (a big face spreads over several waves, small faces share one), handled per pass of ≤ 16 faces staged in LDS together with their per-(face, family) constants - edge slope, first line, end-point order: one IEEE division per family instead of one per item, built by the wave right after the staging - and per-(face, axis) inward ranges.  **Stage 1** (every item, 64 per trip, four trips whose loads are all in flight before the first is tested): family by a 4-step search of the cumulative counts, line geometry from the family constants, then three loads requested together: the line's 16-byte summary, the owner of the sample just inside the edge and the alpha word of the sample just outside - the outward sweep needs a sample this winding owns AND a plane-0 source beyond the edge (exact from first / last position), the inward sweep an empty sample outside AND a plane-1 source inside the triangle's extent (positions + word mask); in the steady state of a fit 71 % of the items stop here (1.95 M items → 557 k, of which 555 k do have pairs) and the rest are queued with the two decisions.  **Stage 2** (queued items on full waves): two 16-byte record loads + popcounts give the slices `[lo, lo+nb)` of the line's source array; the (item, source) pairs are **flattened** over the wave, four consecutive pairs per lane, item of a pair by scatter + max-scan; every term is `diff / dist` with IEEE divisions and is rounded to the 2^-44 grid; per-lane running sums in DOUBLE, flushed into the face's six double LDS accumulators (`ds_add_f64`) when the (face, corner) target changes; a face inside one unit is stored, a face cut by unit boundaries is added by its units with hardware double atomics onto a zeroed target - the sums are exact, so any order gives the same value, nobody waits, and the per-unit partials + tickets of rounds 2-3 are gone; **XCD-aware**: each XCD (workgroup id mod 8) takes one contiguous eighth of the units, so a frame's index-map lines, line records and source slices are fetched into one L2 instead of eight Addresses (round 5): scalar base + 32-bit byte offset formed in 32-bit arithmetic (`k_bwd_sweep<W32>`, instantiated while the source arrays stay below 4 GB; stage 1 spent 30 of 66 instructions per trip on 64-bit address arithmetic, now 12) | VALU issue while every wave is busy (`valu_frac` 0.68; in the 8-clip batch 0.78), then the dependent-load latency of the units with many pair rounds; WORK-bound, not balance-bound: dealing units out dynamically, cost-sorted orders and a chunk list that spreads long sweeps over all waves were each built, bit-identical, and lost (EXPERIMENTS r4 / r5) | B·(F·(68+48) + 512²·4 + 512²) = **49.8 MB** |
 | `k_bwd_gather` | thread / vertex over CSR adjacency: one `double2` per (face, corner), summed exactly, rounded once + projection backward.  Autograd path only: the fused loop gathers inside `k_rigid_bwd` (`hm_rigid_bwd_sil`) | HBM | B·(F·24·2 + V·24) = 5.4 MB |
 | `k_rigid_fwd/bwd`, `k_rigid_bwd_x` | forward: thread / vertex; backward: grid (frame, 256-vertex chunk), sums up to four weighted per-vertex gradient terms + a per-frame vector + optionally the silhouette gradient gathered from the sweeps' per-corner output (no gather / linear-combination launches), 13 block sums behind two barriers, per-frame ticket, rot6d backward by the finishing workgroup.  The OBJECT's backward of the fused loops is `k_rigid_bwd_x`: the same work with every dependent load stage (CSR offsets → corner items → per-corner doubles) issued for all of a thread's vertices at once, the 13 sums EXACT (addends on the 2^-44 grid, DPP reductions on doubles, chunk records of doubles: any split of the vertices gives the same floats), and the object's temporal-smoothness gradient formed in the kernel from the camera-space vertices of the neighbouring frames - on the step-1 sets the object's chain waits for nothing the hand-side stream produces | latency (a chain of ~6 round trips: 15 µs for 180 workgroups) | ≤ 4·B·V·12 |
 | `k_mano_fwd`, `k_mano_bwd` | forward: (13 vertex chunks × ⌈B/4⌉) blocks, a workgroup = one chunk of 64 vertices for FOUR consecutive frames, wave f owning frame f: four chains prepared side by side, then every wave streams its 37 rows of the blend matrix `M` ONCE and accumulates them for all four frames (the 1.35 MB matrix crosses L2 once per four frames: a 240-frame batch used to pull 324 MB through L2 per launch), wave f finishes frame f (partials, skinning, rigid transform, state); per frame the arithmetic and its order are unchanged, so frame grouping is invisible in the results.  Backward: (13 × B) blocks; kinematic tree staged in LDS, chain level-parallel; `M` rows streamed coalesced with all of a wave's rows requested before the first is reduced; rigid hand transform fused into the forward epilogue; the forward keeps the chain state + posed vertices for the backward; backward = ONE launch: chunk partials, then the frame's last workgroup (per-frame ticket) runs the chain / Rodrigues / PCA backward with the prior folded in; `k_mano_bwd<true>` (`hm_mano_bwd_rigid_clips`, one clip) also does the hand's rigid backward - no mesh-gradient buffer, no `k_rigid_bwd` launch for the hand | L2 / latency | 2·C_mano + 2·B·778·12 |
@@ -298,11 +313,15 @@ next to them.  HIP-runtime and hardware facts that shaped it (all measured, EXPE
   per SIMD leave 32 registers - whether a hand-side kernel runs under a heavy kernel or after it is a matter of residency,
   which the LDS ballast knobs (`hm_tune_*`) and the sweep's workgroup count steer per loss set.
 
-## 5. Measured (MI355X, round 4; evidence under `profiles/r04_*`, regenerated by `tools/profile_round.sh r04`)
+## 5. Measured (MI355X, round 5; evidence under `profiles/r05_*`, regenerated by `tools/profile_round.sh r05`)
 
-`python bench.py` = the driver's command: cfg2, 400 steps after 20 warm-up, then - same process, same fit, same hipGraph -
-a `steady_state` leg (iteration ≥ 400, 2000 timed iterations, 0.33 s) so that ONE line carries both regimes whatever
-`--steps / --warmup` the driver passes.
+`python bench.py` prints ONE compact JSON line (<= 2 KB: the contract's keys, `roofline`, `cpu_baseline`, one number each for
+the `steady_state` and `multi_clip` legs) and writes the full record - per-kernel tables, notes, with `--parity` the HIP-vs-oracle
+legs of `bench_parity.py` - to `gpurun_out/bench_detail.json` and stderr; the default run takes 16 s on the GPU box.  (Round 4's
+line was 23 KB, parity traces included, and came back from the driver as `parsed: null`.)  Default workload: cfg2, 400 steps
+after 20 warm-up, then - same process, same fit, same hipGraph - a `steady_state` leg (iteration >= 400, 1000 timed iterations)
+so that ONE line carries both regimes whatever `--steps / --warmup` the driver passes (it passes `--steps 20 --warmup 5`:
+iterations 5-25 of a fresh fit).  `profiles/r05_bench_*.json` are the full records, `*_line.json` the printed lines.
 
 | Quantity | Value |
 |---|---|
@@ -316,20 +335,20 @@ a `steady_state` leg (iteration ≥ 400, 2000 timed iterations, 0.33 s) so that 
 | cfg5 on one rank (8 clips, step-2, one tied scale, RCCL call issued) | @CFG5@ it/s |
 | 2 ranks on ONE GPU through gloo (the driver's `torch.distributed.run` line; weak scaling has nothing to scale on one GPU - this is the N > 1 code path, not a speed-up) | cfg2: @G2@ it/s summed; cfg5 (2 x 4 clips, tied scale): @G5@ it/s, replicas identical |
 | object-pose initialisation (SURVEY §8f rank 1): 500 candidate poses of the bottle against one 256² mask, `python bench.py --pose-init 500` | **@POSE@ pose-steps/s** (@POSEMS@ ms per step of 500 poses; a 50-step fit in @POSEFIT@ s); by loop: @POSELOOPS@; CPU oracle @POSECPU@ pose-steps/s |
-| free-running parity, cfg2 at full size, 400 steps, HIP loop vs the oracle's reproducible loop (`profiles/r04_freerun_cfg2_400.json`) | every parameter (object pose, hand pose, MANO) bit-equal after every step: @FREEALL@ (object alone: @FREEEQ@), final vertices object @FREEVO@ mm / hand @FREEVH@ mm, largest relative loss difference at any step @FREELOSS@ (section 2; the control `r04_control_cfg2_400.json`: the CPU loop against itself from inputs 1e-7 m apart ends 0.85 mm apart) |
+| free-running parity, cfg2 at full size, 400 steps, HIP loop vs the oracle's reproducible loop (`profiles/r05_freerun_cfg2_400.json`) | every parameter (object pose, hand pose, MANO) bit-equal after every step: @FREEALL@ (object alone: @FREEEQ@), final vertices object @FREEVO@ mm / hand @FREEVH@ mm, largest relative loss difference at any step @FREELOSS@ (section 2; the control `r04_control_cfg2_400.json`: the CPU loop against itself from inputs 1e-7 m apart ends 0.85 mm apart) |
 | CPU baseline (oracle loop, 64 host threads) | @CPU@ it/s with the reference's per-step `.item()` logging, @CPUOFF@ it/s without → GPU / CPU ≈ @RATIO@ × (target ≥ 50 ×) |
 | whole iteration vs the SURVEY §8d byte model (144.1 MB) | @WHOLE@ of 8 TB/s at one clip |
 
 **Roofline of the heavy kernels, inside the replayed graph** (ROCm allows no timing events inside graphs, so every
 workgroup of the three kernels stores `s_memrealtime` at entry and exit, `hm_sil_timestamps`; `bench.py` replays THE SAME
-graph 50 more times and averages; `rocprofv3 --kernel-trace --stats` of the same command, `profiles/r04_p_cfg2_headline_kernel_stats.txt`,
+graph 50 more times and averages; `rocprofv3 --kernel-trace --stats` of the same command, `profiles/r05_p_cfg2_headline_kernel_stats.txt`,
 agrees to a few per cent, see the note in EXPERIMENTS.md on what the profiler itself moves):
 
 | kernel (cfg2, steady state) | µs / launch | algorithmic MB | GB/s | frac of 8 TB/s | PMC traffic MB | VALU wave-instr | valu_frac (4-cycle / 2-cycle) |
 |---|---|---|---|---|---|---|---|
 | `k_raster_fwd` | @RAS@ | 72.2 | @RASG@ | @RASF@ | @RAST@ | @RASV@ | @RASVF@ |
 | `k_bwd_sweep` (`roofline.kernel`: the longest launch) | @SWP@ | 49.8 | @SWPG@ | @SWPF@ | @SWPT@ | @SWPV@ | @SWPVF@ |
-| `k_bwd_lines` | @LIN@ | 23.8 | @LING@ | @LINF@ | @LINT@ | @LINV@ | @LINVF@ |
+| `k_bwd_lines` | @LIN@ | 37.2 | @LING@ | @LINF@ | @LINT@ | @LINV@ | @LINVF@ |
 
 `valu_frac` = `SQ_INSTS_VALU` ÷ (launch time × 1024 SIMDs × 2.4 GHz ÷ 4).  The 4: a wave64 VALU instruction runs on a
 SIMD16 as four passes of 16 lanes, and the counters say so - `SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU` = 1.02 quad-cycles
@@ -340,25 +359,39 @@ against that peak as `valu_frac_2cyc` (half the value).  Either way the reading 
 (the kernels are not HBM-bound), and they issue VALU on one third to two thirds of all SIMD cycles; the rest is dependent
 loads (7-8 global round trips per raster workgroup) and LDS.
 
-Pose initialisation (`bench.py --pose-init 500`, its own line with `roofline`; `profiles/r04_p_poseinit_kernel_stats.txt`,
-`r04_pmc_poseinit.json`): per step of 500 candidate poses `k_bwd_sweep` @PISWP@ µs (algorithmic 315 MB → @PISWPG@ GB/s =
+Pose initialisation (`bench.py --pose-init 500`, its own line with `roofline`; `profiles/r05_p_poseinit_kernel_stats.txt`,
+`r05_pmc_poseinit.json`): per step of 500 candidate poses `k_bwd_sweep` @PISWP@ µs (algorithmic 315 MB → @PISWPG@ GB/s =
 **@PISWPF@** of HBM peak, the dominant kernel), `k_raster_fwd` @PIRAS@ µs (@PIRASF@), `k_bwd_lines` @PILIN@ µs (@PILINF@); all
 throughput-bound at 500 frames per launch.
 
-**What bounds the iteration** (EXPERIMENTS.md, round 4).  The silhouette chain is serial and it IS the iteration: setup 8 +
-raster 43 + lines 23-25 + sweeps 46 + object gradients 15 + Adam 4 µs + ≈20 µs of launch gaps and graph edges ≈ 160 µs; the
-hand side (MANO, pair terms, hand gradients) runs under it.  Two facts of this round say where the rest is.  (1) The floor:
-BASELINE cfg1 (10 frames 128², a 500-face cube) runs 11 400 it/s = 88 µs per iteration with nearly empty kernels - six serial
-launches and two cross-queue edges cost that much; cfg2 is that floor plus ~70 µs.  (2) The heavy kernels are NOT issue-bound
-in the sense that instructions cost time one for one: the sweeps' pair loop went from `v_rcp_f32` + multiply to two
-11-instruction IEEE divisions and double-precision accumulation, and the kernel's time did not move (46.1 → 46.0 µs) - LDS
-(`SQ_WAIT_INST_LDS`) and dependent loads bound it.  In aggregate the GPU is work-bound (two 4-clip batches side by side: +2 %
-over one 8-clip batch, four 2-clip batches: −16 %), at one clip it is launch-latency-bound.  Measured and reverted this round
-(EXPERIMENTS.md): a per-(face, family) reject ahead of the sweep's item enumeration from coarse source summaries (−17 % items
-instead of the hoped −60 %: sources are sparse per LINE), Adam folded into the two chains' last launches (−7 %), one large
-workgroup per frame in the rigid backward (−3 %), bin entries carrying the face boxes (±0).  Kept: both winding classes'
-records in one raster pass (raster 46.5 → 43.2 µs, batch +2.5 %), the smoothness gradient inside the rigid backward (+1.5 %).
-The verdict's kernel targets (raster ≤ 38, sweep ≤ 34, rigid backward ≤ 8 µs; steady ≥ 7 000, batch ≥ 10 500 it/s) are NOT met.
+**What bounds the iteration** (EXPERIMENTS.md, rounds 4-5).  The silhouette chain is serial and it IS the iteration: setup 8.5 +
+raster 40 + lines 25 + sweeps 45 + object gradients 17 + Adam 4 µs = 140 µs of kernels + ~13 µs between them = 153 µs; the hand
+side (MANO 16, pair terms 30, hand gradients 42 µs) runs under it.  What round 5 measured about the rest (same-box A/B each):
+* **The launch floor is not launch latency.**  VERDICT r4 asked for the chain as ONE persistent launch with device-side barriers
+  (cfg1 runs 88 µs per iteration "with nearly empty kernels").  Measured instead: a dependent kernel boundary inside a stream costs
+  ~1.5 µs (guide: `boundary` row; the timeline's back-to-back launches agree), removing the cross-stream waits altogether gains
+  0.1-1.5 % (round 4), dropping the Adam launch AND its join altogether (timing experiment, lr = 0 on both sides) gains 1.5 %
+  (3 µs), and the turnaround between two graph replays was 5 µs - taken out by replaying FOUR iterations per graph (kept: +2-3 %).
+  The floor of cfg1 is the sum of six kernels' own latency chains (each 3-6 dependent HBM round trips at 1-2 µs), which a
+  megakernel keeps; what it would add on this GPU is the hand-off: the XCDs' L2s are not coherent with each other, so bulk data
+  passed between phases INSIDE a launch (index map, line records, source arrays: 30-70 MB) must be written through or fenced per
+  producer (guide: 1.7-6.5 µs per release with freshly dirtied lines, `sc1` stores 6-12 x the time per byte for narrow stores) -
+  exactly what a kernel boundary does once, wholesale, in 2-4 µs.  Grid barriers on 1280 workgroups cost 10-14 µs each
+  (`barrier-xcd` row at 4 workgroups per CU).  Not built; the boundary is the cheaper hand-off.
+* **One clip is a zero-sum game between the two streams' kernels.**  Raster at 7 instead of 6 workgroups per CU: raster 40 -> 43.6,
+  lines 25 -> 19.6, sweeps 45.5 -> 48 µs, iteration -1.2 %.  Shortening one kernel moves the others under it.
+* **The sweep is work-bound, not balance-bound.**  Dynamic unit hand-out with one queue head per XCD on its own cache line: 51 -> 60
+  µs.  Long sweeps (>= 64 sources) through a chunk list and a second launch that spreads them over 4096 waves: bit-identical, ±0 in
+  the steady state and over iterations 5-25 - while the ceiling builds that DROP pair rounds gain 15-21 % there: early in a fit
+  the 5-10 M pairs of a launch are 10-19 M wave-instructions wherever they run (two IEEE divisions + two quantised double
+  additions per pair by contract).  Long sweeps walked by their whole wave: -2 % (two loads per lane in flight instead of four).
+* **Instructions pay where the GPU is full**: 32-bit byte offsets off scalar bases in the sweep and the line expansion, the
+  scalar line decomposition, the sign-bit inside test: cfg2 steady +2.0 %, 8-clip batch +2.5 %, iterations 5-25 +2.9 %, pose
+  initialisation +3.1 % (all same box, against K = 4 graphs alone).
+Cumulative against round 4 (its numbers in brackets): steady @STEADY@ (6 257), 8-clip batch @MULTI@ (9 165), the driver's flags
+@DRV@ (5 012), cfg3 @CFG3@ (5 257), pose initialisation @POSE@ (457 795).  The verdict's targets (cfg1 floor <= 50 µs, steady >=
+7 500, sweep <= 38 µs, raster <= 36 µs, batch >= 10 000) are NOT met; the measurements above say why the proposed routes do not
+lead there.
 
 ## 6. Multi-GPU
 
@@ -434,27 +467,26 @@ file the reference never reaches.  More than two hands: the reference's own coll
 
 ## 8. Known gaps / next (ranked)
 
-1. Throughput targets of the last verdict are not met (section 5): steady 6 300 (target 7 000), 8-clip batch 9 200 (10 500),
-   driver-flag headline 4 950-5 050 (5 400); `k_bwd_sweep` is still the longest launch at 0.13-0.14 of HBM peak.  What this
-   round's measurements say would move them: at one clip, fewer NODES per iteration - the hand side's kernels (MANO forward,
-   pair terms, MANO backward) as block ranges of the silhouette chain's launches, which removes the side stream and its fork /
-   join (each cross-queue edge and launch gap is 5-10 µs of an iteration whose floor is 88 µs); in aggregate, less LDS traffic
-   per sweep item and pair (`SQ_WAIT_INST_LDS` is half of `SQ_ACTIVE_INST_VALU`), not fewer VALU instructions.
-2. One launch per kernel over clips of DIFFERENT shapes (today: concurrent shape groups, 88 % of a same-shape batch).
-3. The pose initialisation at @POSE@ pose-steps/s with its resident fitter (target 600 k; it is the pipeline's larger GPU load:
-   one fit per frame of a clip against ONE joint fit per clip): its sweep (0.10 of HBM peak) and raster are throughput-bound
-   at 500 frames per launch, and a fit's first steps are its heaviest (candidates far from the mask); the line expansion no longer gathers a gradient (mode 5: -1 / +1 by plane) but still moves 4.6x its byte model
-   (`r04_pmc_poseinit.json`: 538 MB against 118 MB) - neither the owner gathers nor the size of the source records (both
-   measured, EXPERIMENTS.md): its scattered small record stores per line and plane.
-4. The ordinal depth term: 140 µs on a 160 µs iteration (two more renders at the full-image camera - another camera than the
-   silhouette's ROI, so the index map cannot be reused -, their backward passes, the pair-wise term); in a clip batch it runs
-   one clip per stepper (`ShardStepper`); with two hands (three layers, pair-wise through the two-layer kernels:
-   `ops.ordinal_depth_loss_layers`) it runs in the eager / graph loops, not in the fused one.
-5. The written-out chains cover one hand with `optimize_mano`, the centroid interaction term, every loss set of BASELINE's
-   configurations (step 1, step 1 + depth, step 2), a fixed or free object scale, and the scale tied across the clips of one
-   rank (cfg5: the clips' gradients through one block sum, `reproducible_step_shared_scale`; three clips bit-equal over 10
-   steps), and two hands per frame (each hand's rows through its side's model, per-hand pair terms, three SDF scenes, the hands'
-   rigid backward as the launch of its own the two-hand loop uses).  `optimize_mano=False` and `inter_type="min"` are covered too; the depth term
-   with two hands is compared with the faithful oracle only (value, gradients); across RANKS the tied gradient is one fp32 all-reduce, whose order for
-   more than two ranks is RCCL's.
-6. N > 1 on real multi-GPU hardware (RCCL over xGMI) has only ever run with one rank per process group here.
+1. Throughput: steady @STEADY@ it/s (verdict target 7 500), 8-clip batch @MULTI@ (10 000), `k_bwd_sweep` still the longest launch
+   at 0.14 of HBM peak - a yardstick it will never approach: the sweep and the raster are VALU-issue-bound whenever the GPU is
+   full and latency-chain-bound at one clip (section 5).  What is left on the table, each worth 1-3 %: the family search of the
+   sweep's stage 1 as one ballot per trip instead of four dependent LDS reads per item; a 16-bit index map (the raster's
+   write-back hole, 4 µs, is 60 % index map); the rigid backward's adjacency as a padded per-vertex table (one round trip less).
+2. One launch per kernel over clips of DIFFERENT shapes (per-clip vertex / face offsets in every `hm_*_clips` kernel) is not
+   built.  What stands in for it: `ShardStepper` replays the shape groups' hipGraphs concurrently - 8 clips of 4 shapes @MIXED@
+   it/s against @MULTI@ for 8 clips of one shape as a batch (`profiles/r05_bench_mixed_shard.json`), bit-identical to solo fits.
+   Padding clips to a common shape is not an option: padded vertices change the smoothness / interaction normalisers and can
+   win the nearest-vertex search.
+3. The pose initialisation at @POSE@ pose-steps/s (target 600 k): sweep and raster VALU-bound at 500 frames per launch.  Its line
+   expansion moves 532 MB per launch (PMC, `r05_pmc_poseinit.json`: 2 x FETCH 144 MB + WRITE 244 MB) against a byte model that
+   round 4 had at 118 MB: the model had left out the kernel's own outputs - line records 33 MB, summaries 4 MB, the work list's
+   records / zeroed gradients 84 MB - and the source arrays (12 B per source and orientation: ~100 MB with 500 candidates far
+   from their mask).  With them the model is 239 MB + sources; the remaining factor (~1.5 x) is the guide's x 2 correction on
+   FETCH_SIZE applied to narrow scattered reads (owner gathers), for which it is not calibrated.
+4. The ordinal depth term: 140 µs on a 153 µs iteration; in a clip batch one clip per stepper; with two hands per frame in the
+   eager / graph loops only (three layers pair-wise through the two-layer kernels), compared with the faithful oracle (value,
+   gradients), not written out.  The reference's own call site raises (`homan.py:506-507`): oracle-pinned only.
+5. `hand_proj_mode="ortho"` raises (section 7: its camera conversion is a third-party function absent from `/root/reference`).
+6. N > 1 on real multi-GPU hardware: RCCL has carried one-rank groups and (gloo) 2-3 ranks on one GPU here;
+   `tests/test_dist_gpu.py::test_two_ranks_on_two_gpus_over_rccl` runs the two-GPU case wherever two GPUs are visible and
+   `bench.py --gpus N` reports the process group's rank count, its backend and every rank's own rate.
