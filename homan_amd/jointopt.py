@@ -288,8 +288,6 @@ class FusedStepper:
             raise NotImplementedError("two hands per frame: the fused loop takes one clip at a time (a batch of two-hand "
                                       "clips: one stepper per clip, or mode='graph')")
         lw = self.lw = {k: float(v) for k, v in loss_weights.items()}
-        if lw.get("lw_depth", 0) > 0 and h > 1:
-            raise NotImplementedError("ordinal depth term in the fused loop: one hand per frame (two hands: mode='graph' / 'eager')")
         if lw.get("lw_depth", 0) > 0:
             if not getattr(m, "ordinal_depth", False):
                 # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() without its arguments
@@ -393,7 +391,25 @@ class FusedStepper:
         self.sil_keep, self.sil_ref = sx.pad(m.keep_mask_object), sx.pad(m.ref_mask_object)
         self.sil_eps = sx.eps()
         self.up_sil, self.up_inter = torch.tensor([w["loss_sil_obj"]], device=dev), torch.tensor([w["loss_inter"]], device=dev)
-        if self.on["depth"]:
+        if self.on["depth"] and h > 1:
+            # two hands per frame: the three layers [object, hand 0, hand 1] of reference homan.py:384-419, every unordered pair
+            # through the two-layer kernels, one normaliser for the scene (lossutils.py:133-169; ops.ordinal_depth_loss_layers is
+            # the autograd form of what _forward_backward_hands issues)
+            ctx_o, ctx_hs, m_o, m_hs = m.models[0]._depth_contexts_hands()
+            if ctx_o.padded:
+                raise NotImplementedError("the fused loop renders the depth images at image_size % 32 == 0; other sizes: "
+                                          "mode='graph' or 'eager'")
+            self.dlayers = [(ctx_o, Vo, m_o)] + [(ctx_hs[i], Vh, m_hs[i]) for i in range(h)]
+            self.dpairs = [(a, b) for a in range(h + 1) for b in range(a + 1, h + 1)]
+            Sd = ctx_o.S
+            self.dl_sil, self.dl_dep = [f(B, Sd, Sd) for _ in self.dlayers], [f(B, Sd, Sd) for _ in self.dlayers]
+            self.dl_g = [f(B, Sd, Sd) for _ in self.dlayers]
+            self.dp_part, self.dp_rec = [f(B * 8) for _ in self.dpairs], [f(8) for _ in self.dpairs]
+            self.dp_out, self.dp_up = [f(1) for _ in self.dpairs], [f(1) for _ in self.dpairs]
+            self.dp_g = [(f(B, Sd, Sd), f(B, Sd, Sd)) for _ in self.dpairs]
+            self.rws_dp = [ClipReduceWorkspace(dev, 1) for _ in self.dpairs]
+            self.G_dep_o, self.G_dep_h_d, self.G_dep_h = f(B, Vo, 3), [f(B, Vh, 3) for _ in range(h)], f(N, Vh, 3)
+        elif self.on["depth"]:
             # ordinal depth term (reference homan.py:384-419, opt-in): object and hand rendered with depth at the full-image
             # camera, the pair-wise ordinal loss, and its gradient back through both depth images to the camera-space vertices
             if C == 1:
@@ -572,7 +588,7 @@ class FusedStepper:
                 self.sil_keep.copy_(sx.pad(m.keep_mask_object))
                 self.sil_ref.copy_(sx.pad(m.ref_mask_object))
             self.obj_spheres.copy_(self._group_spheres())
-            if self.on["depth"]:
+            if self.on["depth"] and self.h == 1:     # (two hands: the layers' masks are the model's own tensors, copied in place)
                 self.dctx = m.models[0].depth_contexts()
             for st_m, st_v in self.opt.state:
                 st_m.zero_()
@@ -1055,7 +1071,7 @@ class FusedStepper:
             if on["smooth"]:
                 ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), slot("loss_smooth_obj"), rws_b, 0, NS, sb),
                    "smooth(obj)")
-            pairwise = on["con"] or on["inter"] or on["col"]
+            pairwise = on["con"] or on["inter"] or on["col"] or on["depth"]
             if pairwise:
                 for i in range(h):
                     self.vh_d[i].copy_(self.vh[i::h])
@@ -1085,6 +1101,42 @@ class FusedStepper:
                     ck(L.hm_collision_fwd(P(va), P(cc.f0), cc.V0, cc.f0.shape[0], P(vb), P(cc.f1), cc.V1, cc.f1.shape[0], B,
                                           c.SDF_SCALE_FACTOR, P(ga), P(gb), self.tmp_col[k:k + 1].data_ptr(), P(cc.ws), sb),
                        "collision(scene %d)" % k)
+            if on["depth"]:
+                # three depth renders at the full-image camera, the three pairs' ordinal terms, the scene's normaliser and
+                # every pair's share of it on the device, the pairs' backward passes with that share (times the weight) as
+                # upstream, a layer's two gradient images added, one depth-map backward per layer
+                Sd, K = self.dlayers[0][0].S, P(m.camintr)
+                lverts = [self.vo] + list(self.vh_d)
+                for li, (ctx, V_, _) in enumerate(self.dlayers):
+                    self._depth_render(lverts[li], ctx, V_, self.dl_sil[li], self.dl_dep[li], sb)
+                for k, (a, b) in enumerate(self.dpairs):
+                    ck(L.hm_ordinal_depth_fwd(P(self.dl_dep[a]), P(self.dl_dep[b]), P(self.dl_sil[a]), P(self.dl_sil[b]),
+                                              P(self.dlayers[a][2]), P(self.dlayers[b][2]), B, Sd, P(self.dp_part[k]),
+                                              P(self.dp_rec[k]), P(self.dp_out[k]), P(self.rws_dp[k].buf), sb), "ordinal depth")
+                present = [(sl == 1).flatten(1).any(1).sum().float() for sl in self.dl_sil]
+                npairs = [self.dp_rec[k][0] for k in range(len(self.dpairs))]
+                total = sum(present) + sum(npairs[k] - present[a] - present[b] for k, (a, b) in enumerate(self.dpairs))
+                loss = torch.zeros((), device=self.vo.device)
+                for k in range(len(self.dpairs)):
+                    share = torch.where(npairs[k] > 0, npairs[k] / total, torch.zeros_like(total))
+                    loss = loss + torch.where(npairs[k] > 0, self.dp_out[k][0] * share, torch.zeros_like(total))
+                    self.dp_up[k].copy_((w["loss_depth"] * share).reshape(1))
+                self.vals[0][self.SLOTS.index("loss_depth")] = loss
+                for li in range(len(self.dlayers)):
+                    self.dl_g[li].zero_()
+                for k, (a, b) in enumerate(self.dpairs):
+                    ga, gb = self.dp_g[k]
+                    ck(L.hm_ordinal_depth_bwd(P(self.dl_dep[a]), P(self.dl_dep[b]), P(self.dl_sil[a]), P(self.dl_sil[b]),
+                                              P(self.dlayers[a][2]), P(self.dlayers[b][2]), B, Sd, P(self.dp_rec[k]),
+                                              P(self.dp_up[k]), P(ga), P(gb), sb), "ordinal depth bwd")
+                    self.dl_g[a].add_(ga)
+                    self.dl_g[b].add_(gb)
+                gouts = [self.G_dep_o] + list(self.G_dep_h_d)
+                for li, (ctx, V_, _) in enumerate(self.dlayers):
+                    ck(L.hm_depth_bwd(P(lverts[li]), K, B, V_, ctx.F, Sd, 1.0, P(self.dl_g[li]), P(ctx.adj_off),
+                                      P(ctx.adj_items), P(gouts[li]), P(ctx.workspace), sb), "depth bwd")
+                for i in range(h):
+                    self.G_dep_h[i::h].copy_(self.G_dep_h_d[i])
             # ---- the hands' values combined like the reference does, gradients back onto the interleaved rows
             with torch.cuda.stream(side):
                 v0 = self.vals[0]
@@ -1107,10 +1159,15 @@ class FusedStepper:
                     self.U_colh2[0::h].copy_(self.U_col_d[2])     # ... and from each hand's scene with the object
                     self.U_colh2[1::h].copy_(self.U_col_d[3])
             self.ev_pair.record(side)
+            if on["depth"] and on["col"]:
+                # (a rigid backward sums five weighted terms: with the depth term the two collision buffers share a slot -
+                #  another float summation order than without it, and nothing is written out for this combination)
+                self.U_colh.add_(self.U_colh2)
             tp, tw, tn = _lib.terms([(self.U_smh if on["smooth"] else None, w["loss_smooth_hand"]),
                                      (self.U_v2d if on["v2d"] else None, w["loss_v2d_hand"]),
                                      (self.U_colh if on["col"] else None, w["loss_collision"]),
-                                     (self.U_colh2 if on["col"] else None, w["loss_collision"]),
+                                     ((self.G_dep_h, 1.0) if on["depth"] else
+                                      (self.U_colh2 if on["col"] else None, w["loss_collision"])),
                                      (self.U_conh if on["con"] else None, w["loss_contact"] / h)])
             ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
                                     P(m.int_scales_hand), 0, tp, tw, tn, None,
@@ -1129,7 +1186,8 @@ class FusedStepper:
         tp, tw, tn = _lib.terms([(self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),
                                  (self.U_cono_d[0] if on["con"] else None, w["loss_contact"] / h),
                                  (self.U_cono_d[1] if on["con"] else None, w["loss_contact"] / h),
-                                 (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0)])
+                                 (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0),
+                                 (self.G_dep_o if on["depth"] else None, 1.0)])
         if on["sil"]:
             ck(L.hm_rigid_bwd_sil_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn,
                                         L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),

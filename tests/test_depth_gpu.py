@@ -276,9 +276,32 @@ def test_ordinal_depth_term_with_two_hands_matches_oracle(mano_model):
                                          num_iterations=8, lr=1e-2, camintr=clip["camintr"], optimize_mano=True, image_size=size,
                                          mano_model=mano_model, rend_size=size, ordinal_depth=True, mode="eager")
     assert evo["loss_depth"][-1] < evo["loss_depth"][0]
-    # (mode="auto" takes the graph loop for this configuration: the fused loop covers the term with one hand per frame.  Not run
-    #  here: a captured autograd iteration with depth renders followed later in the same process by a clip-batch graph has
-    #  crashed the HIP graph runtime, see test_model_ordinal_depth_term_matches_oracle)
+    # the FUSED loop on the same configuration (round 5): three renders, three pair terms, the scene's normaliser and the
+    # pairs' shares on the device, one depth-map backward per layer - losses and gradients of HOMan.forward + autograd, next
+    # to the other step-2 terms (three collision scenes, per-hand contact), and a few captured steps bring the term down
     from homan_amd.jointopt import FusedStepper
-    with pytest.raises(NotImplementedError):
-        FusedStepper(hm, lw, 1e-2, 2)
+    lw2 = dict(synth.STEP2_LOSS_WEIGHTS, lw_depth=2.0)
+    ref = HOMan(**copy.deepcopy(kw), **common, sync_metrics=False)
+    ld, md = ref(loss_weights=lw2)
+    total = sum(ld[k] * lw2[k.replace("loss", "lw")] for k in ld)
+    total.sum().backward()
+    ref_grads = {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None}
+    ref_losses = {k: float(v.detach().reshape(-1)[0]) for k, v in ld.items()}
+    assert ref_losses["loss_depth"] > 0
+    fm = HOMan(**copy.deepcopy(kw), **common, sync_metrics=False)
+    st = FusedStepper(fm, lw2, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    for k, v in ref_losses.items():
+        np.testing.assert_allclose(st.log_buf[0, 0, st.SLOTS.index(k)].item(), v, rtol=2e-6, atol=1e-9, err_msg=k)
+    np.testing.assert_allclose(st.log_buf[0, 0, len(st.SLOTS)].item(), float(total.detach().reshape(-1)[0]), rtol=2e-6)
+    for k, p in fm.named_parameters():
+        if k in ref_grads:
+            scale = max(ref_grads[k].abs().max().item(), 1e-20)
+            assert ((p.grad - ref_grads[k]).abs().max() / scale).item() < 2e-5, k
+    fm2 = HOMan(**copy.deepcopy(kw), **common, sync_metrics=False)
+    st2 = FusedStepper(fm2, lw, 1e-2, 12)
+    st2.run(12)
+    evo2 = st2.loss_evolution(12)
+    assert evo2["loss_depth"][-1] < evo2["loss_depth"][0]
+    np.testing.assert_allclose(evo2["loss_depth"][0], lh["loss_depth"].item(), rtol=2e-6)

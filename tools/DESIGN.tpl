@@ -19,7 +19,7 @@ design and the current numbers; how the kernels got here - every measured step a
 | (a) a14 | coarse interaction loss + gating + min-distance metric | `csrc/losses.hip` (`hm_inter_*`), `csrc/contact.hip` (`hm_nn_fwd`) |
 | (a) a16,a17 + N2 | SDF collision loss | `csrc/sdf.hip` (`hm_collision_fwd`) |
 | (a) a18 | contact loss (as executed, Appendix B.1) | `csrc/contact.hip` |
-| (a) a19 | ordinal depth | `csrc/raster.hip`: depth image out of `hm_sil_fwd` (`pooled_depth`), `hm_depth_bwd`, `hm_ordinal_depth_fwd/bwd`. The reference call site is broken (`homan.py:506-507` raises `TypeError`, `lossutils.py:140` builds the accumulator with `torch.Tensor(0.0)`): the default still raises that `TypeError`; `HOMan(ordinal_depth=True)` opts into the loss the method describes, in all three loops - eager, graph and the fused launch sequence (`FusedStepper`, `lw_depth > 0`, one clip; any render size since the rasteriser pads to a multiple of 32, the fused depth renders at `image_size % 32 == 0`). **Oracle-pinned only** (no reference output exists to pin against) |
+| (a) a19 | ordinal depth | `csrc/raster.hip`: depth image out of `hm_sil_fwd` (`pooled_depth`), `hm_depth_bwd`, `hm_ordinal_depth_fwd/bwd`. The reference call site is broken (`homan.py:506-507` raises `TypeError`, `lossutils.py:140` builds the accumulator with `torch.Tensor(0.0)`): the default still raises that `TypeError`; `HOMan(ordinal_depth=True)` opts into the loss the method describes, in all three loops - eager, graph and the fused launch sequence (`FusedStepper`, `lw_depth > 0`, one clip, one or - round 5 - two hands per frame: three layers, three pair terms, the scene's normaliser and the pairs' shares formed on the device; any render size since the rasteriser pads to a multiple of 32, the fused depth renders at `image_size % 32 == 0`). **Oracle-pinned only** (no reference output exists to pin against) |
 | (b) boundary | Python surface + C ABI | `homan_amd/{homan,losses,lossutils,manomodel,jointopt}.py`, `include/homan_amd.h`, `INTEGRATION.md` |
 | (c) oracle | CPU restatement + reference-generated goldens; the object's gradient chain and Adam also written out with order-independent sums (`oracle/objchain.py`, `oracle/csrc/objchain.c`, `oracle/adam.py`) | `oracle/`, `tools/refharness/`, `tests/golden/` |
 | (d) measurement | bench, roofline, CPU baseline, rocprof | `bench.py`, `profiles/`, `tools/prof_summary.py` |
@@ -483,9 +483,11 @@ file the reference never reaches.  More than two hands: the reference's own coll
    records / zeroed gradients 84 MB - and the source arrays (12 B per source and orientation: ~100 MB with 500 candidates far
    from their mask).  With them the model is 239 MB + sources; the remaining factor (~1.5 x) is the guide's x 2 correction on
    FETCH_SIZE applied to narrow scattered reads (owner gathers), for which it is not calibrated.
-4. The ordinal depth term: 140 µs on a 153 µs iteration; in a clip batch one clip per stepper; with two hands per frame in the
-   eager / graph loops only (three layers pair-wise through the two-layer kernels), compared with the faithful oracle (value,
-   gradients), not written out.  The reference's own call site raises (`homan.py:506-507`): oracle-pinned only.
+4. The ordinal depth term: 140 µs on a 153 µs iteration; in a clip batch one clip per stepper.  With two hands per frame it now
+   runs in the fused loop too (round 5: losses and gradients of `HOMan.forward` + autograd at 2e-6 / 2e-5,
+   `tests/test_depth_gpu.py`), compared with the faithful oracle (value, gradients) - not written out: `oracle/handchain.py`
+   raises for depth + two hands and the reproducible loop keeps autograd's gradients there.  The reference's own call site
+   raises (`homan.py:506-507`): oracle-pinned only.
 5. `hand_proj_mode="ortho"` raises (section 7: its camera conversion is a third-party function absent from `/root/reference`).
 6. N > 1 on real multi-GPU hardware: RCCL has carried one-rank groups and (gloo) 2-3 ranks on one GPU here;
    `tests/test_dist_gpu.py::test_two_ranks_on_two_gpus_over_rccl` runs the two-GPU case wherever two GPUs are visible and
