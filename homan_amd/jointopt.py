@@ -14,6 +14,7 @@ Execution modes (`mode=`, a homan_amd extension; default "auto" = "fused" when i
                 and read back once at the end (no host sync inside the loop).
 """
 import ctypes
+import ctypes
 import os
 from collections import OrderedDict, defaultdict
 
@@ -22,128 +23,10 @@ import torch
 
 from . import lib as _lib
 from .homan import HOMan
-
-
-def _tensorify(x):
-    if isinstance(x, torch.Tensor):
-        return x
-    a = np.asarray(x)
-    return torch.from_numpy(a.astype(np.float32) if a.dtype.kind == "f" else a)
-
-
-def collate_inputs(person_parameters, object_parameters, objvertices, objfaces):
-    """Per-frame dicts -> HOMan keyword arguments (reference jointopt.py:52-91)."""
-    cat = torch.cat
-    pp, op = person_parameters, object_parameters
-    return dict(
-        hand_sides=pp[0]["hand_side"],
-        translations_object=cat([o["translations"] for o in op]),
-        rotations_object=cat([o["rotations"] for o in op]),
-        verts_object_og=_tensorify(objvertices),
-        faces_object=_tensorify(objfaces),
-        target_masks_object=cat([o["target_masks"] for o in op]),
-        target_masks_hand=cat([p["target_masks"] for p in pp]),
-        verts_hand_og=cat([p["verts"] for p in pp]),
-        ref_verts2d_hand=cat([p["verts2d"] for p in pp]),
-        mano_trans=cat([p["mano_trans"] for p in pp]),
-        mano_rot=cat([p["mano_rot"] for p in pp]),
-        mano_pca_pose=cat([p["mano_pca_pose"] for p in pp]),
-        mano_betas=cat([p["mano_betas"] for p in pp]),
-        translations_hand=cat([p["translations"] for p in pp]),
-        rotations_hand=cat([p["rotations"] for p in pp]),
-        faces_hand=pp[0]["faces"],
-        masks_object=cat([o["full_mask"].unsqueeze(0) for o in op]),
-        masks_hand=cat([p["masks"] for p in pp]),
-        cams_hand=cat([p["cams"] for p in pp]),
-        camintr_rois_object=cat([o["K_roi"][:, 0] for o in op]),
-        camintr_rois_hand=cat([p["K_roi"] for p in pp]),
-    )
-
-
-def parameter_groups(model, lr):
-    """The three Adam groups of reference jointopt.py:128-151 (selected by parameter-name substring)."""
-    rigid = [v for k, v in model.named_parameters() if "mano" not in k and "rotation" not in k]
-    rotation = [v for k, v in model.named_parameters() if ("rotation" in k) and ("mano" not in k)]
-    return [{"params": rigid, "lr": lr},
-            {"params": [model.mano_pca_pose, model.mano_betas], "lr": lr * 10},
-            {"params": rotation, "lr": lr * 10}]
-
-
-class HmAdam:
-    """Fused multi-tensor Adam on device (csrc/adam.hip): same arithmetic as torch's single-tensor Adam with
-    betas=(0.9,0.999), eps=1e-8, one launch for all tensors, device-side step counter, gradients zeroed in the
-    same launch.  Parameters whose .grad is None are skipped, like torch.optim.Adam does."""
-
-    def __init__(self, groups, betas=(0.9, 0.999), eps=1e-8):
-        self.betas, self.eps = betas, eps
-        self.items = []
-        for g in groups:
-            for p in g["params"]:
-                if isinstance(p, torch.nn.Parameter) and p.requires_grad and p.grad is not None:
-                    self.items.append((p, float(g["lr"])))
-        assert self.items, "run one backward before building HmAdam (static gradient buffers)"
-        dev = self.items[0][0].device
-        self.state = [(torch.zeros_like(p), torch.zeros_like(p)) for p, _ in self.items]
-        self.step_t = torch.zeros(2, dtype=torch.int32, device=dev)     # {steps done, ticket word of k_adam}
-        slot = np.zeros(len(self.items), dtype=[("p", "u8"), ("g", "u8"), ("m", "u8"), ("v", "u8"), ("n", "i8"),
-                                                 ("lr", "f4"), ("pad", "i4")])
-        assert slot.itemsize == _lib.lib().hm_adam_slot_bytes()
-        for i, ((p, lr), (m, v)) in enumerate(zip(self.items, self.state)):
-            assert p.is_contiguous() and p.grad.is_contiguous()
-            slot[i] = (p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, 0)
-        self.slots = torch.from_numpy(slot.view(np.uint8).copy()).to(dev)
-        self.grads = [p.grad for p, _ in self.items]       # keep the static buffers alive
-        self.blocks = max(1, min(64, (max(p.numel() for p, _ in self.items) + 255) // 256))
-
-    def step(self, zero_grad=True, log=None):
-        """log = (vals (C, n+1), weights (n), n, max_steps, log_buf, C): the log row of the step being taken is written by the
-        same launch (hm_adam_step_log = hm_log_total_clips + hm_adam_step)."""
-        for (p, _), g in zip(self.items, self.grads):
-            assert p.grad is g, "gradient buffers must stay static (do not call zero_grad(set_to_none=True))"
-        if log is not None:
-            vals, weights, n, max_steps, log_buf, nclips = log
-            _lib.check(_lib.lib().hm_adam_step_log(_lib.ptr(self.slots), len(self.items), _lib.ptr(self.step_t),
-                                                   self.betas[0], self.betas[1], self.eps, int(zero_grad), self.blocks,
-                                                   _lib.ptr(vals), _lib.ptr(weights), n, max_steps, _lib.ptr(log_buf),
-                                                   nclips, _lib.stream()), "hm_adam_step_log")
-            return
-        _lib.check(_lib.lib().hm_adam_step(_lib.ptr(self.slots), len(self.items), _lib.ptr(self.step_t),
-                                           self.betas[0], self.betas[1], self.eps, int(zero_grad), self.blocks,
-                                           _lib.stream()), "hm_adam_step")
-
-
-class _DeviceLog:
-    """loss_evolution without host syncs: the scalars of one iteration are packed and a kernel writes them into
-    row `step` (device-side counter) of a (max_steps, n) buffer that is read back once at the end."""
-
-    def __init__(self, keys, max_steps, step_t):
-        self.keys = list(keys)
-        self.buf = torch.zeros(max_steps, len(self.keys), device=step_t.device)
-        self.max_steps, self.step_t = max_steps, step_t
-
-    def record(self, scalars):
-        packed = torch.cat([scalars[k].detach().reshape(1) for k in self.keys])
-        _lib.check(_lib.lib().hm_log_scalars(_lib.ptr(packed), len(self.keys), _lib.ptr(self.step_t),
-                                             self.max_steps, _lib.ptr(self.buf), _lib.stream()), "hm_log_scalars")
-
-
-def _weighted_total(loss_dict, loss_weights):
-    """loss = sum_k loss_k * lw[k.replace('loss','lw')]   (reference jointopt.py:180-188), shape (1,)."""
-    return sum(loss_dict[k] * loss_weights[k.replace("loss", "lw")] for k in loss_dict)
-
-
-def build_model(person_parameters, object_parameters, class_name="default", objvertices=None, objfaces=None,
-                camintr=None, hand_proj_mode="persp", optimize_mano=False, optimize_mano_beta=True,
-                optimize_object_scale=False, state_dict=None, image_size=640, mano_model=None, rend_size=256,
-                sync_metrics=True, ordinal_depth=False):
-    kw = collate_inputs(person_parameters, object_parameters, objvertices, objfaces)
-    model = HOMan(camintr=camintr, class_name=class_name, int_scale_init=1, hand_proj_mode=hand_proj_mode,
-                  optimize_mano=optimize_mano, optimize_mano_beta=optimize_mano_beta,
-                  optimize_object_scale=optimize_object_scale, image_size=image_size, mano_model=mano_model,
-                  rend_size=rend_size, sync_metrics=sync_metrics, ordinal_depth=ordinal_depth, **kw)
-    if state_dict is not None:
-        model.load_state_dict(state_dict, strict=False)
-    return model
+from .fused import FusedStepper, _loop_streams, _morton_order  # noqa: F401  (the loops live in their own modules; this is the reference's module name)
+from .loopcommon import (HmAdam, _DeviceLog, _tensorify, _weighted_total, build_model, collate_inputs,  # noqa: F401
+                         parameter_groups)
+from .shard import ClipFitter, ShardStepper, _input_signature, _shape_signature  # noqa: F401
 
 
 class GraphStepper:
@@ -202,1317 +85,6 @@ class GraphStepper:
         torch.cuda.synchronize()
         host = self.log.buf[:steps].cpu().numpy()
         return {k: host[:, i].astype(np.float64).tolist() for i, k in enumerate(self.log.keys)}
-
-
-def _morton_order(verts):
-    """permutation of the (V,3) vertices along a 3-D Morton curve (10 bits per axis): consecutive vertices are neighbours"""
-    v = verts.detach().float().cpu().numpy()
-    lo, hi = v.min(0), v.max(0)
-    q = np.clip(((v - lo) / np.maximum(hi - lo, 1e-12) * 1023.0).astype(np.int64), 0, 1023)
-    code = np.zeros(len(v), np.int64)
-    for bit in range(10):
-        for ax in range(3):
-            code |= ((q[:, ax] >> bit) & 1) << (3 * bit + ax)
-    return torch.from_numpy(np.argsort(code, kind="stable").astype(np.int32))
-
-
-_LOOP_STREAMS = {}
-
-
-def _loop_streams(device):
-    """(capture, side, aux, warm-up) HIP streams of the fused loop, one set per device, pairwise distinct.
-    torch hands streams out of a pool of 32 per device, round-robin: a process that builds many steppers eventually draws
-    a side stream that IS the capture stream, and a capture in which two 'streams' wait on each other both ways crashes
-    the HIP graph runtime at replay.  Steppers replay in stream order anyway, so they share one verified set."""
-    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
-    if key not in _LOOP_STREAMS:
-        got, seen = [], {torch.cuda.current_stream(key).cuda_stream, torch.cuda.default_stream(key).cuda_stream}
-        for _ in range(256):
-            st = torch.cuda.Stream(device=key)
-            if st.cuda_stream not in seen:
-                seen.add(st.cuda_stream)
-                got.append(st)
-            if len(got) == 4:
-                break
-        assert len(got) == 4, "could not obtain four distinct HIP streams"
-        _LOOP_STREAMS[key] = tuple(got)
-    return _LOOP_STREAMS[key]
-
-
-class FusedStepper:
-    """The whole optimisation iteration as a fixed sequence of C-ABI kernel launches (no autograd tape, no torch
-    arithmetic kernels), captured in a hipGraph:
-
-        forward   rigid(obj) . mano . rigid(hand) . priors . smooth x2 . [collision] . [nn] . [contact] . v2d .
-                  silhouettes(project, setup, raster, reduce) . inter . log(total + loss_evolution row)
-        backward  sil(masks, sweeps, gather) . inter . weighted sums of the per-loss vertex gradients .
-                  rigid_bwd(obj) . rigid_bwd(hand) . mano_bwd . prior terms . Adam
-
-    Same kernels, same detach structure and same weighting as HOMan.forward + autograd (reference homan/homan.py:421-508,
-    jointopt.py:178-192); tests/test_model_gpu.py checks the two paths produce the same gradients.  Supports the
-    configurations of BASELINE.json (one right hand, optimize_mano=True, optimize_mano_beta=True, persp); anything
-    else should use mode="graph".
-
-    `model` is one HOMan, or a list of HOMan of identical shapes = a CLIP BATCH (homan_amd.clipbatch): the C clips are
-    then optimised together, every kernel launched once over the C * B frames through the `*_clips` entry points
-    (per-clip normalisers, sums, scales, Adam state and log rows; BASELINE cfg4).  Per clip the arithmetic - including
-    the order of every floating-point sum - is the single-clip one, so a batched step equals C single steps bit for bit.
-    With `shared_scale` (BASELINE cfg5) the object scale is ONE scalar for all clips of all ranks: each clip keeps a
-    replica, the replicas' gradients are summed over the local clips and all-reduced over `group` once per iteration
-    (one 4-byte RCCL all-reduce on the compute stream between the two captured halves of the iteration), and every
-    replica takes the identical Adam step."""
-
-    SLOTS = ["loss_pca", "loss_scale_obj", "loss_scale_hand", "loss_smooth_obj", "loss_smooth_hand", "loss_collision",
-             "loss_contact", "loss_v2d_hand", "v2d_hand", "loss_sil_obj", "iou_object", "loss_inter",
-             "handobj_maxdist", "loss_depth"]
-
-    def __init__(self, model, loss_weights, lr, max_steps, capture=True, shared_scale=False, group=None, collectives=True):
-        from . import constants, ops
-        from .clipbatch import ClipBatch, ClipReduceWorkspace
-        for one in (model.models if isinstance(model, ClipBatch) else model if isinstance(model, (list, tuple)) else [model]):
-            if len(one.hand_sides) not in (1, 2):
-                raise NotImplementedError("one or two hands per frame")
-        m = self.model = model if isinstance(model, ClipBatch) else ClipBatch(model if isinstance(model, (list, tuple))
-                                                                             else [model])
-        if len({tuple(one.hand_sides) for one in m.models}) != 1:
-            raise NotImplementedError("the clips of a batch share the hand side (one MANO model per launch)")
-        if m.int_scales_hand.requires_grad or m.hand_proj_mode != "persp":
-            raise NotImplementedError("FusedStepper covers optimize_mano_beta=True (the hand scale a buffer) and persp")
-        self.h = h = len(m.models[0].hand_sides)
-        kinds = {one.losses.inter_type for one in m.models}
-        # inter_type "min" (reference losses.py:219-221, a HOMan option its loop cannot select): one hand, one clip
-        self.inter_min = kinds == {"min"}
-        if len(kinds) != 1 or (self.inter_min and (h > 1 or m.C > 1)):
-            raise NotImplementedError("inter_type='min' in the fused loop: one hand, one clip (else mode='graph' or 'eager')")
-        if h > 1 and (m.C > 1 or shared_scale):
-            raise NotImplementedError("two hands per frame: the fused loop takes one clip at a time (a batch of two-hand "
-                                      "clips: one stepper per clip, or mode='graph')")
-        lw = self.lw = {k: float(v) for k, v in loss_weights.items()}
-        if lw.get("lw_depth", 0) > 0:
-            if not getattr(m, "ordinal_depth", False):
-                # reference homan.py:506-507 calls lossutils.compute_ordinal_depth_loss() without its arguments
-                raise TypeError("compute_ordinal_depth_loss() missing 3 required positional arguments: "
-                                "'masks', 'silhouettes', and 'depths'")
-        self.shared_scale, self.group = bool(shared_scale), group
-        # collectives=False: the caller (ShardStepper: several steppers of one rank) issues the broadcast / all-reduce of the
-        # tied scale itself - every rank must issue the same number of collectives whatever its number of steppers
-        self.collectives = bool(collectives)
-        if self.shared_scale and not m.optimize_object_scale:
-            raise ValueError("shared_scale needs models built with optimize_object_scale=True")
-        self.L, self.c, self.ops = _lib.lib(), constants, ops
-        dev = m.translations_object.device
-        B, Vo, Vh = m.B, m.verts_object_og.shape[1], 778          # B = frames of the whole batch
-        C, NS = m.C, len(self.SLOTS) + 1
-        self.B, self.C, self.clip_len, self.NS = B, C, m.clip_len, NS
-        # third stream for the silhouette reduction + log row: it pays on a clip batch (+1.5 %); at one clip the graph executor
-        # spends two cross-queue hops (~10 us each) on it, and two streams are 5-6 % faster (same-box A/B, cfg2 and cfg3)
-        self.use_aux = (os.environ.get("HOMAN_AUX") or ("1" if C > 1 else "0")) != "0"
-        if lw.get("lw_depth", 0) > 0:
-            self.use_aux = False         # (with the depth launches on the side stream the three-stream graph dies at replay in
-                                         #  the HIP runtime, like the other patterns listed at _loop_streams: two streams)
-        # two streams, no shared scale: the log row of a step is written by the Adam launch itself (one launch less)
-        self.log_in_adam = (not self.use_aux and not self.shared_scale and
-                            os.environ.get("HOMAN_LOG_IN_ADAM", "1") != "0")
-        self.fork_after_setup = os.environ.get("HOMAN_FORK_AFTER_SETUP", "1") != "0"
-        # the silhouette loss / IoU values (log only) come out of the backward's first launch: one launch less on the chain
-        # (two streams only: with the third stream the reduction and the log row stay there, behind the raster's event)
-        self.sil_reduce_in_bwd = not self.use_aux and os.environ.get("HOMAN_SIL_REDUCE_IN_BWD", "1") != "0"
-        self.Vo, self.Vh, self.P = Vo, Vh, m.mano_pca_pose.shape[1]
-        f = lambda *shape: torch.zeros(*shape, device=dev)
-        N = self.N = B * h                                        # hand rows (hands interleaved frame-major, homan.py:62-63)
-        self.vo, self.vm, self.vh = f(B, Vo, 3), f(N, Vh, 3), f(N, Vh, 3)
-        self.vals = f(C, NS)                                      # row c: the loss / metric slots of clip c + its total
-        on = lambda k: lw.get(k, 0.0) > 0
-        self.on = dict(pca=on("lw_pca"), so=on("lw_scale_obj"), sh=on("lw_scale_hand"),
-                       smooth=on("lw_smooth_hand") or on("lw_smooth_obj"), col=on("lw_collision"),
-                       con=on("lw_contact"), v2d=on("lw_v2d_hand"), sil=on("lw_sil_obj"), inter=on("lw_inter"),
-                       depth=on("lw_depth"))
-        w = {"loss_pca": lw["lw_pca"] if self.on["pca"] else 0, "loss_scale_obj": lw["lw_scale_obj"] if self.on["so"] else 0,
-             "loss_scale_hand": lw["lw_scale_hand"] if self.on["sh"] else 0,
-             "loss_smooth_obj": lw["lw_smooth_obj"] if self.on["smooth"] else 0,
-             "loss_smooth_hand": lw["lw_smooth_hand"] if self.on["smooth"] else 0,
-             "loss_collision": lw["lw_collision"] if self.on["col"] else 0,
-             "loss_contact": lw["lw_contact"] if self.on["con"] else 0,
-             "loss_v2d_hand": lw["lw_v2d_hand"] if self.on["v2d"] else 0,
-             "loss_sil_obj": lw["lw_sil_obj"] if self.on["sil"] else 0,
-             "loss_inter": lw["lw_inter"] if self.on["inter"] else 0,
-             "loss_depth": lw["lw_depth"] if self.on["depth"] else 0}
-        self.w = w
-        self.weights = torch.tensor([w.get(k, 0.0) for k in self.SLOTS], device=dev)
-        self.keys = [k for k in self.SLOTS if self._reported(k)]
-        # with the collision / contact terms the hand-side stream is by far the longer chain: the object's smoothness term
-        # (it only feeds the object's pose gradients) then rides the silhouette chain (measured: cfg3 +5 %, cfg2 -6 %)
-        self.smooth_obj_on_main = (self.on["col"] or self.on["con"]) and m.C == 1      # (a clip batch: -4 %)
-        # unit gradients / scratch
-        self.U_pca, self.U_so, self.U_sh = f(N, self.P), f(C), f(C)
-        self.U_smo, self.U_smh, self.U_v2d = f(B, Vo, 3), f(N, Vh, 3), f(N, Vh, 3)
-        self.U_colh, self.U_colo, self.U_conh, self.U_cono = f(N, Vh, 3), f(B, Vo, 3), f(N, Vh, 3), f(B, Vo, 3)
-        self.G_sil, self.G_int_h, self.G_int_o = f(B, Vo, 3), f(N, Vh, 3), f(B, Vo, 3)
-        self.G_o, self.G_h, self.G_mesh = f(B, Vo, 3), f(N, Vh, 3), f(N, Vh, 3)
-        self.g_pca_mano, self.g_so_part = f(N, self.P), f(B)
-        self.rec = f(N, 8)
-        if self.inter_min:
-            self.G_min_h, self.tmp_inter, self.rows = f(N, Vh, 3), f(2), torch.arange(B, device=dev)
-        if h > 1:
-            # two hands: the pair-wise terms see one hand at a time as a dense (B,778,3) array (hand i = rows i::h)
-            self.vh_d = [f(B, Vh, 3) for _ in range(h)]
-            self.nn_idx_d = [torch.zeros(B, Vh, dtype=torch.int32, device=dev) for _ in range(h)]
-            self.nn_d2_d = [f(B, Vh) for _ in range(h)]
-            self.U_conh_d, self.U_cono_d = [f(B, Vh, 3) for _ in range(h)], [f(B, Vo, 3) for _ in range(h)]
-            self.U_colh2, self.U_col_d = f(N, Vh, 3), [f(B, Vh, 3) for _ in range(4)]      # (h0|h1), (h0|obj), (h1|obj): hand sides
-            self.U_colo_d = f(B, Vo, 3)
-            self.rec_d, self.G_int_o_d = [f(B, 8) for _ in range(h)], [f(B, Vo, 3) for _ in range(h)]
-            self.tmp_h, self.tmp_col = f(h, 4), f(3)
-            self.rws_h = [ClipReduceWorkspace(dev, 1) for _ in range(h)]
-            self.hand_ctx = [m.mano_model.ctx_mean if sd == "right" else m.mano_model._left_ctx(False)
-                             for sd in m.models[0].hand_sides]
-        self.nn_idx = torch.zeros(B, Vh, dtype=torch.int32, device=dev)
-        self.nn_d2 = f(B, Vh)
-        self.obj_order = _morton_order(m.verts_object_og[0]).to(dev)      # spatial sort of the rigid mesh (metric-only search)
-        # ... and of the hand: its template's vertices in the same kind of order, so that the 128 hand vertices of a search
-        # workgroup are a patch of the hand, not a sample of all of it (articulation moves the patches, it does not mix them)
-        side = m.models[0].hand_sides[0]
-        self.mctx = m.mano_model.ctx_mean if side == "right" else m.mano_model._left_ctx(False)      # (see ManoModel)
-        self.hand_order = _morton_order(self.mctx.tensors[0]).to(dev)
-        # bounding spheres, in MESH space, of the groups of 64 vertices in that order, per frame (a clip's frames share one mesh,
-        # the clips of a batch need not): centre = mean, radius = farthest vertex.  The search carries them into camera space
-        # with the frame's rigid transform instead of reducing the transformed vertices of every group in every workgroup.
-        self.Vo, self.B = Vo, B
-        with torch.no_grad():
-            # (repeats of a real vertex pad the last group: they change nothing but the mean, and are masked out of it)
-            self.obj_spheres = self._group_spheres()                                         # (B, ng, 4)
-        self.nn_spheres = os.environ.get("HOMAN_NN_SPHERES", "1") != "0"
-        self.pooled = f(B, m.sil_ctx.S, m.sil_ctx.S)
-        # silhouettes at a size off the kernels' 32-pixel tile grid (the reference's REND_SIZE is 256): rendered on the next
-        # multiple with the first two rows of K rescaled and the masks padded with keep = 0 (ops.SilhouetteContext); all three
-        # are constants of the fit, built once; eps of the pseudo-gradient in the padded grid's NDC units
-        sx = m.sil_ctx
-        self.sil_K = sx.K_eff(m.camintr_rois_object).contiguous()
-        self.sil_keep, self.sil_ref = sx.pad(m.keep_mask_object), sx.pad(m.ref_mask_object)
-        self.sil_eps = sx.eps()
-        self.up_sil, self.up_inter = torch.tensor([w["loss_sil_obj"]], device=dev), torch.tensor([w["loss_inter"]], device=dev)
-        if self.on["depth"] and h > 1:
-            # two hands per frame: the three layers [object, hand 0, hand 1] of reference homan.py:384-419, every unordered pair
-            # through the two-layer kernels, one normaliser for the scene (lossutils.py:133-169; ops.ordinal_depth_loss_layers is
-            # the autograd form of what _forward_backward_hands issues)
-            ctx_o, ctx_hs, m_o, m_hs = m.models[0]._depth_contexts_hands()
-            if ctx_o.padded:
-                raise NotImplementedError("the fused loop renders the depth images at image_size % 32 == 0; other sizes: "
-                                          "mode='graph' or 'eager'")
-            self.dlayers = [(ctx_o, Vo, m_o)] + [(ctx_hs[i], Vh, m_hs[i]) for i in range(h)]
-            self.dpairs = [(a, b) for a in range(h + 1) for b in range(a + 1, h + 1)]
-            Sd = ctx_o.S
-            self.dl_sil, self.dl_dep = [f(B, Sd, Sd) for _ in self.dlayers], [f(B, Sd, Sd) for _ in self.dlayers]
-            self.dl_g = [f(B, Sd, Sd) for _ in self.dlayers]
-            self.dp_part, self.dp_rec = [f(B * 8) for _ in self.dpairs], [f(8) for _ in self.dpairs]
-            self.dp_out, self.dp_up = [f(1) for _ in self.dpairs], [f(1) for _ in self.dpairs]
-            self.dp_g = [(f(B, Sd, Sd), f(B, Sd, Sd)) for _ in self.dpairs]
-            self.rws_dp = [ClipReduceWorkspace(dev, 1) for _ in self.dpairs]
-            self.G_dep_o, self.G_dep_h_d, self.G_dep_h = f(B, Vo, 3), [f(B, Vh, 3) for _ in range(h)], f(N, Vh, 3)
-        elif self.on["depth"]:
-            # ordinal depth term (reference homan.py:384-419, opt-in): object and hand rendered with depth at the full-image
-            # camera, the pair-wise ordinal loss, and its gradient back through both depth images to the camera-space vertices
-            if C == 1:
-                self.dctx = m.models[0].depth_contexts()
-            else:
-                # a clip batch: the two depth renders run over all frames at once, the ordinal term (it normalises over ONE
-                # clip: pairs, mask counts) per clip on its slice of the images
-                m0_, size = m.models[0], int(m.image_size)
-                for one in m.models:
-                    if tuple(one.masks_object.shape[1:]) != (size, size) or tuple(one.masks_human.shape[1:]) != (size, size):
-                        raise NotImplementedError("ordinal depth: instance masks must be (B, image_size, image_size)")
-                self.dctx = (ops.SilhouetteContext(m0_.faces_object[:1].expand(B, -1, -1), Vo, B, size, dev),
-                             ops.SilhouetteContext(m0_.faces_hand[:1].expand(B, -1, -1), 778, B, size, dev),
-                             torch.cat([(one.masks_object != 0).to(torch.uint8) for one in m.models]).contiguous(),
-                             torch.cat([(one.masks_human != 0).to(torch.uint8) for one in m.models]).contiguous())
-            ctx_o, ctx_h = self.dctx[0], self.dctx[1]
-            if ctx_o.padded:
-                raise NotImplementedError("the fused loop renders the depth images at image_size % 32 == 0; other sizes: "
-                                          "mode='graph' or 'eager'")
-            Sd = ctx_o.S
-            self.d_sil_o, self.d_dep_o, self.d_sil_h, self.d_dep_h = f(B, Sd, Sd), f(B, Sd, Sd), f(B, Sd, Sd), f(B, Sd, Sd)
-            self.d_go, self.d_gh, self.d_part, self.d_rec = f(B, Sd, Sd), f(B, Sd, Sd), f(B * 8), f(C, 8)
-            self.rws_depth = ClipReduceWorkspace(dev, C)
-            self.G_dep_o, self.G_dep_h = f(B, Vo, 3), f(B, Vh, 3)
-            self.up_depth = torch.tensor([w["loss_depth"]], device=dev)
-        # static gradient buffers for exactly the parameters that receive gradients in this configuration
-        for p in m.parameters():
-            p.grad = None
-        gp = [m.translations_object, m.rotations_object, m.translations_hand, m.rotations_hand]
-        if m.optimize_mano:          # (optimize_mano=False, the reference function's own default: the hand mesh is the
-            gp += [m.mano_pca_pose, m.mano_rot, m.mano_trans, m.mano_betas]      # constant `verts_hand_og`, homan.py:357-358)
-        if m.optimize_object_scale:
-            gp.append(m.int_scales_object)
-        for p in gp:
-            p.grad = torch.zeros_like(p)
-        self.opt = HmAdam(parameter_groups(m, lr))
-        self.log_buf = torch.zeros(max_steps, C, NS, device=dev)
-        self.max_steps = max_steps
-        self.rigid_ws_h, self.rigid_ws_o = (torch.zeros(self.L.hm_rigid_workspace_bytes(n), dtype=torch.uint8, device=dev)
-                                            for n in (N, B))
-        self.mano_state = torch.empty(self.L.hm_mano_state_bytes(N), dtype=torch.uint8, device=dev)
-        self.graph = self.graph_b = self.graph_k = None
-        # iterations per replay of the second graph (run()): one clip, no collective between the halves of an iteration.  The
-        # turnaround between two replays is ~5 us of a 160 us iteration (same-box A/B: +2-3 % at 4, no more at 8 / 16)
-        self.graph_iters = int(os.environ.get("HOMAN_GRAPH_ITERS") or ("4" if C == 1 else "1"))
-        self.cap_stream, self.side, self.aux, side = _loop_streams(dev)
-        self.ev_vo, self.ev_pair, self.ev_sil, self.ev_fwd, self.ev_smo, self.ev_ras = (torch.cuda.Event() for _ in range(6))
-        self.ev_hand, self.ev_col, self.ev_dep, self.ev_dgrad = (torch.cuda.Event() for _ in range(4))
-        # (option, off: one clip, step-2 sets - the collision chain on the side stream, the rest of the hand side on the third
-        #  stream, see forward_backward; measured +-0.4 % on cfg3: both chains already share a work-bound GPU)
-        self.col_on_aux = (os.environ.get("HOMAN_COL_AUX") or "0") != "0" and C == 1 and self.h == 1
-        self.reduce_ws_b = ClipReduceWorkspace(dev, C)
-        # (the terms of the fused pair-terms launch run side by side: a reduce workspace each)
-        self.reduce_ws_c, self.reduce_ws_d, self.reduce_ws_e = (ClipReduceWorkspace(dev, C) for _ in range(3))
-        # (one clip: the hand-side chain is the iteration's critical path, -6 %; a batch hides that chain under the silhouette
-        #  chain and the fused launch only adds contention there, +1.6 %)
-        # a clip batch: the pair-wise terms wait for the END of the rasteriser.  They used to start there anyway, behind a MANO
-        # forward as long as the raster; since that launch reads the blend matrix once per four frames it is over early, and the
-        # search / smoothness / interaction launches next to the raster cost it more (362 -> 433 us) than they gain next to the
-        # line expansion (230 -> 162 us)
-        self.pairs_after_raster = (self.use_aux and not self.sil_reduce_in_bwd and
-                                   (os.environ.get("HOMAN_PAIRS_AFTER_RASTER") or "1") != "0")
-        # a clip batch: the pair-wise terms of the side stream wait for the END of the line expansion (the backward in two
-        # calls) - that kernel is latency-bound and takes 200 us instead of 150 next to neighbours that hold its wave slots -
-        # and the sweeps run 1024 persistent workgroups instead of 1280 so that the hand's gradient launches find registers
-        # next to them (same-box A/B, 8 clips: step-1 8 650 -> 8 865 it/s, step-2 7 142 -> 7 332; either change alone loses)
-        self.pairs_after_lines = (os.environ.get("HOMAN_PAIRS_AFTER_LINES") or "1") != "0" and C > 1 and self.on["sil"]
-        self.ev_lines = torch.cuda.Event()
-        # the hand's rigid backward inside the MANO backward's launch (hm_mano_bwd_rigid_clips): one launch less on the hand-side
-        # chain.  One clip: cfg2 +1.3 %, cfg3 +1.4 %; a clip batch hides that chain under the silhouette chain and loses 1-1.6 %
-        self.mano_bwd_rigid = (os.environ.get("HOMAN_MANO_BWD_RIGID") or ("1" if C == 1 else "0")) != "0"
-        self.nn_early = (os.environ.get("HOMAN_NN_EARLY") or "0") != "0"
-        self.pair_fused = (os.environ.get("HOMAN_PAIR_FUSED") or ("1" if C == 1 else "0")) != "0"
-        self.hand_terms_fused = os.environ.get("HOMAN_HT_FUSED", "1") != "0"
-        self.nn_full_fused = os.environ.get("HOMAN_NN_FULL_FUSED", "1") != "0"
-        if self.shared_scale:
-            self._sync_shared_scale_start()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            self.forward_backward()              # warm-up, no optimiser step
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        if self.on["sil"]:
-            m.sil_ctx.calibrate()                # cost-sorted launch orders from the current state (scheduling only)
-        if capture:
-            # scheduling hint baked into the captured launches: with the collision / contact terms the hand-side stream is
-            # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way;
-            # same-box A/B on cfg3, round 2 before the launch fusions: 1280 -> 4030, 768 -> 4130, 512 -> 4194 it/s; after them,
-            # with the raster ballast below: 512 -> 4408, 768 -> 4552, 1024 -> 4537, 1280 -> 4512)
-            sb = int(os.environ.get("HOMAN_SWEEP_BLOCKS", "0")) or (768 if (self.on["col"] or self.on["con"]) and C == 1 else
-                                                                    1024 if self.pairs_after_lines else 1280)
-            pad = os.environ.get("HOMAN_RASTER_PAD")
-            # same idea for the rasteriser: 8 KB of LDS ballast = 4 workgroups per CU instead of 6 leaves registers for the
-            # hand-side kernels (cfg3 one clip: 4347 -> 4500 it/s; cfg2, where that chain is short: 5820 -> 5500, so not there)
-            pad = int(pad) if pad is not None else (4096 if (self.on["col"] or self.on["con"]) and C == 1 else 0)
-            # the raster's launch order follows the measured cost of its workgroups from iteration to iteration
-            # (hm_tune_raster_reorder; same-box A/B: raster 57 -> 45 us inside the graph at one clip, 356 -> 298 us at eight; the
-            # iteration: clip batches and the step-2 sets +0.3..1 %, one-clip step-1 fits +4 % in the steady state and over
-            # iterations 5-25 - but only since the metric-only search got shorter: while the hand-side chain was as long as the
-            # silhouette chain it had been running in the raster's tail and a shorter raster pushed it under the sweeps, -4 %)
-            ro = int(os.environ.get("HOMAN_RASTER_REORDER", "1"))
-            # and for the metric-only search of a clip batch: its 1680 small, latency-bound workgroups otherwise take every wave
-            # slot of the CUs next to the line expansion (lines 250 -> 226 us, iteration -4.4 % at 3 search workgroups per CU;
-            # 2 per CU make the search itself the tail)
-            nn_pad = os.environ.get("HOMAN_NN_PAD")
-            # (34 KB: with the sweep's 30.5 KB workgroups a CU then holds 4 sweeps + 1 search, 2 + 2 or 1 + 3 - the mixes the
-            #  40 KB ballast gave next to the 28.9 KB workgroups of the float sweeps; at 40 KB the search found room only
-            #  next to THREE sweep workgroups and took 297 instead of 137 us, same-box profile)
-            nn_pad = int(nn_pad) if nn_pad is not None else (34816 if C > 1 and not self.on["con"] else 0)
-            fam_pads = [int(x) for x in os.environ.get("HOMAN_FAM_PADS", "0,0,0,0,0").split(",")]
-            # the hints are process-wide values read when a launch is issued (= captured): set, capture, restore - whatever
-            # happens in between (a capture that raises must not leave them changed for the next stepper)
-            tune = _lib.lib()
-            prev = tune.hm_tune_sweep_blocks(sb)
-            prev_pad = tune.hm_tune_raster_lds_pad(pad)
-            prev_reorder = tune.hm_tune_raster_reorder(ro)
-            prev_nn_pad = tune.hm_tune_nn_lds_pad(nn_pad)
-            prev_fam = [tune.hm_tune_lds_pad(i, v) for i, v in enumerate(fam_pads)]
-            prev_rc = tune.hm_tune_rigid_chunked(int(os.environ.get("HOMAN_RIGID_CHUNKED", "1")))
-            try:
-                self.graph = _lib.new_graph()
-                with torch.cuda.graph(self.graph, stream=self.cap_stream):
-                    self.forward_backward(log=not self.log_in_adam)
-                    if not self.shared_scale:
-                        self.opt.step(zero_grad=False, log=self._adam_log())
-                if self.shared_scale:        # the all-reduce of the scale gradient runs between two captured halves
-                    self.graph_b = _lib.new_graph()
-                    with torch.cuda.graph(self.graph_b, stream=self.cap_stream):
-                        self._spread_shared_scale_grad()
-                        self.opt.step(zero_grad=False)
-                elif self.graph_iters > 1:
-                    # K iterations in ONE graph: the boundary between two replays (the executor's own start-up, a few
-                    # microseconds of an iteration that lasts 160) is paid once per K iterations; run() replays this graph
-                    # for every full K and the one-iteration graph for the rest - the same launches either way
-                    self.graph_k = _lib.new_graph()
-                    with torch.cuda.graph(self.graph_k, stream=self.cap_stream):
-                        for _ in range(self.graph_iters):
-                            self.forward_backward(log=not self.log_in_adam)
-                            self.opt.step(zero_grad=False, log=self._adam_log())
-            finally:
-                tune.hm_tune_sweep_blocks(prev)
-                tune.hm_tune_raster_lds_pad(prev_pad)
-                tune.hm_tune_raster_reorder(prev_reorder)
-                tune.hm_tune_nn_lds_pad(prev_nn_pad)
-                for i, v in enumerate(prev_fam):
-                    tune.hm_tune_lds_pad(i, v)
-                tune.hm_tune_rigid_chunked(prev_rc)
-
-    # ---- other clips into the resident stepper
-    def reload(self, clip_inputs):
-        """`clip_inputs`: one dict of HOMan data arguments per clip of the batch (what `collate_inputs` returns, + camintr),
-        clips of exactly the shapes and topology this stepper was built for.  Everything that depends on the clip is copied in
-        place - Parameters, buffers, per-clip normalisers, the search's bounding spheres - and everything that depends on the
-        FIT is reset - Adam moments, step counter, loss slots -; buffers, workspaces, streams and the captured hipGraph are
-        reused as they are.  The next `run(steps)` is the fit of the new clips, bit-identical to the fit a freshly built
-        stepper would make (tests/test_clip_fitter_gpu.py)."""
-        m = self.model
-        if self.on["depth"] and m.C > 1:
-            raise NotImplementedError("reload: the depth term's per-clip instance masks of a clip batch are not resident")
-        if len(clip_inputs) != m.C:
-            raise ValueError(f"reload: {len(clip_inputs)} clips for a stepper of {m.C}")
-        from .clipbatch import _PER_CLIP, _PER_FRAME
-        with torch.no_grad():
-            for c, (one, kw) in enumerate(zip(m.models, clip_inputs)):
-                one.load_clip(**kw)
-                if m.C > 1:     # the batch's own concatenated copies of the BUFFERS (Parameters are views of its storage)
-                    for k in _PER_FRAME + _PER_CLIP:
-                        if hasattr(m, k) and not isinstance(getattr(m, k), torch.nn.Parameter):
-                            m.clip_slice(getattr(m, k), c).copy_(getattr(one, k))
-                    m.keep_sum[c:c + 1].copy_(one.losses.keep_sum)
-            if m.C > 1:
-                m.sil_ctx.invalidate_outputs()
-            sx = m.sil_ctx
-            if sx.padded:       # (unpadded: these ARE the model's tensors)
-                self.sil_K.copy_(sx.K_eff(m.camintr_rois_object))
-                self.sil_keep.copy_(sx.pad(m.keep_mask_object))
-                self.sil_ref.copy_(sx.pad(m.ref_mask_object))
-            self.obj_spheres.copy_(self._group_spheres())
-            if self.on["depth"] and self.h == 1:     # (two hands: the layers' masks are the model's own tensors, copied in place)
-                self.dctx = m.models[0].depth_contexts()
-            for st_m, st_v in self.opt.state:
-                st_m.zero_()
-                st_v.zero_()
-            self.opt.step_t.zero_()
-            self.vals.zero_()
-            for p in m.parameters():
-                if p.grad is not None:
-                    p.grad.zero_()
-            if self.shared_scale:
-                self._sync_shared_scale_start()
-
-    def _group_spheres(self):
-        """bounding spheres, in MESH space, of the groups of 64 object vertices in `obj_order`, per frame: (B, groups, 4)"""
-        m, Vo, B = self.model, self.Vo, self.B
-        ng = (Vo + 63) // 64
-        vs = m.verts_object_og.detach()[:, self.obj_order.long()]
-        pad = ng * 64 - Vo
-        valid = torch.ones(Vo + pad, dtype=torch.bool, device=vs.device)
-        if pad:
-            vs = torch.cat([vs, vs[:, -1:].expand(-1, pad, -1)], 1)
-            valid[Vo:] = False
-        grp = vs.reshape(B, ng, 64, 3)
-        wgt = valid.reshape(1, ng, 64, 1).float()
-        ctr = (grp * wgt).sum(2) / wgt.sum(2)
-        rad = ((grp - ctr[:, :, None]) ** 2).sum(-1).sqrt().amax(2)
-        return torch.cat([ctr, rad[..., None]], -1).contiguous()
-
-    # ---- shared object scale (BASELINE cfg5): C local replicas of one scalar, kept identical on every rank
-    def _dist_on(self):
-        import torch.distributed as dist
-        return (self.collectives and dist.is_available() and dist.is_initialized() and
-                dist.get_world_size(self.group) > 1)
-
-    def _sync_shared_scale_start(self):
-        import torch.distributed as dist
-        s = self.model.int_scales_object
-        with torch.no_grad():
-            s0 = s.data[:1].clone()              # one element on the wire whatever the number of local clips
-            if self._dist_on():
-                from .dist import broadcast_shared_scalar, group_src
-                broadcast_shared_scalar(s0, group_src(self.group), self.group)
-            s.copy_(s0.expand_as(s))
-        self.g_shared = torch.zeros(1, device=s.device)
-
-    def _reduce_shared_scale_grad(self):
-        """One fp32 per step over xGMI: sum over ranks of (sum over local clips of d loss / d scale), on the compute
-        stream, no host synchronisation."""
-        if self._dist_on():
-            from .dist import sync_shared_scalar_grad
-            sync_shared_scalar_grad(self.g_shared, self.group)
-
-    def _spread_shared_scale_grad(self):
-        # every replica receives the global sum (identical Adam steps keep the replicas bit-identical)
-        g = self.model.int_scales_object.grad
-        g.copy_(self.g_shared.expand_as(g))
-
-    def _reported(self, k):
-        o = self.on
-        return {"loss_pca": o["pca"], "loss_scale_obj": o["so"], "loss_scale_hand": o["sh"], "loss_smooth_obj": o["smooth"],
-                "loss_smooth_hand": o["smooth"], "loss_collision": o["col"], "loss_contact": o["con"],
-                "loss_v2d_hand": o["v2d"], "v2d_hand": o["v2d"], "loss_sil_obj": o["sil"], "iou_object": o["sil"],
-                "loss_inter": o["inter"], "handobj_maxdist": o["inter"], "loss_depth": o["depth"]}[k]
-
-    def _slot(self, name):
-        """device address of slot `name` of clip 0; clip c is `self.NS` floats further (the kernels' out_stride)"""
-        i = self.SLOTS.index(name)
-        return self.vals.data_ptr() + 4 * i
-
-    def forward_backward(self, log=False):
-        """Two concurrent branches (fork/join on HIP streams, captured as parallel branches of the hipGraph):
-        A (calling stream): object transform, silhouettes forward/backward, object gradients;
-        B (side stream):    MANO, hand transform, priors, 2-D / smoothness / collision / contact / interaction losses,
-                            hand gradients, MANO backward.
-        B waits for the object vertices before the pair-wise losses, A waits for B's object-side gradient terms, both
-        join before the log row and the Adam step.  Every launch covers all the clips of the batch (clip_len frames
-        each, per-clip scalars NS floats apart in `vals`)."""
-        if self.h > 1:
-            return self._forward_backward_hands(log)
-        m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
-        B, Vo, Vh, c, on, w = self.B, self.Vo, self.Vh, self.c, self.on, self.w
-        CL, NS, C = self.clip_len, self.NS, self.C
-        main = torch.cuda.current_stream()
-        side = self.side
-        sa, sb = main.cuda_stream, side.cuda_stream
-        rws_a, rws_b = P(m.reduce_ws.buf), P(self.reduce_ws_b.buf)
-        sctx, cctx = m.sil_ctx, m.collision_ctx
-        pca, rot, betas = m.mano_pca_pose, m.mano_rot, m.mano_betas
-        mtr = m.mano_trans if m.optimize_mano else None
-        npca = self.P * CL                       # PCA entries of one clip
-        side.wait_stream(main)
-        use_aux = self.use_aux
-
-        def tail_block(stream_obj):
-            if on["sil"] and not self.sil_reduce_in_bwd:
-                ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
-                                         P(sctx.workspace), CL, NS, stream_obj.cuda_stream), "sil_reduce")
-            if log:
-                ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
-                                        self.max_steps, P(self.log_buf), C, stream_obj.cuda_stream), "log")
-
-        def aux_block():
-            if not use_aux:
-                return
-            # the silhouette reduction and the log row run on a third stream, off both chains.  (Only this: HIP stream
-            # capture crashes when two captured streams wait for each other's events in both directions, and the hipGraph
-            # executor maps richer fork patterns onto its hardware queues in orders that serialise the branches -- both
-            # measured.  WHERE this block is issued matters too: issued after the hand-side backward, the executor runs it
-            # behind that chain, +20 us on the iteration.)
-            with torch.cuda.stream(self.aux):
-                self.aux.wait_event(self.ev_fwd)
-                if on["smooth"] and self.smooth_obj_on_main:
-                    self.aux.wait_event(self.ev_smo)         # (that loss value comes from the calling stream here)
-                if on["sil"] and not self.sil_reduce_in_bwd:
-                    self.aux.wait_event(self.ev_ras)
-                    ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
-                                             P(sctx.workspace), CL, NS, self.aux.cuda_stream), "sil_reduce")
-                if log:
-                    ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
-                                            self.max_steps, P(self.log_buf), C, self.aux.cuda_stream), "log")
-        # ---------------- A: silhouettes forward + backward (the critical chain: nothing else rides it; the object's rigid
-        # transform is applied inside the face setup, the other losses get the vertices from the side stream)
-        if on["sil"]:
-            fwd_args = (P(m.verts_object_og), P(sctx.faces), 0, P(self.sil_K), B, Vo, sctx.F, sctx.S,
-                        1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(self.sil_keep), P(self.sil_ref),
-                        None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
-                        P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, P(self.vo))
-            if self.fork_after_setup:
-                # the face setup (which also writes the camera-space vertices self.vo), the fork of the side stream, then the
-                # rasteriser: the pair-wise losses do not wait for the raster and the raster has one successor on its chain
-                ck(L.hm_sil_fwd_phase_clips(*fwd_args, 1, sa), "sil_fwd(setup)")
-                self.ev_sil.record(main)
-                ck(L.hm_sil_fwd_phase_clips(*fwd_args, 2, sa), "sil_fwd(raster)")
-                if use_aux and not self.sil_reduce_in_bwd:
-                    self.ev_ras.record(main)     # the tile partials of the fused loss, for the reduction on the third stream
-            else:
-                ck(L.hm_sil_fwd_clips(*fwd_args, sa), "sil_fwd")      # (also writes the camera-space vertices self.vo)
-                self.ev_sil.record(main)         # self.vo for the side stream
-                if use_aux and not self.sil_reduce_in_bwd:
-                    self.ev_ras.record(main)
-            if on["depth"]:
-                # the OBJECT's depth render of the ordinal depth term rides this chain, right behind the silhouette raster (its
-                # vertices are the face setup's): the hand's render runs on the side stream meanwhile - two renders after each
-                # other there made the hand side twice as long as this chain
-                self._depth_render(self.vo, self.dctx[0], Vo, self.d_sil_o, self.d_dep_o, sa)
-                self.ev_dep.record(main)
-            bwd_args = (P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps,
-                        2 if self.lw["lw_sil_obj"] > 0 else 1,
-                        P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items),
-                        P(sctx.face_order), None, None, P(sctx.workspace), CL,
-                        self._slot("loss_sil_obj") if self.sil_reduce_in_bwd else None, NS)
-            q2 = sctx.sum_log2q          # grid of the order-independent sums (the same for the sweeps and the rigid backward)
-            # (no vertex gather; the loss / IoU values come out of its first launch)
-            if self.pairs_after_lines:
-                # a clip batch: the line expansion - latency-bound, and the kernel of this chain that suffers most from
-                # neighbours holding its wave slots - runs ALONE; the pair-wise terms of the side stream wait for its end
-                ck(L.hm_sil_bwd_phase_clips(*bwd_args, 1, q2, sa), "sil_bwd(lines)")
-                self.ev_lines.record(main)
-                ck(L.hm_sil_bwd_phase_clips(*bwd_args, 2, q2, sa), "sil_bwd(sweeps)")
-            else:
-                ck(L.hm_sil_bwd_clips(*bwd_args, q2, sa), "sil_bwd")
-        # ---------------- B: hand forward, pair-wise losses, hand backward
-        with torch.cuda.stream(side):
-            if not on["sil"]:    # (with the silhouette term the face setup of hm_sil_fwd has written self.vo already)
-                ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
-                                        P(m.int_scales_object), 1, B, Vo, None, P(self.vo), CL, sb), "rigid_fwd(obj)")
-                self.ev_vo.record(side)
-            if m.optimize_mano:
-                ck(L.hm_mano_fwd_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
-                                       P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
-                                       P(self.mano_state), CL, sb),
-                   "mano_fwd + rigid(hand)")
-            else:           # the hand mesh is the constant `verts_hand_og` (reference homan.py:357-358): rigid transform only
-                ck(L.hm_rigid_fwd_clips(P(m.verts_hand_og), P(m.rotations_hand), P(m.translations_hand),
-                                        P(m.int_scales_hand), 0, B, Vh, None, P(self.vh), CL, sb), "rigid_fwd(hand)")
-            pri = on["pca"] or on["so"] or on["sh"]
-            # pair terms that feed nothing to each other go in ONE launch (csrc/pairterms.hip): the interaction term, the
-            # object's smoothness when it rides this stream, the metric-only search (no contact term) and the hand-only
-            # reductions
-            sm_here = on["smooth"] and not self.smooth_obj_on_main
-            fuse = self.pair_fused and on["inter"] and Vo <= 4096 and not self.inter_min
-            nn_fused = fuse and not on["con"]
-            # with the contact term the FULL search (nearest object vertex of every hand vertex) is the launch's first block
-            # range instead, and the contact launches follow it: one launch less on the hand-side chain of the step-2 sets
-            nn_full_fused = fuse and on["con"] and self.nn_full_fused
-            ht_fused = fuse and self.hand_terms_fused and on["smooth"] and on["v2d"]
-            ht_args = (P(m.ref_verts2d_hand), float(m.image_size), P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
-                       self._slot("loss_smooth_hand"), P(pca) if pri else None, npca,
-                       P(m.int_scales_object), P(m.int_scale_object_mean), P(m.int_scales_hand),
-                       P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh), self._slot("loss_pca"))
-            if ht_fused:
-                pass
-            elif on["smooth"] and on["v2d"]:       # the three hand-only reductions in one launch
-                ck(L.hm_hand_terms_fwd_clips(P(self.vh), P(m.camintr), 1, ht_args[0], ht_args[1], B, Vh, *ht_args[2:], rws_b, CL,
-                                             NS, sb), "hand terms")
-            else:
-                if pri:
-                    ck(L.hm_priors_fwd_clips(P(pca), npca, P(m.int_scales_object), P(m.int_scale_object_mean),
-                                             P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
-                                             P(self.U_sh), self._slot("loss_pca"), C, NS, sb), "priors")
-                if on["smooth"]:
-                    ck(L.hm_smooth_fwd_clips(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws_b,
-                                             CL, NS, sb), "smooth(hand)")
-                if on["v2d"]:
-                    ck(L.hm_v2d_fwd_clips(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
-                                          P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, CL, NS, sb), "v2d")
-            nn_early = False
-            if on["sil"]:
-                side.wait_event(self.ev_sil)         # self.vo: camera-space object vertices from the calling stream
-                if self.pairs_after_lines:
-                    # (the metric-only search - it feeds nothing but the logged hand-object distance, and is the longest
-                    #  launch of the hand side in a batch - can run before that wait, next to the rasteriser)
-                    nn_early = self.nn_early and on["inter"] and not on["con"] and Vo <= 4096 and not self.inter_min
-                    if nn_early:
-                        ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, None, None, self._slot("handobj_maxdist"),
-                                                   rws_b, CL, NS, P(self.obj_order),
-                                                   (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                                   P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sb), "nn")
-                    side.wait_event(self.ev_lines)   # (scheduling only, see the silhouette chain above)
-                elif self.pairs_after_raster:
-                    side.wait_event(self.ev_ras)     # (scheduling only, see __init__)
-            # one clip, step-2 sets: the collision term (five SDF launches) and the search / contact / interaction launches
-            # both start from the two vertex buffers and feed nothing to each other.  The collision chain stays on this
-            # stream; everything else of the hand side - and, behind both, the hand's gradient launches - moves to the third
-            # stream, which joins the calling stream (the HIP graph runtime crashes at replay when a forked stream rejoins
-            # the SIDE stream: measured twice; forks that rejoin the origin are fine)
-            split = on["col"] and self.col_on_aux and not use_aux
-            side2, sb2 = (self.aux, self.aux.cuda_stream) if split else (side, sb)
-            if on["col"]:
-                if split:
-                    self.ev_hand.record(side)        # both vertex buffers exist on this stream from here on
-                ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
-                                            cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
-                                            self._slot("loss_collision"), P(cctx.ws), CL, NS, sb), "collision")
-                if split:
-                    self.ev_col.record(side)
-                    side2.wait_event(self.ev_hand)
-            if sm_here and not fuse:
-                ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
-                                         sb2), "smooth(obj)")
-            def search_and_contact(stream_obj, rws):
-                sx = stream_obj.cuda_stream
-                if (on["con"] or on["inter"]) and not nn_fused and not nn_full_fused and not nn_early:
-                    # (without the contact term only the logged distance is needed: metric-only search - its group table
-                    #  covers 4096 object vertices, larger meshes take the full search for the same number)
-                    full = on["con"] or Vo > 4096 or self.inter_min      # ('min' names the closest PAIR: indices needed)
-                    ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if full else None,
-                                               P(self.nn_d2) if full else None, self._slot("handobj_maxdist"), rws, CL, NS,
-                                               P(self.obj_order), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                               P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sx), "nn")
-                if on["con"]:
-                    ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
-                                              P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws, CL, NS, sx),
-                       "contact")
-            # (the search on a third stream at one clip / step 1: +1 %; -9 % on an 8-clip batch.  Search + contact as a third
-            #  branch next to the collision term: the HIP graph runtime crashes at replay when two side branches wait for
-            #  each other's events.  Capturing the hand-side forward kernels BEFORE the silhouette chain: -38 %.)
-            if not nn_full_fused:
-                search_and_contact(side2, rws_b)
-            if fuse:
-                ck(L.hm_pair_terms_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo,
-                                             self._slot("handobj_maxdist") if (nn_fused or nn_full_fused) else None,
-                                             P(self.obj_order), rws_b,
-                                             c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(self.rec),
-                                             self._slot("loss_inter"), P(self.reduce_ws_c.buf),
-                                             P(self.U_smo) if sm_here else None,
-                                             self._slot("loss_smooth_obj") if sm_here else None, P(self.reduce_ws_d.buf),
-                                             *(ht_args if ht_fused else (None, 0.0, None, None, None, None, None, 0, None, None,
-                                                                         None, None, None, None, None, None)),
-                                             P(self.reduce_ws_e.buf), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                             P(m.translations_object), P(m.int_scales_object), P(self.hand_order),
-                                             P(self.nn_idx) if nn_full_fused else None, P(self.nn_d2) if nn_full_fused else None,
-                                             CL, NS, sb2),
-                   "pair terms")
-                if nn_full_fused:
-                    search_and_contact(side2, rws_b)          # (the contact launches only: the search ran above)
-            elif on["inter"]:
-                ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
-                                        float(c.INTERACTION_Z_THRESH), P(self.rec),
-                                        P(self.tmp_inter) if self.inter_min else self._slot("loss_inter"), rws_b, CL,
-                                        NS, sb2), "inter")
-            if on["inter"] and self.inter_min:
-                with torch.cuda.stream(side2):
-                    # inter_type "min" (losses.py:219-221): on the frames the gate lets through (rec[:, 0], same gate as the
-                    # centroid form) the smallest squared vertex distance; the search names the pair, the term and its
-                    # gradient live on the two vertices (hand: rigid pose only - the mesh-detached twin; object: only with a free
-                    # scale).  A handful of small device ops, same expressions as Losses.compute_interaction_loss.
-                    flags = (self.rec[:, 0] != 0).float()
-                    i_star = self.nn_d2.argmin(1)
-                    j_star = self.nn_idx.gather(1, i_star[:, None]).long()[:, 0]
-                    diff = self.vh[self.rows, i_star] - self.vo[self.rows, j_star]
-                    self.vals[0, self.SLOTS.index("loss_inter")] = ((diff * diff).sum(1) * flags).sum()
-                    pull = (2.0 * w["loss_inter"]) * diff * flags[:, None]
-                    self.G_min_h.zero_()
-                    self.G_min_h[self.rows, i_star] = pull
-                    if m.optimize_object_scale:
-                        self.G_int_o.zero_()
-                        self.G_int_o[self.rows, j_star] = -pull
-            elif on["inter"] and m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
-                ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb2), "inter_bwd")
-            if on["depth"]:
-                ctx_o, ctx_h, m_o, m_h = self.dctx
-                Sd, K = ctx_o.S, P(m.camintr)
-                self._depth_render(self.vh, ctx_h, Vh, self.d_sil_h, self.d_dep_h, sb2)
-                if on["sil"]:
-                    side2.wait_event(self.ev_dep)        # the object's depth image, from the calling stream
-                else:
-                    self._depth_render(self.vo, ctx_o, Vo, self.d_sil_o, self.d_dep_o, sb2)
-                rw_bytes = L.hm_reduce_workspace_bytes()
-                for ci in range(C):           # per clip: the term normalises over the clip's own pairs and mask counts
-                    fr = slice(ci * CL, (ci + 1) * CL)
-                    args = (P(self.d_dep_o[fr]), P(self.d_dep_h[fr]), P(self.d_sil_o[fr]), P(self.d_sil_h[fr]), P(m_o[fr]),
-                            P(m_h[fr]), CL, Sd)
-                    ck(L.hm_ordinal_depth_fwd(*args, P(self.d_part[8 * ci * CL:]), P(self.d_rec[ci]),
-                                              self._slot("loss_depth") + 4 * NS * ci,
-                                              self.rws_depth.buf.data_ptr() + rw_bytes * ci, sb2), "ordinal depth")
-                    ck(L.hm_ordinal_depth_bwd(*args, P(self.d_rec[ci]), P(self.up_depth), P(self.d_go[fr]), P(self.d_gh[fr]),
-                                              sb2), "ordinal depth bwd")
-                # the two depth images' backward passes are independent: the hand's stays here, the object's goes to the
-                # calling stream (idle between its sweeps and the object's gradient launch) when that stream made the render
-                self.ev_dgrad.record(side2)
-                for verts, ctx, V_, g, G in (((self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h),) if on["sil"] else
-                                             ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o),
-                                              (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h))):
-                    ck(L.hm_depth_bwd(P(verts), K, B, V_, ctx.F, Sd, 1.0, P(g), P(ctx.adj_off), P(ctx.adj_items), P(G),
-                                      P(ctx.workspace), sb2), "depth bwd")
-            if split:
-                side2.wait_event(self.ev_col)    # the collision term's hand gradients, from the side stream
-            self.ev_fwd.record(side2)         # every forward loss value of this stream exists now
-            if not self.smooth_obj_on_main:
-                aux_block()
-            self.ev_pair.record(side2)        # object-side terms of the pair-wise losses are ready
-            # hand (full path: MANO + rigid): smooth + v2d + collision + contact, summed with their weights inside the rigid
-            # backward; the interaction term reaches the rigid pose only, as one vector per frame (rec[:, 2:5] / Vh)
-            tp, tw, tn = _lib.terms([(self.U_smh if on["smooth"] else None, w["loss_smooth_hand"]),
-                                     (self.U_v2d if on["v2d"] else None, w["loss_v2d_hand"]),
-                                     (self.U_colh if on["col"] else None, w["loss_collision"]),
-                                     (self.U_conh if on["con"] else None, w["loss_contact"]),
-                                     (self.G_dep_h if on["depth"] else None, 1.0)])       # (already times its weight)
-            g_rig = P(self.G_min_h) if (on["inter"] and self.inter_min) else None
-            g_frm = (self.rec.data_ptr() + 8) if (on["inter"] and not self.inter_min) else None
-            if m.optimize_mano and self.mano_bwd_rigid:
-                # the hand's rigid backward inside the MANO backward's launch: one launch less on this chain
-                ck(L.hm_mano_bwd_rigid_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B,
-                                             P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
-                                             P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)),
-                                             P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), tp, tw, tn, g_rig, g_frm, 8,
-                                             w["loss_inter"] / Vh, P(m.rotations_hand.grad), P(m.translations_hand.grad), CL,
-                                             sb2), "mano_bwd + rigid_bwd(hand)")
-            else:
-                ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
-                                        P(m.int_scales_hand), 0, tp, tw, tn, g_rig, g_frm, 8, w["loss_inter"] / Vh, B, Vh,
-                                        P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
-                                        P(m.translations_hand.grad), None, P(self.rigid_ws_h), CL, sb2), "rigid_bwd(hand)")
-                if m.optimize_mano:
-                    ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
-                                     P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
-                                     P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb2),
-                       "mano_bwd")
-        # ---------------- A: object backward: silhouette gradient + smooth + contact [+ interaction with a free scale],
-        # summed with their weights inside the rigid backward
-        if on["smooth"] and self.smooth_obj_on_main:
-            # the object's smoothness term only feeds the object's pose gradients: it rides the silhouette chain (behind the
-            # sweeps) instead of lengthening the hand-side chain, which is the longer one at one clip
-            if not on["sil"]:
-                main.wait_event(self.ev_vo)
-            ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_a, CL, NS,
-                                     sa), "smooth(obj)")
-            self.ev_smo.record(main)
-        if self.smooth_obj_on_main:
-            aux_block()
-        if on["depth"] and on["sil"]:
-            main.wait_event(self.ev_dgrad)       # d loss / d (object's depth image), from the side stream
-            ctx_o = self.dctx[0]
-            ck(L.hm_depth_bwd(P(self.vo), P(m.camintr), B, Vo, ctx_o.F, ctx_o.S, 1.0, P(self.d_go), P(ctx_o.adj_off),
-                              P(ctx_o.adj_items), P(self.G_dep_o), P(ctx_o.workspace), sa), "depth bwd(obj)")
-        sc_obj = m.optimize_object_scale
-        # the object's smoothness gradient is formed INSIDE the rigid backward from the camera-space vertices the face setup
-        # wrote (same floats as the unit gradient of the smoothness launch times its weight): on the step-1 sets this chain
-        # then needs nothing from the side stream before the join - one cross-queue edge less on the iteration's tail
-        sm_in = on["smooth"] and on["sil"] and Vo <= 24576 and os.environ.get("HOMAN_SMOOTH_IN_RIGID", "1") != "0"
-        side_terms = on["con"] or (on["inter"] and sc_obj) or (on["smooth"] and not sm_in) or not on["sil"]
-        if side_terms:
-            main.wait_event(self.ev_pair)
-        tp, tw, tn = _lib.terms([(self.U_smo if (on["smooth"] and not sm_in) else None, w["loss_smooth_obj"]),
-                                 (self.U_cono if on["con"] else None, w["loss_contact"]),
-                                 (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0),
-                                 (self.G_dep_o if on["depth"] else None, 1.0)])
-        if on["sil"]:       # the silhouette term is gathered from the sweeps' per-corner gradients inside this launch
-            ck(L.hm_rigid_bwd_sil_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn,
-                                        L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
-                                        P(sctx.adj_items), P(self.vo), P(self.sil_K), 1.0, sctx.F, B, Vo,
-                                        P(m.rotations_object.grad), P(m.translations_object.grad),
-                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sctx.sum_log2q,
-                                        P(self.vo) if sm_in else None, w["loss_smooth_obj"], sa),
-               "rigid_bwd(obj) + silhouette gather")
-        else:
-            ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
-                                    None, 0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
-                                    P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sa), "rigid_bwd(obj)")
-        if not use_aux:
-            # two streams only: the silhouette reduction rides the tail of the silhouette chain (the shorter one at one
-            # clip), the log row follows the join
-            if on["sil"] and not self.sil_reduce_in_bwd:
-                ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
-                                         P(sctx.workspace), CL, NS, sa), "sil_reduce")
-        main.wait_stream(side)               # join
-        if use_aux or (on["col"] and self.col_on_aux):
-            main.wait_stream(self.aux)
-        elif log:
-            ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
-                                    self.max_steps, P(self.log_buf), C, sa), "log")
-        if sc_obj:          # per clip: sum of the frames' d loss / d scale + the scale prior's term
-            ck(L.hm_sum_small_clips(P(self.g_so_part), CL, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
-                                    P(m.int_scales_object.grad), C, sa), "scale grad")
-            if self.shared_scale:
-                # ONE scalar tied across the clips: its gradient is the sum of the replicas' gradients - local clips
-                # here, ranks in _reduce_shared_scale_grad
-                ck(L.hm_sum_small_clips(P(m.int_scales_object.grad), C, 1.0, None, 0.0, P(self.g_shared), 1, sa),
-                   "shared scale grad")
-
-    def _forward_backward_hands(self, log=False):
-        """The iteration for TWO hands per frame (reference homan.py:341-358, lossutils.py:51-59,116-127, losses.py:207-241),
-        one clip.  Hand rows are interleaved frame-major [h0_t0, h1_t0, h0_t1, ...] like the model's Parameters: the MANO
-        launches walk the strided slice of their hand through its side's model (hm_mano_*_rows), the hand-only terms and the
-        rigid backward run once over all rows (the kernels' hand_nb), and the pair-wise terms see each hand as a dense copy:
-        contact = mean over the hands, interaction = their sum, collision = the three two-mesh scenes (h0|h1), (h0|obj),
-        (h1|obj), logged distance = largest per-frame distance to the NEAREST hand.  Same kernels and values as
-        HOMan.forward + autograd; not tuned like the one-hand sequence (no fused pair-term launch)."""
-        m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
-        B, N, h, Vo, Vh, c, on, w = self.B, self.N, self.h, self.Vo, self.Vh, self.c, self.on, self.w
-        NS = self.NS
-        main, side = torch.cuda.current_stream(), self.side
-        sa, sb = main.cuda_stream, side.cuda_stream
-        rws_a, rws_b = P(m.reduce_ws.buf), P(self.reduce_ws_b.buf)
-        sctx, cctx = m.sil_ctx, m.collision_ctx
-        pca, rot, betas = m.mano_pca_pose, m.mano_rot, m.mano_betas
-        mtr = m.mano_trans if m.optimize_mano else None
-        slot = self._slot
-        side.wait_stream(main)
-        # ---------------- A: silhouettes forward + backward (as in the one-hand sequence)
-        if on["sil"]:
-            fwd_args = (P(m.verts_object_og), P(sctx.faces), 0, P(self.sil_K), B, Vo, sctx.F, sctx.S,
-                        1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(self.sil_keep), P(self.sil_ref),
-                        None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
-                        P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), 0, NS, P(self.vo))
-            ck(L.hm_sil_fwd_phase_clips(*fwd_args, 1, sa), "sil_fwd(setup)")
-            self.ev_sil.record(main)
-            ck(L.hm_sil_fwd_phase_clips(*fwd_args, 2, sa), "sil_fwd(raster)")
-            ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps,
-                                  2 if self.lw["lw_sil_obj"] > 0 else 1, P(self.up_sil), None, P(m.keep_sum),
-                                  P(sctx.adj_off), P(sctx.adj_items), P(sctx.face_order), None, None, P(sctx.workspace), 0,
-                                  slot("loss_sil_obj"), NS, sctx.sum_log2q, sa), "sil_bwd")
-        # ---------------- B: hands
-        with torch.cuda.stream(side):
-            if not on["sil"]:
-                ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
-                                        P(m.int_scales_object), 1, B, Vo, None, P(self.vo), 0, sb), "rigid_fwd(obj)")
-                self.ev_vo.record(side)
-            if m.optimize_mano:
-                for i, hctx in enumerate(self.hand_ctx):       # hand i = rows i::h through the model of its side
-                    ck(L.hm_mano_fwd_rows(hctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
-                                          P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
-                                          P(self.mano_state), 0, i, h, sb), "mano_fwd + rigid(hand %d)" % i)
-            else:
-                ck(L.hm_rigid_fwd_clips(P(m.verts_hand_og), P(m.rotations_hand), P(m.translations_hand),
-                                        P(m.int_scales_hand), 0, N, Vh, None, P(self.vh), 0, sb), "rigid_fwd(hands)")
-            if on["pca"] or on["so"] or on["sh"]:
-                ck(L.hm_priors_fwd_clips(P(pca), self.P * N, P(m.int_scales_object), P(m.int_scale_object_mean),
-                                         P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
-                                         P(self.U_sh), slot("loss_pca"), 1, NS, sb), "priors")
-            if on["smooth"]:
-                ck(L.hm_smooth_fwd_clips(P(self.vh), N, Vh, h, P(self.U_smh), slot("loss_smooth_hand"), rws_b, 0, NS, sb),
-                   "smooth(hands)")
-            if on["v2d"]:
-                ck(L.hm_v2d_fwd_clips(P(self.vh), P(m.camintr), h, P(m.ref_verts2d_hand), float(m.image_size), N, Vh,
-                                      P(self.U_v2d), slot("loss_v2d_hand"), rws_b, 0, NS, sb), "v2d")
-            if on["sil"]:
-                side.wait_event(self.ev_sil)
-            if on["smooth"]:
-                ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), slot("loss_smooth_obj"), rws_b, 0, NS, sb),
-                   "smooth(obj)")
-            pairwise = on["con"] or on["inter"] or on["col"] or on["depth"]
-            if pairwise:
-                for i in range(h):
-                    self.vh_d[i].copy_(self.vh[i::h])
-            tmp = self.tmp_h
-            for i in range(h):
-                rws_i = P(self.rws_h[i].buf)
-                if on["con"] or on["inter"]:
-                    ck(L.hm_nn_fwd(P(self.vh_d[i]), P(self.vo), B, Vh, Vo, P(self.nn_idx_d[i]), P(self.nn_d2_d[i]),
-                                   tmp[i, 2:3].data_ptr(), rws_i, sb), "nn(hand %d)" % i)
-                if on["con"]:
-                    ck(L.hm_contact_fwd(P(self.vh_d[i]), P(self.vo), P(self.nn_idx_d[i]), B, Vh, Vo, c.COLLISION_THRESH,
-                                        P(self.U_conh_d[i]), P(self.U_cono_d[i]), tmp[i, 0:1].data_ptr(), rws_i, sb),
-                       "contact(hand %d)" % i)
-                if on["inter"]:
-                    ck(L.hm_inter_fwd(P(self.vh_d[i]), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
-                                      float(c.INTERACTION_Z_THRESH), P(self.rec_d[i]), tmp[i, 1:2].data_ptr(), rws_i, sb),
-                       "inter(hand %d)" % i)
-                    if m.optimize_object_scale:
-                        ck(L.hm_inter_bwd(P(self.rec_d[i]), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o_d[i]), sb),
-                           "inter_bwd(hand %d)" % i)
-            if on["col"]:
-                # scene [hand 0, hand 1, object] (lossutils.py:53-59): the three two-mesh scenes of HOMan.collision_ctx
-                scenes = ((self.vh_d[0], self.vh_d[1], self.U_col_d[0], self.U_col_d[1]),
-                          (self.vh_d[0], self.vo, self.U_col_d[2], self.U_colo_d),
-                          (self.vh_d[1], self.vo, self.U_col_d[3], self.U_colo_d))
-                for k, (cc, (va, vb, ga, gb)) in enumerate(zip(cctx, scenes)):
-                    ck(L.hm_collision_fwd(P(va), P(cc.f0), cc.V0, cc.f0.shape[0], P(vb), P(cc.f1), cc.V1, cc.f1.shape[0], B,
-                                          c.SDF_SCALE_FACTOR, P(ga), P(gb), self.tmp_col[k:k + 1].data_ptr(), P(cc.ws), sb),
-                       "collision(scene %d)" % k)
-            if on["depth"]:
-                # three depth renders at the full-image camera, the three pairs' ordinal terms, the scene's normaliser and
-                # every pair's share of it on the device, the pairs' backward passes with that share (times the weight) as
-                # upstream, a layer's two gradient images added, one depth-map backward per layer
-                Sd, K = self.dlayers[0][0].S, P(m.camintr)
-                lverts = [self.vo] + list(self.vh_d)
-                for li, (ctx, V_, _) in enumerate(self.dlayers):
-                    self._depth_render(lverts[li], ctx, V_, self.dl_sil[li], self.dl_dep[li], sb)
-                for k, (a, b) in enumerate(self.dpairs):
-                    ck(L.hm_ordinal_depth_fwd(P(self.dl_dep[a]), P(self.dl_dep[b]), P(self.dl_sil[a]), P(self.dl_sil[b]),
-                                              P(self.dlayers[a][2]), P(self.dlayers[b][2]), B, Sd, P(self.dp_part[k]),
-                                              P(self.dp_rec[k]), P(self.dp_out[k]), P(self.rws_dp[k].buf), sb), "ordinal depth")
-                present = [(sl == 1).flatten(1).any(1).sum().float() for sl in self.dl_sil]
-                npairs = [self.dp_rec[k][0] for k in range(len(self.dpairs))]
-                total = sum(present) + sum(npairs[k] - present[a] - present[b] for k, (a, b) in enumerate(self.dpairs))
-                loss = torch.zeros((), device=self.vo.device)
-                for k in range(len(self.dpairs)):
-                    share = torch.where(npairs[k] > 0, npairs[k] / total, torch.zeros_like(total))
-                    loss = loss + torch.where(npairs[k] > 0, self.dp_out[k][0] * share, torch.zeros_like(total))
-                    self.dp_up[k].copy_((w["loss_depth"] * share).reshape(1))
-                self.vals[0][self.SLOTS.index("loss_depth")] = loss
-                for li in range(len(self.dlayers)):
-                    self.dl_g[li].zero_()
-                for k, (a, b) in enumerate(self.dpairs):
-                    ga, gb = self.dp_g[k]
-                    ck(L.hm_ordinal_depth_bwd(P(self.dl_dep[a]), P(self.dl_dep[b]), P(self.dl_sil[a]), P(self.dl_sil[b]),
-                                              P(self.dlayers[a][2]), P(self.dlayers[b][2]), B, Sd, P(self.dp_rec[k]),
-                                              P(self.dp_up[k]), P(ga), P(gb), sb), "ordinal depth bwd")
-                    self.dl_g[a].add_(ga)
-                    self.dl_g[b].add_(gb)
-                gouts = [self.G_dep_o] + list(self.G_dep_h_d)
-                for li, (ctx, V_, _) in enumerate(self.dlayers):
-                    ck(L.hm_depth_bwd(P(lverts[li]), K, B, V_, ctx.F, Sd, 1.0, P(self.dl_g[li]), P(ctx.adj_off),
-                                      P(ctx.adj_items), P(gouts[li]), P(ctx.workspace), sb), "depth bwd")
-                for i in range(h):
-                    self.G_dep_h[i::h].copy_(self.G_dep_h_d[i])
-            # ---- the hands' values combined like the reference does, gradients back onto the interleaved rows
-            with torch.cuda.stream(side):
-                v0 = self.vals[0]
-                if on["con"]:
-                    v0[self.SLOTS.index("loss_contact")] = torch.stack([tmp[i, 0] for i in range(h)]).mean()
-                    for i in range(h):
-                        self.U_conh[i::h].copy_(self.U_conh_d[i])
-                if on["inter"]:
-                    v0[self.SLOTS.index("loss_inter")] = tmp[0, 1] + tmp[1, 1]
-                    per_frame = torch.stack([d.min(1)[0] for d in self.nn_d2_d]).min(0)[0]
-                    v0[self.SLOTS.index("handobj_maxdist")] = per_frame.max().clamp_min(0).sqrt()
-                    for i in range(h):
-                        self.rec[i::h].copy_(self.rec_d[i])
-                    if m.optimize_object_scale:
-                        torch.add(self.G_int_o_d[0], self.G_int_o_d[1], out=self.G_int_o)
-                if on["col"]:
-                    v0[self.SLOTS.index("loss_collision")] = (self.tmp_col[0] + self.tmp_col[1]) + self.tmp_col[2]
-                    self.U_colh[0::h].copy_(self.U_col_d[0])      # from the (h0|h1) scene ...
-                    self.U_colh[1::h].copy_(self.U_col_d[1])
-                    self.U_colh2[0::h].copy_(self.U_col_d[2])     # ... and from each hand's scene with the object
-                    self.U_colh2[1::h].copy_(self.U_col_d[3])
-            self.ev_pair.record(side)
-            if on["depth"] and on["col"]:
-                # (a rigid backward sums five weighted terms: with the depth term the two collision buffers share a slot -
-                #  another float summation order than without it, and nothing is written out for this combination)
-                self.U_colh.add_(self.U_colh2)
-            tp, tw, tn = _lib.terms([(self.U_smh if on["smooth"] else None, w["loss_smooth_hand"]),
-                                     (self.U_v2d if on["v2d"] else None, w["loss_v2d_hand"]),
-                                     (self.U_colh if on["col"] else None, w["loss_collision"]),
-                                     ((self.G_dep_h, 1.0) if on["depth"] else
-                                      (self.U_colh2 if on["col"] else None, w["loss_collision"])),
-                                     (self.U_conh if on["con"] else None, w["loss_contact"] / h)])
-            ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
-                                    P(m.int_scales_hand), 0, tp, tw, tn, None,
-                                    (self.rec.data_ptr() + 8) if on["inter"] else None, 8, w["loss_inter"] / Vh, N, Vh,
-                                    P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
-                                    P(m.translations_hand.grad), None, P(self.rigid_ws_h), 0, sb), "rigid_bwd(hands)")
-            if m.optimize_mano:
-                for i, hctx in enumerate(self.hand_ctx):
-                    ck(L.hm_mano_bwd_rows(hctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
-                                          P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
-                                          P(betas.grad), P(mtr.grad), P(self.mano_state), P(hctx.workspace(B)), i, h, sb),
-                       "mano_bwd(hand %d)" % i)
-        # ---------------- A: object backward
-        main.wait_event(self.ev_pair)
-        sc_obj = m.optimize_object_scale
-        tp, tw, tn = _lib.terms([(self.U_smo if on["smooth"] else None, w["loss_smooth_obj"]),
-                                 (self.U_cono_d[0] if on["con"] else None, w["loss_contact"] / h),
-                                 (self.U_cono_d[1] if on["con"] else None, w["loss_contact"] / h),
-                                 (self.G_int_o if (on["inter"] and sc_obj) else None, 1.0),
-                                 (self.G_dep_o if on["depth"] else None, 1.0)])
-        if on["sil"]:
-            ck(L.hm_rigid_bwd_sil_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn,
-                                        L.hm_sil_parts(P(sctx.workspace), B, Vo, sctx.F, sctx.S), P(sctx.adj_off),
-                                        P(sctx.adj_items), P(self.vo), P(self.sil_K), 1.0, sctx.F, B, Vo,
-                                        P(m.rotations_object.grad), P(m.translations_object.grad),
-                                        P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), 0, sctx.sum_log2q, None, 0.0, sa),
-               "rigid_bwd(obj) + silhouette gather")
-        else:
-            ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
-                                    None, 0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
-                                    P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), 0, sa), "rigid_bwd(obj)")
-        main.wait_stream(side)
-        if log:
-            ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t), self.max_steps,
-                                    P(self.log_buf), 1, sa), "log")
-        if sc_obj:
-            ck(L.hm_sum_small_clips(P(self.g_so_part), B, 1.0, P(self.U_so) if on["so"] else None, w["loss_scale_obj"],
-                                    P(m.int_scales_object.grad), 1, sa), "scale grad")
-
-    def sil_chain_only(self):
-        """Measurement helper (tools/bench_sil_kernels.py --chain): just the silhouette chain of an iteration - face setup,
-        raster, lines, sweeps - on the current stream, with nothing on any other stream."""
-        m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
-        sctx, B, Vo, CL, NS = m.sil_ctx, self.B, self.Vo, self.clip_len, self.NS
-        sa = torch.cuda.current_stream().cuda_stream
-        ck(L.hm_sil_fwd_clips(P(m.verts_object_og), P(sctx.faces), 0, P(self.sil_K), B, Vo, sctx.F, sctx.S,
-                              1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(self.sil_keep), P(self.sil_ref),
-                              None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
-                              P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, P(self.vo),
-                              sa), "sil_fwd")
-        ck(L.hm_sil_bwd_clips(P(self.vo), P(self.sil_K), B, Vo, sctx.F, sctx.S, 1.0, self.sil_eps, 2,
-                              P(self.up_sil), None, P(m.keep_sum), P(sctx.adj_off), P(sctx.adj_items), P(sctx.face_order),
-                              None, None, P(sctx.workspace), CL, None, NS, sctx.sum_log2q, sa), "sil_bwd")
-
-    def _depth_render(self, verts, ctx, V_, sil, dep, stream_id):
-        """depth + silhouette images of one mesh at the full-image camera (reference homan.py:391,406), all frames"""
-        m, L, P = self.model, self.L, _lib.ptr
-        _lib.check(L.hm_sil_fwd(P(verts), P(ctx.faces), 0, P(m.camintr), self.B, V_, ctx.F, ctx.S, 1.0, self.ops.NMR_NEAR,
-                                self.ops.NMR_FAR, None, None, None, P(sil), None, P(ctx.work_order), P(dep), None, 0, None, None,
-                                None, 0, 0, P(ctx.workspace), stream_id), "depth render")
-
-    def _adam_log(self):
-        if not self.log_in_adam:
-            return None
-        return (self.vals, self.weights, len(self.SLOTS), self.max_steps, self.log_buf, self.C)
-
-    def _iteration(self):
-        if self.graph is not None:
-            self.graph.replay()
-            if self.shared_scale:
-                self._reduce_shared_scale_grad()
-                self.graph_b.replay()
-        else:
-            self.forward_backward(log=not self.log_in_adam)
-            if self.shared_scale:
-                self._reduce_shared_scale_grad()
-                self._spread_shared_scale_grad()
-            self.opt.step(zero_grad=False, log=self._adam_log())
-
-    def run(self, steps):
-        if self.graph_k is not None:
-            while steps >= self.graph_iters:
-                self.graph_k.replay()
-                steps -= self.graph_iters
-        for _ in range(steps):
-            self._iteration()
-
-    def loss_evolution(self, steps, clip=None):
-        """{name: [float] * steps} of one clip (reference jointopt.py:184-189); a batch of several clips returns the list
-        of its clips' dictionaries unless `clip` picks one."""
-        torch.cuda.synchronize()
-        host = self.log_buf[:steps].cpu().numpy()           # (steps, C, NS)
-
-        def one(ci):
-            out = {k: host[:, ci, self.SLOTS.index(k)].astype(np.float64).tolist() for k in self.keys}
-            out["loss"] = host[:, ci, len(self.SLOTS)].astype(np.float64).tolist()
-            return out
-        if clip is not None:
-            return one(clip)
-        return one(0) if self.C == 1 else [one(ci) for ci in range(self.C)]
-
-
-def _shape_signature(model):
-    """what the clips of one clip batch must share (homan_amd.clipbatch): frames, object topology, hands, sizes, options"""
-    faces = model.faces_object[0].detach().cpu().numpy()
-    return (int(model.translations_object.shape[0]), int(model.verts_object_og.shape[1]), faces.shape[0], hash(faces.tobytes()),
-            tuple(model.hand_sides), bool(model.optimize_mano), bool(model.optimize_object_scale), model.hand_proj_mode,
-            int(model.image_size), int(model.losses.sil_ctx.size), int(model.mano_pca_pose.shape[1]),
-            bool(model.int_scales_hand.requires_grad), model.losses.inter_type, bool(getattr(model, "ordinal_depth", False)))
-
-
-class ShardStepper:
-    """A rank's clips of ANY shapes (a real Core50 shard: every clip its own object mesh, reference homan/datasets/
-    core50.py:22-42, and its own length, fit_vid_dataset.py:190): clips that agree in shape are optimised as ONE clip batch
-    (one launch per kernel over all of them, FusedStepper on a list), and the batches of the different shapes follow each
-    other inside every iteration, each replayed from its own hipGraph.  Every clip keeps its own optimiser and ends up with
-    exactly the result of optimising it alone (bit for bit, like the clips of one batch).
-
-    shared_scale (BASELINE cfg5): ONE object scale tied across all clips of all ranks.  The steppers compute their clips'
-    gradient sums, this class adds them, issues the rank's ONE all-reduce per iteration (and its one broadcast at the start)
-    - so ranks with different numbers of shape groups, or with none, stay in step - and hands the global sum back."""
-
-    def __init__(self, models, loss_weights, lr, max_steps, shared_scale=False, group=None, capture=True):
-        from . import dist as hdist
-        self.models, self.shared_scale, self.group, self.hdist = list(models), bool(shared_scale), group, hdist
-        groups = OrderedDict()
-        for i, mdl in enumerate(self.models):
-            groups.setdefault(_shape_signature(mdl), []).append(i)
-        self.index, self.steppers = [], []                    # per stepper: positions of its clips in `models`
-        make = lambda idxs: FusedStepper([self.models[i] for i in idxs], loss_weights, lr, max_steps, capture=capture,
-                                         shared_scale=shared_scale, group=group, collectives=False)
-        for idxs in groups.values():
-            try:
-                built = [(idxs, make(idxs))]
-            except NotImplementedError:
-                # a configuration the fused loop takes one clip at a time (two hands per frame, inter_type "min"): the clips of
-                # the group become groups of their own - they still run side by side (see run)
-                if len(idxs) == 1:
-                    raise
-                built = [([i], make([i])) for i in idxs]
-            for ix, st in built:
-                self.index.append(ix)
-                self.steppers.append(st)
-        if self.shared_scale:
-            dev = self.models[0].int_scales_object.device if self.models else None
-            if dev is None:     # a rank without clips: the collectives of the others, on the device of the group's backend
-                import torch.distributed as tdist
-                dev = (torch.device("cuda", torch.cuda.current_device())
-                       if (tdist.is_initialized() and tdist.get_backend(group) == "nccl") else torch.device("cpu"))
-            start = (self.steppers[0].model.int_scales_object.detach()[:1].clone() if self.steppers
-                     else torch.zeros(1, device=dev))
-            hdist.broadcast_shared_scalar(start, hdist.group_src(group), group)
-            with torch.no_grad():
-                for st in self.steppers:
-                    st.model.int_scales_object.copy_(start.expand_as(st.model.int_scales_object))
-            self.total = torch.zeros(1, device=dev)
-
-    def _group_streams(self):
-        """one replay stream per shape group: the groups' hipGraphs run CONCURRENTLY.  A one-clip graph is ~90 us of launch
-        and edge latency around ~70 us of kernels, and the kernels of different stages of different groups overlap: eight
-        one-clip groups side by side reach 7 800 it/s against 6 290 one after the other (8 clips of ONE shape as a batch: 8 900)."""
-        if getattr(self, "_streams", None) is None:
-            self._streams = [torch.cuda.Stream() for _ in self.steppers]
-        return self._streams
-
-    def run(self, steps):
-        concurrent = (len(self.steppers) > 1 and all(st.graph is not None for st in self.steppers) and
-                      os.environ.get("HOMAN_SHARD_CONCURRENT", "1") != "0")
-        cur = torch.cuda.current_stream()
-        if concurrent and not self.shared_scale:
-            # independent clips, no collective: every group simply replays its `steps` iterations on its own stream
-            streams = self._group_streams()
-            for s in streams:
-                s.wait_stream(cur)
-            for _ in range(steps):
-                for st, s in zip(self.steppers, streams):
-                    with torch.cuda.stream(s):
-                        st.graph.replay()
-            for s in streams:
-                cur.wait_stream(s)
-            return
-        for _ in range(steps):
-            if not self.shared_scale:
-                for st in self.steppers:
-                    st._iteration()
-                continue
-            self.total.zero_()
-            if concurrent:      # the two halves of the iteration of every group side by side, the collective in between
-                streams = self._group_streams()
-                for st, s in zip(self.steppers, streams):
-                    s.wait_stream(cur)
-                    with torch.cuda.stream(s):
-                        st.graph.replay()
-                for st, s in zip(self.steppers, streams):
-                    cur.wait_stream(s)
-                    self.total += st.g_shared
-                self.hdist.sync_shared_scalar_grad(self.total, self.group)
-                for st, s in zip(self.steppers, streams):
-                    s.wait_stream(cur)
-                    with torch.cuda.stream(s):
-                        st.g_shared.copy_(self.total)
-                        st.graph_b.replay()
-                for s in streams:
-                    cur.wait_stream(s)
-                continue
-            for st in self.steppers:            # forward + backward of every shape group; st.g_shared = sum over its clips
-                if st.graph is not None:
-                    st.graph.replay()
-                else:
-                    st.forward_backward(log=True)
-                self.total += st.g_shared
-            self.hdist.sync_shared_scalar_grad(self.total, self.group)
-            for st in self.steppers:
-                st.g_shared.copy_(self.total)
-                if st.graph_b is not None:
-                    st.graph_b.replay()
-                else:
-                    st._spread_shared_scale_grad()
-                    st.opt.step(zero_grad=False)
-
-    def loss_evolution(self, steps):
-        """one dictionary per clip, in the order the models were given"""
-        out = [None] * len(self.models)
-        for st, idxs in zip(self.steppers, self.index):
-            evo = st.loss_evolution(steps)
-            evo = evo if isinstance(evo, list) else [evo]
-            for i, e in zip(idxs, evo):
-                out[i] = e
-        return out
-
-
-def _input_signature(kw, image_size, rend_size):
-    """what a resident stepper is built for, read off the collated inputs of a clip (cf. _shape_signature of a built model)"""
-    faces = np.ascontiguousarray(torch.as_tensor(kw["faces_object"])[0].cpu().numpy())
-    return (int(kw["translations_object"].shape[0]), int(kw["verts_object_og"].shape[1]), faces.shape[0], hash(faces.tobytes()),
-            tuple(kw["hand_sides"]), int(kw["mano_pca_pose"].shape[1]), tuple(kw["target_masks_object"].shape[1:]),
-            tuple(kw["masks_object"].shape[-2:]), int(image_size), int(rend_size))
-
-
-class ClipFitter:
-    """A stream of clips through RESIDENT steppers: the sample loop of reference fit_vid_dataset.py:190-379 - for every clip
-    `optimize_hand_object(...)`, then `model.state_dict()` / `get_verts_*` read back - without rebuilding anything for a clip
-    whose shapes have been seen before.  Per shape signature (frames, object topology, hands, sizes) ONE set of device buffers,
-    workspaces and ONE captured hipGraph stays resident (`max_resident` signatures, least recently used evicted); a new clip
-    of a known shape is copied into the static buffers (`FusedStepper.reload`), the graph replayed `num_iterations` times,
-    the results copied out.  What a fresh fit spends on building the model, zero-filling ~0.5 GB of workspace, calibrating
-    and capturing (about twice a 400-step fit) is paid once per shape, and the process holds a bounded
-    number of graphs however many clips it walks.  Results are bit-identical to fresh fits (tests/test_clip_fitter_gpu.py).
-
-    `clips_per_batch` > 1: clips of one shape are fitted that many at a time as one clip batch (one launch per kernel over
-    all of them); a last, smaller group of a shape runs through a stepper of its own size.
-    fit(clips) -> one result per clip, in order: {"loss_evolution", "state_dict" (Parameters + the buffers
-    fit_vid_dataset.py:366-379 / postprocess.py:16-77 read, host tensors), "verts_object", "verts_hand"}.
-    `timing` accumulates the seconds spent per stage {collate, build, load, iterations, read_back} and the clip count."""
-
-    READ_BACK = ["translations_object", "rotations_object", "translations_hand", "rotations_hand", "mano_pca_pose", "mano_rot",
-                 "mano_trans", "mano_betas", "int_scales_object", "int_scales_hand", "cams_hand"]
-
-    def __init__(self, loss_weights, num_iterations=400, lr=1e-2, clips_per_batch=1, max_resident=4, class_name="default",
-                 hand_proj_mode="persp", optimize_mano=True, optimize_mano_beta=True, optimize_object_scale=False,
-                 image_size=640, mano_model=None, rend_size=256, ordinal_depth=False):
-        self.lw, self.steps, self.lr = dict(loss_weights), int(num_iterations), float(lr)
-        self.cpb, self.max_resident = max(1, int(clips_per_batch)), max(1, int(max_resident))
-        self.model_kw = dict(class_name=class_name, int_scale_init=1, hand_proj_mode=hand_proj_mode, optimize_mano=optimize_mano,
-                             optimize_mano_beta=optimize_mano_beta, optimize_object_scale=optimize_object_scale,
-                             image_size=image_size, mano_model=mano_model, rend_size=rend_size, sync_metrics=False,
-                             ordinal_depth=ordinal_depth)
-        self.resident = OrderedDict()          # (signature, clips) -> FusedStepper
-        self._one_by_one = set()          # shape signatures whose clips the fused loop takes one at a time
-        self.timing = dict(collate=0.0, build=0.0, load=0.0, iterations=0.0, read_back=0.0, clips=0, built=0, reused=0)
-
-    def _clock(self):
-        import time
-        torch.cuda.synchronize()
-        return time.perf_counter()
-
-    def _inputs(self, clip):
-        kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
-        kw["camintr"] = clip.get("camintr")
-        return kw
-
-    def fit(self, clips):
-        t0 = self._clock()
-        nt = torch.get_num_threads()
-        torch.set_num_threads(1)       # (a few hundred small concatenations: waking a 64-thread pool for each costs 1.5 ms)
-        try:
-            kws = [self._inputs(c) for c in clips]
-        finally:
-            torch.set_num_threads(nt)
-        self.timing["collate"] += self._clock() - t0
-        groups = OrderedDict()
-        for i, kw in enumerate(kws):
-            groups.setdefault(_input_signature(kw, self.model_kw["image_size"], self.model_kw["rend_size"]), []).append(i)
-        results = [None] * len(clips)
-        for sig, idxs in groups.items():
-            for lo in range(0, len(idxs), self.cpb):
-                chunk = idxs[lo:lo + self.cpb]
-                for i, r in zip(chunk, self._fit_group(sig, [kws[i] for i in chunk])):
-                    results[i] = r
-        self.timing["clips"] += len(clips)
-        return results
-
-    def _fit_group(self, sig, kws):
-        key = (sig, len(kws))
-        # configurations the fused loop takes one clip at a time (two hands per frame, inter_type="min"; the depth term, whose
-        # per-clip instance masks a resident BATCH cannot reload): clip by clip through (sig, 1) steppers, like ShardStepper's
-        # singleton groups - decided when the shape is first seen, not on its second batch
-        if len(kws) > 1 and (sig in self._one_by_one or self.lw.get("lw_depth", 0) > 0):
-            return [r for kw in kws for r in self._fit_group(sig, [kw])]
-        t0 = self._clock()
-        stepper = self.resident.get(key)
-        if stepper is None:
-            models = [HOMan(**self.model_kw, **kw) for kw in kws]
-            try:
-                stepper = FusedStepper(models, self.lw, self.lr, self.steps)
-            except NotImplementedError:
-                if len(kws) == 1:
-                    raise
-                del models
-                self._one_by_one.add(sig)
-                return [r for kw in kws for r in self._fit_group(sig, [kw])]
-            self.resident[key] = stepper
-            while len(self.resident) > self.max_resident:
-                self.resident.popitem(last=False)         # (its graph stays in lib._KEPT_GRAPHS: a few kilobytes)
-            self.timing["build"] += self._clock() - t0
-            self.timing["built"] += 1
-        else:
-            self.resident.move_to_end(key)
-            stepper.reload(kws)
-            self.timing["load"] += self._clock() - t0
-            self.timing["reused"] += 1
-        t1 = self._clock()
-        stepper.run(self.steps)
-        t2 = self._clock()
-        self.timing["iterations"] += t2 - t1
-        evo = stepper.loss_evolution(self.steps)
-        evo = evo if isinstance(evo, list) else [evo]
-        out = []
-        with torch.no_grad():
-            for one, e in zip(stepper.model.models, evo):
-                sd = {k: getattr(one, k).detach().cpu() for k in self.READ_BACK if hasattr(one, k)}
-                out.append(dict(loss_evolution=e, state_dict=sd, verts_object=one.get_verts_object()[0].detach().cpu(),
-                                verts_hand=one.get_verts_hand()[0].detach().cpu()))
-        self.timing["read_back"] += self._clock() - t2
-        return out
 
 
 def save_front_top(model, images, step, viz_folder, viz_len=7):
