@@ -474,50 +474,57 @@ class FusedStepper:
                             hand gradients, MANO backward.
         B waits for the object vertices before the pair-wise losses, A waits for B's object-side gradient terms, both
         join before the log row and the Adam step.  Every launch covers all the clips of the batch (clip_len frames
-        each, per-clip scalars NS floats apart in `vals`)."""
+        each, per-clip scalars NS floats apart in `vals`).  The launches are ISSUED in the order of the builders below - the order
+        is part of the design: the graph executor maps the captured branches onto its queues by it (EXPERIMENTS.md)."""
         if self.h > 1:
             return self._forward_backward_hands(log)
-        m, L, P, ck = self.model, self.L, _lib.ptr, _lib.check
-        B, Vo, Vh, c, on, w = self.B, self.Vo, self.Vh, self.c, self.on, self.w
-        CL, NS, C = self.clip_len, self.NS, self.C
+        from types import SimpleNamespace
+        m, P = self.model, _lib.ptr
         main = torch.cuda.current_stream()
-        side = self.side
-        sa, sb = main.cuda_stream, side.cuda_stream
-        rws_a, rws_b = P(m.reduce_ws.buf), P(self.reduce_ws_b.buf)
-        sctx, cctx = m.sil_ctx, m.collision_ctx
-        pca, rot, betas = m.mano_pca_pose, m.mano_rot, m.mano_betas
-        mtr = m.mano_trans if m.optimize_mano else None
-        npca = self.P * CL                       # PCA entries of one clip
-        side.wait_stream(main)
-        use_aux = self.use_aux
+        it = SimpleNamespace(m=m, L=self.L, P=P, ck=_lib.check, B=self.B, Vo=self.Vo, Vh=self.Vh, c=self.c, on=self.on, w=self.w,
+                             CL=self.clip_len, NS=self.NS, C=self.C, main=main, side=self.side, sa=main.cuda_stream,
+                             sb=self.side.cuda_stream, rws_a=P(m.reduce_ws.buf), rws_b=P(self.reduce_ws_b.buf), sctx=m.sil_ctx,
+                             cctx=m.collision_ctx, pca=m.mano_pca_pose, rot=m.mano_rot, betas=m.mano_betas,
+                             mtr=m.mano_trans if m.optimize_mano else None, npca=self.P * self.clip_len,      # PCA entries of one clip
+                             use_aux=self.use_aux, log=log)
+        self.side.wait_stream(main)
+        self._issue_silhouette_chain(it)
+        with torch.cuda.stream(self.side):
+            self._issue_hand_forward(it)
+            self._issue_pair_terms(it)
+            if self.on["depth"]:
+                self._issue_depth_terms(it)
+            self._issue_hand_backward(it)
+        self._issue_object_backward(it)
+        self._issue_join(it)
 
-        def tail_block(stream_obj):
+    def _aux_block(self, it):
+        """the silhouette reduction and the log row on the third stream (clip batches)"""
+        (m, L, P, ck, B, Vo, on, CL, NS, C, sctx, use_aux, log) = \
+            (it.m, it.L, it.P, it.ck, it.B, it.Vo, it.on, it.CL, it.NS, it.C, it.sctx, it.use_aux, it.log)
+        if not use_aux:
+            return
+        # the silhouette reduction and the log row run on a third stream, off both chains.  (Only this: HIP stream
+        # capture crashes when two captured streams wait for each other's events in both directions, and the hipGraph
+        # executor maps richer fork patterns onto its hardware queues in orders that serialise the branches -- both
+        # measured.  WHERE this block is issued matters too: issued after the hand-side backward, the executor runs it
+        # behind that chain, +20 us on the iteration.)
+        with torch.cuda.stream(self.aux):
+            self.aux.wait_event(self.ev_fwd)
+            if on["smooth"] and self.smooth_obj_on_main:
+                self.aux.wait_event(self.ev_smo)         # (that loss value comes from the calling stream here)
             if on["sil"] and not self.sil_reduce_in_bwd:
+                self.aux.wait_event(self.ev_ras)
                 ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
-                                         P(sctx.workspace), CL, NS, stream_obj.cuda_stream), "sil_reduce")
+                                         P(sctx.workspace), CL, NS, self.aux.cuda_stream), "sil_reduce")
             if log:
                 ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
-                                        self.max_steps, P(self.log_buf), C, stream_obj.cuda_stream), "log")
+                                        self.max_steps, P(self.log_buf), C, self.aux.cuda_stream), "log")
 
-        def aux_block():
-            if not use_aux:
-                return
-            # the silhouette reduction and the log row run on a third stream, off both chains.  (Only this: HIP stream
-            # capture crashes when two captured streams wait for each other's events in both directions, and the hipGraph
-            # executor maps richer fork patterns onto its hardware queues in orders that serialise the branches -- both
-            # measured.  WHERE this block is issued matters too: issued after the hand-side backward, the executor runs it
-            # behind that chain, +20 us on the iteration.)
-            with torch.cuda.stream(self.aux):
-                self.aux.wait_event(self.ev_fwd)
-                if on["smooth"] and self.smooth_obj_on_main:
-                    self.aux.wait_event(self.ev_smo)         # (that loss value comes from the calling stream here)
-                if on["sil"] and not self.sil_reduce_in_bwd:
-                    self.aux.wait_event(self.ev_ras)
-                    ck(L.hm_sil_reduce_clips(B, Vo, sctx.F, sctx.S, P(m.keep_sum), self._slot("loss_sil_obj"), None,
-                                             P(sctx.workspace), CL, NS, self.aux.cuda_stream), "sil_reduce")
-                if log:
-                    ck(L.hm_log_total_clips(P(self.vals), P(self.weights), len(self.SLOTS), P(self.opt.step_t),
-                                            self.max_steps, P(self.log_buf), C, self.aux.cuda_stream), "log")
+    def _issue_silhouette_chain(self, it):
+        """A, first half: face setup (+ camera-space vertices), fork point, rasteriser, [object depth render], line expansion + sweeps"""
+        (m, L, P, ck, B, Vo, on, CL, NS, main, sa, sctx, use_aux) = \
+            (it.m, it.L, it.P, it.ck, it.B, it.Vo, it.on, it.CL, it.NS, it.main, it.sa, it.sctx, it.use_aux)
         # ---------------- A: silhouettes forward + backward (the critical chain: nothing else rides it; the object's rigid
         # transform is applied inside the face setup, the other losses get the vertices from the side stream)
         if on["sil"]:
@@ -559,204 +566,237 @@ class FusedStepper:
                 ck(L.hm_sil_bwd_phase_clips(*bwd_args, 2, q2, sa), "sil_bwd(sweeps)")
             else:
                 ck(L.hm_sil_bwd_clips(*bwd_args, q2, sa), "sil_bwd")
-        # ---------------- B: hand forward, pair-wise losses, hand backward
-        with torch.cuda.stream(side):
-            if not on["sil"]:    # (with the silhouette term the face setup of hm_sil_fwd has written self.vo already)
-                ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
-                                        P(m.int_scales_object), 1, B, Vo, None, P(self.vo), CL, sb), "rigid_fwd(obj)")
-                self.ev_vo.record(side)
-            if m.optimize_mano:
-                ck(L.hm_mano_fwd_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
-                                       P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
-                                       P(self.mano_state), CL, sb),
-                   "mano_fwd + rigid(hand)")
-            else:           # the hand mesh is the constant `verts_hand_og` (reference homan.py:357-358): rigid transform only
-                ck(L.hm_rigid_fwd_clips(P(m.verts_hand_og), P(m.rotations_hand), P(m.translations_hand),
-                                        P(m.int_scales_hand), 0, B, Vh, None, P(self.vh), CL, sb), "rigid_fwd(hand)")
-            pri = on["pca"] or on["so"] or on["sh"]
-            # pair terms that feed nothing to each other go in ONE launch (csrc/pairterms.hip): the interaction term, the
-            # object's smoothness when it rides this stream, the metric-only search (no contact term) and the hand-only
-            # reductions
-            sm_here = on["smooth"] and not self.smooth_obj_on_main
-            fuse = self.pair_fused and on["inter"] and Vo <= 4096 and not self.inter_min
-            nn_fused = fuse and not on["con"]
-            # with the contact term the FULL search (nearest object vertex of every hand vertex) is the launch's first block
-            # range instead, and the contact launches follow it: one launch less on the hand-side chain of the step-2 sets
-            nn_full_fused = fuse and on["con"] and self.nn_full_fused
-            ht_fused = fuse and self.hand_terms_fused and on["smooth"] and on["v2d"]
-            ht_args = (P(m.ref_verts2d_hand), float(m.image_size), P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
-                       self._slot("loss_smooth_hand"), P(pca) if pri else None, npca,
-                       P(m.int_scales_object), P(m.int_scale_object_mean), P(m.int_scales_hand),
-                       P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh), self._slot("loss_pca"))
-            if ht_fused:
-                pass
-            elif on["smooth"] and on["v2d"]:       # the three hand-only reductions in one launch
-                ck(L.hm_hand_terms_fwd_clips(P(self.vh), P(m.camintr), 1, ht_args[0], ht_args[1], B, Vh, *ht_args[2:], rws_b, CL,
-                                             NS, sb), "hand terms")
-            else:
-                if pri:
-                    ck(L.hm_priors_fwd_clips(P(pca), npca, P(m.int_scales_object), P(m.int_scale_object_mean),
-                                             P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
-                                             P(self.U_sh), self._slot("loss_pca"), C, NS, sb), "priors")
-                if on["smooth"]:
-                    ck(L.hm_smooth_fwd_clips(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws_b,
-                                             CL, NS, sb), "smooth(hand)")
-                if on["v2d"]:
-                    ck(L.hm_v2d_fwd_clips(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
-                                          P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, CL, NS, sb), "v2d")
-            nn_early = False
-            if on["sil"]:
-                side.wait_event(self.ev_sil)         # self.vo: camera-space object vertices from the calling stream
-                if self.pairs_after_lines:
-                    # (the metric-only search - it feeds nothing but the logged hand-object distance, and is the longest
-                    #  launch of the hand side in a batch - can run before that wait, next to the rasteriser)
-                    nn_early = self.nn_early and on["inter"] and not on["con"] and Vo <= 4096 and not self.inter_min
-                    if nn_early:
-                        ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, None, None, self._slot("handobj_maxdist"),
-                                                   rws_b, CL, NS, P(self.obj_order),
-                                                   (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                                   P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sb), "nn")
-                    side.wait_event(self.ev_lines)   # (scheduling only, see the silhouette chain above)
-                elif self.pairs_after_raster:
-                    side.wait_event(self.ev_ras)     # (scheduling only, see __init__)
-            # one clip, step-2 sets: the collision term (five SDF launches) and the search / contact / interaction launches
-            # both start from the two vertex buffers and feed nothing to each other.  The collision chain stays on this
-            # stream; everything else of the hand side - and, behind both, the hand's gradient launches - moves to the third
-            # stream, which joins the calling stream (the HIP graph runtime crashes at replay when a forked stream rejoins
-            # the SIDE stream: measured twice; forks that rejoin the origin are fine)
-            split = on["col"] and self.col_on_aux and not use_aux
-            side2, sb2 = (self.aux, self.aux.cuda_stream) if split else (side, sb)
-            if on["col"]:
-                if split:
-                    self.ev_hand.record(side)        # both vertex buffers exist on this stream from here on
-                ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
-                                            cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
-                                            self._slot("loss_collision"), P(cctx.ws), CL, NS, sb), "collision")
-                if split:
-                    self.ev_col.record(side)
-                    side2.wait_event(self.ev_hand)
-            if sm_here and not fuse:
-                ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
-                                         sb2), "smooth(obj)")
-            def search_and_contact(stream_obj, rws):
-                sx = stream_obj.cuda_stream
-                if (on["con"] or on["inter"]) and not nn_fused and not nn_full_fused and not nn_early:
-                    # (without the contact term only the logged distance is needed: metric-only search - its group table
-                    #  covers 4096 object vertices, larger meshes take the full search for the same number)
-                    full = on["con"] or Vo > 4096 or self.inter_min      # ('min' names the closest PAIR: indices needed)
-                    ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if full else None,
-                                               P(self.nn_d2) if full else None, self._slot("handobj_maxdist"), rws, CL, NS,
-                                               P(self.obj_order), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                               P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sx), "nn")
-                if on["con"]:
-                    ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
-                                              P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws, CL, NS, sx),
-                       "contact")
-            # (the search on a third stream at one clip / step 1: +1 %; -9 % on an 8-clip batch.  Search + contact as a third
-            #  branch next to the collision term: the HIP graph runtime crashes at replay when two side branches wait for
-            #  each other's events.  Capturing the hand-side forward kernels BEFORE the silhouette chain: -38 %.)
-            if not nn_full_fused:
-                search_and_contact(side2, rws_b)
-            if fuse:
-                ck(L.hm_pair_terms_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo,
-                                             self._slot("handobj_maxdist") if (nn_fused or nn_full_fused) else None,
-                                             P(self.obj_order), rws_b,
-                                             c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(self.rec),
-                                             self._slot("loss_inter"), P(self.reduce_ws_c.buf),
-                                             P(self.U_smo) if sm_here else None,
-                                             self._slot("loss_smooth_obj") if sm_here else None, P(self.reduce_ws_d.buf),
-                                             *(ht_args if ht_fused else (None, 0.0, None, None, None, None, None, 0, None, None,
-                                                                         None, None, None, None, None, None)),
-                                             P(self.reduce_ws_e.buf), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                             P(m.translations_object), P(m.int_scales_object), P(self.hand_order),
-                                             P(self.nn_idx) if nn_full_fused else None, P(self.nn_d2) if nn_full_fused else None,
-                                             CL, NS, sb2),
-                   "pair terms")
-                if nn_full_fused:
-                    search_and_contact(side2, rws_b)          # (the contact launches only: the search ran above)
-            elif on["inter"]:
-                ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
-                                        float(c.INTERACTION_Z_THRESH), P(self.rec),
-                                        P(self.tmp_inter) if self.inter_min else self._slot("loss_inter"), rws_b, CL,
-                                        NS, sb2), "inter")
-            if on["inter"] and self.inter_min:
-                with torch.cuda.stream(side2):
-                    # inter_type "min" (losses.py:219-221): on the frames the gate lets through (rec[:, 0], same gate as the
-                    # centroid form) the smallest squared vertex distance; the search names the pair, the term and its
-                    # gradient live on the two vertices (hand: rigid pose only - the mesh-detached twin; object: only with a free
-                    # scale).  A handful of small device ops, same expressions as Losses.compute_interaction_loss.
-                    flags = (self.rec[:, 0] != 0).float()
-                    i_star = self.nn_d2.argmin(1)
-                    j_star = self.nn_idx.gather(1, i_star[:, None]).long()[:, 0]
-                    diff = self.vh[self.rows, i_star] - self.vo[self.rows, j_star]
-                    self.vals[0, self.SLOTS.index("loss_inter")] = ((diff * diff).sum(1) * flags).sum()
-                    pull = (2.0 * w["loss_inter"]) * diff * flags[:, None]
-                    self.G_min_h.zero_()
-                    self.G_min_h[self.rows, i_star] = pull
-                    if m.optimize_object_scale:
-                        self.G_int_o.zero_()
-                        self.G_int_o[self.rows, j_star] = -pull
-            elif on["inter"] and m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
-                ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb2), "inter_bwd")
-            if on["depth"]:
-                ctx_o, ctx_h, m_o, m_h = self.dctx
-                Sd, K = ctx_o.S, P(m.camintr)
-                self._depth_render(self.vh, ctx_h, Vh, self.d_sil_h, self.d_dep_h, sb2)
-                if on["sil"]:
-                    side2.wait_event(self.ev_dep)        # the object's depth image, from the calling stream
-                else:
-                    self._depth_render(self.vo, ctx_o, Vo, self.d_sil_o, self.d_dep_o, sb2)
-                rw_bytes = L.hm_reduce_workspace_bytes()
-                for ci in range(C):           # per clip: the term normalises over the clip's own pairs and mask counts
-                    fr = slice(ci * CL, (ci + 1) * CL)
-                    args = (P(self.d_dep_o[fr]), P(self.d_dep_h[fr]), P(self.d_sil_o[fr]), P(self.d_sil_h[fr]), P(m_o[fr]),
-                            P(m_h[fr]), CL, Sd)
-                    ck(L.hm_ordinal_depth_fwd(*args, P(self.d_part[8 * ci * CL:]), P(self.d_rec[ci]),
-                                              self._slot("loss_depth") + 4 * NS * ci,
-                                              self.rws_depth.buf.data_ptr() + rw_bytes * ci, sb2), "ordinal depth")
-                    ck(L.hm_ordinal_depth_bwd(*args, P(self.d_rec[ci]), P(self.up_depth), P(self.d_go[fr]), P(self.d_gh[fr]),
-                                              sb2), "ordinal depth bwd")
-                # the two depth images' backward passes are independent: the hand's stays here, the object's goes to the
-                # calling stream (idle between its sweeps and the object's gradient launch) when that stream made the render
-                self.ev_dgrad.record(side2)
-                for verts, ctx, V_, g, G in (((self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h),) if on["sil"] else
-                                             ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o),
-                                              (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h))):
-                    ck(L.hm_depth_bwd(P(verts), K, B, V_, ctx.F, Sd, 1.0, P(g), P(ctx.adj_off), P(ctx.adj_items), P(G),
-                                      P(ctx.workspace), sb2), "depth bwd")
+
+    def _issue_hand_forward(self, it):
+        """B: object / hand vertices, the hand-only terms, then the waits that place the pair-wise terms next to the silhouette chain"""
+        (m, L, P, ck, B, Vo, Vh, on, CL, NS, C, side, sb, rws_b, pca, rot, betas, mtr, npca) = \
+            (it.m, it.L, it.P, it.ck, it.B, it.Vo, it.Vh, it.on, it.CL, it.NS, it.C, it.side, it.sb, it.rws_b, it.pca, it.rot, it.betas, it.mtr, it.npca)
+        if not on["sil"]:    # (with the silhouette term the face setup of hm_sil_fwd has written self.vo already)
+            ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
+                                    P(m.int_scales_object), 1, B, Vo, None, P(self.vo), CL, sb), "rigid_fwd(obj)")
+            self.ev_vo.record(side)
+        if m.optimize_mano:
+            ck(L.hm_mano_fwd_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
+                                   P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
+                                   P(self.mano_state), CL, sb),
+               "mano_fwd + rigid(hand)")
+        else:           # the hand mesh is the constant `verts_hand_og` (reference homan.py:357-358): rigid transform only
+            ck(L.hm_rigid_fwd_clips(P(m.verts_hand_og), P(m.rotations_hand), P(m.translations_hand),
+                                    P(m.int_scales_hand), 0, B, Vh, None, P(self.vh), CL, sb), "rigid_fwd(hand)")
+        pri = on["pca"] or on["so"] or on["sh"]
+        # pair terms that feed nothing to each other go in ONE launch (csrc/pairterms.hip): the interaction term, the
+        # object's smoothness when it rides this stream, the metric-only search (no contact term) and the hand-only
+        # reductions
+        sm_here = on["smooth"] and not self.smooth_obj_on_main
+        fuse = self.pair_fused and on["inter"] and Vo <= 4096 and not self.inter_min
+        nn_fused = fuse and not on["con"]
+        # with the contact term the FULL search (nearest object vertex of every hand vertex) is the launch's first block
+        # range instead, and the contact launches follow it: one launch less on the hand-side chain of the step-2 sets
+        nn_full_fused = fuse and on["con"] and self.nn_full_fused
+        ht_fused = fuse and self.hand_terms_fused and on["smooth"] and on["v2d"]
+        ht_args = (P(m.ref_verts2d_hand), float(m.image_size), P(self.U_v2d), self._slot("loss_v2d_hand"), P(self.U_smh),
+                   self._slot("loss_smooth_hand"), P(pca) if pri else None, npca,
+                   P(m.int_scales_object), P(m.int_scale_object_mean), P(m.int_scales_hand),
+                   P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so), P(self.U_sh), self._slot("loss_pca"))
+        if ht_fused:
+            pass
+        elif on["smooth"] and on["v2d"]:       # the three hand-only reductions in one launch
+            ck(L.hm_hand_terms_fwd_clips(P(self.vh), P(m.camintr), 1, ht_args[0], ht_args[1], B, Vh, *ht_args[2:], rws_b, CL,
+                                         NS, sb), "hand terms")
+        else:
+            if pri:
+                ck(L.hm_priors_fwd_clips(P(pca), npca, P(m.int_scales_object), P(m.int_scale_object_mean),
+                                         P(m.int_scales_hand), P(m.int_scale_hand_mean), P(self.U_pca), P(self.U_so),
+                                         P(self.U_sh), self._slot("loss_pca"), C, NS, sb), "priors")
+            if on["smooth"]:
+                ck(L.hm_smooth_fwd_clips(P(self.vh), B, Vh, 1, P(self.U_smh), self._slot("loss_smooth_hand"), rws_b,
+                                         CL, NS, sb), "smooth(hand)")
+            if on["v2d"]:
+                ck(L.hm_v2d_fwd_clips(P(self.vh), P(m.camintr), 1, P(m.ref_verts2d_hand), float(m.image_size), B, Vh,
+                                      P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, CL, NS, sb), "v2d")
+        nn_early = False
+        if on["sil"]:
+            side.wait_event(self.ev_sil)         # self.vo: camera-space object vertices from the calling stream
+            if self.pairs_after_lines:
+                # (the metric-only search - it feeds nothing but the logged hand-object distance, and is the longest
+                #  launch of the hand side in a batch - can run before that wait, next to the rasteriser)
+                nn_early = self.nn_early and on["inter"] and not on["con"] and Vo <= 4096 and not self.inter_min
+                if nn_early:
+                    ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, None, None, self._slot("handobj_maxdist"),
+                                               rws_b, CL, NS, P(self.obj_order),
+                                               (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
+                                               P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sb), "nn")
+                side.wait_event(self.ev_lines)   # (scheduling only, see the silhouette chain above)
+            elif self.pairs_after_raster:
+                side.wait_event(self.ev_ras)     # (scheduling only, see __init__)
+        # one clip, step-2 sets: the collision term (five SDF launches) and the search / contact / interaction launches
+        # both start from the two vertex buffers and feed nothing to each other.  The collision chain stays on this
+        # stream; everything else of the hand side - and, behind both, the hand's gradient launches - moves to the third
+        it.fuse = fuse
+        it.ht_args = ht_args
+        it.ht_fused = ht_fused
+        it.nn_early = nn_early
+        it.nn_full_fused = nn_full_fused
+        it.nn_fused = nn_fused
+        it.sm_here = sm_here
+
+    def _issue_pair_terms(self, it):
+        """B: collision, nearest-vertex search, contact, interaction (centroid or min) - on the side stream, or split over two"""
+        (m, L, P, ck, B, Vo, Vh, c, on, w, CL, NS, side, sb, rws_b, cctx, use_aux, fuse, ht_args, ht_fused, nn_early, nn_full_fused, nn_fused, sm_here) = \
+            (it.m, it.L, it.P, it.ck, it.B, it.Vo, it.Vh, it.c, it.on, it.w, it.CL, it.NS, it.side, it.sb, it.rws_b, it.cctx, it.use_aux, it.fuse, it.ht_args, it.ht_fused, it.nn_early, it.nn_full_fused, it.nn_fused, it.sm_here)
+        # stream, which joins the calling stream (the HIP graph runtime crashes at replay when a forked stream rejoins
+        # the SIDE stream: measured twice; forks that rejoin the origin are fine)
+        split = on["col"] and self.col_on_aux and not use_aux
+        side2, sb2 = (self.aux, self.aux.cuda_stream) if split else (side, sb)
+        if on["col"]:
             if split:
-                side2.wait_event(self.ev_col)    # the collision term's hand gradients, from the side stream
-            self.ev_fwd.record(side2)         # every forward loss value of this stream exists now
-            if not self.smooth_obj_on_main:
-                aux_block()
-            self.ev_pair.record(side2)        # object-side terms of the pair-wise losses are ready
-            # hand (full path: MANO + rigid): smooth + v2d + collision + contact, summed with their weights inside the rigid
-            # backward; the interaction term reaches the rigid pose only, as one vector per frame (rec[:, 2:5] / Vh)
-            tp, tw, tn = _lib.terms([(self.U_smh if on["smooth"] else None, w["loss_smooth_hand"]),
-                                     (self.U_v2d if on["v2d"] else None, w["loss_v2d_hand"]),
-                                     (self.U_colh if on["col"] else None, w["loss_collision"]),
-                                     (self.U_conh if on["con"] else None, w["loss_contact"]),
-                                     (self.G_dep_h if on["depth"] else None, 1.0)])       # (already times its weight)
-            g_rig = P(self.G_min_h) if (on["inter"] and self.inter_min) else None
-            g_frm = (self.rec.data_ptr() + 8) if (on["inter"] and not self.inter_min) else None
-            if m.optimize_mano and self.mano_bwd_rigid:
-                # the hand's rigid backward inside the MANO backward's launch: one launch less on this chain
-                ck(L.hm_mano_bwd_rigid_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B,
-                                             P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
-                                             P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)),
-                                             P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), tp, tw, tn, g_rig, g_frm, 8,
-                                             w["loss_inter"] / Vh, P(m.rotations_hand.grad), P(m.translations_hand.grad), CL,
-                                             sb2), "mano_bwd + rigid_bwd(hand)")
+                self.ev_hand.record(side)        # both vertex buffers exist on this stream from here on
+            ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
+                                        cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
+                                        self._slot("loss_collision"), P(cctx.ws), CL, NS, sb), "collision")
+            if split:
+                self.ev_col.record(side)
+                side2.wait_event(self.ev_hand)
+        if sm_here and not fuse:
+            ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
+                                     sb2), "smooth(obj)")
+        def search_and_contact(stream_obj, rws):
+            sx = stream_obj.cuda_stream
+            if (on["con"] or on["inter"]) and not nn_fused and not nn_full_fused and not nn_early:
+                # (without the contact term only the logged distance is needed: metric-only search - its group table
+                #  covers 4096 object vertices, larger meshes take the full search for the same number)
+                full = on["con"] or Vo > 4096 or self.inter_min      # ('min' names the closest PAIR: indices needed)
+                ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if full else None,
+                                           P(self.nn_d2) if full else None, self._slot("handobj_maxdist"), rws, CL, NS,
+                                           P(self.obj_order), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
+                                           P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sx), "nn")
+            if on["con"]:
+                ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
+                                          P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws, CL, NS, sx),
+                   "contact")
+        # (the search on a third stream at one clip / step 1: +1 %; -9 % on an 8-clip batch.  Search + contact as a third
+        #  branch next to the collision term: the HIP graph runtime crashes at replay when two side branches wait for
+        #  each other's events.  Capturing the hand-side forward kernels BEFORE the silhouette chain: -38 %.)
+        if not nn_full_fused:
+            search_and_contact(side2, rws_b)
+        if fuse:
+            ck(L.hm_pair_terms_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo,
+                                         self._slot("handobj_maxdist") if (nn_fused or nn_full_fused) else None,
+                                         P(self.obj_order), rws_b,
+                                         c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(self.rec),
+                                         self._slot("loss_inter"), P(self.reduce_ws_c.buf),
+                                         P(self.U_smo) if sm_here else None,
+                                         self._slot("loss_smooth_obj") if sm_here else None, P(self.reduce_ws_d.buf),
+                                         *(ht_args if ht_fused else (None, 0.0, None, None, None, None, None, 0, None, None,
+                                                                     None, None, None, None, None, None)),
+                                         P(self.reduce_ws_e.buf), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
+                                         P(m.translations_object), P(m.int_scales_object), P(self.hand_order),
+                                         P(self.nn_idx) if nn_full_fused else None, P(self.nn_d2) if nn_full_fused else None,
+                                         CL, NS, sb2),
+               "pair terms")
+            if nn_full_fused:
+                search_and_contact(side2, rws_b)          # (the contact launches only: the search ran above)
+        elif on["inter"]:
+            ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
+                                    float(c.INTERACTION_Z_THRESH), P(self.rec),
+                                    P(self.tmp_inter) if self.inter_min else self._slot("loss_inter"), rws_b, CL,
+                                    NS, sb2), "inter")
+        if on["inter"] and self.inter_min:
+            with torch.cuda.stream(side2):
+                # inter_type "min" (losses.py:219-221): on the frames the gate lets through (rec[:, 0], same gate as the
+                # centroid form) the smallest squared vertex distance; the search names the pair, the term and its
+                # gradient live on the two vertices (hand: rigid pose only - the mesh-detached twin; object: only with a free
+                # scale).  A handful of small device ops, same expressions as Losses.compute_interaction_loss.
+                flags = (self.rec[:, 0] != 0).float()
+                i_star = self.nn_d2.argmin(1)
+                j_star = self.nn_idx.gather(1, i_star[:, None]).long()[:, 0]
+                diff = self.vh[self.rows, i_star] - self.vo[self.rows, j_star]
+                self.vals[0, self.SLOTS.index("loss_inter")] = ((diff * diff).sum(1) * flags).sum()
+                pull = (2.0 * w["loss_inter"]) * diff * flags[:, None]
+                self.G_min_h.zero_()
+                self.G_min_h[self.rows, i_star] = pull
+                if m.optimize_object_scale:
+                    self.G_int_o.zero_()
+                    self.G_int_o[self.rows, j_star] = -pull
+        elif on["inter"] and m.optimize_object_scale:      # the object side of the term reaches the (free) scale: per-vertex form
+            ck(L.hm_inter_bwd(P(self.rec), P(self.up_inter), B, Vh, Vo, None, P(self.G_int_o), sb2), "inter_bwd")
+        it.sb2 = sb2
+        it.side2 = side2
+        it.split = split
+
+    def _issue_depth_terms(self, it):
+        """B: ordinal depth term - hand render, pair term per clip, the two depth-map backward passes"""
+        (m, L, P, ck, B, Vo, Vh, on, CL, NS, C, sb2, side2) = \
+            (it.m, it.L, it.P, it.ck, it.B, it.Vo, it.Vh, it.on, it.CL, it.NS, it.C, it.sb2, it.side2)
+        if on["depth"]:
+            ctx_o, ctx_h, m_o, m_h = self.dctx
+            Sd, K = ctx_o.S, P(m.camintr)
+            self._depth_render(self.vh, ctx_h, Vh, self.d_sil_h, self.d_dep_h, sb2)
+            if on["sil"]:
+                side2.wait_event(self.ev_dep)        # the object's depth image, from the calling stream
             else:
-                ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
-                                        P(m.int_scales_hand), 0, tp, tw, tn, g_rig, g_frm, 8, w["loss_inter"] / Vh, B, Vh,
-                                        P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
-                                        P(m.translations_hand.grad), None, P(self.rigid_ws_h), CL, sb2), "rigid_bwd(hand)")
-                if m.optimize_mano:
-                    ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
-                                     P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
-                                     P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb2),
-                       "mano_bwd")
+                self._depth_render(self.vo, ctx_o, Vo, self.d_sil_o, self.d_dep_o, sb2)
+            rw_bytes = L.hm_reduce_workspace_bytes()
+            for ci in range(C):           # per clip: the term normalises over the clip's own pairs and mask counts
+                fr = slice(ci * CL, (ci + 1) * CL)
+                args = (P(self.d_dep_o[fr]), P(self.d_dep_h[fr]), P(self.d_sil_o[fr]), P(self.d_sil_h[fr]), P(m_o[fr]),
+                        P(m_h[fr]), CL, Sd)
+                ck(L.hm_ordinal_depth_fwd(*args, P(self.d_part[8 * ci * CL:]), P(self.d_rec[ci]),
+                                          self._slot("loss_depth") + 4 * NS * ci,
+                                          self.rws_depth.buf.data_ptr() + rw_bytes * ci, sb2), "ordinal depth")
+                ck(L.hm_ordinal_depth_bwd(*args, P(self.d_rec[ci]), P(self.up_depth), P(self.d_go[fr]), P(self.d_gh[fr]),
+                                          sb2), "ordinal depth bwd")
+            # the two depth images' backward passes are independent: the hand's stays here, the object's goes to the
+            # calling stream (idle between its sweeps and the object's gradient launch) when that stream made the render
+            self.ev_dgrad.record(side2)
+            for verts, ctx, V_, g, G in (((self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h),) if on["sil"] else
+                                         ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o),
+                                          (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h))):
+                ck(L.hm_depth_bwd(P(verts), K, B, V_, ctx.F, Sd, 1.0, P(g), P(ctx.adj_off), P(ctx.adj_items), P(G),
+                                  P(ctx.workspace), sb2), "depth bwd")
+
+    def _issue_hand_backward(self, it):
+        """B: join of the split, forward-done / pair-done events, the hand's rigid + MANO backward"""
+        (m, L, P, ck, B, Vh, on, w, CL, pca, rot, betas, mtr, sb2, side2, split) = \
+            (it.m, it.L, it.P, it.ck, it.B, it.Vh, it.on, it.w, it.CL, it.pca, it.rot, it.betas, it.mtr, it.sb2, it.side2, it.split)
+        if split:
+            side2.wait_event(self.ev_col)    # the collision term's hand gradients, from the side stream
+        self.ev_fwd.record(side2)         # every forward loss value of this stream exists now
+        if not self.smooth_obj_on_main:
+            self._aux_block(it)
+        self.ev_pair.record(side2)        # object-side terms of the pair-wise losses are ready
+        # hand (full path: MANO + rigid): smooth + v2d + collision + contact, summed with their weights inside the rigid
+        # backward; the interaction term reaches the rigid pose only, as one vector per frame (rec[:, 2:5] / Vh)
+        tp, tw, tn = _lib.terms([(self.U_smh if on["smooth"] else None, w["loss_smooth_hand"]),
+                                 (self.U_v2d if on["v2d"] else None, w["loss_v2d_hand"]),
+                                 (self.U_colh if on["col"] else None, w["loss_collision"]),
+                                 (self.U_conh if on["con"] else None, w["loss_contact"]),
+                                 (self.G_dep_h if on["depth"] else None, 1.0)])       # (already times its weight)
+        g_rig = P(self.G_min_h) if (on["inter"] and self.inter_min) else None
+        g_frm = (self.rec.data_ptr() + 8) if (on["inter"] and not self.inter_min) else None
+        if m.optimize_mano and self.mano_bwd_rigid:
+            # the hand's rigid backward inside the MANO backward's launch: one launch less on this chain
+            ck(L.hm_mano_bwd_rigid_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B,
+                                         P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
+                                         P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)),
+                                         P(self.vm), P(m.rotations_hand), P(m.int_scales_hand), tp, tw, tn, g_rig, g_frm, 8,
+                                         w["loss_inter"] / Vh, P(m.rotations_hand.grad), P(m.translations_hand.grad), CL,
+                                         sb2), "mano_bwd + rigid_bwd(hand)")
+        else:
+            ck(L.hm_rigid_bwd_clips(P(self.vm if m.optimize_mano else m.verts_hand_og), P(m.rotations_hand),
+                                    P(m.int_scales_hand), 0, tp, tw, tn, g_rig, g_frm, 8, w["loss_inter"] / Vh, B, Vh,
+                                    P(self.G_mesh) if m.optimize_mano else None, P(m.rotations_hand.grad),
+                                    P(m.translations_hand.grad), None, P(self.rigid_ws_h), CL, sb2), "rigid_bwd(hand)")
+            if m.optimize_mano:
+                ck(L.hm_mano_bwd(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), B, P(self.G_mesh),
+                                 P(self.U_pca) if on["pca"] else None, w["loss_pca"], P(pca.grad), P(rot.grad),
+                                 P(betas.grad), P(mtr.grad), P(self.mano_state), P(self.mctx.workspace(B)), sb2),
+                   "mano_bwd")
+
+    def _issue_object_backward(self, it):
+        """A, second half: [object smoothness], [object depth backward], the object's rigid backward with the silhouette gather"""
+        (m, L, P, ck, B, Vo, on, w, CL, NS, main, sa, rws_a, sctx) = \
+            (it.m, it.L, it.P, it.ck, it.B, it.Vo, it.on, it.w, it.CL, it.NS, it.main, it.sa, it.rws_a, it.sctx)
         # ---------------- A: object backward: silhouette gradient + smooth + contact [+ interaction with a free scale],
         # summed with their weights inside the rigid backward
         if on["smooth"] and self.smooth_obj_on_main:
@@ -768,7 +808,7 @@ class FusedStepper:
                                      sa), "smooth(obj)")
             self.ev_smo.record(main)
         if self.smooth_obj_on_main:
-            aux_block()
+            self._aux_block(it)
         if on["depth"] and on["sil"]:
             main.wait_event(self.ev_dgrad)       # d loss / d (object's depth image), from the side stream
             ctx_o = self.dctx[0]
@@ -798,6 +838,12 @@ class FusedStepper:
             ck(L.hm_rigid_bwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.int_scales_object), 1, tp, tw, tn, None,
                                     None, 0, 0.0, B, Vo, None, P(m.rotations_object.grad), P(m.translations_object.grad),
                                     P(self.g_so_part) if sc_obj else None, P(self.rigid_ws_o), CL, sa), "rigid_bwd(obj)")
+        it.sc_obj = sc_obj
+
+    def _issue_join(self, it):
+        """tail: silhouette reduction (two streams), join, log row, scale gradients"""
+        (m, L, P, ck, B, Vo, on, w, CL, NS, C, main, side, sa, sctx, use_aux, log, sc_obj) = \
+            (it.m, it.L, it.P, it.ck, it.B, it.Vo, it.on, it.w, it.CL, it.NS, it.C, it.main, it.side, it.sa, it.sctx, it.use_aux, it.log, it.sc_obj)
         if not use_aux:
             # two streams only: the silhouette reduction rides the tail of the silhouette chain (the shorter one at one
             # clip), the log row follows the join
