@@ -10,7 +10,7 @@ design and the current numbers; how the kernels got here - every measured step a
 
 | §8 row | What | Where |
 |---|---|---|
-| (a) a1 loop | `optimize_hand_object`, three Adam groups, weighting, logging | `homan_amd/jointopt.py` (`mode="auto"` (default) = `"fused"` whenever `FusedStepper` accepts the configuration - its own guards decide - else `"graph"`; `"eager"` = reference loop verbatim; `GraphStepper` = the same autograd iteration in a hipGraph; `FusedStepper` = the iteration as a fixed C-ABI launch sequence on two (one clip) or three (clip batch) streams in a hipGraph, the benchmark path - one clip, a BATCH of equal-shaped clips (`homan_amd/clipbatch.py`), or through `ShardStepper` a shard of clips of any shapes, the shape groups replayed concurrently; `ClipFitter` = the dataset walk of `fit_vid_dataset.py:190-379` on RESIDENT steppers: a clip of a known shape is copied into the static buffers and the resident hipGraph replayed), `csrc/adam.hip` |
+| (a) a1 loop | `optimize_hand_object`, three Adam groups, weighting, logging | `homan_amd/jointopt.py` (the reference's module name: `optimize_hand_object`, `GraphStepper`, re-exports) over `homan_amd/loopcommon.py` (collation, Adam groups, fused Adam, device log), `homan_amd/fused.py` (`FusedStepper`: the iteration issued by per-chain builders - silhouette chain, hand forward, pair terms, depth terms, hand backward, object backward, join) and `homan_amd/shard.py` (`ShardStepper`, `ClipFitter`) (`mode="auto"` (default) = `"fused"` whenever `FusedStepper` accepts the configuration - its own guards decide - else `"graph"`; `"eager"` = reference loop verbatim; `GraphStepper` = the same autograd iteration in a hipGraph; `FusedStepper` = the iteration as a fixed C-ABI launch sequence on two (one clip) or three (clip batch) streams in a hipGraph, the benchmark path - one clip, a BATCH of equal-shaped clips (`homan_amd/clipbatch.py`), or through `ShardStepper` a shard of clips of any shapes, the shape groups replayed concurrently; `ClipFitter` = the dataset walk of `fit_vid_dataset.py:190-379` on RESIDENT steppers: a clip of a known shape is copied into the static buffers and the resident hipGraph replayed), `csrc/adam.hip` |
 | (a) a2,a3,a7,a20 | `HOMan` module: parameter/buffer surface, `get_verts_*`, `forward` | `homan_amd/homan.py` |
 | (a) a4–a6 | rot6d→R, rigid transform (+ mesh-detached twin) | `csrc/geometry.hip` (`hm_rigid_fwd/bwd`) |
 | (a) a8 + N3 | `ManoModel.forward_pca` + MANO LBS | `csrc/mano.hip` (`hm_mano_fwd/bwd`), `homan_amd/manomodel.py`, `mano_assets.py` |
