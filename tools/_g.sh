@@ -14,6 +14,8 @@ PY
 }
 if [ -n "$1" ]; then timeout 1200 python -m pytest "$@" -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3; fi
 run base HOMAN_AMD_LIB=$R/homan_amd/lib/lib_base.so
-run new X=1
+run kb4 X=1
+run kb2 HOMAN_AMD_LIB=$R/homan_amd/lib/lib_kb2.so
 run base2 HOMAN_AMD_LIB=$R/homan_amd/lib/lib_base.so
-run new2 X=1
+run kb4b X=1
+run kb2b HOMAN_AMD_LIB=$R/homan_amd/lib/lib_kb2.so
