@@ -376,8 +376,6 @@ class FusedStepper:
         reused as they are.  The next `run(steps)` is the fit of the new clips, bit-identical to the fit a freshly built
         stepper would make (tests/test_clip_fitter_gpu.py)."""
         m = self.model
-        if self.on["depth"] and m.C > 1:
-            raise NotImplementedError("reload: the depth term's per-clip instance masks of a clip batch are not resident")
         if len(clip_inputs) != m.C:
             raise ValueError(f"reload: {len(clip_inputs)} clips for a stepper of {m.C}")
         from .clipbatch import _PER_CLIP, _PER_FRAME
@@ -397,8 +395,14 @@ class FusedStepper:
                 self.sil_keep.copy_(sx.pad(m.keep_mask_object))
                 self.sil_ref.copy_(sx.pad(m.ref_mask_object))
             self.obj_spheres.copy_(self._group_spheres())
-            if self.on["depth"] and self.h == 1:     # (two hands: the layers' masks are the model's own tensors, copied in place)
+            if self.on["depth"] and self.h == 1 and m.C == 1:     # (two hands: the layers' masks are the model's own tensors, copied in place)
                 self.dctx = m.models[0].depth_contexts()
+            elif self.on["depth"] and self.h == 1:
+                # a clip batch: the instance masks of the depth term are the stepper's own concatenation of the clips' masks
+                CL = m.clip_len
+                for c, one in enumerate(m.models):
+                    self.dctx[2][c * CL:(c + 1) * CL].copy_((one.masks_object != 0).to(torch.uint8))
+                    self.dctx[3][c * CL:(c + 1) * CL].copy_((one.masks_human != 0).to(torch.uint8))
             for st_m, st_v in self.opt.state:
                 st_m.zero_()
                 st_v.zero_()

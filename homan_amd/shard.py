@@ -216,10 +216,9 @@ class ClipFitter:
 
     def _fit_group(self, sig, kws):
         key = (sig, len(kws))
-        # configurations the fused loop takes one clip at a time (two hands per frame, inter_type="min"; the depth term, whose
-        # per-clip instance masks a resident BATCH cannot reload): clip by clip through (sig, 1) steppers, like ShardStepper's
-        # singleton groups - decided when the shape is first seen, not on its second batch
-        if len(kws) > 1 and (sig in self._one_by_one or self.lw.get("lw_depth", 0) > 0):
+        # configurations the fused loop takes one clip at a time (two hands per frame, inter_type="min"): clip by clip through
+        # (sig, 1) steppers, like ShardStepper's singleton groups - decided when the shape is first seen
+        if len(kws) > 1 and sig in self._one_by_one:
             return [r for kw in kws for r in self._fit_group(sig, [kw])]
         t0 = self._clock()
         stepper = self.resident.get(key)

@@ -107,3 +107,31 @@ def test_clip_without_intrinsics_and_one_at_a_time_configurations(mano_model):
     assert len(out) == 3 and pair.timing["built"] == 1 and pair.timing["reused"] == 2
     for clip, r in zip(two, out):
         _same(r, *_fresh(mano_model, clip, lw))
+
+
+def test_depth_term_in_resident_clip_batches(mano_model):
+    """The ordinal depth term (opt-in, reference homan.py:384-419) through ClipFitter with two clips per batch: the second
+    batch is COPIED into the resident stepper - its instance masks included (round 5: a resident batch used to refuse the
+    reload and the fitter fell back to one clip per stepper) - and every clip equals its fresh solo fit bit for bit."""
+    from homan_amd import synth
+    from homan_amd.jointopt import ClipFitter, optimize_hand_object
+    lw = dict(synth.STEP1_LOSS_WEIGHTS, lw_depth=1.0)
+    clips = []
+    for s in (51, 52, 53, 54):
+        clip = _clip(mano_model, s)
+        for pp, op in zip(clip["person_parameters"], clip["object_parameters"]):      # annotations that disagree with the geometry
+            op["full_mask"] = ((pp["masks"][0] > 0) | (op["full_mask"] > 0)).float()
+            pp["masks"] = torch.zeros_like(pp["masks"])
+            pp["translations"] = pp["translations"] + torch.tensor([0.06, 0.0, -0.02])
+        clips.append(clip)
+    fitter = ClipFitter(lw, num_iterations=STEPS, clips_per_batch=2, optimize_mano=True, image_size=64, mano_model=mano_model,
+                        rend_size=64, ordinal_depth=True)
+    res = fitter.fit(clips)
+    assert fitter.timing["built"] == 1 and fitter.timing["reused"] == 1
+    for clip, r in zip(clips, res):
+        model, evo, _ = optimize_hand_object(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                                             objvertices=clip["objvertices"], objfaces=clip["objfaces"], camintr=clip["camintr"],
+                                             loss_weights=lw, num_iterations=STEPS, optimize_mano=True, image_size=64,
+                                             mano_model=mano_model, rend_size=64, ordinal_depth=True)
+        assert evo["loss_depth"][0] > 0
+        _same(r, model, evo)

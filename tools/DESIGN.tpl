@@ -407,7 +407,11 @@ groups side by side fill what a sequence leaves idle: 4 shapes × 2 clips 8 330 
 (8 clips of ONE shape as a batch: 8 900-9 200).  Configurations the fused loop takes one clip at a time (two hands per frame,
 `inter_type="min"`) become singleton groups of the same mechanism.  Every clip ends up with exactly the result of optimising
 it alone, bit for bit (`tests/test_clip_batch_gpu.py`).  What is NOT built: one launch per kernel over clips of DIFFERENT
-shapes (per-clip CSR offsets in every `hm_*_clips` kernel).
+shapes (per-clip CSR offsets in every `hm_*_clips` kernel).  How much it matters for the reference's own driver: a run of
+`fit_vid_dataset.py` cuts every sample to the same `--frame_nb` frames (`fit_vid_dataset.py:50,180`) and Core50's model table holds two dozen object
+meshes (`homan/datasets/core50constants.py:18-130`, loaded by `core50.py:18-45`), so the clips of a rank's shard fall into a handful of (mesh, length)
+groups and each group IS one clip batch; what is left heterogeneous replays concurrently (8 clips of 4 shapes @MIXED@ it/s against
+@MULTI@ for 8 clips of one shape).
 
 A process that walks a dataset does it through `ClipFitter` (`jointopt.py`): per shape signature ONE resident stepper -
 device buffers, workspaces, ONE captured hipGraph - into which the next clip of that shape is copied (`FusedStepper.reload`,
