@@ -135,7 +135,7 @@ HIP ↔ oracle parity is exact where the domain is discrete and tolerance-bound 
 | pose initialisation vs the oracle with the written-out transform | coverage **bit-exact** (0 flipped samples), mask loss equal, gradients 5e-5 of max (autograd side) | `test_hip_poseinit_coverage_bit_exact_and_gradients_vs_written_out_oracle` |
 | pose initialisation, a WHOLE free-running fit vs the oracle's written-out loop (`oracle/posechain.py`) | every candidate's rotation / translation, the per-candidate losses, the best-ever pose **bit-equal** | `test_fused_poseinit_fit_bit_equal_with_the_written_out_oracle` |
 | every stage of the gradient chains at identical parameters vs the oracle's WRITTEN-OUT chains (unit gradients, interaction records, nearest-vertex picks, contact / collision / depth gradients, model-space gradient) and all parameter gradients | **bit-equal** | `tests/test_handchain_gpu.py` |
-| FREE-running fit, HIP loop vs the oracle's reproducible loop: cfg1; cfg2; cfg2 + depth; cfg3; free / tied object scale; two hands; `optimize_mano=False` | EVERY parameter **bit-equal after every step** (400 steps at full size for cfg2 / cfg2 + depth / cfg3), losses 1e-4 (measured 3.6e-7), final vertices 0.0 mm | `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`, `bench_parity.free_run_parity`, `profiles/r05_freerun_cfg2_400.json` (this round's kernels), `profiles/r04_freerun_*.json` |
+| FREE-running fit, HIP loop vs the oracle's reproducible loop: cfg1; cfg2; cfg2 + depth; cfg3; free / tied object scale; two hands; `optimize_mano=False` | EVERY parameter **bit-equal after every step** (400 steps at full size for cfg2 / cfg2 + depth / cfg3), losses 1e-4 (measured 3.6e-7), final vertices 0.0 mm | `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`, `bench_parity.free_run_parity`, `profiles/r05_freerun_{cfg2,cfg2_depth,cfg3}_400.json` |
 | a stream of clips through resident steppers vs fresh fits | **bit-exact** (parameters, vertices, loss_evolution) | `tests/test_clip_fitter_gpu.py` |
 
 **Final-loss / final-vertex parity (the second half of BASELINE's metric): met, free-running.**  The hard rasteriser makes the
@@ -188,10 +188,10 @@ object's chain is closed on itself (`homan/homan.py:482-490`: `loss_inter` sees 
   (`oracle.jointopt.reproducible_step_shared_scale`).
 
 Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`,
-`profiles/r05_freerun_cfg2_400.json`, `profiles/r04_freerun_*.json`): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
+`profiles/r05_freerun_{cfg2,cfg2_depth,cfg3}_400.json`, regenerated with this round's kernels): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
 `translations_hand`, `mano_pca_pose`, `mano_rot`, `mano_betas`, `mano_trans` - is BIT-EQUAL between the two free-running loops
 after every step: cfg1 100 steps x 5 seeds; cfg2, cfg2 + ordinal depth term and cfg3 (step-2: collision + contact) at full size
-over 400 steps (`r04_freerun_cfg2_400.json`, `r04_freerun_cfg2_depth_400.json`, `r04_freerun_cfg3_400.json`:
+over 400 steps (`r05_freerun_cfg2_400.json`, `r05_freerun_cfg2_depth_400.json`, `r05_freerun_cfg3_400.json`:
 `all_params_bit_equal_all_steps: true`); the step-2 set with a free object scale over 12 steps (`tests/test_handchain_gpu.py`); final
 vertices 0.0 mm apart for the object AND the hand, every logged loss within 3.4e-7 at every step (bar 1e-4; the logged VALUES are
 parallel float sums and keep their rounding, the trajectory does not see them).  Until the hand's chain was written out (first
