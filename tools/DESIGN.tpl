@@ -368,7 +368,10 @@ throughput-bound at 500 frames per launch.
 raster 40 + lines 25 + sweeps 45 + object gradients 17 + Adam 4 µs = 140 µs of kernels + ~13 µs between them = 153 µs; the hand
 side (MANO 16, pair terms 30, hand gradients 42 µs) runs under it.  What round 5 measured about the rest (same-box A/B each):
 * **The launch floor is not launch latency.**  VERDICT r4 asked for the chain as ONE persistent launch with device-side barriers
-  (cfg1 runs 88 µs per iteration "with nearly empty kernels").  Measured instead: a dependent kernel boundary inside a stream costs
+  (cfg1 ran 88 µs per iteration "with nearly empty kernels"; `tools/cfg1_floor.py` now: 77.6 µs = 12 900 it/s, 81.5 µs with one
+  iteration per graph).  Its timeline (rocprofv3): silhouette chain setup 6 + raster 17 + lines 11 + sweeps 19 + object
+  gradients 9 µs ending at 72 µs, hand chain MANO forward 13 + 2-D term 5 + MANO backward 31 µs ending at 68 µs, Adam 4 µs: two
+  chains of latency-bound kernels of about equal length, no launch in them that a barrier would shorten.  Measured instead: a dependent kernel boundary inside a stream costs
   ~1.5 µs (guide: `boundary` row; the timeline's back-to-back launches agree), removing the cross-stream waits altogether gains
   0.1-1.5 % (round 4), dropping the Adam launch AND its join altogether (timing experiment, lr = 0 on both sides) gains 1.5 %
   (3 µs), and the turnaround between two graph replays was 5 µs - taken out by replaying FOUR iterations per graph (kept: +2-3 %).
