@@ -2419,6 +2419,14 @@ static SilWs carve(void* ws, int B, int V, int F, int S)
 // workspace; the caller's work_order only seeds it).  Read when the entry points are called (or captured).
 static thread_local int g_raster_reorder = 0;
 // pass 2a (+ the work list of pass 2b in its first workgroups) and pass 2b
+// 32-bit byte offsets (the W32 instantiations of the line expansion and the sweeps) while the largest array they index - the
+// per-line source arrays, 4 B is^2 records of 12 bytes - stays below 4 GB.  HOMAN_FORCE_W64=1 (read once; a test hook)
+// takes the 64-bit instantiations regardless: tests/test_raster_gpu.py runs the bit-exactness tests through both.
+static bool hm_offsets_fit_32(int B, int S)
+{
+    static const bool force64 = [] { const char* e = getenv("HOMAN_FORCE_W64"); return e && atoi(e) != 0; }();
+    return !force64 && 4.0 * B * (2.0 * S) * (2.0 * S) * sizeof(SweepSrc) < 4.0e9;
+}
 static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const float* upstream, const float* keep_sum,
                          int clip_len, hipStream_t stream, float* loss_out = nullptr, int out_stride = 0)
 {
@@ -2427,7 +2435,7 @@ static void launch_lines(const SilWs& w, int B, int F, int S, int mode, const fl
     // whether it is launched alone or in a batch
     const int fpt = (long)clip_len * F >= 400000 ? 4 : 1;      // faces per thread of the work-list blocks
     const int ncomp = (B / clip_len) * hm_cdiv((long)clip_len * F, 256 * fpt);
-    const bool w32 = 4.0 * B * (2.0 * S) * (2.0 * S) * sizeof(SweepSrc) < 4.0e9;      // (as in launch_sweep)
+    const bool w32 = hm_offsets_fit_32(B, S);
     hipLaunchKernelGGL(w32 ? k_bwd_lines<true> : k_bwd_lines<false>, dim3(ncomp + nred + hm_cdiv(4L * B * 2 * S, 16 * LINES_NL)), dim3(256), 0, stream, w.planes,
                        w.gimg, w.dimg, mode, upstream, keep_sum, w.idx_map, B, S, w.srcs, w.lrec, ncomp, fpt, w.faces9, w.boxes,
                        w.owned, F, w.parts, w.sweep, clip_len, w.lsum, nred, w.partials, w.frame_rec, loss_out, out_stride,
@@ -2439,7 +2447,7 @@ static void launch_sweep(const SilWs& w, int B, int F, int S, float eps, int sum
     const int nsort = g_raster_reorder ? 1 : 0;      // (see hm_tune_raster_reorder: one workgroup more, eight workers less)
     const int blocks = max(8, (min(min(hm_cdiv((long)B * F, 2), g_sweep_blocks), TS_SWEEP_WGS - 8) & ~7) - 8 * nsort);   // workers: a multiple of 8, see the unit loop
     // (32-bit byte offsets while the largest array the sweep indexes - the per-line source arrays - stays below 4 GB)
-    const bool w32 = 4.0 * B * (2.0 * S) * (2.0 * S) * sizeof(SweepSrc) < 4.0e9;
+    const bool w32 = hm_offsets_fit_32(B, S);
     hipLaunchKernelGGL(w32 ? k_bwd_sweep<true> : k_bwd_sweep<false>, dim3(nsort + blocks), dim3(256), 0, stream, w.sweep,
                        w.idx_map, w.srcs, w.lrec, B, F, S, eps, hm_sum_magic(sum_log2q), w.parts, w.lsum, w.alpha16, w.counter + 24,
                        w.ts + 2 * (ts_raster_units(B, S) + ts_lines_units(B, F, S)), nsort, w.wo_dyn, w.wo_tmp, w.wg_cost,

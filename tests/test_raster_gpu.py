@@ -290,3 +290,20 @@ def test_nothing_visible_gives_empty_images_and_zero_gradients():
         img.backward(torch.ones_like(img))
         torch.cuda.synchronize()
         assert torch.isfinite(v.grad).all() and float(v.grad.abs().sum()) == 0.0
+
+
+def test_64_bit_offset_instantiations_give_the_same_results():
+    """The line expansion and the sweeps exist twice: with 32-bit byte offsets off scalar bases (taken while the source arrays
+    stay below 4 GB: every test and benchmark size) and with 64-bit element indices (beyond).  HOMAN_FORCE_W64=1 - read when the
+    library first launches them, hence a fresh process - takes the 64-bit instantiations: the bit-exactness tests of the index
+    map's consumers (pseudo-gradient against the oracle, fused loss, the no-anti-aliasing modes) must pass through them too."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, HOMAN_FORCE_W64="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_raster_gpu.py"), "-x", "-q", "-m", "gpu",
+                        "-k", "pseudo_gradient or fused_loss or no_antialiasing or scheduling"], env=env, capture_output=True,
+                       text=True, cwd=root, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
