@@ -195,3 +195,21 @@ def test_committed_golden_regenerates_from_the_reference(tmp_path):
             np.testing.assert_array_equal(new[k], old[k], err_msg=k)        # inputs: exactly today's generator
         else:
             np.testing.assert_allclose(new[k], old[k], rtol=1e-5, atol=1e-7, err_msg=k)      # outputs (thread-count slack)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_written_out_form_against_its_own_pins(name, mano_model):
+    """The written-out oracle form is bounded by the reference-run goldens at 2e-5 (loss_collision 1e-4: one ulp of a hand vertex
+    moves that term by ~5e-5 of itself); against ITSELF it is pinned at 1e-6 (tests/golden/pins_written_out.npz, generated by
+    tools/refharness/gen_written_out_pins.py): a change of its evaluation order shows up here, not as noise inside the wider bar."""
+    import os
+    from oracle import model as o_model
+    pins = np.load(os.path.join(util.GOLDEN_DIR, "pins_written_out.npz"))
+    assert o_model.REFERENCE_FORM is False
+    rec, model, weights, meta = _build(name, mano_model)
+    loss_dict, _ = model(loss_weights=weights)
+    keys = [k for k in pins.files if k.startswith(name + "/")]
+    assert sorted(k.split("/")[1] for k in keys) == sorted(loss_dict)
+    for k in keys:
+        np.testing.assert_allclose(float(loss_dict[k.split("/")[1]].detach().reshape(-1)[0]), float(pins[k]), rtol=1e-6, atol=1e-12,
+                                   err_msg=k)
