@@ -354,13 +354,13 @@ agrees to a few per cent, see the note in EXPERIMENTS.md on what the profiler it
 SIMD16 as four passes of 16 lanes, and the counters say so - `SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU` = 1.02 quad-cycles
 (= 4.1 cycles) per instruction for all three kernels (`quad_cycles_per_valu_instr` in the bench line).  The micro-architecture
 guide's "wave scheduling" section quotes 2 cycles - the rate of dual-issued / packed fp32, which this integer- and
-compare-heavy code rarely reaches (`v_pk_*` are 3 % of the raster's instructions); the bench line carries the same count
+compare-heavy code rarely reaches (`v_pk_*` are a few per cent of the raster's instructions); the bench line carries the same count
 against that peak as `valu_frac_2cyc` (half the value).  Either way the reading is the same: traffic is AT the byte model
 (the kernels are not HBM-bound), and they issue VALU on one third to two thirds of all SIMD cycles; the rest is dependent
-loads (7-8 global round trips per raster workgroup) and LDS.
+loads (5-6 global round trips per active raster workgroup) and LDS.
 
 Pose initialisation (`bench.py --pose-init 500`, its own line with `roofline`; `profiles/r05_p_poseinit_kernel_stats.txt`,
-`r05_pmc_poseinit.json`): per step of 500 candidate poses `k_bwd_sweep` @PISWP@ µs (algorithmic 315 MB → @PISWPG@ GB/s =
+`r05_pmc_poseinit.json`): per step of 500 candidate poses `k_bwd_sweep` @PISWP@ µs (algorithmic 338 MB → @PISWPG@ GB/s =
 **@PISWPF@** of HBM peak, the dominant kernel), `k_raster_fwd` @PIRAS@ µs (@PIRASF@), `k_bwd_lines` @PILIN@ µs (@PILINF@); all
 throughput-bound at 500 frames per launch.
 
