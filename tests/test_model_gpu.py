@@ -437,3 +437,43 @@ def test_cfg1_full_fit_follows_the_reference_loop(mano_model):
     np.testing.assert_allclose(evo["loss_v2d_hand"], rec["evo_loss_v2d_hand"], rtol=1e-4)
     np.testing.assert_allclose(evo["loss"][-1], rec["evo_loss"][-1], rtol=0.1)
     np.testing.assert_array_equal(model.mano_rot.detach().cpu().numpy(), rec["in_mano_rot"])      # never stepped
+
+
+@pytest.mark.parametrize("frames,obj", [(2, "cube"), (2, "bottle")])
+def test_shortest_clip_matches_oracle_and_fits(frames, obj, mano_model):
+    """The shortest clip the reference's loss set is defined on: TWO frames (one frame makes the temporal smoothness a mean over
+    nothing; three frames trigger the reference's dim-less torch.cross).  HIP forward vs the CPU oracle
+    (losses 1e-4), the fused loop a few steps: finite, the objective falls, and a batch of two such clips equals the solo fits."""
+    from homan_amd import HOMan, synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    size = 64
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS)
+
+    def make(seed):
+        clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj=obj, silhouette_fn=sil_fn,
+                               hand_verts_fn=hand_fn)
+        kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+        return kw, dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=size,
+                        mano_model=mano_model, rend_size=size)
+    kw, common = make(71)
+    lo, _ = OracleHOMan(**copy.deepcopy(kw), **common)(loss_weights=lw)
+    lh, _ = HOMan(**copy.deepcopy(kw), **common)(loss_weights=lw)
+    assert sorted(lo) == sorted(lh)
+    for k in lo:
+        np.testing.assert_allclose(lh[k].detach().cpu().numpy().reshape(-1), lo[k].detach().numpy().reshape(-1), rtol=1e-4,
+                                   atol=1e-9, err_msg=k)
+    solo = []
+    for seed in (71, 72):
+        kw_s, common_s = make(seed)
+        st = FusedStepper(HOMan(**kw_s, **common_s, sync_metrics=False), lw, 1e-2, 8)
+        st.run(8)
+        evo = st.loss_evolution(8)
+        assert np.isfinite(evo["loss"]).all() and evo["loss"][-1] < evo["loss"][0]
+        solo.append(evo["loss"])
+    both = FusedStepper([HOMan(**make(s)[0], **make(s)[1], sync_metrics=False) for s in (71, 72)], lw, 1e-2, 8)
+    both.run(8)
+    for e, want in zip(both.loss_evolution(8), solo):
+        np.testing.assert_array_equal(e["loss"], want)
