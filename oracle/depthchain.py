@@ -72,3 +72,65 @@ def depth_vertex_grads(model, lw_depth, return_stages=False):
     if return_stages:
         return out[0], out[1], dict(pooled=(lay[0][2], lay[1][2]), full=(lay[0][3], lay[1][3]), g=g, rec=rec)
     return out[0], out[1]
+
+
+def depth_vertex_grads_layers(model, lw_depth, return_stages=False):
+    """Two hands per frame: the three layers [object, hand 0, hand 1] of reference homan/homan.py:384-419, every unordered pair
+    through the two-layer term, ONE normaliser for the scene (lossutils.py:133-169) - in the order of the fused loop's two-hand
+    path (homan_amd/fused.py `_forward_backward_hands`): pair counts first, the scene's count total = sum(present) +
+    sum(count_pair - present_a - present_b), a pair's share = count_pair / total (one fp32 division), its upstream = lw_depth *
+    share (one fp32 product), the pair's two gradient images, a layer's image = 0 + (its first pair's) + (its second pair's), then
+    the depth-map backward and the vertex gather per layer.  -> [(B,Vo,3), (B,778,3), (B,778,3)] float32."""
+    if model.hand_nb != 2 or not getattr(model, "ordinal_depth", False):
+        raise NotImplementedError("two hands per frame, a model built with ordinal_depth=True")
+    S, h = int(model.image_size), 2
+    with torch.no_grad():
+        vo, vh = model.get_verts_object()[0], model.get_verts_hand()[0]
+    B = vo.shape[0]
+    verts = [vo] + [vh[i::h].contiguous() for i in range(h)]
+    faces = [model.faces_object[0]] + [model.faces_hand[i] for i in range(h)]
+    u8 = lambda t: np.ascontiguousarray((t != 0).numpy().astype(np.uint8))
+    masks = [u8(model.masks_object)] + [u8(model.masks_human[i::h]) for i in range(h)]
+    lay = [render_layers(model, v, f) for v, f in zip(verts, faces)]
+    pairs = [(a, b) for a in range(h + 1) for b in range(a + 1, h + 1)]
+    L = clib.lib()
+
+    def pair_grad(a, b, upstream):
+        ga, gb, rec = np.empty((B, S, S), f32), np.empty((B, S, S), f32), np.zeros(8, f32)
+        L.orc_ordinal_depth_grad(clib.fptr(lay[a][2]), clib.fptr(lay[b][2]), clib.u8ptr(lay[a][3]), clib.u8ptr(lay[b][3]),
+                                 clib.u8ptr(masks[a]), clib.u8ptr(masks[b]), B, S, float(upstream), clib.fptr(ga), clib.fptr(gb),
+                                 clib.fptr(rec))
+        return ga, gb, rec
+    npairs = [f32(pair_grad(a, b, 0.0)[2][0]) for a, b in pairs]
+    present = [f32(int((l[3].reshape(B, -1) != 0).any(1).sum())) for l in lay]      # frames in which the layer covers a pixel fully
+    total = f32(0.0)
+    for p_ in present:
+        total = f32(total + p_)
+    csum = f32(0.0)
+    for k, (a, b) in enumerate(pairs):
+        csum = f32(csum + f32(f32(npairs[k] - present[a]) - present[b]))
+    total = f32(total + csum)
+    g_layer = [np.zeros((B, S, S), f32) for _ in lay]
+    shares = []
+    for k, (a, b) in enumerate(pairs):
+        share = f32(npairs[k] / total) if npairs[k] > 0 else f32(0.0)
+        shares.append(share)
+        ga, gb, _ = pair_grad(a, b, f32(f32(lw_depth) * share))
+        g_layer[a] = g_layer[a] + ga
+        g_layer[b] = g_layer[b] + gb
+    K = np.ascontiguousarray(model.camintr.numpy(), f32)
+    out = []
+    for (ndc, idx, _, _), gp, v_t, f_t in zip(lay, g_layer, verts, faces):
+        F, V = f_t.shape[0], v_t.shape[1]
+        gf9 = np.empty((B, F, 2, 9), f32)
+        L.orc_depth_bwd_faces(clib.fptr(ndc), clib.iptr(idx), clib.fptr(np.ascontiguousarray(gp, f32)), B, F, S, clib.fptr(gf9))
+        adj = build_adjacency(f_t.numpy(), V)
+        gv = np.empty((B, V, 3), f32)
+        v = np.ascontiguousarray(v_t.numpy(), f32)
+        L.orc_depth_bwd_gather(clib.fptr(gf9), clib.iptr(adj[0]), clib.iptr(adj[1]), clib.fptr(v), clib.fptr(K), B, V, F, 1.0,
+                               clib.fptr(gv))
+        out.append(gv)
+    if return_stages:
+        return out, dict(npairs=npairs, present=present, total=total, shares=shares, g_layer=g_layer,
+                         pooled=[l[2] for l in lay], full=[l[3] for l in lay])
+    return out

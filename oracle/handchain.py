@@ -170,11 +170,24 @@ def two_hand_terms(model, loss_weights):
         fo = model.faces_object[0].numpy()
         d = [collision_unit_grad(hands[0], hands[1], rev)[0], collision_unit_grad(hands[1], hands[0], rev)[0],
              collision_unit_grad(hands[0], vo, fo)[0], collision_unit_grad(hands[1], vo, fo)[0]]
+        cols = []
         for a, b in ((d[0], d[1]), (d[2], d[3])):          # from the hand-hand scene, then from each hand's scene with the object
             u = np.empty((N, 778, 3), f32)
             u[0::h], u[1::h] = a, b
-            terms.append((u, lw["lw_collision"]))
+            cols.append(u)
+        if on("lw_depth"):      # (the hands' rigid backward sums five terms: with the depth term the two collision buffers share a slot)
+            terms.append((cols[0] + cols[1], lw["lw_collision"]))
+        else:
+            terms.extend((u, lw["lw_collision"]) for u in cols)
         stages["col"] = d
+    dep = None
+    if on("lw_depth"):          # the ordinal depth term over the three layers (oracle/depthchain.py), already times its weight
+        from . import depthchain
+        dep = depthchain.depth_vertex_grads_layers(model, lw["lw_depth"])
+        u = np.empty((N, 778, 3), f32)
+        u[0::h], u[1::h] = dep[1], dep[2]
+        terms.append((u, 1.0))
+        stages["depth"] = dep
     if on("lw_contact"):
         u = np.empty((N, 778, 3), f32)
         stages["nn_idx"], stages["con_obj"] = [], []
@@ -195,6 +208,8 @@ def two_hand_terms(model, loss_weights):
             gi = [((f32(0.0) - f32(lw["lw_inter"])) * np.ascontiguousarray(rec[i::h, 2:5]) / f32(Vo)) for i in range(h)]
             g = gi[0] + gi[1]
             obj_terms.append((np.ascontiguousarray(np.broadcast_to(g[:, None, :], (B, Vo, 3)), f32), 1.0))
+    if dep is not None:
+        obj_terms.append((dep[0], 1.0))
     return dict(vh=vh, vo=vo, mesh=mesh, terms=terms, rec=rec, obj_terms=obj_terms, stages=stages)
 
 
@@ -239,7 +254,8 @@ def hand_param_grads(model, loss_weights, return_stages=False, pair=None, depth_
     """-> {name: float32 numpy array shaped like the parameter} for the six hand parameters (see the module docstring)."""
     lw = loss_weights
     on = lambda k: lw.get(k, 0.0) > 0
-    if (model.hand_nb == 2 and not on("lw_depth") and not on("lw_sil_hand") and model.optimize_mano and
+    if (model.hand_nb == 2 and (not on("lw_depth") or getattr(model, "ordinal_depth", False)) and not on("lw_sil_hand") and
+            model.optimize_mano and
             isinstance(model.mano_betas, torch.nn.Parameter) and not model.int_scales_hand.requires_grad and
             model.losses.inter_type == "centroid"):
         return _two_hand_param_grads(model, lw, return_stages, two)

@@ -49,7 +49,7 @@ def reproducible_grads(model, loss_weights, log2q=0):
         for p in obj:
             p.requires_grad_(True)
     from . import handchain
-    if model.hand_nb == 2 and not loss_weights.get("lw_depth", 0) > 0:
+    if model.hand_nb == 2 and (not loss_weights.get("lw_depth", 0) > 0 or getattr(model, "ordinal_depth", False)):
         # two hands per frame: the terms between the meshes per hand, then the object's and the hands' chains
         two = handchain.two_hand_terms(model, loss_weights)
         grads = objchain.object_pose_grads(model, loss_weights, log2q, obj_terms=two["obj_terms"])

@@ -137,7 +137,7 @@ def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact
         # d (lw_inter * loss_inter) / d object vertex = -lw_inter * gate * 2 (c_hand - c_obj) / 3 / V, the same for every vertex
         gi = (f32(0.0) - f32(lw["lw_inter"])) * np.ascontiguousarray(inter_rec[:, 2:5], f32) / f32(V)
         terms.append((np.ascontiguousarray(np.broadcast_to(gi[:, None, :], (B, V, 3)), f32), 1.0))
-    if lw.get("lw_depth", 0) > 0:        # d (lw_depth * loss_depth) / d object vertices (oracle/depthchain.py), times its weight
+    if lw.get("lw_depth", 0) > 0 and obj_terms is None:   # d (lw_depth * loss_depth) / d object vertices (oracle/depthchain.py), times its weight (two hands: among obj_terms)
         terms.append((np.ascontiguousarray(depth_obj, f32), 1.0))
     adj = build_adjacency(model.faces_object[0].numpy(), V)
     mesh = np.ascontiguousarray(model.verts_object_og.detach().numpy(), f32)

@@ -266,6 +266,68 @@ def test_two_hands_bit_equal(free_scale, mano_model):
         assert not diff, (i, diff)
 
 
+def _two_hand_depth_pair(mano_model, seed, frames, size):
+    """two hands per frame with instance masks that DISAGREE with the initial geometry (the object annotated in front of both
+    hands everywhere, the hands moved over it): all three pairs of the three-layer ordinal depth term are live"""
+    from homan_amd import HOMan, synth
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    sil_fn, hand_fn = synth.hip_clip_fns(mano_model)
+    clip = synth.make_clip(seed=seed, frames=frames, rend_size=size, image_size=size, obj="bottle", silhouette_fn=sil_fn,
+                           hand_verts_fn=hand_fn, hands=("right", "left"))
+    for pp, op in zip(clip["person_parameters"], clip["object_parameters"]):
+        op["full_mask"] = ((pp["masks"].sum(0) > 0) | (op["full_mask"] > 0)).float()
+        pp["masks"] = torch.zeros_like(pp["masks"])
+        pp["translations"] = pp["translations"] + torch.tensor([[[0.05, 0.0, -0.02]], [[-0.05, 0.0, -0.02]]])
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=size,
+                  mano_model=mano_model, rend_size=size, ordinal_depth=True)
+    return HOMan(**copy.deepcopy(kw), **common), OracleHOMan(**copy.deepcopy(kw), **common)
+
+
+@pytest.mark.parametrize("weights_name", ["STEP1_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS"])
+def test_two_hands_with_depth_term_bit_equal(weights_name, mano_model):
+    """Two hands per frame AND the ordinal depth term (reference homan/homan.py:384-419 with three layers, lossutils.py:133-169
+    over the three pairs with one normaliser): the three pooled depth images, the pairs' counts, every layer's summed gradient
+    image, the three vertex gradients, all parameter gradients, then 10 free-running steps bit-equal in every parameter.  With
+    the step-2 weights the collision families and the depth term feed the hands together."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle import depthchain, handchain, objchain
+    from oracle.jointopt import make_optimizer, reproducible_step
+    lw = dict(getattr(synth, weights_name), lw_depth=1.0)
+    hm, om = _two_hand_depth_pair(mano_model, seed=41, frames=6, size=128)
+    st = FusedStepper(hm, lw, 1e-2, 4, capture=False)
+    st.forward_backward(log=True)
+    torch.cuda.synchronize()
+    dep, stg = depthchain.depth_vertex_grads_layers(om, lw["lw_depth"], return_stages=True)
+    for li in range(3):
+        assert np.array_equal(st.dl_dep[li].cpu().numpy(), stg["pooled"][li]), li
+        assert np.array_equal(st.dl_g[li].cpu().numpy(), stg["g_layer"][li]), li
+    counts = [float(st.dp_rec[k][0]) for k in range(3)]
+    assert counts == [float(n) for n in stg["npairs"]] and min(counts) > 0                 # (every pair is compared somewhere)
+    assert [float(st.dp_up[k]) for k in range(3)] == [float(np.float32(np.float32(lw["lw_depth"]) * s)) for s in stg["shares"]]
+    assert np.array_equal(st.G_dep_o.cpu().numpy(), dep[0])
+    for i in range(2):
+        assert np.abs(dep[1 + i]).max() > 0 and np.array_equal(st.G_dep_h_d[i].cpu().numpy(), dep[1 + i]), i
+    two = handchain.two_hand_terms(om, lw)
+    want = handchain.hand_param_grads(om, lw, two=two)
+    want.update(objchain.object_pose_grads(om, lw, obj_terms=two["obj_terms"]))
+    report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
+    assert all(report.values()), report
+    hm, om = _two_hand_depth_pair(mano_model, seed=42, frames=6, size=128)
+    st = FusedStepper(hm, lw, 1e-2, 10)
+    opt = make_optimizer(om, 1e-2, reproducible=True)
+    for i in range(10):
+        st.run(1)
+        reproducible_step(om, lw, opt)
+        torch.cuda.synchronize()
+        cpu = dict(om.named_parameters())
+        diff = [k for k, p in hm.named_parameters()
+                if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
+        assert not diff, (i, diff)
+
+
 def test_fixed_hand_mesh_bit_equal(mano_model):
     """optimize_mano=False (reference homan/homan.py:104-106: the hand mesh is an input, only its rigid pose is optimised),
     step-2 set: gradients of the four pose tensors, then 12 free-running steps, bit-equal."""

@@ -202,6 +202,42 @@ def test_written_out_chain_with_two_hands(free_scale, mano_model):
                                    err_msg=name)
 
 
+@pytest.mark.parametrize("weights_name", ["depth only", "STEP2_LOSS_WEIGHTS"])
+def test_written_out_chain_with_two_hands_and_the_depth_term(weights_name, mano_model):
+    """hand_nb = 2 with ordinal_depth=True (three layers, three pairs, one normaliser: reference homan/homan.py:384-419,
+    lossutils.py:133-169): oracle/depthchain.py depth_vertex_grads_layers folded into the two-hand chains, against autograd
+    through the faithful restatement - the depth term alone, then next to the step-2 set (the collision terms and the depth
+    term reach the hands through one rigid backward)."""
+    from homan_amd import synth
+    from oracle.jointopt import collate_inputs, reproducible_grads
+    from oracle.model import OracleHOMan
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=4, frames=4, rend_size=64, image_size=64, obj="cube", silhouette_fn=sil_fn, hand_verts_fn=hand_fn,
+                           hands=("right", "left"))
+    for pp, op in zip(clip["person_parameters"], clip["object_parameters"]):      # masks that disagree with the geometry
+        op["full_mask"] = ((pp["masks"].sum(0) > 0) | (op["full_mask"] > 0)).float()
+        pp["masks"] = torch.zeros_like(pp["masks"])
+        pp["translations"] = pp["translations"] + torch.tensor([[[0.05, 0.0, -0.02]], [[-0.05, 0.0, -0.02]]])
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    common = dict(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True, image_size=64,
+                  mano_model=mano_model, rend_size=64, ordinal_depth=True)
+    lw = (dict({k: 0.0 for k in synth.STEP1_LOSS_WEIGHTS}, lw_depth=1.0) if weights_name == "depth only" else
+          dict(getattr(synth, weights_name), lw_depth=2.0))
+    model = OracleHOMan(**copy.deepcopy(kw), **common)
+    loss_dict, _ = model(loss_weights=lw)
+    assert float(loss_dict["loss_depth"].detach()) > 0
+    sum(loss_dict[k] * lw[k.replace("loss", "lw")] for k in loss_dict).sum().backward()
+    written = OracleHOMan(**copy.deepcopy(kw), **common)
+    reproducible_grads(written, lw)
+    names = [k for k, p in written.named_parameters() if p.grad is not None]
+    assert len(names) == 8
+    for name in names:
+        ref, g = getattr(model, name).grad.numpy(), getattr(written, name).grad.numpy()
+        scale = np.abs(ref).max()
+        assert scale > 0, name
+        np.testing.assert_allclose(g / scale, ref / scale, atol=3e-4 if "rotations_object" in name else 1e-4, err_msg=name)
+
+
 def test_exact_pseudo_gradient_equals_the_faithful_loop(mano_model):
     """per (face, corner): the exact-sum variant against orc_nmr_grad_faces_alpha (the published loop order, fp32 sums)"""
     from homan_amd import synth

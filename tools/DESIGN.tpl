@@ -200,8 +200,11 @@ separates from ITSELF when its hand translations start 1e-7 m apart (`r04_contro
 the MANO parameters amplifies any difference, so only a chain without any could close it.  Two hands per frame (right + left,
 rows interleaved, the step-2 set with its three collision scenes, fixed or free scale) are written out as well and bit-equal over
 10 free-running steps (`tests/test_handchain_gpu.py::test_two_hands_bit_equal`).  So are `optimize_mano=False` (the hand mesh an input, its rigid
-pose optimised) and `inter_type="min"` (the closest vertex pair's pull on the hand's rigid pose).  Not written out: the depth term
-with two hands and `inter_type="min"` with a free scale (`oracle/handchain.py` raises NotImplementedError, the oracle then keeps
+pose optimised), `inter_type="min"` (the closest vertex pair's pull on the hand's rigid pose) and - round 5 - two hands WITH the
+ordinal depth term (three layers, three pairs, one normaliser: `oracle/depthchain.py::depth_vertex_grads_layers`; the pooled depth
+images, pair counts, per-layer gradient images, vertex gradients, parameter gradients and 10 free-running steps with the step-1 and
+the step-2 weights, `::test_two_hands_with_depth_term_bit_equal`).  Not written out: `inter_type="min"` with a free scale
+(`oracle/handchain.py` raises NotImplementedError, the oracle then keeps
 autograd's gradients for the hand); there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
 path: nothing at one clip, -2 % on an 8-clip batch (EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the
 divisions; the hand side's kernels did not change but for the sin / cos.
@@ -492,8 +495,8 @@ file the reference never reaches.  More than two hands: the reference's own coll
    FETCH_SIZE applied to narrow scattered reads (owner gathers), for which it is not calibrated.
 4. The ordinal depth term: 140 µs on a 153 µs iteration; in a clip batch one clip per stepper.  With two hands per frame it now
    runs in the fused loop too (round 5: losses and gradients of `HOMan.forward` + autograd at 2e-6 / 2e-5,
-   `tests/test_depth_gpu.py`), compared with the faithful oracle (value, gradients) - not written out: `oracle/handchain.py`
-   raises for depth + two hands and the reproducible loop keeps autograd's gradients there.  The reference's own call site
+   `tests/test_depth_gpu.py`) and the oracle's written-out chain covers it (bit-equal free run,
+   `tests/test_handchain_gpu.py::test_two_hands_with_depth_term_bit_equal`).  The reference's own call site
    raises (`homan.py:506-507`): oracle-pinned only.
 5. `hand_proj_mode="ortho"` raises (section 7: its camera conversion is a third-party function absent from `/root/reference`).
 6. N > 1 on real multi-GPU hardware: RCCL has carried one-rank groups and (gloo) 2-3 ranks on one GPU here;
