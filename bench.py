@@ -678,7 +678,7 @@ def main():
             models.append(build_model(copy.deepcopy(ci["person_parameters"]), copy.deepcopy(ci["object_parameters"]),
                                       objvertices=ci["objvertices"], objfaces=ci["objfaces"], camintr=ci["camintr"],
                                       optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
-                                      sync_metrics=False))
+                                      sync_metrics=False, ordinal_depth=args.depth))
         bst = FusedStepper(models, lw, 1e-2, msteps + 10)
         bst.run(10)
         barrier()

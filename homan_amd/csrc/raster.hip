@@ -1559,6 +1559,39 @@ __device__ __forceinline__ SweepGeo sweep_item_geo(const SweepFace& fc, int j, b
     return q;
 }
 
+// Accumulators that many lanes are about to add onto the SAME LDS word (a long sweep: dozens of consecutive lanes carry the same
+// (face, corner) key) are combined per row of 16 lanes first: when at least SWEEP_COMBINE_MIN lanes of the wave flush at once,
+// every row whose 16 lanes all flush the same key adds its accumulators with a DPP tree (exact sums: any order, see hm_quant) and
+// leaves the flush to its lane 15 - 4 atomics per wave and address instead of 64 serialised ones.  Other rows flush lane by lane.
+#ifndef SWEEP_COMBINE_MIN
+#define SWEEP_COMBINE_MIN 32
+#endif
+#ifndef SWEEP_COMBINE_PAIRS
+#define SWEEP_COMBINE_PAIRS 192     // the flush at the end of a trip looks only from that many pairs on (steady state of a fit: ~100 per trip)
+#endif
+__device__ __forceinline__ double sweep_row_sum(double v)          // lane 15 of every row: the row's total
+{
+    v += hm_dpp_f64<0xb1, 0xf>(v);
+    v += hm_dpp_f64<0x4e, 0xf>(v);
+    v += hm_dpp_f64<0x114, 0xf>(v);
+    v += hm_dpp_f64<0x118, 0xf>(v);
+    return v;
+}
+__device__ __forceinline__ void sweep_combine_rows(int& cur, double& acc0, double& acc1, bool flush, int lane)
+{
+    const unsigned long long nb = __ballot(flush);
+    if (__popcll(nb) < SWEEP_COMBINE_MIN) return;                 // (wave-uniform)
+    const int prev = __builtin_amdgcn_update_dpp(cur, cur, 0x111, 0xf, 0xf, false);      // row_shr:1 (lane 0 of a row: its own)
+    const unsigned long long same = __ballot(prev == cur);
+    const int sh = lane & 48;
+    const bool uni = ((unsigned)(nb >> sh) & (unsigned)(same >> sh) & 0xffffu) == 0xffffu;
+    const double r0 = sweep_row_sum(acc0), r1 = sweep_row_sum(acc1);
+    if (uni) {
+        if ((lane & 15) == 15) { acc0 = r0; acc1 = r1; }
+        else { cur = -1; acc0 = 0.0; acc1 = 0.0; }
+    }
+}
+
 // A wave takes UNITS of 256 consecutive items.  Per unit and per pass of <= 16 faces:
 //   stage 1  every item (64 per trip): family + line geometry, then ONE 8-byte load of its line's summary {first / last set
 //            position of both planes} - in the steady state of a fit ~70 % of the items have no source their sweeps could
@@ -1944,6 +1977,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                         if (ph1[k]) at = (OFF)qq.base1 + (r - q_nb0);
                         sc[k] = *hm_at<W32>(srcs, at);
                     }
+#if SWEEP_COMBINE_MIN <= 64
+                    if (base > 0) {     // (wave-uniform: behind a full round, whose accumulators all 64 lanes still carry)
+                        // between the loads and their use: the lanes whose first pair of this round starts a new key
+                        const int key0 = base + 4 * lane < npairs ? (qmeta[0] & 0x3ff) : cur;
+                        sweep_combine_rows(cur, acc0, acc1, cur >= 0 && key0 != cur, lane);
+                    }
+#endif
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         {
@@ -1953,9 +1993,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                             const int meta = qmeta[k], key = valid ? (meta & 0x3ff) : cur;
                             if (key != cur) {
                                 if (cur >= 0) {
+#if defined(SWEEP_EXP) && SWEEP_EXP == 5          // (timing experiment: every lane its own accumulator - no same-address atomics; results are wrong)
+                                    double* f = s_fg[wv][lane & 15];
+                                    unsafeAtomicAdd(f + (lane >> 4), acc0);
+                                    unsafeAtomicAdd(f + 4 + ((lane >> 4) & 1), acc1);
+#elif defined(SWEEP_EXP) && SWEEP_EXP == 6        // (timing experiment: no LDS atomics in the pair loop; results are wrong)
+                                    if (eps < 0.f) s_fg[wv][0][0] = acc0 + acc1;
+#else
                                     double* f = s_fg[wv][cur & 15];
                                     unsafeAtomicAdd(f + ((cur >> 4) & 7), acc0);
                                     unsafeAtomicAdd(f + ((cur >> 7) & 7), acc1);
+#endif
                                 }
                                 cur = key;
                                 acc0 = 0.0;
@@ -1968,6 +2016,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                         }
                     }
                 }
+#if SWEEP_COMBINE_MIN <= 64
+                if (npairs >= SWEEP_COMBINE_PAIRS) sweep_combine_rows(cur, acc0, acc1, cur >= 0, lane);
+#endif
                 if (cur >= 0) {
                     double* f = s_fg[wv][cur & 15];
                     unsafeAtomicAdd(f + ((cur >> 4) & 7), acc0);

@@ -265,7 +265,7 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | `k_sil_reduce` | block / frame + last-block finish.  One clip: the same body rides as B extra workgroups at the front of the `k_bwd_lines` launch (`hm_sil_bwd_clips(..., loss_out)`): the value is only logged, so it costs no launch; a clip batch keeps it on the third stream | latency | 0.5 MB |
 | `k_bwd_masks` | generic backward only (arbitrary `dL/dsilhouette`, or a negative loss weight): wave / tile, sweep planes via ballots | HBM | ≈ 21 MB |
 | `k_bwd_lines` | one DPP row (16 lanes) per TWO consecutive lines of a (plane, orientation, frame), 32 lines / workgroup (their mask words arrive in the same 4-byte loads; the launch is about one resident round of workgroups): expands a bit line into a position-sorted array of sources {d1, g, owner} + a 16-byte record per 64-bit word {mask, sources before it} (row scan).  Its first ⌈B·F/256⌉ workgroups build the **work list** of the sweeps instead: faces that own a sample → 64-byte records laid end to end in one global item space (block scan, one 64-bit atomic per block; a block's items start on a 64-item boundary so that the composition of every unit — and with it every summation order — is independent of the order in which blocks draw their bases).  Round 5: the 32 lines of a workgroup share plane, orientation and frame - decomposed once per workgroup in scalar registers (two 64-bit divisions per lane before) - and every address is a scalar base + 32-bit byte offset (`hm_at<W32>`) | latency | B·(4·512²/8 + S²·4 + 512² + F·46 [reads] + 4·512·8·16 + 2·512·16 + F·56 [line records, summaries, work list]) = 37.2 MB (+ 12 B per source and orientation, data dependent) |
-| **`k_bwd_sweep`** | persistent waves; a **unit** = 256 consecutive (face, winding, edge, axis, d0) items of the global list, whichever faces they belong to (a big face spreads over several waves, small faces share one), handled per pass of ≤ 16 faces staged in LDS together with their per-(face, family) constants - edge slope, first line, end-point order: one IEEE division per family instead of one per item, built by the wave right after the staging - and per-(face, axis) inward ranges.  **Stage 1** (every item, 64 per trip, four trips whose loads are all in flight before the first is tested): family by a 4-step search of the cumulative counts, line geometry from the family constants, then three loads requested together: the line's 16-byte summary, the owner of the sample just inside the edge and the alpha word of the sample just outside - the outward sweep needs a sample this winding owns AND a plane-0 source beyond the edge (exact from first / last position), the inward sweep an empty sample outside AND a plane-1 source inside the triangle's extent (positions + word mask); in the steady state of a fit 71 % of the items stop here (1.95 M items → 557 k, of which 555 k do have pairs) and the rest are queued with the two decisions.  **Stage 2** (queued items on full waves): two 16-byte record loads + popcounts give the slices `[lo, lo+nb)` of the line's source array; the (item, source) pairs are **flattened** over the wave, four consecutive pairs per lane, item of a pair by scatter + max-scan; every term is `diff / dist` with IEEE divisions and is rounded to the 2^-44 grid; per-lane running sums in DOUBLE, flushed into the face's six double LDS accumulators (`ds_add_f64`) when the (face, corner) target changes; a face inside one unit is stored, a face cut by unit boundaries is added by its units with hardware double atomics onto a zeroed target - the sums are exact, so any order gives the same value, nobody waits, and the per-unit partials + tickets of rounds 2-3 are gone; **XCD-aware**: each XCD (workgroup id mod 8) takes one contiguous eighth of the units, so a frame's index-map lines, line records and source slices are fetched into one L2 instead of eight Addresses (round 5): scalar base + 32-bit byte offset formed in 32-bit arithmetic (`k_bwd_sweep<W32>`, instantiated while the source arrays stay below 4 GB; stage 1 spent 30 of 66 instructions per trip on 64-bit address arithmetic, now 12) | VALU issue while every wave is busy (`valu_frac` 0.68; in the 8-clip batch 0.78), then the dependent-load latency of the units with many pair rounds; WORK-bound, not balance-bound: dealing units out dynamically, cost-sorted orders and a chunk list that spreads long sweeps over all waves were each built, bit-identical, and lost (EXPERIMENTS r4 / r5) | B·(F·(68+48) + 512²·4 + 512²) = **49.8 MB** |
+| **`k_bwd_sweep`** | persistent waves; a **unit** = 256 consecutive (face, winding, edge, axis, d0) items of the global list, whichever faces they belong to (a big face spreads over several waves, small faces share one), handled per pass of ≤ 16 faces staged in LDS together with their per-(face, family) constants - edge slope, first line, end-point order: one IEEE division per family instead of one per item, built by the wave right after the staging - and per-(face, axis) inward ranges.  **Stage 1** (every item, 64 per trip, four trips whose loads are all in flight before the first is tested): family by a 4-step search of the cumulative counts, line geometry from the family constants, then three loads requested together: the line's 16-byte summary, the owner of the sample just inside the edge and the alpha word of the sample just outside - the outward sweep needs a sample this winding owns AND a plane-0 source beyond the edge (exact from first / last position), the inward sweep an empty sample outside AND a plane-1 source inside the triangle's extent (positions + word mask); in the steady state of a fit 71 % of the items stop here (1.95 M items → 557 k, of which 555 k do have pairs) and the rest are queued with the two decisions.  **Stage 2** (queued items on full waves): two 16-byte record loads + popcounts give the slices `[lo, lo+nb)` of the line's source array; the (item, source) pairs are **flattened** over the wave, four consecutive pairs per lane, item of a pair by scatter + max-scan; every term is `diff / dist` with IEEE divisions and is rounded to the 2^-44 grid; per-lane running sums in DOUBLE, flushed into the face's six double LDS accumulators (`ds_add_f64`) when the (face, corner) target changes (behind a full round, rows of 16 lanes that flush one target add up with a DPP tree first and flush once: long sweeps early in a fit put dozens of lanes on the same word); a face inside one unit is stored, a face cut by unit boundaries is added by its units with hardware double atomics onto a zeroed target - the sums are exact, so any order gives the same value, nobody waits, and the per-unit partials + tickets of rounds 2-3 are gone; **XCD-aware**: each XCD (workgroup id mod 8) takes one contiguous eighth of the units, so a frame's index-map lines, line records and source slices are fetched into one L2 instead of eight Addresses (round 5): scalar base + 32-bit byte offset formed in 32-bit arithmetic (`k_bwd_sweep<W32>`, instantiated while the source arrays stay below 4 GB; stage 1 spent 30 of 66 instructions per trip on 64-bit address arithmetic, now 12) | VALU issue while every wave is busy (`valu_frac` 0.68; in the 8-clip batch 0.78), then the dependent-load latency of the units with many pair rounds; WORK-bound, not balance-bound: dealing units out dynamically, cost-sorted orders and a chunk list that spreads long sweeps over all waves were each built, bit-identical, and lost (EXPERIMENTS r4 / r5) | B·(F·(68+48) + 512²·4 + 512²) = **49.8 MB** |
 | `k_bwd_gather` | thread / vertex over CSR adjacency: one `double2` per (face, corner), summed exactly, rounded once + projection backward.  Autograd path only: the fused loop gathers inside `k_rigid_bwd` (`hm_rigid_bwd_sil`) | HBM | B·(F·24·2 + V·24) = 5.4 MB |
 | `k_rigid_fwd/bwd`, `k_rigid_bwd_x` | forward: thread / vertex; backward: grid (frame, 256-vertex chunk), sums up to four weighted per-vertex gradient terms + a per-frame vector + optionally the silhouette gradient gathered from the sweeps' per-corner output (no gather / linear-combination launches), 13 block sums behind two barriers, per-frame ticket, rot6d backward by the finishing workgroup.  The OBJECT's backward of the fused loops is `k_rigid_bwd_x`: the same work with every dependent load stage (CSR offsets → corner items → per-corner doubles) issued for all of a thread's vertices at once, the 13 sums EXACT (addends on the 2^-44 grid, DPP reductions on doubles, chunk records of doubles: any split of the vertices gives the same floats), and the object's temporal-smoothness gradient formed in the kernel from the camera-space vertices of the neighbouring frames - on the step-1 sets the object's chain waits for nothing the hand-side stream produces | latency (a chain of ~6 round trips: 15 µs for 180 workgroups) | ≤ 4·B·V·12 |
 | `k_mano_fwd`, `k_mano_bwd` | forward: (13 vertex chunks × ⌈B/4⌉) blocks, a workgroup = one chunk of 64 vertices for FOUR consecutive frames, wave f owning frame f: four chains prepared side by side, then every wave streams its 37 rows of the blend matrix `M` ONCE and accumulates them for all four frames (the 1.35 MB matrix crosses L2 once per four frames: a 240-frame batch used to pull 324 MB through L2 per launch), wave f finishes frame f (partials, skinning, rigid transform, state); per frame the arithmetic and its order are unchanged, so frame grouping is invisible in the results.  Backward: (13 × B) blocks; kinematic tree staged in LDS, chain level-parallel; `M` rows streamed coalesced with all of a wave's rows requested before the first is reduced; rigid hand transform fused into the forward epilogue; the forward keeps the chain state + posed vertices for the backward; backward = ONE launch: chunk partials, then the frame's last workgroup (per-frame ticket) runs the chain / Rodrigues / PCA backward with the prior folded in; `k_mano_bwd<true>` (`hm_mano_bwd_rigid_clips`, one clip) also does the hand's rigid backward - no mesh-gradient buffer, no `k_rigid_bwd` launch for the hand | L2 / latency | 2·C_mano + 2·B·778·12 |
@@ -391,6 +391,11 @@ side (MANO 16, pair terms 30, hand gradients 42 µs) runs under it.  What round 
   the steady state and over iterations 5-25 - while the ceiling builds that DROP pair rounds gain 15-21 % there: early in a fit
   the 5-10 M pairs of a launch are 10-19 M wave-instructions wherever they run (two IEEE divisions + two quantised double
   additions per pair by contract).  Long sweeps walked by their whole wave: -2 % (two loads per lane in flight instead of four).
+* **The sweep's LDS conflicts cost nothing in the steady state** (`SQ_LDS_ADDR_CONFLICT` 1.33 M, `SQ_LDS_BANK_CONFLICT` 1.60 M per
+  launch, VERDICT r4's candidate bound): the LDS pipe is busy 29 % of the launch, waves wait on it 4 % of their cycles.  Ceiling
+  builds at fixed states of the fit (`tools/ab_state.py`): no same-address atomics at all ±0 converged, +5.3 % at iteration 0,
+  where sweeps are long and dozens of lanes flush the same (face, corner) word.  Kept for that case: rows of 16 lanes that flush
+  one key combine with a DPP tree first (gated on full rounds): start +2.3 %, the driver's iterations 5-25 +1.0 %, converged ±0.
 * **Instructions pay where the GPU is full**: 32-bit byte offsets off scalar bases in the sweep and the line expansion, the
   scalar line decomposition, the sign-bit inside test: cfg2 steady +2.0 %, 8-clip batch +2.5 %, iterations 5-25 +2.9 %, pose
   initialisation +3.1 % (all same box, against K = 4 graphs alone).

@@ -25,7 +25,7 @@ b cfg2_driver_flags --gpus 1 --steps 20 --warmup 5          # the driver's comma
 b cfg2 --parity                                             # the default workload + the opt-in parity / end-to-end legs
 b cfg3 --step2
 b cfg5_n1 --shared-scale --steps 200
-b cfg2_depth --depth --multi-clip 0                         # cfg2 as BASELINE.json words it (sil/kp/depth/smooth)
+b cfg2_depth --depth --multi-clip 4                         # cfg2 as BASELINE.json words it (sil/kp/depth/smooth)
 b poseinit --pose-init 500                                  # object-pose initialisation
 python tools/chain_parity.py cfg2 400 > $O/${N}_freerun_cfg2_400.json 2>/dev/null
 python tools/bench_clips.py --clips 8 --steps 200 --mixed > $O/${N}_bench_mixed_shard.json 2>/dev/null
