@@ -35,7 +35,7 @@ for at in sorted(args.at):
     t0 = sw[:, 0].min(); 
     s = (sw[:, 0] - t0).astype(np.float64) / 100.0; e = (sw[:, 1] - t0).astype(np.float64) / 100.0   # 100 MHz
     busy = e - s
-    print(f"iter {at}: waves {len(sw)} span {e.max():.1f} us; start max {s.max():.1f}; busy mean {busy.mean():.1f} p50 {np.median(busy):.1f} p90 {np.percentile(busy,90):.1f} p99 {np.percentile(busy,99):.1f} max {busy.max():.1f}; end p50 {np.median(e):.1f} p90 {np.percentile(e,90):.1f}")
+    print(f"iter {at}: waves {len(sw)} span {e.max():.1f} us; start p50 {np.median(s):.1f} p90 {np.percentile(s,90):.1f} p99 {np.percentile(s,99):.1f} max {s.max():.1f} late(>5us) {(s > 5).sum()}; busy mean {busy.mean():.1f} p50 {np.median(busy):.1f} p90 {np.percentile(busy,90):.1f} p99 {np.percentile(busy,99):.1f} max {busy.max():.1f}; end p50 {np.median(e):.1f} p90 {np.percentile(e,90):.1f}")
     # raster + lines workgroups
     nr = 30 * args.clips * 32 * 32 // 4
     for name, blk in (("raster", raw[:2 * nr].reshape(-1, 2)), ("lines", raw[2 * nr:-2 * 4 * 4096].reshape(-1, 2))):
