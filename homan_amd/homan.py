@@ -32,6 +32,24 @@ def matrix_to_rot6d(rotmat):
     return rotmat.view(-1, 3, 3)[:, :, :2]
 
 
+def weakcam_persp_trans(cams, K, image_size=640, reference_depth=1.0):
+    """Camera-space translation (B,1,3) of the scaled-orthographic hand cameras `cams` = [s, tx, ty] (reference
+    homan/utils/camera.py:85-97: the camera goes to pixel units of a 640-pixel image - `compute_transformation_ortho`'s default
+    `image_size`, which HOMan.get_verts_hand does not override - and through `libyana.camutils.camconvs.
+    batch_weakcam2persptrans(cams_px, K_px, 1)`).  libyana is not in /root/reference: the conversion is the first-order
+    identity between the two camera models (u = s X + t  vs  u = f (X + T) / (Z + T_z) + c  =>  T_z = f / s,
+    T_xy = (t - c) T_z / f_xy), restated from the model, not from its source (parity unpinned; oracle/yana.py states the
+    same)."""
+    persp_scale = cams[:, :1] / 2 * image_size
+    persp_trans = (cams[:, 1:] + 1 / cams[:, :1]) * persp_scale
+    fx, fy = K[:, 0, 0] * image_size, K[:, 1, 1] * image_size
+    cx, cy = K[:, 0, 2] * image_size, K[:, 1, 2] * image_size
+    tz = reference_depth * fx / persp_scale[:, 0]
+    tx = (persp_trans[:, 0] - cx) * tz / fx
+    ty = (persp_trans[:, 1] - cy) * tz / fy
+    return torch.stack([tx, ty, tz.expand_as(tx)], 1).unsqueeze(1)
+
+
 class HOMan(nn.Module):
     def __init__(self, translations_object, rotations_object, verts_object_og, faces_object, translations_hand,
                  rotations_hand, verts_hand_og, ref_verts2d_hand, hand_sides, mano_trans, mano_rot, mano_betas,
@@ -370,7 +388,16 @@ class HOMan(nn.Module):
             return ops.rigid_transform(verts_hand_og, self.rotations_hand, self.translations_hand, scale,
                                        abs_scale=False)
         if self.hand_proj_mode == "ortho":
-            raise NotImplementedError("hand_proj_mode='ortho' (non-default --hand_proj_mode) is not built")
+            # reference homan.py:364-371 -> utils/camera.py:59-105: no rotation, the translation follows from the weak camera
+            # `cams_hand` (a Parameter with `optimize_ortho_cam`), vertices = s * (v + trans).  On the kernels' rigid
+            # transform that is (s * v) @ I + (s * trans); the twin detaches the MESH only (scale and camera keep their gradient
+            # there, unlike the perspective twin), hence the second call on the detached mesh.  Eager / graph loops only.
+            trans = weakcam_persp_trans(self.cams_hand, self.camintr)
+            ident = torch.eye(3, device=trans.device)[:, :2].expand(trans.shape[0], 3, 2).contiguous()
+            st = scale.view(-1, 1, 1) * trans
+            full = ops.rigid_transform(verts_hand_og, ident, st, scale, abs_scale=False)[0]
+            twin = ops.rigid_transform(verts_hand_og.detach(), ident, st, scale, abs_scale=False)[0]
+            return full, twin
         raise ValueError(f"Expected hand_proj_mode {self.hand_proj_mode} to be in [ortho|persp]")
 
     def get_joints_hand(self):

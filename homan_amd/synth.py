@@ -312,3 +312,17 @@ def hip_clip_fns(mano_model=None, device="cuda"):
             return ops.silhouette_render(verts.to(device), K.to(device), sctx).cpu()
 
     return sil_fn, hand_fn
+
+
+def weakcams_from_translations(translations, camintr, image_size=640):
+    """Scaled-orthographic hand cameras [s, tx, ty] (the `cams` of person_parameters) under which `--hand_proj_mode ortho`
+    places the hand at `translations` (B,1,3 or B,3): the inverse of homan_amd.homan.weakcam_persp_trans (reference
+    homan/utils/camera.py:85-97).  Synthetic-input helper."""
+    t = torch.as_tensor(translations, dtype=torch.float32).reshape(-1, 3)
+    K = torch.as_tensor(camintr, dtype=torch.float32).reshape(-1, 3, 3)
+    fx, fy = K[:, 0, 0] * image_size, K[:, 1, 1] * image_size
+    cx, cy = K[:, 0, 2] * image_size, K[:, 1, 2] * image_size
+    pscale = fx / t[:, 2]
+    px, py = t[:, 0] * fx / t[:, 2] + cx, t[:, 1] * fy / t[:, 2] + cy
+    s = 2.0 * pscale / image_size
+    return torch.stack([s, px / pscale - 1.0 / s, py / pscale - 1.0 / s], 1)

@@ -94,6 +94,22 @@ def transform_persp(meshes, translations, rotations, intrinsic_scales):
             _rowvec_times_matrix(scaled.detach().clone(), rotations) + translations)
 
 
+def transform_ortho(meshes, cams, intrinsic_scales, K, image_size=640):
+    """reference homan/utils/camera.py:59-105 as HOMan.get_verts_hand calls it (homan.py:364-371: no rotations -> identity;
+    `image_size` is NOT passed there, so the function's default 640 applies whatever the clip's image size):
+    the weak camera [s, tx, ty] in pixel units, the translation that reproduces it under K (libyana, oracle/yana.py:
+    parity unpinned), then  s_int * (v @ I + trans)  and the twin with the MESH detached (scale and camera keep their
+    gradient in both - unlike the perspective twin, which detaches the scaled mesh)."""
+    persp_scale = cams[:, :1] / 2 * image_size
+    persp_trans = (cams[:, 1:] + 1 / cams[:, :1]) * persp_scale
+    orthocams_pixels = torch.cat([persp_scale, persp_trans], 1)
+    K_pixels = K.clone()
+    K_pixels[:, :2] = K_pixels[:, :2] * image_size
+    trans = o_yana.batch_weakcam2persptrans(orthocams_pixels, K_pixels, 1).unsqueeze(1)
+    s = intrinsic_scales.view(-1, 1, 1)
+    return s * (meshes + trans), s * (meshes.detach().clone() + trans)
+
+
 def compute_dist_z(verts1, verts2):
     """reference homan/utils/geometry.py:69-86."""
     a, b = verts1[:, 2].min(), verts1[:, 2].max()
@@ -358,7 +374,8 @@ class OracleHOMan(nn.Module):
                  optimize_mano=True, optimize_mano_beta=True, inter_type="centroid", image_size=640,
                  mano_model=None, rend_size=REND_SIZE, ordinal_depth=False):
         super().__init__()
-        assert hand_proj_mode == "persp"
+        assert hand_proj_mode in ("persp", "ortho"), f"Expected hand_proj_mode {hand_proj_mode} to be in [ortho|persp]"
+        self.hand_proj_mode = hand_proj_mode
         self.ordinal_depth = bool(ordinal_depth)
         self.register_buffer("masks_object", (masks_object if masks_object.dim() == 3 else masks_object[None]) != 0)
         self.register_buffer("masks_human", masks_hand != 0)
@@ -495,6 +512,8 @@ class OracleHOMan(nn.Module):
         else:
             verts_og = self.verts_hand_og
         scale = self.int_scales_hand.detach() if detach_scale else self.int_scales_hand
+        if self.hand_proj_mode == "ortho":          # homan.py:364-371 (K = renderer.K = the constructor's camintr, :167-171)
+            return transform_ortho(verts_og, self.cams_hand, scale, self.camintr)
         return transform_persp(verts_og, self.translations_hand, rot6d_to_matrix(self.rotations_hand), scale)
 
     def forward(self, loss_weights=None):

@@ -64,3 +64,20 @@ def get_K_crop_resize(K, boxes, crop_resize):
     new_K[:, 0, 2] = (final_w - 1) / 2 + scale_x * (cx - (crop_w - 1) / 2)
     new_K[:, 1, 2] = (final_h - 1) / 2 + scale_y * (cy - (crop_h - 1) / 2)
     return new_K
+
+
+def batch_weakcam2persptrans(cams, Ks, reference_depth=1):
+    """Scaled-orthographic cameras [s, tx, ty] in PIXEL units -> the camera-space translation under which the pinhole camera
+    `Ks` images an object near the origin the way the weak camera does.  Reference call site: homan/utils/camera.py:96-97
+    (`camconvs.batch_weakcam2persptrans(orthocams_pixels, K_pixels, 1)`).  The function lives in libyana
+    (`libyana.camutils.camconvs`), which is NOT in /root/reference: this is the first-order camera identity, restated from
+    the model and not from its source - PARITY UNPINNED, non-default `--hand_proj_mode ortho` only.
+        weak camera:  u = s * X + t              pinhole:  u = f * (X + T_xy) / (Z + T_z) + c  ~  (f / T_z) * X + f * T_xy / T_z + c
+        => T_z = reference_depth * f / s,   T_xy = (t - c) * T_z / f_xy
+    (f: the focal length along x for the depth, per axis for the offsets).  cams (B,3), Ks (B or 1,3,3) -> (B,3)."""
+    s = cams[:, 0]
+    fx, fy = Ks[:, 0, 0], Ks[:, 1, 1]
+    tz = reference_depth * fx / s
+    tx = (cams[:, 1] - Ks[:, 0, 2]) * tz / fx
+    ty = (cams[:, 2] - Ks[:, 1, 2]) * tz / fy
+    return torch.stack([tx, ty, tz.expand_as(tx)], 1)
