@@ -61,7 +61,8 @@ rescaled, masks padded with keep = 0 and the rasteriser's eps scaled - same rays
 padded render: a face that leaves the image through its right / bottom border still lies inside the raster, so its edges
 sweep where a native render of that size culls them); object meshes of any size (the metric-only search covers 4096
 vertices, larger meshes take the full search; the contact scatter walks the object in ranges of 4096).  What falls back to
-the graph loop: `hand_proj_mode="ortho"` (raises, section 7).  Configurations the fused loop takes ONE clip at a time (two hands
+the graph loop (`HOMan.forward` + autograd captured in a hipGraph): `hand_proj_mode="ortho"` (section 7) and a free hand scale
+(`optimize_mano_beta=False`).  Configurations the fused loop takes ONE clip at a time (two hands
 per frame, `inter_type="min"`) run as one stepper per clip inside a shard, replayed side by side (`ShardStepper`, section 6).
 
 Reference quirks reproduced on purpose (SURVEY Appendix B): `loss_contact ≡ mean 0.02·tanh(d_NN/0.02)`; `loss_inter` is
@@ -474,10 +475,15 @@ against them like against the single-hand goldens.
 
 Evidence extraction (detectron2 / FrankMocap networks), datasets, tracking, dataset-level evaluation (chamfer / ADD-S on
 ground truth, codalab dumps), html / video export: SURVEY §8 marks them out of the hot path and their inputs (weights,
-data) are not available.  `hand_proj_mode="ortho"` (`homan/utils/camera.py:59-105`) converts its weak-perspective camera with
-`libyana.camutils.camconvs.batch_weakcam2persptrans`, a third-party function that is neither in `/root/reference` nor pinned
-anywhere: unbuildable as a parity claim, it raises `NotImplementedError`; `contact_mode≠dist_tanh`: non-default branches of a
-file the reference never reaches.  More than two hands: the reference's own collision term de-interleaves with a stride of 2
+data) are not available.  `contact_mode≠dist_tanh`: non-default branches of a file the reference never reaches.  `hand_proj_mode="ortho"`
+(`homan/homan.py:364-371` -> `utils/camera.py:59-105`, non-default) IS built since round 5 - `HOMan.get_verts_hand` places the
+hand by its scaled-orthographic camera `cams_hand` (identity rotation, translation from the camera, `s (v + t)` on the rigid
+kernels, a twin that detaches the mesh only), `cams_hand` receives its gradient, `optimize_hand_object` takes the graph loop for
+it - but as a PARITY-UNPINNED mode: the camera conversion is `libyana.camutils.camconvs.batch_weakcam2persptrans`, a
+third-party function that is neither in `/root/reference` nor pinned anywhere, restated here from the camera model (first-order
+identity between weak and pinhole camera: `T_z = f / s`, `T_xy = (t - c) T_z / f`), not from its source.  Tests: the identity's
+known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4, vertices 1e-6 m, every gradient incl. the camera's
+2e-4 of scale, the first steps of a fit) - `tests/test_ortho.py`.  More than two hands: the reference's own collision term de-interleaves with a stride of 2
 (`lossutils.py:58`).  `assign_human_masks` (`homan.py:239-296`): never called by the reference.
 
 ## 8. Known gaps / next (ranked)
@@ -498,12 +504,13 @@ file the reference never reaches.  More than two hands: the reference's own coll
    records / zeroed gradients 84 MB - and the source arrays (12 B per source and orientation: ~100 MB with 500 candidates far
    from their mask).  With them the model is 239 MB + sources; the remaining factor (~1.5 x) is the guide's x 2 correction on
    FETCH_SIZE applied to narrow scattered reads (owner gathers), for which it is not calibrated.
-4. The ordinal depth term: 140 µs on a 153 µs iteration; in a clip batch one clip per stepper.  With two hands per frame it now
+4. The ordinal depth term: 140 µs on a 153 µs iteration (clip batches run it over all frames at once, the ordinal term per clip).  With two hands per frame it now
    runs in the fused loop too (round 5: losses and gradients of `HOMan.forward` + autograd at 2e-6 / 2e-5,
    `tests/test_depth_gpu.py`) and the oracle's written-out chain covers it (bit-equal free run,
    `tests/test_handchain_gpu.py::test_two_hands_with_depth_term_bit_equal`).  The reference's own call site
    raises (`homan.py:506-507`): oracle-pinned only.
-5. `hand_proj_mode="ortho"` raises (section 7: its camera conversion is a third-party function absent from `/root/reference`).
+5. `hand_proj_mode="ortho"` is built but parity-unpinned (section 7: its camera conversion is a third-party function absent from
+   `/root/reference`, restated from the camera model) and runs through the graph loop, not the fused one.
 6. N > 1 on real multi-GPU hardware: RCCL has carried one-rank groups and (gloo) 2-3 ranks on one GPU here;
    `tests/test_dist_gpu.py::test_two_ranks_on_two_gpus_over_rccl` runs the two-GPU case wherever two GPUs are visible and
    `bench.py --gpus N` reports the process group's rank count, its backend and every rank's own rate.
