@@ -228,7 +228,14 @@ class ClipFitter:
                 stepper = FusedStepper(models, self.lw, self.lr, self.steps)
             except NotImplementedError:
                 if len(kws) == 1:
-                    raise
+                    # a configuration the fused launch sequence does not cover at all (hand_proj_mode="ortho", a free hand
+                    # scale): the same iteration through HOMan.forward + autograd in a hipGraph, like optimize_hand_object's
+                    # mode="auto" - a fresh model and graph per clip, nothing resident
+                    from .jointopt import GraphStepper
+                    stepper = GraphStepper(models[0], self.lw, self.lr, self.steps)
+                    self.timing["build"] += self._clock() - t0
+                    self.timing["built"] += 1
+                    return self._run_and_read(stepper, models)
                 del models
                 self._one_by_one.add(sig)
                 return [r for kw in kws for r in self._fit_group(sig, [kw])]
@@ -242,6 +249,9 @@ class ClipFitter:
             stepper.reload(kws)
             self.timing["load"] += self._clock() - t0
             self.timing["reused"] += 1
+        return self._run_and_read(stepper, stepper.model.models)
+
+    def _run_and_read(self, stepper, models):
         t1 = self._clock()
         stepper.run(self.steps)
         t2 = self._clock()
@@ -250,7 +260,7 @@ class ClipFitter:
         evo = evo if isinstance(evo, list) else [evo]
         out = []
         with torch.no_grad():
-            for one, e in zip(stepper.model.models, evo):
+            for one, e in zip(models, evo):
                 sd = {k: getattr(one, k).detach().cpu() for k in self.READ_BACK if hasattr(one, k)}
                 out.append(dict(loss_evolution=e, state_dict=sd, verts_object=one.get_verts_object()[0].detach().cpu(),
                                 verts_hand=one.get_verts_hand()[0].detach().cpu()))

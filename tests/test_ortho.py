@@ -116,3 +116,25 @@ def test_hip_ortho_mode_matches_oracle_and_fits(mano_model):
     np.testing.assert_allclose(evo_h["loss"][:3], evo_o["loss"][:3], rtol=5e-3)
     assert evo_h["loss"][-1] < evo_h["loss"][0]
     assert (model.cams_hand.detach().cpu() - kw["cams_hand"]).abs().max() > 0       # the camera moved
+
+
+@pytest.mark.gpu
+def test_clip_fitter_takes_ortho_clips_through_the_graph_loop(mano_model):
+    """A dataset walk in ortho mode: the fused loop refuses the mode for batches and for single clips, ClipFitter then fits
+    every clip through the autograd hipGraph - the result of optimize_hand_object for that clip."""
+    from homan_amd import synth
+    from homan_amd.jointopt import ClipFitter, optimize_hand_object
+    lw = dict(synth.STEP1_LOSS_WEIGHTS)
+    clips = [_ortho_clip(mano_model), _ortho_clip(mano_model, frames=3)]
+    fitter = ClipFitter(lw, num_iterations=5, lr=1e-2, clips_per_batch=2, hand_proj_mode="ortho", optimize_mano=True,
+                        image_size=64, mano_model=mano_model, rend_size=64)
+    results = fitter.fit(copy.deepcopy(clips) + [copy.deepcopy(clips[0])])
+    assert len(results) == 3 and not fitter.resident
+    for clip, res in zip(clips + [clips[0]], results):
+        model, evo, _ = optimize_hand_object(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
+                                             objvertices=clip["objvertices"], objfaces=clip["objfaces"], loss_weights=lw,
+                                             num_iterations=5, lr=1e-2, camintr=clip["camintr"], hand_proj_mode="ortho",
+                                             optimize_mano=True, image_size=64, mano_model=mano_model, rend_size=64)
+        np.testing.assert_array_equal(res["loss_evolution"]["loss"], evo["loss"])
+        assert torch.equal(res["state_dict"]["cams_hand"], model.cams_hand.detach().cpu())
+        assert torch.equal(res["verts_hand"], model.get_verts_hand()[0].detach().cpu())

@@ -1,11 +1,7 @@
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
-r() { echo "== $*"; python tools/bench_clips.py --steps 400 --warmup 100 "$@" 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('ms_per_round %.4f  its/s %.0f' % (d['ms_per_round'], d['its_per_s']))"; }
-r --clips 1 --frames 30
-HOMAN_GRAPH_ITERS=1 r --clips 1 --frames 30
-r --clips 2 --frames 15 --groups 2
-r --clips 2 --frames 15
-r --clips 3 --frames 10 --groups 3
-r --clips 1 --frames 15
-r --clips 2 --frames 30 --groups 2
-r --clips 2 --frames 30
+timeout 1300 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -6
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/final_drv_line.json 2> $O/final_drv.err ) 2>&1 | grep real
+tail -c 1800 $O/final_drv_line.json
+( time python bench.py > $O/final_default_line.json 2> $O/final_default.err ) 2>&1 | grep real
+tail -c 1800 $O/final_default_line.json
