@@ -10,12 +10,15 @@
 # usage (GPU box): bash tools/profile_round.sh r05   (~35 min; copy gpurun_out/r05_* into profiles/)
 R=$(cd "$(dirname "$0")/.." && pwd); N=${1:-r05}; O=$R/gpurun_out; mkdir -p $O
 cd $R
+# (PROFILE_SKIP_PMC=1 / PROFILE_SKIP_FREERUN=1: a shorter refresh that keeps the committed PMC passes / free run)
+if [ -z "$PROFILE_SKIP_PMC" ]; then
 bash tools/pmc_loop.sh > $O/${N}_pmc_loop.json 2>/dev/null
 cp $O/${N}_pmc_loop.json profiles/${N}_pmc_loop.json
 bash tools/pmc_loop.sh --step2 > $O/${N}_pmc_loop_cfg3.json 2>/dev/null
 cp $O/${N}_pmc_loop_cfg3.json profiles/${N}_pmc_loop_cfg3.json
 bash tools/pmc_poseinit.sh > $O/${N}_pmc_poseinit.json 2>/dev/null
 cp $O/${N}_pmc_poseinit.json profiles/${N}_pmc_poseinit.json
+fi
 # bench lines: the COMPACT line bench.py prints goes to *_line.json, the full record (bench.py's detail file) to *.json
 b() { # name, bench flags...
   n=$1; shift
@@ -27,7 +30,7 @@ b cfg3 --step2
 b cfg5_n1 --shared-scale --steps 200
 b cfg2_depth --depth --multi-clip 4                         # cfg2 as BASELINE.json words it (sil/kp/depth/smooth)
 b poseinit --pose-init 500                                  # object-pose initialisation
-python tools/chain_parity.py cfg2 400 > $O/${N}_freerun_cfg2_400.json 2>/dev/null
+[ -z "$PROFILE_SKIP_FREERUN" ] && python tools/chain_parity.py cfg2 400 > $O/${N}_freerun_cfg2_400.json 2>/dev/null
 python tools/bench_clips.py --clips 8 --steps 200 --mixed > $O/${N}_bench_mixed_shard.json 2>/dev/null
 # N > 1 ranks on the one GPU of this box (gloo moves the collectives' 4 bytes through the host): bench.py starts its ranks itself
 HOMAN_BENCH_BACKEND=gloo b cfg2_gpus2_gloo --gpus 2 --steps 200 --warmup 20 --multi-clip 2 --steady 0
