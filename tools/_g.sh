@@ -1,7 +1,7 @@
-R=$(pwd); O=$R/gpurun_out; mkdir -p $O
-timeout 1300 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -6
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
-( time python bench.py --gpus 1 --steps 20 --warmup 5 > $O/final_drv_line.json 2> $O/final_drv.err ) 2>&1 | grep real
-tail -c 1800 $O/final_drv_line.json
-( time python bench.py > $O/final_default_line.json 2> $O/final_default.err ) 2>&1 | grep real
-tail -c 1800 $O/final_default_line.json
+R=$(pwd); O=$R/gpurun_out; mkdir -p $O; N=r05
+cd $R
+timeout 500 bash tools/pmc_loop.sh > $O/${N}_pmc_loop.json 2>/dev/null; echo "pmc_loop rc $?"
+timeout 500 bash tools/pmc_loop.sh --step2 > $O/${N}_pmc_loop_cfg3.json 2>/dev/null; echo "pmc_loop cfg3 rc $?"
+timeout 500 bash tools/pmc_poseinit.sh > $O/${N}_pmc_poseinit.json 2>/dev/null; echo "pmc_poseinit rc $?"
+timeout 600 python tools/chain_parity.py cfg2 400 > $O/${N}_freerun_cfg2_400.json 2>/dev/null; echo "freerun rc $?"
+ls -la $O | grep -E "pmc|freerun"
