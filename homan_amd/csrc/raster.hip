@@ -2143,29 +2143,53 @@ __global__ __launch_bounds__(256) void k_shade_rgb(const int* __restrict__ idx_m
 // tmp[l] = -sum_m inv[m][l] / z_m.  Both factor through A_k = sum_samples g zp^2 w_k, so a wave per (frame, face)
 // strides the face's sample box, tests ownership in the index map, and reduces three numbers per winding.
 // gf9 (B,F,2,9): gradient w.r.t. the NDC vertices in WINDING order.
+#ifndef DBF_FACES
+#define DBF_FACES 4        // consecutive (frame, face) slots per wave
+#endif
 __global__ __launch_bounds__(256) void k_depth_bwd_faces(const float* __restrict__ faces9, const FaceBox* __restrict__ boxes,
                                                          const int* __restrict__ idx_map, const float* __restrict__ gpd,
                                                          const unsigned char* __restrict__ owned, int B, int F, int S,
                                                          float* __restrict__ gf9)
 {
+    // A wave takes DBF_FACES consecutive face slots.  Half the windings own no sample (hidden, back-facing, culled): one lane
+    // per (slot, winding) reads box mask and ownership flag - one coalesced round trip for the run - and writes the nine
+    // zeros of an idle winding itself; the wave then walks only the windings that own something, each exactly as the
+    // one-wave-per-face launch did (same lanes, same sums).  That launch was 90 000 waves for the bottle, most of them a
+    // dependent chain of three round trips to find out they had nothing to do.
     const int lane = threadIdx.x & 63;
     const int is = 2 * S;
-    const long bf = __builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6));
-    if (bf >= (long)B * F) return;
-    const int b = (int)(bf / F), fi = (int)(bf % F);
-    const uint2 bx = reinterpret_cast<const uint2*>(boxes)[bf];
-    const unsigned mask = (bx.x >> 14) & 3u;
-    const int x0 = bx.x & 0x3fff, y0 = (int)(bx.x >> 16), x1 = (int)(bx.y & 0xffff), y1 = (int)(bx.y >> 16);
-    const float* src = faces9 + bf * 9;
-    const int* idx = idx_map + (long)b * is * is;
-    const float* g = gpd + (long)b * S * S;
-    for (int var = 0; var < 2; ++var) {
+    const long nbf = (long)B * F;
+    const long w0 = (long)__builtin_amdgcn_readfirstlane((int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6)) * DBF_FACES;
+    if (w0 >= nbf) return;
+    bool live = false;
+    if (lane < 2 * DBF_FACES) {
+        const long bfl = w0 + (lane >> 1);
+        const int var = lane & 1;
+        if (bfl < nbf) {
+            const int bl = (int)(bfl / F), fl = (int)(bfl % F);
+            const unsigned m = (reinterpret_cast<const uint2*>(boxes)[bfl].x >> 14) & 3u;
+            live = ((m >> var) & 1u) && owned[(long)bl * 2 * F + fl + var * F];
+            if (!live) {
+                float* out = gf9 + (bfl * 2 + var) * 9;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) out[k] = 0.f;
+            }
+        }
+    }
+    unsigned long long todo = __ballot(live);
+    while (todo) {
+        const int t = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const long bf = w0 + (t >> 1);
+        const int var = t & 1;
+        const int b = (int)(bf / F), fi = (int)(bf % F);
+        const uint2 bx = reinterpret_cast<const uint2*>(boxes)[bf];
+        const int x0 = bx.x & 0x3fff, y0 = (int)(bx.x >> 16), x1 = (int)(bx.y & 0xffff), y1 = (int)(bx.y >> 16);
+        const float* src = faces9 + bf * 9;
+        const int* idx = idx_map + (long)b * is * is;
+        const float* g = gpd + (long)b * S * S;
         float* out = gf9 + (bf * 2 + var) * 9;
         const int fn = fi + var * F;
-        if (!((mask >> var) & 1u) || !owned[(long)b * 2 * F + fn]) {
-            if (lane < 9) out[lane] = 0.f;
-            continue;
-        }
         float f[9];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
@@ -2187,22 +2211,25 @@ __global__ __launch_bounds__(256) void k_depth_bwd_faces(const float* __restrict
         float A0 = 0.f, A1 = 0.f, A2 = 0.f;
         for (int e = lane; e < n; e += 64) {
             const int xi = x0 + e % bw, yi = y0 + e / bw;
-            if (idx[(long)yi * is + xi] != fn) continue;
+            // (the upstream gradient of the sample is requested WITH its owner, not behind the test)
+            const int owner = idx[(long)yi * is + xi];
+            const float gs = g[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)];
+            if (owner != fn) continue;
             float wgt[3], ws = 0.f;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                float t = inv[3 * k] * (float)xi;
-                t = t + inv[3 * k + 1] * (float)yi;
-                t = t + inv[3 * k + 2];
-                t = fminf(fmaxf(t, 0.0f), 1.0f);
-                wgt[k] = t;
-                ws += t;
+                float tt = inv[3 * k] * (float)xi;
+                tt = tt + inv[3 * k + 1] * (float)yi;
+                tt = tt + inv[3 * k + 2];
+                tt = fminf(fmaxf(tt, 0.0f), 1.0f);
+                wgt[k] = tt;
+                ws += tt;
             }
             float sum = wgt[0] * rz0;
             sum = sum + wgt[1] * rz1;
             sum = sum + wgt[2] * rz2;
             const float zp = ws / sum;
-            const float a = 0.25f * g[(long)((is - 1 - yi) >> 1) * S + (xi >> 1)] * zp * zp;
+            const float a = 0.25f * gs * zp * zp;
             A0 += a * (wgt[0] / ws); A1 += a * (wgt[1] / ws); A2 += a * (wgt[2] / ws);
         }
         A0 = hm_wave_sum(A0); A1 = hm_wave_sum(A1); A2 = hm_wave_sum(A2);
@@ -2231,19 +2258,37 @@ __global__ void k_depth_bwd_gather(const float* __restrict__ gf9, const int* __r
     if (i >= (long)B * V) return;
     const int b = (int)(i / V), v = (int)(i % V);
     float gu = 0.f, gv = 0.f, gz = 0.f;
-    for (int a = adj_off[v]; a < adj_off[v + 1]; ++a) {
-        const int item = adj_items[a], fi = item / 3, k = item % 3;
-        const float* pf = gf9 + ((long)b * F + fi) * 18;
-        gu += pf[3 * k] + pf[9 + 3 * (2 - k)];
-        gv += pf[3 * k + 1] + pf[9 + 3 * (2 - k) + 1];
-        gz += pf[3 * k + 2] + pf[9 + 3 * (2 - k) + 2];
-    }
-    const float* k = K + b * 9;
+    // a vertex's corners eight at a time: their item numbers in one round trip, their 6 x 8 gradient words in the next, then
+    // the additions in the adjacency's order (the same sums as the corner-by-corner walk, whose 2 x valence dependent round
+    // trips made this 45 000-thread launch 24 us long)
+    const int a_beg = adj_off[v], a_end = adj_off[v + 1];
+    const float* kk = K + b * 9;
     const float x = verts[3 * i], y = verts[3 * i + 1], z = verts[3 * i + 2];
+    const float k0 = kk[0], k1 = kk[1], k3 = kk[3], k4 = kk[4];
+    for (int a = a_beg; a < a_end; a += 8) {
+        int item[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) item[j] = adj_items[min(a + j, a_end - 1)];
+        float val[8][6];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int fi = item[j] / 3, k = item[j] % 3;
+            const float* pf = gf9 + ((long)b * F + fi) * 18;
+            val[j][0] = pf[3 * k]; val[j][1] = pf[3 * k + 1]; val[j][2] = pf[3 * k + 2];
+            val[j][3] = pf[9 + 3 * (2 - k)]; val[j][4] = pf[9 + 3 * (2 - k) + 1]; val[j][5] = pf[9 + 3 * (2 - k) + 2];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (a + j < a_end) {
+                gu += val[j][0] + val[j][3];
+                gv += val[j][1] + val[j][4];
+                gz += val[j][2] + val[j][5];
+            }
+    }
     const float zz = z + 1e-9f;
     const float du0 = gu * (2.0f / orig_size), dv0 = -gv * (2.0f / orig_size);
-    const float dxn = k[0] * du0 + k[3] * dv0;
-    const float dyn = k[1] * du0 + k[4] * dv0;
+    const float dxn = k0 * du0 + k3 * dv0;
+    const float dyn = k1 * du0 + k4 * dv0;
     grad_verts[3 * i] = dxn / zz;
     grad_verts[3 * i + 1] = dyn / zz;
     grad_verts[3 * i + 2] = -(dxn * x + dyn * y) / (zz * zz) + gz;
@@ -2262,6 +2307,7 @@ __global__ void k_depth_bwd_gather(const float* __restrict__ gf9, const int* __r
 //   words 4-5 / 6-7  softplus sums of the two kinds, fixed point 2^-32 (a workgroup's own float sum, then integer adds)
 #define ORD_CHUNKS 16
 #define ORD_FIX 4294967296.0       // 2^32
+#define ORD_MAXB 256               // frames whose records the finishing workgroup stages in LDS (longer clips: thread 0 alone)
 __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__ d0, const float* __restrict__ d1,
                                                         const float* __restrict__ a0, const float* __restrict__ a1,
                                                         const unsigned char* __restrict__ m0,
@@ -2275,15 +2321,29 @@ __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__
     const long base = (long)b * S * S;
     const int per = (S * S + ORD_CHUNKS - 1) / ORD_CHUNKS, i0 = blockIdx.x * per, i1 = min(S * S, i0 + per);
     float c00 = 0.f, c11 = 0.f, c01 = 0.f, ms01 = 0.f, s01 = 0.f, ms10 = 0.f, s10 = 0.f;
-    for (int i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        const bool s0 = a0[base + i] == 1.0f, s1 = a1[base + i] == 1.0f;
-        c00 += s0 ? 1.f : 0.f; c11 += s1 ? 1.f : 0.f;
-        if (s0 && s1) {
-            c01 += 1.f;
-            const float z0 = d0[base + i], z1 = d1[base + i];
-            const bool g0 = m0[base + i] != 0, g1 = m1[base + i] != 0;
-            if (g0 && !g1 && z1 < z0) { ms01 += 1.f; s01 += logf(1.0f + expf(fminf(fmaxf(z0 - z1, 0.f), 2.f))); }
-            if (g1 && !g0 && z0 < z1) { ms10 += 1.f; s10 += logf(1.0f + expf(fminf(fmaxf(z1 - z0, 0.f), 2.f))); }
+    // four of a thread's pixels per trip, all six words of each requested before the first is looked at: 4 dependent round
+    // trips per thread where the pixel-by-pixel walk (alpha -> test -> depths and masks -> test) had 32.  Same pixels in the
+    // same order per thread: the same sums.
+    for (int i = i0 + threadIdx.x; i < i1; i += 4 * blockDim.x) {
+        float av0[4], av1[4], zv0[4], zv1[4];
+        unsigned char mv0[4], mv1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long at = base + min(i + u * (int)blockDim.x, i1 - 1);
+            av0[u] = a0[at]; av1[u] = a1[at]; zv0[u] = d0[at]; zv1[u] = d1[at]; mv0[u] = m0[at]; mv1[u] = m1[at];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i + u * (int)blockDim.x >= i1) break;
+            const bool s0 = av0[u] == 1.0f, s1 = av1[u] == 1.0f;
+            c00 += s0 ? 1.f : 0.f; c11 += s1 ? 1.f : 0.f;
+            if (s0 && s1) {
+                c01 += 1.f;
+                const float z0 = zv0[u], z1 = zv1[u];
+                const bool g0 = mv0[u] != 0, g1 = mv1[u] != 0;
+                if (g0 && !g1 && z1 < z0) { ms01 += 1.f; s01 += logf(1.0f + expf(fminf(fmaxf(z0 - z1, 0.f), 2.f))); }
+                if (g1 && !g0 && z0 < z1) { ms10 += 1.f; s10 += logf(1.0f + expf(fminf(fmaxf(z1 - z0, 0.f), 2.f))); }
+            }
         }
     }
     float v[7] = {c00, c11, c01, ms01, s01, ms10, s10};
@@ -2297,22 +2357,34 @@ __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__
         atomicAdd(fr + 3, (unsigned long long)((double)v[6] * ORD_FIX));
     }
     if (hm_last_block(counter, gridDim.x * gridDim.y, &s_flag)) {
-        // the frames in frame order (fixed), one thread: B is a clip's length
+        // the frames in frame order (fixed), one thread: B is a clip's length.  The frames' records are fetched (and re-armed) by
+        // a thread each first - thread 0 walking them one agent-scope load after the other was B dependent round trips, most of
+        // this launch's time
+        __shared__ unsigned long long s_w[4][ORD_MAXB];
+        unsigned long long* all = reinterpret_cast<unsigned long long*>(frame_part);
+        const bool staged = B <= ORD_MAXB;
+        if (staged) {
+            for (int f = threadIdx.x; f < B; f += blockDim.x) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s_w[k][f] = __hip_atomic_load(all + 4L * f + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all[4L * f] = 0ull; all[4L * f + 1] = 0ull; all[4L * f + 2] = 0ull; all[4L * f + 3] = 0ull;     // re-armed
+            }
+            __syncthreads();
+        }
         if (threadIdx.x == 0) {
             float t[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-            unsigned long long* all = reinterpret_cast<unsigned long long*>(frame_part);
             for (int f = 0; f < B; ++f) {
-                const unsigned long long w0 = __hip_atomic_load(all + 4L * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long w1 = __hip_atomic_load(all + 4L * f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long w2 = __hip_atomic_load(all + 4L * f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long w3 = __hip_atomic_load(all + 4L * f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w0 = staged ? s_w[0][f] : __hip_atomic_load(all + 4L * f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w1 = staged ? s_w[1][f] : __hip_atomic_load(all + 4L * f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w2 = staged ? s_w[2][f] : __hip_atomic_load(all + 4L * f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long w3 = staged ? s_w[3][f] : __hip_atomic_load(all + 4L * f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool h0 = (w0 & 0x1fffffull) != 0ull, h1 = ((w0 >> 21) & 0x1fffffull) != 0ull, h01 = (w0 >> 42) != 0ull;
                 t[0] += (h0 ? 1.f : 0.f) + (h1 ? 1.f : 0.f) + 2.f * (h01 ? 1.f : 0.f);        // pairs of this frame
                 t[1] += (float)(unsigned)(w1 & 0xffffffffull);
                 t[2] += (float)((double)w2 / ORD_FIX);
                 t[3] += (float)(unsigned)(w1 >> 32);
                 t[4] += (float)((double)w3 / ORD_FIX);
-                all[4L * f] = 0ull; all[4L * f + 1] = 0ull; all[4L * f + 2] = 0ull; all[4L * f + 3] = 0ull;     // re-armed
+                if (!staged) { all[4L * f] = 0ull; all[4L * f + 1] = 0ull; all[4L * f + 2] = 0ull; all[4L * f + 3] = 0ull; }     // re-armed
             }
             float loss = 0.f;
             if (t[1] > 0.f) loss += t[2] / t[1];
@@ -2726,7 +2798,7 @@ int hm_depth_bwd(const float* verts, const float* K, int B, int V, int F, int S,
     HM_CHECK_ARG(verts && K && grad_pooled_depth && adj_off && adj_items && grad_verts && workspace);
     if (S % 16 != 0) return HM_ERR_UNSUPPORTED;
     SilWs w = carve(workspace, B, V, F, S);
-    hipLaunchKernelGGL(k_depth_bwd_faces, dim3(hm_cdiv((long)B * F * 64, 256)), dim3(256), 0, stream, w.faces9, w.boxes,
+    hipLaunchKernelGGL(k_depth_bwd_faces, dim3(hm_cdiv(hm_cdiv((long)B * F, DBF_FACES) * 64, 256)), dim3(256), 0, stream, w.faces9, w.boxes,
                        w.idx_map, grad_pooled_depth, w.owned, B, F, S, (float*)w.parts);
     hipLaunchKernelGGL(k_depth_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, (const float*)w.parts, adj_off,
                        adj_items, verts, K, B, V, F, orig_size, grad_verts);
