@@ -278,7 +278,7 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | `k_nn_min` | (step-1 sets: the search only feeds the logged hand-object distance) bounding spheres of 64-vertex groups of the Morton-ordered rigid mesh, carried from a mesh-space table into the frame; per group a lower bound for the workgroup's 128 hand vertices (nearest centre distance − radius); the four groups with the smallest bounds are scanned first, one per wave, and their exact minimum is the upper bound - with "centre distance + radius" 21.5 of the 24 groups of the bottle passed when the hand touches it, now 5.6 do; scans run four object vertices per trip on scalar trip counts with the minima kept as integer bits (a wave is alone on its SIMD: the independent chains hide the arithmetic latency); the result is the same float as `k_nn`'s.  42 → 24 µs stand-alone, and this launch range was the longest link of the hand-side chain | latency | B·(778+V)·12 |
 | `k_contact_obj` | block / frame: hand-vertex gradients added into an LDS accumulator with 64-bit **fixed-point** atomics (order-independent ⇒ deterministic without a sort; the picks are skewed onto a few object vertices) | LDS | B·(778·16 + V·12) |
 | `k_sdf_boxes`, `k_sdf_tris`, `k_sdf_need`, `k_sdf_dist`, `k_sdf_sample` | AABB + normalise; thread / triangle: packed record + +x ray parity of the few (y,z) rows under the triangle (`atomicXor` of 32-bit inside masks); thread / sample: marks touched inside voxels, first setter appends to the grid's list; workgroup / listed voxel: nearest-vertex seed + box-pruned scan of the packed triangles (a single wave was ~70 dependent round trips for one voxel); thread / sample: trilinear value + gradient, ticket reduction | latency | ≈ B·(778+V)·36 + 8.7 MB |
-| `k_depth_bwd_faces`, `k_depth_bwd_gather` (a19) | wave / (frame, face): strides the face's sample box, tests ownership in the index map, reduces the three sums `A_k = Σ g·zp²·w_k` the NMR depth backward factors through (DPP); thread / vertex gather + projection backward | HBM (index-map reads) | B·(512²·4·ρ + S²·4 + F·(44+72)) (ρ ≈ box overlap) |
+| `k_depth_bwd_faces`, `k_depth_bwd_gather` (a19) | a wave per run of 4 (frame, face) slots: a lane per (slot, winding) finds the windings that own a sample in one coalesced trip (idle ones get their zeros there), then the wave walks each live winding: strides the face's sample box, tests ownership in the index map, reduces the three sums `A_k = Σ g·zp²·w_k` the NMR depth backward factors through (DPP); thread / vertex gather + projection backward | HBM (index-map reads) | B·(512²·4·ρ + S²·4 + F·(44+72)) (ρ ≈ box overlap) |
 | `k_ordinal_depth`, `k_ordinal_depth_bwd` (a19) | 16 chunk workgroups per frame; a frame's record collects them with 64-bit INTEGER atomics (pixel counts packed, softplus sums in 2⁻³² fixed point: order-independent, so deterministic), last workgroup finishes the clip; element-wise backward.  In the fused loop the object's depth render and depth backward ride the calling stream (behind the silhouette raster / behind the sweeps), the hand's the side stream | HBM | B·S²·(4·4+2) fwd, + B·S²·8 bwd |
 | `k_adam` | one launch for all tensors (pointer table), bias corrections in double by square-and-multiply (a function of (beta, t) alone: the oracle's Adam forms the same doubles), zeroes grads; the last workgroup (ticket) bumps the device step counter.  One clip: an extra grid row writes the log row of the step being taken (weighted total + every loss / metric slot) before it draws its tickets (`hm_adam_step_log` = `hm_log_total_clips` + `hm_adam_step`, same floats, one launch less on the tail) | latency | 28·79·B |
 
@@ -504,7 +504,7 @@ known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4,
    records / zeroed gradients 84 MB - and the source arrays (12 B per source and orientation: ~100 MB with 500 candidates far
    from their mask).  With them the model is 239 MB + sources; the remaining factor (~1.5 x) is the guide's x 2 correction on
    FETCH_SIZE applied to narrow scattered reads (owner gathers), for which it is not calibrated.
-4. The ordinal depth term: 140 µs on a 153 µs iteration (clip batches run it over all frames at once, the ordinal term per clip).  With two hands per frame it now
+4. The ordinal depth term: ~116 µs on a 153 µs iteration (140 before the depth-map backward walked runs of face slots, EXPERIMENTS.md; `profiles/r05_p_cfg2_depth_timeline.txt`: three rasters make 60 % of the iteration, the calling stream is the critical path; clip batches run it over all frames at once, the ordinal term per clip).  With two hands per frame it now
    runs in the fused loop too (round 5: losses and gradients of `HOMan.forward` + autograd at 2e-6 / 2e-5,
    `tests/test_depth_gpu.py`) and the oracle's written-out chain covers it (bit-equal free run,
    `tests/test_handchain_gpu.py::test_two_hands_with_depth_term_bit_equal`).  The reference's own call site
