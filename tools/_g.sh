@@ -1,4 +1,6 @@
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
-timeout 900 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -4
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | cut -c1-400
+timeout 100 python -m pytest tests/test_depth_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -2
+dep() { env "$@" python bench.py --depth --multi-clip 0 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('   $1 depth %.0f steady %.0f' % (d['value'], d['steady_state']['value']))"; }
+dep HOMAN_DEPTH_CALIBRATE=0
+dep HOMAN_DEPTH_CALIBRATE=1
