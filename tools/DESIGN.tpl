@@ -493,6 +493,14 @@ known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4,
    full and latency-chain-bound at one clip (section 5).  What is left on the table, each worth 1-3 %: the family search of the
    sweep's stage 1 as one ballot per trip instead of four dependent LDS reads per item; a 16-bit index map (the raster's
    write-back hole, 4 µs, is 60 % index map); the rigid backward's adjacency as a padded per-vertex table (one round trip less).
+   Measured at the end of round 5 (EXPERIMENTS.md): an iteration at one clip is ~90 µs of chain floor (six dependent launches)
+   plus ~2.1 µs per frame, and a clip batch saturates at 8 clips with 105 µs per clip-iteration whatever the batch size (the
+   sweeps then issue VALU on 79 % of all SIMD cycles whatever their workgroup count); a second chain does not hide the first
+   one's floor (two 15-frame clips side by side: 210 µs against 153 for one 30-frame clip); the sweep's tail at one clip is two
+   tails of equal length - 100-170 workgroups that find no room next to the MANO backward for ~20 µs (96 VGPRs, 30.5 KB LDS) and
+   waves that walk two heavy 256-item units - and neither a workgroup-local hand-out, fewer workgroups, 25 KB of LDS nor an
+   80-register build shortens it.  So: the single clip moves with a shorter floor per launch (fewer dependent round trips in
+   raster / lines / sweep prologues), the batch only with fewer VALU instructions in sweep stage 1 and the raster's record build.
 2. One launch per kernel over clips of DIFFERENT shapes (per-clip vertex / face offsets in every `hm_*_clips` kernel) is not
    built.  What stands in for it: `ShardStepper` replays the shape groups' hipGraphs concurrently - 8 clips of 4 shapes @MIXED@
    it/s against @MULTI@ for 8 clips of one shape as a batch (`profiles/r05_bench_mixed_shard.json`), bit-identical to solo fits.
