@@ -329,7 +329,7 @@ class FusedStepper:
             #  next to THREE sweep workgroups and took 297 instead of 137 us, same-box profile)
             nn_pad = int(nn_pad) if nn_pad is not None else (34816 if C > 1 and not self.on["con"] else 0)
             fam_pads = [int(x) for x in os.environ.get("HOMAN_FAM_PADS", "0,0,0,0,0").split(",")]
-            # the hints are process-wide values read when a launch is issued (= captured): set, capture, restore - whatever
+            # the hints are per-thread values read when a launch is issued (= captured): set, capture, restore - whatever
             # happens in between (a capture that raises must not leave them changed for the next stepper)
             tune = _lib.lib()
             prev = tune.hm_tune_sweep_blocks(sb)

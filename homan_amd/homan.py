@@ -392,7 +392,11 @@ class HOMan(nn.Module):
             # `cams_hand` (a Parameter with `optimize_ortho_cam`), vertices = s * (v + trans).  On the kernels' rigid
             # transform that is (s * v) @ I + (s * trans); the twin detaches the MESH only (scale and camera keep their gradient
             # there, unlike the perspective twin), hence the second call on the detached mesh.  Eager / graph loops only.
-            trans = weakcam_persp_trans(self.cams_hand, self.camintr)
+            h = len(self.hand_sides)          # (cams_hand holds B * hand_nb rows, frame-major: K once per hand)
+            K = self.camintr if h == 1 else self.camintr.repeat_interleave(h, dim=0)
+            if bool((self.cams_hand.detach()[:, 0] == 0).any()):
+                raise ValueError("hand_proj_mode='ortho' needs cams_hand with a non-zero scale (the default zeros give 1/0)")
+            trans = weakcam_persp_trans(self.cams_hand, K)
             ident = torch.eye(3, device=trans.device)[:, :2].expand(trans.shape[0], 3, 2).contiguous()
             st = scale.view(-1, 1, 1) * trans
             full = ops.rigid_transform(verts_hand_og, ident, st, scale, abs_scale=False)[0]

@@ -14,7 +14,6 @@ Execution modes (`mode=`, a homan_amd extension; default "auto" = "fused" when i
                 and read back once at the end (no host sync inside the loop).
 """
 import ctypes
-import ctypes
 import os
 from collections import OrderedDict, defaultdict
 
@@ -80,6 +79,21 @@ class GraphStepper:
     def run(self, steps):
         for _ in range(steps):
             self.graph.replay()
+
+    def reload(self, clip_inputs):
+        """Another clip of the same shapes into the resident stepper (what FusedStepper.reload does for the fused loop): the
+        clip's data copied in place into the model, everything that belongs to the FIT reset - Adam moments, step counter,
+        gradients, log -, the captured graph reused as it is."""
+        with torch.no_grad():
+            self.model.load_clip(**clip_inputs)
+            for st_m, st_v in self.opt.state:
+                st_m.zero_()
+                st_v.zero_()
+            self.opt.step_t.zero_()
+            self.log.buf.zero_()
+            for p in self.model.parameters():
+                if p.grad is not None:
+                    p.grad.zero_()
 
     def loss_evolution(self, steps):
         torch.cuda.synchronize()

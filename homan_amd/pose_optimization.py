@@ -433,7 +433,6 @@ class PoseFitter:
 from collections import OrderedDict
 
 _FITTERS = OrderedDict()        # least recently used first
-_DIGESTS = {}                   # (data_ptr, version, shape) of a mesh tensor -> digest of its bytes (one host copy per tensor state)
 
 
 def _fitters_max():
@@ -448,17 +447,13 @@ def release_pose_fitters():
     initialisation of a dataset walk and the joint fits when the memory is wanted back.  PoseOptimizers returned by earlier
     fits stay valid (they hold references to what they share)."""
     _FITTERS.clear()
-    _DIGESTS.clear()
 
 
 def _digest(t):
-    key = (t.data_ptr(), t._version, tuple(t.shape), str(t.dtype))
-    d = _DIGESTS.get(key)
-    if d is None:
-        if len(_DIGESTS) > 64:
-            _DIGESTS.clear()
-        d = _DIGESTS[key] = hash(t.detach().cpu().numpy().tobytes())
-    return d
+    """digest of a mesh tensor's BYTES, taken on every call (one pass over a few tens of KB next to a 50 ms fit).  A cache keyed
+    on (address, version, shape) is wrong: the allocator hands the block of a freed mesh to the next mesh of the same shape
+    (version 0 again), which then found the previous mesh's digest - and with it the previous mesh's resident fitter."""
+    return hash((tuple(t.shape), str(t.dtype), t.detach().cpu().contiguous().numpy().tobytes()))
 
 
 def _resident_fitter(vertices, faces, n, size, lr, mesh_key=None):
@@ -489,7 +484,7 @@ def find_optimal_pose(vertices, faces, mask, bbox, square_bbox, image_size, K=No
     mode="eager": the reference loop verbatim (torch autograd + Adam, one host sync per step for the best-ever bookkeeping);
     mode="graph": that same autograd step captured once in a hipGraph and replayed."""
     dev = torch.device("cuda")
-    mesh_key = ((_digest(vertices), _digest(faces)) if torch.is_tensor(vertices) and torch.is_tensor(faces) else None)     # (the caller's tensors: digested once per tensor state)
+    mesh_key = ((_digest(vertices), _digest(faces)) if torch.is_tensor(vertices) and torch.is_tensor(faces) else None)     # (the caller's tensors, before the device copies below)
     vertices = torch.as_tensor(vertices).float().to(dev)
     faces = torch.as_tensor(faces).to(dev)
     x, y, b, _ = [float(t) for t in square_bbox]

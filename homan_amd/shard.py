@@ -181,6 +181,8 @@ class ClipFitter:
                              ordinal_depth=ordinal_depth)
         self.resident = OrderedDict()          # (signature, clips) -> FusedStepper
         self._one_by_one = set()          # shape signatures whose clips the fused loop takes one at a time
+        self._graph_only = set()          # ... and those it refuses altogether (ortho, free hand scale): the autograd hipGraph
+        self.resident_graph = OrderedDict()    # signature -> GraphStepper (one per shape, reloaded per clip)
         self.timing = dict(collate=0.0, build=0.0, load=0.0, iterations=0.0, read_back=0.0, clips=0, built=0, reused=0)
 
     def _clock(self):
@@ -221,6 +223,8 @@ class ClipFitter:
         if len(kws) > 1 and sig in self._one_by_one:
             return [r for kw in kws for r in self._fit_group(sig, [kw])]
         t0 = self._clock()
+        if sig in self._graph_only:
+            return self._fit_graph(sig, kws[0], t0)
         stepper = self.resident.get(key)
         if stepper is None:
             models = [HOMan(**self.model_kw, **kw) for kw in kws]
@@ -229,13 +233,9 @@ class ClipFitter:
             except NotImplementedError:
                 if len(kws) == 1:
                     # a configuration the fused launch sequence does not cover at all (hand_proj_mode="ortho", a free hand
-                    # scale): the same iteration through HOMan.forward + autograd in a hipGraph, like optimize_hand_object's
-                    # mode="auto" - a fresh model and graph per clip, nothing resident
-                    from .jointopt import GraphStepper
-                    stepper = GraphStepper(models[0], self.lw, self.lr, self.steps)
-                    self.timing["build"] += self._clock() - t0
-                    self.timing["built"] += 1
-                    return self._run_and_read(stepper, models)
+                    # scale): remembered per signature - no second attempt at the fused constructor for the clips that follow
+                    self._graph_only.add(sig)
+                    return self._fit_graph(sig, kws[0], t0, model=models[0])
                 del models
                 self._one_by_one.add(sig)
                 return [r for kw in kws for r in self._fit_group(sig, [kw])]
@@ -250,6 +250,27 @@ class ClipFitter:
             self.timing["load"] += self._clock() - t0
             self.timing["reused"] += 1
         return self._run_and_read(stepper, stepper.model.models)
+
+    def _fit_graph(self, sig, kw, t0, model=None):
+        """One clip of a configuration the fused loop refuses: the same iteration through HOMan.forward + autograd in a
+        hipGraph (optimize_hand_object's mode="auto" fallback), on ONE resident GraphStepper per shape signature - the next
+        clip of the shape is copied into its model (`GraphStepper.reload`), so a dataset walk captures one graph per shape,
+        not one per clip."""
+        from .jointopt import GraphStepper
+        stepper = self.resident_graph.get(sig)
+        if stepper is None:
+            model = model if model is not None else HOMan(**self.model_kw, **kw)
+            stepper = self.resident_graph[sig] = GraphStepper(model, self.lw, self.lr, self.steps)
+            while len(self.resident_graph) > self.max_resident:
+                self.resident_graph.popitem(last=False)
+            self.timing["build"] += self._clock() - t0
+            self.timing["built"] += 1
+        else:
+            self.resident_graph.move_to_end(sig)
+            stepper.reload(kw)
+            self.timing["load"] += self._clock() - t0
+            self.timing["reused"] += 1
+        return self._run_and_read(stepper, [stepper.model])
 
     def _run_and_read(self, stepper, models):
         t1 = self._clock()

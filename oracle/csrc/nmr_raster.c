@@ -159,7 +159,7 @@ void orc_nmr_grad_faces_alpha(const float *faces, const int32_t *idx_map,
         const float *ga = grad_alpha + bn * npix;
         float g[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         float *out = grad_faces + bf * 9;
-        if (orc_backside(f)) { memset(out, 0, 9 * sizeof(float)); continue; }
+        if (orc_backside(f) || orc_insane(f)) { memset(out, 0, 9 * sizeof(float)); continue; }   /* (culled in every pass, like the kernels' face setup) */
 
         for (int e = 0; e < 3; ++e) {
             const int pi[3] = {e, (e + 1) % 3, (e + 2) % 3};

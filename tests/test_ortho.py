@@ -130,6 +130,8 @@ def test_clip_fitter_takes_ortho_clips_through_the_graph_loop(mano_model):
                         image_size=64, mano_model=mano_model, rend_size=64)
     results = fitter.fit(copy.deepcopy(clips) + [copy.deepcopy(clips[0])])
     assert len(results) == 3 and not fitter.resident
+    # one resident autograd graph per shape (two shapes), the third clip reloaded into the first one's - not a graph per clip
+    assert len(fitter.resident_graph) == 2 and fitter.timing["built"] == 2 and fitter.timing["reused"] == 1
     for clip, res in zip(clips + [clips[0]], results):
         model, evo, _ = optimize_hand_object(copy.deepcopy(clip["person_parameters"]), copy.deepcopy(clip["object_parameters"]),
                                              objvertices=clip["objvertices"], objfaces=clip["objfaces"], loss_weights=lw,
