@@ -100,7 +100,7 @@ __global__ __launch_bounds__(1024) void k_rigid_bwd(const float* __restrict__ me
             if (terms.p[k]) {
                 gf[0] += terms.w[k] * terms.p[k][o]; gf[1] += terms.w[k] * terms.p[k][o + 1]; gf[2] += terms.w[k] * terms.p[k][o + 2];
             }
-        if (sil.parts) {        // same arithmetic as k_bwd_gather (raster.hip)
+        if (sil.parts) {        // same arithmetic as k_bwd_gather (raster_sweep.hip)
             double su = 0.0, sv = 0.0;       // exact: the per-corner sums are multiples of one quantum
             const double2* pf = reinterpret_cast<const double2*>(sil.parts + (long)n * sil.F * 6);
             // eight adjacent corners at a time: all item loads, then all gradient loads (two dependent round trips per
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(MAXT) void k_rigid_bwd_x(const float* __restrict__ 
             if (terms.p[k]) {
                 gf[0] += terms.w[k] * tv[j][k][0]; gf[1] += terms.w[k] * tv[j][k][1]; gf[2] += terms.w[k] * tv[j][k][2];
             }
-        if (sil.parts) {        // the arithmetic of k_bwd_gather (raster.hip)
+        if (sil.parts) {        // the arithmetic of k_bwd_gather (raster_sweep.hip)
             const float gu = (float)su[j], gv = (float)sw[j];
             const float* k = sil.K + n * 9;
             const float x = cv[j][0], y = cv[j][1], z = cv[j][2];

@@ -362,7 +362,7 @@ def render_rgbd(verts, K, sctx, textures, light_direction=(0, 1, 0), intensity_a
                 background_color=(0, 0, 0), orig_size=1.0):
     """`renderer.render(vertices, faces, textures, K=)` -> (rgb (B,3,S,S), depth (B,S,S), alpha (B,S,S)) for the
     reference's per-face colour textures (B,F,1,1,1,3) (reference homan/homan.py:510-545).  Visualisation only: no
-    gradient.  Rasterises with csrc/raster.hip (hm_sil_fwd) and shades its index map (hm_shade_rgb)."""
+    gradient.  Rasterises with csrc/raster_*.hip (hm_sil_fwd) and shades its index map (hm_shade_rgb)."""
     import ctypes
     with torch.no_grad():
         verts, K = _f32(verts.detach()), _f32(K)

@@ -3,7 +3,7 @@
 Mirrors reference homan/pose_optimization.py: `PoseOptimizer` (:37-160, same constructor keywords minus `textures`,
 same parameter names `rotations` / `translations`, same `forward() -> (loss_dict, iou, image)`) and
 `find_optimal_pose` (:219-383, same arguments and returned module; the debug plots are not provided).  The render leaf
-nr.Renderer(image_size, anti_aliasing=False) is `ops.silhouette_render_noaa` (csrc/raster.hip, hm_sil_fwd `alpha_full`
+nr.Renderer(image_size, anti_aliasing=False) is `ops.silhouette_render_noaa` (csrc/raster_fwd.hip, hm_sil_fwd `alpha_full`
 + hm_sil_bwd mode 3); everything else is host logic in torch, as in the reference.
 """
 import math

@@ -4,7 +4,7 @@ oracle/__init__.py).
 `depth_vertex_grads(model, lw_depth)` -> d (lw_depth * loss_depth) / d camera-space vertices of the object (B,Vo,3) and of the hand
 (B,778,3) for an `oracle.model.OracleHOMan` built with ordinal_depth=True (one hand).  Same mathematics as autograd through
 `OracleHOMan.compute_ordinal_depth_loss` (reference homan/homan.py:384-419 + lossutils.py:133-169 as the method intends - the
-reference's own call site raises); the order of every sum is the one csrc/raster.hip uses (oracle/csrc/lbs_exact.c:
+reference's own call site raises); the order of every sum is the one csrc/raster_depth.hip uses (oracle/csrc/lbs_exact.c:
 orc_ordinal_depth_grad, orc_depth_bwd_faces, orc_depth_bwd_gather), the logistic function is the shared hm_sigmoid.
 
 Chain:  depth + coverage renders of both meshes at the full-image camera (oracle.nmr: hard rasteriser, 2x2 samples per pixel,

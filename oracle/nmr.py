@@ -30,7 +30,7 @@ def projection(vertices, K, R, t, dist_coeffs, orig_size, eps=1e-9):
     The two 3x3 products are written out as ((a*m0 + b*m1) + c*m2) with one IEEE fp32 operation per product / sum
     (upstream: torch.matmul = cuBLAS, whose rounding no CPU reproduces; torch's CPU matmul is an FMA chain or a plain loop
     depending on the size).  A fixed order makes the projected vertices - and the coverage decisions of the hard rasteriser
-    that depend on their last bit - a function of the inputs alone; the HIP kernel (csrc/raster.hip project_vertex) follows
+    that depend on their last bit - a function of the inputs alone; the HIP kernel (csrc/raster_setup.hip project_vertex) follows
     the same order, bit for bit."""
     Rt = R.expand(vertices.shape[0], 3, 3) if R.shape[0] != vertices.shape[0] else R
     X, Y, Z = vertices[:, :, 0], vertices[:, :, 1], vertices[:, :, 2]

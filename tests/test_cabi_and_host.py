@@ -253,3 +253,14 @@ def test_launch_hints_are_per_thread_and_profiling_globals_are_not_in_the_releas
     blob = open(build.LIB_PATH, "rb").read()
     for name in (b"g_raster_ph", b"g_sweep_n", b"g_unit_prof", b"g_chain_ts"):
         assert name not in blob, name
+    # timing-only kernel variants ("results are wrong": ceiling builds of the sweeps) live in csrc/raster_experiments.h, which
+    # refuses to compile without -DHM_EXPERIMENT; the release build never defines it and no kernel source spells a variant out
+    assert not any("HM_EXPERIMENT" in f or "SWEEP_EXP" in f for f in build.FLAGS)
+    exp = open(os.path.join(build.CSRC, "raster_experiments.h")).read()
+    assert "#ifndef HM_EXPERIMENT\n#error" in exp
+    for path in build.sources() + [os.path.join(build.CSRC, h) for h in os.listdir(build.CSRC) if h.endswith(".h")]:
+        if os.path.basename(path) in ("raster_experiments.h", "raster_hooks.h"):
+            continue
+        src = open(path).read()
+        for word in ("SWEEP_EXP", "SWEEP_WGDYN", "results are wrong", "raster_experiments.h"):
+            assert word not in src, (os.path.basename(path), word)

@@ -64,7 +64,7 @@ def test_projection_matches_oracle():
     f9 = sctx.faces9().cpu()
     ndc = nmr.projection(verts, K, torch.eye(3)[None], torch.zeros(1, 3), torch.zeros(1, 5), 1)
     ref = nmr.vertices_to_faces(ndc, faces).reshape(2, -1, 9)
-    # same operations in the same order on both sides (oracle/nmr.py projection, csrc/raster.hip project_vertex): bit-equal
+    # same operations in the same order on both sides (oracle/nmr.py projection, csrc/raster_setup.hip project_vertex): bit-equal
     np.testing.assert_array_equal(f9.numpy(), ref.numpy())
 
 

@@ -1,6 +1,7 @@
+# scratch GPU script of the build sessions (gpurun -- 'bash tools/_g.sh')
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
-timeout 100 python -m pytest tests/test_depth_gpu.py -x -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -2
-dep() { env "$@" python bench.py --depth --multi-clip 0 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('   $1 depth %.0f steady %.0f' % (d['value'], d['steady_state']['value']))"; }
-dep HOMAN_DEPTH_CALIBRATE=0
-dep HOMAN_DEPTH_CALIBRATE=1
+tools/valu_ceiling > $O/r06_valu_ceiling.json 2> $O/valu_ceiling.err; tail -c 600 $O/r06_valu_ceiling.json
+timeout 600 python -m pytest tests/test_poseinit.py tests/test_ortho.py -x -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -3
+python bench.py 2>$O/bench0.err | tail -1 | cut -c1-1500
+bash tools/ledger.sh r06
+cat $O/r06_ledger.json
