@@ -123,6 +123,11 @@ class FusedStepper:
         self.log_in_adam = (not self.use_aux and not self.shared_scale and
                             os.environ.get("HOMAN_LOG_IN_ADAM", "1") != "0")
         self.fork_after_setup = os.environ.get("HOMAN_FORK_AFTER_SETUP", "1") != "0"
+        # the side stream forms the camera-space object vertices ITSELF (hm_rigid_fwd_clips into a buffer of its own: the face
+        # setup's arithmetic, the same floats) instead of waiting for the face setup's copy: the silhouette chain then has no
+        # successor on another queue between the iteration's fork and its join - the rasteriser follows the face setup without
+        # the few microseconds a node with a cross-queue successor costs its own queue (EXPERIMENTS r6)
+        self.side_own_vo = (os.environ.get("HOMAN_SIDE_OWN_VO") or "1") != "0" and self.h == 1 and C == 1 and not lw.get("lw_depth", 0) > 0
         # the silhouette loss / IoU values (log only) come out of the backward's first launch: one launch less on the chain
         # (two streams only: with the third stream the reduction and the log row stay there, behind the raster's event)
         self.sil_reduce_in_bwd = not self.use_aux and os.environ.get("HOMAN_SIL_REDUCE_IN_BWD", "1") != "0"
@@ -130,6 +135,8 @@ class FusedStepper:
         f = lambda *shape: torch.zeros(*shape, device=dev)
         N = self.N = B * h                                        # hand rows (hands interleaved frame-major, homan.py:62-63)
         self.vo, self.vm, self.vh = f(B, Vo, 3), f(N, Vh, 3), f(N, Vh, 3)
+        # the side stream's view of the object's vertices (see side_own_vo)
+        self.vo_b = torch.zeros_like(self.vo) if self.side_own_vo else self.vo
         self.vals = f(C, NS)                                      # row c: the loss / metric slots of clip c + its total
         on = lambda k: lw.get(k, 0.0) > 0
         self.on = dict(pca=on("lw_pca"), so=on("lw_scale_obj"), sh=on("lw_scale_hand"),
@@ -255,6 +262,26 @@ class FusedStepper:
         for p in gp:
             p.grad = torch.zeros_like(p)
         self.opt = HmAdam(parameter_groups(m, lr))
+        # MEASUREMENT ONLY (HOMAN_EXP_MAIN_ONLY=1, tools/chain_only.py): the silhouette chain alone on ONE queue - no side stream,
+        # no fork, no join, Adam over the object's pose only.  The hand stays where it starts (results are NOT the fit's); the
+        # object's chain sees its real workload.  Its iteration time is the floor any re-arrangement of the two chains can reach.
+        self.exp_main_only = os.environ.get("HOMAN_EXP_MAIN_ONLY", "0") != "0"
+        # MEASUREMENT ONLY (HOMAN_EXP_NO_EDGES=1): both chains, no edge between them inside the K-iteration graph (the side stream
+        # reads whatever object pose it finds: results are NOT the fit's) - what the two chains cost each other by sharing the GPU,
+        # without what their fork / join edges cost
+        self.exp_no_edges = os.environ.get("HOMAN_EXP_NO_EDGES", "0") != "0"
+        if self.exp_no_edges:
+            obj = {id(m.translations_object), id(m.rotations_object)}
+            gs = parameter_groups(m, lr)
+            self.opt_hand = HmAdam([g2 for g2 in (dict(g, params=[p for p in g["params"] if id(p) not in obj]) for g in gs) if g2["params"]])
+            self.opt = HmAdam([g2 for g2 in (dict(g, params=[p for p in g["params"] if id(p) in obj]) for g in gs) if g2["params"]])
+            self.side_own_vo = True
+            self.vo_b = torch.zeros_like(self.vo)
+        if self.exp_main_only:
+            obj = {id(m.translations_object), id(m.rotations_object)}
+            groups = [dict(g, params=[p for p in g["params"] if id(p) in obj]) for g in parameter_groups(m, lr)]
+            self.opt = HmAdam([g for g in groups if g["params"]])
+            self.side_own_vo = True
         self.log_buf = torch.zeros(max_steps, C, NS, device=dev)
         self.max_steps = max_steps
         self.rigid_ws_h, self.rigid_ws_o = (torch.zeros(self.L.hm_rigid_workspace_bytes(n), dtype=torch.uint8, device=dev)
@@ -344,6 +371,8 @@ class FusedStepper:
                     self.forward_backward(log=not self.log_in_adam)
                     if not self.shared_scale:
                         self.opt.step(zero_grad=False, log=self._adam_log())
+                        if self.exp_no_edges:
+                            self.opt_hand.step(zero_grad=False)
                 if self.shared_scale:        # the all-reduce of the scale gradient runs between two captured halves
                     self.graph_b = _lib.new_graph()
                     with torch.cuda.graph(self.graph_b, stream=self.cap_stream):
@@ -355,7 +384,9 @@ class FusedStepper:
                     # for every full K and the one-iteration graph for the rest - the same launches either way
                     self.graph_k = _lib.new_graph()
                     with torch.cuda.graph(self.graph_k, stream=self.cap_stream):
-                        for _ in range(self.graph_iters):
+                        if self.exp_no_edges:
+                            self._capture_no_edges(self.graph_iters)
+                        for _ in range(0 if self.exp_no_edges else self.graph_iters):
                             self.forward_backward(log=not self.log_in_adam)
                             self.opt.step(zero_grad=False, log=self._adam_log())
             finally:
@@ -491,6 +522,10 @@ class FusedStepper:
                              cctx=m.collision_ctx, pca=m.mano_pca_pose, rot=m.mano_rot, betas=m.mano_betas,
                              mtr=m.mano_trans if m.optimize_mano else None, npca=self.P * self.clip_len,      # PCA entries of one clip
                              use_aux=self.use_aux, log=log)
+        if self.exp_main_only:
+            self._issue_silhouette_chain(it)
+            self._issue_object_backward(it)
+            return
         self.side.wait_stream(main)
         self._issue_silhouette_chain(it)
         with torch.cuda.stream(self.side):
@@ -501,6 +536,30 @@ class FusedStepper:
             self._issue_hand_backward(it)
         self._issue_object_backward(it)
         self._issue_join(it)
+
+    def _capture_no_edges(self, K):
+        """(HOMAN_EXP_NO_EDGES, measurement only) K iterations: the silhouette chain + the object's Adam on the calling stream, the
+        hand side + its Adam on the side stream, one fork at the start and one join at the end"""
+        from types import SimpleNamespace
+        m, P = self.model, _lib.ptr
+        main = torch.cuda.current_stream()
+        it = SimpleNamespace(m=m, L=self.L, P=P, ck=_lib.check, B=self.B, Vo=self.Vo, Vh=self.Vh, c=self.c, on=self.on, w=self.w,
+                             CL=self.clip_len, NS=self.NS, C=self.C, main=main, side=self.side, sa=main.cuda_stream,
+                             sb=self.side.cuda_stream, rws_a=P(m.reduce_ws.buf), rws_b=P(self.reduce_ws_b.buf), sctx=m.sil_ctx,
+                             cctx=m.collision_ctx, pca=m.mano_pca_pose, rot=m.mano_rot, betas=m.mano_betas,
+                             mtr=m.mano_trans if m.optimize_mano else None, npca=self.P * self.clip_len, use_aux=False, log=False)
+        self.side.wait_stream(main)
+        for _ in range(K):
+            self._issue_silhouette_chain(it)
+            self._issue_object_backward(it)
+            self.opt.step(zero_grad=False)
+        with torch.cuda.stream(self.side):
+            for _ in range(K):
+                self._issue_hand_forward(it)
+                self._issue_pair_terms(it)
+                self._issue_hand_backward(it)
+                self.opt_hand.step(zero_grad=False, log=self._adam_log())
+        main.wait_stream(self.side)
 
     def _aux_block(self, it):
         """the silhouette reduction and the log row on the third stream (clip batches)"""
@@ -536,7 +595,9 @@ class FusedStepper:
                         1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(self.sil_keep), P(self.sil_ref),
                         None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
                         P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, P(self.vo))
-            if self.fork_after_setup:
+            if self.side_own_vo:
+                ck(L.hm_sil_fwd_clips(*fwd_args, sa), "sil_fwd")      # (no successor on the side stream: see side_own_vo)
+            elif self.fork_after_setup:
                 # the face setup (which also writes the camera-space vertices self.vo), the fork of the side stream, then the
                 # rasteriser: the pair-wise losses do not wait for the raster and the raster has one successor on its chain
                 ck(L.hm_sil_fwd_phase_clips(*fwd_args, 1, sa), "sil_fwd(setup)")
@@ -579,6 +640,9 @@ class FusedStepper:
             ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
                                     P(m.int_scales_object), 1, B, Vo, None, P(self.vo), CL, sb), "rigid_fwd(obj)")
             self.ev_vo.record(side)
+        elif self.side_own_vo:
+            ck(L.hm_rigid_fwd_clips(P(m.verts_object_og), P(m.rotations_object), P(m.translations_object),
+                                    P(m.int_scales_object), 1, B, Vo, None, P(self.vo_b), CL, sb), "rigid_fwd(obj, side copy)")
         if m.optimize_mano:
             ck(L.hm_mano_fwd_clips(self.mctx.ptrs, P(pca), self.P, P(rot), P(betas), P(mtr), B, P(self.vm), None,
                                    P(m.rotations_hand), P(m.translations_hand), P(m.int_scales_hand), P(self.vh),
@@ -620,13 +684,14 @@ class FusedStepper:
                                       P(self.U_v2d), self._slot("loss_v2d_hand"), rws_b, CL, NS, sb), "v2d")
         nn_early = False
         if on["sil"]:
-            side.wait_event(self.ev_sil)         # self.vo: camera-space object vertices from the calling stream
+            if not self.side_own_vo:
+                side.wait_event(self.ev_sil)     # self.vo: camera-space object vertices from the calling stream
             if self.pairs_after_lines:
                 # (the metric-only search - it feeds nothing but the logged hand-object distance, and is the longest
                 #  launch of the hand side in a batch - can run before that wait, next to the rasteriser)
                 nn_early = self.nn_early and on["inter"] and not on["con"] and Vo <= 4096 and not self.inter_min
                 if nn_early:
-                    ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, None, None, self._slot("handobj_maxdist"),
+                    ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo_b), B, Vh, Vo, None, None, self._slot("handobj_maxdist"),
                                                rws_b, CL, NS, P(self.obj_order),
                                                (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
                                                P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sb), "nn")
@@ -655,14 +720,14 @@ class FusedStepper:
         if on["col"]:
             if split:
                 self.ev_hand.record(side)        # both vertex buffers exist on this stream from here on
-            ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo), P(cctx.f1), Vo,
+            ck(L.hm_collision_fwd_clips(P(self.vh), P(cctx.f0), Vh, cctx.f0.shape[0], P(self.vo_b), P(cctx.f1), Vo,
                                         cctx.f1.shape[0], B, c.SDF_SCALE_FACTOR, P(self.U_colh), P(self.U_colo),
                                         self._slot("loss_collision"), P(cctx.ws), CL, NS, sb), "collision")
             if split:
                 self.ev_col.record(side)
                 side2.wait_event(self.ev_hand)
         if sm_here and not fuse:
-            ck(L.hm_smooth_fwd_clips(P(self.vo), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
+            ck(L.hm_smooth_fwd_clips(P(self.vo_b), B, Vo, 1, P(self.U_smo), self._slot("loss_smooth_obj"), rws_b, CL, NS,
                                      sb2), "smooth(obj)")
         def search_and_contact(stream_obj, rws):
             sx = stream_obj.cuda_stream
@@ -670,12 +735,12 @@ class FusedStepper:
                 # (without the contact term only the logged distance is needed: metric-only search - its group table
                 #  covers 4096 object vertices, larger meshes take the full search for the same number)
                 full = on["con"] or Vo > 4096 or self.inter_min      # ('min' names the closest PAIR: indices needed)
-                ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo), B, Vh, Vo, P(self.nn_idx) if full else None,
+                ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo_b), B, Vh, Vo, P(self.nn_idx) if full else None,
                                            P(self.nn_d2) if full else None, self._slot("handobj_maxdist"), rws, CL, NS,
                                            P(self.obj_order), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
                                            P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sx), "nn")
             if on["con"]:
-                ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
+                ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo_b), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
                                           P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws, CL, NS, sx),
                    "contact")
         # (the search on a third stream at one clip / step 1: +1 %; -9 % on an 8-clip batch.  Search + contact as a third
@@ -684,7 +749,7 @@ class FusedStepper:
         if not nn_full_fused:
             search_and_contact(side2, rws_b)
         if fuse:
-            ck(L.hm_pair_terms_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo,
+            ck(L.hm_pair_terms_fwd_clips(P(self.vh), P(self.vo_b), P(m.camintr), B, Vh, Vo,
                                          self._slot("handobj_maxdist") if (nn_fused or nn_full_fused) else None,
                                          P(self.obj_order), rws_b,
                                          c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(self.rec),
@@ -701,7 +766,7 @@ class FusedStepper:
             if nn_full_fused:
                 search_and_contact(side2, rws_b)          # (the contact launches only: the search ran above)
         elif on["inter"]:
-            ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
+            ck(L.hm_inter_fwd_clips(P(self.vh), P(self.vo_b), P(m.camintr), B, Vh, Vo, c.INTERACTION_BBOX_EXPANSION,
                                     float(c.INTERACTION_Z_THRESH), P(self.rec),
                                     P(self.tmp_inter) if self.inter_min else self._slot("loss_inter"), rws_b, CL,
                                     NS, sb2), "inter")
@@ -714,7 +779,7 @@ class FusedStepper:
                 flags = (self.rec[:, 0] != 0).float()
                 i_star = self.nn_d2.argmin(1)
                 j_star = self.nn_idx.gather(1, i_star[:, None]).long()[:, 0]
-                diff = self.vh[self.rows, i_star] - self.vo[self.rows, j_star]
+                diff = self.vh[self.rows, i_star] - self.vo_b[self.rows, j_star]
                 self.vals[0, self.SLOTS.index("loss_inter")] = ((diff * diff).sum(1) * flags).sum()
                 pull = (2.0 * w["loss_inter"]) * diff * flags[:, None]
                 self.G_min_h.zero_()

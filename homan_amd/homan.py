@@ -79,7 +79,11 @@ class HOMan(nn.Module):
             rotations_hand = matrix_to_rot6d(rotations_hand)
         self.rotations_hand = nn.Parameter(rotations_hand.detach().clone().contiguous(), requires_grad=True)
         if cams_hand is None:
+            if hand_proj_mode == "ortho":      # (checked here, on the host input: forward may run inside a stream capture)
+                raise ValueError("hand_proj_mode='ortho' needs cams_hand (scaled-orthographic [s, tx, ty] per hand, s != 0)")
             cams_hand = torch.zeros(translations_hand.shape[0], 3)
+        elif hand_proj_mode == "ortho" and bool((torch.as_tensor(cams_hand).detach().reshape(-1, 3)[:, 0] == 0).any()):
+            raise ValueError("hand_proj_mode='ortho': cams_hand holds a zero scale (the translation is f / s)")
         if optimize_ortho_cam:
             self.cams_hand = nn.Parameter(f32(cams_hand), requires_grad=True)
         else:
@@ -394,8 +398,6 @@ class HOMan(nn.Module):
             # there, unlike the perspective twin), hence the second call on the detached mesh.  Eager / graph loops only.
             h = len(self.hand_sides)          # (cams_hand holds B * hand_nb rows, frame-major: K once per hand)
             K = self.camintr if h == 1 else self.camintr.repeat_interleave(h, dim=0)
-            if bool((self.cams_hand.detach()[:, 0] == 0).any()):
-                raise ValueError("hand_proj_mode='ortho' needs cams_hand with a non-zero scale (the default zeros give 1/0)")
             trans = weakcam_persp_trans(self.cams_hand, K)
             ident = torch.eye(3, device=trans.device)[:, :2].expand(trans.shape[0], 3, 2).contiguous()
             st = scale.view(-1, 1, 1) * trans

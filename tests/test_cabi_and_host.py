@@ -207,7 +207,11 @@ def test_bench_line_is_compact_and_keeps_the_contract():
     assert len(json.dumps(full)) > 20000                       # (the record that did not parse)
     worst = dict(full, per_rank_its=[6249.123456789] * 8, ranks=8, backend="nccl", parity_ok=True,
                  parity_vs="oracle's reproducible (written-out) loop, end state",
-                 config=dict(full["config"], workload="x" * 5000, nested={"a": [1] * 1000}))
+                 config=dict(full["config"], workload="x" * 5000, nested={"a": [1] * 1000}),
+                 cfg2_depth=dict(value=3716.123456, unit="it/s", ms_per_step=0.269123456, dominant_kernel_us=54.123456, note="y" * 500),
+                 cfg3=dict(value=5457.123456, unit="it/s", ms_per_step=0.183123456, dominant_kernel_us=46.123456, kernels_us={"a": 1.0}))
+    legs = bench.compact_line(dict(full, cfg2_depth=worst["cfg2_depth"], cfg3=worst["cfg3"]))
+    assert set(legs["cfg2_depth"]) == {"value", "ms_per_step", "dominant_kernel_us"} and "cfg3" in legs      # one number each
     for rec in (full, worst):
         line = bench.compact_line(rec)
         s = json.dumps(line)

@@ -16,18 +16,19 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--warm", type=int, default=100)
     ap.add_argument("--step2", action="store_true")
+    ap.add_argument("--frames", type=int, default=30)
     a = ap.parse_args()
     from homan_amd import lib as _lib, synth
     from homan_amd.jointopt import FusedStepper, build_model
     from homan_amd.mano_assets import synthetic_mano
     mano = synthetic_mano(0)
     sil_fn, hand_fn = synth.hip_clip_fns(mano)
-    clip = synth.make_clip(seed=0, frames=30, rend_size=256, image_size=256, obj="bottle", silhouette_fn=sil_fn,
+    clip = synth.make_clip(seed=0, frames=a.frames, rend_size=256, image_size=256, obj="bottle", silhouette_fn=sil_fn,
                            hand_verts_fn=hand_fn)
     model = build_model(clip["person_parameters"], clip["object_parameters"], objvertices=clip["objvertices"],
                         objfaces=clip["objfaces"], camintr=clip["camintr"], optimize_mano=True, image_size=256,
                         mano_model=mano, rend_size=256, sync_metrics=False)
-    lw = dict(synth.STEP2_LOSS_WEIGHTS if a.step2 else synth.STEP1_LOSS_WEIGHTS)
+    lw = dict(synth.STEP2_LOSS_WEIGHTS if a.step2 else synth.CFG1_LOSS_WEIGHTS if a.frames < 2 else synth.STEP1_LOSS_WEIGHTS)
     st = FusedStepper(model, lw, 1e-2, a.warm + 8, capture=False)
     L = _lib.lib()
     L.hm_debug_sweep_stats.argtypes = [ctypes.c_void_p]

@@ -37,13 +37,16 @@
 #define I4(op, n) op " %" S_(n) ", %" S_(n) ", %16, %17\n"
 
 enum { OP_ADD_U32, OP_ADD_F32, OP_MUL_F32, OP_FMA_F32, OP_MAD_U24, OP_ALIGNBIT, OP_OR3, OP_LSHL_ADD, OP_MUL_LO, OP_CMP_CND, OP_ADD_F64,
-       OP_FMA_F64, OP_PK_FMA, OP_RCP, OP_CVT, OP_DPP_ADD, OP_MINMAX, OP_DIV_F32, OP_N };
+       OP_FMA_F64, OP_PK_FMA, OP_RCP, OP_CVT, OP_DPP_ADD, OP_MINMAX, OP_DIV_F32, OP_MOV, OP_AND, OP_OR, OP_LSHLREV, OP_SUB_U32, OP_XOR,
+       OP_MAX_I32, OP_BFE, OP_CMP_ONLY, OP_CND_ONLY, OP_SUB_F32, OP_N };
 static const char* kNames[OP_N] = {"v_add_u32", "v_add_f32", "v_mul_f32", "v_fma_f32", "v_mad_u32_u24", "v_alignbit_b32", "v_or3_b32",
                                    "v_lshl_add_u32", "v_mul_lo_u32", "v_cmp_lt_f32+v_cndmask_b32", "v_add_f64", "v_fma_f64",
                                    "v_pk_fma_f32", "v_rcp_f32", "v_cvt_f32_i32", "v_add_u32_dpp(row_shr:1)", "v_min_f32/v_max_f32",
-                                   "ieee_div_f32(sequence)"};
+                                   "ieee_div_f32(sequence)", "v_mov_b32", "v_and_b32", "v_or_b32", "v_lshlrev_b32", "v_sub_u32", "v_xor_b32",
+                                   "v_max_i32", "v_bfe_u32", "v_cmp_lt_f32(to sgpr pair)", "v_cndmask_b32(sgpr pair)", "v_sub_f32"};
 // wave-instructions per trip of the timed loop (the division: DIVISIONS per trip; its instruction count comes from the ISA)
-static const int kPerTrip[OP_N] = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 16};
+static const int kPerTrip[OP_N] = {128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 16,
+                                    128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128};
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_valu(unsigned long long* __restrict__ cycles, float* __restrict__ sink, int iters, float fq, float fr)
@@ -94,7 +97,8 @@ __global__ __launch_bounds__(256) void k_valu(unsigned long long* __restrict__ c
         }
         t1 = __builtin_readcyclecounter();
         res = ACC_SUM;
-    } else if constexpr (OP == OP_ADD_F32 || OP == OP_MUL_F32 || OP == OP_FMA_F32 || OP == OP_RCP || OP == OP_MINMAX || OP == OP_CMP_CND) {
+    } else if constexpr (OP == OP_ADD_F32 || OP == OP_MUL_F32 || OP == OP_FMA_F32 || OP == OP_RCP || OP == OP_MINMAX || OP == OP_CMP_CND ||
+                         OP == OP_CMP_ONLY || OP == OP_CND_ONLY || OP == OP_SUB_F32) {
         ACC_DECL(float, 1.0f + (float)(tid & 7));
         const float q = fq, r = fr;
         t0 = __builtin_readcyclecounter();
@@ -102,6 +106,28 @@ __global__ __launch_bounds__(256) void k_valu(unsigned long long* __restrict__ c
             if constexpr (OP == OP_ADD_F32) {
 #define OPX(n) I3("v_add_f32", n)
                 asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
+#undef OPX
+            } else if constexpr (OP == OP_SUB_F32) {
+#define OPX(n) I3("v_sub_f32", n)
+                asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
+#undef OPX
+            } else if constexpr (OP == OP_CMP_ONLY) {
+                // compares only, results into eight SGPR pairs (never read: the accumulators are the sources)
+                asm volatile(
+                    ".rept 8\n"
+                    "v_cmp_lt_f32_e64 s[36:37], %0, %16\n v_cmp_lt_f32_e64 s[38:39], %1, %16\n v_cmp_lt_f32_e64 s[40:41], %2, %16\n"
+                    "v_cmp_lt_f32_e64 s[42:43], %3, %16\n v_cmp_lt_f32_e64 s[44:45], %4, %16\n v_cmp_lt_f32_e64 s[46:47], %5, %16\n"
+                    "v_cmp_lt_f32_e64 s[48:49], %6, %16\n v_cmp_lt_f32_e64 s[50:51], %7, %16\n"
+                    "v_cmp_lt_f32_e64 s[36:37], %8, %16\n v_cmp_lt_f32_e64 s[38:39], %9, %16\n v_cmp_lt_f32_e64 s[40:41], %10, %16\n"
+                    "v_cmp_lt_f32_e64 s[42:43], %11, %16\n v_cmp_lt_f32_e64 s[44:45], %12, %16\n v_cmp_lt_f32_e64 s[46:47], %13, %16\n"
+                    "v_cmp_lt_f32_e64 s[48:49], %14, %16\n v_cmp_lt_f32_e64 s[50:51], %15, %16\n"
+                    ".endr\n"
+                    : ACC_IO : "v"(q), "v"(r)
+                    : "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51");
+            } else if constexpr (OP == OP_CND_ONLY) {
+                // selects only, all reading one SGPR pair written once before the loop body's block (exec: every lane)
+#define OPX(n) "v_cndmask_b32_e64 %" S_(n) ", %" S_(n) ", %17, s[36:37]\n"
+                asm volatile("s_mov_b64 s[36:37], exec\n s_nop 4\n" R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r) : "s36", "s37");
 #undef OPX
             } else if constexpr (OP == OP_MUL_F32) {
 #define OPX(n) I3("v_mul_f32", n)
@@ -180,6 +206,41 @@ __global__ __launch_bounds__(256) void k_valu(unsigned long long* __restrict__ c
 #define OPX(n) "v_cvt_f32_i32 %" S_(n) ", %" S_(n) "\n"
                 asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
 #undef OPX
+            } else if constexpr (OP == OP_MOV) {
+                // (a move chain a_n <- invariant would be dead: the destination alternates between two invariants instead)
+#define OPA(n) "v_mov_b32 %" S_(n) ", %16\n"
+#define OPB(n) "v_mov_b32 %" S_(n) ", %17\n"
+                asm volatile(R16(OPA) R16(OPB) R16(OPA) R16(OPB) R16(OPA) R16(OPB) R16(OPA) R16(OPB) : ACC_IO : "v"(q), "v"(r));
+#undef OPA
+#undef OPB
+            } else if constexpr (OP == OP_AND) {
+#define OPX(n) I3("v_and_b32", n)
+                asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
+#undef OPX
+            } else if constexpr (OP == OP_OR) {
+#define OPX(n) I3("v_or_b32", n)
+                asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
+#undef OPX
+            } else if constexpr (OP == OP_XOR) {
+#define OPX(n) I3("v_xor_b32", n)
+                asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
+#undef OPX
+            } else if constexpr (OP == OP_LSHLREV) {
+#define OPX(n) "v_lshlrev_b32 %" S_(n) ", 1, %" S_(n) "\n"
+                asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
+#undef OPX
+            } else if constexpr (OP == OP_SUB_U32) {
+#define OPX(n) I3("v_sub_u32", n)
+                asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
+#undef OPX
+            } else if constexpr (OP == OP_MAX_I32) {
+#define OPX(n) I3("v_max_i32", n)
+                asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
+#undef OPX
+            } else if constexpr (OP == OP_BFE) {
+#define OPX(n) "v_bfe_u32 %" S_(n) ", %" S_(n) ", 1, 31\n"
+                asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
+#undef OPX
             } else {   // OP_DPP_ADD
 #define OPX(n) "v_add_u32_dpp %" S_(n) ", %" S_(n) ", %16 row_shr:1 row_mask:0xf bank_mask:0xf\n"
                 asm volatile(R8X(R16(OPX)) : ACC_IO : "v"(q), "v"(r));
@@ -201,6 +262,7 @@ static kern_t kernel_of(int op)
 #define C(o) case o: return pick<o>();
         C(OP_ADD_U32) C(OP_ADD_F32) C(OP_MUL_F32) C(OP_FMA_F32) C(OP_MAD_U24) C(OP_ALIGNBIT) C(OP_OR3) C(OP_LSHL_ADD) C(OP_MUL_LO)
         C(OP_CMP_CND) C(OP_ADD_F64) C(OP_FMA_F64) C(OP_PK_FMA) C(OP_RCP) C(OP_CVT) C(OP_DPP_ADD) C(OP_MINMAX) C(OP_DIV_F32)
+        C(OP_MOV) C(OP_AND) C(OP_OR) C(OP_LSHLREV) C(OP_SUB_U32) C(OP_XOR) C(OP_MAX_I32) C(OP_BFE) C(OP_CMP_ONLY) C(OP_CND_ONLY) C(OP_SUB_F32)
 #undef C
     }
     return nullptr;
@@ -253,6 +315,8 @@ int main(int argc, char** argv)
             const double wall = (ms * 1e-3) * nominal_hz / (per_wave * wps);       // (all SIMDs run the same: per-SIMD time = wall)
             printf("%s\"w%d\": {\"cycles_per_instr\": %.3f, \"wall_cycles_per_instr_at_2.4GHz\": %.3f, \"launch_us\": %.1f}",
                    wi ? ", " : "", wps, cyc, wall, ms * 1e3);
+            if (op == OP_DIV_F32 && wps == 8)
+                printf(", \"instructions_per_division\": 11, \"w8_wall_cycles_per_instruction_of_the_sequence\": %.3f", wall / 11.0);
         }
         printf("}%s\n", op + 1 < OP_N ? "," : "");
     }
