@@ -13,7 +13,7 @@
 __global__ __launch_bounds__(256) void k_depth_bwd_faces(const float* __restrict__ faces9, const FaceBox* __restrict__ boxes,
                                                          const int* __restrict__ idx_map, const float* __restrict__ gpd,
                                                          const unsigned char* __restrict__ owned, int B, int F, int S,
-                                                         float* __restrict__ gf9)
+                                                         float* __restrict__ gf9, const unsigned char* __restrict__ gflags)
 {
     // A wave takes DBF_FACES consecutive face slots.  Half the windings own no sample (hidden, back-facing, culled): one lane
     // per (slot, winding) reads box mask and ownership flag - one coalesced round trip for the run - and writes the nine
@@ -33,6 +33,22 @@ __global__ __launch_bounds__(256) void k_depth_bwd_faces(const float* __restrict
             const int bl = (int)(bfl / F), fl = (int)(bfl % F);
             const unsigned m = (reinterpret_cast<const uint2*>(boxes)[bfl].x >> 14) & 3u;
             live = ((m >> var) & 1u) && owned[(long)bl * 2 * F + fl + var * F];
+            if (live && gflags) {
+                // SPARSE upstream gradient (an ordinal depth term is zero wherever render and annotation agree on the order:
+                // nearly everywhere): gflags holds one byte per (frame, pixel row, 64-pixel segment) = "some pixel of the segment
+                // has a non-zero gradient" (hm_ordinal_depth_bwd_flags).  A winding whose sample box touches no flagged segment
+                // would sum exact zeros over its samples: it gets its zeros here, without the walk.  (Boxes taller than 64
+                // pixel rows are walked regardless.)
+                const uint2 fb = reinterpret_cast<const uint2*>(boxes)[bfl];
+                const int bx0 = fb.x & 0x3fff, by0 = (int)(fb.x >> 16), bx1 = (int)(fb.y & 0xffff), by1 = (int)(fb.y >> 16);
+                const int r0 = (is - 1 - by1) >> 1, r1 = (is - 1 - by0) >> 1, s0 = bx0 >> 7, s1 = bx1 >> 7, nseg = S >> 6;
+                if (r1 - r0 < 64) {
+                    unsigned any = 0u;
+                    for (int r = r0; r <= r1; ++r)
+                        for (int sg = s0; sg <= s1; ++sg) any |= gflags[((long)bl * S + r) * nseg + sg];
+                    live = any != 0u;
+                }
+            }
             if (!live) {
                 float* out = gf9 + (bfl * 2 + var) * 9;
 #pragma unroll
@@ -116,9 +132,35 @@ __global__ __launch_bounds__(256) void k_depth_bwd_faces(const float* __restrict
 __global__ void k_depth_bwd_gather(const float* __restrict__ gf9, const int* __restrict__ adj_off,
                                    const int* __restrict__ adj_items, const float* __restrict__ verts,
                                    const float* __restrict__ K, int B, int V, int F, float orig_size,
-                                   float* __restrict__ grad_verts)
+                                   float* __restrict__ grad_verts, const unsigned char* __restrict__ gflags, int S)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gflags) {
+        // a frame without any flagged segment (see k_depth_bwd_faces) has gf9 == 0 throughout: its vertices get their zeros
+        // without the two dependent round trips of the gather.  The workgroup scans the flag bytes of the (one or two) frames
+        // its vertices belong to.
+        __shared__ int s_any[8];
+        const long nv = (long)B * V;
+        const int b_lo = (int)(((long)blockIdx.x * blockDim.x) / V);
+        const int b_hi = (int)(min((long)blockIdx.x * blockDim.x + blockDim.x - 1, nv - 1) / V);
+        if (threadIdx.x < 8) s_any[threadIdx.x] = b_hi - b_lo >= 8 ? 1 : 0;
+        __syncthreads();
+        if (b_hi - b_lo < 8) {
+            const int nflag = S * (S >> 6);                               // bytes per frame, a multiple of 64
+            for (int bb = b_lo; bb <= b_hi; ++bb) {
+                unsigned a = 0u;
+                for (int k = 4 * (int)threadIdx.x; k < nflag; k += 4 * (int)blockDim.x)
+                    a |= *reinterpret_cast<const unsigned*>(gflags + (long)bb * nflag + k);
+                if (a) s_any[bb - b_lo] = 1;
+            }
+        }
+        __syncthreads();
+        if (i >= nv) return;
+        if (!s_any[(int)(i / V) - b_lo]) {
+            grad_verts[3 * i] = 0.f; grad_verts[3 * i + 1] = 0.f; grad_verts[3 * i + 2] = 0.f;
+            return;
+        }
+    }
     if (i >= (long)B * V) return;
     const int b = (int)(i / V), v = (int)(i % V);
     float gu = 0.f, gv = 0.f, gz = 0.f;
@@ -264,10 +306,11 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
                                     const float* __restrict__ a0, const float* __restrict__ a1,
                                     const unsigned char* __restrict__ m0, const unsigned char* __restrict__ m1, long n,
                                     const float* __restrict__ rec, const float* __restrict__ upstream,
-                                    float* __restrict__ g0, float* __restrict__ g1)
+                                    float* __restrict__ g0, float* __restrict__ g1, unsigned char* __restrict__ f0,
+                                    unsigned char* __restrict__ f1)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n) return;          // (with flags: n is a multiple of 64, so a wave is inside or outside as a whole)
     float r0 = 0.f, r1 = 0.f;
     if (a0[i] == 1.0f && a1[i] == 1.0f) {
         const float z0 = d0[i], z1 = d1[i];
@@ -284,23 +327,39 @@ __global__ void k_ordinal_depth_bwd(const float* __restrict__ d0, const float* _
     }
     g0[i] = r0;
     g1[i] = r1;
+    if (f0) {       // one byte per 64 consecutive pixels (= a segment of one row: S is a multiple of 64): "some gradient is non-zero"
+        const unsigned long long b0 = __ballot(r0 != 0.f), b1 = __ballot(r1 != 0.f);
+        if ((threadIdx.x & 63) == 0) { f0[i >> 6] = b0 ? 1 : 0; f1[i >> 6] = b1 ? 1 : 0; }
+    }
 }
 
 extern "C" {
 // Backward of the depth image of the last hm_sil_fwd (called with pooled_depth): grad_pooled_depth (B,S,S) ->
 // grad_verts (B,V,3).  Uses faces9 / boxes / idx_map / owned of the workspace; gf9 scratch lives in `parts`.
+// gflags (optional, S % 64 == 0): the non-zero structure of grad_pooled_depth as hm_ordinal_depth_bwd_flags leaves it - one byte per
+// (frame, pixel row, 64-pixel segment), non-zero iff some pixel of the segment has a non-zero gradient (a byte may be set for an
+// all-zero segment, never clear for a non-zero one).  Faces and frames that touch no flagged segment get their exact zeros
+// without being walked; the result is the same with or without the flags.
+int hm_depth_bwd_sparse(const float* verts, const float* K, int B, int V, int F, int S, float orig_size,
+                        const float* grad_pooled_depth, const int* adj_off, const int* adj_items, float* grad_verts,
+                        const unsigned char* gflags, void* workspace, hipStream_t stream)
+{
+    HM_CHECK_ARG(verts && K && grad_pooled_depth && adj_off && adj_items && grad_verts && workspace);
+    HM_CHECK_ARG(!gflags || S % 64 == 0);
+    if (S % 16 != 0) return HM_ERR_UNSUPPORTED;
+    SilWs w = carve(workspace, B, V, F, S);
+    hipLaunchKernelGGL(k_depth_bwd_faces, dim3(hm_cdiv(hm_cdiv((long)B * F, DBF_FACES) * 64, 256)), dim3(256), 0, stream, w.faces9, w.boxes,
+                       w.idx_map, grad_pooled_depth, w.owned, B, F, S, (float*)w.parts, gflags);
+    hipLaunchKernelGGL(k_depth_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, (const float*)w.parts, adj_off,
+                       adj_items, verts, K, B, V, F, orig_size, grad_verts, gflags, S);
+    return hm_launch_status();
+}
 int hm_depth_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size,
                  const float* grad_pooled_depth, const int* adj_off, const int* adj_items, float* grad_verts,
                  void* workspace, hipStream_t stream)
 {
-    HM_CHECK_ARG(verts && K && grad_pooled_depth && adj_off && adj_items && grad_verts && workspace);
-    if (S % 16 != 0) return HM_ERR_UNSUPPORTED;
-    SilWs w = carve(workspace, B, V, F, S);
-    hipLaunchKernelGGL(k_depth_bwd_faces, dim3(hm_cdiv(hm_cdiv((long)B * F, DBF_FACES) * 64, 256)), dim3(256), 0, stream, w.faces9, w.boxes,
-                       w.idx_map, grad_pooled_depth, w.owned, B, F, S, (float*)w.parts);
-    hipLaunchKernelGGL(k_depth_bwd_gather, dim3(hm_cdiv((long)B * V, 256)), dim3(256), 0, stream, (const float*)w.parts, adj_off,
-                       adj_items, verts, K, B, V, F, orig_size, grad_verts);
-    return hm_launch_status();
+    return hm_depth_bwd_sparse(verts, K, B, V, F, S, orig_size, grad_pooled_depth, adj_off, adj_items, grad_verts, nullptr, workspace,
+                               stream);
 }
 
 // Ordinal depth loss between the object (layer 0) and the hand (layer 1).  workspace: hm_reduce_workspace_bytes()
@@ -315,14 +374,23 @@ int hm_ordinal_depth_fwd(const float* d0, const float* d1, const float* a0, cons
                        (unsigned int*)((float*)workspace + 512), rec, out1);
     return hm_launch_status();
 }
+// flags0 / flags1 (both or neither; S % 64 == 0): B * S * (S / 64) bytes each, one per (frame, pixel row, 64-pixel segment), set to
+// 1 where some pixel of the segment has a non-zero g0 / g1, to 0 elsewhere - the `gflags` of hm_depth_bwd_sparse.
+int hm_ordinal_depth_bwd_flags(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
+                               const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
+                               float* g1, unsigned char* flags0, unsigned char* flags1, hipStream_t stream)
+{
+    HM_CHECK_ARG(d0 && d1 && a0 && a1 && m0 && m1 && rec && upstream && g0 && g1);
+    HM_CHECK_ARG((flags0 != nullptr) == (flags1 != nullptr) && (!flags0 || S % 64 == 0));
+    const long n = (long)B * S * S;
+    hipLaunchKernelGGL(k_ordinal_depth_bwd, dim3(hm_cdiv(n, 256)), dim3(256), 0, stream, d0, d1, a0, a1, m0, m1, n, rec,
+                       upstream, g0, g1, flags0, flags1);
+    return hm_launch_status();
+}
 int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
                          const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
                          float* g1, hipStream_t stream)
 {
-    HM_CHECK_ARG(d0 && d1 && a0 && a1 && m0 && m1 && rec && upstream && g0 && g1);
-    const long n = (long)B * S * S;
-    hipLaunchKernelGGL(k_ordinal_depth_bwd, dim3(hm_cdiv(n, 256)), dim3(256), 0, stream, d0, d1, a0, a1, m0, m1, n, rec,
-                       upstream, g0, g1);
-    return hm_launch_status();
+    return hm_ordinal_depth_bwd_flags(d0, d1, a0, a1, m0, m1, B, S, rec, upstream, g0, g1, nullptr, nullptr, stream);
 }
 }  // extern "C"

@@ -248,6 +248,11 @@ class FusedStepper:
             Sd = ctx_o.S
             self.d_sil_o, self.d_dep_o, self.d_sil_h, self.d_dep_h = f(B, Sd, Sd), f(B, Sd, Sd), f(B, Sd, Sd), f(B, Sd, Sd)
             self.d_go, self.d_gh, self.d_part, self.d_rec = f(B, Sd, Sd), f(B, Sd, Sd), f(B * 8), f(C, 8)
+            # non-zero structure of the two gradient images, one byte per (frame, pixel row, 64-pixel segment): the depth-map
+            # backward skips faces and frames that touch no flagged segment (the term is zero wherever render and annotation
+            # agree on the order); ones = "walk everything" until the first backward has written them
+            self.d_flags = (torch.ones(2, B * Sd * (Sd // 64), dtype=torch.uint8, device=dev)
+                            if Sd % 64 == 0 and os.environ.get("HOMAN_DEPTH_SPARSE", "1") != "0" else None)
             self.rws_depth = ClipReduceWorkspace(dev, C)
             self.G_dep_o, self.G_dep_h = f(B, Vo, 3), f(B, Vh, 3)
             self.up_depth = torch.tensor([w["loss_depth"]], device=dev)
@@ -813,16 +818,23 @@ class FusedStepper:
                 ck(L.hm_ordinal_depth_fwd(*args, P(self.d_part[8 * ci * CL:]), P(self.d_rec[ci]),
                                           self._slot("loss_depth") + 4 * NS * ci,
                                           self.rws_depth.buf.data_ptr() + rw_bytes * ci, sb2), "ordinal depth")
-                ck(L.hm_ordinal_depth_bwd(*args, P(self.d_rec[ci]), P(self.up_depth), P(self.d_go[fr]), P(self.d_gh[fr]),
-                                          sb2), "ordinal depth bwd")
+                if self.d_flags is not None:
+                    fo = ci * CL * Sd * (Sd // 64)
+                    ck(L.hm_ordinal_depth_bwd_flags(*args, P(self.d_rec[ci]), P(self.up_depth), P(self.d_go[fr]), P(self.d_gh[fr]),
+                                                    self.d_flags[0].data_ptr() + fo, self.d_flags[1].data_ptr() + fo, sb2),
+                       "ordinal depth bwd")
+                else:
+                    ck(L.hm_ordinal_depth_bwd(*args, P(self.d_rec[ci]), P(self.up_depth), P(self.d_go[fr]), P(self.d_gh[fr]),
+                                              sb2), "ordinal depth bwd")
             # the two depth images' backward passes are independent: the hand's stays here, the object's goes to the
             # calling stream (idle between its sweeps and the object's gradient launch) when that stream made the render
             self.ev_dgrad.record(side2)
-            for verts, ctx, V_, g, G in (((self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h),) if on["sil"] else
-                                         ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o),
-                                          (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h))):
-                ck(L.hm_depth_bwd(P(verts), K, B, V_, ctx.F, Sd, 1.0, P(g), P(ctx.adj_off), P(ctx.adj_items), P(G),
-                                  P(ctx.workspace), sb2), "depth bwd")
+            for verts, ctx, V_, g, G, li in (((self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h, 1),) if on["sil"] else
+                                             ((self.vo, ctx_o, Vo, self.d_go, self.G_dep_o, 0),
+                                              (self.vh, ctx_h, Vh, self.d_gh, self.G_dep_h, 1))):
+                ck(L.hm_depth_bwd_sparse(P(verts), K, B, V_, ctx.F, Sd, 1.0, P(g), P(ctx.adj_off), P(ctx.adj_items), P(G),
+                                         P(self.d_flags[li]) if self.d_flags is not None else None, P(ctx.workspace), sb2),
+                   "depth bwd")
 
     def _issue_hand_backward(self, it):
         """B: join of the split, forward-done / pair-done events, the hand's rigid + MANO backward"""
@@ -881,8 +893,10 @@ class FusedStepper:
         if on["depth"] and on["sil"]:
             main.wait_event(self.ev_dgrad)       # d loss / d (object's depth image), from the side stream
             ctx_o = self.dctx[0]
-            ck(L.hm_depth_bwd(P(self.vo), P(m.camintr), B, Vo, ctx_o.F, ctx_o.S, 1.0, P(self.d_go), P(ctx_o.adj_off),
-                              P(ctx_o.adj_items), P(self.G_dep_o), P(ctx_o.workspace), sa), "depth bwd(obj)")
+            ck(L.hm_depth_bwd_sparse(P(self.vo), P(m.camintr), B, Vo, ctx_o.F, ctx_o.S, 1.0, P(self.d_go), P(ctx_o.adj_off),
+                                     P(ctx_o.adj_items), P(self.G_dep_o),
+                                     P(self.d_flags[0]) if self.d_flags is not None else None, P(ctx_o.workspace), sa),
+               "depth bwd(obj)")
         sc_obj = m.optimize_object_scale
         # the object's smoothness gradient is formed INSIDE the rigid backward from the camera-space vertices the face setup
         # wrote (same floats as the unit gradient of the smoothness launch times its weight): on the step-1 sets this chain

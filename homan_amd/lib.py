@@ -31,6 +31,8 @@ _SIGNATURES = {
     "hm_rigid_bwd_sil": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _F, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _VP]),
     "hm_sil_reduce": (_I, [_I, _I, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_depth_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_depth_bwd_sparse": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_ordinal_depth_bwd_flags": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_ordinal_depth_fwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_ordinal_depth_bwd": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP]),
     "hm_sil_bwd": (_I, [_VP, _VP, _I, _I, _I, _I, _F, _F, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),

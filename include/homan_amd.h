@@ -189,6 +189,14 @@ int hm_sil_bwd(const float* verts, const float* K, int B, int V, int F, int S, f
 int hm_depth_bwd(const float* verts, const float* K, int B, int V, int F, int S, float orig_size,
                  const float* grad_pooled_depth, const int* adj_off, const int* adj_items, float* grad_verts,
                  void* workspace, hipStream_t stream);
+/* The same with the NON-ZERO STRUCTURE of the upstream image handed over (gflags, optional; S % 64 == 0): B * S * (S / 64) bytes,
+ * one per (frame, pixel row, 64-pixel segment), non-zero wherever some pixel of the segment has a non-zero gradient (as
+ * hm_ordinal_depth_bwd_flags writes them; a set byte over an all-zero segment is harmless).  An ordinal depth term is zero
+ * wherever render and annotation agree on the order - nearly everywhere -, and faces / frames that touch no flagged segment
+ * get their exact zeros without being walked.  Same result as hm_depth_bwd. */
+int hm_depth_bwd_sparse(const float* verts, const float* K, int B, int V, int F, int S, float orig_size,
+                        const float* grad_pooled_depth, const int* adj_off, const int* adj_items, float* grad_verts,
+                        const unsigned char* gflags, void* workspace, hipStream_t stream);
 /* Ordinal depth loss between two rendered layers (0 = object, 1 = hand): reference homan/homan.py:384-419 +
  * homan/lossutils.py:133-169 (as the method intends; the reference call site raises before reaching it, DESIGN.md).
  * d*/a*: depth / silhouette renders (B,S,S) f32; m*: instance masks (B,S,S) u8.  frame_part: B*8 floats (8-byte aligned),
@@ -201,6 +209,10 @@ int hm_ordinal_depth_fwd(const float* d0, const float* d1, const float* a0, cons
 int hm_ordinal_depth_bwd(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
                          const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
                          float* g1, hipStream_t stream);
+/* ... and the per-segment non-zero flags of both gradient images (flags0 / flags1, see hm_depth_bwd_sparse; both or neither) */
+int hm_ordinal_depth_bwd_flags(const float* d0, const float* d1, const float* a0, const float* a1, const unsigned char* m0,
+                               const unsigned char* m1, int B, int S, const float* rec, const float* upstream, float* g0,
+                               float* g1, unsigned char* flags0, unsigned char* flags1, hipStream_t stream);
 /* scheduling hint (no reference counterpart, no effect on results): persistent workgroups of the edge-sweep kernel,
  * default 1280; 768 suits loops whose other streams carry the longer chain (collision + contact terms).  Per calling thread (thread-local),
  * read when hm_sil_bwd is called or captured.  Returns the previous value; blocks <= 0 only queries. */

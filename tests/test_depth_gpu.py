@@ -56,6 +56,61 @@ def test_depth_image_and_backward_match_oracle(which, mano_model):
     np.testing.assert_allclose(got / scale, want / scale, atol=1e-4)
 
 
+@pytest.mark.parametrize("pattern", ["none", "one_pixel", "band", "all"])
+def test_sparse_depth_backward_equals_the_dense_one(pattern, mano_model):
+    """hm_depth_bwd_sparse with the non-zero flags of the upstream image (as hm_ordinal_depth_bwd_flags writes them) returns the
+    vertex gradients of hm_depth_bwd - faces and frames that touch no flagged segment are skipped, not approximated -, for an
+    all-zero image, one pixel, a band of rows in some frames and a dense image; and the flags kernel marks exactly the segments
+    that hold a non-zero gradient."""
+    from homan_amd import lib as hlib, ops
+    size = 128
+    clip, K = _scene(mano_model, frames=5, size=size)
+    verts, faces = clip["gt"]["verts_object"].to(DEV).contiguous(), clip["objfaces"]
+    B, V = verts.shape[:2]
+    sctx = ops.SilhouetteContext(faces.to(DEV), V, B, size, DEV)
+    Kd = K.to(DEV).contiguous()
+    with torch.no_grad():
+        _, depth = ops.depth_render(verts, Kd, sctx, 1.0)
+    rng = np.random.default_rng(5)
+    g = np.zeros((B, size, size), np.float32)
+    if pattern == "one_pixel":
+        ys, xs = np.nonzero(np.isfinite(depth[2].cpu().numpy()) & (depth[2].cpu().numpy() < 50))
+        g[2, ys[len(ys) // 2], xs[len(xs) // 2]] = 0.7
+    elif pattern == "band":
+        g[1, 40:70] = rng.normal(size=(30, size))
+        g[3, 60:62, 64:] = rng.normal(size=(2, size - 64))
+    elif pattern == "all":
+        g[:] = rng.normal(size=g.shape)
+    g = torch.from_numpy(g).to(DEV)
+    flags = (g.reshape(B, size, size // 64, 64) != 0).any(-1).to(torch.uint8).contiguous()
+    L, P = hlib.lib(), hlib.ptr
+    out = [torch.full((B, V, 3), 7.0, device=DEV) for _ in range(2)]
+    for o, fl in zip(out, (None, flags)):
+        hlib.check(L.hm_depth_bwd_sparse(P(verts), P(Kd), B, V, sctx.F, sctx.S, 1.0, P(g), P(sctx.adj_off), P(sctx.adj_items),
+                                         P(o), P(fl) if fl is not None else None, P(sctx.workspace), hlib.stream()), "depth bwd")
+    assert torch.equal(out[0], out[1])
+    assert (out[0] != 0).any() == (pattern != "none")
+    if pattern == "band":
+        assert not out[0][0].any() and not out[0][4].any() and out[0][1].any()
+    # the flags kernel: two layers whose order contradicts the annotation on a few pixels
+    d0 = torch.full((B, size, size), 1.0, device=DEV)
+    d1 = torch.full((B, size, size), 1.5, device=DEV)
+    a = torch.ones(B, size, size, device=DEV)
+    m0 = torch.zeros(B, size, size, dtype=torch.uint8, device=DEV)
+    m1 = torch.zeros_like(m0)
+    m1[1, 10:12, 70:75] = 1                       # annotated: layer 1 in front; rendered: layer 0 in front -> a gradient there
+    rec = torch.tensor([float(B), 0.0, 0.0, 10.0, 1.0], device=DEV)
+    up = torch.ones(1, device=DEV)
+    g0, g1 = torch.empty_like(d0), torch.empty_like(d0)
+    f0 = torch.full((B, size, size // 64), 9, dtype=torch.uint8, device=DEV)
+    f1 = torch.full_like(f0, 9)
+    hlib.check(L.hm_ordinal_depth_bwd_flags(P(d0), P(d1), P(a), P(a), P(m0), P(m1), B, size, P(rec), P(up), P(g0), P(g1), P(f0),
+                                            P(f1), hlib.stream()), "ordinal bwd flags")
+    for gi, fi in ((g0, f0), (g1, f1)):
+        assert torch.equal(fi, (gi.reshape(B, size, size // 64, 64) != 0).any(-1).to(torch.uint8))
+    assert int(f0.sum()) == 2 and int(f1.sum()) == 2
+
+
 def test_ordinal_depth_loss_matches_oracle(mano_model):
     from homan_amd import ops
     from oracle import model as o_model
