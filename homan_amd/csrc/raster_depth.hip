@@ -209,7 +209,7 @@ __global__ void k_depth_bwd_gather(const float* __restrict__ gf9, const int* __r
 // frame record (8 words of frame_part, ZERO on entry, re-zeroed by the finishing workgroup) collects the chunks with 64-bit
 // integer atomics - exact and order-independent, so the result does not depend on which chunk lands first:
 //   words 0-1  pixels of layer 0 | layer 1 << 21 | both << 42   (21 bits each: S <= 1024)
-//   words 2-3  pixels ordered wrongly: (annotated 0 in front) | (annotated 1 in front) << 32
+//   words 2-3  pixels ordered wrongly: (annotated 0 in front) | (annotated 1 in front) << 21 | chunks arrived << 42
 //   words 4-5 / 6-7  softplus sums of the two kinds, fixed point 2^-32 (a workgroup's own float sum, then integer adds)
 #define ORD_CHUNKS 16
 #define ORD_FIX 4294967296.0       // 2^32
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__
                                                         float* __restrict__ frame_part, unsigned int* counter,
                                                         float* __restrict__ rec, float* __restrict__ out)
 {
-    __shared__ float red[16];
+    __shared__ float red[16 * 7];
     __shared__ int s_flag;
     const int b = blockIdx.y;
     const long base = (long)b * S * S;
@@ -253,16 +253,22 @@ __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__
         }
     }
     float v[7] = {c00, c11, c01, ms01, s01, ms10, s10};
-#pragma unroll
-    for (int k = 0; k < 7; ++k) v[k] = hm_block_sum(v[k], red);
+    hm_block_sum_n<7>(v, red);           // (two barriers for the seven sums; the combination order of hm_block_sum)
     unsigned long long* fr = reinterpret_cast<unsigned long long*>(frame_part) + (long)b * 4;
+    // the frame's record; its word 1 also counts the chunks that have arrived (bits 42..), so the chunk that completes a frame
+    // learns it from the atomic it issues anyway, and only ONE workgroup per frame draws the clip's ticket (a ticket per chunk
+    // was ORD_CHUNKS * B returning atomics on one word: they serialise)
     if (threadIdx.x == 0) {
         atomicAdd(fr, (unsigned long long)v[0] | ((unsigned long long)v[1] << 21) | ((unsigned long long)v[2] << 42));
-        atomicAdd(fr + 1, (unsigned long long)v[3] | ((unsigned long long)v[5] << 32));
         atomicAdd(fr + 2, (unsigned long long)((double)v[4] * ORD_FIX));
         atomicAdd(fr + 3, (unsigned long long)((double)v[6] * ORD_FIX));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long old = atomicAdd(fr + 1, (unsigned long long)v[3] | ((unsigned long long)v[5] << 21) | (1ull << 42));
+        s_flag = (int)(old >> 42) == (int)gridDim.x - 1;
     }
-    if (hm_last_block(counter, gridDim.x * gridDim.y, &s_flag)) {
+    __syncthreads();
+    if (!s_flag) return;               // (block-uniform)
+    if (hm_last_block(counter, gridDim.y, &s_flag)) {
         // the frames in frame order (fixed), one thread: B is a clip's length.  The frames' records are fetched (and re-armed) by
         // a thread each first - thread 0 walking them one agent-scope load after the other was B dependent round trips, most of
         // this launch's time
@@ -286,9 +292,9 @@ __global__ __launch_bounds__(256) void k_ordinal_depth(const float* __restrict__
                 const unsigned long long w3 = staged ? s_w[3][f] : __hip_atomic_load(all + 4L * f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const bool h0 = (w0 & 0x1fffffull) != 0ull, h1 = ((w0 >> 21) & 0x1fffffull) != 0ull, h01 = (w0 >> 42) != 0ull;
                 t[0] += (h0 ? 1.f : 0.f) + (h1 ? 1.f : 0.f) + 2.f * (h01 ? 1.f : 0.f);        // pairs of this frame
-                t[1] += (float)(unsigned)(w1 & 0xffffffffull);
+                t[1] += (float)(unsigned)(w1 & 0x1fffffull);
                 t[2] += (float)((double)w2 / ORD_FIX);
-                t[3] += (float)(unsigned)(w1 >> 32);
+                t[3] += (float)(unsigned)((w1 >> 21) & 0x1fffffull);
                 t[4] += (float)((double)w3 / ORD_FIX);
                 if (!staged) { all[4L * f] = 0ull; all[4L * f + 1] = 0ull; all[4L * f + 2] = 0ull; all[4L * f + 3] = 0ull; }     // re-armed
             }

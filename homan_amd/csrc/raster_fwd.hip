@@ -16,7 +16,16 @@
 //   4. epilogue: one wave per 8x8 output tile reads its samples back (lane = output pixel, 2x2 samples).
 // Outputs: idx_map (B,is,is) int32; alpha16 (B,is,is/16) u16 bit-plane; pooled (B,S,S);
 // optional fused loss terms: dimg = keep*(keep*pool-ref), partials (B,ntiles,4); optional pooled depth.
-#ifdef RASTER_PHASES
+#ifdef RASTER_TRACE
+// per-workgroup phase durations of wave 0 in wall-clock ticks (10 ns), stored once at the workgroup's end - no atomics, nothing
+// that would stretch the kernel being measured (the RASTER_PHASES counters below add global atomics per candidate: fine for
+// COUNTS, useless for times).  [blockIdx][0..5] = scan, records (+ barrier), own near units, barrier + hidden-block depths, far
+// units (+ barrier), epilogue; [6] = start tick (low 32 bits), [7] = candidates near | far << 16, [8] = units near | far << 16
+#define RASTER_TRACE_WGS 65536
+__device__ unsigned g_raster_trace[RASTER_TRACE_WGS][9];
+__device__ int g_raster_trace_F = 0, g_raster_trace_depth = -1;     // record only launches over meshes of F faces (0: any) / with (1) or without (0) a depth output
+#define RPH_MARK(k) do { if (tid == 0) { const unsigned long long t_ = wall_clock64(); rtr[k] += (unsigned)(t_ - rtr_t); rtr_t = t_; } } while (0)
+#elif defined(RASTER_PHASES)
 __device__ unsigned long long g_raster_ph[24];   // cycles of wave 0: scan, near records, near units, far hz + records, far units, tail; workgroups: active, idle; units near / far
 #define RPH_MARK(k) do { if (tid == 0) { const unsigned long long t_ = clock64(); rph[k] += t_ - rph_t; rph_t = t_; } } while (0)
 #else
@@ -100,6 +109,10 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     const bool idle = nscan == 0 && rstate0 == 1;
     const bool ts_on = hm_ts_enabled(hint) && tid == 0;
     if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 0, ts_t0);
+#ifdef RASTER_TRACE
+    unsigned rtr[6] = {0, 0, 0, 0, 0, 0}, rtr_cand = 0, rtr_units = 0;
+    unsigned long long rtr_t = ts_t0;
+#endif
 #ifdef RASTER_PHASES
     unsigned long long rph[6] = {0, 0, 0, 0, 0, 0}, rph_t = clock64();
     unsigned long long rph_units[3] = {0, 0, 0};
@@ -328,6 +341,10 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
             if (tid < RB_PASS) ustart[tid] = incl - units;
             __syncthreads();
             const int total_near = wsum[0], total_far = wsum[1];
+#ifdef RASTER_TRACE
+            rtr_cand += (unsigned)min(n_near - e0, RB_PASS / 2) * (e0 < n_near) + ((unsigned)min(n_far - e0, RB_PASS / 2) * (e0 < n_far) << 16);
+            rtr_units += (unsigned)total_near + ((unsigned)total_far << 16);
+#endif
 #ifdef RASTER_PHASES
             if (tid < RB_PASS && ci < (cls ? n_far : n_near)) atomicAdd(&g_raster_ph[12 + cls], 1ull);
             rph_units[0] += total_near;
@@ -531,6 +548,15 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     }
     if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
     if (wg_cost && tid == 0) wg_cost[blockIdx.x] = (unsigned)min((unsigned long long)wall_clock64() - ts_t0, 0xfffffffeull) + 1u;
+#ifdef RASTER_TRACE
+    RPH_MARK(5);
+    if (tid == 0 && blockIdx.x < RASTER_TRACE_WGS && (g_raster_trace_F == 0 || g_raster_trace_F == F) &&
+        (g_raster_trace_depth < 0 || g_raster_trace_depth == (pooled_depth ? 1 : 0))) {
+        unsigned* o = g_raster_trace[blockIdx.x];
+        for (int k = 0; k < 6; ++k) o[k] = rtr[k];
+        o[6] = (unsigned)ts_t0; o[7] = rtr_cand; o[8] = rtr_units;
+    }
+#endif
 #ifdef RASTER_PHASES
     RPH_MARK(5);
     if (tid == 0) {
@@ -630,6 +656,24 @@ int hm_raster_fwd_occupancy(int* blocks_per_cu)
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, k_raster_fwd, 64 * RASTER_WAVES, 0) == hipSuccess ? HM_OK
                                                                                                                         : HM_ERR_LAUNCH;
 }
+#ifdef RASTER_TRACE
+extern "C" int hm_debug_raster_trace_filter(int F, int depth)
+{
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raster_trace_F), &F, sizeof(int));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_raster_trace_depth), &depth, sizeof(int));
+    return HM_OK;
+}
+extern "C" int hm_debug_raster_trace(unsigned* out, int nwg)          // (nwg, 9) -> HOST buffer; then cleared
+{
+    (void)hipDeviceSynchronize();
+    const size_t bytes = sizeof(unsigned) * 9 * (size_t)min(nwg, RASTER_TRACE_WGS);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_raster_trace), bytes);
+    void* dev = nullptr;
+    (void)hipGetSymbolAddress(&dev, HIP_SYMBOL(g_raster_trace));
+    (void)hipMemset(dev, 0, sizeof(unsigned) * 9 * RASTER_TRACE_WGS);
+    return HM_OK;
+}
+#endif
 #ifdef RASTER_PHASES
 extern "C" int hm_debug_raster_phases(unsigned long long* out)
 {

@@ -123,6 +123,10 @@ class FusedStepper:
         self.log_in_adam = (not self.use_aux and not self.shared_scale and
                             os.environ.get("HOMAN_LOG_IN_ADAM", "1") != "0")
         self.fork_after_setup = os.environ.get("HOMAN_FORK_AFTER_SETUP", "1") != "0"
+        # the depth renders write into buffers this stepper owns and keeps passing: a region that is empty again leaves the empty
+        # pattern it wrote last time alone (hm_sil_fwd's persistent_outputs, as the silhouette render does) - at the full-image
+        # camera nine regions in ten are background
+        self.depth_persistent = int(os.environ.get("HOMAN_DEPTH_PERSISTENT", "1") != "0")
         # the side stream forms the camera-space object vertices ITSELF (hm_rigid_fwd_clips into a buffer of its own: the face
         # setup's arithmetic, the same floats) instead of waiting for the face setup's copy: the silhouette chain then has no
         # successor on another queue between the iteration's fork and its join - the rasteriser follows the face setup without
@@ -535,6 +539,8 @@ class FusedStepper:
         self._issue_silhouette_chain(it)
         with torch.cuda.stream(self.side):
             self._issue_hand_forward(it)
+            # (issued in this order on purpose - with the depth term too: its renders BEFORE the pair-wise terms put the hand's
+            #  raster next to the silhouette raster, cfg2 + depth 4 000 -> 3 790 it/s, EXPERIMENTS r6)
             self._issue_pair_terms(it)
             if self.on["depth"]:
                 self._issue_depth_terms(it)
@@ -1165,7 +1171,7 @@ class FusedStepper:
         m, L, P = self.model, self.L, _lib.ptr
         _lib.check(L.hm_sil_fwd(P(verts), P(ctx.faces), 0, P(m.camintr), self.B, V_, ctx.F, ctx.S, 1.0, self.ops.NMR_NEAR,
                                 self.ops.NMR_FAR, None, None, None, P(sil), None, P(ctx.work_order), P(dep), None, 0, None, None,
-                                None, 0, 0, P(ctx.workspace), stream_id), "depth render")
+                                None, 0, self.depth_persistent, P(ctx.workspace), stream_id), "depth render")
 
     def _adam_log(self):
         if not self.log_in_adam:

@@ -16,9 +16,11 @@ from homan_amd import synth  # noqa: E402
 from homan_amd.jointopt import FusedStepper, build_model  # noqa: E402
 from homan_amd.mano_assets import synthetic_mano  # noqa: E402
 
-VARIANTS = [("shipped", {}), ("side_own_vo", {"HOMAN_SIDE_OWN_VO": "1"}), ("main_only", {"HOMAN_EXP_MAIN_ONLY": "1"}),
-            ("no_edges", {"HOMAN_EXP_NO_EDGES": "1"}),
+VARIANTS = [("shipped", {}), ("main_only", {"HOMAN_EXP_MAIN_ONLY": "1"}),
+            ("no_edges", {"HOMAN_EXP_NO_EDGES": "1"}), ("side_waits_for_setup", {"HOMAN_SIDE_OWN_VO": "0"}),
             ("shipped_again", {})]
+if os.environ.get("CHAIN_SKIP"):          # (A/B of library builds: the shipped graph and the one-queue floor only)
+    VARIANTS = VARIANTS[:2]
 extra = os.environ.get("CHAIN_VARIANTS")          # "name:K=V,K=V;name2:K=V"
 if extra:
     for item in extra.split(";"):
