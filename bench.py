@@ -627,14 +627,16 @@ def main():
             if c:
                 rec["traffic_bytes"] = c.get("traffic_bytes")
                 if c.get("SQ_INSTS_VALU"):
-                    # VALU issue roof.  A wave64 VALU instruction runs on a SIMD16 as four passes of 16 lanes: 4 cycles of the
-                    # SIMD's VALU per instruction, which is what the counters show (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU, in
-                    # quad-cycles per instruction: ~1.0) -> 1024 SIMDs x 2.4 GHz / 4.  The micro-architecture guide's
-                    # "wave scheduling" section quotes 2 cycles (dual-issue / packed rate): `valu_frac_2cyc` is the same
-                    # count against THAT peak, i.e. half of valu_frac.  DESIGN.md section 5 reconciles the two.
+                    # VALU issue roof.  tools/valu_ceiling.hip measured what a wave64 instruction costs a SIMD (profiles/
+                    # r06_valu_ceiling.json): ~2.3 cycles for fp32 / integer adds, multiplies and bit ops, ~4.2 for selects, compares,
+                    # shifts, three-operand integer ops, conversions, DPP and doubles - neither the guide's flat 2 nor the counters' flat
+                    # 4 (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1.02 quad-cycles).  Priced with the kernel's STATIC opcode mix
+                    # (tools/valu_mix.py, at 4 waves per SIMD) that is `cyc` cycles per instruction; valu_frac_4cyc is round 5's figure.
+                    cyc = VALU_MIX_CYCLES.get(name, 3.4)
                     rec["valu_wave_instr"] = c["SQ_INSTS_VALU"]
-                    rec["valu_frac"] = c["SQ_INSTS_VALU"] / (sec * 1024 * 2.4e9 / 4)
-                    rec["valu_frac_2cyc"] = c["SQ_INSTS_VALU"] / (sec * 1024 * 2.4e9 / 2)
+                    rec["valu_cycles_per_instr"] = cyc
+                    rec["valu_frac"] = c["SQ_INSTS_VALU"] * cyc / (sec * 1024 * 2.4e9)
+                    rec["valu_frac_4cyc"] = c["SQ_INSTS_VALU"] / (sec * 1024 * 2.4e9 / 4)
                     if c.get("SQ_ACTIVE_INST_VALU"):
                         rec["quad_cycles_per_valu_instr"] = c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"]
             per[name] = rec
@@ -832,6 +834,16 @@ def main():
         dist.destroy_process_group()
 
 
+def _valu_mix_cycles():
+    """mix-weighted cycles per wave64 VALU instruction of the three heavy kernels (profiles/r06_valu_mix.json, 4 waves per SIMD)"""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r06_valu_mix.json")))
+        return {k.split("<")[0]: v["mix_cycles_per_instr_w4"] for k, v in d.items() if "mix_cycles_per_instr_w4" in v}
+    except (OSError, ValueError, KeyError):
+        return {}
+
+
+VALU_MIX_CYCLES = _valu_mix_cycles()
 PMC_FILES = ("r05_pmc_loop.json", "r05_pmc_loop_cfg3.json", "r04_pmc_loop.json", "r04_pmc_loop_cfg3.json")
 
 

@@ -41,11 +41,11 @@ __global__ __launch_bounds__(64 * NN_WAVES) void k_nn_min(const float* __restric
                                                            const float* __restrict__ obj_rot6d,
                                                            const float* __restrict__ obj_trans,
                                                            const float* __restrict__ obj_scale,
-                                                           const int* __restrict__ hand_order)
+                                                           const int* __restrict__ hand_order, int* __restrict__ seed)
 {
     HM_LATENCY_KERNEL();
     nn_min_body(vh, vo, B, Vh, Vo, blockmin, counter, metric_out, clip_len, out_stride, obj_order, blockIdx.x, blockIdx.y,
-                gridDim.x, sph_mesh, obj_rot6d, obj_trans, obj_scale, hand_order);
+                gridDim.x, sph_mesh, obj_rot6d, obj_trans, obj_scale, hand_order, seed);
 }
 
 // Contact loss, hand side.  grid (B): value, d/d hand vertex (= minus the pull on the matched object vertex),
@@ -171,7 +171,7 @@ extern "C" {
 int hm_nn_fwd_rigid_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
                           float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
                           const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
-                          const int* hand_order, hipStream_t stream);
+                          const int* hand_order, int* nn_seed, hipStream_t stream);
 // Scheduling hint, no effect on results: bytes of unused dynamic LDS added to the metric-only search launches.  The search is
 // a chain of dependent loads in small workgroups (24 registers, 4.6 KB of LDS): eight of them fit on a CU and then hold ALL
 // its wave slots while they wait - in an 8-clip batch (1680 workgroups) the line expansion of the silhouette chain, which
@@ -189,17 +189,19 @@ int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int 
                     hipStream_t stream)
 {
     return hm_nn_fwd_rigid_clips(verts_hand, verts_obj, B, Vh, Vo, nn_idx, nn_d2, metric_out, workspace, clip_len, out_stride,
-                                 obj_order, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
+                                 obj_order, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 // metric-only calls on a RIGID object: obj_spheres (B, ceil(Vo/64), 4) = centre + radius, in MESH space, of the groups of 64
 // vertices taken in `obj_order`; obj_rot6d (B,3,2) / obj_trans (B,3) / obj_scale (one per clip, used as |s|) = the transform
 // that produced verts_obj (hm_rigid_fwd with abs_scale); hand_order (Vh) optional: a permutation of the hand's vertices (a spatial
-// sort of the template keeps the 128 vertices of a workgroup one patch of the hand).  Scheduling data only: the result is the
-// exact minimum.
+// sort of the template keeps the 128 vertices of a workgroup one patch of the hand); nn_seed (optional, metric-only calls,
+// (2 + ceil(Vh / 128)) * B ints, zero-filled once, handed to every call of a loop): the vertex pair that held each frame's minimum
+// at the previous call - its current distance bounds this call's minimum before anything is scanned (nn_min_body).  Scheduling
+// data only: the result is the exact minimum.
 int hm_nn_fwd_rigid_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
                           float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
                           const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
-                          const int* hand_order, hipStream_t stream)
+                          const int* hand_order, int* nn_seed, hipStream_t stream)
 {
     HM_CHECK_ARG(!obj_spheres || (obj_rot6d && obj_trans && obj_scale));
     // nn_idx == nn_d2 == NULL: metric only (exact, with pruning of the object-vertex groups that cannot hold the minimum)
@@ -211,7 +213,7 @@ int hm_nn_fwd_rigid_clips(const float* verts_hand, const float* verts_obj, int B
     if (!nn_idx && Vo <= 64 * NN_MAX_GROUPS)
         hipLaunchKernelGGL(k_nn_min, dim3(nchunk, B), dim3(64 * NN_WAVES), g_nn_lds_pad, stream, verts_hand, verts_obj, B, Vh, Vo,
                            (float*)workspace, (unsigned int*)((float*)workspace + 512), metric_out, Bc, out_stride, obj_order,
-                           obj_spheres, obj_rot6d, obj_trans, obj_scale, hand_order);
+                           obj_spheres, obj_rot6d, obj_trans, obj_scale, hand_order, nn_seed);
     else {
         if (!nn_idx) return HM_ERR_UNSUPPORTED;     // metric-only search: <= 4096 object vertices
         hipLaunchKernelGGL(k_nn, dim3(nchunk, B), dim3(64 * NN_WAVES), 0, stream, verts_hand, verts_obj, B, Vh, Vo, nn_idx,

@@ -235,6 +235,7 @@ __device__ __forceinline__ void nn_full_body(const float* __restrict__ vh, const
 }
 
 
+#define NN_SEED_FRAMES 128       // frames of a clip the seed bookkeeping of nn_min_body covers (longer clips search unseeded)
 #ifdef NN_PHASES
 static __device__ unsigned long long g_nn_ph[10];     // wall-clock ticks of thread 0, summed over workgroups: loads+spheres, bounds, list, scan, reduce+ticket, finish; workgroups; survivors
 #define NNP_MARK(k) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_nn_ph[k], t_ - nnp_t); nnp_t = t_; } } while (0)
@@ -249,8 +250,14 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
                                             const float* __restrict__ obj_rot6d = nullptr,
                                             const float* __restrict__ obj_trans = nullptr,
                                             const float* __restrict__ obj_scale = nullptr,
-                                            const int* __restrict__ hand_order = nullptr)
+                                            const int* __restrict__ hand_order = nullptr,
+                                            int* __restrict__ seed = nullptr)
 {
+    // `seed` (optional, 2 B + gdx B ints, zero-filled once by the caller, carried from launch to launch): per frame the vertex
+    // pair (hand i, object j) that held the frame's minimum at the LAST launch.  Its distance at the CURRENT positions is the
+    // distance of a real pair, i.e. an upper bound of this launch's minimum, known before anything is scanned: the workgroups
+    // then scan only the groups that can beat it - for most chunks of the hand none - instead of finding a bound of their own
+    // in four exact scans each.  Scheduling data only: any pair gives a valid bound, the result stays the exact minimum.
     __shared__ float s_sph[NN_MAX_GROUPS][4];
     __shared__ float s_lb[NN_MAX_GROUPS];
     __shared__ unsigned s_ub;
@@ -266,6 +273,7 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
 #endif
     float hx[2], hy[2], hz[2];
     bool hv[2];
+    int hraw[2] = {0, 0};
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const int i = bx * NN_HV + lane + 64 * u;
@@ -273,9 +281,24 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
         hx[u] = hy[u] = hz[u] = 0.f;
         // (hand_order: a spatial sort of the hand's vertices - the minimum does not care which vertex sits in which lane, and
         //  a workgroup whose 128 vertices are one patch of the hand instead of a sample of all of it has few groups in reach)
-        if (hv[u]) { const float* p = vh + ((long)b * Vh + (hand_order ? hand_order[i] : i)) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2]; }
+        if (hv[u]) {
+            hraw[u] = hand_order ? hand_order[i] : i;
+            const float* p = vh + ((long)b * Vh + hraw[u]) * 3; hx[u] = p[0]; hy[u] = p[1]; hz[u] = p[2];
+        }
     }
-    if (threadIdx.x == 0) { s_ub = 0x7f7fffffu; s_n = 0; }      // (s_ub: smallest exact squared distance of the first scans)
+    bool seeded = false;
+    unsigned seed_bits = 0x7f7fffffu;
+    if (seed) {
+        const int si = seed[2 * b], sj = seed[2 * b + 1];          // (uniform)
+        if (si >= 0 && si < Vh && sj >= 0 && sj < Vo) {
+            const float* ph = vh + ((long)b * Vh + si) * 3;
+            const float* po = vo + ((long)b * Vo + sj) * 3;
+            const float dx = po[0] - ph[0], dy = po[1] - ph[1], dz = po[2] - ph[2];      // (the scans' operand order)
+            seed_bits = __float_as_uint(dx * dx + dy * dy + dz * dz);
+            seeded = true;
+        }
+    }
+    if (threadIdx.x == 0) { s_ub = seed_bits; s_n = 0; }      // (s_ub: smallest exact squared distance known before the list is built)
     if (threadIdx.x < NN_WAVES) s_first[threadIdx.x] = -1;
     if (sph_mesh && (int)threadIdx.x < ng) {
         // the object is rigid: the bounding spheres of its groups are a table in MESH space (built once by the caller), and a
@@ -324,7 +347,7 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
     // found there is a far tighter upper bound than "centre distance + radius" (with a hand that touches the object nearly
     // every group passed that test: 21.5 of 24 at cfg2) ...
     int rank = NN_MAX_GROUPS;
-    if ((int)threadIdx.x < ng) {
+    if (!seeded && (int)threadIdx.x < ng) {
         const float mine = s_lb[threadIdx.x];
         rank = 0;
         for (int g = 0; g < ng; ++g) {
@@ -339,7 +362,9 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
     // pair instead of a NaN-quieting float min), four object vertices per trip with the trip count in a scalar: a wave is
     // alone on its SIMD here, so the four independent chains are what hides the arithmetic latency
     unsigned bestu[2] = {0x7f7fffffu, 0x7f7fffffu};
+    int bestg[2] = {0, 0};                  // the group a lane's current minimum came from (for the next launch's seed)
     auto scan_group = [&](const int g) {
+        const unsigned before0 = bestu[0], before1 = bestu[1];
         const int j = 64 * g + lane, n = __builtin_amdgcn_readfirstlane(min(64, Vo - 64 * g));
         float ox = 0.f, oy = 0.f, oz = 0.f;
         if (lane < n) { const float* p = vo + ((long)b * Vo + (obj_order ? obj_order[j] : j)) * 3; ox = p[0]; oy = p[1]; oz = p[2]; }
@@ -354,6 +379,8 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
         int k = 0;
         for (; k + 4 <= n; k += 4) { step(k); step(k + 1); step(k + 2); step(k + 3); }
         for (; k < n; ++k) step(k);
+        bestg[0] = bestu[0] < before0 ? g : bestg[0];
+        bestg[1] = bestu[1] < before1 ? g : bestg[1];
     };
     if (s_first[q] >= 0) {
         scan_group(s_first[q]);
@@ -381,21 +408,61 @@ __device__ __forceinline__ void nn_min_body(const float* __restrict__ vh, const 
     blockmin += (long)clip * HM_RED_WS_FLOATS;
     counter += (long)clip * HM_RED_WS_FLOATS;
     const unsigned nblk = gdx * clip_len;
+    __shared__ unsigned s_pick;
+    const bool seeding = seed && clip_len <= NN_SEED_FRAMES;
+    if (seeding) {
+        // which of this workgroup's vertices holds its minimum, and which group it came from: (raw hand vertex << 6 | group),
+        // any holder in a tie - the clip's last workgroup turns the frame's winner into the next launch's seed pair
+        if (threadIdx.x == 0) s_pick = 0xffffffffu;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (hv[u] && bm < 3.0e38f && __uint_as_float(bestu[u]) == bm) atomicMin(&s_pick, ((unsigned)hraw[u] << 6) | (unsigned)bestg[u]);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_store(seed + 2L * B + (long)b * gdx + bx, (int)s_pick, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if (threadIdx.x == 0) hm_partial_store(blockmin + bl * gdx + bx, bm);
     const bool nn_last_blk = hm_last_block(counter, nblk, &s_flag);
     NNP_MARK(4);
     if (nn_last_blk) {
         float* s_bm = &s_d[0][0];
+        __shared__ int s_rec[NN_SEED_FRAMES];
+        __shared__ unsigned s_mb[NN_SEED_FRAMES];
         for (unsigned i2 = threadIdx.x; i2 < nblk; i2 += blockDim.x) s_bm[i2] = hm_partial_load(blockmin + i2);
         __syncthreads();
         float mx = -3.4e38f;
         for (int bb = threadIdx.x; bb < clip_len; bb += blockDim.x) {
             float m = 3.4e38f;
-            for (unsigned c = 0; c < gdx; ++c) m = fminf(m, s_bm[bb * gdx + c]);
+            unsigned cbest = 0;
+            for (unsigned c = 0; c < gdx; ++c) {
+                const float v = s_bm[bb * gdx + c];
+                if (v < m) { m = v; cbest = c; }          // (the same minimum as a chain of fminf: no NaN among squared distances)
+            }
             mx = fmaxf(mx, sqrtf(m));
+            if (seeding) {
+                s_mb[bb] = __float_as_uint(m);
+                s_rec[bb] = m < 3.0e38f ? __hip_atomic_load(seed + 2L * B + ((long)clip * clip_len + bb) * gdx + cbest, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT) : -1;
+            }
         }
         mx = hm_block_max(mx, red);
         if (threadIdx.x == 0) metric_out[(long)clip * out_stride] = mx;
+        if (seeding) {
+            // the winner's object vertex: the one of its group at exactly the winning distance (a thread per (frame, vertex of the group))
+            __syncthreads();
+            for (int t = threadIdx.x; t < clip_len * 64; t += blockDim.x) {
+                const int bb = t >> 6, k = t & 63, rec = s_rec[bb];
+                const long fb = (long)clip * clip_len + bb;
+                const int j = 64 * (rec & 63) + k;
+                if (rec < 0 || j >= Vo) continue;
+                const int jj = obj_order ? obj_order[j] : j, ii = rec >> 6;
+                const float* po = vo + (fb * Vo + jj) * 3;
+                const float* ph = vh + (fb * Vh + ii) * 3;
+                const float dx = po[0] - ph[0], dy = po[1] - ph[1], dz = po[2] - ph[2];
+                if (__float_as_uint(dx * dx + dy * dy + dz * dz) == s_mb[bb]) { seed[2 * fb] = ii; seed[2 * fb + 1] = jj; }
+            }
+        }
     }
 }
 

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void k_pair_terms(
     int sm_nblk, float* __restrict__ unit_smooth, float* __restrict__ sm_partials, unsigned int* sm_counter,
     float* __restrict__ out_smooth, HandTerms ht, int clips, const float* __restrict__ sph_mesh,
     const float* __restrict__ obj_rot6d, const float* __restrict__ obj_trans, const float* __restrict__ obj_scale,
-    const int* __restrict__ hand_order, int* __restrict__ nn_idx, float* __restrict__ nn_d2)
+    const int* __restrict__ hand_order, int* __restrict__ nn_idx, float* __restrict__ nn_d2, int* __restrict__ nn_seed)
 {
     HM_HAND_KERNEL();
     int i = blockIdx.x;
@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_pair_terms(
                          i / nchunk, nchunk);
         else
             nn_min_body(vh, vo, B, Vh, Vo, nn_blockmin, nn_counter, metric_out, clip_len, out_stride, obj_order, i % nchunk,
-                        i / nchunk, nchunk, sph_mesh, obj_rot6d, obj_trans, obj_scale, hand_order);
+                        i / nchunk, nchunk, sph_mesh, obj_rot6d, obj_trans, obj_scale, hand_order, nn_seed);
         return;
     }
     i -= n_nn;
@@ -77,7 +77,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                             const float* ht_s_obj, const float* ht_m_obj, const float* ht_s_hand, const float* ht_m_hand,
                             float* ht_g_pca, float* ht_g_sobj, float* ht_g_shand, float* ht_out_priors3, void* ws_hand,
                             const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
-                            const int* hand_order, int* nn_idx, float* nn_d2, int clip_len, int out_stride,
+                            const int* hand_order, int* nn_idx, float* nn_d2, int* nn_seed, int clip_len, int out_stride,
                             hipStream_t stream)
 {
     HM_CHECK_ARG((!nn_idx == !nn_d2) && (!nn_idx || metric_out));
@@ -105,7 +105,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                        obj_order, expansion, zthresh, frame_rec,
                        ws_inter ? (unsigned int*)((float*)ws_inter + 512) : nullptr, out_inter, sm_nblk, unit_smooth,
                        (float*)ws_smooth, ws_smooth ? (unsigned int*)((float*)ws_smooth + 512) : nullptr, out_smooth, ht, clips,
-                       obj_spheres, obj_rot6d, obj_trans, obj_scale, hand_order, nn_idx, nn_d2);
+                       obj_spheres, obj_rot6d, obj_trans, obj_scale, hand_order, nn_idx, nn_d2, nn_seed);
     return hm_launch_status();
 }
 }  // extern "C"

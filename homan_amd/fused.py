@@ -187,6 +187,10 @@ class FusedStepper:
             self.hand_ctx = [m.mano_model.ctx_mean if sd == "right" else m.mano_model._left_ctx(False)
                              for sd in m.models[0].hand_sides]
         self.nn_idx = torch.zeros(B, Vh, dtype=torch.int32, device=dev)
+        # the metric-only search's seed pairs (per frame the vertex pair that held the minimum at the last iteration: its distance
+        # now bounds this iteration's minimum before anything is scanned; hm_nn_fwd_rigid_clips).  Scheduling data only.
+        self.nn_seed = (torch.zeros((2 + (Vh + 127) // 128) * B, dtype=torch.int32, device=dev)
+                        if os.environ.get("HOMAN_NN_SEED", "1") != "0" else None)
         self.nn_d2 = f(B, Vh)
         self.obj_order = _morton_order(m.verts_object_og[0]).to(dev)      # spatial sort of the rigid mesh (metric-only search)
         # ... and of the hand: its template's vertices in the same kind of order, so that the 128 hand vertices of a search
@@ -325,7 +329,9 @@ class FusedStepper:
         self.ev_lines = torch.cuda.Event()
         # the hand's rigid backward inside the MANO backward's launch (hm_mano_bwd_rigid_clips): one launch less on the hand-side
         # chain.  One clip: cfg2 +1.3 %, cfg3 +1.4 %; a clip batch hides that chain under the silhouette chain and loses 1-1.6 %
-        self.mano_bwd_rigid = (os.environ.get("HOMAN_MANO_BWD_RIGID") or ("1" if C == 1 else "0")) != "0"
+        # (round 6: a clip batch too, +0.5 % - the separate hand launch was a 1024-thread workgroup per frame that found no room
+        #  next to the persistent sweeps: 106 us on average, up to 365 us in the 8-clip profile of round 5)
+        self.mano_bwd_rigid = (os.environ.get("HOMAN_MANO_BWD_RIGID") or "1") != "0"
         self.nn_early = (os.environ.get("HOMAN_NN_EARLY") or "0") != "0"
         self.pair_fused = (os.environ.get("HOMAN_PAIR_FUSED") or ("1" if C == 1 else "0")) != "0"
         self.hand_terms_fused = os.environ.get("HOMAN_HT_FUSED", "1") != "0"
@@ -705,7 +711,8 @@ class FusedStepper:
                     ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo_b), B, Vh, Vo, None, None, self._slot("handobj_maxdist"),
                                                rws_b, CL, NS, P(self.obj_order),
                                                (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                               P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sb), "nn")
+                                               P(m.translations_object), P(m.int_scales_object), P(self.hand_order),
+                                               P(self.nn_seed), sb), "nn")
                 side.wait_event(self.ev_lines)   # (scheduling only, see the silhouette chain above)
             elif self.pairs_after_raster:
                 side.wait_event(self.ev_ras)     # (scheduling only, see __init__)
@@ -749,7 +756,8 @@ class FusedStepper:
                 ck(L.hm_nn_fwd_rigid_clips(P(self.vh), P(self.vo_b), B, Vh, Vo, P(self.nn_idx) if full else None,
                                            P(self.nn_d2) if full else None, self._slot("handobj_maxdist"), rws, CL, NS,
                                            P(self.obj_order), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
-                                           P(m.translations_object), P(m.int_scales_object), P(self.hand_order), sx), "nn")
+                                           P(m.translations_object), P(m.int_scales_object), P(self.hand_order),
+                                           None if full else P(self.nn_seed), sx), "nn")
             if on["con"]:
                 ck(L.hm_contact_fwd_clips(P(self.vh), P(self.vo_b), P(self.nn_idx), B, Vh, Vo, c.COLLISION_THRESH,
                                           P(self.U_conh), P(self.U_cono), self._slot("loss_contact"), rws, CL, NS, sx),
@@ -772,7 +780,7 @@ class FusedStepper:
                                          P(self.reduce_ws_e.buf), (P(self.obj_spheres) if self.nn_spheres else None), P(m.rotations_object),
                                          P(m.translations_object), P(m.int_scales_object), P(self.hand_order),
                                          P(self.nn_idx) if nn_full_fused else None, P(self.nn_d2) if nn_full_fused else None,
-                                         CL, NS, sb2),
+                                         P(self.nn_seed), CL, NS, sb2),
                "pair terms")
             if nn_full_fused:
                 search_and_contact(side2, rws_b)          # (the contact launches only: the search ran above)

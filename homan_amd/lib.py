@@ -108,10 +108,10 @@ _SIGNATURES = {
                                      _VP, _VP, _VP, _I, _I, _VP]),
     "hm_pair_terms_fwd_clips": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP, _VP, _VP, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP,
                                      _VP, _F, _VP, _VP, _VP, _VP, _VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP,
-                                     _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
+                                     _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_inter_fwd_clips": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_nn_fwd_clips": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP]),
-    "hm_nn_fwd_rigid_clips": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_nn_fwd_rigid_clips": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_contact_fwd_clips": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_collision_fwd_clips": (_I, [_VP, _VP, _I, _I, _VP, _VP, _I, _I, _I, _F, _VP, _VP, _VP, _VP, _I, _I, _VP]),
     "hm_log_total_clips": (_I, [_VP, _VP, _I, _VP, _I, _VP, _I, _VP]),

@@ -444,7 +444,7 @@ int hm_pair_terms_fwd_clips(const float* verts_hand, const float* verts_obj, con
                             const float* ht_s_obj, const float* ht_m_obj, const float* ht_s_hand, const float* ht_m_hand,
                             float* ht_g_pca, float* ht_g_sobj, float* ht_g_shand, float* ht_out_priors3, void* ws_hand,
                             const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
-                            const int* hand_order, int* nn_idx, float* nn_d2,
+                            const int* hand_order, int* nn_idx, float* nn_d2, int* nn_seed,
                             int clip_len, int out_stride, hipStream_t stream);
 /* obj_order (Vo) optional, metric-only calls: a permutation of the object vertices, visited in that order (a spatial sort of
  * the rigid mesh makes 64 consecutive vertices a compact patch: scheduling only, the result is the exact minimum) */
@@ -455,12 +455,15 @@ int hm_nn_fwd_clips(const float* verts_hand, const float* verts_obj, int B, int 
  * 64 vertices taken in `obj_order` (built once by the caller); obj_rot6d (B,3,2) / obj_trans (B,3) / obj_scale (one per clip,
  * used as |s|) = the transform that produced verts_obj (hm_rigid_fwd with abs_scale).  A lane per group carries its sphere
  * into camera space instead of every workgroup reducing all the groups' vertices again.  Scheduling data only: the result is
- * the exact minimum (the spheres only decide which groups are scanned).  All four NULL = hm_nn_fwd_clips. */
+ * the exact minimum (the spheres only decide which groups are scanned).  All four NULL = hm_nn_fwd_clips.
+ * nn_seed (optional; also the last data argument of hm_pair_terms_fwd_clips): (2 + ceil(Vh / 128)) * B ints, zero-filled once by
+ * the caller and handed to every call of a loop - the search keeps there, per frame, the vertex pair that held the minimum at the
+ * previous call; that pair's distance NOW is an upper bound known before any scan, so that most workgroups scan nothing.  Any
+ * content is valid (a pair is a pair); the result does not depend on it. */
 int hm_nn_fwd_rigid_clips(const float* verts_hand, const float* verts_obj, int B, int Vh, int Vo, int* nn_idx, float* nn_d2,
                           float* metric_out, void* workspace, int clip_len, int out_stride, const int* obj_order,
                           const float* obj_spheres, const float* obj_rot6d, const float* obj_trans, const float* obj_scale,
-                            const int* hand_order,
-                          hipStream_t stream);
+                          const int* hand_order, int* nn_seed, hipStream_t stream);
 int hm_contact_fwd_clips(const float* verts_hand, const float* verts_obj, const int* nn_idx, int B, int Vh, int Vo,
                          float thresh, float* g_hand, float* g_obj, float* out1, void* workspace, int clip_len,
                          int out_stride, hipStream_t stream);

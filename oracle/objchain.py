@@ -132,8 +132,17 @@ def object_pose_grads(model, loss_weights, log2q=0, return_stages=False, contact
     elif lw.get("lw_contact", 0) > 0:
         terms.append((np.ascontiguousarray(contact_obj, f32), lw["lw_contact"]))
     if obj_terms is None and free_scale and lw.get("lw_inter", 0) > 0 and model.losses.inter_type != "centroid":
-        raise NotImplementedError("free object scale with inter_type 'min': hand the object's term in through obj_terms")
-    if obj_terms is None and free_scale and lw.get("lw_inter", 0) > 0:
+        # inter_type "min" (homan/losses.py:219-221) with a free scale: the closest pair's pull reaches the object too - minus the
+        # hand's pull, on the ONE object vertex j* of every gated frame (oracle/handchain.py min_pair_pull names the pair; the fused
+        # loop scatters the same vector, homan_amd/fused.py)
+        from .handchain import min_pair_pull
+        with torch.no_grad():
+            vh = np.ascontiguousarray(model.get_verts_hand()[1].numpy(), f32)          # (the mesh-detached twin: same floats)
+        _, st = min_pair_pull(vh, verts, inter_rec, lw["lw_inter"])
+        go = np.zeros((B, V, 3), f32)
+        go[np.arange(B), st["j_star"]] = f32(0.0) - st["pull"]
+        terms.append((go, 1.0))
+    elif obj_terms is None and free_scale and lw.get("lw_inter", 0) > 0:
         # d (lw_inter * loss_inter) / d object vertex = -lw_inter * gate * 2 (c_hand - c_obj) / 3 / V, the same for every vertex
         gi = (f32(0.0) - f32(lw["lw_inter"])) * np.ascontiguousarray(inter_rec[:, 2:5], f32) / f32(V)
         terms.append((np.ascontiguousarray(np.broadcast_to(gi[:, None, :], (B, V, 3)), f32), 1.0))

@@ -10,6 +10,17 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_slow: full-length legs of the GPU parity tests (-m gpu_slow on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """the `gpu_slow` legs run only when asked for by name (-m gpu_slow): neither the CPU suite (-m "not gpu") nor -m gpu takes them"""
+    if "gpu_slow" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="full-length leg: run with -m gpu_slow on the GPU box")
+    for item in items:
+        if "gpu_slow" in item.keywords:
+            item.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

@@ -375,6 +375,43 @@ def test_fixed_hand_mesh_bit_equal(mano_model):
         assert not diff, (i, diff)
 
 
+def test_inter_type_min_with_a_free_object_scale_bit_equal(mano_model):
+    """inter_type="min" AND optimize_object_scale: the closest pair's pull then reaches the object as well (its vertex j*, and
+    through it pose and scale).  The oracle's written-out chain covers it since round 6 (oracle/objchain.py): all gradients incl.
+    the scale's, then 8 free-running steps, bit-equal - step-1 and step-2 sets."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper
+    from oracle import handchain, objchain
+    from oracle.jointopt import make_optimizer, reproducible_step
+    for lw_name, seed in (("STEP1_LOSS_WEIGHTS", 61), ("STEP2_LOSS_WEIGHTS", 62)):
+        lw = dict(getattr(synth, lw_name))
+        hm, om = _pair(mano_model, seed=seed, frames=6, size=128, obj="bottle", inter_type="min", optimize_object_scale=True)
+        st = FusedStepper(hm, lw, 1e-2, 4, capture=False)
+        st.forward_backward(log=True)
+        torch.cuda.synchronize()
+        want, stg = handchain.hand_param_grads(om, lw, return_stages=True)
+        assert np.abs(stg["g_rigid"]).max() > 0
+        with torch.no_grad():
+            rec = handchain.inter_records(np.ascontiguousarray(om.get_verts_hand()[0].numpy(), np.float32),
+                                          np.ascontiguousarray(om.get_verts_object()[0].numpy(), np.float32),
+                                          np.ascontiguousarray(om.camintr.numpy(), np.float32))
+        pair = stg.get("pair") or {}
+        want.update(objchain.object_pose_grads(om, lw, contact_obj=pair.get("con_obj"), inter_rec=rec))
+        report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
+        assert all(report.values()), (lw_name, report)
+        hm, om = _pair(mano_model, seed=seed + 100, frames=6, size=128, obj="bottle", inter_type="min", optimize_object_scale=True)
+        st = FusedStepper(hm, lw, 1e-2, 8)
+        opt = make_optimizer(om, 1e-2, reproducible=True)
+        for i in range(8):
+            st.run(1)
+            reproducible_step(om, lw, opt)
+            torch.cuda.synchronize()
+            cpu = dict(om.named_parameters())
+            diff = [k for k, p in hm.named_parameters()
+                    if k in cpu and not np.array_equal(p.detach().cpu().numpy(), cpu[k].detach().numpy().reshape(p.shape))]
+            assert not diff, (lw_name, i, diff)
+
+
 def test_inter_type_min_bit_equal(mano_model):
     """inter_type="min" (reference homan/losses.py:219-221, a HOMan option its loop cannot select): the closest hand-object vertex
     pair per gated frame pulls on the hand's rigid pose.  Step-2 set: all gradients, then 12 free-running steps, bit-equal."""

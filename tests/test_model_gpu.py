@@ -110,9 +110,11 @@ def test_short_trajectory_eager_and_graph(name, mano_model):
             st.run(steps)
             evo = st.loss_evolution(steps)["loss"]
         ref = rec["evo_loss"][:steps]
-        np.testing.assert_allclose(evo[0], ref[0], rtol=1e-4, err_msg=mode)
-        np.testing.assert_allclose(evo[:3], ref[:3], rtol=5e-3, err_msg=mode)
-        np.testing.assert_allclose(evo, ref, rtol=0.1, err_msg=mode)
+        # bars = what tools/measure_test_bars.py measures on the MI355X (profiles/r06_test_bars.json) x ~1.5-2: first step 7.9e-8,
+        # first three 8.1e-6, all six 5.6e-3 (a flipped sample by then)
+        np.testing.assert_allclose(evo[0], ref[0], rtol=1e-6, err_msg=mode)
+        np.testing.assert_allclose(evo[:3], ref[:3], rtol=2e-5, err_msg=mode)
+        np.testing.assert_allclose(evo, ref, rtol=0.01, err_msg=mode)
         sd = model.state_dict()
         np.testing.assert_array_equal(sd["mano_rot"].cpu().numpy(), rec["in_mano_rot"])      # never stepped
 
@@ -413,8 +415,10 @@ def test_cfg1_full_fit_follows_the_reference_loop(mano_model):
     the `loss_evolution` the REFERENCE's own loop produced on these inputs (tests/golden/ref_cfg1_cube_b10_s128.npz, generated
     by tools/refharness/gen_goldens.py from /root/reference).  Tight while the two runs see the same coverage (the hard
     rasteriser makes the loss piecewise constant in the pose: a last-bit difference flips a sample within a few steps,
-    DESIGN.md section 2), then the same optimisation: every logged term within 35 % + 5 % of its first value, the final
-    total within 10 %, the hand's 2-D term - which does not see the object on this loss set - within 1e-4 throughout."""
+    DESIGN.md section 2), then the same optimisation.  Bars = measured (tools/measure_test_bars.py, profiles/r06_test_bars.json)
+    x 1.5: the total within 8 % at every step (measured 5.5 %), the silhouette term within 6.5 % of its FIRST value (measured
+    4.3 %: late in the fit the term is small and its relative deviation means nothing), the final total within 3.5 % (2.2 %),
+    the hand's 2-D term - which does not see the object on this loss set - within 1e-5 throughout (1.4e-6)."""
     from homan_amd.jointopt import FusedStepper
     rec, model, weights, meta = _build_hip("ref_cfg1_cube_b10_s128", mano_model, sync=False)
     steps = meta["steps"]
@@ -433,9 +437,12 @@ def test_cfg1_full_fit_follows_the_reference_loop(mano_model):
         got, ref = np.asarray(evo[k]), rec["evo_" + k]
         np.testing.assert_allclose(got[0], ref[0], rtol=1e-4, err_msg=k)
         np.testing.assert_allclose(got[:split], ref[:split], rtol=5e-4, atol=1e-7, err_msg=k)
-        np.testing.assert_allclose(got[split:], ref[split:], rtol=0.35, atol=1e-6 + 0.05 * abs(float(ref[0])), err_msg=k)
-    np.testing.assert_allclose(evo["loss_v2d_hand"], rec["evo_loss_v2d_hand"], rtol=1e-4)
-    np.testing.assert_allclose(evo["loss"][-1], rec["evo_loss"][-1], rtol=0.1)
+        if k == "loss_sil_obj":
+            np.testing.assert_allclose(got[split:], ref[split:], rtol=0, atol=0.065 * abs(float(ref[0])), err_msg=k)
+        else:
+            np.testing.assert_allclose(got[split:], ref[split:], rtol=0.08, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(evo["loss_v2d_hand"], rec["evo_loss_v2d_hand"], rtol=1e-5)
+    np.testing.assert_allclose(evo["loss"][-1], rec["evo_loss"][-1], rtol=0.035)
     np.testing.assert_array_equal(model.mano_rot.detach().cpu().numpy(), rec["in_mano_rot"])      # never stepped
 
 

@@ -169,6 +169,35 @@ def test_written_out_chain_with_a_free_object_scale(mano_model):
                                    err_msg=name)
 
 
+def test_written_out_chain_with_inter_type_min_and_a_free_object_scale(mano_model):
+    """inter_type="min" (homan/losses.py:219-221) with optimize_object_scale=True: the closest pair's pull reaches the OBJECT'S
+    vertex j* too, and through it pose and scale - the last configuration the written-out chain used to refuse.  All nine
+    parameters against autograd through the faithful form."""
+    from homan_amd import synth
+    from oracle import handchain, objchain
+    from oracle.jointopt import collate_inputs
+    from oracle.model import OracleHOMan
+    sil_fn, hand_fn = util.oracle_clip_fns(mano_model)
+    clip = synth.make_clip(seed=2, frames=4, rend_size=64, image_size=64, obj="bottle", silhouette_fn=sil_fn, hand_verts_fn=hand_fn)
+    kw = collate_inputs(clip["person_parameters"], clip["object_parameters"], clip["objvertices"], clip["objfaces"])
+    model = OracleHOMan(camintr=clip["camintr"], class_name="default", int_scale_init=1, optimize_mano=True,
+                        optimize_object_scale=True, inter_type="min", image_size=64, mano_model=mano_model, rend_size=64, **kw)
+    lw = dict(synth.STEP1_LOSS_WEIGHTS)
+    with torch.no_grad():
+        model.int_scales_object.add_(0.05)
+    loss_dict, _ = model(loss_weights=lw)
+    assert float(loss_dict["loss_inter"].detach()) > 0                     # (some frame passes the gate: the term is live)
+    sum(loss_dict[k] * lw[k.replace("loss", "lw")] for k in loss_dict).backward()
+    got, stg = handchain.hand_param_grads(model, lw, return_stages=True)
+    got.update(objchain.object_pose_grads(model, lw, inter_rec=stg["rec"]))
+    assert len(got) == 9
+    for name, g in got.items():
+        ref = getattr(model, name).grad.numpy()
+        scale = np.abs(ref).max()
+        np.testing.assert_allclose(g.reshape(ref.shape) / scale, ref / scale, atol=3e-4 if "rotations_object" in name else 5e-5,
+                                   err_msg=name)
+
+
 @pytest.mark.parametrize("free_scale", [False, True])
 def test_written_out_chain_with_two_hands(free_scale, mano_model):
     """hand_nb = 2 (right + left), step-2 set, both hands moved into the object: the written-out chains (oracle/handchain.py

@@ -269,7 +269,7 @@ def test_pair_terms_launch_equals_its_four_entry_points():
             hl.check(L.hm_pair_terms_fwd_clips(P(vh), P(vo), P(camintr), B, Vh, Vo, slot(6), P(order), P(ws[0].buf),
                                                c.INTERACTION_BBOX_EXPANSION, float(c.INTERACTION_Z_THRESH), P(rec), slot(7),
                                                P(ws[1].buf), P(u_smo), slot(8), P(ws[2].buf), *ht, P(ws[3].buf), None, None, None, None,
-                                               None, None, None, CL, stride, stream), "pair terms")
+                                               None, None, None, None, CL, stride, stream), "pair terms")
         else:
             hl.check(L.hm_nn_fwd_clips(P(vh), P(vo), B, Vh, Vo, None, None, slot(6), P(ws[0].buf), CL, stride, P(order), stream),
                      "nn")
@@ -357,10 +357,31 @@ def test_metric_search_with_rigid_group_spheres_is_exact():
         ws = ClipReduceWorkspace(DEV, C)
         hl.check(L.hm_nn_fwd_rigid_clips(P(vh), P(vo), B, Vh, Vo, None, None, P(out), P(ws.buf), CL, 5, P(order),
                                          P(sph) if sph is not None else None, P(rot6d), P(trans.reshape(B, 3).contiguous()),
-                                         P(scale), P(ho) if ho is not None else None, hl.stream()), "nn")
+                                         P(scale), P(ho) if ho is not None else None, None, hl.stream()), "nn")
         torch.cuda.synchronize()
         outs.append(out[:, 0].clone())
     for o in outs[1:]:
         assert torch.equal(outs[0], o)
+    # ... and with the SEED of the previous call (nn_seed: the pair that held each frame's minimum last time bounds this call's
+    # minimum before anything is scanned): zero-filled at first, then carried over three calls while the hand moves - every call
+    # returns the unseeded search's value, and after a call the seed names, per frame, a pair AT the minimum
+    seed = torch.zeros((2 + (Vh + 127) // 128) * B, dtype=torch.int32, device=DEV)
+    vh_t = vh.clone()
+    for it in range(4):
+        res = []
+        for sd in (None, seed):
+            out = torch.zeros(C, 5, device=DEV)
+            ws = ClipReduceWorkspace(DEV, C)
+            hl.check(L.hm_nn_fwd_rigid_clips(P(vh_t), P(vo), B, Vh, Vo, None, None, P(out), P(ws.buf), CL, 5, P(order), P(spheres),
+                                             P(rot6d), P(trans.reshape(B, 3).contiguous()), P(scale), P(perm),
+                                             P(sd) if sd is not None else None, hl.stream()), "nn")
+            torch.cuda.synchronize()
+            res.append(out[:, 0].clone())
+        assert torch.equal(res[0], res[1]), it
+        pairs = seed[:2 * B].reshape(B, 2).long()
+        dpair = (vh_t[torch.arange(B), pairs[:, 0]] - vo[torch.arange(B), pairs[:, 1]]).double().norm(dim=1)
+        dmin = torch.cdist(vh_t.double(), vo.double()).amin((1, 2))
+        np.testing.assert_allclose(dpair.cpu().numpy(), dmin.cpu().numpy(), rtol=1e-5)
+        vh_t = vh_t + 0.004 * (it + 1) * torch.tensor([1.0, -0.5, 0.25], device=DEV)        # the hand moves on
     d = torch.cdist(vh.double(), vo.double()).amin((1, 2)).reshape(C, CL).amax(1)
     np.testing.assert_allclose(outs[1].cpu().numpy(), d.cpu().numpy(), rtol=1e-5)

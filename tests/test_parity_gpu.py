@@ -16,14 +16,15 @@ import sys
 
 import pytest
 
-pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 
 
-def test_cfg1_final_loss_and_vertex_parity(mano_model):
+# (`-m gpu`: one seed - BASELINE's configuration itself; three seeds under the marker `gpu_slow`, see tests/test_lockstep_gpu.py)
+@pytest.mark.parametrize("seeds", [pytest.param([0], marks=pytest.mark.gpu), pytest.param([1, 2], marks=pytest.mark.gpu_slow)])
+def test_cfg1_final_loss_and_vertex_parity(seeds, mano_model):
     sys.path.insert(0, ROOT)
     import bench_parity as bench
-    out = bench.cfg1_parity(mano_model, seeds=[0, 1, 2], steps=100)
+    out = bench.cfg1_parity(mano_model, seeds=seeds, steps=100)
     for row in out["seeds"]:
         assert row["first_step_over_tol"] is None, row                    # every logged loss within 1e-4 at every step
         assert row["max_rel_diff_any_step"] < 1e-4, row
@@ -39,6 +40,7 @@ def test_cfg1_final_loss_and_vertex_parity(mano_model):
     assert ctrl["final_vertex_diff_mm"]["object"] > 1.0, ctrl
 
 
+@pytest.mark.gpu
 def test_free_running_trajectory_is_bit_equal_step1_set(mano_model):
     """a cfg2-shaped clip (bottle, full step-1 loss set) at reduced size: EVERY parameter - object pose, hand pose, MANO pose /
     shape / translation - bit-equal after each of 60 free-running steps, all losses within 1e-4, final vertices identical"""

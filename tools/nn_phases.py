@@ -23,7 +23,7 @@ for at in (0, 200):
     st.run(at - (0 if at == 0 else 0))
     mm = st.model
     args = (P(st.vh), P(st.vo), st.B, st.Vh, st.Vo, None, None, st._slot("handobj_maxdist"), P(st.reduce_ws_b.buf), st.clip_len, st.NS,
-            P(st.obj_order), P(st.obj_spheres), P(mm.rotations_object), P(mm.translations_object), P(mm.int_scales_object), (P(st.hand_order) if HO else None), hlib.stream())
+            P(st.obj_order), P(st.obj_spheres), P(mm.rotations_object), P(mm.translations_object), P(mm.int_scales_object), (P(st.hand_order) if HO else None), (P(st.nn_seed) if os.environ.get('SEED', '1') == '1' else None), hlib.stream())
     for _ in range(3): hlib.check(L.hm_nn_fwd_rigid_clips(*args), "nn")
     L.hm_debug_nn_phases(out)
     torch.cuda.synchronize(); t = time.perf_counter()

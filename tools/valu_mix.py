@@ -5,7 +5,8 @@
 Compiles homan_amd/csrc/*.hip to gfx950 assembly (device side only), histograms the VALU opcodes of k_raster_fwd and
 k_bwd_sweep<true> (STATIC counts: every instruction of the kernel body once - a proxy for the dynamic mix, which the PMC counters
 do not break down by opcode), maps every opcode onto one of the measured classes and prints the mix-weighted cycles per wave64
-instruction at 1 / 2 / 4 / 8 waves per SIMD.  Opcodes without a measured class are listed and priced as `v_add_u32`."""
+instruction at 1 / 2 / 4 / 8 waves per SIMD (from the wall-clock figures at the nominal 2.4 GHz: the in-kernel s_memtime counts
+do not overlap fully across waves at high occupancy).  Opcodes without a measured class are listed and priced as `v_add_u32`."""
 import collections
 import glob
 import json
@@ -18,7 +19,15 @@ import tempfile
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 KERNELS = {"k_raster_fwd": "_Z12k_raster_fwd", "k_bwd_sweep<W32>": "_Z11k_bwd_sweepILb1EE", "k_bwd_lines<W32>": "_Z11k_bwd_linesILb1EE"}
 # opcode prefix -> measured class of valu_ceiling.hip
-CLASS = [("v_pk_", "v_pk_fma_f32"), ("v_fma_f64", "v_fma_f64"), ("v_add_f64", "v_add_f64"), ("v_mul_f64", "v_fma_f64"),
+CLASS = [("v_mov_b32", "v_mov_b32"), ("v_mov_b64", "v_mov_b32"), ("v_and_b32", "v_and_b32"), ("v_or_b32", "v_or_b32"),
+         ("v_xor_b32", "v_xor_b32"), ("v_not_b32", "v_xor_b32"), ("v_lshlrev_b32", "v_lshlrev_b32"), ("v_lshrrev_b32", "v_lshlrev_b32"),
+         ("v_ashrrev_i32", "v_lshlrev_b32"), ("v_lshlrev_b64", "v_lshlrev_b32"), ("v_lshrrev_b64", "v_lshlrev_b32"),
+         ("v_sub_u32", "v_sub_u32"), ("v_subrev_u32", "v_sub_u32"), ("v_sub_co", "v_sub_u32"), ("v_add_co", "v_add_u32"),
+         ("v_addc_co", "v_add_u32"), ("v_subb_co", "v_sub_u32"), ("v_max_i32", "v_max_i32"), ("v_min_i32", "v_max_i32"),
+         ("v_max_u32", "v_max_i32"), ("v_min_u32", "v_max_i32"), ("v_bfe", "v_bfe_u32"), ("v_bitop3", "v_or3_b32"),
+         ("v_bcnt", "v_bfe_u32"), ("v_mbcnt", "v_bfe_u32"), ("v_ffbl", "v_bfe_u32"), ("v_ffbh", "v_bfe_u32"), ("v_lshl_add_u64", "v_lshl_add_u32"),
+         ("v_sub_f32", "v_sub_f32"), ("v_subrev_f32", "v_sub_f32"),
+         ("v_pk_", "v_pk_fma_f32"), ("v_fma_f64", "v_fma_f64"), ("v_add_f64", "v_add_f64"), ("v_mul_f64", "v_fma_f64"),
          ("v_cvt_f64", "v_add_f64"), ("v_cvt_f32_f64", "v_add_f64"), ("v_ldexp_f64", "v_add_f64"), ("v_cmp_", "v_cmp_lt_f32+v_cndmask_b32"),
          ("v_cndmask", "v_cmp_lt_f32+v_cndmask_b32"), ("v_rcp", "v_rcp_f32"), ("v_rsq", "v_rcp_f32"), ("v_sqrt", "v_rcp_f32"),
          ("v_exp", "v_rcp_f32"), ("v_log", "v_rcp_f32"), ("v_mul_lo", "v_mul_lo_u32"), ("v_mul_hi", "v_mul_lo_u32"),
@@ -94,7 +103,7 @@ def main():
                             if cls is None:
                                 unknown[op] += n if w == "w1" else 0
                                 cls = "v_add_u32"
-                            acc += n * ceil["ops"][cls][w]["cycles_per_instr"]
+                            acc += n * ceil["ops"][cls][w]["wall_cycles_per_instr_at_2.4GHz"]
                         rec["mix_cycles_per_instr_" + w] = round(acc / max(total, 1), 3)
                     rec["unclassified_priced_as_v_add_u32"] = dict(unknown.most_common(12))
                 out[name] = rec
