@@ -272,7 +272,7 @@ def pose_init_bench(args):
     stamps = po._fused_loop(sm, 1e-2, max(steps - reps, 3), stamp_reps=reps)[3]
     kb = kernel_bytes(n, size // 2, int(faces.shape[0]), noaa=True)
     pmc = {}
-    ppath = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r05_pmc_poseinit.json", "r04_pmc_poseinit.json"))
+    ppath = next((p for p in (os.path.join(ROOT, "profiles", f) for f in ("r06_pmc_poseinit.json", "r05_pmc_poseinit.json", "r04_pmc_poseinit.json"))
                   if os.path.exists(p)), None)
     if ppath:
         pj = json.load(open(ppath))
@@ -616,7 +616,10 @@ def main():
             ppath = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(ppath):
                 pj = json.load(open(ppath))
-                if pj.get("shape") == dict(frames=B, rend_size=S, faces=int(F), step2=bool(args.step2)) and not args.depth:
+                want = dict(frames=B, rend_size=S, faces=int(F), step2=bool(args.step2))
+                if args.depth:
+                    want["depth"] = True
+                if pj.get("shape") == want:
                     pmc, psrc = pj.get("per_launch", {}), cand      # measured on the same shapes, same steady-state loop
                     break
         per = {}
@@ -844,7 +847,8 @@ def _valu_mix_cycles():
 
 
 VALU_MIX_CYCLES = _valu_mix_cycles()
-PMC_FILES = ("r05_pmc_loop.json", "r05_pmc_loop_cfg3.json", "r04_pmc_loop.json", "r04_pmc_loop_cfg3.json")
+PMC_FILES = ("r06_pmc_loop.json", "r06_pmc_loop_cfg3.json", "r06_pmc_loop_depth.json", "r05_pmc_loop.json", "r05_pmc_loop_cfg3.json",
+             "r04_pmc_loop.json", "r04_pmc_loop_cfg3.json")
 
 
 if __name__ == "__main__":

@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--frames", type=int, default=30)
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--step2", action="store_true")
+    ap.add_argument("--depth", action="store_true", help="with the ordinal depth term (BASELINE configs[1] as worded)")
     ap.add_argument("--sweep-blocks", type=int, default=0)
     ap.add_argument("--object-scale", action="store_true", help="optimize_object_scale=True (one free scale per clip)")
     ap.add_argument("--shared-scale", action="store_true", help="ONE scale tied across the clips (BASELINE cfg5)")
@@ -39,6 +40,8 @@ def main():
     mano = synthetic_mano(0)
     sil_fn, hand_fn = synth.hip_clip_fns(mano)
     lw = dict(synth.CFG1_LOSS_WEIGHTS if args.cfg1 else synth.STEP2_LOSS_WEIGHTS if args.step2 else synth.STEP1_LOSS_WEIGHTS)
+    if args.depth:
+        lw["lw_depth"] = 1.0
     for kv in args.lw:
         k, v = kv.split("=")
         lw[k] = float(v)
@@ -51,7 +54,8 @@ def main():
         models.append(build_model(copy.deepcopy(c["person_parameters"]), copy.deepcopy(c["object_parameters"]),
                                   objvertices=c["objvertices"], objfaces=c["objfaces"], camintr=c["camintr"],
                                   optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
-                                  sync_metrics=False, optimize_object_scale=args.object_scale or args.shared_scale))
+                                  sync_metrics=False, optimize_object_scale=args.object_scale or args.shared_scale,
+                                  ordinal_depth=args.depth))
     if args.sweep_blocks:
         hlib.lib().hm_tune_sweep_blocks(args.sweep_blocks)
     total = args.warmup + args.steps
@@ -126,7 +130,7 @@ def main():
         stamps = dict(raster_us=round(acc[0], 1), lines_us=round(acc[1], 1), sweep_us=round(acc[2], 1))
     evo = st.loss_evolution(total)
     evo = evo if isinstance(evo, list) else [evo]
-    print(json.dumps(dict(in_graph_us=stamps, clips=args.clips, steps=args.steps, step2=args.step2, frames=args.frames, rend_size=args.size,
+    print(json.dumps(dict(in_graph_us=stamps, clips=args.clips, steps=args.steps, step2=args.step2, depth=args.depth, frames=args.frames, rend_size=args.size,
                           faces=int(models[0].faces_object.shape[1]), graph=not args.no_graph, ms_per_round=1e3 * el / args.steps,
                           its_per_s=args.clips * args.steps / el, us_per_clip_iteration=1e6 * el / args.steps / args.clips,
                           first_loss=[e["loss"][0] for e in evo], final_loss=[e["loss"][-1] for e in evo])))

@@ -20,6 +20,8 @@ def main(out_dir, last):
             if line.startswith("{"):
                 j = json.loads(line)
                 shape = dict(frames=j["frames"], rend_size=j["rend_size"], faces=j["faces"], step2=j["step2"])
+                if j.get("depth"):
+                    shape["depth"] = True
                 clips = j["clips"]
     for db in sorted(glob.glob(os.path.join(out_dir, "*.db"))):
         c = sqlite3.connect(db)
@@ -31,15 +33,28 @@ def main(out_dir, last):
             per[(m.group(1) if m else name, cn)].append(v)
         for (k, cn), vals in per.items():
             if k.startswith("k_"):
+                if shape and shape.get("depth") and k in ("k_raster_fwd", "k_setup_faces", "k_depth_bwd_faces", "k_depth_bwd_gather"):
+                    # with the ordinal depth term an iteration holds this kernel once per render: the silhouette's (first in
+                    # dispatch order), the object's depth render, the hand's - averaged apart (k#obj_depth, k#hand_depth)
+                    per_it = 3 if k in ("k_raster_fwd", "k_setup_faces") else 2
+                    names = ([k, k + "#obj_depth", k + "#hand_depth"] if per_it == 3 else [k + "#hand_depth", k + "#obj_depth"])
+                    vals = vals[len(vals) % per_it:]
+                    for r, nm in enumerate(names):
+                        sub = vals[r::per_it][-last:]
+                        if sub:
+                            tab[nm][cn] = sum(sub) / len(sub)
+                            tab[nm]["launches_averaged"] = len(sub)
+                    continue
                 vals = vals[-last:]
                 tab[k][cn] = sum(vals) / len(vals)
                 tab[k]["launches_averaged"] = len(vals)
     for k, t in tab.items():
         if "FETCH_SIZE" in t and "WRITE_SIZE" in t:
             t["traffic_bytes"] = int((2 * t["FETCH_SIZE"] + t["WRITE_SIZE"]) * 1024)
-    keep = ("k_raster_fwd", "k_bwd_lines", "k_bwd_sweep", "k_setup_faces", "k_mano_fwd", "k_mano_bwd", "k_nn", "k_rigid_bwd")
+    keep = ("k_raster_fwd", "k_bwd_lines", "k_bwd_sweep", "k_setup_faces", "k_mano_fwd", "k_mano_bwd", "k_nn", "k_rigid_bwd",
+            "k_rigid_bwd_x", "k_pair_terms", "k_ordinal_depth", "k_ordinal_depth_bwd", "k_depth_bwd_faces", "k_depth_bwd_gather")
     print(json.dumps(dict(note=__doc__.strip(), shape=shape, clips=clips,
-                          per_launch={k: tab[k] for k in keep if k in tab}), indent=1))
+                          per_launch={k: tab[k] for k in sorted(tab) if k.split("#")[0] in keep}), indent=1))
 
 
 if __name__ == "__main__":
