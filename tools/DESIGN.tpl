@@ -15,11 +15,11 @@ design and the current numbers; how the kernels got here - every measured step a
 | (a) a4–a6 | rot6d→R, rigid transform (+ mesh-detached twin) | `csrc/geometry.hip` (`hm_rigid_fwd/bwd`) |
 | (a) a8 + N3 | `ManoModel.forward_pca` + MANO LBS | `csrc/mano.hip` (`hm_mano_fwd/bwd`), `homan_amd/manomodel.py`, `mano_assets.py` |
 | (a) a9,a10,a13,a15 | pca / smooth / v2d / scale priors | `csrc/losses.hip` |
-| (a) a11,a12 + N1 | silhouette renderer + masked MSE + IoU | `csrc/raster.hip` (`hm_sil_fwd/bwd`) |
+| (a) a11,a12 + N1 | silhouette renderer + masked MSE + IoU | `csrc/raster_{setup,fwd,lines,sweep,api}.hip` over `raster_common.h` / `raster_ws.h` (`hm_sil_fwd/bwd`) |
 | (a) a14 | coarse interaction loss + gating + min-distance metric | `csrc/losses.hip` (`hm_inter_*`), `csrc/contact.hip` (`hm_nn_fwd`) |
 | (a) a16,a17 + N2 | SDF collision loss | `csrc/sdf.hip` (`hm_collision_fwd`) |
 | (a) a18 | contact loss (as executed, Appendix B.1) | `csrc/contact.hip` |
-| (a) a19 | ordinal depth | `csrc/raster.hip`: depth image out of `hm_sil_fwd` (`pooled_depth`), `hm_depth_bwd`, `hm_ordinal_depth_fwd/bwd`. The reference call site is broken (`homan.py:506-507` raises `TypeError`, `lossutils.py:140` builds the accumulator with `torch.Tensor(0.0)`): the default still raises that `TypeError`; `HOMan(ordinal_depth=True)` opts into the loss the method describes, in all three loops - eager, graph and the fused launch sequence (`FusedStepper`, `lw_depth > 0`, one clip, one or - round 5 - two hands per frame: three layers, three pair terms, the scene's normaliser and the pairs' shares formed on the device; any render size since the rasteriser pads to a multiple of 32, the fused depth renders at `image_size % 32 == 0`). **Oracle-pinned only** (no reference output exists to pin against) |
+| (a) a19 | ordinal depth | `csrc/raster_depth.hip` (+ the depth output of `raster_fwd.hip`): depth image out of `hm_sil_fwd` (`pooled_depth`), `hm_depth_bwd`, `hm_ordinal_depth_fwd/bwd`. The reference call site is broken (`homan.py:506-507` raises `TypeError`, `lossutils.py:140` builds the accumulator with `torch.Tensor(0.0)`): the default still raises that `TypeError`; `HOMan(ordinal_depth=True)` opts into the loss the method describes, in all three loops - eager, graph and the fused launch sequence (`FusedStepper`, `lw_depth > 0`, one clip, one or - round 5 - two hands per frame: three layers, three pair terms, the scene's normaliser and the pairs' shares formed on the device; any render size since the rasteriser pads to a multiple of 32, the fused depth renders at `image_size % 32 == 0`). **Oracle-pinned only** (no reference output exists to pin against) |
 | (b) boundary | Python surface + C ABI | `homan_amd/{homan,losses,lossutils,manomodel,jointopt}.py`, `include/homan_amd.h`, `INTEGRATION.md` |
 | (c) oracle | CPU restatement + reference-generated goldens; the object's gradient chain and Adam also written out with order-independent sums (`oracle/objchain.py`, `oracle/csrc/objchain.c`, `oracle/adam.py`) | `oracle/`, `tools/refharness/`, `tests/golden/` |
 | (d) measurement | bench, roofline, CPU baseline, rocprof | `bench.py`, `profiles/`, `tools/prof_summary.py` |
@@ -136,7 +136,7 @@ HIP ↔ oracle parity is exact where the domain is discrete and tolerance-bound 
 | pose initialisation vs the oracle with the written-out transform | coverage **bit-exact** (0 flipped samples), mask loss equal, gradients 5e-5 of max (autograd side) | `test_hip_poseinit_coverage_bit_exact_and_gradients_vs_written_out_oracle` |
 | pose initialisation, a WHOLE free-running fit vs the oracle's written-out loop (`oracle/posechain.py`) | every candidate's rotation / translation, the per-candidate losses, the best-ever pose **bit-equal** | `test_fused_poseinit_fit_bit_equal_with_the_written_out_oracle` |
 | every stage of the gradient chains at identical parameters vs the oracle's WRITTEN-OUT chains (unit gradients, interaction records, nearest-vertex picks, contact / collision / depth gradients, model-space gradient) and all parameter gradients | **bit-equal** | `tests/test_handchain_gpu.py` |
-| FREE-running fit, HIP loop vs the oracle's reproducible loop: cfg1; cfg2; cfg2 + depth; cfg3; free / tied object scale; two hands; `optimize_mano=False` | EVERY parameter **bit-equal after every step** (400 steps at full size for cfg2 / cfg2 + depth / cfg3), losses 1e-4 (measured 3.6e-7), final vertices 0.0 mm | `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`, `bench_parity.free_run_parity`, `profiles/r05_freerun_{cfg2,cfg2_depth,cfg3}_400.json` |
+| FREE-running fit, HIP loop vs the oracle's reproducible loop: cfg1; cfg2; cfg2 + depth; cfg3; free / tied object scale; two hands; `optimize_mano=False` | EVERY parameter **bit-equal after every step** (400 steps at full size for cfg2 / cfg2 + depth / cfg3), losses 1e-4 (measured 3.6e-7), final vertices 0.0 mm | `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`, `bench_parity.free_run_parity`, `profiles/r06_freerun_{cfg2,cfg2_depth,cfg3}_400.json` |
 | a stream of clips through resident steppers vs fresh fits | **bit-exact** (parameters, vertices, loss_evolution) | `tests/test_clip_fitter_gpu.py` |
 
 **Final-loss / final-vertex parity (the second half of BASELINE's metric): met, free-running.**  The hard rasteriser makes the
@@ -189,10 +189,10 @@ object's chain is closed on itself (`homan/homan.py:482-490`: `loss_inter` sees 
   (`oracle.jointopt.reproducible_step_shared_scale`).
 
 Measured (`final_loss_parity.{cfg1, free_run}` of the bench line, `tests/test_parity_gpu.py`, `tests/test_handchain_gpu.py`,
-`profiles/r05_freerun_{cfg2,cfg2_depth,cfg3}_400.json`, regenerated with this round's kernels): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
+`profiles/r06_freerun_{cfg2,cfg2_depth,cfg3}_400.json`, regenerated with this round's kernels): EVERY parameter - `rotations_object`, `translations_object`, `rotations_hand`,
 `translations_hand`, `mano_pca_pose`, `mano_rot`, `mano_betas`, `mano_trans` - is BIT-EQUAL between the two free-running loops
 after every step: cfg1 100 steps x 5 seeds; cfg2, cfg2 + ordinal depth term and cfg3 (step-2: collision + contact) at full size
-over 400 steps (`r05_freerun_cfg2_400.json`, `r05_freerun_cfg2_depth_400.json`, `r05_freerun_cfg3_400.json`:
+over 400 steps (`r06_freerun_cfg2_400.json`, `r06_freerun_cfg2_depth_400.json`, `r06_freerun_cfg3_400.json`:
 `all_params_bit_equal_all_steps: true`); the step-2 set with a free object scale over 12 steps (`tests/test_handchain_gpu.py`); final
 vertices 0.0 mm apart for the object AND the hand, every logged loss within 3.4e-7 at every step (bar 1e-4; the logged VALUES are
 parallel float sums and keep their rounding, the trajectory does not see them).  Until the hand's chain was written out (first
@@ -204,9 +204,11 @@ rows interleaved, the step-2 set with its three collision scenes, fixed or free 
 pose optimised), `inter_type="min"` (the closest vertex pair's pull on the hand's rigid pose) and - round 5 - two hands WITH the
 ordinal depth term (three layers, three pairs, one normaliser: `oracle/depthchain.py::depth_vertex_grads_layers`; the pooled depth
 images, pair counts, per-layer gradient images, vertex gradients, parameter gradients and 10 free-running steps with the step-1 and
-the step-2 weights, `::test_two_hands_with_depth_term_bit_equal`).  Not written out: `inter_type="min"` with a free scale
-(`oracle/handchain.py` raises NotImplementedError, the oracle then keeps
-autograd's gradients for the hand); there the per-step bound (lock-step, below 1e-4, vertices bit-equal) is what is claimed.  Cost of the exact
+the step-2 weights, `::test_two_hands_with_depth_term_bit_equal`).  Round 6 wrote out the last refused combination, `inter_type="min"` with a free
+object scale (the closest pair's pull then reaches the object's vertex j* too: `oracle/objchain.py`; against autograd on the CPU,
+`tests/test_objchain.py`, and bit-equal with the fused loop over 8 free-running steps on both loss sets,
+`tests/test_handchain_gpu.py::test_inter_type_min_with_a_free_object_scale_bit_equal`).  What the written-out hand chain still
+refuses is what the fused loop refuses too (a free hand scale, ortho): there autograd's gradients stand.  Cost of the exact
 path: nothing at one clip, -2 % on an 8-clip batch (EXPERIMENTS.md): the sweeps are bound by LDS and dependent loads, not by the
 divisions; the hand side's kernels did not change but for the sin / cos.
 
@@ -275,11 +277,11 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 | `k_smooth`, `k_inter`, `k_contact_hand` | grid-stride + "last block finishes" ticket | latency | 10–100 KB |
 | `k_contact_both` | contact term, both sides in one launch (object meshes of ≤ 4096 vertices; larger: `k_contact_hand` + `k_contact_obj` over ranges of 4096): per frame the hand vertices' gradients go to memory and, from the register, into 64-bit fixed-point LDS accumulators of the object's vertices (order-free integer sums: deterministic) | latency | B·(778·36 + V·12) |
 | `k_nn` | (contact term on) 128 hand vertices (2 / lane) × 4 waves splitting the object vertices; 64-vertex groups broadcast with `v_readlane` (SGPR operands) | VALU | B·(778+V)·12 |
-| `k_nn_min` | (step-1 sets: the search only feeds the logged hand-object distance) bounding spheres of 64-vertex groups of the Morton-ordered rigid mesh, carried from a mesh-space table into the frame; per group a lower bound for the workgroup's 128 hand vertices (nearest centre distance − radius); the four groups with the smallest bounds are scanned first, one per wave, and their exact minimum is the upper bound - with "centre distance + radius" 21.5 of the 24 groups of the bottle passed when the hand touches it, now 5.6 do; scans run four object vertices per trip on scalar trip counts with the minima kept as integer bits (a wave is alone on its SIMD: the independent chains hide the arithmetic latency); the result is the same float as `k_nn`'s.  42 → 24 µs stand-alone, and this launch range was the longest link of the hand-side chain | latency | B·(778+V)·12 |
+| `k_nn_min` | (step-1 sets: the search only feeds the logged hand-object distance) bounding spheres of 64-vertex groups of the Morton-ordered rigid mesh, carried from a mesh-space table into the frame; per group a lower bound for the workgroup's 128 hand vertices (nearest centre distance − radius); the four groups with the smallest bounds are scanned first, one per wave, and their exact minimum is the upper bound - with "centre distance + radius" 21.5 of the 24 groups of the bottle passed when the hand touches it, now 5.6 do; scans run four object vertices per trip on scalar trip counts with the minima kept as integer bits (a wave is alone on its SIMD: the independent chains hide the arithmetic latency); the result is the same float as `k_nn`'s.  Round 6: **seeded** - `nn_seed` (caller-owned, carried from launch to launch) holds per frame the vertex pair that held the minimum at the last launch; that pair's distance NOW is an upper bound known before anything is scanned, the four unconditional first scans go, and a workgroup scans only groups that can beat it (most: none); the clip's finishing workgroup turns each frame's winner (vertex and group, tracked per lane at group granularity) into the next seed by one 64-lane step.  Any seed content is valid - a pair is a pair -: the result is exact whatever it holds  42 → 24 µs stand-alone, and this launch range was the longest link of the hand-side chain | latency | B·(778+V)·12 |
 | `k_contact_obj` | block / frame: hand-vertex gradients added into an LDS accumulator with 64-bit **fixed-point** atomics (order-independent ⇒ deterministic without a sort; the picks are skewed onto a few object vertices) | LDS | B·(778·16 + V·12) |
 | `k_sdf_boxes`, `k_sdf_tris`, `k_sdf_need`, `k_sdf_dist`, `k_sdf_sample` | AABB + normalise; thread / triangle: packed record + +x ray parity of the few (y,z) rows under the triangle (`atomicXor` of 32-bit inside masks); thread / sample: marks touched inside voxels, first setter appends to the grid's list; workgroup / listed voxel: nearest-vertex seed + box-pruned scan of the packed triangles (a single wave was ~70 dependent round trips for one voxel); thread / sample: trilinear value + gradient, ticket reduction | latency | ≈ B·(778+V)·36 + 8.7 MB |
-| `k_depth_bwd_faces`, `k_depth_bwd_gather` (a19) | a wave per run of 4 (frame, face) slots: a lane per (slot, winding) finds the windings that own a sample in one coalesced trip (idle ones get their zeros there), then the wave walks each live winding: strides the face's sample box, tests ownership in the index map, reduces the three sums `A_k = Σ g·zp²·w_k` the NMR depth backward factors through (DPP); thread / vertex gather + projection backward | HBM (index-map reads) | B·(512²·4·ρ + S²·4 + F·(44+72)) (ρ ≈ box overlap) |
-| `k_ordinal_depth`, `k_ordinal_depth_bwd` (a19) | 16 chunk workgroups per frame; a frame's record collects them with 64-bit INTEGER atomics (pixel counts packed, softplus sums in 2⁻³² fixed point: order-independent, so deterministic), last workgroup finishes the clip; element-wise backward.  In the fused loop the object's depth render and depth backward ride the calling stream (behind the silhouette raster / behind the sweeps), the hand's the side stream | HBM | B·S²·(4·4+2) fwd, + B·S²·8 bwd |
+| `k_depth_bwd_faces`, `k_depth_bwd_gather` (a19) | a wave per run of 4 (frame, face) slots: a lane per (slot, winding) finds the windings that own a sample in one coalesced trip (idle ones get their zeros there), then the wave walks each live winding: strides the face's sample box, tests ownership in the index map, reduces the three sums `A_k = Σ g·zp²·w_k` the NMR depth backward factors through (DPP); thread / vertex gather + projection backward.  Round 6: **sparse** (`hm_depth_bwd_sparse`) - the ordinal term's gradient images are zero wherever render and annotation agree on the order; `k_ordinal_depth_bwd` leaves one byte per (frame, pixel row, 64-pixel segment), a winding whose sample box touches no flagged segment gets its exact zeros in the prologue, a frame without flags its zero vertex gradients without the gather's two round trips: 36 + 31 → 11 + 14 µs and 16 + 16 → 13 + 7 µs at cfg2 | HBM (index-map reads) | B·(512²·4·ρ + S²·4 + F·(44+72)) (ρ ≈ box overlap) |
+| `k_ordinal_depth`, `k_ordinal_depth_bwd` (a19) | 16 chunk workgroups per frame; a frame's record collects them with 64-bit INTEGER atomics (pixel counts packed, softplus sums in 2⁻³² fixed point: order-independent, so deterministic), the chunk that completes a frame learns it from the record atomic it issues anyway (arrival count in the record's spare bits) and only that one draws the clip's ticket; seven block sums behind two barriers; last workgroup finishes the clip; element-wise backward.  In the fused loop the object's depth render and depth backward ride the calling stream (behind the silhouette raster / behind the sweeps), the hand's the side stream | HBM | B·S²·(4·4+2) fwd, + B·S²·8 bwd |
 | `k_adam` | one launch for all tensors (pointer table), bias corrections in double by square-and-multiply (a function of (beta, t) alone: the oracle's Adam forms the same doubles), zeroes grads; the last workgroup (ticket) bumps the device step counter.  One clip: an extra grid row writes the log row of the step being taken (weighted total + every loss / metric slot) before it draws its tickets (`hm_adam_step_log` = `hm_log_total_clips` + `hm_adam_step`, same floats, one launch less on the tail) | latency | 28·79·B |
 
 Whole iteration (SURVEY §8d byte model): 144.1 MB (cfg2), 161.8 MB (cfg3).
@@ -317,15 +319,15 @@ next to them.  HIP-runtime and hardware facts that shaped it (all measured, EXPE
   per SIMD leave 32 registers - whether a hand-side kernel runs under a heavy kernel or after it is a matter of residency,
   which the LDS ballast knobs (`hm_tune_*`) and the sweep's workgroup count steer per loss set.
 
-## 5. Measured (MI355X, round 5; evidence under `profiles/r05_*`, regenerated by `tools/profile_round.sh r05`)
+## 5. Measured (MI355X, round 6; evidence under `profiles/r06_*`, regenerated by `tools/profile_round.sh r06`)
 
 `python bench.py` prints ONE compact JSON line (<= 2 KB: the contract's keys, `roofline`, `cpu_baseline`, one number each for
-the `steady_state` and `multi_clip` legs) and writes the full record - per-kernel tables, notes, with `--parity` the HIP-vs-oracle
-legs of `bench_parity.py` - to `gpurun_out/bench_detail.json` and stderr; the default run takes 16 s on the GPU box.  (Round 4's
+the `steady_state`, `multi_clip`, `cfg2_depth` and `cfg3` legs) and writes the full record - per-kernel tables, notes, with `--parity` the HIP-vs-oracle
+legs of `bench_parity.py` - to `gpurun_out/bench_detail.json` and stderr; the default run takes ~25 s on the GPU box.  (Round 4's
 line was 23 KB, parity traces included, and came back from the driver as `parsed: null`.)  Default workload: cfg2, 400 steps
 after 20 warm-up, then - same process, same fit, same hipGraph - a `steady_state` leg (iteration >= 400, 1000 timed iterations)
 so that ONE line carries both regimes whatever `--steps / --warmup` the driver passes (it passes `--steps 20 --warmup 5`:
-iterations 5-25 of a fresh fit).  `profiles/r05_bench_*.json` are the full records, `*_line.json` the printed lines.
+iterations 5-25 of a fresh fit).  `profiles/r06_bench_*.json` are the full records, `*_line.json` the printed lines.
 
 | Quantity | Value |
 |---|---|
@@ -339,71 +341,102 @@ iterations 5-25 of a fresh fit).  `profiles/r05_bench_*.json` are the full recor
 | cfg5 on one rank (8 clips, step-2, one tied scale, RCCL call issued) | @CFG5@ it/s |
 | 2 ranks on ONE GPU through gloo (the driver's `torch.distributed.run` line; weak scaling has nothing to scale on one GPU - this is the N > 1 code path, not a speed-up) | cfg2: @G2@ it/s summed; cfg5 (2 x 4 clips, tied scale): @G5@ it/s, replicas identical |
 | object-pose initialisation (SURVEY §8f rank 1): 500 candidate poses of the bottle against one 256² mask, `python bench.py --pose-init 500` | **@POSE@ pose-steps/s** (@POSEMS@ ms per step of 500 poses; a 50-step fit in @POSEFIT@ s); by loop: @POSELOOPS@; CPU oracle @POSECPU@ pose-steps/s |
-| free-running parity, cfg2 at full size, 400 steps, HIP loop vs the oracle's reproducible loop (`profiles/r05_freerun_cfg2_400.json`) | every parameter (object pose, hand pose, MANO) bit-equal after every step: @FREEALL@ (object alone: @FREEEQ@), final vertices object @FREEVO@ mm / hand @FREEVH@ mm, largest relative loss difference at any step @FREELOSS@ (section 2; the control `r04_control_cfg2_400.json`: the CPU loop against itself from inputs 1e-7 m apart ends 0.85 mm apart) |
+| free-running parity, cfg2 at full size, 400 steps, HIP loop vs the oracle's reproducible loop (`profiles/r06_freerun_cfg2_400.json`) | every parameter (object pose, hand pose, MANO) bit-equal after every step: @FREEALL@ (object alone: @FREEEQ@), final vertices object @FREEVO@ mm / hand @FREEVH@ mm, largest relative loss difference at any step @FREELOSS@ (section 2; the control `r04_control_cfg2_400.json`: the CPU loop against itself from inputs 1e-7 m apart ends 0.85 mm apart) |
 | CPU baseline (oracle loop, 64 host threads) | @CPU@ it/s with the reference's per-step `.item()` logging, @CPUOFF@ it/s without → GPU / CPU ≈ @RATIO@ × (target ≥ 50 ×) |
 | whole iteration vs the SURVEY §8d byte model (144.1 MB) | @WHOLE@ of 8 TB/s at one clip |
 
 **Roofline of the heavy kernels, inside the replayed graph** (ROCm allows no timing events inside graphs, so every
 workgroup of the three kernels stores `s_memrealtime` at entry and exit, `hm_sil_timestamps`; `bench.py` replays THE SAME
-graph 50 more times and averages; `rocprofv3 --kernel-trace --stats` of the same command, `profiles/r05_p_cfg2_headline_kernel_stats.txt`,
+graph 50 more times and averages; `rocprofv3 --kernel-trace --stats` of the same command, `profiles/r06_p_cfg2_headline_kernel_stats.txt`,
 agrees to a few per cent, see the note in EXPERIMENTS.md on what the profiler itself moves):
 
-| kernel (cfg2, steady state) | µs / launch | algorithmic MB | GB/s | frac of 8 TB/s | PMC traffic MB | VALU wave-instr | valu_frac (4-cycle / 2-cycle) |
+| kernel (cfg2, steady state) | µs / launch | algorithmic MB | GB/s | frac of 8 TB/s | PMC traffic MB | VALU wave-instr | valu_frac (measured mix / flat 4 cycles) |
 |---|---|---|---|---|---|---|---|
 | `k_raster_fwd` | @RAS@ | 72.2 | @RASG@ | @RASF@ | @RAST@ | @RASV@ | @RASVF@ |
 | `k_bwd_sweep` (`roofline.kernel`: the longest launch) | @SWP@ | 49.8 | @SWPG@ | @SWPF@ | @SWPT@ | @SWPV@ | @SWPVF@ |
 | `k_bwd_lines` | @LIN@ | 37.2 | @LING@ | @LINF@ | @LINT@ | @LINV@ | @LINVF@ |
 
-`valu_frac` = `SQ_INSTS_VALU` ÷ (launch time × 1024 SIMDs × 2.4 GHz ÷ 4).  The 4: a wave64 VALU instruction runs on a
-SIMD16 as four passes of 16 lanes, and the counters say so - `SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU` = 1.02 quad-cycles
-(= 4.1 cycles) per instruction for all three kernels (`quad_cycles_per_valu_instr` in the bench line).  The micro-architecture
-guide's "wave scheduling" section quotes 2 cycles - the rate of dual-issued / packed fp32, which this integer- and
-compare-heavy code rarely reaches (`v_pk_*` are a few per cent of the raster's instructions); the bench line carries the same count
-against that peak as `valu_frac_2cyc` (half the value).  Either way the reading is the same: traffic is AT the byte model
-(the kernels are not HBM-bound), and they issue VALU on one third to two thirds of all SIMD cycles; the rest is dependent
-loads (5-6 global round trips per active raster workgroup) and LDS.
+The per-launch models above count the kernels' own intermediates (line records, work list) and sum to 159.2 MB; the STRICT
+reading of SURVEY §8(d) - its raster stage, 134.7 MB, over the three kernels' summed durations - is the bench line's
+`roofline.stage_frac_8d` (@STAGEF@).
 
-Pose initialisation (`bench.py --pose-init 500`, its own line with `roofline`; `profiles/r05_p_poseinit_kernel_stats.txt`,
-`r05_pmc_poseinit.json`): per step of 500 candidate poses `k_bwd_sweep` @PISWP@ µs (algorithmic 338 MB → @PISWPG@ GB/s =
+`valu_frac` = `SQ_INSTS_VALU` × c ÷ (launch time × 1024 SIMDs × 2.4 GHz), c = cycles per wave64 instruction.  Round 5 left c
+open between the counters' 4 (`SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU` = 1.02 quad-cycles) and the guide's 2; round 6 MEASURED it
+(`tools/valu_ceiling.hip`, `profiles/r06_valu_ceiling.json`: independent instructions at 1 / 2 / 4 / 8 waves per SIMD, all 1024
+SIMDs, wall clock at the nominal 2.4 GHz): **two classes** - ~2.3 cycles for `v_add / v_sub / v_mul / v_fma_f32`, `v_add / v_sub_u32`,
+`v_mov`, `v_and / v_or / v_xor` (the guide's number), ~4.2 for everything else this code is made of: `v_cmp`, `v_cndmask`,
+shifts, `v_min / v_max`, conversions, every three-operand integer op, DPP, doubles, packed fp32 (the counters' number);
+`v_rcp_f32` 8.1, the IEEE division 47.9 per quotient; ONE wave alone on a SIMD issues an instruction per ~5 cycles whatever the
+class.  Priced with the kernels' static opcode mix (`tools/valu_mix.py`, `profiles/r06_valu_mix.json`) c = 3.3 (raster), 3.5
+(sweep, lines): the table's first number; the second is round 5's flat 4.  Reading: traffic is AT the byte model (the kernels are
+not HBM-bound); at one clip they issue VALU on a half to two thirds of all SIMD cycles, the rest is the dependent chain of every
+workgroup (below); in the 8-clip batch the sweep reaches ~0.7 - close to, not at, its issue ceiling - and what remains there is
+the mix itself (a quarter of the sweep's instructions are selects and compares at 4 cycles).
+
+**Ledger of the iteration** (rocprofv3 per-kernel averages, µs; `tools/ledger.sh`, `profiles/r06_ledger_*`; b1 = ONE frame of the
+cfg2 clip, every kernel at its latency floor):
+
+| kernel | b1 (1 frame) | cfg1 (10 × 128²) | cfg2 (30 × 256²) | dependent global round trips of its critical workgroup |
+|---|---|---|---|---|
+| `k_setup_faces` | 6.5 | 6.3 | 9.2 | kernargs, faces → vertices, bin count (returning atomic), list store |
+| `k_raster_fwd` | 18.2 | 17.3 | 49.6 (40 in-graph) | kernargs, launch-order entry, bin count + state, list, boxes, faces, ticket, keep / ref |
+| `k_bwd_lines` | 9.7 | 10.9 | 21.1 | kernargs, plane words, gradient + owner gathers per word (work-list blocks: scan + one atomic) |
+| `k_bwd_sweep` | 17.5 | 18.8 | 46.1 | totals, unit table, face records, summaries + owner + alpha, line records, sources |
+| `k_rigid_bwd_x` | 15.5 | 9.0 | 17.3 | offsets → items → corner sums, chunk records + ticket, records |
+| `k_adam` | 4.1 | 4.3 | 4.5 | slots, tensors, ticket |
+| hand side: `k_mano_fwd` / `k_pair_terms` (cfg1, b1: `k_v2d`) / `k_mano_bwd` | 13.3 / 5.0 / 30.8 | 13.7 / 5.4 / 32.0 | 16.6 / 30.3 / 42.2 | |
+| iteration, un-profiled | 77.8 | 77.2 | 154.0 (150.2 with this round's launch graph) | |
+
+One frame costs half of thirty frames: the iteration is the sum of its kernels' own latency chains.  What such a chain is made of,
+from per-workgroup phase stamps of the rasteriser (debug build `-DRASTER_TRACE`, `tools/raster_trace.py`,
+`profiles/r06_raster_trace.txt`): an ACTIVE raster workgroup lives 11.9 µs alone on its CU (scan 3.2, records 1.5, its near units
+3.6, barrier + hidden-block depths 0.3, far units 1.1, epilogue 2.2) and 16.6 µs in the 30-frame launch (slowest tenth 23 µs);
+2 746 of the 7 680 workgroups are active, six fit a CU, so the launch is TWO ROUNDS of them (start offsets: median 2 µs, 90th
+percentile 21.8 µs) = 41 µs.  No phase is more than 30 % of a workgroup; the two attempts to shorten one (scan as one round trip
+with box-carrying bin entries requested speculatively; two covered samples per trip of the unit body) measured +2 µs and ±0
+(EXPERIMENTS.md).
+
+Pose initialisation (`bench.py --pose-init 500`, its own line with `roofline`; `profiles/r06_p_poseinit_kernel_stats.txt`,
+`r06_pmc_poseinit.json`): per step of 500 candidate poses `k_bwd_sweep` @PISWP@ µs (algorithmic 338 MB → @PISWPG@ GB/s =
 **@PISWPF@** of HBM peak, the dominant kernel), `k_raster_fwd` @PIRAS@ µs (@PIRASF@), `k_bwd_lines` @PILIN@ µs (@PILINF@); all
 throughput-bound at 500 frames per launch.
 
-**What bounds the iteration** (EXPERIMENTS.md, rounds 4-5).  The silhouette chain is serial and it IS the iteration: setup 8.5 +
-raster 40 + lines 25 + sweeps 45 + object gradients 17 + Adam 4 µs = 140 µs of kernels + ~13 µs between them = 153 µs; the hand
-side (MANO 16, pair terms 30, hand gradients 42 µs) runs under it.  What round 5 measured about the rest (same-box A/B each):
-* **The launch floor is not launch latency.**  VERDICT r4 asked for the chain as ONE persistent launch with device-side barriers
-  (cfg1 ran 88 µs per iteration "with nearly empty kernels"; `tools/cfg1_floor.py` now: 77.6 µs = 12 900 it/s, 81.5 µs with one
-  iteration per graph).  Its timeline (rocprofv3): silhouette chain setup 6 + raster 17 + lines 11 + sweeps 19 + object
-  gradients 9 µs ending at 72 µs, hand chain MANO forward 13 + 2-D term 5 + MANO backward 31 µs ending at 68 µs, Adam 4 µs: two
-  chains of latency-bound kernels of about equal length, no launch in them that a barrier would shorten.  Measured instead: a dependent kernel boundary inside a stream costs
-  ~1.5 µs (guide: `boundary` row; the timeline's back-to-back launches agree), removing the cross-stream waits altogether gains
-  0.1-1.5 % (round 4), dropping the Adam launch AND its join altogether (timing experiment, lr = 0 on both sides) gains 1.5 %
-  (3 µs), and the turnaround between two graph replays was 5 µs - taken out by replaying FOUR iterations per graph (kept: +2-3 %).
-  The floor of cfg1 is the sum of six kernels' own latency chains (each 3-6 dependent HBM round trips at 1-2 µs), which a
-  megakernel keeps; what it would add on this GPU is the hand-off: the XCDs' L2s are not coherent with each other, so bulk data
-  passed between phases INSIDE a launch (index map, line records, source arrays: 30-70 MB) must be written through or fenced per
-  producer (guide: 1.7-6.5 µs per release with freshly dirtied lines, `sc1` stores 6-12 x the time per byte for narrow stores) -
-  exactly what a kernel boundary does once, wholesale, in 2-4 µs.  Grid barriers on 1280 workgroups cost 10-14 µs each
-  (`barrier-xcd` row at 4 workgroups per CU).  Not built; the boundary is the cheaper hand-off.
-* **One clip is a zero-sum game between the two streams' kernels.**  Raster at 7 instead of 6 workgroups per CU: raster 40 -> 43.6,
-  lines 25 -> 19.6, sweeps 45.5 -> 48 µs, iteration -1.2 %.  Shortening one kernel moves the others under it.
-* **The sweep is work-bound, not balance-bound.**  Dynamic unit hand-out with one queue head per XCD on its own cache line: 51 -> 60
-  µs.  Long sweeps (>= 64 sources) through a chunk list and a second launch that spreads them over 4096 waves: bit-identical, ±0 in
-  the steady state and over iterations 5-25 - while the ceiling builds that DROP pair rounds gain 15-21 % there: early in a fit
-  the 5-10 M pairs of a launch are 10-19 M wave-instructions wherever they run (two IEEE divisions + two quantised double
-  additions per pair by contract).  Long sweeps walked by their whole wave: -2 % (two loads per lane in flight instead of four).
-* **The sweep's LDS conflicts cost nothing in the steady state** (`SQ_LDS_ADDR_CONFLICT` 1.33 M, `SQ_LDS_BANK_CONFLICT` 1.60 M per
-  launch, VERDICT r4's candidate bound): the LDS pipe is busy 29 % of the launch, waves wait on it 4 % of their cycles.  Ceiling
-  builds at fixed states of the fit (`tools/ab_state.py`): no same-address atomics at all ±0 converged, +5.3 % at iteration 0,
-  where sweeps are long and dozens of lanes flush the same (face, corner) word.  Kept for that case: rows of 16 lanes that flush
-  one key combine with a DPP tree first (gated on full rounds): start +2.3 %, the driver's iterations 5-25 +1.0 %, converged ±0.
-* **Instructions pay where the GPU is full**: 32-bit byte offsets off scalar bases in the sweep and the line expansion, the
-  scalar line decomposition, the sign-bit inside test: cfg2 steady +2.0 %, 8-clip batch +2.5 %, iterations 5-25 +2.9 %, pose
-  initialisation +3.1 % (all same box, against K = 4 graphs alone).
-Cumulative against round 4 (its numbers in brackets): steady @STEADY@ (6 257), 8-clip batch @MULTI@ (9 165), the driver's flags
-@DRV@ (5 012), cfg3 @CFG3@ (5 257), pose initialisation @POSE@ (457 795).  The verdict's targets (cfg1 floor <= 50 µs, steady >=
-7 500, sweep <= 38 µs, raster <= 36 µs, batch >= 10 000) are NOT met; the measurements above say why the proposed routes do not
-lead there.
+**What bounds the iteration** (EXPERIMENTS.md, rounds 4-6).  The silhouette chain is serial and it IS the iteration: setup 8.5 +
+raster 40 + lines 22 + sweeps 44 + object gradients 17 + Adam 4 µs = 136 µs of kernels + ~14 µs between them = 150 µs; the hand
+side (MANO 16, pair terms 28, hand gradients 42 µs) runs under it.  Round 6 split the 20 µs between that and the chain's own floor
+(`tools/chain_only.py`, `profiles/r06_chain_only.txt`, one process, steppers built one after the other):
+* the silhouette chain ALONE on one queue - no side stream, no fork, no join, Adam over the object's pose only (a floor, not a
+  fit) - runs **134.4 µs** per iteration; the shipped graph of round 5 154.1;
+* both chains with NO edge between them inside the four-iteration graph (the side stream reads whatever pose it finds - not a fit
+  either): 148.2 µs.  So ~6 µs are cross-queue edges and ~14 µs are the two chains sharing the GPU (in-graph stamps raster / lines /
+  sweeps 40.3 / 22.4 / 46.4 µs next to the hand side, 38.3 / 17.3 / 43.2 alone): a fully decoupled launch graph (object Adam on the
+  calling stream, hand Adam + log row on the side stream, ring buffers for the pose, flags instead of edges) could return 3.8 %
+  at most and was not built;
+* what WAS built: the side stream forms its own copy of the object's camera-space vertices (`hm_rigid_fwd_clips`, the face setup's
+  arithmetic: the same floats) instead of forking off the face setup - a node with a successor on another queue costs its OWN queue
+  2-3 µs before its next kernel starts: 154.1 → 151.4 µs; and the metric-only search seeded with last iteration's closest pair
+  (the pair-terms launch shorter, the sweeps next to it 46.6 → 43.8 µs): → 150.2 µs.  Bit-identical both.
+Earlier findings that stand (rounds 4-5, same-box A/B each):
+* **The launch floor is not launch latency.**  A dependent kernel boundary inside a stream costs ~1.5 µs, the turnaround between
+  two graph replays ~5 µs (taken out by replaying FOUR iterations per graph).  The floor of cfg1 (77 µs) is the sum of six
+  kernels' own chains, which a megakernel keeps; what it would add on this GPU is the hand-off: the XCDs' L2s are not coherent
+  with each other, so bulk data passed between phases INSIDE a launch (index map, line records, source arrays: 30-70 MB) must be
+  written through or fenced per producer (guide: 1.7-6.5 µs per release with freshly dirtied lines) - what a kernel boundary does
+  once, wholesale, in 2-4 µs; grid barriers on 1280 workgroups cost 10-14 µs each.  Not built.
+* **One clip is a zero-sum game between the two streams' kernels.**  Raster at 7 instead of 6 workgroups per CU: raster 40 → 43.6,
+  lines 25 → 19.6, sweeps 45.5 → 48 µs, iteration -1.2 %.
+* **The sweep is work-bound, not balance-bound**: dynamic unit hand-out (one queue head per XCD) 51 → 60 µs; heavy sweeps through
+  a chunk list and a second launch ±0; long sweeps walked by their whole wave -2 %.  Its LDS conflicts cost nothing in the steady
+  state (the LDS pipe is busy 29 % of the launch) and ~5 % at iteration 0, where rows of 16 lanes that flush one key now combine
+  with a DPP tree first.
+* **Instructions pay where the GPU is full**: 32-bit byte offsets off scalar bases, the scalar line decomposition, the sign-bit
+  inside test: cfg2 steady +2.0 %, 8-clip batch +2.5 %, iterations 5-25 +2.9 %, pose initialisation +3.1 %.
+Cumulative against round 5 (its numbers in brackets): steady @STEADY@ (6 515), 8-clip batch @MULTI@ (9 379), the driver's flags
+@DRV@ (5 153), cfg3 @CFG3@ (5 457), cfg2 WITH the depth term @DEPTH@ (3 716), pose initialisation @POSE@ (479 199).  VERDICT r5's
+targets: cfg2 + depth >= 4 300 - @DEPTH@; cfg2 steady >= 7 000, cfg1 floor <= 62 µs, 8-clip batch >= 10 000, pose initialisation >=
+550 k: NOT met - the chain alone on one queue would run 7 440 it/s (cfg1: 63.9 µs), the two chains without any edge 6 750; what is
+between those numbers and the shipped graph is the hand side sharing the GPU, and the kernels' own chains were not shortened
+(two structural attempts on the raster measured ±0 / +2 µs).
 
 ## 6. Multi-GPU
 
@@ -488,35 +521,41 @@ known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4,
 
 ## 8. Known gaps / next (ranked)
 
-1. Throughput: steady @STEADY@ it/s (verdict target 7 500), 8-clip batch @MULTI@ (10 000), `k_bwd_sweep` still the longest launch
-   at 0.14 of HBM peak - a yardstick it will never approach: the sweep and the raster are VALU-issue-bound whenever the GPU is
-   full and latency-chain-bound at one clip (section 5).  What is left on the table, each worth 1-3 %: the family search of the
-   sweep's stage 1 as one ballot per trip instead of four dependent LDS reads per item; a 16-bit index map (the raster's
-   write-back hole, 4 µs, is 60 % index map); the rigid backward's adjacency as a padded per-vertex table (one round trip less).
-   Measured at the end of round 5 (EXPERIMENTS.md): an iteration at one clip is ~90 µs of chain floor (six dependent launches)
-   plus ~2.1 µs per frame, and a clip batch saturates at 8 clips with 105 µs per clip-iteration whatever the batch size (the
-   sweeps then issue VALU on 79 % of all SIMD cycles whatever their workgroup count); a second chain does not hide the first
-   one's floor (two 15-frame clips side by side: 210 µs against 153 for one 30-frame clip); the sweep's tail at one clip is two
-   tails of equal length - 100-170 workgroups that find no room next to the MANO backward for ~20 µs (96 VGPRs, 30.5 KB LDS) and
-   waves that walk two heavy 256-item units - and neither a workgroup-local hand-out, fewer workgroups, 25 KB of LDS nor an
-   80-register build shortens it.  So: the single clip moves with a shorter floor per launch (fewer dependent round trips in
-   raster / lines / sweep prologues), the batch only with fewer VALU instructions in sweep stage 1 and the raster's record build.
+1. Throughput: steady @STEADY@ it/s (VERDICT r5's target 7 000), 8-clip batch @MULTI@ (10 000), `k_bwd_sweep` still the longest
+   launch at 0.14 of HBM peak - a yardstick it will never approach: at one clip every heavy kernel is the latency chain of its
+   workgroups (section 5: one FRAME costs 78 µs, thirty cost 150), in a batch the sweeps issue VALU on ~0.7 of the SIMD cycles
+   their opcode mix allows.  Round 6's accounting: the silhouette chain alone on one queue would run 7 440 it/s, both chains
+   without any edge 6 750, the shipped graph 6 650 - so the launch graph has ~1.5 % left, the hand side's presence on the GPU costs
+   ~9 %, and everything else is inside the kernels.  Open, each worth 1-3 %: selects and compares (a quarter of the sweep's
+   instructions, 4 cycles each) turned into adds / ands (2.3); the family search of stage 1 as one ballot per trip; a 16-bit
+   index map; the MANO backward's floor (31 µs for ONE frame: its presence is what the lines / sweeps pay 8 µs for).
+   Closed with measurements (EXPERIMENTS r6): fewer round trips in the raster's scan (+2 µs), two covered samples per trip of
+   its unit body (±0), kernarg preloading (-0.3 µs), a decoupled launch graph (3.8 % at most).
 2. One launch per kernel over clips of DIFFERENT shapes (per-clip vertex / face offsets in every `hm_*_clips` kernel) is not
    built.  What stands in for it: `ShardStepper` replays the shape groups' hipGraphs concurrently - 8 clips of 4 shapes @MIXED@
-   it/s against @MULTI@ for 8 clips of one shape as a batch (`profiles/r05_bench_mixed_shard.json`), bit-identical to solo fits.
+   it/s against @MULTI@ for 8 clips of one shape as a batch (`profiles/r06_bench_mixed_shard.json`), bit-identical to solo fits.
    Padding clips to a common shape is not an option: padded vertices change the smoothness / interaction normalisers and can
    win the nearest-vertex search.
 3. The pose initialisation at @POSE@ pose-steps/s (target 600 k): sweep and raster VALU-bound at 500 frames per launch.  Its line
-   expansion moves 532 MB per launch (PMC, `r05_pmc_poseinit.json`: 2 x FETCH 144 MB + WRITE 244 MB) against a byte model that
+   expansion moves 532 MB per launch (PMC, `r06_pmc_poseinit.json`: 2 x FETCH 144 MB + WRITE 244 MB) against a byte model that
    round 4 had at 118 MB: the model had left out the kernel's own outputs - line records 33 MB, summaries 4 MB, the work list's
    records / zeroed gradients 84 MB - and the source arrays (12 B per source and orientation: ~100 MB with 500 candidates far
    from their mask).  With them the model is 239 MB + sources; the remaining factor (~1.5 x) is the guide's x 2 correction on
    FETCH_SIZE applied to narrow scattered reads (owner gathers), for which it is not calibrated.
-4. The ordinal depth term: ~116 µs on a 153 µs iteration (140 before the depth-map backward walked runs of face slots, EXPERIMENTS.md; `profiles/r05_p_cfg2_depth_timeline.txt`: three rasters make 60 % of the iteration, the calling stream is the critical path; clip batches run it over all frames at once, the ordinal term per clip).  With two hands per frame it now
-   runs in the fused loop too (round 5: losses and gradients of `HOMan.forward` + autograd at 2e-6 / 2e-5,
-   `tests/test_depth_gpu.py`) and the oracle's written-out chain covers it (bit-equal free run,
-   `tests/test_handchain_gpu.py::test_two_hands_with_depth_term_bit_equal`).  The reference's own call site
-   raises (`homan.py:506-507`): oracle-pinned only.
+4. The ordinal depth term (cfg2 as BASELINE.json words it): @DEPTH@ it/s (3 716 in round 5; target 4 300).  Round 6: the depth-map
+   backward is sparse (faces and frames that touch no non-zero gradient are not walked: 100 → 45 µs of kernel time), the depth
+   renders keep their empty regions; timeline `profiles/r06_p_cfg2_depth_timeline.txt`: both chains now end together (object:
+   silhouette raster 49 + object depth render 51 + lines 20 + sweeps 50 + depth backward 24 + pose gradients; hand: MANO 16 +
+   pair terms 33 + hand render 80 + ordinal term 36 + its backward + MANO backward 35).  What is left is the three rasters - the
+   object's depth render lasts as long as its slowest workgroup (37 µs: 114 + 126 candidates in one region, two record passes),
+   the hand's starts its active workgroups up to 32 µs late behind the background regions of its static launch order
+   (`profiles/r06_raster_trace_depth.txt`).  NOT built: the three renders as ONE launch over frames of different meshes
+   (per-frame face / vertex offsets in `k_setup_faces` / `k_raster_fwd`) - with both chains equally long, merging the object's
+   two renders alone would move the critical path to the hand side; cost-sorted orders for the depth contexts measured -3 %
+   in round 5 (two sorted rasters side by side collide).  Two hands per frame run in the fused loop too
+   (`tests/test_depth_gpu.py`), the oracle's written-out chain covers the term (bit-equal free run,
+   `tests/test_handchain_gpu.py::test_two_hands_with_depth_term_bit_equal`).  The reference's own call site raises
+   (`homan.py:506-507`): oracle-pinned only.
 5. `hand_proj_mode="ortho"` is built but parity-unpinned (section 7: its camera conversion is a third-party function absent from
    `/root/reference`, restated from the camera model) and runs through the graph loop, not the fused one.
 6. N > 1 on real multi-GPU hardware: RCCL has carried one-rank groups and (gloo) 2-3 ranks on one GPU here;

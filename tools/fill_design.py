@@ -1,5 +1,5 @@
 """Fills the measured numbers of tools/DESIGN.tpl (section 5) from the round's bench lines under profiles/ -> DESIGN.md.
-usage: python tools/fill_design.py [r05]"""
+usage: python tools/fill_design.py [r06]"""
 import json
 import os
 import sys
@@ -22,7 +22,7 @@ def load(name):
     return None
 
 
-def main(tag="r05"):
+def main(tag="r06"):
     t = open(os.path.join(R, "tools", "DESIGN.tpl")).read()
     d = load(f"{tag}_bench_cfg2.json")
     drv = load(f"{tag}_bench_cfg2_driver_flags.json")
@@ -69,7 +69,9 @@ def main(tag="r05"):
         rep[f"@{key}F@"] = f"**{k['achieved_GBps'] / 8000:.3f}**"
         rep[f"@{key}T@"] = f"{k['traffic_bytes'] / 1e6:.1f}" if k.get("traffic_bytes") else "n/a"
         rep[f"@{key}V@"] = f"{k['valu_wave_instr'] / 1e6:.1f} M" if k.get("valu_wave_instr") else "n/a"
-        rep[f"@{key}VF@"] = f"{k['valu_frac']:.2f} / {k['valu_frac_2cyc']:.2f}" if k.get("valu_frac") else "n/a"
+        rep[f"@{key}VF@"] = f"{k['valu_frac']:.2f} / {k.get('valu_frac_4cyc', 0.0):.2f}" if k.get("valu_frac") else "n/a"
+    st = d["steady_state"]["roofline"].get("raster_stage_8d")
+    rep["@STAGEF@"] = "n/a" if not st else f"{st['frac']:.3f} = {st['algorithmic_bytes'] / 1e6:.1f} MB in {st['kernels_us']:.1f} µs"
     for a, b in rep.items():
         t = t.replace(a, b)
     import re
