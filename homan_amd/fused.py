@@ -345,12 +345,6 @@ class FusedStepper:
         torch.cuda.synchronize()
         if self.on["sil"]:
             m.sil_ctx.calibrate()                # cost-sorted launch orders from the current state (scheduling only)
-        dcal = os.environ.get("HOMAN_DEPTH_CALIBRATE", "0")
-        if self.on["depth"] and self.h == 1 and dcal != "0":       # (A/B knob: launch orders of the depth renders' contexts)
-            if dcal in ("1", "o"):
-                self.dctx[0].calibrate()
-            if dcal in ("1", "h"):
-                self.dctx[1].calibrate()
         if capture:
             # scheduling hint baked into the captured launches: with the collision / contact terms the hand-side stream is
             # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way;
