@@ -1,9 +1,7 @@
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
-dep() { env "$@" python bench.py --depth --multi-clip 0 --no-cpu-baseline --legs '' 2>/dev/null | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('   $1 depth %.0f steady %.0f final %.6f' % (d['value'], d['steady_state']['value'], d['final_loss']))"; }
-dep HOMAN_DEPTH_CALIBRATE=0
-dep HOMAN_DEPTH_CALIBRATE=h
-dep HOMAN_DEPTH_CALIBRATE=o
-dep HOMAN_DEPTH_CALIBRATE=1
-dep HOMAN_DEPTH_CALIBRATE=0
-dep HOMAN_DEPTH_CALIBRATE=h
+FC=$O/fetch_calib; rm -rf $FC; mkdir -p $FC
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $FC -o f -- $R/tools/fetch_calib > $FC/requested.json 2>$FC/err1.txt
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $FC -o w -- $R/tools/fetch_calib > /dev/null 2>$FC/err2.txt )
+ls -R $FC | head; python tools/fetch_calib_summary.py $FC | tee $O/r06_fetch_calib.json | python -c "
+import json,sys; d=json.load(sys.stdin)['kernels']
+for k,v in d.items(): print(k, {a:b for a,b in v.items() if 'over' in a or 'per_access' in a})"

@@ -28,6 +28,12 @@ fi
 if [ -z "$PROFILE_SKIP_MICRO" ]; then
 [ -x tools/valu_ceiling ] && tools/valu_ceiling > $O/${N}_valu_ceiling.json 2>/dev/null && python tools/valu_mix.py $O/${N}_valu_ceiling.json > $O/${N}_valu_mix.json 2>/dev/null
 bash tools/ledger.sh $N
+if [ -x tools/fetch_calib ]; then      # FETCH_SIZE / WRITE_SIZE on narrow and scattered accesses of known size
+  FC=$O/fetch_calib; rm -rf $FC; mkdir -p $FC
+  ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $FC -o f -- $R/tools/fetch_calib > $FC/requested.json 2>/dev/null
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $FC -o w -- $R/tools/fetch_calib > /dev/null 2>&1 )
+  python tools/fetch_calib_summary.py $FC > $O/${N}_fetch_calib.json; rm -rf $FC
+fi
 python tools/chain_only.py cfg2 2>&1 | grep -v amdgpu.ids > $O/${N}_chain_only.txt
 if [ -f variants/lib_trace.so ]; then
   for f in 1 30; do HOMAN_AMD_LIB=variants/lib_trace.so python tools/raster_trace.py --frames $f 2>/dev/null | tail -6; done > $O/${N}_raster_trace.txt
