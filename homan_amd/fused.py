@@ -131,7 +131,10 @@ class FusedStepper:
         # setup's arithmetic, the same floats) instead of waiting for the face setup's copy: the silhouette chain then has no
         # successor on another queue between the iteration's fork and its join - the rasteriser follows the face setup without
         # the few microseconds a node with a cross-queue successor costs its own queue (EXPERIMENTS r6)
-        self.side_own_vo = (os.environ.get("HOMAN_SIDE_OWN_VO") or "1") != "0" and self.h == 1 and C == 1 and not lw.get("lw_depth", 0) > 0
+        # (not on the step-2 sets: there the hand-side chain is the longer one, and one more launch on it costs what the
+        #  silhouette chain gains - cfg3 5 457 -> 5 221 it/s with it)
+        self.side_own_vo = ((os.environ.get("HOMAN_SIDE_OWN_VO") or "1") != "0" and self.h == 1 and C == 1 and
+                            not lw.get("lw_depth", 0) > 0 and not lw.get("lw_collision", 0) > 0 and not lw.get("lw_contact", 0) > 0)
         # the silhouette loss / IoU values (log only) come out of the backward's first launch: one launch less on the chain
         # (two streams only: with the third stream the reduction and the log row stay there, behind the raster's event)
         self.sil_reduce_in_bwd = not self.use_aux and os.environ.get("HOMAN_SIL_REDUCE_IN_BWD", "1") != "0"
@@ -311,7 +314,9 @@ class FusedStepper:
         # chain.  One clip: cfg2 +1.3 %, cfg3 +1.4 %; a clip batch hides that chain under the silhouette chain and loses 1-1.6 %
         # (round 6: a clip batch too, +0.5 % - the separate hand launch was a 1024-thread workgroup per frame that found no room
         #  next to the persistent sweeps: 106 us on average, up to 365 us in the 8-clip profile of round 5)
-        self.mano_bwd_rigid = (os.environ.get("HOMAN_MANO_BWD_RIGID") or "1") != "0"
+        #  (a step-2 batch keeps the separate launch: 7 715 against 7 647 it/s)
+        self.mano_bwd_rigid = (os.environ.get("HOMAN_MANO_BWD_RIGID") or
+                               ("1" if C == 1 or not (self.on["col"] or self.on["con"]) else "0")) != "0"
         self.nn_early = (os.environ.get("HOMAN_NN_EARLY") or "0") != "0"
         self.pair_fused = (os.environ.get("HOMAN_PAIR_FUSED") or ("1" if C == 1 else "0")) != "0"
         self.hand_terms_fused = os.environ.get("HOMAN_HT_FUSED", "1") != "0"

@@ -217,3 +217,41 @@ def test_pseudo_gradient_magnitude_of_a_single_edge(impl):
         np.testing.assert_allclose(g[e, 0], expected[e], rtol=2e-4, err_msg=f"vertex {e}")
         assert expected[e] < 0                                              # gradient descent moves the edge right, into the column
     assert abs(g[0, 0]) < 1e-7 * abs(expected[1])                           # the apex's edges sweep away from the column
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_a_face_with_a_vertex_on_the_image_plane_is_culled_in_every_pass(impl):
+    """A vertex at camera depth ~1e-21 projects beyond 1e15 NDC units: the edge functions of its faces overflow to inf - inf.
+    Such a face is culled - in the forward (no coverage from it) AND in the pseudo-gradient (the oracle's backward
+    used to cull back faces only): a quad next to it renders and gets the finite gradient it gets alone."""
+    S = 32
+    z = 2.0
+    quad = torch.tensor([[0.3, 0.3, 1.0], [0.7, 0.3, 1.0], [0.7, 0.7, 1.0], [0.3, 0.7, 1.0]]) * z
+    wild = torch.tensor([[0.4 * z, 0.4 * z, z], [0.5 * z, 0.6 * z, z], [1e-3, 1e-3, 1e-21]])        # third vertex ON the image plane
+    f_quad = torch.tensor([[[0, 1, 2], [0, 2, 3]]])
+    f_both = torch.tensor([[[0, 1, 2], [0, 2, 3], [4, 5, 6]]])
+    v_alone, v_both = quad[None].clone(), torch.cat([quad, wild])[None].clone()
+    target = torch.zeros(1, S, S)
+    target[:, 8:20, 12:26] = 1.0
+
+    def run(v, f):
+        v = v.clone().requires_grad_(True)
+        if impl == "oracle":
+            from oracle import nmr
+            r = nmr.Renderer(image_size=S, K=K_UNIT, R=torch.eye(3)[None], t=torch.zeros(1, 3), orig_size=1)
+            img = r(v, f, mode="silhouettes")
+            ((img - target) ** 2).sum().backward()
+            return img.detach(), v.grad[0]
+        from homan_amd import ops
+        dev = torch.device("cuda")
+        sctx = ops.SilhouetteContext(f.to(dev), v.shape[1], 1, S, dev)
+        vd = v.detach().to(dev).requires_grad_(True)
+        img = ops.silhouette_render(vd, K_UNIT.to(dev), sctx)
+        ((img - target.to(dev)) ** 2).sum().backward()
+        return img.detach().cpu(), vd.grad[0].cpu()
+
+    img_a, g_a = run(v_alone, f_quad)
+    img_b, g_b = run(v_both, f_both)
+    assert torch.equal(img_a, img_b)                       # the wild face covers nothing
+    assert bool(torch.isfinite(g_b).all())
+    assert torch.equal(g_b[:4], g_a) and not g_b[4:].any()         # ... and pulls on nothing

@@ -536,12 +536,20 @@ known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4,
    it/s against @MULTI@ for 8 clips of one shape as a batch (`profiles/r06_bench_mixed_shard.json`), bit-identical to solo fits.
    Padding clips to a common shape is not an option: padded vertices change the smoothness / interaction normalisers and can
    win the nearest-vertex search.
-3. The pose initialisation at @POSE@ pose-steps/s (target 600 k): sweep and raster VALU-bound at 500 frames per launch.  Its line
-   expansion moves 532 MB per launch (PMC, `r06_pmc_poseinit.json`: 2 x FETCH 144 MB + WRITE 244 MB) against a byte model that
-   round 4 had at 118 MB: the model had left out the kernel's own outputs - line records 33 MB, summaries 4 MB, the work list's
-   records / zeroed gradients 84 MB - and the source arrays (12 B per source and orientation: ~100 MB with 500 candidates far
-   from their mask).  With them the model is 239 MB + sources; the remaining factor (~1.5 x) is the guide's x 2 correction on
-   FETCH_SIZE applied to narrow scattered reads (owner gathers), for which it is not calibrated.
+3. The pose initialisation at @POSE@ pose-steps/s (VERDICT r5's target 550 k): sweep and raster throughput-bound at 500 frames per
+   launch (220 M and 161 M VALU wave-instructions: `profiles/r06_pmc_poseinit.json`); nothing this round shortened them.  Its line
+   expansion's PMC traffic - 532 MB per launch (2 x FETCH 145 MB + WRITE 242 MB) against a byte model of 239 MB + sources - is now
+   EXPLAINED, by calibration (`tools/fetch_calib.hip`, `profiles/r06_fetch_calib.json`: kernels of known requested bytes under the
+   same two counters): coalesced reads report exactly HALF their bytes at 16 AND at 4 bytes per lane (the guide's x 2 holds for
+   both), coalesced stores report their bytes exactly - but an isolated 4-byte gather reports 64 B (128 B after the x 2), an
+   isolated 12-byte gather 68 B, 4-byte gathers inside a 4 KB window 28 B, an isolated 12-byte store 40 B and a 4-byte store 32 B:
+   the counters see LINES, not bytes.  The kernel's narrow accesses are the owner gathers of the plane-1 sources (one 4-byte
+   read of the index map each) and the 12-byte source records: with ~3 M sources per launch (1.5 M of them with an owner
+   gather) the line-granular model gives 2 x (33 + 35 + 96) MB of reads (planes, work-list inputs, gathers) + (121 + 120) MB of
+   writes (line records / summaries / work list, source records) = 569 MB against the measured 532.  So the 1.5 x is real memory
+   traffic - lines moved for a few bytes each - not a counter artefact, and not re-reads: the algorithmic bytes of those 4.5 M
+   accesses are 42 MB, what they move is ~310 MB.  Not fixed: the owner gathers follow the set bits of a line's mask (one
+   per source), there is no denser way to ask for them short of reading the index map's whole lines (256 MB per launch).
 4. The ordinal depth term (cfg2 as BASELINE.json words it): @DEPTH@ it/s (3 716 in round 5; target 4 300).  Round 6: the depth-map
    backward is sparse (faces and frames that touch no non-zero gradient are not walked: 100 → 45 µs of kernel time), the depth
    renders keep their empty regions; timeline `profiles/r06_p_cfg2_depth_timeline.txt`: both chains now end together (object:
