@@ -170,6 +170,46 @@ int hm_sil_fwd(const float* verts, const int* faces, int faces_bstride, const fl
                             rigid_scale, rigid_abs, persistent_outputs, workspace, 0, 0, nullptr, stream);
 }
 
+// Several renders - each with its own mesh, cameras, outputs and workspace - as ONE face-setup launch and ONE raster launch
+// (k_setup_faces_multi / k_raster_fwd_multi: the kernels' bodies, per render the arguments hm_sil_fwd_clips would pass).  What a
+// caller gains is launches: the depth term of reference homan/homan.py:384-419 renders the object twice per iteration (ROI
+// silhouette, full-image depth) and the hand once, and clips of different meshes (reference homan/datasets/core50.py:22-42)
+// are renders of different (V, F) - per-render vertex / face arrays ARE the per-frame mesh offsets.  Results: those of n
+// separate hm_sil_fwd_clips calls, bit for bit (every workgroup runs the same code on the same data); each render's backward
+// (hm_sil_bwd_clips / hm_depth_bwd on ITS workspace) is unchanged.  phases as hm_sil_fwd_phase_clips.
+size_t hm_sil_render_bytes(void) { return sizeof(HmSilRender); }
+int hm_sil_fwd_multi(const HmSilRender* renders, int n, int phases, hipStream_t stream)
+{
+    HM_CHECK_ARG(renders && n >= 1 && n <= HM_MAX_RENDERS && phases >= 1 && phases <= 3);
+    SilWs ws[HM_MAX_RENDERS];
+    SetupFacesArgs sa[HM_MAX_RENDERS];
+    RasterFwdArgs ra[HM_MAX_RENDERS];
+    const RasterTune& tune = hm_raster_tune();
+    for (int g = 0; g < n; ++g) {
+        const HmSilRender& r = renders[g];
+        HM_CHECK_ARG(r.verts && r.faces && r.K && r.pooled && r.workspace && HM_CLIP_LEN_OK(r.B, r.clip_len));
+        HM_CHECK_ARG(!r.rigid_rot6d || (r.rigid_trans && r.rigid_scale));
+        HM_CHECK_ARG(r.B > 0 && r.V > 0 && r.F > 0 && r.S > 0 && (!r.keep == !r.ref));
+        if (r.S % 16 != 0 || 2 * r.S > 8192 || 2L * r.F >= (1L << 30) || r.B >= 32768) return HM_ERR_UNSUPPORTED;
+        HM_CHECK_ARG(r.faces_bstride == 0 || r.faces_bstride == 3 * r.F);
+        HM_CHECK_ARG(!r.cam_verts_out || r.rigid_rot6d);
+        for (int q = 0; q < g; ++q) HM_CHECK_ARG(renders[q].workspace != r.workspace);      // a workspace carries ONE render
+        ws[g] = carve(r.workspace, r.B, r.V, r.F, r.S);
+        const int is = 2 * r.S;
+        int* bins = is <= (SR_MAX == 64 ? 1024 : 0) ? ws[g].bin_cnt : nullptr;
+        const SetupFacesArgs s1 = {r.verts, r.K, r.orig_size, r.faces, r.faces_bstride, r.B, r.V, r.F, is, bins, r.rigid_rot6d,
+                                   r.rigid_trans, r.rigid_scale, r.rigid_abs, r.clip_len ? r.clip_len : r.B, r.cam_verts_out};
+        sa[g] = s1;
+        const bool fused = r.keep && r.ref;
+        const RasterFwdArgs r1 = {r.B, r.F, r.S, r.znear, r.zfar, r.pooled, r.keep, r.ref, fused, r.work_order, r.pooled_depth, bins, 1,
+                                  r.persistent_outputs, nullptr, r.mask_shared & 1, false, false, tune.raster_lds_pad};
+        ra[g] = r1;
+    }
+    if (phases & 1) hm_launch_setup_faces_multi(ws, sa, n, stream);
+    if (phases & 2) hm_launch_raster_fwd_multi(ws, ra, n, stream);
+    return hm_launch_status();
+}
+
 // Scheduling hint, no effect on results: which winding class of the mesh (0: faces as stored, 1: reversed copies of
 // fill_back) holds the camera-facing surface.  The forward rasterises that class first and tests the units of the other
 // class against per-block hidden depths before doing any per-sample work: on a closed mesh the far class owns nothing.

@@ -43,8 +43,10 @@ __device__ unsigned long long g_raster_ph[24];   // cycles of wave 0: scan, near
 #ifndef RASTER_WPE
 #define RASTER_WPE 6       // waves per SIMD the register budget is sized for (LDS: 25 KB per workgroup = 6 per CU)
 #endif
-__global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_eu(RASTER_WPE, 8))) void k_raster_fwd(
-    const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
+// The body of the forward raster: `blk` = index of the workgroup WITHIN its render (k_raster_fwd: blockIdx.x; k_raster_fwd_multi:
+// blockIdx.x minus the first workgroup of the render it serves).  Every argument is workgroup-uniform.
+__device__ __forceinline__ void raster_fwd_body(
+    const int blk, const float* __restrict__ faces9, const FaceBox* __restrict__ boxes, int B, int F, int S, float znear,
     float zfar, int* __restrict__ idx_map, unsigned short* __restrict__ alpha16, float* __restrict__ pooled,
     const float* __restrict__ keep, const float* __restrict__ ref, float* __restrict__ dimg,
     float* __restrict__ partials, const int* __restrict__ work_order, unsigned char* __restrict__ owned,
@@ -54,7 +56,6 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     float* __restrict__ dimg_full, const unsigned int* __restrict__ hint, unsigned long long* __restrict__ ts_slots,
     int* __restrict__ wo_dyn, unsigned int* __restrict__ wg_cost)
 {
-    HM_CHAIN_KERNEL();
     const unsigned long long ts_t0 = (unsigned long long)wall_clock64();       // (see hm_ts_enabled)
     __shared__ unsigned long long zb[32 * 32];
     __shared__ int cand[2 * CAND_CAP];
@@ -77,9 +78,9 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     // for the NEXT forward of this workspace (hint word 2 then says "use wo_dyn").  What is expensive moves during a fit;
     // an order taken from the poses at its start is stale after a few dozen iterations.
     const bool dyn = wo_dyn && hint[2] != 0u;
-    const int wo = __builtin_amdgcn_readfirstlane(dyn ? wo_dyn[blockIdx.x]
-                                                     : work_order ? work_order[blockIdx.x] : (int)(((blockIdx.x % B) << 16) | (blockIdx.x / B)));
-    if (wo_dyn && !dyn && threadIdx.x == 0) wo_dyn[blockIdx.x] = wo;
+    const int wo = __builtin_amdgcn_readfirstlane(dyn ? wo_dyn[blk]
+                                                     : work_order ? work_order[blk] : (int)(((blk % B) << 16) | (blk / B)));
+    if (wo_dyn && !dyn && threadIdx.x == 0) wo_dyn[blk] = wo;
     const int region = wo & 0xffff, b = wo >> 16;
     const int rx = region % regions_x, ry = region / regions_x;
     const int tx = 2 * rx + (w & 1), ty = 2 * ry + (w >> 1);
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     // of the workgroups of a clip, every iteration) - leave before touching LDS.  (The bin ticket still has to be drawn.)
     const bool idle = nscan == 0 && rstate0 == 1;
     const bool ts_on = hm_ts_enabled(hint) && tid == 0;
-    if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 0, ts_t0);
+    if (ts_on) hm_ts_store(ts_slots, blk, 0, ts_t0);
 #ifdef RASTER_TRACE
     unsigned rtr[6] = {0, 0, 0, 0, 0, 0}, rtr_cand = 0, rtr_units = 0;
     unsigned long long rtr_t = ts_t0;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
 #ifdef RASTER_PHASES
         if (tid == 0) atomicAdd(&g_raster_ph[7], 1ull);
 #endif
-        if (wg_cost && tid == 0) wg_cost[blockIdx.x] = 0u;
+        if (wg_cost && tid == 0) wg_cost[blk] = 0u;
         return;
     }
     __syncthreads();          // every thread has read the state before thread 0 rewrites it below
@@ -546,13 +547,13 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
             o[0] = sq; o[1] = inter; o[2] = uni; o[3] = 0.f;
         }
     }
-    if (ts_on) hm_ts_store(ts_slots, blockIdx.x, 1, (unsigned long long)wall_clock64());
-    if (wg_cost && tid == 0) wg_cost[blockIdx.x] = (unsigned)min((unsigned long long)wall_clock64() - ts_t0, 0xfffffffeull) + 1u;
+    if (ts_on) hm_ts_store(ts_slots, blk, 1, (unsigned long long)wall_clock64());
+    if (wg_cost && tid == 0) wg_cost[blk] = (unsigned)min((unsigned long long)wall_clock64() - ts_t0, 0xfffffffeull) + 1u;
 #ifdef RASTER_TRACE
     RPH_MARK(5);
-    if (tid == 0 && blockIdx.x < RASTER_TRACE_WGS && (g_raster_trace_F == 0 || g_raster_trace_F == F) &&
+    if (tid == 0 && blk < RASTER_TRACE_WGS && (g_raster_trace_F == 0 || g_raster_trace_F == F) &&
         (g_raster_trace_depth < 0 || g_raster_trace_depth == (pooled_depth ? 1 : 0))) {
-        unsigned* o = g_raster_trace[blockIdx.x];
+        unsigned* o = g_raster_trace[blk];
         for (int k = 0; k < 6; ++k) o[k] = rtr[k];
         o[6] = (unsigned)ts_t0; o[7] = rtr_cand; o[8] = rtr_units;
     }
@@ -573,6 +574,31 @@ __global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_
     }
 #endif
 }
+
+__global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_eu(RASTER_WPE, 8))) void k_raster_fwd(RasterFwdK a)
+{
+    HM_CHAIN_KERNEL();
+    raster_fwd_body((int)blockIdx.x, a.faces9, a.boxes, a.B, a.F, a.S, a.znear, a.zfar, a.idx_map, a.alpha16, a.pooled, a.keep, a.ref,
+                    a.dimg, a.partials, a.work_order, a.owned, a.pooled_depth, a.planes, a.bin_cnt, a.bin_list, a.done, a.reset_bins,
+                    a.region_state, a.persistent, a.alpha_full, a.mask_shared, a.dimg_full, a.hint, a.ts_slots, a.wo_dyn, a.wg_cost);
+}
+// Several renders (their own meshes, cameras, outputs, workspaces) as ONE launch: the workgroups of render g are
+// [first[g], first[g + 1]); which render a workgroup serves is a scalar search over <= HM_MAX_RENDERS thresholds, its arguments
+// are scalar loads from the kernarg segment as before.  Same body, same results as one launch per render.
+__global__ __launch_bounds__(64 * RASTER_WAVES) __attribute__((amdgpu_waves_per_eu(RASTER_WPE, 8))) void k_raster_fwd_multi(RasterFwdMulti m)
+{
+    HM_CHAIN_KERNEL();
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < HM_MAX_RENDERS; ++k) g += (k < m.n && (int)blockIdx.x >= m.first[k]) ? 1 : 0;
+    g = __builtin_amdgcn_readfirstlane(g);
+    const RasterFwdK& a = m.r[g];
+    raster_fwd_body((int)blockIdx.x - m.first[g], a.faces9, a.boxes, a.B, a.F, a.S, a.znear, a.zfar, a.idx_map, a.alpha16, a.pooled, a.keep,
+                    a.ref, a.dimg, a.partials, a.work_order, a.owned, a.pooled_depth, a.planes, a.bin_cnt, a.bin_list, a.done,
+                    a.reset_bins, a.region_state, a.persistent, a.alpha_full, a.mask_shared, a.dimg_full, a.hint, a.ts_slots,
+                    a.wo_dyn, a.wg_cost);
+}
+
 
 __global__ __launch_bounds__(256) void k_sil_reduce(const float* __restrict__ partials, int B, int ntiles,
                                                      const float* __restrict__ keep_sum, float* __restrict__ frame_rec,
@@ -627,15 +653,34 @@ __global__ __launch_bounds__(256) void k_shade_rgb(const int* __restrict__ idx_m
 }
 
 // ---------------------------------------------------------------- launchers
+static RasterFwdK raster_fwd_k(const SilWs& w, const RasterFwdArgs& a)
+{
+    RasterFwdK k = {w.faces9, w.boxes, a.B, a.F, a.S, a.znear, a.zfar, w.idx_map, w.alpha16, a.pooled, a.keep, a.ref, w.dimg,
+                    a.fused ? w.partials : (float*)nullptr, a.work_order, w.owned, a.pooled_depth, w.planes, a.bins,
+                    w.bin_list, w.bin_done, a.reset_bins, w.region_state, a.persistent, a.alpha_full, a.mask_shared,
+                    a.per_sample_grad ? w.gimg : (float*)nullptr, w.counter + 24, w.ts, a.reorder ? w.wo_dyn : (int*)nullptr,
+                    a.reorder ? w.wg_cost : (unsigned int*)nullptr};
+    return k;
+}
 void hm_launch_raster_fwd(const SilWs& w, const RasterFwdArgs& a, hipStream_t stream)
 {
     const int ntiles = (a.S / 8) * (a.S / 8);
-    hipLaunchKernelGGL(k_raster_fwd, dim3(a.B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), a.lds_pad, stream, w.faces9,
-                       w.boxes, a.B, a.F, a.S, a.znear, a.zfar, w.idx_map, w.alpha16, a.pooled, a.keep, a.ref, w.dimg,
-                       a.fused ? w.partials : (float*)nullptr, a.work_order, w.owned, a.pooled_depth, w.planes, a.bins,
-                       w.bin_list, w.bin_done, a.reset_bins, w.region_state, a.persistent, a.alpha_full, a.mask_shared,
-                       a.per_sample_grad ? w.gimg : (float*)nullptr, w.counter + 24, w.ts, a.reorder ? w.wo_dyn : (int*)nullptr,
-                       a.reorder ? w.wg_cost : (unsigned int*)nullptr);
+    hipLaunchKernelGGL(k_raster_fwd, dim3(a.B * (ntiles / RASTER_WAVES)), dim3(64 * RASTER_WAVES), a.lds_pad, stream,
+                       raster_fwd_k(w, a));
+}
+void hm_launch_raster_fwd_multi(const SilWs* w, const RasterFwdArgs* a, int n, hipStream_t stream)
+{
+    RasterFwdMulti m;
+    m.n = n;
+    int at = 0;
+    for (int g = 0; g < HM_MAX_RENDERS; ++g) {
+        const int q = g < n ? g : n - 1;           // (unused slots repeat the last render: never selected)
+        m.r[g] = raster_fwd_k(w[q], a[q]);
+        m.first[g] = at;
+        if (g < n) at += a[g].B * ((a[g].S / 8) * (a[g].S / 8) / RASTER_WAVES);
+    }
+    m.first[HM_MAX_RENDERS] = at;
+    hipLaunchKernelGGL(k_raster_fwd_multi, dim3(at), dim3(64 * RASTER_WAVES), a[0].lds_pad, stream, m);
 }
 void hm_launch_sil_reduce(const SilWs& w, int B, int S, const float* keep_sum, float* loss_out, float* frame_out, int clip_len,
                           int out_stride, hipStream_t stream)

@@ -26,7 +26,8 @@ __device__ __forceinline__ void project_vertex(const float* __restrict__ p, cons
 // (workgroup, bin)): a raster workgroup then scans the faces of its super-region instead of the whole frame.  The order
 // inside a bin is arbitrary; the raster resolves visibility with a min, so its result does not depend on it.
 // grid (ceil(F/256), B).  bin_cnt must be zero on entry (the raster's last workgroup resets it).
-__global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ verts, const float* __restrict__ K,
+// (body: bx / by = the workgroup's block index within its render / its frame; every argument is workgroup-uniform)
+__device__ __forceinline__ void setup_faces_body(const int bx, const int by, const float* __restrict__ verts, const float* __restrict__ K,
                                                      float orig_size, const int* __restrict__ faces, int faces_bstride,
                                                      int B, int V, int F, int is, float* __restrict__ faces9,
                                                      FaceBox* __restrict__ boxes, unsigned char* __restrict__ owned,
@@ -42,13 +43,13 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
     // optional rigid transform of mesh-space `verts` (same arithmetic as hm_rigid_fwd, so the camera-space vertices the
     // other losses get from that entry point are the very numbers rasterised here): the silhouette chain then does not
     // wait for a separate transform launch
-    if (rigid_rot6d && threadIdx.x == 0) rot6d_to_mat(rigid_rot6d + blockIdx.y * 6, s_R);
-    if ((int)blockIdx.x >= nfb) {
+    if (rigid_rot6d && threadIdx.x == 0) rot6d_to_mat(rigid_rot6d + by * 6, s_R);
+    if (bx >= nfb) {
         // vertex blocks behind the face blocks (cam_out != NULL): the camera-space vertices themselves, for the caller's
         // other losses - the arithmetic of k_rigid_fwd, so hm_rigid_fwd on the same inputs returns the same floats, and the
         // caller's second stream no longer opens with a transform launch of its own
         __syncthreads();
-        const int bb = blockIdx.y, v = ((int)blockIdx.x - nfb) * blockDim.x + threadIdx.x;
+        const int bb = by, v = (bx - nfb) * blockDim.x + threadIdx.x;
         if (v >= V) return;
         float sc = rigid_scale[bb / clip_len];
         if (rigid_abs) sc = fabsf(sc);
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
         o[2] = x * s_R[2] + y * s_R[5] + z * s_R[8] + t[2];
         return;
     }
-    const int b = blockIdx.y, fi = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = by, fi = bx * blockDim.x + threadIdx.x;
     const bool valid = fi < F;
     const int nsx = (is + (1 << hm_sr_shift(is)) - 1) >> hm_sr_shift(is), nsr = nsx * nsx;
     if (threadIdx.x < SR_MAX) s_cnt[threadIdx.x] = 0;
@@ -149,15 +150,57 @@ __global__ __launch_bounds__(256) void k_setup_faces(const float* __restrict__ v
     HM_STAMP_END(0);
 }
 
+__global__ __launch_bounds__(256) void k_setup_faces(SetupFacesK a)
+{
+    setup_faces_body((int)blockIdx.x, (int)blockIdx.y, a.verts, a.K, a.orig_size, a.faces, a.faces_bstride, a.B, a.V, a.F, a.is, a.faces9,
+                     a.boxes, a.owned, a.bin_cnt, a.bin_list, a.rigid_rot6d, a.rigid_trans, a.rigid_scale, a.rigid_abs, a.clip_len,
+                     a.cam_out, a.nfb);
+}
+// Several renders as one launch (hm_sil_fwd_multi): grid (largest block count of a render, all renders' frames); the frames of
+// render g are rows [first[g], first[g + 1]) of the grid, a render's surplus blocks leave at once.
+__global__ __launch_bounds__(256) void k_setup_faces_multi(SetupFacesMulti m)
+{
+    int g = 0;
+#pragma unroll
+    for (int k = 1; k < HM_MAX_RENDERS; ++k) g += (k < m.n && (int)blockIdx.y >= m.first[k]) ? 1 : 0;
+    g = __builtin_amdgcn_readfirstlane(g);
+    const SetupFacesK& a = m.r[g];
+    if ((int)blockIdx.x >= m.nblk[g]) return;
+    setup_faces_body((int)blockIdx.x, (int)blockIdx.y - m.first[g], a.verts, a.K, a.orig_size, a.faces, a.faces_bstride, a.B, a.V, a.F,
+                     a.is, a.faces9, a.boxes, a.owned, a.bin_cnt, a.bin_list, a.rigid_rot6d, a.rigid_trans, a.rigid_scale,
+                     a.rigid_abs, a.clip_len, a.cam_out, a.nfb);
+}
+
+static SetupFacesK setup_faces_k(const SilWs& w, const SetupFacesArgs& a)
+{
+    SetupFacesK k = {a.verts, a.K, a.orig_size, a.faces, a.faces_bstride, a.B, a.V, a.F, a.is, w.faces9, w.boxes, w.owned, a.bins,
+                     w.bin_list, a.rigid_rot6d, a.rigid_trans, a.rigid_scale, a.rigid_abs, a.clip_len, a.cam_verts_out, hm_cdiv(a.F, 256)};
+    return k;
+}
 void hm_launch_setup_faces(const SilWs& w, const float* verts, const float* K, float orig_size, const int* faces,
                            int faces_bstride, int B, int V, int F, int is, int* bins, const float* rigid_rot6d,
                            const float* rigid_trans, const float* rigid_scale, int rigid_abs, int clip_len,
                            float* cam_verts_out, hipStream_t stream)
 {
+    const SetupFacesArgs a = {verts, K, orig_size, faces, faces_bstride, B, V, F, is, bins, rigid_rot6d, rigid_trans, rigid_scale,
+                              rigid_abs, clip_len, cam_verts_out};
     const int nfb = hm_cdiv(F, 256);
-    hipLaunchKernelGGL(k_setup_faces, dim3(nfb + (cam_verts_out ? hm_cdiv(V, 256) : 0), B), dim3(256), 0, stream, verts, K,
-                       orig_size, faces, faces_bstride, B, V, F, is, w.faces9, w.boxes, w.owned, bins, w.bin_list, rigid_rot6d,
-                       rigid_trans, rigid_scale, rigid_abs, clip_len, cam_verts_out, nfb);
+    hipLaunchKernelGGL(k_setup_faces, dim3(nfb + (cam_verts_out ? hm_cdiv(V, 256) : 0), B), dim3(256), 0, stream, setup_faces_k(w, a));
+}
+void hm_launch_setup_faces_multi(const SilWs* w, const SetupFacesArgs* a, int n, hipStream_t stream)
+{
+    SetupFacesMulti m;
+    m.n = n;
+    int rows = 0, cols = 0;
+    for (int g = 0; g < HM_MAX_RENDERS; ++g) {
+        const int q = g < n ? g : n - 1;           // (unused slots repeat the last render: never selected)
+        m.r[g] = setup_faces_k(w[q], a[q]);
+        m.first[g] = rows;
+        m.nblk[g] = hm_cdiv(a[q].F, 256) + (a[q].cam_verts_out ? hm_cdiv(a[q].V, 256) : 0);
+        if (g < n) { rows += a[g].B; cols = max(cols, m.nblk[g]); }
+    }
+    m.first[HM_MAX_RENDERS] = rows;
+    hipLaunchKernelGGL(k_setup_faces_multi, dim3(cols, rows), dim3(256), 0, stream, m);
 }
 
 #ifdef HM_CHAIN_STAMPS

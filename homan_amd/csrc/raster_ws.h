@@ -101,6 +101,26 @@ HM_INTERNAL void hm_launch_setup_faces(const SilWs& w, const float* verts, const
                                        int faces_bstride, int B, int V, int F, int is, int* bins, const float* rigid_rot6d,
                                        const float* rigid_trans, const float* rigid_scale, int rigid_abs, int clip_len,
                                        float* cam_verts_out, hipStream_t stream);
+#define HM_MAX_RENDERS 4      // renders of one hm_sil_fwd_multi launch pair
+// one render of hm_sil_fwd_multi: the layout include/homan_amd.h declares (hm_sil_render_bytes() lets a binding check its own)
+struct HmSilRender {
+    const float* verts; const int* faces; const float* K; const float* keep; const float* ref; float* pooled;
+    const int* work_order; float* pooled_depth; const float* rigid_rot6d; const float* rigid_trans; const float* rigid_scale;
+    float* cam_verts_out; void* workspace;
+    int faces_bstride, B, V, F, S, mask_shared, rigid_abs, persistent_outputs, clip_len;
+    float orig_size, znear, zfar;
+};
+struct SetupFacesArgs {
+    const float* verts; const float* K; float orig_size; const int* faces; int faces_bstride; int B, V, F, is; int* bins;
+    const float* rigid_rot6d; const float* rigid_trans; const float* rigid_scale; int rigid_abs; int clip_len; float* cam_verts_out;
+};
+struct SetupFacesK {         // k_setup_faces' own argument block (one render)
+    const float* verts; const float* K; float orig_size; const int* faces; int faces_bstride; int B, V, F, is; float* faces9;
+    FaceBox* boxes; unsigned char* owned; int* bin_cnt; int* bin_list; const float* rigid_rot6d; const float* rigid_trans;
+    const float* rigid_scale; int rigid_abs; int clip_len; float* cam_out; int nfb;
+};
+struct SetupFacesMulti { SetupFacesK r[HM_MAX_RENDERS]; int first[HM_MAX_RENDERS + 1]; int nblk[HM_MAX_RENDERS]; int n; };
+HM_INTERNAL void hm_launch_setup_faces_multi(const SilWs* w, const SetupFacesArgs* a, int n, hipStream_t stream);
 // raster_fwd.hip: k_raster_fwd over all (frame, region) pairs; fused = masked-MSE / IoU partials from keep / ref
 struct RasterFwdArgs {
     int B, F, S;
@@ -112,6 +132,17 @@ struct RasterFwdArgs {
     int lds_pad;
 };
 HM_INTERNAL void hm_launch_raster_fwd(const SilWs& w, const RasterFwdArgs& a, hipStream_t stream);
+// the kernel's own argument block (one render), and several of them for k_raster_fwd_multi (hm_sil_fwd_multi): the workgroups of
+// render g are [first[g], first[g + 1])
+struct RasterFwdK {
+    const float* faces9; const FaceBox* boxes; int B, F, S; float znear, zfar; int* idx_map; unsigned short* alpha16; float* pooled;
+    const float* keep; const float* ref; float* dimg; float* partials; const int* work_order; unsigned char* owned;
+    float* pooled_depth; unsigned short* planes; int* bin_cnt; const int* bin_list; unsigned int* done; int reset_bins;
+    unsigned char* region_state; int persistent; float* alpha_full; int mask_shared; float* dimg_full; const unsigned int* hint;
+    unsigned long long* ts_slots; int* wo_dyn; unsigned int* wg_cost;
+};
+struct RasterFwdMulti { RasterFwdK r[HM_MAX_RENDERS]; int first[HM_MAX_RENDERS + 1]; int n; };
+HM_INTERNAL void hm_launch_raster_fwd_multi(const SilWs* w, const RasterFwdArgs* a, int n, hipStream_t stream);
 HM_INTERNAL void hm_launch_sil_reduce(const SilWs& w, int B, int S, const float* keep_sum, float* loss_out, float* frame_out,
                                       int clip_len, int out_stride, hipStream_t stream);
 HM_INTERNAL void hm_launch_shade_rgb(const SilWs& w, const float* verts, const int* faces, int faces_bstride, const float* textures,

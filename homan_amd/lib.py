@@ -19,6 +19,8 @@ _SIGNATURES = {
     "hm_sil_fwd": (_I, [_VP, _VP, _I, _VP, _I, _I, _I, _I, _F, _F, _F, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _VP,
                         _VP, _I, _I, _VP, _VP]),
     "hm_sil_parts": (_VP, [_VP, _I, _I, _I, _I]),
+    "hm_sil_fwd_multi": (_I, [_VP, _I, _I, _VP]),
+    "hm_sil_render_bytes": (_SZ, []),
     "hm_sil_hint_near_winding": (_I, [_VP, _I, _VP]),
     "hm_tune_sweep_blocks": (_I, [_I]),
     "hm_tune_raster_lds_pad": (_I, [_I]),
@@ -120,6 +122,26 @@ _SIGNATURES = {
 
 class HomanAmdError(RuntimeError):
     pass
+
+
+class SilRender(ctypes.Structure):
+    """HmSilRender of include/homan_amd.h: one render of hm_sil_fwd_multi (fields as the arguments of hm_sil_fwd_clips)"""
+    _fields_ = ([(k, _VP) for k in ("verts", "faces", "K", "keep", "ref", "pooled", "work_order", "pooled_depth", "rigid_rot6d",
+                                    "rigid_trans", "rigid_scale", "cam_verts_out", "workspace")]
+                + [(k, _I) for k in ("faces_bstride", "B", "V", "F", "S", "mask_shared", "rigid_abs", "persistent_outputs",
+                                     "clip_len")]
+                + [(k, _F) for k in ("orig_size", "znear", "zfar")])
+
+
+def sil_renders(renders):
+    """[dict of HmSilRender fields (tensors or ints / floats; missing = NULL / 0)] -> ctypes array for hm_sil_fwd_multi.
+    The array is read by the library when the call is made (or captured); the tensors must outlive the launches."""
+    arr = (SilRender * len(renders))()
+    for r, d in zip(arr, renders):
+        for k, v in d.items():
+            setattr(r, k, ptr(v) if isinstance(v, torch.Tensor) else v)
+    assert ctypes.sizeof(SilRender) == lib().hm_sil_render_bytes(), "HmSilRender layout differs from the library's"
+    return arr
 
 
 def lib():

@@ -395,6 +395,24 @@ int hm_sil_fwd_phase_clips(const float* verts, const int* faces, int faces_bstri
                            float* alpha_full, int mask_shared, const float* rigid_rot6d, const float* rigid_trans,
                            const float* rigid_scale, int rigid_abs, int persistent_outputs, void* workspace, int clip_len,
                            int out_stride, float* cam_verts_out, int phases, hipStream_t stream);
+/* Several renders - their own meshes (V, F, vertices, faces), cameras, outputs and workspaces - as ONE face-setup launch and ONE
+ * raster launch.  reference: the ordinal depth term renders the object twice per iteration (ROI silhouette homan/losses.py:187,
+ * full-image depth homan/homan.py:391) and the hand once (homan.py:406); clips of a dataset come with their own meshes
+ * (homan/datasets/core50.py:22-42) - a render per mesh is the per-frame mesh offset table of such a batch.  Every field means
+ * what the argument of the same name means in hm_sil_fwd_clips (no alpha_full: anti-aliased renders only; the loss / IoU
+ * reduction of a render with keep / ref: hm_sil_reduce_clips or the backward's loss_out).  The adaptive launch order
+ * (hm_tune_raster_reorder) is not recorded for such launches: every render takes its static work_order.
+ * Results = n separate hm_sil_fwd_clips calls, bit for bit; each render's backward runs on its own workspace as before.
+ * n <= 4; the workspaces must be distinct.  phases: 1 = face setup, 2 = raster, 3 = both. */
+typedef struct HmSilRender {
+    const float* verts; const int* faces; const float* K; const float* keep; const float* ref; float* pooled;
+    const int* work_order; float* pooled_depth; const float* rigid_rot6d; const float* rigid_trans; const float* rigid_scale;
+    float* cam_verts_out; void* workspace;
+    int faces_bstride, B, V, F, S, mask_shared, rigid_abs, persistent_outputs, clip_len;
+    float orig_size, znear, zfar;
+} HmSilRender;
+int hm_sil_fwd_multi(const HmSilRender* renders, int n, int phases, hipStream_t stream);
+size_t hm_sil_render_bytes(void);      /* sizeof(HmSilRender) as the library was built: a binding checks its own layout against it */
 int hm_sil_reduce_clips(int B, int V, int F, int S, const float* keep_sum, float* loss_out, float* frame_out,
                         void* workspace, int clip_len, int out_stride, hipStream_t stream);
 int hm_sil_bwd_clips(const float* verts, const float* K, int B, int V, int F, int S, float orig_size, float eps, int mode,

@@ -307,3 +307,117 @@ def test_64_bit_offset_instantiations_give_the_same_results():
                        text=True, cwd=root, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def _multi_scene(B, S, seed=3):
+    """three renders of one scene: object at ROI cameras with keep / ref masks and the rigid transform in the face setup, the same
+    object at a full-image camera with a depth output, a second mesh (cube: other V, F) with a depth output"""
+    from homan_amd import synth
+    g = torch.Generator().manual_seed(seed)
+    dev = torch.device("cuda")
+    ov, of = synth.bottle_mesh()
+    cv, cf = synth.box_mesh()
+    mesh_o = torch.from_numpy(ov)[None].repeat(B, 1, 1).float().contiguous()
+    rot = torch.randn(B, 3, 2, generator=g)
+    trans = torch.tensor([[0.0, 0.0, 0.6]]) + torch.randn(B, 3, generator=g) * 0.01
+    scale = torch.tensor([1.1])
+    K_roi = torch.tensor([[2.6, 0, 0.5], [0, 2.6, 0.5], [0, 0, 1.0]]).repeat(B, 1, 1)
+    K_full = torch.tensor([[1.3, 0, 0.45], [0, 1.3, 0.55], [0, 0, 1.0]]).repeat(B, 1, 1)
+    keep = (torch.rand(B, S, S, generator=g) > 0.2).float()
+    ref = (torch.rand(B, S, S, generator=g) > 0.5).float() * keep
+    verts_c = torch.from_numpy(cv)[None].repeat(B, 1, 1).float() + torch.tensor([[0.02, -0.01, 0.55]]) \
+        + torch.randn(B, 1, 3, generator=g) * 0.01
+    d = dict(mesh_o=mesh_o, rot=rot, trans=trans, scale=scale, K_roi=K_roi, K_full=K_full, keep=keep, ref=ref, verts_c=verts_c,
+             faces_o=torch.from_numpy(of).int(), faces_c=torch.from_numpy(cf).int())
+    return {k: v.to(dev).contiguous() for k, v in d.items()}
+
+
+@pytest.mark.parametrize("B,S", [(3, 64), (5, 128)])
+def test_multi_render_launch_equals_separate_calls(B, S):
+    """hm_sil_fwd_multi: three renders (two meshes, three cameras, keep / ref on one, depth outputs on two) as ONE setup + ONE raster
+    launch = three hm_sil_fwd_clips calls, bit for bit - outputs, index maps, packed faces, camera-space vertices - and each
+    workspace then feeds its own backward (silhouette sweeps / depth-map backward) to the same gradients."""
+    from homan_amd import lib as hlib
+    from homan_amd import ops
+    sc = _multi_scene(B, S)
+    dev = sc["mesh_o"].device
+    L, P, ck = hlib.lib(), hlib.ptr, hlib.check
+    Vo, Fo, Vc, Fc = sc["mesh_o"].shape[1], sc["faces_o"].shape[0], sc["verts_c"].shape[1], sc["faces_c"].shape[0]
+    stream = hlib.stream()
+
+    def contexts():
+        return (ops.SilhouetteContext(sc["faces_o"][None].expand(B, -1, -1), Vo, B, S, dev),
+                ops.SilhouetteContext(sc["faces_o"][None].expand(B, -1, -1), Vo, B, S, dev),
+                ops.SilhouetteContext(sc["faces_c"][None].expand(B, -1, -1), Vc, B, S, dev))
+
+    def outputs():
+        return [torch.full((B, S, S), -7.0, device=dev) for _ in range(5)] + [torch.full((B, Vo, 3), -7.0, device=dev)]
+
+    def renders(ctxs, out):
+        p_sil, p_do, d_do, p_dc, d_dc, vo = out
+        rigid = dict(rigid_rot6d=sc["rot"], rigid_trans=sc["trans"], rigid_scale=sc["scale"], rigid_abs=1)
+        common = dict(S=S, B=B, orig_size=1.0, znear=ops.NMR_NEAR, zfar=ops.NMR_FAR, clip_len=B)
+        return [dict(verts=sc["mesh_o"], faces=sc["faces_o"], K=sc["K_roi"], keep=sc["keep"], ref=sc["ref"], pooled=p_sil,
+                     work_order=ctxs[0].work_order, cam_verts_out=vo, workspace=ctxs[0].workspace, V=Vo, F=Fo, **rigid, **common),
+                dict(verts=sc["mesh_o"], faces=sc["faces_o"], K=sc["K_full"], pooled=p_do, pooled_depth=d_do,
+                     work_order=ctxs[1].work_order, workspace=ctxs[1].workspace, V=Vo, F=Fo, **rigid, **common),
+                dict(verts=sc["verts_c"], faces=sc["faces_c"], K=sc["K_full"], pooled=p_dc, pooled_depth=d_dc,
+                     work_order=ctxs[2].work_order, workspace=ctxs[2].workspace, V=Vc, F=Fc, **common)]
+
+    # ---- separate calls
+    c_a, o_a = contexts(), outputs()
+    for r in renders(c_a, o_a):
+        ck(L.hm_sil_fwd_clips(P(r["verts"]), P(r["faces"]), 0, P(r["K"]), B, r["V"], r["F"], S, 1.0, ops.NMR_NEAR, ops.NMR_FAR,
+                              P(r.get("keep")), P(r.get("ref")), None, P(r["pooled"]), None, P(r["work_order"]),
+                              P(r.get("pooled_depth")), None, 0, P(r.get("rigid_rot6d")), P(r.get("rigid_trans")),
+                              P(r.get("rigid_scale")), r.get("rigid_abs", 0), 0, P(r["workspace"]), B, 0,
+                              P(r.get("cam_verts_out")), stream), "hm_sil_fwd_clips")
+    # ---- one launch pair
+    c_b, o_b = contexts(), outputs()
+    arr = hlib.sil_renders(renders(c_b, o_b))
+    ck(L.hm_sil_fwd_multi(arr, 3, 3, stream), "hm_sil_fwd_multi")
+    torch.cuda.synchronize()
+    for a, b in zip(o_a, o_b):
+        assert torch.equal(a, b)
+    assert float(o_b[0].sum()) > 10 and float((o_b[2] < ops.NMR_FAR).sum()) > 10 and float((o_b[4] < ops.NMR_FAR).sum()) > 10
+    for ca, cb in zip(c_a, c_b):
+        assert torch.equal(ca.idx_map(), cb.idx_map())
+        assert torch.equal(ca.faces9(), cb.faces9())
+    # ---- the backward passes run on the workspaces the multi launch filled
+    up = torch.ones(1, device=dev)
+    keep_sum = sc["keep"].sum().reshape(1)
+    g_depth = torch.randn(B, S, S, generator=torch.Generator().manual_seed(5)).to(dev)
+    grads = []
+    for ctxs, out in ((c_a, o_a), (c_b, o_b)):
+        gv = torch.empty(B, Vo, 3, device=dev)
+        ck(L.hm_sil_bwd_clips(P(out[5]), P(sc["K_roi"]), B, Vo, Fo, S, 1.0, ops.NMR_EPS, 2, P(up), None, P(keep_sum),
+                              P(ctxs[0].adj_off), P(ctxs[0].adj_items), None, P(gv), None, P(ctxs[0].workspace), B, None, 0, 0,
+                              stream), "hm_sil_bwd_clips")
+        gd_o, gd_c = torch.empty(B, Vo, 3, device=dev), torch.empty(B, Vc, 3, device=dev)
+        ck(L.hm_depth_bwd(P(out[5]), P(sc["K_full"]), B, Vo, Fo, S, 1.0, P(g_depth), P(ctxs[1].adj_off), P(ctxs[1].adj_items),
+                          P(gd_o), P(ctxs[1].workspace), stream), "hm_depth_bwd")
+        ck(L.hm_depth_bwd(P(sc["verts_c"]), P(sc["K_full"]), B, Vc, Fc, S, 1.0, P(g_depth), P(ctxs[2].adj_off),
+                          P(ctxs[2].adj_items), P(gd_c), P(ctxs[2].workspace), stream), "hm_depth_bwd")
+        grads.append((gv, gd_o, gd_c))
+    torch.cuda.synchronize()
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+        assert float(a.abs().sum()) > 0
+    # a second multi launch on the same workspaces (persistent outputs, bins re-armed by the first) gives the same images
+    for r in arr:
+        r.persistent_outputs = 1
+    ck(L.hm_sil_fwd_multi(arr, 3, 3, stream), "hm_sil_fwd_multi")
+    ck(L.hm_sil_fwd_multi(arr, 3, 1, stream), "hm_sil_fwd_multi setup")
+    ck(L.hm_sil_fwd_multi(arr, 3, 2, stream), "hm_sil_fwd_multi raster")
+    torch.cuda.synchronize()
+    for a, b in zip(o_a, o_b):
+        assert torch.equal(a, b)
+
+
+def test_multi_render_rejects_bad_arguments():
+    from homan_amd import lib as hlib
+    L = hlib.lib()
+    arr = (hlib.SilRender * 1)()
+    assert L.hm_sil_fwd_multi(arr, 1, 3, hlib.stream()) == -1          # NULL everything
+    assert L.hm_sil_fwd_multi(arr, 0, 3, hlib.stream()) == -1
+    assert L.hm_sil_fwd_multi(arr, 5, 3, hlib.stream()) == -1
