@@ -202,7 +202,7 @@ int hm_sil_fwd_multi(const HmSilRender* renders, int n, int phases, hipStream_t 
         sa[g] = s1;
         const bool fused = r.keep && r.ref;
         const RasterFwdArgs r1 = {r.B, r.F, r.S, r.znear, r.zfar, r.pooled, r.keep, r.ref, fused, r.work_order, r.pooled_depth, bins, 1,
-                                  r.persistent_outputs, nullptr, r.mask_shared & 1, false, false, tune.raster_lds_pad};
+                                  r.persistent_outputs, nullptr, r.mask_shared & 1, false, tune.raster_reorder != 0, tune.raster_lds_pad};
         ra[g] = r1;
     }
     if (phases & 1) hm_launch_setup_faces_multi(ws, sa, n, stream);

@@ -135,6 +135,10 @@ class FusedStepper:
         #  silhouette chain gains - cfg3 5 457 -> 5 221 it/s with it)
         self.side_own_vo = ((os.environ.get("HOMAN_SIDE_OWN_VO") or "1") != "0" and self.h == 1 and C == 1 and
                             not lw.get("lw_depth", 0) > 0 and not lw.get("lw_collision", 0) > 0 and not lw.get("lw_contact", 0) > 0)
+        # with the ordinal depth term the object's two renders of an iteration - ROI silhouette, full-image depth - are ONE launch
+        # pair (hm_sil_fwd_multi; see _issue_silhouette_chain)
+        self.merge_renders = (os.environ.get("HOMAN_MERGE_RENDERS", "1") != "0" and self.h == 1 and lw.get("lw_depth", 0) > 0 and
+                              lw.get("lw_sil_obj", 0) > 0)
         # the silhouette loss / IoU values (log only) come out of the backward's first launch: one launch less on the chain
         # (two streams only: with the third stream the reduction and the log row stay there, behind the raster's event)
         self.sil_reduce_in_bwd = not self.use_aux and os.environ.get("HOMAN_SIL_REDUCE_IN_BWD", "1") != "0"
@@ -582,7 +586,31 @@ class FusedStepper:
                         1.0, self.ops.NMR_NEAR, self.ops.NMR_FAR, P(self.sil_keep), P(self.sil_ref),
                         None, P(self.pooled), None, P(sctx.work_order), None, None, 0, P(m.rotations_object),
                         P(m.translations_object), P(m.int_scales_object), 1, 1, P(sctx.workspace), CL, NS, P(self.vo))
-            if self.side_own_vo:
+            if self.merge_renders:
+                # with the ordinal depth term: the silhouette render and the OBJECT's depth render (the same mesh and pose at the
+                # full-image camera) as ONE face-setup launch and ONE raster launch (hm_sil_fwd_multi: per render the arguments
+                # of the two calls below, the depth render forming its vertices from the pose like the silhouette render does -
+                # the same floats as self.vo); each render keeps its workspace, the backward passes are unchanged
+                arr = _lib.sil_renders([
+                    dict(verts=m.verts_object_og, faces=sctx.faces, K=self.sil_K, B=B, V=Vo, F=sctx.F, S=sctx.S, orig_size=1.0,
+                         znear=self.ops.NMR_NEAR, zfar=self.ops.NMR_FAR, keep=self.sil_keep, ref=self.sil_ref, pooled=self.pooled,
+                         work_order=sctx.work_order, rigid_rot6d=m.rotations_object, rigid_trans=m.translations_object,
+                         rigid_scale=m.int_scales_object, rigid_abs=1, persistent_outputs=1, workspace=sctx.workspace, clip_len=CL,
+                         cam_verts_out=self.vo),
+                    dict(verts=m.verts_object_og, faces=self.dctx[0].faces, K=m.camintr, B=B, V=Vo, F=self.dctx[0].F,
+                         S=self.dctx[0].S, orig_size=1.0, znear=self.ops.NMR_NEAR, zfar=self.ops.NMR_FAR, pooled=self.d_sil_o,
+                         pooled_depth=self.d_dep_o, work_order=self.dctx[0].work_order, rigid_rot6d=m.rotations_object,
+                         rigid_trans=m.translations_object, rigid_scale=m.int_scales_object, rigid_abs=1,
+                         persistent_outputs=self.depth_persistent, workspace=self.dctx[0].workspace, clip_len=CL)])
+                if self.fork_after_setup:
+                    ck(L.hm_sil_fwd_multi(arr, 2, 1, sa), "sil_fwd_multi(setup)")
+                    self.ev_sil.record(main)
+                    ck(L.hm_sil_fwd_multi(arr, 2, 2, sa), "sil_fwd_multi(raster)")
+                else:
+                    ck(L.hm_sil_fwd_multi(arr, 2, 3, sa), "sil_fwd_multi")
+                    self.ev_sil.record(main)
+                self.ev_dep.record(main)
+            elif self.side_own_vo:
                 ck(L.hm_sil_fwd_clips(*fwd_args, sa), "sil_fwd")      # (no successor on the side stream: see side_own_vo)
             elif self.fork_after_setup:
                 # the face setup (which also writes the camera-space vertices self.vo), the fork of the side stream, then the
@@ -597,7 +625,7 @@ class FusedStepper:
                 self.ev_sil.record(main)         # self.vo for the side stream
                 if use_aux and not self.sil_reduce_in_bwd:
                     self.ev_ras.record(main)
-            if on["depth"]:
+            if on["depth"] and not self.merge_renders:
                 # the OBJECT's depth render of the ordinal depth term rides this chain, right behind the silhouette raster (its
                 # vertices are the face setup's): the hand's render runs on the side stream meanwhile - two renders after each
                 # other there made the hand side twice as long as this chain

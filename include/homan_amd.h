@@ -400,8 +400,8 @@ int hm_sil_fwd_phase_clips(const float* verts, const int* faces, int faces_bstri
  * full-image depth homan/homan.py:391) and the hand once (homan.py:406); clips of a dataset come with their own meshes
  * (homan/datasets/core50.py:22-42) - a render per mesh is the per-frame mesh offset table of such a batch.  Every field means
  * what the argument of the same name means in hm_sil_fwd_clips (no alpha_full: anti-aliased renders only; the loss / IoU
- * reduction of a render with keep / ref: hm_sil_reduce_clips or the backward's loss_out).  The adaptive launch order
- * (hm_tune_raster_reorder) is not recorded for such launches: every render takes its static work_order.
+ * reduction of a render with keep / ref: hm_sil_reduce_clips or the backward's loss_out).  The launch hints (hm_tune_raster_*)
+ * apply as in hm_sil_fwd_clips: each render keeps its own (static or adaptive) order, render after render.
  * Results = n separate hm_sil_fwd_clips calls, bit for bit; each render's backward runs on its own workspace as before.
  * n <= 4; the workspaces must be distinct.  phases: 1 = face setup, 2 = raster, 3 = both. */
 typedef struct HmSilRender {
