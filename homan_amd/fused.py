@@ -334,6 +334,14 @@ class FusedStepper:
         torch.cuda.synchronize()
         if self.on["sil"]:
             m.sil_ctx.calibrate()                # cost-sorted launch orders from the current state (scheduling only)
+        if self.on["depth"] and self.h == 1:
+            # the HAND's depth render gets a cost-sorted launch order and its near-winding hint too (its active workgroups started
+            # up to 32 us late behind background regions of the static order, profiles/r06_raster_trace_depth.txt; with the
+            # object's two renders in one launch the hand side is the longer chain: cfg2 + depth 4 151 -> 4 215 it/s, same box);
+            # the object's depth render keeps the static order (sorted: +-0 alone, -1 % with the hand's)
+            for tag, ctx in zip("oh", self.dctx[:2]):
+                if tag in os.environ.get("HOMAN_DEPTH_CALIBRATE", "h"):
+                    ctx.calibrate()
         if capture:
             # scheduling hint baked into the captured launches: with the collision / contact terms the hand-side stream is
             # the longer chain and the persistent edge sweeps should leave it more of the GPU (same results either way;
