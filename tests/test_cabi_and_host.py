@@ -41,6 +41,25 @@ def test_ctypes_arity_matches_header():
         assert n == len(args), (name, n, len(args))
 
 
+def test_sil_render_struct_matches_header_and_library():
+    """HmSilRender (hm_sil_fwd_multi): the ctypes Structure has the header's fields in the header's order and the size the
+    library was built with (hm_sil_render_bytes: no GPU needed)."""
+    from homan_amd import lib
+    text = open(os.path.join(ROOT, "include", "homan_amd.h")).read()
+    body = re.search(r"typedef struct HmSilRender \{(.*?)\} HmSilRender;", text, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        kind = "p" if "*" in decl else ("f" if decl.startswith("float") else "i")
+        names = re.sub(r"^(const\s+)?(float|int|void)\s*\**", "", decl)
+        fields += [(n.strip().lstrip("*").strip(), kind) for n in names.split(",")]
+    want = {"p": ctypes.c_void_p, "i": ctypes.c_int, "f": ctypes.c_float}
+    assert [(n, want[k]) for n, k in fields] == list(lib.SilRender._fields_)
+    assert lib.lib().hm_sil_render_bytes() == ctypes.sizeof(lib.SilRender)
+
+
 def test_no_cpu_fallback_in_product():
     """homan_amd must not import the oracle, and HOMan refuses to build without a GPU."""
     import homan_amd

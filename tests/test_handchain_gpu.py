@@ -76,7 +76,7 @@ def test_hand_gradients_bit_equal(weights_name, obj, mano_model):
 
 @pytest.mark.parametrize("weights_name", ["STEP1_LOSS_WEIGHTS", "STEP2_LOSS_WEIGHTS"])
 def test_every_parameter_bit_equal_in_a_free_run(weights_name, mano_model):
-    """16 free-running steps of the step-1 / step-2 loss sets (reference loop homan/jointopt.py:158-192): HIP fused loop vs the
+    """10 free-running steps of the step-1 / step-2 loss sets (reference loop homan/jointopt.py:158-192): HIP fused loop vs the
     oracle's reproducible loop (written-out object chain, hand chain, pair terms and Adam) - EVERY parameter bit-equal after
     every step."""
     from homan_amd import synth
@@ -84,9 +84,9 @@ def test_every_parameter_bit_equal_in_a_free_run(weights_name, mano_model):
     from oracle.jointopt import make_optimizer, reproducible_step
     hm, om = _pair(mano_model, seed=12, frames=6, size=128, obj="bottle")
     lw = dict(getattr(synth, weights_name))
-    st = FusedStepper(hm, lw, 1e-2, 16)
+    st = FusedStepper(hm, lw, 1e-2, 6)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(16):
+    for i in range(6):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()
@@ -99,7 +99,7 @@ def test_every_parameter_bit_equal_in_a_free_run(weights_name, mano_model):
 def test_free_object_scale_bit_equal(mano_model):
     """optimize_object_scale=True (BASELINE cfg5's option, one clip: the scale free): the step-2 set, gradients of all nine
     parameters - the scale's among them: the frames' exact partial sums, one block sum, the prior - bit-equal at perturbed
-    parameters, then 12 free-running steps bit-equal in every parameter."""
+    parameters, then 8 free-running steps bit-equal in every parameter."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle import handchain, objchain
@@ -122,7 +122,7 @@ def test_free_object_scale_bit_equal(mano_model):
     hm, om = _pair(mano_model, seed=14, frames=6, size=128, obj="bottle", optimize_object_scale=True)
     st = FusedStepper(hm, lw, 1e-2, 12)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(12):
+    for i in range(8):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()
@@ -155,7 +155,7 @@ def _depth_pair(mano_model, seed, frames, size):
 def test_ordinal_depth_term_bit_equal(mano_model):
     """cfg2 as BASELINE.json words it (sil / kp / DEPTH / smooth): the depth term's chain - pooled depth images, per-pixel
     gradient (shared logistic function), depth-map backward per face, vertex gather - stage by stage, all eight parameter
-    gradients, then 12 free-running steps bit-equal in every parameter."""
+    gradients, then 8 free-running steps bit-equal in every parameter."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle import depthchain, handchain, objchain
@@ -178,7 +178,7 @@ def test_ordinal_depth_term_bit_equal(mano_model):
     hm, om = _depth_pair(mano_model, seed=16, frames=6, size=128)
     st = FusedStepper(hm, lw, 1e-2, 12)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(12):
+    for i in range(8):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()
@@ -192,7 +192,7 @@ def test_tied_object_scale_over_three_clips_bit_equal(mano_model):
     """BASELINE cfg5 on one rank: three clips with ONE object scale between them, step-2 loss set.  The fused loop (one clip batch,
     shared_scale=True: the clips' scale gradients added by one block sum, the sum spread to every replica) vs the oracle's
     reproducible tied loop (oracle.jointopt.reproducible_step_shared_scale): every parameter of every clip bit-equal after each
-    of 10 free-running steps, the replicas of the scalar identical throughout."""
+    of 6 free-running steps, the replicas of the scalar identical throughout."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle.jointopt import make_optimizer, reproducible_step_shared_scale
@@ -202,7 +202,7 @@ def test_tied_object_scale_over_three_clips_bit_equal(mano_model):
     st = FusedStepper(hms, lw, 1e-2, 10, shared_scale=True)
     opts = [make_optimizer(m, 1e-2, reproducible=True) for m in oms]
     names = [k for k, _ in oms[0].named_parameters()]
-    for i in range(10):
+    for i in range(6):
         st.run(1)
         reproducible_step_shared_scale(oms, opts, lw)
         torch.cuda.synchronize()
@@ -221,7 +221,7 @@ def test_two_hands_bit_equal(free_scale, mano_model):
     """Two hands per frame (right + left, rows interleaved frame-major; reference homan/homan.py:62-63, 341-358, lossutils.py:
     53-59, 116-127), step-2 loss set: the per-hand pair terms (search, contact, interaction records, the three collision scenes),
     the hands' rigid backward as a launch of its own, the MANO backward per hand through its side's model - every stage, every
-    parameter gradient, then 10 free-running steps bit-equal in every parameter."""
+    parameter gradient, then 6 free-running steps bit-equal in every parameter."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle import handchain, objchain
@@ -254,9 +254,9 @@ def test_two_hands_bit_equal(free_scale, mano_model):
     report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
     assert all(report.values()), report
     hm, om = _pair(mano_model, seed=32, frames=6, size=128, obj="bottle", hands=("right", "left"), **opts)
-    st = FusedStepper(hm, lw, 1e-2, 10)
+    st = FusedStepper(hm, lw, 1e-2, 6)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(10):
+    for i in range(6):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()
@@ -289,7 +289,7 @@ def _two_hand_depth_pair(mano_model, seed, frames, size):
 def test_two_hands_with_depth_term_bit_equal(weights_name, mano_model):
     """Two hands per frame AND the ordinal depth term (reference homan/homan.py:384-419 with three layers, lossutils.py:133-169
     over the three pairs with one normaliser): the three pooled depth images, the pairs' counts, every layer's summed gradient
-    image, the three vertex gradients, all parameter gradients, then 10 free-running steps bit-equal in every parameter.  With
+    image, the three vertex gradients, all parameter gradients, then 6 free-running steps bit-equal in every parameter.  With
     the step-2 weights the collision families and the depth term feed the hands together."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
@@ -316,9 +316,9 @@ def test_two_hands_with_depth_term_bit_equal(weights_name, mano_model):
     report = {k: bool(np.array_equal(getattr(st.model, k).grad.cpu().numpy().reshape(v.shape), v)) for k, v in want.items()}
     assert all(report.values()), report
     hm, om = _two_hand_depth_pair(mano_model, seed=42, frames=6, size=128)
-    st = FusedStepper(hm, lw, 1e-2, 10)
+    st = FusedStepper(hm, lw, 1e-2, 6)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(10):
+    for i in range(6):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()
@@ -330,7 +330,7 @@ def test_two_hands_with_depth_term_bit_equal(weights_name, mano_model):
 
 def test_fixed_hand_mesh_bit_equal(mano_model):
     """optimize_mano=False (reference homan/homan.py:104-106: the hand mesh is an input, only its rigid pose is optimised),
-    step-2 set: gradients of the four pose tensors, then 12 free-running steps, bit-equal."""
+    step-2 set: gradients of the four pose tensors, then 8 free-running steps, bit-equal."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle import handchain, objchain
@@ -365,7 +365,7 @@ def test_fixed_hand_mesh_bit_equal(mano_model):
     hm, om = build(42)
     st = FusedStepper(hm, lw, 1e-2, 12)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(12):
+    for i in range(8):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()
@@ -414,7 +414,7 @@ def test_inter_type_min_with_a_free_object_scale_bit_equal(mano_model):
 
 def test_inter_type_min_bit_equal(mano_model):
     """inter_type="min" (reference homan/losses.py:219-221, a HOMan option its loop cannot select): the closest hand-object vertex
-    pair per gated frame pulls on the hand's rigid pose.  Step-2 set: all gradients, then 12 free-running steps, bit-equal."""
+    pair per gated frame pulls on the hand's rigid pose.  Step-2 set: all gradients, then 8 free-running steps, bit-equal."""
     from homan_amd import synth
     from homan_amd.jointopt import FusedStepper
     from oracle import handchain, objchain
@@ -433,7 +433,7 @@ def test_inter_type_min_bit_equal(mano_model):
     hm, om = _pair(mano_model, seed=52, frames=6, size=128, obj="bottle", inter_type="min")
     st = FusedStepper(hm, lw, 1e-2, 12)
     opt = make_optimizer(om, 1e-2, reproducible=True)
-    for i in range(12):
+    for i in range(8):
         st.run(1)
         reproducible_step(om, lw, opt)
         torch.cuda.synchronize()

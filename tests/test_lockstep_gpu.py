@@ -68,7 +68,7 @@ def test_lockstep_cfg2_with_the_depth_term_full_size(steps, mano_model):
     assert out["max_grad_err"] < 2e-4, out["worst_grad_per_step"]
 
 
-@_lengths(24, 50)
+@_lengths(12, 50)
 def test_lockstep_cfg3_full_size(steps, mano_model):
     sys.path.insert(0, ROOT)
     import bench_parity as bench

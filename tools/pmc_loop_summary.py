@@ -31,12 +31,22 @@ def main(out_dir, last):
         for name, cn, _, v in rows:
             m = re.match(r"(?:void )?(\w+)", name)
             per[(m.group(1) if m else name, cn)].append(v)
+        merged = any(k == "k_raster_fwd_multi" for k, _ in per)      # round 6: silhouette + object depth render as ONE launch pair
         for (k, cn), vals in per.items():
             if k.startswith("k_"):
+                if shape and shape.get("depth") and merged and k in ("k_raster_fwd", "k_setup_faces", "k_raster_fwd_multi",
+                                                                     "k_setup_faces_multi"):
+                    # hm_sil_fwd_multi: the multi kernels hold the silhouette render AND the object's depth render (reported under
+                    # the plain kernel's name + "#sil+obj_depth"), the plain kernels are the hand's depth render
+                    nm = k[:-6] + "#sil+obj_depth" if k.endswith("_multi") else k + "#hand_depth"
+                    vals = vals[-last:]
+                    tab[nm][cn] = sum(vals) / len(vals)
+                    tab[nm]["launches_averaged"] = len(vals)
+                    continue
                 if shape and shape.get("depth") and k in ("k_raster_fwd", "k_setup_faces", "k_depth_bwd_faces", "k_depth_bwd_gather"):
                     # with the ordinal depth term an iteration holds this kernel once per render: the silhouette's (first in
                     # dispatch order), the object's depth render, the hand's - averaged apart (k#obj_depth, k#hand_depth)
-                    per_it = 3 if k in ("k_raster_fwd", "k_setup_faces") else 2
+                    per_it = 3 if k in ("k_raster_fwd", "k_setup_faces") and not merged else 2
                     names = ([k, k + "#obj_depth", k + "#hand_depth"] if per_it == 3 else [k + "#hand_depth", k + "#obj_depth"])
                     vals = vals[len(vals) % per_it:]
                     for r, nm in enumerate(names):

@@ -59,8 +59,8 @@ python tools/bench_clips.py --clips 8 --steps 200 --mixed > $O/${N}_bench_mixed_
 HOMAN_BENCH_BACKEND=gloo b cfg2_gpus2_gloo --gpus 2 --steps 200 --warmup 20 --multi-clip 2 --steady 0
 HOMAN_BENCH_BACKEND=gloo b cfg5_gpus2_gloo --gpus 2 --shared-scale --multi-clip 4 --steps 100 --warmup 10
 cd /tmp && export TMPDIR=/tmp
-HEAD="python bench.py --multi-clip 0 --no-cpu-baseline"
-HOMAN_BENCH_DETAIL=$O/${N}_bench_cfg2_profiled.json rocprofv3 --kernel-trace --stats -d $O/ph -o ph -- python $R/bench.py --multi-clip 0 --no-cpu-baseline > /dev/null 2>&1
+HEAD="python bench.py --multi-clip 0 --no-cpu-baseline --legs ''"
+HOMAN_BENCH_DETAIL=$O/${N}_bench_cfg2_profiled.json rocprofv3 --kernel-trace --stats -d $O/ph -o ph -- python $R/bench.py --multi-clip 0 --no-cpu-baseline --legs '' > /dev/null 2>&1
 BATCH="python tools/bench_clips.py --clips 8 --steps 100"
 rocprofv3 --kernel-trace --stats -d $O/pb -o pb -- python $R/tools/bench_clips.py --clips 8 --steps 100 > $O/${N}_bench_batch8_profiled.json 2>/dev/null
 POSE="HOMAN_POSEINIT_LOOPS=fused python bench.py --pose-init 500 --no-cpu-baseline"
