@@ -118,19 +118,24 @@ struct SweepGeo {
 // line axis (the IEEE division every item of the family used to repeat), the family's first line and the order of its two
 // end points.  {slope bits, d0_from | (p00 < p10) << 16}
 struct SweepLite { int var, axis, d0r, a_in, a_out; bool geo, pos; };
-// (stage 1: face entry and family come from the pass's scatter + max-scan, the line from the family's base: no searches)
-__device__ __forceinline__ SweepLite sweep_item_lite(const SweepFace& fc, const int2 ft, int fam, int pos, bool mine, int is)
+__device__ __forceinline__ SweepLite sweep_item_lite(const SweepFace& fc, const int2* __restrict__ famtab, int j, bool mine, int is)
 {
     SweepLite q;
+    int fam = 0;
+#pragma unroll
+    for (int stp = 8; stp > 0; stp >>= 1)
+        if ((int)fc.cum[fam + stp - 1] <= j) fam += stp;
+    const int fstart = fam ? (int)fc.cum[fam - 1] : 0;
     q.var = fam >= 6 ? 1 : 0;
     const int ci = fam - 6 * q.var;
     q.axis = ci & 1;
     const int edge = ci >> 1, v0 = q.var ? 2 - edge : edge;
     const float p00 = (q.axis ? fc.py : fc.px)[v0], p01 = (q.axis ? fc.px : fc.py)[v0];
+    const int2 ft = famtab[fam];
     const float slope = __int_as_float(ft.x);
     const bool lt = (ft.y >> 16) & 1;
     const int dir = q.axis == 0 ? (lt ? -1 : 1) : (lt ? 1 : -1);
-    q.d0r = mine ? (int)(short)(ft.y & 0xffff) + pos : 0;       // (family base = its first line - its first position in the pass)
+    q.d0r = mine ? (ft.y & 0xffff) + (j - fstart) : 0;
     const float d1_cross = slope * ((float)q.d0r - p00) + p01;
     bool geo = mine && d1_cross > -8.0f && d1_cross < (float)is + 8.0f;
     const int d1_in = geo ? ((dir > 0) ? (int)floorf(d1_cross) : (int)ceilf(d1_cross)) : 0;
@@ -221,8 +226,6 @@ __device__ __forceinline__ void sweep_combine_rows(int& cur, double& acc0, doubl
 #ifndef SWEEP_WAVES_EU
 #define SWEEP_WAVES_EU 5
 #endif
-static_assert(SWEEP_UNIT == 256 && SWEEP_TBATCH == 4 && SWEEP_TRIPS == 4 && SWEEP_PASS_FACES == 16,
-              "stage 1 hands every lane four consecutive items of a 256-item unit; face entries ride four bits");
 template <bool W32>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES_EU, 8))) void k_bwd_sweep(SweepList sl, const int* __restrict__ idx_map,
                                                    const SweepSrc* __restrict__ srcs,
@@ -329,14 +332,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                 if (ent < nfp) reinterpret_cast<int*>(&s_face[wv][ent].f)[lane & 15] = row[k];
             }
             for (int i = lane; i < SWEEP_PASS_FACES * 6; i += 64) (&s_fg[wv][0][0])[i] = 0.0;
-            reinterpret_cast<int4*>(s_head[wv])[lane] = make_int4(0, 0, 0, 0);
             wave_sync();
-            // family constants of the pass's faces: one division per (face, family) instead of one per item.  Every non-empty
-            // family also drops its number at its first position of the pass (position = item - it_lo; a family cut by the pass's
-            // first item at position 0), every face a "no item" mark behind its last family (padding at the end of a compaction
-            // block belongs to no face): a running maximum over the 256 positions then hands every item of stage 1 its (face,
-            // family) without a search.  Numbers grow with the position; LDS max, so a family that starts where the previous face
-            // ends beats that face's mark.
+            // family constants of the pass's faces: one division per (face, family) instead of one per item
             for (int idx = lane; idx < nfp * 12; idx += 64) {
                 const int e = idx / 12, fam = idx - 12 * e;
                 const SweepFace& f = s_face[wv][e].f;
@@ -348,12 +345,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                 const float p00 = pa[v0], p10 = pa[v1], p01 = pb[v0], p11 = pb[v1];
                 const float slope = (p11 - p01) / (p10 - p00);
                 const int d0_from = (int)fmaxf(ceilf(fminf(p00, p10)), 0.0f);
-                const int fstart = fam ? (int)f.cum[fam - 1] : 0, fend = (int)f.cum[fam];
-                const int rel = f.off + fstart - it_lo, rel_end = f.off + fend - it_lo;
-                s_fam[wv][e][fam] = make_int2(__float_as_int(slope), ((d0_from - rel) & 0xffff) | ((p00 < p10) ? 1 << 16 : 0));
-                if (fend > fstart && rel_end > 0 && rel < SWEEP_UNIT)
-                    atomicMax(&s_head[wv][max(rel, 0)], ((idx + 1) << 8) | (e << 4) | fam);
-                if (fam == 11 && rel_end < SWEEP_UNIT) atomicMax(&s_head[wv][max(rel_end, 0)], ((idx + 1) << 8) | 0xff);
+                s_fam[wv][e][fam] = make_int2(__float_as_int(slope), (d0_from & 0xffff) | ((p00 < p10) ? 1 << 16 : 0));
             }
             if (lane < 2 * nfp) {
                 // the inward sweep stays inside the triangle: its extent along the line bounds the range
@@ -369,25 +361,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
             // all of them are in flight before the first is tested (one dependent round trip per unit, not per trip)
             int qn = 0;
             {
-              // (face entry, family) of this lane's four CONSECUTIVE items (positions 4 lane .. 4 lane + 3 of the pass): the marks
-              // dropped above, carried over the positions by a running maximum (four in the lane, then a wave scan)
-              int hid[4];
-              {
-                  const int4 h = reinterpret_cast<const int4*>(s_head[wv])[lane];
-                  hid[0] = h.x; hid[1] = max(hid[0], h.y); hid[2] = max(hid[1], h.z); hid[3] = max(hid[2], h.w);
-                  int inc = hid[3];
-                  inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xf, 0xf, false));    // row_shr:1
-                  inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xf, 0xf, false));    // row_shr:2
-                  inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xf, 0xf, false));    // row_shr:4
-                  inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xf, 0xf, false));    // row_shr:8
-                  inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x142, 0xa, 0xf, false));    // row_bcast:15
-                  inc = max(inc, __builtin_amdgcn_update_dpp(0, inc, 0x143, 0xc, 0xf, false));    // row_bcast:31
-                  const int before = __builtin_amdgcn_update_dpp(0, inc, 0x138, 0xf, 0xf, false); // wave_shr:1
-                  // (back to LDS: four registers less across the trips' address arithmetic, the kernel sits at its 96-register budget)
-                  reinterpret_cast<int4*>(s_head[wv])[lane] = make_int4(max(hid[0], before), max(hid[1], before), max(hid[2], before),
-                                                                        max(hid[3], before));
-              }
-              __builtin_amdgcn_wave_barrier();
               for (int tb = 0; tb < SWEEP_TRIPS; tb += SWEEP_TBATCH) {      // (<= 4 trips' loads in flight at a time: registers)
                 uint4 sm[SWEEP_TBATCH];
                 // (per trip, packed - the four trips' state lives in registers until their loads have landed:
@@ -396,13 +369,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                 unsigned short s_aw[SWEEP_TBATCH];
 #pragma unroll
                 for (int t = 0; t < SWEEP_TBATCH; ++t) {
-                    const int pos = 4 * lane + (tb + t), g = it_lo + pos;       // (a "trip" = one of the lane's four items)
-                    const int hv = s_head[wv][pos];
-                    // (a "no item" mark: padding past the last face of a compaction block, belongs to no face)
-                    const bool mine = g < it_hi && hv != 0 && (hv & 0xff) != 0xff;
-                    const int el = mine ? (hv >> 4) & 15 : 0, fam = mine ? hv & 15 : 0;
-                    const SweepFace& fc = s_face[wv][el].f;
-                    const SweepLite q = sweep_item_lite(fc, s_fam[wv][el][fam], fam, pos, mine, is);
+                    const int g = it_lo + 64 * (tb + t) + lane;
+                    int el = -1;                                      // my face: last one of the pass with off <= g
+                    for (int i = 0; i < nfp; ++i) el += (__builtin_amdgcn_readlane(o, i) <= g) ? 1 : 0;
+                    const SweepFace& fc = s_face[wv][max(el, 0)].f;
+                    // (past the last face of a compaction block: padding that belongs to no face)
+                    const bool mine = g < it_hi && el >= 0 && g - fc.off < (int)fc.cum[11];
+                    const SweepLite q = sweep_item_lite(fc, s_fam[wv][max(el, 0)], mine ? g - fc.off : 0, mine, is);
                     sm[t] = *reinterpret_cast<const uint4*>(hm_at<W32>(lsum, (((OFF)fc.b * 2 + q.axis) * is + q.d0r) * 8));
                     // the two samples at the edge, requested with the summary (one round trip): the owner of the sample just
                     // inside (the outward sweep runs only from a sample this winding owns) and the alpha word of the sample
@@ -417,10 +390,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SWEEP_WAVES
                     }
                     s_io[t] = q.a_in | (q.pos ? 1 << 12 : 0) | (q.geo ? 1 << 13 : 0);
                     {
-                        const int fbv = s_fb[wv][el][q.axis];
+                        const int fbv = s_fb[wv][max(el, 0)][q.axis];
                         s_lohi[t] = q.pos ? ((fbv & 0xffff) | (q.a_in << 16)) : (q.a_in | (fbv & 0xffff0000));
                     }
-                    s_ent[t] = (g - ubeg) | (el << SWEEP_USHIFT);
+                    s_ent[t] = (g - ubeg) | (max(el, 0) << SWEEP_USHIFT);
                 }
 #pragma unroll
                 for (int t = 0; t < SWEEP_TBATCH; ++t) {
