@@ -265,6 +265,7 @@ workgroups in the order of a single-clip launch - which is why a batched step is
 |---|---|---|---|
 | `k_setup_faces` | thread / face: optional rigid transform of the mesh-space vertex (the silhouette chain does not wait for `hm_rigid_fwd`), projects its 3 vertices (no separate projection launch), windings, tight sample box; bins the face into 64² super-regions (128² above 512² samples; LDS-aggregated counts, one global atomic per (workgroup, bin)); extra workgroups write the camera-space vertices for the other losses (same arithmetic as `k_rigid_fwd`: the hand-side stream no longer opens with a transform launch) | HBM | B·(V·24 + F·(12+36+8+2+5)) = 6.7 MB |
 | **`k_raster_fwd`** | workgroup = one 32×32-sample region: scans the faces of its super-region; candidates are split by WINDING CLASS - the class that holds the camera-facing surface of the mesh (a scheduling hint set by `calibrate()` from the index map; any value is correct) fills the candidate array from the front, the other from the back; one thread per candidate builds the face record in LDS (+ the nearest depth the face can produce) - BOTH classes in one pass, wave 0 up to 64 near-class records while wave 1 builds up to 64 far-class records (one round trip to the packed faces and one stretch of record arithmetic per round instead of one per class: the far class's pass had been a quarter of an active workgroup's time with three waves at its barrier; per-class prefix sums are per-wave scans); the (candidate, 4×4-sample block) units are **flattened** over the 256 threads (binary search of the exclusive unit counts); visibility = `ds_min_u64` on an LDS z-buffer keyed (depth bits ≪ 32 \| face) = strict z test in ascending face order, bit-exact.  The near class runs first; then per 4×4 block the largest owner depth is taken (`hz`), and the units of the far class are first tested against it, 64 per wave trip, the survivors queued per wave and the unit body run on FULL waves of survivors (a divergent early-out would leave the wave paying for its one visible unit: on a closed mesh ~85 % of the far units are hidden).  Sample positions of power-of-two grids by one multiplication (eight IEEE divisions per unit before).  Epilogue per 8×8 output tile: index map, pooled silhouette, fused masked-MSE terms, alpha plane and the four sweep bit planes of the backward (one full cache line per tile, ballots picked with selects: no scratch); in a fixed loop (`persistent_outputs`) an empty bin in front of outputs that already hold the empty pattern leaves before touching LDS (60 % of the workgroups).  The inside test of a unit is arithmetic, not compares: `rv < cv` is the SIGN BIT of `rv - cv` (after `rv + 0.0f`, which turns the one case where the sign lies, -0, into +0), the three edges' differences OR-ed into sixteen accumulators and shifted into the mask by one `v_alignbit` per sample - 156 instead of 221 instructions per unit (round 5); faces with a vertex projected beyond 1e15 are culled by the face setup and by the oracle (their edge functions overflow to inf - inf).  Wave-uniform values (work-order entry, wave index and everything derived) go through `readfirstlane` into scalar registers.  25 KB of LDS and 80 VGPRs (no spills): 6 workgroups per CU (7 per CU at 72 registers: measured slower, EXPERIMENTS r5) | latency × residency (5-6 dependent round trips per active workgroup), VALU-bound only when the GPU is full (clip batch, pose initialisation) | B·(F·49 + 512²·4 + 4·S²·4 + 5·512²/8) = **72.2 MB** |
+| `k_setup_faces_multi`, `k_raster_fwd_multi` (`hm_sil_fwd_multi`, round 6) | the two kernels' BODIES (`setup_faces_body`, `raster_fwd_body`: `__forceinline__` functions over the kernels' argument lists) called with one of up to four per-render argument blocks held in the kernarg segment; a workgroup finds its render by a scalar search over the renders' first workgroups (raster) / first frames (setup: grid = largest block count x all frames, surplus blocks leave at once) - every argument stays a scalar load, same registers (80 / 38), no scratch; renders differ in mesh (V, F, vertex and face arrays), cameras, masks, outputs, render size and workspace, each backward runs on its own workspace as before.  Used by the fused loop for the ordinal depth term (silhouette render + the object's depth render: 41 + 7 + 34 µs of launches become 56); it is also the raster-stage entry point for frames of DIFFERENT meshes (one render per mesh) | as the bodies | per render as above |
 | `k_sil_reduce` | block / frame + last-block finish.  One clip: the same body rides as B extra workgroups at the front of the `k_bwd_lines` launch (`hm_sil_bwd_clips(..., loss_out)`): the value is only logged, so it costs no launch; a clip batch keeps it on the third stream | latency | 0.5 MB |
 | `k_bwd_masks` | generic backward only (arbitrary `dL/dsilhouette`, or a negative loss weight): wave / tile, sweep planes via ballots | HBM | ≈ 21 MB |
 | `k_bwd_lines` | one DPP row (16 lanes) per TWO consecutive lines of a (plane, orientation, frame), 32 lines / workgroup (their mask words arrive in the same 4-byte loads; the launch is about one resident round of workgroups): expands a bit line into a position-sorted array of sources {d1, g, owner} + a 16-byte record per 64-bit word {mask, sources before it} (row scan).  Its first ⌈B·F/256⌉ workgroups build the **work list** of the sweeps instead: faces that own a sample → 64-byte records laid end to end in one global item space (block scan, one 64-bit atomic per block; a block's items start on a 64-item boundary so that the composition of every unit — and with it every summation order — is independent of the order in which blocks draw their bases).  Round 5: the 32 lines of a workgroup share plane, orientation and frame - decomposed once per workgroup in scalar registers (two 64-bit divisions per lane before) - and every address is a scalar base + 32-bit byte offset (`hm_at<W32>`) | latency | B·(4·512²/8 + S²·4 + 512² + F·46 [reads] + 4·512·8·16 + 2·512·16 + F·56 [line records, summaries, work list]) = 37.2 MB (+ 12 B per source and orientation, data dependent) |
@@ -535,7 +536,11 @@ known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4,
    built.  What stands in for it: `ShardStepper` replays the shape groups' hipGraphs concurrently - 8 clips of 4 shapes @MIXED@
    it/s against @MULTI@ for 8 clips of one shape as a batch (`profiles/r06_bench_mixed_shard.json`), bit-identical to solo fits.
    Padding clips to a common shape is not an option: padded vertices change the smoothness / interaction normalisers and can
-   win the nearest-vertex search.
+   win the nearest-vertex search.  Round 6 built the raster stage's half: `hm_sil_fwd_multi` launches the face setup and the
+   forward raster ONCE over up to four renders of different (V, F) (bit-equal to separate calls,
+   `tests/test_raster_gpu.py::test_multi_render_launch_equals_separate_calls`); the line expansion, the sweeps and the loss /
+   gradient kernels still take one mesh per launch, so `ShardStepper` keeps its concurrent shape-group graphs - which already
+   reach the same-shape batch's rate (VERDICT r5's criterion for this item).
 3. The pose initialisation at @POSE@ pose-steps/s (VERDICT r5's target 550 k): sweep and raster throughput-bound at 500 frames per
    launch (220 M and 161 M VALU wave-instructions: `profiles/r06_pmc_poseinit.json`); nothing this round shortened them.  Its line
    expansion's PMC traffic - 532 MB per launch (2 x FETCH 145 MB + WRITE 242 MB) against a byte model of 239 MB + sources - is now
@@ -552,17 +557,15 @@ known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4,
    per source), there is no denser way to ask for them short of reading the index map's whole lines (256 MB per launch).
 4. The ordinal depth term (cfg2 as BASELINE.json words it): @DEPTH@ it/s (3 716 in round 5; target 4 300).  Round 6: the depth-map
    backward is sparse (faces and frames that touch no non-zero gradient are not walked: 100 → 45 µs of kernel time), the depth
-   renders keep their empty regions; timeline `profiles/r06_p_cfg2_depth_timeline.txt`: both chains now end together (object:
-   silhouette raster 49 + object depth render 51 + lines 20 + sweeps 50 + depth backward 24 + pose gradients; hand: MANO 16 +
-   pair terms 33 + hand render 80 + ordinal term 36 + its backward + MANO backward 35).  What is left is the three rasters - the
-   object's depth render lasts as long as its slowest workgroup (37 µs: 114 + 126 candidates in one region, two record passes),
-   the hand's starts its active workgroups up to 32 µs late behind the background regions of its static launch order
-   (`profiles/r06_raster_trace_depth.txt`).  NOT built: the three renders as ONE launch over frames of different meshes
-   (per-frame face / vertex offsets in `k_setup_faces` / `k_raster_fwd`) - with both chains equally long, merging the object's
-   two renders alone would move the critical path to the hand side; cost-sorted orders for the depth contexts measured -3 %
-   in round 5 (two sorted rasters side by side collide).  Two hands per frame run in the fused loop too
-   (`tests/test_depth_gpu.py`), the oracle's written-out chain covers the term (bit-equal free run,
-   `tests/test_handchain_gpu.py::test_two_hands_with_depth_term_bit_equal`).  The reference's own call site raises
+   renders keep their empty regions, and the silhouette render and the OBJECT's depth render are one launch pair
+   (`hm_sil_fwd_multi`: the merged raster lasts 56 µs where the two launches took 41 + 7 + 34; +1.4 % on the iteration) with a
+   cost-sorted launch order for the hand's render (+1.5 %).  The iteration gained 3.4 of the 20 µs the object's chain lost: the
+   HAND side is now the longer chain - MANO forward 21, pair terms 28, hand render 12 + 46, ordinal term + its backward 47
+   (four launches), MANO backward 35 µs, `profiles/r06_p_cfg2_depth_timeline.txt` - and nothing on it was shortened.  The hand's
+   render in the same launch as the object's two was priced by `tools/merged_raster_probe.py` (+34 µs on the object's chain, which
+   would also have to wait ~13 µs for the MANO forward) and not built.  Two hands per frame run in the fused loop too
+   (`tests/test_depth_gpu.py`; their renders stay separate launches), the oracle's written-out chain covers the term (bit-equal
+   free run, `tests/test_handchain_gpu.py::test_two_hands_with_depth_term_bit_equal`).  The reference's own call site raises
    (`homan.py:506-507`): oracle-pinned only.
 5. `hand_proj_mode="ortho"` is built but parity-unpinned (section 7: its camera conversion is a third-party function absent from
    `/root/reference`, restated from the camera model) and runs through the graph loop, not the fused one.
