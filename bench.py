@@ -765,7 +765,9 @@ def main():
                               dominant_kernel_us=kus[dom], kernels_us=kus, first_timed_iteration=400, steps=lsteps,
                               whole_iteration_frac=tot * (lsteps / el) / 8.0e12,
                               note="fresh 400-step fit of the same clip, then its steady state; the silhouette chain's kernels "
-                                   "stamped inside the replayed graph (the depth renders and SDF kernels are not stamped)")
+                                   "stamped inside the replayed graph (the depth renders and SDF kernels are not stamped; with the depth term "
+                                   "k_raster_fwd is the span of the SILHOUETTE render's workgroups inside the hm_sil_fwd_multi launch it "
+                                   "shares with the object's depth render)")
             del sl, ml
 
     cpu = parity = e2e = None

@@ -610,6 +610,14 @@ class FusedStepper:
                          pooled_depth=self.d_dep_o, work_order=self.dctx[0].work_order, rigid_rot6d=m.rotations_object,
                          rigid_trans=m.translations_object, rigid_scale=m.int_scales_object, rigid_abs=1,
                          persistent_outputs=self.depth_persistent, workspace=self.dctx[0].workspace, clip_len=CL)])
+                if os.environ.get("HOMAN_MERGE_ORDER", "1") == "1":
+                    # the DEPTH render's workgroups first: it lasts as long as its slowest workgroup (37 us: one region with 240
+                    # candidates, profiles/r06_raster_trace_depth.txt), which then runs under the silhouette render's two rounds
+                    # instead of behind them (cfg2 + depth 4 208 -> 4 303 it/s, same box; results do not depend on the order)
+                    tmp = _lib.SilRender()
+                    ctypes.memmove(ctypes.byref(tmp), ctypes.byref(arr[0]), ctypes.sizeof(tmp))
+                    ctypes.memmove(ctypes.byref(arr[0]), ctypes.byref(arr[1]), ctypes.sizeof(tmp))
+                    ctypes.memmove(ctypes.byref(arr[1]), ctypes.byref(tmp), ctypes.sizeof(tmp))
                 if self.fork_after_setup:
                     ck(L.hm_sil_fwd_multi(arr, 2, 1, sa), "sil_fwd_multi(setup)")
                     self.ev_sil.record(main)
