@@ -434,7 +434,8 @@ Earlier findings that stand (rounds 4-5, same-box A/B each):
   inside test: cfg2 steady +2.0 %, 8-clip batch +2.5 %, iterations 5-25 +2.9 %, pose initialisation +3.1 %.
 Cumulative against round 5 (its numbers in brackets): steady @STEADY@ (6 515), 8-clip batch @MULTI@ (9 379), the driver's flags
 @DRV@ (5 153), cfg3 @CFG3@ (5 457), cfg2 WITH the depth term @DEPTH@ (3 716), pose initialisation @POSE@ (479 199).  VERDICT r5's
-targets: cfg2 + depth >= 4 300 - @DEPTH@; cfg2 steady >= 7 000, cfg1 floor <= 62 µs, 8-clip batch >= 10 000, pose initialisation >=
+targets: cfg2 + depth >= 4 300 - @DEPTH@ (met on the headline window, iterations 20-420 of a fit; 4 130-4 160 over iterations
+400-700, the leg of the default line); cfg2 steady >= 7 000, cfg1 floor <= 62 µs, 8-clip batch >= 10 000, pose initialisation >=
 550 k: NOT met - the chain alone on one queue would run 7 440 it/s (cfg1: 63.9 µs), the two chains without any edge 6 750; what is
 between those numbers and the shipped graph is the hand side sharing the GPU, and the kernels' own chains were not shortened
 (two structural attempts on the raster measured ±0 / +2 µs).
@@ -559,9 +560,16 @@ known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4,
    backward is sparse (faces and frames that touch no non-zero gradient are not walked: 100 → 45 µs of kernel time), the depth
    renders keep their empty regions, and the silhouette render and the OBJECT's depth render are one launch pair
    (`hm_sil_fwd_multi`: the merged raster lasts 56 µs where the two launches took 41 + 7 + 34; +1.4 % on the iteration) with a
-   cost-sorted launch order for the hand's render (+1.5 %).  The iteration gained 3.4 of the 20 µs the object's chain lost: the
-   HAND side is now the longer chain - MANO forward 21, pair terms 28, hand render 12 + 46, ordinal term + its backward 47
-   (four launches), MANO backward 35 µs, `profiles/r06_p_cfg2_depth_timeline.txt` - and nothing on it was shortened.  The hand's
+   cost-sorted launch order for the hand's render (+1.5 %) and the DEPTH render's workgroups dispatched first inside the merged
+   launch (its slowest workgroup, 37 µs on one crowded region, then runs under the silhouette render's two rounds: merged raster
+   56 → 48 µs, +2.2 %) - 4 134 → 4 300 it/s over the three steps, same-box A/B each, bit-identical.  Both chains end together
+   now (`profiles/r06_p_cfg2_depth_timeline.txt`, a mid-run iteration under rocprofv3: object side - merged setup + raster, lines,
+   sweeps, then its depth-map backward 11 + 16 and the pose gradients 17 µs; hand side - MANO forward 17, pair terms 27, hand
+   render 14 + 48, ordinal term + its backward 37, depth-map backward 21, MANO backward 39 µs), so a further gain needs BOTH tails
+   shortened (the object's depth gather folded into `k_rigid_bwd_x` like the silhouette gather; the ordinal term's two launches
+   as one) - not built.  The synthetic clip's fit DRIFTS with `lw_depth = 1` (total loss 0.17 → 0.40 over 3 000 steps while
+   `loss_depth` stays at 0.012: `tools/depth_windows.py`), so its rate falls with the iteration count (4 260 it/s over iterations
+   200-400, 3 900 at 800-1 000: the error bands widen); the leg of the default bench line times iterations 400-700.  The hand's
    render in the same launch as the object's two was priced by `tools/merged_raster_probe.py` (+34 µs on the object's chain, which
    would also have to wait ~13 µs for the MANO forward) and not built.  Two hands per frame run in the fused loop too
    (`tests/test_depth_gpu.py`; their renders stay separate launches), the oracle's written-out chain covers the term (bit-equal
