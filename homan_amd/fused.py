@@ -167,9 +167,14 @@ class FusedStepper:
         self.w = w
         self.weights = torch.tensor([w.get(k, 0.0) for k in self.SLOTS], device=dev)
         self.keys = [k for k in self.SLOTS if self._reported(k)]
-        # with the collision / contact terms the hand-side stream is by far the longer chain: the object's smoothness term
-        # (it only feeds the object's pose gradients) then rides the silhouette chain (measured: cfg3 +5 %, cfg2 -6 %)
-        self.smooth_obj_on_main = (self.on["col"] or self.on["con"]) and m.C == 1      # (a clip batch: -4 %)
+        # the object's smoothness VALUE (its gradient is formed inside the rigid backward) rides the pair-terms launch of the side
+        # stream as a block range.  Until round 6 the step-2 sets launched it on the silhouette chain instead, behind the sweeps
+        # (round 3: cfg3 +5 % while the hand side was by far the longer chain); since the hand side's launches were fused the
+        # silhouette chain is the longer one there too and an 8 us launch on its tail costs what it lasts: cfg3 5 405 -> 5 510
+        # it/s over iterations 20-420, 5 246 -> 5 304 in the steady state (same box, alternated).  HOMAN_SMOOTH_OBJ_MAIN=1: the old
+        # placement (one clip only: -4 % on a clip batch).
+        self.smooth_obj_on_main = (os.environ.get("HOMAN_SMOOTH_OBJ_MAIN", "0") != "0" and
+                                   (self.on["col"] or self.on["con"]) and m.C == 1)
         # unit gradients / scratch
         self.U_pca, self.U_so, self.U_sh = f(N, self.P), f(C), f(C)
         self.U_smo, self.U_smh, self.U_v2d = f(B, Vo, 3), f(N, Vh, 3), f(N, Vh, 3)
