@@ -421,3 +421,38 @@ def test_multi_render_rejects_bad_arguments():
     assert L.hm_sil_fwd_multi(arr, 1, 3, hlib.stream()) == -1          # NULL everything
     assert L.hm_sil_fwd_multi(arr, 0, 3, hlib.stream()) == -1
     assert L.hm_sil_fwd_multi(arr, 5, 3, hlib.stream()) == -1
+
+
+@pytest.mark.parametrize("n", [1, 4])
+def test_multi_render_launch_one_and_four_renders(n):
+    """hm_sil_fwd_multi at its limits: ONE render (= hm_sil_fwd_clips) and FOUR (the table's capacity), different sizes S per
+    render included - every render's outputs equal its own single call."""
+    from homan_amd import lib as hlib
+    from homan_amd import ops
+    B = 2
+    sc = _multi_scene(B, 64, seed=9)
+    dev = sc["mesh_o"].device
+    L, P, ck = hlib.lib(), hlib.ptr, hlib.check
+    stream = hlib.stream()
+    specs = [("verts_c", "faces_c", "K_full", 64), ("mesh_o", "faces_o", "K_roi", 32), ("verts_c", "faces_c", "K_roi", 96),
+             ("mesh_o", "faces_o", "K_full", 64)][:n]
+    # (mesh_o is mesh-space: rendered as it lies, 0.6 m in front of the camera through the translation below)
+    verts = {"verts_c": sc["verts_c"], "mesh_o": (sc["mesh_o"] + torch.tensor([0.0, 0.0, 0.6], device=dev)).contiguous()}
+    single, multi, rend = [], [], []
+    for vk, fk, kk, S in specs:
+        V, F = verts[vk].shape[1], sc[fk].shape[0]
+        for store in (single, multi):
+            ctx = ops.SilhouetteContext(sc[fk][None].expand(B, -1, -1), V, B, S, dev)
+            store.append((ctx, torch.full((B, S, S), -3.0, device=dev), torch.full((B, S, S), -3.0, device=dev)))
+        ctx, p, d = single[-1]
+        ck(L.hm_sil_fwd_clips(P(verts[vk]), P(sc[fk]), 0, P(sc[kk]), B, V, F, S, 1.0, ops.NMR_NEAR, ops.NMR_FAR, None, None, None, P(p),
+                              None, P(ctx.work_order), P(d), None, 0, None, None, None, 0, 0, P(ctx.workspace), B, 0, None, stream),
+           "hm_sil_fwd_clips")
+        ctx, p, d = multi[-1]
+        rend.append(dict(verts=verts[vk], faces=sc[fk], K=sc[kk], pooled=p, pooled_depth=d, work_order=ctx.work_order,
+                         workspace=ctx.workspace, B=B, V=V, F=F, S=S, orig_size=1.0, znear=ops.NMR_NEAR, zfar=ops.NMR_FAR, clip_len=B))
+    ck(L.hm_sil_fwd_multi(hlib.sil_renders(rend), n, 3, stream), "hm_sil_fwd_multi")
+    torch.cuda.synchronize()
+    for (ca, pa, da), (cb, pb, db) in zip(single, multi):
+        assert torch.equal(pa, pb) and torch.equal(da, db) and torch.equal(ca.idx_map(), cb.idx_map())
+        assert float(pa.sum()) > 1.0
