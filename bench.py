@@ -293,7 +293,9 @@ def pose_init_bench(args):
                 frac=per[dom]["achieved_GBps"] / 8000.0, traffic=per[dom].get("traffic_bytes"),
                 avg_launch_us=per[dom]["avg_launch_us"], kernels=per,
                 timing=f"device wall clock stored by every workgroup at entry and exit in the last {reps} replays of a "
-                       f"{steps}-step fit's hipGraph (hm_sil_timestamps)",
+                       f"{steps}-step fit's hipGraph (hm_sil_timestamps) - ONE loop over all {n} candidates (po._fused_loop), its "
+                       f"launches alone on the GPU; the timed fits run through the resident fitter, which walks the candidates as "
+                       f"`candidate_groups` loops side by side (same kernels over a third of the candidates each, overlapping)",
                 traffic_source=f"profiles/{os.path.basename(ppath)} (committed rocprofv3 --pmc passes, tools/pmc_poseinit.sh)" if per[dom].get("traffic_bytes") else None)
     cpu = None
     if not args.no_cpu_baseline:
@@ -319,6 +321,7 @@ def pose_init_bench(args):
                                              f"find_optimal_pose keeps per mesh - the state of every fit of a clip but its "
                                              f"first; `cold_fit` = a fit that builds everything itself)",
                                  "poses": n, "rend_size": size,
+                                 "candidate_groups": next((f.parts for f in po._FITTERS.values()), 1),
                                  "pose_steps_per_s_by_loop": {k: n * steps / v for k, v in loops.items()},
                                  "cold_fit": (dict(seconds_per_fit=cold, pose_steps_per_s=n * steps / cold) if cold else None)},
                       "best_iou": float(iou.max()), "seconds_per_fit": el, "roofline": roof, "cpu_baseline": cpu})

@@ -201,10 +201,15 @@ __global__ __launch_bounds__(256) void k_offscreen(const float* __restrict__ ver
 // losses[i] = sums[i * stride] + extra[i]; (lmin, ind) = first minimum (torch.argmin); if lmin < best_loss[0] (strict; a NaN
 // among the losses makes the minimum NaN, as torch.min does: no update) the pose of candidate `ind` - as it is NOW, i.e. after
 // the optimiser step that followed the evaluation - becomes the best one.
+// log != NULL (hm_pose_keep_best_log): no best-ever state is touched; the step's record - {minimum, its candidate (int bits), "some
+// loss is NaN", that candidate's rot6d (6) and trans (3), 0 x 4} - goes to row step[0] - 1 of `log` (step[0] = the optimiser's step
+// counter AFTER the step that followed the evaluation), for a caller that walks the candidates as several independent loops and
+// applies the rule below over all of them afterwards.
 __global__ __launch_bounds__(256) void k_pose_keep_best(const float* __restrict__ sums, int stride, const float* __restrict__ extra,
                                                         int n, const float* __restrict__ rot6d, const float* __restrict__ trans,
                                                         float* __restrict__ best_loss, float* __restrict__ best_rot,
-                                                        float* __restrict__ best_trans, float* __restrict__ losses_out)
+                                                        float* __restrict__ best_trans, float* __restrict__ losses_out,
+                                                        const int* __restrict__ step, int max_steps, float* __restrict__ log)
 {
     __shared__ float s_v[4];
     __shared__ int s_i[4], s_nan[4];
@@ -233,6 +238,16 @@ __global__ __launch_bounds__(256) void k_pose_keep_best(const float* __restrict_
             nb |= s_nan[k];
             if (s_v[k] < bv || (s_v[k] == bv && s_i[k] < bi)) { bv = s_v[k]; bi = s_i[k]; }
         }
+        if (log) {
+            float* rec = log + (long)min(max(step[0] - 1, 0), max_steps - 1) * 16;
+            const int e = threadIdx.x;
+            const bool has = bi < n;
+            if (e < 6) rec[3 + e] = has ? rot6d[(long)bi * 6 + e] : 0.f;
+            else rec[3 + e] = has ? trans[(long)bi * 3 + (e - 6)] : 0.f;
+            if (e == 0) { rec[0] = bv; rec[1] = __int_as_float(has ? bi : -1); rec[2] = nb ? 1.f : 0.f; }
+            if (e < 4) rec[12 + e] = 0.f;
+            return;
+        }
         // (lanes 0..8 are one wave: all of them have read best_loss before lane 0 writes it)
         const bool better = !nb && bi < n && bv < best_loss[0];
         if (better) {
@@ -250,7 +265,15 @@ int hm_pose_keep_best(const float* sums, int stride, const float* extra, int n, 
 {
     HM_CHECK_ARG(sums && extra && rot6d && trans && best_loss && best_rot6d && best_trans && losses_out && n > 0 && stride > 0);
     hipLaunchKernelGGL(k_pose_keep_best, dim3(1), dim3(256), 0, stream, sums, stride, extra, n, rot6d, trans, best_loss,
-                       best_rot6d, best_trans, losses_out);
+                       best_rot6d, best_trans, losses_out, (const int*)nullptr, 0, (float*)nullptr);
+    return hm_launch_status();
+}
+int hm_pose_keep_best_log(const float* sums, int stride, const float* extra, int n, const float* rot6d, const float* trans,
+                          const int* step, int max_steps, float* log, float* losses_out, hipStream_t stream)
+{
+    HM_CHECK_ARG(sums && extra && rot6d && trans && step && log && losses_out && n > 0 && stride > 0 && max_steps > 0);
+    hipLaunchKernelGGL(k_pose_keep_best, dim3(1), dim3(256), 0, stream, sums, stride, extra, n, rot6d, trans, (float*)nullptr,
+                       (float*)nullptr, (float*)nullptr, losses_out, step, max_steps, log);
     return hm_launch_status();
 }
 int hm_offscreen_fwd(const float* verts, const float* K, int N, int V, float zfar, float weight, float* out, float* grad,

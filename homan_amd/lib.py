@@ -73,6 +73,7 @@ _SIGNATURES = {
     "hm_priors_fwd": (_I, [_VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_hand_terms_fwd": (_I, [_VP, _VP, _I, _VP, _F, _I, _I, _VP, _VP, _VP, _VP, _VP, _L, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "hm_pose_keep_best": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "hm_pose_keep_best_log": (_I, [_VP, _I, _VP, _I, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "hm_offscreen_fwd": (_I, [_VP, _VP, _I, _I, _F, _F, _VP, _VP, _VP]),
     "hm_inter_fwd": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _F, _VP, _VP, _VP, _VP]),
     "hm_inter_bwd": (_I, [_VP, _VP, _I, _I, _I, _VP, _VP, _VP]),

@@ -7,6 +7,7 @@ nr.Renderer(image_size, anti_aliasing=False) is `ops.silhouette_render_noaa` (cs
 + hm_sil_bwd mode 3); everything else is host logic in torch, as in the reference.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -265,7 +266,10 @@ class _FusedPoseLoop:
     The loop is BOUND to one PoseOptimizer: the graph reads its `rotations` / `translations` / `_keep1` / `_ref1` / `K` where
     they lie.  `restart()` makes it the loop of a new fit whose data the caller copied INTO those tensors (PoseFitter)."""
 
-    def __init__(self, model, lr):
+    def __init__(self, model, lr, log_steps=0):
+        """log_steps > 0: the loop of ONE GROUP of a fit's candidates (PoseFitter): no best-ever state here - every step leaves its
+        record {minimum, candidate, NaN flag, that candidate's pose} in `self.log` (log_steps, 16) and the fitter applies the
+        best-ever rule over all groups afterwards (hm_pose_keep_best_log)."""
         from .jointopt import HmAdam
         assert model.lw_chamfer == 0, "the fused loop covers the reference's configuration (lw_chamfer = 0)"
         self.model, self.lr = model, lr
@@ -290,6 +294,8 @@ class _FusedPoseLoop:
         self.best_rot, self.best_trans = torch.zeros_like(model.rotations[0]), torch.zeros_like(model.translations[0])
         best_rot, best_trans = self.best_rot, self.best_trans
         self.losses_out = losses_out = f(n)
+        self.log_steps = int(log_steps)
+        self.log = log = f(self.log_steps, 16) if self.log_steps > 0 else None
         self._keepalive = (verts, g_off, off, pooled, frame, ones, rws, tp, tw)
 
         def step():
@@ -311,8 +317,12 @@ class _FusedPoseLoop:
                "hm_rigid_bwd_sil")
             opt.step(zero_grad=False)
             # mask + (chamfer = 0) + offscreen, the order of sum(loss_dict.values()); best-ever bookkeeping in the same launch
-            ck(L.hm_pose_keep_best(P(frame), 2, P(off), n, P(model.rotations), P(model.translations), P(best_loss), P(best_rot),
-                                   P(best_trans), P(losses_out), st), "hm_pose_keep_best")
+            if log is not None:
+                ck(L.hm_pose_keep_best_log(P(frame), 2, P(off), n, P(model.rotations), P(model.translations), P(opt.step_t),
+                                           self.log_steps, P(log), P(losses_out), st), "hm_pose_keep_best_log")
+            else:
+                ck(L.hm_pose_keep_best(P(frame), 2, P(off), n, P(model.rotations), P(model.translations), P(best_loss), P(best_rot),
+                                       P(best_trans), P(losses_out), st), "hm_pose_keep_best")
 
         self._step = step
         self.graph = None
@@ -337,6 +347,13 @@ class _FusedPoseLoop:
         """`num_iterations` steps.  The first two steps of a loop's life run un-captured (lazy initialisation of the library)
         - they ARE steps, same launches - then one step is captured and every further step, of this and of later fits, is a
         replay.  -> (final losses (n,), best-ever rotation, best-ever translation)"""
+        done = self.prepare(num_iterations)
+        for _ in range(num_iterations - done):
+            self.graph.replay()
+        return self.losses_out, self.best_rot.clone(), self.best_trans.clone()
+
+    def prepare(self, num_iterations):
+        """the un-captured first steps of the loop's life and the capture (see run) -> steps done (0 once the graph exists)"""
         done = 0
         if self.graph is None:
             side = torch.cuda.Stream()
@@ -351,9 +368,7 @@ class _FusedPoseLoop:
                 self.graph = _lib.new_graph()
                 with torch.cuda.graph(self.graph):
                     self._step()
-        for _ in range(num_iterations - done):
-            self.graph.replay()
-        return self.losses_out, self.best_rot.clone(), self.best_trans.clone()
+        return done
 
     def stamped_replays(self, stamp_reps):
         """(bench.py) `stamp_reps` MORE replays with the heavy silhouette kernels stamping the device wall clock
@@ -396,21 +411,118 @@ class PoseFitter:
     """A RESIDENT pose initialiser for one mesh, candidate count and mask size: the mesh copies, the rasteriser's context, the
     loop's buffers and its captured hipGraph are built once; every further fit copies its mask, intrinsics and starting poses
     into place and replays.  `find_optimal_pose` keeps one per (mesh, n, size, lr) - the per-frame fits of `find_optimal_poses`
-    (reference homan/pose_optimization.py:386-488: one fit per frame of a clip, same mesh) pay the construction once."""
+    (reference homan/pose_optimization.py:386-488: one fit per frame of a clip, same mesh) pay the construction once.
+
+    From 48 candidates on the fitter walks them as two, from 96 on as THREE GROUPS (HOMAN_POSE_PARTS): a resident loop each - own
+    mesh copies, rasteriser context, Adam state, hipGraph - replayed side by side on streams of their own.  The candidates of a fit are independent but
+    for the best-ever bookkeeping, and a step is one dependent chain of launches: with several chains in flight the small launches
+    and tails of one group (a seventh of a step) run under the other groups' rasteriser and sweeps (bench.py --pose-init 500:
+    476 k -> 565 k pose-steps/s with three groups; the probe behind it: tools/poseinit_split_probe.py).  Every group's loop leaves one record per step
+    (hm_pose_keep_best_log); the rule of reference :340-353 - no update in a step with a NaN loss anywhere, first minimum over
+    all candidates, strict `<` - is applied over the groups' records after the last step: the same champion, the same poses and
+    losses as one loop over all candidates, bit for bit (tests/test_poseinit.py)."""
 
     def __init__(self, vertices, faces, num_initializations, size, lr):
         n = num_initializations
-        rot0 = matrix_to_rot6d(torch.eye(3)[None].repeat(n, 1, 1))
-        self.shell = PoseOptimizer(ref_image=np.zeros((size, size), np.float32), vertices=vertices, faces=faces, rotation_init=rot0,
-                                   translation_init=torch.tensor([[[0.0, 0.0, 1.0]]]), num_initializations=n,
-                                   K=torch.tensor([[[1.0, 0, 0.5], [0, 1.0, 0.5], [0, 0, 1]]]))
-        self.loop = _FusedPoseLoop(self.shell, lr)
+        # (same-box bench.py --pose-init N, pose-steps/s with 1 / 2 / 3 / 4 groups: N = 128: 312 k / 354 k / 371 k; 250: 410 k / 420 k /
+        #  467 k; 500: 476 k / 533 k / 565 k / 517 k; 2000: 502 k / 574 k / 585 k)
+        parts = int(os.environ.get("HOMAN_POSE_PARTS", "0")) or (3 if n >= 96 else 2 if n >= 48 else 1)
+        self.parts = parts = max(1, min(parts, n))
+        self.cuts = [n * i // parts for i in range(parts + 1)]
+        self.shells, self.loops = [], []
+        for lo, hi in zip(self.cuts[:-1], self.cuts[1:]):
+            rot0 = matrix_to_rot6d(torch.eye(3)[None].repeat(hi - lo, 1, 1))
+            shell = PoseOptimizer(ref_image=np.zeros((size, size), np.float32), vertices=vertices, faces=faces, rotation_init=rot0,
+                                  translation_init=torch.tensor([[[0.0, 0.0, 1.0]]]), num_initializations=hi - lo,
+                                  K=torch.tensor([[[1.0, 0, 0.5], [0, 1.0, 0.5], [0, 0, 1]]]))
+            self.shells.append(shell)
+        self.lr = lr
+        self.shell = self.shells[0]                # (one group: the loop's own best-ever state, as before)
+        self.loop = _FusedPoseLoop(self.shell, lr) if parts == 1 else None
+        self.streams = [torch.cuda.Stream() for _ in range(parts)] if parts > 1 else []
         self.n, self.size = n, size
         self.fits = 0
+        if parts > 1:
+            # the (n,)-sized views a fit's result module shares (PoseOptimizer(_shared=...)): the first group's mesh copies tiled
+            # to n candidates would be a second copy of the mesh per candidate - the result module gets a shell of its own
+            # instead, without a rasteriser workspace until someone renders with it
+            self._result_shell = None
+
+    def _loops_for(self, num_iterations):
+        if not self.loops:
+            self.loops = [_FusedPoseLoop(sh, self.lr, log_steps=max(int(num_iterations), 64)) for sh in self.shells]
+        elif self.loops[0].log_steps < num_iterations:         # (a longer fit than any before: larger logs, new graphs)
+            for lp in self.loops:
+                lp.release()
+            self.loops = [_FusedPoseLoop(sh, self.lr, log_steps=int(num_iterations)) for sh in self.shells]
+        return self.loops
 
     def fit(self, mask, rotation_init, translation_init, K, num_iterations):
         """-> (PoseOptimizer holding the fitted candidates in their original order, final losses, champion rotation, champion
         translation); the returned module shares this fitter's mesh copies and rasteriser context, nothing of the fit."""
+        if self.parts == 1:
+            return self._fit_one(mask, rotation_init, translation_init, K, num_iterations)
+        if self._result_shell is None:
+            sh0 = self.shells[0]
+            self._result_shell = PoseOptimizer(ref_image=np.zeros((self.size, self.size), np.float32), vertices=sh0.vertices[0],
+                                               faces=sh0.faces[0], rotation_init=matrix_to_rot6d(torch.eye(3)[None].repeat(self.n, 1, 1)),
+                                               translation_init=torch.tensor([[[0.0, 0.0, 1.0]]]), num_initializations=self.n,
+                                               K=torch.tensor([[[1.0, 0, 0.5], [0, 1.0, 0.5], [0, 0, 1]]]))
+        result = PoseOptimizer(ref_image=mask, vertices=None, faces=None, rotation_init=rotation_init,
+                               translation_init=translation_init, num_initializations=self.n, K=K, _shared=self._result_shell)
+        loops = self._loops_for(num_iterations)
+        with torch.no_grad():
+            for (lo, hi), sh in zip(zip(self.cuts[:-1], self.cuts[1:]), self.shells):
+                sh._keep1.copy_(result._keep1)
+                sh._ref1.copy_(result._ref1)
+                sh.K.copy_(result.K)
+                sh._K_all.copy_(result._K_all[lo:hi])
+                sh.rotations.copy_(result.rotations[lo:hi])
+                sh.translations.copy_(result.translations[lo:hi])
+        done = []
+        for lp in loops:
+            lp.restart()
+            done.append(lp.prepare(num_iterations))            # (a loop's first steps and its capture: one loop after the other)
+        main = torch.cuda.current_stream()
+        for st in self.streams:
+            st.wait_stream(main)
+        for k in range(max(num_iterations - d for d in done)):
+            for lp, st, d in zip(loops, self.streams, done):
+                if k < num_iterations - d:
+                    with torch.cuda.stream(st):
+                        lp.graph.replay()
+        for st in self.streams:
+            main.wait_stream(st)
+        # the best-ever rule over the groups' per-step records (k_pose_keep_best's own: NaN anywhere -> no update; the lowest
+        # value, the lowest candidate among equals; strict `<` against the best so far)
+        logs = torch.stack([lp.log[:num_iterations] for lp in loops]).cpu().numpy()        # (parts, T, 16)
+        best, champ = np.float32(np.inf), None
+        for t in range(num_iterations):
+            rows = logs[:, t]
+            if (rows[:, 2] != 0).any():
+                continue
+            idx = rows[:, 1].copy().view(np.int32)
+            cand = [(rows[g, 0], self.cuts[g] + int(idx[g]), g) for g in range(self.parts) if idx[g] >= 0]
+            if not cand:
+                continue
+            v, _, g = min(cand, key=lambda c: (c[0], c[1]))
+            if v < best:
+                best, champ = v, rows[g, 3:12].copy()
+        dev = result.rotations.device
+        if champ is None:
+            champ_rot, champ_trans = torch.zeros(3, 2, device=dev), torch.zeros(1, 3, device=dev)
+        else:
+            champ_rot = torch.from_numpy(champ[:6]).reshape(3, 2).to(dev)
+            champ_trans = torch.from_numpy(champ[6:9]).reshape(1, 3).to(dev)
+        with torch.no_grad():
+            for (lo, hi), sh in zip(zip(self.cuts[:-1], self.cuts[1:]), self.shells):
+                result.rotations[lo:hi].copy_(sh.rotations)
+                result.translations[lo:hi].copy_(sh.translations)
+        losses = torch.cat([lp.losses_out for lp in loops])
+        self.fits += 1
+        return result, losses, champ_rot, champ_trans
+
+    def _fit_one(self, mask, rotation_init, translation_init, K, num_iterations):
         sh = self.shell
         result = PoseOptimizer(ref_image=mask, vertices=None, faces=None, rotation_init=rotation_init,
                                translation_init=translation_init, num_initializations=self.n, K=K, _shared=sh)

@@ -87,6 +87,13 @@ int hm_offscreen_fwd(const float* verts, const float* K, int N, int V, float zfa
  * rot6d (6) / trans (3) and the minimum are copied to best_rot6d / best_trans / best_loss (one float, start it at +inf). */
 int hm_pose_keep_best(const float* sums, int stride, const float* extra, int n, const float* rot6d, const float* trans,
                       float* best_loss, float* best_rot6d, float* best_trans, float* losses_out, hipStream_t stream);
+/* The same evaluation WITHOUT touching a best-ever state, for a caller that walks the candidates of one fit as several independent
+ * loops (own Adam state and step counter each, their launches overlapping on separate streams) and applies the rule of :340-353
+ * over all of them afterwards: row step[0] - 1 of log (max_steps, 16) receives {minimum of this loop's candidates, its index
+ * (int bits; -1: none), 1.0 if some loss is NaN, that candidate's CURRENT rot6d (6) and trans (3), 0 x 4}; step = the device
+ * counter of hm_adam_step, read after the step that followed the evaluation. */
+int hm_pose_keep_best_log(const float* sums, int stride, const float* extra, int n, const float* rot6d, const float* trans,
+                          const int* step, int max_steps, float* log, float* losses_out, hipStream_t stream);
 /* out = s[0] * in ;  out = s0[0]*a + s1[0]*b   (backward of the losses whose unit gradient is produced forward) */
 int hm_scale_by(const float* in, const float* s, long n, float* out, hipStream_t stream);
 int hm_scale2_by(const float* a, const float* s0, const float* b, const float* s1, long n, float* out,

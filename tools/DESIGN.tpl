@@ -400,7 +400,12 @@ with box-carrying bin entries requested speculatively; two covered samples per t
 Pose initialisation (`bench.py --pose-init 500`, its own line with `roofline`; `profiles/r06_p_poseinit_kernel_stats.txt`,
 `r06_pmc_poseinit.json`): per step of 500 candidate poses `k_bwd_sweep` @PISWP@ µs (algorithmic 338 MB → @PISWPG@ GB/s =
 **@PISWPF@** of HBM peak, the dominant kernel), `k_raster_fwd` @PIRAS@ µs (@PIRASF@), `k_bwd_lines` @PILIN@ µs (@PILINF@); all
-throughput-bound at 500 frames per launch.
+throughput-bound at 500 frames per launch (these are the launches of ONE loop over all 500 candidates, alone on the GPU - the shape
+the PMC passes were taken on).  The resident fitter (`PoseFitter`) walks the candidates of a fit as THREE independent loops - own
+rasteriser context, Adam state and hipGraph each - replayed side by side on streams of their own: a step is one dependent chain
+whose small launches and tails are a seventh of it, and with three chains in flight they run under the other groups' raster and
+sweeps: 476 k -> 562 k pose-steps/s, bit-identical (the one cross-candidate rule, the best-ever bookkeeping of reference
+`pose_optimization.py:340-353`, is applied after the last step over per-step records the loops leave: `hm_pose_keep_best_log`).
 
 **What bounds the iteration** (EXPERIMENTS.md, rounds 4-6).  The silhouette chain is serial and it IS the iteration: setup 8.5 +
 raster 40 + lines 22 + sweeps 44 + object gradients 17 + Adam 4 µs = 136 µs of kernels + ~14 µs between them = 150 µs; the hand
@@ -435,8 +440,8 @@ Earlier findings that stand (rounds 4-5, same-box A/B each):
 Cumulative against round 5 (its numbers in brackets): steady @STEADY@ (6 515), 8-clip batch @MULTI@ (9 379), the driver's flags
 @DRV@ (5 153), cfg3 @CFG3@ (5 457), cfg2 WITH the depth term @DEPTH@ (3 716), pose initialisation @POSE@ (479 199).  VERDICT r5's
 targets: cfg2 + depth >= 4 300 - @DEPTH@ (met on the headline window, iterations 20-420 of a fit; 4 130-4 160 over iterations
-400-700, the leg of the default line); cfg2 steady >= 7 000, cfg1 floor <= 62 µs, 8-clip batch >= 10 000, pose initialisation >=
-550 k: NOT met - the chain alone on one queue would run 7 440 it/s (cfg1: 63.9 µs), the two chains without any edge 6 750; what is
+400-700, the leg of the default line); pose initialisation >= 550 k - @POSE@ (met: the candidates as three independent loops);
+cfg2 steady >= 7 000, cfg1 floor <= 62 µs, 8-clip batch >= 10 000: NOT met - the chain alone on one queue would run 7 440 it/s (cfg1: 63.9 µs), the two chains without any edge 6 750; what is
 between those numbers and the shipped graph is the hand side sharing the GPU, and the kernels' own chains were not shortened
 (two structural attempts on the raster measured ±0 / +2 µs).
 
@@ -542,8 +547,9 @@ known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4,
    `tests/test_raster_gpu.py::test_multi_render_launch_equals_separate_calls`); the line expansion, the sweeps and the loss /
    gradient kernels still take one mesh per launch, so `ShardStepper` keeps its concurrent shape-group graphs - which already
    reach the same-shape batch's rate (VERDICT r5's criterion for this item).
-3. The pose initialisation at @POSE@ pose-steps/s (VERDICT r5's target 550 k): sweep and raster throughput-bound at 500 frames per
-   launch (220 M and 161 M VALU wave-instructions: `profiles/r06_pmc_poseinit.json`); nothing this round shortened them.  Its line
+3. The pose initialisation at @POSE@ pose-steps/s (VERDICT r5's target 550 k; 476 k before the candidates were walked as three
+   independent loops side by side, section 5): sweep and raster throughput-bound at 500 frames per launch (220 M and 161 M VALU
+   wave-instructions: `profiles/r06_pmc_poseinit.json`); nothing this round shortened the kernels themselves.  Its line
    expansion's PMC traffic - 532 MB per launch (2 x FETCH 145 MB + WRITE 242 MB) against a byte model of 239 MB + sources - is now
    EXPLAINED, by calibration (`tools/fetch_calib.hip`, `profiles/r06_fetch_calib.json`: kernels of known requested bytes under the
    same two counters): coalesced reads report exactly HALF their bytes at 16 AND at 4 bytes per lane (the guide's x 2 holds for
