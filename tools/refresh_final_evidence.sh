@@ -21,5 +21,5 @@ s pd cfg2_depth "python bench.py --depth --multi-clip 0 --no-cpu-baseline --stea
 s p3 cfg3 "python bench.py --step2 --multi-clip 0 --no-cpu-baseline --steady 0 --legs ''"
 s ph cfg2_headline "python bench.py --multi-clip 0 --no-cpu-baseline --legs ''"
 s pb cfg4_batch8 "python tools/bench_clips.py --clips 8 --steps 100"
-s pp poseinit "HOMAN_POSEINIT_LOOPS=fused python bench.py --pose-init 500 --no-cpu-baseline"
+python tools/prof_summary.py $O/pp/pp_results.db "HOMAN_POSEINIT_LOOPS=fused python bench.py --pose-init 500 --no-cpu-baseline" > $O/${N}_p_poseinit_kernel_stats.txt; python tools/prof_timeline.py $O/pp/pp_results.db k_pose_keep_best > $O/${N}_p_poseinit_timeline.txt      # (the window between two best-ever launches of ANY candidate group)
 rm -rf $O/ph $O/pb $O/pp $O/pd $O/p3
