@@ -704,7 +704,11 @@ def main():
                                       objvertices=ci["objvertices"], objfaces=ci["objfaces"], camintr=ci["camintr"],
                                       optimize_mano=True, image_size=args.size, mano_model=mano, rend_size=args.size,
                                       sync_metrics=False, ordinal_depth=args.depth))
-        bst = FusedStepper(models, lw, 1e-2, msteps + 10)
+        # (the per-GPU worker of cfg4, dist.optimize_clip_shard, drives its shard through ShardStepper: clips of one shape as clip
+        #  batches - two batches side by side for a step-1 shard of one shape, one batch otherwise)
+        from homan_amd.jointopt import ShardStepper
+        bst = ShardStepper(models, lw, 1e-2, msteps + 10)
+        nbatches = len(bst.steppers)
         bst.run(10)
         barrier()
         t1 = time.perf_counter()
@@ -723,8 +727,10 @@ def main():
                      roofline=dict(bound="hbm", unit="GB/s", peak=8000.0 * world,
                                    achieved=mtot * mval / 1e9, frac=mtot * mval / (8.0e12 * world),
                                    note="whole iteration: SURVEY 8(d) algorithmic bytes per clip-iteration x clip-iterations/s"),
-                     note="one clip batch per GPU: ONE launch per kernel over all clips, one hipGraph per iteration; "
-                          "max over ranks")
+                     clip_batches=nbatches,
+                     note="the shard of a GPU through ShardStepper (dist.optimize_clip_shard's engine): clip batches - ONE launch per "
+                          "kernel over the clips of a batch, one hipGraph per batch and iteration, the batches' graphs replayed side by "
+                          "side; max over ranks")
         del bst, models
 
     legs = {}

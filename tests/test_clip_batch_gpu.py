@@ -224,3 +224,36 @@ def test_shard_of_two_hand_clips_runs_through_the_fused_loop(mano_model):
         for (k, p), (_, q) in zip(m_s.named_parameters(), m_b.named_parameters()):
             assert torch.equal(p, q), k
         np.testing.assert_array_equal(np.asarray(st.loss_evolution(6)["loss"]), np.asarray(e["loss"]))
+
+
+def test_one_shape_shard_runs_as_two_batches_and_equals_solo_runs(mano_model, monkeypatch):
+    """A step-1 shard of ONE shape: ShardStepper fits it as two clip batches side by side (five clips: 3 + 2); every clip ends up
+    with the rows and parameters of optimising it alone, and with those of the one-batch run (HOMAN_SHARD_SPLIT=0).  With the
+    collision / contact terms the shard stays one batch."""
+    from homan_amd import synth
+    from homan_amd.jointopt import FusedStepper, ShardStepper
+    lw, steps, seeds = dict(synth.STEP1_LOSS_WEIGHTS), 6, [11, 12, 13, 14, 15]
+    solo, evo_solo = _clips(mano_model, seeds, 6, 64, "cube"), []
+    for m in solo:
+        st = FusedStepper(m, lw, 1e-2, steps)
+        st.run(steps)
+        evo_solo.append(st.loss_evolution(steps))
+    shard = _clips(mano_model, seeds, 6, 64, "cube")
+    sh = ShardStepper(shard, lw, 1e-2, steps)
+    assert [len(i) for i in sh.index] == [3, 2]
+    sh.run(steps)
+    monkeypatch.setenv("HOMAN_SHARD_SPLIT", "0")
+    whole = _clips(mano_model, seeds, 6, 64, "cube")
+    sw = ShardStepper(whole, lw, 1e-2, steps)
+    assert [len(i) for i in sw.index] == [5]
+    sw.run(steps)
+    monkeypatch.delenv("HOMAN_SHARD_SPLIT")
+    for c, (es, eb, ew) in enumerate(zip(evo_solo, sh.loss_evolution(steps), sw.loss_evolution(steps))):
+        for k in es:
+            np.testing.assert_array_equal(np.asarray(eb[k]), np.asarray(es[k]), err_msg=f"clip {c} {k}")
+            np.testing.assert_array_equal(np.asarray(ew[k]), np.asarray(es[k]), err_msg=f"clip {c} {k} (one batch)")
+    for c, (ms, mb) in enumerate(zip(solo, shard)):
+        for k in PARAMS:
+            assert torch.equal(getattr(ms, k).detach(), getattr(mb, k).detach()), f"clip {c} {k}"
+    assert [len(i) for i in ShardStepper(_clips(mano_model, seeds[:4], 6, 64, "cube"), dict(synth.STEP2_LOSS_WEIGHTS), 1e-2, 2,
+                                         capture=False).index] == [4]
