@@ -46,11 +46,12 @@ class ShardStepper:
         # A shard of ONE shape with the step-1 loss set runs as TWO clip batches side by side (their hipGraphs replayed concurrently,
         # see run): the tails and latency-bound launches of one batch run under the other's heavy kernels - same box, one batch /
         # two: 4 clips 9 073 / 9 988 it/s, 6: 9 333 / 10 148, 8: 9 565 / 10 198, 12: 9 503 / 10 066, 16: 9 626 / 9 971 (four batches:
-        # 7 827 at 8 clips, 9 080 at 16: worse).  Not with the collision / contact terms (8 clips: 7 687 / 7 583) and not with a
-        # tied scale (its iteration is two graph halves around a collective).  Results do not depend on batch composition.
+        # 7 827 at 8 clips, 9 080 at 16: worse; 2 clips: 7 489 / 7 167).  Not with the collision / contact terms (8 clips: 7 687 /
+        # 7 583), not with the ordinal depth term (4 clips: 4 757 / 4 089; 8: 5 009 / 4 599 - three rasters per batch) and not
+        # with a tied scale (its iteration is two graph halves around a collective).  Results do not depend on batch composition.
         lwf = {k: float(v) for k, v in loss_weights.items()}
         halve = (os.environ.get("HOMAN_SHARD_SPLIT", "1") != "0" and len(groups) == 1 and not shared_scale and
-                 not lwf.get("lw_collision", 0) > 0 and not lwf.get("lw_contact", 0) > 0)
+                 not lwf.get("lw_collision", 0) > 0 and not lwf.get("lw_contact", 0) > 0 and not lwf.get("lw_depth", 0) > 0)
         chunks = []
         for idxs in groups.values():
             if halve and len(idxs) >= 4:
