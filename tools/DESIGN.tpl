@@ -541,13 +541,16 @@ known answers and its inverse on the CPU, HIP == oracle on the GPU (losses 1e-4,
    its unit body (±0), kernarg preloading (-0.3 µs), a decoupled launch graph (3.8 % at most).
 2. One launch per kernel over clips of DIFFERENT shapes (per-clip vertex / face offsets in every `hm_*_clips` kernel) is not
    built.  What stands in for it: `ShardStepper` replays the shape groups' hipGraphs concurrently - 8 clips of 4 shapes @MIXED@
-   it/s against @MULTI@ for 8 clips of one shape as a batch (`profiles/r06_bench_mixed_shard.json`), bit-identical to solo fits.
+   it/s against @MULTI@ for 8 clips of one shape as two batches side by side (9 565 as ONE batch, the figure VERDICT r5 compared
+   with; `profiles/r06_bench_mixed_shard.json`), bit-identical to solo fits.
    Padding clips to a common shape is not an option: padded vertices change the smoothness / interaction normalisers and can
    win the nearest-vertex search.  Round 6 built the raster stage's half: `hm_sil_fwd_multi` launches the face setup and the
    forward raster ONCE over up to four renders of different (V, F) (bit-equal to separate calls,
    `tests/test_raster_gpu.py::test_multi_render_launch_equals_separate_calls`); the line expansion, the sweeps and the loss /
-   gradient kernels still take one mesh per launch, so `ShardStepper` keeps its concurrent shape-group graphs - which already
-   reach the same-shape batch's rate (VERDICT r5's criterion for this item).
+   gradient kernels still take one mesh per launch, so `ShardStepper` keeps its concurrent shape-group graphs - at the rate of ONE
+   same-shape batch of eight (VERDICT r5's criterion for this item), below the two-batch rate this round found for one-shape shards.
+   The same measurement says what one launch over all shapes would NOT buy: the fewer concurrent batches, the fewer latency-bound
+   launches - but one batch of eight is slower than two of four.
 3. The pose initialisation at @POSE@ pose-steps/s (VERDICT r5's target 550 k; 476 k before the candidates were walked as three
    independent loops side by side, section 5): sweep and raster throughput-bound at 500 frames per launch (220 M and 161 M VALU
    wave-instructions: `profiles/r06_pmc_poseinit.json`); nothing this round shortened the kernels themselves.  Its line
